@@ -1,0 +1,68 @@
+/*
+ * iile_host.h — C ABI of libiile_host.so: host-side scene preparation and film
+ * finalisation around the GPU path. No HIP dependency; loads without a GPU.
+ *
+ * In the reference these steps live in the C++ host that stays on the CPU:
+ *   - scene description -> Scene:   src/core/parser.cpp:712+, src/core/api.cpp:1371-1430,
+ *                                   1632-1692 (pbrtShape / pbrtWorldEnd / MakeScene)
+ *   - BVH build:                    src/accelerators/bvh.cpp:183-402, 640-658
+ *   - Halton tables:                src/samplers/halton.cpp:65-93,
+ *                                   src/core/lowdiscrepancy.cpp:2490-2504
+ *   - camera matrices:              src/cameras/perspective.cpp:50-72, src/core/camera.h:90-111
+ *   - film normalisation + output:  src/core/film.cpp:187-235 (to_rgb_array / WriteImage)
+ * The GPU box receives only this repository, so the path carries its own
+ * minimal versions of them.
+ *
+ * All functions return 0 on success, non-zero on error (message via
+ * iile_host_last_error()); thread-compatible, not thread-safe.
+ */
+#ifndef IILE_HOST_H
+#define IILE_HOST_H
+
+#include "iile_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct iile_host_scene iile_host_scene;
+
+/* Values <= 0 keep what the scene file says. Equivalent of editing the Film /
+ * Sampler / Integrator lines of the .pbrt file (BASELINE.json configs override
+ * resolution and pixelsamples of scenes/killeroo-simple.pbrt this way). */
+typedef struct iile_host_overrides {
+    int32_t xres, yres;
+    int32_t spp;
+    int32_t max_depth;
+} iile_host_overrides;
+
+typedef struct iile_host_scene_info {
+    int32_t n_prims, n_triangles, n_spheres, n_meshes;
+    int32_t n_nodes, n_interior_nodes, n_leaf_nodes;
+    int32_t n_materials, n_lights;
+    int32_t xres, yres, spp, max_depth;
+} iile_host_scene_info;
+
+/* Parse a .pbrt file (plus its Includes), tessellate, build the BVH and the
+ * sampler tables. Stands where ParseFile + pbrtWorldEnd's MakeScene /
+ * MakeIntegrator stand (src/main/pbrt.cpp:97-219, src/core/api.cpp:1632-1660). */
+int iile_host_load_pbrt(const char *path, const iile_host_overrides *ov, iile_host_scene **out);
+/* The flattened scene; valid until iile_host_scene_free. */
+const iile_scene_desc *iile_host_scene_desc(const iile_host_scene *scene);
+int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info *info);
+void iile_host_scene_free(iile_host_scene *scene);
+
+/* Film::to_rgb_array (src/core/film.cpp:187-225) on a film of
+ * {X, Y, Z, filterWeightSum} float4 pixels over the cropped pixel bounds:
+ * XYZ->RGB, divide by weight, clamp at 0, multiply by scale. rgb: 3 floats/pixel. */
+int iile_host_film_to_rgb(const iile_film_desc *film, const float *film_xyzw, float *rgb);
+/* PFM writer (the reference's WriteImage needs OpenEXR for .exr; PFM is its
+ * own float format, src/core/imageio.cpp WriteImagePFM: bottom-to-top scanlines). */
+int iile_host_write_pfm(const char *path, const float *rgb, int32_t width, int32_t height);
+
+const char *iile_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IILE_HOST_H */

@@ -1,0 +1,142 @@
+/*
+ * iile_scene.h — the flattened, POD scene description that crosses the C ABI.
+ *
+ * This is the data the reference keeps behind `Scene`, `BVHAccel` (private
+ * arrays, /root/reference/src/accelerators/bvh.h:90-94), `TriangleMesh`,
+ * `Sphere`, `Material`, `DiffuseAreaLight`, `PerspectiveCamera`, `Film` and
+ * `HaltonSampler` objects, laid out as plain arrays so that a GPU library (or
+ * the CPU oracle used by the tests) can consume it without any C++ types.
+ *
+ * Producer : libiile_host.so  (iile_host.h: iile_host_load_pbrt)
+ * Consumers: libiile_gpu.so   (iile_gpu.h:  iile_scene_create)
+ *            oracle/          (tests only)
+ *
+ * All matrices are row-major float[16] (m[r][c] = a[4*r+c]), exactly the
+ * reference's Matrix4x4 (src/core/transform.h:60-110).
+ */
+#ifndef IILE_SCENE_H
+#define IILE_SCENE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors LinearBVHNode, src/accelerators/bvh.cpp:95-104 (32 bytes). */
+typedef struct iile_bvh_node {
+    float bmin[3];
+    float bmax[3];
+    int32_t offset;  /* leaf: first primitive; interior: second child index */
+    uint16_t nprims; /* 0 -> interior */
+    uint8_t axis;    /* interior: split axis */
+    uint8_t pad;
+} iile_bvh_node;
+
+/* prim_flags bits (one u32 per primitive, primitives are in BVH leaf order,
+ * i.e. the order of BVHAccel::primitives after the build). */
+enum {
+    IILE_PRIM_SPHERE = 1u << 0,      /* else triangle */
+    IILE_PRIM_HAS_NORMALS = 1u << 1, /* TriangleMesh::n != null */
+    IILE_PRIM_HAS_UV = 1u << 2,      /* TriangleMesh::uv != null */
+    IILE_PRIM_FLIP = 1u << 3         /* reverseOrientation ^ transformSwapsHandedness */
+};
+
+/* Sphere, src/shapes/sphere.h:47-76 + Shape base (src/core/shape.cpp:45-52). */
+typedef struct iile_sphere {
+    float o2w[16], o2w_inv[16]; /* ObjectToWorld.m / .mInv; WorldToObject is the swap */
+    float radius, zmin, zmax, theta_min, theta_max, phi_max;
+    int32_t reverse_orientation;
+    int32_t swaps_handedness;
+} iile_sphere;
+
+enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1 };
+
+/* MatteMaterial / PlasticMaterial with constant textures
+ * (src/materials/matte.cpp:45-62, plastic.cpp:45-70). */
+typedef struct iile_material {
+    int32_t type;
+    float kd[3];
+    float ks[3];
+    float sigma;     /* matte; only sigma == 0 (Lambertian) is supported on device */
+    float roughness; /* plastic, as given */
+    float alpha;     /* plastic: RoughnessToAlpha(roughness) if remap else roughness
+                        (src/core/microfacet.h:123-128) */
+    int32_t remap_roughness;
+    int32_t pad;
+} iile_material;
+
+/* DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75). */
+typedef struct iile_light {
+    float lemit[3];
+    int32_t two_sided;
+    int32_t sphere; /* index into spheres[] (only sphere emitters are supported) */
+    int32_t pad[3];
+} iile_light;
+
+/* PerspectiveCamera (src/cameras/perspective.cpp:50-72, src/core/camera.h:90-111). */
+typedef struct iile_camera {
+    float raster_to_camera[16];
+    float camera_to_world[16];
+    float lens_radius, focal_distance, shutter_open, shutter_close;
+} iile_camera;
+
+/* Film + box filter (src/core/film.cpp:45-91, src/filters/box.cpp:41-47). */
+typedef struct iile_film_desc {
+    int32_t xres, yres;              /* fullResolution */
+    int32_t crop_x0, crop_y0, crop_x1, crop_y1; /* croppedPixelBounds */
+    int32_t samp_x0, samp_y0, samp_x1, samp_y1; /* GetSampleBounds() */
+    float filter_rx, filter_ry;      /* box filter radius */
+    float scale;
+    float max_sample_luminance;
+} iile_film_desc;
+
+/* HaltonSampler state (src/samplers/halton.cpp:65-127). */
+typedef struct iile_halton {
+    int32_t spp;
+    int32_t base_scales[2];
+    int32_t base_exponents[2];
+    int32_t sample_stride;
+    int32_t mult_inverse[2];
+    int32_t n_dims;            /* number of prime bases covered by perms */
+    const uint16_t *perms;     /* concatenated digit permutations, PrimeSums layout */
+    const int32_t *primes;     /* [n_dims] */
+    const int32_t *prime_sums; /* [n_dims] */
+    int32_t n_perms;           /* total u16 entries */
+} iile_halton;
+
+/* PathIntegrator knobs (src/integrators/path.cpp:214-231). */
+typedef struct iile_integrator {
+    int32_t max_depth;
+    float rr_threshold;
+} iile_integrator;
+
+typedef struct iile_scene_desc {
+    /* BVH, depth-first flattened (src/accelerators/bvh.cpp:640-658) */
+    int32_t n_nodes;
+    const iile_bvh_node *nodes;
+    /* primitives in BVH order */
+    int32_t n_prims;
+    const uint32_t *prim_flags;    /* [n_prims] */
+    const int32_t *prim_material;  /* [n_prims] index into materials */
+    const int32_t *prim_light;     /* [n_prims] index into lights or -1 */
+    const int32_t *prim_shape;     /* [n_prims] sphere index for spheres, mesh id for triangles */
+    const float *tri_p;            /* [n_prims*9] world-space p0,p1,p2 (unused for spheres) */
+    const float *tri_n;            /* [n_prims*9] world-space vertex normals (if HAS_NORMALS) */
+    const float *tri_uv;           /* [n_prims*6] (if HAS_UV) */
+    int32_t n_spheres;
+    const iile_sphere *spheres;
+    int32_t n_materials;
+    const iile_material *materials;
+    int32_t n_lights;
+    const iile_light *lights;
+    iile_camera camera;
+    iile_film_desc film;
+    iile_halton halton;
+    iile_integrator integrator;
+} iile_scene_desc;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IILE_SCENE_H */

@@ -1,0 +1,189 @@
+// bvh_build.cpp — SAH BVH construction and depth-first flattening.
+//
+// Host-side, once per scene. Restates
+// /root/reference/src/accelerators/bvh.cpp:183-402 (recursiveBuild, SAH with
+// 12 buckets, leaf when nPrims <= maxPrimsInNode and leafCost <= splitCost) and
+// :640-658 (flattenBVHTree: first child at i+1, second at secondChildOffset).
+// The node layout and near/far visiting order are what make equal-t ties
+// resolve as in the reference (SURVEY.md §7 "Tie-breaking"), so the tree is
+// reproduced exactly, including std::partition / std::nth_element for the
+// in-range primitive order.
+#include <memory>
+
+#include "host_scene.h"
+
+namespace iile {
+namespace {
+
+struct PrimInfo {
+    size_t number;
+    Bounds3 bounds;
+    V3 centroid;
+};
+
+struct BuildNode {
+    Bounds3 bounds;
+    int children[2] = {-1, -1};
+    int split_axis = 0, first_prim = 0, n_prims = 0;
+};
+
+struct Builder {
+    int max_prims_in_node;
+    std::vector<PrimInfo> info;
+    std::vector<BuildNode> nodes;
+    std::vector<size_t> ordered;  // creation-order primitive numbers in leaf order
+    int n_interior = 0, n_leaf = 0;
+
+    int make_leaf(int node, int start, int end, const Bounds3 &b) {
+        int first = int(ordered.size());
+        for (int i = start; i < end; ++i) ordered.push_back(info[i].number);
+        nodes[node].first_prim = first;
+        nodes[node].n_prims = end - start;
+        nodes[node].bounds = b;
+        ++n_leaf;
+        return node;
+    }
+
+    int build(int start, int end) {
+        nodes.emplace_back();
+        const int node = int(nodes.size()) - 1;
+        Bounds3 bounds;
+        for (int i = start; i < end; ++i) bounds = bunion(bounds, info[i].bounds);
+        const int n = end - start;
+        if (n == 1) return make_leaf(node, start, end, bounds);
+        Bounds3 cb;
+        for (int i = start; i < end; ++i) cb = bunion(cb, info[i].centroid);
+        const int dim = cb.maximum_extent();
+        int mid = (start + end) / 2;
+        if (cb.pmax[dim] == cb.pmin[dim]) return make_leaf(node, start, end, bounds);
+        if (n <= 2) {
+            std::nth_element(&info[start], &info[mid], &info[end - 1] + 1,
+                             [dim](const PrimInfo &a, const PrimInfo &b) {
+                                 return a.centroid[dim] < b.centroid[dim];
+                             });
+        } else {
+            constexpr int nBuckets = 12;
+            struct Bucket {
+                int count = 0;
+                Bounds3 bounds;
+            } buckets[nBuckets];
+            for (int i = start; i < end; ++i) {
+                int b = int(nBuckets * cb.offset(info[i].centroid)[dim]);
+                if (b == nBuckets) b = nBuckets - 1;
+                buckets[b].count++;
+                buckets[b].bounds = bunion(buckets[b].bounds, info[i].bounds);
+            }
+            float cost[nBuckets - 1];
+            for (int i = 0; i < nBuckets - 1; ++i) {
+                Bounds3 b0, b1;
+                int c0 = 0, c1 = 0;
+                for (int j = 0; j <= i; ++j) {
+                    b0 = bunion(b0, buckets[j].bounds);
+                    c0 += buckets[j].count;
+                }
+                for (int j = i + 1; j < nBuckets; ++j) {
+                    b1 = bunion(b1, buckets[j].bounds);
+                    c1 += buckets[j].count;
+                }
+                cost[i] = 1 + (c0 * b0.surface_area() + c1 * b1.surface_area()) / bounds.surface_area();
+            }
+            float min_cost = cost[0];
+            int min_bucket = 0;
+            for (int i = 1; i < nBuckets - 1; ++i)
+                if (cost[i] < min_cost) {
+                    min_cost = cost[i];
+                    min_bucket = i;
+                }
+            float leaf_cost = float(n);
+            if (n > max_prims_in_node || min_cost < leaf_cost) {
+                PrimInfo *pmid = std::partition(&info[start], &info[end - 1] + 1, [=](const PrimInfo &pi) {
+                    int b = int(nBuckets * cb.offset(pi.centroid)[dim]);
+                    if (b == nBuckets) b = nBuckets - 1;
+                    return b <= min_bucket;
+                });
+                mid = int(pmid - &info[0]);
+            } else
+                return make_leaf(node, start, end, bounds);
+        }
+        int c0 = build(start, mid);
+        int c1 = build(mid, end);
+        nodes[node].children[0] = c0;
+        nodes[node].children[1] = c1;
+        nodes[node].bounds = bunion(nodes[c0].bounds, nodes[c1].bounds);
+        nodes[node].split_axis = dim;
+        nodes[node].n_prims = 0;
+        ++n_interior;
+        return node;
+    }
+
+    int flatten(int node, std::vector<iile_bvh_node> &out) {
+        const int my = int(out.size());
+        out.emplace_back();
+        const BuildNode bn = nodes[node];
+        iile_bvh_node ln;
+        std::memset(&ln, 0, sizeof(ln));
+        for (int i = 0; i < 3; ++i) {
+            ln.bmin[i] = bn.bounds.pmin[i];
+            ln.bmax[i] = bn.bounds.pmax[i];
+        }
+        if (bn.n_prims > 0) {
+            ln.offset = bn.first_prim;
+            ln.nprims = uint16_t(bn.n_prims);
+            out[my] = ln;
+        } else {
+            ln.axis = uint8_t(bn.split_axis);
+            ln.nprims = 0;
+            flatten(bn.children[0], out);
+            ln.offset = flatten(bn.children[1], out);
+            out[my] = ln;
+        }
+        return my;
+    }
+};
+
+}  // namespace
+
+void build_bvh(HostScene *scene) {
+    Builder b;
+    b.max_prims_in_node = std::min(255, scene->max_node_prims);
+    const size_t n = scene->prims.size();
+    b.info.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Bounds3 &wb = scene->prims[i].world_bound;
+        b.info[i].number = i;
+        b.info[i].bounds = wb;
+        b.info[i].centroid = .5f * wb.pmin + .5f * wb.pmax;  // bvh.cpp:53-56
+    }
+    scene->nodes.clear();
+    if (n == 0) return;
+    b.nodes.reserve(2 * n);
+    b.ordered.reserve(n);
+    int root = b.build(0, int(n));
+    scene->nodes.reserve(b.nodes.size());
+    b.flatten(root, scene->nodes);
+    scene->n_interior = b.n_interior;
+    scene->n_leaf = b.n_leaf;
+
+    scene->o_flags.resize(n);
+    scene->o_material.resize(n);
+    scene->o_light.resize(n);
+    scene->o_shape.resize(n);
+    scene->o_tri_p.assign(n * 9, 0.f);
+    scene->o_tri_n.assign(n * 9, 0.f);
+    scene->o_tri_uv.assign(n * 6, 0.f);
+    for (size_t i = 0; i < n; ++i) {
+        const HostPrim &p = scene->prims[b.ordered[i]];
+        scene->o_flags[i] = p.flags;
+        scene->o_material[i] = p.material;
+        scene->o_light[i] = p.light;
+        scene->o_shape[i] = p.shape;
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 3; ++c) {
+                scene->o_tri_p[9 * i + 3 * k + c] = p.p[k][c];
+                scene->o_tri_n[9 * i + 3 * k + c] = p.n[k][c];
+            }
+        for (int c = 0; c < 6; ++c) scene->o_tri_uv[6 * i + c] = p.uv[c];
+    }
+}
+
+}  // namespace iile

@@ -1,0 +1,186 @@
+// finalize.cpp — camera matrices, film bounds, Halton tables and the flattened
+// iile_scene_desc. Citations are relative to /root/reference/src.
+#include "host_scene.h"
+
+namespace iile {
+namespace {
+
+// PCG32 with the reference's default state/stream (core/rng.h:62-64, 143-156).
+struct Pcg32 {
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    uint32_t next() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xs = uint32_t(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = uint32_t(old >> 59u);
+        return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+    }
+    uint32_t bounded(uint32_t b) {  // core/rng.h:76-82
+        uint32_t threshold = (~b + 1u) % b;
+        while (true) {
+            uint32_t r = next();
+            if (r >= threshold) return r % b;
+        }
+    }
+};
+
+// samplers/halton.cpp:46-63
+void extended_gcd(uint64_t a, uint64_t b, int64_t *x, int64_t *y) {
+    if (b == 0) {
+        *x = 1;
+        *y = 0;
+        return;
+    }
+    int64_t d = int64_t(a / b), xp, yp;
+    extended_gcd(b, a % b, &xp, &yp);
+    *x = yp;
+    *y = xp - (d * yp);
+}
+uint64_t multiplicative_inverse(int64_t a, int64_t n) {
+    int64_t x, y;
+    extended_gcd(uint64_t(a), uint64_t(n), &x, &y);
+    int64_t r = x - (x / n) * n;  // Mod(), core/pbrt.h:310-314
+    return uint64_t(r < 0 ? r + n : r);
+}
+
+}  // namespace
+
+// Digit permutations for the scrambled radical inverse
+// (core/lowdiscrepancy.cpp:2490-2504, core/sampling.h:150-157). The reference
+// shuffles all 1000 prime bases from one default-seeded PCG32 stream; the
+// stream is consumed base by base, so a prefix of the bases yields a prefix of
+// the table. PathIntegrator with maxdepth d touches 5 + 7*d + 1 dimensions.
+void build_halton_tables(HostScene *scene) {
+    const int n_dims = std::max(64, 5 + 7 * (scene->max_depth + 1) + 2);
+    scene->primes.clear();
+    scene->prime_sums.clear();
+    int sum = 0;
+    for (int cand = 2; int(scene->primes.size()) < n_dims; ++cand) {
+        bool is_prime = true;
+        for (int d = 2; d * d <= cand; ++d)
+            if (cand % d == 0) {
+                is_prime = false;
+                break;
+            }
+        if (!is_prime) continue;
+        scene->primes.push_back(cand);
+        scene->prime_sums.push_back(sum);
+        sum += cand;
+    }
+    scene->perms.assign(sum, 0);
+    Pcg32 rng;
+    uint16_t *p = scene->perms.data();
+    for (int i = 0; i < n_dims; ++i) {
+        const int count = scene->primes[i];
+        for (int j = 0; j < count; ++j) p[j] = uint16_t(j);
+        for (int j = 0; j < count; ++j) {
+            int other = j + int(rng.bounded(uint32_t(count - j)));
+            std::swap(p[j], p[other]);
+        }
+        p += count;
+    }
+}
+
+bool finalize_scene(HostScene *s, std::string *err) {
+    if (s->prims.empty()) {
+        if (err) *err = "scene has no primitives";
+        return false;
+    }
+    build_bvh(s);
+    build_halton_tables(s);
+
+    iile_scene_desc &d = s->desc;
+    std::memset(&d, 0, sizeof(d));
+    d.n_nodes = int(s->nodes.size());
+    d.nodes = s->nodes.data();
+    d.n_prims = int(s->prims.size());
+    d.prim_flags = s->o_flags.data();
+    d.prim_material = s->o_material.data();
+    d.prim_light = s->o_light.data();
+    d.prim_shape = s->o_shape.data();
+    d.tri_p = s->o_tri_p.data();
+    d.tri_n = s->o_tri_n.data();
+    d.tri_uv = s->o_tri_uv.data();
+    d.n_spheres = int(s->spheres.size());
+    d.spheres = s->spheres.data();
+    d.n_materials = int(s->materials.size());
+    d.materials = s->materials.data();
+    d.n_lights = int(s->lights.size());
+    d.lights = s->lights.data();
+
+    // Film, core/film.cpp:45-82
+    iile_film_desc &f = d.film;
+    f.xres = s->xres;
+    f.yres = s->yres;
+    f.crop_x0 = int(std::ceil(s->xres * s->crop[0]));
+    f.crop_y0 = int(std::ceil(s->yres * s->crop[2]));
+    f.crop_x1 = int(std::ceil(s->xres * s->crop[1]));
+    f.crop_y1 = int(std::ceil(s->yres * s->crop[3]));
+    f.filter_rx = s->filter_rx;
+    f.filter_ry = s->filter_ry;
+    f.scale = s->film_scale;
+    f.max_sample_luminance = s->max_sample_luminance;
+    // Film::GetSampleBounds, core/film.cpp:76-82
+    f.samp_x0 = int(std::floor(float(f.crop_x0) + 0.5f - f.filter_rx));
+    f.samp_y0 = int(std::floor(float(f.crop_y0) + 0.5f - f.filter_ry));
+    f.samp_x1 = int(std::ceil(float(f.crop_x1) - 0.5f + f.filter_rx));
+    f.samp_y1 = int(std::ceil(float(f.crop_y1) - 0.5f + f.filter_ry));
+
+    // Camera, cameras/perspective.cpp:297-330 and core/camera.h:90-111
+    float frame = s->frame_aspect > 0 ? s->frame_aspect : float(s->xres) / float(s->yres);
+    float sw[4];  // pMin.x, pMax.x, pMin.y, pMax.y
+    if (frame > 1.f) {
+        sw[0] = -frame;
+        sw[1] = frame;
+        sw[2] = -1.f;
+        sw[3] = 1.f;
+    } else {
+        sw[0] = -1.f;
+        sw[1] = 1.f;
+        sw[2] = -1.f / frame;
+        sw[3] = 1.f / frame;
+    }
+    if (s->has_screen_window)
+        for (int i = 0; i < 4; ++i) sw[i] = s->screen_window[i];
+    Xform camera_to_screen = xf_perspective(s->fov, 1e-2f, 1000.f);
+    Xform screen_to_raster = xf_scale(float(s->xres), float(s->yres), 1) *
+                             xf_scale(1 / (sw[1] - sw[0]), 1 / (sw[2] - sw[3]), 1) *
+                             xf_translate(V3(-sw[0], -sw[3], 0));
+    Xform raster_to_screen = inverse(screen_to_raster);
+    Xform raster_to_camera = inverse(camera_to_screen) * raster_to_screen;
+    std::memcpy(d.camera.raster_to_camera, raster_to_camera.m.m, sizeof(float) * 16);
+    std::memcpy(d.camera.camera_to_world, s->camera_to_world.m.m, sizeof(float) * 16);
+    d.camera.lens_radius = s->lens_radius;
+    d.camera.focal_distance = s->focal_distance;
+    d.camera.shutter_open = s->shutter_open;
+    d.camera.shutter_close = s->shutter_close;
+
+    // HaltonSampler ctor, samplers/halton.cpp:65-93 (kMaxResolution = 128)
+    iile_halton &h = d.halton;
+    h.spp = s->spp;
+    int res[2] = {f.samp_x1 - f.samp_x0, f.samp_y1 - f.samp_y0};
+    for (int i = 0; i < 2; ++i) {
+        int base = (i == 0) ? 2 : 3;
+        int scale = 1, exp = 0;
+        while (scale < std::min(res[i], 128)) {
+            scale *= base;
+            ++exp;
+        }
+        h.base_scales[i] = scale;
+        h.base_exponents[i] = exp;
+    }
+    h.sample_stride = h.base_scales[0] * h.base_scales[1];
+    h.mult_inverse[0] = int(multiplicative_inverse(h.base_scales[1], h.base_scales[0]));
+    h.mult_inverse[1] = int(multiplicative_inverse(h.base_scales[0], h.base_scales[1]));
+    h.n_dims = int(s->primes.size());
+    h.perms = s->perms.data();
+    h.primes = s->primes.data();
+    h.prime_sums = s->prime_sums.data();
+    h.n_perms = int(s->perms.size());
+
+    d.integrator.max_depth = s->max_depth;
+    d.integrator.rr_threshold = s->rr_threshold;
+    return true;
+}
+
+}  // namespace iile

@@ -1,0 +1,118 @@
+// host_api.cpp — C ABI of libiile_host.so (see include/iile_host.h).
+#include <cstdio>
+
+#include "../../../include/iile_host.h"
+#include "host_scene.h"
+
+struct iile_host_scene {
+    iile::HostScene s;
+};
+
+namespace {
+thread_local std::string g_err;
+}
+
+extern "C" {
+
+const char *iile_host_last_error(void) { return g_err.c_str(); }
+
+int iile_host_load_pbrt(const char *path, const iile_host_overrides *ov, iile_host_scene **out) {
+    if (!path || !out) {
+        g_err = "iile_host_load_pbrt: null argument";
+        return 1;
+    }
+    iile_host_scene *hs = new iile_host_scene;
+    std::string err;
+    if (!iile::load_pbrt_file(path, &hs->s, &err)) {
+        g_err = err;
+        delete hs;
+        return 2;
+    }
+    if (ov) {
+        if (ov->xres > 0) hs->s.xres = ov->xres;
+        if (ov->yres > 0) hs->s.yres = ov->yres;
+        if (ov->spp > 0) hs->s.spp = ov->spp;
+        if (ov->max_depth > 0) hs->s.max_depth = ov->max_depth;
+    }
+    if (!iile::finalize_scene(&hs->s, &err)) {
+        g_err = err;
+        delete hs;
+        return 3;
+    }
+    *out = hs;
+    return 0;
+}
+
+const iile_scene_desc *iile_host_scene_desc(const iile_host_scene *scene) {
+    return scene ? &scene->s.desc : nullptr;
+}
+
+int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info *info) {
+    if (!scene || !info) {
+        g_err = "iile_host_scene_get_info: null argument";
+        return 1;
+    }
+    const iile::HostScene &s = scene->s;
+    info->n_prims = int(s.prims.size());
+    info->n_spheres = int(s.spheres.size());
+    info->n_triangles = info->n_prims - info->n_spheres;
+    info->n_meshes = s.n_meshes;
+    info->n_nodes = int(s.nodes.size());
+    info->n_interior_nodes = s.n_interior;
+    info->n_leaf_nodes = s.n_leaf;
+    info->n_materials = int(s.materials.size());
+    info->n_lights = int(s.lights.size());
+    info->xres = s.xres;
+    info->yres = s.yres;
+    info->spp = s.spp;
+    info->max_depth = s.max_depth;
+    return 0;
+}
+
+void iile_host_scene_free(iile_host_scene *scene) { delete scene; }
+
+// Film::to_rgb_array, /root/reference/src/core/film.cpp:187-225, with the
+// XYZ->RGB matrix of src/core/spectrum.h:56-60. No splats on this path.
+int iile_host_film_to_rgb(const iile_film_desc *film, const float *xyzw, float *rgb) {
+    if (!film || !xyzw || !rgb) {
+        g_err = "iile_host_film_to_rgb: null argument";
+        return 1;
+    }
+    const long n = long(film->crop_x1 - film->crop_x0) * long(film->crop_y1 - film->crop_y0);
+    for (long i = 0; i < n; ++i) {
+        const float *p = xyzw + 4 * i;
+        float r = 3.240479f * p[0] - 1.537150f * p[1] - 0.498535f * p[2];
+        float g = -0.969256f * p[0] + 1.875991f * p[1] + 0.041556f * p[2];
+        float b = 0.055648f * p[0] - 0.204043f * p[1] + 1.057311f * p[2];
+        float w = p[3];
+        if (w != 0) {
+            float inv = 1.f / w;
+            r = std::max(0.f, r * inv);
+            g = std::max(0.f, g * inv);
+            b = std::max(0.f, b * inv);
+        }
+        // splatScale * splatRGB adds +0 here (film.cpp:209-215)
+        r += 0.f;
+        g += 0.f;
+        b += 0.f;
+        rgb[3 * i] = r * film->scale;
+        rgb[3 * i + 1] = g * film->scale;
+        rgb[3 * i + 2] = b * film->scale;
+    }
+    return 0;
+}
+
+int iile_host_write_pfm(const char *path, const float *rgb, int32_t width, int32_t height) {
+    FILE *fp = fopen(path, "wb");
+    if (!fp) {
+        g_err = std::string("cannot open ") + path;
+        return 1;
+    }
+    // little-endian host: negative scale; scanlines bottom-to-top
+    fprintf(fp, "PF\n%d %d\n-1.0\n", width, height);
+    for (int y = height - 1; y >= 0; --y) fwrite(rgb + 3 * size_t(y) * width, sizeof(float), 3 * size_t(width), fp);
+    fclose(fp);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// host_scene.h — in-memory scene produced by the .pbrt loader; owns the arrays
+// that iile_scene_desc points into.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/iile_scene.h"
+#include "hmath.h"
+
+namespace iile {
+
+// One entry per GeometricPrimitive, in creation order (pbrtShape order,
+// /root/reference/src/core/api.cpp:1371-1430), before the BVH reorders them.
+struct HostPrim {
+    uint32_t flags = 0;
+    int32_t material = 0;
+    int32_t light = -1;
+    int32_t shape = 0;  // sphere index or mesh id
+    V3 p[3];
+    V3 n[3];
+    float uv[6] = {0, 0, 0, 0, 0, 0};
+    Bounds3 world_bound;
+};
+
+struct HostScene {
+    std::vector<HostPrim> prims;  // creation order
+    std::vector<iile_sphere> spheres;
+    std::vector<iile_material> materials;
+    std::vector<iile_light> lights;
+    int n_meshes = 0;
+
+    // camera / film / sampler / integrator options gathered before WorldBegin
+    Xform camera_to_world;
+    std::string camera_name = "perspective";
+    float fov = 90.f, lens_radius = 0.f, focal_distance = 1e6f;
+    float shutter_open = 0.f, shutter_close = 1.f;
+    float frame_aspect = -1.f;
+    bool has_screen_window = false;
+    float screen_window[4] = {0, 0, 0, 0};
+    int xres = 1280, yres = 720;
+    float crop[4] = {0, 1, 0, 1};
+    float film_scale = 1.f, film_diagonal = 35.f;
+    float max_sample_luminance = std::numeric_limits<float>::infinity();
+    std::string film_filename = "pbrt.exr";
+    std::string filter_name = "box";
+    float filter_rx = 0.5f, filter_ry = 0.5f;
+    std::string sampler_name = "halton";
+    int spp = 16;
+    std::string integrator_name = "path";
+    int max_depth = 5;
+    float rr_threshold = 1.f;
+    std::string accel_split = "sah";
+    int max_node_prims = 4;
+
+    // ---- flattened output (filled by finalize) ----
+    std::vector<iile_bvh_node> nodes;
+    std::vector<uint32_t> o_flags;
+    std::vector<int32_t> o_material, o_light, o_shape;
+    std::vector<float> o_tri_p, o_tri_n, o_tri_uv;
+    std::vector<uint16_t> perms;
+    std::vector<int32_t> primes, prime_sums;
+    int n_interior = 0, n_leaf = 0;
+    iile_scene_desc desc;
+};
+
+// pbrt_loader.cpp
+bool load_pbrt_file(const std::string &path, HostScene *scene, std::string *err);
+// finalize.cpp: BVH build + camera + halton tables + desc
+bool finalize_scene(HostScene *scene, std::string *err);
+// loopsubdiv.cpp
+void loop_subdivide(int n_levels, const std::vector<int> &indices, const std::vector<V3> &P,
+                    std::vector<int> *out_indices, std::vector<V3> *out_P, std::vector<V3> *out_N);
+// bvh_build.cpp
+void build_bvh(HostScene *scene);
+// halton_tables.cpp
+void build_halton_tables(HostScene *scene);
+
+}  // namespace iile

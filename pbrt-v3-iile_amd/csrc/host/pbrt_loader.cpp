@@ -1,0 +1,572 @@
+// pbrt_loader.cpp — minimal .pbrt scene-description front end.
+//
+// The reference's parser/API layer (src/core/parser.cpp, api.cpp, paramset.cpp)
+// is OUT OF SCOPE as a re-implementation; the GPU box
+// only receives this repository, so the path needs its own loader for the
+// directives killeroo-class scenes use. What IS in scope is bit-equal scene
+// preparation: number parsing through strtol/strtof
+// (parser.cpp:258-300), CTM post-multiplication (api.cpp:934-995),
+// `Camera` storing Inverse(CTM) (api.cpp:1118-1123), one primitive per
+// triangle with the area light attached per shape (api.cpp:1371-1430).
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "host_scene.h"
+
+namespace iile {
+namespace {
+
+struct Token {
+    enum Kind { Word, String, LBracket, RBracket, End } kind = End;
+    std::string text;
+};
+
+class Lexer {
+  public:
+    bool open(const std::string &path) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return false;
+        std::stringstream ss;
+        ss << f.rdbuf();
+        buf_ = ss.str();
+        pos_ = 0;
+        return true;
+    }
+    // parser.cpp:150-255: whitespace, '#' comments, quoted strings, brackets,
+    // everything else runs to the next delimiter.
+    Token next() {
+        Token t;
+        while (pos_ < buf_.size()) {
+            char ch = buf_[pos_];
+            if (ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r') {
+                ++pos_;
+            } else if (ch == '#') {
+                while (pos_ < buf_.size() && buf_[pos_] != '\n' && buf_[pos_] != '\r') ++pos_;
+            } else
+                break;
+        }
+        if (pos_ >= buf_.size()) return t;
+        char ch = buf_[pos_];
+        if (ch == '"') {
+            size_t e = buf_.find('"', pos_ + 1);
+            if (e == std::string::npos) e = buf_.size();
+            t.kind = Token::String;
+            t.text = buf_.substr(pos_ + 1, e - pos_ - 1);
+            pos_ = e + 1;
+        } else if (ch == '[') {
+            t.kind = Token::LBracket;
+            ++pos_;
+        } else if (ch == ']') {
+            t.kind = Token::RBracket;
+            ++pos_;
+        } else {
+            size_t s = pos_;
+            while (pos_ < buf_.size()) {
+                char c = buf_[pos_];
+                if (c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '"' || c == '[' || c == ']')
+                    break;
+                ++pos_;
+            }
+            t.kind = Token::Word;
+            t.text = buf_.substr(s, pos_ - s);
+        }
+        return t;
+    }
+
+  private:
+    std::string buf_;
+    size_t pos_ = 0;
+};
+
+// parser.cpp:258-300: all-digit tokens go through strtol, everything else
+// through strtof; the value travels as double and is cast at the use site.
+bool parse_number(const std::string &s, double *out) {
+    if (s.size() == 1) {
+        if (!(s[0] >= '0' && s[0] <= '9')) return false;
+        *out = s[0] - '0';
+        return true;
+    }
+    bool is_int = true;
+    for (char c : s)
+        if (!(c >= '0' && c <= '9')) is_int = false;
+    char *end = nullptr;
+    double v;
+    if (is_int)
+        v = double(strtol(s.c_str(), &end, 10));
+    else
+        v = strtof(s.c_str(), &end);
+    if (v == 0 && end == s.c_str()) return false;
+    *out = v;
+    return true;
+}
+
+struct Param {
+    std::string type, name;
+    std::vector<double> nums;
+    std::vector<std::string> strs;
+};
+struct ParamSet {
+    std::vector<Param> params;
+    const Param *find(const std::string &name) const {
+        for (const Param &p : params)
+            if (p.name == name) return &p;
+        return nullptr;
+    }
+    float one_float(const std::string &name, float def) const {
+        const Param *p = find(name);
+        return (p && p->type == "float" && p->nums.size() == 1) ? float(p->nums[0]) : def;
+    }
+    int one_int(const std::string &name, int def) const {
+        const Param *p = find(name);
+        return (p && p->type == "integer" && p->nums.size() == 1) ? int(p->nums[0]) : def;
+    }
+    bool one_bool(const std::string &name, bool def) const {
+        const Param *p = find(name);
+        if (!p || p->type != "bool" || p->strs.size() != 1) return def;
+        return p->strs[0] == "true";
+    }
+    std::string one_string(const std::string &name, const std::string &def) const {
+        const Param *p = find(name);
+        return (p && p->type == "string" && p->strs.size() == 1) ? p->strs[0] : def;
+    }
+    bool rgb(const std::string &name, float out[3]) const {
+        const Param *p = find(name);
+        if (!p || (p->type != "color" && p->type != "rgb") || p->nums.size() != 3) return false;
+        for (int i = 0; i < 3; ++i) out[i] = float(p->nums[i]);
+        return true;
+    }
+};
+
+struct GraphicsState {
+    int material = -1;  // index into scene->materials, -1 = default matte
+    bool has_area_light = false;
+    ParamSet area_light_params;
+    bool reverse_orientation = false;
+};
+
+class Loader {
+  public:
+    Loader(HostScene *s, std::string *err) : scene_(s), err_(err) {}
+
+    bool run(const std::string &path) {
+        size_t slash = path.find_last_of('/');
+        search_dir_ = (slash == std::string::npos) ? "." : path.substr(0, slash);
+        return parse_file(path);
+    }
+
+  private:
+    HostScene *scene_;
+    std::string *err_;
+    std::string search_dir_;
+    Xform ctm_;
+    std::map<std::string, Xform> named_cs_;
+    GraphicsState gs_;
+    std::vector<GraphicsState> gs_stack_;
+    std::vector<Xform> ctm_stack_;
+    bool in_world_ = false;
+    int default_material_ = -1;
+
+    bool fail(const std::string &m) {
+        if (err_) *err_ = m;
+        return false;
+    }
+
+    bool parse_file(const std::string &path) {
+        Lexer lex;
+        if (!lex.open(path)) return fail("cannot open scene file " + path);
+        Token pending;
+        bool have_pending = false;
+        auto next = [&]() {
+            if (have_pending) {
+                have_pending = false;
+                return pending;
+            }
+            return lex.next();
+        };
+        auto unget = [&](const Token &t) {
+            pending = t;
+            have_pending = true;
+        };
+        auto numbers = [&](int n, float *out) -> bool {
+            for (int i = 0; i < n; ++i) {
+                Token t = next();
+                double v;
+                if (t.kind != Token::Word || !parse_number(t.text, &v)) return false;
+                out[i] = float(v);
+            }
+            return true;
+        };
+        // parser.cpp:549-700 (parseParams): `"type name" value | [ values ]`
+        auto params = [&](ParamSet *ps) -> bool {
+            while (true) {
+                Token t = next();
+                if (t.kind != Token::String) {
+                    unget(t);
+                    return true;
+                }
+                Param p;
+                std::istringstream decl(t.text);
+                decl >> p.type >> p.name;
+                if (p.type.empty() || p.name.empty()) return fail("bad parameter declaration \"" + t.text + "\"");
+                auto add_value = [&](const Token &v) -> bool {
+                    if (v.kind == Token::String) {
+                        p.strs.push_back(v.text);
+                        return true;
+                    }
+                    if (v.kind != Token::Word) return false;
+                    if (p.type == "bool") {
+                        p.strs.push_back(v.text);
+                        return true;
+                    }
+                    double d;
+                    if (!parse_number(v.text, &d)) return false;
+                    p.nums.push_back(d);
+                    return true;
+                };
+                Token v = next();
+                if (v.kind == Token::LBracket) {
+                    while (true) {
+                        v = next();
+                        if (v.kind == Token::RBracket) break;
+                        if (v.kind == Token::End) return fail("premature EOF in parameter list");
+                        if (!add_value(v)) return fail("bad value for parameter " + p.name);
+                    }
+                } else if (!add_value(v))
+                    return fail("bad value for parameter " + p.name);
+                if (p.type == "point3") p.type = "point";
+                if (p.type == "vector3") p.type = "vector";
+                if (p.type == "normal3") p.type = "normal";
+                ps->params.push_back(std::move(p));
+            }
+        };
+
+        while (true) {
+            Token t = next();
+            if (t.kind == Token::End) break;
+            if (t.kind != Token::Word) return fail("unexpected token \"" + t.text + "\"");
+            const std::string &d = t.text;
+            float f[16];
+            if (d == "AttributeBegin") {
+                gs_stack_.push_back(gs_);
+                ctm_stack_.push_back(ctm_);
+            } else if (d == "AttributeEnd") {
+                if (gs_stack_.empty()) return fail("unmatched AttributeEnd");
+                gs_ = gs_stack_.back();
+                gs_stack_.pop_back();
+                ctm_ = ctm_stack_.back();
+                ctm_stack_.pop_back();
+            } else if (d == "TransformBegin") {
+                ctm_stack_.push_back(ctm_);
+            } else if (d == "TransformEnd") {
+                if (ctm_stack_.empty()) return fail("unmatched TransformEnd");
+                ctm_ = ctm_stack_.back();
+                ctm_stack_.pop_back();
+            } else if (d == "Identity") {
+                ctm_ = Xform();
+            } else if (d == "Translate") {  // api.cpp:934-942
+                if (!numbers(3, f)) return fail("Translate: expected 3 numbers");
+                ctm_ = ctm_ * xf_translate(V3(f[0], f[1], f[2]));
+            } else if (d == "Scale") {  // api.cpp:984-991
+                if (!numbers(3, f)) return fail("Scale: expected 3 numbers");
+                ctm_ = ctm_ * xf_scale(f[0], f[1], f[2]);
+            } else if (d == "Rotate") {  // api.cpp:973-982
+                if (!numbers(4, f)) return fail("Rotate: expected 4 numbers");
+                ctm_ = ctm_ * xf_rotate(f[0], V3(f[1], f[2], f[3]));
+            } else if (d == "LookAt") {  // api.cpp:993-1007
+                if (!numbers(9, f)) return fail("LookAt: expected 9 numbers");
+                Xform la;
+                xf_lookat(V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]), V3(f[6], f[7], f[8]), &la);
+                ctm_ = ctm_ * la;
+            } else if (d == "Transform" || d == "ConcatTransform") {  // api.cpp:944-971
+                Token b = next();
+                if (b.kind != Token::LBracket) return fail(d + ": expected [");
+                if (!numbers(16, f)) return fail(d + ": expected 16 numbers");
+                b = next();
+                if (b.kind != Token::RBracket) return fail(d + ": expected ]");
+                Xform x(Mat4(f[0], f[4], f[8], f[12], f[1], f[5], f[9], f[13], f[2], f[6], f[10], f[14],
+                             f[3], f[7], f[11], f[15]));
+                ctm_ = (d == "Transform") ? x : ctm_ * x;
+            } else if (d == "CoordinateSystem" || d == "CoordSysTransform") {
+                Token n = next();
+                if (n.kind != Token::String) return fail(d + ": expected name");
+                if (d == "CoordinateSystem")
+                    named_cs_[n.text] = ctm_;
+                else if (named_cs_.count(n.text))
+                    ctm_ = named_cs_[n.text];
+            } else if (d == "ReverseOrientation") {
+                gs_.reverse_orientation = !gs_.reverse_orientation;
+            } else if (d == "WorldBegin") {  // api.cpp:1160-1168
+                in_world_ = true;
+                ctm_ = Xform();
+                named_cs_["world"] = ctm_;
+            } else if (d == "WorldEnd") {
+                in_world_ = false;
+            } else if (d == "Include") {
+                Token n = next();
+                if (n.kind != Token::String) return fail("Include: expected filename");
+                std::string p = n.text;
+                if (p.empty() || p[0] != '/') p = search_dir_ + "/" + p;
+                if (!parse_file(p)) return false;
+            } else if (d == "Camera" || d == "Film" || d == "Sampler" || d == "Integrator" ||
+                       d == "PixelFilter" || d == "Accelerator" || d == "Material" ||
+                       d == "AreaLightSource" || d == "Shape" || d == "LightSource") {
+                Token n = next();
+                if (n.kind != Token::String) return fail(d + ": expected quoted name");
+                ParamSet ps;
+                if (!params(&ps)) return false;
+                if (!directive(d, n.text, ps)) return false;
+            } else
+                return fail("unsupported directive \"" + d + "\"");
+        }
+        return true;
+    }
+
+    bool directive(const std::string &d, const std::string &name, const ParamSet &ps) {
+        HostScene &s = *scene_;
+        if (d == "Camera") {  // api.cpp:1118-1123, cameras/perspective.cpp:283-330
+            if (name != "perspective") return fail("only the perspective camera is supported, got " + name);
+            s.camera_name = name;
+            s.camera_to_world = inverse(ctm_);
+            named_cs_["camera"] = s.camera_to_world;
+            s.shutter_open = ps.one_float("shutteropen", 0.f);
+            s.shutter_close = ps.one_float("shutterclose", 1.f);
+            if (s.shutter_close < s.shutter_open) std::swap(s.shutter_close, s.shutter_open);
+            s.lens_radius = ps.one_float("lensradius", 0.f);
+            s.focal_distance = ps.one_float("focaldistance", 1e6);
+            s.frame_aspect = ps.one_float("frameaspectratio", -1.f);
+            const Param *sw = ps.find("screenwindow");
+            if (sw && sw->nums.size() == 4) {
+                s.has_screen_window = true;
+                for (int i = 0; i < 4; ++i) s.screen_window[i] = float(sw->nums[i]);
+            }
+            s.fov = ps.one_float("fov", 90.);
+            float half = ps.one_float("halffov", -1.f);
+            if (half > 0.f) s.fov = 2.f * half;
+        } else if (d == "Film") {  // film.cpp:259-304
+            if (name != "image") return fail("only Film \"image\" is supported");
+            s.xres = ps.one_int("xresolution", 1280);
+            s.yres = ps.one_int("yresolution", 720);
+            s.film_filename = ps.one_string("filename", "pbrt.exr");
+            const Param *cw = ps.find("cropwindow");
+            if (cw && cw->nums.size() == 4) {
+                float c[4];
+                for (int i = 0; i < 4; ++i) c[i] = float(cw->nums[i]);
+                s.crop[0] = clampT(std::min(c[0], c[1]), 0.f, 1.f);
+                s.crop[1] = clampT(std::max(c[0], c[1]), 0.f, 1.f);
+                s.crop[2] = clampT(std::min(c[2], c[3]), 0.f, 1.f);
+                s.crop[3] = clampT(std::max(c[2], c[3]), 0.f, 1.f);
+            }
+            s.film_scale = ps.one_float("scale", 1.);
+            s.film_diagonal = ps.one_float("diagonal", 35.);
+            s.max_sample_luminance =
+                ps.one_float("maxsampleluminance", std::numeric_limits<float>::infinity());
+        } else if (d == "Sampler") {  // samplers/halton.cpp:129-135
+            if (name != "halton") return fail("only Sampler \"halton\" is supported, got " + name);
+            s.sampler_name = name;
+            s.spp = ps.one_int("pixelsamples", 16);
+            if (ps.one_bool("samplepixelcenter", false)) return fail("samplepixelcenter is not supported");
+        } else if (d == "PixelFilter") {  // filters/box.cpp:43-47
+            if (name != "box") return fail("only PixelFilter \"box\" is supported, got " + name);
+            s.filter_rx = ps.one_float("xwidth", 0.5f);
+            s.filter_ry = ps.one_float("ywidth", 0.5f);
+        } else if (d == "Integrator") {  // integrators/path.cpp:214-231
+            if (name != "path") return fail("only Integrator \"path\" is supported, got " + name);
+            s.max_depth = ps.one_int("maxdepth", 5);
+            s.rr_threshold = ps.one_float("rrthreshold", 1.);
+            if (ps.find("pixelbounds")) return fail("pixelbounds is not supported");
+        } else if (d == "Accelerator") {  // accelerators/bvh.cpp:740-760
+            if (name != "bvh") return fail("only Accelerator \"bvh\" is supported");
+            s.accel_split = ps.one_string("splitmethod", "sah");
+            if (s.accel_split != "sah") return fail("only splitmethod \"sah\" is supported");
+            s.max_node_prims = ps.one_int("maxnodeprims", 4);
+        } else if (d == "Material") {
+            int idx = make_material(name, ps);
+            if (idx < 0) return false;
+            gs_.material = idx;
+        } else if (d == "AreaLightSource") {  // api.cpp:1360-1369
+            if (name != "area" && name != "diffuse") return fail("unknown area light " + name);
+            gs_.has_area_light = true;
+            gs_.area_light_params = ps;
+        } else if (d == "LightSource") {
+            return fail("LightSource \"" + name + "\" is not supported (area lights on spheres only)");
+        } else if (d == "Shape") {
+            return make_shape(name, ps);
+        }
+        return true;
+    }
+
+    // materials/matte.cpp:64-71, plastic.cpp:72-84, microfacet.h:123-128
+    int make_material(const std::string &name, const ParamSet &ps) {
+        iile_material m;
+        std::memset(&m, 0, sizeof(m));
+        if (name == "matte") {
+            m.type = IILE_MAT_MATTE;
+            float kd[3] = {0.5f, 0.5f, 0.5f};
+            ps.rgb("Kd", kd);
+            for (int i = 0; i < 3; ++i) m.kd[i] = kd[i];
+            m.sigma = ps.one_float("sigma", 0.f);
+            if (clampT(m.sigma, 0.f, 90.f) != 0.f) {
+                fail("matte with sigma != 0 (Oren-Nayar) is not supported");
+                return -1;
+            }
+        } else if (name == "plastic") {
+            m.type = IILE_MAT_PLASTIC;
+            float kd[3] = {0.25f, 0.25f, 0.25f}, ks[3] = {0.25f, 0.25f, 0.25f};
+            ps.rgb("Kd", kd);
+            ps.rgb("Ks", ks);
+            for (int i = 0; i < 3; ++i) {
+                m.kd[i] = kd[i];
+                m.ks[i] = ks[i];
+            }
+            m.roughness = ps.one_float("roughness", .1f);
+            m.remap_roughness = ps.one_bool("remaproughness", true) ? 1 : 0;
+            if (m.remap_roughness) {
+                // The reference re-evaluates this per hit (plastic.cpp:61-63);
+                // it is a per-material constant, so it is evaluated once here.
+                float r = std::max(m.roughness, 1e-3f);
+                float x = std::log(r);
+                m.alpha = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x +
+                          0.000640711f * x * x * x * x;
+            } else
+                m.alpha = m.roughness;
+        } else {
+            fail("Material \"" + name + "\" is not supported (matte, plastic)");
+            return -1;
+        }
+        for (const char *tex : {"bumpmap"})
+            if (ps.find(tex)) {
+                fail("bump maps are not supported");
+                return -1;
+            }
+        scene_->materials.push_back(m);
+        return int(scene_->materials.size()) - 1;
+    }
+
+    int current_material() {
+        if (gs_.material >= 0) return gs_.material;
+        if (default_material_ < 0) default_material_ = make_material("matte", ParamSet());
+        return default_material_;
+    }
+
+    bool make_shape(const std::string &name, const ParamSet &ps) {
+        HostScene &s = *scene_;
+        const Xform o2w = ctm_;
+        const bool flip = gs_.reverse_orientation ^ o2w.swaps_handedness();
+        int mat = current_material();
+        if (mat < 0) return false;
+        if (name == "sphere") {  // shapes/sphere.cpp:318-327, sphere.h:50-60
+            float radius = ps.one_float("radius", 1.f);
+            float zmin = ps.one_float("zmin", -radius);
+            float zmax = ps.one_float("zmax", radius);
+            float phimax = ps.one_float("phimax", 360.f);
+            iile_sphere sp;
+            std::memset(&sp, 0, sizeof(sp));
+            std::memcpy(sp.o2w, o2w.m.m, sizeof(sp.o2w));
+            std::memcpy(sp.o2w_inv, o2w.inv.m, sizeof(sp.o2w_inv));
+            sp.radius = radius;
+            sp.zmin = clampT(std::min(zmin, zmax), -radius, radius);
+            sp.zmax = clampT(std::max(zmin, zmax), -radius, radius);
+            sp.theta_min = std::acos(clampT(std::min(zmin, zmax) / radius, -1.f, 1.f));
+            sp.theta_max = std::acos(clampT(std::max(zmin, zmax) / radius, -1.f, 1.f));
+            sp.phi_max = radians(clampT(phimax, 0.f, 360.f));
+            sp.reverse_orientation = gs_.reverse_orientation;
+            sp.swaps_handedness = o2w.swaps_handedness();
+            s.spheres.push_back(sp);
+            HostPrim pr;
+            pr.flags = IILE_PRIM_SPHERE | (flip ? IILE_PRIM_FLIP : 0);
+            pr.material = mat;
+            pr.shape = int(s.spheres.size()) - 1;
+            // Shape::WorldBound = ObjectToWorld(ObjectBound()), shape.cpp:54, sphere.cpp:43-46
+            pr.world_bound =
+                o2w.bounds(Bounds3(V3(-radius, -radius, sp.zmin), V3(radius, radius, sp.zmax)));
+            if (gs_.has_area_light) {  // api.cpp:808-826 (MakeAreaLight), lights/diffuse.cpp:125-146
+                float L[3] = {1, 1, 1}, sc[3] = {1, 1, 1};
+                gs_.area_light_params.rgb("L", L);
+                gs_.area_light_params.rgb("scale", sc);
+                iile_light lt;
+                std::memset(&lt, 0, sizeof(lt));
+                for (int i = 0; i < 3; ++i) lt.lemit[i] = L[i] * sc[i];
+                lt.two_sided = gs_.area_light_params.one_bool("twosided", false);
+                lt.sphere = pr.shape;
+                s.lights.push_back(lt);
+                pr.light = int(s.lights.size()) - 1;
+            }
+            s.prims.push_back(pr);
+            return true;
+        }
+        std::vector<int> indices;
+        std::vector<V3> P, N;
+        std::vector<float> uv;
+        const Param *pi = ps.find("indices");
+        const Param *pp = ps.find("P");
+        if (!pi || !pp) return fail("Shape " + name + ": \"indices\" and \"P\" are required");
+        for (double v : pi->nums) indices.push_back(int(v));
+        for (size_t i = 0; i + 2 < pp->nums.size(); i += 3)
+            P.push_back(V3(float(pp->nums[i]), float(pp->nums[i + 1]), float(pp->nums[i + 2])));
+        if (name == "trianglemesh") {  // shapes/triangle.cpp:616-714
+            const Param *pu = ps.find("uv");
+            if (!pu) pu = ps.find("st");
+            if (pu) {
+                for (double v : pu->nums) uv.push_back(float(v));
+                if (uv.size() / 2 < P.size()) uv.clear();
+            }
+            const Param *pn = ps.find("N");
+            if (pn && pn->nums.size() == 3 * P.size())
+                for (size_t i = 0; i + 2 < pn->nums.size(); i += 3)
+                    N.push_back(V3(float(pn->nums[i]), float(pn->nums[i + 1]), float(pn->nums[i + 2])));
+            if (ps.find("S")) return fail("trianglemesh \"S\" tangents are not supported");
+            if (ps.find("alpha") || ps.find("shadowalpha")) return fail("alpha masks are not supported");
+        } else if (name == "loopsubdiv") {  // shapes/loopsubdiv.cpp:402-424
+            int levels = ps.one_int("levels", ps.one_int("nlevels", 3));
+            std::vector<int> oi;
+            std::vector<V3> oP, oN;
+            loop_subdivide(levels, indices, P, &oi, &oP, &oN);
+            indices.swap(oi);
+            P.swap(oP);
+            N.swap(oN);
+        } else
+            return fail("Shape \"" + name + "\" is not supported (sphere, trianglemesh, loopsubdiv)");
+        if (gs_.has_area_light) return fail("area lights on triangle meshes are not supported");
+        for (int idx : indices)
+            if (idx < 0 || idx >= int(P.size())) return fail("trianglemesh has out-of-bounds vertex index");
+        // TriangleMesh ctor, shapes/triangle.cpp:54-93: vertices and normals to world space
+        std::vector<V3> Pw(P.size()), Nw(N.size());
+        for (size_t i = 0; i < P.size(); ++i) Pw[i] = o2w.point(P[i]);
+        for (size_t i = 0; i < N.size(); ++i) Nw[i] = o2w.normal(N[i]);
+        int mesh_id = s.n_meshes++;
+        size_t ntris = indices.size() / 3;
+        s.prims.reserve(s.prims.size() + ntris);
+        for (size_t t = 0; t < ntris; ++t) {
+            HostPrim pr;
+            pr.flags = (N.empty() ? 0 : IILE_PRIM_HAS_NORMALS) | (uv.empty() ? 0 : IILE_PRIM_HAS_UV) |
+                       (flip ? IILE_PRIM_FLIP : 0);
+            pr.material = mat;
+            pr.shape = mesh_id;
+            for (int k = 0; k < 3; ++k) {
+                int vi = indices[3 * t + k];
+                pr.p[k] = Pw[vi];
+                if (!N.empty()) pr.n[k] = Nw[vi];
+                if (!uv.empty()) {
+                    pr.uv[2 * k] = uv[2 * vi];
+                    pr.uv[2 * k + 1] = uv[2 * vi + 1];
+                }
+            }
+            // Triangle::WorldBound, shapes/triangle.cpp:180-186
+            pr.world_bound = bunion(Bounds3(pr.p[0], pr.p[1]), pr.p[2]);
+            s.prims.push_back(pr);
+        }
+        return true;
+    }
+};
+
+}  // namespace
+
+bool load_pbrt_file(const std::string &path, HostScene *scene, std::string *err) {
+    Loader l(scene, err);
+    return l.run(path);
+}
+
+}  // namespace iile
