@@ -49,6 +49,8 @@ typedef struct iile_host_scene_info {
 int iile_host_load_pbrt(const char *path, const iile_host_overrides *ov, iile_host_scene **out);
 /* The flattened scene; valid until iile_host_scene_free. */
 const iile_scene_desc *iile_host_scene_desc(const iile_host_scene *scene);
+/* &desc->film, for bindings that do not mirror the whole iile_scene_desc. */
+const iile_film_desc *iile_host_scene_film(const iile_host_scene *scene);
 int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info *info);
 void iile_host_scene_free(iile_host_scene *scene);
 

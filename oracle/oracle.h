@@ -1,0 +1,86 @@
+/*
+ * oracle.h — C interface of the CPU oracle (TEST INFRASTRUCTURE, not product).
+ *
+ * The oracle is a scalar CPU restatement of the reference's path-tracing hot
+ * path (PathIntegrator::Li, BVHAccel::Intersect/IntersectP, the
+ * SamplerIntegrator::Render tile loop, HaltonSampler, FilmTile) consuming the
+ * same flattened iile_scene_desc as the GPU library. Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * product (libiile_gpu.so) never links or calls it.
+ */
+#ifndef IILE_ORACLE_H
+#define IILE_ORACLE_H
+
+#include <stdint.h>
+
+#include "../include/iile_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* trig_mode: how sin/cos/acos on the path are evaluated.
+ *   ORACLE_TRIG_LIBM     — call the host libm exactly where the reference does
+ *                          (float overloads; double in microfacet.cpp:241-246).
+ *                          This is the mode that is pinned against the reference.
+ *   ORACLE_TRIG_PORTABLE — a fixed double-precision polynomial evaluation that the
+ *                          HIP kernels restate operation for operation, so device
+ *                          and oracle agree bit for bit. */
+enum { ORACLE_TRIG_LIBM = 0, ORACLE_TRIG_PORTABLE = 1 };
+
+typedef struct oracle_stats {
+    uint64_t camera_rays;      /* integrator.cpp:286 */
+    uint64_t regular_rays;     /* Scene::Intersect calls, scene.cpp:45-50 */
+    uint64_t shadow_rays;      /* Scene::IntersectP calls, scene.cpp:52-57 */
+    uint64_t tri_tests;        /* triangle.cpp:45 nTests (Intersect + IntersectP) */
+    uint64_t tri_hits;         /* nHits */
+    uint64_t sphere_tests;
+    uint64_t nodes_closest;    /* BVH nodes visited by Intersect */
+    uint64_t nodes_any;        /* BVH nodes visited by IntersectP */
+    uint64_t nee_evals;        /* path.cpp:122 totalPaths */
+    uint64_t zero_radiance;    /* path.cpp:126 */
+    uint64_t path_length[8];   /* histogram of `bounces` at ReportValue, path.cpp:192 */
+    int32_t max_stack_depth;
+    int32_t threads;
+    double seconds;            /* wall time of the render loop only */
+} oracle_stats;
+
+/* SamplerIntegrator::Render restated: tiles of 16x16 over the sample bounds,
+ * samples k in [k_begin,k_end) (0,-1 => all spp), only tiles with
+ * tile_index % tile_nranks == tile_rank. film_xyzw: {X,Y,Z,weightSum} per pixel
+ * of the cropped pixel bounds (Film::Pixel after MergeFilmTile). */
+int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, int k_begin, int k_end,
+                  int tile_rank, int tile_nranks, float *film_xyzw, oracle_stats *stats);
+
+/* ---- unit-level entry points for known-answer and parity tests ---- */
+int64_t oracle_halton_index(const iile_scene_desc *scene, int px, int py, int64_t k);
+float oracle_halton_sample(const iile_scene_desc *scene, int64_t index, int dim);
+float oracle_radical_inverse(int base_index, uint64_t a);
+float oracle_scrambled_radical_inverse(const iile_scene_desc *scene, int base_index, uint64_t a);
+void oracle_camera_ray(const iile_scene_desc *scene, float pfilm_x, float pfilm_y, float plens_x,
+                       float plens_y, float *o3, float *d3);
+/* closest hit for n rays: prim[i] = -1 on miss; tb[4*i..] = {t, b0, b1, b2}
+ * (for spheres b* are 0). */
+void oracle_intersect(const iile_scene_desc *scene, int n, const float *o, const float *d,
+                      const float *tmax, int32_t *prim, float *tb);
+void oracle_intersect_p(const iile_scene_desc *scene, int n, const float *o, const float *d,
+                        const float *tmax, int32_t *hit);
+/* Per-sample radiance Li for n (pixel, k) pairs; L: 3 floats each after the
+ * NaN/negative/inf guards of integrator.cpp:293-314; nrays (optional): 2 per
+ * sample {regular, shadow}. */
+void oracle_li(const iile_scene_desc *scene, int trig_mode, int n, const int32_t *px, const int32_t *py,
+               const int32_t *k, float *L, int32_t *nrays);
+/* BSDF probes in the local shading frame of material `mat` with ns=ng=(0,0,1),
+ * ss=(1,0,0): f (3), pdf and Sample_f -> {wi(3), f(3), pdf}. */
+void oracle_bsdf_eval(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3,
+                      const float *wi3, float *f3, float *pdf);
+void oracle_bsdf_sample(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3,
+                        const float *u2, float *wi3, float *f3, float *pdf);
+void oracle_sincos(int trig_mode, float x, float *s, float *c);
+void oracle_sincos_d(int trig_mode, double x, double *s, double *c);
+float oracle_acos(int trig_mode, float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1695 @@
+// oracle_path.cpp — CPU restatement of the reference's path-tracing hot path.
+//
+// *** TEST INFRASTRUCTURE ***  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load this library. The product
+// (libiile_gpu.so) never links, calls or falls back to it.
+//
+// What it restates (citations relative to /root/reference/src), scalar, one
+// sample at a time, float arithmetic in the reference's evaluation order:
+//   SamplerIntegrator::Render tile loop        core/integrator.cpp:227-339
+//   PathIntegrator::Li                         integrators/path.cpp:64-194
+//   UniformSampleOneLight / EstimateDirect     core/integrator.cpp:85-215
+//   BVHAccel::Intersect / IntersectP           accelerators/bvh.cpp:662-738
+//   Bounds3::IntersectP                        core/geometry.h:1411-1438
+//   Triangle::Intersect / IntersectP           shapes/triangle.cpp:188-544
+//   Sphere::Intersect / IntersectP / Sample / Pdf   shapes/sphere.cpp:49-306
+//   EFloat, Quadratic                          core/efloat.h
+//   BSDF, Lambertian, MicrofacetReflection, TrowbridgeReitz, FrDielectric
+//                                              core/reflection.{h,cpp}, core/microfacet.cpp
+//   DiffuseAreaLight, VisibilityTester, SpawnRay*, OffsetRayOrigin
+//   HaltonSampler / GlobalSampler / radical inverses
+//                                              samplers/halton.cpp, core/sampler.cpp, core/lowdiscrepancy.cpp
+//   PerspectiveCamera::GenerateRayDifferential cameras/perspective.cpp:100-149
+//   FilmTile::AddSample / Film::MergeFilmTile  core/film.h:153-193, core/film.cpp:135-148
+//
+// Pinning (see DESIGN.md "Oracle"): the reference cannot be built in this
+// image without a stand-in for the absent glog submodule, so there is no
+// oracle/_ref. The restatement is pinned against the reference's own
+// known-answer tests and against outputs of the reference recorded in
+// SURVEY.md §6/§8c (Halton values, ray / triangle-test / node counts, image
+// mean) — tests/test_oracle_pins.py.
+#include "oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// constants (core/pbrt.h:196-208, core/rng.h:53)
+constexpr float Pi = 3.14159265358979323846f;
+constexpr float InvPi = 0.31830988618379067154f;
+constexpr float PiOver2 = 1.57079632679489661923f;
+constexpr float PiOver4 = 0.78539816339744830961f;
+constexpr float Infinity = std::numeric_limits<float>::infinity();
+constexpr float MachineEpsilon = std::numeric_limits<float>::epsilon() * 0.5f;
+constexpr float ShadowEpsilon = 0.0001f;
+constexpr float OneMinusEpsilon = 0x1.fffffep-1f;
+inline float gamma_n(int n) { return (n * MachineEpsilon) / (1 - n * MachineEpsilon); }
+
+inline uint32_t f2b(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+inline float b2f(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// core/pbrt.h:238-262
+inline float next_up(float v) {
+    if (std::isinf(v) && v > 0.) return v;
+    if (v == -0.f) v = 0.f;
+    uint32_t ui = f2b(v);
+    if (v >= 0)
+        ++ui;
+    else
+        --ui;
+    return b2f(ui);
+}
+inline float next_down(float v) {
+    if (std::isinf(v) && v < 0.) return v;
+    if (v == 0.f) v = -0.f;
+    uint32_t ui = f2b(v);
+    if (v > 0)
+        --ui;
+    else
+        ++ui;
+    return b2f(ui);
+}
+inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ----------------------------------------------------------------------------
+// trigonometry: libm (reference behaviour) or the portable evaluation shared
+// with the HIP kernels.
+void portable_sincos(double x, double *s, double *c) {
+    // Cody-Waite reduction by pi/2 (two-term) + degree-13/12 minimax polynomials
+    // on [-pi/4, pi/4] (classic fdlibm coefficients). Plain IEEE double
+    // operations, no FMA contraction: restated verbatim in the device code.
+    const double k = std::nearbyint(x * 6.36619772367581382433e-01);
+    const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double ps =
+        r + r * z *
+                (-1.66666666666666324348e-01 +
+                 z * (8.33333333332248946124e-03 +
+                      z * (-1.98412698298579493134e-04 +
+                           z * (2.75573137070700676789e-06 +
+                                z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+    const double pc =
+        (1.0 - 0.5 * z) +
+        z * z *
+            (4.16666666666666019037e-02 +
+             z * (-1.38888888888741095749e-03 +
+                  z * (2.48015872894767294178e-05 +
+                       z * (-2.75573143513906633035e-07 +
+                            z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    switch (int(k) & 3) {
+    case 0: *s = ps; *c = pc; break;
+    case 1: *s = pc; *c = -ps; break;
+    case 2: *s = -ps; *c = -pc; break;
+    default: *s = -pc; *c = ps; break;
+    }
+}
+double portable_acos(double x) {
+    // rational approximation of asin on [0, 0.5] (fdlibm e_acos.c structure)
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+                 pi = 3.14159265358979311600e+00;
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+                 pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+                 pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+                 qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    const double ax = std::fabs(x);
+    if (ax >= 1.0) {
+        if (x == 1.0) return 0.0;
+        if (x == -1.0) return pi + 2.0 * pio2_lo;
+        return std::numeric_limits<double>::quiet_NaN();
+    }
+    if (ax < 0.5) {
+        if (ax < 6.938893903907228e-18) return pio2_hi + pio2_lo;
+        const double z = x * x;
+        const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    } else if (x < 0) {
+        const double z = (1.0 + x) * 0.5;
+        const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double s = std::sqrt(z);
+        const double r = p / q;
+        const double w = r * s - pio2_lo;
+        return pi - 2.0 * (s + w);
+    } else {
+        const double z = (1.0 - x) * 0.5;
+        const double s = std::sqrt(z);
+        uint64_t bits;
+        std::memcpy(&bits, &s, 8);
+        bits &= 0xffffffff00000000ULL;
+        double df;
+        std::memcpy(&df, &bits, 8);
+        const double c = (z - df * df) / (s + df);
+        const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double r = p / q;
+        const double w = r * s + c;
+        return 2.0 * (df + w);
+    }
+}
+
+struct Trig {
+    int mode;
+    float sin_f(float x) const {
+        if (mode == ORACLE_TRIG_LIBM) return std::sin(x);
+        double s, c;
+        portable_sincos(double(x), &s, &c);
+        return float(s);
+    }
+    float cos_f(float x) const {
+        if (mode == ORACLE_TRIG_LIBM) return std::cos(x);
+        double s, c;
+        portable_sincos(double(x), &s, &c);
+        return float(c);
+    }
+    double sin_d(double x) const {
+        if (mode == ORACLE_TRIG_LIBM) return ::sin(x);
+        double s, c;
+        portable_sincos(x, &s, &c);
+        return s;
+    }
+    double cos_d(double x) const {
+        if (mode == ORACLE_TRIG_LIBM) return ::cos(x);
+        double s, c;
+        portable_sincos(x, &s, &c);
+        return c;
+    }
+    float acos_f(float x) const {
+        if (mode == ORACLE_TRIG_LIBM) return std::acos(x);
+        return float(portable_acos(double(x)));
+    }
+};
+
+// ----------------------------------------------------------------------------
+// vectors (core/geometry.h)
+struct V3 {
+    float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(float x, float y, float z) : x(x), y(y), z(z) {}
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    float &operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+inline V3 operator*(float s, V3 a) { return V3(s * a.x, s * a.y, s * a.z); }
+inline V3 operator*(V3 a, float s) { return V3(s * a.x, s * a.y, s * a.z); }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float absdot(V3 a, V3 b) { return std::abs(dot(a, b)); }
+inline float length_sq(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+inline float length(V3 a) { return std::sqrt(length_sq(a)); }
+inline V3 vdiv(V3 a, float f) {  // geometry.h:242-246: multiply by float reciprocal
+    float inv = 1.f / f;
+    return V3(a.x * inv, a.y * inv, a.z * inv);
+}
+inline V3 normalize(V3 a) { return vdiv(a, length(a)); }
+inline V3 vabs(V3 a) { return V3(std::abs(a.x), std::abs(a.y), std::abs(a.z)); }
+inline V3 cross(V3 a, V3 b) {  // geometry.h:957-963: evaluated in double
+    double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    return V3(float((ay * bz) - (az * by)), float((az * bx) - (ax * bz)), float((ax * by) - (ay * bx)));
+}
+inline V3 faceforward(V3 n, V3 v) { return (dot(n, v) < 0.f) ? -n : n; }
+inline int max_dimension(V3 v) { return (v.x > v.y) ? ((v.x > v.z) ? 0 : 2) : ((v.y > v.z) ? 1 : 2); }
+inline float max_component(V3 v) { return std::max(v.x, std::max(v.y, v.z)); }
+inline V3 permute(V3 v, int x, int y, int z) { return V3(v[x], v[y], v[z]); }
+// geometry.h:1020-1027
+inline void coordinate_system(V3 v1, V3 *v2, V3 *v3) {
+    if (std::abs(v1.x) > std::abs(v1.y))
+        *v2 = vdiv(V3(-v1.z, 0, v1.x), std::sqrt(v1.x * v1.x + v1.z * v1.z));
+    else
+        *v2 = vdiv(V3(0, v1.z, -v1.y), std::sqrt(v1.y * v1.y + v1.z * v1.z));
+    *v3 = cross(v1, *v2);
+}
+
+struct Rgb {
+    float c[3];
+    Rgb(float v = 0.f) { c[0] = c[1] = c[2] = v; }
+    Rgb(float r, float g, float b) {
+        c[0] = r;
+        c[1] = g;
+        c[2] = b;
+    }
+    bool is_black() const { return c[0] == 0. && c[1] == 0. && c[2] == 0.; }
+    float y() const { return 0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]; }
+    float max_component() const { return std::max(std::max(c[0], c[1]), c[2]); }
+    bool has_nans() const { return std::isnan(c[0]) || std::isnan(c[1]) || std::isnan(c[2]); }
+};
+inline Rgb operator+(Rgb a, Rgb b) { return Rgb(a.c[0] + b.c[0], a.c[1] + b.c[1], a.c[2] + b.c[2]); }
+inline Rgb operator*(Rgb a, Rgb b) { return Rgb(a.c[0] * b.c[0], a.c[1] * b.c[1], a.c[2] * b.c[2]); }
+inline Rgb operator*(Rgb a, float s) { return Rgb(a.c[0] * s, a.c[1] * s, a.c[2] * s); }
+inline Rgb operator/(Rgb a, float s) { return Rgb(a.c[0] / s, a.c[1] / s, a.c[2] / s); }
+
+struct Ray {
+    V3 o, d;
+    float tmax;
+};
+
+// ----------------------------------------------------------------------------
+// transforms (core/transform.h:217-410), m row-major
+struct M4 {
+    const float *a;
+    float operator()(int r, int c) const { return a[4 * r + c]; }
+};
+inline V3 xf_point(M4 m, V3 p) {
+    float x = p.x, y = p.y, z = p.z;
+    float xp = m(0, 0) * x + m(0, 1) * y + m(0, 2) * z + m(0, 3);
+    float yp = m(1, 0) * x + m(1, 1) * y + m(1, 2) * z + m(1, 3);
+    float zp = m(2, 0) * x + m(2, 1) * y + m(2, 2) * z + m(2, 3);
+    float wp = m(3, 0) * x + m(3, 1) * y + m(3, 2) * z + m(3, 3);
+    if (wp == 1) return V3(xp, yp, zp);
+    return vdiv(V3(xp, yp, zp), wp);
+}
+inline V3 xf_point_err(M4 m, V3 p, V3 *err) {  // transform.h:278-300
+    float x = p.x, y = p.y, z = p.z;
+    float xp = m(0, 0) * x + m(0, 1) * y + m(0, 2) * z + m(0, 3);
+    float yp = m(1, 0) * x + m(1, 1) * y + m(1, 2) * z + m(1, 3);
+    float zp = m(2, 0) * x + m(2, 1) * y + m(2, 2) * z + m(2, 3);
+    float wp = m(3, 0) * x + m(3, 1) * y + m(3, 2) * z + m(3, 3);
+    float xs = (std::abs(m(0, 0) * x) + std::abs(m(0, 1) * y) + std::abs(m(0, 2) * z) + std::abs(m(0, 3)));
+    float ys = (std::abs(m(1, 0) * x) + std::abs(m(1, 1) * y) + std::abs(m(1, 2) * z) + std::abs(m(1, 3)));
+    float zs = (std::abs(m(2, 0) * x) + std::abs(m(2, 1) * y) + std::abs(m(2, 2) * z) + std::abs(m(2, 3)));
+    *err = gamma_n(3) * V3(xs, ys, zs);
+    if (wp == 1) return V3(xp, yp, zp);
+    return vdiv(V3(xp, yp, zp), wp);
+}
+inline V3 xf_point_err2(M4 m, V3 pt, V3 pe, V3 *err) {  // transform.h:302-331
+    float x = pt.x, y = pt.y, z = pt.z;
+    float xp = m(0, 0) * x + m(0, 1) * y + m(0, 2) * z + m(0, 3);
+    float yp = m(1, 0) * x + m(1, 1) * y + m(1, 2) * z + m(1, 3);
+    float zp = m(2, 0) * x + m(2, 1) * y + m(2, 2) * z + m(2, 3);
+    float wp = m(3, 0) * x + m(3, 1) * y + m(3, 2) * z + m(3, 3);
+    err->x = (gamma_n(3) + 1.f) * (std::abs(m(0, 0)) * pe.x + std::abs(m(0, 1)) * pe.y + std::abs(m(0, 2)) * pe.z) +
+             gamma_n(3) * (std::abs(m(0, 0) * x) + std::abs(m(0, 1) * y) + std::abs(m(0, 2) * z) + std::abs(m(0, 3)));
+    err->y = (gamma_n(3) + 1.f) * (std::abs(m(1, 0)) * pe.x + std::abs(m(1, 1)) * pe.y + std::abs(m(1, 2)) * pe.z) +
+             gamma_n(3) * (std::abs(m(1, 0) * x) + std::abs(m(1, 1) * y) + std::abs(m(1, 2) * z) + std::abs(m(1, 3)));
+    err->z = (gamma_n(3) + 1.f) * (std::abs(m(2, 0)) * pe.x + std::abs(m(2, 1)) * pe.y + std::abs(m(2, 2)) * pe.z) +
+             gamma_n(3) * (std::abs(m(2, 0) * x) + std::abs(m(2, 1) * y) + std::abs(m(2, 2) * z) + std::abs(m(2, 3)));
+    if (wp == 1.) return V3(xp, yp, zp);
+    return vdiv(V3(xp, yp, zp), wp);
+}
+inline V3 xf_vector(M4 m, V3 v) {
+    float x = v.x, y = v.y, z = v.z;
+    return V3(m(0, 0) * x + m(0, 1) * y + m(0, 2) * z, m(1, 0) * x + m(1, 1) * y + m(1, 2) * z,
+              m(2, 0) * x + m(2, 1) * y + m(2, 2) * z);
+}
+inline V3 xf_vector_err(M4 m, V3 v, V3 *err) {  // transform.h:333-349
+    float x = v.x, y = v.y, z = v.z;
+    err->x = gamma_n(3) * (std::abs(m(0, 0) * v.x) + std::abs(m(0, 1) * v.y) + std::abs(m(0, 2) * v.z));
+    err->y = gamma_n(3) * (std::abs(m(1, 0) * v.x) + std::abs(m(1, 1) * v.y) + std::abs(m(1, 2) * v.z));
+    err->z = gamma_n(3) * (std::abs(m(2, 0) * v.x) + std::abs(m(2, 1) * v.y) + std::abs(m(2, 2) * v.z));
+    return V3(m(0, 0) * x + m(0, 1) * y + m(0, 2) * z, m(1, 0) * x + m(1, 1) * y + m(1, 2) * z,
+              m(2, 0) * x + m(2, 1) * y + m(2, 2) * z);
+}
+inline V3 xf_normal(M4 minv, V3 n) {  // transform.h:243-249: transpose of the inverse
+    float x = n.x, y = n.y, z = n.z;
+    return V3(minv(0, 0) * x + minv(1, 0) * y + minv(2, 0) * z, minv(0, 1) * x + minv(1, 1) * y + minv(2, 1) * z,
+              minv(0, 2) * x + minv(1, 2) * y + minv(2, 2) * z);
+}
+
+// ----------------------------------------------------------------------------
+// EFloat (core/efloat.h), NDEBUG flavour (no long double shadow value)
+struct EFloat {
+    float v, low, high;
+    EFloat() : v(0), low(0), high(0) {}
+    EFloat(float v_, float err = 0.f) : v(v_) {
+        if (err == 0.)
+            low = high = v_;
+        else {
+            low = next_down(v_ - err);
+            high = next_up(v_ + err);
+        }
+    }
+};
+inline EFloat operator+(EFloat a, EFloat b) {
+    EFloat r;
+    r.v = a.v + b.v;
+    r.low = next_down(a.low + b.low);
+    r.high = next_up(a.high + b.high);
+    return r;
+}
+inline EFloat operator-(EFloat a, EFloat b) {
+    EFloat r;
+    r.v = a.v - b.v;
+    r.low = next_down(a.low - b.high);
+    r.high = next_up(a.high - b.low);
+    return r;
+}
+inline EFloat operator*(EFloat a, EFloat b) {
+    EFloat r;
+    r.v = a.v * b.v;
+    float prod[4] = {a.low * b.low, a.high * b.low, a.low * b.high, a.high * b.high};
+    r.low = next_down(std::min(std::min(prod[0], prod[1]), std::min(prod[2], prod[3])));
+    r.high = next_up(std::max(std::max(prod[0], prod[1]), std::max(prod[2], prod[3])));
+    return r;
+}
+inline EFloat operator/(EFloat a, EFloat b) {
+    EFloat r;
+    r.v = a.v / b.v;
+    if (b.low < 0 && b.high > 0) {
+        r.low = -Infinity;
+        r.high = Infinity;
+    } else {
+        float div[4] = {a.low / b.low, a.high / b.low, a.low / b.high, a.high / b.high};
+        r.low = next_down(std::min(std::min(div[0], div[1]), std::min(div[2], div[3])));
+        r.high = next_up(std::max(std::max(div[0], div[1]), std::max(div[2], div[3])));
+    }
+    return r;
+}
+// efloat.h:267-285
+inline bool ef_quadratic(EFloat A, EFloat B, EFloat C, EFloat *t0, EFloat *t1) {
+    double discrim = (double)B.v * (double)B.v - 4. * (double)A.v * (double)C.v;
+    if (discrim < 0.) return false;
+    double root = std::sqrt(discrim);
+    EFloat froot(float(root), float(MachineEpsilon * root));
+    EFloat q;
+    if (B.v < 0)
+        q = EFloat(-.5f) * (B - froot);
+    else
+        q = EFloat(-.5f) * (B + froot);
+    *t0 = q / A;
+    *t1 = C / q;
+    if (t0->v > t1->v) std::swap(*t0, *t1);
+    return true;
+}
+
+// ----------------------------------------------------------------------------
+// counters
+struct Counters {
+    uint64_t camera_rays = 0, regular_rays = 0, shadow_rays = 0, tri_tests = 0, tri_hits = 0,
+             sphere_tests = 0, nodes_closest = 0, nodes_any = 0, nee_evals = 0, zero_radiance = 0;
+    uint64_t path_length[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int max_stack = 0;
+    void add(const Counters &o) {
+        camera_rays += o.camera_rays;
+        regular_rays += o.regular_rays;
+        shadow_rays += o.shadow_rays;
+        tri_tests += o.tri_tests;
+        tri_hits += o.tri_hits;
+        sphere_tests += o.sphere_tests;
+        nodes_closest += o.nodes_closest;
+        nodes_any += o.nodes_any;
+        nee_evals += o.nee_evals;
+        zero_radiance += o.zero_radiance;
+        for (int i = 0; i < 8; ++i) path_length[i] += o.path_length[i];
+        max_stack = std::max(max_stack, o.max_stack);
+    }
+};
+
+// What Li needs of a SurfaceInteraction (core/interaction.h)
+struct Isect {
+    int prim = -1;
+    float t = 0, b0 = 0, b1 = 0, b2 = 0;
+    V3 p, perr, n, wo;
+    V3 sn;     // shading.n
+    V3 sdpdu;  // shading.dpdu
+};
+
+struct Oracle {
+    const iile_scene_desc &S;
+    Trig trig;
+    Counters *ctr;
+    Oracle(const iile_scene_desc &s, int mode, Counters *c) : S(s), trig{mode}, ctr(c) {}
+
+    // ------------------------------------------------------------------------
+    // Halton (samplers/halton.cpp:96-127, core/lowdiscrepancy.cpp:389-427)
+    static uint64_t inverse_radical_inverse(int base, uint64_t inverse, int n_digits) {
+        uint64_t index = 0;
+        for (int i = 0; i < n_digits; ++i) {
+            uint64_t digit = inverse % base;
+            inverse /= base;
+            index = index * base + digit;
+        }
+        return index;
+    }
+    int64_t halton_index(int px, int py, int64_t sample_num) const {
+        const iile_halton &h = S.halton;
+        int64_t offset = 0;
+        if (h.sample_stride > 1) {
+            auto mod = [](int a, int b) {
+                int r = a - (a / b) * b;
+                return r < 0 ? r + b : r;
+            };
+            int pm[2] = {mod(px, 128), mod(py, 128)};
+            for (int i = 0; i < 2; ++i) {
+                uint64_t dim_offset = inverse_radical_inverse(i == 0 ? 2 : 3, uint64_t(pm[i]), h.base_exponents[i]);
+                offset += dim_offset * uint64_t(h.sample_stride / h.base_scales[i]) * uint64_t(h.mult_inverse[i]);
+            }
+            offset %= h.sample_stride;
+        }
+        return offset + sample_num * h.sample_stride;
+    }
+    static uint32_t reverse_bits32(uint32_t n) {
+        n = (n << 16) | (n >> 16);
+        n = ((n & 0x00ff00ff) << 8) | ((n & 0xff00ff00) >> 8);
+        n = ((n & 0x0f0f0f0f) << 4) | ((n & 0xf0f0f0f0) >> 4);
+        n = ((n & 0x33333333) << 2) | ((n & 0xcccccccc) >> 2);
+        n = ((n & 0x55555555) << 1) | ((n & 0xaaaaaaaa) >> 1);
+        return n;
+    }
+    static float radical_inverse(int base_index, int base, uint64_t a) {
+        if (base_index == 0) {
+            uint64_t n0 = reverse_bits32(uint32_t(a));
+            uint64_t n1 = reverse_bits32(uint32_t(a >> 32));
+            uint64_t rev = (n0 << 32) | n1;
+            return float(double(rev) * 0x1p-64);
+        }
+        const float inv_base = 1.f / float(base);
+        uint64_t reversed = 0;
+        float inv_base_n = 1;
+        while (a) {
+            uint64_t next = a / base;
+            uint64_t digit = a - next * base;
+            reversed = reversed * base + digit;
+            inv_base_n *= inv_base;
+            a = next;
+        }
+        return std::min(float(reversed) * inv_base_n, OneMinusEpsilon);
+    }
+    static float scrambled_radical_inverse(int base, const uint16_t *perm, uint64_t a) {
+        const float inv_base = 1.f / float(base);
+        uint64_t reversed = 0;
+        float inv_base_n = 1;
+        while (a) {
+            uint64_t next = a / base;
+            uint64_t digit = a - next * base;
+            reversed = reversed * base + perm[digit];
+            inv_base_n *= inv_base;
+            a = next;
+        }
+        return std::min(inv_base_n * (float(reversed) + inv_base * perm[0] / (1 - inv_base)), OneMinusEpsilon);
+    }
+    float sample_dimension(int64_t index, int dim) const {
+        const iile_halton &h = S.halton;
+        if (dim == 0) return radical_inverse(0, 2, uint64_t(index >> h.base_exponents[0]));
+        if (dim == 1) return radical_inverse(1, 3, uint64_t(index / h.base_scales[1]));
+        return scrambled_radical_inverse(h.primes[dim], h.perms + h.prime_sums[dim], uint64_t(index));
+    }
+    // GlobalSampler::Get1D/Get2D with no sample arrays requested
+    // (core/sampler.cpp:180-195: arrayStartDim == arrayEndDim == 5, nothing is skipped)
+    struct Sampler {
+        const Oracle *o;
+        int64_t index;
+        int dim;
+        float get1d() { return o->sample_dimension(index, dim++); }
+        void get2d(float *u) {
+            u[0] = o->sample_dimension(index, dim);
+            u[1] = o->sample_dimension(index, dim + 1);
+            dim += 2;
+        }
+    };
+
+    // ------------------------------------------------------------------------
+    // sampling warps (core/sampling.cpp:113-130, core/sampling.h:159-163)
+    void concentric_sample_disk(const float *u, float *dx, float *dy) const {
+        float ox = 2.f * u[0] - 1, oy = 2.f * u[1] - 1;
+        if (ox == 0 && oy == 0) {
+            *dx = 0;
+            *dy = 0;
+            return;
+        }
+        float theta, r;
+        if (std::abs(ox) > std::abs(oy)) {
+            r = ox;
+            theta = PiOver4 * (oy / ox);
+        } else {
+            r = oy;
+            theta = PiOver2 - PiOver4 * (ox / oy);
+        }
+        *dx = r * trig.cos_f(theta);
+        *dy = r * trig.sin_f(theta);
+    }
+    V3 cosine_sample_hemisphere(const float *u) const {
+        float dx, dy;
+        concentric_sample_disk(u, &dx, &dy);
+        float z = std::sqrt(std::max(0.f, 1 - dx * dx - dy * dy));
+        return V3(dx, dy, z);
+    }
+
+    // ------------------------------------------------------------------------
+    // camera (cameras/perspective.cpp:100-149; transform.h:251-264)
+    Ray camera_ray(float pfx, float pfy, const float *plens) const {
+        const iile_camera &c = S.camera;
+        V3 pcam = xf_point(M4{c.raster_to_camera}, V3(pfx, pfy, 0));
+        V3 dir = normalize(V3(pcam.x, pcam.y, pcam.z));
+        Ray r{V3(0, 0, 0), dir, Infinity};
+        if (c.lens_radius > 0) {
+            float lx, ly;
+            concentric_sample_disk(plens, &lx, &ly);
+            lx = c.lens_radius * lx;
+            ly = c.lens_radius * ly;
+            float ft = c.focal_distance / r.d.z;
+            V3 pfocus = r.o + r.d * ft;
+            r.o = V3(lx, ly, 0);
+            r.d = normalize(pfocus - r.o);
+        }
+        M4 m{c.camera_to_world};
+        V3 oerr;
+        V3 o = xf_point_err(m, r.o, &oerr);
+        V3 d = xf_vector(m, r.d);
+        float len2 = length_sq(d);
+        float tmax = r.tmax;
+        if (len2 > 0) {
+            float dt = dot(vabs(d), oerr) / len2;
+            o = o + d * dt;
+            tmax -= dt;
+        }
+        return Ray{o, d, tmax};
+    }
+
+    // ------------------------------------------------------------------------
+    // OffsetRayOrigin / SpawnRay / SpawnRayTo (geometry.h:1440-1460, interaction.h:64-78)
+    static V3 offset_ray_origin(V3 p, V3 perr, V3 n, V3 w) {
+        float d = dot(vabs(n), perr);
+        V3 offset = d * n;
+        if (dot(w, n) < 0) offset = -offset;
+        V3 po = p + offset;
+        for (int i = 0; i < 3; ++i) {
+            if (offset[i] > 0)
+                po[i] = next_up(po[i]);
+            else if (offset[i] < 0)
+                po[i] = next_down(po[i]);
+        }
+        return po;
+    }
+    static Ray spawn_ray(const Isect &it, V3 d) { return Ray{offset_ray_origin(it.p, it.perr, it.n, d), d, Infinity}; }
+
+    // ------------------------------------------------------------------------
+    // Triangle (shapes/triangle.cpp:188-403, 405-544)
+    bool triangle_test(const Ray &ray, int prim, float *t_out, float *b0o, float *b1o, float *b2o) const {
+        ++ctr->tri_tests;
+        const float *tp = S.tri_p + 9 * size_t(prim);
+        V3 p0(tp[0], tp[1], tp[2]), p1(tp[3], tp[4], tp[5]), p2(tp[6], tp[7], tp[8]);
+        V3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
+        int kz = max_dimension(vabs(ray.d));
+        int kx = kz + 1;
+        if (kx == 3) kx = 0;
+        int ky = kx + 1;
+        if (ky == 3) ky = 0;
+        V3 d = permute(ray.d, kx, ky, kz);
+        p0t = permute(p0t, kx, ky, kz);
+        p1t = permute(p1t, kx, ky, kz);
+        p2t = permute(p2t, kx, ky, kz);
+        float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+        p0t.x += Sx * p0t.z;
+        p0t.y += Sy * p0t.z;
+        p1t.x += Sx * p1t.z;
+        p1t.y += Sy * p1t.z;
+        p2t.x += Sx * p2t.z;
+        p2t.y += Sy * p2t.z;
+        float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+        float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+        float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+        if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+            double p2txp1ty = (double)p2t.x * (double)p1t.y;
+            double p2typ1tx = (double)p2t.y * (double)p1t.x;
+            e0 = (float)(p2typ1tx - p2txp1ty);
+            double p0txp2ty = (double)p0t.x * (double)p2t.y;
+            double p0typ2tx = (double)p0t.y * (double)p2t.x;
+            e1 = (float)(p0typ2tx - p0txp2ty);
+            double p1txp0ty = (double)p1t.x * (double)p0t.y;
+            double p1typ0tx = (double)p1t.y * (double)p0t.x;
+            e2 = (float)(p1typ0tx - p1txp0ty);
+        }
+        if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+        float det = e0 + e1 + e2;
+        if (det == 0) return false;
+        p0t.z *= Sz;
+        p1t.z *= Sz;
+        p2t.z *= Sz;
+        float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+        if (det < 0 && (t_scaled >= 0 || t_scaled < ray.tmax * det))
+            return false;
+        else if (det > 0 && (t_scaled <= 0 || t_scaled > ray.tmax * det))
+            return false;
+        float inv_det = 1 / det;
+        float b0 = e0 * inv_det, b1 = e1 * inv_det, b2 = e2 * inv_det;
+        float t = t_scaled * inv_det;
+        float max_zt = max_component(vabs(V3(p0t.z, p1t.z, p2t.z)));
+        float delta_z = gamma_n(3) * max_zt;
+        float max_xt = max_component(vabs(V3(p0t.x, p1t.x, p2t.x)));
+        float max_yt = max_component(vabs(V3(p0t.y, p1t.y, p2t.y)));
+        float delta_x = gamma_n(5) * (max_xt + max_zt);
+        float delta_y = gamma_n(5) * (max_yt + max_zt);
+        float delta_e = 2 * (gamma_n(2) * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
+        float max_e = max_component(vabs(V3(e0, e1, e2)));
+        float delta_t = 3 * (gamma_n(3) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * std::abs(inv_det);
+        if (t <= delta_t) return false;
+        *t_out = t;
+        *b0o = b0;
+        *b1o = b1;
+        *b2o = b2;
+        ++ctr->tri_hits;
+        return true;
+    }
+    // the SurfaceInteraction part of Triangle::Intersect (triangle.cpp:277-400)
+    void triangle_interaction(const Ray &ray, int prim, float b0, float b1, float b2, Isect *is) const {
+        const float *tp = S.tri_p + 9 * size_t(prim);
+        V3 p0(tp[0], tp[1], tp[2]), p1(tp[3], tp[4], tp[5]), p2(tp[6], tp[7], tp[8]);
+        const uint32_t flags = S.prim_flags[prim];
+        float uv[3][2] = {{0, 0}, {1, 0}, {1, 1}};  // triangle.h:98-108
+        if (flags & IILE_PRIM_HAS_UV) {
+            const float *u = S.tri_uv + 6 * size_t(prim);
+            for (int i = 0; i < 3; ++i) {
+                uv[i][0] = u[2 * i];
+                uv[i][1] = u[2 * i + 1];
+            }
+        }
+        float duv02[2] = {uv[0][0] - uv[2][0], uv[0][1] - uv[2][1]};
+        float duv12[2] = {uv[1][0] - uv[2][0], uv[1][1] - uv[2][1]};
+        V3 dp02 = p0 - p2, dp12 = p1 - p2;
+        float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+        bool degenerate = std::abs(determinant) < 1e-8;
+        V3 dpdu, dpdv;
+        if (!degenerate) {
+            float invdet = 1 / determinant;
+            dpdu = (duv12[1] * dp02 - duv02[1] * dp12) * invdet;
+            dpdv = (-duv12[0] * dp02 + duv02[0] * dp12) * invdet;
+        }
+        if (degenerate || length_sq(cross(dpdu, dpdv)) == 0)
+            coordinate_system(normalize(cross(p2 - p0, p1 - p0)), &dpdu, &dpdv);
+        float xs = (std::abs(b0 * p0.x) + std::abs(b1 * p1.x) + std::abs(b2 * p2.x));
+        float ys = (std::abs(b0 * p0.y) + std::abs(b1 * p1.y) + std::abs(b2 * p2.y));
+        float zs = (std::abs(b0 * p0.z) + std::abs(b1 * p1.z) + std::abs(b2 * p2.z));
+        is->perr = gamma_n(7) * V3(xs, ys, zs);
+        is->p = b0 * p0 + b1 * p1 + b2 * p2;
+        is->wo = normalize(-ray.d);  // Interaction ctor normalises wo, interaction.h:60
+        V3 n = normalize(cross(dp02, dp12));
+        const bool flip = (flags & IILE_PRIM_FLIP) != 0;
+        if (flags & IILE_PRIM_HAS_NORMALS) {
+            const float *nn = S.tri_n + 9 * size_t(prim);
+            V3 n0(nn[0], nn[1], nn[2]), n1(nn[3], nn[4], nn[5]), n2(nn[6], nn[7], nn[8]);
+            V3 ns = (b0 * n0 + b1 * n1 + b2 * n2);
+            if (length_sq(ns) > 0)
+                ns = normalize(ns);
+            else
+                ns = n;
+            V3 ss = normalize(dpdu);
+            V3 ts = cross(ss, ns);
+            if (length_sq(ts) > 0.f) {
+                ts = normalize(ts);
+                ss = cross(ts, ns);
+            } else
+                coordinate_system(ns, &ss, &ts);
+            // SetShadingGeometry(ss, ts, ..., true), interaction.cpp:72-92
+            V3 sn = normalize(cross(ss, ts));
+            if (flip) sn = -sn;
+            n = faceforward(n, sn);
+            is->sn = sn;
+            is->sdpdu = ss;
+            n = faceforward(n, is->sn);  // triangle.cpp:396-397
+        } else {
+            if (flip) n = -n;  // triangle.cpp:398-399
+            is->sn = n;
+            is->sdpdu = dpdu;
+        }
+        is->n = n;
+    }
+
+    // ------------------------------------------------------------------------
+    // Sphere (shapes/sphere.cpp:49-215)
+    bool sphere_test(const Ray &r, const iile_sphere &sp, Ray *obj_ray, float *t_hit, V3 *phit_out) const {
+        ++ctr->sphere_tests;
+        M4 w2o{sp.o2w_inv};
+        V3 oerr, derr;
+        // Transform::operator()(Ray, oError, dError), transform.h:382-394 (tMax kept)
+        V3 o = xf_point_err(w2o, r.o, &oerr);
+        V3 d = xf_vector_err(w2o, r.d, &derr);
+        float len2 = length_sq(d);
+        if (len2 > 0) {
+            float dt = dot(vabs(d), oerr) / len2;
+            o = o + d * dt;
+        }
+        Ray ray{o, d, r.tmax};
+        EFloat ox(ray.o.x, oerr.x), oy(ray.o.y, oerr.y), oz(ray.o.z, oerr.z);
+        EFloat dx(ray.d.x, derr.x), dy(ray.d.y, derr.y), dz(ray.d.z, derr.z);
+        EFloat a = dx * dx + dy * dy + dz * dz;
+        EFloat b = EFloat(2.f) * (dx * ox + dy * oy + dz * oz);
+        EFloat c = ox * ox + oy * oy + oz * oz - EFloat(sp.radius) * EFloat(sp.radius);
+        EFloat t0, t1;
+        if (!ef_quadratic(a, b, c, &t0, &t1)) return false;
+        if (t0.high > ray.tmax || t1.low <= 0) return false;
+        EFloat ts = t0;
+        if (ts.low <= 0) {
+            ts = t1;
+            if (ts.high > ray.tmax) return false;
+        }
+        auto refine = [&](float t) {
+            V3 ph = ray.o + ray.d * t;
+            float scale = sp.radius / length(ph);  // Distance(pHit, (0,0,0))
+            ph = V3(ph.x * scale, ph.y * scale, ph.z * scale);
+            if (ph.x == 0 && ph.y == 0) ph.x = 1e-5f * sp.radius;
+            return ph;
+        };
+        V3 ph = refine(ts.v);
+        float phi = std::atan2(ph.y, ph.x);
+        if (phi < 0) phi += 2 * Pi;
+        if ((sp.zmin > -sp.radius && ph.z < sp.zmin) || (sp.zmax < sp.radius && ph.z > sp.zmax) ||
+            phi > sp.phi_max) {
+            if (ts.v == t1.v) return false;
+            if (t1.high > ray.tmax) return false;
+            ts = t1;
+            ph = refine(ts.v);
+            phi = std::atan2(ph.y, ph.x);
+            if (phi < 0) phi += 2 * Pi;
+            if ((sp.zmin > -sp.radius && ph.z < sp.zmin) || (sp.zmax < sp.radius && ph.z > sp.zmax) ||
+                phi > sp.phi_max)
+                return false;
+        }
+        *obj_ray = ray;
+        *t_hit = ts.v;
+        *phit_out = ph;
+        return true;
+    }
+    // the SurfaceInteraction part of Sphere::Intersect (sphere.cpp:104-155)
+    // followed by Transform::operator()(SurfaceInteraction) (transform.cpp:262-297)
+    void sphere_interaction(const iile_sphere &sp, const Ray &obj_ray, V3 ph, Isect *is) const {
+        float theta = trig.acos_f(clampf(ph.z / sp.radius, -1, 1));
+        float z_radius = std::sqrt(ph.x * ph.x + ph.y * ph.y);
+        float inv_z_radius = 1 / z_radius;
+        float cos_phi = ph.x * inv_z_radius;
+        float sin_phi = ph.y * inv_z_radius;
+        V3 dpdu(-sp.phi_max * ph.y, sp.phi_max * ph.x, 0);
+        V3 dpdv = (sp.theta_max - sp.theta_min) * V3(ph.z * cos_phi, ph.z * sin_phi, -sp.radius * trig.sin_f(theta));
+        V3 perr = gamma_n(5) * vabs(ph);
+        // SurfaceInteraction ctor, interaction.cpp:44-70
+        V3 n = normalize(cross(dpdu, dpdv));
+        V3 sn = n;
+        if (sp.reverse_orientation ^ sp.swaps_handedness) {
+            n = n * -1.f;
+            sn = sn * -1.f;
+        }
+        V3 wo = normalize(-obj_ray.d);
+        // object -> world
+        M4 m{sp.o2w}, mi{sp.o2w_inv};
+        is->p = xf_point_err2(m, ph, perr, &is->perr);
+        is->n = normalize(xf_normal(mi, n));
+        is->wo = normalize(xf_vector(m, wo));
+        V3 snw = normalize(xf_normal(mi, sn));
+        is->sdpdu = xf_vector(m, dpdu);
+        is->sn = faceforward(snw, is->n);
+    }
+
+    // ------------------------------------------------------------------------
+    // BVH traversal (accelerators/bvh.cpp:662-738, geometry.h:1411-1438)
+    static bool slab(const iile_bvh_node &nd, const Ray &ray, V3 inv_dir, const int neg[3]) {
+        const float *bmin = nd.bmin, *bmax = nd.bmax;
+        auto b = [&](int hi, int axis) { return hi ? bmax[axis] : bmin[axis]; };
+        float tmin = (b(neg[0], 0) - ray.o.x) * inv_dir.x;
+        float tmax = (b(1 - neg[0], 0) - ray.o.x) * inv_dir.x;
+        float tymin = (b(neg[1], 1) - ray.o.y) * inv_dir.y;
+        float tymax = (b(1 - neg[1], 1) - ray.o.y) * inv_dir.y;
+        tmax *= 1 + 2 * gamma_n(3);
+        tymax *= 1 + 2 * gamma_n(3);
+        if (tmin > tymax || tymin > tmax) return false;
+        if (tymin > tmin) tmin = tymin;
+        if (tymax < tmax) tmax = tymax;
+        float tzmin = (b(neg[2], 2) - ray.o.z) * inv_dir.z;
+        float tzmax = (b(1 - neg[2], 2) - ray.o.z) * inv_dir.z;
+        tzmax *= 1 + 2 * gamma_n(3);
+        if (tmin > tzmax || tzmin > tmax) return false;
+        if (tzmin > tmin) tmin = tzmin;
+        if (tzmax < tmax) tmax = tzmax;
+        return (tmin < ray.tmax) && (tmax > 0);
+    }
+    // closest hit; fills prim/t/b* and, if want_isect, the interaction
+    bool intersect(Ray ray, Isect *is, bool want_isect = true) const {
+        ++ctr->regular_rays;
+        if (S.n_nodes == 0) return false;
+        bool hit = false;
+        V3 inv_dir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
+        int neg[3] = {inv_dir.x < 0, inv_dir.y < 0, inv_dir.z < 0};
+        int to_visit = 0, cur = 0;
+        int stack[64];
+        bool hit_is_sphere = false;
+        Ray sph_obj_ray{};
+        V3 sph_ph;
+        int sph_index = -1;
+        while (true) {
+            const iile_bvh_node &nd = S.nodes[cur];
+            ++ctr->nodes_closest;
+            if (slab(nd, ray, inv_dir, neg)) {
+                if (nd.nprims > 0) {
+                    for (int i = 0; i < nd.nprims; ++i) {
+                        int prim = nd.offset + i;
+                        if (S.prim_flags[prim] & IILE_PRIM_SPHERE) {
+                            Ray orr;
+                            float t;
+                            V3 ph;
+                            const iile_sphere &sp = S.spheres[S.prim_shape[prim]];
+                            if (sphere_test(ray, sp, &orr, &t, &ph)) {
+                                hit = true;
+                                ray.tmax = t;
+                                is->prim = prim;
+                                is->t = t;
+                                is->b0 = is->b1 = is->b2 = 0;
+                                hit_is_sphere = true;
+                                sph_obj_ray = orr;
+                                sph_ph = ph;
+                                sph_index = S.prim_shape[prim];
+                            }
+                        } else {
+                            float t, b0, b1, b2;
+                            if (triangle_test(ray, prim, &t, &b0, &b1, &b2)) {
+                                hit = true;
+                                ray.tmax = t;
+                                is->prim = prim;
+                                is->t = t;
+                                is->b0 = b0;
+                                is->b1 = b1;
+                                is->b2 = b2;
+                                hit_is_sphere = false;
+                            }
+                        }
+                    }
+                    if (to_visit == 0) break;
+                    cur = stack[--to_visit];
+                } else {
+                    if (neg[nd.axis]) {
+                        stack[to_visit++] = cur + 1;
+                        cur = nd.offset;
+                    } else {
+                        stack[to_visit++] = nd.offset;
+                        cur = cur + 1;
+                    }
+                    ctr->max_stack = std::max(ctr->max_stack, to_visit);
+                }
+            } else {
+                if (to_visit == 0) break;
+                cur = stack[--to_visit];
+            }
+        }
+        if (hit && want_isect) {
+            if (hit_is_sphere)
+                sphere_interaction(S.spheres[sph_index], sph_obj_ray, sph_ph, is);
+            else
+                triangle_interaction(ray, is->prim, is->b0, is->b1, is->b2, is);
+        }
+        return hit;
+    }
+    bool intersect_p(const Ray &ray) const {
+        ++ctr->shadow_rays;
+        if (S.n_nodes == 0) return false;
+        V3 inv_dir(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+        int neg[3] = {inv_dir.x < 0, inv_dir.y < 0, inv_dir.z < 0};
+        int stack[64];
+        int to_visit = 0, cur = 0;
+        while (true) {
+            const iile_bvh_node &nd = S.nodes[cur];
+            ++ctr->nodes_any;
+            if (slab(nd, ray, inv_dir, neg)) {
+                if (nd.nprims > 0) {
+                    for (int i = 0; i < nd.nprims; ++i) {
+                        int prim = nd.offset + i;
+                        if (S.prim_flags[prim] & IILE_PRIM_SPHERE) {
+                            Ray orr;
+                            float t;
+                            V3 ph;
+                            if (sphere_test(ray, S.spheres[S.prim_shape[prim]], &orr, &t, &ph)) return true;
+                        } else {
+                            float t, b0, b1, b2;
+                            if (triangle_test(ray, prim, &t, &b0, &b1, &b2)) return true;
+                        }
+                    }
+                    if (to_visit == 0) break;
+                    cur = stack[--to_visit];
+                } else {
+                    if (neg[nd.axis]) {
+                        stack[to_visit++] = cur + 1;
+                        cur = nd.offset;
+                    } else {
+                        stack[to_visit++] = nd.offset;
+                        cur = cur + 1;
+                    }
+                    ctr->max_stack = std::max(ctr->max_stack, to_visit);
+                }
+            } else {
+                if (to_visit == 0) break;
+                cur = stack[--to_visit];
+            }
+        }
+        return false;
+    }
+
+    // ------------------------------------------------------------------------
+    // BSDF (core/reflection.{h,cpp}, core/microfacet.cpp)
+    struct Bsdf {
+        V3 ns, ng, ss, ts;
+        int n_lobes = 0;
+        bool has_lambert = false, has_micro = false;
+        Rgb kd, ks;
+        float alpha = 0;
+        V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
+        V3 to_world(V3 v) const {
+            return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z,
+                      ss.z * v.x + ts.z * v.y + ns.z * v.z);
+        }
+    };
+    // {Matte,Plastic}Material::ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70)
+    Bsdf make_bsdf(const Isect &is) const {
+        Bsdf b;
+        b.ns = is.sn;
+        b.ng = is.n;
+        b.ss = normalize(is.sdpdu);
+        b.ts = cross(b.ns, b.ss);
+        const iile_material &m = S.materials[S.prim_material[is.prim]];
+        auto clamp0 = [](const float *c) {
+            return Rgb(clampf(c[0], 0, Infinity), clampf(c[1], 0, Infinity), clampf(c[2], 0, Infinity));
+        };
+        Rgb kd = clamp0(m.kd);
+        if (!kd.is_black()) {
+            b.has_lambert = true;
+            b.kd = kd;
+            ++b.n_lobes;
+        }
+        if (m.type == IILE_MAT_PLASTIC) {
+            Rgb ks = clamp0(m.ks);
+            if (!ks.is_black()) {
+                b.has_micro = true;
+                b.ks = ks;
+                b.alpha = m.alpha;
+                ++b.n_lobes;
+            }
+        }
+        return b;
+    }
+    // trig helpers, reflection.h:56-84
+    static float cos2_theta(V3 w) { return w.z * w.z; }
+    static float sin2_theta(V3 w) { return std::max(0.f, 1.f - cos2_theta(w)); }
+    static float sin_theta(V3 w) { return std::sqrt(sin2_theta(w)); }
+    static float tan_theta(V3 w) { return sin_theta(w) / w.z; }
+    static float tan2_theta(V3 w) { return sin2_theta(w) / cos2_theta(w); }
+    static float cos_phi(V3 w) {
+        float st = sin_theta(w);
+        return (st == 0) ? 1 : clampf(w.x / st, -1, 1);
+    }
+    static float sin_phi(V3 w) {
+        float st = sin_theta(w);
+        return (st == 0) ? 0 : clampf(w.y / st, -1, 1);
+    }
+    static float cos2_phi(V3 w) { return cos_phi(w) * cos_phi(w); }
+    static float sin2_phi(V3 w) { return sin_phi(w) * sin_phi(w); }
+    static bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0; }
+    // reflection.cpp:47-68
+    static float fr_dielectric(float cos_i, float eta_i, float eta_t) {
+        cos_i = clampf(cos_i, -1, 1);
+        bool entering = cos_i > 0.f;
+        if (!entering) {
+            std::swap(eta_i, eta_t);
+            cos_i = std::abs(cos_i);
+        }
+        float sin_i = std::sqrt(std::max(0.f, 1 - cos_i * cos_i));
+        float sin_t = eta_i / eta_t * sin_i;
+        if (sin_t >= 1) return 1;
+        float cos_t = std::sqrt(std::max(0.f, 1 - sin_t * sin_t));
+        float r_parl = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+        float r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+        return (r_parl * r_parl + r_perp * r_perp) / 2;
+    }
+    // TrowbridgeReitzDistribution, microfacet.cpp:155-163, 176-184
+    static float tr_d(V3 wh, float ax, float ay) {
+        float t2 = tan2_theta(wh);
+        if (std::isinf(t2)) return 0.;
+        const float cos4 = cos2_theta(wh) * cos2_theta(wh);
+        float e = (cos2_phi(wh) / (ax * ax) + sin2_phi(wh) / (ay * ay)) * t2;
+        return 1 / (Pi * ax * ay * cos4 * (1 + e) * (1 + e));
+    }
+    static float tr_lambda(V3 w, float ax, float ay) {
+        float abs_tan = std::abs(tan_theta(w));
+        if (std::isinf(abs_tan)) return 0.;
+        float alpha = std::sqrt(cos2_phi(w) * ax * ax + sin2_phi(w) * ay * ay);
+        float a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
+        return (-1 + std::sqrt(1.f + a2t2)) / 2;
+    }
+    static float tr_g1(V3 w, float a) { return 1 / (1 + tr_lambda(w, a, a)); }
+    static float tr_g(V3 wo, V3 wi, float a) { return 1 / (1 + tr_lambda(wo, a, a) + tr_lambda(wi, a, a)); }
+    // MicrofacetDistribution::Pdf with sampleVisibleArea, microfacet.cpp:338-344
+    static float tr_pdf(V3 wo, V3 wh, float a) { return tr_d(wh, a, a) * tr_g1(wo, a) * absdot(wo, wh) / std::abs(wo.z); }
+    // TrowbridgeReitzSample11, microfacet.cpp:238-283 (unqualified sqrt/cos/sin:
+    // double overloads, see DESIGN.md "Double precision islands")
+    void tr_sample11(float cos_theta, float U1, float U2, float *slope_x, float *slope_y) const {
+        if (cos_theta > .9999) {
+            float r = float(std::sqrt(double(U1 / (1 - U1))));
+            float phi = float(6.28318530718 * U2);
+            *slope_x = float(r * trig.cos_d(phi));
+            *slope_y = float(r * trig.sin_d(phi));
+            return;
+        }
+        float sin_t = std::sqrt(std::max(0.f, 1.f - cos_theta * cos_theta));
+        float tan_t = sin_t / cos_theta;
+        float a = 1 / tan_t;
+        float G1 = 2 / (1 + std::sqrt(1.f + 1.f / (a * a)));
+        float A = 2 * U1 / G1 - 1;
+        float tmp = 1.f / (A * A - 1.f);
+        if (tmp > 1e10) tmp = 1e10;
+        float B = tan_t;
+        float D = std::sqrt(std::max(float(B * B * tmp * tmp - (A * A - B * B) * tmp), 0.f));
+        float slope_x_1 = B * tmp - D;
+        float slope_x_2 = B * tmp + D;
+        *slope_x = (A < 0 || slope_x_2 > 1.f / tan_t) ? slope_x_1 : slope_x_2;
+        float Sg;
+        if (U2 > 0.5f) {
+            Sg = 1.f;
+            U2 = 2.f * (U2 - .5f);
+        } else {
+            Sg = -1.f;
+            U2 = 2.f * (.5f - U2);
+        }
+        float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
+                  (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+        *slope_y = Sg * z * std::sqrt(1.f + *slope_x * *slope_x);
+    }
+    // TrowbridgeReitzSample + Sample_wh (visible area), microfacet.cpp:285-336
+    V3 tr_sample_wh(V3 wo, const float *u, float a) const {
+        bool flip = wo.z < 0;
+        V3 wi = flip ? -wo : wo;
+        V3 ws = normalize(V3(a * wi.x, a * wi.y, wi.z));
+        float sx, sy;
+        tr_sample11(ws.z, u[0], u[1], &sx, &sy);
+        float tmp = cos_phi(ws) * sx - sin_phi(ws) * sy;
+        sy = sin_phi(ws) * sx + cos_phi(ws) * sy;
+        sx = tmp;
+        sx = a * sx;
+        sy = a * sy;
+        V3 wh = normalize(V3(-sx, -sy, 1.));
+        if (flip) wh = -wh;
+        return wh;
+    }
+    // MicrofacetReflection::f, reflection.cpp:226-236 with FresnelDielectric(1.5, 1)
+    static Rgb micro_f(const Bsdf &b, V3 wo, V3 wi) {
+        float cos_o = std::abs(wo.z), cos_i = std::abs(wi.z);
+        V3 wh = wi + wo;
+        if (cos_i == 0 || cos_o == 0) return Rgb(0.);
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Rgb(0.);
+        wh = normalize(wh);
+        Rgb F(fr_dielectric(dot(wi, wh), 1.5f, 1.f));
+        return b.ks * tr_d(wh, b.alpha, b.alpha) * tr_g(wo, wi, b.alpha) * F / (4 * cos_i * cos_o);
+    }
+    static float micro_pdf(const Bsdf &b, V3 wo, V3 wi) {  // reflection.cpp:419-423
+        if (!same_hemisphere(wo, wi)) return 0;
+        V3 wh = normalize(wo + wi);
+        return tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
+    }
+    static float lambert_pdf(V3 wo, V3 wi) { return same_hemisphere(wo, wi) ? std::abs(wi.z) * InvPi : 0; }
+
+    // BSDF::f, reflection.cpp:686-699 (all lobes are BSDF_REFLECTION, non-specular)
+    static Rgb bsdf_f(const Bsdf &b, V3 woW, V3 wiW) {
+        V3 wi = b.to_local(wiW), wo = b.to_local(woW);
+        if (wo.z == 0) return Rgb(0.);
+        bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+        Rgb f(0.f);
+        if (reflect) {
+            if (b.has_lambert) f = f + b.kd * InvPi;
+            if (b.has_micro) f = f + micro_f(b, wo, wi);
+        }
+        return f;
+    }
+    // BSDF::Pdf, reflection.cpp:786-801
+    static float bsdf_pdf(const Bsdf &b, V3 woW, V3 wiW) {
+        if (b.n_lobes == 0) return 0.f;
+        V3 wo = b.to_local(woW), wi = b.to_local(wiW);
+        if (wo.z == 0) return 0.;
+        float pdf = 0.f;
+        int matching = 0;
+        if (b.has_lambert) {
+            ++matching;
+            pdf += lambert_pdf(wo, wi);
+        }
+        if (b.has_micro) {
+            ++matching;
+            pdf += micro_pdf(b, wo, wi);
+        }
+        return matching > 0 ? pdf / matching : 0.f;
+    }
+    // BSDF::Sample_f, reflection.cpp:719-784. Returns f; *pdf is left untouched
+    // on the early `wo.z == 0` return exactly as in the reference.
+    Rgb bsdf_sample_f(const Bsdf &b, V3 woW, V3 *wiW, const float *u, float *pdf) const {
+        int matching = b.n_lobes;
+        if (matching == 0) {
+            *pdf = 0;
+            return Rgb(0);
+        }
+        int comp = std::min((int)std::floor(u[0] * matching), matching - 1);
+        // lobe order: Lambertian first, then the microfacet lobe (plastic.cpp:53-69)
+        bool pick_micro = b.has_lambert ? (comp == 1) : b.has_micro;
+        float ur[2] = {std::min(u[0] * matching - comp, OneMinusEpsilon), u[1]};
+        V3 wi, wo = b.to_local(woW);
+        if (wo.z == 0) return Rgb(0.);
+        *pdf = 0;
+        Rgb f;
+        if (!pick_micro) {  // BxDF::Sample_f, reflection.cpp:378-385
+            wi = cosine_sample_hemisphere(ur);
+            if (wo.z < 0) wi.z *= -1;
+            *pdf = lambert_pdf(wo, wi);
+            f = b.kd * InvPi;
+        } else {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
+            // `if (wo.z == 0) return 0.` is unreachable here
+            V3 wh = tr_sample_wh(wo, ur, b.alpha);
+            wi = -wo + 2 * dot(wo, wh) * wh;  // Reflect(), reflection.h:86-88
+            if (!same_hemisphere(wo, wi))
+                f = Rgb(0.f);
+            else {
+                *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
+                f = micro_f(b, wo, wi);
+            }
+        }
+        if (*pdf == 0) return Rgb(0);
+        *wiW = b.to_world(wi);
+        if (matching > 1) {
+            if (pick_micro)
+                *pdf += lambert_pdf(wo, wi);
+            else
+                *pdf += micro_pdf(b, wo, wi);
+        }
+        if (matching > 1) *pdf /= matching;
+        if (matching > 1) {
+            bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
+            f = Rgb(0.);
+            if (reflect) {
+                if (b.has_lambert) f = f + b.kd * InvPi;
+                if (b.has_micro) f = f + micro_f(b, wo, wi);
+            }
+        }
+        return f;
+    }
+
+    // ------------------------------------------------------------------------
+    // sphere as emitter (shapes/sphere.cpp:219-306, core/shape.cpp:72-87)
+    struct LightSample {
+        V3 p, perr, n;
+    };
+    static V3 sphere_center(const iile_sphere &sp) { return xf_point(M4{sp.o2w}, V3(0, 0, 0)); }
+    LightSample sphere_sample_area(const iile_sphere &sp, const float *u, float *pdf) const {
+        // UniformSampleSphere, sampling.cpp:98-103
+        float z = 1 - 2 * u[0];
+        float r = std::sqrt(std::max(0.f, 1.f - z * z));
+        float phi = 2 * Pi * u[1];
+        V3 us(r * trig.cos_f(phi), r * trig.sin_f(phi), z);
+        V3 pobj = V3(0, 0, 0) + sp.radius * us;
+        LightSample it;
+        it.n = normalize(xf_normal(M4{sp.o2w_inv}, V3(pobj.x, pobj.y, pobj.z)));
+        if (sp.reverse_orientation) it.n = it.n * -1.f;
+        float scale = sp.radius / length(pobj);
+        pobj = V3(pobj.x * scale, pobj.y * scale, pobj.z * scale);
+        V3 pobj_err = gamma_n(5) * vabs(pobj);
+        it.p = xf_point_err2(M4{sp.o2w}, pobj, pobj_err, &it.perr);
+        float area = sp.phi_max * sp.radius * (sp.zmax - sp.zmin);
+        *pdf = 1 / area;
+        return it;
+    }
+    LightSample sphere_sample(const iile_sphere &sp, const Isect &ref, const float *u, float *pdf) const {
+        V3 pc = sphere_center(sp);
+        V3 porigin = offset_ray_origin(ref.p, ref.perr, ref.n, pc - ref.p);
+        if (length_sq(porigin - pc) <= sp.radius * sp.radius) {
+            LightSample intr = sphere_sample_area(sp, u, pdf);
+            V3 wi = intr.p - ref.p;
+            if (length_sq(wi) == 0)
+                *pdf = 0;
+            else {
+                wi = normalize(wi);
+                *pdf *= length_sq(ref.p - intr.p) / absdot(intr.n, -wi);
+            }
+            if (std::isinf(*pdf)) *pdf = 0.f;
+            return intr;
+        }
+        V3 wc = normalize(pc - ref.p);
+        V3 wcx, wcy;
+        coordinate_system(wc, &wcx, &wcy);
+        float sin_tmax2 = sp.radius * sp.radius / length_sq(ref.p - pc);
+        float cos_tmax = std::sqrt(std::max(0.f, 1 - sin_tmax2));
+        float cos_t = (1 - u[0]) + u[0] * cos_tmax;
+        float sin_t = std::sqrt(std::max(0.f, 1 - cos_t * cos_t));
+        float phi = u[1] * 2 * Pi;
+        float dc = length(ref.p - pc);
+        float ds = dc * cos_t - std::sqrt(std::max(0.f, sp.radius * sp.radius - dc * dc * sin_t * sin_t));
+        float cos_a = (dc * dc + sp.radius * sp.radius - ds * ds) / (2 * dc * sp.radius);
+        float sin_a = std::sqrt(std::max(0.f, 1 - cos_a * cos_a));
+        // SphericalDirection(sinAlpha, cosAlpha, phi, -wcX, -wcY, -wc), geometry.h:1467-1472
+        V3 nw = sin_a * trig.cos_f(phi) * (-wcx) + sin_a * trig.sin_f(phi) * (-wcy) + cos_a * (-wc);
+        V3 pw = pc + sp.radius * V3(nw.x, nw.y, nw.z);
+        LightSample it;
+        it.p = pw;
+        it.perr = gamma_n(5) * vabs(pw);
+        it.n = nw;
+        if (sp.reverse_orientation) it.n = it.n * -1.f;
+        *pdf = 1 / (2 * Pi * (1 - cos_tmax));
+        return it;
+    }
+    float sphere_pdf(const iile_sphere &sp, const Isect &ref, V3 wi) const {
+        V3 pc = sphere_center(sp);
+        V3 porigin = offset_ray_origin(ref.p, ref.perr, ref.n, pc - ref.p);
+        if (length_sq(porigin - pc) <= sp.radius * sp.radius) {
+            // Shape::Pdf, shape.cpp:72-87: intersect the shape alone (not a scene ray)
+            Ray ray = spawn_ray(ref, wi);
+            Ray orr;
+            float t;
+            V3 ph;
+            uint64_t keep = ctr->sphere_tests;
+            bool ok = sphere_test(ray, sp, &orr, &t, &ph);
+            ctr->sphere_tests = keep;
+            if (!ok) return 0;
+            Isect li;
+            sphere_interaction(sp, orr, ph, &li);
+            float area = sp.phi_max * sp.radius * (sp.zmax - sp.zmin);
+            float pdf = length_sq(ref.p - li.p) / (absdot(li.n, -wi) * area);
+            if (std::isinf(pdf)) pdf = 0.f;
+            return pdf;
+        }
+        float sin_tmax2 = sp.radius * sp.radius / length_sq(ref.p - pc);
+        float cos_tmax = std::sqrt(std::max(0.f, 1 - sin_tmax2));
+        return 1 / (2 * Pi * (1 - cos_tmax));
+    }
+    // DiffuseAreaLight::L, lights/diffuse.h:56-58
+    static Rgb light_L(const iile_light &lt, V3 n, V3 w) {
+        return (lt.two_sided || dot(n, w) > 0) ? Rgb(lt.lemit[0], lt.lemit[1], lt.lemit[2]) : Rgb(0.f);
+    }
+    Rgb isect_le(const Isect &is, V3 w) const {  // interaction.cpp:151-154
+        int l = S.prim_light[is.prim];
+        return l >= 0 ? light_L(S.lights[l], is.n, w) : Rgb(0.f);
+    }
+
+    // ------------------------------------------------------------------------
+    // EstimateDirect for one area light with MIS, core/integrator.cpp:108-215
+    static float power_heuristic(int nf, float fpdf, int ng, float gpdf) {
+        float f = nf * fpdf, g = ng * gpdf;
+        return (f * f) / (f * f + g * g);
+    }
+    Rgb estimate_direct(const Isect &it, const Bsdf &bsdf, const float *u_scatter, int light_index,
+                        const float *u_light) const {
+        const iile_light &lt = S.lights[light_index];
+        const iile_sphere &sp = S.spheres[lt.sphere];
+        Rgb Ld(0.f);
+        V3 wi;
+        float light_pdf = 0, scattering_pdf = 0;
+        // DiffuseAreaLight::Sample_Li, lights/diffuse.cpp:68-81
+        Rgb Li(0.f);
+        LightSample ps = sphere_sample(sp, it, u_light, &light_pdf);
+        if (light_pdf == 0 || length_sq(ps.p - it.p) == 0) {
+            light_pdf = 0;
+            Li = Rgb(0.f);
+        } else {
+            wi = normalize(ps.p - it.p);
+            Li = light_L(lt, ps.n, -wi);
+        }
+        if (light_pdf > 0 && !Li.is_black()) {
+            Rgb f = bsdf_f(bsdf, it.wo, wi) * absdot(wi, it.sn);
+            scattering_pdf = bsdf_pdf(bsdf, it.wo, wi);
+            if (!f.is_black()) {
+                // VisibilityTester::Unoccluded -> SpawnRayTo(Interaction), interaction.h:73-78
+                V3 origin = offset_ray_origin(it.p, it.perr, it.n, ps.p - it.p);
+                V3 target = offset_ray_origin(ps.p, ps.perr, ps.n, origin - ps.p);
+                Ray sr{origin, target - origin, 1 - ShadowEpsilon};
+                if (intersect_p(sr)) Li = Rgb(0.f);
+                if (!Li.is_black()) {
+                    float weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                    Ld = Ld + f * Li * weight / light_pdf;
+                }
+            }
+        }
+        // BSDF sampling half
+        {
+            Rgb f = bsdf_sample_f(bsdf, it.wo, &wi, u_scatter, &scattering_pdf);
+            f = f * absdot(wi, it.sn);
+            if (!f.is_black() && scattering_pdf > 0) {
+                light_pdf = sphere_pdf(sp, it, wi);
+                if (light_pdf == 0) return Ld;
+                float weight = power_heuristic(1, scattering_pdf, 1, light_pdf);
+                Isect li;
+                Ray ray = spawn_ray(it, wi);
+                bool found = intersect(ray, &li);
+                Rgb Li2(0.f);
+                if (found) {
+                    if (S.prim_light[li.prim] == light_index) Li2 = isect_le(li, -wi);
+                }
+                if (!Li2.is_black()) Ld = Ld + f * Li2 * Rgb(1.f) * weight / scattering_pdf;
+            }
+        }
+        return Ld;
+    }
+
+    // ------------------------------------------------------------------------
+    // PathIntegrator::Li, integrators/path.cpp:64-194
+    Rgb li(Ray ray, Sampler &smp) const {
+        Rgb L(0.f), beta(1.f);
+        bool specular_bounce = false;
+        int bounces;
+        const int max_depth = S.integrator.max_depth;
+        const float rr_threshold = S.integrator.rr_threshold;
+        float eta_scale = 1;
+        for (bounces = 0;; ++bounces) {
+            Isect is;
+            bool found = intersect(ray, &is);
+            if (bounces == 0 || specular_bounce) {
+                if (found) L = L + beta * isect_le(is, -ray.d);
+            }
+            if (!found || bounces >= max_depth) break;
+            Bsdf bsdf = make_bsdf(is);
+            // UniformLightDistribution::Lookup ignores the point; SampleDiscrete
+            // still consumes one 1D sample (integrator.cpp:95).
+            if (bsdf.n_lobes > 0) {
+                ++ctr->nee_evals;
+                Rgb Ld_in(0.f);
+                if (S.n_lights > 0) {
+                    int n_lights = S.n_lights;
+                    // Distribution1D::SampleDiscrete over a constant function of n_lights
+                    // entries (sampling.h:90-100); pdf = 1/n
+                    float ul = smp.get1d();
+                    int light_num = std::min(int(ul * n_lights), n_lights - 1);
+                    float light_pdf = 1.f / n_lights;
+                    float u_light[2], u_scatter[2];
+                    smp.get2d(u_light);
+                    smp.get2d(u_scatter);
+                    Ld_in = estimate_direct(is, bsdf, u_scatter, light_num, u_light) / light_pdf;
+                }
+                Rgb Ld = beta * Ld_in;
+                if (Ld.is_black()) ++ctr->zero_radiance;
+                L = L + Ld;
+            }
+            V3 wo = -ray.d, wi;
+            float pdf;
+            float u[2];
+            smp.get2d(u);
+            pdf = 0;
+            Rgb f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf);
+            if (f.is_black() || pdf == 0.f) break;
+            beta = beta * (f * absdot(wi, is.sn) / pdf);
+            if (beta.y() < 0.f || std::isnan(beta.y())) return L;
+            specular_bounce = false;
+            ray = spawn_ray(is, wi);
+            Rgb rr_beta = beta * eta_scale;
+            if (rr_beta.max_component() < rr_threshold && bounces > 3) {
+                float q = std::max(.05f, 1 - rr_beta.max_component());
+                if (smp.get1d() < q) break;
+                beta = beta / (1 - q);
+            }
+        }
+        ctr->path_length[std::min(bounces, 7)]++;
+        return L;
+    }
+
+    // one camera sample -> guarded radiance (integrator.cpp:270-314)
+    Rgb sample_radiance(int px, int py, int64_t k, float *pfilm) const {
+        Sampler smp{this, halton_index(px, py, k), 0};
+        float u[2];
+        smp.get2d(u);
+        pfilm[0] = float(px) + u[0];
+        pfilm[1] = float(py) + u[1];
+        smp.get1d();  // time
+        float plens[2];
+        smp.get2d(plens);
+        Ray ray = camera_ray(pfilm[0], pfilm[1], plens);
+        ++ctr->camera_rays;
+        Rgb L = li(ray, smp);
+        if (L.has_nans())
+            L = Rgb(0.f);
+        else if (L.y() < -1e-5)
+            L = Rgb(0.f);
+        else if (std::isinf(L.y()))
+            L = Rgb(0.f);
+        return L;
+    }
+};
+
+// SampleDiscrete on a uniform distribution: FindInterval over cdf[i] = i/n picks
+// the last i with cdf[i] <= u, i.e. min(int(u*n), n-1) for n == 1 (the only
+// case this path supports on device); for n > 1 the product i/n is compared in
+// float, which this helper does not reproduce bit-exactly — rejected at load.
+
+// ----------------------------------------------------------------------------
+// film tile (core/film.h:140-213, core/film.cpp:92-103, 135-148)
+struct TilePixel {
+    float rgb[3] = {0, 0, 0};
+    float wsum = 0;
+};
+struct FilmTile {
+    int x0, y0, x1, y1;  // pixel bounds
+    std::vector<TilePixel> px;
+};
+
+}  // namespace
+
+extern "C" {
+
+int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, int k_begin, int k_end, int tile_rank,
+                  int tile_nranks, float *film_xyzw, oracle_stats *stats) {
+    if (!scene || !film_xyzw) return 1;
+    const iile_scene_desc &S = *scene;
+    const iile_film_desc &F = S.film;
+    if (k_end < 0) {
+        k_begin = 0;
+        k_end = S.halton.spp;
+    }
+    if (tile_nranks <= 0) {
+        tile_rank = 0;
+        tile_nranks = 1;
+    }
+    if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = 1;
+    const int tile_size = 16;
+    const int sx = F.samp_x1 - F.samp_x0, sy = F.samp_y1 - F.samp_y0;
+    const int ntx = (sx + tile_size - 1) / tile_size, nty = (sy + tile_size - 1) / tile_size;
+    const int n_tiles = ntx * nty;
+    std::vector<std::unique_ptr<FilmTile>> tiles(n_tiles);
+    std::vector<Counters> counters(n_threads);
+    std::atomic<int> next_tile(0);
+    auto t_start = std::chrono::steady_clock::now();
+    auto worker = [&](int tid) {
+        Oracle orc(S, trig_mode, &counters[tid]);
+        while (true) {
+            int tile = next_tile.fetch_add(1);
+            if (tile >= n_tiles) break;
+            if (tile % tile_nranks != tile_rank) continue;
+            int tx = tile % ntx, ty = tile / ntx;
+            int x0 = F.samp_x0 + tx * tile_size, x1 = std::min(x0 + tile_size, F.samp_x1);
+            int y0 = F.samp_y0 + ty * tile_size, y1 = std::min(y0 + tile_size, F.samp_y1);
+            // Film::GetFilmTile, film.cpp:92-103
+            std::unique_ptr<FilmTile> ft(new FilmTile);
+            ft->x0 = std::max(int(std::ceil(float(x0) - 0.5f - F.filter_rx)), F.crop_x0);
+            ft->y0 = std::max(int(std::ceil(float(y0) - 0.5f - F.filter_ry)), F.crop_y0);
+            ft->x1 = std::min(int(std::floor(float(x1) - 0.5f + F.filter_rx)) + 1, F.crop_x1);
+            ft->y1 = std::min(int(std::floor(float(y1) - 0.5f + F.filter_ry)) + 1, F.crop_y1);
+            const int tw = std::max(0, ft->x1 - ft->x0), th = std::max(0, ft->y1 - ft->y0);
+            ft->px.resize(size_t(tw) * th);
+            for (int py = y0; py < y1; ++py)
+                for (int px = x0; px < x1; ++px)
+                    for (int64_t k = k_begin; k < k_end; ++k) {
+                        float pf[2];
+                        Rgb L = orc.sample_radiance(px, py, k, pf);
+                        if (L.y() > F.max_sample_luminance) L = L * (F.max_sample_luminance / L.y());
+                        // FilmTile::AddSample, film.h:153-193 (box filter: every table entry is 1)
+                        float dxf = pf[0] - 0.5f, dyf = pf[1] - 0.5f;
+                        int ax0 = std::max(int(std::ceil(dxf - F.filter_rx)), ft->x0);
+                        int ay0 = std::max(int(std::ceil(dyf - F.filter_ry)), ft->y0);
+                        int ax1 = std::min(int(std::floor(dxf + F.filter_rx)) + 1, ft->x1);
+                        int ay1 = std::min(int(std::floor(dyf + F.filter_ry)) + 1, ft->y1);
+                        for (int y = ay0; y < ay1; ++y)
+                            for (int x = ax0; x < ax1; ++x) {
+                                TilePixel &tp = ft->px[size_t(y - ft->y0) * tw + (x - ft->x0)];
+                                const float fw = 1.f;
+                                for (int c = 0; c < 3; ++c) tp.rgb[c] += L.c[c] * 1.f * fw;
+                                tp.wsum += fw;
+                            }
+                    }
+            tiles[tile] = std::move(ft);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_threads; ++i) th.emplace_back(worker, i);
+    worker(0);
+    for (auto &t : th) t.join();
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+
+    // Film::MergeFilmTile, film.cpp:135-148 — merged here in tile index order so
+    // the oracle is deterministic (the reference merges in completion order).
+    const int fw = F.crop_x1 - F.crop_x0, fh = F.crop_y1 - F.crop_y0;
+    std::memset(film_xyzw, 0, sizeof(float) * 4 * size_t(fw) * fh);
+    for (int t = 0; t < n_tiles; ++t) {
+        if (!tiles[t]) continue;
+        const FilmTile &ft = *tiles[t];
+        const int tw = std::max(0, ft.x1 - ft.x0);
+        for (int y = ft.y0; y < ft.y1; ++y)
+            for (int x = ft.x0; x < ft.x1; ++x) {
+                const TilePixel &tp = ft.px[size_t(y - ft.y0) * tw + (x - ft.x0)];
+                float *out = film_xyzw + 4 * (size_t(y - F.crop_y0) * fw + (x - F.crop_x0));
+                float xyz[3];  // RGBToXYZ, spectrum.h:62-66
+                xyz[0] = 0.412453f * tp.rgb[0] + 0.357580f * tp.rgb[1] + 0.180423f * tp.rgb[2];
+                xyz[1] = 0.212671f * tp.rgb[0] + 0.715160f * tp.rgb[1] + 0.072169f * tp.rgb[2];
+                xyz[2] = 0.019334f * tp.rgb[0] + 0.119193f * tp.rgb[1] + 0.950227f * tp.rgb[2];
+                for (int c = 0; c < 3; ++c) out[c] += xyz[c];
+                out[3] += tp.wsum;
+            }
+    }
+    if (stats) {
+        Counters tot;
+        for (const Counters &c : counters) tot.add(c);
+        std::memset(stats, 0, sizeof(*stats));
+        stats->camera_rays = tot.camera_rays;
+        stats->regular_rays = tot.regular_rays;
+        stats->shadow_rays = tot.shadow_rays;
+        stats->tri_tests = tot.tri_tests;
+        stats->tri_hits = tot.tri_hits;
+        stats->sphere_tests = tot.sphere_tests;
+        stats->nodes_closest = tot.nodes_closest;
+        stats->nodes_any = tot.nodes_any;
+        stats->nee_evals = tot.nee_evals;
+        stats->zero_radiance = tot.zero_radiance;
+        for (int i = 0; i < 8; ++i) stats->path_length[i] = tot.path_length[i];
+        stats->max_stack_depth = tot.max_stack;
+        stats->threads = n_threads;
+        stats->seconds = secs;
+    }
+    return 0;
+}
+
+int64_t oracle_halton_index(const iile_scene_desc *scene, int px, int py, int64_t k) {
+    Counters c;
+    Oracle o(*scene, ORACLE_TRIG_LIBM, &c);
+    return o.halton_index(px, py, k);
+}
+float oracle_halton_sample(const iile_scene_desc *scene, int64_t index, int dim) {
+    Counters c;
+    Oracle o(*scene, ORACLE_TRIG_LIBM, &c);
+    return o.sample_dimension(index, dim);
+}
+static const int kFirstPrimes[64] = {2,   3,   5,   7,   11,  13,  17,  19,  23,  29,  31,  37,  41,  43,  47,  53,
+                                     59,  61,  67,  71,  73,  79,  83,  89,  97,  101, 103, 107, 109, 113, 127, 131,
+                                     137, 139, 149, 151, 157, 163, 167, 173, 179, 181, 191, 193, 197, 199, 211, 223,
+                                     227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283, 293, 307, 311};
+float oracle_radical_inverse(int base_index, uint64_t a) {
+    return Oracle::radical_inverse(base_index, kFirstPrimes[base_index & 63], a);
+}
+float oracle_scrambled_radical_inverse(const iile_scene_desc *scene, int base_index, uint64_t a) {
+    const iile_halton &h = scene->halton;
+    return Oracle::scrambled_radical_inverse(h.primes[base_index], h.perms + h.prime_sums[base_index], a);
+}
+void oracle_camera_ray(const iile_scene_desc *scene, float pfx, float pfy, float plx, float ply, float *o3, float *d3) {
+    Counters c;
+    Oracle o(*scene, ORACLE_TRIG_PORTABLE, &c);
+    float pl[2] = {plx, ply};
+    Ray r = o.camera_ray(pfx, pfy, pl);
+    for (int i = 0; i < 3; ++i) {
+        o3[i] = r.o[i];
+        d3[i] = r.d[i];
+    }
+}
+void oracle_intersect(const iile_scene_desc *scene, int n, const float *o, const float *d, const float *tmax,
+                      int32_t *prim, float *tb) {
+    Counters c;
+    Oracle orc(*scene, ORACLE_TRIG_PORTABLE, &c);
+    for (int i = 0; i < n; ++i) {
+        Ray r{V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]};
+        Isect is;
+        bool hit = orc.intersect(r, &is, false);
+        prim[i] = hit ? is.prim : -1;
+        tb[4 * i] = hit ? is.t : 0;
+        tb[4 * i + 1] = hit ? is.b0 : 0;
+        tb[4 * i + 2] = hit ? is.b1 : 0;
+        tb[4 * i + 3] = hit ? is.b2 : 0;
+    }
+}
+void oracle_intersect_p(const iile_scene_desc *scene, int n, const float *o, const float *d, const float *tmax,
+                        int32_t *hit) {
+    Counters c;
+    Oracle orc(*scene, ORACLE_TRIG_PORTABLE, &c);
+    for (int i = 0; i < n; ++i) {
+        Ray r{V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]};
+        hit[i] = orc.intersect_p(r) ? 1 : 0;
+    }
+}
+void oracle_li(const iile_scene_desc *scene, int trig_mode, int n, const int32_t *px, const int32_t *py,
+               const int32_t *k, float *L, int32_t *nrays) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    for (int i = 0; i < n; ++i) {
+        uint64_t r0 = c.regular_rays, s0 = c.shadow_rays;
+        float pf[2];
+        Rgb v = orc.sample_radiance(px[i], py[i], k[i], pf);
+        for (int j = 0; j < 3; ++j) L[3 * i + j] = v.c[j];
+        if (nrays) {
+            nrays[2 * i] = int32_t(c.regular_rays - r0);
+            nrays[2 * i + 1] = int32_t(c.shadow_rays - s0);
+        }
+    }
+}
+static Oracle::Bsdf local_bsdf(const Oracle &, const iile_scene_desc *scene, int mat) {
+    Oracle::Bsdf b;
+    b.ns = V3(0, 0, 1);
+    b.ng = V3(0, 0, 1);
+    b.ss = V3(1, 0, 0);
+    b.ts = cross(b.ns, b.ss);
+    const iile_material &m = scene->materials[mat];
+    Rgb kd(clampf(m.kd[0], 0, Infinity), clampf(m.kd[1], 0, Infinity), clampf(m.kd[2], 0, Infinity));
+    if (!kd.is_black()) {
+        b.has_lambert = true;
+        b.kd = kd;
+        ++b.n_lobes;
+    }
+    if (m.type == IILE_MAT_PLASTIC) {
+        Rgb ks(clampf(m.ks[0], 0, Infinity), clampf(m.ks[1], 0, Infinity), clampf(m.ks[2], 0, Infinity));
+        if (!ks.is_black()) {
+            b.has_micro = true;
+            b.ks = ks;
+            b.alpha = m.alpha;
+            ++b.n_lobes;
+        }
+    }
+    return b;
+}
+void oracle_bsdf_eval(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3, const float *wi3,
+                      float *f3, float *pdf) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    Oracle::Bsdf b = local_bsdf(orc, scene, mat);
+    V3 wo(wo3[0], wo3[1], wo3[2]), wi(wi3[0], wi3[1], wi3[2]);
+    Rgb f = Oracle::bsdf_f(b, wo, wi);
+    for (int i = 0; i < 3; ++i) f3[i] = f.c[i];
+    *pdf = Oracle::bsdf_pdf(b, wo, wi);
+}
+void oracle_bsdf_sample(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3, const float *u2,
+                        float *wi3, float *f3, float *pdf) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    Oracle::Bsdf b = local_bsdf(orc, scene, mat);
+    V3 wo(wo3[0], wo3[1], wo3[2]), wi;
+    float p = 0;
+    Rgb f = orc.bsdf_sample_f(b, wo, &wi, u2, &p);
+    for (int i = 0; i < 3; ++i) {
+        f3[i] = f.c[i];
+        wi3[i] = wi[i];
+    }
+    *pdf = p;
+}
+void oracle_sincos(int trig_mode, float x, float *s, float *c) {
+    Trig t{trig_mode};
+    *s = t.sin_f(x);
+    *c = t.cos_f(x);
+}
+void oracle_sincos_d(int trig_mode, double x, double *s, double *c) {
+    Trig t{trig_mode};
+    *s = t.sin_d(x);
+    *c = t.cos_d(x);
+}
+float oracle_acos(int trig_mode, float x) {
+    Trig t{trig_mode};
+    return t.acos_f(x);
+}
+
+}  // extern "C"

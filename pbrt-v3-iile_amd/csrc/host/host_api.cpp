@@ -47,6 +47,10 @@ const iile_scene_desc *iile_host_scene_desc(const iile_host_scene *scene) {
     return scene ? &scene->s.desc : nullptr;
 }
 
+const iile_film_desc *iile_host_scene_film(const iile_host_scene *scene) {
+    return scene ? &scene->s.desc.film : nullptr;
+}
+
 int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info *info) {
     if (!scene || !info) {
         g_err = "iile_host_scene_get_info: null argument";
