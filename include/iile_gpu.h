@@ -1,0 +1,117 @@
+/*
+ * iile_gpu.h — C ABI of libiile_gpu.so: the MI355X (gfx950) path-tracing
+ * integrator behind the reference's Integrator plugin surface.
+ *
+ * The reference has no binary plugin ABI; its surface for this path is
+ *   class Integrator { virtual void Render(const Scene &scene) = 0; }
+ *                                         src/core/integrator.h:53-58
+ *   class SamplerIntegrator : Integrator  { Render(); virtual Li(...); Preprocess(); }
+ *                                         src/core/integrator.h:77-107
+ *   PathIntegrator *CreatePathIntegrator(const ParamSet&, std::shared_ptr<Sampler>,
+ *                                        std::shared_ptr<const Camera>)
+ *                                         src/integrators/path.h:70-72
+ * called from pbrtWorldEnd as `integrator->Render(*scene)` (src/core/api.cpp:1650-1662).
+ * The BVH arrays are private to BVHAccel (src/accelerators/bvh.h:90-94), so a
+ * replacement cannot read the built tree: the host flattens the scene into an
+ * iile_scene_desc (iile_scene.h) and hands it over once.
+ *
+ *   iile_scene_create   <->  MakeScene + integrator construction (api.cpp:1694-1747):
+ *                            uploads BVH, triangles, spheres, materials, lights,
+ *                            camera matrices and Halton tables to HBM
+ *   iile_render         <->  SamplerIntegrator::Render(scene) (integrator.cpp:227-331)
+ *                            minus WriteImage: runs generate/extend/shade/connect
+ *                            wavefront kernels and leaves the merged film
+ *                            ({X,Y,Z,filterWeightSum} per pixel == Film::Pixel after
+ *                            MergeFilmTile, film.cpp:135-148) in `film_xyzw`
+ *   iile_scene_destroy  <->  ~Scene / ~Integrator
+ *
+ * Errors: the reference reports through Error()/LOG(FATAL) (src/core/error.h:54-55);
+ * here every call returns 0 on success or a non-zero code, message in
+ * iile_last_error(). There is NO CPU fallback: without a HIP device every
+ * compute entry point fails with IILE_ERR_NO_DEVICE.
+ * Threading: thread-compatible, not thread-safe (one scene per host thread).
+ */
+#ifndef IILE_GPU_H
+#define IILE_GPU_H
+
+#include "iile_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct iile_scene iile_scene;
+
+enum {
+    IILE_OK = 0,
+    IILE_ERR_ARG = 1,
+    IILE_ERR_NO_DEVICE = 2,
+    IILE_ERR_HIP = 3,
+    IILE_ERR_UNSUPPORTED = 4
+};
+
+typedef struct iile_render_params {
+    int32_t k_begin, k_end;         /* sample indices [k_begin, k_end); k_end <= 0: all pixelsamples */
+    int32_t tile_rank, tile_nranks; /* this call renders the 16x16 tiles with index % nranks == rank;
+                                       nranks <= 0: all tiles (single GPU) */
+    int32_t spp_per_pass;           /* samples per wavefront pass; 0 = sized to the workspace budget */
+    int32_t collect_stats;          /* 1: instrumented kernels (ray / node / triangle counters) */
+    int32_t time_kernels;           /* 1: bracket every kernel with HIP events on `stream` */
+    int32_t film_on_device;         /* 1: film_xyzw is a device pointer (stays in HBM) */
+    void *stream;                   /* hipStream_t to launch on; NULL = the null stream */
+} iile_render_params;
+
+typedef struct iile_stats {
+    /* counters named after the reference's STAT_COUNTERs (scene.cpp:45-47,
+     * triangle.cpp:45, path.cpp:45-46, integrator.cpp:48); filled when collect_stats */
+    uint64_t camera_rays, closest_rays, shadow_rays;
+    uint64_t nodes_closest, nodes_any, tri_tests, tri_hits, sphere_tests;
+    uint64_t nee_evals, zero_radiance;
+    uint64_t path_length[8];
+    /* timings in milliseconds; per-kernel sums filled when time_kernels */
+    double ms_total;
+    double ms_generate, ms_extend, ms_shade, ms_connect, ms_film;
+    int32_t n_extend_launches, n_connect_launches, n_shade_launches, n_passes;
+    uint64_t n_paths;             /* camera samples rendered by this call */
+    uint64_t workspace_bytes;     /* HBM held by the wavefront queues */
+} iile_stats;
+
+int iile_device_count(void);
+const char *iile_last_error(void);
+
+int iile_scene_create(const iile_scene_desc *desc, iile_scene **out);
+void iile_scene_destroy(iile_scene *scene);
+
+/* film_xyzw: 4 floats per pixel of the cropped pixel bounds, row-major.
+ * With tile sharding each rank's film holds its own tiles' contributions
+ * (zeros elsewhere); ranks are combined with one sum-reduction. */
+int iile_render(iile_scene *scene, const iile_render_params *params, float *film_xyzw, iile_stats *stats);
+
+/* ---- kernel-level entry points (parity tests; host pointers, synchronous) ---- */
+/* BVHAccel::Intersect on n rays. prim[i] = -1 on miss; tb[4i..] = {t, b0, b1, b2}. */
+int iile_trace_closest(iile_scene *scene, int32_t n, const float *o3, const float *d3, const float *tmax,
+                       int32_t *prim, float *tb, iile_stats *stats);
+/* BVHAccel::IntersectP on n rays. */
+int iile_trace_any(iile_scene *scene, int32_t n, const float *o3, const float *d3, const float *tmax,
+                   int32_t *hit, iile_stats *stats);
+/* HaltonSampler: index_out[i] = GetIndexForSample(k) of pixel i; out[i*ndims + d] =
+ * SampleDimension(index, dim0 + d). */
+int iile_halton_samples(iile_scene *scene, int32_t n, const int32_t *px, const int32_t *py, const int32_t *k,
+                        int32_t dim0, int32_t ndims, float *out, uint32_t *index_out);
+/* PerspectiveCamera::GenerateRayDifferential (origin / direction only). plens may be NULL. */
+int iile_camera_rays(iile_scene *scene, int32_t n, const float *pfilm2, const float *plens2, float *o3, float *d3);
+/* Radiance of n individual camera samples through the full wavefront pipeline,
+ * after the NaN / negative / inf guards; nrays (optional): {closest, shadow} per sample. */
+int iile_li_samples(iile_scene *scene, int32_t n, const int32_t *px, const int32_t *py, const int32_t *k,
+                    float *L3, int32_t *nrays2);
+/* BSDF::f / Pdf (out: 4 floats {f.rgb, pdf}) and BSDF::Sample_f (out: 7 floats
+ * {wi.xyz, f.rgb, pdf}) of material `mat` in the canonical frame ns=ng=+z, ss=+x. */
+int iile_bsdf_eval(iile_scene *scene, int32_t n, int32_t mat, const float *wo3, const float *wi3, float *out4);
+int iile_bsdf_sample(iile_scene *scene, int32_t n, int32_t mat, const float *wo3, const float *u2, float *out7);
+/* portable sin / cos / acos used on the device: out[3i..] = {sin x, cos x, acos clamp(x)} */
+int iile_trig_probe(int32_t n, const float *x, float *out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IILE_GPU_H */

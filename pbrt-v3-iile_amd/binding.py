@@ -1,0 +1,295 @@
+"""ctypes bindings over the two C-ABI libraries of the path.
+
+    libiile_host.so  scene preparation + film finalisation   (include/iile_host.h)
+    libiile_gpu.so   gfx950 wavefront path tracer            (include/iile_gpu.h)
+
+Python is plumbing only (tests, bench.py, __graft_entry__): every number comes
+out of the HIP kernels. There is no CPU fallback here — if libiile_gpu.so is
+missing or no GPU is visible, the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+REPO_ROOT = os.path.dirname(_HERE)
+DEFAULT_SCENE = os.path.join(REPO_ROOT, "scenes", "killeroo-simple.pbrt")
+
+c_i32, c_u32, c_u64, c_f32, c_f64 = (ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float,
+                                     ctypes.c_double)
+c_vp = ctypes.c_void_p
+
+
+class HostOverrides(ctypes.Structure):
+    _fields_ = [("xres", c_i32), ("yres", c_i32), ("spp", c_i32), ("max_depth", c_i32)]
+
+
+class HostSceneInfo(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("n_prims n_triangles n_spheres n_meshes n_nodes n_interior_nodes "
+                                      "n_leaf_nodes n_materials n_lights xres yres spp max_depth").split()]
+
+
+class FilmDesc(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in "xres yres crop_x0 crop_y0 crop_x1 crop_y1 samp_x0 samp_y0 samp_x1 samp_y1".split()
+                ] + [(n, c_f32) for n in "filter_rx filter_ry scale max_sample_luminance".split()]
+
+
+class RenderParams(ctypes.Structure):
+    _fields_ = [("k_begin", c_i32), ("k_end", c_i32), ("tile_rank", c_i32), ("tile_nranks", c_i32),
+                ("spp_per_pass", c_i32), ("collect_stats", c_i32), ("time_kernels", c_i32),
+                ("film_on_device", c_i32), ("stream", c_vp)]
+
+
+class GpuStats(ctypes.Structure):
+    _fields_ = [(n, c_u64) for n in ("camera_rays closest_rays shadow_rays nodes_closest nodes_any tri_tests "
+                                     "tri_hits sphere_tests nee_evals zero_radiance").split()] + [
+        ("path_length", c_u64 * 8),
+        ("ms_total", c_f64), ("ms_generate", c_f64), ("ms_extend", c_f64), ("ms_shade", c_f64),
+        ("ms_connect", c_f64), ("ms_film", c_f64),
+        ("n_extend_launches", c_i32), ("n_connect_launches", c_i32), ("n_shade_launches", c_i32),
+        ("n_passes", c_i32), ("n_paths", c_u64), ("workspace_bytes", c_u64)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if name == "path_length" else v
+        return d
+
+
+# every symbol the headers declare; checked by tests/test_abi.py
+HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_film", "iile_host_scene_get_info",
+                "iile_host_scene_free", "iile_host_film_to_rgb", "iile_host_write_pfm", "iile_host_last_error"]
+GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
+               "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
+               "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe"]
+
+_host = None
+_gpu = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        path = os.path.join(LIB_DIR, "libiile_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (make -C pbrt-v3-iile_amd/csrc host)")
+        lib = ctypes.CDLL(path)
+        lib.iile_host_last_error.restype = ctypes.c_char_p
+        lib.iile_host_load_pbrt.argtypes = [ctypes.c_char_p, ctypes.POINTER(HostOverrides), ctypes.POINTER(c_vp)]
+        lib.iile_host_scene_desc.restype = c_vp
+        lib.iile_host_scene_desc.argtypes = [c_vp]
+        lib.iile_host_scene_film.restype = ctypes.POINTER(FilmDesc)
+        lib.iile_host_scene_film.argtypes = [c_vp]
+        lib.iile_host_scene_get_info.argtypes = [c_vp, ctypes.POINTER(HostSceneInfo)]
+        lib.iile_host_scene_free.argtypes = [c_vp]
+        lib.iile_host_scene_free.restype = None
+        lib.iile_host_film_to_rgb.argtypes = [ctypes.POINTER(FilmDesc), c_vp, c_vp]
+        lib.iile_host_write_pfm.argtypes = [ctypes.c_char_p, c_vp, c_i32, c_i32]
+        _host = lib
+    return _host
+
+
+def gpu_lib():
+    """The HIP library. Fails loudly when it has not been built."""
+    global _gpu
+    if _gpu is None:
+        path = os.path.join(LIB_DIR, "libiile_gpu.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: the HIP extension was not built; there is no CPU fallback "
+                               "(run __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        lib.iile_last_error.restype = ctypes.c_char_p
+        lib.iile_scene_create.argtypes = [c_vp, ctypes.POINTER(c_vp)]
+        lib.iile_scene_destroy.argtypes = [c_vp]
+        lib.iile_scene_destroy.restype = None
+        lib.iile_render.argtypes = [c_vp, ctypes.POINTER(RenderParams), c_vp, ctypes.POINTER(GpuStats)]
+        lib.iile_trace_closest.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GpuStats)]
+        lib.iile_trace_any.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GpuStats)]
+        lib.iile_halton_samples.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]
+        lib.iile_camera_rays.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]
+        lib.iile_li_samples.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
+        lib.iile_bsdf_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
+        lib.iile_bsdf_sample.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
+        lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
+        _gpu = lib
+    return _gpu
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class HostScene:
+    """Scene loaded and flattened by libiile_host (ParseFile + MakeScene in the reference)."""
+
+    def __init__(self, path=DEFAULT_SCENE, xres=0, yres=0, spp=0, max_depth=0):
+        lib = host_lib()
+        self._h = c_vp()
+        ov = HostOverrides(int(xres), int(yres), int(spp), int(max_depth))
+        rc = lib.iile_host_load_pbrt(os.fsencode(path), ctypes.byref(ov), ctypes.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"iile_host_load_pbrt({path}) failed: {lib.iile_host_last_error().decode()}")
+        self.desc = lib.iile_host_scene_desc(self._h)
+        self._film = lib.iile_host_scene_film(self._h)
+        self.film = self._film.contents
+        info = HostSceneInfo()
+        lib.iile_host_scene_get_info(self._h, ctypes.byref(info))
+        self.info = {n: getattr(info, n) for n, _ in HostSceneInfo._fields_}
+
+    @property
+    def film_shape(self):
+        f = self.film
+        return (f.crop_y1 - f.crop_y0, f.crop_x1 - f.crop_x0)
+
+    def film_to_rgb(self, film_xyzw):
+        """Film::to_rgb_array on a (H, W, 4) {X,Y,Z,weight} film."""
+        h, w = self.film_shape
+        film = _f32(film_xyzw).reshape(h, w, 4)
+        rgb = np.empty((h, w, 3), np.float32)
+        rc = host_lib().iile_host_film_to_rgb(self._film, film.ctypes.data, rgb.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(host_lib().iile_host_last_error().decode())
+        return rgb
+
+    def write_pfm(self, path, rgb):
+        rgb = _f32(rgb)
+        rc = host_lib().iile_host_write_pfm(os.fsencode(path), rgb.ctypes.data, rgb.shape[1], rgb.shape[0])
+        if rc != 0:
+            raise RuntimeError(host_lib().iile_host_last_error().decode())
+
+    def close(self):
+        if self._h:
+            host_lib().iile_host_scene_free(self._h)
+            self._h = c_vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuScene:
+    """Device-resident scene + wavefront integrator (libiile_gpu)."""
+
+    def __init__(self, host_scene):
+        lib = gpu_lib()
+        self.host = host_scene
+        self._s = c_vp()
+        rc = lib.iile_scene_create(host_scene.desc, ctypes.byref(self._s))
+        if rc != 0:
+            raise RuntimeError(f"iile_scene_create failed ({rc}): {lib.iile_last_error().decode()}")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {gpu_lib().iile_last_error().decode()}")
+
+    def render(self, k_begin=0, k_end=0, tile_rank=0, tile_nranks=1, spp_per_pass=0, collect_stats=False,
+               time_kernels=False, film_device_ptr=None, stream=None, want_stats=True):
+        """SamplerIntegrator::Render. Returns (film, stats): film is a (H, W, 4) float32
+        array, or None when `film_device_ptr` (a raw device pointer) receives it."""
+        prm = RenderParams(int(k_begin), int(k_end), int(tile_rank), int(tile_nranks), int(spp_per_pass),
+                           int(bool(collect_stats)), int(bool(time_kernels)), int(film_device_ptr is not None),
+                           c_vp(stream) if stream else None)
+        st = GpuStats()
+        if film_device_ptr is not None:
+            film, ptr = None, c_vp(int(film_device_ptr))
+        else:
+            h, w = self.host.film_shape
+            film = np.zeros((h, w, 4), np.float32)
+            ptr = film.ctypes.data
+        rc = gpu_lib().iile_render(self._s, ctypes.byref(prm), ptr, ctypes.byref(st) if want_stats else None)
+        self._check(rc, "iile_render")
+        return film, (st.as_dict() if want_stats else None)
+
+    def trace_closest(self, o, d, tmax):
+        o, d, tmax = _f32(o), _f32(d), _f32(tmax)
+        n = len(tmax)
+        prim = np.empty(n, np.int32)
+        tb = np.empty((n, 4), np.float32)
+        st = GpuStats()
+        self._check(gpu_lib().iile_trace_closest(self._s, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data,
+                                                 prim.ctypes.data, tb.ctypes.data, ctypes.byref(st)), "iile_trace_closest")
+        return prim, tb, st.as_dict()
+
+    def trace_any(self, o, d, tmax):
+        o, d, tmax = _f32(o), _f32(d), _f32(tmax)
+        n = len(tmax)
+        hit = np.empty(n, np.int32)
+        st = GpuStats()
+        self._check(gpu_lib().iile_trace_any(self._s, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data,
+                                             hit.ctypes.data, ctypes.byref(st)), "iile_trace_any")
+        return hit, st.as_dict()
+
+    def halton_samples(self, px, py, k, dim0, ndims):
+        px, py, k = _i32(px), _i32(py), _i32(k)
+        n = len(px)
+        out = np.empty((n, ndims), np.float32)
+        idx = np.empty(n, np.uint32)
+        self._check(gpu_lib().iile_halton_samples(self._s, n, px.ctypes.data, py.ctypes.data, k.ctypes.data, dim0,
+                                                  ndims, out.ctypes.data, idx.ctypes.data), "iile_halton_samples")
+        return out, idx
+
+    def camera_rays(self, pfilm, plens=None):
+        pfilm = _f32(pfilm)
+        n = len(pfilm)
+        o = np.empty((n, 3), np.float32)
+        d = np.empty((n, 3), np.float32)
+        pl = _f32(plens) if plens is not None else None
+        self._check(gpu_lib().iile_camera_rays(self._s, n, pfilm.ctypes.data, pl.ctypes.data if pl is not None else None,
+                                               o.ctypes.data, d.ctypes.data), "iile_camera_rays")
+        return o, d
+
+    def li_samples(self, px, py, k):
+        px, py, k = _i32(px), _i32(py), _i32(k)
+        n = len(px)
+        L = np.empty((n, 3), np.float32)
+        nr = np.empty((n, 2), np.int32)
+        self._check(gpu_lib().iile_li_samples(self._s, n, px.ctypes.data, py.ctypes.data, k.ctypes.data, L.ctypes.data,
+                                              nr.ctypes.data), "iile_li_samples")
+        return L, nr
+
+    def bsdf_eval(self, mat, wo, wi):
+        wo, wi = _f32(wo), _f32(wi)
+        out = np.empty((len(wo), 4), np.float32)
+        self._check(gpu_lib().iile_bsdf_eval(self._s, len(wo), mat, wo.ctypes.data, wi.ctypes.data, out.ctypes.data),
+                    "iile_bsdf_eval")
+        return out
+
+    def bsdf_sample(self, mat, wo, u):
+        wo, u = _f32(wo), _f32(u)
+        out = np.empty((len(wo), 7), np.float32)
+        self._check(gpu_lib().iile_bsdf_sample(self._s, len(wo), mat, wo.ctypes.data, u.ctypes.data, out.ctypes.data),
+                    "iile_bsdf_sample")
+        return out
+
+    def close(self):
+        if self._s:
+            gpu_lib().iile_scene_destroy(self._s)
+            self._s = c_vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def trig_probe(x):
+    x = _f32(x)
+    out = np.empty((len(x), 3), np.float32)
+    rc = gpu_lib().iile_trig_probe(len(x), x.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"iile_trig_probe failed ({rc}): {gpu_lib().iile_last_error().decode()}")
+    return out
+
+
+def device_count():
+    return int(gpu_lib().iile_device_count())

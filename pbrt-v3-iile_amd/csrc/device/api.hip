@@ -1,0 +1,757 @@
+// api.hip — C ABI of libiile_gpu.so (see include/iile_gpu.h): scene upload,
+// wavefront scheduling of the kernels in kernels.hip, film download.
+//
+// There is no CPU fallback anywhere in this file: every compute entry point
+// needs a HIP device and fails loudly without one.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/iile_gpu.h"
+#include "kernels.h"
+
+using namespace iile;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(IILE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;  // 0 generate, 1 extend, 2 shade, 3 connect, 4 film
+};
+
+}  // namespace
+
+struct iile_scene {
+    DScene ds;
+    std::vector<void *> allocs;
+    int n_cus = 256;
+    int max_depth = 5;
+    int spp = 1;
+    // wavefront workspace, grown on demand and kept across renders
+    uint32_t ws_paths = 0;
+    uint64_t ws_bytes = 0;
+    PassBuffers pb;
+    void *ws_block = nullptr;
+    uint32_t *nray_buf = nullptr;
+    uint32_t nray_cap = 0;
+    // film workspace
+    uint32_t film_tiles = 0;
+    uint32_t film_pixels = 0;
+    FilmBuffers fb;
+    void *film_block = nullptr;
+    int *spill = nullptr;  // HBM overflow of the LDS traversal stacks
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int upload(iile_scene *sc, const T *host, size_t n, const T **dev) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    sc->allocs.push_back(p);
+    if (n) HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T *>(p);
+    return IILE_OK;
+}
+
+int ensure_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(IILE_ERR_NO_DEVICE,
+                    "no HIP device available: libiile_gpu has no CPU fallback (hipGetDeviceCount: " +
+                        std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
+    return IILE_OK;
+}
+
+int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
+    if (n_paths <= sc->ws_paths) return IILE_OK;
+    if (sc->ws_block) {
+        HIP_TRY(hipFree(sc->ws_block));
+        sc->ws_block = nullptr;
+        sc->ws_paths = 0;
+    }
+    const size_t n = n_paths;
+    // L, beta, ray_o[2], ray_d[2], hits, nee[6]  -> 13 float4 planes; hindex; counts; counters
+    const size_t f4 = sizeof(float4);
+    size_t bytes = 13 * n * f4 + n * sizeof(uint32_t) + 64 * sizeof(uint32_t) + sizeof(DCounters) + 4096;
+    void *blk = nullptr;
+    HIP_TRY(hipMalloc(&blk, bytes));
+    sc->ws_block = blk;
+    sc->ws_bytes = bytes;
+    char *p = static_cast<char *>(blk);
+    auto take = [&](size_t b) {
+        char *r = p;
+        p += (b + 255) & ~size_t(255);
+        return r;
+    };
+    PassBuffers &B = sc->pb;
+    B.L = reinterpret_cast<float4 *>(take(n * f4));
+    B.beta = reinterpret_cast<float4 *>(take(n * f4));
+    B.ray_o[0] = reinterpret_cast<float4 *>(take(n * f4));
+    B.ray_o[1] = reinterpret_cast<float4 *>(take(n * f4));
+    B.ray_d[0] = reinterpret_cast<float4 *>(take(n * f4));
+    B.ray_d[1] = reinterpret_cast<float4 *>(take(n * f4));
+    B.hits = reinterpret_cast<float4 *>(take(n * f4));
+    B.nee = reinterpret_cast<float4 *>(take(6 * n * f4));
+    B.hindex = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
+    B.counts = reinterpret_cast<uint32_t *>(take(64 * sizeof(uint32_t)));
+    B.counters = reinterpret_cast<DCounters *>(take(sizeof(DCounters)));
+    B.nray_out = nullptr;
+    B.spill = sc->spill;
+    sc->ws_paths = n_paths;
+    return IILE_OK;
+}
+
+int ensure_film(iile_scene *sc, uint32_t n_tiles, uint32_t n_pixels) {
+    if (n_tiles <= sc->film_tiles && n_pixels <= sc->film_pixels) return IILE_OK;
+    if (sc->film_block) {
+        HIP_TRY(hipFree(sc->film_block));
+        sc->film_block = nullptr;
+    }
+    n_tiles = std::max(n_tiles, sc->film_tiles);
+    n_pixels = std::max(n_pixels, sc->film_pixels);
+    const size_t tile_bytes = size_t(n_tiles) * 256 * sizeof(float4);
+    const size_t bytes = 2 * tile_bytes + size_t(n_pixels) * sizeof(float4) + 1024;
+    void *blk = nullptr;
+    HIP_TRY(hipMalloc(&blk, bytes));
+    sc->film_block = blk;
+    char *p = static_cast<char *>(blk);
+    sc->fb.tile_rgbw = reinterpret_cast<float4 *>(p);
+    sc->fb.k0_rgbv = reinterpret_cast<float4 *>(p + tile_bytes);
+    sc->fb.film_xyzw = reinterpret_cast<float4 *>(p + 2 * tile_bytes);
+    sc->film_tiles = n_tiles;
+    sc->film_pixels = n_pixels;
+    return IILE_OK;
+}
+
+int get_events(iile_scene *sc, int kind, EventPair **out) {
+    if (sc->events_used == sc->events.size()) {
+        EventPair ep;
+        HIP_TRY(hipEventCreate(&ep.a));
+        HIP_TRY(hipEventCreate(&ep.b));
+        sc->events.push_back(ep);
+    }
+    *out = &sc->events[sc->events_used++];
+    (*out)->kind = kind;
+    return IILE_OK;
+}
+
+void copy_counters(const DCounters &c, iile_stats *st) {
+    st->camera_rays = c.camera_rays;
+    st->closest_rays = c.closest_rays;
+    st->shadow_rays = c.shadow_rays;
+    st->nodes_closest = c.nodes_closest;
+    st->nodes_any = c.nodes_any;
+    st->tri_tests = c.tri_tests;
+    st->tri_hits = c.tri_hits;
+    st->sphere_tests = c.sphere_tests;
+    st->nee_evals = c.nee_evals;
+    st->zero_radiance = c.zero_radiance;
+    for (int i = 0; i < 8; ++i) st->path_length[i] = c.path_length[i];
+}
+
+// Enqueue one wavefront pass on cfg.stream.
+int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed) {
+    const DScene &S = sc->ds;
+    PassBuffers &B = sc->pb;
+    HIP_TRY(hipMemsetAsync(B.counts, 0, 64 * sizeof(uint32_t), cfg.stream));
+    auto timed_launch = [&](int kind, auto &&fn) -> int {
+        EventPair *ep = nullptr;
+        if (timed) {
+            int rc = get_events(sc, kind, &ep);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ep->a, cfg.stream));
+        }
+        fn();
+        if (timed) HIP_TRY(hipEventRecord(ep->b, cfg.stream));
+        return IILE_OK;
+    };
+    int rc = timed_launch(0, [&] { launch_generate(S, P, B, cfg); });
+    if (rc) return rc;
+    // bounces 0 .. maxDepth: the path loop exits at `bounces >= maxDepth` after
+    // intersecting (path.cpp:104), so maxDepth + 1 extend launches are needed
+    for (int b = 0; b <= sc->max_depth; ++b) {
+        rc = timed_launch(1, [&] { launch_extend(S, B, b, P.n_paths, cfg); });
+        if (rc) return rc;
+        rc = timed_launch(2, [&] { launch_shade(S, B, b, P.n_paths, cfg); });
+        if (rc) return rc;
+        if (b < sc->max_depth) {
+            rc = timed_launch(3, [&] { launch_connect(S, B, b, P.n_paths, cfg); });
+            if (rc) return rc;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return IILE_OK;
+}
+
+int collect_times(iile_scene *sc, iile_stats *st) {
+    for (size_t i = 0; i < sc->events_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->events[i].a, sc->events[i].b));
+        switch (sc->events[i].kind) {
+        case 0: st->ms_generate += ms; break;
+        case 1: st->ms_extend += ms; st->n_extend_launches++; break;
+        case 2: st->ms_shade += ms; st->n_shade_launches++; break;
+        case 3: st->ms_connect += ms; st->n_connect_launches++; break;
+        default: st->ms_film += ms; break;
+        }
+    }
+    return IILE_OK;
+}
+
+}  // namespace
+
+namespace {
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t n) {
+        HIP_TRY(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+        return IILE_OK;
+    }
+    int put(const T *h, size_t n) {
+        int rc = alloc(n);
+        if (rc) return rc;
+        if (n) HIP_TRY(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice));
+        return IILE_OK;
+    }
+    int get(T *h, size_t n) {
+        if (n) HIP_TRY(hipMemcpy(h, p, n * sizeof(T), hipMemcpyDeviceToHost));
+        return IILE_OK;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+const char *iile_last_error(void) { return g_err.c_str(); }
+
+int iile_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
+    if (!d || !out) return fail(IILE_ERR_ARG, "iile_scene_create: null argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    // ---- what the device path supports -------------------------------------
+    if (d->n_lights > 1)
+        return fail(IILE_ERR_UNSUPPORTED, "more than one light needs the spatial light distribution (not built)");
+    if (d->n_spheres > kMaxSpheres || d->n_materials > kMaxMaterials || d->n_lights > kMaxLights)
+        return fail(IILE_ERR_UNSUPPORTED, "too many spheres / materials / lights");
+    for (int i = 0; i < d->n_spheres; ++i) {
+        const iile_sphere &s = d->spheres[i];
+        if (!(s.zmin == -s.radius && s.zmax == s.radius && s.phi_max >= 6.2831850f))
+            return fail(IILE_ERR_UNSUPPORTED, "partial spheres (zmin/zmax/phimax) are not supported on device");
+    }
+    for (int i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC)
+            return fail(IILE_ERR_UNSUPPORTED, "unsupported material type");
+    if (d->halton.n_dims > kMaxHaltonDims) return fail(IILE_ERR_UNSUPPORTED, "too many Halton dimensions");
+    const int need_dims = 5 + 7 * d->integrator.max_depth + 1;
+    if (d->halton.n_dims < need_dims) return fail(IILE_ERR_ARG, "Halton table covers too few dimensions for maxdepth");
+    if (d->integrator.max_depth > 14) return fail(IILE_ERR_UNSUPPORTED, "maxdepth > 14");
+    if ((double(d->halton.spp) + 1) * double(d->halton.sample_stride) >= 4294967296.0)
+        return fail(IILE_ERR_UNSUPPORTED, "Halton index exceeds 32 bits (pixelsamples too large)");
+    if (d->film.filter_rx != 0.5f || d->film.filter_ry != 0.5f)
+        return fail(IILE_ERR_UNSUPPORTED, "only the box filter of radius 0.5 is supported");
+
+    iile_scene *sc = new iile_scene;
+    std::memset(&sc->ds, 0, sizeof(sc->ds));
+    std::memset(&sc->pb, 0, sizeof(sc->pb));
+    std::memset(&sc->fb, 0, sizeof(sc->fb));
+    DScene &S = sc->ds;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        sc->n_cus = prop.multiProcessorCount;
+
+    auto bail = [&](int code) {
+        iile_scene_destroy(sc);
+        return code;
+    };
+    // nodes: the 32-byte LinearBVHNode image is already two float4s
+    static_assert(sizeof(iile_bvh_node) == 32, "node layout");
+    rc = upload(sc, reinterpret_cast<const float4 *>(d->nodes), size_t(d->n_nodes) * 2, &S.nodes);
+    if (rc) return bail(rc);
+    // primitives: gather into 48-byte vertex records + normal / uv records
+    {
+        const size_t n = size_t(d->n_prims);
+        std::vector<float4> verts(3 * n), norms(3 * n);
+        std::vector<float2> uvs(3 * n);
+        for (size_t i = 0; i < n; ++i) {
+            const float *p = d->tri_p + 9 * i, *nn = d->tri_n + 9 * i, *uv = d->tri_uv + 6 * i;
+            uint32_t w[3] = {d->prim_flags[i], uint32_t(d->prim_material[i]), uint32_t(d->prim_light[i])};
+            for (int k = 0; k < 3; ++k) {
+                float wf;
+                std::memcpy(&wf, &w[k], 4);
+                verts[3 * i + k] = make_float4(p[3 * k], p[3 * k + 1], p[3 * k + 2], wf);
+                norms[3 * i + k] = make_float4(nn[3 * k], nn[3 * k + 1], nn[3 * k + 2], 0.f);
+                uvs[3 * i + k] = make_float2(uv[2 * k], uv[2 * k + 1]);
+            }
+            if ((d->prim_flags[i] & IILE_PRIM_SPHERE) && (d->prim_light[i] >= 0) &&
+                d->lights[d->prim_light[i]].sphere != d->prim_shape[i])
+                return bail(fail(IILE_ERR_ARG, "light / sphere cross reference is inconsistent"));
+        }
+        rc = upload(sc, verts.data(), verts.size(), &S.tri_verts);
+        if (rc) return bail(rc);
+        rc = upload(sc, norms.data(), norms.size(), &S.tri_norms);
+        if (rc) return bail(rc);
+        rc = upload(sc, uvs.data(), uvs.size(), &S.tri_uv);
+        if (rc) return bail(rc);
+        rc = upload(sc, d->prim_shape, n, &S.prim_shape);
+        if (rc) return bail(rc);
+    }
+    {
+        std::vector<DSphere> sp(d->n_spheres);
+        for (int i = 0; i < d->n_spheres; ++i) {
+            const iile_sphere &s = d->spheres[i];
+            std::memcpy(sp[i].o2w.m, s.o2w, 64);
+            std::memcpy(sp[i].o2w_inv.m, s.o2w_inv, 64);
+            sp[i].radius = s.radius;
+            sp[i].zmin = s.zmin;
+            sp[i].zmax = s.zmax;
+            sp[i].theta_min = s.theta_min;
+            sp[i].theta_max = s.theta_max;
+            sp[i].phi_max = s.phi_max;
+            sp[i].reverse_orientation = s.reverse_orientation;
+            sp[i].swaps_handedness = s.swaps_handedness;
+        }
+        rc = upload(sc, sp.data(), sp.size(), &S.spheres);
+        if (rc) return bail(rc);
+        std::vector<DMaterial> mats(d->n_materials);
+        for (int i = 0; i < d->n_materials; ++i) {
+            const iile_material &m = d->materials[i];
+            mats[i].type = m.type;
+            for (int c = 0; c < 3; ++c) {
+                mats[i].kd[c] = m.kd[c];
+                mats[i].ks[c] = m.ks[c];
+            }
+            mats[i].alpha = m.alpha;
+        }
+        rc = upload(sc, mats.data(), mats.size(), &S.materials);
+        if (rc) return bail(rc);
+        std::vector<DLight> lts(d->n_lights);
+        for (int i = 0; i < d->n_lights; ++i) {
+            for (int c = 0; c < 3; ++c) lts[i].lemit[c] = d->lights[i].lemit[c];
+            lts[i].two_sided = d->lights[i].two_sided;
+            lts[i].sphere = d->lights[i].sphere;
+        }
+        rc = upload(sc, lts.data(), lts.size(), &S.lights);
+        if (rc) return bail(rc);
+    }
+    // Halton: permutations + per-dimension division magic
+    {
+        const iile_halton &h = d->halton;
+        rc = upload(sc, h.perms, size_t(h.n_perms), &S.perms);
+        if (rc) return bail(rc);
+        std::vector<DHaltonDim> dims(h.n_dims);
+        for (int i = 0; i < h.n_dims; ++i) {
+            const uint32_t base = uint32_t(h.primes[i]);
+            uint32_t l = 0;
+            while ((1ull << l) < base) ++l;  // ceil(log2 base)
+            const unsigned long long m = ((1ull << 32) * ((1ull << l) - base)) / base + 1;
+            dims[i].base = base;
+            dims[i].magic = uint32_t(m);
+            dims[i].shift = l - 1;
+            dims[i].perm_offset = uint32_t(h.prime_sums[i]);
+            const float inv_base = 1.f / float(int(base));
+            dims[i].inv_base = inv_base;
+            dims[i].perm0_term = inv_base * h.perms[h.prime_sums[i]] / (1 - inv_base);
+            dims[i].pad0 = dims[i].pad1 = 0;
+        }
+        rc = upload(sc, dims.data(), dims.size(), &S.hdims);
+        if (rc) return bail(rc);
+        S.n_hdims = h.n_dims;
+        S.base_scale0 = h.base_scales[0];
+        S.base_scale1 = h.base_scales[1];
+        S.base_exp0 = h.base_exponents[0];
+        S.base_exp1 = h.base_exponents[1];
+        S.sample_stride = h.sample_stride;
+        S.mult_inv0 = h.mult_inverse[0];
+        S.mult_inv1 = h.mult_inverse[1];
+        sc->spp = h.spp;
+    }
+    S.n_nodes = d->n_nodes;
+    S.n_prims = d->n_prims;
+    S.n_spheres = d->n_spheres;
+    S.n_materials = d->n_materials;
+    S.n_lights = d->n_lights;
+    std::memcpy(S.raster_to_camera.m, d->camera.raster_to_camera, 64);
+    std::memcpy(S.camera_to_world.m, d->camera.camera_to_world, 64);
+    S.lens_radius = d->camera.lens_radius;
+    S.focal_distance = d->camera.focal_distance;
+    const iile_film_desc &f = d->film;
+    S.xres = f.xres;
+    S.yres = f.yres;
+    S.crop_x0 = f.crop_x0;
+    S.crop_y0 = f.crop_y0;
+    S.crop_x1 = f.crop_x1;
+    S.crop_y1 = f.crop_y1;
+    S.samp_x0 = f.samp_x0;
+    S.samp_y0 = f.samp_y0;
+    S.samp_x1 = f.samp_x1;
+    S.samp_y1 = f.samp_y1;
+    S.filter_rx = f.filter_rx;
+    S.filter_ry = f.filter_ry;
+    S.max_sample_luminance = f.max_sample_luminance;
+    S.max_depth = d->integrator.max_depth;
+    S.rr_threshold = d->integrator.rr_threshold;
+    sc->max_depth = d->integrator.max_depth;
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, size_t(max_traversal_threads(sc->n_cus)) * sizeof(int)) != hipSuccess)
+            return bail(fail(IILE_ERR_HIP, "hipMalloc(spill) failed"));
+        sc->allocs.push_back(p);
+        sc->spill = static_cast<int *>(p);
+    }
+    if (hipEventCreate(&sc->ev_begin) != hipSuccess || hipEventCreate(&sc->ev_end) != hipSuccess)
+        return bail(fail(IILE_ERR_HIP, "hipEventCreate failed"));
+    *out = sc;
+    return IILE_OK;
+}
+
+void iile_scene_destroy(iile_scene *sc) {
+    if (!sc) return;
+    for (void *p : sc->allocs) (void)hipFree(p);
+    if (sc->ws_block) (void)hipFree(sc->ws_block);
+    if (sc->film_block) (void)hipFree(sc->film_block);
+    if (sc->nray_buf) (void)hipFree(sc->nray_buf);
+    for (EventPair &e : sc->events) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (sc->ev_begin) (void)hipEventDestroy(sc->ev_begin);
+    if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
+    delete sc;
+}
+
+int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw, iile_stats *stats) {
+    if (!sc || !prm || !film_xyzw) return fail(IILE_ERR_ARG, "iile_render: null argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    const DScene &S = sc->ds;
+    int k_begin = prm->k_begin, k_end = prm->k_end;
+    if (k_end <= 0) {
+        k_begin = 0;
+        k_end = sc->spp;
+    }
+    if (k_begin < 0 || k_begin >= k_end) return fail(IILE_ERR_ARG, "iile_render: empty sample range");
+    int rank = prm->tile_rank, nranks = prm->tile_nranks;
+    if (nranks <= 0) {
+        rank = 0;
+        nranks = 1;
+    }
+    if (rank < 0 || rank >= nranks) return fail(IILE_ERR_ARG, "iile_render: tile_rank out of range");
+    hipStream_t stream = static_cast<hipStream_t>(prm->stream);
+    LaunchCfg cfg{sc->n_cus, stream, prm->collect_stats != 0};
+    const bool timed = prm->time_kernels != 0;
+
+    PassDesc P;
+    std::memset(&P, 0, sizeof(P));
+    P.n_tiles_x = (S.samp_x1 - S.samp_x0 + 15) / 16;
+    P.n_tiles_y = (S.samp_y1 - S.samp_y0 + 15) / 16;
+    const int n_tiles = P.n_tiles_x * P.n_tiles_y;
+    P.tile_rank = rank;
+    P.tile_nranks = nranks;
+    P.n_owned_tiles = (n_tiles - rank + nranks - 1) / nranks;
+    if (P.n_owned_tiles < 0) P.n_owned_tiles = 0;
+    const uint64_t pix_slots = uint64_t(P.n_owned_tiles) * 256;
+    const int n_samples = k_end - k_begin;
+    // samples per pass: bounded by the workspace budget (212 B per path)
+    int kc = prm->spp_per_pass;
+    if (kc <= 0) {
+        double budget_mb = 12288;
+        if (const char *e = std::getenv("IILE_WORKSPACE_MB")) budget_mb = std::max(64.0, atof(e));
+        uint64_t max_paths = uint64_t(budget_mb * 1048576.0 / 212.0);
+        max_paths = std::min<uint64_t>(max_paths, 0xfff00000ull);
+        int kc_max = int(std::max<uint64_t>(1, max_paths / std::max<uint64_t>(1, pix_slots)));
+        int n_passes = (n_samples + kc_max - 1) / kc_max;
+        kc = (n_samples + n_passes - 1) / n_passes;
+    }
+    kc = std::min(kc, n_samples);
+    if (pix_slots * uint64_t(kc) >= 0xfff00000ull) return fail(IILE_ERR_ARG, "pass too large: lower spp_per_pass");
+    const uint32_t fw = uint32_t(S.crop_x1 - S.crop_x0), fh = uint32_t(S.crop_y1 - S.crop_y0);
+
+    if (pix_slots) {
+        rc = ensure_workspace(sc, uint32_t(pix_slots * kc));
+        if (rc) return rc;
+    }
+    rc = ensure_film(sc, uint32_t(P.n_owned_tiles), fw * fh);
+    if (rc) return rc;
+    sc->pb.nray_out = nullptr;
+    sc->events_used = 0;
+    iile_stats st;
+    std::memset(&st, 0, sizeof(st));
+
+    HIP_TRY(hipEventRecord(sc->ev_begin, stream));
+    if (prm->collect_stats && pix_slots) HIP_TRY(hipMemsetAsync(sc->pb.counters, 0, sizeof(DCounters), stream));
+    if (pix_slots) HIP_TRY(hipMemsetAsync(sc->fb.tile_rgbw, 0, size_t(pix_slots) * sizeof(float4) * 2, stream));
+    for (int k0 = k_begin; k0 < k_end && pix_slots; k0 += kc) {
+        P.k0 = k0;
+        P.kc = std::min(kc, k_end - k0);
+        P.n_paths = uint32_t(pix_slots * P.kc);
+        rc = run_pass(sc, P, cfg, timed);
+        if (rc) return rc;
+        EventPair *ep = nullptr;
+        if (timed) {
+            rc = get_events(sc, 4, &ep);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ep->a, stream));
+        }
+        launch_film_accumulate(S, P, sc->pb, sc->fb, cfg);
+        if (timed) HIP_TRY(hipEventRecord(ep->b, stream));
+        st.n_passes++;
+        st.n_paths += P.n_paths;
+    }
+    FilmBuffers F = sc->fb;
+    if (prm->film_on_device) F.film_xyzw = reinterpret_cast<float4 *>(film_xyzw);
+    launch_film_resolve(S, P, F, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sc->ev_end, stream));
+    if (!prm->film_on_device) {
+        HIP_TRY(hipMemcpyAsync(film_xyzw, F.film_xyzw, size_t(fw) * fh * sizeof(float4), hipMemcpyDeviceToHost, stream));
+    }
+    // The film is complete once the stream drains. Statistics need the drain;
+    // a device-resident film without stats stays asynchronous.
+    if (stats || !prm->film_on_device) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
+        st.ms_total = ms;
+        if (timed) {
+            rc = collect_times(sc, &st);
+            if (rc) return rc;
+        }
+        if (prm->collect_stats && pix_slots) {
+            DCounters c;
+            HIP_TRY(hipMemcpy(&c, sc->pb.counters, sizeof(c), hipMemcpyDeviceToHost));
+            copy_counters(c, &st);
+        }
+        st.workspace_bytes = sc->ws_bytes;
+        if (stats) *stats = st;
+    }
+    return IILE_OK;
+}
+
+// ---- kernel-level entry points ---------------------------------------------
+
+static int trace_common(iile_scene *sc, int32_t n, const float *o3, const float *d3, const float *tmax, int any,
+                        std::vector<float4> *hits, iile_stats *stats) {
+    if (!sc || n < 0 || !o3 || !d3 || !tmax) return fail(IILE_ERR_ARG, "iile_trace: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::vector<float4> ro(n), rd(n);
+    for (int i = 0; i < n; ++i) {
+        ro[i] = make_float4(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2], 0);
+        rd[i] = make_float4(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2], tmax[i]);
+    }
+    float4 *dro = nullptr, *drd = nullptr, *dh = nullptr;
+    DCounters *dc = nullptr;
+    const size_t nb = std::max<size_t>(size_t(n), 1) * sizeof(float4);
+    HIP_TRY(hipMalloc(&dro, nb));
+    HIP_TRY(hipMalloc(&drd, nb));
+    HIP_TRY(hipMalloc(&dh, 2 * nb));
+    HIP_TRY(hipMalloc(&dc, sizeof(DCounters)));
+    HIP_TRY(hipMemset(dc, 0, sizeof(DCounters)));
+    HIP_TRY(hipMemcpy(dro, ro.data(), size_t(n) * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(drd, rd.data(), size_t(n) * sizeof(float4), hipMemcpyHostToDevice));
+    LaunchCfg cfg{sc->n_cus, nullptr, true};
+    if (n) launch_trace(sc->ds, n, dro, drd, dh, any, dc, sc->spill, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    hits->resize(2 * size_t(n));
+    HIP_TRY(hipMemcpy(hits->data(), dh, 2 * size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));
+    if (stats) {
+        DCounters c;
+        HIP_TRY(hipMemcpy(&c, dc, sizeof(c), hipMemcpyDeviceToHost));
+        std::memset(stats, 0, sizeof(*stats));
+        copy_counters(c, stats);
+    }
+    (void)hipFree(dro);
+    (void)hipFree(drd);
+    (void)hipFree(dh);
+    (void)hipFree(dc);
+    return IILE_OK;
+}
+
+int iile_trace_closest(iile_scene *sc, int32_t n, const float *o3, const float *d3, const float *tmax, int32_t *prim,
+                       float *tb, iile_stats *stats) {
+    if (!prim || !tb) return fail(IILE_ERR_ARG, "iile_trace_closest: null output");
+    std::vector<float4> hits;
+    int rc = trace_common(sc, n, o3, d3, tmax, 0, &hits, stats);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        uint32_t u;
+        std::memcpy(&u, &hits[2 * i].x, 4);
+        prim[i] = int32_t(u);
+        tb[4 * i] = hits[2 * i].y;
+        tb[4 * i + 1] = hits[2 * i + 1].x;
+        tb[4 * i + 2] = hits[2 * i + 1].y;
+        tb[4 * i + 3] = hits[2 * i + 1].z;
+    }
+    return IILE_OK;
+}
+
+int iile_trace_any(iile_scene *sc, int32_t n, const float *o3, const float *d3, const float *tmax, int32_t *hit,
+                   iile_stats *stats) {
+    if (!hit) return fail(IILE_ERR_ARG, "iile_trace_any: null output");
+    std::vector<float4> hits;
+    int rc = trace_common(sc, n, o3, d3, tmax, 1, &hits, stats);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        uint32_t u;
+        std::memcpy(&u, &hits[2 * i].x, 4);
+        hit[i] = int32_t(u);
+    }
+    return IILE_OK;
+}
+
+
+int iile_halton_samples(iile_scene *sc, int32_t n, const int32_t *px, const int32_t *py, const int32_t *k,
+                        int32_t dim0, int32_t ndims, float *out, uint32_t *index_out) {
+    if (!sc || n < 0 || !px || !py || !k || !out || ndims <= 0 || dim0 < 0 || dim0 + ndims > sc->ds.n_hdims)
+        return fail(IILE_ERR_ARG, "iile_halton_samples: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    DevBuf<int> dx, dy, dk;
+    DevBuf<float> dout;
+    DevBuf<uint32_t> dindex;
+    if ((rc = dx.put(px, n)) || (rc = dy.put(py, n)) || (rc = dk.put(k, n)) || (rc = dout.alloc(size_t(n) * ndims)) ||
+        (rc = dindex.alloc(n)))
+        return rc;
+    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    if (n) launch_halton(sc->ds, n, dx.p, dy.p, dk.p, dim0, ndims, dout.p, dindex.p, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = dout.get(out, size_t(n) * ndims))) return rc;
+    if (index_out && (rc = dindex.get(index_out, n))) return rc;
+    return IILE_OK;
+}
+
+int iile_camera_rays(iile_scene *sc, int32_t n, const float *pfilm2, const float *plens2, float *o3, float *d3) {
+    if (!sc || n < 0 || !pfilm2 || !o3 || !d3) return fail(IILE_ERR_ARG, "iile_camera_rays: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    DevBuf<float> df, dl, dox, ddx;
+    if ((rc = df.put(pfilm2, 2 * size_t(n))) || (rc = dox.alloc(3 * size_t(n))) || (rc = ddx.alloc(3 * size_t(n))))
+        return rc;
+    if (plens2 && (rc = dl.put(plens2, 2 * size_t(n)))) return rc;
+    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    if (n) launch_camera(sc->ds, n, df.p, plens2 ? dl.p : nullptr, dox.p, ddx.p, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = dox.get(o3, 3 * size_t(n))) || (rc = ddx.get(d3, 3 * size_t(n)))) return rc;
+    return IILE_OK;
+}
+
+int iile_li_samples(iile_scene *sc, int32_t n, const int32_t *px, const int32_t *py, const int32_t *k, float *L3,
+                    int32_t *nrays2) {
+    if (!sc || n <= 0 || !px || !py || !k || !L3) return fail(IILE_ERR_ARG, "iile_li_samples: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    DevBuf<int> dx, dy, dk;
+    DevBuf<uint32_t> dn;
+    if ((rc = dx.put(px, n)) || (rc = dy.put(py, n)) || (rc = dk.put(k, n)) || (rc = dn.alloc(2 * size_t(n)))) return rc;
+    rc = ensure_workspace(sc, uint32_t(n));
+    if (rc) return rc;
+    PassDesc P;
+    std::memset(&P, 0, sizeof(P));
+    P.n_tiles_x = P.n_tiles_y = 1;
+    P.tile_nranks = 1;
+    P.kc = 1;
+    P.n_paths = uint32_t(n);
+    P.list_px = dx.p;
+    P.list_py = dy.p;
+    P.list_k = dk.p;
+    LaunchCfg cfg{sc->n_cus, nullptr, true};
+    HIP_TRY(hipMemset(sc->pb.counters, 0, sizeof(DCounters)));
+    sc->pb.nray_out = dn.p;
+    sc->events_used = 0;
+    rc = run_pass(sc, P, cfg, false);
+    sc->pb.nray_out = nullptr;
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float4> L(n);
+    HIP_TRY(hipMemcpy(L.data(), sc->pb.L, size_t(n) * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        // guards of SamplerIntegrator::Render (integrator.cpp:293-314)
+        float r = L[i].x, g = L[i].y, b = L[i].z;
+        float y = 0.212671f * r + 0.715160f * g + 0.072169f * b;
+        if (std::isnan(r) || std::isnan(g) || std::isnan(b) || y < -1e-5 || std::isinf(y)) r = g = b = 0.f;
+        L3[3 * i] = r;
+        L3[3 * i + 1] = g;
+        L3[3 * i + 2] = b;
+    }
+    if (nrays2) {
+        std::vector<uint32_t> nr(2 * size_t(n));
+        if ((rc = dn.get(nr.data(), nr.size()))) return rc;
+        for (size_t i = 0; i < nr.size(); ++i) nrays2[i] = int32_t(nr[i]);
+    }
+    return IILE_OK;
+}
+
+static int bsdf_probe(iile_scene *sc, int32_t n, int32_t mat, const float *wo3, const float *in, size_t in_stride,
+                      int sample, float *out, size_t out_stride) {
+    if (!sc || n < 0 || !wo3 || !in || !out || mat < 0 || mat >= sc->ds.n_materials)
+        return fail(IILE_ERR_ARG, "iile_bsdf: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    DevBuf<float> dwo, din, dout;
+    if ((rc = dwo.put(wo3, 3 * size_t(n))) || (rc = din.put(in, in_stride * size_t(n))) ||
+        (rc = dout.alloc(out_stride * size_t(n))))
+        return rc;
+    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    if (n) launch_bsdf_probe(sc->ds, n, mat, dwo.p, din.p, sample, dout.p, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return dout.get(out, out_stride * size_t(n));
+}
+int iile_bsdf_eval(iile_scene *sc, int32_t n, int32_t mat, const float *wo3, const float *wi3, float *out4) {
+    return bsdf_probe(sc, n, mat, wo3, wi3, 3, 0, out4, 4);
+}
+int iile_bsdf_sample(iile_scene *sc, int32_t n, int32_t mat, const float *wo3, const float *u2, float *out7) {
+    return bsdf_probe(sc, n, mat, wo3, u2, 2, 1, out7, 7);
+}
+
+int iile_trig_probe(int32_t n, const float *x, float *out3) {
+    if (n < 0 || !x || !out3) return fail(IILE_ERR_ARG, "iile_trig_probe: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    DevBuf<float> dx, dout;
+    if ((rc = dx.put(x, n)) || (rc = dout.alloc(3 * size_t(n)))) return rc;
+    LaunchCfg cfg{256, nullptr, false};
+    if (n) launch_trig_probe(n, dx.p, dout.p, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return dout.get(out3, 3 * size_t(n));
+}
+
+}  // extern "C"

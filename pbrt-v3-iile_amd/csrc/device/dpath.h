@@ -1,0 +1,813 @@
+// dpath.h — device functions of the wavefront path tracer: Halton sampling,
+// camera rays, ray/primitive tests, BVH traversal with an LDS-resident stack,
+// surface interactions, BSDFs and light sampling.
+//
+// Citations are relative to /root/reference/src. The traversal keeps the
+// reference's node layout and near-first order (bvh.cpp:686-692), so equal-t
+// ties resolve to the same primitive as on the CPU.
+#pragma once
+#include "dscene.h"
+
+namespace iile {
+
+// ===========================================================================
+// Halton sampler (samplers/halton.cpp:96-127, core/lowdiscrepancy.cpp:389-427)
+// ===========================================================================
+// exact a / base for any 32-bit a (Granlund-Montgomery round-up form)
+DEV uint32_t div_magic(uint32_t a, uint32_t magic, uint32_t shift) {
+    uint32_t t = __umulhi(magic, a);
+    return (t + ((a - t) >> 1)) >> shift;
+}
+
+// Global Halton index of sample k of pixel (px, py): offset(pixel mod 128) +
+// k * stride. 32-bit arithmetic is exact here: the render entry point rejects
+// (spp + 1) * stride >= 2^32.
+DEV uint32_t halton_index(const DScene &S, int px, int py, uint32_t k) {
+    uint32_t offset = 0;
+    if (S.sample_stride > 1) {
+        int pmx = px - (px / 128) * 128, pmy = py - (py / 128) * 128;  // Mod(), pbrt.h:310-314
+        if (pmx < 0) pmx += 128;
+        if (pmy < 0) pmy += 128;
+        // InverseRadicalInverse<2>, <3> (lowdiscrepancy.h:82-91)
+        uint32_t inv = uint32_t(pmx), idx0 = 0;
+        for (int i = 0; i < S.base_exp0; ++i) {
+            idx0 = idx0 * 2 + (inv & 1);
+            inv >>= 1;
+        }
+        inv = uint32_t(pmy);
+        uint32_t idx1 = 0;
+        for (int i = 0; i < S.base_exp1; ++i) {
+            uint32_t q = inv / 3;
+            idx1 = idx1 * 3 + (inv - q * 3);
+            inv = q;
+        }
+        unsigned long long off = (unsigned long long)idx0 * (unsigned long long)(S.sample_stride / S.base_scale0) *
+                                     (unsigned long long)S.mult_inv0 +
+                                 (unsigned long long)idx1 * (unsigned long long)(S.sample_stride / S.base_scale1) *
+                                     (unsigned long long)S.mult_inv1;
+        offset = uint32_t(off % (unsigned long long)S.sample_stride);
+    }
+    return offset + k * uint32_t(S.sample_stride);
+}
+
+DEV float radical_inverse_base2(uint32_t a) {
+    // ReverseBits64(a) * 0x1p-64 with a < 2^32: the reversed bits land in the
+    // upper word (lowdiscrepancy.cpp:430-434); double product, one rounding to float.
+    unsigned long long rev = (unsigned long long)__brev(a) << 32;
+    return float(double(rev) * 0x1p-64);
+}
+DEV float radical_inverse_base3(uint32_t a) {
+    const float inv_base = 1.f / 3.f;
+    unsigned long long reversed = 0;
+    float inv_base_n = 1;
+    while (a) {
+        uint32_t next = a / 3u;
+        uint32_t digit = a - next * 3u;
+        reversed = reversed * 3u + digit;
+        inv_base_n *= inv_base;
+        a = next;
+    }
+    return mn(float(reversed) * inv_base_n, kOneMinusEpsilon);
+}
+DEV float scrambled_radical_inverse(const DScene &S, int dim, uint32_t a) {
+    const DHaltonDim hd = S.hdims[dim];
+    const uint16_t *perm = S.perms + hd.perm_offset;
+    unsigned long long reversed = 0;
+    float inv_base_n = 1;
+    while (a) {
+        uint32_t next = div_magic(a, hd.magic, hd.shift);
+        uint32_t digit = a - next * hd.base;
+        reversed = reversed * hd.base + perm[digit];
+        inv_base_n *= hd.inv_base;
+        a = next;
+    }
+    return mn(inv_base_n * (float(reversed) + hd.perm0_term), kOneMinusEpsilon);
+}
+DEV float sample_dimension(const DScene &S, uint32_t index, int dim) {
+    if (dim == 0) return radical_inverse_base2(index >> S.base_exp0);
+    if (dim == 1) return radical_inverse_base3(index / uint32_t(S.base_scale1));
+    return scrambled_radical_inverse(S, dim, index);
+}
+
+// ===========================================================================
+// sampling warps (core/sampling.cpp:113-130, core/sampling.h:159-163)
+// ===========================================================================
+DEV void concentric_sample_disk(float u0, float u1, float *dx, float *dy) {
+    float ox = 2.f * u0 - 1, oy = 2.f * u1 - 1;
+    if (ox == 0 && oy == 0) {
+        *dx = 0;
+        *dy = 0;
+        return;
+    }
+    float theta, r;
+    if (fabsf(ox) > fabsf(oy)) {
+        r = ox;
+        theta = kPiOver4 * (oy / ox);
+    } else {
+        r = oy;
+        theta = kPiOver2 - kPiOver4 * (ox / oy);
+    }
+    float s, c;
+    sincos_f(theta, &s, &c);
+    *dx = r * c;
+    *dy = r * s;
+}
+DEV F3 cosine_sample_hemisphere(float u0, float u1) {
+    float dx, dy;
+    concentric_sample_disk(u0, u1, &dx, &dy);
+    float z = sqrtf(mx(0.f, 1 - dx * dx - dy * dy));
+    return F3{dx, dy, z};
+}
+
+// ===========================================================================
+// camera (cameras/perspective.cpp:100-149, core/transform.h:251-264)
+// ===========================================================================
+DEV void camera_ray(const DScene &S, float pfx, float pfy, float lu0, float lu1, F3 *o_out, F3 *d_out, float *tmax) {
+    F3 pcam = xf_point(S.raster_to_camera, F3{pfx, pfy, 0});
+    F3 ro = F3{0, 0, 0};
+    F3 rd = normalize(pcam);
+    if (S.lens_radius > 0) {
+        float lx, ly;
+        concentric_sample_disk(lu0, lu1, &lx, &ly);
+        lx = S.lens_radius * lx;
+        ly = S.lens_radius * ly;
+        float ft = S.focal_distance / rd.z;
+        F3 pfocus = ro + rd * ft;
+        ro = F3{lx, ly, 0};
+        rd = normalize(pfocus - ro);
+    }
+    F3 oerr;
+    F3 o = xf_point_err(S.camera_to_world, ro, &oerr);
+    F3 d = xf_vector(S.camera_to_world, rd);
+    float len2 = length_sq(d);
+    float tm = IILE_INF;
+    if (len2 > 0) {
+        float dt = dot(vabs(d), oerr) / len2;
+        o = o + d * dt;
+        tm -= dt;
+    }
+    *o_out = o;
+    *d_out = d;
+    *tmax = tm;
+}
+
+// ===========================================================================
+// ray / primitive tests
+// ===========================================================================
+struct RayCtx {  // per-ray constants of the watertight test (triangle.cpp:206-226)
+    F3 o, d;
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+    F3 inv_dir;
+    int neg_mask;
+};
+DEV float comp(F3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+DEV RayCtx make_ray_ctx(F3 o, F3 d) {
+    RayCtx c;
+    c.o = o;
+    c.d = d;
+    F3 ad = vabs(d);
+    c.kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxDimension
+    c.kx = c.kz + 1;
+    if (c.kx == 3) c.kx = 0;
+    c.ky = c.kx + 1;
+    if (c.ky == 3) c.ky = 0;
+    float dx = comp(d, c.kx), dy = comp(d, c.ky), dz = comp(d, c.kz);
+    c.Sx = -dx / dz;
+    c.Sy = -dy / dz;
+    c.Sz = 1.f / dz;
+    c.inv_dir = F3{1 / d.x, 1 / d.y, 1 / d.z};  // bvh.cpp:666
+    c.neg_mask = (c.inv_dir.x < 0 ? 1 : 0) | (c.inv_dir.y < 0 ? 2 : 0) | (c.inv_dir.z < 0 ? 4 : 0);
+    return c;
+}
+
+// Triangle::Intersect up to the conservative t test (triangle.cpp:196-275);
+// the SurfaceInteraction part is deferred to the shade kernel.
+DEV bool triangle_test(const RayCtx &rc, float tmax, F3 p0, F3 p1, F3 p2, float *t_out, float *b0o, float *b1o,
+                       float *b2o) {
+    F3 a = p0 - rc.o, b = p1 - rc.o, c = p2 - rc.o;
+    float ax = comp(a, rc.kx), ay = comp(a, rc.ky), az = comp(a, rc.kz);
+    float bx = comp(b, rc.kx), by = comp(b, rc.ky), bz = comp(b, rc.kz);
+    float cx = comp(c, rc.kx), cy = comp(c, rc.ky), cz = comp(c, rc.kz);
+    ax += rc.Sx * az;
+    ay += rc.Sy * az;
+    bx += rc.Sx * bz;
+    by += rc.Sy * bz;
+    cx += rc.Sx * cz;
+    cy += rc.Sy * cz;
+    float e0 = bx * cy - by * cx;
+    float e1 = cx * ay - cy * ax;
+    float e2 = ax * by - ay * bx;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // double-precision fallback on edges
+        double p2txp1ty = (double)cx * (double)by;
+        double p2typ1tx = (double)cy * (double)bx;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)ax * (double)cy;
+        double p0typ2tx = (double)ay * (double)cx;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)bx * (double)ay;
+        double p1typ0tx = (double)by * (double)ax;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    az *= rc.Sz;
+    bz *= rc.Sz;
+    cz *= rc.Sz;
+    float t_scaled = e0 * az + e1 * bz + e2 * cz;
+    if (det < 0 && (t_scaled >= 0 || t_scaled < tmax * det))
+        return false;
+    else if (det > 0 && (t_scaled <= 0 || t_scaled > tmax * det))
+        return false;
+    float inv_det = 1 / det;
+    float b0 = e0 * inv_det, b1 = e1 * inv_det, b2 = e2 * inv_det;
+    float t = t_scaled * inv_det;
+    float max_zt = max3(fabsf(az), fabsf(bz), fabsf(cz));
+    float delta_z = kGamma3 * max_zt;
+    float max_xt = max3(fabsf(ax), fabsf(bx), fabsf(cx));
+    float max_yt = max3(fabsf(ay), fabsf(by), fabsf(cy));
+    float delta_x = kGamma5 * (max_xt + max_zt);
+    float delta_y = kGamma5 * (max_yt + max_zt);
+    float delta_e = 2 * (kGamma2 * max_xt * max_yt + delta_y * max_xt + delta_x * max_yt);
+    float max_e = max3(fabsf(e0), fabsf(e1), fabsf(e2));
+    float delta_t = 3 * (kGamma3 * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * fabsf(inv_det);
+    if (t <= delta_t) return false;
+    *t_out = t;
+    *b0o = b0;
+    *b1o = b1;
+    *b2o = b2;
+    return true;
+}
+
+// Sphere::Intersect / IntersectP up to the hit decision (sphere.cpp:49-103).
+// Full spheres only (zmin=-r, zmax=r, phimax=360 — enforced at scene upload),
+// so the phi / z clipping branch cannot reject and phi (atan2) is dead.
+// Outputs the object-space ray and refined hit point for sphere_interaction.
+DEV bool sphere_test(const DSphere &sp, F3 ro, F3 rd, float tmax, float *t_hit, F3 *obj_d, F3 *phit) {
+    F3 oerr, derr;
+    F3 o = xf_point_err(sp.o2w_inv, ro, &oerr);
+    F3 d = xf_vector_err(sp.o2w_inv, rd, &derr);
+    float len2 = length_sq(d);
+    if (len2 > 0) {  // transform.h:382-394 (tMax unchanged)
+        float dt = dot(vabs(d), oerr) / len2;
+        o = o + d * dt;
+    }
+    EF ox = ef(o.x, oerr.x), oy = ef(o.y, oerr.y), oz = ef(o.z, oerr.z);
+    EF dx = ef(d.x, derr.x), dy = ef(d.y, derr.y), dz = ef(d.z, derr.z);
+    EF a = dx * dx + dy * dy + dz * dz;
+    EF b = ef(2.f) * (dx * ox + dy * oy + dz * oz);
+    EF c = ox * ox + oy * oy + oz * oz - ef(sp.radius) * ef(sp.radius);
+    EF t0, t1;
+    if (!ef_quadratic(a, b, c, &t0, &t1)) return false;
+    if (t0.hi > tmax || t1.lo <= 0) return false;
+    EF ts = t0;
+    if (ts.lo <= 0) {
+        ts = t1;
+        if (ts.hi > tmax) return false;
+    }
+    F3 ph = o + d * ts.v;
+    float scale = sp.radius / length(ph);
+    ph = F3{ph.x * scale, ph.y * scale, ph.z * scale};
+    if (ph.x == 0 && ph.y == 0) ph.x = 1e-5f * sp.radius;
+    *t_hit = ts.v;
+    *obj_d = d;
+    *phit = ph;
+    return true;
+}
+
+// What shading needs of a SurfaceInteraction (core/interaction.h)
+struct Isect {
+    F3 p, perr, n, wo, sn, sdpdu;
+};
+
+// Sphere::Intersect's interaction + Transform::operator()(SurfaceInteraction)
+// (sphere.cpp:104-155, interaction.cpp:44-70, transform.cpp:262-297)
+DEV void sphere_interaction(const DSphere &sp, F3 obj_d, F3 ph, Isect *is) {
+    float theta = acos_f(clampf(ph.z / sp.radius, -1, 1));
+    float z_radius = sqrtf(ph.x * ph.x + ph.y * ph.y);
+    float inv_z_radius = 1 / z_radius;
+    float cos_phi = ph.x * inv_z_radius;
+    float sin_phi = ph.y * inv_z_radius;
+    float st, ct;
+    sincos_f(theta, &st, &ct);
+    F3 dpdu = F3{-sp.phi_max * ph.y, sp.phi_max * ph.x, 0};
+    F3 dpdv = (sp.theta_max - sp.theta_min) * F3{ph.z * cos_phi, ph.z * sin_phi, -sp.radius * st};
+    F3 perr = kGamma5 * vabs(ph);
+    F3 n = normalize(cross(dpdu, dpdv));
+    F3 sn = n;
+    if (sp.reverse_orientation ^ sp.swaps_handedness) {
+        n = n * -1.f;
+        sn = sn * -1.f;
+    }
+    F3 wo = normalize(-obj_d);
+    is->p = xf_point_err2(sp.o2w, ph, perr, &is->perr);
+    is->n = normalize(xf_normal(sp.o2w_inv, n));
+    is->wo = normalize(xf_vector(sp.o2w, wo));
+    F3 snw = normalize(xf_normal(sp.o2w_inv, sn));
+    is->sdpdu = xf_vector(sp.o2w, dpdu);
+    is->sn = faceforward(snw, is->n);
+}
+
+// Triangle::Intersect's interaction (triangle.cpp:277-400) from the stored
+// barycentrics of the closest hit.
+DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, F3 p1, F3 p2, F3 ray_d, float b0,
+                              float b1, float b2, Isect *is) {
+    float uv00 = 0, uv01 = 0, uv10 = 1, uv11 = 0, uv20 = 1, uv21 = 1;  // triangle.h:98-108
+    if (flags & 4u) {
+        const float2 *u = S.tri_uv + 3 * size_t(prim);
+        float2 a = u[0], b = u[1], c = u[2];
+        uv00 = a.x;
+        uv01 = a.y;
+        uv10 = b.x;
+        uv11 = b.y;
+        uv20 = c.x;
+        uv21 = c.y;
+    }
+    float duv02x = uv00 - uv20, duv02y = uv01 - uv21;
+    float duv12x = uv10 - uv20, duv12y = uv11 - uv21;
+    F3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = duv02x * duv12y - duv02y * duv12x;
+    bool degenerate = double(fabsf(determinant)) < 1e-8;
+    F3 dpdu = F3{0, 0, 0}, dpdv = F3{0, 0, 0};
+    if (!degenerate) {
+        float invdet = 1 / determinant;
+        dpdu = (duv12y * dp02 - duv02y * dp12) * invdet;
+        dpdv = (-duv12x * dp02 + duv02x * dp12) * invdet;
+    }
+    if (degenerate || length_sq(cross(dpdu, dpdv)) == 0)
+        coordinate_system(normalize(cross(p2 - p0, p1 - p0)), &dpdu, &dpdv);
+    float xs = (fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x));
+    float ys = (fabsf(b0 * p0.y) + fabsf(b1 * p1.y) + fabsf(b2 * p2.y));
+    float zs = (fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z));
+    is->perr = kGamma7 * F3{xs, ys, zs};
+    is->p = b0 * p0 + b1 * p1 + b2 * p2;
+    is->wo = normalize(-ray_d);
+    F3 n = normalize(cross(dp02, dp12));
+    const bool flip = (flags & 8u) != 0;
+    if (flags & 2u) {
+        const float4 *nn = S.tri_norms + 3 * size_t(prim);
+        float4 a = nn[0], b = nn[1], c = nn[2];
+        F3 n0 = F3{a.x, a.y, a.z}, n1 = F3{b.x, b.y, b.z}, n2 = F3{c.x, c.y, c.z};
+        F3 ns = (b0 * n0 + b1 * n1 + b2 * n2);
+        if (length_sq(ns) > 0)
+            ns = normalize(ns);
+        else
+            ns = n;
+        F3 ss = normalize(dpdu);
+        F3 ts = cross(ss, ns);
+        if (length_sq(ts) > 0.f) {
+            ts = normalize(ts);
+            ss = cross(ts, ns);
+        } else
+            coordinate_system(ns, &ss, &ts);
+        F3 sn = normalize(cross(ss, ts));  // SetShadingGeometry, interaction.cpp:72-92
+        if (flip) sn = -sn;
+        n = faceforward(n, sn);
+        is->sn = sn;
+        is->sdpdu = ss;
+    } else {
+        if (flip) n = -n;
+        is->sn = n;
+        is->sdpdu = dpdu;
+    }
+    is->n = n;
+}
+
+// ===========================================================================
+// BVH traversal (accelerators/bvh.cpp:662-738, core/geometry.h:1411-1438)
+// ===========================================================================
+// One ray per lane; the per-lane stack of node indices lives in LDS as
+// stack[level][lane] (64 dwords per level): lane l always hits bank l mod 32,
+// so pushes and pops are conflict-free whatever depth each lane is at.
+// LDS pointers carry their address space explicitly so that pushes and pops
+// compile to ds_write_b32 / ds_read_b32 (a generic pointer would go through flat_*).
+typedef __attribute__((address_space(3))) int lds_int;
+constexpr int kLdsStackDepth = 32;   // measured max depth on killeroo-simple: 19
+constexpr int kSpillStackDepth = 32; // reference allows 64 (bvh.cpp:670); levels 32..63 spill to HBM
+
+struct TraceStats {
+    uint32_t nodes, tris, tri_hits, spheres;
+};
+
+struct HitRec {
+    int prim;  // -1 = miss
+    float t, b0, b1, b2;
+};
+
+template <bool ANY_HIT, bool COUNT>
+DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack, int *spill, uint32_t spill_stride,
+                  HitRec *hit, TraceStats *st) {
+    // `spill` points at this lane's column of a [kSpillStackDepth][spill_stride]
+    // HBM array; it is only touched by trees deeper than the LDS stack.
+    const RayCtx rc = make_ray_ctx(ro, rd);
+    int sp = 0, cur = 0;
+    bool found = false;
+    hit->prim = -1;
+    if (S.n_nodes == 0) return false;
+    while (true) {
+        const float4 n0 = S.nodes[2 * cur], n1 = S.nodes[2 * cur + 1];
+        if (COUNT) ++st->nodes;
+        // Bounds3::IntersectP(ray, invDir, dirIsNeg): n0 = (min.xyz, max.x), n1 = (max.yz, offset, meta)
+        const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
+        float tmin = ((nx ? n0.w : n0.x) - rc.o.x) * rc.inv_dir.x;
+        float tmx = ((nx ? n0.x : n0.w) - rc.o.x) * rc.inv_dir.x;
+        float tymin = ((ny ? n1.x : n0.y) - rc.o.y) * rc.inv_dir.y;
+        float tymax = ((ny ? n0.y : n1.x) - rc.o.y) * rc.inv_dir.y;
+        tmx *= kSlabScale;
+        tymax *= kSlabScale;
+        bool overlap = !(tmin > tymax || tymin > tmx);
+        if (overlap) {
+            if (tymin > tmin) tmin = tymin;
+            if (tymax < tmx) tmx = tymax;
+            float tzmin = ((nz ? n1.y : n0.z) - rc.o.z) * rc.inv_dir.z;
+            float tzmax = ((nz ? n0.z : n1.y) - rc.o.z) * rc.inv_dir.z;
+            tzmax *= kSlabScale;
+            overlap = !(tmin > tzmax || tzmin > tmx);
+            if (overlap) {
+                if (tzmin > tmin) tmin = tzmin;
+                if (tzmax < tmx) tmx = tzmax;
+                overlap = (tmin < tmax) && (tmx > 0);
+            }
+        }
+        if (overlap) {
+            const uint32_t meta = f2b(n1.w);
+            const int nprims = int(meta & 0xffffu);
+            const int offset = int(f2b(n1.z));
+            if (nprims > 0) {
+                for (int i = 0; i < nprims; ++i) {
+                    const int prim = offset + i;
+                    const float4 v0 = S.tri_verts[3 * size_t(prim)];
+                    const uint32_t flags = f2b(v0.w);
+                    if (flags & 1u) {
+                        if (COUNT) ++st->spheres;
+                        float t;
+                        F3 od, ph;
+                        if (sphere_test(S.spheres[S.prim_shape[prim]], ro, rd, tmax, &t, &od, &ph)) {
+                            if (ANY_HIT) return true;
+                            found = true;
+                            tmax = t;
+                            hit->prim = prim;
+                            hit->t = t;
+                            hit->b0 = hit->b1 = hit->b2 = 0;
+                        }
+                    } else {
+                        const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
+                        const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
+                        if (COUNT) ++st->tris;
+                        float t, b0, b1, b2;
+                        if (triangle_test(rc, tmax, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z},
+                                          F3{v2.x, v2.y, v2.z}, &t, &b0, &b1, &b2)) {
+                            if (COUNT) ++st->tri_hits;
+                            if (ANY_HIT) return true;
+                            found = true;
+                            tmax = t;
+                            hit->prim = prim;
+                            hit->t = t;
+                            hit->b0 = b0;
+                            hit->b1 = b1;
+                            hit->b2 = b2;
+                        }
+                    }
+                }
+                if (sp == 0) break;
+                --sp;
+                cur = (sp < kLdsStackDepth) ? lds_stack[sp * 64] : spill[size_t(sp - kLdsStackDepth) * spill_stride];
+            } else {
+                const int axis = int((meta >> 16) & 0xffu);
+                int push;
+                if ((rc.neg_mask >> axis) & 1) {
+                    push = cur + 1;
+                    cur = offset;
+                } else {
+                    push = offset;
+                    cur = cur + 1;
+                }
+                if (sp < kLdsStackDepth)
+                    lds_stack[sp * 64] = push;
+                else
+                    spill[size_t(sp - kLdsStackDepth) * spill_stride] = push;
+                ++sp;
+            }
+        } else {
+            if (sp == 0) break;
+            --sp;
+            cur = (sp < kLdsStackDepth) ? lds_stack[sp * 64] : spill[size_t(sp - kLdsStackDepth) * spill_stride];
+        }
+    }
+    return found;
+}
+
+// ===========================================================================
+// BSDF (core/reflection.{h,cpp}, core/microfacet.cpp)
+// ===========================================================================
+struct Bsdf {
+    F3 ns, ng, ss, ts;
+    F3 kd, ks;
+    float alpha;
+    int n_lobes;
+    bool has_lambert, has_micro;
+};
+DEV F3 to_local(const Bsdf &b, F3 v) { return F3{dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)}; }
+DEV F3 to_world(const Bsdf &b, F3 v) {
+    return F3{b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
+              b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z};
+}
+// Matte / Plastic ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70)
+DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
+    Bsdf b;
+    b.ns = is.sn;
+    b.ng = is.n;
+    b.ss = normalize(is.sdpdu);
+    b.ts = cross(b.ns, b.ss);
+    b.n_lobes = 0;
+    b.kd = F3{clampf(m.kd[0], 0, IILE_INF), clampf(m.kd[1], 0, IILE_INF), clampf(m.kd[2], 0, IILE_INF)};
+    b.has_lambert = !is_black(b.kd);
+    if (b.has_lambert) ++b.n_lobes;
+    b.ks = F3{0, 0, 0};
+    b.has_micro = false;
+    b.alpha = m.alpha;
+    if (m.type == 1) {
+        b.ks = F3{clampf(m.ks[0], 0, IILE_INF), clampf(m.ks[1], 0, IILE_INF), clampf(m.ks[2], 0, IILE_INF)};
+        b.has_micro = !is_black(b.ks);
+        if (b.has_micro) ++b.n_lobes;
+    }
+    return b;
+}
+// reflection.h:56-84
+DEV float cos2_theta(F3 w) { return w.z * w.z; }
+DEV float sin2_theta(F3 w) { return mx(0.f, 1.f - cos2_theta(w)); }
+DEV float sin_theta(F3 w) { return sqrtf(sin2_theta(w)); }
+DEV float tan_theta(F3 w) { return sin_theta(w) / w.z; }
+DEV float tan2_theta(F3 w) { return sin2_theta(w) / cos2_theta(w); }
+DEV float cos_phi(F3 w) {
+    float st = sin_theta(w);
+    return (st == 0) ? 1 : clampf(w.x / st, -1, 1);
+}
+DEV float sin_phi(F3 w) {
+    float st = sin_theta(w);
+    return (st == 0) ? 0 : clampf(w.y / st, -1, 1);
+}
+DEV float cos2_phi(F3 w) { return cos_phi(w) * cos_phi(w); }
+DEV float sin2_phi(F3 w) { return sin_phi(w) * sin_phi(w); }
+DEV bool same_hemisphere(F3 a, F3 b) { return a.z * b.z > 0; }
+// FrDielectric, reflection.cpp:47-68
+DEV float fr_dielectric(float cos_i, float eta_i, float eta_t) {
+    cos_i = clampf(cos_i, -1, 1);
+    bool entering = cos_i > 0.f;
+    if (!entering) {
+        float tmp = eta_i;
+        eta_i = eta_t;
+        eta_t = tmp;
+        cos_i = fabsf(cos_i);
+    }
+    float sin_i = sqrtf(mx(0.f, 1 - cos_i * cos_i));
+    float sin_t = eta_i / eta_t * sin_i;
+    if (sin_t >= 1) return 1;
+    float cos_t = sqrtf(mx(0.f, 1 - sin_t * sin_t));
+    float r_parl = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+    float r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return (r_parl * r_parl + r_perp * r_perp) / 2;
+}
+// TrowbridgeReitzDistribution::D / Lambda, microfacet.cpp:155-163, 176-184
+DEV float tr_d(F3 wh, float a) {
+    float t2 = tan2_theta(wh);
+    if (is_inf(t2)) return 0.f;
+    const float cos4 = cos2_theta(wh) * cos2_theta(wh);
+    float e = (cos2_phi(wh) / (a * a) + sin2_phi(wh) / (a * a)) * t2;
+    return 1 / (kPi * a * a * cos4 * (1 + e) * (1 + e));
+}
+DEV float tr_lambda(F3 w, float a) {
+    float abs_tan = fabsf(tan_theta(w));
+    if (is_inf(abs_tan)) return 0.f;
+    float alpha = sqrtf(cos2_phi(w) * a * a + sin2_phi(w) * a * a);
+    float a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
+    return (-1 + sqrtf(1.f + a2t2)) / 2;
+}
+DEV float tr_g1(F3 w, float a) { return 1 / (1 + tr_lambda(w, a)); }
+DEV float tr_g(F3 wo, F3 wi, float a) { return 1 / (1 + tr_lambda(wo, a) + tr_lambda(wi, a)); }
+DEV float tr_pdf(F3 wo, F3 wh, float a) { return tr_d(wh, a) * tr_g1(wo, a) * absdot(wo, wh) / fabsf(wo.z); }
+// TrowbridgeReitzSample11, microfacet.cpp:238-283. The normal-incidence branch
+// evaluates sqrt/cos/sin through the C (double) overloads in the reference.
+DEV void tr_sample11(float cos_theta, float U1, float U2, float *slope_x, float *slope_y) {
+    if (double(cos_theta) > .9999) {
+        float r = float(sqrt(double(U1 / (1 - U1))));
+        float phi = float(6.28318530718 * double(U2));
+        double s, c;
+        sincos_d(double(phi), &s, &c);
+        *slope_x = float(double(r) * c);
+        *slope_y = float(double(r) * s);
+        return;
+    }
+    float sin_t = sqrtf(mx(0.f, 1.f - cos_theta * cos_theta));
+    float tan_t = sin_t / cos_theta;
+    float a = 1 / tan_t;
+    float G1 = 2 / (1 + sqrtf(1.f + 1.f / (a * a)));
+    float A = 2 * U1 / G1 - 1;
+    float tmp = 1.f / (A * A - 1.f);
+    if (double(tmp) > 1e10) tmp = 1e10f;
+    float B = tan_t;
+    float D = sqrtf(mx(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.f));
+    float slope_x_1 = B * tmp - D;
+    float slope_x_2 = B * tmp + D;
+    *slope_x = (A < 0 || slope_x_2 > 1.f / tan_t) ? slope_x_1 : slope_x_2;
+    float Sg;
+    if (U2 > 0.5f) {
+        Sg = 1.f;
+        U2 = 2.f * (U2 - .5f);
+    } else {
+        Sg = -1.f;
+        U2 = 2.f * (.5f - U2);
+    }
+    float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
+              (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    *slope_y = Sg * z * sqrtf(1.f + *slope_x * *slope_x);
+}
+// TrowbridgeReitzSample + Sample_wh (visible-area), microfacet.cpp:285-336
+DEV F3 tr_sample_wh(F3 wo, float u0, float u1, float a) {
+    bool flip = wo.z < 0;
+    F3 wi = flip ? -wo : wo;
+    F3 ws = normalize(F3{a * wi.x, a * wi.y, wi.z});
+    float sx, sy;
+    tr_sample11(ws.z, u0, u1, &sx, &sy);
+    float tmp = cos_phi(ws) * sx - sin_phi(ws) * sy;
+    sy = sin_phi(ws) * sx + cos_phi(ws) * sy;
+    sx = tmp;
+    sx = a * sx;
+    sy = a * sy;
+    F3 wh = normalize(F3{-sx, -sy, 1.f});
+    if (flip) wh = -wh;
+    return wh;
+}
+// MicrofacetReflection::f with FresnelDielectric(1.5, 1), reflection.cpp:226-236
+DEV F3 micro_f(const Bsdf &b, F3 wo, F3 wi) {
+    float cos_o = fabsf(wo.z), cos_i = fabsf(wi.z);
+    F3 wh = wi + wo;
+    if (cos_i == 0 || cos_o == 0) return F3{0, 0, 0};
+    if (wh.x == 0 && wh.y == 0 && wh.z == 0) return F3{0, 0, 0};
+    wh = normalize(wh);
+    float Fr = fr_dielectric(dot(wi, wh), 1.5f, 1.f);
+    F3 F = F3{Fr, Fr, Fr};
+    return sdiv(b.ks * tr_d(wh, b.alpha) * tr_g(wo, wi, b.alpha) * F, 4 * cos_i * cos_o);
+}
+DEV float micro_pdf(const Bsdf &b, F3 wo, F3 wi) {
+    if (!same_hemisphere(wo, wi)) return 0;
+    F3 wh = normalize(wo + wi);
+    return tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
+}
+DEV float lambert_pdf(F3 wo, F3 wi) { return same_hemisphere(wo, wi) ? fabsf(wi.z) * kInvPi : 0; }
+DEV F3 lobes_f(const Bsdf &b, F3 wo, F3 wi) {
+    F3 f = F3{0, 0, 0};
+    if (b.has_lambert) f = f + b.kd * kInvPi;
+    if (b.has_micro) f = f + micro_f(b, wo, wi);
+    return f;
+}
+// BSDF::f, reflection.cpp:686-699
+DEV F3 bsdf_f(const Bsdf &b, F3 woW, F3 wiW) {
+    F3 wi = to_local(b, wiW), wo = to_local(b, woW);
+    if (wo.z == 0) return F3{0, 0, 0};
+    bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
+    return reflect ? lobes_f(b, wo, wi) : F3{0, 0, 0};
+}
+// BSDF::Pdf, reflection.cpp:786-801
+DEV float bsdf_pdf(const Bsdf &b, F3 woW, F3 wiW) {
+    if (b.n_lobes == 0) return 0.f;
+    F3 wo = to_local(b, woW), wi = to_local(b, wiW);
+    if (wo.z == 0) return 0.f;
+    float pdf = 0.f;
+    if (b.has_lambert) pdf += lambert_pdf(wo, wi);
+    if (b.has_micro) pdf += micro_pdf(b, wo, wi);
+    return pdf / b.n_lobes;
+}
+// BSDF::Sample_f, reflection.cpp:719-784. *pdf is untouched on the early
+// `wo.z == 0` return, as in the reference.
+DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *pdf) {
+    const int matching = b.n_lobes;
+    if (matching == 0) {
+        *pdf = 0;
+        return F3{0, 0, 0};
+    }
+    int comp = int(floorf(u0 * matching));
+    if (comp > matching - 1) comp = matching - 1;
+    const bool pick_micro = b.has_lambert ? (comp == 1) : b.has_micro;
+    const float ur0 = mn(u0 * matching - comp, kOneMinusEpsilon);
+    F3 wo = to_local(b, woW);
+    if (wo.z == 0) return F3{0, 0, 0};
+    *pdf = 0;
+    F3 wi = F3{0, 0, 0}, f;
+    if (!pick_micro) {  // BxDF::Sample_f, reflection.cpp:378-385
+        wi = cosine_sample_hemisphere(ur0, u1);
+        if (wo.z < 0) wi.z *= -1;
+        *pdf = lambert_pdf(wo, wi);
+        f = b.kd * kInvPi;
+    } else {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
+        F3 wh = tr_sample_wh(wo, ur0, u1, b.alpha);
+        wi = -wo + 2 * dot(wo, wh) * wh;
+        if (!same_hemisphere(wo, wi))
+            f = F3{0, 0, 0};
+        else {
+            *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
+            f = micro_f(b, wo, wi);
+        }
+    }
+    if (*pdf == 0) return F3{0, 0, 0};
+    *wiW = to_world(b, wi);
+    if (matching > 1) {
+        *pdf += pick_micro ? lambert_pdf(wo, wi) : micro_pdf(b, wo, wi);
+        *pdf /= matching;
+        bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
+        f = reflect ? lobes_f(b, wo, wi) : F3{0, 0, 0};
+    }
+    return f;
+}
+
+// ===========================================================================
+// sphere emitter (shapes/sphere.cpp:219-306, core/shape.cpp:72-87)
+// ===========================================================================
+struct LightSample {
+    F3 p, perr, n;
+};
+DEV float sphere_area(const DSphere &sp) { return sp.phi_max * sp.radius * (sp.zmax - sp.zmin); }
+DEV LightSample sphere_sample_area(const DSphere &sp, float u0, float u1, float *pdf) {
+    float z = 1 - 2 * u0;  // UniformSampleSphere, sampling.cpp:98-103
+    float r = sqrtf(mx(0.f, 1.f - z * z));
+    float phi = 2 * kPi * u1;
+    float s, c;
+    sincos_f(phi, &s, &c);
+    F3 us = F3{r * c, r * s, z};
+    F3 pobj = F3{0, 0, 0} + sp.radius * us;
+    LightSample it;
+    it.n = normalize(xf_normal(sp.o2w_inv, pobj));
+    if (sp.reverse_orientation) it.n = it.n * -1.f;
+    float scale = sp.radius / length(pobj);
+    pobj = F3{pobj.x * scale, pobj.y * scale, pobj.z * scale};
+    F3 pobj_err = kGamma5 * vabs(pobj);
+    it.p = xf_point_err2(sp.o2w, pobj, pobj_err, &it.perr);
+    *pdf = 1 / sphere_area(sp);
+    return it;
+}
+DEV LightSample sphere_sample(const DSphere &sp, const Isect &ref, float u0, float u1, float *pdf) {
+    F3 pc = xf_point(sp.o2w, F3{0, 0, 0});
+    F3 porigin = offset_ray_origin(ref.p, ref.perr, ref.n, pc - ref.p);
+    if (length_sq(porigin - pc) <= sp.radius * sp.radius) {
+        LightSample intr = sphere_sample_area(sp, u0, u1, pdf);
+        F3 wi = intr.p - ref.p;
+        if (length_sq(wi) == 0)
+            *pdf = 0;
+        else {
+            wi = normalize(wi);
+            *pdf *= length_sq(ref.p - intr.p) / absdot(intr.n, -wi);
+        }
+        if (is_inf(*pdf)) *pdf = 0.f;
+        return intr;
+    }
+    F3 wc = normalize(pc - ref.p);
+    F3 wcx, wcy;
+    coordinate_system(wc, &wcx, &wcy);
+    float sin_tmax2 = sp.radius * sp.radius / length_sq(ref.p - pc);
+    float cos_tmax = sqrtf(mx(0.f, 1 - sin_tmax2));
+    float cos_t = (1 - u0) + u0 * cos_tmax;
+    float sin_t = sqrtf(mx(0.f, 1 - cos_t * cos_t));
+    float phi = u1 * 2 * kPi;
+    float dc = length(ref.p - pc);
+    float ds = dc * cos_t - sqrtf(mx(0.f, sp.radius * sp.radius - dc * dc * sin_t * sin_t));
+    float cos_a = (dc * dc + sp.radius * sp.radius - ds * ds) / (2 * dc * sp.radius);
+    float sin_a = sqrtf(mx(0.f, 1 - cos_a * cos_a));
+    float sphi, cphi;
+    sincos_f(phi, &sphi, &cphi);
+    // SphericalDirection(sinAlpha, cosAlpha, phi, -wcX, -wcY, -wc), geometry.h:1467-1472
+    F3 nw = sin_a * cphi * (-wcx) + sin_a * sphi * (-wcy) + cos_a * (-wc);
+    F3 pw = pc + sp.radius * nw;
+    LightSample it;
+    it.p = pw;
+    it.perr = kGamma5 * vabs(pw);
+    it.n = nw;
+    if (sp.reverse_orientation) it.n = it.n * -1.f;
+    *pdf = 1 / (2 * kPi * (1 - cos_tmax));
+    return it;
+}
+DEV float sphere_pdf(const DSphere &sp, const Isect &ref, F3 wi) {
+    F3 pc = xf_point(sp.o2w, F3{0, 0, 0});
+    F3 porigin = offset_ray_origin(ref.p, ref.perr, ref.n, pc - ref.p);
+    if (length_sq(porigin - pc) <= sp.radius * sp.radius) {
+        // Shape::Pdf, shape.cpp:72-87 — the shape alone, not a scene ray
+        F3 ro = offset_ray_origin(ref.p, ref.perr, ref.n, wi);
+        float t;
+        F3 od, ph;
+        if (!sphere_test(sp, ro, wi, IILE_INF, &t, &od, &ph)) return 0;
+        Isect li;
+        sphere_interaction(sp, od, ph, &li);
+        float pdf = length_sq(ref.p - li.p) / (absdot(li.n, -wi) * sphere_area(sp));
+        if (is_inf(pdf)) pdf = 0.f;
+        return pdf;
+    }
+    float sin_tmax2 = sp.radius * sp.radius / length_sq(ref.p - pc);
+    float cos_tmax = sqrtf(mx(0.f, 1 - sin_tmax2));
+    return 1 / (2 * kPi * (1 - cos_tmax));
+}
+DEV float power_heuristic(float fpdf, float gpdf) {  // sampling.h:169-172 with nf = ng = 1
+    float f = 1 * fpdf, g = 1 * gpdf;
+    return (f * f) / (f * f + g * g);
+}
+
+}  // namespace iile

@@ -1,0 +1,90 @@
+// dscene.h — device-resident scene layout (HBM) and queue records.
+//
+// Layout choices (DESIGN.md "Data layout in HBM"):
+//  * BVH nodes keep the reference's 32-byte LinearBVHNode (bvh.cpp:95-104) and
+//    are fetched as two 16-byte loads per lane.
+//  * Triangle vertices are pre-gathered per primitive in BVH leaf order:
+//    3 x float4 = 48 contiguous bytes per triangle test, with the primitive's
+//    flags / material / light packed into the .w lanes, replacing the
+//    reference's shared_ptr<Primitive> -> Triangle -> mesh->p[v[i]] chase.
+//  * Ray / hit / NEE queues are arrays of float4 records so that a wavefront's
+//    64 lanes issue full-width 16-byte coalesced loads and stores.
+#pragma once
+#include "dmath.h"
+
+namespace iile {
+
+struct DSphere {
+    M44 o2w, o2w_inv;
+    float radius, zmin, zmax, theta_min, theta_max, phi_max;
+    int reverse_orientation, swaps_handedness;
+};
+struct DMaterial {
+    int type;
+    float kd[3];
+    float ks[3];
+    float alpha;
+};
+struct DLight {
+    float lemit[3];
+    int two_sided;
+    int sphere;
+};
+// Per Halton dimension: base, exact u32 division magic (round-up method),
+// float reciprocal and offset of its digit permutation.
+struct DHaltonDim {
+    uint32_t base, magic, shift, perm_offset;
+    float inv_base;
+    float perm0_term;  // invBase * perm[0] / (1 - invBase), lowdiscrepancy.cpp:422
+    uint32_t pad0, pad1;
+};
+constexpr int kMaxHaltonDims = 128;
+constexpr int kMaxSpheres = 8;
+constexpr int kMaxMaterials = 64;
+constexpr int kMaxLights = 8;
+
+struct DScene {
+    // HBM arrays
+    const float4 *nodes;      // 2 float4 per node
+    const float4 *tri_verts;  // 3 float4 per primitive: (p.xyz, w): w0=flags w1=material w2=light
+    const float4 *tri_norms;  // 3 float4 per primitive: (n.xyz, uv.{x,y} spread over w)
+    const float2 *tri_uv;     // 3 float2 per primitive
+    const int *prim_shape;    // sphere index for sphere primitives
+    const uint16_t *perms;
+    const DHaltonDim *hdims;
+    const DSphere *spheres;
+    const DMaterial *materials;
+    const DLight *lights;
+    int n_nodes, n_prims, n_spheres, n_materials, n_lights, n_hdims;
+    // camera
+    M44 raster_to_camera, camera_to_world;
+    float lens_radius, focal_distance;
+    // film
+    int xres, yres;
+    int crop_x0, crop_y0, crop_x1, crop_y1;
+    int samp_x0, samp_y0, samp_x1, samp_y1;
+    float filter_rx, filter_ry, max_sample_luminance;
+    // halton
+    int base_scale0, base_scale1, base_exp0, base_exp1, sample_stride, mult_inv0, mult_inv1;
+    // integrator
+    int max_depth;
+    float rr_threshold;
+};
+
+// queue records -------------------------------------------------------------
+// ray:  ro = (o.xyz, bitcast pid)   rd = (d.xyz, tmax)
+// hit:  (bitcast prim or -1, b0 | t, b1, b2)
+// NEE entry (6 float4, SoA of float4 planes):
+//   n0 = (shadow o.xyz, bitcast pid)      n1 = (shadow d.xyz, bitcast flags)
+//   n2 = (mis o.xyz, A.x)                 n3 = (mis d.xyz, A.y)
+//   n4 = (B.xyz, A.z)                     n5 = (beta.xyz, bitcast light index)
+enum { NEE_HAS_SHADOW = 1, NEE_HAS_MIS = 2 };
+
+struct DCounters {
+    unsigned long long camera_rays, closest_rays, shadow_rays;
+    unsigned long long nodes_closest, nodes_any, tri_tests, tri_hits, sphere_tests;
+    unsigned long long nee_evals, zero_radiance;
+    unsigned long long path_length[8];
+};
+
+}  // namespace iile

@@ -1,0 +1,64 @@
+// kernels.h — launch interface between api.hip and kernels.hip.
+#pragma once
+#include "dscene.h"
+
+namespace iile {
+
+// One render pass = all pixels of the owned tiles x a chunk of sample indices.
+struct PassDesc {
+    // tile ownership (SamplerIntegrator::Render's 16x16 tiles, integrator.cpp:235-237)
+    int n_tiles_x, n_tiles_y, tile_rank, tile_nranks, n_owned_tiles;
+    int k0, kc;        // sample indices [k0, k0 + kc)
+    uint32_t n_paths;  // n_owned_tiles * 256 * kc, or the explicit list length
+    // explicit path list (kernel-level tests); null for tile enumeration
+    const int *list_px, *list_py, *list_k;
+};
+
+struct PassBuffers {
+    float4 *L;          // [n_paths] radiance so far (xyz)
+    float4 *beta;       // [n_paths] throughput (xyz), w = bitcast sampler dimension
+    uint32_t *hindex;   // [n_paths] Halton index of the sample
+    float4 *ray_o[2];   // ping-pong ray queues
+    float4 *ray_d[2];
+    float4 *hits;       // [n_paths]
+    float4 *nee;        // 6 planes of n_paths float4
+    uint32_t *counts;   // [0..15] ray-queue sizes per bounce, [16..31] NEE-queue sizes per bounce
+    DCounters *counters;
+    uint32_t *nray_out; // optional [2*n_paths] per-path {closest, shadow} ray counts (tests)
+    int *spill;         // [kSpillStackDepth][max grid threads] overflow of the LDS traversal stacks
+};
+
+struct FilmBuffers {
+    float4 *tile_rgbw;  // [n_owned_tiles*256] per-pixel RGB contribSum + weight of own samples
+    float4 *k0_rgbv;    // [n_owned_tiles*256] guarded radiance of sample k=0 (xyz), w = splat mask bits
+    float4 *film_xyzw;  // [crop_w*crop_h] output {X,Y,Z,weightSum}
+};
+
+struct LaunchCfg {
+    int n_cus;
+    hipStream_t stream;
+    bool count_stats;
+};
+
+void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg);
+void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_connect(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
+                            const LaunchCfg &cfg);
+void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg);
+
+// kernel-level entry points for parity tests
+void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, float4 *hits, int any_hit,
+                  DCounters *counters, int *spill, const LaunchCfg &cfg);
+// number of ints of the HBM spill array: kSpillStackDepth x the largest traversal grid
+uint32_t max_traversal_threads(int n_cus);
+void launch_halton(const DScene &S, int n, const int *px, const int *py, const int *k, int dim0, int ndims,
+                   float *out, uint32_t *index_out, const LaunchCfg &cfg);
+void launch_camera(const DScene &S, int n, const float *pfilm, const float *plens, float *o, float *d,
+                   const LaunchCfg &cfg);
+void launch_bsdf_probe(const DScene &S, int n, int mat, const float *wo, const float *wi_or_u, int sample,
+                       float *out, const LaunchCfg &cfg);
+void launch_trig_probe(int n, const float *x, float *out, const LaunchCfg &cfg);
+
+}  // namespace iile

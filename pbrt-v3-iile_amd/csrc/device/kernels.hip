@@ -1,0 +1,698 @@
+// kernels.hip — hand-written gfx950 kernels of the wavefront path tracer.
+//
+// Pipeline per pass (one pass = owned tiles x a chunk of sample indices):
+//   generate -> [ extend -> shade -> connect ] x (maxDepth + 1) -> film_accumulate
+// and, after the last pass, film_resolve.
+//
+//   generate  HaltonSampler + PerspectiveCamera::GenerateRayDifferential; fills ray queue 0
+//   extend    BVHAccel::Intersect over a ray queue (closest hit), LDS traversal stacks
+//   shade     the body of PathIntegrator::Li for one bounce: interaction, Le, BSDF, light
+//             sampling + BSDF sampling of EstimateDirect (emits one NEE record holding a
+//             shadow ray and an MIS ray), next direction, Russian roulette; compacts the
+//             surviving paths into the next ray queue with ballot + one atomic per wavefront
+//   connect   BVHAccel::IntersectP for the shadow ray and BVHAccel::Intersect for the MIS
+//             ray of each NEE record, then L += beta * Ld
+//
+// All kernels are persistent grid-stride loops that read their queue length
+// from device memory, so a whole pass is enqueued without host synchronisation.
+// 64-lane wavefronts throughout: ballots are 64-bit, lane = threadIdx.x & 63.
+#include "dpath.h"
+#include "kernels.h"
+
+namespace iile {
+
+constexpr int kBlock = 256;            // 4 wavefronts
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kTile = 16;
+
+DEV int lane_id() { return int(threadIdx.x & 63); }
+DEV uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+// Wavefront-aggregated append: one atomic per wavefront reserves a contiguous
+// run of queue slots; lanes take slots in lane order.
+DEV uint32_t wave_append(bool emit, uint32_t *counter) {
+    const unsigned long long mask = __ballot(emit);
+    if (mask == 0) return 0;
+    const uint32_t n = uint32_t(__popcll(mask));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader);
+    return base + lanes_below(mask);
+}
+DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+DEV void flush_counter(unsigned long long *dst, unsigned long long v) {
+    v = wave_sum(v);
+    if (lane_id() == 0 && v) atomicAdd(dst, v);
+}
+static inline int grid_blocks(uint32_t n, int n_cus, int per_cu) {
+    long want = (long(n) + kBlock - 1) / kBlock;
+    long cap = long(n_cus) * per_cu;
+    if (want < 1) want = 1;
+    return int(want < cap ? want : cap);
+}
+
+// pid -> (pixel, sample) for tile enumeration: pid = ((tile_slot*256 + pix)*kc + kk)
+DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, int *py, uint32_t *k) {
+    if (P.list_px) {
+        *px = P.list_px[pid];
+        *py = P.list_py[pid];
+        *k = uint32_t(P.list_k[pid]);
+        return true;
+    }
+    const uint32_t kk = pid % uint32_t(P.kc);
+    const uint32_t pt = pid / uint32_t(P.kc);
+    const uint32_t pix = pt & 255u, slot = pt >> 8;
+    const int tile = P.tile_rank + int(slot) * P.tile_nranks;
+    const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
+    *px = S.samp_x0 + tx * kTile + int(pix & 15u);
+    *py = S.samp_y0 + ty * kTile + int(pix >> 4);
+    *k = uint32_t(P.k0) + kk;
+    return *px < S.samp_x1 && *py < S.samp_y1;
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassBuffers B, int count_stats) {
+    unsigned long long n_cam = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < P.n_paths; base += gridDim.x * kBlock) {
+        const uint32_t pid = base + threadIdx.x;
+        bool valid = pid < P.n_paths;
+        int px = 0, py = 0;
+        uint32_t k = 0;
+        if (valid) valid = path_pixel(S, P, pid, &px, &py, &k);
+        F3 o = F3{0, 0, 0}, d = F3{0, 0, 1};
+        float tmax = 0;
+        if (valid) {
+            // Sampler::GetCameraSample (sampler.cpp:46-52): dims 0,1 film, 2 time, 3,4 lens
+            const uint32_t idx = halton_index(S, px, py, k);
+            const float u0 = sample_dimension(S, idx, 0), u1 = sample_dimension(S, idx, 1);
+            float l0 = 0, l1 = 0;
+            if (S.lens_radius > 0) {
+                l0 = sample_dimension(S, idx, 3);
+                l1 = sample_dimension(S, idx, 4);
+            }
+            camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
+            B.hindex[pid] = idx;
+            B.L[pid] = make_float4(0, 0, 0, 0);
+            B.beta[pid] = make_float4(1, 1, 1, b2f(5u));
+            if (B.nray_out) {
+                B.nray_out[2 * pid] = 0;
+                B.nray_out[2 * pid + 1] = 0;
+            }
+            ++n_cam;
+        } else if (pid < P.n_paths) {
+            B.L[pid] = make_float4(0, 0, 0, 0);
+        }
+        const uint32_t slot = wave_append(valid, &B.counts[0]);
+        if (valid) {
+            B.ray_o[0][slot] = make_float4(o.x, o.y, o.z, b2f(pid));
+            B.ray_d[0][slot] = make_float4(d.x, d.y, d.z, tmax);
+        }
+    }
+    if (count_stats) flush_counter(&B.counters->camera_rays, n_cam);
+}
+
+// ---------------------------------------------------------------------------
+// extend: closest hit for every ray of queue `bounce & 1`.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_extend(DScene S, PassBuffers B, int bounce) {
+    int *const SPILL = B.spill;
+    __shared__ int lds_stack[kWavesPerBlock][kLdsStackDepth][64];
+    lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
+    const uint32_t spill_stride = gridDim.x * kBlock;
+    int *my_spill = SPILL + blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t count = B.counts[bounce];
+    const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
+    TraceStats st = {0, 0, 0, 0};
+    unsigned long long n_rays = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+        const uint32_t slot = base + threadIdx.x;
+        if (slot < count) {
+            const float4 o4 = ro[slot], d4 = rd[slot];
+            HitRec h;
+            traverse<false, COUNT>(S, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, my_stack, my_spill, spill_stride, &h,
+                                   &st);
+            B.hits[slot] = make_float4(b2f(uint32_t(h.prim)), h.b0, h.b1, h.b2);
+            if (COUNT) {
+                ++n_rays;
+                if (B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
+            }
+        }
+    }
+    if (COUNT) {
+        flush_counter(&B.counters->closest_rays, n_rays);
+        flush_counter(&B.counters->nodes_closest, st.nodes);
+        flush_counter(&B.counters->tri_tests, st.tris);
+        flush_counter(&B.counters->tri_hits, st.tri_hits);
+        flush_counter(&B.counters->sphere_tests, st.spheres);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// DiffuseAreaLight::L (lights/diffuse.h:56-58)
+DEV F3 light_L(const DLight &lt, F3 n, F3 w) {
+    return (lt.two_sided || dot(n, w) > 0) ? F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} : F3{0, 0, 0};
+}
+
+// shade: one bounce of PathIntegrator::Li (path.cpp:81-191) for every hit of the
+// queue that extend just resolved.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int bounce, uint32_t plane) {
+    const uint32_t count = B.counts[bounce];
+    const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
+    float4 *no = B.ray_o[(bounce + 1) & 1], *nd = B.ray_d[(bounce + 1) & 1];
+    unsigned long long n_nee = 0, n_term = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+        const uint32_t slot = base + threadIdx.x;
+        const bool valid = slot < count;
+        bool alive = false, emit_nee = false;
+        uint32_t pid = 0;
+        F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
+        // NEE record fields
+        F3 so = F3{0, 0, 0}, sd = F3{0, 0, 1}, mo = F3{0, 0, 0}, md = F3{0, 0, 1};
+        F3 A = F3{0, 0, 0}, Bc = F3{0, 0, 0}, beta_nee = F3{0, 0, 0};
+        uint32_t nee_flags = 0, nee_light = 0;
+        bool returned_early = false;
+        if (valid) {
+            const float4 o4 = ro[slot], d4 = rd[slot], h4 = B.hits[slot];
+            pid = f2b(o4.w);
+            const int prim = int(f2b(h4.x));
+            const F3 ray_o = F3{o4.x, o4.y, o4.z}, ray_d = F3{d4.x, d4.y, d4.z};
+            if (prim >= 0) {
+                const float4 v0 = S.tri_verts[3 * size_t(prim)];
+                const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
+                const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
+                const uint32_t flags = f2b(v0.w);
+                const int material = int(f2b(v1.w)), light = int(f2b(v2.w));
+                Isect is;
+                if (flags & 1u) {
+                    // the closest hit was the sphere: redo its (deterministic) root
+                    // selection to recover the object-space ray and refined hit point
+                    float t;
+                    F3 od, ph;
+                    const DSphere &sp = S.spheres[S.prim_shape[prim]];
+                    sphere_test(sp, ray_o, ray_d, IILE_INF, &t, &od, &ph);
+                    sphere_interaction(sp, od, ph, &is);
+                } else {
+                    triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z},
+                                         F3{v2.x, v2.y, v2.z}, ray_d, h4.y, h4.z, h4.w, &is);
+                }
+                const float4 beta4 = B.beta[pid];
+                F3 beta = F3{beta4.x, beta4.y, beta4.z};
+                int dim = int(f2b(beta4.w));
+                const uint32_t hidx = B.hindex[pid];
+                // emitted light at the first vertex only: there are no specular lobes
+                // on this path, so specularBounce stays false (path.cpp:91-101)
+                if (bounce == 0 && light >= 0) {
+                    const float4 L4 = B.L[pid];
+                    const F3 L = F3{L4.x, L4.y, L4.z} + beta * light_L(S.lights[light], is.n, -ray_d);
+                    B.L[pid] = make_float4(L.x, L.y, L.z, 0);
+                }
+                if (bounce < S.max_depth) {
+                    const Bsdf bsdf = make_bsdf(S.materials[material], is);
+                    if (bsdf.n_lobes > 0) {
+                        ++n_nee;
+                        if (S.n_lights > 0) {
+                            // UniformSampleOneLight (integrator.cpp:85-106): one light, pdf 1;
+                            // SampleDiscrete still consumes a 1D sample
+                            ++dim;
+                            const int li = 0;
+                            const DLight &lt = S.lights[li];
+                            const DSphere &sp = S.spheres[lt.sphere];
+                            const float ul0 = sample_dimension(S, hidx, dim), ul1 = sample_dimension(S, hidx, dim + 1);
+                            const float us0 = sample_dimension(S, hidx, dim + 2),
+                                        us1 = sample_dimension(S, hidx, dim + 3);
+                            dim += 4;
+                            // EstimateDirect, light-sampling half (integrator.cpp:117-163)
+                            float light_pdf = 0, scattering_pdf = 0;
+                            F3 wi = F3{0, 0, 0}, Li = F3{0, 0, 0};
+                            LightSample ps = sphere_sample(sp, is, ul0, ul1, &light_pdf);
+                            if (light_pdf == 0 || length_sq(ps.p - is.p) == 0) {
+                                light_pdf = 0;
+                            } else {
+                                wi = normalize(ps.p - is.p);
+                                Li = light_L(lt, ps.n, -wi);
+                            }
+                            if (light_pdf > 0 && !is_black(Li)) {
+                                F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
+                                scattering_pdf = bsdf_pdf(bsdf, is.wo, wi);
+                                if (!is_black(f)) {
+                                    // VisibilityTester -> SpawnRayTo(Interaction), interaction.h:73-78
+                                    so = offset_ray_origin(is.p, is.perr, is.n, ps.p - is.p);
+                                    F3 target = offset_ray_origin(ps.p, ps.perr, ps.n, so - ps.p);
+                                    sd = target - so;
+                                    const float weight = power_heuristic(light_pdf, scattering_pdf);
+                                    A = sdiv(f * Li * weight, light_pdf);
+                                    nee_flags |= NEE_HAS_SHADOW;
+                                }
+                            }
+                            // BSDF-sampling half (integrator.cpp:165-213)
+                            F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
+                            f2 = f2 * absdot(wi, is.sn);
+                            if (!is_black(f2) && scattering_pdf > 0) {
+                                const float lp = sphere_pdf(sp, is, wi);
+                                if (lp != 0) {
+                                    const float weight = power_heuristic(scattering_pdf, lp);
+                                    mo = offset_ray_origin(is.p, is.perr, is.n, wi);
+                                    md = wi;
+                                    // Li is Lemit when the MIS ray finds this light facing it
+                                    Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * weight, scattering_pdf);
+                                    nee_flags |= NEE_HAS_MIS;
+                                }
+                            }
+                            nee_light = uint32_t(li);
+                            beta_nee = beta;
+                            emit_nee = true;
+                        }
+                    }
+                    // next direction (path.cpp:133-156)
+                    const float u0 = sample_dimension(S, hidx, dim), u1 = sample_dimension(S, hidx, dim + 1);
+                    dim += 2;
+                    float pdf = 0;
+                    F3 wi = F3{0, 0, 0};
+                    const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf);
+                    if (!(is_black(f) || pdf == 0.f)) {
+                        beta = beta * sdiv(f * absdot(wi, is.sn), pdf);
+                        const float by = lum_y(beta);
+                        if (by < 0.f || is_nan(by)) {
+                            returned_early = true;  // `return L` (path.cpp:143-145)
+                        } else {
+                            next_o = offset_ray_origin(is.p, is.perr, is.n, wi);
+                            next_d = wi;
+                            alive = true;
+                            // Russian roulette (path.cpp:182-190), etaScale == 1
+                            const float mc = max3(beta.x, beta.y, beta.z);
+                            if (mc < S.rr_threshold && bounce > 3) {
+                                const float q = mx(.05f, 1 - mc);
+                                const float ur = sample_dimension(S, hidx, dim);
+                                ++dim;
+                                if (ur < q)
+                                    alive = false;
+                                else
+                                    beta = sdiv(beta, 1 - q);
+                            }
+                        }
+                    }
+                    if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim)));
+                }
+            }
+            if (COUNT && !alive && !returned_early) {
+                // ReportValue(pathLength, bounces): a path that dies in this iteration
+                // exits the loop with bounces == bounce; one that survives Russian
+                // roulette bookkeeping is counted when it eventually terminates
+                ++n_term;
+            }
+        }
+        const uint32_t nslot = wave_append(alive, &B.counts[bounce + 1]);
+        if (alive) {
+            no[nslot] = make_float4(next_o.x, next_o.y, next_o.z, b2f(pid));
+            nd[nslot] = make_float4(next_d.x, next_d.y, next_d.z, IILE_INF);
+        }
+        const uint32_t eslot = wave_append(emit_nee, &B.counts[16 + bounce]);
+        if (emit_nee) {
+            B.nee[eslot] = make_float4(so.x, so.y, so.z, b2f(pid));
+            B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
+            B.nee[2 * plane + eslot] = make_float4(mo.x, mo.y, mo.z, A.x);
+            B.nee[3 * plane + eslot] = make_float4(md.x, md.y, md.z, A.y);
+            B.nee[4 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, A.z);
+            B.nee[5 * plane + eslot] = make_float4(beta_nee.x, beta_nee.y, beta_nee.z, b2f(nee_light));
+        }
+    }
+    if (COUNT) {
+        flush_counter(&B.counters->nee_evals, n_nee);
+        flush_counter(&B.counters->path_length[bounce < 7 ? bounce : 7], n_term);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// connect: resolve the two rays of each NEE record and add beta * Ld to L.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_connect(DScene S, PassBuffers B, int bounce, uint32_t plane) {
+    int *const SPILL = B.spill;
+    __shared__ int lds_stack[kWavesPerBlock][kLdsStackDepth][64];
+    lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
+    const uint32_t spill_stride = gridDim.x * kBlock;
+    int *my_spill = SPILL + blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t count = B.counts[16 + bounce];
+    TraceStats st_any = {0, 0, 0, 0}, st_cl = {0, 0, 0, 0};
+    unsigned long long n_shadow = 0, n_closest = 0, n_zero = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+        const uint32_t e = base + threadIdx.x;
+        if (e >= count) continue;
+        const float4 n0 = B.nee[e], n1 = B.nee[plane + e], n2 = B.nee[2 * plane + e], n3 = B.nee[3 * plane + e],
+                     n4 = B.nee[4 * plane + e], n5 = B.nee[5 * plane + e];
+        const uint32_t pid = f2b(n0.w), flags = f2b(n1.w);
+        const int li = int(f2b(n5.w));
+        F3 Ld = F3{0, 0, 0};
+        if (flags & NEE_HAS_SHADOW) {
+            HitRec h;
+            const bool occluded = traverse<true, COUNT>(S, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z},
+                                                        1 - kShadowEpsilon, my_stack, my_spill, spill_stride, &h, &st_any);
+            if (!occluded) Ld = Ld + F3{n2.w, n3.w, n4.w};
+            if (COUNT) {
+                ++n_shadow;
+                if (B.nray_out) B.nray_out[2 * pid + 1] += 1;
+            }
+        }
+        if (flags & NEE_HAS_MIS) {
+            HitRec h;
+            const F3 mo = F3{n2.x, n2.y, n2.z}, md = F3{n3.x, n3.y, n3.z};
+            const bool found = traverse<false, COUNT>(S, mo, md, IILE_INF, my_stack, my_spill, spill_stride, &h, &st_cl);
+            if (COUNT) {
+                ++n_closest;
+                if (B.nray_out) B.nray_out[2 * pid] += 1;
+            }
+            if (found) {
+                const float4 v0 = S.tri_verts[3 * size_t(h.prim)];
+                const float4 v2 = S.tri_verts[3 * size_t(h.prim) + 2];
+                // `lightIsect.primitive->GetAreaLight() == &light` (integrator.cpp:207)
+                if (int(f2b(v2.w)) == li && (f2b(v0.w) & 1u)) {
+                    const DSphere &sp = S.spheres[S.prim_shape[h.prim]];
+                    float t;
+                    F3 od, ph;
+                    Isect lis;
+                    sphere_test(sp, mo, md, IILE_INF, &t, &od, &ph);
+                    sphere_interaction(sp, od, ph, &lis);
+                    const DLight &lt = S.lights[li];
+                    if (lt.two_sided || dot(lis.n, -md) > 0) Ld = Ld + F3{n4.x, n4.y, n4.z};
+                }
+            }
+        }
+        // UniformSampleOneLight divides by lightPdf == 1; L += beta * Ld (path.cpp:123-128)
+        const F3 add = F3{n5.x, n5.y, n5.z} * Ld;
+        if (COUNT && is_black(add)) ++n_zero;
+        float4 L4 = B.L[pid];
+        B.L[pid] = make_float4(L4.x + add.x, L4.y + add.y, L4.z + add.z, 0);
+    }
+    if (COUNT) {
+        flush_counter(&B.counters->shadow_rays, n_shadow);
+        flush_counter(&B.counters->closest_rays, n_closest);
+        flush_counter(&B.counters->zero_radiance, n_zero);
+        flush_counter(&B.counters->nodes_any, st_any.nodes);
+        flush_counter(&B.counters->nodes_closest, st_cl.nodes);
+        flush_counter(&B.counters->tri_tests, (unsigned long long)st_any.tris + st_cl.tris);
+        flush_counter(&B.counters->tri_hits, (unsigned long long)st_any.tri_hits + st_cl.tri_hits);
+        flush_counter(&B.counters->sphere_tests, (unsigned long long)st_any.spheres + st_cl.spheres);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// radiance guards of SamplerIntegrator::Render (integrator.cpp:293-314) and the
+// luminance clamp of FilmTile::AddSample (film.h:157-158)
+DEV F3 guard_radiance(const DScene &S, F3 L) {
+    const float y = lum_y(L);
+    if (is_nan(L.x) || is_nan(L.y) || is_nan(L.z))
+        L = F3{0, 0, 0};
+    else if (double(y) < -1e-5)
+        L = F3{0, 0, 0};
+    else if (is_inf(y))
+        L = F3{0, 0, 0};
+    const float y2 = lum_y(L);
+    if (y2 > S.max_sample_luminance) L = L * (S.max_sample_luminance / y2);
+    return L;
+}
+
+// film_accumulate: one thread per owned pixel adds this pass's samples, in
+// sample order, to the pixel's RGB contribSum (FilmTile::AddSample, film.h:153-193
+// with the box filter: weight 1 for the pixel containing pFilm).
+__global__ __launch_bounds__(kBlock) void k_film_accumulate(DScene S, PassDesc P, PassBuffers B, FilmBuffers F) {
+    const uint32_t n_pix = uint32_t(P.n_owned_tiles) * 256u;
+    for (uint32_t pt = blockIdx.x * kBlock + threadIdx.x; pt < n_pix; pt += gridDim.x * kBlock) {
+        int px, py;
+        uint32_t k;
+        const uint32_t pid0 = pt * uint32_t(P.kc);
+        if (!path_pixel(S, P, pid0, &px, &py, &k)) continue;
+        float4 acc = F.tile_rgbw[pt];
+        for (int kk = 0; kk < P.kc; ++kk) {
+            const float4 L4 = B.L[pid0 + kk];
+            const F3 L = guard_radiance(S, F3{L4.x, L4.y, L4.z});
+            acc.x += L.x;
+            acc.y += L.y;
+            acc.z += L.z;
+            acc.w += 1.f;
+            if (P.k0 + kk == 0) {
+                // a sample whose fractional film offset is exactly 0 also lands in the
+                // left / upper neighbour (support ceil(pd-.5) .. floor(pd+.5))
+                const uint32_t idx = B.hindex[pid0 + kk];
+                uint32_t mask = 0;
+                if (sample_dimension(S, idx, 0) == 0.f) mask |= 1u;
+                if (sample_dimension(S, idx, 1) == 0.f) mask |= 2u;
+                F.k0_rgbv[pt] = make_float4(L.x, L.y, L.z, b2f(mask));
+            }
+        }
+        F.tile_rgbw[pt] = acc;
+    }
+}
+
+DEV bool tile_owned(const PassDesc &P, int tx, int ty, uint32_t *slot) {
+    if (tx < 0 || ty < 0 || tx >= P.n_tiles_x || ty >= P.n_tiles_y) return false;
+    const int t = ty * P.n_tiles_x + tx;
+    if (t % P.tile_nranks != P.tile_rank) return false;
+    *slot = uint32_t(t / P.tile_nranks);
+    return true;
+}
+DEV void add_xyz(float4 *out, float r, float g, float b, float w) {  // RGBToXYZ, spectrum.h:62-66
+    out->x += 0.412453f * r + 0.357580f * g + 0.180423f * b;
+    out->y += 0.212671f * r + 0.715160f * g + 0.072169f * b;
+    out->z += 0.019334f * r + 0.119193f * g + 0.950227f * b;
+    out->w += w;
+}
+
+// film_resolve: Film::MergeFilmTile (film.cpp:135-148) as a gather. For film
+// pixel Q the contributions are grouped by the tile whose FilmTile holds them
+// (Q's own tile, then the tiles right / below / diagonal whose k=0 samples
+// splat onto Q), each group summed in RGB in pixel order, converted to XYZ and
+// added in tile-index order.
+__global__ __launch_bounds__(kBlock) void k_film_resolve(DScene S, PassDesc P, FilmBuffers F) {
+    const int fw = S.crop_x1 - S.crop_x0, fh = S.crop_y1 - S.crop_y0;
+    const uint32_t n = uint32_t(fw) * uint32_t(fh);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int qx = S.crop_x0 + int(i % uint32_t(fw)), qy = S.crop_y0 + int(i / uint32_t(fw));
+        float4 out = make_float4(0, 0, 0, 0);
+        const int lx = qx - S.samp_x0, ly = qy - S.samp_y0;
+        const bool q_in = lx >= 0 && ly >= 0 && qx < S.samp_x1 && qy < S.samp_y1;
+        const int tx0 = lx >= 0 ? lx / kTile : -1, ty0 = ly >= 0 ? ly / kTile : -1;
+        const int tx1 = (lx + 1) >= 0 ? (lx + 1) / kTile : -1, ty1 = (ly + 1) >= 0 ? (ly + 1) / kTile : -1;
+        // sources: S1 = (qx+1, qy) needs mask bit0; S2 = (qx, qy+1) bit1; S3 = (qx+1, qy+1) both
+        auto source = [&](int sx, int sy, int tx, int ty, uint32_t need, float *r, float *g, float *b, float *w) {
+            if (sx >= S.samp_x1 || sy >= S.samp_y1 || sx < S.samp_x0 || sy < S.samp_y0) return;
+            uint32_t slot;
+            if (!tile_owned(P, tx, ty, &slot)) return;
+            const uint32_t pix = uint32_t((sy - S.samp_y0 - ty * kTile) * kTile + (sx - S.samp_x0 - tx * kTile));
+            const float4 v = F.k0_rgbv[slot * 256u + pix];
+            if ((f2b(v.w) & need) != need) return;
+            *r += v.x;
+            *g += v.y;
+            *b += v.z;
+            *w += 1.f;
+        };
+        // group 0: Q's own tile
+        {
+            uint32_t slot;
+            float r = 0, g = 0, b = 0, w = 0;
+            bool any = false;
+            if (q_in && tile_owned(P, tx0, ty0, &slot)) {
+                const float4 own = F.tile_rgbw[slot * 256u + uint32_t((ly - ty0 * kTile) * kTile + (lx - tx0 * kTile))];
+                r = own.x;
+                g = own.y;
+                b = own.z;
+                w = own.w;
+                any = true;
+                if (tx1 == tx0) source(qx + 1, qy, tx0, ty0, 1u, &r, &g, &b, &w);
+                if (ty1 == ty0) source(qx, qy + 1, tx0, ty0, 2u, &r, &g, &b, &w);
+                if (tx1 == tx0 && ty1 == ty0) source(qx + 1, qy + 1, tx0, ty0, 3u, &r, &g, &b, &w);
+            }
+            if (any) add_xyz(&out, r, g, b, w);
+        }
+        // group 1: tile to the right in the same tile row
+        if (tx1 != tx0 && ty0 >= 0) {
+            float r = 0, g = 0, b = 0, w = 0;
+            source(qx + 1, qy, tx1, ty0, 1u, &r, &g, &b, &w);
+            if (ty1 == ty0) source(qx + 1, qy + 1, tx1, ty0, 3u, &r, &g, &b, &w);
+            if (w > 0) add_xyz(&out, r, g, b, w);
+        }
+        // group 2: tile below in the same tile column
+        if (ty1 != ty0 && tx0 >= 0) {
+            float r = 0, g = 0, b = 0, w = 0;
+            source(qx, qy + 1, tx0, ty1, 2u, &r, &g, &b, &w);
+            if (tx1 == tx0) source(qx + 1, qy + 1, tx0, ty1, 3u, &r, &g, &b, &w);
+            if (w > 0) add_xyz(&out, r, g, b, w);
+        }
+        // group 3: diagonal tile
+        if (tx1 != tx0 && ty1 != ty0) {
+            float r = 0, g = 0, b = 0, w = 0;
+            source(qx + 1, qy + 1, tx1, ty1, 3u, &r, &g, &b, &w);
+            if (w > 0) add_xyz(&out, r, g, b, w);
+        }
+        F.film_xyzw[i] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel-level probes for parity tests
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace(DScene S, int n, const float4 *ro, const float4 *rd, float4 *hits,
+                                                  DCounters *counters, int *SPILL) {
+    __shared__ int lds_stack[kWavesPerBlock][kLdsStackDepth][64];
+    lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
+    const uint32_t spill_stride = gridDim.x * kBlock;
+    int *my_spill = SPILL + blockIdx.x * kBlock + threadIdx.x;
+    TraceStats st = {0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < uint32_t(n); i += gridDim.x * kBlock) {
+        const float4 o4 = ro[i], d4 = rd[i];
+        HitRec h;
+        h.t = h.b0 = h.b1 = h.b2 = 0;
+        const bool found = traverse<ANY, COUNT>(S, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, my_stack, my_spill,
+                                                spill_stride, &h, &st);
+        if (ANY) {
+            hits[2 * i] = make_float4(b2f(found ? 1u : 0u), 0, 0, 0);
+            hits[2 * i + 1] = make_float4(0, 0, 0, 0);
+        } else {
+            hits[2 * i] = make_float4(b2f(uint32_t(found ? h.prim : -1)), found ? h.t : 0.f, 0, 0);
+            hits[2 * i + 1] = make_float4(found ? h.b0 : 0.f, found ? h.b1 : 0.f, found ? h.b2 : 0.f, 0);
+        }
+    }
+    if (COUNT && counters) {
+        flush_counter(ANY ? &counters->nodes_any : &counters->nodes_closest, st.nodes);
+        flush_counter(&counters->tri_tests, st.tris);
+        flush_counter(&counters->tri_hits, st.tri_hits);
+        flush_counter(&counters->sphere_tests, st.spheres);
+    }
+}
+__global__ void k_halton(DScene S, int n, const int *px, const int *py, const int *k, int dim0, int ndims, float *out,
+                         uint32_t *index_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t idx = halton_index(S, px[i], py[i], uint32_t(k[i]));
+    if (index_out) index_out[i] = idx;
+    for (int d = 0; d < ndims; ++d) out[size_t(i) * ndims + d] = sample_dimension(S, idx, dim0 + d);
+}
+__global__ void k_camera(DScene S, int n, const float *pfilm, const float *plens, float *o, float *d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 ro, rd;
+    float tm;
+    camera_ray(S, pfilm[2 * i], pfilm[2 * i + 1], plens ? plens[2 * i] : 0.f, plens ? plens[2 * i + 1] : 0.f, &ro, &rd,
+               &tm);
+    o[3 * i] = ro.x;
+    o[3 * i + 1] = ro.y;
+    o[3 * i + 2] = ro.z;
+    d[3 * i] = rd.x;
+    d[3 * i + 1] = rd.y;
+    d[3 * i + 2] = rd.z;
+}
+// BSDF in a canonical frame (ns = ng = +z, ss = +x). sample == 0: out = {f.xyz, pdf}
+// for (wo, wi); sample == 1: out = {wi.xyz, f.xyz, pdf} for (wo, u).
+__global__ void k_bsdf_probe(DScene S, int n, int mat, const float *wo, const float *wi_or_u, int sample, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Isect is;
+    is.sn = F3{0, 0, 1};
+    is.n = F3{0, 0, 1};
+    is.sdpdu = F3{1, 0, 0};
+    is.p = is.perr = is.wo = F3{0, 0, 0};
+    Bsdf b = make_bsdf(S.materials[mat], is);
+    b.ss = F3{1, 0, 0};
+    b.ts = cross(b.ns, b.ss);
+    const F3 w = F3{wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]};
+    if (!sample) {
+        const F3 wi = F3{wi_or_u[3 * i], wi_or_u[3 * i + 1], wi_or_u[3 * i + 2]};
+        const F3 f = bsdf_f(b, w, wi);
+        out[4 * i] = f.x;
+        out[4 * i + 1] = f.y;
+        out[4 * i + 2] = f.z;
+        out[4 * i + 3] = bsdf_pdf(b, w, wi);
+    } else {
+        F3 wi = F3{0, 0, 0};
+        float pdf = 0;
+        const F3 f = bsdf_sample_f(b, w, &wi, wi_or_u[2 * i], wi_or_u[2 * i + 1], &pdf);
+        out[7 * i] = wi.x;
+        out[7 * i + 1] = wi.y;
+        out[7 * i + 2] = wi.z;
+        out[7 * i + 3] = f.x;
+        out[7 * i + 4] = f.y;
+        out[7 * i + 5] = f.z;
+        out[7 * i + 6] = pdf;
+    }
+}
+__global__ void k_trig_probe(int n, const float *x, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    sincos_f(x[i], &s, &c);
+    out[3 * i] = s;
+    out[3 * i + 1] = c;
+    out[3 * i + 2] = acos_f(clampf(x[i], -1.f, 1.f));
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+constexpr int kTraverseBlocksPerCu = 5;  // 32 KB of LDS stacks per block -> 5 blocks per 160 KB CU
+uint32_t max_traversal_threads(int n_cus) { return uint32_t(n_cus) * kTraverseBlocksPerCu * kBlock * kSpillStackDepth; }
+void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B,
+                       cfg.count_stats ? 1 : 0);
+}
+void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, kTraverseBlocksPerCu));
+    if (cfg.count_stats)
+        hipLaunchKernelGGL(k_extend<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+    else
+        hipLaunchKernelGGL(k_extend<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+}
+void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 4));
+    if (cfg.count_stats)
+        hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, max_rays);
+    else
+        hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, max_rays);
+}
+void launch_connect(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, kTraverseBlocksPerCu));
+    if (cfg.count_stats)
+        hipLaunchKernelGGL(k_connect<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, max_rays);
+    else
+        hipLaunchKernelGGL(k_connect<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, max_rays);
+}
+void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
+                            const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_film_accumulate, dim3(grid_blocks(uint32_t(P.n_owned_tiles) * 256u, cfg.n_cus, 8)),
+                       dim3(kBlock), 0, cfg.stream, S, P, B, F);
+}
+void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg) {
+    const uint32_t n = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0);
+    hipLaunchKernelGGL(k_film_resolve, dim3(grid_blocks(n, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, F);
+}
+void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, float4 *hits, int any_hit,
+                  DCounters *counters, int *spill, const LaunchCfg &cfg) {
+    const dim3 grid(grid_blocks(uint32_t(n), cfg.n_cus, kTraverseBlocksPerCu));
+    if (any_hit)
+        hipLaunchKernelGGL((k_trace<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, n, ro, rd, hits, counters,
+                           spill);
+    else
+        hipLaunchKernelGGL((k_trace<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, n, ro, rd, hits, counters,
+                           spill);
+}
+void launch_halton(const DScene &S, int n, const int *px, const int *py, const int *k, int dim0, int ndims,
+                   float *out, uint32_t *index_out, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_halton, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, S, n, px, py, k, dim0, ndims, out,
+                       index_out);
+}
+void launch_camera(const DScene &S, int n, const float *pfilm, const float *plens, float *o, float *d,
+                   const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_camera, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, S, n, pfilm, plens, o, d);
+}
+void launch_bsdf_probe(const DScene &S, int n, int mat, const float *wo, const float *wi_or_u, int sample,
+                       float *out, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_bsdf_probe, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, S, n, mat, wo, wi_or_u, sample,
+                       out);
+}
+void launch_trig_probe(int n, const float *x, float *out, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_trig_probe, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, n, x, out);
+}
+
+}  // namespace iile

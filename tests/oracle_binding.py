@@ -1,0 +1,153 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never by the product package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(REPO, "oracle", "_build", "liboracle.so")
+
+TRIG_LIBM, TRIG_PORTABLE = 0, 1
+
+c_vp = ctypes.c_void_p
+
+
+class OracleStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("camera_rays regular_rays shadow_rays tri_tests tri_hits sphere_tests "
+                                               "nodes_closest nodes_any nee_evals zero_radiance").split()] + [
+        ("path_length", ctypes.c_uint64 * 8), ("max_stack_depth", ctypes.c_int32), ("threads", ctypes.c_int32),
+        ("seconds", ctypes.c_double)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "path_length"}
+        d["path_length"] = list(self.path_length)
+        return d
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"{LIB} missing: run __graft_entry__.build()")
+        lib = ctypes.CDLL(LIB)
+        lib.oracle_render.argtypes = [c_vp] + [ctypes.c_int] * 6 + [c_vp, ctypes.POINTER(OracleStats)]
+        lib.oracle_halton_index.restype = ctypes.c_int64
+        lib.oracle_halton_index.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64]
+        lib.oracle_halton_sample.restype = ctypes.c_float
+        lib.oracle_halton_sample.argtypes = [c_vp, ctypes.c_int64, ctypes.c_int]
+        lib.oracle_radical_inverse.restype = ctypes.c_float
+        lib.oracle_radical_inverse.argtypes = [ctypes.c_int, ctypes.c_uint64]
+        lib.oracle_scrambled_radical_inverse.restype = ctypes.c_float
+        lib.oracle_scrambled_radical_inverse.argtypes = [c_vp, ctypes.c_int, ctypes.c_uint64]
+        lib.oracle_camera_ray.argtypes = [c_vp] + [ctypes.c_float] * 4 + [c_vp, c_vp]
+        lib.oracle_intersect.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
+        lib.oracle_intersect_p.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp]
+        lib.oracle_li.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
+        lib.oracle_bsdf_eval.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp]
+        lib.oracle_bsdf_sample.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
+        lib.oracle_sincos.argtypes = [ctypes.c_int, ctypes.c_float, c_vp, c_vp]
+        lib.oracle_sincos_d.argtypes = [ctypes.c_int, ctypes.c_double, c_vp, c_vp]
+        lib.oracle_acos.restype = ctypes.c_float
+        lib.oracle_acos.argtypes = [ctypes.c_int, ctypes.c_float]
+        self.lib = lib
+
+    def render(self, scene, trig_mode=TRIG_PORTABLE, threads=0, k_begin=0, k_end=-1, tile_rank=0, tile_nranks=1):
+        h, w = scene.film_shape
+        film = np.zeros((h, w, 4), np.float32)
+        st = OracleStats()
+        rc = self.lib.oracle_render(scene.desc, trig_mode, threads, k_begin, k_end, tile_rank, tile_nranks,
+                                    film.ctypes.data, ctypes.byref(st))
+        assert rc == 0
+        return film, st.as_dict()
+
+    def halton_index(self, scene, px, py, k):
+        return int(self.lib.oracle_halton_index(scene.desc, int(px), int(py), int(k)))
+
+    def halton_sample(self, scene, index, dim):
+        return np.float32(self.lib.oracle_halton_sample(scene.desc, int(index), int(dim)))
+
+    def radical_inverse(self, base_index, a):
+        return np.float32(self.lib.oracle_radical_inverse(int(base_index), int(a)))
+
+    def scrambled_radical_inverse(self, scene, base_index, a):
+        return np.float32(self.lib.oracle_scrambled_radical_inverse(scene.desc, int(base_index), int(a)))
+
+    def camera_rays(self, scene, pfilm, plens=None):
+        pfilm = _f32(pfilm)
+        n = len(pfilm)
+        o = np.empty((n, 3), np.float32)
+        d = np.empty((n, 3), np.float32)
+        for i in range(n):
+            lx, ly = (plens[i] if plens is not None else (0.0, 0.0))
+            self.lib.oracle_camera_ray(scene.desc, float(pfilm[i, 0]), float(pfilm[i, 1]), float(lx), float(ly),
+                                       o[i].ctypes.data, d[i].ctypes.data)
+        return o, d
+
+    def intersect(self, scene, o, d, tmax):
+        o, d, tmax = _f32(o), _f32(d), _f32(tmax)
+        n = len(tmax)
+        prim = np.empty(n, np.int32)
+        tb = np.empty((n, 4), np.float32)
+        self.lib.oracle_intersect(scene.desc, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, prim.ctypes.data,
+                                  tb.ctypes.data)
+        return prim, tb
+
+    def intersect_p(self, scene, o, d, tmax):
+        o, d, tmax = _f32(o), _f32(d), _f32(tmax)
+        n = len(tmax)
+        hit = np.empty(n, np.int32)
+        self.lib.oracle_intersect_p(scene.desc, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, hit.ctypes.data)
+        return hit
+
+    def li(self, scene, px, py, k, trig_mode=TRIG_PORTABLE):
+        px, py, k = _i32(px), _i32(py), _i32(k)
+        n = len(px)
+        L = np.empty((n, 3), np.float32)
+        nr = np.empty((n, 2), np.int32)
+        self.lib.oracle_li(scene.desc, trig_mode, n, px.ctypes.data, py.ctypes.data, k.ctypes.data, L.ctypes.data,
+                           nr.ctypes.data)
+        return L, nr
+
+    def bsdf_eval(self, scene, mat, wo, wi, trig_mode=TRIG_PORTABLE):
+        wo, wi = _f32(wo), _f32(wi)
+        out = np.empty((len(wo), 4), np.float32)
+        for i in range(len(wo)):
+            self.lib.oracle_bsdf_eval(scene.desc, trig_mode, mat, wo[i].ctypes.data, wi[i].ctypes.data,
+                                      out[i].ctypes.data, out[i, 3:].ctypes.data)
+        return out
+
+    def bsdf_sample(self, scene, mat, wo, u, trig_mode=TRIG_PORTABLE):
+        wo, u = _f32(wo), _f32(u)
+        out = np.zeros((len(wo), 7), np.float32)
+        for i in range(len(wo)):
+            self.lib.oracle_bsdf_sample(scene.desc, trig_mode, mat, wo[i].ctypes.data, u[i].ctypes.data,
+                                        out[i].ctypes.data, out[i, 3:].ctypes.data, out[i, 6:].ctypes.data)
+        return out
+
+    def sincos(self, x, trig_mode=TRIG_PORTABLE):
+        x = _f32(x)
+        out = np.empty((len(x), 2), np.float32)
+        for i in range(len(x)):
+            self.lib.oracle_sincos(trig_mode, float(x[i]), out[i].ctypes.data, out[i, 1:].ctypes.data)
+        return out
+
+    def sincos_d(self, x, trig_mode=TRIG_PORTABLE):
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.empty((len(x), 2), np.float64)
+        for i in range(len(x)):
+            self.lib.oracle_sincos_d(trig_mode, float(x[i]), out[i].ctypes.data, out[i, 1:].ctypes.data)
+        return out
+
+    def acos(self, x, trig_mode=TRIG_PORTABLE):
+        return np.array([self.lib.oracle_acos(trig_mode, float(v)) for v in _f32(x)], np.float32)

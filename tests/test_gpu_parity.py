@@ -1,0 +1,222 @@
+"""GPU parity: every stage of the HIP path against the CPU oracle, through the C ABI.
+
+The oracle runs in ORACLE_TRIG_PORTABLE mode, i.e. with the same double-precision
+sin/cos/acos evaluation the kernels use, so all comparisons are bit-exact
+(index / integer work) or bitwise on float32 (everything else). The tolerance
+north_star states for radiance (1e-4 relative) is therefore met with margin;
+tests that compare against the libm-mode oracle state their tolerance inline.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bitwise(a, b, what):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    same = bits(a) == bits(b)
+    # +0 / -0 and NaN payloads are not distinguished by the path
+    same |= (a == b) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"{what}: {int((~same).sum())} of {same.size} values differ, first at {np.argwhere(~same)[0]}"
+
+
+def test_device_present(binding):
+    assert binding.device_count() >= 1
+
+
+def test_trig_matches_oracle(binding, oracle):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-7, 7, 20000), rng.uniform(-1, 1, 20000), [0.0, 1.0, -1.0, 0.5, -0.5, 6.2831855]])
+    x = x.astype(np.float32)
+    dev = binding.trig_probe(x)
+    sc = oracle.sincos(x)
+    assert_bitwise(dev[:, 0], sc[:, 0], "sin")
+    assert_bitwise(dev[:, 1], sc[:, 1], "cos")
+    assert_bitwise(dev[:, 2], oracle.acos(np.clip(x, -1, 1)), "acos")
+
+
+def test_halton_matches_oracle(gpu_c1, scene_c1, oracle):
+    # pixels / sample numbers SURVEY.md §8c lists for the Halton capture
+    pix = [(0, 0), (5, 7), (127, 127), (128, 130), (399, 399), (255, 1), (17, 300)]
+    ks = [0, 1, 7]
+    px = np.array([p[0] for p in pix for _ in ks], np.int32)
+    py = np.array([p[1] for p in pix for _ in ks], np.int32)
+    k = np.array([kk for _ in pix for kk in ks], np.int32)
+    ndims = 42
+    dev, idx = gpu_c1.halton_samples(px, py, k, 0, ndims)
+    for i in range(len(px)):
+        ref_idx = oracle.halton_index(scene_c1, px[i], py[i], k[i])
+        assert int(idx[i]) == ref_idx
+        ref = np.array([oracle.halton_sample(scene_c1, ref_idx, d) for d in range(ndims)], np.float32)
+        assert_bitwise(dev[i], ref, f"halton pixel {pix[i // len(ks)]} k {k[i]}")
+
+
+def test_halton_reference_kat(gpu_c1):
+    # outputs of the reference recorded in SURVEY.md §8c (sampleBounds [0,400)^2)
+    dev, idx = gpu_c1.halton_samples([5, 5], [7, 7], [0, 1], 0, 10)
+    assert int(idx[0]) == 20304 and int(idx[1]) == 51408
+    want = np.array([0.47265625, 0.67078203, 0.130083218, 0.290784538, 0.161110461, 0.937937021, 0.528595328,
+                     0.759349823, 0.738907099, 0.000506668701], np.float32)
+    assert_bitwise(dev[0], want, "Halton KAT pixel (5,7) k=0")
+    assert_bitwise(dev[1, :2], np.array([0.537109375, 0.539094746], np.float32), "Halton KAT k=1")
+
+
+def test_camera_rays_match_oracle(gpu_c1, scene_c1, oracle):
+    rng = np.random.default_rng(2)
+    pf = np.stack([rng.uniform(0, 400, 1024), rng.uniform(0, 400, 1024)], 1).astype(np.float32)
+    pf[:4] = [[0, 0], [400, 400], [5.4726562, 7.670782], [200, 200]]
+    o, d = gpu_c1.camera_rays(pf)
+    ro, rd = oracle.camera_rays(scene_c1, pf)
+    assert_bitwise(o, ro, "camera origin")
+    assert_bitwise(d, rd, "camera direction")
+
+
+def _camera_and_random_rays(scene, oracle, n, seed):
+    rng = np.random.default_rng(seed)
+    h, w = scene.film_shape
+    pf = np.stack([rng.uniform(0, w, n // 2), rng.uniform(0, h, n // 2)], 1).astype(np.float32)
+    o1, d1 = oracle.camera_rays(scene, pf)
+    # rays from random points around the scene towards the killeroos / light
+    o2 = rng.uniform(-300, 300, (n - n // 2, 3)).astype(np.float32)
+    tgt = rng.uniform(-150, 150, (n - n // 2, 3)).astype(np.float32)
+    d2 = (tgt - o2).astype(np.float32)
+    o = np.concatenate([o1, o2]).astype(np.float32)
+    d = np.concatenate([d1, d2]).astype(np.float32)
+    tmax = np.full(n, np.inf, np.float32)
+    tmax[n // 2:] = rng.choice([np.inf, 1.0, 0.9999, 0.5], n - n // 2).astype(np.float32)
+    return o, d, tmax
+
+
+def test_closest_hit_matches_oracle(gpu_c1, scene_c1, oracle):
+    o, d, tmax = _camera_and_random_rays(scene_c1, oracle, 65536, 3)
+    prim, tb, st = gpu_c1.trace_closest(o, d, tmax)
+    rprim, rtb = oracle.intersect(scene_c1, o, d, tmax)
+    assert np.array_equal(prim, rprim), f"{int((prim != rprim).sum())} closest-hit primitives differ"
+    assert (prim >= 0).sum() > 10000
+    assert_bitwise(tb, rtb, "closest hit (t, b0, b1, b2)")
+
+
+def test_any_hit_matches_oracle(gpu_c1, scene_c1, oracle):
+    o, d, tmax = _camera_and_random_rays(scene_c1, oracle, 65536, 4)
+    hit, st = gpu_c1.trace_any(o, d, tmax)
+    rhit = oracle.intersect_p(scene_c1, o, d, tmax)
+    assert np.array_equal(hit, rhit)
+    assert 1000 < hit.sum() < len(hit)
+
+
+def test_bsdf_matches_oracle(gpu_c1, scene_c1, oracle):
+    rng = np.random.default_rng(5)
+    n = 4096
+
+    def dirs(m):
+        v = rng.normal(size=(m, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return v.astype(np.float32)
+
+    wo, wi = dirs(n), dirs(n)
+    wo[:8, 2] = [0, 1e-8, -1e-8, 1, -1, 0.99995, 0.5, -0.5]
+    u = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    u[:4] = [[0, 0], [0.99999994, 0.99999994], [0.5, 0.5], [0.49999997, 0.5]]
+    for mat in range(scene_c1.info["n_materials"]):
+        ev = gpu_c1.bsdf_eval(mat, wo, wi)
+        assert_bitwise(ev, oracle.bsdf_eval(scene_c1, mat, wo, wi), f"BSDF f/pdf material {mat}")
+        sm = gpu_c1.bsdf_sample(mat, wo, u)
+        assert_bitwise(sm, oracle.bsdf_sample(scene_c1, mat, wo, u), f"BSDF Sample_f material {mat}")
+
+
+def test_li_per_sample_matches_oracle(gpu_c1, scene_c1, oracle):
+    # all 8 samples of 256 pixels incl. silhouette / light / shadow-edge regions
+    rng = np.random.default_rng(6)
+    pix = np.stack([rng.integers(0, 400, 256), rng.integers(0, 400, 256)], 1)
+    px = np.repeat(pix[:, 0], 8).astype(np.int32)
+    py = np.repeat(pix[:, 1], 8).astype(np.int32)
+    k = np.tile(np.arange(8), 256).astype(np.int32)
+    L, nr = gpu_c1.li_samples(px, py, k)
+    rL, rnr = oracle.li(scene_c1, px, py, k)
+    assert np.array_equal(nr, rnr), "per-sample ray counts differ"
+    assert_bitwise(L, rL, "per-sample radiance")
+    assert (L > 0).any()
+
+
+def test_film_small_bitwise_and_counters(gpu_small, scene_small, oracle):
+    film, st = gpu_small.render(collect_stats=True, time_kernels=True)
+    ref, ost = oracle.render(scene_small)
+    assert_bitwise(film, ref, "film {X,Y,Z,w}")
+    assert st["camera_rays"] == ost["camera_rays"] == 160 * 120 * 4
+    assert st["closest_rays"] == ost["regular_rays"]
+    assert st["shadow_rays"] == ost["shadow_rays"]
+    assert st["tri_tests"] == ost["tri_tests"] and st["tri_hits"] == ost["tri_hits"]
+    assert st["nodes_closest"] == ost["nodes_closest"] and st["nodes_any"] == ost["nodes_any"]
+    assert st["nee_evals"] == ost["nee_evals"] and st["zero_radiance"] == ost["zero_radiance"]
+    assert st["path_length"] == ost["path_length"]
+    assert st["ms_extend"] > 0 and st["n_extend_launches"] == 6 * st["n_passes"]
+
+
+def test_film_c1_bitwise_vs_oracle_and_reference_pins(gpu_c1, scene_c1, oracle):
+    """BASELINE config 0 (400x400, 8 spp) end to end."""
+    film, st = gpu_c1.render(collect_stats=True)
+    ref, ost = oracle.render(scene_c1)
+    assert_bitwise(film, ref, "C1 film")
+    # ray counts of the device equal the portable-mode oracle's exactly ...
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    # ... and sit within a handful of flipped paths of the reference's own counts
+    # (5,509,699 + 2,009,697; the libm-mode oracle reproduces them exactly)
+    assert abs(st["closest_rays"] - 5509699) <= 64 and abs(st["shadow_rays"] - 2009697) <= 64
+    rgb = scene_c1.film_to_rgb(film)
+    mean = float(rgb.mean(dtype=np.float64))
+    assert abs(mean - 2.2752316) / 2.2752316 < 1e-5  # image-mean tolerance stated in SURVEY.md §7
+
+
+def test_film_c1_vs_libm_oracle_tolerance(gpu_c1, scene_c1, oracle):
+    """Against the oracle evaluated with the host libm (the mode pinned to the
+    reference): <= 1e-4 relative on >= 99.9 % of pixels, image mean within 1e-5."""
+    film, _ = gpu_c1.render()
+    ref, _ = oracle.render(scene_c1, trig_mode=ob.TRIG_LIBM)
+    a, b = scene_c1.film_to_rgb(film), scene_c1.film_to_rgb(ref)
+    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-6)
+    frac_bad = float((rel.max(axis=2) > 1e-4).mean())
+    assert frac_bad <= 1e-3, frac_bad
+    assert abs(a.mean(dtype=np.float64) - b.mean(dtype=np.float64)) / b.mean(dtype=np.float64) < 1e-5
+
+
+def test_passes_and_sample_split_are_equivalent(gpu_small, scene_small):
+    """The film is independent of how samples are chunked into wavefront passes."""
+    full, _ = gpu_small.render()
+    chunked, st = gpu_small.render(spp_per_pass=1)
+    assert st["n_passes"] == 4
+    assert_bitwise(chunked, full, "1 spp per pass vs one pass")
+
+
+def test_tile_sharding_sums_to_full_film(gpu_small, scene_small, oracle):
+    """Multi-GPU decomposition: rank r renders tiles t % n == r into a
+    full-resolution film; the sum over ranks equals the single-GPU film."""
+    full, _ = gpu_small.render()
+    for nranks in (2, 3, 8):
+        acc = np.zeros_like(full)
+        for r in range(nranks):
+            part, _ = gpu_small.render(tile_rank=r, tile_nranks=nranks)
+            ref_part, _ = oracle.render(scene_small, tile_rank=r, tile_nranks=nranks)
+            assert_bitwise(part, ref_part, f"shard {r}/{nranks}")
+            acc += part
+        # disjoint tiles: x + 0 is exact; only the k=0 halo splats add two non-zeros
+        assert np.allclose(acc, full, rtol=1e-6, atol=0)
+        assert np.array_equal(acc[..., 3], full[..., 3])
+
+
+def test_film_on_device_pointer(gpu_small, scene_small):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    h, w = scene_small.film_shape
+    film_t = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    _, st = gpu_small.render(film_device_ptr=film_t.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    host, _ = gpu_small.render()
+    assert_bitwise(film_t.cpu().numpy(), host, "device-resident film")
