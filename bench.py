@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s and samples/s of the HIP path tracer on killeroo-simple 1080p.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one complete pass of the hot path over the configured workload:
+SamplerIntegrator::Render of killeroo-simple at 1920x1080, 64*N pixel samples,
+16x16 tiles interleaved over the N ranks (one process per GPU; for N > 1 the
+driver launches this file through torch.distributed.run), finished by ONE
+sum-reduction of the {X,Y,Z,w} film to rank 0 over RCCL. Per-GPU work is fixed
+as N grows (each rank renders 1/N of the tiles at 64*N spp), so scaling is weak.
+The film stays in HBM for the whole timed region.
+
+Rank 0 prints one JSON line. `value` is whole-job Mray/s (rays = Scene::Intersect +
+Scene::IntersectP calls, the reference's own ray definition); `roofline` prices
+the dominant kernel against the HBM roof using SURVEY.md §8(d)'s algorithmic
+bytes per ray; `cpu_baseline` is the CPU oracle timed on this box's host cores on
+a bounded sample of the same workload (baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(rays, nodes, tris):
+    """B = 32 B per BVH node visited + 48 B per triangle test +
+    48 B of queue traffic per ray (32 B ray record in, 16 B hit record out)."""
+    return 32 * nodes + 48 * tris + 48 * rays
+
+
+def cpu_baseline(scene_path, xres, yres, target_seconds):
+    """Time the CPU oracle (restatement of the reference path, all host cores, 16x16
+    tile self-scheduling, render loop only) on a bounded number of pixel samples."""
+    import __graft_entry__ as ge
+    import oracle_binding as ob
+    b = ge._load_binding()
+    threads = os.cpu_count() or 1
+    scene = b.HostScene(path=scene_path, xres=xres, yres=yres, spp=64)
+    orc = ob.Oracle()
+    _, st = orc.render(scene, trig_mode=ob.TRIG_LIBM, threads=threads, k_begin=0, k_end=1)
+    t1 = max(st["seconds"], 1e-3)
+    n = int(max(1, min(16, round(target_seconds / t1))))
+    _, st = orc.render(scene, trig_mode=ob.TRIG_LIBM, threads=threads, k_begin=1, k_end=1 + n)
+    rays = st["regular_rays"] + st["shadow_rays"]
+    return {
+        "value": round(rays / st["seconds"] / 1e6, 3),
+        "unit": "Mray/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"killeroo-simple {xres}x{yres}, pixel samples k=1..{n} of 64 ({st['camera_rays']} camera samples, "
+                  f"{rays} rays, {st['seconds']:.2f} s, libm trig)",
+        "msamples_per_s": round(st["camera_rays"] / st["seconds"] / 1e6, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--xres", type=int, default=1920)
+    ap.add_argument("--yres", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64, help="pixel samples per GPU-equivalent (total = spp * gpus)")
+    ap.add_argument("--spp-per-pass", type=int, default=0)
+    ap.add_argument("--scene", default=os.path.join(REPO, "scenes", "killeroo-simple.pbrt"))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    ge.build_if_needed()
+    b = ge._load_binding()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    total_spp = args.spp * world
+    scene = b.HostScene(path=args.scene, xres=args.xres, yres=args.yres, spp=total_spp)
+    gpu = b.GpuScene(scene)
+    h, w = scene.film_shape
+    film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(collect=False, timed=False):
+        _, st = gpu.render(tile_rank=rank, tile_nranks=world, spp_per_pass=args.spp_per_pass, collect_stats=collect,
+                           time_kernels=timed, film_device_ptr=film.data_ptr(), stream=stream, want_stats=True)
+        if dist is not None:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # the one collective: film shards -> rank 0
+        return st
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # instrumented pass (untimed): ray / node / triangle counts of one step on this rank
+    cst = step(collect=True)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    agg = {"ms_extend": 0.0, "ms_connect": 0.0, "ms_shade": 0.0, "ms_generate": 0.0, "ms_film": 0.0, "ms_total": 0.0,
+           "n_extend_launches": 0, "n_connect_launches": 0}
+    for _ in range(args.steps):
+        st = step(timed=True)
+        for k in agg:
+            agg[k] += st[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        rays_closest, rays_shadow, cam = (int(x) for x in cnt.tolist())
+    else:
+        rays_closest, rays_shadow, cam = cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"]
+
+    if rank == 0:
+        rays_step = rays_closest + rays_shadow
+        ms_per_step = elapsed * 1e3 / args.steps
+        mray = rays_step * args.steps / elapsed / 1e6
+        # per-ray averages of this rank's instrumented step
+        r_all = cst["closest_rays"] + cst["shadow_rays"]
+        n_node = (cst["nodes_closest"] + cst["nodes_any"]) / max(r_all, 1)
+        n_tri = cst["tri_tests"] / max(r_all, 1)
+        b_ray = 32 * n_node + 48 * n_tri + 48
+        # dominant kernel by measured HIP-event time on this rank
+        ext_bytes = algorithmic_bytes(cst["ext_rays"], cst["ext_nodes"], cst["ext_tri_tests"])
+        con_rays = r_all - cst["ext_rays"]
+        con_bytes = algorithmic_bytes(con_rays, cst["nodes_closest"] + cst["nodes_any"] - cst["ext_nodes"],
+                                      cst["tri_tests"] - cst["ext_tri_tests"])
+        kernels = {
+            "k_extend": (agg["ms_extend"], agg["n_extend_launches"], ext_bytes, cst["ext_rays"]),
+            "k_connect": (agg["ms_connect"], agg["n_connect_launches"], con_bytes, con_rays),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms_k, n_launch, bytes_step, rays_k = kernels[dom]
+        launches_per_step = n_launch / args.steps
+        avg_ms = ms_k / max(n_launch, 1)
+        achieved = (bytes_step / launches_per_step) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mray/s on killeroo-simple 1080p (path integrator, rays = Scene::Intersect + IntersectP calls)",
+            "value": round(mray, 2),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "scenes/killeroo-simple.pbrt (the reference's shipped scene file); Halton samples generated "
+                    "on device",
+            "config": {
+                "workload": f"killeroo-simple {args.xres}x{args.yres}, {total_spp} spp ({args.spp} per GPU), "
+                            f"path maxdepth 5, halton, box filter, 16x16 tiles interleaved over {world} rank(s)",
+                "xres": args.xres, "yres": args.yres, "spp_total": total_spp, "spp_per_gpu": args.spp,
+                "passes_per_step": st["n_passes"],
+            },
+            "msamples_per_s": round(cam * args.steps / elapsed / 1e6, 3),
+            "rays_per_step": rays_step,
+            "camera_samples_per_step": cam,
+            "rays_per_camera_sample": round(rays_step / max(cam, 1), 4),
+            "n_node_per_ray": round(n_node, 3),
+            "n_tri_per_ray": round(n_tri, 4),
+            "b_ray_bytes": round(b_ray, 1),
+            "job_algorithmic_gbs": round(mray * 1e6 * b_ray / 1e9, 1),
+            "job_frac_of_hbm_roofline": round(mray * 1e6 * b_ray / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "kernel_ms_per_step_rank0": {k: round(agg[k] / args.steps, 3) for k in
+                                         ("ms_generate", "ms_extend", "ms_shade", "ms_connect", "ms_film", "ms_total")},
+            "roofline": {
+                "kernel": dom,
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "launches_per_step": launches_per_step,
+                "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": int(bytes_step / max(launches_per_step, 1)),
+                "rays_per_launch": int(rays_k / max(launches_per_step, 1)),
+                "note": "algorithmic bytes = 32 B/node visited + 48 B/triangle test + 48 B/ray queue traffic "
+                        "(SURVEY.md 8d); BVH+mesh (5.4 MB) are cache resident, so PMC-measured HBM bytes are far "
+                        "lower (see profiles/)",
+            },
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.xres, args.yres, args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = round(mray / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

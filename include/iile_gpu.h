@@ -74,6 +74,8 @@ typedef struct iile_stats {
     int32_t n_extend_launches, n_connect_launches, n_shade_launches, n_passes;
     uint64_t n_paths;             /* camera samples rendered by this call */
     uint64_t workspace_bytes;     /* HBM held by the wavefront queues */
+    /* the extend kernel alone (main-path closest-hit rays): inputs of its roofline */
+    uint64_t ext_rays, ext_nodes, ext_tri_tests, ext_sphere_tests;
 } iile_stats;
 
 int iile_device_count(void);

@@ -170,6 +170,10 @@ void copy_counters(const DCounters &c, iile_stats *st) {
     st->nee_evals = c.nee_evals;
     st->zero_radiance = c.zero_radiance;
     for (int i = 0; i < 8; ++i) st->path_length[i] = c.path_length[i];
+    st->ext_rays = c.ext_rays;
+    st->ext_nodes = c.ext_nodes;
+    st->ext_tri_tests = c.ext_tri_tests;
+    st->ext_sphere_tests = c.ext_sphere_tests;
 }
 
 // Enqueue one wavefront pass on cfg.stream.

@@ -85,6 +85,8 @@ struct DCounters {
     unsigned long long nodes_closest, nodes_any, tri_tests, tri_hits, sphere_tests;
     unsigned long long nee_evals, zero_radiance;
     unsigned long long path_length[8];
+    // the extend kernel alone (closest-hit rays of the main path), for its roofline
+    unsigned long long ext_rays, ext_nodes, ext_tri_tests, ext_sphere_tests;
 };
 
 }  // namespace iile

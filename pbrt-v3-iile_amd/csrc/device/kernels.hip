@@ -145,6 +145,10 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene S, PassBuffers B, int 
     }
     if (COUNT) {
         flush_counter(&B.counters->closest_rays, n_rays);
+        flush_counter(&B.counters->ext_rays, n_rays);
+        flush_counter(&B.counters->ext_nodes, st.nodes);
+        flush_counter(&B.counters->ext_tri_tests, st.tris);
+        flush_counter(&B.counters->ext_sphere_tests, st.spheres);
         flush_counter(&B.counters->nodes_closest, st.nodes);
         flush_counter(&B.counters->tri_tests, st.tris);
         flush_counter(&B.counters->tri_hits, st.tri_hits);
