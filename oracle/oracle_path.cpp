@@ -392,8 +392,8 @@ inline bool ef_quadratic(EFloat A, EFloat B, EFloat C, EFloat *t0, EFloat *t1) {
 }
 
 // ----------------------------------------------------------------------------
-// counters
-struct Counters {
+// counters (one per worker thread; padded so neighbours never share a cache line)
+struct alignas(128) Counters {
     uint64_t camera_rays = 0, regular_rays = 0, shadow_rays = 0, tri_tests = 0, tri_hits = 0,
              sphere_tests = 0, nodes_closest = 0, nodes_any = 0, nee_evals = 0, zero_radiance = 0;
     uint64_t path_length[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -301,18 +301,59 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         iile_scene_destroy(sc);
         return code;
     };
-    // nodes: the 32-byte LinearBVHNode image is already two float4s
-    static_assert(sizeof(iile_bvh_node) == 32, "node layout");
-    rc = upload(sc, reinterpret_cast<const float4 *>(d->nodes), size_t(d->n_nodes) * 2, &S.nodes);
-    if (rc) return bail(rc);
+    // BVH: re-pack the depth-first LinearBVHNode array (bvh.cpp:640-658) into wide
+    // interior records {children[0] box, children[1] box, refs, axis}. A reference is
+    // the interior record index, or ~firstPrimitive for a leaf child.
+    std::vector<uint32_t> last_in_leaf(size_t(d->n_prims), 0);
+    {
+        const int n = d->n_nodes;
+        std::vector<int> interior_id(size_t(std::max(n, 1)), -1);
+        int n_interior = 0;
+        for (int i = 0; i < n; ++i)
+            if (d->nodes[i].nprims == 0) interior_id[i] = n_interior++;
+        auto ref_of = [&](int node) -> int {
+            const iile_bvh_node &nd = d->nodes[node];
+            return nd.nprims == 0 ? interior_id[node] : ~nd.offset;
+        };
+        std::vector<float4> wide(4 * size_t(std::max(n_interior, 1)), make_float4(0, 0, 0, 0));
+        for (int i = 0; i < n; ++i) {
+            const iile_bvh_node &nd = d->nodes[i];
+            if (nd.nprims > 0) {
+                if (nd.offset < 0 || nd.offset + nd.nprims > d->n_prims) return bail(fail(IILE_ERR_ARG, "bad leaf range"));
+                last_in_leaf[size_t(nd.offset) + nd.nprims - 1] = 16u;
+                continue;
+            }
+            if (i + 1 >= n || nd.offset <= i || nd.offset >= n) return bail(fail(IILE_ERR_ARG, "bad BVH child index"));
+            const iile_bvh_node &a = d->nodes[i + 1], &b = d->nodes[nd.offset];
+            const int ra = ref_of(i + 1), rb = ref_of(nd.offset), meta = int(nd.axis);
+            float fa, fb, fm;
+            std::memcpy(&fa, &ra, 4);
+            std::memcpy(&fb, &rb, 4);
+            std::memcpy(&fm, &meta, 4);
+            float4 *w = &wide[4 * size_t(interior_id[i])];
+            w[0] = make_float4(a.bmin[0], a.bmin[1], a.bmin[2], a.bmax[0]);
+            w[1] = make_float4(a.bmax[1], a.bmax[2], b.bmin[0], b.bmin[1]);
+            w[2] = make_float4(b.bmin[2], b.bmax[0], b.bmax[1], b.bmax[2]);
+            w[3] = make_float4(fa, fb, fm, 0.f);
+        }
+        rc = upload(sc, wide.data(), wide.size(), &S.wide);
+        if (rc) return bail(rc);
+        if (n > 0) {
+            for (int c = 0; c < 3; ++c) {
+                S.root_box[c] = d->nodes[0].bmin[c];
+                S.root_box[3 + c] = d->nodes[0].bmax[c];
+            }
+            S.root_ref = ref_of(0);
+        }
+    }
     // primitives: gather into 48-byte vertex records + normal / uv records
     {
         const size_t n = size_t(d->n_prims);
-        std::vector<float4> verts(3 * n), norms(3 * n);
+        std::vector<float4> verts(3 * n + 3), norms(3 * n);  // one pad record, flagged last-in-leaf
         std::vector<float2> uvs(3 * n);
         for (size_t i = 0; i < n; ++i) {
             const float *p = d->tri_p + 9 * i, *nn = d->tri_n + 9 * i, *uv = d->tri_uv + 6 * i;
-            uint32_t w[3] = {d->prim_flags[i], uint32_t(d->prim_material[i]), uint32_t(d->prim_light[i])};
+            uint32_t w[3] = {d->prim_flags[i] | last_in_leaf[i], uint32_t(d->prim_material[i]), uint32_t(d->prim_light[i])};
             for (int k = 0; k < 3; ++k) {
                 float wf;
                 std::memcpy(&wf, &w[k], 4);
@@ -323,6 +364,12 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             if ((d->prim_flags[i] & IILE_PRIM_SPHERE) && (d->prim_light[i] >= 0) &&
                 d->lights[d->prim_light[i]].sphere != d->prim_shape[i])
                 return bail(fail(IILE_ERR_ARG, "light / sphere cross reference is inconsistent"));
+        }
+        {
+            const uint32_t last = 16u;
+            float lf;
+            std::memcpy(&lf, &last, 4);
+            verts[3 * n] = verts[3 * n + 1] = verts[3 * n + 2] = make_float4(0, 0, 0, lf);
         }
         rc = upload(sc, verts.data(), verts.size(), &S.tri_verts);
         if (rc) return bail(rc);

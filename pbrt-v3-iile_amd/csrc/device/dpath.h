@@ -253,6 +253,29 @@ DEV bool sphere_test(const DSphere &sp, F3 ro, F3 rd, float tmax, float *t_hit, 
         float dt = dot(vabs(d), oerr) / len2;
         o = o + d * dt;
     }
+    // Exact early-out on the value track of the interval arithmetic. Every EFloat
+    // keeps lo <= v <= hi, and `v` never depends on lo/hi, so
+    //   t0.v > tMax  =>  t0.hi > tMax   and   t1.v <= 0  =>  t1.lo <= 0,
+    // i.e. the reference's rejection `t0.UpperBound() > tMax || t1.LowerBound() <= 0`
+    // (sphere.cpp:72) is already decided. Shadow rays all end 1e-4 short of the
+    // light they aim at, so nearly every sphere test on this path leaves here
+    // without the ~40 next_up/next_down pairs of the interval track.
+    {
+        const float av = (d.x * d.x + d.y * d.y) + d.z * d.z;
+        const float bv = 2.f * ((d.x * o.x + d.y * o.y) + d.z * o.z);
+        const float cv = ((o.x * o.x + o.y * o.y) + o.z * o.z) - sp.radius * sp.radius;
+        const double discrim = (double)bv * (double)bv - 4. * (double)av * (double)cv;
+        if (discrim < 0.) return false;
+        const float root = float(sqrt(discrim));
+        const float qv = (bv < 0) ? -.5f * (bv - root) : -.5f * (bv + root);
+        float t0v = qv / av, t1v = cv / qv;
+        if (t0v > t1v) {
+            const float tmp = t0v;
+            t0v = t1v;
+            t1v = tmp;
+        }
+        if (t0v > tmax || t1v <= 0) return false;
+    }
     EF ox = ef(o.x, oerr.x), oy = ef(o.y, oerr.y), oz = ef(o.z, oerr.z);
     EF dx = ef(d.x, derr.x), dy = ef(d.y, derr.y), dz = ef(d.z, derr.z);
     EF a = dx * dx + dy * dy + dz * dz;
@@ -377,14 +400,33 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
 // ===========================================================================
 // BVH traversal (accelerators/bvh.cpp:662-738, core/geometry.h:1411-1438)
 // ===========================================================================
-// One ray per lane; the per-lane stack of node indices lives in LDS as
-// stack[level][lane] (64 dwords per level): lane l always hits bank l mod 32,
-// so pushes and pops are conflict-free whatever depth each lane is at.
+// Same tree, same visiting order and the same accept / reject decisions as the
+// reference, restructured for 64-lane wavefronts:
+//
+//  * "Wide" 64-byte interior records hold the boxes of BOTH children
+//    (children[0] = the node at i+1, children[1] = secondChildOffset), so one
+//    fetch resolves two of the reference's node visits and leaves need no node
+//    fetch at all (a leaf reference is ~firstPrimitive; the last primitive of a
+//    leaf carries a flag bit in its vertex record).
+//  * The near child is tested and entered at once. The far child's slab test
+//    does not depend on ray.tMax except for its final `tMin < ray.tMax`
+//    comparison (geometry.h:1437), so its tMin is cached on the stack and that
+//    one comparison is repeated at pop time against the tMax of that moment —
+//    the decision the reference takes when it visits the node later.
+//  * while-while: lanes first walk interior nodes (cheap iterations), then all
+//    lanes that reached a leaf run the triangle test together, instead of paying
+//    the triangle code on every iteration because some lane is at a leaf.
+//  * One ray per lane; per-lane stack of (ref, tMin) in LDS as stack[level][lane]
+//    (64 dwords per level): lane l always hits bank l mod 32, so pushes and pops
+//    are conflict-free whatever depth each lane is at. Levels >= kLdsStackDepth
+//    spill to an HBM column (the reference allows depth 64, bvh.cpp:670).
+//
 // LDS pointers carry their address space explicitly so that pushes and pops
 // compile to ds_write_b32 / ds_read_b32 (a generic pointer would go through flat_*).
 typedef __attribute__((address_space(3))) int lds_int;
-constexpr int kLdsStackDepth = 32;   // measured max depth on killeroo-simple: 19
-constexpr int kSpillStackDepth = 32; // reference allows 64 (bvh.cpp:670); levels 32..63 spill to HBM
+constexpr int kLdsStackDepth = 16;    // measured max depth on killeroo-simple: 19
+constexpr int kSpillStackDepth = 48;  // 16 + 48 = the reference's 64 entries
+constexpr int kStackWordsPerWave = 2 * kLdsStackDepth * 64;  // ref plane + tMin plane
 
 struct TraceStats {
     uint32_t nodes, tris, tri_hits, spheres;
@@ -395,104 +437,155 @@ struct HitRec {
     float t, b0, b1, b2;
 };
 
+// Bounds3::IntersectP(ray, invDir, dirIsNeg) without its final ray.tMax
+// comparison: returns whether the slabs overlap with tMax_box > 0 and the entry
+// distance tMin. The caller finishes with `tMin < ray.tMax`.
+DEV bool slab_entry(const RayCtx &rc, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
+                    float *tmin_out) {
+    const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
+    float tmin = ((nx ? bmaxx : bminx) - rc.o.x) * rc.inv_dir.x;
+    float tmx = ((nx ? bminx : bmaxx) - rc.o.x) * rc.inv_dir.x;
+    float tymin = ((ny ? bmaxy : bminy) - rc.o.y) * rc.inv_dir.y;
+    float tymax = ((ny ? bminy : bmaxy) - rc.o.y) * rc.inv_dir.y;
+    tmx *= kSlabScale;
+    tymax *= kSlabScale;
+    bool ok = !(tmin > tymax || tymin > tmx);
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmx) tmx = tymax;
+    float tzmin = ((nz ? bmaxz : bminz) - rc.o.z) * rc.inv_dir.z;
+    float tzmax = ((nz ? bminz : bmaxz) - rc.o.z) * rc.inv_dir.z;
+    tzmax *= kSlabScale;
+    ok = ok && !(tmin > tzmax || tzmin > tmx);
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmx) tmx = tzmax;
+    *tmin_out = tmin;
+    return ok && (tmx > 0);
+}
+
 template <bool ANY_HIT, bool COUNT>
 DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack, int *spill, uint32_t spill_stride,
                   HitRec *hit, TraceStats *st) {
-    // `spill` points at this lane's column of a [kSpillStackDepth][spill_stride]
-    // HBM array; it is only touched by trees deeper than the LDS stack.
+    // lds_stack -> this lane's column: ref plane at [level*64], tMin plane at
+    // [(kLdsStackDepth + level)*64]. spill -> this lane's HBM column, 2 ints per level.
     const RayCtx rc = make_ray_ctx(ro, rd);
-    int sp = 0, cur = 0;
     bool found = false;
     hit->prim = -1;
     if (S.n_nodes == 0) return false;
-    while (true) {
-        const float4 n0 = S.nodes[2 * cur], n1 = S.nodes[2 * cur + 1];
+    int sp = 0;
+    int cur;  // >= 0: wide interior record; < 0: leaf, ~cur = first primitive
+    bool have = false;
+    {
+        // the root is visited like any node: its own box against ray.tMax
+        float tmin;
         if (COUNT) ++st->nodes;
-        // Bounds3::IntersectP(ray, invDir, dirIsNeg): n0 = (min.xyz, max.x), n1 = (max.yz, offset, meta)
-        const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
-        float tmin = ((nx ? n0.w : n0.x) - rc.o.x) * rc.inv_dir.x;
-        float tmx = ((nx ? n0.x : n0.w) - rc.o.x) * rc.inv_dir.x;
-        float tymin = ((ny ? n1.x : n0.y) - rc.o.y) * rc.inv_dir.y;
-        float tymax = ((ny ? n0.y : n1.x) - rc.o.y) * rc.inv_dir.y;
-        tmx *= kSlabScale;
-        tymax *= kSlabScale;
-        bool overlap = !(tmin > tymax || tymin > tmx);
-        if (overlap) {
-            if (tymin > tmin) tmin = tymin;
-            if (tymax < tmx) tmx = tymax;
-            float tzmin = ((nz ? n1.y : n0.z) - rc.o.z) * rc.inv_dir.z;
-            float tzmax = ((nz ? n0.z : n1.y) - rc.o.z) * rc.inv_dir.z;
-            tzmax *= kSlabScale;
-            overlap = !(tmin > tzmax || tzmin > tmx);
-            if (overlap) {
-                if (tzmin > tmin) tmin = tzmin;
-                if (tzmax < tmx) tmx = tzmax;
-                overlap = (tmin < tmax) && (tmx > 0);
+        const bool ok = slab_entry(rc, S.root_box[0], S.root_box[1], S.root_box[2], S.root_box[3], S.root_box[4],
+                                   S.root_box[5], &tmin);
+        have = ok && (tmin < tmax);
+        cur = S.root_ref;
+    }
+    auto pop = [&]() {
+        // resume at the most recent deferred (far) child that still passes `tMin < ray.tMax`
+        have = false;
+        while (sp > 0) {
+            --sp;
+            int ref;
+            float tmin;
+            if (sp < kLdsStackDepth) {
+                ref = lds_stack[sp * 64];
+                tmin = __int_as_float(lds_stack[(kLdsStackDepth + sp) * 64]);
+            } else {
+                const size_t off = size_t(sp - kLdsStackDepth) * 2 * spill_stride;
+                ref = spill[off];
+                tmin = __int_as_float(spill[off + spill_stride]);
+            }
+            if (COUNT) ++st->nodes;
+            if (tmin < tmax) {
+                cur = ref;
+                have = true;
+                break;
             }
         }
-        if (overlap) {
-            const uint32_t meta = f2b(n1.w);
-            const int nprims = int(meta & 0xffffu);
-            const int offset = int(f2b(n1.z));
-            if (nprims > 0) {
-                for (int i = 0; i < nprims; ++i) {
-                    const int prim = offset + i;
-                    const float4 v0 = S.tri_verts[3 * size_t(prim)];
-                    const uint32_t flags = f2b(v0.w);
-                    if (flags & 1u) {
-                        if (COUNT) ++st->spheres;
-                        float t;
-                        F3 od, ph;
-                        if (sphere_test(S.spheres[S.prim_shape[prim]], ro, rd, tmax, &t, &od, &ph)) {
-                            if (ANY_HIT) return true;
-                            found = true;
-                            tmax = t;
-                            hit->prim = prim;
-                            hit->t = t;
-                            hit->b0 = hit->b1 = hit->b2 = 0;
-                        }
-                    } else {
-                        const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
-                        const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
-                        if (COUNT) ++st->tris;
-                        float t, b0, b1, b2;
-                        if (triangle_test(rc, tmax, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z},
-                                          F3{v2.x, v2.y, v2.z}, &t, &b0, &b1, &b2)) {
-                            if (COUNT) ++st->tri_hits;
-                            if (ANY_HIT) return true;
-                            found = true;
-                            tmax = t;
-                            hit->prim = prim;
-                            hit->t = t;
-                            hit->b0 = b0;
-                            hit->b1 = b1;
-                            hit->b2 = b2;
-                        }
-                    }
-                }
-                if (sp == 0) break;
-                --sp;
-                cur = (sp < kLdsStackDepth) ? lds_stack[sp * 64] : spill[size_t(sp - kLdsStackDepth) * spill_stride];
-            } else {
-                const int axis = int((meta >> 16) & 0xffu);
-                int push;
-                if ((rc.neg_mask >> axis) & 1) {
-                    push = cur + 1;
-                    cur = offset;
+    };
+    if (!have) return false;
+    while (have) {
+        // ---- interior phase ----
+        while (have && cur >= 0) {
+            // index clamped so that a load the compiler hoists above the loop test
+            // (observed with hipcc 7.2 on this loop nest) can never leave the array
+            const float4 *w = S.wide + 4 * size_t(cur < 0 ? 0 : cur);
+            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+            const int ref_a = __float_as_int(q3.x), ref_b = __float_as_int(q3.y);
+            const int axis = __float_as_int(q3.z) & 3;
+            // children[0] = (q0.xyz, q0.w q1.xy), children[1] = (q1.zw q2.x, q2.yzw)
+            float tmin_a, tmin_b;
+            const bool ok_a = slab_entry(rc, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, &tmin_a);
+            const bool ok_b = slab_entry(rc, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, &tmin_b);
+            // bvh.cpp:686-692: with a negative direction along the split axis the second
+            // child is nearer; the other one is deferred
+            const bool second_first = (rc.neg_mask >> axis) & 1;
+            const int near_ref = second_first ? ref_b : ref_a, far_ref = second_first ? ref_a : ref_b;
+            const bool near_ok = second_first ? ok_b : ok_a, far_ok = second_first ? ok_a : ok_b;
+            const float near_tmin = second_first ? tmin_b : tmin_a, far_tmin = second_first ? tmin_a : tmin_b;
+            if (COUNT || far_ok) {
+                // a far child whose slabs can never pass is only kept for the visit count
+                const float ft = far_ok ? far_tmin : IILE_INF;
+                if (sp < kLdsStackDepth) {
+                    lds_stack[sp * 64] = far_ref;
+                    lds_stack[(kLdsStackDepth + sp) * 64] = __float_as_int(ft);
                 } else {
-                    push = offset;
-                    cur = cur + 1;
+                    const size_t off = size_t(sp - kLdsStackDepth) * 2 * spill_stride;
+                    spill[off] = far_ref;
+                    spill[off + spill_stride] = __float_as_int(ft);
                 }
-                if (sp < kLdsStackDepth)
-                    lds_stack[sp * 64] = push;
-                else
-                    spill[size_t(sp - kLdsStackDepth) * spill_stride] = push;
                 ++sp;
             }
-        } else {
-            if (sp == 0) break;
-            --sp;
-            cur = (sp < kLdsStackDepth) ? lds_stack[sp * 64] : spill[size_t(sp - kLdsStackDepth) * spill_stride];
+            if (COUNT) ++st->nodes;
+            if (near_ok && near_tmin < tmax)
+                cur = near_ref;
+            else
+                pop();
+        }
+        // ---- leaf phase ----
+        if (have) {
+            int prim = cur < 0 ? ~cur : 0;  // clamped for the same reason; tri_verts has one pad record
+            bool last;
+            do {
+                const float4 v0 = S.tri_verts[3 * size_t(prim)];
+                const uint32_t flags = f2b(v0.w);
+                last = (flags & 16u) != 0;
+                if (flags & 1u) {
+                    if (COUNT) ++st->spheres;
+                    float t;
+                    F3 od, ph;
+                    if (sphere_test(S.spheres[S.prim_shape[prim]], ro, rd, tmax, &t, &od, &ph)) {
+                        if (ANY_HIT) return true;
+                        found = true;
+                        tmax = t;
+                        hit->prim = prim;
+                        hit->t = t;
+                        hit->b0 = hit->b1 = hit->b2 = 0;
+                    }
+                } else {
+                    const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
+                    const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
+                    if (COUNT) ++st->tris;
+                    float t, b0, b1, b2;
+                    if (triangle_test(rc, tmax, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, &t,
+                                      &b0, &b1, &b2)) {
+                        if (COUNT) ++st->tri_hits;
+                        if (ANY_HIT) return true;
+                        found = true;
+                        tmax = t;
+                        hit->prim = prim;
+                        hit->t = t;
+                        hit->b0 = b0;
+                        hit->b1 = b1;
+                        hit->b2 = b2;
+                    }
+                }
+                ++prim;
+            } while (!last);
+            pop();
         }
     }
     return found;

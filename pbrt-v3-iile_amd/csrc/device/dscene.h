@@ -1,8 +1,10 @@
 // dscene.h — device-resident scene layout (HBM) and queue records.
 //
 // Layout choices (DESIGN.md "Data layout in HBM"):
-//  * BVH nodes keep the reference's 32-byte LinearBVHNode (bvh.cpp:95-104) and
-//    are fetched as two 16-byte loads per lane.
+//  * The BVH keeps the reference's tree (bvh.cpp:640-658) but interior nodes are
+//    re-packed into 64-byte records holding both children's boxes; leaves have no
+//    record (a leaf reference is ~firstPrimitive, the last primitive of a leaf
+//    is flagged in its vertex record).
 //  * Triangle vertices are pre-gathered per primitive in BVH leaf order:
 //    3 x float4 = 48 contiguous bytes per triangle test, with the primitive's
 //    flags / material / light packed into the .w lanes, replacing the
@@ -45,7 +47,7 @@ constexpr int kMaxLights = 8;
 
 struct DScene {
     // HBM arrays
-    const float4 *nodes;      // 2 float4 per node
+    const float4 *wide;       // 4 float4 per interior node: both child boxes + child refs + split axis
     const float4 *tri_verts;  // 3 float4 per primitive: (p.xyz, w): w0=flags w1=material w2=light
     const float4 *tri_norms;  // 3 float4 per primitive: (n.xyz, uv.{x,y} spread over w)
     const float2 *tri_uv;     // 3 float2 per primitive
@@ -56,6 +58,8 @@ struct DScene {
     const DMaterial *materials;
     const DLight *lights;
     int n_nodes, n_prims, n_spheres, n_materials, n_lights, n_hdims;
+    float root_box[6];        // bounds of the root node (min.xyz, max.xyz)
+    int root_ref;             // >= 0: wide record; < 0: ~first primitive of a single-leaf tree
     // camera
     M44 raster_to_camera, camera_to_world;
     float lens_radius, focal_distance;

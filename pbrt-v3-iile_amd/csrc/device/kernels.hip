@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend(DScene S, PassBuffers B, int bounce) {
     int *const SPILL = B.spill;
-    __shared__ int lds_stack[kWavesPerBlock][kLdsStackDepth][64];
+    __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
     const uint32_t spill_stride = gridDim.x * kBlock;
     int *my_spill = SPILL + blockIdx.x * kBlock + threadIdx.x;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_connect(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     int *const SPILL = B.spill;
-    __shared__ int lds_stack[kWavesPerBlock][kLdsStackDepth][64];
+    __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
     const uint32_t spill_stride = gridDim.x * kBlock;
     int *my_spill = SPILL + blockIdx.x * kBlock + threadIdx.x;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(kBlock) void k_film_resolve(DScene S, PassDesc P, F
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace(DScene S, int n, const float4 *ro, const float4 *rd, float4 *hits,
                                                   DCounters *counters, int *SPILL) {
-    __shared__ int lds_stack[kWavesPerBlock][kLdsStackDepth][64];
+    __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
     const uint32_t spill_stride = gridDim.x * kBlock;
     int *my_spill = SPILL + blockIdx.x * kBlock + threadIdx.x;
@@ -636,7 +636,9 @@ __global__ void k_trig_probe(int n, const float *x, float *out) {
 // ---------------------------------------------------------------------------
 // launchers
 constexpr int kTraverseBlocksPerCu = 5;  // 32 KB of LDS stacks per block -> 5 blocks per 160 KB CU
-uint32_t max_traversal_threads(int n_cus) { return uint32_t(n_cus) * kTraverseBlocksPerCu * kBlock * kSpillStackDepth; }
+uint32_t max_traversal_threads(int n_cus) {
+    return uint32_t(n_cus) * kTraverseBlocksPerCu * kBlock * kSpillStackDepth * 2;  // (ref, tMin) per level
+}
 void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_generate, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B,
                        cfg.count_stats ? 1 : 0);
