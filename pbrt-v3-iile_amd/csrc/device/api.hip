@@ -93,9 +93,11 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
         sc->ws_paths = 0;
     }
     const size_t n = n_paths;
-    // L, beta, ray_o[2], ray_d[2], hits, nee[6]  -> 13 float4 planes; hindex; counts; counters
+    const size_t cap = queue_capacity(n_paths, sc->n_cus);
+    // per path: L, beta (float4), hindex; per queue slot: ray_o[2], ray_d[2], hits, nee[7] (float4), shade_q
     const size_t f4 = sizeof(float4);
-    size_t bytes = 13 * n * f4 + n * sizeof(uint32_t) + 64 * sizeof(uint32_t) + sizeof(DCounters) + 4096;
+    size_t bytes = 2 * n * f4 + n * sizeof(uint32_t) + 12 * cap * f4 + cap * sizeof(uint32_t) +
+                   128 * sizeof(uint32_t) + sizeof(DCounters) + 16384;
     void *blk = nullptr;
     HIP_TRY(hipMalloc(&blk, bytes));
     sc->ws_block = blk;
@@ -107,16 +109,18 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
         return r;
     };
     PassBuffers &B = sc->pb;
+    B.queue_cap = uint32_t(cap);
     B.L = reinterpret_cast<float4 *>(take(n * f4));
     B.beta = reinterpret_cast<float4 *>(take(n * f4));
-    B.ray_o[0] = reinterpret_cast<float4 *>(take(n * f4));
-    B.ray_o[1] = reinterpret_cast<float4 *>(take(n * f4));
-    B.ray_d[0] = reinterpret_cast<float4 *>(take(n * f4));
-    B.ray_d[1] = reinterpret_cast<float4 *>(take(n * f4));
-    B.hits = reinterpret_cast<float4 *>(take(n * f4));
-    B.nee = reinterpret_cast<float4 *>(take(6 * n * f4));
+    B.ray_o[0] = reinterpret_cast<float4 *>(take(cap * f4));
+    B.ray_o[1] = reinterpret_cast<float4 *>(take(cap * f4));
+    B.ray_d[0] = reinterpret_cast<float4 *>(take(cap * f4));
+    B.ray_d[1] = reinterpret_cast<float4 *>(take(cap * f4));
+    B.hits = reinterpret_cast<float4 *>(take(cap * f4));
+    B.nee = reinterpret_cast<float4 *>(take(7 * cap * f4));
     B.hindex = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
-    B.counts = reinterpret_cast<uint32_t *>(take(64 * sizeof(uint32_t)));
+    B.shade_q = reinterpret_cast<uint32_t *>(take(cap * sizeof(uint32_t)));
+    B.counts = reinterpret_cast<uint32_t *>(take(128 * sizeof(uint32_t)));
     B.counters = reinterpret_cast<DCounters *>(take(sizeof(DCounters)));
     B.nray_out = nullptr;
     B.spill = sc->spill;
@@ -180,7 +184,7 @@ void copy_counters(const DCounters &c, iile_stats *st) {
 int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed) {
     const DScene &S = sc->ds;
     PassBuffers &B = sc->pb;
-    HIP_TRY(hipMemsetAsync(B.counts, 0, 64 * sizeof(uint32_t), cfg.stream));
+    HIP_TRY(hipMemsetAsync(B.counts, 0, 128 * sizeof(uint32_t), cfg.stream));
     auto timed_launch = [&](int kind, auto &&fn) -> int {
         EventPair *ep = nullptr;
         if (timed) {
@@ -197,12 +201,12 @@ int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed
     // bounces 0 .. maxDepth: the path loop exits at `bounces >= maxDepth` after
     // intersecting (path.cpp:104), so maxDepth + 1 extend launches are needed
     for (int b = 0; b <= sc->max_depth; ++b) {
-        rc = timed_launch(1, [&] { launch_extend(S, B, b, P.n_paths, cfg); });
+        rc = timed_launch(1, [&] { launch_extend(S, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
-        rc = timed_launch(2, [&] { launch_shade(S, B, b, P.n_paths, cfg); });
+        rc = timed_launch(2, [&] { launch_shade(S, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (b < sc->max_depth) {
-            rc = timed_launch(3, [&] { launch_connect(S, B, b, P.n_paths, cfg); });
+            rc = timed_launch(3, [&] { launch_connect(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
         }
     }
@@ -523,6 +527,8 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (rank < 0 || rank >= nranks) return fail(IILE_ERR_ARG, "iile_render: tile_rank out of range");
     hipStream_t stream = static_cast<hipStream_t>(prm->stream);
     LaunchCfg cfg{sc->n_cus, stream, prm->collect_stats != 0};
+    if (const char *e = std::getenv("IILE_SCHED_K")) cfg.sched_k = atoi(e);
+    if (const char *e = std::getenv("IILE_TRAV_BLOCKS")) cfg.trav_blocks_per_cu = std::max(1, std::min(5, atoi(e)));
     const bool timed = prm->time_kernels != 0;
 
     PassDesc P;
@@ -536,12 +542,12 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (P.n_owned_tiles < 0) P.n_owned_tiles = 0;
     const uint64_t pix_slots = uint64_t(P.n_owned_tiles) * 256;
     const int n_samples = k_end - k_begin;
-    // samples per pass: bounded by the workspace budget (212 B per path)
+    // samples per pass: bounded by the workspace budget (~260 B per path incl. queue padding)
     int kc = prm->spp_per_pass;
     if (kc <= 0) {
         double budget_mb = 12288;
         if (const char *e = std::getenv("IILE_WORKSPACE_MB")) budget_mb = std::max(64.0, atof(e));
-        uint64_t max_paths = uint64_t(budget_mb * 1048576.0 / 212.0);
+        uint64_t max_paths = uint64_t(budget_mb * 1048576.0 / 260.0);
         max_paths = std::min<uint64_t>(max_paths, 0xfff00000ull);
         int kc_max = int(std::max<uint64_t>(1, max_paths / std::max<uint64_t>(1, pix_slots)));
         int n_passes = (n_samples + kc_max - 1) / kc_max;

@@ -154,30 +154,27 @@ DEV void camera_ray(const DScene &S, float pfx, float pfy, float lu0, float lu1,
 // ===========================================================================
 // ray / primitive tests
 // ===========================================================================
-struct RayCtx {  // per-ray constants of the watertight test (triangle.cpp:206-226)
-    F3 o, d;
-    int kx, ky, kz;
+struct RayCtx {  // per-ray constants of the watertight test (triangle.cpp:206-226) and the slab test
+    F3 o;
     float Sx, Sy, Sz;
     F3 inv_dir;
-    int neg_mask;
+    int neg_mask;  // bits 0..2: dirIsNeg[xyz] (bvh.cpp:667); bits 4..5: kz, the max-|d| axis
 };
 DEV float comp(F3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 DEV RayCtx make_ray_ctx(F3 o, F3 d) {
     RayCtx c;
     c.o = o;
-    c.d = d;
     F3 ad = vabs(d);
-    c.kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxDimension
-    c.kx = c.kz + 1;
-    if (c.kx == 3) c.kx = 0;
-    c.ky = c.kx + 1;
-    if (c.ky == 3) c.ky = 0;
-    float dx = comp(d, c.kx), dy = comp(d, c.ky), dz = comp(d, c.kz);
+    const int kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxDimension
+    // Permute(d, kx, ky, kz) with kx = kz+1, ky = kx+1 (mod 3)
+    const float dx = kz == 0 ? d.y : (kz == 1 ? d.z : d.x);
+    const float dy = kz == 0 ? d.z : (kz == 1 ? d.x : d.y);
+    const float dz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
     c.Sx = -dx / dz;
     c.Sy = -dy / dz;
     c.Sz = 1.f / dz;
     c.inv_dir = F3{1 / d.x, 1 / d.y, 1 / d.z};  // bvh.cpp:666
-    c.neg_mask = (c.inv_dir.x < 0 ? 1 : 0) | (c.inv_dir.y < 0 ? 2 : 0) | (c.inv_dir.z < 0 ? 4 : 0);
+    c.neg_mask = (c.inv_dir.x < 0 ? 1 : 0) | (c.inv_dir.y < 0 ? 2 : 0) | (c.inv_dir.z < 0 ? 4 : 0) | (kz << 4);
     return c;
 }
 
@@ -186,9 +183,14 @@ DEV RayCtx make_ray_ctx(F3 o, F3 d) {
 DEV bool triangle_test(const RayCtx &rc, float tmax, F3 p0, F3 p1, F3 p2, float *t_out, float *b0o, float *b1o,
                        float *b2o) {
     F3 a = p0 - rc.o, b = p1 - rc.o, c = p2 - rc.o;
-    float ax = comp(a, rc.kx), ay = comp(a, rc.ky), az = comp(a, rc.kz);
-    float bx = comp(b, rc.kx), by = comp(b, rc.ky), bz = comp(b, rc.kz);
-    float cx = comp(c, rc.kx), cy = comp(c, rc.ky), cz = comp(c, rc.kz);
+    const int kz = (rc.neg_mask >> 4) & 3;
+    // Permute(p, kx, ky, kz): kz == 0 -> (y,z,x); kz == 1 -> (z,x,y); kz == 2 -> (x,y,z)
+    float ax = kz == 0 ? a.y : (kz == 1 ? a.z : a.x), ay = kz == 0 ? a.z : (kz == 1 ? a.x : a.y),
+          az = kz == 0 ? a.x : (kz == 1 ? a.y : a.z);
+    float bx = kz == 0 ? b.y : (kz == 1 ? b.z : b.x), by = kz == 0 ? b.z : (kz == 1 ? b.x : b.y),
+          bz = kz == 0 ? b.x : (kz == 1 ? b.y : b.z);
+    float cx = kz == 0 ? c.y : (kz == 1 ? c.z : c.x), cy = kz == 0 ? c.z : (kz == 1 ? c.x : c.y),
+          cz = kz == 0 ? c.x : (kz == 1 ? c.y : c.z);
     ax += rc.Sx * az;
     ay += rc.Sy * az;
     bx += rc.Sx * bz;
@@ -462,133 +464,236 @@ DEV bool slab_entry(const RayCtx &rc, float bminx, float bminy, float bminz, flo
     return ok && (tmx > 0);
 }
 
+// Resumable traversal state of one lane. The persistent kernels keep a Trav per
+// lane and run the interior / leaf phases for the whole wavefront, refilling
+// lanes whose ray has finished; traverse() below is the single-ray wrapper.
+struct Trav {
+    RayCtx rc;
+    float tmax;
+    int cur;  // >= 0: wide interior record; < 0: leaf, ~cur = first primitive
+    int sp;
+    bool have;  // cur is a node that passed its box test and still has to be processed
+    int hit_prim;
+    float b0, b1, b2;  // barycentrics of the closest triangle hit (t itself is t.tmax)
+};
+struct StackRef {
+    lds_int *lds;          // this lane's LDS column: ref plane [level*64], tMin plane [(kLdsStackDepth+level)*64]
+    int *spill_base;       // HBM overflow: lane column = spill_base + spill_col, 2 ints per level
+    uint32_t spill_col;
+    uint32_t spill_stride;
+    DEV int *spill() const { return spill_base + spill_col; }
+};
+
+template <bool COUNT>
+DEV void trav_begin(const DScene &S, Trav &t, F3 ro, F3 rd, float tmax, TraceStats *st) {
+    t.rc = make_ray_ctx(ro, rd);
+    t.tmax = tmax;
+    t.sp = 0;
+    t.hit_prim = -1;
+    t.b0 = t.b1 = t.b2 = 0;
+    t.cur = S.root_ref;
+    t.have = false;
+    if (S.n_nodes == 0) return;
+    // the root is visited like any node: its own box against ray.tMax
+    float tmin;
+    if (COUNT) ++st->nodes;
+    const bool ok = slab_entry(t.rc, S.root_box[0], S.root_box[1], S.root_box[2], S.root_box[3], S.root_box[4],
+                               S.root_box[5], &tmin);
+    t.have = ok && (tmin < tmax);
+}
+
+// resume at the most recent deferred (far) child that still passes `tMin < ray.tMax`
+template <bool COUNT>
+DEV void trav_pop(Trav &t, const StackRef &sr, TraceStats *st) {
+    t.have = false;
+    while (t.sp > 0) {
+        --t.sp;
+        int ref;
+        float tmin;
+        if (t.sp < kLdsStackDepth) {
+            ref = sr.lds[t.sp * 64];
+            tmin = __int_as_float(sr.lds[(kLdsStackDepth + t.sp) * 64]);
+        } else {
+            const size_t off = size_t(t.sp - kLdsStackDepth) * 2 * sr.spill_stride;
+            ref = sr.spill()[off];
+            tmin = __int_as_float(sr.spill()[off + sr.spill_stride]);
+        }
+        if (COUNT) ++st->nodes;
+        if (tmin < t.tmax) {
+            t.cur = ref;
+            t.have = true;
+            break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Quad-cooperative record fetch. A lane needs the whole 64-byte record of ITS
+// node, but four dwordx4 loads per lane to one line cost four vector-L1 tag
+// lookups, the last three stalling behind the pending miss of the first
+// (rocprofv3: TCP_PENDING_STALL 70 % of kernel time, TD busy 90 %). Instead the
+// four lanes of a quad fetch the four records of the quad together: in round r
+// every lane j loads chunk j of the record lane r asked for — one coalesced
+// 64-byte request per record — and a 4x4 transpose through DPP quad_perm moves
+// hands each lane its own record. ALL lanes of the wavefront must execute this
+// (DPP reads from disabled lanes are undefined), so idle lanes pass record 0.
+template <int CTRL>
+DEV float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+DEV float4 dpp_f4(float4 v) {
+    return make_float4(dpp_f<CTRL>(v.x), dpp_f<CTRL>(v.y), dpp_f<CTRL>(v.z), dpp_f<CTRL>(v.w));
+}
+DEV float4 sel4(bool c, float4 a, float4 b) { return c ? a : b; }
+// in: r[i] on lane j = chunk j of the record requested by quad lane i; out: r[i] = chunk i of this lane's record
+DEV void quad_transpose(float4 &r0, float4 &r1, float4 &r2, float4 &r3) {
+    const int j = int(threadIdx.x) & 3;
+    const bool odd = (j & 1) != 0, hi = (j & 2) != 0;
+    float4 y;
+    y = dpp_f4<0xB1>(sel4(odd, r0, r1));  // quad_perm [1,0,3,2]
+    r0 = sel4(odd, y, r0);
+    r1 = sel4(odd, r1, y);
+    y = dpp_f4<0xB1>(sel4(odd, r2, r3));
+    r2 = sel4(odd, y, r2);
+    r3 = sel4(odd, r3, y);
+    y = dpp_f4<0x4E>(sel4(hi, r0, r2));  // quad_perm [2,3,0,1]
+    r0 = sel4(hi, y, r0);
+    r2 = sel4(hi, r2, y);
+    y = dpp_f4<0x4E>(sel4(hi, r1, r3));
+    r1 = sel4(hi, y, r1);
+    r3 = sel4(hi, r3, y);
+}
+DEV void quad_fetch_wide(const float4 *wide, int rec, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
+    const int j = int(threadIdx.x) & 3;
+    const int n0 = __builtin_amdgcn_mov_dpp(rec, 0x00, 0xf, 0xf, false);
+    const int n1 = __builtin_amdgcn_mov_dpp(rec, 0x55, 0xf, 0xf, false);
+    const int n2 = __builtin_amdgcn_mov_dpp(rec, 0xAA, 0xf, 0xf, false);
+    const int n3 = __builtin_amdgcn_mov_dpp(rec, 0xFF, 0xf, 0xf, false);
+    q0 = wide[4 * size_t(n0) + j];
+    q1 = wide[4 * size_t(n1) + j];
+    q2 = wide[4 * size_t(n2) + j];
+    q3 = wide[4 * size_t(n3) + j];
+    quad_transpose(q0, q1, q2, q3);
+}
+
+// one wide interior record (already fetched): two of the reference's node visits
+template <bool COUNT>
+DEV void trav_interior(Trav &t, const StackRef &sr, TraceStats *st, const float4 q0, const float4 q1, const float4 q2,
+                       const float4 q3) {
+    const int ref_a = __float_as_int(q3.x), ref_b = __float_as_int(q3.y);
+    const int axis = __float_as_int(q3.z) & 3;
+    // children[0] = (q0.xyz, q0.w q1.xy), children[1] = (q1.zw q2.x, q2.yzw)
+    float tmin_a, tmin_b;
+    const bool ok_a = slab_entry(t.rc, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, &tmin_a);
+    const bool ok_b = slab_entry(t.rc, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, &tmin_b);
+    // bvh.cpp:686-692: with a negative direction along the split axis the second
+    // child is nearer; the other one is deferred
+    const bool second_first = (t.rc.neg_mask >> axis) & 1;
+    const int near_ref = second_first ? ref_b : ref_a, far_ref = second_first ? ref_a : ref_b;
+    const bool near_ok = second_first ? ok_b : ok_a, far_ok = second_first ? ok_a : ok_b;
+    const float near_tmin = second_first ? tmin_b : tmin_a, far_tmin = second_first ? tmin_a : tmin_b;
+    if (COUNT || far_ok) {
+        // a far child whose slabs can never pass is only kept for the visit count
+        const float ft = far_ok ? far_tmin : IILE_INF;
+        if (t.sp < kLdsStackDepth) {
+            sr.lds[t.sp * 64] = far_ref;
+            sr.lds[(kLdsStackDepth + t.sp) * 64] = __float_as_int(ft);
+        } else {
+            const size_t off = size_t(t.sp - kLdsStackDepth) * 2 * sr.spill_stride;
+            sr.spill()[off] = far_ref;
+            sr.spill()[off + sr.spill_stride] = __float_as_int(ft);
+        }
+        ++t.sp;
+    }
+    if (COUNT) ++st->nodes;
+    if (near_ok && near_tmin < t.tmax)
+        t.cur = near_ref;
+    else
+        trav_pop<COUNT>(t, sr, st);
+}
+// Interior step for the whole wavefront (call from converged code): lanes with
+// `want` advance by one wide record.
+template <bool COUNT>
+DEV void wave_interior_step(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st, bool want) {
+    float4 q0, q1, q2, q3;
+    quad_fetch_wide(S.wide, want ? t.cur : 0, q0, q1, q2, q3);
+    if (want) trav_interior<COUNT>(t, sr, st, q0, q1, q2, q3);
+}
+
+// ray_d: the float4 record holding the ray direction — only the (rare) sphere
+// test needs it, so it is re-read there instead of living in registers.
+template <bool COUNT>
+DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st, const bool any_hit,
+                   const float4 *ray_d) {
+    int prim = t.cur < 0 ? ~t.cur : 0;  // clamped like trav_interior's index; tri_verts has one pad record
+    bool last;
+    do {
+        const float4 v0 = S.tri_verts[3 * size_t(prim)];
+        const uint32_t flags = f2b(v0.w);
+        last = (flags & 16u) != 0;
+        if (flags & 1u) {
+            if (COUNT) ++st->spheres;
+            float th;
+            F3 od, ph;
+            const float4 d4 = *ray_d;
+            if (sphere_test(S.spheres[S.prim_shape[prim]], t.rc.o, F3{d4.x, d4.y, d4.z}, t.tmax, &th, &od, &ph)) {
+                if (any_hit) {
+                    t.have = false;
+                    return true;
+                }
+                t.tmax = th;
+                t.hit_prim = prim;
+                t.b0 = t.b1 = t.b2 = 0;
+            }
+        } else {
+            const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
+            const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
+            if (COUNT) ++st->tris;
+            float th, b0, b1, b2;
+            if (triangle_test(t.rc, t.tmax, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, &th, &b0,
+                              &b1, &b2)) {
+                if (COUNT) ++st->tri_hits;
+                if (any_hit) {
+                    t.have = false;
+                    return true;
+                }
+                t.tmax = th;
+                t.hit_prim = prim;
+                t.b0 = b0;
+                t.b1 = b1;
+                t.b2 = b2;
+            }
+        }
+        ++prim;
+    } while (!last);
+    trav_pop<COUNT>(t, sr, st);
+    return false;
+}
+
+// single-ray wrapper (kernel-level probes)
 template <bool ANY_HIT, bool COUNT>
 DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack, int *spill, uint32_t spill_stride,
                   HitRec *hit, TraceStats *st) {
-    // lds_stack -> this lane's column: ref plane at [level*64], tMin plane at
-    // [(kLdsStackDepth + level)*64]. spill -> this lane's HBM column, 2 ints per level.
-    const RayCtx rc = make_ray_ctx(ro, rd);
-    bool found = false;
-    hit->prim = -1;
-    if (S.n_nodes == 0) return false;
-    int sp = 0;
-    int cur;  // >= 0: wide interior record; < 0: leaf, ~cur = first primitive
-    bool have = false;
-    {
-        // the root is visited like any node: its own box against ray.tMax
-        float tmin;
-        if (COUNT) ++st->nodes;
-        const bool ok = slab_entry(rc, S.root_box[0], S.root_box[1], S.root_box[2], S.root_box[3], S.root_box[4],
-                                   S.root_box[5], &tmin);
-        have = ok && (tmin < tmax);
-        cur = S.root_ref;
-    }
-    auto pop = [&]() {
-        // resume at the most recent deferred (far) child that still passes `tMin < ray.tMax`
-        have = false;
-        while (sp > 0) {
-            --sp;
-            int ref;
-            float tmin;
-            if (sp < kLdsStackDepth) {
-                ref = lds_stack[sp * 64];
-                tmin = __int_as_float(lds_stack[(kLdsStackDepth + sp) * 64]);
-            } else {
-                const size_t off = size_t(sp - kLdsStackDepth) * 2 * spill_stride;
-                ref = spill[off];
-                tmin = __int_as_float(spill[off + spill_stride]);
-            }
-            if (COUNT) ++st->nodes;
-            if (tmin < tmax) {
-                cur = ref;
-                have = true;
-                break;
-            }
-        }
-    };
-    if (!have) return false;
-    while (have) {
-        // ---- interior phase ----
-        while (have && cur >= 0) {
+    Trav t;
+    const StackRef sr{lds_stack, spill, 0u, spill_stride};
+    const float4 d4 = make_float4(rd.x, rd.y, rd.z, 0.f);
+    trav_begin<COUNT>(S, t, ro, rd, tmax, st);
+    while (t.have) {
+        while (t.have && t.cur >= 0) {
             // index clamped so that a load the compiler hoists above the loop test
             // (observed with hipcc 7.2 on this loop nest) can never leave the array
-            const float4 *w = S.wide + 4 * size_t(cur < 0 ? 0 : cur);
-            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
-            const int ref_a = __float_as_int(q3.x), ref_b = __float_as_int(q3.y);
-            const int axis = __float_as_int(q3.z) & 3;
-            // children[0] = (q0.xyz, q0.w q1.xy), children[1] = (q1.zw q2.x, q2.yzw)
-            float tmin_a, tmin_b;
-            const bool ok_a = slab_entry(rc, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, &tmin_a);
-            const bool ok_b = slab_entry(rc, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, &tmin_b);
-            // bvh.cpp:686-692: with a negative direction along the split axis the second
-            // child is nearer; the other one is deferred
-            const bool second_first = (rc.neg_mask >> axis) & 1;
-            const int near_ref = second_first ? ref_b : ref_a, far_ref = second_first ? ref_a : ref_b;
-            const bool near_ok = second_first ? ok_b : ok_a, far_ok = second_first ? ok_a : ok_b;
-            const float near_tmin = second_first ? tmin_b : tmin_a, far_tmin = second_first ? tmin_a : tmin_b;
-            if (COUNT || far_ok) {
-                // a far child whose slabs can never pass is only kept for the visit count
-                const float ft = far_ok ? far_tmin : IILE_INF;
-                if (sp < kLdsStackDepth) {
-                    lds_stack[sp * 64] = far_ref;
-                    lds_stack[(kLdsStackDepth + sp) * 64] = __float_as_int(ft);
-                } else {
-                    const size_t off = size_t(sp - kLdsStackDepth) * 2 * spill_stride;
-                    spill[off] = far_ref;
-                    spill[off + spill_stride] = __float_as_int(ft);
-                }
-                ++sp;
-            }
-            if (COUNT) ++st->nodes;
-            if (near_ok && near_tmin < tmax)
-                cur = near_ref;
-            else
-                pop();
+            const float4 *w = S.wide + 4 * size_t(t.cur < 0 ? 0 : t.cur);
+            trav_interior<COUNT>(t, sr, st, w[0], w[1], w[2], w[3]);
         }
-        // ---- leaf phase ----
-        if (have) {
-            int prim = cur < 0 ? ~cur : 0;  // clamped for the same reason; tri_verts has one pad record
-            bool last;
-            do {
-                const float4 v0 = S.tri_verts[3 * size_t(prim)];
-                const uint32_t flags = f2b(v0.w);
-                last = (flags & 16u) != 0;
-                if (flags & 1u) {
-                    if (COUNT) ++st->spheres;
-                    float t;
-                    F3 od, ph;
-                    if (sphere_test(S.spheres[S.prim_shape[prim]], ro, rd, tmax, &t, &od, &ph)) {
-                        if (ANY_HIT) return true;
-                        found = true;
-                        tmax = t;
-                        hit->prim = prim;
-                        hit->t = t;
-                        hit->b0 = hit->b1 = hit->b2 = 0;
-                    }
-                } else {
-                    const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
-                    const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
-                    if (COUNT) ++st->tris;
-                    float t, b0, b1, b2;
-                    if (triangle_test(rc, tmax, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, &t,
-                                      &b0, &b1, &b2)) {
-                        if (COUNT) ++st->tri_hits;
-                        if (ANY_HIT) return true;
-                        found = true;
-                        tmax = t;
-                        hit->prim = prim;
-                        hit->t = t;
-                        hit->b0 = b0;
-                        hit->b1 = b1;
-                        hit->b2 = b2;
-                    }
-                }
-                ++prim;
-            } while (!last);
-            pop();
-        }
+        if (t.have && trav_leaf<COUNT>(S, t, sr, st, ANY_HIT, &d4)) return true;
     }
-    return found;
+    hit->prim = t.hit_prim;
+    hit->t = t.tmax;
+    hit->b0 = t.b0;
+    hit->b1 = t.b1;
+    hit->b2 = t.b2;
+    return t.hit_prim >= 0;
 }
 
 // ===========================================================================

@@ -78,10 +78,10 @@ struct DScene {
 // queue records -------------------------------------------------------------
 // ray:  ro = (o.xyz, bitcast pid)   rd = (d.xyz, tmax)
 // hit:  (bitcast prim or -1, b0 | t, b1, b2)
-// NEE entry (6 float4, SoA of float4 planes):
+// NEE entry (7 float4 planes):
 //   n0 = (shadow o.xyz, bitcast pid)      n1 = (shadow d.xyz, bitcast flags)
-//   n2 = (mis o.xyz, A.x)                 n3 = (mis d.xyz, A.y)
-//   n4 = (B.xyz, A.z)                     n5 = (beta.xyz, bitcast light index)
+//   n2 = (mis o.xyz, bitcast light)       n3 = (mis d.xyz, -)
+//   n4 = (A.xyz, -)   n5 = (B.xyz, -)     n6 = (beta.xyz, -)
 enum { NEE_HAS_SHADOW = 1, NEE_HAS_MIS = 2 };
 
 struct DCounters {

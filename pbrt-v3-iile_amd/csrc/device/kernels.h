@@ -14,15 +14,19 @@ struct PassDesc {
     const int *list_px, *list_py, *list_k;
 };
 
+// Queue arrays (ray_o/ray_d/hits/shade_q/nee) hold `queue_cap` slots: the paths of a
+// pass plus the padding that block-reserved appends leave behind (kernels.hip).
 struct PassBuffers {
+    uint32_t queue_cap;
     float4 *L;          // [n_paths] radiance so far (xyz)
     float4 *beta;       // [n_paths] throughput (xyz), w = bitcast sampler dimension
     uint32_t *hindex;   // [n_paths] Halton index of the sample
     float4 *ray_o[2];   // ping-pong ray queues
     float4 *ray_d[2];
     float4 *hits;       // [n_paths]
-    float4 *nee;        // 6 planes of n_paths float4
-    uint32_t *counts;   // [0..15] ray-queue sizes per bounce, [16..31] NEE-queue sizes per bounce
+    float4 *nee;        // 7 planes of n_paths float4
+    uint32_t *shade_q;  // [n_paths] queue slots whose ray hit something (input of shade)
+    uint32_t *counts;   // 128 words: queue sizes and chunk cursors per bounce (layout in kernels.hip)
     DCounters *counters;
     uint32_t *nray_out; // optional [2*n_paths] per-path {closest, shadow} ray counts (tests)
     int *spill;         // [kSpillStackDepth][max grid threads] overflow of the LDS traversal stacks
@@ -38,8 +42,12 @@ struct LaunchCfg {
     int n_cus;
     hipStream_t stream;
     bool count_stats;
+    int sched_k = 2;              // connect: take an interior step when 4*n_interior >= sched_k*n_leaf
+    int trav_blocks_per_cu = 5;   // persistent traversal blocks per CU (5 x 32 KB of LDS stacks)
 };
 
+// slots a queue needs for n_paths paths
+uint32_t queue_capacity(uint32_t n_paths, int n_cus);
 void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg);
 void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);

@@ -16,6 +16,8 @@
 // All kernels are persistent grid-stride loops that read their queue length
 // from device memory, so a whole pass is enqueued without host synchronisation.
 // 64-lane wavefronts throughout: ballots are 64-bit, lane = threadIdx.x & 63.
+#include <algorithm>
+
 #include "dpath.h"
 #include "kernels.h"
 
@@ -41,6 +43,43 @@ DEV uint32_t wave_append(bool emit, uint32_t *counter) {
     base = __shfl(base, leader);
     return base + lanes_below(mask);
 }
+// Block-reserved queue output. A returning atomic on one queue-tail word per
+// wavefront per iteration saturates that word (~88 atomics/us on MI355X) long
+// before the kernels run out of anything else, so a wavefront instead reserves
+// kOutBlock slots at a time with ONE atomic and appends into its private block
+// (ballot + mbcnt, no memory traffic). Slots it cannot use — the < 64 left when a
+// block runs out, and the tail of its last block — are padded with an INVALID
+// record that consumers skip. The queue length a consumer sees is the number of
+// reserved slots.
+constexpr uint32_t kOutBlock = 1024;
+constexpr uint32_t kInvalid = 0xffffffffu;
+struct WaveOut {
+    uint32_t cur, end;
+};
+template <typename Pad>
+DEV uint32_t out_take(WaveOut &o, uint32_t *counter, bool emit, Pad pad) {
+    const unsigned long long mask = __ballot(emit);
+    const uint32_t n = uint32_t(__popcll(mask));
+    if (n == 0) return 0;
+    if (o.end - o.cur < n) {
+        const uint32_t left = o.end - o.cur;  // < n <= 64
+        if (uint32_t(lane_id()) < left) pad(o.cur + uint32_t(lane_id()));
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(counter, kOutBlock);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        o.cur = base;
+        o.end = base + kOutBlock;
+    }
+    const uint32_t slot = o.cur + lanes_below(mask);
+    o.cur += n;
+    return slot;
+}
+template <typename Pad>
+DEV void out_flush(WaveOut &o, Pad pad) {
+    for (uint32_t sl = o.cur + uint32_t(lane_id()); sl < o.end; sl += 64) pad(sl);
+    o.cur = o.end;
+}
+
 DEV unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
@@ -54,6 +93,48 @@ static inline int grid_blocks(uint32_t n, int n_cus, int per_cu) {
     long cap = long(n_cus) * per_cu;
     if (want < 1) want = 1;
     return int(want < cap ? want : cap);
+}
+
+// layout of PassBuffers::counts (zeroed once per pass)
+constexpr int kCntRay = 0;       // [bounce] rays in the extend queue
+constexpr int kCntNee = 16;      // [bounce] NEE records
+constexpr int kCntShade = 32;    // [bounce] hits to shade
+constexpr int kCntExtHead = 48;  // [bounce] chunk cursor of the extend queue
+constexpr int kCntConHead = 64;  // [bounce] chunk cursor of the NEE queue
+
+// Persistent-wavefront work feed. A wavefront reserves kChunk consecutive queue
+// slots with one atomic and hands them to its lanes as they go idle, so lanes
+// whose ray terminated early pick up new rays instead of waiting for the slowest
+// lane of the wavefront (the classic while-while + dynamic fetch scheme, sized
+// for 64 lanes). 512-slot chunks keep the head word at a few atomics per
+// microsecond, far below its ~88/us saturation point.
+constexpr uint32_t kChunk = 512;
+constexpr int kRefillIdle = 16;  // refill once this many lanes are idle (or all)
+struct WaveFeed {
+    uint32_t cur, end;
+    bool exhausted;
+};
+DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint32_t *slot) {
+    const unsigned long long mask = __ballot(idle);
+    const uint32_t n_idle = uint32_t(__popcll(mask));
+    if (f.cur == f.end) {
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(head, kChunk);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        if (base >= count) {
+            f.exhausted = true;
+            f.cur = f.end = 0;
+            return false;
+        }
+        f.cur = base;
+        f.end = (base + kChunk < count) ? base + kChunk : count;
+    }
+    const uint32_t avail = f.end - f.cur;
+    const uint32_t take = n_idle < avail ? n_idle : avail;
+    const uint32_t rank = lanes_below(mask);
+    *slot = f.cur + rank;
+    f.cur += take;
+    return idle && rank < take;
 }
 
 // pid -> (pixel, sample) for tile enumeration: pid = ((tile_slot*256 + pix)*kc + kk)
@@ -107,42 +188,81 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
         } else if (pid < P.n_paths) {
             B.L[pid] = make_float4(0, 0, 0, 0);
         }
-        const uint32_t slot = wave_append(valid, &B.counts[0]);
-        if (valid) {
-            B.ray_o[0][slot] = make_float4(o.x, o.y, o.z, b2f(pid));
-            B.ray_d[0][slot] = make_float4(d.x, d.y, d.z, tmax);
+        // queue 0 is dense (slot == pid); pixel slots outside the sample bounds are INVALID records
+        if (pid < P.n_paths) {
+            B.ray_o[0][pid] = make_float4(o.x, o.y, o.z, b2f(valid ? pid : kInvalid));
+            B.ray_d[0][pid] = make_float4(d.x, d.y, d.z, tmax);
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.counts[kCntRay] = P.n_paths;
     if (count_stats) flush_counter(&B.counters->camera_rays, n_cam);
 }
 
 // ---------------------------------------------------------------------------
-// extend: closest hit for every ray of queue `bounce & 1`.
+// extend: BVHAccel::Intersect for every ray of queue `bounce & 1`; hits are
+// appended (ballot-compacted) to the shade queue.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_extend(DScene S, PassBuffers B, int bounce) {
-    int *const SPILL = B.spill;
+__global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, int bounce, int sched_k) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
-    lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
-    const uint32_t spill_stride = gridDim.x * kBlock;
-    int *my_spill = SPILL + blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t count = B.counts[bounce];
+    const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
+                      blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    const uint32_t count = B.counts[kCntRay + bounce];
+    uint32_t *head = &B.counts[kCntExtHead + bounce];
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     TraceStats st = {0, 0, 0, 0};
-    unsigned long long n_rays = 0;
-    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
-        const uint32_t slot = base + threadIdx.x;
-        if (slot < count) {
-            const float4 o4 = ro[slot], d4 = rd[slot];
-            HitRec h;
-            traverse<false, COUNT>(S, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, my_stack, my_spill, spill_stride, &h,
-                                   &st);
-            B.hits[slot] = make_float4(b2f(uint32_t(h.prim)), h.b0, h.b1, h.b2);
-            if (COUNT) {
-                ++n_rays;
-                if (B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
+    unsigned long long n_rays = 0, n_term = 0;
+    WaveFeed feed{0, 0, count == 0};
+    WaveOut shade_out{0, 0};
+    auto pad_shade = [&](uint32_t sl) { B.shade_q[sl] = kInvalid; };
+    Trav t;
+    t.have = false;
+    t.cur = 0;
+    t.sp = 0;
+    t.hit_prim = -1;
+    bool active = false;
+    uint32_t slot = 0;
+    while (true) {
+        const unsigned long long idle_mask = __ballot(!active);
+        if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
+            uint32_t s_new;
+            if (feed_take(feed, head, count, !active, &s_new)) {
+                slot = s_new;
+                const float4 o4 = ro[slot], d4 = rd[slot];
+                if (f2b(o4.w) != kInvalid) {
+                    trav_begin<COUNT>(S, t, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, &st);
+                    active = true;
+                    if (COUNT) {
+                        ++n_rays;
+                        if (B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
+                    }
+                }
             }
         }
+        if (__ballot(active) == 0) {
+            if (feed.exhausted) break;
+            continue;
+        }
+        // while-while: every lane walks interior records until it stands at a leaf (or is
+        // done), then all lanes at a leaf run the primitive tests together. Main-path rays
+        // are coherent enough that this beats finer-grained phase scheduling (measured:
+        // 96 ms vs 180+ ms per 1080p/64spp step).
+        while (true) {
+            const bool want = active && t.have && t.cur >= 0;
+            if (__ballot(want) == 0) break;
+            wave_interior_step<COUNT>(S, t, sr, &st, want);
+        }
+        if (active && t.have) trav_leaf<COUNT>(S, t, sr, &st, false, &rd[slot]);
+        const bool fin = active && !t.have;
+        const bool is_hit = fin && t.hit_prim >= 0;
+        if (fin) {
+            B.hits[slot] = make_float4(b2f(uint32_t(t.hit_prim)), t.b0, t.b1, t.b2);
+            active = false;
+            if (COUNT && t.hit_prim < 0) ++n_term;  // the path left the scene: ReportValue(pathLength, bounces)
+        }
+        const uint32_t pos = out_take(shade_out, &B.counts[kCntShade + bounce], is_hit, pad_shade);
+        if (is_hit) B.shade_q[pos] = slot;
     }
+    out_flush(shade_out, pad_shade);
     if (COUNT) {
         flush_counter(&B.counters->closest_rays, n_rays);
         flush_counter(&B.counters->ext_rays, n_rays);
@@ -153,6 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene S, PassBuffers B, int 
         flush_counter(&B.counters->tri_tests, st.tris);
         flush_counter(&B.counters->tri_hits, st.tri_hits);
         flush_counter(&B.counters->sphere_tests, st.spheres);
+        flush_counter(&B.counters->path_length[bounce < 7 ? bounce : 7], n_term);
     }
 }
 
@@ -166,13 +287,17 @@ DEV F3 light_L(const DLight &lt, F3 n, F3 w) {
 // queue that extend just resolved.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int bounce, uint32_t plane) {
-    const uint32_t count = B.counts[bounce];
+    const uint32_t count = B.counts[kCntShade + bounce];
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     float4 *no = B.ray_o[(bounce + 1) & 1], *nd = B.ray_d[(bounce + 1) & 1];
     unsigned long long n_nee = 0, n_term = 0;
+    WaveOut ray_out{0, 0}, nee_out{0, 0};
+    auto pad_ray = [&](uint32_t sl) { no[sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
+    auto pad_nee = [&](uint32_t sl) { B.nee[plane + sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
     for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
-        const uint32_t slot = base + threadIdx.x;
-        const bool valid = slot < count;
+        const uint32_t qi = base + threadIdx.x;
+        const uint32_t slot = qi < count ? B.shade_q[qi] : kInvalid;
+        const bool valid = slot != kInvalid;
         bool alive = false, emit_nee = false;
         uint32_t pid = 0;
         F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
@@ -311,21 +436,24 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
                 ++n_term;
             }
         }
-        const uint32_t nslot = wave_append(alive, &B.counts[bounce + 1]);
+        const uint32_t nslot = out_take(ray_out, &B.counts[kCntRay + bounce + 1], alive, pad_ray);
         if (alive) {
             no[nslot] = make_float4(next_o.x, next_o.y, next_o.z, b2f(pid));
             nd[nslot] = make_float4(next_d.x, next_d.y, next_d.z, IILE_INF);
         }
-        const uint32_t eslot = wave_append(emit_nee, &B.counts[16 + bounce]);
+        const uint32_t eslot = out_take(nee_out, &B.counts[kCntNee + bounce], emit_nee, pad_nee);
         if (emit_nee) {
             B.nee[eslot] = make_float4(so.x, so.y, so.z, b2f(pid));
             B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
-            B.nee[2 * plane + eslot] = make_float4(mo.x, mo.y, mo.z, A.x);
-            B.nee[3 * plane + eslot] = make_float4(md.x, md.y, md.z, A.y);
-            B.nee[4 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, A.z);
-            B.nee[5 * plane + eslot] = make_float4(beta_nee.x, beta_nee.y, beta_nee.z, b2f(nee_light));
+            B.nee[2 * plane + eslot] = make_float4(mo.x, mo.y, mo.z, b2f(nee_light));
+            B.nee[3 * plane + eslot] = make_float4(md.x, md.y, md.z, 0.f);
+            B.nee[4 * plane + eslot] = make_float4(A.x, A.y, A.z, 0.f);
+            B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, 0.f);
+            B.nee[6 * plane + eslot] = make_float4(beta_nee.x, beta_nee.y, beta_nee.z, 0.f);
         }
     }
+    out_flush(ray_out, pad_ray);
+    out_flush(nee_out, pad_nee);
     if (COUNT) {
         flush_counter(&B.counters->nee_evals, n_nee);
         flush_counter(&B.counters->path_length[bounce < 7 ? bounce : 7], n_term);
@@ -334,63 +462,134 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
 
 // ---------------------------------------------------------------------------
 // connect: resolve the two rays of each NEE record and add beta * Ld to L.
+// A lane walks its record through stage 1 (shadow ray, BVHAccel::IntersectP) and
+// stage 2 (MIS ray, BVHAccel::Intersect), then takes the next record.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_connect(DScene S, PassBuffers B, int bounce, uint32_t plane) {
-    int *const SPILL = B.spill;
+__global__ __launch_bounds__(kBlock, 5) void k_connect(DScene S, PassBuffers B, int bounce, uint32_t plane, int sched_k) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
-    lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
-    const uint32_t spill_stride = gridDim.x * kBlock;
-    int *my_spill = SPILL + blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t count = B.counts[16 + bounce];
+    const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
+                      blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    const uint32_t count = B.counts[kCntNee + bounce];
+    uint32_t *head = &B.counts[kCntConHead + bounce];
     TraceStats st_any = {0, 0, 0, 0}, st_cl = {0, 0, 0, 0};
     unsigned long long n_shadow = 0, n_closest = 0, n_zero = 0;
-    for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
-        const uint32_t e = base + threadIdx.x;
-        if (e >= count) continue;
-        const float4 n0 = B.nee[e], n1 = B.nee[plane + e], n2 = B.nee[2 * plane + e], n3 = B.nee[3 * plane + e],
-                     n4 = B.nee[4 * plane + e], n5 = B.nee[5 * plane + e];
-        const uint32_t pid = f2b(n0.w), flags = f2b(n1.w);
-        const int li = int(f2b(n5.w));
-        F3 Ld = F3{0, 0, 0};
-        if (flags & NEE_HAS_SHADOW) {
-            HitRec h;
-            const bool occluded = traverse<true, COUNT>(S, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z},
-                                                        1 - kShadowEpsilon, my_stack, my_spill, spill_stride, &h, &st_any);
-            if (!occluded) Ld = Ld + F3{n2.w, n3.w, n4.w};
-            if (COUNT) {
-                ++n_shadow;
-                if (B.nray_out) B.nray_out[2 * pid + 1] += 1;
+    WaveFeed feed{0, 0, count == 0};
+    Trav t;
+    t.have = false;
+    t.cur = 0;
+    t.sp = 0;
+    t.hit_prim = -1;
+    bool active = false;
+    // per-lane record state is just the record index, the stage and two flags; everything
+    // else is re-read from the record when a stage ends (keeps the kernel at 5 waves/SIMD)
+    uint32_t e = 0;
+    int stage = 0;  // 1: shadow ray in flight, 2: MIS ray in flight, 3: nothing to trace
+    bool occluded = false, mis_lit = false;
+    auto begin_mis = [&]() {
+        const float4 n2 = B.nee[2 * plane + e], n3 = B.nee[3 * plane + e];
+        trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st_cl);
+        stage = 2;
+        if (COUNT) {
+            ++n_closest;
+            if (B.nray_out) B.nray_out[2 * f2b(B.nee[e].w)] += 1;
+        }
+    };
+    while (true) {
+        const unsigned long long idle_mask = __ballot(!active);
+        if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
+            uint32_t e_new;
+            if (feed_take(feed, head, count, !active, &e_new)) {
+                e = e_new;
+                const float4 n1 = B.nee[plane + e];
+                const uint32_t flags = f2b(n1.w);
+                occluded = false;
+                mis_lit = false;
+                active = flags != kInvalid;
+                t.have = false;
+                if (!active) {
+                    stage = 0;
+                } else if (flags & NEE_HAS_SHADOW) {
+                    const float4 n0 = B.nee[e];
+                    trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st_any);
+                    stage = 1;
+                    if (COUNT) {
+                        ++n_shadow;
+                        if (B.nray_out) B.nray_out[2 * f2b(n0.w) + 1] += 1;
+                    }
+                } else if (flags & NEE_HAS_MIS) {
+                    begin_mis();
+                } else
+                    stage = 3;
             }
         }
-        if (flags & NEE_HAS_MIS) {
-            HitRec h;
-            const F3 mo = F3{n2.x, n2.y, n2.z}, md = F3{n3.x, n3.y, n3.z};
-            const bool found = traverse<false, COUNT>(S, mo, md, IILE_INF, my_stack, my_spill, spill_stride, &h, &st_cl);
-            if (COUNT) {
-                ++n_closest;
-                if (B.nray_out) B.nray_out[2 * pid] += 1;
+        if (__ballot(active) == 0) {
+            if (feed.exhausted) break;
+            continue;
+        }
+        // Shadow and MIS rays of different records are incoherent: one step per iteration,
+        // interior or leaf, whichever keeps more lanes busy (measured 71 ms vs 80 ms for
+        // strict while-while on the 1080p/64spp step).
+        {
+            const bool wi = active && t.have && t.cur >= 0;
+            const bool wl = active && t.have && t.cur < 0;
+            const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
+            if (n_int > 0 && n_int * 4 >= n_leaf * sched_k) {
+                wave_interior_step<COUNT>(S, t, sr, stage == 1 ? &st_any : &st_cl, wi);
+            } else if (n_leaf > 0) {
+                if (wl && trav_leaf<COUNT>(S, t, sr, stage == 1 ? &st_any : &st_cl, stage == 1,
+                                         &B.nee[(stage == 1 ? 1u : 3u) * plane + e]))
+                    occluded = true;
             }
-            if (found) {
-                const float4 v0 = S.tri_verts[3 * size_t(h.prim)];
-                const float4 v2 = S.tri_verts[3 * size_t(h.prim) + 2];
-                // `lightIsect.primitive->GetAreaLight() == &light` (integrator.cpp:207)
-                if (int(f2b(v2.w)) == li && (f2b(v0.w) & 1u)) {
-                    const DSphere &sp = S.spheres[S.prim_shape[h.prim]];
-                    float t;
-                    F3 od, ph;
-                    Isect lis;
-                    sphere_test(sp, mo, md, IILE_INF, &t, &od, &ph);
-                    sphere_interaction(sp, od, ph, &lis);
-                    const DLight &lt = S.lights[li];
-                    if (lt.two_sided || dot(lis.n, -md) > 0) Ld = Ld + F3{n4.x, n4.y, n4.z};
+        }
+        if (active && !t.have) {
+            bool done = true;
+            if (stage == 1) {
+                if (f2b(B.nee[plane + e].w) & NEE_HAS_MIS) {
+                    begin_mis();
+                    done = false;
+                }
+            } else if (stage == 2) {
+                if (t.hit_prim >= 0) {
+                    const float4 v0 = S.tri_verts[3 * size_t(t.hit_prim)];
+                    const float4 v2 = S.tri_verts[3 * size_t(t.hit_prim) + 2];
+                    const int li = int(f2b(B.nee[2 * plane + e].w));
+                    // `lightIsect.primitive->GetAreaLight() == &light` (integrator.cpp:207)
+                    if (int(f2b(v2.w)) == li && (f2b(v0.w) & 1u)) {
+                        const DSphere &sp = S.spheres[S.prim_shape[t.hit_prim]];
+                        float th;
+                        F3 od, ph;
+                        Isect lis;
+                        const float4 d4 = B.nee[3 * plane + e];
+                        const F3 md = F3{d4.x, d4.y, d4.z};
+                        sphere_test(sp, t.rc.o, md, IILE_INF, &th, &od, &ph);
+                        sphere_interaction(sp, od, ph, &lis);
+                        const DLight &lt = S.lights[li];
+                        mis_lit = lt.two_sided || dot(lis.n, -md) > 0;
+                    }
                 }
             }
+            if (done) {
+                // Ld = [unoccluded light sample] + [MIS ray reached the light]; UniformSampleOneLight
+                // divides by lightPdf == 1; L += beta * Ld (integrator.cpp:150-158, 208-211; path.cpp:123-128)
+                const uint32_t flags = f2b(B.nee[plane + e].w);
+                F3 Ld = F3{0, 0, 0};
+                if ((flags & NEE_HAS_SHADOW) && !occluded) {
+                    const float4 a4 = B.nee[4 * plane + e];
+                    Ld = Ld + F3{a4.x, a4.y, a4.z};
+                }
+                if (mis_lit) {
+                    const float4 b4 = B.nee[5 * plane + e];
+                    Ld = Ld + F3{b4.x, b4.y, b4.z};
+                }
+                const float4 be = B.nee[6 * plane + e];
+                const F3 add = F3{be.x, be.y, be.z} * Ld;
+                if (COUNT && is_black(add)) ++n_zero;
+                const uint32_t pid = f2b(B.nee[e].w);
+                const float4 L4 = B.L[pid];
+                B.L[pid] = make_float4(L4.x + add.x, L4.y + add.y, L4.z + add.z, 0);
+                active = false;
+            }
         }
-        // UniformSampleOneLight divides by lightPdf == 1; L += beta * Ld (path.cpp:123-128)
-        const F3 add = F3{n5.x, n5.y, n5.z} * Ld;
-        if (COUNT && is_black(add)) ++n_zero;
-        float4 L4 = B.L[pid];
-        B.L[pid] = make_float4(L4.x + add.x, L4.y + add.y, L4.z + add.z, 0);
     }
     if (COUNT) {
         flush_counter(&B.counters->shadow_rays, n_shadow);
@@ -639,30 +838,36 @@ constexpr int kTraverseBlocksPerCu = 5;  // 32 KB of LDS stacks per block -> 5 b
 uint32_t max_traversal_threads(int n_cus) {
     return uint32_t(n_cus) * kTraverseBlocksPerCu * kBlock * kSpillStackDepth * 2;  // (ref, tMin) per level
 }
+uint32_t queue_capacity(uint32_t n_paths, int n_cus) {
+    // every wavefront that appends can leave < 64 slots per kOutBlock it fills plus one
+    // partly filled block behind
+    const uint64_t waves = std::min<uint64_t>(uint64_t(n_cus) * kTraverseBlocksPerCu * kWavesPerBlock, n_paths / 64 + 8);
+    return uint32_t(std::min<uint64_t>(uint64_t(n_paths) + n_paths / 8 + waves * kOutBlock, 0xffff0000ull));
+}
 void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_generate, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B,
                        cfg.count_stats ? 1 : 0);
 }
 void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, kTraverseBlocksPerCu));
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_extend<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+        hipLaunchKernelGGL(k_extend<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, cfg.sched_k);
     else
-        hipLaunchKernelGGL(k_extend<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+        hipLaunchKernelGGL(k_extend<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, cfg.sched_k);
 }
 void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 4));
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, max_rays);
+        hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     else
-        hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, max_rays);
+        hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
 }
 void launch_connect(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, kTraverseBlocksPerCu));
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_connect<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, max_rays);
+        hipLaunchKernelGGL(k_connect<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.sched_k);
     else
-        hipLaunchKernelGGL(k_connect<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, max_rays);
+        hipLaunchKernelGGL(k_connect<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.sched_k);
 }
 void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
                             const LaunchCfg &cfg) {
