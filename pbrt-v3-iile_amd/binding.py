@@ -97,7 +97,8 @@ def gpu_lib():
     """The HIP library. Fails loudly when it has not been built."""
     global _gpu
     if _gpu is None:
-        path = os.path.join(LIB_DIR, "libiile_gpu.so")
+        # IILE_GPU_LIB selects an alternative build of the same library (kernel A/B experiments)
+        path = os.environ.get("IILE_GPU_LIB") or os.path.join(LIB_DIR, "libiile_gpu.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension was not built; there is no CPU fallback "
                                "(run __graft_entry__.build())")

@@ -545,7 +545,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     // samples per pass: bounded by the workspace budget (~260 B per path incl. queue padding)
     int kc = prm->spp_per_pass;
     if (kc <= 0) {
-        double budget_mb = 12288;
+        double budget_mb = 49152;  // 48 GiB of the 288 GB: one pass covers 1080p x 64 spp
         if (const char *e = std::getenv("IILE_WORKSPACE_MB")) budget_mb = std::max(64.0, atof(e));
         uint64_t max_paths = uint64_t(budget_mb * 1048576.0 / 260.0);
         max_paths = std::min<uint64_t>(max_paths, 0xfff00000ull);

@@ -527,56 +527,6 @@ DEV void trav_pop(Trav &t, const StackRef &sr, TraceStats *st) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// Quad-cooperative record fetch. A lane needs the whole 64-byte record of ITS
-// node, but four dwordx4 loads per lane to one line cost four vector-L1 tag
-// lookups, the last three stalling behind the pending miss of the first
-// (rocprofv3: TCP_PENDING_STALL 70 % of kernel time, TD busy 90 %). Instead the
-// four lanes of a quad fetch the four records of the quad together: in round r
-// every lane j loads chunk j of the record lane r asked for — one coalesced
-// 64-byte request per record — and a 4x4 transpose through DPP quad_perm moves
-// hands each lane its own record. ALL lanes of the wavefront must execute this
-// (DPP reads from disabled lanes are undefined), so idle lanes pass record 0.
-template <int CTRL>
-DEV float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-DEV float4 dpp_f4(float4 v) {
-    return make_float4(dpp_f<CTRL>(v.x), dpp_f<CTRL>(v.y), dpp_f<CTRL>(v.z), dpp_f<CTRL>(v.w));
-}
-DEV float4 sel4(bool c, float4 a, float4 b) { return c ? a : b; }
-// in: r[i] on lane j = chunk j of the record requested by quad lane i; out: r[i] = chunk i of this lane's record
-DEV void quad_transpose(float4 &r0, float4 &r1, float4 &r2, float4 &r3) {
-    const int j = int(threadIdx.x) & 3;
-    const bool odd = (j & 1) != 0, hi = (j & 2) != 0;
-    float4 y;
-    y = dpp_f4<0xB1>(sel4(odd, r0, r1));  // quad_perm [1,0,3,2]
-    r0 = sel4(odd, y, r0);
-    r1 = sel4(odd, r1, y);
-    y = dpp_f4<0xB1>(sel4(odd, r2, r3));
-    r2 = sel4(odd, y, r2);
-    r3 = sel4(odd, r3, y);
-    y = dpp_f4<0x4E>(sel4(hi, r0, r2));  // quad_perm [2,3,0,1]
-    r0 = sel4(hi, y, r0);
-    r2 = sel4(hi, r2, y);
-    y = dpp_f4<0x4E>(sel4(hi, r1, r3));
-    r1 = sel4(hi, y, r1);
-    r3 = sel4(hi, r3, y);
-}
-DEV void quad_fetch_wide(const float4 *wide, int rec, float4 &q0, float4 &q1, float4 &q2, float4 &q3) {
-    const int j = int(threadIdx.x) & 3;
-    const int n0 = __builtin_amdgcn_mov_dpp(rec, 0x00, 0xf, 0xf, false);
-    const int n1 = __builtin_amdgcn_mov_dpp(rec, 0x55, 0xf, 0xf, false);
-    const int n2 = __builtin_amdgcn_mov_dpp(rec, 0xAA, 0xf, 0xf, false);
-    const int n3 = __builtin_amdgcn_mov_dpp(rec, 0xFF, 0xf, 0xf, false);
-    q0 = wide[4 * size_t(n0) + j];
-    q1 = wide[4 * size_t(n1) + j];
-    q2 = wide[4 * size_t(n2) + j];
-    q3 = wide[4 * size_t(n3) + j];
-    quad_transpose(q0, q1, q2, q3);
-}
-
 // one wide interior record (already fetched): two of the reference's node visits
 template <bool COUNT>
 DEV void trav_interior(Trav &t, const StackRef &sr, TraceStats *st, const float4 q0, const float4 q1, const float4 q2,
@@ -612,13 +562,16 @@ DEV void trav_interior(Trav &t, const StackRef &sr, TraceStats *st, const float4
     else
         trav_pop<COUNT>(t, sr, st);
 }
-// Interior step for the whole wavefront (call from converged code): lanes with
-// `want` advance by one wide record.
+// Interior step of one lane: fetch its 64-byte record (4 x dwordx4) and process it.
+// (A quad-cooperative fetch — four lanes loading one record per request and a DPP 4x4
+// transpose — was measured: it removes the vector-L1 pending-miss stalls but its
+// 64 extra VALU/DPP moves cost more than they save: 61 ms vs 49 ms per step.)
 template <bool COUNT>
-DEV void wave_interior_step(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st, bool want) {
-    float4 q0, q1, q2, q3;
-    quad_fetch_wide(S.wide, want ? t.cur : 0, q0, q1, q2, q3);
-    if (want) trav_interior<COUNT>(t, sr, st, q0, q1, q2, q3);
+DEV void trav_interior_step(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st) {
+    // index clamped so that a load the compiler hoists above the loop test
+    // (observed with hipcc 7.2 on this loop nest) can never leave the array
+    const float4 *w = S.wide + 4 * size_t(t.cur < 0 ? 0 : t.cur);
+    trav_interior<COUNT>(t, sr, st, w[0], w[1], w[2], w[3]);
 }
 
 // ray_d: the float4 record holding the ray direction — only the (rare) sphere
@@ -680,12 +633,7 @@ DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack,
     const float4 d4 = make_float4(rd.x, rd.y, rd.z, 0.f);
     trav_begin<COUNT>(S, t, ro, rd, tmax, st);
     while (t.have) {
-        while (t.have && t.cur >= 0) {
-            // index clamped so that a load the compiler hoists above the loop test
-            // (observed with hipcc 7.2 on this loop nest) can never leave the array
-            const float4 *w = S.wide + 4 * size_t(t.cur < 0 ? 0 : t.cur);
-            trav_interior<COUNT>(t, sr, st, w[0], w[1], w[2], w[3]);
-        }
+        while (t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, st);
         if (t.have && trav_leaf<COUNT>(S, t, sr, st, ANY_HIT, &d4)) return true;
     }
     hit->prim = t.hit_prim;

@@ -246,11 +246,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, i
         // done), then all lanes at a leaf run the primitive tests together. Main-path rays
         // are coherent enough that this beats finer-grained phase scheduling (measured:
         // 96 ms vs 180+ ms per 1080p/64spp step).
-        while (true) {
-            const bool want = active && t.have && t.cur >= 0;
-            if (__ballot(want) == 0) break;
-            wave_interior_step<COUNT>(S, t, sr, &st, want);
-        }
+        while (active && t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, &st);
         if (active && t.have) trav_leaf<COUNT>(S, t, sr, &st, false, &rd[slot]);
         const bool fin = active && !t.have;
         const bool is_hit = fin && t.hit_prim >= 0;
@@ -464,8 +460,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
 // connect: resolve the two rays of each NEE record and add beta * Ld to L.
 // A lane walks its record through stage 1 (shadow ray, BVHAccel::IntersectP) and
 // stage 2 (MIS ray, BVHAccel::Intersect), then takes the next record.
+#ifndef IILE_CONNECT_WAVES
+#define IILE_CONNECT_WAVES 5
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, 5) void k_connect(DScene S, PassBuffers B, int bounce, uint32_t plane, int sched_k) {
+__global__ __launch_bounds__(kBlock, IILE_CONNECT_WAVES) void k_connect(DScene S, PassBuffers B, int bounce, uint32_t plane, int sched_k) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -534,7 +533,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_connect(DScene S, PassBuffers B, 
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * 4 >= n_leaf * sched_k) {
-                wave_interior_step<COUNT>(S, t, sr, stage == 1 ? &st_any : &st_cl, wi);
+                if (wi) trav_interior_step<COUNT>(S, t, sr, stage == 1 ? &st_any : &st_cl);
             } else if (n_leaf > 0) {
                 if (wl && trav_leaf<COUNT>(S, t, sr, stage == 1 ? &st_any : &st_cl, stage == 1,
                                          &B.nee[(stage == 1 ? 1u : 3u) * plane + e]))
