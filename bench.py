@@ -100,12 +100,21 @@ def main():
     film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("iile_multigpu", os.path.join(REPO, "pbrt-v3-iile_amd", "multigpu.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+
     def step(collect=False, timed=False):
-        _, st = gpu.render(tile_rank=rank, tile_nranks=world, spp_per_pass=args.spp_per_pass, collect_stats=collect,
-                           time_kernels=timed, film_device_ptr=film.data_ptr(), stream=stream, want_stats=True)
-        if dist is not None:
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)  # the one collective: film shards -> rank 0
-        return st
+        box = {}
+
+        def render(tile_rank, tile_nranks):
+            _, box["st"] = gpu.render(tile_rank=tile_rank, tile_nranks=tile_nranks, spp_per_pass=args.spp_per_pass,
+                                      collect_stats=collect, time_kernels=timed, film_device_ptr=film.data_ptr(),
+                                      stream=stream, want_stats=True)
+
+        mg.render_sharded(render, film, dist)  # N > 1: one sum-reduction of the film shards to rank 0 (RCCL)
+        return box["st"]
 
     def barrier():
         if dist is not None:

@@ -57,6 +57,8 @@ int64_t oracle_halton_index(const iile_scene_desc *scene, int px, int py, int64_
 float oracle_halton_sample(const iile_scene_desc *scene, int64_t index, int dim);
 float oracle_radical_inverse(int base_index, uint64_t a);
 float oracle_scrambled_radical_inverse(const iile_scene_desc *scene, int base_index, uint64_t a);
+/* same function with a caller-supplied digit permutation of `base` entries */
+float oracle_scrambled_radical_inverse_perm(int base, const uint16_t *perm, uint64_t a);
 void oracle_camera_ray(const iile_scene_desc *scene, float pfilm_x, float pfilm_y, float plens_x,
                        float plens_y, float *o3, float *d3);
 /* closest hit for n rays: prim[i] = -1 on miss; tb[4*i..] = {t, b0, b1, b2}

@@ -1580,6 +1580,9 @@ float oracle_scrambled_radical_inverse(const iile_scene_desc *scene, int base_in
     const iile_halton &h = scene->halton;
     return Oracle::scrambled_radical_inverse(h.primes[base_index], h.perms + h.prime_sums[base_index], a);
 }
+float oracle_scrambled_radical_inverse_perm(int base, const uint16_t *perm, uint64_t a) {
+    return Oracle::scrambled_radical_inverse(base, perm, a);
+}
 void oracle_camera_ray(const iile_scene_desc *scene, float pfx, float pfy, float plx, float ply, float *o3, float *d3) {
     Counters c;
     Oracle o(*scene, ORACLE_TRIG_PORTABLE, &c);

@@ -283,7 +283,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         if (d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC)
             return fail(IILE_ERR_UNSUPPORTED, "unsupported material type");
     if (d->halton.n_dims > kMaxHaltonDims) return fail(IILE_ERR_UNSUPPORTED, "too many Halton dimensions");
-    const int need_dims = 5 + 7 * d->integrator.max_depth + 1;
+    const int need_dims = 5 + 8 * d->integrator.max_depth + 1;
     if (d->halton.n_dims < need_dims) return fail(IILE_ERR_ARG, "Halton table covers too few dimensions for maxdepth");
     if (d->integrator.max_depth > 14) return fail(IILE_ERR_UNSUPPORTED, "maxdepth > 14");
     if ((double(d->halton.spp) + 1) * double(d->halton.sample_stride) >= 4294967296.0)

@@ -49,9 +49,10 @@ uint64_t multiplicative_inverse(int64_t a, int64_t n) {
 // (core/lowdiscrepancy.cpp:2490-2504, core/sampling.h:150-157). The reference
 // shuffles all 1000 prime bases from one default-seeded PCG32 stream; the
 // stream is consumed base by base, so a prefix of the bases yields a prefix of
-// the table. PathIntegrator with maxdepth d touches 5 + 7*d + 1 dimensions.
+// the table. PathIntegrator with maxdepth d touches at most 5 + 8*d dimensions
+// (7 per bounce plus one Russian-roulette sample per bounce past the third).
 void build_halton_tables(HostScene *scene) {
-    const int n_dims = std::max(64, 5 + 7 * (scene->max_depth + 1) + 2);
+    const int n_dims = std::max(64, 5 + 8 * (scene->max_depth + 1) + 2);
     scene->primes.clear();
     scene->prime_sums.clear();
     int sum = 0;

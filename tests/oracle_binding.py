@@ -50,6 +50,8 @@ class Oracle:
         lib.oracle_radical_inverse.argtypes = [ctypes.c_int, ctypes.c_uint64]
         lib.oracle_scrambled_radical_inverse.restype = ctypes.c_float
         lib.oracle_scrambled_radical_inverse.argtypes = [c_vp, ctypes.c_int, ctypes.c_uint64]
+        lib.oracle_scrambled_radical_inverse_perm.restype = ctypes.c_float
+        lib.oracle_scrambled_radical_inverse_perm.argtypes = [ctypes.c_int, c_vp, ctypes.c_uint64]
         lib.oracle_camera_ray.argtypes = [c_vp] + [ctypes.c_float] * 4 + [c_vp, c_vp]
         lib.oracle_intersect.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
         lib.oracle_intersect_p.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp]
@@ -82,6 +84,10 @@ class Oracle:
 
     def scrambled_radical_inverse(self, scene, base_index, a):
         return np.float32(self.lib.oracle_scrambled_radical_inverse(scene.desc, int(base_index), int(a)))
+
+    def scrambled_radical_inverse_perm(self, base, perm, a):
+        perm = np.ascontiguousarray(perm, np.uint16)
+        return np.float32(self.lib.oracle_scrambled_radical_inverse_perm(int(base), perm.ctypes.data, int(a)))
 
     def camera_rays(self, scene, pfilm, plens=None):
         pfilm = _f32(pfilm)

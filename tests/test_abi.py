@@ -1,0 +1,61 @@
+"""The two C-ABI libraries load without a GPU and export every symbol include/*.h declares."""
+import ctypes
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(REPO, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(iile_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_host_library_exports_every_declared_symbol(binding):
+    lib = binding.host_lib()
+    names = declared_functions("iile_host.h")
+    assert sorted(names) == sorted(binding.HOST_SYMBOLS)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_gpu_library_exports_every_declared_symbol(binding):
+    lib = binding.gpu_lib()  # loading needs no GPU
+    names = declared_functions("iile_gpu.h")
+    assert sorted(names) == sorted(binding.GPU_SYMBOLS)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_struct_sizes_match_headers(binding):
+    # layouts the Python side mirrors (kept in sync with include/*.h by hand)
+    assert ctypes.sizeof(binding.FilmDesc) == 14 * 4
+    assert ctypes.sizeof(binding.HostOverrides) == 16
+    assert ctypes.sizeof(binding.RenderParams) == 8 * 4 + 8
+    assert ctypes.sizeof(binding.GpuStats) == 10 * 8 + 8 * 8 + 6 * 8 + 4 * 4 + 2 * 8 + 4 * 8
+
+
+def test_no_cpu_fallback(binding, scene_small):
+    """Without a GPU the product fails loudly instead of computing on the CPU."""
+    if binding.device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is visible")
+    import pytest
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        binding.GpuScene(scene_small)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under the package or include/ may include,
+    link, load or call it (prose mentions in comments are fine)."""
+    bad = []
+    for root in ("pbrt-v3-iile_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if f.endswith((".so", ".o", ".pyc")):
+                    continue
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r'#include\s*[<"][^>"]*oracle|liboracle|oracle_binding|\boracle_[a-z_]+\s*\(|import oracle', txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

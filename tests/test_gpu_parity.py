@@ -185,6 +185,21 @@ def test_film_c1_vs_libm_oracle_tolerance(gpu_c1, scene_c1, oracle):
     assert abs(a.mean(dtype=np.float64) - b.mean(dtype=np.float64)) / b.mean(dtype=np.float64) < 1e-5
 
 
+def test_furnace_scene_on_device(binding, oracle):
+    """Analytic furnace scene of src/tests/analytic_scenes.cpp: exercises shading ON the
+    emitting sphere, light sampling from inside the sphere and maxdepth 8 (Russian roulette
+    on several bounces). Mean radiance 1.0 +- 0.02, and bitwise equal to the oracle."""
+    import os
+    scene = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_area.pbrt"))
+    gpu = binding.GpuScene(scene)
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(scene)
+    assert_bitwise(film, ref, "furnace film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["path_length"] == ost["path_length"]
+    assert abs(float(scene.film_to_rgb(film).mean(dtype=np.float64)) - 1.0) < 0.02
+
+
 def test_passes_and_sample_split_are_equivalent(gpu_small, scene_small):
     """The film is independent of how samples are chunked into wavefront passes."""
     full, _ = gpu_small.render()

@@ -1,0 +1,116 @@
+"""Host-side scene preparation (libiile_host): parser, Loop subdivision, SAH BVH,
+Halton tables, camera — against facts recorded from the reference."""
+import ctypes
+
+import numpy as np
+
+
+class BvhNode(ctypes.Structure):
+    _fields_ = [("bmin", ctypes.c_float * 3), ("bmax", ctypes.c_float * 3), ("offset", ctypes.c_int32),
+                ("nprims", ctypes.c_uint16), ("axis", ctypes.c_uint8), ("pad", ctypes.c_uint8)]
+
+
+class SceneHead(ctypes.Structure):
+    """Leading fields of iile_scene_desc (include/iile_scene.h)."""
+    _fields_ = [("n_nodes", ctypes.c_int32), ("nodes", ctypes.POINTER(BvhNode)), ("n_prims", ctypes.c_int32),
+                ("prim_flags", ctypes.POINTER(ctypes.c_uint32)), ("prim_material", ctypes.POINTER(ctypes.c_int32)),
+                ("prim_light", ctypes.POINTER(ctypes.c_int32)), ("prim_shape", ctypes.POINTER(ctypes.c_int32)),
+                ("tri_p", ctypes.POINTER(ctypes.c_float)), ("tri_n", ctypes.POINTER(ctypes.c_float)),
+                ("tri_uv", ctypes.POINTER(ctypes.c_float))]
+
+
+def head(scene):
+    return ctypes.cast(scene.desc, ctypes.POINTER(SceneHead)).contents
+
+
+def test_killeroo_counts_match_reference(scene_c1):
+    i = scene_c1.info
+    # reference probe: 59 188 interior + 59 189 leaf nodes, 66 533 primitives
+    assert (i["n_interior_nodes"], i["n_leaf_nodes"], i["n_nodes"]) == (59188, 59189, 118377)
+    assert (i["n_prims"], i["n_triangles"], i["n_spheres"], i["n_meshes"]) == (66533, 66532, 1, 4)
+    assert (i["n_lights"], i["n_materials"]) == (1, 4)
+    assert ctypes.sizeof(BvhNode) == 32
+
+
+def test_bvh_is_depth_first_and_consistent(scene_c1):
+    h = head(scene_c1)
+    n = h.n_nodes
+    nodes = np.ctypeslib.as_array(ctypes.cast(h.nodes, ctypes.POINTER(ctypes.c_uint8)), (n * 32,)).view(
+        np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("nprims", "<u2"), ("axis", "u1"),
+                  ("pad", "u1")]))
+    interior = nodes["nprims"] == 0
+    idx = np.arange(n)
+    # flattenBVHTree: first child at i+1, second child after the first subtree
+    assert (nodes["offset"][interior] > idx[interior] + 1).all() and (nodes["offset"][interior] < n).all()
+    assert (nodes["axis"][interior] < 3).all()
+    # children's boxes lie inside the parent's
+    for child in (idx[interior] + 1, nodes["offset"][interior]):
+        assert (nodes["bmin"][child] >= nodes["bmin"][interior]).all()
+        assert (nodes["bmax"][child] <= nodes["bmax"][interior]).all()
+    # leaves partition the primitive array
+    leaves = nodes[~interior]
+    covered = np.zeros(h.n_prims, np.int32)
+    for off, cnt in zip(leaves["offset"], leaves["nprims"]):
+        covered[off:off + cnt] += 1
+    assert (covered == 1).all()
+    assert leaves["nprims"].max() <= 4  # maxnodeprims default (bvh.cpp:758)
+    # leaf boxes bound their triangles
+    tri = np.ctypeslib.as_array(h.tri_p, (h.n_prims, 3, 3))
+    flags = np.ctypeslib.as_array(h.prim_flags, (h.n_prims,))
+    for nd in leaves[:2000]:
+        for p in range(nd["offset"], nd["offset"] + nd["nprims"]):
+            if flags[p] & 1:
+                continue
+            assert (tri[p] >= nd["bmin"] - 0).all() and (tri[p] <= nd["bmax"] + 0).all()
+
+
+def test_primitive_attributes(scene_c1):
+    h = head(scene_c1)
+    flags = np.ctypeslib.as_array(h.prim_flags, (h.n_prims,))
+    light = np.ctypeslib.as_array(h.prim_light, (h.n_prims,))
+    sphere = (flags & 1) != 0
+    assert sphere.sum() == 1 and light[sphere][0] == 0 and (light[~sphere] == -1).all()
+    # the two killeroo meshes carry vertex normals (Loop subdivision), the two quads carry uv
+    assert ((flags & 2) != 0).sum() == 2 * 33264
+    assert ((flags & 4) != 0).sum() == 4
+
+
+def test_film_and_sample_bounds(scene_c1, binding):
+    f = scene_c1.film
+    assert (f.xres, f.yres) == (400, 400)
+    assert (f.crop_x0, f.crop_y0, f.crop_x1, f.crop_y1) == (0, 0, 400, 400)
+    assert (f.samp_x0, f.samp_y0, f.samp_x1, f.samp_y1) == (0, 0, 400, 400)  # box filter radius 0.5
+    big = binding.HostScene(xres=1920, yres=1080, spp=64)
+    assert big.film_shape == (1080, 1920)
+
+
+def test_overrides_and_errors(binding, tmp_path):
+    s = binding.HostScene()  # values of the scene file itself
+    assert (s.info["xres"], s.info["yres"], s.info["spp"], s.info["max_depth"]) == (700, 700, 8, 5)
+    bad = tmp_path / "bad.pbrt"
+    bad.write_text('Camera "orthographic"\nWorldBegin\nWorldEnd\n')
+    import pytest
+    with pytest.raises(RuntimeError, match="perspective"):
+        binding.HostScene(path=str(bad))
+    with pytest.raises(RuntimeError, match="cannot open"):
+        binding.HostScene(path=str(tmp_path / "missing.pbrt"))
+
+
+def test_film_to_rgb_and_pfm(scene_small, binding, tmp_path):
+    h, w = scene_small.film_shape
+    rng = np.random.default_rng(0)
+    film = np.zeros((h, w, 4), np.float32)
+    film[..., :3] = rng.uniform(0, 4, (h, w, 3))
+    film[..., 3] = rng.integers(1, 9, (h, w))
+    rgb = scene_small.film_to_rgb(film)
+    # Film::to_rgb_array: XYZ->RGB (spectrum.h:56-60), / weight, clamp at 0
+    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]],
+                 np.float32)
+    want = np.maximum(film[..., :3] @ m.T / film[..., 3:4], 0)
+    assert np.allclose(rgb, want, rtol=1e-5, atol=1e-6)
+    path = tmp_path / "x.pfm"
+    scene_small.write_pfm(str(path), rgb)
+    raw = path.read_bytes()
+    assert raw.startswith(b"PF\n160 120\n-1.0\n")
+    data = np.frombuffer(raw[len(b"PF\n160 120\n-1.0\n"):], "<f4").reshape(h, w, 3)
+    assert np.array_equal(data[::-1], rgb)
