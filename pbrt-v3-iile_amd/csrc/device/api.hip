@@ -445,6 +445,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         rc = upload(sc, dims.data(), dims.size(), &S.hdims);
         if (rc) return bail(rc);
         S.n_hdims = h.n_dims;
+        S.n_perms = h.n_perms;
         S.base_scale0 = h.base_scales[0];
         S.base_scale1 = h.base_scales[1];
         S.base_exp0 = h.base_exponents[0];

@@ -69,9 +69,14 @@ DEV float radical_inverse_base3(uint32_t a) {
     }
     return mn(float(reversed) * inv_base_n, kOneMinusEpsilon);
 }
-DEV float scrambled_radical_inverse(const DScene &S, int dim, uint32_t a) {
+// `perms` is the concatenated permutation table, either in HBM (const uint16_t *) or
+// staged in LDS by the shade kernel (lds_u16 *): a path needs one table lookup per
+// digit per dimension, ~30 dependent lookups per bounce.
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+template <typename PermPtr>
+DEV float scrambled_radical_inverse(const DScene &S, PermPtr perms, int dim, uint32_t a) {
     const DHaltonDim hd = S.hdims[dim];
-    const uint16_t *perm = S.perms + hd.perm_offset;
+    PermPtr perm = perms + hd.perm_offset;
     unsigned long long reversed = 0;
     float inv_base_n = 1;
     while (a) {
@@ -83,10 +88,14 @@ DEV float scrambled_radical_inverse(const DScene &S, int dim, uint32_t a) {
     }
     return mn(inv_base_n * (float(reversed) + hd.perm0_term), kOneMinusEpsilon);
 }
-DEV float sample_dimension(const DScene &S, uint32_t index, int dim) {
+template <typename PermPtr>
+DEV float sample_dimension(const DScene &S, PermPtr perms, uint32_t index, int dim) {
     if (dim == 0) return radical_inverse_base2(index >> S.base_exp0);
     if (dim == 1) return radical_inverse_base3(index / uint32_t(S.base_scale1));
-    return scrambled_radical_inverse(S, dim, index);
+    return scrambled_radical_inverse(S, perms, dim, index);
+}
+DEV float sample_dimension(const DScene &S, uint32_t index, int dim) {
+    return sample_dimension(S, S.perms, index, dim);
 }
 
 // ===========================================================================
@@ -426,8 +435,11 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
 // LDS pointers carry their address space explicitly so that pushes and pops
 // compile to ds_write_b32 / ds_read_b32 (a generic pointer would go through flat_*).
 typedef __attribute__((address_space(3))) int lds_int;
-constexpr int kLdsStackDepth = 16;    // measured max depth on killeroo-simple: 19
-constexpr int kSpillStackDepth = 48;  // 16 + 48 = the reference's 64 entries
+#ifndef IILE_LDS_STACK
+#define IILE_LDS_STACK 14
+#endif
+constexpr int kLdsStackDepth = IILE_LDS_STACK;         // measured max depth on killeroo-simple: 19
+constexpr int kSpillStackDepth = 64 - IILE_LDS_STACK;  // together the reference's 64 entries (bvh.cpp:670)
 constexpr int kStackWordsPerWave = 2 * kLdsStackDepth * 64;  // ref plane + tMin plane
 
 struct TraceStats {

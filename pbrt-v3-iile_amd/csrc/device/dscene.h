@@ -58,6 +58,7 @@ struct DScene {
     const DMaterial *materials;
     const DLight *lights;
     int n_nodes, n_prims, n_spheres, n_materials, n_lights, n_hdims;
+    int n_perms;              // u16 entries of `perms`
     float root_box[6];        // bounds of the root node (min.xyz, max.xyz)
     int root_ref;             // >= 0: wide record; < 0: ~first primitive of a single-leaf tree
     // camera

@@ -283,6 +283,11 @@ DEV F3 light_L(const DLight &lt, F3 n, F3 w) {
 // queue that extend just resolved.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int bounce, uint32_t plane) {
+    // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
+    for (int i = threadIdx.x; i < S.n_perms; i += kBlock) s_perms_raw[i] = S.perms[i];
+    __syncthreads();
+    lds_u16 *const s_perms = (lds_u16 *)s_perms_raw;
     const uint32_t count = B.counts[kCntShade + bounce];
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     float4 *no = B.ray_o[(bounce + 1) & 1], *nd = B.ray_d[(bounce + 1) & 1];
@@ -348,9 +353,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
                             const int li = 0;
                             const DLight &lt = S.lights[li];
                             const DSphere &sp = S.spheres[lt.sphere];
-                            const float ul0 = sample_dimension(S, hidx, dim), ul1 = sample_dimension(S, hidx, dim + 1);
-                            const float us0 = sample_dimension(S, hidx, dim + 2),
-                                        us1 = sample_dimension(S, hidx, dim + 3);
+                            const float ul0 = sample_dimension(S, s_perms, hidx, dim), ul1 = sample_dimension(S, s_perms, hidx, dim + 1);
+                            const float us0 = sample_dimension(S, s_perms, hidx, dim + 2),
+                                        us1 = sample_dimension(S, s_perms, hidx, dim + 3);
                             dim += 4;
                             // EstimateDirect, light-sampling half (integrator.cpp:117-163)
                             float light_pdf = 0, scattering_pdf = 0;
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
                         }
                     }
                     // next direction (path.cpp:133-156)
-                    const float u0 = sample_dimension(S, hidx, dim), u1 = sample_dimension(S, hidx, dim + 1);
+                    const float u0 = sample_dimension(S, s_perms, hidx, dim), u1 = sample_dimension(S, s_perms, hidx, dim + 1);
                     dim += 2;
                     float pdf = 0;
                     F3 wi = F3{0, 0, 0};
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
                             const float mc = max3(beta.x, beta.y, beta.z);
                             if (mc < S.rr_threshold && bounce > 3) {
                                 const float q = mx(.05f, 1 - mc);
-                                const float ur = sample_dimension(S, hidx, dim);
+                                const float ur = sample_dimension(S, s_perms, hidx, dim);
                                 ++dim;
                                 if (ur < q)
                                     alive = false;
@@ -856,10 +861,11 @@ void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t m
 }
 void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 4));
+    const size_t perm_bytes = (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+        hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
     else
-        hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+        hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
 }
 void launch_connect(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));

@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:  # torch first: its bundled HIP runtime and the one libiile_gpu.so links must be the same copy
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
