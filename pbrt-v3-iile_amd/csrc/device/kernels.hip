@@ -281,8 +281,9 @@ DEV F3 light_L(const DLight &lt, F3 n, F3 w) {
 
 // shade: one bounce of PathIntegrator::Li (path.cpp:81-191) for every hit of the
 // queue that extend just resolved.
+// 3 waves/SIMD (<= 168 VGPRs, 6 spilled): measured 38.0 ms vs 40.2 ms at 2 waves/SIMD
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int bounce, uint32_t plane) {
+__global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
     for (int i = threadIdx.x; i < S.n_perms; i += kBlock) s_perms_raw[i] = S.perms[i];
@@ -299,26 +300,33 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
         const uint32_t qi = base + threadIdx.x;
         const uint32_t slot = qi < count ? B.shade_q[qi] : kInvalid;
         const bool valid = slot != kInvalid;
-        bool alive = false, emit_nee = false;
-        uint32_t pid = 0;
-        F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
-        // NEE record fields
-        F3 so = F3{0, 0, 0}, sd = F3{0, 0, 1}, mo = F3{0, 0, 0}, md = F3{0, 0, 1};
-        F3 A = F3{0, 0, 0}, Bc = F3{0, 0, 0}, beta_nee = F3{0, 0, 0};
-        uint32_t nee_flags = 0, nee_light = 0;
-        bool returned_early = false;
-        if (valid) {
-            const float4 o4 = ro[slot], d4 = rd[slot], h4 = B.hits[slot];
-            pid = f2b(o4.w);
-            const int prim = int(f2b(h4.x));
-            const F3 ray_o = F3{o4.x, o4.y, o4.z}, ray_d = F3{d4.x, d4.y, d4.z};
-            if (prim >= 0) {
+        // The loop body is two converged sections, each ending in a queue append, so that the
+        // NEE record's ~20 registers are dead before the continuation is sampled:
+        //   A: interaction, Le, BSDF, both halves of EstimateDirect  -> NEE record
+        //   B: next direction, throughput, Russian roulette          -> next ray
+        bool surface = false;  // a hit that still scatters (bounces < maxDepth)
+        bool alive = false, returned_early = false;
+        uint32_t pid = 0, hidx = 0;
+        int dim = 0;
+        Isect is;
+        Bsdf bsdf;
+        F3 beta = F3{0, 0, 0}, ray_d = F3{0, 0, 1};
+        {
+            bool emit_nee = false;
+            F3 so = F3{0, 0, 0}, sd = F3{0, 0, 1}, mo = F3{0, 0, 0}, md = F3{0, 0, 1};
+            F3 A = F3{0, 0, 0}, Bc = F3{0, 0, 0};
+            uint32_t nee_flags = 0, nee_light = 0;
+            if (valid) {
+                const float4 o4 = ro[slot], d4 = rd[slot], h4 = B.hits[slot];
+                pid = f2b(o4.w);
+                const int prim = int(f2b(h4.x));
+                const F3 ray_o = F3{o4.x, o4.y, o4.z};
+                ray_d = F3{d4.x, d4.y, d4.z};
                 const float4 v0 = S.tri_verts[3 * size_t(prim)];
                 const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
                 const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
                 const uint32_t flags = f2b(v0.w);
                 const int material = int(f2b(v1.w)), light = int(f2b(v2.w));
-                Isect is;
                 if (flags & 1u) {
                     // the closest hit was the sphere: redo its (deterministic) root
                     // selection to recover the object-space ray and refined hit point
@@ -332,9 +340,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
                                          F3{v2.x, v2.y, v2.z}, ray_d, h4.y, h4.z, h4.w, &is);
                 }
                 const float4 beta4 = B.beta[pid];
-                F3 beta = F3{beta4.x, beta4.y, beta4.z};
-                int dim = int(f2b(beta4.w));
-                const uint32_t hidx = B.hindex[pid];
+                beta = F3{beta4.x, beta4.y, beta4.z};
+                dim = int(f2b(beta4.w));
+                hidx = B.hindex[pid];
                 // emitted light at the first vertex only: there are no specular lobes
                 // on this path, so specularBounce stays false (path.cpp:91-101)
                 if (bounce == 0 && light >= 0) {
@@ -343,7 +351,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
                     B.L[pid] = make_float4(L.x, L.y, L.z, 0);
                 }
                 if (bounce < S.max_depth) {
-                    const Bsdf bsdf = make_bsdf(S.materials[material], is);
+                    surface = true;
+                    bsdf = make_bsdf(S.materials[material], is);
                     if (bsdf.n_lobes > 0) {
                         ++n_nee;
                         if (S.n_lights > 0) {
@@ -353,7 +362,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
                             const int li = 0;
                             const DLight &lt = S.lights[li];
                             const DSphere &sp = S.spheres[lt.sphere];
-                            const float ul0 = sample_dimension(S, s_perms, hidx, dim), ul1 = sample_dimension(S, s_perms, hidx, dim + 1);
+                            const float ul0 = sample_dimension(S, s_perms, hidx, dim),
+                                        ul1 = sample_dimension(S, s_perms, hidx, dim + 1);
                             const float us0 = sample_dimension(S, s_perms, hidx, dim + 2),
                                         us1 = sample_dimension(S, s_perms, hidx, dim + 3);
                             dim += 4;
@@ -395,62 +405,61 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, PassBuffers B, int b
                                 }
                             }
                             nee_light = uint32_t(li);
-                            beta_nee = beta;
                             emit_nee = true;
                         }
                     }
-                    // next direction (path.cpp:133-156)
-                    const float u0 = sample_dimension(S, s_perms, hidx, dim), u1 = sample_dimension(S, s_perms, hidx, dim + 1);
-                    dim += 2;
-                    float pdf = 0;
-                    F3 wi = F3{0, 0, 0};
-                    const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf);
-                    if (!(is_black(f) || pdf == 0.f)) {
-                        beta = beta * sdiv(f * absdot(wi, is.sn), pdf);
-                        const float by = lum_y(beta);
-                        if (by < 0.f || is_nan(by)) {
-                            returned_early = true;  // `return L` (path.cpp:143-145)
-                        } else {
-                            next_o = offset_ray_origin(is.p, is.perr, is.n, wi);
-                            next_d = wi;
-                            alive = true;
-                            // Russian roulette (path.cpp:182-190), etaScale == 1
-                            const float mc = max3(beta.x, beta.y, beta.z);
-                            if (mc < S.rr_threshold && bounce > 3) {
-                                const float q = mx(.05f, 1 - mc);
-                                const float ur = sample_dimension(S, s_perms, hidx, dim);
-                                ++dim;
-                                if (ur < q)
-                                    alive = false;
-                                else
-                                    beta = sdiv(beta, 1 - q);
-                            }
-                        }
-                    }
-                    if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim)));
                 }
             }
-            if (COUNT && !alive && !returned_early) {
-                // ReportValue(pathLength, bounces): a path that dies in this iteration
-                // exits the loop with bounces == bounce; one that survives Russian
-                // roulette bookkeeping is counted when it eventually terminates
-                ++n_term;
+            const uint32_t eslot = out_take(nee_out, &B.counts[kCntNee + bounce], emit_nee, pad_nee);
+            if (emit_nee) {
+                B.nee[eslot] = make_float4(so.x, so.y, so.z, b2f(pid));
+                B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
+                B.nee[2 * plane + eslot] = make_float4(mo.x, mo.y, mo.z, b2f(nee_light));
+                B.nee[3 * plane + eslot] = make_float4(md.x, md.y, md.z, 0.f);
+                B.nee[4 * plane + eslot] = make_float4(A.x, A.y, A.z, 0.f);
+                B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, 0.f);
+                B.nee[6 * plane + eslot] = make_float4(beta.x, beta.y, beta.z, 0.f);  // beta before this bounce
             }
         }
+        F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
+        if (surface) {
+            // next direction (path.cpp:133-156)
+            const float u0 = sample_dimension(S, s_perms, hidx, dim), u1 = sample_dimension(S, s_perms, hidx, dim + 1);
+            dim += 2;
+            float pdf = 0;
+            F3 wi = F3{0, 0, 0};
+            const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf);
+            if (!(is_black(f) || pdf == 0.f)) {
+                beta = beta * sdiv(f * absdot(wi, is.sn), pdf);
+                const float by = lum_y(beta);
+                if (by < 0.f || is_nan(by)) {
+                    returned_early = true;  // `return L` (path.cpp:143-145)
+                } else {
+                    next_o = offset_ray_origin(is.p, is.perr, is.n, wi);
+                    next_d = wi;
+                    alive = true;
+                    // Russian roulette (path.cpp:182-190), etaScale == 1
+                    const float mc = max3(beta.x, beta.y, beta.z);
+                    if (mc < S.rr_threshold && bounce > 3) {
+                        const float q = mx(.05f, 1 - mc);
+                        const float ur = sample_dimension(S, s_perms, hidx, dim);
+                        ++dim;
+                        if (ur < q)
+                            alive = false;
+                        else
+                            beta = sdiv(beta, 1 - q);
+                    }
+                }
+            }
+            if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim)));
+        }
+        // ReportValue(pathLength, bounces): a path that ends in this iteration leaves the
+        // loop with bounces == bounce (not counted on the early `return L`)
+        if (COUNT && valid && !alive && !returned_early) ++n_term;
         const uint32_t nslot = out_take(ray_out, &B.counts[kCntRay + bounce + 1], alive, pad_ray);
         if (alive) {
             no[nslot] = make_float4(next_o.x, next_o.y, next_o.z, b2f(pid));
             nd[nslot] = make_float4(next_d.x, next_d.y, next_d.z, IILE_INF);
-        }
-        const uint32_t eslot = out_take(nee_out, &B.counts[kCntNee + bounce], emit_nee, pad_nee);
-        if (emit_nee) {
-            B.nee[eslot] = make_float4(so.x, so.y, so.z, b2f(pid));
-            B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
-            B.nee[2 * plane + eslot] = make_float4(mo.x, mo.y, mo.z, b2f(nee_light));
-            B.nee[3 * plane + eslot] = make_float4(md.x, md.y, md.z, 0.f);
-            B.nee[4 * plane + eslot] = make_float4(A.x, A.y, A.z, 0.f);
-            B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, 0.f);
-            B.nee[6 * plane + eslot] = make_float4(beta_nee.x, beta_nee.y, beta_nee.z, 0.f);
         }
     }
     out_flush(ray_out, pad_ray);
