@@ -127,8 +127,8 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    agg = {"ms_extend": 0.0, "ms_connect": 0.0, "ms_shade": 0.0, "ms_generate": 0.0, "ms_film": 0.0, "ms_total": 0.0,
-           "n_extend_launches": 0, "n_connect_launches": 0}
+    agg = {"ms_extend": 0.0, "ms_connect": 0.0, "ms_shadow": 0.0, "ms_mis": 0.0, "ms_shade": 0.0, "ms_generate": 0.0,
+           "ms_film": 0.0, "ms_total": 0.0, "n_extend_launches": 0, "n_connect_launches": 0}
     for _ in range(args.steps):
         st = step(timed=True)
         for k in agg:
@@ -156,12 +156,14 @@ def main():
         b_ray = 32 * n_node + 48 * n_tri + 48
         # dominant kernel by measured HIP-event time on this rank
         ext_bytes = algorithmic_bytes(cst["ext_rays"], cst["ext_nodes"], cst["ext_tri_tests"])
-        con_rays = r_all - cst["ext_rays"]
-        con_bytes = algorithmic_bytes(con_rays, cst["nodes_closest"] + cst["nodes_any"] - cst["ext_nodes"],
-                                      cst["tri_tests"] - cst["ext_tri_tests"])
+        sh_bytes = algorithmic_bytes(cst["shadow_rays"], cst["nodes_any"], cst["any_tri_tests"])
+        mis_rays = cst["closest_rays"] - cst["ext_rays"]
+        mis_bytes = algorithmic_bytes(mis_rays, cst["nodes_closest"] - cst["ext_nodes"],
+                                      cst["tri_tests"] - cst["ext_tri_tests"] - cst["any_tri_tests"])
         kernels = {
             "k_extend": (agg["ms_extend"], agg["n_extend_launches"], ext_bytes, cst["ext_rays"]),
-            "k_connect": (agg["ms_connect"], agg["n_connect_launches"], con_bytes, con_rays),
+            "k_shadow": (agg["ms_shadow"], agg["n_connect_launches"], sh_bytes, cst["shadow_rays"]),
+            "k_mis": (agg["ms_mis"], agg["n_connect_launches"], mis_bytes, mis_rays),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms_k, n_launch, bytes_step, rays_k = kernels[dom]
@@ -198,7 +200,7 @@ def main():
             "job_algorithmic_gbs": round(mray * 1e6 * b_ray / 1e9, 1),
             "job_frac_of_hbm_roofline": round(mray * 1e6 * b_ray / 1e9 / (HBM_PEAK_GBS * world), 4),
             "kernel_ms_per_step_rank0": {k: round(agg[k] / args.steps, 3) for k in
-                                         ("ms_generate", "ms_extend", "ms_shade", "ms_connect", "ms_film", "ms_total")},
+                                         ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_film", "ms_total")},
             "roofline": {
                 "kernel": dom,
                 "bound": "hbm",

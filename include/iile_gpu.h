@@ -71,11 +71,13 @@ typedef struct iile_stats {
     /* timings in milliseconds; per-kernel sums filled when time_kernels */
     double ms_total;
     double ms_generate, ms_extend, ms_shade, ms_connect, ms_film;
-    int32_t n_extend_launches, n_connect_launches, n_shade_launches, n_passes;
+    int32_t n_extend_launches, n_connect_launches /* per NEE kernel */, n_shade_launches, n_passes;
     uint64_t n_paths;             /* camera samples rendered by this call */
     uint64_t workspace_bytes;     /* HBM held by the wavefront queues */
     /* the extend kernel alone (main-path closest-hit rays): inputs of its roofline */
     uint64_t ext_rays, ext_nodes, ext_tri_tests, ext_sphere_tests;
+    uint64_t any_tri_tests;       /* triangle tests of the shadow (any-hit) kernel */
+    double ms_shadow, ms_mis;     /* the two NEE kernels; ms_connect is their sum */
 } iile_stats;
 
 int iile_device_count(void);

@@ -33,7 +33,7 @@ int fail(int code, const std::string &msg) {
 
 struct EventPair {
     hipEvent_t a, b;
-    int kind;  // 0 generate, 1 extend, 2 shade, 3 connect, 4 film
+    int kind;  // 0 generate, 1 extend, 2 shade, 3 shadow, 4 film, 5 mis
 };
 
 }  // namespace
@@ -178,6 +178,7 @@ void copy_counters(const DCounters &c, iile_stats *st) {
     st->ext_nodes = c.ext_nodes;
     st->ext_tri_tests = c.ext_tri_tests;
     st->ext_sphere_tests = c.ext_sphere_tests;
+    st->any_tri_tests = c.any_tri_tests;
 }
 
 // Enqueue one wavefront pass on cfg.stream.
@@ -206,7 +207,9 @@ int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed
         rc = timed_launch(2, [&] { launch_shade(S, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (b < sc->max_depth) {
-            rc = timed_launch(3, [&] { launch_connect(S, B, b, B.queue_cap, cfg); });
+            rc = timed_launch(3, [&] { launch_shadow(S, B, b, B.queue_cap, cfg); });
+            if (rc) return rc;
+            rc = timed_launch(5, [&] { launch_mis(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
         }
     }
@@ -222,7 +225,8 @@ int collect_times(iile_scene *sc, iile_stats *st) {
         case 0: st->ms_generate += ms; break;
         case 1: st->ms_extend += ms; st->n_extend_launches++; break;
         case 2: st->ms_shade += ms; st->n_shade_launches++; break;
-        case 3: st->ms_connect += ms; st->n_connect_launches++; break;
+        case 3: st->ms_connect += ms; st->ms_shadow += ms; st->n_connect_launches++; break;
+        case 5: st->ms_connect += ms; st->ms_mis += ms; break;
         default: st->ms_film += ms; break;
         }
     }
@@ -528,7 +532,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (rank < 0 || rank >= nranks) return fail(IILE_ERR_ARG, "iile_render: tile_rank out of range");
     hipStream_t stream = static_cast<hipStream_t>(prm->stream);
     LaunchCfg cfg{sc->n_cus, stream, prm->collect_stats != 0};
-    if (const char *e = std::getenv("IILE_SCHED_K")) cfg.sched_k = atoi(e);
+    if (const char *e = std::getenv("IILE_DEBUG_SKIP")) cfg.dbg_skip = atoi(e) & 3;
     if (const char *e = std::getenv("IILE_TRAV_BLOCKS")) cfg.trav_blocks_per_cu = std::max(1, std::min(5, atoi(e)));
     const bool timed = prm->time_kernels != 0;
 

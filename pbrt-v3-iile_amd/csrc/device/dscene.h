@@ -83,7 +83,7 @@ struct DScene {
 //   n0 = (shadow o.xyz, bitcast pid)      n1 = (shadow d.xyz, bitcast flags)
 //   n2 = (mis o.xyz, bitcast light)       n3 = (mis d.xyz, -)
 //   n4 = (A.xyz, -)   n5 = (B.xyz, -)     n6 = (beta.xyz, -)
-enum { NEE_HAS_SHADOW = 1, NEE_HAS_MIS = 2 };
+enum { NEE_HAS_SHADOW = 1, NEE_HAS_MIS = 2 };  // + NEE_OCCLUDED = 4, set by the shadow kernel
 
 struct DCounters {
     unsigned long long camera_rays, closest_rays, shadow_rays;
@@ -92,6 +92,7 @@ struct DCounters {
     unsigned long long path_length[8];
     // the extend kernel alone (closest-hit rays of the main path), for its roofline
     unsigned long long ext_rays, ext_nodes, ext_tri_tests, ext_sphere_tests;
+    unsigned long long any_tri_tests;  // triangle tests of the shadow kernel
 };
 
 }  // namespace iile

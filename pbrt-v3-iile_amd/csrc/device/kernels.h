@@ -42,7 +42,7 @@ struct LaunchCfg {
     int n_cus;
     hipStream_t stream;
     bool count_stats;
-    int sched_k = 2;              // connect: take an interior step when 4*n_interior >= sched_k*n_leaf
+    int dbg_skip = 0;             // timing experiments only: bit0 skip shadow rays, bit1 skip MIS rays
     int trav_blocks_per_cu = 5;   // persistent traversal blocks per CU (5 x 32 KB of LDS stacks)
 };
 
@@ -51,7 +51,8 @@ uint32_t queue_capacity(uint32_t n_paths, int n_cus);
 void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg);
 void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
-void launch_connect(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
                             const LaunchCfg &cfg);
 void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg);

@@ -1,7 +1,7 @@
 // kernels.hip — hand-written gfx950 kernels of the wavefront path tracer.
 //
 // Pipeline per pass (one pass = owned tiles x a chunk of sample indices):
-//   generate -> [ extend -> shade -> connect ] x (maxDepth + 1) -> film_accumulate
+//   generate -> [ extend -> shade -> shadow -> mis ] x (maxDepth + 1) -> film_accumulate
 // and, after the last pass, film_resolve.
 //
 //   generate  HaltonSampler + PerspectiveCamera::GenerateRayDifferential; fills ray queue 0
@@ -10,8 +10,8 @@
 //             sampling + BSDF sampling of EstimateDirect (emits one NEE record holding a
 //             shadow ray and an MIS ray), next direction, Russian roulette; compacts the
 //             surviving paths into the next ray queue with ballot + one atomic per wavefront
-//   connect   BVHAccel::IntersectP for the shadow ray and BVHAccel::Intersect for the MIS
-//             ray of each NEE record, then L += beta * Ld
+//   shadow    BVHAccel::IntersectP for the shadow ray of each NEE record
+//   mis       BVHAccel::Intersect for the MIS ray of each NEE record, then L += beta * Ld
 //
 // All kernels are persistent grid-stride loops that read their queue length
 // from device memory, so a whole pass is enqueued without host synchronisation.
@@ -100,7 +100,8 @@ constexpr int kCntRay = 0;       // [bounce] rays in the extend queue
 constexpr int kCntNee = 16;      // [bounce] NEE records
 constexpr int kCntShade = 32;    // [bounce] hits to shade
 constexpr int kCntExtHead = 48;  // [bounce] chunk cursor of the extend queue
-constexpr int kCntConHead = 64;  // [bounce] chunk cursor of the NEE queue
+constexpr int kCntConHead = 64;  // [bounce] chunk cursor of the NEE queue (shadow kernel)
+constexpr int kCntMisHead = 80;  // [bounce] chunk cursor of the NEE queue (MIS kernel)
 
 // Persistent-wavefront work feed. A wavefront reserves kChunk consecutive queue
 // slots with one atomic and hands them to its lanes as they go idle, so lanes
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
 // extend: BVHAccel::Intersect for every ray of queue `bounce & 1`; hits are
 // appended (ballot-compacted) to the shade queue.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, int bounce, int sched_k) {
+__global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, int bounce) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -471,42 +472,31 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
 }
 
 // ---------------------------------------------------------------------------
-// connect: resolve the two rays of each NEE record and add beta * Ld to L.
-// A lane walks its record through stage 1 (shadow ray, BVHAccel::IntersectP) and
-// stage 2 (MIS ray, BVHAccel::Intersect), then takes the next record.
-#ifndef IILE_CONNECT_WAVES
-#define IILE_CONNECT_WAVES 5
-#endif
+// NEE resolution: two homogeneous kernels over the NEE records of one bounce.
+//   k_shadow  BVHAccel::IntersectP for the shadow ray; marks occluded records
+//   k_mis     BVHAccel::Intersect for the MIS ray, then L += beta * Ld
+// (One fused kernel walking each record through both rays measured 60 ms per
+// 1080p/64spp step against 7 + 17.5 + 26.4 ms for its parts: any-hit and
+// closest-hit lanes in one wavefront keep each other waiting.)
+enum { NEE_OCCLUDED = 4 };
+
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, IILE_CONNECT_WAVES) void k_connect(DScene S, PassBuffers B, int bounce, uint32_t plane, int sched_k) {
+__global__ __launch_bounds__(kBlock, 5) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
     const uint32_t count = B.counts[kCntNee + bounce];
     uint32_t *head = &B.counts[kCntConHead + bounce];
-    TraceStats st_any = {0, 0, 0, 0}, st_cl = {0, 0, 0, 0};
-    unsigned long long n_shadow = 0, n_closest = 0, n_zero = 0;
+    TraceStats st = {0, 0, 0, 0};
+    unsigned long long n_shadow = 0;
     WaveFeed feed{0, 0, count == 0};
     Trav t;
     t.have = false;
     t.cur = 0;
     t.sp = 0;
     t.hit_prim = -1;
-    bool active = false;
-    // per-lane record state is just the record index, the stage and two flags; everything
-    // else is re-read from the record when a stage ends (keeps the kernel at 5 waves/SIMD)
+    bool active = false, occluded = false;
     uint32_t e = 0;
-    int stage = 0;  // 1: shadow ray in flight, 2: MIS ray in flight, 3: nothing to trace
-    bool occluded = false, mis_lit = false;
-    auto begin_mis = [&]() {
-        const float4 n2 = B.nee[2 * plane + e], n3 = B.nee[3 * plane + e];
-        trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st_cl);
-        stage = 2;
-        if (COUNT) {
-            ++n_closest;
-            if (B.nray_out) B.nray_out[2 * f2b(B.nee[e].w)] += 1;
-        }
-    };
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
@@ -515,104 +505,135 @@ __global__ __launch_bounds__(kBlock, IILE_CONNECT_WAVES) void k_connect(DScene S
                 e = e_new;
                 const float4 n1 = B.nee[plane + e];
                 const uint32_t flags = f2b(n1.w);
-                occluded = false;
-                mis_lit = false;
-                active = flags != kInvalid;
-                t.have = false;
-                if (!active) {
-                    stage = 0;
-                } else if (flags & NEE_HAS_SHADOW) {
+                if (flags != kInvalid && (flags & NEE_HAS_SHADOW & ~uint32_t(dbg_skip))) {
                     const float4 n0 = B.nee[e];
-                    trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st_any);
-                    stage = 1;
+                    trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st);
+                    active = true;
+                    occluded = false;
                     if (COUNT) {
                         ++n_shadow;
                         if (B.nray_out) B.nray_out[2 * f2b(n0.w) + 1] += 1;
                     }
-                } else if (flags & NEE_HAS_MIS) {
-                    begin_mis();
-                } else
-                    stage = 3;
+                }
             }
         }
         if (__ballot(active) == 0) {
             if (feed.exhausted) break;
             continue;
         }
-        // Shadow and MIS rays of different records are incoherent: one step per iteration,
-        // interior or leaf, whichever keeps more lanes busy (measured 71 ms vs 80 ms for
-        // strict while-while on the 1080p/64spp step).
-        {
-            const bool wi = active && t.have && t.cur >= 0;
-            const bool wl = active && t.have && t.cur < 0;
-            const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
-            if (n_int > 0 && n_int * 4 >= n_leaf * sched_k) {
-                if (wi) trav_interior_step<COUNT>(S, t, sr, stage == 1 ? &st_any : &st_cl);
-            } else if (n_leaf > 0) {
-                if (wl && trav_leaf<COUNT>(S, t, sr, stage == 1 ? &st_any : &st_cl, stage == 1,
-                                         &B.nee[(stage == 1 ? 1u : 3u) * plane + e]))
-                    occluded = true;
-            }
-        }
+        while (active && t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, &st);
+        if (active && t.have && trav_leaf<COUNT>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
         if (active && !t.have) {
-            bool done = true;
-            if (stage == 1) {
-                if (f2b(B.nee[plane + e].w) & NEE_HAS_MIS) {
-                    begin_mis();
-                    done = false;
-                }
-            } else if (stage == 2) {
-                if (t.hit_prim >= 0) {
-                    const float4 v0 = S.tri_verts[3 * size_t(t.hit_prim)];
-                    const float4 v2 = S.tri_verts[3 * size_t(t.hit_prim) + 2];
-                    const int li = int(f2b(B.nee[2 * plane + e].w));
-                    // `lightIsect.primitive->GetAreaLight() == &light` (integrator.cpp:207)
-                    if (int(f2b(v2.w)) == li && (f2b(v0.w) & 1u)) {
-                        const DSphere &sp = S.spheres[S.prim_shape[t.hit_prim]];
-                        float th;
-                        F3 od, ph;
-                        Isect lis;
-                        const float4 d4 = B.nee[3 * plane + e];
-                        const F3 md = F3{d4.x, d4.y, d4.z};
-                        sphere_test(sp, t.rc.o, md, IILE_INF, &th, &od, &ph);
-                        sphere_interaction(sp, od, ph, &lis);
-                        const DLight &lt = S.lights[li];
-                        mis_lit = lt.two_sided || dot(lis.n, -md) > 0;
-                    }
-                }
+            if (occluded) {
+                float4 *rec = &B.nee[plane + e];
+                reinterpret_cast<uint32_t *>(rec)[3] |= NEE_OCCLUDED;
             }
-            if (done) {
-                // Ld = [unoccluded light sample] + [MIS ray reached the light]; UniformSampleOneLight
-                // divides by lightPdf == 1; L += beta * Ld (integrator.cpp:150-158, 208-211; path.cpp:123-128)
-                const uint32_t flags = f2b(B.nee[plane + e].w);
-                F3 Ld = F3{0, 0, 0};
-                if ((flags & NEE_HAS_SHADOW) && !occluded) {
-                    const float4 a4 = B.nee[4 * plane + e];
-                    Ld = Ld + F3{a4.x, a4.y, a4.z};
-                }
-                if (mis_lit) {
-                    const float4 b4 = B.nee[5 * plane + e];
-                    Ld = Ld + F3{b4.x, b4.y, b4.z};
-                }
-                const float4 be = B.nee[6 * plane + e];
-                const F3 add = F3{be.x, be.y, be.z} * Ld;
-                if (COUNT && is_black(add)) ++n_zero;
-                const uint32_t pid = f2b(B.nee[e].w);
-                const float4 L4 = B.L[pid];
-                B.L[pid] = make_float4(L4.x + add.x, L4.y + add.y, L4.z + add.z, 0);
-                active = false;
-            }
+            active = false;
         }
     }
     if (COUNT) {
         flush_counter(&B.counters->shadow_rays, n_shadow);
+        flush_counter(&B.counters->nodes_any, st.nodes);
+        flush_counter(&B.counters->any_tri_tests, st.tris);
+        flush_counter(&B.counters->tri_tests, st.tris);
+        flush_counter(&B.counters->tri_hits, st.tri_hits);
+        flush_counter(&B.counters->sphere_tests, st.spheres);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, 5) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
+    __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
+    const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
+                      blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    const uint32_t count = B.counts[kCntNee + bounce];
+    uint32_t *head = &B.counts[kCntMisHead + bounce];
+    TraceStats st = {0, 0, 0, 0};
+    unsigned long long n_closest = 0, n_zero = 0;
+    WaveFeed feed{0, 0, count == 0};
+    Trav t;
+    t.have = false;
+    t.cur = 0;
+    t.sp = 0;
+    t.hit_prim = -1;
+    bool active = false;
+    uint32_t e = 0;
+    while (true) {
+        const unsigned long long idle_mask = __ballot(!active);
+        if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
+            uint32_t e_new;
+            if (feed_take(feed, head, count, !active, &e_new)) {
+                e = e_new;
+                const uint32_t flags = f2b(B.nee[plane + e].w);
+                if (flags != kInvalid) {
+                    active = true;
+                    t.have = false;
+                    t.hit_prim = -1;
+                    if (flags & NEE_HAS_MIS & ~uint32_t(dbg_skip)) {
+                        const float4 n2 = B.nee[2 * plane + e], n3 = B.nee[3 * plane + e];
+                        trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st);
+                        if (COUNT) {
+                            ++n_closest;
+                            if (B.nray_out) B.nray_out[2 * f2b(B.nee[e].w)] += 1;
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(active) == 0) {
+            if (feed.exhausted) break;
+            continue;
+        }
+        while (active && t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, &st);
+        if (active && t.have) trav_leaf<COUNT>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
+        if (active && !t.have) {
+            bool mis_lit = false;
+            if (t.hit_prim >= 0) {
+                const float4 v0 = S.tri_verts[3 * size_t(t.hit_prim)];
+                const float4 v2 = S.tri_verts[3 * size_t(t.hit_prim) + 2];
+                const int li = int(f2b(B.nee[2 * plane + e].w));
+                // `lightIsect.primitive->GetAreaLight() == &light` (integrator.cpp:207)
+                if (int(f2b(v2.w)) == li && (f2b(v0.w) & 1u)) {
+                    const DSphere &sp = S.spheres[S.prim_shape[t.hit_prim]];
+                    float th;
+                    F3 od, ph;
+                    Isect lis;
+                    const float4 d4 = B.nee[3 * plane + e];
+                    const F3 md = F3{d4.x, d4.y, d4.z};
+                    sphere_test(sp, t.rc.o, md, IILE_INF, &th, &od, &ph);
+                    sphere_interaction(sp, od, ph, &lis);
+                    const DLight &lt = S.lights[li];
+                    mis_lit = lt.two_sided || dot(lis.n, -md) > 0;
+                }
+            }
+            // Ld = [unoccluded light sample] + [MIS ray reached the light]; UniformSampleOneLight
+            // divides by lightPdf == 1; L += beta * Ld (integrator.cpp:150-158, 208-211; path.cpp:123-128)
+            const uint32_t flags = f2b(B.nee[plane + e].w);
+            F3 Ld = F3{0, 0, 0};
+            if ((flags & NEE_HAS_SHADOW) && !(flags & NEE_OCCLUDED)) {
+                const float4 a4 = B.nee[4 * plane + e];
+                Ld = Ld + F3{a4.x, a4.y, a4.z};
+            }
+            if (mis_lit) {
+                const float4 b4 = B.nee[5 * plane + e];
+                Ld = Ld + F3{b4.x, b4.y, b4.z};
+            }
+            const float4 be = B.nee[6 * plane + e];
+            const F3 add = F3{be.x, be.y, be.z} * Ld;
+            if (COUNT && is_black(add)) ++n_zero;
+            const uint32_t pid = f2b(B.nee[e].w);
+            const float4 L4 = B.L[pid];
+            B.L[pid] = make_float4(L4.x + add.x, L4.y + add.y, L4.z + add.z, 0);
+            active = false;
+        }
+    }
+    if (COUNT) {
         flush_counter(&B.counters->closest_rays, n_closest);
         flush_counter(&B.counters->zero_radiance, n_zero);
-        flush_counter(&B.counters->nodes_any, st_any.nodes);
-        flush_counter(&B.counters->nodes_closest, st_cl.nodes);
-        flush_counter(&B.counters->tri_tests, (unsigned long long)st_any.tris + st_cl.tris);
-        flush_counter(&B.counters->tri_hits, (unsigned long long)st_any.tri_hits + st_cl.tri_hits);
-        flush_counter(&B.counters->sphere_tests, (unsigned long long)st_any.spheres + st_cl.spheres);
+        flush_counter(&B.counters->nodes_closest, st.nodes);
+        flush_counter(&B.counters->tri_tests, st.tris);
+        flush_counter(&B.counters->tri_hits, st.tri_hits);
+        flush_counter(&B.counters->sphere_tests, st.spheres);
     }
 }
 
@@ -864,9 +885,9 @@ void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, c
 void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_extend<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, cfg.sched_k);
+        hipLaunchKernelGGL(k_extend<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
     else
-        hipLaunchKernelGGL(k_extend<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, cfg.sched_k);
+        hipLaunchKernelGGL(k_extend<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
 }
 void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 4));
@@ -876,12 +897,19 @@ void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t ma
     else
         hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
 }
-void launch_connect(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_connect<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.sched_k);
+        hipLaunchKernelGGL(k_shadow<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
     else
-        hipLaunchKernelGGL(k_connect<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.sched_k);
+        hipLaunchKernelGGL(k_shadow<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+}
+void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));
+    if (cfg.count_stats)
+        hipLaunchKernelGGL(k_mis<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+    else
+        hipLaunchKernelGGL(k_mis<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
 }
 void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
                             const LaunchCfg &cfg) {
