@@ -235,3 +235,22 @@ def test_film_on_device_pointer(gpu_small, scene_small):
     torch.cuda.synchronize()
     host, _ = gpu_small.render()
     assert_bitwise(film_t.cpu().numpy(), host, "device-resident film")
+
+
+def test_cpp_cli_renders_same_film(scene_small, gpu_small, tmp_path):
+    """The C++ host (`iile_pbrt`, GpuPathIntegrator::Render) produces the image the C ABI does."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pbrt-v3-iile_amd", "lib",
+                       "iile_pbrt")
+    out = tmp_path / "cli.pfm"
+    p = subprocess.run([exe, os.path.join(os.path.dirname(exe), "..", "..", "scenes", "killeroo-simple.pbrt"),
+                        "--xres", "160", "--yres", "120", "--spp", "4", "--outfile", str(out), "--stats"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    raw = out.read_bytes()
+    head = b"PF\n160 120\n-1.0\n"
+    assert raw.startswith(head)
+    img = np.frombuffer(raw[len(head):], "<f4").reshape(120, 160, 3)[::-1]
+    film, _ = gpu_small.render()
+    assert_bitwise(img, scene_small.film_to_rgb(film), "CLI image")
