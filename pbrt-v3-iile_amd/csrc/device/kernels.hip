@@ -131,7 +131,12 @@ struct WaveFeed {
     uint32_t cur, end;
     bool exhausted;
 };
-DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint32_t *slot) {
+// `warm(first_slot)` is called once per new chunk: the wavefront touches every 128-byte
+// line of the chunk's records (lane l -> records first+8l .. first+8l+7), so the per-lane
+// refill loads that follow hit L2 instead of paying an HBM round trip each time a few
+// lanes go idle.
+template <typename Warm>
+DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint32_t *slot, Warm warm) {
     const unsigned long long mask = __ballot(idle);
     const uint32_t n_idle = uint32_t(__popcll(mask));
     if (f.cur == f.end) {
@@ -145,6 +150,7 @@ DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint3
         }
         f.cur = base;
         f.end = (base + kChunk < count) ? base + kChunk : count;
+        warm(base);
     }
     const uint32_t avail = f.end - f.cur;
     const uint32_t take = n_idle < avail ? n_idle : avail;
@@ -152,6 +158,16 @@ DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint3
     *slot = f.cur + rank;
     f.cur += take;
     return idle && rank < take;
+}
+
+// touch one float4 of every 128-byte line of records [first, first + kChunk) of a float4 plane
+static_assert(kChunk == 64 * 8, "one lane per 128-byte line of a chunk");
+DEV void warm_plane(const float4 *plane_base, uint32_t first, uint32_t limit) {
+    const uint32_t i = first + uint32_t(lane_id()) * 8u;
+    if (i < limit) {
+        const float v = plane_base[i].x;
+        asm volatile("" ::"v"(v));  // keep the load; the value itself is not needed
+    }
 }
 
 // pid -> (pixel, sample) for tile enumeration: pid = ((tile_slot*256 + pix)*kc + kk)
@@ -231,6 +247,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, i
     WaveFeed feed{0, 0, count == 0};
     WaveOut shade_out{0, 0};
     auto pad_shade = [&](uint32_t sl) { B.shade_q[sl] = kInvalid; };
+    auto warm = [&](uint32_t first) {
+        warm_plane(ro, first, count);
+        warm_plane(rd, first, count);
+    };
     Trav t;
     t.have = false;
     t.cur = 0;
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, i
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
             uint32_t s_new;
-            if (feed_take(feed, head, count, !active, &s_new)) {
+            if (feed_take(feed, head, count, !active, &s_new, warm)) {
                 slot = s_new;
                 const float4 o4 = ro[slot], d4 = rd[slot];
                 if (f2b(o4.w) != kInvalid) {
@@ -533,7 +553,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_shadow(DScene S, PassBuffers B, i
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
             uint32_t e_new;
-            if (feed_take(feed, head, count, !active, &e_new)) {
+            if (feed_take(feed, head, count, !active, &e_new, [&](uint32_t first) {
+                    warm_plane(B.nee, first, count);
+                    warm_plane(B.nee + plane, first, count);
+                })) {
                 e = e_new;
                 const float4 n1 = B.nee[plane + e];
                 const uint32_t flags = f2b(n1.w);
@@ -610,7 +633,11 @@ __global__ __launch_bounds__(kBlock, 5) void k_mis(DScene S, PassBuffers B, int 
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
             uint32_t e_new;
-            if (feed_take(feed, head, count, !active, &e_new)) {
+            if (feed_take(feed, head, count, !active, &e_new, [&](uint32_t first) {
+                    warm_plane(B.nee + plane, first, count);
+                    warm_plane(B.nee + 2 * size_t(plane), first, count);
+                    warm_plane(B.nee + 3 * size_t(plane), first, count);
+                })) {
                 e = e_new;
                 const uint32_t flags = f2b(B.nee[plane + e].w);
                 if (flags != kInvalid) {
@@ -654,7 +681,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_mis(DScene S, PassBuffers B, int 
                 const float4 v2 = S.tri_verts[3 * size_t(t.hit_prim) + 2];
                 const int li = int(f2b(B.nee[2 * plane + e].w));
                 // `lightIsect.primitive->GetAreaLight() == &light` (integrator.cpp:207)
-                if (int(f2b(v2.w)) == li && (f2b(v0.w) & 1u)) {
+                if (int(f2b(v2.w)) == li && (f2b(v0.w) & 1u) && !(dbg_skip & 4)) {
                     const DSphere &sp = S.spheres[S.prim_shape[t.hit_prim]];
                     float th;
                     F3 od, ph;
