@@ -127,7 +127,7 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    agg = {"ms_extend": 0.0, "ms_connect": 0.0, "ms_shadow": 0.0, "ms_mis": 0.0, "ms_shade": 0.0, "ms_generate": 0.0,
+    agg = {"ms_extend": 0.0, "ms_connect": 0.0, "ms_shadow": 0.0, "ms_mis": 0.0, "ms_resolve": 0.0, "ms_shade": 0.0, "ms_generate": 0.0,
            "ms_film": 0.0, "ms_total": 0.0, "n_extend_launches": 0, "n_connect_launches": 0}
     for _ in range(args.steps):
         st = step(timed=True)
@@ -213,7 +213,7 @@ def main():
             "job_algorithmic_gbs": round(mray * 1e6 * b_ray / 1e9, 1),
             "job_frac_of_hbm_roofline": round(mray * 1e6 * b_ray / 1e9 / (HBM_PEAK_GBS * world), 4),
             "kernel_ms_per_step_rank0": {k: round(agg[k] / args.steps, 3) for k in
-                                         ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_film", "ms_total")},
+                                         ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_resolve", "ms_film", "ms_total")},
             "roofline": {
                 "kernel": dom,
                 "bound": "hbm",

@@ -96,7 +96,7 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     const size_t cap = queue_capacity(n_paths, sc->n_cus);
     // per path: L, beta (float4), hindex; per queue slot: ray_o[2], ray_d[2], hits, nee[7] (float4), shade_q
     const size_t f4 = sizeof(float4);
-    size_t bytes = 2 * n * f4 + n * sizeof(uint32_t) + 12 * cap * f4 + cap * sizeof(uint32_t) +
+    size_t bytes = 2 * n * f4 + n * sizeof(uint32_t) + 12 * cap * f4 + cap * sizeof(uint32_t) + 2 * cap +
                    128 * sizeof(uint32_t) + sizeof(DCounters) + 16384;
     void *blk = nullptr;
     HIP_TRY(hipMalloc(&blk, bytes));
@@ -120,6 +120,8 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     B.nee = reinterpret_cast<float4 *>(take(7 * cap * f4));
     B.hindex = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
     B.shade_q = reinterpret_cast<uint32_t *>(take(cap * sizeof(uint32_t)));
+    B.nee_occl = reinterpret_cast<uint8_t *>(take(cap));
+    B.nee_mis = reinterpret_cast<uint8_t *>(take(cap));
     B.counts = reinterpret_cast<uint32_t *>(take(128 * sizeof(uint32_t)));
     B.counters = reinterpret_cast<DCounters *>(take(sizeof(DCounters)));
     B.nray_out = nullptr;
@@ -211,6 +213,8 @@ int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed
             if (rc) return rc;
             rc = timed_launch(5, [&] { launch_mis(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
+            rc = timed_launch(6, [&] { launch_nee_resolve(S, B, b, B.queue_cap, cfg); });
+            if (rc) return rc;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -227,6 +231,7 @@ int collect_times(iile_scene *sc, iile_stats *st) {
         case 2: st->ms_shade += ms; st->n_shade_launches++; break;
         case 3: st->ms_connect += ms; st->ms_shadow += ms; st->n_connect_launches++; break;
         case 5: st->ms_connect += ms; st->ms_mis += ms; break;
+        case 6: st->ms_connect += ms; st->ms_resolve += ms; break;
         default: st->ms_film += ms; break;
         }
     }
@@ -276,6 +281,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     // ---- what the device path supports -------------------------------------
     if (d->n_lights > 1)
         return fail(IILE_ERR_UNSUPPORTED, "more than one light needs the spatial light distribution (not built)");
+    if (d->n_prims >= (1 << 24)) return fail(IILE_ERR_UNSUPPORTED, "more than 2^24 primitives");
     if (d->n_spheres > kMaxSpheres || d->n_materials > kMaxMaterials || d->n_lights > kMaxLights)
         return fail(IILE_ERR_UNSUPPORTED, "too many spheres / materials / lights");
     for (int i = 0; i < d->n_spheres; ++i) {
@@ -361,7 +367,9 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         std::vector<float2> uvs(3 * n);
         for (size_t i = 0; i < n; ++i) {
             const float *p = d->tri_p + 9 * i, *nn = d->tri_n + 9 * i, *uv = d->tri_uv + 6 * i;
-            uint32_t w[3] = {d->prim_flags[i] | last_in_leaf[i], uint32_t(d->prim_material[i]), uint32_t(d->prim_light[i])};
+            // flag word: bits 0..3 iile_scene.h, bit 4 last primitive of its leaf, bits 8..14 area light index + 1
+            uint32_t w[3] = {d->prim_flags[i] | last_in_leaf[i] | (uint32_t(d->prim_light[i] + 1) << 8),
+                             uint32_t(d->prim_material[i]), uint32_t(d->prim_light[i])};
             for (int k = 0; k < 3; ++k) {
                 float wf;
                 std::memcpy(&wf, &w[k], 4);

@@ -485,9 +485,15 @@ struct Trav {
     int cur;  // >= 0: wide interior record; < 0: leaf, ~cur = first primitive
     int sp;
     bool have;  // cur is a node that passed its box test and still has to be processed
-    int hit_prim;
+    int hit_prim;      // -1: none; else primitive index | (area light index + 1) << kHitLightShift
     float b0, b1, b2;  // barycentrics of the closest triangle hit (t itself is t.tmax)
 };
+// The vertex record's flag word carries (area light index + 1) of the primitive in bits
+// 8..14; it rides along in hit_prim so that the MIS kernel knows whether its ray ended on
+// an emitter without fetching the primitive again.
+constexpr int kHitLightShift = 24;
+constexpr int kHitPrimMask = (1 << kHitLightShift) - 1;
+DEV int hit_index(int hit_prim) { return hit_prim < 0 ? -1 : (hit_prim & kHitPrimMask); }
 struct StackRef {
     lds_int *lds;          // this lane's LDS column: ref plane [level*64], tMin plane [(kLdsStackDepth+level)*64]
     int *spill_base;       // HBM overflow: lane column = spill_base + spill_col, 2 ints per level
@@ -608,7 +614,7 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
                     return true;
                 }
                 t.tmax = th;
-                t.hit_prim = prim;
+                t.hit_prim = prim | int((flags >> 8) & 0x7fu) << kHitLightShift;
                 t.b0 = t.b1 = t.b2 = 0;
             }
         } else {
@@ -624,7 +630,7 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
                     return true;
                 }
                 t.tmax = th;
-                t.hit_prim = prim;
+                t.hit_prim = prim | int((flags >> 8) & 0x7fu) << kHitLightShift;
                 t.b0 = b0;
                 t.b1 = b1;
                 t.b2 = b2;
@@ -648,7 +654,7 @@ DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack,
         while (t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, st);
         if (t.have && trav_leaf<COUNT>(S, t, sr, st, ANY_HIT, &d4)) return true;
     }
-    hit->prim = t.hit_prim;
+    hit->prim = hit_index(t.hit_prim);
     hit->t = t.tmax;
     hit->b0 = t.b0;
     hit->b1 = t.b1;
