@@ -367,8 +367,11 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         std::vector<float2> uvs(3 * n);
         for (size_t i = 0; i < n; ++i) {
             const float *p = d->tri_p + 9 * i, *nn = d->tri_n + 9 * i, *uv = d->tri_uv + 6 * i;
-            // flag word: bits 0..3 iile_scene.h, bit 4 last primitive of its leaf, bits 8..14 area light index + 1
-            uint32_t w[3] = {d->prim_flags[i] | last_in_leaf[i] | (uint32_t(d->prim_light[i] + 1) << 8),
+            // flag word: bits 0..3 iile_scene.h, bit 4 last primitive of its leaf, bits 5..7 shading
+            // class (material type, +4 for a sphere), bits 8..11 area light index + 1
+            const int mt = d->prim_material[i] >= 0 ? d->materials[d->prim_material[i]].type : 3;
+            const uint32_t cls = uint32_t(mt < 0 ? 3 : (mt > 3 ? 3 : mt)) | ((d->prim_flags[i] & 1u) ? 4u : 0u);
+            uint32_t w[3] = {d->prim_flags[i] | last_in_leaf[i] | (cls == 7u ? 6u : cls) << 5 | (uint32_t(d->prim_light[i] + 1) << 8),
                              uint32_t(d->prim_material[i]), uint32_t(d->prim_light[i])};
             for (int k = 0; k < 3; ++k) {
                 float wf;
@@ -561,13 +564,13 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         double budget_mb = 49152;  // 48 GiB of the 288 GB: one pass covers 1080p x 64 spp
         if (const char *e = std::getenv("IILE_WORKSPACE_MB")) budget_mb = std::max(64.0, atof(e));
         uint64_t max_paths = uint64_t(budget_mb * 1048576.0 / 260.0);
-        max_paths = std::min<uint64_t>(max_paths, 0xfff00000ull);
+        max_paths = std::min<uint64_t>(max_paths, 200000000ull);  // queue slots must fit kSlotBits
         int kc_max = int(std::max<uint64_t>(1, max_paths / std::max<uint64_t>(1, pix_slots)));
         int n_passes = (n_samples + kc_max - 1) / kc_max;
         kc = (n_samples + n_passes - 1) / n_passes;
     }
     kc = std::min(kc, n_samples);
-    if (pix_slots * uint64_t(kc) >= 0xfff00000ull) return fail(IILE_ERR_ARG, "pass too large: lower spp_per_pass");
+    if (pix_slots * uint64_t(kc) > 200000000ull) return fail(IILE_ERR_ARG, "pass too large: lower spp_per_pass");
     const uint32_t fw = uint32_t(S.crop_x1 - S.crop_x0), fh = uint32_t(S.crop_y1 - S.crop_y0);
 
     if (pix_slots) {

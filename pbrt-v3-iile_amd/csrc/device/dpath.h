@@ -485,14 +485,17 @@ struct Trav {
     int cur;  // >= 0: wide interior record; < 0: leaf, ~cur = first primitive
     int sp;
     bool have;  // cur is a node that passed its box test and still has to be processed
-    int hit_prim;      // -1: none; else primitive index | (area light index + 1) << kHitLightShift
+    int hit_prim;      // -1: none; else primitive index | hit_tag(flags)
     float b0, b1, b2;  // barycentrics of the closest triangle hit (t itself is t.tmax)
 };
-// The vertex record's flag word carries (area light index + 1) of the primitive in bits
-// 8..14; it rides along in hit_prim so that the MIS kernel knows whether its ray ended on
-// an emitter without fetching the primitive again.
-constexpr int kHitLightShift = 24;
-constexpr int kHitPrimMask = (1 << kHitLightShift) - 1;
+// The vertex record's flag word carries the primitive's shading class (bits 5..7: material
+// type, +4 for a sphere) and its (area light index + 1) (bits 8..11). Both ride along in
+// hit_prim bits 24..30, so that extend can tag shade-queue entries with the class and the
+// MIS kernel knows whether its ray ended on an emitter, without fetching the primitive again.
+constexpr int kHitClassShift = 24;
+constexpr int kHitLightShift = 27;
+constexpr int kHitPrimMask = (1 << kHitClassShift) - 1;
+DEV int hit_tag(uint32_t flags) { return int((flags >> 5) & 0x7fu) << kHitClassShift; }
 DEV int hit_index(int hit_prim) { return hit_prim < 0 ? -1 : (hit_prim & kHitPrimMask); }
 struct StackRef {
     lds_int *lds;          // this lane's LDS column: ref plane [level*64], tMin plane [(kLdsStackDepth+level)*64]
@@ -614,7 +617,7 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
                     return true;
                 }
                 t.tmax = th;
-                t.hit_prim = prim | int((flags >> 8) & 0x7fu) << kHitLightShift;
+                t.hit_prim = prim | hit_tag(flags);
                 t.b0 = t.b1 = t.b2 = 0;
             }
         } else {
@@ -630,7 +633,7 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
                     return true;
                 }
                 t.tmax = th;
-                t.hit_prim = prim | int((flags >> 8) & 0x7fu) << kHitLightShift;
+                t.hit_prim = prim | hit_tag(flags);
                 t.b0 = b0;
                 t.b1 = b1;
                 t.b2 = b2;

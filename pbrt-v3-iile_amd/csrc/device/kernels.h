@@ -16,6 +16,8 @@ struct PassDesc {
 
 // Queue arrays (ray_o/ray_d/hits/shade_q/nee) hold `queue_cap` slots: the paths of a
 // pass plus the padding that block-reserved appends leave behind (kernels.hip).
+// shade-queue entries carry the shading class above the slot number
+constexpr int kSlotBits = 28;
 struct PassBuffers {
     uint32_t queue_cap;
     float4 *L;          // [n_paths] radiance so far (xyz)
