@@ -120,6 +120,7 @@ constexpr int kCntShade = 32;    // [bounce] hits to shade
 constexpr int kCntExtHead = 48;  // [bounce] chunk cursor of the extend queue
 constexpr int kCntConHead = 64;  // [bounce] chunk cursor of the NEE queue (shadow kernel)
 constexpr int kCntMisHead = 80;  // [bounce] chunk cursor of the NEE queue (MIS kernel)
+constexpr int kCntShdHead = 96;  // [bounce] chunk cursor of the shade queue
 
 // Persistent-wavefront work feed. A wavefront reserves kChunk consecutive queue
 // slots with one atomic and hands them to its lanes as they go idle, so lanes
@@ -358,8 +359,13 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
     };
     __shared__ uint32_t s_entry[kWavesPerBlock][kShadeChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
-    for (uint32_t base = (blockIdx.x * kWavesPerBlock + wave) * kShadeChunk; base < count; base += n_waves * kShadeChunk) {
+    uint32_t *const head = &B.counts[kCntShdHead + bounce];
+    for (;;) {
+        // chunks are drawn dynamically: a chunk of glossy hits costs several matte ones
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, uint32_t(kShadeChunk));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= count) break;
         // Each wavefront takes kShadeChunk consecutive hits and regroups them by shading class
         // (material type, sphere) so that its rounds below run one code path each: past the
         // first bounce neighbouring queue entries hit unrelated materials (VALU lane
