@@ -437,7 +437,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         rc = upload(sc, lts.data(), lts.size(), &S.lights);
         if (rc) return bail(rc);
     }
-    // Halton: permutations + per-dimension division magic
+    // Halton: permutations + per-dimension constants
     {
         const iile_halton &h = d->halton;
         rc = upload(sc, h.perms, size_t(h.n_perms), &S.perms);
@@ -445,17 +445,13 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         std::vector<DHaltonDim> dims(h.n_dims);
         for (int i = 0; i < h.n_dims; ++i) {
             const uint32_t base = uint32_t(h.primes[i]);
-            uint32_t l = 0;
-            while ((1ull << l) < base) ++l;  // ceil(log2 base)
-            const unsigned long long m = ((1ull << 32) * ((1ull << l) - base)) / base + 1;
             dims[i].base = base;
-            dims[i].magic = uint32_t(m);
-            dims[i].shift = l - 1;
             dims[i].perm_offset = uint32_t(h.prime_sums[i]);
             const float inv_base = 1.f / float(int(base));
             dims[i].inv_base = inv_base;
             dims[i].perm0_term = inv_base * h.perms[h.prime_sums[i]] / (1 - inv_base);
-            dims[i].pad0 = dims[i].pad1 = 0;
+            dims[i].base_d = double(base);
+            dims[i].inv_base_d = 1.0 / double(base);
         }
         rc = upload(sc, dims.data(), dims.size(), &S.hdims);
         if (rc) return bail(rc);

@@ -73,20 +73,69 @@ DEV float radical_inverse_base3(uint32_t a) {
 // staged in LDS by the shade kernel (lds_u16 *): a path needs one table lookup per
 // digit per dimension, ~30 dependent lookups per bounce.
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
+// ScrambledRadicalInverseSpecialized (lowdiscrepancy.cpp:409-424). The digits are peeled in
+// double arithmetic: next = trunc((a + 0.5) / base) is exact for every u32 a (the fractional
+// part of (a + 0.5) / base stays >= 0.5 / base away from an integer, far more than the 2^-22
+// the rounded product can be off by), digit = a - next * base and reversed * base + perm are
+// exact integers below 2^53, and the final uint64 -> float conversion of the reference rounds
+// the same integer the same way as double -> float here.
 template <typename PermPtr>
-DEV float scrambled_radical_inverse(const DScene &S, PermPtr perms, int dim, uint32_t a) {
+DEV float scrambled_radical_inverse(const DScene &S, PermPtr perms, int dim, uint32_t a0) {
     const DHaltonDim hd = S.hdims[dim];
     PermPtr perm = perms + hd.perm_offset;
-    unsigned long long reversed = 0;
+    double a = double(a0), reversed = 0;
     float inv_base_n = 1;
-    while (a) {
-        uint32_t next = div_magic(a, hd.magic, hd.shift);
-        uint32_t digit = a - next * hd.base;
-        reversed = reversed * hd.base + perm[digit];
+    while (a != 0) {
+        const double next = __builtin_trunc((a + 0.5) * hd.inv_base_d);
+        const uint32_t digit = uint32_t(__builtin_fma(-next, hd.base_d, a));
+        reversed = __builtin_fma(reversed, hd.base_d, double(uint32_t(perm[digit])));
         inv_base_n *= hd.inv_base;
         a = next;
     }
     return mn(inv_base_n * (float(reversed) + hd.perm0_term), kOneMinusEpsilon);
+}
+// N consecutive dimensions of one sample index, `dim0` wave-uniform: the per-dimension
+// constants come through scalar loads, and the N digit chains advance together so that their
+// LDS lookups overlap (one chain alone waits out one LDS round trip per digit).
+typedef const __attribute__((address_space(4))) DHaltonDim *HaltonDimConst;
+template <int N, typename PermPtr>
+DEV void scrambled_radical_inverse_n(const DScene &S, PermPtr perms, int dim0, uint32_t index, float *out) {
+    const HaltonDimConst hd = (HaltonDimConst)(S.hdims) + dim0;
+    double a[N], reversed[N];
+    float inv_base_n[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        a[i] = double(index);
+        reversed[i] = 0;
+        inv_base_n[i] = 1;
+    }
+    bool any = index != 0;
+    while (any) {
+        uint32_t digit[N], p[N];
+        double next[N];
+        bool act[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            act[i] = a[i] != 0;
+            next[i] = __builtin_trunc((a[i] + 0.5) * hd[i].inv_base_d);
+            digit[i] = uint32_t(__builtin_fma(-next[i], hd[i].base_d, a[i]));  // 0 once the chain has ended
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = uint32_t(perms[hd[i].perm_offset + digit[i]]);
+        any = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double r = __builtin_fma(reversed[i], hd[i].base_d, double(p[i]));
+            const float s = inv_base_n[i] * hd[i].inv_base;
+            reversed[i] = act[i] ? r : reversed[i];
+            inv_base_n[i] = act[i] ? s : inv_base_n[i];
+            a[i] = next[i];
+            any = any || next[i] != 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        out[i] = mn(inv_base_n[i] * (float(reversed[i]) + hd[i].perm0_term), kOneMinusEpsilon);
 }
 template <typename PermPtr>
 DEV float sample_dimension(const DScene &S, PermPtr perms, uint32_t index, int dim) {
@@ -167,7 +216,8 @@ struct RayCtx {  // per-ray constants of the watertight test (triangle.cpp:206-2
     F3 o;
     float Sx, Sy, Sz;
     F3 inv_dir;
-    int neg_mask;  // bits 0..2: dirIsNeg[xyz] (bvh.cpp:667); bits 4..5: kz, the max-|d| axis
+    int neg_mask;  // bits 0..2: dirIsNeg[xyz] (bvh.cpp:667); bits 4..5: kz, the max-|d| axis;
+                   // bit 7: some 1/d is infinite, so a slab product can be NaN (0 * inf)
 };
 DEV float comp(F3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 DEV RayCtx make_ray_ctx(F3 o, F3 d) {
@@ -184,6 +234,7 @@ DEV RayCtx make_ray_ctx(F3 o, F3 d) {
     c.Sz = 1.f / dz;
     c.inv_dir = F3{1 / d.x, 1 / d.y, 1 / d.z};  // bvh.cpp:666
     c.neg_mask = (c.inv_dir.x < 0 ? 1 : 0) | (c.inv_dir.y < 0 ? 2 : 0) | (c.inv_dir.z < 0 ? 4 : 0) | (kz << 4);
+    if (!(fabsf(c.inv_dir.x) < IILE_INF && fabsf(c.inv_dir.y) < IILE_INF && fabsf(c.inv_dir.z) < IILE_INF)) c.neg_mask |= 0x80;
     return c;
 }
 
@@ -476,6 +527,35 @@ DEV bool slab_entry(const RayCtx &rc, float bminx, float bminy, float bminz, flo
     return ok && (tmx > 0);
 }
 
+// The same test for a ray whose slab products cannot be NaN (all 1/d finite: neg_mask bit 7
+// clear). Without NaNs the reference's compare-and-replace chain selects exactly
+// max(tx0, ty0, tz0) and min(tx1, ty1, tz1), and its two overlap tests pass iff the three
+// intervals share a point, i.e. iff that maximum <= that minimum. (The chain never tests an
+// axis interval against itself; one can only be inverted by the 1+2*gamma(3) scaling of a
+// negative far plane, and then tMax < 0 fails both formulations.) v_max3/v_min3 replace
+// eight compare/select pairs; signed zeros can differ but tMin/tMax are only ever compared.
+// Both child boxes at once, as float2 lanes (v_pk_add_f32 / v_pk_mul_f32 are full rate).
+typedef float v2f __attribute__((ext_vector_type(2)));
+DEV void slab_entry_finite2(const RayCtx &rc, const float4 q0, const float4 q1, const float4 q2, bool *ok_a,
+                            bool *ok_b, float *tmin_a, float *tmin_b) {
+    // children[0] = (q0.xyz, q0.w q1.xy), children[1] = (q1.zw q2.x, q2.yzw)
+    const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
+    const v2f x0 = v2f{nx ? q0.w : q0.x, nx ? q2.y : q1.z}, x1 = v2f{nx ? q0.x : q0.w, nx ? q1.z : q2.y};
+    const v2f y0 = v2f{ny ? q1.x : q0.y, ny ? q2.z : q1.w}, y1 = v2f{ny ? q0.y : q1.x, ny ? q1.w : q2.z};
+    const v2f z0 = v2f{nz ? q1.y : q0.z, nz ? q2.w : q2.x}, z1 = v2f{nz ? q0.z : q1.y, nz ? q2.x : q2.w};
+    const v2f tx0 = (x0 - rc.o.x) * rc.inv_dir.x, tx1 = (x1 - rc.o.x) * rc.inv_dir.x * kSlabScale;
+    const v2f ty0 = (y0 - rc.o.y) * rc.inv_dir.y, ty1 = (y1 - rc.o.y) * rc.inv_dir.y * kSlabScale;
+    const v2f tz0 = (z0 - rc.o.z) * rc.inv_dir.z, tz1 = (z1 - rc.o.z) * rc.inv_dir.z * kSlabScale;
+    const float mna = __builtin_fmaxf(__builtin_fmaxf(tx0.x, ty0.x), tz0.x);
+    const float mxa = __builtin_fminf(__builtin_fminf(tx1.x, ty1.x), tz1.x);
+    const float mnb = __builtin_fmaxf(__builtin_fmaxf(tx0.y, ty0.y), tz0.y);
+    const float mxb = __builtin_fminf(__builtin_fminf(tx1.y, ty1.y), tz1.y);
+    *tmin_a = mna;
+    *tmin_b = mnb;
+    *ok_a = mna <= mxa && mxa > 0;
+    *ok_b = mnb <= mxb && mxb > 0;
+}
+
 // Resumable traversal state of one lane. The persistent kernels keep a Trav per
 // lane and run the interior / leaf phases for the whole wavefront, refilling
 // lanes whose ray has finished; traverse() below is the single-ray wrapper.
@@ -556,8 +636,13 @@ DEV void trav_interior(Trav &t, const StackRef &sr, TraceStats *st, const float4
     const int axis = __float_as_int(q3.z) & 3;
     // children[0] = (q0.xyz, q0.w q1.xy), children[1] = (q1.zw q2.x, q2.yzw)
     float tmin_a, tmin_b;
-    const bool ok_a = slab_entry(t.rc, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, &tmin_a);
-    const bool ok_b = slab_entry(t.rc, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, &tmin_b);
+    bool ok_a, ok_b;
+    if (__builtin_expect(__ballot(t.rc.neg_mask & 0x80) == 0, 1)) {
+        slab_entry_finite2(t.rc, q0, q1, q2, &ok_a, &ok_b, &tmin_a, &tmin_b);
+    } else {
+        ok_a = slab_entry(t.rc, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, &tmin_a);
+        ok_b = slab_entry(t.rc, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, &tmin_b);
+    }
     // bvh.cpp:686-692: with a negative direction along the split axis the second
     // child is nearer; the other one is deferred
     const bool second_first = (t.rc.neg_mask >> axis) & 1;

@@ -32,13 +32,15 @@ struct DLight {
     int two_sided;
     int sphere;
 };
-// Per Halton dimension: base, exact u32 division magic (round-up method),
-// float reciprocal and offset of its digit permutation.
+// Per Halton dimension: base, float reciprocal and offset of its digit permutation.
+// The digits are peeled in double arithmetic (exact for any u32 index, see
+// scrambled_radical_inverse): FP64 is full rate on CDNA, 32-bit integer multiplies are not.
 struct DHaltonDim {
-    uint32_t base, magic, shift, perm_offset;
+    uint32_t base, perm_offset;
     float inv_base;
     float perm0_term;  // invBase * perm[0] / (1 - invBase), lowdiscrepancy.cpp:422
-    uint32_t pad0, pad1;
+    double base_d;     // double(base)
+    double inv_base_d; // 1.0 / base, only ever used to estimate a quotient that is then exact
 };
 constexpr int kMaxHaltonDims = 128;
 constexpr int kMaxSpheres = 8;

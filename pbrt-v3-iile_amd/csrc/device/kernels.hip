@@ -35,9 +35,9 @@ namespace iile {
 #ifndef IILE_FLAT_MIS
 #define IILE_FLAT_MIS 1
 #endif
-#ifndef IILE_SHADOW_NUM
-#define IILE_SHADOW_NUM 1
-#define IILE_SHADOW_DEN 1
+#ifndef IILE_VOTE_NUM
+#define IILE_VOTE_NUM 1
+#define IILE_VOTE_DEN 1
 #endif
 
 constexpr int kBlock = 256;            // 4 wavefronts
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, i
             const bool wi = active && t.have && t.cur >= 0;
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
-            if (n_int > 0 && n_int >= n_leaf) {
+            if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_interior_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
                 if (wl) trav_leaf<COUNT>(S, t, sr, &st, false, &rd[slot]);
@@ -414,6 +414,22 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             if (valid) {
                 const float4 o4 = ro[slot], d4 = rd[slot], h4 = B.hits[slot];
                 pid = f2b(o4.w);
+                const float4 beta4 = B.beta[pid];
+                beta = F3{beta4.x, beta4.y, beta4.z};
+                dim = int(f2b(beta4.w));
+                hidx = B.hindex[pid];
+                // The four samples of EstimateDirect (dims dim+1 .. dim+4; dim itself is the
+                // 1D sample SampleDiscrete consumes), drawn here while few registers are live.
+                // Every path of a bounce normally sits at the same dimension.
+                float u_nee[4] = {0, 0, 0, 0};
+                if (bounce < S.max_depth) {
+                    const int dim_u = __builtin_amdgcn_readfirstlane(dim);
+                    if (__ballot(dim != dim_u) == 0) {
+                        scrambled_radical_inverse_n<4>(S, s_perms, dim_u + 1, hidx, u_nee);
+                    } else {
+                        for (int i = 0; i < 4; ++i) u_nee[i] = sample_dimension(S, s_perms, hidx, dim + 1 + i);
+                    }
+                }
                 const int prim = int(f2b(h4.x));
                 const F3 ray_o = F3{o4.x, o4.y, o4.z};
                 ray_d = F3{d4.x, d4.y, d4.z};
@@ -434,10 +450,6 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                     triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z},
                                          F3{v2.x, v2.y, v2.z}, ray_d, h4.y, h4.z, h4.w, &is);
                 }
-                const float4 beta4 = B.beta[pid];
-                beta = F3{beta4.x, beta4.y, beta4.z};
-                dim = int(f2b(beta4.w));
-                hidx = B.hindex[pid];
                 // emitted light at the first vertex only: there are no specular lobes
                 // on this path, so specularBounce stays false (path.cpp:91-101)
                 if (bounce == 0 && light >= 0) {
@@ -457,10 +469,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                             const int li = 0;
                             const DLight &lt = S.lights[li];
                             const DSphere &sp = S.spheres[lt.sphere];
-                            const float ul0 = sample_dimension(S, s_perms, hidx, dim),
-                                        ul1 = sample_dimension(S, s_perms, hidx, dim + 1);
-                            const float us0 = sample_dimension(S, s_perms, hidx, dim + 2),
-                                        us1 = sample_dimension(S, s_perms, hidx, dim + 3);
+                            const float ul0 = u_nee[0], ul1 = u_nee[1], us0 = u_nee[2], us1 = u_nee[3];
                             dim += 4;
                             // EstimateDirect, light-sampling half (integrator.cpp:117-163)
                             float light_pdf = 0, scattering_pdf = 0;
@@ -520,7 +529,17 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
         F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
         if (surface) {
             // next direction (path.cpp:133-156)
-            const float u0 = sample_dimension(S, s_perms, hidx, dim), u1 = sample_dimension(S, s_perms, hidx, dim + 1);
+            float u_bsdf[2];
+            {
+                const int dim_u = __builtin_amdgcn_readfirstlane(dim);
+                if (__ballot(dim != dim_u) == 0) {
+                    scrambled_radical_inverse_n<2>(S, s_perms, dim_u, hidx, u_bsdf);
+                } else {
+                    u_bsdf[0] = sample_dimension(S, s_perms, hidx, dim);
+                    u_bsdf[1] = sample_dimension(S, s_perms, hidx, dim + 1);
+                }
+            }
+            const float u0 = u_bsdf[0], u1 = u_bsdf[1];
             dim += 2;
             float pdf = 0;
             F3 wi = F3{0, 0, 0};
@@ -632,7 +651,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_shadow(DScene S, PassBuffers B, i
             const bool wi = active && t.have && t.cur >= 0;
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
-            if (n_int > 0 && n_int * IILE_SHADOW_NUM >= n_leaf * IILE_SHADOW_DEN) {
+            if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_interior_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
                 if (wl && trav_leaf<COUNT>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
@@ -705,7 +724,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_mis(DScene S, PassBuffers B, int 
             const bool wi = active && t.have && t.cur >= 0;
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
-            if (n_int > 0 && n_int >= n_leaf) {
+            if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_interior_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
                 if (wl) trav_leaf<COUNT>(S, t, sr, &st, false, &B.nee[3 * plane + e]);

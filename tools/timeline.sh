@@ -1,0 +1,20 @@
+#!/bin/bash
+# per-launch kernel durations of one bench step (rocprofv3 --kernel-trace)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/timeline
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 > $O/t.log 2>&1
+python3 - <<PY
+import csv,glob
+f=glob.glob('$O/t/*/*kernel_trace.csv')[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+# last pipeline run = after the last k_generate
+idx=max(i for i,r in enumerate(rows) if 'k_generate' in r['Kernel_Name'])
+out=[]
+for r in rows[idx:]:
+    n=r['Kernel_Name'].split('(')[0].replace('void iile::','').replace('iile::','')
+    out.append('%s %.2f'%(n.replace('<false>',''),(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6))
+print(' | '.join(out))
+PY
