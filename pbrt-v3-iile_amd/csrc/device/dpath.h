@@ -109,28 +109,36 @@ DEV void scrambled_radical_inverse_n(const DScene &S, PermPtr perms, int dim0, u
         reversed[i] = 0;
         inv_base_n[i] = 1;
     }
-    bool any = index != 0;
-    while (any) {
+    // all chains run unpredicated while every one of them still has digits left ...
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) all = all && a[i] != 0;
+        if (!all) break;
         uint32_t digit[N], p[N];
-        double next[N];
-        bool act[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            act[i] = a[i] != 0;
-            next[i] = __builtin_trunc((a[i] + 0.5) * hd[i].inv_base_d);
-            digit[i] = uint32_t(__builtin_fma(-next[i], hd[i].base_d, a[i]));  // 0 once the chain has ended
+            const double next = __builtin_trunc((a[i] + 0.5) * hd[i].inv_base_d);
+            digit[i] = uint32_t(__builtin_fma(-next, hd[i].base_d, a[i]));
+            a[i] = next;
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) p[i] = uint32_t(perms[hd[i].perm_offset + digit[i]]);
-        any = false;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const double r = __builtin_fma(reversed[i], hd[i].base_d, double(p[i]));
-            const float s = inv_base_n[i] * hd[i].inv_base;
-            reversed[i] = act[i] ? r : reversed[i];
-            inv_base_n[i] = act[i] ? s : inv_base_n[i];
-            a[i] = next[i];
-            any = any || next[i] != 0;
+            reversed[i] = __builtin_fma(reversed[i], hd[i].base_d, double(p[i]));
+            inv_base_n[i] *= hd[i].inv_base;
+        }
+    }
+    // ... then the larger bases' last digit or two, chain by chain
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        while (a[i] != 0) {
+            const double next = __builtin_trunc((a[i] + 0.5) * hd[i].inv_base_d);
+            const uint32_t digit = uint32_t(__builtin_fma(-next, hd[i].base_d, a[i]));
+            reversed[i] = __builtin_fma(reversed[i], hd[i].base_d, double(uint32_t(perms[hd[i].perm_offset + digit])));
+            inv_base_n[i] *= hd[i].inv_base;
+            a[i] = next;
         }
     }
 #pragma unroll
