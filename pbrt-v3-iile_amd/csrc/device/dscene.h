@@ -83,9 +83,12 @@ struct DScene {
 // hit:  (bitcast prim or -1, b0 | t, b1, b2)
 // NEE entry (7 float4 planes):
 //   n0 = (shadow o.xyz, bitcast pid)      n1 = (shadow d.xyz, bitcast flags)
-//   n2 = (mis o.xyz, bitcast light)       n3 = (mis d.xyz, -)
-//   n4 = (A.xyz, -)   n5 = (B.xyz, -)     n6 = (beta.xyz, -)
-enum { NEE_HAS_SHADOW = 1, NEE_HAS_MIS = 2 };  // + NEE_OCCLUDED = 4, set by the shadow kernel
+//   n2 = (mis o.xyz, bitcast light)       n3 = (mis d.xyz, bitcast flags)
+//   n4 = (A.xyz, bitcast flags)   n5 = (B.xyz, bitcast light)   n6 = (beta.xyz, bitcast pid)
+// (flags / light / pid are repeated so that each consumer streams only the planes it needs)
+// plus two byte planes written by the traversal kernels: nee_occl (shadow ray occluded),
+// nee_mis (area light index + 1 of the primitive the MIS ray ended on, 0 = none)
+enum { NEE_HAS_SHADOW = 1, NEE_HAS_MIS = 2 };
 
 struct DCounters {
     unsigned long long camera_rays, closest_rays, shadow_rays;

@@ -596,7 +596,6 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
 // (One fused kernel walking each record through both rays measured 60 ms per
 // 1080p/64spp step against 7 + 17.5 + 26.4 ms for its parts: any-hit and
 // closest-hit lanes in one wavefront keep each other waiting.)
-enum { NEE_OCCLUDED = 4 };
 
 
 template <bool COUNT>
