@@ -465,6 +465,32 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         S.mult_inv0 = h.mult_inverse[0];
         S.mult_inv1 = h.mult_inverse[1];
         sc->spp = h.spp;
+        // HaltonSampler::GetIndexForSample's per-pixel offset (halton.cpp:96-122) depends only on
+        // the pixel modulo kMaxResolution = 128: tabulated once (integer arithmetic, exact)
+        std::vector<uint32_t> offs(128 * 128, 0u);
+        if (h.sample_stride > 1) {
+            for (int pmy = 0; pmy < 128; ++pmy)
+                for (int pmx = 0; pmx < 128; ++pmx) {
+                    uint32_t inv = uint32_t(pmx), idx0 = 0, idx1 = 0;  // InverseRadicalInverse<2>, <3>
+                    for (int i = 0; i < h.base_exponents[0]; ++i) {
+                        idx0 = idx0 * 2 + (inv & 1);
+                        inv >>= 1;
+                    }
+                    inv = uint32_t(pmy);
+                    for (int i = 0; i < h.base_exponents[1]; ++i) {
+                        idx1 = idx1 * 3 + inv % 3;
+                        inv /= 3;
+                    }
+                    const unsigned long long off =
+                        (unsigned long long)idx0 * (unsigned long long)(h.sample_stride / h.base_scales[0]) *
+                            (unsigned long long)h.mult_inverse[0] +
+                        (unsigned long long)idx1 * (unsigned long long)(h.sample_stride / h.base_scales[1]) *
+                            (unsigned long long)h.mult_inverse[1];
+                    offs[pmy * 128 + pmx] = uint32_t(off % (unsigned long long)h.sample_stride);
+                }
+        }
+        rc = upload(sc, offs.data(), offs.size(), &S.pixel_offsets);
+        if (rc) return bail(rc);
     }
     S.n_nodes = d->n_nodes;
     S.n_prims = d->n_prims;

@@ -23,31 +23,11 @@ DEV uint32_t div_magic(uint32_t a, uint32_t magic, uint32_t shift) {
 // k * stride. 32-bit arithmetic is exact here: the render entry point rejects
 // (spp + 1) * stride >= 2^32.
 DEV uint32_t halton_index(const DScene &S, int px, int py, uint32_t k) {
-    uint32_t offset = 0;
-    if (S.sample_stride > 1) {
-        int pmx = px - (px / 128) * 128, pmy = py - (py / 128) * 128;  // Mod(), pbrt.h:310-314
-        if (pmx < 0) pmx += 128;
-        if (pmy < 0) pmy += 128;
-        // InverseRadicalInverse<2>, <3> (lowdiscrepancy.h:82-91)
-        uint32_t inv = uint32_t(pmx), idx0 = 0;
-        for (int i = 0; i < S.base_exp0; ++i) {
-            idx0 = idx0 * 2 + (inv & 1);
-            inv >>= 1;
-        }
-        inv = uint32_t(pmy);
-        uint32_t idx1 = 0;
-        for (int i = 0; i < S.base_exp1; ++i) {
-            uint32_t q = inv / 3;
-            idx1 = idx1 * 3 + (inv - q * 3);
-            inv = q;
-        }
-        unsigned long long off = (unsigned long long)idx0 * (unsigned long long)(S.sample_stride / S.base_scale0) *
-                                     (unsigned long long)S.mult_inv0 +
-                                 (unsigned long long)idx1 * (unsigned long long)(S.sample_stride / S.base_scale1) *
-                                     (unsigned long long)S.mult_inv1;
-        offset = uint32_t(off % (unsigned long long)S.sample_stride);
-    }
-    return offset + k * uint32_t(S.sample_stride);
+    int pmx = px - (px / 128) * 128, pmy = py - (py / 128) * 128;  // Mod(), pbrt.h:310-314
+    if (pmx < 0) pmx += 128;
+    if (pmy < 0) pmy += 128;
+    // offsetForCurrentPixel (halton.cpp:96-122), tabulated at scene upload
+    return S.pixel_offsets[pmy * 128 + pmx] + k * uint32_t(S.sample_stride);
 }
 
 DEV float radical_inverse_base2(uint32_t a) {
@@ -56,14 +36,15 @@ DEV float radical_inverse_base2(uint32_t a) {
     unsigned long long rev = (unsigned long long)__brev(a) << 32;
     return float(double(rev) * 0x1p-64);
 }
-DEV float radical_inverse_base3(uint32_t a) {
+DEV float radical_inverse_base3(uint32_t a0) {
+    // RadicalInverseSpecialized<3> (lowdiscrepancy.cpp:389-407); digits peeled in double
+    // arithmetic, exact for every u32 (see scrambled_radical_inverse)
     const float inv_base = 1.f / 3.f;
-    unsigned long long reversed = 0;
+    double a = double(a0), reversed = 0;
     float inv_base_n = 1;
-    while (a) {
-        uint32_t next = a / 3u;
-        uint32_t digit = a - next * 3u;
-        reversed = reversed * 3u + digit;
+    while (a != 0) {
+        const double next = __builtin_trunc((a + 0.5) * (1.0 / 3.0));
+        reversed = __builtin_fma(reversed, 3.0, __builtin_fma(-next, 3.0, a));
         inv_base_n *= inv_base;
         a = next;
     }

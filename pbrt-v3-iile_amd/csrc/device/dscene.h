@@ -56,6 +56,7 @@ struct DScene {
     const int *prim_shape;    // sphere index for sphere primitives
     const uint16_t *perms;
     const DHaltonDim *hdims;
+    const uint32_t *pixel_offsets;  // [128*128] Halton index offset of pixel (x mod 128, y mod 128)
     const DSphere *spheres;
     const DMaterial *materials;
     const DLight *lights;
