@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../../include/iile_gpu.h"
@@ -352,6 +353,58 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         }
         rc = upload(sc, wide.data(), wide.size(), &S.wide);
         if (rc) return bail(rc);
+        // Four-wide records (dpath.h trav_interior4): per binary interior node P the boxes / refs
+        // of its grandchildren in fixed slots {L's children | L if leaf, -} {R's children | R, -},
+        // as six SoA planes, then refs, then the split axes of P, L and R. An unused slot gets an
+        // inverted infinite box, which no ray can enter.
+        {
+            const float inf = std::numeric_limits<float>::infinity();
+            std::vector<float4> wide4(8 * size_t(std::max(n_interior, 1)), make_float4(0, 0, 0, 0));
+            for (int i = 0; i < n; ++i) {
+                const iile_bvh_node &nd = d->nodes[i];
+                if (nd.nprims > 0) continue;
+                float bx[6][4];
+                int refs[4];
+                for (int k = 0; k < 4; ++k) {
+                    for (int c = 0; c < 3; ++c) {
+                        bx[c][k] = inf;
+                        bx[3 + c][k] = -inf;
+                    }
+                    refs[k] = 0;
+                }
+                auto fill = [&](int slot, int node) {
+                    const iile_bvh_node &nn = d->nodes[node];
+                    for (int c = 0; c < 3; ++c) {
+                        bx[c][slot] = nn.bmin[c];
+                        bx[3 + c][slot] = nn.bmax[c];
+                    }
+                    refs[slot] = ref_of(node);
+                };
+                uint32_t meta = uint32_t(nd.axis) & 3u;
+                const int child[2] = {i + 1, nd.offset};
+                for (int side = 0; side < 2; ++side) {
+                    const iile_bvh_node &c = d->nodes[child[side]];
+                    if (c.nprims > 0) {
+                        fill(2 * side, child[side]);
+                    } else {
+                        if (child[side] + 1 >= n || c.offset <= child[side] || c.offset >= n)
+                            return bail(fail(IILE_ERR_ARG, "bad BVH child index"));
+                        fill(2 * side, child[side] + 1);
+                        fill(2 * side + 1, c.offset);
+                        meta |= (uint32_t(c.axis) & 3u) << (2 + 2 * side);
+                    }
+                }
+                float4 *w = &wide4[8 * size_t(interior_id[i])];
+                for (int pl = 0; pl < 6; ++pl) w[pl] = make_float4(bx[pl][0], bx[pl][1], bx[pl][2], bx[pl][3]);
+                float fr[4], fm;
+                std::memcpy(fr, refs, 16);
+                std::memcpy(&fm, &meta, 4);
+                w[6] = make_float4(fr[0], fr[1], fr[2], fr[3]);
+                w[7] = make_float4(fm, 0.f, 0.f, 0.f);
+            }
+            rc = upload(sc, wide4.data(), wide4.size(), &S.wide4);
+            if (rc) return bail(rc);
+        }
         if (n > 0) {
             for (int c = 0; c < 3; ++c) {
                 S.root_box[c] = d->nodes[0].bmin[c];

@@ -669,6 +669,100 @@ DEV void trav_interior_step(const DScene &S, Trav &t, const StackRef &sr, TraceS
     trav_interior<COUNT>(t, sr, st, w[0], w[1], w[2], w[3]);
 }
 
+// ---------------------------------------------------------------------------
+// Four-wide step (uninstrumented kernels only). A wide4 record of binary node P holds the
+// boxes and refs of its *grandchildren* in fixed slots — slots 0,1: children of P's first
+// child L (or L itself in slot 0 when L is a leaf), slots 2,3: likewise for P's second child
+// R — and the split axes of P, L and R. One step enters the first grandchild the reference
+// would reach and defers the others in the reference's order (L's near, L's far, R's near,
+// R's far, each pair and the pairs themselves ordered by dirIsNeg of the respective axis).
+//
+// The intermediate nodes L and R are never tested. That cannot change which leaves are tested,
+// nor in which order: a child's box lies inside its parent's (Union is exact), every slab
+// operation ((plane - o) * invDir, * (1 + 2 gamma3), max3/min3) is monotone, so for a ray
+// without NaN slab products "child passes" implies "parent passes" — both the slab overlap
+// with tMax > 0 and tMin < ray.tMax, whatever ray.tMax was when the parent was visited
+// (it only shrinks). What the reference decides at L or R is therefore implied by what it
+// decides at their children. Rays with an infinite 1/d (NaN-capable) take the binary step,
+// which shares refs and stack entries with this one. The visit *counters* do need L and R,
+// so the instrumented kernels keep the binary step.
+DEV void stack_push(Trav &t, const StackRef &sr, int ref, float tmin) {
+    if (t.sp < kLdsStackDepth) {
+        sr.lds[t.sp * 64] = ref;
+        sr.lds[(kLdsStackDepth + t.sp) * 64] = __float_as_int(tmin);
+    } else {
+        const size_t off = size_t(t.sp - kLdsStackDepth) * 2 * sr.spill_stride;
+        sr.spill()[off] = ref;
+        sr.spill()[off + sr.spill_stride] = __float_as_int(tmin);
+    }
+    ++t.sp;
+}
+DEV void trav_interior4(Trav &t, const StackRef &sr, const float4 mnx, const float4 mny, const float4 mnz,
+                        const float4 mxx, const float4 mxy, const float4 mxz, const float4 refs, const uint32_t meta) {
+    const RayCtx &rc = t.rc;
+    const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
+    // entry / exit planes of slots (0,1) and (2,3) as float2 lanes
+    const v2f x0a = v2f{nx ? mxx.x : mnx.x, nx ? mxx.y : mnx.y}, x0b = v2f{nx ? mxx.z : mnx.z, nx ? mxx.w : mnx.w};
+    const v2f x1a = v2f{nx ? mnx.x : mxx.x, nx ? mnx.y : mxx.y}, x1b = v2f{nx ? mnx.z : mxx.z, nx ? mnx.w : mxx.w};
+    const v2f y0a = v2f{ny ? mxy.x : mny.x, ny ? mxy.y : mny.y}, y0b = v2f{ny ? mxy.z : mny.z, ny ? mxy.w : mny.w};
+    const v2f y1a = v2f{ny ? mny.x : mxy.x, ny ? mny.y : mxy.y}, y1b = v2f{ny ? mny.z : mxy.z, ny ? mny.w : mxy.w};
+    const v2f z0a = v2f{nz ? mxz.x : mnz.x, nz ? mxz.y : mnz.y}, z0b = v2f{nz ? mxz.z : mnz.z, nz ? mxz.w : mnz.w};
+    const v2f z1a = v2f{nz ? mnz.x : mxz.x, nz ? mnz.y : mxz.y}, z1b = v2f{nz ? mnz.z : mxz.z, nz ? mnz.w : mxz.w};
+    const v2f tx0a = (x0a - rc.o.x) * rc.inv_dir.x, tx0b = (x0b - rc.o.x) * rc.inv_dir.x;
+    const v2f tx1a = (x1a - rc.o.x) * rc.inv_dir.x * kSlabScale, tx1b = (x1b - rc.o.x) * rc.inv_dir.x * kSlabScale;
+    const v2f ty0a = (y0a - rc.o.y) * rc.inv_dir.y, ty0b = (y0b - rc.o.y) * rc.inv_dir.y;
+    const v2f ty1a = (y1a - rc.o.y) * rc.inv_dir.y * kSlabScale, ty1b = (y1b - rc.o.y) * rc.inv_dir.y * kSlabScale;
+    const v2f tz0a = (z0a - rc.o.z) * rc.inv_dir.z, tz0b = (z0b - rc.o.z) * rc.inv_dir.z;
+    const v2f tz1a = (z1a - rc.o.z) * rc.inv_dir.z * kSlabScale, tz1b = (z1b - rc.o.z) * rc.inv_dir.z * kSlabScale;
+    // per slot: tMin, and whether it is to be visited as things stand (key = tMin, else +inf;
+    // a visitable tMin is < ray.tMax <= inf, so +inf is free to mean "no")
+    auto slot_key = [&](float a0, float b0, float c0, float a1, float b1, float c1) {
+        const float tmin = __builtin_fmaxf(__builtin_fmaxf(a0, b0), c0);
+        const float tmx = __builtin_fminf(__builtin_fminf(a1, b1), c1);
+        return (tmin <= tmx && tmx > 0 && tmin < t.tmax) ? tmin : IILE_INF;
+    };
+    const float k0 = slot_key(tx0a.x, ty0a.x, tz0a.x, tx1a.x, ty1a.x, tz1a.x);
+    const float k1 = slot_key(tx0a.y, ty0a.y, tz0a.y, tx1a.y, ty1a.y, tz1a.y);
+    const float k2 = slot_key(tx0b.x, ty0b.x, tz0b.x, tx1b.x, ty1b.x, tz1b.x);
+    const float k3 = slot_key(tx0b.y, ty0b.y, tz0b.y, tx1b.y, ty1b.y, tz1b.y);
+    const int r0 = __float_as_int(refs.x), r1 = __float_as_int(refs.y), r2 = __float_as_int(refs.z),
+              r3 = __float_as_int(refs.w);
+    // the reference's visiting order (bvh.cpp:686-692 applied at P, L and R)
+    const bool swap_p = (rc.neg_mask >> (meta & 3u)) & 1, swap_l = (rc.neg_mask >> ((meta >> 2) & 3u)) & 1,
+               swap_r = (rc.neg_mask >> ((meta >> 4) & 3u)) & 1;
+    const int a0r = swap_l ? r1 : r0, a1r = swap_l ? r0 : r1, b0r = swap_r ? r3 : r2, b1r = swap_r ? r2 : r3;
+    const float a0k = swap_l ? k1 : k0, a1k = swap_l ? k0 : k1, b0k = swap_r ? k3 : k2, b1k = swap_r ? k2 : k3;
+    const int e0r = swap_p ? b0r : a0r, e1r = swap_p ? b1r : a1r, e2r = swap_p ? a0r : b0r, e3r = swap_p ? a1r : b1r;
+    const float e0k = swap_p ? b0k : a0k, e1k = swap_p ? b1k : a1k, e2k = swap_p ? a0k : b0k, e3k = swap_p ? a1k : b1k;
+    const bool v0 = e0k < IILE_INF, v1 = e1k < IILE_INF, v2 = e2k < IILE_INF, v3 = e3k < IILE_INF;
+    // defer everything behind the first visitable slot, farthest first
+    if (v3 && (v0 || v1 || v2)) stack_push(t, sr, e3r, e3k);
+    if (v2 && (v0 || v1)) stack_push(t, sr, e2r, e2k);
+    if (v1 && v0) stack_push(t, sr, e1r, e1k);
+    if (v0 || v1 || v2 || v3)
+        t.cur = v0 ? e0r : (v1 ? e1r : (v2 ? e2r : e3r));
+    else
+        trav_pop<false>(t, sr, nullptr);
+}
+// One interior step of the uninstrumented kernels: the four-wide record, unless a lane of the
+// wavefront carries a NaN-capable ray.
+DEV void trav_interior_step_fast(const DScene &S, Trav &t, const StackRef &sr) {
+    if (__builtin_expect(__ballot(t.rc.neg_mask & 0x80) == 0, 1)) {
+        const float4 *w = S.wide4 + 8 * size_t(t.cur < 0 ? 0 : t.cur);
+        trav_interior4(t, sr, w[0], w[1], w[2], w[3], w[4], w[5], w[6], __float_as_uint(w[7].x));
+    } else {
+        const float4 *w = S.wide + 4 * size_t(t.cur < 0 ? 0 : t.cur);
+        trav_interior<false>(t, sr, nullptr, w[0], w[1], w[2], w[3]);
+    }
+}
+template <bool COUNT>
+DEV void trav_step(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st) {
+    if (COUNT)
+        trav_interior_step<true>(S, t, sr, st);
+    else
+        trav_interior_step_fast(S, t, sr);
+}
+
 // ray_d: the float4 record holding the ray direction — only the (rare) sphere
 // test needs it, so it is re-read there instead of living in registers.
 template <bool COUNT>
@@ -728,7 +822,7 @@ DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack,
     const float4 d4 = make_float4(rd.x, rd.y, rd.z, 0.f);
     trav_begin<COUNT>(S, t, ro, rd, tmax, st);
     while (t.have) {
-        while (t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, st);
+        while (t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, st);
         if (t.have && trav_leaf<COUNT>(S, t, sr, st, ANY_HIT, &d4)) return true;
     }
     hit->prim = hit_index(t.hit_prim);

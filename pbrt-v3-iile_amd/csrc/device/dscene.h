@@ -50,6 +50,7 @@ constexpr int kMaxLights = 8;
 struct DScene {
     // HBM arrays
     const float4 *wide;       // 4 float4 per interior node: both child boxes + child refs + split axis
+    const float4 *wide4;      // four-wide records (8 float4 per interior node), see trav_interior4
     const float4 *tri_verts;  // 3 float4 per primitive: (p.xyz, w): w0=flags w1=material w2=light
     const float4 *tri_norms;  // 3 float4 per primitive: (n.xyz, uv.{x,y} spread over w)
     const float2 *tri_uv;     // 3 float2 per primitive

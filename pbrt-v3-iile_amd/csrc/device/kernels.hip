@@ -297,13 +297,13 @@ __global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, i
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
-                if (wi) trav_interior_step<COUNT>(S, t, sr, &st);
+                if (wi) trav_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
                 if (wl) trav_leaf<COUNT>(S, t, sr, &st, false, &rd[slot]);
             }
         }
 #else
-        while (active && t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, &st);
+        while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
         if (active && t.have) trav_leaf<COUNT>(S, t, sr, &st, false, &rd[slot]);
 #endif
         const bool fin = active && !t.have;
@@ -651,13 +651,13 @@ __global__ __launch_bounds__(kBlock, 5) void k_shadow(DScene S, PassBuffers B, i
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
-                if (wi) trav_interior_step<COUNT>(S, t, sr, &st);
+                if (wi) trav_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
                 if (wl && trav_leaf<COUNT>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
             }
         }
 #else
-        while (active && t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, &st);
+        while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
         if (active && t.have && trav_leaf<COUNT>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
 #endif
         if (active && !t.have) {
@@ -724,13 +724,13 @@ __global__ __launch_bounds__(kBlock, 5) void k_mis(DScene S, PassBuffers B, int 
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
-                if (wi) trav_interior_step<COUNT>(S, t, sr, &st);
+                if (wi) trav_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
                 if (wl) trav_leaf<COUNT>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
             }
         }
 #else
-        while (active && t.have && t.cur >= 0) trav_interior_step<COUNT>(S, t, sr, &st);
+        while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
         if (active && t.have) trav_leaf<COUNT>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
 #endif
         if (active && !t.have) {
