@@ -92,7 +92,9 @@ void iile_scene_destroy(iile_scene *scene);
 int iile_render(iile_scene *scene, const iile_render_params *params, float *film_xyzw, iile_stats *stats);
 
 /* ---- kernel-level entry points (parity tests; host pointers, synchronous) ---- */
-/* BVHAccel::Intersect on n rays. prim[i] = -1 on miss; tb[4i..] = {t, b0, b1, b2}. */
+/* BVHAccel::Intersect on n rays. prim[i] = -1 on miss; tb[4i..] = {t, b0, b1, b2}.
+ * With stats != NULL the instrumented traversal runs (visit counters, binary steps); with
+ * stats == NULL the traversal of the uninstrumented render kernels (four-wide steps). */
 int iile_trace_closest(iile_scene *scene, int32_t n, const float *o3, const float *d3, const float *tmax,
                        int32_t *prim, float *tb, iile_stats *stats);
 /* BVHAccel::IntersectP on n rays. */

@@ -212,23 +212,26 @@ class GpuScene:
         self._check(rc, "iile_render")
         return film, (st.as_dict() if want_stats else None)
 
-    def trace_closest(self, o, d, tmax):
+    def trace_closest(self, o, d, tmax, instrumented=True):
+        """instrumented=False runs the traversal of the uninstrumented render kernels."""
         o, d, tmax = _f32(o), _f32(d), _f32(tmax)
         n = len(tmax)
         prim = np.empty(n, np.int32)
         tb = np.empty((n, 4), np.float32)
         st = GpuStats()
         self._check(gpu_lib().iile_trace_closest(self._s, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data,
-                                                 prim.ctypes.data, tb.ctypes.data, ctypes.byref(st)), "iile_trace_closest")
+                                                 prim.ctypes.data, tb.ctypes.data,
+                                                 ctypes.byref(st) if instrumented else None), "iile_trace_closest")
         return prim, tb, st.as_dict()
 
-    def trace_any(self, o, d, tmax):
+    def trace_any(self, o, d, tmax, instrumented=True):
         o, d, tmax = _f32(o), _f32(d), _f32(tmax)
         n = len(tmax)
         hit = np.empty(n, np.int32)
         st = GpuStats()
         self._check(gpu_lib().iile_trace_any(self._s, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data,
-                                             hit.ctypes.data, ctypes.byref(st)), "iile_trace_any")
+                                             hit.ctypes.data, ctypes.byref(st) if instrumented else None),
+                    "iile_trace_any")
         return hit, st.as_dict()
 
     def halton_samples(self, px, py, k, dim0, ndims):

@@ -731,7 +731,7 @@ static int trace_common(iile_scene *sc, int32_t n, const float *o3, const float 
     HIP_TRY(hipMemset(dc, 0, sizeof(DCounters)));
     HIP_TRY(hipMemcpy(dro, ro.data(), size_t(n) * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(drd, rd.data(), size_t(n) * sizeof(float4), hipMemcpyHostToDevice));
-    LaunchCfg cfg{sc->n_cus, nullptr, true};
+    LaunchCfg cfg{sc->n_cus, nullptr, stats != nullptr};
     if (n) launch_trace(sc->ds, n, dro, drd, dh, any, dc, sc->spill, cfg);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

@@ -1085,12 +1085,19 @@ void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &
 void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, float4 *hits, int any_hit,
                   DCounters *counters, int *spill, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(uint32_t(n), cfg.n_cus, kTraverseBlocksPerCu));
-    if (any_hit)
-        hipLaunchKernelGGL((k_trace<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, n, ro, rd, hits, counters,
-                           spill);
-    else
-        hipLaunchKernelGGL((k_trace<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, n, ro, rd, hits, counters,
-                           spill);
+    // count_stats selects the instrumented traversal (binary steps) or the one the render
+    // kernels run uninstrumented (four-wide steps)
+    if (any_hit) {
+        if (cfg.count_stats)
+            hipLaunchKernelGGL((k_trace<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, n, ro, rd, hits, counters, spill);
+        else
+            hipLaunchKernelGGL((k_trace<true, false>), grid, dim3(kBlock), 0, cfg.stream, S, n, ro, rd, hits, counters, spill);
+    } else {
+        if (cfg.count_stats)
+            hipLaunchKernelGGL((k_trace<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, n, ro, rd, hits, counters, spill);
+        else
+            hipLaunchKernelGGL((k_trace<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, n, ro, rd, hits, counters, spill);
+    }
 }
 void launch_halton(const DScene &S, int n, const int *px, const int *py, const int *k, int dim0, int ndims,
                    float *out, uint32_t *index_out, const LaunchCfg &cfg) {

@@ -93,18 +93,52 @@ def _camera_and_random_rays(scene, oracle, n, seed):
     return o, d, tmax
 
 
-def test_closest_hit_matches_oracle(gpu_c1, scene_c1, oracle):
+def _degenerate_rays(n, seed):
+    """Rays whose slab products hit 0 * inf (NaN) or +-inf: directions with zero (and negative
+    zero) components, origins exactly on box planes of killeroo-simple (floor z = -140, wall
+    x = -400, quad extents +-1000, -1140, 860) — the cases where Bounds3::IntersectP's
+    compare-and-replace chain is not a plain min/max."""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-500, 500, (n, 3)).astype(np.float32)
+    d = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    kind = rng.integers(0, 8, n)
+    planes = {0: (2, -140.0), 1: (0, -400.0), 2: (0, 1000.0), 3: (1, -1000.0), 4: (2, 860.0), 5: (2, -1140.0)}
+    for i in range(n):
+        k = int(kind[i])
+        if k in planes:  # on a box plane, travelling inside it
+            ax, val = planes[k]
+            o[i, ax] = val
+            d[i, ax] = 0.0 if rng.random() < .5 else -0.0
+        elif k == 6:  # one zero component, arbitrary origin
+            d[i, rng.integers(0, 3)] = 0.0 if rng.random() < .5 else -0.0
+        else:  # axis aligned: two zero components
+            ax = rng.integers(0, 3)
+            keep = d[i, ax] if d[i, ax] != 0 else 1.0
+            d[i] = [0.0 if rng.random() < .5 else -0.0 for _ in range(3)]
+            d[i, ax] = keep
+    tmax = rng.choice([np.inf, 2000.0, 500.0], n).astype(np.float32)
+    return o, d, tmax
+
+
+@pytest.mark.parametrize("instrumented", [True, False])
+def test_closest_hit_matches_oracle(gpu_c1, scene_c1, oracle, instrumented):
+    """instrumented=False is the traversal the timed render kernels run (four-wide steps)."""
     o, d, tmax = _camera_and_random_rays(scene_c1, oracle, 65536, 3)
-    prim, tb, st = gpu_c1.trace_closest(o, d, tmax)
+    o2, d2, t2 = _degenerate_rays(16384, 13)
+    o, d, tmax = np.concatenate([o, o2]), np.concatenate([d, d2]), np.concatenate([tmax, t2])
+    prim, tb, st = gpu_c1.trace_closest(o, d, tmax, instrumented=instrumented)
     rprim, rtb = oracle.intersect(scene_c1, o, d, tmax)
     assert np.array_equal(prim, rprim), f"{int((prim != rprim).sum())} closest-hit primitives differ"
-    assert (prim >= 0).sum() > 10000
+    assert (prim >= 0).sum() > 10000 and (prim[65536:] >= 0).sum() > 1000
     assert_bitwise(tb, rtb, "closest hit (t, b0, b1, b2)")
 
 
-def test_any_hit_matches_oracle(gpu_c1, scene_c1, oracle):
+@pytest.mark.parametrize("instrumented", [True, False])
+def test_any_hit_matches_oracle(gpu_c1, scene_c1, oracle, instrumented):
     o, d, tmax = _camera_and_random_rays(scene_c1, oracle, 65536, 4)
-    hit, st = gpu_c1.trace_any(o, d, tmax)
+    o2, d2, t2 = _degenerate_rays(16384, 14)
+    o, d, tmax = np.concatenate([o, o2]), np.concatenate([d, d2]), np.concatenate([tmax, t2])
+    hit, st = gpu_c1.trace_any(o, d, tmax, instrumented=instrumented)
     rhit = oracle.intersect_p(scene_c1, o, d, tmax)
     assert np.array_equal(hit, rhit)
     assert 1000 < hit.sum() < len(hit)
@@ -156,6 +190,8 @@ def test_film_small_bitwise_and_counters(gpu_small, scene_small, oracle):
     assert st["nee_evals"] == ost["nee_evals"] and st["zero_radiance"] == ost["zero_radiance"]
     assert st["path_length"] == ost["path_length"]
     assert st["ms_extend"] > 0 and st["n_extend_launches"] == 6 * st["n_passes"]
+    plain, _ = gpu_small.render()  # the uninstrumented kernels (what bench.py times)
+    assert_bitwise(plain, ref, "film, uninstrumented kernels")
 
 
 def test_film_c1_bitwise_vs_oracle_and_reference_pins(gpu_c1, scene_c1, oracle):
@@ -163,6 +199,8 @@ def test_film_c1_bitwise_vs_oracle_and_reference_pins(gpu_c1, scene_c1, oracle):
     film, st = gpu_c1.render(collect_stats=True)
     ref, ost = oracle.render(scene_c1)
     assert_bitwise(film, ref, "C1 film")
+    plain, _ = gpu_c1.render()
+    assert_bitwise(plain, ref, "C1 film, uninstrumented kernels")
     # ray counts of the device equal the portable-mode oracle's exactly ...
     assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
     # ... and sit within a handful of flipped paths of the reference's own counts
@@ -195,6 +233,8 @@ def test_furnace_scene_on_device(binding, oracle):
     film, st = gpu.render(collect_stats=True)
     ref, ost = oracle.render(scene)
     assert_bitwise(film, ref, "furnace film")
+    plain, _ = gpu.render()
+    assert_bitwise(plain, ref, "furnace film, uninstrumented kernels")
     assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
     assert st["path_length"] == ost["path_length"]
     assert abs(float(scene.film_to_rgb(film).mean(dtype=np.float64)) - 1.0) < 0.02
