@@ -36,8 +36,8 @@ namespace iile {
 #define IILE_FLAT_MIS 1
 #endif
 #ifndef IILE_VOTE_NUM
-#define IILE_VOTE_NUM 1
-#define IILE_VOTE_DEN 1
+#define IILE_VOTE_NUM 3
+#define IILE_VOTE_DEN 2
 #endif
 
 constexpr int kBlock = 256;            // 4 wavefronts
