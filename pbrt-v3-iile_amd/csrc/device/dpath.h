@@ -202,7 +202,10 @@ DEV void camera_ray(const DScene &S, float pfx, float pfy, float lu0, float lu1,
 // ray / primitive tests
 // ===========================================================================
 struct RayCtx {  // per-ray constants of the watertight test (triangle.cpp:206-226) and the slab test
-    F3 o;
+    // origin as three scalars, not an F3: as a sub-struct it survived scalar replacement (the
+    // vectorizer gave it overlapping float2 accesses) and lived in scratch / LDS, not registers
+    float ox, oy, oz;
+    DEV F3 o() const { return F3{ox, oy, oz}; }
     float Sx, Sy, Sz;
     F3 inv_dir;
     int neg_mask;  // bits 0..2: dirIsNeg[xyz] (bvh.cpp:667); bits 4..5: kz, the max-|d| axis;
@@ -211,7 +214,9 @@ struct RayCtx {  // per-ray constants of the watertight test (triangle.cpp:206-2
 DEV float comp(F3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 DEV RayCtx make_ray_ctx(F3 o, F3 d) {
     RayCtx c;
-    c.o = o;
+    c.ox = o.x;
+    c.oy = o.y;
+    c.oz = o.z;
     F3 ad = vabs(d);
     const int kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxDimension
     // Permute(d, kx, ky, kz) with kx = kz+1, ky = kx+1 (mod 3)
@@ -231,7 +236,8 @@ DEV RayCtx make_ray_ctx(F3 o, F3 d) {
 // the SurfaceInteraction part is deferred to the shade kernel.
 DEV bool triangle_test(const RayCtx &rc, float tmax, F3 p0, F3 p1, F3 p2, float *t_out, float *b0o, float *b1o,
                        float *b2o) {
-    F3 a = p0 - rc.o, b = p1 - rc.o, c = p2 - rc.o;
+    const F3 ro = rc.o();
+    F3 a = p0 - ro, b = p1 - ro, c = p2 - ro;
     const int kz = (rc.neg_mask >> 4) & 3;
     // Permute(p, kx, ky, kz): kz == 0 -> (y,z,x); kz == 1 -> (z,x,y); kz == 2 -> (x,y,z)
     float ax = kz == 0 ? a.y : (kz == 1 ? a.z : a.x), ay = kz == 0 ? a.z : (kz == 1 ? a.x : a.y),
@@ -497,17 +503,17 @@ struct HitRec {
 DEV bool slab_entry(const RayCtx &rc, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
                     float *tmin_out) {
     const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
-    float tmin = ((nx ? bmaxx : bminx) - rc.o.x) * rc.inv_dir.x;
-    float tmx = ((nx ? bminx : bmaxx) - rc.o.x) * rc.inv_dir.x;
-    float tymin = ((ny ? bmaxy : bminy) - rc.o.y) * rc.inv_dir.y;
-    float tymax = ((ny ? bminy : bmaxy) - rc.o.y) * rc.inv_dir.y;
+    float tmin = ((nx ? bmaxx : bminx) - rc.ox) * rc.inv_dir.x;
+    float tmx = ((nx ? bminx : bmaxx) - rc.ox) * rc.inv_dir.x;
+    float tymin = ((ny ? bmaxy : bminy) - rc.oy) * rc.inv_dir.y;
+    float tymax = ((ny ? bminy : bmaxy) - rc.oy) * rc.inv_dir.y;
     tmx *= kSlabScale;
     tymax *= kSlabScale;
     bool ok = !(tmin > tymax || tymin > tmx);
     if (tymin > tmin) tmin = tymin;
     if (tymax < tmx) tmx = tymax;
-    float tzmin = ((nz ? bmaxz : bminz) - rc.o.z) * rc.inv_dir.z;
-    float tzmax = ((nz ? bminz : bmaxz) - rc.o.z) * rc.inv_dir.z;
+    float tzmin = ((nz ? bmaxz : bminz) - rc.oz) * rc.inv_dir.z;
+    float tzmax = ((nz ? bminz : bmaxz) - rc.oz) * rc.inv_dir.z;
     tzmax *= kSlabScale;
     ok = ok && !(tmin > tzmax || tzmin > tmx);
     if (tzmin > tmin) tmin = tzmin;
@@ -532,9 +538,12 @@ DEV void slab_entry_finite2(const RayCtx &rc, const float4 q0, const float4 q1, 
     const v2f x0 = v2f{nx ? q0.w : q0.x, nx ? q2.y : q1.z}, x1 = v2f{nx ? q0.x : q0.w, nx ? q1.z : q2.y};
     const v2f y0 = v2f{ny ? q1.x : q0.y, ny ? q2.z : q1.w}, y1 = v2f{ny ? q0.y : q1.x, ny ? q1.w : q2.z};
     const v2f z0 = v2f{nz ? q1.y : q0.z, nz ? q2.w : q2.x}, z1 = v2f{nz ? q0.z : q1.y, nz ? q2.x : q2.w};
-    const v2f tx0 = (x0 - rc.o.x) * rc.inv_dir.x, tx1 = (x1 - rc.o.x) * rc.inv_dir.x * kSlabScale;
-    const v2f ty0 = (y0 - rc.o.y) * rc.inv_dir.y, ty1 = (y1 - rc.o.y) * rc.inv_dir.y * kSlabScale;
-    const v2f tz0 = (z0 - rc.o.z) * rc.inv_dir.z, tz1 = (z1 - rc.o.z) * rc.inv_dir.z * kSlabScale;
+    const float fox = rc.ox, foy = rc.oy, foz = rc.oz, fix = rc.inv_dir.x, fiy = rc.inv_dir.y, fiz = rc.inv_dir.z;
+    const v2f ox = v2f{fox, fox}, oy = v2f{foy, foy}, oz = v2f{foz, foz}, ix = v2f{fix, fix}, iy = v2f{fiy, fiy},
+              iz = v2f{fiz, fiz}, sc = v2f{kSlabScale, kSlabScale};
+    const v2f tx0 = (x0 - ox) * ix, tx1 = (x1 - ox) * ix * sc;
+    const v2f ty0 = (y0 - oy) * iy, ty1 = (y1 - oy) * iy * sc;
+    const v2f tz0 = (z0 - oz) * iz, tz1 = (z1 - oz) * iz * sc;
     const float mna = __builtin_fmaxf(__builtin_fmaxf(tx0.x, ty0.x), tz0.x);
     const float mxa = __builtin_fminf(__builtin_fminf(tx1.x, ty1.x), tz1.x);
     const float mnb = __builtin_fmaxf(__builtin_fmaxf(tx0.y, ty0.y), tz0.y);
@@ -592,21 +601,52 @@ DEV void trav_begin(const DScene &S, Trav &t, F3 ro, F3 rd, float tmax, TraceSta
     t.have = ok && (tmin < tmax);
 }
 
+// The per-lane stack keeps its *newest* kLdsStackDepth levels in LDS, as a ring
+// (level l lives in LDS slot l mod kLdsStackDepth); when it grows beyond that, the oldest
+// level is evicted to the lane's HBM column — a store nobody waits for — and comes back only
+// if the traversal ever unwinds that far. (Spilling the newest levels instead, as a plain
+// array would, puts an HBM round trip on the very next pop: 12 vs 14 LDS levels cost 5 ms
+// per frame that way.) Trav::sp packs both cursors: bits 0..7 = number of levels on the
+// stack, bits 8.. = number of levels that live in HBM (levels [0, lo)).
+// level % kLdsStackDepth for level < 128 without an integer division (exact for depths 8..32)
+static_assert(kLdsStackDepth >= 8 && kLdsStackDepth <= 32, "lds_slot's reciprocal is checked for depths 8..32");
+DEV int lds_slot(int level) {
+    constexpr int kRecip = (65536 + kLdsStackDepth - 1) / kLdsStackDepth;
+    return level - kLdsStackDepth * ((level * kRecip) >> 16);
+}
+DEV int stack_size(const Trav &t) { return t.sp & 0xff; }
+DEV void stack_push(Trav &t, const StackRef &sr, int ref, float tmin) {
+    const int sp = t.sp & 0xff, lo = t.sp >> 8;
+    if (sp - lo == kLdsStackDepth) {
+        const int slot = lds_slot(lo);
+        const size_t off = size_t(lo) * 2 * sr.spill_stride;
+        sr.spill()[off] = sr.lds[slot * 64];
+        sr.spill()[off + sr.spill_stride] = sr.lds[(kLdsStackDepth + slot) * 64];
+        t.sp += 256;
+    }
+    const int slot = lds_slot(sp);
+    sr.lds[slot * 64] = ref;
+    sr.lds[(kLdsStackDepth + slot) * 64] = __float_as_int(tmin);
+    t.sp += 1;
+}
 // resume at the most recent deferred (far) child that still passes `tMin < ray.tMax`
 template <bool COUNT>
 DEV void trav_pop(Trav &t, const StackRef &sr, TraceStats *st) {
     t.have = false;
-    while (t.sp > 0) {
+    while ((t.sp & 0xff) > 0) {
         --t.sp;
+        const int sp = t.sp & 0xff, lo = t.sp >> 8;
         int ref;
         float tmin;
-        if (t.sp < kLdsStackDepth) {
-            ref = sr.lds[t.sp * 64];
-            tmin = __int_as_float(sr.lds[(kLdsStackDepth + t.sp) * 64]);
-        } else {
-            const size_t off = size_t(t.sp - kLdsStackDepth) * 2 * sr.spill_stride;
+        if (sp >= lo) {
+            const int slot = lds_slot(sp);
+            ref = sr.lds[slot * 64];
+            tmin = __int_as_float(sr.lds[(kLdsStackDepth + slot) * 64]);
+        } else {  // LDS ring empty: level sp is the newest one in HBM
+            const size_t off = size_t(sp) * 2 * sr.spill_stride;
             ref = sr.spill()[off];
             tmin = __int_as_float(sr.spill()[off + sr.spill_stride]);
+            t.sp = sp | (sp << 8);
         }
         if (COUNT) ++st->nodes;
         if (tmin < t.tmax) {
@@ -641,15 +681,7 @@ DEV void trav_interior(Trav &t, const StackRef &sr, TraceStats *st, const float4
     if (COUNT || far_ok) {
         // a far child whose slabs can never pass is only kept for the visit count
         const float ft = far_ok ? far_tmin : IILE_INF;
-        if (t.sp < kLdsStackDepth) {
-            sr.lds[t.sp * 64] = far_ref;
-            sr.lds[(kLdsStackDepth + t.sp) * 64] = __float_as_int(ft);
-        } else {
-            const size_t off = size_t(t.sp - kLdsStackDepth) * 2 * sr.spill_stride;
-            sr.spill()[off] = far_ref;
-            sr.spill()[off + sr.spill_stride] = __float_as_int(ft);
-        }
-        ++t.sp;
+        stack_push(t, sr, far_ref, ft);
     }
     if (COUNT) ++st->nodes;
     if (near_ok && near_tmin < t.tmax)
@@ -686,17 +718,6 @@ DEV void trav_interior_step(const DScene &S, Trav &t, const StackRef &sr, TraceS
 // decides at their children. Rays with an infinite 1/d (NaN-capable) take the binary step,
 // which shares refs and stack entries with this one. The visit *counters* do need L and R,
 // so the instrumented kernels keep the binary step.
-DEV void stack_push(Trav &t, const StackRef &sr, int ref, float tmin) {
-    if (t.sp < kLdsStackDepth) {
-        sr.lds[t.sp * 64] = ref;
-        sr.lds[(kLdsStackDepth + t.sp) * 64] = __float_as_int(tmin);
-    } else {
-        const size_t off = size_t(t.sp - kLdsStackDepth) * 2 * sr.spill_stride;
-        sr.spill()[off] = ref;
-        sr.spill()[off + sr.spill_stride] = __float_as_int(tmin);
-    }
-    ++t.sp;
-}
 DEV void trav_interior4(Trav &t, const StackRef &sr, const float4 mnx, const float4 mny, const float4 mnz,
                         const float4 mxx, const float4 mxy, const float4 mxz, const float4 refs, const uint32_t meta) {
     const RayCtx &rc = t.rc;
@@ -708,12 +729,15 @@ DEV void trav_interior4(Trav &t, const StackRef &sr, const float4 mnx, const flo
     const v2f y1a = v2f{ny ? mny.x : mxy.x, ny ? mny.y : mxy.y}, y1b = v2f{ny ? mny.z : mxy.z, ny ? mny.w : mxy.w};
     const v2f z0a = v2f{nz ? mxz.x : mnz.x, nz ? mxz.y : mnz.y}, z0b = v2f{nz ? mxz.z : mnz.z, nz ? mxz.w : mnz.w};
     const v2f z1a = v2f{nz ? mnz.x : mxz.x, nz ? mnz.y : mxz.y}, z1b = v2f{nz ? mnz.z : mxz.z, nz ? mnz.w : mxz.w};
-    const v2f tx0a = (x0a - rc.o.x) * rc.inv_dir.x, tx0b = (x0b - rc.o.x) * rc.inv_dir.x;
-    const v2f tx1a = (x1a - rc.o.x) * rc.inv_dir.x * kSlabScale, tx1b = (x1b - rc.o.x) * rc.inv_dir.x * kSlabScale;
-    const v2f ty0a = (y0a - rc.o.y) * rc.inv_dir.y, ty0b = (y0b - rc.o.y) * rc.inv_dir.y;
-    const v2f ty1a = (y1a - rc.o.y) * rc.inv_dir.y * kSlabScale, ty1b = (y1b - rc.o.y) * rc.inv_dir.y * kSlabScale;
-    const v2f tz0a = (z0a - rc.o.z) * rc.inv_dir.z, tz0b = (z0b - rc.o.z) * rc.inv_dir.z;
-    const v2f tz1a = (z1a - rc.o.z) * rc.inv_dir.z * kSlabScale, tz1b = (z1b - rc.o.z) * rc.inv_dir.z * kSlabScale;
+    const float fox = rc.ox, foy = rc.oy, foz = rc.oz, fix = rc.inv_dir.x, fiy = rc.inv_dir.y, fiz = rc.inv_dir.z;
+    const v2f ox = v2f{fox, fox}, oy = v2f{foy, foy}, oz = v2f{foz, foz}, ix = v2f{fix, fix}, iy = v2f{fiy, fiy},
+              iz = v2f{fiz, fiz}, sc = v2f{kSlabScale, kSlabScale};
+    const v2f tx0a = (x0a - ox) * ix, tx0b = (x0b - ox) * ix;
+    const v2f tx1a = (x1a - ox) * ix * sc, tx1b = (x1b - ox) * ix * sc;
+    const v2f ty0a = (y0a - oy) * iy, ty0b = (y0b - oy) * iy;
+    const v2f ty1a = (y1a - oy) * iy * sc, ty1b = (y1b - oy) * iy * sc;
+    const v2f tz0a = (z0a - oz) * iz, tz0b = (z0b - oz) * iz;
+    const v2f tz1a = (z1a - oz) * iz * sc, tz1b = (z1b - oz) * iz * sc;
     // per slot: tMin, and whether it is to be visited as things stand (key = tMin, else +inf;
     // a visitable tMin is < ray.tMax <= inf, so +inf is free to mean "no")
     auto slot_key = [&](float a0, float b0, float c0, float a1, float b1, float c1) {
@@ -779,7 +803,11 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
             float th;
             F3 od, ph;
             const float4 d4 = *ray_d;
-            if (sphere_test(S.spheres[S.prim_shape[prim]], t.rc.o, F3{d4.x, d4.y, d4.z}, t.tmax, &th, &od, &ph)) {
+#ifdef IILE_DBG_NO_SPHERE_ANY
+            if (!any_hit && sphere_test(S.spheres[S.prim_shape[prim]], t.rc.o(), F3{d4.x, d4.y, d4.z}, t.tmax, &th, &od, &ph)) {
+#else
+            if (sphere_test(S.spheres[S.prim_shape[prim]], t.rc.o(), F3{d4.x, d4.y, d4.z}, t.tmax, &th, &od, &ph)) {
+#endif
                 if (any_hit) {
                     t.have = false;
                     return true;

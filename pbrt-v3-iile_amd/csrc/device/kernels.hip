@@ -35,6 +35,9 @@ namespace iile {
 #ifndef IILE_FLAT_MIS
 #define IILE_FLAT_MIS 1
 #endif
+#ifndef IILE_SHADOW_WAVES
+#define IILE_SHADOW_WAVES 5  // waves per SIMD = resident blocks per CU of k_shadow
+#endif
 #ifndef IILE_VOTE_NUM
 #define IILE_VOTE_NUM 3
 #define IILE_VOTE_DEN 2
@@ -422,7 +425,12 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                 // 1D sample SampleDiscrete consumes), drawn here while few registers are live.
                 // Every path of a bounce normally sits at the same dimension.
                 float u_nee[4] = {0, 0, 0, 0};
+#ifdef IILE_DBG_NO_HALTON
+                u_nee[0] = 0.3f + 1e-9f * hidx; u_nee[1] = 0.6f; u_nee[2] = 0.2f; u_nee[3] = 0.7f;
+                if (false) {
+#else
                 if (bounce < S.max_depth) {
+#endif
                     const int dim_u = __builtin_amdgcn_readfirstlane(dim);
                     if (__ballot(dim != dim_u) == 0) {
                         scrambled_radical_inverse_n<4>(S, s_perms, dim_u + 1, hidx, u_nee);
@@ -474,7 +482,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                             // EstimateDirect, light-sampling half (integrator.cpp:117-163)
                             float light_pdf = 0, scattering_pdf = 0;
                             F3 wi = F3{0, 0, 0}, Li = F3{0, 0, 0};
+#ifdef IILE_DBG_NO_NEE_LIGHT
+                            LightSample ps; ps.p = is.p; ps.n = is.n; ps.perr = is.perr; light_pdf = 0;
+#else
                             LightSample ps = sphere_sample(sp, is, ul0, ul1, &light_pdf);
+#endif
                             if (light_pdf == 0 || length_sq(ps.p - is.p) == 0) {
                                 light_pdf = 0;
                             } else {
@@ -495,7 +507,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                                 }
                             }
                             // BSDF-sampling half (integrator.cpp:165-213)
+#ifdef IILE_DBG_NO_NEE_BSDF
+                            F3 f2 = F3{0, 0, 0};
+#else
                             F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
+#endif
                             f2 = f2 * absdot(wi, is.sn);
                             if (!is_black(f2) && scattering_pdf > 0) {
                                 const float lp = sphere_pdf(sp, is, wi);
@@ -527,7 +543,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             }
         }
         F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
+#ifdef IILE_DBG_NO_CONT
+        if (false) {
+#else
         if (surface) {
+#endif
             // next direction (path.cpp:133-156)
             float u_bsdf[2];
             {
@@ -599,7 +619,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
 
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, 5) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
+__global__ __launch_bounds__(kBlock, IILE_SHADOW_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -1020,9 +1040,10 @@ __global__ void k_trig_probe(int n, const float *x, float *out) {
 
 // ---------------------------------------------------------------------------
 // launchers
-constexpr int kTraverseBlocksPerCu = 5;  // 32 KB of LDS stacks per block -> 5 blocks per 160 KB CU
+constexpr int kTraverseBlocksPerCu = 5;  // 28 KB of LDS stacks per block -> 5 blocks per 160 KB CU
+constexpr int kMaxTraverseBlocksPerCu = 8;  // spill columns are sized for this many
 uint32_t max_traversal_threads(int n_cus) {
-    return uint32_t(n_cus) * kTraverseBlocksPerCu * kBlock * kSpillStackDepth * 2;  // (ref, tMin) per level
+    return uint32_t(n_cus) * kMaxTraverseBlocksPerCu * kBlock * kSpillStackDepth * 2;  // (ref, tMin) per level
 }
 uint32_t queue_capacity(uint32_t n_paths, int n_cus) {
     // every wavefront that appends can leave < 64 slots per kOutBlock it fills plus one
@@ -1053,7 +1074,7 @@ void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t ma
         hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
 }
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu == 5 ? IILE_SHADOW_WAVES : cfg.trav_blocks_per_cu));
     if (cfg.count_stats)
         hipLaunchKernelGGL(k_shadow<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
     else
