@@ -619,7 +619,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     hipStream_t stream = static_cast<hipStream_t>(prm->stream);
     LaunchCfg cfg{sc->n_cus, stream, prm->collect_stats != 0};
     if (const char *e = std::getenv("IILE_DEBUG_SKIP")) cfg.dbg_skip = atoi(e) & 7;
-    if (const char *e = std::getenv("IILE_TRAV_BLOCKS")) cfg.trav_blocks_per_cu = std::max(1, std::min(5, atoi(e)));
+    if (const char *e = std::getenv("IILE_TRAV_BLOCKS")) cfg.trav_blocks_per_cu = std::max(1, std::min(8, atoi(e)));
     const bool timed = prm->time_kernels != 0;
 
     PassDesc P;

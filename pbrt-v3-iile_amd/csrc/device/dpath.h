@@ -475,17 +475,19 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
 //    the triangle code on every iteration because some lane is at a leaf.
 //  * One ray per lane; per-lane stack of (ref, tMin) in LDS as stack[level][lane]
 //    (64 dwords per level): lane l always hits bank l mod 32, so pushes and pops
-//    are conflict-free whatever depth each lane is at. Levels >= kLdsStackDepth
-//    spill to an HBM column (the reference allows depth 64, bvh.cpp:670).
+//    are conflict-free whatever depth each lane is at. The LDS part is a ring holding the
+//    newest kLdsStackDepth levels; older ones are evicted to an HBM column (see stack_push).
 //
 // LDS pointers carry their address space explicitly so that pushes and pops
 // compile to ds_write_b32 / ds_read_b32 (a generic pointer would go through flat_*).
 typedef __attribute__((address_space(3))) int lds_int;
 #ifndef IILE_LDS_STACK
-#define IILE_LDS_STACK 14
+#define IILE_LDS_STACK 12  // 24 KB per block: six blocks per 160 KB CU
 #endif
-constexpr int kLdsStackDepth = IILE_LDS_STACK;         // measured max depth on killeroo-simple: 19
-constexpr int kSpillStackDepth = 64 - IILE_LDS_STACK;  // together the reference's 64 entries (bvh.cpp:670)
+constexpr int kLdsStackDepth = IILE_LDS_STACK;  // measured max depth on killeroo-simple: 19 (binary steps)
+// The reference's stack holds 64 binary entries (bvh.cpp:670); a four-wide step defers up to
+// three slots where the binary walk defers one child, so the same tree needs up to 1.5x that.
+constexpr int kSpillStackDepth = 128 - IILE_LDS_STACK;
 constexpr int kStackWordsPerWave = 2 * kLdsStackDepth * 64;  // ref plane + tMin plane
 
 struct TraceStats {

@@ -47,7 +47,7 @@ struct LaunchCfg {
     hipStream_t stream;
     bool count_stats;
     int dbg_skip = 0;             // timing experiments only: bit0 skip shadow rays, bit1 skip MIS rays
-    int trav_blocks_per_cu = 5;   // persistent traversal blocks per CU (5 x 32 KB of LDS stacks)
+    int trav_blocks_per_cu = 0;   // persistent traversal blocks per CU; 0 = default_trav_blocks_per_cu()
 };
 
 // slots a queue needs for n_paths paths
@@ -67,6 +67,7 @@ void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, fl
                   DCounters *counters, int *spill, const LaunchCfg &cfg);
 // number of ints of the HBM spill array: kSpillStackDepth x the largest traversal grid
 uint32_t max_traversal_threads(int n_cus);
+int default_trav_blocks_per_cu();
 void launch_halton(const DScene &S, int n, const int *px, const int *py, const int *k, int dim0, int ndims,
                    float *out, uint32_t *index_out, const LaunchCfg &cfg);
 void launch_camera(const DScene &S, int n, const float *pfilm, const float *plens, float *o, float *d,

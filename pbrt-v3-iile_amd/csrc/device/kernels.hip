@@ -35,8 +35,8 @@ namespace iile {
 #ifndef IILE_FLAT_MIS
 #define IILE_FLAT_MIS 1
 #endif
-#ifndef IILE_SHADOW_WAVES
-#define IILE_SHADOW_WAVES 5  // waves per SIMD = resident blocks per CU of k_shadow
+#ifndef IILE_TRAV_WAVES
+#define IILE_TRAV_WAVES 6  // waves per SIMD = resident blocks per CU of the traversal kernels (<= 80 VGPRs, no scratch)
 #endif
 #ifndef IILE_VOTE_NUM
 #define IILE_VOTE_NUM 3
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
 // extend: BVHAccel::Intersect for every ray of queue `bounce & 1`; hits are
 // appended (ballot-compacted) to the shade queue.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, 5) void k_extend(DScene S, PassBuffers B, int bounce) {
+__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, PassBuffers B, int bounce) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
 
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, IILE_SHADOW_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
+__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kBlock, IILE_SHADOW_WAVES) void k_shadow(DScene S, 
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, 5) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
+__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -1040,7 +1040,8 @@ __global__ void k_trig_probe(int n, const float *x, float *out) {
 
 // ---------------------------------------------------------------------------
 // launchers
-constexpr int kTraverseBlocksPerCu = 5;  // 28 KB of LDS stacks per block -> 5 blocks per 160 KB CU
+constexpr int kTraverseBlocksPerCu = IILE_TRAV_WAVES;  // resident blocks per CU (LDS stacks, VGPRs)
+int default_trav_blocks_per_cu() { return kTraverseBlocksPerCu; }
 constexpr int kMaxTraverseBlocksPerCu = 8;  // spill columns are sized for this many
 uint32_t max_traversal_threads(int n_cus) {
     return uint32_t(n_cus) * kMaxTraverseBlocksPerCu * kBlock * kSpillStackDepth * 2;  // (ref, tMin) per level
@@ -1056,7 +1057,7 @@ void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, c
                        cfg.count_stats ? 1 : 0);
 }
 void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
     if (cfg.count_stats)
         hipLaunchKernelGGL(k_extend<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
     else
@@ -1074,14 +1075,14 @@ void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t ma
         hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
 }
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu == 5 ? IILE_SHADOW_WAVES : cfg.trav_blocks_per_cu));
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
     if (cfg.count_stats)
         hipLaunchKernelGGL(k_shadow<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
     else
         hipLaunchKernelGGL(k_shadow<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
 }
 void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu));
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
     if (cfg.count_stats)
         hipLaunchKernelGGL(k_mis<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
     else
