@@ -221,7 +221,6 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
             camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
             B.hindex[pid] = idx;
             B.L[pid] = make_float4(0, 0, 0, 0);
-            B.beta[pid] = make_float4(1, 1, 1, b2f(5u));
             if (B.nray_out) {
                 B.nray_out[2 * pid] = 0;
                 B.nray_out[2 * pid + 1] = 0;
@@ -417,7 +416,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             if (valid) {
                 const float4 o4 = ro[slot], d4 = rd[slot], h4 = B.hits[slot];
                 pid = f2b(o4.w);
-                const float4 beta4 = B.beta[pid];
+                // a path arrives at its first vertex with beta = 1 at sampler dimension 5 (after
+                // the camera sample): k_generate does not spend 16 B per path on saying so
+                const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, b2f(5u)) : B.beta[pid];
                 beta = F3{beta4.x, beta4.y, beta4.z};
                 dim = int(f2b(beta4.w));
                 hidx = B.hindex[pid];
@@ -717,7 +718,6 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
             uint32_t e_new;
             if (feed_take(feed, head, count, !active, &e_new, [&](uint32_t first) {
-                    warm_plane(B.nee + plane, first, count);
                     warm_plane(B.nee + 2 * size_t(plane), first, count);
                     warm_plane(B.nee + 3 * size_t(plane), first, count);
                 })) {
@@ -836,21 +836,30 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate(DScene S, PassDesc P
         const uint32_t pid0 = pt * uint32_t(P.kc);
         if (!path_pixel(S, P, pid0, &px, &py, &k)) continue;
         float4 acc = F.tile_rgbw[pt];
-        for (int kk = 0; kk < P.kc; ++kk) {
-            const float4 L4 = B.L[pid0 + kk];
-            const F3 L = guard_radiance(S, F3{L4.x, L4.y, L4.z});
-            acc.x += L.x;
-            acc.y += L.y;
-            acc.z += L.z;
-            acc.w += 1.f;
-            if (P.k0 + kk == 0) {
-                // a sample whose fractional film offset is exactly 0 also lands in the
-                // left / upper neighbour (support ceil(pd-.5) .. floor(pd+.5))
-                const uint32_t idx = B.hindex[pid0 + kk];
-                uint32_t mask = 0;
-                if (sample_dimension(S, idx, 0) == 0.f) mask |= 1u;
-                if (sample_dimension(S, idx, 1) == 0.f) mask |= 2u;
-                F.k0_rgbv[pt] = make_float4(L.x, L.y, L.z, b2f(mask));
+        // A lane's samples are consecutive in memory (1 KB apart from its neighbour's at 64 spp):
+        // eight loads = one whole 128-byte line are issued together, then summed in sample order.
+        for (int k8 = 0; k8 < P.kc; k8 += 8) {
+            float4 Lb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Lb[j] = B.L[pid0 + uint32_t(k8 + j < P.kc ? k8 + j : k8)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = k8 + j;
+                if (kk >= P.kc) break;
+                const F3 L = guard_radiance(S, F3{Lb[j].x, Lb[j].y, Lb[j].z});
+                acc.x += L.x;
+                acc.y += L.y;
+                acc.z += L.z;
+                acc.w += 1.f;
+                if (P.k0 + kk == 0) {
+                    // a sample whose fractional film offset is exactly 0 also lands in the
+                    // left / upper neighbour (support ceil(pd-.5) .. floor(pd+.5))
+                    const uint32_t idx = B.hindex[pid0 + kk];
+                    uint32_t mask = 0;
+                    if (sample_dimension(S, idx, 0) == 0.f) mask |= 1u;
+                    if (sample_dimension(S, idx, 1) == 0.f) mask |= 2u;
+                    F.k0_rgbv[pt] = make_float4(L.x, L.y, L.z, b2f(mask));
+                }
             }
         }
         F.tile_rgbw[pt] = acc;
