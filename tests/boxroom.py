@@ -1,0 +1,93 @@
+"""Synthetic deep-BVH stress scene (the stand-in for BASELINE config 4, whose
+Sponza asset does not ship with the reference): a closed box room of tessellated quads, noisy
+icospheres in matte and plastic, one spherical area light — only features of the hot path.
+Deterministic: geometry from a seeded numpy generator, floats written with %.9g so that strtof
+reads back exactly the float32 values generated here."""
+import numpy as np
+
+
+def _icosphere(levels):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(levels):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, np.float64), np.array(f, np.int32)
+
+
+def _fmt(a):
+    return " ".join("%.9g" % x for x in np.asarray(a, np.float32).ravel())
+
+
+def _mesh(P, F):
+    return 'Shape "trianglemesh" "point P" [ %s ]\n  "integer indices" [ %s ]\n' % (
+        _fmt(P), " ".join(str(int(i)) for i in F.ravel()))
+
+
+def _grid_quad(origin, du, dv, n):
+    """n x n tessellated parallelogram (2 n^2 triangles)."""
+    o, du, dv = (np.array(x, np.float64) for x in (origin, du, dv))
+    P = np.array([o + du * (i / n) + dv * (j / n) for j in range(n + 1) for i in range(n + 1)])
+    F = []
+    for j in range(n):
+        for i in range(n):
+            a = j * (n + 1) + i
+            F += [(a, a + 1, a + n + 2), (a, a + n + 2, a + n + 1)]
+    return P, np.array(F, np.int32)
+
+
+def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, seed=12111, maxdepth=5):
+    """Returns the scene text. Triangles: 5 * 2 * wall_n^2 + n_blobs * 20 * 4^ico_levels
+    (defaults: 5 760 + 30 720; ico_levels=5, n_blobs=12, wall_n=64 gives ~287 k)."""
+    rng = np.random.default_rng(seed)
+    out = ['LookAt 0 -9.5 1   0 0 0.5   0 0 1', 'Camera "perspective" "float fov" [55]',
+           'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (xres, yres),
+           'Sampler "halton" "integer pixelsamples" [%d]' % spp, 'Integrator "path" "integer maxdepth" [%d]' % maxdepth,
+           'WorldBegin',
+           'AttributeBegin\n  Material "matte" "color Kd" [0 0 0]\n  Translate 1.5 -2 7.5\n'
+           '  AreaLightSource "area" "color L" [60 60 60]\n  Shape "sphere" "float radius" [0.6]\nAttributeEnd']
+    s = 10.0
+    walls = [((-s, -s, -3), (2 * s, 0, 0), (0, 2 * s, 0), (.7, .7, .7)),      # floor
+             ((-s, -s, 9), (0, 2 * s, 0), (2 * s, 0, 0), (.8, .8, .8)),       # ceiling
+             ((-s, s, -3), (2 * s, 0, 0), (0, 0, 12), (.6, .6, .8)),          # back
+             ((-s, -s, -3), (0, 2 * s, 0), (0, 0, 12), (.8, .3, .3)),         # left
+             ((s, -s, -3), (0, 0, 12), (0, 2 * s, 0), (.3, .8, .3))]          # right
+    for o, du, dv, kd in walls:
+        P, F = _grid_quad(o, du, dv, wall_n)
+        out.append('AttributeBegin\n  Material "matte" "color Kd" [%g %g %g]\n%sAttributeEnd' % (*kd, _mesh(P, F)))
+    V, F = _icosphere(ico_levels)
+    for b in range(n_blobs):
+        r = rng.uniform(0.7, 1.6)
+        c = np.array([rng.uniform(-6, 6), rng.uniform(-4, 7), rng.uniform(-2, 5)])
+        noise = 1.0 + 0.18 * rng.standard_normal(len(V)).clip(-2.5, 2.5)
+        P = c + V * (r * noise)[:, None]
+        if b % 2 == 0:
+            mat = 'Material "plastic" "color Kd" [%g %g %g] "color Ks" [.4 .4 .4] "float roughness" [%g]' % (
+                *rng.uniform(.2, .7, 3), rng.uniform(.02, .3))
+        else:
+            mat = 'Material "matte" "color Kd" [%g %g %g]' % tuple(rng.uniform(.2, .8, 3))
+        out.append('AttributeBegin\n  %s\n%sAttributeEnd' % (mat, _mesh(P, F)))
+    out.append('WorldEnd')
+    return "\n".join(out) + "\n"
+
+
+if __name__ == "__main__":
+    import sys
+    sys.stdout.write(boxroom_pbrt())

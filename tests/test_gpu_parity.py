@@ -294,3 +294,29 @@ def test_cpp_cli_renders_same_film(scene_small, gpu_small, tmp_path):
     img = np.frombuffer(raw[len(head):], "<f4").reshape(120, 160, 3)[::-1]
     film, _ = gpu_small.render()
     assert_bitwise(img, scene_small.film_to_rgb(film), "CLI image")
+
+
+def test_boxroom_deep_bvh_bitwise(binding, oracle, tmp_path):
+    """Synthetic closed room (tests/boxroom.py; SURVEY.md §8d's stand-in for the deep-BVH config):
+    ~65 reference node visits per ray instead of killeroo-simple's 17, every path runs to
+    maxdepth, twelve materials. Film and all counters bitwise equal to the oracle, with the
+    instrumented (binary steps) and the plain (four-wide steps) kernels."""
+    import boxroom
+    path = tmp_path / "boxroom.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4))
+    scene = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(scene)
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(scene)
+    assert_bitwise(film, ref, "boxroom film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["nodes_closest"] == ost["nodes_closest"] and st["nodes_any"] == ost["nodes_any"]
+    assert st["tri_tests"] == ost["tri_tests"] and st["path_length"] == ost["path_length"]
+    assert st["nodes_closest"] / st["closest_rays"] > 40  # it is a deep tree
+    plain, _ = gpu.render()
+    assert_bitwise(plain, ref, "boxroom film, uninstrumented kernels")
+    # several samples per pass boundary and sharding on the same scene
+    part0, _ = gpu.render(tile_rank=0, tile_nranks=2, spp_per_pass=3)
+    part1, _ = gpu.render(tile_rank=1, tile_nranks=2, spp_per_pass=1)
+    assert np.array_equal((part0 + part1)[..., 3], ref[..., 3])
+    assert np.allclose(part0 + part1, ref, rtol=1e-6, atol=0)

@@ -114,3 +114,21 @@ def test_film_to_rgb_and_pfm(scene_small, binding, tmp_path):
     assert raw.startswith(b"PF\n160 120\n-1.0\n")
     data = np.frombuffer(raw[len(b"PF\n160 120\n-1.0\n"):], "<f4").reshape(h, w, 3)
     assert np.array_equal(data[::-1], rgb)
+
+
+def test_boxroom_scene_loads_and_oracle_renders_it(binding, oracle, tmp_path):
+    """The synthetic deep-BVH scene of tests/boxroom.py goes through the loader (11 meshes,
+    12 materials, one sphere light) and the oracle; its text round-trips float32 exactly."""
+    import boxroom
+    import numpy as np
+    txt = boxroom.boxroom_pbrt(xres=32, yres=24, spp=2)
+    assert txt == boxroom.boxroom_pbrt(xres=32, yres=24, spp=2)  # deterministic
+    path = tmp_path / "boxroom.pbrt"
+    path.write_text(txt)
+    scene = binding.HostScene(path=str(path))
+    info = scene.info
+    assert info["n_triangles"] == 5 * 2 * 24 * 24 + 6 * 20 * 4 ** 4 and info["n_spheres"] == 1
+    assert info["n_materials"] == 12 and info["n_lights"] == 1
+    film, st = oracle.render(scene)
+    assert st["camera_rays"] == 32 * 24 * 2 and np.isfinite(film).all()
+    assert st["nodes_closest"] / st["regular_rays"] > 40
