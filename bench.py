@@ -36,7 +36,24 @@ def algorithmic_bytes(rays, nodes, tris):
     return 32 * nodes + 48 * tris + 48 * rays
 
 
-def cpu_baseline(scene_path, xres, yres, target_seconds):
+def measured_copy_gbs(torch):
+    """Device-to-device copy rate on this box (read + write bytes / time): the practical HBM
+    ceiling next to the 8 TB/s spec figure (SURVEY.md 8d asks for both)."""
+    n = 1 << 28  # 1 GiB of float32
+    x = torch.empty(n, dtype=torch.float32, device="cuda")
+    y = torch.empty_like(x)
+    y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def cpu_baseline(scene_path, xres, yres, target_seconds, workload_name="killeroo-simple"):
     """Time the CPU oracle (restatement of the reference path, all host cores, 16x16
     tile self-scheduling, render loop only) on a bounded number of pixel samples."""
     import __graft_entry__ as ge
@@ -55,7 +72,7 @@ def cpu_baseline(scene_path, xres, yres, target_seconds):
         "unit": "Mray/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"killeroo-simple {xres}x{yres}, pixel samples k=1..{n} of 64 ({st['camera_rays']} camera samples, "
+        "sample": f"{workload_name} {xres}x{yres}, pixel samples k=1..{n} of 64 ({st['camera_rays']} camera samples, "
                   f"{rays} rays, {st['seconds']:.2f} s, libm trig)",
         "msamples_per_s": round(st["camera_rays"] / st["seconds"] / 1e6, 4),
     }
@@ -72,7 +89,19 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--scene", default=os.path.join(REPO, "scenes", "killeroo-simple.pbrt"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--workload", choices=["killeroo", "boxroom"], default="killeroo",
+                    help="boxroom: the synthetic ~287 k-triangle closed room of tests/boxroom.py (deep-BVH stress, "
+                         "SURVEY.md 8d's stand-in for the Sponza config that does not ship with the reference)")
     args = ap.parse_args()
+    workload_name = "killeroo-simple"
+    if args.workload == "boxroom":
+        import tempfile
+        import boxroom
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".pbrt", delete=False)
+        tmp.write(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64))
+        tmp.close()
+        args.scene = tmp.name
+        workload_name = "synthetic boxroom (287k triangles, tests/boxroom.py)"
 
     import numpy as np
     import torch
@@ -174,17 +203,37 @@ def main():
             try:
                 tj = json.load(open(f))
                 ent = tj["kernels"].get(dom + "<false>")
-                if ent and world == 1 and (args.xres, args.yres, args.spp) == (1920, 1080, 64):
+                if ent and world == 1 and (args.xres, args.yres, args.spp, args.workload) == (1920, 1080, 64, "killeroo"):
                     traffic, traffic_src = ent["hbm_bytes_per_launch"], os.path.basename(f)
                     break
             except Exception:
                 pass
+        # every pipeline kernel priced the same way (HIP-event time of this rank, algorithmic bytes)
+        nee = cst["nee_evals"]
+        next_rays = cst["ext_rays"] - cst["camera_rays"]
+        other = {
+            "k_shade": (agg["ms_shade"], 48 * nee + 112 * nee + 32 * next_rays,
+                        "approx.: 48 B in per hit, 112 B NEE record + 32 B next ray out; VALU bound"),
+            "k_nee_resolve": (agg["ms_resolve"], 66 * nee, "34 B record + 32 B L read-modify-write"),
+            "k_generate": (agg["ms_generate"], 52 * cst["camera_rays"], "ray, Halton index, L written"),
+            "k_film": (agg["ms_film"], 16 * cst["camera_rays"], "L read per sample"),
+        }
+        per_kernel = {}
+        for k, (ms_k_, nl_, by_, _r) in kernels.items():
+            per_kernel[k] = {"ms_per_step": round(ms_k_ / args.steps, 3),
+                             "algorithmic_gbs": round(by_ * args.steps / max(ms_k_, 1e-9) / 1e6, 1)}
+        for k, (ms_k_, by_, note_) in other.items():
+            per_kernel[k] = {"ms_per_step": round(ms_k_ / args.steps, 3),
+                             "algorithmic_gbs": round(by_ * args.steps / max(ms_k_, 1e-9) / 1e6, 1), "note": note_}
+        for k in per_kernel:
+            per_kernel[k]["frac_of_hbm_peak"] = round(per_kernel[k]["algorithmic_gbs"] / HBM_PEAK_GBS, 4)
+        copy_gbs = measured_copy_gbs(torch)
         ms_k, n_launch, bytes_step, rays_k = kernels[dom]
         launches_per_step = n_launch / args.steps
         avg_ms = ms_k / max(n_launch, 1)
         achieved = (bytes_step / launches_per_step) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
-            "metric": "Mray/s on killeroo-simple 1080p (path integrator, rays = Scene::Intersect + IntersectP calls)",
+            "metric": f"Mray/s on {workload_name} 1080p (path integrator, rays = Scene::Intersect + IntersectP calls)",
             "value": round(mray, 2),
             "unit": "Mray/s",
             "n_gpus": world,
@@ -195,10 +244,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "scenes/killeroo-simple.pbrt (the reference's shipped scene file); Halton samples generated "
-                    "on device",
+            "data": ("scenes/killeroo-simple.pbrt (the reference's shipped scene file)" if args.workload == "killeroo"
+                     else "synthetic scene generated by tests/boxroom.py (seed 12111)") + "; Halton samples generated on device",
             "config": {
-                "workload": f"killeroo-simple {args.xres}x{args.yres}, {total_spp} spp ({args.spp} per GPU), "
+                "workload": f"{workload_name} {args.xres}x{args.yres}, {total_spp} spp ({args.spp} per GPU), "
                             f"path maxdepth 5, halton, box filter, 16x16 tiles interleaved over {world} rank(s)",
                 "xres": args.xres, "yres": args.yres, "spp_total": total_spp, "spp_per_gpu": args.spp,
                 "passes_per_step": st["n_passes"],
@@ -227,14 +276,20 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(bytes_step / max(launches_per_step, 1)),
                 "rays_per_launch": int(rays_k / max(launches_per_step, 1)),
+                "peak_measured_copy_gbs": round(copy_gbs, 1),
+                "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+                "kernel_choice": "the BVH traversal kernel family (extend / shadow / MIS: one traversal code, "
+                                 "61 % of the step) priced on its longest member; k_shade is VALU bound, see "
+                                 "roofline_all_kernels",
                 "note": "algorithmic bytes = 32 B/node visited + 48 B/triangle test + 48 B/ray queue traffic "
                         "(SURVEY.md 8d), counted by the instrumented kernels; `traffic` = PMC HBM bytes per launch "
                         "(2*FETCH_SIZE + WRITE_SIZE): the BVH and mesh (~7 MB) are cache resident, so real HBM "
                         "traffic is the queue traffic and sits far below the algorithmic bytes",
             },
         }
+        out["roofline_all_kernels"] = per_kernel
         if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.scene, args.xres, args.yres, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.xres, args.yres, args.cpu_seconds, workload_name)
             out["speedup_vs_cpu_baseline"] = round(mray / max(out["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
