@@ -66,12 +66,16 @@ typedef struct iile_material {
     int32_t pad;
 } iile_material;
 
-/* DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75). */
+/* A light: DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75) or a PointLight
+ * (src/lights/point.h:49-70). */
+#define IILE_LIGHT_DIFFUSE_AREA 0
+#define IILE_LIGHT_POINT 1
 typedef struct iile_light {
-    float lemit[3];
+    float lemit[3];  /* area: Lemit (L * scale); point: I (I * scale) */
     int32_t two_sided;
-    int32_t sphere; /* index into spheres[] (only sphere emitters are supported) */
-    int32_t pad[3];
+    int32_t sphere;  /* area: index into spheres[] (only sphere emitters are supported); point: -1 */
+    int32_t type;    /* IILE_LIGHT_* */
+    float pos[3];    /* point: pLight = LightToWorld(0,0,0), LightToWorld = Translate(from) * CTM */
 } iile_light;
 
 /* PerspectiveCamera (src/cameras/perspective.cpp:50-72, src/core/camera.h:90-111). */

@@ -1292,9 +1292,32 @@ struct Oracle {
         float f = nf * fpdf, g = ng * gpdf;
         return (f * f) / (f * f + g * g);
     }
+    // EstimateDirect for a PointLight (delta position: IsDeltaLight, so no MIS weight and no
+    // BSDF-sampling half, core/integrator.cpp:150-166). PointLight::Sample_Li, lights/point.cpp:43-52.
+    Rgb estimate_direct_point(const Isect &it, const Bsdf &bsdf, const iile_light &lt) const {
+        Rgb Ld(0.f);
+        const V3 pl(lt.pos[0], lt.pos[1], lt.pos[2]);
+        V3 wi = normalize(pl - it.p);
+        float light_pdf = 1.f;
+        Rgb Li = Rgb(lt.lemit[0], lt.lemit[1], lt.lemit[2]) / length_sq(pl - it.p);  // I / DistanceSquared
+        if (light_pdf > 0 && !Li.is_black()) {
+            Rgb f = bsdf_f(bsdf, it.wo, wi) * absdot(wi, it.sn);
+            if (!f.is_black()) {
+                // VisibilityTester(ref, Interaction(pLight)): the light-side interaction has no
+                // normal and no error bounds, so its OffsetRayOrigin is the point itself
+                V3 origin = offset_ray_origin(it.p, it.perr, it.n, pl - it.p);
+                V3 target = offset_ray_origin(pl, V3(0, 0, 0), V3(0, 0, 0), origin - pl);
+                Ray sr{origin, target - origin, 1 - ShadowEpsilon};
+                if (intersect_p(sr)) Li = Rgb(0.f);
+                if (!Li.is_black()) Ld = Ld + f * Li / light_pdf;
+            }
+        }
+        return Ld;
+    }
     Rgb estimate_direct(const Isect &it, const Bsdf &bsdf, const float *u_scatter, int light_index,
                         const float *u_light) const {
         const iile_light &lt = S.lights[light_index];
+        if (lt.type == IILE_LIGHT_POINT) return estimate_direct_point(it, bsdf, lt);
         const iile_sphere &sp = S.spheres[lt.sphere];
         Rgb Ld(0.f);
         V3 wi;

@@ -275,6 +275,7 @@ int iile_device_count(void) {
     return n;
 }
 
+static_assert(kLightDiffuseArea == IILE_LIGHT_DIFFUSE_AREA && kLightPoint == IILE_LIGHT_POINT, "light type codes");
 int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     if (!d || !out) return fail(IILE_ERR_ARG, "iile_scene_create: null argument");
     int rc = ensure_device();
@@ -289,6 +290,14 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         const iile_sphere &s = d->spheres[i];
         if (!(s.zmin == -s.radius && s.zmax == s.radius && s.phi_max >= 6.2831850f))
             return fail(IILE_ERR_UNSUPPORTED, "partial spheres (zmin/zmax/phimax) are not supported on device");
+    }
+    for (int i = 0; i < d->n_lights; ++i) {
+        const iile_light &l = d->lights[i];
+        if (l.type == IILE_LIGHT_DIFFUSE_AREA) {
+            if (l.sphere < 0 || l.sphere >= d->n_spheres) return fail(IILE_ERR_ARG, "area light without a sphere");
+        } else if (l.type != IILE_LIGHT_POINT) {
+            return fail(IILE_ERR_UNSUPPORTED, "unsupported light type");
+        }
     }
     for (int i = 0; i < d->n_materials; ++i)
         if (d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC)
@@ -486,6 +495,8 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             for (int c = 0; c < 3; ++c) lts[i].lemit[c] = d->lights[i].lemit[c];
             lts[i].two_sided = d->lights[i].two_sided;
             lts[i].sphere = d->lights[i].sphere;
+            lts[i].type = d->lights[i].type;
+            for (int c = 0; c < 3; ++c) lts[i].pos[c] = d->lights[i].pos[c];
         }
         rc = upload(sc, lts.data(), lts.size(), &S.lights);
         if (rc) return bail(rc);

@@ -27,10 +27,13 @@ struct DMaterial {
     float ks[3];
     float alpha;
 };
+enum { kLightDiffuseArea = 0, kLightPoint = 1 };  // = IILE_LIGHT_* (checked in api.hip)
 struct DLight {
-    float lemit[3];
+    float lemit[3];  // area: Lemit; point: I
     int two_sided;
     int sphere;
+    int type;        // kLight*
+    float pos[3];    // point: pLight
 };
 // Per Halton dimension: base, float reciprocal and offset of its digit permutation.
 // The digits are peeled in double arithmetic (exact for any u32 index, see

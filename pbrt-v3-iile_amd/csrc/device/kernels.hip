@@ -477,52 +477,72 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                             ++dim;
                             const int li = 0;
                             const DLight &lt = S.lights[li];
-                            const DSphere &sp = S.spheres[lt.sphere];
-                            const float ul0 = u_nee[0], ul1 = u_nee[1], us0 = u_nee[2], us1 = u_nee[3];
-                            dim += 4;
-                            // EstimateDirect, light-sampling half (integrator.cpp:117-163)
-                            float light_pdf = 0, scattering_pdf = 0;
-                            F3 wi = F3{0, 0, 0}, Li = F3{0, 0, 0};
-#ifdef IILE_DBG_NO_NEE_LIGHT
-                            LightSample ps; ps.p = is.p; ps.n = is.n; ps.perr = is.perr; light_pdf = 0;
-#else
-                            LightSample ps = sphere_sample(sp, is, ul0, ul1, &light_pdf);
-#endif
-                            if (light_pdf == 0 || length_sq(ps.p - is.p) == 0) {
-                                light_pdf = 0;
-                            } else {
-                                wi = normalize(ps.p - is.p);
-                                Li = light_L(lt, ps.n, -wi);
-                            }
-                            if (light_pdf > 0 && !is_black(Li)) {
-                                F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
-                                scattering_pdf = bsdf_pdf(bsdf, is.wo, wi);
-                                if (!is_black(f)) {
-                                    // VisibilityTester -> SpawnRayTo(Interaction), interaction.h:73-78
-                                    so = offset_ray_origin(is.p, is.perr, is.n, ps.p - is.p);
-                                    F3 target = offset_ray_origin(ps.p, ps.perr, ps.n, so - ps.p);
-                                    sd = target - so;
-                                    const float weight = power_heuristic(light_pdf, scattering_pdf);
-                                    A = sdiv(f * Li * weight, light_pdf);
-                                    nee_flags |= NEE_HAS_SHADOW;
+                            if (lt.type == kLightPoint) {
+                                // EstimateDirect for a delta light (integrator.cpp:150-166): light
+                                // sample only, weight 1; PointLight::Sample_Li, lights/point.cpp:43-52
+                                dim += 4;  // uLight and uScattering are drawn all the same
+                                const F3 pl = F3{lt.pos[0], lt.pos[1], lt.pos[2]};
+                                const F3 wi = normalize(pl - is.p);
+                                const F3 Li = sdiv(F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]}, length_sq(pl - is.p));
+                                if (!is_black(Li)) {
+                                    const F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
+                                    if (!is_black(f)) {
+                                        // the light-side Interaction has neither normal nor error
+                                        // bounds: its OffsetRayOrigin is pLight itself (interaction.h:73-78)
+                                        so = offset_ray_origin(is.p, is.perr, is.n, pl - is.p);
+                                        sd = pl - so;
+                                        A = sdiv(f * Li, 1.f);
+                                        nee_flags |= NEE_HAS_SHADOW;
+                                    }
                                 }
-                            }
-                            // BSDF-sampling half (integrator.cpp:165-213)
-#ifdef IILE_DBG_NO_NEE_BSDF
-                            F3 f2 = F3{0, 0, 0};
-#else
-                            F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
-#endif
-                            f2 = f2 * absdot(wi, is.sn);
-                            if (!is_black(f2) && scattering_pdf > 0) {
-                                const float lp = sphere_pdf(sp, is, wi);
-                                if (lp != 0) {
-                                    const float weight = power_heuristic(scattering_pdf, lp);
-                                    mo = offset_ray_origin(is.p, is.perr, is.n, wi);
-                                    md = wi;
-                                    // Li is Lemit when the MIS ray finds this light facing it
-                                    Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * weight, scattering_pdf);
-                                    nee_flags |= NEE_HAS_MIS;
+                            } else {
+                                const DSphere &sp = S.spheres[lt.sphere];
+                                const float ul0 = u_nee[0], ul1 = u_nee[1], us0 = u_nee[2], us1 = u_nee[3];
+                                dim += 4;
+                                // EstimateDirect, light-sampling half (integrator.cpp:117-163)
+                                float light_pdf = 0, scattering_pdf = 0;
+                                F3 wi = F3{0, 0, 0}, Li = F3{0, 0, 0};
+    #ifdef IILE_DBG_NO_NEE_LIGHT
+                                LightSample ps; ps.p = is.p; ps.n = is.n; ps.perr = is.perr; light_pdf = 0;
+    #else
+                                LightSample ps = sphere_sample(sp, is, ul0, ul1, &light_pdf);
+    #endif
+                                if (light_pdf == 0 || length_sq(ps.p - is.p) == 0) {
+                                    light_pdf = 0;
+                                } else {
+                                    wi = normalize(ps.p - is.p);
+                                    Li = light_L(lt, ps.n, -wi);
+                                }
+                                if (light_pdf > 0 && !is_black(Li)) {
+                                    F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
+                                    scattering_pdf = bsdf_pdf(bsdf, is.wo, wi);
+                                    if (!is_black(f)) {
+                                        // VisibilityTester -> SpawnRayTo(Interaction), interaction.h:73-78
+                                        so = offset_ray_origin(is.p, is.perr, is.n, ps.p - is.p);
+                                        F3 target = offset_ray_origin(ps.p, ps.perr, ps.n, so - ps.p);
+                                        sd = target - so;
+                                        const float weight = power_heuristic(light_pdf, scattering_pdf);
+                                        A = sdiv(f * Li * weight, light_pdf);
+                                        nee_flags |= NEE_HAS_SHADOW;
+                                    }
+                                }
+                                // BSDF-sampling half (integrator.cpp:165-213)
+    #ifdef IILE_DBG_NO_NEE_BSDF
+                                F3 f2 = F3{0, 0, 0};
+    #else
+                                F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
+    #endif
+                                f2 = f2 * absdot(wi, is.sn);
+                                if (!is_black(f2) && scattering_pdf > 0) {
+                                    const float lp = sphere_pdf(sp, is, wi);
+                                    if (lp != 0) {
+                                        const float weight = power_heuristic(scattering_pdf, lp);
+                                        mo = offset_ray_origin(is.p, is.perr, is.n, wi);
+                                        md = wi;
+                                        // Li is Lemit when the MIS ray finds this light facing it
+                                        Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * weight, scattering_pdf);
+                                        nee_flags |= NEE_HAS_MIS;
+                                    }
                                 }
                             }
                             nee_light = uint32_t(li);

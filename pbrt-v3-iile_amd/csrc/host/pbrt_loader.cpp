@@ -390,8 +390,29 @@ class Loader {
             if (name != "area" && name != "diffuse") return fail("unknown area light " + name);
             gs_.has_area_light = true;
             gs_.area_light_params = ps;
-        } else if (d == "LightSource") {
-            return fail("LightSource \"" + name + "\" is not supported (area lights on spheres only)");
+        } else if (d == "LightSource") {  // api.cpp:1344-1358 (pbrtLightSource), MakeLight api.cpp:770-806
+            if (name != "point")
+                return fail("LightSource \"" + name + "\" is not supported (point lights and area lights on spheres only)");
+            // CreatePointLight, lights/point.cpp:80-88
+            float I[3] = {1, 1, 1}, sc[3] = {1, 1, 1};
+            ps.rgb("I", I);
+            ps.rgb("scale", sc);
+            V3 from(0, 0, 0);
+            if (const Param *pp = ps.find("from")) {
+                if (pp->type != "point" || pp->nums.size() != 3) return fail("point light: bad \"from\"");
+                from = V3(float(pp->nums[0]), float(pp->nums[1]), float(pp->nums[2]));
+            }
+            const Xform l2w = xf_translate(from) * ctm_;
+            const V3 pl = l2w.point(V3(0, 0, 0));
+            iile_light lt;
+            std::memset(&lt, 0, sizeof(lt));
+            for (int i = 0; i < 3; ++i) lt.lemit[i] = I[i] * sc[i];
+            lt.sphere = -1;
+            lt.type = IILE_LIGHT_POINT;
+            lt.pos[0] = pl.x;
+            lt.pos[1] = pl.y;
+            lt.pos[2] = pl.z;
+            scene_->lights.push_back(lt);
         } else if (d == "Shape") {
             return make_shape(name, ps);
         }

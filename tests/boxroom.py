@@ -53,16 +53,20 @@ def _grid_quad(origin, du, dv, n):
     return P, np.array(F, np.int32)
 
 
-def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, seed=12111, maxdepth=5):
+def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, seed=12111, maxdepth=5, light="area"):
     """Returns the scene text. Triangles: 5 * 2 * wall_n^2 + n_blobs * 20 * 4^ico_levels
     (defaults: 5 760 + 30 720; ico_levels=5, n_blobs=12, wall_n=64 gives ~287 k)."""
     rng = np.random.default_rng(seed)
     out = ['LookAt 0 -9.5 1   0 0 0.5   0 0 1', 'Camera "perspective" "float fov" [55]',
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (xres, yres),
            'Sampler "halton" "integer pixelsamples" [%d]' % spp, 'Integrator "path" "integer maxdepth" [%d]' % maxdepth,
-           'WorldBegin',
-           'AttributeBegin\n  Material "matte" "color Kd" [0 0 0]\n  Translate 1.5 -2 7.5\n'
-           '  AreaLightSource "area" "color L" [60 60 60]\n  Shape "sphere" "float radius" [0.6]\nAttributeEnd']
+           'WorldBegin']
+    if light == "point":  # a delta light instead of the emitting sphere (same position, similar power)
+        out.append('AttributeBegin\n  Translate 1.5 -2 0\n  LightSource "point" "color I" [68 68 68] "point from" [0 0 7.5]\n'
+                   'AttributeEnd')
+    else:
+        out.append('AttributeBegin\n  Material "matte" "color Kd" [0 0 0]\n  Translate 1.5 -2 7.5\n'
+                   '  AreaLightSource "area" "color L" [60 60 60]\n  Shape "sphere" "float radius" [0.6]\nAttributeEnd')
     s = 10.0
     walls = [((-s, -s, -3), (2 * s, 0, 0), (0, 2 * s, 0), (.7, .7, .7)),      # floor
              ((-s, -s, 9), (0, 2 * s, 0), (2 * s, 0, 0), (.8, .8, .8)),       # ceiling

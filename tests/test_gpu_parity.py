@@ -320,3 +320,23 @@ def test_boxroom_deep_bvh_bitwise(binding, oracle, tmp_path):
     part1, _ = gpu.render(tile_rank=1, tile_nranks=2, spp_per_pass=1)
     assert np.array_equal((part0 + part1)[..., 3], ref[..., 3])
     assert np.allclose(part0 + part1, ref, rtol=1e-6, atol=0)
+
+
+def test_point_light_scenes_bitwise(binding, oracle, tmp_path):
+    """PointLight (first step): the reference's analytic point-light furnace
+    scene and the synthetic box room lit by a point light, both bitwise equal to the oracle."""
+    import os
+    import boxroom
+    furnace = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_point.pbrt"))
+    path = tmp_path / "boxroom_point.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="point"))
+    room = binding.HostScene(path=str(path))
+    for name, scene in (("furnace", furnace), ("boxroom", room)):
+        gpu = binding.GpuScene(scene)
+        film, st = gpu.render(collect_stats=True)
+        ref, ost = oracle.render(scene)
+        assert_bitwise(film, ref, f"{name} (point light) film")
+        assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+        assert st["path_length"] == ost["path_length"] and st["zero_radiance"] == ost["zero_radiance"]
+        plain, _ = gpu.render()
+        assert_bitwise(plain, ref, f"{name} (point light) film, uninstrumented kernels")

@@ -199,3 +199,18 @@ def test_watertight_closed_mesh(binding, oracle, tmp_path):
     prim, tb = oracle.intersect(scene, o, d.astype(np.float32), np.full(n, np.inf, np.float32))
     assert (prim >= 0).all()
     assert oracle.intersect_p(scene, o, d.astype(np.float32), np.full(n, np.inf, np.float32)).all()
+
+
+def test_point_light_furnace_scene_matches_reference_expectation(binding, oracle):
+    """First scene of src/tests/analytic_scenes.cpp:72-99 (unit sphere, Kd = 0.5, point light of
+    intensity pi at the centre; path integrator depth 8, Halton 256, 10x10 pixels): the
+    reference's own test expects mean radiance 1.0 within 0.02. Pins PointLight::Sample_Li and the
+    delta-light branch of EstimateDirect in the oracle."""
+    import os
+    scene = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_point.pbrt"))
+    assert scene.info["n_lights"] == 1 and scene.info["n_spheres"] == 1
+    film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+    mean = float(scene.film_to_rgb(film).mean(dtype=np.float64))
+    assert abs(mean - 1.0) < 0.02, mean
+    # a delta light traces no MIS ray: one shadow ray per scattering vertex, nothing else
+    assert st["shadow_rays"] == st["nee_evals"]
