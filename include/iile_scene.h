@@ -50,19 +50,22 @@ typedef struct iile_sphere {
     int32_t swaps_handedness;
 } iile_sphere;
 
-enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1 };
+enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1, IILE_MAT_UBER = 2, IILE_MAT_MIRROR = 3 };
 
-/* MatteMaterial / PlasticMaterial with constant textures
- * (src/materials/matte.cpp:45-62, plastic.cpp:45-70). */
+/* MatteMaterial / PlasticMaterial / UberMaterial / MirrorMaterial with constant textures
+ * (src/materials/matte.cpp:45-62, plastic.cpp:45-70, uber.cpp:45-100, mirror.cpp:44-55).
+ * Uber: opacity 1 and Kt 0 only (no transmission), uroughness == vroughness. */
 typedef struct iile_material {
     int32_t type;
-    float kd[3];
-    float ks[3];
+    float kd[3];     /* matte, plastic, uber; 0 for mirror */
+    float ks[3];     /* plastic, uber: glossy (microfacet) reflectance */
     float sigma;     /* matte; only sigma == 0 (Lambertian) is supported on device */
-    float roughness; /* plastic, as given */
-    float alpha;     /* plastic: RoughnessToAlpha(roughness) if remap else roughness
+    float roughness; /* plastic, uber: as given */
+    float alpha;     /* plastic, uber: RoughnessToAlpha(roughness) if remap else roughness
                         (src/core/microfacet.h:123-128) */
     int32_t remap_roughness;
+    float eta;       /* uber: index of refraction e of FresnelDielectric(1, e) */
+    float kr[3];     /* uber, mirror: specular reflectance */
     int32_t pad;
 } iile_material;
 

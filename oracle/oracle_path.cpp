@@ -953,17 +953,22 @@ struct Oracle {
     // BSDF (core/reflection.{h,cpp}, core/microfacet.cpp)
     struct Bsdf {
         V3 ns, ng, ss, ts;
-        int n_lobes = 0;
-        bool has_lambert = false, has_micro = false;
-        Rgb kd, ks;
+        int n_lobes = 0;    // nBxDFs; BxDF order: Lambertian, microfacet, specular reflection
+        bool has_lambert = false, has_micro = false, has_spec = false;
+        Rgb kd, ks, kr;
         float alpha = 0;
+        float micro_eta_i = 1.5f, micro_eta_t = 1.f;  // FresnelDielectric of the microfacet lobe
+        bool spec_noop = true;                        // FresnelNoOp (mirror) or FresnelDielectric(1, spec_eta)
+        float spec_eta = 1.f;
+        int n_nonspec() const { return (has_lambert ? 1 : 0) + (has_micro ? 1 : 0); }
         V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
         V3 to_world(V3 v) const {
             return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z,
                       ss.z * v.x + ts.z * v.y + ns.z * v.z);
         }
     };
-    // {Matte,Plastic}Material::ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70)
+    // {Matte,Plastic,Uber,Mirror}Material::ComputeScatteringFunctions (matte.cpp:45-62,
+    // plastic.cpp:45-70, uber.cpp:45-100 with opacity 1 and Kt 0, mirror.cpp:44-55)
     Bsdf make_bsdf(const Isect &is) const {
         Bsdf b;
         b.ns = is.sn;
@@ -980,12 +985,26 @@ struct Oracle {
             b.kd = kd;
             ++b.n_lobes;
         }
-        if (m.type == IILE_MAT_PLASTIC) {
+        if (m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) {
             Rgb ks = clamp0(m.ks);
             if (!ks.is_black()) {
                 b.has_micro = true;
                 b.ks = ks;
                 b.alpha = m.alpha;
+                if (m.type == IILE_MAT_UBER) {  // FresnelDielectric(1.f, e), uber.cpp:70
+                    b.micro_eta_i = 1.f;
+                    b.micro_eta_t = m.eta;
+                }
+                ++b.n_lobes;
+            }
+        }
+        if (m.type == IILE_MAT_UBER || m.type == IILE_MAT_MIRROR) {
+            Rgb kr = clamp0(m.kr);
+            if (!kr.is_black()) {
+                b.has_spec = true;
+                b.kr = kr;
+                b.spec_noop = m.type == IILE_MAT_MIRROR;
+                b.spec_eta = m.eta;
                 ++b.n_lobes;
             }
         }
@@ -1093,14 +1112,14 @@ struct Oracle {
         if (flip) wh = -wh;
         return wh;
     }
-    // MicrofacetReflection::f, reflection.cpp:226-236 with FresnelDielectric(1.5, 1)
+    // MicrofacetReflection::f, reflection.cpp:226-236 with FresnelDielectric(1.5, 1) (plastic) or (1, e) (uber)
     static Rgb micro_f(const Bsdf &b, V3 wo, V3 wi) {
         float cos_o = std::abs(wo.z), cos_i = std::abs(wi.z);
         V3 wh = wi + wo;
         if (cos_i == 0 || cos_o == 0) return Rgb(0.);
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Rgb(0.);
         wh = normalize(wh);
-        Rgb F(fr_dielectric(dot(wi, wh), 1.5f, 1.f));
+        Rgb F(fr_dielectric(dot(wi, wh), b.micro_eta_i, b.micro_eta_t));
         return b.ks * tr_d(wh, b.alpha, b.alpha) * tr_g(wo, wi, b.alpha) * F / (4 * cos_i * cos_o);
     }
     static float micro_pdf(const Bsdf &b, V3 wo, V3 wi) {  // reflection.cpp:419-423
@@ -1141,26 +1160,32 @@ struct Oracle {
     }
     // BSDF::Sample_f, reflection.cpp:719-784. Returns f; *pdf is left untouched
     // on the early `wo.z == 0` return exactly as in the reference.
-    Rgb bsdf_sample_f(const Bsdf &b, V3 woW, V3 *wiW, const float *u, float *pdf) const {
-        int matching = b.n_lobes;
+    Rgb bsdf_sample_f(const Bsdf &b, V3 woW, V3 *wiW, const float *u, float *pdf, bool allow_specular = false,
+                      bool *sampled_specular = nullptr) const {
+        // `type` is BSDF_ALL (allow_specular) or BSDF_ALL & ~BSDF_SPECULAR
+        if (sampled_specular) *sampled_specular = false;
+        int matching = allow_specular ? b.n_lobes : b.n_nonspec();
         if (matching == 0) {
             *pdf = 0;
             return Rgb(0);
         }
         int comp = std::min((int)std::floor(u[0] * matching), matching - 1);
-        // lobe order: Lambertian first, then the microfacet lobe (plastic.cpp:53-69)
-        bool pick_micro = b.has_lambert ? (comp == 1) : b.has_micro;
+        // BxDF order: Lambertian, microfacet, specular reflection (plastic.cpp:53-69, uber.cpp:62-92)
+        int pick = -1, count = comp;  // 0 Lambertian, 1 microfacet, 2 specular
+        if (b.has_lambert && count-- == 0) pick = 0;
+        if (pick < 0 && b.has_micro && count-- == 0) pick = 1;
+        if (pick < 0 && b.has_spec && allow_specular && count-- == 0) pick = 2;
         float ur[2] = {std::min(u[0] * matching - comp, OneMinusEpsilon), u[1]};
         V3 wi, wo = b.to_local(woW);
         if (wo.z == 0) return Rgb(0.);
         *pdf = 0;
         Rgb f;
-        if (!pick_micro) {  // BxDF::Sample_f, reflection.cpp:378-385
+        if (pick == 0) {  // BxDF::Sample_f, reflection.cpp:378-385
             wi = cosine_sample_hemisphere(ur);
             if (wo.z < 0) wi.z *= -1;
             *pdf = lambert_pdf(wo, wi);
             f = b.kd * InvPi;
-        } else {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
+        } else if (pick == 1) {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
             // `if (wo.z == 0) return 0.` is unreachable here
             V3 wh = tr_sample_wh(wo, ur, b.alpha);
             wi = -wo + 2 * dot(wo, wh) * wh;  // Reflect(), reflection.h:86-88
@@ -1170,17 +1195,25 @@ struct Oracle {
                 *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
                 f = micro_f(b, wo, wi);
             }
+        } else {  // SpecularReflection::Sample_f, reflection.cpp:136-143
+            wi = V3(-wo.x, -wo.y, wo.z);
+            *pdf = 1;
+            Rgb fr = b.spec_noop ? Rgb(1.f) : Rgb(fr_dielectric(wi.z, 1.f, b.spec_eta));
+            f = fr * b.kr / std::abs(wi.z);
+            if (sampled_specular) *sampled_specular = true;
         }
-        if (*pdf == 0) return Rgb(0);
+        if (*pdf == 0) {
+            if (sampled_specular) *sampled_specular = false;
+            return Rgb(0);
+        }
         *wiW = b.to_world(wi);
-        if (matching > 1) {
-            if (pick_micro)
-                *pdf += lambert_pdf(wo, wi);
-            else
-                *pdf += micro_pdf(b, wo, wi);
+        const bool specular = pick == 2;
+        if (!specular && matching > 1) {  // a specular lobe's Pdf() is 0
+            if (pick == 1 && b.has_lambert) *pdf += lambert_pdf(wo, wi);
+            if (pick == 0 && b.has_micro) *pdf += micro_pdf(b, wo, wi);
         }
         if (matching > 1) *pdf /= matching;
-        if (matching > 1) {
+        if (!specular && matching > 1) {  // a specular lobe's f() is 0
             bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
             f = Rgb(0.);
             if (reflect) {
@@ -1387,7 +1420,7 @@ struct Oracle {
             Bsdf bsdf = make_bsdf(is);
             // UniformLightDistribution::Lookup ignores the point; SampleDiscrete
             // still consumes one 1D sample (integrator.cpp:95).
-            if (bsdf.n_lobes > 0) {
+            if (bsdf.n_nonspec() > 0) {  // NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0, path.cpp:118
                 ++ctr->nee_evals;
                 Rgb Ld_in(0.f);
                 if (S.n_lights > 0) {
@@ -1411,11 +1444,12 @@ struct Oracle {
             float u[2];
             smp.get2d(u);
             pdf = 0;
-            Rgb f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf);
+            bool sampled_specular = false;
+            Rgb f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf, true, &sampled_specular);
             if (f.is_black() || pdf == 0.f) break;
             beta = beta * (f * absdot(wi, is.sn) / pdf);
             if (beta.y() < 0.f || std::isnan(beta.y())) return L;
-            specular_bounce = false;
+            specular_bounce = sampled_specular;  // no specular transmission here: etaScale stays 1
             ray = spawn_ray(is, wi);
             Rgb rr_beta = beta * eta_scale;
             if (rr_beta.max_component() < rr_threshold && bounces > 3) {

@@ -276,6 +276,9 @@ int iile_device_count(void) {
 }
 
 static_assert(kLightDiffuseArea == IILE_LIGHT_DIFFUSE_AREA && kLightPoint == IILE_LIGHT_POINT, "light type codes");
+static_assert(kMatMatte == IILE_MAT_MATTE && kMatPlastic == IILE_MAT_PLASTIC && kMatUber == IILE_MAT_UBER &&
+                  kMatMirror == IILE_MAT_MIRROR,
+              "material type codes");
 int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     if (!d || !out) return fail(IILE_ERR_ARG, "iile_scene_create: null argument");
     int rc = ensure_device();
@@ -300,7 +303,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         }
     }
     for (int i = 0; i < d->n_materials; ++i)
-        if (d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC)
+        if (d->materials[i].type < IILE_MAT_MATTE || d->materials[i].type > IILE_MAT_MIRROR)
             return fail(IILE_ERR_UNSUPPORTED, "unsupported material type");
     if (d->halton.n_dims > kMaxHaltonDims) return fail(IILE_ERR_UNSUPPORTED, "too many Halton dimensions");
     const int need_dims = 5 + 8 * d->integrator.max_depth + 1;
@@ -487,6 +490,8 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 mats[i].ks[c] = m.ks[c];
             }
             mats[i].alpha = m.alpha;
+            for (int c = 0; c < 3; ++c) mats[i].kr[c] = m.kr[c];
+            mats[i].eta = m.eta;
         }
         rc = upload(sc, mats.data(), mats.size(), &S.materials);
         if (rc) return bail(rc);

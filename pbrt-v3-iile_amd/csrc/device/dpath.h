@@ -868,17 +868,20 @@ DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack,
 // ===========================================================================
 struct Bsdf {
     F3 ns, ng, ss, ts;
-    F3 kd, ks;
-    float alpha;
-    int n_lobes;
-    bool has_lambert, has_micro;
+    F3 kd, ks, kr;
+    float alpha, eta;
+    int n_lobes;  // nBxDFs; BxDF order: Lambertian, microfacet, specular reflection
+    int mtype;    // kMat*: selects the Fresnel terms (plastic 1.5/1; uber 1/eta; mirror none)
+    bool has_lambert, has_micro, has_spec;
 };
+DEV int n_nonspec(const Bsdf &b) { return (b.has_lambert ? 1 : 0) + (b.has_micro ? 1 : 0); }
 DEV F3 to_local(const Bsdf &b, F3 v) { return F3{dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)}; }
 DEV F3 to_world(const Bsdf &b, F3 v) {
     return F3{b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
               b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z};
 }
-// Matte / Plastic ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70)
+// Matte / Plastic / Uber / Mirror ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70,
+// uber.cpp:45-100 with opacity 1 and Kt 0, mirror.cpp:44-55)
 DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     Bsdf b;
     b.ns = is.sn;
@@ -892,10 +895,19 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.ks = F3{0, 0, 0};
     b.has_micro = false;
     b.alpha = m.alpha;
-    if (m.type == 1) {
+    b.mtype = m.type;
+    b.eta = m.eta;
+    if (m.type == kMatPlastic || m.type == kMatUber) {
         b.ks = F3{clampf(m.ks[0], 0, IILE_INF), clampf(m.ks[1], 0, IILE_INF), clampf(m.ks[2], 0, IILE_INF)};
         b.has_micro = !is_black(b.ks);
         if (b.has_micro) ++b.n_lobes;
+    }
+    b.kr = F3{0, 0, 0};
+    b.has_spec = false;
+    if (m.type == kMatUber || m.type == kMatMirror) {
+        b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
+        b.has_spec = !is_black(b.kr);
+        if (b.has_spec) ++b.n_lobes;
     }
     return b;
 }
@@ -1004,14 +1016,14 @@ DEV F3 tr_sample_wh(F3 wo, float u0, float u1, float a) {
     if (flip) wh = -wh;
     return wh;
 }
-// MicrofacetReflection::f with FresnelDielectric(1.5, 1), reflection.cpp:226-236
+// MicrofacetReflection::f, reflection.cpp:226-236, with FresnelDielectric(1.5, 1) (plastic) or (1, e) (uber)
 DEV F3 micro_f(const Bsdf &b, F3 wo, F3 wi) {
     float cos_o = fabsf(wo.z), cos_i = fabsf(wi.z);
     F3 wh = wi + wo;
     if (cos_i == 0 || cos_o == 0) return F3{0, 0, 0};
     if (wh.x == 0 && wh.y == 0 && wh.z == 0) return F3{0, 0, 0};
     wh = normalize(wh);
-    float Fr = fr_dielectric(dot(wi, wh), 1.5f, 1.f);
+    float Fr = b.mtype == kMatUber ? fr_dielectric(dot(wi, wh), 1.f, b.eta) : fr_dielectric(dot(wi, wh), 1.5f, 1.f);
     F3 F = F3{Fr, Fr, Fr};
     return sdiv(b.ks * tr_d(wh, b.alpha) * tr_g(wo, wi, b.alpha) * F, 4 * cos_i * cos_o);
 }
@@ -1042,30 +1054,41 @@ DEV float bsdf_pdf(const Bsdf &b, F3 woW, F3 wiW) {
     float pdf = 0.f;
     if (b.has_lambert) pdf += lambert_pdf(wo, wi);
     if (b.has_micro) pdf += micro_pdf(b, wo, wi);
-    return pdf / b.n_lobes;
+    const int matching = n_nonspec(b);  // flags = BSDF_ALL & ~BSDF_SPECULAR
+    return matching > 0 ? pdf / matching : 0.f;
 }
 // BSDF::Sample_f, reflection.cpp:719-784. *pdf is untouched on the early
 // `wo.z == 0` return, as in the reference.
-DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *pdf) {
-    const int matching = b.n_lobes;
+DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *pdf, const bool allow_specular = false,
+                     bool *sampled_specular = nullptr) {
+    // `type` is BSDF_ALL (allow_specular) or BSDF_ALL & ~BSDF_SPECULAR
+    if (sampled_specular) *sampled_specular = false;
+    const int matching = allow_specular ? b.n_lobes : n_nonspec(b);
     if (matching == 0) {
         *pdf = 0;
         return F3{0, 0, 0};
     }
     int comp = int(floorf(u0 * matching));
     if (comp > matching - 1) comp = matching - 1;
-    const bool pick_micro = b.has_lambert ? (comp == 1) : b.has_micro;
+    // the comp-th present lobe in BxDF order: 0 Lambertian, 1 microfacet, 2 specular reflection
+    int pick, count = comp;
+    if (b.has_lambert && count-- == 0)
+        pick = 0;
+    else if (b.has_micro && count-- == 0)
+        pick = 1;
+    else
+        pick = 2;
     const float ur0 = mn(u0 * matching - comp, kOneMinusEpsilon);
     F3 wo = to_local(b, woW);
     if (wo.z == 0) return F3{0, 0, 0};
     *pdf = 0;
     F3 wi = F3{0, 0, 0}, f;
-    if (!pick_micro) {  // BxDF::Sample_f, reflection.cpp:378-385
+    if (pick == 0) {  // BxDF::Sample_f, reflection.cpp:378-385
         wi = cosine_sample_hemisphere(ur0, u1);
         if (wo.z < 0) wi.z *= -1;
         *pdf = lambert_pdf(wo, wi);
         f = b.kd * kInvPi;
-    } else {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
+    } else if (pick == 1) {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
         F3 wh = tr_sample_wh(wo, ur0, u1, b.alpha);
         wi = -wo + 2 * dot(wo, wh) * wh;
         if (!same_hemisphere(wo, wi))
@@ -1074,12 +1097,24 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
             *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
             f = micro_f(b, wo, wi);
         }
+    } else {  // SpecularReflection::Sample_f, reflection.cpp:136-143
+        wi = F3{-wo.x, -wo.y, wo.z};
+        *pdf = 1;
+        const float fr = b.mtype == kMatMirror ? 1.f : fr_dielectric(wi.z, 1.f, b.eta);
+        f = sdiv(F3{fr, fr, fr} * b.kr, fabsf(wi.z));
+        if (sampled_specular) *sampled_specular = true;
     }
-    if (*pdf == 0) return F3{0, 0, 0};
+    if (*pdf == 0) {
+        if (sampled_specular) *sampled_specular = false;
+        return F3{0, 0, 0};
+    }
     *wiW = to_world(b, wi);
-    if (matching > 1) {
-        *pdf += pick_micro ? lambert_pdf(wo, wi) : micro_pdf(b, wo, wi);
-        *pdf /= matching;
+    if (pick != 2 && matching > 1) {  // a specular lobe's Pdf() and f() are 0
+        if (pick == 1 && b.has_lambert) *pdf += lambert_pdf(wo, wi);
+        if (pick == 0 && b.has_micro) *pdf += micro_pdf(b, wo, wi);
+    }
+    if (matching > 1) *pdf /= matching;
+    if (pick != 2 && matching > 1) {
         bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
         f = reflect ? lobes_f(b, wo, wi) : F3{0, 0, 0};
     }

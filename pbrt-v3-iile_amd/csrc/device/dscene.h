@@ -21,11 +21,14 @@ struct DSphere {
     float radius, zmin, zmax, theta_min, theta_max, phi_max;
     int reverse_orientation, swaps_handedness;
 };
+enum { kMatMatte = 0, kMatPlastic = 1, kMatUber = 2, kMatMirror = 3 };  // = IILE_MAT_* (checked in api.hip)
 struct DMaterial {
     int type;
     float kd[3];
     float ks[3];
     float alpha;
+    float kr[3];  // uber, mirror: specular reflectance
+    float eta;    // uber: FresnelDielectric(1, eta)
 };
 enum { kLightDiffuseArea = 0, kLightPoint = 1 };  // = IILE_LIGHT_* (checked in api.hip)
 struct DLight {

@@ -420,7 +420,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                 // the camera sample): k_generate does not spend 16 B per path on saying so
                 const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, b2f(5u)) : B.beta[pid];
                 beta = F3{beta4.x, beta4.y, beta4.z};
-                dim = int(f2b(beta4.w));
+                dim = int(f2b(beta4.w) & 0xffffu);
+                const bool prev_specular = (f2b(beta4.w) >> 16) != 0;  // specularBounce of path.cpp:150
                 hidx = B.hindex[pid];
                 // The four samples of EstimateDirect (dims dim+1 .. dim+4; dim itself is the
                 // 1D sample SampleDiscrete consumes), drawn here while few registers are live.
@@ -459,9 +460,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                     triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z},
                                          F3{v2.x, v2.y, v2.z}, ray_d, h4.y, h4.z, h4.w, &is);
                 }
-                // emitted light at the first vertex only: there are no specular lobes
-                // on this path, so specularBounce stays false (path.cpp:91-101)
-                if (bounce == 0 && light >= 0) {
+                // emitted light at the first vertex and after a specular bounce (path.cpp:91-101)
+                if ((bounce == 0 || prev_specular) && light >= 0) {
                     const float4 L4 = B.L[pid];
                     const F3 L = F3{L4.x, L4.y, L4.z} + beta * light_L(S.lights[light], is.n, -ray_d);
                     B.L[pid] = make_float4(L.x, L.y, L.z, 0);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                 if (bounce < S.max_depth) {
                     surface = true;
                     bsdf = make_bsdf(S.materials[material], is);
-                    if (bsdf.n_lobes > 0) {
+                    if (n_nonspec(bsdf) > 0) {  // NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0, path.cpp:118
                         ++n_nee;
                         if (S.n_lights > 0) {
                             // UniformSampleOneLight (integrator.cpp:85-106): one light, pdf 1;
@@ -584,7 +584,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             dim += 2;
             float pdf = 0;
             F3 wi = F3{0, 0, 0};
-            const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf);
+            bool sampled_specular = false;
+            const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf, true, &sampled_specular);
             if (!(is_black(f) || pdf == 0.f)) {
                 beta = beta * sdiv(f * absdot(wi, is.sn), pdf);
                 const float by = lum_y(beta);
@@ -607,7 +608,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                     }
                 }
             }
-            if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim)));
+            // sampler dimension | specularBounce << 16 (no specular transmission here: etaScale stays 1)
+            if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim) | (sampled_specular ? 0x10000u : 0u)));
         }
         // ReportValue(pathLength, bounces): a path that ends in this iteration leaves the
         // loop with bounces == bounce (not counted on the early `return L`)

@@ -433,8 +433,9 @@ class Loader {
                 fail("matte with sigma != 0 (Oren-Nayar) is not supported");
                 return -1;
             }
-        } else if (name == "plastic") {
-            m.type = IILE_MAT_PLASTIC;
+        } else if (name == "plastic" || name == "uber") {
+            const bool uber = name == "uber";
+            m.type = uber ? IILE_MAT_UBER : IILE_MAT_PLASTIC;
             float kd[3] = {0.25f, 0.25f, 0.25f}, ks[3] = {0.25f, 0.25f, 0.25f};
             ps.rgb("Kd", kd);
             ps.rgb("Ks", ks);
@@ -443,9 +444,27 @@ class Loader {
                 m.ks[i] = ks[i];
             }
             m.roughness = ps.one_float("roughness", .1f);
+            if (uber) {  // CreateUberMaterial, uber.cpp:102-127
+                float kr[3] = {0, 0, 0}, kt[3] = {0, 0, 0}, op[3] = {1, 1, 1};
+                ps.rgb("Kr", kr);
+                ps.rgb("Kt", kt);
+                ps.rgb("opacity", op);
+                if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0 || op[0] != 1 || op[1] != 1 || op[2] != 1) {
+                    fail("uber: specular transmission (Kt, opacity < 1) is not supported");
+                    return -1;
+                }
+                for (int i = 0; i < 3; ++i) m.kr[i] = kr[i];
+                const float ur = ps.one_float("uroughness", m.roughness), vr = ps.one_float("vroughness", ur);
+                if (ur != vr) {
+                    fail("uber: anisotropic roughness is not supported");
+                    return -1;
+                }
+                m.roughness = ur;
+                m.eta = ps.find("eta") ? ps.one_float("eta", 1.5f) : ps.one_float("index", 1.5f);
+            }
             m.remap_roughness = ps.one_bool("remaproughness", true) ? 1 : 0;
             if (m.remap_roughness) {
-                // The reference re-evaluates this per hit (plastic.cpp:61-63);
+                // The reference re-evaluates this per hit (plastic.cpp:61-63, uber.cpp:79-82);
                 // it is a per-material constant, so it is evaluated once here.
                 float r = std::max(m.roughness, 1e-3f);
                 float x = std::log(r);
@@ -453,8 +472,13 @@ class Loader {
                           0.000640711f * x * x * x * x;
             } else
                 m.alpha = m.roughness;
+        } else if (name == "mirror") {  // CreateMirrorMaterial, mirror.cpp:57-63
+            m.type = IILE_MAT_MIRROR;
+            float kr[3] = {0.9f, 0.9f, 0.9f};
+            ps.rgb("Kr", kr);
+            for (int i = 0; i < 3; ++i) m.kr[i] = kr[i];
         } else {
-            fail("Material \"" + name + "\" is not supported (matte, plastic)");
+            fail("Material \"" + name + "\" is not supported (matte, plastic, uber, mirror)");
             return -1;
         }
         for (const char *tex : {"bumpmap"})

@@ -53,7 +53,7 @@ def _grid_quad(origin, du, dv, n):
     return P, np.array(F, np.int32)
 
 
-def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, seed=12111, maxdepth=5, light="area"):
+def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, seed=12111, maxdepth=5, light="area", materials="plain"):
     """Returns the scene text. Triangles: 5 * 2 * wall_n^2 + n_blobs * 20 * 4^ico_levels
     (defaults: 5 760 + 30 720; ico_levels=5, n_blobs=12, wall_n=64 gives ~287 k)."""
     rng = np.random.default_rng(seed)
@@ -82,7 +82,12 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         c = np.array([rng.uniform(-6, 6), rng.uniform(-4, 7), rng.uniform(-2, 5)])
         noise = 1.0 + 0.18 * rng.standard_normal(len(V)).clip(-2.5, 2.5)
         P = c + V * (r * noise)[:, None]
-        if b % 2 == 0:
+        if materials == "mixed" and b % 3 == 1:  # specular lobes: uber (diffuse + glossy + mirror-like) and mirror
+            mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "color Kr" [.3 .3 .3] "float roughness" [%g] "float index" [%g]' % (
+                *rng.uniform(.1, .4, 3), rng.uniform(.05, .3), rng.uniform(1.2, 1.8))
+        elif materials == "mixed" and b % 3 == 2:
+            mat = 'Material "mirror" "color Kr" [%g %g %g]' % tuple(rng.uniform(.6, .95, 3))
+        elif b % 2 == 0:
             mat = 'Material "plastic" "color Kd" [%g %g %g] "color Ks" [.4 .4 .4] "float roughness" [%g]' % (
                 *rng.uniform(.2, .7, 3), rng.uniform(.02, .3))
         else:

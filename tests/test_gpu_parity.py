@@ -340,3 +340,24 @@ def test_point_light_scenes_bitwise(binding, oracle, tmp_path):
         assert st["path_length"] == ost["path_length"] and st["zero_radiance"] == ost["zero_radiance"]
         plain, _ = gpu.render()
         assert_bitwise(plain, ref, f"{name} (point light) film, uninstrumented kernels")
+
+
+def test_specular_materials_bitwise(binding, oracle, tmp_path):
+    """UberMaterial and MirrorMaterial: the reference's analytic uber scene, and
+    the box room with uber / mirror / plastic / matte blobs under the area light, where paths
+    reach the emitter through specular bounces (the `specularBounce` branch of Li)."""
+    import os
+    import boxroom
+    furnace = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_uber.pbrt"))
+    path = tmp_path / "boxroom_mixed.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, materials="mixed"))
+    room = binding.HostScene(path=str(path))
+    for name, scene in (("furnace", furnace), ("boxroom", room)):
+        gpu = binding.GpuScene(scene)
+        film, st = gpu.render(collect_stats=True)
+        ref, ost = oracle.render(scene)
+        assert_bitwise(film, ref, f"{name} (specular materials) film")
+        assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+        assert st["nee_evals"] == ost["nee_evals"] and st["path_length"] == ost["path_length"]
+        plain, _ = gpu.render()
+        assert_bitwise(plain, ref, f"{name} (specular materials) film, uninstrumented kernels")

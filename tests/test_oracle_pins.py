@@ -214,3 +214,16 @@ def test_point_light_furnace_scene_matches_reference_expectation(binding, oracle
     assert abs(mean - 1.0) < 0.02, mean
     # a delta light traces no MIS ray: one shadow ray per scattering vertex, nothing else
     assert st["shadow_rays"] == st["nee_evals"]
+
+
+def test_uber_material_furnace_scene_matches_reference_expectation(binding, oracle):
+    """Fourth scene of src/tests/analytic_scenes.cpp:167-202 (UberMaterial Kd = 0.25, Kr = 0.5,
+    eta 1; point light 3 pi): the reference expects mean radiance 1.0 within 0.02. Pins the
+    specular-lobe handling of BSDF::Sample_f / NumComponents and UberMaterial in the oracle."""
+    import os
+    scene = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_uber.pbrt"))
+    film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+    mean = float(scene.film_to_rgb(film).mean(dtype=np.float64))
+    assert abs(mean - 1.0) < 0.02, mean
+    # FresnelDielectric(1, 1) is 0: a path that picks the specular lobe ends there
+    assert st["path_length"][0] > 10000
