@@ -97,7 +97,7 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     const size_t cap = queue_capacity(n_paths, sc->n_cus);
     // per path: L, beta (float4), hindex; per queue slot: ray_o[2], ray_d[2], hits, nee[7] (float4), shade_q
     const size_t f4 = sizeof(float4);
-    size_t bytes = 2 * n * f4 + n * sizeof(uint32_t) + 12 * cap * f4 + cap * sizeof(uint32_t) + 2 * cap +
+    size_t bytes = 2 * n * f4 + n * sizeof(uint32_t) + 12 * cap * f4 + cap * sizeof(uint32_t) + cap +
                    128 * sizeof(uint32_t) + sizeof(DCounters) + 16384;
     void *blk = nullptr;
     HIP_TRY(hipMalloc(&blk, bytes));
@@ -121,7 +121,6 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     B.nee = reinterpret_cast<float4 *>(take(7 * cap * f4));
     B.hindex = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
     B.shade_q = reinterpret_cast<uint32_t *>(take(cap * sizeof(uint32_t)));
-    B.nee_occl = reinterpret_cast<uint8_t *>(take(cap));
     B.nee_mis = reinterpret_cast<uint8_t *>(take(cap));
     B.counts = reinterpret_cast<uint32_t *>(take(128 * sizeof(uint32_t)));
     B.counters = reinterpret_cast<DCounters *>(take(sizeof(DCounters)));
@@ -210,11 +209,12 @@ int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed
         rc = timed_launch(2, [&] { launch_shade(S, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (b < sc->max_depth) {
-            rc = timed_launch(3, [&] { launch_shadow(S, B, b, B.queue_cap, cfg); });
-            if (rc) return rc;
+            // MIS rays first: the shadow kernel finishes each record (L += beta * Ld)
             rc = timed_launch(5, [&] { launch_mis(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
-            rc = timed_launch(6, [&] { launch_nee_resolve(S, B, b, B.queue_cap, cfg); });
+            rc = timed_launch(6, [&] { launch_mis_lit(S, B, b, B.queue_cap, cfg); });
+            if (rc) return rc;
+            rc = timed_launch(3, [&] { launch_shadow(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
         }
     }

@@ -27,8 +27,8 @@ struct PassBuffers {
     float4 *ray_d[2];
     float4 *hits;       // [n_paths]
     float4 *nee;        // 7 planes of queue_cap float4
-    uint8_t *nee_occl;  // [queue_cap] shadow ray occluded (written by k_shadow)
-    uint8_t *nee_mis;   // [queue_cap] area light index + 1 the MIS ray ended on, 0 = none (k_mis)
+    uint8_t *nee_mis;   // [queue_cap] k_mis: area light index + 1 the MIS ray ended on, 0 = none;
+                        // after k_mis_lit: 1 = it reached the sampled light on its emitting side
     uint32_t *shade_q;  // [n_paths] queue slots whose ray hit something (input of shade)
     uint32_t *counts;   // 128 words: queue sizes and chunk cursors per bounce (layout in kernels.hip)
     DCounters *counters;
@@ -57,7 +57,7 @@ void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t m
 void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
-void launch_nee_resolve(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_mis_lit(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
                             const LaunchCfg &cfg);
 void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg);

@@ -1,7 +1,7 @@
 // kernels.hip — hand-written gfx950 kernels of the wavefront path tracer.
 //
 // Pipeline per pass (one pass = owned tiles x a chunk of sample indices):
-//   generate -> [ extend -> shade -> shadow -> mis -> resolve ] x (maxDepth + 1) -> film_accumulate
+//   generate -> [ extend -> shade -> mis -> mis_lit -> shadow ] x (maxDepth + 1) -> film_accumulate
 // and, after the last pass, film_resolve.
 //
 //   generate  HaltonSampler + PerspectiveCamera::GenerateRayDifferential; fills ray queue 0
@@ -12,7 +12,7 @@
 //             surviving paths into the next ray queue with ballot + one atomic per wavefront
 //   shadow    BVHAccel::IntersectP for the shadow ray of each NEE record
 //   mis       BVHAccel::Intersect for the MIS ray of each NEE record
-//   resolve   L += beta * Ld once both rays of a record are known
+//   shadow    BVHAccel::IntersectP for its shadow ray; L += beta * Ld
 //
 // All kernels are persistent grid-stride loops that read their queue length
 // from device memory, so a whole pass is enqueued without host synchronisation.
@@ -632,10 +632,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
 
 // ---------------------------------------------------------------------------
 // NEE resolution: two homogeneous kernels over the NEE records of one bounce.
-//   k_shadow  BVHAccel::IntersectP for the shadow ray; marks occluded records
 //   k_mis     BVHAccel::Intersect for the MIS ray; records which emitter (if any) it ended on
-// Both finish a record with a single byte store, so no load ever stalls their loops;
-// k_nee_resolve then streams over the records once and adds beta * Ld to L.
+//   k_shadow  BVHAccel::IntersectP for the shadow ray, then L += beta * Ld
+// Both finish a record with a single store, so no load ever stalls their loops.
 // (One fused kernel walking each record through both rays measured 60 ms per
 // 1080p/64spp step against 7 + 17.5 + 26.4 ms for its parts: any-hit and
 // closest-hit lanes in one wavefront keep each other waiting.)
@@ -649,7 +648,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
     const uint32_t count = B.counts[kCntNee + bounce];
     uint32_t *head = &B.counts[kCntConHead + bounce];
     TraceStats st = {0, 0, 0, 0};
-    unsigned long long n_shadow = 0;
+    unsigned long long n_shadow = 0, n_zero = 0;
     WaveFeed feed{0, 0, count == 0};
     Trav t;
     t.have = false;
@@ -657,7 +656,13 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
     t.sp = 0;
     t.hit_prim = -1;
     bool active = false, occluded = false;
-    uint32_t e = 0;
+    uint32_t e = 0, pid = 0;
+    // The record's two possible outcomes, L + beta * Ld with and without the light sample, are
+    // formed when the lane takes the record (its loads ride along with the shadow ray's), so a
+    // lane that finishes only stores one of them: no load inside the traversal loop, and no
+    // separate pass over the records (a streaming resolve kernel cost 4.9 ms per frame).
+    F3 L_unoccluded = F3{0, 0, 0}, L_occluded = F3{0, 0, 0};
+    bool zero_unoccluded = false, zero_occluded = false;
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
@@ -665,18 +670,45 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
             if (feed_take(feed, head, count, !active, &e_new, [&](uint32_t first) {
                     warm_plane(B.nee, first, count);
                     warm_plane(B.nee + plane, first, count);
+                    warm_plane(B.nee + 4 * size_t(plane), first, count);
+                    warm_plane(B.nee + 6 * size_t(plane), first, count);
                 })) {
                 e = e_new;
                 const float4 n1 = B.nee[plane + e];
                 const uint32_t flags = f2b(n1.w);
-                if (flags != kInvalid && (flags & NEE_HAS_SHADOW & ~uint32_t(dbg_skip))) {
-                    const float4 n0 = B.nee[e];
-                    trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st);
-                    active = true;
-                    occluded = false;
+                if (flags != kInvalid) {
+                    // Ld = [light sample unoccluded] A + [MIS ray reached the sampled light, facing it] B,
+                    // L += beta * Ld (integrator.cpp:150-158, 205-211; path.cpp:123-128)
+                    const float4 n0 = B.nee[e], a4 = B.nee[4 * size_t(plane) + e], be = B.nee[6 * size_t(plane) + e];
+                    const bool lit = (flags & NEE_HAS_MIS) && B.nee_mis[e] != 0;
+                    pid = f2b(be.w);
+                    const float4 L4 = B.L[pid];
+                    const bool has_shadow = (flags & NEE_HAS_SHADOW & ~uint32_t(dbg_skip)) != 0;
+                    F3 Ld_u = F3{0, 0, 0}, Ld_o = F3{0, 0, 0};
+                    if (has_shadow) Ld_u = Ld_u + F3{a4.x, a4.y, a4.z};
+                    if (lit) {
+                        const float4 b4 = B.nee[5 * size_t(plane) + e];
+                        Ld_u = Ld_u + F3{b4.x, b4.y, b4.z};
+                        Ld_o = Ld_o + F3{b4.x, b4.y, b4.z};
+                    }
+                    const F3 beta = F3{be.x, be.y, be.z}, add_u = beta * Ld_u, add_o = beta * Ld_o;
+                    L_unoccluded = F3{L4.x, L4.y, L4.z} + add_u;
+                    L_occluded = F3{L4.x, L4.y, L4.z} + add_o;
                     if (COUNT) {
-                        ++n_shadow;
-                        if (B.nray_out) B.nray_out[2 * f2b(n0.w) + 1] += 1;
+                        zero_unoccluded = is_black(add_u);
+                        zero_occluded = is_black(add_o);
+                    }
+                    if (has_shadow) {
+                        trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st);
+                        active = true;
+                        occluded = false;
+                        if (COUNT) {
+                            ++n_shadow;
+                            if (B.nray_out) B.nray_out[2 * f2b(n0.w) + 1] += 1;
+                        }
+                    } else {  // no light sample to test: the record is complete
+                        B.L[pid] = make_float4(L_occluded.x, L_occluded.y, L_occluded.z, 0);
+                        if (COUNT && zero_occluded) ++n_zero;
                     }
                 }
             }
@@ -704,12 +736,15 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
         if (active && t.have && trav_leaf<COUNT>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
 #endif
         if (active && !t.have) {
-            B.nee_occl[e] = occluded ? 1 : 0;  // store only: no load ever stalls this loop
+            const F3 Ln = occluded ? L_occluded : L_unoccluded;  // store only: no load ever stalls this loop
+            B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
+            if (COUNT && (occluded ? zero_occluded : zero_unoccluded)) ++n_zero;
             active = false;
         }
     }
     if (COUNT) {
         flush_counter(&B.counters->shadow_rays, n_shadow);
+        flush_counter(&B.counters->zero_radiance, n_zero);
         flush_counter(&B.counters->nodes_any, st.nodes);
         flush_counter(&B.counters->any_tri_tests, st.tris);
         flush_counter(&B.counters->tri_tests, st.tris);
@@ -753,6 +788,8 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
                         ++n_closest;
                         if (B.nray_out) B.nray_out[2 * f2b(B.nee[e].w)] += 1;
                     }
+                } else if (flags != kInvalid) {
+                    B.nee_mis[e] = 0;  // no MIS ray: k_mis_lit has nothing to look at
                 }
             }
         }
@@ -790,30 +827,24 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
     }
 }
 
-// nee_resolve: one streaming pass over the NEE records of a bounce after both rays are
-// known: Ld = [light sample unoccluded] + [MIS ray ended on the sampled light, facing it],
-// L += beta * Ld (integrator.cpp:150-158, 205-211; path.cpp:123-128).
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_nee_resolve(DScene S, PassBuffers B, int bounce, uint32_t plane) {
+// mis_lit: k_mis leaves, per record, the (area light index + 1) of the primitive its MIS ray
+// ended on. This pass over that byte plane turns it into "the ray reached the *sampled* light,
+// on its emitting side" (`lightIsect.primitive->GetAreaLight() == &light`, then
+// SurfaceInteraction::Le -> DiffuseAreaLight::L; integrator.cpp:205-209). Only the rare records
+// whose ray did end on an emitter are looked at any further.
+__global__ __launch_bounds__(kBlock) void k_mis_lit(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     const uint32_t count = B.counts[kCntNee + bounce];
-    unsigned long long n_zero = 0;
     for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < count; e += gridDim.x * kBlock) {
-        // everything the common case needs, issued together: A|flags, beta|pid, the two result bytes
-        const float4 a4 = B.nee[4 * plane + e], be = B.nee[6 * plane + e];
-        const uint32_t occl = B.nee_occl[e], mis = B.nee_mis[e];
-        const uint32_t flags = f2b(a4.w), pid = f2b(be.w);
-        if (flags == kInvalid) continue;
-        const float4 L4 = B.L[pid];
-        F3 Ld = F3{0, 0, 0};
-        if ((flags & NEE_HAS_SHADOW) && !occl) Ld = Ld + F3{a4.x, a4.y, a4.z};
-        if ((flags & NEE_HAS_MIS) && mis != 0) {
-            const float4 b4 = B.nee[5 * plane + e];
-            const int li = int(f2b(b4.w));
-            // `lightIsect.primitive->GetAreaLight() == &light` (integrator.cpp:207)
+        const uint32_t mis = B.nee_mis[e];
+        if (mis == 0) continue;
+        const float4 n2 = B.nee[2 * size_t(plane) + e], n3 = B.nee[3 * size_t(plane) + e];
+        const uint32_t flags = f2b(n3.w);
+        bool lit = false;
+        if (flags != kInvalid && (flags & NEE_HAS_MIS)) {
+            const int li = int(f2b(n2.w));
             if (int(mis) == li + 1) {
                 const DLight &lt = S.lights[li];
                 const DSphere &sp = S.spheres[lt.sphere];
-                const float4 n2 = B.nee[2 * plane + e], n3 = B.nee[3 * plane + e];
                 const F3 mo = F3{n2.x, n2.y, n2.z}, md = F3{n3.x, n3.y, n3.z};
                 float th;
                 F3 od, ph;
@@ -821,14 +852,11 @@ __global__ __launch_bounds__(kBlock) void k_nee_resolve(DScene S, PassBuffers B,
                 // the closest hit was this sphere: redo its root selection for the hit point
                 sphere_test(sp, mo, md, IILE_INF, &th, &od, &ph);
                 sphere_interaction(sp, od, ph, &lis);
-                if (lt.two_sided || dot(lis.n, -md) > 0) Ld = Ld + F3{b4.x, b4.y, b4.z};
+                lit = lt.two_sided || dot(lis.n, -md) > 0;
             }
         }
-        const F3 add = F3{be.x, be.y, be.z} * Ld;
-        if (COUNT && is_black(add)) ++n_zero;
-        B.L[pid] = make_float4(L4.x + add.x, L4.y + add.y, L4.z + add.z, 0);
+        B.nee_mis[e] = lit ? 1 : 0;
     }
-    if (COUNT) flush_counter(&B.counters->zero_radiance, n_zero);
 }
 
 // ---------------------------------------------------------------------------
@@ -1119,12 +1147,9 @@ void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_
     else
         hipLaunchKernelGGL(k_mis<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
 }
-void launch_nee_resolve(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+void launch_mis_lit(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 8));
-    if (cfg.count_stats)
-        hipLaunchKernelGGL(k_nee_resolve<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
-    else
-        hipLaunchKernelGGL(k_nee_resolve<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+    hipLaunchKernelGGL(k_mis_lit, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
 }
 void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
                             const LaunchCfg &cfg) {
