@@ -661,8 +661,9 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
     // formed when the lane takes the record (its loads ride along with the shadow ray's), so a
     // lane that finishes only stores one of them: no load inside the traversal loop, and no
     // separate pass over the records (a streaming resolve kernel cost 4.9 ms per frame).
-    F3 L_unoccluded = F3{0, 0, 0}, L_occluded = F3{0, 0, 0};
-    bool zero_unoccluded = false, zero_occluded = false;
+    // (L itself is only *consumed* at the store, so its load — the one scattered access of the
+    // record — overlaps the ray's first traversal steps instead of holding up the refill.)
+    F3 L_old = F3{0, 0, 0}, add_unoccluded = F3{0, 0, 0}, add_occluded = F3{0, 0, 0};
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
@@ -691,13 +692,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                         Ld_u = Ld_u + F3{b4.x, b4.y, b4.z};
                         Ld_o = Ld_o + F3{b4.x, b4.y, b4.z};
                     }
-                    const F3 beta = F3{be.x, be.y, be.z}, add_u = beta * Ld_u, add_o = beta * Ld_o;
-                    L_unoccluded = F3{L4.x, L4.y, L4.z} + add_u;
-                    L_occluded = F3{L4.x, L4.y, L4.z} + add_o;
-                    if (COUNT) {
-                        zero_unoccluded = is_black(add_u);
-                        zero_occluded = is_black(add_o);
-                    }
+                    const F3 beta = F3{be.x, be.y, be.z};
+                    add_unoccluded = beta * Ld_u;
+                    add_occluded = beta * Ld_o;
+                    L_old = F3{L4.x, L4.y, L4.z};
                     if (has_shadow) {
                         trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st);
                         active = true;
@@ -707,8 +705,9 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                             if (B.nray_out) B.nray_out[2 * f2b(n0.w) + 1] += 1;
                         }
                     } else {  // no light sample to test: the record is complete
-                        B.L[pid] = make_float4(L_occluded.x, L_occluded.y, L_occluded.z, 0);
-                        if (COUNT && zero_occluded) ++n_zero;
+                        const F3 Ln = L_old + add_occluded;
+                        B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
+                        if (COUNT && is_black(add_occluded)) ++n_zero;
                     }
                 }
             }
@@ -736,9 +735,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
         if (active && t.have && trav_leaf<COUNT>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
 #endif
         if (active && !t.have) {
-            const F3 Ln = occluded ? L_occluded : L_unoccluded;  // store only: no load ever stalls this loop
+            const F3 add = occluded ? add_occluded : add_unoccluded;
+            const F3 Ln = L_old + add;  // store only: nothing is loaded here
             B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
-            if (COUNT && (occluded ? zero_occluded : zero_unoccluded)) ++n_zero;
+            if (COUNT && is_black(add)) ++n_zero;
             active = false;
         }
     }
