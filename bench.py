@@ -214,7 +214,7 @@ def main():
         other = {
             "k_shade": (agg["ms_shade"], 48 * nee + 112 * nee + 32 * next_rays,
                         "approx.: 48 B in per hit, 112 B NEE record + 32 B next ray out; VALU bound"),
-            "k_nee_resolve": (agg["ms_resolve"], 66 * nee, "34 B record + 32 B L read-modify-write"),
+            "k_mis_lit": (agg["ms_resolve"], 1 * nee, "one result byte per NEE record"),
             "k_generate": (agg["ms_generate"], 52 * cst["camera_rays"], "ray, Halton index, L written"),
             "k_film": (agg["ms_film"], 16 * cst["camera_rays"], "L read per sample"),
         }

@@ -77,7 +77,7 @@ typedef struct iile_stats {
     /* the extend kernel alone (main-path closest-hit rays): inputs of its roofline */
     uint64_t ext_rays, ext_nodes, ext_tri_tests, ext_sphere_tests;
     uint64_t any_tri_tests;       /* triangle tests of the shadow (any-hit) kernel */
-    double ms_shadow, ms_mis, ms_resolve; /* the NEE kernels; ms_connect is their sum */
+    double ms_shadow, ms_mis, ms_resolve; /* the NEE kernels (ms_resolve: k_mis_lit); ms_connect is their sum */
 } iile_stats;
 
 int iile_device_count(void);
