@@ -481,6 +481,9 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
 // LDS pointers carry their address space explicitly so that pushes and pops
 // compile to ds_write_b32 / ds_read_b32 (a generic pointer would go through flat_*).
 typedef __attribute__((address_space(3))) int lds_int;
+#ifndef IILE_LEAF_ONE
+#define IILE_LEAF_ONE 1
+#endif
 #ifndef IILE_LDS_STACK
 #define IILE_LDS_STACK 12  // 24 KB per block: six blocks per 160 KB CU
 #endif
@@ -838,6 +841,14 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
             }
         }
         ++prim;
+#if IILE_LEAF_ONE
+        // one primitive per step: the wavefront's next vote sees the lanes whose leaf goes on,
+        // instead of every lane waiting for the longest leaf (most leaves hold one primitive)
+        if (!last) {
+            t.cur = ~prim;
+            return false;
+        }
+#endif
     } while (!last);
     trav_pop<COUNT>(t, sr, st);
     return false;

@@ -39,8 +39,8 @@ namespace iile {
 #define IILE_TRAV_WAVES 6  // waves per SIMD = resident blocks per CU of the traversal kernels (<= 80 VGPRs, no scratch)
 #endif
 #ifndef IILE_VOTE_NUM
-#define IILE_VOTE_NUM 3
-#define IILE_VOTE_DEN 2
+#define IILE_VOTE_NUM 4
+#define IILE_VOTE_DEN 5
 #endif
 
 constexpr int kBlock = 256;            // 4 wavefronts
