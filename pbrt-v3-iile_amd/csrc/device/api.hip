@@ -365,6 +365,19 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         }
         rc = upload(sc, wide.data(), wide.size(), &S.wide);
         if (rc) return bail(rc);
+        // The four-wide step never tests the two children themselves; that is exact because a
+        // child's box lies inside its parent's (Union in recursiveBuild is exact). Verify it for
+        // the tree we were handed; a tree that violates it is traversed with binary steps only.
+        S.boxes_nested = 1;
+        for (int i = 0; i < n && S.boxes_nested; ++i) {
+            const iile_bvh_node &nd = d->nodes[i];
+            if (nd.nprims > 0) continue;
+            const int child[2] = {i + 1, nd.offset};
+            for (int k = 0; k < 2; ++k)
+                for (int c = 0; c < 3; ++c)
+                    if (!(d->nodes[child[k]].bmin[c] >= nd.bmin[c] && d->nodes[child[k]].bmax[c] <= nd.bmax[c]))
+                        S.boxes_nested = 0;
+        }
         // Four-wide records (dpath.h trav_interior4): per binary interior node P the boxes / refs
         // of its grandchildren in fixed slots {L's children | L if leaf, -} {R's children | R, -},
         // as six SoA planes, then refs, then the split axes of P, L and R. An unused slot gets an

@@ -774,9 +774,10 @@ DEV void trav_interior4(Trav &t, const StackRef &sr, const float4 mnx, const flo
         trav_pop<false>(t, sr, nullptr);
 }
 // One interior step of the uninstrumented kernels: the four-wide record, unless a lane of the
-// wavefront carries a NaN-capable ray.
+// wavefront carries a NaN-capable ray (or the scene's boxes are not nested, which a BVH built as
+// bvh.cpp:236-402 builds it cannot produce; iile_scene_create checks).
 DEV void trav_interior_step_fast(const DScene &S, Trav &t, const StackRef &sr) {
-    if (__builtin_expect(__ballot(t.rc.neg_mask & 0x80) == 0, 1)) {
+    if (__builtin_expect(S.boxes_nested && __ballot(t.rc.neg_mask & 0x80) == 0, 1)) {
         const float4 *w = S.wide4 + 8 * size_t(t.cur < 0 ? 0 : t.cur);
         trav_interior4(t, sr, w[0], w[1], w[2], w[3], w[4], w[5], w[6], __float_as_uint(w[7].x));
     } else {

@@ -71,6 +71,8 @@ struct DScene {
     int n_perms;              // u16 entries of `perms`
     float root_box[6];        // bounds of the root node (min.xyz, max.xyz)
     int root_ref;             // >= 0: wide record; < 0: ~first primitive of a single-leaf tree
+    int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide
+                              // step's skipping of intermediate nodes is exact only then
     // camera
     M44 raster_to_camera, camera_to_world;
     float lens_radius, focal_distance;
