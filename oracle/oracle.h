@@ -82,6 +82,19 @@ void oracle_sincos(int trig_mode, float x, float *s, float *c);
 void oracle_sincos_d(int trig_mode, double x, double *s, double *c);
 float oracle_acos(int trig_mode, float x);
 
+/* Property tests of the reference (src/tests/fp_tests.cpp, src/tests/shapes.cpp), run against the
+ * restatement's own float machinery. Each returns the number of violated expectations.
+ *   oracle_check_next_float   FloatingPoint.NextUpDownFloat (:29-47): vs nextafterf
+ *   oracle_check_efloat       EFloat.Add/Sub/Mul/Div (:201-270): the interval contains the result
+ *                             computed from precise values chosen inside the operands' intervals
+ *   oracle_check_reintersect  Triangle.Reintersect / FullSphere.Reintersect (shapes.cpp:154-208,
+ *                             :374-436): rays spawned from a hit (SpawnRay / SpawnRayTo) never hit
+ *                             the primitive they leave. stats = {hits found, spawned rays tested}. */
+int64_t oracle_check_next_float(int iters, uint64_t seed);
+int64_t oracle_check_efloat(int iters, uint64_t seed);
+int64_t oracle_check_reintersect(const iile_scene_desc *scene, int n, const float *o, const float *d, int n_out,
+                                 uint64_t seed, int64_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

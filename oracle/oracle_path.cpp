@@ -905,6 +905,17 @@ struct Oracle {
         }
         return hit;
     }
+    // one primitive alone (the reference's shape-level Intersect / IntersectP), for the property tests
+    bool prim_intersects(const Ray &ray, int prim) const {
+        if (S.prim_flags[prim] & IILE_PRIM_SPHERE) {
+            Ray orr;
+            float t;
+            V3 ph;
+            return sphere_test(ray, S.spheres[S.prim_shape[prim]], &orr, &t, &ph);
+        }
+        float t, b0, b1, b2;
+        return triangle_test(ray, prim, &t, &b0, &b1, &b2);
+    }
     bool intersect_p(const Ray &ray) const {
         ++ctr->shadow_rays;
         if (S.n_nodes == 0) return false;
@@ -1753,3 +1764,124 @@ float oracle_acos(int trig_mode, float x) {
 }
 
 }  // extern "C"
+
+// ----------------------------------------------------------------------------
+// property tests of the reference, see oracle.h
+namespace {
+struct SplitMix {
+    uint64_t s;
+    uint64_t next() {
+        uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+    float uniform() { return float(next() >> 40) * 0x1p-24f; }
+    uint32_t below(uint32_t n) { return uint32_t(next() % n); }
+};
+// fp_tests.cpp:97-118 (getFloat): a random float with a wide range of exponents
+float random_float(SplitMix &r, float min_exp = -6.f, float max_exp = 6.f) {
+    float logu = min_exp + r.uniform() * (max_exp - min_exp);
+    float sign = r.uniform() < .5f ? -1.f : 1.f;
+    return sign * std::pow(10.f, logu);
+}
+EFloat random_efloat(SplitMix &r) {  // fp_tests.cpp:105-143
+    float val = std::abs(random_float(r));
+    float err = 0;
+    switch (r.below(4)) {
+    case 0: break;
+    case 1: err = std::abs(b2f(f2b(val) + r.below(1024)) - val); break;
+    case 2: err = std::abs(b2f(f2b(val) + r.below(1024 * 1024)) - val); break;
+    default: err = (4 * r.uniform()) * std::abs(val);
+    }
+    float sign = r.uniform() < .5f ? -1.f : 1.f;
+    return EFloat(sign * val, err);
+}
+double precise_in(const EFloat &e, SplitMix &r) {  // fp_tests.cpp:147-166
+    switch (r.below(3)) {
+    case 0: return e.low;
+    case 1: return e.high;
+    default: {
+        float t = r.uniform();
+        double p = (1 - t) * double(e.low) + t * double(e.high);
+        return std::min(std::max(p, double(e.low)), double(e.high));
+    }
+    }
+}
+}  // namespace
+
+int64_t oracle_check_next_float(int iters, uint64_t seed) {
+    int64_t bad = 0;
+    if (!(next_up(-0.f) > 0.f) || !(next_down(0.f) < 0.f)) ++bad;
+    if (next_up(Infinity) != Infinity || !(next_down(Infinity) < Infinity)) ++bad;
+    if (next_down(-Infinity) != -Infinity || !(next_up(-Infinity) > -Infinity)) ++bad;
+    SplitMix r{seed};
+    for (int i = 0; i < iters; ++i) {
+        float f = b2f(uint32_t(r.next()));  // any bit pattern
+        if (std::isinf(f) || std::isnan(f)) continue;
+        if (std::nextafter(f, Infinity) != next_up(f)) ++bad;
+        if (std::nextafter(f, -Infinity) != next_down(f)) ++bad;
+    }
+    return bad;
+}
+
+int64_t oracle_check_efloat(int iters, uint64_t seed) {
+    int64_t bad = 0;
+    for (int i = 0; i < iters; ++i) {
+        SplitMix r{seed + uint64_t(i)};
+        EFloat e[2] = {random_efloat(r), random_efloat(r)};
+        double p[2] = {precise_in(e[0], r), precise_in(e[1], r)};
+        auto check = [&](const EFloat &res, float precise) {  // the reference compares in float
+            if (!(precise >= res.low && precise <= res.high)) ++bad;
+        };
+        check(e[0] + e[1], float(p[0] + p[1]));
+        check(e[0] - e[1], float(p[0] - p[1]));
+        check(e[0] * e[1], float(p[0] * p[1]));
+        const float abs_err = (e[1].high - e[1].low) / 2;  // GetAbsoluteError, efloat.h:112
+        if (!(double(e[1].low) * double(e[1].high) < 0. || abs_err > .25 * std::abs(e[1].low)))
+            check(e[0] / e[1], float(p[0] / p[1]));
+    }
+    return bad;
+}
+
+int64_t oracle_check_reintersect(const iile_scene_desc *scene, int n, const float *o, const float *d, int n_out,
+                                 uint64_t seed, int64_t *stats) {
+    Counters c;
+    Oracle orc(*scene, ORACLE_TRIG_LIBM, &c);
+    SplitMix r{seed};
+    int64_t bad = 0, hits = 0, tested = 0;
+    for (int i = 0; i < n; ++i) {
+        Ray ray{V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), Infinity};
+        Isect is;
+        if (!orc.intersect(ray, &is, true)) continue;
+        ++hits;
+        const bool convex_only = (scene->prim_flags[is.prim] & IILE_PRIM_SPHERE) != 0;
+        for (int j = 0; j < n_out; ++j) {
+            // UniformSampleSphere, sampling.cpp:98-103
+            float u0 = r.uniform(), u1 = r.uniform();
+            float z = 1 - 2 * u0, rr = std::sqrt(std::max(0.f, 1.f - z * z)), phi = 2 * Pi * u1;
+            V3 w(rr * std::cos(phi), rr * std::sin(phi), z);
+            // a sphere is only convex: stay on the side of the surface normal (shapes.cpp:402-404)
+            if (convex_only && dot(w, is.n) < 0) w = -w;
+            Ray out = Oracle::spawn_ray(is, w);
+            ++tested;
+            if (orc.prim_intersects(out, is.prim)) ++bad;
+            // SpawnRayTo a random point (shapes.cpp:196-205, 411-423)
+            V3 p2(random_float(r, -3.f, 3.f), random_float(r, -3.f, 3.f), random_float(r, -3.f, 3.f));
+            if (convex_only) {
+                V3 w2 = p2 - is.p;
+                if (dot(w2, is.n) < 0) w2 = -w2;
+                p2 = is.p + w2;
+            }
+            V3 origin = Oracle::offset_ray_origin(is.p, is.perr, is.n, p2 - is.p);
+            Ray to{origin, p2 - is.p, 1 - ShadowEpsilon};  // Interaction::SpawnRayTo(Point3f), interaction.h:68-72
+            ++tested;
+            if (orc.prim_intersects(to, is.prim)) ++bad;
+        }
+    }
+    if (stats) {
+        stats[0] = hits;
+        stats[1] = tested;
+    }
+    return bad;
+}

@@ -20,8 +20,8 @@ namespace iile {
 namespace {
 
 struct Token {
-    enum Kind { Word, String, LBracket, RBracket, End } kind = End;
-    std::string text;
+    enum Kind { Word, String, LBracket, RBracket, End, Error } kind = End;
+    std::string text;  // Error: the tokenizer's message ("premature EOF", "unterminated string")
 };
 
 class Lexer {
@@ -51,11 +51,47 @@ class Lexer {
         if (pos_ >= buf_.size()) return t;
         char ch = buf_[pos_];
         if (ch == '"') {
-            size_t e = buf_.find('"', pos_ + 1);
-            if (e == std::string::npos) e = buf_.size();
+            // scan to the closing quote (parser.cpp:196-232): a newline ends the string in error,
+            // a backslash takes the next character with it (decodeEscaped, parser.cpp:67-93)
             t.kind = Token::String;
-            t.text = buf_.substr(pos_ + 1, e - pos_ - 1);
-            pos_ = e + 1;
+            ++pos_;
+            for (;;) {
+                if (pos_ >= buf_.size()) {
+                    t.kind = Token::Error;
+                    t.text = "premature EOF";
+                    return t;
+                }
+                char c = buf_[pos_++];
+                if (c == '"') break;
+                if (c == '\n') {
+                    t.kind = Token::Error;
+                    t.text = "unterminated string";
+                    return t;
+                }
+                if (c == '\\') {
+                    if (pos_ >= buf_.size()) {
+                        t.kind = Token::Error;
+                        t.text = "premature EOF";
+                        return t;
+                    }
+                    const char e = buf_[pos_++];
+                    switch (e) {
+                    case 'b': c = '\b'; break;
+                    case 'f': c = '\f'; break;
+                    case 'n': c = '\n'; break;
+                    case 'r': c = '\r'; break;
+                    case 't': c = '\t'; break;
+                    case '\\': c = '\\'; break;
+                    case '\'': c = '\''; break;
+                    case '"': c = '"'; break;
+                    default:
+                        t.kind = Token::Error;
+                        t.text = std::string("unexpected escaped character \"") + e + "\"";
+                        return t;
+                    }
+                }
+                t.text.push_back(c);
+            }
         } else if (ch == '[') {
             t.kind = Token::LBracket;
             ++pos_;
@@ -170,9 +206,12 @@ class Loader {
     int default_material_ = -1;
 
     bool fail(const std::string &m) {
-        if (err_) *err_ = m;
+        // a tokenizer error ends the token stream; whatever the parser then complains about,
+        // the tokenizer's message is the cause (parser.cpp:199-212)
+        if (err_) *err_ = lex_error_.empty() ? m : lex_error_;
         return false;
     }
+    std::string lex_error_;
 
     bool parse_file(const std::string &path) {
         Lexer lex;
@@ -184,7 +223,12 @@ class Loader {
                 have_pending = false;
                 return pending;
             }
-            return lex.next();
+            Token t = lex.next();
+            if (t.kind == Token::Error) {
+                if (lex_error_.empty()) lex_error_ = t.text;
+                t.kind = Token::End;
+            }
+            return t;
         };
         auto unget = [&](const Token &t) {
             pending = t;
@@ -245,7 +289,10 @@ class Loader {
 
         while (true) {
             Token t = next();
-            if (t.kind == Token::End) break;
+            if (t.kind == Token::End) {
+                if (!lex_error_.empty()) return fail(lex_error_);
+                break;
+            }
             if (t.kind != Token::Word) return fail("unexpected token \"" + t.text + "\"");
             const std::string &d = t.text;
             float f[16];

@@ -43,6 +43,12 @@ class Oracle:
         lib = ctypes.CDLL(LIB)
         lib.oracle_render.argtypes = [c_vp] + [ctypes.c_int] * 6 + [c_vp, ctypes.POINTER(OracleStats)]
         lib.oracle_halton_index.restype = ctypes.c_int64
+        lib.oracle_check_next_float.restype = ctypes.c_int64
+        lib.oracle_check_next_float.argtypes = [ctypes.c_int, ctypes.c_uint64]
+        lib.oracle_check_efloat.restype = ctypes.c_int64
+        lib.oracle_check_efloat.argtypes = [ctypes.c_int, ctypes.c_uint64]
+        lib.oracle_check_reintersect.restype = ctypes.c_int64
+        lib.oracle_check_reintersect.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_int, ctypes.c_uint64, c_vp]
         lib.oracle_halton_index.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64]
         lib.oracle_halton_sample.restype = ctypes.c_float
         lib.oracle_halton_sample.argtypes = [c_vp, ctypes.c_int64, ctypes.c_int]
@@ -108,6 +114,19 @@ class Oracle:
         self.lib.oracle_intersect(scene.desc, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, prim.ctypes.data,
                                   tb.ctypes.data)
         return prim, tb
+
+    def check_next_float(self, iters=100000, seed=1):
+        return int(self.lib.oracle_check_next_float(iters, seed))
+
+    def check_efloat(self, iters=200000, seed=1):
+        return int(self.lib.oracle_check_efloat(iters, seed))
+
+    def check_reintersect(self, scene, o, d, n_out=200, seed=1):
+        o, d = _f32(o), _f32(d)
+        stats = np.zeros(2, np.int64)
+        bad = int(self.lib.oracle_check_reintersect(scene.desc, len(o), o.ctypes.data, d.ctypes.data, n_out, seed,
+                                                    stats.ctypes.data))
+        return bad, int(stats[0]), int(stats[1])
 
     def intersect_p(self, scene, o, d, tmax):
         o, d, tmax = _f32(o), _f32(d), _f32(tmax)

@@ -3,6 +3,7 @@ Halton tables, camera â€” against facts recorded from the reference (SURVEY.md Â
 import ctypes
 
 import numpy as np
+import pytest
 
 
 class BvhNode(ctypes.Structure):
@@ -132,3 +133,25 @@ def test_boxroom_scene_loads_and_oracle_renders_it(binding, oracle, tmp_path):
     film, st = oracle.render(scene)
     assert st["camera_rays"] == 32 * 24 * 2 and np.isfinite(film).all()
     assert st["nodes_closest"] / st["regular_rays"] > 40
+
+
+def test_tokenizer_cases_of_the_reference_parser_tests(binding, tmp_path):
+    """Parser.TokenizerBasics / TokenizerErrors of src/tests/parser.cpp:37-106, through the loader:
+    no space before a quoted string, comments that contain brackets, a single unbracketed value,
+    and the two tokenizer errors with the reference's messages."""
+    head = ('Camera "perspective" "float fov" [45]\nFilm "image" "integer xresolution" [8] "integer yresolution" [8]\n'
+            'Sampler "halton" "integer pixelsamples" [1]\nWorldBegin\nAreaLightSource "diffuse" "color L" [1 1 1]\n')
+
+    def load(body, end="WorldEnd\n"):
+        p = tmp_path / "t.pbrt"
+        p.write_text(head + body + end)
+        return binding.HostScene(path=str(p))
+
+    for body in ('Shape "sphere" "float radius" [1]\n', 'Shape "sphere"\n"float radius" [1]\n',
+                 'Shape"sphere" # foo bar [\n"float radius" 1\n'):
+        assert load(body).info["n_spheres"] == 1
+    for body, msg in (('Shape"sphere"\t\t # foo bar\n"float radius', "premature EOF"),
+                      ('Shape"sphere"\t\t # foo bar\n"float radius\\', "premature EOF"),
+                      ('Shape"sphere"\t\t # foo bar\n"float radius\n" 5\n', "unterminated string")):
+        with pytest.raises(RuntimeError, match=msg):
+            load(body, end="")

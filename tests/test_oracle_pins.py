@@ -227,3 +227,28 @@ def test_uber_material_furnace_scene_matches_reference_expectation(binding, orac
     assert abs(mean - 1.0) < 0.02, mean
     # FresnelDielectric(1, 1) is 0: a path that picks the specular lobe ends there
     assert st["path_length"][0] > 10000
+
+
+def test_reference_float_property_tests(oracle):
+    """FloatingPoint.NextUpDownFloat and EFloat.Add/Sub/Mul/Div of src/tests/fp_tests.cpp:29-270,
+    run against the restatement's NextFloatUp/Down and EFloat (the error-bound machinery behind
+    OffsetRayOrigin and the sphere test): no expectation may fail."""
+    assert oracle.check_next_float(200000, seed=7) == 0
+    assert oracle.check_efloat(300000, seed=11) == 0
+
+
+def test_reference_reintersect_property(oracle, scene_c1, binding):
+    """Triangle.Reintersect / FullSphere.Reintersect of src/tests/shapes.cpp:154-208, 374-436: a ray
+    spawned at a hit (SpawnRay, SpawnRayTo) must not hit the primitive it leaves — the property
+    pError / OffsetRayOrigin exist for. Checked on killeroo-simple's triangles and on its sphere."""
+    rng = np.random.default_rng(5)
+    h, w = scene_c1.film_shape
+    pf = np.stack([rng.uniform(0, w, 3000), rng.uniform(0, h, 3000)], 1).astype(np.float32)
+    o, d = oracle.camera_rays(scene_c1, pf)
+    # plus rays aimed at the emitter sphere (centre (150, 120, 20), radius 3)
+    o2 = rng.uniform(-200, 400, (500, 3)).astype(np.float32)
+    tgt = (np.array([150, 120, 20]) + rng.uniform(-2, 2, (500, 3))).astype(np.float32)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, (tgt - o2).astype(np.float32)])
+    bad, hits, tested = oracle.check_reintersect(scene_c1, o, d, n_out=200, seed=3)
+    assert hits > 1500 and tested == hits * 400
+    assert bad == 0, f"{bad} of {tested} spawned rays re-hit their own primitive"
