@@ -78,6 +78,11 @@ void oracle_bsdf_eval(const iile_scene_desc *scene, int trig_mode, int mat, cons
                       const float *wi3, float *f3, float *pdf);
 void oracle_bsdf_sample(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3,
                         const float *u2, float *wi3, float *f3, float *pdf);
+/* n samples / pdf evaluations for one outgoing direction (chi-square test of src/tests/bsdfs.cpp) */
+void oracle_bsdf_sample_batch(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3, int n,
+                              const float *u2n, float *wi3n, float *pdfn);
+void oracle_bsdf_pdf_batch(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3, int n,
+                           const float *wi3n, float *pdfn);
 void oracle_sincos(int trig_mode, float x, float *s, float *c);
 void oracle_sincos_d(int trig_mode, double x, double *s, double *c);
 float oracle_acos(int trig_mode, float x);

@@ -1748,6 +1748,30 @@ void oracle_bsdf_sample(const iile_scene_desc *scene, int trig_mode, int mat, co
     }
     *pdf = p;
 }
+void oracle_bsdf_sample_batch(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3, int n,
+                              const float *u2n, float *wi3n, float *pdfn) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    Oracle::Bsdf b = local_bsdf(orc, scene, mat);
+    V3 wo(wo3[0], wo3[1], wo3[2]);
+    for (int i = 0; i < n; ++i) {
+        V3 wi(0, 0, 0);
+        float p = 0;
+        Rgb f = orc.bsdf_sample_f(b, wo, &wi, u2n + 2 * i, &p);
+        if (f.is_black()) p = 0;  // the reference's FrequencyTable skips black samples (bsdfs.cpp:78)
+        for (int k = 0; k < 3; ++k) wi3n[3 * i + k] = wi[k];
+        pdfn[i] = p;
+    }
+}
+void oracle_bsdf_pdf_batch(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3, int n,
+                           const float *wi3n, float *pdfn) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    Oracle::Bsdf b = local_bsdf(orc, scene, mat);
+    V3 wo(wo3[0], wo3[1], wo3[2]);
+    for (int i = 0; i < n; ++i)
+        pdfn[i] = Oracle::bsdf_pdf(b, wo, V3(wi3n[3 * i], wi3n[3 * i + 1], wi3n[3 * i + 2]));
+}
 void oracle_sincos(int trig_mode, float x, float *s, float *c) {
     Trig t{trig_mode};
     *s = t.sin_f(x);

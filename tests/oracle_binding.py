@@ -43,6 +43,8 @@ class Oracle:
         lib = ctypes.CDLL(LIB)
         lib.oracle_render.argtypes = [c_vp] + [ctypes.c_int] * 6 + [c_vp, ctypes.POINTER(OracleStats)]
         lib.oracle_halton_index.restype = ctypes.c_int64
+        lib.oracle_bsdf_sample_batch.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]
+        lib.oracle_bsdf_pdf_batch.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
         lib.oracle_check_next_float.restype = ctypes.c_int64
         lib.oracle_check_next_float.argtypes = [ctypes.c_int, ctypes.c_uint64]
         lib.oracle_check_efloat.restype = ctypes.c_int64
@@ -159,6 +161,21 @@ class Oracle:
             self.lib.oracle_bsdf_sample(scene.desc, trig_mode, mat, wo[i].ctypes.data, u[i].ctypes.data,
                                         out[i].ctypes.data, out[i, 3:].ctypes.data, out[i, 6:].ctypes.data)
         return out
+
+    def bsdf_sample_batch(self, scene, mat, wo, u, trig_mode=TRIG_LIBM):
+        wo, u = _f32(wo), _f32(u)
+        n = len(u)
+        wi, pdf = np.empty((n, 3), np.float32), np.empty(n, np.float32)
+        self.lib.oracle_bsdf_sample_batch(scene.desc, trig_mode, mat, wo.ctypes.data, n, u.ctypes.data, wi.ctypes.data,
+                                          pdf.ctypes.data)
+        return wi, pdf
+
+    def bsdf_pdf_batch(self, scene, mat, wo, wi, trig_mode=TRIG_LIBM):
+        wo, wi = _f32(wo), _f32(wi)
+        pdf = np.empty(len(wi), np.float32)
+        self.lib.oracle_bsdf_pdf_batch(scene.desc, trig_mode, mat, wo.ctypes.data, len(wi), wi.ctypes.data,
+                                       pdf.ctypes.data)
+        return pdf
 
     def sincos(self, x, trig_mode=TRIG_PORTABLE):
         x = _f32(x)

@@ -252,3 +252,63 @@ def test_reference_reintersect_property(oracle, scene_c1, binding):
     bad, hits, tested = oracle.check_reintersect(scene_c1, o, d, n_out=200, seed=3)
     assert hits > 1500 and tested == hits * 400
     assert bad == 0, f"{bad} of {tested} spawned rays re-hit their own primitive"
+
+
+@pytest.mark.parametrize("mat,label", [(0, "Lambertian"), (1, "TR_VA_0p5"), (2, "TR_VA_0p3")])
+def test_bsdf_sampling_chi_square(binding, oracle, tmp_path, mat, label):
+    """BSDFSampling.{Lambertian, TR_VA_0p5, TR_VA_0p3} of src/tests/bsdfs.cpp:372-560: for random
+    outgoing directions, the histogram of 10^6 directions drawn by BSDF::Sample_f must match the
+    integral of BSDF::Pdf over the same (theta, phi) cells — chi-square test at significance 0.01
+    with the Sidak correction for 5 runs, cells with expected frequency < 5 pooled."""
+    from scipy.stats import chi2
+    path = tmp_path / "mats.pbrt"
+    path.write_text(
+        'Camera "perspective"\nFilm "image" "integer xresolution" [4] "integer yresolution" [4]\n'
+        'Sampler "halton" "integer pixelsamples" [1]\nWorldBegin\n'
+        'Material "matte" "color Kd" [1 1 1]\nShape "sphere"\n'
+        'Material "plastic" "color Kd" [0 0 0] "color Ks" [1 1 1] "float roughness" [.5]\nShape "sphere"\n'
+        'Material "plastic" "color Kd" [0 0 0] "color Ks" [1 1 1] "float roughness" [.3]\nShape "sphere"\n'
+        'AttributeBegin\nAreaLightSource "diffuse"\nShape "sphere"\nAttributeEnd\nWorldEnd\n')
+    scene = binding.HostScene(path=str(path))
+    theta_res, phi_res, n, runs, q = 10, 20, 1000000, 5, 24
+    rng = np.random.default_rng(100 + mat)
+    for run in range(runs):
+        # CosineSampleHemisphere for wo (bsdfs.cpp:412-414)
+        r, ph = np.sqrt(rng.random()), 2 * np.pi * rng.random()
+        wo = np.array([r * np.cos(ph), r * np.sin(ph), np.sqrt(max(0.0, 1 - r * r))], np.float32)
+        wi, pdf = oracle.bsdf_sample_batch(scene, mat, wo, rng.random((n, 2), dtype=np.float32))
+        ok = pdf > 0
+        th = np.arccos(np.clip(wi[ok, 2], -1, 1)) * (theta_res / np.pi)
+        phi = np.arctan2(wi[ok, 1], wi[ok, 0]) * (phi_res / (2 * np.pi))
+        phi = np.where(phi < 0, phi + phi_res, phi)
+        tb = np.clip(np.floor(th).astype(int), 0, theta_res - 1)
+        pb = np.clip(np.floor(phi).astype(int), 0, phi_res - 1)
+        freq = np.bincount(tb * phi_res + pb, minlength=theta_res * phi_res).astype(np.float64)
+        # expected frequencies: n * integral of pdf * sin(theta) over each cell (midpoint rule, q x q)
+        t = (np.arange(theta_res * q) + .5) * (np.pi / (theta_res * q))
+        p = (np.arange(phi_res * q) + .5) * (2 * np.pi / (phi_res * q))
+        T, P = np.meshgrid(t, p, indexing="ij")
+        dirs = np.stack([np.sin(T) * np.cos(P), np.sin(T) * np.sin(P), np.cos(T)], -1).reshape(-1, 3)
+        dens = oracle.bsdf_pdf_batch(scene, mat, wo, dirs).astype(np.float64).reshape(T.shape) * np.sin(T)
+        cell = dens.reshape(theta_res, q, phi_res, q).sum(axis=(1, 3)) * (np.pi / (theta_res * q)) * (2 * np.pi / (phi_res * q))
+        exp = n * cell.reshape(-1)
+        # Chi2Test, bsdfs.cpp:271-367
+        order = np.argsort(exp)
+        chsq, dof, pooled_f, pooled_e = 0.0, 0, 0.0, 0.0
+        for c in order:
+            if exp[c] == 0:
+                assert freq[c] <= n * 1e-5, f"{label}: {freq[c]} samples in a cell with expected frequency 0"
+            elif exp[c] < 5 or (0 < pooled_e < 5):
+                pooled_f += freq[c]
+                pooled_e += exp[c]
+            else:
+                chsq += (freq[c] - exp[c]) ** 2 / exp[c]
+                dof += 1
+        if pooled_e > 0 or pooled_f > 0:
+            chsq += (pooled_f - pooled_e) ** 2 / pooled_e
+            dof += 1
+        dof -= 1
+        assert dof > 0
+        pval = chi2.sf(chsq, dof)
+        alpha = 1.0 - (1.0 - 0.01) ** (1.0 / runs)
+        assert pval >= alpha, f"{label} run {run}: chi2 {chsq:.1f} over {dof} dof, p = {pval:.2e} < {alpha:.2e}"
