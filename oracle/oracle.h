@@ -95,6 +95,11 @@ float oracle_acos(int trig_mode, float x);
  *   oracle_check_reintersect  Triangle.Reintersect / FullSphere.Reintersect (shapes.cpp:154-208,
  *                             :374-436): rays spawned from a hit (SpawnRay / SpawnRayTo) never hit
  *                             the primitive they leave. stats = {hits found, spawned rays tested}. */
+/* Sphere.SolidAngle (shapes.cpp:316-348): the solid angle a sphere subtends from point p, once by
+ * Shape::SolidAngle (shape.cpp:89-102: Sphere::Sample + IntersectP) and once by uniform sphere
+ * sampling (mcSolidAngle, shapes.cpp:318-329), both with Halton points (0, 1). */
+void oracle_sphere_solid_angle(const iile_scene_desc *scene, int sphere, const float *p3, int n_samples,
+                               double *by_sampling, double *by_uniform_directions);
 int64_t oracle_check_next_float(int iters, uint64_t seed);
 int64_t oracle_check_efloat(int iters, uint64_t seed);
 int64_t oracle_check_reintersect(const iile_scene_desc *scene, int n, const float *o, const float *d, int n_out,

@@ -312,3 +312,15 @@ def test_bsdf_sampling_chi_square(binding, oracle, tmp_path, mat, label):
         pval = chi2.sf(chsq, dof)
         alpha = 1.0 - (1.0 - 0.01) ** (1.0 / runs)
         assert pval >= alpha, f"{label} run {run}: chi2 {chsq:.1f} over {dof} dof, p = {pval:.2e} < {alpha:.2e}"
+
+
+def test_sphere_solid_angle_like_the_reference_test(oracle, scene_c1):
+    """Sphere.SolidAngle of src/tests/shapes.cpp:331-348 on killeroo-simple's emitter (radius 3 at
+    (150, 120, 20)): 4 pi from inside the sphere (the uniform-area branch of Sphere::Sample), and from
+    outside agreement of Shape::SolidAngle (cone sampling) with uniform-direction Monte Carlo."""
+    n = 128 * 1024
+    by_sampling, by_dirs = oracle.sphere_solid_angle(scene_c1, 0, [150.0, 120.9, 20.0], n)
+    assert abs(by_dirs - 4 * np.pi) < .01 and abs(by_sampling - 4 * np.pi) < .01
+    # outside, at the reference test's relative position ((-1.25, -1.5, 1.6) radii from the centre)
+    by_sampling, by_dirs = oracle.sphere_solid_angle(scene_c1, 0, [150 - 3.75, 120 - 4.5, 20 + 4.8], n)
+    assert abs(by_sampling - by_dirs) < .001 and by_dirs > 0.1
