@@ -50,11 +50,12 @@ typedef struct iile_sphere {
     int32_t swaps_handedness;
 } iile_sphere;
 
-enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1, IILE_MAT_UBER = 2, IILE_MAT_MIRROR = 3 };
+enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1, IILE_MAT_UBER = 2, IILE_MAT_MIRROR = 3, IILE_MAT_GLASS = 4 };
 
-/* MatteMaterial / PlasticMaterial / UberMaterial / MirrorMaterial with constant textures
- * (src/materials/matte.cpp:45-62, plastic.cpp:45-70, uber.cpp:45-100, mirror.cpp:44-55).
- * Uber: opacity 1 and Kt 0 only (no transmission), uroughness == vroughness. */
+/* MatteMaterial / PlasticMaterial / UberMaterial / MirrorMaterial / GlassMaterial with constant
+ * textures (src/materials/matte.cpp:45-62, plastic.cpp:45-70, uber.cpp:45-100, mirror.cpp:44-55,
+ * glass.cpp:45-92). Uber: opacity 1 and Kt 0 only, uroughness == vroughness. Glass: smooth only
+ * (uroughness = vroughness = 0: one FresnelSpecular lobe, as the path integrator gets it). */
 typedef struct iile_material {
     int32_t type;
     float kd[3];     /* matte, plastic, uber; 0 for mirror */
@@ -64,9 +65,10 @@ typedef struct iile_material {
     float alpha;     /* plastic, uber: RoughnessToAlpha(roughness) if remap else roughness
                         (src/core/microfacet.h:123-128) */
     int32_t remap_roughness;
-    float eta;       /* uber: index of refraction e of FresnelDielectric(1, e) */
-    float kr[3];     /* uber, mirror: specular reflectance */
-    int32_t pad;
+    float eta;       /* uber, glass: index of refraction of FresnelDielectric(1, eta) */
+    float kr[3];     /* uber, mirror, glass: specular reflectance */
+    float kt[3];     /* glass: specular transmittance */
+    int32_t pad[2];
 } iile_material;
 
 /* A light: DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75) or a PointLight

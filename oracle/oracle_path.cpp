@@ -971,6 +971,9 @@ struct Oracle {
         float micro_eta_i = 1.5f, micro_eta_t = 1.f;  // FresnelDielectric of the microfacet lobe
         bool spec_noop = true;                        // FresnelNoOp (mirror) or FresnelDielectric(1, spec_eta)
         float spec_eta = 1.f;
+        bool spec_glass = false;                      // the specular lobe is FresnelSpecular(kr, kt, 1, spec_eta)
+        Rgb kt;
+        float eta = 1.f;                              // BSDF::eta (path.cpp:152)
         int n_nonspec() const { return (has_lambert ? 1 : 0) + (has_micro ? 1 : 0); }
         V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
         V3 to_world(V3 v) const {
@@ -1015,6 +1018,19 @@ struct Oracle {
                 b.has_spec = true;
                 b.kr = kr;
                 b.spec_noop = m.type == IILE_MAT_MIRROR;
+                b.spec_eta = m.eta;
+                ++b.n_lobes;
+            }
+            if (m.type == IILE_MAT_UBER) b.eta = m.eta;  // BSDF(*si, e), uber.cpp:58
+        }
+        if (m.type == IILE_MAT_GLASS) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
+            b.eta = m.eta;
+            Rgb R = clamp0(m.kr), T = clamp0(m.kt);
+            if (!(R.is_black() && T.is_black())) {
+                b.has_spec = true;
+                b.spec_glass = true;
+                b.kr = R;
+                b.kt = T;
                 b.spec_eta = m.eta;
                 ++b.n_lobes;
             }
@@ -1172,9 +1188,10 @@ struct Oracle {
     // BSDF::Sample_f, reflection.cpp:719-784. Returns f; *pdf is left untouched
     // on the early `wo.z == 0` return exactly as in the reference.
     Rgb bsdf_sample_f(const Bsdf &b, V3 woW, V3 *wiW, const float *u, float *pdf, bool allow_specular = false,
-                      bool *sampled_specular = nullptr) const {
+                      bool *sampled_specular = nullptr, bool *sampled_transmission = nullptr) const {
         // `type` is BSDF_ALL (allow_specular) or BSDF_ALL & ~BSDF_SPECULAR
         if (sampled_specular) *sampled_specular = false;
+        if (sampled_transmission) *sampled_transmission = false;
         int matching = allow_specular ? b.n_lobes : b.n_nonspec();
         if (matching == 0) {
             *pdf = 0;
@@ -1206,6 +1223,32 @@ struct Oracle {
                 *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
                 f = micro_f(b, wo, wi);
             }
+        } else if (b.spec_glass) {  // FresnelSpecular::Sample_f, reflection.cpp:629-672 (mode == Radiance)
+            const float eta_a = 1.f, eta_b = b.spec_eta;
+            float F = fr_dielectric(wo.z, eta_a, eta_b);
+            if (ur[0] < F) {
+                wi = V3(-wo.x, -wo.y, wo.z);
+                *pdf = F;
+                f = F * b.kr / std::abs(wi.z);
+            } else {
+                bool entering = wo.z > 0;
+                float eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
+                // Refract(wo, Faceforward(Normal3f(0, 0, 1), wo), etaI / etaT, wi), reflection.h:96-108
+                V3 n = (wo.z < 0.f) ? -V3(0, 0, 1) : V3(0, 0, 1);  // -n carries negative zeros, as there
+                float eta = eta_i / eta_t;
+                float cos_i = dot(n, wo);
+                float sin2_i = std::max(0.f, 1 - cos_i * cos_i);
+                float sin2_t = eta * eta * sin2_i;
+                if (sin2_t >= 1) return Rgb(0);  // total internal reflection: `return 0`, pdf stays 0
+                float cos_t = std::sqrt(1 - sin2_t);
+                wi = eta * -wo + (eta * cos_i - cos_t) * n;
+                Rgb ft = b.kt * (1 - F);
+                ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+                *pdf = 1 - F;
+                f = ft / std::abs(wi.z);
+                if (sampled_transmission) *sampled_transmission = true;
+            }
+            if (sampled_specular) *sampled_specular = true;
         } else {  // SpecularReflection::Sample_f, reflection.cpp:136-143
             wi = V3(-wo.x, -wo.y, wo.z);
             *pdf = 1;
@@ -1215,6 +1258,7 @@ struct Oracle {
         }
         if (*pdf == 0) {
             if (sampled_specular) *sampled_specular = false;
+            if (sampled_transmission) *sampled_transmission = false;
             return Rgb(0);
         }
         *wiW = b.to_world(wi);
@@ -1455,12 +1499,16 @@ struct Oracle {
             float u[2];
             smp.get2d(u);
             pdf = 0;
-            bool sampled_specular = false;
-            Rgb f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf, true, &sampled_specular);
+            bool sampled_specular = false, sampled_transmission = false;
+            Rgb f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf, true, &sampled_specular, &sampled_transmission);
             if (f.is_black() || pdf == 0.f) break;
             beta = beta * (f * absdot(wi, is.sn) / pdf);
             if (beta.y() < 0.f || std::isnan(beta.y())) return L;
-            specular_bounce = sampled_specular;  // no specular transmission here: etaScale stays 1
+            specular_bounce = sampled_specular;
+            if (sampled_specular && sampled_transmission) {  // path.cpp:151-157
+                float eta = bsdf.eta;
+                eta_scale *= (dot(wo, is.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+            }
             ray = spawn_ray(is, wi);
             Rgb rr_beta = beta * eta_scale;
             if (rr_beta.max_component() < rr_threshold && bounces > 3) {

@@ -97,7 +97,7 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     const size_t cap = queue_capacity(n_paths, sc->n_cus);
     // per path: L, beta (float4), hindex; per queue slot: ray_o[2], ray_d[2], hits, nee[7] (float4), shade_q
     const size_t f4 = sizeof(float4);
-    size_t bytes = 2 * n * f4 + n * sizeof(uint32_t) + 12 * cap * f4 + cap * sizeof(uint32_t) + cap +
+    size_t bytes = 2 * n * f4 + 2 * n * sizeof(uint32_t) + 12 * cap * f4 + cap * sizeof(uint32_t) + cap +
                    128 * sizeof(uint32_t) + sizeof(DCounters) + 16384;
     void *blk = nullptr;
     HIP_TRY(hipMalloc(&blk, bytes));
@@ -120,6 +120,7 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     B.hits = reinterpret_cast<float4 *>(take(cap * f4));
     B.nee = reinterpret_cast<float4 *>(take(7 * cap * f4));
     B.hindex = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
+    B.eta_scale = reinterpret_cast<float *>(take(n * sizeof(float)));
     B.shade_q = reinterpret_cast<uint32_t *>(take(cap * sizeof(uint32_t)));
     B.nee_mis = reinterpret_cast<uint8_t *>(take(cap));
     B.counts = reinterpret_cast<uint32_t *>(take(128 * sizeof(uint32_t)));
@@ -277,7 +278,7 @@ int iile_device_count(void) {
 
 static_assert(kLightDiffuseArea == IILE_LIGHT_DIFFUSE_AREA && kLightPoint == IILE_LIGHT_POINT, "light type codes");
 static_assert(kMatMatte == IILE_MAT_MATTE && kMatPlastic == IILE_MAT_PLASTIC && kMatUber == IILE_MAT_UBER &&
-                  kMatMirror == IILE_MAT_MIRROR,
+                  kMatMirror == IILE_MAT_MIRROR && kMatGlass == IILE_MAT_GLASS,
               "material type codes");
 int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     if (!d || !out) return fail(IILE_ERR_ARG, "iile_scene_create: null argument");
@@ -303,7 +304,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         }
     }
     for (int i = 0; i < d->n_materials; ++i)
-        if (d->materials[i].type < IILE_MAT_MATTE || d->materials[i].type > IILE_MAT_MIRROR)
+        if (d->materials[i].type < IILE_MAT_MATTE || d->materials[i].type > IILE_MAT_GLASS)
             return fail(IILE_ERR_UNSUPPORTED, "unsupported material type");
     if (d->halton.n_dims > kMaxHaltonDims) return fail(IILE_ERR_UNSUPPORTED, "too many Halton dimensions");
     const int need_dims = 5 + 8 * d->integrator.max_depth + 1;
@@ -504,6 +505,8 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             }
             mats[i].alpha = m.alpha;
             for (int c = 0; c < 3; ++c) mats[i].kr[c] = m.kr[c];
+            for (int c = 0; c < 3; ++c) mats[i].kt[c] = m.kt[c];
+            if (m.type == IILE_MAT_GLASS) S.has_glass = 1;
             mats[i].eta = m.eta;
         }
         rc = upload(sc, mats.data(), mats.size(), &S.materials);

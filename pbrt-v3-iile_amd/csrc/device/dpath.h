@@ -880,10 +880,11 @@ DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack,
 // ===========================================================================
 struct Bsdf {
     F3 ns, ng, ss, ts;
-    F3 kd, ks, kr;
+    F3 kd, ks, kr, kt;
     float alpha, eta;
     int n_lobes;  // nBxDFs; BxDF order: Lambertian, microfacet, specular reflection
-    int mtype;    // kMat*: selects the Fresnel terms (plastic 1.5/1; uber 1/eta; mirror none)
+    int mtype;    // kMat*: selects the Fresnel terms (plastic 1.5/1; uber 1/eta; mirror none) and, for
+                  // glass, makes the specular lobe a FresnelSpecular(kr, kt, 1, eta)
     bool has_lambert, has_micro, has_spec;
 };
 DEV int n_nonspec(const Bsdf &b) { return (b.has_lambert ? 1 : 0) + (b.has_micro ? 1 : 0); }
@@ -915,10 +916,17 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
         if (b.has_micro) ++b.n_lobes;
     }
     b.kr = F3{0, 0, 0};
+    b.kt = F3{0, 0, 0};
     b.has_spec = false;
     if (m.type == kMatUber || m.type == kMatMirror) {
         b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
         b.has_spec = !is_black(b.kr);
+        if (b.has_spec) ++b.n_lobes;
+    }
+    if (m.type == kMatGlass) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
+        b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
+        b.kt = F3{clampf(m.kt[0], 0, IILE_INF), clampf(m.kt[1], 0, IILE_INF), clampf(m.kt[2], 0, IILE_INF)};
+        b.has_spec = !(is_black(b.kr) && is_black(b.kt));
         if (b.has_spec) ++b.n_lobes;
     }
     return b;
@@ -1072,9 +1080,10 @@ DEV float bsdf_pdf(const Bsdf &b, F3 woW, F3 wiW) {
 // BSDF::Sample_f, reflection.cpp:719-784. *pdf is untouched on the early
 // `wo.z == 0` return, as in the reference.
 DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *pdf, const bool allow_specular = false,
-                     bool *sampled_specular = nullptr) {
+                     bool *sampled_specular = nullptr, bool *sampled_transmission = nullptr) {
     // `type` is BSDF_ALL (allow_specular) or BSDF_ALL & ~BSDF_SPECULAR
     if (sampled_specular) *sampled_specular = false;
+    if (sampled_transmission) *sampled_transmission = false;
     const int matching = allow_specular ? b.n_lobes : n_nonspec(b);
     if (matching == 0) {
         *pdf = 0;
@@ -1109,6 +1118,33 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
             *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
             f = micro_f(b, wo, wi);
         }
+    } else if (b.mtype == kMatGlass) {  // FresnelSpecular::Sample_f, reflection.cpp:477-511 (mode == Radiance)
+        const float eta_a = 1.f, eta_b = b.eta;
+        const float F = fr_dielectric(wo.z, eta_a, eta_b);
+        if (ur0 < F) {
+            wi = F3{-wo.x, -wo.y, wo.z};
+            *pdf = F;
+            f = sdiv(F * b.kr, fabsf(wi.z));
+        } else {
+            const bool entering = wo.z > 0;
+            const float eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
+            // Refract(wo, Faceforward(Normal3f(0, 0, 1), wo), etaI / etaT, wi), reflection.h:96-108;
+            // -n carries negative zeros, as there
+            const F3 n = (wo.z < 0.f) ? -F3{0, 0, 1} : F3{0, 0, 1};
+            const float eta = eta_i / eta_t;
+            const float cos_i = dot(n, wo);
+            const float sin2_i = mx(0.f, 1 - cos_i * cos_i);
+            const float sin2_t = eta * eta * sin2_i;
+            if (sin2_t >= 1) return F3{0, 0, 0};  // total internal reflection: `return 0`, pdf stays 0
+            const float cos_t = sqrtf(1 - sin2_t);
+            wi = eta * -wo + (eta * cos_i - cos_t) * n;
+            F3 ft = b.kt * (1 - F);
+            ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+            *pdf = 1 - F;
+            f = sdiv(ft, fabsf(wi.z));
+            if (sampled_transmission) *sampled_transmission = true;
+        }
+        if (sampled_specular) *sampled_specular = true;
     } else {  // SpecularReflection::Sample_f, reflection.cpp:136-143
         wi = F3{-wo.x, -wo.y, wo.z};
         *pdf = 1;
@@ -1118,6 +1154,7 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
     }
     if (*pdf == 0) {
         if (sampled_specular) *sampled_specular = false;
+        if (sampled_transmission) *sampled_transmission = false;
         return F3{0, 0, 0};
     }
     *wiW = to_world(b, wi);

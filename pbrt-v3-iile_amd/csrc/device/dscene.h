@@ -21,14 +21,15 @@ struct DSphere {
     float radius, zmin, zmax, theta_min, theta_max, phi_max;
     int reverse_orientation, swaps_handedness;
 };
-enum { kMatMatte = 0, kMatPlastic = 1, kMatUber = 2, kMatMirror = 3 };  // = IILE_MAT_* (checked in api.hip)
+enum { kMatMatte = 0, kMatPlastic = 1, kMatUber = 2, kMatMirror = 3, kMatGlass = 4 };  // = IILE_MAT_* (checked in api.hip)
 struct DMaterial {
     int type;
     float kd[3];
     float ks[3];
     float alpha;
-    float kr[3];  // uber, mirror: specular reflectance
-    float eta;    // uber: FresnelDielectric(1, eta)
+    float kr[3];  // uber, mirror, glass: specular reflectance
+    float eta;    // uber, glass: FresnelDielectric(1, eta)
+    float kt[3];  // glass: specular transmittance
 };
 enum { kLightDiffuseArea = 0, kLightPoint = 1 };  // = IILE_LIGHT_* (checked in api.hip)
 struct DLight {
@@ -71,6 +72,7 @@ struct DScene {
     int n_perms;              // u16 entries of `perms`
     float root_box[6];        // bounds of the root node (min.xyz, max.xyz)
     int root_ref;             // >= 0: wide record; < 0: ~first primitive of a single-leaf tree
+    int has_glass;            // some material transmits: the paths' etaScale is tracked
     int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide
                               // step's skipping of intermediate nodes is exact only then
     // camera

@@ -23,6 +23,7 @@ struct PassBuffers {
     float4 *L;          // [n_paths] radiance so far (xyz)
     float4 *beta;       // [n_paths] throughput (xyz), w = bitcast sampler dimension
     uint32_t *hindex;   // [n_paths] Halton index of the sample
+    float *eta_scale;   // [n_paths] etaScale of path.cpp:81 (touched only when the scene has glass)
     float4 *ray_o[2];   // ping-pong ray queues
     float4 *ray_d[2];
     float4 *hits;       // [n_paths]

@@ -584,8 +584,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             dim += 2;
             float pdf = 0;
             F3 wi = F3{0, 0, 0};
-            bool sampled_specular = false;
-            const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf, true, &sampled_specular);
+            bool sampled_specular = false, sampled_transmission = false;
+            const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf, true, &sampled_specular, &sampled_transmission);
+            // etaScale (path.cpp:81, 151-157): a path state of its own, touched only in scenes with glass
+            float eta_scale = 1.f;
+            if (S.has_glass && bounce > 0) eta_scale = B.eta_scale[pid];
             if (!(is_black(f) || pdf == 0.f)) {
                 beta = beta * sdiv(f * absdot(wi, is.sn), pdf);
                 const float by = lum_y(beta);
@@ -595,8 +598,13 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                     next_o = offset_ray_origin(is.p, is.perr, is.n, wi);
                     next_d = wi;
                     alive = true;
-                    // Russian roulette (path.cpp:182-190), etaScale == 1
-                    const float mc = max3(beta.x, beta.y, beta.z);
+                    if (sampled_specular && sampled_transmission) {
+                        const float eta = bsdf.eta;
+                        eta_scale *= (dot(-ray_d, is.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                    }
+                    // Russian roulette on rrBeta = beta * etaScale (path.cpp:182-190)
+                    const F3 rr_beta = beta * eta_scale;
+                    const float mc = max3(rr_beta.x, rr_beta.y, rr_beta.z);
                     if (mc < S.rr_threshold && bounce > 3) {
                         const float q = mx(.05f, 1 - mc);
                         const float ur = sample_dimension(S, s_perms, hidx, dim);
@@ -608,7 +616,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                     }
                 }
             }
-            // sampler dimension | specularBounce << 16 (no specular transmission here: etaScale stays 1)
+            if (alive && S.has_glass) B.eta_scale[pid] = eta_scale;
+            // sampler dimension | specularBounce << 16
             if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim) | (sampled_specular ? 0x10000u : 0u)));
         }
         // ReportValue(pathLength, bounces): a path that ends in this iteration leaves the

@@ -519,13 +519,27 @@ class Loader {
                           0.000640711f * x * x * x * x;
             } else
                 m.alpha = m.roughness;
+        } else if (name == "glass") {  // CreateGlassMaterial, glass.cpp:94-113
+            m.type = IILE_MAT_GLASS;
+            float kr[3] = {1, 1, 1}, kt[3] = {1, 1, 1};
+            ps.rgb("Kr", kr);
+            ps.rgb("Kt", kt);
+            for (int i = 0; i < 3; ++i) {
+                m.kr[i] = kr[i];
+                m.kt[i] = kt[i];
+            }
+            m.eta = ps.find("eta") ? ps.one_float("eta", 1.5f) : ps.one_float("index", 1.5f);
+            if (ps.one_float("uroughness", 0.f) != 0.f || ps.one_float("vroughness", 0.f) != 0.f) {
+                fail("glass: rough dielectrics (uroughness / vroughness) are not supported");
+                return -1;
+            }
         } else if (name == "mirror") {  // CreateMirrorMaterial, mirror.cpp:57-63
             m.type = IILE_MAT_MIRROR;
             float kr[3] = {0.9f, 0.9f, 0.9f};
             ps.rgb("Kr", kr);
             for (int i = 0; i < 3; ++i) m.kr[i] = kr[i];
         } else {
-            fail("Material \"" + name + "\" is not supported (matte, plastic, uber, mirror)");
+            fail("Material \"" + name + "\" is not supported (matte, plastic, uber, mirror, glass)");
             return -1;
         }
         for (const char *tex : {"bumpmap"})

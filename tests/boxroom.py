@@ -87,6 +87,9 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
                 *rng.uniform(.1, .4, 3), rng.uniform(.05, .3), rng.uniform(1.2, 1.8))
         elif materials == "mixed" and b % 3 == 2:
             mat = 'Material "mirror" "color Kr" [%g %g %g]' % tuple(rng.uniform(.6, .95, 3))
+        elif materials == "glass" and b % 2 == 1:  # closed refractive blobs, one of them tinted
+            mat = 'Material "glass" "color Kr" [1 1 1] "color Kt" [%g %g %g] "float index" [%g]' % (
+                *((1, 1, 1) if b % 4 == 1 else rng.uniform(.7, 1, 3)), rng.uniform(1.3, 1.7))
         elif b % 2 == 0:
             mat = 'Material "plastic" "color Kd" [%g %g %g] "color Ks" [.4 .4 .4] "float roughness" [%g]' % (
                 *rng.uniform(.2, .7, 3), rng.uniform(.02, .3))

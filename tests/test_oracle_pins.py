@@ -324,3 +324,16 @@ def test_sphere_solid_angle_like_the_reference_test(oracle, scene_c1):
     # outside, at the reference test's relative position ((-1.25, -1.5, 1.6) radii from the centre)
     by_sampling, by_dirs = oracle.sphere_solid_angle(scene_c1, 0, [150 - 3.75, 120 - 4.5, 20 + 4.8], n)
     assert abs(by_sampling - by_dirs) < .001 and by_dirs > 0.1
+
+
+def test_glass_white_furnace(binding, oracle):
+    """No reference test covers GlassMaterial, so the restatement of FresnelSpecular / Refract / the
+    etaScale bookkeeping is held to the white-furnace property instead: inside the analytic furnace
+    (radiance 1 everywhere) a lossless glass ball must leave every pixel at 1 — the eta^2 radiance
+    scaling on entry has to cancel on exit, and Russian roulette must not see it."""
+    import os
+    scene = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_glass.pbrt"))
+    film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+    rgb = scene.film_to_rgb(film)
+    assert abs(float(rgb.mean(dtype=np.float64)) - 1.0) < 0.01
+    assert rgb.min() > 0.9 and rgb.max() < 1.1
