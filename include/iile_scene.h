@@ -71,16 +71,22 @@ typedef struct iile_material {
     int32_t pad[2];
 } iile_material;
 
-/* A light: DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75) or a PointLight
- * (src/lights/point.h:49-70). */
+/* A light: DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75) or one of the delta lights
+ * PointLight (src/lights/point.h:49-70), SpotLight (src/lights/spot.h:49-74), DistantLight
+ * (src/lights/distant.h:49-72). */
 #define IILE_LIGHT_DIFFUSE_AREA 0
 #define IILE_LIGHT_POINT 1
+#define IILE_LIGHT_SPOT 2
+#define IILE_LIGHT_DISTANT 3
 typedef struct iile_light {
-    float lemit[3];  /* area: Lemit (L * scale); point: I (I * scale) */
+    float lemit[3];  /* area: Lemit (L * scale); point, spot: I * scale; distant: L * scale */
     int32_t two_sided;
-    int32_t sphere;  /* area: index into spheres[] (only sphere emitters are supported); point: -1 */
+    int32_t sphere;  /* area: index into spheres[] (only sphere emitters are supported); else -1 */
     int32_t type;    /* IILE_LIGHT_* */
-    float pos[3];    /* point: pLight = LightToWorld(0,0,0), LightToWorld = Translate(from) * CTM */
+    float pos[3];    /* point, spot: pLight = LightToWorld(0,0,0); distant: wLight = Normalize(LightToWorld(dir)) */
+    float w2l[9];    /* spot: rows of the upper 3x3 of WorldToLight (for Falloff, spot.cpp:66-76) */
+    float cos_total_width, cos_falloff_start; /* spot */
+    float world_radius; /* distant: radius of the scene's bounding sphere (Light::Preprocess, distant.cpp:63-65) */
 } iile_light;
 
 /* PerspectiveCamera (src/cameras/perspective.cpp:50-72, src/core/camera.h:90-111). */

@@ -1380,22 +1380,51 @@ struct Oracle {
         float f = nf * fpdf, g = ng * gpdf;
         return (f * f) / (f * f + g * g);
     }
-    // EstimateDirect for a PointLight (delta position: IsDeltaLight, so no MIS weight and no
-    // BSDF-sampling half, core/integrator.cpp:150-166). PointLight::Sample_Li, lights/point.cpp:43-52.
-    Rgb estimate_direct_point(const Isect &it, const Bsdf &bsdf, const iile_light &lt) const {
+    // EstimateDirect for the delta lights (IsDeltaLight: no MIS weight, no BSDF-sampling half,
+    // core/integrator.cpp:150-166). Sample_Li of PointLight (lights/point.cpp:43-52), SpotLight
+    // (lights/spot.cpp:53-76) and DistantLight (lights/distant.cpp:50-61).
+    Rgb estimate_direct_delta(const Isect &it, const Bsdf &bsdf, const iile_light &lt) const {
         Rgb Ld(0.f);
-        const V3 pl(lt.pos[0], lt.pos[1], lt.pos[2]);
-        V3 wi = normalize(pl - it.p);
-        float light_pdf = 1.f;
-        Rgb Li = Rgb(lt.lemit[0], lt.lemit[1], lt.lemit[2]) / length_sq(pl - it.p);  // I / DistanceSquared
+        const V3 pos(lt.pos[0], lt.pos[1], lt.pos[2]);
+        const Rgb I(lt.lemit[0], lt.lemit[1], lt.lemit[2]);
+        V3 wi, target;
+        Rgb Li;
+        if (lt.type == IILE_LIGHT_DISTANT) {
+            wi = pos;  // wLight
+            target = it.p + pos * (2 * lt.world_radius);  // pOutside
+            Li = I;
+        } else {
+            wi = normalize(pos - it.p);
+            target = pos;  // pLight
+            if (lt.type == IILE_LIGHT_SPOT) {
+                // Falloff(-wi), spot.cpp:66-76
+                const V3 w = -wi;
+                V3 wl = normalize(V3(lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z,
+                                     lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
+                                     lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z));
+                float cos_theta = wl.z, falloff;
+                if (cos_theta < lt.cos_total_width)
+                    falloff = 0;
+                else if (cos_theta >= lt.cos_falloff_start)
+                    falloff = 1;
+                else {
+                    float delta = (cos_theta - lt.cos_total_width) / (lt.cos_falloff_start - lt.cos_total_width);
+                    falloff = (delta * delta) * (delta * delta);
+                }
+                Li = I * falloff / length_sq(pos - it.p);
+            } else {
+                Li = I / length_sq(pos - it.p);  // I / DistanceSquared
+            }
+        }
+        const float light_pdf = 1.f;
         if (light_pdf > 0 && !Li.is_black()) {
             Rgb f = bsdf_f(bsdf, it.wo, wi) * absdot(wi, it.sn);
             if (!f.is_black()) {
-                // VisibilityTester(ref, Interaction(pLight)): the light-side interaction has no
+                // VisibilityTester(ref, Interaction(target)): the light-side interaction has no
                 // normal and no error bounds, so its OffsetRayOrigin is the point itself
-                V3 origin = offset_ray_origin(it.p, it.perr, it.n, pl - it.p);
-                V3 target = offset_ray_origin(pl, V3(0, 0, 0), V3(0, 0, 0), origin - pl);
-                Ray sr{origin, target - origin, 1 - ShadowEpsilon};
+                V3 origin = offset_ray_origin(it.p, it.perr, it.n, target - it.p);
+                V3 tgt = offset_ray_origin(target, V3(0, 0, 0), V3(0, 0, 0), origin - target);
+                Ray sr{origin, tgt - origin, 1 - ShadowEpsilon};
                 if (intersect_p(sr)) Li = Rgb(0.f);
                 if (!Li.is_black()) Ld = Ld + f * Li / light_pdf;
             }
@@ -1405,7 +1434,7 @@ struct Oracle {
     Rgb estimate_direct(const Isect &it, const Bsdf &bsdf, const float *u_scatter, int light_index,
                         const float *u_light) const {
         const iile_light &lt = S.lights[light_index];
-        if (lt.type == IILE_LIGHT_POINT) return estimate_direct_point(it, bsdf, lt);
+        if (lt.type != IILE_LIGHT_DIFFUSE_AREA) return estimate_direct_delta(it, bsdf, lt);
         const iile_sphere &sp = S.spheres[lt.sphere];
         Rgb Ld(0.f);
         V3 wi;

@@ -276,7 +276,9 @@ int iile_device_count(void) {
     return n;
 }
 
-static_assert(kLightDiffuseArea == IILE_LIGHT_DIFFUSE_AREA && kLightPoint == IILE_LIGHT_POINT, "light type codes");
+static_assert(kLightDiffuseArea == IILE_LIGHT_DIFFUSE_AREA && kLightPoint == IILE_LIGHT_POINT &&
+                  kLightSpot == IILE_LIGHT_SPOT && kLightDistant == IILE_LIGHT_DISTANT,
+              "light type codes");
 static_assert(kMatMatte == IILE_MAT_MATTE && kMatPlastic == IILE_MAT_PLASTIC && kMatUber == IILE_MAT_UBER &&
                   kMatMirror == IILE_MAT_MIRROR && kMatGlass == IILE_MAT_GLASS,
               "material type codes");
@@ -299,7 +301,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         const iile_light &l = d->lights[i];
         if (l.type == IILE_LIGHT_DIFFUSE_AREA) {
             if (l.sphere < 0 || l.sphere >= d->n_spheres) return fail(IILE_ERR_ARG, "area light without a sphere");
-        } else if (l.type != IILE_LIGHT_POINT) {
+        } else if (l.type != IILE_LIGHT_POINT && l.type != IILE_LIGHT_SPOT && l.type != IILE_LIGHT_DISTANT) {
             return fail(IILE_ERR_UNSUPPORTED, "unsupported light type");
         }
     }
@@ -518,6 +520,10 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             lts[i].sphere = d->lights[i].sphere;
             lts[i].type = d->lights[i].type;
             for (int c = 0; c < 3; ++c) lts[i].pos[c] = d->lights[i].pos[c];
+            for (int c = 0; c < 9; ++c) lts[i].w2l[c] = d->lights[i].w2l[c];
+            lts[i].cos_total_width = d->lights[i].cos_total_width;
+            lts[i].cos_falloff_start = d->lights[i].cos_falloff_start;
+            lts[i].world_radius = d->lights[i].world_radius;
         }
         rc = upload(sc, lts.data(), lts.size(), &S.lights);
         if (rc) return bail(rc);

@@ -477,20 +477,49 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                             ++dim;
                             const int li = 0;
                             const DLight &lt = S.lights[li];
-                            if (lt.type == kLightPoint) {
-                                // EstimateDirect for a delta light (integrator.cpp:150-166): light
-                                // sample only, weight 1; PointLight::Sample_Li, lights/point.cpp:43-52
+                            if (lt.type != kLightDiffuseArea) {
+                                // EstimateDirect for a delta light (integrator.cpp:150-166): light sample
+                                // only, weight 1. Sample_Li of PointLight (lights/point.cpp:43-52),
+                                // SpotLight (spot.cpp:53-76), DistantLight (distant.cpp:50-61).
                                 dim += 4;  // uLight and uScattering are drawn all the same
-                                const F3 pl = F3{lt.pos[0], lt.pos[1], lt.pos[2]};
-                                const F3 wi = normalize(pl - is.p);
-                                const F3 Li = sdiv(F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]}, length_sq(pl - is.p));
+                                const F3 pos = F3{lt.pos[0], lt.pos[1], lt.pos[2]};
+                                const F3 I = F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]};
+                                F3 wi, target, Li;
+                                if (lt.type == kLightDistant) {
+                                    wi = pos;                                     // wLight
+                                    target = is.p + pos * (2 * lt.world_radius);  // pOutside
+                                    Li = I;
+                                } else {
+                                    wi = normalize(pos - is.p);
+                                    target = pos;  // pLight
+                                    if (lt.type == kLightSpot) {  // Falloff(-wi)
+                                        const F3 w = -wi;
+                                        const F3 wl = normalize(F3{lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z,
+                                                                   lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
+                                                                   lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z});
+                                        const float cos_theta = wl.z;
+                                        float falloff;
+                                        if (cos_theta < lt.cos_total_width)
+                                            falloff = 0;
+                                        else if (cos_theta >= lt.cos_falloff_start)
+                                            falloff = 1;
+                                        else {
+                                            const float delta =
+                                                (cos_theta - lt.cos_total_width) / (lt.cos_falloff_start - lt.cos_total_width);
+                                            falloff = (delta * delta) * (delta * delta);
+                                        }
+                                        Li = sdiv(I * falloff, length_sq(pos - is.p));
+                                    } else {
+                                        Li = sdiv(I, length_sq(pos - is.p));
+                                    }
+                                }
                                 if (!is_black(Li)) {
                                     const F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
                                     if (!is_black(f)) {
-                                        // the light-side Interaction has neither normal nor error
-                                        // bounds: its OffsetRayOrigin is pLight itself (interaction.h:73-78)
-                                        so = offset_ray_origin(is.p, is.perr, is.n, pl - is.p);
-                                        sd = pl - so;
+                                        // the light-side Interaction has neither normal nor error bounds:
+                                        // its OffsetRayOrigin is the point itself (interaction.h:73-78)
+                                        so = offset_ray_origin(is.p, is.perr, is.n, target - is.p);
+                                        sd = target - so;
                                         A = sdiv(f * Li, 1.f);
                                         nee_flags |= NEE_HAS_SHADOW;
                                     }

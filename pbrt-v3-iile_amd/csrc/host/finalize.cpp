@@ -106,6 +106,17 @@ bool finalize_scene(HostScene *s, std::string *err) {
     d.spheres = s->spheres.data();
     d.n_materials = int(s->materials.size());
     d.materials = s->materials.data();
+    // Light::Preprocess of DistantLight (distant.cpp:63-65): Scene::WorldBound().BoundingSphere
+    // (scene.h:56, geometry.h:808-811); the world bound is the BVH root's
+    if (!s->nodes.empty()) {
+        const iile_bvh_node &root = s->nodes[0];
+        const V3 pmin(root.bmin[0], root.bmin[1], root.bmin[2]), pmax(root.bmax[0], root.bmax[1], root.bmax[2]);
+        const V3 c = div(pmin + pmax, 2.f);
+        const bool inside = c.x >= pmin.x && c.x <= pmax.x && c.y >= pmin.y && c.y <= pmax.y && c.z >= pmin.z && c.z <= pmax.z;
+        const float radius = inside ? length(c - pmax) : 0.f;
+        for (iile_light &lt : s->lights)
+            if (lt.type == IILE_LIGHT_DISTANT) lt.world_radius = radius;
+    }
     d.n_lights = int(s->lights.size());
     d.lights = s->lights.data();
 

@@ -438,27 +438,65 @@ class Loader {
             gs_.has_area_light = true;
             gs_.area_light_params = ps;
         } else if (d == "LightSource") {  // api.cpp:1344-1358 (pbrtLightSource), MakeLight api.cpp:770-806
-            if (name != "point")
-                return fail("LightSource \"" + name + "\" is not supported (point lights and area lights on spheres only)");
-            // CreatePointLight, lights/point.cpp:80-88
+            if (name != "point" && name != "spot" && name != "distant")
+                return fail("LightSource \"" + name + "\" is not supported (point, spot, distant; area lights on spheres)");
             float I[3] = {1, 1, 1}, sc[3] = {1, 1, 1};
-            ps.rgb("I", I);
+            ps.rgb(name == "distant" ? "L" : "I", I);
             ps.rgb("scale", sc);
-            V3 from(0, 0, 0);
-            if (const Param *pp = ps.find("from")) {
-                if (pp->type != "point" || pp->nums.size() != 3) return fail("point light: bad \"from\"");
-                from = V3(float(pp->nums[0]), float(pp->nums[1]), float(pp->nums[2]));
-            }
-            const Xform l2w = xf_translate(from) * ctm_;
-            const V3 pl = l2w.point(V3(0, 0, 0));
+            auto point_param = [&](const char *pname, V3 def, V3 *out) -> bool {
+                *out = def;
+                if (const Param *pp = ps.find(pname)) {
+                    if (pp->type != "point" || pp->nums.size() != 3) return false;
+                    *out = V3(float(pp->nums[0]), float(pp->nums[1]), float(pp->nums[2]));
+                }
+                return true;
+            };
+            V3 from, to;
+            if (!point_param("from", V3(0, 0, 0), &from) || !point_param("to", V3(0, 0, 1), &to))
+                return fail(name + " light: bad \"from\" / \"to\"");
             iile_light lt;
             std::memset(&lt, 0, sizeof(lt));
             for (int i = 0; i < 3; ++i) lt.lemit[i] = I[i] * sc[i];
             lt.sphere = -1;
-            lt.type = IILE_LIGHT_POINT;
-            lt.pos[0] = pl.x;
-            lt.pos[1] = pl.y;
-            lt.pos[2] = pl.z;
+            if (name == "point") {  // CreatePointLight, lights/point.cpp:80-88
+                const Xform l2w = xf_translate(from) * ctm_;
+                const V3 pl = l2w.point(V3(0, 0, 0));
+                lt.type = IILE_LIGHT_POINT;
+                lt.pos[0] = pl.x;
+                lt.pos[1] = pl.y;
+                lt.pos[2] = pl.z;
+            } else if (name == "spot") {  // CreateSpotLight, lights/spot.cpp:104-124
+                const float coneangle = ps.one_float("coneangle", 30.f), conedelta = ps.one_float("conedeltaangle", 5.f);
+                const V3 dir = normalize(to - from);
+                V3 du, dv;  // CoordinateSystem, geometry.h:1020-1028
+                if (std::abs(dir.x) > std::abs(dir.y))
+                    du = div(V3(-dir.z, 0, dir.x), std::sqrt(dir.x * dir.x + dir.z * dir.z));
+                else
+                    du = div(V3(0, dir.z, -dir.y), std::sqrt(dir.y * dir.y + dir.z * dir.z));
+                dv = cross(dir, du);
+                Mat4 m;
+                const float rows[4][4] = {{du.x, du.y, du.z, 0}, {dv.x, dv.y, dv.z, 0}, {dir.x, dir.y, dir.z, 0}, {0, 0, 0, 1}};
+                for (int r = 0; r < 4; ++r)
+                    for (int c = 0; c < 4; ++c) m.m[r][c] = rows[r][c];
+                const Xform dir_to_z(m);
+                const Xform l2w = ctm_ * xf_translate(from) * inverse(dir_to_z);
+                const V3 pl = l2w.point(V3(0, 0, 0));
+                lt.type = IILE_LIGHT_SPOT;
+                lt.pos[0] = pl.x;
+                lt.pos[1] = pl.y;
+                lt.pos[2] = pl.z;
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) lt.w2l[3 * r + c] = l2w.inv.m[r][c];  // WorldToLight = Inverse(LightToWorld)
+                lt.cos_total_width = std::cos(radians(coneangle));                   // SpotLight ctor, spot.cpp:43-51
+                lt.cos_falloff_start = std::cos(radians(coneangle - conedelta));
+            } else {  // CreateDistantLight, lights/distant.cpp:94-102; ctor :43-48
+                const V3 w = normalize(ctm_.vector(from - to));
+                lt.type = IILE_LIGHT_DISTANT;
+                lt.pos[0] = w.x;
+                lt.pos[1] = w.y;
+                lt.pos[2] = w.z;
+                // world_radius is set once the scene bounds are known (finalize_scene)
+            }
             scene_->lights.push_back(lt);
         } else if (d == "Shape") {
             return make_shape(name, ps);

@@ -61,7 +61,13 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (xres, yres),
            'Sampler "halton" "integer pixelsamples" [%d]' % spp, 'Integrator "path" "integer maxdepth" [%d]' % maxdepth,
            'WorldBegin']
-    if light == "point":  # a delta light instead of the emitting sphere (same position, similar power)
+    if light == "spot":  # a spot light from the emitter's position down into the room
+        out.append('AttributeBegin\n  Translate 1.5 -2 0\n  LightSource "spot" "color I" [300 300 300] "point from" [0 0 7.5] '
+                   '"point to" [-1.5 3 -3] "float coneangle" [40] "float conedeltaangle" [12]\nAttributeEnd')
+    elif light == "distant":  # sun through the open top (the ceiling is left out below)
+        out.append('AttributeBegin\n  Rotate 20 1 0 0\n  LightSource "distant" "color L" [3 3 2.7] "point from" [0.2 -0.3 1] '
+                   '"point to" [0 0 0]\nAttributeEnd')
+    elif light == "point":  # a delta light instead of the emitting sphere (same position, similar power)
         out.append('AttributeBegin\n  Translate 1.5 -2 0\n  LightSource "point" "color I" [68 68 68] "point from" [0 0 7.5]\n'
                    'AttributeEnd')
     else:
@@ -74,6 +80,8 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
              ((-s, -s, -3), (0, 2 * s, 0), (0, 0, 12), (.8, .3, .3)),         # left
              ((s, -s, -3), (0, 0, 12), (0, 2 * s, 0), (.3, .8, .3))]          # right
     for o, du, dv, kd in walls:
+        if light == "distant" and o[2] == 9:
+            continue  # no ceiling
         P, F = _grid_quad(o, du, dv, wall_n)
         out.append('AttributeBegin\n  Material "matte" "color Kd" [%g %g %g]\n%sAttributeEnd' % (*kd, _mesh(P, F)))
     V, F = _icosphere(ico_levels)

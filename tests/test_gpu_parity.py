@@ -323,18 +323,25 @@ def test_boxroom_deep_bvh_bitwise(binding, oracle, tmp_path):
 
 
 def test_point_light_scenes_bitwise(binding, oracle, tmp_path):
-    """PointLight (first step): the reference's analytic point-light furnace
-    scene and the synthetic box room lit by a point light, both bitwise equal to the oracle."""
+    """Delta lights (first step): the reference's analytic point-light furnace
+    scene and the synthetic box room lit by a point, a spot and a distant light, all bitwise
+    equal to the oracle. (Only the point light has a test in the reference.)"""
     import os
     import boxroom
     furnace = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_point.pbrt"))
     path = tmp_path / "boxroom_point.pbrt"
     path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="point"))
     room = binding.HostScene(path=str(path))
-    for name, scene in (("furnace", furnace), ("boxroom", room)):
+    scenes = [("furnace", furnace), ("boxroom", room)]
+    for kind in ("spot", "distant"):
+        p2 = tmp_path / f"boxroom_{kind}.pbrt"
+        p2.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light=kind))
+        scenes.append((f"boxroom {kind}", binding.HostScene(path=str(p2))))
+    for name, scene in scenes:
         gpu = binding.GpuScene(scene)
         film, st = gpu.render(collect_stats=True)
         ref, ost = oracle.render(scene)
+        assert float(scene.film_to_rgb(ref).mean()) > 1e-3, f"{name}: the light reaches nothing"
         assert_bitwise(film, ref, f"{name} (point light) film")
         assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
         assert st["path_length"] == ost["path_length"] and st["zero_radiance"] == ost["zero_radiance"]
