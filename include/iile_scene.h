@@ -74,6 +74,7 @@ typedef struct iile_material {
 /* A light: DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75) or one of the delta lights
  * PointLight (src/lights/point.h:49-70), SpotLight (src/lights/spot.h:49-74), DistantLight
  * (src/lights/distant.h:49-72). */
+#define IILE_MAX_LIGHTS 8 /* the device keeps per-voxel light distributions for this many */
 #define IILE_LIGHT_DIFFUSE_AREA 0
 #define IILE_LIGHT_POINT 1
 #define IILE_LIGHT_SPOT 2

@@ -39,6 +39,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -1380,6 +1381,129 @@ struct Oracle {
         float f = nf * fpdf, g = ng * gpdf;
         return (f * f) / (f * f + g * g);
     }
+    // ------------------------------------------------------------------------
+    // SpatialLightDistribution (core/lightdistrib.cpp:91-299), the path integrator's default
+    // "spatial" strategy whenever the scene has more than one light (lightdistrib.cpp:47-66).
+    // The reference fills a hash table lazily; a voxel's distribution is a pure function of its
+    // index, so a per-instance cache gives the same values.
+    struct LightDist {  // Distribution1D, sampling.h:55-109
+        int n = 0;
+        float func[IILE_MAX_LIGHTS], cdf[IILE_MAX_LIGHTS + 1], func_int = 0;
+    };
+    mutable std::unordered_map<uint64_t, LightDist> light_cache;
+    void light_grid(V3 *pmin, V3 *pmax, int nv[3]) const {  // lightdistrib.cpp:91-110, maxVoxels = 64
+        const iile_bvh_node &root = S.nodes[0];
+        *pmin = V3(root.bmin[0], root.bmin[1], root.bmin[2]);
+        *pmax = V3(root.bmax[0], root.bmax[1], root.bmax[2]);
+        V3 diag = *pmax - *pmin;
+        int me = (diag.x > diag.y && diag.x > diag.z) ? 0 : (diag.y > diag.z ? 1 : 2);  // MaximumExtent, geometry.h:771-779
+        float bmax = diag[me];
+        for (int i = 0; i < 3; ++i) nv[i] = std::max(1, int(std::round(diag[i] / bmax * 64)));
+    }
+    // Light::Sample_Li at an Interaction without normal or error bounds; returns Li, sets *pdf
+    Rgb sample_li_plain(const iile_light &lt, V3 po, const float *u, float *pdf) const {
+        const V3 pos(lt.pos[0], lt.pos[1], lt.pos[2]);
+        const Rgb I(lt.lemit[0], lt.lemit[1], lt.lemit[2]);
+        *pdf = 1;
+        if (lt.type == IILE_LIGHT_DISTANT) return I;
+        if (lt.type == IILE_LIGHT_POINT) return I / length_sq(pos - po);
+        if (lt.type == IILE_LIGHT_SPOT) {
+            const V3 w = -normalize(pos - po);
+            V3 wl = normalize(V3(lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z,
+                                 lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
+                                 lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z));
+            float cos_theta = wl.z, falloff;
+            if (cos_theta < lt.cos_total_width)
+                falloff = 0;
+            else if (cos_theta >= lt.cos_falloff_start)
+                falloff = 1;
+            else {
+                float delta = (cos_theta - lt.cos_total_width) / (lt.cos_falloff_start - lt.cos_total_width);
+                falloff = (delta * delta) * (delta * delta);
+            }
+            return I * falloff / length_sq(pos - po);
+        }
+        // DiffuseAreaLight::Sample_Li, lights/diffuse.cpp:68-81
+        Isect ref;
+        ref.p = po;
+        ref.perr = V3(0, 0, 0);
+        ref.n = V3(0, 0, 0);
+        LightSample ps = sphere_sample(S.spheres[lt.sphere], ref, u, pdf);
+        if (*pdf == 0 || length_sq(ps.p - po) == 0) {
+            *pdf = 0;
+            return Rgb(0.f);
+        }
+        V3 wi = normalize(ps.p - po);
+        return light_L(lt, ps.n, -wi);
+    }
+    LightDist compute_light_distribution(const int pi[3]) const {  // lightdistrib.cpp:228-299
+        V3 bmin, bmax;
+        int nv[3];
+        light_grid(&bmin, &bmax, nv);
+        auto lerp = [](float t, float a, float b) { return (1 - t) * a + t * b; };  // pbrt.h:414
+        V3 p0(float(pi[0]) / float(nv[0]), float(pi[1]) / float(nv[1]), float(pi[2]) / float(nv[2]));
+        V3 p1(float(pi[0] + 1) / float(nv[0]), float(pi[1] + 1) / float(nv[1]), float(pi[2] + 1) / float(nv[2]));
+        V3 vmin(lerp(p0.x, bmin.x, bmax.x), lerp(p0.y, bmin.y, bmax.y), lerp(p0.z, bmin.z, bmax.z));
+        V3 vmax(lerp(p1.x, bmin.x, bmax.x), lerp(p1.y, bmin.y, bmax.y), lerp(p1.z, bmin.z, bmax.z));
+        const int n_samples = 128, n = S.n_lights;
+        float contrib[IILE_MAX_LIGHTS] = {0};
+        for (int i = 0; i < n_samples; ++i) {
+            V3 t(oracle_radical_inverse(0, i), oracle_radical_inverse(1, i), oracle_radical_inverse(2, i));
+            V3 po(lerp(t.x, vmin.x, vmax.x), lerp(t.y, vmin.y, vmax.y), lerp(t.z, vmin.z, vmax.z));
+            float u[2] = {oracle_radical_inverse(3, i), oracle_radical_inverse(4, i)};
+            for (int j = 0; j < n; ++j) {
+                float pdf;
+                Rgb Li = sample_li_plain(S.lights[j], po, u, &pdf);
+                if (pdf > 0) contrib[j] += Li.y() / pdf;
+            }
+        }
+        float sum = 0;  // std::accumulate(..., Float(0))
+        for (int j = 0; j < n; ++j) sum = sum + contrib[j];
+        float avg = sum / (n_samples * n);
+        float min_contrib = (avg > 0) ? float(.001 * avg) : 1.f;
+        LightDist d;
+        d.n = n;
+        for (int j = 0; j < n; ++j) d.func[j] = std::max(contrib[j], min_contrib);
+        d.cdf[0] = 0;
+        for (int i = 1; i < n + 1; ++i) d.cdf[i] = d.cdf[i - 1] + d.func[i - 1] / n;
+        d.func_int = d.cdf[n];
+        if (d.func_int == 0)
+            for (int i = 1; i < n + 1; ++i) d.cdf[i] = float(i) / float(n);
+        else
+            for (int i = 1; i < n + 1; ++i) d.cdf[i] /= d.func_int;
+        return d;
+    }
+    const LightDist &light_distribution(V3 p) const {  // SpatialLightDistribution::Lookup, lightdistrib.cpp:134-226
+        V3 bmin, bmax;
+        int nv[3];
+        light_grid(&bmin, &bmax, nv);
+        V3 o = p - bmin;  // Bounds3::Offset, geometry.h:800-806
+        if (bmax.x > bmin.x) o.x /= bmax.x - bmin.x;
+        if (bmax.y > bmin.y) o.y /= bmax.y - bmin.y;
+        if (bmax.z > bmin.z) o.z /= bmax.z - bmin.z;
+        int pi[3];
+        for (int i = 0; i < 3; ++i) pi[i] = std::min(std::max(int(o[i] * nv[i]), 0), nv[i] - 1);
+        uint64_t key = (uint64_t(pi[0]) << 40) | (uint64_t(pi[1]) << 20) | uint64_t(pi[2]);
+        auto it = light_cache.find(key);
+        if (it == light_cache.end()) it = light_cache.emplace(key, compute_light_distribution(pi)).first;
+        return it->second;
+    }
+    // Distribution1D::SampleDiscrete, sampling.h:90-100 with FindInterval, pbrt.h:399-412
+    static int sample_discrete(const LightDist &d, float u, float *pdf) {
+        int size = d.n + 1, first = 0, len = size;
+        while (len > 0) {
+            int half = len >> 1, middle = first + half;
+            if (d.cdf[middle] <= u) {
+                first = middle + 1;
+                len -= half + 1;
+            } else
+                len = half;
+        }
+        int offset = std::min(std::max(first - 1, 0), size - 2);
+        *pdf = (d.func_int > 0) ? d.func[offset] / (d.func_int * d.n) : 0;
+        return offset;
+    }
+
     // EstimateDirect for the delta lights (IsDeltaLight: no MIS weight, no BSDF-sampling half,
     // core/integrator.cpp:150-166). Sample_Li of PointLight (lights/point.cpp:43-52), SpotLight
     // (lights/spot.cpp:53-76) and DistantLight (lights/distant.cpp:50-61).
@@ -1507,17 +1631,25 @@ struct Oracle {
             if (bsdf.n_nonspec() > 0) {  // NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0, path.cpp:118
                 ++ctr->nee_evals;
                 Rgb Ld_in(0.f);
-                if (S.n_lights > 0) {
-                    int n_lights = S.n_lights;
-                    // Distribution1D::SampleDiscrete over a constant function of n_lights
-                    // entries (sampling.h:90-100); pdf = 1/n
-                    float ul = smp.get1d();
-                    int light_num = std::min(int(ul * n_lights), n_lights - 1);
-                    float light_pdf = 1.f / n_lights;
+                if (S.n_lights == 1) {
+                    // UniformLightDistribution over one light (lightdistrib.cpp:50): SampleDiscrete
+                    // returns light 0 with pdf 1 and still consumes a 1D sample (integrator.cpp:95)
+                    smp.get1d();
                     float u_light[2], u_scatter[2];
                     smp.get2d(u_light);
                     smp.get2d(u_scatter);
-                    Ld_in = estimate_direct(is, bsdf, u_scatter, light_num, u_light) / light_pdf;
+                    Ld_in = estimate_direct(is, bsdf, u_scatter, 0, u_light) / 1.f;
+                } else if (S.n_lights > 1) {
+                    // UniformSampleOneLight with the spatial distribution (integrator.cpp:85-106)
+                    const LightDist &dist = light_distribution(is.p);
+                    float light_pdf;
+                    int light_num = sample_discrete(dist, smp.get1d(), &light_pdf);
+                    if (light_pdf != 0) {  // `if (lightPdf == 0) return Spectrum(0.f)` before any Get2D
+                        float u_light[2], u_scatter[2];
+                        smp.get2d(u_light);
+                        smp.get2d(u_scatter);
+                        Ld_in = estimate_direct(is, bsdf, u_scatter, light_num, u_light) / light_pdf;
+                    }
                 }
                 Rgb Ld = beta * Ld_in;
                 if (Ld.is_black()) ++ctr->zero_radiance;

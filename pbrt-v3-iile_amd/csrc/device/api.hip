@@ -287,8 +287,6 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     int rc = ensure_device();
     if (rc) return rc;
     // ---- what the device path supports -------------------------------------
-    if (d->n_lights > 1)
-        return fail(IILE_ERR_UNSUPPORTED, "more than one light needs the spatial light distribution (not built)");
     if (d->n_prims >= (1 << 24)) return fail(IILE_ERR_UNSUPPORTED, "more than 2^24 primitives");
     if (d->n_spheres > kMaxSpheres || d->n_materials > kMaxMaterials || d->n_lights > kMaxLights)
         return fail(IILE_ERR_UNSUPPORTED, "too many spheres / materials / lights");
@@ -618,6 +616,51 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     }
     if (hipEventCreate(&sc->ev_begin) != hipSuccess || hipEventCreate(&sc->ev_end) != hipSuccess)
         return bail(fail(IILE_ERR_HIP, "hipEventCreate failed"));
+    // More than one light: tabulate the spatial light distribution (lightdistrib.cpp:91-299) for
+    // every voxel of its grid — up to 64 per axis, cubes along the longest one.
+    S.light_dist = nullptr;
+    S.light_nv[0] = S.light_nv[1] = S.light_nv[2] = 1;
+    if (d->n_lights > 1 && d->n_nodes > 0) {
+        const float diag[3] = {S.root_box[3] - S.root_box[0], S.root_box[4] - S.root_box[1], S.root_box[5] - S.root_box[2]};
+        const int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);  // MaximumExtent
+        const float bmax = diag[me];
+        for (int i = 0; i < 3; ++i) S.light_nv[i] = std::max(1, int(std::round(diag[i] / bmax * 64)));
+        // RadicalInverse(0..4, i), i < 128 (lowdiscrepancy.cpp:389-444): bases 2, 3, 5, 7, 11
+        std::vector<float> samples(128 * 5);
+        const int bases[5] = {2, 3, 5, 7, 11};
+        for (int i = 0; i < 128; ++i)
+            for (int b = 0; b < 5; ++b) {
+                if (b == 0) {
+                    uint64_t v = uint64_t(i), r = 0;  // ReverseBits64(a) * 0x1p-64
+                    for (int k = 0; k < 64; ++k) r |= ((v >> k) & 1ull) << (63 - k);
+                    samples[5 * i] = float(double(r) * 0x1p-64);
+                    continue;
+                }
+                const float inv_base = 1.f / float(bases[b]);
+                uint64_t a = uint64_t(i), rev = 0;
+                float inv_base_n = 1;
+                while (a) {
+                    const uint64_t next = a / uint64_t(bases[b]);
+                    rev = rev * uint64_t(bases[b]) + (a - next * uint64_t(bases[b]));
+                    inv_base_n *= inv_base;
+                    a = next;
+                }
+                samples[5 * i + b] = std::min(float(rev) * inv_base_n, 0x1.fffffep-1f);
+            }
+        const float *dsamples = nullptr;
+        rc = upload(sc, samples.data(), samples.size(), &dsamples);
+        if (rc) return bail(rc);
+        const size_t n_vox = size_t(S.light_nv[0]) * S.light_nv[1] * S.light_nv[2];
+        void *p = nullptr;
+        if (hipMalloc(&p, n_vox * kLightDistFloats * sizeof(float)) != hipSuccess)
+            return bail(fail(IILE_ERR_HIP, "hipMalloc(light distributions) failed"));
+        sc->allocs.push_back(p);
+        S.light_dist = static_cast<const float *>(p);
+        LaunchCfg cfg{sc->n_cus, nullptr, false};
+        launch_light_distributions(S, dsamples, static_cast<float *>(p), cfg);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
+            return bail(fail(IILE_ERR_HIP, "light distribution kernel failed"));
+    }
     *out = sc;
     return IILE_OK;
 }

@@ -74,6 +74,9 @@ struct DScene {
     int n_perms;              // u16 entries of `perms`
     float root_box[6];        // bounds of the root node (min.xyz, max.xyz)
     int root_ref;             // >= 0: wide record; < 0: ~first primitive of a single-leaf tree
+    // SpatialLightDistribution (n_lights > 1): per voxel {func[kMaxLights], cdf[kMaxLights + 1], funcInt}
+    const float *light_dist;
+    int light_nv[3];
     int has_glass;            // some material transmits: the paths' etaScale is tracked
     int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide
                               // step's skipping of intermediate nodes is exact only then
@@ -96,7 +99,7 @@ struct DScene {
 // ray:  ro = (o.xyz, bitcast pid)   rd = (d.xyz, tmax)
 // hit:  (bitcast prim or -1, b0 | t, b1, b2)
 // NEE entry (7 float4 planes):
-//   n0 = (shadow o.xyz, bitcast pid)      n1 = (shadow d.xyz, bitcast flags)
+//   n0 = (shadow o.xyz, light selection pdf)   n1 = (shadow d.xyz, bitcast flags)
 //   n2 = (mis o.xyz, bitcast light)       n3 = (mis d.xyz, bitcast flags)
 //   n4 = (A.xyz, bitcast flags)   n5 = (B.xyz, bitcast light)   n6 = (beta.xyz, bitcast pid)
 // (flags / light / pid are repeated so that each consumer streams only the planes it needs)

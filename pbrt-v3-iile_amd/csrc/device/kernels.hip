@@ -340,6 +340,133 @@ DEV F3 light_L(const DLight &lt, F3 n, F3 w) {
     return (lt.two_sided || dot(n, w) > 0) ? F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} : F3{0, 0, 0};
 }
 
+// ---------------------------------------------------------------------------
+// SpatialLightDistribution (core/lightdistrib.cpp:91-299): with more than one light the path
+// integrator picks the light to sample from a per-voxel distribution. The reference fills a
+// hash table lazily; a voxel's distribution is a pure function of its index, so all of them are
+// tabulated once at scene creation (k_light_distributions) and looked up densely.
+constexpr int kLightDistStride = 2 * kMaxLights + 2;  // func[kMaxLights], cdf[kMaxLights + 1], funcInt
+// Light::Sample_Li at an Interaction without normal or error bounds (lightdistrib.cpp:258-262)
+DEV F3 sample_li_plain(const DScene &S, const DLight &lt, F3 po, float u0, float u1, float *pdf) {
+    const F3 pos = F3{lt.pos[0], lt.pos[1], lt.pos[2]};
+    const F3 I = F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]};
+    *pdf = 1;
+    if (lt.type == kLightDistant) return I;
+    if (lt.type == kLightPoint) return sdiv(I, length_sq(pos - po));
+    if (lt.type == kLightSpot) {
+        const F3 w = -normalize(pos - po);
+        const F3 wl = normalize(F3{lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z,
+                                   lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
+                                   lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z});
+        const float cos_theta = wl.z;
+        float falloff;
+        if (cos_theta < lt.cos_total_width)
+            falloff = 0;
+        else if (cos_theta >= lt.cos_falloff_start)
+            falloff = 1;
+        else {
+            const float delta = (cos_theta - lt.cos_total_width) / (lt.cos_falloff_start - lt.cos_total_width);
+            falloff = (delta * delta) * (delta * delta);
+        }
+        return sdiv(I * falloff, length_sq(pos - po));
+    }
+    Isect ref;  // DiffuseAreaLight::Sample_Li, lights/diffuse.cpp:68-81
+    ref.p = po;
+    ref.perr = F3{0, 0, 0};
+    ref.n = F3{0, 0, 0};
+    const LightSample ps = sphere_sample(S.spheres[lt.sphere], ref, u0, u1, pdf);
+    if (*pdf == 0 || length_sq(ps.p - po) == 0) {
+        *pdf = 0;
+        return F3{0, 0, 0};
+    }
+    const F3 wi = normalize(ps.p - po);
+    return light_L(lt, ps.n, -wi);
+}
+DEV float lerp_f(float t, float a, float b) { return (1 - t) * a + t * b; }  // pbrt.h:414
+// SpatialLightDistribution::ComputeDistribution (lightdistrib.cpp:228-299), one thread per voxel.
+// samples: RadicalInverse(0..4, i) for i < 128 (host table)
+__global__ void k_light_distributions(DScene S, const float *samples, float *out) {
+    const int nv0 = S.light_nv[0], nv1 = S.light_nv[1], nv2 = S.light_nv[2];
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv0 * nv1 * nv2) return;
+    const int pi2 = v % nv2, pi1 = (v / nv2) % nv1, pi0 = v / (nv2 * nv1);
+    const F3 bmin = F3{S.root_box[0], S.root_box[1], S.root_box[2]}, bmax = F3{S.root_box[3], S.root_box[4], S.root_box[5]};
+    const F3 p0 = F3{float(pi0) / float(nv0), float(pi1) / float(nv1), float(pi2) / float(nv2)};
+    const F3 p1 = F3{float(pi0 + 1) / float(nv0), float(pi1 + 1) / float(nv1), float(pi2 + 1) / float(nv2)};
+    const F3 vmin = F3{lerp_f(p0.x, bmin.x, bmax.x), lerp_f(p0.y, bmin.y, bmax.y), lerp_f(p0.z, bmin.z, bmax.z)};
+    const F3 vmax = F3{lerp_f(p1.x, bmin.x, bmax.x), lerp_f(p1.y, bmin.y, bmax.y), lerp_f(p1.z, bmin.z, bmax.z)};
+    const int n = S.n_lights;
+    float contrib[kMaxLights];
+#pragma unroll
+    for (int j = 0; j < kMaxLights; ++j) contrib[j] = 0;
+    for (int i = 0; i < 128; ++i) {
+        const float *t = samples + 5 * i;
+        const F3 po = F3{lerp_f(t[0], vmin.x, vmax.x), lerp_f(t[1], vmin.y, vmax.y), lerp_f(t[2], vmin.z, vmax.z)};
+#pragma unroll
+        for (int j = 0; j < kMaxLights; ++j) {
+            if (j < n) {
+                float pdf;
+                const F3 Li = sample_li_plain(S, S.lights[j], po, t[3], t[4], &pdf);
+                if (pdf > 0) contrib[j] += lum_y(Li) / pdf;
+            }
+        }
+    }
+    float sum = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxLights; ++j)
+        if (j < n) sum = sum + contrib[j];
+    const float avg = sum / float(128 * n);
+    const float min_contrib = (avg > 0) ? float(.001 * double(avg)) : 1.f;
+    float *d = out + size_t(v) * kLightDistStride;
+    float cdf = 0;
+    d[kMaxLights] = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxLights; ++j) {
+        if (j < n) {
+            const float f = mx(contrib[j], min_contrib);
+            d[j] = f;
+            cdf = cdf + f / float(n);
+            d[kMaxLights + 1 + j] = cdf;
+        }
+    }
+    const float func_int = cdf;
+    d[2 * kMaxLights + 1] = func_int;
+    for (int i = 1; i < n + 1; ++i) {
+        if (func_int == 0)
+            d[kMaxLights + i] = float(i) / float(n);
+        else
+            d[kMaxLights + i] = d[kMaxLights + i] / func_int;
+    }
+}
+// SpatialLightDistribution::Lookup + Distribution1D::SampleDiscrete (sampling.h:90-100, FindInterval pbrt.h:399-412)
+DEV int sample_light(const DScene &S, F3 p, float u, float *pdf) {
+    const F3 bmin = F3{S.root_box[0], S.root_box[1], S.root_box[2]}, bmax = F3{S.root_box[3], S.root_box[4], S.root_box[5]};
+    F3 o = p - bmin;  // Bounds3::Offset, geometry.h:800-806
+    if (bmax.x > bmin.x) o.x = o.x / (bmax.x - bmin.x);
+    if (bmax.y > bmin.y) o.y = o.y / (bmax.y - bmin.y);
+    if (bmax.z > bmin.z) o.z = o.z / (bmax.z - bmin.z);
+    int pi0 = int(o.x * float(S.light_nv[0])), pi1 = int(o.y * float(S.light_nv[1])), pi2 = int(o.z * float(S.light_nv[2]));
+    pi0 = pi0 < 0 ? 0 : (pi0 > S.light_nv[0] - 1 ? S.light_nv[0] - 1 : pi0);
+    pi1 = pi1 < 0 ? 0 : (pi1 > S.light_nv[1] - 1 ? S.light_nv[1] - 1 : pi1);
+    pi2 = pi2 < 0 ? 0 : (pi2 > S.light_nv[2] - 1 ? S.light_nv[2] - 1 : pi2);
+    const float *d = S.light_dist + size_t((pi0 * S.light_nv[1] + pi1) * S.light_nv[2] + pi2) * kLightDistStride;
+    const int n = S.n_lights, size = n + 1;
+    int first = 0, len = size;
+    while (len > 0) {
+        const int half = len >> 1, middle = first + half;
+        if (d[kMaxLights + middle] <= u) {
+            first = middle + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    int offset = first - 1;
+    offset = offset < 0 ? 0 : (offset > size - 2 ? size - 2 : offset);
+    const float func_int = d[2 * kMaxLights + 1];
+    *pdf = (func_int > 0) ? d[offset] / (func_int * float(n)) : 0.f;
+    return offset;
+}
+
 // shade: one bounce of PathIntegrator::Li (path.cpp:81-191) for every hit of the
 // queue that extend just resolved.
 // 3 waves/SIMD (<= 168 VGPRs, 6 spilled): measured 38.0 ms vs 40.2 ms at 2 waves/SIMD
@@ -413,6 +540,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             F3 so = F3{0, 0, 0}, sd = F3{0, 0, 1}, mo = F3{0, 0, 0}, md = F3{0, 0, 1};
             F3 A = F3{0, 0, 0}, Bc = F3{0, 0, 0};
             uint32_t nee_flags = 0, nee_light = 0;
+            float light_sel_pdf = 1.f;  // lightPdf of UniformSampleOneLight: Ld is divided by it
             if (valid) {
                 const float4 o4 = ro[slot], d4 = rd[slot], h4 = B.hits[slot];
                 pid = f2b(o4.w);
@@ -471,11 +599,17 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                     bsdf = make_bsdf(S.materials[material], is);
                     if (n_nonspec(bsdf) > 0) {  // NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0, path.cpp:118
                         ++n_nee;
-                        if (S.n_lights > 0) {
-                            // UniformSampleOneLight (integrator.cpp:85-106): one light, pdf 1;
-                            // SampleDiscrete still consumes a 1D sample
-                            ++dim;
-                            const int li = 0;
+                        // UniformSampleOneLight (integrator.cpp:85-106). One light: it is chosen with pdf 1
+                        // (SampleDiscrete still consumes a 1D sample). Several: through the voxel's
+                        // distribution of the spatial light distribution (lightdistrib.cpp:134-226,
+                        // tabulated at scene creation); a zero pdf returns before any further sample.
+                        int li = 0;
+                        if (S.n_lights > 1) {
+                            const float ul = sample_dimension(S, s_perms, hidx, dim);
+                            li = sample_light(S, is.p, ul, &light_sel_pdf);
+                        }
+                        if (S.n_lights > 0) ++dim;
+                        if (S.n_lights > 0 && light_sel_pdf != 0) {
                             const DLight &lt = S.lights[li];
                             if (lt.type != kLightDiffuseArea) {
                                 // EstimateDirect for a delta light (integrator.cpp:150-166): light sample
@@ -582,7 +716,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             }
             const uint32_t eslot = out_take(nee_out, &B.counts[kCntNee + bounce], emit_nee, pad_nee);
             if (emit_nee) {
-                B.nee[eslot] = make_float4(so.x, so.y, so.z, b2f(pid));
+                B.nee[eslot] = make_float4(so.x, so.y, so.z, light_sel_pdf);
                 B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
                 B.nee[2 * plane + eslot] = make_float4(mo.x, mo.y, mo.z, b2f(nee_light));
                 // flags / light / pid are repeated in the planes each consumer streams anyway
@@ -730,9 +864,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                         Ld_u = Ld_u + F3{b4.x, b4.y, b4.z};
                         Ld_o = Ld_o + F3{b4.x, b4.y, b4.z};
                     }
+                    // UniformSampleOneLight returns EstimateDirect / lightPdf (n0.w; 1 with a single light)
                     const F3 beta = F3{be.x, be.y, be.z};
-                    add_unoccluded = beta * Ld_u;
-                    add_occluded = beta * Ld_o;
+                    add_unoccluded = beta * sdiv(Ld_u, n0.w);
+                    add_occluded = beta * sdiv(Ld_o, n0.w);
                     L_old = F3{L4.x, L4.y, L4.z};
                     if (has_shadow) {
                         trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st);
@@ -740,7 +875,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                         occluded = false;
                         if (COUNT) {
                             ++n_shadow;
-                            if (B.nray_out) B.nray_out[2 * f2b(n0.w) + 1] += 1;
+                            if (B.nray_out) B.nray_out[2 * pid + 1] += 1;
                         }
                     } else {  // no light sample to test: the record is complete
                         const F3 Ln = L_old + add_occluded;
@@ -824,7 +959,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
                     active = true;
                     if (COUNT) {
                         ++n_closest;
-                        if (B.nray_out) B.nray_out[2 * f2b(B.nee[e].w)] += 1;
+                        if (B.nray_out) B.nray_out[2 * f2b(B.nee[6 * size_t(plane) + e].w)] += 1;
                     }
                 } else if (flags != kInvalid) {
                     B.nee_mis[e] = 0;  // no MIS ray: k_mis_lit has nothing to look at
@@ -1184,6 +1319,10 @@ void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_
         hipLaunchKernelGGL(k_mis<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
     else
         hipLaunchKernelGGL(k_mis<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+}
+void launch_light_distributions(const DScene &S, const float *samples, float *out, const LaunchCfg &cfg) {
+    const int n = S.light_nv[0] * S.light_nv[1] * S.light_nv[2];
+    hipLaunchKernelGGL(k_light_distributions, dim3((n + 127) / 128), dim3(128), 0, cfg.stream, S, samples, out);
 }
 void launch_mis_lit(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 8));

@@ -61,7 +61,13 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (xres, yres),
            'Sampler "halton" "integer pixelsamples" [%d]' % spp, 'Integrator "path" "integer maxdepth" [%d]' % maxdepth,
            'WorldBegin']
-    if light == "spot":  # a spot light from the emitter's position down into the room
+    if light == "multi":  # three lights of three kinds: the path integrator's spatial light distribution
+        out.append('AttributeBegin\n  Material "matte" "color Kd" [0 0 0]\n  Translate 1.5 -2 7.5\n'
+                   '  AreaLightSource "area" "color L" [40 40 40]\n  Shape "sphere" "float radius" [0.6]\nAttributeEnd')
+        out.append('LightSource "point" "color I" [30 20 10] "point from" [-6 5 2]')
+        out.append('LightSource "spot" "color I" [200 200 260] "point from" [7 -6 6] "point to" [0 2 -3] '
+                   '"float coneangle" [35] "float conedeltaangle" [10]')
+    elif light == "spot":  # a spot light from the emitter's position down into the room
         out.append('AttributeBegin\n  Translate 1.5 -2 0\n  LightSource "spot" "color I" [300 300 300] "point from" [0 0 7.5] '
                    '"point to" [-1.5 3 -3] "float coneangle" [40] "float conedeltaangle" [12]\nAttributeEnd')
     elif light == "distant":  # sun through the open top (the ceiling is left out below)

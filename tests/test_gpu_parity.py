@@ -393,3 +393,25 @@ def test_glass_scenes_bitwise(binding, oracle, tmp_path):
         assert_bitwise(plain, ref, f"{name} (glass) film, uninstrumented kernels")
         if name == "furnace":
             assert abs(float(scene.film_to_rgb(film).mean(dtype=np.float64)) - 1.0) < 0.02
+
+
+def test_several_lights_bitwise(binding, oracle, tmp_path):
+    """More than one light: the spatial light distribution (tabulated per voxel on the device at
+    scene creation) picks the light to sample. The reference's four-point-light analytic scene, and
+    the box room lit by an emitting sphere, a point light and a spot light at once."""
+    import os
+    import boxroom
+    furnace = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_4points.pbrt"))
+    path = tmp_path / "boxroom_multi.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="multi", materials="mixed"))
+    room = binding.HostScene(path=str(path))
+    assert room.info["n_lights"] == 3
+    for name, scene in (("furnace", furnace), ("boxroom", room)):
+        gpu = binding.GpuScene(scene)
+        film, st = gpu.render(collect_stats=True)
+        ref, ost = oracle.render(scene)
+        assert_bitwise(film, ref, f"{name} (several lights) film")
+        assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+        assert st["nee_evals"] == ost["nee_evals"] and st["zero_radiance"] == ost["zero_radiance"]
+        plain, _ = gpu.render()
+        assert_bitwise(plain, ref, f"{name} (several lights) film, uninstrumented kernels")

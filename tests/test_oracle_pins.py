@@ -337,3 +337,16 @@ def test_glass_white_furnace(binding, oracle):
     rgb = scene.film_to_rgb(film)
     assert abs(float(rgb.mean(dtype=np.float64)) - 1.0) < 0.01
     assert rgb.min() > 0.9 and rgb.max() < 1.1
+
+
+def test_four_point_lights_furnace_scene_matches_reference_expectation(binding, oracle):
+    """Second scene of src/tests/analytic_scenes.cpp:101-133 (four point lights of intensity pi/4 at the
+    centre of the Kd = 0.5 sphere): expected mean radiance 1.0 within 0.02. With more than one light
+    the path integrator samples lights through its SpatialLightDistribution, so this pins the
+    restatement of lightdistrib.cpp and of Distribution1D::SampleDiscrete."""
+    import os
+    scene = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_4points.pbrt"))
+    assert scene.info["n_lights"] == 4
+    film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+    assert abs(float(scene.film_to_rgb(film).mean(dtype=np.float64)) - 1.0) < 0.02
+    assert st["shadow_rays"] == st["nee_evals"]
