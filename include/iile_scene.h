@@ -79,15 +79,18 @@ typedef struct iile_material {
 #define IILE_LIGHT_POINT 1
 #define IILE_LIGHT_SPOT 2
 #define IILE_LIGHT_DISTANT 3
+#define IILE_LIGHT_AREA_TRIANGLE 4 /* DiffuseAreaLight on one triangle (every triangle of an emitting mesh is a light) */
 typedef struct iile_light {
     float lemit[3];  /* area: Lemit (L * scale); point, spot: I * scale; distant: L * scale */
     int32_t two_sided;
-    int32_t sphere;  /* area: index into spheres[] (only sphere emitters are supported); else -1 */
+    int32_t sphere;  /* area light on a sphere: index into spheres[]; else -1 */
     int32_t type;    /* IILE_LIGHT_* */
     float pos[3];    /* point, spot: pLight = LightToWorld(0,0,0); distant: wLight = Normalize(LightToWorld(dir)) */
     float w2l[9];    /* spot: rows of the upper 3x3 of WorldToLight (for Falloff, spot.cpp:66-76) */
     float cos_total_width, cos_falloff_start; /* spot */
     float world_radius; /* distant: radius of the scene's bounding sphere (Light::Preprocess, distant.cpp:63-65) */
+    int32_t prim;       /* triangle area light: its primitive, in BVH order */
+    int32_t pad;
 } iile_light;
 
 /* PerspectiveCamera (src/cameras/perspective.cpp:50-72, src/core/camera.h:90-111). */

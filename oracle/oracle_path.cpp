@@ -1382,6 +1382,63 @@ struct Oracle {
         return (f * f) / (f * f + g * g);
     }
     // ------------------------------------------------------------------------
+    // Triangle emitter (shapes/triangle.cpp:546-579) through the generic Shape::Sample(ref, u) /
+    // Shape::Pdf(ref, wi) (core/shape.cpp:56-87), and the sphere / triangle dispatch
+    float triangle_area(int prim) const {
+        const float *tp = S.tri_p + 9 * size_t(prim);
+        V3 p0(tp[0], tp[1], tp[2]), p1(tp[3], tp[4], tp[5]), p2(tp[6], tp[7], tp[8]);
+        return float(0.5 * length(cross(p1 - p0, p2 - p0)));
+    }
+    LightSample triangle_sample_area(int prim, const float *u, float *pdf) const {
+        float su0 = std::sqrt(u[0]);  // UniformSampleTriangle, sampling.cpp:154-157
+        float b0 = 1 - su0, b1 = u[1] * su0;
+        const float *tp = S.tri_p + 9 * size_t(prim);
+        V3 p0(tp[0], tp[1], tp[2]), p1(tp[3], tp[4], tp[5]), p2(tp[6], tp[7], tp[8]);
+        const uint32_t flags = S.prim_flags[prim];
+        LightSample it;
+        it.p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+        it.n = normalize(cross(p1 - p0, p2 - p0));
+        if (flags & IILE_PRIM_HAS_NORMALS) {
+            const float *nn = S.tri_n + 9 * size_t(prim);
+            V3 n0(nn[0], nn[1], nn[2]), n1(nn[3], nn[4], nn[5]), n2(nn[6], nn[7], nn[8]);
+            V3 ns = b0 * n0 + b1 * n1 + (1 - b0 - b1) * n2;
+            it.n = faceforward(it.n, ns);
+        } else if (flags & IILE_PRIM_FLIP)
+            it.n = it.n * -1.f;
+        V3 abs_sum = vabs(b0 * p0) + vabs(b1 * p1) + vabs((1 - b0 - b1) * p2);
+        it.perr = gamma_n(6) * abs_sum;
+        *pdf = 1 / triangle_area(prim);
+        return it;
+    }
+    LightSample shape_sample(const iile_light &lt, const Isect &ref, const float *u, float *pdf) const {
+        if (lt.type == IILE_LIGHT_DIFFUSE_AREA) return sphere_sample(S.spheres[lt.sphere], ref, u, pdf);
+        // Shape::Sample(ref, u, pdf), shape.cpp:56-70
+        LightSample intr = triangle_sample_area(lt.prim, u, pdf);
+        V3 wi = intr.p - ref.p;
+        if (length_sq(wi) == 0)
+            *pdf = 0;
+        else {
+            wi = normalize(wi);
+            *pdf *= length_sq(ref.p - intr.p) / absdot(intr.n, -wi);
+            if (std::isinf(*pdf)) *pdf = 0.f;
+        }
+        return intr;
+    }
+    float shape_pdf(const iile_light &lt, const Isect &ref, V3 wi) const {
+        if (lt.type == IILE_LIGHT_DIFFUSE_AREA) return sphere_pdf(S.spheres[lt.sphere], ref, wi);
+        // Shape::Pdf(ref, wi), shape.cpp:72-87: intersect the shape alone (Triangle::Intersect counts
+        // its tests and hits like any other call)
+        Ray ray = spawn_ray(ref, wi);
+        float t, b0, b1, b2;
+        if (!triangle_test(ray, lt.prim, &t, &b0, &b1, &b2)) return 0;
+        Isect li;
+        triangle_interaction(ray, lt.prim, b0, b1, b2, &li);
+        float pdf = length_sq(ref.p - li.p) / (absdot(li.n, -wi) * triangle_area(lt.prim));
+        if (std::isinf(pdf)) pdf = 0.f;
+        return pdf;
+    }
+
+    // ------------------------------------------------------------------------
     // SpatialLightDistribution (core/lightdistrib.cpp:91-299), the path integrator's default
     // "spatial" strategy whenever the scene has more than one light (lightdistrib.cpp:47-66).
     // The reference fills a hash table lazily; a voxel's distribution is a pure function of its
@@ -1428,7 +1485,7 @@ struct Oracle {
         ref.p = po;
         ref.perr = V3(0, 0, 0);
         ref.n = V3(0, 0, 0);
-        LightSample ps = sphere_sample(S.spheres[lt.sphere], ref, u, pdf);
+        LightSample ps = shape_sample(lt, ref, u, pdf);
         if (*pdf == 0 || length_sq(ps.p - po) == 0) {
             *pdf = 0;
             return Rgb(0.f);
@@ -1558,14 +1615,14 @@ struct Oracle {
     Rgb estimate_direct(const Isect &it, const Bsdf &bsdf, const float *u_scatter, int light_index,
                         const float *u_light) const {
         const iile_light &lt = S.lights[light_index];
-        if (lt.type != IILE_LIGHT_DIFFUSE_AREA) return estimate_direct_delta(it, bsdf, lt);
-        const iile_sphere &sp = S.spheres[lt.sphere];
+        if (lt.type != IILE_LIGHT_DIFFUSE_AREA && lt.type != IILE_LIGHT_AREA_TRIANGLE)
+            return estimate_direct_delta(it, bsdf, lt);
         Rgb Ld(0.f);
         V3 wi;
         float light_pdf = 0, scattering_pdf = 0;
         // DiffuseAreaLight::Sample_Li, lights/diffuse.cpp:68-81
         Rgb Li(0.f);
-        LightSample ps = sphere_sample(sp, it, u_light, &light_pdf);
+        LightSample ps = shape_sample(lt, it, u_light, &light_pdf);
         if (light_pdf == 0 || length_sq(ps.p - it.p) == 0) {
             light_pdf = 0;
             Li = Rgb(0.f);
@@ -1593,7 +1650,7 @@ struct Oracle {
             Rgb f = bsdf_sample_f(bsdf, it.wo, &wi, u_scatter, &scattering_pdf);
             f = f * absdot(wi, it.sn);
             if (!f.is_black() && scattering_pdf > 0) {
-                light_pdf = sphere_pdf(sp, it, wi);
+                light_pdf = shape_pdf(lt, it, wi);
                 if (light_pdf == 0) return Ld;
                 float weight = power_heuristic(1, scattering_pdf, 1, light_pdf);
                 Isect li;

@@ -277,7 +277,8 @@ int iile_device_count(void) {
 }
 
 static_assert(kLightDiffuseArea == IILE_LIGHT_DIFFUSE_AREA && kLightPoint == IILE_LIGHT_POINT &&
-                  kLightSpot == IILE_LIGHT_SPOT && kLightDistant == IILE_LIGHT_DISTANT,
+                  kLightSpot == IILE_LIGHT_SPOT && kLightDistant == IILE_LIGHT_DISTANT &&
+                  kLightAreaTriangle == IILE_LIGHT_AREA_TRIANGLE,
               "light type codes");
 static_assert(kMatMatte == IILE_MAT_MATTE && kMatPlastic == IILE_MAT_PLASTIC && kMatUber == IILE_MAT_UBER &&
                   kMatMirror == IILE_MAT_MIRROR && kMatGlass == IILE_MAT_GLASS,
@@ -299,6 +300,9 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         const iile_light &l = d->lights[i];
         if (l.type == IILE_LIGHT_DIFFUSE_AREA) {
             if (l.sphere < 0 || l.sphere >= d->n_spheres) return fail(IILE_ERR_ARG, "area light without a sphere");
+        } else if (l.type == IILE_LIGHT_AREA_TRIANGLE) {
+            if (l.prim < 0 || l.prim >= d->n_prims || (d->prim_flags[l.prim] & IILE_PRIM_SPHERE) || d->prim_light[l.prim] != i)
+                return fail(IILE_ERR_ARG, "triangle area light without its triangle");
         } else if (l.type != IILE_LIGHT_POINT && l.type != IILE_LIGHT_SPOT && l.type != IILE_LIGHT_DISTANT) {
             return fail(IILE_ERR_UNSUPPORTED, "unsupported light type");
         }
@@ -522,6 +526,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             lts[i].cos_total_width = d->lights[i].cos_total_width;
             lts[i].cos_falloff_start = d->lights[i].cos_falloff_start;
             lts[i].world_radius = d->lights[i].world_radius;
+            lts[i].prim = d->lights[i].prim;
         }
         rc = upload(sc, lts.data(), lts.size(), &S.lights);
         if (rc) return bail(rc);

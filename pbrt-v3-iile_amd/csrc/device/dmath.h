@@ -24,7 +24,8 @@ constexpr float kOneMinusEpsilon = 0x1.fffffep-1f;
 #define IILE_INF __builtin_huge_valf()
 // gamma(n), core/pbrt.h:286-288 — folded at compile time in float
 constexpr float gamma_c(int n) { return (n * kMachineEpsilon) / (1 - n * kMachineEpsilon); }
-constexpr float kGamma2 = gamma_c(2), kGamma3 = gamma_c(3), kGamma5 = gamma_c(5), kGamma7 = gamma_c(7);
+constexpr float kGamma2 = gamma_c(2), kGamma3 = gamma_c(3), kGamma5 = gamma_c(5), kGamma6 = gamma_c(6),
+                kGamma7 = gamma_c(7);
 constexpr float kSlabScale = 1 + 2 * gamma_c(3);  // geometry.h:1422
 
 DEV float mn(float a, float b) { return b < a ? b : a; }  // std::min

@@ -809,11 +809,7 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
             float th;
             F3 od, ph;
             const float4 d4 = *ray_d;
-#ifdef IILE_DBG_NO_SPHERE_ANY
-            if (!any_hit && sphere_test(S.spheres[S.prim_shape[prim]], t.rc.o(), F3{d4.x, d4.y, d4.z}, t.tmax, &th, &od, &ph)) {
-#else
             if (sphere_test(S.spheres[S.prim_shape[prim]], t.rc.o(), F3{d4.x, d4.y, d4.z}, t.tmax, &th, &od, &ph)) {
-#endif
                 if (any_hit) {
                     t.have = false;
                     return true;
@@ -1253,6 +1249,71 @@ DEV float sphere_pdf(const DSphere &sp, const Isect &ref, F3 wi) {
     float sin_tmax2 = sp.radius * sp.radius / length_sq(ref.p - pc);
     float cos_tmax = sqrtf(mx(0.f, 1 - sin_tmax2));
     return 1 / (2 * kPi * (1 - cos_tmax));
+}
+// Triangle emitter (shapes/triangle.cpp:546-579) through the generic Shape::Sample(ref, u) /
+// Shape::Pdf(ref, wi) (core/shape.cpp:56-87), and the sphere / triangle dispatch of an area light
+DEV float triangle_area(const DScene &S, int prim) {
+    const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1],
+                 v2 = S.tri_verts[3 * size_t(prim) + 2];
+    const F3 p0 = F3{v0.x, v0.y, v0.z}, p1 = F3{v1.x, v1.y, v1.z}, p2 = F3{v2.x, v2.y, v2.z};
+    return float(0.5 * double(length(cross(p1 - p0, p2 - p0))));
+}
+DEV LightSample triangle_sample_area(const DScene &S, int prim, float u0, float u1, float *pdf) {
+    const float su0 = sqrtf(u0);  // UniformSampleTriangle, sampling.cpp:154-157
+    const float b0 = 1 - su0, b1 = u1 * su0;
+    const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1],
+                 v2 = S.tri_verts[3 * size_t(prim) + 2];
+    const F3 p0 = F3{v0.x, v0.y, v0.z}, p1 = F3{v1.x, v1.y, v1.z}, p2 = F3{v2.x, v2.y, v2.z};
+    const uint32_t flags = f2b(v0.w);
+    LightSample it;
+    it.p = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+    it.n = normalize(cross(p1 - p0, p2 - p0));
+    if (flags & 2u) {  // the mesh has normals
+        const float4 a = S.tri_norms[3 * size_t(prim)], b = S.tri_norms[3 * size_t(prim) + 1],
+                     c = S.tri_norms[3 * size_t(prim) + 2];
+        const F3 ns = b0 * F3{a.x, a.y, a.z} + b1 * F3{b.x, b.y, b.z} + (1 - b0 - b1) * F3{c.x, c.y, c.z};
+        it.n = faceforward(it.n, ns);
+    } else if (flags & 8u)  // reverseOrientation ^ transformSwapsHandedness
+        it.n = it.n * -1.f;
+    const F3 abs_sum = vabs(b0 * p0) + vabs(b1 * p1) + vabs((1 - b0 - b1) * p2);
+    it.perr = kGamma6 * abs_sum;
+    *pdf = 1 / triangle_area(S, prim);
+    return it;
+}
+DEV LightSample shape_sample(const DScene &S, const DLight &lt, const Isect &ref, float u0, float u1, float *pdf) {
+    if (lt.type == kLightDiffuseArea) return sphere_sample(S.spheres[lt.sphere], ref, u0, u1, pdf);
+    LightSample intr = triangle_sample_area(S, lt.prim, u0, u1, pdf);  // Shape::Sample(ref, u, pdf), shape.cpp:56-70
+    F3 wi = intr.p - ref.p;
+    if (length_sq(wi) == 0)
+        *pdf = 0;
+    else {
+        wi = normalize(wi);
+        *pdf *= length_sq(ref.p - intr.p) / absdot(intr.n, -wi);
+        if (is_inf(*pdf)) *pdf = 0.f;
+    }
+    return intr;
+}
+// n_tests / n_hits: Triangle::Intersect counts its calls wherever they come from (stats of the
+// instrumented kernels)
+DEV float shape_pdf(const DScene &S, const DLight &lt, const Isect &ref, F3 wi, unsigned long long *n_tests,
+                    unsigned long long *n_hits) {
+    if (lt.type == kLightDiffuseArea) return sphere_pdf(S.spheres[lt.sphere], ref, wi);
+    // Shape::Pdf(ref, wi), shape.cpp:72-87: intersect the shape alone
+    const F3 o = offset_ray_origin(ref.p, ref.perr, ref.n, wi);
+    const RayCtx rc = make_ray_ctx(o, wi);
+    const int prim = lt.prim;
+    const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1],
+                 v2 = S.tri_verts[3 * size_t(prim) + 2];
+    const F3 p0 = F3{v0.x, v0.y, v0.z}, p1 = F3{v1.x, v1.y, v1.z}, p2 = F3{v2.x, v2.y, v2.z};
+    float t, b0, b1, b2;
+    ++*n_tests;
+    if (!triangle_test(rc, IILE_INF, p0, p1, p2, &t, &b0, &b1, &b2)) return 0;
+    ++*n_hits;
+    Isect li;
+    triangle_interaction(S, prim, f2b(v0.w), p0, p1, p2, wi, b0, b1, b2, &li);
+    float pdf = length_sq(ref.p - li.p) / (absdot(li.n, -wi) * triangle_area(S, prim));
+    if (is_inf(pdf)) pdf = 0.f;
+    return pdf;
 }
 DEV float power_heuristic(float fpdf, float gpdf) {  // sampling.h:169-172 with nf = ng = 1
     float f = 1 * fpdf, g = 1 * gpdf;

@@ -31,7 +31,7 @@ struct DMaterial {
     float eta;    // uber, glass: FresnelDielectric(1, eta)
     float kt[3];  // glass: specular transmittance
 };
-enum { kLightDiffuseArea = 0, kLightPoint = 1, kLightSpot = 2, kLightDistant = 3 };  // = IILE_LIGHT_* (checked in api.hip)
+enum { kLightDiffuseArea = 0, kLightPoint = 1, kLightSpot = 2, kLightDistant = 3, kLightAreaTriangle = 4 };  // = IILE_LIGHT_* (checked in api.hip)
 struct DLight {
     float lemit[3];  // area: Lemit; point: I
     int two_sided;
@@ -40,6 +40,7 @@ struct DLight {
     float pos[3];    // point, spot: pLight; distant: wLight
     float w2l[9];    // spot: upper 3x3 of WorldToLight, row major
     float cos_total_width, cos_falloff_start, world_radius;
+    int prim;        // triangle emitter: its primitive
 };
 // Per Halton dimension: base, float reciprocal and offset of its digit permutation.
 // The digits are peeled in double arithmetic (exact for any u32 index, see

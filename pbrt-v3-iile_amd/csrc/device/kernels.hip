@@ -374,7 +374,7 @@ DEV F3 sample_li_plain(const DScene &S, const DLight &lt, F3 po, float u0, float
     ref.p = po;
     ref.perr = F3{0, 0, 0};
     ref.n = F3{0, 0, 0};
-    const LightSample ps = sphere_sample(S.spheres[lt.sphere], ref, u0, u1, pdf);
+    const LightSample ps = shape_sample(S, lt, ref, u0, u1, pdf);
     if (*pdf == 0 || length_sq(ps.p - po) == 0) {
         *pdf = 0;
         return F3{0, 0, 0};
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
     const uint32_t count = B.counts[kCntShade + bounce];
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     float4 *no = B.ray_o[(bounce + 1) & 1], *nd = B.ray_d[(bounce + 1) & 1];
-    unsigned long long n_nee = 0, n_term = 0;
+    unsigned long long n_nee = 0, n_term = 0, n_pdf_tests = 0, n_pdf_hits = 0;
     WaveOut ray_out{0, 0}, nee_out{0, 0};
     auto pad_ray = [&](uint32_t sl) { no[sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
     auto pad_nee = [&](uint32_t sl) {
@@ -555,12 +555,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                 // 1D sample SampleDiscrete consumes), drawn here while few registers are live.
                 // Every path of a bounce normally sits at the same dimension.
                 float u_nee[4] = {0, 0, 0, 0};
-#ifdef IILE_DBG_NO_HALTON
-                u_nee[0] = 0.3f + 1e-9f * hidx; u_nee[1] = 0.6f; u_nee[2] = 0.2f; u_nee[3] = 0.7f;
-                if (false) {
-#else
                 if (bounce < S.max_depth) {
-#endif
                     const int dim_u = __builtin_amdgcn_readfirstlane(dim);
                     if (__ballot(dim != dim_u) == 0) {
                         scrambled_radical_inverse_n<4>(S, s_perms, dim_u + 1, hidx, u_nee);
@@ -611,7 +606,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                         if (S.n_lights > 0) ++dim;
                         if (S.n_lights > 0 && light_sel_pdf != 0) {
                             const DLight &lt = S.lights[li];
-                            if (lt.type != kLightDiffuseArea) {
+                            if (lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
                                 // EstimateDirect for a delta light (integrator.cpp:150-166): light sample
                                 // only, weight 1. Sample_Li of PointLight (lights/point.cpp:43-52),
                                 // SpotLight (spot.cpp:53-76), DistantLight (distant.cpp:50-61).
@@ -659,17 +654,12 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                                     }
                                 }
                             } else {
-                                const DSphere &sp = S.spheres[lt.sphere];
                                 const float ul0 = u_nee[0], ul1 = u_nee[1], us0 = u_nee[2], us1 = u_nee[3];
                                 dim += 4;
                                 // EstimateDirect, light-sampling half (integrator.cpp:117-163)
                                 float light_pdf = 0, scattering_pdf = 0;
                                 F3 wi = F3{0, 0, 0}, Li = F3{0, 0, 0};
-    #ifdef IILE_DBG_NO_NEE_LIGHT
-                                LightSample ps; ps.p = is.p; ps.n = is.n; ps.perr = is.perr; light_pdf = 0;
-    #else
-                                LightSample ps = sphere_sample(sp, is, ul0, ul1, &light_pdf);
-    #endif
+                                LightSample ps = shape_sample(S, lt, is, ul0, ul1, &light_pdf);
                                 if (light_pdf == 0 || length_sq(ps.p - is.p) == 0) {
                                     light_pdf = 0;
                                 } else {
@@ -690,14 +680,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                                     }
                                 }
                                 // BSDF-sampling half (integrator.cpp:165-213)
-    #ifdef IILE_DBG_NO_NEE_BSDF
-                                F3 f2 = F3{0, 0, 0};
-    #else
                                 F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
-    #endif
                                 f2 = f2 * absdot(wi, is.sn);
                                 if (!is_black(f2) && scattering_pdf > 0) {
-                                    const float lp = sphere_pdf(sp, is, wi);
+                                    const float lp = shape_pdf(S, lt, is, wi, &n_pdf_tests, &n_pdf_hits);
                                     if (lp != 0) {
                                         const float weight = power_heuristic(scattering_pdf, lp);
                                         mo = offset_ray_origin(is.p, is.perr, is.n, wi);
@@ -727,11 +713,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             }
         }
         F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
-#ifdef IILE_DBG_NO_CONT
-        if (false) {
-#else
         if (surface) {
-#endif
             // next direction (path.cpp:133-156)
             float u_bsdf[2];
             {
@@ -799,6 +781,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
     if (COUNT) {
         flush_counter(&B.counters->nee_evals, n_nee);
         flush_counter(&B.counters->path_length[bounce < 7 ? bounce : 7], n_term);
+        flush_counter(&B.counters->tri_tests, n_pdf_tests);  // Triangle::Intersect calls of Shape::Pdf
+        flush_counter(&B.counters->tri_hits, n_pdf_hits);
     }
 }
 
@@ -987,7 +971,11 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
 #endif
         if (active && !t.have) {
             // store only: (area light index + 1) of the primitive the MIS ray ended on, 0 for none
-            B.nee_mis[e] = uint8_t(t.hit_prim < 0 ? 0 : (t.hit_prim >> kHitLightShift));
+            const uint8_t on_light = uint8_t(t.hit_prim < 0 ? 0 : (t.hit_prim >> kHitLightShift));
+            B.nee_mis[e] = on_light;
+            // the rare ray that ends on an emitter leaves its hit for k_mis_lit (the hit records are
+            // idle between shade and the next extend)
+            if (on_light) B.hits[e] = make_float4(b2f(uint32_t(hit_index(t.hit_prim))), t.b0, t.b1, t.b2);
             active = false;
         }
     }
@@ -1017,14 +1005,23 @@ __global__ __launch_bounds__(kBlock) void k_mis_lit(DScene S, PassBuffers B, int
             const int li = int(f2b(n2.w));
             if (int(mis) == li + 1) {
                 const DLight &lt = S.lights[li];
-                const DSphere &sp = S.spheres[lt.sphere];
                 const F3 mo = F3{n2.x, n2.y, n2.z}, md = F3{n3.x, n3.y, n3.z};
-                float th;
-                F3 od, ph;
                 Isect lis;
-                // the closest hit was this sphere: redo its root selection for the hit point
-                sphere_test(sp, mo, md, IILE_INF, &th, &od, &ph);
-                sphere_interaction(sp, od, ph, &lis);
+                if (lt.type == kLightAreaTriangle) {
+                    const float4 h4 = B.hits[e];  // left by k_mis
+                    const int prim = int(f2b(h4.x));
+                    const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1],
+                                 v2 = S.tri_verts[3 * size_t(prim) + 2];
+                    triangle_interaction(S, prim, f2b(v0.w), F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z},
+                                         F3{v2.x, v2.y, v2.z}, md, h4.y, h4.z, h4.w, &lis);
+                } else {
+                    const DSphere &sp = S.spheres[lt.sphere];
+                    float th;
+                    F3 od, ph;
+                    // the closest hit was this sphere: redo its root selection for the hit point
+                    sphere_test(sp, mo, md, IILE_INF, &th, &od, &ph);
+                    sphere_interaction(sp, od, ph, &lis);
+                }
                 lit = lt.two_sided || dot(lis.n, -md) > 0;
             }
         }

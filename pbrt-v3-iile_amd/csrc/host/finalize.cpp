@@ -117,6 +117,9 @@ bool finalize_scene(HostScene *s, std::string *err) {
         for (iile_light &lt : s->lights)
             if (lt.type == IILE_LIGHT_DISTANT) lt.world_radius = radius;
     }
+    for (size_t i = 0; i < s->o_light.size(); ++i)  // a triangle emitter's primitive, in BVH order
+        if (s->o_light[i] >= 0 && s->lights[size_t(s->o_light[i])].type == IILE_LIGHT_AREA_TRIANGLE)
+            s->lights[size_t(s->o_light[i])].prim = int(i);
     d.n_lights = int(s->lights.size());
     d.lights = s->lights.data();
 

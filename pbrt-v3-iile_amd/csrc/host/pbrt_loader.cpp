@@ -673,7 +673,6 @@ class Loader {
             N.swap(oN);
         } else
             return fail("Shape \"" + name + "\" is not supported (sphere, trianglemesh, loopsubdiv)");
-        if (gs_.has_area_light) return fail("area lights on triangle meshes are not supported");
         for (int idx : indices)
             if (idx < 0 || idx >= int(P.size())) return fail("trianglemesh has out-of-bounds vertex index");
         // TriangleMesh ctor, shapes/triangle.cpp:54-93: vertices and normals to world space
@@ -700,6 +699,20 @@ class Loader {
             }
             // Triangle::WorldBound, shapes/triangle.cpp:180-186
             pr.world_bound = bunion(Bounds3(pr.p[0], pr.p[1]), pr.p[2]);
+            if (gs_.has_area_light) {  // pbrtShape: one DiffuseAreaLight per shape, i.e. per triangle (api.cpp:1403-1419)
+                float L[3] = {1, 1, 1}, sc[3] = {1, 1, 1};
+                gs_.area_light_params.rgb("L", L);
+                gs_.area_light_params.rgb("scale", sc);
+                iile_light lt;
+                std::memset(&lt, 0, sizeof(lt));
+                for (int i = 0; i < 3; ++i) lt.lemit[i] = L[i] * sc[i];
+                lt.two_sided = gs_.area_light_params.one_bool("twosided", false);
+                lt.sphere = -1;
+                lt.type = IILE_LIGHT_AREA_TRIANGLE;
+                lt.prim = -1;  // set once the primitives are in BVH order (finalize_scene)
+                s.lights.push_back(lt);
+                pr.light = int(s.lights.size()) - 1;
+            }
             s.prims.push_back(pr);
         }
         return true;

@@ -61,7 +61,12 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (xres, yres),
            'Sampler "halton" "integer pixelsamples" [%d]' % spp, 'Integrator "path" "integer maxdepth" [%d]' % maxdepth,
            'WorldBegin']
-    if light == "multi":  # three lights of three kinds: the path integrator's spatial light distribution
+    if light == "quad":  # a rectangular ceiling panel: two triangle emitters (one light each) + a point light
+        out.append('AttributeBegin\n  Material "matte" "color Kd" [.1 .1 .1]\n  AreaLightSource "diffuse" "color L" [12 12 11]\n'
+                   '  Shape "trianglemesh" "point P" [ -2 -3 8.5   3 -3 8.5   3 1 8.5   -2 1 8.5 ]\n'
+                   '    "integer indices" [ 0 2 1   0 3 2 ]\nAttributeEnd')
+        out.append('LightSource "point" "color I" [15 10 5] "point from" [-6 5 2]')
+    elif light == "multi":  # three lights of three kinds: the path integrator's spatial light distribution
         out.append('AttributeBegin\n  Material "matte" "color Kd" [0 0 0]\n  Translate 1.5 -2 7.5\n'
                    '  AreaLightSource "area" "color L" [40 40 40]\n  Shape "sphere" "float radius" [0.6]\nAttributeEnd')
         out.append('LightSource "point" "color I" [30 20 10] "point from" [-6 5 2]')

@@ -406,12 +406,20 @@ def test_several_lights_bitwise(binding, oracle, tmp_path):
     path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="multi", materials="mixed"))
     room = binding.HostScene(path=str(path))
     assert room.info["n_lights"] == 3
-    for name, scene in (("furnace", furnace), ("boxroom", room)):
+    # triangle emitters: the closed tetrahedron furnace, and a two-triangle ceiling panel + a point light
+    tetra = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_tetrahedron.pbrt"))
+    path2 = tmp_path / "boxroom_quad.pbrt"
+    path2.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="quad"))
+    panel = binding.HostScene(path=str(path2))
+    assert panel.info["n_lights"] == 3
+    for name, scene in (("furnace", furnace), ("boxroom", room), ("tetrahedron", tetra), ("panel", panel)):
         gpu = binding.GpuScene(scene)
         film, st = gpu.render(collect_stats=True)
         ref, ost = oracle.render(scene)
+        assert float(scene.film_to_rgb(ref).mean()) > 1e-3
         assert_bitwise(film, ref, f"{name} (several lights) film")
         assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+        assert st["tri_tests"] == ost["tri_tests"] and st["tri_hits"] == ost["tri_hits"]
         assert st["nee_evals"] == ost["nee_evals"] and st["zero_radiance"] == ost["zero_radiance"]
         plain, _ = gpu.render()
         assert_bitwise(plain, ref, f"{name} (several lights) film, uninstrumented kernels")

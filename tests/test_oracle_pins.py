@@ -350,3 +350,18 @@ def test_four_point_lights_furnace_scene_matches_reference_expectation(binding, 
     film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
     assert abs(float(scene.film_to_rgb(film).mean(dtype=np.float64)) - 1.0) < 0.02
     assert st["shadow_rays"] == st["nee_evals"]
+
+
+def test_triangle_emitters_white_furnace(binding, oracle):
+    """No scene of the reference's tests uses a triangle emitter, so Triangle::Sample, the generic
+    Shape::Sample / Shape::Pdf and DiffuseAreaLight on triangles are held to the white-furnace
+    property: inside a closed tetrahedron of two-sided emitters (Le = 0.5 on Kd = 0.5) every pixel
+    converges to 1 — any inconsistency between the light-sampling pdf and the BSDF-sampling pdf of the
+    MIS estimator shows up as a bias here."""
+    import os
+    scene = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_tetrahedron.pbrt"))
+    assert scene.info["n_lights"] == 4 and scene.info["n_triangles"] == 4
+    film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+    rgb = scene.film_to_rgb(film)
+    assert abs(float(rgb.mean(dtype=np.float64)) - 1.0) < 0.01
+    assert rgb.min() > 0.85 and rgb.max() < 1.15
