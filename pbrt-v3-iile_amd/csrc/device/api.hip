@@ -666,6 +666,11 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
             return bail(fail(IILE_ERR_HIP, "light distribution kernel failed"));
     }
+    // which build of k_shade the scene needs (kernels.hip launch_shade)
+    S.extended_features = 0;
+    for (int i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC) S.extended_features = 1;
+    if (d->n_lights > 1 || (d->n_lights == 1 && d->lights[0].type != IILE_LIGHT_DIFFUSE_AREA)) S.extended_features = 1;
     *out = sc;
     return IILE_OK;
 }

@@ -891,6 +891,8 @@ DEV F3 to_world(const Bsdf &b, F3 v) {
 }
 // Matte / Plastic / Uber / Mirror ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70,
 // uber.cpp:45-100 with opacity 1 and Kt 0, mirror.cpp:44-55)
+// EXT = false: the scene has matte and plastic only (checked at upload); the specular lobes then fold away
+template <bool EXT = true>
 DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     Bsdf b;
     b.ns = is.sn;
@@ -904,9 +906,9 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.ks = F3{0, 0, 0};
     b.has_micro = false;
     b.alpha = m.alpha;
-    b.mtype = m.type;
+    b.mtype = EXT ? m.type : kMatPlastic;
     b.eta = m.eta;
-    if (m.type == kMatPlastic || m.type == kMatUber) {
+    if (m.type == kMatPlastic || (EXT && m.type == kMatUber)) {
         b.ks = F3{clampf(m.ks[0], 0, IILE_INF), clampf(m.ks[1], 0, IILE_INF), clampf(m.ks[2], 0, IILE_INF)};
         b.has_micro = !is_black(b.ks);
         if (b.has_micro) ++b.n_lobes;
@@ -914,12 +916,12 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.kr = F3{0, 0, 0};
     b.kt = F3{0, 0, 0};
     b.has_spec = false;
-    if (m.type == kMatUber || m.type == kMatMirror) {
+    if (EXT && (m.type == kMatUber || m.type == kMatMirror)) {
         b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
         b.has_spec = !is_black(b.kr);
         if (b.has_spec) ++b.n_lobes;
     }
-    if (m.type == kMatGlass) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
+    if (EXT && m.type == kMatGlass) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
         b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
         b.kt = F3{clampf(m.kt[0], 0, IILE_INF), clampf(m.kt[1], 0, IILE_INF), clampf(m.kt[2], 0, IILE_INF)};
         b.has_spec = !(is_black(b.kr) && is_black(b.kt));

@@ -78,6 +78,7 @@ struct DScene {
     // SpatialLightDistribution (n_lights > 1): per voxel {func[kMaxLights], cdf[kMaxLights + 1], funcInt}
     const float *light_dist;
     int light_nv[3];
+    int extended_features;    // anything beyond one emitting sphere + matte / plastic: k_shade<.., EXT = true>
     int has_glass;            // some material transmits: the paths' etaScale is tracked
     int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide
                               // step's skipping of intermediate nodes is exact only then

@@ -470,7 +470,7 @@ DEV int sample_light(const DScene &S, F3 p, float u, float *pdf) {
 // shade: one bounce of PathIntegrator::Li (path.cpp:81-191) for every hit of the
 // queue that extend just resolved.
 // 3 waves/SIMD (<= 168 VGPRs, 6 spilled): measured 38.0 ms vs 40.2 ms at 2 waves/SIMD
-template <bool COUNT>
+template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                 const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, b2f(5u)) : B.beta[pid];
                 beta = F3{beta4.x, beta4.y, beta4.z};
                 dim = int(f2b(beta4.w) & 0xffffu);
-                const bool prev_specular = (f2b(beta4.w) >> 16) != 0;  // specularBounce of path.cpp:150
+                const bool prev_specular = EXT && (f2b(beta4.w) >> 16) != 0;  // specularBounce of path.cpp:150
                 hidx = B.hindex[pid];
                 // The four samples of EstimateDirect (dims dim+1 .. dim+4; dim itself is the
                 // 1D sample SampleDiscrete consumes), drawn here while few registers are live.
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                 }
                 if (bounce < S.max_depth) {
                     surface = true;
-                    bsdf = make_bsdf(S.materials[material], is);
+                    bsdf = make_bsdf<EXT>(S.materials[material], is);
                     if (n_nonspec(bsdf) > 0) {  // NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0, path.cpp:118
                         ++n_nee;
                         // UniformSampleOneLight (integrator.cpp:85-106). One light: it is chosen with pdf 1
@@ -599,14 +599,14 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                         // distribution of the spatial light distribution (lightdistrib.cpp:134-226,
                         // tabulated at scene creation); a zero pdf returns before any further sample.
                         int li = 0;
-                        if (S.n_lights > 1) {
+                        if (EXT && S.n_lights > 1) {
                             const float ul = sample_dimension(S, s_perms, hidx, dim);
                             li = sample_light(S, is.p, ul, &light_sel_pdf);
                         }
                         if (S.n_lights > 0) ++dim;
                         if (S.n_lights > 0 && light_sel_pdf != 0) {
                             const DLight &lt = S.lights[li];
-                            if (lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
+                            if (EXT && lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
                                 // EstimateDirect for a delta light (integrator.cpp:150-166): light sample
                                 // only, weight 1. Sample_Li of PointLight (lights/point.cpp:43-52),
                                 // SpotLight (spot.cpp:53-76), DistantLight (distant.cpp:50-61).
@@ -659,7 +659,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                                 // EstimateDirect, light-sampling half (integrator.cpp:117-163)
                                 float light_pdf = 0, scattering_pdf = 0;
                                 F3 wi = F3{0, 0, 0}, Li = F3{0, 0, 0};
-                                LightSample ps = shape_sample(S, lt, is, ul0, ul1, &light_pdf);
+                                LightSample ps = EXT ? shape_sample(S, lt, is, ul0, ul1, &light_pdf)
+                                                     : sphere_sample(S.spheres[lt.sphere], is, ul0, ul1, &light_pdf);
                                 if (light_pdf == 0 || length_sq(ps.p - is.p) == 0) {
                                     light_pdf = 0;
                                 } else {
@@ -683,7 +684,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                                 F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
                                 f2 = f2 * absdot(wi, is.sn);
                                 if (!is_black(f2) && scattering_pdf > 0) {
-                                    const float lp = shape_pdf(S, lt, is, wi, &n_pdf_tests, &n_pdf_hits);
+                                    const float lp = EXT ? shape_pdf(S, lt, is, wi, &n_pdf_tests, &n_pdf_hits)
+                                                         : sphere_pdf(S.spheres[lt.sphere], is, wi);
                                     if (lp != 0) {
                                         const float weight = power_heuristic(scattering_pdf, lp);
                                         mo = offset_ray_origin(is.p, is.perr, is.n, wi);
@@ -730,10 +732,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
             float pdf = 0;
             F3 wi = F3{0, 0, 0};
             bool sampled_specular = false, sampled_transmission = false;
-            const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf, true, &sampled_specular, &sampled_transmission);
+            const F3 f = bsdf_sample_f(bsdf, -ray_d, &wi, u0, u1, &pdf, EXT, &sampled_specular, &sampled_transmission);
             // etaScale (path.cpp:81, 151-157): a path state of its own, touched only in scenes with glass
             float eta_scale = 1.f;
-            if (S.has_glass && bounce > 0) eta_scale = B.eta_scale[pid];
+            if (EXT && S.has_glass && bounce > 0) eta_scale = B.eta_scale[pid];
             if (!(is_black(f) || pdf == 0.f)) {
                 beta = beta * sdiv(f * absdot(wi, is.sn), pdf);
                 const float by = lum_y(beta);
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                     }
                 }
             }
-            if (alive && S.has_glass) B.eta_scale[pid] = eta_scale;
+            if (EXT && alive && S.has_glass) B.eta_scale[pid] = eta_scale;
             // sampler dimension | specularBounce << 16
             if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim) | (sampled_specular ? 0x10000u : 0u)));
         }
@@ -1299,9 +1301,14 @@ void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t ma
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, IILE_SHADE_BLOCKS));
     const size_t perm_bytes = (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_shade<true>, grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
+        hipLaunchKernelGGL((k_shade<true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
     else
-        hipLaunchKernelGGL(k_shade<false>, grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
+        // Scenes of killeroo-simple's kind (one emitting sphere, matte / plastic only) run a build of the
+        // kernel without the code for the wider feature set: it costs them registers otherwise (+0.7 ms)
+        if (S.extended_features)
+            hipLaunchKernelGGL((k_shade<false, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
+        else
+            hipLaunchKernelGGL((k_shade<false, false>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
 }
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
