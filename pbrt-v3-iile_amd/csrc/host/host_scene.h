@@ -75,4 +75,8 @@ void build_bvh(HostScene *scene);
 // halton_tables.cpp
 void build_halton_tables(HostScene *scene);
 
+// plymesh.cpp
+bool load_ply(const std::string &path, std::vector<V3> *P, std::vector<V3> *N, std::vector<float> *uv,
+              std::vector<int> *indices, std::string *err);
+
 }  // namespace iile

@@ -644,13 +644,23 @@ class Loader {
         std::vector<int> indices;
         std::vector<V3> P, N;
         std::vector<float> uv;
-        const Param *pi = ps.find("indices");
-        const Param *pp = ps.find("P");
-        if (!pi || !pp) return fail("Shape " + name + ": \"indices\" and \"P\" are required");
-        for (double v : pi->nums) indices.push_back(int(v));
-        for (size_t i = 0; i + 2 < pp->nums.size(); i += 3)
-            P.push_back(V3(float(pp->nums[i]), float(pp->nums[i + 1]), float(pp->nums[i + 2])));
-        if (name == "trianglemesh") {  // shapes/triangle.cpp:616-714
+        if (name == "plymesh") {  // shapes/plymesh.cpp:149-300
+            std::string fn = ps.one_string("filename", "");
+            if (fn.empty()) return fail("plymesh: \"filename\" is required");
+            if (fn[0] != '/') fn = search_dir_ + "/" + fn;
+            if (ps.find("alpha") || ps.find("shadowalpha")) return fail("alpha masks are not supported");
+            std::string perr;
+            if (!load_ply(fn, &P, &N, &uv, &indices, &perr)) return fail(perr);
+        } else {
+            const Param *pi = ps.find("indices");
+            const Param *pp = ps.find("P");
+            if (!pi || !pp) return fail("Shape " + name + ": \"indices\" and \"P\" are required");
+            for (double v : pi->nums) indices.push_back(int(v));
+            for (size_t i = 0; i + 2 < pp->nums.size(); i += 3)
+                P.push_back(V3(float(pp->nums[i]), float(pp->nums[i + 1]), float(pp->nums[i + 2])));
+        }
+        if (name == "plymesh") {
+        } else if (name == "trianglemesh") {  // shapes/triangle.cpp:616-714
             const Param *pu = ps.find("uv");
             if (!pu) pu = ps.find("st");
             if (pu) {
@@ -672,7 +682,7 @@ class Loader {
             P.swap(oP);
             N.swap(oN);
         } else
-            return fail("Shape \"" + name + "\" is not supported (sphere, trianglemesh, loopsubdiv)");
+            return fail("Shape \"" + name + "\" is not supported (sphere, trianglemesh, plymesh, loopsubdiv)");
         for (int idx : indices)
             if (idx < 0 || idx >= int(P.size())) return fail("trianglemesh has out-of-bounds vertex index");
         // TriangleMesh ctor, shapes/triangle.cpp:54-93: vertices and normals to world space

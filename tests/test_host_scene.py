@@ -155,3 +155,69 @@ def test_tokenizer_cases_of_the_reference_parser_tests(binding, tmp_path):
                       ('Shape"sphere"\t\t # foo bar\n"float radius\n" 5\n', "unterminated string")):
         with pytest.raises(RuntimeError, match=msg):
             load(body, end="")
+
+
+def _write_ply(path, P, faces, fmt, N=None, uv=None):
+    import struct
+    props = ["property float x", "property float y", "property float z"]
+    if N is not None:
+        props += ["property float nx", "property float ny", "property float nz"]
+    if uv is not None:
+        props += ["property float u", "property float v"]
+    head = ["ply", f"format {fmt} 1.0", "comment written by the test", f"element vertex {len(P)}"] + props + [
+        f"element face {len(faces)}", "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode())
+        rows = [list(P[i]) + (list(N[i]) if N is not None else []) + (list(uv[i]) if uv is not None else [])
+                for i in range(len(P))]
+        if fmt == "ascii":
+            for r in rows:
+                f.write((" ".join("%.9g" % x for x in r) + "\n").encode())
+            for fc in faces:
+                f.write((" ".join(str(x) for x in [len(fc)] + list(fc)) + "\n").encode())
+        else:
+            e = "<" if fmt == "binary_little_endian" else ">"
+            for r in rows:
+                f.write(struct.pack(e + "%df" % len(r), *r))
+            for fc in faces:
+                f.write(struct.pack(e + "B%di" % len(fc), len(fc), *fc))
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_plymesh_equals_trianglemesh(binding, oracle, tmp_path, fmt):
+    """`Shape "plymesh"` (src/shapes/plymesh.cpp:149-300): vertices, normals, (u, v) and faces of
+    three or four vertices, a quad (a, b, c, d) read as the triangles (a, b, c), (d, a, c) — the
+    flattened scene, and the oracle's render of it, must equal those of the same mesh given inline."""
+    import boxroom
+    rng = np.random.default_rng(3)
+    V, F = boxroom._icosphere(2)
+    P = (V * 1.2 + [0, 0, 0.5]).astype(np.float32)
+    N = V.astype(np.float32)
+    uv = rng.random((len(P), 2)).astype(np.float32)
+    faces = [tuple(int(i) for i in f) for f in F]
+    # a floor quad as one four-vertex face
+    base = len(P)
+    P = np.concatenate([P, np.array([[-4, -4, -1], [4, -4, -1], [4, 4, -1], [-4, 4, -1]], np.float32)])
+    N = np.concatenate([N, np.array([[0, 0, 1]] * 4, np.float32)])
+    uv = np.concatenate([uv, np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)])
+    faces.append((base, base + 1, base + 2, base + 3))
+    _write_ply(tmp_path / "mesh.ply", P, faces, fmt, N, uv)
+    tri_idx = []
+    for fc in faces:
+        tri_idx += list(fc[:3]) + ([fc[3], fc[0], fc[2]] if len(fc) == 4 else [])
+    head = ('LookAt 0 -6 1.5  0 0 0.3  0 0 1\nCamera "perspective" "float fov" [45]\n'
+            'Film "image" "integer xresolution" [48] "integer yresolution" [32]\nSampler "halton" "integer pixelsamples" [4]\n'
+            'WorldBegin\nAttributeBegin\nTranslate 2 -3 5\nAreaLightSource "diffuse" "color L" [30 30 30]\n'
+            'Shape "sphere" "float radius" [.5]\nAttributeEnd\nMaterial "plastic" "color Kd" [.5 .3 .2]\n')
+    fmtf = lambda a: " ".join("%.9g" % x for x in np.asarray(a, np.float32).ravel())
+    (tmp_path / "ply.pbrt").write_text(head + 'Shape "plymesh" "string filename" "mesh.ply"\nWorldEnd\n')
+    (tmp_path / "inline.pbrt").write_text(
+        head + 'Shape "trianglemesh" "point P" [%s] "normal N" [%s] "float uv" [%s] "integer indices" [%s]\nWorldEnd\n'
+        % (fmtf(P), fmtf(N), fmtf(uv), " ".join(map(str, tri_idx))))
+    a = binding.HostScene(path=str(tmp_path / "ply.pbrt"))
+    b = binding.HostScene(path=str(tmp_path / "inline.pbrt"))
+    assert a.info == b.info and a.info["n_triangles"] == len(tri_idx) // 3
+    fa, sa = oracle.render(a)
+    fb, sb = oracle.render(b)
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and sa["tri_tests"] == sb["tri_tests"]
+    assert float(a.film_to_rgb(fa).mean()) > 1e-3
