@@ -106,6 +106,13 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
                 *rng.uniform(.1, .4, 3), rng.uniform(.05, .3), rng.uniform(1.2, 1.8))
         elif materials == "mixed" and b % 3 == 2:
             mat = 'Material "mirror" "color Kr" [%g %g %g]' % tuple(rng.uniform(.6, .95, 3))
+        elif materials == "all" and b % 5 == 3:
+            mat = 'Material "glass" "color Kr" [1 1 1] "color Kt" [%g %g %g] "float index" [%g]' % (*rng.uniform(.7, 1, 3), rng.uniform(1.3, 1.7))
+        elif materials == "all" and b % 5 == 1:
+            mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "color Kr" [.3 .3 .3] "float roughness" [%g] "float index" [%g]' % (
+                *rng.uniform(.1, .4, 3), rng.uniform(.05, .3), rng.uniform(1.2, 1.8))
+        elif materials == "all" and b % 5 == 2:
+            mat = 'Material "mirror" "color Kr" [%g %g %g]' % tuple(rng.uniform(.6, .95, 3))
         elif materials == "glass" and b % 2 == 1:  # closed refractive blobs, one of them tinted
             mat = 'Material "glass" "color Kr" [1 1 1] "color Kt" [%g %g %g] "float index" [%g]' % (
                 *((1, 1, 1) if b % 4 == 1 else rng.uniform(.7, 1, 3)), rng.uniform(1.3, 1.7))
