@@ -100,6 +100,11 @@ float oracle_acos(int trig_mode, float x);
  * sampling (mcSolidAngle, shapes.cpp:318-329), both with Halton points (0, 1). */
 void oracle_sphere_solid_angle(const iile_scene_desc *scene, int sphere, const float *p3, int n_samples,
                                double *by_sampling, double *by_uniform_directions);
+/* Triangle.Sampling (shapes.cpp:210-271) for the area light `light` (a triangle or a sphere emitter):
+ * the solid angle it subtends from p as sum 1 / (n pdf) over Shape::Sample(ref, u) with Halton (0, 1)
+ * points, and by uniform-direction Monte Carlo with the same points. */
+void oracle_light_solid_angle(const iile_scene_desc *scene, int light, const float *p3, int n_samples,
+                              double *by_sampling, double *by_uniform_directions);
 int64_t oracle_check_next_float(int iters, uint64_t seed);
 int64_t oracle_check_efloat(int iters, uint64_t seed);
 int64_t oracle_check_reintersect(const iile_scene_desc *scene, int n, const float *o, const float *d, int n_out,

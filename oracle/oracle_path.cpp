@@ -2131,6 +2131,35 @@ void oracle_sphere_solid_angle(const iile_scene_desc *scene, int sphere, const f
     *by_uniform_directions = hits / ((1.0 / (4 * 3.14159265358979323846)) * n_samples);
 }
 
+void oracle_light_solid_angle(const iile_scene_desc *scene, int light, const float *p3, int n_samples,
+                              double *by_sampling, double *by_uniform_directions) {
+    Counters c;
+    Oracle orc(*scene, ORACLE_TRIG_LIBM, &c);
+    const iile_light &lt = scene->lights[light];
+    const V3 p(p3[0], p3[1], p3[2]);
+    int prim = lt.prim;
+    if (lt.type == IILE_LIGHT_DIFFUSE_AREA)
+        for (int i = 0; i < scene->n_prims; ++i)
+            if ((scene->prim_flags[i] & IILE_PRIM_SPHERE) && scene->prim_shape[i] == lt.sphere) prim = i;
+    Isect ref;  // Interaction(pc, Normal3f(), Vector3f(), ...)
+    ref.p = p;
+    ref.perr = V3(0, 0, 0);
+    ref.n = V3(0, 0, 0);
+    double sa = 0;
+    int hits = 0;
+    for (int i = 0; i < n_samples; ++i) {
+        float u[2] = {oracle_radical_inverse(0, uint64_t(i)), oracle_radical_inverse(1, uint64_t(i))};
+        float pdf = 0;
+        (void)orc.shape_sample(lt, ref, u, &pdf);
+        if (pdf > 0) sa += 1. / (double(n_samples) * pdf);
+        float z = 1 - 2 * u[0], rr = std::sqrt(std::max(0.f, 1.f - z * z)), phi = 2 * Pi * u[1];
+        Ray w{p, V3(rr * std::cos(phi), rr * std::sin(phi), z), Infinity};
+        if (orc.prim_intersects(w, prim)) ++hits;
+    }
+    *by_sampling = sa;
+    *by_uniform_directions = hits / (double(n_samples) * (1.0 / (4 * 3.14159265358979323846)));
+}
+
 int64_t oracle_check_next_float(int iters, uint64_t seed) {
     int64_t bad = 0;
     if (!(next_up(-0.f) > 0.f) || !(next_down(0.f) < 0.f)) ++bad;

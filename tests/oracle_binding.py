@@ -45,6 +45,7 @@ class Oracle:
         lib.oracle_halton_index.restype = ctypes.c_int64
         lib.oracle_bsdf_sample_batch.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]
         lib.oracle_bsdf_pdf_batch.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
+        lib.oracle_light_solid_angle.argtypes = [c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
         lib.oracle_sphere_solid_angle.argtypes = [c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
         lib.oracle_check_next_float.restype = ctypes.c_int64
         lib.oracle_check_next_float.argtypes = [ctypes.c_int, ctypes.c_uint64]
@@ -117,6 +118,12 @@ class Oracle:
         self.lib.oracle_intersect(scene.desc, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, prim.ctypes.data,
                                   tb.ctypes.data)
         return prim, tb
+
+    def light_solid_angle(self, scene, light, p, n_samples):
+        p = _f32(p)
+        a, b = ctypes.c_double(), ctypes.c_double()
+        self.lib.oracle_light_solid_angle(scene.desc, light, p.ctypes.data, n_samples, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
 
     def sphere_solid_angle(self, scene, sphere, p, n_samples):
         p = _f32(p)

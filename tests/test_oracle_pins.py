@@ -365,3 +365,37 @@ def test_triangle_emitters_white_furnace(binding, oracle):
     rgb = scene.film_to_rgb(film)
     assert abs(float(rgb.mean(dtype=np.float64)) - 1.0) < 0.01
     assert rgb.min() > 0.85 and rgb.max() < 1.15
+
+
+def test_triangle_sampling_like_the_reference_test(binding, oracle, tmp_path):
+    """Triangle.Sampling of src/tests/shapes.cpp:210-271: for random triangles in [-10, 10]^3 and
+    reference points pushed 3 units outside that cube along one axis, the solid angle estimated
+    through Triangle::Sample (Shape::Sample(ref, u): sum 1 / (n pdf)) must agree with uniform-direction
+    Monte Carlo to 10 % (absolute error below 1e-4), both with 512 K Halton points."""
+    rng = np.random.default_rng(42)
+    checked = 0
+    for scene_i in range(4):
+        tris, pcs = [], []
+        while len(tris) < 7:
+            v = rng.uniform(-10, 10, (3, 3))
+            if (np.cross(v[1] - v[0], v[2] - v[0]) ** 2).sum() < 1e-20:
+                continue
+            pc = rng.uniform(-10, 10, 3)
+            pc[rng.integers(0, 3)] = -13.0 if rng.random() > .5 else 13.0
+            tris.append(v.astype(np.float32))
+            pcs.append(pc.astype(np.float32))
+        body = "".join('AttributeBegin\nAreaLightSource "diffuse" "bool twosided" ["true"]\nShape "trianglemesh" "point P" [%s] '
+                       '"integer indices" [0 1 2]\nAttributeEnd\n' % " ".join("%.9g" % x for x in t.ravel()) for t in tris)
+        path = tmp_path / f"tris{scene_i}.pbrt"
+        path.write_text('Camera "perspective"\nFilm "image" "integer xresolution" [4] "integer yresolution" [4]\n'
+                        'Sampler "halton" "integer pixelsamples" [1]\nWorldBegin\n' + body + "WorldEnd\n")
+        scene = binding.HostScene(path=str(path))
+        assert scene.info["n_lights"] == 7
+        for light in range(7):
+            by_sampling, by_dirs = oracle.light_solid_angle(scene, light, pcs[light], 512 * 1024)
+            assert by_sampling > 0
+            if by_sampling > 1e-3:
+                err = abs(by_sampling - by_dirs) if min(abs(by_sampling), abs(by_dirs)) < 1e-4 else abs((by_sampling - by_dirs) / by_dirs)
+                assert err < .1, (scene_i, light, by_sampling, by_dirs)
+                checked += 1
+    assert checked >= 20
