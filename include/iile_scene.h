@@ -80,6 +80,7 @@ typedef struct iile_material {
 #define IILE_LIGHT_SPOT 2
 #define IILE_LIGHT_DISTANT 3
 #define IILE_LIGHT_AREA_TRIANGLE 4 /* DiffuseAreaLight on one triangle (every triangle of an emitting mesh is a light) */
+#define IILE_LIGHT_INFINITE 5      /* InfiniteAreaLight without an environment map (src/lights/infinite.h:51-84) */
 typedef struct iile_light {
     float lemit[3];  /* area: Lemit (L * scale); point, spot: I * scale; distant: L * scale */
     int32_t two_sided;
@@ -91,6 +92,14 @@ typedef struct iile_light {
     float world_radius; /* distant: radius of the scene's bounding sphere (Light::Preprocess, distant.cpp:63-65) */
     int32_t prim;       /* triangle area light: its primitive, in BVH order */
     int32_t pad;
+    /* infinite: lemit is the single texel of Lmap (L * scale); w2l as for the spot light; world_radius as
+     * for the distant light; and */
+    float l2w[9];       /* upper 3x3 of LightToWorld, row major */
+    /* the Distribution2D over the 2 x 2 luminance * sin(theta) image of the 1 x 1 map (infinite.cpp:63-83,
+     * sampling.cpp:159-174): per row v the conditional Distribution1D {func[2], cdf[3], funcInt}, then the
+     * marginal one over the rows' funcInt */
+    float dist_cond[2][6];
+    float dist_marg[6];
 } iile_light;
 
 /* PerspectiveCamera (src/cameras/perspective.cpp:50-72, src/core/camera.h:90-111). */

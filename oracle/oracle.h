@@ -86,6 +86,8 @@ void oracle_bsdf_pdf_batch(const iile_scene_desc *scene, int trig_mode, int mat,
 void oracle_sincos(int trig_mode, float x, float *s, float *c);
 void oracle_sincos_d(int trig_mode, double x, double *s, double *c);
 float oracle_acos(int trig_mode, float x);
+float oracle_atan2(int trig_mode, float y, float x);
+double oracle_atan2_d(double y, double x); /* the portable double evaluation itself */
 
 /* Property tests of the reference (src/tests/fp_tests.cpp, src/tests/shapes.cpp), run against the
  * restatement's own float machinery. Each returns the number of violated expectations.

@@ -48,6 +48,7 @@ namespace {
 // constants (core/pbrt.h:196-208, core/rng.h:53)
 constexpr float Pi = 3.14159265358979323846f;
 constexpr float InvPi = 0.31830988618379067154f;
+constexpr float Inv2Pi = 0.15915494309189533577f;
 constexpr float PiOver2 = 1.57079632679489661923f;
 constexpr float PiOver4 = 0.78539816339744830961f;
 constexpr float Infinity = std::numeric_limits<float>::infinity();
@@ -168,6 +169,101 @@ double portable_acos(double x) {
     }
 }
 
+// atan / atan2 with the structure and coefficients of fdlibm's s_atan.c / e_atan2.c (double);
+// results are rounded once to float by the callers.
+double portable_atan(double x) {
+    static const double atanhi[] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01,
+                                    1.57079632679489655800e+00};
+    static const double atanlo[] = {2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17,
+                                    6.12323399573676603587e-17};
+    static const double aT[] = {3.33333333333329318027e-01,  -1.99999999998764832476e-01, 1.42857142725034663711e-01,
+                                -1.11111104054623557880e-01, 9.09088713343650656196e-02,  -7.69187620504482999495e-02,
+                                6.66107313738753120669e-02,  -5.83357013379057348645e-02, 4.97687799461593236017e-02,
+                                -3.65315727442169155270e-02, 1.62858201153657823623e-02};
+    const bool neg = std::signbit(x);
+    double ax = std::fabs(x);
+    int id;
+    if (!(ax < 7.378697629483821e19)) {  // |x| >= 2^66 (or NaN)
+        if (x != x) return x + x;
+        return neg ? -(atanhi[3] + atanlo[3]) : (atanhi[3] + atanlo[3]);
+    }
+    if (ax < 0.4375) {
+        if (ax < 1.862645149230957e-09) return x;  // |x| < 2^-29
+        id = -1;
+        ax = x;
+    } else if (ax < 1.1875) {
+        if (ax < 0.6875) {
+            id = 0;
+            ax = (2.0 * ax - 1.0) / (2.0 + ax);
+        } else {
+            id = 1;
+            ax = (ax - 1.0) / (ax + 1.0);
+        }
+    } else if (ax < 2.4375) {
+        id = 2;
+        ax = (ax - 1.5) / (1.0 + 1.5 * ax);
+    } else {
+        id = 3;
+        ax = -1.0 / ax;
+    }
+    const double z = ax * ax, w = z * z;
+    const double s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const double s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return ax - ax * (s1 + s2);
+    const double r = atanhi[id] - ((ax * (s1 + s2) - atanlo[id]) - ax);
+    return neg ? -r : r;
+}
+double portable_atan2(double y, double x) {
+    const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16, pi_o_2 = 1.5707963267948965580E+00,
+                 pi_o_4 = 7.8539816339744827900E-01, tiny = 1.0e-300;
+    if (x != x || y != y) return x + y;
+    if (x == 1.0) return portable_atan(y);
+    const int m = (std::signbit(y) ? 1 : 0) | (std::signbit(x) ? 2 : 0);
+    if (y == 0) {
+        switch (m) {
+        case 0:
+        case 1: return y;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (x == 0) return std::signbit(y) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (std::isinf(x)) {
+        if (std::isinf(y)) {
+            switch (m) {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0 * pi_o_4 + tiny;
+            default: return -3.0 * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+        case 0: return 0.0;
+        case 1: return -0.0;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (std::isinf(y)) return std::signbit(y) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    int ey, ex;
+    std::frexp(y, &ey);
+    std::frexp(x, &ex);
+    const int k = ey - ex;
+    double z;
+    if (k > 60)
+        z = pi_o_2 + 0.5 * pi_lo;
+    else if (std::signbit(x) && k < -60)
+        z = 0.0;
+    else
+        z = portable_atan(std::fabs(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return -z;
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
 struct Trig {
     int mode;
     float sin_f(float x) const {
@@ -197,6 +293,10 @@ struct Trig {
     float acos_f(float x) const {
         if (mode == ORACLE_TRIG_LIBM) return std::acos(x);
         return float(portable_acos(double(x)));
+    }
+    float atan2_f(float y, float x) const {
+        if (mode == ORACLE_TRIG_LIBM) return std::atan2(y, x);
+        return float(portable_atan2(double(y), double(x)));
     }
 };
 
@@ -1462,6 +1562,10 @@ struct Oracle {
         const V3 pos(lt.pos[0], lt.pos[1], lt.pos[2]);
         const Rgb I(lt.lemit[0], lt.lemit[1], lt.lemit[2]);
         *pdf = 1;
+        if (lt.type == IILE_LIGHT_INFINITE) {
+            V3 wi, target;
+            return inf_sample_li(lt, po, u, &wi, pdf, &target);
+        }
         if (lt.type == IILE_LIGHT_DISTANT) return I;
         if (lt.type == IILE_LIGHT_POINT) return I / length_sq(pos - po);
         if (lt.type == IILE_LIGHT_SPOT) {
@@ -1561,6 +1665,118 @@ struct Oracle {
         return offset;
     }
 
+    // ------------------------------------------------------------------------
+    // InfiniteAreaLight without an environment map (lights/infinite.cpp:42-174). Lmap holds one
+    // texel; its MIPMap lookup is the triangle filter over that texel (mipmap.h:351-389), and the
+    // sampling distribution a 2 x 2 Distribution2D built on the host (pbrt_loader.cpp).
+    static Rgb inf_lookup(const iile_light &lt, float s_, float t_) {  // Lmap->Lookup(st): level < 0 -> triangle(0, st)
+        float s = s_ * 1 - 0.5f, t = t_ * 1 - 0.5f;
+        float s0 = std::floor(s), t0 = std::floor(t);
+        float ds = s - s0, dt = t - t0;
+        Rgb T(lt.lemit[0], lt.lemit[1], lt.lemit[2]);
+        return (1 - ds) * (1 - dt) * T + (1 - ds) * dt * T + ds * (1 - dt) * T + ds * dt * T;
+    }
+    // Distribution1D::SampleContinuous over n = 2 entries {func[2], cdf[3], funcInt}, sampling.h:71-89
+    static float dist1d_sample(const float *d, float u, float *pdf, int *off) {
+        const float *func = d, *cdf = d + 2;
+        const float func_int = d[5];
+        const int size = 3;
+        int first = 0, len = size;
+        while (len > 0) {
+            int half = len >> 1, middle = first + half;
+            if (cdf[middle] <= u) {
+                first = middle + 1;
+                len -= half + 1;
+            } else
+                len = half;
+        }
+        int offset = std::min(std::max(first - 1, 0), size - 2);
+        if (off) *off = offset;
+        float du = u - cdf[offset];
+        if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
+        *pdf = (func_int > 0) ? func[offset] / func_int : 0;
+        return (offset + du) / 2;
+    }
+    V3 inf_w2l(const iile_light &lt, V3 w) const {
+        return V3(lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z, lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
+                  lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z);
+    }
+    float spherical_theta(V3 v) const { return trig.acos_f(clampf(v.z, -1, 1)); }  // geometry.h:1474-1481
+    float spherical_phi(V3 v) const {
+        float p = trig.atan2_f(v.y, v.x);
+        return (p < 0) ? (p + 2 * Pi) : p;
+    }
+    Rgb inf_le(const iile_light &lt, V3 d) const {  // InfiniteAreaLight::Le, infinite.cpp:99-104
+        V3 w = normalize(inf_w2l(lt, d));
+        return inf_lookup(lt, spherical_phi(w) * Inv2Pi, spherical_theta(w) * InvPi);
+    }
+    Rgb inf_sample_li(const iile_light &lt, V3 ref_p, const float *u, V3 *wi, float *pdf, V3 *target) const {  // :106-137
+        float pdfs[2];
+        int v;
+        float d1 = dist1d_sample(lt.dist_marg, u[1], &pdfs[1], &v);
+        float d0 = dist1d_sample(lt.dist_cond[v], u[0], &pdfs[0], nullptr);
+        float map_pdf = pdfs[0] * pdfs[1];
+        *pdf = 0;
+        if (map_pdf == 0) return Rgb(0.f);
+        float theta = d1 * Pi, phi = d0 * 2 * Pi;
+        float cos_theta = trig.cos_f(theta), sin_theta = trig.sin_f(theta);
+        float sin_phi = trig.sin_f(phi), cos_phi = trig.cos_f(phi);
+        V3 wl(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+        *wi = V3(lt.l2w[0] * wl.x + lt.l2w[1] * wl.y + lt.l2w[2] * wl.z, lt.l2w[3] * wl.x + lt.l2w[4] * wl.y + lt.l2w[5] * wl.z,
+                 lt.l2w[6] * wl.x + lt.l2w[7] * wl.y + lt.l2w[8] * wl.z);
+        *pdf = map_pdf / (2 * Pi * Pi * sin_theta);
+        if (sin_theta == 0) *pdf = 0;
+        *target = ref_p + *wi * (2 * lt.world_radius);
+        return inf_lookup(lt, d0, d1);
+    }
+    float inf_pdf_li(const iile_light &lt, V3 w) const {  // :139-148
+        V3 wi = inf_w2l(lt, w);
+        float theta = spherical_theta(wi), phi = spherical_phi(wi);
+        float sin_theta = trig.sin_f(theta);
+        if (sin_theta == 0) return 0;
+        float p0 = phi * Inv2Pi, p1 = theta * InvPi;  // Distribution2D::Pdf, sampling.h:135-142
+        int iu = std::min(std::max(int(p0 * 2), 0), 1), iv = std::min(std::max(int(p1 * 2), 0), 1);
+        return (lt.dist_cond[iv][iu] / lt.dist_marg[5]) / (2 * Pi * Pi * sin_theta);
+    }
+    // EstimateDirect for the infinite light: both halves, with Le(ray) where the BSDF-sampled ray escapes
+    Rgb estimate_direct_infinite(const Isect &it, const Bsdf &bsdf, const float *u_scatter, const iile_light &lt,
+                                 const float *u_light) const {
+        Rgb Ld(0.f);
+        V3 wi, target;
+        float light_pdf = 0, scattering_pdf = 0;
+        Rgb Li = inf_sample_li(lt, it.p, u_light, &wi, &light_pdf, &target);
+        if (light_pdf > 0 && !Li.is_black()) {
+            Rgb f = bsdf_f(bsdf, it.wo, wi) * absdot(wi, it.sn);
+            scattering_pdf = bsdf_pdf(bsdf, it.wo, wi);
+            if (!f.is_black()) {
+                V3 origin = offset_ray_origin(it.p, it.perr, it.n, target - it.p);
+                V3 tgt = offset_ray_origin(target, V3(0, 0, 0), V3(0, 0, 0), origin - target);
+                Ray sr{origin, tgt - origin, 1 - ShadowEpsilon};
+                if (intersect_p(sr)) Li = Rgb(0.f);
+                if (!Li.is_black()) {
+                    float weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                    Ld = Ld + f * Li * weight / light_pdf;
+                }
+            }
+        }
+        {
+            Rgb f = bsdf_sample_f(bsdf, it.wo, &wi, u_scatter, &scattering_pdf);
+            f = f * absdot(wi, it.sn);
+            if (!f.is_black() && scattering_pdf > 0) {
+                light_pdf = inf_pdf_li(lt, wi);
+                if (light_pdf == 0) return Ld;
+                float weight = power_heuristic(1, scattering_pdf, 1, light_pdf);
+                Isect li;
+                Ray ray = spawn_ray(it, wi);
+                bool found = intersect(ray, &li);
+                Rgb Li2(0.f);
+                if (!found) Li2 = inf_le(lt, ray.d);  // a surface hit never is this light
+                if (!Li2.is_black()) Ld = Ld + f * Li2 * Rgb(1.f) * weight / scattering_pdf;
+            }
+        }
+        return Ld;
+    }
+
     // EstimateDirect for the delta lights (IsDeltaLight: no MIS weight, no BSDF-sampling half,
     // core/integrator.cpp:150-166). Sample_Li of PointLight (lights/point.cpp:43-52), SpotLight
     // (lights/spot.cpp:53-76) and DistantLight (lights/distant.cpp:50-61).
@@ -1615,6 +1831,7 @@ struct Oracle {
     Rgb estimate_direct(const Isect &it, const Bsdf &bsdf, const float *u_scatter, int light_index,
                         const float *u_light) const {
         const iile_light &lt = S.lights[light_index];
+        if (lt.type == IILE_LIGHT_INFINITE) return estimate_direct_infinite(it, bsdf, u_scatter, lt, u_light);
         if (lt.type != IILE_LIGHT_DIFFUSE_AREA && lt.type != IILE_LIGHT_AREA_TRIANGLE)
             return estimate_direct_delta(it, bsdf, lt);
         Rgb Ld(0.f);
@@ -1679,7 +1896,11 @@ struct Oracle {
             Isect is;
             bool found = intersect(ray, &is);
             if (bounces == 0 || specular_bounce) {
-                if (found) L = L + beta * isect_le(is, -ray.d);
+                if (found)
+                    L = L + beta * isect_le(is, -ray.d);
+                else  // `for (const auto &light : scene.infiniteLights) L += beta * light->Le(ray)`, path.cpp:97-99
+                    for (int l = 0; l < S.n_lights; ++l)
+                        if (S.lights[l].type == IILE_LIGHT_INFINITE) L = L + beta * inf_le(S.lights[l], ray.d);
             }
             if (!found || bounces >= max_depth) break;
             Bsdf bsdf = make_bsdf(is);
@@ -2048,6 +2269,11 @@ void oracle_sincos_d(int trig_mode, double x, double *s, double *c) {
     *s = t.sin_d(x);
     *c = t.cos_d(x);
 }
+float oracle_atan2(int trig_mode, float y, float x) {
+    Trig t{trig_mode};
+    return t.atan2_f(y, x);
+}
+double oracle_atan2_d(double y, double x) { return portable_atan2(y, x); }
 float oracle_acos(int trig_mode, float x) {
     Trig t{trig_mode};
     return t.acos_f(x);

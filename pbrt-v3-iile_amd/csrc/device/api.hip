@@ -207,6 +207,10 @@ int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed
     for (int b = 0; b <= sc->max_depth; ++b) {
         rc = timed_launch(1, [&] { launch_extend(S, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
+        if (S.has_infinite) {  // escaped rays see the infinite lights (path.cpp:97-99)
+            rc = timed_launch(6, [&] { launch_miss(S, B, b, B.queue_cap, cfg); });
+            if (rc) return rc;
+        }
         rc = timed_launch(2, [&] { launch_shade(S, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (b < sc->max_depth) {
@@ -278,7 +282,7 @@ int iile_device_count(void) {
 
 static_assert(kLightDiffuseArea == IILE_LIGHT_DIFFUSE_AREA && kLightPoint == IILE_LIGHT_POINT &&
                   kLightSpot == IILE_LIGHT_SPOT && kLightDistant == IILE_LIGHT_DISTANT &&
-                  kLightAreaTriangle == IILE_LIGHT_AREA_TRIANGLE,
+                  kLightAreaTriangle == IILE_LIGHT_AREA_TRIANGLE && kLightInfinite == IILE_LIGHT_INFINITE,
               "light type codes");
 static_assert(kMatMatte == IILE_MAT_MATTE && kMatPlastic == IILE_MAT_PLASTIC && kMatUber == IILE_MAT_UBER &&
                   kMatMirror == IILE_MAT_MIRROR && kMatGlass == IILE_MAT_GLASS,
@@ -303,7 +307,8 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         } else if (l.type == IILE_LIGHT_AREA_TRIANGLE) {
             if (l.prim < 0 || l.prim >= d->n_prims || (d->prim_flags[l.prim] & IILE_PRIM_SPHERE) || d->prim_light[l.prim] != i)
                 return fail(IILE_ERR_ARG, "triangle area light without its triangle");
-        } else if (l.type != IILE_LIGHT_POINT && l.type != IILE_LIGHT_SPOT && l.type != IILE_LIGHT_DISTANT) {
+        } else if (l.type != IILE_LIGHT_POINT && l.type != IILE_LIGHT_SPOT && l.type != IILE_LIGHT_DISTANT &&
+                   l.type != IILE_LIGHT_INFINITE) {
             return fail(IILE_ERR_UNSUPPORTED, "unsupported light type");
         }
     }
@@ -527,6 +532,10 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             lts[i].cos_falloff_start = d->lights[i].cos_falloff_start;
             lts[i].world_radius = d->lights[i].world_radius;
             lts[i].prim = d->lights[i].prim;
+            std::memcpy(lts[i].l2w, d->lights[i].l2w, sizeof(lts[i].l2w));
+            std::memcpy(lts[i].dist_cond, d->lights[i].dist_cond, sizeof(lts[i].dist_cond));
+            std::memcpy(lts[i].dist_marg, d->lights[i].dist_marg, sizeof(lts[i].dist_marg));
+            if (d->lights[i].type == IILE_LIGHT_INFINITE) S.has_infinite = 1;
         }
         rc = upload(sc, lts.data(), lts.size(), &S.lights);
         if (rc) return bail(rc);
@@ -671,6 +680,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     for (int i = 0; i < d->n_materials; ++i)
         if (d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC) S.extended_features = 1;
     if (d->n_lights > 1 || (d->n_lights == 1 && d->lights[0].type != IILE_LIGHT_DIFFUSE_AREA)) S.extended_features = 1;
+    if (S.has_infinite) S.extended_features = 1;
     *out = sc;
     return IILE_OK;
 }

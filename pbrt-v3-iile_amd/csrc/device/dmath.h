@@ -16,6 +16,7 @@ namespace iile {
 // core/pbrt.h:196-208, core/rng.h:53
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kInvPi = 0.31830988618379067154f;
+constexpr float kInv2Pi = 0.15915494309189533577f;
 constexpr float kPiOver2 = 1.57079632679489661923f;
 constexpr float kPiOver4 = 0.78539816339744830961f;
 constexpr float kMachineEpsilon = 5.9604644775390625e-08f;  // 2^-24
@@ -177,6 +178,92 @@ DEV double acos_d(double x) {
     }
 }
 DEV float acos_f(float x) { return float(acos_d(double(x))); }
+// atan / atan2 with the structure and coefficients of fdlibm's s_atan.c / e_atan2.c, operation for
+// operation as oracle/oracle_path.cpp portable_atan / portable_atan2 (finite arguments only: the callers
+// pass components of normalised directions)
+DEV double atan_d(double x) {
+    const double atanhi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01,
+                              1.57079632679489655800e+00};
+    const double atanlo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17,
+                              6.12323399573676603587e-17};
+    const bool neg = x < 0 || (x == 0 && __double_as_longlong(x) < 0);
+    double ax = fabs(x);
+    int id;
+    if (!(ax < 7.378697629483821e19)) {
+        if (x != x) return x + x;
+        return neg ? -(atanhi[3] + atanlo[3]) : (atanhi[3] + atanlo[3]);
+    }
+    double hi = 0, lo = 0;
+    if (ax < 0.4375) {
+        if (ax < 1.862645149230957e-09) return x;
+        id = -1;
+        ax = x;
+    } else if (ax < 1.1875) {
+        if (ax < 0.6875) {
+            id = 0;
+            hi = atanhi[0];
+            lo = atanlo[0];
+            ax = (2.0 * ax - 1.0) / (2.0 + ax);
+        } else {
+            id = 1;
+            hi = atanhi[1];
+            lo = atanlo[1];
+            ax = (ax - 1.0) / (ax + 1.0);
+        }
+    } else if (ax < 2.4375) {
+        id = 2;
+        hi = atanhi[2];
+        lo = atanlo[2];
+        ax = (ax - 1.5) / (1.0 + 1.5 * ax);
+    } else {
+        id = 3;
+        hi = atanhi[3];
+        lo = atanlo[3];
+        ax = -1.0 / ax;
+    }
+    const double z = ax * ax, w = z * z;
+    const double s1 =
+        z * (3.33333333333329318027e-01 +
+             w * (1.42857142725034663711e-01 +
+                  w * (9.09088713343650656196e-02 +
+                       w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 +
+                           w * (-1.11111104054623557880e-01 +
+                                w * (-7.69187620504482999495e-02 +
+                                     w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    if (id < 0) return ax - ax * (s1 + s2);
+    const double r = hi - ((ax * (s1 + s2) - lo) - ax);
+    return neg ? -r : r;
+}
+DEV double atan2_d(double y, double x) {
+    const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16, pi_o_2 = 1.5707963267948965580E+00,
+                 tiny = 1.0e-300;
+    if (x != x || y != y) return x + y;
+    if (x == 1.0) return atan_d(y);
+    const bool sy = __double_as_longlong(y) < 0, sx = __double_as_longlong(x) < 0;
+    const int m = (sy ? 1 : 0) | (sx ? 2 : 0);
+    if (y == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (x == 0) return sy ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    // exponents as frexp reports them (the arguments are finite and non-zero here)
+    int ey, ex;
+    (void)frexp(y, &ey);
+    (void)frexp(x, &ex);
+    const int k = ey - ex;
+    double z;
+    if (k > 60)
+        z = pi_o_2 + 0.5 * pi_lo;
+    else if (sx && k < -60)
+        z = 0.0;
+    else
+        z = atan_d(fabs(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return -z;
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+DEV float atan2_f(float y, float x) { return float(atan2_d(double(y), double(x))); }
 
 // ---------------------------------------------------------------------------
 // 4x4 row-major transforms (core/transform.h:217-410)

@@ -1252,6 +1252,85 @@ DEV float sphere_pdf(const DSphere &sp, const Isect &ref, F3 wi) {
     float cos_tmax = sqrtf(mx(0.f, 1 - sin_tmax2));
     return 1 / (2 * kPi * (1 - cos_tmax));
 }
+// InfiniteAreaLight without an environment map (lights/infinite.cpp:42-174), operation for operation
+// as the oracle's inf_* functions: one texel behind a triangle-filter lookup, a 2 x 2 Distribution2D.
+DEV F3 inf_lookup(const DLight &lt, float s_, float t_) {  // Lmap->Lookup(st) -> triangle(0, st), mipmap.h:375-389
+    const float s = s_ * 1 - 0.5f, t = t_ * 1 - 0.5f;
+    const float s0 = floorf(s), t0 = floorf(t);
+    const float ds = s - s0, dt = t - t0;
+    const F3 T = F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]};
+    return (1 - ds) * (1 - dt) * T + (1 - ds) * dt * T + ds * (1 - dt) * T + ds * dt * T;
+}
+DEV float dist1d_sample(const float *d, float u, float *pdf, int *off) {  // Distribution1D::SampleContinuous, n = 2
+    const float c1 = d[3];  // cdf = {d[2], d[3], d[4]} = {0, c1, 1}
+    // FindInterval(3, cdf[i] <= u), pbrt.h:399-412, unrolled: the last i in {0, 1} with cdf[i] <= u
+    int first = 0, len = 3;
+    while (len > 0) {
+        const int half = len >> 1, middle = first + half;
+        const float cm = middle == 0 ? d[2] : (middle == 1 ? c1 : d[4]);
+        if (cm <= u) {
+            first = middle + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    int offset = first - 1;
+    offset = offset < 0 ? 0 : (offset > 1 ? 1 : offset);
+    if (off) *off = offset;
+    const float lo = offset == 0 ? d[2] : c1, hi = offset == 0 ? c1 : d[4];
+    float du = u - lo;
+    if ((hi - lo) > 0) du /= (hi - lo);
+    *pdf = (d[5] > 0) ? (offset == 0 ? d[0] : d[1]) / d[5] : 0.f;
+    return (offset + du) / 2;
+}
+DEV F3 inf_w2l(const DLight &lt, F3 w) {
+    return F3{lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z, lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
+              lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z};
+}
+DEV float spherical_theta(F3 v) { return acos_f(clampf(v.z, -1, 1)); }  // geometry.h:1474-1481
+DEV float spherical_phi(F3 v) {
+    const float p = atan2_f(v.y, v.x);
+    return (p < 0) ? (p + 2 * kPi) : p;
+}
+DEV F3 inf_le(const DLight &lt, F3 d) {  // InfiniteAreaLight::Le, infinite.cpp:99-104
+    const F3 w = normalize(inf_w2l(lt, d));
+    return inf_lookup(lt, spherical_phi(w) * kInv2Pi, spherical_theta(w) * kInvPi);
+}
+DEV F3 inf_sample_li(const DLight &lt, F3 ref_p, float u0, float u1, F3 *wi, float *pdf, F3 *target) {  // :106-137
+    float pdf0, pdf1;
+    int v;
+    const float d1 = dist1d_sample(lt.dist_marg, u1, &pdf1, &v);
+    const float d0 = dist1d_sample(v == 0 ? lt.dist_cond[0] : lt.dist_cond[1], u0, &pdf0, nullptr);
+    const float map_pdf = pdf0 * pdf1;
+    *pdf = 0;
+    if (map_pdf == 0) return F3{0, 0, 0};
+    const float theta = d1 * kPi, phi = d0 * 2 * kPi;
+    float sin_theta, cos_theta, sin_phi, cos_phi;
+    sincos_f(theta, &sin_theta, &cos_theta);
+    sincos_f(phi, &sin_phi, &cos_phi);
+    const F3 wl = F3{sin_theta * cos_phi, sin_theta * sin_phi, cos_theta};
+    *wi = F3{lt.l2w[0] * wl.x + lt.l2w[1] * wl.y + lt.l2w[2] * wl.z, lt.l2w[3] * wl.x + lt.l2w[4] * wl.y + lt.l2w[5] * wl.z,
+             lt.l2w[6] * wl.x + lt.l2w[7] * wl.y + lt.l2w[8] * wl.z};
+    *pdf = map_pdf / (2 * kPi * kPi * sin_theta);
+    if (sin_theta == 0) *pdf = 0;
+    *target = ref_p + *wi * (2 * lt.world_radius);
+    return inf_lookup(lt, d0, d1);
+}
+DEV float inf_pdf_li(const DLight &lt, F3 w) {  // :139-148 with Distribution2D::Pdf, sampling.h:135-142
+    const F3 wi = inf_w2l(lt, w);
+    const float theta = spherical_theta(wi), phi = spherical_phi(wi);
+    float sin_theta, cos_theta;
+    sincos_f(theta, &sin_theta, &cos_theta);
+    if (sin_theta == 0) return 0;
+    const float p0 = phi * kInv2Pi, p1 = theta * kInvPi;
+    int iu = int(p0 * 2), iv = int(p1 * 2);
+    iu = iu < 0 ? 0 : (iu > 1 ? 1 : iu);
+    iv = iv < 0 ? 0 : (iv > 1 ? 1 : iv);
+    const float func = iv == 0 ? (iu == 0 ? lt.dist_cond[0][0] : lt.dist_cond[0][1])
+                               : (iu == 0 ? lt.dist_cond[1][0] : lt.dist_cond[1][1]);
+    return (func / lt.dist_marg[5]) / (2 * kPi * kPi * sin_theta);
+}
+
 // Triangle emitter (shapes/triangle.cpp:546-579) through the generic Shape::Sample(ref, u) /
 // Shape::Pdf(ref, wi) (core/shape.cpp:56-87), and the sphere / triangle dispatch of an area light
 DEV float triangle_area(const DScene &S, int prim) {

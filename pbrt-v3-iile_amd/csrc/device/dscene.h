@@ -31,7 +31,8 @@ struct DMaterial {
     float eta;    // uber, glass: FresnelDielectric(1, eta)
     float kt[3];  // glass: specular transmittance
 };
-enum { kLightDiffuseArea = 0, kLightPoint = 1, kLightSpot = 2, kLightDistant = 3, kLightAreaTriangle = 4 };  // = IILE_LIGHT_* (checked in api.hip)
+enum { kLightDiffuseArea = 0, kLightPoint = 1, kLightSpot = 2, kLightDistant = 3, kLightAreaTriangle = 4,
+       kLightInfinite = 5 };  // = IILE_LIGHT_* (checked in api.hip)
 struct DLight {
     float lemit[3];  // area: Lemit; point: I
     int two_sided;
@@ -41,6 +42,10 @@ struct DLight {
     float w2l[9];    // spot: upper 3x3 of WorldToLight, row major
     float cos_total_width, cos_falloff_start, world_radius;
     int prim;        // triangle emitter: its primitive
+    // infinite light (no map): LightToWorld 3x3 and the 2 x 2 Distribution2D, see iile_scene.h
+    float l2w[9];
+    float dist_cond[2][6];
+    float dist_marg[6];
 };
 // Per Halton dimension: base, float reciprocal and offset of its digit permutation.
 // The digits are peeled in double arithmetic (exact for any u32 index, see
@@ -78,6 +83,7 @@ struct DScene {
     // SpatialLightDistribution (n_lights > 1): per voxel {func[kMaxLights], cdf[kMaxLights + 1], funcInt}
     const float *light_dist;
     int light_nv[3];
+    int has_infinite;         // some light is an InfiniteAreaLight: escaped rays carry radiance (k_miss)
     int extended_features;    // anything beyond one emitting sphere + matte / plastic: k_shade<.., EXT = true>
     int has_glass;            // some material transmits: the paths' etaScale is tracked
     int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide

@@ -60,6 +60,7 @@ void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t m
 void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_light_distributions(const DScene &S, const float *samples, float *out, const LaunchCfg &cfg);
 constexpr int kLightDistFloats = 2 * kMaxLights + 2;  // per voxel
+void launch_miss(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_mis_lit(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
                             const LaunchCfg &cfg);

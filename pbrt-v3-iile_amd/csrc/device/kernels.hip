@@ -351,6 +351,10 @@ DEV F3 sample_li_plain(const DScene &S, const DLight &lt, F3 po, float u0, float
     const F3 pos = F3{lt.pos[0], lt.pos[1], lt.pos[2]};
     const F3 I = F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]};
     *pdf = 1;
+    if (lt.type == kLightInfinite) {
+        F3 wi, target;
+        return inf_sample_li(lt, po, u0, u1, &wi, pdf, &target);
+    }
     if (lt.type == kLightDistant) return I;
     if (lt.type == kLightPoint) return sdiv(I, length_sq(pos - po));
     if (lt.type == kLightSpot) {
@@ -606,7 +610,39 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                         if (S.n_lights > 0) ++dim;
                         if (S.n_lights > 0 && light_sel_pdf != 0) {
                             const DLight &lt = S.lights[li];
-                            if (EXT && lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
+                            if (EXT && lt.type == kLightInfinite) {
+                                // EstimateDirect for the infinite light (integrator.cpp:108-215): both halves; the
+                                // BSDF-sampled ray contributes Le(ray) when it escapes (:209-210)
+                                const float ul0 = u_nee[0], ul1 = u_nee[1], us0 = u_nee[2], us1 = u_nee[3];
+                                dim += 4;
+                                float light_pdf = 0, scattering_pdf = 0;
+                                F3 wi = F3{0, 0, 0}, target = F3{0, 0, 0};
+                                const F3 Li = inf_sample_li(lt, is.p, ul0, ul1, &wi, &light_pdf, &target);
+                                if (light_pdf > 0 && !is_black(Li)) {
+                                    const F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
+                                    scattering_pdf = bsdf_pdf(bsdf, is.wo, wi);
+                                    if (!is_black(f)) {
+                                        so = offset_ray_origin(is.p, is.perr, is.n, target - is.p);
+                                        sd = target - so;
+                                        const float weight = power_heuristic(light_pdf, scattering_pdf);
+                                        A = sdiv(f * Li * weight, light_pdf);
+                                        nee_flags |= NEE_HAS_SHADOW;
+                                    }
+                                }
+                                F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
+                                f2 = f2 * absdot(wi, is.sn);
+                                if (!is_black(f2) && scattering_pdf > 0) {
+                                    const float lp = inf_pdf_li(lt, wi);
+                                    if (lp != 0) {
+                                        const float weight = power_heuristic(scattering_pdf, lp);
+                                        mo = offset_ray_origin(is.p, is.perr, is.n, wi);
+                                        md = wi;
+                                        // Li is Le(ray) when the MIS ray escapes the scene
+                                        Bc = sdiv(f2 * inf_le(lt, wi) * weight, scattering_pdf);
+                                        nee_flags |= NEE_HAS_MIS;
+                                    }
+                                }
+                            } else if (EXT && lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
                                 // EstimateDirect for a delta light (integrator.cpp:150-166): light sample
                                 // only, weight 1. Sample_Li of PointLight (lights/point.cpp:43-52),
                                 // SpotLight (spot.cpp:53-76), DistantLight (distant.cpp:50-61).
@@ -973,11 +1009,12 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
 #endif
         if (active && !t.have) {
             // store only: (area light index + 1) of the primitive the MIS ray ended on, 0 for none
-            const uint8_t on_light = uint8_t(t.hit_prim < 0 ? 0 : (t.hit_prim >> kHitLightShift));
+            // 255: the ray escaped (matters to an infinite light only)
+            const uint8_t on_light = uint8_t(t.hit_prim < 0 ? (S.has_infinite ? 255 : 0) : (t.hit_prim >> kHitLightShift));
             B.nee_mis[e] = on_light;
             // the rare ray that ends on an emitter leaves its hit for k_mis_lit (the hit records are
             // idle between shade and the next extend)
-            if (on_light) B.hits[e] = make_float4(b2f(uint32_t(hit_index(t.hit_prim))), t.b0, t.b1, t.b2);
+            if (on_light && t.hit_prim >= 0) B.hits[e] = make_float4(b2f(uint32_t(hit_index(t.hit_prim))), t.b0, t.b1, t.b2);
             active = false;
         }
     }
@@ -987,6 +1024,29 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
         flush_counter(&B.counters->tri_tests, st.tris);
         flush_counter(&B.counters->tri_hits, st.tri_hits);
         flush_counter(&B.counters->sphere_tests, st.spheres);
+    }
+}
+
+// miss: a ray that left the scene at the first vertex or after a specular bounce picks up the
+// infinite lights' radiance (path.cpp:91-99). Only launched for scenes that have one: a pass over
+// the hit records of the bounce, so the traversal kernels stay as they are.
+__global__ __launch_bounds__(kBlock) void k_miss(DScene S, PassBuffers B, int bounce) {
+    const uint32_t count = B.counts[kCntRay + bounce];
+    const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
+    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < count; slot += gridDim.x * kBlock) {
+        const float4 h4 = B.hits[slot];
+        if (int(f2b(h4.x)) >= 0) continue;
+        const uint32_t pid = f2b(ro[slot].w);
+        if (pid == kInvalid) continue;
+        const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, b2f(5u)) : B.beta[pid];
+        if (!(bounce == 0 || (f2b(beta4.w) >> 16) != 0)) continue;
+        const float4 d4 = rd[slot];
+        const F3 beta = F3{beta4.x, beta4.y, beta4.z}, d = F3{d4.x, d4.y, d4.z};
+        const float4 L4 = B.L[pid];
+        F3 L = F3{L4.x, L4.y, L4.z};
+        for (int l = 0; l < S.n_lights; ++l)
+            if (S.lights[l].type == kLightInfinite) L = L + beta * inf_le(S.lights[l], d);
+        B.L[pid] = make_float4(L.x, L.y, L.z, 0);
     }
 }
 
@@ -1005,7 +1065,9 @@ __global__ __launch_bounds__(kBlock) void k_mis_lit(DScene S, PassBuffers B, int
         bool lit = false;
         if (flags != kInvalid && (flags & NEE_HAS_MIS)) {
             const int li = int(f2b(n2.w));
-            if (int(mis) == li + 1) {
+            if (mis == 255u) {
+                lit = S.lights[li].type == kLightInfinite;  // `else Li = light.Le(ray)`, integrator.cpp:209-210
+            } else if (int(mis) == li + 1) {
                 const DLight &lt = S.lights[li];
                 const F3 mo = F3{n2.x, n2.y, n2.z}, md = F3{n3.x, n3.y, n3.z};
                 Isect lis;
@@ -1327,6 +1389,10 @@ void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_
 void launch_light_distributions(const DScene &S, const float *samples, float *out, const LaunchCfg &cfg) {
     const int n = S.light_nv[0] * S.light_nv[1] * S.light_nv[2];
     hipLaunchKernelGGL(k_light_distributions, dim3((n + 127) / 128), dim3(128), 0, cfg.stream, S, samples, out);
+}
+void launch_miss(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 8));
+    hipLaunchKernelGGL(k_miss, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
 }
 void launch_mis_lit(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 8));

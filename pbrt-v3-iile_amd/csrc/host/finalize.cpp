@@ -115,7 +115,7 @@ bool finalize_scene(HostScene *s, std::string *err) {
         const bool inside = c.x >= pmin.x && c.x <= pmax.x && c.y >= pmin.y && c.y <= pmax.y && c.z >= pmin.z && c.z <= pmax.z;
         const float radius = inside ? length(c - pmax) : 0.f;
         for (iile_light &lt : s->lights)
-            if (lt.type == IILE_LIGHT_DISTANT) lt.world_radius = radius;
+            if (lt.type == IILE_LIGHT_DISTANT || lt.type == IILE_LIGHT_INFINITE) lt.world_radius = radius;
     }
     for (size_t i = 0; i < s->o_light.size(); ++i)  // a triangle emitter's primitive, in BVH order
         if (s->o_light[i] >= 0 && s->lights[size_t(s->o_light[i])].type == IILE_LIGHT_AREA_TRIANGLE)

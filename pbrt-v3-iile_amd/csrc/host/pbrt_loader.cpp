@@ -438,10 +438,10 @@ class Loader {
             gs_.has_area_light = true;
             gs_.area_light_params = ps;
         } else if (d == "LightSource") {  // api.cpp:1344-1358 (pbrtLightSource), MakeLight api.cpp:770-806
-            if (name != "point" && name != "spot" && name != "distant")
-                return fail("LightSource \"" + name + "\" is not supported (point, spot, distant; area lights on spheres)");
+            if (name != "point" && name != "spot" && name != "distant" && name != "infinite" && name != "exinfinite")
+                return fail("LightSource \"" + name + "\" is not supported (point, spot, distant, infinite; area lights)");
             float I[3] = {1, 1, 1}, sc[3] = {1, 1, 1};
-            ps.rgb(name == "distant" ? "L" : "I", I);
+            ps.rgb((name == "distant" || name == "infinite" || name == "exinfinite") ? "L" : "I", I);
             ps.rgb("scale", sc);
             auto point_param = [&](const char *pname, V3 def, V3 *out) -> bool {
                 *out = def;
@@ -489,6 +489,54 @@ class Loader {
                     for (int c = 0; c < 3; ++c) lt.w2l[3 * r + c] = l2w.inv.m[r][c];  // WorldToLight = Inverse(LightToWorld)
                 lt.cos_total_width = std::cos(radians(coneangle));                   // SpotLight ctor, spot.cpp:43-51
                 lt.cos_falloff_start = std::cos(radians(coneangle - conedelta));
+            } else if (name == "infinite" || name == "exinfinite") {  // CreateInfiniteLight, lights/infinite.cpp:176-186
+                if (!ps.one_string("mapname", "").empty()) return fail("infinite light: environment maps are not supported");
+                lt.type = IILE_LIGHT_INFINITE;
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) {
+                        lt.l2w[3 * r + c] = ctm_.m.m[r][c];
+                        lt.w2l[3 * r + c] = ctm_.inv.m[r][c];
+                    }
+                // InfiniteAreaLight ctor without a map (infinite.cpp:42-84): Lmap is one texel, the sampling
+                // distribution is built over a 2 x 2 image of its filtered luminance times sin(theta)
+                const float T[3] = {lt.lemit[0], lt.lemit[1], lt.lemit[2]};
+                float img[4];
+                const int width = 2, height = 2;
+                for (int v = 0; v < height; ++v) {
+                    const float vp = (v + .5f) / float(height);
+                    const float sin_theta = std::sin(kPi * (v + .5f) / height);
+                    for (int u = 0; u < width; ++u) {
+                        const float up = (u + .5f) / float(width);
+                        // MIPMap::Lookup(st, width 0.25) on one level -> triangle(0, st), mipmap.h:375-389
+                        const float s = up * 1 - 0.5f, t = vp * 1 - 0.5f;
+                        const float s0 = std::floor(s), t0 = std::floor(t);
+                        const float ds = s - s0, dt = t - t0;
+                        float rgb[3];
+                        for (int c = 0; c < 3; ++c)
+                            rgb[c] = (1 - ds) * (1 - dt) * T[c] + (1 - ds) * dt * T[c] + ds * (1 - dt) * T[c] + ds * dt * T[c];
+                        const float y = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];  // RGBSpectrum::y
+                        img[u + v * width] = y;
+                        img[u + v * width] *= sin_theta;
+                    }
+                }
+                auto dist1d = [](const float *f, int n, float *out) {  // Distribution1D, sampling.h:57-69
+                    float *func = out, *cdf = out + 2, *func_int = out + 5;
+                    for (int i = 0; i < n; ++i) func[i] = f[i];
+                    cdf[0] = 0;
+                    for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+                    *func_int = cdf[n];
+                    if (*func_int == 0)
+                        for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n);
+                    else
+                        for (int i = 1; i < n + 1; ++i) cdf[i] /= *func_int;
+                };
+                float marg[2];
+                for (int v = 0; v < height; ++v) {  // Distribution2D, sampling.cpp:159-174
+                    dist1d(&img[v * width], width, lt.dist_cond[v]);
+                    marg[v] = lt.dist_cond[v][5];
+                }
+                dist1d(marg, height, lt.dist_marg);
+                // world_radius is set once the scene bounds are known (finalize_scene)
             } else {  // CreateDistantLight, lights/distant.cpp:94-102; ctor :43-48
                 const V3 w = normalize(ctm_.vector(from - to));
                 lt.type = IILE_LIGHT_DISTANT;

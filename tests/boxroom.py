@@ -61,7 +61,10 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (xres, yres),
            'Sampler "halton" "integer pixelsamples" [%d]' % spp, 'Integrator "path" "integer maxdepth" [%d]' % maxdepth,
            'WorldBegin']
-    if light == "quad":  # a rectangular ceiling panel: two triangle emitters (one light each) + a point light
+    if light == "sky":  # uniform sky through the open top (no ceiling below) and a warm point light inside
+        out.append('AttributeBegin\n  Rotate 25 0 1 0\n  LightSource "infinite" "color L" [.6 .7 1] "color scale" [1.5 1.5 1.5]\nAttributeEnd')
+        out.append('LightSource "point" "color I" [25 15 8] "point from" [-6 5 2]')
+    elif light == "quad":  # a rectangular ceiling panel: two triangle emitters (one light each) + a point light
         out.append('AttributeBegin\n  Material "matte" "color Kd" [.1 .1 .1]\n  AreaLightSource "diffuse" "color L" [12 12 11]\n'
                    '  Shape "trianglemesh" "point P" [ -2 -3 8.5   3 -3 8.5   3 1 8.5   -2 1 8.5 ]\n'
                    '    "integer indices" [ 0 2 1   0 3 2 ]\nAttributeEnd')
@@ -91,7 +94,7 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
              ((-s, -s, -3), (0, 2 * s, 0), (0, 0, 12), (.8, .3, .3)),         # left
              ((s, -s, -3), (0, 0, 12), (0, 2 * s, 0), (.3, .8, .3))]          # right
     for o, du, dv, kd in walls:
-        if light == "distant" and o[2] == 9:
+        if light in ("distant", "sky") and o[2] == 9:
             continue  # no ceiling
         P, F = _grid_quad(o, du, dv, wall_n)
         out.append('AttributeBegin\n  Material "matte" "color Kd" [%g %g %g]\n%sAttributeEnd' % (*kd, _mesh(P, F)))

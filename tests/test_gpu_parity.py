@@ -446,3 +446,27 @@ def test_random_rooms_bitwise(binding, oracle, tmp_path, seed, light):
         assert st[k_dev] == ost[k_ref], k_dev
     plain, _ = gpu.render(spp_per_pass=2)
     assert_bitwise(plain, ref, f"room seed {seed} / {light}, uninstrumented kernels, two passes")
+
+
+def test_infinite_light_bitwise(binding, oracle, tmp_path):
+    """InfiniteAreaLight (constant): the white-furnace sky scene, and the box room open to a tinted sky
+    with a point light inside (two lights: the spatial light distribution samples the sky too). The
+    device evaluates SphericalPhi / SphericalTheta with the portable atan2 / acos of the oracle."""
+    import os
+    import boxroom
+    sky = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_sky.pbrt"))
+    path = tmp_path / "boxroom_sky.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="sky", materials="all", maxdepth=6))
+    room = binding.HostScene(path=str(path))
+    assert room.info["n_lights"] == 2
+    for name, scene in (("sky furnace", sky), ("boxroom sky", room)):
+        gpu = binding.GpuScene(scene)
+        film, st = gpu.render(collect_stats=True)
+        ref, ost = oracle.render(scene)
+        assert float(scene.film_to_rgb(ref).mean()) > 1e-2
+        assert_bitwise(film, ref, f"{name} film")
+        assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+        assert st["zero_radiance"] == ost["zero_radiance"] and st["path_length"] == ost["path_length"]
+        plain, _ = gpu.render()
+        assert_bitwise(plain, ref, f"{name} film, uninstrumented kernels")
+    assert abs(float(sky.film_to_rgb(gpu_film := binding.GpuScene(sky).render()[0]).mean(dtype=np.float64)) - 1.0) < 0.005

@@ -399,3 +399,33 @@ def test_triangle_sampling_like_the_reference_test(binding, oracle, tmp_path):
                 assert err < .1, (scene_i, light, by_sampling, by_dirs)
                 checked += 1
     assert checked >= 20
+
+
+def test_infinite_light_white_furnace(binding, oracle):
+    """No reference test covers InfiniteAreaLight, so its restatement (Sample_Li / Pdf_Li / Le over the
+    one-texel map, the escaped-ray terms of Li and of EstimateDirect's BSDF-sampling half) is held to the
+    white-furnace property: a white Lambertian sphere under a uniform sky of radiance 1 must show
+    radiance 1 at every pixel, background and sphere alike."""
+    import os
+    scene = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_sky.pbrt"))
+    for mode in (ob.TRIG_LIBM, ob.TRIG_PORTABLE):
+        film, st = oracle.render(scene, trig_mode=mode)
+        rgb = scene.film_to_rgb(film)
+        assert abs(float(rgb.mean(dtype=np.float64)) - 1.0) < 0.005
+        assert rgb.min() > 0.95 and rgb.max() < 1.05
+
+
+def test_portable_atan2_accuracy(oracle):
+    """The portable atan2 (fdlibm structure, double) behind SphericalPhi in the portable trig mode: within
+    one double ulp of the correctly rounded value, so its float rounding is almost always the correctly
+    rounded float."""
+    import ctypes
+    lib = oracle.lib
+    lib.oracle_atan2_d.restype = ctypes.c_double
+    lib.oracle_atan2_d.argtypes = [ctypes.c_double, ctypes.c_double]
+    rng = np.random.default_rng(0)
+    ys = np.concatenate([rng.normal(size=20000), rng.normal(size=500) * 1e-8, [0.0, -0.0, 1, -1, 0, 0]])
+    xs = np.concatenate([rng.normal(size=20000), rng.normal(size=500), [1, 1, 0, 0, -1, -0.0]])
+    got = np.array([lib.oracle_atan2_d(float(y), float(x)) for y, x in zip(ys, xs)])
+    ref = np.arctan2(ys, xs)
+    assert (np.abs(got - ref) <= np.spacing(np.abs(ref))).all()
