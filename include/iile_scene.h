@@ -60,7 +60,7 @@ typedef struct iile_material {
     int32_t type;
     float kd[3];     /* matte, plastic, uber; 0 for mirror */
     float ks[3];     /* plastic, uber: glossy (microfacet) reflectance */
-    float sigma;     /* matte; only sigma == 0 (Lambertian) is supported on device */
+    float sigma;     /* matte: Clamp(sigma, 0, 90) degrees; 0 = Lambertian, else Oren-Nayar (reflection.h:410-427) */
     float roughness; /* plastic, uber: as given */
     float alpha;     /* plastic, uber: RoughnessToAlpha(roughness) if remap else roughness
                         (src/core/microfacet.h:123-128) */
@@ -68,7 +68,7 @@ typedef struct iile_material {
     float eta;       /* uber, glass: index of refraction of FresnelDielectric(1, eta) */
     float kr[3];     /* uber, mirror, glass: specular reflectance */
     float kt[3];     /* glass: specular transmittance */
-    int32_t pad[2];
+    float on_a, on_b; /* matte with sigma != 0: the Oren-Nayar constants A, B (reflection.h:416-419) */
 } iile_material;
 
 /* A light: DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75) or one of the delta lights

@@ -1067,6 +1067,8 @@ struct Oracle {
         V3 ns, ng, ss, ts;
         int n_lobes = 0;    // nBxDFs; BxDF order: Lambertian, microfacet, specular reflection
         bool has_lambert = false, has_micro = false, has_spec = false;
+        bool oren_nayar = false;  // the diffuse lobe is OrenNayar(kd, sigma) instead of LambertianReflection
+        float on_a = 1, on_b = 0;
         Rgb kd, ks, kr;
         float alpha = 0;
         float micro_eta_i = 1.5f, micro_eta_t = 1.f;  // FresnelDielectric of the microfacet lobe
@@ -1099,6 +1101,11 @@ struct Oracle {
             b.has_lambert = true;
             b.kd = kd;
             ++b.n_lobes;
+            if (m.type == IILE_MAT_MATTE && m.sigma != 0) {  // matte.cpp:56-61
+                b.oren_nayar = true;
+                b.on_a = m.on_a;
+                b.on_b = m.on_b;
+            }
         }
         if (m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) {
             Rgb ks = clamp0(m.ks);
@@ -1255,6 +1262,27 @@ struct Oracle {
         V3 wh = normalize(wo + wi);
         return tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
     }
+    // LambertianReflection::f (reflection.cpp:178-180) or OrenNayar::f (reflection.cpp:197-219)
+    static Rgb diffuse_f(const Bsdf &b, V3 wo, V3 wi) {
+        if (!b.oren_nayar) return b.kd * InvPi;
+        float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
+        float max_cos = 0;
+        if (sin_i > 1e-4 && sin_o > 1e-4) {
+            float sin_phi_i = sin_phi(wi), cos_phi_i = cos_phi(wi);
+            float sin_phi_o = sin_phi(wo), cos_phi_o = cos_phi(wo);
+            float d_cos = cos_phi_i * cos_phi_o + sin_phi_i * sin_phi_o;
+            max_cos = std::max(0.f, d_cos);
+        }
+        float sin_alpha, tan_beta;
+        if (std::abs(wi.z) > std::abs(wo.z)) {
+            sin_alpha = sin_o;
+            tan_beta = sin_i / std::abs(wi.z);
+        } else {
+            sin_alpha = sin_i;
+            tan_beta = sin_o / std::abs(wo.z);
+        }
+        return b.kd * InvPi * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta);
+    }
     static float lambert_pdf(V3 wo, V3 wi) { return same_hemisphere(wo, wi) ? std::abs(wi.z) * InvPi : 0; }
 
     // BSDF::f, reflection.cpp:686-699 (all lobes are BSDF_REFLECTION, non-specular)
@@ -1264,7 +1292,7 @@ struct Oracle {
         bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
         Rgb f(0.f);
         if (reflect) {
-            if (b.has_lambert) f = f + b.kd * InvPi;
+            if (b.has_lambert) f = f + diffuse_f(b, wo, wi);
             if (b.has_micro) f = f + micro_f(b, wo, wi);
         }
         return f;
@@ -1313,7 +1341,7 @@ struct Oracle {
             wi = cosine_sample_hemisphere(ur);
             if (wo.z < 0) wi.z *= -1;
             *pdf = lambert_pdf(wo, wi);
-            f = b.kd * InvPi;
+            f = diffuse_f(b, wo, wi);
         } else if (pick == 1) {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
             // `if (wo.z == 0) return 0.` is unreachable here
             V3 wh = tr_sample_wh(wo, ur, b.alpha);
@@ -1373,7 +1401,7 @@ struct Oracle {
             bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
             f = Rgb(0.);
             if (reflect) {
-                if (b.has_lambert) f = f + b.kd * InvPi;
+                if (b.has_lambert) f = f + diffuse_f(b, wo, wi);
                 if (b.has_micro) f = f + micro_f(b, wo, wi);
             }
         }

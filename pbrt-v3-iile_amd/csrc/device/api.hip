@@ -515,6 +515,9 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             mats[i].alpha = m.alpha;
             for (int c = 0; c < 3; ++c) mats[i].kr[c] = m.kr[c];
             for (int c = 0; c < 3; ++c) mats[i].kt[c] = m.kt[c];
+            const bool oren_nayar = m.type == IILE_MAT_MATTE && m.sigma != 0;
+            mats[i].on_a = oren_nayar ? m.on_a : 1.f;
+            mats[i].on_b = oren_nayar ? m.on_b : 0.f;
             if (m.type == IILE_MAT_GLASS) S.has_glass = 1;
             mats[i].eta = m.eta;
         }
@@ -678,7 +681,9 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     // which build of k_shade the scene needs (kernels.hip launch_shade)
     S.extended_features = 0;
     for (int i = 0; i < d->n_materials; ++i)
-        if (d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC) S.extended_features = 1;
+        if ((d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC) ||
+            (d->materials[i].type == IILE_MAT_MATTE && d->materials[i].sigma != 0))
+            S.extended_features = 1;
     if (d->n_lights > 1 || (d->n_lights == 1 && d->lights[0].type != IILE_LIGHT_DIFFUSE_AREA)) S.extended_features = 1;
     if (S.has_infinite) S.extended_features = 1;
     *out = sc;

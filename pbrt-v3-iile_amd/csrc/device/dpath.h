@@ -879,6 +879,8 @@ struct Bsdf {
     F3 kd, ks, kr, kt;
     float alpha, eta;
     int n_lobes;  // nBxDFs; BxDF order: Lambertian, microfacet, specular reflection
+    float on_a, on_b;  // Oren-Nayar constants of the diffuse lobe (oren_nayar set)
+    bool oren_nayar;
     int mtype;    // kMat*: selects the Fresnel terms (plastic 1.5/1; uber 1/eta; mirror none) and, for
                   // glass, makes the specular lobe a FresnelSpecular(kr, kt, 1, eta)
     bool has_lambert, has_micro, has_spec;
@@ -906,6 +908,9 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.ks = F3{0, 0, 0};
     b.has_micro = false;
     b.alpha = m.alpha;
+    b.oren_nayar = EXT && m.type == kMatMatte && m.on_b != 0.f;  // matte.cpp:56-61 (B == 0 iff sigma == 0)
+    b.on_a = m.on_a;
+    b.on_b = m.on_b;
     b.mtype = EXT ? m.type : kMatPlastic;
     b.eta = m.eta;
     if (m.type == kMatPlastic || (EXT && m.type == kMatUber)) {
@@ -1050,10 +1055,31 @@ DEV float micro_pdf(const Bsdf &b, F3 wo, F3 wi) {
     F3 wh = normalize(wo + wi);
     return tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
 }
+// LambertianReflection::f (reflection.cpp:178-180) or OrenNayar::f (reflection.cpp:197-219)
+DEV F3 diffuse_f(const Bsdf &b, F3 wo, F3 wi) {
+    if (!b.oren_nayar) return b.kd * kInvPi;
+    const float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
+    float max_cos = 0;
+    if (double(sin_i) > 1e-4 && double(sin_o) > 1e-4) {
+        const float sin_phi_i = sin_phi(wi), cos_phi_i = cos_phi(wi);
+        const float sin_phi_o = sin_phi(wo), cos_phi_o = cos_phi(wo);
+        const float d_cos = cos_phi_i * cos_phi_o + sin_phi_i * sin_phi_o;
+        max_cos = mx(0.f, d_cos);
+    }
+    float sin_alpha, tan_beta;
+    if (fabsf(wi.z) > fabsf(wo.z)) {
+        sin_alpha = sin_o;
+        tan_beta = sin_i / fabsf(wi.z);
+    } else {
+        sin_alpha = sin_i;
+        tan_beta = sin_o / fabsf(wo.z);
+    }
+    return b.kd * kInvPi * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta);
+}
 DEV float lambert_pdf(F3 wo, F3 wi) { return same_hemisphere(wo, wi) ? fabsf(wi.z) * kInvPi : 0; }
 DEV F3 lobes_f(const Bsdf &b, F3 wo, F3 wi) {
     F3 f = F3{0, 0, 0};
-    if (b.has_lambert) f = f + b.kd * kInvPi;
+    if (b.has_lambert) f = f + diffuse_f(b, wo, wi);
     if (b.has_micro) f = f + micro_f(b, wo, wi);
     return f;
 }
@@ -1106,7 +1132,7 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
         wi = cosine_sample_hemisphere(ur0, u1);
         if (wo.z < 0) wi.z *= -1;
         *pdf = lambert_pdf(wo, wi);
-        f = b.kd * kInvPi;
+        f = diffuse_f(b, wo, wi);
     } else if (pick == 1) {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
         F3 wh = tr_sample_wh(wo, ur0, u1, b.alpha);
         wi = -wo + 2 * dot(wo, wh) * wh;

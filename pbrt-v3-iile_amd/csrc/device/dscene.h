@@ -30,6 +30,7 @@ struct DMaterial {
     float kr[3];  // uber, mirror, glass: specular reflectance
     float eta;    // uber, glass: FresnelDielectric(1, eta)
     float kt[3];  // glass: specular transmittance
+    float on_a, on_b;  // matte with sigma != 0: Oren-Nayar A, B (on_b == 0 and on_a == 1 otherwise)
 };
 enum { kLightDiffuseArea = 0, kLightPoint = 1, kLightSpot = 2, kLightDistant = 3, kLightAreaTriangle = 4,
        kLightInfinite = 5 };  // = IILE_LIGHT_* (checked in api.hip)

@@ -561,10 +561,12 @@ class Loader {
             float kd[3] = {0.5f, 0.5f, 0.5f};
             ps.rgb("Kd", kd);
             for (int i = 0; i < 3; ++i) m.kd[i] = kd[i];
-            m.sigma = ps.one_float("sigma", 0.f);
-            if (clampT(m.sigma, 0.f, 90.f) != 0.f) {
-                fail("matte with sigma != 0 (Oren-Nayar) is not supported");
-                return -1;
+            m.sigma = clampT(ps.one_float("sigma", 0.f), 0.f, 90.f);  // matte.cpp:56
+            if (m.sigma != 0.f) {  // OrenNayar ctor, reflection.h:414-420
+                const float sg = radians(m.sigma);
+                const float sigma2 = sg * sg;
+                m.on_a = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                m.on_b = 0.45f * sigma2 / (sigma2 + 0.09f);
             }
         } else if (name == "plastic" || name == "uber") {
             const bool uber = name == "uber";

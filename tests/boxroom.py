@@ -97,7 +97,8 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         if light in ("distant", "sky") and o[2] == 9:
             continue  # no ceiling
         P, F = _grid_quad(o, du, dv, wall_n)
-        out.append('AttributeBegin\n  Material "matte" "color Kd" [%g %g %g]\n%sAttributeEnd' % (*kd, _mesh(P, F)))
+        rough = ' "float sigma" [%g]' % (20 + 10 * len(out) % 50) if materials == "all" else ""  # Oren-Nayar walls
+        out.append('AttributeBegin\n  Material "matte" "color Kd" [%g %g %g]%s\n%sAttributeEnd' % (*kd, rough, _mesh(P, F)))
     V, F = _icosphere(ico_levels)
     for b in range(n_blobs):
         r = rng.uniform(0.7, 1.6)
