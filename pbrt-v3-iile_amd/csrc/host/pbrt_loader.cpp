@@ -176,11 +176,19 @@ struct ParamSet {
     }
 };
 
+// A named texture, folded to its value: only textures that are constant over the surface are
+// supported ("constant", and "scale" / "mix" of such), so evaluating one at a hit is the same as
+// evaluating it once here (textures/constant.h, scale.h, mix.h).
+struct ConstTexture {
+    bool is_float = true;
+    float v[3] = {0, 0, 0};
+};
 struct GraphicsState {
     int material = -1;  // index into scene->materials, -1 = default matte
     bool has_area_light = false;
     ParamSet area_light_params;
     bool reverse_orientation = false;
+    std::map<std::string, ConstTexture> textures;  // graphicsState.floatTextures / spectrumTextures, api.cpp:1190-1260
 };
 
 class Loader {
@@ -212,6 +220,7 @@ class Loader {
         return false;
     }
     std::string lex_error_;
+    std::map<std::string, int> named_materials_;  // MakeNamedMaterial, api.cpp:1286-1316
 
     bool parse_file(const std::string &path) {
         Lexer lex;
@@ -357,6 +366,29 @@ class Loader {
                 std::string p = n.text;
                 if (p.empty() || p[0] != '/') p = search_dir_ + "/" + p;
                 if (!parse_file(p)) return false;
+            } else if (d == "Texture") {  // pbrtTexture, api.cpp:1190-1260: "name" "float|spectrum|color" "class" params
+                Token n1 = next(), n2 = next(), n3 = next();
+                if (n1.kind != Token::String || n2.kind != Token::String || n3.kind != Token::String)
+                    return fail("Texture: expected \"name\" \"type\" \"class\"");
+                ParamSet ps;
+                if (!params(&ps)) return false;
+                if (!make_texture(n1.text, n2.text, n3.text, ps)) return false;
+            } else if (d == "MakeNamedMaterial") {  // api.cpp:1286-1316
+                Token n = next();
+                if (n.kind != Token::String) return fail("MakeNamedMaterial: expected quoted name");
+                ParamSet ps;
+                if (!params(&ps)) return false;
+                const std::string type = ps.one_string("type", "");
+                if (type.empty()) return fail("MakeNamedMaterial: the \"string type\" parameter is required");
+                const int idx = make_material(type, ps);
+                if (idx < 0) return false;
+                named_materials_[n.text] = idx;
+            } else if (d == "NamedMaterial") {  // api.cpp:1318-1336
+                Token n = next();
+                if (n.kind != Token::String) return fail("NamedMaterial: expected quoted name");
+                auto it = named_materials_.find(n.text);
+                if (it == named_materials_.end()) return fail("NamedMaterial \"" + n.text + "\" unknown.");
+                gs_.material = it->second;
             } else if (d == "Camera" || d == "Film" || d == "Sampler" || d == "Integrator" ||
                        d == "PixelFilter" || d == "Accelerator" || d == "Material" ||
                        d == "AreaLightSource" || d == "Shape" || d == "LightSource") {
@@ -553,7 +585,73 @@ class Loader {
     }
 
     // materials/matte.cpp:64-71, plastic.cpp:72-84, microfacet.h:123-128
-    int make_material(const std::string &name, const ParamSet &ps) {
+    // value of a float / spectrum parameter that may be given directly or as a reference to a named
+    // texture (TextureParams::GetFloatTexture / GetSpectrumTexture, paramset.cpp)
+    bool tex_value(const ParamSet &ps, const std::string &name, bool want_float, const float def[3], float out[3]) {
+        for (int i = 0; i < 3; ++i) out[i] = def[i];
+        const Param *p = ps.find(name);
+        if (!p) return true;
+        if (p->type == "texture") {
+            if (p->strs.size() != 1) return fail("bad texture reference for \"" + name + "\"");
+            auto it = gs_.textures.find(p->strs[0]);
+            if (it == gs_.textures.end() || it->second.is_float != want_float)
+                return fail(std::string("Couldn't find ") + (want_float ? "float" : "spectrum") + " texture named \"" +
+                            p->strs[0] + "\" for parameter \"" + name + "\"");
+            for (int i = 0; i < 3; ++i) out[i] = it->second.v[i];
+            return true;
+        }
+        if (want_float) {
+            if (p->type == "float" && p->nums.size() == 1) out[0] = out[1] = out[2] = float(p->nums[0]);
+        } else if ((p->type == "color" || p->type == "rgb") && p->nums.size() == 3) {
+            for (int i = 0; i < 3; ++i) out[i] = float(p->nums[i]);
+        }
+        return true;
+    }
+    bool make_texture(const std::string &name, const std::string &type, const std::string &cls, const ParamSet &ps) {
+        const bool is_float = type == "float";
+        if (!is_float && type != "spectrum" && type != "color") return fail("Texture type \"" + type + "\" unknown.");
+        const float zero[3] = {0, 0, 0}, one[3] = {1, 1, 1}, half[3] = {.5f, .5f, .5f};
+        ConstTexture t;
+        t.is_float = is_float;
+        if (cls == "constant") {  // CreateConstant*Texture, textures/constant.cpp: "value" default 1
+            if (!tex_value(ps, "value", is_float, one, t.v)) return false;
+        } else if (cls == "scale") {  // ScaleTexture::Evaluate = tex1 * tex2, textures/scale.h:56-58 (defaults 1, 1)
+            float a[3], b[3];
+            if (!tex_value(ps, "tex1", is_float, one, a) || !tex_value(ps, "tex2", is_float, one, b)) return false;
+            for (int i = 0; i < 3; ++i) t.v[i] = a[i] * b[i];
+        } else if (cls == "mix") {  // MixTexture::Evaluate = (1 - amt) * t1 + amt * t2, textures/mix.h:57-61 (0, 1, 0.5)
+            float a[3], b[3], amt[3];
+            if (!tex_value(ps, "tex1", is_float, zero, a) || !tex_value(ps, "tex2", is_float, one, b) ||
+                !tex_value(ps, "amount", true, half, amt))
+                return false;
+            for (int i = 0; i < 3; ++i) t.v[i] = (1 - amt[0]) * a[i] + amt[0] * b[i];
+        } else
+            return fail("Texture class \"" + cls + "\" is not supported (constant, scale, mix of constants)");
+        gs_.textures[name] = t;
+        return true;
+    }
+    // replaces references to named textures among a material's parameters by their values
+    bool resolve_textures(const ParamSet &in, ParamSet *out) {
+        *out = in;
+        for (Param &p : out->params) {
+            if (p.type != "texture") continue;
+            if (p.strs.size() != 1) return fail("bad texture reference for \"" + p.name + "\"");
+            auto it = gs_.textures.find(p.strs[0]);
+            if (it == gs_.textures.end()) return fail("Couldn't find texture named \"" + p.strs[0] + "\" for parameter \"" + p.name + "\"");
+            p.strs.clear();
+            if (it->second.is_float) {
+                p.type = "float";
+                p.nums = {double(it->second.v[0])};
+            } else {
+                p.type = "color";
+                p.nums = {double(it->second.v[0]), double(it->second.v[1]), double(it->second.v[2])};
+            }
+        }
+        return true;
+    }
+    int make_material(const std::string &name, const ParamSet &ps_in) {
+        ParamSet ps;
+        if (!resolve_textures(ps_in, &ps)) return -1;
         iile_material m;
         std::memset(&m, 0, sizeof(m));
         if (name == "matte") {

@@ -221,3 +221,43 @@ def test_plymesh_equals_trianglemesh(binding, oracle, tmp_path, fmt):
     fb, sb = oracle.render(b)
     assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and sa["tri_tests"] == sb["tri_tests"]
     assert float(a.film_to_rgb(fa).mean()) > 1e-3
+
+
+def test_constant_textures_and_named_materials(binding, oracle, tmp_path):
+    """`Texture` of the classes that are constant over a surface ("constant", "scale" and "mix" of such;
+    textures/constant.h, scale.h, mix.h) and `MakeNamedMaterial` / `NamedMaterial` (api.cpp:1190-1336):
+    the scene written with them flattens and renders exactly like the one with the values inline."""
+    head = ('LookAt 0 -6 1.5  0 0 0.3  0 0 1\nCamera "perspective" "float fov" [45]\n'
+            'Film "image" "integer xresolution" [40] "integer yresolution" [28]\nSampler "halton" "integer pixelsamples" [4]\n'
+            'WorldBegin\nAttributeBegin\nTranslate 2 -3 5\nAreaLightSource "diffuse" "color L" [30 30 30]\n'
+            'Shape "sphere" "float radius" [.5]\nAttributeEnd\n')
+    floor = 'Shape "trianglemesh" "point P" [-4 -4 -1  4 -4 -1  4 4 -1  -4 4 -1] "integer indices" [0 1 2 0 2 3]\n'
+    ball = 'AttributeBegin\nTranslate 0 0 0.2\nShape "sphere" "float radius" [1]\nAttributeEnd\n'
+    textured = (head +
+                'Texture "base" "spectrum" "constant" "color value" [.8 .4 .2]\n'
+                'Texture "half" "float" "constant" "float value" [.5]\n'
+                'Texture "dim" "spectrum" "scale" "texture tex1" "base" "color tex2" [.5 .5 .5]\n'
+                'Texture "blend" "spectrum" "mix" "texture tex1" "base" "color tex2" [.1 .2 .9] "texture amount" "half"\n'
+                'Texture "rough" "float" "scale" "float tex1" [.4] "texture tex2" "half"\n'
+                'MakeNamedMaterial "shiny" "string type" "plastic" "texture Kd" "blend" "color Ks" [.3 .3 .3] "texture roughness" "rough"\n'
+                'Material "matte" "texture Kd" "dim" "float sigma" [25]\n' + floor +
+                'NamedMaterial "shiny"\n' + ball + 'WorldEnd\n')
+    f32 = np.float32
+    dim = [f32(.8) * f32(.5), f32(.4) * f32(.5), f32(.2) * f32(.5)]
+    amt = f32(.5)
+    blend = [(f32(1) - amt) * f32(a) + amt * f32(b) for a, b in zip((.8, .4, .2), (.1, .2, .9))]
+    rough = f32(.4) * f32(.5)
+    inline = (head + 'Material "matte" "color Kd" [%.9g %.9g %.9g] "float sigma" [25]\n' % tuple(dim) + floor +
+              'Material "plastic" "color Kd" [%.9g %.9g %.9g] "color Ks" [.3 .3 .3] "float roughness" [%.9g]\n' % (*blend, rough) +
+              ball + 'WorldEnd\n')
+    (tmp_path / "a.pbrt").write_text(textured)
+    (tmp_path / "b.pbrt").write_text(inline)
+    a = binding.HostScene(path=str(tmp_path / "a.pbrt"))
+    b = binding.HostScene(path=str(tmp_path / "b.pbrt"))
+    assert a.info == b.info and a.info["n_materials"] == 3  # light's default material + the two above
+    fa, _ = oracle.render(a)
+    fb, _ = oracle.render(b)
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)) and float(a.film_to_rgb(fa).mean()) > 1e-3
+    (tmp_path / "c.pbrt").write_text(head + 'Material "matte" "texture Kd" "nope"\n' + floor + 'WorldEnd\n')
+    with pytest.raises(RuntimeError, match="nope"):
+        binding.HostScene(path=str(tmp_path / "c.pbrt"))
