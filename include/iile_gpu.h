@@ -114,6 +114,9 @@ int iile_li_samples(iile_scene *scene, int32_t n, const int32_t *px, const int32
  * {wi.xyz, f.rgb, pdf}) of material `mat` in the canonical frame ns=ng=+z, ss=+x. */
 int iile_bsdf_eval(iile_scene *scene, int32_t n, int32_t mat, const float *wo3, const float *wi3, float *out4);
 int iile_bsdf_sample(iile_scene *scene, int32_t n, int32_t mat, const float *wo3, const float *u2, float *out7);
+/* ImageTexture<RGBSpectrum, Spectrum>::Evaluate (src/textures/imagemap.h:87-94) of image texture `tex` at n
+ * surface points given by (u, v) and the screen-space differentials {du/dx, dv/dx, du/dy, dv/dy}. */
+int iile_texture_eval(iile_scene *scene, int32_t tex, int32_t n, const float *uv2, const float *duv4, float *rgb3);
 /* portable sin / cos / acos used on the device: out[3i..] = {sin x, cos x, acos clamp(x)} */
 int iile_trig_probe(int32_t n, const float *x, float *out3);
 

@@ -62,6 +62,15 @@ int iile_host_film_to_rgb(const iile_film_desc *film, const float *film_xyzw, fl
  * own float format, src/core/imageio.cpp WriteImagePFM: bottom-to-top scanlines). */
 int iile_host_write_pfm(const char *path, const float *rgb, int32_t width, int32_t height);
 
+/* ReadImage (src/core/imageio.cpp:60-82) for .pfm / .png / .tga: RGB floats, row 0 = top scanline. Call with
+ * rgb == NULL to get the size, then with a buffer of 3 * width * height floats. */
+int iile_host_read_image(const char *path, int32_t *width, int32_t *height, float *rgb);
+/* The MIP pyramid built for image texture `index` of a loaded scene (ImageTexture::GetTexture + MIPMap's
+ * constructor, src/textures/imagemap.cpp:53-101, src/core/mipmap.h:111-208). */
+int iile_host_scene_texture(const iile_host_scene *scene, int32_t index, iile_texture *out);
+/* Copies level `level` (level_w x level_h RGB texels, row 0 = bottom scanline) of that texture. */
+int iile_host_scene_texture_level(const iile_host_scene *scene, int32_t index, int32_t level, float *rgb);
+
 const char *iile_host_last_error(void);
 
 #ifdef __cplusplus

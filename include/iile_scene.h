@@ -69,7 +69,31 @@ typedef struct iile_material {
     float kr[3];     /* uber, mirror, glass: specular reflectance */
     float kt[3];     /* glass: specular transmittance */
     float on_a, on_b; /* matte with sigma != 0: the Oren-Nayar constants A, B (reflection.h:416-419) */
+    /* image textures (index into iile_scene_desc::textures) that replace the constant kd / ks / kr / kt at a
+     * hit, or -1: Texture<Spectrum>::Evaluate of an ImageTexture (textures/imagemap.h:87-94) */
+    int32_t kd_tex, ks_tex, kr_tex, kt_tex;
 } iile_material;
+
+/* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (src/textures/imagemap.h:78-112,
+ * src/core/texture.cpp:170-180) with its MIPMap (src/core/mipmap.h:61-110): the pyramid is built on the
+ * host exactly as MIPMap's constructor does (Lanczos resampling to powers of two, 2x2 box levels) and
+ * handed over as plain arrays. Level l is level_w[l] x level_h[l] RGB texels, row-major (t * w + s), row 0 =
+ * the image's BOTTOM scanline (imagemap.cpp:67-74 flips), starting at float index 3 * level_offset[l]
+ * of iile_scene_desc::texels. */
+#define IILE_MAX_TEX_LEVELS 16
+#define IILE_WRAP_REPEAT 0
+#define IILE_WRAP_BLACK 1
+#define IILE_WRAP_CLAMP 2
+#define IILE_EWA_LUT_SIZE 128
+typedef struct iile_texture {
+    int32_t n_levels;
+    int32_t wrap;      /* IILE_WRAP_* */
+    int32_t trilinear; /* doTrilinear */
+    float max_aniso;
+    float su, sv, du, dv; /* UVMapping2D */
+    int32_t level_w[IILE_MAX_TEX_LEVELS], level_h[IILE_MAX_TEX_LEVELS];
+    int64_t level_offset[IILE_MAX_TEX_LEVELS]; /* in texels */
+} iile_texture;
 
 /* A light: DiffuseAreaLight on a shape (src/lights/diffuse.h:48-75) or one of the delta lights
  * PointLight (src/lights/point.h:49-70), SpotLight (src/lights/spot.h:49-74), DistantLight
@@ -107,6 +131,9 @@ typedef struct iile_camera {
     float raster_to_camera[16];
     float camera_to_world[16];
     float lens_radius, focal_distance, shutter_open, shutter_close;
+    /* dxCamera, dyCamera: RasterToCamera((1,0,0)) - RasterToCamera((0,0,0)) and the same for y
+     * (perspective.cpp:58-62); the ray differentials of camera rays are built from them */
+    float dx_camera[3], dy_camera[3];
 } iile_camera;
 
 /* Film + box filter (src/core/film.cpp:45-91, src/filters/box.cpp:41-47). */
@@ -158,6 +185,11 @@ typedef struct iile_scene_desc {
     const iile_material *materials;
     int32_t n_lights;
     const iile_light *lights;
+    int32_t n_textures;
+    const iile_texture *textures;
+    int64_t n_texels;              /* RGB texels in all levels of all textures */
+    const float *texels;           /* [3 * n_texels] */
+    float ewa_lut[IILE_EWA_LUT_SIZE]; /* MIPMap::weightLut, mipmap.h:199-205 */
     iile_camera camera;
     iile_film_desc film;
     iile_halton halton;

@@ -83,6 +83,13 @@ void oracle_bsdf_sample_batch(const iile_scene_desc *scene, int trig_mode, int m
                               const float *u2n, float *wi3n, float *pdfn);
 void oracle_bsdf_pdf_batch(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3, int n,
                            const float *wi3n, float *pdfn);
+/* ImageTexture::Evaluate of texture `tex` at n (u, v) with differentials {dudx, dvdx, dudy, dvdy} */
+void oracle_texture_eval(const iile_scene_desc *scene, int trig_mode, int tex, int n, const float *uv2, const float *duv4,
+                         float *rgb3);
+/* first hit of the camera ray through film point (pfx, pfy): {u, v, du/dx, dv/dx, du/dy, dv/dy} as
+ * ComputeDifferentials leaves them (interaction.cpp:103-149); returns 0 when the ray escapes */
+int oracle_camera_hit_differentials(const iile_scene_desc *scene, int trig_mode, float pfx, float pfy, float *out6);
+float oracle_log(int trig_mode, float x);
 void oracle_sincos(int trig_mode, float x, float *s, float *c);
 void oracle_sincos_d(int trig_mode, double x, double *s, double *c);
 float oracle_acos(int trig_mode, float x);

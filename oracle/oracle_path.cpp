@@ -264,8 +264,45 @@ double portable_atan2(double y, double x) {
     }
 }
 
+// Natural logarithm in double: x = 2^k * m with sqrt(1/2) < m <= sqrt(2), log(m) from the atanh series in
+// s = (m - 1) / (m + 1) with the classic minimax coefficients. Error well below a float ulp; restated
+// operation for operation on the device (dmath.h log_d). x must be a positive finite normal double.
+double portable_log(double x) {
+    if (std::isnan(x) || x < 0) return std::numeric_limits<double>::quiet_NaN();
+    if (x == 0) return -std::numeric_limits<double>::infinity();
+    if (std::isinf(x)) return x;
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                        Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                        Lg7 = 1.479819860511658591e-01;
+    uint64_t bits;
+    std::memcpy(&bits, &x, 8);
+    int k = int((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    std::memcpy(&m, &bits, 8);
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        k += 1;
+    }
+    const double f = m - 1.0;
+    const double sq = f / (2.0 + f);
+    const double z = sq * sq;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = double(k);
+    return dk * ln2_hi - ((hfsq - (sq * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
 struct Trig {
     int mode;
+    float log_f(float x) const {
+        if (mode == ORACLE_TRIG_LIBM) return std::log(x);
+        return float(portable_log(double(x)));
+    }
     float sin_f(float x) const {
         if (mode == ORACLE_TRIG_LIBM) return std::sin(x);
         double s, c;
@@ -522,6 +559,16 @@ struct Isect {
     V3 p, perr, n, wo;
     V3 sn;     // shading.n
     V3 sdpdu;  // shading.dpdu
+    // what texture lookups need (triangles only): uv, dpdu, dpdv and, after compute_differentials, du/dx ...
+    float uv[2] = {0, 0};
+    V3 dpdu, dpdv;
+    float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
+};
+
+// the auxiliary rays of a RayDifferential (geometry.h:890-925)
+struct RayDiff {
+    bool has = false;
+    V3 rxo, ryo, rxd, ryd;
 };
 
 struct Oracle {
@@ -647,7 +694,9 @@ struct Oracle {
 
     // ------------------------------------------------------------------------
     // camera (cameras/perspective.cpp:100-149; transform.h:251-264)
-    Ray camera_ray(float pfx, float pfy, const float *plens) const {
+    // with `rd`: GenerateRayDifferential (perspective.cpp:100-149) followed by the render loop's
+    // ScaleDifferentials(1 / sqrt(spp)) (integrator.cpp:284-285, geometry.h:908-913)
+    Ray camera_ray(float pfx, float pfy, const float *plens, RayDiff *rd = nullptr) const {
         const iile_camera &c = S.camera;
         V3 pcam = xf_point(M4{c.raster_to_camera}, V3(pfx, pfy, 0));
         V3 dir = normalize(V3(pcam.x, pcam.y, pcam.z));
@@ -662,6 +711,30 @@ struct Oracle {
             r.o = V3(lx, ly, 0);
             r.d = normalize(pfocus - r.o);
         }
+        V3 rxo, ryo, rxd, ryd;
+        if (rd) {
+            const V3 dxc(c.dx_camera[0], c.dx_camera[1], c.dx_camera[2]), dyc(c.dy_camera[0], c.dy_camera[1], c.dy_camera[2]);
+            if (c.lens_radius > 0) {
+                float lx, ly;
+                concentric_sample_disk(plens, &lx, &ly);
+                lx = c.lens_radius * lx;
+                ly = c.lens_radius * ly;
+                V3 dx = normalize(pcam + dxc);
+                float ft = c.focal_distance / dx.z;
+                V3 pfocus = V3(0, 0, 0) + (ft * dx);
+                rxo = V3(lx, ly, 0);
+                rxd = normalize(pfocus - rxo);
+                V3 dy = normalize(pcam + dyc);
+                ft = c.focal_distance / dy.z;
+                pfocus = V3(0, 0, 0) + (ft * dy);
+                ryo = V3(lx, ly, 0);
+                ryd = normalize(pfocus - ryo);
+            } else {
+                rxo = ryo = r.o;
+                rxd = normalize(pcam + dxc);
+                ryd = normalize(pcam + dyc);
+            }
+        }
         M4 m{c.camera_to_world};
         V3 oerr;
         V3 o = xf_point_err(m, r.o, &oerr);
@@ -673,7 +746,166 @@ struct Oracle {
             o = o + d * dt;
             tmax -= dt;
         }
+        if (rd) {  // Transform::operator()(RayDifferential), transform.h:265-274
+            rxo = xf_point(m, rxo);
+            ryo = xf_point(m, ryo);
+            rxd = xf_vector(m, rxd);
+            ryd = xf_vector(m, ryd);
+            const float sc = 1 / std::sqrt(float(S.halton.spp));
+            rd->has = true;
+            rd->rxo = o + (rxo - o) * sc;
+            rd->ryo = o + (ryo - o) * sc;
+            rd->rxd = d + (rxd - d) * sc;
+            rd->ryd = d + (ryd - d) * sc;
+        }
         return Ray{o, d, tmax};
+    }
+
+    // SurfaceInteraction::ComputeDifferentials (interaction.cpp:103-149); only du/dx ... are kept
+    // (dpdx, dpdy feed bump mapping and the non-uv mappings only)
+    static bool solve_2x2(const float A[2][2], const float B[2], float *x0, float *x1) {  // transform.cpp:41-49
+        float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+        if (std::abs(det) < 1e-10f) return false;
+        *x0 = (A[1][1] * B[0] - A[0][1] * B[1]) / det;
+        *x1 = (A[0][0] * B[1] - A[1][0] * B[0]) / det;
+        if (std::isnan(*x0) || std::isnan(*x1)) return false;
+        return true;
+    }
+    static void compute_differentials(Isect *is, const RayDiff &rd) {
+        is->dudx = is->dvdx = is->dudy = is->dvdy = 0;
+        if (!rd.has) return;
+        const V3 n = is->n, p = is->p;
+        float d = dot(n, p);
+        float tx = -(dot(n, rd.rxo) - d) / dot(n, rd.rxd);
+        if (std::isinf(tx) || std::isnan(tx)) return;
+        V3 px = rd.rxo + tx * rd.rxd;
+        float ty = -(dot(n, rd.ryo) - d) / dot(n, rd.ryd);
+        if (std::isinf(ty) || std::isnan(ty)) return;
+        V3 py = rd.ryo + ty * rd.ryd;
+        int dim[2];
+        if (std::abs(n.x) > std::abs(n.y) && std::abs(n.x) > std::abs(n.z)) {
+            dim[0] = 1;
+            dim[1] = 2;
+        } else if (std::abs(n.y) > std::abs(n.z)) {
+            dim[0] = 0;
+            dim[1] = 2;
+        } else {
+            dim[0] = 0;
+            dim[1] = 1;
+        }
+        float A[2][2] = {{is->dpdu[dim[0]], is->dpdv[dim[0]]}, {is->dpdu[dim[1]], is->dpdv[dim[1]]}};
+        float Bx[2] = {px[dim[0]] - p[dim[0]], px[dim[1]] - p[dim[1]]};
+        float By[2] = {py[dim[0]] - p[dim[0]], py[dim[1]] - p[dim[1]]};
+        if (!solve_2x2(A, Bx, &is->dudx, &is->dvdx)) is->dudx = is->dvdx = 0;
+        if (!solve_2x2(A, By, &is->dudy, &is->dvdy)) is->dudy = is->dvdy = 0;
+    }
+
+    // ------------------------------------------------------------------------
+    // ImageTexture<RGBSpectrum, Spectrum>::Evaluate over UVMapping2D (imagemap.h:87-94, texture.cpp:93-99)
+    // and MIPMap<RGBSpectrum>::Lookup / triangle / EWA / Texel (mipmap.h:210-355) on the host-built pyramid
+    Rgb tex_texel(const iile_texture &t, int level, int s, int tt) const {
+        const int w = t.level_w[level], h = t.level_h[level];
+        auto mod = [](int a, int b) {
+            int r = a - (a / b) * b;
+            return r < 0 ? r + b : r;
+        };
+        switch (t.wrap) {
+        case IILE_WRAP_REPEAT:
+            s = mod(s, w);
+            tt = mod(tt, h);
+            break;
+        case IILE_WRAP_CLAMP:
+            s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s);
+            tt = tt < 0 ? 0 : (tt > h - 1 ? h - 1 : tt);
+            break;
+        default:
+            if (s < 0 || s >= w || tt < 0 || tt >= h) return Rgb(0.f);
+        }
+        const float *c = S.texels + 3 * (t.level_offset[level] + int64_t(tt) * w + s);
+        return Rgb(c[0], c[1], c[2]);
+    }
+    Rgb tex_triangle(const iile_texture &t, int level, const float st[2]) const {
+        level = level < 0 ? 0 : (level > t.n_levels - 1 ? t.n_levels - 1 : level);
+        float s = st[0] * t.level_w[level] - 0.5f;
+        float tt = st[1] * t.level_h[level] - 0.5f;
+        int s0 = int(std::floor(s)), t0 = int(std::floor(tt));
+        float ds = s - s0, dt = tt - t0;
+        return tex_texel(t, level, s0, t0) * ((1 - ds) * (1 - dt)) + tex_texel(t, level, s0, t0 + 1) * ((1 - ds) * dt) +
+               tex_texel(t, level, s0 + 1, t0) * (ds * (1 - dt)) + tex_texel(t, level, s0 + 1, t0 + 1) * (ds * dt);
+    }
+    float log2_f(float x) const {  // pbrt.h:325-328
+        const float inv_log2 = 1.442695040888963387004650940071f;
+        return trig.log_f(x) * inv_log2;
+    }
+    static Rgb lerp_rgb(float t, Rgb a, Rgb b) { return a * (1 - t) + b * t; }
+    Rgb tex_lookup_width(const iile_texture &t, const float st[2], float width) const {  // mipmap.h:233-250
+        float level = t.n_levels - 1 + log2_f(std::max(width, 1e-8f));
+        if (level < 0) return tex_triangle(t, 0, st);
+        if (level >= t.n_levels - 1) return tex_texel(t, t.n_levels - 1, 0, 0);
+        int il = int(std::floor(level));
+        float delta = level - il;
+        return lerp_rgb(delta, tex_triangle(t, il, st), tex_triangle(t, il + 1, st));
+    }
+    Rgb tex_ewa(const iile_texture &t, int level, const float st_in[2], const float d0_in[2], const float d1_in[2]) const {
+        if (level >= t.n_levels) return tex_texel(t, t.n_levels - 1, 0, 0);
+        const int w = t.level_w[level], h = t.level_h[level];
+        float st[2] = {st_in[0] * w - 0.5f, st_in[1] * h - 0.5f};
+        float d0[2] = {d0_in[0] * w, d0_in[1] * h}, d1[2] = {d1_in[0] * w, d1_in[1] * h};
+        float A = d0[1] * d0[1] + d1[1] * d1[1] + 1;
+        float B = -2 * (d0[0] * d0[1] + d1[0] * d1[1]);
+        float C = d0[0] * d0[0] + d1[0] * d1[0] + 1;
+        float invF = 1 / (A * C - B * B * 0.25f);
+        A *= invF;
+        B *= invF;
+        C *= invF;
+        float det = -B * B + 4 * A * C;
+        float inv_det = 1 / det;
+        float u_sqrt = std::sqrt(det * C), v_sqrt = std::sqrt(A * det);
+        int s0 = int(std::ceil(st[0] - 2 * inv_det * u_sqrt));
+        int s1 = int(std::floor(st[0] + 2 * inv_det * u_sqrt));
+        int t0 = int(std::ceil(st[1] - 2 * inv_det * v_sqrt));
+        int t1 = int(std::floor(st[1] + 2 * inv_det * v_sqrt));
+        Rgb sum(0.f);
+        float sum_wts = 0;
+        for (int it = t0; it <= t1; ++it) {
+            float tt = it - st[1];
+            for (int is = s0; is <= s1; ++is) {
+                float ss = is - st[0];
+                float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+                if (r2 < 1) {
+                    int index = std::min(int(r2 * IILE_EWA_LUT_SIZE), IILE_EWA_LUT_SIZE - 1);
+                    float weight = S.ewa_lut[index];
+                    sum = sum + tex_texel(t, level, is, it) * weight;
+                    sum_wts += weight;
+                }
+            }
+        }
+        return sum / sum_wts;
+    }
+    Rgb tex_evaluate(int tex, const Isect &is) const {
+        const iile_texture &t = S.textures[tex];
+        float d0[2] = {t.su * is.dudx, t.sv * is.dvdx}, d1[2] = {t.su * is.dudy, t.sv * is.dvdy};
+        const float st[2] = {t.su * is.uv[0] + t.du, t.sv * is.uv[1] + t.dv};
+        if (t.trilinear) {
+            float width = std::max(std::max(std::abs(d0[0]), std::abs(d0[1])), std::max(std::abs(d1[0]), std::abs(d1[1])));
+            return tex_lookup_width(t, st, 2 * width);
+        }
+        if (d0[0] * d0[0] + d0[1] * d0[1] < d1[0] * d1[0] + d1[1] * d1[1]) {
+            std::swap(d0[0], d1[0]);
+            std::swap(d0[1], d1[1]);
+        }
+        float major = std::sqrt(d0[0] * d0[0] + d0[1] * d0[1]);
+        float minor = std::sqrt(d1[0] * d1[0] + d1[1] * d1[1]);
+        if (minor * t.max_aniso < major && minor > 0) {
+            float scale = major / (minor * t.max_aniso);
+            d1[0] *= scale;
+            d1[1] *= scale;
+            minor *= scale;
+        }
+        if (minor == 0) return tex_triangle(t, 0, st);
+        float lod = std::max(0.f, t.n_levels - 1.f + log2_f(minor));
+        int ilod = int(std::floor(lod));
+        return lerp_rgb(lod - ilod, tex_ewa(t, ilod, st, d0, d1), tex_ewa(t, ilod + 1, st, d0, d1));
     }
 
     // ------------------------------------------------------------------------
@@ -792,6 +1024,10 @@ struct Oracle {
         float zs = (std::abs(b0 * p0.z) + std::abs(b1 * p1.z) + std::abs(b2 * p2.z));
         is->perr = gamma_n(7) * V3(xs, ys, zs);
         is->p = b0 * p0 + b1 * p1 + b2 * p2;
+        is->uv[0] = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];  // uvHit, triangle.cpp:318
+        is->uv[1] = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
+        is->dpdu = dpdu;
+        is->dpdv = dpdv;
         is->wo = normalize(-ray.d);  // Interaction ctor normalises wo, interaction.h:60
         V3 n = normalize(cross(dp02, dp12));
         const bool flip = (flags & IILE_PRIM_FLIP) != 0;
@@ -1096,7 +1332,13 @@ struct Oracle {
         auto clamp0 = [](const float *c) {
             return Rgb(clampf(c[0], 0, Infinity), clampf(c[1], 0, Infinity), clampf(c[2], 0, Infinity));
         };
-        Rgb kd = clamp0(m.kd);
+        // a parameter given as an image texture is looked up at the hit (Texture::Evaluate(*si))
+        auto param = [&](const float *constant, int tex) {
+            if (tex < 0) return clamp0(constant);
+            Rgb v = tex_evaluate(tex, is);
+            return clamp0(v.c);
+        };
+        Rgb kd = param(m.kd, m.kd_tex);
         if (!kd.is_black()) {
             b.has_lambert = true;
             b.kd = kd;
@@ -1108,7 +1350,7 @@ struct Oracle {
             }
         }
         if (m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) {
-            Rgb ks = clamp0(m.ks);
+            Rgb ks = param(m.ks, m.ks_tex);
             if (!ks.is_black()) {
                 b.has_micro = true;
                 b.ks = ks;
@@ -1121,7 +1363,7 @@ struct Oracle {
             }
         }
         if (m.type == IILE_MAT_UBER || m.type == IILE_MAT_MIRROR) {
-            Rgb kr = clamp0(m.kr);
+            Rgb kr = param(m.kr, m.kr_tex);
             if (!kr.is_black()) {
                 b.has_spec = true;
                 b.kr = kr;
@@ -1133,7 +1375,7 @@ struct Oracle {
         }
         if (m.type == IILE_MAT_GLASS) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
             b.eta = m.eta;
-            Rgb R = clamp0(m.kr), T = clamp0(m.kt);
+            Rgb R = param(m.kr, m.kr_tex), T = param(m.kt, m.kt_tex);
             if (!(R.is_black() && T.is_black())) {
                 b.has_spec = true;
                 b.spec_glass = true;
@@ -1913,7 +2155,7 @@ struct Oracle {
 
     // ------------------------------------------------------------------------
     // PathIntegrator::Li, integrators/path.cpp:64-194
-    Rgb li(Ray ray, Sampler &smp) const {
+    Rgb li(Ray ray, Sampler &smp, RayDiff rdiff = RayDiff()) const {
         Rgb L(0.f), beta(1.f);
         bool specular_bounce = false;
         int bounces;
@@ -1931,6 +2173,10 @@ struct Oracle {
                         if (S.lights[l].type == IILE_LIGHT_INFINITE) L = L + beta * inf_le(S.lights[l], ray.d);
             }
             if (!found || bounces >= max_depth) break;
+            // isect.ComputeScatteringFunctions(ray, ...): ComputeDifferentials first (interaction.cpp:95-101);
+            // only the camera ray has differentials (spawned rays are plain Rays, path.cpp:159)
+            if (S.n_textures > 0) compute_differentials(&is, rdiff);
+            rdiff.has = false;
             Bsdf bsdf = make_bsdf(is);
             // UniformLightDistribution::Lookup ignores the point; SampleDiscrete
             // still consumes one 1D sample (integrator.cpp:95).
@@ -1998,9 +2244,10 @@ struct Oracle {
         smp.get1d();  // time
         float plens[2];
         smp.get2d(plens);
-        Ray ray = camera_ray(pfilm[0], pfilm[1], plens);
+        RayDiff rdiff;
+        Ray ray = camera_ray(pfilm[0], pfilm[1], plens, S.n_textures > 0 ? &rdiff : nullptr);
         ++ctr->camera_rays;
-        Rgb L = li(ray, smp);
+        Rgb L = li(ray, smp, rdiff);
         if (L.has_nans())
             L = Rgb(0.f);
         else if (L.y() < -1e-5)
@@ -2286,6 +2533,43 @@ void oracle_bsdf_pdf_batch(const iile_scene_desc *scene, int trig_mode, int mat,
     V3 wo(wo3[0], wo3[1], wo3[2]);
     for (int i = 0; i < n; ++i)
         pdfn[i] = Oracle::bsdf_pdf(b, wo, V3(wi3n[3 * i], wi3n[3 * i + 1], wi3n[3 * i + 2]));
+}
+void oracle_texture_eval(const iile_scene_desc *scene, int trig_mode, int tex, int n, const float *uv2, const float *duv4,
+                         float *rgb3) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    for (int i = 0; i < n; ++i) {
+        Isect is;
+        is.uv[0] = uv2[2 * i];
+        is.uv[1] = uv2[2 * i + 1];
+        is.dudx = duv4[4 * i];
+        is.dvdx = duv4[4 * i + 1];
+        is.dudy = duv4[4 * i + 2];
+        is.dvdy = duv4[4 * i + 3];
+        Rgb v = orc.tex_evaluate(tex, is);
+        for (int k = 0; k < 3; ++k) rgb3[3 * i + k] = v.c[k];
+    }
+}
+int oracle_camera_hit_differentials(const iile_scene_desc *scene, int trig_mode, float pfx, float pfy, float *out6) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    const float plens[2] = {0.5f, 0.5f};
+    RayDiff rd;
+    Ray ray = orc.camera_ray(pfx, pfy, plens, &rd);
+    Isect is;
+    if (!orc.intersect(ray, &is)) return 0;
+    Oracle::compute_differentials(&is, rd);
+    out6[0] = is.uv[0];
+    out6[1] = is.uv[1];
+    out6[2] = is.dudx;
+    out6[3] = is.dvdx;
+    out6[4] = is.dudy;
+    out6[5] = is.dvdy;
+    return 1;
+}
+float oracle_log(int trig_mode, float x) {
+    Trig t{trig_mode};
+    return t.log_f(x);
 }
 void oracle_sincos(int trig_mode, float x, float *s, float *c) {
     Trig t{trig_mode};

@@ -36,6 +36,13 @@ class FilmDesc(ctypes.Structure):
                 ] + [(n, c_f32) for n in "filter_rx filter_ry scale max_sample_luminance".split()]
 
 
+class Texture(ctypes.Structure):
+    """iile_texture (include/iile_scene.h)."""
+    _fields_ = [("n_levels", c_i32), ("wrap", c_i32), ("trilinear", c_i32), ("max_aniso", c_f32), ("su", c_f32),
+                ("sv", c_f32), ("du", c_f32), ("dv", c_f32), ("level_w", c_i32 * 16), ("level_h", c_i32 * 16),
+                ("level_offset", ctypes.c_int64 * 16)]
+
+
 class RenderParams(ctypes.Structure):
     _fields_ = [("k_begin", c_i32), ("k_end", c_i32), ("tile_rank", c_i32), ("tile_nranks", c_i32),
                 ("spp_per_pass", c_i32), ("collect_stats", c_i32), ("time_kernels", c_i32),
@@ -63,10 +70,11 @@ class GpuStats(ctypes.Structure):
 
 # every symbol the headers declare; checked by tests/test_abi.py
 HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_film", "iile_host_scene_get_info",
-                "iile_host_scene_free", "iile_host_film_to_rgb", "iile_host_write_pfm", "iile_host_last_error"]
+                "iile_host_scene_free", "iile_host_film_to_rgb", "iile_host_write_pfm", "iile_host_last_error", "iile_host_read_image",
+                "iile_host_scene_texture", "iile_host_scene_texture_level"]
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
-               "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe"]
+               "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval"]
 
 _host = None
 _gpu = None
@@ -90,8 +98,23 @@ def host_lib():
         lib.iile_host_scene_free.restype = None
         lib.iile_host_film_to_rgb.argtypes = [ctypes.POINTER(FilmDesc), c_vp, c_vp]
         lib.iile_host_write_pfm.argtypes = [ctypes.c_char_p, c_vp, c_i32, c_i32]
+        lib.iile_host_read_image.argtypes = [ctypes.c_char_p, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_vp]
+        lib.iile_host_scene_texture.argtypes = [c_vp, c_i32, ctypes.POINTER(Texture)]
+        lib.iile_host_scene_texture_level.argtypes = [c_vp, c_i32, c_i32, c_vp]
         _host = lib
     return _host
+
+
+def read_image(path):
+    """ReadImage for .pfm / .png / .tga: (H, W, 3) float32, row 0 = top scanline."""
+    lib = host_lib()
+    w, h = c_i32(), c_i32()
+    if lib.iile_host_read_image(os.fsencode(path), ctypes.byref(w), ctypes.byref(h), None) != 0:
+        raise RuntimeError(lib.iile_host_last_error().decode())
+    rgb = np.empty((h.value, w.value, 3), np.float32)
+    if lib.iile_host_read_image(os.fsencode(path), ctypes.byref(w), ctypes.byref(h), rgb.ctypes.data) != 0:
+        raise RuntimeError(lib.iile_host_last_error().decode())
+    return rgb
 
 
 def gpu_lib():
@@ -115,6 +138,7 @@ def gpu_lib():
         lib.iile_camera_rays.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]
         lib.iile_li_samples.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         lib.iile_bsdf_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
+        lib.iile_texture_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_bsdf_sample.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
         _gpu = lib
@@ -160,6 +184,19 @@ class HostScene:
         if rc != 0:
             raise RuntimeError(host_lib().iile_host_last_error().decode())
         return rgb
+
+    def texture(self, index):
+        """(iile_texture, [level arrays (h, w, 3), row 0 = bottom scanline]) of image texture `index`."""
+        lib = host_lib()
+        t = Texture()
+        if lib.iile_host_scene_texture(self._h, index, ctypes.byref(t)) != 0:
+            raise RuntimeError(lib.iile_host_last_error().decode())
+        levels = []
+        for l in range(t.n_levels):
+            a = np.empty((t.level_h[l], t.level_w[l], 3), np.float32)
+            lib.iile_host_scene_texture_level(self._h, index, l, a.ctypes.data)
+            levels.append(a)
+        return t, levels
 
     def write_pfm(self, path, rgb):
         rgb = _f32(rgb)
@@ -267,6 +304,14 @@ class GpuScene:
         out = np.empty((len(wo), 4), np.float32)
         self._check(gpu_lib().iile_bsdf_eval(self._s, len(wo), mat, wo.ctypes.data, wi.ctypes.data, out.ctypes.data),
                     "iile_bsdf_eval")
+        return out
+
+    def texture_eval(self, tex, uv, duv):
+        """ImageTexture::Evaluate at (n, 2) uv with (n, 4) differentials {dudx, dvdx, dudy, dvdy} -> (n, 3) RGB."""
+        uv, duv = _f32(uv), _f32(duv)
+        out = np.empty((len(uv), 3), np.float32)
+        self._check(gpu_lib().iile_texture_eval(self._s, tex, len(uv), uv.ctypes.data, duv.ctypes.data, out.ctypes.data),
+                    "iile_texture_eval")
         return out
 
     def bsdf_sample(self, mat, wo, u):

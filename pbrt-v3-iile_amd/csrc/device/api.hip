@@ -211,7 +211,7 @@ int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed
             rc = timed_launch(6, [&] { launch_miss(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
         }
-        rc = timed_launch(2, [&] { launch_shade(S, B, b, B.queue_cap, cfg); });
+        rc = timed_launch(2, [&] { launch_shade(S, P, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (b < sc->max_depth) {
             // MIS rays first: the shadow kernel finishes each record (L += beta * Ld)
@@ -520,9 +520,52 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             mats[i].on_b = oren_nayar ? m.on_b : 0.f;
             if (m.type == IILE_MAT_GLASS) S.has_glass = 1;
             mats[i].eta = m.eta;
+            mats[i].kd_tex = d->n_textures > 0 ? m.kd_tex : -1;
+            mats[i].ks_tex = d->n_textures > 0 ? m.ks_tex : -1;
+            mats[i].kr_tex = d->n_textures > 0 ? m.kr_tex : -1;
+            mats[i].kt_tex = d->n_textures > 0 ? m.kt_tex : -1;
+            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex})
+                if (t >= d->n_textures) return bail(fail(IILE_ERR_ARG, "material refers to a texture that does not exist"));
         }
         rc = upload(sc, mats.data(), mats.size(), &S.materials);
         if (rc) return bail(rc);
+        // image textures: the host-built pyramids, texels widened to float4 (one 16-byte load each)
+        S.n_textures = d->n_textures;
+        if (d->n_textures > 0) {
+            std::vector<DTexture> tx(d->n_textures);
+            for (int i = 0; i < d->n_textures; ++i) {
+                const iile_texture &t = d->textures[i];
+                if (t.n_levels < 1 || t.n_levels > kMaxTexLevels) return bail(fail(IILE_ERR_ARG, "texture with a bad level count"));
+                tx[i].n_levels = t.n_levels;
+                tx[i].wrap = t.wrap;
+                tx[i].trilinear = t.trilinear;
+                tx[i].max_aniso = t.max_aniso;
+                tx[i].su = t.su, tx[i].sv = t.sv, tx[i].du = t.du, tx[i].dv = t.dv;
+                for (int l = 0; l < kMaxTexLevels; ++l) {
+                    tx[i].level_w[l] = l < t.n_levels ? t.level_w[l] : 1;
+                    tx[i].level_h[l] = l < t.n_levels ? t.level_h[l] : 1;
+                    tx[i].level_offset[l] = l < t.n_levels ? t.level_offset[l] : 0;
+                    if (l < t.n_levels && (t.level_offset[l] < 0 || t.level_offset[l] + int64_t(t.level_w[l]) * t.level_h[l] > d->n_texels))
+                        return bail(fail(IILE_ERR_ARG, "texture level outside the texel array"));
+                }
+            }
+            rc = upload(sc, tx.data(), tx.size(), &S.textures);
+            if (rc) return bail(rc);
+            std::vector<float4> tex4(size_t(d->n_texels));
+            for (int64_t i = 0; i < d->n_texels; ++i)
+                tex4[size_t(i)] = make_float4(d->texels[3 * i], d->texels[3 * i + 1], d->texels[3 * i + 2], 0.f);
+            rc = upload(sc, tex4.data(), tex4.size(), &S.texels);
+            if (rc) return bail(rc);
+            rc = upload(sc, d->ewa_lut, size_t(IILE_EWA_LUT_SIZE), &S.ewa_lut);
+            if (rc) return bail(rc);
+            // textures are looked up through a triangle's (u, v): a sphere would need its own parametrisation
+            for (int i = 0; i < d->n_prims; ++i)
+                if ((d->prim_flags[i] & IILE_PRIM_SPHERE) && d->prim_material[i] >= 0) {
+                    const iile_material &m = d->materials[d->prim_material[i]];
+                    if (m.kd_tex >= 0 || m.ks_tex >= 0 || m.kr_tex >= 0 || m.kt_tex >= 0)
+                        return bail(fail(IILE_ERR_UNSUPPORTED, "image textures on spheres are not supported"));
+                }
+        }
         std::vector<DLight> lts(d->n_lights);
         for (int i = 0; i < d->n_lights; ++i) {
             for (int c = 0; c < 3; ++c) lts[i].lemit[c] = d->lights[i].lemit[c];
@@ -607,6 +650,11 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     std::memcpy(S.camera_to_world.m, d->camera.camera_to_world, 64);
     S.lens_radius = d->camera.lens_radius;
     S.focal_distance = d->camera.focal_distance;
+    for (int c = 0; c < 3; ++c) {
+        S.dx_camera[c] = d->camera.dx_camera[c];
+        S.dy_camera[c] = d->camera.dy_camera[c];
+    }
+    S.diff_scale = 1 / std::sqrt(float(d->halton.spp));  // integrator.cpp:284-285
     const iile_film_desc &f = d->film;
     S.xres = f.xres;
     S.yres = f.yres;
@@ -993,6 +1041,19 @@ int iile_bsdf_eval(iile_scene *sc, int32_t n, int32_t mat, const float *wo3, con
 }
 int iile_bsdf_sample(iile_scene *sc, int32_t n, int32_t mat, const float *wo3, const float *u2, float *out7) {
     return bsdf_probe(sc, n, mat, wo3, u2, 2, 1, out7, 7);
+}
+
+int iile_texture_eval(iile_scene *sc, int32_t tex, int32_t n, const float *uv2, const float *duv4, float *rgb3) {
+    if (!sc || n < 0 || !uv2 || !duv4 || !rgb3 || tex < 0 || tex >= sc->ds.n_textures)
+        return fail(IILE_ERR_ARG, "iile_texture_eval: bad argument");
+    DevBuf<float> duv, dd, dout;
+    int rc;
+    if ((rc = duv.put(uv2, 2 * size_t(n))) || (rc = dd.put(duv4, 4 * size_t(n))) || (rc = dout.alloc(3 * size_t(n)))) return rc;
+    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    if (n) launch_texture_probe(sc->ds, n, tex, duv.p, dd.p, dout.p, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return dout.get(rgb3, 3 * size_t(n));
 }
 
 int iile_trig_probe(int32_t n, const float *x, float *out3) {

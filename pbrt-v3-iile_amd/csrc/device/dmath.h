@@ -264,6 +264,36 @@ DEV double atan2_d(double y, double x) {
     }
 }
 DEV float atan2_f(float y, float x) { return float(atan2_d(double(y), double(x))); }
+// Natural logarithm, operation for operation as oracle/oracle_path.cpp portable_log (argument reduction to
+// sqrt(1/2) < m <= sqrt(2), atanh series with the classic minimax coefficients). Callers pass positive floats.
+DEV double log_d(double x) {
+    if (x != x || x < 0) return __builtin_nan("");
+    if (x == 0) return -__builtin_huge_val();
+    if (x == __builtin_huge_val()) return x;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, Lg1 = 6.666666666666735130e-01,
+                 Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    int k = int((bits >> 52) & 0x7ffull) - 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m = __longlong_as_double((long long)bits);
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        k += 1;
+    }
+    const double f = m - 1.0;
+    const double sq = f / (2.0 + f);
+    const double z = sq * sq;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = double(k);
+    return dk * ln2_hi - ((hfsq - (sq * (hfsq + R) + dk * ln2_lo)) - f);
+}
+DEV float log_f(float x) { return float(log_d(double(x))); }
+DEV float log2_f(float x) { return log_f(x) * 1.442695040888963387004650940071f; }  // pbrt.h:325-328
 
 // ---------------------------------------------------------------------------
 // 4x4 row-major transforms (core/transform.h:217-410)

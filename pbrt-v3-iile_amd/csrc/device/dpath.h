@@ -198,6 +198,48 @@ DEV void camera_ray(const DScene &S, float pfx, float pfy, float lu0, float lu1,
     *tmax = tm;
 }
 
+// The auxiliary rays of the camera ray's RayDifferential: GenerateRayDifferential (perspective.cpp:124-148),
+// Transform::operator()(RayDifferential) (transform.h:265-274) and the render loop's
+// ScaleDifferentials(1 / sqrt(spp)) (geometry.h:908-913). (o, d) is the camera ray as camera_ray returns it.
+struct RayDiff {
+    F3 rxo, ryo, rxd, ryd;
+};
+DEV RayDiff camera_differentials(const DScene &S, float pfx, float pfy, float lu0, float lu1, F3 o, F3 d) {
+    const F3 pcam = xf_point(S.raster_to_camera, F3{pfx, pfy, 0});
+    const F3 dxc = F3{S.dx_camera[0], S.dx_camera[1], S.dx_camera[2]}, dyc = F3{S.dy_camera[0], S.dy_camera[1], S.dy_camera[2]};
+    F3 rxo = F3{0, 0, 0}, ryo = F3{0, 0, 0}, rxd, ryd;
+    if (S.lens_radius > 0) {
+        float lx, ly;
+        concentric_sample_disk(lu0, lu1, &lx, &ly);
+        lx = S.lens_radius * lx;
+        ly = S.lens_radius * ly;
+        const F3 dx = normalize(pcam + dxc);
+        float ft = S.focal_distance / dx.z;
+        F3 pfocus = F3{0, 0, 0} + (ft * dx);
+        rxo = F3{lx, ly, 0};
+        rxd = normalize(pfocus - rxo);
+        const F3 dy = normalize(pcam + dyc);
+        ft = S.focal_distance / dy.z;
+        pfocus = F3{0, 0, 0} + (ft * dy);
+        ryo = F3{lx, ly, 0};
+        ryd = normalize(pfocus - ryo);
+    } else {
+        rxd = normalize(pcam + dxc);
+        ryd = normalize(pcam + dyc);
+    }
+    rxo = xf_point(S.camera_to_world, rxo);
+    ryo = xf_point(S.camera_to_world, ryo);
+    rxd = xf_vector(S.camera_to_world, rxd);
+    ryd = xf_vector(S.camera_to_world, ryd);
+    const float sc = S.diff_scale;
+    RayDiff r;
+    r.rxo = o + (rxo - o) * sc;
+    r.ryo = o + (ryo - o) * sc;
+    r.rxd = d + (rxd - d) * sc;
+    r.ryd = d + (ryd - d) * sc;
+    return r;
+}
+
 // ===========================================================================
 // ray / primitive tests
 // ===========================================================================
@@ -359,6 +401,9 @@ DEV bool sphere_test(const DSphere &sp, F3 ro, F3 rd, float tmax, float *t_hit, 
 // What shading needs of a SurfaceInteraction (core/interaction.h)
 struct Isect {
     F3 p, perr, n, wo, sn, sdpdu;
+    // texture lookups (triangles): the hit's (u, v) and dp/du, dp/dv; dead code where no texture is read
+    float u, v;
+    F3 dpdu, dpdv;
 };
 
 // Sphere::Intersect's interaction + Transform::operator()(SurfaceInteraction)
@@ -422,6 +467,10 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
     float zs = (fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z));
     is->perr = kGamma7 * F3{xs, ys, zs};
     is->p = b0 * p0 + b1 * p1 + b2 * p2;
+    is->u = b0 * uv00 + b1 * uv10 + b2 * uv20;  // uvHit, triangle.cpp:318
+    is->v = b0 * uv01 + b1 * uv11 + b2 * uv21;
+    is->dpdu = dpdu;
+    is->dpdv = dpdv;
     is->wo = normalize(-ray_d);
     F3 n = normalize(cross(dp02, dp12));
     const bool flip = (flags & 8u) != 0;
@@ -891,6 +940,182 @@ DEV F3 to_world(const Bsdf &b, F3 v) {
     return F3{b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
               b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z};
 }
+// ===========================================================================
+// image textures: SurfaceInteraction::ComputeDifferentials (interaction.cpp:103-149),
+// UVMapping2D::Map (texture.cpp:93-99), MIPMap<RGBSpectrum>::Lookup / triangle / EWA / Texel
+// (mipmap.h:210-355) over the host-built pyramid — operation for operation as the oracle's tex_* functions
+// ===========================================================================
+struct TexDiff {
+    float dudx, dvdx, dudy, dvdy;
+};
+DEV bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float *x0, float *x1) {  // transform.cpp:41-49
+    const float det = a00 * a11 - a01 * a10;
+    if (fabsf(det) < 1e-10f) return false;
+    *x0 = (a11 * b0 - a01 * b1) / det;
+    *x1 = (a00 * b1 - a10 * b0) / det;
+    if (*x0 != *x0 || *x1 != *x1) return false;
+    return true;
+}
+DEV bool is_inf_or_nan(float v) { return !(fabsf(v) < IILE_INF); }
+DEV TexDiff compute_differentials(const Isect &is, const RayDiff &rd) {
+    TexDiff t = TexDiff{0, 0, 0, 0};
+    const F3 n = is.n, p = is.p;
+    const float d = dot(n, p);
+    const float tx = -(dot(n, rd.rxo) - d) / dot(n, rd.rxd);
+    if (is_inf_or_nan(tx)) return t;
+    const F3 px = rd.rxo + tx * rd.rxd;
+    const float ty = -(dot(n, rd.ryo) - d) / dot(n, rd.ryd);
+    if (is_inf_or_nan(ty)) return t;
+    const F3 py = rd.ryo + ty * rd.ryd;
+    int d0, d1;
+    if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) {
+        d0 = 1;
+        d1 = 2;
+    } else if (fabsf(n.y) > fabsf(n.z)) {
+        d0 = 0;
+        d1 = 2;
+    } else {
+        d0 = 0;
+        d1 = 1;
+    }
+    const float a00 = comp(is.dpdu, d0), a01 = comp(is.dpdv, d0), a10 = comp(is.dpdu, d1), a11 = comp(is.dpdv, d1);
+    const float bx0 = comp(px, d0) - comp(p, d0), bx1 = comp(px, d1) - comp(p, d1);
+    const float by0 = comp(py, d0) - comp(p, d0), by1 = comp(py, d1) - comp(p, d1);
+    if (!solve_2x2(a00, a01, a10, a11, bx0, bx1, &t.dudx, &t.dvdx)) t.dudx = t.dvdx = 0;
+    if (!solve_2x2(a00, a01, a10, a11, by0, by1, &t.dudy, &t.dvdy)) t.dudy = t.dvdy = 0;
+    return t;
+}
+DEV int mod_i(int a, int b) {  // pbrt.h:310-314
+    const int r = a - (a / b) * b;
+    return r < 0 ? r + b : r;
+}
+DEV F3 tex_texel(const DScene &S, const DTexture &t, int level, int s, int tt) {
+    const int w = t.level_w[level], h = t.level_h[level];
+    if (t.wrap == kWrapRepeat) {
+        // level sizes are powers of two: Mod is a mask (two's complement handles negative s)
+        s = s & (w - 1);
+        tt = tt & (h - 1);
+    } else if (t.wrap == kWrapClamp) {
+        s = s < 0 ? 0 : (s > w - 1 ? w - 1 : s);
+        tt = tt < 0 ? 0 : (tt > h - 1 ? h - 1 : tt);
+    } else if (s < 0 || s >= w || tt < 0 || tt >= h) {
+        return F3{0, 0, 0};
+    }
+    const float4 c = S.texels[t.level_offset[level] + (long long)tt * w + s];
+    return F3{c.x, c.y, c.z};
+}
+DEV F3 tex_triangle(const DScene &S, const DTexture &t, int level, float st0, float st1) {
+    level = level < 0 ? 0 : (level > t.n_levels - 1 ? t.n_levels - 1 : level);
+    const float s = st0 * float(t.level_w[level]) - 0.5f;
+    const float tt = st1 * float(t.level_h[level]) - 0.5f;
+    const float fs = floorf(s), ft = floorf(tt);
+    const int s0 = int(fs), t0 = int(ft);
+    const float ds = s - float(s0), dt = tt - float(t0);
+    return tex_texel(S, t, level, s0, t0) * ((1 - ds) * (1 - dt)) + tex_texel(S, t, level, s0, t0 + 1) * ((1 - ds) * dt) +
+           tex_texel(S, t, level, s0 + 1, t0) * (ds * (1 - dt)) + tex_texel(S, t, level, s0 + 1, t0 + 1) * (ds * dt);
+}
+DEV F3 lerp_f3(float t, F3 a, F3 b) { return a * (1 - t) + b * t; }
+DEV F3 tex_lookup_width(const DScene &S, const DTexture &t, float st0, float st1, float width) {  // mipmap.h:233-250
+    const float level = float(t.n_levels - 1) + log2_f(mx(width, 1e-8f));
+    if (level < 0) return tex_triangle(S, t, 0, st0, st1);
+    if (level >= float(t.n_levels - 1)) return tex_texel(S, t, t.n_levels - 1, 0, 0);
+    const int il = int(floorf(level));
+    const float delta = level - float(il);
+    return lerp_f3(delta, tex_triangle(S, t, il, st0, st1), tex_triangle(S, t, il + 1, st0, st1));
+}
+DEV F3 tex_ewa(const DScene &S, const DTexture &t, int level, float st0, float st1, float d00, float d01, float d10, float d11) {
+    if (level >= t.n_levels) return tex_texel(S, t, t.n_levels - 1, 0, 0);
+    const float w = float(t.level_w[level]), h = float(t.level_h[level]);
+    st0 = st0 * w - 0.5f;
+    st1 = st1 * h - 0.5f;
+    d00 *= w;
+    d01 *= h;
+    d10 *= w;
+    d11 *= h;
+    float A = d01 * d01 + d11 * d11 + 1;
+    float B = -2 * (d00 * d01 + d10 * d11);
+    float C = d00 * d00 + d10 * d10 + 1;
+    const float invF = 1 / (A * C - B * B * 0.25f);
+    A *= invF;
+    B *= invF;
+    C *= invF;
+    const float det = -B * B + 4 * A * C;
+    const float inv_det = 1 / det;
+    const float u_sqrt = sqrtf(det * C), v_sqrt = sqrtf(A * det);
+    const int s0 = int(ceilf(st0 - 2 * inv_det * u_sqrt));
+    const int s1 = int(floorf(st0 + 2 * inv_det * u_sqrt));
+    const int t0 = int(ceilf(st1 - 2 * inv_det * v_sqrt));
+    const int t1 = int(floorf(st1 + 2 * inv_det * v_sqrt));
+    F3 sum = F3{0, 0, 0};
+    float sum_wts = 0;
+    for (int it = t0; it <= t1; ++it) {
+        const float tt = float(it) - st1;
+        for (int is = s0; is <= s1; ++is) {
+            const float ss = float(is) - st0;
+            const float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+            if (r2 < 1) {
+                int index = int(r2 * 128.f);
+                index = index < 127 ? index : 127;
+                const float weight = S.ewa_lut[index];
+                sum = sum + tex_texel(S, t, level, is, it) * weight;
+                sum_wts += weight;
+            }
+        }
+    }
+    return F3{sum.x / sum_wts, sum.y / sum_wts, sum.z / sum_wts};
+}
+DEV F3 tex_evaluate(const DScene &S, int tex, float u, float v, const TexDiff &td) {
+    const DTexture &t = S.textures[tex];
+    float d00 = t.su * td.dudx, d01 = t.sv * td.dvdx, d10 = t.su * td.dudy, d11 = t.sv * td.dvdy;
+    const float st0 = t.su * u + t.du, st1 = t.sv * v + t.dv;
+    if (t.trilinear) {
+        const float width = mx(mx(fabsf(d00), fabsf(d01)), mx(fabsf(d10), fabsf(d11)));
+        return tex_lookup_width(S, t, st0, st1, 2 * width);
+    }
+    if (d00 * d00 + d01 * d01 < d10 * d10 + d11 * d11) {
+        float tmp = d00;
+        d00 = d10;
+        d10 = tmp;
+        tmp = d01;
+        d01 = d11;
+        d11 = tmp;
+    }
+    const float major = sqrtf(d00 * d00 + d01 * d01);
+    float minor = sqrtf(d10 * d10 + d11 * d11);
+    if (minor * t.max_aniso < major && minor > 0) {
+        const float scale = major / (minor * t.max_aniso);
+        d10 *= scale;
+        d11 *= scale;
+        minor *= scale;
+    }
+    if (minor == 0) return tex_triangle(S, t, 0, st0, st1);
+    const float lod = mx(0.f, float(t.n_levels) - 1.f + log2_f(minor));
+    const int ilod = int(floorf(lod));
+    return lerp_f3(lod - float(ilod), tex_ewa(S, t, ilod, st0, st1, d00, d01, d10, d11),
+                   tex_ewa(S, t, ilod + 1, st0, st1, d00, d01, d10, d11));
+}
+// the material with its textured parameters looked up at the hit (Texture::Evaluate(*si))
+DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect &is, const TexDiff &td) {
+    DMaterial r = m;
+    if (m.kd_tex >= 0) {
+        const F3 c = tex_evaluate(S, m.kd_tex, is.u, is.v, td);
+        r.kd[0] = c.x, r.kd[1] = c.y, r.kd[2] = c.z;
+    }
+    if (m.ks_tex >= 0) {
+        const F3 c = tex_evaluate(S, m.ks_tex, is.u, is.v, td);
+        r.ks[0] = c.x, r.ks[1] = c.y, r.ks[2] = c.z;
+    }
+    if (m.kr_tex >= 0) {
+        const F3 c = tex_evaluate(S, m.kr_tex, is.u, is.v, td);
+        r.kr[0] = c.x, r.kr[1] = c.y, r.kr[2] = c.z;
+    }
+    if (m.kt_tex >= 0) {
+        const F3 c = tex_evaluate(S, m.kt_tex, is.u, is.v, td);
+        r.kt[0] = c.x, r.kt[1] = c.y, r.kt[2] = c.z;
+    }
+    return r;
+}
+
 // Matte / Plastic / Uber / Mirror ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70,
 // uber.cpp:45-100 with opacity 1 and Kt 0, mirror.cpp:44-55)
 // EXT = false: the scene has matte and plastic only (checked at upload); the specular lobes then fold away

@@ -31,6 +31,17 @@ struct DMaterial {
     float eta;    // uber, glass: FresnelDielectric(1, eta)
     float kt[3];  // glass: specular transmittance
     float on_a, on_b;  // matte with sigma != 0: Oren-Nayar A, B (on_b == 0 and on_a == 1 otherwise)
+    int kd_tex, ks_tex, kr_tex, kt_tex;  // image texture replacing the constant at a hit, or -1
+};
+// ImageTexture + MIPMap (iile_texture): level l holds w x h float4 texels (rgb, w unused) at
+// texels[offset[l] + t * w + s], row 0 = bottom scanline
+constexpr int kMaxTexLevels = 16;
+enum { kWrapRepeat = 0, kWrapBlack = 1, kWrapClamp = 2 };
+struct DTexture {
+    int n_levels, wrap, trilinear;
+    float max_aniso, su, sv, du, dv;
+    int level_w[kMaxTexLevels], level_h[kMaxTexLevels];
+    long long level_offset[kMaxTexLevels];
 };
 enum { kLightDiffuseArea = 0, kLightPoint = 1, kLightSpot = 2, kLightDistant = 3, kLightAreaTriangle = 4,
        kLightInfinite = 5 };  // = IILE_LIGHT_* (checked in api.hip)
@@ -77,6 +88,10 @@ struct DScene {
     const DSphere *spheres;
     const DMaterial *materials;
     const DLight *lights;
+    const DTexture *textures;  // image textures (k_shade<.., TEX = true>)
+    const float4 *texels;
+    const float *ewa_lut;      // MIPMap::weightLut[128]
+    int n_textures;
     int n_nodes, n_prims, n_spheres, n_materials, n_lights, n_hdims;
     int n_perms;              // u16 entries of `perms`
     float root_box[6];        // bounds of the root node (min.xyz, max.xyz)
@@ -92,6 +107,8 @@ struct DScene {
     // camera
     M44 raster_to_camera, camera_to_world;
     float lens_radius, focal_distance;
+    float dx_camera[3], dy_camera[3];  // PerspectiveCamera::dxCamera / dyCamera
+    float diff_scale;                  // 1 / sqrt(spp): ScaleDifferentials of the render loop
     // film
     int xres, yres;
     int crop_x0, crop_y0, crop_x1, crop_y1;

@@ -55,7 +55,7 @@ struct LaunchCfg {
 uint32_t queue_capacity(uint32_t n_paths, int n_cus);
 void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg);
 void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
-void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_light_distributions(const DScene &S, const float *samples, float *out, const LaunchCfg &cfg);
@@ -79,5 +79,6 @@ void launch_camera(const DScene &S, int n, const float *pfilm, const float *plen
 void launch_bsdf_probe(const DScene &S, int n, int mat, const float *wo, const float *wi_or_u, int sample,
                        float *out, const LaunchCfg &cfg);
 void launch_trig_probe(int n, const float *x, float *out, const LaunchCfg &cfg);
+void launch_texture_probe(const DScene &S, int n, int tex, const float *uv, const float *duv, float *out, const LaunchCfg &cfg);
 
 }  // namespace iile

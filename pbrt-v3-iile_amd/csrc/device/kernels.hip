@@ -474,8 +474,9 @@ DEV int sample_light(const DScene &S, F3 p, float u, float *pdf) {
 // shade: one bounce of PathIntegrator::Li (path.cpp:81-191) for every hit of the
 // queue that extend just resolved.
 // 3 waves/SIMD (<= 168 VGPRs, 6 spilled): measured 38.0 ms vs 40.2 ms at 2 waves/SIMD
-template <bool COUNT, bool EXT>
-__global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, int bounce, uint32_t plane) {
+// TEX: some material takes a parameter from an image texture (implies EXT)
+template <bool COUNT, bool EXT, bool TEX>
+__global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
     // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
     for (int i = threadIdx.x; i < S.n_perms; i += kBlock) s_perms_raw[i] = S.perms[i];
@@ -595,7 +596,35 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassBuffers B, in
                 }
                 if (bounce < S.max_depth) {
                     surface = true;
-                    bsdf = make_bsdf<EXT>(S.materials[material], is);
+                    if (TEX && S.n_textures > 0) {
+                        // isect.ComputeScatteringFunctions(ray, ...): ComputeDifferentials (interaction.cpp:95-149)
+                        // then the material's Texture::Evaluate calls. Only the camera ray carries differentials
+                        // (path.cpp:159 spawns plain Rays); its auxiliary rays are a function of the camera
+                        // sample, rebuilt here from the path's pixel instead of travelling with the ray.
+                        const DMaterial &m0 = S.materials[material];
+                        if (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0) {
+                            TexDiff td = TexDiff{0, 0, 0, 0};
+                            if (bounce == 0) {
+                                int px = 0, py = 0;
+                                uint32_t kk = 0;
+                                path_pixel(S, P, pid, &px, &py, &kk);
+                                const float u0 = sample_dimension(S, s_perms, hidx, 0), u1 = sample_dimension(S, s_perms, hidx, 1);
+                                float l0 = 0, l1 = 0;
+                                if (S.lens_radius > 0) {
+                                    l0 = sample_dimension(S, s_perms, hidx, 3);
+                                    l1 = sample_dimension(S, s_perms, hidx, 4);
+                                }
+                                const RayDiff rdiff = camera_differentials(S, float(px) + u0, float(py) + u1, l0, l1, ray_o, ray_d);
+                                td = compute_differentials(is, rdiff);
+                            }
+                            const DMaterial mm = textured_material(S, m0, is, td);
+                            bsdf = make_bsdf<EXT>(mm, is);
+                        } else {
+                            bsdf = make_bsdf<EXT>(m0, is);
+                        }
+                    } else {
+                        bsdf = make_bsdf<EXT>(S.materials[material], is);
+                    }
                     if (n_nonspec(bsdf) > 0) {  // NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0, path.cpp:118
                         ++n_nee;
                         // UniformSampleOneLight (integrator.cpp:85-106). One light: it is chosen with pdf 1
@@ -1356,21 +1385,24 @@ void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t m
     else
         hipLaunchKernelGGL(k_extend<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
 }
-void launch_shade(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
 #ifndef IILE_SHADE_BLOCKS
 #define IILE_SHADE_BLOCKS 3  // = resident blocks per CU at 3 waves/SIMD: the static split has no tail
 #endif
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, IILE_SHADE_BLOCKS));
     const size_t perm_bytes = (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
     if (cfg.count_stats)
-        hipLaunchKernelGGL((k_shade<true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
+        hipLaunchKernelGGL((k_shade<true, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
     else
         // Scenes of killeroo-simple's kind (one emitting sphere, matte / plastic only) run a build of the
-        // kernel without the code for the wider feature set: it costs them registers otherwise (+0.7 ms)
-        if (S.extended_features)
-            hipLaunchKernelGGL((k_shade<false, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
+        // kernel without the code for the wider feature set: it costs them registers otherwise (+0.7 ms);
+        // likewise image textures have their own build
+        if (S.n_textures > 0)
+            hipLaunchKernelGGL((k_shade<false, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
+        else if (S.extended_features)
+            hipLaunchKernelGGL((k_shade<false, true, false>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
         else
-            hipLaunchKernelGGL((k_shade<false, false>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, B, bounce, B.queue_cap);
+            hipLaunchKernelGGL((k_shade<false, false, false>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
 }
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
@@ -1437,6 +1469,19 @@ void launch_bsdf_probe(const DScene &S, int n, int mat, const float *wo, const f
                        float *out, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_bsdf_probe, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, S, n, mat, wo, wi_or_u, sample,
                        out);
+}
+// ImageTexture::Evaluate for given (u, v) and differentials (test probe)
+__global__ void k_texture_probe(DScene S, int n, int tex, const float *uv, const float *duv, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const TexDiff td = TexDiff{duv[4 * i], duv[4 * i + 1], duv[4 * i + 2], duv[4 * i + 3]};
+    const F3 c = tex_evaluate(S, tex, uv[2 * i], uv[2 * i + 1], td);
+    out[3 * i] = c.x;
+    out[3 * i + 1] = c.y;
+    out[3 * i + 2] = c.z;
+}
+void launch_texture_probe(const DScene &S, int n, int tex, const float *uv, const float *duv, float *out, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_texture_probe, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, S, n, tex, uv, duv, out);
 }
 void launch_trig_probe(int n, const float *x, float *out, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_trig_probe, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, n, x, out);

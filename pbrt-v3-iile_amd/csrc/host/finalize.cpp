@@ -123,6 +123,22 @@ bool finalize_scene(HostScene *s, std::string *err) {
     d.n_lights = int(s->lights.size());
     d.lights = s->lights.data();
 
+    // image textures: concatenate the pyramids
+    s->o_textures.clear();
+    s->o_texels.clear();
+    for (const HostTexture &ht : s->textures) {
+        iile_texture t = ht.t;
+        const int64_t base = int64_t(s->o_texels.size() / 3);
+        for (int l = 0; l < t.n_levels; ++l) t.level_offset[l] += base;
+        s->o_texels.insert(s->o_texels.end(), ht.texels.begin(), ht.texels.end());
+        s->o_textures.push_back(t);
+    }
+    d.n_textures = int(s->o_textures.size());
+    d.textures = s->o_textures.data();
+    d.n_texels = int64_t(s->o_texels.size() / 3);
+    d.texels = s->o_texels.data();
+    ewa_weight_lut(d.ewa_lut);
+
     // Film, core/film.cpp:45-82
     iile_film_desc &f = d.film;
     f.xres = s->xres;
@@ -165,6 +181,12 @@ bool finalize_scene(HostScene *s, std::string *err) {
     Xform raster_to_camera = inverse(camera_to_screen) * raster_to_screen;
     std::memcpy(d.camera.raster_to_camera, raster_to_camera.m.m, sizeof(float) * 16);
     std::memcpy(d.camera.camera_to_world, s->camera_to_world.m.m, sizeof(float) * 16);
+    {  // PerspectiveCamera ctor, perspective.cpp:58-62
+        V3 o = raster_to_camera.point(V3(0, 0, 0));
+        V3 dx = raster_to_camera.point(V3(1, 0, 0)) - o, dy = raster_to_camera.point(V3(0, 1, 0)) - o;
+        d.camera.dx_camera[0] = dx.x, d.camera.dx_camera[1] = dx.y, d.camera.dx_camera[2] = dx.z;
+        d.camera.dy_camera[0] = dy.x, d.camera.dy_camera[1] = dy.y, d.camera.dy_camera[2] = dy.z;
+    }
     d.camera.lens_radius = s->lens_radius;
     d.camera.focal_distance = s->focal_distance;
     d.camera.shutter_open = s->shutter_open;

@@ -119,4 +119,39 @@ int iile_host_write_pfm(const char *path, const float *rgb, int32_t width, int32
     return 0;
 }
 
+int iile_host_read_image(const char *path, int32_t *width, int32_t *height, float *rgb) {
+    std::vector<float> data;
+    int w = 0, h = 0;
+    std::string err;
+    if (!iile::read_image(path, &data, &w, &h, &err)) {
+        g_err = err;
+        return 1;
+    }
+    *width = w;
+    *height = h;
+    if (rgb) std::memcpy(rgb, data.data(), data.size() * sizeof(float));
+    return 0;
+}
+
+int iile_host_scene_texture(const iile_host_scene *scene, int32_t index, iile_texture *out) {
+    const iile_scene_desc &d = *iile_host_scene_desc(scene);
+    if (index < 0 || index >= d.n_textures) {
+        g_err = "texture index out of range";
+        return 1;
+    }
+    *out = d.textures[index];
+    return 0;
+}
+
+int iile_host_scene_texture_level(const iile_host_scene *scene, int32_t index, int32_t level, float *rgb) {
+    const iile_scene_desc &d = *iile_host_scene_desc(scene);
+    if (index < 0 || index >= d.n_textures || level < 0 || level >= d.textures[index].n_levels) {
+        g_err = "texture index / level out of range";
+        return 1;
+    }
+    const iile_texture &t = d.textures[index];
+    std::memcpy(rgb, d.texels + 3 * t.level_offset[level], sizeof(float) * 3 * size_t(t.level_w[level]) * t.level_h[level]);
+    return 0;
+}
+
 }  // extern "C"

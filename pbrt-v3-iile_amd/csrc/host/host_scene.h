@@ -22,8 +22,15 @@ struct HostPrim {
     Bounds3 world_bound;
 };
 
+// One ImageTexture: its mapping / filtering options and its MIP pyramid (mipmap.cpp)
+struct HostTexture {
+    iile_texture t;
+    std::vector<float> texels;  // RGB, all levels; level_offset[] is relative to this texture until finalize
+};
+
 struct HostScene {
     std::vector<HostPrim> prims;  // creation order
+    std::vector<HostTexture> textures;
     std::vector<iile_sphere> spheres;
     std::vector<iile_material> materials;
     std::vector<iile_light> lights;
@@ -59,6 +66,8 @@ struct HostScene {
     std::vector<float> o_tri_p, o_tri_n, o_tri_uv;
     std::vector<uint16_t> perms;
     std::vector<int32_t> primes, prime_sums;
+    std::vector<iile_texture> o_textures;
+    std::vector<float> o_texels;
     int n_interior = 0, n_leaf = 0;
     iile_scene_desc desc;
 };
@@ -78,5 +87,14 @@ void build_halton_tables(HostScene *scene);
 // plymesh.cpp
 bool load_ply(const std::string &path, std::vector<V3> *P, std::vector<V3> *N, std::vector<float> *uv,
               std::vector<int> *indices, std::string *err);
+
+// imageio.cpp
+bool read_image(const std::string &path, std::vector<float> *rgb, int *w, int *h, std::string *err);
+bool image_is_8bit(const std::string &path);
+// mipmap.cpp
+bool build_image_texture(const std::vector<float> &rgb, int width, int height, float scale, bool gamma, HostTexture *out,
+                         std::string *err);
+void ewa_weight_lut(float *lut);
+float inverse_gamma_correct(float value);
 
 }  // namespace iile

@@ -182,6 +182,7 @@ struct ParamSet {
 struct ConstTexture {
     bool is_float = true;
     float v[3] = {0, 0, 0};
+    int image = -1;  // an "imagemap" spectrum texture: index into HostScene::textures (not constant: kept by reference)
 };
 struct GraphicsState {
     int material = -1;  // index into scene->materials, -1 = default matte
@@ -597,6 +598,8 @@ class Loader {
             if (it == gs_.textures.end() || it->second.is_float != want_float)
                 return fail(std::string("Couldn't find ") + (want_float ? "float" : "spectrum") + " texture named \"" +
                             p->strs[0] + "\" for parameter \"" + name + "\"");
+            if (it->second.image >= 0)
+                return fail("texture \"" + p->strs[0] + "\": scale / mix of image textures is not supported");
             for (int i = 0; i < 3; ++i) out[i] = it->second.v[i];
             return true;
         }
@@ -625,19 +628,61 @@ class Loader {
                 !tex_value(ps, "amount", true, half, amt))
                 return false;
             for (int i = 0; i < 3; ++i) t.v[i] = (1 - amt[0]) * a[i] + amt[0] * b[i];
+        } else if (cls == "imagemap") {  // CreateImageSpectrumTexture, textures/imagemap.cpp:148-187
+            if (is_float) return fail("float image textures are not supported (spectrum imagemap only)");
+            const std::string mapping = ps.one_string("mapping", "uv");
+            if (mapping != "uv") return fail("2D texture mapping \"" + mapping + "\" is not supported (uv only)");
+            HostTexture ht;
+            std::memset(&ht.t, 0, sizeof(ht.t));
+            ht.t.su = ps.one_float("uscale", 1.f);
+            ht.t.sv = ps.one_float("vscale", 1.f);
+            ht.t.du = ps.one_float("udelta", 0.f);
+            ht.t.dv = ps.one_float("vdelta", 0.f);
+            ht.t.max_aniso = ps.one_float("maxanisotropy", 8.f);
+            ht.t.trilinear = ps.one_bool("trilinear", false) ? 1 : 0;
+            const std::string wrap = ps.one_string("wrap", "repeat");
+            ht.t.wrap = wrap == "black" ? IILE_WRAP_BLACK : (wrap == "clamp" ? IILE_WRAP_CLAMP : IILE_WRAP_REPEAT);
+            const float scale = ps.one_float("scale", 1.f);
+            std::string filename = ps.one_string("filename", "");
+            if (!filename.empty() && filename[0] != '/') filename = search_dir_ + "/" + filename;  // ParamSet::FindOneFilename
+            const bool gamma = ps.one_bool("gamma", image_is_8bit(filename));
+            std::vector<float> rgb;
+            int w = 0, h = 0;
+            std::string why;
+            if (!read_image(filename, &rgb, &w, &h, &why)) {
+                // imagemap.cpp:63-70: Warning + a constant grey 1 x 1 texture
+                std::fprintf(stderr, "Warning: %s\nWarning: Creating a constant grey texture to replace \"%s\".\n", why.c_str(),
+                             filename.c_str());
+                rgb.assign(3, 0.5f);
+                w = h = 1;
+            }
+            if (!build_image_texture(rgb, w, h, scale, gamma, &ht, &why)) return fail("Texture \"" + name + "\": " + why);
+            scene_->textures.push_back(std::move(ht));
+            t.image = int(scene_->textures.size()) - 1;
         } else
-            return fail("Texture class \"" + cls + "\" is not supported (constant, scale, mix of constants)");
+            return fail("Texture class \"" + cls + "\" is not supported (constant, scale, mix of constants; imagemap)");
         gs_.textures[name] = t;
         return true;
     }
     // replaces references to named textures among a material's parameters by their values
-    bool resolve_textures(const ParamSet &in, ParamSet *out) {
+    // (an image texture stays a reference: `image_of` gets parameter name -> texture index, and the
+    // parameter a placeholder colour that the material's constant-value checks see as non-black)
+    bool resolve_textures(const ParamSet &in, ParamSet *out, std::map<std::string, int> *image_of) {
         *out = in;
         for (Param &p : out->params) {
             if (p.type != "texture") continue;
             if (p.strs.size() != 1) return fail("bad texture reference for \"" + p.name + "\"");
             auto it = gs_.textures.find(p.strs[0]);
             if (it == gs_.textures.end()) return fail("Couldn't find texture named \"" + p.strs[0] + "\" for parameter \"" + p.name + "\"");
+            if (it->second.image >= 0) {
+                if (p.name != "Kd" && p.name != "Ks" && p.name != "Kr" && p.name != "Kt")
+                    return fail("image texture \"" + p.strs[0] + "\" on parameter \"" + p.name + "\" is not supported (Kd, Ks, Kr, Kt)");
+                (*image_of)[p.name] = it->second.image;
+                p.strs.clear();
+                p.type = "color";
+                p.nums = {1.0, 1.0, 1.0};
+                continue;
+            }
             p.strs.clear();
             if (it->second.is_float) {
                 p.type = "float";
@@ -651,9 +696,15 @@ class Loader {
     }
     int make_material(const std::string &name, const ParamSet &ps_in) {
         ParamSet ps;
-        if (!resolve_textures(ps_in, &ps)) return -1;
+        std::map<std::string, int> image_of;
+        if (!resolve_textures(ps_in, &ps, &image_of)) return -1;
         iile_material m;
         std::memset(&m, 0, sizeof(m));
+        m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = -1;
+        auto image = [&](const char *param) {
+            auto it = image_of.find(param);
+            return it == image_of.end() ? -1 : it->second;
+        };
         if (name == "matte") {
             m.type = IILE_MAT_MATTE;
             float kd[3] = {0.5f, 0.5f, 0.5f};
@@ -728,6 +779,16 @@ class Loader {
             fail("Material \"" + name + "\" is not supported (matte, plastic, uber, mirror, glass)");
             return -1;
         }
+        // which parameters each material looks up (an image given for one it does not have is ignored, as a
+        // constant would be)
+        if (m.type == IILE_MAT_MATTE || m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) m.kd_tex = image("Kd");
+        if (m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) m.ks_tex = image("Ks");
+        if (m.type == IILE_MAT_UBER || m.type == IILE_MAT_MIRROR || m.type == IILE_MAT_GLASS) m.kr_tex = image("Kr");
+        if (m.type == IILE_MAT_GLASS) m.kt_tex = image("Kt");
+        if (m.type == IILE_MAT_UBER && image("Kt") >= 0) {
+            fail("uber: specular transmission (Kt) is not supported");
+            return -1;
+        }
         for (const char *tex : {"bumpmap"})
             if (ps.find(tex)) {
                 fail("bump maps are not supported");
@@ -750,6 +811,11 @@ class Loader {
         int mat = current_material();
         if (mat < 0) return false;
         if (name == "sphere") {  // shapes/sphere.cpp:318-327, sphere.h:50-60
+            {
+                const iile_material &sm = s.materials[size_t(mat)];
+                if (sm.kd_tex >= 0 || sm.ks_tex >= 0 || sm.kr_tex >= 0 || sm.kt_tex >= 0)
+                    return fail("image textures on spheres are not supported (triangle meshes only)");
+            }
             float radius = ps.one_float("radius", 1.f);
             float zmin = ps.one_float("zmin", -radius);
             float zmax = ps.one_float("zmax", radius);

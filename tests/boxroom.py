@@ -36,9 +36,66 @@ def _fmt(a):
     return " ".join("%.9g" % x for x in np.asarray(a, np.float32).ravel())
 
 
-def _mesh(P, F):
-    return 'Shape "trianglemesh" "point P" [ %s ]\n  "integer indices" [ %s ]\n' % (
-        _fmt(P), " ".join(str(int(i)) for i in F.ravel()))
+def _mesh(P, F, uv=None):
+    return 'Shape "trianglemesh" "point P" [ %s ]\n  "integer indices" [ %s ]\n%s' % (
+        _fmt(P), " ".join(str(int(i)) for i in F.ravel()), "" if uv is None else '  "float uv" [ %s ]\n' % _fmt(uv))
+
+
+def write_test_images(directory, seed=5):
+    """Image files for the textured room, one per reader: a non-power-of-two PFM (Lanczos resampling), an
+    8-bit PNG (inverse gamma) and a run-length TGA. Returns {name: path}."""
+    import os
+    import struct
+    import zlib
+    rng = np.random.default_rng(seed)
+    os.makedirs(directory, exist_ok=True)
+    paths = {}
+    # PFM 24 x 20: soft checker with a colour ramp
+    h, w = 20, 24
+    y, x = np.mgrid[0:h, 0:w]
+    chk = ((x // 4 + y // 5) % 2).astype(np.float32)
+    img = np.stack([0.15 + 0.7 * chk, 0.2 + 0.6 * (x / (w - 1)), 0.25 + 0.5 * (y / (h - 1))], -1).astype(np.float32)
+    paths["checker"] = os.path.join(directory, "checker.pfm")
+    open(paths["checker"], "wb").write(b"PF\n%d %d\n-1.0\n" % (w, h) + img[::-1].tobytes())
+    # PNG 32 x 32 RGB noise blobs, filter type "up" on every row
+    n = 32
+    base = rng.integers(40, 230, (n // 4, n // 4, 3))
+    px = np.repeat(np.repeat(base, 4, 0), 4, 1).astype(np.uint8)
+    rows = px.reshape(n, n * 3).astype(np.int32)
+    raw = b""
+    prev = np.zeros(n * 3, np.int32)
+    for r in rows:
+        raw += b"\x02" + ((r - prev) & 255).astype(np.uint8).tobytes()
+        prev = r
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+
+    paths["noise"] = os.path.join(directory, "noise.png")
+    open(paths["noise"], "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", n, n, 8, 2, 0, 0, 0)) +
+                                     chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    # TGA 16 x 8, 24 bit, run-length encoded, bottom-up: vertical stripes
+    w, h = 16, 8
+    stripes = np.zeros((h, w, 3), np.uint8)
+    for i in range(w):
+        stripes[:, i] = (250, 240, 230) if (i // 2) % 2 == 0 else (60, 90, 140)
+    stripes[h // 2:, :, 1] //= 2
+    body = b""
+    for row in stripes[::-1, :, ::-1].reshape(h, w, 3):
+        i = 0
+        while i < w:
+            j = i
+            while j + 1 < w and (row[j + 1] == row[i]).all():
+                j += 1
+            body += bytes([0x80 | (j - i)]) + row[i].tobytes()
+            i = j + 1
+    paths["stripes"] = os.path.join(directory, "stripes.tga")
+    open(paths["stripes"], "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 10, 0, 0, 0, 0, 0, w, h, 24, 0) + body)
+    return paths
+
+
+def _grid_uv(n, repeat):
+    return np.array([(repeat * i / n, repeat * j / n) for j in range(n + 1) for i in range(n + 1)], np.float64)
 
 
 def _grid_quad(origin, du, dv, n):
@@ -53,9 +110,12 @@ def _grid_quad(origin, du, dv, n):
     return P, np.array(F, np.int32)
 
 
-def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, seed=12111, maxdepth=5, light="area", materials="plain"):
+def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, seed=12111, maxdepth=5, light="area", materials="plain",
+                 textures=None):
     """Returns the scene text. Triangles: 5 * 2 * wall_n^2 + n_blobs * 20 * 4^ico_levels
-    (defaults: 5 760 + 30 720; ico_levels=5, n_blobs=12, wall_n=64 gives ~287 k)."""
+    (defaults: 5 760 + 30 720; ico_levels=5, n_blobs=12, wall_n=64 gives ~287 k).
+    `textures`: a directory — image files are written there (write_test_images) and the walls (uv-mapped,
+    repeated) and the matte / plastic blobs (per-triangle default uv) take their Kd / Ks from image textures."""
     rng = np.random.default_rng(seed)
     out = ['LookAt 0 -9.5 1   0 0 0.5   0 0 1', 'Camera "perspective" "float fov" [55]',
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (xres, yres),
@@ -87,6 +147,17 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
     else:
         out.append('AttributeBegin\n  Material "matte" "color Kd" [0 0 0]\n  Translate 1.5 -2 7.5\n'
                    '  AreaLightSource "area" "color L" [60 60 60]\n  Shape "sphere" "float radius" [0.6]\nAttributeEnd')
+    tex = None
+    if textures is not None:
+        tex = write_test_images(textures)
+        out.append('Texture "checker" "spectrum" "imagemap" "string filename" ["%s"]' % tex["checker"])
+        out.append('Texture "checker-tri" "spectrum" "imagemap" "string filename" ["%s"] "bool trilinear" ["true"] '
+                   '"float uscale" [2] "float vscale" [3] "float udelta" [.25]' % tex["checker"])
+        out.append('Texture "noise" "spectrum" "imagemap" "string filename" ["%s"] "string wrap" ["clamp"] "float scale" [.9]' % tex["noise"])
+        out.append('Texture "noise-black" "spectrum" "imagemap" "string filename" ["%s"] "string wrap" ["black"] '
+                   '"float uscale" [1.5] "float vscale" [1.5] "float maxanisotropy" [2]' % tex["noise"])
+        out.append('Texture "stripes" "spectrum" "imagemap" "string filename" ["%s"] "bool gamma" ["false"]' % tex["stripes"])
+    wall_tex = ["checker", "noise", "checker-tri", "stripes", "noise-black"]
     s = 10.0
     walls = [((-s, -s, -3), (2 * s, 0, 0), (0, 2 * s, 0), (.7, .7, .7)),      # floor
              ((-s, -s, 9), (0, 2 * s, 0), (2 * s, 0, 0), (.8, .8, .8)),       # ceiling
@@ -98,6 +169,11 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
             continue  # no ceiling
         P, F = _grid_quad(o, du, dv, wall_n)
         rough = ' "float sigma" [%g]' % (20 + 10 * len(out) % 50) if materials == "all" else ""  # Oren-Nayar walls
+        if tex is not None:
+            name = wall_tex[walls.index((o, du, dv, kd))]
+            out.append('AttributeBegin\n  Material "matte" "texture Kd" ["%s"]%s\n%sAttributeEnd' % (
+                name, rough, _mesh(P, F, _grid_uv(wall_n, 3.0))))
+            continue
         out.append('AttributeBegin\n  Material "matte" "color Kd" [%g %g %g]%s\n%sAttributeEnd' % (*kd, rough, _mesh(P, F)))
     V, F = _icosphere(ico_levels)
     for b in range(n_blobs):
@@ -120,6 +196,10 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         elif materials == "glass" and b % 2 == 1:  # closed refractive blobs, one of them tinted
             mat = 'Material "glass" "color Kr" [1 1 1] "color Kt" [%g %g %g] "float index" [%g]' % (
                 *((1, 1, 1) if b % 4 == 1 else rng.uniform(.7, 1, 3)), rng.uniform(1.3, 1.7))
+        elif tex is not None and b % 4 == 0:  # blobs have no uv: every triangle maps the unit half-square
+            mat = 'Material "plastic" "texture Kd" ["noise"] "texture Ks" ["stripes"] "float roughness" [%g]' % rng.uniform(.02, .3)
+        elif tex is not None and b % 4 == 1:
+            mat = 'Material "matte" "texture Kd" ["checker"]'
         elif b % 2 == 0:
             mat = 'Material "plastic" "color Kd" [%g %g %g] "color Ks" [.4 .4 .4] "float roughness" [%g]' % (
                 *rng.uniform(.2, .7, 3), rng.uniform(.02, .3))

@@ -45,6 +45,10 @@ class Oracle:
         lib.oracle_halton_index.restype = ctypes.c_int64
         lib.oracle_bsdf_sample_batch.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]
         lib.oracle_bsdf_pdf_batch.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
+        lib.oracle_texture_eval.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp]
+        lib.oracle_camera_hit_differentials.argtypes = [c_vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_vp]
+        lib.oracle_log.argtypes = [ctypes.c_int, ctypes.c_float]
+        lib.oracle_log.restype = ctypes.c_float
         lib.oracle_light_solid_angle.argtypes = [c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
         lib.oracle_sphere_solid_angle.argtypes = [c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
         lib.oracle_check_next_float.restype = ctypes.c_int64
@@ -190,6 +194,21 @@ class Oracle:
         self.lib.oracle_bsdf_pdf_batch(scene.desc, trig_mode, mat, wo.ctypes.data, len(wi), wi.ctypes.data,
                                        pdf.ctypes.data)
         return pdf
+
+    def texture_eval(self, scene, tex, uv, duv, trig_mode=TRIG_PORTABLE):
+        uv, duv = _f32(uv), _f32(duv)
+        out = np.empty((len(uv), 3), np.float32)
+        self.lib.oracle_texture_eval(scene.desc, trig_mode, tex, len(uv), uv.ctypes.data, duv.ctypes.data, out.ctypes.data)
+        return out
+
+    def camera_hit_differentials(self, scene, pfx, pfy, trig_mode=TRIG_PORTABLE):
+        out = np.zeros(6, np.float32)
+        if not self.lib.oracle_camera_hit_differentials(scene.desc, trig_mode, pfx, pfy, out.ctypes.data):
+            return None
+        return out
+
+    def log(self, x, trig_mode=TRIG_PORTABLE):
+        return np.array([self.lib.oracle_log(trig_mode, float(v)) for v in _f32(x)], np.float32)
 
     def sincos(self, x, trig_mode=TRIG_PORTABLE):
         x = _f32(x)

@@ -488,3 +488,54 @@ def test_film_1080p_bitwise_vs_oracle(binding, oracle):
     eight, st8 = gpu64.render(spp_per_pass=8)
     assert st1["n_passes"] == 1 and st8["n_passes"] == 8
     assert_bitwise(eight, one, "1080p x 64 spp, eight passes vs one")
+
+
+def test_image_textures_bitwise(binding, oracle, tmp_path):
+    """Image textures (SURVEY.md §8 f1): ImageTexture::Evaluate on the device — UV mapping, EWA with the
+    anisotropy clamp, trilinear, the bilinear fallback, repeat / clamp / black wrapping, the portable log2 of
+    the level choice — bit for bit the oracle's on random lookups in all five textures of the textured room
+    (a Lanczos-resampled PFM, an inverse-gamma PNG, a run-length TGA); then the room itself, where the camera
+    rays' differentials are rebuilt in k_shade from the pixel: film and counters bitwise, with the instrumented
+    and the plain kernels, in several passes and shards; and a thin-lens camera (the lens branch of
+    GenerateRayDifferential)."""
+    import boxroom
+    path = tmp_path / "room_tex.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, textures=str(tmp_path / "img")))
+    scene = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(scene)
+    rng = np.random.default_rng(2024)
+    n = 20000
+    uv = rng.uniform(-1.5, 2.5, (n, 2)).astype(np.float32)
+    duv = (rng.standard_normal((n, 4)) * 10.0 ** rng.uniform(-5, 0.3, (n, 1))).astype(np.float32)
+    duv[::5] = 0            # no differentials: bilinear at level 0
+    duv[1::9, 2:] = 0       # a degenerate ellipse (minor axis 0)
+    duv[2::13, :2] *= 50    # anisotropy beyond maxanisotropy
+    for tex in range(5):
+        assert_bitwise(gpu.texture_eval(tex, uv, duv), oracle.texture_eval(scene, tex, uv, duv), f"texture {tex} lookups")
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(scene)
+    assert_bitwise(film, ref, "textured room film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["path_length"] == ost["path_length"] and st["zero_radiance"] == ost["zero_radiance"]
+    plain, _ = gpu.render()
+    assert_bitwise(plain, ref, "textured room film, uninstrumented kernels")
+    part0, _ = gpu.render(tile_rank=0, tile_nranks=2, spp_per_pass=3)
+    part1, _ = gpu.render(tile_rank=1, tile_nranks=2, spp_per_pass=1)
+    assert np.array_equal((part0 + part1)[..., 3], ref[..., 3])
+    assert np.allclose(part0 + part1, ref, rtol=1e-6, atol=0)
+    # the textures must matter: the same room without them renders differently
+    path2 = tmp_path / "room_plain.pbrt"
+    path2.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4))
+    other, _ = binding.GpuScene(binding.HostScene(path=str(path2))).render()
+    assert np.abs(other[..., :3] - film[..., :3]).max() > 0.01
+    # thin lens
+    lens = path.read_text().replace('Camera "perspective" "float fov" [55]',
+                                    'Camera "perspective" "float fov" [55] "float lensradius" [.15] "float focaldistance" [9]')
+    assert lens != path.read_text()
+    path3 = tmp_path / "room_tex_lens.pbrt"
+    path3.write_text(lens)
+    scene3 = binding.HostScene(path=str(path3))
+    film3, _ = binding.GpuScene(scene3).render()
+    ref3, _ = oracle.render(scene3)
+    assert_bitwise(film3, ref3, "textured room through a thin lens")
+    assert not np.array_equal(film3, film)

@@ -261,3 +261,174 @@ def test_constant_textures_and_named_materials(binding, oracle, tmp_path):
     (tmp_path / "c.pbrt").write_text(head + 'Material "matte" "texture Kd" "nope"\n' + floor + 'WorldEnd\n')
     with pytest.raises(RuntimeError, match="nope"):
         binding.HostScene(path=str(tmp_path / "c.pbrt"))
+
+
+# ---- image readers and the MIP pyramid behind ImageTexture ------------------------------------
+def _png_bytes(arr, ctype, filters):
+    """Minimal PNG writer (8 bit), scanline filter types cycled from `filters`."""
+    import struct
+    import zlib
+    h, w = arr.shape[:2]
+    ch = arr.shape[2] if arr.ndim == 3 else 1
+    a = arr.reshape(h, w * ch).astype(np.int32)
+    prev = np.zeros(w * ch, np.int32)
+    raw = b""
+    for y in range(h):
+        ft = filters[y % len(filters)]
+        row, out = a[y], np.zeros(w * ch, np.int32)
+        for i in range(w * ch):
+            A = row[i - ch] if i >= ch else 0
+            B = prev[i]
+            C = prev[i - ch] if i >= ch else 0
+            if ft == 0:
+                p = 0
+            elif ft == 1:
+                p = A
+            elif ft == 2:
+                p = B
+            elif ft == 3:
+                p = (A + B) // 2
+            else:
+                pp = A + B - C
+                pa, pb, pc = abs(pp - A), abs(pp - B), abs(pp - C)
+                p = A if (pa <= pb and pa <= pc) else (B if pb <= pc else C)
+            out[i] = (row[i] - p) & 255
+        raw += bytes([ft]) + out.astype(np.uint8).tobytes()
+        prev = row
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+
+    z = zlib.compress(raw)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", z[:11]) +
+            chunk(b"tEXt", b"k\0v") + chunk(b"IDAT", z[11:]) + chunk(b"IEND", b""))
+
+
+def test_image_readers_return_what_the_reference_readers_return(binding, tmp_path):
+    """ReadImage (src/core/imageio.cpp:60-82): PNG through every scanline filter and colour type (RGB,
+    RGBA, grey: lodepng_decode24 semantics), PFM in both byte orders / channel counts with its scale and
+    bottom-up rows (imageio.cpp:350-436), TGA bottom-up / top-down, raw / run-length, with alpha
+    (imageio.cpp:216-256). 8-bit samples come back as c / 255.f, row 0 is the top scanline — the
+    round trip src/tests/imageio.cpp makes through the reference's writers."""
+    import struct
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    want = img.astype(np.float32) / np.float32(255)
+    (tmp_path / "a.png").write_bytes(_png_bytes(img, 2, [0, 1, 2, 3, 4]))
+    assert (binding.read_image(str(tmp_path / "a.png")) == want).all()
+    rgba = np.concatenate([img, rng.integers(0, 256, (5, 7, 1), dtype=np.uint8)], 2)
+    (tmp_path / "b.png").write_bytes(_png_bytes(rgba, 6, [4, 3, 1]))
+    assert (binding.read_image(str(tmp_path / "b.png")) == want).all()
+    (tmp_path / "c.png").write_bytes(_png_bytes(img[:, :, :1], 0, [2, 4]))
+    assert (binding.read_image(str(tmp_path / "c.png")) == np.repeat(want[:, :, :1], 3, 2)).all()
+    bad = bytearray(_png_bytes(img, 2, [0]))
+    bad[40] ^= 1  # inside IHDR/IDAT: the CRC no longer matches
+    (tmp_path / "bad.png").write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError, match="Error reading PNG"):
+        binding.read_image(str(tmp_path / "bad.png"))
+
+    f = rng.random((4, 6, 3), dtype=np.float32)
+    (tmp_path / "a.pfm").write_bytes(b"PF\n6 4\n-1.0\n" + f[::-1].tobytes())
+    assert (binding.read_image(str(tmp_path / "a.pfm")) == f).all()
+    (tmp_path / "b.pfm").write_bytes(b"PF\n6 4\n2.0\n" + f[::-1].astype(">f4").tobytes())
+    assert (binding.read_image(str(tmp_path / "b.pfm")) == f * np.float32(2)).all()
+    (tmp_path / "c.pfm").write_bytes(b"Pf\n6 4\n-1.0\n" + f[::-1, :, 0].tobytes())
+    assert (binding.read_image(str(tmp_path / "c.pfm")) == np.repeat(f[:, :, :1], 3, 2)).all()
+    (tmp_path / "d.pfm").write_bytes(b"P6\n6 4\n-1.0\n")
+    with pytest.raises(RuntimeError, match="Error reading PFM file"):
+        binding.read_image(str(tmp_path / "d.pfm"))
+
+    def tga(arr, top, rle=False, alpha=False):
+        h, w = arr.shape[:2]
+        bgr = arr[:, :, ::-1]
+        if alpha:
+            bgr = np.concatenate([bgr, np.full((h, w, 1), 200, np.uint8)], 2)
+        rows = bgr if top else bgr[::-1]
+        bpp = 4 if alpha else 3
+        hdr = struct.pack("<BBBHHBHHHHBB", 0, 0, 10 if rle else 2, 0, 0, 0, 0, 0, w, h, 8 * bpp,
+                          (0x20 if top else 0) | (8 if alpha else 0))
+        px = rows.reshape(-1, bpp)
+        if not rle:
+            return hdr + px.tobytes()
+        body, i = b"", 0
+        while i < len(px):  # alternate raw packets of up to 3 pixels and run packets of 1
+            if (i // 3) % 2 == 0:
+                n = min(3, len(px) - i)
+                body += bytes([n - 1]) + px[i:i + n].tobytes()
+            else:
+                n = 1
+                body += bytes([0x80]) + px[i].tobytes()
+            i += n
+        return hdr + body
+
+    (tmp_path / "a.tga").write_bytes(tga(img, top=False))
+    assert (binding.read_image(str(tmp_path / "a.tga")) == want).all()
+    (tmp_path / "b.tga").write_bytes(tga(img, top=True, rle=True, alpha=True))
+    assert (binding.read_image(str(tmp_path / "b.tga")) == want).all()
+    with pytest.raises(RuntimeError, match="OpenEXR"):
+        binding.read_image(str(tmp_path / "x.exr"))
+    with pytest.raises(RuntimeError, match='stored in format "gif"'):
+        binding.read_image(str(tmp_path / "x.gif"))
+
+
+def _texture_scene(tmp_path, binding, texture_line):
+    (tmp_path / "tex.pbrt").write_text(
+        'Camera "perspective"\nFilm "image" "integer xresolution" [4] "integer yresolution" [4]\n'
+        'Sampler "halton" "integer pixelsamples" [1]\nWorldBegin\nLightSource "point"\n' + texture_line +
+        '\nMaterial "matte" "texture Kd" ["t"]\nShape "trianglemesh" "point P" [0 0 1 1 0 1 0 1 1] "integer indices" [0 1 2]\nWorldEnd\n')
+    return binding.HostScene(path=str(tmp_path / "tex.pbrt"))
+
+
+def test_mip_pyramid_follows_the_reference_constructor(binding, tmp_path):
+    """ImageTexture::GetTexture + MIPMap's constructor (imagemap.cpp:53-101, mipmap.h:111-208): a
+    power-of-two float image becomes level 0 unchanged but for the y flip; each further level is the 2 x 2
+    box average (.25f * (((a + b) + c) + d)) down to 1 x 1; an 8-bit image goes through InverseGammaCorrect
+    and `scale`; a non-power-of-two image is Lanczos-resampled up to the next powers of two (a constant image
+    stays constant: the four weights are normalised); a missing file becomes the 1 x 1 grey texture (0.5 before convertIn)."""
+    rng = np.random.default_rng(3)
+    f = rng.random((8, 16, 3), dtype=np.float32)
+    (tmp_path / "p.pfm").write_bytes(b"PF\n16 8\n-1.0\n" + f[::-1].tobytes())
+    scene = _texture_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["p.pfm"]')
+    t, levels = scene.texture(0)
+    assert (t.n_levels, t.wrap, t.trilinear, t.max_aniso, t.su, t.sv, t.du, t.dv) == (5, 0, 0, 8.0, 1.0, 1.0, 0.0, 0.0)
+    assert [l.shape[:2] for l in levels] == [(8, 16), (4, 8), (2, 4), (1, 2), (1, 1)]
+    assert (levels[0] == f[::-1]).all()
+    for fine, coarse in zip(levels[:-1], levels[1:]):
+        h, w = fine.shape[:2]
+        ys, xs = np.arange(coarse.shape[0]), np.arange(coarse.shape[1])
+        a = fine[(2 * ys)[:, None] % h, (2 * xs)[None] % w]
+        b = fine[(2 * ys)[:, None] % h, (2 * xs + 1)[None] % w]
+        c = fine[(2 * ys + 1)[:, None] % h, (2 * xs)[None] % w]
+        d = fine[(2 * ys + 1)[:, None] % h, (2 * xs + 1)[None] % w]
+        assert (coarse == np.float32(.25) * (((a + b) + c) + d)).all()
+
+    img = rng.integers(0, 256, (4, 4, 3), dtype=np.uint8)
+    (tmp_path / "g.png").write_bytes(_png_bytes(img, 2, [0]))
+    scene = _texture_scene(tmp_path, binding, 'Texture "t" "color" "imagemap" "string filename" ["g.png"] "float scale" [.5] '
+                                               '"string wrap" ["clamp"] "bool trilinear" ["true"] "float uscale" [2]')
+    t, levels = scene.texture(0)
+    assert (t.wrap, t.trilinear, t.su) == (2, 1, 2.0)
+    v = img[::-1].astype(np.float32) / np.float32(255)
+    lin = np.where(v <= np.float32(0.04045), v * np.float32(1) / np.float32(12.92),
+                   ((v + np.float32(0.055)) * np.float32(1) / np.float32(1.055)).astype(np.float64) ** 2.4)
+    assert np.allclose(levels[0], np.float32(.5) * lin.astype(np.float32), rtol=3e-7, atol=0)
+    scene = _texture_scene(tmp_path, binding, 'Texture "t" "color" "imagemap" "string filename" ["g.png"] "bool gamma" ["false"]')
+    assert (scene.texture(0)[1][0] == v).all()
+
+    const = np.full((5, 12, 3), np.float32(0.625), np.float32)
+    (tmp_path / "c.pfm").write_bytes(b"PF\n12 5\n-1.0\n" + const.tobytes())
+    scene = _texture_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["c.pfm"]')
+    t, levels = scene.texture(0)
+    assert [l.shape[:2] for l in levels] == [(8, 16), (4, 8), (2, 4), (1, 2), (1, 1)]
+    for l in levels:
+        assert np.abs(l - np.float32(0.625)).max() < 2e-7
+
+    scene = _texture_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["missing.png"]')
+    t, levels = scene.texture(0)
+    # the grey replacement goes through convertIn like any texel: a .png name means gamma = true
+    assert t.n_levels == 1 and np.allclose(levels[0], ((0.5 + 0.055) / 1.055) ** 2.4, rtol=1e-6)
+
+    for bad, why in (('Texture "t" "float" "imagemap" "string filename" ["p.pfm"]', "float image textures"),
+                     ('Texture "t" "spectrum" "imagemap" "string filename" ["p.pfm"] "string mapping" ["spherical"]', "mapping")):
+        with pytest.raises(RuntimeError, match=why):
+            _texture_scene(tmp_path, binding, bad)

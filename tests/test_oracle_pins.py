@@ -429,3 +429,120 @@ def test_portable_atan2_accuracy(oracle):
     got = np.array([lib.oracle_atan2_d(float(y), float(x)) for y, x in zip(ys, xs)])
     ref = np.arctan2(ys, xs)
     assert (np.abs(got - ref) <= np.spacing(np.abs(ref))).all()
+
+
+# ---- image textures -------------------------------------------------------------------------------------
+def _quad_scene(tmp_path, binding, texture_line, xres=64, yres=64, spp=4, fov=40, dist=5.0, half=1.0, name="quad.pbrt"):
+    """A uv-mapped square of side 2 * half facing the camera at distance `dist`, lit by a point light."""
+    (tmp_path / name).write_text(
+        'LookAt 0 0 0  0 0 1  0 1 0\nCamera "perspective" "float fov" [%g]\n'
+        'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]\nSampler "halton" "integer pixelsamples" [%d]\n'
+        'WorldBegin\nLightSource "point" "point from" [0 0 0]\n%s\nMaterial "matte" "texture Kd" ["t"]\n'
+        'Shape "trianglemesh" "point P" [%g %g %g  %g %g %g  %g %g %g  %g %g %g] "integer indices" [0 1 2 0 2 3] '
+        '"float uv" [0 0 1 0 1 1 0 1]\nWorldEnd\n' % (fov, xres, yres, spp, texture_line, -half, -half, dist, half, -half, dist,
+                                                        half, half, dist, -half, half, dist))
+    return binding.HostScene(path=str(tmp_path / name))
+
+
+def test_camera_ray_differentials_match_the_pixel_footprint(binding, oracle, tmp_path):
+    """GenerateRayDifferential + ScaleDifferentials + ComputeDifferentials (perspective.cpp:124-148,
+    integrator.cpp:284-285, interaction.cpp:103-149) against geometry: on a square of side 2 facing the
+    camera at distance 5 (uv = position / 2 + 1/2), one pixel step moves the hit by 2 * 5 * tan(fov / 2) / yres,
+    so |du/dx| = |dv/dy| = that / 2 / sqrt(spp) and the cross terms vanish; (u, v) follow the pixel linearly."""
+    rng = np.random.default_rng(7)
+    (tmp_path / "w.pfm").write_bytes(b"PF\n2 2\n-1.0\n" + rng.random((2, 2, 3), dtype=np.float32).tobytes())
+    for spp in (1, 4, 16):
+        scene = _quad_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["w.pfm"]', spp=spp)
+        step = 2 * 5.0 * np.tan(np.radians(40.0) / 2) / 64
+        want = step / 2 / np.sqrt(spp)
+        for pfx, pfy in ((32.0, 32.0), (20.5, 40.25), (40.0, 25.0), (28.125, 35.5)):
+            d = oracle.camera_hit_differentials(scene, pfx, pfy)
+            assert d is not None
+            u, v, dudx, dvdx, dudy, dvdy = (float(x) for x in d)
+            # raster x grows towards -x of this camera frame, raster y downwards
+            assert abs(abs(dudx) - want) < 2e-3 * want and abs(abs(dvdy) - want) < 2e-3 * want
+            assert abs(dvdx) < 1e-3 * want and abs(dudy) < 1e-3 * want
+            assert abs(u - (0.5 - (pfx - 32) * step / 2)) < 1e-5 or abs(u - (0.5 + (pfx - 32) * step / 2)) < 1e-5
+            assert abs(v - (0.5 - (pfy - 32) * step / 2)) < 1e-5
+    assert oracle.camera_hit_differentials(scene, 0.5, 0.5) is None  # the corner ray misses the square
+
+
+def test_texture_lookup_properties(binding, oracle, tmp_path):
+    """MIPMap::Lookup (mipmap.h:233-355) held to what it must satisfy whatever the filter: at texel centres
+    with no differentials the bilinear `triangle` returns the texel itself; a constant image returns its
+    constant under EWA, trilinear and bilinear filtering; a footprint as wide as the image returns the
+    1 x 1 level (the image mean for a power-of-two image); black / clamp / repeat wrap modes differ exactly
+    outside [0, 1]^2; the portable log2 behind the level choice is libm's to the last bit."""
+    rng = np.random.default_rng(11)
+    f = rng.random((8, 8, 3), dtype=np.float32)
+    (tmp_path / "r.pfm").write_bytes(b"PF\n8 8\n-1.0\n" + f.tobytes())  # PFM rows run bottom-up: f[0] is v just above 0
+    scene = _quad_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["r.pfm"]')
+    ys, xs = np.mgrid[0:8, 0:8]
+    uv = np.stack([(xs.ravel() + .5) / 8, (ys.ravel() + .5) / 8], -1).astype(np.float32)
+    zero = np.zeros((64, 4), np.float32)
+    assert (oracle.texture_eval(scene, 0, uv, zero) == f.reshape(64, 3)).all()
+    # the whole image inside the footprint: trilinear -> level n-1; EWA keeps filtering
+    wide = np.tile(np.float32([[1.0, 0, 0, 1.0]]), (64, 1))
+    mean = f.astype(np.float64).mean((0, 1))
+    assert np.allclose(oracle.texture_eval(scene, 0, uv, wide), mean, rtol=0.2)
+    scene_tri = _quad_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["r.pfm"] "bool trilinear" ["true"]')
+    top = oracle.texture_eval(scene_tri, 0, uv, wide)
+    assert (top == top[0]).all() and np.allclose(top[0], mean, rtol=1e-6)
+    assert (scene_tri.texture(0)[1][-1].reshape(3) == top[0]).all()
+
+    const = np.full((4, 4, 3), np.float32(0.625), np.float32)
+    (tmp_path / "c.pfm").write_bytes(b"PF\n4 4\n-1.0\n" + const.tobytes())
+    n = 4096
+    uvr = rng.uniform(-2, 3, (n, 2)).astype(np.float32)
+    dr = (rng.standard_normal((n, 4)) * 10.0 ** rng.uniform(-4, 0.5, (n, 1))).astype(np.float32)
+    dr[::7] = 0
+    dr[3::11, 2:] = 0
+    for opts in ('', ' "bool trilinear" ["true"]', ' "float maxanisotropy" [1]', ' "string wrap" ["clamp"]'):
+        sc = _quad_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["c.pfm"]' + opts)
+        got = oracle.texture_eval(sc, 0, uvr, dr)
+        assert np.abs(got - 0.625).max() < 3e-7, opts
+
+    # wrap modes, bilinear at level 0: inside the unit square all three agree; outside, "black" is 0 and
+    # "clamp" repeats the border texel while "repeat" tiles
+    res = {}
+    for wrap in ("repeat", "black", "clamp"):
+        sc = _quad_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["r.pfm"] "string wrap" ["%s"]' % wrap)
+        res[wrap] = oracle.texture_eval(sc, 0, uvr, np.zeros((n, 4), np.float32))
+    inside = ((uvr > 1 / 16) & (uvr < 15 / 16)).all(1)
+    far = ((uvr < -1 / 16) | (uvr > 17 / 16)).any(1)
+    assert inside.sum() > 50 and far.sum() > 1000
+    assert (res["repeat"][inside] == res["black"][inside]).all() and (res["repeat"][inside] == res["clamp"][inside]).all()
+    assert (res["black"][far] == 0).all()
+    tiled = oracle.texture_eval(sc, 0, uvr, np.zeros((n, 4), np.float32))  # (sc is the clamp scene)
+    cu = np.clip(uvr, 1 / 16, 15 / 16).astype(np.float32)
+    assert np.allclose(tiled, oracle.texture_eval(sc, 0, cu, np.zeros((n, 4), np.float32)), atol=1e-6)
+    wrapped = (uvr - np.floor(uvr)).astype(np.float32)
+    ok = ((wrapped > 1 / 16) & (wrapped < 15 / 16)).all(1)
+    sc = _quad_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["r.pfm"]')
+    assert np.allclose(res["repeat"][ok], oracle.texture_eval(sc, 0, wrapped, np.zeros((n, 4), np.float32))[ok], atol=2e-5)
+
+    x = (np.float32(10.0) ** rng.uniform(-30, 30, 4000)).astype(np.float32)
+    assert (oracle.log(x) == np.log(x.astype(np.float64)).astype(np.float32)).all()
+    assert (oracle.log(x, trig_mode=ob.TRIG_LIBM) == oracle.log(x)).mean() > 0.99
+
+
+def test_constant_image_texture_renders_like_the_constant(binding, oracle, tmp_path):
+    """Film-level pin of the whole texture path (differentials -> mapping -> filtered lookup -> material):
+    the tetrahedron white furnace with Kd read from a constant 0.5 image (all pyramid levels exactly 0.5) is
+    the furnace with the constant Kd = 0.5, to the rounding of the filter weights' sum."""
+    import os
+    src = open(os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_tetrahedron.pbrt")).read()
+    src = src.replace('[256]', '[16]')
+    (tmp_path / "half.pfm").write_bytes(b"PF\n4 4\n-1.0\n" + np.full((4, 4, 3), np.float32(.5), np.float32).tobytes())
+    (tmp_path / "plain.pbrt").write_text(src)
+    films = {}
+    for opts in ("", ' "bool trilinear" ["true"]'):
+        tex = src.replace('Material "matte" "color Kd" [.5 .5 .5]',
+                          'Texture "half" "spectrum" "imagemap" "string filename" ["half.pfm"]%s\n'
+                          'Material "matte" "texture Kd" ["half"]' % opts)
+        assert tex != src
+        (tmp_path / "tex.pbrt").write_text(tex)
+        films[opts], _ = oracle.render(binding.HostScene(path=str(tmp_path / "tex.pbrt")))
+    plain, _ = oracle.render(binding.HostScene(path=str(tmp_path / "plain.pbrt")))
+    for f in films.values():
+        assert np.allclose(f, plain, rtol=2e-6, atol=0)
