@@ -39,8 +39,13 @@ enum {
     IILE_PRIM_SPHERE = 1u << 0,      /* else triangle */
     IILE_PRIM_HAS_NORMALS = 1u << 1, /* TriangleMesh::n != null */
     IILE_PRIM_HAS_UV = 1u << 2,      /* TriangleMesh::uv != null */
-    IILE_PRIM_FLIP = 1u << 3         /* reverseOrientation ^ transformSwapsHandedness */
+    IILE_PRIM_FLIP = 1u << 3,        /* reverseOrientation ^ transformSwapsHandedness */
+    IILE_PRIM_HAS_ALPHA = 1u << 4    /* TriangleMesh::alphaMask or shadowAlphaMask: see prim_alpha */
 };
+/* prim_alpha values: an image texture index (a "float" imagemap: all three channels of its texels hold
+ * the float), or */
+#define IILE_ALPHA_NONE (-1) /* no mask (or a constant non-zero one: it never rejects) */
+#define IILE_ALPHA_ZERO (-2) /* ConstantTexture<Float>(0): every hit is rejected */
 
 /* Sphere, src/shapes/sphere.h:47-76 + Shape base (src/core/shape.cpp:45-52). */
 typedef struct iile_sphere {
@@ -179,6 +184,8 @@ typedef struct iile_scene_desc {
     const float *tri_p;            /* [n_prims*9] world-space p0,p1,p2 (unused for spheres) */
     const float *tri_n;            /* [n_prims*9] world-space vertex normals (if HAS_NORMALS) */
     const float *tri_uv;           /* [n_prims*6] (if HAS_UV) */
+    const int32_t *prim_alpha;     /* [n_prims*2] {alphaMask, shadowAlphaMask} of the primitive's mesh
+                                      (triangle.cpp:325-331, 509-541); NULL when no primitive has HAS_ALPHA */
     int32_t n_spheres;
     const iile_sphere *spheres;
     int32_t n_materials;

@@ -927,7 +927,9 @@ struct Oracle {
 
     // ------------------------------------------------------------------------
     // Triangle (shapes/triangle.cpp:188-403, 405-544)
-    bool triangle_test(const Ray &ray, int prim, float *t_out, float *b0o, float *b1o, float *b2o) const {
+    // alpha_mode: 0 = testAlphaTexture false (Shape::Pdf's Intersect, shape.cpp:72-87); 1 = Triangle::Intersect
+    // (alphaMask, triangle.cpp:325-331); 2 = Triangle::IntersectP (alphaMask and shadowAlphaMask, :509-541)
+    bool triangle_test(const Ray &ray, int prim, float *t_out, float *b0o, float *b1o, float *b2o, int alpha_mode = 0) const {
         ++ctr->tri_tests;
         const float *tp = S.tri_p + 9 * size_t(prim);
         V3 p0(tp[0], tp[1], tp[2]), p1(tp[3], tp[4], tp[5]), p2(tp[6], tp[7], tp[8]);
@@ -986,6 +988,25 @@ struct Oracle {
         float max_e = max_component(vabs(V3(e0, e1, e2)));
         float delta_t = 3 * (gamma_n(3) * max_e * max_zt + delta_e * max_zt + delta_z * max_e) * std::abs(inv_det);
         if (t <= delta_t) return false;
+        if (alpha_mode != 0 && (S.prim_flags[prim] & IILE_PRIM_HAS_ALPHA) && S.prim_alpha) {
+            // isectLocal carries uvHit and zero differentials: an ImageTexture filters bilinearly at level 0
+            float uv[3][2] = {{0, 0}, {1, 0}, {1, 1}};
+            if (S.prim_flags[prim] & IILE_PRIM_HAS_UV) {
+                const float *u = S.tri_uv + 6 * size_t(prim);
+                for (int i = 0; i < 3; ++i) {
+                    uv[i][0] = u[2 * i];
+                    uv[i][1] = u[2 * i + 1];
+                }
+            }
+            Isect local;
+            local.uv[0] = b0 * uv[0][0] + b1 * uv[1][0] + b2 * uv[2][0];
+            local.uv[1] = b0 * uv[0][1] + b1 * uv[1][1] + b2 * uv[2][1];
+            for (int k = 0; k < alpha_mode; ++k) {
+                const int mask = S.prim_alpha[2 * size_t(prim) + k];
+                if (mask == IILE_ALPHA_ZERO) return false;
+                if (mask >= 0 && tex_evaluate(mask, local).c[0] == 0) return false;
+            }
+        }
         *t_out = t;
         *b0o = b0;
         *b1o = b1;
@@ -1205,7 +1226,7 @@ struct Oracle {
                             }
                         } else {
                             float t, b0, b1, b2;
-                            if (triangle_test(ray, prim, &t, &b0, &b1, &b2)) {
+                            if (triangle_test(ray, prim, &t, &b0, &b1, &b2, 1)) {
                                 hit = true;
                                 ray.tmax = t;
                                 is->prim = prim;
@@ -1251,7 +1272,7 @@ struct Oracle {
             return sphere_test(ray, S.spheres[S.prim_shape[prim]], &orr, &t, &ph);
         }
         float t, b0, b1, b2;
-        return triangle_test(ray, prim, &t, &b0, &b1, &b2);
+        return triangle_test(ray, prim, &t, &b0, &b1, &b2, 1);
     }
     bool intersect_p(const Ray &ray) const {
         ++ctr->shadow_rays;
@@ -1274,7 +1295,7 @@ struct Oracle {
                             if (sphere_test(ray, S.spheres[S.prim_shape[prim]], &orr, &t, &ph)) return true;
                         } else {
                             float t, b0, b1, b2;
-                            if (triangle_test(ray, prim, &t, &b0, &b1, &b2)) return true;
+                            if (triangle_test(ray, prim, &t, &b0, &b1, &b2, 2)) return true;
                         }
                     }
                     if (to_visit == 0) break;

@@ -459,7 +459,10 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             // class (material type, +4 for a sphere), bits 8..11 area light index + 1
             const int mt = d->prim_material[i] >= 0 ? d->materials[d->prim_material[i]].type : 3;
             const uint32_t cls = uint32_t(mt < 0 ? 3 : (mt > 3 ? 3 : mt)) | ((d->prim_flags[i] & 1u) ? 4u : 0u);
-            uint32_t w[3] = {d->prim_flags[i] | last_in_leaf[i] | (cls == 7u ? 6u : cls) << 5 | (uint32_t(d->prim_light[i] + 1) << 8),
+            const bool masked = (d->prim_flags[i] & IILE_PRIM_HAS_ALPHA) && d->prim_alpha &&
+                                (d->prim_alpha[2 * i] != IILE_ALPHA_NONE || d->prim_alpha[2 * i + 1] != IILE_ALPHA_NONE);
+            if (masked) S.has_alpha = 1;  // bit 12 of the flag word
+            uint32_t w[3] = {(d->prim_flags[i] & 15u) | (masked ? 4096u : 0u) | last_in_leaf[i] | (cls == 7u ? 6u : cls) << 5 | (uint32_t(d->prim_light[i] + 1) << 8),
                              uint32_t(d->prim_material[i]), uint32_t(d->prim_light[i])};
             for (int k = 0; k < 3; ++k) {
                 float wf;
@@ -486,6 +489,16 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         if (rc) return bail(rc);
         rc = upload(sc, d->prim_shape, n, &S.prim_shape);
         if (rc) return bail(rc);
+        if (S.has_alpha) {
+            std::vector<int2> masks(n);
+            for (size_t i = 0; i < n; ++i) {
+                masks[i] = make_int2(d->prim_alpha[2 * i], d->prim_alpha[2 * i + 1]);
+                for (int m : {masks[i].x, masks[i].y})
+                    if (m >= d->n_textures || m < IILE_ALPHA_ZERO) return bail(fail(IILE_ERR_ARG, "alpha mask refers to a texture that does not exist"));
+            }
+            rc = upload(sc, masks.data(), masks.size(), &S.prim_alpha);
+            if (rc) return bail(rc);
+        }
     }
     {
         std::vector<DSphere> sp(d->n_spheres);

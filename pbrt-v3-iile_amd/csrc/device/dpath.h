@@ -842,9 +842,38 @@ DEV void trav_step(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st)
         trav_interior_step_fast(S, t, sr);
 }
 
+// screen-space derivatives of a hit's (u, v): SurfaceInteraction::dudx ... (interaction.h:127-128)
+struct TexDiff {
+    float dudx, dvdx, dudy, dvdy;
+};
+DEV F3 tex_evaluate(const DScene &S, int tex, float u, float v, const TexDiff &td);  // defined with the textures below
+
+// The alpha test of Triangle::Intersect / IntersectP (triangle.cpp:325-331, 509-541) on a hit that passed the
+// geometric test: isectLocal carries uvHit and zero differentials, so an ImageTexture<Float, Float> filters
+// bilinearly at level 0. any_hit (IntersectP) also asks the shadow alpha mask.
+DEV bool alpha_rejects(const DScene &S, int prim, uint32_t flags, float b0, float b1, float b2, bool any_hit) {
+    float uv00 = 0, uv01 = 0, uv10 = 1, uv11 = 0, uv20 = 1, uv21 = 1;  // triangle.h:98-108
+    if (flags & 4u) {
+        const float2 *u = S.tri_uv + 3 * size_t(prim);
+        const float2 a = u[0], b = u[1], c = u[2];
+        uv00 = a.x, uv01 = a.y, uv10 = b.x, uv11 = b.y, uv20 = c.x, uv21 = c.y;
+    }
+    const float u = b0 * uv00 + b1 * uv10 + b2 * uv20, v = b0 * uv01 + b1 * uv11 + b2 * uv21;
+    const int2 masks = S.prim_alpha[prim];
+    const TexDiff zero = TexDiff{0, 0, 0, 0};
+    if (masks.x == -2) return true;  // IILE_ALPHA_ZERO
+    if (masks.x >= 0 && tex_evaluate(S, masks.x, u, v, zero).x == 0) return true;
+    if (any_hit) {
+        if (masks.y == -2) return true;
+        if (masks.y >= 0 && tex_evaluate(S, masks.y, u, v, zero).x == 0) return true;
+    }
+    return false;
+}
+
 // ray_d: the float4 record holding the ray direction — only the (rare) sphere
 // test needs it, so it is re-read there instead of living in registers.
-template <bool COUNT>
+// ALPHA: some mesh of the scene has an alpha mask (vertex-record flag bit 12 marks its triangles)
+template <bool COUNT, bool ALPHA = false>
 DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st, const bool any_hit,
                    const float4 *ray_d) {
     int prim = t.cur < 0 ? ~t.cur : 0;  // clamped like trav_interior's index; tri_verts has one pad record
@@ -873,7 +902,8 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
             if (COUNT) ++st->tris;
             float th, b0, b1, b2;
             if (triangle_test(t.rc, t.tmax, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, &th, &b0,
-                              &b1, &b2)) {
+                              &b1, &b2) &&
+                !(ALPHA && (flags & 4096u) && alpha_rejects(S, prim, flags, b0, b1, b2, any_hit))) {
                 if (COUNT) ++st->tri_hits;
                 if (any_hit) {
                     t.have = false;
@@ -901,7 +931,7 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
 }
 
 // single-ray wrapper (kernel-level probes)
-template <bool ANY_HIT, bool COUNT>
+template <bool ANY_HIT, bool COUNT, bool ALPHA = true>
 DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack, int *spill, uint32_t spill_stride,
                   HitRec *hit, TraceStats *st) {
     Trav t;
@@ -910,7 +940,7 @@ DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack,
     trav_begin<COUNT>(S, t, ro, rd, tmax, st);
     while (t.have) {
         while (t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, st);
-        if (t.have && trav_leaf<COUNT>(S, t, sr, st, ANY_HIT, &d4)) return true;
+        if (t.have && trav_leaf<COUNT, ALPHA>(S, t, sr, st, ANY_HIT, &d4)) return true;
     }
     hit->prim = hit_index(t.hit_prim);
     hit->t = t.tmax;
@@ -945,9 +975,6 @@ DEV F3 to_world(const Bsdf &b, F3 v) {
 // UVMapping2D::Map (texture.cpp:93-99), MIPMap<RGBSpectrum>::Lookup / triangle / EWA / Texel
 // (mipmap.h:210-355) over the host-built pyramid — operation for operation as the oracle's tex_* functions
 // ===========================================================================
-struct TexDiff {
-    float dudx, dvdx, dudy, dvdy;
-};
 DEV bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float *x0, float *x1) {  // transform.cpp:41-49
     const float det = a00 * a11 - a01 * a10;
     if (fabsf(det) < 1e-10f) return false;

@@ -82,6 +82,7 @@ struct DScene {
     const float4 *tri_norms;  // 3 float4 per primitive: (n.xyz, uv.{x,y} spread over w)
     const float2 *tri_uv;     // 3 float2 per primitive
     const int *prim_shape;    // sphere index for sphere primitives
+    const int2 *prim_alpha;   // {alphaMask, shadowAlphaMask} texture per primitive (has_alpha scenes)
     const uint16_t *perms;
     const DHaltonDim *hdims;
     const uint32_t *pixel_offsets;  // [128*128] Halton index offset of pixel (x mod 128, y mod 128)
@@ -102,6 +103,7 @@ struct DScene {
     int has_infinite;         // some light is an InfiniteAreaLight: escaped rays carry radiance (k_miss)
     int extended_features;    // anything beyond one emitting sphere + matte / plastic: k_shade<.., EXT = true>
     int has_glass;            // some material transmits: the paths' etaScale is tracked
+    int has_alpha;            // some mesh has an alpha mask: the ALPHA builds of the traversal kernels run
     int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide
                               // step's skipping of intermediate nodes is exact only then
     // camera

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
 // ---------------------------------------------------------------------------
 // extend: BVHAccel::Intersect for every ray of queue `bounce & 1`; hits are
 // appended (ballot-compacted) to the shade queue.
-template <bool COUNT>
+template <bool COUNT, bool ALPHA>
 __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, PassBuffers B, int bounce) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
@@ -301,12 +301,12 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
-                if (wl) trav_leaf<COUNT>(S, t, sr, &st, false, &rd[slot]);
+                if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &rd[slot]);
             }
         }
 #else
         while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
-        if (active && t.have) trav_leaf<COUNT>(S, t, sr, &st, false, &rd[slot]);
+        if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &rd[slot]);
 #endif
         const bool fin = active && !t.have;
         const bool is_hit = fin && t.hit_prim >= 0;
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
 // closest-hit lanes in one wavefront keep each other waiting.)
 
 
-template <bool COUNT>
+template <bool COUNT, bool ALPHA>
 __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
@@ -951,12 +951,12 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
-                if (wl && trav_leaf<COUNT>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
+                if (wl && trav_leaf<COUNT, ALPHA>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
             }
         }
 #else
         while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
-        if (active && t.have && trav_leaf<COUNT>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
+        if (active && t.have && trav_leaf<COUNT, ALPHA>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
 #endif
         if (active && !t.have) {
             const F3 add = occluded ? add_occluded : add_unoccluded;
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool ALPHA>
 __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
@@ -1029,12 +1029,12 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
-                if (wl) trav_leaf<COUNT>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
+                if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
             }
         }
 #else
         while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
-        if (active && t.have) trav_leaf<COUNT>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
+        if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
 #endif
         if (active && !t.have) {
             // store only: (area light index + 1) of the primitive the MIS ray ended on, 0 for none
@@ -1381,9 +1381,14 @@ void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, c
 void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_extend<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+        hipLaunchKernelGGL((k_extend<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
     else
-        hipLaunchKernelGGL(k_extend<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+        {
+        if (S.has_alpha)
+            hipLaunchKernelGGL((k_extend<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+        else
+            hipLaunchKernelGGL((k_extend<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+    }
 }
 void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
 #ifndef IILE_SHADE_BLOCKS
@@ -1407,16 +1412,26 @@ void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int 
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_shadow<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+        hipLaunchKernelGGL((k_shadow<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
     else
-        hipLaunchKernelGGL(k_shadow<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+        {
+        if (S.has_alpha)
+            hipLaunchKernelGGL((k_shadow<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+        else
+            hipLaunchKernelGGL((k_shadow<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+    }
 }
 void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL(k_mis<true>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+        hipLaunchKernelGGL((k_mis<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
     else
-        hipLaunchKernelGGL(k_mis<false>, grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+        {
+        if (S.has_alpha)
+            hipLaunchKernelGGL((k_mis<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+        else
+            hipLaunchKernelGGL((k_mis<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+    }
 }
 void launch_light_distributions(const DScene &S, const float *samples, float *out, const LaunchCfg &cfg) {
     const int n = S.light_nv[0] * S.light_nv[1] * S.light_nv[2];

@@ -171,6 +171,12 @@ void build_bvh(HostScene *scene) {
     scene->o_tri_p.assign(n * 9, 0.f);
     scene->o_tri_n.assign(n * 9, 0.f);
     scene->o_tri_uv.assign(n * 6, 0.f);
+    scene->o_alpha.clear();
+    for (const HostPrim &p : scene->prims)
+        if (p.flags & IILE_PRIM_HAS_ALPHA) {
+            scene->o_alpha.assign(n * 2, IILE_ALPHA_NONE);
+            break;
+        }
     for (size_t i = 0; i < n; ++i) {
         const HostPrim &p = scene->prims[b.ordered[i]];
         scene->o_flags[i] = p.flags;
@@ -183,6 +189,10 @@ void build_bvh(HostScene *scene) {
                 scene->o_tri_n[9 * i + 3 * k + c] = p.n[k][c];
             }
         for (int c = 0; c < 6; ++c) scene->o_tri_uv[6 * i + c] = p.uv[c];
+        if (!scene->o_alpha.empty()) {
+            scene->o_alpha[2 * i] = p.alpha;
+            scene->o_alpha[2 * i + 1] = p.shadow_alpha;
+        }
     }
 }
 

@@ -99,6 +99,7 @@ bool finalize_scene(HostScene *s, std::string *err) {
     d.prim_material = s->o_material.data();
     d.prim_light = s->o_light.data();
     d.prim_shape = s->o_shape.data();
+    d.prim_alpha = s->o_alpha.empty() ? nullptr : s->o_alpha.data();
     d.tri_p = s->o_tri_p.data();
     d.tri_n = s->o_tri_n.data();
     d.tri_uv = s->o_tri_uv.data();

@@ -19,6 +19,7 @@ struct HostPrim {
     V3 p[3];
     V3 n[3];
     float uv[6] = {0, 0, 0, 0, 0, 0};
+    int32_t alpha = IILE_ALPHA_NONE, shadow_alpha = IILE_ALPHA_NONE;
     Bounds3 world_bound;
 };
 
@@ -64,6 +65,7 @@ struct HostScene {
     std::vector<uint32_t> o_flags;
     std::vector<int32_t> o_material, o_light, o_shape;
     std::vector<float> o_tri_p, o_tri_n, o_tri_uv;
+    std::vector<int32_t> o_alpha;
     std::vector<uint16_t> perms;
     std::vector<int32_t> primes, prime_sums;
     std::vector<iile_texture> o_textures;
@@ -92,8 +94,8 @@ bool load_ply(const std::string &path, std::vector<V3> *P, std::vector<V3> *N, s
 bool read_image(const std::string &path, std::vector<float> *rgb, int *w, int *h, std::string *err);
 bool image_is_8bit(const std::string &path);
 // mipmap.cpp
-bool build_image_texture(const std::vector<float> &rgb, int width, int height, float scale, bool gamma, HostTexture *out,
-                         std::string *err);
+bool build_image_texture(const std::vector<float> &rgb, int width, int height, float scale, bool gamma, bool as_float,
+                         HostTexture *out, std::string *err);
 void ewa_weight_lut(float *lut);
 float inverse_gamma_correct(float value);
 

@@ -105,14 +105,21 @@ void ewa_weight_lut(float *lut) {  // mipmap.h:199-205
 
 // `rgb`: the image as the readers return it (row 0 = top scanline). Does GetTexture's y flip and convertIn
 // (scale, inverse gamma), then MIPMap's constructor.
-bool build_image_texture(const std::vector<float> &rgb, int width, int height, float scale, bool gamma, HostTexture *out,
-                         std::string *err) {
+// `as_float`: ImageTexture<Float, Float> — each texel is the luminance of the image's texel (convertIn to Float,
+// imagemap.h:101-104), kept in all three channels: MIPMap<Float> does per texel what MIPMap<RGBSpectrum> does
+// per channel, so the pyramid and the lookups are shared.
+bool build_image_texture(const std::vector<float> &rgb, int width, int height, float scale, bool gamma, bool as_float,
+                         HostTexture *out, std::string *err) {
     std::vector<Rgb3> img(size_t(width) * height);
     for (int y = 0; y < height; ++y)
         for (int x = 0; x < width; ++x) {
             const float *src = &rgb[(size_t(height - 1 - y) * width + x) * 3];  // imagemap.cpp:67-74
             Rgb3 &d = img[size_t(y) * width + x];
-            for (int c = 0; c < 3; ++c) d.c[c] = scale * (gamma ? inverse_gamma_correct(src[c]) : src[c]);  // imagemap.h:96-100
+            if (as_float) {
+                const float y = 0.212671f * src[0] + 0.715160f * src[1] + 0.072169f * src[2];  // RGBSpectrum::y()
+                d.c[0] = d.c[1] = d.c[2] = scale * (gamma ? inverse_gamma_correct(y) : y);
+            } else
+                for (int c = 0; c < 3; ++c) d.c[c] = scale * (gamma ? inverse_gamma_correct(src[c]) : src[c]);  // imagemap.h:96-100
         }
     const int wrap = out->t.wrap;
     int res[2] = {width, height};

@@ -629,7 +629,6 @@ class Loader {
                 return false;
             for (int i = 0; i < 3; ++i) t.v[i] = (1 - amt[0]) * a[i] + amt[0] * b[i];
         } else if (cls == "imagemap") {  // CreateImageSpectrumTexture, textures/imagemap.cpp:148-187
-            if (is_float) return fail("float image textures are not supported (spectrum imagemap only)");
             const std::string mapping = ps.one_string("mapping", "uv");
             if (mapping != "uv") return fail("2D texture mapping \"" + mapping + "\" is not supported (uv only)");
             HostTexture ht;
@@ -656,7 +655,7 @@ class Loader {
                 rgb.assign(3, 0.5f);
                 w = h = 1;
             }
-            if (!build_image_texture(rgb, w, h, scale, gamma, &ht, &why)) return fail("Texture \"" + name + "\": " + why);
+            if (!build_image_texture(rgb, w, h, scale, gamma, is_float, &ht, &why)) return fail("Texture \"" + name + "\": " + why);
             scene_->textures.push_back(std::move(ht));
             t.image = int(scene_->textures.size()) - 1;
         } else
@@ -675,7 +674,7 @@ class Loader {
             auto it = gs_.textures.find(p.strs[0]);
             if (it == gs_.textures.end()) return fail("Couldn't find texture named \"" + p.strs[0] + "\" for parameter \"" + p.name + "\"");
             if (it->second.image >= 0) {
-                if (p.name != "Kd" && p.name != "Ks" && p.name != "Kr" && p.name != "Kt")
+                if (it->second.is_float || (p.name != "Kd" && p.name != "Ks" && p.name != "Kr" && p.name != "Kt"))
                     return fail("image texture \"" + p.strs[0] + "\" on parameter \"" + p.name + "\" is not supported (Kd, Ks, Kr, Kt)");
                 (*image_of)[p.name] = it->second.image;
                 p.strs.clear();
@@ -862,7 +861,6 @@ class Loader {
             std::string fn = ps.one_string("filename", "");
             if (fn.empty()) return fail("plymesh: \"filename\" is required");
             if (fn[0] != '/') fn = search_dir_ + "/" + fn;
-            if (ps.find("alpha") || ps.find("shadowalpha")) return fail("alpha masks are not supported");
             std::string perr;
             if (!load_ply(fn, &P, &N, &uv, &indices, &perr)) return fail(perr);
         } else {
@@ -886,7 +884,6 @@ class Loader {
                 for (size_t i = 0; i + 2 < pn->nums.size(); i += 3)
                     N.push_back(V3(float(pn->nums[i]), float(pn->nums[i + 1]), float(pn->nums[i + 2])));
             if (ps.find("S")) return fail("trianglemesh \"S\" tangents are not supported");
-            if (ps.find("alpha") || ps.find("shadowalpha")) return fail("alpha masks are not supported");
         } else if (name == "loopsubdiv") {  // shapes/loopsubdiv.cpp:402-424
             int levels = ps.one_int("levels", ps.one_int("nlevels", 3));
             std::vector<int> oi;
@@ -897,6 +894,28 @@ class Loader {
             N.swap(oN);
         } else
             return fail("Shape \"" + name + "\" is not supported (sphere, trianglemesh, plymesh, loopsubdiv)");
+        // "alpha" / "shadowalpha": a float texture by name, or a float that masks everything when it is 0
+        // (CreateTriangleMeshShape, triangle.cpp:689-710; CreatePLYMesh, plymesh.cpp:259-285)
+        int alpha_mask[2] = {IILE_ALPHA_NONE, IILE_ALPHA_NONE};
+        if (name == "trianglemesh" || name == "plymesh") {
+            const char *pnames[2] = {"alpha", "shadowalpha"};
+            for (int k = 0; k < 2; ++k) {
+                const Param *pa = ps.find(pnames[k]);
+                if (!pa) continue;
+                if (pa->type == "texture") {
+                    if (pa->strs.size() != 1) return fail(std::string("bad texture reference for \"") + pnames[k] + "\"");
+                    auto it = gs_.textures.find(pa->strs[0]);
+                    if (it == gs_.textures.end() || !it->second.is_float)
+                        return fail("Couldn't find float texture \"" + pa->strs[0] + "\" for \"" + pnames[k] + "\" parameter");
+                    if (it->second.image >= 0)
+                        alpha_mask[k] = it->second.image;
+                    else if (it->second.v[0] == 0.f)
+                        alpha_mask[k] = IILE_ALPHA_ZERO;
+                } else if (pa->type == "float" && pa->nums.size() == 1 && float(pa->nums[0]) == 0.f) {
+                    alpha_mask[k] = IILE_ALPHA_ZERO;
+                }
+            }
+        }
         for (int idx : indices)
             if (idx < 0 || idx >= int(P.size())) return fail("trianglemesh has out-of-bounds vertex index");
         // TriangleMesh ctor, shapes/triangle.cpp:54-93: vertices and normals to world space
@@ -909,7 +928,10 @@ class Loader {
         for (size_t t = 0; t < ntris; ++t) {
             HostPrim pr;
             pr.flags = (N.empty() ? 0 : IILE_PRIM_HAS_NORMALS) | (uv.empty() ? 0 : IILE_PRIM_HAS_UV) |
-                       (flip ? IILE_PRIM_FLIP : 0);
+                       (flip ? IILE_PRIM_FLIP : 0) |
+                       ((alpha_mask[0] != IILE_ALPHA_NONE || alpha_mask[1] != IILE_ALPHA_NONE) ? IILE_PRIM_HAS_ALPHA : 0);
+            pr.alpha = alpha_mask[0];
+            pr.shadow_alpha = alpha_mask[1];
             pr.material = mat;
             pr.shape = mesh_id;
             for (int k = 0; k < 3; ++k) {

@@ -91,6 +91,13 @@ def write_test_images(directory, seed=5):
             i = j + 1
     paths["stripes"] = os.path.join(directory, "stripes.tga")
     open(paths["stripes"], "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 10, 0, 0, 0, 0, 0, w, h, 24, 0) + body)
+    # single-channel PFM 8 x 8 alpha mask: zeros (holes), ones, and a few fractional texels
+    m = np.ones((8, 8), np.float32)
+    m[2:6, 1:4] = 0
+    m[0:2, 5:8] = 0
+    m[6, 6] = 0.25
+    paths["mask"] = os.path.join(directory, "mask.pfm")
+    open(paths["mask"], "wb").write(b"Pf\n8 8\n-1.0\n" + m.tobytes())
     return paths
 
 
@@ -157,6 +164,17 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         out.append('Texture "noise-black" "spectrum" "imagemap" "string filename" ["%s"] "string wrap" ["black"] '
                    '"float uscale" [1.5] "float vscale" [1.5] "float maxanisotropy" [2]' % tex["noise"])
         out.append('Texture "stripes" "spectrum" "imagemap" "string filename" ["%s"] "bool gamma" ["false"]' % tex["stripes"])
+        # alpha masks (triangle.cpp:325-331, 509-541): a free-standing screen full of holes whose shadow has
+        # further holes (shadowalpha), and an invisible box ("float alpha" [0]) around a blob
+        out.append('Texture "mask" "float" "imagemap" "string filename" ["%s"] "float uscale" [3] "float vscale" [2]' % tex["mask"])
+        out.append('Texture "mask-coarse" "float" "imagemap" "string filename" ["%s"] "bool trilinear" ["true"]' % tex["mask"])
+        P, F = _grid_quad((-5, -4, -3), (6, 1.5, 0), (0, 0, 7), 6)
+        out.append('AttributeBegin\n  Material "matte" "texture Kd" ["noise"]\n%s  "texture alpha" ["mask"] "texture shadowalpha" ["mask-coarse"]\nAttributeEnd'
+                   % _mesh(P, F, _grid_uv(6, 1.0)))
+        P, F = _grid_quad((1, -6, -2.5), (4, 0, 0), (0, 0, 4), 2)
+        out.append('AttributeBegin\n  Material "mirror"\n%s  "float alpha" [0]\nAttributeEnd' % _mesh(P, F))
+        P, F = _grid_quad((-8, 2, 4), (5, 0, 0), (0, 3, 0), 3)
+        out.append('AttributeBegin\n  Material "matte" "color Kd" [.9 .2 .2]\n%s  "float shadowalpha" [0]\nAttributeEnd' % _mesh(P, F))
     wall_tex = ["checker", "noise", "checker-tri", "stripes", "noise-black"]
     s = 10.0
     walls = [((-s, -s, -3), (2 * s, 0, 0), (0, 2 * s, 0), (.7, .7, .7)),      # floor

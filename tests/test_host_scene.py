@@ -428,7 +428,22 @@ def test_mip_pyramid_follows_the_reference_constructor(binding, tmp_path):
     # the grey replacement goes through convertIn like any texel: a .png name means gamma = true
     assert t.n_levels == 1 and np.allclose(levels[0], ((0.5 + 0.055) / 1.055) ** 2.4, rtol=1e-6)
 
-    for bad, why in (('Texture "t" "float" "imagemap" "string filename" ["p.pfm"]', "float image textures"),
-                     ('Texture "t" "spectrum" "imagemap" "string filename" ["p.pfm"] "string mapping" ["spherical"]', "mapping")):
-        with pytest.raises(RuntimeError, match=why):
-            _texture_scene(tmp_path, binding, bad)
+    with pytest.raises(RuntimeError, match="mapping"):
+        _texture_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["p.pfm"] "string mapping" ["spherical"]')
+    with pytest.raises(RuntimeError, match="image texture"):  # a float image texture cannot stand for a colour
+        _texture_scene(tmp_path, binding, 'Texture "t" "float" "imagemap" "string filename" ["p.pfm"]')
+
+    # ImageTexture<Float, Float>: convertIn takes the texel's luminance (imagemap.h:101-104); used for alpha masks
+    (tmp_path / "alpha.pbrt").write_text(
+        'Camera "perspective"\nFilm "image" "integer xresolution" [4] "integer yresolution" [4]\n'
+        'Sampler "halton" "integer pixelsamples" [1]\nWorldBegin\nLightSource "point"\n'
+        'Texture "a" "float" "imagemap" "string filename" ["p.pfm"] "float scale" [2]\n'
+        'Shape "trianglemesh" "point P" [0 0 1 1 0 1 0 1 1] "integer indices" [0 1 2] "texture alpha" ["a"]\n'
+        'Shape "trianglemesh" "point P" [0 0 2 1 0 2 0 1 2] "integer indices" [0 1 2] "float alpha" [0] "float shadowalpha" [.5]\nWorldEnd\n')
+    scene = binding.HostScene(path=str(tmp_path / "alpha.pbrt"))
+    t, levels = scene.texture(0)
+    y = np.float32(0.212671) * f[::-1, :, 0] + np.float32(0.715160) * f[::-1, :, 1] + np.float32(0.072169) * f[::-1, :, 2]
+    assert (levels[0] == (np.float32(2) * y)[..., None]).all()
+    with pytest.raises(RuntimeError, match="Couldn't find float texture"):
+        _texture_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["p.pfm"]\n'
+                       'Shape "trianglemesh" "point P" [0 0 1 1 0 1 0 1 1] "integer indices" [0 1 2] "texture alpha" ["t"]')

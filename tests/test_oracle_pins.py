@@ -546,3 +546,64 @@ def test_constant_image_texture_renders_like_the_constant(binding, oracle, tmp_p
     plain, _ = oracle.render(binding.HostScene(path=str(tmp_path / "plain.pbrt")))
     for f in films.values():
         assert np.allclose(f, plain, rtol=2e-6, atol=0)
+
+
+def test_alpha_masks(binding, oracle, tmp_path):
+    """Alpha masks of triangle meshes (triangle.cpp:325-331, 509-541; CreateTriangleMeshShape :689-710), pinned on
+    what they must do: (1) a wall whose mask is 0 over half of its texels lets through exactly the camera rays
+    whose bilinearly filtered alpha is 0 — a band of u one texel narrower than the zero half; (2) "float alpha" [0]
+    makes a mesh invisible: the film equals the film of the scene without it, bit for bit; (3) "float shadowalpha" [0]
+    is ignored by camera rays and honoured by shadow rays: with direct lighting only, the floor under such an
+    occluder is lit as if the occluder were not there, while the camera still sees the occluder."""
+    m = np.ones((8, 8), np.float32)
+    m[:, :4] = 0
+    (tmp_path / "half.pfm").write_bytes(b"Pf\n8 8\n-1.0\n" + m.tobytes())
+    head = ('LookAt 0 0 0  0 0 1  0 1 0\nCamera "perspective" "float fov" [40]\n'
+            'Film "image" "integer xresolution" [128] "integer yresolution" [128]\nSampler "halton" "integer pixelsamples" [1]\n'
+            'Integrator "path" "integer maxdepth" [1]\nWorldBegin\nLightSource "point" "point from" [0 0 0]\n')
+    wall = ('Texture "a" "float" "imagemap" "string filename" ["half.pfm"]\nMaterial "matte"\n'
+            'Shape "trianglemesh" "point P" [-3 -3 5  3 -3 5  3 3 5  -3 3 5] "integer indices" [0 1 2 0 2 3] '
+            '"float uv" [0 0 1 0 1 1 0 1] "texture alpha" ["a"]\n')
+    (tmp_path / "wall.pbrt").write_text(head + wall + "WorldEnd\n")
+    scene = binding.HostScene(path=str(tmp_path / "wall.pbrt"))
+    film, st = oracle.render(scene)
+    lit = film[64, :, 1] > 0
+    # columns map linearly to u; alpha(u) == 0 exactly for u in [1/16, 7/16] (texel centres 0.5/8 .. 3.5/8 of
+    # the zero columns: any other u blends in a non-zero texel)
+    step = 2 * 5 * np.tan(np.radians(20.0)) / 128  # world width of one pixel at the wall
+    cols = np.arange(128)
+    u_lo = 0.5 + (cols - 64) * step / 6            # u across the pixel's width (u grows with the column)
+    u_hi = 0.5 + (cols + 1 - 64) * step / 6
+    surely_hole = (u_lo > 1 / 16 + 1e-4) & (u_hi < 7 / 16 - 1e-4)
+    surely_wall = (u_lo > 7 / 16 + 1e-4) | (u_hi < 1 / 16 - 1e-4)
+    assert surely_hole.sum() > 40 and surely_wall.sum() > 60
+    assert not lit[surely_hole].any() and lit[surely_wall].all()
+
+    room = ('Material "matte" "color Kd" [.6 .6 .6]\n'
+            'Shape "trianglemesh" "point P" [-4 -1 2  4 -1 2  4 -1 9  -4 -1 9] "integer indices" [0 2 1 0 3 2]\n')
+    ghost = ('AttributeBegin\nMaterial "mirror"\nShape "trianglemesh" "point P" [-1 -1 4  1 -1 4  1 1 4  -1 1 4] '
+             '"integer indices" [0 1 2 0 2 3] "float alpha" [0]\nAttributeEnd\n')
+    head2 = head.replace('"integer xresolution" [128] "integer yresolution" [128]', '"integer xresolution" [48] "integer yresolution" [32]').replace(
+        '"integer pixelsamples" [1]', '"integer pixelsamples" [4]').replace(
+        '"point from" [0 0 0]', '"point from" [0 3 5]')
+    (tmp_path / "plain.pbrt").write_text(head2 + room + "WorldEnd\n")
+    (tmp_path / "ghost.pbrt").write_text(head2 + room + ghost + "WorldEnd\n")
+    plain, _ = oracle.render(binding.HostScene(path=str(tmp_path / "plain.pbrt")))
+    with_ghost, _ = oracle.render(binding.HostScene(path=str(tmp_path / "ghost.pbrt")))
+    assert plain[..., 1].max() > 0 and np.array_equal(plain, with_ghost)
+
+    shade = ('AttributeBegin\nMaterial "matte" "color Kd" [.9 .1 .1]\nShape "trianglemesh" "point P" [-2 1 3  2 1 3  2 1 8  -2 1 8] '
+             '"integer indices" [0 1 2 0 2 3] %s\nAttributeEnd\n')
+    films = {}
+    for name, extra in (("opaque", ""), ("noshadow", '"float shadowalpha" [0]')):
+        (tmp_path / f"{name}.pbrt").write_text(head2 + room + shade % extra + "WorldEnd\n")
+        films[name], _ = oracle.render(binding.HostScene(path=str(tmp_path / f"{name}.pbrt")))
+    floor = plain[..., 1] > 0                                   # pixels that see the lit floor in the plain scene
+    sees_occluder = np.abs(films["opaque"] - plain).max(-1) > 0  # ... the opaque occluder changes them
+    under = floor & (films["opaque"][..., 1] == 0)              # floor pixels the opaque occluder puts in shadow
+    assert under.sum() > 20
+    assert np.array_equal(films["noshadow"][under], plain[under])  # shadow rays pass through
+    # camera rays ignore the shadow mask: where the camera sees the occluder (pixels that are empty in the plain
+    # scene) both variants agree
+    assert np.array_equal(films["noshadow"][~floor], films["opaque"][~floor])
+    assert sees_occluder.sum() >= under.sum()
