@@ -121,14 +121,17 @@ typedef struct iile_light {
     float world_radius; /* distant: radius of the scene's bounding sphere (Light::Preprocess, distant.cpp:63-65) */
     int32_t prim;       /* triangle area light: its primitive, in BVH order */
     int32_t pad;
-    /* infinite: lemit is the single texel of Lmap (L * scale); w2l as for the spot light; world_radius as
-     * for the distant light; and */
+    /* infinite: lemit is L * scale; w2l as for the spot light; world_radius as for the distant light; and */
     float l2w[9];       /* upper 3x3 of LightToWorld, row major */
-    /* the Distribution2D over the 2 x 2 luminance * sin(theta) image of the 1 x 1 map (infinite.cpp:63-83,
-     * sampling.cpp:159-174): per row v the conditional Distribution1D {func[2], cdf[3], funcInt}, then the
-     * marginal one over the rows' funcInt */
-    float dist_cond[2][6];
-    float dist_marg[6];
+    /* Lmap (infinite.cpp:49-63): index into iile_scene_desc::textures of the pyramid of the environment map
+     * times L (one texel without a map; not flipped in y; repeat wrap) */
+    int32_t env_tex;
+    /* the Distribution2D over the dist_w x dist_h (= 2 * the map's size) image of filtered luminance *
+     * sin(theta) (infinite.cpp:65-83, sampling.cpp:159-174), at float index dist_offset of
+     * iile_scene_desc::env_dist: per row v the conditional Distribution1D {func[w], cdf[w + 1], funcInt},
+     * then the marginal one {func[h], cdf[h + 1], funcInt} over the rows' funcInt */
+    int32_t dist_w, dist_h;
+    int64_t dist_offset;
 } iile_light;
 
 /* PerspectiveCamera (src/cameras/perspective.cpp:50-72, src/core/camera.h:90-111). */
@@ -192,6 +195,8 @@ typedef struct iile_scene_desc {
     const iile_material *materials;
     int32_t n_lights;
     const iile_light *lights;
+    int64_t n_env_dist;            /* floats in env_dist */
+    const float *env_dist;         /* sampling distributions of the infinite lights (iile_light::dist_offset) */
     int32_t n_textures;
     const iile_texture *textures;
     int64_t n_texels;              /* RGB texels in all levels of all textures */

@@ -1960,18 +1960,17 @@ struct Oracle {
     // InfiniteAreaLight without an environment map (lights/infinite.cpp:42-174). Lmap holds one
     // texel; its MIPMap lookup is the triangle filter over that texel (mipmap.h:351-389), and the
     // sampling distribution a 2 x 2 Distribution2D built on the host (pbrt_loader.cpp).
-    static Rgb inf_lookup(const iile_light &lt, float s_, float t_) {  // Lmap->Lookup(st): level < 0 -> triangle(0, st)
-        float s = s_ * 1 - 0.5f, t = t_ * 1 - 0.5f;
-        float s0 = std::floor(s), t0 = std::floor(t);
-        float ds = s - s0, dt = t - t0;
-        Rgb T(lt.lemit[0], lt.lemit[1], lt.lemit[2]);
-        return (1 - ds) * (1 - dt) * T + (1 - ds) * dt * T + ds * (1 - dt) * T + ds * dt * T;
+    // Lmap->Lookup(st) = Lookup(st, width 0): level = Levels - 1 + Log2(1e-8) < 0 for any pyramid of fewer than
+    // 27 levels -> triangle(0, st) (mipmap.h:233-262)
+    Rgb inf_lookup(const iile_light &lt, float s_, float t_) const {
+        const float st[2] = {s_, t_};
+        return tex_triangle(S.textures[lt.env_tex], 0, st);
     }
-    // Distribution1D::SampleContinuous over n = 2 entries {func[2], cdf[3], funcInt}, sampling.h:71-89
-    static float dist1d_sample(const float *d, float u, float *pdf, int *off) {
-        const float *func = d, *cdf = d + 2;
-        const float func_int = d[5];
-        const int size = 3;
+    // Distribution1D::SampleContinuous over n entries {func[n], cdf[n + 1], funcInt}, sampling.h:71-89
+    static float dist1d_sample(const float *d, int n, float u, float *pdf, int *off) {
+        const float *func = d, *cdf = d + n;
+        const float func_int = d[2 * n + 1];
+        const int size = n + 1;
         int first = 0, len = size;
         while (len > 0) {
             int half = len >> 1, middle = first + half;
@@ -1986,8 +1985,10 @@ struct Oracle {
         float du = u - cdf[offset];
         if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
         *pdf = (func_int > 0) ? func[offset] / func_int : 0;
-        return (offset + du) / 2;
+        return (offset + du) / n;
     }
+    const float *inf_cond(const iile_light &lt, int v) const { return S.env_dist + lt.dist_offset + size_t(2 * lt.dist_w + 2) * v; }
+    const float *inf_marg(const iile_light &lt) const { return inf_cond(lt, lt.dist_h); }
     V3 inf_w2l(const iile_light &lt, V3 w) const {
         return V3(lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z, lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
                   lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z);
@@ -2004,8 +2005,8 @@ struct Oracle {
     Rgb inf_sample_li(const iile_light &lt, V3 ref_p, const float *u, V3 *wi, float *pdf, V3 *target) const {  // :106-137
         float pdfs[2];
         int v;
-        float d1 = dist1d_sample(lt.dist_marg, u[1], &pdfs[1], &v);
-        float d0 = dist1d_sample(lt.dist_cond[v], u[0], &pdfs[0], nullptr);
+        float d1 = dist1d_sample(inf_marg(lt), lt.dist_h, u[1], &pdfs[1], &v);
+        float d0 = dist1d_sample(inf_cond(lt, v), lt.dist_w, u[0], &pdfs[0], nullptr);
         float map_pdf = pdfs[0] * pdfs[1];
         *pdf = 0;
         if (map_pdf == 0) return Rgb(0.f);
@@ -2026,8 +2027,8 @@ struct Oracle {
         float sin_theta = trig.sin_f(theta);
         if (sin_theta == 0) return 0;
         float p0 = phi * Inv2Pi, p1 = theta * InvPi;  // Distribution2D::Pdf, sampling.h:135-142
-        int iu = std::min(std::max(int(p0 * 2), 0), 1), iv = std::min(std::max(int(p1 * 2), 0), 1);
-        return (lt.dist_cond[iv][iu] / lt.dist_marg[5]) / (2 * Pi * Pi * sin_theta);
+        int iu = std::min(std::max(int(p0 * lt.dist_w), 0), lt.dist_w - 1), iv = std::min(std::max(int(p1 * lt.dist_h), 0), lt.dist_h - 1);
+        return (inf_cond(lt, iv)[iu] / inf_marg(lt)[2 * lt.dist_h + 1]) / (2 * Pi * Pi * sin_theta);
     }
     // EstimateDirect for the infinite light: both halves, with Le(ray) where the BSDF-sampled ray escapes
     Rgb estimate_direct_infinite(const Isect &it, const Bsdf &bsdf, const float *u_scatter, const iile_light &lt,

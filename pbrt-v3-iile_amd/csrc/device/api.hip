@@ -538,6 +538,8 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             mats[i].kr_tex = d->n_textures > 0 ? m.kr_tex : -1;
             mats[i].kt_tex = d->n_textures > 0 ? m.kt_tex : -1;
             for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex})
+                if (t >= 0) S.textured_materials = 1;
+            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex})
                 if (t >= d->n_textures) return bail(fail(IILE_ERR_ARG, "material refers to a texture that does not exist"));
         }
         rc = upload(sc, mats.data(), mats.size(), &S.materials);
@@ -592,11 +594,21 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             lts[i].world_radius = d->lights[i].world_radius;
             lts[i].prim = d->lights[i].prim;
             std::memcpy(lts[i].l2w, d->lights[i].l2w, sizeof(lts[i].l2w));
-            std::memcpy(lts[i].dist_cond, d->lights[i].dist_cond, sizeof(lts[i].dist_cond));
-            std::memcpy(lts[i].dist_marg, d->lights[i].dist_marg, sizeof(lts[i].dist_marg));
-            if (d->lights[i].type == IILE_LIGHT_INFINITE) S.has_infinite = 1;
+            lts[i].env_tex = d->lights[i].env_tex;
+            lts[i].dist_w = d->lights[i].dist_w;
+            lts[i].dist_h = d->lights[i].dist_h;
+            lts[i].dist_offset = d->lights[i].dist_offset;
+            if (d->lights[i].type == IILE_LIGHT_INFINITE) {
+                S.has_infinite = 1;
+                const iile_light &il = d->lights[i];
+                if (il.env_tex < 0 || il.env_tex >= d->n_textures || il.dist_w < 1 || il.dist_h < 1 || il.dist_offset < 0 ||
+                    il.dist_offset + int64_t(2 * il.dist_w + 2) * il.dist_h + 2 * il.dist_h + 2 > d->n_env_dist)
+                    return bail(fail(IILE_ERR_ARG, "infinite light: bad environment map / distribution reference"));
+            }
         }
         rc = upload(sc, lts.data(), lts.size(), &S.lights);
+        if (rc) return bail(rc);
+        rc = upload(sc, d->env_dist, size_t(d->n_env_dist), &S.env_dist);
         if (rc) return bail(rc);
     }
     // Halton: permutations + per-dimension constants

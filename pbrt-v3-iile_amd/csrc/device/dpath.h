@@ -1530,37 +1530,35 @@ DEV float sphere_pdf(const DSphere &sp, const Isect &ref, F3 wi) {
     float cos_tmax = sqrtf(mx(0.f, 1 - sin_tmax2));
     return 1 / (2 * kPi * (1 - cos_tmax));
 }
-// InfiniteAreaLight without an environment map (lights/infinite.cpp:42-174), operation for operation
-// as the oracle's inf_* functions: one texel behind a triangle-filter lookup, a 2 x 2 Distribution2D.
-DEV F3 inf_lookup(const DLight &lt, float s_, float t_) {  // Lmap->Lookup(st) -> triangle(0, st), mipmap.h:375-389
-    const float s = s_ * 1 - 0.5f, t = t_ * 1 - 0.5f;
-    const float s0 = floorf(s), t0 = floorf(t);
-    const float ds = s - s0, dt = t - t0;
-    const F3 T = F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]};
-    return (1 - ds) * (1 - dt) * T + (1 - ds) * dt * T + ds * (1 - dt) * T + ds * dt * T;
+// InfiniteAreaLight (lights/infinite.cpp:42-174), operation for operation as the oracle's inf_* functions: Lmap is
+// a host-built pyramid among the textures (one texel without an environment map), the Distribution2D a table
+// in HBM: per row {func[w], cdf[w + 1], funcInt}, then the marginal {func[h], cdf[h + 1], funcInt}.
+DEV F3 inf_lookup(const DScene &S, const DLight &lt, float s_, float t_) {  // Lmap->Lookup(st) -> triangle(0, st), mipmap.h:233-262
+    return tex_triangle(S, S.textures[lt.env_tex], 0, s_, t_);
 }
-DEV float dist1d_sample(const float *d, float u, float *pdf, int *off) {  // Distribution1D::SampleContinuous, n = 2
-    const float c1 = d[3];  // cdf = {d[2], d[3], d[4]} = {0, c1, 1}
-    // FindInterval(3, cdf[i] <= u), pbrt.h:399-412, unrolled: the last i in {0, 1} with cdf[i] <= u
-    int first = 0, len = 3;
+DEV float dist1d_sample(const float *d, int n, float u, float *pdf, int *off) {  // Distribution1D::SampleContinuous, sampling.h:71-89
+    const float *cdf = d + n;
+    // FindInterval(n + 1, cdf[i] <= u), pbrt.h:399-412
+    int first = 0, len = n + 1;
     while (len > 0) {
         const int half = len >> 1, middle = first + half;
-        const float cm = middle == 0 ? d[2] : (middle == 1 ? c1 : d[4]);
-        if (cm <= u) {
+        if (cdf[middle] <= u) {
             first = middle + 1;
             len -= half + 1;
         } else
             len = half;
     }
     int offset = first - 1;
-    offset = offset < 0 ? 0 : (offset > 1 ? 1 : offset);
+    offset = offset < 0 ? 0 : (offset > n - 1 ? n - 1 : offset);
     if (off) *off = offset;
-    const float lo = offset == 0 ? d[2] : c1, hi = offset == 0 ? c1 : d[4];
+    const float lo = cdf[offset], hi = cdf[offset + 1];
     float du = u - lo;
     if ((hi - lo) > 0) du /= (hi - lo);
-    *pdf = (d[5] > 0) ? (offset == 0 ? d[0] : d[1]) / d[5] : 0.f;
-    return (offset + du) / 2;
+    const float func_int = d[2 * n + 1];
+    *pdf = (func_int > 0) ? d[offset] / func_int : 0.f;
+    return (float(offset) + du) / float(n);
 }
+DEV const float *inf_cond(const DScene &S, const DLight &lt, int v) { return S.env_dist + lt.dist_offset + (long long)(2 * lt.dist_w + 2) * v; }
 DEV F3 inf_w2l(const DLight &lt, F3 w) {
     return F3{lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z, lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
               lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z};
@@ -1570,15 +1568,15 @@ DEV float spherical_phi(F3 v) {
     const float p = atan2_f(v.y, v.x);
     return (p < 0) ? (p + 2 * kPi) : p;
 }
-DEV F3 inf_le(const DLight &lt, F3 d) {  // InfiniteAreaLight::Le, infinite.cpp:99-104
+DEV F3 inf_le(const DScene &S, const DLight &lt, F3 d) {  // InfiniteAreaLight::Le, infinite.cpp:99-104
     const F3 w = normalize(inf_w2l(lt, d));
-    return inf_lookup(lt, spherical_phi(w) * kInv2Pi, spherical_theta(w) * kInvPi);
+    return inf_lookup(S, lt, spherical_phi(w) * kInv2Pi, spherical_theta(w) * kInvPi);
 }
-DEV F3 inf_sample_li(const DLight &lt, F3 ref_p, float u0, float u1, F3 *wi, float *pdf, F3 *target) {  // :106-137
+DEV F3 inf_sample_li(const DScene &S, const DLight &lt, F3 ref_p, float u0, float u1, F3 *wi, float *pdf, F3 *target) {  // :106-137
     float pdf0, pdf1;
     int v;
-    const float d1 = dist1d_sample(lt.dist_marg, u1, &pdf1, &v);
-    const float d0 = dist1d_sample(v == 0 ? lt.dist_cond[0] : lt.dist_cond[1], u0, &pdf0, nullptr);
+    const float d1 = dist1d_sample(inf_cond(S, lt, lt.dist_h), lt.dist_h, u1, &pdf1, &v);
+    const float d0 = dist1d_sample(inf_cond(S, lt, v), lt.dist_w, u0, &pdf0, nullptr);
     const float map_pdf = pdf0 * pdf1;
     *pdf = 0;
     if (map_pdf == 0) return F3{0, 0, 0};
@@ -1592,21 +1590,20 @@ DEV F3 inf_sample_li(const DLight &lt, F3 ref_p, float u0, float u1, F3 *wi, flo
     *pdf = map_pdf / (2 * kPi * kPi * sin_theta);
     if (sin_theta == 0) *pdf = 0;
     *target = ref_p + *wi * (2 * lt.world_radius);
-    return inf_lookup(lt, d0, d1);
+    return inf_lookup(S, lt, d0, d1);
 }
-DEV float inf_pdf_li(const DLight &lt, F3 w) {  // :139-148 with Distribution2D::Pdf, sampling.h:135-142
+DEV float inf_pdf_li(const DScene &S, const DLight &lt, F3 w) {  // :139-148 with Distribution2D::Pdf, sampling.h:135-142
     const F3 wi = inf_w2l(lt, w);
     const float theta = spherical_theta(wi), phi = spherical_phi(wi);
     float sin_theta, cos_theta;
     sincos_f(theta, &sin_theta, &cos_theta);
     if (sin_theta == 0) return 0;
     const float p0 = phi * kInv2Pi, p1 = theta * kInvPi;
-    int iu = int(p0 * 2), iv = int(p1 * 2);
-    iu = iu < 0 ? 0 : (iu > 1 ? 1 : iu);
-    iv = iv < 0 ? 0 : (iv > 1 ? 1 : iv);
-    const float func = iv == 0 ? (iu == 0 ? lt.dist_cond[0][0] : lt.dist_cond[0][1])
-                               : (iu == 0 ? lt.dist_cond[1][0] : lt.dist_cond[1][1]);
-    return (func / lt.dist_marg[5]) / (2 * kPi * kPi * sin_theta);
+    int iu = int(p0 * float(lt.dist_w)), iv = int(p1 * float(lt.dist_h));
+    iu = iu < 0 ? 0 : (iu > lt.dist_w - 1 ? lt.dist_w - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > lt.dist_h - 1 ? lt.dist_h - 1 : iv);
+    const float func = inf_cond(S, lt, iv)[iu];
+    return (func / inf_cond(S, lt, lt.dist_h)[2 * lt.dist_h + 1]) / (2 * kPi * kPi * sin_theta);
 }
 
 // Triangle emitter (shapes/triangle.cpp:546-579) through the generic Shape::Sample(ref, u) /

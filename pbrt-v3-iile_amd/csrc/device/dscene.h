@@ -56,8 +56,9 @@ struct DLight {
     int prim;        // triangle emitter: its primitive
     // infinite light (no map): LightToWorld 3x3 and the 2 x 2 Distribution2D, see iile_scene.h
     float l2w[9];
-    float dist_cond[2][6];
-    float dist_marg[6];
+    int env_tex;            // infinite: Lmap among the textures
+    int dist_w, dist_h;     // infinite: size of the Distribution2D
+    long long dist_offset;  // its tables in DScene::env_dist
 };
 // Per Halton dimension: base, float reciprocal and offset of its digit permutation.
 // The digits are peeled in double arithmetic (exact for any u32 index, see
@@ -92,7 +93,9 @@ struct DScene {
     const DTexture *textures;  // image textures (k_shade<.., TEX = true>)
     const float4 *texels;
     const float *ewa_lut;      // MIPMap::weightLut[128]
+    const float *env_dist;     // Distribution2D tables of the infinite lights
     int n_textures;
+    int textured_materials;    // some material reads an image texture
     int n_nodes, n_prims, n_spheres, n_materials, n_lights, n_hdims;
     int n_perms;              // u16 entries of `perms`
     float root_box[6];        // bounds of the root node (min.xyz, max.xyz)

@@ -353,7 +353,7 @@ DEV F3 sample_li_plain(const DScene &S, const DLight &lt, F3 po, float u0, float
     *pdf = 1;
     if (lt.type == kLightInfinite) {
         F3 wi, target;
-        return inf_sample_li(lt, po, u0, u1, &wi, pdf, &target);
+        return inf_sample_li(S, lt, po, u0, u1, &wi, pdf, &target);
     }
     if (lt.type == kLightDistant) return I;
     if (lt.type == kLightPoint) return sdiv(I, length_sq(pos - po));
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                 }
                 if (bounce < S.max_depth) {
                     surface = true;
-                    if (TEX && S.n_textures > 0) {
+                    if (TEX && S.textured_materials) {
                         // isect.ComputeScatteringFunctions(ray, ...): ComputeDifferentials (interaction.cpp:95-149)
                         // then the material's Texture::Evaluate calls. Only the camera ray carries differentials
                         // (path.cpp:159 spawns plain Rays); its auxiliary rays are a function of the camera
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                                 dim += 4;
                                 float light_pdf = 0, scattering_pdf = 0;
                                 F3 wi = F3{0, 0, 0}, target = F3{0, 0, 0};
-                                const F3 Li = inf_sample_li(lt, is.p, ul0, ul1, &wi, &light_pdf, &target);
+                                const F3 Li = inf_sample_li(S, lt, is.p, ul0, ul1, &wi, &light_pdf, &target);
                                 if (light_pdf > 0 && !is_black(Li)) {
                                     const F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
                                     scattering_pdf = bsdf_pdf(bsdf, is.wo, wi);
@@ -661,13 +661,13 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                                 F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
                                 f2 = f2 * absdot(wi, is.sn);
                                 if (!is_black(f2) && scattering_pdf > 0) {
-                                    const float lp = inf_pdf_li(lt, wi);
+                                    const float lp = inf_pdf_li(S, lt, wi);
                                     if (lp != 0) {
                                         const float weight = power_heuristic(scattering_pdf, lp);
                                         mo = offset_ray_origin(is.p, is.perr, is.n, wi);
                                         md = wi;
                                         // Li is Le(ray) when the MIS ray escapes the scene
-                                        Bc = sdiv(f2 * inf_le(lt, wi) * weight, scattering_pdf);
+                                        Bc = sdiv(f2 * inf_le(S, lt, wi) * weight, scattering_pdf);
                                         nee_flags |= NEE_HAS_MIS;
                                     }
                                 }
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(kBlock) void k_miss(DScene S, PassBuffers B, int bo
         const float4 L4 = B.L[pid];
         F3 L = F3{L4.x, L4.y, L4.z};
         for (int l = 0; l < S.n_lights; ++l)
-            if (S.lights[l].type == kLightInfinite) L = L + beta * inf_le(S.lights[l], d);
+            if (S.lights[l].type == kLightInfinite) L = L + beta * inf_le(S, S.lights[l], d);
         B.L[pid] = make_float4(L.x, L.y, L.z, 0);
     }
 }
@@ -1402,7 +1402,7 @@ void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int 
         // Scenes of killeroo-simple's kind (one emitting sphere, matte / plastic only) run a build of the
         // kernel without the code for the wider feature set: it costs them registers otherwise (+0.7 ms);
         // likewise image textures have their own build
-        if (S.n_textures > 0)
+        if (S.textured_materials)
             hipLaunchKernelGGL((k_shade<false, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
         else if (S.extended_features)
             hipLaunchKernelGGL((k_shade<false, true, false>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);

@@ -134,6 +134,8 @@ bool finalize_scene(HostScene *s, std::string *err) {
         s->o_texels.insert(s->o_texels.end(), ht.texels.begin(), ht.texels.end());
         s->o_textures.push_back(t);
     }
+    d.n_env_dist = int64_t(s->env_dist.size());
+    d.env_dist = s->env_dist.data();
     d.n_textures = int(s->o_textures.size());
     d.textures = s->o_textures.data();
     d.n_texels = int64_t(s->o_texels.size() / 3);

@@ -68,6 +68,7 @@ struct HostScene {
     std::vector<int32_t> o_alpha;
     std::vector<uint16_t> perms;
     std::vector<int32_t> primes, prime_sums;
+    std::vector<float> env_dist;  // Distribution2D tables of the infinite lights
     std::vector<iile_texture> o_textures;
     std::vector<float> o_texels;
     int n_interior = 0, n_leaf = 0;
@@ -96,6 +97,12 @@ bool image_is_8bit(const std::string &path);
 // mipmap.cpp
 bool build_image_texture(const std::vector<float> &rgb, int width, int height, float scale, bool gamma, bool as_float,
                          HostTexture *out, std::string *err);
+// MIPMap's constructor alone on prepared texels (row-major, width x height RGB), wrap mode from out->t.wrap
+bool build_mip_pyramid(const std::vector<float> &rgb, int width, int height, HostTexture *out, std::string *err);
+// InfiniteAreaLight's constructor (infinite.cpp:42-84): Lmap from `rgb` (already times L) into `tex`, the
+// Distribution2D tables appended to `dist`; returns their size through w, h and their offset
+bool build_environment_light(const std::vector<float> &rgb, int width, int height, HostTexture *tex, std::vector<float> *dist,
+                             int *dist_w, int *dist_h, int64_t *dist_offset, std::string *err);
 void ewa_weight_lut(float *lut);
 float inverse_gamma_correct(float value);
 

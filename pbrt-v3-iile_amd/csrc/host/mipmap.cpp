@@ -37,7 +37,7 @@ inline int round_up_pow2(int v) {  // pbrt.h:341-349
 }
 inline int log2_int(uint32_t v) { return 31 - __builtin_clz(v); }
 
-const float kPi = 3.14159265358979323846f;
+
 // texture.cpp:254-262 with tau = 2 (texture.h:148)
 float lanczos(float x, float tau = 2.f) {
     x = std::abs(x);
@@ -121,6 +121,14 @@ bool build_image_texture(const std::vector<float> &rgb, int width, int height, f
             } else
                 for (int c = 0; c < 3; ++c) d.c[c] = scale * (gamma ? inverse_gamma_correct(src[c]) : src[c]);  // imagemap.h:96-100
         }
+    std::vector<float> flat(img.size() * 3);
+    std::memcpy(flat.data(), img.data(), flat.size() * sizeof(float));
+    return build_mip_pyramid(flat, width, height, out, err);
+}
+
+bool build_mip_pyramid(const std::vector<float> &rgb, int width, int height, HostTexture *out, std::string *err) {
+    std::vector<Rgb3> img(size_t(width) * height);
+    std::memcpy(img.data(), rgb.data(), img.size() * sizeof(Rgb3));
     const int wrap = out->t.wrap;
     int res[2] = {width, height};
     if (!is_pow2(res[0]) || !is_pow2(res[1])) {
@@ -194,6 +202,82 @@ bool build_image_texture(const std::vector<float> &rgb, int width, int height, f
     }
     out->texels.resize(all.size() * 3);
     std::memcpy(out->texels.data(), all.data(), all.size() * sizeof(Rgb3));
+    return true;
+}
+
+namespace {
+// MIPMap::triangle and Lookup(st, width) (mipmap.h:233-262) on a built pyramid; Log2 through libm as in the
+// reference (this runs on the host there too)
+Rgb3 pyr_texel(const HostTexture &t, int level, int s, int tt) {
+    return texel(reinterpret_cast<const Rgb3 *>(t.texels.data()) + t.t.level_offset[level], t.t.level_w[level], t.t.level_h[level],
+                 t.t.wrap, s, tt);
+}
+Rgb3 pyr_triangle(const HostTexture &t, int level, float s_, float t_) {
+    level = clampT(level, 0, t.t.n_levels - 1);
+    float s = s_ * t.t.level_w[level] - 0.5f;
+    float tt = t_ * t.t.level_h[level] - 0.5f;
+    int s0 = int(std::floor(s)), t0 = int(std::floor(tt));
+    float ds = s - s0, dt = tt - t0;
+    return (((1 - ds) * (1 - dt)) * pyr_texel(t, level, s0, t0) + ((1 - ds) * dt) * pyr_texel(t, level, s0, t0 + 1)) +
+           (ds * (1 - dt)) * pyr_texel(t, level, s0 + 1, t0) + (ds * dt) * pyr_texel(t, level, s0 + 1, t0 + 1);
+}
+Rgb3 pyr_lookup(const HostTexture &t, float s, float tt, float width) {
+    const float inv_log2 = 1.442695040888963387004650940071f;
+    float level = t.t.n_levels - 1 + std::log(std::max(width, 1e-8f)) * inv_log2;
+    if (level < 0) return pyr_triangle(t, 0, s, tt);
+    if (level >= t.t.n_levels - 1) return pyr_texel(t, t.t.n_levels - 1, 0, 0);
+    int il = int(std::floor(level));
+    float delta = level - il;
+    return (1 - delta) * pyr_triangle(t, il, s, tt) + delta * pyr_triangle(t, il + 1, s, tt);
+}
+// Distribution1D, sampling.h:57-69: {func[n], cdf[n + 1], funcInt}
+void dist1d(const float *f, int n, float *out) {
+    float *func = out, *cdf = out + n, *func_int = out + 2 * n + 1;
+    for (int i = 0; i < n; ++i) func[i] = f[i];
+    cdf[0] = 0;
+    for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+    *func_int = cdf[n];
+    if (*func_int == 0)
+        for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n);
+    else
+        for (int i = 1; i < n + 1; ++i) cdf[i] /= *func_int;
+}
+}  // namespace
+
+bool build_environment_light(const std::vector<float> &rgb, int width, int height, HostTexture *tex, std::vector<float> *dist,
+                             int *dist_w, int *dist_h, int64_t *dist_offset, std::string *err) {
+    std::memset(&tex->t, 0, sizeof(tex->t));  // MIPMap defaults: EWA, maxAniso 8, repeat (mipmap.h:66-67)
+    tex->t.wrap = IILE_WRAP_REPEAT;
+    tex->t.max_aniso = 8.f;
+    tex->t.su = tex->t.sv = 1.f;
+    if (!build_mip_pyramid(rgb, width, height, tex, err)) return false;
+    // scalar image of filtered luminance * sin(theta), infinite.cpp:65-80
+    const int w = 2 * tex->t.level_w[0], h = 2 * tex->t.level_h[0];
+    std::vector<float> img(size_t(w) * h);
+    const float fwidth = 0.5f / std::min(w, h);
+    for (int v = 0; v < h; ++v) {
+        const float vp = (v + .5f) / float(h);
+        const float sin_theta = std::sin(kPi * (v + .5f) / h);
+        for (int u = 0; u < w; ++u) {
+            const float up = (u + .5f) / float(w);
+            const Rgb3 c = pyr_lookup(*tex, up, vp, fwidth);
+            img[u + size_t(v) * w] = 0.212671f * c.c[0] + 0.715160f * c.c[1] + 0.072169f * c.c[2];  // RGBSpectrum::y
+            img[u + size_t(v) * w] *= sin_theta;
+        }
+    }
+    // Distribution2D, sampling.cpp:159-174
+    *dist_w = w;
+    *dist_h = h;
+    *dist_offset = int64_t(dist->size());
+    const size_t row = size_t(2 * w + 2);
+    dist->resize(dist->size() + row * h + size_t(2 * h + 2));
+    float *base = dist->data() + *dist_offset;
+    std::vector<float> marg(h);
+    for (int v = 0; v < h; ++v) {
+        dist1d(&img[size_t(v) * w], w, base + row * v);
+        marg[v] = base[row * v + 2 * w + 1];
+    }
+    dist1d(marg.data(), h, base + row * h);
     return true;
 }
 

@@ -523,52 +523,37 @@ class Loader {
                 lt.cos_total_width = std::cos(radians(coneangle));                   // SpotLight ctor, spot.cpp:43-51
                 lt.cos_falloff_start = std::cos(radians(coneangle - conedelta));
             } else if (name == "infinite" || name == "exinfinite") {  // CreateInfiniteLight, lights/infinite.cpp:176-186
-                if (!ps.one_string("mapname", "").empty()) return fail("infinite light: environment maps are not supported");
                 lt.type = IILE_LIGHT_INFINITE;
                 for (int r = 0; r < 3; ++r)
                     for (int c = 0; c < 3; ++c) {
                         lt.l2w[3 * r + c] = ctm_.m.m[r][c];
                         lt.w2l[3 * r + c] = ctm_.inv.m[r][c];
                     }
-                // InfiniteAreaLight ctor without a map (infinite.cpp:42-84): Lmap is one texel, the sampling
-                // distribution is built over a 2 x 2 image of its filtered luminance times sin(theta)
-                const float T[3] = {lt.lemit[0], lt.lemit[1], lt.lemit[2]};
-                float img[4];
-                const int width = 2, height = 2;
-                for (int v = 0; v < height; ++v) {
-                    const float vp = (v + .5f) / float(height);
-                    const float sin_theta = std::sin(kPi * (v + .5f) / height);
-                    for (int u = 0; u < width; ++u) {
-                        const float up = (u + .5f) / float(width);
-                        // MIPMap::Lookup(st, width 0.25) on one level -> triangle(0, st), mipmap.h:375-389
-                        const float s = up * 1 - 0.5f, t = vp * 1 - 0.5f;
-                        const float s0 = std::floor(s), t0 = std::floor(t);
-                        const float ds = s - s0, dt = t - t0;
-                        float rgb[3];
-                        for (int c = 0; c < 3; ++c)
-                            rgb[c] = (1 - ds) * (1 - dt) * T[c] + (1 - ds) * dt * T[c] + ds * (1 - dt) * T[c] + ds * dt * T[c];
-                        const float y = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];  // RGBSpectrum::y
-                        img[u + v * width] = y;
-                        img[u + v * width] *= sin_theta;
+                // InfiniteAreaLight ctor (infinite.cpp:42-84): Lmap = the environment map times L (one texel of L
+                // without a map or when it cannot be read), not flipped; then the sampling distribution
+                std::vector<float> rgb;
+                int w = 0, h = 0;
+                std::string mapname = ps.one_string("mapname", "");
+                if (!mapname.empty()) {
+                    if (mapname[0] != '/') mapname = search_dir_ + "/" + mapname;
+                    std::string why;
+                    if (read_image(mapname, &rgb, &w, &h, &why)) {
+                        for (size_t i = 0; i < rgb.size(); ++i) rgb[i] *= lt.lemit[i % 3];
+                    } else {
+                        std::fprintf(stderr, "Warning: %s\n", why.c_str());
+                        rgb.clear();
                     }
                 }
-                auto dist1d = [](const float *f, int n, float *out) {  // Distribution1D, sampling.h:57-69
-                    float *func = out, *cdf = out + 2, *func_int = out + 5;
-                    for (int i = 0; i < n; ++i) func[i] = f[i];
-                    cdf[0] = 0;
-                    for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
-                    *func_int = cdf[n];
-                    if (*func_int == 0)
-                        for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n);
-                    else
-                        for (int i = 1; i < n + 1; ++i) cdf[i] /= *func_int;
-                };
-                float marg[2];
-                for (int v = 0; v < height; ++v) {  // Distribution2D, sampling.cpp:159-174
-                    dist1d(&img[v * width], width, lt.dist_cond[v]);
-                    marg[v] = lt.dist_cond[v][5];
+                if (rgb.empty()) {
+                    rgb.assign(lt.lemit, lt.lemit + 3);
+                    w = h = 1;
                 }
-                dist1d(marg, height, lt.dist_marg);
+                HostTexture ht;
+                std::string why;
+                if (!build_environment_light(rgb, w, h, &ht, &scene_->env_dist, &lt.dist_w, &lt.dist_h, &lt.dist_offset, &why))
+                    return fail("infinite light: " + why);
+                scene_->textures.push_back(std::move(ht));
+                lt.env_tex = int(scene_->textures.size()) - 1;
                 // world_radius is set once the scene bounds are known (finalize_scene)
             } else {  // CreateDistantLight, lights/distant.cpp:94-102; ctor :43-48
                 const V3 w = normalize(ctm_.vector(from - to));

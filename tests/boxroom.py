@@ -128,7 +128,19 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
            'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (xres, yres),
            'Sampler "halton" "integer pixelsamples" [%d]' % spp, 'Integrator "path" "integer maxdepth" [%d]' % maxdepth,
            'WorldBegin']
-    if light == "sky":  # uniform sky through the open top (no ceiling below) and a warm point light inside
+    if light == "envmap":  # an environment-mapped sky (lat-long PFM, 12 x 6: resampled to 16 x 8) through the open top
+        import os
+        assert textures is not None, "light='envmap' writes its map into the `textures` directory"
+        os.makedirs(textures, exist_ok=True)
+        h, w = 6, 12
+        y, x = np.mgrid[0:h, 0:w]
+        sky = np.stack([0.3 + 0.05 * y, 0.4 + 0.04 * y, 0.9 - 0.1 * y], -1).astype(np.float32)
+        sky[1, 3] = (60, 50, 30)   # the sun
+        sky[4:, :] *= 0.2          # dim ground
+        open(os.path.join(textures, "sky.pfm"), "wb").write(b"PF\n%d %d\n-1.0\n" % (w, h) + sky[::-1].tobytes())
+        out.append('AttributeBegin\n  Rotate 25 0 1 0\n  Rotate 40 0 0 1\n  LightSource "infinite" "color L" [1 .9 .8] "color scale" [1.5 1.5 1.5] '
+                   '"string mapname" ["%s"]\nAttributeEnd' % os.path.join(textures, "sky.pfm"))
+    elif light == "sky":  # uniform sky through the open top (no ceiling below) and a warm point light inside
         out.append('AttributeBegin\n  Rotate 25 0 1 0\n  LightSource "infinite" "color L" [.6 .7 1] "color scale" [1.5 1.5 1.5]\nAttributeEnd')
         out.append('LightSource "point" "color I" [25 15 8] "point from" [-6 5 2]')
     elif light == "quad":  # a rectangular ceiling panel: two triangle emitters (one light each) + a point light
@@ -183,7 +195,7 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
              ((-s, -s, -3), (0, 2 * s, 0), (0, 0, 12), (.8, .3, .3)),         # left
              ((s, -s, -3), (0, 0, 12), (0, 2 * s, 0), (.3, .8, .3))]          # right
     for o, du, dv, kd in walls:
-        if light in ("distant", "sky") and o[2] == 9:
+        if light in ("distant", "sky", "envmap") and o[2] == 9:
             continue  # no ceiling
         P, F = _grid_quad(o, du, dv, wall_n)
         rough = ' "float sigma" [%g]' % (20 + 10 * len(out) % 50) if materials == "all" else ""  # Oren-Nayar walls

@@ -449,9 +449,11 @@ def test_random_rooms_bitwise(binding, oracle, tmp_path, seed, light):
 
 
 def test_infinite_light_bitwise(binding, oracle, tmp_path):
-    """InfiniteAreaLight (constant): the white-furnace sky scene, and the box room open to a tinted sky
-    with a point light inside (two lights: the spatial light distribution samples the sky too). The
-    device evaluates SphericalPhi / SphericalTheta with the portable atan2 / acos of the oracle."""
+    """InfiniteAreaLight: the white-furnace sky scene (constant), the box room open to a tinted sky
+    with a point light inside (two lights: the spatial light distribution samples the sky too), and the
+    textured room under an environment map (a 12 x 6 lat-long PFM resampled to 16 x 8, its 32 x 16
+    Distribution2D searched on the device). The device evaluates SphericalPhi / SphericalTheta with the
+    portable atan2 / acos of the oracle."""
     import os
     import boxroom
     sky = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_sky.pbrt"))
@@ -459,7 +461,11 @@ def test_infinite_light_bitwise(binding, oracle, tmp_path):
     path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="sky", materials="all", maxdepth=6))
     room = binding.HostScene(path=str(path))
     assert room.info["n_lights"] == 2
-    for name, scene in (("sky furnace", sky), ("boxroom sky", room)):
+    path2 = tmp_path / "boxroom_env.pbrt"
+    path2.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="envmap", materials="mixed", textures=str(tmp_path / "img")))
+    env = binding.HostScene(path=str(path2))
+    assert env.info["n_lights"] == 1 and env.texture(0)[1][0].shape == (8, 16, 3)  # Lmap: the first pyramid
+    for name, scene in (("sky furnace", sky), ("boxroom sky", room), ("boxroom under an environment map", env)):
         gpu = binding.GpuScene(scene)
         film, st = gpu.render(collect_stats=True)
         ref, ost = oracle.render(scene)

@@ -607,3 +607,41 @@ def test_alpha_masks(binding, oracle, tmp_path):
     # scene) both variants agree
     assert np.array_equal(films["noshadow"][~floor], films["opaque"][~floor])
     assert sees_occluder.sum() >= under.sum()
+
+
+def test_environment_map_irradiance(binding, oracle, tmp_path):
+    """InfiniteAreaLight with an environment map (infinite.cpp:42-148) against quadrature: a Lambertian ground
+    plane (Kd = 0.5) under the map alone, direct lighting only, must show (Kd / pi) * integral of L cos(theta) over
+    the upper hemisphere — L the map (times `L`, bilinearly filtered, phi = 2 pi u, theta = pi v measured from the
+    light's +z) — whatever mix of light sampling (Distribution2D over the 2W x 2H luminance * sin(theta) image) and
+    BSDF sampling the MIS estimator used. A wrong orientation, pdf or texel lookup shows up as a bias."""
+    h, w = 8, 16
+    rng = np.random.default_rng(5)
+    sky = (0.2 + rng.random((h, w, 3))).astype(np.float32)
+    sky[1, 5] = (40, 30, 20)      # a sun high in the sky
+    sky[h // 2:, :] *= 0.1        # below the horizon (theta > pi / 2): must not matter for an upward plane
+    (tmp_path / "sky.pfm").write_bytes(b"PF\n%d %d\n-1.0\n" % (w, h) + sky[::-1].tobytes())
+    (tmp_path / "env.pbrt").write_text(
+        'LookAt 0 -3 2  0 0 0  0 0 1\nCamera "perspective" "float fov" [30]\n'
+        'Film "image" "integer xresolution" [16] "integer yresolution" [16]\nSampler "halton" "integer pixelsamples" [1024]\n'
+        'Integrator "path" "integer maxdepth" [1]\nWorldBegin\n'
+        'LightSource "infinite" "color L" [1 .5 2] "string mapname" ["sky.pfm"]\n'
+        'Material "matte" "color Kd" [.5 .5 .5]\n'
+        'Shape "trianglemesh" "point P" [-50 -50 0  50 -50 0  50 50 0  -50 50 0] "integer indices" [0 1 2 0 2 3]\nWorldEnd\n')
+    scene = binding.HostScene(path=str(tmp_path / "env.pbrt"))
+    film, _ = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+    rgb = scene.film_to_rgb(film).reshape(-1, 3).astype(np.float64).mean(0)
+    # quadrature over the upper hemisphere with the bilinear (repeat) reconstruction of the map at level 0
+    n_t, n_p = 512, 1024
+    theta = (np.arange(n_t) + .5) / n_t * (np.pi / 2)
+    phi = (np.arange(n_p) + .5) / n_p * 2 * np.pi
+    s = phi / (2 * np.pi) * w - .5
+    t = theta / np.pi * h - .5
+    s0, t0 = np.floor(s).astype(int), np.floor(t).astype(int)
+    ds, dt = (s - s0)[None, :, None], (t - t0)[:, None, None]
+    img = sky.astype(np.float64)   # row 0 = top scanline = v near 0 (not flipped)
+    tex = lambda tt, ss: img[np.mod(tt, h)[:, None], np.mod(ss, w)[None, :]]
+    L = (1 - ds) * (1 - dt) * tex(t0, s0) + (1 - ds) * dt * tex(t0 + 1, s0) + ds * (1 - dt) * tex(t0, s0 + 1) + ds * dt * tex(t0 + 1, s0 + 1)
+    E = (L * (np.cos(theta) * np.sin(theta))[:, None, None]).sum((0, 1)) * (np.pi / 2 / n_t) * (2 * np.pi / n_p)
+    want = 0.5 / np.pi * E * np.array([1, .5, 2])
+    assert np.allclose(rgb, want, rtol=0.03), (rgb, want)
