@@ -89,19 +89,26 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--scene", default=os.path.join(REPO, "scenes", "killeroo-simple.pbrt"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
-    ap.add_argument("--workload", choices=["killeroo", "boxroom"], default="killeroo",
+    ap.add_argument("--workload", choices=["killeroo", "boxroom", "boxroom-textured"], default="killeroo",
                     help="boxroom: the synthetic ~287 k-triangle closed room of tests/boxroom.py (deep-BVH stress, "
-                         "SURVEY.md 8d's stand-in for the Sponza config that does not ship with the reference)")
+                         "SURVEY.md 8d's stand-in for the Sponza config that does not ship with the reference); "
+                         "boxroom-textured: the same room open to an environment-mapped sky, with image textures, "
+                         "alpha masks and specular materials (the whole feature set of SURVEY.md 8 f1)")
     args = ap.parse_args()
     workload_name = "killeroo-simple"
-    if args.workload == "boxroom":
+    if args.workload in ("boxroom", "boxroom-textured"):
         import tempfile
         import boxroom
         tmp = tempfile.NamedTemporaryFile("w", suffix=".pbrt", delete=False)
-        tmp.write(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64))
+        if args.workload == "boxroom":
+            tmp.write(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64))
+            workload_name = "synthetic boxroom (287k triangles, tests/boxroom.py)"
+        else:
+            tmp.write(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64, light="envmap", materials="mixed",
+                                           textures=tempfile.mkdtemp(prefix="boxroom_img_")))
+            workload_name = "synthetic textured boxroom (266k triangles, environment map, image textures, alpha masks; tests/boxroom.py)"
         tmp.close()
         args.scene = tmp.name
-        workload_name = "synthetic boxroom (287k triangles, tests/boxroom.py)"
 
     import numpy as np
     import torch
@@ -202,7 +209,7 @@ def main():
         for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))[::-1]:
             try:
                 tj = json.load(open(f))
-                ent = tj["kernels"].get(dom + "<false>")
+                ent = tj["kernels"].get(dom + "<false, false>") or tj["kernels"].get(dom + "<false>")
                 if ent and world == 1 and (args.xres, args.yres, args.spp, args.workload) == (1920, 1080, 64, "killeroo"):
                     traffic, traffic_src = ent["hbm_bytes_per_launch"], os.path.basename(f)
                     break
