@@ -71,6 +71,10 @@ int iile_host_scene_texture(const iile_host_scene *scene, int32_t index, iile_te
 /* Copies level `level` (level_w x level_h RGB texels, row 0 = bottom scanline) of that texture. */
 int iile_host_scene_texture_level(const iile_host_scene *scene, int32_t index, int32_t level, float *rgb);
 
+/* Film::filterTable of the scene's pixel filter (src/core/film.cpp:65-74): 16 x 16 floats; returns whether the
+ * filter is wider than the one-pixel box (iile_scene_desc::film_filter_wide). */
+int iile_host_scene_filter_table(const iile_host_scene *scene, float *table256);
+
 const char *iile_host_last_error(void);
 
 #ifdef __cplusplus

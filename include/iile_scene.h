@@ -202,6 +202,11 @@ typedef struct iile_scene_desc {
     int64_t n_texels;              /* RGB texels in all levels of all textures */
     const float *texels;           /* [3 * n_texels] */
     float ewa_lut[IILE_EWA_LUT_SIZE]; /* MIPMap::weightLut, mipmap.h:199-205 */
+    /* Film::filterTable (film.cpp:65-74): filter->Evaluate at the centres of a 16 x 16 grid over the positive
+     * quadrant of its support, for box / gaussian / mitchell / sinc / triangle (src/filters). film_filter_wide = 0
+     * for the box filter of radius 0.5 (every sample lands in its own pixel; the fast film kernels), 1 otherwise */
+    int32_t film_filter_wide;
+    float film_filter_table[256];
     iile_camera camera;
     iile_film_desc film;
     iile_halton halton;

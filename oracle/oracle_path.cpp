@@ -2346,19 +2346,25 @@ int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, in
                         float pf[2];
                         Rgb L = orc.sample_radiance(px, py, k, pf);
                         if (L.y() > F.max_sample_luminance) L = L * (F.max_sample_luminance / L.y());
-                        // FilmTile::AddSample, film.h:153-193 (box filter: every table entry is 1)
+                        // FilmTile::AddSample, film.h:153-193
                         float dxf = pf[0] - 0.5f, dyf = pf[1] - 0.5f;
                         int ax0 = std::max(int(std::ceil(dxf - F.filter_rx)), ft->x0);
                         int ay0 = std::max(int(std::ceil(dyf - F.filter_ry)), ft->y0);
                         int ax1 = std::min(int(std::floor(dxf + F.filter_rx)) + 1, ft->x1);
                         int ay1 = std::min(int(std::floor(dyf + F.filter_ry)) + 1, ft->y1);
-                        for (int y = ay0; y < ay1; ++y)
+                        const float inv_rx = 1 / F.filter_rx, inv_ry = 1 / F.filter_ry;  // Filter::invRadius
+                        for (int y = ay0; y < ay1; ++y) {
+                            const float fy = std::abs((y - dyf) * inv_ry * 16);
+                            const int ify = std::min(int(std::floor(fy)), 15);
                             for (int x = ax0; x < ax1; ++x) {
+                                const float fx = std::abs((x - dxf) * inv_rx * 16);
+                                const int ifx = std::min(int(std::floor(fx)), 15);
                                 TilePixel &tp = ft->px[size_t(y - ft->y0) * tw + (x - ft->x0)];
-                                const float fw = 1.f;
+                                const float fw = S.film_filter_table[ify * 16 + ifx];
                                 for (int c = 0; c < 3; ++c) tp.rgb[c] += L.c[c] * 1.f * fw;
                                 tp.wsum += fw;
                             }
+                        }
                     }
             tiles[tile] = std::move(ft);
         }

@@ -71,7 +71,7 @@ class GpuStats(ctypes.Structure):
 # every symbol the headers declare; checked by tests/test_abi.py
 HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_film", "iile_host_scene_get_info",
                 "iile_host_scene_free", "iile_host_film_to_rgb", "iile_host_write_pfm", "iile_host_last_error", "iile_host_read_image",
-                "iile_host_scene_texture", "iile_host_scene_texture_level"]
+                "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table"]
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval"]
@@ -101,6 +101,7 @@ def host_lib():
         lib.iile_host_read_image.argtypes = [ctypes.c_char_p, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_vp]
         lib.iile_host_scene_texture.argtypes = [c_vp, c_i32, ctypes.POINTER(Texture)]
         lib.iile_host_scene_texture_level.argtypes = [c_vp, c_i32, c_i32, c_vp]
+        lib.iile_host_scene_filter_table.argtypes = [c_vp, c_vp]
         _host = lib
     return _host
 
@@ -184,6 +185,12 @@ class HostScene:
         if rc != 0:
             raise RuntimeError(host_lib().iile_host_last_error().decode())
         return rgb
+
+    def filter_table(self):
+        """(Film::filterTable as a (16, 16) array [y][x], wide?)"""
+        t = np.empty((16, 16), np.float32)
+        wide = host_lib().iile_host_scene_filter_table(self._h, t.ctypes.data)
+        return t, bool(wide)
 
     def texture(self, index):
         """(iile_texture, [level arrays (h, w, 3), row 0 = bottom scanline]) of image texture `index`."""

@@ -57,6 +57,8 @@ struct iile_scene {
     uint32_t film_pixels = 0;
     FilmBuffers fb;
     void *film_block = nullptr;
+    void *wide_block = nullptr;
+    uint64_t film_wide = 0;
     int *spill = nullptr;  // HBM overflow of the LDS traversal stacks
     std::vector<EventPair> events;
     size_t events_used = 0;
@@ -131,7 +133,19 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     return IILE_OK;
 }
 
-int ensure_film(iile_scene *sc, uint32_t n_tiles, uint32_t n_pixels) {
+int ensure_film(iile_scene *sc, uint32_t n_tiles, uint32_t n_pixels, uint64_t n_wide = 0) {
+    if (n_wide > sc->film_wide) {  // the frame's samples for a wide pixel filter: 24 B each
+        if (sc->wide_block) HIP_TRY(hipFree(sc->wide_block));
+        sc->wide_block = nullptr;
+        sc->film_wide = 0;
+        void *w = nullptr;
+        if (hipMalloc(&w, size_t(n_wide) * 24 + 256) != hipSuccess)
+            return fail(IILE_ERR_HIP, "out of device memory for the sample store of a wide pixel filter (24 B per camera sample)");
+        sc->wide_block = w;
+        sc->film_wide = n_wide;
+        sc->fb.wide_L = reinterpret_cast<float4 *>(w);
+        sc->fb.wide_pf = reinterpret_cast<float2 *>(static_cast<char *>(w) + size_t(n_wide) * 16);
+    }
     if (n_tiles <= sc->film_tiles && n_pixels <= sc->film_pixels) return IILE_OK;
     if (sc->film_block) {
         HIP_TRY(hipFree(sc->film_block));
@@ -321,8 +335,10 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     if (d->integrator.max_depth > 14) return fail(IILE_ERR_UNSUPPORTED, "maxdepth > 14");
     if ((double(d->halton.spp) + 1) * double(d->halton.sample_stride) >= 4294967296.0)
         return fail(IILE_ERR_UNSUPPORTED, "Halton index exceeds 32 bits (pixelsamples too large)");
-    if (d->film.filter_rx != 0.5f || d->film.filter_ry != 0.5f)
-        return fail(IILE_ERR_UNSUPPORTED, "only the box filter of radius 0.5 is supported");
+    if (!(d->film.filter_rx > 0) || !(d->film.filter_ry > 0) || d->film.filter_rx > 16 || d->film.filter_ry > 16)
+        return fail(IILE_ERR_UNSUPPORTED, "pixel filter radius must lie in (0, 16]");
+    if (!d->film_filter_wide && (d->film.filter_rx != 0.5f || d->film.filter_ry != 0.5f))
+        return fail(IILE_ERR_ARG, "film_filter_wide must be set for any filter but the box of radius 0.5");
 
     iile_scene *sc = new iile_scene;
     std::memset(&sc->ds, 0, sizeof(sc->ds));
@@ -680,6 +696,9 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         S.dy_camera[c] = d->camera.dy_camera[c];
     }
     S.diff_scale = 1 / std::sqrt(float(d->halton.spp));  // integrator.cpp:284-285
+    S.filter_wide = d->film_filter_wide;
+    rc = upload(sc, d->film_filter_table, size_t(256), &S.filter_table);
+    if (rc) return bail(rc);
     const iile_film_desc &f = d->film;
     S.xres = f.xres;
     S.yres = f.yres;
@@ -768,6 +787,7 @@ void iile_scene_destroy(iile_scene *sc) {
     for (void *p : sc->allocs) (void)hipFree(p);
     if (sc->ws_block) (void)hipFree(sc->ws_block);
     if (sc->film_block) (void)hipFree(sc->film_block);
+    if (sc->wide_block) (void)hipFree(sc->wide_block);
     if (sc->nray_buf) (void)hipFree(sc->nray_buf);
     for (EventPair &e : sc->events) {
         (void)hipEventDestroy(e.a);
@@ -831,7 +851,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         rc = ensure_workspace(sc, uint32_t(pix_slots * kc));
         if (rc) return rc;
     }
-    rc = ensure_film(sc, uint32_t(P.n_owned_tiles), fw * fh);
+    rc = ensure_film(sc, uint32_t(P.n_owned_tiles), fw * fh, S.filter_wide ? pix_slots * uint64_t(n_samples) : 0);
     if (rc) return rc;
     sc->pb.nray_out = nullptr;
     sc->events_used = 0;
@@ -853,14 +873,20 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ep->a, stream));
         }
-        launch_film_accumulate(S, P, sc->pb, sc->fb, cfg);
+        if (S.filter_wide)
+            launch_film_store(S, P, sc->pb, sc->fb, k_begin, n_samples, cfg);
+        else
+            launch_film_accumulate(S, P, sc->pb, sc->fb, cfg);
         if (timed) HIP_TRY(hipEventRecord(ep->b, stream));
         st.n_passes++;
         st.n_paths += P.n_paths;
     }
     FilmBuffers F = sc->fb;
     if (prm->film_on_device) F.film_xyzw = reinterpret_cast<float4 *>(film_xyzw);
-    launch_film_resolve(S, P, F, cfg);
+    if (S.filter_wide)
+        launch_film_gather(S, P, F, n_samples, cfg);
+    else
+        launch_film_resolve(S, P, F, cfg);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, stream));
     if (!prm->film_on_device) {

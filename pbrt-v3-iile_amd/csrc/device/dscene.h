@@ -119,6 +119,8 @@ struct DScene {
     int crop_x0, crop_y0, crop_x1, crop_y1;
     int samp_x0, samp_y0, samp_x1, samp_y1;
     float filter_rx, filter_ry, max_sample_luminance;
+    int filter_wide;             // not the one-pixel box: samples are kept and gathered (k_film_store / k_film_gather)
+    const float *filter_table;   // Film::filterTable, 16 x 16
     // halton
     int base_scale0, base_scale1, base_exp0, base_exp1, sample_stride, mult_inv0, mult_inv1;
     // integrator

@@ -41,6 +41,9 @@ struct FilmBuffers {
     float4 *tile_rgbw;  // [n_owned_tiles*256] per-pixel RGB contribSum + weight of own samples
     float4 *k0_rgbv;    // [n_owned_tiles*256] guarded radiance of sample k=0 (xyz), w = splat mask bits
     float4 *film_xyzw;  // [crop_w*crop_h] output {X,Y,Z,weightSum}
+    // filters wider than one pixel: every sample of the frame, [owned pixel slot][k]
+    float4 *wide_L;     // guarded radiance (rgb)
+    float2 *wide_pf;    // pFilm
 };
 
 struct LaunchCfg {
@@ -64,6 +67,9 @@ void launch_miss(const DScene &S, const PassBuffers &B, int bounce, uint32_t max
 void launch_mis_lit(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
                             const LaunchCfg &cfg);
+void launch_film_store(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int k_begin, int n_samples,
+                       const LaunchCfg &cfg);
+void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F, int n_samples, const LaunchCfg &cfg);
 void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg);
 
 // kernel-level entry points for parity tests

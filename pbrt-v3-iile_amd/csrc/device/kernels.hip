@@ -1179,6 +1179,25 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate(DScene S, PassDesc P
     }
 }
 
+// Filters wider than a pixel (gaussian, mitchell, sinc, triangle, larger boxes). A pixel then sums samples of
+// neighbouring pixels and tiles, in the order FilmTile::AddSample / MergeFilmTile give: inside a tile in pixel
+// (row-major) then sample order, tiles in index order. That order cuts across passes (a pass holds a range of k
+// for every pixel), so the frame's samples are kept — k_film_store, 24 B each — and summed once at the end by a
+// gather per film pixel (k_film_gather).
+__global__ __launch_bounds__(kBlock) void k_film_store(DScene S, PassDesc P, PassBuffers B, FilmBuffers F, int k_begin, int n_samples) {
+    for (uint32_t pid = blockIdx.x * kBlock + threadIdx.x; pid < P.n_paths; pid += gridDim.x * kBlock) {
+        int px, py;
+        uint32_t k;
+        if (!path_pixel(S, P, pid, &px, &py, &k)) continue;
+        const float4 L4 = B.L[pid];
+        const F3 L = guard_radiance(S, F3{L4.x, L4.y, L4.z});
+        const uint32_t idx = B.hindex[pid];
+        const size_t at = size_t(pid / uint32_t(P.kc)) * size_t(n_samples) + size_t(int(k) - k_begin);
+        F.wide_L[at] = make_float4(L.x, L.y, L.z, 0.f);
+        F.wide_pf[at] = make_float2(float(px) + sample_dimension(S, idx, 0), float(py) + sample_dimension(S, idx, 1));
+    }
+}
+
 DEV bool tile_owned(const PassDesc &P, int tx, int ty, uint32_t *slot) {
     if (tx < 0 || ty < 0 || tx >= P.n_tiles_x || ty >= P.n_tiles_y) return false;
     const int t = ty * P.n_tiles_x + tx;
@@ -1191,6 +1210,57 @@ DEV void add_xyz(float4 *out, float r, float g, float b, float w) {  // RGBToXYZ
     out->y += 0.212671f * r + 0.715160f * g + 0.072169f * b;
     out->z += 0.019334f * r + 0.119193f * g + 0.950227f * b;
     out->w += w;
+}
+
+__global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, FilmBuffers F, int n_samples) {
+    const int fw = S.crop_x1 - S.crop_x0, fh = S.crop_y1 - S.crop_y0;
+    const uint32_t n = uint32_t(fw) * uint32_t(fh);
+    const float rx = S.filter_rx, ry = S.filter_ry;
+    const float inv_rx = 1 / rx, inv_ry = 1 / ry;  // Filter::invRadius
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int x = S.crop_x0 + int(i % uint32_t(fw)), y = S.crop_y0 + int(i / uint32_t(fw));
+        // sample pixels that can reach (x, y): |q + u - 0.5 - x| <= r with u in [0, 1)
+        const int qx0 = max(int(floorf(float(x) - rx - 0.5f)) - 1, S.samp_x0), qx1 = min(int(ceilf(float(x) + rx + 0.5f)) + 1, S.samp_x1 - 1);
+        const int qy0 = max(int(floorf(float(y) - ry - 0.5f)) - 1, S.samp_y0), qy1 = min(int(ceilf(float(y) + ry + 0.5f)) + 1, S.samp_y1 - 1);
+        float4 out = make_float4(0, 0, 0, 0);
+        if (qx0 <= qx1 && qy0 <= qy1) {
+            const int tx0 = (qx0 - S.samp_x0) / kTile, tx1 = (qx1 - S.samp_x0) / kTile;
+            const int ty0 = (qy0 - S.samp_y0) / kTile, ty1 = (qy1 - S.samp_y0) / kTile;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) {  // tile index order
+                    uint32_t slot;
+                    if (!tile_owned(P, tx, ty, &slot)) continue;
+                    // the tile's FilmTile (Film::GetFilmTile, film.cpp:92-103) must hold (x, y)
+                    const int sx0 = S.samp_x0 + tx * kTile, sy0 = S.samp_y0 + ty * kTile;
+                    const int sx1 = min(sx0 + kTile, S.samp_x1), sy1 = min(sy0 + kTile, S.samp_y1);
+                    const int fx0 = max(int(ceilf(float(sx0) - 0.5f - rx)), S.crop_x0), fx1 = min(int(floorf(float(sx1) - 0.5f + rx)) + 1, S.crop_x1);
+                    const int fy0 = max(int(ceilf(float(sy0) - 0.5f - ry)), S.crop_y0), fy1 = min(int(floorf(float(sy1) - 0.5f + ry)) + 1, S.crop_y1);
+                    if (x < fx0 || x >= fx1 || y < fy0 || y >= fy1) continue;
+                    float r = 0, g = 0, b = 0, w = 0;
+                    for (int qy = max(qy0, sy0); qy <= min(qy1, sy1 - 1); ++qy)
+                        for (int qx = max(qx0, sx0); qx <= min(qx1, sx1 - 1); ++qx) {
+                            const size_t base = (size_t(slot) * 256u + size_t((qy - sy0) * kTile + (qx - sx0))) * size_t(n_samples);
+                            for (int k = 0; k < n_samples; ++k) {
+                                const float2 pf = F.wide_pf[base + k];
+                                // FilmTile::AddSample's support test and table lookup for this pixel (film.h:159-188)
+                                const float dxf = pf.x - 0.5f, dyf = pf.y - 0.5f;
+                                if (x < max(int(ceilf(dxf - rx)), fx0) || x >= min(int(floorf(dxf + rx)) + 1, fx1)) continue;
+                                if (y < max(int(ceilf(dyf - ry)), fy0) || y >= min(int(floorf(dyf + ry)) + 1, fy1)) continue;
+                                const float ffx = fabsf((float(x) - dxf) * inv_rx * 16.f), ffy = fabsf((float(y) - dyf) * inv_ry * 16.f);
+                                const int ifx = min(int(floorf(ffx)), 15), ify = min(int(floorf(ffy)), 15);
+                                const float fwt = S.filter_table[ify * 16 + ifx];
+                                const float4 L = F.wide_L[base + k];
+                                r += L.x * 1.f * fwt;
+                                g += L.y * 1.f * fwt;
+                                b += L.z * 1.f * fwt;
+                                w += fwt;
+                            }
+                        }
+                    add_xyz(&out, r, g, b, w);
+                }
+        }
+        F.film_xyzw[i] = out;
+    }
 }
 
 // film_resolve: Film::MergeFilmTile (film.cpp:135-148) as a gather. For film
@@ -1449,6 +1519,14 @@ void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffer
                             const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_film_accumulate, dim3(grid_blocks(uint32_t(P.n_owned_tiles) * 256u, cfg.n_cus, 8)),
                        dim3(kBlock), 0, cfg.stream, S, P, B, F);
+}
+void launch_film_store(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int k_begin, int n_samples,
+                       const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_film_store, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B, F, k_begin, n_samples);
+}
+void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F, int n_samples, const LaunchCfg &cfg) {
+    const uint32_t n = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0);
+    hipLaunchKernelGGL(k_film_gather, dim3(grid_blocks(n, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, F, n_samples);
 }
 void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg) {
     const uint32_t n = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0);

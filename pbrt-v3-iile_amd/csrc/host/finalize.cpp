@@ -160,6 +160,51 @@ bool finalize_scene(HostScene *s, std::string *err) {
     f.samp_x1 = int(std::ceil(float(f.crop_x1) - 0.5f + f.filter_rx));
     f.samp_y1 = int(std::ceil(float(f.crop_y1) - 0.5f + f.filter_ry));
 
+    // Film::filterTable, film.cpp:65-74, over the filters of src/filters/{box,gaussian,mitchell,sinc,triangle}
+    {
+        const float rx = s->filter_rx, ry = s->filter_ry, p0 = s->filter_p0, p1 = s->filter_p1;
+        const std::string &fn = s->filter_name;
+        const float exp_x = std::exp(-p0 * rx * rx), exp_y = std::exp(-p0 * ry * ry);  // gaussian.h:53-54
+        auto gaussian = [&](float dd, float expv) { return std::max(0.f, float(std::exp(-p0 * dd * dd) - expv)); };
+        auto mitchell = [&](float x) {  // mitchell.h:53-63
+            const float B = p0, C = p1;
+            x = std::abs(2 * x);
+            if (x > 1)
+                return ((-B - 6 * C) * x * x * x + (6 * B + 30 * C) * x * x + (-12 * B - 48 * C) * x + (8 * B + 24 * C)) * (1.f / 6.f);
+            return ((12 - 9 * B - 6 * C) * x * x * x + (-18 + 12 * B + 6 * C) * x * x + (6 - 2 * B)) * (1.f / 6.f);
+        };
+        auto sinc = [](float x) {  // sinc.h:53-57
+            x = std::abs(x);
+            if (x < 1e-5) return 1.f;
+            return std::sin(kPi * x) / (kPi * x);
+        };
+        auto windowed_sinc = [&](float x, float radius) {  // sinc.h:58-63
+            x = std::abs(x);
+            if (x > radius) return 0.f;
+            float lanczos = sinc(x / p0);
+            return sinc(x) * lanczos;
+        };
+        const float inv_rx = 1.f / rx, inv_ry = 1.f / ry;  // Filter::invRadius
+        int offset = 0;
+        for (int y = 0; y < 16; ++y)
+            for (int x = 0; x < 16; ++x, ++offset) {
+                const float px = (x + 0.5f) * rx / 16, py = (y + 0.5f) * ry / 16;
+                float v;
+                if (fn == "gaussian")
+                    v = gaussian(px, exp_x) * gaussian(py, exp_y);
+                else if (fn == "mitchell")
+                    v = mitchell(px * inv_rx) * mitchell(py * inv_ry);
+                else if (fn == "sinc")
+                    v = windowed_sinc(px, rx) * windowed_sinc(py, ry);
+                else if (fn == "triangle")
+                    v = std::max(0.f, rx - std::abs(px)) * std::max(0.f, ry - std::abs(py));
+                else
+                    v = 1.f;
+                d.film_filter_table[offset] = v;
+            }
+        d.film_filter_wide = (fn == "box" && rx == 0.5f && ry == 0.5f) ? 0 : 1;
+    }
+
     // Camera, cameras/perspective.cpp:297-330 and core/camera.h:90-111
     float frame = s->frame_aspect > 0 ? s->frame_aspect : float(s->xres) / float(s->yres);
     float sw[4];  // pMin.x, pMax.x, pMin.y, pMax.y

@@ -133,6 +133,12 @@ int iile_host_read_image(const char *path, int32_t *width, int32_t *height, floa
     return 0;
 }
 
+int iile_host_scene_filter_table(const iile_host_scene *scene, float *table256) {
+    const iile_scene_desc &d = *iile_host_scene_desc(scene);
+    std::memcpy(table256, d.film_filter_table, sizeof(d.film_filter_table));
+    return d.film_filter_wide;
+}
+
 int iile_host_scene_texture(const iile_host_scene *scene, int32_t index, iile_texture *out) {
     const iile_scene_desc &d = *iile_host_scene_desc(scene);
     if (index < 0 || index >= d.n_textures) {

@@ -52,6 +52,7 @@ struct HostScene {
     std::string film_filename = "pbrt.exr";
     std::string filter_name = "box";
     float filter_rx = 0.5f, filter_ry = 0.5f;
+    float filter_p0 = 0.f, filter_p1 = 0.f;  // gaussian: alpha; mitchell: B, C; sinc: tau
     std::string sampler_name = "halton";
     int spp = 16;
     std::string integrator_name = "path";

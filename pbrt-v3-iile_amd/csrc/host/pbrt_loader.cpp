@@ -448,10 +448,29 @@ class Loader {
             s.sampler_name = name;
             s.spp = ps.one_int("pixelsamples", 16);
             if (ps.one_bool("samplepixelcenter", false)) return fail("samplepixelcenter is not supported");
-        } else if (d == "PixelFilter") {  // filters/box.cpp:43-47
-            if (name != "box") return fail("only PixelFilter \"box\" is supported, got " + name);
-            s.filter_rx = ps.one_float("xwidth", 0.5f);
-            s.filter_ry = ps.one_float("ywidth", 0.5f);
+        } else if (d == "PixelFilter") {  // MakeFilter, api.cpp:855-874; Create*Filter in src/filters/*.cpp
+            s.filter_name = name;
+            if (name == "box") {
+                s.filter_rx = ps.one_float("xwidth", 0.5f);
+                s.filter_ry = ps.one_float("ywidth", 0.5f);
+            } else if (name == "gaussian") {
+                s.filter_rx = ps.one_float("xwidth", 2.f);
+                s.filter_ry = ps.one_float("ywidth", 2.f);
+                s.filter_p0 = ps.one_float("alpha", 2.f);
+            } else if (name == "mitchell") {
+                s.filter_rx = ps.one_float("xwidth", 2.f);
+                s.filter_ry = ps.one_float("ywidth", 2.f);
+                s.filter_p0 = ps.one_float("B", 1.f / 3.f);
+                s.filter_p1 = ps.one_float("C", 1.f / 3.f);
+            } else if (name == "sinc") {
+                s.filter_rx = ps.one_float("xwidth", 4.f);
+                s.filter_ry = ps.one_float("ywidth", 4.f);
+                s.filter_p0 = ps.one_float("tau", 3.f);
+            } else if (name == "triangle") {
+                s.filter_rx = ps.one_float("xwidth", 2.f);
+                s.filter_ry = ps.one_float("ywidth", 2.f);
+            } else
+                return fail("Filter \"" + name + "\" unknown.");
         } else if (d == "Integrator") {  // integrators/path.cpp:214-231
             if (name != "path") return fail("only Integrator \"path\" is supported, got " + name);
             s.max_depth = ps.one_int("maxdepth", 5);

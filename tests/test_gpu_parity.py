@@ -545,3 +545,35 @@ def test_image_textures_bitwise(binding, oracle, tmp_path):
     ref3, _ = oracle.render(scene3)
     assert_bitwise(film3, ref3, "textured room through a thin lens")
     assert not np.array_equal(film3, film)
+
+
+def test_wide_pixel_filters_bitwise(binding, oracle, tmp_path):
+    """Pixel filters wider than the one-pixel box (FilmTile::AddSample with the filter table, film.h:153-193): every
+    filter of src/filters with default and non-default parameters, on the furnace (a border-dominated 12 x 10 image)
+    and on the box room — the film of the sample store + gather kernels is bit for bit the oracle's (same sums in
+    the same order: pixel-major inside a tile, tiles in index order), in one pass and in several, and shard by shard."""
+    import boxroom
+    from test_oracle_pins import FILTERS, _FILTER_SCENE
+    for i, line in enumerate(FILTERS):
+        path = tmp_path / f"filter{i}.pbrt"
+        path.write_text(_FILTER_SCENE % (12, 10, line, 4))
+        scene = binding.HostScene(path=str(path))
+        gpu = binding.GpuScene(scene)
+        ref, ost = oracle.render(scene)
+        film, st = gpu.render(collect_stats=True)
+        assert st["camera_rays"] == ost["camera_rays"]
+        assert_bitwise(film, ref, f"{line}: film")
+        assert_bitwise(gpu.render(spp_per_pass=3)[0], ref, f"{line}: film in two passes")
+    for line in (FILTERS[0], FILTERS[3], FILTERS[4]):
+        path = tmp_path / "room_filter.pbrt"
+        text = boxroom.boxroom_pbrt(xres=96, yres=64, spp=4)
+        assert 'Sampler "halton"' in text
+        path.write_text(text.replace('Sampler "halton"', line + '\nSampler "halton"'))
+        scene = binding.HostScene(path=str(path))
+        gpu = binding.GpuScene(scene)
+        ref, _ = oracle.render(scene)
+        assert_bitwise(gpu.render()[0], ref, f"box room, {line}")
+        for rank in range(3):  # shards: each rank's partial film is the oracle's for the same tiles
+            part, _ = gpu.render(tile_rank=rank, tile_nranks=3, spp_per_pass=1 + rank)
+            pref, _ = oracle.render(scene, tile_rank=rank, tile_nranks=3)
+            assert_bitwise(part, pref, f"box room, {line}, shard {rank} of 3")

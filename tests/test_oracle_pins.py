@@ -645,3 +645,62 @@ def test_environment_map_irradiance(binding, oracle, tmp_path):
     E = (L * (np.cos(theta) * np.sin(theta))[:, None, None]).sum((0, 1)) * (np.pi / 2 / n_t) * (2 * np.pi / n_p)
     want = 0.5 / np.pi * E * np.array([1, .5, 2])
     assert np.allclose(rgb, want, rtol=0.03), (rgb, want)
+
+
+# ---- pixel filters --------------------------------------------------------------------------------------
+_FILTER_SCENE = ('Camera "perspective" "float fov" [45] "float screenwindow" [-1 1 -1 1] "float focaldistance" [10]\n'
+                 'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]\n%s\n'
+                 'Sampler "halton" "integer pixelsamples" [%d]\nIntegrator "path" "integer maxdepth" [8]\nWorldBegin\n'
+                 'Material "matte" "color Kd" [.5 .5 .5]\nAreaLightSource "diffuse" "color L" [.5 .5 .5] "bool twosided" ["true"]\n'
+                 'Shape "trianglemesh" "point P" [ 1 1 1   1 -1 -1   -1 1 -1   -1 -1 1 ]\n  "integer indices" [ 0 1 2   0 3 1   0 2 3   1 3 2 ]\nWorldEnd\n')
+FILTERS = ['PixelFilter "gaussian"', 'PixelFilter "gaussian" "float xwidth" [1.5] "float ywidth" [3] "float alpha" [1]',
+           'PixelFilter "mitchell"', 'PixelFilter "mitchell" "float B" [.2] "float C" [.6] "float xwidth" [3]',
+           'PixelFilter "sinc"', 'PixelFilter "sinc" "float tau" [2] "float xwidth" [2.5] "float ywidth" [2.5]',
+           'PixelFilter "triangle"', 'PixelFilter "box" "float xwidth" [1.25] "float ywidth" [.75]', 'PixelFilter "box"']
+
+
+def test_pixel_filter_tables_and_normalisation(binding, oracle, tmp_path):
+    """Film::filterTable (film.cpp:65-74) against the filters' formulas (src/filters/*.cpp) evaluated here in float64,
+    the sample bounds a wide filter asks for (Film::GetSampleBounds, film.cpp:76-82), and the property every filter
+    shares: the film divides by the sum of the weights (film.cpp:196-204), so inside the white furnace (radiance 1
+    from everywhere) every pixel is 1 whatever the filter — also at the image border, where the support is clipped."""
+    c = (np.arange(16) + .5) / 16
+
+    def table_of(line):
+        (tmp_path / "f.pbrt").write_text(_FILTER_SCENE % (12, 10, line, 16))
+        scene = binding.HostScene(path=str(tmp_path / "f.pbrt"))
+        return scene, *scene.filter_table()
+
+    def sinc(x):
+        x = np.abs(x)
+        return np.where(x < 1e-5, 1.0, np.sin(np.pi * x) / np.where(x == 0, 1, np.pi * x))
+
+    def mitchell(x, B, C):
+        x = np.abs(2 * x)
+        return np.where(x > 1, ((-B - 6 * C) * x ** 3 + (6 * B + 30 * C) * x ** 2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C)) / 6,
+                        ((12 - 9 * B - 6 * C) * x ** 3 + (-18 + 12 * B + 6 * C) * x ** 2 + (6 - 2 * B)) / 6)
+
+    cases = {
+        FILTERS[0]: (2, 2, lambda px, py: np.maximum(0, np.exp(-2 * px * px) - np.exp(-8.0)) * np.maximum(0, np.exp(-2 * py * py) - np.exp(-8.0))),
+        FILTERS[1]: (1.5, 3, lambda px, py: np.maximum(0, np.exp(-px * px) - np.exp(-2.25)) * np.maximum(0, np.exp(-py * py) - np.exp(-9.0))),
+        FILTERS[2]: (2, 2, lambda px, py: mitchell(px / 2, 1 / 3, 1 / 3) * mitchell(py / 2, 1 / 3, 1 / 3)),
+        FILTERS[3]: (3, 2, lambda px, py: mitchell(px / 3, .2, .6) * mitchell(py / 2, .2, .6)),
+        FILTERS[4]: (4, 4, lambda px, py: sinc(px) * sinc(px / 3) * sinc(py) * sinc(py / 3)),
+        FILTERS[5]: (2.5, 2.5, lambda px, py: sinc(px) * sinc(px / 2) * sinc(py) * sinc(py / 2)),
+        FILTERS[6]: (2, 2, lambda px, py: np.maximum(0, 2 - px) * np.maximum(0, 2 - py)),
+        FILTERS[7]: (1.25, .75, lambda px, py: np.ones_like(px * py)),
+        FILTERS[8]: (.5, .5, lambda px, py: np.ones_like(px * py)),
+    }
+    for line, (rx, ry, f) in cases.items():
+        scene, table, wide = table_of(line)
+        want = f((c * rx)[None, :], (c * ry)[:, None])
+        assert np.allclose(table, want, rtol=2e-5, atol=3e-6), line  # float cancellation near the zero crossings
+        assert wide == (line != FILTERS[8])
+        fd = scene.film
+        assert (fd.samp_x0, fd.samp_y0) == (int(np.floor(.5 - rx)), int(np.floor(.5 - ry)))
+        assert (fd.samp_x1, fd.samp_y1) == (int(np.ceil(12 - .5 + rx)), int(np.ceil(10 - .5 + ry)))
+        film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+        assert st["camera_rays"] == (fd.samp_x1 - fd.samp_x0) * (fd.samp_y1 - fd.samp_y0) * 16
+        rgb = scene.film_to_rgb(film)
+        assert abs(float(rgb.mean(dtype=np.float64)) - 1.0) < 0.03, line
+        assert rgb.min() > 0.6 and rgb.max() < 1.4, line
