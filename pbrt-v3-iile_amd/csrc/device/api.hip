@@ -883,9 +883,16 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     }
     FilmBuffers F = sc->fb;
     if (prm->film_on_device) F.film_xyzw = reinterpret_cast<float4 *>(film_xyzw);
-    if (S.filter_wide)
+    if (S.filter_wide) {
+        EventPair *ep = nullptr;
+        if (timed) {  // counted with the film kernels (ms_film)
+            rc = get_events(sc, 4, &ep);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ep->a, stream));
+        }
         launch_film_gather(S, P, F, n_samples, cfg);
-    else
+        if (timed) HIP_TRY(hipEventRecord(ep->b, stream));
+    } else
         launch_film_resolve(S, P, F, cfg);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, stream));

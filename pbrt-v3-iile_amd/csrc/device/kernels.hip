@@ -1192,7 +1192,9 @@ __global__ __launch_bounds__(kBlock) void k_film_store(DScene S, PassDesc P, Pas
         const float4 L4 = B.L[pid];
         const F3 L = guard_radiance(S, F3{L4.x, L4.y, L4.z});
         const uint32_t idx = B.hindex[pid];
-        const size_t at = size_t(pid / uint32_t(P.kc)) * size_t(n_samples) + size_t(int(k) - k_begin);
+        // [tile slot][k][pixel of the tile]: the gather's lanes (neighbouring film pixels) read neighbouring records
+        const uint32_t pt = pid / uint32_t(P.kc);
+        const size_t at = (size_t(pt >> 8) * size_t(n_samples) + size_t(int(k) - k_begin)) * 256u + size_t(pt & 255u);
         F.wide_L[at] = make_float4(L.x, L.y, L.z, 0.f);
         F.wide_pf[at] = make_float2(float(px) + sample_dimension(S, idx, 0), float(py) + sample_dimension(S, idx, 1));
     }
@@ -1213,15 +1215,19 @@ DEV void add_xyz(float4 *out, float r, float g, float b, float w) {  // RGBToXYZ
 }
 
 __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, FilmBuffers F, int n_samples) {
+    __shared__ float s_table[256];
+    for (int j = threadIdx.x; j < 256; j += kBlock) s_table[j] = S.filter_table[j];
+    __syncthreads();
     const int fw = S.crop_x1 - S.crop_x0, fh = S.crop_y1 - S.crop_y0;
     const uint32_t n = uint32_t(fw) * uint32_t(fh);
     const float rx = S.filter_rx, ry = S.filter_ry;
     const float inv_rx = 1 / rx, inv_ry = 1 / ry;  // Filter::invRadius
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const int x = S.crop_x0 + int(i % uint32_t(fw)), y = S.crop_y0 + int(i / uint32_t(fw));
-        // sample pixels that can reach (x, y): |q + u - 0.5 - x| <= r with u in [0, 1)
-        const int qx0 = max(int(floorf(float(x) - rx - 0.5f)) - 1, S.samp_x0), qx1 = min(int(ceilf(float(x) + rx + 0.5f)) + 1, S.samp_x1 - 1);
-        const int qy0 = max(int(floorf(float(y) - ry - 0.5f)) - 1, S.samp_y0), qy1 = min(int(ceilf(float(y) + ry + 0.5f)) + 1, S.samp_y1 - 1);
+        // sample pixels that can reach (x, y): |q + u - 0.5 - x| <= r with u in [0, 1), i.e. x - r - 0.5 < q <= x + r + 0.5
+        // (floor / ceil keep a pixel of slack on either side against the rounding of the sums in AddSample)
+        const int qx0 = max(int(floorf(float(x) - rx - 0.5f)), S.samp_x0), qx1 = min(int(ceilf(float(x) + rx + 0.5f)), S.samp_x1 - 1);
+        const int qy0 = max(int(floorf(float(y) - ry - 0.5f)), S.samp_y0), qy1 = min(int(ceilf(float(y) + ry + 0.5f)), S.samp_y1 - 1);
         float4 out = make_float4(0, 0, 0, 0);
         if (qx0 <= qx1 && qy0 <= qy1) {
             const int tx0 = (qx0 - S.samp_x0) / kTile, tx1 = (qx1 - S.samp_x0) / kTile;
@@ -1239,21 +1245,34 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, Fi
                     float r = 0, g = 0, b = 0, w = 0;
                     for (int qy = max(qy0, sy0); qy <= min(qy1, sy1 - 1); ++qy)
                         for (int qx = max(qx0, sx0); qx <= min(qx1, sx1 - 1); ++qx) {
-                            const size_t base = (size_t(slot) * 256u + size_t((qy - sy0) * kTile + (qx - sx0))) * size_t(n_samples);
-                            for (int k = 0; k < n_samples; ++k) {
-                                const float2 pf = F.wide_pf[base + k];
-                                // FilmTile::AddSample's support test and table lookup for this pixel (film.h:159-188)
-                                const float dxf = pf.x - 0.5f, dyf = pf.y - 0.5f;
-                                if (x < max(int(ceilf(dxf - rx)), fx0) || x >= min(int(floorf(dxf + rx)) + 1, fx1)) continue;
-                                if (y < max(int(ceilf(dyf - ry)), fy0) || y >= min(int(floorf(dyf + ry)) + 1, fy1)) continue;
-                                const float ffx = fabsf((float(x) - dxf) * inv_rx * 16.f), ffy = fabsf((float(y) - dyf) * inv_ry * 16.f);
-                                const int ifx = min(int(floorf(ffx)), 15), ify = min(int(floorf(ffy)), 15);
-                                const float fwt = S.filter_table[ify * 16 + ifx];
-                                const float4 L = F.wide_L[base + k];
-                                r += L.x * 1.f * fwt;
-                                g += L.y * 1.f * fwt;
-                                b += L.z * 1.f * fwt;
-                                w += fwt;
+                            const size_t base = size_t(slot) * size_t(n_samples) * 256u + size_t((qy - sy0) * kTile + (qx - sx0));
+                            for (int k4 = 0; k4 < n_samples; k4 += 4) {
+                                // four records in flight, then summed in sample order
+                                float2 pfb[4];
+                                float4 Lb[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const size_t at = base + size_t(k4 + j < n_samples ? k4 + j : k4) * 256u;
+                                    pfb[j] = F.wide_pf[at];
+                                    Lb[j] = F.wide_L[at];
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    if (k4 + j >= n_samples) break;
+                                    // FilmTile::AddSample's support test and table lookup for this pixel (film.h:159-188)
+                                    const float dxf = pfb[j].x - 0.5f, dyf = pfb[j].y - 0.5f;
+                                    const bool in = x >= max(int(ceilf(dxf - rx)), fx0) && x < min(int(floorf(dxf + rx)) + 1, fx1) &&
+                                                    y >= max(int(ceilf(dyf - ry)), fy0) && y < min(int(floorf(dyf + ry)) + 1, fy1);
+                                    if (in) {
+                                        const float ffx = fabsf((float(x) - dxf) * inv_rx * 16.f), ffy = fabsf((float(y) - dyf) * inv_ry * 16.f);
+                                        const int ifx = min(int(floorf(ffx)), 15), ify = min(int(floorf(ffy)), 15);
+                                        const float fwt = s_table[ify * 16 + ifx];
+                                        r += Lb[j].x * 1.f * fwt;
+                                        g += Lb[j].y * 1.f * fwt;
+                                        b += Lb[j].z * 1.f * fwt;
+                                        w += fwt;
+                                    }
+                                }
                             }
                         }
                     add_xyz(&out, r, g, b, w);
