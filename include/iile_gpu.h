@@ -114,6 +114,16 @@ int iile_li_samples(iile_scene *scene, int32_t n, const int32_t *px, const int32
  * {wi.xyz, f.rgb, pdf}) of material `mat` in the canonical frame ns=ng=+z, ss=+x. */
 int iile_bsdf_eval(iile_scene *scene, int32_t n, int32_t mat, const float *wo3, const float *wi3, float *out4);
 int iile_bsdf_sample(iile_scene *scene, int32_t n, int32_t mat, const float *wo3, const float *u2, float *out7);
+/* The IISPT probe pass: for each of n probes, what iisptrenderrunner.cpp:316-346 obtains from
+ * CreateHemisphericCamera(hemi, hemi, pos, dir) + IISPTdIntegrator::RenderView + get_intensity_film /
+ * get_normal_film / get_distance_film (src/integrators/iispt_d.cpp:66-470, src/cameras/hemispheric.cpp) — the three
+ * inputs of the IISPT network — rendered as one batched wavefront pass. pos3 / dir3: the probe origins and
+ * directions (the runner passes the spawned ray of the surface normal). Outputs per probe hemi x hemi pixels, [y][x]
+ * in the probe camera's raster coordinates (the reference's ImageFilm keeps row hemi - 1 - y): intensity RGB,
+ * camera-space normals, distances (-1 where the ray escaped). Film, sampler and depth come from
+ * iile_scene_desc::probe. */
+int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, const float *dir3, float *intensity_rgb,
+                       float *normals_xyz, float *distance, iile_stats *stats);
 /* ImageTexture<RGBSpectrum, Spectrum>::Evaluate (src/textures/imagemap.h:87-94) of image texture `tex` at n
  * surface points given by (u, v) and the screen-space differentials {du/dx, dv/dx, du/dy, dv/dy}. */
 int iile_texture_eval(iile_scene *scene, int32_t tex, int32_t n, const float *uv2, const float *duv4, float *rgb3);

@@ -174,6 +174,19 @@ typedef struct iile_integrator {
     float rr_threshold;
 } iile_integrator;
 
+/* The IISPT probe pass: what IISPTdIntegrator::RenderView renders from a HemisphericCamera
+ * (src/integrators/iispt_d.cpp:66-470, src/cameras/hemispheric.cpp:15-160): a hemi_size x hemi_size film behind a
+ * Gaussian filter (radius 2, alpha 2; CreateHemisphericCamera), one Halton sample per pixel from a sampler built
+ * for the film's sample bounds (CreateIISPTdIntegrator with iileDSampler "halton"), maxdepth 3. The host fills
+ * this once; the probes' cameras (position, direction) arrive per call. */
+typedef struct iile_probe_setup {
+    int32_t hemi_size;       /* PbrtOptions.iisptHemiSize, 32 */
+    int32_t max_depth;       /* 3, hard-coded in CreateIISPTdIntegrator */
+    iile_film_desc film;     /* hemi_size^2, crop = full, sample bounds -2 .. hemi_size + 2 */
+    float filter_table[256]; /* GaussianFilter((2, 2), 2) */
+    int32_t base_scales[2], base_exponents[2], sample_stride, mult_inverse[2]; /* HaltonSampler(1, sampleBounds) */
+} iile_probe_setup;
+
 typedef struct iile_scene_desc {
     /* BVH, depth-first flattened (src/accelerators/bvh.cpp:640-658) */
     int32_t n_nodes;
@@ -211,6 +224,7 @@ typedef struct iile_scene_desc {
     iile_film_desc film;
     iile_halton halton;
     iile_integrator integrator;
+    iile_probe_setup probe;
 } iile_scene_desc;
 
 #ifdef __cplusplus

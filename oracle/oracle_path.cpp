@@ -571,11 +571,113 @@ struct RayDiff {
     V3 rxo, ryo, rxd, ryd;
 };
 
+// Inverse(Matrix4x4), transform.cpp:82-141: Gauss-Jordan elimination with full pivoting
+static bool invert4(const float in[16], float out[16]) {
+    int indxc[4], indxr[4];
+    int ipiv[4] = {0, 0, 0, 0};
+    float a[4][4];
+    std::memcpy(a, in, sizeof(a));
+    for (int i = 0; i < 4; i++) {
+        int irow = 0, icol = 0;
+        float big = 0.f;
+        for (int j = 0; j < 4; j++) {
+            if (ipiv[j] != 1) {
+                for (int k = 0; k < 4; k++) {
+                    if (ipiv[k] == 0) {
+                        if (std::abs(a[j][k]) >= big) {
+                            big = float(std::abs(a[j][k]));
+                            irow = j;
+                            icol = k;
+                        }
+                    } else if (ipiv[k] > 1)
+                        return false;
+                }
+            }
+        }
+        ++ipiv[icol];
+        if (irow != icol)
+            for (int k = 0; k < 4; ++k) std::swap(a[irow][k], a[icol][k]);
+        indxr[i] = irow;
+        indxc[i] = icol;
+        if (a[icol][icol] == 0.f) return false;
+        float pivinv = float(1. / a[icol][icol]);  // `Float pivinv = 1. / minv[icol][icol]`: a double divide
+        a[icol][icol] = 1.;
+        for (int j = 0; j < 4; j++) a[icol][j] *= pivinv;
+        for (int j = 0; j < 4; j++) {
+            if (j != icol) {
+                float save = a[j][icol];
+                a[j][icol] = 0;
+                for (int k = 0; k < 4; k++) a[j][k] -= a[icol][k] * save;
+            }
+        }
+    }
+    for (int j = 3; j >= 0; j--) {
+        if (indxr[j] != indxc[j])
+            for (int k = 0; k < 4; k++) std::swap(a[k][indxr[j]], a[k][indxc[j]]);
+    }
+    std::memcpy(out, a, sizeof(a));
+    return true;
+}
+
+// CreateHemisphericCamera (hemispheric.cpp:109-160): the probe's CameraToWorld = LookAt(pos, pos + dir, up)'s
+// cameraToWorld (transform.cpp:203-236), and its WorldToCamera = Transform(Inverse(cameraToWorld)) whose own inverse
+// (a second numerical inversion) is what transforms normals (transform.h:243-249)
+struct ProbeCam {
+    float c2w[16];
+    float w2c_minv[16];  // mInv of WorldToCamera
+    int hemi_size;
+};
+static bool make_probe_camera(const float pos[3], const float dir[3], int hemi_size, ProbeCam *cam) {
+    const V3 up = (dir[0] == 0.0 && dir[1] == 0.0) ? V3(0.f, 1.f, 0.f) : V3(0.f, 0.f, 1.f);
+    const V3 p(pos[0], pos[1], pos[2]);
+    const V3 look(pos[0] + dir[0], pos[1] + dir[1], pos[2] + dir[2]);
+    float m[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // Matrix4x4() is the identity ...
+    m[0] = m[5] = m[10] = m[15] = 1;
+    m[3] = p.x;
+    m[7] = p.y;
+    m[11] = p.z;
+    m[15] = 1;
+    V3 d = normalize(look - p);
+    if (length(cross(normalize(up), d)) == 0) return false;
+    V3 right = normalize(cross(normalize(up), d));
+    V3 new_up = cross(d, right);
+    m[0] = right.x, m[4] = right.y, m[8] = right.z, m[12] = 0.f;
+    m[1] = new_up.x, m[5] = new_up.y, m[9] = new_up.z, m[13] = 0.f;
+    m[2] = d.x, m[6] = d.y, m[10] = d.z, m[14] = 0.f;
+    std::memcpy(cam->c2w, m, sizeof(m));
+    float inv[16];
+    if (!invert4(m, inv)) return false;           // cameraTransform->GetInverseMatrix()
+    if (!invert4(inv, cam->w2c_minv)) return false;  // WorldToCamera = Transform(that): its mInv
+    cam->hemi_size = hemi_size;
+    return true;
+}
+
 struct Oracle {
     const iile_scene_desc &S;
     Trig trig;
     Counters *ctr;
+    const ProbeCam *probe = nullptr;  // probe pass: HemisphericCamera + IISPTdIntegrator::Li
+    float probe_aux[4] = {0, 0, 0, -1.f};  // camera-space normal and distance of the last camera ray's first hit
     Oracle(const iile_scene_desc &s, int mode, Counters *c) : S(s), trig{mode}, ctr(c) {}
+
+    // HemisphericCamera::GenerateRay (hemispheric.cpp:15-41) + Transform::operator()(Ray) (transform.h:251-264)
+    Ray probe_ray(float pfx, float pfy) const {
+        float theta = Pi * pfy / float(probe->hemi_size);
+        float phi = Pi * pfx / float(probe->hemi_size);
+        V3 dir(trig.sin_f(theta) * trig.cos_f(phi), trig.cos_f(theta), trig.sin_f(theta) * trig.sin_f(phi));
+        M4 m{probe->c2w};
+        V3 oerr;
+        V3 o = xf_point_err(m, V3(0, 0, 0), &oerr);
+        V3 d = xf_vector(m, dir);
+        float len2 = length_sq(d);
+        float tmax = Infinity;
+        if (len2 > 0) {
+            float dt = dot(vabs(d), oerr) / len2;
+            o = o + d * dt;
+            tmax -= dt;
+        }
+        return Ray{o, d, tmax};
+    }
 
     // ------------------------------------------------------------------------
     // Halton (samplers/halton.cpp:96-127, core/lowdiscrepancy.cpp:389-427)
@@ -2177,7 +2279,9 @@ struct Oracle {
 
     // ------------------------------------------------------------------------
     // PathIntegrator::Li, integrators/path.cpp:64-194
-    Rgb li(Ray ray, Sampler &smp, RayDiff rdiff = RayDiff()) const {
+    // aux != null: IISPTdIntegrator::Li (iispt_d.cpp:66-222) — no emitted light at the camera ray's own vertex
+    // (hit or escaped), and the first hit's distance and camera-space normal recorded
+    Rgb li(Ray ray, Sampler &smp, RayDiff rdiff = RayDiff(), float *aux = nullptr) const {
         Rgb L(0.f), beta(1.f);
         bool specular_bounce = false;
         int bounces;
@@ -2187,7 +2291,21 @@ struct Oracle {
         for (bounces = 0;; ++bounces) {
             Isect is;
             bool found = intersect(ray, &is);
-            if (bounces == 0 || specular_bounce) {
+            if (aux && bounces == 0) {  // iispt_d.cpp:96-113
+                if (found) {
+                    V3 cv = is.p - ray.o;
+                    float d2 = dot(cv, cv);
+                    aux[3] = std::sqrt(d2);
+                    const float *mi = probe->w2c_minv;  // Transform::operator()(Normal3f): transpose of mInv
+                    aux[0] = mi[0] * is.n.x + mi[4] * is.n.y + mi[8] * is.n.z;
+                    aux[1] = mi[1] * is.n.x + mi[5] * is.n.y + mi[9] * is.n.z;
+                    aux[2] = mi[2] * is.n.x + mi[6] * is.n.y + mi[10] * is.n.z;
+                } else {
+                    aux[0] = aux[1] = aux[2] = 0.f;
+                    aux[3] = -1.f;  // NO_INTERSECTION_DISTANCE
+                }
+            }
+            if ((bounces == 0 && !aux) || (bounces != 0 && specular_bounce)) {
                 if (found)
                     L = L + beta * isect_le(is, -ray.d);
                 else  // `for (const auto &light : scene.infiniteLights) L += beta * light->Le(ray)`, path.cpp:97-99
@@ -2267,9 +2385,9 @@ struct Oracle {
         float plens[2];
         smp.get2d(plens);
         RayDiff rdiff;
-        Ray ray = camera_ray(pfilm[0], pfilm[1], plens, S.n_textures > 0 ? &rdiff : nullptr);
+        Ray ray = probe ? probe_ray(pfilm[0], pfilm[1]) : camera_ray(pfilm[0], pfilm[1], plens, S.n_textures > 0 ? &rdiff : nullptr);
         ++ctr->camera_rays;
-        Rgb L = li(ray, smp, rdiff);
+        Rgb L = li(ray, smp, rdiff, probe ? const_cast<float *>(probe_aux) : nullptr);
         if (L.has_nans())
             L = Rgb(0.f);
         else if (L.y() < -1e-5)
@@ -2300,8 +2418,13 @@ struct FilmTile {
 
 extern "C" {
 
-int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, int k_begin, int k_end, int tile_rank,
-                  int tile_nranks, float *film_xyzw, oracle_stats *stats) {
+}  // extern "C"
+
+// SamplerIntegrator::Render's tile loop (integrator.cpp:227-339); with `probe`: IISPTdIntegrator::RenderView
+// (iispt_d.cpp:388-470) — pixels outside the film's pixel bounds are skipped (:428-429) and the first hits' camera-space
+// normals and distances go to aux_nd[(y * w + x) * 4]
+static int render_impl(const iile_scene_desc *scene, int trig_mode, int n_threads, int k_begin, int k_end, int tile_rank,
+                       int tile_nranks, float *film_xyzw, oracle_stats *stats, const ProbeCam *probe, float *aux_nd) {
     if (!scene || !film_xyzw) return 1;
     const iile_scene_desc &S = *scene;
     const iile_film_desc &F = S.film;
@@ -2325,6 +2448,7 @@ int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, in
     auto t_start = std::chrono::steady_clock::now();
     auto worker = [&](int tid) {
         Oracle orc(S, trig_mode, &counters[tid]);
+        orc.probe = probe;
         while (true) {
             int tile = next_tile.fetch_add(1);
             if (tile >= n_tiles) break;
@@ -2343,8 +2467,12 @@ int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, in
             for (int py = y0; py < y1; ++py)
                 for (int px = x0; px < x1; ++px)
                     for (int64_t k = k_begin; k < k_end; ++k) {
+                        if (probe && (px < F.crop_x0 || px >= F.crop_x1 || py < F.crop_y0 || py >= F.crop_y1)) continue;
                         float pf[2];
                         Rgb L = orc.sample_radiance(px, py, k, pf);
+                        if (probe && aux_nd)
+                            std::memcpy(aux_nd + 4 * (size_t(py - F.crop_y0) * (F.crop_x1 - F.crop_x0) + (px - F.crop_x0)),
+                                        orc.probe_aux, 4 * sizeof(float));
                         if (L.y() > F.max_sample_luminance) L = L * (F.max_sample_luminance / L.y());
                         // FilmTile::AddSample, film.h:153-193
                         float dxf = pf[0] - 0.5f, dyf = pf[1] - 0.5f;
@@ -2413,6 +2541,65 @@ int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, in
         stats->max_stack_depth = tot.max_stack;
         stats->threads = n_threads;
         stats->seconds = secs;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, int k_begin, int k_end, int tile_rank,
+                  int tile_nranks, float *film_xyzw, oracle_stats *stats) {
+    return render_impl(scene, trig_mode, n_threads, k_begin, k_end, tile_rank, tile_nranks, film_xyzw, stats, nullptr, nullptr);
+}
+
+// One IISPT probe (iisptrenderrunner.cpp:316-346): CreateHemisphericCamera(hemi, hemi, pos, dir), IISPTdIntegrator::
+// RenderView, then get_intensity_film / get_normal_film / get_distance_film. Outputs are indexed [y][x] in the camera's
+// raster coordinates (the reference's ImageFilm stores row height - 1 - y, imagefilm.cpp:26-31, film.cpp:245-254).
+int oracle_render_probe(const iile_scene_desc *scene, int trig_mode, const float *pos3, const float *dir3, float *intensity_rgb,
+                        float *normals_xyz, float *distance) {
+    if (!scene || !pos3 || !dir3) return 1;
+    for (int i = 0; i < scene->n_materials; ++i) {
+        const iile_material &m = scene->materials[i];
+        if (scene->n_textures > 0 && (m.kd_tex >= 0 || m.ks_tex >= 0 || m.kr_tex >= 0 || m.kt_tex >= 0)) return 2;
+    }
+    const iile_probe_setup &pr = scene->probe;
+    ProbeCam cam;
+    if (!make_probe_camera(pos3, dir3, pr.hemi_size, &cam)) return 3;
+    iile_scene_desc sp = *scene;  // the probe's film, sampler and depth in place of the frame's
+    sp.film = pr.film;
+    sp.film_filter_wide = 1;
+    std::memcpy(sp.film_filter_table, pr.filter_table, sizeof(pr.filter_table));
+    sp.halton.spp = 1;
+    for (int i = 0; i < 2; ++i) {
+        sp.halton.base_scales[i] = pr.base_scales[i];
+        sp.halton.base_exponents[i] = pr.base_exponents[i];
+        sp.halton.mult_inverse[i] = pr.mult_inverse[i];
+    }
+    sp.halton.sample_stride = pr.sample_stride;
+    sp.integrator.max_depth = pr.max_depth;
+    const int n = pr.hemi_size;
+    std::vector<float> film(size_t(4) * n * n), aux(size_t(4) * n * n, 0.f);
+    for (int i = 0; i < n * n; ++i) aux[4 * size_t(i) + 3] = 0.f;  // normal_film / distance_film->clear(): zeros
+    int rc = render_impl(&sp, trig_mode, 1, 0, 1, 0, 1, film.data(), nullptr, &cam, aux.data());
+    if (rc) return rc;
+    for (int i = 0; i < n * n; ++i) {
+        // Film::to_rgb_array(1.0), film.cpp:187-225
+        const float *px = &film[4 * size_t(i)];
+        float rgb[3];
+        rgb[0] = 3.240479f * px[0] - 1.537150f * px[1] - 0.498535f * px[2];  // XYZToRGB, spectrum.h:56-60
+        rgb[1] = -0.969256f * px[0] + 1.875991f * px[1] + 0.041556f * px[2];
+        rgb[2] = 0.055648f * px[0] - 0.204043f * px[1] + 1.057311f * px[2];
+        if (px[3] != 0) {
+            float inv_wt = 1.f / px[3];
+            for (int c = 0; c < 3; ++c) rgb[c] = std::max(0.f, rgb[c] * inv_wt);
+        }
+        for (int c = 0; c < 3; ++c) {
+            rgb[c] += 1.f * 0.f;  // no splats
+            rgb[c] *= sp.film.scale;
+            if (intensity_rgb) intensity_rgb[3 * size_t(i) + c] = rgb[c];
+            if (normals_xyz) normals_xyz[3 * size_t(i) + c] = aux[4 * size_t(i) + c];
+        }
+        if (distance) distance[i] = aux[4 * size_t(i) + 3];
     }
     return 0;
 }

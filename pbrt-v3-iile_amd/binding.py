@@ -74,7 +74,7 @@ HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_
                 "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table"]
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
-               "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval"]
+               "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes"]
 
 _host = None
 _gpu = None
@@ -140,6 +140,7 @@ def gpu_lib():
         lib.iile_li_samples.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         lib.iile_bsdf_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_texture_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
+        lib.iile_render_probes.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GpuStats)]
         lib.iile_bsdf_sample.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
         _gpu = lib
@@ -312,6 +313,19 @@ class GpuScene:
         self._check(gpu_lib().iile_bsdf_eval(self._s, len(wo), mat, wo.ctypes.data, wi.ctypes.data, out.ctypes.data),
                     "iile_bsdf_eval")
         return out
+
+    def render_probes(self, pos, direction, hemi=32):
+        """IISPT probe pass: (n, 3) origins and directions -> intensity (n, hemi, hemi, 3), camera-space normals
+        (n, hemi, hemi, 3), distances (n, hemi, hemi), [y][x] in raster order; plus the stats dict."""
+        pos, direction = _f32(pos).reshape(-1, 3), _f32(direction).reshape(-1, 3)
+        n = len(pos)
+        inten = np.zeros((n, hemi, hemi, 3), np.float32)
+        nrm = np.zeros((n, hemi, hemi, 3), np.float32)
+        dist = np.zeros((n, hemi, hemi), np.float32)
+        st = GpuStats()
+        self._check(gpu_lib().iile_render_probes(self._s, n, pos.ctypes.data, direction.ctypes.data, inten.ctypes.data,
+                                                 nrm.ctypes.data, dist.ctypes.data, ctypes.byref(st)), "iile_render_probes")
+        return inten, nrm, dist, st.as_dict()
 
     def texture_eval(self, tex, uv, duv):
         """ImageTexture::Evaluate at (n, 2) uv with (n, 4) differentials {dudx, dvdx, dudy, dvdy} -> (n, 3) RGB."""

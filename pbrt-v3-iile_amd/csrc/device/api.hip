@@ -56,6 +56,11 @@ struct iile_scene {
     uint32_t film_tiles = 0;
     uint32_t film_pixels = 0;
     FilmBuffers fb;
+    iile_probe_setup probe;
+    const uint32_t *probe_pixel_offsets = nullptr;
+    const float *probe_filter_table = nullptr;
+    void *probe_block = nullptr;  // cameras + aux + outputs of the last probe batch
+    size_t probe_block_bytes = 0;
     void *film_block = nullptr;
     void *wide_block = nullptr;
     uint64_t film_wide = 0;
@@ -199,8 +204,7 @@ void copy_counters(const DCounters &c, iile_stats *st) {
 }
 
 // Enqueue one wavefront pass on cfg.stream.
-int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed) {
-    const DScene &S = sc->ds;
+int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P, const LaunchCfg &cfg, bool timed) {
     PassBuffers &B = sc->pb;
     HIP_TRY(hipMemsetAsync(B.counts, 0, 128 * sizeof(uint32_t), cfg.stream));
     auto timed_launch = [&](int kind, auto &&fn) -> int {
@@ -218,7 +222,7 @@ int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed
     if (rc) return rc;
     // bounces 0 .. maxDepth: the path loop exits at `bounces >= maxDepth` after
     // intersecting (path.cpp:104), so maxDepth + 1 extend launches are needed
-    for (int b = 0; b <= sc->max_depth; ++b) {
+    for (int b = 0; b <= max_depth; ++b) {
         rc = timed_launch(1, [&] { launch_extend(S, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (S.has_infinite) {  // escaped rays see the infinite lights (path.cpp:97-99)
@@ -227,7 +231,7 @@ int run_pass(iile_scene *sc, const PassDesc &P, const LaunchCfg &cfg, bool timed
         }
         rc = timed_launch(2, [&] { launch_shade(S, P, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
-        if (b < sc->max_depth) {
+        if (b < max_depth) {
             // MIS rays first: the shadow kernel finishes each record (L += beta * Ld)
             rc = timed_launch(5, [&] { launch_mis(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
@@ -657,27 +661,39 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         sc->spp = h.spp;
         // HaltonSampler::GetIndexForSample's per-pixel offset (halton.cpp:96-122) depends only on
         // the pixel modulo kMaxResolution = 128: tabulated once (integer arithmetic, exact)
-        std::vector<uint32_t> offs(128 * 128, 0u);
-        if (h.sample_stride > 1) {
-            for (int pmy = 0; pmy < 128; ++pmy)
-                for (int pmx = 0; pmx < 128; ++pmx) {
-                    uint32_t inv = uint32_t(pmx), idx0 = 0, idx1 = 0;  // InverseRadicalInverse<2>, <3>
-                    for (int i = 0; i < h.base_exponents[0]; ++i) {
-                        idx0 = idx0 * 2 + (inv & 1);
-                        inv >>= 1;
+        auto pixel_offsets = [](const int32_t *scales, const int32_t *exps, int32_t stride, const int32_t *mult_inv) {
+            std::vector<uint32_t> offs(128 * 128, 0u);
+            if (stride > 1) {
+                for (int pmy = 0; pmy < 128; ++pmy)
+                    for (int pmx = 0; pmx < 128; ++pmx) {
+                        uint32_t inv = uint32_t(pmx), idx0 = 0, idx1 = 0;  // InverseRadicalInverse<2>, <3>
+                        for (int i = 0; i < exps[0]; ++i) {
+                            idx0 = idx0 * 2 + (inv & 1);
+                            inv >>= 1;
+                        }
+                        inv = uint32_t(pmy);
+                        for (int i = 0; i < exps[1]; ++i) {
+                            idx1 = idx1 * 3 + inv % 3;
+                            inv /= 3;
+                        }
+                        const unsigned long long off =
+                            (unsigned long long)idx0 * (unsigned long long)(stride / scales[0]) * (unsigned long long)mult_inv[0] +
+                            (unsigned long long)idx1 * (unsigned long long)(stride / scales[1]) * (unsigned long long)mult_inv[1];
+                        offs[pmy * 128 + pmx] = uint32_t(off % (unsigned long long)stride);
                     }
-                    inv = uint32_t(pmy);
-                    for (int i = 0; i < h.base_exponents[1]; ++i) {
-                        idx1 = idx1 * 3 + inv % 3;
-                        inv /= 3;
-                    }
-                    const unsigned long long off =
-                        (unsigned long long)idx0 * (unsigned long long)(h.sample_stride / h.base_scales[0]) *
-                            (unsigned long long)h.mult_inverse[0] +
-                        (unsigned long long)idx1 * (unsigned long long)(h.sample_stride / h.base_scales[1]) *
-                            (unsigned long long)h.mult_inverse[1];
-                    offs[pmy * 128 + pmx] = uint32_t(off % (unsigned long long)h.sample_stride);
-                }
+            }
+            return offs;
+        };
+        const std::vector<uint32_t> offs = pixel_offsets(h.base_scales, h.base_exponents, h.sample_stride, h.mult_inverse);
+        // the IISPT probe pass has its own film and sampler (iile_probe_setup)
+        sc->probe = d->probe;
+        if (d->probe.hemi_size > 0 && d->probe.sample_stride > 0) {
+            const std::vector<uint32_t> poffs =
+                pixel_offsets(d->probe.base_scales, d->probe.base_exponents, d->probe.sample_stride, d->probe.mult_inverse);
+            rc = upload(sc, poffs.data(), poffs.size(), &sc->probe_pixel_offsets);
+            if (rc) return bail(rc);
+            rc = upload(sc, d->probe.filter_table, size_t(256), &sc->probe_filter_table);
+            if (rc) return bail(rc);
         }
         rc = upload(sc, offs.data(), offs.size(), &S.pixel_offsets);
         if (rc) return bail(rc);
@@ -788,6 +804,7 @@ void iile_scene_destroy(iile_scene *sc) {
     if (sc->ws_block) (void)hipFree(sc->ws_block);
     if (sc->film_block) (void)hipFree(sc->film_block);
     if (sc->wide_block) (void)hipFree(sc->wide_block);
+    if (sc->probe_block) (void)hipFree(sc->probe_block);
     if (sc->nray_buf) (void)hipFree(sc->nray_buf);
     for (EventPair &e : sc->events) {
         (void)hipEventDestroy(e.a);
@@ -865,7 +882,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         P.k0 = k0;
         P.kc = std::min(kc, k_end - k0);
         P.n_paths = uint32_t(pix_slots * P.kc);
-        rc = run_pass(sc, P, cfg, timed);
+        rc = run_pass(sc, S, sc->max_depth, P, cfg, timed);
         if (rc) return rc;
         EventPair *ep = nullptr;
         if (timed) {
@@ -918,6 +935,204 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         st.workspace_bytes = sc->ws_bytes;
         if (stats) *stats = st;
     }
+    return IILE_OK;
+}
+
+// ---- IISPT probe pass ---------------------------------------------------------
+namespace {
+// Inverse(Matrix4x4), transform.cpp:82-141 (Gauss-Jordan, full pivoting; the pivot reciprocal is a double divide)
+bool invert4(const float in[16], float out[16]) {
+    int indxc[4], indxr[4];
+    int ipiv[4] = {0, 0, 0, 0};
+    float a[4][4];
+    std::memcpy(a, in, sizeof(a));
+    for (int i = 0; i < 4; i++) {
+        int irow = 0, icol = 0;
+        float big = 0.f;
+        for (int j = 0; j < 4; j++) {
+            if (ipiv[j] == 1) continue;
+            for (int k = 0; k < 4; k++) {
+                if (ipiv[k] == 0) {
+                    if (std::abs(a[j][k]) >= big) {
+                        big = std::abs(a[j][k]);
+                        irow = j;
+                        icol = k;
+                    }
+                } else if (ipiv[k] > 1)
+                    return false;
+            }
+        }
+        ++ipiv[icol];
+        if (irow != icol)
+            for (int k = 0; k < 4; ++k) std::swap(a[irow][k], a[icol][k]);
+        indxr[i] = irow;
+        indxc[i] = icol;
+        if (a[icol][icol] == 0.f) return false;
+        const float pivinv = float(1. / double(a[icol][icol]));
+        a[icol][icol] = 1.f;
+        for (int j = 0; j < 4; j++) a[icol][j] *= pivinv;
+        for (int j = 0; j < 4; j++) {
+            if (j == icol) continue;
+            const float save = a[j][icol];
+            a[j][icol] = 0;
+            for (int k = 0; k < 4; k++) a[j][k] -= a[icol][k] * save;
+        }
+    }
+    for (int j = 3; j >= 0; j--)
+        if (indxr[j] != indxc[j])
+            for (int k = 0; k < 4; k++) std::swap(a[k][indxr[j]], a[k][indxc[j]]);
+    std::memcpy(out, a, sizeof(a));
+    return true;
+}
+struct H3 {
+    float x, y, z;
+};
+H3 h_normalize(H3 v) {  // Vector3::operator/ multiplies by the float reciprocal (geometry.h:242-246)
+    const float inv = 1.f / std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    return H3{v.x * inv, v.y * inv, v.z * inv};
+}
+H3 h_cross(H3 a, H3 b) {  // geometry.h:957-963: in double
+    const double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    return H3{float((ay * bz) - (az * by)), float((az * bx) - (ax * bz)), float((ax * by) - (ay * bx))};
+}
+// CreateHemisphericCamera (hemispheric.cpp:109-160) over LookAt (transform.cpp:203-236)
+bool make_probe_camera(const float *pos, const float *dir, DProbeCam *cam) {
+    const H3 up = (dir[0] == 0.0 && dir[1] == 0.0) ? H3{0.f, 1.f, 0.f} : H3{0.f, 0.f, 1.f};
+    const H3 look = H3{pos[0] + dir[0], pos[1] + dir[1], pos[2] + dir[2]};
+    const H3 d = h_normalize(H3{look.x - pos[0], look.y - pos[1], look.z - pos[2]});
+    const H3 c = h_cross(h_normalize(up), d);
+    if (std::sqrt(c.x * c.x + c.y * c.y + c.z * c.z) == 0) return false;
+    const H3 right = h_normalize(c);
+    const H3 new_up = h_cross(d, right);
+    const float m[16] = {right.x, new_up.x, d.x, pos[0], right.y, new_up.y, d.y, pos[1], right.z, new_up.z, d.z, pos[2], 0.f, 0.f, 0.f, 1.f};
+    std::memcpy(cam->c2w.m, m, sizeof(m));
+    float inv[16], minv[16];
+    if (!invert4(m, inv) || !invert4(inv, minv)) return false;
+    for (int r = 0; r < 3; ++r)
+        for (int cidx = 0; cidx < 3; ++cidx) cam->nrm[3 * r + cidx] = minv[4 * cidx + r];  // transpose of mInv
+    return true;
+}
+}  // namespace
+
+int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, const float *dir3, float *intensity_rgb, float *normals_xyz,
+                       float *distance, iile_stats *stats) {
+    if (!sc || n_probes < 0 || !pos3 || !dir3 || !intensity_rgb || !normals_xyz || !distance)
+        return fail(IILE_ERR_ARG, "iile_render_probes: null argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    const iile_probe_setup &pr = sc->probe;
+    if (pr.hemi_size <= 0 || !sc->probe_pixel_offsets) return fail(IILE_ERR_ARG, "iile_render_probes: the scene has no probe setup");
+    if (sc->ds.textured_materials)
+        return fail(IILE_ERR_UNSUPPORTED, "iile_render_probes: image-textured materials (the probe camera's ray differentials) are not supported");
+    if (pr.max_depth > 14) return fail(IILE_ERR_UNSUPPORTED, "probe maxdepth > 14");
+    iile_stats st;
+    std::memset(&st, 0, sizeof(st));
+    if (n_probes == 0) {
+        if (stats) *stats = st;
+        return IILE_OK;
+    }
+    // the probe's film, sampler and depth in place of the frame's
+    DScene S = sc->ds;
+    const iile_film_desc &f = pr.film;
+    S.probe_mode = 1;
+    S.xres = f.xres, S.yres = f.yres;
+    S.crop_x0 = f.crop_x0, S.crop_y0 = f.crop_y0, S.crop_x1 = f.crop_x1, S.crop_y1 = f.crop_y1;
+    S.samp_x0 = f.samp_x0, S.samp_y0 = f.samp_y0, S.samp_x1 = f.samp_x1, S.samp_y1 = f.samp_y1;
+    S.filter_rx = f.filter_rx, S.filter_ry = f.filter_ry;
+    S.max_sample_luminance = f.max_sample_luminance;
+    S.filter_wide = 1;
+    S.filter_table = sc->probe_filter_table;
+    S.pixel_offsets = sc->probe_pixel_offsets;
+    S.base_scale0 = pr.base_scales[0], S.base_scale1 = pr.base_scales[1];
+    S.base_exp0 = pr.base_exponents[0], S.base_exp1 = pr.base_exponents[1];
+    S.sample_stride = pr.sample_stride;
+    S.mult_inv0 = pr.mult_inverse[0], S.mult_inv1 = pr.mult_inverse[1];
+    S.max_depth = pr.max_depth;
+    S.lens_radius = 0;
+    const int need_dims = 5 + 8 * (pr.max_depth + 1) + 2;
+    if (S.n_hdims < need_dims) return fail(IILE_ERR_ARG, "Halton table covers too few dimensions for the probe depth");
+
+    PassDesc P;
+    std::memset(&P, 0, sizeof(P));
+    P.n_tiles_x = (S.samp_x1 - S.samp_x0 + 15) / 16;
+    P.n_tiles_y = (S.samp_y1 - S.samp_y0 + 15) / 16;
+    P.probe_mode = 1;
+    P.probe_tiles = P.n_tiles_x * P.n_tiles_y;
+    P.tile_rank = 0;
+    P.tile_nranks = 1;
+    P.k0 = 0;
+    P.kc = 1;
+    const uint32_t per_pixels = uint32_t(f.crop_x1 - f.crop_x0) * uint32_t(f.crop_y1 - f.crop_y0);
+    const uint64_t slots_per_probe = uint64_t(P.probe_tiles) * 256;
+    // probes per pass: bounded by the workspace budget like iile_render's passes
+    double budget_mb = 49152;
+    if (const char *e = std::getenv("IILE_WORKSPACE_MB")) budget_mb = std::max(64.0, atof(e));
+    uint64_t max_paths = std::min<uint64_t>(uint64_t(budget_mb * 1048576.0 / 300.0), 200000000ull);
+    const int batch = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(n_probes), max_paths / slots_per_probe)));
+
+    std::vector<DProbeCam> cams;
+    cams.resize(size_t(n_probes));
+    for (int i = 0; i < n_probes; ++i)
+        if (!make_probe_camera(pos3 + 3 * size_t(i), dir3 + 3 * size_t(i), &cams[size_t(i)]))
+            return fail(IILE_ERR_ARG, "iile_render_probes: degenerate probe direction (probe " + std::to_string(i) + ")");
+
+    hipStream_t stream = nullptr;
+    LaunchCfg cfg{sc->n_cus, stream, false};
+    if (const char *e = std::getenv("IILE_TRAV_BLOCKS")) cfg.trav_blocks_per_cu = std::max(1, std::min(8, atoi(e)));
+    const uint64_t batch_paths = uint64_t(batch) * slots_per_probe;
+    rc = ensure_workspace(sc, uint32_t(batch_paths));
+    if (rc) return rc;
+    rc = ensure_film(sc, uint32_t(uint64_t(batch) * P.probe_tiles), uint32_t(uint64_t(batch) * per_pixels), batch_paths);
+    if (rc) return rc;
+    // cameras + aux + device-side outputs of one batch
+    const size_t cam_bytes = (size_t(batch) * sizeof(DProbeCam) + 255) & ~size_t(255);
+    const size_t aux_bytes = size_t(batch_paths) * sizeof(float4);
+    const size_t out_floats = size_t(batch) * per_pixels * 7;
+    const size_t need = cam_bytes + aux_bytes + out_floats * sizeof(float) + 1024;
+    if (need > sc->probe_block_bytes) {
+        if (sc->probe_block) HIP_TRY(hipFree(sc->probe_block));
+        sc->probe_block = nullptr;
+        sc->probe_block_bytes = 0;
+        HIP_TRY(hipMalloc(&sc->probe_block, need));
+        sc->probe_block_bytes = need;
+    }
+    char *blk = static_cast<char *>(sc->probe_block);
+    DProbeCam *d_cams = reinterpret_cast<DProbeCam *>(blk);
+    sc->pb.aux = reinterpret_cast<float4 *>(blk + cam_bytes);
+    float *d_int = reinterpret_cast<float *>(blk + cam_bytes + aux_bytes);
+    float *d_nrm = d_int + size_t(batch) * per_pixels * 3;
+    float *d_dist = d_nrm + size_t(batch) * per_pixels * 3;
+    sc->pb.nray_out = nullptr;
+    sc->events_used = 0;
+    HIP_TRY(hipEventRecord(sc->ev_begin, stream));
+    for (int first = 0; first < n_probes; first += batch) {
+        const int nb = std::min(batch, n_probes - first);
+        HIP_TRY(hipMemcpyAsync(d_cams, cams.data() + first, size_t(nb) * sizeof(DProbeCam), hipMemcpyHostToDevice, stream));
+        P.probe_cams = d_cams;
+        P.n_owned_tiles = nb * P.probe_tiles;
+        P.n_paths = uint32_t(uint64_t(nb) * slots_per_probe);
+        rc = run_pass(sc, S, pr.max_depth, P, cfg, false);
+        if (rc) return rc;
+        launch_film_store(S, P, sc->pb, sc->fb, 0, 1, cfg);
+        launch_film_gather(S, P, sc->fb, 1, cfg);
+        launch_probe_finish(S, P, sc->pb, sc->fb, nb, d_int, d_nrm, d_dist, cfg);
+        HIP_TRY(hipGetLastError());
+        const size_t px = size_t(nb) * per_pixels, off = size_t(first) * per_pixels;
+        HIP_TRY(hipMemcpyAsync(intensity_rgb + 3 * off, d_int, px * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(normals_xyz + 3 * off, d_nrm, px * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(distance + off, d_dist, px * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        st.n_passes++;
+        st.n_paths += uint64_t(nb) * per_pixels;
+    }
+    HIP_TRY(hipEventRecord(sc->ev_end, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sc->ev_begin, sc->ev_end));
+    st.ms_total = ms;
+    st.workspace_bytes = sc->ws_bytes;
+    sc->pb.aux = nullptr;
+    if (stats) *stats = st;
     return IILE_OK;
 }
 
@@ -1055,7 +1270,7 @@ int iile_li_samples(iile_scene *sc, int32_t n, const int32_t *px, const int32_t 
     HIP_TRY(hipMemset(sc->pb.counters, 0, sizeof(DCounters)));
     sc->pb.nray_out = dn.p;
     sc->events_used = 0;
-    rc = run_pass(sc, P, cfg, false);
+    rc = run_pass(sc, sc->ds, sc->max_depth, P, cfg, false);
     sc->pb.nray_out = nullptr;
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());

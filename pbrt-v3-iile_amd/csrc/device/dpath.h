@@ -198,6 +198,29 @@ DEV void camera_ray(const DScene &S, float pfx, float pfy, float lu0, float lu1,
     *tmax = tm;
 }
 
+// HemisphericCamera::GenerateRay (hemispheric.cpp:15-41) + Transform::operator()(Ray) (transform.h:251-264)
+DEV void probe_ray(const DScene &S, const DProbeCam &cam, float pfx, float pfy, F3 *o_out, F3 *d_out, float *tmax) {
+    const float theta = kPi * pfy / float(S.yres);
+    const float phi = kPi * pfx / float(S.xres);
+    float st, ct, sp, cp;
+    sincos_f(theta, &st, &ct);
+    sincos_f(phi, &sp, &cp);
+    const F3 dir = F3{st * cp, ct, st * sp};
+    F3 oerr;
+    F3 o = xf_point_err(cam.c2w, F3{0, 0, 0}, &oerr);
+    const F3 d = xf_vector(cam.c2w, dir);
+    const float len2 = length_sq(d);
+    float tm = IILE_INF;
+    if (len2 > 0) {
+        const float dt = dot(vabs(d), oerr) / len2;
+        o = o + d * dt;
+        tm -= dt;
+    }
+    *o_out = o;
+    *d_out = d;
+    *tmax = tm;
+}
+
 // The auxiliary rays of the camera ray's RayDifferential: GenerateRayDifferential (perspective.cpp:124-148),
 // Transform::operator()(RayDifferential) (transform.h:265-274) and the render loop's
 // ScaleDifferentials(1 / sqrt(spp)) (geometry.h:908-913). (o, d) is the camera ray as camera_ray returns it.

@@ -75,6 +75,13 @@ constexpr int kMaxSpheres = 8;
 constexpr int kMaxMaterials = 64;
 constexpr int kMaxLights = 8;
 
+// One IISPT probe camera (HemisphericCamera, hemispheric.cpp:109-160): CameraToWorld and the rows that transform a
+// world normal into the camera's frame (transpose of WorldToCamera's mInv, transform.h:243-249)
+struct DProbeCam {
+    M44 c2w;
+    float nrm[9];
+};
+
 struct DScene {
     // HBM arrays
     const float4 *wide;       // 4 float4 per interior node: both child boxes + child refs + split axis
@@ -119,6 +126,7 @@ struct DScene {
     int crop_x0, crop_y0, crop_x1, crop_y1;
     int samp_x0, samp_y0, samp_x1, samp_y1;
     float filter_rx, filter_ry, max_sample_luminance;
+    int probe_mode;              // IISPT probe pass: hemispheric cameras, IISPTdIntegrator::Li (k_shade / k_miss)
     int filter_wide;             // not the one-pixel box: samples are kept and gathered (k_film_store / k_film_gather)
     const float *filter_table;   // Film::filterTable, 16 x 16
     // halton

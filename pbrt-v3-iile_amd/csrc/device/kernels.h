@@ -12,6 +12,9 @@ struct PassDesc {
     uint32_t n_paths;  // n_owned_tiles * 256 * kc, or the explicit list length
     // explicit path list (kernel-level tests); null for tile enumeration
     const int *list_px, *list_py, *list_k;
+    // IISPT probe batch: n_owned_tiles = n_probes * tiles per probe, tile slot = probe * tiles + tile
+    int probe_mode, probe_tiles;
+    const DProbeCam *probe_cams;
 };
 
 // Queue arrays (ray_o/ray_d/hits/shade_q/nee) hold `queue_cap` slots: the paths of a
@@ -35,6 +38,7 @@ struct PassBuffers {
     DCounters *counters;
     uint32_t *nray_out; // optional [2*n_paths] per-path {closest, shadow} ray counts (tests)
     int *spill;         // [kSpillStackDepth][max grid threads] overflow of the LDS traversal stacks
+    float4 *aux;        // probe pass only: [n_paths] camera-space normal (xyz) and distance (w) of the first hit
 };
 
 struct FilmBuffers {
@@ -70,6 +74,8 @@ void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffer
 void launch_film_store(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int k_begin, int n_samples,
                        const LaunchCfg &cfg);
 void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F, int n_samples, const LaunchCfg &cfg);
+void launch_probe_finish(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int n_probes,
+                         float *intensity, float *normals, float *distance, const LaunchCfg &cfg);
 void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg);
 
 // kernel-level entry points for parity tests

@@ -190,6 +190,16 @@ DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, i
     const uint32_t kk = pid % uint32_t(P.kc);
     const uint32_t pt = pid / uint32_t(P.kc);
     const uint32_t pix = pt & 255u, slot = pt >> 8;
+    if (P.probe_mode) {
+        // every probe has its own film: tile `slot % probe_tiles` of probe `slot / probe_tiles`; RenderView skips the
+        // pixels outside the film's pixel bounds (iispt_d.cpp:428-429)
+        const int tile = int(slot % uint32_t(P.probe_tiles));
+        const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
+        *px = S.samp_x0 + tx * kTile + int(pix & 15u);
+        *py = S.samp_y0 + ty * kTile + int(pix >> 4);
+        *k = uint32_t(P.k0) + kk;
+        return *px >= S.crop_x0 && *py >= S.crop_y0 && *px < S.crop_x1 && *py < S.crop_y1;
+    }
     const int tile = P.tile_rank + int(slot) * P.tile_nranks;
     const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
     *px = S.samp_x0 + tx * kTile + int(pix & 15u);
@@ -218,7 +228,12 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
                 l0 = sample_dimension(S, idx, 3);
                 l1 = sample_dimension(S, idx, 4);
             }
-            camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
+            if (P.probe_mode) {
+                const uint32_t probe = (pid / uint32_t(P.kc)) / (256u * uint32_t(P.probe_tiles));
+                probe_ray(S, P.probe_cams[probe], float(px) + u0, float(py) + u1, &o, &d, &tmax);
+                B.aux[pid] = make_float4(0, 0, 0, -1.f);  // no intersection: normal 0, NO_INTERSECTION_DISTANCE
+            } else
+                camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
             B.hindex[pid] = idx;
             B.L[pid] = make_float4(0, 0, 0, 0);
             if (B.nray_out) {
@@ -588,8 +603,16 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                     triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z},
                                          F3{v2.x, v2.y, v2.z}, ray_d, h4.y, h4.z, h4.w, &is);
                 }
-                // emitted light at the first vertex and after a specular bounce (path.cpp:91-101)
-                if ((bounce == 0 || prev_specular) && light >= 0) {
+                if (EXT && S.probe_mode && bounce == 0) {  // IISPTdIntegrator::Li, iispt_d.cpp:96-108
+                    const F3 cv = is.p - ray_o;
+                    const DProbeCam &cam = P.probe_cams[(pid / uint32_t(P.kc)) / (256u * uint32_t(P.probe_tiles))];
+                    B.aux[pid] = make_float4(cam.nrm[0] * is.n.x + cam.nrm[1] * is.n.y + cam.nrm[2] * is.n.z,
+                                             cam.nrm[3] * is.n.x + cam.nrm[4] * is.n.y + cam.nrm[5] * is.n.z,
+                                             cam.nrm[6] * is.n.x + cam.nrm[7] * is.n.y + cam.nrm[8] * is.n.z, sqrtf(dot(cv, cv)));
+                }
+                // emitted light at the first vertex and after a specular bounce (path.cpp:91-101); the probe
+                // integrator leaves out the camera ray's own vertex (iispt_d.cpp:116-123)
+                if (((bounce == 0 && !(EXT && S.probe_mode)) || prev_specular) && light >= 0) {
                     const float4 L4 = B.L[pid];
                     const F3 L = F3{L4.x, L4.y, L4.z} + beta * light_L(S.lights[light], is.n, -ray_d);
                     B.L[pid] = make_float4(L.x, L.y, L.z, 0);
@@ -1068,7 +1091,7 @@ __global__ __launch_bounds__(kBlock) void k_miss(DScene S, PassBuffers B, int bo
         const uint32_t pid = f2b(ro[slot].w);
         if (pid == kInvalid) continue;
         const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, b2f(5u)) : B.beta[pid];
-        if (!(bounce == 0 || (f2b(beta4.w) >> 16) != 0)) continue;
+        if (!((bounce == 0 && !S.probe_mode) || (bounce != 0 && (f2b(beta4.w) >> 16) != 0))) continue;  // iispt_d.cpp:124-131
         const float4 d4 = rd[slot];
         const F3 beta = F3{beta4.x, beta4.y, beta4.z}, d = F3{d4.x, d4.y, d4.z};
         const float4 L4 = B.L[pid];
@@ -1214,20 +1237,55 @@ DEV void add_xyz(float4 *out, float r, float g, float b, float w) {  // RGBToXYZ
     out->w += w;
 }
 
+// Probe pass: film + aux images of every probe. Film::to_rgb_array (film.cpp:187-225) on the gathered {X, Y, Z, w},
+// and the first hits' normals / distances picked from the paths (1 spp): outputs [probe][y][x].
+__global__ __launch_bounds__(kBlock) void k_probe_finish(DScene S, PassDesc P, PassBuffers B, FilmBuffers F, int n_probes, float *intensity,
+                                                         float *normals, float *distance) {
+    const int fw = S.crop_x1 - S.crop_x0, fh = S.crop_y1 - S.crop_y0;
+    const uint32_t per = uint32_t(fw) * uint32_t(fh), n = per * uint32_t(n_probes);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 px = F.film_xyzw[i];
+        float rgb[3];
+        rgb[0] = 3.240479f * px.x - 1.537150f * px.y - 0.498535f * px.z;  // XYZToRGB, spectrum.h:56-60
+        rgb[1] = -0.969256f * px.x + 1.875991f * px.y + 0.041556f * px.z;
+        rgb[2] = 0.055648f * px.x - 0.204043f * px.y + 1.057311f * px.z;
+        if (px.w != 0) {
+            const float inv_wt = 1.f / px.w;
+            for (int c = 0; c < 3; ++c) rgb[c] = mx(0.f, rgb[c] * inv_wt);
+        }
+        for (int c = 0; c < 3; ++c) intensity[3 * size_t(i) + c] = (rgb[c] + 0.f) * 1.f;
+        const uint32_t probe = i / per, loc = i % per;
+        const int x = S.crop_x0 + int(loc % uint32_t(fw)), y = S.crop_y0 + int(loc / uint32_t(fw));
+        const int tx = (x - S.samp_x0) / kTile, ty = (y - S.samp_y0) / kTile;
+        const uint32_t slot = probe * uint32_t(P.probe_tiles) + uint32_t(ty * P.n_tiles_x + tx);
+        const uint32_t pix = uint32_t((y - S.samp_y0 - ty * kTile) * kTile + (x - S.samp_x0 - tx * kTile));
+        const float4 a = B.aux[(size_t(slot) * 256u + pix) * size_t(P.kc)];
+        normals[3 * size_t(i)] = a.x;
+        normals[3 * size_t(i) + 1] = a.y;
+        normals[3 * size_t(i) + 2] = a.z;
+        distance[i] = a.w;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, FilmBuffers F, int n_samples) {
     __shared__ float s_table[256];
     for (int j = threadIdx.x; j < 256; j += kBlock) s_table[j] = S.filter_table[j];
     __syncthreads();
     const int fw = S.crop_x1 - S.crop_x0, fh = S.crop_y1 - S.crop_y0;
-    const uint32_t n = uint32_t(fw) * uint32_t(fh);
+    const uint32_t per = uint32_t(fw) * uint32_t(fh);
+    const uint32_t n = per * (P.probe_mode ? uint32_t(P.n_owned_tiles / P.probe_tiles) : 1u);  // one film per probe
     const float rx = S.filter_rx, ry = S.filter_ry;
     const float inv_rx = 1 / rx, inv_ry = 1 / ry;  // Filter::invRadius
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const int x = S.crop_x0 + int(i % uint32_t(fw)), y = S.crop_y0 + int(i / uint32_t(fw));
+        const uint32_t probe = i / per, loc = i % per;
+        const int x = S.crop_x0 + int(loc % uint32_t(fw)), y = S.crop_y0 + int(loc / uint32_t(fw));
         // sample pixels that can reach (x, y): |q + u - 0.5 - x| <= r with u in [0, 1), i.e. x - r - 0.5 < q <= x + r + 0.5
         // (floor / ceil keep a pixel of slack on either side against the rounding of the sums in AddSample)
-        const int qx0 = max(int(floorf(float(x) - rx - 0.5f)), S.samp_x0), qx1 = min(int(ceilf(float(x) + rx + 0.5f)), S.samp_x1 - 1);
-        const int qy0 = max(int(floorf(float(y) - ry - 0.5f)), S.samp_y0), qy1 = min(int(ceilf(float(y) + ry + 0.5f)), S.samp_y1 - 1);
+        // (a probe's RenderView takes no samples outside the film's pixel bounds: those records do not exist)
+        const int lo_x = P.probe_mode ? S.crop_x0 : S.samp_x0, hi_x = P.probe_mode ? S.crop_x1 : S.samp_x1;
+        const int lo_y = P.probe_mode ? S.crop_y0 : S.samp_y0, hi_y = P.probe_mode ? S.crop_y1 : S.samp_y1;
+        const int qx0 = max(int(floorf(float(x) - rx - 0.5f)), lo_x), qx1 = min(int(ceilf(float(x) + rx + 0.5f)), hi_x - 1);
+        const int qy0 = max(int(floorf(float(y) - ry - 0.5f)), lo_y), qy1 = min(int(ceilf(float(y) + ry + 0.5f)), hi_y - 1);
         float4 out = make_float4(0, 0, 0, 0);
         if (qx0 <= qx1 && qy0 <= qy1) {
             const int tx0 = (qx0 - S.samp_x0) / kTile, tx1 = (qx1 - S.samp_x0) / kTile;
@@ -1235,7 +1293,10 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, Fi
             for (int ty = ty0; ty <= ty1; ++ty)
                 for (int tx = tx0; tx <= tx1; ++tx) {  // tile index order
                     uint32_t slot;
-                    if (!tile_owned(P, tx, ty, &slot)) continue;
+                    if (P.probe_mode)
+                        slot = probe * uint32_t(P.probe_tiles) + uint32_t(ty * P.n_tiles_x + tx);
+                    else if (!tile_owned(P, tx, ty, &slot))
+                        continue;
                     // the tile's FilmTile (Film::GetFilmTile, film.cpp:92-103) must hold (x, y)
                     const int sx0 = S.samp_x0 + tx * kTile, sy0 = S.samp_y0 + ty * kTile;
                     const int sx1 = min(sx0 + kTile, S.samp_x1), sy1 = min(sy0 + kTile, S.samp_y1);
@@ -1491,7 +1552,7 @@ void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int 
         // Scenes of killeroo-simple's kind (one emitting sphere, matte / plastic only) run a build of the
         // kernel without the code for the wider feature set: it costs them registers otherwise (+0.7 ms);
         // likewise image textures have their own build
-        if (S.textured_materials)
+        if (S.textured_materials || S.probe_mode)
             hipLaunchKernelGGL((k_shade<false, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
         else if (S.extended_features)
             hipLaunchKernelGGL((k_shade<false, true, false>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
@@ -1543,8 +1604,15 @@ void launch_film_store(const DScene &S, const PassDesc &P, const PassBuffers &B,
                        const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_film_store, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B, F, k_begin, n_samples);
 }
+void launch_probe_finish(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int n_probes,
+                         float *intensity, float *normals, float *distance, const LaunchCfg &cfg) {
+    const uint32_t n = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0) * uint32_t(n_probes);
+    hipLaunchKernelGGL(k_probe_finish, dim3(grid_blocks(n, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B, F, n_probes, intensity,
+                       normals, distance);
+}
 void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F, int n_samples, const LaunchCfg &cfg) {
-    const uint32_t n = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0);
+    const uint32_t n = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0) *
+                       (P.probe_mode ? uint32_t(P.n_owned_tiles / P.probe_tiles) : 1u);
     hipLaunchKernelGGL(k_film_gather, dim3(grid_blocks(n, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, F, n_samples);
 }
 void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg) {

@@ -265,6 +265,46 @@ bool finalize_scene(HostScene *s, std::string *err) {
 
     d.integrator.max_depth = s->max_depth;
     d.integrator.rr_threshold = s->rr_threshold;
+
+    // IISPT probe pass: CreateHemisphericCamera's film (hemispheric.cpp:131-147) and CreateIISPTdIntegrator's
+    // sampler and depth (iispt_d.cpp:492-527)
+    {
+        iile_probe_setup &pr = d.probe;
+        std::memset(&pr, 0, sizeof(pr));
+        pr.hemi_size = 32;
+        pr.max_depth = 3;
+        iile_film_desc &pf = pr.film;
+        pf.xres = pf.yres = pr.hemi_size;
+        pf.crop_x0 = pf.crop_y0 = 0;
+        pf.crop_x1 = pf.crop_y1 = pr.hemi_size;
+        pf.filter_rx = pf.filter_ry = 2.f;
+        pf.scale = 1.f;
+        pf.max_sample_luminance = std::numeric_limits<float>::infinity();
+        pf.samp_x0 = int(std::floor(float(pf.crop_x0) + 0.5f - pf.filter_rx));
+        pf.samp_y0 = int(std::floor(float(pf.crop_y0) + 0.5f - pf.filter_ry));
+        pf.samp_x1 = int(std::ceil(float(pf.crop_x1) - 0.5f + pf.filter_rx));
+        pf.samp_y1 = int(std::ceil(float(pf.crop_y1) - 0.5f + pf.filter_ry));
+        const float alpha = 2.f, exp_r = std::exp(-alpha * 2.f * 2.f);
+        auto gaussian = [&](float dd) { return std::max(0.f, float(std::exp(-alpha * dd * dd) - exp_r)); };
+        int offset = 0;
+        for (int y = 0; y < 16; ++y)
+            for (int x = 0; x < 16; ++x, ++offset)
+                pr.filter_table[offset] = gaussian((x + 0.5f) * 2.f / 16) * gaussian((y + 0.5f) * 2.f / 16);
+        const int pres[2] = {pf.samp_x1 - pf.samp_x0, pf.samp_y1 - pf.samp_y0};
+        for (int i = 0; i < 2; ++i) {
+            const int base = (i == 0) ? 2 : 3;
+            int scale = 1, exp = 0;
+            while (scale < std::min(pres[i], 128)) {
+                scale *= base;
+                ++exp;
+            }
+            pr.base_scales[i] = scale;
+            pr.base_exponents[i] = exp;
+        }
+        pr.sample_stride = pr.base_scales[0] * pr.base_scales[1];
+        pr.mult_inverse[0] = int(multiplicative_inverse(pr.base_scales[1], pr.base_scales[0]));
+        pr.mult_inverse[1] = int(multiplicative_inverse(pr.base_scales[0], pr.base_scales[1]));
+    }
     return true;
 }
 

@@ -45,6 +45,7 @@ class Oracle:
         lib.oracle_halton_index.restype = ctypes.c_int64
         lib.oracle_bsdf_sample_batch.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp, c_vp]
         lib.oracle_bsdf_pdf_batch.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
+        lib.oracle_render_probe.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
         lib.oracle_texture_eval.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp]
         lib.oracle_camera_hit_differentials.argtypes = [c_vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_vp]
         lib.oracle_log.argtypes = [ctypes.c_int, ctypes.c_float]
@@ -194,6 +195,16 @@ class Oracle:
         self.lib.oracle_bsdf_pdf_batch(scene.desc, trig_mode, mat, wo.ctypes.data, len(wi), wi.ctypes.data,
                                        pdf.ctypes.data)
         return pdf
+
+    def render_probe(self, scene, pos, direction, hemi=32, trig_mode=TRIG_PORTABLE):
+        """(intensity (h, h, 3), normals (h, h, 3), distance (h, h)) of one IISPT probe, [y][x] raster order."""
+        pos, direction = _f32(pos), _f32(direction)
+        inten, nrm, dist = np.zeros((hemi, hemi, 3), np.float32), np.zeros((hemi, hemi, 3), np.float32), np.zeros((hemi, hemi), np.float32)
+        rc = self.lib.oracle_render_probe(scene.desc, trig_mode, pos.ctypes.data, direction.ctypes.data, inten.ctypes.data,
+                                          nrm.ctypes.data, dist.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"oracle_render_probe failed ({rc})")
+        return inten, nrm, dist
 
     def texture_eval(self, scene, tex, uv, duv, trig_mode=TRIG_PORTABLE):
         uv, duv = _f32(uv), _f32(duv)

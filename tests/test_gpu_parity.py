@@ -577,3 +577,57 @@ def test_wide_pixel_filters_bitwise(binding, oracle, tmp_path):
             part, _ = gpu.render(tile_rank=rank, tile_nranks=3, spp_per_pass=1 + rank)
             pref, _ = oracle.render(scene, tile_rank=rank, tile_nranks=3)
             assert_bitwise(part, pref, f"box room, {line}, shard {rank} of 3")
+
+
+def test_iispt_probe_pass_bitwise(binding, oracle, tmp_path):
+    """The IISPT probe pass (SURVEY.md §8 f3): hemispheric cameras rendered by IISPTdIntegrator::RenderView — a
+    32 x 32 film behind a Gaussian filter, one Halton sample per pixel, depth 3, no emitted light at the camera ray's
+    own vertex — plus the first hits' camera-space normals and distances: the three inputs of the IISPT network.
+    A batch of probes in one wavefront pass gives, probe by probe, the oracle's images bit for bit: on killeroo-simple,
+    in the point-light and the sky furnaces, and in the box room with three lights and specular materials (probe
+    directions include the +z / -z axes, where CreateHemisphericCamera switches its up vector)."""
+    import os
+    import boxroom
+    gold = os.path.join(os.path.dirname(__file__), "golden", "scenes")
+    rng = np.random.default_rng(77)
+
+    def probes(n, lo, hi):
+        pos = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+        d = rng.standard_normal((n, 3)).astype(np.float32)
+        d[0] = (0, 0, 1)
+        d[1] = (0, 0, -2.5)
+        d[2] = (1e-3, 0, 1)
+        return pos, d
+
+    path = tmp_path / "room_multi.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=32, yres=32, spp=1, light="multi", materials="mixed"))
+    cases = [("killeroo-simple", binding.HostScene(xres=64, yres=64, spp=1), probes(6, (-150, -100, -130), (250, 150, 0))),
+             ("point furnace", binding.HostScene(path=os.path.join(gold, "furnace_point.pbrt")), probes(5, -0.4, 0.4)),
+             ("sky furnace", binding.HostScene(path=os.path.join(gold, "furnace_sky.pbrt")), probes(5, (-3, -3, 1.2), (3, 3, 3))),
+             ("box room, three lights", binding.HostScene(path=str(path)), probes(8, (-8, -8, -2), (8, 8, 8)))]
+    for name, scene, (pos, d) in cases:
+        gpu = binding.GpuScene(scene)
+        inten, nrm, dist, st = gpu.render_probes(pos, d)
+        assert st["n_passes"] == 1 and st["n_paths"] == len(pos) * 1024
+        for i in range(len(pos)):
+            oi, on, od = oracle.render_probe(scene, pos[i], d[i])
+            assert_bitwise(inten[i], oi, f"{name}: intensity of probe {i}")
+            assert_bitwise(nrm[i], on, f"{name}: normals of probe {i}")
+            assert_bitwise(dist[i], od, f"{name}: distances of probe {i}")
+        assert np.isfinite(inten).all() and inten.max() > 0
+        # the frame renders as before after a probe batch (shared workspace, the frame's own film and sampler)
+        assert_bitwise(gpu.render()[0], oracle.render(scene)[0], f"{name}: frame after the probe batch")
+    # batches split across passes give the same images
+    os.environ["IILE_WORKSPACE_MB"] = "64"
+    try:
+        name, scene, (pos, d) = cases[0]
+        many = (np.tile(pos, (40, 1)), np.tile(d, (40, 1)))
+        gpu = binding.GpuScene(scene)
+        i2, n2, d2, st = gpu.render_probes(*many)
+        assert st["n_passes"] > 1
+        ref = binding.GpuScene(scene).render_probes(pos, d)
+    finally:
+        del os.environ["IILE_WORKSPACE_MB"]
+    for j in range(40):
+        assert_bitwise(i2[6 * j:6 * j + 6], ref[0], "probe intensities across passes")
+        assert_bitwise(d2[6 * j:6 * j + 6], ref[2], "probe distances across passes")

@@ -704,3 +704,41 @@ def test_pixel_filter_tables_and_normalisation(binding, oracle, tmp_path):
         rgb = scene.film_to_rgb(film)
         assert abs(float(rgb.mean(dtype=np.float64)) - 1.0) < 0.03, line
         assert rgb.min() > 0.6 and rgb.max() < 1.4, line
+
+
+def test_iispt_probe_pass_pins(binding, oracle, tmp_path):
+    """The IISPT probe (HemisphericCamera + IISPTdIntegrator, no reference test or recorded output exists — parity of
+    the probe pass rests on the restatement plus these): (1) inside the emitting white furnace (Le = Kd = 0.5,
+    radiance 1) a probe sees everything but the camera ray's own emission, cut at depth 3: 0.25 + 0.125 + 0.0625;
+    (2) over a ground plane the distance image is h / (sin theta sin phi) with theta = pi y / 32, phi = pi x / 32 —
+    the camera's mapping of raster positions to the hemisphere around `dir` — every pixel between the values at
+    its corners, and the normal image is the plane's normal in the camera frame: (0, 0, -1) when looking straight
+    at it; (3) rays that escape leave distance -1 and a zero normal."""
+    import os
+    scene = binding.HostScene(path=os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_tetrahedron.pbrt"))
+    rng = np.random.default_rng(3)
+    vals = []
+    for _ in range(12):
+        inten, nrm, dist = oracle.render_probe(scene, rng.uniform(-.2, .2, 3), rng.standard_normal(3), trig_mode=ob.TRIG_LIBM)
+        vals.append(inten.astype(np.float64).mean())
+        assert (dist > 0.577 - 0.35).all() and (dist < 1.74 + 0.35).all()  # inradius 1/sqrt 3, vertices at sqrt 3, origin within 0.35
+        assert np.allclose(np.linalg.norm(nrm, axis=-1), 1, atol=1e-5)
+    assert abs(np.mean(vals) - 0.4375) < 0.01, np.mean(vals)
+
+    (tmp_path / "plane.pbrt").write_text(
+        'Camera "perspective"\nFilm "image" "integer xresolution" [8] "integer yresolution" [8]\n'
+        'Sampler "halton" "integer pixelsamples" [1]\nWorldBegin\nLightSource "point" "point from" [0 0 5]\n'
+        'Material "matte"\nShape "trianglemesh" "point P" [-1e3 -1e3 0  1e3 -1e3 0  1e3 1e3 0  -1e3 1e3 0] "integer indices" [0 1 2 0 2 3]\nWorldEnd\n')
+    plane = binding.HostScene(path=str(tmp_path / "plane.pbrt"))
+    h = 2.0
+    inten, nrm, dist = oracle.render_probe(plane, (0, 0, h), (0, 0, -1), trig_mode=ob.TRIG_LIBM)
+    ys, xs = np.mgrid[0:32, 0:32]
+    corners = [h / (np.sin(np.pi * (ys + dy) / 32) * np.sin(np.pi * (xs + dx) / 32) + 1e-30) for dy in (0, 1) for dx in (0, 1)]
+    lo, hi = np.minimum.reduce(corners), np.maximum.reduce(corners)
+    near = hi < 300                       # the plane is finite: 1e3 units
+    assert near.sum() >= 850  # all but the pixels near the horizon
+    assert (dist[near] >= lo[near] * (1 - 5e-4)).all() and (dist[near] <= hi[near] * (1 + 5e-4)).all()
+    assert np.allclose(nrm[near], (0, 0, -1), atol=1e-5)
+    assert inten[near].min() > 0          # lit by the point light above
+    up, nrm_up, dist_up = oracle.render_probe(plane, (0, 0, h), (0, 0, 1), trig_mode=ob.TRIG_LIBM)
+    assert (dist_up == -1).all() and (nrm_up == 0).all() and (up == 0).all()
