@@ -1,0 +1,35 @@
+"""Throughput of the IISPT probe pass: probes placed at the first hits of a grid of camera rays of
+killeroo-simple 1920x1080 (every `step`-th pixel), each looking back along its camera ray (the reference uses the
+surface normal; for timing the hemisphere's orientation does not matter).
+usage: python tools/probe_bench.py [step=10]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import __graft_entry__ as ge  # noqa: E402
+
+step = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+b = ge._load_binding()
+scene = b.HostScene(xres=1920, yres=1080, spp=1)
+gpu = b.GpuScene(scene)
+ys, xs = np.mgrid[0:1080:step, 0:1920:step]
+pf = np.stack([xs.ravel() + .5, ys.ravel() + .5], -1).astype(np.float32)
+o, d = gpu.camera_rays(pf)
+prim, tb, _ = gpu.trace_closest(o, d, np.full(len(o), np.inf, np.float32), instrumented=False)
+hit = prim >= 0
+pos = (o + d * tb[:, :1])[hit] - d[hit] * 1e-3
+direction = -d[hit]
+print("probes", len(pos), "of", len(o), "grid points")
+gpu.render_probes(pos[:64], direction[:64])
+for _ in range(3):
+    t = time.time()
+    inten, nrm, dist, st = gpu.render_probes(pos, direction)
+    wall = time.time() - t
+    print("device %.1f ms (%d passes), wall %.3f s: %.0f probes/s device, %.0f probes/s incl. host cameras + copies; "
+          "%.1f M probe pixels/s" % (st["ms_total"], st["n_passes"], wall, len(pos) / st["ms_total"] * 1e3, len(pos) / wall,
+                                     len(pos) * 1024 / st["ms_total"] / 1e3))
+print("mean intensity %.4f, hit fraction of probe rays %.3f" % (float(inten.mean()), float((dist >= 0).mean())))
