@@ -121,9 +121,10 @@ int iile_bsdf_sample(iile_scene *scene, int32_t n, int32_t mat, const float *wo3
  * directions (the runner passes the spawned ray of the surface normal). Outputs per probe hemi x hemi pixels, [y][x]
  * in the probe camera's raster coordinates (the reference's ImageFilm keeps row hemi - 1 - y): intensity RGB,
  * camera-space normals, distances (-1 where the ray escaped). Film, sampler and depth come from
- * iile_scene_desc::probe. */
+ * iile_scene_desc::probe. outputs_on_device != 0: the three output pointers are device memory (the images stay in
+ * HBM for the network); pos3 / dir3 are host memory either way. */
 int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, const float *dir3, float *intensity_rgb,
-                       float *normals_xyz, float *distance, iile_stats *stats);
+                       float *normals_xyz, float *distance, int32_t outputs_on_device, iile_stats *stats);
 /* ImageTexture<RGBSpectrum, Spectrum>::Evaluate (src/textures/imagemap.h:87-94) of image texture `tex` at n
  * surface points given by (u, v) and the screen-space differentials {du/dx, dv/dx, du/dy, dv/dy}. */
 int iile_texture_eval(iile_scene *scene, int32_t tex, int32_t n, const float *uv2, const float *duv4, float *rgb3);

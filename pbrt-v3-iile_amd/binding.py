@@ -140,7 +140,7 @@ def gpu_lib():
         lib.iile_li_samples.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         lib.iile_bsdf_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_texture_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
-        lib.iile_render_probes.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GpuStats)]
+        lib.iile_render_probes.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(GpuStats)]
         lib.iile_bsdf_sample.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
         _gpu = lib
@@ -314,17 +314,22 @@ class GpuScene:
                     "iile_bsdf_eval")
         return out
 
-    def render_probes(self, pos, direction, hemi=32):
+    def render_probes(self, pos, direction, hemi=32, device_out=None):
         """IISPT probe pass: (n, 3) origins and directions -> intensity (n, hemi, hemi, 3), camera-space normals
-        (n, hemi, hemi, 3), distances (n, hemi, hemi), [y][x] in raster order; plus the stats dict."""
+        (n, hemi, hemi, 3), distances (n, hemi, hemi), [y][x] in raster order; plus the stats dict.
+        device_out: three device pointers (ints) to write the images to instead (they then stay in HBM)."""
         pos, direction = _f32(pos).reshape(-1, 3), _f32(direction).reshape(-1, 3)
         n = len(pos)
+        st = GpuStats()
+        if device_out is not None:
+            self._check(gpu_lib().iile_render_probes(self._s, n, pos.ctypes.data, direction.ctypes.data, device_out[0], device_out[1],
+                                                     device_out[2], 1, ctypes.byref(st)), "iile_render_probes")
+            return None, None, None, st.as_dict()
         inten = np.zeros((n, hemi, hemi, 3), np.float32)
         nrm = np.zeros((n, hemi, hemi, 3), np.float32)
         dist = np.zeros((n, hemi, hemi), np.float32)
-        st = GpuStats()
         self._check(gpu_lib().iile_render_probes(self._s, n, pos.ctypes.data, direction.ctypes.data, inten.ctypes.data,
-                                                 nrm.ctypes.data, dist.ctypes.data, ctypes.byref(st)), "iile_render_probes")
+                                                 nrm.ctypes.data, dist.ctypes.data, 0, ctypes.byref(st)), "iile_render_probes")
         return inten, nrm, dist, st.as_dict()
 
     def texture_eval(self, tex, uv, duv):

@@ -1015,7 +1015,7 @@ bool make_probe_camera(const float *pos, const float *dir, DProbeCam *cam) {
 }  // namespace
 
 int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, const float *dir3, float *intensity_rgb, float *normals_xyz,
-                       float *distance, iile_stats *stats) {
+                       float *distance, int32_t outputs_on_device, iile_stats *stats) {
     if (!sc || n_probes < 0 || !pos3 || !dir3 || !intensity_rgb || !normals_xyz || !distance)
         return fail(IILE_ERR_ARG, "iile_render_probes: null argument");
     int rc = ensure_device();
@@ -1115,12 +1115,17 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
         if (rc) return rc;
         launch_film_store(S, P, sc->pb, sc->fb, 0, 1, cfg);
         launch_film_gather(S, P, sc->fb, 1, cfg);
-        launch_probe_finish(S, P, sc->pb, sc->fb, nb, d_int, d_nrm, d_dist, cfg);
-        HIP_TRY(hipGetLastError());
         const size_t px = size_t(nb) * per_pixels, off = size_t(first) * per_pixels;
-        HIP_TRY(hipMemcpyAsync(intensity_rgb + 3 * off, d_int, px * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(normals_xyz + 3 * off, d_nrm, px * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(distance + off, d_dist, px * sizeof(float), hipMemcpyDeviceToHost, stream));
+        if (outputs_on_device) {  // the images stay in HBM for whatever consumes them next (the network)
+            launch_probe_finish(S, P, sc->pb, sc->fb, nb, intensity_rgb + 3 * off, normals_xyz + 3 * off, distance + off, cfg);
+            HIP_TRY(hipGetLastError());
+        } else {
+            launch_probe_finish(S, P, sc->pb, sc->fb, nb, d_int, d_nrm, d_dist, cfg);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(intensity_rgb + 3 * off, d_int, px * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(normals_xyz + 3 * off, d_nrm, px * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(distance + off, d_dist, px * sizeof(float), hipMemcpyDeviceToHost, stream));
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         st.n_passes++;
         st.n_paths += uint64_t(nb) * per_pixels;

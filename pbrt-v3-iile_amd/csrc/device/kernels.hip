@@ -1304,38 +1304,59 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, Fi
                     const int fy0 = max(int(ceilf(float(sy0) - 0.5f - ry)), S.crop_y0), fy1 = min(int(floorf(float(sy1) - 0.5f + ry)) + 1, S.crop_y1);
                     if (x < fx0 || x >= fx1 || y < fy0 || y >= fy1) continue;
                     float r = 0, g = 0, b = 0, w = 0;
-                    for (int qy = max(qy0, sy0); qy <= min(qy1, sy1 - 1); ++qy)
-                        for (int qx = max(qx0, sx0); qx <= min(qx1, sx1 - 1); ++qx) {
-                            const size_t base = size_t(slot) * size_t(n_samples) * 256u + size_t((qy - sy0) * kTile + (qx - sx0));
+                    // FilmTile::AddSample's support test and table lookup for this pixel (film.h:159-188)
+                    auto add_sample = [&](float2 pf, float4 L) {
+                        const float dxf = pf.x - 0.5f, dyf = pf.y - 0.5f;
+                        const bool in = x >= max(int(ceilf(dxf - rx)), fx0) && x < min(int(floorf(dxf + rx)) + 1, fx1) &&
+                                        y >= max(int(ceilf(dyf - ry)), fy0) && y < min(int(floorf(dyf + ry)) + 1, fy1);
+                        if (in) {
+                            const float ffx = fabsf((float(x) - dxf) * inv_rx * 16.f), ffy = fabsf((float(y) - dyf) * inv_ry * 16.f);
+                            const int ifx = min(int(floorf(ffx)), 15), ify = min(int(floorf(ffy)), 15);
+                            const float fwt = s_table[ify * 16 + ifx];
+                            r += L.x * 1.f * fwt;
+                            g += L.y * 1.f * fwt;
+                            b += L.z * 1.f * fwt;
+                            w += fwt;
+                        }
+                    };
+                    const int xa = max(qx0, sx0), xb = min(qx1, sx1 - 1);
+                    for (int qy = max(qy0, sy0); qy <= min(qy1, sy1 - 1); ++qy) {
+                        const size_t row = size_t(slot) * size_t(n_samples) * 256u + size_t((qy - sy0) * kTile - sx0);
+                        if (n_samples == 1) {
+                            // one sample per pixel (the probe pass): four neighbouring pixels' records in flight
+                            for (int q4 = xa; q4 <= xb; q4 += 4) {
+                                float2 pfb[4];
+                                float4 Lb[4];
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    const size_t at = row + size_t(q4 + jj <= xb ? q4 + jj : q4);
+                                    pfb[jj] = F.wide_pf[at];
+                                    Lb[jj] = F.wide_L[at];
+                                }
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj)
+                                    if (q4 + jj <= xb) add_sample(pfb[jj], Lb[jj]);
+                            }
+                            continue;
+                        }
+                        for (int qx = xa; qx <= xb; ++qx) {
+                            const size_t base = row + size_t(qx);
                             for (int k4 = 0; k4 < n_samples; k4 += 4) {
                                 // four records in flight, then summed in sample order
                                 float2 pfb[4];
                                 float4 Lb[4];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const size_t at = base + size_t(k4 + j < n_samples ? k4 + j : k4) * 256u;
-                                    pfb[j] = F.wide_pf[at];
-                                    Lb[j] = F.wide_L[at];
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    const size_t at = base + size_t(k4 + jj < n_samples ? k4 + jj : k4) * 256u;
+                                    pfb[jj] = F.wide_pf[at];
+                                    Lb[jj] = F.wide_L[at];
                                 }
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    if (k4 + j >= n_samples) break;
-                                    // FilmTile::AddSample's support test and table lookup for this pixel (film.h:159-188)
-                                    const float dxf = pfb[j].x - 0.5f, dyf = pfb[j].y - 0.5f;
-                                    const bool in = x >= max(int(ceilf(dxf - rx)), fx0) && x < min(int(floorf(dxf + rx)) + 1, fx1) &&
-                                                    y >= max(int(ceilf(dyf - ry)), fy0) && y < min(int(floorf(dyf + ry)) + 1, fy1);
-                                    if (in) {
-                                        const float ffx = fabsf((float(x) - dxf) * inv_rx * 16.f), ffy = fabsf((float(y) - dyf) * inv_ry * 16.f);
-                                        const int ifx = min(int(floorf(ffx)), 15), ify = min(int(floorf(ffy)), 15);
-                                        const float fwt = s_table[ify * 16 + ifx];
-                                        r += Lb[j].x * 1.f * fwt;
-                                        g += Lb[j].y * 1.f * fwt;
-                                        b += Lb[j].z * 1.f * fwt;
-                                        w += fwt;
-                                    }
-                                }
+                                for (int jj = 0; jj < 4; ++jj)
+                                    if (k4 + jj < n_samples) add_sample(pfb[jj], Lb[jj]);
                             }
                         }
+                    }
                     add_xyz(&out, r, g, b, w);
                 }
         }

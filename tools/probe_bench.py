@@ -7,6 +7,9 @@ import sys
 import time
 
 import numpy as np
+import torch
+
+torch.cuda.init()  # before libiile_gpu touches HIP (as bench.py does)
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -33,3 +36,15 @@ for _ in range(3):
           "%.1f M probe pixels/s" % (st["ms_total"], st["n_passes"], wall, len(pos) / st["ms_total"] * 1e3, len(pos) / wall,
                                      len(pos) * 1024 / st["ms_total"] / 1e3))
 print("mean intensity %.4f, hit fraction of probe rays %.3f" % (float(inten.mean()), float((dist >= 0).mean())))
+# outputs left in HBM (what an in-process network would read): torch only allocates the buffers
+n = len(pos)
+t_int = torch.empty((n, 32, 32, 3), dtype=torch.float32, device="cuda")
+t_nrm = torch.empty((n, 32, 32, 3), dtype=torch.float32, device="cuda")
+t_dst = torch.empty((n, 32, 32), dtype=torch.float32, device="cuda")
+for _ in range(3):
+    torch.cuda.synchronize()
+    t = time.time()
+    _, _, _, st = gpu.render_probes(pos, direction, device_out=(t_int.data_ptr(), t_nrm.data_ptr(), t_dst.data_ptr()))
+    wall = time.time() - t
+    print("outputs in HBM: device %.1f ms, wall %.3f s: %.0f probes/s" % (st["ms_total"], wall, n / wall))
+assert np.array_equal(t_int.cpu().numpy(), inten) and np.array_equal(t_dst.cpu().numpy(), dist)
