@@ -1,0 +1,143 @@
+"""The network stage behind the IISPT probe pass, in-process on the GPU.
+
+The reference pipes every probe through a child Python process (`ml/main_stdio_net.py`, 47 ms per probe,
+`Doc.md:58-61`): `IisptRenderRunner` normalises the three probe images (`normalizeMapsDownstream`,
+`src/integrators/iisptrenderrunner.cpp:1041-1092`), writes 32*32*7 floats to the pipe, reads 32*32*3 back and
+rescales them (`transformMapsUpstream`, `:1095-1133`). Here the probe images never leave HBM: `iile_render_probes`
+(include/iile_gpu.h) writes them into torch tensors, the two transforms run batched over all probes, and the
+network runs once over the whole batch.
+
+* `normalize_downstream` / `transform_upstream`: the two transforms, per probe, in the reference's arithmetic
+  (double sums for the means, `log(1.0 + v)` / `exp(v) - 1.0` in double, everything else in float).
+* `IISPTNet`: the U-Net of `ml/iispt_net.py:8-109` (K = 64; 7 -> 3 channels at 32 x 32). Its `state_dict` has the
+  reference's parameter names and shapes, so a checkpoint trained with the reference's `ml/main_train.py` loads
+  unchanged. **No weights ship with the reference**: with random weights the output means nothing, and parity of
+  this stage is unpinned beyond the transforms (tests/test_iispt_nn.py) and the checkpoint-compatible layout.
+
+Image layout: the reference's `ImageFilm` stores raster row y at index h - 1 - y (`src/film/imagefilm.cpp:26-31`,
+`src/core/film.cpp:245-254`) and the network was trained on that; `iile_render_probes` returns raster order.
+`normalize_downstream` flips on the way in, `transform_upstream` flips back.
+"""
+import torch
+from torch import nn
+
+HEMI = 32
+K = 64
+
+# One row per block: (name, layers). Layers: ("pool",), ("conv", cin, cout, kernel), ("deconv", cin, cout, kernel),
+# ("lrelu",), ("bn", channels), ("up",), ("relu",). Order and indices inside a block fix the state_dict keys.
+_BLOCKS = (
+    ("encoder0", (("conv", 7, K, 3), ("lrelu",), ("conv", K, K, 3), ("lrelu",))),
+    ("encoder1", (("pool",), ("conv", K, 2 * K, 3), ("lrelu",), ("bn", 2 * K), ("conv", 2 * K, 2 * K, 3), ("lrelu",))),
+    ("encoder2", (("pool",), ("conv", 2 * K, 4 * K, 3), ("lrelu",), ("bn", 4 * K), ("conv", 4 * K, 4 * K, 3), ("lrelu",))),
+    ("encoder3", (("pool",), ("conv", 4 * K, 8 * K, 3), ("lrelu",), ("bn", 8 * K), ("conv", 8 * K, 4 * K, 3), ("lrelu",), ("up",))),
+    ("decoder0", (("deconv", 8 * K, 4 * K, 3), ("lrelu",), ("bn", 4 * K), ("deconv", 4 * K, 2 * K, 3), ("lrelu",), ("up",))),
+    ("decoder1", (("deconv", 4 * K, 2 * K, 3), ("lrelu",), ("bn", 2 * K), ("deconv", 2 * K, K, 3), ("lrelu",), ("up",))),
+    ("decoder2", (("deconv", 2 * K, K, 3), ("lrelu",), ("deconv", K, K, 3), ("lrelu",), ("conv", K, 3, 1), ("relu",))),
+)
+
+
+def _layer(spec):
+    kind = spec[0]
+    if kind == "conv":
+        return nn.Conv2d(spec[1], spec[2], spec[3], stride=1, padding=spec[3] // 2)
+    if kind == "deconv":
+        return nn.ConvTranspose2d(spec[1], spec[2], spec[3], stride=1, padding=spec[3] // 2)
+    if kind == "lrelu":
+        return nn.LeakyReLU(0.2)
+    if kind == "relu":
+        return nn.ReLU()
+    if kind == "bn":
+        return nn.BatchNorm2d(spec[1])
+    if kind == "pool":
+        return nn.MaxPool2d(2)
+    if kind == "up":
+        return nn.Upsample(scale_factor=2, mode="bilinear")
+    raise ValueError(kind)
+
+
+class IISPTNet(nn.Module):
+    """ml/iispt_net.py:8-109: three encoder levels, a bottleneck that upsamples back, three decoder levels fed by
+    the concatenation of the level below with the matching encoder output."""
+
+    def __init__(self):
+        super().__init__()
+        for name, layers in _BLOCKS:
+            setattr(self, name, nn.Sequential(*[_layer(s) for s in layers]))
+
+    def forward(self, x):
+        e0 = self.encoder0(x)
+        e1 = self.encoder1(e0)
+        e2 = self.encoder2(e1)
+        y = self.encoder3(e2)
+        y = self.decoder0(torch.cat((y, e2), 1))
+        y = self.decoder1(torch.cat((y, e1), 1))
+        return self.decoder2(torch.cat((y, e0), 1))
+
+
+def normalize_downstream(intensity, normals, distance):
+    """normalizeMapsDownstream, batched: intensity (n, h, h, 3), normals (n, h, h, 3), distance (n, h, h) in raster
+    order -> network input (n, 7, h, h) float32 in the reference's row order, and the per-probe channel means
+    (n, 3) that transform_upstream needs."""
+    n = intensity.shape[0]
+    i64 = intensity.double()
+    # computeMeanChannels / computeMean: double sums over float texels (imagefilm.cpp:203-254)
+    chan_mean = i64.reshape(n, -1, 3).mean(1).float()
+    mean = i64.reshape(n, -1).mean(1).float()
+    ratio = torch.where(mean == 0, torch.zeros_like(mean, dtype=torch.float64), 1.0 / (10.0 * mean.double())).float()
+    x = intensity * ratio.view(n, 1, 1, 1)                                  # multiply(float)
+    x = torch.log(1.0 + torch.clamp(x, min=0).double()).float()             # positiveLog: log(1.0 + v) in double
+    x = x + torch.tensor(-0.1, dtype=torch.float32, device=x.device)        # add(-0.1)
+    nrm = torch.clamp((normals - 0.0) / 1.0, -1.0, 1.0)                      # normalize(-1, 1): mid 0, r 1
+    z_mean = distance.double().reshape(n, -1).mean(1).float()
+    d = distance + 1.0
+    div = (10.0 * (z_mean.double() + 1.0)).float()
+    div = torch.where(div == 0, torch.ones_like(div), div)
+    d = d * (1.0 / div.double()).float().view(n, 1, 1)
+    d = torch.log(1.0 + torch.clamp(d, min=0).double()).float()
+    d = d + torch.tensor(-0.1, dtype=torch.float32, device=d.device)
+    x7 = torch.cat((x, nrm, d.unsqueeze(-1)), -1)                            # (n, h, h, 7), raster rows
+    x7 = torch.flip(x7, dims=(1,))                                           # ImageFilm row = h - 1 - y
+    return x7.permute(0, 3, 1, 2).contiguous(), chan_mean                   # (channels, height, width) per probe
+
+
+def transform_upstream(out, chan_mean):
+    """transformMapsUpstream, batched: network output (n, 3, h, h) -> predicted intensity (n, h, h, 3) in raster order,
+    rescaled so that each channel's mean is the rendered probe's."""
+    n = out.shape[0]
+    y = torch.exp(torch.clamp(out.float(), min=0).double()) - 1.0           # positiveLogInverse in double
+    y = y.float()
+    actual = y.double().reshape(n, 3, -1).mean(2).float()                   # computeMeanChannels
+    mul = torch.where(actual > 1e-10, chan_mean / actual, torch.zeros_like(actual))
+    y = y * mul.view(n, 3, 1, 1)
+    return torch.flip(y.permute(0, 2, 3, 1), dims=(1,)).contiguous()
+
+
+class IisptPipeline:
+    """render probes -> normalise -> network -> rescale, everything resident in HBM."""
+
+    def __init__(self, gpu_scene, net=None, dtype=torch.float32, device="cuda"):
+        self.gpu = gpu_scene
+        self.device = torch.device(device)
+        self.net = (net if net is not None else IISPTNet()).to(self.device).eval()
+        self.dtype = dtype
+        if dtype != torch.float32:
+            self.net = self.net.to(dtype)
+        self.net = self.net.to(memory_format=torch.channels_last)
+
+    @torch.no_grad()
+    def __call__(self, pos, direction, batch=8192):
+        """(n, 3) probe origins and directions -> (predicted intensity (n, h, h, 3), rendered intensity, normals,
+        distance), all torch tensors on the device, raster order."""
+        n = len(pos)
+        inten = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
+        nrm = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
+        dist = torch.empty((n, HEMI, HEMI), dtype=torch.float32, device=self.device)
+        self.gpu.render_probes(pos, direction, device_out=(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr()))
+        pred = torch.empty_like(inten)
+        for first in range(0, n, batch):
+            sl = slice(first, min(n, first + batch))
+            x, means = normalize_downstream(inten[sl], nrm[sl], dist[sl])
+            y = self.net(x.to(self.dtype).contiguous(memory_format=torch.channels_last))
+            pred[sl] = transform_upstream(y, means)
+        return pred, inten, nrm, dist
