@@ -77,6 +77,9 @@ typedef struct iile_material {
     /* image textures (index into iile_scene_desc::textures) that replace the constant kd / ks / kr / kt at a
      * hit, or -1: Texture<Spectrum>::Evaluate of an ImageTexture (textures/imagemap.h:87-94) */
     int32_t kd_tex, ks_tex, kr_tex, kt_tex;
+    /* "bumpmap": a float image texture (its float in all three channels of the texels) displacing the shading
+     * geometry at a hit (Material::Bump, src/core/material.cpp:45-86), or -1 */
+    int32_t bump_tex;
 } iile_material;
 
 /* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (src/textures/imagemap.h:78-112,

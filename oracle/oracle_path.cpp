@@ -563,6 +563,9 @@ struct Isect {
     float uv[2] = {0, 0};
     V3 dpdu, dpdv;
     float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
+    // bump mapping: the rest of the shading geometry (shading.dpdv, shading.dndu / dndv) and the orientation flag
+    V3 sdpdv, dndu, dndv;
+    bool flip = false;
 };
 
 // the auxiliary rays of a RayDifferential (geometry.h:890-925)
@@ -1169,18 +1172,31 @@ struct Oracle {
                 ss = cross(ts, ns);
             } else
                 coordinate_system(ns, &ss, &ts);
+            // dndu, dndv of the interpolated normal, triangle.cpp:374-392
+            V3 dn1 = n0 - n2, dn2 = n1 - n2;
+            if (std::abs(determinant) < 1e-8)
+                is->dndu = is->dndv = V3(0, 0, 0);
+            else {
+                float inv_det = 1 / determinant;
+                is->dndu = (duv12[1] * dn1 - duv02[1] * dn2) * inv_det;
+                is->dndv = (-duv12[0] * dn1 + duv02[0] * dn2) * inv_det;
+            }
             // SetShadingGeometry(ss, ts, ..., true), interaction.cpp:72-92
             V3 sn = normalize(cross(ss, ts));
             if (flip) sn = -sn;
             n = faceforward(n, sn);
             is->sn = sn;
             is->sdpdu = ss;
+            is->sdpdv = ts;
             n = faceforward(n, is->sn);  // triangle.cpp:396-397
         } else {
             if (flip) n = -n;  // triangle.cpp:398-399
             is->sn = n;
             is->sdpdu = dpdu;
+            is->sdpdv = dpdv;
+            is->dndu = is->dndv = V3(0, 0, 0);
         }
+        is->flip = flip;
         is->n = n;
     }
 
@@ -1445,6 +1461,30 @@ struct Oracle {
     };
     // {Matte,Plastic,Uber,Mirror}Material::ComputeScatteringFunctions (matte.cpp:45-62,
     // plastic.cpp:45-70, uber.cpp:45-100 with opacity 1 and Kt 0, mirror.cpp:44-55)
+    // Material::Bump (material.cpp:45-86) with an ImageTexture<Float, Float> displacement, then
+    // SetShadingGeometry(dpdu, dpdv, dndu, dndv, false) (interaction.cpp:72-92)
+    void bump(int tex, Isect *is) const {
+        Isect ev = *is;
+        float du = .5f * (std::abs(is->dudx) + std::abs(is->dudy));
+        if (du == 0) du = .0005f;
+        ev.uv[0] = is->uv[0] + du;
+        ev.uv[1] = is->uv[1] + 0.f;
+        float u_displace = tex_evaluate(tex, ev).c[0];
+        float dv = .5f * (std::abs(is->dvdx) + std::abs(is->dvdy));
+        if (dv == 0) dv = .0005f;
+        ev.uv[0] = is->uv[0] + 0.f;
+        ev.uv[1] = is->uv[1] + dv;
+        float v_displace = tex_evaluate(tex, ev).c[0];
+        float displace = tex_evaluate(tex, *is).c[0];
+        V3 dpdu = is->sdpdu + (u_displace - displace) / du * is->sn + displace * is->dndu;
+        V3 dpdv = is->sdpdv + (v_displace - displace) / dv * is->sn + displace * is->dndv;
+        V3 sn = normalize(cross(dpdu, dpdv));
+        if (is->flip) sn = -sn;
+        sn = faceforward(sn, is->n);
+        is->sn = sn;
+        is->sdpdu = dpdu;
+        is->sdpdv = dpdv;
+    }
     Bsdf make_bsdf(const Isect &is) const {
         Bsdf b;
         b.ns = is.sn;
@@ -2317,6 +2357,10 @@ struct Oracle {
             // only the camera ray has differentials (spawned rays are plain Rays, path.cpp:159)
             if (S.n_textures > 0) compute_differentials(&is, rdiff);
             rdiff.has = false;
+            {  // every material's ComputeScatteringFunctions starts with `if (bumpMap) Bump(bumpMap, si)`
+                const iile_material &mb = S.materials[S.prim_material[is.prim]];
+                if (S.n_textures > 0 && mb.bump_tex >= 0) bump(mb.bump_tex, &is);
+            }
             Bsdf bsdf = make_bsdf(is);
             // UniformLightDistribution::Lookup ignores the point; SampleDiscrete
             // still consumes one 1D sample (integrator.cpp:95).
@@ -2560,7 +2604,7 @@ int oracle_render_probe(const iile_scene_desc *scene, int trig_mode, const float
     if (!scene || !pos3 || !dir3) return 1;
     for (int i = 0; i < scene->n_materials; ++i) {
         const iile_material &m = scene->materials[i];
-        if (scene->n_textures > 0 && (m.kd_tex >= 0 || m.ks_tex >= 0 || m.kr_tex >= 0 || m.kt_tex >= 0)) return 2;
+        if (scene->n_textures > 0 && (m.kd_tex >= 0 || m.ks_tex >= 0 || m.kr_tex >= 0 || m.kt_tex >= 0 || m.bump_tex >= 0)) return 2;
     }
     const iile_probe_setup &pr = scene->probe;
     ProbeCam cam;

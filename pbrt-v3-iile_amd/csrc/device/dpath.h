@@ -427,6 +427,9 @@ struct Isect {
     // texture lookups (triangles): the hit's (u, v) and dp/du, dp/dv; dead code where no texture is read
     float u, v;
     F3 dpdu, dpdv;
+    // bump mapping: shading.dpdv, shading.dndu / dndv, reverseOrientation ^ transformSwapsHandedness
+    F3 sdpdv, dndu, dndv;
+    bool flip;
 };
 
 // Sphere::Intersect's interaction + Transform::operator()(SurfaceInteraction)
@@ -513,16 +516,29 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
             ss = cross(ts, ns);
         } else
             coordinate_system(ns, &ss, &ts);
+        // dndu, dndv of the interpolated normal, triangle.cpp:374-392
+        const F3 dn1 = n0 - n2, dn2 = n1 - n2;
+        if (double(fabsf(determinant)) < 1e-8) {
+            is->dndu = is->dndv = F3{0, 0, 0};
+        } else {
+            const float inv_det = 1 / determinant;
+            is->dndu = (duv12y * dn1 - duv02y * dn2) * inv_det;
+            is->dndv = (-duv12x * dn1 + duv02x * dn2) * inv_det;
+        }
         F3 sn = normalize(cross(ss, ts));  // SetShadingGeometry, interaction.cpp:72-92
         if (flip) sn = -sn;
         n = faceforward(n, sn);
         is->sn = sn;
         is->sdpdu = ss;
+        is->sdpdv = ts;
     } else {
         if (flip) n = -n;
         is->sn = n;
         is->sdpdu = dpdu;
+        is->sdpdv = dpdv;
+        is->dndu = is->dndv = F3{0, 0, 0};
     }
+    is->flip = flip;
     is->n = n;
 }
 
@@ -1144,6 +1160,26 @@ DEV F3 tex_evaluate(const DScene &S, int tex, float u, float v, const TexDiff &t
     return lerp_f3(lod - float(ilod), tex_ewa(S, t, ilod, st0, st1, d00, d01, d10, d11),
                    tex_ewa(S, t, ilod + 1, st0, st1, d00, d01, d10, d11));
 }
+// Material::Bump (material.cpp:45-86) with an ImageTexture<Float, Float> displacement, then
+// SetShadingGeometry(dpdu, dpdv, dndu, dndv, false) (interaction.cpp:72-92)
+DEV void bump(const DScene &S, int tex, const TexDiff &td, Isect *is) {
+    float du = .5f * (fabsf(td.dudx) + fabsf(td.dudy));
+    if (du == 0) du = .0005f;
+    const float u_displace = tex_evaluate(S, tex, is->u + du, is->v + 0.f, td).x;
+    float dv = .5f * (fabsf(td.dvdx) + fabsf(td.dvdy));
+    if (dv == 0) dv = .0005f;
+    const float v_displace = tex_evaluate(S, tex, is->u + 0.f, is->v + dv, td).x;
+    const float displace = tex_evaluate(S, tex, is->u, is->v, td).x;
+    const F3 dpdu = is->sdpdu + (u_displace - displace) / du * is->sn + displace * is->dndu;
+    const F3 dpdv = is->sdpdv + (v_displace - displace) / dv * is->sn + displace * is->dndv;
+    F3 sn = normalize(cross(dpdu, dpdv));
+    if (is->flip) sn = -sn;
+    sn = faceforward(sn, is->n);
+    is->sn = sn;
+    is->sdpdu = dpdu;
+    is->sdpdv = dpdv;
+}
+
 // the material with its textured parameters looked up at the hit (Texture::Evaluate(*si))
 DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect &is, const TexDiff &td) {
     DMaterial r = m;

@@ -677,6 +677,12 @@ class Loader {
             if (p.strs.size() != 1) return fail("bad texture reference for \"" + p.name + "\"");
             auto it = gs_.textures.find(p.strs[0]);
             if (it == gs_.textures.end()) return fail("Couldn't find texture named \"" + p.strs[0] + "\" for parameter \"" + p.name + "\"");
+            if (it->second.image >= 0 && it->second.is_float && p.name == "bumpmap") {
+                (*image_of)[p.name] = it->second.image;
+                p.strs.clear();
+                p.type = "bumpimage";  // consumed below; no material reads a parameter of this type
+                continue;
+            }
             if (it->second.image >= 0) {
                 if (it->second.is_float || (p.name != "Kd" && p.name != "Ks" && p.name != "Kr" && p.name != "Kt"))
                     return fail("image texture \"" + p.strs[0] + "\" on parameter \"" + p.name + "\" is not supported (Kd, Ks, Kr, Kt)");
@@ -703,7 +709,7 @@ class Loader {
         if (!resolve_textures(ps_in, &ps, &image_of)) return -1;
         iile_material m;
         std::memset(&m, 0, sizeof(m));
-        m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = -1;
+        m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = -1;
         auto image = [&](const char *param) {
             auto it = image_of.find(param);
             return it == image_of.end() ? -1 : it->second;
@@ -792,11 +798,13 @@ class Loader {
             fail("uber: specular transmission (Kt) is not supported");
             return -1;
         }
-        for (const char *tex : {"bumpmap"})
-            if (ps.find(tex)) {
-                fail("bump maps are not supported");
+        if (const Param *bp = ps.find("bumpmap")) {  // GetFloatTextureOrNull("bumpmap") of every material's Create*
+            if (bp->type != "bumpimage" || m.type == IILE_MAT_GLASS) {
+                fail("bumpmap: only a float \"imagemap\" texture on matte / plastic / uber / mirror is supported");
                 return -1;
             }
+            m.bump_tex = image("bumpmap");
+        }
         scene_->materials.push_back(m);
         return int(scene_->materials.size()) - 1;
     }
@@ -816,7 +824,7 @@ class Loader {
         if (name == "sphere") {  // shapes/sphere.cpp:318-327, sphere.h:50-60
             {
                 const iile_material &sm = s.materials[size_t(mat)];
-                if (sm.kd_tex >= 0 || sm.ks_tex >= 0 || sm.kr_tex >= 0 || sm.kt_tex >= 0)
+                if (sm.kd_tex >= 0 || sm.ks_tex >= 0 || sm.kr_tex >= 0 || sm.kt_tex >= 0 || sm.bump_tex >= 0)
                     return fail("image textures on spheres are not supported (triangle meshes only)");
             }
             float radius = ps.one_float("radius", 1.f);

@@ -96,6 +96,11 @@ def write_test_images(directory, seed=5):
     m[2:6, 1:4] = 0
     m[0:2, 5:8] = 0
     m[6, 6] = 0.25
+    # single-channel PFM 32 x 32 height field for bump maps: smooth bumps
+    yy, xx = np.mgrid[0:32, 0:32]
+    bumps = (0.04 * (np.sin(xx * np.pi / 4) * np.cos(yy * np.pi / 8) + 1)).astype(np.float32)
+    paths["bumps"] = os.path.join(directory, "bumps.pfm")
+    open(paths["bumps"], "wb").write(b"Pf\n32 32\n-1.0\n" + bumps.tobytes())
     paths["mask"] = os.path.join(directory, "mask.pfm")
     open(paths["mask"], "wb").write(b"Pf\n8 8\n-1.0\n" + m.tobytes())
     return paths
@@ -176,6 +181,7 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         out.append('Texture "noise-black" "spectrum" "imagemap" "string filename" ["%s"] "string wrap" ["black"] '
                    '"float uscale" [1.5] "float vscale" [1.5] "float maxanisotropy" [2]' % tex["noise"])
         out.append('Texture "stripes" "spectrum" "imagemap" "string filename" ["%s"] "bool gamma" ["false"]' % tex["stripes"])
+        out.append('Texture "bumps" "float" "imagemap" "string filename" ["%s"] "float uscale" [4] "float vscale" [4]' % tex["bumps"])
         # alpha masks (triangle.cpp:325-331, 509-541): a free-standing screen full of holes whose shadow has
         # further holes (shadowalpha), and an invisible box ("float alpha" [0]) around a blob
         out.append('Texture "mask" "float" "imagemap" "string filename" ["%s"] "float uscale" [3] "float vscale" [2]' % tex["mask"])
@@ -201,8 +207,9 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         rough = ' "float sigma" [%g]' % (20 + 10 * len(out) % 50) if materials == "all" else ""  # Oren-Nayar walls
         if tex is not None:
             name = wall_tex[walls.index((o, du, dv, kd))]
-            out.append('AttributeBegin\n  Material "matte" "texture Kd" ["%s"]%s\n%sAttributeEnd' % (
-                name, rough, _mesh(P, F, _grid_uv(wall_n, 3.0))))
+            bump = ' "texture bumpmap" ["bumps"]' if name in ("checker", "stripes") else ""
+            out.append('AttributeBegin\n  Material "matte" "texture Kd" ["%s"]%s%s\n%sAttributeEnd' % (
+                name, rough, bump, _mesh(P, F, _grid_uv(wall_n, 3.0))))
             continue
         out.append('AttributeBegin\n  Material "matte" "color Kd" [%g %g %g]%s\n%sAttributeEnd' % (*kd, rough, _mesh(P, F)))
     V, F = _icosphere(ico_levels)
@@ -228,6 +235,12 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
                 *((1, 1, 1) if b % 4 == 1 else rng.uniform(.7, 1, 3)), rng.uniform(1.3, 1.7))
         elif tex is not None and b % 4 == 0:  # blobs have no uv: every triangle maps the unit half-square
             mat = 'Material "plastic" "texture Kd" ["noise"] "texture Ks" ["stripes"] "float roughness" [%g]' % rng.uniform(.02, .3)
+        elif tex is not None and b % 4 == 2:  # smooth-shaded (vertex normals: dn/du, dn/dv enter Material::Bump) and bumpy
+            mat = 'Material "plastic" "color Kd" [.5 .4 .2] "color Ks" [.3 .3 .3] "float roughness" [.1] "texture bumpmap" ["bumps"]'
+            nrm = P - c
+            nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+            out.append('AttributeBegin\n  %s\n%s  "normal N" [ %s ]\nAttributeEnd' % (mat, _mesh(P, F), _fmt(nrm)))
+            continue
         elif tex is not None and b % 4 == 1:
             mat = 'Material "matte" "texture Kd" ["checker"]'
         elif b % 2 == 0:

@@ -742,3 +742,40 @@ def test_iispt_probe_pass_pins(binding, oracle, tmp_path):
     assert inten[near].min() > 0          # lit by the point light above
     up, nrm_up, dist_up = oracle.render_probe(plane, (0, 0, h), (0, 0, 1), trig_mode=ob.TRIG_LIBM)
     assert (dist_up == -1).all() and (nrm_up == 0).all() and (up == 0).all()
+
+
+def test_bump_mapping_pins(binding, oracle, tmp_path):
+    """Material::Bump (material.cpp:45-86) with a float image texture, pinned by geometry: (1) a constant displacement
+    leaves a mesh without vertex normals as it was (dn/du = 0: only the shading normal's recomputation rounds);
+    (2) a height ramp h = a * u on a square of side W tilts the shading normal to (-a, 0, W) / sqrt(a^2 + W^2): under
+    a light from straight above, direct lighting only, the Lambertian radiance falls by W / sqrt(a^2 + W^2)."""
+    W, a = 2.0, 2.0
+    ramp = np.tile((a * (np.arange(64) + .5) / 64).astype(np.float32)[None, :], (64, 1))
+    (tmp_path / "ramp.pfm").write_bytes(b"Pf\n64 64\n-1.0\n" + ramp.tobytes())
+    (tmp_path / "flat.pfm").write_bytes(b"Pf\n4 4\n-1.0\n" + np.full((4, 4), np.float32(.75), np.float32).tobytes())
+    scene_text = ('LookAt 0 0 5  0 0 0  0 1 0\nCamera "perspective" "float fov" [12]\n'
+                  'Film "image" "integer xresolution" [32] "integer yresolution" [32]\nSampler "halton" "integer pixelsamples" [4]\n'
+                  'Integrator "path" "integer maxdepth" [1]\nWorldBegin\n'
+                  'LightSource "distant" "point from" [0 0 1] "point to" [0 0 0] "color L" [3 3 3]\n%s'
+                  'Shape "trianglemesh" "point P" [-1 -1 0  1 -1 0  1 1 0  -1 1 0] "integer indices" [0 1 2 0 2 3] '
+                  '"float uv" [0 0 1 0 1 1 0 1]\nWorldEnd\n')
+    films = {}
+    for name, mat in (("plain", 'Material "matte" "color Kd" [.5 .5 .5]\n'),
+                      ("flat", 'Texture "b" "float" "imagemap" "string filename" ["flat.pfm"]\nMaterial "matte" "color Kd" [.5 .5 .5] "texture bumpmap" ["b"]\n'),
+                      ("ramp", 'Texture "b" "float" "imagemap" "string filename" ["ramp.pfm"] "string wrap" ["clamp"]\n'
+                               'Material "matte" "color Kd" [.5 .5 .5] "texture bumpmap" ["b"]\n')):
+        (tmp_path / f"{name}.pbrt").write_text(scene_text % mat)
+        scene = binding.HostScene(path=str(tmp_path / f"{name}.pbrt"))
+        film, _ = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+        films[name] = scene.film_to_rgb(film)
+    assert films["plain"].min() > 0.4        # the square fills the view: Kd / pi * L = 0.477
+    assert np.allclose(films["flat"], films["plain"], rtol=1e-5)
+    ratio = films["ramp"][8:24, 8:24] / films["plain"][8:24, 8:24]
+    # the finite difference runs over EWA-filtered lookups a pixel footprint apart: exact in the mean, a few per cent
+    # of filter discretisation per pixel
+    want = W / np.sqrt(a * a + W * W)
+    assert abs(float(ratio.mean()) - want) < 0.01 * want, ratio.mean()
+    assert np.allclose(ratio, want, rtol=0.06), (ratio.min(), ratio.max())
+    with pytest.raises(RuntimeError, match="bumpmap"):
+        (tmp_path / "bad.pbrt").write_text(scene_text % 'Material "matte" "float bumpmap" [.1]\n')
+        binding.HostScene(path=str(tmp_path / "bad.pbrt"))
