@@ -74,8 +74,9 @@ typedef struct iile_material {
     float kr[3];     /* uber, mirror, glass: specular reflectance */
     float kt[3];     /* glass: specular transmittance */
     float on_a, on_b; /* matte with sigma != 0: the Oren-Nayar constants A, B (reflection.h:416-419) */
-    /* image textures (index into iile_scene_desc::textures) that replace the constant kd / ks / kr / kt at a
-     * hit, or -1: Texture<Spectrum>::Evaluate of an ImageTexture (textures/imagemap.h:87-94) */
+    /* image textures (index into iile_scene_desc::textures) whose value at a hit, multiplied by the constant kd /
+     * ks / kr / kt (1 for a plain "imagemap", the constant factor of a "scale" texture, textures/scale.h:56-58),
+     * replaces that constant, or -1: Texture<Spectrum>::Evaluate of an ImageTexture (textures/imagemap.h:87-94) */
     int32_t kd_tex, ks_tex, kr_tex, kt_tex;
     /* "bumpmap": a float image texture (its float in all three channels of the texels) displacing the shading
      * geometry at a hit (Material::Bump, src/core/material.cpp:45-86), or -1 */

@@ -1498,7 +1498,7 @@ struct Oracle {
         // a parameter given as an image texture is looked up at the hit (Texture::Evaluate(*si))
         auto param = [&](const float *constant, int tex) {
             if (tex < 0) return clamp0(constant);
-            Rgb v = tex_evaluate(tex, is);
+            Rgb v = tex_evaluate(tex, is) * Rgb(constant[0], constant[1], constant[2]);  // ScaleTexture: tex1 * tex2 (x 1 if plain)
             return clamp0(v.c);
         };
         Rgb kd = param(m.kd, m.kd_tex);

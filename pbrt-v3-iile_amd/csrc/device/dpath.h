@@ -1184,20 +1184,20 @@ DEV void bump(const DScene &S, int tex, const TexDiff &td, Isect *is) {
 DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect &is, const TexDiff &td) {
     DMaterial r = m;
     if (m.kd_tex >= 0) {
-        const F3 c = tex_evaluate(S, m.kd_tex, is.u, is.v, td);
-        r.kd[0] = c.x, r.kd[1] = c.y, r.kd[2] = c.z;
+        const F3 c = tex_evaluate(S, m.kd_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
+        r.kd[0] = c.x * m.kd[0], r.kd[1] = c.y * m.kd[1], r.kd[2] = c.z * m.kd[2];
     }
     if (m.ks_tex >= 0) {
-        const F3 c = tex_evaluate(S, m.ks_tex, is.u, is.v, td);
-        r.ks[0] = c.x, r.ks[1] = c.y, r.ks[2] = c.z;
+        const F3 c = tex_evaluate(S, m.ks_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
+        r.ks[0] = c.x * m.ks[0], r.ks[1] = c.y * m.ks[1], r.ks[2] = c.z * m.ks[2];
     }
     if (m.kr_tex >= 0) {
-        const F3 c = tex_evaluate(S, m.kr_tex, is.u, is.v, td);
-        r.kr[0] = c.x, r.kr[1] = c.y, r.kr[2] = c.z;
+        const F3 c = tex_evaluate(S, m.kr_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
+        r.kr[0] = c.x * m.kr[0], r.kr[1] = c.y * m.kr[1], r.kr[2] = c.z * m.kr[2];
     }
     if (m.kt_tex >= 0) {
-        const F3 c = tex_evaluate(S, m.kt_tex, is.u, is.v, td);
-        r.kt[0] = c.x, r.kt[1] = c.y, r.kt[2] = c.z;
+        const F3 c = tex_evaluate(S, m.kt_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
+        r.kt[0] = c.x * m.kt[0], r.kt[1] = c.y * m.kt[1], r.kt[2] = c.z * m.kt[2];
     }
     return r;
 }

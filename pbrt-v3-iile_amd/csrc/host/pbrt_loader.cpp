@@ -183,6 +183,7 @@ struct ConstTexture {
     bool is_float = true;
     float v[3] = {0, 0, 0};
     int image = -1;  // an "imagemap" spectrum texture: index into HostScene::textures (not constant: kept by reference)
+    bool scaled = false;  // a "scale" of that image with a constant: v is the constant factor
 };
 struct GraphicsState {
     int material = -1;  // index into scene->materials, -1 = default matte
@@ -614,6 +615,33 @@ class Loader {
         }
         return true;
     }
+    // "scale" with exactly one plain spectrum image texture among tex1 / tex2 and a constant for the other
+    bool scale_of_image(const ParamSet &ps, ConstTexture *t) {
+        const char *names[2] = {"tex1", "tex2"};
+        int which = -1;
+        for (int k = 0; k < 2; ++k) {
+            const Param *p = ps.find(names[k]);
+            if (!p || p->type != "texture" || p->strs.size() != 1) continue;
+            auto it = gs_.textures.find(p->strs[0]);
+            if (it == gs_.textures.end() || it->second.image < 0 || it->second.is_float || it->second.scaled) continue;
+            if (which >= 0) return false;  // two images: not folded
+            which = k;
+            t->image = it->second.image;
+        }
+        if (which < 0) return false;
+        const float one[3] = {1, 1, 1};
+        ParamSet rest;
+        for (const Param &p : ps.params)
+            if (p.name != names[which]) rest.params.push_back(p);
+        float c[3];
+        if (!tex_value(rest, names[1 - which], false, one, c)) {
+            t->image = -1;
+            return false;
+        }
+        for (int i = 0; i < 3; ++i) t->v[i] = c[i];
+        t->scaled = true;
+        return true;
+    }
     bool make_texture(const std::string &name, const std::string &type, const std::string &cls, const ParamSet &ps) {
         const bool is_float = type == "float";
         if (!is_float && type != "spectrum" && type != "color") return fail("Texture type \"" + type + "\" unknown.");
@@ -622,6 +650,8 @@ class Loader {
         t.is_float = is_float;
         if (cls == "constant") {  // CreateConstant*Texture, textures/constant.cpp: "value" default 1
             if (!tex_value(ps, "value", is_float, one, t.v)) return false;
+        } else if (cls == "scale" && !is_float && scale_of_image(ps, &t)) {
+            // an image texture times a constant: kept as (image, factor); the product is taken at the hit
         } else if (cls == "scale") {  // ScaleTexture::Evaluate = tex1 * tex2, textures/scale.h:56-58 (defaults 1, 1)
             float a[3], b[3];
             if (!tex_value(ps, "tex1", is_float, one, a) || !tex_value(ps, "tex2", is_float, one, b)) return false;
@@ -688,8 +718,11 @@ class Loader {
                     return fail("image texture \"" + p.strs[0] + "\" on parameter \"" + p.name + "\" is not supported (Kd, Ks, Kr, Kt)");
                 (*image_of)[p.name] = it->second.image;
                 p.strs.clear();
-                p.type = "color";
-                p.nums = {1.0, 1.0, 1.0};
+                p.type = "color";  // the constant the image's value is multiplied with at the hit (1 unless "scale"d)
+                if (it->second.scaled)
+                    p.nums = {double(it->second.v[0]), double(it->second.v[1]), double(it->second.v[2])};
+                else
+                    p.nums = {1.0, 1.0, 1.0};
                 continue;
             }
             p.strs.clear();

@@ -181,6 +181,7 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         out.append('Texture "noise-black" "spectrum" "imagemap" "string filename" ["%s"] "string wrap" ["black"] '
                    '"float uscale" [1.5] "float vscale" [1.5] "float maxanisotropy" [2]' % tex["noise"])
         out.append('Texture "stripes" "spectrum" "imagemap" "string filename" ["%s"] "bool gamma" ["false"]' % tex["stripes"])
+        out.append('Texture "noise-tint" "spectrum" "scale" "texture tex1" ["noise"] "color tex2" [.9 .6 .3]')
         out.append('Texture "bumps" "float" "imagemap" "string filename" ["%s"] "float uscale" [4] "float vscale" [4]' % tex["bumps"])
         # alpha masks (triangle.cpp:325-331, 509-541): a free-standing screen full of holes whose shadow has
         # further holes (shadowalpha), and an invisible box ("float alpha" [0]) around a blob
@@ -193,7 +194,7 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         out.append('AttributeBegin\n  Material "mirror"\n%s  "float alpha" [0]\nAttributeEnd' % _mesh(P, F))
         P, F = _grid_quad((-8, 2, 4), (5, 0, 0), (0, 3, 0), 3)
         out.append('AttributeBegin\n  Material "matte" "color Kd" [.9 .2 .2]\n%s  "float shadowalpha" [0]\nAttributeEnd' % _mesh(P, F))
-    wall_tex = ["checker", "noise", "checker-tri", "stripes", "noise-black"]
+    wall_tex = ["checker", "noise-tint", "checker-tri", "stripes", "noise-black"]
     s = 10.0
     walls = [((-s, -s, -3), (2 * s, 0, 0), (0, 2 * s, 0), (.7, .7, .7)),      # floor
              ((-s, -s, 9), (0, 2 * s, 0), (2 * s, 0, 0), (.8, .8, .8)),       # ceiling

@@ -546,6 +546,15 @@ def test_constant_image_texture_renders_like_the_constant(binding, oracle, tmp_p
     plain, _ = oracle.render(binding.HostScene(path=str(tmp_path / "plain.pbrt")))
     for f in films.values():
         assert np.allclose(f, plain, rtol=2e-6, atol=0)
+    # a "scale" texture (ScaleTexture, textures/scale.h:56-58) of the image with a constant: 1.0 (image) x 0.5
+    (tmp_path / "one.pfm").write_bytes(b"PF\n4 4\n-1.0\n" + np.ones((4, 4, 3), np.float32).tobytes())
+    tex = src.replace('Material "matte" "color Kd" [.5 .5 .5]',
+                      'Texture "one" "spectrum" "imagemap" "string filename" ["one.pfm"]\n'
+                      'Texture "half" "spectrum" "scale" "color tex1" [.5 .5 .5] "texture tex2" ["one"]\n'
+                      'Material "matte" "texture Kd" ["half"]')
+    (tmp_path / "scaled.pbrt").write_text(tex)
+    scaled, _ = oracle.render(binding.HostScene(path=str(tmp_path / "scaled.pbrt")))
+    assert np.allclose(scaled, plain, rtol=2e-6, atol=0)
 
 
 def test_alpha_masks(binding, oracle, tmp_path):
