@@ -95,6 +95,8 @@ void oracle_texture_eval(const iile_scene_desc *scene, int trig_mode, int tex, i
 /* first hit of the camera ray through film point (pfx, pfy): {u, v, du/dx, dv/dx, du/dy, dv/dy} as
  * ComputeDifferentials leaves them (interaction.cpp:103-149); returns 0 when the ray escapes */
 int oracle_camera_hit_differentials(const iile_scene_desc *scene, int trig_mode, float pfx, float pfy, float *out6);
+/* Distribution1D (sampling.h:55-109) over func[0..n), n <= 8: mode 0 SampleDiscrete, mode 1 SampleContinuous */
+int oracle_distribution1d(const float *func, int n, int mode, float u, float *value, float *pdf);
 float oracle_log(int trig_mode, float x);
 void oracle_sincos(int trig_mode, float x, float *s, float *c);
 void oracle_sincos_d(int trig_mode, double x, double *s, double *c);

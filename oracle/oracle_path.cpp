@@ -2058,6 +2058,13 @@ struct Oracle {
         LightDist d;
         d.n = n;
         for (int j = 0; j < n; ++j) d.func[j] = std::max(contrib[j], min_contrib);
+        finish_distribution(&d);
+        return d;
+    }
+    // Distribution1D's constructor, sampling.h:57-69, over d->func[0 .. n)
+    static void finish_distribution(LightDist *dp) {
+        LightDist &d = *dp;
+        const int n = d.n;
         d.cdf[0] = 0;
         for (int i = 1; i < n + 1; ++i) d.cdf[i] = d.cdf[i - 1] + d.func[i - 1] / n;
         d.func_int = d.cdf[n];
@@ -2065,7 +2072,6 @@ struct Oracle {
             for (int i = 1; i < n + 1; ++i) d.cdf[i] = float(i) / float(n);
         else
             for (int i = 1; i < n + 1; ++i) d.cdf[i] /= d.func_int;
-        return d;
     }
     const LightDist &light_distribution(V3 p) const {  // SpatialLightDistribution::Lookup, lightdistrib.cpp:134-226
         V3 bmin, bmax;
@@ -2825,6 +2831,24 @@ int oracle_camera_hit_differentials(const iile_scene_desc *scene, int trig_mode,
     out6[4] = is.dudy;
     out6[5] = is.dvdy;
     return 1;
+}
+// Distribution1D over func[0 .. n), n <= IILE_MAX_LIGHTS (src/tests/sampling.cpp:231-304): mode 0 SampleDiscrete (the
+// light selection of UniformSampleOneLight) -> returns the offset, *pdf = DiscretePDF-style pdf; mode 1
+// SampleContinuous (the environment map's rows and columns) -> *value, *pdf, returns the offset
+int oracle_distribution1d(const float *func, int n, int mode, float u, float *value, float *pdf) {
+    if (n < 1 || n > IILE_MAX_LIGHTS) return -1;
+    Oracle::LightDist d;
+    d.n = n;
+    for (int i = 0; i < n; ++i) d.func[i] = func[i];
+    Oracle::finish_distribution(&d);
+    if (mode == 0) return Oracle::sample_discrete(d, u, pdf);
+    std::vector<float> flat(size_t(2 * n + 2));
+    for (int i = 0; i < n; ++i) flat[size_t(i)] = d.func[i];
+    for (int i = 0; i <= n; ++i) flat[size_t(n + i)] = d.cdf[i];
+    flat[size_t(2 * n + 1)] = d.func_int;
+    int off = 0;
+    *value = Oracle::dist1d_sample(flat.data(), n, u, pdf, &off);
+    return off;
 }
 float oracle_log(int trig_mode, float x) {
     Trig t{trig_mode};

@@ -48,6 +48,8 @@ class Oracle:
         lib.oracle_render_probe.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
         lib.oracle_texture_eval.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp]
         lib.oracle_camera_hit_differentials.argtypes = [c_vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_vp]
+        lib.oracle_distribution1d.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_float),
+                                              ctypes.POINTER(ctypes.c_float)]
         lib.oracle_log.argtypes = [ctypes.c_int, ctypes.c_float]
         lib.oracle_log.restype = ctypes.c_float
         lib.oracle_light_solid_angle.argtypes = [c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp]
@@ -217,6 +219,15 @@ class Oracle:
         if not self.lib.oracle_camera_hit_differentials(scene.desc, trig_mode, pfx, pfy, out.ctypes.data):
             return None
         return out
+
+    def distribution1d(self, func, u, continuous=False):
+        """Distribution1D(func).SampleDiscrete(u) -> (offset, pdf) or SampleContinuous(u) -> (value, pdf, offset)."""
+        func = _f32(func)
+        value, pdf = ctypes.c_float(), ctypes.c_float()
+        off = self.lib.oracle_distribution1d(func.ctypes.data, len(func), 1 if continuous else 0, float(u), ctypes.byref(value),
+                                             ctypes.byref(pdf))
+        assert off >= 0
+        return (value.value, pdf.value, off) if continuous else (off, pdf.value)
 
     def log(self, x, trig_mode=TRIG_PORTABLE):
         return np.array([self.lib.oracle_log(trig_mode, float(v)) for v in _f32(x)], np.float32)

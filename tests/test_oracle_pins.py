@@ -788,3 +788,39 @@ def test_bump_mapping_pins(binding, oracle, tmp_path):
     with pytest.raises(RuntimeError, match="bumpmap"):
         (tmp_path / "bad.pbrt").write_text(scene_text % 'Material "matte" "float bumpmap" [.1]\n')
         binding.HostScene(path=str(tmp_path / "bad.pbrt"))
+
+
+def test_distribution1d_like_the_reference_tests(oracle):
+    """Distribution1D.Discrete / .Continuous and FindInterval.Basics of src/tests/sampling.cpp:231-304 and
+    src/tests/find_interval.cpp:8-29, on the restatement behind the light selection (SampleDiscrete) and the
+    environment map's rows and columns (SampleContinuous). DiscretePDF(i) = func[i] / (funcInt * n)."""
+    f = [0, 1., 0., 3.]
+    for u, want, pdf in ((0., 1, .25), (0.125, 1, .25), (.24999, 1, .25), (.250001, 3, .75), (0.625, 3, .75),
+                         (float(np.nextafter(np.float32(1), np.float32(0))), 3, .75), (1., 3, .75)):
+        off, p = oracle.distribution1d(f, u)
+        assert (off, p) == (want, pdf), u
+    # a stream of hits in interval 1 up to the cross-over at 0.25 (plus / minus fp slop), interval 3 from there on
+    u = u_max = np.float32(.25)
+    for _ in range(20):
+        u, u_max = np.nextafter(u, np.float32(0)), np.nextafter(u_max, np.float32(1))
+    seen3 = False
+    while u <= u_max:
+        off, _ = oracle.distribution1d(f, float(u))
+        assert off == (3 if seen3 else off) and off in (1, 3)
+        seen3 |= off == 3
+        u = np.nextafter(u, np.float32(1))
+    assert seen3
+    g = [1, 1, 2, 4, 8]
+    v, p, off = oracle.distribution1d(g, 0., continuous=True)
+    assert (v, off) == (0., 0) and abs(p - 5 * 1. / 16.) < 1e-6
+    assert abs(oracle.distribution1d(g, 0.5, continuous=True)[0] - .8) < 1e-6      # between the 4 and the 8 segment
+    v, p, off = oracle.distribution1d(g, 0.75, continuous=True)
+    assert abs(v - .9) < 1e-6 and abs(p - 5 * 8. / 16.) < 1e-6 and off == 4
+    assert abs(oracle.distribution1d(g, 1., continuous=True)[0] - 1.) < 1e-6
+    # FindInterval.Basics through a uniform distribution (cdf[i] = i / 8): clamping and the interval of i/8, (i + .5)/8
+    ones = [1.] * 8
+    assert oracle.distribution1d(ones, -1.)[0] == 0 and oracle.distribution1d(ones, 100.)[0] == 7
+    for i in range(8):
+        assert oracle.distribution1d(ones, i / 8)[0] == i and oracle.distribution1d(ones, (i + .5) / 8)[0] == i
+        if i > 0:
+            assert oracle.distribution1d(ones, (i - .5) / 8)[0] == i - 1
