@@ -204,8 +204,11 @@ void copy_counters(const DCounters &c, iile_stats *st) {
 }
 
 // Enqueue one wavefront pass on cfg.stream.
-int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P, const LaunchCfg &cfg, bool timed) {
+int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_in, const LaunchCfg &cfg, bool timed) {
     PassBuffers &B = sc->pb;
+    PassDesc P = P_in;
+    // camera rays made inside the first extend / shade (see PassDesc::gen_fused) where nothing else reads queue 0
+    P.gen_fused = !cfg.count_stats && !P.list_px && !S.has_infinite && !S.probe_mode && !B.nray_out && !std::getenv("IILE_NO_FUSED_GEN");
     HIP_TRY(hipMemsetAsync(B.counts, 0, 128 * sizeof(uint32_t), cfg.stream));
     auto timed_launch = [&](int kind, auto &&fn) -> int {
         EventPair *ep = nullptr;
@@ -218,12 +221,19 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P, 
         if (timed) HIP_TRY(hipEventRecord(ep->b, cfg.stream));
         return IILE_OK;
     };
-    int rc = timed_launch(0, [&] { launch_generate(S, P, B, cfg); });
-    if (rc) return rc;
+    int rc = IILE_OK;
+    if (P.gen_fused) {
+        // no k_generate: L starts at 0, queue 0 is the dense range of path ids
+        HIP_TRY(hipMemsetAsync(B.L, 0, size_t(P.n_paths) * sizeof(float4), cfg.stream));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&B.counts[0]), int(P.n_paths), 1, cfg.stream));
+    } else {
+        rc = timed_launch(0, [&] { launch_generate(S, P, B, cfg); });
+        if (rc) return rc;
+    }
     // bounces 0 .. maxDepth: the path loop exits at `bounces >= maxDepth` after
     // intersecting (path.cpp:104), so maxDepth + 1 extend launches are needed
     for (int b = 0; b <= max_depth; ++b) {
-        rc = timed_launch(1, [&] { launch_extend(S, B, b, B.queue_cap, cfg); });
+        rc = timed_launch(1, [&] { launch_extend(S, P, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (S.has_infinite) {  // escaped rays see the infinite lights (path.cpp:97-99)
             rc = timed_launch(6, [&] { launch_miss(S, B, b, B.queue_cap, cfg); });

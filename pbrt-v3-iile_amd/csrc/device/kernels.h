@@ -15,6 +15,9 @@ struct PassDesc {
     // IISPT probe batch: n_owned_tiles = n_probes * tiles per probe, tile slot = probe * tiles + tile
     int probe_mode, probe_tiles;
     const DProbeCam *probe_cams;
+    // camera rays are generated inside the first k_extend and rebuilt in the first k_shade: no k_generate, no ray
+    // queue for bounce 0 (run_pass decides; needs L cleared and counts[kCntRay] set beforehand)
+    int gen_fused;
 };
 
 // Queue arrays (ray_o/ray_d/hits/shade_q/nee) hold `queue_cap` slots: the paths of a
@@ -61,7 +64,7 @@ struct LaunchCfg {
 // slots a queue needs for n_paths paths
 uint32_t queue_capacity(uint32_t n_paths, int n_cus);
 void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg);
-void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_extend(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg);

@@ -257,8 +257,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
 // ---------------------------------------------------------------------------
 // extend: BVHAccel::Intersect for every ray of queue `bounce & 1`; hits are
 // appended (ballot-compacted) to the shade queue.
-template <bool COUNT, bool ALPHA>
-__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, PassBuffers B, int bounce) {
+// GEN (first bounce, PassDesc::gen_fused): the queue is the dense range of path ids and a lane makes its camera ray
+// itself (what k_generate would have written and this kernel read back: 64 B per path)
+template <bool COUNT, bool ALPHA, bool GEN>
+__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, PassDesc P, PassBuffers B, int bounce) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
     WaveOut shade_out{0, 0};
     auto pad_shade = [&](uint32_t sl) { B.shade_q[sl] = kInvalid; };
     auto warm = [&](uint32_t first) {
+        if (GEN) return;
         warm_plane(ro, first, count);
         warm_plane(rd, first, count);
     };
@@ -281,19 +284,41 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
     t.hit_prim = -1;
     bool active = false;
     uint32_t slot = 0;
+    float4 gen_d = make_float4(0, 0, 1, 0);  // GEN: the ray direction (the sphere test reads it back)
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
             uint32_t s_new;
             if (feed_take(feed, head, count, !active, &s_new, warm)) {
                 slot = s_new;
-                const float4 o4 = ro[slot], d4 = rd[slot];
-                if (f2b(o4.w) != kInvalid) {
-                    trav_begin<COUNT>(S, t, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, &st);
-                    active = true;
-                    if (COUNT) {
-                        ++n_rays;
-                        if (B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
+                if (GEN) {
+                    int px = 0, py = 0;
+                    uint32_t k = 0;
+                    if (path_pixel(S, P, slot, &px, &py, &k)) {  // queue 0 is dense: slot == path id
+                        const uint32_t idx = halton_index(S, px, py, k);
+                        const float u0 = sample_dimension(S, idx, 0), u1 = sample_dimension(S, idx, 1);
+                        float l0 = 0, l1 = 0;
+                        if (S.lens_radius > 0) {
+                            l0 = sample_dimension(S, idx, 3);
+                            l1 = sample_dimension(S, idx, 4);
+                        }
+                        F3 o, d;
+                        float tmax;
+                        camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
+                        B.hindex[slot] = idx;
+                        gen_d = make_float4(d.x, d.y, d.z, tmax);
+                        trav_begin<COUNT>(S, t, o, d, tmax, &st);
+                        active = true;
+                    }
+                } else {
+                    const float4 o4 = ro[slot], d4 = rd[slot];
+                    if (f2b(o4.w) != kInvalid) {
+                        trav_begin<COUNT>(S, t, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, &st);
+                        active = true;
+                        if (COUNT) {
+                            ++n_rays;
+                            if (B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
+                        }
                     }
                 }
             }
@@ -316,12 +341,12 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
-                if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &rd[slot]);
+                if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, GEN ? &gen_d : &rd[slot]);
             }
         }
 #else
         while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
-        if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &rd[slot]);
+        if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, GEN ? &gen_d : &rd[slot]);
 #endif
         const bool fin = active && !t.have;
         const bool is_hit = fin && t.hit_prim >= 0;
@@ -562,7 +587,29 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
             uint32_t nee_flags = 0, nee_light = 0;
             float light_sel_pdf = 1.f;  // lightPdf of UniformSampleOneLight: Ld is divided by it
             if (valid) {
-                const float4 o4 = ro[slot], d4 = rd[slot], h4 = B.hits[slot];
+                float4 o4, d4;
+                const float4 h4 = B.hits[slot];
+                if (bounce == 0 && P.gen_fused) {
+                    // the camera ray again, as the first k_extend made it (queue 0 is dense: slot == path id)
+                    int cpx = 0, cpy = 0;
+                    uint32_t ck = 0;
+                    path_pixel(S, P, slot, &cpx, &cpy, &ck);
+                    const uint32_t cidx = B.hindex[slot];
+                    const float cu0 = sample_dimension(S, s_perms, cidx, 0), cu1 = sample_dimension(S, s_perms, cidx, 1);
+                    float cl0 = 0, cl1 = 0;
+                    if (S.lens_radius > 0) {
+                        cl0 = sample_dimension(S, s_perms, cidx, 3);
+                        cl1 = sample_dimension(S, s_perms, cidx, 4);
+                    }
+                    F3 co, cd;
+                    float ctm;
+                    camera_ray(S, float(cpx) + cu0, float(cpy) + cu1, cl0, cl1, &co, &cd, &ctm);
+                    o4 = make_float4(co.x, co.y, co.z, b2f(slot));
+                    d4 = make_float4(cd.x, cd.y, cd.z, ctm);
+                } else {
+                    o4 = ro[slot];
+                    d4 = rd[slot];
+                }
                 pid = f2b(o4.w);
                 // a path arrives at its first vertex with beta = 1 at sampler dimension 5 (after
                 // the camera sample): k_generate does not spend 16 B per path on saying so
@@ -1550,16 +1597,21 @@ void launch_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, c
     hipLaunchKernelGGL(k_generate, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B,
                        cfg.count_stats ? 1 : 0);
 }
-void launch_extend(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
+void launch_extend(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
+    const bool gen = bounce == 0 && P.gen_fused && !cfg.count_stats;
     if (cfg.count_stats)
-        hipLaunchKernelGGL((k_extend<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
-    else
-        {
-        if (S.has_alpha)
-            hipLaunchKernelGGL((k_extend<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+        hipLaunchKernelGGL((k_extend<true, true, false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
+    else if (S.has_alpha) {
+        if (gen)
+            hipLaunchKernelGGL((k_extend<false, true, true>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
         else
-            hipLaunchKernelGGL((k_extend<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce);
+            hipLaunchKernelGGL((k_extend<false, true, false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
+    } else {
+        if (gen)
+            hipLaunchKernelGGL((k_extend<false, false, true>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
+        else
+            hipLaunchKernelGGL((k_extend<false, false, false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
     }
 }
 void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
