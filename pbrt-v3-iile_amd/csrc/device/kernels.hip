@@ -304,8 +304,12 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                         }
                         F3 o, d;
                         float tmax;
-                        camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
+                        const float pfx = float(px) + u0, pfy = float(py) + u1;
+                        camera_ray(S, pfx, pfy, l0, l1, &o, &d, &tmax);
                         B.hindex[slot] = idx;
+                        // the film position rides in the path's (not yet used) throughput record: the first k_shade
+                        // rebuilds the ray from it instead of evaluating the Halton dimensions again
+                        reinterpret_cast<float2 *>(&B.beta[slot])[0] = make_float2(pfx, pfy);
                         gen_d = make_float4(d.x, d.y, d.z, tmax);
                         trav_begin<COUNT>(S, t, o, d, tmax, &st);
                         active = true;
@@ -591,19 +595,16 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                 const float4 h4 = B.hits[slot];
                 if (bounce == 0 && P.gen_fused) {
                     // the camera ray again, as the first k_extend made it (queue 0 is dense: slot == path id)
-                    int cpx = 0, cpy = 0;
-                    uint32_t ck = 0;
-                    path_pixel(S, P, slot, &cpx, &cpy, &ck);
-                    const uint32_t cidx = B.hindex[slot];
-                    const float cu0 = sample_dimension(S, s_perms, cidx, 0), cu1 = sample_dimension(S, s_perms, cidx, 1);
+                    const float2 cpf = reinterpret_cast<const float2 *>(&B.beta[slot])[0];  // pFilm, left by k_extend
                     float cl0 = 0, cl1 = 0;
                     if (S.lens_radius > 0) {
+                        const uint32_t cidx = B.hindex[slot];
                         cl0 = sample_dimension(S, s_perms, cidx, 3);
                         cl1 = sample_dimension(S, s_perms, cidx, 4);
                     }
                     F3 co, cd;
                     float ctm;
-                    camera_ray(S, float(cpx) + cu0, float(cpy) + cu1, cl0, cl1, &co, &cd, &ctm);
+                    camera_ray(S, cpf.x, cpf.y, cl0, cl1, &co, &cd, &ctm);
                     o4 = make_float4(co.x, co.y, co.z, b2f(slot));
                     d4 = make_float4(cd.x, cd.y, cd.z, ctm);
                 } else {
