@@ -480,7 +480,10 @@ class Loader {
         } else if (d == "Accelerator") {  // accelerators/bvh.cpp:740-760
             if (name != "bvh") return fail("only Accelerator \"bvh\" is supported");
             s.accel_split = ps.one_string("splitmethod", "sah");
-            if (s.accel_split != "sah") return fail("only splitmethod \"sah\" is supported");
+            if (s.accel_split != "sah" && s.accel_split != "hlbvh" && s.accel_split != "middle" && s.accel_split != "equal") {
+                std::fprintf(stderr, "Warning: BVH split method \"%s\" unknown.  Using \"sah\".\n", s.accel_split.c_str());  // bvh.cpp:753-756
+                s.accel_split = "sah";
+            }
             s.max_node_prims = ps.one_int("maxnodeprims", 4);
         } else if (d == "Material") {
             int idx = make_material(name, ps);

@@ -631,3 +631,25 @@ def test_iispt_probe_pass_bitwise(binding, oracle, tmp_path):
     for j in range(40):
         assert_bitwise(i2[6 * j:6 * j + 6], ref[0], "probe intensities across passes")
         assert_bitwise(d2[6 * j:6 * j + 6], ref[2], "probe distances across passes")
+
+
+def test_other_bvh_split_methods_bitwise(binding, oracle):
+    """Trees of the other BVHAccel split methods ("middle", "equal", "hlbvh": leaves of more than four primitives,
+    a different shape of the upper tree): film and traversal counters bitwise equal to the oracle's walk of the same
+    tree, with the instrumented (binary) and the plain (four-wide) kernels."""
+    import os
+    src = open(binding.DEFAULT_SCENE).read()
+    for method in ("middle", "equal", "hlbvh"):
+        path = os.path.join(os.path.dirname(binding.DEFAULT_SCENE), f"_killeroo_gpu_{method}.pbrt")
+        open(path, "w").write(src.replace("WorldBegin", 'Accelerator "bvh" "string splitmethod" ["%s"] "integer maxnodeprims" [8]\nWorldBegin' % method, 1))
+        try:
+            scene = binding.HostScene(path=path, xres=128, yres=96, spp=2)
+        finally:
+            os.remove(path)
+        gpu = binding.GpuScene(scene)
+        film, st = gpu.render(collect_stats=True)
+        ref, ost = oracle.render(scene)
+        assert_bitwise(film, ref, f"{method}: film")
+        assert st["nodes_closest"] == ost["nodes_closest"] and st["nodes_any"] == ost["nodes_any"]
+        assert st["tri_tests"] == ost["tri_tests"] and st["closest_rays"] == ost["regular_rays"]
+        assert_bitwise(gpu.render()[0], ref, f"{method}: film, uninstrumented kernels")

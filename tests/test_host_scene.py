@@ -447,3 +447,50 @@ def test_mip_pyramid_follows_the_reference_constructor(binding, tmp_path):
     with pytest.raises(RuntimeError, match="Couldn't find float texture"):
         _texture_scene(tmp_path, binding, 'Texture "t" "spectrum" "imagemap" "string filename" ["p.pfm"]\n'
                        'Shape "trianglemesh" "point P" [0 0 1 1 0 1 0 1 1] "integer indices" [0 1 2] "texture alpha" ["t"]')
+
+
+def _bvh_invariants(scene):
+    h = head(scene)
+    n = h.n_nodes
+    nodes = np.ctypeslib.as_array(ctypes.cast(h.nodes, ctypes.POINTER(ctypes.c_uint8)), (n * 32,)).view(
+        np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("nprims", "<u2"), ("axis", "u1"), ("pad", "u1")]))
+    interior = nodes["nprims"] == 0
+    idx = np.arange(n)
+    assert (nodes["offset"][interior] > idx[interior] + 1).all() and (nodes["offset"][interior] < n).all()
+    assert (nodes["axis"][interior] < 3).all()
+    for child in (idx[interior] + 1, nodes["offset"][interior]):
+        assert (nodes["bmin"][child] >= nodes["bmin"][interior]).all() and (nodes["bmax"][child] <= nodes["bmax"][interior]).all()
+    leaves = nodes[~interior]
+    covered = np.zeros(h.n_prims, np.int32)
+    for off, cnt in zip(leaves["offset"], leaves["nprims"]):
+        covered[off:off + cnt] += 1
+    assert (covered == 1).all()
+    return int(interior.sum()), int((~interior).sum()), int(leaves["nprims"].max())
+
+
+def test_bvh_split_methods(binding, oracle, tmp_path):
+    """BVHAccel's other split methods (bvh.cpp:236-402 "middle" / "equal", :404-638 "hlbvh": Morton codes, the 6-bit
+    radix sort, LBVH treelets of the top 12 bits, SAH over the treelets; built in treelet order, as one thread does).
+    Every tree is a valid depth-first BVH over all primitives, and — since a closest hit does not depend on the tree
+    but for exact ties — all four render killeroo-simple to the same film as the SAH tree the reference's recorded
+    node counts pin."""
+    import os
+    src = open(binding.DEFAULT_SCENE).read()
+    assert "WorldBegin" in src
+    films, shape = {}, {}
+    for method in ("sah", "middle", "equal", "hlbvh"):
+        path = os.path.join(os.path.dirname(binding.DEFAULT_SCENE), f"_killeroo_{method}.pbrt")
+        open(path, "w").write(src.replace("WorldBegin", 'Accelerator "bvh" "string splitmethod" ["%s"]\nWorldBegin' % method, 1))
+        try:
+            scene = binding.HostScene(path=path, xres=96, yres=96, spp=2)
+        finally:
+            os.remove(path)
+        shape[method] = _bvh_invariants(scene)
+        films[method], _ = oracle.render(scene)
+    assert shape["sah"][:2] == (59188, 59189) and shape["sah"][2] <= 4
+    assert shape["equal"][2] <= 3 and shape["middle"][2] <= 3        # these split down to single primitives (or coincident centroids)
+    assert shape["hlbvh"][2] >= 2                                     # LBVH leaves hold up to maxnodeprims - 1 ... or a whole Morton cell
+    assert len({shape[m][:2] for m in shape}) == 4                    # four different trees
+    for method in ("middle", "equal", "hlbvh"):
+        same = films[method] == films["sah"]
+        assert same.mean() > 0.9999, (method, float(same.mean()))
