@@ -85,8 +85,8 @@ void oracle_bsdf_pdf_batch(const iile_scene_desc *scene, int trig_mode, int mat,
                            const float *wi3n, float *pdfn);
 /* One IISPT probe: HemisphericCamera at `pos` looking along `dir` rendered by IISPTdIntegrator::RenderView
  * (iispt_d.cpp, hemispheric.cpp, iisptrenderrunner.cpp:316-346) with scene->probe's film / sampler / depth. Outputs
- * [y][x] in raster coordinates: intensity (hemi^2 x 3), camera-space normals (x 3), distances. Returns 2 for scenes
- * with textured materials (the probe camera's differentials are not restated), 3 for a degenerate direction. */
+ * [y][x] in raster coordinates: intensity (hemi^2 x 3), camera-space normals (x 3), distances. Returns 3 for a
+ * degenerate direction. */
 int oracle_render_probe(const iile_scene_desc *scene, int trig_mode, const float *pos3, const float *dir3, float *intensity_rgb,
                         float *normals_xyz, float *distance);
 /* ImageTexture::Evaluate of texture `tex` at n (u, v) with differentials {dudx, dvdx, dudy, dvdy} */

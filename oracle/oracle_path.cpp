@@ -663,6 +663,24 @@ struct Oracle {
     float probe_aux[4] = {0, 0, 0, -1.f};  // camera-space normal and distance of the last camera ray's first hit
     Oracle(const iile_scene_desc &s, int mode, Counters *c) : S(s), trig{mode}, ctr(c) {}
 
+    // Camera::GenerateRayDifferential (camera.cpp:60-96) for the hemispheric camera: the rays through film points
+    // shifted by eps = 0.05 in x and in y, differenced (the render loop's ScaleDifferentials is by 1 / sqrt(1 spp))
+    RayDiff probe_differentials(float pfx, float pfy, const Ray &r) const {
+        RayDiff rd;
+        const float eps = .05f;  // `for (Float eps : {.05, -.05})`: the first shift always succeeds (weight 1)
+        Ray rx = probe_ray(pfx + eps, pfy), ry = probe_ray(pfx, pfy + eps);
+        rd.has = true;
+        rd.rxo = r.o + vdiv(rx.o - r.o, eps);
+        rd.rxd = r.d + vdiv(rx.d - r.d, eps);
+        rd.ryo = r.o + vdiv(ry.o - r.o, eps);
+        rd.ryd = r.d + vdiv(ry.d - r.d, eps);
+        const float sc = 1 / std::sqrt(float(S.halton.spp));
+        rd.rxo = r.o + (rd.rxo - r.o) * sc;
+        rd.ryo = r.o + (rd.ryo - r.o) * sc;
+        rd.rxd = r.d + (rd.rxd - r.d) * sc;
+        rd.ryd = r.d + (rd.ryd - r.d) * sc;
+        return rd;
+    }
     // HemisphericCamera::GenerateRay (hemispheric.cpp:15-41) + Transform::operator()(Ray) (transform.h:251-264)
     Ray probe_ray(float pfx, float pfy) const {
         float theta = Pi * pfy / float(probe->hemi_size);
@@ -2436,6 +2454,7 @@ struct Oracle {
         smp.get2d(plens);
         RayDiff rdiff;
         Ray ray = probe ? probe_ray(pfilm[0], pfilm[1]) : camera_ray(pfilm[0], pfilm[1], plens, S.n_textures > 0 ? &rdiff : nullptr);
+        if (probe && S.n_textures > 0) rdiff = probe_differentials(pfilm[0], pfilm[1], ray);
         ++ctr->camera_rays;
         Rgb L = li(ray, smp, rdiff, probe ? const_cast<float *>(probe_aux) : nullptr);
         if (L.has_nans())
@@ -2608,10 +2627,6 @@ int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, in
 int oracle_render_probe(const iile_scene_desc *scene, int trig_mode, const float *pos3, const float *dir3, float *intensity_rgb,
                         float *normals_xyz, float *distance) {
     if (!scene || !pos3 || !dir3) return 1;
-    for (int i = 0; i < scene->n_materials; ++i) {
-        const iile_material &m = scene->materials[i];
-        if (scene->n_textures > 0 && (m.kd_tex >= 0 || m.ks_tex >= 0 || m.kr_tex >= 0 || m.kt_tex >= 0 || m.bump_tex >= 0)) return 2;
-    }
     const iile_probe_setup &pr = scene->probe;
     ProbeCam cam;
     if (!make_probe_camera(pos3, dir3, pr.hemi_size, &cam)) return 3;

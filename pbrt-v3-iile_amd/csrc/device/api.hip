@@ -1033,8 +1033,6 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
     if (rc) return rc;
     const iile_probe_setup &pr = sc->probe;
     if (pr.hemi_size <= 0 || !sc->probe_pixel_offsets) return fail(IILE_ERR_ARG, "iile_render_probes: the scene has no probe setup");
-    if (sc->ds.textured_materials)
-        return fail(IILE_ERR_UNSUPPORTED, "iile_render_probes: image-textured materials (the probe camera's ray differentials) are not supported");
     if (pr.max_depth > 14) return fail(IILE_ERR_UNSUPPORTED, "probe maxdepth > 14");
     iile_stats st;
     std::memset(&st, 0, sizeof(st));
@@ -1060,6 +1058,7 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
     S.mult_inv0 = pr.mult_inverse[0], S.mult_inv1 = pr.mult_inverse[1];
     S.max_depth = pr.max_depth;
     S.lens_radius = 0;
+    S.diff_scale = 1.f;  // ScaleDifferentials(1 / sqrt(1 sample per pixel))
     const int need_dims = 5 + 8 * (pr.max_depth + 1) + 2;
     if (S.n_hdims < need_dims) return fail(IILE_ERR_ARG, "Halton table covers too few dimensions for the probe depth");
 

@@ -262,6 +262,25 @@ DEV RayDiff camera_differentials(const DScene &S, float pfx, float pfy, float lu
     r.ryd = d + (ryd - d) * sc;
     return r;
 }
+// Camera::GenerateRayDifferential (camera.cpp:60-96) for the hemispheric probe camera: the rays through the film
+// points shifted by eps = 0.05 in x and in y, differenced; then ScaleDifferentials as above
+DEV RayDiff probe_differentials(const DScene &S, const DProbeCam &cam, float pfx, float pfy, F3 o, F3 d) {
+    const float eps = .05f;
+    F3 xo, xd, yo, yd;
+    float tm;
+    probe_ray(S, cam, pfx + eps, pfy, &xo, &xd, &tm);
+    probe_ray(S, cam, pfx, pfy + eps, &yo, &yd, &tm);
+    const float inv = 1.f / eps;  // Vector3::operator/ multiplies by the reciprocal
+    const F3 rxo = o + (xo - o) * inv, rxd = d + (xd - d) * inv;
+    const F3 ryo = o + (yo - o) * inv, ryd = d + (yd - d) * inv;
+    const float sc = S.diff_scale;
+    RayDiff r;
+    r.rxo = o + (rxo - o) * sc;
+    r.ryo = o + (ryo - o) * sc;
+    r.rxd = d + (rxd - d) * sc;
+    r.ryd = d + (ryd - d) * sc;
+    return r;
+}
 
 // ===========================================================================
 // ray / primitive tests

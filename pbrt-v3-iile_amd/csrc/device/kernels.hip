@@ -685,7 +685,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                                     l0 = sample_dimension(S, s_perms, hidx, 3);
                                     l1 = sample_dimension(S, s_perms, hidx, 4);
                                 }
-                                const RayDiff rdiff = camera_differentials(S, float(px) + u0, float(py) + u1, l0, l1, ray_o, ray_d);
+                                const RayDiff rdiff =
+                                    S.probe_mode ? probe_differentials(S, P.probe_cams[(pid / uint32_t(P.kc)) / (256u * uint32_t(P.probe_tiles))],
+                                                                       float(px) + u0, float(py) + u1, ray_o, ray_d)
+                                                 : camera_differentials(S, float(px) + u0, float(py) + u1, l0, l1, ray_o, ray_d);
                                 td = compute_differentials(is, rdiff);
                             }
                             if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, &is);  // `if (bumpMap) Bump(bumpMap, si)` comes first

@@ -601,10 +601,13 @@ def test_iispt_probe_pass_bitwise(binding, oracle, tmp_path):
 
     path = tmp_path / "room_multi.pbrt"
     path.write_text(boxroom.boxroom_pbrt(xres=32, yres=32, spp=1, light="multi", materials="mixed"))
+    path_tex = tmp_path / "room_tex.pbrt"   # image textures, bump maps, alpha masks: the probe camera's own ray differentials
+    path_tex.write_text(boxroom.boxroom_pbrt(xres=32, yres=32, spp=1, textures=str(tmp_path / "img")))
     cases = [("killeroo-simple", binding.HostScene(xres=64, yres=64, spp=1), probes(6, (-150, -100, -130), (250, 150, 0))),
              ("point furnace", binding.HostScene(path=os.path.join(gold, "furnace_point.pbrt")), probes(5, -0.4, 0.4)),
              ("sky furnace", binding.HostScene(path=os.path.join(gold, "furnace_sky.pbrt")), probes(5, (-3, -3, 1.2), (3, 3, 3))),
-             ("box room, three lights", binding.HostScene(path=str(path)), probes(8, (-8, -8, -2), (8, 8, 8)))]
+             ("box room, three lights", binding.HostScene(path=str(path)), probes(8, (-8, -8, -2), (8, 8, 8))),
+             ("textured box room", binding.HostScene(path=str(path_tex)), probes(8, (-8, -8, -2), (8, 8, 8)))]
     for name, scene, (pos, d) in cases:
         gpu = binding.GpuScene(scene)
         inten, nrm, dist, st = gpu.render_probes(pos, d)
