@@ -492,7 +492,9 @@ def test_film_1080p_bitwise_vs_oracle(binding, oracle):
     gpu64 = binding.GpuScene(scene64)
     one, st1 = gpu64.render()
     eight, st8 = gpu64.render(spp_per_pass=8)
-    assert st1["n_passes"] == 1 and st8["n_passes"] == 8
+    import os
+    if "IILE_WORKSPACE_MB" not in os.environ:  # (a small workspace splits both renders further)
+        assert st1["n_passes"] == 1 and st8["n_passes"] == 8
     assert_bitwise(eight, one, "1080p x 64 spp, eight passes vs one")
 
 
