@@ -173,9 +173,14 @@ typedef struct iile_halton {
 } iile_halton;
 
 /* PathIntegrator knobs (src/integrators/path.cpp:214-231). */
+#define IILE_LIGHTS_SPATIAL 0 /* SpatialLightDistribution, the default (lightdistrib.cpp:91-299) */
+#define IILE_LIGHTS_UNIFORM 1 /* UniformLightDistribution (lightdistrib.cpp:65-72) */
+#define IILE_LIGHTS_POWER 2   /* PowerLightDistribution over Light::Power().y() (integrator.cpp:217-225) */
 typedef struct iile_integrator {
     int32_t max_depth;
     float rr_threshold;
+    int32_t light_strategy;             /* "lightsamplestrategy" of the path integrator (path.cpp:231), IILE_LIGHTS_* */
+    float light_power[IILE_MAX_LIGHTS]; /* power strategy: Power().y() of every light */
 } iile_integrator;
 
 /* The IISPT probe pass: what IISPTdIntegrator::RenderView renders from a HemisphericCamera

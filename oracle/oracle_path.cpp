@@ -2091,7 +2091,20 @@ struct Oracle {
         else
             for (int i = 1; i < n + 1; ++i) d.cdf[i] /= d.func_int;
     }
-    const LightDist &light_distribution(V3 p) const {  // SpatialLightDistribution::Lookup, lightdistrib.cpp:134-226
+    mutable LightDist fixed_dist;  // UniformLightDistribution / PowerLightDistribution: one Distribution1D for every point
+    mutable bool fixed_dist_ready = false;
+    const LightDist &light_distribution(V3 p) const {  // LightDistribution::Lookup
+        if (S.integrator.light_strategy != IILE_LIGHTS_SPATIAL) {  // lightdistrib.cpp:65-82, integrator.cpp:217-225
+            if (!fixed_dist_ready) {
+                fixed_dist.n = S.n_lights;
+                for (int i = 0; i < S.n_lights; ++i)
+                    fixed_dist.func[i] = S.integrator.light_strategy == IILE_LIGHTS_UNIFORM ? 1.f : S.integrator.light_power[i];
+                finish_distribution(&fixed_dist);
+                fixed_dist_ready = true;
+            }
+            return fixed_dist;
+        }
+        // SpatialLightDistribution::Lookup, lightdistrib.cpp:134-226
         V3 bmin, bmax;
         int nv[3];
         light_grid(&bmin, &bmax, nv);

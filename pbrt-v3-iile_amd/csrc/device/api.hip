@@ -756,7 +756,24 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     // every voxel of its grid — up to 64 per axis, cubes along the longest one.
     S.light_dist = nullptr;
     S.light_nv[0] = S.light_nv[1] = S.light_nv[2] = 1;
-    if (d->n_lights > 1 && d->n_nodes > 0) {
+    if (d->n_lights > 1 && d->integrator.light_strategy != IILE_LIGHTS_SPATIAL) {
+        // UniformLightDistribution / PowerLightDistribution (lightdistrib.cpp:65-82, integrator.cpp:217-225): one
+        // Distribution1D for every point — a grid of a single voxel, built here (sampling.h:57-69)
+        std::vector<float> tab(size_t(kLightDistStride), 0.f);
+        const int n = d->n_lights;
+        float *func = tab.data(), *cdf = tab.data() + kMaxLights;
+        for (int i = 0; i < n; ++i) func[i] = d->integrator.light_strategy == IILE_LIGHTS_UNIFORM ? 1.f : d->integrator.light_power[i];
+        cdf[0] = 0;
+        for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / n;
+        const float func_int = cdf[n];
+        if (func_int == 0)
+            for (int i = 1; i < n + 1; ++i) cdf[i] = float(i) / float(n);
+        else
+            for (int i = 1; i < n + 1; ++i) cdf[i] /= func_int;
+        tab[2 * kMaxLights + 1] = func_int;
+        rc = upload(sc, tab.data(), tab.size(), &S.light_dist);
+        if (rc) return bail(rc);
+    } else if (d->n_lights > 1 && d->n_nodes > 0) {
         const float diag[3] = {S.root_box[3] - S.root_box[0], S.root_box[4] - S.root_box[1], S.root_box[5] - S.root_box[2]};
         const int me = (diag[0] > diag[1] && diag[0] > diag[2]) ? 0 : (diag[1] > diag[2] ? 1 : 2);  // MaximumExtent
         const float bmax = diag[me];

@@ -75,6 +75,7 @@ constexpr int kMaxHaltonDims = 128;
 constexpr int kMaxSpheres = 8;
 constexpr int kMaxMaterials = 64;
 constexpr int kMaxLights = 8;
+constexpr int kLightDistStride = 2 * kMaxLights + 2;  // a light distribution: func[kMaxLights], cdf[kMaxLights + 1], funcInt
 
 // One IISPT probe camera (HemisphericCamera, hemispheric.cpp:109-160): CameraToWorld and the rows that transform a
 // world normal into the camera's frame (transpose of WorldToCamera's mInv, transform.h:243-249)

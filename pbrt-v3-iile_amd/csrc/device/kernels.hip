@@ -389,7 +389,6 @@ DEV F3 light_L(const DLight &lt, F3 n, F3 w) {
 // integrator picks the light to sample from a per-voxel distribution. The reference fills a
 // hash table lazily; a voxel's distribution is a pure function of its index, so all of them are
 // tabulated once at scene creation (k_light_distributions) and looked up densely.
-constexpr int kLightDistStride = 2 * kMaxLights + 2;  // func[kMaxLights], cdf[kMaxLights + 1], funcInt
 // Light::Sample_Li at an Interaction without normal or error bounds (lightdistrib.cpp:258-262)
 DEV F3 sample_li_plain(const DScene &S, const DLight &lt, F3 po, float u0, float u1, float *pdf) {
     const F3 pos = F3{lt.pos[0], lt.pos[1], lt.pos[2]};

@@ -265,6 +265,41 @@ bool finalize_scene(HostScene *s, std::string *err) {
 
     d.integrator.max_depth = s->max_depth;
     d.integrator.rr_threshold = s->rr_threshold;
+    d.integrator.light_strategy = s->light_strategy == "uniform" ? IILE_LIGHTS_UNIFORM : (s->light_strategy == "power" ? IILE_LIGHTS_POWER : IILE_LIGHTS_SPATIAL);
+    // Light::Power().y() of every light (ComputeLightPowerDistribution, integrator.cpp:217-225)
+    for (int i = 0; i < IILE_MAX_LIGHTS; ++i) d.integrator.light_power[i] = 0;
+    for (size_t i = 0; i < s->lights.size() && i < size_t(IILE_MAX_LIGHTS); ++i) {
+        const iile_light &lt = s->lights[i];
+        float pw[3] = {0, 0, 0};
+        const float wr = lt.world_radius;
+        for (int c = 0; c < 3; ++c) {
+            const float L = lt.lemit[c];
+            switch (lt.type) {
+            case IILE_LIGHT_DIFFUSE_AREA: {  // diffuse.cpp:64-66 with Sphere::Area (sphere.cpp:217)
+                const iile_sphere &sp = s->spheres[size_t(lt.sphere)];
+                const float area = sp.phi_max * sp.radius * (sp.zmax - sp.zmin);
+                pw[c] = (lt.two_sided ? 2 : 1) * L * area * kPi;
+                break;
+            }
+            case IILE_LIGHT_AREA_TRIANGLE: {  // Triangle::Area, triangle.cpp:546-552
+                const float *tp = &s->o_tri_p[9 * size_t(lt.prim)];
+                const V3 p0(tp[0], tp[1], tp[2]), p1(tp[3], tp[4], tp[5]), p2(tp[6], tp[7], tp[8]);
+                const float area = float(0.5 * length(cross(p1 - p0, p2 - p0)));
+                pw[c] = (lt.two_sided ? 2 : 1) * L * area * kPi;
+                break;
+            }
+            case IILE_LIGHT_POINT: pw[c] = 4 * kPi * L; break;  // point.cpp:55
+            case IILE_LIGHT_SPOT: pw[c] = L * 2 * kPi * (1 - .5f * (lt.cos_falloff_start + lt.cos_total_width)); break;  // spot.cpp:75-77
+            case IILE_LIGHT_DISTANT: pw[c] = L * kPi * wr * wr; break;  // distant.cpp:61-63
+            default: {  // infinite.cpp:86-90: Pi r^2 * Lmap->Lookup((.5, .5), .5)
+                float rgb[3];
+                mip_lookup_width(s->textures[size_t(lt.env_tex)], .5f, .5f, .5f, rgb);
+                pw[c] = kPi * wr * wr * rgb[c];
+            }
+            }
+        }
+        d.integrator.light_power[i] = 0.212671f * pw[0] + 0.715160f * pw[1] + 0.072169f * pw[2];
+    }
 
     // IISPT probe pass: CreateHemisphericCamera's film (hemispheric.cpp:131-147) and CreateIISPTdIntegrator's
     // sampler and depth (iispt_d.cpp:492-527)

@@ -58,6 +58,7 @@ struct HostScene {
     std::string integrator_name = "path";
     int max_depth = 5;
     float rr_threshold = 1.f;
+    std::string light_strategy = "spatial";
     std::string accel_split = "sah";
     int max_node_prims = 4;
 
@@ -98,6 +99,8 @@ bool image_is_8bit(const std::string &path);
 // mipmap.cpp
 bool build_image_texture(const std::vector<float> &rgb, int width, int height, float scale, bool gamma, bool as_float,
                          HostTexture *out, std::string *err);
+// MIPMap::Lookup(st, width) (trilinear, mipmap.h:233-250) on a built pyramid
+void mip_lookup_width(const HostTexture &t, float s, float tt, float width, float rgb[3]);
 // MIPMap's constructor alone on prepared texels (row-major, width x height RGB), wrap mode from out->t.wrap
 bool build_mip_pyramid(const std::vector<float> &rgb, int width, int height, HostTexture *out, std::string *err);
 // InfiniteAreaLight's constructor (infinite.cpp:42-84): Lmap from `rgb` (already times L) into `tex`, the

@@ -244,6 +244,11 @@ void dist1d(const float *f, int n, float *out) {
 }
 }  // namespace
 
+void mip_lookup_width(const HostTexture &t, float s, float tt, float width, float rgb[3]) {
+    const Rgb3 c = pyr_lookup(t, s, tt, width);
+    for (int i = 0; i < 3; ++i) rgb[i] = c.c[i];
+}
+
 bool build_environment_light(const std::vector<float> &rgb, int width, int height, HostTexture *tex, std::vector<float> *dist,
                              int *dist_w, int *dist_h, int64_t *dist_offset, std::string *err) {
     std::memset(&tex->t, 0, sizeof(tex->t));  // MIPMap defaults: EWA, maxAniso 8, repeat (mipmap.h:66-67)

@@ -476,6 +476,12 @@ class Loader {
             if (name != "path") return fail("only Integrator \"path\" is supported, got " + name);
             s.max_depth = ps.one_int("maxdepth", 5);
             s.rr_threshold = ps.one_float("rrthreshold", 1.);
+            s.light_strategy = ps.one_string("lightsamplestrategy", "spatial");
+            if (s.light_strategy != "spatial" && s.light_strategy != "uniform" && s.light_strategy != "power") {
+                // CreateLightSampleDistribution, lightdistrib.cpp:58-63
+                std::fprintf(stderr, "Error: Light sample distribution type \"%s\" unknown. Using \"spatial\".\n", s.light_strategy.c_str());
+                s.light_strategy = "spatial";
+            }
             if (ps.find("pixelbounds")) return fail("pixelbounds is not supported");
         } else if (d == "Accelerator") {  // accelerators/bvh.cpp:740-760
             if (name != "bvh") return fail("only Accelerator \"bvh\" is supported");

@@ -412,7 +412,13 @@ def test_several_lights_bitwise(binding, oracle, tmp_path):
     path2.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="quad"))
     panel = binding.HostScene(path=str(path2))
     assert panel.info["n_lights"] == 3
-    for name, scene in (("furnace", furnace), ("boxroom", room), ("tetrahedron", tetra), ("panel", panel)):
+    # the other light sample strategies (path.cpp:231): one Distribution1D for the whole scene
+    others = []
+    for strategy in ("uniform", "power"):
+        p3 = tmp_path / f"boxroom_multi_{strategy}.pbrt"
+        p3.write_text(path.read_text().replace('Integrator "path"', 'Integrator "path" "string lightsamplestrategy" ["%s"]' % strategy))
+        others.append((f"boxroom, {strategy} light sampling", binding.HostScene(path=str(p3))))
+    for name, scene in [("furnace", furnace), ("boxroom", room), ("tetrahedron", tetra), ("panel", panel)] + others:
         gpu = binding.GpuScene(scene)
         film, st = gpu.render(collect_stats=True)
         ref, ost = oracle.render(scene)

@@ -824,3 +824,28 @@ def test_distribution1d_like_the_reference_tests(oracle):
         assert oracle.distribution1d(ones, i / 8)[0] == i and oracle.distribution1d(ones, (i + .5) / 8)[0] == i
         if i > 0:
             assert oracle.distribution1d(ones, (i - .5) / 8)[0] == i - 1
+
+
+def test_light_sample_strategies_are_unbiased(binding, oracle, tmp_path):
+    """"lightsamplestrategy" of the path integrator (path.cpp:231; lightdistrib.cpp:47-82, integrator.cpp:217-225):
+    the reference's four-point-light analytic scene, with the total intensity pi split unevenly (1/8, 1/8, 1/4, 1/2)
+    so that "power" samples the lights 1:1:2:4, must still show radiance 1.0 +- 0.02 under every strategy."""
+    import os
+    src = open(os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_4points.pbrt")).read()
+    lines = src.split("\n")
+    shares, k = [1 / 8, 1 / 8, 1 / 4, 1 / 2], 0
+    for i, line in enumerate(lines):
+        if line.startswith("LightSource"):
+            v = np.float32(np.pi * shares[k])
+            lines[i] = 'LightSource "point" "color I" [%.9g %.9g %.9g]' % (v, v, v)
+            k += 1
+    assert k == 4
+    films = {}
+    for strategy in ("spatial", "uniform", "power"):
+        text = "\n".join(lines).replace('Integrator "path"', 'Integrator "path" "string lightsamplestrategy" ["%s"]' % strategy)
+        (tmp_path / f"{strategy}.pbrt").write_text(text)
+        scene = binding.HostScene(path=str(tmp_path / f"{strategy}.pbrt"))
+        film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+        films[strategy] = film
+        assert abs(float(scene.film_to_rgb(film).mean(dtype=np.float64)) - 1.0) < 0.02, strategy
+    assert not np.array_equal(films["uniform"], films["power"]) and not np.array_equal(films["uniform"], films["spatial"])
