@@ -170,6 +170,7 @@ typedef struct iile_halton {
     const int32_t *primes;     /* [n_dims] */
     const int32_t *prime_sums; /* [n_dims] */
     int32_t n_perms;           /* total u16 entries */
+    int32_t sample_at_pixel_center; /* "samplepixelcenter": dimensions 0 and 1 are 0.5 (halton.cpp:119) */
 } iile_halton;
 
 /* PathIntegrator knobs (src/integrators/path.cpp:214-231). */

@@ -770,6 +770,7 @@ struct Oracle {
     }
     float sample_dimension(int64_t index, int dim) const {
         const iile_halton &h = S.halton;
+        if (h.sample_at_pixel_center && (dim == 0 || dim == 1)) return 0.5f;  // halton.cpp:119
         if (dim == 0) return radical_inverse(0, 2, uint64_t(index >> h.base_exponents[0]));
         if (dim == 1) return radical_inverse(1, 3, uint64_t(index / h.base_scales[1]));
         return scrambled_radical_inverse(h.primes[dim], h.perms + h.prime_sums[dim], uint64_t(index));
@@ -2648,6 +2649,7 @@ int oracle_render_probe(const iile_scene_desc *scene, int trig_mode, const float
     sp.film_filter_wide = 1;
     std::memcpy(sp.film_filter_table, pr.filter_table, sizeof(pr.filter_table));
     sp.halton.spp = 1;
+    sp.halton.sample_at_pixel_center = 0;  // HaltonSampler(1, sampleBounds): the default
     for (int i = 0; i < 2; ++i) {
         sp.halton.base_scales[i] = pr.base_scales[i];
         sp.halton.base_exponents[i] = pr.base_exponents[i];

@@ -669,6 +669,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         S.sample_stride = h.sample_stride;
         S.mult_inv0 = h.mult_inverse[0];
         S.mult_inv1 = h.mult_inverse[1];
+        S.sample_center = h.sample_at_pixel_center;
         sc->spp = h.spp;
         // HaltonSampler::GetIndexForSample's per-pixel offset (halton.cpp:96-122) depends only on
         // the pixel modulo kMaxResolution = 128: tabulated once (integer arithmetic, exact)
@@ -1074,6 +1075,7 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
     S.sample_stride = pr.sample_stride;
     S.mult_inv0 = pr.mult_inverse[0], S.mult_inv1 = pr.mult_inverse[1];
     S.max_depth = pr.max_depth;
+    S.sample_center = 0;  // the probes' own sampler: HaltonSampler(1, sampleBounds)
     S.lens_radius = 0;
     S.diff_scale = 1.f;  // ScaleDifferentials(1 / sqrt(1 sample per pixel))
     const int need_dims = 5 + 8 * (pr.max_depth + 1) + 2;

@@ -128,6 +128,7 @@ DEV void scrambled_radical_inverse_n(const DScene &S, PermPtr perms, int dim0, u
 }
 template <typename PermPtr>
 DEV float sample_dimension(const DScene &S, PermPtr perms, uint32_t index, int dim) {
+    if (S.sample_center && dim < 2) return 0.5f;  // "samplepixelcenter", halton.cpp:119
     if (dim == 0) return radical_inverse_base2(index >> S.base_exp0);
     if (dim == 1) return radical_inverse_base3(index / uint32_t(S.base_scale1));
     return scrambled_radical_inverse(S, perms, dim, index);

@@ -133,6 +133,7 @@ struct DScene {
     const float *filter_table;   // Film::filterTable, 16 x 16
     // halton
     int base_scale0, base_scale1, base_exp0, base_exp1, sample_stride, mult_inv0, mult_inv1;
+    int sample_center;  // dimensions 0 and 1 of every sample are 0.5
     // integrator
     int max_depth;
     float rr_threshold;

@@ -262,6 +262,7 @@ bool finalize_scene(HostScene *s, std::string *err) {
     h.primes = s->primes.data();
     h.prime_sums = s->prime_sums.data();
     h.n_perms = int(s->perms.size());
+    h.sample_at_pixel_center = s->sample_at_pixel_center ? 1 : 0;
 
     d.integrator.max_depth = s->max_depth;
     d.integrator.rr_threshold = s->rr_threshold;

@@ -55,6 +55,7 @@ struct HostScene {
     float filter_p0 = 0.f, filter_p1 = 0.f;  // gaussian: alpha; mitchell: B, C; sinc: tau
     std::string sampler_name = "halton";
     int spp = 16;
+    bool sample_at_pixel_center = false;
     std::string integrator_name = "path";
     int max_depth = 5;
     float rr_threshold = 1.f;

@@ -448,7 +448,7 @@ class Loader {
             if (name != "halton") return fail("only Sampler \"halton\" is supported, got " + name);
             s.sampler_name = name;
             s.spp = ps.one_int("pixelsamples", 16);
-            if (ps.one_bool("samplepixelcenter", false)) return fail("samplepixelcenter is not supported");
+            s.sample_at_pixel_center = ps.one_bool("samplepixelcenter", false);
         } else if (d == "PixelFilter") {  // MakeFilter, api.cpp:855-874; Create*Filter in src/filters/*.cpp
             s.filter_name = name;
             if (name == "box") {

@@ -572,11 +572,17 @@ def test_wide_pixel_filters_bitwise(binding, oracle, tmp_path):
         assert st["camera_rays"] == ost["camera_rays"]
         assert_bitwise(film, ref, f"{line}: film")
         assert_bitwise(gpu.render(spp_per_pass=3)[0], ref, f"{line}: film in two passes")
-    for line in (FILTERS[0], FILTERS[3], FILTERS[4]):
+    for line in (FILTERS[0], FILTERS[3], FILTERS[4], 'Sampler "halton" "bool samplepixelcenter" ["true"] "integer pixelsamples" [3]\nPixelFilter "triangle"',
+                 'Sampler "halton" "bool samplepixelcenter" ["true"] "integer pixelsamples" [2]'):
         path = tmp_path / "room_filter.pbrt"
         text = boxroom.boxroom_pbrt(xres=96, yres=64, spp=4)
         assert 'Sampler "halton"' in text
-        path.write_text(text.replace('Sampler "halton"', line + '\nSampler "halton"'))
+        if line.startswith("Sampler"):  # every sample through its pixel's centre (halton.cpp:119), box and wide filter
+            text = text.replace('Sampler "halton" "integer pixelsamples" [4]', line)
+            assert "samplepixelcenter" in text
+            path.write_text(text)
+        else:
+            path.write_text(text.replace('Sampler "halton"', line + '\nSampler "halton"'))
         scene = binding.HostScene(path=str(path))
         gpu = binding.GpuScene(scene)
         ref, _ = oracle.render(scene)
