@@ -4,12 +4,14 @@
 // There is no CPU fallback anywhere in this file: every compute entry point
 // needs a HIP device and fails loudly without one.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <limits>
+#include <map>
 #include <vector>
 
 #include "../../../include/iile_gpu.h"
@@ -59,6 +61,10 @@ struct iile_scene {
     iile_probe_setup probe;
     const uint32_t *probe_pixel_offsets = nullptr;
     const float *probe_filter_table = nullptr;
+    uint32_t *flag_count = nullptr;  // whole-number film positions (PassBuffers::flag_count / flag_rec)
+    float *flag_rec = nullptr;
+    float *flag_host = nullptr;      // pinned staging for the records (count first)
+    size_t flag_host_floats = 0;
     void *probe_block = nullptr;  // cameras + aux + outputs of the last probe batch
     size_t probe_block_bytes = 0;
     void *film_block = nullptr;
@@ -753,6 +759,13 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     }
     if (hipEventCreate(&sc->ev_begin) != hipSuccess || hipEventCreate(&sc->ev_end) != hipSuccess)
         return bail(fail(IILE_ERR_HIP, "hipEventCreate failed"));
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, 256 + size_t(kMaxFlagged) * 6 * sizeof(float)) != hipSuccess) return bail(fail(IILE_ERR_HIP, "hipMalloc(flag records) failed"));
+        sc->allocs.push_back(p);
+        sc->flag_count = static_cast<uint32_t *>(p);
+        sc->flag_rec = reinterpret_cast<float *>(static_cast<char *>(p) + 256);
+    }
     // More than one light: tabulate the spatial light distribution (lightdistrib.cpp:91-299) for
     // every voxel of its grid — up to 64 per axis, cubes along the longest one.
     S.light_dist = nullptr;
@@ -833,6 +846,7 @@ void iile_scene_destroy(iile_scene *sc) {
     if (sc->ws_block) (void)hipFree(sc->ws_block);
     if (sc->film_block) (void)hipFree(sc->film_block);
     if (sc->wide_block) (void)hipFree(sc->wide_block);
+    if (sc->flag_host) (void)hipHostFree(sc->flag_host);
     if (sc->probe_block) (void)hipFree(sc->probe_block);
     if (sc->nray_buf) (void)hipFree(sc->nray_buf);
     for (EventPair &e : sc->events) {
@@ -843,6 +857,285 @@ void iile_scene_destroy(iile_scene *sc) {
     if (sc->ev_end) (void)hipEventDestroy(sc->ev_end);
     delete sc;
 }
+
+namespace {
+// The one-pixel box film's exact finish. k_film_accumulate / k_film_resolve give every pixel the sum of its own
+// samples (plus the k = 0 zero-offset splats) — all there is unless a sample's film position is a whole number, when
+// FilmTile::AddSample (film.h:159-188) also adds it to a neighbouring pixel, in sample order inside its tile. The
+// generation code listed those samples (rare: ~1e-4 of them where pixel coordinates pass 1024); here every pixel
+// they touch is recomputed the way the reference sums it: per contributing tile, own samples and neighbours'
+// samples merged in generation order (pixel-major, then k), tiles added in index order (MergeFilmTile, film.cpp:135-148;
+// the reference merges in completion order, the oracle and this in index order). Radiances come from re-rendering
+// the few paths involved through the explicit-list pass (bitwise the same values).
+struct Flagged {
+    int px, py, k;
+    float pfx, pfy;
+    uint32_t pid;
+    int tile, pix;  // tile index and row-major pixel rank inside the tile: generation order = (tile, pix, k)
+};
+// `single_pass`: the frame was one pass, so every sample's radiance still sits in the pass buffer (L[path id]) and is
+// gathered from there; otherwise the few paths involved are rendered again through the explicit-list pass (bitwise the
+// same values). `pid_of_own`: path id of sample (pixel slot, k) in that single pass.
+int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &Pf, int k_begin, int k_end, bool single_pass,
+                               float4 *film_dev, uint64_t *n_patched) {
+    uint32_t n_flag = 0;
+    HIP_TRY(hipMemcpy(&n_flag, sc->flag_count, sizeof(n_flag), hipMemcpyDeviceToHost));
+    *n_patched = 0;
+    const bool dbg = std::getenv("IILE_PATCH_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[patch] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
+    if (n_flag == 0) return IILE_OK;
+    if (n_flag > kMaxFlagged) return fail(IILE_ERR_UNSUPPORTED, "more than 2^20 camera samples with whole-number film positions in one render");
+    if (sc->flag_host_floats < size_t(n_flag) * 6) {  // pinned: a pageable copy of this size stalls for milliseconds now and then
+        if (sc->flag_host) (void)hipHostFree(sc->flag_host);
+        sc->flag_host = nullptr;
+        sc->flag_host_floats = 0;
+        void *hp = nullptr;
+        const size_t want = std::max<size_t>(size_t(n_flag) * 6 * 2, 1 << 16);
+        HIP_TRY(hipHostMalloc(&hp, want * sizeof(float), hipHostMallocDefault));
+        sc->flag_host = static_cast<float *>(hp);
+        sc->flag_host_floats = want;
+    }
+    HIP_TRY(hipMemcpy(sc->flag_host, sc->flag_rec, size_t(n_flag) * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    const float *rec = sc->flag_host;
+    lap("download records");
+    const int ntx = Pf.n_tiles_x;
+    auto tile_of = [&](int x, int y, int *pix) {
+        const int tx = (x - S.samp_x0) / 16, ty = (y - S.samp_y0) / 16;
+        *pix = (y - S.samp_y0 - ty * 16) * 16 + (x - S.samp_x0 - tx * 16);
+        return ty * ntx + tx;
+    };
+    auto owned = [&](int tile) { return tile % Pf.tile_nranks == Pf.tile_rank; };
+    std::vector<Flagged> fl(n_flag);
+    for (uint32_t i = 0; i < n_flag; ++i) {
+        uint32_t u[6];
+        std::memcpy(u, rec + 6 * size_t(i), sizeof(u));
+        Flagged &f = fl[i];
+        f.px = int(u[0]), f.py = int(u[1]), f.k = int(u[2]);
+        f.pfx = rec[6 * size_t(i) + 3], f.pfy = rec[6 * size_t(i) + 4];
+        f.pid = u[5];
+        f.tile = tile_of(f.px, f.py, &f.pix);
+    }
+    {  // generation order: one 64-bit key per sample
+        std::vector<std::pair<uint64_t, uint32_t>> keys(n_flag);
+        for (uint32_t i = 0; i < n_flag; ++i)
+            keys[i] = {(uint64_t(uint32_t(fl[i].tile)) << 40) | (uint64_t(uint32_t(fl[i].pix)) << 32) | uint64_t(uint32_t(fl[i].k)), i};
+        std::sort(keys.begin(), keys.end());
+        std::vector<Flagged> sorted(n_flag);
+        for (uint32_t i = 0; i < n_flag; ++i) sorted[i] = fl[keys[i].second];
+        fl.swap(sorted);
+    }
+    lap("sort samples");
+    // (destination pixel, flagged sample of another pixel that lands in it), by destination, generation order kept
+    const int fw = S.crop_x1 - S.crop_x0;
+    std::vector<std::pair<uint32_t, int>> hits;  // sorted as pairs: by destination, then by (ascending = generation order) sample index
+    hits.reserve(size_t(n_flag) * 2);
+    const float r = 0.5f;
+    for (int i = 0; i < int(fl.size()); ++i) {
+        const Flagged &f = fl[i];
+        const int tx = f.tile % ntx, ty = f.tile / ntx;
+        const int sx0 = S.samp_x0 + tx * 16, sy0 = S.samp_y0 + ty * 16;
+        const int sx1 = std::min(sx0 + 16, S.samp_x1), sy1 = std::min(sy0 + 16, S.samp_y1);
+        // Film::GetFilmTile bounds of the sample's tile, film.cpp:92-103
+        const int fx0 = std::max(int(std::ceil(float(sx0) - 0.5f - r)), S.crop_x0), fx1 = std::min(int(std::floor(float(sx1) - 0.5f + r)) + 1, S.crop_x1);
+        const int fy0 = std::max(int(std::ceil(float(sy0) - 0.5f - r)), S.crop_y0), fy1 = std::min(int(std::floor(float(sy1) - 0.5f + r)) + 1, S.crop_y1);
+        const float dxf = f.pfx - 0.5f, dyf = f.pfy - 0.5f;
+        const int ax0 = std::max(int(std::ceil(dxf - r)), fx0), ax1 = std::min(int(std::floor(dxf + r)) + 1, fx1);
+        const int ay0 = std::max(int(std::ceil(dyf - r)), fy0), ay1 = std::min(int(std::floor(dyf + r)) + 1, fy1);
+        for (int y = ay0; y < ay1; ++y)
+            for (int x = ax0; x < ax1; ++x)
+                if (x != f.px || y != f.py) hits.emplace_back(uint32_t(y - S.crop_y0) * uint32_t(fw) + uint32_t(x - S.crop_x0), i);
+    }
+    if (hits.empty()) return IILE_OK;
+    lap("destinations");
+    std::sort(hits.begin(), hits.end());
+    lap("records + destinations");
+    // which radiances are needed: every flagged sample that lands somewhere else, and all own samples of a pixel that
+    // receives from a pixel generated before it in its own tile
+    struct Dest {
+        uint32_t film_index;
+        int qx, qy, tile, pix;
+        bool in_bounds, need_own;
+        uint32_t own_slot;     // index into tile_rgbw
+        size_t first, last;    // its range of `hits`
+        size_t own_first;      // first of its own samples in the list
+    };
+    std::vector<Dest> dests;
+    const int n_k = k_end - k_begin;
+    std::vector<uint32_t> list_pid;                  // single pass: path ids to gather
+    std::vector<int> lpx, lpy, lk;                   // otherwise: samples to render again
+    std::vector<int> list_of_flag(fl.size(), -1);
+    size_t n_list = 0;
+    for (size_t a = 0; a < hits.size();) {
+        size_t b = a;
+        while (b < hits.size() && hits[b].first == hits[a].first) ++b;
+        Dest d;
+        d.film_index = hits[a].first;
+        d.first = a, d.last = b;
+        d.qx = S.crop_x0 + int(d.film_index % uint32_t(fw));
+        d.qy = S.crop_y0 + int(d.film_index / uint32_t(fw));
+        d.in_bounds = d.qx >= S.samp_x0 && d.qx < S.samp_x1 && d.qy >= S.samp_y0 && d.qy < S.samp_y1;
+        d.tile = d.in_bounds ? tile_of(d.qx, d.qy, &d.pix) : -1;
+        if (d.in_bounds && !owned(d.tile)) d.in_bounds = false;
+        d.need_own = false;
+        d.own_slot = d.in_bounds ? uint32_t(d.tile / Pf.tile_nranks) * 256u + uint32_t(d.pix) : 0u;
+        d.own_first = 0;
+        for (size_t h = a; h < b; ++h) {
+            const int i = hits[h].second;
+            if (list_of_flag[i] < 0) {
+                list_of_flag[i] = int(n_list++);
+                if (single_pass)
+                    list_pid.push_back(fl[i].pid);
+                else
+                    lpx.push_back(fl[i].px), lpy.push_back(fl[i].py), lk.push_back(fl[i].k);
+            }
+            if (d.in_bounds && fl[i].tile == d.tile && fl[i].pix < d.pix) d.need_own = true;
+        }
+        dests.push_back(d);
+        a = b;
+    }
+    for (Dest &d : dests)
+        if (d.need_own) {
+            d.own_first = n_list;
+            n_list += size_t(n_k);
+            for (int k = 0; k < n_k; ++k) {
+                if (single_pass)
+                    list_pid.push_back(d.own_slot * uint32_t(n_k) + uint32_t(k));  // pid = pixel slot * kc + kk
+                else
+                    lpx.push_back(d.qx), lpy.push_back(d.qy), lk.push_back(k_begin + k);
+            }
+        }
+    lap("lists");
+    if (dbg) std::fprintf(stderr, "[patch] %u flagged samples, %zu pixels to finish, %zu radiances needed (%s)\n", n_flag, dests.size(), n_list, single_pass ? "gathered" : "rendered again");
+    // own sums of the pixels that keep them ride at the end of the same gather
+    std::vector<uint32_t> own_idx;
+    for (const Dest &d : dests)
+        if (d.in_bounds && !d.need_own) own_idx.push_back(d.own_slot);
+    std::vector<float4> L, own;
+    L.resize(n_list);
+    own.resize(own_idx.size());
+    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    int rc;
+    if (!own_idx.empty()) {  // (before the list pass below reuses the workspace — the film buffers are separate, but keep the order simple)
+        DevBuf<uint32_t> di;
+        DevBuf<float4> dv;
+        if ((rc = di.put(own_idx.data(), own_idx.size())) || (rc = dv.alloc(own_idx.size()))) return rc;
+        launch_gather4(sc->fb.tile_rgbw, di.p, int(own_idx.size()), dv.p, cfg);
+        HIP_TRY(hipGetLastError());
+        if ((rc = dv.get(own.data(), own.size()))) return rc;
+    }
+    lap("own sums");
+    if (single_pass) {
+        DevBuf<uint32_t> di;
+        DevBuf<float4> dv;
+        if ((rc = di.put(list_pid.data(), list_pid.size())) || (rc = dv.alloc(list_pid.size()))) return rc;
+        launch_gather4(sc->pb.L, di.p, int(list_pid.size()), dv.p, cfg);
+        HIP_TRY(hipGetLastError());
+        if ((rc = dv.get(L.data(), L.size()))) return rc;
+        lap("gather L");
+    } else {
+        // the explicit-list pass of iile_li_samples
+        DevBuf<int> dx, dy, dk;
+        if ((rc = dx.put(lpx.data(), n_list)) || (rc = dy.put(lpy.data(), n_list)) || (rc = dk.put(lk.data(), n_list))) return rc;
+        PassDesc P;
+        std::memset(&P, 0, sizeof(P));
+        P.n_tiles_x = P.n_tiles_y = 1;
+        P.tile_nranks = 1;
+        P.kc = 1;
+        P.n_paths = uint32_t(n_list);
+        P.list_px = dx.p, P.list_py = dy.p, P.list_k = dk.p;
+        rc = ensure_workspace(sc, uint32_t(n_list));
+        if (rc) return rc;
+        sc->pb.nray_out = nullptr;
+        rc = run_pass(sc, S, sc->max_depth, P, cfg, false);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(L.data(), sc->pb.L, n_list * sizeof(float4), hipMemcpyDeviceToHost));
+        lap("list pass + download");
+    }
+    for (float4 &v : L) {  // guard_radiance (kernels.hip)
+        const float y = 0.212671f * v.x + 0.715160f * v.y + 0.072169f * v.z;
+        if (std::isnan(v.x) || std::isnan(v.y) || std::isnan(v.z) || double(y) < -1e-5 || std::isinf(y)) v.x = v.y = v.z = 0.f;
+        const float y2 = 0.212671f * v.x + 0.715160f * v.y + 0.072169f * v.z;
+        if (y2 > S.max_sample_luminance) {
+            const float sc2 = S.max_sample_luminance / y2;
+            v.x *= sc2, v.y *= sc2, v.z *= sc2;
+        }
+    }
+    // the exact sums
+    std::vector<uint32_t> out_idx(dests.size());
+    std::vector<float4> out_val(dests.size());
+    size_t own_at = 0;
+    int tiles[8];
+    for (size_t di = 0; di < dests.size(); ++di) {
+        const Dest &d = dests[di];
+        int n_tiles = 0;  // contributing tiles, ascending (a pixel is reached from at most its own and three neighbouring tiles)
+        for (size_t h = d.first; h < d.last; ++h) {
+            const int t = fl[hits[h].second].tile;
+            if ((n_tiles == 0 || tiles[n_tiles - 1] != t) && n_tiles < 8) tiles[n_tiles++] = t;
+        }
+        if (d.in_bounds && std::find(tiles, tiles + n_tiles, d.tile) == tiles + n_tiles && n_tiles < 8) tiles[n_tiles++] = d.tile;
+        std::sort(tiles, tiles + n_tiles);
+        n_tiles = int(std::unique(tiles, tiles + n_tiles) - tiles);
+        float4 o = make_float4(0, 0, 0, 0);
+        float4 own_sum = make_float4(0, 0, 0, 0);
+        if (d.in_bounds && !d.need_own) own_sum = own[own_at++];
+        for (int ti = 0; ti < n_tiles; ++ti) {
+            const int t = tiles[ti];
+            float rr = 0, gg = 0, bb = 0, ww = 0;
+            auto add = [&](const float4 &v) {
+                rr += v.x * 1.f * 1.f;
+                gg += v.y * 1.f * 1.f;
+                bb += v.z * 1.f * 1.f;
+                ww += 1.f;
+            };
+            if (d.in_bounds && t == d.tile && d.need_own) {
+                bool own_done = false;
+                for (size_t h = d.first; h < d.last; ++h) {
+                    const int i = hits[h].second;
+                    if (fl[i].tile != t) continue;
+                    if (!own_done && fl[i].pix > d.pix) {
+                        for (int k = 0; k < n_k; ++k) add(L[d.own_first + size_t(k)]);
+                        own_done = true;
+                    }
+                    add(L[size_t(list_of_flag[i])]);
+                }
+                if (!own_done)
+                    for (int k = 0; k < n_k; ++k) add(L[d.own_first + size_t(k)]);
+            } else {
+                if (d.in_bounds && t == d.tile) rr = own_sum.x, gg = own_sum.y, bb = own_sum.z, ww = own_sum.w;
+                for (size_t h = d.first; h < d.last; ++h) {
+                    const int i = hits[h].second;
+                    if (fl[i].tile == t) add(L[size_t(list_of_flag[i])]);
+                }
+            }
+            o.x += 0.412453f * rr + 0.357580f * gg + 0.180423f * bb;  // RGBToXYZ, spectrum.h:62-66
+            o.y += 0.212671f * rr + 0.715160f * gg + 0.072169f * bb;
+            o.z += 0.019334f * rr + 0.119193f * gg + 0.950227f * bb;
+            o.w += ww;
+        }
+        out_idx[di] = d.film_index;
+        out_val[di] = o;
+    }
+    lap("sums");
+    {
+        DevBuf<uint32_t> di;
+        DevBuf<float4> dv;
+        if ((rc = di.put(out_idx.data(), out_idx.size())) || (rc = dv.put(out_val.data(), out_val.size()))) return rc;
+        launch_scatter4(film_dev, di.p, int(out_idx.size()), dv.p, cfg);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    lap("scatter");
+    *n_patched = out_idx.size();
+    return IILE_OK;
+}
+}  // namespace
 
 int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw, iile_stats *stats) {
     if (!sc || !prm || !film_xyzw) return fail(IILE_ERR_ARG, "iile_render: null argument");
@@ -903,6 +1196,10 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     sc->events_used = 0;
     iile_stats st;
     std::memset(&st, 0, sizeof(st));
+    // whole-number film positions are listed for the one-pixel box film (the sample store of wider filters handles them)
+    sc->pb.flag_count = S.filter_wide ? nullptr : sc->flag_count;
+    sc->pb.flag_rec = sc->flag_rec;
+    if (sc->pb.flag_count) HIP_TRY(hipMemsetAsync(sc->flag_count, 0, sizeof(uint32_t), stream));
 
     HIP_TRY(hipEventRecord(sc->ev_begin, stream));
     if (prm->collect_stats && pix_slots) HIP_TRY(hipMemsetAsync(sc->pb.counters, 0, sizeof(DCounters), stream));
@@ -938,8 +1235,16 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         }
         launch_film_gather(S, P, F, n_samples, cfg);
         if (timed) HIP_TRY(hipEventRecord(ep->b, stream));
-    } else
+    } else {
         launch_film_resolve(S, P, F, cfg);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+        uint64_t n_patched = 0;
+        sc->pb.flag_count = nullptr;
+        rc = patch_whole_film_positions(sc, S, P, k_begin, k_end, st.n_passes == 1, F.film_xyzw, &n_patched);
+        if (rc) return rc;
+    }
+    sc->pb.flag_count = nullptr;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_end, stream));
     if (!prm->film_on_device) {

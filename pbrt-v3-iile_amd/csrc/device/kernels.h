@@ -42,7 +42,12 @@ struct PassBuffers {
     uint32_t *nray_out; // optional [2*n_paths] per-path {closest, shadow} ray counts (tests)
     int *spill;         // [kSpillStackDepth][max grid threads] overflow of the LDS traversal stacks
     float4 *aux;        // probe pass only: [n_paths] camera-space normal (xyz) and distance (w) of the first hit
+    // camera samples whose film position is a whole number after float rounding (they also land in a neighbouring
+    // pixel, film.h:159-166): {px, py, k, pFilm.x, pFilm.y, path id} records, appended by the generation code, count in [0]
+    uint32_t *flag_count;
+    float *flag_rec;    // [kMaxFlagged * 6]
 };
+constexpr uint32_t kMaxFlagged = 1u << 20;
 
 struct FilmBuffers {
     float4 *tile_rgbw;  // [n_owned_tiles*256] per-pixel RGB contribSum + weight of own samples
@@ -94,6 +99,8 @@ void launch_camera(const DScene &S, int n, const float *pfilm, const float *plen
 void launch_bsdf_probe(const DScene &S, int n, int mat, const float *wo, const float *wi_or_u, int sample,
                        float *out, const LaunchCfg &cfg);
 void launch_trig_probe(int n, const float *x, float *out, const LaunchCfg &cfg);
+void launch_gather4(const float4 *src, const uint32_t *idx, int n, float4 *out, const LaunchCfg &cfg);
+void launch_scatter4(float4 *dst, const uint32_t *idx, int n, const float4 *in, const LaunchCfg &cfg);
 void launch_texture_probe(const DScene &S, int n, int tex, const float *uv, const float *duv, float *out, const LaunchCfg &cfg);
 
 }  // namespace iile

@@ -208,6 +208,26 @@ DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, i
     return *px < S.samp_x1 && *py < S.samp_y1;
 }
 
+// A film position that is a whole number (u == 0, or float(px) + u rounded to px or px + 1 where the pixel
+// coordinate is large) puts the sample into two pixels along that axis under the one-pixel box filter
+// (FilmTile::AddSample, film.h:159-166: pixels ceil(pFilm - 1) .. floor(pFilm)). Rare (1080p x 64 spp: ~1e-4 of the
+// samples); they are listed here and the pixels they touch are finished exactly by iile_render (api.hip).
+DEV void flag_whole_film_position(const PassBuffers &B, uint32_t pid, int px, int py, uint32_t k, float pfx, float pfy) {
+    if (!B.flag_count) return;
+    if (pfx == float(px) || pfx == float(px + 1) || pfy == float(py) || pfy == float(py + 1)) {
+        const uint32_t at = atomicAdd(B.flag_count, 1u);
+        if (at < kMaxFlagged) {
+            float *r = B.flag_rec + 6 * size_t(at);
+            r[0] = b2f(uint32_t(px));
+            r[1] = b2f(uint32_t(py));
+            r[2] = b2f(k);
+            r[3] = pfx;
+            r[4] = pfy;
+            r[5] = b2f(pid);  // its path id in the pass that made it
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassBuffers B, int count_stats) {
     unsigned long long n_cam = 0;
@@ -234,6 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
                 B.aux[pid] = make_float4(0, 0, 0, -1.f);  // no intersection: normal 0, NO_INTERSECTION_DISTANCE
             } else
                 camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
+            if (!P.list_px && !P.probe_mode) flag_whole_film_position(B, pid, px, py, k, float(px) + u0, float(py) + u1);
             B.hindex[pid] = idx;
             B.L[pid] = make_float4(0, 0, 0, 0);
             if (B.nray_out) {
@@ -305,6 +326,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                         F3 o, d;
                         float tmax;
                         const float pfx = float(px) + u0, pfy = float(py) + u1;
+                        flag_whole_film_position(B, slot, px, py, k, pfx, pfy);
                         camera_ray(S, pfx, pfy, l0, l1, &o, &d, &tmax);
                         B.hindex[slot] = idx;
                         // the film position rides in the path's (not yet used) throughput record: the first k_shade
@@ -1739,6 +1761,20 @@ __global__ void k_texture_probe(DScene S, int n, int tex, const float *uv, const
 }
 void launch_texture_probe(const DScene &S, int n, int tex, const float *uv, const float *duv, float *out, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_texture_probe, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, S, n, tex, uv, duv, out);
+}
+__global__ void k_gather4(const float4 *src, const uint32_t *idx, int n, float4 *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+__global__ void k_scatter4(float4 *dst, const uint32_t *idx, int n, const float4 *in) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = in[i];
+}
+void launch_gather4(const float4 *src, const uint32_t *idx, int n, float4 *out, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_gather4, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, src, idx, n, out);
+}
+void launch_scatter4(float4 *dst, const uint32_t *idx, int n, const float4 *in, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_scatter4, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, dst, idx, n, in);
 }
 void launch_trig_probe(int n, const float *x, float *out, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_trig_probe, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, n, x, out);

@@ -670,3 +670,27 @@ def test_other_bvh_split_methods_bitwise(binding, oracle):
         assert st["nodes_closest"] == ost["nodes_closest"] and st["nodes_any"] == ost["nodes_any"]
         assert st["tri_tests"] == ost["tri_tests"] and st["closest_rays"] == ost["regular_rays"]
         assert_bitwise(gpu.render()[0], ref, f"{method}: film, uninstrumented kernels")
+
+
+def test_whole_number_film_positions_bitwise(binding, oracle):
+    """Where pixel coordinates pass 1024 a film position px + u rounds to a whole number for u below (or within) 6e-5
+    of 0 (or 1), and FilmTile::AddSample (film.h:159-166) then adds the sample to two pixels: the left / upper
+    neighbour when it rounds down — as for the exact zeros of the first Halton samples — the right / lower one when it
+    rounds up (whose own samples come later in the tile: the sum's order changes). A 1900 x 24 strip of killeroo-simple
+    at 48 samples per pixel holds dozens of each kind: the film must be the oracle's bit for bit, in one pass (the
+    radiances are gathered from the pass buffer) and in several (the paths involved are rendered again), shard by
+    shard, and with the instrumented kernels."""
+    scene = binding.HostScene(xres=1900, yres=24, spp=48)
+    gpu = binding.GpuScene(scene)
+    ref, ost = oracle.render(scene)
+    weights = ref[..., 3]
+    assert (weights > 48).sum() > 100 and (weights > 48)[:, 1100:].sum() > 20   # pixels that received a neighbour's sample
+    film, st = gpu.render()
+    assert st["n_passes"] == 1
+    assert_bitwise(film, ref, "strip, one pass")
+    assert_bitwise(gpu.render(spp_per_pass=10)[0], ref, "strip, five passes")
+    assert_bitwise(gpu.render(collect_stats=True)[0], ref, "strip, instrumented kernels")
+    for rank in range(2):
+        part, _ = gpu.render(tile_rank=rank, tile_nranks=2, spp_per_pass=24 + 24 * rank)
+        pref, _ = oracle.render(scene, tile_rank=rank, tile_nranks=2)
+        assert_bitwise(part, pref, f"strip, shard {rank} of 2")
