@@ -872,6 +872,7 @@ struct Flagged {
     float pfx, pfy;
     uint32_t pid;
     int tile, pix;  // tile index and row-major pixel rank inside the tile: generation order = (tile, pix, k)
+    bool plain_k0;  // sample 0 with exact zero offsets only: k_film_resolve adds it to its neighbours by itself
 };
 // `single_pass`: the frame was one pass, so every sample's radiance still sits in the pass buffer (L[path id]) and is
 // gathered from there; otherwise the few paths involved are rendered again through the explicit-list pass (bitwise the
@@ -916,20 +917,16 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
         uint32_t u[6];
         std::memcpy(u, rec + 6 * size_t(i), sizeof(u));
         Flagged &f = fl[i];
-        f.px = int(u[0]), f.py = int(u[1]), f.k = int(u[2]);
+        f.px = int(u[0]), f.py = int(u[1]), f.k = int(u[2] & 0x3fffffffu);
         f.pfx = rec[6 * size_t(i) + 3], f.pfy = rec[6 * size_t(i) + 4];
         f.pid = u[5];
         f.tile = tile_of(f.px, f.py, &f.pix);
+        const bool zero_x = (u[2] >> 30) & 1u, zero_y = (u[2] >> 31) & 1u;
+        const bool whole_x = f.pfx == float(f.px) || f.pfx == float(f.px + 1), whole_y = f.pfy == float(f.py) || f.pfy == float(f.py + 1);
+        f.plain_k0 = f.k == 0 && (!whole_x || zero_x) && (!whole_y || zero_y);
     }
-    {  // generation order: one 64-bit key per sample
-        std::vector<std::pair<uint64_t, uint32_t>> keys(n_flag);
-        for (uint32_t i = 0; i < n_flag; ++i)
-            keys[i] = {(uint64_t(uint32_t(fl[i].tile)) << 40) | (uint64_t(uint32_t(fl[i].pix)) << 32) | uint64_t(uint32_t(fl[i].k)), i};
-        std::sort(keys.begin(), keys.end());
-        std::vector<Flagged> sorted(n_flag);
-        for (uint32_t i = 0; i < n_flag; ++i) sorted[i] = fl[keys[i].second];
-        fl.swap(sorted);
-    }
+    // generation order of a sample: one 64-bit key (tile, pixel rank in the tile, k)
+    auto gen_key = [&](int i) { return (uint64_t(uint32_t(fl[i].tile)) << 40) | (uint64_t(uint32_t(fl[i].pix)) << 32) | uint64_t(uint32_t(fl[i].k)); };
     lap("sort samples");
     // (destination pixel, flagged sample of another pixel that lands in it), by destination, generation order kept
     const int fw = S.crop_x1 - S.crop_x0;
@@ -953,7 +950,23 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
     }
     if (hits.empty()) return IILE_OK;
     lap("destinations");
-    std::sort(hits.begin(), hits.end());
+    {
+        // only pixels reached by a sample k_film_resolve does not handle need finishing here: keep their hits (all of
+        // them, the plain ones too) and order those by destination, then generation order
+        std::vector<uint32_t> needed;
+        for (const auto &h : hits)
+            if (!fl[h.second].plain_k0) needed.push_back(h.first);
+        if (needed.empty()) return IILE_OK;
+        std::sort(needed.begin(), needed.end());
+        needed.erase(std::unique(needed.begin(), needed.end()), needed.end());
+        std::vector<std::pair<uint32_t, int>> kept;
+        for (const auto &h : hits)
+            if (std::binary_search(needed.begin(), needed.end(), h.first)) kept.push_back(h);
+        std::sort(kept.begin(), kept.end(), [&](const std::pair<uint32_t, int> &a, const std::pair<uint32_t, int> &b) {
+            return a.first != b.first ? a.first < b.first : gen_key(a.second) < gen_key(b.second);
+        });
+        hits.swap(kept);
+    }
     lap("records + destinations");
     // which radiances are needed: every flagged sample that lands somewhere else, and all own samples of a pixel that
     // receives from a pixel generated before it in its own tile
@@ -974,6 +987,12 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
     for (size_t a = 0; a < hits.size();) {
         size_t b = a;
         while (b < hits.size() && hits[b].first == hits[a].first) ++b;
+        bool only_plain = true;
+        for (size_t h = a; h < b; ++h) only_plain = only_plain && fl[hits[h].second].plain_k0;
+        if (only_plain) {  // k_film_resolve already finished this pixel
+            a = b;
+            continue;
+        }
         Dest d;
         d.film_index = hits[a].first;
         d.first = a, d.last = b;
@@ -1010,6 +1029,7 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
                     lpx.push_back(d.qx), lpy.push_back(d.qy), lk.push_back(k_begin + k);
             }
         }
+    if (dests.empty()) return IILE_OK;
     lap("lists");
     if (dbg) std::fprintf(stderr, "[patch] %u flagged samples, %zu pixels to finish, %zu radiances needed (%s)\n", n_flag, dests.size(), n_list, single_pass ? "gathered" : "rendered again");
     // own sums of the pixels that keep them ride at the end of the same gather

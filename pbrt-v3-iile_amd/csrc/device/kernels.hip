@@ -212,7 +212,8 @@ DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, i
 // coordinate is large) puts the sample into two pixels along that axis under the one-pixel box filter
 // (FilmTile::AddSample, film.h:159-166: pixels ceil(pFilm - 1) .. floor(pFilm)). Rare (1080p x 64 spp: ~1e-4 of the
 // samples); they are listed here and the pixels they touch are finished exactly by iile_render (api.hip).
-DEV void flag_whole_film_position(const PassBuffers &B, uint32_t pid, int px, int py, uint32_t k, float pfx, float pfy) {
+DEV void flag_whole_film_position(const PassBuffers &B, uint32_t pid, int px, int py, uint32_t k, float pfx, float pfy, float u0,
+                                  float u1) {
     if (!B.flag_count) return;
     if (pfx == float(px) || pfx == float(px + 1) || pfy == float(py) || pfy == float(py + 1)) {
         const uint32_t at = atomicAdd(B.flag_count, 1u);
@@ -220,7 +221,7 @@ DEV void flag_whole_film_position(const PassBuffers &B, uint32_t pid, int px, in
             float *r = B.flag_rec + 6 * size_t(at);
             r[0] = b2f(uint32_t(px));
             r[1] = b2f(uint32_t(py));
-            r[2] = b2f(k);
+            r[2] = b2f(k | (u0 == 0.f ? 1u << 30 : 0u) | (u1 == 0.f ? 1u << 31 : 0u));  // + "the offset is an exact zero"
             r[3] = pfx;
             r[4] = pfy;
             r[5] = b2f(pid);  // its path id in the pass that made it
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
                 B.aux[pid] = make_float4(0, 0, 0, -1.f);  // no intersection: normal 0, NO_INTERSECTION_DISTANCE
             } else
                 camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
-            if (!P.list_px && !P.probe_mode) flag_whole_film_position(B, pid, px, py, k, float(px) + u0, float(py) + u1);
+            if (!P.list_px && !P.probe_mode) flag_whole_film_position(B, pid, px, py, k, float(px) + u0, float(py) + u1, u0, u1);
             B.hindex[pid] = idx;
             B.L[pid] = make_float4(0, 0, 0, 0);
             if (B.nray_out) {
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                         F3 o, d;
                         float tmax;
                         const float pfx = float(px) + u0, pfy = float(py) + u1;
-                        flag_whole_film_position(B, slot, px, py, k, pfx, pfy);
+                        flag_whole_film_position(B, slot, px, py, k, pfx, pfy, u0, u1);
                         camera_ray(S, pfx, pfy, l0, l1, &o, &d, &tmax);
                         B.hindex[slot] = idx;
                         // the film position rides in the path's (not yet used) throughput record: the first k_shade
