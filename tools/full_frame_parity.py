@@ -1,6 +1,6 @@
 """BASELINE config 1 in full: killeroo-simple 1920x1080 x 64 spp rendered by the GPU kernels bench.py times and by
 the CPU oracle on all host cores, compared bit for bit (film {X, Y, Z, weight} and the traversal counters).
-usage: python tools/full_frame_parity.py [out.json]"""
+usage: python tools/full_frame_parity.py [out.json] [boxroom-textured SPP]   (default: killeroo-simple at 64 spp)"""
 import json
 import os
 import sys
@@ -16,7 +16,19 @@ import __graft_entry__ as ge  # noqa: E402
 b = ge._load_binding()
 import oracle_binding  # noqa: E402
 
-scene = b.HostScene(xres=1920, yres=1080, spp=64)
+workload = "killeroo-simple 1920x1080, 64 spp, path maxdepth 5 (BASELINE.json configs[1])"
+if len(sys.argv) > 2 and sys.argv[2] == "boxroom-textured":
+    import tempfile
+    import boxroom
+    spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".pbrt", delete=False)
+    tmp.write(boxroom.boxroom_pbrt(xres=1920, yres=1080, spp=spp, ico_levels=5, n_blobs=12, wall_n=64, light="envmap", materials="mixed",
+                                   textures=tempfile.mkdtemp(prefix="boxroom_img_")))
+    tmp.close()
+    scene = b.HostScene(path=tmp.name)
+    workload = f"synthetic textured boxroom (tests/boxroom.py: environment map, image / scale textures, bump maps, alpha masks) 1920x1080, {spp} spp"
+else:
+    scene = b.HostScene(xres=1920, yres=1080, spp=64)
 gpu = b.GpuScene(scene)
 gpu.render(k_begin=0, k_end=1)
 t = time.time()
@@ -33,7 +45,7 @@ def same(a, c):
 
 
 out = {
-    "workload": "killeroo-simple 1920x1080, 64 spp, path maxdepth 5 (BASELINE.json configs[1])",
+    "workload": workload,
     "camera_samples": int(ost["camera_rays"]), "rays": int(ost["regular_rays"] + ost["shadow_rays"]),
     "film_bitwise_equal_plain_kernels": same(film, ref), "film_bitwise_equal_instrumented_kernels": same(counted, ref),
     "counters_equal": all(int(cst[a]) == int(ost[o]) for a, o in (("closest_rays", "regular_rays"), ("shadow_rays", "shadow_rays"),
