@@ -65,6 +65,8 @@ struct iile_scene {
     float *flag_rec = nullptr;
     float *flag_host = nullptr;      // pinned staging for the records (count first)
     size_t flag_host_floats = 0;
+    hipStream_t aux_stream = nullptr;  // copies the flagged list to the host beside a running pass
+    hipEvent_t ev_flags = nullptr;     // recorded after the first k_extend of a pass: the list is complete
     void *probe_block = nullptr;  // cameras + aux + outputs of the last probe batch
     size_t probe_block_bytes = 0;
     void *film_block = nullptr;
@@ -241,6 +243,7 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
     for (int b = 0; b <= max_depth; ++b) {
         rc = timed_launch(1, [&] { launch_extend(S, P, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
+        if (b == 0 && B.flag_count && sc->ev_flags) HIP_TRY(hipEventRecord(sc->ev_flags, cfg.stream));
         if (S.has_infinite) {  // escaped rays see the infinite lights (path.cpp:97-99)
             rc = timed_launch(6, [&] { launch_miss(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
@@ -765,6 +768,9 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         sc->allocs.push_back(p);
         sc->flag_count = static_cast<uint32_t *>(p);
         sc->flag_rec = reinterpret_cast<float *>(static_cast<char *>(p) + 256);
+        if (hipStreamCreateWithFlags(&sc->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sc->ev_flags, hipEventDisableTiming) != hipSuccess)
+            return bail(fail(IILE_ERR_HIP, "hipStreamCreate / hipEventCreate failed"));
     }
     // More than one light: tabulate the spatial light distribution (lightdistrib.cpp:91-299) for
     // every voxel of its grid — up to 64 per axis, cubes along the longest one.
@@ -847,6 +853,8 @@ void iile_scene_destroy(iile_scene *sc) {
     if (sc->film_block) (void)hipFree(sc->film_block);
     if (sc->wide_block) (void)hipFree(sc->wide_block);
     if (sc->flag_host) (void)hipHostFree(sc->flag_host);
+    if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
+    if (sc->ev_flags) (void)hipEventDestroy(sc->ev_flags);
     if (sc->probe_block) (void)hipFree(sc->probe_block);
     if (sc->nray_buf) (void)hipFree(sc->nray_buf);
     for (EventPair &e : sc->events) {
@@ -874,14 +882,57 @@ struct Flagged {
     int tile, pix;  // tile index and row-major pixel rank inside the tile: generation order = (tile, pix, k)
     bool plain_k0;  // sample 0 with exact zero offsets only: k_film_resolve adds it to its neighbours by itself
 };
+struct PatchDest {
+    uint32_t film_index;
+    int qx, qy, tile, pix;
+    bool in_bounds, need_own;
+    uint32_t own_slot;     // index into tile_rgbw
+    size_t first, last;    // its range of `hits`
+    size_t own_first;      // first of its own samples in the list
+};
+// What patch_prepare works out on the host (it only needs the list of flagged samples, complete once the first k_extend
+// has run — in a one-pass frame that is while the GPU is still busy with the rest of the pass) for patch_finish.
+struct PatchPlan {
+    bool active = false, single_pass = false;
+    uint32_t n_flag = 0;
+    int k_begin = 0, k_end = 0;
+    std::vector<Flagged> fl;
+    std::vector<std::pair<uint32_t, int>> hits;
+    std::vector<PatchDest> dests;
+    std::vector<uint32_t> list_pid;
+    std::vector<int> lpx, lpy, lk, list_of_flag;
+    size_t n_list = 0;
+};
 // `single_pass`: the frame was one pass, so every sample's radiance still sits in the pass buffer (L[path id]) and is
 // gathered from there; otherwise the few paths involved are rendered again through the explicit-list pass (bitwise the
 // same values). `pid_of_own`: path id of sample (pixel slot, k) in that single pass.
-int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &Pf, int k_begin, int k_end, bool single_pass,
-                               float4 *film_dev, uint64_t *n_patched) {
+int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, int k_begin, int k_end, bool single_pass, hipStream_t copy_stream,
+                  PatchPlan *plan) {
+    plan->active = false;
+    plan->single_pass = single_pass;
+    plan->k_begin = k_begin, plan->k_end = k_end;
     uint32_t n_flag = 0;
-    HIP_TRY(hipMemcpy(&n_flag, sc->flag_count, sizeof(n_flag), hipMemcpyDeviceToHost));
-    *n_patched = 0;
+    {   // (through the pinned staging buffer so that the copy can run on `copy_stream` beside the render)
+        if (sc->flag_host_floats < 64) {
+            void *hp = nullptr;
+            HIP_TRY(hipHostMalloc(&hp, (size_t(1) << 16) * sizeof(float), hipHostMallocDefault));
+            if (sc->flag_host) (void)hipHostFree(sc->flag_host);
+            sc->flag_host = static_cast<float *>(hp);
+            sc->flag_host_floats = size_t(1) << 16;
+        }
+        HIP_TRY(hipMemcpyAsync(sc->flag_host, sc->flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, copy_stream));
+        HIP_TRY(hipStreamSynchronize(copy_stream));
+        std::memcpy(&n_flag, sc->flag_host, sizeof(n_flag));
+    }
+    plan->n_flag = n_flag;
+    std::vector<Flagged> &fl = plan->fl;
+    std::vector<std::pair<uint32_t, int>> &hits = plan->hits;
+    std::vector<PatchDest> &dests = plan->dests;
+    std::vector<uint32_t> &list_pid = plan->list_pid;
+    std::vector<int> &lpx = plan->lpx, &lpy = plan->lpy, &lk = plan->lk, &list_of_flag = plan->list_of_flag;
+    size_t &n_list = plan->n_list;
+    fl.clear(), hits.clear(), dests.clear(), list_pid.clear(), lpx.clear(), lpy.clear(), lk.clear(), list_of_flag.clear();
+    n_list = 0;
     const bool dbg = std::getenv("IILE_PATCH_DEBUG") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -902,7 +953,8 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
         sc->flag_host = static_cast<float *>(hp);
         sc->flag_host_floats = want;
     }
-    HIP_TRY(hipMemcpy(sc->flag_host, sc->flag_rec, size_t(n_flag) * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(sc->flag_host, sc->flag_rec, size_t(n_flag) * 6 * sizeof(float), hipMemcpyDeviceToHost, copy_stream));
+    HIP_TRY(hipStreamSynchronize(copy_stream));
     const float *rec = sc->flag_host;
     lap("download records");
     const int ntx = Pf.n_tiles_x;
@@ -912,7 +964,7 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
         return ty * ntx + tx;
     };
     auto owned = [&](int tile) { return tile % Pf.tile_nranks == Pf.tile_rank; };
-    std::vector<Flagged> fl(n_flag);
+    fl.resize(n_flag);
     for (uint32_t i = 0; i < n_flag; ++i) {
         uint32_t u[6];
         std::memcpy(u, rec + 6 * size_t(i), sizeof(u));
@@ -930,7 +982,6 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
     lap("sort samples");
     // (destination pixel, flagged sample of another pixel that lands in it), by destination, generation order kept
     const int fw = S.crop_x1 - S.crop_x0;
-    std::vector<std::pair<uint32_t, int>> hits;  // sorted as pairs: by destination, then by (ascending = generation order) sample index
     hits.reserve(size_t(n_flag) * 2);
     const float r = 0.5f;
     for (int i = 0; i < int(fl.size()); ++i) {
@@ -970,20 +1021,10 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
     lap("records + destinations");
     // which radiances are needed: every flagged sample that lands somewhere else, and all own samples of a pixel that
     // receives from a pixel generated before it in its own tile
-    struct Dest {
-        uint32_t film_index;
-        int qx, qy, tile, pix;
-        bool in_bounds, need_own;
-        uint32_t own_slot;     // index into tile_rgbw
-        size_t first, last;    // its range of `hits`
-        size_t own_first;      // first of its own samples in the list
-    };
-    std::vector<Dest> dests;
+    typedef PatchDest Dest;
     const int n_k = k_end - k_begin;
-    std::vector<uint32_t> list_pid;                  // single pass: path ids to gather
-    std::vector<int> lpx, lpy, lk;                   // otherwise: samples to render again
-    std::vector<int> list_of_flag(fl.size(), -1);
-    size_t n_list = 0;
+    // list_pid: single pass, path ids to gather; lpx / lpy / lk: otherwise, samples to render again
+    list_of_flag.assign(fl.size(), -1);
     for (size_t a = 0; a < hits.size();) {
         size_t b = a;
         while (b < hits.size() && hits[b].first == hits[a].first) ++b;
@@ -1032,6 +1073,30 @@ int patch_whole_film_positions(iile_scene *sc, const DScene &S, const PassDesc &
     if (dests.empty()) return IILE_OK;
     lap("lists");
     if (dbg) std::fprintf(stderr, "[patch] %u flagged samples, %zu pixels to finish, %zu radiances needed (%s)\n", n_flag, dests.size(), n_list, single_pass ? "gathered" : "rendered again");
+    plan->active = true;
+    return IILE_OK;
+}
+
+int patch_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, float4 *film_dev, uint64_t *n_patched) {
+    *n_patched = 0;
+    if (!plan->active) return IILE_OK;
+    typedef PatchDest Dest;
+    const bool single_pass = plan->single_pass;
+    const int n_k = plan->k_end - plan->k_begin;
+    std::vector<Flagged> &fl = plan->fl;
+    std::vector<std::pair<uint32_t, int>> &hits = plan->hits;
+    std::vector<PatchDest> &dests = plan->dests;
+    std::vector<uint32_t> &list_pid = plan->list_pid;
+    std::vector<int> &lpx = plan->lpx, &lpy = plan->lpy, &lk = plan->lk, &list_of_flag = plan->list_of_flag;
+    const size_t n_list = plan->n_list;
+    const bool dbg = std::getenv("IILE_PATCH_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[patch] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     // own sums of the pixels that keep them ride at the end of the same gather
     std::vector<uint32_t> own_idx;
     for (const Dest &d : dests)
@@ -1217,6 +1282,8 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     iile_stats st;
     std::memset(&st, 0, sizeof(st));
     // whole-number film positions are listed for the one-pixel box film (the sample store of wider filters handles them)
+    PatchPlan plan;
+    bool planned = false;
     sc->pb.flag_count = S.filter_wide ? nullptr : sc->flag_count;
     sc->pb.flag_rec = sc->flag_rec;
     if (sc->pb.flag_count) HIP_TRY(hipMemsetAsync(sc->flag_count, 0, sizeof(uint32_t), stream));
@@ -1230,6 +1297,14 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         P.n_paths = uint32_t(pix_slots * P.kc);
         rc = run_pass(sc, S, sc->max_depth, P, cfg, timed);
         if (rc) return rc;
+        if (sc->pb.flag_count && k0 == k_begin && P.kc == n_samples) {
+            // one pass: the list of whole-number film positions is final after the first k_extend; fetch and sort it
+            // on the host while the GPU works through the rest of the pass
+            HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_flags, 0));
+            rc = patch_prepare(sc, S, P, k_begin, k_end, true, sc->aux_stream, &plan);
+            if (rc) return rc;
+            planned = true;
+        }
         EventPair *ep = nullptr;
         if (timed) {
             rc = get_events(sc, 4, &ep);
@@ -1261,7 +1336,11 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         HIP_TRY(hipStreamSynchronize(stream));
         uint64_t n_patched = 0;
         sc->pb.flag_count = nullptr;
-        rc = patch_whole_film_positions(sc, S, P, k_begin, k_end, st.n_passes == 1, F.film_xyzw, &n_patched);
+        if (!planned && pix_slots) {
+            rc = patch_prepare(sc, S, P, k_begin, k_end, st.n_passes == 1, stream, &plan);
+            if (rc) return rc;
+        }
+        rc = patch_finish(sc, S, &plan, F.film_xyzw, &n_patched);
         if (rc) return rc;
     }
     sc->pb.flag_count = nullptr;
