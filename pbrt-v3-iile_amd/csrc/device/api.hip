@@ -885,85 +885,79 @@ struct Flagged {
 struct PatchDest {
     uint32_t film_index;
     int qx, qy, tile, pix;
-    bool in_bounds, need_own;
-    uint32_t own_slot;     // index into tile_rgbw
-    size_t first, last;    // its range of `hits`
-    size_t own_first;      // first of its own samples in the list
+    bool own_in_pass, need_own;  // its own tile is rendered by this pass; it receives from a pixel generated before it there
+    uint32_t own_slot;           // index into tile_rgbw
+    size_t first, last;          // its range of `hits`
+    size_t own_first;            // first of its own samples in the gather list
 };
-// What patch_prepare works out on the host (it only needs the list of flagged samples, complete once the first k_extend
-// has run — in a one-pass frame that is while the GPU is still busy with the rest of the pass) for patch_finish.
+// What patch_prepare works out on the host for one pass. It needs only the pass's list of flagged samples, complete once
+// the pass's first k_extend has run — i.e. while the GPU is still busy with the rest of the pass.
 struct PatchPlan {
-    bool active = false, single_pass = false;
-    uint32_t n_flag = 0;
-    int k_begin = 0, k_end = 0;
+    bool active = false;
+    int k_begin = 0, k_end = 0, slot0 = 0;
     std::vector<Flagged> fl;
-    std::vector<std::pair<uint32_t, int>> hits;
+    std::vector<std::pair<uint32_t, int>> hits;  // (destination film pixel, flagged sample) by destination, then generation order
     std::vector<PatchDest> dests;
-    std::vector<uint32_t> list_pid;
-    std::vector<int> lpx, lpy, lk, list_of_flag;
-    size_t n_list = 0;
+    std::vector<uint32_t> list_pid;              // path ids (of this pass) whose radiance is needed
+    std::vector<int> list_of_flag;
 };
-// `single_pass`: the frame was one pass, so every sample's radiance still sits in the pass buffer (L[path id]) and is
-// gathered from there; otherwise the few paths involved are rendered again through the explicit-list pass (bitwise the
-// same values). `pid_of_own`: path id of sample (pixel slot, k) in that single pass.
-int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, int k_begin, int k_end, bool single_pass, hipStream_t copy_stream,
-                  PatchPlan *plan) {
-    plan->active = false;
-    plan->single_pass = single_pass;
-    plan->k_begin = k_begin, plan->k_end = k_end;
-    uint32_t n_flag = 0;
-    {   // (through the pinned staging buffer so that the copy can run on `copy_stream` beside the render)
-        if (sc->flag_host_floats < 64) {
-            void *hp = nullptr;
-            HIP_TRY(hipHostMalloc(&hp, (size_t(1) << 16) * sizeof(float), hipHostMallocDefault));
-            if (sc->flag_host) (void)hipHostFree(sc->flag_host);
-            sc->flag_host = static_cast<float *>(hp);
-            sc->flag_host_floats = size_t(1) << 16;
-        }
-        HIP_TRY(hipMemcpyAsync(sc->flag_host, sc->flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, copy_stream));
-        HIP_TRY(hipStreamSynchronize(copy_stream));
-        std::memcpy(&n_flag, sc->flag_host, sizeof(n_flag));
-    }
-    plan->n_flag = n_flag;
-    std::vector<Flagged> &fl = plan->fl;
-    std::vector<std::pair<uint32_t, int>> &hits = plan->hits;
-    std::vector<PatchDest> &dests = plan->dests;
-    std::vector<uint32_t> &list_pid = plan->list_pid;
-    std::vector<int> &lpx = plan->lpx, &lpy = plan->lpy, &lk = plan->lk, &list_of_flag = plan->list_of_flag;
-    size_t &n_list = plan->n_list;
-    fl.clear(), hits.clear(), dests.clear(), list_pid.clear(), lpx.clear(), lpy.clear(), lk.clear(), list_of_flag.clear();
-    n_list = 0;
-    const bool dbg = std::getenv("IILE_PATCH_DEBUG") != nullptr;
-    auto t0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!dbg) return;
+// One exact FilmTile sum: what tile `tile` adds to film pixel `film_index` (rgb contribSum, weight sum)
+struct PatchEntry {
+    uint32_t film_index;
+    int tile;
+    float r, g, b, w;
+    bool nonplain;  // involves a sample that k_film_resolve does not place
+};
+struct PatchTimer {
+    bool on = std::getenv("IILE_PATCH_DEBUG") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
         auto t1 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[patch] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
-    };
-    if (n_flag == 0) return IILE_OK;
-    if (n_flag > kMaxFlagged) return fail(IILE_ERR_UNSUPPORTED, "more than 2^20 camera samples with whole-number film positions in one render");
-    if (sc->flag_host_floats < size_t(n_flag) * 6) {  // pinned: a pageable copy of this size stalls for milliseconds now and then
-        if (sc->flag_host) (void)hipHostFree(sc->flag_host);
-        sc->flag_host = nullptr;
-        sc->flag_host_floats = 0;
+    }
+};
+
+int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, hipStream_t copy_stream, PatchPlan *plan) {
+    PatchTimer tm;
+    plan->active = false;
+    plan->k_begin = Pf.k0, plan->k_end = Pf.k0 + Pf.kc, plan->slot0 = Pf.slot0;
+    uint32_t n_flag = 0;
+    if (sc->flag_host_floats < 64) {  // pinned staging: count first, then the records
         void *hp = nullptr;
-        const size_t want = std::max<size_t>(size_t(n_flag) * 6 * 2, 1 << 16);
+        HIP_TRY(hipHostMalloc(&hp, (size_t(1) << 16) * sizeof(float), hipHostMallocDefault));
+        if (sc->flag_host) (void)hipHostFree(sc->flag_host);
+        sc->flag_host = static_cast<float *>(hp);
+        sc->flag_host_floats = size_t(1) << 16;
+    }
+    HIP_TRY(hipMemcpyAsync(sc->flag_host, sc->flag_count, sizeof(uint32_t), hipMemcpyDeviceToHost, copy_stream));
+    HIP_TRY(hipStreamSynchronize(copy_stream));
+    std::memcpy(&n_flag, sc->flag_host, sizeof(n_flag));
+    std::vector<Flagged> &fl = plan->fl;
+    std::vector<std::pair<uint32_t, int>> &hits = plan->hits;
+    std::vector<PatchDest> &dests = plan->dests;
+    fl.clear(), hits.clear(), dests.clear(), plan->list_pid.clear(), plan->list_of_flag.clear();
+    if (n_flag == 0) return IILE_OK;
+    if (n_flag > kMaxFlagged) return fail(IILE_ERR_UNSUPPORTED, "more than 2^20 camera samples with whole-number film positions in one pass");
+    if (sc->flag_host_floats < size_t(n_flag) * 6) {
+        void *hp = nullptr;
+        const size_t want = size_t(n_flag) * 6 * 2;
         HIP_TRY(hipHostMalloc(&hp, want * sizeof(float), hipHostMallocDefault));
+        if (sc->flag_host) (void)hipHostFree(sc->flag_host);
         sc->flag_host = static_cast<float *>(hp);
         sc->flag_host_floats = want;
     }
     HIP_TRY(hipMemcpyAsync(sc->flag_host, sc->flag_rec, size_t(n_flag) * 6 * sizeof(float), hipMemcpyDeviceToHost, copy_stream));
     HIP_TRY(hipStreamSynchronize(copy_stream));
     const float *rec = sc->flag_host;
-    lap("download records");
+    tm.lap("download records");
     const int ntx = Pf.n_tiles_x;
     auto tile_of = [&](int x, int y, int *pix) {
         const int tx = (x - S.samp_x0) / 16, ty = (y - S.samp_y0) / 16;
         *pix = (y - S.samp_y0 - ty * 16) * 16 + (x - S.samp_x0 - tx * 16);
         return ty * ntx + tx;
     };
-    auto owned = [&](int tile) { return tile % Pf.tile_nranks == Pf.tile_rank; };
     fl.resize(n_flag);
     for (uint32_t i = 0; i < n_flag; ++i) {
         uint32_t u[6];
@@ -977,10 +971,8 @@ int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, int k_beg
         const bool whole_x = f.pfx == float(f.px) || f.pfx == float(f.px + 1), whole_y = f.pfy == float(f.py) || f.pfy == float(f.py + 1);
         f.plain_k0 = f.k == 0 && (!whole_x || zero_x) && (!whole_y || zero_y);
     }
-    // generation order of a sample: one 64-bit key (tile, pixel rank in the tile, k)
     auto gen_key = [&](int i) { return (uint64_t(uint32_t(fl[i].tile)) << 40) | (uint64_t(uint32_t(fl[i].pix)) << 32) | uint64_t(uint32_t(fl[i].k)); };
-    lap("sort samples");
-    // (destination pixel, flagged sample of another pixel that lands in it), by destination, generation order kept
+    // every (destination pixel, flagged sample of another pixel that lands in it)
     const int fw = S.crop_x1 - S.crop_x0;
     hits.reserve(size_t(n_flag) * 2);
     const float r = 0.5f;
@@ -1000,149 +992,108 @@ int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, int k_beg
                 if (x != f.px || y != f.py) hits.emplace_back(uint32_t(y - S.crop_y0) * uint32_t(fw) + uint32_t(x - S.crop_x0), i);
     }
     if (hits.empty()) return IILE_OK;
-    lap("destinations");
-    {
-        // only pixels reached by a sample k_film_resolve does not handle need finishing here: keep their hits (all of
-        // them, the plain ones too) and order those by destination, then generation order
-        std::vector<uint32_t> needed;
-        for (const auto &h : hits)
-            if (!fl[h.second].plain_k0) needed.push_back(h.first);
-        if (needed.empty()) return IILE_OK;
-        std::sort(needed.begin(), needed.end());
-        needed.erase(std::unique(needed.begin(), needed.end()), needed.end());
-        std::vector<std::pair<uint32_t, int>> kept;
-        for (const auto &h : hits)
-            if (std::binary_search(needed.begin(), needed.end(), h.first)) kept.push_back(h);
-        std::sort(kept.begin(), kept.end(), [&](const std::pair<uint32_t, int> &a, const std::pair<uint32_t, int> &b) {
-            return a.first != b.first ? a.first < b.first : gen_key(a.second) < gen_key(b.second);
-        });
-        hits.swap(kept);
-    }
-    lap("records + destinations");
+    std::sort(hits.begin(), hits.end(), [&](const std::pair<uint32_t, int> &a, const std::pair<uint32_t, int> &b) {
+        return a.first != b.first ? a.first < b.first : gen_key(a.second) < gen_key(b.second);
+    });
+    tm.lap("destinations");
     // which radiances are needed: every flagged sample that lands somewhere else, and all own samples of a pixel that
     // receives from a pixel generated before it in its own tile
-    typedef PatchDest Dest;
-    const int n_k = k_end - k_begin;
-    // list_pid: single pass, path ids to gather; lpx / lpy / lk: otherwise, samples to render again
-    list_of_flag.assign(fl.size(), -1);
+    const int n_k = Pf.kc;
+    plan->list_of_flag.assign(fl.size(), -1);
     for (size_t a = 0; a < hits.size();) {
         size_t b = a;
         while (b < hits.size() && hits[b].first == hits[a].first) ++b;
-        bool only_plain = true;
-        for (size_t h = a; h < b; ++h) only_plain = only_plain && fl[hits[h].second].plain_k0;
-        if (only_plain) {  // k_film_resolve already finished this pixel
-            a = b;
-            continue;
-        }
-        Dest d;
+        PatchDest d;
         d.film_index = hits[a].first;
         d.first = a, d.last = b;
         d.qx = S.crop_x0 + int(d.film_index % uint32_t(fw));
         d.qy = S.crop_y0 + int(d.film_index / uint32_t(fw));
-        d.in_bounds = d.qx >= S.samp_x0 && d.qx < S.samp_x1 && d.qy >= S.samp_y0 && d.qy < S.samp_y1;
-        d.tile = d.in_bounds ? tile_of(d.qx, d.qy, &d.pix) : -1;
-        if (d.in_bounds && !owned(d.tile)) d.in_bounds = false;
+        const bool in_bounds = d.qx >= S.samp_x0 && d.qx < S.samp_x1 && d.qy >= S.samp_y0 && d.qy < S.samp_y1;
+        d.tile = in_bounds ? tile_of(d.qx, d.qy, &d.pix) : -1;
+        d.own_in_pass = false;
+        d.own_slot = 0;
+        if (in_bounds && d.tile % Pf.tile_nranks == Pf.tile_rank) {
+            const int slot = d.tile / Pf.tile_nranks;
+            d.own_in_pass = slot >= Pf.slot0 && slot < Pf.slot0 + Pf.n_pass_tiles;
+            d.own_slot = uint32_t(slot) * 256u + uint32_t(d.pix);
+        }
         d.need_own = false;
-        d.own_slot = d.in_bounds ? uint32_t(d.tile / Pf.tile_nranks) * 256u + uint32_t(d.pix) : 0u;
         d.own_first = 0;
         for (size_t h = a; h < b; ++h) {
             const int i = hits[h].second;
-            if (list_of_flag[i] < 0) {
-                list_of_flag[i] = int(n_list++);
-                if (single_pass)
-                    list_pid.push_back(fl[i].pid);
-                else
-                    lpx.push_back(fl[i].px), lpy.push_back(fl[i].py), lk.push_back(fl[i].k);
+            if (plan->list_of_flag[i] < 0) {
+                plan->list_of_flag[i] = int(plan->list_pid.size());
+                plan->list_pid.push_back(fl[i].pid);
             }
-            if (d.in_bounds && fl[i].tile == d.tile && fl[i].pix < d.pix) d.need_own = true;
+            if (d.own_in_pass && fl[i].tile == d.tile && fl[i].pix < d.pix) d.need_own = true;
         }
         dests.push_back(d);
         a = b;
     }
-    for (Dest &d : dests)
-        if (d.need_own) {
-            d.own_first = n_list;
-            n_list += size_t(n_k);
-            for (int k = 0; k < n_k; ++k) {
-                if (single_pass)
-                    list_pid.push_back(d.own_slot * uint32_t(n_k) + uint32_t(k));  // pid = pixel slot * kc + kk
-                else
-                    lpx.push_back(d.qx), lpy.push_back(d.qy), lk.push_back(k_begin + k);
-            }
-        }
-    if (dests.empty()) return IILE_OK;
-    lap("lists");
-    if (dbg) std::fprintf(stderr, "[patch] %u flagged samples, %zu pixels to finish, %zu radiances needed (%s)\n", n_flag, dests.size(), n_list, single_pass ? "gathered" : "rendered again");
+    (void)n_k;  // (the own samples of need_own pixels are summed on the device: k_patch_own)
+    tm.lap("lists");
+    if (tm.on) std::fprintf(stderr, "[patch] pass at slot %d: %u flagged samples, %zu pixels reached, %zu radiances to gather\n", Pf.slot0, n_flag, dests.size(), plan->list_pid.size());
     plan->active = true;
     return IILE_OK;
 }
 
-int patch_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, float4 *film_dev, uint64_t *n_patched) {
-    *n_patched = 0;
+// After the pass's film accumulation: the exact sum every tile of this pass adds to every pixel reached by a flagged sample.
+int patch_pass_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, std::vector<PatchEntry> *entries) {
     if (!plan->active) return IILE_OK;
-    typedef PatchDest Dest;
-    const bool single_pass = plan->single_pass;
+    PatchTimer tm;
+    const std::vector<Flagged> &fl = plan->fl;
+    const std::vector<std::pair<uint32_t, int>> &hits = plan->hits;
     const int n_k = plan->k_end - plan->k_begin;
-    std::vector<Flagged> &fl = plan->fl;
-    std::vector<std::pair<uint32_t, int>> &hits = plan->hits;
-    std::vector<PatchDest> &dests = plan->dests;
-    std::vector<uint32_t> &list_pid = plan->list_pid;
-    std::vector<int> &lpx = plan->lpx, &lpy = plan->lpy, &lk = plan->lk, &list_of_flag = plan->list_of_flag;
-    const size_t n_list = plan->n_list;
-    const bool dbg = std::getenv("IILE_PATCH_DEBUG") != nullptr;
-    auto t0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!dbg) return;
-        auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[patch] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    };
-    // own sums of the pixels that keep them ride at the end of the same gather
     std::vector<uint32_t> own_idx;
-    for (const Dest &d : dests)
-        if (d.in_bounds && !d.need_own) own_idx.push_back(d.own_slot);
-    std::vector<float4> L, own;
-    L.resize(n_list);
+    // need_own pixels: their own-tile sum is taken on the device (own samples never leave HBM)
+    std::vector<uint32_t> no_local, no_range, no_pid;
+    for (const PatchDest &d : plan->dests) {
+        if (d.own_in_pass && !d.need_own) own_idx.push_back(d.own_slot);
+        if (d.need_own) {
+            no_local.push_back(d.own_slot - uint32_t(plan->slot0) * 256u);
+            no_range.push_back(uint32_t(no_pid.size()));
+            uint32_t split = 0;
+            bool split_set = false;
+            for (size_t h = d.first; h < d.last; ++h) {
+                const Flagged &f = fl[hits[h].second];
+                if (f.tile != d.tile) continue;
+                if (!split_set && f.pix > d.pix) {
+                    split = uint32_t(no_pid.size());
+                    split_set = true;
+                }
+                no_pid.push_back(f.pid);
+            }
+            no_range.push_back(split_set ? split : uint32_t(no_pid.size()));
+            no_range.push_back(uint32_t(no_pid.size()));
+        }
+    }
+    std::vector<float4> L, own, no_sum;
+    L.resize(plan->list_pid.size());
     own.resize(own_idx.size());
+    no_sum.resize(no_local.size());
     LaunchCfg cfg{sc->n_cus, nullptr, false};
     int rc;
-    if (!own_idx.empty()) {  // (before the list pass below reuses the workspace — the film buffers are separate, but keep the order simple)
-        DevBuf<uint32_t> di;
-        DevBuf<float4> dv;
-        if ((rc = di.put(own_idx.data(), own_idx.size())) || (rc = dv.alloc(own_idx.size()))) return rc;
-        launch_gather4(sc->fb.tile_rgbw, di.p, int(own_idx.size()), dv.p, cfg);
-        HIP_TRY(hipGetLastError());
-        if ((rc = dv.get(own.data(), own.size()))) return rc;
-    }
-    lap("own sums");
-    if (single_pass) {
-        DevBuf<uint32_t> di;
-        DevBuf<float4> dv;
-        if ((rc = di.put(list_pid.data(), list_pid.size())) || (rc = dv.alloc(list_pid.size()))) return rc;
-        launch_gather4(sc->pb.L, di.p, int(list_pid.size()), dv.p, cfg);
+    {
+        DevBuf<uint32_t> di, dj, d1, d2, d3;
+        DevBuf<float4> dv, dw, dn;
+        if ((rc = di.put(plan->list_pid.data(), plan->list_pid.size())) || (rc = dv.alloc(plan->list_pid.size()))) return rc;
+        launch_gather4(sc->pb.L, di.p, int(plan->list_pid.size()), dv.p, cfg);
+        if (!own_idx.empty()) {
+            if ((rc = dj.put(own_idx.data(), own_idx.size())) || (rc = dw.alloc(own_idx.size()))) return rc;
+            launch_gather4(sc->fb.tile_rgbw, dj.p, int(own_idx.size()), dw.p, cfg);
+        }
+        if (!no_local.empty()) {
+            if ((rc = d1.put(no_local.data(), no_local.size())) || (rc = d2.put(no_range.data(), no_range.size())) ||
+                (rc = d3.put(no_pid.data(), no_pid.size())) || (rc = dn.alloc(no_local.size())))
+                return rc;
+            launch_patch_own(S, sc->pb.L, int(no_local.size()), d1.p, d2.p, d3.p, n_k, dn.p, cfg);
+        }
         HIP_TRY(hipGetLastError());
         if ((rc = dv.get(L.data(), L.size()))) return rc;
-        lap("gather L");
-    } else {
-        // the explicit-list pass of iile_li_samples
-        DevBuf<int> dx, dy, dk;
-        if ((rc = dx.put(lpx.data(), n_list)) || (rc = dy.put(lpy.data(), n_list)) || (rc = dk.put(lk.data(), n_list))) return rc;
-        PassDesc P;
-        std::memset(&P, 0, sizeof(P));
-        P.n_tiles_x = P.n_tiles_y = 1;
-        P.tile_nranks = 1;
-        P.kc = 1;
-        P.n_paths = uint32_t(n_list);
-        P.list_px = dx.p, P.list_py = dy.p, P.list_k = dk.p;
-        rc = ensure_workspace(sc, uint32_t(n_list));
-        if (rc) return rc;
-        sc->pb.nray_out = nullptr;
-        rc = run_pass(sc, S, sc->max_depth, P, cfg, false);
-        if (rc) return rc;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(L.data(), sc->pb.L, n_list * sizeof(float4), hipMemcpyDeviceToHost));
-        lap("list pass + download");
+        if (!own_idx.empty() && (rc = dw.get(own.data(), own.size()))) return rc;
+        if (!no_local.empty() && (rc = dn.get(no_sum.data(), no_sum.size()))) return rc;
     }
+    tm.lap("gathers");
     for (float4 &v : L) {  // guard_radiance (kernels.hip)
         const float y = 0.212671f * v.x + 0.715160f * v.y + 0.072169f * v.z;
         if (std::isnan(v.x) || std::isnan(v.y) || std::isnan(v.z) || double(y) < -1e-5 || std::isinf(y)) v.x = v.y = v.z = 0.f;
@@ -1152,26 +1103,21 @@ int patch_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, float4 *film_
             v.x *= sc2, v.y *= sc2, v.z *= sc2;
         }
     }
-    // the exact sums
-    std::vector<uint32_t> out_idx(dests.size());
-    std::vector<float4> out_val(dests.size());
-    size_t own_at = 0;
-    int tiles[8];
-    for (size_t di = 0; di < dests.size(); ++di) {
-        const Dest &d = dests[di];
-        int n_tiles = 0;  // contributing tiles, ascending (a pixel is reached from at most its own and three neighbouring tiles)
-        for (size_t h = d.first; h < d.last; ++h) {
-            const int t = fl[hits[h].second].tile;
-            if ((n_tiles == 0 || tiles[n_tiles - 1] != t) && n_tiles < 8) tiles[n_tiles++] = t;
-        }
-        if (d.in_bounds && std::find(tiles, tiles + n_tiles, d.tile) == tiles + n_tiles && n_tiles < 8) tiles[n_tiles++] = d.tile;
-        std::sort(tiles, tiles + n_tiles);
-        n_tiles = int(std::unique(tiles, tiles + n_tiles) - tiles);
-        float4 o = make_float4(0, 0, 0, 0);
+    size_t own_at = 0, no_at = 0;
+    for (const PatchDest &d : plan->dests) {
         float4 own_sum = make_float4(0, 0, 0, 0);
-        if (d.in_bounds && !d.need_own) own_sum = own[own_at++];
-        for (int ti = 0; ti < n_tiles; ++ti) {
-            const int t = tiles[ti];
+        if (d.own_in_pass && !d.need_own) own_sum = own[own_at++];
+        float4 own_tile_sum = make_float4(0, 0, 0, 0);  // need_own: the finished sum of its own tile (k_patch_own)
+        if (d.need_own) own_tile_sum = no_sum[no_at++];
+        // the hits of one destination are in generation order: runs of equal tile, ascending
+        for (size_t a = d.first; a < d.last;) {
+            const int t = fl[hits[a].second].tile;
+            size_t b = a;
+            while (b < d.last && fl[hits[b].second].tile == t) ++b;
+            PatchEntry e;
+            e.film_index = d.film_index;
+            e.tile = t;
+            e.nonplain = false;
             float rr = 0, gg = 0, bb = 0, ww = 0;
             auto add = [&](const float4 &v) {
                 rr += v.x * 1.f * 1.f;
@@ -1179,35 +1125,103 @@ int patch_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, float4 *film_
                 bb += v.z * 1.f * 1.f;
                 ww += 1.f;
             };
-            if (d.in_bounds && t == d.tile && d.need_own) {
-                bool own_done = false;
-                for (size_t h = d.first; h < d.last; ++h) {
-                    const int i = hits[h].second;
-                    if (fl[i].tile != t) continue;
-                    if (!own_done && fl[i].pix > d.pix) {
-                        for (int k = 0; k < n_k; ++k) add(L[d.own_first + size_t(k)]);
-                        own_done = true;
-                    }
-                    add(L[size_t(list_of_flag[i])]);
-                }
-                if (!own_done)
-                    for (int k = 0; k < n_k; ++k) add(L[d.own_first + size_t(k)]);
+            if (d.own_in_pass && t == d.tile && d.need_own) {
+                rr = own_tile_sum.x, gg = own_tile_sum.y, bb = own_tile_sum.z, ww = own_tile_sum.w;
             } else {
-                if (d.in_bounds && t == d.tile) rr = own_sum.x, gg = own_sum.y, bb = own_sum.z, ww = own_sum.w;
-                for (size_t h = d.first; h < d.last; ++h) {
-                    const int i = hits[h].second;
-                    if (fl[i].tile == t) add(L[size_t(list_of_flag[i])]);
+                if (d.own_in_pass && t == d.tile) rr = own_sum.x, gg = own_sum.y, bb = own_sum.z, ww = own_sum.w;
+                for (size_t h = a; h < b; ++h) add(L[size_t(plan->list_of_flag[hits[h].second])]);
+            }
+            for (size_t h = a; h < b; ++h) e.nonplain = e.nonplain || !fl[hits[h].second].plain_k0;
+            e.r = rr, e.g = gg, e.b = bb, e.w = ww;
+            entries->push_back(e);
+            a = b;
+        }
+    }
+    tm.lap("tile sums");
+    return IILE_OK;
+}
+
+// After k_film_resolve: every pixel reached by a sample the resolve kernel does not place is rebuilt from its tiles'
+// exact sums, added in tile index order (Film::MergeFilmTile, film.cpp:135-148).
+int patch_merge(iile_scene *sc, const DScene &S, const PassDesc &Pf, std::vector<PatchEntry> *entries, float4 *film_dev, uint64_t *n_patched) {
+    *n_patched = 0;
+    if (entries->empty()) return IILE_OK;
+    PatchTimer tm;
+    std::sort(entries->begin(), entries->end(), [](const PatchEntry &a, const PatchEntry &b) {
+        return a.film_index != b.film_index ? a.film_index < b.film_index : a.tile < b.tile;
+    });
+    const int fw = S.crop_x1 - S.crop_x0, ntx = Pf.n_tiles_x;
+    struct Group {
+        size_t first, last;
+        int own_tile;        // the pixel's own (owned) tile if no entry covers it, else -1
+        uint32_t own_slot;
+    };
+    std::vector<Group> groups;
+    std::vector<uint32_t> own_idx;
+    for (size_t a = 0; a < entries->size();) {
+        size_t b = a;
+        bool nonplain = false;
+        while (b < entries->size() && (*entries)[b].film_index == (*entries)[a].film_index) {
+            if ((*entries)[b].nonplain) nonplain = true;
+            ++b;
+        }
+        if (nonplain) {
+            Group g{a, b, -1, 0u};
+            const uint32_t fi = (*entries)[a].film_index;
+            const int qx = S.crop_x0 + int(fi % uint32_t(fw)), qy = S.crop_y0 + int(fi / uint32_t(fw));
+            if (qx >= S.samp_x0 && qx < S.samp_x1 && qy >= S.samp_y0 && qy < S.samp_y1) {
+                const int tx = (qx - S.samp_x0) / 16, ty = (qy - S.samp_y0) / 16, t = ty * ntx + tx;
+                bool covered = false;
+                for (size_t h = a; h < b; ++h) covered = covered || (*entries)[h].tile == t;
+                if (!covered && t % Pf.tile_nranks == Pf.tile_rank) {
+                    g.own_tile = t;
+                    g.own_slot = uint32_t(t / Pf.tile_nranks) * 256u + uint32_t((qy - S.samp_y0 - ty * 16) * 16 + (qx - S.samp_x0 - tx * 16));
+                    own_idx.push_back(g.own_slot);
                 }
             }
+            groups.push_back(g);
+        }
+        a = b;
+    }
+    if (groups.empty()) return IILE_OK;
+    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    int rc;
+    std::vector<float4> own(own_idx.size());
+    if (!own_idx.empty()) {
+        DevBuf<uint32_t> di;
+        DevBuf<float4> dv;
+        if ((rc = di.put(own_idx.data(), own_idx.size())) || (rc = dv.alloc(own_idx.size()))) return rc;
+        launch_gather4(sc->fb.tile_rgbw, di.p, int(own_idx.size()), dv.p, cfg);
+        HIP_TRY(hipGetLastError());
+        if ((rc = dv.get(own.data(), own.size()))) return rc;
+    }
+    std::vector<uint32_t> out_idx(groups.size());
+    std::vector<float4> out_val(groups.size());
+    size_t own_at = 0;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Group &g = groups[gi];
+        float4 o = make_float4(0, 0, 0, 0);
+        auto add_tile = [&](float rr, float gg, float bb, float ww) {
             o.x += 0.412453f * rr + 0.357580f * gg + 0.180423f * bb;  // RGBToXYZ, spectrum.h:62-66
             o.y += 0.212671f * rr + 0.715160f * gg + 0.072169f * bb;
             o.z += 0.019334f * rr + 0.119193f * gg + 0.950227f * bb;
             o.w += ww;
+        };
+        bool own_added = g.own_tile < 0;
+        float4 own_sum = make_float4(0, 0, 0, 0);
+        if (g.own_tile >= 0) own_sum = own[own_at++];
+        for (size_t h = g.first; h < g.last; ++h) {
+            const PatchEntry &e = (*entries)[h];
+            if (!own_added && g.own_tile < e.tile) {
+                add_tile(own_sum.x, own_sum.y, own_sum.z, own_sum.w);
+                own_added = true;
+            }
+            add_tile(e.r, e.g, e.b, e.w);
         }
-        out_idx[di] = d.film_index;
-        out_val[di] = o;
+        if (!own_added) add_tile(own_sum.x, own_sum.y, own_sum.z, own_sum.w);
+        out_idx[gi] = (*entries)[g.first].film_index;
+        out_val[gi] = o;
     }
-    lap("sums");
     {
         DevBuf<uint32_t> di;
         DevBuf<float4> dv;
@@ -1216,7 +1230,7 @@ int patch_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, float4 *film_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
-    lap("scatter");
+    tm.lap("merge + scatter");
     *n_patched = out_idx.size();
     return IILE_OK;
 }
@@ -1256,23 +1270,23 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (P.n_owned_tiles < 0) P.n_owned_tiles = 0;
     const uint64_t pix_slots = uint64_t(P.n_owned_tiles) * 256;
     const int n_samples = k_end - k_begin;
-    // samples per pass: bounded by the workspace budget (~260 B per path incl. queue padding)
-    int kc = prm->spp_per_pass;
-    if (kc <= 0) {
+    // A pass renders all samples of a range of owned tiles; the range is bounded by the workspace budget (~260 B per
+    // path incl. queue padding). `spp_per_pass` (tests) asks for passes of about that many samples per pixel's worth
+    // of paths: n_owned_tiles * spp_per_pass / n_samples tiles each.
+    uint64_t max_paths;
+    {
         double budget_mb = 49152;  // 48 GiB of the 288 GB: one pass covers 1080p x 64 spp
         if (const char *e = std::getenv("IILE_WORKSPACE_MB")) budget_mb = std::max(64.0, atof(e));
-        uint64_t max_paths = uint64_t(budget_mb * 1048576.0 / 260.0);
-        max_paths = std::min<uint64_t>(max_paths, 200000000ull);  // queue slots must fit kSlotBits
-        int kc_max = int(std::max<uint64_t>(1, max_paths / std::max<uint64_t>(1, pix_slots)));
-        int n_passes = (n_samples + kc_max - 1) / kc_max;
-        kc = (n_samples + n_passes - 1) / n_passes;
+        max_paths = std::min<uint64_t>(uint64_t(budget_mb * 1048576.0 / 260.0), 200000000ull);  // queue slots must fit kSlotBits
+        if (prm->spp_per_pass > 0) max_paths = std::min<uint64_t>(max_paths, std::max<uint64_t>(1, pix_slots * uint64_t(prm->spp_per_pass)));
     }
-    kc = std::min(kc, n_samples);
-    if (pix_slots * uint64_t(kc) > 200000000ull) return fail(IILE_ERR_ARG, "pass too large: lower spp_per_pass");
+    const uint64_t paths_per_tile = uint64_t(256) * uint64_t(n_samples);
+    if (paths_per_tile > 200000000ull) return fail(IILE_ERR_UNSUPPORTED, "more than 781 250 samples per pixel in one render: split the sample range");
+    const int tiles_per_pass = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(std::max(P.n_owned_tiles, 1)), max_paths / paths_per_tile)));
     const uint32_t fw = uint32_t(S.crop_x1 - S.crop_x0), fh = uint32_t(S.crop_y1 - S.crop_y0);
 
     if (pix_slots) {
-        rc = ensure_workspace(sc, uint32_t(pix_slots * kc));
+        rc = ensure_workspace(sc, uint32_t(uint64_t(tiles_per_pass) * paths_per_tile));
         if (rc) return rc;
     }
     rc = ensure_film(sc, uint32_t(P.n_owned_tiles), fw * fh, S.filter_wide ? pix_slots * uint64_t(n_samples) : 0);
@@ -1283,28 +1297,22 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     std::memset(&st, 0, sizeof(st));
     // whole-number film positions are listed for the one-pixel box film (the sample store of wider filters handles them)
     PatchPlan plan;
-    bool planned = false;
+    std::vector<PatchEntry> entries;
     sc->pb.flag_count = S.filter_wide ? nullptr : sc->flag_count;
     sc->pb.flag_rec = sc->flag_rec;
-    if (sc->pb.flag_count) HIP_TRY(hipMemsetAsync(sc->flag_count, 0, sizeof(uint32_t), stream));
 
     HIP_TRY(hipEventRecord(sc->ev_begin, stream));
     if (prm->collect_stats && pix_slots) HIP_TRY(hipMemsetAsync(sc->pb.counters, 0, sizeof(DCounters), stream));
     if (pix_slots) HIP_TRY(hipMemsetAsync(sc->fb.tile_rgbw, 0, size_t(pix_slots) * sizeof(float4) * 2, stream));
-    for (int k0 = k_begin; k0 < k_end && pix_slots; k0 += kc) {
-        P.k0 = k0;
-        P.kc = std::min(kc, k_end - k0);
-        P.n_paths = uint32_t(pix_slots * P.kc);
+    P.k0 = k_begin;
+    P.kc = n_samples;
+    for (int slot0 = 0; slot0 < P.n_owned_tiles; slot0 += tiles_per_pass) {
+        P.slot0 = slot0;
+        P.n_pass_tiles = std::min(tiles_per_pass, P.n_owned_tiles - slot0);
+        P.n_paths = uint32_t(uint64_t(P.n_pass_tiles) * paths_per_tile);
+        if (sc->pb.flag_count) HIP_TRY(hipMemsetAsync(sc->flag_count, 0, sizeof(uint32_t), stream));
         rc = run_pass(sc, S, sc->max_depth, P, cfg, timed);
         if (rc) return rc;
-        if (sc->pb.flag_count && k0 == k_begin && P.kc == n_samples) {
-            // one pass: the list of whole-number film positions is final after the first k_extend; fetch and sort it
-            // on the host while the GPU works through the rest of the pass
-            HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_flags, 0));
-            rc = patch_prepare(sc, S, P, k_begin, k_end, true, sc->aux_stream, &plan);
-            if (rc) return rc;
-            planned = true;
-        }
         EventPair *ep = nullptr;
         if (timed) {
             rc = get_events(sc, 4, &ep);
@@ -1316,6 +1324,16 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         else
             launch_film_accumulate(S, P, sc->pb, sc->fb, cfg);
         if (timed) HIP_TRY(hipEventRecord(ep->b, stream));
+        if (sc->pb.flag_count) {
+            // the pass's list of whole-number film positions is final after its first k_extend: fetch and sort it on the
+            // host while the GPU works through the rest of the pass, then take the exact tile sums once it is done
+            HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_flags, 0));
+            rc = patch_prepare(sc, S, P, sc->aux_stream, &plan);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(stream));
+            rc = patch_pass_finish(sc, S, &plan, &entries);
+            if (rc) return rc;
+        }
         st.n_passes++;
         st.n_paths += P.n_paths;
     }
@@ -1333,15 +1351,12 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     } else {
         launch_film_resolve(S, P, F, cfg);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(stream));
-        uint64_t n_patched = 0;
-        sc->pb.flag_count = nullptr;
-        if (!planned && pix_slots) {
-            rc = patch_prepare(sc, S, P, k_begin, k_end, st.n_passes == 1, stream, &plan);
+        if (!entries.empty()) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            uint64_t n_patched = 0;
+            rc = patch_merge(sc, S, P, &entries, F.film_xyzw, &n_patched);
             if (rc) return rc;
         }
-        rc = patch_finish(sc, S, &plan, F.film_xyzw, &n_patched);
-        if (rc) return rc;
     }
     sc->pb.flag_count = nullptr;
     HIP_TRY(hipGetLastError());

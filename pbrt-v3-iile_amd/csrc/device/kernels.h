@@ -8,8 +8,11 @@ namespace iile {
 struct PassDesc {
     // tile ownership (SamplerIntegrator::Render's 16x16 tiles, integrator.cpp:235-237)
     int n_tiles_x, n_tiles_y, tile_rank, tile_nranks, n_owned_tiles;
-    int k0, kc;        // sample indices [k0, k0 + kc)
-    uint32_t n_paths;  // n_owned_tiles * 256 * kc, or the explicit list length
+    // a pass renders ALL samples [k0, k0 + kc) of the owned tiles [slot0, slot0 + n_pass_tiles): whole tiles, so that
+    // every FilmTile sum is complete when the pass ends (path id = ((slot - slot0) * 256 + pixel) * kc + k - k0)
+    int slot0, n_pass_tiles;
+    int k0, kc;
+    uint32_t n_paths;  // n_pass_tiles * 256 * kc, or the explicit list length
     // explicit path list (kernel-level tests); null for tile enumeration
     const int *list_px, *list_py, *list_k;
     // IISPT probe batch: n_owned_tiles = n_probes * tiles per probe, tile slot = probe * tiles + tile
@@ -99,6 +102,8 @@ void launch_camera(const DScene &S, int n, const float *pfilm, const float *plen
 void launch_bsdf_probe(const DScene &S, int n, int mat, const float *wo, const float *wi_or_u, int sample,
                        float *out, const LaunchCfg &cfg);
 void launch_trig_probe(int n, const float *x, float *out, const LaunchCfg &cfg);
+void launch_patch_own(const DScene &S, const float4 *L, int n, const uint32_t *local_slot, const uint32_t *range3, const uint32_t *flag_pid,
+                      int kc, float4 *out, const LaunchCfg &cfg);
 void launch_gather4(const float4 *src, const uint32_t *idx, int n, float4 *out, const LaunchCfg &cfg);
 void launch_scatter4(float4 *dst, const uint32_t *idx, int n, const float4 *in, const LaunchCfg &cfg);
 void launch_texture_probe(const DScene &S, int n, int tex, const float *uv, const float *duv, float *out, const LaunchCfg &cfg);

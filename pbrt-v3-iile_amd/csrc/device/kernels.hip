@@ -200,7 +200,7 @@ DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, i
         *k = uint32_t(P.k0) + kk;
         return *px >= S.crop_x0 && *py >= S.crop_y0 && *px < S.crop_x1 && *py < S.crop_y1;
     }
-    const int tile = P.tile_rank + int(slot) * P.tile_nranks;
+    const int tile = P.tile_rank + (P.slot0 + int(slot)) * P.tile_nranks;
     const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
     *px = S.samp_x0 + tx * kTile + int(pix & 15u);
     *py = S.samp_y0 + ty * kTile + int(pix >> 4);
@@ -1239,12 +1239,13 @@ DEV F3 guard_radiance(const DScene &S, F3 L) {
 // sample order, to the pixel's RGB contribSum (FilmTile::AddSample, film.h:153-193
 // with the box filter: weight 1 for the pixel containing pFilm).
 __global__ __launch_bounds__(kBlock) void k_film_accumulate(DScene S, PassDesc P, PassBuffers B, FilmBuffers F) {
-    const uint32_t n_pix = uint32_t(P.n_owned_tiles) * 256u;
-    for (uint32_t pt = blockIdx.x * kBlock + threadIdx.x; pt < n_pix; pt += gridDim.x * kBlock) {
+    const uint32_t n_pix = uint32_t(P.n_pass_tiles) * 256u;
+    for (uint32_t lpt = blockIdx.x * kBlock + threadIdx.x; lpt < n_pix; lpt += gridDim.x * kBlock) {
         int px, py;
         uint32_t k;
-        const uint32_t pid0 = pt * uint32_t(P.kc);
+        const uint32_t pid0 = lpt * uint32_t(P.kc);
         if (!path_pixel(S, P, pid0, &px, &py, &k)) continue;
+        const uint32_t pt = uint32_t(P.slot0) * 256u + lpt;  // the pixel's slot among all owned tiles
         float4 acc = F.tile_rgbw[pt];
         // A lane's samples are consecutive in memory (1 KB apart from its neighbour's at 64 spp):
         // eight loads = one whole 128-byte line are issued together, then summed in sample order.
@@ -1290,7 +1291,7 @@ __global__ __launch_bounds__(kBlock) void k_film_store(DScene S, PassDesc P, Pas
         const F3 L = guard_radiance(S, F3{L4.x, L4.y, L4.z});
         const uint32_t idx = B.hindex[pid];
         // [tile slot][k][pixel of the tile]: the gather's lanes (neighbouring film pixels) read neighbouring records
-        const uint32_t pt = pid / uint32_t(P.kc);
+        const uint32_t pt = uint32_t(P.slot0) * 256u + pid / uint32_t(P.kc);
         const size_t at = (size_t(pt >> 8) * size_t(n_samples) + size_t(int(k) - k_begin)) * 256u + size_t(pt & 255u);
         F.wide_L[at] = make_float4(L.x, L.y, L.z, 0.f);
         F.wide_pf[at] = make_float2(float(px) + sample_dimension(S, idx, 0), float(py) + sample_dimension(S, idx, 1));
@@ -1697,7 +1698,7 @@ void launch_mis_lit(const DScene &S, const PassBuffers &B, int bounce, uint32_t 
 }
 void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F,
                             const LaunchCfg &cfg) {
-    hipLaunchKernelGGL(k_film_accumulate, dim3(grid_blocks(uint32_t(P.n_owned_tiles) * 256u, cfg.n_cus, 8)),
+    hipLaunchKernelGGL(k_film_accumulate, dim3(grid_blocks(uint32_t(P.n_pass_tiles) * 256u, cfg.n_cus, 8)),
                        dim3(kBlock), 0, cfg.stream, S, P, B, F);
 }
 void launch_film_store(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int k_begin, int n_samples,
@@ -1770,6 +1771,32 @@ __global__ void k_gather4(const float4 *src, const uint32_t *idx, int n, float4 
 __global__ void k_scatter4(float4 *dst, const uint32_t *idx, int n, const float4 *in) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[idx[i]] = in[i];
+}
+// One exact FilmTile sum per thread for a pixel that receives flagged samples from pixels generated before it in its
+// own tile: those samples first, then its own kc samples, then the flagged samples of later pixels — all in generation
+// order, guarded like k_film_accumulate (see patch_pass_finish in api.hip).
+__global__ void k_patch_own(DScene S, const float4 *L, int n, const uint32_t *local_slot, const uint32_t *range3, const uint32_t *flag_pid,
+                            int kc, float4 *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0, g = 0, b = 0, w = 0;
+    auto add = [&](float4 v) {
+        const F3 c = guard_radiance(S, F3{v.x, v.y, v.z});
+        r += c.x * 1.f * 1.f;
+        g += c.y * 1.f * 1.f;
+        b += c.z * 1.f * 1.f;
+        w += 1.f;
+    };
+    const uint32_t b0 = range3[3 * i], b1 = range3[3 * i + 1], b2 = range3[3 * i + 2];
+    for (uint32_t h = b0; h < b1; ++h) add(L[flag_pid[h]]);
+    const uint32_t first = local_slot[i] * uint32_t(kc);
+    for (int k = 0; k < kc; ++k) add(L[first + uint32_t(k)]);
+    for (uint32_t h = b1; h < b2; ++h) add(L[flag_pid[h]]);
+    out[i] = make_float4(r, g, b, w);
+}
+void launch_patch_own(const DScene &S, const float4 *L, int n, const uint32_t *local_slot, const uint32_t *range3, const uint32_t *flag_pid,
+                      int kc, float4 *out, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_patch_own, dim3((n + 63) / 64), dim3(64), 0, cfg.stream, S, L, n, local_slot, range3, flag_pid, kc, out);
 }
 void launch_gather4(const float4 *src, const uint32_t *idx, int n, float4 *out, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_gather4, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, src, idx, n, out);
