@@ -1003,6 +1003,15 @@ int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, hipStream
     for (size_t a = 0; a < hits.size();) {
         size_t b = a;
         while (b < hits.size() && hits[b].first == hits[a].first) ++b;
+        if (Pf.n_pass_tiles == Pf.n_owned_tiles) {
+            // the pass is the whole frame: a pixel reached only by samples k_film_resolve places itself needs nothing
+            bool only_plain = true;
+            for (size_t h = a; h < b; ++h) only_plain = only_plain && fl[hits[h].second].plain_k0;
+            if (only_plain) {
+                a = b;
+                continue;
+            }
+        }
         PatchDest d;
         d.film_index = hits[a].first;
         d.first = a, d.last = b;
@@ -1031,6 +1040,7 @@ int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, hipStream
         a = b;
     }
     (void)n_k;  // (the own samples of need_own pixels are summed on the device: k_patch_own)
+    if (dests.empty()) return IILE_OK;
     tm.lap("lists");
     if (tm.on) std::fprintf(stderr, "[patch] pass at slot %d: %u flagged samples, %zu pixels reached, %zu radiances to gather\n", Pf.slot0, n_flag, dests.size(), plan->list_pid.size());
     plan->active = true;
