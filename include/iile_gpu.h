@@ -54,7 +54,8 @@ typedef struct iile_render_params {
     int32_t k_begin, k_end;         /* sample indices [k_begin, k_end); k_end <= 0: all pixelsamples */
     int32_t tile_rank, tile_nranks; /* this call renders the 16x16 tiles with index % nranks == rank;
                                        nranks <= 0: all tiles (single GPU) */
-    int32_t spp_per_pass;           /* samples per wavefront pass; 0 = sized to the workspace budget */
+    int32_t spp_per_pass;           /* 0 = passes sized to the workspace budget. A pass renders all samples of a range
+                                       of tiles; > 0 asks for passes of about (owned pixels x spp_per_pass) paths (tests) */
     int32_t collect_stats;          /* 1: instrumented kernels (ray / node / triangle counters) */
     int32_t time_kernels;           /* 1: bracket every kernel with HIP events on `stream` */
     int32_t film_on_device;         /* 1: film_xyzw is a device pointer (stays in HBM) */

@@ -1279,9 +1279,9 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate(DScene S, PassDesc P
 
 // Filters wider than a pixel (gaussian, mitchell, sinc, triangle, larger boxes). A pixel then sums samples of
 // neighbouring pixels and tiles, in the order FilmTile::AddSample / MergeFilmTile give: inside a tile in pixel
-// (row-major) then sample order, tiles in index order. That order cuts across passes (a pass holds a range of k
-// for every pixel), so the frame's samples are kept — k_film_store, 24 B each — and summed once at the end by a
-// gather per film pixel (k_film_gather).
+// (row-major) then sample order, tiles in index order. The neighbouring pixels may belong to tiles of another pass, so
+// the frame's samples are kept — k_film_store, 24 B each — and summed once at the end by a gather per film pixel
+// (k_film_gather).
 __global__ __launch_bounds__(kBlock) void k_film_store(DScene S, PassDesc P, PassBuffers B, FilmBuffers F, int k_begin, int n_samples) {
     for (uint32_t pid = blockIdx.x * kBlock + threadIdx.x; pid < P.n_paths; pid += gridDim.x * kBlock) {
         int px, py;
