@@ -1,6 +1,6 @@
 """BASELINE config 1 in full: killeroo-simple 1920x1080 x 64 spp rendered by the GPU kernels bench.py times and by
 the CPU oracle on all host cores, compared bit for bit (film {X, Y, Z, weight} and the traversal counters).
-usage: python tools/full_frame_parity.py [out.json] [boxroom-textured SPP]   (default: killeroo-simple at 64 spp)"""
+usage: python tools/full_frame_parity.py [out.json] [boxroom-textured SPP | killeroo SPP]   (default: killeroo-simple at 64 spp)"""
 import json
 import os
 import sys
@@ -27,6 +27,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "boxroom-textured":
     tmp.close()
     scene = b.HostScene(path=tmp.name)
     workload = f"synthetic textured boxroom (tests/boxroom.py: environment map, image / scale textures, bump maps, alpha masks) 1920x1080, {spp} spp"
+elif len(sys.argv) > 3 and sys.argv[2] == "killeroo":
+    spp = int(sys.argv[3])
+    scene = b.HostScene(xres=1920, yres=1080, spp=spp)
+    workload = f"killeroo-simple 1920x1080, {spp} spp, path maxdepth 5 (BASELINE.json configs[2] is this frame at 1024 spp over 8 GPUs)"
 else:
     scene = b.HostScene(xres=1920, yres=1080, spp=64)
 gpu = b.GpuScene(scene)
