@@ -81,6 +81,9 @@ typedef struct iile_material {
     /* "bumpmap": a float image texture (its float in all three channels of the texels) displacing the shading
      * geometry at a hit (Material::Bump, src/core/material.cpp:45-86), or -1 */
     int32_t bump_tex;
+    /* "roughness" of plastic / uber as a float image texture, looked up at the hit and mapped by RoughnessToAlpha
+     * if remap_roughness (plastic.cpp:60-63, uber.cpp:79-84, microfacet.h:123-128), or -1 */
+    int32_t rough_tex;
 } iile_material;
 
 /* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (src/textures/imagemap.h:78-112,

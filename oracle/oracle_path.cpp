@@ -1537,6 +1537,15 @@ struct Oracle {
                 b.has_micro = true;
                 b.ks = ks;
                 b.alpha = m.alpha;
+                if (m.rough_tex >= 0) {  // roughness->Evaluate(*si), then RoughnessToAlpha (microfacet.h:123-128)
+                    float rough = tex_evaluate(m.rough_tex, is).c[0];
+                    if (m.remap_roughness) {
+                        rough = std::max(rough, 1e-3f);
+                        const float x = trig.log_f(rough);
+                        rough = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+                    }
+                    b.alpha = rough;
+                }
                 if (m.type == IILE_MAT_UBER) {  // FresnelDielectric(1.f, e), uber.cpp:70
                     b.micro_eta_i = 1.f;
                     b.micro_eta_t = m.eta;

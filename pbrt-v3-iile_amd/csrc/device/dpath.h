@@ -1215,6 +1215,15 @@ DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect
         const F3 c = tex_evaluate(S, m.kr_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
         r.kr[0] = c.x * m.kr[0], r.kr[1] = c.y * m.kr[1], r.kr[2] = c.z * m.kr[2];
     }
+    if (m.rough_tex >= 0) {  // roughness->Evaluate(*si), then RoughnessToAlpha (microfacet.h:123-128)
+        float rough = tex_evaluate(S, m.rough_tex, is.u, is.v, td).x;
+        if (m.remap_roughness) {
+            rough = mx(rough, 1e-3f);
+            const float x = log_f(rough);
+            rough = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+        }
+        r.alpha = rough;
+    }
     if (m.kt_tex >= 0) {
         const F3 c = tex_evaluate(S, m.kt_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
         r.kt[0] = c.x * m.kt[0], r.kt[1] = c.y * m.kt[1], r.kt[2] = c.z * m.kt[2];

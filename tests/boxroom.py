@@ -182,6 +182,7 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
                    '"float uscale" [1.5] "float vscale" [1.5] "float maxanisotropy" [2]' % tex["noise"])
         out.append('Texture "stripes" "spectrum" "imagemap" "string filename" ["%s"] "bool gamma" ["false"]' % tex["stripes"])
         out.append('Texture "noise-tint" "spectrum" "scale" "texture tex1" ["noise"] "color tex2" [.9 .6 .3]')
+        out.append('Texture "rough" "float" "imagemap" "string filename" ["%s"] "float scale" [4] "bool gamma" ["false"]' % tex["bumps"])
         out.append('Texture "bumps" "float" "imagemap" "string filename" ["%s"] "float uscale" [4] "float vscale" [4]' % tex["bumps"])
         # alpha masks (triangle.cpp:325-331, 509-541): a free-standing screen full of holes whose shadow has
         # further holes (shadowalpha), and an invisible box ("float alpha" [0]) around a blob
@@ -235,7 +236,8 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
             mat = 'Material "glass" "color Kr" [1 1 1] "color Kt" [%g %g %g] "float index" [%g]' % (
                 *((1, 1, 1) if b % 4 == 1 else rng.uniform(.7, 1, 3)), rng.uniform(1.3, 1.7))
         elif tex is not None and b % 4 == 0:  # blobs have no uv: every triangle maps the unit half-square
-            mat = 'Material "plastic" "texture Kd" ["noise"] "texture Ks" ["stripes"] "float roughness" [%g]' % rng.uniform(.02, .3)
+            mat = 'Material "plastic" "texture Kd" ["noise"] "texture Ks" ["stripes"] "texture roughness" ["rough"]'
+            rng.uniform(.02, .3)
         elif tex is not None and b % 4 == 2:  # smooth-shaded (vertex normals: dn/du, dn/dv enter Material::Bump) and bumpy
             mat = 'Material "plastic" "color Kd" [.5 .4 .2] "color Ks" [.3 .3 .3] "float roughness" [.1] "texture bumpmap" ["bumps"]'
             nrm = P - c

@@ -849,3 +849,22 @@ def test_light_sample_strategies_are_unbiased(binding, oracle, tmp_path):
         films[strategy] = film
         assert abs(float(scene.film_to_rgb(film).mean(dtype=np.float64)) - 1.0) < 0.02, strategy
     assert not np.array_equal(films["uniform"], films["power"]) and not np.array_equal(films["uniform"], films["spatial"])
+
+
+def test_roughness_from_a_constant_image_matches_the_constant(binding, oracle, tmp_path):
+    """"roughness" as a float image texture (plastic.cpp:60-63: roughness->Evaluate, then RoughnessToAlpha): a
+    constant image gives the film of the constant parameter, to the rounding of the bilinear weights' sum."""
+    import os
+    src = open(os.path.join(os.path.dirname(__file__), "golden", "scenes", "furnace_tetrahedron.pbrt")).read()
+    assert 'Material "matte"' in src
+    (tmp_path / "r.pfm").write_bytes(b"Pf\n4 4\n-1.0\n" + np.full((4, 4), np.float32(.25), np.float32).tobytes())
+    plain = src.replace('Sampler "halton" "integer pixelsamples" [256]', 'Sampler "halton" "integer pixelsamples" [16]')
+    assert plain != src
+    films = []
+    for mat in ('Material "plastic" "color Kd" [.3 .3 .3] "color Ks" [.2 .2 .2] "float roughness" [.25]',
+                'Texture "r" "float" "imagemap" "string filename" ["r.pfm"]\nMaterial "plastic" "color Kd" [.3 .3 .3] "color Ks" [.2 .2 .2] "texture roughness" ["r"]'):
+        i = plain.index('Material "matte"')
+        j = plain.index("\n", i)
+        (tmp_path / "s.pbrt").write_text(plain[:i] + mat + plain[j:])
+        films.append(oracle.render(binding.HostScene(path=str(tmp_path / "s.pbrt")), trig_mode=ob.TRIG_LIBM)[0])
+    assert films[0][..., 1].max() > 0 and np.allclose(films[1], films[0], rtol=1e-4, atol=0)
