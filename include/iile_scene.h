@@ -84,6 +84,8 @@ typedef struct iile_material {
     /* "roughness" of plastic / uber as a float image texture, looked up at the hit and mapped by RoughnessToAlpha
      * if remap_roughness (plastic.cpp:60-63, uber.cpp:79-84, microfacet.h:123-128), or -1 */
     int32_t rough_tex;
+    /* "sigma" of matte as a float image texture (degrees, clamped to [0, 90] at the hit: matte.cpp:56-61), or -1 */
+    int32_t sigma_tex;
 } iile_material;
 
 /* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (src/textures/imagemap.h:78-112,

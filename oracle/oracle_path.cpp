@@ -1525,7 +1525,16 @@ struct Oracle {
             b.has_lambert = true;
             b.kd = kd;
             ++b.n_lobes;
-            if (m.type == IILE_MAT_MATTE && m.sigma != 0) {  // matte.cpp:56-61
+            if (m.type == IILE_MAT_MATTE && m.sigma_tex >= 0) {  // sigma->Evaluate(*si), matte.cpp:56-61; OrenNayar ctor, reflection.h:414-420
+                const float sig = clampf(tex_evaluate(m.sigma_tex, is).c[0], 0.f, 90.f);
+                if (sig != 0) {
+                    const float sg = (Pi / 180) * sig;
+                    const float sigma2 = sg * sg;
+                    b.oren_nayar = true;
+                    b.on_a = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                    b.on_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+                }
+            } else if (m.type == IILE_MAT_MATTE && m.sigma != 0) {  // matte.cpp:56-61
                 b.oren_nayar = true;
                 b.on_a = m.on_a;
                 b.on_b = m.on_b;

@@ -578,10 +578,11 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             mats[i].kt_tex = d->n_textures > 0 ? m.kt_tex : -1;
             mats[i].bump_tex = d->n_textures > 0 ? m.bump_tex : -1;
             mats[i].rough_tex = d->n_textures > 0 ? m.rough_tex : -1;
+            mats[i].sigma_tex = d->n_textures > 0 ? m.sigma_tex : -1;
             mats[i].remap_roughness = m.remap_roughness;
-            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex})
+            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex})
                 if (t >= 0) S.textured_materials = 1;
-            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex})
+            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex})
                 if (t >= d->n_textures) return bail(fail(IILE_ERR_ARG, "material refers to a texture that does not exist"));
         }
         rc = upload(sc, mats.data(), mats.size(), &S.materials);
@@ -619,7 +620,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             for (int i = 0; i < d->n_prims; ++i)
                 if ((d->prim_flags[i] & IILE_PRIM_SPHERE) && d->prim_material[i] >= 0) {
                     const iile_material &m = d->materials[d->prim_material[i]];
-                    if (m.kd_tex >= 0 || m.ks_tex >= 0 || m.kr_tex >= 0 || m.kt_tex >= 0 || m.bump_tex >= 0 || m.rough_tex >= 0)
+                    if (m.kd_tex >= 0 || m.ks_tex >= 0 || m.kr_tex >= 0 || m.kt_tex >= 0 || m.bump_tex >= 0 || m.rough_tex >= 0 || m.sigma_tex >= 0)
                         return bail(fail(IILE_ERR_UNSUPPORTED, "image textures on spheres are not supported"));
                 }
         }

@@ -1215,6 +1215,17 @@ DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect
         const F3 c = tex_evaluate(S, m.kr_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
         r.kr[0] = c.x * m.kr[0], r.kr[1] = c.y * m.kr[1], r.kr[2] = c.z * m.kr[2];
     }
+    if (m.sigma_tex >= 0) {  // sigma->Evaluate(*si), matte.cpp:56-61; OrenNayar's constants, reflection.h:414-420
+        const float sig = clampf(tex_evaluate(S, m.sigma_tex, is.u, is.v, td).x, 0.f, 90.f);
+        r.on_a = 1.f;
+        r.on_b = 0.f;
+        if (sig != 0) {
+            const float sg = (kPi / 180) * sig;
+            const float sigma2 = sg * sg;
+            r.on_a = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+            r.on_b = 0.45f * sigma2 / (sigma2 + 0.09f);
+        }
+    }
     if (m.rough_tex >= 0) {  // roughness->Evaluate(*si), then RoughnessToAlpha (microfacet.h:123-128)
         float rough = tex_evaluate(S, m.rough_tex, is.u, is.v, td).x;
         if (m.remap_roughness) {

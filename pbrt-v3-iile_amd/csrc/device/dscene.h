@@ -33,6 +33,7 @@ struct DMaterial {
     float on_a, on_b;  // matte with sigma != 0: Oren-Nayar A, B (on_b == 0 and on_a == 1 otherwise)
     int kd_tex, ks_tex, kr_tex, kt_tex;  // image texture replacing the constant at a hit, or -1
     int bump_tex;                        // float image texture displacing the shading geometry (Material::Bump), or -1
+    int sigma_tex;                       // float image texture for matte's "sigma" (Oren-Nayar A, B per hit), or -1
     int rough_tex, remap_roughness;      // float image texture for "roughness" (-1: the constant alpha), RoughnessToAlpha or not
 };
 // ImageTexture + MIPMap (iile_texture): level l holds w x h float4 texels (rgb, w unused) at

@@ -716,10 +716,10 @@ class Loader {
             if (p.strs.size() != 1) return fail("bad texture reference for \"" + p.name + "\"");
             auto it = gs_.textures.find(p.strs[0]);
             if (it == gs_.textures.end()) return fail("Couldn't find texture named \"" + p.strs[0] + "\" for parameter \"" + p.name + "\"");
-            if (it->second.image >= 0 && it->second.is_float && (p.name == "bumpmap" || p.name == "roughness")) {
+            if (it->second.image >= 0 && it->second.is_float && (p.name == "bumpmap" || p.name == "roughness" || p.name == "sigma")) {
                 (*image_of)[p.name] = it->second.image;
                 p.strs.clear();
-                p.type = p.name == "bumpmap" ? "bumpimage" : "roughimage";  // consumed below; no material reads a parameter of these types
+                p.type = p.name == "bumpmap" ? "bumpimage" : (p.name == "sigma" ? "sigmaimage" : "roughimage");  // consumed below; no material reads a parameter of these types
                 continue;
             }
             if (it->second.image >= 0) {
@@ -751,7 +751,7 @@ class Loader {
         if (!resolve_textures(ps_in, &ps, &image_of)) return -1;
         iile_material m;
         std::memset(&m, 0, sizeof(m));
-        m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = -1;
+        m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = -1;
         auto image = [&](const char *param) {
             auto it = image_of.find(param);
             return it == image_of.end() ? -1 : it->second;
@@ -840,6 +840,14 @@ class Loader {
             fail("uber: specular transmission (Kt) is not supported");
             return -1;
         }
+        if (const Param *sp = ps.find("sigma"))
+            if (sp->type == "sigmaimage") {
+                if (m.type != IILE_MAT_MATTE) {
+                    fail("sigma: a float \"imagemap\" texture is supported on matte only");
+                    return -1;
+                }
+                m.sigma_tex = image("sigma");
+            }
         if (const Param *rp = ps.find("roughness"))
             if (rp->type == "roughimage") {
                 if ((m.type != IILE_MAT_PLASTIC && m.type != IILE_MAT_UBER) || ps.find("uroughness") || ps.find("vroughness")) {
@@ -874,7 +882,7 @@ class Loader {
         if (name == "sphere") {  // shapes/sphere.cpp:318-327, sphere.h:50-60
             {
                 const iile_material &sm = s.materials[size_t(mat)];
-                if (sm.kd_tex >= 0 || sm.ks_tex >= 0 || sm.kr_tex >= 0 || sm.kt_tex >= 0 || sm.bump_tex >= 0 || sm.rough_tex >= 0)
+                if (sm.kd_tex >= 0 || sm.ks_tex >= 0 || sm.kr_tex >= 0 || sm.kt_tex >= 0 || sm.bump_tex >= 0 || sm.rough_tex >= 0 || sm.sigma_tex >= 0)
                     return fail("image textures on spheres are not supported (triangle meshes only)");
             }
             float radius = ps.one_float("radius", 1.f);

@@ -182,6 +182,7 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
                    '"float uscale" [1.5] "float vscale" [1.5] "float maxanisotropy" [2]' % tex["noise"])
         out.append('Texture "stripes" "spectrum" "imagemap" "string filename" ["%s"] "bool gamma" ["false"]' % tex["stripes"])
         out.append('Texture "noise-tint" "spectrum" "scale" "texture tex1" ["noise"] "color tex2" [.9 .6 .3]')
+        out.append('Texture "sigma" "float" "imagemap" "string filename" ["%s"] "float scale" [700] "bool gamma" ["false"]' % tex["bumps"])
         out.append('Texture "rough" "float" "imagemap" "string filename" ["%s"] "float scale" [4] "bool gamma" ["false"]' % tex["bumps"])
         out.append('Texture "bumps" "float" "imagemap" "string filename" ["%s"] "float uscale" [4] "float vscale" [4]' % tex["bumps"])
         # alpha masks (triangle.cpp:325-331, 509-541): a free-standing screen full of holes whose shadow has
@@ -245,7 +246,7 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
             out.append('AttributeBegin\n  %s\n%s  "normal N" [ %s ]\nAttributeEnd' % (mat, _mesh(P, F), _fmt(nrm)))
             continue
         elif tex is not None and b % 4 == 1:
-            mat = 'Material "matte" "texture Kd" ["checker"]'
+            mat = 'Material "matte" "texture Kd" ["checker"] "texture sigma" ["sigma"]'
         elif b % 2 == 0:
             mat = 'Material "plastic" "color Kd" [%g %g %g] "color Ks" [.4 .4 .4] "float roughness" [%g]' % (
                 *rng.uniform(.2, .7, 3), rng.uniform(.02, .3))
