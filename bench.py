@@ -209,9 +209,13 @@ def main():
         for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))[::-1]:
             try:
                 tj = json.load(open(f))
-                ent = tj["kernels"].get(dom + "<false, false>") or tj["kernels"].get(dom + "<false>")
-                if ent and world == 1 and (args.xres, args.yres, args.spp, args.workload) == (1920, 1080, 64, "killeroo"):
-                    traffic, traffic_src = ent["hbm_bytes_per_launch"], os.path.basename(f)
+                # the product builds of the kernel (no counting, no alpha; k_extend has one more template argument:
+                # its first launch of a step also makes the camera rays), averaged over the launches of a step
+                ents = [v for k, v in tj["kernels"].items() if k.startswith(dom + "<false, false") or k == dom + "<false>"]
+                if ents and world == 1 and (args.xres, args.yres, args.spp, args.workload) == (1920, 1080, 64, "killeroo"):
+                    n_l = sum(e.get("launches_in_step", 1) for e in ents)
+                    traffic = int(sum(e["hbm_bytes_per_launch"] * e.get("launches_in_step", 1) for e in ents) / n_l)
+                    traffic_src = os.path.basename(f)
                     break
             except Exception:
                 pass
@@ -230,10 +234,14 @@ def main():
             per_kernel[k] = {"ms_per_step": round(ms_k_ / args.steps, 3),
                              "algorithmic_gbs": round(by_ * args.steps / max(ms_k_, 1e-9) / 1e6, 1)}
         for k, (ms_k_, by_, note_) in other.items():
+            if ms_k_ <= 0:  # k_generate when camera rays are made inside k_extend's first launch: nothing to price
+                per_kernel[k] = {"ms_per_step": 0.0, "algorithmic_gbs": None, "note": note_ + " (not launched: fused into k_extend)"}
+                continue
             per_kernel[k] = {"ms_per_step": round(ms_k_ / args.steps, 3),
                              "algorithmic_gbs": round(by_ * args.steps / max(ms_k_, 1e-9) / 1e6, 1), "note": note_}
         for k in per_kernel:
-            per_kernel[k]["frac_of_hbm_peak"] = round(per_kernel[k]["algorithmic_gbs"] / HBM_PEAK_GBS, 4)
+            g_ = per_kernel[k]["algorithmic_gbs"]
+            per_kernel[k]["frac_of_hbm_peak"] = None if g_ is None else round(g_ / HBM_PEAK_GBS, 4)
         copy_gbs = measured_copy_gbs(torch)
         ms_k, n_launch, bytes_step, rays_k = kernels[dom]
         launches_per_step = n_launch / args.steps
