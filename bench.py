@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — Mray/s and samples/s of the HIP path tracer on killeroo-simple 1080p.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
 A *step* is one complete pass of the hot path over the configured workload:
-SamplerIntegrator::Render of killeroo-simple at 1920x1080, 64*N pixel samples,
-16x16 tiles interleaved over the N ranks (one process per GPU; for N > 1 the
-driver launches this file through torch.distributed.run), finished by ONE
-sum-reduction of the {X,Y,Z,w} film to rank 0 over RCCL. Per-GPU work is fixed
-as N grows (each rank renders 1/N of the tiles at 64*N spp), so scaling is weak.
-The film stays in HBM for the whole timed region.
+SamplerIntegrator::Render of killeroo-simple at 1920x1080 through the C ABI (iile_render), 16x16 tiles
+shared out over the N ranks by iile_tile_owner (one process per GPU; for N > 1 the driver launches this
+file through torch.distributed.run), finished by ONE sum-reduction of the {X,Y,Z,w} film to rank 0 over
+RCCL through the C ABI (iile_dist_film_reduce). The film stays in HBM for the whole timed region.
 
-Rank 0 prints one JSON line. `value` is whole-job Mray/s (rays = Scene::Intersect +
-Scene::IntersectP calls, the reference's own ray definition); `roofline` prices
-the dominant kernel against the HBM roof using SURVEY.md §8(d)'s algorithmic
-bytes per ray; `cpu_baseline` is the CPU oracle timed on this box's host cores on
-a bounded sample of the same workload (baseline only).
+Workloads (BASELINE.json configs):
+  N = 1                      config 2: 1920x1080 x 64 spp on one GPU
+  N > 1, --scaling weak      1920x1080 x 128*N spp, every rank renders its 1/N of the tiles at 128*N spp:
+                             per-GPU work fixed; N = 8 is config 3 (1024 spp over 8 GPUs)
+  --scaling strong           the fixed 1920x1080 x 1024 spp frame of config 3 at any N
+The primary mode's number is `value`; the other mode is measured too (a few steps, `--other-steps 0`
+turns it off) and reported under `other_mode`, so that one run per N yields both curves.
+
+Rank 0 prints one JSON line. `value` is whole-job Mray/s (rays = Scene::Intersect + Scene::IntersectP calls,
+the reference's own ray definition). `roofline` prices the kernel with the largest HIP-event time against the
+HBM roof by its algorithmic bytes and by the PMC-counted HBM traffic, and says what actually binds it (VALU
+issue) with the counters committed under profiles/; `cpu_baseline` is the CPU oracle timed on this box's host
+cores on a bounded sample of the same workload (baseline only).
+
+The timed region verifies itself: the film of the last timed step must equal, bit for bit, the film of the
+instrumented step (different kernel builds: counting, binary BVH steps, separate camera-ray generation), and the
+run refuses to start with any IILE_DEBUG_* / IILE_NO_* switch in the environment.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -27,7 +38,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0    # aggregate L2 bandwidth, same guide ("L2 (per XCD)")
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # CUs x SIMDs x lanes per clock x max clock: 78.6 T lane-ops/s
 
 
 def algorithmic_bytes(rays, nodes, tris):
@@ -53,6 +66,12 @@ def measured_copy_gbs(torch):
     return 5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+# Per-thread rate of the reference binary relative to this port, from the one measurement that exists of both on the
+# same machine (the reference's own build rendered C1 at 5.8 Mray/s on 8 threads of the survey
+# container; the oracle renders the same frame at 3.9 Mray/s there).
+PORT_VS_REFERENCE = 3.9 / 5.8
+
+
 def cpu_baseline(scene_path, xres, yres, target_seconds, workload_name="killeroo-simple"):
     """Time the CPU oracle (restatement of the reference path, all host cores, 16x16
     tile self-scheduling, render loop only) on a bounded number of pixel samples."""
@@ -75,7 +94,34 @@ def cpu_baseline(scene_path, xres, yres, target_seconds, workload_name="killeroo
         "sample": f"{workload_name} {xres}x{yres}, pixel samples k=1..{n} of 64 ({st['camera_rays']} camera samples, "
                   f"{rays} rays, {st['seconds']:.2f} s, libm trig)",
         "msamples_per_s": round(st["camera_rays"] / st["seconds"] / 1e6, 4),
+        "note": f"a port, not the reference binary (which cannot be built in this image): on the one machine where "
+                f"both were timed (BASELINE.md §2, 8 threads) the port ran {PORT_VS_REFERENCE:.2f}x the reference's rate, "
+                f"so the reference on these cores would be about {1 / PORT_VS_REFERENCE:.2f}x this value; the port also "
+                f"scales sub-linearly past ~64 threads (tile self-scheduling over {((xres + 15) // 16) * ((yres + 15) // 16)} tiles, "
+                f"shared L3)",
+        "value_scaled_to_reference": round(rays / st["seconds"] / 1e6 / PORT_VS_REFERENCE, 3),
     }
+
+
+def load_pmc(world, args):
+    """The committed counter summaries (tools/summarize_profiles.py): newest profiles/*_pmc_traffic.json and
+    *_pmc_lanes.json. They describe the default workload on one GPU only."""
+    if not (world == 1 and (args.xres, args.yres, args.spp, args.workload) == (1920, 1080, 64, "killeroo")):
+        return {}, {}, None, None
+
+    def newest(pattern):
+        for f in sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))[::-1]:
+            try:
+                j = json.load(open(f))
+                if "families" in j:
+                    return j["families"], os.path.basename(f)
+            except Exception:
+                pass
+        return {}, None
+
+    tr, tr_src = newest("*_pmc_traffic.json")
+    la, la_src = newest("*_pmc_lanes.json")
+    return tr, la, tr_src, la_src
 
 
 def main():
@@ -85,7 +131,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--xres", type=int, default=1920)
     ap.add_argument("--yres", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64, help="pixel samples per GPU-equivalent (total = spp * gpus)")
+    ap.add_argument("--spp", type=int, default=0,
+                    help="weak mode: pixel samples per GPU-equivalent (total = spp * gpus); default 64 at 1 GPU "
+                         "(BASELINE config 2), 128 at N > 1 (N = 8: config 3's 1024 spp)")
+    ap.add_argument("--strong-spp", type=int, default=1024, help="strong mode: pixel samples of the fixed frame (config 3)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--other-steps", type=int, default=2, help="timed steps of the other scaling mode (0: skip it)")
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--scene", default=os.path.join(REPO, "scenes", "killeroo-simple.pbrt"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
@@ -95,17 +146,38 @@ def main():
                          "boxroom-textured: the same room open to an environment-mapped sky, with image textures, "
                          "alpha masks and specular materials (the whole feature set of SURVEY.md 8 f1)")
     args = ap.parse_args()
+
+    bad_env = sorted(k for k in os.environ if k.startswith("IILE_DEBUG") or k.startswith("IILE_NO_"))
+    if bad_env:
+        raise SystemExit(f"bench.py refuses to run with {bad_env} set: those switches change what the kernels do")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
+    if args.spp <= 0:
+        args.spp = 64 if world == 1 else 128
+
+    cleanup = []
     workload_name = "killeroo-simple"
     if args.workload in ("boxroom", "boxroom-textured"):
+        import atexit
+        import shutil
         import tempfile
         import boxroom
         tmp = tempfile.NamedTemporaryFile("w", suffix=".pbrt", delete=False)
+        cleanup.append(tmp.name)
+        atexit.register(lambda: [shutil.rmtree(p, ignore_errors=True) if os.path.isdir(p) else (os.path.exists(p) and os.remove(p))
+                                 for p in cleanup])
         if args.workload == "boxroom":
             tmp.write(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64))
             workload_name = "synthetic boxroom (287k triangles, tests/boxroom.py)"
         else:
-            tmp.write(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64, light="envmap", materials="mixed",
-                                           textures=tempfile.mkdtemp(prefix="boxroom_img_")))
+            texdir = tempfile.mkdtemp(prefix="boxroom_img_")
+            cleanup.append(texdir)
+            tmp.write(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64, light="envmap", materials="mixed", textures=texdir))
             workload_name = "synthetic textured boxroom (266k triangles, environment map, image textures, alpha masks; tests/boxroom.py)"
         tmp.close()
         args.scene = tmp.name
@@ -116,158 +188,217 @@ def main():
     ge.build_if_needed()
     b = ge._load_binding()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    total_spp = args.spp * world
-    scene = b.HostScene(path=args.scene, xres=args.xres, yres=args.yres, spp=total_spp)
-    gpu = b.GpuScene(scene)
-    h, w = scene.film_shape
-    film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-
+    dist, comm = None, None
     import importlib.util
     spec = importlib.util.spec_from_file_location("iile_multigpu", os.path.join(REPO, "pbrt-v3-iile_amd", "multigpu.py"))
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
-
-    def step(collect=False, timed=False):
-        box = {}
-
-        def render(tile_rank, tile_nranks):
-            _, box["st"] = gpu.render(tile_rank=tile_rank, tile_nranks=tile_nranks, spp_per_pass=args.spp_per_pass,
-                                      collect_stats=collect, time_kernels=timed, film_device_ptr=film.data_ptr(),
-                                      stream=stream, want_stats=True)
-
-        mg.render_sharded(render, film, dist)  # N > 1: one sum-reduction of the film shards to rank 0 (RCCL)
-        return box["st"]
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        comm = mg.create_comm(dist, f"cuda:{local_rank}")  # the film merge goes through the C ABI (libiile_dist.so)
+    stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # instrumented pass (untimed): ray / node / triangle counts of one step on this rank
-    cst = step(collect=True)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    agg = {"ms_extend": 0.0, "ms_connect": 0.0, "ms_shadow": 0.0, "ms_mis": 0.0, "ms_resolve": 0.0, "ms_shade": 0.0, "ms_generate": 0.0,
-           "ms_film": 0.0, "ms_total": 0.0, "n_extend_launches": 0, "n_connect_launches": 0}
-    for _ in range(args.steps):
-        st = step(timed=True)
-        for k in agg:
-            agg[k] += st[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"]], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        rays_closest, rays_shadow, cam = (int(x) for x in cnt.tolist())
-    else:
-        rays_closest, rays_shadow, cam = cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"]
+    def measure(total_spp, steps, warmup, want_kernels):
+        """Instrumented step, warm-up, `steps` timed steps between barriers; returns the job's numbers (rank 0)."""
+        scene = b.HostScene(path=args.scene, xres=args.xres, yres=args.yres, spp=total_spp)
+        gpu = b.GpuScene(scene)
+        h, w = scene.film_shape
+        film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+
+        def step(collect=False, timed=False):
+            box = {}
+
+            def render(tile_rank, tile_nranks):
+                _, box["st"] = gpu.render(tile_rank=tile_rank, tile_nranks=tile_nranks, spp_per_pass=args.spp_per_pass,
+                                          collect_stats=collect, time_kernels=timed, film_device_ptr=film.data_ptr(),
+                                          stream=stream, want_stats=True)
+
+            mg.render_sharded(render, film, dist, comm=comm, stream=stream)  # N > 1: one RCCL sum-reduction to rank 0
+            return box["st"]
+
+        # instrumented step (untimed): ray / node / triangle counts of one step on this rank, and the film every
+        # timed step must reproduce bit for bit
+        cst = step(collect=True)
+        torch.cuda.synchronize()
+        film_check = film.clone()
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        agg = {"ms_extend": 0.0, "ms_connect": 0.0, "ms_shadow": 0.0, "ms_mis": 0.0, "ms_resolve": 0.0, "ms_shade": 0.0,
+               "ms_generate": 0.0, "ms_film": 0.0, "ms_total": 0.0, "n_extend_launches": 0, "n_connect_launches": 0,
+               "n_shade_launches": 0}
+        st = None
+        for _ in range(steps):
+            st = step(timed=want_kernels)
+            for k in agg:
+                agg[k] += st[k]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # self-verification of the timed region: every rank's last timed film (rank 0: the merged film) against the
+        # instrumented step's
+        same = bool(torch.equal(film.view(torch.int32), film_check.view(torch.int32)))
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            cnt = torch.tensor([cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"], 1 if same else 0], dtype=torch.int64, device="cuda")
+            mn = cnt[3:].clone()
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            rays_closest, rays_shadow, cam = (int(x) for x in cnt[:3].tolist())
+            same = bool(int(mn.item()))
+        else:
+            rays_closest, rays_shadow, cam = cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"]
+        if not same:
+            raise SystemExit("bench.py: the film of the last timed step differs from the instrumented step's film — "
+                             "the timed kernels did not do the reference's work; no number is reported")
+        rays = rays_closest + rays_shadow
+        res = {"elapsed": elapsed, "steps": steps, "rays_step": rays, "cam": cam, "cst": cst, "agg": agg, "n_passes": st["n_passes"],
+               "ms_per_step": elapsed * 1e3 / steps, "mray": rays * steps / elapsed / 1e6, "total_spp": total_spp}
+        del gpu, scene, film, film_check
+        torch.cuda.empty_cache()
+        return res
+
+    modes = {"weak": args.spp * world, "strong": args.strong_spp}
+    primary = measure(modes[args.scaling], args.steps, args.warmup, True)
+    other_name = "strong" if args.scaling == "weak" else "weak"
+    other = None
+    if args.other_steps > 0 and args.workload == "killeroo" and modes[other_name] != modes[args.scaling]:
+        other = measure(modes[other_name], args.other_steps, 1, False)
 
     if rank == 0:
-        rays_step = rays_closest + rays_shadow
-        ms_per_step = elapsed * 1e3 / args.steps
-        mray = rays_step * args.steps / elapsed / 1e6
+        cst, agg = primary["cst"], primary["agg"]
+        steps = args.steps
+        rays_step, cam, mray = primary["rays_step"], primary["cam"], primary["mray"]
+        total_spp = primary["total_spp"]
         # per-ray averages of this rank's instrumented step
         r_all = cst["closest_rays"] + cst["shadow_rays"]
         n_node = (cst["nodes_closest"] + cst["nodes_any"]) / max(r_all, 1)
         n_tri = cst["tri_tests"] / max(r_all, 1)
         b_ray = 32 * n_node + 48 * n_tri + 48
-        # dominant kernel by measured HIP-event time on this rank
-        ext_bytes = algorithmic_bytes(cst["ext_rays"], cst["ext_nodes"], cst["ext_tri_tests"])
-        sh_bytes = algorithmic_bytes(cst["shadow_rays"], cst["nodes_any"], cst["any_tri_tests"])
+        # algorithmic bytes per step of every pipeline kernel (this rank): SURVEY.md 8d's figure for the traversal
+        # kernels; queue / path-state records for the others (the bytes that have to cross HBM: the ~7 MB scene is
+        # cache resident and is not counted for them)
         mis_rays = cst["closest_rays"] - cst["ext_rays"]
-        mis_bytes = algorithmic_bytes(mis_rays, cst["nodes_closest"] - cst["ext_nodes"],
-                                      cst["tri_tests"] - cst["ext_tri_tests"] - cst["any_tri_tests"])
-        kernels = {
-            "k_extend": (agg["ms_extend"], agg["n_extend_launches"], ext_bytes, cst["ext_rays"]),
-            "k_shadow": (agg["ms_shadow"], agg["n_connect_launches"], sh_bytes, cst["shadow_rays"]),
-            "k_mis": (agg["ms_mis"], agg["n_connect_launches"], mis_bytes, mis_rays),
-        }
-        dom = max(kernels, key=lambda k: kernels[k][0])
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
-        # runs of this same command: tools/collect_profiles.sh -> profiles/*_pmc_traffic.json)
-        traffic, traffic_src = None, None
-        import glob
-        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))[::-1]:
-            try:
-                tj = json.load(open(f))
-                # the product builds of the kernel (no counting, no alpha; k_extend has one more template argument:
-                # its first launch of a step also makes the camera rays), averaged over the launches of a step
-                ents = [v for k, v in tj["kernels"].items() if k.startswith(dom + "<false, false") or k == dom + "<false>"]
-                if ents and world == 1 and (args.xres, args.yres, args.spp, args.workload) == (1920, 1080, 64, "killeroo"):
-                    n_l = sum(e.get("launches_in_step", 1) for e in ents)
-                    traffic = int(sum(e["hbm_bytes_per_launch"] * e.get("launches_in_step", 1) for e in ents) / n_l)
-                    traffic_src = os.path.basename(f)
-                    break
-            except Exception:
-                pass
-        # every pipeline kernel priced the same way (HIP-event time of this rank, algorithmic bytes)
         nee = cst["nee_evals"]
         next_rays = cst["ext_rays"] - cst["camera_rays"]
-        other = {
-            "k_shade": (agg["ms_shade"], 48 * nee + 112 * nee + 32 * next_rays,
-                        "approx.: 48 B in per hit, 112 B NEE record + 32 B next ray out; VALU bound"),
-            "k_mis_lit": (agg["ms_resolve"], 1 * nee, "one result byte per NEE record"),
-            "k_generate": (agg["ms_generate"], 52 * cst["camera_rays"], "ray, Halton index, L written"),
-            "k_film": (agg["ms_film"], 16 * cst["camera_rays"], "L read per sample"),
+        fam = {
+            "k_extend": (agg["ms_extend"], agg["n_extend_launches"], algorithmic_bytes(cst["ext_rays"], cst["ext_nodes"], cst["ext_tri_tests"]),
+                         cst["ext_rays"], "32 B/node + 48 B/triangle test + 48 B/ray (SURVEY.md 8d)"),
+            "k_shade": (agg["ms_shade"], agg["n_shade_launches"], 72 * nee + 112 * nee + 48 * next_rays, nee,
+                        "per hit 72 B in (queue entry, hit, ray, throughput, Halton index), 112 B NEE record out, 48 B next ray + "
+                        "throughput out per continued path (queue and path-state records only)"),
+            "k_shadow": (agg["ms_shadow"], agg["n_connect_launches"], algorithmic_bytes(cst["shadow_rays"], cst["nodes_any"], cst["any_tri_tests"]),
+                         cst["shadow_rays"], "as k_extend (+ 65 B record in, 32 B L read-modify-write, not counted in SURVEY's figure)"),
+            "k_mis": (agg["ms_mis"], agg["n_connect_launches"],
+                      algorithmic_bytes(mis_rays, cst["nodes_closest"] - cst["ext_nodes"], cst["tri_tests"] - cst["ext_tri_tests"] - cst["any_tri_tests"]),
+                      mis_rays, "as k_extend"),
+            "k_mis_lit": (agg["ms_resolve"], agg["n_connect_launches"], 1 * nee, nee, "one result byte per NEE record"),
+            "k_film": (agg["ms_film"], primary["n_passes"] * steps, 16 * cst["camera_rays"], cst["camera_rays"], "L read per sample"),
         }
+        pmc_traffic, pmc_lanes, tr_src, la_src = load_pmc(world, args)
         per_kernel = {}
-        for k, (ms_k_, nl_, by_, _r) in kernels.items():
-            per_kernel[k] = {"ms_per_step": round(ms_k_ / args.steps, 3),
-                             "algorithmic_gbs": round(by_ * args.steps / max(ms_k_, 1e-9) / 1e6, 1)}
-        for k, (ms_k_, by_, note_) in other.items():
-            if ms_k_ <= 0:  # k_generate when camera rays are made inside k_extend's first launch: nothing to price
-                per_kernel[k] = {"ms_per_step": 0.0, "algorithmic_gbs": None, "note": note_ + " (not launched: fused into k_extend)"}
+        for k, (ms_k, n_l, by, units, note) in fam.items():
+            if ms_k <= 0:
                 continue
-            per_kernel[k] = {"ms_per_step": round(ms_k_ / args.steps, 3),
-                             "algorithmic_gbs": round(by_ * args.steps / max(ms_k_, 1e-9) / 1e6, 1), "note": note_}
-        for k in per_kernel:
-            g_ = per_kernel[k]["algorithmic_gbs"]
-            per_kernel[k]["frac_of_hbm_peak"] = None if g_ is None else round(g_ / HBM_PEAK_GBS, 4)
-        copy_gbs = measured_copy_gbs(torch)
-        ms_k, n_launch, bytes_step, rays_k = kernels[dom]
-        launches_per_step = n_launch / args.steps
+            e = {"ms_per_step": round(ms_k / steps, 3), "launches_per_step": round(n_l / steps, 2),
+                 "algorithmic_gbs": round(by * steps / ms_k / 1e6, 1), "algorithmic_bytes_note": note}
+            tr = pmc_traffic.get(k)
+            if tr:
+                e["hbm_counter_bytes_per_step"] = tr["hbm_bytes_per_step"]
+                e["hbm_counter_gbs"] = round(tr["hbm_bytes_per_step"] / (ms_k / steps) / 1e6, 1)
+                e["hbm_counter_frac_of_peak"] = round(e["hbm_counter_gbs"] / HBM_PEAK_GBS, 4)
+            la = pmc_lanes.get(k)
+            if la:
+                # VALU issue: wave-instructions x 64 lane slots against CUs x SIMDs x 32 lanes x clock, over THIS run's time
+                tl = la["SQ_INSTS_VALU"] * 64 / (ms_k / steps * 1e-3) / 1e12
+                e["valu"] = {"issued_tlaneops": round(tl, 2), "peak_tlaneops": round(VALU_PEAK_TLANEOPS, 1),
+                             "issue_frac": round(tl / VALU_PEAK_TLANEOPS, 4), "lane_util": la.get("lane_util"),
+                             "valu_busy": la.get("valu_busy"), "insts_valu_per_step": la["SQ_INSTS_VALU"]}
+                if "TCC_REQ_sum" in la:
+                    l2 = la["TCC_REQ_sum"] * 128 / (ms_k / steps * 1e-3) / 1e9
+                    e["l2"] = {"requests_per_step": la["TCC_REQ_sum"], "hit_rate": la.get("l2_hit_rate"),
+                               "gbs_at_128B_per_request": round(l2, 1), "frac_of_l2_peak": round(l2 / L2_PEAK_GBS, 4)}
+            per_kernel[k] = e
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
+        ms_k, n_launch, bytes_all, units_k, note_k = fam[dom]
+        launches_per_step = n_launch / steps
         avg_ms = ms_k / max(n_launch, 1)
-        achieved = (bytes_step / launches_per_step) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved = (bytes_all / launches_per_step) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        if dom in pmc_traffic:
+            traffic = int(pmc_traffic[dom]["hbm_bytes_per_step"] / max(pmc_traffic[dom]["launches_in_step"], 1))
+        cache_resident = dom in ("k_extend", "k_shadow", "k_mis")
+        roof = {
+            "kernel": dom,
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": None,
+            "traffic": traffic,
+            "traffic_source": tr_src,
+            "launches_per_step": launches_per_step,
+            "avg_launch_ms": round(avg_ms, 4),
+            "algorithmic_bytes_per_launch": int(bytes_all / max(launches_per_step, 1)),
+            "algorithmic_bytes_note": note_k,
+            "units_per_launch": int(units_k / max(launches_per_step, 1)),
+            "binding": "valu",
+            "valu": per_kernel[dom].get("valu"),
+            "l2": per_kernel[dom].get("l2"),
+            "lanes_source": la_src,
+            "kernel_choice": "largest HIP-event time over all kernels of the step (this run)",
+            "note": "frac = algorithmic bytes per launch / average launch time / 8 TB/s; for the traversal kernels, whose "
+                    "32 B/node + 48 B/triangle bytes are served from cache (~7 MB scene), frac is the PMC-counted HBM "
+                    "traffic instead (never above 1) and the algorithmic rate is kept as `achieved`. `traffic` = HBM bytes "
+                    "per launch from separate rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE). What "
+                    "binds the kernel is VALU issue: see `valu` (counters in profiles/, lane-ops = wave instructions x 64).",
+        }
+        frac_alg = achieved / HBM_PEAK_GBS
+        if traffic:
+            roof["frac_traffic"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # a kernel whose algorithmic bytes are served from cache is priced by its counted HBM traffic (null without counters)
+        roof["frac"] = (roof.get("frac_traffic") if cache_resident else round(frac_alg, 4))
+        roof["frac_algorithmic"] = round(frac_alg, 4)
+        copy_gbs = measured_copy_gbs(torch)
+        roof["peak_measured_copy_gbs"] = round(copy_gbs, 1)
         out = {
             "metric": f"Mray/s on {workload_name} 1080p (path integrator, rays = Scene::Intersect + IntersectP calls)",
             "value": round(mray, 2),
             "unit": "Mray/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step": round(primary["ms_per_step"], 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": ("scenes/killeroo-simple.pbrt (the reference's shipped scene file)" if args.workload == "killeroo"
                      else "synthetic scene generated by tests/boxroom.py (seed 12111)") + "; Halton samples generated on device",
             "config": {
-                "workload": f"{workload_name} {args.xres}x{args.yres}, {total_spp} spp ({args.spp} per GPU), "
-                            f"path maxdepth 5, halton, box filter, 16x16 tiles interleaved over {world} rank(s)",
-                "xres": args.xres, "yres": args.yres, "spp_total": total_spp, "spp_per_gpu": args.spp,
-                "passes_per_step": st["n_passes"],
+                "workload": f"{workload_name} {args.xres}x{args.yres}, {total_spp} spp in all"
+                            + (f" ({total_spp // world} spp-equivalents of work per GPU)" if world > 1 else "")
+                            + f", path maxdepth 5, halton, box filter, 16x16 tiles dealt diagonally over {world} rank(s)"
+                            + (", films merged by one RCCL reduce (iile_dist_film_reduce)" if world > 1 else ""),
+                "xres": args.xres, "yres": args.yres, "spp_total": total_spp,
+                "baseline_config": ("2 (1080p x 64 spp, 1 GPU)" if (world, total_spp) == (1, 64) else
+                                    "3 (1080p x 1024 spp over 8 GPUs)" if (world, total_spp) == (8, 1024) else
+                                    "3's frame (1080p x 1024 spp) on fewer GPUs" if total_spp == 1024 else "scaled between 2 and 3"),
+                "passes_per_step": primary["n_passes"],
             },
-            "msamples_per_s": round(cam * args.steps / elapsed / 1e6, 3),
+            "timed_film_verified": "bitwise equal to the instrumented step's film (all ranks)",
+            "msamples_per_s": round(cam * steps / primary["elapsed"] / 1e6, 3),
             "rays_per_step": rays_step,
             "camera_samples_per_step": cam,
             "rays_per_camera_sample": round(rays_step / max(cam, 1), 4),
@@ -275,40 +406,26 @@ def main():
             "n_tri_per_ray": round(n_tri, 4),
             "b_ray_bytes": round(b_ray, 1),
             "job_algorithmic_gbs": round(mray * 1e6 * b_ray / 1e9, 1),
-            "job_frac_of_hbm_roofline": round(mray * 1e6 * b_ray / 1e9 / (HBM_PEAK_GBS * world), 4),
-            "kernel_ms_per_step_rank0": {k: round(agg[k] / args.steps, 3) for k in
+            "kernel_ms_per_step_rank0": {k: round(agg[k] / steps, 3) for k in
                                          ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_resolve", "ms_film", "ms_total")},
-            "roofline": {
-                "kernel": dom,
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "launches_per_step": launches_per_step,
-                "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_launch": int(bytes_step / max(launches_per_step, 1)),
-                "rays_per_launch": int(rays_k / max(launches_per_step, 1)),
-                "peak_measured_copy_gbs": round(copy_gbs, 1),
-                "frac_of_measured_copy": round(achieved / copy_gbs, 4),
-                "kernel_choice": "the BVH traversal kernel family (extend / shadow / MIS: one traversal code, "
-                                 "61 % of the step) priced on its longest member; k_shade is VALU bound, see "
-                                 "roofline_all_kernels",
-                "note": "algorithmic bytes = 32 B/node visited + 48 B/triangle test + 48 B/ray queue traffic "
-                        "(SURVEY.md 8d), counted by the instrumented kernels; `traffic` = PMC HBM bytes per launch "
-                        "(2*FETCH_SIZE + WRITE_SIZE): the BVH and mesh (~7 MB) are cache resident, so real HBM "
-                        "traffic is the queue traffic and sits far below the algorithmic bytes",
-            },
+            "roofline": roof,
+            "roofline_all_kernels": per_kernel,
         }
-        out["roofline_all_kernels"] = per_kernel
+        if other is not None:
+            out["other_mode"] = {"scaling": other_name, "spp_total": other["total_spp"], "value": round(other["mray"], 2), "unit": "Mray/s",
+                                 "ms_per_step": round(other["ms_per_step"], 3), "steps": other["steps"],
+                                 "msamples_per_s": round(other["cam"] * other["steps"] / other["elapsed"] / 1e6, 3),
+                                 "timed_film_verified": "bitwise equal to the instrumented step's film (all ranks)"}
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.xres, args.yres, args.cpu_seconds, workload_name)
             out["speedup_vs_cpu_baseline"] = round(mray / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        if os.environ.get("IILE_GPU_LIB"):
+            out["gpu_lib_override"] = os.environ["IILE_GPU_LIB"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

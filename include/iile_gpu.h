@@ -52,8 +52,8 @@ enum {
 
 typedef struct iile_render_params {
     int32_t k_begin, k_end;         /* sample indices [k_begin, k_end); k_end <= 0: all pixelsamples */
-    int32_t tile_rank, tile_nranks; /* this call renders the 16x16 tiles with index % nranks == rank;
-                                       nranks <= 0: all tiles (single GPU) */
+    int32_t tile_rank, tile_nranks; /* this call renders the 16x16 tiles (tx, ty) with iile_tile_owner(tx, ty, nranks)
+                                       == rank (iile_scene.h); nranks <= 0: all tiles (single GPU) */
     int32_t spp_per_pass;           /* 0 = passes sized to the workspace budget. A pass renders all samples of a range
                                        of tiles; > 0 asks for passes of about (owned pixels x spp_per_pass) paths (tests) */
     int32_t collect_stats;          /* 1: instrumented kernels (ray / node / triangle counters) */
@@ -83,6 +83,13 @@ typedef struct iile_stats {
 
 int iile_device_count(void);
 const char *iile_last_error(void);
+
+/* Device memory for hosts built without hipcc (the C++ host keeps the film in HBM between iile_render and the
+ * multi-GPU merge of iile_dist.h): select the GPU of this process, allocate / free / read back a buffer. */
+int iile_device_select(int32_t device);
+int iile_device_alloc(uint64_t bytes, void **out_dev);
+void iile_device_free(void *dev);
+int iile_device_download(void *dst_host, const void *src_dev, uint64_t bytes, void *stream); /* waits for `stream` */
 
 int iile_scene_create(const iile_scene_desc *desc, iile_scene **out);
 void iile_scene_destroy(iile_scene *scene);

@@ -41,6 +41,7 @@ typedef struct iile_host_scene_info {
     int32_t n_nodes, n_interior_nodes, n_leaf_nodes;
     int32_t n_materials, n_lights;
     int32_t xres, yres, spp, max_depth;
+    int32_t probe_hemi_size; /* side of the IISPT probe films iile_render_probes writes (iile_scene_desc::probe) */
 } iile_host_scene_info;
 
 /* Parse a .pbrt file (plus its Includes), tessellate, build the BVH and the

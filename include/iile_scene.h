@@ -242,6 +242,15 @@ typedef struct iile_scene_desc {
     iile_probe_setup probe;
 } iile_scene_desc;
 
+/* Which rank of an n-rank job renders the 16x16 tile (tx, ty) of SamplerIntegrator::Render's tile grid
+ * (src/core/integrator.cpp:235-248: tiles are independent units of work). Diagonal interleave: every run of n
+ * consecutive tiles of a tile row OR column holds one tile of each rank, for any n (an interleave of the linear
+ * tile index would collapse to vertical stripes whenever the tiles per row are a multiple of n: 1080p has 120).
+ * The map is part of the boundary: libiile_gpu.so, the C++ host and the test oracle all use this one definition. */
+static inline int32_t iile_tile_owner(int32_t tx, int32_t ty, int32_t nranks) {
+    return nranks <= 1 ? 0 : (int32_t)(((uint32_t)tx + (uint32_t)ty) % (uint32_t)nranks);
+}
+
 #ifdef __cplusplus
 }
 #endif

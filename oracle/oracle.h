@@ -47,7 +47,7 @@ typedef struct oracle_stats {
 
 /* SamplerIntegrator::Render restated: tiles of 16x16 over the sample bounds,
  * samples k in [k_begin,k_end) (0,-1 => all spp), only tiles with
- * tile_index % tile_nranks == tile_rank. film_xyzw: {X,Y,Z,weightSum} per pixel
+ * iile_tile_owner(tx, ty, tile_nranks) == tile_rank (iile_scene.h). film_xyzw: {X,Y,Z,weightSum} per pixel
  * of the cropped pixel bounds (Film::Pixel after MergeFilmTile). */
 int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, int k_begin, int k_end,
                   int tile_rank, int tile_nranks, float *film_xyzw, oracle_stats *stats);
@@ -126,6 +126,9 @@ int64_t oracle_check_next_float(int iters, uint64_t seed);
 int64_t oracle_check_efloat(int iters, uint64_t seed);
 int64_t oracle_check_reintersect(const iile_scene_desc *scene, int n, const float *o, const float *d, int n_out,
                                  uint64_t seed, int64_t *stats);
+
+/* iile_tile_owner of iile_scene.h (a static inline there), exported so that tests can call the header's own definition */
+int oracle_tile_owner(int tx, int ty, int nranks);
 
 #ifdef __cplusplus
 }

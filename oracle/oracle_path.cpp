@@ -2553,8 +2553,8 @@ static int render_impl(const iile_scene_desc *scene, int trig_mode, int n_thread
         while (true) {
             int tile = next_tile.fetch_add(1);
             if (tile >= n_tiles) break;
-            if (tile % tile_nranks != tile_rank) continue;
             int tx = tile % ntx, ty = tile / ntx;
+            if (iile_tile_owner(tx, ty, tile_nranks) != tile_rank) continue;
             int x0 = F.samp_x0 + tx * tile_size, x1 = std::min(x0 + tile_size, F.samp_x1);
             int y0 = F.samp_y0 + ty * tile_size, y1 = std::min(y0 + tile_size, F.samp_y1);
             // Film::GetFilmTile, film.cpp:92-103
@@ -2647,6 +2647,8 @@ static int render_impl(const iile_scene_desc *scene, int trig_mode, int n_thread
 }
 
 extern "C" {
+
+int oracle_tile_owner(int tx, int ty, int nranks) { return iile_tile_owner(tx, ty, nranks); }
 
 int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, int k_begin, int k_end, int tile_rank,
                   int tile_nranks, float *film_xyzw, oracle_stats *stats) {

@@ -2,6 +2,7 @@
 
     libiile_host.so  scene preparation + film finalisation   (include/iile_host.h)
     libiile_gpu.so   gfx950 wavefront path tracer            (include/iile_gpu.h)
+    libiile_dist.so  the multi-GPU film merge over RCCL      (include/iile_dist.h)
 
 Python is plumbing only (tests, bench.py, __graft_entry__): every number comes
 out of the HIP kernels. There is no CPU fallback here — if libiile_gpu.so is
@@ -28,7 +29,7 @@ class HostOverrides(ctypes.Structure):
 
 class HostSceneInfo(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("n_prims n_triangles n_spheres n_meshes n_nodes n_interior_nodes "
-                                      "n_leaf_nodes n_materials n_lights xres yres spp max_depth").split()]
+                                      "n_leaf_nodes n_materials n_lights xres yres spp max_depth probe_hemi_size").split()]
 
 
 class FilmDesc(ctypes.Structure):
@@ -74,10 +75,16 @@ HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_
                 "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table"]
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
-               "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes"]
+               "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
+               "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download"]
+DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size",
+                "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
+                "iile_dist_rendezvous_file", "iile_dist_last_error"]
+DIST_ID_BYTES = 128
 
 _host = None
 _gpu = None
+_dist = None
 
 
 def host_lib():
@@ -145,6 +152,83 @@ def gpu_lib():
         lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
         _gpu = lib
     return _gpu
+
+
+def dist_lib():
+    """The RCCL film-merge library (needs librccl; loads without a GPU)."""
+    global _dist
+    if _dist is None:
+        path = os.path.join(LIB_DIR, "libiile_dist.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (make -C pbrt-v3-iile_amd/csrc dist)")
+        lib = ctypes.CDLL(path)
+        lib.iile_dist_last_error.restype = ctypes.c_char_p
+        lib.iile_dist_unique_id.argtypes = [c_vp]
+        lib.iile_dist_create.argtypes = [c_vp, c_i32, c_i32, ctypes.POINTER(c_vp)]
+        lib.iile_dist_destroy.argtypes = [c_vp]
+        lib.iile_dist_destroy.restype = None
+        lib.iile_dist_rank.argtypes = [c_vp]
+        lib.iile_dist_size.argtypes = [c_vp]
+        lib.iile_dist_film_reduce.argtypes = [c_vp, c_vp, ctypes.c_int64, c_i32, c_vp]
+        lib.iile_dist_barrier.argtypes = [c_vp, c_vp]
+        lib.iile_dist_sum_u64.argtypes = [c_vp, c_vp, c_i32]
+        lib.iile_dist_max_f64.argtypes = [c_vp, c_vp, c_i32]
+        lib.iile_dist_rendezvous_file.argtypes = [ctypes.c_char_p, c_i32, c_vp, c_i32]
+        _dist = lib
+    return _dist
+
+
+class Dist:
+    """One rank of the film-merge communicator (include/iile_dist.h)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_uint8 * DIST_ID_BYTES)()
+        lib = dist_lib()
+        if lib.iile_dist_unique_id(buf) != 0:
+            raise RuntimeError(f"iile_dist_unique_id failed: {lib.iile_dist_last_error().decode()}")
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, nranks):
+        lib = dist_lib()
+        self._c = c_vp()
+        buf = (ctypes.c_uint8 * DIST_ID_BYTES).from_buffer_copy(unique_id)
+        rc = lib.iile_dist_create(buf, int(rank), int(nranks), ctypes.byref(self._c))
+        if rc != 0:
+            raise RuntimeError(f"iile_dist_create failed ({rc}): {lib.iile_dist_last_error().decode()}")
+        self.rank, self.size = int(rank), int(nranks)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {dist_lib().iile_dist_last_error().decode()}")
+
+    def film_reduce(self, film_device_ptr, n_pixels, root=0, stream=None):
+        self._check(dist_lib().iile_dist_film_reduce(self._c, c_vp(int(film_device_ptr)), int(n_pixels), int(root),
+                                                     c_vp(stream) if stream else None), "iile_dist_film_reduce")
+
+    def barrier(self, stream=None):
+        self._check(dist_lib().iile_dist_barrier(self._c, c_vp(stream) if stream else None), "iile_dist_barrier")
+
+    def sum_u64(self, values):
+        a = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        self._check(dist_lib().iile_dist_sum_u64(self._c, a.ctypes.data, len(a)), "iile_dist_sum_u64")
+        return a
+
+    def max_f64(self, values):
+        a = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(dist_lib().iile_dist_max_f64(self._c, a.ctypes.data, len(a)), "iile_dist_max_f64")
+        return a
+
+    def close(self):
+        if self._c:
+            dist_lib().iile_dist_destroy(self._c)
+            self._c = c_vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _f32(a):
@@ -314,12 +398,18 @@ class GpuScene:
                     "iile_bsdf_eval")
         return out
 
-    def render_probes(self, pos, direction, hemi=32, device_out=None):
+    def render_probes(self, pos, direction, hemi=None, device_out=None):
         """IISPT probe pass: (n, 3) origins and directions -> intensity (n, hemi, hemi, 3), camera-space normals
-        (n, hemi, hemi, 3), distances (n, hemi, hemi), [y][x] in raster order; plus the stats dict.
-        device_out: three device pointers (ints) to write the images to instead (they then stay in HBM)."""
+        (n, hemi, hemi, 3), distances (n, hemi, hemi), [y][x] in raster order; plus the stats dict. hemi is the
+        scene's probe film size (iile_scene_desc::probe.hemi_size through iile_host_scene_get_info); passing another
+        value is an error. device_out: three device pointers (ints), each with room for n * hemi * hemi pixels, to
+        write the images to instead (they then stay in HBM)."""
         pos, direction = _f32(pos).reshape(-1, 3), _f32(direction).reshape(-1, 3)
         n = len(pos)
+        scene_hemi = int(self.host.info["probe_hemi_size"])
+        if hemi is not None and int(hemi) != scene_hemi:
+            raise ValueError(f"render_probes: the scene's probe films are {scene_hemi} x {scene_hemi}, not {hemi}")
+        hemi = scene_hemi
         st = GpuStats()
         if device_out is not None:
             self._check(gpu_lib().iile_render_probes(self._s, n, pos.ctypes.data, direction.ctypes.data, device_out[0], device_out[1],

@@ -1,6 +1,11 @@
 // iile_pbrt — command-line front end: `pbrt scene.pbrt` for the GPU path.
 //
 //   iile_pbrt scene.pbrt [--outfile out.pfm] [--xres N --yres N --spp N --maxdepth N] [--stats]
+//             [--gpurank R/N --rendezvous FILE]
+//
+// Multi-GPU: start N copies, one per GPU, with --gpurank 0/N .. N-1/N and a common --rendezvous file on a shared
+// file system (rank 0 publishes the RCCL id there). Rank R uses GPU R modulo the visible devices, renders its tiles
+// and the films are merged on rank 0 by one RCCL reduction (include/iile_dist.h); rank 0 writes the image.
 //
 // Mirrors src/main/pbrt.cpp:97-219 (argument loop, ParseFile, Render) on top of
 // the C ABI: libiile_host loads and flattens the scene, libiile_gpu renders it,
@@ -15,6 +20,8 @@ int main(int argc, char **argv) {
     std::string scene_file, out = "iile.pfm";
     iile::ParamSet ps;
     bool stats = false;
+    int gpu_rank = 0, gpu_nranks = 1;
+    std::string rendezvous;
     for (int i = 1; i < argc; ++i) {
         auto arg_int = [&](int &dst) {
             if (i + 1 < argc) dst = atoi(argv[++i]);
@@ -31,9 +38,16 @@ int main(int argc, char **argv) {
             arg_int(ps.maxdepth);
         else if (!strcmp(argv[i], "--stats"))
             stats = true;
+        else if (!strcmp(argv[i], "--gpurank") && i + 1 < argc) {
+            if (sscanf(argv[++i], "%d/%d", &gpu_rank, &gpu_nranks) != 2 || gpu_nranks < 1 || gpu_rank < 0 || gpu_rank >= gpu_nranks) {
+                fprintf(stderr, "iile_pbrt: --gpurank wants R/N with 0 <= R < N\n");
+                return 1;
+            }
+        } else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc)
+            rendezvous = argv[++i];
         else if (argv[i][0] == '-') {
             fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.pfm] [--xres N] [--yres N] [--spp N] "
-                            "[--maxdepth N] [--stats]\n");
+                            "[--maxdepth N] [--stats] [--gpurank R/N --rendezvous FILE]\n");
             return 1;
         } else
             scene_file = argv[i];
@@ -42,9 +56,30 @@ int main(int argc, char **argv) {
         fprintf(stderr, "iile_pbrt: no scene file given\n");
         return 1;
     }
+    iile_dist *comm = nullptr;
+    if (gpu_nranks > 1) {
+        if (rendezvous.empty()) {
+            fprintf(stderr, "iile_pbrt: --gpurank R/N needs --rendezvous FILE\n");
+            return 1;
+        }
+        const int n_dev = iile_device_count();
+        if (n_dev < 1 || iile_device_select(gpu_rank % n_dev) != IILE_OK) {
+            fprintf(stderr, "Error: GPU path: %s\n", n_dev < 1 ? "no HIP device" : iile_last_error());
+            return 1;
+        }
+        uint8_t id[IILE_DIST_ID_BYTES];
+        if (iile_dist_rendezvous_file(rendezvous.c_str(), gpu_rank, id, 120) != IILE_OK ||
+            iile_dist_create(id, gpu_rank, gpu_nranks, &comm) != IILE_OK) {
+            fprintf(stderr, "Error: multi-GPU set-up: %s\n", iile_dist_last_error());
+            return 1;
+        }
+    }
     iile::Scene scene(scene_file, ps);
-    std::unique_ptr<iile::GpuPathIntegrator> integrator(iile::CreateGpuPathIntegrator(ps, out, 0, 1, stats));
-    if (!integrator->Render(scene)) return 1;
+    std::unique_ptr<iile::GpuPathIntegrator> integrator(iile::CreateGpuPathIntegrator(ps, out, 0, 1, stats, comm));
+    const bool ok = integrator->Render(scene);
+    if (comm) iile_dist_destroy(comm);
+    if (!ok) return 1;
+    if (gpu_rank != 0) return 0;
     const iile_stats &st = integrator->last_stats;
     printf("rendered %llu camera samples in %.1f ms -> %s\n", (unsigned long long)st.n_paths, st.ms_total, out.c_str());
     if (stats)

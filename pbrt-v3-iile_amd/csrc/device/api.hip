@@ -76,6 +76,15 @@ struct iile_scene {
     std::vector<EventPair> events;
     size_t events_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // tile ownership of the last sharded render (iile_tile_owner): the rank's tiles in index order and the inverse
+    std::vector<int> tile_of_slot, slot_of_tile;
+    int *d_tile_tables = nullptr;  // tile_of_slot, then slot_of_tile
+    size_t d_tile_tables_ints = 0;
+    int map_key[4] = {0, 0, 0, 0};  // {n_tiles_x, n_tiles_y, rank, nranks} the tables were built for
+    int slot_of(int tile) const { return slot_of_tile.empty() ? tile : slot_of_tile[size_t(tile)]; }
+    // grow-only device scratch of the exact film finish (index lists in, gathered values out), used on the render's stream
+    char *scratch = nullptr;
+    size_t scratch_cap = 0, scratch_used = 0;
 };
 
 namespace {
@@ -189,6 +198,49 @@ int get_events(iile_scene *sc, int kind, EventPair **out) {
     }
     *out = &sc->events[sc->events_used++];
     (*out)->kind = kind;
+    return IILE_OK;
+}
+
+// The rank's share of SamplerIntegrator::Render's tile grid (iile_tile_owner, iile_scene.h) as two tables in HBM:
+// slot -> tile (tile index order) and tile -> slot. One rank owning everything needs none (slot == tile).
+int ensure_tile_map(iile_scene *sc, PassDesc *P, hipStream_t stream) {
+    const int ntx = P->n_tiles_x, nty = P->n_tiles_y, n_tiles = ntx * nty, rank = P->tile_rank, nranks = P->tile_nranks;
+    P->tile_of_slot = P->slot_of_tile = nullptr;
+    if (nranks <= 1) {
+        sc->tile_of_slot.clear();
+        sc->slot_of_tile.clear();
+        sc->map_key[3] = 0;
+        P->n_owned_tiles = n_tiles;
+        return IILE_OK;
+    }
+    const int key[4] = {ntx, nty, rank, nranks};
+    if (std::memcmp(key, sc->map_key, sizeof(key)) != 0 || sc->slot_of_tile.size() != size_t(n_tiles)) {
+        sc->tile_of_slot.clear();
+        sc->slot_of_tile.assign(size_t(n_tiles), -1);
+        for (int t = 0; t < n_tiles; ++t)
+            if (iile_tile_owner(t % ntx, t / ntx, nranks) == rank) {
+                sc->slot_of_tile[size_t(t)] = int(sc->tile_of_slot.size());
+                sc->tile_of_slot.push_back(t);
+            }
+        const size_t ints = sc->tile_of_slot.size() + sc->slot_of_tile.size();
+        if (ints > sc->d_tile_tables_ints) {
+            if (sc->d_tile_tables) HIP_TRY(hipFree(sc->d_tile_tables));
+            sc->d_tile_tables = nullptr;
+            sc->d_tile_tables_ints = 0;
+            HIP_TRY(hipMalloc(&sc->d_tile_tables, std::max<size_t>(ints, 1) * sizeof(int)));
+            sc->d_tile_tables_ints = ints;
+        }
+        // (synchronous copies from pageable vectors: a few KB, once per change of the sharding)
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (!sc->tile_of_slot.empty())
+            HIP_TRY(hipMemcpy(sc->d_tile_tables, sc->tile_of_slot.data(), sc->tile_of_slot.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sc->d_tile_tables + sc->tile_of_slot.size(), sc->slot_of_tile.data(), sc->slot_of_tile.size() * sizeof(int),
+                          hipMemcpyHostToDevice));
+        std::memcpy(sc->map_key, key, sizeof(key));
+    }
+    P->n_owned_tiles = int(sc->tile_of_slot.size());
+    P->tile_of_slot = sc->d_tile_tables;
+    P->slot_of_tile = sc->d_tile_tables + sc->tile_of_slot.size();
     return IILE_OK;
 }
 
@@ -307,6 +359,39 @@ struct DevBuf {
 };
 }  // namespace
 
+namespace {
+// Device scratch for the finish: reserve once per use (may reallocate: nothing of an earlier use is live), then carve.
+int scratch_reserve(iile_scene *sc, size_t bytes, hipStream_t stream) {
+    sc->scratch_used = 0;
+    if (bytes <= sc->scratch_cap) return IILE_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (sc->scratch) HIP_TRY(hipFree(sc->scratch));
+    sc->scratch = nullptr;
+    sc->scratch_cap = 0;
+    const size_t want = std::max<size_t>(2 * bytes, size_t(1) << 20);
+    HIP_TRY(hipMalloc(&sc->scratch, want));
+    sc->scratch_cap = want;
+    return IILE_OK;
+}
+template <typename T>
+T *scratch_take(iile_scene *sc, size_t n) {
+    char *p = sc->scratch + sc->scratch_used;
+    sc->scratch_used += (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~size_t(255);
+    return reinterpret_cast<T *>(p);
+}
+template <typename T>
+size_t scratch_bytes(size_t n) {
+    return (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~size_t(255);
+}
+template <typename T>
+int scratch_put(iile_scene *sc, const std::vector<T> &h, hipStream_t stream, T **dev) {
+    *dev = scratch_take<T>(sc, h.size());
+    if (!h.empty()) HIP_TRY(hipMemcpyAsync(*dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    return IILE_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char *iile_last_error(void) { return g_err.c_str(); }
@@ -315,6 +400,30 @@ int iile_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int iile_device_select(int32_t device) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return IILE_OK;
+}
+int iile_device_alloc(uint64_t bytes, void **out_dev) {
+    if (!out_dev) return fail(IILE_ERR_ARG, "iile_device_alloc: null argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(out_dev, std::max<size_t>(size_t(bytes), 1)));
+    return IILE_OK;
+}
+void iile_device_free(void *dev) {
+    if (dev) (void)hipFree(dev);
+}
+int iile_device_download(void *dst_host, const void *src_dev, uint64_t bytes, void *stream) {
+    if (!dst_host || !src_dev) return fail(IILE_ERR_ARG, "iile_device_download: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, size_t(bytes), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return IILE_OK;
 }
 
 static_assert(kLightDiffuseArea == IILE_LIGHT_DIFFUSE_AREA && kLightPoint == IILE_LIGHT_POINT &&
@@ -854,6 +963,8 @@ void iile_scene_destroy(iile_scene *sc) {
     for (void *p : sc->allocs) (void)hipFree(p);
     if (sc->ws_block) (void)hipFree(sc->ws_block);
     if (sc->film_block) (void)hipFree(sc->film_block);
+    if (sc->d_tile_tables) (void)hipFree(sc->d_tile_tables);
+    if (sc->scratch) (void)hipFree(sc->scratch);
     if (sc->wide_block) (void)hipFree(sc->wide_block);
     if (sc->flag_host) (void)hipHostFree(sc->flag_host);
     if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
@@ -1024,8 +1135,8 @@ int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, hipStream
         d.tile = in_bounds ? tile_of(d.qx, d.qy, &d.pix) : -1;
         d.own_in_pass = false;
         d.own_slot = 0;
-        if (in_bounds && d.tile % Pf.tile_nranks == Pf.tile_rank) {
-            const int slot = d.tile / Pf.tile_nranks;
+        if (in_bounds && sc->slot_of(d.tile) >= 0) {
+            const int slot = sc->slot_of(d.tile);
             d.own_in_pass = slot >= Pf.slot0 && slot < Pf.slot0 + Pf.n_pass_tiles;
             d.own_slot = uint32_t(slot) * 256u + uint32_t(d.pix);
         }
@@ -1051,7 +1162,8 @@ int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, hipStream
 }
 
 // After the pass's film accumulation: the exact sum every tile of this pass adds to every pixel reached by a flagged sample.
-int patch_pass_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, std::vector<PatchEntry> *entries) {
+// Everything runs on the render's stream (no null-stream work, no device-wide synchronisation).
+int patch_pass_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, std::vector<PatchEntry> *entries, hipStream_t stream) {
     if (!plan->active) return IILE_OK;
     PatchTimer tm;
     const std::vector<Flagged> &fl = plan->fl;
@@ -1084,27 +1196,35 @@ int patch_pass_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, std::vec
     L.resize(plan->list_pid.size());
     own.resize(own_idx.size());
     no_sum.resize(no_local.size());
-    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    LaunchCfg cfg{sc->n_cus, stream, false};
     int rc;
     {
-        DevBuf<uint32_t> di, dj, d1, d2, d3;
-        DevBuf<float4> dv, dw, dn;
-        if ((rc = di.put(plan->list_pid.data(), plan->list_pid.size())) || (rc = dv.alloc(plan->list_pid.size()))) return rc;
-        launch_gather4(sc->pb.L, di.p, int(plan->list_pid.size()), dv.p, cfg);
+        rc = scratch_reserve(sc, scratch_bytes<uint32_t>(plan->list_pid.size()) + scratch_bytes<float4>(L.size()) +
+                                     scratch_bytes<uint32_t>(own_idx.size()) + scratch_bytes<float4>(own.size()) +
+                                     scratch_bytes<uint32_t>(no_local.size()) + scratch_bytes<uint32_t>(no_range.size()) +
+                                     scratch_bytes<uint32_t>(no_pid.size()) + scratch_bytes<float4>(no_sum.size()), stream);
+        if (rc) return rc;
+        uint32_t *di = nullptr, *dj = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
+        if ((rc = scratch_put(sc, plan->list_pid, stream, &di))) return rc;
+        float4 *dv = scratch_take<float4>(sc, L.size()), *dw = nullptr, *dn = nullptr;
+        launch_gather4(sc->pb.L, di, int(plan->list_pid.size()), dv, cfg);
         if (!own_idx.empty()) {
-            if ((rc = dj.put(own_idx.data(), own_idx.size())) || (rc = dw.alloc(own_idx.size()))) return rc;
-            launch_gather4(sc->fb.tile_rgbw, dj.p, int(own_idx.size()), dw.p, cfg);
+            if ((rc = scratch_put(sc, own_idx, stream, &dj))) return rc;
+            dw = scratch_take<float4>(sc, own.size());
+            launch_gather4(sc->fb.tile_rgbw, dj, int(own_idx.size()), dw, cfg);
         }
         if (!no_local.empty()) {
-            if ((rc = d1.put(no_local.data(), no_local.size())) || (rc = d2.put(no_range.data(), no_range.size())) ||
-                (rc = d3.put(no_pid.data(), no_pid.size())) || (rc = dn.alloc(no_local.size())))
+            if ((rc = scratch_put(sc, no_local, stream, &d1)) || (rc = scratch_put(sc, no_range, stream, &d2)) ||
+                (rc = scratch_put(sc, no_pid, stream, &d3)))
                 return rc;
-            launch_patch_own(S, sc->pb.L, int(no_local.size()), d1.p, d2.p, d3.p, n_k, dn.p, cfg);
+            dn = scratch_take<float4>(sc, no_sum.size());
+            launch_patch_own(S, sc->pb.L, int(no_local.size()), d1, d2, d3, n_k, dn, cfg);
         }
         HIP_TRY(hipGetLastError());
-        if ((rc = dv.get(L.data(), L.size()))) return rc;
-        if (!own_idx.empty() && (rc = dw.get(own.data(), own.size()))) return rc;
-        if (!no_local.empty() && (rc = dn.get(no_sum.data(), no_sum.size()))) return rc;
+        if (!L.empty()) HIP_TRY(hipMemcpyAsync(L.data(), dv, L.size() * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        if (!own.empty()) HIP_TRY(hipMemcpyAsync(own.data(), dw, own.size() * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        if (!no_sum.empty()) HIP_TRY(hipMemcpyAsync(no_sum.data(), dn, no_sum.size() * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
     }
     tm.lap("gathers");
     for (float4 &v : L) {  // guard_radiance (kernels.hip)
@@ -1156,7 +1276,8 @@ int patch_pass_finish(iile_scene *sc, const DScene &S, PatchPlan *plan, std::vec
 
 // After k_film_resolve: every pixel reached by a sample the resolve kernel does not place is rebuilt from its tiles'
 // exact sums, added in tile index order (Film::MergeFilmTile, film.cpp:135-148).
-int patch_merge(iile_scene *sc, const DScene &S, const PassDesc &Pf, std::vector<PatchEntry> *entries, float4 *film_dev, uint64_t *n_patched) {
+int patch_merge(iile_scene *sc, const DScene &S, const PassDesc &Pf, std::vector<PatchEntry> *entries, float4 *film_dev, uint64_t *n_patched,
+                hipStream_t stream) {
     *n_patched = 0;
     if (entries->empty()) return IILE_OK;
     PatchTimer tm;
@@ -1186,9 +1307,9 @@ int patch_merge(iile_scene *sc, const DScene &S, const PassDesc &Pf, std::vector
                 const int tx = (qx - S.samp_x0) / 16, ty = (qy - S.samp_y0) / 16, t = ty * ntx + tx;
                 bool covered = false;
                 for (size_t h = a; h < b; ++h) covered = covered || (*entries)[h].tile == t;
-                if (!covered && t % Pf.tile_nranks == Pf.tile_rank) {
+                if (!covered && sc->slot_of(t) >= 0) {
                     g.own_tile = t;
-                    g.own_slot = uint32_t(t / Pf.tile_nranks) * 256u + uint32_t((qy - S.samp_y0 - ty * 16) * 16 + (qx - S.samp_x0 - tx * 16));
+                    g.own_slot = uint32_t(sc->slot_of(t)) * 256u + uint32_t((qy - S.samp_y0 - ty * 16) * 16 + (qx - S.samp_x0 - tx * 16));
                     own_idx.push_back(g.own_slot);
                 }
             }
@@ -1197,16 +1318,18 @@ int patch_merge(iile_scene *sc, const DScene &S, const PassDesc &Pf, std::vector
         a = b;
     }
     if (groups.empty()) return IILE_OK;
-    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    LaunchCfg cfg{sc->n_cus, stream, false};
     int rc;
     std::vector<float4> own(own_idx.size());
     if (!own_idx.empty()) {
-        DevBuf<uint32_t> di;
-        DevBuf<float4> dv;
-        if ((rc = di.put(own_idx.data(), own_idx.size())) || (rc = dv.alloc(own_idx.size()))) return rc;
-        launch_gather4(sc->fb.tile_rgbw, di.p, int(own_idx.size()), dv.p, cfg);
+        if ((rc = scratch_reserve(sc, scratch_bytes<uint32_t>(own_idx.size()) + scratch_bytes<float4>(own.size()), stream))) return rc;
+        uint32_t *di = nullptr;
+        if ((rc = scratch_put(sc, own_idx, stream, &di))) return rc;
+        float4 *dv = scratch_take<float4>(sc, own.size());
+        launch_gather4(sc->fb.tile_rgbw, di, int(own_idx.size()), dv, cfg);
         HIP_TRY(hipGetLastError());
-        if ((rc = dv.get(own.data(), own.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(own.data(), dv, own.size() * sizeof(float4), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
     }
     std::vector<uint32_t> out_idx(groups.size());
     std::vector<float4> out_val(groups.size());
@@ -1236,12 +1359,14 @@ int patch_merge(iile_scene *sc, const DScene &S, const PassDesc &Pf, std::vector
         out_val[gi] = o;
     }
     {
-        DevBuf<uint32_t> di;
-        DevBuf<float4> dv;
-        if ((rc = di.put(out_idx.data(), out_idx.size())) || (rc = dv.put(out_val.data(), out_val.size()))) return rc;
-        launch_scatter4(film_dev, di.p, int(out_idx.size()), dv.p, cfg);
+        if ((rc = scratch_reserve(sc, scratch_bytes<uint32_t>(out_idx.size()) + scratch_bytes<float4>(out_val.size()), stream))) return rc;
+        uint32_t *di = nullptr;
+        float4 *dv = nullptr;
+        if ((rc = scratch_put(sc, out_idx, stream, &di)) || (rc = scratch_put(sc, out_val, stream, &dv))) return rc;
+        launch_scatter4(film_dev, di, int(out_idx.size()), dv, cfg);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
+        // out_idx / out_val are pageable host vectors that die with this scope: the copies must have been taken
+        HIP_TRY(hipStreamSynchronize(stream));
     }
     tm.lap("merge + scatter");
     *n_patched = out_idx.size();
@@ -1268,7 +1393,6 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (rank < 0 || rank >= nranks) return fail(IILE_ERR_ARG, "iile_render: tile_rank out of range");
     hipStream_t stream = static_cast<hipStream_t>(prm->stream);
     LaunchCfg cfg{sc->n_cus, stream, prm->collect_stats != 0};
-    if (const char *e = std::getenv("IILE_DEBUG_SKIP")) cfg.dbg_skip = atoi(e) & 7;
     if (const char *e = std::getenv("IILE_TRAV_BLOCKS")) cfg.trav_blocks_per_cu = std::max(1, std::min(8, atoi(e)));
     const bool timed = prm->time_kernels != 0;
 
@@ -1276,11 +1400,10 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     std::memset(&P, 0, sizeof(P));
     P.n_tiles_x = (S.samp_x1 - S.samp_x0 + 15) / 16;
     P.n_tiles_y = (S.samp_y1 - S.samp_y0 + 15) / 16;
-    const int n_tiles = P.n_tiles_x * P.n_tiles_y;
     P.tile_rank = rank;
     P.tile_nranks = nranks;
-    P.n_owned_tiles = (n_tiles - rank + nranks - 1) / nranks;
-    if (P.n_owned_tiles < 0) P.n_owned_tiles = 0;
+    rc = ensure_tile_map(sc, &P, stream);
+    if (rc) return rc;
     const uint64_t pix_slots = uint64_t(P.n_owned_tiles) * 256;
     const int n_samples = k_end - k_begin;
     // A pass renders all samples of a range of owned tiles; the range is bounded by the workspace budget (~260 B per
@@ -1313,6 +1436,10 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     std::vector<PatchEntry> entries;
     sc->pb.flag_count = S.filter_wide ? nullptr : sc->flag_count;
     sc->pb.flag_rec = sc->flag_rec;
+    struct FlagGuard {  // error returns below must not leave the list armed for the kernel-level entry points
+        PassBuffers *pb;
+        ~FlagGuard() { pb->flag_count = nullptr; }
+    } flag_guard{&sc->pb};
 
     HIP_TRY(hipEventRecord(sc->ev_begin, stream));
     if (prm->collect_stats && pix_slots) HIP_TRY(hipMemsetAsync(sc->pb.counters, 0, sizeof(DCounters), stream));
@@ -1344,7 +1471,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
             rc = patch_prepare(sc, S, P, sc->aux_stream, &plan);
             if (rc) return rc;
             HIP_TRY(hipStreamSynchronize(stream));
-            rc = patch_pass_finish(sc, S, &plan, &entries);
+            rc = patch_pass_finish(sc, S, &plan, &entries, stream);
             if (rc) return rc;
         }
         st.n_passes++;
@@ -1367,7 +1494,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         if (!entries.empty()) {
             HIP_TRY(hipStreamSynchronize(stream));
             uint64_t n_patched = 0;
-            rc = patch_merge(sc, S, P, &entries, F.film_xyzw, &n_patched);
+            rc = patch_merge(sc, S, P, &entries, F.film_xyzw, &n_patched, stream);
             if (rc) return rc;
         }
     }
@@ -1377,8 +1504,9 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (!prm->film_on_device) {
         HIP_TRY(hipMemcpyAsync(film_xyzw, F.film_xyzw, size_t(fw) * fh * sizeof(float4), hipMemcpyDeviceToHost, stream));
     }
-    // The film is complete once the stream drains. Statistics need the drain;
-    // a device-resident film without stats stays asynchronous.
+    // The film is complete once the stream drains. Statistics need the drain; a device-resident film without stats
+    // stays asynchronous on `stream` past the last pass (the exact film finish waits for each pass on that stream, and
+    // only on it: nothing here touches the null stream or synchronises the device).
     if (stats || !prm->film_on_device) {
         HIP_TRY(hipStreamSynchronize(stream));
         float ms = 0;

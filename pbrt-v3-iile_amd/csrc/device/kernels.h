@@ -8,6 +8,9 @@ namespace iile {
 struct PassDesc {
     // tile ownership (SamplerIntegrator::Render's 16x16 tiles, integrator.cpp:235-237)
     int n_tiles_x, n_tiles_y, tile_rank, tile_nranks, n_owned_tiles;
+    // the rank's tiles in tile index order (its "slots") and the inverse map (-1: another rank's tile); both null
+    // when one rank owns every tile (slot == tile index). Ownership: iile_tile_owner (iile_scene.h).
+    const int *tile_of_slot, *slot_of_tile;
     // a pass renders ALL samples [k0, k0 + kc) of the owned tiles [slot0, slot0 + n_pass_tiles): whole tiles, so that
     // every FilmTile sum is complete when the pass ends (path id = ((slot - slot0) * 256 + pixel) * kc + k - k0)
     int slot0, n_pass_tiles;
@@ -65,7 +68,6 @@ struct LaunchCfg {
     int n_cus;
     hipStream_t stream;
     bool count_stats;
-    int dbg_skip = 0;             // timing experiments only: bit0 skip shadow rays, bit1 skip MIS rays
     int trav_blocks_per_cu = 0;   // persistent traversal blocks per CU; 0 = default_trav_blocks_per_cu()
 };
 

@@ -200,7 +200,7 @@ DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, i
         *k = uint32_t(P.k0) + kk;
         return *px >= S.crop_x0 && *py >= S.crop_y0 && *px < S.crop_x1 && *py < S.crop_y1;
     }
-    const int tile = P.tile_rank + (P.slot0 + int(slot)) * P.tile_nranks;
+    const int tile = P.tile_of_slot ? P.tile_of_slot[P.slot0 + int(slot)] : P.slot0 + int(slot);
     const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
     *px = S.samp_x0 + tx * kTile + int(pix & 15u);
     *py = S.samp_y0 + ty * kTile + int(pix >> 4);
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
 
 
 template <bool COUNT, bool ALPHA>
-__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
+__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                     const bool lit = (flags & NEE_HAS_MIS) && B.nee_mis[e] != 0;
                     pid = f2b(be.w);
                     const float4 L4 = B.L[pid];
-                    const bool has_shadow = (flags & NEE_HAS_SHADOW & ~uint32_t(dbg_skip)) != 0;
+                    const bool has_shadow = (flags & NEE_HAS_SHADOW) != 0;
                     F3 Ld_u = F3{0, 0, 0}, Ld_o = F3{0, 0, 0};
                     if (has_shadow) Ld_u = Ld_u + F3{a4.x, a4.y, a4.z};
                     if (lit) {
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
 }
 
 template <bool COUNT, bool ALPHA>
-__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane, int dbg_skip) {
+__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
                 e = e_new;
                 const float4 n2 = B.nee[2 * plane + e], n3 = B.nee[3 * plane + e];
                 const uint32_t flags = f2b(n3.w);
-                if (flags != kInvalid && (flags & NEE_HAS_MIS & ~uint32_t(dbg_skip))) {
+                if (flags != kInvalid && (flags & NEE_HAS_MIS)) {
                     trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st);
                     active = true;
                     if (COUNT) {
@@ -1301,8 +1301,9 @@ __global__ __launch_bounds__(kBlock) void k_film_store(DScene S, PassDesc P, Pas
 DEV bool tile_owned(const PassDesc &P, int tx, int ty, uint32_t *slot) {
     if (tx < 0 || ty < 0 || tx >= P.n_tiles_x || ty >= P.n_tiles_y) return false;
     const int t = ty * P.n_tiles_x + tx;
-    if (t % P.tile_nranks != P.tile_rank) return false;
-    *slot = uint32_t(t / P.tile_nranks);
+    const int s = P.slot_of_tile ? P.slot_of_tile[t] : t;
+    if (s < 0) return false;
+    *slot = uint32_t(s);
     return true;
 }
 DEV void add_xyz(float4 *out, float r, float g, float b, float w) {  // RGBToXYZ, spectrum.h:62-66
@@ -1663,25 +1664,25 @@ void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int 
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL((k_shadow<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+        hipLaunchKernelGGL((k_shadow<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     else
         {
         if (S.has_alpha)
-            hipLaunchKernelGGL((k_shadow<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+            hipLaunchKernelGGL((k_shadow<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
         else
-            hipLaunchKernelGGL((k_shadow<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+            hipLaunchKernelGGL((k_shadow<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     }
 }
 void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
     if (cfg.count_stats)
-        hipLaunchKernelGGL((k_mis<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+        hipLaunchKernelGGL((k_mis<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     else
         {
         if (S.has_alpha)
-            hipLaunchKernelGGL((k_mis<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+            hipLaunchKernelGGL((k_mis<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
         else
-            hipLaunchKernelGGL((k_mis<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap, cfg.dbg_skip);
+            hipLaunchKernelGGL((k_mis<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     }
 }
 void launch_light_distributions(const DScene &S, const float *samples, float *out, const LaunchCfg &cfg) {

@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include "../../../include/iile_dist.h"
 #include "../../../include/iile_gpu.h"
 #include "../../../include/iile_host.h"
 
@@ -62,9 +63,13 @@ class Integrator {
 
 class GpuPathIntegrator : public Integrator {
   public:
-    // tile_rank / tile_nranks: this process renders tiles with index % nranks == rank
-    GpuPathIntegrator(std::string output_pfm, int tile_rank = 0, int tile_nranks = 1, bool print_stats = false)
-        : output_(std::move(output_pfm)), rank_(tile_rank), nranks_(tile_nranks), stats_(print_stats) {}
+    // One process per GPU: with a communicator (iile_dist.h) this process renders the tiles iile_tile_owner gives
+    // rank `iile_dist_rank(comm)` and the films are merged by one RCCL sum-reduction to rank 0, which writes the image
+    // (the reference: tiles over threads, Film::MergeFilmTile under a mutex, src/core/film.cpp:135-148).
+    // Without one: tile_rank / tile_nranks select a shard and the caller merges (tests), default all tiles.
+    GpuPathIntegrator(std::string output_pfm, int tile_rank = 0, int tile_nranks = 1, bool print_stats = false, iile_dist *comm = nullptr)
+        : output_(std::move(output_pfm)), rank_(comm ? iile_dist_rank(comm) : tile_rank), nranks_(comm ? iile_dist_size(comm) : tile_nranks),
+          stats_(print_stats), comm_(comm) {}
 
     bool Render(const Scene &scene) override {
         if (!scene.ok()) return false;
@@ -75,19 +80,52 @@ class GpuPathIntegrator : public Integrator {
         }
         const iile_film_desc *f = scene.film();
         const int w = f->crop_x1 - f->crop_x0, h = f->crop_y1 - f->crop_y0;
-        std::vector<float> xyzw(size_t(4) * w * h), rgb(size_t(3) * w * h);
+        const size_t n_pix = size_t(w) * h;
+        std::vector<float> xyzw(4 * n_pix), rgb(3 * n_pix);
         iile_render_params prm = {};
         prm.tile_rank = rank_;
         prm.tile_nranks = nranks_;
         prm.collect_stats = stats_ ? 1 : 0;
         iile_stats st;
-        const int rc = iile_render(gpu, &prm, xyzw.data(), &st);
+        int rc;
+        if (comm_) {
+            // the film stays in HBM from the render through the merge; only rank 0 reads it back
+            void *film_dev = nullptr;
+            if (iile_device_alloc(4 * n_pix * sizeof(float), &film_dev) != IILE_OK) {
+                fprintf(stderr, "Error: GPU path: %s\n", iile_last_error());
+                iile_scene_destroy(gpu);
+                return false;
+            }
+            prm.film_on_device = 1;
+            rc = iile_render(gpu, &prm, static_cast<float *>(film_dev), &st);
+            if (rc == IILE_OK && iile_dist_film_reduce(comm_, static_cast<float *>(film_dev), int64_t(n_pix), 0, nullptr) != IILE_OK) {
+                fprintf(stderr, "Error: film merge: %s\n", iile_dist_last_error());
+                rc = IILE_ERR_HIP;
+            } else if (rc == IILE_OK) {
+                rc = iile_device_download(xyzw.data(), film_dev, 4 * n_pix * sizeof(float), nullptr);
+            }
+            iile_device_free(film_dev);
+            if (rc == IILE_OK && stats_) {  // job totals of the counters
+                uint64_t c[7] = {st.camera_rays, st.closest_rays, st.shadow_rays, st.nodes_closest, st.nodes_any, st.tri_tests, st.tri_hits};
+                uint64_t np = st.n_paths;
+                if (iile_dist_sum_u64(comm_, c, 7) == IILE_OK && iile_dist_sum_u64(comm_, &np, 1) == IILE_OK) {
+                    st.camera_rays = c[0], st.closest_rays = c[1], st.shadow_rays = c[2], st.nodes_closest = c[3];
+                    st.nodes_any = c[4], st.tri_tests = c[5], st.tri_hits = c[6];
+                    st.n_paths = np;
+                }
+                double ms = st.ms_total;
+                if (iile_dist_max_f64(comm_, &ms, 1) == IILE_OK) st.ms_total = ms;
+            }
+        } else {
+            rc = iile_render(gpu, &prm, xyzw.data(), &st);
+        }
         iile_scene_destroy(gpu);
         if (rc != IILE_OK) {
             fprintf(stderr, "Error: GPU path: %s\n", iile_last_error());
             return false;
         }
         last_stats = st;
+        if (comm_ && rank_ != 0) return true;  // rank 0 holds the merged film
         iile_host_film_to_rgb(f, xyzw.data(), rgb.data());                 // Film::to_rgb_array
         if (!output_.empty() && iile_host_write_pfm(output_.c_str(), rgb.data(), w, h) != 0) {  // Film::WriteImage
             fprintf(stderr, "Error: %s\n", iile_host_last_error());
@@ -101,11 +139,12 @@ class GpuPathIntegrator : public Integrator {
     std::string output_;
     int rank_, nranks_;
     bool stats_;
+    iile_dist *comm_;
 };
 
 inline GpuPathIntegrator *CreateGpuPathIntegrator(const ParamSet &, const std::string &output_pfm, int tile_rank = 0,
-                                                  int tile_nranks = 1, bool print_stats = false) {
-    return new GpuPathIntegrator(output_pfm, tile_rank, tile_nranks, print_stats);
+                                                  int tile_nranks = 1, bool print_stats = false, iile_dist *comm = nullptr) {
+    return new GpuPathIntegrator(output_pfm, tile_rank, tile_nranks, print_stats, comm);
 }
 
 }  // namespace iile

@@ -1,5 +1,6 @@
 // host_api.cpp — C ABI of libiile_host.so (see include/iile_host.h).
 #include <cstdio>
+#include <exception>
 
 #include "../../../include/iile_host.h"
 #include "host_scene.h"
@@ -21,23 +22,31 @@ int iile_host_load_pbrt(const char *path, const iile_host_overrides *ov, iile_ho
         g_err = "iile_host_load_pbrt: null argument";
         return 1;
     }
-    iile_host_scene *hs = new iile_host_scene;
-    std::string err;
-    if (!iile::load_pbrt_file(path, &hs->s, &err)) {
-        g_err = err;
+    iile_host_scene *hs = nullptr;
+    // no C++ exception may cross the C boundary (a malformed file can make a vector throw length_error / bad_alloc)
+    try {
+        hs = new iile_host_scene;
+        std::string err;
+        if (!iile::load_pbrt_file(path, &hs->s, &err)) {
+            g_err = err;
+            delete hs;
+            return 2;
+        }
+        if (ov) {
+            if (ov->xres > 0) hs->s.xres = ov->xres;
+            if (ov->yres > 0) hs->s.yres = ov->yres;
+            if (ov->spp > 0) hs->s.spp = ov->spp;
+            if (ov->max_depth > 0) hs->s.max_depth = ov->max_depth;
+        }
+        if (!iile::finalize_scene(&hs->s, &err)) {
+            g_err = err;
+            delete hs;
+            return 3;
+        }
+    } catch (const std::exception &e) {
+        g_err = std::string("iile_host_load_pbrt: ") + e.what();
         delete hs;
-        return 2;
-    }
-    if (ov) {
-        if (ov->xres > 0) hs->s.xres = ov->xres;
-        if (ov->yres > 0) hs->s.yres = ov->yres;
-        if (ov->spp > 0) hs->s.spp = ov->spp;
-        if (ov->max_depth > 0) hs->s.max_depth = ov->max_depth;
-    }
-    if (!iile::finalize_scene(&hs->s, &err)) {
-        g_err = err;
-        delete hs;
-        return 3;
+        return 4;
     }
     *out = hs;
     return 0;
@@ -70,6 +79,7 @@ int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info 
     info->yres = s.yres;
     info->spp = s.spp;
     info->max_depth = s.max_depth;
+    info->probe_hemi_size = s.desc.probe.hemi_size;
     return 0;
 }
 

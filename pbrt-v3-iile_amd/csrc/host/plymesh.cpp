@@ -163,9 +163,21 @@ bool load_ply(const std::string &path, std::vector<V3> *P, std::vector<V3> *N, s
         return false;
     }
     long n_vert = 0, n_face = 0;
+    int seen_vert = 0, seen_face = 0;
+    const long remaining = long(buf.size()) - long(pos);
     for (const Element &e : elems) {
-        if (e.name == "vertex") n_vert = e.count;
-        if (e.name == "face") n_face = e.count;
+        // an element of n records takes at least n bytes of body (ascii: one character per value): a header that
+        // promises more than the file holds, or a negative count, is rejected before anything is sized from it
+        if (e.count < 0 || (!e.props.empty() && e.count > remaining)) {
+            *err = path + ": PLY element \"" + e.name + "\" has an impossible count";
+            return false;
+        }
+        if (e.name == "vertex") n_vert = e.count, ++seen_vert;
+        if (e.name == "face") n_face = e.count, ++seen_face;
+    }
+    if (seen_vert > 1 || seen_face > 1) {
+        *err = path + ": PLY file declares a vertex / face element twice";
+        return false;
     }
     if (n_vert == 0 || n_face == 0) {
         *err = path + ": PLY file is invalid! No face/vertex elements found!";

@@ -90,6 +90,9 @@ class Oracle:
         assert rc == 0
         return film, st.as_dict()
 
+    def tile_owner(self, tx, ty, nranks):
+        return int(self.lib.oracle_tile_owner(int(tx), int(ty), int(nranks)))
+
     def halton_index(self, scene, px, py, k):
         return int(self.lib.oracle_halton_index(scene.desc, int(px), int(py), int(k)))
 

@@ -28,10 +28,29 @@ def test_gpu_library_exports_every_declared_symbol(binding):
         assert getattr(lib, n) is not None
 
 
+def test_dist_library_exports_every_declared_symbol(binding):
+    lib = binding.dist_lib()  # loading needs librccl but no GPU
+    names = declared_functions("iile_dist.h")
+    assert sorted(names) == sorted(binding.DIST_SYMBOLS)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_dist_needs_a_device(binding):
+    """The film merge has no CPU path either."""
+    if binding.device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is visible")
+    import pytest
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        binding.Dist(bytes(128), 0, 1)
+
+
 def test_struct_sizes_match_headers(binding):
     # layouts the Python side mirrors (kept in sync with include/*.h by hand)
     assert ctypes.sizeof(binding.FilmDesc) == 14 * 4
     assert ctypes.sizeof(binding.HostOverrides) == 16
+    assert ctypes.sizeof(binding.HostSceneInfo) == 14 * 4
     assert ctypes.sizeof(binding.RenderParams) == 8 * 4 + 8
     assert ctypes.sizeof(binding.GpuStats) == 10 * 8 + 8 * 8 + 6 * 8 + 4 * 4 + 2 * 8 + 4 * 8 + 4 * 8
 

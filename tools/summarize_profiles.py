@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof_<tag>/ into the tracked summaries under profiles/:
+"""Turn gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the tracked summaries under profiles/:
    profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
-   profiles/<tag>_pmc_traffic.json   per-kernel HBM bytes per launch from FETCH_SIZE / WRITE_SIZE
-FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE reports half the bytes of
-16-byte-per-lane reads (MI355X_MICROARCH.md, HBM section), so reads are doubled;
-WRITE_SIZE is exact for 16-byte-per-lane stores."""
+   profiles/<tag>_pmc_traffic.json   HBM bytes per kernel from FETCH_SIZE / WRITE_SIZE
+   profiles/<tag>_pmc_lanes.json     VALU / L2 counters per kernel (SQ_*, TCC_*)
+Each JSON has `kernels` (every template instantiation as the profiler names it, per launch) and `families` (the
+product builds of a kernel — first template argument COUNT = false — summed over the launches of ONE bench step:
+what bench.py reads). FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE reports half the bytes of
+16-byte-per-lane reads (MI355X_MICROARCH.md, HBM section), so reads are doubled; WRITE_SIZE is exact for
+16-byte-per-lane stores. The PMC passes run `bench.py --steps 1 --warmup 0`: one instrumented step (COUNT builds, not
+part of `families`) and exactly one timed step."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(repo, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(repo, "profiles")
@@ -23,27 +27,75 @@ def short(name):
     return name.split("(")[0].replace("void iile::", "").replace("iile::", "")
 
 
-out = collections.defaultdict(lambda: {"launches": 0, "FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0})
-for kind in ("fetch", "write"):
-    for f in glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True):
-        seen = set()
-        for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
-            if not k.startswith("k_"):
-                continue
-            c = r["Counter_Name"]
-            out[k][c + "_KiB"] += float(r["Counter_Value"])
-            if kind == "fetch" and r["Dispatch_Id"] not in seen:
-                seen.add(r["Dispatch_Id"])
-                out[k]["launches"] += 1
-res = {}
-for k, v in out.items():
-    n = max(v["launches"], 1)
-    rd = 2 * v["FETCH_SIZE_KiB"] * 1024 / n
-    wr = v["WRITE_SIZE_KiB"] * 1024 / n
-    res[k] = {"launches_in_step": v["launches"], "hbm_read_bytes_per_launch": int(rd),
-              "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
-              "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes, averaged over the launches of one step"}
-json.dump({"workload": "bench.py --steps 1 --warmup 0 (killeroo-simple 1920x1080, 64 spp)", "kernels": res},
-          open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(res, indent=1))
+def family(k):
+    fam = k.split("<")[0]
+    args = k[k.index("<") + 1:].rstrip(">").split(",") if "<" in k else []
+    product = (not args or args[0].strip() == "false") and fam != "k_generate"
+    return fam, product
+
+
+def load(kinds):
+    """{kernel: {counter: sum over dispatches, 'launches': n}}"""
+    out = collections.defaultdict(lambda: collections.defaultdict(float))
+    for kind in kinds:
+        for f in glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True):
+            seen = collections.defaultdict(set)
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if not k.startswith("k_"):
+                    continue
+                out[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                seen[k].add(r["Dispatch_Id"])
+            for k, s in seen.items():
+                out[k]["launches@" + kind] = len(s)
+    return out
+
+
+# ---- HBM traffic
+raw = load(("fetch", "write"))
+kernels, fams = {}, collections.defaultdict(lambda: {"launches_in_step": 0, "hbm_read_bytes_per_step": 0, "hbm_write_bytes_per_step": 0})
+for k, v in raw.items():
+    n = int(max(v.get("launches@fetch", 0), v.get("launches@write", 0), 1))
+    rd = 2 * v.get("FETCH_SIZE", 0.0) * 1024
+    wr = v.get("WRITE_SIZE", 0.0) * 1024
+    kernels[k] = {"launches_in_step": n, "hbm_read_bytes_per_launch": int(rd / n), "hbm_write_bytes_per_launch": int(wr / n),
+                  "hbm_bytes_per_launch": int((rd + wr) / n)}
+    fam, product = family(k)
+    if product:
+        fams[fam]["launches_in_step"] += n
+        fams[fam]["hbm_read_bytes_per_step"] += int(rd)
+        fams[fam]["hbm_write_bytes_per_step"] += int(wr)
+for f in fams.values():
+    f["hbm_bytes_per_step"] = f["hbm_read_bytes_per_step"] + f["hbm_write_bytes_per_step"]
+if kernels:
+    json.dump({"workload": "bench.py --steps 1 --warmup 0 --other-steps 0 (killeroo-simple 1920x1080, 64 spp, 1 GPU)",
+               "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes; separate rocprofv3 --pmc passes",
+               "families": fams, "kernels": kernels}, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+
+# ---- VALU / L2
+raw = load(("sq", "tcc", "sq2"))
+kernels, fams = {}, collections.defaultdict(lambda: collections.defaultdict(float))
+for k, v in raw.items():
+    kernels[k] = {c: (int(x) if not c.startswith("launches@") else int(x)) for c, x in v.items()}
+    fam, product = family(k)
+    if product:
+        for c, x in v.items():
+            fams[fam][c] += x
+out_f = {}
+for fam, v in fams.items():
+    e = {c: int(x) for c, x in v.items()}
+    if v.get("SQ_ACTIVE_INST_VALU"):
+        # useful lanes per issued VALU lane slot; share of the busy cycles in which a VALU instruction was in flight
+        # (quad-cycle counters: x4; SQ_BUSY_CYCLES is summed over the 32 shader engines, the others over 1024 SIMDs)
+        e["lane_util"] = round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (v["SQ_ACTIVE_INST_VALU"] * 64), 4)
+        if v.get("SQ_BUSY_CYCLES"):
+            e["valu_busy"] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v["SQ_BUSY_CYCLES"] / 32), 4)
+    if v.get("TCC_HIT_sum") or v.get("TCC_MISS_sum"):
+        e["l2_hit_rate"] = round(v.get("TCC_HIT_sum", 0.0) / max(v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0), 1.0), 4)
+    out_f[fam] = e
+if kernels:
+    json.dump({"workload": "bench.py --steps 1 --warmup 0 --other-steps 0 (killeroo-simple 1920x1080, 64 spp, 1 GPU)",
+               "note": "counter sums over the launches of one timed bench step, product builds only; lane_util = SQ_THREAD_CYCLES_VALU / "
+                       "(64 x SQ_ACTIVE_INST_VALU); valu_busy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs)",
+               "families": out_f, "kernels": kernels}, open(os.path.join(dst, f"{tag}_pmc_lanes.json"), "w"), indent=1)
+print(json.dumps({"traffic_families": list(fams.keys()), "lanes": out_f}, indent=1)[:3000])
