@@ -17,8 +17,9 @@ Workloads (BASELINE.json configs):
 The primary mode's number is `value`; the other mode is measured too (a few steps, `--other-steps 0`
 turns it off) and reported under `other_mode`, so that one run per N yields both curves.
 
-Rank 0 prints one JSON line. `value` is whole-job Mray/s (rays = Scene::Intersect + Scene::IntersectP calls,
-the reference's own ray definition). `roofline` prices the kernel with the largest HIP-event time against the
+Rank 0 prints one JSON line. `value` is whole-job Mray/s over the rays the timed kernels traced (a ray = one
+Scene::Intersect or Scene::IntersectP call of the reference; MIS rays that provably cannot end on the sampled light are
+not traced and not counted — `value_reference_ray_equivalents` counts every call the reference makes). `roofline` prices the kernel with the largest HIP-event time against the
 HBM roof by its algorithmic bytes and by the PMC-counted HBM traffic, and says what actually binds it (VALU
 issue) with the counters committed under profiles/; `cpu_baseline` is the CPU oracle timed on this box's host
 cores on a bounded sample of the same workload (baseline only).
@@ -247,15 +248,18 @@ def main():
         # self-verification of the timed region: every rank's last timed film (rank 0: the merged film) against the
         # instrumented step's
         same = bool(torch.equal(film.view(torch.int32), film_check.view(torch.int32)))
+        # rays the timed kernels traced on this rank: every main-path and shadow ray, and the MIS rays the plain build
+        # does not prove irrelevant (counted by the timed step itself)
+        traced = cst["ext_rays"] + cst["shadow_rays"] + st["mis_rays_traced"]
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            cnt = torch.tensor([cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"], 1 if same else 0], dtype=torch.int64, device="cuda")
-            mn = cnt[3:].clone()
+            cnt = torch.tensor([cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"], traced, 1 if same else 0], dtype=torch.int64, device="cuda")
+            mn = cnt[4:].clone()
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
             dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-            rays_closest, rays_shadow, cam = (int(x) for x in cnt[:3].tolist())
+            rays_closest, rays_shadow, cam, traced = (int(x) for x in cnt[:4].tolist())
             same = bool(int(mn.item()))
         else:
             rays_closest, rays_shadow, cam = cst["closest_rays"], cst["shadow_rays"], cst["camera_rays"]
@@ -263,8 +267,9 @@ def main():
             raise SystemExit("bench.py: the film of the last timed step differs from the instrumented step's film — "
                              "the timed kernels did not do the reference's work; no number is reported")
         rays = rays_closest + rays_shadow
-        res = {"elapsed": elapsed, "steps": steps, "rays_step": rays, "cam": cam, "cst": cst, "agg": agg, "n_passes": st["n_passes"],
-               "ms_per_step": elapsed * 1e3 / steps, "mray": rays * steps / elapsed / 1e6, "total_spp": total_spp}
+        res = {"elapsed": elapsed, "steps": steps, "rays_step": rays, "rays_traced_step": traced, "cam": cam, "cst": cst, "agg": agg, "n_passes": st["n_passes"],
+               "ms_per_step": elapsed * 1e3 / steps, "mray": traced * steps / elapsed / 1e6,
+               "mray_reference": rays * steps / elapsed / 1e6, "total_spp": total_spp}
         del gpu, scene, film, film_check
         torch.cuda.empty_cache()
         return res
@@ -399,9 +404,15 @@ def main():
             },
             "timed_film_verified": "bitwise equal to the instrumented step's film (all ranks)",
             "msamples_per_s": round(cam * steps / primary["elapsed"] / 1e6, 3),
-            "rays_per_step": rays_step,
+            "rays_per_step": primary["rays_traced_step"],
+            "reference_rays_per_step": rays_step,
+            "value_reference_ray_equivalents": round(primary["mray_reference"], 2),
+            "rays_note": "value counts the rays the timed kernels traced. The reference makes `reference_rays_per_step` Scene::Intersect / "
+                         "IntersectP calls for this frame (counted by the instrumented step); the difference is EstimateDirect's BSDF-sampled "
+                         "rays that the shade kernel proves unable to end on the sampled light (exact: the film is bit for bit the same) and "
+                         "does not trace. `value_reference_ray_equivalents` divides the reference's count by the same time.",
             "camera_samples_per_step": cam,
-            "rays_per_camera_sample": round(rays_step / max(cam, 1), 4),
+            "rays_per_camera_sample": round(primary["rays_traced_step"] / max(cam, 1), 4),
             "n_node_per_ray": round(n_node, 3),
             "n_tri_per_ray": round(n_tri, 4),
             "b_ray_bytes": round(b_ray, 1),

@@ -79,6 +79,10 @@ typedef struct iile_stats {
     uint64_t ext_rays, ext_nodes, ext_tri_tests, ext_sphere_tests;
     uint64_t any_tri_tests;       /* triangle tests of the shadow (any-hit) kernel */
     double ms_shadow, ms_mis, ms_resolve; /* the NEE kernels (ms_resolve: k_mis_lit); ms_connect is their sum */
+    /* filled by every render that returns stats: the MIS rays (EstimateDirect's BSDF-sampled rays) the call really
+     * traced. The instrumented build traces all of them (== closest_rays - ext_rays); the plain build skips those its
+     * shade kernel proves unable to end on the sampled light (exact: see k_shade) */
+    uint64_t mis_rays_traced;
 } iile_stats;
 
 int iile_device_count(void);

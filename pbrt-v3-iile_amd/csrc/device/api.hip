@@ -261,6 +261,7 @@ void copy_counters(const DCounters &c, iile_stats *st) {
     st->ext_tri_tests = c.ext_tri_tests;
     st->ext_sphere_tests = c.ext_sphere_tests;
     st->any_tri_tests = c.any_tri_tests;
+    st->mis_rays_traced = c.mis_traced;
 }
 
 // Enqueue one wavefront pass on cfg.stream.
@@ -1442,7 +1443,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     } flag_guard{&sc->pb};
 
     HIP_TRY(hipEventRecord(sc->ev_begin, stream));
-    if (prm->collect_stats && pix_slots) HIP_TRY(hipMemsetAsync(sc->pb.counters, 0, sizeof(DCounters), stream));
+    if (pix_slots) HIP_TRY(hipMemsetAsync(sc->pb.counters, 0, sizeof(DCounters), stream));
     if (pix_slots) HIP_TRY(hipMemsetAsync(sc->fb.tile_rgbw, 0, size_t(pix_slots) * sizeof(float4) * 2, stream));
     P.k0 = k_begin;
     P.kc = n_samples;
@@ -1516,10 +1517,14 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
             rc = collect_times(sc, &st);
             if (rc) return rc;
         }
-        if (prm->collect_stats && pix_slots) {
+        if (pix_slots) {
             DCounters c;
-            HIP_TRY(hipMemcpy(&c, sc->pb.counters, sizeof(c), hipMemcpyDeviceToHost));
-            copy_counters(c, &st);
+            HIP_TRY(hipMemcpyAsync(&c, sc->pb.counters, sizeof(c), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (prm->collect_stats)
+                copy_counters(c, &st);
+            else
+                st.mis_rays_traced = c.mis_traced;
         }
         st.workspace_bytes = sc->ws_bytes;
         if (stats) *stats = st;

@@ -161,6 +161,9 @@ struct DCounters {
     // the extend kernel alone (closest-hit rays of the main path), for its roofline
     unsigned long long ext_rays, ext_nodes, ext_tri_tests, ext_sphere_tests;
     unsigned long long any_tri_tests;  // triangle tests of the shadow kernel
+    // counted by every build (one atomic per wavefront at kernel end): the MIS rays k_mis really traced — the
+    // uninstrumented k_shade drops those that cannot reach the sampled light
+    unsigned long long mis_traced;
 };
 
 }  // namespace iile

@@ -45,7 +45,10 @@ namespace iile {
 
 constexpr int kBlock = 256;            // 4 wavefronts
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kShadeChunk = 512;  // hits one k_shade wavefront regroups by shading class at a time
+#ifndef IILE_SHADE_CHUNK
+#define IILE_SHADE_CHUNK 512
+#endif
+constexpr int kShadeChunk = IILE_SHADE_CHUNK;  // hits one k_shade wavefront regroups by shading class at a time
 constexpr int kTile = 16;
 
 DEV int lane_id() { return int(threadIdx.x & 63); }
@@ -854,12 +857,28 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                                         md = wi;
                                         // Li is Lemit when the MIS ray finds this light facing it
                                         Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * weight, scattering_pdf);
-                                        nee_flags |= NEE_HAS_MIS;
+                                        // The ray only matters if its closest hit is the sampled light (integrator.cpp:205-209),
+                                        // and Sphere::Pdf is the cone's pdf for ANY direction (sphere.cpp:294-306): most of these
+                                        // rays point away from the light. The traversal would run Sphere::Intersect on this very
+                                        // ray with some tMax <= inf, and every rejection of that test that depends on tMax only
+                                        // gets stricter as tMax shrinks (t0.hi > tMax, ts.hi > tMax): a ray the sphere test
+                                        // rejects at tMax = inf can never end on the light, whatever else it hits. Those rays are
+                                        // not traced by the uninstrumented kernels (the instrumented build traces them all: the
+                                        // reference's ray counters are part of parity). Triangle emitters: Shape::Pdf has already
+                                        // intersected the triangle with this ray (lp == 0 on a miss).
+                                        bool can_reach = true;
+                                        if (!COUNT && lt.type == kLightDiffuseArea) {
+                                            float t_l;
+                                            F3 od_l, ph_l;
+                                            can_reach = sphere_test(S.spheres[lt.sphere], mo, md, IILE_INF, &t_l, &od_l, &ph_l);
+                                        }
+                                        if (can_reach) nee_flags |= NEE_HAS_MIS;
                                     }
                                 }
                             }
                             nee_light = uint32_t(li);
-                            emit_nee = true;
+                            // a record with neither ray adds nothing to L; only the instrumented build needs it (zero_radiance)
+                            emit_nee = COUNT || nee_flags != 0;
                         }
                     }
                 }
@@ -1082,7 +1101,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
     const uint32_t count = B.counts[kCntNee + bounce];
     uint32_t *head = &B.counts[kCntMisHead + bounce];
     TraceStats st = {0, 0, 0, 0};
-    unsigned long long n_closest = 0;
+    unsigned long long n_closest = 0, n_traced = 0;
     WaveFeed feed{0, 0, count == 0};
     Trav t;
     t.have = false;
@@ -1105,6 +1124,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
                 if (flags != kInvalid && (flags & NEE_HAS_MIS)) {
                     trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st);
                     active = true;
+                    ++n_traced;
                     if (COUNT) {
                         ++n_closest;
                         if (B.nray_out) B.nray_out[2 * f2b(B.nee[6 * size_t(plane) + e].w)] += 1;
@@ -1144,6 +1164,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
             active = false;
         }
     }
+    flush_counter(&B.counters->mis_traced, n_traced);
     if (COUNT) {
         flush_counter(&B.counters->closest_rays, n_closest);
         flush_counter(&B.counters->nodes_closest, st.nodes);
