@@ -144,13 +144,15 @@ struct DScene {
 // queue records -------------------------------------------------------------
 // ray:  ro = (o.xyz, bitcast pid)   rd = (d.xyz, tmax)
 // hit:  (bitcast prim or -1, b0 | t, b1, b2)
-// NEE entry (7 float4 planes):
+// NEE record (five of the seven float4 planes of PassBuffers::nee, indexed by record slot):
 //   n0 = (shadow o.xyz, light selection pdf)   n1 = (shadow d.xyz, bitcast flags)
-//   n2 = (mis o.xyz, bitcast light)       n3 = (mis d.xyz, bitcast flags)
 //   n4 = (A.xyz, bitcast flags)   n5 = (B.xyz, bitcast light)   n6 = (beta.xyz, bitcast pid)
 // (flags / light / pid are repeated so that each consumer streams only the planes it needs)
-// plus two byte planes written by the traversal kernels: nee_occl (shadow ray occluded),
-// nee_mis (area light index + 1 of the primitive the MIS ray ended on, 0 = none)
+// MIS rays (planes 2 and 3, a dense queue of their own, indexed by MIS-queue slot: only records whose
+// BSDF-sampled ray can matter have one):
+//   n2 = (mis o.xyz, bitcast record slot)   n3 = (mis d.xyz, bitcast light)
+// plus a byte plane written by k_mis / k_mis_lit, indexed by record slot:
+// nee_mis (area light index + 1 of the primitive the MIS ray ended on, 0 = none; then 1 = lit)
 enum { NEE_HAS_SHADOW = 1, NEE_HAS_MIS = 2 };
 
 struct DCounters {

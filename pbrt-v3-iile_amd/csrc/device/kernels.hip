@@ -127,6 +127,7 @@ constexpr int kCntExtHead = 48;  // [bounce] chunk cursor of the extend queue
 constexpr int kCntConHead = 64;  // [bounce] chunk cursor of the NEE queue (shadow kernel)
 constexpr int kCntMisHead = 80;  // [bounce] chunk cursor of the NEE queue (MIS kernel)
 constexpr int kCntShdHead = 96;  // [bounce] chunk cursor of the shade queue
+constexpr int kCntMis = 112;     // [bounce] MIS rays (a dense queue of its own: most NEE records have none)
 
 // Persistent-wavefront work feed. A wavefront reserves kChunk consecutive queue
 // slots with one atomic and hands them to its lanes as they go idle, so lanes
@@ -555,11 +556,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     float4 *no = B.ray_o[(bounce + 1) & 1], *nd = B.ray_d[(bounce + 1) & 1];
     unsigned long long n_nee = 0, n_term = 0, n_pdf_tests = 0, n_pdf_hits = 0;
-    WaveOut ray_out{0, 0}, nee_out{0, 0};
+    WaveOut ray_out{0, 0}, nee_out{0, 0}, mis_out{0, 0};
     auto pad_ray = [&](uint32_t sl) { no[sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
-    auto pad_nee = [&](uint32_t sl) {
-        B.nee[plane + sl] = B.nee[3 * plane + sl] = B.nee[4 * plane + sl] = make_float4(0, 0, 0, b2f(kInvalid));
-    };
+    auto pad_nee = [&](uint32_t sl) { B.nee[plane + sl] = B.nee[4 * plane + sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
+    auto pad_mis = [&](uint32_t sl) { B.nee[2 * plane + sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
     __shared__ uint32_t s_entry[kWavesPerBlock][kShadeChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *const head = &B.counts[kCntShdHead + bounce];
@@ -884,15 +884,20 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                 }
             }
             const uint32_t eslot = out_take(nee_out, &B.counts[kCntNee + bounce], emit_nee, pad_nee);
+            // the MIS rays go to a dense queue of their own (planes 2 and 3): most records have none
+            const bool emit_mis = emit_nee && (nee_flags & NEE_HAS_MIS) != 0;
+            const uint32_t mslot = out_take(mis_out, &B.counts[kCntMis + bounce], emit_mis, pad_mis);
             if (emit_nee) {
                 B.nee[eslot] = make_float4(so.x, so.y, so.z, light_sel_pdf);
                 B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
-                B.nee[2 * plane + eslot] = make_float4(mo.x, mo.y, mo.z, b2f(nee_light));
                 // flags / light / pid are repeated in the planes each consumer streams anyway
-                B.nee[3 * plane + eslot] = make_float4(md.x, md.y, md.z, b2f(nee_flags));
                 B.nee[4 * plane + eslot] = make_float4(A.x, A.y, A.z, b2f(nee_flags));
                 B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, b2f(nee_light));
                 B.nee[6 * plane + eslot] = make_float4(beta.x, beta.y, beta.z, b2f(pid));  // beta before this bounce
+            }
+            if (emit_mis) {
+                B.nee[2 * plane + mslot] = make_float4(mo.x, mo.y, mo.z, b2f(eslot));  // + the record it belongs to
+                B.nee[3 * plane + mslot] = make_float4(md.x, md.y, md.z, b2f(nee_light));
             }
         }
         F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
@@ -961,6 +966,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
     }
     out_flush(ray_out, pad_ray);
     out_flush(nee_out, pad_nee);
+    out_flush(mis_out, pad_mis);
     if (COUNT) {
         flush_counter(&B.counters->nee_evals, n_nee);
         flush_counter(&B.counters->path_length[bounce < 7 ? bounce : 7], n_term);
@@ -1098,7 +1104,8 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
                       blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
-    const uint32_t count = B.counts[kCntNee + bounce];
+    // the dense queue of MIS rays k_shade wrote beside the NEE records: (o, record) in plane 2, (d, light) in plane 3
+    const uint32_t count = B.counts[kCntMis + bounce];
     uint32_t *head = &B.counts[kCntMisHead + bounce];
     TraceStats st = {0, 0, 0, 0};
     unsigned long long n_closest = 0, n_traced = 0;
@@ -1109,19 +1116,20 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
     t.sp = 0;
     t.hit_prim = -1;
     bool active = false;
-    uint32_t e = 0;
+    uint32_t q = 0, e = 0;
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
-            uint32_t e_new;
-            if (feed_take(feed, head, count, !active, &e_new, [&](uint32_t first) {
+            uint32_t q_new;
+            if (feed_take(feed, head, count, !active, &q_new, [&](uint32_t first) {
                     warm_plane(B.nee + 2 * size_t(plane), first, count);
                     warm_plane(B.nee + 3 * size_t(plane), first, count);
                 })) {
-                e = e_new;
-                const float4 n2 = B.nee[2 * plane + e], n3 = B.nee[3 * plane + e];
-                const uint32_t flags = f2b(n3.w);
-                if (flags != kInvalid && (flags & NEE_HAS_MIS)) {
+                q = q_new;
+                const float4 n2 = B.nee[2 * size_t(plane) + q];
+                if (f2b(n2.w) != kInvalid) {
+                    const float4 n3 = B.nee[3 * size_t(plane) + q];
+                    e = f2b(n2.w);
                     trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st);
                     active = true;
                     ++n_traced;
@@ -1129,8 +1137,6 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
                         ++n_closest;
                         if (B.nray_out) B.nray_out[2 * f2b(B.nee[6 * size_t(plane) + e].w)] += 1;
                     }
-                } else if (flags != kInvalid) {
-                    B.nee_mis[e] = 0;  // no MIS ray: k_mis_lit has nothing to look at
                 }
             }
         }
@@ -1146,12 +1152,12 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
             } else if (n_leaf > 0) {
-                if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
+                if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * size_t(plane) + q]);
             }
         }
 #else
         while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
-        if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * plane + e]);
+        if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * size_t(plane) + q]);
 #endif
         if (active && !t.have) {
             // store only: (area light index + 1) of the primitive the MIS ray ended on, 0 for none
@@ -1203,15 +1209,17 @@ __global__ __launch_bounds__(kBlock) void k_miss(DScene S, PassBuffers B, int bo
 // SurfaceInteraction::Le -> DiffuseAreaLight::L; integrator.cpp:205-209). Only the rare records
 // whose ray did end on an emitter are looked at any further.
 __global__ __launch_bounds__(kBlock) void k_mis_lit(DScene S, PassBuffers B, int bounce, uint32_t plane) {
-    const uint32_t count = B.counts[kCntNee + bounce];
-    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < count; e += gridDim.x * kBlock) {
+    const uint32_t count = B.counts[kCntMis + bounce];
+    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < count; q += gridDim.x * kBlock) {
+        const float4 n2 = B.nee[2 * size_t(plane) + q];
+        const uint32_t e = f2b(n2.w);  // the NEE record of this MIS ray
+        if (e == kInvalid) continue;
         const uint32_t mis = B.nee_mis[e];
         if (mis == 0) continue;
-        const float4 n2 = B.nee[2 * size_t(plane) + e], n3 = B.nee[3 * size_t(plane) + e];
-        const uint32_t flags = f2b(n3.w);
+        const float4 n3 = B.nee[3 * size_t(plane) + q];
         bool lit = false;
-        if (flags != kInvalid && (flags & NEE_HAS_MIS)) {
-            const int li = int(f2b(n2.w));
+        {
+            const int li = int(f2b(n3.w));
             if (mis == 255u) {
                 lit = S.lights[li].type == kLightInfinite;  // `else Li = light.Le(ray)`, integrator.cpp:209-210
             } else if (int(mis) == li + 1) {
