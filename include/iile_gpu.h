@@ -112,7 +112,8 @@ int iile_trace_closest(iile_scene *scene, int32_t n, const float *o3, const floa
 /* BVHAccel::IntersectP on n rays. */
 int iile_trace_any(iile_scene *scene, int32_t n, const float *o3, const float *d3, const float *tmax,
                    int32_t *hit, iile_stats *stats);
-/* HaltonSampler: index_out[i] = GetIndexForSample(k) of pixel i; out[i*ndims + d] =
+/* The scene's sampler (HaltonSampler, or SobolSampler when iile_scene_desc::sobol is enabled):
+ * index_out[i] = GetIndexForSample(k) of pixel i; out[i*ndims + d] =
  * SampleDimension(index, dim0 + d). */
 int iile_halton_samples(iile_scene *scene, int32_t n, const int32_t *px, const int32_t *py, const int32_t *k,
                         int32_t dim0, int32_t ndims, float *out, uint32_t *index_out);

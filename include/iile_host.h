@@ -34,7 +34,12 @@ typedef struct iile_host_overrides {
     int32_t xres, yres;
     int32_t spp;
     int32_t max_depth;
+    int32_t sampler; /* IILE_SAMPLER_*: which sampler renders the frame. SOBOL is what the fork's path integrator does
+                        under IILE_PATH_SAMPLES_OVERRIDE = spp (src/integrators/path.cpp:202-212) */
 } iile_host_overrides;
+#define IILE_SAMPLER_KEEP 0
+#define IILE_SAMPLER_HALTON 1
+#define IILE_SAMPLER_SOBOL 2
 
 typedef struct iile_host_scene_info {
     int32_t n_prims, n_triangles, n_spheres, n_meshes;
@@ -75,6 +80,12 @@ int iile_host_scene_texture_level(const iile_host_scene *scene, int32_t index, i
 /* Film::filterTable of the scene's pixel filter (src/core/film.cpp:65-74): 16 x 16 floats; returns whether the
  * filter is wider than the one-pixel box (iile_scene_desc::film_filter_wide). */
 int iile_host_scene_filter_table(const iile_host_scene *scene, float *table256);
+
+/* The Sobol' generator matrices the host builds (csrc/host/sobol.cpp): SobolMatrices32 / SobolMatrices64 of
+ * src/core/sobolmatrices.cpp for dimensions [0, n_dims): n_dims * 52 entries each (either pointer may be NULL); and
+ * VdCSobolMatrices[log2_resolution - 1] / VdCSobolMatricesInv[log2_resolution - 1], 52 entries each (unused ones 0). */
+int iile_host_sobol_matrices(int32_t n_dims, uint32_t *m32, uint64_t *m64);
+int iile_host_sobol_vdc(int32_t log2_resolution, uint64_t *vdc52, uint64_t *vdc_inv52);
 
 const char *iile_host_last_error(void);
 

@@ -178,6 +178,21 @@ typedef struct iile_halton {
     int32_t sample_at_pixel_center; /* "samplepixelcenter": dimensions 0 and 1 are 0.5 (halton.cpp:119) */
 } iile_halton;
 
+/* SobolSampler state (src/samplers/sobol.h:57-75, sobol.cpp:42-59; the sampler the fork's CreatePathIntegrator puts in
+ * place of the scene's under IILE_PATH_SAMPLES_OVERRIDE, src/integrators/path.cpp:202-212). enabled != 0: the frame is
+ * sampled with it and iile_halton is unused (the IISPT probe pass keeps its own Halton sampler). Sample indices are
+ * confined to 32 bits (spp << 2 log2_resolution <= 2^32), so 32 of the 52 columns of each generator matrix suffice. */
+typedef struct iile_sobol {
+    int32_t enabled;
+    int32_t spp;                /* RoundUpPow2(pixelsamples) */
+    int32_t resolution;         /* RoundUpPow2(max extent of the sample bounds) */
+    int32_t log2_resolution;
+    int32_t n_dims;
+    const uint32_t *matrices32; /* [n_dims * 32]: columns 0 .. 31 of SobolMatrices32 (src/core/sobolmatrices.cpp) per dimension */
+    uint32_t vdc[32];           /* VdCSobolMatrices[log2_resolution - 1][c] */
+    uint32_t vdc_inv[32];       /* VdCSobolMatricesInv[log2_resolution - 1][c] */
+} iile_sobol;
+
 /* PathIntegrator knobs (src/integrators/path.cpp:214-231). */
 #define IILE_LIGHTS_SPATIAL 0 /* SpatialLightDistribution, the default (lightdistrib.cpp:91-299) */
 #define IILE_LIGHTS_UNIFORM 1 /* UniformLightDistribution (lightdistrib.cpp:65-72) */
@@ -240,6 +255,7 @@ typedef struct iile_scene_desc {
     iile_halton halton;
     iile_integrator integrator;
     iile_probe_setup probe;
+    iile_sobol sobol;
 } iile_scene_desc;
 
 /* Which rank of an n-rank job renders the 16x16 tile (tx, ty) of SamplerIntegrator::Render's tile grid

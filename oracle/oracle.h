@@ -55,6 +55,18 @@ int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, in
 /* ---- unit-level entry points for known-answer and parity tests ---- */
 int64_t oracle_halton_index(const iile_scene_desc *scene, int px, int py, int64_t k);
 float oracle_halton_sample(const iile_scene_desc *scene, int64_t index, int dim);
+/* the scene's sampler, HaltonSampler or SobolSampler (samplers/sobol.cpp:42-59): sample index of (pixel, k); dimension
+ * `dim` of a sample for current pixel (px, py) */
+int64_t oracle_sample_index(const iile_scene_desc *scene, int px, int py, int64_t k);
+float oracle_sample_dimension(const iile_scene_desc *scene, int64_t index, int dim, int px, int py);
+/* core/lowdiscrepancy.h:93-126, 229-288 on caller-supplied matrices */
+uint32_t oracle_reverse_bits32(uint32_t n);
+uint32_t oracle_multiply_generator(const uint32_t *C, uint32_t a);
+float oracle_sample_generator_matrix(const uint32_t *C, uint32_t a, uint32_t scramble);
+void oracle_gray_code_sample(const uint32_t *C, uint32_t n, uint32_t scramble, float *p);
+float oracle_sobol_sample_float(const uint32_t *m32, int64_t a, int dimension, uint32_t scramble);
+double oracle_sobol_sample_double(const uint64_t *m64, int64_t a, int dimension, uint64_t scramble);
+uint64_t oracle_sobol_interval_to_index(const uint64_t *vdc, const uint64_t *vdc_inv, uint32_t m, uint64_t frame, int px, int py);
 float oracle_radical_inverse(int base_index, uint64_t a);
 float oracle_scrambled_radical_inverse(const iile_scene_desc *scene, int base_index, uint64_t a);
 /* same function with a caller-supplied digit permutation of `base` entries */

@@ -768,7 +768,51 @@ struct Oracle {
         }
         return std::min(inv_base_n * (float(reversed) + inv_base * perm[0] / (1 - inv_base)), OneMinusEpsilon);
     }
-    float sample_dimension(int64_t index, int dim) const {
+    // ------------------------------------------------------------------------
+    // Sobol' (samplers/sobol.cpp:42-59, core/lowdiscrepancy.h:229-274). The generator matrices are scene data built on
+    // the host (iile_sobol: 32 columns per dimension, sample indices below 2^32); tests/test_sobol.py holds them against
+    // the reference's tables.
+    // SobolIntervalToIndex, lowdiscrepancy.h:229-252
+    uint64_t sobol_interval_to_index(uint32_t m, uint64_t frame, int px, int py) const {
+        if (m == 0) return 0;
+        const iile_sobol &sb = S.sobol;
+        const uint32_t m2 = m << 1;
+        uint64_t index = uint64_t(frame) << m2;
+        uint64_t delta = 0;
+        for (int c = 0; frame; frame >>= 1, ++c)
+            if (frame & 1) delta ^= sb.vdc[c];  // Add flipped column m + c + 1.
+        uint64_t b = (((uint64_t)((uint32_t)px) << m) | ((uint32_t)py)) ^ delta;  // flipped b
+        for (int c = 0; b; b >>= 1, ++c)
+            if (b & 1) index ^= sb.vdc_inv[c];  // Add column 2 * m - c.
+        return index;
+    }
+    // SobolSampleFloat, lowdiscrepancy.h:262-274 (scramble 0)
+    float sobol_sample_float(int64_t a, int dimension) const {
+        uint32_t v = 0;
+        for (int i = dimension * 32; a != 0; a >>= 1, i++)
+            if (a & 1) v ^= S.sobol.matrices32[i];
+        return std::min(v * 0x1p-32f /* 1/2^32 */, OneMinusEpsilon);
+    }
+    // SobolSampler::GetIndexForSample / SampleDimension, sobol.cpp:42-59
+    int64_t sobol_index(int px, int py, int64_t sample_num) const {
+        return int64_t(sobol_interval_to_index(uint32_t(S.sobol.log2_resolution), uint64_t(sample_num), px - S.film.samp_x0, py - S.film.samp_y0));
+    }
+    float sobol_sample_dimension(int64_t index, int dim, int px, int py) const {
+        float s = sobol_sample_float(index, dim);
+        // Remap Sobol' dimensions used for pixel samples
+        if (dim == 0 || dim == 1) {
+            const int pmin = dim == 0 ? S.film.samp_x0 : S.film.samp_y0, cur = dim == 0 ? px : py;
+            s = s * S.sobol.resolution + pmin;
+            s = std::min(std::max(s - cur, 0.f), OneMinusEpsilon);  // Clamp(s - currentPixel[dim], 0, OneMinusEpsilon)
+        }
+        return s;
+    }
+    // the scene's sampler: GetIndexForSample / SampleDimension of HaltonSampler or SobolSampler
+    int64_t sample_index(int px, int py, int64_t sample_num) const {
+        return S.sobol.enabled && !probe ? sobol_index(px, py, sample_num) : halton_index(px, py, sample_num);
+    }
+    float sample_dimension(int64_t index, int dim, int px = 0, int py = 0) const {
+        if (S.sobol.enabled && !probe) return sobol_sample_dimension(index, dim, px, py);
         const iile_halton &h = S.halton;
         if (h.sample_at_pixel_center && (dim == 0 || dim == 1)) return 0.5f;  // halton.cpp:119
         if (dim == 0) return radical_inverse(0, 2, uint64_t(index >> h.base_exponents[0]));
@@ -781,10 +825,11 @@ struct Oracle {
         const Oracle *o;
         int64_t index;
         int dim;
-        float get1d() { return o->sample_dimension(index, dim++); }
+        int px, py;  // currentPixel (SobolSampler's dimensions 0 and 1 are relative to it)
+        float get1d() { return o->sample_dimension(index, dim++, px, py); }
         void get2d(float *u) {
-            u[0] = o->sample_dimension(index, dim);
-            u[1] = o->sample_dimension(index, dim + 1);
+            u[0] = o->sample_dimension(index, dim, px, py);
+            u[1] = o->sample_dimension(index, dim + 1, px, py);
             dim += 2;
         }
     };
@@ -2476,7 +2521,7 @@ struct Oracle {
 
     // one camera sample -> guarded radiance (integrator.cpp:270-314)
     Rgb sample_radiance(int px, int py, int64_t k, float *pfilm) const {
-        Sampler smp{this, halton_index(px, py, k), 0};
+        Sampler smp{this, sample_index(px, py, k), 0, px, py};
         float u[2];
         smp.get2d(u);
         pfilm[0] = float(px) + u[0];
@@ -2713,6 +2758,62 @@ float oracle_halton_sample(const iile_scene_desc *scene, int64_t index, int dim)
     Counters c;
     Oracle o(*scene, ORACLE_TRIG_LIBM, &c);
     return o.sample_dimension(index, dim);
+}
+// the scene's sampler (Halton or Sobol'): GetIndexForSample / SampleDimension for pixel (px, py)
+int64_t oracle_sample_index(const iile_scene_desc *scene, int px, int py, int64_t k) {
+    Counters c;
+    Oracle o(*scene, ORACLE_TRIG_LIBM, &c);
+    return o.sample_index(px, py, k);
+}
+float oracle_sample_dimension(const iile_scene_desc *scene, int64_t index, int dim, int px, int py) {
+    Counters c;
+    Oracle o(*scene, ORACLE_TRIG_LIBM, &c);
+    return o.sample_dimension(index, dim, px, py);
+}
+// Generator-matrix helpers of core/lowdiscrepancy.h on caller-supplied matrices (the reference's own tests of them,
+// src/tests/sampling.cpp:75-138, are re-run through these).
+uint32_t oracle_reverse_bits32(uint32_t n) { return Oracle::reverse_bits32(n); }
+uint32_t oracle_multiply_generator(const uint32_t *C, uint32_t a) {  // lowdiscrepancy.h:93-98
+    uint32_t v = 0;
+    for (int i = 0; a != 0; ++i, a >>= 1)
+        if (a & 1) v ^= C[i];
+    return v;
+}
+float oracle_sample_generator_matrix(const uint32_t *C, uint32_t a, uint32_t scramble) {  // lowdiscrepancy.h:100-109
+    return std::min((oracle_multiply_generator(C, a) ^ scramble) * 0x1p-32f, OneMinusEpsilon);
+}
+void oracle_gray_code_sample(const uint32_t *C, uint32_t n, uint32_t scramble, float *p) {  // lowdiscrepancy.h:113-126
+    uint32_t v = scramble;
+    for (uint32_t i = 0; i < n; ++i) {
+        p[i] = std::min(v * 0x1p-32f /* 1/2^32 */, OneMinusEpsilon);
+        v ^= C[__builtin_ctz(i + 1)];
+    }
+}
+// SobolSampleFloat / SobolSampleDouble (lowdiscrepancy.h:262-288) on full 52-column matrices
+float oracle_sobol_sample_float(const uint32_t *m32, int64_t a, int dimension, uint32_t scramble) {
+    uint32_t v = scramble;
+    for (int i = dimension * 52; a != 0; a >>= 1, i++)
+        if (a & 1) v ^= m32[i];
+    return std::min(v * 0x1p-32f /* 1/2^32 */, OneMinusEpsilon);
+}
+double oracle_sobol_sample_double(const uint64_t *m64, int64_t a, int dimension, uint64_t scramble) {
+    uint64_t result = scramble & ~-(1LL << 52);
+    for (int i = dimension * 52; a != 0; a >>= 1, i++)
+        if (a & 1) result ^= m64[i];
+    return std::min(result * (1.0 / (1ULL << 52)), 0x1.fffffffffffffp-1);
+}
+// SobolIntervalToIndex (lowdiscrepancy.h:229-252) on caller-supplied VdC matrices
+uint64_t oracle_sobol_interval_to_index(const uint64_t *vdc, const uint64_t *vdc_inv, uint32_t m, uint64_t frame, int px, int py) {
+    if (m == 0) return 0;
+    const uint32_t m2 = m << 1;
+    uint64_t index = uint64_t(frame) << m2;
+    uint64_t delta = 0;
+    for (int c = 0; frame; frame >>= 1, ++c)
+        if (frame & 1) delta ^= vdc[c];
+    uint64_t b = (((uint64_t)((uint32_t)px) << m) | ((uint32_t)py)) ^ delta;
+    for (int c = 0; b; b >>= 1, ++c)
+        if (b & 1) index ^= vdc_inv[c];
+    return index;
 }
 static const int kFirstPrimes[64] = {2,   3,   5,   7,   11,  13,  17,  19,  23,  29,  31,  37,  41,  43,  47,  53,
                                      59,  61,  67,  71,  73,  79,  83,  89,  97,  101, 103, 107, 109, 113, 127, 131,

@@ -24,7 +24,10 @@ c_vp = ctypes.c_void_p
 
 
 class HostOverrides(ctypes.Structure):
-    _fields_ = [("xres", c_i32), ("yres", c_i32), ("spp", c_i32), ("max_depth", c_i32)]
+    _fields_ = [("xres", c_i32), ("yres", c_i32), ("spp", c_i32), ("max_depth", c_i32), ("sampler", c_i32)]
+
+
+SAMPLERS = {None: 0, "": 0, "halton": 1, "sobol": 2}  # IILE_SAMPLER_* of include/iile_host.h
 
 
 class HostSceneInfo(ctypes.Structure):
@@ -73,7 +76,8 @@ class GpuStats(ctypes.Structure):
 # every symbol the headers declare; checked by tests/test_abi.py
 HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_film", "iile_host_scene_get_info",
                 "iile_host_scene_free", "iile_host_film_to_rgb", "iile_host_write_pfm", "iile_host_last_error", "iile_host_read_image",
-                "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table"]
+                "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table",
+                "iile_host_sobol_matrices", "iile_host_sobol_vdc"]
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
@@ -110,8 +114,28 @@ def host_lib():
         lib.iile_host_scene_texture.argtypes = [c_vp, c_i32, ctypes.POINTER(Texture)]
         lib.iile_host_scene_texture_level.argtypes = [c_vp, c_i32, c_i32, c_vp]
         lib.iile_host_scene_filter_table.argtypes = [c_vp, c_vp]
+        lib.iile_host_sobol_matrices.argtypes = [c_i32, c_vp, c_vp]
+        lib.iile_host_sobol_vdc.argtypes = [c_i32, c_vp, c_vp]
         _host = lib
     return _host
+
+
+def sobol_matrices(n_dims):
+    """(SobolMatrices32, SobolMatrices64) as the host builds them: (n_dims, 52) uint32 / uint64."""
+    m32 = np.zeros((n_dims, 52), np.uint32)
+    m64 = np.zeros((n_dims, 52), np.uint64)
+    if host_lib().iile_host_sobol_matrices(int(n_dims), m32.ctypes.data, m64.ctypes.data) != 0:
+        raise RuntimeError(host_lib().iile_host_last_error().decode())
+    return m32, m64
+
+
+def sobol_vdc(log2_resolution):
+    """(VdCSobolMatrices[m - 1], VdCSobolMatricesInv[m - 1]) as the host builds them: 52 uint64 each."""
+    vdc = np.zeros(52, np.uint64)
+    inv = np.zeros(52, np.uint64)
+    if host_lib().iile_host_sobol_vdc(int(log2_resolution), vdc.ctypes.data, inv.ctypes.data) != 0:
+        raise RuntimeError(host_lib().iile_host_last_error().decode())
+    return vdc, inv
 
 
 def read_image(path):
@@ -243,10 +267,12 @@ def _i32(a):
 class HostScene:
     """Scene loaded and flattened by libiile_host (ParseFile + MakeScene in the reference)."""
 
-    def __init__(self, path=DEFAULT_SCENE, xres=0, yres=0, spp=0, max_depth=0):
+    def __init__(self, path=DEFAULT_SCENE, xres=0, yres=0, spp=0, max_depth=0, sampler=None):
+        """sampler: None keeps the scene file's; "sobol" is what the fork's path integrator renders with under
+        IILE_PATH_SAMPLES_OVERRIDE (src/integrators/path.cpp:202-212)."""
         lib = host_lib()
         self._h = c_vp()
-        ov = HostOverrides(int(xres), int(yres), int(spp), int(max_depth))
+        ov = HostOverrides(int(xres), int(yres), int(spp), int(max_depth), SAMPLERS[sampler])
         rc = lib.iile_host_load_pbrt(os.fsencode(path), ctypes.byref(ov), ctypes.byref(self._h))
         if rc != 0:
             raise RuntimeError(f"iile_host_load_pbrt({path}) failed: {lib.iile_host_last_error().decode()}")

@@ -38,7 +38,10 @@ int main(int argc, char **argv) {
             arg_int(ps.maxdepth);
         else if (!strcmp(argv[i], "--stats"))
             stats = true;
-        else if (!strcmp(argv[i], "--gpurank") && i + 1 < argc) {
+        else if (!strcmp(argv[i], "--sampler") && i + 1 < argc) {
+            const char *sn = argv[++i];
+            ps.sampler = !strcmp(sn, "sobol") ? IILE_SAMPLER_SOBOL : (!strcmp(sn, "halton") ? IILE_SAMPLER_HALTON : IILE_SAMPLER_KEEP);
+        } else if (!strcmp(argv[i], "--gpurank") && i + 1 < argc) {
             if (sscanf(argv[++i], "%d/%d", &gpu_rank, &gpu_nranks) != 2 || gpu_nranks < 1 || gpu_rank < 0 || gpu_rank >= gpu_nranks) {
                 fprintf(stderr, "iile_pbrt: --gpurank wants R/N with 0 <= R < N\n");
                 return 1;
@@ -47,10 +50,16 @@ int main(int argc, char **argv) {
             rendezvous = argv[++i];
         else if (argv[i][0] == '-') {
             fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.pfm] [--xres N] [--yres N] [--spp N] "
-                            "[--maxdepth N] [--stats] [--gpurank R/N --rendezvous FILE]\n");
+                            "[--maxdepth N] [--stats] [--sampler halton|sobol] [--gpurank R/N --rendezvous FILE]\n");
             return 1;
         } else
             scene_file = argv[i];
+    }
+    // the fork's sampler override: `path` renders with a SobolSampler of that many samples (src/integrators/path.cpp:202-212)
+    if (const char *ovr = getenv("IILE_PATH_SAMPLES_OVERRIDE")) {
+        ps.sampler = IILE_SAMPLER_SOBOL;
+        ps.pixelsamples = atoi(ovr);
+        fprintf(stderr, "iile_pbrt: Created override sampler with [%d] spp\n", ps.pixelsamples);
     }
     if (scene_file.empty()) {
         fprintf(stderr, "iile_pbrt: no scene file given\n");

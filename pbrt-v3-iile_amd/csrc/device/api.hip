@@ -832,6 +832,28 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         rc = upload(sc, offs.data(), offs.size(), &S.pixel_offsets);
         if (rc) return bail(rc);
     }
+    // SobolSampler in place of the Halton sampler (iile_sobol): matrices [n_dims][32], then vdc[32], vdc_inv[32]
+    S.sobol = 0;
+    if (d->sobol.enabled) {
+        const iile_sobol &sb = d->sobol;
+        if (sb.n_dims < need_dims || sb.n_dims > 256 || !sb.matrices32 || sb.log2_resolution < 1 || sb.log2_resolution > 16 ||
+            sb.resolution != (1 << sb.log2_resolution) || (uint64_t(sb.spp) << (2 * sb.log2_resolution)) > (uint64_t(1) << 32))
+            return bail(fail(IILE_ERR_ARG, "iile_sobol: bad dimension count / resolution, or sample indices beyond 32 bits"));
+        if (sb.resolution < d->film.samp_x1 - d->film.samp_x0 || sb.resolution < d->film.samp_y1 - d->film.samp_y0)
+            return bail(fail(IILE_ERR_ARG, "iile_sobol: resolution smaller than the sample bounds"));
+        std::vector<uint32_t> tab(size_t(sb.n_dims) * 32 + 64);
+        std::memcpy(tab.data(), sb.matrices32, size_t(sb.n_dims) * 32 * sizeof(uint32_t));
+        std::memcpy(tab.data() + size_t(sb.n_dims) * 32, sb.vdc, 32 * sizeof(uint32_t));
+        std::memcpy(tab.data() + size_t(sb.n_dims) * 32 + 32, sb.vdc_inv, 32 * sizeof(uint32_t));
+        rc = upload(sc, tab.data(), tab.size(), &S.sobol_mat);
+        if (rc) return bail(rc);
+        S.sobol_vdc = S.sobol_mat + size_t(sb.n_dims) * 32;
+        S.sobol = 1;
+        S.sobol_log2res = sb.log2_resolution;
+        S.sobol_res = sb.resolution;
+        S.sobol_dims = sb.n_dims;
+        sc->spp = sb.spp;
+    }
     S.n_nodes = d->n_nodes;
     S.n_prims = d->n_prims;
     S.n_spheres = d->n_spheres;
@@ -1641,6 +1663,7 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
     S.mult_inv0 = pr.mult_inverse[0], S.mult_inv1 = pr.mult_inverse[1];
     S.max_depth = pr.max_depth;
     S.sample_center = 0;  // the probes' own sampler: HaltonSampler(1, sampleBounds)
+    S.sobol = 0;
     S.lens_radius = 0;
     S.diff_scale = 1.f;  // ScaleDifferentials(1 / sqrt(1 sample per pixel))
     const int need_dims = 5 + 8 * (pr.max_depth + 1) + 2;
@@ -1811,7 +1834,7 @@ int iile_trace_any(iile_scene *sc, int32_t n, const float *o3, const float *d3, 
 
 int iile_halton_samples(iile_scene *sc, int32_t n, const int32_t *px, const int32_t *py, const int32_t *k,
                         int32_t dim0, int32_t ndims, float *out, uint32_t *index_out) {
-    if (!sc || n < 0 || !px || !py || !k || !out || ndims <= 0 || dim0 < 0 || dim0 + ndims > sc->ds.n_hdims)
+    if (!sc || n < 0 || !px || !py || !k || !out || ndims <= 0 || dim0 < 0 || dim0 + ndims > (sc->ds.sobol ? sc->ds.sobol_dims : sc->ds.n_hdims))
         return fail(IILE_ERR_ARG, "iile_halton_samples: bad argument");
     int rc = ensure_device();
     if (rc) return rc;

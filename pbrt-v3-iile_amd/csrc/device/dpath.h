@@ -126,15 +126,70 @@ DEV void scrambled_radical_inverse_n(const DScene &S, PermPtr perms, int dim0, u
     for (int i = 0; i < N; ++i)
         out[i] = mn(inv_base_n[i] * (float(reversed[i]) + hd[i].perm0_term), kOneMinusEpsilon);
 }
+// ===========================================================================
+// Sobol' sampler (samplers/sobol.cpp:42-59, core/lowdiscrepancy.h:229-274): the sampler the fork's path integrator
+// renders with under IILE_PATH_SAMPLES_OVERRIDE (integrators/path.cpp:202-212). Indices stay below 2^32 (checked on the
+// host), so 32 columns per generator matrix are kept.
+// ===========================================================================
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// column i of the [n_dims][32] matrix table: in HBM, or staged in LDS by the shade kernel in place of the Halton
+// permutations (the same pointer argument carries either)
+DEV uint32_t sobol_column(const DScene &S, const uint16_t *, int i) { return S.sobol_mat[i]; }
+DEV uint32_t sobol_column(const DScene &, lds_u16 *staged, int i) { return ((lds_u32 *)staged)[i]; }
+// SobolIntervalToIndex with m = log2Resolution, p = pixel - sampleBounds.pMin
+DEV uint32_t sobol_index(const DScene &S, int px, int py, uint32_t k) {
+    const int m = S.sobol_log2res, m2 = 2 * m;
+    uint32_t index = k << m2, delta = 0;
+    for (int c = 0; c < 32 - m2; ++c)
+        if ((k >> c) & 1u) delta ^= S.sobol_vdc[c];  // Add flipped column m + c + 1.
+    const uint32_t b = ((uint32_t(px - S.samp_x0) << m) | uint32_t(py - S.samp_y0)) ^ delta;  // flipped b
+    for (int c = 0; c < m2; ++c)
+        if ((b >> c) & 1u) index ^= S.sobol_vdc[32 + c];  // Add column 2 * m - c.
+    return index;
+}
+// SobolSampleFloat (scramble 0) followed by SobolSampler::SampleDimension's remapping of the two pixel dimensions
 template <typename PermPtr>
-DEV float sample_dimension(const DScene &S, PermPtr perms, uint32_t index, int dim) {
+DEV float sobol_sample_dimension(const DScene &S, PermPtr mats, uint32_t index, int dim, int px, int py) {
+    uint32_t v = 0;
+    for (int i = 0; i < 32 && (index >> i) != 0; ++i)
+        if ((index >> i) & 1u) v ^= sobol_column(S, mats, dim * 32 + i);
+    float s = mn(float(v) * 0x1p-32f /* 1/2^32 */, kOneMinusEpsilon);
+    if (dim == 0 || dim == 1) {  // s * resolution + sampleBounds.pMin[dim], then Clamp(s - currentPixel[dim], 0, OneMinusEpsilon)
+        const int pmin = dim == 0 ? S.samp_x0 : S.samp_y0, cur = dim == 0 ? px : py;
+        s = s * float(S.sobol_res) + float(pmin);
+        s = s - float(cur);
+        s = s < 0.f ? 0.f : (s > kOneMinusEpsilon ? kOneMinusEpsilon : s);
+    }
+    return s;
+}
+
+// The scene's sampler: GetIndexForSample / SampleDimension of HaltonSampler or SobolSampler. (px, py) is the sample's
+// pixel — only SobolSampler's dimensions 0 and 1 depend on it.
+DEV uint32_t sample_index(const DScene &S, int px, int py, uint32_t k) {
+    return S.sobol ? sobol_index(S, px, py, k) : halton_index(S, px, py, k);
+}
+template <typename PermPtr>
+DEV float sample_dimension(const DScene &S, PermPtr perms, uint32_t index, int dim, int px = 0, int py = 0) {
+    if (S.sobol) return sobol_sample_dimension(S, perms, index, dim, px, py);
     if (S.sample_center && dim < 2) return 0.5f;  // "samplepixelcenter", halton.cpp:119
     if (dim == 0) return radical_inverse_base2(index >> S.base_exp0);
     if (dim == 1) return radical_inverse_base3(index / uint32_t(S.base_scale1));
     return scrambled_radical_inverse(S, perms, dim, index);
 }
-DEV float sample_dimension(const DScene &S, uint32_t index, int dim) {
-    return sample_dimension(S, S.perms, index, dim);
+DEV float sample_dimension(const DScene &S, uint32_t index, int dim, int px = 0, int py = 0) {
+    return sample_dimension(S, S.perms, index, dim, px, py);
+}
+// N consecutive dimensions >= 2 of one sample (the shade kernel's batches)
+template <int N, typename PermPtr>
+DEV void sample_dimensions_n(const DScene &S, PermPtr perms, int dim0, bool dim_uniform, int dim_lane, uint32_t index, float *out) {
+    if (S.sobol) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[i] = sobol_sample_dimension(S, perms, index, dim_lane + i, 0, 0);
+    } else if (dim_uniform) {
+        scrambled_radical_inverse_n<N>(S, perms, dim0, index, out);
+    } else {
+        for (int i = 0; i < N; ++i) out[i] = sample_dimension(S, perms, index, dim_lane + i);
+    }
 }
 
 // ===========================================================================

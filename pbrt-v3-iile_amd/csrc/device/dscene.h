@@ -136,6 +136,10 @@ struct DScene {
     // halton
     int base_scale0, base_scale1, base_exp0, base_exp1, sample_stride, mult_inv0, mult_inv1;
     int sample_center;  // dimensions 0 and 1 of every sample are 0.5
+    // sobol (iile_sobol): the frame's sampler is SobolSampler — generator matrices [n_dims][32], then vdc[32], vdc_inv[32]
+    int sobol, sobol_log2res, sobol_res, sobol_dims;
+    const uint32_t *sobol_mat;
+    const uint32_t *sobol_vdc;
     // integrator
     int max_depth;
     float rr_threshold;

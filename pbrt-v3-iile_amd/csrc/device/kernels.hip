@@ -246,8 +246,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene S, PassDesc P, PassB
         float tmax = 0;
         if (valid) {
             // Sampler::GetCameraSample (sampler.cpp:46-52): dims 0,1 film, 2 time, 3,4 lens
-            const uint32_t idx = halton_index(S, px, py, k);
-            const float u0 = sample_dimension(S, idx, 0), u1 = sample_dimension(S, idx, 1);
+            const uint32_t idx = sample_index(S, px, py, k);
+            const float u0 = sample_dimension(S, idx, 0, px, py), u1 = sample_dimension(S, idx, 1, px, py);
             float l0 = 0, l1 = 0;
             if (S.lens_radius > 0) {
                 l0 = sample_dimension(S, idx, 3);
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                     int px = 0, py = 0;
                     uint32_t k = 0;
                     if (path_pixel(S, P, slot, &px, &py, &k)) {  // queue 0 is dense: slot == path id
-                        const uint32_t idx = halton_index(S, px, py, k);
-                        const float u0 = sample_dimension(S, idx, 0), u1 = sample_dimension(S, idx, 1);
+                        const uint32_t idx = sample_index(S, px, py, k);
+                        const float u0 = sample_dimension(S, idx, 0, px, py), u1 = sample_dimension(S, idx, 1, px, py);
                         float l0 = 0, l1 = 0;
                         if (S.lens_radius > 0) {
                             l0 = sample_dimension(S, idx, 3);
@@ -548,8 +548,13 @@ DEV int sample_light(const DScene &S, F3 p, float u, float *pdf) {
 template <bool COUNT, bool EXT, bool TEX>
 __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
     // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
+    // (or, for SobolSampler, its generator matrices: sobol_column)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
-    for (int i = threadIdx.x; i < S.n_perms; i += kBlock) s_perms_raw[i] = S.perms[i];
+    if (S.sobol) {
+        for (int i = threadIdx.x; i < S.sobol_dims * 32; i += kBlock) reinterpret_cast<uint32_t *>(s_perms_raw)[i] = S.sobol_mat[i];
+    } else {
+        for (int i = threadIdx.x; i < S.n_perms; i += kBlock) s_perms_raw[i] = S.perms[i];
+    }
     __syncthreads();
     lds_u16 *const s_perms = (lds_u16 *)s_perms_raw;
     const uint32_t count = B.counts[kCntShade + bounce];
@@ -650,11 +655,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                 float u_nee[4] = {0, 0, 0, 0};
                 if (bounce < S.max_depth) {
                     const int dim_u = __builtin_amdgcn_readfirstlane(dim);
-                    if (__ballot(dim != dim_u) == 0) {
-                        scrambled_radical_inverse_n<4>(S, s_perms, dim_u + 1, hidx, u_nee);
-                    } else {
-                        for (int i = 0; i < 4; ++i) u_nee[i] = sample_dimension(S, s_perms, hidx, dim + 1 + i);
-                    }
+                    sample_dimensions_n<4>(S, s_perms, dim_u + 1, __ballot(dim != dim_u) == 0, dim + 1, hidx, u_nee);
                 }
                 const int prim = int(f2b(h4.x));
                 const F3 ray_o = F3{o4.x, o4.y, o4.z};
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                                 int px = 0, py = 0;
                                 uint32_t kk = 0;
                                 path_pixel(S, P, pid, &px, &py, &kk);
-                                const float u0 = sample_dimension(S, s_perms, hidx, 0), u1 = sample_dimension(S, s_perms, hidx, 1);
+                                const float u0 = sample_dimension(S, s_perms, hidx, 0, px, py), u1 = sample_dimension(S, s_perms, hidx, 1, px, py);
                                 float l0 = 0, l1 = 0;
                                 if (S.lens_radius > 0) {
                                     l0 = sample_dimension(S, s_perms, hidx, 3);
@@ -906,12 +907,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
             float u_bsdf[2];
             {
                 const int dim_u = __builtin_amdgcn_readfirstlane(dim);
-                if (__ballot(dim != dim_u) == 0) {
-                    scrambled_radical_inverse_n<2>(S, s_perms, dim_u, hidx, u_bsdf);
-                } else {
-                    u_bsdf[0] = sample_dimension(S, s_perms, hidx, dim);
-                    u_bsdf[1] = sample_dimension(S, s_perms, hidx, dim + 1);
-                }
+                sample_dimensions_n<2>(S, s_perms, dim_u, __ballot(dim != dim_u) == 0, dim, hidx, u_bsdf);
             }
             const float u0 = u_bsdf[0], u1 = u_bsdf[1];
             dim += 2;
@@ -1296,8 +1292,8 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate(DScene S, PassDesc P
                     // left / upper neighbour (support ceil(pd-.5) .. floor(pd+.5))
                     const uint32_t idx = B.hindex[pid0 + kk];
                     uint32_t mask = 0;
-                    if (sample_dimension(S, idx, 0) == 0.f) mask |= 1u;
-                    if (sample_dimension(S, idx, 1) == 0.f) mask |= 2u;
+                    if (sample_dimension(S, idx, 0, px, py) == 0.f) mask |= 1u;
+                    if (sample_dimension(S, idx, 1, px, py) == 0.f) mask |= 2u;
                     F.k0_rgbv[pt] = make_float4(L.x, L.y, L.z, b2f(mask));
                 }
             }
@@ -1323,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void k_film_store(DScene S, PassDesc P, Pas
         const uint32_t pt = uint32_t(P.slot0) * 256u + pid / uint32_t(P.kc);
         const size_t at = (size_t(pt >> 8) * size_t(n_samples) + size_t(int(k) - k_begin)) * 256u + size_t(pt & 255u);
         F.wide_L[at] = make_float4(L.x, L.y, L.z, 0.f);
-        F.wide_pf[at] = make_float2(float(px) + sample_dimension(S, idx, 0), float(py) + sample_dimension(S, idx, 1));
+        F.wide_pf[at] = make_float2(float(px) + sample_dimension(S, idx, 0, px, py), float(py) + sample_dimension(S, idx, 1, px, py));
     }
 }
 
@@ -1574,9 +1570,9 @@ __global__ void k_halton(DScene S, int n, const int *px, const int *py, const in
                          uint32_t *index_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t idx = halton_index(S, px[i], py[i], uint32_t(k[i]));
+    const uint32_t idx = sample_index(S, px[i], py[i], uint32_t(k[i]));
     if (index_out) index_out[i] = idx;
-    for (int d = 0; d < ndims; ++d) out[size_t(i) * ndims + d] = sample_dimension(S, idx, dim0 + d);
+    for (int d = 0; d < ndims; ++d) out[size_t(i) * ndims + d] = sample_dimension(S, idx, dim0 + d, px[i], py[i]);
 }
 __global__ void k_camera(DScene S, int n, const float *pfilm, const float *plens, float *o, float *d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1676,7 +1672,7 @@ void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int 
 #define IILE_SHADE_BLOCKS 3  // = resident blocks per CU at 3 waves/SIMD: the static split has no tail
 #endif
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, IILE_SHADE_BLOCKS));
-    const size_t perm_bytes = (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
+    const size_t perm_bytes = S.sobol ? size_t(S.sobol_dims) * 32 * sizeof(uint32_t) : (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
     if (cfg.count_stats)
         hipLaunchKernelGGL((k_shade<true, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
     else

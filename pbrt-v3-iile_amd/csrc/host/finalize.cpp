@@ -1,5 +1,7 @@
 // finalize.cpp — camera matrices, film bounds, Halton tables and the flattened
 // iile_scene_desc. Citations are relative to /root/reference/src.
+#include <cstdio>
+
 #include "host_scene.h"
 
 namespace iile {
@@ -89,6 +91,13 @@ bool finalize_scene(HostScene *s, std::string *err) {
     }
     build_bvh(s);
     build_halton_tables(s);
+    if (s->sampler_name == "sobol") {
+        // GlobalSampler(RoundUpPow2(samplesPerPixel)), samplers/sobol.h:59-64 — before anything reads the sample count
+        int64_t r = 1;
+        while (r < s->spp) r <<= 1;
+        if (r != s->spp) fprintf(stderr, "Warning: Non power-of-two sample count rounded up to %lld for SobolSampler.\n", (long long)r);
+        s->spp = int(r);
+    }
 
     iile_scene_desc &d = s->desc;
     std::memset(&d, 0, sizeof(d));
@@ -263,6 +272,38 @@ bool finalize_scene(HostScene *s, std::string *err) {
     h.prime_sums = s->prime_sums.data();
     h.n_perms = int(s->perms.size());
     h.sample_at_pixel_center = s->sample_at_pixel_center ? 1 : 0;
+
+    // SobolSampler ctor, samplers/sobol.h:57-75
+    iile_sobol &sb = d.sobol;
+    std::memset(&sb, 0, sizeof(sb));
+    if (s->sampler_name == "sobol") {
+        auto round_up_pow2 = [](int64_t v) {  // pbrt.h:348-357
+            int64_t r = 1;
+            while (r < v) r <<= 1;
+            return r;
+        };
+        sb.enabled = 1;
+        sb.spp = int(round_up_pow2(s->spp));  // (set before the Halton state above was filled: see finalize_scene)
+        sb.resolution = int(round_up_pow2(std::max(res[0], res[1])));
+        int lg = 0;
+        while ((1 << lg) < sb.resolution) ++lg;
+        sb.log2_resolution = lg;
+        if (lg < 1 || lg > 16 || (uint64_t(sb.spp) << (2 * lg)) > (uint64_t(1) << 32)) {
+            *err = "Sampler \"sobol\": pixelsamples x resolution^2 exceeds the 32-bit sample index of the GPU path";
+            return false;
+        }
+        sb.n_dims = std::min(sobol_num_dimensions(), 128);
+        s->sobol_matrices.resize(size_t(sb.n_dims) * 32);
+        for (int dim = 0; dim < sb.n_dims; ++dim) {
+            uint32_t cols[52];
+            sobol_columns32(dim, cols);
+            std::memcpy(&s->sobol_matrices[size_t(dim) * 32], cols, 32 * sizeof(uint32_t));
+        }
+        sb.matrices32 = s->sobol_matrices.data();
+        uint64_t vdc[52], inv[52];
+        sobol_vdc(lg, vdc, inv);
+        for (int c = 0; c < 32; ++c) sb.vdc[c] = uint32_t(vdc[c]), sb.vdc_inv[c] = uint32_t(inv[c]);
+    }
 
     d.integrator.max_depth = s->max_depth;
     d.integrator.rr_threshold = s->rr_threshold;

@@ -31,12 +31,13 @@ namespace iile {
 struct ParamSet {  // the two knobs CreatePathIntegrator reads; <= 0 keeps the scene file's value
     int maxdepth = 0;
     int xresolution = 0, yresolution = 0, pixelsamples = 0;
+    int sampler = IILE_SAMPLER_KEEP;  // IILE_SAMPLER_SOBOL: the fork's IILE_PATH_SAMPLES_OVERRIDE (path.cpp:202-212)
 };
 
 class Scene {
   public:
     explicit Scene(const std::string &pbrt_file, const ParamSet &ps = ParamSet()) {
-        iile_host_overrides ov = {ps.xresolution, ps.yresolution, ps.pixelsamples, ps.maxdepth};
+        iile_host_overrides ov = {ps.xresolution, ps.yresolution, ps.pixelsamples, ps.maxdepth, ps.sampler};
         if (iile_host_load_pbrt(pbrt_file.c_str(), &ov, &host_) != 0) {
             fprintf(stderr, "Error: %s\n", iile_host_last_error());
             host_ = nullptr;

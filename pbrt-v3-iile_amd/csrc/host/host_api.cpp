@@ -37,6 +37,8 @@ int iile_host_load_pbrt(const char *path, const iile_host_overrides *ov, iile_ho
             if (ov->yres > 0) hs->s.yres = ov->yres;
             if (ov->spp > 0) hs->s.spp = ov->spp;
             if (ov->max_depth > 0) hs->s.max_depth = ov->max_depth;
+            if (ov->sampler == IILE_SAMPLER_HALTON) hs->s.sampler_name = "halton";
+            if (ov->sampler == IILE_SAMPLER_SOBOL) hs->s.sampler_name = "sobol", hs->s.sample_at_pixel_center = false;
         }
         if (!iile::finalize_scene(&hs->s, &err)) {
             g_err = err;
@@ -84,6 +86,25 @@ int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info 
 }
 
 void iile_host_scene_free(iile_host_scene *scene) { delete scene; }
+
+int iile_host_sobol_matrices(int32_t n_dims, uint32_t *m32, uint64_t *m64) {
+    if (n_dims < 0 || n_dims > iile::sobol_num_dimensions()) {
+        g_err = "iile_host_sobol_matrices: dimension count out of range";
+        return 1;
+    }
+    for (int d = 0; d < n_dims; ++d) {
+        if (m32) iile::sobol_columns32(d, m32 + 52 * size_t(d));
+        if (m64) iile::sobol_columns64(d, reinterpret_cast<uint64_t *>(m64) + 52 * size_t(d));
+    }
+    return 0;
+}
+int iile_host_sobol_vdc(int32_t log2_resolution, uint64_t *vdc52, uint64_t *vdc_inv52) {
+    if (!vdc52 || !vdc_inv52 || !iile::sobol_vdc(log2_resolution, reinterpret_cast<uint64_t *>(vdc52), reinterpret_cast<uint64_t *>(vdc_inv52))) {
+        g_err = "iile_host_sobol_vdc: log2_resolution must lie in 1 .. 16";
+        return 1;
+    }
+    return 0;
+}
 
 // Film::to_rgb_array, /root/reference/src/core/film.cpp:187-225, with the
 // XYZ->RGB matrix of src/core/spectrum.h:56-60. No splats on this path.

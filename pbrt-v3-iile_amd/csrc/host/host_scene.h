@@ -71,6 +71,7 @@ struct HostScene {
     std::vector<int32_t> o_alpha;
     std::vector<uint16_t> perms;
     std::vector<int32_t> primes, prime_sums;
+    std::vector<uint32_t> sobol_matrices;  // [n_dims][32] when the sampler is "sobol"
     std::vector<float> env_dist;  // Distribution2D tables of the infinite lights
     std::vector<iile_texture> o_textures;
     std::vector<float> o_texels;
@@ -89,6 +90,12 @@ void loop_subdivide(int n_levels, const std::vector<int> &indices, const std::ve
 void build_bvh(HostScene *scene);
 // halton_tables.cpp
 void build_halton_tables(HostScene *scene);
+
+// sobol.cpp
+int sobol_num_dimensions();
+bool sobol_columns64(int dim, uint64_t cols[52]);
+bool sobol_columns32(int dim, uint32_t cols[52]);
+bool sobol_vdc(int log2_resolution, uint64_t vdc[52], uint64_t inv[52]);
 
 // plymesh.cpp
 bool load_ply(const std::string &path, std::vector<V3> *P, std::vector<V3> *N, std::vector<float> *uv,

@@ -444,11 +444,11 @@ class Loader {
             s.film_diagonal = ps.one_float("diagonal", 35.);
             s.max_sample_luminance =
                 ps.one_float("maxsampleluminance", std::numeric_limits<float>::infinity());
-        } else if (d == "Sampler") {  // samplers/halton.cpp:129-135
-            if (name != "halton") return fail("only Sampler \"halton\" is supported, got " + name);
+        } else if (d == "Sampler") {  // samplers/halton.cpp:129-135, samplers/sobol.cpp:65-71
+            if (name != "halton" && name != "sobol") return fail("only Sampler \"halton\" and \"sobol\" are supported, got " + name);
             s.sampler_name = name;
             s.spp = ps.one_int("pixelsamples", 16);
-            s.sample_at_pixel_center = ps.one_bool("samplepixelcenter", false);
+            s.sample_at_pixel_center = name == "halton" && ps.one_bool("samplepixelcenter", false);
         } else if (d == "PixelFilter") {  // MakeFilter, api.cpp:855-874; Create*Filter in src/filters/*.cpp
             s.filter_name = name;
             if (name == "box") {

@@ -63,6 +63,23 @@ class Oracle:
         lib.oracle_halton_index.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64]
         lib.oracle_halton_sample.restype = ctypes.c_float
         lib.oracle_halton_sample.argtypes = [c_vp, ctypes.c_int64, ctypes.c_int]
+        lib.oracle_sample_index.restype = ctypes.c_int64
+        lib.oracle_sample_index.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64]
+        lib.oracle_sample_dimension.restype = ctypes.c_float
+        lib.oracle_sample_dimension.argtypes = [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.oracle_reverse_bits32.restype = ctypes.c_uint32
+        lib.oracle_reverse_bits32.argtypes = [ctypes.c_uint32]
+        lib.oracle_multiply_generator.restype = ctypes.c_uint32
+        lib.oracle_multiply_generator.argtypes = [c_vp, ctypes.c_uint32]
+        lib.oracle_sample_generator_matrix.restype = ctypes.c_float
+        lib.oracle_sample_generator_matrix.argtypes = [c_vp, ctypes.c_uint32, ctypes.c_uint32]
+        lib.oracle_gray_code_sample.argtypes = [c_vp, ctypes.c_uint32, ctypes.c_uint32, c_vp]
+        lib.oracle_sobol_sample_float.restype = ctypes.c_float
+        lib.oracle_sobol_sample_float.argtypes = [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32]
+        lib.oracle_sobol_sample_double.restype = ctypes.c_double
+        lib.oracle_sobol_sample_double.argtypes = [c_vp, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64]
+        lib.oracle_sobol_interval_to_index.restype = ctypes.c_uint64
+        lib.oracle_sobol_interval_to_index.argtypes = [c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
         lib.oracle_radical_inverse.restype = ctypes.c_float
         lib.oracle_radical_inverse.argtypes = [ctypes.c_int, ctypes.c_uint64]
         lib.oracle_scrambled_radical_inverse.restype = ctypes.c_float
@@ -92,6 +109,12 @@ class Oracle:
 
     def tile_owner(self, tx, ty, nranks):
         return int(self.lib.oracle_tile_owner(int(tx), int(ty), int(nranks)))
+
+    def sample_index(self, scene, px, py, k):
+        return int(self.lib.oracle_sample_index(scene.desc, int(px), int(py), int(k)))
+
+    def sample_dimension(self, scene, index, dim, px, py):
+        return np.float32(self.lib.oracle_sample_dimension(scene.desc, int(index), int(dim), int(px), int(py)))
 
     def halton_index(self, scene, px, py, k):
         return int(self.lib.oracle_halton_index(scene.desc, int(px), int(py), int(k)))
