@@ -138,6 +138,20 @@ int iile_bsdf_sample(iile_scene *scene, int32_t n, int32_t mat, const float *wo3
  * HBM for the network); pos3 / dir3 are host memory either way. */
 int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, const float *dir3, float *intensity_rgb,
                        float *normals_xyz, float *distance, int32_t outputs_on_device, iile_stats *stats);
+/* The IISPT render runner around the probe pass and the network (src/integrators/iisptrenderrunner.cpp:216-596),
+ * one task (iile_iispt_task, iile_scene.h) at a time:
+ *   iile_iispt_hemi_points  for every hemi point of the task (row by row): whether it has a probe (find_intersection found
+ *                           a surface that scatters, :632-757) and the aux ray its HemisphericCamera is placed on
+ *                           (:299-312) — feed pos3 / dir3 of the valid ones to iile_render_probes, the images to the network;
+ *   iile_iispt_gather       the per-pixel loop (:414-596): compute_fpixel_weights (:961-1039) and sample_hemisphere
+ *                           (:142-178) over the four neighbouring predicted hemispheres. nn_films: per hemi point (valid or
+ *                           not) hemi x hemi RGB, row 0 the top scanline as the network emits it (device memory when
+ *                           nn_on_device); out_rgbw: per film pixel of the task, row-major, {f_beta * L, weight} as handed
+ *                           to IisptFilmMonitor::add_n_samples (zeros where the runner records nothing).
+ * Needs the scene's Halton sampler (the runner clones the scene's sampler) and probe setup. */
+int iile_iispt_hemi_points(iile_scene *scene, const iile_iispt_task *task, uint8_t *valid, float *pos3, float *dir3);
+int iile_iispt_gather(iile_scene *scene, const iile_iispt_task *task, const uint8_t *valid, const float *pos3, const float *dir3,
+                      const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device);
 /* ImageTexture<RGBSpectrum, Spectrum>::Evaluate (src/textures/imagemap.h:87-94) of image texture `tex` at n
  * surface points given by (u, v) and the screen-space differentials {du/dx, dv/dx, du/dy, dv/dy}. */
 int iile_texture_eval(iile_scene *scene, int32_t tex, int32_t n, const float *uv2, const float *duv4, float *rgb3);

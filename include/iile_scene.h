@@ -23,6 +23,13 @@
 extern "C" {
 #endif
 
+/* the few inline helpers of this header are also called from the HIP kernels */
+#if defined(__HIPCC__)
+#define IILE_INLINE static inline __host__ __device__
+#else
+#define IILE_INLINE static inline
+#endif
+
 /* Mirrors LinearBVHNode, src/accelerators/bvh.cpp:95-104 (32 bytes). */
 typedef struct iile_bvh_node {
     float bmin[3];
@@ -258,12 +265,43 @@ typedef struct iile_scene_desc {
     iile_sobol sobol;
 } iile_scene_desc;
 
+/* One task of the IISPT render runner (IisptScheduleMonitorTask, src/integrators/iisptschedulemonitor.cpp:40-79): the
+ * film pixels [x0, x1) x [y0, y1) with hemi points every `tilesize` pixels, at x0, x0 + tilesize, ... and at x1 - 1
+ * (likewise in y), visited row by row (src/integrators/iisptrenderrunner.cpp:248-260, 387-412). */
+typedef struct iile_iispt_task {
+    int32_t x0, y0, x1, y1;
+    int32_t tilesize;
+    uint32_t counter_base; /* IisptRenderRunner::sampler_pixel_counter.x before the task (iisptrenderrunner.cpp:941-953):
+                              the task's i-th camera sample (hemi points first, then film pixels row-major) is taken with
+                              the sampler on pixel (counter_base + 1 + i, 0) */
+    uint64_t rng_seed;     /* film pixel j of the task (row-major) draws from pbrt's RNG(rng_seed + j); the reference uses one
+                              RNG per thread, consumed in scheduling order — not reproducible, nor needed, in parallel */
+} iile_iispt_task;
+/* number of hemi points of a task along one axis of extent [a0, a1) */
+IILE_INLINE int32_t iile_iispt_grid_count(int32_t a0, int32_t a1, int32_t tilesize) {
+    int32_t n = 1, t = a0;
+    if (a1 <= a0 || tilesize < 1) return 0;
+    while (t != a1 - 1) {
+        t = t + tilesize < a1 - 1 ? t + tilesize : a1 - 1;
+        ++n;
+    }
+    return n;
+}
+/* position of hemi point i along that axis, and the index of the hemi point at position t */
+IILE_INLINE int32_t iile_iispt_grid_pos(int32_t a0, int32_t a1, int32_t tilesize, int32_t i) {
+    const int32_t t = a0 + i * tilesize;
+    return t < a1 - 1 ? t : a1 - 1;
+}
+IILE_INLINE int32_t iile_iispt_grid_index(int32_t a0, int32_t a1, int32_t tilesize, int32_t t) {
+    return t == a1 - 1 ? iile_iispt_grid_count(a0, a1, tilesize) - 1 : (t - a0) / tilesize;
+}
+
 /* Which rank of an n-rank job renders the 16x16 tile (tx, ty) of SamplerIntegrator::Render's tile grid
  * (src/core/integrator.cpp:235-248: tiles are independent units of work). Diagonal interleave: every run of n
  * consecutive tiles of a tile row OR column holds one tile of each rank, for any n (an interleave of the linear
  * tile index would collapse to vertical stripes whenever the tiles per row are a multiple of n: 1080p has 120).
  * The map is part of the boundary: libiile_gpu.so, the C++ host and the test oracle all use this one definition. */
-static inline int32_t iile_tile_owner(int32_t tx, int32_t ty, int32_t nranks) {
+IILE_INLINE int32_t iile_tile_owner(int32_t tx, int32_t ty, int32_t nranks) {
     return nranks <= 1 ? 0 : (int32_t)(((uint32_t)tx + (uint32_t)ty) % (uint32_t)nranks);
 }
 

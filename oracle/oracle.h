@@ -139,6 +139,12 @@ int64_t oracle_check_efloat(int iters, uint64_t seed);
 int64_t oracle_check_reintersect(const iile_scene_desc *scene, int n, const float *o, const float *d, int n_out,
                                  uint64_t seed, int64_t *stats);
 
+/* The IISPT render runner's gather (src/integrators/iisptrenderrunner.cpp:248-596): the hemi points of a task
+ * (valid flag, aux ray origin and direction: where the probe cameras go), and the per-pixel loop over the predicted
+ * hemispheres nn_films [hemi point][hemi][hemi][3] -> {f_beta * L, weight} per film pixel of the task. */
+int oracle_iispt_hemi_points(const iile_scene_desc *scene, int trig_mode, const iile_iispt_task *task, uint8_t *valid, float *pos3, float *dir3);
+int oracle_iispt_gather(const iile_scene_desc *scene, int trig_mode, const iile_iispt_task *task, const uint8_t *valid, const float *pos3,
+                        const float *dir3, const float *nn_films, float *out_rgbw);
 /* iile_tile_owner of iile_scene.h (a static inline there), exported so that tests can call the header's own definition */
 int oracle_tile_owner(int tx, int ty, int nranks);
 

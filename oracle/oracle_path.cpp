@@ -865,7 +865,7 @@ struct Oracle {
     // camera (cameras/perspective.cpp:100-149; transform.h:251-264)
     // with `rd`: GenerateRayDifferential (perspective.cpp:100-149) followed by the render loop's
     // ScaleDifferentials(1 / sqrt(spp)) (integrator.cpp:284-285, geometry.h:908-913)
-    Ray camera_ray(float pfx, float pfy, const float *plens, RayDiff *rd = nullptr) const {
+    Ray camera_ray(float pfx, float pfy, const float *plens, RayDiff *rd = nullptr, bool unit_diff_scale = false) const {
         const iile_camera &c = S.camera;
         V3 pcam = xf_point(M4{c.raster_to_camera}, V3(pfx, pfy, 0));
         V3 dir = normalize(V3(pcam.x, pcam.y, pcam.z));
@@ -920,7 +920,9 @@ struct Oracle {
             ryo = xf_point(m, ryo);
             rxd = xf_vector(m, rxd);
             ryd = xf_vector(m, ryd);
-            const float sc = 1 / std::sqrt(float(S.halton.spp));
+            // ScaleDifferentials(1 / sqrt(samplesPerPixel)) in the render loop (integrator.cpp:284-285); the IISPT runner
+            // scales by 1.0 (iisptrenderrunner.cpp:272)
+            const float sc = unit_diff_scale ? 1.f : 1 / std::sqrt(float(S.halton.spp));
             rd->has = true;
             rd->rxo = o + (rxo - o) * sc;
             rd->ryo = o + (ryo - o) * sc;
@@ -2542,6 +2544,258 @@ struct Oracle {
             L = Rgb(0.f);
         return L;
     }
+
+    // ========================================================================
+    // The IISPT render runner's gather (second half): what IisptRenderRunner::run does with the predicted
+    // hemispheres (integrators/iisptrenderrunner.cpp:414-596). The random numbers: the reference draws them from one
+    // PCG32 per thread (IisptRng(thread_no)) in whatever order its tasks are scheduled; here every film pixel of a task
+    // has its own stream RNG(rng_seed + pixel rank), and the camera samples come from the runner's "one sampler pixel per
+    // call" counter (sampler_next_pixel, :941-953) in the single-thread order: hemi points row by row, then film pixels.
+    // ========================================================================
+    struct Pcg {  // core/rng.h:62-156
+        uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+        explicit Pcg(uint64_t seq) {  // RNG(sequenceIndex) -> SetSequence
+            state = 0u;
+            inc = (seq << 1u) | 1u;
+            uniform_u32();
+            state += 0x853c49e6748fea9bULL;
+            uniform_u32();
+        }
+        uint32_t uniform_u32() {
+            uint64_t oldstate = state;
+            state = oldstate * 0x5851f42d4c957f2dULL + inc;
+            uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+            uint32_t rot = (uint32_t)(oldstate >> 59u);
+            return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+        }
+        uint32_t uniform_u32(uint32_t b) {
+            uint32_t threshold = (~b + 1u) % b;
+            while (true) {
+                uint32_t r = uniform_u32();
+                if (r >= threshold) return r % b;
+            }
+        }
+        float uniform_float() { return std::min(OneMinusEpsilon, float(uniform_u32() * 0x1p-32f)); }
+    };
+    // a hemi point's camera as the gather sees it (HemisphericCamera: hemispheric.h:23-82, hemispheric.cpp:109-160)
+    struct HemiCam {
+        bool valid = false;
+        float c2w[16], w2c[16];  // CameraToWorld's matrix; WorldToCamera's matrix (its numerical inverse)
+        V3 origin, look;
+        const float *nn;         // the predicted intensity image, hemi x hemi x 3, row 0 = top scanline (ImageFilm order)
+    };
+    static bool make_hemi_cam(const float pos[3], const float dir[3], const float *nn, HemiCam *hc) {
+        ProbeCam pc;
+        if (!make_probe_camera(pos, dir, 0, &pc)) return false;
+        std::memcpy(hc->c2w, pc.c2w, sizeof(pc.c2w));
+        if (!invert4(pc.c2w, hc->w2c)) return false;
+        hc->origin = V3(pos[0], pos[1], pos[2]);
+        hc->look = V3(dir[0], dir[1], dir[2]);
+        hc->nn = nn;
+        hc->valid = true;
+        return true;
+    }
+    // sampler_next_pixel + GetCameraSample + GenerateRayDifferential for the counter-th call (counter >= 1): the
+    // sampler sits on pixel (counter, 0), sample 0; the camera sample is `pixel` + its first two dimensions
+    Ray iispt_camera_ray(int fx, int fy, uint32_t counter, Sampler *smp_out, RayDiff *rd) const {
+        Sampler smp{this, sample_index(int(counter), 0, 0), 0, int(counter), 0};
+        float u[2];
+        smp.get2d(u);
+        const float pfx = float(fx) + u[0], pfy = float(fy) + u[1];
+        smp.get1d();  // time
+        float plens[2];
+        smp.get2d(plens);
+        RayDiff rdiff;
+        Ray ray = camera_ray(pfx, pfy, plens, S.n_textures > 0 ? &rdiff : nullptr, true);  // r.ScaleDifferentials(1.0)
+        *smp_out = smp;
+        *rd = rdiff;
+        return ray;
+    }
+    // IisptRenderRunner::find_intersection, iisptrenderrunner.cpp:632-757 (without the emitted / background outputs,
+    // which belong to the direct pass)
+    bool iispt_find_intersection(Ray ray, RayDiff rdiff, Sampler &smp, Isect *is_out, Ray *ray_out, Rgb *beta_out) const {
+        Rgb beta(1.f);
+        for (int bounces = 0; bounces < 24; ++bounces) {
+            Isect is;
+            if (!intersect(ray, &is)) return false;
+            if (S.prim_material[is.prim] < 0) {  // `if (!isect.bsdf)`: skip this intersection
+                ray = spawn_ray(is, ray.d);
+                rdiff.has = false;
+                continue;
+            }
+            if (S.n_textures > 0) compute_differentials(&is, rdiff);
+            rdiff.has = false;
+            {
+                const iile_material &mb = S.materials[S.prim_material[is.prim]];
+                if (S.n_textures > 0 && mb.bump_tex >= 0) bump(mb.bump_tex, &is);
+            }
+            Bsdf bsdf = make_bsdf(is);
+            const V3 wo = -ray.d;
+            V3 wi;
+            float pdf = 0, u[2];
+            smp.get2d(u);
+            bool spec = false, trans = false;
+            Rgb f = bsdf_sample_f(bsdf, wo, &wi, u, &pdf, true, &spec, &trans);
+            if (f.is_black() || pdf == 0.f) {
+                *beta_out = Rgb(0.f);
+                return true;
+            }
+            if (!spec) {  // the current bounce is not specular: IISPT proceeds from here
+                *is_out = is;
+                *ray_out = ray;
+                *beta_out = beta;
+                return true;
+            }
+            beta = beta * (f * absdot(wi, is.sn) / pdf);
+            if (beta.y() < 0.f || std::isnan(beta.y())) {
+                *beta_out = Rgb(0.f);
+                return true;
+            }
+            ray = spawn_ray(is, wi);
+        }
+        *beta_out = Rgb(0.f);
+        return true;
+    }
+    // the aux ray of a first hit: `isect.SpawnRay(Vector3f(surface_normal))` with the normal turned against the ray
+    // (iisptrenderrunner.cpp:299-312 and :969-980)
+    static Ray iispt_aux_ray(const Isect &is, const Ray &ray) {
+        V3 n = is.n;
+        if (dot(is.n, ray.d) > 0.0) n = -is.n;
+        return spawn_ray(is, n);
+    }
+    // HemisphericCamera::get_light_sample_nn (hemispheric.cpp:89-105) / getLightSampleNn (:44-60) over
+    // IntensityFilm::get_camera_coord_jacobian (film/intensityfilm.cpp:60-66); `jac` = sin(pi * y / hemi), y < hemi
+    Rgb iispt_nn_pixel(const HemiCam &hc, int x, int y, int hemi, const float *jac) const {
+        const float *px = hc.nn + 3 * (size_t(hemi - 1 - y) * hemi + x);  // film->get(x, height - 1 - y)
+        return Rgb(px[0] * jac[y], px[1] * jac[y], px[2] * jac[y]);
+    }
+    Rgb iispt_light_sample_xy(const HemiCam &hc, int x, int y, int hemi, const float *jac, V3 *wi) const {
+        float theta = Pi * y / hemi;
+        float phi = Pi * x / hemi;
+        V3 dir(trig.sin_f(theta) * trig.cos_f(phi), trig.cos_f(theta), trig.sin_f(theta) * trig.sin_f(phi));
+        *wi = xf_vector(M4{hc.c2w}, dir);  // CameraToWorld(ray).d
+        return iispt_nn_pixel(hc, x, y, hemi, jac);
+    }
+    Rgb iispt_light_sample_dir(const HemiCam &hc, V3 wi, int hemi, const float *jac) const {
+        V3 wc = xf_vector(M4{hc.w2c}, wi);
+        float theta = trig.acos_f(wc.y);
+        float phi = trig.atan2_f(wc.z, wc.x);
+        if (std::isnan(theta) || std::isnan(phi)) return Rgb(0.f);  // (int)NaN is INT_MIN on x86: outside the film
+        int y = int(hemi * theta / Pi);
+        int x = int(hemi * phi / Pi);
+        if (x >= 0 && x < hemi && y >= 0 && y < hemi) return iispt_nn_pixel(hc, x, y, hemi, jac);
+        return Rgb(0.f);
+    }
+    // estimate_direct, iisptrenderrunner.cpp:16-140
+    Rgb iispt_estimate_direct(const Isect &it, const Bsdf &bsdf, int rx, int ry, const HemiCam &hc, int hemi, const float *jac, Pcg &rng) const {
+        Rgb Ld(0.f);
+        V3 wi;
+        const float light_pdf = float(1.0 / 6.28);
+        const float BSDF_RATIO = float(0.4394);
+        const float EM_RATIO = float(1.098);
+        float scattering_pdf = 0;
+        Rgb Li = iispt_light_sample_xy(hc, rx, ry, hemi, jac, &wi);
+        if (light_pdf > 0 && !Li.is_black()) {
+            Rgb f = bsdf_f(bsdf, it.wo, wi) * absdot(wi, it.sn);
+            scattering_pdf = bsdf_pdf(bsdf, it.wo, wi);
+            if (!f.is_black()) {
+                if (!Li.is_black()) {
+                    float weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                    Ld = Ld + EM_RATIO * f * Li * weight / light_pdf;
+                }
+            }
+        }
+        {
+            // `Point2f uScattering(rng->uniform_float(), rng->uniform_float())`: g++ evaluates the arguments right to
+            // left, so the first draw is y
+            float u[2];
+            u[1] = rng.uniform_float();
+            u[0] = rng.uniform_float();
+            Rgb f = bsdf_sample_f(bsdf, it.wo, &wi, u, &scattering_pdf);
+            f = f * absdot(wi, it.sn);
+            if (!f.is_black() && scattering_pdf > 0) {
+                float weight = power_heuristic(1, scattering_pdf, 1, light_pdf);  // (no specular lobe can be sampled)
+                Rgb Li2 = iispt_light_sample_dir(hc, wi, hemi, jac);
+                if (!Li2.is_black()) Ld = Ld + BSDF_RATIO * f * Li2 * weight / scattering_pdf;
+            }
+        }
+        return Ld;
+    }
+    // IisptRenderRunner::sample_hemisphere, iisptrenderrunner.cpp:142-178 (HEMISPHERIC_IMPORTANCE_SAMPLES = 16)
+    Rgb iispt_sample_hemisphere(const Isect &it, const Bsdf &bsdf, int len, const float *weights, const HemiCam *const *cams, int hemi,
+                                const float *jac, Pcg &rng) const {
+        Rgb L(0.f);
+        int samples_taken = 0;
+        for (int i = 0; i < len; i++) {
+            for (int j = 0; j < 16; j++) {
+                float rr = rng.uniform_float();
+                if (rr < weights[i]) {
+                    samples_taken++;
+                    if (cams[i] != nullptr) {
+                        int rx = int(rng.uniform_u32(uint32_t(hemi)));
+                        int ry = int(rng.uniform_u32(uint32_t(hemi)));
+                        L = L + iispt_estimate_direct(it, bsdf, rx, ry, *cams[i], hemi, jac, rng);
+                    }
+                }
+            }
+        }
+        if (samples_taken > 0) return L / float(samples_taken);
+        return Rgb(0.f);
+    }
+    // IisptRenderRunner::compute_fpixel_weights, iisptrenderrunner.cpp:961-1039 with tools/iisptmathutils.h:44-130, 179-197
+    void iispt_fpixel_weights(int len, const int (*neigh)[2], const HemiCam *const *cams, int fx, int fy, const Isect &f_isect, int tilesize,
+                              const Ray &f_ray, V3 main_cam_origin, float *out) const {
+        const Ray aux = iispt_aux_ray(f_isect, f_ray);
+        float wdpos[4], wdnor[4], wdd[4], wod[4];
+        for (int i = 0; i < len; i++) {  // weighting_distance_positions
+            float dx2 = float(fx - neigh[i][0]);
+            dx2 = dx2 * dx2;
+            float dy2 = float(fy - neigh[i][1]);
+            dy2 = dy2 * dy2;
+            const float pdist = std::sqrt(dx2 + dy2);
+            const float tile_distance = float(tilesize);
+            float res = tile_distance != 0.0 ? pdist / tile_distance : pdist;
+            wdpos[i] = res < 0.0 ? 0.f : (res > 1.0 ? 1.f : res);
+        }
+        for (int i = 0; i < len; i++) {  // weighting_distance_normals
+            if (!cams[i]) {
+                wdnor[i] = 0.0f;
+                continue;
+            }
+            V3 a = aux.d, b = cams[i]->look;
+            const float al = length(a), bl = length(b);
+            if (al <= 0.0 || bl <= 0.0) {
+                wdnor[i] = 1.f;
+                continue;
+            }
+            a = vdiv(a, al);
+            b = vdiv(b, bl);
+            const float dt = dot(a, b);
+            wdnor[i] = dt < 0.0 ? 1.f : 1.f - dt;
+        }
+        for (int i = 0; i < len; i++) {  // weightingCameraDistance
+            if (!cams[i]) {
+                wdd[i] = 0.0f;
+                continue;
+            }
+            const float i2c = length(main_cam_origin - f_isect.p);
+            if (i2c < 1e-10) {
+                wdd[i] = 0.f;
+                continue;
+            }
+            const float s2c = length(main_cam_origin - cams[i]->origin);
+            float rel = std::abs(i2c - s2c) / i2c;
+            rel *= 1.f;
+            const float w = 1.0f - rel;
+            wdd[i] = w < 0.f ? 0.f : (w > 1.f ? 1.f : w);
+        }
+        for (int i = 0; i < len; i++) wod[i] = wdpos[i] * wdnor[i] + wdpos[i] * wdd[i] + wdpos[i];
+        for (int i = 0; i < len; i++) out[i] = float(std::max(0.0, 2.0 - double(wod[i])) + 0.001);
+        float tot = 0.0;
+        for (int i = 0; i < len; i++) tot += out[i];
+        if (tot > 0.0)
+            for (int i = 0; i < len; i++) out[i] = out[i] / tot;
+    }
 };
 
 // SampleDiscrete on a uniform distribution: FindInterval over cdf[i] = i/n picks
@@ -2694,6 +2948,90 @@ static int render_impl(const iile_scene_desc *scene, int trig_mode, int n_thread
 extern "C" {
 
 int oracle_tile_owner(int tx, int ty, int nranks) { return iile_tile_owner(tx, ty, nranks); }
+
+// ---- the IISPT runner's gather (iisptrenderrunner.cpp:248-596) -------------------------------------------------
+// hemi points of a task: find_intersection for each, then the aux ray the probe camera is placed on
+int oracle_iispt_hemi_points(const iile_scene_desc *scene, int trig_mode, const iile_iispt_task *task, uint8_t *valid, float *pos3, float *dir3) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    const int nx = iile_iispt_grid_count(task->x0, task->x1, task->tilesize), ny = iile_iispt_grid_count(task->y0, task->y1, task->tilesize);
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+            const int k = j * nx + i;
+            const int tx = iile_iispt_grid_pos(task->x0, task->x1, task->tilesize, i), ty = iile_iispt_grid_pos(task->y0, task->y1, task->tilesize, j);
+            Oracle::Sampler smp{&orc, 0, 0, 0, 0};
+            RayDiff rd;
+            Ray r = orc.iispt_camera_ray(tx, ty, task->counter_base + 1 + uint32_t(k), &smp, &rd);
+            Isect is;
+            Ray ray;
+            Rgb beta;
+            const bool found = orc.iispt_find_intersection(r, rd, smp, &is, &ray, &beta);
+            valid[k] = 0;
+            for (int a = 0; a < 3; ++a) pos3[3 * k + a] = 0, dir3[3 * k + a] = 0;
+            if (!found || beta.y() <= 0.0) continue;  // "set a black hemi"
+            const Ray aux = Oracle::iispt_aux_ray(is, ray);
+            valid[k] = 1;
+            pos3[3 * k] = aux.o.x, pos3[3 * k + 1] = aux.o.y, pos3[3 * k + 2] = aux.o.z;
+            dir3[3 * k] = aux.d.x, dir3[3 * k + 1] = aux.d.y, dir3[3 * k + 2] = aux.d.z;
+        }
+    return nx * ny;
+}
+// the per-pixel loop: out_rgbw[4 * j ..] = {f_beta * L (RGB), weight 0.5} of film pixel j of the task (row-major), or
+// zeros where the runner records nothing
+int oracle_iispt_gather(const iile_scene_desc *scene, int trig_mode, const iile_iispt_task *task, const uint8_t *valid, const float *pos3,
+                        const float *dir3, const float *nn_films, float *out_rgbw) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    const int hemi = scene->probe.hemi_size;
+    const int nx = iile_iispt_grid_count(task->x0, task->x1, task->tilesize), ny = iile_iispt_grid_count(task->y0, task->y1, task->tilesize);
+    std::vector<Oracle::HemiCam> cams(size_t(nx) * ny);
+    for (int k = 0; k < nx * ny; ++k)
+        if (valid[k] && !Oracle::make_hemi_cam(pos3 + 3 * k, dir3 + 3 * k, nn_films + size_t(k) * hemi * hemi * 3, &cams[size_t(k)])) return 1;
+    std::vector<float> jac(static_cast<size_t>(hemi), 0.f);  // IntensityFilm::get_camera_coord_jacobian, intensityfilm.cpp:60-66
+    for (int y = 0; y < hemi; ++y) {
+        float abs_vertical_value = float(y) / hemi;
+        float polar_vertical_value = float(M_PI * abs_vertical_value);
+        jac[size_t(y)] = float(sin(polar_vertical_value));
+    }
+    float zero_lens[2] = {0, 0};
+    const V3 main_origin = orc.camera_ray(0.f, 0.f, zero_lens).o;  // Camera::getCameraWorldPosition, camera.cpp:115-124
+    const int w = task->x1 - task->x0;
+    for (int fy = task->y0; fy < task->y1; ++fy)
+        for (int fx = task->x0; fx < task->x1; ++fx) {
+            const int j = (fy - task->y0) * w + (fx - task->x0);
+            float *out = out_rgbw + 4 * size_t(j);
+            out[0] = out[1] = out[2] = out[3] = 0;
+            const int ts = task->tilesize;
+            auto pmod = [](int i, int n) { return (i % n + n) % n; };
+            const int sx = fx - pmod(fx - task->x0, ts), sy = fy - pmod(fy - task->y0, ts);
+            const int ex = std::min(sx + ts, task->x1 - 1), ey = std::min(sy + ts, task->y1 - 1);
+            const int neigh[4][2] = {{sx, sy}, {ex, ey}, {ex, sy}, {sx, ey}};  // S, E, R, B
+            const Oracle::HemiCam *hc[4];
+            for (int i = 0; i < 4; ++i) {
+                const int gi = iile_iispt_grid_index(task->x0, task->x1, ts, neigh[i][0]), gj = iile_iispt_grid_index(task->y0, task->y1, ts, neigh[i][1]);
+                const Oracle::HemiCam &cam = cams[size_t(gj) * nx + gi];
+                hc[i] = cam.valid ? &cam : nullptr;
+            }
+            Oracle::Sampler smp{&orc, 0, 0, 0, 0};
+            RayDiff rd;
+            Ray r = orc.iispt_camera_ray(fx, fy, task->counter_base + 1 + uint32_t(nx * ny) + uint32_t(j), &smp, &rd);
+            Isect f_isect;
+            Ray f_ray;
+            Rgb f_beta;
+            if (!orc.iispt_find_intersection(r, rd, smp, &f_isect, &f_ray, &f_beta)) continue;
+            if (f_beta.y() <= 0.0) continue;
+            float weights[4];
+            orc.iispt_fpixel_weights(4, neigh, hc, fx, fy, f_isect, ts, f_ray, main_origin, weights);
+            // f_isect.ComputeScatteringFunctions(f_ray, arena) again (iisptrenderrunner.cpp:548): f_isect came out of
+            // find_intersection with its differentials and bump already applied; the BSDF is a function of that state
+            const Oracle::Bsdf bsdf = orc.make_bsdf(f_isect);
+            Oracle::Pcg rng(task->rng_seed + uint64_t(j));
+            const Rgb L = orc.iispt_sample_hemisphere(f_isect, bsdf, 4, weights, hc, hemi, jac.data(), rng);
+            const Rgb v = f_beta * L;
+            out[0] = v.c[0], out[1] = v.c[1], out[2] = v.c[2], out[3] = 0.5f;
+        }
+    return 0;
+}
 
 int oracle_render(const iile_scene_desc *scene, int trig_mode, int n_threads, int k_begin, int k_end, int tile_rank,
                   int tile_nranks, float *film_xyzw, oracle_stats *stats) {

@@ -53,6 +53,21 @@ class RenderParams(ctypes.Structure):
                 ("film_on_device", c_i32), ("stream", c_vp)]
 
 
+class IisptTask(ctypes.Structure):
+    """iile_iispt_task (include/iile_scene.h): one task of the IISPT render runner."""
+    _fields_ = [("x0", c_i32), ("y0", c_i32), ("x1", c_i32), ("y1", c_i32), ("tilesize", c_i32), ("counter_base", c_u32),
+                ("rng_seed", c_u64)]
+
+    def grid(self):
+        def count(a0, a1, ts):
+            n, t = 1, a0
+            while t != a1 - 1:
+                t = min(t + ts, a1 - 1)
+                n += 1
+            return n
+        return count(self.x0, self.x1, self.tilesize), count(self.y0, self.y1, self.tilesize)
+
+
 class GpuStats(ctypes.Structure):
     _fields_ = [(n, c_u64) for n in ("camera_rays closest_rays shadow_rays nodes_closest nodes_any tri_tests "
                                      "tri_hits sphere_tests nee_evals zero_radiance").split()] + [
@@ -81,7 +96,8 @@ HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
-               "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download"]
+               "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download",
+               "iile_iispt_hemi_points", "iile_iispt_gather"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_last_error"]
@@ -175,6 +191,8 @@ def gpu_lib():
         lib.iile_render_probes.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(GpuStats)]
         lib.iile_bsdf_sample.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
+        lib.iile_iispt_hemi_points.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_vp, c_vp, c_vp]
+        lib.iile_iispt_gather.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32]
         _gpu = lib
     return _gpu
 
@@ -448,6 +466,29 @@ class GpuScene:
         self._check(gpu_lib().iile_render_probes(self._s, n, pos.ctypes.data, direction.ctypes.data, inten.ctypes.data,
                                                  nrm.ctypes.data, dist.ctypes.data, 0, ctypes.byref(st)), "iile_render_probes")
         return inten, nrm, dist, st.as_dict()
+
+    def iispt_hemi_points(self, task):
+        """The hemi points of an IISPT task: (valid (ny, nx) uint8, aux ray origins (ny, nx, 3), directions (ny, nx, 3))."""
+        nx, ny = task.grid()
+        valid = np.zeros((ny, nx), np.uint8)
+        pos = np.zeros((ny, nx, 3), np.float32)
+        dr = np.zeros((ny, nx, 3), np.float32)
+        self._check(gpu_lib().iile_iispt_hemi_points(self._s, ctypes.byref(task), valid.ctypes.data, pos.ctypes.data, dr.ctypes.data),
+                    "iile_iispt_hemi_points")
+        return valid, pos, dr
+
+    def iispt_gather(self, task, valid, pos, direction, nn_films=None, nn_device_ptr=None, out_device_ptr=None):
+        """The runner's per-pixel loop over the predicted hemispheres nn_films (ny, nx, 32, 32, 3) -> (h, w, 4)
+        {f_beta * L, weight}; nn_device_ptr / out_device_ptr: raw device pointers instead of host arrays."""
+        valid, pos, direction = np.ascontiguousarray(valid, np.uint8), _f32(pos), _f32(direction)
+        h, w = task.y1 - task.y0, task.x1 - task.x0
+        out = None if out_device_ptr is not None else np.zeros((h, w, 4), np.float32)
+        nn = _f32(nn_films) if nn_device_ptr is None else None
+        self._check(gpu_lib().iile_iispt_gather(self._s, ctypes.byref(task), valid.ctypes.data, pos.ctypes.data, direction.ctypes.data,
+                                                nn.ctypes.data if nn is not None else c_vp(int(nn_device_ptr)), int(nn is None),
+                                                out.ctypes.data if out is not None else c_vp(int(out_device_ptr)), int(out is None)),
+                    "iile_iispt_gather")
+        return out
 
     def texture_eval(self, tex, uv, duv):
         """ImageTexture::Evaluate at (n, 2) uv with (n, 4) differentials {dudx, dvdx, dudy, dvdy} -> (n, 3) RGB."""

@@ -1758,6 +1758,97 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
     return IILE_OK;
 }
 
+// ---- the IISPT runner's gather ----------------------------------------------------
+namespace {
+int iispt_check(iile_scene *sc, const iile_iispt_task *t, int *nx, int *ny) {
+    if (!sc || !t) return fail(IILE_ERR_ARG, "iile_iispt: null argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (t->x1 <= t->x0 || t->y1 <= t->y0 || t->tilesize < 1) return fail(IILE_ERR_ARG, "iile_iispt: empty task or tilesize < 1");
+    if (sc->ds.sobol) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the runner's camera samples need the scene's Halton sampler");
+    if (sc->probe.hemi_size != 32) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the gather is built for 32 x 32 hemispheres (iisptHemiSize)");
+    *nx = iile_iispt_grid_count(t->x0, t->x1, t->tilesize);
+    *ny = iile_iispt_grid_count(t->y0, t->y1, t->tilesize);
+    if (uint64_t(t->counter_base) + uint64_t(*nx) * uint64_t(*ny) + uint64_t(t->x1 - t->x0) * uint64_t(t->y1 - t->y0) >= 0x7fffffffull)
+        return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the sampler's pixel counter would pass INT_MAX");
+    return IILE_OK;
+}
+}  // namespace
+
+int iile_iispt_hemi_points(iile_scene *sc, const iile_iispt_task *t, uint8_t *valid, float *pos3, float *dir3) {
+    int nx = 0, ny = 0;
+    int rc = iispt_check(sc, t, &nx, &ny);
+    if (rc) return rc;
+    if (!valid || !pos3 || !dir3) return fail(IILE_ERR_ARG, "iile_iispt_hemi_points: null output");
+    const size_t n = size_t(nx) * ny;
+    DevBuf<uint8_t> dv;
+    DevBuf<float> dp, dd;
+    if ((rc = dv.alloc(n)) || (rc = dp.alloc(3 * n)) || (rc = dd.alloc(3 * n))) return rc;
+    DScene S = sc->ds;
+    S.diff_scale = 1.f;  // r.ScaleDifferentials(1.0), iisptrenderrunner.cpp:272
+    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    launch_iispt_hemi_points(S, *t, nx, ny, dv.p, dp.p, dd.p, sc->spill, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = dv.get(valid, n)) || (rc = dp.get(pos3, 3 * n)) || (rc = dd.get(dir3, 3 * n))) return rc;
+    return IILE_OK;
+}
+
+int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *valid, const float *pos3, const float *dir3, const float *nn_films,
+                      int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
+    int nx = 0, ny = 0;
+    int rc = iispt_check(sc, t, &nx, &ny);
+    if (rc) return rc;
+    if (!valid || !pos3 || !dir3 || !nn_films || !out_rgbw) return fail(IILE_ERR_ARG, "iile_iispt_gather: null argument");
+    const size_t n = size_t(nx) * ny, n_pix = size_t(t->x1 - t->x0) * size_t(t->y1 - t->y0);
+    const int hemi = sc->probe.hemi_size;
+    // the hemi points' cameras: CreateHemisphericCamera (hemispheric.cpp:109-160) — CameraToWorld from LookAt, WorldToCamera
+    // its numerical inverse, the look direction and origin as given
+    std::vector<DHemiCam> cams(n);
+    for (size_t k = 0; k < n; ++k) {
+        DHemiCam &hc = cams[k];
+        std::memset(&hc, 0, sizeof(hc));
+        if (!valid[k]) continue;
+        DProbeCam pc;
+        float inv[16];
+        if (!make_probe_camera(pos3 + 3 * k, dir3 + 3 * k, &pc) || !invert4(pc.c2w.m, inv))
+            return fail(IILE_ERR_ARG, "iile_iispt_gather: degenerate hemi point direction (hemi point " + std::to_string(k) + ")");
+        hc.c2w = pc.c2w;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) hc.w2c[3 * r + c] = inv[4 * r + c];
+        for (int c = 0; c < 3; ++c) hc.look[c] = dir3[3 * k + c], hc.origin[c] = pos3[3 * k + c];
+        hc.valid = 1;
+    }
+    std::vector<float> jac(size_t(hemi), 0.f);  // IntensityFilm::get_camera_coord_jacobian, intensityfilm.cpp:60-66
+    for (int y = 0; y < hemi; ++y) {
+        const float abs_vertical_value = float(y) / hemi;
+        const float polar_vertical_value = float(M_PI * abs_vertical_value);
+        jac[size_t(y)] = float(std::sin(polar_vertical_value));
+    }
+    DevBuf<DHemiCam> dc;
+    DevBuf<float> dj, dnn;
+    DevBuf<float4> dout;
+    if ((rc = dc.put(cams.data(), n)) || (rc = dj.put(jac.data(), jac.size()))) return rc;
+    const float *nn_dev = nn_films;
+    if (!nn_on_device) {
+        if ((rc = dnn.put(nn_films, n * size_t(hemi) * hemi * 3))) return rc;
+        nn_dev = dnn.p;
+    }
+    float4 *out_dev = reinterpret_cast<float4 *>(out_rgbw);
+    if (!out_on_device) {
+        if ((rc = dout.alloc(n_pix))) return rc;
+        out_dev = dout.p;
+    }
+    DScene S = sc->ds;
+    S.diff_scale = 1.f;
+    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    launch_iispt_gather(S, *t, nx, ny, dc.p, nn_dev, dj.p, out_dev, sc->spill, cfg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (!out_on_device && (rc = dout.get(reinterpret_cast<float4 *>(out_rgbw), n_pix))) return rc;
+    return IILE_OK;
+}
+
 // ---- kernel-level entry points ---------------------------------------------
 
 static int trace_common(iile_scene *sc, int32_t n, const float *o3, const float *d3, const float *tmax, int any,

@@ -1,5 +1,6 @@
 // kernels.h — launch interface between api.hip and kernels.hip.
 #pragma once
+#include "../../../include/iile_scene.h"
 #include "dscene.h"
 
 namespace iile {
@@ -90,6 +91,18 @@ void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F
 void launch_probe_finish(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int n_probes,
                          float *intensity, float *normals, float *distance, const LaunchCfg &cfg);
 void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg);
+
+// ---- the IISPT runner's gather (iispt.hip) ----
+struct DHemiCam {  // a hemi point's HemisphericCamera as the gather uses it (cameras/hemispheric.h:23-82)
+    M44 c2w;       // CameraToWorld
+    float w2c[9];  // upper 3 x 3 of WorldToCamera's matrix (row major)
+    float look[3], origin[3];
+    int valid;
+};
+void launch_iispt_hemi_points(const DScene &S, const iile_iispt_task &T, int nx, int ny, uint8_t *valid, float *pos3, float *dir3, int *spill,
+                              const LaunchCfg &cfg);
+void launch_iispt_gather(const DScene &S, const iile_iispt_task &T, int nx, int ny, const DHemiCam *cams, const float *nn_films, const float *jac,
+                         float4 *out, int *spill, const LaunchCfg &cfg);
 
 // kernel-level entry points for parity tests
 void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, float4 *hits, int any_hit,

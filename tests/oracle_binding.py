@@ -107,6 +107,25 @@ class Oracle:
         assert rc == 0
         return film, st.as_dict()
 
+    def iispt_hemi_points(self, scene, task, trig_mode=TRIG_PORTABLE):
+        nx, ny = task.grid()
+        valid = np.zeros((ny, nx), np.uint8)
+        pos = np.zeros((ny, nx, 3), np.float32)
+        dr = np.zeros((ny, nx, 3), np.float32)
+        self.lib.oracle_iispt_hemi_points.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp]
+        n = self.lib.oracle_iispt_hemi_points(scene.desc, trig_mode, ctypes.byref(task), valid.ctypes.data, pos.ctypes.data, dr.ctypes.data)
+        assert n == nx * ny
+        return valid, pos, dr
+
+    def iispt_gather(self, scene, task, valid, pos, direction, nn_films, trig_mode=TRIG_PORTABLE):
+        valid, pos, direction, nn = np.ascontiguousarray(valid, np.uint8), _f32(pos), _f32(direction), _f32(nn_films)
+        out = np.zeros((task.y1 - task.y0, task.x1 - task.x0, 4), np.float32)
+        self.lib.oracle_iispt_gather.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
+        rc = self.lib.oracle_iispt_gather(scene.desc, trig_mode, ctypes.byref(task), valid.ctypes.data, pos.ctypes.data, direction.ctypes.data,
+                                          nn.ctypes.data, out.ctypes.data)
+        assert rc == 0
+        return out
+
     def tile_owner(self, tx, ty, nranks):
         return int(self.lib.oracle_tile_owner(int(tx), int(ty), int(nranks)))
 

@@ -1,0 +1,99 @@
+"""The IISPT render runner's gather (second half; src/integrators/iisptrenderrunner.cpp:216-596).
+
+CPU: properties of the oracle's restatement (the reference has no test for the runner and no weights for the network, so
+parity of these functions rests on the restatement plus these properties). GPU: the device kernels against the oracle,
+bit for bit, on seeded synthetic "predictions" (the gather needs no network weights to be tested)."""
+import numpy as np
+import pytest
+
+
+def _task(binding, w, h, ts, counter=0, seed=99):
+    return binding.IisptTask(0, 0, w, h, ts, counter, seed)
+
+
+def _bits_equal(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (a == b)).all()
+
+
+def test_hemi_grid_of_a_task(binding):
+    """Hemi points sit every `tilesize` pixels and on the last row / column (iisptrenderrunner.cpp:387-412)."""
+    for (a1, ts, want) in ((96, 10, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 95]), (81, 10, [0, 10, 20, 30, 40, 50, 60, 70, 80]),
+                           (5, 10, [0, 4]), (1, 3, [0])):
+        t = binding.IisptTask(0, 0, a1, a1, ts, 0, 0)
+        nx, ny = t.grid()
+        assert nx == ny == len(want)
+
+
+def test_oracle_gather_properties(binding, oracle):
+    scene = binding.HostScene(xres=96, yres=80, spp=4)
+    task = _task(binding, 96, 80, 10)
+    valid, pos, dr = oracle.iispt_hemi_points(scene, task)
+    assert valid.shape == (9, 11) and valid.sum() > 0
+    # a valid hemi point's aux ray leaves along the unit normal
+    n = np.linalg.norm(dr[valid == 1], axis=1)
+    assert np.allclose(n, 1, atol=1e-5) and (dr[valid == 0] == 0).all()
+    rng = np.random.default_rng(5)
+    nn = rng.uniform(0.1, 2.0, valid.shape + (32, 32, 3)).astype(np.float32)
+    out = oracle.iispt_gather(scene, task, valid, pos, dr, nn)
+    assert np.isfinite(out).all() and (out[..., :3] >= 0).all()
+    w = out[..., 3]
+    assert set(np.unique(w)) <= {0.0, 0.5} and (w == 0.5).sum() > 1000
+    assert (out[w == 0][:, :3] == 0).all()
+    # radiance is linear in the predicted hemispheres: a power-of-two factor carries through every float product exactly
+    out2 = oracle.iispt_gather(scene, task, valid, pos, dr, nn * np.float32(4))
+    assert np.array_equal(out2[..., :3], out[..., :3] * np.float32(4))
+    # dark hemispheres give black pixels that are still recorded; hemi points without a camera still take their share of
+    # the 16 draws per neighbour (samples_taken) but add nothing
+    zero = oracle.iispt_gather(scene, task, valid, pos, dr, nn * 0)
+    assert (zero[..., :3] == 0).all() and np.array_equal(zero[..., 3], w)
+    none = oracle.iispt_gather(scene, task, np.zeros_like(valid), pos, dr, nn)
+    assert (none[..., :3] == 0).all() and np.array_equal(none[..., 3], w)
+    # another RNG stream: a different estimate of the same quantity
+    other = oracle.iispt_gather(scene, _task(binding, 96, 80, 10, seed=7), valid, pos, dr, nn)
+    assert not np.array_equal(other, out)
+    m0, m1 = out[..., :3][w > 0].mean(), other[..., :3][w > 0].mean()
+    assert abs(m0 - m1) / m0 < 0.05
+
+
+@pytest.mark.gpu
+def test_gather_on_device_matches_oracle(binding, oracle):
+    scene = binding.HostScene(xres=96, yres=80, spp=4)
+    gpu = binding.GpuScene(scene)
+    for task in (_task(binding, 96, 80, 10), binding.IisptTask(16, 8, 90, 71, 7, 500, 3)):
+        valid, pos, dr = gpu.iispt_hemi_points(task)
+        rv, rp, rd = oracle.iispt_hemi_points(scene, task)
+        assert np.array_equal(valid, rv) and _bits_equal(pos, rp) and _bits_equal(dr, rd)
+        rng = np.random.default_rng(17)
+        nn = rng.uniform(0.0, 3.0, valid.shape + (32, 32, 3)).astype(np.float32)
+        nn[rng.uniform(size=nn.shape[:4]) < 0.1] = 0  # black texels: the is_black branches
+        out = gpu.iispt_gather(task, valid, pos, dr, nn)
+        ref = oracle.iispt_gather(scene, task, valid, pos, dr, nn)
+        assert _bits_equal(out, ref)
+        assert (out[..., 3] == 0.5).sum() > 500
+
+
+@pytest.mark.gpu
+def test_gather_in_a_textured_room_with_specular_chains(binding, oracle, tmp_path):
+    """find_intersection's specular chain (mirror / glass blobs), textured and bump-mapped first hits, plastic and uber BSDFs
+    under sample_hemisphere; the predictions stay in HBM (device pointers in and out)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    import boxroom
+    path = tmp_path / "room.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, light="envmap", materials="mixed", textures=str(tmp_path)))
+    scene = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(scene)
+    task = _task(binding, 96, 64, 12, counter=40, seed=2024)
+    valid, pos, dr = gpu.iispt_hemi_points(task)
+    rv, rp, rd = oracle.iispt_hemi_points(scene, task)
+    assert np.array_equal(valid, rv) and _bits_equal(pos, rp) and _bits_equal(dr, rd)
+    rng = np.random.default_rng(23)
+    nn = rng.uniform(0.0, 1.5, valid.shape + (32, 32, 3)).astype(np.float32)
+    nn_t = torch.from_numpy(nn).cuda()
+    out_t = torch.zeros((64, 96, 4), dtype=torch.float32, device="cuda")
+    gpu.iispt_gather(task, valid, pos, dr, nn_device_ptr=nn_t.data_ptr(), out_device_ptr=out_t.data_ptr())
+    torch.cuda.synchronize()
+    ref = oracle.iispt_gather(scene, task, valid, pos, dr, nn)
+    assert _bits_equal(out_t.cpu().numpy(), ref)
