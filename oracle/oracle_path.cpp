@@ -2991,7 +2991,8 @@ int oracle_iispt_gather(const iile_scene_desc *scene, int trig_mode, const iile_
     for (int y = 0; y < hemi; ++y) {
         float abs_vertical_value = float(y) / hemi;
         float polar_vertical_value = float(M_PI * abs_vertical_value);
-        jac[size_t(y)] = float(sin(polar_vertical_value));
+        // intensityfilm.cpp includes <math.h>: with libstdc++ `sin(Float)` resolves to the float overload (sinf)
+        jac[size_t(y)] = std::sin(polar_vertical_value);
     }
     float zero_lens[2] = {0, 0};
     const V3 main_origin = orc.camera_ray(0.f, 0.f, zero_lens).o;  // Camera::getCameraWorldPosition, camera.cpp:115-124

@@ -1775,6 +1775,25 @@ int iispt_check(iile_scene *sc, const iile_iispt_task *t, int *nx, int *ny) {
 }
 }  // namespace
 
+namespace {
+// the items of a task in HBM: hemi points first, then (with_pixels) the film pixels
+struct ItemBuffers {
+    DevBuf<float4> planes;
+    DevBuf<uint32_t> words;
+    IisptItems I;
+    int make(int n_hemi, int n_pix, int nx) {
+        const size_t n = size_t(n_hemi) + size_t(n_pix);
+        int rc;
+        if ((rc = planes.alloc(5 * n)) || (rc = words.alloc(n + 64))) return rc;
+        I.ro = planes.p, I.rd = planes.p + n, I.beta = planes.p + 2 * n, I.hit = planes.p + 3 * n, I.pf = planes.p + 4 * n;
+        I.idx = words.p + 64;
+        I.n_active = words.p;
+        I.n_items = int(n), I.n_hemi = n_hemi, I.nx = nx;
+        return IILE_OK;
+    }
+};
+}  // namespace
+
 int iile_iispt_hemi_points(iile_scene *sc, const iile_iispt_task *t, uint8_t *valid, float *pos3, float *dir3) {
     int nx = 0, ny = 0;
     int rc = iispt_check(sc, t, &nx, &ny);
@@ -1783,11 +1802,14 @@ int iile_iispt_hemi_points(iile_scene *sc, const iile_iispt_task *t, uint8_t *va
     const size_t n = size_t(nx) * ny;
     DevBuf<uint8_t> dv;
     DevBuf<float> dp, dd;
-    if ((rc = dv.alloc(n)) || (rc = dp.alloc(3 * n)) || (rc = dd.alloc(3 * n))) return rc;
+    ItemBuffers items;
+    if ((rc = dv.alloc(n)) || (rc = dp.alloc(3 * n)) || (rc = dd.alloc(3 * n)) || (rc = items.make(int(n), 0, nx))) return rc;
     DScene S = sc->ds;
     S.diff_scale = 1.f;  // r.ScaleDifferentials(1.0), iisptrenderrunner.cpp:272
     LaunchCfg cfg{sc->n_cus, nullptr, false};
-    launch_iispt_hemi_points(S, *t, nx, ny, dv.p, dp.p, dd.p, sc->spill, cfg);
+    uint32_t active = 0;
+    launch_iispt_first_hits(S, *t, items.I, sc->spill, &active, cfg);
+    launch_iispt_hemi_out(S, items.I, dv.p, dp.p, dd.p, cfg);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if ((rc = dv.get(valid, n)) || (rc = dp.get(pos3, 3 * n)) || (rc = dd.get(dir3, 3 * n))) return rc;
@@ -1819,16 +1841,17 @@ int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *v
         for (int c = 0; c < 3; ++c) hc.look[c] = dir3[3 * k + c], hc.origin[c] = pos3[3 * k + c];
         hc.valid = 1;
     }
-    std::vector<float> jac(size_t(hemi), 0.f);  // IntensityFilm::get_camera_coord_jacobian, intensityfilm.cpp:60-66
+    std::vector<float> jac(static_cast<size_t>(hemi), 0.f);  // IntensityFilm::get_camera_coord_jacobian, intensityfilm.cpp:60-66
     for (int y = 0; y < hemi; ++y) {
         const float abs_vertical_value = float(y) / hemi;
         const float polar_vertical_value = float(M_PI * abs_vertical_value);
-        jac[size_t(y)] = float(std::sin(polar_vertical_value));
+        jac[size_t(y)] = std::sin(polar_vertical_value);  // sin(Float): the float overload (sinf), as in the reference
     }
     DevBuf<DHemiCam> dc;
     DevBuf<float> dj, dnn;
     DevBuf<float4> dout;
-    if ((rc = dc.put(cams.data(), n)) || (rc = dj.put(jac.data(), jac.size()))) return rc;
+    ItemBuffers items;
+    if ((rc = dc.put(cams.data(), n)) || (rc = dj.put(jac.data(), jac.size())) || (rc = items.make(int(n), int(n_pix), nx))) return rc;
     const float *nn_dev = nn_films;
     if (!nn_on_device) {
         if ((rc = dnn.put(nn_films, n * size_t(hemi) * hemi * 3))) return rc;
@@ -1842,7 +1865,9 @@ int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *v
     DScene S = sc->ds;
     S.diff_scale = 1.f;
     LaunchCfg cfg{sc->n_cus, nullptr, false};
-    launch_iispt_gather(S, *t, nx, ny, dc.p, nn_dev, dj.p, out_dev, sc->spill, cfg);
+    uint32_t active = 0;
+    launch_iispt_first_hits(S, *t, items.I, sc->spill, &active, cfg);
+    launch_iispt_gather(S, *t, items.I, ny, dc.p, nn_dev, dj.p, out_dev, cfg);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (!out_on_device && (rc = dout.get(reinterpret_cast<float4 *>(out_rgbw), n_pix))) return rc;

@@ -1,14 +1,21 @@
 // iispt.hip — the IISPT render runner's gather on the device (second half).
 //
-// What IisptRenderRunner::run does around the probe pass and the network (integrators/iisptrenderrunner.cpp:216-596):
-//   k_iispt_hemi_points   the hemi points of a task: camera sample, find_intersection (:632-757), the aux ray the probe
-//                         camera is placed on (:299-312) — the inputs of iile_render_probes
-//   k_iispt_gather        the per-pixel loop (:414-596): camera sample, find_intersection, compute_fpixel_weights
-//                         (:961-1039), sample_hemisphere (:142-178) / estimate_direct (:16-140) over the four neighbouring
-//                         hemispheres the network predicted (read where the network left them in HBM), f_beta * L
-// One thread per hemi point / film pixel: a task has 10^4..10^6 pixels with ~16 BSDF evaluations and one traversal
-// each, so this pass is two orders of magnitude below the probe pass and the network in cost; it is written for
-// exactness (bit for bit the oracle's restatement), not yet tuned.
+// What IisptRenderRunner::run does around the probe pass and the network (integrators/iisptrenderrunner.cpp:216-596),
+// as a small wavefront pipeline over the items of a task (its hemi points, then its film pixels):
+//   k_iispt_begin    sampler_next_pixel + GetCameraSample + GenerateRayDifferential (:262-272, 941-953) per item
+//   k_iispt_trace    BVHAccel::Intersect for the items still looking for their vertex
+//   k_iispt_vertex   one iteration of find_intersection's loop (:632-757): interaction, BSDF, Sample_f; the item ends
+//                    (no surface / black / first non-specular vertex) or follows the specular bounce
+//   k_iispt_hemi_out the aux ray a hemi point's probe camera is placed on (:299-312) — the inputs of iile_render_probes
+//   k_iispt_gather   the per-pixel loop (:414-596): compute_fpixel_weights (:961-1039), sample_hemisphere (:142-178) /
+//                    estimate_direct (:16-140) over the four neighbouring hemispheres the network predicted (read where
+//                    the network left them in HBM), f_beta * L
+// The host (api.hip) repeats trace + vertex until no item is left on a specular chain (at most 24 times, as the
+// reference's loop). Each kernel is one thread per item and about the size of the kernel-level probes of kernels.hip:
+// a first version that ran the whole loop, traversal included, inside one kernel (245 VGPRs, 170-200 spilled SGPRs)
+// produced kernels that read outside their buffers or returned garbage for glossy hits depending on the optimisation
+// level and on the heap layout of the process. This pass costs two orders of magnitude less than the probe pass and
+// the network it sits between; it is written for exactness (bit for bit the oracle's restatement).
 // Random numbers: every film pixel draws from its own PCG32 stream RNG(rng_seed + pixel rank) (iile_iispt_task).
 #include "dpath.h"
 #include "kernels.h"
@@ -17,6 +24,7 @@ namespace iile {
 
 namespace {
 constexpr int kIisptBlock = 256;
+enum { kItemActive = 0, kItemNoSurface = 1, kItemBlack = 2, kItemVertex = 3 };
 
 // core/rng.h:62-156
 struct Pcg {
@@ -45,100 +53,168 @@ struct Pcg {
     DEV float uniform_float() { return mn(kOneMinusEpsilon, float(uniform_u32()) * 0x1p-32f); }
 };
 
-struct FirstHit {
-    bool found;  // find_intersection's return value
-    Isect is;
-    Bsdf bsdf;   // of the returned intersection (valid when found && beta != 0)
-    F3 ray_d;    // direction of the ray that found it
-    F3 beta;
-};
 
-// sampler_next_pixel + GetCameraSample + GenerateRayDifferential (iisptrenderrunner.cpp:262-272, 941-953) for the
-// counter-th call, then find_intersection (:632-757): camera ray, specular chain, the first non-specular vertex
-DEV FirstHit iispt_first_hit(const DScene &S, int fx, int fy, uint32_t counter, lds_int *my_stack, int *my_spill, uint32_t spill_stride) {
-    FirstHit out;
-    out.found = false;
-    out.beta = F3{0, 0, 0};
-    out.ray_d = F3{0, 0, 1};
-    const int cpx = int(counter), cpy = 0;  // the sampler's pixel
-    const uint32_t idx = sample_index(S, cpx, cpy, 0u);
-    int dim = 0;
-    const float u0 = sample_dimension(S, idx, 0, cpx, cpy), u1 = sample_dimension(S, idx, 1, cpx, cpy);
-    float l0 = 0, l1 = 0;
-    if (S.lens_radius > 0) {
-        l0 = sample_dimension(S, idx, 3, cpx, cpy);
-        l1 = sample_dimension(S, idx, 4, cpx, cpy);
+// item -> film pixel it looks through and its camera-sample counter (hemi points first, row by row, then film pixels)
+DEV void item_pixel(const iile_iispt_task &T, int nx, int n_hemi, int item, int *fx, int *fy) {
+    if (item < n_hemi) {
+        *fx = iile_iispt_grid_pos(T.x0, T.x1, T.tilesize, item % nx);
+        *fy = iile_iispt_grid_pos(T.y0, T.y1, T.tilesize, item / nx);
+    } else {
+        const int j = item - n_hemi, w = T.x1 - T.x0;
+        *fx = T.x0 + j % w;
+        *fy = T.y0 + j / w;
     }
-    dim = 5;
-    const float pfx = float(fx) + u0, pfy = float(fy) + u1;
-    F3 ro, rd;
-    float tmax;
-    camera_ray(S, pfx, pfy, l0, l1, &ro, &rd, &tmax);
-    bool have_diff = S.textured_materials != 0;
-    F3 beta = F3{1, 1, 1};
+}
+// the vertex of a finished item again: SurfaceInteraction + BSDF from its hit record, exactly as k_iispt_vertex built
+// them (ComputeScatteringFunctions is a pure function of the hit, the ray and — for textures — the camera sample)
+DEV void vertex_state(const DScene &S, const float4 o4, const float4 d4, const float4 h4, const float4 pf4, bool camera_ray_hit, Isect *is,
+                      Bsdf *bsdf, int *material_out) {
+    const int prim = int(f2b(h4.x));
+    const F3 ro = F3{o4.x, o4.y, o4.z}, rd = F3{d4.x, d4.y, d4.z};
+    const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1], v2 = S.tri_verts[3 * size_t(prim) + 2];
+    const uint32_t flags = f2b(v0.w);
+    const int material = int(f2b(v1.w));
+    *material_out = material;
+    if (flags & 1u) {
+        float t;
+        F3 od, ph;
+        const DSphere &sp = S.spheres[S.prim_shape[prim]];
+        sphere_test(sp, ro, rd, IILE_INF, &t, &od, &ph);
+        sphere_interaction(sp, od, ph, is);
+    } else {
+        triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, rd, h4.y, h4.z, h4.w, is);
+    }
+    if (material < 0) return;
+    const DMaterial &m0 = S.materials[material];
+    if (S.textured_materials &&
+        (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0)) {
+        TexDiff td = TexDiff{0, 0, 0, 0};
+        // only the camera ray carries differentials (r.ScaleDifferentials(1.0): S.diff_scale is 1 in these kernels)
+        if (camera_ray_hit) td = compute_differentials(*is, camera_differentials(S, pf4.x, pf4.y, pf4.z, pf4.w, ro, rd));
+        if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, is);
+        const DMaterial mm = textured_material(S, m0, *is, td);
+        *bsdf = make_bsdf<true>(mm, *is);
+    } else {
+        *bsdf = make_bsdf<true>(m0, *is);
+    }
+}
+}  // namespace
+
+// Per-item records (IisptItems, kernels.h; float4 planes of n_items each, api.hip allocates them):
+//   ro = (ray o, tMax)   rd = (ray d, bitcast {state | bounce << 8 | sampler dimension << 16})   beta = (rgb, -)
+//   hit = (bitcast prim, b0, b1, b2)   pf = (pFilm.xy, lens u)   idx[] = Halton index of the item's camera sample
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_begin(DScene S, iile_iispt_task T, IisptItems I) {
+    for (int item = blockIdx.x * kIisptBlock + threadIdx.x; item < I.n_items; item += gridDim.x * kIisptBlock) {
+        int fx, fy;
+        item_pixel(T, I.nx, I.n_hemi, item, &fx, &fy);
+        const int cpx = int(T.counter_base + 1u + uint32_t(item)), cpy = 0;  // the sampler's pixel for this call
+        const uint32_t idx = sample_index(S, cpx, cpy, 0u);
+        const float u0 = sample_dimension(S, idx, 0, cpx, cpy), u1 = sample_dimension(S, idx, 1, cpx, cpy);
+        float l0 = 0, l1 = 0;
+        if (S.lens_radius > 0) {
+            l0 = sample_dimension(S, idx, 3, cpx, cpy);
+            l1 = sample_dimension(S, idx, 4, cpx, cpy);
+        }
+        const float pfx = float(fx) + u0, pfy = float(fy) + u1;
+        F3 ro, rd;
+        float tmax;
+        camera_ray(S, pfx, pfy, l0, l1, &ro, &rd, &tmax);
+        I.ro[item] = make_float4(ro.x, ro.y, ro.z, tmax);
+        I.rd[item] = make_float4(rd.x, rd.y, rd.z, b2f(uint32_t(kItemActive) | (0u << 8) | (5u << 16)));
+        I.beta[item] = make_float4(1, 1, 1, 0);
+        I.pf[item] = make_float4(pfx, pfy, l0, l1);
+        I.hit[item] = make_float4(b2f(0xffffffffu), 0, 0, 0);
+        I.idx[item] = idx;
+    }
+}
+
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_trace(DScene S, IisptItems I, int *SPILL) {
+    __shared__ int lds_stack[kIisptBlock / 64][2 * kLdsStackDepth][64];
+    lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
+    const uint32_t spill_stride = gridDim.x * kIisptBlock;
+    int *my_spill = SPILL + blockIdx.x * kIisptBlock + threadIdx.x;
     TraceStats st = {0, 0, 0, 0};
-    for (int bounces = 0; bounces < 24; ++bounces) {
+    for (int item = blockIdx.x * kIisptBlock + threadIdx.x; item < I.n_items; item += gridDim.x * kIisptBlock) {
+        const float4 o4 = I.ro[item], d4 = I.rd[item];
+        if ((f2b(d4.w) & 0xffu) != uint32_t(kItemActive)) continue;
         HitRec h;
         h.t = h.b0 = h.b1 = h.b2 = 0;
         h.prim = -1;
-        if (!traverse<false, false, true>(S, ro, rd, tmax, my_stack, my_spill, spill_stride, &h, &st)) return out;  // no intersection
-        const int prim = h.prim;
-        const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1], v2 = S.tri_verts[3 * size_t(prim) + 2];
-        const uint32_t flags = f2b(v0.w);
-        const int material = int(f2b(v1.w));
-        Isect is;
-        if (flags & 1u) {
-            float t;
-            F3 od, ph;
-            const DSphere &sp = S.spheres[S.prim_shape[prim]];
-            sphere_test(sp, ro, rd, IILE_INF, &t, &od, &ph);
-            sphere_interaction(sp, od, ph, &is);
-        } else {
-            triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, rd, h.b0, h.b1, h.b2, &is);
-        }
-        if (material < 0) {  // `if (!isect.bsdf)`: skip this intersection
-            ro = offset_ray_origin(is.p, is.perr, is.n, rd);
-            tmax = IILE_INF;
-            have_diff = false;
-            continue;
-        }
-        Bsdf bsdf;
-        const DMaterial &m0 = S.materials[material];
-        if (S.textured_materials &&
-            (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0)) {
-            TexDiff td = TexDiff{0, 0, 0, 0};
-            if (have_diff) td = compute_differentials(is, camera_differentials(S, pfx, pfy, l0, l1, ro, rd));  // (S.diff_scale is 1 here)
-            if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, &is);
-            const DMaterial mm = textured_material(S, m0, is, td);
-            bsdf = make_bsdf<true>(mm, is);
-        } else {
-            bsdf = make_bsdf<true>(m0, is);
-        }
-        have_diff = false;
-        const float us0 = sample_dimension(S, idx, dim, cpx, cpy), us1 = sample_dimension(S, idx, dim + 1, cpx, cpy);
-        dim += 2;
-        F3 wi = F3{0, 0, 0};
-        float pdf = 0;
-        bool spec = false, trans = false;
-        const F3 f = bsdf_sample_f(bsdf, -rd, &wi, us0, us1, &pdf, true, &spec, &trans);
-        out.found = true;
-        if (is_black(f) || pdf == 0.f) return out;  // beta 0
-        if (!spec) {
-            out.is = is;
-            out.bsdf = bsdf;
-            out.ray_d = rd;
-            out.beta = beta;
-            return out;
-        }
-        beta = beta * sdiv(f * absdot(wi, is.sn), pdf);
-        const float by = lum_y(beta);
-        if (by < 0.f || is_nan(by)) return out;
-        ro = offset_ray_origin(is.p, is.perr, is.n, wi);
-        rd = wi;
-        tmax = IILE_INF;
+        const bool found = traverse<false, false, true>(S, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, o4.w, my_stack, my_spill, spill_stride, &h, &st);
+        I.hit[item] = make_float4(b2f(uint32_t(found ? h.prim : -1)), h.b0, h.b1, h.b2);
     }
-    out.found = true;  // max depth reached: 0 beta
-    return out;
+}
+
+// one iteration of find_intersection's loop for every active item
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_vertex(DScene S, iile_iispt_task T, IisptItems I) {
+    for (int item = blockIdx.x * kIisptBlock + threadIdx.x; item < I.n_items; item += gridDim.x * kIisptBlock) {
+        const float4 o4 = I.ro[item], d4 = I.rd[item];
+        const uint32_t word = f2b(d4.w);
+        if ((word & 0xffu) != uint32_t(kItemActive)) continue;
+        const int bounce = int((word >> 8) & 0xffu);
+        int dim = int(word >> 16);
+        const float4 h4 = I.hit[item];
+        const F3 rd = F3{d4.x, d4.y, d4.z};
+        uint32_t state = kItemActive;
+        F3 new_o = F3{o4.x, o4.y, o4.z}, new_d = rd;
+        float4 beta4 = I.beta[item];
+        if (int(f2b(h4.x)) < 0) {
+            state = kItemNoSurface;  // no intersection: find_intersection returns false
+        } else {
+            Isect is;
+            Bsdf bsdf;
+            int material;
+            vertex_state(S, o4, d4, h4, I.pf[item], bounce == 0, &is, &bsdf, &material);
+            if (material < 0) {  // `if (!isect.bsdf)`: skip this intersection
+                new_o = offset_ray_origin(is.p, is.perr, is.n, rd);
+            } else {
+                const int cpx = int(T.counter_base + 1u + uint32_t(item)), cpy = 0;
+                const uint32_t idx = I.idx[item];
+                const float us0 = sample_dimension(S, idx, dim, cpx, cpy), us1 = sample_dimension(S, idx, dim + 1, cpx, cpy);
+                dim += 2;
+                F3 wi = F3{0, 0, 0};
+                float pdf = 0;
+                bool spec = false, trans = false;
+                const F3 f = bsdf_sample_f(bsdf, -rd, &wi, us0, us1, &pdf, true, &spec, &trans);
+                if (is_black(f) || pdf == 0.f) {
+                    state = kItemBlack;
+                } else if (!spec) {
+                    state = kItemVertex;  // the first non-specular vertex: IISPT proceeds from here (ray, hit, beta stay)
+                } else {
+                    F3 beta = F3{beta4.x, beta4.y, beta4.z};
+                    beta = beta * sdiv(f * absdot(wi, is.sn), pdf);
+                    const float by = lum_y(beta);
+                    beta4 = make_float4(beta.x, beta.y, beta.z, 0);
+                    if (by < 0.f || is_nan(by)) {
+                        state = kItemBlack;
+                    } else {
+                        new_o = offset_ray_origin(is.p, is.perr, is.n, wi);
+                        new_d = wi;
+                    }
+                }
+            }
+        }
+        int next_bounce = bounce;
+        if (state == uint32_t(kItemActive)) {
+            next_bounce = bounce + 1;
+            if (next_bounce >= 24) state = kItemBlack;  // "max depth reached, return 0 beta"
+        }
+        if (state == uint32_t(kItemActive)) {
+            I.ro[item] = make_float4(new_o.x, new_o.y, new_o.z, IILE_INF);
+            I.beta[item] = beta4;
+            atomicAdd(I.n_active, 1u);
+        }
+        if (state == uint32_t(kItemActive))
+            I.rd[item] = make_float4(new_d.x, new_d.y, new_d.z, b2f(state | (uint32_t(next_bounce) << 8) | (uint32_t(dim) << 16)));
+        else  // finished: the ray that found the vertex stays, with the bounce it was found at
+            I.rd[item] = make_float4(d4.x, d4.y, d4.z, b2f(state | (uint32_t(bounce) << 8) | (uint32_t(dim) << 16)));
+    }
+}
+
+namespace {
+// a finished item has a vertex the runner works with: find_intersection returned true and beta.y() > 0
+DEV bool item_has_vertex(const float4 d4, const float4 beta4) {
+    return (f2b(d4.w) & 0xffu) == uint32_t(kItemVertex) && double(lum_y(F3{beta4.x, beta4.y, beta4.z})) > 0.0;
 }
 // the aux ray: isect.SpawnRay(surface normal turned against the ray)
 DEV void iispt_aux_ray(const Isect &is, F3 ray_d, F3 *o, F3 *d) {
@@ -149,20 +225,18 @@ DEV void iispt_aux_ray(const Isect &is, F3 ray_d, F3 *o, F3 *d) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(kIisptBlock) void k_iispt_hemi_points(DScene S, iile_iispt_task T, int nx, int ny, uint8_t *valid, float *pos3, float *dir3,
-                                                                  int *SPILL) {
-    __shared__ int lds_stack[kIisptBlock / 64][2 * kLdsStackDepth][64];
-    lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
-    const uint32_t spill_stride = gridDim.x * kIisptBlock;
-    int *my_spill = SPILL + blockIdx.x * kIisptBlock + threadIdx.x;
-    const int n = nx * ny;
-    for (int k = blockIdx.x * kIisptBlock + threadIdx.x; k < n; k += gridDim.x * kIisptBlock) {
-        const int i = k % nx, j = k / nx;
-        const int tx = iile_iispt_grid_pos(T.x0, T.x1, T.tilesize, i), ty = iile_iispt_grid_pos(T.y0, T.y1, T.tilesize, j);
-        const FirstHit fh = iispt_first_hit(S, tx, ty, T.counter_base + 1u + uint32_t(k), my_stack, my_spill, spill_stride);
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_hemi_out(DScene S, IisptItems I, uint8_t *valid, float *pos3, float *dir3) {
+    for (int k = blockIdx.x * kIisptBlock + threadIdx.x; k < I.n_hemi; k += gridDim.x * kIisptBlock) {
+        const float4 o4 = I.ro[k], d4 = I.rd[k], beta4 = I.beta[k];
         F3 o = F3{0, 0, 0}, d = F3{0, 0, 0};
-        const bool ok = fh.found && double(lum_y(fh.beta)) > 0.0;  // else "set a black hemi"
-        if (ok) iispt_aux_ray(fh.is, fh.ray_d, &o, &d);
+        const bool ok = item_has_vertex(d4, beta4);  // else "set a black hemi"
+        if (ok) {
+            Isect is;
+            Bsdf bsdf;
+            int material;
+            vertex_state(S, o4, d4, I.hit[k], I.pf[k], ((f2b(d4.w) >> 8) & 0xffu) == 0u, &is, &bsdf, &material);
+            iispt_aux_ray(is, F3{d4.x, d4.y, d4.z}, &o, &d);
+        }
         valid[k] = ok ? 1 : 0;
         pos3[3 * k] = o.x, pos3[3 * k + 1] = o.y, pos3[3 * k + 2] = o.z;
         dir3[3 * k] = d.x, dir3[3 * k + 1] = d.y, dir3[3 * k + 2] = d.z;
@@ -232,12 +306,9 @@ DEV F3 estimate_direct_nn(const Isect &it, const Bsdf &bsdf, int rx, int ry, con
 }
 }  // namespace
 
-__global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iispt_task T, int nx, int ny, const DHemiCam *cams, const float *nn_films,
-                                                             const float *jac, float4 *out, int *SPILL) {
-    __shared__ int lds_stack[kIisptBlock / 64][2 * kLdsStackDepth][64];
-    lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
-    const uint32_t spill_stride = gridDim.x * kIisptBlock;
-    int *my_spill = SPILL + blockIdx.x * kIisptBlock + threadIdx.x;
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iispt_task T, IisptItems I, int ny, const DHemiCam *cams,
+                                                             const float *nn_films, const float *jac, float4 *out) {
+    const int nx = I.nx;
     const int hemi = 32;  // PbrtOptions.iisptHemiSize (checked on the host)
     const int w = T.x1 - T.x0, n = w * (T.y1 - T.y0), ts = T.tilesize;
     // Camera::getCameraWorldPosition (camera.cpp:115-124): the origin of the ray through film point (0, 0), lens (0, 0)
@@ -246,9 +317,15 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iis
     camera_ray(S, 0.f, 0.f, 0.f, 0.f, &main_o, &main_d, &main_t);
     for (int j = blockIdx.x * kIisptBlock + threadIdx.x; j < n; j += gridDim.x * kIisptBlock) {
         const int fx = T.x0 + j % w, fy = T.y0 + j / w;
+        const int item = I.n_hemi + j;
         float4 res = make_float4(0, 0, 0, 0);
-        const FirstHit fh = iispt_first_hit(S, fx, fy, T.counter_base + 1u + uint32_t(nx * ny) + uint32_t(j), my_stack, my_spill, spill_stride);
-        if (fh.found && double(lum_y(fh.beta)) > 0.0) {
+        const float4 o4 = I.ro[item], d4 = I.rd[item], beta4 = I.beta[item];
+        if (item_has_vertex(d4, beta4)) {
+            Isect f_is;
+            Bsdf f_bsdf;
+            int material;
+            vertex_state(S, o4, d4, I.hit[item], I.pf[item], ((f2b(d4.w) >> 8) & 0xffu) == 0u, &f_is, &f_bsdf, &material);
+            const F3 f_ray_d = F3{d4.x, d4.y, d4.z}, f_beta = F3{beta4.x, beta4.y, beta4.z};
             // the four neighbouring hemi points: S top left, E bottom right, R top right, B bottom left (:424-468)
             const int mx = (fx - T.x0) % ts, my = (fy - T.y0) % ts;
             const int sx = fx - mx, sy = fy - my;
@@ -262,7 +339,7 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iis
             }
             // compute_fpixel_weights (:961-1039) with tools/iisptmathutils.h:44-130, 179-197
             F3 aux_o, aux_d;
-            iispt_aux_ray(fh.is, fh.ray_d, &aux_o, &aux_d);
+            iispt_aux_ray(f_is, f_ray_d, &aux_o, &aux_d);
             float weights[4];
             float tot = 0.f;
             for (int i = 0; i < 4; ++i) {
@@ -286,7 +363,7 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iis
                         const float dt = dot(a, b);
                         wdnor = double(dt) < 0.0 ? 1.f : 1.f - dt;
                     }
-                    const float i2c = length(main_o - fh.is.p);
+                    const float i2c = length(main_o - f_is.p);
                     if (double(i2c) < 1e-10)
                         wdd = 0.f;
                     else {
@@ -316,14 +393,14 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iis
                         if (cam_index[i] >= 0) {
                             const int rx = int(rng.uniform_u32(uint32_t(hemi)));
                             const int ry = int(rng.uniform_u32(uint32_t(hemi)));
-                            L = L + estimate_direct_nn(fh.is, fh.bsdf, rx, ry, cams[cam_index[i]], nn_films + size_t(cam_index[i]) * hemi * hemi * 3, hemi,
+                            L = L + estimate_direct_nn(f_is, f_bsdf, rx, ry, cams[cam_index[i]], nn_films + size_t(cam_index[i]) * hemi * hemi * 3, hemi,
                                                        jac, rng);
                         }
                     }
                 }
             if (samples_taken > 0) {
                 L = sdiv(L, float(samples_taken));
-                const F3 v = fh.beta * L;
+                const F3 v = f_beta * L;
                 res = make_float4(v.x, v.y, v.z, 0.5f);
             } else {
                 res = make_float4(0.f, 0.f, 0.f, 0.5f);
@@ -333,18 +410,29 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iis
     }
 }
 
-void launch_iispt_hemi_points(const DScene &S, const iile_iispt_task &T, int nx, int ny, uint8_t *valid, float *pos3, float *dir3, int *spill,
-                              const LaunchCfg &cfg) {
-    const int n = nx * ny;
-    const int blocks = std::max(1, std::min((n + kIisptBlock - 1) / kIisptBlock, cfg.n_cus * 4));
-    hipLaunchKernelGGL(k_iispt_hemi_points, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, T, nx, ny, valid, pos3, dir3, spill);
+void launch_iispt_first_hits(const DScene &S, const iile_iispt_task &T, const IisptItems &I, int *spill, uint32_t *host_active, const LaunchCfg &cfg) {
+    const int blocks = std::max(1, std::min((I.n_items + kIisptBlock - 1) / kIisptBlock, cfg.n_cus * 6));
+    hipLaunchKernelGGL(k_iispt_begin, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, T, I);
+    // find_intersection's loop: trace, then one vertex step; again while some item follows a specular bounce
+    for (int bounce = 0; bounce < 24; ++bounce) {
+        (void)hipMemsetAsync(I.n_active, 0, sizeof(uint32_t), cfg.stream);
+        hipLaunchKernelGGL(k_iispt_trace, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, I, spill);
+        hipLaunchKernelGGL(k_iispt_vertex, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, T, I);
+        *host_active = 0;
+        if (hipMemcpyAsync(host_active, I.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, cfg.stream) != hipSuccess) return;
+        if (hipStreamSynchronize(cfg.stream) != hipSuccess) return;
+        if (*host_active == 0) break;
+    }
 }
-void launch_iispt_gather(const DScene &S, const iile_iispt_task &T, int nx, int ny, const DHemiCam *cams, const float *nn_films, const float *jac,
-                         float4 *out, int *spill, const LaunchCfg &cfg) {
+void launch_iispt_hemi_out(const DScene &S, const IisptItems &I, uint8_t *valid, float *pos3, float *dir3, const LaunchCfg &cfg) {
+    const int blocks = std::max(1, std::min((I.n_hemi + kIisptBlock - 1) / kIisptBlock, cfg.n_cus * 6));
+    hipLaunchKernelGGL(k_iispt_hemi_out, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, I, valid, pos3, dir3);
+}
+void launch_iispt_gather(const DScene &S, const iile_iispt_task &T, const IisptItems &I, int ny, const DHemiCam *cams, const float *nn_films,
+                         const float *jac, float4 *out, const LaunchCfg &cfg) {
     const int n = (T.x1 - T.x0) * (T.y1 - T.y0);
-    const int blocks = std::max(1, std::min((n + kIisptBlock - 1) / kIisptBlock, cfg.n_cus * 4));
-    hipLaunchKernelGGL(k_iispt_gather, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, T, nx, ny, cams, nn_films, jac, out,
-                       spill);
+    const int blocks = std::max(1, std::min((n + kIisptBlock - 1) / kIisptBlock, cfg.n_cus * 6));
+    hipLaunchKernelGGL(k_iispt_gather, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, T, I, ny, cams, nn_films, jac, out);
 }
 
 }  // namespace iile

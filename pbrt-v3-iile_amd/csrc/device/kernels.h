@@ -99,10 +99,18 @@ struct DHemiCam {  // a hemi point's HemisphericCamera as the gather uses it (ca
     float look[3], origin[3];
     int valid;
 };
-void launch_iispt_hemi_points(const DScene &S, const iile_iispt_task &T, int nx, int ny, uint8_t *valid, float *pos3, float *dir3, int *spill,
-                              const LaunchCfg &cfg);
-void launch_iispt_gather(const DScene &S, const iile_iispt_task &T, int nx, int ny, const DHemiCam *cams, const float *nn_films, const float *jac,
-                         float4 *out, int *spill, const LaunchCfg &cfg);
+// Per-item records of the gather's small wavefront pipeline (float4 planes of n_items each; layout in iispt.hip)
+struct IisptItems {
+    float4 *ro, *rd, *beta, *hit, *pf;
+    uint32_t *idx;
+    uint32_t *n_active;
+    int n_items, n_hemi, nx;
+};
+// camera samples + find_intersection for every item (hemi points, then film pixels); synchronises cfg.stream
+void launch_iispt_first_hits(const DScene &S, const iile_iispt_task &T, const IisptItems &I, int *spill, uint32_t *host_active, const LaunchCfg &cfg);
+void launch_iispt_hemi_out(const DScene &S, const IisptItems &I, uint8_t *valid, float *pos3, float *dir3, const LaunchCfg &cfg);
+void launch_iispt_gather(const DScene &S, const iile_iispt_task &T, const IisptItems &I, int ny, const DHemiCam *cams, const float *nn_films,
+                         const float *jac, float4 *out, const LaunchCfg &cfg);
 
 // kernel-level entry points for parity tests
 void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, float4 *hits, int any_hit,
