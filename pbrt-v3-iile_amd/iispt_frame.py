@@ -1,0 +1,86 @@
+"""The indirect pass of the IISPT integrator, end to end on the GPU (BASELINE config 5).
+
+IisptRenderRunner::run (src/integrators/iisptrenderrunner.cpp:216-596) per task of the schedule
+(IisptScheduleMonitor::next_task, src/integrators/iisptschedulemonitor.cpp:40-79: square tasks of NUMBER_TILES = 10
+tiles of `radius` pixels, the radius shrinking by sqrt(0.795...) after every sweep of the frame):
+
+    hemi points of the task  --iile_iispt_hemi_points-->  probe cameras
+    probe pass               --iile_render_probes------>  intensity / normals / distance images (HBM)
+    normalizeMapsDownstream, IISPTNet, transformMapsUpstream (iispt_nn.py, PyTorch-ROCm, HBM)
+    per-pixel gather         --iile_iispt_gather------->  {f_beta * L, weight} per pixel (HBM)
+    IisptFilmMonitor::add_n_samples (src/integrators/iisptfilmmonitor.cpp:47-72): sums of RGB and weight per pixel
+
+Nothing but the hemi points' positions (a few KB per task) crosses PCIe. No trained weights ship with the reference:
+with the default random-initialised network the numbers mean nothing; a checkpoint of the reference's ml/ training
+loads into IISPTNet unchanged.
+"""
+import math
+
+import numpy as np
+import torch
+
+NUMBER_TILES = 10  # iisptschedulemonitor.h:33
+
+
+def schedule(bounds, n_tasks, radius_start=100.0, update_multiplier=math.sqrt(0.79541357)):
+    """IisptScheduleMonitor::next_task for task numbers 0 .. n_tasks - 1 over film bounds (x0, y0, x1, y1):
+    yields (x0, y0, x1, y1, tilesize)."""
+    bx0, by0, bx1, by1 = bounds
+    radius, nextx, nexty = float(radius_start), bx0, by0
+    for _ in range(n_tasks):
+        eff = max(1, int(math.floor(radius)))
+        size = eff * NUMBER_TILES
+        yield nextx, nexty, min(nextx + size, bx1), min(nexty + size, by1), eff
+        nextx += size
+        if nextx >= bx1:
+            nextx = bx0
+            nexty += size
+        if nexty >= by1:
+            nexty = by0
+            radius *= float(np.float32(update_multiplier))
+
+
+class IisptFrame:
+    """Accumulates the indirect film of IisptFilmMonitor over tasks; everything stays in HBM."""
+
+    def __init__(self, binding, gpu_scene, pipeline, rng_seed=0):
+        self.b, self.gpu, self.pipe = binding, gpu_scene, pipeline
+        h, w = gpu_scene.host.film_shape
+        self.film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")  # r, g, b sums and the weight sum
+        self.counter = 0       # sampler_pixel_counter.x of the (single) runner
+        self.rng_seed = rng_seed
+        self.stats = {"tasks": 0, "hemi_points": 0, "probes": 0, "pixels": 0}
+
+    @torch.no_grad()
+    def run_task(self, x0, y0, x1, y1, tilesize):
+        task = self.b.IisptTask(x0, y0, x1, y1, tilesize, self.counter, self.rng_seed)
+        nx, ny = task.grid()
+        valid, pos, dr = self.gpu.iispt_hemi_points(task)
+        sel = valid.reshape(-1) == 1
+        nn = torch.zeros((ny * nx, 32, 32, 3), dtype=torch.float32, device="cuda")
+        if sel.any():
+            pred, _, _, _ = self.pipe(pos.reshape(-1, 3)[sel], dr.reshape(-1, 3)[sel])
+            # the gather reads the network's own row order (ImageFilm: row 0 = top scanline); the pipeline hands back raster order
+            nn[torch.from_numpy(sel).cuda()] = torch.flip(pred, dims=(1,))
+        h, w = y1 - y0, x1 - x0
+        out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+        self.gpu.iispt_gather(task, valid, pos, dr, nn_device_ptr=nn.data_ptr(), out_device_ptr=out.data_ptr())
+        torch.cuda.synchronize()
+        self.film[y0:y1, x0:x1] += out  # add_n_samples
+        self.counter += nx * ny + w * h
+        self.rng_seed += w * h
+        self.stats["tasks"] += 1
+        self.stats["hemi_points"] += nx * ny
+        self.stats["probes"] += int(sel.sum())
+        self.stats["pixels"] += w * h
+
+    def run(self, n_tasks, radius_start=100.0):
+        h, w = self.gpu.host.film_shape
+        for t in schedule((0, 0, w, h), n_tasks, radius_start):
+            self.run_task(*t)
+        return self.image()
+
+    def image(self):
+        """IisptFilmMonitor::to_intensity_film: rgb sums over weight where a sample was recorded."""
+        wgt = self.film[..., 3:4]
+        return torch.where(wgt > 0, self.film[..., :3] / wgt.clamp_min(1e-30), torch.zeros_like(self.film[..., :3]))

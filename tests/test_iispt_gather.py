@@ -97,3 +97,39 @@ def test_gather_in_a_textured_room_with_specular_chains(binding, oracle, tmp_pat
     torch.cuda.synchronize()
     ref = oracle.iispt_gather(scene, task, valid, pos, dr, nn)
     assert _bits_equal(out_t.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_iispt_frame_end_to_end(binding):
+    """BASELINE config 5's data flow on a small frame: schedule -> hemi points -> probe pass -> network (random weights) ->
+    gather -> film monitor, everything resident in HBM. With an untrained network only structure can be asserted: every
+    pixel whose camera ray finds a scattering surface gets exactly one sample of weight 0.5 per sweep, values are finite
+    and non-negative, and a second sweep (smaller radius, other random streams) doubles the weights."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+    frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
+    scene = binding.HostScene(xres=96, yres=80, spp=1)
+    gpu = binding.GpuScene(scene)
+    torch.manual_seed(0)
+    pipe = nn_mod.IisptPipeline(gpu)
+    frame = frame_mod.IisptFrame(binding, gpu, pipe)
+    tasks = list(frame_mod.schedule((0, 0, 96, 80), 100, radius_start=4.0))
+    sweep = [t for t in tasks if t[4] == 4]
+    assert len(sweep) == 3 * 2 and sweep[0] == (0, 0, 40, 40, 4) and sweep[-1] == (80, 40, 96, 80, 4)
+    for t in sweep:
+        frame.run_task(*t)
+    w1 = frame.film[..., 3].clone()
+    assert set(torch.unique(w1).tolist()) <= {0.0, 0.5} and float((w1 == 0.5).float().mean()) > 0.9
+    img = frame.image()
+    assert bool(torch.isfinite(img).all()) and float(img.min()) >= 0
+    assert frame.stats["pixels"] == 96 * 80 and frame.stats["probes"] > 0
+    n3 = [t for t in tasks if t[4] == 3]
+    for t in n3[: (-(-96 // 30)) * (-(-80 // 30))]:
+        frame.run_task(*t)
+    assert torch.equal(frame.film[..., 3], 2 * w1)
