@@ -104,7 +104,7 @@ def test_iispt_frame_end_to_end(binding):
     """BASELINE config 5's data flow on a small frame: schedule -> hemi points -> probe pass -> network (random weights) ->
     gather -> film monitor, everything resident in HBM. With an untrained network only structure can be asserted: every
     pixel whose camera ray finds a scattering surface gets exactly one sample of weight 0.5 per sweep, values are finite
-    and non-negative, and a second sweep (smaller radius, other random streams) doubles the weights."""
+    and non-negative, and a second sweep (smaller radius, other camera samples and random streams) adds as much again."""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
@@ -132,4 +132,6 @@ def test_iispt_frame_end_to_end(binding):
     n3 = [t for t in tasks if t[4] == 3]
     for t in n3[: (-(-96 // 30)) * (-(-80 // 30))]:
         frame.run_task(*t)
-    assert torch.equal(frame.film[..., 3], 2 * w1)
+    w2 = frame.film[..., 3]
+    assert set(torch.unique(w2).tolist()) <= {0.0, 0.5, 1.0}
+    assert abs(float(w2.mean()) / float(w1.mean()) - 2.0) < 0.02  # (a silhouette pixel may find a surface in one sweep only)
