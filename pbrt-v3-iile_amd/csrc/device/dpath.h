@@ -365,8 +365,9 @@ DEV RayCtx make_ray_ctx(F3 o, F3 d) {
     const float dz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
     c.Sx = -dx / dz;
     c.Sy = -dy / dz;
-    c.Sz = 1.f / dz;
     c.inv_dir = F3{1 / d.x, 1 / d.y, 1 / d.z};  // bvh.cpp:666
+    // Sz = 1.f / dz with dz the kz-th component of d: the quotient invDir already holds (one IEEE division less per ray)
+    c.Sz = kz == 0 ? c.inv_dir.x : (kz == 1 ? c.inv_dir.y : c.inv_dir.z);
     c.neg_mask = (c.inv_dir.x < 0 ? 1 : 0) | (c.inv_dir.y < 0 ? 2 : 0) | (c.inv_dir.z < 0 ? 4 : 0) | (kz << 4);
     if (!(fabsf(c.inv_dir.x) < IILE_INF && fabsf(c.inv_dir.y) < IILE_INF && fabsf(c.inv_dir.z) < IILE_INF)) c.neg_mask |= 0x80;
     return c;
@@ -936,24 +937,74 @@ DEV void trav_interior4(Trav &t, const StackRef &sr, const float4 mnx, const flo
     else
         trav_pop<false>(t, sr, nullptr);
 }
+// The same step for any-hit rays (BVHAccel::IntersectP, bvh.cpp:702-738) in the uninstrumented kernels: whether SOME
+// primitive is hit does not depend on the order the tree is walked in, and ray.tMax never shrinks, so the reference's
+// near / far ordering (three dirIsNeg decisions and the selects that apply them to four refs and keys) is dropped:
+// enter the first visitable slot, defer the rest as they come. Only the visit counters depend on the order, and the
+// instrumented kernels keep the ordered binary walk.
+DEV void trav_interior4_any(Trav &t, const StackRef &sr, const float4 mnx, const float4 mny, const float4 mnz, const float4 mxx,
+                            const float4 mxy, const float4 mxz, const float4 refs) {
+    const RayCtx &rc = t.rc;
+    const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
+    const v2f x0a = v2f{nx ? mxx.x : mnx.x, nx ? mxx.y : mnx.y}, x0b = v2f{nx ? mxx.z : mnx.z, nx ? mxx.w : mnx.w};
+    const v2f x1a = v2f{nx ? mnx.x : mxx.x, nx ? mnx.y : mxx.y}, x1b = v2f{nx ? mnx.z : mxx.z, nx ? mnx.w : mxx.w};
+    const v2f y0a = v2f{ny ? mxy.x : mny.x, ny ? mxy.y : mny.y}, y0b = v2f{ny ? mxy.z : mny.z, ny ? mxy.w : mny.w};
+    const v2f y1a = v2f{ny ? mny.x : mxy.x, ny ? mny.y : mxy.y}, y1b = v2f{ny ? mny.z : mxy.z, ny ? mny.w : mxy.w};
+    const v2f z0a = v2f{nz ? mxz.x : mnz.x, nz ? mxz.y : mnz.y}, z0b = v2f{nz ? mxz.z : mnz.z, nz ? mxz.w : mnz.w};
+    const v2f z1a = v2f{nz ? mnz.x : mxz.x, nz ? mnz.y : mxz.y}, z1b = v2f{nz ? mnz.z : mxz.z, nz ? mnz.w : mxz.w};
+    const float fox = rc.ox, foy = rc.oy, foz = rc.oz, fix = rc.inv_dir.x, fiy = rc.inv_dir.y, fiz = rc.inv_dir.z;
+    const v2f ox = v2f{fox, fox}, oy = v2f{foy, foy}, oz = v2f{foz, foz}, ix = v2f{fix, fix}, iy = v2f{fiy, fiy},
+              iz = v2f{fiz, fiz}, sc = v2f{kSlabScale, kSlabScale};
+    const v2f tx0a = (x0a - ox) * ix, tx0b = (x0b - ox) * ix;
+    const v2f tx1a = (x1a - ox) * ix * sc, tx1b = (x1b - ox) * ix * sc;
+    const v2f ty0a = (y0a - oy) * iy, ty0b = (y0b - oy) * iy;
+    const v2f ty1a = (y1a - oy) * iy * sc, ty1b = (y1b - oy) * iy * sc;
+    const v2f tz0a = (z0a - oz) * iz, tz0b = (z0b - oz) * iz;
+    const v2f tz1a = (z1a - oz) * iz * sc, tz1b = (z1b - oz) * iz * sc;
+    auto visit = [&](float a0, float b0, float c0, float a1, float b1, float c1) {
+        const float tmin = __builtin_fmaxf(__builtin_fmaxf(a0, b0), c0);
+        const float tmx = __builtin_fminf(__builtin_fminf(a1, b1), c1);
+        return tmin <= tmx && tmx > 0 && tmin < t.tmax;
+    };
+    const bool v0 = visit(tx0a.x, ty0a.x, tz0a.x, tx1a.x, ty1a.x, tz1a.x);
+    const bool v1 = visit(tx0a.y, ty0a.y, tz0a.y, tx1a.y, ty1a.y, tz1a.y);
+    const bool v2 = visit(tx0b.x, ty0b.x, tz0b.x, tx1b.x, ty1b.x, tz1b.x);
+    const bool v3 = visit(tx0b.y, ty0b.y, tz0b.y, tx1b.y, ty1b.y, tz1b.y);
+    const int r0 = __float_as_int(refs.x), r1 = __float_as_int(refs.y), r2 = __float_as_int(refs.z), r3 = __float_as_int(refs.w);
+    // (the cached tMin of a deferred slot only feeds trav_pop's `tMin < ray.tMax`, already decided: any value below tMax)
+    if (v3 && (v0 || v1 || v2)) stack_push(t, sr, r3, 0.f);
+    if (v2 && (v0 || v1)) stack_push(t, sr, r2, 0.f);
+    if (v1 && v0) stack_push(t, sr, r1, 0.f);
+    if (v0 || v1 || v2 || v3)
+        t.cur = v0 ? r0 : (v1 ? r1 : (v2 ? r2 : r3));
+    else
+        trav_pop<false>(t, sr, nullptr);
+}
 // One interior step of the uninstrumented kernels: the four-wide record, unless a lane of the
 // wavefront carries a NaN-capable ray (or the scene's boxes are not nested, which a BVH built as
 // bvh.cpp:236-402 builds it cannot produce; iile_scene_create checks).
+#ifndef IILE_ANYHIT_UNORDERED
+#define IILE_ANYHIT_UNORDERED 1
+#endif
+template <bool ANY = false>
 DEV void trav_interior_step_fast(const DScene &S, Trav &t, const StackRef &sr) {
     if (__builtin_expect(S.boxes_nested && __ballot(t.rc.neg_mask & 0x80) == 0, 1)) {
         const float4 *w = S.wide4 + 8 * size_t(t.cur < 0 ? 0 : t.cur);
-        trav_interior4(t, sr, w[0], w[1], w[2], w[3], w[4], w[5], w[6], __float_as_uint(w[7].x));
+        if (ANY && IILE_ANYHIT_UNORDERED)
+            trav_interior4_any(t, sr, w[0], w[1], w[2], w[3], w[4], w[5], w[6]);
+        else
+            trav_interior4(t, sr, w[0], w[1], w[2], w[3], w[4], w[5], w[6], __float_as_uint(w[7].x));
     } else {
         const float4 *w = S.wide + 4 * size_t(t.cur < 0 ? 0 : t.cur);
         trav_interior<false>(t, sr, nullptr, w[0], w[1], w[2], w[3]);
     }
 }
-template <bool COUNT>
+template <bool COUNT, bool ANY = false>
 DEV void trav_step(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st) {
     if (COUNT)
         trav_interior_step<true>(S, t, sr, st);
     else
-        trav_interior_step_fast(S, t, sr);
+        trav_interior_step_fast<ANY>(S, t, sr);
 }
 
 // screen-space derivatives of a hit's (u, v): SurfaceInteraction::dudx ... (interaction.h:127-128)
@@ -1053,7 +1104,7 @@ DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack,
     const float4 d4 = make_float4(rd.x, rd.y, rd.z, 0.f);
     trav_begin<COUNT>(S, t, ro, rd, tmax, st);
     while (t.have) {
-        while (t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, st);
+        while (t.have && t.cur >= 0) trav_step<COUNT, ANY_HIT>(S, t, sr, st);
         if (t.have && trav_leaf<COUNT, ALPHA>(S, t, sr, st, ANY_HIT, &d4)) return true;
     }
     hit->prim = hit_index(t.hit_prim);

@@ -1,0 +1,223 @@
+// kcommon.h — what the kernel translation units share: block geometry, wavefront-aggregated queue appends, the
+// persistent work feed, the layout of the per-pass counters, path -> pixel enumeration.
+// (kernels_trav.hip: extend / shadow / MIS / trace; kernels_shade.hip: shade, light distributions;
+//  kernels.hip: generation, film, probes and the remaining launchers; iispt.hip: the IISPT runner's gather.)
+#pragma once
+#include <algorithm>
+
+#include "dpath.h"
+#include "kernels.h"
+
+namespace iile {
+
+// Phase scheduling of the traversal kernels: 1 = one step per iteration for the whole
+// wavefront, interior or leaf, whichever has more lanes waiting; 0 = strict while-while.
+#ifndef IILE_FLAT_EXTEND
+#define IILE_FLAT_EXTEND 1
+#endif
+#ifndef IILE_FLAT_SHADOW
+#define IILE_FLAT_SHADOW 1
+#endif
+#ifndef IILE_FLAT_MIS
+#define IILE_FLAT_MIS 1
+#endif
+#ifndef IILE_TRAV_WAVES
+#define IILE_TRAV_WAVES 6  // waves per SIMD = resident blocks per CU of the traversal kernels (<= 80 VGPRs, no scratch)
+#endif
+#ifndef IILE_VOTE_NUM
+#define IILE_VOTE_NUM 4
+#define IILE_VOTE_DEN 5
+#endif
+
+constexpr int kBlock = 256;            // 4 wavefronts
+constexpr int kWavesPerBlock = kBlock / 64;
+#ifndef IILE_SHADE_CHUNK
+#define IILE_SHADE_CHUNK 1024
+#endif
+constexpr int kShadeChunk = IILE_SHADE_CHUNK;  // hits one k_shade wavefront regroups by shading class at a time
+constexpr int kTile = 16;
+
+DEV int lane_id() { return int(threadIdx.x & 63); }
+DEV uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+// Wavefront-aggregated append: one atomic per wavefront reserves a contiguous
+// run of queue slots; lanes take slots in lane order.
+DEV uint32_t wave_append(bool emit, uint32_t *counter) {
+    const unsigned long long mask = __ballot(emit);
+    if (mask == 0) return 0;
+    const uint32_t n = uint32_t(__popcll(mask));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader);
+    return base + lanes_below(mask);
+}
+// Block-reserved queue output. A returning atomic on one queue-tail word per
+// wavefront per iteration saturates that word (~88 atomics/us on MI355X) long
+// before the kernels run out of anything else, so a wavefront instead reserves
+// kOutBlock slots at a time with ONE atomic and appends into its private block
+// (ballot + mbcnt, no memory traffic). Slots it cannot use — the < 64 left when a
+// block runs out, and the tail of its last block — are padded with an INVALID
+// record that consumers skip. The queue length a consumer sees is the number of
+// reserved slots.
+constexpr uint32_t kOutBlock = 1024;
+constexpr uint32_t kInvalid = 0xffffffffu;
+struct WaveOut {
+    uint32_t cur, end;
+};
+template <typename Pad>
+DEV uint32_t out_take(WaveOut &o, uint32_t *counter, bool emit, Pad pad) {
+    const unsigned long long mask = __ballot(emit);
+    const uint32_t n = uint32_t(__popcll(mask));
+    if (n == 0) return 0;
+    if (o.end - o.cur < n) {
+        const uint32_t left = o.end - o.cur;  // < n <= 64
+        if (uint32_t(lane_id()) < left) pad(o.cur + uint32_t(lane_id()));
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(counter, kOutBlock);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        o.cur = base;
+        o.end = base + kOutBlock;
+    }
+    const uint32_t slot = o.cur + lanes_below(mask);
+    o.cur += n;
+    return slot;
+}
+template <typename Pad>
+DEV void out_flush(WaveOut &o, Pad pad) {
+    for (uint32_t sl = o.cur + uint32_t(lane_id()); sl < o.end; sl += 64) pad(sl);
+    o.cur = o.end;
+}
+
+DEV unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+DEV void flush_counter(unsigned long long *dst, unsigned long long v) {
+    v = wave_sum(v);
+    if (lane_id() == 0 && v) atomicAdd(dst, v);
+}
+static inline int grid_blocks(uint32_t n, int n_cus, int per_cu) {
+    long want = (long(n) + kBlock - 1) / kBlock;
+    long cap = long(n_cus) * per_cu;
+    if (want < 1) want = 1;
+    return int(want < cap ? want : cap);
+}
+
+// layout of PassBuffers::counts (zeroed once per pass)
+constexpr int kCntRay = 0;       // [bounce] rays in the extend queue
+constexpr int kCntNee = 16;      // [bounce] NEE records
+constexpr int kCntShade = 32;    // [bounce] hits to shade
+constexpr int kCntExtHead = 48;  // [bounce] chunk cursor of the extend queue
+constexpr int kCntConHead = 64;  // [bounce] chunk cursor of the NEE queue (shadow kernel)
+constexpr int kCntMisHead = 80;  // [bounce] chunk cursor of the NEE queue (MIS kernel)
+constexpr int kCntShdHead = 96;  // [bounce] chunk cursor of the shade queue
+constexpr int kCntMis = 112;     // [bounce] MIS rays (a dense queue of its own: most NEE records have none)
+
+// Persistent-wavefront work feed. A wavefront reserves kChunk consecutive queue
+// slots with one atomic and hands them to its lanes as they go idle, so lanes
+// whose ray terminated early pick up new rays instead of waiting for the slowest
+// lane of the wavefront (the classic while-while + dynamic fetch scheme, sized
+// for 64 lanes). 512-slot chunks keep the head word at a few atomics per
+// microsecond, far below its ~88/us saturation point.
+constexpr uint32_t kChunk = 512;
+#ifndef IILE_REFILL_IDLE
+#define IILE_REFILL_IDLE 16
+#endif
+constexpr int kRefillIdle = IILE_REFILL_IDLE;  // refill once this many lanes are idle (or all)
+struct WaveFeed {
+    uint32_t cur, end;
+    bool exhausted;
+};
+// `warm(first_slot)` is called once per new chunk: the wavefront touches every 128-byte
+// line of the chunk's records (lane l -> records first+8l .. first+8l+7), so the per-lane
+// refill loads that follow hit L2 instead of paying an HBM round trip each time a few
+// lanes go idle.
+template <typename Warm>
+DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint32_t *slot, Warm warm) {
+    const unsigned long long mask = __ballot(idle);
+    const uint32_t n_idle = uint32_t(__popcll(mask));
+    if (f.cur == f.end) {
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(head, kChunk);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        if (base >= count) {
+            f.exhausted = true;
+            f.cur = f.end = 0;
+            return false;
+        }
+        f.cur = base;
+        f.end = (base + kChunk < count) ? base + kChunk : count;
+        warm(base);
+    }
+    const uint32_t avail = f.end - f.cur;
+    const uint32_t take = n_idle < avail ? n_idle : avail;
+    const uint32_t rank = lanes_below(mask);
+    *slot = f.cur + rank;
+    f.cur += take;
+    return idle && rank < take;
+}
+
+// touch one float4 of every 128-byte line of records [first, first + kChunk) of a float4 plane
+static_assert(kChunk == 64 * 8, "one lane per 128-byte line of a chunk");
+DEV void warm_plane(const float4 *plane_base, uint32_t first, uint32_t limit) {
+    const uint32_t i = first + uint32_t(lane_id()) * 8u;
+    if (i < limit) {
+        const float v = plane_base[i].x;
+        asm volatile("" ::"v"(v));  // keep the load; the value itself is not needed
+    }
+}
+
+// pid -> (pixel, sample) for tile enumeration: pid = ((tile_slot*256 + pix)*kc + kk)
+DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, int *py, uint32_t *k) {
+    if (P.list_px) {
+        *px = P.list_px[pid];
+        *py = P.list_py[pid];
+        *k = uint32_t(P.list_k[pid]);
+        return true;
+    }
+    const uint32_t kk = pid % uint32_t(P.kc);
+    const uint32_t pt = pid / uint32_t(P.kc);
+    const uint32_t pix = pt & 255u, slot = pt >> 8;
+    if (P.probe_mode) {
+        // every probe has its own film: tile `slot % probe_tiles` of probe `slot / probe_tiles`; RenderView skips the
+        // pixels outside the film's pixel bounds (iispt_d.cpp:428-429)
+        const int tile = int(slot % uint32_t(P.probe_tiles));
+        const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
+        *px = S.samp_x0 + tx * kTile + int(pix & 15u);
+        *py = S.samp_y0 + ty * kTile + int(pix >> 4);
+        *k = uint32_t(P.k0) + kk;
+        return *px >= S.crop_x0 && *py >= S.crop_y0 && *px < S.crop_x1 && *py < S.crop_y1;
+    }
+    const int tile = P.tile_of_slot ? P.tile_of_slot[P.slot0 + int(slot)] : P.slot0 + int(slot);
+    const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
+    *px = S.samp_x0 + tx * kTile + int(pix & 15u);
+    *py = S.samp_y0 + ty * kTile + int(pix >> 4);
+    *k = uint32_t(P.k0) + kk;
+    return *px < S.samp_x1 && *py < S.samp_y1;
+}
+
+// A film position that is a whole number (u == 0, or float(px) + u rounded to px or px + 1 where the pixel
+// coordinate is large) puts the sample into two pixels along that axis under the one-pixel box filter
+// (FilmTile::AddSample, film.h:159-166: pixels ceil(pFilm - 1) .. floor(pFilm)). Rare (1080p x 64 spp: ~1e-4 of the
+// samples); they are listed here and the pixels they touch are finished exactly by iile_render (api.hip).
+DEV void flag_whole_film_position(const PassBuffers &B, uint32_t pid, int px, int py, uint32_t k, float pfx, float pfy, float u0,
+                                  float u1) {
+    if (!B.flag_count) return;
+    if (pfx == float(px) || pfx == float(px + 1) || pfy == float(py) || pfy == float(py + 1)) {
+        const uint32_t at = atomicAdd(B.flag_count, 1u);
+        if (at < kMaxFlagged) {
+            float *r = B.flag_rec + 6 * size_t(at);
+            r[0] = b2f(uint32_t(px));
+            r[1] = b2f(uint32_t(py));
+            r[2] = b2f(k | (u0 == 0.f ? 1u << 30 : 0u) | (u1 == 0.f ? 1u << 31 : 0u));  // + "the offset is an exact zero"
+            r[3] = pfx;
+            r[4] = pfy;
+            r[5] = b2f(pid);  // its path id in the pass that made it
+        }
+    }
+}
+
+
+}  // namespace iile
