@@ -34,6 +34,9 @@ def family(k):
     return fam, product
 
 
+per_dispatch = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> dispatch id -> {counter: value}
+
+
 def load(kinds):
     """{kernel: {counter: sum over dispatches, 'launches': n}}"""
     out = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -46,9 +49,30 @@ def load(kinds):
                     continue
                 out[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 seen[k].add(r["Dispatch_Id"])
+                per_dispatch[k][(kind, int(r["Dispatch_Id"]))][r["Counter_Name"]] = per_dispatch[k][(kind, int(r["Dispatch_Id"]))].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             for k, s in seen.items():
                 out[k]["launches@" + kind] = len(s)
     return out
+
+
+def launches_in_order(fam):
+    """Counters of the product builds of `fam`, launch by launch (= bounce by bounce for the pipeline kernels): the passes
+    run the same command, so the i-th dispatch of a kernel family is the same launch in every pass."""
+    by_kind = collections.defaultdict(list)
+    for k, d in per_dispatch.items():
+        f, product = family(k)
+        if f != fam or not product:
+            continue
+        for (kind, did), c in d.items():
+            by_kind[kind].append((did, c))
+    rows = []
+    for kind, lst in by_kind.items():
+        lst.sort()
+        for i, (_, c) in enumerate(lst):
+            while len(rows) <= i:
+                rows.append({})
+            rows[i].update({n: int(v) for n, v in c.items()})
+    return rows
 
 
 # ---- HBM traffic
@@ -92,10 +116,12 @@ for fam, v in fams.items():
             e["valu_busy"] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v["SQ_BUSY_CYCLES"] / 32), 4)
     if v.get("TCC_HIT_sum") or v.get("TCC_MISS_sum"):
         e["l2_hit_rate"] = round(v.get("TCC_HIT_sum", 0.0) / max(v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0), 1.0), 4)
+    if fam in ("k_extend", "k_shade", "k_shadow", "k_mis"):
+        e["per_launch"] = launches_in_order(fam)
     out_f[fam] = e
 if kernels:
     json.dump({"workload": "bench.py --steps 1 --warmup 0 --other-steps 0 (killeroo-simple 1920x1080, 64 spp, 1 GPU)",
-               "note": "counter sums over the launches of one timed bench step, product builds only; lane_util = SQ_THREAD_CYCLES_VALU / "
+               "note": "counter sums over the launches of one timed bench step, product builds only (per_launch: launch by launch = bounce by bounce); lane_util = SQ_THREAD_CYCLES_VALU / "
                        "(64 x SQ_ACTIVE_INST_VALU); valu_busy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs)",
                "families": out_f, "kernels": kernels}, open(os.path.join(dst, f"{tag}_pmc_lanes.json"), "w"), indent=1)
 print(json.dumps({"traffic_families": list(fams.keys()), "lanes": out_f}, indent=1)[:3000])
