@@ -868,3 +868,103 @@ def test_roughness_from_a_constant_image_matches_the_constant(binding, oracle, t
         (tmp_path / "s.pbrt").write_text(plain[:i] + mat + plain[j:])
         films.append(oracle.render(binding.HostScene(path=str(tmp_path / "s.pbrt")), trig_mode=ob.TRIG_LIBM)[0])
     assert films[0][..., 1].max() > 0 and np.allclose(films[1], films[0], rtol=1e-4, atol=0)
+
+
+def test_triangle_solid_angle_like_the_reference_test(binding, oracle, tmp_path):
+    """Triangle.SolidAngle of src/tests/shapes.cpp:273-328: the solid angle a random triangle subtends from a point
+    pushed 3 units outside the [-10, 10]^3 cube, estimated through Triangle::Sample (sum 1 / (n pdf) over 64 K (2, 3)
+    radical-inverse points), must agree with the closed form to 1.5 % (absolute below 1e-4). The reference calls
+    Triangle::SolidAngle for the closed form; that function is not on the path, the spherical-triangle area (Van
+    Oosterom & Strackee) is evaluated here in float64."""
+    def closed_form(tri, pc):
+        a, b, c = (tri - pc).astype(np.float64)
+        la, lb, lc = np.linalg.norm(a), np.linalg.norm(b), np.linalg.norm(c)
+        num = abs(np.dot(a, np.cross(b, c)))
+        den = la * lb * lc + np.dot(a, b) * lc + np.dot(a, c) * lb + np.dot(b, c) * la
+        return 2 * np.arctan2(num, den) % (2 * np.pi)
+
+    rng = np.random.default_rng(100)
+    checked = 0
+    for scene_i in range(7):
+        tris, pcs = [], []
+        while len(tris) < 7:
+            v = rng.uniform(-10, 10, (3, 3))
+            if (np.cross(v[1] - v[0], v[2] - v[0]) ** 2).sum() < 1e-20:
+                continue
+            pc = rng.uniform(-10, 10, 3)
+            pc[rng.integers(0, 3)] = -13.0 if rng.random() > .5 else 13.0
+            tris.append(v.astype(np.float32))
+            pcs.append(pc.astype(np.float32))
+        body = "".join('AttributeBegin\nAreaLightSource "diffuse" "bool twosided" ["true"]\nShape "trianglemesh" "point P" [%s] '
+                       '"integer indices" [0 1 2]\nAttributeEnd\n' % " ".join("%.9g" % x for x in t.ravel()) for t in tris)
+        path = tmp_path / f"sa{scene_i}.pbrt"
+        path.write_text('Camera "perspective"\nFilm "image" "integer xresolution" [4] "integer yresolution" [4]\n'
+                        'Sampler "halton" "integer pixelsamples" [1]\nWorldBegin\n' + body + "WorldEnd\n")
+        scene = binding.HostScene(path=str(path))
+        for light in range(7):
+            by_sampling, _ = oracle.light_solid_angle(scene, light, pcs[light], 64 * 1024)
+            exact = closed_form(tris[light], pcs[light])
+            err = abs(by_sampling - exact) if min(abs(by_sampling), abs(exact)) < 1e-4 else abs((by_sampling - exact) / exact)
+            assert err < .015, (scene_i, light, by_sampling, exact)
+            checked += 1
+    assert checked == 49  # the reference runs 50 triangles
+
+
+def test_bsdf_reciprocity_and_energy(binding, oracle, tmp_path):
+    """Properties every reflective BSDF of the path must have, on the oracle's BSDF::f / Sample_f / Pdf for each material
+    kind the loader produces (matte incl. Oren-Nayar, plastic, uber incl. its specular lobe, mirror, glass): Helmholtz
+    reciprocity of the non-specular part f(wo, wi) = f(wi, wo); Sample_f's returned pdf equals Pdf() of the sampled
+    direction for non-specular samples; and the sampled estimate of the directional albedo E[f cos / pdf] stays within
+    [0, 1 + 2 %] (no material creates energy). A transcription slip in a lobe cannot hide behind device == oracle."""
+    path = tmp_path / "mats.pbrt"
+    path.write_text('''Camera "perspective"
+Film "image" "integer xresolution" [4] "integer yresolution" [4]
+Sampler "halton" "integer pixelsamples" [1]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "color L" [1 1 1]
+  Shape "sphere" "float radius" [1]
+AttributeEnd
+Material "matte" "color Kd" [.6 .5 .4]
+Shape "trianglemesh" "point P" [0 0 5 1 0 5 0 1 5] "integer indices" [0 1 2]
+Material "matte" "color Kd" [.6 .5 .4] "float sigma" [30]
+Shape "trianglemesh" "point P" [0 0 6 1 0 6 0 1 6] "integer indices" [0 1 2]
+Material "plastic" "color Kd" [.3 .3 .4] "color Ks" [.4 .4 .4] "float roughness" [.1]
+Shape "trianglemesh" "point P" [0 0 7 1 0 7 0 1 7] "integer indices" [0 1 2]
+Material "uber" "color Kd" [.25 .3 .2] "color Ks" [.3 .3 .3] "color Kr" [.2 .2 .2] "float roughness" [.2]
+Shape "trianglemesh" "point P" [0 0 8 1 0 8 0 1 8] "integer indices" [0 1 2]
+Material "mirror" "color Kr" [.9 .9 .9]
+Shape "trianglemesh" "point P" [0 0 9 1 0 9 0 1 9] "integer indices" [0 1 2]
+Material "glass" "color Kr" [1 1 1] "color Kt" [1 1 1] "float index" [1.5]
+Shape "trianglemesh" "point P" [0 0 10 1 0 10 0 1 10] "integer indices" [0 1 2]
+WorldEnd
+''')
+    scene = binding.HostScene(path=str(path))
+    n_mat = scene.info["n_materials"]
+    assert n_mat >= 6
+    rng = np.random.default_rng(9)
+
+    def hemi(n):
+        v = rng.normal(size=(n, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        v[:, 2] = np.abs(v[:, 2]) * 0.98 + 0.02
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    for mat in range(n_mat):
+        wo, wi = hemi(400), hemi(400)
+        a = oracle.bsdf_eval(scene, mat, wo, wi, trig_mode=ob.TRIG_LIBM)[:, :3]
+        b = oracle.bsdf_eval(scene, mat, wi, wo, trig_mode=ob.TRIG_LIBM)[:, :3]
+        assert np.allclose(a, b, rtol=2e-4, atol=1e-7), f"material {mat}: f is not reciprocal"
+        assert (a >= 0).all()
+        # Sample_f against Pdf, and the albedo estimate, for a few outgoing directions
+        for w in hemi(3):
+            u = rng.uniform(size=(20000, 2)).astype(np.float32)
+            s = oracle.bsdf_sample(scene, mat, np.repeat(w[None], len(u), 0), u, trig_mode=ob.TRIG_LIBM)
+            wi_s, f_s, pdf_s = s[:, :3], s[:, 3:6], s[:, 6]
+            ok = pdf_s > 0
+            if not ok.any():
+                continue
+            pdf_again = oracle.bsdf_eval(scene, mat, np.repeat(w[None], int(ok.sum()), 0), wi_s[ok], trig_mode=ob.TRIG_LIBM)[:, 3]
+            assert np.allclose(pdf_again, pdf_s[ok], rtol=2e-3, atol=1e-6), f"material {mat}: Sample_f's pdf is not Pdf()"
+            albedo = (f_s[ok] * np.abs(wi_s[ok, 2:3]) / pdf_s[ok, None]).sum(0) / len(u)
+            assert (albedo >= 0).all() and (albedo <= 1.02).all(), (mat, albedo)

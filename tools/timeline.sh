@@ -4,14 +4,16 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/timeline
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 > $O/t.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --other-steps 0 > $O/t.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob('$O/t/*/*kernel_trace.csv')[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-# last pipeline run = after the last k_generate
-idx=max(i for i,r in enumerate(rows) if 'k_generate' in r['Kernel_Name'])
+# the last plain pass starts at the last bounce-0 k_extend of the product build (camera rays are made inside it: template
+# arguments <false, ., true>); passes that launch k_generate (instrumented / explicit lists) are not the timed ones
+gen=[i for i,r in enumerate(rows) if 'k_extend<false' in r['Kernel_Name'] and r['Kernel_Name'].split('(')[0].rstrip().endswith('true>')]
+idx=gen[-1] if gen else 0
 out=[]
 for r in rows[idx:]:
     n=r['Kernel_Name'].split('(')[0].replace('void iile::','').replace('iile::','')

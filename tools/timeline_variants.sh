@@ -11,7 +11,10 @@ import csv,glob
 f=glob.glob('$O/t/*/*kernel_trace.csv')[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=max(i for i,r in enumerate(rows) if 'k_generate' in r['Kernel_Name'])
+# the last plain pass starts at the last bounce-0 k_extend of the product build (camera rays are made inside it: template
+# arguments <false, ., true>); passes that launch k_generate (instrumented / explicit lists) are not the timed ones
+gen=[i for i,r in enumerate(rows) if 'k_extend<false' in r['Kernel_Name'] and r['Kernel_Name'].split('(')[0].rstrip().endswith('true>')]
+idx=gen[-1] if gen else 0
 out=[]
 for r in rows[idx:idx+12]:
     n=r['Kernel_Name'].split('(')[0].replace('void iile::','').replace('iile::','')
