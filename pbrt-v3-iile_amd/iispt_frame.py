@@ -80,6 +80,61 @@ class IisptFrame:
             self.run_task(*t)
         return self.image()
 
+    @torch.no_grad()
+    def run_batched(self, n_tasks, radius_start=100.0, max_probes=32768, timers=None):
+        """The same film as run(): a task's result depends only on its rectangle, its sampler counter and its seed, all of
+        which the schedule fixes in advance — so the stages run task-major instead of interleaved: hemi points of a group of
+        tasks, ONE probe pass and ONE network call over all their probes (the reference pays a pipe round trip per probe),
+        then the gathers. Groups are cut at max_probes hemi points. timers: dict that receives seconds per stage."""
+        import time
+        h, w = self.gpu.host.film_shape
+        tasks = list(schedule((0, 0, w, h), n_tasks, radius_start))
+
+        def tick(name, t0):
+            if timers is not None:
+                torch.cuda.synchronize()
+                timers[name] = timers.get(name, 0.0) + time.time() - t0
+
+        i = 0
+        while i < len(tasks):
+            group, n_pts = [], 0
+            while i < len(tasks) and (not group or n_pts < max_probes):
+                x0, y0, x1, y1, ts = tasks[i]
+                task = self.b.IisptTask(x0, y0, x1, y1, ts, self.counter, self.rng_seed)
+                nx, ny = task.grid()
+                t0 = time.time()
+                valid, pos, dr = self.gpu.iispt_hemi_points(task)
+                tick("hemi_points", t0)
+                group.append((task, valid, pos, dr, nx, ny))
+                n_pts += nx * ny
+                self.counter += nx * ny + (x1 - x0) * (y1 - y0)
+                self.rng_seed += (x1 - x0) * (y1 - y0)
+                i += 1
+            t0 = time.time()
+            sel = np.concatenate([g[1].reshape(-1) == 1 for g in group])
+            pos_all = np.concatenate([g[2].reshape(-1, 3) for g in group])[sel]
+            dir_all = np.concatenate([g[3].reshape(-1, 3) for g in group])[sel]
+            nn = torch.zeros((n_pts, 32, 32, 3), dtype=torch.float32, device="cuda")
+            if len(pos_all):
+                pred, _, _, _ = self.pipe(pos_all, dir_all)
+                nn[torch.from_numpy(sel).cuda()] = torch.flip(pred, dims=(1,))
+            tick("probes_and_network", t0)
+            first = 0
+            for task, valid, pos, dr, nx, ny in group:
+                t0 = time.time()
+                th, tw = task.y1 - task.y0, task.x1 - task.x0
+                out = torch.empty((th, tw, 4), dtype=torch.float32, device="cuda")
+                self.gpu.iispt_gather(task, valid, pos, dr, nn_device_ptr=nn[first:first + nx * ny].data_ptr(), out_device_ptr=out.data_ptr())
+                self.film[task.y0:task.y1, task.x0:task.x1] += out
+                first += nx * ny
+                tick("gather", t0)
+                self.stats["tasks"] += 1
+                self.stats["hemi_points"] += nx * ny
+                self.stats["probes"] += int((valid == 1).sum())
+                self.stats["pixels"] += tw * th
+        torch.cuda.synchronize()
+        return self.image()
+
     def image(self):
         """IisptFilmMonitor::to_intensity_film: rgb sums over weight where a sample was recorded."""
         wgt = self.film[..., 3:4]

@@ -135,3 +135,10 @@ def test_iispt_frame_end_to_end(binding):
     w2 = frame.film[..., 3]
     assert set(torch.unique(w2).tolist()) <= {0.0, 0.5, 1.0}
     assert abs(float(w2.mean()) / float(w1.mean()) - 2.0) < 0.02  # (a silhouette pixel may find a surface in one sweep only)
+    # task-major staging (one probe pass + one network call per group of tasks) is the same frame: the same samples are
+    # recorded (weights exactly equal); values agree up to the network's batch-size dependent convolution algorithms
+    batched = frame_mod.IisptFrame(binding, gpu, pipe)
+    batched.run_batched(len(sweep) + (-(-96 // 30)) * (-(-80 // 30)), radius_start=4.0, max_probes=150)
+    assert torch.equal(batched.film[..., 3], w2) and batched.stats == frame.stats
+    scale = float(frame.film[..., :3].abs().max())
+    assert float((batched.film[..., :3] - frame.film[..., :3]).abs().max()) <= 2e-3 * scale

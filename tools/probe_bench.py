@@ -1,7 +1,8 @@
 """BASELINE config 5 exercised end to end on one GPU: the IISPT integrator's indirect pass over killeroo-simple —
 hemi points, probe pass, in-process network, per-pixel gather (pbrt-v3-iile_amd/iispt_frame.py) — timed per stage.
 The network has random weights (none ship with the reference), so the image is meaningless; the data flow and the cost are real.
-usage: python tools/probe_bench.py [xres=1920] [yres=1080] [radius_start=10] [sweeps=1] [dtype=bf16|f32]"""
+usage: python tools/probe_bench.py [xres=1920] [yres=1080] [radius_start=10] [sweeps=1] [dtype=bf16|f32]
+IILE_IISPT_BATCHED=0: task by task as the reference's runner; IILE_IISPT_TIMERS=1: seconds per stage (adds syncs)"""
 import importlib
 import json
 import os
@@ -34,8 +35,13 @@ frame = frame_mod.IisptFrame(b, gpu, pipe)
 frame.run_task(0, 0, min(size, xres), min(size, yres), int(radius))  # warm-up: MIOpen kernel selection, workspace
 torch.cuda.synchronize()
 frame = frame_mod.IisptFrame(b, gpu, pipe)
+batched = os.environ.get("IILE_IISPT_BATCHED", "1") != "0"
+timers = {} if os.environ.get("IILE_IISPT_TIMERS") else None
 t0 = time.time()
-img = frame.run(tasks_per_sweep * sweeps, radius_start=radius)
+if batched:
+    img = frame.run_batched(tasks_per_sweep * sweeps, radius_start=radius, timers=timers)
+else:
+    img = frame.run(tasks_per_sweep * sweeps, radius_start=radius)
 torch.cuda.synchronize()
 wall = time.time() - t0
 st = frame.stats
@@ -43,5 +49,6 @@ rec = float((frame.film[..., 3] > 0).float().mean())
 print(json.dumps({"workload": f"IISPT indirect pass, killeroo-simple {xres}x{yres}, radius {radius} -> tasks of {size}^2 px, {sweeps} sweep(s)",
                   "tasks": st["tasks"], "hemi_points": st["hemi_points"], "probes": st["probes"], "pixels": st["pixels"],
                   "wall_s": round(wall, 3), "probes_per_s": round(st["probes"] / wall, 1), "mpixels_gathered_per_s": round(st["pixels"] / wall / 1e6, 3),
+                  "order": "task-major stages (run_batched)" if batched else "task by task (run)", "stage_seconds": timers,
                   "network_dtype": str(dtype).split(".")[-1], "pixels_with_a_sample": round(rec, 4),
                   "image_mean": float(img.mean()), "finite": bool(torch.isfinite(img).all())}))
