@@ -28,14 +28,19 @@ scene = b.HostScene(xres=xres, yres=yres, spp=1)
 gpu = b.GpuScene(scene)
 nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
 frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
+torch.manual_seed(0)
 pipe = nn_mod.IisptPipeline(gpu, dtype=dtype)
 size = int(radius) * frame_mod.NUMBER_TILES
 tasks_per_sweep = -(-xres // size) * -(-yres // size)
+batched = os.environ.get("IILE_IISPT_BATCHED", "1") != "0"
 frame = frame_mod.IisptFrame(b, gpu, pipe)
-frame.run_task(0, 0, min(size, xres), min(size, yres), int(radius))  # warm-up: MIOpen kernel selection, workspace
+# warm-up: MIOpen kernel selection (per batch size: tens of seconds the first time a size is seen), workspace
+if batched:
+    frame.run_batched(tasks_per_sweep * sweeps, radius_start=radius)
+else:
+    frame.run_task(0, 0, min(size, xres), min(size, yres), int(radius))
 torch.cuda.synchronize()
 frame = frame_mod.IisptFrame(b, gpu, pipe)
-batched = os.environ.get("IILE_IISPT_BATCHED", "1") != "0"
 timers = {} if os.environ.get("IILE_IISPT_TIMERS") else None
 t0 = time.time()
 if batched:
