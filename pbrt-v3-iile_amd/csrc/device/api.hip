@@ -1674,7 +1674,9 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
     P.n_tiles_x = (S.samp_x1 - S.samp_x0 + 15) / 16;
     P.n_tiles_y = (S.samp_y1 - S.samp_y0 + 15) / 16;
     P.probe_mode = 1;
-    P.probe_tiles = P.n_tiles_x * P.n_tiles_y;
+    // path slots cover the film's pixel bounds only (no samples are taken elsewhere): 16 x 16 storage tiles over them
+    P.probe_stx = (f.crop_x1 - f.crop_x0 + 15) / 16;
+    P.probe_tiles = P.probe_stx * ((f.crop_y1 - f.crop_y0 + 15) / 16);
     P.tile_rank = 0;
     P.tile_nranks = 1;
     P.k0 = 0;

@@ -181,14 +181,15 @@ DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, i
     const uint32_t pt = pid / uint32_t(P.kc);
     const uint32_t pix = pt & 255u, slot = pt >> 8;
     if (P.probe_mode) {
-        // every probe has its own film: tile `slot % probe_tiles` of probe `slot / probe_tiles`; RenderView skips the
-        // pixels outside the film's pixel bounds (iispt_d.cpp:428-429)
+        // every probe has its own film. RenderView takes no samples outside the film's pixel bounds (iispt_d.cpp:428-429),
+        // so the slots cover those pixels only: storage tile `slot % probe_tiles` of probe `slot / probe_tiles`, laid over
+        // the pixel bounds (not the reference's tile grid over the sample bounds, which k_film_gather keeps for its sums)
         const int tile = int(slot % uint32_t(P.probe_tiles));
-        const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
-        *px = S.samp_x0 + tx * kTile + int(pix & 15u);
-        *py = S.samp_y0 + ty * kTile + int(pix >> 4);
+        const int tx = tile % P.probe_stx, ty = tile / P.probe_stx;
+        *px = S.crop_x0 + tx * kTile + int(pix & 15u);
+        *py = S.crop_y0 + ty * kTile + int(pix >> 4);
         *k = uint32_t(P.k0) + kk;
-        return *px >= S.crop_x0 && *py >= S.crop_y0 && *px < S.crop_x1 && *py < S.crop_y1;
+        return *px < S.crop_x1 && *py < S.crop_y1;
     }
     const int tile = P.tile_of_slot ? P.tile_of_slot[P.slot0 + int(slot)] : P.slot0 + int(slot);
     const int tx = tile % P.n_tiles_x, ty = tile / P.n_tiles_x;
@@ -196,6 +197,13 @@ DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, i
     *py = S.samp_y0 + ty * kTile + int(pix >> 4);
     *k = uint32_t(P.k0) + kk;
     return *px < S.samp_x1 && *py < S.samp_y1;
+}
+
+// probe pass: the record ((storage slot) * 256 + pixel of the tile) of sample pixel (x, y) of probe `probe`
+DEV size_t probe_record(const DScene &S, const PassDesc &P, uint32_t probe, int x, int y) {
+    const int rx = x - S.crop_x0, ry = y - S.crop_y0;
+    const uint32_t slot = probe * uint32_t(P.probe_tiles) + uint32_t((ry / kTile) * P.probe_stx + rx / kTile);
+    return size_t(slot) * 256u + size_t((ry % kTile) * kTile + rx % kTile);
 }
 
 // A film position that is a whole number (u == 0, or float(px) + u rounded to px or px + 1 where the pixel

@@ -20,7 +20,7 @@ struct PassDesc {
     // explicit path list (kernel-level tests); null for tile enumeration
     const int *list_px, *list_py, *list_k;
     // IISPT probe batch: n_owned_tiles = n_probes * tiles per probe, tile slot = probe * tiles + tile
-    int probe_mode, probe_tiles;
+    int probe_mode, probe_tiles, probe_stx;  // probe pass: storage tiles per probe / per row (16 x 16 slots over the film's pixel bounds)
     const DProbeCam *probe_cams;
     // camera rays are generated inside the first k_extend and rebuilt in the first k_shade: no k_generate, no ray
     // queue for bounce 0 (run_pass decides; needs L cleared and counts[kCntRay] set beforehand)

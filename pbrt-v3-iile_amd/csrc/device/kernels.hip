@@ -249,10 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_probe_finish(DScene S, PassDesc P, P
         for (int c = 0; c < 3; ++c) intensity[3 * size_t(i) + c] = (rgb[c] + 0.f) * 1.f;
         const uint32_t probe = i / per, loc = i % per;
         const int x = S.crop_x0 + int(loc % uint32_t(fw)), y = S.crop_y0 + int(loc / uint32_t(fw));
-        const int tx = (x - S.samp_x0) / kTile, ty = (y - S.samp_y0) / kTile;
-        const uint32_t slot = probe * uint32_t(P.probe_tiles) + uint32_t(ty * P.n_tiles_x + tx);
-        const uint32_t pix = uint32_t((y - S.samp_y0 - ty * kTile) * kTile + (x - S.samp_x0 - tx * kTile));
-        const float4 a = B.aux[(size_t(slot) * 256u + pix) * size_t(P.kc)];
+        const float4 a = B.aux[probe_record(S, P, probe, x, y) * size_t(P.kc)];
         normals[3 * size_t(i)] = a.x;
         normals[3 * size_t(i) + 1] = a.y;
         normals[3 * size_t(i) + 2] = a.z;
@@ -285,11 +282,8 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, Fi
             const int ty0 = (qy0 - S.samp_y0) / kTile, ty1 = (qy1 - S.samp_y0) / kTile;
             for (int ty = ty0; ty <= ty1; ++ty)
                 for (int tx = tx0; tx <= tx1; ++tx) {  // tile index order
-                    uint32_t slot;
-                    if (P.probe_mode)
-                        slot = probe * uint32_t(P.probe_tiles) + uint32_t(ty * P.n_tiles_x + tx);
-                    else if (!tile_owned(P, tx, ty, &slot))
-                        continue;
+                    uint32_t slot = 0;  // (probe pass: the tiles here are the reference's, the records are found per pixel)
+                    if (!P.probe_mode && !tile_owned(P, tx, ty, &slot)) continue;
                     // the tile's FilmTile (Film::GetFilmTile, film.cpp:92-103) must hold (x, y)
                     const int sx0 = S.samp_x0 + tx * kTile, sy0 = S.samp_y0 + ty * kTile;
                     const int sx1 = min(sx0 + kTile, S.samp_x1), sy1 = min(sy0 + kTile, S.samp_y1);
@@ -322,7 +316,8 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, Fi
                                 float4 Lb[4];
 #pragma unroll
                                 for (int jj = 0; jj < 4; ++jj) {
-                                    const size_t at = row + size_t(q4 + jj <= xb ? q4 + jj : q4);
+                                    const int qx = q4 + jj <= xb ? q4 + jj : q4;
+                                    const size_t at = P.probe_mode ? probe_record(S, P, probe, qx, qy) : row + size_t(qx);
                                     pfb[jj] = F.wide_pf[at];
                                     Lb[jj] = F.wide_L[at];
                                 }
