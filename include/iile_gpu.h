@@ -152,6 +152,24 @@ int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, c
 int iile_iispt_hemi_points(iile_scene *scene, const iile_iispt_task *task, uint8_t *valid, float *pos3, float *dir3);
 int iile_iispt_gather(iile_scene *scene, const iile_iispt_task *task, const uint8_t *valid, const float *pos3, const float *dir3,
                       const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device);
+/* BVHAccel's HLBVH build (src/accelerators/bvh.cpp:404-472: Morton codes :413-427, RadixSort :133-181, treelets and
+ * emitLBVH :434-452, 555-618, buildUpperSAH :474-553) and flattenBVHTree (:640-658) — SURVEY.md §8 f4. bounds6: per
+ * primitive WorldBound() as {min xyz, max xyz} (host memory); nodes_out: room for 2 * n_prims nodes; order_out[i] = the
+ * number of the primitive at position i of BVHAccel::primitives after the build. The tree is the one the reference
+ * builds with one thread (treelets in index order); Morton codes, the sort, the treelets and the flattening run on the
+ * device, the SAH over the <= 4096 treelet roots on the host. The signature doubles as the `bvh_build` hook of
+ * iile_host_overrides (include/iile_host.h). */
+typedef struct iile_bvh_build_stats {
+    float ms_total, ms_morton, ms_sort, ms_treelets, ms_upper, ms_flatten, ms_download;
+    int32_t n_treelets, n_nodes, n_interior, n_leaf;
+} iile_bvh_build_stats;
+int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32_t max_prims_in_node, iile_bvh_node *nodes_out,
+                         int32_t *n_nodes_out, int32_t *order_out, iile_bvh_build_stats *stats);
+/* Test probe: the traversal kernels' records of a flattened tree as iile_scene_create packs them on the device —
+ * wide16: 16 floats per interior node (two child boxes, refs, axis), wide4_32: 32 floats (four grandchild boxes as six
+ * SoA planes, refs, axes); *nested = every child box lies inside its parent's. Layout: DESIGN.md §3. */
+int iile_bvh_pack_probe(int32_t n_nodes, const iile_bvh_node *nodes, int32_t n_interior, float *wide16, float *wide4_32,
+                        int32_t *nested);
 /* ImageTexture<RGBSpectrum, Spectrum>::Evaluate (src/textures/imagemap.h:87-94) of image texture `tex` at n
  * surface points given by (u, v) and the screen-space differentials {du/dx, dv/dx, du/dy, dv/dy}. */
 int iile_texture_eval(iile_scene *scene, int32_t tex, int32_t n, const float *uv2, const float *duv4, float *rgb3);

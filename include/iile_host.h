@@ -36,7 +36,17 @@ typedef struct iile_host_overrides {
     int32_t max_depth;
     int32_t sampler; /* IILE_SAMPLER_*: which sampler renders the frame. SOBOL is what the fork's path integrator does
                         under IILE_PATH_SAMPLES_OVERRIDE = spp (src/integrators/path.cpp:202-212) */
+    int32_t accel_split; /* IILE_SPLIT_*: BVHAccel's "splitmethod" (src/accelerators/bvh.cpp:740-760) in place of the file's */
+    /* Builder for the "hlbvh" split method in place of the host's (csrc/host/bvh_build.cpp): iile_bvh_build_hlbvh of
+     * libiile_gpu.so has this signature (the last argument receives NULL). libiile_host itself stays free of HIP. */
+    int (*bvh_build)(int32_t n_prims, const float *bounds6, int32_t max_prims_in_node, iile_bvh_node *nodes_out,
+                     int32_t *n_nodes_out, int32_t *order_out, void *stats);
 } iile_host_overrides;
+#define IILE_SPLIT_KEEP 0
+#define IILE_SPLIT_SAH 1
+#define IILE_SPLIT_HLBVH 2
+#define IILE_SPLIT_MIDDLE 3
+#define IILE_SPLIT_EQUAL 4
 #define IILE_SAMPLER_KEEP 0
 #define IILE_SAMPLER_HALTON 1
 #define IILE_SAMPLER_SOBOL 2

@@ -24,10 +24,12 @@ c_vp = ctypes.c_void_p
 
 
 class HostOverrides(ctypes.Structure):
-    _fields_ = [("xres", c_i32), ("yres", c_i32), ("spp", c_i32), ("max_depth", c_i32), ("sampler", c_i32)]
+    _fields_ = [("xres", c_i32), ("yres", c_i32), ("spp", c_i32), ("max_depth", c_i32), ("sampler", c_i32),
+                ("accel_split", c_i32), ("bvh_build", c_vp)]
 
 
 SAMPLERS = {None: 0, "": 0, "halton": 1, "sobol": 2}  # IILE_SAMPLER_* of include/iile_host.h
+SPLITS = {None: 0, "": 0, "sah": 1, "hlbvh": 2, "middle": 3, "equal": 4}  # IILE_SPLIT_*
 
 
 class HostSceneInfo(ctypes.Structure):
@@ -68,6 +70,21 @@ class IisptTask(ctypes.Structure):
         return count(self.x0, self.x1, self.tilesize), count(self.y0, self.y1, self.tilesize)
 
 
+# iile_bvh_node (include/iile_scene.h): LinearBVHNode
+BVH_NODE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("nprims", "<u2"), ("axis", "u1"), ("pad", "u1")])
+
+
+class BvhBuildStats(ctypes.Structure):
+    _fields_ = [(n, c_f32) for n in "ms_total ms_morton ms_sort ms_treelets ms_upper ms_flatten ms_download".split()] + [
+        (n, c_i32) for n in "n_treelets n_nodes n_interior n_leaf".split()]
+
+
+class SceneDescHead(ctypes.Structure):
+    """The first members of iile_scene_desc (include/iile_scene.h): the flattened BVH and the primitives in BVH order."""
+    _fields_ = [("n_nodes", c_i32), ("nodes", c_vp), ("n_prims", c_i32), ("prim_flags", c_vp), ("prim_material", c_vp),
+                ("prim_light", c_vp), ("prim_shape", c_vp), ("tri_p", c_vp)]
+
+
 class GpuStats(ctypes.Structure):
     _fields_ = [(n, c_u64) for n in ("camera_rays closest_rays shadow_rays nodes_closest nodes_any tri_tests "
                                      "tri_hits sphere_tests nee_evals zero_radiance").split()] + [
@@ -97,7 +114,7 @@ GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iil
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
                "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download",
-               "iile_iispt_hemi_points", "iile_iispt_gather"]
+               "iile_iispt_hemi_points", "iile_iispt_gather", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_last_error"]
@@ -193,6 +210,8 @@ def gpu_lib():
         lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
         lib.iile_iispt_hemi_points.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_vp, c_vp, c_vp]
         lib.iile_iispt_gather.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32]
+        lib.iile_bvh_build_hlbvh.argtypes = [c_i32, c_vp, c_i32, c_vp, ctypes.POINTER(c_i32), c_vp, ctypes.POINTER(BvhBuildStats)]
+        lib.iile_bvh_pack_probe.argtypes = [c_i32, c_vp, c_i32, c_vp, c_vp, ctypes.POINTER(c_i32)]
         _gpu = lib
     return _gpu
 
@@ -285,12 +304,19 @@ def _i32(a):
 class HostScene:
     """Scene loaded and flattened by libiile_host (ParseFile + MakeScene in the reference)."""
 
-    def __init__(self, path=DEFAULT_SCENE, xres=0, yres=0, spp=0, max_depth=0, sampler=None):
+    def __init__(self, path=DEFAULT_SCENE, xres=0, yres=0, spp=0, max_depth=0, sampler=None, accel_split=None, bvh_on_device=False):
         """sampler: None keeps the scene file's; "sobol" is what the fork's path integrator renders with under
-        IILE_PATH_SAMPLES_OVERRIDE (src/integrators/path.cpp:202-212)."""
+        IILE_PATH_SAMPLES_OVERRIDE (src/integrators/path.cpp:202-212). accel_split: BVHAccel's "splitmethod" in place of
+        the file's. bvh_on_device: split method "hlbvh" is built by libiile_gpu's iile_bvh_build_hlbvh,
+        plugged into the host loader as its bvh_build hook."""
         lib = host_lib()
         self._h = c_vp()
-        ov = HostOverrides(int(xres), int(yres), int(spp), int(max_depth), SAMPLERS[sampler])
+        hook = None
+        if bvh_on_device is True:
+            hook = ctypes.cast(gpu_lib().iile_bvh_build_hlbvh, c_vp)
+        elif bvh_on_device:  # any other builder with iile_host_overrides::bvh_build's signature (a ctypes function object)
+            hook = ctypes.cast(bvh_on_device, c_vp)
+        ov = HostOverrides(int(xres), int(yres), int(spp), int(max_depth), SAMPLERS[sampler], SPLITS[accel_split], hook)
         rc = lib.iile_host_load_pbrt(os.fsencode(path), ctypes.byref(ov), ctypes.byref(self._h))
         if rc != 0:
             raise RuntimeError(f"iile_host_load_pbrt({path}) failed: {lib.iile_host_last_error().decode()}")
@@ -305,6 +331,14 @@ class HostScene:
     def film_shape(self):
         f = self.film
         return (f.crop_y1 - f.crop_y0, f.crop_x1 - f.crop_x0)
+
+    def bvh(self):
+        """(flattened nodes as a BVH_NODE array, triangle vertices (n_prims, 9) in BVH order, prim_shape (n_prims,)): copies."""
+        head = ctypes.cast(self.desc, ctypes.POINTER(SceneDescHead)).contents
+        nodes = np.frombuffer(ctypes.string_at(head.nodes, head.n_nodes * BVH_NODE.itemsize), dtype=BVH_NODE).copy()
+        tri_p = np.frombuffer(ctypes.string_at(head.tri_p, head.n_prims * 36), dtype=np.float32).reshape(-1, 9).copy()
+        shape = np.frombuffer(ctypes.string_at(head.prim_shape, head.n_prims * 4), dtype=np.int32).copy()
+        return nodes, tri_p, shape
 
     def film_to_rgb(self, film_xyzw):
         """Film::to_rgb_array on a (H, W, 4) {X,Y,Z,weight} film."""
@@ -515,6 +549,35 @@ class GpuScene:
             self.close()
         except Exception:
             pass
+
+
+def bvh_build_hlbvh(bounds6, max_prims_in_node=4):
+    """BVHAccel's HLBVH build + flattening on the device: (nodes as a BVH_NODE array, order (n,) int32, stats dict)."""
+    b = _f32(bounds6).reshape(-1, 6)
+    n = len(b)
+    nodes = np.zeros(max(2 * n, 1), dtype=BVH_NODE)
+    order = np.zeros(max(n, 1), dtype=np.int32)
+    n_nodes = c_i32(0)
+    st = BvhBuildStats()
+    rc = gpu_lib().iile_bvh_build_hlbvh(n, b.ctypes.data, int(max_prims_in_node), nodes.ctypes.data, ctypes.byref(n_nodes), order.ctypes.data,
+                                        ctypes.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"iile_bvh_build_hlbvh failed ({rc}): {gpu_lib().iile_last_error().decode()}")
+    return nodes[:n_nodes.value].copy(), order[:n].copy(), {k: getattr(st, k) for k, _ in BvhBuildStats._fields_}
+
+
+def bvh_pack_probe(nodes):
+    """The traversal records iile_scene_create packs on the device for a flattened tree: (wide (ni, 16) float32,
+    wide4 (ni, 32) float32, nested bool)."""
+    nodes = np.ascontiguousarray(nodes, dtype=BVH_NODE)
+    ni = int((nodes["nprims"] == 0).sum())
+    wide = np.zeros((max(ni, 1), 16), np.float32)
+    wide4 = np.zeros((max(ni, 1), 32), np.float32)
+    nested = c_i32(0)
+    rc = gpu_lib().iile_bvh_pack_probe(len(nodes), nodes.ctypes.data, ni, wide.ctypes.data, wide4.ctypes.data, ctypes.byref(nested))
+    if rc != 0:
+        raise RuntimeError(f"iile_bvh_pack_probe failed ({rc}): {gpu_lib().iile_last_error().decode()}")
+    return wide[:ni], wide4[:ni], bool(nested.value)
 
 
 def trig_probe(x):

@@ -41,7 +41,12 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--sampler") && i + 1 < argc) {
             const char *sn = argv[++i];
             ps.sampler = !strcmp(sn, "sobol") ? IILE_SAMPLER_SOBOL : (!strcmp(sn, "halton") ? IILE_SAMPLER_HALTON : IILE_SAMPLER_KEEP);
-        } else if (!strcmp(argv[i], "--gpurank") && i + 1 < argc) {
+        } else if (!strcmp(argv[i], "--splitmethod") && i + 1 < argc) {
+            const char *sm = argv[++i];
+            ps.splitmethod = !strcmp(sm, "hlbvh") ? IILE_SPLIT_HLBVH : (!strcmp(sm, "middle") ? IILE_SPLIT_MIDDLE : (!strcmp(sm, "equal") ? IILE_SPLIT_EQUAL : IILE_SPLIT_SAH));
+        } else if (!strcmp(argv[i], "--bvh-device"))
+            ps.bvh_on_device = true;
+        else if (!strcmp(argv[i], "--gpurank") && i + 1 < argc) {
             if (sscanf(argv[++i], "%d/%d", &gpu_rank, &gpu_nranks) != 2 || gpu_nranks < 1 || gpu_rank < 0 || gpu_rank >= gpu_nranks) {
                 fprintf(stderr, "iile_pbrt: --gpurank wants R/N with 0 <= R < N\n");
                 return 1;
@@ -50,7 +55,8 @@ int main(int argc, char **argv) {
             rendezvous = argv[++i];
         else if (argv[i][0] == '-') {
             fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.pfm] [--xres N] [--yres N] [--spp N] "
-                            "[--maxdepth N] [--stats] [--sampler halton|sobol] [--gpurank R/N --rendezvous FILE]\n");
+                            "[--maxdepth N] [--stats] [--sampler halton|sobol] [--splitmethod sah|hlbvh|middle|equal] [--bvh-device] "
+                            "[--gpurank R/N --rendezvous FILE]\n");
             return 1;
         } else
             scene_file = argv[i];

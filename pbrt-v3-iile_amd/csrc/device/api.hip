@@ -27,6 +27,11 @@ int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+}  // namespace
+namespace iile {
+int api_fail(int code, const std::string &msg) { return fail(code, msg); }  // the other translation units' errors
+}  // namespace iile
+namespace {
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -487,21 +492,14 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         iile_scene_destroy(sc);
         return code;
     };
-    // BVH: re-pack the depth-first LinearBVHNode array (bvh.cpp:640-658) into wide
-    // interior records {children[0] box, children[1] box, refs, axis}. A reference is
-    // the interior record index, or ~firstPrimitive for a leaf child.
+    // BVH: the depth-first LinearBVHNode array (bvh.cpp:640-658) is validated here and re-packed on the device
+    // (bvh_build.hip, pack_wide_records) into the two-wide records {children[0] box, children[1] box, refs, axis} of the
+    // instrumented kernels and the four-wide records of dpath.h trav_interior4. A reference is the interior record
+    // index, or ~firstPrimitive for a leaf child.
     std::vector<uint32_t> last_in_leaf(size_t(d->n_prims), 0);
     {
         const int n = d->n_nodes;
-        std::vector<int> interior_id(size_t(std::max(n, 1)), -1);
         int n_interior = 0;
-        for (int i = 0; i < n; ++i)
-            if (d->nodes[i].nprims == 0) interior_id[i] = n_interior++;
-        auto ref_of = [&](int node) -> int {
-            const iile_bvh_node &nd = d->nodes[node];
-            return nd.nprims == 0 ? interior_id[node] : ~nd.offset;
-        };
-        std::vector<float4> wide(4 * size_t(std::max(n_interior, 1)), make_float4(0, 0, 0, 0));
         for (int i = 0; i < n; ++i) {
             const iile_bvh_node &nd = d->nodes[i];
             if (nd.nprims > 0) {
@@ -510,91 +508,32 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 continue;
             }
             if (i + 1 >= n || nd.offset <= i || nd.offset >= n) return bail(fail(IILE_ERR_ARG, "bad BVH child index"));
-            const iile_bvh_node &a = d->nodes[i + 1], &b = d->nodes[nd.offset];
-            const int ra = ref_of(i + 1), rb = ref_of(nd.offset), meta = int(nd.axis);
-            float fa, fb, fm;
-            std::memcpy(&fa, &ra, 4);
-            std::memcpy(&fb, &rb, 4);
-            std::memcpy(&fm, &meta, 4);
-            float4 *w = &wide[4 * size_t(interior_id[i])];
-            w[0] = make_float4(a.bmin[0], a.bmin[1], a.bmin[2], a.bmax[0]);
-            w[1] = make_float4(a.bmax[1], a.bmax[2], b.bmin[0], b.bmin[1]);
-            w[2] = make_float4(b.bmin[2], b.bmax[0], b.bmax[1], b.bmax[2]);
-            w[3] = make_float4(fa, fb, fm, 0.f);
+            ++n_interior;
         }
-        rc = upload(sc, wide.data(), wide.size(), &S.wide);
+        const iile_bvh_node *d_nodes = nullptr;
+        rc = upload(sc, d->nodes, size_t(std::max(n, 0)), &d_nodes);
         if (rc) return bail(rc);
-        // The four-wide step never tests the two children themselves; that is exact because a
-        // child's box lies inside its parent's (Union in recursiveBuild is exact). Verify it for
-        // the tree we were handed; a tree that violates it is traversed with binary steps only.
+        float4 *wide = nullptr, *wide4 = nullptr;
+        if (hipMalloc(&wide, 4 * size_t(std::max(n_interior, 1)) * sizeof(float4)) != hipSuccess)
+            return bail(fail(IILE_ERR_HIP, "out of device memory for the BVH records"));
+        sc->allocs.push_back(wide);
+        if (hipMalloc(&wide4, 8 * size_t(std::max(n_interior, 1)) * sizeof(float4)) != hipSuccess)
+            return bail(fail(IILE_ERR_HIP, "out of device memory for the BVH records"));
+        sc->allocs.push_back(wide4);
+        // The four-wide step never tests the two children themselves; that is exact because a child's box lies inside
+        // its parent's (Union in recursiveBuild is exact). pack_wide_records verifies it for the tree we were handed; a
+        // tree that violates it is traversed with binary steps only.
         S.boxes_nested = 1;
-        for (int i = 0; i < n && S.boxes_nested; ++i) {
-            const iile_bvh_node &nd = d->nodes[i];
-            if (nd.nprims > 0) continue;
-            const int child[2] = {i + 1, nd.offset};
-            for (int k = 0; k < 2; ++k)
-                for (int c = 0; c < 3; ++c)
-                    if (!(d->nodes[child[k]].bmin[c] >= nd.bmin[c] && d->nodes[child[k]].bmax[c] <= nd.bmax[c]))
-                        S.boxes_nested = 0;
-        }
-        // Four-wide records (dpath.h trav_interior4): per binary interior node P the boxes / refs
-        // of its grandchildren in fixed slots {L's children | L if leaf, -} {R's children | R, -},
-        // as six SoA planes, then refs, then the split axes of P, L and R. An unused slot gets an
-        // inverted infinite box, which no ray can enter.
-        {
-            const float inf = std::numeric_limits<float>::infinity();
-            std::vector<float4> wide4(8 * size_t(std::max(n_interior, 1)), make_float4(0, 0, 0, 0));
-            for (int i = 0; i < n; ++i) {
-                const iile_bvh_node &nd = d->nodes[i];
-                if (nd.nprims > 0) continue;
-                float bx[6][4];
-                int refs[4];
-                for (int k = 0; k < 4; ++k) {
-                    for (int c = 0; c < 3; ++c) {
-                        bx[c][k] = inf;
-                        bx[3 + c][k] = -inf;
-                    }
-                    refs[k] = 0;
-                }
-                auto fill = [&](int slot, int node) {
-                    const iile_bvh_node &nn = d->nodes[node];
-                    for (int c = 0; c < 3; ++c) {
-                        bx[c][slot] = nn.bmin[c];
-                        bx[3 + c][slot] = nn.bmax[c];
-                    }
-                    refs[slot] = ref_of(node);
-                };
-                uint32_t meta = uint32_t(nd.axis) & 3u;
-                const int child[2] = {i + 1, nd.offset};
-                for (int side = 0; side < 2; ++side) {
-                    const iile_bvh_node &c = d->nodes[child[side]];
-                    if (c.nprims > 0) {
-                        fill(2 * side, child[side]);
-                    } else {
-                        if (child[side] + 1 >= n || c.offset <= child[side] || c.offset >= n)
-                            return bail(fail(IILE_ERR_ARG, "bad BVH child index"));
-                        fill(2 * side, child[side] + 1);
-                        fill(2 * side + 1, c.offset);
-                        meta |= (uint32_t(c.axis) & 3u) << (2 + 2 * side);
-                    }
-                }
-                float4 *w = &wide4[8 * size_t(interior_id[i])];
-                for (int pl = 0; pl < 6; ++pl) w[pl] = make_float4(bx[pl][0], bx[pl][1], bx[pl][2], bx[pl][3]);
-                float fr[4], fm;
-                std::memcpy(fr, refs, 16);
-                std::memcpy(&fm, &meta, 4);
-                w[6] = make_float4(fr[0], fr[1], fr[2], fr[3]);
-                w[7] = make_float4(fm, 0.f, 0.f, 0.f);
-            }
-            rc = upload(sc, wide4.data(), wide4.size(), &S.wide4);
-            if (rc) return bail(rc);
-        }
+        rc = pack_wide_records(d_nodes, n, n_interior, wide, wide4, &S.boxes_nested);
+        if (rc) return bail(rc);
+        S.wide = wide;
+        S.wide4 = wide4;
         if (n > 0) {
             for (int c = 0; c < 3; ++c) {
                 S.root_box[c] = d->nodes[0].bmin[c];
                 S.root_box[3 + c] = d->nodes[0].bmax[c];
             }
-            S.root_ref = ref_of(0);
+            S.root_ref = d->nodes[0].nprims == 0 ? 0 : ~d->nodes[0].offset;  // the root is interior record 0
         }
     }
     // primitives: gather into 48-byte vertex records + normal / uv records

@@ -1,0 +1,634 @@
+// bvh_build.hip — BVHAccel's HLBVH construction on the device and the re-packing of a flattened
+// tree into the traversal kernels' wide records.
+//
+// iile_bvh_build_hlbvh builds, from the primitives' world bounds, the tree BVHAccel::HLBVHBuild
+// (src/accelerators/bvh.cpp:404-472) builds when its treelets are emitted in index order (what one thread does; with
+// several threads the reference's `orderedPrimsOffset->fetch_add` makes the leaf order depend on scheduling), already
+// flattened as flattenBVHTree (:640-658) lays it out. Stages:
+//
+//   k_centroid_bounds   bounds of the primitive centroids (:413-416): min / max are exact and order-free
+//   k_morton            30-bit Morton codes of the centroids, 10 bits per axis (:418-427, LeftShift3 / EncodeMorton3 :107-130)
+//   rocprim radix sort  (code, primitive number) pairs, stable, bits 0-29: the order RadixSort's five 6-bit passes give (:133-181, :430)
+//   k_treelet_flags + scan + k_treelet_starts   runs of equal top 12 bits = treelets (:434-452)
+//   k_emit_treelets     emitLBVH (:555-618) for one treelet per thread, nodes in preorder into the treelet's own pool
+//                       region; its leaves take their primitives in sorted order, so the leaf order IS the sorted order
+//   host: buildUpperSAH (:620-638+) over the <= 4096 treelet roots — a sequential SAH with std::partition over a few
+//                       thousand boxes (the reference runs it on one thread too) — and the preorder offsets of the subtrees
+//   k_place_nodes / k_place_upper   flattenBVHTree: every node to its depth-first index, second-child offsets rebased
+//
+// The result must equal the host builder's (csrc/host/bvh_build.cpp, split method "hlbvh") node for node:
+// tests/test_gpu_bvh_build.py. Float arithmetic is IEEE (no contraction, correctly rounded division) like the rest.
+//
+// pack_wide_records: the two-wide and four-wide interior records of DESIGN.md §3 from a flattened tree in HBM — what
+// iile_scene_create did in host loops — one thread per node.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <limits>
+#include <rocprim/rocprim.hpp>
+#include <string>
+#include <vector>
+
+#include "../../../include/iile_gpu.h"
+#include "kernels.h"
+
+namespace iile {
+namespace {
+
+#define HIP_TRYB(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return api_fail(IILE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kBB = 256;
+constexpr float kFltMax = 3.402823466e+38f;
+
+struct Box {
+    float mn[3], mx[3];
+};
+
+__device__ __forceinline__ uint32_t order_key(float f) {  // monotone float -> u32
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// bvh.cpp:53-56: centroid = .5f * pMin + .5f * pMax
+__device__ __forceinline__ void centroid_of(const float *b6, float c[3]) {
+    for (int a = 0; a < 3; ++a) c[a] = .5f * b6[a] + .5f * b6[3 + a];
+}
+
+__global__ __launch_bounds__(kBB) void k_centroid_bounds(int n, const float *bounds6, uint32_t *keys6) {
+    float mn[3] = {kFltMax, kFltMax, kFltMax}, mx[3] = {-kFltMax, -kFltMax, -kFltMax};
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
+        float c[3];
+        centroid_of(bounds6 + 6 * size_t(i), c);
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], c[a]);
+            mx[a] = fmaxf(mx[a], c[a]);
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&keys6[a], order_key(mn[a]));
+            atomicMax(&keys6[3 + a], order_key(mx[a]));
+        }
+}
+
+__device__ __forceinline__ uint32_t left_shift3(uint32_t x) {  // bvh.cpp:107-117
+    if (x == (1u << 10)) --x;
+    x = (x | (x << 16)) & 0x30000ffu;
+    x = (x | (x << 8)) & 0x300f00fu;
+    x = (x | (x << 4)) & 0x30c30c3u;
+    x = (x | (x << 2)) & 0x9249249u;
+    return x;
+}
+
+__global__ __launch_bounds__(kBB) void k_morton(int n, const float *bounds6, const uint32_t *keys6, uint32_t *codes, int *numbers) {
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) lo[a] = key_float(keys6[a]), hi[a] = key_float(keys6[3 + a]);
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
+        float c[3];
+        centroid_of(bounds6 + 6 * size_t(i), c);
+        uint32_t q[3];
+        for (int a = 0; a < 3; ++a) {
+            float o = c[a] - lo[a];  // Bounds3::Offset, geometry.h:804-810
+            if (hi[a] > lo[a]) o /= hi[a] - lo[a];
+            q[a] = uint32_t(o * 1024.f);  // mortonScale = 1 << 10
+        }
+        codes[i] = (left_shift3(q[2]) << 2) | (left_shift3(q[1]) << 1) | left_shift3(q[0]);
+        numbers[i] = i;
+    }
+}
+
+constexpr uint32_t kTreeletMask = 0x3ffc0000u;  // bvh.cpp:437: the top 12 of the 30 bits
+
+__global__ __launch_bounds__(kBB) void k_treelet_flags(int n, const uint32_t *codes, int *flags) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB)
+        flags[i] = (i == 0 || ((codes[i] ^ codes[i - 1]) & kTreeletMask) != 0) ? 1 : 0;
+}
+// incl[i] - 1 = the treelet of sorted position i
+__global__ __launch_bounds__(kBB) void k_treelet_starts(int n, const int *flags, const int *incl, int *starts) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
+        if (flags[i]) starts[incl[i] - 1] = i;
+        if (i == n - 1) starts[incl[i]] = n;
+    }
+}
+
+__device__ __forceinline__ void box_union(float *mn, float *mx, const float *b6) {
+    // Union(Bounds3, Bounds3), geometry.h: std::min / std::max component by component
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = b6[a] < mn[a] ? b6[a] : mn[a];
+        mx[a] = mx[a] < b6[3 + a] ? b6[3 + a] : mx[a];
+    }
+}
+
+// emitLBVH (bvh.cpp:555-618), one treelet per thread, recursion unrolled over an explicit stack (at most one interior
+// node per Morton bit 17 .. 0 on any path). Nodes go to pool[2 * start ...] in preorder: first child = node + 1, the
+// second child's (local) index in `offset`; leaves hold the global sorted position of their first primitive.
+struct EmitFrame {
+    int node, rstart, rn, rbit, state;
+};
+__global__ __launch_bounds__(64) void k_emit_treelets(int n_treelets, const int *starts, const uint32_t *codes, const int *numbers,
+                                                      const float *bounds6, int max_prims, iile_bvh_node *pool, int *n_nodes,
+                                                      int *totals, int *error) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n_treelets) return;
+    const int t0 = starts[t], tn = starts[t + 1] - t0;
+    const uint32_t *mp = codes + t0;
+    iile_bvh_node *out = pool + 2 * size_t(t0);
+    EmitFrame stack[20];
+    int sp = 0, next = 0, n_int = 0, n_leaf = 0;
+    int start = 0, n = tn, bit = 29 - 12;
+    for (;;) {
+        // descend: resolve (start, n, bit) into a leaf or an interior node
+        bool leaf;
+        for (;;) {
+            if (bit == -1 || n < max_prims) {
+                leaf = true;
+                break;
+            }
+            const uint32_t mask = 1u << bit;
+            if ((mp[start] & mask) == (mp[start + n - 1] & mask)) {
+                --bit;
+                continue;
+            }
+            leaf = false;
+            break;
+        }
+        if (!leaf) {
+            const uint32_t mask = 1u << bit;
+            int s0 = 0, s1 = n - 1;  // binary search for the first primitive whose bit differs (:586-596)
+            while (s0 + 1 != s1) {
+                const int mid = (s0 + s1) / 2;
+                if ((mp[start + s0] & mask) == (mp[start + mid] & mask))
+                    s0 = mid;
+                else
+                    s1 = mid;
+            }
+            const int split = s1;
+            const int node = next++;
+            stack[sp++] = EmitFrame{node, start + split, n - split, bit - 1, 0};
+            out[node].axis = uint8_t(bit % 3);
+            n = split;
+            --bit;
+            continue;
+        }
+        int ret = next++;
+        {
+            float mn[3] = {kFltMax, kFltMax, kFltMax}, mx[3] = {-kFltMax, -kFltMax, -kFltMax};
+            for (int i = 0; i < n; ++i) box_union(mn, mx, bounds6 + 6 * size_t(numbers[t0 + start + i]));
+            iile_bvh_node nd;
+            for (int a = 0; a < 3; ++a) nd.bmin[a] = mn[a], nd.bmax[a] = mx[a];
+            nd.offset = t0 + start;
+            if (n > 65535) atomicExch(error, 1);  // LinearBVHNode::nPrimitives is 16 bits
+            nd.nprims = uint16_t(n);
+            nd.axis = 0;
+            nd.pad = 0;
+            out[ret] = nd;
+            ++n_leaf;
+        }
+        // return upwards
+        bool more = false;
+        while (sp > 0) {
+            EmitFrame &f = stack[sp - 1];
+            if (f.state == 0) {  // left subtree done: emit the right one
+                f.state = 1;
+                start = f.rstart, n = f.rn, bit = f.rbit;
+                more = true;
+                break;
+            }
+            // both done: ret is the second child
+            const iile_bvh_node a = out[f.node + 1], b = out[ret];
+            iile_bvh_node nd;
+            for (int c = 0; c < 3; ++c) {
+                nd.bmin[c] = b.bmin[c] < a.bmin[c] ? b.bmin[c] : a.bmin[c];
+                nd.bmax[c] = a.bmax[c] < b.bmax[c] ? b.bmax[c] : a.bmax[c];
+            }
+            nd.offset = ret;
+            nd.nprims = 0;
+            nd.axis = out[f.node].axis;
+            nd.pad = 0;
+            out[f.node] = nd;
+            ++n_int;
+            ret = f.node;
+            --sp;
+        }
+        if (!more) break;
+    }
+    n_nodes[t] = next;
+    atomicAdd(&totals[0], n_int);
+    atomicAdd(&totals[1], n_leaf);
+}
+
+__global__ __launch_bounds__(kBB) void k_treelet_roots(int n_treelets, const int *starts, const iile_bvh_node *pool, Box *roots) {
+    const int t = blockIdx.x * kBB + threadIdx.x;
+    if (t >= n_treelets) return;
+    const iile_bvh_node &r = pool[2 * size_t(starts[t])];
+    for (int a = 0; a < 3; ++a) roots[t].mn[a] = r.bmin[a], roots[t].mx[a] = r.bmax[a];
+}
+
+// flattenBVHTree: pool slot i belongs to the treelet of sorted position i / 2
+__global__ __launch_bounds__(kBB) void k_place_nodes(int n, const int *incl, const int *starts, const int *n_nodes, const int *base,
+                                                     const iile_bvh_node *pool, iile_bvh_node *out) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < 2 * n; i += gridDim.x * kBB) {
+        const int t = incl[i >> 1] - 1;
+        const int local = i - 2 * starts[t];
+        if (local >= n_nodes[t]) continue;
+        iile_bvh_node nd = pool[i];
+        if (nd.nprims == 0) nd.offset += base[t];
+        out[base[t] + local] = nd;
+    }
+}
+struct PlacedNode {
+    int index;
+    iile_bvh_node node;
+};
+__global__ __launch_bounds__(kBB) void k_place_upper(int n, const PlacedNode *upper, iile_bvh_node *out) {
+    const int i = blockIdx.x * kBB + threadIdx.x;
+    if (i < n) out[upper[i].index] = upper[i].node;
+}
+
+// ---- buildUpperSAH on the host (bvh.cpp:474-553): 12-bucket SAH over the treelet roots -----------------------------
+struct HBox {
+    float mn[3], mx[3];
+    HBox() {  // Bounds3(), geometry.h:752-757
+        for (int a = 0; a < 3; ++a) mn[a] = std::numeric_limits<float>::max(), mx[a] = std::numeric_limits<float>::lowest();
+    }
+    void add(const HBox &b) {
+        for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], b.mn[a]), mx[a] = std::max(mx[a], b.mx[a]);
+    }
+    void add_point(const float p[3]) {
+        for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], p[a]), mx[a] = std::max(mx[a], p[a]);
+    }
+    float area() const {  // geometry.h:782-785
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return 2 * (dx * dy + dx * dz + dy * dz);
+    }
+    int max_extent() const {  // geometry.h:790-798
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx > dy && dx > dz) return 0;
+        return dy > dz ? 1 : 2;
+    }
+};
+struct UpperNode {
+    HBox box;
+    int child[2];  // >= 0: upper node, < 0: ~treelet
+    int axis;
+};
+struct UpperBuilder {
+    const std::vector<HBox> &roots;  // per treelet
+    std::vector<UpperNode> nodes;
+    explicit UpperBuilder(const std::vector<HBox> &r) : roots(r) {}
+    const HBox &box_of(int ref) const { return ref >= 0 ? nodes[size_t(ref)].box : roots[size_t(~ref)]; }
+
+    int build(std::vector<int> &refs, int start, int end) {
+        if (end - start == 1) return refs[size_t(start)];
+        nodes.emplace_back();
+        const int node = int(nodes.size()) - 1;
+        HBox bounds, cb;
+        for (int i = start; i < end; ++i) bounds.add(box_of(refs[size_t(i)]));
+        for (int i = start; i < end; ++i) {
+            const HBox &b = box_of(refs[size_t(i)]);
+            const float c[3] = {(b.mn[0] + b.mx[0]) * 0.5f, (b.mn[1] + b.mx[1]) * 0.5f, (b.mn[2] + b.mx[2]) * 0.5f};
+            cb.add_point(c);
+        }
+        const int dim = cb.max_extent();
+        constexpr int nBuckets = 12;
+        struct Bucket {
+            int count = 0;
+            HBox bounds;
+        } buckets[nBuckets];
+        const float lo = cb.mn[dim], hi = cb.mx[dim];
+        auto bucket_of = [&](int ref) {
+            const HBox &b = box_of(ref);
+            const float centroid = (b.mn[dim] + b.mx[dim]) * 0.5f;
+            int k = int(nBuckets * ((centroid - lo) / (hi - lo)));
+            if (k == nBuckets) k = nBuckets - 1;
+            return k;
+        };
+        for (int i = start; i < end; ++i) {
+            const int k = bucket_of(refs[size_t(i)]);
+            buckets[k].count++;
+            buckets[k].bounds.add(box_of(refs[size_t(i)]));
+        }
+        float cost[nBuckets - 1];
+        for (int i = 0; i < nBuckets - 1; ++i) {
+            HBox b0, b1;
+            int c0 = 0, c1 = 0;
+            for (int j = 0; j <= i; ++j) b0.add(buckets[j].bounds), c0 += buckets[j].count;
+            for (int j = i + 1; j < nBuckets; ++j) b1.add(buckets[j].bounds), c1 += buckets[j].count;
+            cost[i] = .125f + (c0 * b0.area() + c1 * b1.area()) / bounds.area();
+        }
+        float min_cost = cost[0];
+        int min_bucket = 0;
+        for (int i = 1; i < nBuckets - 1; ++i)
+            if (cost[i] < min_cost) min_cost = cost[i], min_bucket = i;
+        int *pmid = std::partition(&refs[size_t(start)], &refs[size_t(end - 1)] + 1, [&](int r) { return bucket_of(r) <= min_bucket; });
+        const int mid = int(pmid - &refs[0]);
+        const int c0 = build(refs, start, mid);
+        const int c1 = build(refs, mid, end);
+        UpperNode &nd = nodes[size_t(node)];
+        nd.child[0] = c0, nd.child[1] = c1;
+        nd.box = box_of(c0);
+        nd.box.add(box_of(c1));
+        nd.axis = dim;
+        return node;
+    }
+};
+
+template <typename T>
+struct Dev {
+    T *p = nullptr;
+    ~Dev() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)); }
+};
+
+int grid_for(int n) { return std::max(1, std::min((n + kBB - 1) / kBB, 256 * 8)); }
+
+// ---- wide records -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBB) void k_interior_flags(int n, const iile_bvh_node *nodes, int *flags) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) flags[i] = nodes[i].nprims == 0 ? 1 : 0;
+}
+__device__ __forceinline__ int ref_of(const iile_bvh_node *nodes, const int *excl, int node) {
+    return nodes[node].nprims == 0 ? excl[node] : ~nodes[node].offset;
+}
+__global__ __launch_bounds__(kBB) void k_pack_wide(int n, const iile_bvh_node *nodes, const int *excl, float4 *wide, float4 *wide4,
+                                                   int *not_nested) {
+    const float inf = __builtin_huge_valf();
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
+        const iile_bvh_node nd = nodes[i];
+        if (nd.nprims > 0) continue;
+        const int child[2] = {i + 1, nd.offset};
+        const iile_bvh_node a = nodes[child[0]], b = nodes[child[1]];
+        // two-wide record (instrumented kernels): both children's boxes, their refs, the split axis
+        float4 *w = wide + 4 * size_t(excl[i]);
+        const int ra = ref_of(nodes, excl, child[0]), rb = ref_of(nodes, excl, child[1]);
+        w[0] = make_float4(a.bmin[0], a.bmin[1], a.bmin[2], a.bmax[0]);
+        w[1] = make_float4(a.bmax[1], a.bmax[2], b.bmin[0], b.bmin[1]);
+        w[2] = make_float4(b.bmin[2], b.bmax[0], b.bmax[1], b.bmax[2]);
+        w[3] = make_float4(__int_as_float(ra), __int_as_float(rb), __int_as_float(int(nd.axis)), 0.f);
+        // a child's box must lie inside its parent's for the four-wide step to skip the children (dpath.h trav_interior4)
+        bool nested = true;
+        for (int c = 0; c < 3; ++c)
+            nested = nested && a.bmin[c] >= nd.bmin[c] && a.bmax[c] <= nd.bmax[c] && b.bmin[c] >= nd.bmin[c] && b.bmax[c] <= nd.bmax[c];
+        if (!nested) atomicExch(not_nested, 1);
+        // four-wide record: grandchildren in slots {L's children | L, -} {R's children | R, -}; an unused slot gets an
+        // inverted infinite box no ray can enter
+        float bx[6][4];
+        int refs[4];
+        for (int k = 0; k < 4; ++k) {
+            for (int c = 0; c < 3; ++c) bx[c][k] = inf, bx[3 + c][k] = -inf;
+            refs[k] = 0;
+        }
+        uint32_t meta = uint32_t(nd.axis) & 3u;
+        for (int side = 0; side < 2; ++side) {
+            const iile_bvh_node &c = side ? b : a;
+            if (c.nprims > 0) {
+                for (int k = 0; k < 3; ++k) bx[k][2 * side] = c.bmin[k], bx[3 + k][2 * side] = c.bmax[k];
+                refs[2 * side] = ~c.offset;
+            } else {
+                const int gc[2] = {child[side] + 1, c.offset};
+                for (int j = 0; j < 2; ++j) {
+                    const iile_bvh_node g = nodes[gc[j]];
+                    for (int k = 0; k < 3; ++k) bx[k][2 * side + j] = g.bmin[k], bx[3 + k][2 * side + j] = g.bmax[k];
+                    refs[2 * side + j] = g.nprims == 0 ? excl[gc[j]] : ~g.offset;
+                }
+                meta |= (uint32_t(c.axis) & 3u) << (2 + 2 * side);
+            }
+        }
+        float4 *w4 = wide4 + 8 * size_t(excl[i]);
+        for (int pl = 0; pl < 6; ++pl) w4[pl] = make_float4(bx[pl][0], bx[pl][1], bx[pl][2], bx[pl][3]);
+        w4[6] = make_float4(__int_as_float(refs[0]), __int_as_float(refs[1]), __int_as_float(refs[2]), __int_as_float(refs[3]));
+        w4[7] = make_float4(__uint_as_float(meta), 0.f, 0.f, 0.f);
+    }
+}
+
+}  // namespace
+
+// Validates the child indices and leaf ranges of a flattened tree on the host side of the caller (api.hip) before this.
+int pack_wide_records(const iile_bvh_node *d_nodes, int n_nodes, int n_interior, float4 *d_wide, float4 *d_wide4, int *nested_out) {
+    *nested_out = 1;
+    if (n_nodes <= 0) return IILE_OK;
+    Dev<int> flags, excl, bad;
+    HIP_TRYB(flags.alloc(size_t(n_nodes)));
+    HIP_TRYB(excl.alloc(size_t(n_nodes)));
+    HIP_TRYB(bad.alloc(1));
+    HIP_TRYB(hipMemsetAsync(bad.p, 0, sizeof(int), nullptr));
+    hipLaunchKernelGGL(k_interior_flags, dim3(grid_for(n_nodes)), dim3(kBB), 0, nullptr, n_nodes, d_nodes, flags.p);
+    size_t tmp_bytes = 0;
+    HIP_TRYB(rocprim::exclusive_scan(nullptr, tmp_bytes, flags.p, excl.p, 0, size_t(n_nodes), rocprim::plus<int>(), nullptr));
+    Dev<char> tmp;
+    HIP_TRYB(tmp.alloc(tmp_bytes));
+    HIP_TRYB(rocprim::exclusive_scan(tmp.p, tmp_bytes, flags.p, excl.p, 0, size_t(n_nodes), rocprim::plus<int>(), nullptr));
+    hipLaunchKernelGGL(k_pack_wide, dim3(grid_for(n_nodes)), dim3(kBB), 0, nullptr, n_nodes, d_nodes, excl.p, d_wide, d_wide4, bad.p);
+    HIP_TRYB(hipGetLastError());
+    int not_nested = 0;
+    HIP_TRYB(hipMemcpy(&not_nested, bad.p, sizeof(int), hipMemcpyDeviceToHost));
+    *nested_out = not_nested ? 0 : 1;
+    (void)n_interior;
+    return IILE_OK;
+}
+
+}  // namespace iile
+
+using namespace iile;
+
+extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32_t max_prims_in_node, iile_bvh_node *nodes_out,
+                                    int32_t *n_nodes_out, int32_t *order_out, iile_bvh_build_stats *stats) {
+    if (n_prims < 0 || (n_prims > 0 && (!bounds6 || !nodes_out || !order_out)) || !n_nodes_out)
+        return api_fail(IILE_ERR_ARG, "iile_bvh_build_hlbvh: null argument");
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0)
+        return api_fail(IILE_ERR_NO_DEVICE, "no HIP device available: libiile_gpu has no CPU fallback (iile_bvh_build_hlbvh)");
+    iile_bvh_build_stats st;
+    std::memset(&st, 0, sizeof(st));
+    *n_nodes_out = 0;
+    if (n_prims == 0) {
+        if (stats) *stats = st;
+        return IILE_OK;
+    }
+    if (n_prims > (1 << 30)) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: more than 2^30 primitives");
+    const int n = n_prims;
+    const int max_prims = std::min(255, max_prims_in_node);  // BVHAccel's constructor, bvh.cpp:187
+    hipEvent_t ev[7];
+    for (hipEvent_t &e : ev) HIP_TRYB(hipEventCreate(&e));
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard() {
+            for (int i = 0; i < 7; ++i) (void)hipEventDestroy(e[i]);
+        }
+    } guard{ev};
+    hipStream_t s = nullptr;
+
+    Dev<float> d_bounds;
+    Dev<uint32_t> keys6, codes, codes_sorted;
+    Dev<int> numbers, numbers_sorted, flags, incl, starts, n_nodes_t, totals, base;
+    Dev<iile_bvh_node> pool, out;
+    HIP_TRYB(d_bounds.alloc(6 * size_t(n)));
+    HIP_TRYB(keys6.alloc(6));
+    HIP_TRYB(codes.alloc(size_t(n)));
+    HIP_TRYB(codes_sorted.alloc(size_t(n)));
+    HIP_TRYB(numbers.alloc(size_t(n)));
+    HIP_TRYB(numbers_sorted.alloc(size_t(n)));
+    HIP_TRYB(flags.alloc(size_t(n)));
+    HIP_TRYB(incl.alloc(size_t(n)));
+    HIP_TRYB(starts.alloc(size_t(n) + 1));
+    HIP_TRYB(totals.alloc(4));
+    HIP_TRYB(pool.alloc(2 * size_t(n)));
+    HIP_TRYB(hipMemcpyAsync(d_bounds.p, bounds6, 6 * size_t(n) * sizeof(float), hipMemcpyHostToDevice, s));
+    const uint32_t key_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    HIP_TRYB(hipMemcpyAsync(keys6.p, key_init, sizeof(key_init), hipMemcpyHostToDevice, s));
+    HIP_TRYB(hipMemsetAsync(totals.p, 0, 4 * sizeof(int), s));
+
+    HIP_TRYB(hipEventRecord(ev[0], s));
+    hipLaunchKernelGGL(k_centroid_bounds, dim3(grid_for(n)), dim3(kBB), 0, s, n, d_bounds.p, keys6.p);
+    hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kBB), 0, s, n, d_bounds.p, keys6.p, codes.p, numbers.p);
+    HIP_TRYB(hipEventRecord(ev[1], s));
+    {
+        size_t tmp_bytes = 0;
+        HIP_TRYB(rocprim::radix_sort_pairs(nullptr, tmp_bytes, codes.p, codes_sorted.p, numbers.p, numbers_sorted.p, size_t(n), 0, 30, s));
+        Dev<char> tmp;
+        HIP_TRYB(tmp.alloc(tmp_bytes));
+        HIP_TRYB(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, codes.p, codes_sorted.p, numbers.p, numbers_sorted.p, size_t(n), 0, 30, s));
+        HIP_TRYB(hipStreamSynchronize(s));
+    }
+    HIP_TRYB(hipEventRecord(ev[2], s));
+    hipLaunchKernelGGL(k_treelet_flags, dim3(grid_for(n)), dim3(kBB), 0, s, n, codes_sorted.p, flags.p);
+    {
+        size_t tmp_bytes = 0;
+        HIP_TRYB(rocprim::inclusive_scan(nullptr, tmp_bytes, flags.p, incl.p, size_t(n), rocprim::plus<int>(), s));
+        Dev<char> tmp;
+        HIP_TRYB(tmp.alloc(tmp_bytes));
+        HIP_TRYB(rocprim::inclusive_scan(tmp.p, tmp_bytes, flags.p, incl.p, size_t(n), rocprim::plus<int>(), s));
+        HIP_TRYB(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_treelet_starts, dim3(grid_for(n)), dim3(kBB), 0, s, n, flags.p, incl.p, starts.p);
+    int n_treelets = 0;
+    HIP_TRYB(hipMemcpyAsync(&n_treelets, incl.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRYB(hipStreamSynchronize(s));
+    HIP_TRYB(n_nodes_t.alloc(size_t(n_treelets)));
+    HIP_TRYB(base.alloc(size_t(n_treelets)));
+    Dev<int> err_flag;
+    HIP_TRYB(err_flag.alloc(1));
+    HIP_TRYB(hipMemsetAsync(err_flag.p, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_emit_treelets, dim3((n_treelets + 63) / 64), dim3(64), 0, s, n_treelets, starts.p, codes_sorted.p,
+                       numbers_sorted.p, d_bounds.p, max_prims, pool.p, n_nodes_t.p, totals.p, err_flag.p);
+    HIP_TRYB(hipEventRecord(ev[3], s));
+    // the treelet roots come to the host: the upper SAH tree and the preorder offsets of all subtrees
+    Dev<Box> d_roots;
+    HIP_TRYB(d_roots.alloc(size_t(n_treelets)));
+    hipLaunchKernelGGL(k_treelet_roots, dim3((n_treelets + kBB - 1) / kBB), dim3(kBB), 0, s, n_treelets, starts.p, pool.p, d_roots.p);
+    std::vector<HBox> roots(static_cast<size_t>(n_treelets));
+    std::vector<int> counts(static_cast<size_t>(n_treelets));
+    int h_totals[4] = {0, 0, 0, 0}, h_err = 0;
+    static_assert(sizeof(HBox) == sizeof(Box), "box layouts");
+    HIP_TRYB(hipMemcpyAsync(roots.data(), d_roots.p, size_t(n_treelets) * sizeof(Box), hipMemcpyDeviceToHost, s));
+    HIP_TRYB(hipMemcpyAsync(counts.data(), n_nodes_t.p, size_t(n_treelets) * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRYB(hipMemcpyAsync(h_totals, totals.p, sizeof(h_totals), hipMemcpyDeviceToHost, s));
+    HIP_TRYB(hipMemcpyAsync(&h_err, err_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRYB(hipStreamSynchronize(s));
+    if (h_err) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: a leaf holds more than 65535 primitives (equal Morton codes)");
+    UpperBuilder ub(roots);
+    std::vector<int> refs(static_cast<size_t>(n_treelets));
+    for (int t = 0; t < n_treelets; ++t) refs[size_t(t)] = ~t;
+    ub.nodes.reserve(size_t(n_treelets));
+    const int root = ub.build(refs, 0, n_treelets);
+    // flattenBVHTree over the upper tree; a treelet reference places its whole preorder block
+    std::vector<int> h_base(static_cast<size_t>(n_treelets));
+    std::vector<PlacedNode> placed;
+    placed.reserve(ub.nodes.size());
+    int cursor = 0;
+    {
+        struct Item {
+            int ref, placed_index;  // placed_index >= 0: the second child of that placed node starts here
+        };
+        // iterative preorder: explicit stack of (ref, owner whose second-child offset this is)
+        std::vector<Item> stack;
+        stack.push_back({root, -1});
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.placed_index >= 0) placed[size_t(it.placed_index)].node.offset = cursor;
+            if (it.ref < 0) {
+                h_base[size_t(~it.ref)] = cursor;
+                cursor += counts[size_t(~it.ref)];
+                continue;
+            }
+            const UpperNode &u = ub.nodes[size_t(it.ref)];
+            PlacedNode pn;
+            std::memset(&pn, 0, sizeof(pn));
+            pn.index = cursor++;
+            for (int a = 0; a < 3; ++a) pn.node.bmin[a] = u.box.mn[a], pn.node.bmax[a] = u.box.mx[a];
+            pn.node.nprims = 0;
+            pn.node.axis = uint8_t(u.axis);
+            placed.push_back(pn);
+            const int me = int(placed.size()) - 1;
+            stack.push_back({u.child[1], me});  // visited after the whole first subtree
+            stack.push_back({u.child[0], -1});
+        }
+    }
+    const int n_nodes = cursor;
+    HIP_TRYB(hipEventRecord(ev[4], s));
+    HIP_TRYB(out.alloc(size_t(n_nodes)));
+    HIP_TRYB(hipMemcpyAsync(base.p, h_base.data(), size_t(n_treelets) * sizeof(int), hipMemcpyHostToDevice, s));
+    Dev<PlacedNode> d_placed;
+    HIP_TRYB(d_placed.alloc(placed.size()));
+    if (!placed.empty())
+        HIP_TRYB(hipMemcpyAsync(d_placed.p, placed.data(), placed.size() * sizeof(PlacedNode), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_place_nodes, dim3(grid_for(2 * n)), dim3(kBB), 0, s, n, incl.p, starts.p, n_nodes_t.p, base.p, pool.p, out.p);
+    if (!placed.empty())
+        hipLaunchKernelGGL(k_place_upper, dim3((int(placed.size()) + kBB - 1) / kBB), dim3(kBB), 0, s, int(placed.size()), d_placed.p, out.p);
+    HIP_TRYB(hipGetLastError());
+    HIP_TRYB(hipEventRecord(ev[5], s));
+    HIP_TRYB(hipMemcpyAsync(nodes_out, out.p, size_t(n_nodes) * sizeof(iile_bvh_node), hipMemcpyDeviceToHost, s));
+    HIP_TRYB(hipMemcpyAsync(order_out, numbers_sorted.p, size_t(n) * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRYB(hipEventRecord(ev[6], s));
+    HIP_TRYB(hipStreamSynchronize(s));
+    *n_nodes_out = n_nodes;
+    auto ms = [&](int a, int b) {
+        float v = 0;
+        (void)hipEventElapsedTime(&v, ev[a], ev[b]);
+        return v;
+    };
+    st.ms_morton = ms(0, 1), st.ms_sort = ms(1, 2), st.ms_treelets = ms(2, 3), st.ms_upper = ms(3, 4), st.ms_flatten = ms(4, 5);
+    st.ms_download = ms(5, 6), st.ms_total = ms(0, 6);
+    st.n_treelets = n_treelets;
+    st.n_nodes = n_nodes;
+    st.n_interior = h_totals[0] + int(ub.nodes.size());
+    st.n_leaf = h_totals[1];
+    if (stats) *stats = st;
+    return IILE_OK;
+}
+
+// Test probe for pack_wide_records: the records of a flattened tree handed over by the host.
+extern "C" int iile_bvh_pack_probe(int32_t n_nodes, const iile_bvh_node *nodes, int32_t n_interior, float *wide16, float *wide4_32,
+                                   int32_t *nested) {
+    if (n_nodes <= 0 || !nodes || !wide16 || !wide4_32 || !nested) return api_fail(IILE_ERR_ARG, "iile_bvh_pack_probe: bad argument");
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0)
+        return api_fail(IILE_ERR_NO_DEVICE, "no HIP device available: libiile_gpu has no CPU fallback (iile_bvh_pack_probe)");
+    Dev<iile_bvh_node> d_nodes;
+    Dev<float4> w, w4;
+    HIP_TRYB(d_nodes.alloc(size_t(n_nodes)));
+    HIP_TRYB(w.alloc(4 * size_t(std::max(n_interior, 1))));
+    HIP_TRYB(w4.alloc(8 * size_t(std::max(n_interior, 1))));
+    HIP_TRYB(hipMemcpy(d_nodes.p, nodes, size_t(n_nodes) * sizeof(iile_bvh_node), hipMemcpyHostToDevice));
+    int nest = 1;
+    const int rc = pack_wide_records(d_nodes.p, n_nodes, n_interior, w.p, w4.p, &nest);
+    if (rc) return rc;
+    HIP_TRYB(hipMemcpy(wide16, w.p, 4 * size_t(n_interior) * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRYB(hipMemcpy(wide4_32, w4.p, 8 * size_t(n_interior) * sizeof(float4), hipMemcpyDeviceToHost));
+    *nested = nest;
+    return IILE_OK;
+}

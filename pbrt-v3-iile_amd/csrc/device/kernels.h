@@ -1,5 +1,7 @@
 // kernels.h — launch interface between api.hip and kernels.hip.
 #pragma once
+#include <string>
+
 #include "../../../include/iile_scene.h"
 #include "dscene.h"
 
@@ -71,6 +73,12 @@ struct LaunchCfg {
     bool count_stats;
     int trav_blocks_per_cu = 0;   // persistent traversal blocks per CU; 0 = default_trav_blocks_per_cu()
 };
+
+// api.hip: records the message iile_last_error() returns, hands back `code`
+int api_fail(int code, const std::string &msg);
+// bvh_build.hip: two-wide (4 float4) and four-wide (8 float4) records per interior node of a flattened tree in HBM
+// (record index = rank of the node among the interior nodes); *nested_out = every child box lies inside its parent's
+int pack_wide_records(const iile_bvh_node *d_nodes, int n_nodes, int n_interior, float4 *d_wide, float4 *d_wide4, int *nested_out);
 
 // slots a queue needs for n_paths paths
 uint32_t queue_capacity(uint32_t n_paths, int n_cus);

@@ -9,6 +9,8 @@
 // reproduced exactly, including std::partition / std::nth_element for the
 // in-range primitive order.
 #include <memory>
+#include <stdexcept>
+#include <string>
 
 #include "host_scene.h"
 
@@ -322,11 +324,34 @@ void build_bvh(HostScene *scene) {
     }
     scene->nodes.clear();
     if (n == 0) return;
-    b.nodes.reserve(2 * n);
-    b.ordered.reserve(n);
-    int root = b.split_method == kHLBVH ? b.build_hlbvh() : b.build(0, int(n));
-    scene->nodes.reserve(b.nodes.size());
-    b.flatten(root, scene->nodes);
+    if (b.split_method == kHLBVH && scene->bvh_hook) {
+        // the plugged-in builder (the device build of libiile_gpu) hands back the flattened tree and the leaf order
+        std::vector<float> bounds6(6 * n);
+        for (size_t i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c) {
+                bounds6[6 * i + c] = b.info[i].bounds.pmin[c];
+                bounds6[6 * i + 3 + c] = b.info[i].bounds.pmax[c];
+            }
+        std::vector<int32_t> order(n);
+        scene->nodes.resize(2 * n);
+        int32_t n_nodes = 0;
+        const int rc = scene->bvh_hook(int32_t(n), bounds6.data(), scene->max_node_prims, scene->nodes.data(), &n_nodes, order.data(), nullptr);
+        if (rc != 0 || n_nodes <= 0 || size_t(n_nodes) > 2 * n) throw std::runtime_error("the bvh_build hook failed (code " + std::to_string(rc) + ")");
+        scene->nodes.resize(size_t(n_nodes));
+        b.ordered.assign(order.begin(), order.end());
+        std::vector<char> seen(n, 0);
+        for (size_t v : b.ordered) {
+            if (v >= n || seen[v]) throw std::runtime_error("the bvh_build hook returned an order that is no permutation");
+            seen[v] = 1;
+        }
+        for (const iile_bvh_node &nd : scene->nodes) (nd.nprims ? b.n_leaf : b.n_interior)++;
+    } else {
+        b.nodes.reserve(2 * n);
+        b.ordered.reserve(n);
+        int root = b.split_method == kHLBVH ? b.build_hlbvh() : b.build(0, int(n));
+        scene->nodes.reserve(b.nodes.size());
+        b.flatten(root, scene->nodes);
+    }
     scene->n_interior = b.n_interior;
     scene->n_leaf = b.n_leaf;
 

@@ -39,6 +39,9 @@ int iile_host_load_pbrt(const char *path, const iile_host_overrides *ov, iile_ho
             if (ov->max_depth > 0) hs->s.max_depth = ov->max_depth;
             if (ov->sampler == IILE_SAMPLER_HALTON) hs->s.sampler_name = "halton";
             if (ov->sampler == IILE_SAMPLER_SOBOL) hs->s.sampler_name = "sobol", hs->s.sample_at_pixel_center = false;
+            static const char *const kSplit[] = {nullptr, "sah", "hlbvh", "middle", "equal"};
+            if (ov->accel_split >= IILE_SPLIT_SAH && ov->accel_split <= IILE_SPLIT_EQUAL) hs->s.accel_split = kSplit[ov->accel_split];
+            hs->s.bvh_hook = ov->bvh_build;
         }
         if (!iile::finalize_scene(&hs->s, &err)) {
             g_err = err;

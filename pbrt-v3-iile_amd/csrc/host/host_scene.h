@@ -62,6 +62,8 @@ struct HostScene {
     std::string light_strategy = "spatial";
     std::string accel_split = "sah";
     int max_node_prims = 4;
+    // optional builder for split method "hlbvh" (iile_host_overrides::bvh_build)
+    int (*bvh_hook)(int32_t, const float *, int32_t, iile_bvh_node *, int32_t *, int32_t *, void *) = nullptr;
 
     // ---- flattened output (filled by finalize) ----
     std::vector<iile_bvh_node> nodes;

@@ -537,3 +537,34 @@ def test_host_library_under_asan_and_ubsan(tmp_path):
     r = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "selftest: 0 failure(s)" in r.stdout, r.stdout[-4000:]
     assert "ERROR: AddressSanitizer" not in r.stdout and "runtime error" not in r.stdout
+
+
+def test_bvh_build_hook_is_called_and_checked(binding):
+    """iile_host_overrides::bvh_build (the seam the device HLBVH build plugs into): called for split method "hlbvh" only,
+    its failures and malformed answers become loader errors."""
+    import ctypes
+    calls = []
+    proto = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p)
+
+    def failing(n, bounds6, max_prims, nodes, n_nodes, order, stats):
+        calls.append((n, max_prims))
+        return 7
+
+    def not_a_permutation(n, bounds6, max_prims, nodes, n_nodes, order, stats):
+        n_nodes[0] = 1
+        for i in range(n):
+            order[i] = 0
+        return 0
+
+    cb = proto(failing)
+    with pytest.raises(RuntimeError, match="bvh_build hook failed"):
+        binding.HostScene(xres=16, yres=16, spp=1, accel_split="hlbvh", bvh_on_device=cb)
+    assert len(calls) == 1 and calls[0][0] > 60000 and calls[0][1] == 4
+    cb2 = proto(not_a_permutation)
+    with pytest.raises(RuntimeError, match="no permutation"):
+        binding.HostScene(xres=16, yres=16, spp=1, accel_split="hlbvh", bvh_on_device=cb2)
+    # other split methods never reach the hook
+    calls.clear()
+    s = binding.HostScene(xres=16, yres=16, spp=1, accel_split="sah", bvh_on_device=cb)
+    assert not calls and s.info["n_nodes"] > 0
