@@ -10,8 +10,9 @@
 //   k_morton            30-bit Morton codes of the centroids, 10 bits per axis (:418-427, LeftShift3 / EncodeMorton3 :107-130)
 //   rocprim radix sort  (code, primitive number) pairs, stable, bits 0-29: the order RadixSort's five 6-bit passes give (:133-181, :430)
 //   k_treelet_flags + scan + k_treelet_starts   runs of equal top 12 bits = treelets (:434-452)
-//   k_emit_treelets     emitLBVH (:555-618) for one treelet per thread, nodes in preorder into the treelet's own pool
-//                       region; its leaves take their primitives in sorted order, so the leaf order IS the sorted order
+//   k_lbvh_*            emitLBVH (:555-618) for all treelets at once, one thread per sorted position (see below), nodes in
+//                       preorder into the treelet's own pool region; leaves take their primitives in sorted order, so
+//                       the leaf order IS the sorted order
 //   host: buildUpperSAH (:620-638+) over the <= 4096 treelet roots — a sequential SAH with std::partition over a few
 //                       thousand boxes (the reference runs it on one thread too) — and the preorder offsets of the subtrees
 //   k_place_nodes / k_place_upper   flattenBVHTree: every node to its depth-first index, second-child offsets rebased
@@ -131,102 +132,155 @@ __device__ __forceinline__ void box_union(float *mn, float *mx, const float *b6)
     }
 }
 
-// emitLBVH (bvh.cpp:555-618), one treelet per thread, recursion unrolled over an explicit stack (at most one interior
-// node per Morton bit 17 .. 0 on any path). Nodes go to pool[2 * start ...] in preorder: first child = node + 1, the
-// second child's (local) index in `offset`; leaves hold the global sorted position of their first primitive.
-struct EmitFrame {
-    int node, rstart, rn, rbit, state;
+// emitLBVH (bvh.cpp:555-618) without the recursion. Inside a treelet the codes are sorted, so the recursion's node for a
+// range [l, r) splits where the highest differing bit changes: with delta(i) = the highest of the low 18 bits in which
+// codes[i - 1] and codes[i] differ (-1: equal codes), the split is the one position of (l, r) with the largest delta (it
+// is unique: bit k can only rise twice inside a range if a higher bit changed in between), "same bit at both ends, try
+// the next bit" (:569-572) is that maximum being below the current bit, and a leaf is a range with fewer than
+// maxPrimsInNode primitives or with equal codes throughout (:558). Hence: position i is the split of an interior node
+// iff delta(i) >= 0 and its range — from the nearest position on the left to the nearest on the right with a larger
+// delta (or the treelet's ends) — holds at least maxPrimsInNode primitives; the ranges between consecutive splits are the
+// leaves; a node's parent is the bounding split with the smaller delta. Preorder index of a node = its depth + the
+// number of nodes that end at or before its first primitive. All of that is independent per position:
+//
+//   k_lbvh_ranges   delta, the range by two binary searches over the codes, the interior flag
+//   (scan)          F = running count of splits; ipos = the splits compacted
+//   k_lbvh_parents  parent split, histogram of range ends
+//   (scan)          PE = running count of interior range ends
+//   k_lbvh_interior depth by walking the parent chain (<= 18 steps), preorder index, the node minus its box
+//   k_lbvh_leaves   one thread per leaf: box of its primitives, then upwards — the second child to arrive at a parent
+//                   (atomic counter, device-scope fences) joins the two boxes and continues
+//
+// Nodes go to pool[2 * t0 + preorder index] (t0 = the treelet's first sorted position): first child = node + 1, the second
+// child's (local) index in `offset`; leaves hold the global sorted position of their first primitive.
+struct LbvhArrays {
+    const uint32_t *codes;
+    const int *numbers, *flags, *incl, *starts;  // flags / incl: treelet starts and their running count
+    int *L, *R, *K, *interior, *F, *ipos, *par, *ends, *PE, *pre, *visit;
 };
-__global__ __launch_bounds__(64) void k_emit_treelets(int n_treelets, const int *starts, const uint32_t *codes, const int *numbers,
-                                                      const float *bounds6, int max_prims, iile_bvh_node *pool, int *n_nodes,
-                                                      int *totals, int *error) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= n_treelets) return;
-    const int t0 = starts[t], tn = starts[t + 1] - t0;
-    const uint32_t *mp = codes + t0;
-    iile_bvh_node *out = pool + 2 * size_t(t0);
-    EmitFrame stack[20];
-    int sp = 0, next = 0, n_int = 0, n_leaf = 0;
-    int start = 0, n = tn, bit = 29 - 12;
-    for (;;) {
-        // descend: resolve (start, n, bit) into a leaf or an interior node
-        bool leaf;
-        for (;;) {
-            if (bit == -1 || n < max_prims) {
-                leaf = true;
-                break;
+__device__ __forceinline__ int delta_of(uint32_t a, uint32_t b) {
+    const uint32_t x = (a ^ b) & 0x3ffffu;
+    return x ? 31 - __clz(x) : -1;
+}
+__global__ __launch_bounds__(kBB) void k_lbvh_ranges(int n, LbvhArrays A, int max_prims) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
+        int interior = 0, l = 0, r = 0, k = -1;
+        if (!A.flags[i]) {
+            const uint32_t ci = A.codes[i];
+            k = delta_of(A.codes[i - 1], ci);
+            if (k >= 0) {
+                const int t = A.incl[i] - 1, t0 = A.starts[t], t1 = A.starts[t + 1];
+                const int sh = k + 1;
+                // lowest a in [t0, i - 1] whose code agrees with ci above bit k (they form a run ending at i - 1... and
+                // going on through i: bit k is 0 on the left of i, 1 from i on)
+                int lo = t0, hi = i - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (((A.codes[mid] ^ ci) >> sh) == 0)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                l = lo;
+                lo = i, hi = t1 - 1;  // highest b in [i, t1 - 1] that agrees
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (((A.codes[mid] ^ ci) >> sh) == 0)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                r = lo + 1;
+                interior = (r - l) >= max_prims ? 1 : 0;
             }
-            const uint32_t mask = 1u << bit;
-            if ((mp[start] & mask) == (mp[start + n - 1] & mask)) {
-                --bit;
-                continue;
-            }
-            leaf = false;
-            break;
         }
-        if (!leaf) {
-            const uint32_t mask = 1u << bit;
-            int s0 = 0, s1 = n - 1;  // binary search for the first primitive whose bit differs (:586-596)
-            while (s0 + 1 != s1) {
-                const int mid = (s0 + s1) / 2;
-                if ((mp[start + s0] & mask) == (mp[start + mid] & mask))
-                    s0 = mid;
-                else
-                    s1 = mid;
-            }
-            const int split = s1;
-            const int node = next++;
-            stack[sp++] = EmitFrame{node, start + split, n - split, bit - 1, 0};
-            out[node].axis = uint8_t(bit % 3);
-            n = split;
-            --bit;
-            continue;
-        }
-        int ret = next++;
-        {
-            float mn[3] = {kFltMax, kFltMax, kFltMax}, mx[3] = {-kFltMax, -kFltMax, -kFltMax};
-            for (int i = 0; i < n; ++i) box_union(mn, mx, bounds6 + 6 * size_t(numbers[t0 + start + i]));
-            iile_bvh_node nd;
-            for (int a = 0; a < 3; ++a) nd.bmin[a] = mn[a], nd.bmax[a] = mx[a];
-            nd.offset = t0 + start;
-            if (n > 65535) atomicExch(error, 1);  // LinearBVHNode::nPrimitives is 16 bits
-            nd.nprims = uint16_t(n);
-            nd.axis = 0;
-            nd.pad = 0;
-            out[ret] = nd;
-            ++n_leaf;
-        }
-        // return upwards
-        bool more = false;
-        while (sp > 0) {
-            EmitFrame &f = stack[sp - 1];
-            if (f.state == 0) {  // left subtree done: emit the right one
-                f.state = 1;
-                start = f.rstart, n = f.rn, bit = f.rbit;
-                more = true;
-                break;
-            }
-            // both done: ret is the second child
-            const iile_bvh_node a = out[f.node + 1], b = out[ret];
-            iile_bvh_node nd;
-            for (int c = 0; c < 3; ++c) {
-                nd.bmin[c] = b.bmin[c] < a.bmin[c] ? b.bmin[c] : a.bmin[c];
-                nd.bmax[c] = a.bmax[c] < b.bmax[c] ? b.bmax[c] : a.bmax[c];
-            }
-            nd.offset = ret;
-            nd.nprims = 0;
-            nd.axis = out[f.node].axis;
-            nd.pad = 0;
-            out[f.node] = nd;
-            ++n_int;
-            ret = f.node;
-            --sp;
-        }
-        if (!more) break;
+        A.L[i] = l, A.R[i] = r, A.K[i] = k, A.interior[i] = interior;
     }
-    n_nodes[t] = next;
-    atomicAdd(&totals[0], n_int);
-    atomicAdd(&totals[1], n_leaf);
+}
+__global__ __launch_bounds__(kBB) void k_lbvh_parents(int n, LbvhArrays A) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
+        A.visit[i] = 0;
+        if (!A.interior[i]) continue;
+        A.ipos[A.F[i] - 1] = i;
+        const int t = A.incl[i] - 1, t0 = A.starts[t], t1 = A.starts[t + 1];
+        const int l = A.L[i], r = A.R[i];
+        int p = -1;
+        if (l != t0) p = l;
+        if (r != t1 && (p < 0 || A.K[r] < A.K[p])) p = r;
+        A.par[i] = p;
+        atomicAdd(&A.ends[r], 1);
+    }
+}
+// nodes of the treelet [t0, t1) that end at or before position p (p: a leaf boundary of the treelet)
+__device__ __forceinline__ int ended_before(const LbvhArrays &A, int t0, int t1, int p) {
+    const int interior_ends = A.PE[p] - A.PE[t0];
+    const int q = p < t1 ? p : t1 - 1;
+    const int leaf_ends = (A.F[q] - A.F[t0]) + (p == t1 ? 1 : 0);
+    return interior_ends + leaf_ends;
+}
+__global__ __launch_bounds__(kBB) void k_lbvh_interior(int n, LbvhArrays A, iile_bvh_node *pool) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
+        if (!A.interior[i]) continue;
+        const int t = A.incl[i] - 1, t0 = A.starts[t], t1 = A.starts[t + 1];
+        int depth = 0;
+        for (int q = A.par[i]; q >= 0; q = A.par[q]) ++depth;
+        const int l = A.L[i];
+        const int pre = depth + (l == t0 ? 0 : ended_before(A, t0, t1, l));
+        A.pre[i] = pre;
+        iile_bvh_node nd;
+        for (int c = 0; c < 3; ++c) nd.bmin[c] = 0.f, nd.bmax[c] = 0.f;
+        const int inside_left = A.F[i - 1] - A.F[l];  // splits strictly inside (l, i): the first subtree has 2 * that + 1 nodes
+        nd.offset = pre + 2 + 2 * inside_left;
+        nd.nprims = 0;
+        nd.axis = uint8_t(A.K[i] % 3);
+        nd.pad = 0;
+        pool[2 * size_t(t0) + size_t(pre)] = nd;
+    }
+}
+__global__ __launch_bounds__(kBB) void k_lbvh_leaves(int n, LbvhArrays A, const float *bounds6, iile_bvh_node *pool, int *n_nodes,
+                                                     int *error) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
+        if (!A.flags[i] && !A.interior[i]) continue;  // leaves start at the treelet's first position and at every split
+        const int t = A.incl[i] - 1, t0 = A.starts[t], t1 = A.starts[t + 1];
+        const int splits_to_end = A.F[t1 - 1];
+        const int e = A.F[i] < splits_to_end ? A.ipos[A.F[i]] : t1;
+        int p = -1;
+        if (i != t0) p = i;
+        if (e != t1 && (p < 0 || A.K[e] < A.K[p])) p = e;
+        const int depth_above = p < 0 ? 0 : 1;
+        int pre = 0;
+        if (p >= 0) {
+            int depth = depth_above;
+            for (int q = A.par[p]; q >= 0; q = A.par[q]) ++depth;
+            pre = depth + (i == t0 ? 0 : ended_before(A, t0, t1, i));
+        }
+        if (i == t0) n_nodes[t] = 2 * (splits_to_end - A.F[t0]) + 1;
+        float mn[3] = {kFltMax, kFltMax, kFltMax}, mx[3] = {-kFltMax, -kFltMax, -kFltMax};
+        for (int j = i; j < e; ++j) box_union(mn, mx, bounds6 + 6 * size_t(A.numbers[j]));
+        iile_bvh_node *out = pool + 2 * size_t(t0);
+        iile_bvh_node nd;
+        for (int c = 0; c < 3; ++c) nd.bmin[c] = mn[c], nd.bmax[c] = mx[c];
+        nd.offset = i;
+        if (e - i > 65535) atomicExch(error, 1);  // LinearBVHNode::nPrimitives is 16 bits
+        nd.nprims = uint16_t(e - i);
+        nd.axis = 0;
+        nd.pad = 0;
+        out[pre] = nd;
+        // upwards: the second arrival at a parent owns it
+        for (int q = p; q >= 0; q = A.par[q]) {
+            __threadfence();
+            if (atomicAdd(&A.visit[q], 1) == 0) break;
+            __threadfence();
+            const int qp = A.pre[q];
+            iile_bvh_node me = out[qp];
+            const iile_bvh_node a = out[qp + 1], b = out[me.offset];
+            for (int c = 0; c < 3; ++c) {
+                me.bmin[c] = b.bmin[c] < a.bmin[c] ? b.bmin[c] : a.bmin[c];
+                me.bmax[c] = a.bmax[c] < b.bmax[c] ? b.bmax[c] : a.bmax[c];
+            }
+            out[qp] = me;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBB) void k_treelet_roots(int n_treelets, const int *starts, const iile_bvh_node *pool, Box *roots) {
@@ -473,7 +527,7 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
 
     Dev<float> d_bounds;
     Dev<uint32_t> keys6, codes, codes_sorted;
-    Dev<int> numbers, numbers_sorted, flags, incl, starts, n_nodes_t, totals, base;
+    Dev<int> numbers, numbers_sorted, flags, incl, starts, n_nodes_t, base;
     Dev<iile_bvh_node> pool, out;
     HIP_TRYB(d_bounds.alloc(6 * size_t(n)));
     HIP_TRYB(keys6.alloc(6));
@@ -484,12 +538,10 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     HIP_TRYB(flags.alloc(size_t(n)));
     HIP_TRYB(incl.alloc(size_t(n)));
     HIP_TRYB(starts.alloc(size_t(n) + 1));
-    HIP_TRYB(totals.alloc(4));
     HIP_TRYB(pool.alloc(2 * size_t(n)));
     HIP_TRYB(hipMemcpyAsync(d_bounds.p, bounds6, 6 * size_t(n) * sizeof(float), hipMemcpyHostToDevice, s));
     const uint32_t key_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRYB(hipMemcpyAsync(keys6.p, key_init, sizeof(key_init), hipMemcpyHostToDevice, s));
-    HIP_TRYB(hipMemsetAsync(totals.p, 0, 4 * sizeof(int), s));
 
     HIP_TRYB(hipEventRecord(ev[0], s));
     hipLaunchKernelGGL(k_centroid_bounds, dim3(grid_for(n)), dim3(kBB), 0, s, n, d_bounds.p, keys6.p);
@@ -522,8 +574,32 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     Dev<int> err_flag;
     HIP_TRYB(err_flag.alloc(1));
     HIP_TRYB(hipMemsetAsync(err_flag.p, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_emit_treelets, dim3((n_treelets + 63) / 64), dim3(64), 0, s, n_treelets, starts.p, codes_sorted.p,
-                       numbers_sorted.p, d_bounds.p, max_prims, pool.p, n_nodes_t.p, totals.p, err_flag.p);
+    int n_splits = 0;
+    {
+        Dev<int> arena;  // eleven int arrays of n (+ 1) entries in one allocation
+        const size_t stride = (size_t(n) + 1 + 63) & ~size_t(63);
+        HIP_TRYB(arena.alloc(11 * stride));
+        int *ap[11];
+        for (int k = 0; k < 11; ++k) ap[k] = arena.p + size_t(k) * stride;
+        int *const aEnds = ap[7], *const aPE = ap[8], *const aI = ap[3], *const aF = ap[4];
+        HIP_TRYB(hipMemsetAsync(aEnds, 0, (size_t(n) + 1) * sizeof(int), s));
+        LbvhArrays A{codes_sorted.p, numbers_sorted.p, flags.p, incl.p, starts.p, ap[0], ap[1], ap[2], aI, aF, ap[5],
+                     ap[6], aEnds, aPE, ap[9], ap[10]};
+        hipLaunchKernelGGL(k_lbvh_ranges, dim3(grid_for(n)), dim3(kBB), 0, s, n, A, max_prims);
+        size_t tmp_bytes = 0, tmp2 = 0;
+        HIP_TRYB(rocprim::inclusive_scan(nullptr, tmp_bytes, aI, aF, size_t(n), rocprim::plus<int>(), s));
+        HIP_TRYB(rocprim::inclusive_scan(nullptr, tmp2, aEnds, aPE, size_t(n) + 1, rocprim::plus<int>(), s));
+        Dev<char> tmp;
+        HIP_TRYB(tmp.alloc(std::max(tmp_bytes, tmp2)));
+        HIP_TRYB(rocprim::inclusive_scan(tmp.p, tmp_bytes, aI, aF, size_t(n), rocprim::plus<int>(), s));
+        hipLaunchKernelGGL(k_lbvh_parents, dim3(grid_for(n)), dim3(kBB), 0, s, n, A);
+        HIP_TRYB(rocprim::inclusive_scan(tmp.p, tmp2, aEnds, aPE, size_t(n) + 1, rocprim::plus<int>(), s));
+        hipLaunchKernelGGL(k_lbvh_interior, dim3(grid_for(n)), dim3(kBB), 0, s, n, A, pool.p);
+        hipLaunchKernelGGL(k_lbvh_leaves, dim3(grid_for(n)), dim3(kBB), 0, s, n, A, d_bounds.p, pool.p, n_nodes_t.p, err_flag.p);
+        HIP_TRYB(hipGetLastError());
+        HIP_TRYB(hipMemcpyAsync(&n_splits, aF + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRYB(hipStreamSynchronize(s));
+    }
     HIP_TRYB(hipEventRecord(ev[3], s));
     // the treelet roots come to the host: the upper SAH tree and the preorder offsets of all subtrees
     Dev<Box> d_roots;
@@ -531,11 +607,10 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     hipLaunchKernelGGL(k_treelet_roots, dim3((n_treelets + kBB - 1) / kBB), dim3(kBB), 0, s, n_treelets, starts.p, pool.p, d_roots.p);
     std::vector<HBox> roots(static_cast<size_t>(n_treelets));
     std::vector<int> counts(static_cast<size_t>(n_treelets));
-    int h_totals[4] = {0, 0, 0, 0}, h_err = 0;
+    int h_err = 0;
     static_assert(sizeof(HBox) == sizeof(Box), "box layouts");
     HIP_TRYB(hipMemcpyAsync(roots.data(), d_roots.p, size_t(n_treelets) * sizeof(Box), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipMemcpyAsync(counts.data(), n_nodes_t.p, size_t(n_treelets) * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRYB(hipMemcpyAsync(h_totals, totals.p, sizeof(h_totals), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipMemcpyAsync(&h_err, err_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipStreamSynchronize(s));
     if (h_err) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: a leaf holds more than 65535 primitives (equal Morton codes)");
@@ -605,8 +680,8 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     st.ms_download = ms(5, 6), st.ms_total = ms(0, 6);
     st.n_treelets = n_treelets;
     st.n_nodes = n_nodes;
-    st.n_interior = h_totals[0] + int(ub.nodes.size());
-    st.n_leaf = h_totals[1];
+    st.n_interior = n_splits + int(ub.nodes.size());
+    st.n_leaf = n_splits + n_treelets;
     if (stats) *stats = st;
     return IILE_OK;
 }

@@ -66,12 +66,11 @@ def test_direct_call_on_killeroo_bounds(binding, max_prims):
     assert sorted(order.tolist()) == list(range(n))
     assert st["n_nodes"] == len(nodes) == st["n_interior"] + st["n_leaf"] and st["n_interior"] == st["n_leaf"] - 1
     leaves = nodes[nodes["nprims"] > 0]
+    leaves = leaves[np.argsort(leaves["offset"])]  # (the upper SAH tree visits the treelets in its own order)
     assert np.array_equal(leaves["offset"], np.concatenate([[0], np.cumsum(leaves["nprims"].astype(np.int64))[:-1]]))
     assert int(leaves["nprims"].sum()) == n
-    if max_prims > 1:
-        assert int(leaves["nprims"].max()) < max(max_prims, 2) or True  # (equal Morton codes may exceed it: bit_index == -1)
     sb = b6[order]
-    for i in np.random.default_rng(5).choice(len(nodes), 2000, replace=False):
+    for i in np.random.default_rng(5).choice(len(nodes), min(2000, len(nodes)), replace=False):
         nd = nodes[i]
         if nd["nprims"] > 0:
             s = sb[nd["offset"]:nd["offset"] + nd["nprims"]]
