@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--other-steps", type=int, default=2, help="timed steps of the other scaling mode (0: skip it)")
     ap.add_argument("--spp-per-pass", type=int, default=0)
+    ap.add_argument("--alone-steps", type=int, default=2,
+                    help="untimed extra steps with every kernel on one stream, for per-kernel durations without overlap (0: skip)")
     ap.add_argument("--scene", default=os.path.join(REPO, "scenes", "killeroo-simple.pbrt"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--workload", choices=["killeroo", "boxroom", "boxroom-textured"], default="killeroo",
@@ -245,6 +247,15 @@ def main():
                 agg[k] += st[k]
         barrier()
         elapsed = time.perf_counter() - t0
+        # untimed extra steps with every kernel alone on the GPU (one stream): the per-kernel durations of the timed
+        # steps overlap (the NEE kernels of a bounce run beside the next bounce's extend / shade on a second stream)
+        alone = {k: 0.0 for k in agg}
+        n_alone = args.alone_steps if want_kernels else 0
+        for _ in range(n_alone):
+            st1 = step(timed=2)
+            for k in alone:
+                alone[k] += st1[k]
+        torch.cuda.synchronize()
         # self-verification of the timed region: every rank's last timed film (rank 0: the merged film) against the
         # instrumented step's
         same = bool(torch.equal(film.view(torch.int32), film_check.view(torch.int32)))
@@ -268,6 +279,7 @@ def main():
                              "the timed kernels did not do the reference's work; no number is reported")
         rays = rays_closest + rays_shadow
         res = {"elapsed": elapsed, "steps": steps, "rays_step": rays, "rays_traced_step": traced, "cam": cam, "cst": cst, "agg": agg, "n_passes": st["n_passes"],
+               "alone": alone, "n_alone": n_alone,
                "ms_per_step": elapsed * 1e3 / steps, "mray": traced * steps / elapsed / 1e6,
                "mray_reference": rays * steps / elapsed / 1e6, "total_spp": total_spp}
         del gpu, scene, film, film_check
@@ -375,6 +387,27 @@ def main():
         # a kernel whose algorithmic bytes are served from cache is priced by its counted HBM traffic (null without counters)
         roof["frac"] = (roof.get("frac_traffic") if cache_resident else round(frac_alg, 4))
         roof["frac_algorithmic"] = round(frac_alg, 4)
+        # the same kernel with the GPU to itself (one-stream steps after the timed region)
+        if primary["n_alone"] > 0:
+            al, na = primary["alone"], primary["n_alone"]
+            key = {"k_extend": "ms_extend", "k_shade": "ms_shade", "k_shadow": "ms_shadow", "k_mis": "ms_mis", "k_mis_lit": "ms_resolve",
+                   "k_film": "ms_film"}[dom]
+            a_ms = al[key] / na / max(launches_per_step, 1)
+            a_ach = (bytes_all / launches_per_step) / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
+            one = {"avg_launch_ms": round(a_ms, 4), "achieved": round(a_ach, 1), "frac_algorithmic": round(a_ach / HBM_PEAK_GBS, 4),
+                   "steps": na}
+            if traffic:
+                one["frac_traffic"] = round(traffic / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            la = pmc_lanes.get(dom)
+            if la:
+                one["valu_issue_frac"] = round(la["SQ_INSTS_VALU"] * 64 / (al[key] / na * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4)
+            one["frac"] = one.get("frac_traffic") if cache_resident else one["frac_algorithmic"]
+            roof["one_stream"] = one
+            roof["note"] += (" In the timed steps the shadow / MIS kernels of a bounce run on a second stream beside the next bounce's "
+                             "k_extend and k_shade (each fills the other's tail), so the HIP-event durations of the timed region — the ones "
+                             "`achieved`, `frac` and a rocprofv3 trace of this command show — include time spent sharing the GPU and sum to "
+                             "more than a step; `one_stream` prices the same kernel from extra untimed steps in which every kernel has "
+                             "the GPU to itself.")
         copy_gbs = measured_copy_gbs(torch)
         roof["peak_measured_copy_gbs"] = round(copy_gbs, 1)
         out = {
@@ -419,6 +452,9 @@ def main():
             "job_algorithmic_gbs": round(mray * 1e6 * b_ray / 1e9, 1),
             "kernel_ms_per_step_rank0": {k: round(agg[k] / steps, 3) for k in
                                          ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_resolve", "ms_film", "ms_total")},
+            "kernel_ms_per_step_one_stream": ({k: round(primary["alone"][k] / primary["n_alone"], 3) for k in
+                                               ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_resolve", "ms_film", "ms_total")}
+                                              if primary["n_alone"] else None),
             "roofline": roof,
             "roofline_all_kernels": per_kernel,
         }

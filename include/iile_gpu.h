@@ -57,7 +57,10 @@ typedef struct iile_render_params {
     int32_t spp_per_pass;           /* 0 = passes sized to the workspace budget. A pass renders all samples of a range
                                        of tiles; > 0 asks for passes of about (owned pixels x spp_per_pass) paths (tests) */
     int32_t collect_stats;          /* 1: instrumented kernels (ray / node / triangle counters) */
-    int32_t time_kernels;           /* 1: bracket every kernel with HIP events on `stream` */
+    int32_t time_kernels;           /* 1: bracket every kernel with HIP events (iile_stats::ms_*). The NEE kernels of a
+                                       bounce run on a second stream beside the next bounce's k_extend / k_shade, so
+                                       these durations overlap and sum to more than ms_total; 2: the same with every
+                                       kernel on `stream`, one after the other (each kernel alone on the GPU) */
     int32_t film_on_device;         /* 1: film_xyzw is a device pointer (stays in HBM) */
     void *stream;                   /* hipStream_t to launch on; NULL = the null stream */
 } iile_render_params;

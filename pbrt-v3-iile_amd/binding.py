@@ -407,7 +407,7 @@ class GpuScene:
         """SamplerIntegrator::Render. Returns (film, stats): film is a (H, W, 4) float32
         array, or None when `film_device_ptr` (a raw device pointer) receives it."""
         prm = RenderParams(int(k_begin), int(k_end), int(tile_rank), int(tile_nranks), int(spp_per_pass),
-                           int(bool(collect_stats)), int(bool(time_kernels)), int(film_device_ptr is not None),
+                           int(bool(collect_stats)), int(time_kernels), int(film_device_ptr is not None),
                            c_vp(stream) if stream else None)
         st = GpuStats()
         if film_device_ptr is not None:

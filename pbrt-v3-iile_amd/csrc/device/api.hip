@@ -78,6 +78,11 @@ struct iile_scene {
     void *wide_block = nullptr;
     uint64_t film_wide = 0;
     int *spill = nullptr;  // HBM overflow of the LDS traversal stacks
+    // the NEE kernels of bounce b (k_mis, k_mis_lit, k_shadow) run on a stream of their own beside k_extend of bounce
+    // b + 1: each fills the other's tail (run_pass)
+    hipStream_t nee_stream = nullptr;
+    int *spill_nee = nullptr;
+    hipEvent_t ev_shade[16] = {}, ev_nee[16] = {};
     std::vector<EventPair> events;
     size_t events_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -124,9 +129,9 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     }
     const size_t n = n_paths;
     const size_t cap = queue_capacity(n_paths, sc->n_cus);
-    // per path: L, beta (float4), hindex; per queue slot: ray_o[2], ray_d[2], hits, nee[7] (float4), shade_q
+    // per path: L, beta (float4), hindex; per queue slot: ray_o[2], ray_d[2], hits, 2 x {nee[7], mis_hit} (float4), shade_q
     const size_t f4 = sizeof(float4);
-    size_t bytes = 2 * n * f4 + 2 * n * sizeof(uint32_t) + 12 * cap * f4 + cap * sizeof(uint32_t) + cap +
+    size_t bytes = 2 * n * f4 + 2 * n * sizeof(uint32_t) + 21 * cap * f4 + cap * sizeof(uint32_t) + 2 * cap +
                    128 * sizeof(uint32_t) + sizeof(DCounters) + 16384;
     void *blk = nullptr;
     HIP_TRY(hipMalloc(&blk, bytes));
@@ -148,6 +153,10 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     B.ray_d[1] = reinterpret_cast<float4 *>(take(cap * f4));
     B.hits = reinterpret_cast<float4 *>(take(cap * f4));
     B.nee = reinterpret_cast<float4 *>(take(7 * cap * f4));
+    B.mis_hit = reinterpret_cast<float4 *>(take(cap * f4));
+    B.nee_alt = reinterpret_cast<float4 *>(take(7 * cap * f4));
+    B.mis_hit_alt = reinterpret_cast<float4 *>(take(cap * f4));
+    B.nee_mis_alt = reinterpret_cast<uint8_t *>(take(cap));
     B.hindex = reinterpret_cast<uint32_t *>(take(n * sizeof(uint32_t)));
     B.eta_scale = reinterpret_cast<float *>(take(n * sizeof(float)));
     B.shade_q = reinterpret_cast<uint32_t *>(take(cap * sizeof(uint32_t)));
@@ -270,22 +279,40 @@ void copy_counters(const DCounters &c, iile_stats *st) {
 }
 
 // Enqueue one wavefront pass on cfg.stream.
-int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_in, const LaunchCfg &cfg, bool timed) {
+int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_in, const LaunchCfg &cfg, bool timed, bool one_stream = false) {
     PassBuffers &B = sc->pb;
     PassDesc P = P_in;
     // camera rays made inside the first extend / shade (see PassDesc::gen_fused) where nothing else reads queue 0
     P.gen_fused = !cfg.count_stats && !P.list_px && !S.has_infinite && !S.probe_mode && !B.nray_out && !std::getenv("IILE_NO_FUSED_GEN");
     HIP_TRY(hipMemsetAsync(B.counts, 0, 128 * sizeof(uint32_t), cfg.stream));
-    auto timed_launch = [&](int kind, auto &&fn) -> int {
+    auto timed_launch_on = [&](hipStream_t stream, int kind, auto &&fn) -> int {
         EventPair *ep = nullptr;
         if (timed) {
             int rc = get_events(sc, kind, &ep);
             if (rc) return rc;
-            HIP_TRY(hipEventRecord(ep->a, cfg.stream));
+            HIP_TRY(hipEventRecord(ep->a, stream));
         }
         fn();
-        if (timed) HIP_TRY(hipEventRecord(ep->b, cfg.stream));
+        if (timed) HIP_TRY(hipEventRecord(ep->b, stream));
         return IILE_OK;
+    };
+    auto timed_launch = [&](int kind, auto &&fn) -> int { return timed_launch_on(cfg.stream, kind, fn); };
+    // Two streams: the shadow / MIS rays of bounce b and the extension rays of bounce b + 1 both hang on k_shade of bounce
+    // b and on nothing else of each other (k_shadow accumulates into L, k_extend reads the ray queue), so they run side
+    // by side and each fills the idle compute units of the other's tail; k_shade of bounce b + 1 waits for both (it
+    // overwrites the NEE records, and may add emitted light to L after the NEE contribution of bounce b as path.cpp
+    // does). Not with infinite lights (k_miss adds to L between the two) and not in the instrumented pass.
+    const bool two_streams = sc->nee_stream && !one_stream && !cfg.count_stats && !S.has_infinite && max_depth < 15 && !std::getenv("IILE_ONE_STREAM");
+    // Without specular lobes k_shade touches L at bounce 0 only, and with the NEE arrays doubled (even / odd bounces) it
+    // need not wait for k_shadow of the bounce before: the NEE stream then trails the main one by up to a bounce.
+    const bool nee_doubled = two_streams && !S.extended_features && B.nee_alt;
+    LaunchCfg cfg_nee = cfg;
+    if (two_streams) cfg_nee.stream = sc->nee_stream;
+    auto buffers_of = [&](int bounce, bool nee_side) {
+        PassBuffers X = B;
+        if (nee_doubled && (bounce & 1)) X.nee = B.nee_alt, X.mis_hit = B.mis_hit_alt, X.nee_mis = B.nee_mis_alt;
+        if (two_streams && nee_side) X.spill = sc->spill_nee;
+        return X;
     };
     int rc = IILE_OK;
     if (P.gen_fused) {
@@ -306,18 +333,27 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
             rc = timed_launch(6, [&] { launch_miss(S, B, b, B.queue_cap, cfg); });
             if (rc) return rc;
         }
-        rc = timed_launch(2, [&] { launch_shade(S, P, B, b, B.queue_cap, cfg); });
+        if (two_streams && !nee_doubled && b > 0) HIP_TRY(hipStreamWaitEvent(cfg.stream, sc->ev_nee[b - 1], 0));
+        if (nee_doubled && b > 1) HIP_TRY(hipStreamWaitEvent(cfg.stream, sc->ev_nee[b - 2], 0));  // its records are overwritten now
+        const PassBuffers B_shade = buffers_of(b, false), B_nee = buffers_of(b, true);
+        rc = timed_launch(2, [&] { launch_shade(S, P, B_shade, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (b < max_depth) {
+            if (two_streams) {
+                HIP_TRY(hipEventRecord(sc->ev_shade[b], cfg.stream));
+                HIP_TRY(hipStreamWaitEvent(cfg_nee.stream, sc->ev_shade[b], 0));
+            }
             // MIS rays first: the shadow kernel finishes each record (L += beta * Ld)
-            rc = timed_launch(5, [&] { launch_mis(S, B, b, B.queue_cap, cfg); });
+            rc = timed_launch_on(cfg_nee.stream, 5, [&] { launch_mis(S, B_nee, b, B.queue_cap, cfg_nee); });
             if (rc) return rc;
-            rc = timed_launch(6, [&] { launch_mis_lit(S, B, b, B.queue_cap, cfg); });
+            rc = timed_launch_on(cfg_nee.stream, 6, [&] { launch_mis_lit(S, B_nee, b, B.queue_cap, cfg_nee); });
             if (rc) return rc;
-            rc = timed_launch(3, [&] { launch_shadow(S, B, b, B.queue_cap, cfg); });
+            rc = timed_launch_on(cfg_nee.stream, 3, [&] { launch_shadow(S, B_nee, b, B.queue_cap, cfg_nee); });
             if (rc) return rc;
+            if (two_streams) HIP_TRY(hipEventRecord(sc->ev_nee[b], cfg_nee.stream));
         }
     }
+    if (two_streams && max_depth > 0) HIP_TRY(hipStreamWaitEvent(cfg.stream, sc->ev_nee[max_depth - 1], 0));
     HIP_TRY(hipGetLastError());
     return IILE_OK;
 }
@@ -833,6 +869,16 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             return bail(fail(IILE_ERR_HIP, "hipMalloc(spill) failed"));
         sc->allocs.push_back(p);
         sc->spill = static_cast<int *>(p);
+        if (hipMalloc(&p, size_t(max_traversal_threads(sc->n_cus)) * sizeof(int)) != hipSuccess)
+            return bail(fail(IILE_ERR_HIP, "hipMalloc(spill) failed"));
+        sc->allocs.push_back(p);
+        sc->spill_nee = static_cast<int *>(p);
+        if (hipStreamCreateWithFlags(&sc->nee_stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(fail(IILE_ERR_HIP, "hipStreamCreate failed"));
+        for (int i = 0; i < 16; ++i)
+            if (hipEventCreateWithFlags(&sc->ev_shade[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&sc->ev_nee[i], hipEventDisableTiming) != hipSuccess)
+                return bail(fail(IILE_ERR_HIP, "hipEventCreate failed"));
     }
     if (hipEventCreate(&sc->ev_begin) != hipSuccess || hipEventCreate(&sc->ev_end) != hipSuccess)
         return bail(fail(IILE_ERR_HIP, "hipEventCreate failed"));
@@ -931,6 +977,11 @@ void iile_scene_destroy(iile_scene *sc) {
     if (sc->flag_host) (void)hipHostFree(sc->flag_host);
     if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
     if (sc->ev_flags) (void)hipEventDestroy(sc->ev_flags);
+    if (sc->nee_stream) (void)hipStreamDestroy(sc->nee_stream);
+    for (int i = 0; i < 16; ++i) {
+        if (sc->ev_shade[i]) (void)hipEventDestroy(sc->ev_shade[i]);
+        if (sc->ev_nee[i]) (void)hipEventDestroy(sc->ev_nee[i]);
+    }
     if (sc->probe_block) (void)hipFree(sc->probe_block);
     if (sc->nray_buf) (void)hipFree(sc->nray_buf);
     for (EventPair &e : sc->events) {
@@ -1368,14 +1419,14 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (rc) return rc;
     const uint64_t pix_slots = uint64_t(P.n_owned_tiles) * 256;
     const int n_samples = k_end - k_begin;
-    // A pass renders all samples of a range of owned tiles; the range is bounded by the workspace budget (~260 B per
+    // A pass renders all samples of a range of owned tiles; the range is bounded by the workspace budget (~410 B per
     // path incl. queue padding). `spp_per_pass` (tests) asks for passes of about that many samples per pixel's worth
     // of paths: n_owned_tiles * spp_per_pass / n_samples tiles each.
     uint64_t max_paths;
     {
-        double budget_mb = 49152;  // 48 GiB of the 288 GB: one pass covers 1080p x 64 spp
+        double budget_mb = 65536;  // 64 GiB of the 288 GB: one pass covers 1080p x 64 spp
         if (const char *e = std::getenv("IILE_WORKSPACE_MB")) budget_mb = std::max(64.0, atof(e));
-        max_paths = std::min<uint64_t>(uint64_t(budget_mb * 1048576.0 / 260.0), 200000000ull);  // queue slots must fit kSlotBits
+        max_paths = std::min<uint64_t>(uint64_t(budget_mb * 1048576.0 / 410.0), 200000000ull);  // queue slots must fit kSlotBits
         if (prm->spp_per_pass > 0) max_paths = std::min<uint64_t>(max_paths, std::max<uint64_t>(1, pix_slots * uint64_t(prm->spp_per_pass)));
     }
     const uint64_t paths_per_tile = uint64_t(256) * uint64_t(n_samples);
@@ -1413,7 +1464,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
         P.n_pass_tiles = std::min(tiles_per_pass, P.n_owned_tiles - slot0);
         P.n_paths = uint32_t(uint64_t(P.n_pass_tiles) * paths_per_tile);
         if (sc->pb.flag_count) HIP_TRY(hipMemsetAsync(sc->flag_count, 0, sizeof(uint32_t), stream));
-        rc = run_pass(sc, S, sc->max_depth, P, cfg, timed);
+        rc = run_pass(sc, S, sc->max_depth, P, cfg, timed, prm->time_kernels == 2);
         if (rc) return rc;
         EventPair *ep = nullptr;
         if (timed) {
@@ -1623,9 +1674,9 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
     const uint32_t per_pixels = uint32_t(f.crop_x1 - f.crop_x0) * uint32_t(f.crop_y1 - f.crop_y0);
     const uint64_t slots_per_probe = uint64_t(P.probe_tiles) * 256;
     // probes per pass: bounded by the workspace budget like iile_render's passes
-    double budget_mb = 49152;
+    double budget_mb = 65536;
     if (const char *e = std::getenv("IILE_WORKSPACE_MB")) budget_mb = std::max(64.0, atof(e));
-    uint64_t max_paths = std::min<uint64_t>(uint64_t(budget_mb * 1048576.0 / 300.0), 200000000ull);
+    uint64_t max_paths = std::min<uint64_t>(uint64_t(budget_mb * 1048576.0 / 430.0), 200000000ull);
     const int batch = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(n_probes), max_paths / slots_per_probe)));
 
     std::vector<DProbeCam> cams;

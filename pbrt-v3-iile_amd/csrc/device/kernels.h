@@ -42,6 +42,11 @@ struct PassBuffers {
     float4 *ray_o[2];   // ping-pong ray queues
     float4 *ray_d[2];
     float4 *hits;       // [n_paths]
+    float4 *mis_hit;    // [queue_cap] k_mis -> k_mis_lit: where a MIS ray met an emitter (indexed by NEE record)
+    // second set of the NEE arrays (odd bounces): k_shade of bounce b + 1 writes its records while k_shadow of bounce b
+    // still reads (run_pass); null when the workspace holds one set
+    float4 *nee_alt, *mis_hit_alt;
+    uint8_t *nee_mis_alt;
     float4 *nee;        // 7 planes of queue_cap float4
     uint8_t *nee_mis;   // [queue_cap] k_mis: area light index + 1 the MIS ray ended on, 0 = none;
                         // after k_mis_lit: 1 = it reached the sampled light on its emitting side

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_mis_lit(DScene S, PassBuffers B, int
                 const F3 mo = F3{n2.x, n2.y, n2.z}, md = F3{n3.x, n3.y, n3.z};
                 Isect lis;
                 if (lt.type == kLightAreaTriangle) {
-                    const float4 h4 = B.hits[e];  // left by k_mis
+                    const float4 h4 = B.mis_hit[e];  // left by k_mis
                     const int prim = int(f2b(h4.x));
                     const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1],
                                  v2 = S.tri_verts[3 * size_t(prim) + 2];

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
             B.nee_mis[e] = on_light;
             // the rare ray that ends on an emitter leaves its hit for k_mis_lit (the hit records are
             // idle between shade and the next extend)
-            if (on_light && t.hit_prim >= 0) B.hits[e] = make_float4(b2f(uint32_t(hit_index(t.hit_prim))), t.b0, t.b1, t.b2);
+            if (on_light && t.hit_prim >= 0) B.mis_hit[e] = make_float4(b2f(uint32_t(hit_index(t.hit_prim))), t.b0, t.b1, t.b2);
             active = false;
         }
     }

@@ -694,3 +694,20 @@ def test_whole_number_film_positions_bitwise(binding, oracle):
         part, _ = gpu.render(tile_rank=rank, tile_nranks=2, spp_per_pass=24 + 24 * rank)
         pref, _ = oracle.render(scene, tile_rank=rank, tile_nranks=2)
         assert_bitwise(part, pref, f"strip, shard {rank} of 2")
+
+
+def test_two_stream_schedule_is_the_one_stream_film(gpu_small, scene_small, oracle):
+    """The NEE kernels of a bounce run on a second stream beside the next bounce's k_extend / k_shade (doubled NEE
+    records); time_kernels = 2 puts every kernel on the caller's stream. Same film, also across several passes, and the
+    per-kernel times of the overlapped schedule sum to at least the serial ones' order of magnitude."""
+    ref, _ = oracle.render(scene_small)
+    two, st2 = gpu_small.render(time_kernels=1)
+    one, st1 = gpu_small.render(time_kernels=2)
+    assert_bitwise(two, ref, "two streams")
+    assert_bitwise(one, ref, "one stream")
+    assert st1["ms_shade"] > 0 and st2["ms_shade"] > 0 and st1["ms_shadow"] > 0 and st2["ms_shadow"] > 0
+    chunked, st = gpu_small.render(spp_per_pass=1)
+    assert st["n_passes"] > 1
+    assert_bitwise(chunked, ref, "two streams, several passes")
+    for _ in range(3):  # the schedule is not deterministic, the film is
+        assert_bitwise(gpu_small.render()[0], ref, "repeat")
