@@ -562,6 +562,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         S.boxes_nested = 1;
         rc = pack_wide_records(d_nodes, n, n_interior, wide, wide4, &S.boxes_nested);
         if (rc) return bail(rc);
+        if (n_interior >= (1 << 25)) S.boxes_nested = 0;  // the four-wide step addresses its records with 32-bit byte offsets
         S.wide = wide;
         S.wide4 = wide4;
         if (n > 0) {

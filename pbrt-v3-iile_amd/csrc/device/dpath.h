@@ -349,7 +349,9 @@ struct RayCtx {  // per-ray constants of the watertight test (triangle.cpp:206-2
     float Sx, Sy, Sz;
     F3 inv_dir;
     int neg_mask;  // bits 0..2: dirIsNeg[xyz] (bvh.cpp:667); bits 4..5: kz, the max-|d| axis;
-                   // bit 7: some 1/d is infinite, so a slab product can be NaN (0 * inf)
+                   // bit 7: some 1/d is infinite, so a slab product can be NaN (0 * inf);
+                   // bytes 1..3: where the ray's ENTRY planes sit in a four-wide record (byte offsets of the x, y, z
+                   // planes it meets first: min planes at 0 / 16 / 32, max planes 48 further on; trav_interior4)
 };
 DEV float comp(F3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 DEV RayCtx make_ray_ctx(F3 o, F3 d) {
@@ -369,6 +371,7 @@ DEV RayCtx make_ray_ctx(F3 o, F3 d) {
     // Sz = 1.f / dz with dz the kz-th component of d: the quotient invDir already holds (one IEEE division less per ray)
     c.Sz = kz == 0 ? c.inv_dir.x : (kz == 1 ? c.inv_dir.y : c.inv_dir.z);
     c.neg_mask = (c.inv_dir.x < 0 ? 1 : 0) | (c.inv_dir.y < 0 ? 2 : 0) | (c.inv_dir.z < 0 ? 4 : 0) | (kz << 4);
+    c.neg_mask |= int(((c.inv_dir.x < 0 ? 48u : 0u) << 8) | ((c.inv_dir.y < 0 ? 64u : 16u) << 16) | ((c.inv_dir.z < 0 ? 80u : 32u) << 24));
     if (!(fabsf(c.inv_dir.x) < IILE_INF && fabsf(c.inv_dir.y) < IILE_INF && fabsf(c.inv_dir.z) < IILE_INF)) c.neg_mask |= 0x80;
     return c;
 }
@@ -887,17 +890,38 @@ DEV void trav_interior_step(const DScene &S, Trav &t, const StackRef &sr, TraceS
 // decides at their children. Rays with an infinite 1/d (NaN-capable) take the binary step,
 // which shares refs and stack entries with this one. The visit *counters* do need L and R,
 // so the instrumented kernels keep the binary step.
-DEV void trav_interior4(Trav &t, const StackRef &sr, const float4 mnx, const float4 mny, const float4 mnz,
-                        const float4 mxx, const float4 mxy, const float4 mxz, const float4 refs, const uint32_t meta) {
+// The six box planes of a record are loaded as "entry x / y / z" and "exit x / y / z": which of the min / max planes
+// that is depends on the ray's direction signs only, so the choice is made in the load ADDRESS (per-lane anyway) from the
+// three byte offsets RayCtx keeps, instead of 24 selects on loaded values per step. The exit plane of an axis is 48 bytes
+// from its entry plane, in the direction an XOR gives (records are 128-byte aligned: offset bits 0..6 are the plane's).
+struct Wide4Planes {
+    float4 ex, ey, ez, lx, ly, lz, refs;
+    uint32_t meta;
+};
+template <bool WITH_META>
+DEV Wide4Planes load_wide4(const float4 *wide4, int cur, int neg_mask) {
+    const char *base = reinterpret_cast<const char *>(wide4);
+    const uint32_t nm = uint32_t(neg_mask), rec = uint32_t(cur < 0 ? 0 : cur) * 128u;  // (32-bit offsets: checked at upload)
+    const uint32_t ax = rec + ((nm >> 8) & 0xffu), ay = rec + ((nm >> 16) & 0xffu), az = rec + (nm >> 24);
+    Wide4Planes w;
+    w.ex = *reinterpret_cast<const float4 *>(base + ax);
+    w.ey = *reinterpret_cast<const float4 *>(base + ay);
+    w.ez = *reinterpret_cast<const float4 *>(base + az);
+    w.lx = *reinterpret_cast<const float4 *>(base + (ax ^ 48u));
+    w.ly = *reinterpret_cast<const float4 *>(base + (ay ^ 80u));
+    w.lz = *reinterpret_cast<const float4 *>(base + (az ^ 112u));
+    w.refs = *reinterpret_cast<const float4 *>(base + (rec + 96u));
+    w.meta = WITH_META ? *reinterpret_cast<const uint32_t *>(base + (rec + 112u)) : 0u;
+    return w;
+}
+DEV void trav_interior4(Trav &t, const StackRef &sr, const Wide4Planes &w) {
     const RayCtx &rc = t.rc;
-    const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
+    const float4 refs = w.refs;
+    const uint32_t meta = w.meta;
     // entry / exit planes of slots (0,1) and (2,3) as float2 lanes
-    const v2f x0a = v2f{nx ? mxx.x : mnx.x, nx ? mxx.y : mnx.y}, x0b = v2f{nx ? mxx.z : mnx.z, nx ? mxx.w : mnx.w};
-    const v2f x1a = v2f{nx ? mnx.x : mxx.x, nx ? mnx.y : mxx.y}, x1b = v2f{nx ? mnx.z : mxx.z, nx ? mnx.w : mxx.w};
-    const v2f y0a = v2f{ny ? mxy.x : mny.x, ny ? mxy.y : mny.y}, y0b = v2f{ny ? mxy.z : mny.z, ny ? mxy.w : mny.w};
-    const v2f y1a = v2f{ny ? mny.x : mxy.x, ny ? mny.y : mxy.y}, y1b = v2f{ny ? mny.z : mxy.z, ny ? mny.w : mxy.w};
-    const v2f z0a = v2f{nz ? mxz.x : mnz.x, nz ? mxz.y : mnz.y}, z0b = v2f{nz ? mxz.z : mnz.z, nz ? mxz.w : mnz.w};
-    const v2f z1a = v2f{nz ? mnz.x : mxz.x, nz ? mnz.y : mxz.y}, z1b = v2f{nz ? mnz.z : mxz.z, nz ? mnz.w : mxz.w};
+    const v2f x0a = v2f{w.ex.x, w.ex.y}, x0b = v2f{w.ex.z, w.ex.w}, x1a = v2f{w.lx.x, w.lx.y}, x1b = v2f{w.lx.z, w.lx.w};
+    const v2f y0a = v2f{w.ey.x, w.ey.y}, y0b = v2f{w.ey.z, w.ey.w}, y1a = v2f{w.ly.x, w.ly.y}, y1b = v2f{w.ly.z, w.ly.w};
+    const v2f z0a = v2f{w.ez.x, w.ez.y}, z0b = v2f{w.ez.z, w.ez.w}, z1a = v2f{w.lz.x, w.lz.y}, z1b = v2f{w.lz.z, w.lz.w};
     const float fox = rc.ox, foy = rc.oy, foz = rc.oz, fix = rc.inv_dir.x, fiy = rc.inv_dir.y, fiz = rc.inv_dir.z;
     const v2f ox = v2f{fox, fox}, oy = v2f{foy, foy}, oz = v2f{foz, foz}, ix = v2f{fix, fix}, iy = v2f{fiy, fiy},
               iz = v2f{fiz, fiz}, sc = v2f{kSlabScale, kSlabScale};
@@ -942,16 +966,12 @@ DEV void trav_interior4(Trav &t, const StackRef &sr, const float4 mnx, const flo
 // near / far ordering (three dirIsNeg decisions and the selects that apply them to four refs and keys) is dropped:
 // enter the first visitable slot, defer the rest as they come. Only the visit counters depend on the order, and the
 // instrumented kernels keep the ordered binary walk.
-DEV void trav_interior4_any(Trav &t, const StackRef &sr, const float4 mnx, const float4 mny, const float4 mnz, const float4 mxx,
-                            const float4 mxy, const float4 mxz, const float4 refs) {
+DEV void trav_interior4_any(Trav &t, const StackRef &sr, const Wide4Planes &w) {
     const RayCtx &rc = t.rc;
-    const bool nx = rc.neg_mask & 1, ny = (rc.neg_mask & 2) != 0, nz = (rc.neg_mask & 4) != 0;
-    const v2f x0a = v2f{nx ? mxx.x : mnx.x, nx ? mxx.y : mnx.y}, x0b = v2f{nx ? mxx.z : mnx.z, nx ? mxx.w : mnx.w};
-    const v2f x1a = v2f{nx ? mnx.x : mxx.x, nx ? mnx.y : mxx.y}, x1b = v2f{nx ? mnx.z : mxx.z, nx ? mnx.w : mxx.w};
-    const v2f y0a = v2f{ny ? mxy.x : mny.x, ny ? mxy.y : mny.y}, y0b = v2f{ny ? mxy.z : mny.z, ny ? mxy.w : mny.w};
-    const v2f y1a = v2f{ny ? mny.x : mxy.x, ny ? mny.y : mxy.y}, y1b = v2f{ny ? mny.z : mxy.z, ny ? mny.w : mxy.w};
-    const v2f z0a = v2f{nz ? mxz.x : mnz.x, nz ? mxz.y : mnz.y}, z0b = v2f{nz ? mxz.z : mnz.z, nz ? mxz.w : mnz.w};
-    const v2f z1a = v2f{nz ? mnz.x : mxz.x, nz ? mnz.y : mxz.y}, z1b = v2f{nz ? mnz.z : mxz.z, nz ? mnz.w : mxz.w};
+    const float4 refs = w.refs;
+    const v2f x0a = v2f{w.ex.x, w.ex.y}, x0b = v2f{w.ex.z, w.ex.w}, x1a = v2f{w.lx.x, w.lx.y}, x1b = v2f{w.lx.z, w.lx.w};
+    const v2f y0a = v2f{w.ey.x, w.ey.y}, y0b = v2f{w.ey.z, w.ey.w}, y1a = v2f{w.ly.x, w.ly.y}, y1b = v2f{w.ly.z, w.ly.w};
+    const v2f z0a = v2f{w.ez.x, w.ez.y}, z0b = v2f{w.ez.z, w.ez.w}, z1a = v2f{w.lz.x, w.lz.y}, z1b = v2f{w.lz.z, w.lz.w};
     const float fox = rc.ox, foy = rc.oy, foz = rc.oz, fix = rc.inv_dir.x, fiy = rc.inv_dir.y, fiz = rc.inv_dir.z;
     const v2f ox = v2f{fox, fox}, oy = v2f{foy, foy}, oz = v2f{foz, foz}, ix = v2f{fix, fix}, iy = v2f{fiy, fiy},
               iz = v2f{fiz, fiz}, sc = v2f{kSlabScale, kSlabScale};
@@ -989,11 +1009,10 @@ DEV void trav_interior4_any(Trav &t, const StackRef &sr, const float4 mnx, const
 template <bool ANY = false>
 DEV void trav_interior_step_fast(const DScene &S, Trav &t, const StackRef &sr) {
     if (__builtin_expect(S.boxes_nested && __ballot(t.rc.neg_mask & 0x80) == 0, 1)) {
-        const float4 *w = S.wide4 + 8 * size_t(t.cur < 0 ? 0 : t.cur);
         if (ANY && IILE_ANYHIT_UNORDERED)
-            trav_interior4_any(t, sr, w[0], w[1], w[2], w[3], w[4], w[5], w[6]);
+            trav_interior4_any(t, sr, load_wide4<false>(S.wide4, t.cur, t.rc.neg_mask));
         else
-            trav_interior4(t, sr, w[0], w[1], w[2], w[3], w[4], w[5], w[6], __float_as_uint(w[7].x));
+            trav_interior4(t, sr, load_wide4<true>(S.wide4, t.cur, t.rc.neg_mask));
     } else {
         const float4 *w = S.wide + 4 * size_t(t.cur < 0 ? 0 : t.cur);
         trav_interior<false>(t, sr, nullptr, w[0], w[1], w[2], w[3]);
