@@ -449,30 +449,34 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                                 F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
                                 f2 = f2 * absdot(wi, is.sn);
                                 if (!is_black(f2) && scattering_pdf > 0) {
-                                    const float lp = EXT ? shape_pdf(S, lt, is, wi, &n_pdf_tests, &n_pdf_hits)
-                                                         : sphere_pdf(S.spheres[lt.sphere], is, wi);
-                                    if (lp != 0) {
-                                        const float weight = power_heuristic(scattering_pdf, lp);
-                                        mo = offset_ray_origin(is.p, is.perr, is.n, wi);
-                                        md = wi;
-                                        // Li is Lemit when the MIS ray finds this light facing it
-                                        Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * weight, scattering_pdf);
-                                        // The ray only matters if its closest hit is the sampled light (integrator.cpp:205-209),
-                                        // and Sphere::Pdf is the cone's pdf for ANY direction (sphere.cpp:294-306): most of these
-                                        // rays point away from the light. The traversal would run Sphere::Intersect on this very
-                                        // ray with some tMax <= inf, and every rejection of that test that depends on tMax only
-                                        // gets stricter as tMax shrinks (t0.hi > tMax, ts.hi > tMax): a ray the sphere test
-                                        // rejects at tMax = inf can never end on the light, whatever else it hits. Those rays are
-                                        // not traced by the uninstrumented kernels (the instrumented build traces them all: the
-                                        // reference's ray counters are part of parity). Triangle emitters: Shape::Pdf has already
-                                        // intersected the triangle with this ray (lp == 0 on a miss).
-                                        bool can_reach = true;
-                                        if (!COUNT && lt.type == kLightDiffuseArea) {
-                                            float t_l;
-                                            F3 od_l, ph_l;
-                                            can_reach = sphere_test(S.spheres[lt.sphere], mo, md, IILE_INF, &t_l, &od_l, &ph_l);
+                                    mo = offset_ray_origin(is.p, is.perr, is.n, wi);
+                                    md = wi;
+                                    // The ray only matters if its closest hit is the sampled light (integrator.cpp:205-209),
+                                    // and Sphere::Pdf is the cone's pdf for ANY direction (sphere.cpp:294-306): most of these
+                                    // rays point away from the light. The traversal would run Sphere::Intersect on this very
+                                    // ray with some tMax <= inf, and every rejection of that test that depends on tMax only
+                                    // gets stricter as tMax shrinks (t0.hi > tMax, ts.hi > tMax): a ray the sphere test
+                                    // rejects at tMax = inf can never end on the light, whatever else it hits. Those rays are
+                                    // not traced by the uninstrumented kernels (the instrumented build traces them all: the
+                                    // reference's ray counters are part of parity), and nothing else of this half is worked
+                                    // out for them — the test comes first, so a wavefront whose rays all miss skips the light's
+                                    // pdf, the weight and the contribution. Triangle emitters: Shape::Pdf intersects the
+                                    // triangle with this ray anyway (lp == 0 on a miss).
+                                    bool can_reach = true;
+                                    if (!COUNT && lt.type == kLightDiffuseArea) {
+                                        float t_l;
+                                        F3 od_l, ph_l;
+                                        can_reach = sphere_test(S.spheres[lt.sphere], mo, md, IILE_INF, &t_l, &od_l, &ph_l);
+                                    }
+                                    if (can_reach) {
+                                        const float lp = EXT ? shape_pdf(S, lt, is, wi, &n_pdf_tests, &n_pdf_hits)
+                                                             : sphere_pdf(S.spheres[lt.sphere], is, wi);
+                                        if (lp != 0) {
+                                            const float weight = power_heuristic(scattering_pdf, lp);
+                                            // Li is Lemit when the MIS ray finds this light facing it
+                                            Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * weight, scattering_pdf);
+                                            nee_flags |= NEE_HAS_MIS;
                                         }
-                                        if (can_reach) nee_flags |= NEE_HAS_MIS;
                                     }
                                 }
                             }
