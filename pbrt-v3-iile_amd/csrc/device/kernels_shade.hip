@@ -496,7 +496,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassB
                 B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
                 // flags / light / pid are repeated in the planes each consumer streams anyway
                 B.nee[4 * plane + eslot] = make_float4(A.x, A.y, A.z, b2f(nee_flags));
-                B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, b2f(nee_light));
+                // (the MIS contribution is read only for records whose MIS ray was lit: k_shadow)
+                if (COUNT || (nee_flags & NEE_HAS_MIS)) B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, b2f(nee_light));
                 B.nee[6 * plane + eslot] = make_float4(beta.x, beta.y, beta.z, b2f(pid));  // beta before this bounce
             }
             if (emit_mis) {
