@@ -711,3 +711,50 @@ def test_two_stream_schedule_is_the_one_stream_film(gpu_small, scene_small, orac
     assert_bitwise(chunked, ref, "two streams, several passes")
     for _ in range(3):  # the schedule is not deterministic, the film is
         assert_bitwise(gpu_small.render()[0], ref, "repeat")
+
+
+def test_edge_sizes_depths_and_crops_bitwise(binding, oracle):
+    """The small and ragged ends of the tile loop (integrator.cpp:235-330): a one-pixel film, a film narrower than a tile
+    with ragged tiles, a rank with no tile at all, maxdepth 0 (camera ray + emitted light only) and 1, a crop window whose
+    sample bounds start inside a tile grid of their own (film.cpp:47-61) — film and counters, both kernel sets."""
+    import os
+    src = open(binding.DEFAULT_SCENE).read()
+
+    def check(scene, what, ranks=()):
+        gpu = binding.GpuScene(scene)
+        ref, ost = oracle.render(scene)
+        film, st = gpu.render(collect_stats=True)
+        assert_bitwise(film, ref, what + ": film, instrumented")
+        assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"] and st["camera_rays"] == ost["camera_rays"]
+        assert_bitwise(gpu.render()[0], ref, what + ": film")
+        for rank, n in ranks:
+            part, pst = gpu.render(tile_rank=rank, tile_nranks=n)
+            pref, _ = oracle.render(scene, tile_rank=rank, tile_nranks=n)
+            assert_bitwise(part, pref, f"{what}: shard {rank}/{n}")
+        return gpu
+
+    check(binding.HostScene(xres=1, yres=1, spp=1), "1 x 1, 1 spp", ranks=((0, 8), (3, 8), (7, 8)))
+    check(binding.HostScene(xres=1, yres=1, spp=7), "1 x 1, 7 spp")
+    check(binding.HostScene(xres=37, yres=5, spp=3), "37 x 5, 3 spp", ranks=((0, 2), (1, 2), (4, 5)))
+    for depth in (0, 1):
+        path = os.path.join(os.path.dirname(binding.DEFAULT_SCENE), f"_killeroo_gpu_depth{depth}.pbrt")
+        text = src.replace('Integrator "path"', 'Integrator "path" "integer maxdepth" [%d]' % depth, 1)
+        assert text != src
+        open(path, "w").write(text)
+        try:
+            scene = binding.HostScene(path=path, xres=96, yres=64, spp=2)
+        finally:
+            os.remove(path)
+        assert scene.info["max_depth"] == depth
+        check(scene, f"maxdepth {depth}")
+    path = os.path.join(os.path.dirname(binding.DEFAULT_SCENE), "_killeroo_gpu_crop.pbrt")
+    text = src.replace('"integer yresolution"', '"float cropwindow" [0.21 0.83 0.3 0.66] "integer yresolution"', 1)
+    assert text != src
+    open(path, "w").write(text)
+    try:
+        scene = binding.HostScene(path=path, xres=200, yres=150, spp=3)
+    finally:
+        os.remove(path)
+    f = scene.film
+    assert 0 < f.crop_x0 < f.crop_x1 < 200 and 0 < f.crop_y0 < f.crop_y1 < 150 and f.crop_x0 % 16 != 0
+    check(scene, "crop window", ranks=((0, 3), (2, 3)))
