@@ -316,8 +316,7 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
     };
     int rc = IILE_OK;
     if (P.gen_fused) {
-        // no k_generate: L starts at 0, queue 0 is the dense range of path ids
-        HIP_TRY(hipMemsetAsync(B.L, 0, size_t(P.n_paths) * sizeof(float4), cfg.stream));
+        // no k_generate: queue 0 is the dense range of path ids (and the first k_extend zeroes each path's L)
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&B.counts[0]), int(P.n_paths), 1, cfg.stream));
     } else {
         rc = timed_launch(0, [&] { launch_generate(S, P, B, cfg); });
