@@ -67,7 +67,7 @@ DEV float scrambled_radical_inverse(const DScene &S, PermPtr perms, int dim, uin
     double a = double(a0), reversed = 0;
     float inv_base_n = 1;
     while (a != 0) {
-        const double next = __builtin_trunc((a + 0.5) * hd.inv_base_d);
+        const double next = __builtin_trunc(__builtin_fma(a, hd.inv_base_d, 0.5 * hd.inv_base_d));  // (a + 0.5) / base, one rounding
         const uint32_t digit = uint32_t(__builtin_fma(-next, hd.base_d, a));
         reversed = __builtin_fma(reversed, hd.base_d, double(uint32_t(perm[digit])));
         inv_base_n *= hd.inv_base;
@@ -99,7 +99,7 @@ DEV void scrambled_radical_inverse_n(const DScene &S, PermPtr perms, int dim0, u
         uint32_t digit[N], p[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const double next = __builtin_trunc((a[i] + 0.5) * hd[i].inv_base_d);
+            const double next = __builtin_trunc(__builtin_fma(a[i], hd[i].inv_base_d, 0.5 * hd[i].inv_base_d));  // (a + 0.5) / base, one rounding
             digit[i] = uint32_t(__builtin_fma(-next, hd[i].base_d, a[i]));
             a[i] = next;
         }
@@ -115,7 +115,7 @@ DEV void scrambled_radical_inverse_n(const DScene &S, PermPtr perms, int dim0, u
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         while (a[i] != 0) {
-            const double next = __builtin_trunc((a[i] + 0.5) * hd[i].inv_base_d);
+            const double next = __builtin_trunc(__builtin_fma(a[i], hd[i].inv_base_d, 0.5 * hd[i].inv_base_d));  // (a + 0.5) / base, one rounding
             const uint32_t digit = uint32_t(__builtin_fma(-next, hd[i].base_d, a[i]));
             reversed[i] = __builtin_fma(reversed[i], hd[i].base_d, double(uint32_t(perms[hd[i].perm_offset + digit])));
             inv_base_n[i] *= hd[i].inv_base;
