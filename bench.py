@@ -143,6 +143,9 @@ def main():
                     help="untimed extra steps with every kernel on one stream, for per-kernel durations without overlap (0: skip)")
     ap.add_argument("--scene", default=os.path.join(REPO, "scenes", "killeroo-simple.pbrt"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--sampler", choices=["halton", "sobol"], default=None,
+                    help="sampler in place of the scene file's (sobol: what the fork's path integrator renders with under "
+                         "IILE_PATH_SAMPLES_OVERRIDE; the headline metric is quoted with the scene's own Halton sampler)")
     ap.add_argument("--workload", choices=["killeroo", "boxroom", "boxroom-textured"], default="killeroo",
                     help="boxroom: the synthetic ~287 k-triangle closed room of tests/boxroom.py (deep-BVH stress, "
                          "SURVEY.md 8d's stand-in for the Sponza config that does not ship with the reference); "
@@ -212,7 +215,7 @@ def main():
 
     def measure(total_spp, steps, warmup, want_kernels):
         """Instrumented step, warm-up, `steps` timed steps between barriers; returns the job's numbers (rank 0)."""
-        scene = b.HostScene(path=args.scene, xres=args.xres, yres=args.yres, spp=total_spp)
+        scene = b.HostScene(path=args.scene, xres=args.xres, yres=args.yres, spp=total_spp, sampler=args.sampler)
         gpu = b.GpuScene(scene)
         h, w = scene.film_shape
         film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
@@ -430,11 +433,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": ("scenes/killeroo-simple.pbrt (the reference's shipped scene file)" if args.workload == "killeroo"
-                     else "synthetic scene generated by tests/boxroom.py (seed 12111)") + "; Halton samples generated on device",
+                     else "synthetic scene generated by tests/boxroom.py (seed 12111)") + f"; {'Sobol' if args.sampler == 'sobol' else 'Halton'} samples generated on device",
             "config": {
                 "workload": f"{workload_name} {args.xres}x{args.yres}, {total_spp} spp in all"
                             + (f" ({total_spp // world} spp-equivalents of work per GPU)" if world > 1 else "")
-                            + f", path maxdepth 5, halton, box filter, 16x16 tiles dealt diagonally over {world} rank(s)"
+                            + f", path maxdepth 5, {args.sampler or 'halton'}, box filter, 16x16 tiles dealt diagonally over {world} rank(s)"
                             + (", films merged by one RCCL reduce (iile_dist_film_reduce)" if world > 1 else ""),
                 "xres": args.xres, "yres": args.yres, "spp_total": total_spp,
                 "baseline_config": ("2 (1080p x 64 spp, 1 GPU)" if (world, total_spp) == (1, 64) else

@@ -823,6 +823,25 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         rc = upload(sc, tab.data(), tab.size(), &S.sobol_mat);
         if (rc) return bail(rc);
         S.sobol_vdc = S.sobol_mat + size_t(sb.n_dims) * 32;
+        {
+            auto byte_tables = [](const uint32_t *cols, int n_cols, uint32_t *out) {  // out[4][256]
+                for (int q = 0; q < 4; ++q)
+                    for (int v = 0; v < 256; ++v) {
+                        uint32_t x = 0;
+                        for (int j = 0; j < 8; ++j)
+                            if (((v >> j) & 1) && 8 * q + j < n_cols) x ^= cols[8 * q + j];
+                        out[q * 256 + v] = x;
+                    }
+            };
+            std::vector<uint32_t> bt(size_t(sb.n_dims) * 1024 + 2048);
+            for (int dd = 0; dd < sb.n_dims; ++dd) byte_tables(sb.matrices32 + size_t(dd) * 32, 32, bt.data() + size_t(dd) * 1024);
+            const int m2 = 2 * sb.log2_resolution;
+            byte_tables(sb.vdc, 32 - m2, bt.data() + size_t(sb.n_dims) * 1024);          // bits of the sample number k
+            byte_tables(sb.vdc_inv, m2, bt.data() + size_t(sb.n_dims) * 1024 + 1024);    // bits of the pixel word b
+            rc = upload(sc, bt.data(), bt.size(), &S.sobol_bt);
+            if (rc) return bail(rc);
+            S.sobol_vdc_bt = S.sobol_bt + size_t(sb.n_dims) * 1024;
+        }
         S.sobol = 1;
         S.sobol_log2res = sb.log2_resolution;
         S.sobol_res = sb.resolution;

@@ -131,28 +131,24 @@ DEV void scrambled_radical_inverse_n(const DScene &S, PermPtr perms, int dim0, u
 // renders with under IILE_PATH_SAMPLES_OVERRIDE (integrators/path.cpp:202-212). Indices stay below 2^32 (checked on the
 // host), so 32 columns per generator matrix are kept.
 // ===========================================================================
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-// column i of the [n_dims][32] matrix table: in HBM, or staged in LDS by the shade kernel in place of the Halton
-// permutations (the same pointer argument carries either)
-DEV uint32_t sobol_column(const DScene &S, const uint16_t *, int i) { return S.sobol_mat[i]; }
-DEV uint32_t sobol_column(const DScene &, lds_u16 *staged, int i) { return ((lds_u32 *)staged)[i]; }
-// SobolIntervalToIndex with m = log2Resolution, p = pixel - sampleBounds.pMin
+// XOR of the columns a 32-bit word selects, through its four bytes (byte tables: DScene::sobol_bt)
+DEV uint32_t sobol_xor4(const uint32_t *bt, uint32_t w) {
+    return bt[w & 255u] ^ bt[256u + ((w >> 8) & 255u)] ^ bt[512u + ((w >> 16) & 255u)] ^ bt[768u + (w >> 24)];
+}
 DEV uint32_t sobol_index(const DScene &S, int px, int py, uint32_t k) {
     const int m = S.sobol_log2res, m2 = 2 * m;
-    uint32_t index = k << m2, delta = 0;
-    for (int c = 0; c < 32 - m2; ++c)
-        if ((k >> c) & 1u) delta ^= S.sobol_vdc[c];  // Add flipped column m + c + 1.
-    const uint32_t b = ((uint32_t(px - S.samp_x0) << m) | uint32_t(py - S.samp_y0)) ^ delta;  // flipped b
-    for (int c = 0; c < m2; ++c)
-        if ((b >> c) & 1u) index ^= S.sobol_vdc[32 + c];  // Add column 2 * m - c.
-    return index;
+    // `for (c ...) if ((k >> c) & 1) delta ^= vdc[c]` ("add flipped column m + c + 1"; k < 2^(32 - 2m))
+    const uint32_t delta = sobol_xor4(S.sobol_vdc_bt, k);
+    const uint32_t b = ((uint32_t(px - S.samp_x0) << m) | uint32_t(py - S.samp_y0)) ^ delta;  // flipped b, < 2^(2m)
+    // `for (c ...) if ((b >> c) & 1) index ^= vdc_inv[c]` ("add column 2 m - c")
+    return (k << m2) ^ sobol_xor4(S.sobol_vdc_bt + 1024, b);
 }
 // SobolSampleFloat (scramble 0) followed by SobolSampler::SampleDimension's remapping of the two pixel dimensions
 template <typename PermPtr>
 DEV float sobol_sample_dimension(const DScene &S, PermPtr mats, uint32_t index, int dim, int px, int py) {
-    uint32_t v = 0;
-    for (int i = 0; i < 32 && (index >> i) != 0; ++i)
-        if ((index >> i) & 1u) v ^= sobol_column(S, mats, dim * 32 + i);
+    // SobolSample: XOR of the generator-matrix columns the index's bits select (lowdiscrepancy.h:229-241)
+    (void)mats;
+    const uint32_t v = sobol_xor4(S.sobol_bt + size_t(dim) * 1024, index);
     float s = mn(float(v) * 0x1p-32f /* 1/2^32 */, kOneMinusEpsilon);
     if (dim == 0 || dim == 1) {  // s * resolution + sampleBounds.pMin[dim], then Clamp(s - currentPixel[dim], 0, OneMinusEpsilon)
         const int pmin = dim == 0 ? S.samp_x0 : S.samp_y0, cur = dim == 0 ? px : py;

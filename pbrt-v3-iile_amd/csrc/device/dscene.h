@@ -140,6 +140,11 @@ struct DScene {
     int sobol, sobol_log2res, sobol_res, sobol_dims;
     const uint32_t *sobol_mat;
     const uint32_t *sobol_vdc;
+    // byte tables of the same matrices: entry [q][v] = XOR of the columns 8 q + j over the set bits j of the byte v, so a
+    // 32-bit index takes four lookups instead of a loop over its bits. sobol_bt: [n_dims][4][256];
+    // sobol_vdc_bt: [2][4][256] for the sample number k and for the interleaved pixel bits b of SobolIntervalToIndex
+    const uint32_t *sobol_bt;
+    const uint32_t *sobol_vdc_bt;
     // integrator
     int max_depth;
     float rr_threshold;

@@ -147,10 +147,9 @@ DEV int sample_light(const DScene &S, F3 p, float u, float *pdf) {
 template <bool COUNT, bool EXT, bool TEX>
 __global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
     // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
-    // (or, for SobolSampler, its generator matrices: sobol_column)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
     if (S.sobol) {
-        for (int i = threadIdx.x; i < S.sobol_dims * 32; i += kBlock) reinterpret_cast<uint32_t *>(s_perms_raw)[i] = S.sobol_mat[i];
+        // SobolSampler: four byte-table lookups per dimension, read through the caches (DScene::sobol_bt) — nothing staged
     } else {
         for (int i = threadIdx.x; i < S.n_perms; i += kBlock) s_perms_raw[i] = S.perms[i];
     }
@@ -583,7 +582,7 @@ void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int 
 #define IILE_SHADE_BLOCKS 3  // = resident blocks per CU at 3 waves/SIMD: the static split has no tail
 #endif
     const dim3 grid(grid_blocks(max_rays, cfg.n_cus, IILE_SHADE_BLOCKS));
-    const size_t perm_bytes = S.sobol ? size_t(S.sobol_dims) * 32 * sizeof(uint32_t) : (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
+    const size_t perm_bytes = S.sobol ? size_t(16) : (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
     if (cfg.count_stats)
         hipLaunchKernelGGL((k_shade<true, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
     else
