@@ -144,3 +144,23 @@ def test_wide_records_packed_on_the_device(binding, split):
     k = int(np.nonzero(bad["nprims"] == 0)[0][3])
     bad["bmax"][k + 1][0] = bad["bmax"][k][0] + 1
     assert not binding.bvh_pack_probe(bad)[2]
+
+
+def test_cpp_host_with_the_device_builder(binding, tmp_path):
+    """iile_pbrt --splitmethod hlbvh --bvh-device (the C++ host plugging iile_bvh_build_hlbvh into the loader) writes the
+    image the Python binding renders from the host-built HLBVH tree."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "pbrt-v3-iile_amd", "lib", "iile_pbrt")
+    out = tmp_path / "cli.pfm"
+    p = subprocess.run([exe, os.path.join(repo, "scenes", "killeroo-simple.pbrt"), "--xres", "96", "--yres", "64", "--spp", "2",
+                        "--splitmethod", "hlbvh", "--bvh-device", "--outfile", str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    img = binding.read_image(str(out))
+    scene = binding.HostScene(xres=96, yres=64, spp=2, accel_split="hlbvh")
+    film, _ = binding.GpuScene(scene).render()
+    rgb = scene.film_to_rgb(film)
+    assert img.shape == (64, 96, 3)
+    assert np.array_equal(img.view(np.uint32), rgb.view(np.uint32))
