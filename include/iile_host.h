@@ -68,17 +68,26 @@ const iile_scene_desc *iile_host_scene_desc(const iile_host_scene *scene);
 /* &desc->film, for bindings that do not mirror the whole iile_scene_desc. */
 const iile_film_desc *iile_host_scene_film(const iile_host_scene *scene);
 int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info *info);
+/* Film "string filename" of the scene file ("pbrt.exr" when it names none, src/core/api.cpp MakeFilm / film.cpp:262). */
+const char *iile_host_scene_film_filename(const iile_host_scene *scene);
 void iile_host_scene_free(iile_host_scene *scene);
 
 /* Film::to_rgb_array (src/core/film.cpp:187-225) on a film of
  * {X, Y, Z, filterWeightSum} float4 pixels over the cropped pixel bounds:
  * XYZ->RGB, divide by weight, clamp at 0, multiply by scale. rgb: 3 floats/pixel. */
 int iile_host_film_to_rgb(const iile_film_desc *film, const float *film_xyzw, float *rgb);
-/* PFM writer (the reference's WriteImage needs OpenEXR for .exr; PFM is its
- * own float format, src/core/imageio.cpp WriteImagePFM: bottom-to-top scanlines). */
+/* PFM writer (src/core/imageio.cpp WriteImagePFM: bottom-to-top scanlines). */
 int iile_host_write_pfm(const char *path, const float *rgb, int32_t width, int32_t height);
+/* WriteImageEXR (src/core/imageio.cpp:180-214) without the OpenEXR library: R, G, B as 16-bit half, ZIP-compressed
+ * scan-line blocks; the (x1 - x0) x (y1 - y0) pixels are the data window at (x0, y0) of a total_w x total_h display
+ * window (Film::WriteImage passes the cropped pixel bounds and the full resolution). */
+int iile_host_write_exr(const char *path, const float *rgb, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t total_w,
+                        int32_t total_h);
+/* WriteImage (src/core/imageio.cpp:84-136) for a whole film: .exr or .pfm by the file name's extension. */
+int iile_host_write_image(const char *path, const iile_film_desc *film, const float *rgb);
 
-/* ReadImage (src/core/imageio.cpp:60-82) for .pfm / .png / .tga: RGB floats, row 0 = top scanline. Call with
+/* ReadImage (src/core/imageio.cpp:60-82) for .exr (scan-line files; ZIP, ZIPS or uncompressed; values arrive as halfs,
+ * as through Imf::RgbaInputFile) / .pfm / .png / .tga: RGB floats, row 0 = top scanline. Call with
  * rgb == NULL to get the size, then with a buffer of 3 * width * height floats. */
 int iile_host_read_image(const char *path, int32_t *width, int32_t *height, float *rgb);
 /* The MIP pyramid built for image texture `index` of a loaded scene (ImageTexture::GetTexture + MIPMap's

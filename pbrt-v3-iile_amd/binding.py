@@ -109,7 +109,8 @@ class GpuStats(ctypes.Structure):
 HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_film", "iile_host_scene_get_info",
                 "iile_host_scene_free", "iile_host_film_to_rgb", "iile_host_write_pfm", "iile_host_last_error", "iile_host_read_image",
                 "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table",
-                "iile_host_sobol_matrices", "iile_host_sobol_vdc"]
+                "iile_host_sobol_matrices", "iile_host_sobol_vdc", "iile_host_write_exr", "iile_host_write_image",
+                "iile_host_scene_film_filename"]
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
@@ -144,6 +145,10 @@ def host_lib():
         lib.iile_host_film_to_rgb.argtypes = [ctypes.POINTER(FilmDesc), c_vp, c_vp]
         lib.iile_host_write_pfm.argtypes = [ctypes.c_char_p, c_vp, c_i32, c_i32]
         lib.iile_host_read_image.argtypes = [ctypes.c_char_p, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_vp]
+        lib.iile_host_write_exr.argtypes = [ctypes.c_char_p, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]
+        lib.iile_host_write_image.argtypes = [ctypes.c_char_p, ctypes.POINTER(FilmDesc), c_vp]
+        lib.iile_host_scene_film_filename.argtypes = [c_vp]
+        lib.iile_host_scene_film_filename.restype = ctypes.c_char_p
         lib.iile_host_scene_texture.argtypes = [c_vp, c_i32, ctypes.POINTER(Texture)]
         lib.iile_host_scene_texture_level.argtypes = [c_vp, c_i32, c_i32, c_vp]
         lib.iile_host_scene_filter_table.argtypes = [c_vp, c_vp]
@@ -181,6 +186,17 @@ def read_image(path):
     if lib.iile_host_read_image(os.fsencode(path), ctypes.byref(w), ctypes.byref(h), rgb.ctypes.data) != 0:
         raise RuntimeError(lib.iile_host_last_error().decode())
     return rgb
+
+
+def write_exr(path, rgb, origin=(0, 0), display=None):
+    """WriteImageEXR: (H, W, 3) float32 (row 0 = top scanline) as a half-float RGB OpenEXR file; `origin` = (x0, y0) of
+    the data window, `display` = (total_w, total_h) of the display window (default: the image itself)."""
+    rgb = _f32(rgb)
+    h, w = rgb.shape[:2]
+    x0, y0 = origin
+    tw, th = display if display else (x0 + w, y0 + h)
+    if host_lib().iile_host_write_exr(os.fsencode(path), rgb.ctypes.data, x0, y0, x0 + w, y0 + h, tw, th) != 0:
+        raise RuntimeError(host_lib().iile_host_last_error().decode())
 
 
 def gpu_lib():
@@ -368,6 +384,17 @@ class HostScene:
             lib.iile_host_scene_texture_level(self._h, index, l, a.ctypes.data)
             levels.append(a)
         return t, levels
+
+    @property
+    def film_filename(self):
+        """The scene file's Film "filename"."""
+        return host_lib().iile_host_scene_film_filename(self._h).decode()
+
+    def write_image(self, path, rgb):
+        """Film::WriteImage: .exr (data window = the cropped pixel bounds) or .pfm by the extension."""
+        rgb = _f32(rgb)
+        if host_lib().iile_host_write_image(os.fsencode(path), self._film, rgb.ctypes.data) != 0:
+            raise RuntimeError(host_lib().iile_host_last_error().decode())
 
     def write_pfm(self, path, rgb):
         rgb = _f32(rgb)

@@ -1,6 +1,6 @@
 // iile_pbrt — command-line front end: `pbrt scene.pbrt` for the GPU path.
 //
-//   iile_pbrt scene.pbrt [--outfile out.pfm] [--xres N --yres N --spp N --maxdepth N] [--stats]
+//   iile_pbrt scene.pbrt [--outfile out.exr|out.pfm] [--xres N --yres N --spp N --maxdepth N] [--stats]
 //             [--gpurank R/N --rendezvous FILE]
 //
 // Multi-GPU: start N copies, one per GPU, with --gpurank 0/N .. N-1/N and a common --rendezvous file on a shared
@@ -17,7 +17,7 @@
 #include "../host/gpu_integrator.h"
 
 int main(int argc, char **argv) {
-    std::string scene_file, out = "iile.pfm";
+    std::string scene_file, out;  // --outfile, else the scene's Film "filename" (as pbrt: src/main/pbrt.cpp:137, film.cpp:262)
     iile::ParamSet ps;
     bool stats = false;
     int gpu_rank = 0, gpu_nranks = 1;
@@ -54,7 +54,7 @@ int main(int argc, char **argv) {
         } else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc)
             rendezvous = argv[++i];
         else if (argv[i][0] == '-') {
-            fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.pfm] [--xres N] [--yres N] [--spp N] "
+            fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.exr|f.pfm] [--xres N] [--yres N] [--spp N] "
                             "[--maxdepth N] [--stats] [--sampler halton|sobol] [--splitmethod sah|hlbvh|middle|equal] [--bvh-device] "
                             "[--gpurank R/N --rendezvous FILE]\n");
             return 1;
@@ -90,6 +90,7 @@ int main(int argc, char **argv) {
         }
     }
     iile::Scene scene(scene_file, ps);
+    if (out.empty()) out = scene.ok() ? scene.film_filename() : std::string("pbrt.exr");
     std::unique_ptr<iile::GpuPathIntegrator> integrator(iile::CreateGpuPathIntegrator(ps, out, 0, 1, stats, comm));
     const bool ok = integrator->Render(scene);
     if (comm) iile_dist_destroy(comm);

@@ -57,6 +57,7 @@ class Scene {
     bool ok() const { return host_ != nullptr; }
     const iile_scene_desc *desc() const { return iile_host_scene_desc(host_); }
     const iile_film_desc *film() const { return iile_host_scene_film(host_); }
+    std::string film_filename() const { return host_ ? iile_host_scene_film_filename(host_) : std::string(); }
 
   private:
     iile_host_scene *host_ = nullptr;
@@ -134,7 +135,7 @@ class GpuPathIntegrator : public Integrator {
         last_stats = st;
         if (comm_ && rank_ != 0) return true;  // rank 0 holds the merged film
         iile_host_film_to_rgb(f, xyzw.data(), rgb.data());                 // Film::to_rgb_array
-        if (!output_.empty() && iile_host_write_pfm(output_.c_str(), rgb.data(), w, h) != 0) {  // Film::WriteImage
+        if (!output_.empty() && iile_host_write_image(output_.c_str(), f, rgb.data()) != 0) {  // Film::WriteImage: .exr or .pfm
             fprintf(stderr, "Error: %s\n", iile_host_last_error());
             return false;
         }

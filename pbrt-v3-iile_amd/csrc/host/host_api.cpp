@@ -65,6 +65,8 @@ const iile_film_desc *iile_host_scene_film(const iile_host_scene *scene) {
     return scene ? &scene->s.desc.film : nullptr;
 }
 
+const char *iile_host_scene_film_filename(const iile_host_scene *scene) { return scene ? scene->s.film_filename.c_str() : ""; }
+
 int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info *info) {
     if (!scene || !info) {
         g_err = "iile_host_scene_get_info: null argument";
@@ -153,13 +155,61 @@ int iile_host_write_pfm(const char *path, const float *rgb, int32_t width, int32
     return 0;
 }
 
+int iile_host_write_exr(const char *path, const float *rgb, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t total_w,
+                        int32_t total_h) {
+    if (!path || !rgb) {
+        g_err = "iile_host_write_exr: null argument";
+        return 1;
+    }
+    std::string err;
+    try {
+        if (!iile::write_exr(path, rgb, x0, y0, x1, y1, total_w, total_h, &err)) {
+            g_err = err;
+            return 2;
+        }
+    } catch (const std::exception &e) {
+        g_err = std::string("iile_host_write_exr: ") + e.what();
+        return 3;
+    }
+    return 0;
+}
+
+int iile_host_write_image(const char *path, const iile_film_desc *film, const float *rgb) {
+    if (!path || !film || !rgb) {
+        g_err = "iile_host_write_image: null argument";
+        return 1;
+    }
+    const std::string p(path);
+    auto ends_with = [&](const char *ext) {
+        const size_t n = std::strlen(ext);
+        if (p.size() < n) return false;
+        for (size_t i = 0; i < n; ++i)
+            if (std::tolower(static_cast<unsigned char>(p[p.size() - n + i])) != ext[i]) return false;
+        return true;
+    };
+    if (ends_with(".exr"))
+        return iile_host_write_exr(path, rgb, film->crop_x0, film->crop_y0, film->crop_x1, film->crop_y1, film->xres, film->yres);
+    if (ends_with(".pfm")) return iile_host_write_pfm(path, rgb, film->crop_x1 - film->crop_x0, film->crop_y1 - film->crop_y0);
+    g_err = "Can't determine image file type from suffix of filename \"" + p + "\" (.exr and .pfm are written)";
+    return 2;
+}
+
 int iile_host_read_image(const char *path, int32_t *width, int32_t *height, float *rgb) {
     std::vector<float> data;
     int w = 0, h = 0;
     std::string err;
-    if (!iile::read_image(path, &data, &w, &h, &err)) {
-        g_err = err;
-        return 1;
+    try {  // (no exception may cross the C boundary: a damaged header can ask for more memory than there is)
+        if (!path || !width || !height) {
+            g_err = "iile_host_read_image: null argument";
+            return 1;
+        }
+        if (!iile::read_image(path, &data, &w, &h, &err)) {
+            g_err = err;
+            return 1;
+        }
+    } catch (const std::exception &e) {
+        g_err = std::string("iile_host_read_image: ") + e.what();
+        return 2;
     }
     *width = w;
     *height = h;

@@ -106,6 +106,9 @@ bool load_ply(const std::string &path, std::vector<V3> *P, std::vector<V3> *N, s
 // imageio.cpp
 bool read_image(const std::string &path, std::vector<float> *rgb, int *w, int *h, std::string *err);
 bool image_is_8bit(const std::string &path);
+// exr.cpp: ReadImageEXR / WriteImageEXR (src/core/imageio.cpp:138-214) for scan-line files, without the OpenEXR library
+bool read_exr(const std::string &path, std::vector<float> *rgb, int *w, int *h, std::string *err);
+bool write_exr(const std::string &path, const float *rgb, int x0, int y0, int x1, int y1, int total_w, int total_h, std::string *err);
 // mipmap.cpp
 bool build_image_texture(const std::vector<float> &rgb, int width, int height, float scale, bool gamma, bool as_float,
                          HostTexture *out, std::string *err);

@@ -1,7 +1,7 @@
 // imageio.cpp — the image readers behind ImageTexture: ReadImage of
 // /root/reference/src/core/imageio.cpp:60-82 for the formats that need no library the image lacks:
 // PFM (imageio.cpp:350-436), TGA (imageio.cpp:216-256 over ext/targa) and PNG (imageio.cpp:258-287
-// over ext/lodepng; here: the chunk walk and un-filtering over zlib's inflate). OpenEXR is absent.
+// over ext/lodepng; here: the chunk walk and un-filtering over zlib's inflate). OpenEXR scan-line files: exr.cpp.
 //
 // All three return what the reference's readers return: RGB floats, row 0 = top scanline, 8-bit samples
 // as c / 255.f.
@@ -320,10 +320,7 @@ bool read_png(const std::string &path, std::vector<float> *rgb, int *w, int *h, 
 }  // namespace
 
 bool read_image(const std::string &path, std::vector<float> *rgb, int *w, int *h, std::string *err) {
-    if (has_extension(path, ".exr")) {
-        *err = "Unable to load \"" + path + "\": OpenEXR is not available in this build (use .pfm, .png or .tga)";
-        return false;
-    }
+    if (has_extension(path, ".exr")) return read_exr(path, rgb, w, h, err);  // exr.cpp: scan-line files, ZIP / ZIPS / none
     if (has_extension(path, ".tga")) return read_tga(path, rgb, w, h, err);
     if (has_extension(path, ".png")) return read_png(path, rgb, w, h, err);
     if (has_extension(path, ".pfm")) return read_pfm(path, rgb, w, h, err);

@@ -2,9 +2,11 @@
 // counterpart on the GPU, so the CPU side carries one). `make asan` links this driver with the host sources compiled
 // -fsanitize=address,undefined; it loads every scene file given on the command line through the C ABI (parser, Loop
 // subdivision, PLY / image readers, MIP pyramids, BVH build, sampler tables incl. the Sobol' matrices), touches the
-// flattened arrays, converts a film and frees everything. Files that are expected to be rejected are prefixed `!`.
+// flattened arrays, converts a film and frees everything. Files that are expected to be rejected are prefixed `!`; image
+// files to push through ReadImage / WriteImageEXR (well-formed or not) are prefixed `@`.
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../../include/iile_host.h"
@@ -12,6 +14,20 @@
 int main(int argc, char **argv) {
     int failures = 0;
     for (int i = 1; i < argc; ++i) {
+        if (argv[i][0] == '@') {  // an image file through ReadImage (it may be malformed: any outcome but a sanitizer report)
+            int32_t w = 0, h = 0;
+            int rc = iile_host_read_image(argv[i] + 1, &w, &h, nullptr);
+            if (rc == 0) {
+                std::vector<float> px(3 * size_t(w) * size_t(h));
+                rc = iile_host_read_image(argv[i] + 1, &w, &h, px.data());
+                if (rc == 0 && !px.empty()) {  // and back out through WriteImageEXR
+                    const std::string out = std::string(argv[i] + 1) + ".copy.exr";
+                    if (iile_host_write_exr(out.c_str(), px.data(), 1, 2, 1 + w, 2 + h, w + 5, h + 5) != 0) ++failures;
+                }
+            }
+            printf("selftest: image %s: %s (%d x %d)\n", argv[i] + 1, rc == 0 ? "read" : iile_host_last_error(), w, h);
+            continue;
+        }
         const bool expect_error = argv[i][0] == '!';
         const char *path = argv[i] + (expect_error ? 1 : 0);
         for (int sampler = 1; sampler <= 2; ++sampler) {

@@ -758,3 +758,21 @@ def test_edge_sizes_depths_and_crops_bitwise(binding, oracle):
     f = scene.film
     assert 0 < f.crop_x0 < f.crop_x1 < 200 and 0 < f.crop_y0 < f.crop_y1 < 150 and f.crop_x0 % 16 != 0
     check(scene, "crop window", ranks=((0, 3), (2, 3)))
+
+
+def test_cpp_cli_writes_the_exr_the_scene_names(scene_small, gpu_small, tmp_path):
+    """Without --outfile iile_pbrt writes the scene file's Film "filename" (killeroo-simple.exr), as pbrt does: half-float RGB
+    of the same film the C ABI renders."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "pbrt-v3-iile_amd", "lib", "iile_pbrt")
+    p = subprocess.run([exe, os.path.join(repo, "scenes", "killeroo-simple.pbrt"), "--xres", "160", "--yres", "120", "--spp", "4"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout
+    out = tmp_path / "killeroo-simple.exr"
+    assert out.exists(), p.stdout
+    img = __import__("importlib").import_module("pbrt-v3-iile_amd.binding").read_image(str(out))
+    film, _ = gpu_small.render()
+    want = scene_small.film_to_rgb(film).astype(np.float16).astype(np.float32)
+    assert_bitwise(img, want, "CLI image through OpenEXR")
