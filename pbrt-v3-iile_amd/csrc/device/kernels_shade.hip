@@ -145,7 +145,10 @@ DEV int sample_light(const DScene &S, F3 p, float u, float *pdf) {
 // 3 waves/SIMD (<= 168 VGPRs, 6 spilled): measured 38.0 ms vs 40.2 ms at 2 waves/SIMD
 // TEX: some material takes a parameter from an image texture (implies EXT)
 template <bool COUNT, bool EXT, bool TEX>
-__global__ __launch_bounds__(kBlock, 3) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
+#ifndef IILE_SHADE_WAVES
+#define IILE_SHADE_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock, IILE_SHADE_WAVES) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
     // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
     if (S.sobol) {
