@@ -123,7 +123,7 @@ constexpr int kCntMis = 112;     // [bounce] MIS rays (a dense queue of its own:
 // microsecond, far below its ~88/us saturation point.
 constexpr uint32_t kChunk = 512;
 #ifndef IILE_REFILL_IDLE
-#define IILE_REFILL_IDLE 16
+#define IILE_REFILL_IDLE 32
 #endif
 constexpr int kRefillIdle = IILE_REFILL_IDLE;  // refill once this many lanes are idle (or all)
 struct WaveFeed {
