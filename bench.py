@@ -264,7 +264,7 @@ def main():
         same = bool(torch.equal(film.view(torch.int32), film_check.view(torch.int32)))
         # rays the timed kernels traced on this rank: every main-path and shadow ray, and the MIS rays the plain build
         # does not prove irrelevant (counted by the timed step itself)
-        traced = cst["ext_rays"] + cst["shadow_rays"] + st["mis_rays_traced"]
+        traced = st["ext_rays_traced"] + cst["shadow_rays"] + st["mis_rays_traced"]
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -452,8 +452,10 @@ def main():
             "value_reference_ray_equivalents": round(primary["mray_reference"], 2),
             "rays_note": "value counts the rays the timed kernels traced. The reference makes `reference_rays_per_step` Scene::Intersect / "
                          "IntersectP calls for this frame (counted by the instrumented step); the difference is EstimateDirect's BSDF-sampled "
-                         "rays that the shade kernel proves unable to end on the sampled light (exact: the film is bit for bit the same) and "
-                         "does not trace. `value_reference_ray_equivalents` divides the reference's count by the same time.",
+                         "rays that the shade kernel proves unable to end on the sampled light, and the rays of bounce maxDepth, whose "
+                         "intersection the path loop only uses to add emitted light after a specular bounce or from an infinite light — "
+                         "neither exists in this scene (both exact: the film is bit for bit the same). `value_reference_ray_equivalents` "
+                         "divides the reference's count by the same time.",
             "camera_samples_per_step": cam,
             "rays_per_camera_sample": round(primary["rays_traced_step"] / max(cam, 1), 4),
             "n_node_per_ray": round(n_node, 3),

@@ -86,6 +86,8 @@ typedef struct iile_stats {
      * traced. The instrumented build traces all of them (== closest_rays - ext_rays); the plain build skips those its
      * shade kernel proves unable to end on the sampled light (exact: see k_shade) */
     uint64_t mis_rays_traced;
+    uint64_t ext_rays_traced;   /* extension rays k_extend traced (every build; the uninstrumented pass of a scene without specular
+                                   lobes or infinite lights does not trace the rays of bounce maxDepth, which can add nothing) */
 } iile_stats;
 
 int iile_device_count(void);

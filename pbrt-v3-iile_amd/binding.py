@@ -95,7 +95,7 @@ class GpuStats(ctypes.Structure):
         ("n_passes", c_i32), ("n_paths", c_u64), ("workspace_bytes", c_u64),
         ("ext_rays", c_u64), ("ext_nodes", c_u64), ("ext_tri_tests", c_u64), ("ext_sphere_tests", c_u64),
         ("any_tri_tests", c_u64), ("ms_shadow", c_f64), ("ms_mis", c_f64), ("ms_resolve", c_f64),
-        ("mis_rays_traced", c_u64)]
+        ("mis_rays_traced", c_u64), ("ext_rays_traced", c_u64)]
 
     def as_dict(self):
         d = {}

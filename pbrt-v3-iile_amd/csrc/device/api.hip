@@ -276,6 +276,7 @@ void copy_counters(const DCounters &c, iile_stats *st) {
     st->ext_sphere_tests = c.ext_sphere_tests;
     st->any_tri_tests = c.any_tri_tests;
     st->mis_rays_traced = c.mis_traced;
+    st->ext_rays_traced = c.ext_traced;
 }
 
 // Enqueue one wavefront pass on cfg.stream.
@@ -323,8 +324,13 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
         if (rc) return rc;
     }
     // bounces 0 .. maxDepth: the path loop exits at `bounces >= maxDepth` after
-    // intersecting (path.cpp:104), so maxDepth + 1 extend launches are needed
-    for (int b = 0; b <= max_depth; ++b) {
+    // intersecting (path.cpp:104), so maxDepth + 1 extend launches are needed — to reproduce the reference's ray count.
+    // The radiance does not need the last of them unless a specular bounce or an infinite light can add emitted light
+    // at that vertex (path.cpp:91-101): the uninstrumented pass of a scene with neither leaves the bounce out.
+    P.skip_last_bounce = !cfg.count_stats && max_depth >= 1 && !S.has_specular && !S.has_infinite && !S.probe_mode && !B.nray_out &&
+                         !std::getenv("IILE_TRACE_LAST_BOUNCE");
+    const int last_bounce = P.skip_last_bounce ? max_depth - 1 : max_depth;
+    for (int b = 0; b <= last_bounce; ++b) {
         rc = timed_launch(1, [&] { launch_extend(S, P, B, b, B.queue_cap, cfg); });
         if (rc) return rc;
         if (b == 0 && B.flag_count && sc->ev_flags) HIP_TRY(hipEventRecord(sc->ev_flags, cfg.stream));
@@ -975,6 +981,9 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     }
     // which build of k_shade the scene needs (kernels.hip launch_shade)
     S.extended_features = 0;
+    S.has_specular = 0;
+    for (int i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC) S.has_specular = 1;
     for (int i = 0; i < d->n_materials; ++i)
         if ((d->materials[i].type != IILE_MAT_MATTE && d->materials[i].type != IILE_MAT_PLASTIC) ||
             (d->materials[i].type == IILE_MAT_MATTE && d->materials[i].sigma != 0))
@@ -1555,7 +1564,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
             if (prm->collect_stats)
                 copy_counters(c, &st);
             else
-                st.mis_rays_traced = c.mis_traced;
+                st.mis_rays_traced = c.mis_traced, st.ext_rays_traced = c.ext_traced;
         }
         st.workspace_bytes = sc->ws_bytes;
         if (stats) *stats = st;

@@ -117,6 +117,7 @@ struct DScene {
     int has_infinite;         // some light is an InfiniteAreaLight: escaped rays carry radiance (k_miss)
     int extended_features;    // anything beyond one emitting sphere + matte / plastic: k_shade<.., EXT = true>
     int has_glass;            // some material transmits: the paths' etaScale is tracked
+    int has_specular;         // some material has a specular lobe (mirror, glass, uber): emitted light after such a bounce
     int has_alpha;            // some mesh has an alpha mask: the ALPHA builds of the traversal kernels run
     int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide
                               // step's skipping of intermediate nodes is exact only then
@@ -175,6 +176,9 @@ struct DCounters {
     // counted by every build (one atomic per wavefront at kernel end): the MIS rays k_mis really traced — the
     // uninstrumented k_shade drops those that cannot reach the sampled light
     unsigned long long mis_traced;
+    // likewise the extension rays k_extend really traced (the uninstrumented pass of a scene without specular lobes does
+    // not trace the rays of bounce maxDepth: path.cpp:104 breaks right after that intersection)
+    unsigned long long ext_traced;
 };
 
 }  // namespace iile

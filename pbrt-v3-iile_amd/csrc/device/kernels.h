@@ -27,6 +27,10 @@ struct PassDesc {
     // camera rays are generated inside the first k_extend and rebuilt in the first k_shade: no k_generate, no ray
     // queue for bounce 0 (run_pass decides; needs L cleared and counts[kCntRay] set beforehand)
     int gen_fused;
+    // the rays of bounce maxDepth are not traced: the path loop breaks right after intersecting them (path.cpp:104) and only
+    // a specular bounce or an infinite light makes that intersection add anything (path.cpp:91-101). Set by run_pass for
+    // uninstrumented passes of scenes with neither; k_shade of bounce maxDepth - 1 then samples no continuation.
+    int skip_last_bounce;
 };
 
 // Queue arrays (ray_o/ray_d/hits/shade_q/nee) hold `queue_cap` slots: the paths of a

@@ -508,6 +508,7 @@ __global__ __launch_bounds__(kBlock, IILE_SHADE_WAVES) void k_shade(DScene S, Pa
             }
         }
         F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
+        if (P.skip_last_bounce && bounce + 1 >= S.max_depth) surface = false;  // the next vertex could add nothing: see PassDesc
         if (surface) {
             // next direction (path.cpp:133-156)
             float u_bsdf[2];

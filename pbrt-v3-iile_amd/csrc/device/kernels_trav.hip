@@ -66,16 +66,15 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                         gen_d = make_float4(d.x, d.y, d.z, tmax);
                         trav_begin<COUNT>(S, t, o, d, tmax, &st);
                         active = true;
+                        ++n_rays;  // (GEN is never an instrumented build)
                     }
                 } else {
                     const float4 o4 = ro[slot], d4 = rd[slot];
                     if (f2b(o4.w) != kInvalid) {
                         trav_begin<COUNT>(S, t, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, &st);
                         active = true;
-                        if (COUNT) {
-                            ++n_rays;
-                            if (B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
-                        }
+                        ++n_rays;
+                        if (COUNT && B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
                     }
                 }
             }
@@ -117,6 +116,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
         if (is_hit) B.shade_q[pos] = slot | (uint32_t(t.hit_prim >> kHitClassShift) & 7u) << kSlotBits;
     }
     out_flush(shade_out, pad_shade);
+    flush_counter(&B.counters->ext_traced, n_rays);  // every build: the uninstrumented pass leaves out rays that cannot matter
     if (COUNT) {
         flush_counter(&B.counters->closest_rays, n_rays);
         flush_counter(&B.counters->ext_rays, n_rays);

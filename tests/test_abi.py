@@ -53,7 +53,7 @@ def test_struct_sizes_match_headers(binding):
     assert ctypes.sizeof(binding.BvhBuildStats) == 7 * 4 + 4 * 4 and binding.BVH_NODE.itemsize == 32
     assert ctypes.sizeof(binding.HostSceneInfo) == 14 * 4
     assert ctypes.sizeof(binding.RenderParams) == 8 * 4 + 8
-    assert ctypes.sizeof(binding.GpuStats) == 10 * 8 + 8 * 8 + 6 * 8 + 4 * 4 + 2 * 8 + 4 * 8 + 4 * 8 + 8
+    assert ctypes.sizeof(binding.GpuStats) == 10 * 8 + 8 * 8 + 6 * 8 + 4 * 4 + 2 * 8 + 4 * 8 + 4 * 8 + 8 + 8
 
 
 def test_no_cpu_fallback(binding, scene_small):
