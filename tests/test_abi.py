@@ -79,3 +79,22 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r'#include\s*[<"][^>"]*oracle|liboracle|oracle_binding|\boracle_[a-z_]+\s*\(|import oracle', txt):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_bvh_builder_has_no_cpu_path_either(binding):
+    """iile_bvh_build_hlbvh / iile_bvh_pack_probe: argument errors are reported as such; without a GPU both fail loudly."""
+    import numpy as np
+    import pytest
+    lib = binding.gpu_lib()
+    n_nodes = ctypes.c_int32(0)
+    assert lib.iile_bvh_build_hlbvh(3, None, 4, None, ctypes.byref(n_nodes), None, None) == 1  # IILE_ERR_ARG
+    assert b"null argument" in lib.iile_last_error()
+    if binding.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        binding.bvh_build_hlbvh(np.zeros((4, 6), np.float32), 4)
+    nodes = np.zeros(3, binding.BVH_NODE)
+    nodes["nprims"][1:] = 1
+    nodes["offset"][0] = 2
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        binding.bvh_pack_probe(nodes)
