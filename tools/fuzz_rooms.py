@@ -1,0 +1,51 @@
+"""One-off robustness sweep: differently seeded box rooms (tests/boxroom.py) under every light set-up and material mix,
+odd resolutions, sample counts and depths — the uninstrumented and the instrumented film against the oracle, counters too.
+usage: python tools/fuzz_rooms.py [first_seed=100] [n=24]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import __graft_entry__ as ge  # noqa: E402
+import boxroom  # noqa: E402
+import oracle_binding  # noqa: E402
+
+b = ge._load_binding()
+o = oracle_binding.Oracle()
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+lights = ["area", "quad", "multi", "spot", "point"]
+mats = ["plain", "all", "mixed"]
+bad = 0
+with tempfile.TemporaryDirectory() as td:
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        kw = dict(xres=int(rng.integers(17, 120)), yres=int(rng.integers(9, 90)), spp=int(rng.integers(1, 6)), ico_levels=int(rng.integers(1, 4)),
+                  n_blobs=int(rng.integers(1, 12)), wall_n=int(rng.integers(2, 16)), seed=seed, maxdepth=int(rng.integers(1, 8)),
+                  light=lights[seed % len(lights)], materials=mats[(seed // len(lights)) % len(mats)])
+        path = os.path.join(td, "room.pbrt")
+        try:
+            open(path, "w").write(boxroom.boxroom_pbrt(**kw))
+        except TypeError as e:
+            print("skip", kw, e)
+            continue
+        try:
+            scene = b.HostScene(path=path)
+        except RuntimeError as e:
+            print("seed", seed, "not loadable:", str(e)[:100])
+            continue
+        gpu = b.GpuScene(scene)
+        ref, ost = o.render(scene)
+        film, st = gpu.render(collect_stats=True)
+        plain, pst = gpu.render(spp_per_pass=int(rng.integers(0, 3)))
+        ok = np.array_equal(film.view(np.uint32), ref.view(np.uint32)) and np.array_equal(plain.view(np.uint32), ref.view(np.uint32))
+        ok = ok and st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"] and st["nodes_closest"] == ost["nodes_closest"]
+        print("seed", seed, kw["light"], kw["materials"], f'{kw["xres"]}x{kw["yres"]}x{kw["spp"]} depth {kw["maxdepth"]}', "OK" if ok else "MISMATCH",
+              "traced", pst["ext_rays_traced"], "of", st["ext_rays"])
+        bad += 0 if ok else 1
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
