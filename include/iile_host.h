@@ -86,7 +86,7 @@ int iile_host_write_exr(const char *path, const float *rgb, int32_t x0, int32_t 
 /* WriteImage (src/core/imageio.cpp:84-136) for a whole film: .exr or .pfm by the file name's extension. */
 int iile_host_write_image(const char *path, const iile_film_desc *film, const float *rgb);
 
-/* ReadImage (src/core/imageio.cpp:60-82) for .exr (scan-line files; ZIP, ZIPS or uncompressed; values arrive as halfs,
+/* ReadImage (src/core/imageio.cpp:60-82) for .exr (scan-line files; ZIP, ZIPS, RLE or uncompressed; values arrive as halfs,
  * as through Imf::RgbaInputFile) / .pfm / .png / .tga: RGB floats, row 0 = top scanline. Call with
  * rgb == NULL to get the size, then with a buffer of 3 * width * height floats. */
 int iile_host_read_image(const char *path, int32_t *width, int32_t *height, float *rgb);

@@ -6,9 +6,9 @@
 // over the three, the image is the file's DATA window. WriteImageEXR writes R, G, B as half (Imf::WRITE_RGB), data
 // window = the cropped pixel bounds inside a display window of the full resolution.
 //
-// Supported here: single-part scan-line files, compression NONE, ZIPS (one line per block) and ZIP (16 lines), channel
+// Supported here: single-part scan-line files, compression NONE, RLE, ZIPS (one line per block) and ZIP (16 lines), channel
 // types HALF / FLOAT / UINT, both line orders. Tiles, deep data, multi-part files, sub-sampled channels and the PIZ /
-// RLE / PXR24 / B44 / DWA coders are refused with a message naming what was found (Imf's default coder for RGBA
+// PXR24 / B44 / DWA coders are refused with a message naming what was found (Imf's default coder for RGBA
 // files is PIZ: such files have to be re-saved as ZIP). The writer emits ZIP.
 //
 // File layout (OpenEXR "Technical Introduction" / ImfHeader, ImfZip): magic 0x01312f76, version 2, attributes
@@ -182,9 +182,9 @@ bool read_exr(const std::string &path, std::vector<float> *rgb, int *w, int *h, 
     }
     if (!have_dw || channels.empty() || compression < 0) return fail("header lacks channels, compression or dataWindow");
     static const char *const kCoder[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
-    if (compression != 0 && compression != 2 && compression != 3)
+    if (compression < 0 || compression > 3)
         return fail(std::string("compression ") + (compression < 10 ? kCoder[compression] : "?") +
-                    " is not supported (re-save the file with ZIP, ZIPS or no compression)");
+                    " is not supported (re-save the file with ZIP, ZIPS, RLE or no compression)");
     const int64_t width = int64_t(dw[2]) - dw[0] + 1, height = int64_t(dw[3]) - dw[1] + 1;
     if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return fail("bad data window");
     (void)line_order;  // every chunk names its first line
@@ -229,9 +229,29 @@ bool read_exr(const std::string &path, std::vector<float> *rgb, int *w, int *h, 
             std::memcpy(raw.data(), d.data() + c.pos, want);
         } else {
             tmp.resize(want);
-            uLongf got = uLongf(want);
-            if (uncompress(tmp.data(), &got, d.data() + c.pos, uLong(nbytes)) != Z_OK || got != want)
-                return fail("zlib stream does not decode to the block size");
+            if (compression == 1) {  // ImfRle rleUncompress: a negative count n copies -n bytes, a count n >= 0 repeats the next byte n + 1 times
+                const uint8_t *in = d.data() + c.pos;
+                size_t left = size_t(nbytes), at = 0;
+                while (left > 0) {
+                    const int cnt = int(int8_t(*in++));
+                    if (cnt < 0) {
+                        const size_t k = size_t(-cnt);
+                        if (left < k + 1 || at + k > want) return fail("run-length data does not decode to the block size");
+                        std::memcpy(tmp.data() + at, in, k);
+                        in += k, at += k, left -= k + 1;
+                    } else {
+                        const size_t k = size_t(cnt) + 1;
+                        if (left < 2 || at + k > want) return fail("run-length data does not decode to the block size");
+                        std::memset(tmp.data() + at, *in++, k);
+                        at += k, left -= 2;
+                    }
+                }
+                if (at != want) return fail("run-length data does not decode to the block size");
+            } else {
+                uLongf got = uLongf(want);
+                if (uncompress(tmp.data(), &got, d.data() + c.pos, uLong(nbytes)) != Z_OK || got != want)
+                    return fail("zlib stream does not decode to the block size");
+            }
             for (size_t i = 1; i < want; ++i) tmp[i] = uint8_t(tmp[i - 1] + tmp[i] - 128);  // predictor
             const size_t half = (want + 1) / 2;
             for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];  // re-interleave

@@ -22,6 +22,37 @@ def _zip_block(raw):
     return packed if len(packed) < len(raw) else raw.tobytes()
 
 
+def _rle_block(raw):
+    """ImfRle over the same de-interleaved, delta-coded bytes: runs of 3 .. 128 equal bytes as (n - 1, byte), other bytes in
+    literal groups of up to 127 as (-n, bytes...); raw when that is no shorter."""
+    raw = np.frombuffer(raw, np.uint8)
+    t = np.concatenate([raw[0::2], raw[1::2]]).astype(np.int32)
+    d = t.copy()
+    d[1:] = (t[1:] - t[:-1] + 384) & 255
+    d = d.astype(np.uint8).tobytes()
+    out, i, lit = bytearray(), 0, bytearray()
+
+    def flush():
+        while lit:
+            k = min(127, len(lit))
+            out.extend(struct.pack("b", -k) + bytes(lit[:k]))
+            del lit[:k]
+
+    while i < len(d):
+        j = i
+        while j < len(d) and d[j] == d[i] and j - i < 128:
+            j += 1
+        if j - i >= 3:
+            flush()
+            out.extend(struct.pack("b", j - i - 1) + d[i:i + 1])
+            i = j
+        else:
+            lit.append(d[i])
+            i += 1
+    flush()
+    return bytes(out) if len(out) < len(raw) else raw.tobytes()
+
+
 def _unzip_block(data, n):
     if len(data) == n:
         return np.frombuffer(data, np.uint8)
@@ -55,14 +86,14 @@ def _make_exr(channels, data_window, compression, line_order=0, display=None, ve
     head += _attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0))
     head += _attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
     head += b"\0"
-    per = {0: 1, 2: 1, 3: 16}[compression]
+    per = {0: 1, 1: 1, 2: 1, 3: 16}[compression]
     blocks = []
     for first in range(0, h, per):
         raw = b""
         for y in range(first, min(first + per, h)):
             for _, typ, arr in channels:
                 raw += arr[y].astype({0: "<u4", 1: "<f2", 2: "<f4"}[typ]).tobytes()
-        blocks.append((y0 + first, raw if compression == 0 else _zip_block(raw)))
+        blocks.append((y0 + first, raw if compression == 0 else _rle_block(raw) if compression == 1 else _zip_block(raw)))
     order = blocks if line_order == 0 else blocks[::-1]  # decreasing Y: chunks stored bottom-up, table still by block
     pos = len(head) + 8 * len(blocks)
     offsets, body = {}, b""
@@ -131,7 +162,7 @@ def test_written_file_decodes_independently(binding, tmp_path):
     assert np.array_equal(binding.read_image(str(path)), _as_half(img))
 
 
-@pytest.mark.parametrize("compression", [0, 2, 3])
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
 @pytest.mark.parametrize("line_order", [0, 1])
 def test_reads_independently_encoded_files(binding, tmp_path, compression, line_order):
     """FLOAT and HALF channels mixed, an alpha channel to skip, both line orders, every supported coder: values arrive as
@@ -142,6 +173,11 @@ def test_reads_independently_encoded_files(binding, tmp_path, compression, line_
     path = tmp_path / "f.exr"
     path.write_bytes(_make_exr([("R", 2, r), ("G", 1, g), ("B", 2, b), ("A", 1, a)], (3, 4, 3 + w - 1, 4 + h - 1), compression, line_order,
                                display=(0, 0, 99, 99)))
+    if compression == 1:  # something for the run-length coder to find
+        g[5:9] = 0.5
+        a[:] = 1.0
+        path.write_bytes(_make_exr([("R", 2, r), ("G", 1, g), ("B", 2, b), ("A", 1, a)], (3, 4, 3 + w - 1, 4 + h - 1), compression, line_order,
+                                   display=(0, 0, 99, 99)))
     img = binding.read_image(str(path))
     assert img.shape == (h, w, 3)
     assert np.array_equal(img, np.stack([_as_half(r), _as_half(g), _as_half(b)], axis=-1))
