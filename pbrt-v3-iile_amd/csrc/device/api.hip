@@ -306,7 +306,7 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
     const bool two_streams = sc->nee_stream && !one_stream && !cfg.count_stats && !S.has_infinite && max_depth < 15 && !std::getenv("IILE_ONE_STREAM");
     // Without specular lobes k_shade touches L at bounce 0 only, and with the NEE arrays doubled (even / odd bounces) it
     // need not wait for k_shadow of the bounce before: the NEE stream then trails the main one by up to a bounce.
-    const bool nee_doubled = two_streams && !S.extended_features && B.nee_alt;
+    const bool nee_doubled = two_streams && !S.has_specular && B.nee_alt;
     LaunchCfg cfg_nee = cfg;
     if (two_streams) cfg_nee.stream = sc->nee_stream;
     auto buffers_of = [&](int bounce, bool nee_side) {
