@@ -327,9 +327,13 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
     // intersecting (path.cpp:104), so maxDepth + 1 extend launches are needed — to reproduce the reference's ray count.
     // The radiance does not need the last of them unless a specular bounce or an infinite light can add emitted light
     // at that vertex (path.cpp:91-101): the uninstrumented pass of a scene with neither leaves the bounce out.
-    P.skip_last_bounce = !cfg.count_stats && max_depth >= 1 && !S.has_specular && !S.has_infinite && !S.probe_mode && !B.nray_out &&
-                         !std::getenv("IILE_TRACE_LAST_BOUNCE");
-    const int last_bounce = P.skip_last_bounce ? max_depth - 1 : max_depth;
+    // With specular lobes (or an infinite light) around, the rays that leave the last shaded vertex through a specular
+    // lobe are the only ones whose intersection can still add something: the others are dropped there (1); without
+    // either, the whole bounce is (2).
+    P.skip_last_bounce = 0;
+    if (!cfg.count_stats && max_depth >= 1 && !S.probe_mode && !B.nray_out && !std::getenv("IILE_TRACE_LAST_BOUNCE"))
+        P.skip_last_bounce = S.has_specular ? 1 : 2;
+    const int last_bounce = (P.skip_last_bounce == 2) ? max_depth - 1 : max_depth;
     for (int b = 0; b <= last_bounce; ++b) {
         rc = timed_launch(1, [&] { launch_extend(S, P, B, b, B.queue_cap, cfg); });
         if (rc) return rc;

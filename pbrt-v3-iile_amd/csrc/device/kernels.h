@@ -27,9 +27,11 @@ struct PassDesc {
     // camera rays are generated inside the first k_extend and rebuilt in the first k_shade: no k_generate, no ray
     // queue for bounce 0 (run_pass decides; needs L cleared and counts[kCntRay] set beforehand)
     int gen_fused;
-    // the rays of bounce maxDepth are not traced: the path loop breaks right after intersecting them (path.cpp:104) and only
-    // a specular bounce or an infinite light makes that intersection add anything (path.cpp:91-101). Set by run_pass for
-    // uninstrumented passes of scenes with neither; k_shade of bounce maxDepth - 1 then samples no continuation.
+    // The path loop breaks right after intersecting the ray of bounce maxDepth (path.cpp:104), and that intersection adds
+    // emitted light — from the surface hit or, for an escaped ray, from the infinite lights — only after a specular bounce
+    // (path.cpp:91-101). Set by run_pass for uninstrumented passes: 1 = k_shade of bounce maxDepth - 1 keeps only the
+    // continuations sampled from a specular lobe; 2 = the scene has no specular lobe: no continuation is sampled there and
+    // bounce maxDepth is not launched at all.
     int skip_last_bounce;
 };
 

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kBlock, IILE_SHADE_WAVES) void k_shade(DScene S, Pa
             }
         }
         F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
-        if (P.skip_last_bounce && bounce + 1 >= S.max_depth) surface = false;  // the next vertex could add nothing: see PassDesc
+        if (P.skip_last_bounce == 2 && bounce + 1 >= S.max_depth) surface = false;  // the next vertex could add nothing: see PassDesc
         if (surface) {
             // next direction (path.cpp:133-156)
             float u_bsdf[2];
@@ -552,6 +552,8 @@ __global__ __launch_bounds__(kBlock, IILE_SHADE_WAVES) void k_shade(DScene S, Pa
                     }
                 }
             }
+            // last shaded vertex: only a specular continuation can still pick up emitted light (PassDesc::skip_last_bounce)
+            if (EXT && P.skip_last_bounce == 1 && bounce + 1 >= S.max_depth && !sampled_specular) alive = false;
             if (EXT && alive && S.has_glass) B.eta_scale[pid] = eta_scale;
             // sampler dimension | specularBounce << 16
             if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim) | (sampled_specular ? 0x10000u : 0u)));
