@@ -41,6 +41,8 @@ typedef struct iile_host_overrides {
      * libiile_gpu.so has this signature (the last argument receives NULL). libiile_host itself stays free of HIP. */
     int (*bvh_build)(int32_t n_prims, const float *bounds6, int32_t max_prims_in_node, iile_bvh_node *nodes_out,
                      int32_t *n_nodes_out, int32_t *order_out, void *stats);
+    int32_t quick_render; /* pbrt --quick (PbrtOptions.quickRender): a quarter of the file's resolution per axis (film.cpp:284-285)
+                             and one pixel sample (halton.cpp:136, sobol.cpp:69); explicit xres / yres / spp above still win */
 } iile_host_overrides;
 #define IILE_SPLIT_KEEP 0
 #define IILE_SPLIT_SAH 1

@@ -25,7 +25,7 @@ c_vp = ctypes.c_void_p
 
 class HostOverrides(ctypes.Structure):
     _fields_ = [("xres", c_i32), ("yres", c_i32), ("spp", c_i32), ("max_depth", c_i32), ("sampler", c_i32),
-                ("accel_split", c_i32), ("bvh_build", c_vp)]
+                ("accel_split", c_i32), ("bvh_build", c_vp), ("quick_render", c_i32)]
 
 
 SAMPLERS = {None: 0, "": 0, "halton": 1, "sobol": 2}  # IILE_SAMPLER_* of include/iile_host.h
@@ -320,7 +320,8 @@ def _i32(a):
 class HostScene:
     """Scene loaded and flattened by libiile_host (ParseFile + MakeScene in the reference)."""
 
-    def __init__(self, path=DEFAULT_SCENE, xres=0, yres=0, spp=0, max_depth=0, sampler=None, accel_split=None, bvh_on_device=False):
+    def __init__(self, path=DEFAULT_SCENE, xres=0, yres=0, spp=0, max_depth=0, sampler=None, accel_split=None, bvh_on_device=False,
+                 quick=False):
         """sampler: None keeps the scene file's; "sobol" is what the fork's path integrator renders with under
         IILE_PATH_SAMPLES_OVERRIDE (src/integrators/path.cpp:202-212). accel_split: BVHAccel's "splitmethod" in place of
         the file's. bvh_on_device: split method "hlbvh" is built by libiile_gpu's iile_bvh_build_hlbvh,
@@ -332,7 +333,7 @@ class HostScene:
             hook = ctypes.cast(gpu_lib().iile_bvh_build_hlbvh, c_vp)
         elif bvh_on_device:  # any other builder with iile_host_overrides::bvh_build's signature (a ctypes function object)
             hook = ctypes.cast(bvh_on_device, c_vp)
-        ov = HostOverrides(int(xres), int(yres), int(spp), int(max_depth), SAMPLERS[sampler], SPLITS[accel_split], hook)
+        ov = HostOverrides(int(xres), int(yres), int(spp), int(max_depth), SAMPLERS[sampler], SPLITS[accel_split], hook, int(bool(quick)))
         rc = lib.iile_host_load_pbrt(os.fsencode(path), ctypes.byref(ov), ctypes.byref(self._h))
         if rc != 0:
             raise RuntimeError(f"iile_host_load_pbrt({path}) failed: {lib.iile_host_last_error().decode()}")

@@ -19,15 +19,30 @@
 int main(int argc, char **argv) {
     std::string scene_file, out;  // --outfile, else the scene's Film "filename" (as pbrt: src/main/pbrt.cpp:137, film.cpp:262)
     iile::ParamSet ps;
-    bool stats = false;
+    bool stats = false, quiet = false;
     int gpu_rank = 0, gpu_nranks = 1;
     std::string rendezvous;
     for (int i = 1; i < argc; ++i) {
         auto arg_int = [&](int &dst) {
             if (i + 1 < argc) dst = atoi(argv[++i]);
         };
-        if (!strcmp(argv[i], "--outfile") && i + 1 < argc)
+        // pbrt's own options keep their spellings (src/main/pbrt.cpp:106-186): --outfile, --quick, --quiet, --nthreads and
+        // the logging flags are accepted (the last three change nothing here: no thread pool, no glog)
+        if ((!strcmp(argv[i], "--outfile") || !strcmp(argv[i], "-outfile")) && i + 1 < argc)
             out = argv[++i];
+        else if (!strncmp(argv[i], "--outfile=", 10))
+            out = argv[i] + 10;
+        else if (!strcmp(argv[i], "--quick") || !strcmp(argv[i], "-quick"))
+            ps.quick = true;
+        else if (!strcmp(argv[i], "--quiet") || !strcmp(argv[i], "-quiet"))
+            quiet = true;
+        else if (!strcmp(argv[i], "--logtostderr") || !strncmp(argv[i], "--nthreads=", 11) || !strncmp(argv[i], "--logdir=", 9) ||
+                 !strncmp(argv[i], "--minloglevel=", 14) || !strncmp(argv[i], "--v=", 4))
+            ;
+        else if ((!strcmp(argv[i], "--nthreads") || !strcmp(argv[i], "-nthreads") || !strcmp(argv[i], "--logdir") || !strcmp(argv[i], "-logdir") ||
+                  !strcmp(argv[i], "--minloglevel") || !strcmp(argv[i], "-minloglevel") || !strcmp(argv[i], "--v") || !strcmp(argv[i], "-v")) &&
+                 i + 1 < argc)
+            ++i;
         else if (!strcmp(argv[i], "--xres"))
             arg_int(ps.xresolution);
         else if (!strcmp(argv[i], "--yres"))
@@ -54,7 +69,7 @@ int main(int argc, char **argv) {
         } else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc)
             rendezvous = argv[++i];
         else if (argv[i][0] == '-') {
-            fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.exr|f.pfm] [--xres N] [--yres N] [--spp N] "
+            fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.exr|f.pfm] [--quick] [--quiet] [--nthreads N] [--xres N] [--yres N] [--spp N] "
                             "[--maxdepth N] [--stats] [--sampler halton|sobol] [--splitmethod sah|hlbvh|middle|equal] [--bvh-device] "
                             "[--gpurank R/N --rendezvous FILE]\n");
             return 1;
@@ -97,7 +112,7 @@ int main(int argc, char **argv) {
     if (!ok) return 1;
     if (gpu_rank != 0) return 0;
     const iile_stats &st = integrator->last_stats;
-    printf("rendered %llu camera samples in %.1f ms -> %s\n", (unsigned long long)st.n_paths, st.ms_total, out.c_str());
+    if (!quiet) printf("rendered %llu camera samples in %.1f ms -> %s\n", (unsigned long long)st.n_paths, st.ms_total, out.c_str());
     if (stats)
         printf("rays: %llu closest + %llu shadow; BVH nodes visited %llu + %llu; triangle tests %llu (%llu hits)\n",
                (unsigned long long)st.closest_rays, (unsigned long long)st.shadow_rays,

@@ -34,12 +34,13 @@ struct ParamSet {  // the two knobs CreatePathIntegrator reads; <= 0 keeps the s
     int sampler = IILE_SAMPLER_KEEP;  // IILE_SAMPLER_SOBOL: the fork's IILE_PATH_SAMPLES_OVERRIDE (path.cpp:202-212)
     int splitmethod = IILE_SPLIT_KEEP;  // BVHAccel "splitmethod" (bvh.cpp:740-760) in place of the file's
     bool bvh_on_device = false;         // split method "hlbvh" built by iile_bvh_build_hlbvh instead of the host builder
+    bool quick = false;                 // pbrt --quick
 };
 
 class Scene {
   public:
     explicit Scene(const std::string &pbrt_file, const ParamSet &ps = ParamSet()) {
-        iile_host_overrides ov = {ps.xresolution, ps.yresolution, ps.pixelsamples, ps.maxdepth, ps.sampler, ps.splitmethod, nullptr};
+        iile_host_overrides ov = {ps.xresolution, ps.yresolution, ps.pixelsamples, ps.maxdepth, ps.sampler, ps.splitmethod, nullptr, ps.quick ? 1 : 0};
         if (ps.bvh_on_device)
             ov.bvh_build = [](int32_t n, const float *b6, int32_t maxp, iile_bvh_node *nodes, int32_t *n_nodes, int32_t *order, void *) {
                 return iile_bvh_build_hlbvh(n, b6, maxp, nodes, n_nodes, order, nullptr);

@@ -1,4 +1,6 @@
 // host_api.cpp — C ABI of libiile_host.so (see include/iile_host.h).
+#include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <exception>
 
@@ -33,6 +35,11 @@ int iile_host_load_pbrt(const char *path, const iile_host_overrides *ov, iile_ho
             return 2;
         }
         if (ov) {
+            if (ov->quick_render) {
+                hs->s.xres = std::max(1, hs->s.xres / 4);
+                hs->s.yres = std::max(1, hs->s.yres / 4);
+                hs->s.spp = 1;
+            }
             if (ov->xres > 0) hs->s.xres = ov->xres;
             if (ov->yres > 0) hs->s.yres = ov->yres;
             if (ov->spp > 0) hs->s.spp = ov->spp;

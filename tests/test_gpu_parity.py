@@ -776,3 +776,23 @@ def test_cpp_cli_writes_the_exr_the_scene_names(scene_small, gpu_small, tmp_path
     film, _ = gpu_small.render()
     want = scene_small.film_to_rgb(film).astype(np.float16).astype(np.float32)
     assert_bitwise(img, want, "CLI image through OpenEXR")
+
+
+def test_cpp_cli_takes_pbrts_own_options(tmp_path):
+    """iile_pbrt accepts pbrt's command line (src/main/pbrt.cpp:106-186): --quick renders a quarter of the resolution at one
+    sample per pixel, --outfile= / --nthreads / --quiet / the logging flags are taken as pbrt spells them."""
+    import importlib
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "pbrt-v3-iile_amd", "lib", "iile_pbrt")
+    out = tmp_path / "q.pfm"
+    p = subprocess.run([exe, "--quick", "--quiet", "--nthreads", "8", "--nthreads=4", "--logtostderr", "--v=1", "--outfile=" + str(out),
+                        os.path.join(repo, "scenes", "killeroo-simple.pbrt")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "rendered" not in p.stdout, p.stdout
+    b = importlib.import_module("pbrt-v3-iile_amd.binding")
+    img = b.read_image(str(out))
+    scene = b.HostScene(quick=True)
+    assert img.shape == (scene.info["yres"], scene.info["xres"], 3) == (175, 175, 3) and scene.info["spp"] == 1
+    film, _ = b.GpuScene(scene).render()
+    assert_bitwise(img, scene.film_to_rgb(film), "--quick image")

@@ -606,3 +606,13 @@ def test_bvh_build_hook_is_called_and_checked(binding):
     calls.clear()
     s = binding.HostScene(xres=16, yres=16, spp=1, accel_split="sah", bvh_on_device=cb)
     assert not calls and s.info["n_nodes"] > 0
+
+
+def test_quick_render_override(binding):
+    """pbrt --quick: a quarter of the file's resolution per axis (film.cpp:284-285) and one pixel sample (halton.cpp:136);
+    explicit overrides still win."""
+    full = binding.HostScene()
+    q = binding.HostScene(quick=True)
+    assert (q.info["xres"], q.info["yres"], q.info["spp"]) == (max(1, full.info["xres"] // 4), max(1, full.info["yres"] // 4), 1)
+    q2 = binding.HostScene(quick=True, xres=50, spp=3)
+    assert (q2.info["xres"], q2.info["yres"], q2.info["spp"]) == (50, max(1, full.info["yres"] // 4), 3)
