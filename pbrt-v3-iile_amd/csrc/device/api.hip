@@ -1515,7 +1515,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
             HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_flags, 0));
             rc = patch_prepare(sc, S, P, sc->aux_stream, &plan);
             if (rc) return rc;
-            HIP_TRY(hipStreamSynchronize(stream));
+            // (its index lists are built on the host while the pass is still running; its gathers queue up behind the pass)
             rc = patch_pass_finish(sc, S, &plan, &entries, stream);
             if (rc) return rc;
         }
