@@ -515,14 +515,15 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     if (n_prims > (1 << 30)) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: more than 2^30 primitives");
     const int n = n_prims;
     const int max_prims = std::min(255, max_prims_in_node);  // BVHAccel's constructor, bvh.cpp:187
-    hipEvent_t ev[7];
-    for (hipEvent_t &e : ev) HIP_TRYB(hipEventCreate(&e));
+    hipEvent_t ev[7] = {};
     struct EvGuard {
         hipEvent_t *e;
         ~EvGuard() {
-            for (int i = 0; i < 7; ++i) (void)hipEventDestroy(e[i]);
+            for (int i = 0; i < 7; ++i)
+                if (e[i]) (void)hipEventDestroy(e[i]);
         }
     } guard{ev};
+    for (hipEvent_t &e : ev) HIP_TRYB(hipEventCreate(&e));
     hipStream_t s = nullptr;
 
     Dev<float> d_bounds;
