@@ -10,12 +10,15 @@ file through torch.distributed.run), finished by ONE sum-reduction of the {X,Y,Z
 RCCL through the C ABI (iile_dist_film_reduce). The film stays in HBM for the whole timed region.
 
 Workloads (BASELINE.json configs):
-  N = 1                      config 2: 1920x1080 x 64 spp on one GPU
-  N > 1, --scaling weak      1920x1080 x 128*N spp, every rank renders its 1/N of the tiles at 128*N spp:
-                             per-GPU work fixed; N = 8 is config 3 (1024 spp over 8 GPUs)
-  --scaling strong           the fixed 1920x1080 x 1024 spp frame of config 3 at any N
-The primary mode's number is `value`; the other mode is measured too (a few steps, `--other-steps 0`
-turns it off) and reported under `other_mode`, so that one run per N yields both curves.
+  N = 1                      config 2: 1920x1080 x 64 spp on one GPU (the configuration the metric is quoted on)
+  N > 1 (default: strong)    config 3: the fixed 1920x1080 x 1024 spp frame, its tiles shared out over the N ranks —
+                             the SAME frame at every N, so that the N = 1, 2, 4, 8 values are one scaling curve
+                             (`"scaling": "strong"`; rays/s is the unit at every N, and one GPU renders 1024 spp at the
+                             rate it renders 64: `other_mode` of the N = 1 line)
+  --scaling weak             1920x1080 x 128*N spp, every rank renders its 1/N of the tiles at 128*N spp:
+                             per-GPU work fixed; N = 8 is config 3 again
+The primary mode's number is `value` over the full `--steps`; the other mode is measured too (a few steps,
+`--other-steps 0` turns it off) and reported under `other_mode`.
 
 Rank 0 prints one JSON line. `value` is whole-job Mray/s over the rays the timed kernels traced (a ray = one
 Scene::Intersect or Scene::IntersectP call of the reference; MIS rays that provably cannot end on the sampled light are
@@ -136,7 +139,8 @@ def main():
                     help="weak mode: pixel samples per GPU-equivalent (total = spp * gpus); default 64 at 1 GPU "
                          "(BASELINE config 2), 128 at N > 1 (N = 8: config 3's 1024 spp)")
     ap.add_argument("--strong-spp", type=int, default=1024, help="strong mode: pixel samples of the fixed frame (config 3)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: weak at N = 1 (config 2), strong at N > 1 (config 3's fixed 1024 spp frame)")
     ap.add_argument("--other-steps", type=int, default=2, help="timed steps of the other scaling mode (0: skip it)")
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--alone-steps", type=int, default=2,
@@ -165,6 +169,8 @@ def main():
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     if args.spp <= 0:
         args.spp = 64 if world == 1 else 128
+    if args.scaling is None:
+        args.scaling = "weak" if world == 1 else "strong"
 
     cleanup = []
     workload_name = "killeroo-simple"
@@ -206,6 +212,11 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         comm = mg.create_comm(dist, f"cuda:{local_rank}")  # the film merge goes through the C ABI (libiile_dist.so)
+    # libiile_dist.so is linked against librccl by SONAME and torch ships its own copy: two RCCL instances in one
+    # process would each think they own the GPUs' IPC state. Exactly one may be mapped.
+    rccl_mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+    if world > 1 and len({os.path.realpath(x) for x in rccl_mapped}) != 1:
+        raise SystemExit(f"bench.py: libiile_dist and torch resolved different RCCL libraries: {rccl_mapped}")
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():

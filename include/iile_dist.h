@@ -48,9 +48,20 @@ int iile_dist_barrier(iile_dist *comm, void *stream);
 int iile_dist_sum_u64(iile_dist *comm, uint64_t *values, int32_t n);
 int iile_dist_max_f64(iile_dist *comm, double *values, int32_t n);
 
-/* Rendezvous for hosts without a launcher (iile_pbrt --gpurank r/n --rendezvous FILE): rank 0 creates the id and
- * writes it to `path` (atomically: temporary file + rename), the others wait until it appears (timeout_s seconds). */
+/* One status word agreed by all ranks (collective; synchronous): *all_ok = 1 iff every rank passed ok != 0. A rank that
+ * failed locally (scene did not load, out of memory, render error) calls it with 0 instead of leaving the collective
+ * sequence, so that the others do not wait for it inside the film merge. */
+int iile_dist_all_ok(iile_dist *comm, int32_t ok, int32_t *all_ok);
+
+/* Rendezvous for hosts without a launcher (iile_pbrt --gpurank r/n --rendezvous FILE [--job TOKEN]): rank 0 removes
+ * whatever `path` holds, creates the id and publishes {magic, token, id} there (atomically: temporary file + rename);
+ * the others wait (timeout_s seconds) for a file of THIS launch: with a token != 0 the file's token must match,
+ * without one the file must not be older than the call (a file left behind by an earlier run is rejected either
+ * way, never handed to ncclCommInitRank). iile_dist_rendezvous_file is the token-less form. */
+int iile_dist_rendezvous_file_token(const char *path, int32_t rank, uint64_t token, uint8_t id[IILE_DIST_ID_BYTES], int32_t timeout_s);
 int iile_dist_rendezvous_file(const char *path, int32_t rank, uint8_t id[IILE_DIST_ID_BYTES], int32_t timeout_s);
+/* After iile_dist_create on every rank (collective): once all ranks have joined, rank 0 removes the file. */
+int iile_dist_rendezvous_done(iile_dist *comm, const char *path);
 
 const char *iile_dist_last_error(void);
 

@@ -118,7 +118,8 @@ GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iil
                "iile_iispt_hemi_points", "iile_iispt_gather", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
-                "iile_dist_rendezvous_file", "iile_dist_last_error"]
+                "iile_dist_rendezvous_file", "iile_dist_rendezvous_file_token", "iile_dist_rendezvous_done", "iile_dist_all_ok",
+                "iile_dist_last_error"]
 DIST_ID_BYTES = 128
 
 _host = None
@@ -252,6 +253,9 @@ def dist_lib():
         lib.iile_dist_sum_u64.argtypes = [c_vp, c_vp, c_i32]
         lib.iile_dist_max_f64.argtypes = [c_vp, c_vp, c_i32]
         lib.iile_dist_rendezvous_file.argtypes = [ctypes.c_char_p, c_i32, c_vp, c_i32]
+        lib.iile_dist_rendezvous_file_token.argtypes = [ctypes.c_char_p, c_i32, ctypes.c_uint64, c_vp, c_i32]
+        lib.iile_dist_rendezvous_done.argtypes = [c_vp, ctypes.c_char_p]
+        lib.iile_dist_all_ok.argtypes = [c_vp, c_i32, ctypes.POINTER(c_i32)]
         _dist = lib
     return _dist
 

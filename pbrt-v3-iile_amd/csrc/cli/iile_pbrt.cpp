@@ -1,11 +1,14 @@
 // iile_pbrt — command-line front end: `pbrt scene.pbrt` for the GPU path.
 //
 //   iile_pbrt scene.pbrt [--outfile out.exr|out.pfm] [--xres N --yres N --spp N --maxdepth N] [--stats]
-//             [--gpurank R/N --rendezvous FILE]
+//             [--gpurank R/N --rendezvous FILE [--job TOKEN]]
 //
 // Multi-GPU: start N copies, one per GPU, with --gpurank 0/N .. N-1/N and a common --rendezvous file on a shared
-// file system (rank 0 publishes the RCCL id there). Rank R uses GPU R modulo the visible devices, renders its tiles
+// file system (rank 0 publishes the RCCL id there; --job TOKEN, any number the launcher picks per launch, ties the file
+// to this launch). Rank R uses GPU R modulo the visible devices, renders its tiles
 // and the films are merged on rank 0 by one RCCL reduction (include/iile_dist.h); rank 0 writes the image.
+// --gpurank 0/1 is the same code path with a communicator of one rank (tools/multi_gpu_cmdline.sh prints the N-rank
+// command lines).
 //
 // Mirrors src/main/pbrt.cpp:97-219 (argument loop, ParseFile, Render) on top of
 // the C ABI: libiile_host loads and flattens the scene, libiile_gpu renders it,
@@ -21,6 +24,8 @@ int main(int argc, char **argv) {
     iile::ParamSet ps;
     bool stats = false, quiet = false;
     int gpu_rank = 0, gpu_nranks = 1;
+    bool ranked = false;  // --gpurank given: render through the communicator branch, also for N = 1
+    unsigned long long job_token = 0;
     std::string rendezvous;
     for (int i = 1; i < argc; ++i) {
         auto arg_int = [&](int &dst) {
@@ -66,12 +71,15 @@ int main(int argc, char **argv) {
                 fprintf(stderr, "iile_pbrt: --gpurank wants R/N with 0 <= R < N\n");
                 return 1;
             }
+            ranked = true;
         } else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc)
             rendezvous = argv[++i];
+        else if (!strcmp(argv[i], "--job") && i + 1 < argc)
+            job_token = strtoull(argv[++i], nullptr, 0);
         else if (argv[i][0] == '-') {
             fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.exr|f.pfm] [--quick] [--quiet] [--nthreads N] [--xres N] [--yres N] [--spp N] "
                             "[--maxdepth N] [--stats] [--sampler halton|sobol] [--splitmethod sah|hlbvh|middle|equal] [--bvh-device] "
-                            "[--gpurank R/N --rendezvous FILE]\n");
+                            "[--gpurank R/N --rendezvous FILE [--job TOKEN]]\n");
             return 1;
         } else
             scene_file = argv[i];
@@ -87,7 +95,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     iile_dist *comm = nullptr;
-    if (gpu_nranks > 1) {
+    if (ranked) {
         if (rendezvous.empty()) {
             fprintf(stderr, "iile_pbrt: --gpurank R/N needs --rendezvous FILE\n");
             return 1;
@@ -98,8 +106,8 @@ int main(int argc, char **argv) {
             return 1;
         }
         uint8_t id[IILE_DIST_ID_BYTES];
-        if (iile_dist_rendezvous_file(rendezvous.c_str(), gpu_rank, id, 120) != IILE_OK ||
-            iile_dist_create(id, gpu_rank, gpu_nranks, &comm) != IILE_OK) {
+        if (iile_dist_rendezvous_file_token(rendezvous.c_str(), gpu_rank, job_token, id, 120) != IILE_OK ||
+            iile_dist_create(id, gpu_rank, gpu_nranks, &comm) != IILE_OK || iile_dist_rendezvous_done(comm, rendezvous.c_str()) != IILE_OK) {
             fprintf(stderr, "Error: multi-GPU set-up: %s\n", iile_dist_last_error());
             return 1;
         }

@@ -132,7 +132,7 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     // per path: L, beta (float4), hindex; per queue slot: ray_o[2], ray_d[2], hits, 2 x {nee[7], mis_hit} (float4), shade_q
     const size_t f4 = sizeof(float4);
     size_t bytes = 2 * n * f4 + 2 * n * sizeof(uint32_t) + 21 * cap * f4 + cap * sizeof(uint32_t) + 2 * cap +
-                   128 * sizeof(uint32_t) + sizeof(DCounters) + 16384;
+                   kCntWords * sizeof(uint32_t) + sizeof(DCounters) + 16384;
     void *blk = nullptr;
     HIP_TRY(hipMalloc(&blk, bytes));
     sc->ws_block = blk;
@@ -161,7 +161,7 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     B.eta_scale = reinterpret_cast<float *>(take(n * sizeof(float)));
     B.shade_q = reinterpret_cast<uint32_t *>(take(cap * sizeof(uint32_t)));
     B.nee_mis = reinterpret_cast<uint8_t *>(take(cap));
-    B.counts = reinterpret_cast<uint32_t *>(take(128 * sizeof(uint32_t)));
+    B.counts = reinterpret_cast<uint32_t *>(take(kCntWords * sizeof(uint32_t)));
     B.counters = reinterpret_cast<DCounters *>(take(sizeof(DCounters)));
     B.nray_out = nullptr;
     B.spill = sc->spill;
@@ -285,7 +285,7 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
     PassDesc P = P_in;
     // camera rays made inside the first extend / shade (see PassDesc::gen_fused) where nothing else reads queue 0
     P.gen_fused = !cfg.count_stats && !P.list_px && !S.has_infinite && !S.probe_mode && !B.nray_out && !std::getenv("IILE_NO_FUSED_GEN");
-    HIP_TRY(hipMemsetAsync(B.counts, 0, 128 * sizeof(uint32_t), cfg.stream));
+    HIP_TRY(hipMemsetAsync(B.counts, 0, kCntWords * sizeof(uint32_t), cfg.stream));
     auto timed_launch_on = [&](hipStream_t stream, int kind, auto &&fn) -> int {
         EventPair *ep = nullptr;
         if (timed) {

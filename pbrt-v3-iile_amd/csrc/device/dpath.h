@@ -1366,7 +1366,9 @@ DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect
 // Matte / Plastic / Uber / Mirror ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70,
 // uber.cpp:45-100 with opacity 1 and Kt 0, mirror.cpp:44-55)
 // EXT = false: the scene has matte and plastic only (checked at upload); the specular lobes then fold away
-template <bool EXT = true>
+// MICRO = false: the caller knows the material has no microfacet lobe (a matte-only build of k_shade): has_micro is a
+// constant and everything behind it folds away
+template <bool EXT = true, bool MICRO = true>
 DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     Bsdf b;
     b.ns = is.sn;
@@ -1385,7 +1387,7 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.on_b = m.on_b;
     b.mtype = EXT ? m.type : kMatPlastic;
     b.eta = m.eta;
-    if (m.type == kMatPlastic || (EXT && m.type == kMatUber)) {
+    if (MICRO && (m.type == kMatPlastic || (EXT && m.type == kMatUber))) {
         b.ks = F3{clampf(m.ks[0], 0, IILE_INF), clampf(m.ks[1], 0, IILE_INF), clampf(m.ks[2], 0, IILE_INF)};
         b.has_micro = !is_black(b.ks);
         if (b.has_micro) ++b.n_lobes;

@@ -114,6 +114,8 @@ constexpr int kCntConHead = 64;  // [bounce] chunk cursor of the NEE queue (shad
 constexpr int kCntMisHead = 80;  // [bounce] chunk cursor of the NEE queue (MIS kernel)
 constexpr int kCntShdHead = 96;  // [bounce] chunk cursor of the shade queue
 constexpr int kCntMis = 112;     // [bounce] MIS rays (a dense queue of its own: most NEE records have none)
+constexpr int kCntShdHead2 = 128; // [bounce] chunk cursor of the shade queue, the second class-specialised k_shade build
+static_assert(kCntShdHead2 + 16 <= kCntWords, "PassBuffers::counts layout");
 
 // Persistent-wavefront work feed. A wavefront reserves kChunk consecutive queue
 // slots with one atomic and hands them to its lanes as they go idle, so lanes

@@ -39,6 +39,7 @@ struct PassDesc {
 // pass plus the padding that block-reserved appends leave behind (kernels.hip).
 // shade-queue entries carry the shading class above the slot number
 constexpr int kSlotBits = 28;
+constexpr int kCntWords = 144;  // words of PassBuffers::counts (layout in kcommon.h)
 struct PassBuffers {
     uint32_t queue_cap;
     float4 *L;          // [n_paths] radiance so far (xyz)
@@ -57,7 +58,7 @@ struct PassBuffers {
     uint8_t *nee_mis;   // [queue_cap] k_mis: area light index + 1 the MIS ray ended on, 0 = none;
                         // after k_mis_lit: 1 = it reached the sampled light on its emitting side
     uint32_t *shade_q;  // [n_paths] queue slots whose ray hit something (input of shade)
-    uint32_t *counts;   // 128 words: queue sizes and chunk cursors per bounce (layout in kernels.hip)
+    uint32_t *counts;   // kCntWords words: queue sizes and chunk cursors per bounce (layout in kernels.hip)
     DCounters *counters;
     uint32_t *nray_out; // optional [2*n_paths] per-path {closest, shadow} ray counts (tests)
     int *spill;         // [kSpillStackDepth][max grid threads] overflow of the LDS traversal stacks

@@ -9,6 +9,8 @@
 #include <string>
 #include <thread>
 
+#include <sys/stat.h>
+
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -126,30 +128,89 @@ int iile_dist_barrier(iile_dist *d, void *stream) {
 int iile_dist_sum_u64(iile_dist *d, uint64_t *values, int32_t n) { return all_reduce_host(d, values, n, ncclUint64, ncclSum); }
 int iile_dist_max_f64(iile_dist *d, double *values, int32_t n) { return all_reduce_host(d, values, n, ncclFloat64, ncclMax); }
 
-int iile_dist_rendezvous_file(const char *path, int32_t rank, uint8_t id[IILE_DIST_ID_BYTES], int32_t timeout_s) {
+// File layout: "IILEDIST" (8 bytes), the job token (u64, 0 = none), the RCCL unique id (128 bytes).
+namespace {
+constexpr char kRvMagic[8] = {'I', 'I', 'L', 'E', 'D', 'I', 'S', 'T'};
+constexpr size_t kRvBytes = 16 + IILE_DIST_ID_BYTES;
+}  // namespace
+
+int iile_dist_rendezvous_file_token(const char *path, int32_t rank, uint64_t token, uint8_t id[IILE_DIST_ID_BYTES], int32_t timeout_s) {
     if (!path || !id || rank < 0) return fail(IILE_ERR_ARG, "iile_dist_rendezvous_file: bad argument");
+    const auto wall_start = std::chrono::system_clock::now();
     if (rank == 0) {
+        // a file left by an earlier run holds a dead id: it goes before anything of this run can be read
+        (void)std::remove(path);
         int rc = iile_dist_unique_id(id);
         if (rc) return rc;
         const std::string tmp = std::string(path) + ".tmp";
         FILE *f = std::fopen(tmp.c_str(), "wb");
         if (!f) return fail(IILE_ERR_ARG, "iile_dist_rendezvous_file: cannot write " + tmp);
-        const bool ok = std::fwrite(id, 1, IILE_DIST_ID_BYTES, f) == IILE_DIST_ID_BYTES;
+        bool ok = std::fwrite(kRvMagic, 1, 8, f) == 8 && std::fwrite(&token, 1, 8, f) == 8;
+        ok = ok && std::fwrite(id, 1, IILE_DIST_ID_BYTES, f) == IILE_DIST_ID_BYTES;
         if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path) != 0)
             return fail(IILE_ERR_ARG, std::string("iile_dist_rendezvous_file: cannot publish ") + path);
         return IILE_OK;
     }
+    // Ranks != 0 accept a file only if it belongs to THIS launch: with a token, the token must match; without one, the
+    // file must not be older than this call (a rank that starts before rank 0 has removed a previous run's file would
+    // otherwise pick up that run's dead id and hang in ncclCommInitRank). One second of slack for file-system time stamps.
     const auto t0 = std::chrono::steady_clock::now();
+    std::string why = "no file";
     for (;;) {
+        struct stat sb;
         if (FILE *f = std::fopen(path, "rb")) {
-            const size_t n = std::fread(id, 1, IILE_DIST_ID_BYTES, f);
+            unsigned char buf[kRvBytes];
+            const size_t n = std::fread(buf, 1, kRvBytes, f);
+            const bool have_stat = fstat(fileno(f), &sb) == 0;
             std::fclose(f);
-            if (n == IILE_DIST_ID_BYTES) return IILE_OK;
+            uint64_t file_token = 0;
+            if (n == kRvBytes && std::memcmp(buf, kRvMagic, 8) == 0) {
+                std::memcpy(&file_token, buf + 8, 8);
+                bool fresh;
+                if (token != 0) {
+                    fresh = file_token == token;
+                    if (!fresh) why = "a file of another launch (token mismatch)";
+                } else {
+                    const auto mtime = std::chrono::system_clock::from_time_t(have_stat ? sb.st_mtime : 0);
+                    fresh = have_stat && file_token == 0 && mtime + std::chrono::seconds(1) >= wall_start;
+                    if (!fresh) why = file_token != 0 ? "a file published with a token" : "a file older than this process (a previous run's)";
+                }
+                if (fresh) {
+                    std::memcpy(id, buf + 16, IILE_DIST_ID_BYTES);
+                    return IILE_OK;
+                }
+            } else {
+                why = "a file that is not a rendezvous record";
+            }
         }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > double(timeout_s))
-            return fail(IILE_ERR_ARG, std::string("iile_dist_rendezvous_file: timed out waiting for ") + path);
+            return fail(IILE_ERR_ARG, std::string("iile_dist_rendezvous_file: timed out waiting for ") + path + " (last seen: " + why + ")");
         std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
+}
+
+int iile_dist_rendezvous_file(const char *path, int32_t rank, uint8_t id[IILE_DIST_ID_BYTES], int32_t timeout_s) {
+    return iile_dist_rendezvous_file_token(path, rank, 0, id, timeout_s);
+}
+
+int iile_dist_rendezvous_done(iile_dist *d, const char *path) {
+    if (!d || !path) return fail(IILE_ERR_ARG, "iile_dist_rendezvous_done: bad argument");
+    // every rank has joined once a collective over the communicator completes; then nobody reads the file any more
+    uint64_t one = 1;
+    int rc = iile_dist_sum_u64(d, &one, 1);
+    if (rc) return rc;
+    if (one != uint64_t(d->size)) return fail(IILE_ERR_HIP, "iile_dist_rendezvous_done: the communicator does not span every rank");
+    if (d->rank == 0) (void)std::remove(path);
+    return IILE_OK;
+}
+
+int iile_dist_all_ok(iile_dist *d, int32_t ok, int32_t *all_ok) {
+    if (!d || !all_ok) return fail(IILE_ERR_ARG, "iile_dist_all_ok: bad argument");
+    uint64_t failed = ok ? 0 : 1;
+    int rc = iile_dist_sum_u64(d, &failed, 1);
+    if (rc) return rc;
+    *all_ok = failed == 0 ? 1 : 0;
+    return IILE_OK;
 }
 
 }  // extern "C"

@@ -89,8 +89,8 @@ struct Reader {
     size_t pos = 0;
     bool ok = true;
     explicit Reader(const std::vector<uint8_t> &data) : d(data) {}
-    bool need(size_t n) {
-        if (pos + n > d.size()) ok = false;
+    bool need(size_t n) {  // (no addition that could wrap: pos <= d.size() is the invariant)
+        if (pos > d.size() || n > d.size() - pos) ok = false;
         return ok;
     }
     uint8_t u8() { return need(1) ? d[pos++] : 0; }
@@ -210,11 +210,16 @@ bool read_exr(const std::string &path, std::vector<float> *rgb, int *w, int *h, 
     }
     if (ci[0] < 0 && ci[1] < 0 && ci[2] < 0 && cy < 0) return fail("no R, G, B or Y channel");
     const bool luminance = ci[0] < 0 && ci[1] < 0 && ci[2] < 0;
+    // a header of a few KB must not make the reader zero-fill gigabytes before it has seen a chunk: no coder here expands
+    // more than zlib's ~1032 : 1 (RLE: 128 : 1; none: 1 : 1)
+    const uint64_t decoded = uint64_t(line_bytes) * uint64_t(height);
+    const uint64_t max_ratio = compression == 0 ? 1 : (compression == 1 ? 128 : 1040);
+    if (decoded / max_ratio > d.size()) return fail("data window larger than the file can hold");
     rgb->assign(size_t(width) * size_t(height) * 3, 0.f);
     std::vector<uint8_t> raw, tmp;
     for (int64_t b = 0; b < n_blocks; ++b) {
         const uint64_t off = offsets[size_t(b)];
-        if (off + 8 > d.size()) return fail("chunk offset beyond the file");
+        if (off > d.size() || d.size() - off < 8) return fail("chunk offset beyond the file");  // off + 8 would wrap for offsets near 2^64
         Reader c(d);
         c.pos = size_t(off);
         const int32_t y0 = c.i32(), nbytes = c.i32();

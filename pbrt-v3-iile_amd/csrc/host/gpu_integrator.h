@@ -81,6 +81,7 @@ class GpuPathIntegrator : public Integrator {
           stats_(print_stats), comm_(comm) {}
 
     bool Render(const Scene &scene) override {
+        if (comm_) return RenderRanks(scene);
         if (!scene.ok()) return false;
         iile_scene *gpu = nullptr;
         if (iile_scene_create(scene.desc(), &gpu) != IILE_OK) {
@@ -88,53 +89,27 @@ class GpuPathIntegrator : public Integrator {
             return false;
         }
         const iile_film_desc *f = scene.film();
-        const int w = f->crop_x1 - f->crop_x0, h = f->crop_y1 - f->crop_y0;
-        const size_t n_pix = size_t(w) * h;
-        std::vector<float> xyzw(4 * n_pix), rgb(3 * n_pix);
+        const size_t n_pix = size_t(f->crop_x1 - f->crop_x0) * size_t(f->crop_y1 - f->crop_y0);
+        std::vector<float> xyzw(4 * n_pix);
         iile_render_params prm = {};
         prm.tile_rank = rank_;
         prm.tile_nranks = nranks_;
         prm.collect_stats = stats_ ? 1 : 0;
         iile_stats st;
-        int rc;
-        if (comm_) {
-            // the film stays in HBM from the render through the merge; only rank 0 reads it back
-            void *film_dev = nullptr;
-            if (iile_device_alloc(4 * n_pix * sizeof(float), &film_dev) != IILE_OK) {
-                fprintf(stderr, "Error: GPU path: %s\n", iile_last_error());
-                iile_scene_destroy(gpu);
-                return false;
-            }
-            prm.film_on_device = 1;
-            rc = iile_render(gpu, &prm, static_cast<float *>(film_dev), &st);
-            if (rc == IILE_OK && iile_dist_film_reduce(comm_, static_cast<float *>(film_dev), int64_t(n_pix), 0, nullptr) != IILE_OK) {
-                fprintf(stderr, "Error: film merge: %s\n", iile_dist_last_error());
-                rc = IILE_ERR_HIP;
-            } else if (rc == IILE_OK) {
-                rc = iile_device_download(xyzw.data(), film_dev, 4 * n_pix * sizeof(float), nullptr);
-            }
-            iile_device_free(film_dev);
-            if (rc == IILE_OK && stats_) {  // job totals of the counters
-                uint64_t c[7] = {st.camera_rays, st.closest_rays, st.shadow_rays, st.nodes_closest, st.nodes_any, st.tri_tests, st.tri_hits};
-                uint64_t np = st.n_paths;
-                if (iile_dist_sum_u64(comm_, c, 7) == IILE_OK && iile_dist_sum_u64(comm_, &np, 1) == IILE_OK) {
-                    st.camera_rays = c[0], st.closest_rays = c[1], st.shadow_rays = c[2], st.nodes_closest = c[3];
-                    st.nodes_any = c[4], st.tri_tests = c[5], st.tri_hits = c[6];
-                    st.n_paths = np;
-                }
-                double ms = st.ms_total;
-                if (iile_dist_max_f64(comm_, &ms, 1) == IILE_OK) st.ms_total = ms;
-            }
-        } else {
-            rc = iile_render(gpu, &prm, xyzw.data(), &st);
-        }
+        const int rc = iile_render(gpu, &prm, xyzw.data(), &st);
         iile_scene_destroy(gpu);
         if (rc != IILE_OK) {
             fprintf(stderr, "Error: GPU path: %s\n", iile_last_error());
             return false;
         }
         last_stats = st;
-        if (comm_ && rank_ != 0) return true;  // rank 0 holds the merged film
+        return WriteFilm(f, xyzw);
+    }
+    iile_stats last_stats = {};
+
+  private:
+    bool WriteFilm(const iile_film_desc *f, const std::vector<float> &xyzw) {
+        std::vector<float> rgb(xyzw.size() / 4 * 3);
         iile_host_film_to_rgb(f, xyzw.data(), rgb.data());                 // Film::to_rgb_array
         if (!output_.empty() && iile_host_write_image(output_.c_str(), f, rgb.data()) != 0) {  // Film::WriteImage: .exr or .pfm
             fprintf(stderr, "Error: %s\n", iile_host_last_error());
@@ -142,7 +117,84 @@ class GpuPathIntegrator : public Integrator {
         }
         return true;
     }
-    iile_stats last_stats = {};
+    // Every rank walks the same sequence of collectives whatever happens to it locally: a rank whose scene did not load,
+    // whose allocation failed or whose render returned an error says so through iile_dist_all_ok and all ranks leave
+    // together — nobody is left waiting inside ncclReduce for a rank that has already returned.
+    bool Agree(bool ok) {
+        int32_t all = 0;
+        if (iile_dist_all_ok(comm_, ok ? 1 : 0, &all) != IILE_OK) {
+            fprintf(stderr, "Error: multi-GPU status exchange: %s\n", iile_dist_last_error());
+            return false;
+        }
+        if (ok && !all) fprintf(stderr, "Error: GPU path: rank %d stops because another rank failed\n", rank_);
+        return all != 0;
+    }
+    bool RenderRanks(const Scene &scene) {
+        iile_scene *gpu = nullptr;
+        void *film_dev = nullptr;
+        size_t n_pix = 0;
+        const iile_film_desc *f = nullptr;
+        bool ok = scene.ok();
+        if (ok && iile_scene_create(scene.desc(), &gpu) != IILE_OK) {
+            fprintf(stderr, "Error: GPU path: %s\n", iile_last_error());
+            ok = false;
+        }
+        if (ok) {
+            f = scene.film();
+            n_pix = size_t(f->crop_x1 - f->crop_x0) * size_t(f->crop_y1 - f->crop_y0);
+            // the film stays in HBM from the render through the merge; only rank 0 reads it back
+            if (iile_device_alloc(4 * n_pix * sizeof(float), &film_dev) != IILE_OK) {
+                fprintf(stderr, "Error: GPU path: %s\n", iile_last_error());
+                ok = false;
+            }
+        }
+        iile_stats st = {};
+        if (ok) {
+            iile_render_params prm = {};
+            prm.tile_rank = rank_;
+            prm.tile_nranks = nranks_;
+            prm.collect_stats = stats_ ? 1 : 0;
+            prm.film_on_device = 1;
+            if (iile_render(gpu, &prm, static_cast<float *>(film_dev), &st) != IILE_OK) {
+                fprintf(stderr, "Error: GPU path: %s\n", iile_last_error());
+                ok = false;
+            }
+        }
+        std::vector<float> xyzw;
+        if (Agree(ok)) {  // all films are ready: the one collective of the frame (Film::MergeFilmTile, film.cpp:135-148)
+            if (iile_dist_film_reduce(comm_, static_cast<float *>(film_dev), int64_t(n_pix), 0, nullptr) != IILE_OK) {
+                fprintf(stderr, "Error: film merge: %s\n", iile_dist_last_error());
+                ok = false;
+            }
+            if (ok && rank_ == 0) {
+                xyzw.resize(4 * n_pix);
+                if (iile_device_download(xyzw.data(), film_dev, 4 * n_pix * sizeof(float), nullptr) != IILE_OK) {
+                    fprintf(stderr, "Error: GPU path: %s\n", iile_last_error());
+                    ok = false;
+                }
+            }
+            // job totals of the counters (every rank takes part, with or without --stats on its own command line)
+            uint64_t c[8] = {st.camera_rays, st.closest_rays, st.shadow_rays, st.nodes_closest, st.nodes_any, st.tri_tests, st.tri_hits, st.n_paths};
+            double ms = st.ms_total;
+            if (iile_dist_sum_u64(comm_, c, 8) == IILE_OK && iile_dist_max_f64(comm_, &ms, 1) == IILE_OK) {
+                st.camera_rays = c[0], st.closest_rays = c[1], st.shadow_rays = c[2], st.nodes_closest = c[3];
+                st.nodes_any = c[4], st.tri_tests = c[5], st.tri_hits = c[6], st.n_paths = c[7];
+                st.ms_total = ms;
+            } else {
+                fprintf(stderr, "Error: job totals: %s\n", iile_dist_last_error());
+                ok = false;
+            }
+            ok = Agree(ok);
+        } else {
+            ok = false;
+        }
+        if (film_dev) iile_device_free(film_dev);
+        if (gpu) iile_scene_destroy(gpu);
+        if (!ok) return false;
+        last_stats = st;
+        if (rank_ != 0) return true;  // rank 0 holds the merged film
+        return WriteFilm(f, xyzw);
+    }
 
   private:
     std::string output_;

@@ -1,6 +1,7 @@
 """BASELINE.json's configurations at their real sizes, on one GPU (marked gpu).
 
-config 2  killeroo-simple 1920x1080 x 64 spp, one GPU          -> test_config2_1080p_frame_bitwise
+config 2  killeroo-simple 1920x1080 x 64 spp, one GPU          -> test_config2_full_frame_vs_oracle (the whole frame),
+                                                                  test_config2_1080p_frame_bitwise
 config 3  1920x1080 x 1024 spp, film tiles sharded over 8 GPUs -> test_config3_1080p_1024spp_eight_shards
                                                                   (the eight ranks' renders run back to back on the one GPU)
 config 4  Sponza-class deep BVH at 1080p                        -> test_config4_full_size_room_1080p
@@ -48,6 +49,33 @@ def test_config2_1080p_frame_bitwise(binding, oracle):
     many, st8 = gpu64.render(spp_per_pass=8)
     assert st1["n_passes"] == 1 and st8["n_passes"] >= 8
     assert _bits_equal(one, many).all()
+
+
+def test_config2_full_frame_vs_oracle(binding, oracle):
+    """The headline frame itself under the oracle: 1920x1080 x 64 spp (132.7 M camera samples, 765 M reference rays),
+    rendered by the kernels bench.py times (plain build: four-wide BVH steps, MIS-ray culling, dense MIS queue, two
+    streams, camera rays made in k_extend, the last bounce left out) AND by the instrumented build, against the CPU
+    oracle on all host cores — film {X, Y, Z, weight} bit for bit (1e-4 relative is the north star's tolerance; the test
+    asks for equality), every traversal counter, the path-length histogram. 8 spp does not stand in for 64: whole-number
+    film positions only appear past sample 8 (round 1's bug). SamplerIntegrator::Render, integrator.cpp:227-339."""
+    scene = binding.HostScene(xres=1920, yres=1080, spp=64)
+    gpu = binding.GpuScene(scene)
+    plain, pst = gpu.render()
+    assert pst["n_passes"] == 1
+    counted, cst = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(scene)
+    assert ost["camera_rays"] == 1920 * 1080 * 64
+    for name, film in (("plain kernels", plain), ("instrumented kernels", counted)):
+        same = _bits_equal(film, ref)
+        assert same.all(), f"{name}: {int((~same).any(-1).sum())} pixels differ from the oracle"
+    assert cst["camera_rays"] == ost["camera_rays"]
+    assert cst["closest_rays"] == ost["regular_rays"] and cst["shadow_rays"] == ost["shadow_rays"]
+    assert cst["nodes_closest"] == ost["nodes_closest"] and cst["nodes_any"] == ost["nodes_any"]
+    assert cst["tri_tests"] == ost["tri_tests"] and cst["tri_hits"] == ost["tri_hits"]
+    assert list(cst["path_length"]) == list(ost["path_length"])
+    assert cst["nee_evals"] == ost["nee_evals"] and cst["zero_radiance"] == ost["zero_radiance"]
+    # what the plain build does not trace is exactly what it may leave out: fewer rays, the same film
+    assert pst["ext_rays_traced"] + pst["mis_rays_traced"] < cst["closest_rays"]
 
 
 def test_config3_1080p_1024spp_eight_shards(binding, oracle):

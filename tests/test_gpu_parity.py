@@ -296,6 +296,41 @@ def test_cpp_cli_renders_same_film(scene_small, gpu_small, tmp_path):
     assert_bitwise(img, scene_small.film_to_rgb(film), "CLI image")
 
 
+def test_cpp_cli_ranked_branch_world1(scene_small, gpu_small, tmp_path):
+    """`iile_pbrt --gpurank 0/1 --rendezvous F` goes through GpuPathIntegrator's communicator branch (device film,
+    iile_dist_all_ok, iile_dist_film_reduce over RCCL, download, iile_dist_sum_u64 / max_f64; where Film::MergeFilmTile
+    stands, film.cpp:135-148) with a communicator of one rank: its image equals the plain CLI's bit for bit, the summed
+    statistics equal the single-rank ones, a stale rendezvous file from an earlier run is replaced, and the file is gone
+    once the ranks have joined."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "pbrt-v3-iile_amd", "lib", "iile_pbrt")
+    scene = os.path.join(repo, "scenes", "killeroo-simple.pbrt")
+    size = ["--xres", "160", "--yres", "120", "--spp", "4", "--stats"]
+    plain, ranked, rv = tmp_path / "plain.pfm", tmp_path / "ranked.pfm", tmp_path / "rendezvous"
+    rv.write_bytes(bytes(128))  # what a round-2 run would have left behind
+    p0 = subprocess.run([exe, scene, *size, "--outfile", str(plain)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p0.returncode == 0, p0.stdout
+    p1 = subprocess.run([exe, scene, *size, "--outfile", str(ranked), "--gpurank", "0/1", "--rendezvous", str(rv), "--job", "77"],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p1.returncode == 0, p1.stdout
+    assert plain.read_bytes() == ranked.read_bytes()
+    assert not rv.exists()
+    stats = [[l for l in p.stdout.splitlines() if l.startswith("rays:")] for p in (p0, p1)]
+    assert stats[0] and stats[0] == stats[1], (p0.stdout, p1.stdout)
+    # and the film is the C ABI's
+    raw = ranked.read_bytes()
+    head = b"PF\n160 120\n-1.0\n"
+    img = np.frombuffer(raw[len(head):], "<f4").reshape(120, 160, 3)[::-1]
+    film, _ = gpu_small.render()
+    assert_bitwise(img, scene_small.film_to_rgb(film), "ranked CLI image")
+    # a rank whose scene does not load leaves through the status exchange with an error, not a hang
+    p2 = subprocess.run([exe, str(tmp_path / "missing.pbrt"), "--gpurank", "0/1", "--rendezvous", str(rv)],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert p2.returncode == 1 and "Error" in p2.stdout
+
+
 def test_boxroom_deep_bvh_bitwise(binding, oracle, tmp_path):
     """Synthetic closed room (tests/boxroom.py; SURVEY.md §8d's stand-in for the deep-BVH config):
     ~65 reference node visits per ray instead of killeroo-simple's 17, every path runs to

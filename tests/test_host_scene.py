@@ -569,6 +569,21 @@ def test_host_library_under_asan_and_ubsan(tmp_path):
         f = tmp_path / f"bad{k}.exr"
         f.write_bytes(bytes(dmg))
         images.append(str(f))
+    # deterministic cases the random damage almost never produces: chunk offsets at the top of the 64-bit range
+    # (offset + 8 wraps), an offset at the last byte, and a data window far larger than the file can hold
+    n_blocks = 3  # 40 lines in ZIP blocks of 16
+    table = next(p for p in range(8, len(raw) - 8 * n_blocks) if struct.unpack_from("<Q", raw, p)[0] == p + 8 * n_blocks)
+    for k, off in enumerate((2 ** 64 - 4, 2 ** 64 - 8, 2 ** 64 - 1, len(raw) - 1, len(raw) - 7)):
+        dmg = bytearray(raw)
+        struct.pack_into("<Q", dmg, table, off)
+        f = tmp_path / f"offset{k}.exr"
+        f.write_bytes(bytes(dmg))
+        images.append(str(f))
+    dw = raw.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    dmg = bytearray(raw)
+    struct.pack_into("<4i", dmg, dw, 0, 0, 65535, 4095)
+    (tmp_path / "hugewindow.exr").write_bytes(bytes(dmg))
+    images.append(str(tmp_path / "hugewindow.exr"))
     exe = os.path.join(repo, "pbrt-v3-iile_amd", "lib", "host_selftest_asan")
     args = [exe, os.path.join(repo, "scenes", "killeroo-simple.pbrt"), str(room), good_ascii, good_bin] + ["!" + b for b in bad] + ["@" + f for f in images]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
