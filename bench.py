@@ -109,12 +109,15 @@ def cpu_baseline(scene_path, xres, yres, target_seconds, workload_name="killeroo
 
 def load_pmc(world, args):
     """The committed counter summaries (tools/summarize_profiles.py): newest profiles/*_pmc_traffic.json and
-    *_pmc_lanes.json. They describe the default workload on one GPU only."""
-    if not (world == 1 and (args.xres, args.yres, args.spp, args.workload) == (1920, 1080, 64, "killeroo")):
+    *_pmc_lanes.json of this workload on one GPU (killeroo-simple: the default frame; boxroom: files tagged `_room`)."""
+    if not (world == 1 and (args.xres, args.yres, args.spp) == (1920, 1080, 64) and args.workload in ("killeroo", "boxroom") and not args.sampler):
         return {}, {}, None, None
+    room = args.workload == "boxroom"
 
     def newest(pattern):
         for f in sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))[::-1]:
+            if ("_room" in os.path.basename(f)) != room:
+                continue
             try:
                 j = json.load(open(f))
                 if "families" in j:
@@ -355,7 +358,15 @@ def main():
                 tl = la["SQ_INSTS_VALU"] * 64 / (ms_k / steps * 1e-3) / 1e12
                 e["valu"] = {"issued_tlaneops": round(tl, 2), "peak_tlaneops": round(VALU_PEAK_TLANEOPS, 1),
                              "issue_frac": round(tl / VALU_PEAK_TLANEOPS, 4), "lane_util": la.get("lane_util"),
-                             "valu_busy": la.get("valu_busy"), "insts_valu_per_step": la["SQ_INSTS_VALU"]}
+                             "valu_busy": la.get("valu_busy"), "insts_valu_per_step": la["SQ_INSTS_VALU"],
+                             # where a resident wave's time goes (SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES)
+                             "wave_wait_any_frac": la.get("wave_wait_any_frac"), "wave_wait_inst_frac": la.get("wave_wait_inst_frac"),
+                             "wave_active_inst_frac": la.get("wave_active_inst_frac"),
+                             "calibration": "profiles/r03_valu_calib.json: independent v_fma_f32 saturate at 0.5 wave-instructions per cycle per "
+                                            "SIMD (= peak_tlaneops) from ~4 ready waves per SIMD, one wave alone issues 0.19-0.25; `valu_busy` "
+                                            "(4 x SQ_ACTIVE_INST_VALU / SIMDs / busy cycles) reads 0.76 for one wave per SIMD and 1.5-1.8 when "
+                                            "saturated, so it is not a utilisation out of 1; FP64 / packed FP32 cost 2 issue slots, "
+                                            "transcendentals 4, a correctly rounded a/b ~17, sqrt ~22 — `issue_frac` counts every instruction as one slot"}
                 if "TCC_REQ_sum" in la:
                     l2 = la["TCC_REQ_sum"] * 128 / (ms_k / steps * 1e-3) / 1e9
                     e["l2"] = {"requests_per_step": la["TCC_REQ_sum"], "hit_rate": la.get("l2_hit_rate"),

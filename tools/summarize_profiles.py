@@ -11,11 +11,18 @@ what bench.py reads). FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE r
 part of `families`) and exactly one timed step."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(repo, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(repo, "profiles")
 os.makedirs(dst, exist_ok=True)
+try:
+    bench_args = open(os.path.join(src, "bench_args.txt")).read().strip()
+except OSError:
+    bench_args = ""
+WORKLOAD = ("bench.py --steps 1 --warmup 0 --other-steps 0 " + bench_args).strip() + (
+    " (synthetic 287 k-triangle closed room of tests/boxroom.py, 1920x1080, 64 spp, 1 GPU)" if "boxroom" in bench_args
+    else " (killeroo-simple 1920x1080, 64 spp, 1 GPU)")
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 b = os.path.join(src, "bench_under_profiler.json")
@@ -92,7 +99,7 @@ for k, v in raw.items():
 for f in fams.values():
     f["hbm_bytes_per_step"] = f["hbm_read_bytes_per_step"] + f["hbm_write_bytes_per_step"]
 if kernels:
-    json.dump({"workload": "bench.py --steps 1 --warmup 0 --other-steps 0 (killeroo-simple 1920x1080, 64 spp, 1 GPU)",
+    json.dump({"workload": WORKLOAD,
                "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes; separate rocprofv3 --pmc passes",
                "families": fams, "kernels": kernels}, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 
@@ -113,14 +120,22 @@ for fam, v in fams.items():
         # (quad-cycle counters: x4; SQ_BUSY_CYCLES is summed over the 32 shader engines, the others over 1024 SIMDs)
         e["lane_util"] = round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (v["SQ_ACTIVE_INST_VALU"] * 64), 4)
         if v.get("SQ_BUSY_CYCLES"):
+            # NOT a utilisation out of 1: tools/valu_calib.sh (profiles/r03_valu_calib*.json) measures this expression at
+            # 1.5-1.8 for a saturated VALU (0.5 wave-instructions per cycle per SIMD) and 0.76 for ONE wave per SIMD
             e["valu_busy"] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v["SQ_BUSY_CYCLES"] / 32), 4)
+            e["valu_issue_per_cycle_simd"] = round(v.get("SQ_INSTS_VALU", 0.0) / 1024 / (v["SQ_BUSY_CYCLES"] / 32), 4)  # ceiling 0.5
+    if v.get("SQ_WAVE_CYCLES"):
+        # where a resident wave's time goes (disjoint, MI355X_MICROARCH.md "rocprofv3 PMC slots")
+        e["wave_wait_any_frac"] = round(v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 4)
+        e["wave_wait_inst_frac"] = round(v.get("SQ_WAIT_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 4)
+        e["wave_active_inst_frac"] = round(v.get("SQ_ACTIVE_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 4)
     if v.get("TCC_HIT_sum") or v.get("TCC_MISS_sum"):
         e["l2_hit_rate"] = round(v.get("TCC_HIT_sum", 0.0) / max(v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0), 1.0), 4)
     if fam in ("k_extend", "k_shade", "k_shadow", "k_mis"):
         e["per_launch"] = launches_in_order(fam)
     out_f[fam] = e
 if kernels:
-    json.dump({"workload": "bench.py --steps 1 --warmup 0 --other-steps 0 (killeroo-simple 1920x1080, 64 spp, 1 GPU)",
+    json.dump({"workload": WORKLOAD,
                "note": "counter sums over the launches of one timed bench step, product builds only (per_launch: launch by launch = bounce by bounce); lane_util = SQ_THREAD_CYCLES_VALU / "
                        "(64 x SQ_ACTIVE_INST_VALU); valu_busy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs)",
                "families": out_f, "kernels": kernels}, open(os.path.join(dst, f"{tag}_pmc_lanes.json"), "w"), indent=1)
