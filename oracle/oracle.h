@@ -148,6 +148,13 @@ int oracle_iispt_gather(const iile_scene_desc *scene, int trig_mode, const iile_
 /* iile_tile_owner of iile_scene.h (a static inline there), exported so that tests can call the header's own definition */
 int oracle_tile_owner(int tx, int ty, int nranks);
 
+/* BVHAccel(prims, maxPrimsInNode, SplitMethod::HLBVH) as one thread builds it (oracle_bvh.cpp; src/accelerators/bvh.cpp:
+ * 107-181, 404-658): nodes_out (room for 2 * n_prims) in flattenBVHTree's order, order_out[p] = number of the primitive at
+ * position p of BVHAccel::primitives after the build, codes_out (optional) the sorted Morton codes. 0 = ok, 1 = a CHECK of
+ * the reference would abort, 2 = bad arguments. */
+int oracle_bvh_hlbvh(int32_t n_prims, const float *bounds6, int32_t max_prims_in_node, iile_bvh_node *nodes_out, int32_t *n_nodes_out,
+                     int32_t *order_out, uint32_t *codes_out);
+
 #ifdef __cplusplus
 }
 #endif

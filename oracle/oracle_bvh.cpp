@@ -101,6 +101,7 @@ void radix_sort(std::vector<MortonPrim> *v) {
 struct Builder {
     const std::vector<PrimInfo> &info;
     int max_prims_in_node;
+    Builder(const std::vector<PrimInfo> &i, int m) : info(i), max_prims_in_node(m) {}
     std::vector<int> ordered;     // orderedPrims: primitive number per final position
     int ordered_offset = 0;       // orderedPrimsOffset (one thread: treelets in index order)
     bool failed = false;          // a CHECK of the reference would have aborted
@@ -252,7 +253,8 @@ int oracle_bvh_hlbvh(int32_t n_prims, const float *bounds6, int32_t max_prims_in
     *n_nodes_out = 0;
     if (n_prims == 0) return 0;  // BVHAccel::BVHAccel returns before building (bvh.cpp:189)
     const int max_prims = std::min(255, max_prims_in_node);  // bvh.cpp:186
-    std::vector<PrimInfo> info(size_t(n_prims));
+    std::vector<PrimInfo> info;
+    info.resize(size_t(n_prims));
     for (int i = 0; i < n_prims; ++i) {
         const float *b = bounds6 + 6 * size_t(i);
         PrimInfo &pi = info[size_t(i)];
@@ -263,7 +265,8 @@ int oracle_bvh_hlbvh(int32_t n_prims, const float *bounds6, int32_t max_prims_in
     }
     B3 bounds;
     for (const PrimInfo &pi : info) bounds = unite(bounds, pi.centroid);
-    std::vector<MortonPrim> mp(size_t(n_prims));
+    std::vector<MortonPrim> mp;
+    mp.resize(size_t(n_prims));
     for (int i = 0; i < n_prims; ++i) {
         constexpr int morton_scale = 1 << 10;
         mp[size_t(i)].prim = info[size_t(i)].number;
@@ -287,11 +290,15 @@ int oracle_bvh_hlbvh(int32_t n_prims, const float *bounds6, int32_t max_prims_in
     for (int start = 0, end = 1; end <= n_prims; ++end) {
         const uint32_t mask = 0x3ffc0000u;
         if (end == n_prims || ((mp[size_t(start)].code & mask) != (mp[size_t(end)].code & mask))) {
-            treelets.push_back(Treelet{start, end - start, {}, nullptr});
+            {
+            Treelet tr;
+            tr.start = start, tr.n = end - start;
+            treelets.push_back(std::move(tr));
+            }
             start = end;
         }
     }
-    Builder bld{info, max_prims};
+    Builder bld(info, max_prims);
     bld.ordered.assign(size_t(n_prims), -1);
     int total = 0;
     for (Treelet &tr : treelets) {

@@ -581,6 +581,57 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             }
             S.root_ref = d->nodes[0].nprims == 0 ? 0 : ~d->nodes[0].offset;  // the root is interior record 0
         }
+        // The top of the four-wide tree, breadth first, for the traversal kernels' LDS copies (dpath.h, load_wide4): the
+        // records are read back once, the references among the chosen ones become kTopFlag | slot, each copy keeps its own
+        // record index (the binary fallback step needs it) in the word behind its axes.
+        S.top4 = nullptr;
+        S.n_top = 0;
+        S.root_ref_top = S.root_ref;
+        int want_top = kMaxTop;
+        if (const char *e = std::getenv("IILE_TOP_RECORDS")) want_top = std::max(0, std::min(kMaxTop, atoi(e)));
+        if (n_interior > 0 && S.boxes_nested && want_top > 0 && S.root_ref >= 0) {
+            std::vector<float4> all(8 * size_t(n_interior));
+            if (hipMemcpy(all.data(), wide4, all.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess)
+                return bail(fail(IILE_ERR_HIP, "reading back the BVH records failed"));
+            std::vector<int> order;       // record index per slot
+            std::map<int, int> slot_of;   // record index -> slot
+            order.push_back(S.root_ref);
+            slot_of[S.root_ref] = 0;
+            for (size_t at = 0; at < order.size() && int(order.size()) < want_top; ++at) {
+                const float4 refs = all[8 * size_t(order[at]) + 6];
+                const float rf[4] = {refs.x, refs.y, refs.z, refs.w};
+                for (int j = 0; j < 4 && int(order.size()) < want_top; ++j) {
+                    int r;
+                    std::memcpy(&r, &rf[j], sizeof(r));
+                    // (an empty slot — the second one of a leaf child — holds no box: its planes are +-inf and its ref is unused)
+                    const float bmin_x = (&all[8 * size_t(order[at]) + 0].x)[j];
+                    if (r < 0 || r >= n_interior || !(bmin_x < std::numeric_limits<float>::infinity()) || slot_of.count(r)) continue;
+                    slot_of[r] = int(order.size());
+                    order.push_back(r);
+                }
+            }
+            std::vector<float4> top(8 * order.size());
+            for (size_t sl = 0; sl < order.size(); ++sl) {
+                for (int q = 0; q < 8; ++q) top[8 * sl + q] = all[8 * size_t(order[sl]) + q];
+                float *refs = &top[8 * sl + 6].x;
+                for (int j = 0; j < 4; ++j) {
+                    int r;
+                    std::memcpy(&r, &refs[j], sizeof(r));
+                    const float bmin_x = (&top[8 * sl + 0].x)[j];
+                    if (r >= 0 && r < n_interior && bmin_x < std::numeric_limits<float>::infinity() && slot_of.count(r)) {
+                        const int tagged = kTopFlag | slot_of[r];
+                        std::memcpy(&refs[j], &tagged, sizeof(r));
+                    }
+                }
+                std::memcpy(&top[8 * sl + 7].y, &order[sl], sizeof(int));
+            }
+            const float4 *d_top = nullptr;
+            rc = upload(sc, top.data(), top.size(), &d_top);
+            if (rc) return bail(rc);
+            S.top4 = d_top;
+            S.n_top = int(order.size());
+            S.root_ref_top = kTopFlag | 0;
+        }
     }
     // primitives: gather into 48-byte vertex records + normal / uv records
     {

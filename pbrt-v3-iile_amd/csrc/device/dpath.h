@@ -648,7 +648,7 @@ typedef __attribute__((address_space(3))) int lds_int;
 #define IILE_LEAF_ONE 1
 #endif
 #ifndef IILE_LDS_STACK
-#define IILE_LDS_STACK 12  // 24 KB per block: six blocks per 160 KB CU
+#define IILE_LDS_STACK 11  // 22 KB per block + the 3 KB copy of the tree's top: six blocks per 160 KB CU
 #endif
 constexpr int kLdsStackDepth = IILE_LDS_STACK;  // measured max depth on killeroo-simple: 19 (binary steps)
 // The reference's stack holds 64 binary entries (bvh.cpp:670); a four-wide step defers up to
@@ -743,22 +743,45 @@ constexpr int kHitLightShift = 27;
 constexpr int kHitPrimMask = (1 << kHitClassShift) - 1;
 DEV int hit_tag(uint32_t flags) { return int((flags >> 5) & 0x7fu) << kHitClassShift; }
 DEV int hit_index(int hit_prim) { return hit_prim < 0 ? -1 : (hit_prim & kHitPrimMask); }
+// The top of the tree in LDS. The traversal kernels are bound by the vector memory pipe, not by arithmetic (r03 counters:
+// TA busy 0.74-0.86, TD busy 0.92-0.99 of the kernel's cycles; a divergent dwordx4 load costs ~26 address-unit cycles and an
+// interior step issues seven of them against ~60 cycles of VALU per CU): the records every ray passes through first — the
+// breadth-first top of the four-wide tree — are therefore read from a per-block LDS copy, which takes no part in that pipe.
+// A reference to such a record is kTopFlag | slot (still > 0 = interior); the copies refer to each other that way and to
+// everything below by the ordinary record index. Same records, same decisions.
+constexpr int kTopStride = 144;  // bytes per LDS record: 128 + 16, so that neighbouring records start 4 banks apart
+typedef __attribute__((address_space(3))) char lds_char;
 struct StackRef {
     lds_int *lds;          // this lane's LDS column: ref plane [level*64], tMin plane [(kLdsStackDepth+level)*64]
     int *spill_base;       // HBM overflow: lane column = spill_base + spill_col, 2 ints per level
     uint32_t spill_col;
     uint32_t spill_stride;
+    lds_char *top = nullptr;  // the block's copy of DScene::top4 (kTopStride bytes per record), or null
+    int root = 0;             // where a traversal starts: DScene::root_ref_top with `top`, else DScene::root_ref
     DEV int *spill() const { return spill_base + spill_col; }
 };
+// a block's threads copy the top records into its LDS array (kMaxTop * kTopStride bytes); the caller synchronises
+typedef float lds_v4f_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lds_v4f_t lds_v4f;  // (HIP's float4 is a class: no assignment across address spaces)
+DEV float4 lds_load4(lds_char *p) {
+    const lds_v4f_t v = *reinterpret_cast<lds_v4f *>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+DEV void stage_top_records(const DScene &S, lds_char *top, int tid, int n_threads) {
+    for (int i = tid; i < S.n_top * 8; i += n_threads) {
+        const float4 v = S.top4[i];
+        *reinterpret_cast<lds_v4f *>(top + (i >> 3) * kTopStride + (i & 7) * 16) = lds_v4f_t{v.x, v.y, v.z, v.w};
+    }
+}
 
 template <bool COUNT>
-DEV void trav_begin(const DScene &S, Trav &t, F3 ro, F3 rd, float tmax, TraceStats *st) {
+DEV void trav_begin(const DScene &S, Trav &t, F3 ro, F3 rd, float tmax, TraceStats *st, int root) {
     t.rc = make_ray_ctx(ro, rd);
     t.tmax = tmax;
     t.sp = 0;
     t.hit_prim = -1;
     t.b0 = t.b1 = t.b2 = 0;
-    t.cur = S.root_ref;
+    t.cur = root;
     t.have = false;
     if (S.n_nodes == 0) return;
     // the root is visited like any node: its own box against ray.tMax
@@ -895,19 +918,39 @@ struct Wide4Planes {
     uint32_t meta;
 };
 template <bool WITH_META>
-DEV Wide4Planes load_wide4(const float4 *wide4, int cur, int neg_mask) {
+DEV Wide4Planes load_wide4(const float4 *wide4, int cur, int neg_mask, lds_char *top = nullptr) {
     const char *base = reinterpret_cast<const char *>(wide4);
-    const uint32_t nm = uint32_t(neg_mask), rec = uint32_t(cur < 0 ? 0 : cur) * 128u;  // (32-bit offsets: checked at upload)
-    const uint32_t ax = rec + ((nm >> 8) & 0xffu), ay = rec + ((nm >> 16) & 0xffu), az = rec + (nm >> 24);
+    const uint32_t nm = uint32_t(neg_mask);
+    const uint32_t px = (nm >> 8) & 0xffu, py = (nm >> 16) & 0xffu, pz = nm >> 24;  // entry planes' offsets inside a record
     Wide4Planes w;
-    w.ex = *reinterpret_cast<const float4 *>(base + ax);
-    w.ey = *reinterpret_cast<const float4 *>(base + ay);
-    w.ez = *reinterpret_cast<const float4 *>(base + az);
-    w.lx = *reinterpret_cast<const float4 *>(base + (ax ^ 48u));
-    w.ly = *reinterpret_cast<const float4 *>(base + (ay ^ 80u));
-    w.lz = *reinterpret_cast<const float4 *>(base + (az ^ 112u));
-    w.refs = *reinterpret_cast<const float4 *>(base + (rec + 96u));
-    w.meta = WITH_META ? *reinterpret_cast<const uint32_t *>(base + (rec + 112u)) : 0u;
+    const bool in_top = top != nullptr && cur >= kTopFlag;
+    if (top != nullptr && __ballot(in_top) != 0) {
+        if (in_top) {
+            typedef __attribute__((address_space(3))) uint32_t lu32;
+            lds_char *r = top + uint32_t(cur - kTopFlag) * uint32_t(kTopStride);
+            w.ex = lds_load4(r + px);
+            w.ey = lds_load4(r + py);
+            w.ez = lds_load4(r + pz);
+            w.lx = lds_load4(r + (px ^ 48u));
+            w.ly = lds_load4(r + (py ^ 80u));
+            w.lz = lds_load4(r + (pz ^ 112u));
+            w.refs = lds_load4(r + 96u);
+            w.meta = WITH_META ? *reinterpret_cast<lu32 *>(r + 112u) : 0u;
+        }
+        if (__ballot(!in_top) == 0) return w;  // (wave-uniform: a wavefront fresh from a refill is all in the top levels)
+    }
+    if (!in_top) {
+        const uint32_t rec = uint32_t(cur < 0 ? 0 : cur) * 128u;  // (32-bit offsets: checked at upload)
+        const uint32_t ax = rec + px, ay = rec + py, az = rec + pz;
+        w.ex = *reinterpret_cast<const float4 *>(base + ax);
+        w.ey = *reinterpret_cast<const float4 *>(base + ay);
+        w.ez = *reinterpret_cast<const float4 *>(base + az);
+        w.lx = *reinterpret_cast<const float4 *>(base + (ax ^ 48u));
+        w.ly = *reinterpret_cast<const float4 *>(base + (ay ^ 80u));
+        w.lz = *reinterpret_cast<const float4 *>(base + (az ^ 112u));
+        w.refs = *reinterpret_cast<const float4 *>(base + (rec + 96u));
+        w.meta = WITH_META ? *reinterpret_cast<const uint32_t *>(base + (rec + 112u)) : 0u;
+    }
     return w;
 }
 DEV void trav_interior4(Trav &t, const StackRef &sr, const Wide4Planes &w) {
@@ -1006,11 +1049,15 @@ template <bool ANY = false>
 DEV void trav_interior_step_fast(const DScene &S, Trav &t, const StackRef &sr) {
     if (__builtin_expect(S.boxes_nested && __ballot(t.rc.neg_mask & 0x80) == 0, 1)) {
         if (ANY && IILE_ANYHIT_UNORDERED)
-            trav_interior4_any(t, sr, load_wide4<false>(S.wide4, t.cur, t.rc.neg_mask));
+            trav_interior4_any(t, sr, load_wide4<false>(S.wide4, t.cur, t.rc.neg_mask, sr.top));
         else
-            trav_interior4(t, sr, load_wide4<true>(S.wide4, t.cur, t.rc.neg_mask));
+            trav_interior4(t, sr, load_wide4<true>(S.wide4, t.cur, t.rc.neg_mask, sr.top));
     } else {
-        const float4 *w = S.wide + 4 * size_t(t.cur < 0 ? 0 : t.cur);
+        int g = t.cur < 0 ? 0 : t.cur;
+        // a record of the LDS top carries its own index among the binary records behind its axes word
+        if (sr.top != nullptr && g >= kTopFlag)
+            g = int(*reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(sr.top + uint32_t(g - kTopFlag) * uint32_t(kTopStride) + 116u));
+        const float4 *w = S.wide + 4 * size_t(g);
         trav_interior<false>(t, sr, nullptr, w[0], w[1], w[2], w[3]);
     }
 }
@@ -1115,9 +1162,10 @@ template <bool ANY_HIT, bool COUNT, bool ALPHA = true>
 DEV bool traverse(const DScene &S, F3 ro, F3 rd, float tmax, lds_int *lds_stack, int *spill, uint32_t spill_stride,
                   HitRec *hit, TraceStats *st) {
     Trav t;
-    const StackRef sr{lds_stack, spill, 0u, spill_stride};
+    StackRef sr{lds_stack, spill, 0u, spill_stride};
+    sr.root = S.root_ref;
     const float4 d4 = make_float4(rd.x, rd.y, rd.z, 0.f);
-    trav_begin<COUNT>(S, t, ro, rd, tmax, st);
+    trav_begin<COUNT>(S, t, ro, rd, tmax, st, sr.root);
     while (t.have) {
         while (t.have && t.cur >= 0) trav_step<COUNT, ANY_HIT>(S, t, sr, st);
         if (t.have && trav_leaf<COUNT, ALPHA>(S, t, sr, st, ANY_HIT, &d4)) return true;

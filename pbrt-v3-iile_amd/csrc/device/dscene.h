@@ -86,6 +86,12 @@ struct DProbeCam {
     float nrm[9];
 };
 
+#ifndef IILE_TOP_RECORDS
+#define IILE_TOP_RECORDS 21  // levels 0..2 of the four-wide tree (1 + 4 + 16); 85 = levels 0..3
+#endif
+constexpr int kMaxTop = IILE_TOP_RECORDS;  // records of the tree's top kept in LDS by the traversal kernels (dpath.h)
+constexpr int kTopFlag = 1 << 30;          // reference to one of them: kTopFlag | slot
+
 struct DScene {
     // HBM arrays
     const float4 *wide;       // 4 float4 per interior node: both child boxes + child refs + split axis
@@ -111,6 +117,11 @@ struct DScene {
     int n_perms;              // u16 entries of `perms`
     float root_box[6];        // bounds of the root node (min.xyz, max.xyz)
     int root_ref;             // >= 0: wide record; < 0: ~first primitive of a single-leaf tree
+    // The top levels of the four-wide tree once more (breadth first, at most kMaxTop records of 8 float4): every block of a
+    // traversal kernel keeps a copy in LDS, and references between them are kTopFlag | slot (dpath.h, load_wide4).
+    const float4 *top4;
+    int n_top;
+    int root_ref_top;         // root_ref, or kTopFlag | 0 when the root record is among them
     // SpatialLightDistribution (n_lights > 1): per voxel {func[kMaxLights], cdf[kMaxLights + 1], funcInt}
     const float *light_dist;
     int light_nv[3];

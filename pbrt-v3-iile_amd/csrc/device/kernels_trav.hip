@@ -13,8 +13,15 @@ namespace iile {
 template <bool COUNT, bool ALPHA, bool GEN>
 __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, PassDesc P, PassBuffers B, int bounce) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
-    const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
-                      blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    __shared__ __attribute__((aligned(16))) char lds_top[COUNT ? 16 : kMaxTop * kTopStride];
+    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    sr.root = S.root_ref;
+    if (!COUNT && S.n_top > 0) {  // the instrumented build walks the binary records: no four-wide steps, no top
+        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kBlock);
+        __syncthreads();
+        sr.top = (lds_char *)lds_top;
+        sr.root = S.root_ref_top;
+    }
     const uint32_t count = B.counts[kCntRay + bounce];
     uint32_t *head = &B.counts[kCntExtHead + bounce];
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
@@ -64,14 +71,14 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                         // rebuilds the ray from it instead of evaluating the Halton dimensions again
                         reinterpret_cast<float2 *>(&B.beta[slot])[0] = make_float2(pfx, pfy);
                         gen_d = make_float4(d.x, d.y, d.z, tmax);
-                        trav_begin<COUNT>(S, t, o, d, tmax, &st);
+                        trav_begin<COUNT>(S, t, o, d, tmax, &st, sr.root);
                         active = true;
                         ++n_rays;  // (GEN is never an instrumented build)
                     }
                 } else {
                     const float4 o4 = ro[slot], d4 = rd[slot];
                     if (f2b(o4.w) != kInvalid) {
-                        trav_begin<COUNT>(S, t, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, &st);
+                        trav_begin<COUNT>(S, t, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, &st, sr.root);
                         active = true;
                         ++n_rays;
                         if (COUNT && B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
@@ -144,8 +151,15 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
 template <bool COUNT, bool ALPHA>
 __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
-    const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
-                      blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    __shared__ __attribute__((aligned(16))) char lds_top[COUNT ? 16 : kMaxTop * kTopStride];
+    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    sr.root = S.root_ref;
+    if (!COUNT && S.n_top > 0) {  // the instrumented build walks the binary records: no four-wide steps, no top
+        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kBlock);
+        __syncthreads();
+        sr.top = (lds_char *)lds_top;
+        sr.root = S.root_ref_top;
+    }
     const uint32_t count = B.counts[kCntNee + bounce];
     uint32_t *head = &B.counts[kCntConHead + bounce];
     TraceStats st = {0, 0, 0, 0};
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                     }
                     L_old = F3{L4.x, L4.y, L4.z};
                     if (has_shadow) {
-                        trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st);
+                        trav_begin<COUNT>(S, t, F3{n0.x, n0.y, n0.z}, F3{n1.x, n1.y, n1.z}, 1 - kShadowEpsilon, &st, sr.root);
                         active = true;
                         occluded = false;
                         if (COUNT) {
@@ -264,8 +278,15 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
 template <bool COUNT, bool ALPHA>
 __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
-    const StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill,
-                      blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    __shared__ __attribute__((aligned(16))) char lds_top[COUNT ? 16 : kMaxTop * kTopStride];
+    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    sr.root = S.root_ref;
+    if (!COUNT && S.n_top > 0) {  // the instrumented build walks the binary records: no four-wide steps, no top
+        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kBlock);
+        __syncthreads();
+        sr.top = (lds_char *)lds_top;
+        sr.root = S.root_ref_top;
+    }
     // the dense queue of MIS rays k_shade wrote beside the NEE records: (o, record) in plane 2, (d, light) in plane 3
     const uint32_t count = B.counts[kCntMis + bounce];
     uint32_t *head = &B.counts[kCntMisHead + bounce];
@@ -292,7 +313,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
                 if (f2b(n2.w) != kInvalid) {
                     const float4 n3 = B.nee[3 * size_t(plane) + q];
                     e = f2b(n2.w);
-                    trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st);
+                    trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st, sr.root);
                     active = true;
                     ++n_traced;
                     if (COUNT) {

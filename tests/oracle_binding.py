@@ -126,6 +126,26 @@ class Oracle:
         assert rc == 0
         return out
 
+    def bvh_hlbvh(self, bounds6, max_prims_in_node=4):
+        """oracle_bvh_hlbvh (oracle/oracle_bvh.cpp): (nodes as the binding's BVH_NODE array, order (n,) int32, sorted Morton codes)."""
+        import importlib.util
+        import sys
+        b = sys.modules.get("iile_binding")
+        dt = b.BVH_NODE if b is not None else np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("offset", "<i4"), ("nprims", "<u2"), ("axis", "u1"), ("pad", "u1")])
+        b6 = _f32(bounds6).reshape(-1, 6)
+        n = len(b6)
+        nodes = np.zeros(max(2 * n, 1), dtype=dt)
+        order = np.zeros(max(n, 1), dtype=np.int32)
+        codes = np.zeros(max(n, 1), dtype=np.uint32)
+        n_nodes = ctypes.c_int32(0)
+        f = self.lib.oracle_bvh_hlbvh
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, ctypes.c_void_p]
+        rc = f(n, b6.ctypes.data, int(max_prims_in_node), nodes.ctypes.data, ctypes.byref(n_nodes), order.ctypes.data, codes.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"oracle_bvh_hlbvh: {rc} (1: a CHECK of the reference would abort)")
+        return nodes[:n_nodes.value].copy(), order[:n].copy(), codes[:n].copy()
+
     def tile_owner(self, tx, ty, nranks):
         return int(self.lib.oracle_tile_owner(int(tx), int(ty), int(nranks)))
 

@@ -1,8 +1,12 @@
-"""BVHAccel's HLBVH build on the device (iile_bvh_build_hlbvh) against the host builder
-(csrc/host/bvh_build.cpp, split method "hlbvh": the tree of src/accelerators/bvh.cpp:404-658 built by one thread), and
-the device-side packing of the traversal records against a numpy restatement of their layout."""
+"""BVHAccel's HLBVH build on the device (iile_bvh_build_hlbvh) against the ORACLE's restatement of
+src/accelerators/bvh.cpp:404-658 (oracle/oracle_bvh.cpp, pinned by the hand-derived tree of tests/test_oracle_bvh.py) —
+the hand-derived case itself, the shipped scene and the deep-tree room through the loader's build hook, random soups through
+the direct call — then against the product's host builder, and the device-side packing of the traversal records against a
+numpy restatement of their layout."""
 import numpy as np
 import pytest
+
+import test_oracle_bvh as tob
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +22,48 @@ def _same_tree(a, b):
 def _prim_bounds(tri_p):
     p = tri_p.reshape(-1, 3, 3)
     return np.concatenate([p.min(axis=1), p.max(axis=1)], axis=1).astype(np.float32)
+
+
+def test_device_builder_reproduces_the_hand_derived_tree(binding):
+    """The 12-primitive tree worked out from the reference's code (tests/test_oracle_bvh.py's docstring): Morton codes, the sort,
+    one treelet with four interior nodes, the SAH over eight treelet roots, the flattening."""
+    nodes, order, st = binding.bvh_build_hlbvh(tob._hand_case_bounds(), 2)
+    tob.check_hand_case(nodes, order)
+    assert st["n_treelets"] == 8 and st["n_interior"] == 11 and st["n_leaf"] == 12
+
+
+def test_device_builder_matches_the_oracle_on_loaded_scenes(binding, oracle, tmp_path):
+    """killeroo-simple (66 532 triangles + the light's sphere) and the 287 k-triangle room, each loaded twice through the host
+    loader's build hook — once around the device builder's tree, once around the oracle's: nodes, boxes, primitive order."""
+    import boxroom
+    path = tmp_path / "room.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64, xres=64, yres=64, spp=1))
+    for kw in (dict(xres=64, yres=48, spp=1), dict(path=str(path))):
+        by_oracle = binding.HostScene(accel_split="hlbvh", bvh_on_device=tob.oracle_build_hook(oracle), **kw)
+        by_device = binding.HostScene(accel_split="hlbvh", bvh_on_device=True, **kw)
+        tob.scenes_equal(by_oracle, by_device)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_builder_matches_the_oracle_on_soups(binding, oracle, seed):
+    """Direct calls on random boxes: clusters, exact duplicates (equal Morton codes: the sort must be stable), flat sheets,
+    maxPrimsInNode 1 .. 255."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(2, 20000))
+    kind = seed % 3
+    c = rng.random((n, 3))
+    if kind == 1:
+        c = c[rng.integers(0, max(n // 50, 1), n)] + rng.normal(0, 1e-3, (n, 3))  # clusters
+        c[rng.integers(0, n, n // 10)] = c[0]  # exact duplicates
+    if kind == 2:
+        c[:, int(rng.integers(0, 3))] = 0.25  # a sheet: one axis without extent (Offset() does not divide there)
+    half = rng.random((n, 3)) * 0.01
+    b6 = np.concatenate([c - half, c + half], axis=1).astype(np.float32)
+    max_prims = int(rng.choice([1, 2, 4, 7, 255]))
+    dn, do, _ = binding.bvh_build_hlbvh(b6, max_prims)
+    on, oo, _ = oracle.bvh_hlbvh(b6, max_prims)
+    assert np.array_equal(do, oo)
+    tob.same_tree(dn, on)
 
 
 def test_killeroo_tree_is_the_host_builders(binding):
