@@ -148,6 +148,12 @@ int oracle_iispt_gather(const iile_scene_desc *scene, int trig_mode, const iile_
 /* iile_tile_owner of iile_scene.h (a static inline there), exported so that tests can call the header's own definition */
 int oracle_tile_owner(int tx, int ty, int nranks);
 
+/* The IISPT integrator's direct pass (DirectProgressiveIntegrator driven by IisptRenderRunner::run_direct; oracle_path.cpp,
+ * "DIRECT pass") accumulated into a film monitor of doubles {sum r, g, b, weight} per pixel of the cropped pixel bounds, and
+ * IisptFilmMonitor::merge_into + to_intensity_film. */
+int oracle_iispt_direct(const iile_scene_desc *scene, int trig_mode, int n_passes, int first_pass, int n_threads, double *film_rgbw);
+void oracle_iispt_merge(int64_t n_pixels, const double *direct_rgbw, const double *indirect_rgbw, float *out_rgb);
+
 /* BVHAccel(prims, maxPrimsInNode, SplitMethod::HLBVH) as one thread builds it (oracle_bvh.cpp; src/accelerators/bvh.cpp:
  * 107-181, 404-658): nodes_out (room for 2 * n_prims) in flattenBVHTree's order, order_out[p] = number of the primitive at
  * position p of BVHAccel::primitives after the build, codes_out (optional) the sorted Morton codes. 0 = ok, 1 = a CHECK of

@@ -865,7 +865,8 @@ struct Oracle {
     // camera (cameras/perspective.cpp:100-149; transform.h:251-264)
     // with `rd`: GenerateRayDifferential (perspective.cpp:100-149) followed by the render loop's
     // ScaleDifferentials(1 / sqrt(spp)) (integrator.cpp:284-285, geometry.h:908-913)
-    Ray camera_ray(float pfx, float pfy, const float *plens, RayDiff *rd = nullptr, bool unit_diff_scale = false) const {
+    Ray camera_ray(float pfx, float pfy, const float *plens, RayDiff *rd = nullptr, bool unit_diff_scale = false,
+                   float diff_scale_override = 0.f) const {
         const iile_camera &c = S.camera;
         V3 pcam = xf_point(M4{c.raster_to_camera}, V3(pfx, pfy, 0));
         V3 dir = normalize(V3(pcam.x, pcam.y, pcam.z));
@@ -922,7 +923,7 @@ struct Oracle {
             ryd = xf_vector(m, ryd);
             // ScaleDifferentials(1 / sqrt(samplesPerPixel)) in the render loop (integrator.cpp:284-285); the IISPT runner
             // scales by 1.0 (iisptrenderrunner.cpp:272)
-            const float sc = unit_diff_scale ? 1.f : 1 / std::sqrt(float(S.halton.spp));
+            const float sc = diff_scale_override > 0 ? diff_scale_override : (unit_diff_scale ? 1.f : 1 / std::sqrt(float(S.halton.spp)));
             rd->has = true;
             rd->rxo = o + (rxo - o) * sc;
             rd->ryo = o + (ryo - o) * sc;
@@ -2577,6 +2578,142 @@ struct Oracle {
         }
         float uniform_float() { return std::min(OneMinusEpsilon, float(uniform_u32() * 0x1p-32f)); }
     };
+    // ========================================================================
+    // The IISPT integrator's DIRECT pass: DirectProgressiveIntegrator::Li / RenderOnePass
+    // (integrators/directprogressiveintegrator.cpp:22-150) as IisptRenderRunner::run_direct drives it
+    // (iisptrenderrunner.cpp:601-633), with the sampler CreateIISPTIntegrator makes (iispt.cpp:813-816): a RandomSampler of
+    // PbrtOptions.iileDirectSamples = 16 samples per pixel (pbrt.h:178), cloned per runner thread with seed
+    // 6284 + 17 * thread_no. preprocess() requests, for each of maxDepth = 5 levels and each light, two 2D arrays of
+    // nLightSamples = RoundCount(light->nSamples) = 1 entry per pixel sample; RenderOnePass calls StartPixel for every pixel
+    // of every pass and never StartNextSample, so each pixel reads entry 0 of every array and is a fresh draw per pass.
+    //
+    // Random numbers: the reference's RandomSampler is ONE PCG32 stream per thread, consumed pixel after pixel (arrays, camera
+    // sample, Li), and which thread renders which pass is a race (getNextDirectPass) — its image is not a function of its
+    // inputs. Restated here as a function: pass p is rendered with the seed a thread with thread_no = p would clone
+    // (6284 + 17 p), and every pixel of it has its own stream RNG((seed << 32) + pixel rank in the sample bounds), consumed
+    // in the reference's per-pixel order: RandomSampler::StartPixel fills ALL the arrays (16 entries each, x then y:
+    // samplers/random.cpp:62-72), then GetCameraSample (pFilm, time, pLens: sampler.cpp:46-52), then Li's Get2D calls.
+    // The functions are the reference's; the schedule of a thread pool is not restated (as for the gather above).
+    struct DirectSampler {
+        static constexpr int kSpp = 16, kMaxDepth = 5;
+        Pcg rng;
+        std::vector<float> entry0;  // per 2D array: its entry for pixel sample 0
+        size_t array_offset = 0;    // Sampler::array2DOffset
+        DirectSampler(uint64_t seq, int n_lights) : rng(seq) {
+            const int n_arrays = kMaxDepth * n_lights * 2;
+            entry0.resize(size_t(2 * n_arrays));
+            for (int i = 0; i < n_arrays; ++i)
+                for (int j = 0; j < kSpp; ++j) {  // sampleArray2D[i][j] = {rng.UniformFloat(), rng.UniformFloat()}
+                    const float x = rng.uniform_float(), y = rng.uniform_float();
+                    if (j == 0) entry0[size_t(2 * i)] = x, entry0[size_t(2 * i + 1)] = y;
+                }
+        }
+        const float *get2d_array() {  // Sampler::Get2DArray(1), sampler.cpp:97-102, currentPixelSampleIndex = 0
+            if (array_offset == entry0.size() / 2) return nullptr;
+            return &entry0[2 * array_offset++];
+        }
+        float get1d() { return rng.uniform_float(); }
+        void get2d(float *u) {
+            u[0] = rng.uniform_float();
+            u[1] = rng.uniform_float();
+        }
+    };
+    // BSDF::Sample_f(wo, &wi, u, &pdf, BSDF_REFLECTION | BSDF_SPECULAR) (reflection.cpp:719-784): of the lobes built here only
+    // SpecularReflection matches that type (FresnelSpecular is REFLECTION | TRANSMISSION | SPECULAR and does not: glass adds
+    // nothing to the direct pass beyond its direct lighting, which is none). One matching lobe: the remapped u is not used.
+    Rgb sample_specular_reflection(const Bsdf &b, V3 woW, V3 *wiW, float *pdf) const {
+        *pdf = 0;
+        if (!b.has_spec || b.spec_glass) return Rgb(0.f);  // matchingComps == 0
+        V3 wo = b.to_local(woW);
+        if (wo.z == 0) return Rgb(0.f);
+        V3 wi = V3(-wo.x, -wo.y, wo.z);  // SpecularReflection::Sample_f, reflection.cpp:136-143
+        *pdf = 1;
+        const float fr = b.spec_noop ? 1.f : fr_dielectric(wi.z, 1.f, b.spec_eta);
+        Rgb f = Rgb(fr) * b.kr / std::abs(wi.z);
+        *wiW = b.to_world(wi);
+        return f;
+    }
+    // UniformSampleAllLights, integrator.cpp:54-83
+    Rgb uniform_sample_all_lights(const Isect &it, const Bsdf &bsdf, DirectSampler &smp) const {
+        Rgb L(0.f);
+        for (int j = 0; j < S.n_lights; ++j) {
+            const int n_samples = 1;
+            const float *u_light_array = smp.get2d_array();
+            const float *u_scattering_array = smp.get2d_array();
+            if (!u_light_array || !u_scattering_array) {
+                float u_light[2], u_scattering[2];
+                smp.get2d(u_light);
+                smp.get2d(u_scattering);
+                L = L + estimate_direct(it, bsdf, u_scattering, j, u_light);
+            } else {
+                Rgb Ld(0.f);
+                for (int k = 0; k < n_samples; ++k) Ld = Ld + estimate_direct(it, bsdf, u_scattering_array + 2 * k, j, u_light_array + 2 * k);
+                L = L + Ld / float(n_samples);
+            }
+        }
+        return L;
+    }
+    // DirectProgressiveIntegrator::Li, directprogressiveintegrator.cpp:22-58. Differentials: the camera ray's only; the
+    // reflected ray's (SpecularReflect, :152-186) feed nothing but texture filtering and are not carried — scenes that
+    // combine image textures with specular reflection lobes are rejected by oracle_iispt_direct.
+    Rgb direct_li(Ray ray, DirectSampler &smp, RayDiff rdiff, int depth) const {
+        Rgb L(0.f);
+        Isect is;
+        if (!intersect(ray, &is)) {
+            for (int l = 0; l < S.n_lights; ++l)  // `for (const auto &light : scene.lights) L += light->Le(ray)`
+                if (S.lights[l].type == IILE_LIGHT_INFINITE) L = L + inf_le(S.lights[l], ray.d);
+            return L;
+        }
+        if (S.n_textures > 0) compute_differentials(&is, rdiff);
+        {
+            const iile_material &mb = S.materials[S.prim_material[is.prim]];
+            if (S.n_textures > 0 && mb.bump_tex >= 0) bump(mb.bump_tex, &is);
+        }
+        Bsdf bsdf = make_bsdf(is);  // (every primitive of a flattened scene has a material: isect.bsdf is never null)
+        V3 wo = is.wo;
+        L = L + isect_le(is, wo);
+        if (S.n_lights > 0) L = L + uniform_sample_all_lights(is, bsdf, smp);
+        if (depth + 1 < DirectSampler::kMaxDepth) {
+            {  // SpecularReflect, :134-190
+                float u[2];
+                smp.get2d(u);
+                V3 wi;
+                float pdf;
+                Rgb f = sample_specular_reflection(bsdf, wo, &wi, &pdf);
+                Rgb R(0.f);
+                if (pdf > 0.f && !f.is_black() && absdot(wi, is.sn) != 0.f)
+                    R = f * direct_li(spawn_ray(is, wi), smp, RayDiff(), depth + 1) * absdot(wi, is.sn) / pdf;
+                L = L + R;
+            }
+            {  // SpecularTransmit, :192-245: no lobe built here is BSDF_TRANSMISSION | BSDF_SPECULAR alone — pdf = 0
+                float u[2];
+                smp.get2d(u);
+                L = L + Rgb(0.f);
+            }
+        }
+        return L;
+    }
+    // one pixel of one pass: RenderOnePass's loop body (:84-140); returns false outside the pixel bounds
+    Rgb direct_pixel(int px, int py, int pass, int rank) const {
+        DirectSampler smp((uint64_t(6284 + 17 * pass) << 32) + uint64_t(rank), S.n_lights);
+        float u[2], plens[2];
+        smp.get2d(u);   // GetCameraSample: pFilm = pixel + Get2D(), time = Get1D(), pLens = Get2D()
+        smp.get1d();
+        smp.get2d(plens);
+        RayDiff rdiff;
+        // ray.ScaleDifferentials(1 / sqrt(samplesPerPixel)) with the RandomSampler's 16 samples per pixel
+        Ray ray = camera_ray(float(px) + u[0], float(py) + u[1], plens, S.n_textures > 0 ? &rdiff : nullptr, false,
+                             1 / std::sqrt(float(DirectSampler::kSpp)));
+        Rgb L = direct_li(ray, smp, rdiff, 0);
+        if (L.has_nans())
+            L = Rgb(0.f);
+        else if (L.y() < -1e-5)
+            L = Rgb(0.f);
+        else if (std::isinf(L.y()))
+            L = Rgb(0.f);
+        return L;
+    }
+
     // a hemi point's camera as the gather sees it (HemisphericCamera: hemispheric.h:23-82, hemispheric.cpp:109-160)
     struct HemiCam {
         bool valid = false;
@@ -3546,3 +3683,67 @@ int64_t oracle_check_reintersect(const iile_scene_desc *scene, int n, const floa
     }
     return bad;
 }
+
+extern "C" {
+
+// The IISPT direct pass into a film monitor (IisptFilmMonitor::add_n_samples, iisptfilmmonitor.cpp:47-72: doubles): n_passes
+// passes of DirectProgressiveIntegrator::RenderOnePass, pass p seeded as described at DirectSampler, added in pass order into
+// film_rgbw[(y * w + x) * 4] = {sum r, sum g, sum b, sum of ray weights} over the film's cropped pixel bounds (zeroed first).
+// 0 = ok, 1 = bad arguments, 3 = image textures together with specular reflection lobes (reflected rays' differentials).
+int oracle_iispt_direct(const iile_scene_desc *scene, int trig_mode, int n_passes, int first_pass, int n_threads, double *film_rgbw) {
+    if (!scene || !film_rgbw || n_passes < 0) return 1;
+    const iile_scene_desc &S = *scene;
+    const iile_film_desc &F = S.film;
+    if (S.n_textures > 0)
+        for (int m = 0; m < S.n_materials; ++m)
+            if (S.materials[m].type == IILE_MAT_MIRROR || (S.materials[m].type == IILE_MAT_UBER && (S.materials[m].kr[0] > 0 || S.materials[m].kr[1] > 0 || S.materials[m].kr[2] > 0)))
+                return 3;
+    const int fw = F.crop_x1 - F.crop_x0, fh = F.crop_y1 - F.crop_y0;
+    std::memset(film_rgbw, 0, sizeof(double) * 4 * size_t(fw) * fh);
+    if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = 1;
+    const int sw = F.samp_x1 - F.samp_x0;
+    std::vector<Counters> counters(static_cast<size_t>(n_threads));
+    for (int p = 0; p < n_passes; ++p) {
+        std::atomic<int> next_row(F.samp_y0);
+        auto worker = [&](int tid) {
+            Oracle orc(S, trig_mode, &counters[size_t(tid)]);
+            for (;;) {
+                const int y = next_row.fetch_add(1);
+                if (y >= F.samp_y1) break;
+                for (int x = F.samp_x0; x < F.samp_x1; ++x) {
+                    // (StartPixel is called for every pixel of the sample bounds; one outside the pixel bounds is skipped)
+                    if (x < F.crop_x0 || x >= F.crop_x1 || y < F.crop_y0 || y >= F.crop_y1) continue;
+                    const Rgb L = orc.direct_pixel(x, y, first_pass + p, (y - F.samp_y0) * sw + (x - F.samp_x0));
+                    double *out = film_rgbw + 4 * (size_t(y - F.crop_y0) * fw + (x - F.crop_x0));
+                    out[0] += double(L.c[0]);  // pix.r += rgb[0] (float to double)
+                    out[1] += double(L.c[1]);
+                    out[2] += double(L.c[2]);
+                    out[3] += 1.0;             // rayWeight of the perspective camera
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_threads; ++i) th.emplace_back(worker, i);
+        worker(0);
+        for (auto &t : th) t.join();
+    }
+    return 0;
+}
+
+// IisptFilmMonitor::merge_into (iisptfilmmonitor.cpp:231-275) followed by to_intensity_film (:158-196): both pixels
+// normalised (sums over weight where the weight is positive), added, and the sum — weight 1 — converted to float.
+void oracle_iispt_merge(int64_t n_pixels, const double *direct_rgbw, const double *indirect_rgbw, float *out_rgb) {
+    for (int64_t i = 0; i < n_pixels; ++i) {
+        double a[3] = {direct_rgbw[4 * i], direct_rgbw[4 * i + 1], direct_rgbw[4 * i + 2]};
+        double b[3] = {indirect_rgbw[4 * i], indirect_rgbw[4 * i + 1], indirect_rgbw[4 * i + 2]};
+        if (direct_rgbw[4 * i + 3] > 0.0)
+            for (double &v : a) v /= direct_rgbw[4 * i + 3];
+        if (indirect_rgbw[4 * i + 3] > 0.0)
+            for (double &v : b) v /= indirect_rgbw[4 * i + 3];
+        for (int c = 0; c < 3; ++c) out_rgb[3 * i + c] = float((a[c] + b[c]) / 1.0);
+    }
+}
+
+}  // extern "C"
+

@@ -146,6 +146,29 @@ class Oracle:
             raise RuntimeError(f"oracle_bvh_hlbvh: {rc} (1: a CHECK of the reference would abort)")
         return nodes[:n_nodes.value].copy(), order[:n].copy(), codes[:n].copy()
 
+    def iispt_direct(self, scene, n_passes, first_pass=0, threads=0, trig_mode=TRIG_PORTABLE):
+        """oracle_iispt_direct: the direct film monitor {sum r, g, b, weight} as float64 (h, w, 4)."""
+        h, w = scene.film_shape
+        film = np.zeros((h, w, 4), np.float64)
+        f = self.lib.oracle_iispt_direct
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        rc = f(scene.desc, trig_mode, int(n_passes), int(first_pass), int(threads), film.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"oracle_iispt_direct: {rc}")
+        return film
+
+    def iispt_merge(self, direct, indirect):
+        """oracle_iispt_merge: IisptFilmMonitor::merge_into + to_intensity_film of two (h, w, 4) float64 monitors -> (h, w, 3) float32."""
+        d = np.ascontiguousarray(direct, np.float64)
+        i = np.ascontiguousarray(indirect, np.float64)
+        out = np.zeros(d.shape[:2] + (3,), np.float32)
+        f = self.lib.oracle_iispt_merge
+        f.restype = None
+        f.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        f(d.shape[0] * d.shape[1], d.ctypes.data, i.ctypes.data, out.ctypes.data)
+        return out
+
     def tile_owner(self, tx, ty, nranks):
         return int(self.lib.oracle_tile_owner(int(tx), int(ty), int(nranks)))
 
