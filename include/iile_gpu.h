@@ -143,6 +143,24 @@ int iile_bsdf_sample(iile_scene *scene, int32_t n, int32_t mat, const float *wo3
  * HBM for the network); pos3 / dir3 are host memory either way. */
 int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, const float *dir3, float *intensity_rgb,
                        float *normals_xyz, float *distance, int32_t outputs_on_device, iile_stats *stats);
+/* The IISPT integrator's DIRECT pass: what IisptRenderRunner::run_direct
+ * (src/integrators/iisptrenderrunner.cpp:601-633) leaves in film_monitor_direct — n_passes calls of
+ * DirectProgressiveIntegrator::RenderOnePass (src/integrators/directprogressiveintegrator.cpp:60-150: one camera sample per
+ * pixel; Li = emitted light + UniformSampleAllLights + the mirror recursion, five levels deep) with the 16-samples-per-pixel
+ * RandomSampler of src/integrators/iispt.cpp:813-816, added by IisptFilmMonitor::add_n_samples
+ * (src/integrators/iisptfilmmonitor.cpp:47-72) into film_rgbw[(y * w + x) * 4] = {sum r, sum g, sum b, sum of ray weights},
+ * DOUBLES, over the film's cropped pixel bounds. The reference consumes ONE random stream per thread, and which thread renders
+ * which pass is a race; here pass p (= first_pass + i) is seeded 6284 + 17 p — the seed a runner thread with that number would
+ * clone its sampler with — and every pixel of it has its own PCG32 stream, consumed in the reference's per-pixel order (kernels_direct.hip).
+ * accumulate == 0: the film is zeroed first. Infinite lights, and image textures combined with mirror lobes (the reflected
+ * ray's differentials), are not built: IILE_ERR_UNSUPPORTED. */
+typedef struct iile_direct_params {
+    int32_t n_passes, first_pass;
+    int32_t accumulate;
+    int32_t film_on_device; /* 1: film_rgbw is a device pointer */
+    void *stream;
+} iile_direct_params;
+int iile_render_direct(iile_scene *scene, const iile_direct_params *params, double *film_rgbw);
 /* The IISPT render runner around the probe pass and the network (src/integrators/iisptrenderrunner.cpp:216-596),
  * one task (iile_iispt_task, iile_scene.h) at a time:
  *   iile_iispt_hemi_points  for every hemi point of the task (row by row): whether it has a probe (find_intersection found

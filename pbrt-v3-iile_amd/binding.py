@@ -111,11 +111,16 @@ HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_
                 "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table",
                 "iile_host_sobol_matrices", "iile_host_sobol_vdc", "iile_host_write_exr", "iile_host_write_image",
                 "iile_host_scene_film_filename"]
+class DirectParams(ctypes.Structure):  # iile_direct_params
+    _fields_ = [("n_passes", ctypes.c_int32), ("first_pass", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("film_on_device", ctypes.c_int32),
+                ("stream", ctypes.c_void_p)]
+
+
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
                "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download",
-               "iile_iispt_hemi_points", "iile_iispt_gather", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe"]
+               "iile_iispt_hemi_points", "iile_iispt_gather", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_rendezvous_file_token", "iile_dist_rendezvous_done", "iile_dist_all_ok",
@@ -554,6 +559,17 @@ class GpuScene:
                                                 nn.ctypes.data if nn is not None else c_vp(int(nn_device_ptr)), int(nn is None),
                                                 out.ctypes.data if out is not None else c_vp(int(out_device_ptr)), int(out is None)),
                     "iile_iispt_gather")
+        return out
+
+    def render_direct(self, n_passes, first_pass=0, film_device_ptr=None, accumulate=False, stream=None):
+        """The IISPT direct pass (iile_render_direct): the direct film monitor {sum r, g, b, weight} as (h, w, 4) float64, or
+        accumulated into device memory at film_device_ptr (returns None)."""
+        h, w = self.host.film_shape
+        out = None if film_device_ptr is not None else np.zeros((h, w, 4), np.float64)
+        prm = DirectParams(int(n_passes), int(first_pass), int(bool(accumulate)), int(out is None), c_vp(stream) if stream else None)
+        f = gpu_lib().iile_render_direct
+        f.argtypes = [c_vp, ctypes.POINTER(DirectParams), c_vp]
+        self._check(f(self._s, ctypes.byref(prm), out.ctypes.data if out is not None else c_vp(int(film_device_ptr))), "iile_render_direct")
         return out
 
     def texture_eval(self, tex, uv, duv):

@@ -1627,6 +1627,109 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     return IILE_OK;
 }
 
+// ---- IISPT direct pass (kernels_direct.hip) -------------------------------------
+int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *film_rgbw) {
+    if (!sc || !prm || !film_rgbw || prm->n_passes < 0 || prm->first_pass < 0) return fail(IILE_ERR_ARG, "iile_render_direct: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    DScene S = sc->ds;
+    if (S.has_infinite) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: infinite lights are not built for the direct pass");
+    if (S.textured_materials && S.has_specular)
+        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: image textures together with specular lobes (the reflected ray's differentials)");
+    if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
+    S.diff_scale = 0.25f;  // ScaleDifferentials(1 / sqrt(16)): the RandomSampler's samples per pixel
+    hipStream_t stream = static_cast<hipStream_t>(prm->stream);
+    LaunchCfg cfg{sc->n_cus, stream, false};
+    PassDesc P;
+    std::memset(&P, 0, sizeof(P));
+    P.n_tiles_x = (S.samp_x1 - S.samp_x0 + 15) / 16;
+    P.n_tiles_y = (S.samp_y1 - S.samp_y0 + 15) / 16;
+    P.tile_rank = 0;
+    P.tile_nranks = 1;
+    rc = ensure_tile_map(sc, &P, stream);
+    if (rc) return rc;
+    P.slot0 = 0;
+    P.n_pass_tiles = P.n_owned_tiles;
+    P.k0 = 0;
+    P.kc = 1;
+    const uint64_t n_paths64 = uint64_t(P.n_owned_tiles) * 256;
+    if (n_paths64 > 200000000ull) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: frame too large for one pass");
+    P.n_paths = uint32_t(n_paths64);
+    const uint32_t fw = uint32_t(S.crop_x1 - S.crop_x0), fh = uint32_t(S.crop_y1 - S.crop_y0);
+    const size_t film_bytes = size_t(fw) * fh * 4 * sizeof(double);
+    if (P.n_paths == 0 || fw == 0 || fh == 0) return IILE_OK;
+    rc = ensure_workspace(sc, P.n_paths);
+    if (rc) return rc;
+    sc->pb.nray_out = nullptr;
+    sc->pb.flag_count = nullptr;
+    // E, F (5 levels) and D (5 levels x lights) of every path, the PCG jump table, the film
+    const int n_lights = std::max(S.n_lights, 0), n_arrays = 5 * n_lights * 2;
+    const size_t np = P.n_paths, vec = sizeof(float4);
+    const size_t d_bytes = std::max<size_t>(size_t(5) * size_t(n_lights) * np * vec, vec), ef_bytes = size_t(5) * np * vec;
+    const size_t jump_bytes = (size_t(n_arrays) + 1) * 2 * sizeof(unsigned long long);
+    DevBuf<char> block;
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, d_bytes + 2 * ef_bytes + jump_bytes + (prm->film_on_device ? 0 : film_bytes) + 1024) != hipSuccess)
+            return fail(IILE_ERR_HIP, "out of device memory for the direct pass (" + std::to_string((d_bytes + 2 * ef_bytes) >> 20) + " MiB of per-vertex records)");
+        block.p = static_cast<char *>(p);
+    }
+    char *at = block.p;
+    float4 *D = reinterpret_cast<float4 *>(at);
+    at += d_bytes;
+    float4 *E = reinterpret_cast<float4 *>(at);
+    at += ef_bytes;
+    float4 *F = reinterpret_cast<float4 *>(at);
+    at += ef_bytes;
+    unsigned long long *jump_dev = reinterpret_cast<unsigned long long *>(at);
+    at += (jump_bytes + 255) & ~size_t(255);
+    double *film_dev = prm->film_on_device ? film_rgbw : reinterpret_cast<double *>(at);
+    {   // the stream 32 i draws on: every array holds 16 entries of two floats (RandomSampler::StartPixel, random.cpp:62-72)
+        std::vector<unsigned long long> jump(size_t(n_arrays + 1) * 2);
+        const unsigned long long a = 0x5851f42d4c957f2dULL;
+        unsigned long long A = 1, G = 0;
+        for (int i = 0; i <= n_arrays; ++i) {
+            jump[2 * size_t(i)] = A;
+            jump[2 * size_t(i) + 1] = G;
+            for (int s = 0; s < 32; ++s) {  // one more draw: state' = a state + inc
+                G = G * a + 1;
+                A = A * a;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(jump_dev, jump.data(), jump_bytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));  // (the vector dies with this scope)
+    }
+    if (!prm->accumulate) HIP_TRY(hipMemsetAsync(film_dev, 0, film_bytes, stream));
+    else if (!prm->film_on_device) HIP_TRY(hipMemcpyAsync(film_dev, film_rgbw, film_bytes, hipMemcpyHostToDevice, stream));
+    PassBuffers B = sc->pb;
+    B.L = D;
+    B.dir_E = E;
+    B.dir_F = F;
+    B.dir_paths = P.n_paths;
+    B.spill = sc->spill;
+    P.direct_arrays = n_arrays;
+    P.direct_jump = jump_dev;
+    for (int i = 0; i < prm->n_passes; ++i) {
+        P.direct_seed = uint32_t(6284 + 17 * (prm->first_pass + i));
+        HIP_TRY(hipMemsetAsync(B.counts, 0, kCntWords * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(D, 0, d_bytes + 2 * ef_bytes, stream));
+        launch_direct_generate(S, P, B, cfg);
+        for (int d = 0; d < 5; ++d) {
+            launch_extend(S, P, B, d, B.queue_cap, cfg);
+            launch_direct_shade(S, P, B, d, B.queue_cap, cfg);
+            launch_mis(S, B, d, B.queue_cap, cfg);
+            launch_mis_lit(S, B, d, B.queue_cap, cfg);
+            launch_shadow(S, B, d, B.queue_cap, cfg);
+            if (!S.has_specular) break;  // no mirror lobe anywhere: Li never recurses
+        }
+        launch_direct_fold(S, P, B, film_dev, cfg);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!prm->film_on_device) HIP_TRY(hipMemcpyAsync(film_rgbw, film_dev, film_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // the per-vertex records are freed on return
+    return IILE_OK;
+}
+
 // ---- IISPT probe pass ---------------------------------------------------------
 namespace {
 // Inverse(Matrix4x4), transform.cpp:82-141 (Gauss-Jordan, full pivoting; the pivot reciprocal is a double divide)

@@ -33,6 +33,11 @@ struct PassDesc {
     // continuations sampled from a specular lobe; 2 = the scene has no specular lobe: no continuation is sampled there and
     // bounce maxDepth is not launched at all.
     int skip_last_bounce;
+    // the IISPT direct pass (kernels_direct.hip): pass seed 6284 + 17 * pass, number of 2D sample arrays a pixel's stream
+    // starts with (5 levels x lights x 2), and the PCG32 jump table {A, G} per array start + one for the camera sample
+    uint32_t direct_seed;
+    int direct_arrays;
+    const unsigned long long *direct_jump;
 };
 
 // Queue arrays (ray_o/ray_d/hits/shade_q/nee) hold `queue_cap` slots: the paths of a
@@ -67,6 +72,10 @@ struct PassBuffers {
     // pixel, film.h:159-166): {px, py, k, pFilm.x, pFilm.y, path id} records, appended by the generation code, count in [0]
     uint32_t *flag_count;
     float *flag_rec;    // [kMaxFlagged * 6]
+    // the IISPT direct pass: per vertex depth d < 5 and path, emitted light E[d * dir_paths + path] and the mirror lobe's
+    // {f, |cos|} F[d * dir_paths + path]; the lights' direct light lands in L[(d * n_lights + light) * dir_paths + path]
+    float4 *dir_E, *dir_F;
+    uint32_t dir_paths;
 };
 constexpr uint32_t kMaxFlagged = 1u << 20;
 
@@ -108,6 +117,9 @@ void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffer
 void launch_film_store(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int k_begin, int n_samples,
                        const LaunchCfg &cfg);
 void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F, int n_samples, const LaunchCfg &cfg);
+void launch_direct_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg);
+void launch_direct_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int depth, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_direct_fold(const DScene &S, const PassDesc &P, const PassBuffers &B, double *film_rgbw, const LaunchCfg &cfg);
 void launch_probe_finish(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int n_probes,
                          float *intensity, float *normals, float *distance, const LaunchCfg &cfg);
 void launch_film_resolve(const DScene &S, const PassDesc &P, const FilmBuffers &F, const LaunchCfg &cfg);

@@ -1,0 +1,355 @@
+// kernels_direct.hip — the IISPT integrator's DIRECT pass on the device:
+// DirectProgressiveIntegrator::Li / RenderOnePass (src/integrators/directprogressiveintegrator.cpp:22-150) as
+// IisptRenderRunner::run_direct drives it (src/integrators/iisptrenderrunner.cpp:601-633), with the RandomSampler
+// CreateIISPTIntegrator makes (src/integrators/iispt.cpp:813-816). Operation for operation the oracle's "DIRECT pass"
+// (oracle/oracle_path.cpp: DirectSampler, direct_li, direct_pixel), which also says how the reference's per-thread random
+// stream is restated as a function of (pass, pixel).
+//
+// One pass = one camera sample per pixel through the wavefront pipeline of the path integrator, with three kernels of its own:
+//   k_direct_generate   camera sample from the pixel's PCG32 stream (behind the 2D arrays StartPixel fills first)
+//   [k_extend]          closest hit, as ever
+//   k_direct_shade      one vertex of Li: Le -> E[depth], one EstimateDirect per light -> NEE records whose results the
+//                       ordinary k_mis / k_mis_lit / k_shadow leave in D[depth * n_lights + light], the mirror direction
+//                       (SpecularReflect) -> F[depth] and the next ray
+//   k_direct_fold       L = ((Le + sum of the lights' Ld) + f * L(next vertex) * |cos| / pdf) + 0 from the deepest vertex
+//                       back to the camera — the recursion's own order of float operations —, the render loop's radiance
+//                       guards, IisptFilmMonitor::add_n_samples in double precision
+// Li's recursion is a chain here, never a tree: of the lobes this build knows only SpecularReflection matches
+// BSDF_REFLECTION | BSDF_SPECULAR and none matches BSDF_TRANSMISSION | BSDF_SPECULAR (FresnelSpecular is both at once and
+// matches neither), so SpecularTransmit always returns 0.
+#include "kcommon.h"
+
+namespace iile {
+
+namespace {
+
+// PCG32 (core/rng.h:62-156)
+struct DPcg {
+    unsigned long long state, inc;
+};
+DEV uint32_t pcg_u32(DPcg &r) {
+    const unsigned long long old = r.state;
+    r.state = old * 0x5851f42d4c957f2dULL + r.inc;
+    const uint32_t xorshifted = uint32_t(((old >> 18u) ^ old) >> 27u);
+    const uint32_t rot = uint32_t(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+DEV float pcg_float(DPcg &r) { return mn(kOneMinusEpsilon, float(pcg_u32(r)) * 0x1p-32f); }
+DEV DPcg pcg_seed(unsigned long long seq) {  // RNG(sequenceIndex) -> SetSequence
+    DPcg r;
+    r.state = 0u;
+    r.inc = (seq << 1u) | 1u;
+    (void)pcg_u32(r);
+    r.state += 0x853c49e6748fea9bULL;
+    (void)pcg_u32(r);
+    return r;
+}
+// the stream n draws further on: state_n = A_n state + G_n inc (A_n = a^n, G_n = 1 + a + .. + a^(n-1), host-made table)
+DEV DPcg pcg_at(const DPcg &base, const unsigned long long *jump, int i) {
+    DPcg r;
+    r.state = jump[2 * i] * base.state + jump[2 * i + 1] * base.inc;
+    r.inc = base.inc;
+    return r;
+}
+DEV DPcg pixel_stream(const DScene &S, const PassDesc &P, int px, int py) {
+    const uint32_t rank = uint32_t(py - S.samp_y0) * uint32_t(S.samp_x1 - S.samp_x0) + uint32_t(px - S.samp_x0);
+    return pcg_seed((static_cast<unsigned long long>(P.direct_seed) << 32) + rank);
+}
+
+DEV F3 area_light_L(const DLight &lt, F3 n, F3 w) {  // DiffuseAreaLight::L, lights/diffuse.h:56-58
+    return (lt.two_sided || dot(n, w) > 0) ? F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} : F3{0, 0, 0};
+}
+
+}  // namespace
+
+// jump[2 i], jump[2 i + 1]: the stream 32 i draws on (array i's first entry); entry n_arrays: the camera sample
+__global__ __launch_bounds__(kBlock) void k_direct_generate(DScene S, PassDesc P, PassBuffers B) {
+    for (uint32_t pid = blockIdx.x * kBlock + threadIdx.x; pid < P.n_paths; pid += gridDim.x * kBlock) {
+        int px = 0, py = 0;
+        uint32_t k = 0;
+        const bool valid = path_pixel(S, P, pid, &px, &py, &k) && px >= S.crop_x0 && px < S.crop_x1 && py >= S.crop_y0 && py < S.crop_y1;
+        F3 o = F3{0, 0, 0}, d = F3{0, 0, 1};
+        float tmax = 0;
+        if (valid) {
+            DPcg r = pcg_at(pixel_stream(S, P, px, py), P.direct_jump, P.direct_arrays);
+            // GetCameraSample: pFilm = pixel + Get2D(), time = Get1D(), pLens = Get2D()
+            const float u0 = pcg_float(r), u1 = pcg_float(r);
+            (void)pcg_float(r);
+            const float l0 = pcg_float(r), l1 = pcg_float(r);
+            camera_ray(S, float(px) + u0, float(py) + u1, l0, l1, &o, &d, &tmax);
+            reinterpret_cast<float2 *>(&B.beta[pid])[0] = make_float2(float(px) + u0, float(py) + u1);  // for the differentials
+            reinterpret_cast<float2 *>(&B.beta[pid])[1] = make_float2(l0, l1);
+        }
+        B.ray_o[0][pid] = make_float4(o.x, o.y, o.z, b2f(valid ? pid : kInvalid));
+        B.ray_d[0][pid] = make_float4(d.x, d.y, d.z, tmax);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.counts[kCntRay] = P.n_paths;
+}
+
+// One vertex of DirectProgressiveIntegrator::Li for every hit of the bounce's shade queue.
+template <bool TEX>
+__global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P, PassBuffers B, int depth, uint32_t plane) {
+    const uint32_t count = B.counts[kCntShade + depth];
+    const float4 *ro = B.ray_o[depth & 1], *rd = B.ray_d[depth & 1];
+    float4 *no = B.ray_o[(depth + 1) & 1], *nd = B.ray_d[(depth + 1) & 1];
+    WaveOut ray_out{0, 0}, nee_out{0, 0}, mis_out{0, 0};
+    auto pad_ray = [&](uint32_t sl) { no[sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
+    auto pad_nee = [&](uint32_t sl) { B.nee[plane + sl] = B.nee[4 * plane + sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
+    auto pad_mis = [&](uint32_t sl) { B.nee[2 * plane + sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
+    const uint32_t rounds = (count + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+    for (uint32_t it = 0; it < rounds; ++it) {  // (every lane walks every round: the queue appends are wavefront-wide)
+        const uint32_t qi = (it * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        const uint32_t ent = qi < count ? B.shade_q[qi] : kInvalid;
+        const bool valid = ent != kInvalid;
+        const uint32_t slot = ent & ((1u << kSlotBits) - 1u);
+        uint32_t pid = 0;
+        Isect is;
+        Bsdf bsdf;
+        F3 ray_d = F3{0, 0, 1};
+        bool lit_surface = false;  // a surface with a non-specular lobe: EstimateDirect can return something
+        DPcg stream{0, 1};
+        if (valid) {
+            const float4 h4 = B.hits[slot], o4 = ro[slot], d4 = rd[slot];
+            pid = f2b(o4.w);
+            const int prim = int(f2b(h4.x));
+            const F3 ray_o = F3{o4.x, o4.y, o4.z};
+            ray_d = F3{d4.x, d4.y, d4.z};
+            const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1], v2 = S.tri_verts[3 * size_t(prim) + 2];
+            const uint32_t flags = f2b(v0.w);
+            const int material = int(f2b(v1.w)), light = int(f2b(v2.w));
+            if (flags & 1u) {
+                float t;
+                F3 od, ph;
+                const DSphere &sp = S.spheres[S.prim_shape[prim]];
+                sphere_test(sp, ray_o, ray_d, IILE_INF, &t, &od, &ph);
+                sphere_interaction(sp, od, ph, &is);
+            } else {
+                triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, ray_d, h4.y, h4.z,
+                                     h4.w, &is);
+            }
+            int px = 0, py = 0;
+            uint32_t kk = 0;
+            path_pixel(S, P, pid, &px, &py, &kk);
+            stream = pixel_stream(S, P, px, py);
+            // isect.ComputeScatteringFunctions(ray, arena): differentials of the camera ray only (see the oracle's direct_li)
+            const DMaterial &m0 = S.materials[material];
+            if (TEX && S.textured_materials &&
+                (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0)) {
+                TexDiff td = TexDiff{0, 0, 0, 0};
+                if (depth == 0) {
+                    const float4 cs = B.beta[pid];  // pFilm, pLens left by k_direct_generate
+                    td = compute_differentials(is, camera_differentials(S, cs.x, cs.y, cs.z, cs.w, ray_o, ray_d));
+                }
+                if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, &is);
+                bsdf = make_bsdf<true>(textured_material(S, m0, is, td), is);
+            } else {
+                bsdf = make_bsdf<true>(m0, is);
+            }
+            // L += isect.Le(wo)
+            if (light >= 0) {
+                const F3 Le = area_light_L(S.lights[light], is.n, -ray_d);
+                B.dir_E[size_t(depth) * B.dir_paths + pid] = make_float4(Le.x, Le.y, Le.z, 0);
+            }
+            lit_surface = n_nonspec(bsdf) > 0;
+        }
+        // UniformSampleAllLights (integrator.cpp:54-83): every light once, its two samples from the arrays the pixel's stream
+        // filled first (array 2 c: uLight, 2 c + 1: uScattering, c = depth * n_lights + light: the c-th pair of Get2DArray calls)
+        for (int li = 0; li < S.n_lights; ++li) {
+            bool emit_nee = false;
+            F3 so = F3{0, 0, 0}, sd = F3{0, 0, 1}, mo = F3{0, 0, 0}, md = F3{0, 0, 1}, A = F3{0, 0, 0}, Bc = F3{0, 0, 0};
+            uint32_t nee_flags = 0;
+            const int c = depth * S.n_lights + li;
+            if (valid && lit_surface) {
+                const DLight &lt = S.lights[li];
+                DPcg ra = pcg_at(stream, P.direct_jump, 2 * c), rb = pcg_at(stream, P.direct_jump, 2 * c + 1);
+                const float ul0 = pcg_float(ra), ul1 = pcg_float(ra), us0 = pcg_float(rb), us1 = pcg_float(rb);
+                if (lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
+                    // EstimateDirect for a delta light (integrator.cpp:150-166): light sample only. PointLight (lights/point.cpp:
+                    // 43-52), SpotLight (spot.cpp:53-76), DistantLight (distant.cpp:50-61). (Infinite lights: rejected up front.)
+                    const F3 pos = F3{lt.pos[0], lt.pos[1], lt.pos[2]};
+                    const F3 I = F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]};
+                    F3 wi, target, Li;
+                    if (lt.type == kLightDistant) {
+                        wi = pos;
+                        target = is.p + pos * (2 * lt.world_radius);
+                        Li = I;
+                    } else {
+                        wi = normalize(pos - is.p);
+                        target = pos;
+                        if (lt.type == kLightSpot) {
+                            const F3 w = -wi;
+                            const F3 wl = normalize(F3{lt.w2l[0] * w.x + lt.w2l[1] * w.y + lt.w2l[2] * w.z,
+                                                       lt.w2l[3] * w.x + lt.w2l[4] * w.y + lt.w2l[5] * w.z,
+                                                       lt.w2l[6] * w.x + lt.w2l[7] * w.y + lt.w2l[8] * w.z});
+                            const float cos_theta = wl.z;
+                            float falloff;
+                            if (cos_theta < lt.cos_total_width)
+                                falloff = 0;
+                            else if (cos_theta >= lt.cos_falloff_start)
+                                falloff = 1;
+                            else {
+                                const float delta = (cos_theta - lt.cos_total_width) / (lt.cos_falloff_start - lt.cos_total_width);
+                                falloff = (delta * delta) * (delta * delta);
+                            }
+                            Li = sdiv(I * falloff, length_sq(pos - is.p));
+                        } else {
+                            Li = sdiv(I, length_sq(pos - is.p));
+                        }
+                    }
+                    if (!is_black(Li)) {
+                        const F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
+                        if (!is_black(f)) {
+                            so = offset_ray_origin(is.p, is.perr, is.n, target - is.p);
+                            sd = target - so;
+                            A = sdiv(f * Li, 1.f);
+                            nee_flags |= NEE_HAS_SHADOW;
+                        }
+                    }
+                } else {
+                    // EstimateDirect, light-sampling half (integrator.cpp:117-163)
+                    float light_pdf = 0, scattering_pdf = 0;
+                    F3 wi = F3{0, 0, 0}, Li = F3{0, 0, 0};
+                    const LightSample ps = shape_sample(S, lt, is, ul0, ul1, &light_pdf);
+                    if (light_pdf == 0 || length_sq(ps.p - is.p) == 0) {
+                        light_pdf = 0;
+                    } else {
+                        wi = normalize(ps.p - is.p);
+                        Li = area_light_L(lt, ps.n, -wi);
+                    }
+                    if (light_pdf > 0 && !is_black(Li)) {
+                        const F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
+                        scattering_pdf = bsdf_pdf(bsdf, is.wo, wi);
+                        if (!is_black(f)) {
+                            so = offset_ray_origin(is.p, is.perr, is.n, ps.p - is.p);
+                            const F3 target = offset_ray_origin(ps.p, ps.perr, ps.n, so - ps.p);
+                            sd = target - so;
+                            A = sdiv(f * Li * power_heuristic(light_pdf, scattering_pdf), light_pdf);
+                            nee_flags |= NEE_HAS_SHADOW;
+                        }
+                    }
+                    // BSDF-sampling half (integrator.cpp:165-213); every such ray is traced (no culling here)
+                    F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
+                    f2 = f2 * absdot(wi, is.sn);
+                    if (!is_black(f2) && scattering_pdf > 0) {
+                        unsigned long long nt = 0, nh = 0;
+                        const float lp = shape_pdf(S, lt, is, wi, &nt, &nh);
+                        if (lp != 0) {
+                            mo = offset_ray_origin(is.p, is.perr, is.n, wi);
+                            md = wi;
+                            Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * power_heuristic(scattering_pdf, lp), scattering_pdf);
+                            nee_flags |= NEE_HAS_MIS;
+                        }
+                    }
+                }
+                emit_nee = nee_flags != 0;
+            }
+            const uint32_t eslot = out_take(nee_out, &B.counts[kCntNee + depth], emit_nee, pad_nee);
+            const bool emit_mis = emit_nee && (nee_flags & NEE_HAS_MIS) != 0;
+            const uint32_t mslot = out_take(mis_out, &B.counts[kCntMis + depth], emit_mis, pad_mis);
+            if (emit_nee) {
+                // the record's "path" is the slot of D this light's result belongs in: k_shadow stores L[that] = 0 + 1 * Ld
+                const uint32_t dslot = uint32_t(c) * B.dir_paths + pid;
+                B.nee[eslot] = make_float4(so.x, so.y, so.z, 1.f);
+                B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
+                B.nee[4 * plane + eslot] = make_float4(A.x, A.y, A.z, b2f(nee_flags));
+                if (nee_flags & NEE_HAS_MIS) B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, b2f(uint32_t(li)));
+                B.nee[6 * plane + eslot] = make_float4(1.f, 1.f, 1.f, b2f(dslot));
+            }
+            if (emit_mis) {
+                B.nee[2 * plane + mslot] = make_float4(mo.x, mo.y, mo.z, b2f(eslot));
+                B.nee[3 * plane + mslot] = make_float4(md.x, md.y, md.z, b2f(uint32_t(li)));
+            }
+        }
+        // SpecularReflect (directprogressiveintegrator.cpp:134-190): BSDF::Sample_f(wo, &wi, Get2D(), &pdf, BSDF_REFLECTION |
+        // BSDF_SPECULAR) finds a SpecularReflection lobe or nothing (its sample is not used; pdf = 1)
+        bool alive = false;
+        F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
+        if (valid && depth + 1 < 5 && bsdf.has_spec && bsdf.mtype != kMatGlass) {
+            const F3 wo_w = is.wo;
+            const F3 wo = to_local(bsdf, wo_w);
+            if (wo.z != 0) {
+                const F3 wi_l = F3{-wo.x, -wo.y, wo.z};
+                const float fr = bsdf.mtype == kMatMirror ? 1.f : fr_dielectric(wi_l.z, 1.f, bsdf.eta);
+                const F3 f = sdiv(F3{fr, fr, fr} * bsdf.kr, fabsf(wi_l.z));
+                const F3 wi = to_world(bsdf, wi_l);
+                const float ad = absdot(wi, is.sn);
+                if (!is_black(f) && ad != 0.f) {
+                    B.dir_F[size_t(depth) * B.dir_paths + pid] = make_float4(f.x, f.y, f.z, ad);
+                    next_o = offset_ray_origin(is.p, is.perr, is.n, wi);
+                    next_d = wi;
+                    alive = true;
+                }
+            }
+        }
+        const uint32_t nslot = out_take(ray_out, &B.counts[kCntRay + depth + 1], alive, pad_ray);
+        if (alive) {
+            no[nslot] = make_float4(next_o.x, next_o.y, next_o.z, b2f(pid));
+            nd[nslot] = make_float4(next_d.x, next_d.y, next_d.z, IILE_INF);
+        }
+    }
+    out_flush(ray_out, pad_ray);
+    out_flush(nee_out, pad_nee);
+    out_flush(mis_out, pad_mis);
+}
+
+// Li folded from the deepest vertex back (the recursion returns in that order), the render loop's guards
+// (directprogressiveintegrator.cpp:104-127), IisptFilmMonitor::add_n_samples (iisptfilmmonitor.cpp:47-72: doubles)
+__global__ __launch_bounds__(kBlock) void k_direct_fold(DScene S, PassDesc P, PassBuffers B, double *film_rgbw) {
+    const int fw = S.crop_x1 - S.crop_x0;
+    for (uint32_t pid = blockIdx.x * kBlock + threadIdx.x; pid < P.n_paths; pid += gridDim.x * kBlock) {
+        int px = 0, py = 0;
+        uint32_t k = 0;
+        if (!(path_pixel(S, P, pid, &px, &py, &k) && px >= S.crop_x0 && px < S.crop_x1 && py >= S.crop_y0 && py < S.crop_y1)) continue;
+        F3 Lnext = F3{0, 0, 0};
+        for (int d = 4; d >= 0; --d) {
+            const float4 e4 = B.dir_E[size_t(d) * B.dir_paths + pid];
+            F3 L = F3{0, 0, 0};
+            L = L + F3{e4.x, e4.y, e4.z};  // L += isect.Le(wo)
+            F3 all = F3{0, 0, 0};          // UniformSampleAllLights' own L(0.f)
+            for (int li = 0; li < S.n_lights; ++li) {
+                const float4 d4 = B.L[size_t(d * S.n_lights + li) * B.dir_paths + pid];
+                F3 Ld = F3{0, 0, 0};
+                Ld = Ld + F3{d4.x, d4.y, d4.z};
+                all = all + sdiv(Ld, 1.f);  // L += Ld / nSamples
+            }
+            if (S.n_lights > 0) L = L + all;
+            if (d + 1 < 5) {
+                const float4 f4 = B.dir_F[size_t(d) * B.dir_paths + pid];
+                F3 R = F3{0, 0, 0};
+                if (f4.w != 0.f) R = sdiv(F3{f4.x, f4.y, f4.z} * Lnext * f4.w, 1.f);  // f * Li(..) * AbsDot(wi, ns) / pdf
+                L = L + R;
+                L = L + F3{0, 0, 0};  // SpecularTransmit
+            }
+            Lnext = L;
+        }
+        F3 L = Lnext;
+        const float y = lum_y(L);
+        if (is_nan(L.x) || is_nan(L.y) || is_nan(L.z))
+            L = F3{0, 0, 0};
+        else if (double(y) < -1e-5)
+            L = F3{0, 0, 0};
+        else if (is_inf(y))
+            L = F3{0, 0, 0};
+        double *out = film_rgbw + 4 * (size_t(py - S.crop_y0) * fw + (px - S.crop_x0));
+        out[0] += double(L.x);
+        out[1] += double(L.y);
+        out[2] += double(L.z);
+        out[3] += 1.0;
+    }
+}
+
+void launch_direct_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_direct_generate, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B);
+}
+void launch_direct_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int depth, uint32_t max_rays, const LaunchCfg &cfg) {
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, 2));
+    if (S.textured_materials)
+        hipLaunchKernelGGL((k_direct_shade<true>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, depth, B.queue_cap);
+    else
+        hipLaunchKernelGGL((k_direct_shade<false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, depth, B.queue_cap);
+}
+void launch_direct_fold(const DScene &S, const PassDesc &P, const PassBuffers &B, double *film_rgbw, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_direct_fold, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
+}
+
+}  // namespace iile

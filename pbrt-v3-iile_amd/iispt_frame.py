@@ -1,4 +1,6 @@
-"""The indirect pass of the IISPT integrator, end to end on the GPU (BASELINE config 5).
+"""The IISPT integrator's frame, end to end on the GPU (BASELINE config 5): the indirect pass (below), the
+direct pass (IisptRenderRunner::run_direct -> iile_render_direct) and the final merge of the two film monitors
+(IisptFilmMonitor::merge_into, src/integrators/iisptfilmmonitor.cpp:231-275, as src/integrators/iispt.cpp:405-446 ends).
 
 IisptRenderRunner::run (src/integrators/iisptrenderrunner.cpp:216-596) per task of the schedule
 (IisptScheduleMonitor::next_task, src/integrators/iisptschedulemonitor.cpp:40-79: square tasks of NUMBER_TILES = 10
@@ -8,7 +10,7 @@ tiles of `radius` pixels, the radius shrinking by sqrt(0.795...) after every swe
     probe pass               --iile_render_probes------>  intensity / normals / distance images (HBM)
     normalizeMapsDownstream, IISPTNet, transformMapsUpstream (iispt_nn.py, PyTorch-ROCm, HBM)
     per-pixel gather         --iile_iispt_gather------->  {f_beta * L, weight} per pixel (HBM)
-    IisptFilmMonitor::add_n_samples (src/integrators/iisptfilmmonitor.cpp:47-72): sums of RGB and weight per pixel
+    IisptFilmMonitor::add_n_samples (src/integrators/iisptfilmmonitor.cpp:47-72): sums of RGB and weight per pixel, doubles
 
 Nothing but the hemi points' positions (a few KB per task) crosses PCIe. No trained weights ship with the reference:
 with the default random-initialised network the numbers mean nothing; a checkpoint of the reference's ml/ training
@@ -40,13 +42,20 @@ def schedule(bounds, n_tasks, radius_start=100.0, update_multiplier=math.sqrt(0.
             radius *= float(np.float32(update_multiplier))
 
 
+DIRECT_SAMPLES = 16  # PbrtOptions.iileDirectSamples, pbrt.h:178
+
+
 class IisptFrame:
-    """Accumulates the indirect film of IisptFilmMonitor over tasks; everything stays in HBM."""
+    """The two film monitors of IISPTIntegrator::Render (indirect: accumulated over tasks; direct: run_direct) and their
+    merge; everything stays in HBM."""
 
     def __init__(self, binding, gpu_scene, pipeline, rng_seed=0):
         self.b, self.gpu, self.pipe = binding, gpu_scene, pipeline
         h, w = gpu_scene.host.film_shape
-        self.film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")  # r, g, b sums and the weight sum
+        # IisptPixel (iisptpixel.h): r, g, b sums and the weight sum, doubles
+        self.film = torch.zeros((h, w, 4), dtype=torch.float64, device="cuda")         # film_monitor_indirect
+        self.film_direct = torch.zeros((h, w, 4), dtype=torch.float64, device="cuda")  # film_monitor_direct
+        self.direct_passes = 0
         self.counter = 0       # sampler_pixel_counter.x of the (single) runner
         self.rng_seed = rng_seed
         self.stats = {"tasks": 0, "hemi_points": 0, "probes": 0, "pixels": 0}
@@ -66,7 +75,7 @@ class IisptFrame:
         out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
         self.gpu.iispt_gather(task, valid, pos, dr, nn_device_ptr=nn.data_ptr(), out_device_ptr=out.data_ptr())
         torch.cuda.synchronize()
-        self.film[y0:y1, x0:x1] += out  # add_n_samples
+        self.film[y0:y1, x0:x1] += out.double()  # add_n_samples
         self.counter += nx * ny + w * h
         self.rng_seed += w * h
         self.stats["tasks"] += 1
@@ -125,7 +134,7 @@ class IisptFrame:
                 th, tw = task.y1 - task.y0, task.x1 - task.x0
                 out = torch.empty((th, tw, 4), dtype=torch.float32, device="cuda")
                 self.gpu.iispt_gather(task, valid, pos, dr, nn_device_ptr=nn[first:first + nx * ny].data_ptr(), out_device_ptr=out.data_ptr())
-                self.film[task.y0:task.y1, task.x0:task.x1] += out
+                self.film[task.y0:task.y1, task.x0:task.x1] += out.double()
                 first += nx * ny
                 tick("gather", t0)
                 self.stats["tasks"] += 1
@@ -135,7 +144,29 @@ class IisptFrame:
         torch.cuda.synchronize()
         return self.image()
 
+    def run_direct(self, n_passes=DIRECT_SAMPLES):
+        """IisptRenderRunner::run_direct: n_passes more passes of DirectProgressiveIntegrator::RenderOnePass into the direct
+        monitor (iile_render_direct; pass numbers continue where the last call stopped)."""
+        self.gpu.render_direct(n_passes, first_pass=self.direct_passes, film_device_ptr=self.film_direct.data_ptr(),
+                               accumulate=self.direct_passes > 0, stream=torch.cuda.current_stream().cuda_stream)
+        self.direct_passes += n_passes
+        return self.film_direct
+
+    @staticmethod
+    def _normalised(monitor):
+        """IisptPixel::normalize: sums over the weight where it is positive (a pixel never written stays 0)."""
+        wgt = monitor[..., 3:4]
+        return torch.where(wgt > 0, monitor[..., :3] / torch.where(wgt > 0, wgt, torch.ones_like(wgt)), monitor[..., :3])
+
+    def indirect_image(self):
+        """film_monitor_indirect->to_intensity_film(): /tmp/iispt_indirect.exr of the reference."""
+        return self._normalised(self.film).float()
+
+    def direct_image(self):
+        """film_monitor_direct->to_intensity_film(): /tmp/iispt_direct.exr of the reference."""
+        return self._normalised(self.film_direct).float()
+
     def image(self):
-        """IisptFilmMonitor::to_intensity_film: rgb sums over weight where a sample was recorded."""
-        wgt = self.film[..., 3:4]
-        return torch.where(wgt > 0, self.film[..., :3] / wgt.clamp_min(1e-30), torch.zeros_like(self.film[..., :3]))
+        """The integrator's output (iispt.cpp:436-446): film_monitor_direct->merge_into(film_monitor_indirect) — both
+        monitors normalised, added, weight 1 — through to_intensity_film: float RGB per pixel."""
+        return (self._normalised(self.film_direct) + self._normalised(self.film)).float()

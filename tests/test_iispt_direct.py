@@ -63,3 +63,53 @@ def test_merge_normalises_both_monitors(oracle):
     want = d[..., :3] / d[..., 3:4] + np.where(i[..., 3:4] > 0, i[..., :3] / np.where(i[..., 3:4] > 0, i[..., 3:4], 1.0), i[..., :3])
     assert np.array_equal(out, want.astype(np.float32))
     assert np.array_equal(out[0, 0], (d[0, 0, :3] / 16.0).astype(np.float32))
+
+
+# ---- the device pass against the oracle -------------------------------------------------------------------------------------
+
+
+@pytest.mark.gpu
+def test_device_direct_pass_bitwise_on_analytic_scenes(binding, oracle):
+    """iile_render_direct against oracle_iispt_direct, film monitor doubles bit for bit: a point light, an area light with
+    MIS, UberMaterial (diffuse + a specular lobe whose Fresnel term is 0), the emitting mirror ball (four recursions)."""
+    for name in ("furnace_point.pbrt", "furnace_area.pbrt", "furnace_uber.pbrt", "furnace_mirror_emitter.pbrt"):
+        scene = binding.HostScene(path=os.path.join(SCENES, name))
+        gpu = binding.GpuScene(scene)
+        dev = gpu.render_direct(3)
+        ref = oracle.iispt_direct(scene, 3)
+        assert np.array_equal(dev.view(np.uint64), ref.view(np.uint64)), name
+
+
+@pytest.mark.gpu
+def test_device_direct_pass_bitwise_on_killeroo_and_rooms(binding, oracle, tmp_path):
+    """killeroo-simple (sphere light, matte / plastic) and two rooms of tests/boxroom.py (triangle emitters with several
+    lights: UniformSampleAllLights samples every one of them; uber / mirror blobs: the recursion), passes added in order; a
+    second call continuing at pass 2 accumulates into the same monitor."""
+    import boxroom
+    scenes = [binding.HostScene(xres=160, yres=120, spp=1)]
+    for i, kw in enumerate((dict(light="quad"), dict(light="multi", materials="mixed"), dict(light="spot", materials="mixed"))):
+        path = tmp_path / f"room{i}.pbrt"
+        path.write_text(boxroom.boxroom_pbrt(ico_levels=2, n_blobs=5, wall_n=6, xres=96, yres=64, spp=1, **kw))
+        scenes.append(binding.HostScene(path=str(path)))
+    for scene in scenes:
+        gpu = binding.GpuScene(scene)
+        dev = gpu.render_direct(3)
+        ref = oracle.iispt_direct(scene, 3)
+        assert np.array_equal(dev.view(np.uint64), ref.view(np.uint64))
+        import torch
+        h, w = scene.film_shape
+        film = torch.zeros((h, w, 4), dtype=torch.float64, device="cuda")
+        gpu.render_direct(2, film_device_ptr=film.data_ptr())
+        gpu.render_direct(1, first_pass=2, film_device_ptr=film.data_ptr(), accumulate=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(film.cpu().numpy().view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_direct_pass_rejects_what_it_does_not_build(binding, tmp_path):
+    import boxroom
+    path = tmp_path / "env.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(ico_levels=2, n_blobs=3, wall_n=4, xres=32, yres=32, spp=1, light="envmap", materials="mixed", textures=str(tmp_path)))
+    gpu = binding.GpuScene(binding.HostScene(path=str(path)))
+    with pytest.raises(RuntimeError, match="not built|differentials"):
+        gpu.render_direct(1)

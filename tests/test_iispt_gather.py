@@ -126,7 +126,7 @@ def test_iispt_frame_end_to_end(binding):
         frame.run_task(*t)
     w1 = frame.film[..., 3].clone()
     assert set(torch.unique(w1).tolist()) <= {0.0, 0.5} and float((w1 == 0.5).float().mean()) > 0.9
-    img = frame.image()
+    img = frame.indirect_image()
     assert bool(torch.isfinite(img).all()) and float(img.min()) >= 0
     assert frame.stats["pixels"] == 96 * 80 and frame.stats["probes"] > 0
     n3 = [t for t in tasks if t[4] == 3]
@@ -142,3 +142,15 @@ def test_iispt_frame_end_to_end(binding):
     assert torch.equal(batched.film[..., 3], w2) and batched.stats == frame.stats
     scale = float(frame.film[..., :3].abs().max())
     assert float((batched.film[..., :3] - frame.film[..., :3]).abs().max()) <= 2e-3 * scale
+    # the direct pass and the merge (iispt.cpp:405-446): the direct monitor is the oracle's bit for bit, also when it is filled
+    # in two calls; the frame's image is merge_into + to_intensity_film of the two monitors as the oracle computes it
+    import oracle_binding
+    orc = oracle_binding.Oracle()
+    frame.run_direct(2)
+    frame.run_direct(1)
+    torch.cuda.synchronize()
+    ref_direct = orc.iispt_direct(scene, 3)
+    assert np.array_equal(frame.film_direct.cpu().numpy().view(np.uint64), ref_direct.view(np.uint64))
+    merged = orc.iispt_merge(ref_direct, frame.film.cpu().numpy())
+    assert np.array_equal(frame.image().cpu().numpy().view(np.uint32), merged.view(np.uint32))
+    assert float(frame.image().mean()) > float(frame.indirect_image().mean())

@@ -1,5 +1,6 @@
-"""BASELINE config 5 exercised end to end on one GPU: the IISPT integrator's indirect pass over killeroo-simple —
-hemi points, probe pass, in-process network, per-pixel gather (pbrt-v3-iile_amd/iispt_frame.py) — timed per stage.
+"""BASELINE config 5 exercised end to end on one GPU: the IISPT integrator's frame over killeroo-simple — the indirect pass
+(hemi points, probe pass, in-process network, per-pixel gather), the direct pass (16 passes of DirectProgressiveIntegrator) and
+the merge of the two film monitors (pbrt-v3-iile_amd/iispt_frame.py) — timed per stage.
 The network has random weights (none ship with the reference), so the image is meaningless; the data flow and the cost are real.
 usage: python tools/probe_bench.py [xres=1920] [yres=1080] [radius_start=10] [sweeps=1] [dtype=bf16|f32]
 IILE_IISPT_BATCHED=0: task by task as the reference's runner; IILE_IISPT_TIMERS=1: seconds per stage (adds syncs)"""
@@ -49,11 +50,27 @@ else:
     img = frame.run(tasks_per_sweep * sweeps, radius_start=radius)
 torch.cuda.synchronize()
 wall = time.time() - t0
+frame.run_direct(1)  # (first call: allocation)
+frame_d = frame_mod.IisptFrame(b, gpu, pipe)
+torch.cuda.synchronize()
+t0 = time.time()
+frame_d.run_direct(frame_mod.DIRECT_SAMPLES)
+torch.cuda.synchronize()
+wall_direct = time.time() - t0
+frame.film_direct.copy_(frame_d.film_direct)
+t0 = time.time()
+final = frame.image()
+torch.cuda.synchronize()
+wall_merge = time.time() - t0
 st = frame.stats
 rec = float((frame.film[..., 3] > 0).float().mean())
-print(json.dumps({"workload": f"IISPT indirect pass, killeroo-simple {xres}x{yres}, radius {radius} -> tasks of {size}^2 px, {sweeps} sweep(s)",
+print(json.dumps({"workload": f"IISPT frame (indirect pass + 16 direct passes + merge), killeroo-simple {xres}x{yres}, radius {radius} -> tasks of {size}^2 px, {sweeps} sweep(s)",
                   "tasks": st["tasks"], "hemi_points": st["hemi_points"], "probes": st["probes"], "pixels": st["pixels"],
                   "wall_s": round(wall, 3), "probes_per_s": round(st["probes"] / wall, 1), "mpixels_gathered_per_s": round(st["pixels"] / wall / 1e6, 3),
                   "order": "task-major stages (run_batched)" if batched else "task by task (run)", "stage_seconds": timers,
                   "network_dtype": str(dtype).split(".")[-1], "pixels_with_a_sample": round(rec, 4),
-                  "image_mean": float(img.mean()), "finite": bool(torch.isfinite(img).all())}))
+                  "indirect_image_mean": float(frame.indirect_image().mean()), "finite": bool(torch.isfinite(final).all()),
+                  "direct_passes": frame_mod.DIRECT_SAMPLES, "direct_wall_s": round(wall_direct, 4),
+                  "direct_msamples_per_s": round(frame_mod.DIRECT_SAMPLES * xres * yres / wall_direct / 1e6, 1), "merge_wall_s": round(wall_merge, 4),
+                  "frame_wall_s": round(wall + wall_direct + wall_merge, 3), "direct_image_mean": float(frame.direct_image().mean()),
+                  "image_mean": float(final.mean())}))
