@@ -76,13 +76,40 @@ def measured_copy_gbs(torch):
 PORT_VS_REFERENCE = 3.9 / 5.8
 
 
+def effective_cpus():
+    """Host threads this process can really keep busy: os.cpu_count() capped by the affinity mask and by the cgroup's CPU
+    quota (cpu.max = "quota period": the GPU boxes of this pool show 256 hardware threads and grant 16 CPUs' worth of time —
+    profiles/r03_cpu_scaling.json: the oracle scales 7.9x on 8 threads, 13.6x on 16 and is throttled beyond)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
 def cpu_baseline(scene_path, xres, yres, target_seconds, workload_name="killeroo-simple"):
-    """Time the CPU oracle (restatement of the reference path, all host cores, 16x16
-    tile self-scheduling, render loop only) on a bounded number of pixel samples."""
+    """Time the CPU oracle (restatement of the reference path, 16x16 tile self-scheduling, render loop only) on a bounded
+    number of pixel samples, on as many threads as the box really grants (effective_cpus)."""
     import __graft_entry__ as ge
     import oracle_binding as ob
     b = ge._load_binding()
-    threads = os.cpu_count() or 1
+    threads, quota = effective_cpus()
     scene = b.HostScene(path=scene_path, xres=xres, yres=yres, spp=64)
     orc = ob.Oracle()
     _, st = orc.render(scene, trig_mode=ob.TRIG_LIBM, threads=threads, k_begin=0, k_end=1)
@@ -98,11 +125,14 @@ def cpu_baseline(scene_path, xres, yres, target_seconds, workload_name="killeroo
         "sample": f"{workload_name} {xres}x{yres}, pixel samples k=1..{n} of 64 ({st['camera_rays']} camera samples, "
                   f"{rays} rays, {st['seconds']:.2f} s, libm trig)",
         "msamples_per_s": round(st["camera_rays"] / st["seconds"] / 1e6, 4),
+        "host": {"hardware_threads": os.cpu_count(), "cgroup_cpu_quota": quota},
         "note": f"a port, not the reference binary (which cannot be built in this image): on the one machine where "
                 f"both were timed (BASELINE.md §2, 8 threads) the port ran {PORT_VS_REFERENCE:.2f}x the reference's rate, "
-                f"so the reference on these cores would be about {1 / PORT_VS_REFERENCE:.2f}x this value; the port also "
-                f"scales sub-linearly past ~64 threads (tile self-scheduling over {((xres + 15) // 16) * ((yres + 15) // 16)} tiles, "
-                f"shared L3)",
+                f"so the reference on these cores would be about {1 / PORT_VS_REFERENCE:.2f}x this value. Threads = what the "
+                f"box grants: the pool's hosts show {os.cpu_count()} hardware threads but a cgroup quota of "
+                f"{quota if quota else 'none'} CPUs; the measured thread curve (profiles/r03_cpu_scaling.json, tools/cpu_scaling.py) is "
+                f"linear up to that (7.9x on 8 threads, 13.6x on 16) and throttled beyond — rounds 1 and 2 ran 256 threads "
+                f"against that quota and quoted the throttled figure as '256 cores'",
         "value_scaled_to_reference": round(rays / st["seconds"] / 1e6 / PORT_VS_REFERENCE, 3),
     }
 

@@ -182,6 +182,23 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     float4 *no = B.ray_o[(bounce + 1) & 1], *nd = B.ray_d[(bounce + 1) & 1];
     unsigned long long n_nee = 0, n_term = 0, n_pdf_tests = 0, n_pdf_hits = 0;
+#ifdef IILE_SHADE_STAMPS
+    // diagnostic build only: wave cycles (s_memtime) per section of a round, summed per wavefront, added to
+    // DCounters::path_length[0..7] at the end: 0 regroup, 1 loads + Halton, 2 interaction + BSDF, 3 light half, 4 BSDF half,
+    // 5 record stores, 6 continuation, 7 next-ray store
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#define SHADE_STAMP(i)                                                  \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        stamp_sum[i] += now_ - stamp_t;                                 \
+        stamp_t = now_;                                                 \
+    } while (0)
+#else
+#define SHADE_STAMP(i) \
+    do {               \
+    } while (0)
+#endif
     WaveOut ray_out{0, 0}, nee_out{0, 0}, mis_out{0, 0};
     auto pad_ray = [&](uint32_t sl) { no[sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
     auto pad_nee = [&](uint32_t sl) { B.nee[plane + sl] = B.nee[4 * plane + sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
@@ -225,6 +242,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        SHADE_STAMP(0);
       for (int round = 0; round < kShadeChunk / 64; ++round) {
         const uint32_t mine = s_entry[wave][round * 64 + lane];
         const bool valid = mine != kInvalid;
@@ -303,6 +321,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                     const int dim_u = __builtin_amdgcn_readfirstlane(dim);
                     sample_dimensions_n<4>(S, s_perms, dim_u + 1, __ballot(dim != dim_u) == 0, dim + 1, hidx, u_nee);
                 }
+                SHADE_STAMP(1);
                 const int prim = int(f2b(h4.x));
                 const F3 ray_o = F3{o4.x, o4.y, o4.z};
                 ray_d = F3{d4.x, d4.y, d4.z};
@@ -372,6 +391,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                     } else {
                         bsdf = make_bsdf<EXT, ONLY != 1>(S.materials[material], is);
                     }
+                    SHADE_STAMP(2);
                     if (n_nonspec(bsdf) > 0) {  // NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0, path.cpp:118
                         ++n_nee;
                         // UniformSampleOneLight (integrator.cpp:85-106). One light: it is chosen with pdf 1
@@ -492,6 +512,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                                         nee_flags |= NEE_HAS_SHADOW;
                                     }
                                 }
+                                SHADE_STAMP(3);
                                 // BSDF-sampling half (integrator.cpp:165-213)
                                 F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
                                 f2 = f2 * absdot(wi, is.sn);
@@ -548,6 +569,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
 #endif
             }
 #endif
+            SHADE_STAMP(4);
             const uint32_t eslot = out_take(nee_out, &B.counts[kCntNee + bounce], emit_nee, pad_nee);
             // the MIS rays go to a dense queue of their own (planes 2 and 3): most records have none
             const bool emit_mis = emit_nee && (nee_flags & NEE_HAS_MIS) != 0;
@@ -566,6 +588,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                 B.nee[3 * plane + mslot] = make_float4(md.x, md.y, md.z, b2f(nee_light));
             }
         }
+        SHADE_STAMP(5);
         F3 next_o = F3{0, 0, 0}, next_d = F3{0, 0, 1};
         if (P.skip_last_bounce == 2 && bounce + 1 >= S.max_depth) surface = false;  // the next vertex could add nothing: see PassDesc
         if (surface) {
@@ -620,17 +643,23 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
         // ReportValue(pathLength, bounces): a path that ends in this iteration leaves the
         // loop with bounces == bounce (not counted on the early `return L`)
         if (COUNT && valid && !alive && !returned_early) ++n_term;
+        SHADE_STAMP(6);
         const uint32_t nslot = out_take(ray_out, &B.counts[kCntRay + bounce + 1], alive, pad_ray);
         if (alive) {
             no[nslot] = make_float4(next_o.x, next_o.y, next_o.z, b2f(pid));
             nd[nslot] = make_float4(next_d.x, next_d.y, next_d.z, IILE_INF);
         }
+        SHADE_STAMP(7);
       }
         __builtin_amdgcn_wave_barrier();  // the next chunk overwrites s_entry
     }
     out_flush(ray_out, pad_ray);
     out_flush(nee_out, pad_nee);
     out_flush(mis_out, pad_mis);
+#ifdef IILE_SHADE_STAMPS
+    if (!COUNT && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&B.counters->path_length[i], stamp_sum[i]);
+#endif
     if (COUNT) {
         flush_counter(&B.counters->nee_evals, n_nee);
         flush_counter(&B.counters->path_length[bounce < 7 ? bounce : 7], n_term);
