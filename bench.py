@@ -379,6 +379,21 @@ def main():
                  "algorithmic_gbs": round(by * steps / ms_k / 1e6, 1), "algorithmic_bytes_note": note}
             tr = pmc_traffic.get(k)
             if tr:
+                # The counters sit at the L2's memory side: they count what the Infinity Cache serves as well as what HBM
+                # serves (MI355X_MICROARCH.md, HBM section). A kernel must stream its queue records from HBM once; whatever it
+                # reads beyond that is scene data (7.6 MB of four-wide records + 3.2 MB of triangles for killeroo-simple,
+                # against 4 MiB of L2 per XCD) re-fetched through L2 misses — far below the 256 MiB Infinity Cache, so served
+                # on-die: an upper estimate of the share that never reaches HBM.
+                q_in = {"k_extend": cst["ext_rays"] * 32, "k_shadow": cst["shadow_rays"] * (64 + 1 + 16), "k_mis": mis_rays * 32}.get(k)
+                q_out = {"k_extend": cst["ext_rays"] * (16 + 4), "k_shadow": cst["shadow_rays"] * 16, "k_mis": mis_rays * 1}.get(k)
+                if q_in:
+                    e["hbm_counter_vs_queue_records"] = {
+                        "queue_bytes_in_per_step": int(q_in), "queue_bytes_out_per_step": int(q_out),
+                        "counter_over_queue": round(tr["hbm_bytes_per_step"] / (q_in + q_out), 3),
+                        "infinity_cache_served_estimate_bytes": int(max(0, tr["hbm_read_bytes_per_step"] - q_in)),
+                        "note": "queue records the kernel has to stream (rays / NEE records in — k_shadow: + the 16 B read of L —, hits / "
+                                "results out); reads beyond its input records are scene data missing the 4 MiB L2 and found in the 256 MiB "
+                                "Infinity Cache (FETCH_SIZE counts those too): an upper estimate of what is not HBM traffic"}
                 e["hbm_counter_bytes_per_step"] = tr["hbm_bytes_per_step"]
                 e["hbm_counter_gbs"] = round(tr["hbm_bytes_per_step"] / (ms_k / steps) / 1e6, 1)
                 e["hbm_counter_frac_of_peak"] = round(e["hbm_counter_gbs"] / HBM_PEAK_GBS, 4)
