@@ -513,6 +513,7 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
         return IILE_OK;
     }
     if (n_prims > (1 << 30)) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: more than 2^30 primitives");
+    if (max_prims_in_node < 1) return api_fail(IILE_ERR_ARG, "iile_bvh_build_hlbvh: max_prims_in_node must be at least 1");
     const int n = n_prims;
     const int max_prims = std::min(255, max_prims_in_node);  // BVHAccel's constructor, bvh.cpp:187
     hipEvent_t ev[7] = {};
@@ -691,6 +692,19 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
 extern "C" int iile_bvh_pack_probe(int32_t n_nodes, const iile_bvh_node *nodes, int32_t n_interior, float *wide16, float *wide4_32,
                                    int32_t *nested) {
     if (n_nodes <= 0 || !nodes || !wide16 || !wide4_32 || !nested) return api_fail(IILE_ERR_ARG, "iile_bvh_pack_probe: bad argument");
+    // the checks iile_scene_create makes before it packs a tree it was handed: the kernel indexes by these fields, and the
+    // caller's buffers are sized by n_interior
+    int counted = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        const iile_bvh_node &nd = nodes[i];
+        if (nd.nprims > 0) {
+            if (nd.offset < 0) return api_fail(IILE_ERR_ARG, "iile_bvh_pack_probe: bad leaf range");
+            continue;
+        }
+        if (i + 1 >= n_nodes || nd.offset <= i || nd.offset >= n_nodes) return api_fail(IILE_ERR_ARG, "iile_bvh_pack_probe: bad BVH child index");
+        ++counted;
+    }
+    if (counted != n_interior) return api_fail(IILE_ERR_ARG, "iile_bvh_pack_probe: n_interior does not match the tree");
     int dev_count = 0;
     if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0)
         return api_fail(IILE_ERR_NO_DEVICE, "no HIP device available: libiile_gpu has no CPU fallback (iile_bvh_pack_probe)");

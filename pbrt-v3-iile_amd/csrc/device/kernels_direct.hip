@@ -251,9 +251,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
                 const uint32_t dslot = uint32_t(c) * B.dir_paths + pid;
                 B.nee[eslot] = make_float4(so.x, so.y, so.z, 1.f);
                 B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
-                B.nee[4 * plane + eslot] = make_float4(A.x, A.y, A.z, b2f(nee_flags));
-                if (nee_flags & NEE_HAS_MIS) B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, b2f(uint32_t(li)));
-                B.nee[6 * plane + eslot] = make_float4(1.f, 1.f, 1.f, b2f(dslot));
+                if (nee_flags & NEE_HAS_MIS) {
+                    B.nee[4 * plane + eslot] = make_float4(A.x, A.y, A.z, b2f(dslot));
+                    B.nee[5 * plane + eslot] = make_float4(Bc.x, Bc.y, Bc.z, b2f(uint32_t(li)));
+                    B.nee[6 * plane + eslot] = make_float4(1.f, 1.f, 1.f, b2f(dslot));
+                } else {  // (the record format of k_shade: without a MIS ray, beta * ((0 + A) / lightPdf) ready made — here 1 * A)
+                    const F3 pre = F3{1.f, 1.f, 1.f} * (F3{0, 0, 0} + A);
+                    B.nee[4 * plane + eslot] = make_float4(pre.x, pre.y, pre.z, b2f(dslot));
+                }
             }
             if (emit_mis) {
                 B.nee[2 * plane + mslot] = make_float4(mo.x, mo.y, mo.z, b2f(eslot));

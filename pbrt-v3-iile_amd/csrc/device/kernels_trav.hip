@@ -187,35 +187,35 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                     warm_plane(B.nee, first, count);
                     warm_plane(B.nee + plane, first, count);
                     warm_plane(B.nee + 4 * size_t(plane), first, count);
-                    warm_plane(B.nee + 6 * size_t(plane), first, count);
                 })) {
                 e = e_new;
                 const float4 n1 = B.nee[plane + e];
                 const uint32_t flags = f2b(n1.w);
                 if (flags != kInvalid) {
                     // Ld = [light sample unoccluded] A + [MIS ray reached the sampled light, facing it] B,
-                    // L += beta * Ld (integrator.cpp:150-158, 205-211; path.cpp:123-128)
-                    const float4 n0 = B.nee[e], a4 = B.nee[4 * size_t(plane) + e], be = B.nee[6 * size_t(plane) + e];
-                    const bool lit = (flags & NEE_HAS_MIS) && B.nee_mis[e] != 0;
-                    pid = f2b(be.w);
+                    // L += beta * Ld / lightPdf (integrator.cpp:150-158, 205-211; path.cpp:123-128). A record without a MIS
+                    // ray carries beta * (A / lightPdf) ready made (k_shade) and no throughput plane.
+                    const float4 n0 = B.nee[e], a4 = B.nee[4 * size_t(plane) + e];
+                    pid = f2b(a4.w);
                     const float4 L4 = B.L[pid];
                     const bool has_shadow = (flags & NEE_HAS_SHADOW) != 0;
-                    F3 Ld_u = F3{0, 0, 0}, Ld_o = F3{0, 0, 0};
-                    if (has_shadow) Ld_u = Ld_u + F3{a4.x, a4.y, a4.z};
-                    if (lit) {
-                        const float4 b4 = B.nee[5 * size_t(plane) + e];
-                        Ld_u = Ld_u + F3{b4.x, b4.y, b4.z};
-                        Ld_o = Ld_o + F3{b4.x, b4.y, b4.z};
-                    }
-                    // UniformSampleOneLight returns EstimateDirect / lightPdf (n0.w; 1 with a single light)
-                    const F3 beta = F3{be.x, be.y, be.z};
-                    // x / 1 is x: with a single light (lightPdf 1 in every record) the six divisions are skipped
-                    if (__ballot(n0.w != 1.f) == 0) {
-                        add_unoccluded = beta * Ld_u;
-                        add_occluded = beta * Ld_o;
-                    } else {
+                    if (flags & NEE_HAS_MIS) {
+                        const float4 be = B.nee[6 * size_t(plane) + e];
+                        const bool lit = B.nee_mis[e] != 0;
+                        F3 Ld_u = F3{0, 0, 0}, Ld_o = F3{0, 0, 0};
+                        if (has_shadow) Ld_u = Ld_u + F3{a4.x, a4.y, a4.z};
+                        if (lit) {
+                            const float4 b4 = B.nee[5 * size_t(plane) + e];
+                            Ld_u = Ld_u + F3{b4.x, b4.y, b4.z};
+                            Ld_o = Ld_o + F3{b4.x, b4.y, b4.z};
+                        }
+                        // UniformSampleOneLight returns EstimateDirect / lightPdf (n0.w; 1 with a single light: x / 1 is x)
+                        const F3 beta = F3{be.x, be.y, be.z};
                         add_unoccluded = beta * sdiv(Ld_u, n0.w);
                         add_occluded = beta * sdiv(Ld_o, n0.w);
+                    } else {
+                        add_unoccluded = F3{a4.x, a4.y, a4.z};
+                        add_occluded = F3{0, 0, 0};  // beta * (0 / lightPdf)
                     }
                     L_old = F3{L4.x, L4.y, L4.z};
                     if (has_shadow) {
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
                     ++n_traced;
                     if (COUNT) {
                         ++n_closest;
-                        if (B.nray_out) B.nray_out[2 * f2b(B.nee[6 * size_t(plane) + e].w)] += 1;
+                        if (B.nray_out) B.nray_out[2 * f2b(B.nee[4 * size_t(plane) + e].w)] += 1;
                     }
                 }
             }

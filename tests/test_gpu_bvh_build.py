@@ -141,6 +141,8 @@ def test_degenerate_inputs(binding):
     assert st["n_treelets"] >= 2 and sorted(order.tolist()) == list(range(1000))
     nodes, order, _ = binding.bvh_build_hlbvh(np.zeros((0, 6), np.float32), 4)
     assert len(nodes) == 0
+    with pytest.raises(RuntimeError, match="max_prims_in_node"):
+        binding.bvh_build_hlbvh(one, 0)
 
 
 def _pack_reference(nodes):
@@ -190,6 +192,11 @@ def test_wide_records_packed_on_the_device(binding, split):
     k = int(np.nonzero(bad["nprims"] == 0)[0][3])
     bad["bmax"][k + 1][0] = bad["bmax"][k][0] + 1
     assert not binding.bvh_pack_probe(bad)[2]
+    # a tree whose links leave the array, or whose interior count is not the buffers' size, is refused (not packed blindly)
+    broken = nodes.copy()
+    broken["offset"][k] = len(nodes) + 5
+    with pytest.raises(RuntimeError, match="child index"):
+        binding.bvh_pack_probe(broken)
 
 
 def test_cpp_host_with_the_device_builder(binding, tmp_path):
