@@ -131,7 +131,7 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     const size_t cap = queue_capacity(n_paths, sc->n_cus);
     // per path: L, beta (float4), hindex; per queue slot: ray_o[2], ray_d[2], hits, 2 x {nee[7], mis_hit} (float4), shade_q
     const size_t f4 = sizeof(float4);
-    size_t bytes = 2 * n * f4 + 2 * n * sizeof(uint32_t) + 21 * cap * f4 + cap * sizeof(uint32_t) + 2 * cap +
+    size_t bytes = 2 * n * f4 + 2 * n * sizeof(uint32_t) + 23 * cap * f4 + cap * sizeof(uint32_t) + 2 * cap +
                    kCntWords * sizeof(uint32_t) + sizeof(DCounters) + 16384;
     void *blk = nullptr;
     HIP_TRY(hipMalloc(&blk, bytes));
@@ -151,6 +151,8 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     B.ray_o[1] = reinterpret_cast<float4 *>(take(cap * f4));
     B.ray_d[0] = reinterpret_cast<float4 *>(take(cap * f4));
     B.ray_d[1] = reinterpret_cast<float4 *>(take(cap * f4));
+    B.ray_s[0] = reinterpret_cast<float4 *>(take(cap * f4));
+    B.ray_s[1] = reinterpret_cast<float4 *>(take(cap * f4));
     B.hits = reinterpret_cast<float4 *>(take(cap * f4));
     B.nee = reinterpret_cast<float4 *>(take(7 * cap * f4));
     B.mis_hit = reinterpret_cast<float4 *>(take(cap * f4));

@@ -53,6 +53,10 @@ struct PassBuffers {
     float *eta_scale;   // [n_paths] etaScale of path.cpp:81 (touched only when the scene has glass)
     float4 *ray_o[2];   // ping-pong ray queues
     float4 *ray_d[2];
+    // the path's state travels with its ray from bounce 1 on (dense, in queue order) instead of being fetched by path id
+    // (scattered: 64-byte sectors for 16 + 4 bytes): ray_s = (throughput xyz, Halton index), and the ray's direction record
+    // carries sampler dimension | specularBounce << 16 in .w where tMax (always infinite there) stood
+    float4 *ray_s[2];
     float4 *hits;       // [n_paths]
     float4 *mis_hit;    // [queue_cap] k_mis -> k_mis_lit: where a MIS ray met an emitter (indexed by NEE record)
     // second set of the NEE arrays (odd bounces): k_shade of bounce b + 1 writes its records while k_shadow of bounce b

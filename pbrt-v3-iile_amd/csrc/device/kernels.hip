@@ -79,9 +79,11 @@ __global__ __launch_bounds__(kBlock) void k_miss(DScene S, PassBuffers B, int bo
         if (int(f2b(h4.x)) >= 0) continue;
         const uint32_t pid = f2b(ro[slot].w);
         if (pid == kInvalid) continue;
-        const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, b2f(5u)) : B.beta[pid];
-        if (!((bounce == 0 && !S.probe_mode) || (bounce != 0 && (f2b(beta4.w) >> 16) != 0))) continue;  // iispt_d.cpp:124-131
         const float4 d4 = rd[slot];
+        // (path state rides with the ray from bounce 1 on: throughput in ray_s, specularBounce in the direction record's .w)
+        const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, b2f(5u)) : B.ray_s[bounce & 1][slot];
+        const uint32_t state_w = bounce == 0 ? 5u : f2b(d4.w);
+        if (!((bounce == 0 && !S.probe_mode) || (bounce != 0 && (state_w >> 16) != 0))) continue;  // iispt_d.cpp:124-131
         const F3 beta = F3{beta4.x, beta4.y, beta4.z}, d = F3{d4.x, d4.y, d4.z};
         const float4 L4 = B.L[pid];
         F3 L = F3{L4.x, L4.y, L4.z};

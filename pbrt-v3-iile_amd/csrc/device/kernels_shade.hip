@@ -181,6 +181,8 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
     const uint32_t count = B.counts[kCntShade + bounce];
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     float4 *no = B.ray_o[(bounce + 1) & 1], *nd = B.ray_d[(bounce + 1) & 1];
+    const float4 *rs = B.ray_s[bounce & 1];
+    float4 *ns = B.ray_s[(bounce + 1) & 1];
     unsigned long long n_nee = 0, n_term = 0, n_pdf_tests = 0, n_pdf_hits = 0;
 #ifdef IILE_SHADE_STAMPS
     // diagnostic build only: wave cycles (s_memtime) per section of a round, summed per wavefront, added to
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
         Isect is;
         Bsdf bsdf;
         F3 beta = F3{0, 0, 0}, ray_d = F3{0, 0, 1};
+        uint32_t state_next = 0;
         {
             bool emit_nee = false;
             F3 so = F3{0, 0, 0}, sd = F3{0, 0, 1}, mo = F3{0, 0, 0}, md = F3{0, 0, 1};
@@ -308,11 +311,14 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                 pid = f2b(o4.w);
                 // a path arrives at its first vertex with beta = 1 at sampler dimension 5 (after
                 // the camera sample): k_generate does not spend 16 B per path on saying so
-                const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, b2f(5u)) : B.beta[pid];
+                // from bounce 1 on the path's state arrived with its ray (PassBuffers::ray_s; dimension | specularBounce << 16 in
+                // the direction record's .w)
+                const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, 0) : rs[slot];
+                const uint32_t state_w = bounce == 0 ? 5u : f2b(d4.w);
                 beta = F3{beta4.x, beta4.y, beta4.z};
-                dim = int(f2b(beta4.w) & 0xffffu);
-                const bool prev_specular = EXT && (f2b(beta4.w) >> 16) != 0;  // specularBounce of path.cpp:150
-                hidx = B.hindex[pid];
+                dim = int(state_w & 0xffffu);
+                const bool prev_specular = EXT && (state_w >> 16) != 0;  // specularBounce of path.cpp:150
+                hidx = bounce == 0 ? B.hindex[pid] : f2b(beta4.w);
                 // The four samples of EstimateDirect (dims dim+1 .. dim+4; dim itself is the
                 // 1D sample SampleDiscrete consumes), drawn here while few registers are live.
                 // Every path of a bounce normally sits at the same dimension.
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
             if (EXT && P.skip_last_bounce == 1 && bounce + 1 >= S.max_depth && !sampled_specular) alive = false;
             if (EXT && alive && S.has_glass) B.eta_scale[pid] = eta_scale;
             // sampler dimension | specularBounce << 16
-            if (alive) B.beta[pid] = make_float4(beta.x, beta.y, beta.z, b2f(uint32_t(dim) | (sampled_specular ? 0x10000u : 0u)));
+            state_next = uint32_t(dim) | (sampled_specular ? 0x10000u : 0u);  // sampler dimension | specularBounce << 16
         }
         // ReportValue(pathLength, bounces): a path that ends in this iteration leaves the
         // loop with bounces == bounce (not counted on the early `return L`)
@@ -655,7 +661,8 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
         const uint32_t nslot = out_take(ray_out, &B.counts[kCntRay + bounce + 1], alive, pad_ray);
         if (alive) {
             no[nslot] = make_float4(next_o.x, next_o.y, next_o.z, b2f(pid));
-            nd[nslot] = make_float4(next_d.x, next_d.y, next_d.z, IILE_INF);
+            nd[nslot] = make_float4(next_d.x, next_d.y, next_d.z, b2f(state_next));
+            ns[nslot] = make_float4(beta.x, beta.y, beta.z, b2f(hidx));
         }
         SHADE_STAMP(7);
       }

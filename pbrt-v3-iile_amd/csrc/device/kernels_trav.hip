@@ -78,7 +78,8 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                 } else {
                     const float4 o4 = ro[slot], d4 = rd[slot];
                     if (f2b(o4.w) != kInvalid) {
-                        trav_begin<COUNT>(S, t, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, d4.w, &st, sr.root);
+                        // (from bounce 1 on the direction record's .w carries path state: those rays have no far end)
+                        trav_begin<COUNT>(S, t, F3{o4.x, o4.y, o4.z}, F3{d4.x, d4.y, d4.z}, bounce > 0 ? IILE_INF : d4.w, &st, sr.root);
                         active = true;
                         ++n_rays;
                         if (COUNT && B.nray_out) B.nray_out[2 * f2b(o4.w)] += 1;
