@@ -359,11 +359,11 @@ def main():
         fam = {
             "k_extend": (agg["ms_extend"], agg["n_extend_launches"], algorithmic_bytes(cst["ext_rays"], cst["ext_nodes"], cst["ext_tri_tests"]),
                          cst["ext_rays"], "32 B/node + 48 B/triangle test + 48 B/ray (SURVEY.md 8d)"),
-            "k_shade": (agg["ms_shade"], agg["n_shade_launches"], 72 * nee + 112 * nee + 48 * next_rays, nee,
-                        "per hit 72 B in (queue entry, hit, ray, throughput, Halton index), 112 B NEE record out, 48 B next ray + "
-                        "throughput out per continued path (queue and path-state records only)"),
+            "k_shade": (agg["ms_shade"], agg["n_shade_launches"], 68 * nee + 48 * nee + 48 * next_rays, nee,
+                        "per hit 68 B in (queue entry 4, hit 16, ray 32, throughput + Halton index 16), 48 B NEE record out, 48 B next ray with "
+                        "its path state out per continued path (queue records only; round 2 moved 72 + 112 + 48)"),
             "k_shadow": (agg["ms_shadow"], agg["n_connect_launches"], algorithmic_bytes(cst["shadow_rays"], cst["nodes_any"], cst["any_tri_tests"]),
-                         cst["shadow_rays"], "as k_extend (+ 65 B record in, 32 B L read-modify-write, not counted in SURVEY's figure)"),
+                         cst["shadow_rays"], "as k_extend (+ 48 B record in, 32 B L read-modify-write, not counted in SURVEY's figure)"),
             "k_mis": (agg["ms_mis"], agg["n_connect_launches"],
                       algorithmic_bytes(mis_rays, cst["nodes_closest"] - cst["ext_nodes"], cst["tri_tests"] - cst["ext_tri_tests"] - cst["any_tri_tests"]),
                       mis_rays, "as k_extend"),
@@ -384,7 +384,7 @@ def main():
                 # reads beyond that is scene data (7.6 MB of four-wide records + 3.2 MB of triangles for killeroo-simple,
                 # against 4 MiB of L2 per XCD) re-fetched through L2 misses — far below the 256 MiB Infinity Cache, so served
                 # on-die: an upper estimate of the share that never reaches HBM.
-                q_in = {"k_extend": cst["ext_rays"] * 32, "k_shadow": cst["shadow_rays"] * (64 + 1 + 16), "k_mis": mis_rays * 32}.get(k)
+                q_in = {"k_extend": cst["ext_rays"] * 32, "k_shadow": cst["shadow_rays"] * (48 + 16), "k_mis": mis_rays * 32}.get(k)
                 q_out = {"k_extend": cst["ext_rays"] * (16 + 4), "k_shadow": cst["shadow_rays"] * 16, "k_mis": mis_rays * 1}.get(k)
                 if q_in:
                     e["hbm_counter_vs_queue_records"] = {

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
         const bool fin = active && !t.have;
         const bool is_hit = fin && t.hit_prim >= 0;
         if (fin) {
-            B.hits[slot] = make_float4(b2f(uint32_t(hit_index(t.hit_prim))), t.b0, t.b1, t.b2);
+            // (a miss's record is read by k_miss alone, which runs only for scenes with an infinite light)
+            if (is_hit || S.has_infinite) B.hits[slot] = make_float4(b2f(uint32_t(hit_index(t.hit_prim))), t.b0, t.b1, t.b2);
             active = false;
             if (COUNT && t.hit_prim < 0) ++n_term;  // the path left the scene: ReportValue(pathLength, bounces)
         }
