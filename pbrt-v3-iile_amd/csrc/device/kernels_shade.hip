@@ -289,15 +289,16 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
             float light_sel_pdf = 1.f;  // lightPdf of UniformSampleOneLight: Ld is divided by it
             if (valid) {
                 float4 o4, d4;
+                uint32_t fused_hidx = 0;
                 const float4 h4 = B.hits[slot];
                 if (bounce == 0 && P.gen_fused) {
                     // the camera ray again, as the first k_extend made it (queue 0 is dense: slot == path id)
-                    const float2 cpf = reinterpret_cast<const float2 *>(&B.beta[slot])[0];  // pFilm, left by k_extend
+                    const float4 cpf = B.beta[slot];  // pFilm and the Halton index, left by k_extend
+                    fused_hidx = f2b(cpf.z);
                     float cl0 = 0, cl1 = 0;
                     if (S.lens_radius > 0) {
-                        const uint32_t cidx = B.hindex[slot];
-                        cl0 = sample_dimension(S, s_perms, cidx, 3);
-                        cl1 = sample_dimension(S, s_perms, cidx, 4);
+                        cl0 = sample_dimension(S, s_perms, fused_hidx, 3);
+                        cl1 = sample_dimension(S, s_perms, fused_hidx, 4);
                     }
                     F3 co, cd;
                     float ctm;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                 beta = F3{beta4.x, beta4.y, beta4.z};
                 dim = int(state_w & 0xffffu);
                 const bool prev_specular = EXT && (state_w >> 16) != 0;  // specularBounce of path.cpp:150
-                hidx = bounce == 0 ? B.hindex[pid] : f2b(beta4.w);
+                hidx = bounce == 0 ? ((P.gen_fused) ? fused_hidx : B.hindex[pid]) : f2b(beta4.w);
                 // The four samples of EstimateDirect (dims dim+1 .. dim+4; dim itself is the
                 // 1D sample SampleDiscrete consumes), drawn here while few registers are live.
                 // Every path of a bounce normally sits at the same dimension.

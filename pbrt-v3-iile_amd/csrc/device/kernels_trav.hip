@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                         B.hindex[slot] = idx;
                         // the film position rides in the path's (not yet used) throughput record: the first k_shade
                         // rebuilds the ray from it instead of evaluating the Halton dimensions again
-                        reinterpret_cast<float2 *>(&B.beta[slot])[0] = make_float2(pfx, pfy);
+                        B.beta[slot] = make_float4(pfx, pfy, b2f(idx), 0.f);  // (+ the Halton index: one record, one load in k_shade)
                         gen_d = make_float4(d.x, d.y, d.z, tmax);
                         trav_begin<COUNT>(S, t, o, d, tmax, &st, sr.root);
                         active = true;
@@ -261,7 +261,9 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
         if (active && !t.have) {
             const F3 add = occluded ? add_occluded : add_unoccluded;
             const F3 Ln = L_old + add;  // store only: nothing is loaded here
-            B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
+            // (an occluded light sample without a lit MIS ray adds +0: L stands as it is — a sum of non-negative terms from +0,
+            //  never -0 — and the scattered 16-byte store is left out: a sixth of the records)
+            if (!is_black(add)) B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
             if (COUNT && is_black(add)) ++n_zero;
             active = false;
         }
