@@ -33,6 +33,13 @@ DEV float mn(float a, float b) { return b < a ? b : a; }  // std::min
 DEV float mx(float a, float b) { return a < b ? b : a; }  // std::max
 DEV float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 DEV uint32_t f2b(float f) { return __float_as_uint(f); }
+// Keeps a loaded float4 whole: with its four lanes consumed at one point the compiler issues ONE 16-byte load instead of
+// narrowing it into a 12-byte load where xyz is used and a 4-byte load where w is (every vector memory instruction of a
+// wavefront costs address-unit cycles whatever its width: DESIGN.md §6 "What binds")
+DEV void keep_whole(float4 &a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+DEV void keep_whole(float4 &a, float4 &b, float4 &c) {
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
+}
 DEV float b2f(uint32_t u) { return __uint_as_float(u); }
 DEV bool is_inf(float f) { return (f2b(f) & 0x7fffffffu) == 0x7f800000u; }
 DEV bool is_nan(float f) { return (f2b(f) & 0x7fffffffu) > 0x7f800000u; }

@@ -79,6 +79,18 @@ DEV float scrambled_radical_inverse(const DScene &S, PermPtr perms, int dim, uin
 // constants come through scalar loads, and the N digit chains advance together so that their
 // LDS lookups overlap (one chain alone waits out one LDS round trip per digit).
 typedef const __attribute__((address_space(4))) DHaltonDim *HaltonDimConst;
+// An entry of the sphere / light table whose index is the same in every lane (the scene's only sphere, the only light):
+// read through the constant address space its fields arrive by scalar loads into SGPRs, once per wavefront, instead of
+// one vector-memory instruction per field with 64 identical addresses (k_shade spent ~13 of its ~30 loads per hit so).
+// (a copy, field by field out of that address space: a reference would have to pass through a generic pointer, and the
+// constant address space is lost on the way whenever the index folds to a constant; loads of unused fields are dropped)
+template <typename T>
+DEV T uniform_entry(const T *table, int idx) {
+    typedef const __attribute__((address_space(4))) T *ConstPtr;
+    T out;
+    __builtin_memcpy(&out, (ConstPtr)(table) + __builtin_amdgcn_readfirstlane(idx), sizeof(T));
+    return out;
+}
 template <int N, typename PermPtr>
 DEV void scrambled_radical_inverse_n(const DScene &S, PermPtr perms, int dim0, uint32_t index, float *out) {
     const HaltonDimConst hd = (HaltonDimConst)(S.hdims) + dim0;
@@ -1114,7 +1126,18 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
             float th;
             F3 od, ph;
             const float4 d4 = *ray_d;
-            if (sphere_test(S.spheres[S.prim_shape[prim]], t.rc.o(), F3{d4.x, d4.y, d4.z}, t.tmax, &th, &od, &ph)) {
+            // the lanes that test the same sphere go together, the sphere's fields in SGPRs (uniform_entry): one turn of the
+            // loop when the scene has one sphere, which is the common case
+            const int sphere = S.n_spheres == 1 ? 0 : S.prim_shape[prim];
+            bool sphere_hit = false;
+            for (bool pending = true; pending;) {
+                const int s_now = __builtin_amdgcn_readfirstlane(sphere);
+                if (sphere == s_now) {
+                    sphere_hit = sphere_test(uniform_entry(S.spheres, s_now), t.rc.o(), F3{d4.x, d4.y, d4.z}, t.tmax, &th, &od, &ph);
+                    pending = false;
+                }
+            }
+            if (sphere_hit) {
                 if (any_hit) {
                     t.have = false;
                     return true;
@@ -1424,31 +1447,38 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.ss = normalize(is.sdpdu);
     b.ts = cross(b.ns, b.ss);
     b.n_lobes = 0;
-    b.kd = F3{clampf(m.kd[0], 0, IILE_INF), clampf(m.kd[1], 0, IILE_INF), clampf(m.kd[2], 0, IILE_INF)};
+    // the material's first 32 bytes as two 16-byte loads (field by field they come as four)
+    float4 m_kd, m_ks;  // (bitcast type, kd), (ks, alpha)
+    __builtin_memcpy(&m_kd, &m.type, 16);
+    __builtin_memcpy(&m_ks, &m.ks[0], 16);
+    keep_whole(m_kd);
+    keep_whole(m_ks);
+    const int m_type = int(f2b(m_kd.x));
+    b.kd = F3{clampf(m_kd.y, 0, IILE_INF), clampf(m_kd.z, 0, IILE_INF), clampf(m_kd.w, 0, IILE_INF)};
     b.has_lambert = !is_black(b.kd);
     if (b.has_lambert) ++b.n_lobes;
     b.ks = F3{0, 0, 0};
     b.has_micro = false;
-    b.alpha = m.alpha;
-    b.oren_nayar = EXT && m.type == kMatMatte && m.on_b != 0.f;  // matte.cpp:56-61 (B == 0 iff sigma == 0)
+    b.alpha = m_ks.w;
+    b.oren_nayar = EXT && m_type == kMatMatte && m.on_b != 0.f;  // matte.cpp:56-61 (B == 0 iff sigma == 0)
     b.on_a = m.on_a;
     b.on_b = m.on_b;
-    b.mtype = EXT ? m.type : kMatPlastic;
-    b.eta = m.eta;
-    if (MICRO && (m.type == kMatPlastic || (EXT && m.type == kMatUber))) {
-        b.ks = F3{clampf(m.ks[0], 0, IILE_INF), clampf(m.ks[1], 0, IILE_INF), clampf(m.ks[2], 0, IILE_INF)};
+    b.mtype = EXT ? m_type : kMatPlastic;
+    b.eta = EXT ? m.eta : 1.f;  // (only uber, mirror and glass read it)
+    if (MICRO && (m_type == kMatPlastic || (EXT && m_type == kMatUber))) {
+        b.ks = F3{clampf(m_ks.x, 0, IILE_INF), clampf(m_ks.y, 0, IILE_INF), clampf(m_ks.z, 0, IILE_INF)};
         b.has_micro = !is_black(b.ks);
         if (b.has_micro) ++b.n_lobes;
     }
     b.kr = F3{0, 0, 0};
     b.kt = F3{0, 0, 0};
     b.has_spec = false;
-    if (EXT && (m.type == kMatUber || m.type == kMatMirror)) {
+    if (EXT && (m_type == kMatUber || m_type == kMatMirror)) {
         b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
         b.has_spec = !is_black(b.kr);
         if (b.has_spec) ++b.n_lobes;
     }
-    if (EXT && m.type == kMatGlass) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
+    if (EXT && m_type == kMatGlass) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
         b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
         b.kt = F3{clampf(m.kt[0], 0, IILE_INF), clampf(m.kt[1], 0, IILE_INF), clampf(m.kt[2], 0, IILE_INF)};
         b.has_spec = !(is_black(b.kr) && is_black(b.kt));
@@ -1645,6 +1675,9 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
         pick = 1;
     else
         pick = 2;
+    // (comp < matching: the specular lobe is only ever picked when there is one — said aloud so that the builds whose
+    // materials have none, where has_spec is a constant, drop that branch and the loads that feed it)
+    if (pick == 2 && !b.has_spec) __builtin_unreachable();
     const float ur0 = mn(u0 * matching - comp, kOneMinusEpsilon);
     F3 wo = to_local(b, woW);
     if (wo.z == 0) return F3{0, 0, 0};

@@ -22,7 +22,8 @@ struct DSphere {
     int reverse_orientation, swaps_handedness;
 };
 enum { kMatMatte = 0, kMatPlastic = 1, kMatUber = 2, kMatMirror = 3, kMatGlass = 4 };  // = IILE_MAT_* (checked in api.hip)
-struct DMaterial {
+// (16-byte aligned, and the fields every hit reads first: (type, kd) and (ks, alpha) are one float4 each, see make_bsdf)
+struct alignas(16) DMaterial {
     int type;
     float kd[3];
     float ks[3];

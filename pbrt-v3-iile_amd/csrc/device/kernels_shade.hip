@@ -332,9 +332,10 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                 const int prim = int(f2b(h4.x));
                 const F3 ray_o = F3{o4.x, o4.y, o4.z};
                 ray_d = F3{d4.x, d4.y, d4.z};
-                const float4 v0 = S.tri_verts[3 * size_t(prim)];
-                const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
-                const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
+                float4 v0 = S.tri_verts[3 * size_t(prim)];
+                float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
+                float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
+                keep_whole(v0, v1, v2);  // three 16-byte loads (not three of 12 bytes and three of 4)
                 const uint32_t flags = f2b(v0.w);
                 const int material = int(f2b(v1.w)), light = int(f2b(v2.w));
                 if (ONLY != 1 && (flags & 1u)) {
@@ -412,7 +413,15 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                         }
                         if (S.n_lights > 0) ++dim;
                         if (S.n_lights > 0 && light_sel_pdf != 0) {
-                            const DLight &lt = S.lights[li];
+                            // (the plain build has one light, an emitting sphere: both wave-uniform, see uniform_sphere)
+                            DLight lt_u;
+                            DSphere lsp_u;
+                            if (!EXT) {
+                                lt_u = uniform_entry(S.lights, 0);
+                                lsp_u = uniform_entry(S.spheres, lt_u.sphere);
+                            }
+                            const DLight &lt = EXT ? S.lights[li] : lt_u;
+                            const DSphere &lsp = EXT ? S.spheres[lt.sphere] : lsp_u;
                             if (EXT && lt.type == kLightInfinite) {
                                 // EstimateDirect for the infinite light (integrator.cpp:108-215): both halves; the
                                 // BSDF-sampled ray contributes Le(ray) when it escapes (:209-210)
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                                 float light_pdf = 0, scattering_pdf = 0;
                                 F3 wi = F3{0, 0, 0}, Li = F3{0, 0, 0};
                                 LightSample ps = EXT ? shape_sample(S, lt, is, ul0, ul1, &light_pdf)
-                                                     : sphere_sample(S.spheres[lt.sphere], is, ul0, ul1, &light_pdf);
+                                                     : sphere_sample(lsp, is, ul0, ul1, &light_pdf);
                                 if (light_pdf == 0 || length_sq(ps.p - is.p) == 0) {
                                     light_pdf = 0;
                                 } else {
@@ -541,11 +550,11 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                                     if (!COUNT && lt.type == kLightDiffuseArea) {
                                         float t_l;
                                         F3 od_l, ph_l;
-                                        can_reach = sphere_test(S.spheres[lt.sphere], mo, md, IILE_INF, &t_l, &od_l, &ph_l);
+                                        can_reach = sphere_test(lsp, mo, md, IILE_INF, &t_l, &od_l, &ph_l);
                                     }
                                     if (can_reach) {
                                         const float lp = EXT ? shape_pdf(S, lt, is, wi, &n_pdf_tests, &n_pdf_hits)
-                                                             : sphere_pdf(S.spheres[lt.sphere], is, wi);
+                                                             : sphere_pdf(lsp, is, wi);
                                         if (lp != 0) {
                                             const float weight = power_heuristic(scattering_pdf, lp);
                                             // Li is Lemit when the MIS ray finds this light facing it
