@@ -701,6 +701,18 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             sp[i].phi_max = s.phi_max;
             sp[i].reverse_orientation = s.reverse_orientation;
             sp[i].swaps_handedness = s.swaps_handedness;
+            // xf_point(o2w, (0, 0, 0)) (dmath.h), operation by operation: products with zero included, the division by w as
+            // a multiplication with its reciprocal (this file is compiled without contraction or fast math, host side too)
+            const float *m = s.o2w;
+            const float zero = 0.f;
+            float c[4];
+            for (int r = 0; r < 4; ++r) c[r] = m[4 * r] * zero + m[4 * r + 1] * zero + m[4 * r + 2] * zero + m[4 * r + 3];
+            if (c[3] != 1) {
+                const float inv = 1.f / c[3];
+                for (int r = 0; r < 3; ++r) c[r] = c[r] * inv;
+            }
+            for (int r = 0; r < 3; ++r) sp[i].center[r] = c[r];
+            sp[i].pad_ = 0.f;
         }
         rc = upload(sc, sp.data(), sp.size(), &S.spheres);
         if (rc) return bail(rc);

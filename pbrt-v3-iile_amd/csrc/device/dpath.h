@@ -184,19 +184,27 @@ DEV float sample_dimension(const DScene &S, PermPtr perms, uint32_t index, int d
     if (dim == 1) return radical_inverse_base3(index / uint32_t(S.base_scale1));
     return scrambled_radical_inverse(S, perms, dim, index);
 }
+// the same for a dimension the caller knows to be >= 2 (every dimension after the camera sample's film position): none of the
+// code — and none of the hoisted constants — of the two pixel dimensions
+template <typename PermPtr>
+DEV float sample_dimension_hi(const DScene &S, PermPtr perms, uint32_t index, int dim) {
+    if (dim < 2) __builtin_unreachable();
+    return sample_dimension(S, perms, index, dim);
+}
 DEV float sample_dimension(const DScene &S, uint32_t index, int dim, int px = 0, int py = 0) {
     return sample_dimension(S, S.perms, index, dim, px, py);
 }
 // N consecutive dimensions >= 2 of one sample (the shade kernel's batches)
 template <int N, typename PermPtr>
 DEV void sample_dimensions_n(const DScene &S, PermPtr perms, int dim0, bool dim_uniform, int dim_lane, uint32_t index, float *out) {
+    if (dim_lane < 2) __builtin_unreachable();
     if (S.sobol) {
 #pragma unroll
         for (int i = 0; i < N; ++i) out[i] = sobol_sample_dimension(S, perms, index, dim_lane + i, 0, 0);
     } else if (dim_uniform) {
         scrambled_radical_inverse_n<N>(S, perms, dim0, index, out);
     } else {
-        for (int i = 0; i < N; ++i) out[i] = sample_dimension(S, perms, index, dim_lane + i);
+        for (int i = 0; i < N; ++i) out[i] = sample_dimension_hi(S, perms, index, dim_lane + i);
     }
 }
 
@@ -233,9 +241,18 @@ DEV F3 cosine_sample_hemisphere(float u0, float u1) {
 // ===========================================================================
 // camera (cameras/perspective.cpp:100-149, core/transform.h:251-264)
 // ===========================================================================
-DEV void camera_ray(const DScene &S, float pfx, float pfy, float lu0, float lu1, F3 *o_out, F3 *d_out, float *tmax) {
-    F3 pcam = xf_point(S.raster_to_camera, F3{pfx, pfy, 0});
-    F3 ro = F3{0, 0, 0};
+// `zero` is 0.f: a caller inside a persistent loop passes one the compiler cannot see through (opaque_zero), so that the
+// products of matrix entries (SGPRs) with it are worked out where they are used instead of being hoisted out of the loop
+// into VGPRs that then live — or spill — across the whole kernel.
+DEV float opaque_zero() {
+    float z = 0.f;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+DEV void camera_ray(const DScene &S, float pfx, float pfy, float lu0, float lu1, F3 *o_out, F3 *d_out, float *tmax,
+                    const float zero = 0.f) {
+    F3 pcam = xf_point(S.raster_to_camera, F3{pfx, pfy, zero});
+    F3 ro = F3{zero, zero, zero};
     F3 rd = normalize(pcam);
     if (S.lens_radius > 0) {
         float lx, ly;
@@ -244,7 +261,7 @@ DEV void camera_ray(const DScene &S, float pfx, float pfy, float lu0, float lu1,
         ly = S.lens_radius * ly;
         float ft = S.focal_distance / rd.z;
         F3 pfocus = ro + rd * ft;
-        ro = F3{lx, ly, 0};
+        ro = F3{lx, ly, zero};
         rd = normalize(pfocus - ro);
     }
     F3 oerr;
@@ -1775,7 +1792,7 @@ DEV LightSample sphere_sample_area(const DSphere &sp, float u0, float u1, float 
     return it;
 }
 DEV LightSample sphere_sample(const DSphere &sp, const Isect &ref, float u0, float u1, float *pdf) {
-    F3 pc = xf_point(sp.o2w, F3{0, 0, 0});
+    const F3 pc = F3{sp.center[0], sp.center[1], sp.center[2]};  // (*ObjectToWorld)(Point3f(0, 0, 0)), see DSphere
     F3 porigin = offset_ray_origin(ref.p, ref.perr, ref.n, pc - ref.p);
     if (length_sq(porigin - pc) <= sp.radius * sp.radius) {
         LightSample intr = sphere_sample_area(sp, u0, u1, pdf);
@@ -1815,7 +1832,7 @@ DEV LightSample sphere_sample(const DSphere &sp, const Isect &ref, float u0, flo
     return it;
 }
 DEV float sphere_pdf(const DSphere &sp, const Isect &ref, F3 wi) {
-    F3 pc = xf_point(sp.o2w, F3{0, 0, 0});
+    const F3 pc = F3{sp.center[0], sp.center[1], sp.center[2]};  // (*ObjectToWorld)(Point3f(0, 0, 0)), see DSphere
     F3 porigin = offset_ray_origin(ref.p, ref.perr, ref.n, pc - ref.p);
     if (length_sq(porigin - pc) <= sp.radius * sp.radius) {
         // Shape::Pdf, shape.cpp:72-87 — the shape alone, not a scene ray

@@ -20,6 +20,10 @@ struct DSphere {
     M44 o2w, o2w_inv;
     float radius, zmin, zmax, theta_min, theta_max, phi_max;
     int reverse_orientation, swaps_handedness;
+    // (*ObjectToWorld)(Point3f(0, 0, 0)), sphere.cpp:254 / :296, worked out once at upload with xf_point's own operations
+    // (api.hip): the light-sampling code of every hit starts from it
+    float center[3];
+    float pad_;
 };
 enum { kMatMatte = 0, kMatPlastic = 1, kMatUber = 2, kMatMirror = 3, kMatGlass = 4 };  // = IILE_MAT_* (checked in api.hip)
 // (16-byte aligned, and the fields every hit reads first: (type, kd) and (ks, alpha) are one float4 each, see make_bsdf)

@@ -150,13 +150,19 @@ DEV void pf_touch(const T *src, uint32_t *row) {
 
 // shade: one bounce of PathIntegrator::Li (path.cpp:81-191) for every hit of the
 // queue that extend just resolved.
-// 3 waves/SIMD (<= 168 VGPRs, 6 spilled): measured 38.0 ms vs 40.2 ms at 2 waves/SIMD
+// Waves per SIMD = resident blocks per CU. The plain and the extended builds run at 4 (<= 128 VGPRs, ~10 spilled to scratch
+// outside the hot sections: killeroo 18.3 -> 17.2 ms, the closed room 53.5 -> 50.1 ms against 3 waves, profiles/r03_ab_shade_4_waves.txt
+// — at the 168 VGPRs the kernel wanted before its uniform table reads became scalar loads, 4 waves lost: 23.6 vs 22.0 ms);
+// the textured build is better off at 3 (<= 168 VGPRs; 50.2 vs 52.8 ms at 4).
 // TEX: some material takes a parameter from an image texture (implies EXT)
 // ONLY: 0 = every hit of the queue; the two class-specialised builds share one queue and each takes its classes out of
 // every chunk: 1 = hits on matte triangles only (shading class 0: no microfacet lobe, so none of that code or its
 // registers: more waves per SIMD), 2 = every other class.
 #ifndef IILE_SHADE_WAVES
-#define IILE_SHADE_WAVES 3
+#define IILE_SHADE_WAVES 4
+#endif
+#ifndef IILE_SHADE_WAVES_TEX
+#define IILE_SHADE_WAVES_TEX 3
 #endif
 #ifndef IILE_SHADE_PREFETCH
 #define IILE_SHADE_PREFETCH 0
@@ -167,8 +173,9 @@ DEV void pf_touch(const T *src, uint32_t *row) {
 #ifndef IILE_SHADE_WAVES_MATTE
 #define IILE_SHADE_WAVES_MATTE 4
 #endif
+constexpr int shade_waves(bool tex, int only) { return only == 1 ? IILE_SHADE_WAVES_MATTE : (tex ? IILE_SHADE_WAVES_TEX : IILE_SHADE_WAVES); }
 template <bool COUNT, bool EXT, bool TEX, int ONLY = 0>
-__global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_SHADE_WAVES) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
+__global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
     // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
     if (S.sobol) {
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                     }
                     F3 co, cd;
                     float ctm;
-                    camera_ray(S, cpf.x, cpf.y, cl0, cl1, &co, &cd, &ctm);
+                    camera_ray(S, cpf.x, cpf.y, cl0, cl1, &co, &cd, &ctm, opaque_zero());
                     o4 = make_float4(co.x, co.y, co.z, b2f(slot));
                     d4 = make_float4(cd.x, cd.y, cd.z, ctm);
                 } else {
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                         // tabulated at scene creation); a zero pdf returns before any further sample.
                         int li = 0;
                         if (EXT && S.n_lights > 1) {
-                            const float ul = sample_dimension(S, s_perms, hidx, dim);
+                            const float ul = sample_dimension_hi(S, s_perms, hidx, dim);
                             li = sample_light(S, is.p, ul, &light_sel_pdf);
                         }
                         if (S.n_lights > 0) ++dim;
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(kBlock, ONLY == 1 ? IILE_SHADE_WAVES_MATTE : IILE_S
                     const float mc = max3(rr_beta.x, rr_beta.y, rr_beta.z);
                     if (mc < S.rr_threshold && bounce > 3) {
                         const float q = mx(.05f, 1 - mc);
-                        const float ur = sample_dimension(S, s_perms, hidx, dim);
+                        const float ur = sample_dimension_hi(S, s_perms, hidx, dim);
                         ++dim;
                         if (ur < q)
                             alive = false;
@@ -704,10 +711,9 @@ static bool shade_split() {
     return on;
 }
 void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-#ifndef IILE_SHADE_BLOCKS
-#define IILE_SHADE_BLOCKS 3  // = resident blocks per CU at 3 waves/SIMD: the static split has no tail
-#endif
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, IILE_SHADE_BLOCKS));
+    // as many blocks as are resident at the build's waves per SIMD: the static split has no tail
+    const bool tex_build = cfg.count_stats || S.textured_materials || S.probe_mode;
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, shade_waves(tex_build, 0)));
     const size_t perm_bytes = S.sobol ? size_t(16) : (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
     if (cfg.count_stats)
         hipLaunchKernelGGL((k_shade<true, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);

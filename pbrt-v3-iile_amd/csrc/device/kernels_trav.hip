@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                         float tmax;
                         const float pfx = float(px) + u0, pfy = float(py) + u1;
                         flag_whole_film_position(B, slot, px, py, k, pfx, pfy, u0, u1);
-                        camera_ray(S, pfx, pfy, l0, l1, &o, &d, &tmax);
+                        camera_ray(S, pfx, pfy, l0, l1, &o, &d, &tmax, opaque_zero());
                         B.hindex[slot] = idx;
                         // the film position rides in the path's (not yet used) throughput record: the first k_shade
                         // rebuilds the ray from it instead of evaluating the Halton dimensions again
