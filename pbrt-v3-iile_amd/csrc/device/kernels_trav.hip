@@ -50,7 +50,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
             if (feed_take(feed, head, count, !active, &s_new, warm)) {
                 slot = s_new;
                 if (GEN) {
-                    B.L[slot] = make_float4(0, 0, 0, 0);  // the path's radiance starts here (no memset of 2 GB ahead of the pass)
+                    // the path's radiance starts here (no memset of 2 GB ahead of the pass); the zeros are made on the spot, or
+                    // four registers of them live — spilled — through the whole kernel
+                    const float z = opaque_zero();
+                    B.L[slot] = make_float4(z, z, z, z);
                     int px = 0, py = 0;
                     uint32_t k = 0;
                     if (path_pixel(S, P, slot, &px, &py, &k)) {  // queue 0 is dense: slot == path id
