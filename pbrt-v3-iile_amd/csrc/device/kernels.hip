@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_film_accumulate(DScene S, PassDesc P
                 if (P.k0 + kk == 0) {
                     // a sample whose fractional film offset is exactly 0 also lands in the
                     // left / upper neighbour (support ceil(pd-.5) .. floor(pd+.5))
-                    const uint32_t idx = B.hindex[pid0 + kk];
+                    const uint32_t idx = sample_index(S, px, py, 0u);  // (= the index its camera ray was made with)
                     uint32_t mask = 0;
                     if (sample_dimension(S, idx, 0, px, py) == 0.f) mask |= 1u;
                     if (sample_dimension(S, idx, 1, px, py) == 0.f) mask |= 2u;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_film_store(DScene S, PassDesc P, Pas
         if (!path_pixel(S, P, pid, &px, &py, &k)) continue;
         const float4 L4 = B.L[pid];
         const F3 L = guard_radiance(S, F3{L4.x, L4.y, L4.z});
-        const uint32_t idx = B.hindex[pid];
+        const uint32_t idx = sample_index(S, px, py, k);  // (= the index its camera ray was made with)
         // [tile slot][k][pixel of the tile]: the gather's lanes (neighbouring film pixels) read neighbouring records
         const uint32_t pt = uint32_t(P.slot0) * 256u + pid / uint32_t(P.kc);
         const size_t at = (size_t(pt >> 8) * size_t(n_samples) + size_t(int(k) - k_begin)) * 256u + size_t(pt & 255u);

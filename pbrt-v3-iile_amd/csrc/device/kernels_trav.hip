@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                         const float pfx = float(px) + u0, pfy = float(py) + u1;
                         flag_whole_film_position(B, slot, px, py, k, pfx, pfy, u0, u1);
                         camera_ray(S, pfx, pfy, l0, l1, &o, &d, &tmax, opaque_zero());
-                        B.hindex[slot] = idx;
+                        // (no PassBuffers::hindex entry: the index rides in the record below, the film kernels work it out again)
                         // the film position rides in the path's (not yet used) throughput record: the first k_shade
                         // rebuilds the ray from it instead of evaluating the Halton dimensions again
                         B.beta[slot] = make_float4(pfx, pfy, b2f(idx), 0.f);  // (+ the Halton index: one record, one load in k_shade)
