@@ -829,7 +829,7 @@ DEV void trav_begin(const DScene &S, Trav &t, F3 ro, F3 rd, float tmax, TraceSta
 // per frame that way.) Trav::sp packs both cursors: bits 0..7 = number of levels on the
 // stack, bits 8.. = number of levels that live in HBM (levels [0, lo)).
 // level % kLdsStackDepth for level < 128 without an integer division (exact for depths 8..32)
-static_assert(kLdsStackDepth >= 8 && kLdsStackDepth <= 32, "lds_slot's reciprocal is checked for depths 8..32");
+static_assert(kLdsStackDepth >= 5 && kLdsStackDepth <= 32, "lds_slot's reciprocal is checked for depths 5..32 (levels < 256)");
 DEV int lds_slot(int level) {
     constexpr int kRecip = (65536 + kLdsStackDepth - 1) / kLdsStackDepth;
     return level - kLdsStackDepth * ((level * kRecip) >> 16);
