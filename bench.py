@@ -447,7 +447,9 @@ def main():
             "algorithmic_bytes_per_launch": int(bytes_all / max(launches_per_step, 1)),
             "algorithmic_bytes_note": note_k,
             "units_per_launch": int(units_k / max(launches_per_step, 1)),
-            "binding": "valu",
+            "binding": ("vector-memory pipe in front of the L1 (address unit busy 0.74-0.86, data-return unit 0.92-0.99 of the kernel's cycles: "
+                        "profiles/*_pmc_mem.json), not VALU issue and not HBM" if cache_resident else
+                        "registers (waves per SIMD) and vector-memory instructions per hit; VALU issue at ~0.6 of the calibrated ceiling (DESIGN.md section 6)"),
             "valu": per_kernel[dom].get("valu"),
             "l2": per_kernel[dom].get("l2"),
             "lanes_source": la_src,
@@ -457,7 +459,7 @@ def main():
                     "32 B/node + 48 B/triangle bytes are served from cache (~7 MB scene), frac is the PMC-counted HBM "
                     "traffic instead (never above 1) and the algorithmic rate is kept as `achieved`. `traffic` = HBM bytes "
                     "per launch from separate rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE). What "
-                    "binds the kernel is VALU issue: see `valu` (counters in profiles/, lane-ops = wave instructions x 64).",
+                    "binds the kernel: see `binding`; `valu` carries the issue-side counters (profiles/, lane-ops = wave instructions x 64).",
         }
         frac_alg = achieved / HBM_PEAK_GBS
         if traffic:
