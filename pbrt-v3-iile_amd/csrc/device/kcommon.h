@@ -127,6 +127,9 @@ constexpr uint32_t kChunk = 512;
 #ifndef IILE_REFILL_IDLE
 #define IILE_REFILL_IDLE 32
 #endif
+#ifndef IILE_REFILL_IDLE_GEN
+#define IILE_REFILL_IDLE_GEN 56  // 47.5 -> 47.1 ms against 32: profiles/r03_ab_gen_refill.txt
+#endif
 constexpr int kRefillIdle = IILE_REFILL_IDLE;  // refill once this many lanes are idle (or all)
 struct WaveFeed {
     uint32_t cur, end;

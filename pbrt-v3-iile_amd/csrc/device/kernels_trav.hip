@@ -45,7 +45,8 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
     float4 gen_d = make_float4(0, 0, 1, 0);  // GEN: the ray direction (the sphere test reads it back)
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
-        if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
+        // (the camera-ray build makes its rays here, some 400 instructions each: it waits for more idle lanes than the others)
+        if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= (GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle) || idle_mask == ~0ull)) {
             uint32_t s_new;
             if (feed_take(feed, head, count, !active, &s_new, warm)) {
                 slot = s_new;
