@@ -43,7 +43,25 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
     bool active = false;
     uint32_t slot = 0;
     float4 gen_d = make_float4(0, 0, 1, 0);  // GEN: the ray direction (the sphere test reads it back)
+#ifdef IILE_TRAV_STAMPS
+    // diagnostic build only (tools/trav_stamps.py): wave cycles per section of the loop, summed per wavefront and added to
+    // DCounters::path_length: the camera-ray build [0] refill + ray generation, [1] interior steps, [2] leaf steps,
+    // [3] finish + queue append; the other bounces the same in [4..7]
+    unsigned long long stamp_sum[4] = {0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#define TRAV_STAMP(i)                                                   \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        stamp_sum[i] += now_ - stamp_t;                                 \
+        stamp_t = now_;                                                 \
+    } while (0)
+#else
+#define TRAV_STAMP(i) \
+    do {              \
+    } while (0)
+#endif
     while (true) {
+        TRAV_STAMP(3);
         const unsigned long long idle_mask = __ballot(!active);
         // (the camera-ray build makes its rays here, some 400 instructions each: it waits for more idle lanes than the others)
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= (GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle) || idle_mask == ~0ull)) {
@@ -91,6 +109,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
                 }
             }
         }
+        TRAV_STAMP(0);
         if (__ballot(active) == 0) {
             if (feed.exhausted) break;
             continue;
@@ -108,8 +127,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
+                TRAV_STAMP(1);
             } else if (n_leaf > 0) {
                 if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, GEN ? &gen_d : &rd[slot]);
+                TRAV_STAMP(2);
             }
         }
 #else
@@ -129,6 +150,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
         if (is_hit) B.shade_q[pos] = slot | (uint32_t(t.hit_prim >> kHitClassShift) & 7u) << kSlotBits;
     }
     out_flush(shade_out, pad_shade);
+#ifdef IILE_TRAV_STAMPS
+    if (!COUNT && (threadIdx.x & 63) == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&B.counters->path_length[(GEN ? 0 : 4) + i], stamp_sum[i]);
+#endif
     flush_counter(&B.counters->ext_traced, n_rays);  // every build: the uninstrumented pass leaves out rays that cannot matter
     if (COUNT) {
         flush_counter(&B.counters->closest_rays, n_rays);
