@@ -123,7 +123,10 @@ static_assert(kCntShdHead2 + 16 <= kCntWords, "PassBuffers::counts layout");
 // lane of the wavefront (the classic while-while + dynamic fetch scheme, sized
 // for 64 lanes). 512-slot chunks keep the head word at a few atomics per
 // microsecond, far below its ~88/us saturation point.
-constexpr uint32_t kChunk = 512;
+#ifndef IILE_CHUNK
+#define IILE_CHUNK 512
+#endif
+constexpr uint32_t kChunk = IILE_CHUNK;
 #ifndef IILE_REFILL_IDLE
 #define IILE_REFILL_IDLE 32
 #endif
@@ -165,10 +168,10 @@ DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint3
 }
 
 // touch one float4 of every 128-byte line of records [first, first + kChunk) of a float4 plane
-static_assert(kChunk == 64 * 8, "one lane per 128-byte line of a chunk");
+static_assert(kChunk <= 64 * 8 && kChunk % 64 == 0, "at most one lane per 128-byte line of a chunk");
 DEV void warm_plane(const float4 *plane_base, uint32_t first, uint32_t limit) {
     const uint32_t i = first + uint32_t(lane_id()) * 8u;
-    if (i < limit) {
+    if (i < limit && i < first + kChunk) {
         const float v = plane_base[i].x;
         asm volatile("" ::"v"(v));  // keep the load; the value itself is not needed
     }
