@@ -466,6 +466,57 @@ def test_several_lights_bitwise(binding, oracle, tmp_path):
         assert_bitwise(plain, ref, f"{name} (several lights) film, uninstrumented kernels")
 
 
+SPHERES_SCENE = """LookAt 0 -8 3  0 0 1  0 0 1
+Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [96] "integer yresolution" [64]
+Sampler "halton" "integer pixelsamples" [4]
+Integrator "path" "integer maxdepth" [5]
+WorldBegin
+AttributeBegin
+  Translate 1 -1 4
+  Rotate 30 0 1 0
+  AreaLightSource "area" "color L" [30 30 30]
+  Shape "sphere" "float radius" [0.5]
+AttributeEnd
+AttributeBegin
+  Material "plastic" "color Kd" [.2 .5 .3] "color Ks" [.3 .3 .3] "float roughness" [0.1]
+  Translate -1.5 0 1
+  Rotate 40 1 1 0
+  Scale 1 0.6 1.3
+  Shape "sphere" "float radius" [0.8]
+AttributeEnd
+AttributeBegin
+  Material "matte" "color Kd" [.6 .3 .2]
+  Translate 1.2 0.5 0.7
+  Shape "sphere" "float radius" [0.7]
+AttributeEnd
+AttributeBegin
+  Material "matte" "color Kd" [.5 .5 .5]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-5 -5 0  5 -5 0  5 5 0  -5 5 0]
+AttributeEnd
+WorldEnd
+"""
+
+
+def test_several_spheres_with_transforms_bitwise(binding, oracle, tmp_path):
+    """Three spheres under different transforms (a rotated emitter, a rotated and unevenly scaled plastic one, a translated
+    matte one) over a floor: the traversal's leaf test takes the spheres of a wavefront's lanes one at a time with the sphere's
+    fields in scalar registers, k_shade reads the light's sphere the same way, and the sphere's centre is worked out at
+    upload — all three against the oracle, which does none of that."""
+    path = tmp_path / "spheres.pbrt"
+    path.write_text(SPHERES_SCENE)
+    scene = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(scene)
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(scene)
+    assert float(scene.film_to_rgb(ref).mean()) > 1e-3
+    assert_bitwise(film, ref, "three spheres film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["sphere_tests"] == ost["sphere_tests"] and st["nee_evals"] == ost["nee_evals"]
+    plain, _ = gpu.render()
+    assert_bitwise(plain, ref, "three spheres film, uninstrumented kernels")
+
+
 @pytest.mark.parametrize("seed,light", [(1, "quad"), (2, "multi"), (3, "area"), (4, "spot")])
 def test_random_rooms_bitwise(binding, oracle, tmp_path, seed, light):
     """Differently seeded box rooms (other blob positions, sizes, noise, material parameters) with all
