@@ -1634,7 +1634,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
                 copy_counters(c, &st);
             else
                 st.mis_rays_traced = c.mis_traced, st.ext_rays_traced = c.ext_traced;
-#if defined(IILE_SHADE_STAMPS) || defined(IILE_TRAV_STAMPS)
+#if defined(IILE_SHADE_STAMPS) || defined(IILE_TRAV_STAMPS) || defined(IILE_SHADOW_STAMPS)
             // diagnostic builds (tools/shade_stamps.py, tools/trav_stamps.py): per-section wave cycles ride out in the path-length histogram
             if (!prm->collect_stats)
                 for (int i = 0; i < 8; ++i) st.path_length[i] = c.path_length[i];

@@ -210,7 +210,23 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
     // (L itself is only *consumed* at the store, so its load — the one scattered access of the
     // record — overlaps the ray's first traversal steps instead of holding up the refill.)
     F3 L_old = F3{0, 0, 0}, add_unoccluded = F3{0, 0, 0}, add_occluded = F3{0, 0, 0};
+#ifdef IILE_SHADOW_STAMPS
+    // diagnostic build only (tools/trav_stamps.py shadow): as in k_extend — [0] refill, [1] interior steps, [2] leaf steps, [3] finish
+    unsigned long long stamp_sum[4] = {0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#define SHADOW_STAMP(i)                                                 \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        stamp_sum[i] += now_ - stamp_t;                                 \
+        stamp_t = now_;                                                 \
+    } while (0)
+#else
+#define SHADOW_STAMP(i) \
+    do {                \
+    } while (0)
+#endif
     while (true) {
+        SHADOW_STAMP(3);
         const unsigned long long idle_mask = __ballot(!active);
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
             uint32_t e_new;
@@ -265,6 +281,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                 }
             }
         }
+        SHADOW_STAMP(0);
         if (__ballot(active) == 0) {
             if (feed.exhausted) break;
             continue;
@@ -279,8 +296,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT, true>(S, t, sr, &st);
+                SHADOW_STAMP(1);
             } else if (n_leaf > 0) {
                 if (wl && trav_leaf<COUNT, ALPHA>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
+                SHADOW_STAMP(2);
             }
         }
 #else
@@ -297,6 +316,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
             active = false;
         }
     }
+#ifdef IILE_SHADOW_STAMPS
+    if (!COUNT && (threadIdx.x & 63) == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&B.counters->path_length[i], stamp_sum[i]);
+#endif
     if (COUNT) {
         flush_counter(&B.counters->shadow_rays, n_shadow);
         flush_counter(&B.counters->zero_radiance, n_zero);

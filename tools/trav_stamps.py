@@ -1,7 +1,8 @@
 """Where a k_extend wavefront's cycles go: the diagnostic build (-DIILE_TRAV_STAMPS: s_memtime stamps between the sections of the
 persistent loop; tools/build_variant.sh tstamps "kernels_trav api" "-DIILE_TRAV_STAMPS") renders the bench frame once and prints the
 per-section share of the waves' cycles, for the camera-ray build (bounce 0) and for the later bounces. Shares, not absolute times.
-usage: IILE_GPU_LIB=pbrt-v3-iile_amd/lib/variants/libiile_gpu_tstamps.so python tools/trav_stamps.py [boxroom]"""
+usage: IILE_GPU_LIB=pbrt-v3-iile_amd/lib/variants/libiile_gpu_tstamps.so python tools/trav_stamps.py [killeroo|boxroom] [shadow]
+(shadow: the build made with -DIILE_SHADOW_STAMPS instead, k_shadow's sections in the first four counters)"""
 import json
 import os
 import sys
@@ -13,6 +14,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 import __graft_entry__ as ge  # noqa: E402
 
 b = ge._load_binding()
+shadow = "shadow" in sys.argv[1:]
 if len(sys.argv) > 1 and sys.argv[1] == "boxroom":
     import boxroom
     tmp = tempfile.NamedTemporaryFile("w", suffix=".pbrt", delete=False)
@@ -26,8 +28,8 @@ gpu.render()
 _, st = gpu.render(want_stats=True, time_kernels=2)
 names = ["refill (+ camera-ray generation at bounce 0)", "interior steps", "leaf steps", "finish + shade-queue append + loop head"]
 cyc = [int(x) for x in st["path_length"]]
-out = {"ms_extend_one_stream": st["ms_extend"]}
-for label, part in (("bounce 0 (camera-ray build)", cyc[0:4]), ("bounces >= 1", cyc[4:8])):
+out = {"ms_extend_one_stream": st["ms_extend"], "ms_shadow_one_stream": st["ms_shadow"]}
+for label, part in ((("k_shadow, all bounces", cyc[0:4]),) if shadow else (("bounce 0 (camera-ray build)", cyc[0:4]), ("bounces >= 1", cyc[4:8]))):
     tot = sum(part) or 1
     out[label] = {"wave_cycles": tot, "sections": {n: round(c / tot, 4) for n, c in zip(names, part)}}
 print(json.dumps(out, indent=1))
