@@ -12,6 +12,7 @@
 #include <string>
 #include <limits>
 #include <map>
+#include <numeric>
 #include <vector>
 
 #include "../../../include/iile_gpu.h"
@@ -571,7 +572,23 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         // its parent's (Union in recursiveBuild is exact). pack_wide_records verifies it for the tree we were handed; a
         // tree that violates it is traversed with binary steps only.
         S.boxes_nested = 1;
-        rc = pack_wide_records(d_nodes, n, n_interior, wide, wide4, &S.boxes_nested);
+        // Where the records sit in memory is free (a reference is a record slot): depth-first rank by default. The diagnostic
+        // order IILE_RECORD_ORDER=scramble scatters them (rank * prime mod n) to measure what the order is worth at all.
+        std::vector<int> remap;
+        const int *d_remap = nullptr;
+        if (const char *e = std::getenv("IILE_RECORD_ORDER")) {
+            if (std::string(e) == "scramble" && n_interior > 2) {
+                long long prime = 7919;
+                while (std::gcd<long long>(prime, n_interior) != 1) prime += 2;
+                remap.resize(size_t(n_interior));
+                for (int j = 0; j < n_interior; ++j) remap[size_t(j)] = int((j * prime) % n_interior);
+            }
+        }
+        if (!remap.empty()) {
+            rc = upload(sc, remap.data(), remap.size(), &d_remap);
+            if (rc) return bail(rc);
+        }
+        rc = pack_wide_records(d_nodes, n, n_interior, wide, wide4, &S.boxes_nested, d_remap);
         if (rc) return bail(rc);
         if (n_interior >= (1 << 25)) S.boxes_nested = 0;  // the four-wide step addresses its records with 32-bit byte offsets
         S.wide = wide;
@@ -581,7 +598,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 S.root_box[c] = d->nodes[0].bmin[c];
                 S.root_box[3 + c] = d->nodes[0].bmax[c];
             }
-            S.root_ref = d->nodes[0].nprims == 0 ? 0 : ~d->nodes[0].offset;  // the root is interior record 0
+            S.root_ref = d->nodes[0].nprims == 0 ? (remap.empty() ? 0 : remap[0]) : ~d->nodes[0].offset;  // the root is interior rank 0
         }
         // The top of the four-wide tree, breadth first, for the traversal kernels' LDS copies (dpath.h, load_wide4): the
         // records are read back once, the references among the chosen ones become kTopFlag | slot, each copy keeps its own

@@ -414,11 +414,13 @@ int grid_for(int n) { return std::max(1, std::min((n + kBB - 1) / kBB, 256 * 8))
 __global__ __launch_bounds__(kBB) void k_interior_flags(int n, const iile_bvh_node *nodes, int *flags) {
     for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) flags[i] = nodes[i].nprims == 0 ? 1 : 0;
 }
-__device__ __forceinline__ int ref_of(const iile_bvh_node *nodes, const int *excl, int node) {
-    return nodes[node].nprims == 0 ? excl[node] : ~nodes[node].offset;
+// record slot of an interior node: its rank among the interior nodes (depth-first), or where `remap` sends that rank
+__device__ __forceinline__ int slot_of_rank(const int *remap, int rank) { return remap ? remap[rank] : rank; }
+__device__ __forceinline__ int ref_of(const iile_bvh_node *nodes, const int *excl, const int *remap, int node) {
+    return nodes[node].nprims == 0 ? slot_of_rank(remap, excl[node]) : ~nodes[node].offset;
 }
-__global__ __launch_bounds__(kBB) void k_pack_wide(int n, const iile_bvh_node *nodes, const int *excl, float4 *wide, float4 *wide4,
-                                                   int *not_nested) {
+__global__ __launch_bounds__(kBB) void k_pack_wide(int n, const iile_bvh_node *nodes, const int *excl, const int *remap, float4 *wide,
+                                                   float4 *wide4, int *not_nested) {
     const float inf = __builtin_huge_valf();
     for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) {
         const iile_bvh_node nd = nodes[i];
@@ -426,8 +428,9 @@ __global__ __launch_bounds__(kBB) void k_pack_wide(int n, const iile_bvh_node *n
         const int child[2] = {i + 1, nd.offset};
         const iile_bvh_node a = nodes[child[0]], b = nodes[child[1]];
         // two-wide record (instrumented kernels): both children's boxes, their refs, the split axis
-        float4 *w = wide + 4 * size_t(excl[i]);
-        const int ra = ref_of(nodes, excl, child[0]), rb = ref_of(nodes, excl, child[1]);
+        const int my_slot = slot_of_rank(remap, excl[i]);
+        float4 *w = wide + 4 * size_t(my_slot);
+        const int ra = ref_of(nodes, excl, remap, child[0]), rb = ref_of(nodes, excl, remap, child[1]);
         w[0] = make_float4(a.bmin[0], a.bmin[1], a.bmin[2], a.bmax[0]);
         w[1] = make_float4(a.bmax[1], a.bmax[2], b.bmin[0], b.bmin[1]);
         w[2] = make_float4(b.bmin[2], b.bmax[0], b.bmax[1], b.bmax[2]);
@@ -456,12 +459,12 @@ __global__ __launch_bounds__(kBB) void k_pack_wide(int n, const iile_bvh_node *n
                 for (int j = 0; j < 2; ++j) {
                     const iile_bvh_node g = nodes[gc[j]];
                     for (int k = 0; k < 3; ++k) bx[k][2 * side + j] = g.bmin[k], bx[3 + k][2 * side + j] = g.bmax[k];
-                    refs[2 * side + j] = g.nprims == 0 ? excl[gc[j]] : ~g.offset;
+                    refs[2 * side + j] = g.nprims == 0 ? slot_of_rank(remap, excl[gc[j]]) : ~g.offset;
                 }
                 meta |= (uint32_t(c.axis) & 3u) << (2 + 2 * side);
             }
         }
-        float4 *w4 = wide4 + 8 * size_t(excl[i]);
+        float4 *w4 = wide4 + 8 * size_t(my_slot);
         for (int pl = 0; pl < 6; ++pl) w4[pl] = make_float4(bx[pl][0], bx[pl][1], bx[pl][2], bx[pl][3]);
         w4[6] = make_float4(__int_as_float(refs[0]), __int_as_float(refs[1]), __int_as_float(refs[2]), __int_as_float(refs[3]));
         w4[7] = make_float4(__uint_as_float(meta), 0.f, 0.f, 0.f);
@@ -471,7 +474,8 @@ __global__ __launch_bounds__(kBB) void k_pack_wide(int n, const iile_bvh_node *n
 }  // namespace
 
 // Validates the child indices and leaf ranges of a flattened tree on the host side of the caller (api.hip) before this.
-int pack_wide_records(const iile_bvh_node *d_nodes, int n_nodes, int n_interior, float4 *d_wide, float4 *d_wide4, int *nested_out) {
+int pack_wide_records(const iile_bvh_node *d_nodes, int n_nodes, int n_interior, float4 *d_wide, float4 *d_wide4, int *nested_out,
+                      const int *d_remap) {
     *nested_out = 1;
     if (n_nodes <= 0) return IILE_OK;
     Dev<int> flags, excl, bad;
@@ -485,7 +489,7 @@ int pack_wide_records(const iile_bvh_node *d_nodes, int n_nodes, int n_interior,
     Dev<char> tmp;
     HIP_TRYB(tmp.alloc(tmp_bytes));
     HIP_TRYB(rocprim::exclusive_scan(tmp.p, tmp_bytes, flags.p, excl.p, 0, size_t(n_nodes), rocprim::plus<int>(), nullptr));
-    hipLaunchKernelGGL(k_pack_wide, dim3(grid_for(n_nodes)), dim3(kBB), 0, nullptr, n_nodes, d_nodes, excl.p, d_wide, d_wide4, bad.p);
+    hipLaunchKernelGGL(k_pack_wide, dim3(grid_for(n_nodes)), dim3(kBB), 0, nullptr, n_nodes, d_nodes, excl.p, d_remap, d_wide, d_wide4, bad.p);
     HIP_TRYB(hipGetLastError());
     int not_nested = 0;
     HIP_TRYB(hipMemcpy(&not_nested, bad.p, sizeof(int), hipMemcpyDeviceToHost));

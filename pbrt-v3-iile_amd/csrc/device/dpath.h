@@ -673,6 +673,9 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
 // LDS pointers carry their address space explicitly so that pushes and pops
 // compile to ds_write_b32 / ds_read_b32 (a generic pointer would go through flat_*).
 typedef __attribute__((address_space(3))) int lds_int;
+#ifndef IILE_LEAF_LOAD3
+#define IILE_LEAF_LOAD3 0
+#endif
 #ifndef IILE_LEAF_ONE
 #define IILE_LEAF_ONE 1
 #endif
@@ -1135,7 +1138,16 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
     int prim = t.cur < 0 ? ~t.cur : 0;  // clamped like trav_interior's index; tri_verts has one pad record
     bool last;
     do {
+#if IILE_LEAF_LOAD3
+        // the primitive's three records in one round trip: the flag word (sphere? last of its leaf?) rides in the first one, and
+        // waiting for it before asking for the other two made every leaf step two dependent trips to memory
+        float4 v0 = S.tri_verts[3 * size_t(prim)];
+        float4 v1_ = S.tri_verts[3 * size_t(prim) + 1];
+        float4 v2_ = S.tri_verts[3 * size_t(prim) + 2];
+        asm volatile("" : "+v"(v0.w), "+v"(v1_.x), "+v"(v2_.x));  // (keeps the compiler from sinking the two loads behind the flag test)
+#else
         const float4 v0 = S.tri_verts[3 * size_t(prim)];
+#endif
         const uint32_t flags = f2b(v0.w);
         last = (flags & 16u) != 0;
         if (flags & 1u) {
@@ -1164,8 +1176,12 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
                 t.b0 = t.b1 = t.b2 = 0;
             }
         } else {
+#if IILE_LEAF_LOAD3
+            const float4 v1 = v1_, v2 = v2_;
+#else
             const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
             const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
+#endif
             if (COUNT) ++st->tris;
             float th, b0, b1, b2;
             if (triangle_test(t.rc, t.tmax, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, &th, &b0,

@@ -137,7 +137,20 @@ constexpr int kRefillIdle = IILE_REFILL_IDLE;  // refill once this many lanes ar
 struct WaveFeed {
     uint32_t cur, end;
     bool exhausted;
+    uint32_t tried = 0;  // IILE_XCD_FEED: partitions of the queue this wavefront has found empty (its own XCD's first)
 };
+// IILE_XCD_FEED: a queue is cut into eight contiguous partitions, one per XCD, each with a chunk cursor of its own; a wavefront
+// draws from the partition of the XCD it runs on and moves on to the next one when that is used up. Rays that are neighbours in a
+// queue (the same pixels, the same surfaces) then walk the tree behind ONE 4 MiB L2 instead of all eight.
+#ifndef IILE_XCD_FEED
+#define IILE_XCD_FEED 0
+#endif
+constexpr int kCntXcd = 144;  // [kind 0..2: extend, shadow, MIS][bounce 0..15][partition 0..7] chunk cursors (IILE_XCD_FEED)
+static_assert(kCntXcd + 3 * 16 * 8 <= kCntWords, "PassBuffers::counts layout");
+DEV uint32_t xcd_id() {
+    // XCC_ID hardware register (id 20), bits 0..3
+    return uint32_t(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 7u;
+}
 // `warm(first_slot)` is called once per new chunk: the wavefront touches every 128-byte
 // line of the chunk's records (lane l -> records first+8l .. first+8l+7), so the per-lane
 // refill loads that follow hit L2 instead of paying an HBM round trip each time a few
@@ -148,8 +161,26 @@ DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint3
     const uint32_t n_idle = uint32_t(__popcll(mask));
     if (f.cur == f.end) {
         uint32_t base = 0;
+#if IILE_XCD_FEED
+        // `head` = the eight partition cursors of this queue (counted in chunks)
+        const uint32_t n_chunks = (count + kChunk - 1) / kChunk, home = xcd_id();
+        base = count;
+        while (f.tried < 8) {
+            const uint32_t p = (home + f.tried) & 7u;
+            const uint32_t lo = uint32_t((uint64_t(n_chunks) * p) >> 3), hi = uint32_t((uint64_t(n_chunks) * (p + 1)) >> 3);
+            uint32_t c = 0;
+            if (lane_id() == 0) c = atomicAdd(head + p, 1u);
+            c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
+            if (c < hi - lo) {
+                base = (lo + c) * kChunk;
+                break;
+            }
+            ++f.tried;
+        }
+#else
         if (lane_id() == 0) base = atomicAdd(head, kChunk);
         base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+#endif
         if (base >= count) {
             f.exhausted = true;
             f.cur = f.end = 0;

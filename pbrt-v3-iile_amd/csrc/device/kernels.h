@@ -44,7 +44,7 @@ struct PassDesc {
 // pass plus the padding that block-reserved appends leave behind (kernels.hip).
 // shade-queue entries carry the shading class above the slot number
 constexpr int kSlotBits = 28;
-constexpr int kCntWords = 144;  // words of PassBuffers::counts (layout in kcommon.h)
+constexpr int kCntWords = 144 + 3 * 16 * 8;  // words of PassBuffers::counts (layout in kcommon.h)
 struct PassBuffers {
     uint32_t queue_cap;
     float4 *L;          // [n_paths] radiance so far (xyz)
@@ -102,8 +102,10 @@ struct LaunchCfg {
 // api.hip: records the message iile_last_error() returns, hands back `code`
 int api_fail(int code, const std::string &msg);
 // bvh_build.hip: two-wide (4 float4) and four-wide (8 float4) records per interior node of a flattened tree in HBM
-// (record index = rank of the node among the interior nodes); *nested_out = every child box lies inside its parent's
-int pack_wide_records(const iile_bvh_node *d_nodes, int n_nodes, int n_interior, float4 *d_wide, float4 *d_wide4, int *nested_out);
+// (record index = rank of the node among the interior nodes in depth-first order, or d_remap[rank] when a record order is
+// given: a permutation of [0, n_interior)); *nested_out = every child box lies inside its parent's
+int pack_wide_records(const iile_bvh_node *d_nodes, int n_nodes, int n_interior, float4 *d_wide, float4 *d_wide4, int *nested_out,
+                      const int *d_remap = nullptr);
 
 // slots a queue needs for n_paths paths
 uint32_t queue_capacity(uint32_t n_paths, int n_cus);

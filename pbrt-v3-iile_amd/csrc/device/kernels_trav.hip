@@ -5,6 +5,25 @@
 
 namespace iile {
 
+// Several interior steps per vote (IILE_INT_STEPS > 1): once the wavefront has voted for an interior step, the lanes that still
+// stand at an interior record take up to IILE_INT_STEPS - 1 more without going round the loop head (refill test, finish test,
+// two ballots and the vote), as long as three quarters of the lanes that voted are still walking; lanes that reached a leaf wait.
+#ifndef IILE_INT_STEPS
+#define IILE_INT_STEPS 1
+#endif
+#if IILE_INT_STEPS > 1
+#define IILE_MORE_INTERIOR_STEPS(STEP)                                       \
+    for (int more_ = 1; more_ < IILE_INT_STEPS; ++more_) {                   \
+        const bool wi2_ = active && t.have && t.cur >= 0;                    \
+        if (__popcll(__ballot(wi2_)) * 4 < n_int * 3) break;                 \
+        if (wi2_) STEP;                                                      \
+    }
+#else
+#define IILE_MORE_INTERIOR_STEPS(STEP) \
+    do {                               \
+    } while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // extend: BVHAccel::Intersect for every ray of queue `bounce & 1`; hits are
 // appended (ballot-compacted) to the shade queue.
@@ -23,7 +42,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
         sr.root = S.root_ref_top;
     }
     const uint32_t count = B.counts[kCntRay + bounce];
-    uint32_t *head = &B.counts[kCntExtHead + bounce];
+    uint32_t *head = IILE_XCD_FEED ? &B.counts[kCntXcd + (0 * 16 + bounce) * 8] : &B.counts[kCntExtHead + bounce];
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     TraceStats st = {0, 0, 0, 0};
     unsigned long long n_rays = 0, n_term = 0;
@@ -43,6 +62,23 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
     bool active = false;
     uint32_t slot = 0;
     float4 gen_d = make_float4(0, 0, 1, 0);  // GEN: the ray direction (the sphere test reads it back)
+#ifdef IILE_TRAV_ITERSTATS
+    // diagnostic build only (tools/trav_stamps.py iterstats): what the wavefronts of bounces >= 1 look like at each vote —
+    // [0] interior votes, [1] lanes stepping in them, [2] lanes waiting at a leaf meanwhile, [3] leaf votes, [4] lanes stepping,
+    // [5] lanes waiting at an interior record meanwhile, [6] idle lanes (no ray) summed over all votes, [7] refills
+    unsigned long long iter_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ITER_STAT(kind, n_go, n_wait)                                            \
+    do {                                                                         \
+        iter_stat[3 * (kind)] += 1;                                              \
+        iter_stat[3 * (kind) + 1] += uint32_t(n_go);                             \
+        iter_stat[3 * (kind) + 2] += uint32_t(n_wait);                           \
+        iter_stat[6] += uint32_t(64 - (n_go) - (n_wait));                        \
+    } while (0)
+#else
+#define ITER_STAT(kind, n_go, n_wait) \
+    do {                              \
+    } while (0)
+#endif
 #ifdef IILE_TRAV_STAMPS
     // diagnostic build only (tools/trav_stamps.py): wave cycles per section of the loop, summed per wavefront and added to
     // DCounters::path_length: the camera-ray build [0] refill + ray generation, [1] interior steps, [2] leaf steps,
@@ -66,6 +102,9 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
         // (the camera-ray build makes its rays here, some 400 instructions each: it waits for more idle lanes than the others)
         if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= (GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle) || idle_mask == ~0ull)) {
             uint32_t s_new;
+#ifdef IILE_TRAV_ITERSTATS
+            iter_stat[7] += 1;
+#endif
             if (feed_take(feed, head, count, !active, &s_new, warm)) {
                 slot = s_new;
                 if (GEN) {
@@ -127,8 +166,11 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
+                IILE_MORE_INTERIOR_STEPS(trav_step<COUNT>(S, t, sr, &st));
+                ITER_STAT(0, n_int, n_leaf);
                 TRAV_STAMP(1);
             } else if (n_leaf > 0) {
+                ITER_STAT(1, n_leaf, n_int);
                 if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, GEN ? &gen_d : &rd[slot]);
                 TRAV_STAMP(2);
             }
@@ -153,6 +195,10 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
 #ifdef IILE_TRAV_STAMPS
     if (!COUNT && (threadIdx.x & 63) == 0)
         for (int i = 0; i < 4; ++i) atomicAdd(&B.counters->path_length[(GEN ? 0 : 4) + i], stamp_sum[i]);
+#endif
+#ifdef IILE_TRAV_ITERSTATS
+    if (!COUNT && !GEN && (threadIdx.x & 63) == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&B.counters->path_length[i], iter_stat[i]);
 #endif
     flush_counter(&B.counters->ext_traced, n_rays);  // every build: the uninstrumented pass leaves out rays that cannot matter
     if (COUNT) {
@@ -192,7 +238,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
         sr.root = S.root_ref_top;
     }
     const uint32_t count = B.counts[kCntNee + bounce];
-    uint32_t *head = &B.counts[kCntConHead + bounce];
+    uint32_t *head = IILE_XCD_FEED ? &B.counts[kCntXcd + (1 * 16 + bounce) * 8] : &B.counts[kCntConHead + bounce];
     TraceStats st = {0, 0, 0, 0};
     unsigned long long n_shadow = 0, n_zero = 0;
     WaveFeed feed{0, 0, count == 0};
@@ -296,6 +342,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT, true>(S, t, sr, &st);
+                IILE_MORE_INTERIOR_STEPS((trav_step<COUNT, true>(S, t, sr, &st)));
                 SHADOW_STAMP(1);
             } else if (n_leaf > 0) {
                 if (wl && trav_leaf<COUNT, ALPHA>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
@@ -345,7 +392,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
     }
     // the dense queue of MIS rays k_shade wrote beside the NEE records: (o, record) in plane 2, (d, light) in plane 3
     const uint32_t count = B.counts[kCntMis + bounce];
-    uint32_t *head = &B.counts[kCntMisHead + bounce];
+    uint32_t *head = IILE_XCD_FEED ? &B.counts[kCntXcd + (2 * 16 + bounce) * 8] : &B.counts[kCntMisHead + bounce];
     TraceStats st = {0, 0, 0, 0};
     unsigned long long n_closest = 0, n_traced = 0;
     WaveFeed feed{0, 0, count == 0};
@@ -390,6 +437,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
+                IILE_MORE_INTERIOR_STEPS(trav_step<COUNT>(S, t, sr, &st));
             } else if (n_leaf > 0) {
                 if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * size_t(plane) + q]);
             }

@@ -11,8 +11,10 @@ network runs once over the whole batch.
   (double sums for the means, `log(1.0 + v)` / `exp(v) - 1.0` in double, everything else in float).
 * `IISPTNet`: the U-Net of `ml/iispt_net.py:8-109` (K = 64; 7 -> 3 channels at 32 x 32). Its `state_dict` has the
   reference's parameter names and shapes, so a checkpoint trained with the reference's `ml/main_train.py` loads
-  unchanged. **No weights ship with the reference**: with random weights the output means nothing, and parity of
-  this stage is unpinned beyond the transforms (tests/test_iispt_nn.py) and the checkpoint-compatible layout.
+  unchanged. **No weights ship with the reference**: with random weights the output means nothing; what is pinned is the
+  function — `tests/golden/iispt_net_fixture.npz` holds a forward of the REFERENCE's module (imported in the build
+  container, weights from the recipe of tests/iispt_net_recipe.py) and the pipe's wire order as `read_input` /
+  `output_to_stdout` of `ml/main_stdio_net.py:47-86` produce it; this module must reproduce both (tests/test_iispt_nn.py).
 
 Image layout: the reference's `ImageFilm` stores raster row y at index h - 1 - y (`src/film/imagefilm.cpp:26-31`,
 `src/core/film.cpp:245-254`) and the network was trained on that; `iile_render_probes` returns raster order.
@@ -75,6 +77,19 @@ class IISPTNet(nn.Module):
         return self.decoder2(torch.cat((y, e0), 1))
 
 
+def wire_to_network_input(intensity, normals, distance):
+    """The pipe's layout -> the network's (`read_input`, ml/main_stdio_net.py:47-72): three images as the runner writes them,
+    (n, h, w, 3), (n, h, w, 3) and (n, h, w) in ImageFilm row order, become (n, 7, h, w): intensity RGB, normal XYZ,
+    distance. Pinned against the reference's own function by tests/golden/iispt_net_fixture.npz."""
+    x7 = torch.cat((intensity, normals, distance.unsqueeze(-1)), -1)
+    return x7.permute(0, 3, 1, 2).contiguous()
+
+
+def network_output_to_wire(out):
+    """`output_to_stdout` (ml/main_stdio_net.py:77-86): the network's (n, 3, h, w) goes back as (n, h, w, 3)."""
+    return out.permute(0, 2, 3, 1)
+
+
 def normalize_downstream(intensity, normals, distance):
     """normalizeMapsDownstream, batched: intensity (n, h, h, 3), normals (n, h, h, 3), distance (n, h, h) in raster
     order -> network input (n, 7, h, h) float32 in the reference's row order, and the per-probe channel means
@@ -96,9 +111,8 @@ def normalize_downstream(intensity, normals, distance):
     d = d * (1.0 / div.double()).float().view(n, 1, 1)
     d = torch.log(1.0 + torch.clamp(d, min=0).double()).float()
     d = d + torch.tensor(-0.1, dtype=torch.float32, device=d.device)
-    x7 = torch.cat((x, nrm, d.unsqueeze(-1)), -1)                            # (n, h, h, 7), raster rows
-    x7 = torch.flip(x7, dims=(1,))                                           # ImageFilm row = h - 1 - y
-    return x7.permute(0, 3, 1, 2).contiguous(), chan_mean                   # (channels, height, width) per probe
+    # ImageFilm row = h - 1 - y; then the pipe's (h, w, c) images become (channels, height, width) per probe
+    return wire_to_network_input(torch.flip(x, dims=(1,)), torch.flip(nrm, dims=(1,)), torch.flip(d, dims=(1,))), chan_mean
 
 
 def transform_upstream(out, chan_mean):
@@ -110,7 +124,7 @@ def transform_upstream(out, chan_mean):
     actual = y.double().reshape(n, 3, -1).mean(2).float()                   # computeMeanChannels
     mul = torch.where(actual > 1e-10, chan_mean / actual, torch.zeros_like(actual))
     y = y * mul.view(n, 3, 1, 1)
-    return torch.flip(y.permute(0, 2, 3, 1), dims=(1,)).contiguous()
+    return torch.flip(network_output_to_wire(y), dims=(1,)).contiguous()
 
 
 class IisptPipeline:

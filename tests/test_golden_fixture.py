@@ -1,6 +1,7 @@
-"""Committed golden vectors (tests/golden/c1_golden.npz, made by make_golden.py from the
-reference-pinned oracle): the oracle must keep reproducing them (CPU), and the HIP path must
-match them without the oracle in the loop (GPU)."""
+"""Oracle self-consistency, not a second witness: tests/golden/c1_golden.npz was written by make_golden.py from this
+repository's own oracle (itself pinned to the reference elsewhere: tests/test_oracle_pins.py). What these tests guard is
+drift — the oracle must keep reproducing what it produced when the fixture was made (CPU), and the HIP path must match
+the same vectors without the oracle in the loop on the GPU box."""
 import hashlib
 import os
 
@@ -12,7 +13,7 @@ import oracle_binding as ob
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_golden.npz"))
 
 
-def test_oracle_reproduces_golden_vectors(oracle, scene_c1):
+def test_oracle_self_consistency_with_its_stored_vectors(oracle, scene_c1):
     L, nr = oracle.li(scene_c1, G["px"], G["py"], G["k"], trig_mode=ob.TRIG_PORTABLE)
     assert np.array_equal(L.view(np.uint32), G["L_portable"].view(np.uint32))
     assert np.array_equal(nr, G["nrays"])

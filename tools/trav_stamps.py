@@ -26,8 +26,24 @@ else:
 gpu = b.GpuScene(scene)
 gpu.render()
 _, st = gpu.render(want_stats=True, time_kernels=2)
-names = ["refill (+ camera-ray generation at bounce 0)", "interior steps", "leaf steps", "finish + shade-queue append + loop head"]
 cyc = [int(x) for x in st["path_length"]]
+if "iterstats" in sys.argv[1:]:
+    # the build made with -DIILE_TRAV_ITERSTATS: k_extend's votes at bounces >= 1 (kernels_trav.hip, ITER_STAT)
+    iv, il, ilw, lv, ll, lw, idle, refills = cyc
+    votes = max(1, iv + lv)
+    print(json.dumps({
+        "ms_extend_one_stream": st["ms_extend"],
+        "votes": {"interior": iv, "leaf": lv, "interior_share": round(iv / votes, 4)},
+        "lanes_stepping_per_interior_vote": round(il / max(1, iv), 2),
+        "lanes_waiting_at_a_leaf_per_interior_vote": round(ilw / max(1, iv), 2),
+        "lanes_stepping_per_leaf_vote": round(ll / max(1, lv), 2),
+        "lanes_waiting_at_an_interior_record_per_leaf_vote": round(lw / max(1, lv), 2),
+        "idle_lanes_per_vote": round(idle / votes, 2),
+        "refill_rounds": refills,
+        "votes_per_refill_round": round(votes / max(1, refills), 1),
+    }, indent=1))
+    sys.exit(0)
+names = ["refill (+ camera-ray generation at bounce 0)", "interior steps", "leaf steps", "finish + shade-queue append + loop head"]
 out = {"ms_extend_one_stream": st["ms_extend"], "ms_shadow_one_stream": st["ms_shadow"]}
 for label, part in ((("k_shadow, all bounces", cyc[0:4]),) if shadow else (("bounce 0 (camera-ray build)", cyc[0:4]), ("bounces >= 1", cyc[4:8]))):
     tot = sum(part) or 1
