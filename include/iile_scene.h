@@ -136,7 +136,10 @@ typedef struct iile_light {
     float cos_total_width, cos_falloff_start; /* spot */
     float world_radius; /* distant: radius of the scene's bounding sphere (Light::Preprocess, distant.cpp:63-65) */
     int32_t prim;       /* triangle area light: its primitive, in BVH order */
-    int32_t pad;
+    /* Light::nSamples (area and infinite lights: "samples" / "nsamples", diffuse.cpp:140-141, infinite.cpp:181-182; 0 means 1).
+     * The path integrator never looks at it (UniformSampleOneLight); the IISPT direct pass's UniformSampleAllLights does
+     * (integrator.cpp:54-83) and is built for 1 only: iile_render_direct rejects a scene where it is larger. */
+    int32_t n_samples;
     /* infinite: lemit is L * scale; w2l as for the spot light; world_radius as for the distant light; and */
     float l2w[9];       /* upper 3x3 of LightToWorld, row major */
     /* Lmap (infinite.cpp:49-63): index into iile_scene_desc::textures of the pyramid of the environment map

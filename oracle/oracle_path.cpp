@@ -2584,8 +2584,9 @@ struct Oracle {
     // (iisptrenderrunner.cpp:601-633), with the sampler CreateIISPTIntegrator makes (iispt.cpp:813-816): a RandomSampler of
     // PbrtOptions.iileDirectSamples = 16 samples per pixel (pbrt.h:178), cloned per runner thread with seed
     // 6284 + 17 * thread_no. preprocess() requests, for each of maxDepth = 5 levels and each light, two 2D arrays of
-    // nLightSamples = RoundCount(light->nSamples) = 1 entry per pixel sample; RenderOnePass calls StartPixel for every pixel
-    // of every pass and never StartNextSample, so each pixel reads entry 0 of every array and is a fresh draw per pass.
+    // nLightSamples = RoundCount(light->nSamples) entries per pixel sample (killeroo-simple's area light: "nsamples" 8; round 3
+    // assumed 1 everywhere, which its advisor caught); RenderOnePass calls StartPixel for every pixel of every pass and never
+    // StartNextSample, so each pixel reads the first nLightSamples entries of every array and is a fresh draw per pass.
     //
     // Random numbers: the reference's RandomSampler is ONE PCG32 stream per thread, consumed pixel after pixel (arrays, camera
     // sample, Li), and which thread renders which pass is a race (getNextDirectPass) — its image is not a function of its
@@ -2597,20 +2598,25 @@ struct Oracle {
     struct DirectSampler {
         static constexpr int kSpp = 16, kMaxDepth = 5;
         Pcg rng;
-        std::vector<float> entry0;  // per 2D array: its entry for pixel sample 0
-        size_t array_offset = 0;    // Sampler::array2DOffset
-        DirectSampler(uint64_t seq, int n_lights) : rng(seq) {
-            const int n_arrays = kMaxDepth * n_lights * 2;
-            entry0.resize(size_t(2 * n_arrays));
-            for (int i = 0; i < n_arrays; ++i)
-                for (int j = 0; j < kSpp; ++j) {  // sampleArray2D[i][j] = {rng.UniformFloat(), rng.UniformFloat()}
-                    const float x = rng.uniform_float(), y = rng.uniform_float();
-                    if (j == 0) entry0[size_t(2 * i)] = x, entry0[size_t(2 * i + 1)] = y;
-                }
+        std::vector<float> entry0;   // per 2D array: its entries for pixel sample 0 (the first nSamples of its 16 x nSamples)
+        std::vector<size_t> start;   // per 2D array: where they begin in entry0
+        size_t array_offset = 0;     // Sampler::array2DOffset
+        // n_samples[l] = nLightSamples of light l (Light::nSamples, RoundCount is the identity for a RandomSampler)
+        DirectSampler(uint64_t seq, int n_lights, const int *n_samples) : rng(seq) {
+            for (int d = 0; d < kMaxDepth; ++d)
+                for (int l = 0; l < n_lights; ++l)
+                    for (int rep = 0; rep < 2; ++rep) {  // Request2DArray(nLightSamples[j]) twice, preprocess()
+                        const int n = n_samples[l];
+                        start.push_back(entry0.size());
+                        for (int j = 0; j < n * kSpp; ++j) {  // sampleArray2D[i][j] = {rng.UniformFloat(), rng.UniformFloat()}
+                            const float x = rng.uniform_float(), y = rng.uniform_float();
+                            if (j < n) entry0.push_back(x), entry0.push_back(y);
+                        }
+                    }
         }
-        const float *get2d_array() {  // Sampler::Get2DArray(1), sampler.cpp:97-102, currentPixelSampleIndex = 0
-            if (array_offset == entry0.size() / 2) return nullptr;
-            return &entry0[2 * array_offset++];
+        const float *get2d_array() {  // Sampler::Get2DArray(n), sampler.cpp:97-102, currentPixelSampleIndex = 0
+            if (array_offset == start.size()) return nullptr;
+            return entry0.data() + start[array_offset++];
         }
         float get1d() { return rng.uniform_float(); }
         void get2d(float *u) {
@@ -2619,8 +2625,9 @@ struct Oracle {
         }
     };
     // BSDF::Sample_f(wo, &wi, u, &pdf, BSDF_REFLECTION | BSDF_SPECULAR) (reflection.cpp:719-784): of the lobes built here only
-    // SpecularReflection matches that type (FresnelSpecular is REFLECTION | TRANSMISSION | SPECULAR and does not: glass adds
-    // nothing to the direct pass beyond its direct lighting, which is none). One matching lobe: the remapped u is not used.
+    // SpecularReflection matches that type. (Glass never gets here: with allowMultipleLobes = false it would carry separate
+    // reflection and transmission lobes and Li would branch; oracle_iispt_direct rejects scenes with glass.)
+    // One matching lobe: the remapped u is not used.
     Rgb sample_specular_reflection(const Bsdf &b, V3 woW, V3 *wiW, float *pdf) const {
         *pdf = 0;
         if (!b.has_spec || b.spec_glass) return Rgb(0.f);  // matchingComps == 0
@@ -2637,7 +2644,7 @@ struct Oracle {
     Rgb uniform_sample_all_lights(const Isect &it, const Bsdf &bsdf, DirectSampler &smp) const {
         Rgb L(0.f);
         for (int j = 0; j < S.n_lights; ++j) {
-            const int n_samples = 1;
+            const int n_samples = std::max(1, int(S.lights[j].n_samples));
             const float *u_light_array = smp.get2d_array();
             const float *u_scattering_array = smp.get2d_array();
             if (!u_light_array || !u_scattering_array) {
@@ -2695,7 +2702,9 @@ struct Oracle {
     }
     // one pixel of one pass: RenderOnePass's loop body (:84-140); returns false outside the pixel bounds
     Rgb direct_pixel(int px, int py, int pass, int rank) const {
-        DirectSampler smp((uint64_t(6284 + 17 * pass) << 32) + uint64_t(rank), S.n_lights);
+        int n_samples[64];
+        for (int l = 0; l < S.n_lights && l < 64; ++l) n_samples[l] = std::max(1, int(S.lights[l].n_samples));
+        DirectSampler smp((uint64_t(6284 + 17 * pass) << 32) + uint64_t(rank), std::min(S.n_lights, 64), n_samples);
         float u[2], plens[2];
         smp.get2d(u);   // GetCameraSample: pFilm = pixel + Get2D(), time = Get1D(), pLens = Get2D()
         smp.get1d();
@@ -3689,11 +3698,16 @@ extern "C" {
 // The IISPT direct pass into a film monitor (IisptFilmMonitor::add_n_samples, iisptfilmmonitor.cpp:47-72: doubles): n_passes
 // passes of DirectProgressiveIntegrator::RenderOnePass, pass p seeded as described at DirectSampler, added in pass order into
 // film_rgbw[(y * w + x) * 4] = {sum r, sum g, sum b, sum of ray weights} over the film's cropped pixel bounds (zeroed first).
-// 0 = ok, 1 = bad arguments, 3 = image textures together with specular reflection lobes (reflected rays' differentials).
+// 0 = ok, 1 = bad arguments, 3 = image textures together with specular reflection lobes (reflected rays' differentials),
+// 4 = glass: DirectProgressiveIntegrator::Li calls ComputeScatteringFunctions with allowMultipleLobes = false
+// (interaction.h:130-133), so GlassMaterial adds SpecularReflection + SpecularTransmission (glass.cpp:62-90) and Li recurses
+// through both — a tree this restatement (a chain per pixel) does not walk; round 3 rendered such surfaces black, which was wrong.
 int oracle_iispt_direct(const iile_scene_desc *scene, int trig_mode, int n_passes, int first_pass, int n_threads, double *film_rgbw) {
     if (!scene || !film_rgbw || n_passes < 0) return 1;
     const iile_scene_desc &S = *scene;
     const iile_film_desc &F = S.film;
+    for (int m = 0; m < S.n_materials; ++m)
+        if (S.materials[m].type == IILE_MAT_GLASS) return 4;
     if (S.n_textures > 0)
         for (int m = 0; m < S.n_materials; ++m)
             if (S.materials[m].type == IILE_MAT_MIRROR || (S.materials[m].type == IILE_MAT_UBER && (S.materials[m].kr[0] > 0 || S.materials[m].kr[1] > 0 || S.materials[m].kr[2] > 0)))

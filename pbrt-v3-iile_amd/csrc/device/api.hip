@@ -53,6 +53,7 @@ struct iile_scene {
     int n_cus = 256;
     int max_depth = 5;
     int spp = 1;
+    int light_samples[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // Light::nSamples (iile_light::n_samples), the direct pass's nLightSamples
     // wavefront workspace, grown on demand and kept across renders
     uint32_t ws_paths = 0;
     uint64_t ws_bytes = 0;
@@ -974,6 +975,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     S.max_depth = d->integrator.max_depth;
     S.rr_threshold = d->integrator.rr_threshold;
     sc->max_depth = d->integrator.max_depth;
+    for (int i = 0; i < d->n_lights && i < 8; ++i) sc->light_samples[i] = std::max(1, int(d->lights[i].n_samples));
     {
         void *p = nullptr;
         if (hipMalloc(&p, size_t(max_traversal_threads(sc->n_cus)) * sizeof(int)) != hipSuccess)
@@ -1651,7 +1653,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
                 copy_counters(c, &st);
             else
                 st.mis_rays_traced = c.mis_traced, st.ext_rays_traced = c.ext_traced;
-#if defined(IILE_SHADE_STAMPS) || defined(IILE_TRAV_STAMPS) || defined(IILE_SHADOW_STAMPS)
+#if defined(IILE_SHADE_STAMPS) || defined(IILE_TRAV_STAMPS) || defined(IILE_SHADOW_STAMPS) || defined(IILE_TRAV_ITERSTATS)
             // diagnostic builds (tools/shade_stamps.py, tools/trav_stamps.py): per-section wave cycles ride out in the path-length histogram
             if (!prm->collect_stats)
                 for (int i = 0; i < 8; ++i) st.path_length[i] = c.path_length[i];
@@ -1673,6 +1675,10 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     if (S.textured_materials && S.has_specular)
         return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: image textures together with specular lobes (the reflected ray's differentials)");
     if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
+    // DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), so GlassMaterial
+    // adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and BOTH SpecularReflect and SpecularTransmit
+    // recurse: Li is a tree there, which this pass (a chain per pixel) does not walk. Rejected rather than rendered black.
+    if (S.has_glass) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: glass (the direct integrator's reflection + transmission recursion tree) is not built");
     S.diff_scale = 0.25f;  // ScaleDifferentials(1 / sqrt(16)): the RandomSampler's samples per pixel
     hipStream_t stream = static_cast<hipStream_t>(prm->stream);
     LaunchCfg cfg{sc->n_cus, stream, false};
@@ -1694,14 +1700,29 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     const uint32_t fw = uint32_t(S.crop_x1 - S.crop_x0), fh = uint32_t(S.crop_y1 - S.crop_y0);
     const size_t film_bytes = size_t(fw) * fh * 4 * sizeof(double);
     if (P.n_paths == 0 || fw == 0 || fh == 0) return IILE_OK;
-    rc = ensure_workspace(sc, P.n_paths);
+    // k_direct_shade appends one NEE record (and at most one MIS ray) per LIGHT and hit (UniformSampleAllLights), where the path
+    // integrator's k_shade appends one per hit: the record planes are sized for paths x lights (a workspace sized for the
+    // paths alone overflowed from 4 lights on at 1080p; found by the round-3 advisor)
+    // UniformSampleAllLights takes Light::nSamples samples of every light (directprogressiveintegrator.cpp:9-18, integrator.cpp:54-83)
+    const int n_lights = std::max(S.n_lights, 0), n_arrays = 5 * n_lights * 2;
+    int total_samples = 0;
+    for (int l = 0; l < n_lights && l < 8; ++l) {
+        P.direct_nsamples[l] = std::max(1, sc->light_samples[l]);
+        total_samples += P.direct_nsamples[l];
+    }
+    P.direct_total_samples = total_samples;
+    if (total_samples > 64)
+        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: " + std::to_string(total_samples) + " light samples per vertex (the lights' nsamples summed; at most 64)");
+    const uint64_t n_records64 = n_paths64 * uint64_t(std::max(total_samples, 1));
+    if (n_records64 > 400000000ull)
+        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: pixels x light samples = " + std::to_string(n_records64) + " NEE records per level exceed one pass");
+    rc = ensure_workspace(sc, uint32_t(n_records64));
     if (rc) return rc;
     sc->pb.nray_out = nullptr;
     sc->pb.flag_count = nullptr;
-    // E, F (5 levels) and D (5 levels x lights) of every path, the PCG jump table, the film
-    const int n_lights = std::max(S.n_lights, 0), n_arrays = 5 * n_lights * 2;
+    // E, F (5 levels) and D (5 levels x light samples) of every path, the PCG jump table, the film
     const size_t np = P.n_paths, vec = sizeof(float4);
-    const size_t d_bytes = std::max<size_t>(size_t(5) * size_t(n_lights) * np * vec, vec), ef_bytes = size_t(5) * np * vec;
+    const size_t d_bytes = std::max<size_t>(size_t(5) * size_t(total_samples) * np * vec, vec), ef_bytes = size_t(5) * np * vec;
     const size_t jump_bytes = (size_t(n_arrays) + 1) * 2 * sizeof(unsigned long long);
     DevBuf<char> block;
     {
@@ -1720,14 +1741,16 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     unsigned long long *jump_dev = reinterpret_cast<unsigned long long *>(at);
     at += (jump_bytes + 255) & ~size_t(255);
     double *film_dev = prm->film_on_device ? film_rgbw : reinterpret_cast<double *>(at);
-    {   // the stream 32 i draws on: every array holds 16 entries of two floats (RandomSampler::StartPixel, random.cpp:62-72)
+    {   // the stream at every array's first entry: array i (of light (i / 2) % n_lights) holds 16 x nSamples entries of two
+        // floats (RandomSampler::StartPixel, random.cpp:62-72; Request2DArray(nLightSamples[j]) twice per level and light)
         std::vector<unsigned long long> jump(size_t(n_arrays + 1) * 2);
         const unsigned long long a = 0x5851f42d4c957f2dULL;
         unsigned long long A = 1, G = 0;
         for (int i = 0; i <= n_arrays; ++i) {
             jump[2 * size_t(i)] = A;
             jump[2 * size_t(i) + 1] = G;
-            for (int s = 0; s < 32; ++s) {  // one more draw: state' = a state + inc
+            const int draws = i < n_arrays ? 32 * P.direct_nsamples[(i / 2) % std::max(n_lights, 1)] : 0;
+            for (int s = 0; s < draws; ++s) {  // one more draw: state' = a state + inc
                 G = G * a + 1;
                 A = A * a;
             }

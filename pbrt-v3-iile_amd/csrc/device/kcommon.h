@@ -138,7 +138,34 @@ struct WaveFeed {
     uint32_t cur, end;
     bool exhausted;
     uint32_t tried = 0;  // IILE_XCD_FEED: partitions of the queue this wavefront has found empty (its own XCD's first)
+    uint32_t waste = 0;  // lane-steps lost to idle lanes since the last refill (refill_due)
 };
+// When to refill. A refill runs with only the idle lanes active and costs the wavefront a fixed number of steps whatever
+// their number, so it should wait for a batch of them; every step it waits costs one lane-step per idle lane. With rays
+// finishing at a rate of r lanes per step the cheapest batch is sqrt(2 C r) lanes (C = the refill's cost in lane-steps: the
+// economic-order-quantity rule) — 32 for killeroo-simple's short rays (5.5 votes between refills), about 10 for the deep
+// room's long ones (52 votes) — and it is reached exactly when the lane-steps wasted since the last refill add up to C,
+// which needs no estimate of r: the wavefront sums its idle lanes step by step and refills when the sum reaches `waste_max`
+// (or, as before, at `idle_min` idle lanes when waste_max is 0).
+#ifndef IILE_REFILL_WASTE
+#define IILE_REFILL_WASTE 0
+#endif
+#ifndef IILE_REFILL_WASTE_GEN
+#define IILE_REFILL_WASTE_GEN 0
+#endif
+DEV bool refill_due(unsigned long long idle_mask, WaveFeed &f, int idle_min, uint32_t waste_max) {
+    if (f.exhausted || idle_mask == 0) return false;
+    const uint32_t n_idle = uint32_t(__popcll(idle_mask));
+    bool due;
+    if (waste_max > 0) {
+        f.waste += n_idle;
+        due = f.waste >= waste_max || idle_mask == ~0ull;
+        if (due) f.waste = 0;
+    } else {
+        due = int(n_idle) >= idle_min || idle_mask == ~0ull;
+    }
+    return due;
+}
 // IILE_XCD_FEED: a queue is cut into eight contiguous partitions, one per XCD, each with a chunk cursor of its own; a wavefront
 // draws from the partition of the XCD it runs on and moves on to the next one when that is used up. Rays that are neighbours in a
 // queue (the same pixels, the same surfaces) then walk the tree behind ONE 4 MiB L2 instead of all eight.

@@ -38,7 +38,12 @@ struct PassDesc {
     uint32_t direct_seed;
     int direct_arrays;
     const unsigned long long *direct_jump;
+    // Light::nSamples per light (directprogressiveintegrator.cpp:9-18: nLightSamples; killeroo-simple's area light says 8) and
+    // their sum: UniformSampleAllLights makes that many EstimateDirect calls per vertex, each with a result slot of its own
+    int direct_nsamples[8];
+    int direct_total_samples;
 };
+static_assert(kMaxLights <= 8, "PassDesc::direct_nsamples");
 
 // Queue arrays (ray_o/ray_d/hits/shade_q/nee) hold `queue_cap` slots: the paths of a
 // pass plus the padding that block-reserved appends leave behind (kernels.hip).

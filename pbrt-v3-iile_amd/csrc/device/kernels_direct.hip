@@ -8,15 +8,17 @@
 // One pass = one camera sample per pixel through the wavefront pipeline of the path integrator, with three kernels of its own:
 //   k_direct_generate   camera sample from the pixel's PCG32 stream (behind the 2D arrays StartPixel fills first)
 //   [k_extend]          closest hit, as ever
-//   k_direct_shade      one vertex of Li: Le -> E[depth], one EstimateDirect per light -> NEE records whose results the
-//                       ordinary k_mis / k_mis_lit / k_shadow leave in D[depth * n_lights + light], the mirror direction
+//   k_direct_shade      one vertex of Li: Le -> E[depth], nSamples EstimateDirect calls per light -> NEE records whose results the
+//                       ordinary k_mis / k_mis_lit / k_shadow leave in D[depth * (sum of nSamples) + sample], the mirror direction
 //                       (SpecularReflect) -> F[depth] and the next ray
 //   k_direct_fold       L = ((Le + sum of the lights' Ld) + f * L(next vertex) * |cos| / pdf) + 0 from the deepest vertex
 //                       back to the camera — the recursion's own order of float operations —, the render loop's radiance
 //                       guards, IisptFilmMonitor::add_n_samples in double precision
-// Li's recursion is a chain here, never a tree: of the lobes this build knows only SpecularReflection matches
-// BSDF_REFLECTION | BSDF_SPECULAR and none matches BSDF_TRANSMISSION | BSDF_SPECULAR (FresnelSpecular is both at once and
-// matches neither), so SpecularTransmit always returns 0.
+// Li's recursion is a chain here, never a tree: of the lobes of matte / plastic / uber (Kr) / mirror only SpecularReflection
+// matches BSDF_REFLECTION | BSDF_SPECULAR and none matches BSDF_TRANSMISSION | BSDF_SPECULAR, so SpecularTransmit returns 0.
+// Glass would branch — Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), GlassMaterial then adds a
+// SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and both recursions fire —: iile_render_direct rejects
+// scenes with glass (round 3 rendered them black beyond their direct light, which the round-3 advisor showed to be wrong).
 #include "kcommon.h"
 
 namespace iile {
@@ -62,7 +64,8 @@ DEV F3 area_light_L(const DLight &lt, F3 n, F3 w) {  // DiffuseAreaLight::L, lig
 
 }  // namespace
 
-// jump[2 i], jump[2 i + 1]: the stream 32 i draws on (array i's first entry); entry n_arrays: the camera sample
+// jump[2 i], jump[2 i + 1]: the stream at array i's first entry (the arrays before it hold 16 x nSamples entries of two draws
+// each: RandomSampler::StartPixel, random.cpp:62-72); entry n_arrays: the camera sample
 __global__ __launch_bounds__(kBlock) void k_direct_generate(DScene S, PassDesc P, PassBuffers B) {
     for (uint32_t pid = blockIdx.x * kBlock + threadIdx.x; pid < P.n_paths; pid += gridDim.x * kBlock) {
         int px = 0, py = 0;
@@ -152,16 +155,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
             }
             lit_surface = n_nonspec(bsdf) > 0;
         }
-        // UniformSampleAllLights (integrator.cpp:54-83): every light once, its two samples from the arrays the pixel's stream
-        // filled first (array 2 c: uLight, 2 c + 1: uScattering, c = depth * n_lights + light: the c-th pair of Get2DArray calls)
+        // UniformSampleAllLights (integrator.cpp:54-83): every light nSamples times, sample k from entry k of the two arrays the
+        // pixel's stream filled first for it (array 2 c: uLight, 2 c + 1: uScattering, c = depth * n_lights + light: the c-th pair
+        // of Get2DArray calls; pixel sample 0 reads the arrays' first nSamples entries)
+        int sample_slot = depth * P.direct_total_samples;  // result slot of (depth, light, k) in D
         for (int li = 0; li < S.n_lights; ++li) {
+          const int c = depth * S.n_lights + li;
+          DPcg ra{0, 1}, rb{0, 1};
+          if (valid && lit_surface) {
+              ra = pcg_at(stream, P.direct_jump, 2 * c);
+              rb = pcg_at(stream, P.direct_jump, 2 * c + 1);
+          }
+          for (int ks = 0; ks < P.direct_nsamples[li]; ++ks, ++sample_slot) {
             bool emit_nee = false;
             F3 so = F3{0, 0, 0}, sd = F3{0, 0, 1}, mo = F3{0, 0, 0}, md = F3{0, 0, 1}, A = F3{0, 0, 0}, Bc = F3{0, 0, 0};
             uint32_t nee_flags = 0;
-            const int c = depth * S.n_lights + li;
             if (valid && lit_surface) {
                 const DLight &lt = S.lights[li];
-                DPcg ra = pcg_at(stream, P.direct_jump, 2 * c), rb = pcg_at(stream, P.direct_jump, 2 * c + 1);
                 const float ul0 = pcg_float(ra), ul1 = pcg_float(ra), us0 = pcg_float(rb), us1 = pcg_float(rb);
                 if (lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
                     // EstimateDirect for a delta light (integrator.cpp:150-166): light sample only. PointLight (lights/point.cpp:
@@ -247,8 +257,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
             const bool emit_mis = emit_nee && (nee_flags & NEE_HAS_MIS) != 0;
             const uint32_t mslot = out_take(mis_out, &B.counts[kCntMis + depth], emit_mis, pad_mis);
             if (emit_nee) {
-                // the record's "path" is the slot of D this light's result belongs in: k_shadow stores L[that] = 0 + 1 * Ld
-                const uint32_t dslot = uint32_t(c) * B.dir_paths + pid;
+                // the record's "path" is the slot of D this light sample's result belongs in: k_shadow stores L[that] = 0 + 1 * Ld
+                const uint32_t dslot = uint32_t(sample_slot) * B.dir_paths + pid;
                 B.nee[eslot] = make_float4(so.x, so.y, so.z, 1.f);
                 B.nee[plane + eslot] = make_float4(sd.x, sd.y, sd.z, b2f(nee_flags));
                 if (nee_flags & NEE_HAS_MIS) {
@@ -264,6 +274,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
                 B.nee[2 * plane + mslot] = make_float4(mo.x, mo.y, mo.z, b2f(eslot));
                 B.nee[3 * plane + mslot] = make_float4(md.x, md.y, md.z, b2f(uint32_t(li)));
             }
+          }
         }
         // SpecularReflect (directprogressiveintegrator.cpp:134-190): BSDF::Sample_f(wo, &wi, Get2D(), &pdf, BSDF_REFLECTION |
         // BSDF_SPECULAR) finds a SpecularReflection lobe or nothing (its sample is not used; pdf = 1)
@@ -311,11 +322,14 @@ __global__ __launch_bounds__(kBlock) void k_direct_fold(DScene S, PassDesc P, Pa
             F3 L = F3{0, 0, 0};
             L = L + F3{e4.x, e4.y, e4.z};  // L += isect.Le(wo)
             F3 all = F3{0, 0, 0};          // UniformSampleAllLights' own L(0.f)
+            int sample_slot = d * P.direct_total_samples;
             for (int li = 0; li < S.n_lights; ++li) {
-                const float4 d4 = B.L[size_t(d * S.n_lights + li) * B.dir_paths + pid];
                 F3 Ld = F3{0, 0, 0};
-                Ld = Ld + F3{d4.x, d4.y, d4.z};
-                all = all + sdiv(Ld, 1.f);  // L += Ld / nSamples
+                for (int ks = 0; ks < P.direct_nsamples[li]; ++ks, ++sample_slot) {  // Ld += EstimateDirect(.., uScatteringArray[k], .., uLightArray[k], ..)
+                    const float4 d4 = B.L[size_t(sample_slot) * B.dir_paths + pid];
+                    Ld = Ld + F3{d4.x, d4.y, d4.z};
+                }
+                all = all + sdiv(Ld, float(P.direct_nsamples[li]));  // L += Ld / nSamples
             }
             if (S.n_lights > 0) L = L + all;
             if (d + 1 < 5) {

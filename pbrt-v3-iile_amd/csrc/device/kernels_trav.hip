@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
         TRAV_STAMP(3);
         const unsigned long long idle_mask = __ballot(!active);
         // (the camera-ray build makes its rays here, some 400 instructions each: it waits for more idle lanes than the others)
-        if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= (GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle) || idle_mask == ~0ull)) {
+        if (refill_due(idle_mask, feed, GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle, GEN ? IILE_REFILL_WASTE_GEN : IILE_REFILL_WASTE)) {
             uint32_t s_new;
 #ifdef IILE_TRAV_ITERSTATS
             iter_stat[7] += 1;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
     while (true) {
         SHADOW_STAMP(3);
         const unsigned long long idle_mask = __ballot(!active);
-        if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
+        if (refill_due(idle_mask, feed, kRefillIdle, IILE_REFILL_WASTE)) {
             uint32_t e_new;
             if (feed_take(feed, head, count, !active, &e_new, [&](uint32_t first) {
                     warm_plane(B.nee, first, count);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
     uint32_t q = 0, e = 0;
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
-        if (!feed.exhausted && idle_mask != 0 && (__popcll(idle_mask) >= kRefillIdle || idle_mask == ~0ull)) {
+        if (refill_due(idle_mask, feed, kRefillIdle, IILE_REFILL_WASTE)) {
             uint32_t q_new;
             if (feed_take(feed, head, count, !active, &q_new, [&](uint32_t first) {
                     warm_plane(B.nee + 2 * size_t(plane), first, count);

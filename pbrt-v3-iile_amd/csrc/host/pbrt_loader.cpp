@@ -917,6 +917,7 @@ class Loader {
                 std::memset(&lt, 0, sizeof(lt));
                 for (int i = 0; i < 3; ++i) lt.lemit[i] = L[i] * sc[i];
                 lt.two_sided = gs_.area_light_params.one_bool("twosided", false);
+                lt.n_samples = gs_.area_light_params.one_int("samples", gs_.area_light_params.one_int("nsamples", 1));
                 lt.sphere = pr.shape;
                 s.lights.push_back(lt);
                 pr.light = int(s.lights.size()) - 1;
@@ -1023,6 +1024,7 @@ class Loader {
                 std::memset(&lt, 0, sizeof(lt));
                 for (int i = 0; i < 3; ++i) lt.lemit[i] = L[i] * sc[i];
                 lt.two_sided = gs_.area_light_params.one_bool("twosided", false);
+                lt.n_samples = gs_.area_light_params.one_int("samples", gs_.area_light_params.one_int("nsamples", 1));
                 lt.sphere = -1;
                 lt.type = IILE_LIGHT_AREA_TRIANGLE;
                 lt.prim = -1;  // set once the primitives are in BVH order (finalize_scene)

@@ -159,6 +159,10 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         out.append('LightSource "point" "color I" [30 20 10] "point from" [-6 5 2]')
         out.append('LightSource "spot" "color I" [200 200 260] "point from" [7 -6 6] "point to" [0 2 -3] '
                    '"float coneangle" [35] "float conedeltaangle" [10]')
+    elif light == "many":  # eight point lights (kMaxLights): UniformSampleAllLights makes eight NEE records per hit
+        for i in range(8):
+            out.append('LightSource "point" "color I" [%g %g %g] "point from" [%g %g %g]' % (
+                8 + i, 9, 10 - i, -6 + 1.7 * i, 5 - 1.2 * i, 1.5 + 0.7 * (i % 4)))
     elif light == "spot":  # a spot light from the emitter's position down into the room
         out.append('AttributeBegin\n  Translate 1.5 -2 0\n  LightSource "spot" "color I" [300 300 300] "point from" [0 0 7.5] '
                    '"point to" [-1.5 3 -3] "float coneangle" [40] "float conedeltaangle" [12]\nAttributeEnd')

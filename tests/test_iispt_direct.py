@@ -65,6 +65,62 @@ def test_merge_normalises_both_monitors(oracle):
     assert np.array_equal(out[0, 0], (d[0, 0, :3] / 16.0).astype(np.float32))
 
 
+def test_direct_pass_refuses_glass(binding, oracle, tmp_path):
+    """What the restatement does not cover is refused, not approximated (round-3 advisor): with allowMultipleLobes = false
+    (interaction.h:130-133) GlassMaterial adds separate reflection and transmission lobes (glass.cpp:62-90) and the direct
+    integrator's Li recurses through both — a tree, where this pass walks a chain per pixel."""
+    import boxroom
+    path = tmp_path / "glass.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(ico_levels=1, n_blobs=4, wall_n=2, xres=16, yres=16, spp=1, materials="glass"))
+    with pytest.raises(RuntimeError, match="oracle_iispt_direct: 4"):
+        oracle.iispt_direct(binding.HostScene(path=str(path)), 1)
+
+
+_PANEL_SCENE = """LookAt 0 -3.5 0.8  0 0 0  0 0 1
+Camera "perspective" "float fov" [30]
+Film "image" "integer xresolution" [24] "integer yresolution" [24]
+Sampler "halton" "integer pixelsamples" [1]
+Integrator "path"
+WorldBegin
+AttributeBegin
+  Material "matte" "color Kd" [.6 .6 .6]
+  Shape "trianglemesh" "point P" [ -40 -40 0  40 -40 0  40 40 0  -40 40 0 ] "integer indices" [ 0 1 2  0 2 3 ]
+AttributeEnd
+AttributeBegin
+  Material "matte" "color Kd" [0 0 0]
+  AreaLightSource "diffuse" "color L" [5 5 5] %s
+  Shape "trianglemesh" "point P" [ -1.5 -1.5 1  1.5 -1.5 1  1.5 1.5 1  -1.5 1.5 1 ] "integer indices" [ 0 2 1  0 3 2 ]
+AttributeEnd
+WorldEnd
+"""
+
+
+def test_direct_pass_takes_nsamples_light_samples(binding, oracle, tmp_path):
+    """UniformSampleAllLights calls EstimateDirect Light::nSamples times per light and vertex and divides by it
+    (integrator.cpp:54-83; nLightSamples from directprogressiveintegrator.cpp:9-18; "samples" / "nsamples" of
+    diffuse.cpp:140-141 — killeroo-simple's light says 8, which round 3 ignored). A floor under a large emitting panel
+    (two triangle lights, uniform area sampling: all the noise is light sampling): n = 1 spelled out equals the default,
+    "samples" wins over "nsamples" as in the reference's FindOneInt nesting, the mean is unchanged and the noise between two
+    independent sets of passes falls like 1 / n (measured 0.136 for n = 8)."""
+    def render(extra, first_pass=0, passes=2):
+        path = tmp_path / "f.pbrt"
+        path.write_text(_PANEL_SCENE % extra)
+        film = oracle.iispt_direct(binding.HostScene(path=str(path)), passes, first_pass=first_pass)
+        return film[..., :3] / film[..., 3:4]
+
+    one = render("")
+    assert np.array_equal(one, render('"integer nsamples" [1]'))
+    eight = render('"integer nsamples" [8]')
+    assert np.array_equal(eight, render('"integer samples" [8] "integer nsamples" [2]'))
+    noise1 = ((one - render("", first_pass=2)) ** 2).mean()
+    noise8 = ((eight - render('"integer nsamples" [8]', first_pass=2)) ** 2).mean()
+    assert noise1 > 0.1 and noise1 / 12 < noise8 < noise1 / 5
+    assert abs(eight.mean() / one.mean() - 1) < 0.05
+    # the shipped scene's light has nsamples 8: the path integrator never looks at it (UniformSampleOneLight)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert '"integer nsamples" [8]' in open(os.path.join(repo, "scenes", "killeroo-simple.pbrt")).read()
+
+
 # ---- the device pass against the oracle -------------------------------------------------------------------------------------
 
 
@@ -82,14 +138,19 @@ def test_device_direct_pass_bitwise_on_analytic_scenes(binding, oracle):
 
 @pytest.mark.gpu
 def test_device_direct_pass_bitwise_on_killeroo_and_rooms(binding, oracle, tmp_path):
-    """killeroo-simple (sphere light, matte / plastic) and two rooms of tests/boxroom.py (triangle emitters with several
+    """killeroo-simple (sphere light with "nsamples" 8: eight light samples per vertex; matte / plastic) and rooms of tests/boxroom.py, one
+    of them with a 3-sample sphere light beside two delta lights (triangle emitters with several
     lights: UniformSampleAllLights samples every one of them; uber / mirror blobs: the recursion), passes added in order; a
     second call continuing at pass 2 accumulates into the same monitor."""
     import boxroom
     scenes = [binding.HostScene(xres=160, yres=120, spp=1)]
     for i, kw in enumerate((dict(light="quad"), dict(light="multi", materials="mixed"), dict(light="spot", materials="mixed"))):
         path = tmp_path / f"room{i}.pbrt"
-        path.write_text(boxroom.boxroom_pbrt(ico_levels=2, n_blobs=5, wall_n=6, xres=96, yres=64, spp=1, **kw))
+        text = boxroom.boxroom_pbrt(ico_levels=2, n_blobs=5, wall_n=6, xres=96, yres=64, spp=1, **kw)
+        if i == 1:
+            assert '"color L" [40 40 40]' in text
+            text = text.replace('"color L" [40 40 40]', '"color L" [40 40 40] "integer nsamples" [3]')
+        path.write_text(text)
         scenes.append(binding.HostScene(path=str(path)))
     for scene in scenes:
         gpu = binding.GpuScene(scene)
@@ -106,6 +167,22 @@ def test_device_direct_pass_bitwise_on_killeroo_and_rooms(binding, oracle, tmp_p
 
 
 @pytest.mark.gpu
+def test_device_direct_pass_eight_lights_on_a_large_frame(binding, oracle, tmp_path):
+    """UniformSampleAllLights appends one NEE record per light and hit: 1280 x 800 pixels x 8 point lights = 8.2 M records per
+    level, more than a workspace sized for the 1.02 M paths holds with all its slack (1.125 n + 6 144 wavefronts x 1 024 slots
+    = 7.4 M: the round-3 build overflowed its record planes here, silently). Film monitor bit for bit the oracle's."""
+    import boxroom
+    path = tmp_path / "many.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(ico_levels=2, n_blobs=5, wall_n=6, xres=1280, yres=800, spp=1, light="many", materials="mixed"))
+    scene = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(scene)
+    dev = gpu.render_direct(1)
+    ref = oracle.iispt_direct(scene, 1)
+    assert np.array_equal(dev.view(np.uint64), ref.view(np.uint64))
+    assert (ref[..., :3].sum(axis=2) > 0).mean() > 0.9  # a closed, lit room: nearly every pixel carries eight light samples
+
+
+@pytest.mark.gpu
 def test_direct_pass_rejects_what_it_does_not_build(binding, tmp_path):
     import boxroom
     path = tmp_path / "env.pbrt"
@@ -113,3 +190,12 @@ def test_direct_pass_rejects_what_it_does_not_build(binding, tmp_path):
     gpu = binding.GpuScene(binding.HostScene(path=str(path)))
     with pytest.raises(RuntimeError, match="not built|differentials"):
         gpu.render_direct(1)
+    path = tmp_path / "glass.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(ico_levels=1, n_blobs=4, wall_n=2, xres=16, yres=16, spp=1, materials="glass"))
+    with pytest.raises(RuntimeError, match="glass"):
+        binding.GpuScene(binding.HostScene(path=str(path))).render_direct(1)
+    path = tmp_path / "ns.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(ico_levels=1, n_blobs=2, wall_n=2, xres=16, yres=16, spp=1).replace(
+        '"color L" [60 60 60]', '"color L" [60 60 60] "integer nsamples" [100]'))
+    with pytest.raises(RuntimeError, match="light samples per vertex"):
+        binding.GpuScene(binding.HostScene(path=str(path))).render_direct(1)

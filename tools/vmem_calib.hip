@@ -12,6 +12,8 @@
 //           (2 instructions for the whole record, 16 chains per wavefront)
 //   mode 2  as mode 0, but piece p comes from record (i + p * 977) mod n: PIECES different cache lines per step
 //           (separates "per line" from "per instruction")
+//   mode 3  mode 0 plus one 4-byte load from the same record; mode 4 / 5: the pieces as 12-byte / 4-byte loads
+//           (is a load charged by the lane or by the byte?)
 // Active lanes: the first n of the wavefront, or every (64 / n)-th.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/vmem_calib.hip -o tools/_build/vmem_calib ; run: vmem_calib [iters] > table.json
 #include <hip/hip_runtime.h>
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void k_chase(const float4 *__restrict__ table,
             if (MODE == 0) {
                 const float4 *r = table + size_t(idx) * 8;
                 const float4 nx = r[6];
-                float4 p[7];
+                float4 p[8];
 #pragma unroll
                 for (int k = 0; k < PIECES - 1; ++k) p[k] = r[k < 6 ? k : 7];
 #pragma unroll
@@ -67,6 +69,36 @@ __global__ __launch_bounds__(256) void k_chase(const float4 *__restrict__ table,
                 // piece 6 sits in lane 2 of the quad (its second load): broadcast its .x to the quad
                 const uint32_t nxt = f2b(b.x);
                 idx = uint32_t(__builtin_amdgcn_mov_dpp(int(nxt), 0xAA, 0xf, 0xf, false));  // quad_perm [2,2,2,2]
+            } else if (MODE == 3) {  // mode 0 + one more 4-byte load from the same record (k_extend's axes word)
+                const float4 *r = table + size_t(idx) * 8;
+                const float4 nx = r[6];
+                const float meta = r[7].x;
+                float4 p[8];
+#pragma unroll
+                for (int k = 0; k < PIECES - 1; ++k) p[k] = r[k];
+#pragma unroll
+                for (int k = 0; k < PIECES - 1; ++k) acc += p[k].x + p[k].w;
+                acc += meta;
+                idx = f2b(nx.x);
+            } else if (MODE == 4) {  // the same pieces as 12-byte loads
+                const float *r = reinterpret_cast<const float *>(table + size_t(idx) * 8);
+                typedef float f3_t __attribute__((ext_vector_type(3)));
+                const f3_t nx = *reinterpret_cast<const f3_t *>(r + 24);
+                f3_t p[8];
+#pragma unroll
+                for (int k = 0; k < PIECES - 1; ++k) p[k] = *reinterpret_cast<const f3_t *>(r + 4 * (k < 6 ? k : 7));
+#pragma unroll
+                for (int k = 0; k < PIECES - 1; ++k) acc += p[k].x + p[k].z;
+                idx = f2b(nx.x);
+            } else if (MODE == 5) {  // ... as 4-byte loads
+                const float *r = reinterpret_cast<const float *>(table + size_t(idx) * 8);
+                const float nx = r[24];
+                float p[8];
+#pragma unroll
+                for (int k = 0; k < PIECES - 1; ++k) p[k] = r[4 * (k < 6 ? k : 7)];
+#pragma unroll
+                for (int k = 0; k < PIECES - 1; ++k) acc += p[k];
+                idx = f2b(nx);
             } else {
                 const float4 nx = table[size_t(idx) * 8 + 6];
                 float4 p[7];
@@ -156,7 +188,7 @@ int main(int argc, char **argv) {
     unsigned long long *d_cyc;
     CHECK(hipMalloc(&d_sink, 16));
     CHECK(hipMalloc(&d_cyc, 8));
-    const double sizes_mb[3] = {1.0, 18.0, 72.0};
+    const double sizes_mb[3] = {1.0, 18.0, 72.0};  // L2-resident; the room's records; beyond one XCD's share of anything
     for (double mb : sizes_mb) {
         const uint32_t n_rec = uint32_t(mb * 1048576.0 / 128);
         // one random cycle through all records (Sattolo): next[i] in piece 6
@@ -190,6 +222,16 @@ int main(int argc, char **argv) {
         for (int n : {16, 64}) {
             RUN(2, 4, first_n(n), "first");
             RUN(2, 7, first_n(n), "first");
+        }
+        // what a load costs by its width: 8 x 16 bytes, 7 x 16 + 4, 7 x 12, 7 x 4, with full and half-full wavefronts
+        for (unsigned long long m : {first_n(64), every(32)}) {
+            const char *pat = m == first_n(64) ? "first" : "every";
+            RUN(0, 8, m, pat);
+            RUN(3, 7, m, pat);
+            RUN(4, 7, m, pat);
+            RUN(5, 7, m, pat);
+            RUN(0, 3, m, pat);
+            RUN(4, 3, m, pat);
         }
         // fewer resident waves: 3 blocks per CU
         rows.push_back(run<0, 7>(d_table, n_rec, iters, first_n(64), "first", n_cus, 3, d_sink, d_cyc));
