@@ -13,6 +13,7 @@
 // Mirrors src/main/pbrt.cpp:97-219 (argument loop, ParseFile, Render) on top of
 // the C ABI: libiile_host loads and flattens the scene, libiile_gpu renders it,
 // the film is normalised and written as PFM.
+#include <cerrno>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -74,8 +75,18 @@ int main(int argc, char **argv) {
             ranked = true;
         } else if (!strcmp(argv[i], "--rendezvous") && i + 1 < argc)
             rendezvous = argv[++i];
-        else if (!strcmp(argv[i], "--job") && i + 1 < argc)
-            job_token = strtoull(argv[++i], nullptr, 0);
+        else if (!strcmp(argv[i], "--job") && i + 1 < argc) {
+            // decimal only, the whole argument, not 0 (0 means "no token"): a token that starts with 0 read in base 0 is octal
+            // and stops at an 8 or 9, and garbage would silently become the token-less mode
+            const char *arg = argv[++i];
+            char *end = nullptr;
+            errno = 0;
+            job_token = strtoull(arg, &end, 10);
+            if (errno != 0 || end == arg || *end != '\0' || job_token == 0 || arg[0] == '-') {
+                fprintf(stderr, "iile_pbrt: --job wants a decimal number > 0 (the same for every rank of one launch), got \"%s\"\n", arg);
+                return 1;
+            }
+        }
         else if (argv[i][0] == '-') {
             fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.exr|f.pfm] [--quick] [--quiet] [--nthreads N] [--xres N] [--yres N] [--spp N] "
                             "[--maxdepth N] [--stats] [--sampler halton|sobol] [--splitmethod sah|hlbvh|middle|equal] [--bvh-device] "

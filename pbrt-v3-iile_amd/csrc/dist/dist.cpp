@@ -134,9 +134,14 @@ constexpr char kRvMagic[8] = {'I', 'I', 'L', 'E', 'D', 'I', 'S', 'T'};
 constexpr size_t kRvBytes = 16 + IILE_DIST_ID_BYTES;
 }  // namespace
 
+namespace {
+// when this library was loaded: for a program linked against it (iile_pbrt) that is process start, before any HIP initialisation
+const std::chrono::system_clock::time_point g_loaded_at = std::chrono::system_clock::now();
+constexpr int kRvSlackSeconds = 5;  // file-system time stamps, small clock differences between launcher and ranks
+}  // namespace
+
 int iile_dist_rendezvous_file_token(const char *path, int32_t rank, uint64_t token, uint8_t id[IILE_DIST_ID_BYTES], int32_t timeout_s) {
     if (!path || !id || rank < 0) return fail(IILE_ERR_ARG, "iile_dist_rendezvous_file: bad argument");
-    const auto wall_start = std::chrono::system_clock::now();
     if (rank == 0) {
         // a file left by an earlier run holds a dead id: it goes before anything of this run can be read
         (void)std::remove(path);
@@ -151,11 +156,19 @@ int iile_dist_rendezvous_file_token(const char *path, int32_t rank, uint64_t tok
             return fail(IILE_ERR_ARG, std::string("iile_dist_rendezvous_file: cannot publish ") + path);
         return IILE_OK;
     }
-    // Ranks != 0 accept a file only if it belongs to THIS launch: with a token, the token must match; without one, the
-    // file must not be older than this call (a rank that starts before rank 0 has removed a previous run's file would
-    // otherwise pick up that run's dead id and hang in ncclCommInitRank). One second of slack for file-system time stamps.
+    // Ranks != 0 accept a file only if it belongs to THIS launch (a rank that starts before rank 0 has removed a previous
+    // run's file would otherwise pick up that run's dead id and hang in ncclCommInitRank). With a token: the token must match,
+    // any start order and any delay work. Without one: (a) a file that was not there, or was a different file, when this call
+    // began was written since — rank 0 of this launch published it —: accepted whenever it appears; (b) a file that WAS there
+    // is either a previous run's or this launch's rank 0 having been quicker: accepted if it is not older than this process
+    // (the library's load time, not this call's: HIP initialisation between the two can take seconds when eight ranks start
+    // together, which the round-3 rule — the reader's clock at call time, one second of slack — turned into a 120 s timeout).
+    // What stays out of reach without a token: a rank started more than kRvSlackSeconds after rank 0 has published (by hand,
+    // over ssh). The error message says so; tools/multi_gpu_cmdline.sh always passes --job.
     const auto t0 = std::chrono::steady_clock::now();
     std::string why = "no file";
+    struct stat at_entry;
+    const bool had_file = stat(path, &at_entry) == 0;
     for (;;) {
         struct stat sb;
         if (FILE *f = std::fopen(path, "rb")) {
@@ -172,8 +185,13 @@ int iile_dist_rendezvous_file_token(const char *path, int32_t rank, uint64_t tok
                     if (!fresh) why = "a file of another launch (token mismatch)";
                 } else {
                     const auto mtime = std::chrono::system_clock::from_time_t(have_stat ? sb.st_mtime : 0);
-                    fresh = have_stat && file_token == 0 && mtime + std::chrono::seconds(1) >= wall_start;
-                    if (!fresh) why = file_token != 0 ? "a file published with a token" : "a file older than this process (a previous run's)";
+                    const bool replaced = have_stat && (!had_file || sb.st_ino != at_entry.st_ino || sb.st_mtim.tv_sec != at_entry.st_mtim.tv_sec ||
+                                                        sb.st_mtim.tv_nsec != at_entry.st_mtim.tv_nsec);
+                    fresh = have_stat && file_token == 0 && (replaced || mtime + std::chrono::seconds(kRvSlackSeconds) >= g_loaded_at);
+                    if (!fresh)
+                        why = file_token != 0 ? "a file published with a token"
+                                              : "a file older than this process (a previous run's; or this rank started long after rank 0: pass the "
+                                                "same --job token to every rank)";
                 }
                 if (fresh) {
                     std::memcpy(id, buf + 16, IILE_DIST_ID_BYTES);

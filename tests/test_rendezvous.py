@@ -80,3 +80,27 @@ def test_stale_then_republished(binding, tmp_path):
     rc, got, err = out["r"]
     assert rc == 0, err
     assert got == bytes([2]) * 128
+
+
+def test_file_published_before_this_rank_called_is_accepted(binding, tmp_path):
+    """rank 0 published, and this rank reaches the call seconds later (HIP initialisation of eight processes
+    starting together): the file was there at entry, so it is judged by its age against the PROCESS (library load), not against
+    the call — round 3 compared with the reader's clock at call time and one second of slack, and timed out after 120 s."""
+    f = tmp_path / "rv"
+    f.write_bytes(_record(0, 3))
+    time.sleep(2.2)  # "HIP initialisation"
+    rc, got, err = _wait(binding, f, 1, 0, 2)
+    assert rc == 0, err
+    assert got == bytes([3]) * 128
+
+
+def test_cli_job_token_is_decimal_and_checked(binding):
+    """iile_pbrt --job: decimal, whole argument, > 0 ('0123489' in base 0 is octal and stops at the 8; 'abc' became 0 =
+    token-less mode in round 3)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(binding.__file__), "lib", "iile_pbrt")
+    for bad in ("abc", "0", "012x", "-5", ""):
+        p = subprocess.run([exe, "nothing.pbrt", "--gpurank", "0/1", "--rendezvous", "/tmp/x", "--job", bad], capture_output=True, text=True)
+        assert p.returncode == 1 and "--job wants a decimal number" in p.stderr, (bad, p.stderr)
+    script = open(os.path.join(os.path.dirname(os.path.dirname(binding.__file__)), "tools", "multi_gpu_cmdline.sh")).read()
+    assert "JOB=1$RANDOM$RANDOM" in script

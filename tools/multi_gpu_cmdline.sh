@@ -3,7 +3,7 @@
 #   tools/multi_gpu_cmdline.sh [N] [scene.pbrt]
 N=${1:-8}
 SCENE=${2:-scenes/killeroo-simple.pbrt}
-JOB=$RANDOM$RANDOM
+JOB=1$RANDOM$RANDOM   # (never starts with 0; iile_pbrt reads it as a decimal number > 0)
 echo "# C++ host, one process per GPU (rank R uses GPU R); rank 0 writes the image:"
 echo "export HSA_ENABLE_IPC_MODE_LEGACY=0"
 for ((r = 0; r < N; r++)); do
