@@ -161,6 +161,21 @@ def load_pmc(world, args):
     return tr, la, tr_src, la_src
 
 
+def load_vmem_calibration():
+    """The measured ceiling of the vector-memory path for the traversal's access shape (tools/vmem_calib.hip: dependent
+    fetches of 128-byte records, 7 loads of 16 bytes per lane and step, 24 wavefronts per CU): lane-loads per ns per CU."""
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_vmem_calib.json")))[::-1]:
+        try:
+            j = json.load(open(f))
+            rows = [r for r in j["rows"] if r["mode"] == 0 and r["pieces"] == 7 and r["active"] == 64 and r["blocks_per_cu"] == 6]
+            by_mb = {int(r["table_mb"]): r["lane_loads_per_ns_cu"] for r in rows}
+            if by_mb:
+                return by_mb, os.path.basename(f)
+        except Exception:
+            pass
+    return {}, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,7 +245,7 @@ def main():
     import numpy as np
     import torch
     import __graft_entry__ as ge
-    ge.build_if_needed()
+    compiled_now = ge.build_if_needed()
     b = ge._load_binding()
 
     if not torch.cuda.is_available():
@@ -264,15 +279,25 @@ def main():
         h, w = scene.film_shape
         film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
 
-        def step(collect=False, timed=False):
+        rank_times = []  # per timed step: (render ms, film-reduce ms) of THIS rank, from events on the render stream
+
+        def step(collect=False, timed=False, clock=False):
             box = {}
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if clock else None
 
             def render(tile_rank, tile_nranks):
+                if ev:
+                    ev[0].record()
                 _, box["st"] = gpu.render(tile_rank=tile_rank, tile_nranks=tile_nranks, spp_per_pass=args.spp_per_pass,
                                           collect_stats=collect, time_kernels=timed, film_device_ptr=film.data_ptr(),
                                           stream=stream, want_stats=True)
+                if ev:
+                    ev[1].record()
 
             mg.render_sharded(render, film, dist, comm=comm, stream=stream)  # N > 1: one RCCL sum-reduction to rank 0
+            if ev:
+                ev[2].record()
+                rank_times.append(ev)
             return box["st"]
 
         # instrumented step (untimed): ray / node / triangle counts of one step on this rank, and the film every
@@ -289,11 +314,14 @@ def main():
                "n_shade_launches": 0}
         st = None
         for _ in range(steps):
-            st = step(timed=want_kernels)
+            st = step(timed=want_kernels, clock=True)
             for k in agg:
                 agg[k] += st[k]
         barrier()
         elapsed = time.perf_counter() - t0
+        # this rank's share of a step: its render (iile_render on its tiles) and its part of the one film reduction
+        ms_render = sum(e[0].elapsed_time(e[1]) for e in rank_times) / max(len(rank_times), 1)
+        ms_reduce = sum(e[1].elapsed_time(e[2]) for e in rank_times) / max(len(rank_times), 1)
         # untimed extra steps with every kernel alone on the GPU (one stream): the per-kernel durations of the timed
         # steps overlap (the NEE kernels of a bounce run beside the next bounce's extend / shade on a second stream)
         alone = {k: 0.0 for k in agg}
@@ -309,7 +337,13 @@ def main():
         # rays the timed kernels traced on this rank: every main-path and shadow ray, and the MIS rays the plain build
         # does not prove irrelevant (counted by the timed step itself)
         traced = st["ext_rays_traced"] + cst["shadow_rays"] + st["mis_rays_traced"]
+        per_rank = {"ms_render": [ms_render], "ms_reduce": [ms_reduce], "rays_traced": [int(traced)]}
         if dist is not None:
+            mine = torch.tensor([ms_render, ms_reduce, float(traced)], dtype=torch.float64, device="cuda")
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank = {"ms_render": [float(x[0]) for x in every], "ms_reduce": [float(x[1]) for x in every],
+                        "rays_traced": [int(x[2]) for x in every]}
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -326,6 +360,7 @@ def main():
                              "the timed kernels did not do the reference's work; no number is reported")
         rays = rays_closest + rays_shadow
         res = {"elapsed": elapsed, "steps": steps, "rays_step": rays, "rays_traced_step": traced, "cam": cam, "cst": cst, "agg": agg, "n_passes": st["n_passes"],
+               "per_rank": per_rank,
                "alone": alone, "n_alone": n_alone,
                "ms_per_step": elapsed * 1e3 / steps, "mray": traced * steps / elapsed / 1e6,
                "mray_reference": rays * steps / elapsed / 1e6, "total_spp": total_spp}
@@ -371,13 +406,27 @@ def main():
             "k_film": (agg["ms_film"], primary["n_passes"] * steps, 16 * cst["camera_rays"], cst["camera_rays"], "L read per sample"),
         }
         pmc_traffic, pmc_lanes, tr_src, la_src = load_pmc(world, args)
+        vmem_peak, vmem_src = load_vmem_calibration()
+        # What the counters say binds each kernel family (profiles/*_pmc_mem.json, *_pmc_lanes.json, r04_vmem_calib.json):
+        BINDS = {
+            "k_extend": "vmem", "k_shadow": "vmem", "k_mis": "vmem",
+            "k_shade": "registers+vmem", "k_mis_lit": "hbm", "k_film": "hbm",
+        }
+        BIND_NOTES = {
+            "vmem": "the vector-memory path in front of the L1: the kernel retires 16-byte lane-loads at the rate tools/vmem_calib.hip "
+                    "measures as the ceiling for dependent fetches of 128-byte records (address unit busy 0.6-0.86, data return 0.9-0.99 of "
+                    "the kernel's cycles: profiles/*_pmc_mem.json); not HBM (the scene is cache resident), not VALU issue (0.4-0.45 of its ceiling)",
+            "registers+vmem": "waves per SIMD (128 VGPRs: four) and vector-memory instructions per hit; VALU issue at ~0.6 of the calibrated ceiling (DESIGN.md section 6)",
+            "hbm": "streams its records once: HBM bandwidth",
+        }
         per_kernel = {}
+        step_counter_bytes, step_counter_kernels = 0, []
         for k, (ms_k, n_l, by, units, note) in fam.items():
             if ms_k <= 0:
                 continue
-            e = {"ms_per_step": round(ms_k / steps, 3), "launches_per_step": round(n_l / steps, 2),
+            e = {"ms_per_step": round(ms_k / steps, 3), "launches_per_step": round(n_l / steps, 2), "bound": BINDS.get(k, "hbm"),
                  "algorithmic_gbs": round(by * steps / ms_k / 1e6, 1), "algorithmic_bytes_note": note}
-            tr = pmc_traffic.get(k)
+            tr = pmc_traffic.get(k if k != "k_film" else "k_film_accumulate")
             if tr:
                 # The counters sit at the L2's memory side: they count what the Infinity Cache serves as well as what HBM
                 # serves (MI355X_MICROARCH.md, HBM section). A kernel must stream its queue records from HBM once; whatever it
@@ -396,7 +445,12 @@ def main():
                                 "Infinity Cache (FETCH_SIZE counts those too): an upper estimate of what is not HBM traffic"}
                 e["hbm_counter_bytes_per_step"] = tr["hbm_bytes_per_step"]
                 e["hbm_counter_gbs"] = round(tr["hbm_bytes_per_step"] / (ms_k / steps) / 1e6, 1)
-                e["hbm_counter_frac_of_peak"] = round(e["hbm_counter_gbs"] / HBM_PEAK_GBS, 4)
+                # ONE definition for every kernel: counted memory-side bytes / the kernel's HIP-event time / 8 TB/s
+                e["frac"] = round(e["hbm_counter_gbs"] / HBM_PEAK_GBS, 4)
+                step_counter_bytes += tr["hbm_bytes_per_step"]
+                step_counter_kernels.append(k)
+                if k == "k_film" and "k_film_resolve" in pmc_traffic:
+                    step_counter_bytes += pmc_traffic["k_film_resolve"]["hbm_bytes_per_step"]
             la = pmc_lanes.get(k)
             if la:
                 # VALU issue: wave-instructions x 64 lane slots against CUs x SIMDs x 32 lanes x clock, over THIS run's time
@@ -416,6 +470,15 @@ def main():
                     l2 = la["TCC_REQ_sum"] * 128 / (ms_k / steps * 1e-3) / 1e9
                     e["l2"] = {"requests_per_step": la["TCC_REQ_sum"], "hit_rate": la.get("l2_hit_rate"),
                                "gbs_at_128B_per_request": round(l2, 1), "frac_of_l2_peak": round(l2 / L2_PEAK_GBS, 4)}
+                if "TCP_TOTAL_CACHE_ACCESSES_sum" in la and vmem_peak:
+                    # the vector-memory roofline: L1 accesses (one per lane and load instruction when the lanes diverge) per ns per
+                    # CU against the ceiling measured for the same access shape (scene-sized table: 18 MB for the room, 1 MB when the
+                    # tree fits an XCD's L2 many times over)
+                    rate = la["TCP_TOTAL_CACHE_ACCESSES_sum"] / (ms_k / steps * 1e6) / 256.0
+                    peak = vmem_peak.get(18 if args.workload.startswith("boxroom") else 1) or max(vmem_peak.values())
+                    e["vmem"] = {"l1_accesses_per_step": la["TCP_TOTAL_CACHE_ACCESSES_sum"], "l1_accesses_per_ns_cu": round(rate, 3),
+                                 "calibrated_peak_per_ns_cu": peak, "frac": round(rate / peak, 4), "calibration": vmem_src,
+                                 "ta_busy": la.get("ta_busy"), "td_busy": la.get("td_busy")}
             per_kernel[k] = e
         # the dominant kernel: by the one-stream steps when there are any (with two streams the HIP-event durations of the
         # timed region depend on what happened to run beside a kernel, and the order of the top two flips from run to run)
@@ -433,13 +496,27 @@ def main():
         if dom in pmc_traffic:
             traffic = int(pmc_traffic[dom]["hbm_bytes_per_step"] / max(pmc_traffic[dom]["launches_in_step"], 1))
         cache_resident = dom in ("k_extend", "k_shadow", "k_mis")
+        frac_alg = achieved / HBM_PEAK_GBS
+        frac_traffic = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None
         roof = {
             "kernel": dom,
-            "bound": "hbm",
+            "bound": BINDS.get(dom, "hbm"),
+            "bound_note": BIND_NOTES[BINDS.get(dom, "hbm")],
+            "priced_against": "hbm",
+            # the contract's pair: algorithmic bytes per launch / launch time, against the HBM peak ...
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": None,
+            # ... and the fraction, which for EVERY kernel is counted memory-side bytes per launch / launch time / peak
+            # (`traffic` / avg_launch_ms / 8 TB/s; null without a committed counter set for this workload)
+            "frac": frac_traffic,
+            "frac_definition": "traffic / avg_launch_ms / peak: PMC-counted memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc "
+                               "passes of this command, profiles/" + str(tr_src) + "), the same definition for every kernel of roofline_all_kernels",
+            "frac_algorithmic": round(frac_alg, 4),
+            "frac_algorithmic_note": "achieved / peak with SURVEY.md 8(d)'s bytes (32 B per BVH node of the REFERENCE's layout + 48 B per triangle test "
+                                     "+ 48 B per ray). It can exceed 1 for the traversal kernels: the scene (7 MB; the room 35 MB) is served from L2 / "
+                                     "Infinity Cache, and a four-wide step does several of the reference's node visits per fetch — the bytes are a model "
+                                     "of the reference's work, not traffic",
             "traffic": traffic,
             "traffic_source": tr_src,
             "launches_per_step": launches_per_step,
@@ -447,26 +524,13 @@ def main():
             "algorithmic_bytes_per_launch": int(bytes_all / max(launches_per_step, 1)),
             "algorithmic_bytes_note": note_k,
             "units_per_launch": int(units_k / max(launches_per_step, 1)),
-            "binding": ("vector-memory pipe in front of the L1 (address unit busy 0.74-0.86, data-return unit 0.92-0.99 of the kernel's cycles: "
-                        "profiles/*_pmc_mem.json), not VALU issue and not HBM" if cache_resident else
-                        "registers (waves per SIMD) and vector-memory instructions per hit; VALU issue at ~0.6 of the calibrated ceiling (DESIGN.md section 6)"),
             "valu": per_kernel[dom].get("valu"),
             "l2": per_kernel[dom].get("l2"),
+            "vmem": per_kernel[dom].get("vmem"),
             "lanes_source": la_src,
             "kernel_choice": ("largest HIP-event time over all kernels of a step with every kernel alone on the GPU (the one-stream steps of this run)"
                               if primary["n_alone"] > 0 else "largest HIP-event time over all kernels of the step (this run)"),
-            "note": "frac = algorithmic bytes per launch / average launch time / 8 TB/s; for the traversal kernels, whose "
-                    "32 B/node + 48 B/triangle bytes are served from cache (~7 MB scene), frac is the PMC-counted HBM "
-                    "traffic instead (never above 1) and the algorithmic rate is kept as `achieved`. `traffic` = HBM bytes "
-                    "per launch from separate rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE). What "
-                    "binds the kernel: see `binding`; `valu` carries the issue-side counters (profiles/, lane-ops = wave instructions x 64).",
         }
-        frac_alg = achieved / HBM_PEAK_GBS
-        if traffic:
-            roof["frac_traffic"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        # a kernel whose algorithmic bytes are served from cache is priced by its counted HBM traffic (null without counters)
-        roof["frac"] = (roof.get("frac_traffic") if cache_resident else round(frac_alg, 4))
-        roof["frac_algorithmic"] = round(frac_alg, 4)
         # the same kernel with the GPU to itself (one-stream steps after the timed region)
         if primary["n_alone"] > 0:
             al, na = primary["alone"], primary["n_alone"]
@@ -474,21 +538,25 @@ def main():
             a_ms = al[key] / na / max(launches_per_step, 1)
             a_ach = (bytes_all / launches_per_step) / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
             one = {"avg_launch_ms": round(a_ms, 4), "achieved": round(a_ach, 1), "frac_algorithmic": round(a_ach / HBM_PEAK_GBS, 4),
-                   "steps": na}
-            if traffic:
-                one["frac_traffic"] = round(traffic / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                   "steps": na, "frac": round(traffic / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
             la = pmc_lanes.get(dom)
             if la:
                 one["valu_issue_frac"] = round(la["SQ_INSTS_VALU"] * 64 / (al[key] / na * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4)
-            one["frac"] = one.get("frac_traffic") if cache_resident else one["frac_algorithmic"]
+                if "TCP_TOTAL_CACHE_ACCESSES_sum" in la and per_kernel[dom].get("vmem"):
+                    r1 = la["TCP_TOTAL_CACHE_ACCESSES_sum"] / (al[key] / na * 1e6) / 256.0
+                    one["vmem_frac"] = round(r1 / per_kernel[dom]["vmem"]["calibrated_peak_per_ns_cu"], 4)
             roof["one_stream"] = one
-            roof["note"] += (" In the timed steps the shadow / MIS kernels of a bounce run on a second stream beside the next bounce's "
-                             "k_extend and k_shade (each fills the other's tail), so the HIP-event durations of the timed region — the ones "
-                             "`achieved`, `frac` and a rocprofv3 trace of this command show — include time spent sharing the GPU and sum to "
-                             "more than a step; `one_stream` prices the same kernel from extra untimed steps in which every kernel has "
-                             "the GPU to itself.")
+            roof["one_stream_note"] = ("In the timed steps the shadow / MIS kernels of a bounce run on a second stream beside the next bounce's "
+                                       "k_extend and k_shade (each fills the other's tail), so the HIP-event durations of the timed region — the ones "
+                                       "`achieved`, `frac` and a rocprofv3 trace of this command show — include time spent sharing the GPU and sum to "
+                                       "more than a step; `one_stream` prices the same kernel from extra untimed steps in which every kernel has "
+                                       "the GPU to itself.")
         copy_gbs = measured_copy_gbs(torch)
         roof["peak_measured_copy_gbs"] = round(copy_gbs, 1)
+        # the whole step against HBM: counted bytes of every kernel of a step / ms_per_step / peak; and SURVEY.md 8(d)'s own
+        # figure for the job: rays/s x B_ray / peak
+        step_hbm_frac = round(step_counter_bytes / (primary["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if step_counter_bytes else None
+        job_algorithmic_frac = round(mray * 1e6 * b_ray / 1e9 / HBM_PEAK_GBS, 4)
         out = {
             "metric": f"Mray/s on {workload_name} 1080p (path integrator, rays = Scene::Intersect + IntersectP calls)",
             "value": round(mray, 2),
@@ -538,6 +606,26 @@ def main():
                                               if primary["n_alone"] else None),
             "roofline": roof,
             "roofline_all_kernels": per_kernel,
+            "step_hbm_frac": step_hbm_frac,
+            "step_hbm_frac_note": ("counted memory-side bytes of " + ", ".join(step_counter_kernels) + " over one step (profiles/" + str(tr_src) +
+                                   ") / ms_per_step / 8 TB/s" if step_counter_bytes else "no committed counter set for this workload"),
+            "job_algorithmic_frac": job_algorithmic_frac,
+            "job_algorithmic_frac_note": "value x b_ray_bytes / 8 TB/s: SURVEY.md 8(d)'s `roofline.achieved` for the whole job (rays traced per second x "
+                                         "the reference layout's bytes per ray), not traffic",
+            "built": ge.build_provenance(compiled_now),
+            "per_rank": dict(primary["per_rank"], **{
+                "ranks": world,
+                "rccl_ranks": (comm.size if comm is not None else 1),
+                "ms_render_min_mean_max": [round(min(primary["per_rank"]["ms_render"]), 3),
+                                           round(sum(primary["per_rank"]["ms_render"]) / len(primary["per_rank"]["ms_render"]), 3),
+                                           round(max(primary["per_rank"]["ms_render"]), 3)],
+                "ms_reduce_max": round(max(primary["per_rank"]["ms_reduce"]), 3),
+                "imbalance_max_over_mean": round(max(primary["per_rank"]["ms_render"]) /
+                                                 max(sum(primary["per_rank"]["ms_render"]) / len(primary["per_rank"]["ms_render"]), 1e-9), 4),
+                "note": "per timed step and rank, from events on the render stream: ms_render = iile_render of the rank's tiles, ms_reduce = "
+                        "its part of the one film reduction (iile_dist_film_reduce; 0 at one rank). A rank that fails raises and exits "
+                        "non-zero: the launcher (torch.distributed.run, max_restarts 0) tears the job down; nothing restarts a process "
+                        "that has touched the GPU"}),
         }
         if other is not None:
             out["other_mode"] = {"scaling": other_name, "spp_total": other["total_spp"], "value": round(other["mray"], 2), "unit": "Mray/s",

@@ -196,6 +196,9 @@ int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32_t max_prim
  * SoA planes, refs, axes); *nested = every child box lies inside its parent's. Layout: DESIGN.md §3. */
 int iile_bvh_pack_probe(int32_t n_nodes, const iile_bvh_node *nodes, int32_t n_interior, float *wide16, float *wide4_32,
                         int32_t *nested);
+/* How this build packs the refs of a four-wide record: 0 = the plain ref and an axes word of its own; 2 = ref << 2 | split
+ * axis (of the node, its first child, its second child) — one vector load less per interior step. */
+int32_t iile_wide_ref_shift(void);
 /* ImageTexture<RGBSpectrum, Spectrum>::Evaluate (src/textures/imagemap.h:87-94) of image texture `tex` at n
  * surface points given by (u, v) and the screen-space differentials {du/dx, dv/dx, du/dy, dv/dy}. */
 int iile_texture_eval(iile_scene *scene, int32_t tex, int32_t n, const float *uv2, const float *duv4, float *rgb3);

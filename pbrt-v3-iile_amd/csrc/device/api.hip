@@ -591,7 +591,9 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         }
         rc = pack_wide_records(d_nodes, n, n_interior, wide, wide4, &S.boxes_nested, d_remap);
         if (rc) return bail(rc);
-        if (n_interior >= (1 << 25)) S.boxes_nested = 0;  // the four-wide step addresses its records with 32-bit byte offsets
+        // the four-wide step addresses its records with 32-bit byte offsets (and, with IILE_AXES_IN_REFS, gives two bits of
+        // every ref to a split axis: leaf refs ~prim must survive the shift)
+        if (n_interior >= (1 << 25) || (kRefShift && d->n_prims >= (1 << 28))) S.boxes_nested = 0;
         S.wide = wide;
         S.wide4 = wide4;
         if (n > 0) {
@@ -623,6 +625,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 for (int j = 0; j < 4 && int(order.size()) < want_top; ++j) {
                     int r;
                     std::memcpy(&r, &rf[j], sizeof(r));
+                    r >>= kRefShift;  // (IILE_AXES_IN_REFS: the low bits are a split axis)
                     // (an empty slot — the second one of a leaf child — holds no box: its planes are +-inf and its ref is unused)
                     const float bmin_x = (&all[8 * size_t(order[at]) + 0].x)[j];
                     if (r < 0 || r >= n_interior || !(bmin_x < std::numeric_limits<float>::infinity()) || slot_of.count(r)) continue;
@@ -635,12 +638,13 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 for (int q = 0; q < 8; ++q) top[8 * sl + q] = all[8 * size_t(order[sl]) + q];
                 float *refs = &top[8 * sl + 6].x;
                 for (int j = 0; j < 4; ++j) {
-                    int r;
-                    std::memcpy(&r, &refs[j], sizeof(r));
+                    int raw;
+                    std::memcpy(&raw, &refs[j], sizeof(raw));
+                    const int r = raw >> kRefShift;
                     const float bmin_x = (&top[8 * sl + 0].x)[j];
                     if (r >= 0 && r < n_interior && bmin_x < std::numeric_limits<float>::infinity() && slot_of.count(r)) {
-                        const int tagged = kTopFlag | slot_of[r];
-                        std::memcpy(&refs[j], &tagged, sizeof(r));
+                        const int tagged = int(uint32_t(kTopFlag | slot_of[r]) << kRefShift) | (raw & ((1 << kRefShift) - 1));
+                        std::memcpy(&refs[j], &tagged, sizeof(raw));
                     }
                 }
                 std::memcpy(&top[8 * sl + 7].y, &order[sl], sizeof(int));

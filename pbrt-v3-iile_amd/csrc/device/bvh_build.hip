@@ -466,6 +466,12 @@ __global__ __launch_bounds__(kBB) void k_pack_wide(int n, const iile_bvh_node *n
         }
         float4 *w4 = wide4 + 8 * size_t(my_slot);
         for (int pl = 0; pl < 6; ++pl) w4[pl] = make_float4(bx[pl][0], bx[pl][1], bx[pl][2], bx[pl][3]);
+        if (kRefShift) {  // IILE_AXES_IN_REFS: ref << 2 | axis of {the node, its first child, its second child, -}
+            refs[0] = int((uint32_t(refs[0]) << kRefShift) | (meta & 3u));
+            refs[1] = int((uint32_t(refs[1]) << kRefShift) | ((meta >> 2) & 3u));
+            refs[2] = int((uint32_t(refs[2]) << kRefShift) | ((meta >> 4) & 3u));
+            refs[3] = int(uint32_t(refs[3]) << kRefShift);
+        }
         w4[6] = make_float4(__int_as_float(refs[0]), __int_as_float(refs[1]), __int_as_float(refs[2]), __int_as_float(refs[3]));
         w4[7] = make_float4(__uint_as_float(meta), 0.f, 0.f, 0.f);
     }
@@ -693,6 +699,8 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
 }
 
 // Test probe for pack_wide_records: the records of a flattened tree handed over by the host.
+extern "C" int32_t iile_wide_ref_shift(void) { return kRefShift; }
+
 extern "C" int iile_bvh_pack_probe(int32_t n_nodes, const iile_bvh_node *nodes, int32_t n_interior, float *wide16, float *wide4_32,
                                    int32_t *nested) {
     if (n_nodes <= 0 || !nodes || !wide16 || !wide4_32 || !nested) return api_fail(IILE_ERR_ARG, "iile_bvh_pack_probe: bad argument");

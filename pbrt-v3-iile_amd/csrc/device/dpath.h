@@ -967,7 +967,7 @@ DEV Wide4Planes load_wide4(const float4 *wide4, int cur, int neg_mask, lds_char 
             w.ly = lds_load4(r + (py ^ 80u));
             w.lz = lds_load4(r + (pz ^ 112u));
             w.refs = lds_load4(r + 96u);
-            w.meta = WITH_META ? *reinterpret_cast<lu32 *>(r + 112u) : 0u;
+            w.meta = (WITH_META && !kRefShift) ? *reinterpret_cast<lu32 *>(r + 112u) : 0u;
         }
         if (__ballot(!in_top) == 0) return w;  // (wave-uniform: a wavefront fresh from a refill is all in the top levels)
     }
@@ -981,14 +981,23 @@ DEV Wide4Planes load_wide4(const float4 *wide4, int cur, int neg_mask, lds_char 
         w.ly = *reinterpret_cast<const float4 *>(base + (ay ^ 80u));
         w.lz = *reinterpret_cast<const float4 *>(base + (az ^ 112u));
         w.refs = *reinterpret_cast<const float4 *>(base + (rec + 96u));
-        w.meta = WITH_META ? *reinterpret_cast<const uint32_t *>(base + (rec + 112u)) : 0u;
+        w.meta = (WITH_META && !kRefShift) ? *reinterpret_cast<const uint32_t *>(base + (rec + 112u)) : 0u;
     }
     return w;
 }
+// the four refs of a record as the step uses them, and its axes word (IILE_AXES_IN_REFS: both unpacked from the refs)
+DEV void unpack_refs(const Wide4Planes &w, int *r0, int *r1, int *r2, int *r3, uint32_t *meta) {
+    const int p0 = __float_as_int(w.refs.x), p1 = __float_as_int(w.refs.y), p2 = __float_as_int(w.refs.z), p3 = __float_as_int(w.refs.w);
+    if (kRefShift) {
+        *meta = uint32_t(p0 & 3) | uint32_t(p1 & 3) << 2 | uint32_t(p2 & 3) << 4;
+        *r0 = p0 >> kRefShift, *r1 = p1 >> kRefShift, *r2 = p2 >> kRefShift, *r3 = p3 >> kRefShift;  // (arithmetic: a leaf ref is negative)
+    } else {
+        *meta = w.meta;
+        *r0 = p0, *r1 = p1, *r2 = p2, *r3 = p3;
+    }
+}
 DEV void trav_interior4(Trav &t, const StackRef &sr, const Wide4Planes &w) {
     const RayCtx &rc = t.rc;
-    const float4 refs = w.refs;
-    const uint32_t meta = w.meta;
     // entry / exit planes of slots (0,1) and (2,3) as float2 lanes
     const v2f x0a = v2f{w.ex.x, w.ex.y}, x0b = v2f{w.ex.z, w.ex.w}, x1a = v2f{w.lx.x, w.lx.y}, x1b = v2f{w.lx.z, w.lx.w};
     const v2f y0a = v2f{w.ey.x, w.ey.y}, y0b = v2f{w.ey.z, w.ey.w}, y1a = v2f{w.ly.x, w.ly.y}, y1b = v2f{w.ly.z, w.ly.w};
@@ -1013,8 +1022,9 @@ DEV void trav_interior4(Trav &t, const StackRef &sr, const Wide4Planes &w) {
     const float k1 = slot_key(tx0a.y, ty0a.y, tz0a.y, tx1a.y, ty1a.y, tz1a.y);
     const float k2 = slot_key(tx0b.x, ty0b.x, tz0b.x, tx1b.x, ty1b.x, tz1b.x);
     const float k3 = slot_key(tx0b.y, ty0b.y, tz0b.y, tx1b.y, ty1b.y, tz1b.y);
-    const int r0 = __float_as_int(refs.x), r1 = __float_as_int(refs.y), r2 = __float_as_int(refs.z),
-              r3 = __float_as_int(refs.w);
+    int r0, r1, r2, r3;
+    uint32_t meta;
+    unpack_refs(w, &r0, &r1, &r2, &r3, &meta);
     // the reference's visiting order (bvh.cpp:686-692 applied at P, L and R)
     const bool swap_p = (rc.neg_mask >> (meta & 3u)) & 1, swap_l = (rc.neg_mask >> ((meta >> 2) & 3u)) & 1,
                swap_r = (rc.neg_mask >> ((meta >> 4) & 3u)) & 1;
@@ -1039,7 +1049,6 @@ DEV void trav_interior4(Trav &t, const StackRef &sr, const Wide4Planes &w) {
 // instrumented kernels keep the ordered binary walk.
 DEV void trav_interior4_any(Trav &t, const StackRef &sr, const Wide4Planes &w) {
     const RayCtx &rc = t.rc;
-    const float4 refs = w.refs;
     const v2f x0a = v2f{w.ex.x, w.ex.y}, x0b = v2f{w.ex.z, w.ex.w}, x1a = v2f{w.lx.x, w.lx.y}, x1b = v2f{w.lx.z, w.lx.w};
     const v2f y0a = v2f{w.ey.x, w.ey.y}, y0b = v2f{w.ey.z, w.ey.w}, y1a = v2f{w.ly.x, w.ly.y}, y1b = v2f{w.ly.z, w.ly.w};
     const v2f z0a = v2f{w.ez.x, w.ez.y}, z0b = v2f{w.ez.z, w.ez.w}, z1a = v2f{w.lz.x, w.lz.y}, z1b = v2f{w.lz.z, w.lz.w};
@@ -1061,7 +1070,9 @@ DEV void trav_interior4_any(Trav &t, const StackRef &sr, const Wide4Planes &w) {
     const bool v1 = visit(tx0a.y, ty0a.y, tz0a.y, tx1a.y, ty1a.y, tz1a.y);
     const bool v2 = visit(tx0b.x, ty0b.x, tz0b.x, tx1b.x, ty1b.x, tz1b.x);
     const bool v3 = visit(tx0b.y, ty0b.y, tz0b.y, tx1b.y, ty1b.y, tz1b.y);
-    const int r0 = __float_as_int(refs.x), r1 = __float_as_int(refs.y), r2 = __float_as_int(refs.z), r3 = __float_as_int(refs.w);
+    int r0, r1, r2, r3;
+    uint32_t meta_unused;
+    unpack_refs(w, &r0, &r1, &r2, &r3, &meta_unused);
     // (the cached tMin of a deferred slot only feeds trav_pop's `tMin < ray.tMax`, already decided: any value below tMax)
     if (v3 && (v0 || v1 || v2)) stack_push(t, sr, r3, 0.f);
     if (v2 && (v0 || v1)) stack_push(t, sr, r2, 0.f);

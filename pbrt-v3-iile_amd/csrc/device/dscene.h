@@ -95,7 +95,15 @@ struct DProbeCam {
 #define IILE_TOP_RECORDS 21  // levels 0..2 of the four-wide tree (1 + 4 + 16); 85 = levels 0..3
 #endif
 constexpr int kMaxTop = IILE_TOP_RECORDS;  // records of the tree's top kept in LDS by the traversal kernels (dpath.h)
-constexpr int kTopFlag = 1 << 30;          // reference to one of them: kTopFlag | slot
+// IILE_AXES_IN_REFS: the three split axes of a four-wide record ride in the low two bits of its first three refs (ref << 2 |
+// axis) instead of a word of their own, so that k_extend's interior step issues 7 vector loads per lane instead of 8 — on the
+// deep-tree room the traversal kernels retire vector-memory lane-loads at the rate the L1 path allows at all
+// (tools/vmem_calib.hip, profiles/r04_vmem_calib.json), and the only way to go faster is fewer of them.
+#ifndef IILE_AXES_IN_REFS
+#define IILE_AXES_IN_REFS 0
+#endif
+constexpr int kRefShift = IILE_AXES_IN_REFS ? 2 : 0;
+constexpr int kTopFlag = IILE_AXES_IN_REFS ? (1 << 28) : (1 << 30);  // reference to one of them: kTopFlag | slot (survives the shift)
 
 struct DScene {
     // HBM arrays

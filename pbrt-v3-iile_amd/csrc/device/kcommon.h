@@ -140,24 +140,38 @@ struct WaveFeed {
     uint32_t tried = 0;  // IILE_XCD_FEED: partitions of the queue this wavefront has found empty (its own XCD's first)
     uint32_t waste = 0;  // lane-steps lost to idle lanes since the last refill (refill_due)
 };
-// When to refill. A refill runs with only the idle lanes active and costs the wavefront a fixed number of steps whatever
-// their number, so it should wait for a batch of them; every step it waits costs one lane-step per idle lane. With rays
-// finishing at a rate of r lanes per step the cheapest batch is sqrt(2 C r) lanes (C = the refill's cost in lane-steps: the
-// economic-order-quantity rule) — 32 for killeroo-simple's short rays (5.5 votes between refills), about 10 for the deep
-// room's long ones (52 votes) — and it is reached exactly when the lane-steps wasted since the last refill add up to C,
-// which needs no estimate of r: the wavefront sums its idle lanes step by step and refills when the sum reaches `waste_max`
-// (or, as before, at `idle_min` idle lanes when waste_max is 0).
+// When to refill. A refill runs with only the idle lanes active, so it should wait for a batch of them; but every step it
+// waits costs one lane-step per idle lane, and how fast lanes go idle differs by two orders of magnitude between workloads:
+// killeroo-simple's rays end after ~14 steps (5.5 votes between refills at a batch of 32), the deep room's after ~90 (52
+// votes). A fixed batch of 32 idle lanes — right for the former — left the room's wavefronts a quarter empty (15.8 idle
+// lanes per vote, profiles/r04_vote_stats.json); 12 is right for the room (433 vs 455 ms) and costs killeroo 1 %. Measured
+// on both (profiles/r04_ab_refill_rule.txt): fixed batches of 8 / 12 / 16 / 24 / 32, a budget of wasted lane-steps (the
+// economic-order-quantity rule; worse than any fixed batch on both scenes: it refills two or three lanes at a time once they
+// have waited long enough), and the rule kept: the batch shrinks by one lane for every step the idle lanes have waited,
+//     refill when  idle lanes + steps since the first lane went idle >= idle_min   (and at least kRefillFloor lanes are idle),
+// which is a batch of ~28 for killeroo and ~12 for the room without knowing the scene.
+#ifndef IILE_REFILL_RAMP
+#define IILE_REFILL_RAMP 0
+#endif
+#ifndef IILE_REFILL_FLOOR
+#define IILE_REFILL_FLOOR 8
+#endif
 #ifndef IILE_REFILL_WASTE
 #define IILE_REFILL_WASTE 0
 #endif
 #ifndef IILE_REFILL_WASTE_GEN
 #define IILE_REFILL_WASTE_GEN 0
 #endif
+constexpr int kRefillFloor = IILE_REFILL_FLOOR;
 DEV bool refill_due(unsigned long long idle_mask, WaveFeed &f, int idle_min, uint32_t waste_max) {
     if (f.exhausted || idle_mask == 0) return false;
     const uint32_t n_idle = uint32_t(__popcll(idle_mask));
     bool due;
-    if (waste_max > 0) {
+    if (IILE_REFILL_RAMP) {
+        f.waste += 1;  // steps with idle lanes since the last refill
+        due = (n_idle >= uint32_t(kRefillFloor) && n_idle + f.waste >= uint32_t(idle_min)) || idle_mask == ~0ull;
+        if (due) f.waste = 0;
+    } else if (waste_max > 0) {
         f.waste += n_idle;
         due = f.waste >= waste_max || idle_mask == ~0ull;
         if (due) f.waste = 0;
@@ -166,9 +180,11 @@ DEV bool refill_due(unsigned long long idle_mask, WaveFeed &f, int idle_min, uin
     }
     return due;
 }
+
 // IILE_XCD_FEED: a queue is cut into eight contiguous partitions, one per XCD, each with a chunk cursor of its own; a wavefront
-// draws from the partition of the XCD it runs on and moves on to the next one when that is used up. Rays that are neighbours in a
-// queue (the same pixels, the same surfaces) then walk the tree behind ONE 4 MiB L2 instead of all eight.
+// draws from the partition of the XCD it runs on and moves on to the next one when that is used up, so that rays that are
+// neighbours in a queue walk the tree behind ONE 4 MiB L2 instead of all eight. Measured and left off: the room 484 vs 474 ms,
+// killeroo 52.4 vs 47.3 (profiles/r04_ab_traversal_scheduling.txt) — the L2s' hit rates are not what the traversal waits for.
 #ifndef IILE_XCD_FEED
 #define IILE_XCD_FEED 0
 #endif

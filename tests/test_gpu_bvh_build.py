@@ -3,6 +3,8 @@ src/accelerators/bvh.cpp:404-658 (oracle/oracle_bvh.cpp, pinned by the hand-deri
 the hand-derived case itself, the shipped scene and the deep-tree room through the loader's build hook, random soups through
 the direct call — then against the product's host builder, and the device-side packing of the traversal records against a
 numpy restatement of their layout."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -145,7 +147,7 @@ def test_degenerate_inputs(binding):
         binding.bvh_build_hlbvh(one, 0)
 
 
-def _pack_reference(nodes):
+def _pack_reference(nodes, ref_shift=0):
     """The two-wide and four-wide records of a flattened tree, restated with numpy."""
     interior = nodes["nprims"] == 0
     rec = np.cumsum(interior) - 1
@@ -175,6 +177,9 @@ def _pack_reference(nodes):
             w4i[ok, 24 + slot] = ref[gi][ok]
         meta |= np.where(leaf, 0, (nodes["axis"][C].astype(np.uint32) & 3) << (2 + 2 * side)).astype(np.uint32)
     w4i[:, 28] = meta.astype(np.int32)
+    if ref_shift:  # the refs carry the axes in their low two bits: slot 0 that of the node, slots 1 and 2 those of its children
+        axes = np.stack([meta & 3, (meta >> 2) & 3, (meta >> 4) & 3, np.zeros_like(meta)], axis=1).astype(np.int64)
+        w4i[:, 24:28] = ((w4i[:, 24:28].astype(np.int64) << ref_shift) | axes).astype(np.int32)
     return wide, w4
 
 
@@ -183,7 +188,9 @@ def test_wide_records_packed_on_the_device(binding, split):
     scene = binding.HostScene(xres=32, yres=32, spp=1, accel_split=split)
     nodes, _, _ = scene.bvh()
     wide, wide4, nested = binding.bvh_pack_probe(nodes)
-    rw, rw4 = _pack_reference(nodes)
+    lib = binding.gpu_lib()
+    lib.iile_wide_ref_shift.restype = ctypes.c_int32
+    rw, rw4 = _pack_reference(nodes, int(lib.iile_wide_ref_shift()))
     assert nested
     assert np.array_equal(wide.view(np.uint32), rw.view(np.uint32))
     assert np.array_equal(wide4.view(np.uint32), rw4.view(np.uint32))

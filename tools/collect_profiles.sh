@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun):
-#   tools/collect_profiles.sh <tag> [bench.py arguments, e.g. --workload boxroom]   -> gpurun_out/prof_<tag>/{stats,fetch,write,sq,tcc}/...
+#   tools/collect_profiles.sh <tag> [bench.py arguments, e.g. --workload boxroom]   -> gpurun_out/prof_<tag>/{stats,fetch,write,sq,tcc,sq2,mem}/...
 # (a tag containing "_room" marks the deep-tree workload: bench.py --workload boxroom loads profiles/*_room_pmc_*.json)
 # Pass 1: --kernel-trace --stats of the bench command (--alone-steps 0: only the instrumented step, the warm-up and the
 # timed steps launch kernels, so the plain builds' average durations are those of the two-stream schedule bench.py times). Passes 2-5: PMC counters in their own runs
@@ -24,5 +24,6 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d "$O/sq" -- python3 $ONE > "$O/sq.log" 2>&1
 timeout 600 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$O/tcc" -- python3 $ONE > "$O/tcc.log" 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 --kernel-trace --output-format csv -d "$O/sq2" -- python3 $ONE > "$O/sq2.log" 2>&1
+timeout 600 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/mem" -- python3 $ONE > "$O/mem.log" 2>&1
 find "$O" -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head -20
 tail -2 "$O"/*.log | cut -c1-300

@@ -113,7 +113,7 @@ if kernels:
                "families": fams, "kernels": kernels}, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 
 # ---- VALU / L2
-raw = load(("sq", "tcc", "sq2"))
+raw = load(("sq", "tcc", "sq2", "mem"))
 kernels, fams = {}, collections.defaultdict(lambda: collections.defaultdict(float))
 for k, v in raw.items():
     kernels[k] = {c: (int(x) if not c.startswith("launches@") else int(x)) for c, x in v.items()}
@@ -138,6 +138,13 @@ for fam, v in fams.items():
         e["wave_wait_any_frac"] = round(v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 4)
         e["wave_wait_inst_frac"] = round(v.get("SQ_WAIT_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 4)
         e["wave_active_inst_frac"] = round(v.get("SQ_ACTIVE_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 4)
+    if v.get("GRBM_GUI_ACTIVE") and v.get("TA_TA_BUSY_sum"):
+        # the vector-memory path, per CU and as a share of the kernel's own cycles (*_sum counters add up 256 CUs,
+        # GRBM_GUI_ACTIVE the 8 XCDs): address unit, data return; TCP_TOTAL_CACHE_ACCESSES = L1 accesses (the lane-loads of
+        # a divergent load instruction), the unit of bench.py's `vmem` roofline (tools/vmem_calib.hip)
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        e["ta_busy"] = round(v["TA_TA_BUSY_sum"] / 256.0 / cyc, 4)
+        e["td_busy"] = round(v.get("TD_TD_BUSY_sum", 0.0) / 256.0 / cyc, 4)
     if v.get("TCC_HIT_sum") or v.get("TCC_MISS_sum"):
         e["l2_hit_rate"] = round(v.get("TCC_HIT_sum", 0.0) / max(v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0), 1.0), 4)
     if fam in ("k_extend", "k_shade", "k_shadow", "k_mis"):
