@@ -615,7 +615,7 @@ def main():
             "built": ge.build_provenance(compiled_now),
             "per_rank": dict(primary["per_rank"], **{
                 "ranks": world,
-                "rccl_ranks": (comm.size if comm is not None else 1),
+                "rccl_ranks": (comm.ranks_seen if comm is not None else 1),   # ncclCommCount of the film-merge communicator
                 "ms_render_min_mean_max": [round(min(primary["per_rank"]["ms_render"]), 3),
                                            round(sum(primary["per_rank"]["ms_render"]) / len(primary["per_rank"]["ms_render"]), 3),
                                            round(max(primary["per_rank"]["ms_render"]), 3)],

@@ -36,6 +36,9 @@ int iile_dist_create(const uint8_t id[IILE_DIST_ID_BYTES], int32_t rank, int32_t
 void iile_dist_destroy(iile_dist *comm);
 int iile_dist_rank(const iile_dist *comm);
 int iile_dist_size(const iile_dist *comm);
+/* ncclCommCount of the communicator as RCCL reports it after ncclCommInitRank (0 if the query failed): bench.py prints it
+ * beside the launcher's world size, so that a communicator that does not span every rank shows in the bench line. */
+int iile_dist_ranks_seen(const iile_dist *comm);
 
 /* The film merge: film_xyzw_dev (device memory, 4 floats per pixel, n_pixels pixels on every rank) is summed over
  * the ranks, in place, into rank `root`'s buffer; the other ranks' buffers are unchanged. Enqueued on `stream`

@@ -152,11 +152,12 @@ int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, c
  * DOUBLES, over the film's cropped pixel bounds. The reference consumes ONE random stream per thread, and which thread renders
  * which pass is a race; here pass p (= first_pass + i) is seeded 6284 + 17 p — the seed a runner thread with that number would
  * clone its sampler with — and every pixel of it has its own PCG32 stream, consumed in the reference's per-pixel order (kernels_direct.hip).
- * accumulate == 0: the film is zeroed first. Not built, IILE_ERR_UNSUPPORTED: infinite lights; image textures combined with
- * mirror lobes (the reflected ray's differentials); glass (with allowMultipleLobes = false the direct integrator's Li branches
- * into a reflection and a transmission recursion at every glass vertex, glass.cpp:62-90); area lights with "nsamples" != 1
- * (the loader does not read the parameter: UniformSampleAllLights takes one sample per light, integrator.cpp:54-83).
- * The NEE record planes are sized for pixels x lights records per level. */
+ * accumulate == 0: the film is zeroed first. Every light is sampled Light::nSamples times per vertex (iile_light::n_samples;
+ * UniformSampleAllLights, integrator.cpp:54-83), infinite lights included (escaped rays return Le at every depth,
+ * directprogressiveintegrator.cpp:29-32); the NEE record planes are sized for pixels x (sum of the lights' nSamples) records
+ * per level, at most 64 light samples per vertex. Not built, IILE_ERR_UNSUPPORTED: image textures combined with mirror lobes
+ * (the reflected ray's differentials); glass (with allowMultipleLobes = false the direct integrator's Li branches into a
+ * reflection and a transmission recursion at every glass vertex, glass.cpp:62-90). */
 typedef struct iile_direct_params {
     int32_t n_passes, first_pass;
     int32_t accumulate;

@@ -3708,7 +3708,15 @@ int oracle_iispt_direct(const iile_scene_desc *scene, int trig_mode, int n_passe
     const iile_film_desc &F = S.film;
     for (int m = 0; m < S.n_materials; ++m)
         if (S.materials[m].type == IILE_MAT_GLASS) return 4;
+    // (textures that only an environment light uses — n_textures counts its Lmap — need no ray differentials)
+    bool textured_material = false;
     if (S.n_textures > 0)
+        for (int m = 0; m < S.n_materials; ++m) {
+            const iile_material &mm = S.materials[m];
+            for (int t : {mm.kd_tex, mm.ks_tex, mm.kr_tex, mm.kt_tex, mm.bump_tex, mm.rough_tex, mm.sigma_tex})
+                if (t >= 0) textured_material = true;
+        }
+    if (textured_material)
         for (int m = 0; m < S.n_materials; ++m)
             if (S.materials[m].type == IILE_MAT_MIRROR || (S.materials[m].type == IILE_MAT_UBER && (S.materials[m].kr[0] > 0 || S.materials[m].kr[1] > 0 || S.materials[m].kr[2] > 0)))
                 return 3;

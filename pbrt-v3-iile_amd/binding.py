@@ -122,7 +122,7 @@ GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iil
                "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download",
                "iile_iispt_hemi_points", "iile_iispt_gather", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct",
                "iile_wide_ref_shift"]
-DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size",
+DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size", "iile_dist_ranks_seen",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_rendezvous_file_token", "iile_dist_rendezvous_done", "iile_dist_all_ok",
                 "iile_dist_last_error"]
@@ -285,6 +285,9 @@ class Dist:
         if rc != 0:
             raise RuntimeError(f"iile_dist_create failed ({rc}): {lib.iile_dist_last_error().decode()}")
         self.rank, self.size = int(rank), int(nranks)
+        lib.iile_dist_ranks_seen.restype = ctypes.c_int
+        lib.iile_dist_ranks_seen.argtypes = [c_vp]
+        self.ranks_seen = int(lib.iile_dist_ranks_seen(self._c))  # ncclCommCount
 
     def _check(self, rc, what):
         if rc != 0:

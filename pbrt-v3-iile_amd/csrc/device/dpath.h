@@ -674,7 +674,7 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
 // compile to ds_write_b32 / ds_read_b32 (a generic pointer would go through flat_*).
 typedef __attribute__((address_space(3))) int lds_int;
 #ifndef IILE_LEAF_LOAD3
-#define IILE_LEAF_LOAD3 0
+#define IILE_LEAF_LOAD3 1  // round 4: the room 474 -> 455 ms, killeroo 47.3 -> 46.7 (profiles/r04_ab_traversal_scheduling.txt)
 #endif
 #ifndef IILE_LEAF_ONE
 #define IILE_LEAF_ONE 1

@@ -100,7 +100,7 @@ constexpr int kMaxTop = IILE_TOP_RECORDS;  // records of the tree's top kept in 
 // deep-tree room the traversal kernels retire vector-memory lane-loads at the rate the L1 path allows at all
 // (tools/vmem_calib.hip, profiles/r04_vmem_calib.json), and the only way to go faster is fewer of them.
 #ifndef IILE_AXES_IN_REFS
-#define IILE_AXES_IN_REFS 0
+#define IILE_AXES_IN_REFS 1
 #endif
 constexpr int kRefShift = IILE_AXES_IN_REFS ? 2 : 0;
 constexpr int kTopFlag = IILE_AXES_IN_REFS ? (1 << 28) : (1 << 30);  // reference to one of them: kTopFlag | slot (survives the shift)

@@ -134,22 +134,38 @@ constexpr uint32_t kChunk = IILE_CHUNK;
 #define IILE_REFILL_IDLE_GEN 56  // 47.5 -> 47.1 ms against 32: profiles/r03_ab_gen_refill.txt
 #endif
 constexpr int kRefillIdle = IILE_REFILL_IDLE;  // refill once this many lanes are idle (or all)
+#ifndef IILE_REFILL_START_SLOW
+#define IILE_REFILL_START_SLOW 0
+#endif
 struct WaveFeed {
     uint32_t cur, end;
     bool exhausted;
     uint32_t tried = 0;  // IILE_XCD_FEED: partitions of the queue this wavefront has found empty (its own XCD's first)
-    uint32_t waste = 0;  // lane-steps lost to idle lanes since the last refill (refill_due)
+    uint32_t waste = 0;  // votes with idle lanes (or lane-steps lost to them) since the last refill (refill_due)
+    bool slow = IILE_REFILL_START_SLOW != 0;  // IILE_REFILL_ADAPT: this wavefront's lanes go idle slowly: refill in small batches
 };
 // When to refill. A refill runs with only the idle lanes active, so it should wait for a batch of them; but every step it
-// waits costs one lane-step per idle lane, and how fast lanes go idle differs by two orders of magnitude between workloads:
-// killeroo-simple's rays end after ~14 steps (5.5 votes between refills at a batch of 32), the deep room's after ~90 (52
-// votes). A fixed batch of 32 idle lanes — right for the former — left the room's wavefronts a quarter empty (15.8 idle
-// lanes per vote, profiles/r04_vote_stats.json); 12 is right for the room (433 vs 455 ms) and costs killeroo 1 %. Measured
-// on both (profiles/r04_ab_refill_rule.txt): fixed batches of 8 / 12 / 16 / 24 / 32, a budget of wasted lane-steps (the
-// economic-order-quantity rule; worse than any fixed batch on both scenes: it refills two or three lanes at a time once they
-// have waited long enough), and the rule kept: the batch shrinks by one lane for every step the idle lanes have waited,
-//     refill when  idle lanes + steps since the first lane went idle >= idle_min   (and at least kRefillFloor lanes are idle),
-// which is a batch of ~28 for killeroo and ~12 for the room without knowing the scene.
+// waits costs one lane-step per idle lane, and how fast lanes go idle differs by an order of magnitude between workloads:
+// killeroo-simple's rays end after ~14 steps (5.8 lanes per vote go idle, 5.5 votes between refills at a batch of 32), the deep
+// room's after ~90 (0.6 lanes per vote, 52 votes). A fixed batch of 32 idle lanes — right for the former — left the room's
+// wavefronts a quarter empty (15.8 idle lanes per vote, profiles/r04_vote_stats.json); 12 is right for the room (432 vs 455 ms)
+// and wrong for killeroo. Measured on both (profiles/r04_ab_refill_rule.txt): fixed batches of 8 / 12 / 16 / 24 / 32; a budget of
+// wasted lane-steps (the economic-order-quantity rule: worse than any fixed batch on both scenes — it refills two or three lanes
+// at a time once they have waited long enough); a batch that shrinks by one lane per step waited (between the fixed batches);
+// and the rule kept (IILE_REFILL_ADAPT): every wavefront measures the rate at which ITS lanes go idle — idle lanes at a refill /
+// votes since the one before — and uses the small batch while that rate is below kRefillSlowRate lanes per vote.
+#ifndef IILE_REFILL_ADAPT
+#define IILE_REFILL_ADAPT 1
+#endif
+#ifndef IILE_REFILL_IDLE_SLOW
+#define IILE_REFILL_IDLE_SLOW 12      // batch for slowly finishing rays (deep trees)
+#endif
+#ifndef IILE_REFILL_IDLE_GEN_SLOW
+#define IILE_REFILL_IDLE_GEN_SLOW 24  // the same for the camera-ray build
+#endif
+#ifndef IILE_REFILL_SLOW_RATE
+#define IILE_REFILL_SLOW_RATE 3       // lanes per vote
+#endif
 #ifndef IILE_REFILL_RAMP
 #define IILE_REFILL_RAMP 0
 #endif
@@ -163,11 +179,20 @@ struct WaveFeed {
 #define IILE_REFILL_WASTE_GEN 0
 #endif
 constexpr int kRefillFloor = IILE_REFILL_FLOOR;
-DEV bool refill_due(unsigned long long idle_mask, WaveFeed &f, int idle_min, uint32_t waste_max) {
+constexpr int kRefillSlowRate = IILE_REFILL_SLOW_RATE;
+DEV bool refill_due(unsigned long long idle_mask, WaveFeed &f, int idle_min, uint32_t waste_max, int idle_min_slow = IILE_REFILL_IDLE_SLOW) {
     if (f.exhausted || idle_mask == 0) return false;
     const uint32_t n_idle = uint32_t(__popcll(idle_mask));
     bool due;
-    if (IILE_REFILL_RAMP) {
+    if (IILE_REFILL_ADAPT) {
+        f.waste += 1;  // votes with idle lanes since the last refill
+        const uint32_t batch = f.slow ? uint32_t(idle_min_slow) : uint32_t(idle_min);
+        due = n_idle >= batch || idle_mask == ~0ull;
+        if (due) {
+            f.slow = n_idle < uint32_t(kRefillSlowRate) * f.waste;  // fewer than kRefillSlowRate lanes per vote went idle
+            f.waste = 0;
+        }
+    } else if (IILE_REFILL_RAMP) {
         f.waste += 1;  // steps with idle lanes since the last refill
         due = (n_idle >= uint32_t(kRefillFloor) && n_idle + f.waste >= uint32_t(idle_min)) || idle_mask == ~0ull;
         if (due) f.waste = 0;

@@ -97,6 +97,21 @@ struct FilmBuffers {
     float2 *wide_pf;    // pFilm
 };
 
+// The exact finish of film pixels reached by samples with whole-number film positions, on the device (kernels.hip
+// "exact film finish"; DESIGN.md section 4 "Whole-number film positions"): hit records {destination pixel, flagged sample},
+// a hash table destination -> list of its hits, and the exact FilmTile sums ("entries") the passes of a frame produce.
+struct PatchDev {
+    uint32_t *counters;   // [0] hits of this pass, [1] entries of this render, [2] error bits (1: list overflow, 2: table full)
+    uint4 *hits;          // {destination film index, flagged sample, next hit of the same destination, -}
+    uint32_t *keys;       // open-addressing table over film indices (0xffffffff: empty) ...
+    uint32_t *heads;      // ... and the head of each one's list (0xffffffff: none)
+    uint32_t table_mask;
+    uint4 *ent_a;         // {film index, tile, nonplain, next entry of the same film index}
+    float4 *ent_b;        // {r, g, b, w}: what that tile's FilmTile holds for that pixel
+    uint32_t cap_hits, cap_entries;
+};
+constexpr uint32_t kPatchNil = 0xffffffffu;
+
 struct LaunchCfg {
     int n_cus;
     hipStream_t stream;
@@ -130,6 +145,7 @@ void launch_film_store(const DScene &S, const PassDesc &P, const PassBuffers &B,
 void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F, int n_samples, const LaunchCfg &cfg);
 void launch_direct_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg);
 void launch_direct_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int depth, uint32_t max_rays, const LaunchCfg &cfg);
+void launch_direct_miss(const DScene &S, const PassBuffers &B, int depth, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_direct_fold(const DScene &S, const PassDesc &P, const PassBuffers &B, double *film_rgbw, const LaunchCfg &cfg);
 void launch_probe_finish(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int n_probes,
                          float *intensity, float *normals, float *distance, const LaunchCfg &cfg);
@@ -168,6 +184,9 @@ void launch_camera(const DScene &S, int n, const float *pfilm, const float *plen
 void launch_bsdf_probe(const DScene &S, int n, int mat, const float *wo, const float *wi_or_u, int sample,
                        float *out, const LaunchCfg &cfg);
 void launch_trig_probe(int n, const float *x, float *out, const LaunchCfg &cfg);
+// one pass's flagged samples -> entries (after the pass's k_film_accumulate); all entries -> film (after k_film_resolve)
+void launch_patch_pass(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, const PatchDev &D, const LaunchCfg &cfg);
+void launch_patch_merge(const DScene &S, const PassDesc &P, const FilmBuffers &F, const PatchDev &D, const LaunchCfg &cfg);
 void launch_patch_own(const DScene &S, const float4 *L, int n, const uint32_t *local_slot, const uint32_t *range3, const uint32_t *flag_pid,
                       int kc, float4 *out, const LaunchCfg &cfg);
 void launch_gather4(const float4 *src, const uint32_t *idx, int n, float4 *out, const LaunchCfg &cfg);

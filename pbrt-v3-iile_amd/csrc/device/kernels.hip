@@ -587,6 +587,264 @@ __global__ void k_patch_own(DScene S, const float4 *L, int n, const uint32_t *lo
     for (uint32_t h = b1; h < b2; ++h) add(L[flag_pid[h]]);
     out[i] = make_float4(r, g, b, w);
 }
+// ---------------------------------------------------------------------------
+// Exact film finish on the device. What patch_prepare / patch_pass_finish / patch_merge of api.hip do with the host in the
+// loop (kept behind IILE_DEBUG_HOST_FILM_FINISH as the A/B witness), as four small kernels that never leave the stream:
+//   k_patch_hits    every flagged sample (kcommon.h flag_whole_film_position) -> one hit record per OTHER pixel it lands in
+//                   (FilmTile::AddSample's support, film.h:159-166, clipped to its tile's FilmTile bounds, film.cpp:92-103),
+//                   linked into the list of its destination through a hash table over film indices
+//   k_patch_dests   the thread that finds its hit at the head of a destination's list walks that list in GENERATION order
+//                   (tile, pixel of the tile, sample: the order in which one thread of the reference would have added them)
+//                   and forms, per contributing tile, the exact FilmTile sum for that pixel -> an entry
+//   k_patch_index / k_patch_merge   after k_film_resolve: per film pixel with an entry that the resolve kernel cannot have
+//                   placed, the tiles' sums (and the pixel's own tile sum if no entry covers it) converted to XYZ and added
+//                   in tile index order (Film::MergeFilmTile, film.cpp:135-148)
+// Lists are short (a sample lands in at most three other pixels, a pixel is reached by a handful): they are walked by repeated
+// selection of the next key instead of being sorted, which needs no bound on their length.
+namespace {
+struct FlagRec {
+    int px, py, k, tile, pix;
+    float pfx, pfy;
+    uint32_t pid;
+    bool plain_k0;
+};
+DEV FlagRec flag_decode(const DScene &S, int ntx, const float *flag_rec, uint32_t i) {
+    const float *r = flag_rec + 6 * size_t(i);
+    const uint32_t u2 = f2b(r[2]);
+    FlagRec f;
+    f.px = int(f2b(r[0])), f.py = int(f2b(r[1])), f.k = int(u2 & 0x3fffffffu);
+    f.pfx = r[3], f.pfy = r[4];
+    f.pid = f2b(r[5]);
+    const int tx = (f.px - S.samp_x0) / kTile, ty = (f.py - S.samp_y0) / kTile;
+    f.pix = (f.py - S.samp_y0 - ty * kTile) * kTile + (f.px - S.samp_x0 - tx * kTile);
+    f.tile = ty * ntx + tx;
+    const bool zero_x = (u2 >> 30) & 1u, zero_y = (u2 >> 31) & 1u;
+    const bool whole_x = f.pfx == float(f.px) || f.pfx == float(f.px + 1), whole_y = f.pfy == float(f.py) || f.pfy == float(f.py + 1);
+    f.plain_k0 = f.k == 0 && (!whole_x || zero_x) && (!whole_y || zero_y);  // k_film_resolve places these by itself
+    return f;
+}
+DEV unsigned long long gen_key(const FlagRec &f) {
+    return (static_cast<unsigned long long>(uint32_t(f.tile)) << 40) | (static_cast<unsigned long long>(uint32_t(f.pix)) << 32) |
+           static_cast<unsigned long long>(uint32_t(f.k));
+}
+DEV uint32_t patch_hash(uint32_t key) { return key * 2654435761u; }
+// claim (or find) the table slot of `key`; kPatchNil when the table is full
+DEV uint32_t patch_slot(const PatchDev &D, uint32_t key, bool insert) {
+    uint32_t s = patch_hash(key) & D.table_mask;
+    for (uint32_t probe = 0; probe <= D.table_mask; ++probe, s = (s + 1) & D.table_mask) {
+        const uint32_t seen = insert ? atomicCAS(&D.keys[s], kPatchNil, key) : D.keys[s];
+        if (seen == key || (insert && seen == kPatchNil)) return s;
+        if (!insert && seen == kPatchNil) return kPatchNil;
+    }
+    return kPatchNil;
+}
+}  // namespace
+
+__global__ __launch_bounds__(kBlock) void k_patch_hits(DScene S, int ntx, PatchDev D, const uint32_t *flag_count, const float *flag_rec) {
+    uint32_t n_flag = *flag_count;
+    if (n_flag > kMaxFlagged) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&D.counters[2], 1u);
+        n_flag = kMaxFlagged;
+    }
+    const int fw = S.crop_x1 - S.crop_x0;
+    const float r = 0.5f;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_flag; i += gridDim.x * kBlock) {
+        const FlagRec f = flag_decode(S, ntx, flag_rec, i);
+        const int tx = f.tile % ntx, ty = f.tile / ntx;
+        const int sx0 = S.samp_x0 + tx * kTile, sy0 = S.samp_y0 + ty * kTile;
+        const int sx1 = min(sx0 + kTile, S.samp_x1), sy1 = min(sy0 + kTile, S.samp_y1);
+        // Film::GetFilmTile bounds of the sample's tile, film.cpp:92-103
+        const int fx0 = max(int(ceilf(float(sx0) - 0.5f - r)), S.crop_x0), fx1 = min(int(floorf(float(sx1) - 0.5f + r)) + 1, S.crop_x1);
+        const int fy0 = max(int(ceilf(float(sy0) - 0.5f - r)), S.crop_y0), fy1 = min(int(floorf(float(sy1) - 0.5f + r)) + 1, S.crop_y1);
+        const float dxf = f.pfx - 0.5f, dyf = f.pfy - 0.5f;
+        const int ax0 = max(int(ceilf(dxf - r)), fx0), ax1 = min(int(floorf(dxf + r)) + 1, fx1);
+        const int ay0 = max(int(ceilf(dyf - r)), fy0), ay1 = min(int(floorf(dyf + r)) + 1, fy1);
+        for (int y = ay0; y < ay1; ++y)
+            for (int x = ax0; x < ax1; ++x) {
+                if (x == f.px && y == f.py) continue;
+                const uint32_t dest = uint32_t(y - S.crop_y0) * uint32_t(fw) + uint32_t(x - S.crop_x0);
+                const uint32_t h = atomicAdd(&D.counters[0], 1u);
+                if (h >= D.cap_hits) {
+                    atomicOr(&D.counters[2], 1u);
+                    continue;
+                }
+                const uint32_t s = patch_slot(D, dest, true);
+                if (s == kPatchNil) {
+                    atomicOr(&D.counters[2], 2u);
+                    D.hits[h] = make_uint4(dest, i, kPatchNil, 1u);  // (never a list head: no thread processes it)
+                    continue;
+                }
+                const uint32_t before = atomicExch(&D.heads[s], h);
+                D.hits[h] = make_uint4(dest, i, before, 0u);
+            }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_patch_dests(DScene S, PassDesc P, PassBuffers B, FilmBuffers F, PatchDev D, int whole_frame) {
+    const uint32_t n_hits = min(D.counters[0], D.cap_hits);
+    const int ntx = P.n_tiles_x, fw = S.crop_x1 - S.crop_x0;
+    for (uint32_t h0 = blockIdx.x * kBlock + threadIdx.x; h0 < n_hits; h0 += gridDim.x * kBlock) {
+        const uint4 me = D.hits[h0];
+        if (me.w != 0u) continue;
+        const uint32_t slot_t = patch_slot(D, me.x, false);
+        if (slot_t == kPatchNil || D.heads[slot_t] != h0) continue;  // one thread per destination: the head of its list
+        // the destination pixel
+        const uint32_t film_index = me.x;
+        const int qx = S.crop_x0 + int(film_index % uint32_t(fw)), qy = S.crop_y0 + int(film_index / uint32_t(fw));
+        const bool in_bounds = qx >= S.samp_x0 && qx < S.samp_x1 && qy >= S.samp_y0 && qy < S.samp_y1;
+        int d_tile = -1, d_pix = 0;
+        bool own_in_pass = false;
+        uint32_t own_slot = 0;
+        if (in_bounds) {
+            const int tx = (qx - S.samp_x0) / kTile, ty = (qy - S.samp_y0) / kTile;
+            d_pix = (qy - S.samp_y0 - ty * kTile) * kTile + (qx - S.samp_x0 - tx * kTile);
+            d_tile = ty * ntx + tx;
+            const int slot = P.slot_of_tile ? P.slot_of_tile[d_tile] : d_tile;
+            if (slot >= 0) {
+                own_in_pass = slot >= P.slot0 && slot < P.slot0 + P.n_pass_tiles;
+                own_slot = uint32_t(slot) * 256u + uint32_t(d_pix);
+            }
+        }
+        bool all_plain = true, need_own = false;
+        for (uint32_t h = h0; h != kPatchNil; h = D.hits[h].z) {
+            const FlagRec f = flag_decode(S, ntx, B.flag_rec, D.hits[h].y);
+            all_plain = all_plain && f.plain_k0;
+            if (own_in_pass && f.tile == d_tile && f.pix < d_pix) need_own = true;
+        }
+        // the pass is the whole frame: a pixel reached only by samples k_film_resolve places itself needs nothing
+        if (whole_frame && all_plain) continue;
+        float rr = 0, gg = 0, bb = 0, ww = 0;
+        auto add = [&](uint32_t pid) {
+            const float4 v = B.L[pid];
+            const F3 c = guard_radiance(S, F3{v.x, v.y, v.z});
+            rr += c.x * 1.f * 1.f;
+            gg += c.y * 1.f * 1.f;
+            bb += c.z * 1.f * 1.f;
+            ww += 1.f;
+        };
+        auto add_own_samples = [&]() {  // (need_own: the pixel's own samples between the earlier and the later pixels' ones)
+            const uint32_t first = (own_slot - uint32_t(P.slot0) * 256u) * uint32_t(P.kc);
+            for (int k = 0; k < P.kc; ++k) add(first + uint32_t(k));
+        };
+        int cur_tile = -1;
+        bool nonplain = false, own_run = false, own_done = false;
+        auto emit = [&]() {
+            if (own_run && need_own && !own_done) add_own_samples();
+            const uint32_t e = atomicAdd(&D.counters[1], 1u);
+            if (e >= D.cap_entries) {
+                atomicOr(&D.counters[2], 1u);
+                return;
+            }
+            D.ent_a[e] = make_uint4(film_index, uint32_t(cur_tile), nonplain ? 1u : 0u, kPatchNil);
+            D.ent_b[e] = make_float4(rr, gg, bb, ww);
+        };
+        unsigned long long prev = 0;
+        bool have_prev = false;
+        for (;;) {
+            // the next hit in generation order
+            uint32_t best = kPatchNil;
+            unsigned long long best_key = ~0ull;
+            for (uint32_t h = h0; h != kPatchNil; h = D.hits[h].z) {
+                const unsigned long long key = gen_key(flag_decode(S, ntx, B.flag_rec, D.hits[h].y));
+                if ((!have_prev || key > prev) && key < best_key) best = h, best_key = key;
+            }
+            if (best == kPatchNil) break;
+            prev = best_key, have_prev = true;
+            const FlagRec f = flag_decode(S, ntx, B.flag_rec, D.hits[best].y);
+            if (f.tile != cur_tile) {
+                if (cur_tile >= 0) emit();
+                cur_tile = f.tile;
+                rr = gg = bb = ww = 0.f;
+                nonplain = false;
+                own_run = own_in_pass && f.tile == d_tile;
+                own_done = false;
+                if (own_run && !need_own) {  // the finished sum of its own samples (k_film_accumulate), the later pixels' ones follow
+                    const float4 own = F.tile_rgbw[own_slot];
+                    rr = own.x, gg = own.y, bb = own.z, ww = own.w;
+                }
+            }
+            if (own_run && need_own && !own_done && f.pix > d_pix) {
+                add_own_samples();
+                own_done = true;
+            }
+            add(f.pid);
+            nonplain = nonplain || !f.plain_k0;
+        }
+        if (cur_tile >= 0) emit();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_patch_index(PatchDev D) {
+    const uint32_t n = min(D.counters[1], D.cap_entries);
+    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < n; e += gridDim.x * kBlock) {
+        const uint32_t s = patch_slot(D, D.ent_a[e].x, true);
+        if (s == kPatchNil) {
+            atomicOr(&D.counters[2], 2u);
+            continue;
+        }
+        D.ent_a[e].w = atomicExch(&D.heads[s], e);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_patch_merge(DScene S, PassDesc P, FilmBuffers F, PatchDev D) {
+    const uint32_t n = min(D.counters[1], D.cap_entries);
+    const int ntx = P.n_tiles_x, fw = S.crop_x1 - S.crop_x0;
+    for (uint32_t e0 = blockIdx.x * kBlock + threadIdx.x; e0 < n; e0 += gridDim.x * kBlock) {
+        const uint32_t film_index = D.ent_a[e0].x;
+        const uint32_t slot_t = patch_slot(D, film_index, false);
+        if (slot_t == kPatchNil || D.heads[slot_t] != e0) continue;  // one thread per film pixel
+        bool nonplain = false;
+        for (uint32_t e = e0; e != kPatchNil; e = D.ent_a[e].w) nonplain = nonplain || D.ent_a[e].z != 0u;
+        if (!nonplain) continue;  // k_film_resolve has placed everything that reaches this pixel
+        // the pixel's own tile, if it is owned and no entry covers it: its finished sum takes its place in tile order
+        const int qx = S.crop_x0 + int(film_index % uint32_t(fw)), qy = S.crop_y0 + int(film_index / uint32_t(fw));
+        int own_tile = -1;
+        float4 own = make_float4(0, 0, 0, 0);
+        if (qx >= S.samp_x0 && qx < S.samp_x1 && qy >= S.samp_y0 && qy < S.samp_y1) {
+            const int tx = (qx - S.samp_x0) / kTile, ty = (qy - S.samp_y0) / kTile, t = ty * ntx + tx;
+            bool covered = false;
+            for (uint32_t e = e0; e != kPatchNil; e = D.ent_a[e].w) covered = covered || int(D.ent_a[e].y) == t;
+            const int slot = P.slot_of_tile ? P.slot_of_tile[t] : t;
+            if (!covered && slot >= 0) {
+                own_tile = t;
+                own = F.tile_rgbw[uint32_t(slot) * 256u + uint32_t((qy - S.samp_y0 - ty * kTile) * kTile + (qx - S.samp_x0 - tx * kTile))];
+            }
+        }
+        float4 o = make_float4(0, 0, 0, 0);
+        bool own_added = own_tile < 0;
+        int prev_tile = -1;
+        for (;;) {
+            uint32_t best = kPatchNil;
+            int best_tile = 0x7fffffff;
+            for (uint32_t e = e0; e != kPatchNil; e = D.ent_a[e].w) {
+                const int t = int(D.ent_a[e].y);
+                if (t > prev_tile && t < best_tile) best = e, best_tile = t;
+            }
+            if (best == kPatchNil) break;
+            prev_tile = best_tile;
+            if (!own_added && own_tile < best_tile) {
+                add_xyz(&o, own.x, own.y, own.z, own.w);
+                own_added = true;
+            }
+            const float4 v = D.ent_b[best];
+            add_xyz(&o, v.x, v.y, v.z, v.w);
+        }
+        if (!own_added) add_xyz(&o, own.x, own.y, own.z, own.w);
+        F.film_xyzw[film_index] = o;
+    }
+}
+
+void launch_patch_pass(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, const PatchDev &D, const LaunchCfg &cfg) {
+    // (the table is cleared by the caller: two hipMemsetAsync of 0xff)
+    const int whole_frame = P.n_pass_tiles == P.n_owned_tiles ? 1 : 0;
+    hipLaunchKernelGGL(k_patch_hits, dim3(64), dim3(kBlock), 0, cfg.stream, S, P.n_tiles_x, D, B.flag_count, B.flag_rec);
+    hipLaunchKernelGGL(k_patch_dests, dim3(128), dim3(kBlock), 0, cfg.stream, S, P, B, F, D, whole_frame);
+}
+void launch_patch_merge(const DScene &S, const PassDesc &P, const FilmBuffers &F, const PatchDev &D, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_patch_index, dim3(64), dim3(kBlock), 0, cfg.stream, D);
+    hipLaunchKernelGGL(k_patch_merge, dim3(128), dim3(kBlock), 0, cfg.stream, S, P, F, D);
+}
+
 void launch_patch_own(const DScene &S, const float4 *L, int n, const uint32_t *local_slot, const uint32_t *range3, const uint32_t *flag_pid,
                       int kc, float4 *out, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_patch_own, dim3((n + 63) / 64), dim3(64), 0, cfg.stream, S, L, n, local_slot, range3, flag_pid, kc, out);

@@ -173,9 +173,37 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
             if (valid && lit_surface) {
                 const DLight &lt = S.lights[li];
                 const float ul0 = pcg_float(ra), ul1 = pcg_float(ra), us0 = pcg_float(rb), us1 = pcg_float(rb);
-                if (lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
+                if (lt.type == kLightInfinite) {
+                    // EstimateDirect for the infinite light (integrator.cpp:108-215), as k_shade has it: the light-sampling half
+                    // through the environment map's Distribution2D, the BSDF-sampling half whose ray contributes Le(ray) when it
+                    // escapes (:209-210; k_mis marks escaped rays, k_mis_lit accepts them for an infinite light)
+                    float light_pdf = 0, scattering_pdf = 0;
+                    F3 wi = F3{0, 0, 0}, target = F3{0, 0, 0};
+                    const F3 Li = inf_sample_li(S, lt, is.p, ul0, ul1, &wi, &light_pdf, &target);
+                    if (light_pdf > 0 && !is_black(Li)) {
+                        const F3 f = bsdf_f(bsdf, is.wo, wi) * absdot(wi, is.sn);
+                        scattering_pdf = bsdf_pdf(bsdf, is.wo, wi);
+                        if (!is_black(f)) {
+                            so = offset_ray_origin(is.p, is.perr, is.n, target - is.p);
+                            sd = target - so;
+                            A = sdiv(f * Li * power_heuristic(light_pdf, scattering_pdf), light_pdf);
+                            nee_flags |= NEE_HAS_SHADOW;
+                        }
+                    }
+                    F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
+                    f2 = f2 * absdot(wi, is.sn);
+                    if (!is_black(f2) && scattering_pdf > 0) {
+                        const float lp = inf_pdf_li(S, lt, wi);
+                        if (lp != 0) {
+                            mo = offset_ray_origin(is.p, is.perr, is.n, wi);
+                            md = wi;
+                            Bc = sdiv(f2 * inf_le(S, lt, wi) * power_heuristic(scattering_pdf, lp), scattering_pdf);
+                            nee_flags |= NEE_HAS_MIS;
+                        }
+                    }
+                } else if (lt.type != kLightDiffuseArea && lt.type != kLightAreaTriangle) {
                     // EstimateDirect for a delta light (integrator.cpp:150-166): light sample only. PointLight (lights/point.cpp:
-                    // 43-52), SpotLight (spot.cpp:53-76), DistantLight (distant.cpp:50-61). (Infinite lights: rejected up front.)
+                    // 43-52), SpotLight (spot.cpp:53-76), DistantLight (distant.cpp:50-61).
                     const F3 pos = F3{lt.pos[0], lt.pos[1], lt.pos[2]};
                     const F3 I = F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]};
                     F3 wi, target, Li;
@@ -308,6 +336,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
     out_flush(mis_out, pad_mis);
 }
 
+// A ray that leaves the scene returns the infinite lights' radiance (directprogressiveintegrator.cpp:29-32: `for (const auto
+// &light : scene.lights) L += light->Le(ray)`, at ANY depth — the path integrator adds it only at the camera vertex or after a
+// specular bounce): it lands in E[depth], where a hit vertex has its emitted light. Launched for scenes with an infinite light.
+__global__ __launch_bounds__(kBlock) void k_direct_miss(DScene S, PassBuffers B, int depth) {
+    const uint32_t count = B.counts[kCntRay + depth];
+    const float4 *ro = B.ray_o[depth & 1], *rd = B.ray_d[depth & 1];
+    for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < count; slot += gridDim.x * kBlock) {
+        const uint32_t pid = f2b(ro[slot].w);
+        if (pid == kInvalid) continue;
+        if (int(f2b(B.hits[slot].x)) >= 0) continue;
+        const float4 d4 = rd[slot];
+        const F3 d = F3{d4.x, d4.y, d4.z};
+        F3 L = F3{0, 0, 0};
+        for (int l = 0; l < S.n_lights; ++l)
+            if (S.lights[l].type == kLightInfinite) L = L + inf_le(S, S.lights[l], d);
+        B.dir_E[size_t(depth) * B.dir_paths + pid] = make_float4(L.x, L.y, L.z, 0);
+    }
+}
+
 // Li folded from the deepest vertex back (the recursion returns in that order), the render loop's guards
 // (directprogressiveintegrator.cpp:104-127), IisptFilmMonitor::add_n_samples (iisptfilmmonitor.cpp:47-72: doubles)
 __global__ __launch_bounds__(kBlock) void k_direct_fold(DScene S, PassDesc P, PassBuffers B, double *film_rgbw) {
@@ -366,6 +413,9 @@ void launch_direct_shade(const DScene &S, const PassDesc &P, const PassBuffers &
         hipLaunchKernelGGL((k_direct_shade<true>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, depth, B.queue_cap);
     else
         hipLaunchKernelGGL((k_direct_shade<false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, depth, B.queue_cap);
+}
+void launch_direct_miss(const DScene &S, const PassBuffers &B, int depth, uint32_t max_rays, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_direct_miss, dim3(grid_blocks(max_rays, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, B, depth);
 }
 void launch_direct_fold(const DScene &S, const PassDesc &P, const PassBuffers &B, double *film_rgbw, const LaunchCfg &cfg) {
     hipLaunchKernelGGL(k_direct_fold, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);

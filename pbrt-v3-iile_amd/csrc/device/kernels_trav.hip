@@ -100,7 +100,8 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
         TRAV_STAMP(3);
         const unsigned long long idle_mask = __ballot(!active);
         // (the camera-ray build makes its rays here, some 400 instructions each: it waits for more idle lanes than the others)
-        if (refill_due(idle_mask, feed, GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle, GEN ? IILE_REFILL_WASTE_GEN : IILE_REFILL_WASTE)) {
+        if (refill_due(idle_mask, feed, GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle, GEN ? IILE_REFILL_WASTE_GEN : IILE_REFILL_WASTE,
+                       GEN ? IILE_REFILL_IDLE_GEN_SLOW : IILE_REFILL_IDLE_SLOW)) {
             uint32_t s_new;
 #ifdef IILE_TRAV_ITERSTATS
             iter_stat[7] += 1;

@@ -41,6 +41,10 @@ struct iile_dist {
     int rank = 0, size = 1;
     void *scratch = nullptr;  // device staging of the small host-side totals
     size_t scratch_bytes = 0;
+    // the host-value collectives (iile_dist_sum_u64 / _max_f64 / _all_ok) run on a non-blocking stream of the communicator's
+    // own: the null stream they used until round 3 synchronises with every blocking stream of the process, i.e. with the render
+    hipStream_t host_stream = nullptr;
+    int ranks_seen = 0;       // ncclCommCount at creation: what RCCL itself thinks the communicator spans
 };
 
 namespace {
@@ -59,10 +63,11 @@ int all_reduce_host(iile_dist *d, T *values, int n, ncclDataType_t type, ncclRed
     if (n == 0) return IILE_OK;
     int rc = ensure_scratch(d, size_t(n) * sizeof(T));
     if (rc) return rc;
-    HIPD_TRY(hipMemcpy(d->scratch, values, size_t(n) * sizeof(T), hipMemcpyHostToDevice));
-    NCCL_TRY(ncclAllReduce(d->scratch, d->scratch, size_t(n), type, op, d->comm, nullptr));
-    HIPD_TRY(hipStreamSynchronize(nullptr));
-    HIPD_TRY(hipMemcpy(values, d->scratch, size_t(n) * sizeof(T), hipMemcpyDeviceToHost));
+    if (!d->host_stream) HIPD_TRY(hipStreamCreateWithFlags(&d->host_stream, hipStreamNonBlocking));
+    HIPD_TRY(hipMemcpyAsync(d->scratch, values, size_t(n) * sizeof(T), hipMemcpyHostToDevice, d->host_stream));
+    NCCL_TRY(ncclAllReduce(d->scratch, d->scratch, size_t(n), type, op, d->comm, d->host_stream));
+    HIPD_TRY(hipMemcpyAsync(values, d->scratch, size_t(n) * sizeof(T), hipMemcpyDeviceToHost, d->host_stream));
+    HIPD_TRY(hipStreamSynchronize(d->host_stream));  // the caller wants the values: it waits for THIS stream only
     return IILE_OK;
 }
 }  // namespace
@@ -95,12 +100,14 @@ int iile_dist_create(const uint8_t id[IILE_DIST_ID_BYTES], int32_t rank, int32_t
         delete d;
         return fail(IILE_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
     }
+    if (ncclCommCount(d->comm, &d->ranks_seen) != ncclSuccess) d->ranks_seen = 0;
     *out = d;
     return IILE_OK;
 }
 
 void iile_dist_destroy(iile_dist *d) {
     if (!d) return;
+    if (d->host_stream) (void)hipStreamDestroy(d->host_stream);
     if (d->scratch) (void)hipFree(d->scratch);
     if (d->comm) (void)ncclCommDestroy(d->comm);
     delete d;
@@ -108,6 +115,7 @@ void iile_dist_destroy(iile_dist *d) {
 
 int iile_dist_rank(const iile_dist *d) { return d ? d->rank : 0; }
 int iile_dist_size(const iile_dist *d) { return d ? d->size : 1; }
+int iile_dist_ranks_seen(const iile_dist *d) { return d ? d->ranks_seen : 0; }
 
 int iile_dist_film_reduce(iile_dist *d, float *film, int64_t n_pixels, int32_t root, void *stream) {
     if (!d || !film || n_pixels < 0 || root < 0 || root >= d->size) return fail(IILE_ERR_ARG, "iile_dist_film_reduce: bad argument");

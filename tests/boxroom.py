@@ -123,7 +123,7 @@ def _grid_quad(origin, du, dv, n):
 
 
 def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, seed=12111, maxdepth=5, light="area", materials="plain",
-                 textures=None):
+                 textures=None, env_dir=None):
     """Returns the scene text. Triangles: 5 * 2 * wall_n^2 + n_blobs * 20 * 4^ico_levels
     (defaults: 5 760 + 30 720; ico_levels=5, n_blobs=12, wall_n=64 gives ~287 k).
     `textures`: a directory — image files are written there (write_test_images) and the walls (uv-mapped,
@@ -135,16 +135,18 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
            'WorldBegin']
     if light == "envmap":  # an environment-mapped sky (lat-long PFM, 12 x 6: resampled to 16 x 8) through the open top
         import os
-        assert textures is not None, "light='envmap' writes its map into the `textures` directory"
-        os.makedirs(textures, exist_ok=True)
+        # the map goes into `env_dir` (an environment map over untextured materials), else into the `textures` directory
+        env_dir = env_dir if env_dir is not None else textures
+        assert env_dir is not None, "light='envmap' writes its map into the `env_dir` / `textures` directory"
+        os.makedirs(env_dir, exist_ok=True)
         h, w = 6, 12
         y, x = np.mgrid[0:h, 0:w]
         sky = np.stack([0.3 + 0.05 * y, 0.4 + 0.04 * y, 0.9 - 0.1 * y], -1).astype(np.float32)
         sky[1, 3] = (60, 50, 30)   # the sun
         sky[4:, :] *= 0.2          # dim ground
-        open(os.path.join(textures, "sky.pfm"), "wb").write(b"PF\n%d %d\n-1.0\n" % (w, h) + sky[::-1].tobytes())
+        open(os.path.join(env_dir, "sky.pfm"), "wb").write(b"PF\n%d %d\n-1.0\n" % (w, h) + sky[::-1].tobytes())
         out.append('AttributeBegin\n  Rotate 25 0 1 0\n  Rotate 40 0 0 1\n  LightSource "infinite" "color L" [1 .9 .8] "color scale" [1.5 1.5 1.5] '
-                   '"string mapname" ["%s"]\nAttributeEnd' % os.path.join(textures, "sky.pfm"))
+                   '"string mapname" ["%s"]\nAttributeEnd' % os.path.join(env_dir, "sky.pfm"))
     elif light == "sky":  # uniform sky through the open top (no ceiling below) and a warm point light inside
         out.append('AttributeBegin\n  Rotate 25 0 1 0\n  LightSource "infinite" "color L" [.6 .7 1] "color scale" [1.5 1.5 1.5]\nAttributeEnd')
         out.append('LightSource "point" "color I" [25 15 8] "point from" [-6 5 2]')

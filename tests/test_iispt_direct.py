@@ -121,6 +121,33 @@ def test_direct_pass_takes_nsamples_light_samples(binding, oracle, tmp_path):
     assert '"integer nsamples" [8]' in open(os.path.join(repo, "scenes", "killeroo-simple.pbrt")).read()
 
 
+_SKY_SCENE = """LookAt 0 -4 0  0 0 0  0 0 1
+Camera "perspective" "float fov" [40]
+Film "image" "integer xresolution" [32] "integer yresolution" [32]
+Sampler "halton" "integer pixelsamples" [1]
+Integrator "path"
+WorldBegin
+LightSource "infinite" "color L" [1 1 1] "color scale" [.8 .8 .8]
+Material "matte" "color Kd" [.5 .5 .5]
+Shape "sphere" "float radius" [1]
+WorldEnd
+"""
+
+
+def test_direct_pass_under_a_uniform_sky(binding, oracle, tmp_path):
+    """directprogressiveintegrator.cpp:29-32: a ray that leaves the scene returns the lights' Le(ray) — at any depth, not only
+    at the camera vertex as in the path integrator. A convex Lambertian body under a uniform sky L is the analytic case
+    (VERDICT r03 "next" 7): the background is L, every point of the body receives irradiance pi L unoccluded and shows Kd L."""
+    path = tmp_path / "sky.pbrt"
+    path.write_text(_SKY_SCENE)
+    scene = binding.HostScene(path=str(path))
+    film = oracle.iispt_direct(scene, 64, trig_mode=ob.TRIG_LIBM)
+    img = film[..., :3] / film[..., 3:4]
+    assert np.allclose(img[0, 0], 0.8, atol=1e-6) and np.allclose(img[-1, -1], 0.8, atol=1e-6)   # corners: sky
+    centre = img[12:20, 12:20]                                                                    # well inside the sphere's disc
+    assert abs(centre.mean() - 0.4) < 0.01, centre.mean()
+
+
 # ---- the device pass against the oracle -------------------------------------------------------------------------------------
 
 
@@ -180,6 +207,30 @@ def test_device_direct_pass_eight_lights_on_a_large_frame(binding, oracle, tmp_p
     ref = oracle.iispt_direct(scene, 1)
     assert np.array_equal(dev.view(np.uint64), ref.view(np.uint64))
     assert (ref[..., :3].sum(axis=2) > 0).mean() > 0.9  # a closed, lit room: nearly every pixel carries eight light samples
+
+
+@pytest.mark.gpu
+def test_device_direct_pass_with_infinite_lights_bitwise(binding, oracle, tmp_path):
+    """The sphere under the uniform sky, a room open to a uniform sky (plus a point light) and one open to an environment map
+    (its Distribution2D sampled by UniformSampleAllLights; uber / mirror blobs: the recursion): escaped rays return Le at every depth,
+    EstimateDirect's BSDF-sampled ray contributes Le when it escapes. Film monitor doubles bit for bit the oracle's."""
+    import boxroom
+    paths = []
+    p = tmp_path / "sky_sphere.pbrt"
+    p.write_text(_SKY_SCENE)
+    paths.append(p)
+    p = tmp_path / "sky_room.pbrt"
+    p.write_text(boxroom.boxroom_pbrt(ico_levels=2, n_blobs=5, wall_n=6, xres=96, yres=64, spp=1, light="sky", materials="mixed"))
+    paths.append(p)
+    p = tmp_path / "env_room.pbrt"
+    p.write_text(boxroom.boxroom_pbrt(ico_levels=2, n_blobs=5, wall_n=6, xres=96, yres=64, spp=1, light="envmap", materials="mixed", env_dir=str(tmp_path)))
+    paths.append(p)
+    for p in paths:
+        scene = binding.HostScene(path=str(p))
+        dev = binding.GpuScene(scene).render_direct(3)
+        ref = oracle.iispt_direct(scene, 3)
+        assert np.array_equal(dev.view(np.uint64), ref.view(np.uint64)), p.name
+        assert (ref[..., :3].sum(axis=2) > 0).mean() > 0.5
 
 
 @pytest.mark.gpu
