@@ -563,6 +563,7 @@ struct Isect {
     float uv[2] = {0, 0};
     V3 dpdu, dpdv;
     float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
+    V3 dpdx, dpdy;  // interaction.cpp:117-118 (zero without differentials): the direct pass's reflected-ray differentials use them
     // bump mapping: the rest of the shading geometry (shading.dpdv, shading.dndu / dndv) and the orientation flag
     V3 sdpdv, dndu, dndv;
     bool flip = false;
@@ -945,6 +946,7 @@ struct Oracle {
     }
     static void compute_differentials(Isect *is, const RayDiff &rd) {
         is->dudx = is->dvdx = is->dudy = is->dvdy = 0;
+        is->dpdx = is->dpdy = V3(0, 0, 0);
         if (!rd.has) return;
         const V3 n = is->n, p = is->p;
         float d = dot(n, p);
@@ -954,6 +956,8 @@ struct Oracle {
         float ty = -(dot(n, rd.ryo) - d) / dot(n, rd.ryd);
         if (std::isinf(ty) || std::isnan(ty)) return;
         V3 py = rd.ryo + ty * rd.ryd;
+        is->dpdx = px - p;
+        is->dpdy = py - p;
         int dim[2];
         if (std::abs(n.x) > std::abs(n.y) && std::abs(n.x) > std::abs(n.z)) {
             dim[0] = 1;
@@ -2660,9 +2664,10 @@ struct Oracle {
         }
         return L;
     }
-    // DirectProgressiveIntegrator::Li, directprogressiveintegrator.cpp:22-58. Differentials: the camera ray's only; the
-    // reflected ray's (SpecularReflect, :152-186) feed nothing but texture filtering and are not carried — scenes that
-    // combine image textures with specular reflection lobes are rejected by oracle_iispt_direct.
+    // DirectProgressiveIntegrator::Li, directprogressiveintegrator.cpp:22-58. Differentials: the camera ray's, and — they feed
+    // the texture filtering of whatever a mirror shows — the reflected rays' (SpecularReflect, :165-184), from the hit's dpdx /
+    // dpdy, du/dx .. and shading.dndu / dndv (triangles; a textured scene with a specular SPHERE is rejected by
+    // oracle_iispt_direct: its dndu / dndv are not restated).
     Rgb direct_li(Ray ray, DirectSampler &smp, RayDiff rdiff, int depth) const {
         Rgb L(0.f);
         Isect is;
@@ -2688,8 +2693,23 @@ struct Oracle {
                 float pdf;
                 Rgb f = sample_specular_reflection(bsdf, wo, &wi, &pdf);
                 Rgb R(0.f);
-                if (pdf > 0.f && !f.is_black() && absdot(wi, is.sn) != 0.f)
-                    R = f * direct_li(spawn_ray(is, wi), smp, RayDiff(), depth + 1) * absdot(wi, is.sn) / pdf;
+                if (pdf > 0.f && !f.is_black() && absdot(wi, is.sn) != 0.f) {
+                    RayDiff rd;  // `RayDifferential rd = isect.SpawnRay(wi); if (ray.hasDifferentials) { ... }`
+                    if (rdiff.has) {
+                        const V3 ns = is.sn;
+                        rd.has = true;
+                        rd.rxo = is.p + is.dpdx;
+                        rd.ryo = is.p + is.dpdy;
+                        const V3 dndx = is.dndu * is.dudx + is.dndv * is.dvdx;
+                        const V3 dndy = is.dndu * is.dudy + is.dndv * is.dvdy;
+                        const V3 dwodx = -rdiff.rxd - wo, dwody = -rdiff.ryd - wo;
+                        const float dDNdx = dot(dwodx, ns) + dot(wo, dndx);
+                        const float dDNdy = dot(dwody, ns) + dot(wo, dndy);
+                        rd.rxd = wi - dwodx + 2.f * V3(dot(wo, ns) * dndx + dDNdx * ns);
+                        rd.ryd = wi - dwody + 2.f * V3(dot(wo, ns) * dndy + dDNdy * ns);
+                    }
+                    R = f * direct_li(spawn_ray(is, wi), smp, rd, depth + 1) * absdot(wi, is.sn) / pdf;
+                }
                 L = L + R;
             }
             {  // SpecularTransmit, :192-245: no lobe built here is BSDF_TRANSMISSION | BSDF_SPECULAR alone — pdf = 0
@@ -3698,7 +3718,7 @@ extern "C" {
 // The IISPT direct pass into a film monitor (IisptFilmMonitor::add_n_samples, iisptfilmmonitor.cpp:47-72: doubles): n_passes
 // passes of DirectProgressiveIntegrator::RenderOnePass, pass p seeded as described at DirectSampler, added in pass order into
 // film_rgbw[(y * w + x) * 4] = {sum r, sum g, sum b, sum of ray weights} over the film's cropped pixel bounds (zeroed first).
-// 0 = ok, 1 = bad arguments, 3 = image textures together with specular reflection lobes (reflected rays' differentials),
+// 0 = ok, 1 = bad arguments, 3 = image textures together with a specular SPHERE (the reflected ray's differentials need its dndu / dndv),
 // 4 = glass: DirectProgressiveIntegrator::Li calls ComputeScatteringFunctions with allowMultipleLobes = false
 // (interaction.h:130-133), so GlassMaterial adds SpecularReflection + SpecularTransmission (glass.cpp:62-90) and Li recurses
 // through both — a tree this restatement (a chain per pixel) does not walk; round 3 rendered such surfaces black, which was wrong.
@@ -3716,10 +3736,12 @@ int oracle_iispt_direct(const iile_scene_desc *scene, int trig_mode, int n_passe
             for (int t : {mm.kd_tex, mm.ks_tex, mm.kr_tex, mm.kt_tex, mm.bump_tex, mm.rough_tex, mm.sigma_tex})
                 if (t >= 0) textured_material = true;
         }
-    if (textured_material)
-        for (int m = 0; m < S.n_materials; ++m)
-            if (S.materials[m].type == IILE_MAT_MIRROR || (S.materials[m].type == IILE_MAT_UBER && (S.materials[m].kr[0] > 0 || S.materials[m].kr[1] > 0 || S.materials[m].kr[2] > 0)))
-                return 3;
+    if (textured_material)  // a specular SPHERE in a textured scene: the reflected ray's differentials need the sphere's dndu / dndv
+        for (int i = 0; i < S.n_prims; ++i) {
+            if (!(S.prim_flags[i] & IILE_PRIM_SPHERE) || S.prim_material[i] < 0) continue;
+            const iile_material &mm = S.materials[S.prim_material[i]];
+            if (mm.type == IILE_MAT_MIRROR || (mm.type == IILE_MAT_UBER && (mm.kr[0] > 0 || mm.kr[1] > 0 || mm.kr[2] > 0))) return 3;
+        }
     const int fw = F.crop_x1 - F.crop_x0, fh = F.crop_y1 - F.crop_y0;
     std::memset(film_rgbw, 0, sizeof(double) * 4 * size_t(fw) * fh);
     if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());

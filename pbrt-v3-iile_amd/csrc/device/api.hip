@@ -53,6 +53,7 @@ struct iile_scene {
     int n_cus = 256;
     int max_depth = 5;
     int spp = 1;
+    bool specular_sphere = false;  // a sphere with a mirror / uber-Kr material (the direct pass's reflected-ray differentials)
     int light_samples[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // Light::nSamples (iile_light::n_samples), the direct pass's nLightSamples
     // wavefront workspace, grown on demand and kept across renders
     uint32_t ws_paths = 0;
@@ -1009,6 +1010,11 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     S.rr_threshold = d->integrator.rr_threshold;
     sc->max_depth = d->integrator.max_depth;
     for (int i = 0; i < d->n_lights && i < 8; ++i) sc->light_samples[i] = std::max(1, int(d->lights[i].n_samples));
+    for (int i = 0; i < d->n_prims; ++i) {
+        if (!(d->prim_flags[i] & IILE_PRIM_SPHERE) || d->prim_material[i] < 0 || d->prim_material[i] >= d->n_materials) continue;
+        const iile_material &mm = d->materials[d->prim_material[i]];
+        if (mm.type == IILE_MAT_MIRROR || (mm.type == IILE_MAT_UBER && (mm.kr[0] > 0 || mm.kr[1] > 0 || mm.kr[2] > 0))) sc->specular_sphere = true;
+    }
     {
         void *p = nullptr;
         if (hipMalloc(&p, size_t(max_traversal_threads(sc->n_cus)) * sizeof(int)) != hipSuccess)
@@ -1732,8 +1738,11 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     int rc = ensure_device();
     if (rc) return rc;
     DScene S = sc->ds;
-    if (S.textured_materials && S.has_specular)
-        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: image textures together with specular lobes (the reflected ray's differentials)");
+    // reflected rays carry differentials in textured scenes (SpecularReflect, directprogressiveintegrator.cpp:165-184), built from the
+    // hit's shading.dndu / dndv — which this build has for triangles only
+    const bool reflect_diffs = S.textured_materials && S.has_specular;
+    if (reflect_diffs && sc->specular_sphere)
+        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: image textures together with a specular sphere (the reflected ray's differentials need the sphere's dndu / dndv)");
     if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
     // DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), so GlassMaterial
     // adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and BOTH SpecularReflect and SpecularTransmit
@@ -1784,10 +1793,11 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     const size_t np = P.n_paths, vec = sizeof(float4);
     const size_t d_bytes = std::max<size_t>(size_t(5) * size_t(total_samples) * np * vec, vec), ef_bytes = size_t(5) * np * vec;
     const size_t jump_bytes = (size_t(n_arrays) + 1) * 2 * sizeof(unsigned long long);
+    const size_t rd_bytes = reflect_diffs ? size_t(4) * np * vec : 0;
     DevBuf<char> block;
     {
         void *p = nullptr;
-        if (hipMalloc(&p, d_bytes + 2 * ef_bytes + jump_bytes + (prm->film_on_device ? 0 : film_bytes) + 1024) != hipSuccess)
+        if (hipMalloc(&p, d_bytes + 2 * ef_bytes + rd_bytes + jump_bytes + (prm->film_on_device ? 0 : film_bytes) + 1024) != hipSuccess)
             return fail(IILE_ERR_HIP, "out of device memory for the direct pass (" + std::to_string((d_bytes + 2 * ef_bytes) >> 20) + " MiB of per-vertex records)");
         block.p = static_cast<char *>(p);
     }
@@ -1798,6 +1808,8 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     at += ef_bytes;
     float4 *F = reinterpret_cast<float4 *>(at);
     at += ef_bytes;
+    float4 *RD = reflect_diffs ? reinterpret_cast<float4 *>(at) : nullptr;
+    at += rd_bytes;
     unsigned long long *jump_dev = reinterpret_cast<unsigned long long *>(at);
     at += (jump_bytes + 255) & ~size_t(255);
     double *film_dev = prm->film_on_device ? film_rgbw : reinterpret_cast<double *>(at);
@@ -1824,6 +1836,7 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     B.L = D;
     B.dir_E = E;
     B.dir_F = F;
+    B.dir_RD = RD;
     B.dir_paths = P.n_paths;
     B.spill = sc->spill;
     P.direct_arrays = n_arrays;

@@ -1279,8 +1279,11 @@ DEV bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b
     return true;
 }
 DEV bool is_inf_or_nan(float v) { return !(fabsf(v) < IILE_INF); }
-DEV TexDiff compute_differentials(const Isect &is, const RayDiff &rd) {
+// (dpdx / dpdy, interaction.cpp:117-118 — zero when the auxiliary rays miss the tangent plane —, are what the direct pass's
+//  reflected-ray differentials start from; every other caller leaves them out)
+DEV TexDiff compute_differentials(const Isect &is, const RayDiff &rd, F3 *dpdx = nullptr, F3 *dpdy = nullptr) {
     TexDiff t = TexDiff{0, 0, 0, 0};
+    if (dpdx) *dpdx = *dpdy = F3{0, 0, 0};
     const F3 n = is.n, p = is.p;
     const float d = dot(n, p);
     const float tx = -(dot(n, rd.rxo) - d) / dot(n, rd.rxd);
@@ -1289,6 +1292,7 @@ DEV TexDiff compute_differentials(const Isect &is, const RayDiff &rd) {
     const float ty = -(dot(n, rd.ryo) - d) / dot(n, rd.ryd);
     if (is_inf_or_nan(ty)) return t;
     const F3 py = rd.ryo + ty * rd.ryd;
+    if (dpdx) *dpdx = px - p, *dpdy = py - p;
     int d0, d1;
     if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) {
         d0 = 1;

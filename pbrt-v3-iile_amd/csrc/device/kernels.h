@@ -84,6 +84,10 @@ struct PassBuffers {
     // the IISPT direct pass: per vertex depth d < 5 and path, emitted light E[d * dir_paths + path] and the mirror lobe's
     // {f, |cos|} F[d * dir_paths + path]; the lights' direct light lands in L[(d * n_lights + light) * dir_paths + path]
     float4 *dir_E, *dir_F;
+    // ... and, in textured scenes with specular lobes, the differentials of the ray that reaches the path's current vertex
+    // (SpecularReflect, directprogressiveintegrator.cpp:165-184): {rxOrigin, has}, {ryOrigin}, {rxDirection}, {ryDirection} at
+    // [plane * dir_paths + path]; null otherwise
+    float4 *dir_RD;
     uint32_t dir_paths;
 };
 constexpr uint32_t kMaxFlagged = 1u << 20;

@@ -111,6 +111,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
         F3 ray_d = F3{0, 0, 1};
         bool lit_surface = false;  // a surface with a non-specular lobe: EstimateDirect can return something
         DPcg stream{0, 1};
+        RayDiff rdiff = RayDiff{F3{0, 0, 0}, F3{0, 0, 0}, F3{0, 0, 1}, F3{0, 0, 1}};
+        bool has_diff = false;
+        TexDiff td = TexDiff{0, 0, 0, 0};
+        F3 dpdx = F3{0, 0, 0}, dpdy = F3{0, 0, 0};
         if (valid) {
             const float4 h4 = B.hits[slot], o4 = ro[slot], d4 = rd[slot];
             pid = f2b(o4.w);
@@ -134,15 +138,28 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
             uint32_t kk = 0;
             path_pixel(S, P, pid, &px, &py, &kk);
             stream = pixel_stream(S, P, px, py);
-            // isect.ComputeScatteringFunctions(ray, arena): differentials of the camera ray only (see the oracle's direct_li)
+            // isect.ComputeScatteringFunctions(ray, arena): the differentials of the camera ray at depth 0, of the reflected ray
+            // (left by the vertex before, below) further on; computed for every hit when reflected rays carry them, else only
+            // where a texture is looked up
             const DMaterial &m0 = S.materials[material];
-            if (TEX && S.textured_materials &&
-                (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0)) {
-                TexDiff td = TexDiff{0, 0, 0, 0};
+            const bool mat_tex = m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0;
+            if (TEX && S.textured_materials && (mat_tex || B.dir_RD)) {
                 if (depth == 0) {
                     const float4 cs = B.beta[pid];  // pFilm, pLens left by k_direct_generate
-                    td = compute_differentials(is, camera_differentials(S, cs.x, cs.y, cs.z, cs.w, ray_o, ray_d));
+                    rdiff = camera_differentials(S, cs.x, cs.y, cs.z, cs.w, ray_o, ray_d);
+                    has_diff = true;
+                } else if (B.dir_RD) {
+                    const float4 r0 = B.dir_RD[pid];
+                    has_diff = r0.w != 0.f;
+                    if (has_diff) {
+                        const float4 r1 = B.dir_RD[size_t(B.dir_paths) + pid], r2 = B.dir_RD[2 * size_t(B.dir_paths) + pid],
+                                     r3 = B.dir_RD[3 * size_t(B.dir_paths) + pid];
+                        rdiff = RayDiff{F3{r0.x, r0.y, r0.z}, F3{r1.x, r1.y, r1.z}, F3{r2.x, r2.y, r2.z}, F3{r3.x, r3.y, r3.z}};
+                    }
                 }
+                if (has_diff) td = compute_differentials(is, rdiff, &dpdx, &dpdy);
+            }
+            if (TEX && S.textured_materials && mat_tex) {
                 if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, &is);
                 bsdf = make_bsdf<true>(textured_material(S, m0, is, td), is);
             } else {
@@ -322,6 +339,29 @@ __global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P
                     next_o = offset_ray_origin(is.p, is.perr, is.n, wi);
                     next_d = wi;
                     alive = true;
+                    if (TEX && B.dir_RD) {
+                        // the reflected ray's differentials (directprogressiveintegrator.cpp:165-184), for the next vertex
+                        float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
+                        if (has_diff) {
+                            const F3 ns = is.sn;
+                            const F3 rxo = is.p + dpdx, ryo = is.p + dpdy;
+                            const F3 dndx = is.dndu * td.dudx + is.dndv * td.dvdx;
+                            const F3 dndy = is.dndu * td.dudy + is.dndv * td.dvdy;
+                            const F3 dwodx = -rdiff.rxd - wo_w, dwody = -rdiff.ryd - wo_w;
+                            const float dDNdx = dot(dwodx, ns) + dot(wo_w, dndx);
+                            const float dDNdy = dot(dwody, ns) + dot(wo_w, dndy);
+                            const F3 rxd = wi - dwodx + 2.f * (dot(wo_w, ns) * dndx + dDNdx * ns);
+                            const F3 ryd = wi - dwody + 2.f * (dot(wo_w, ns) * dndy + dDNdy * ns);
+                            o0 = make_float4(rxo.x, rxo.y, rxo.z, 1.f);
+                            o1 = make_float4(ryo.x, ryo.y, ryo.z, 0);
+                            o2 = make_float4(rxd.x, rxd.y, rxd.z, 0);
+                            o3 = make_float4(ryd.x, ryd.y, ryd.z, 0);
+                        }
+                        B.dir_RD[pid] = o0;
+                        B.dir_RD[size_t(B.dir_paths) + pid] = o1;
+                        B.dir_RD[2 * size_t(B.dir_paths) + pid] = o2;
+                        B.dir_RD[3 * size_t(B.dir_paths) + pid] = o3;
+                    }
                 }
             }
         }

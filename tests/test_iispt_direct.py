@@ -148,6 +148,55 @@ def test_direct_pass_under_a_uniform_sky(binding, oracle, tmp_path):
     assert abs(centre.mean() - 0.4) < 0.01, centre.mean()
 
 
+def _mirror_scene(images, camera, mirror):
+    s = """LookAt %s
+Camera "perspective" "float fov" [50]
+Film "image" "integer xresolution" [48] "integer yresolution" [32]
+Sampler "halton" "integer pixelsamples" [1]
+Integrator "path"
+WorldBegin
+Texture "checker" "spectrum" "imagemap" "string filename" ["%s"] "float uscale" [300] "float vscale" [300]
+LightSource "distant" "color L" [3 3 3] "point from" [0 0 1] "point to" [0 0 0]
+AttributeBegin
+  Material "matte" "texture Kd" ["checker"]
+  Shape "trianglemesh" "point P" [ -300 -300 0  300 -300 0  300 300 0  -300 300 0 ] "integer indices" [ 0 1 2  0 2 3 ] "float uv" [0 0 1 0 1 1 0 1]
+AttributeEnd
+""" % (camera, images["checker"])
+    if mirror:
+        s += """AttributeBegin
+  Material "mirror" "color Kr" [1 1 1]
+  Shape "trianglemesh" "point P" [ -400 2 -10  400 2 -10  400 2 400  -400 2 400 ] "integer indices" [ 0 1 2  0 2 3 ]
+AttributeEnd
+"""
+    return s + "WorldEnd\n"
+
+
+def test_reflected_rays_carry_differentials(binding, oracle, tmp_path):
+    """SpecularReflect gives the reflected ray differentials (directprogressiveintegrator.cpp:165-184) so that what a mirror shows
+    is texture-filtered like what the camera sees. No reference output exists; the property: a plane mirror showing a finely
+    textured floor must look like the floor seen from the mirrored camera — same means, and the same amount of filtering
+    (pixel-to-pixel spread) in every distance band, which zero differentials (point sampling: the texture's full contrast
+    everywhere) or wrong ones would not give."""
+    import boxroom
+    images = boxroom.write_test_images(str(tmp_path))
+
+    def render(text):
+        path = tmp_path / "m.pbrt"
+        path.write_text(text)
+        film = oracle.iispt_direct(binding.HostScene(path=str(path)), 4)
+        return film[..., :3] / film[..., 3:4]
+
+    via_mirror = render(_mirror_scene(images, "0 -2 1.5   0 2 1.2   0 0 1", True))
+    direct = render(_mirror_scene(images, "0 6 1.5   0 2 1.2   0 0 1", False))[:, ::-1]
+    spreads = []
+    for r0, r1 in ((17, 20), (20, 24), (24, 32)):   # far ... near rows of the floor
+        a, b = via_mirror[r0:r1], direct[r0:r1]
+        assert abs(a.mean() / b.mean() - 1) < 0.08
+        assert abs(a.std() / b.std() - 1) < 0.05, (r0, a.std(), b.std())
+        spreads.append(a.std())
+    assert spreads[0] < 0.6 * spreads[2]   # the far band is filtered towards the texture's mean
+
+
 # ---- the device pass against the oracle -------------------------------------------------------------------------------------
 
 
@@ -234,12 +283,37 @@ def test_device_direct_pass_with_infinite_lights_bitwise(binding, oracle, tmp_pa
 
 
 @pytest.mark.gpu
+def test_device_direct_pass_textured_rooms_with_mirrors_bitwise(binding, oracle, tmp_path):
+    """Image textures together with specular lobes: the reflected rays carry differentials from vertex to vertex (bump maps,
+    alpha masks, EWA / trilinear lookups behind uber and mirror blobs), under the sphere light and under the environment map —
+    the textured room of BASELINE config 4's feature set now renders in the direct pass. Bit for bit the oracle's; and the
+    mirror / mirrored-camera pair of the property test above."""
+    import boxroom
+    scenes = []
+    for i, kw in enumerate((dict(light="area"), dict(light="envmap"))):
+        path = tmp_path / f"tex{i}.pbrt"
+        path.write_text(boxroom.boxroom_pbrt(ico_levels=2, n_blobs=6, wall_n=6, xres=96, yres=64, spp=1, materials="mixed", textures=str(tmp_path), **kw))
+        scenes.append(path)
+    images = boxroom.write_test_images(str(tmp_path))
+    path = tmp_path / "mirror.pbrt"
+    path.write_text(_mirror_scene(images, "0 -2 1.5   0 2 1.2   0 0 1", True))
+    scenes.append(path)
+    for path in scenes:
+        scene = binding.HostScene(path=str(path))
+        dev = binding.GpuScene(scene).render_direct(2)
+        ref = oracle.iispt_direct(scene, 2)
+        assert np.array_equal(dev.view(np.uint64), ref.view(np.uint64)), path.name
+
+
+@pytest.mark.gpu
 def test_direct_pass_rejects_what_it_does_not_build(binding, tmp_path):
     import boxroom
-    path = tmp_path / "env.pbrt"
-    path.write_text(boxroom.boxroom_pbrt(ico_levels=2, n_blobs=3, wall_n=4, xres=32, yres=32, spp=1, light="envmap", materials="mixed", textures=str(tmp_path)))
+    images = boxroom.write_test_images(str(tmp_path))
+    path = tmp_path / "ball.pbrt"
+    path.write_text(_mirror_scene(images, "0 -2 1.5   0 2 1.2   0 0 1", False).replace(
+        "WorldEnd", 'AttributeBegin\n  Material "mirror"\n  Translate 0 3 1\n  Shape "sphere" "float radius" [1]\nAttributeEnd\nWorldEnd'))
     gpu = binding.GpuScene(binding.HostScene(path=str(path)))
-    with pytest.raises(RuntimeError, match="not built|differentials"):
+    with pytest.raises(RuntimeError, match="specular sphere"):
         gpu.render_direct(1)
     path = tmp_path / "glass.pbrt"
     path.write_text(boxroom.boxroom_pbrt(ico_levels=1, n_blobs=4, wall_n=2, xres=16, yres=16, spp=1, materials="glass"))
