@@ -1631,6 +1631,7 @@ struct Oracle {
             if (!(R.is_black() && T.is_black())) {
                 b.has_spec = true;
                 b.spec_glass = true;
+                b.spec_noop = false;  // (the direct pass's SpecularReflection(R, FresnelDielectric(1, eta)) reads it)
                 b.kr = R;
                 b.kt = T;
                 b.spec_eta = m.eta;
@@ -2629,12 +2630,12 @@ struct Oracle {
         }
     };
     // BSDF::Sample_f(wo, &wi, u, &pdf, BSDF_REFLECTION | BSDF_SPECULAR) (reflection.cpp:719-784): of the lobes built here only
-    // SpecularReflection matches that type. (Glass never gets here: with allowMultipleLobes = false it would carry separate
-    // reflection and transmission lobes and Li would branch; oracle_iispt_direct rejects scenes with glass.)
+    // SpecularReflection matches that type — the mirror / uber lobe, or glass's SpecularReflection(R, FresnelDielectric(1, eta)).
     // One matching lobe: the remapped u is not used.
     Rgb sample_specular_reflection(const Bsdf &b, V3 woW, V3 *wiW, float *pdf) const {
         *pdf = 0;
-        if (!b.has_spec || b.spec_glass) return Rgb(0.f);  // matchingComps == 0
+        if (!b.has_spec) return Rgb(0.f);  // matchingComps == 0
+        if (b.spec_glass && b.kr.is_black()) return Rgb(0.f);  // glass.cpp:75: no reflection lobe for a black Kr
         V3 wo = b.to_local(woW);
         if (wo.z == 0) return Rgb(0.f);
         V3 wi = V3(-wo.x, -wo.y, wo.z);  // SpecularReflection::Sample_f, reflection.cpp:136-143
@@ -2643,6 +2644,32 @@ struct Oracle {
         Rgb f = Rgb(fr) * b.kr / std::abs(wi.z);
         *wiW = b.to_world(wi);
         return f;
+    }
+    // BSDF::Sample_f(wo, &wi, u, &pdf, BSDF_TRANSMISSION | BSDF_SPECULAR): the SpecularTransmission(T, 1, eta, Radiance) lobe glass
+    // carries beside its SpecularReflection when ComputeScatteringFunctions runs with allowMultipleLobes = false (glass.cpp:62-90,
+    // interaction.h:130-133 — the direct integrator's Li does): SpecularTransmission::Sample_f, reflection.cpp:154-170
+    Rgb sample_specular_transmission(const Bsdf &b, V3 woW, V3 *wiW, float *pdf) const {
+        *pdf = 0;
+        if (!b.has_spec || !b.spec_glass || b.kt.is_black()) return Rgb(0.f);
+        V3 wo = b.to_local(woW);
+        if (wo.z == 0) return Rgb(0.f);
+        const float eta_a = 1.f, eta_b = b.spec_eta;
+        const bool entering = wo.z > 0;
+        const float eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
+        // Refract(wo, Faceforward(Normal3f(0, 0, 1), wo), etaI / etaT, wi), reflection.h:96-108
+        V3 n = (wo.z < 0.f) ? -V3(0, 0, 1) : V3(0, 0, 1);
+        const float eta = eta_i / eta_t;
+        const float cos_i = dot(n, wo);
+        const float sin2_i = std::max(0.f, 1 - cos_i * cos_i);
+        const float sin2_t = eta * eta * sin2_i;
+        if (sin2_t >= 1) return Rgb(0.f);
+        const float cos_t = std::sqrt(1 - sin2_t);
+        V3 wi = eta * -wo + (eta * cos_i - cos_t) * n;
+        *pdf = 1;
+        Rgb ft = b.kt * (1.f - fr_dielectric(wi.z, eta_a, eta_b));  // T * (Spectrum(1.) - fresnel.Evaluate(CosTheta(*wi)))
+        ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+        *wiW = b.to_world(wi);
+        return ft / std::abs(wi.z);
     }
     // UniformSampleAllLights, integrator.cpp:54-83
     Rgb uniform_sample_all_lights(const Isect &it, const Bsdf &bsdf, DirectSampler &smp) const {
@@ -2712,10 +2739,37 @@ struct Oracle {
                 }
                 L = L + R;
             }
-            {  // SpecularTransmit, :192-245: no lobe built here is BSDF_TRANSMISSION | BSDF_SPECULAR alone — pdf = 0
+            {  // SpecularTransmit, :190-237: glass alone has a lobe that is BSDF_TRANSMISSION | BSDF_SPECULAR
                 float u[2];
                 smp.get2d(u);
-                L = L + Rgb(0.f);
+                V3 wi;
+                float pdf;
+                Rgb f = sample_specular_transmission(bsdf, wo, &wi, &pdf);
+                Rgb T(0.f);
+                if (pdf > 0.f && !f.is_black() && absdot(wi, is.sn) != 0.f) {
+                    RayDiff rd;
+                    if (rdiff.has) {
+                        const V3 ns = is.sn;
+                        rd.has = true;
+                        rd.rxo = is.p + is.dpdx;
+                        rd.ryo = is.p + is.dpdy;
+                        float eta = bsdf.eta;
+                        const V3 w = -wo;
+                        if (dot(wo, ns) < 0) eta = 1.f / eta;
+                        const V3 dndx = is.dndu * is.dudx + is.dndv * is.dvdx;
+                        const V3 dndy = is.dndu * is.dudy + is.dndv * is.dvdy;
+                        const V3 dwodx = -rdiff.rxd - wo, dwody = -rdiff.ryd - wo;
+                        const float dDNdx = dot(dwodx, ns) + dot(wo, dndx);
+                        const float dDNdy = dot(dwody, ns) + dot(wo, dndy);
+                        const float mu = eta * dot(w, ns) - dot(wi, ns);
+                        const float dmudx = (eta - (eta * eta * dot(w, ns)) / dot(wi, ns)) * dDNdx;
+                        const float dmudy = (eta - (eta * eta * dot(w, ns)) / dot(wi, ns)) * dDNdy;
+                        rd.rxd = wi + eta * dwodx - V3(mu * dndx + dmudx * ns);
+                        rd.ryd = wi + eta * dwody - V3(mu * dndy + dmudy * ns);
+                    }
+                    T = f * direct_li(spawn_ray(is, wi), smp, rd, depth + 1) * absdot(wi, is.sn) / pdf;
+                }
+                L = L + T;
             }
         }
         return L;
@@ -3719,15 +3773,13 @@ extern "C" {
 // passes of DirectProgressiveIntegrator::RenderOnePass, pass p seeded as described at DirectSampler, added in pass order into
 // film_rgbw[(y * w + x) * 4] = {sum r, sum g, sum b, sum of ray weights} over the film's cropped pixel bounds (zeroed first).
 // 0 = ok, 1 = bad arguments, 3 = image textures together with a specular SPHERE (the reflected ray's differentials need its dndu / dndv),
-// 4 = glass: DirectProgressiveIntegrator::Li calls ComputeScatteringFunctions with allowMultipleLobes = false
-// (interaction.h:130-133), so GlassMaterial adds SpecularReflection + SpecularTransmission (glass.cpp:62-90) and Li recurses
-// through both — a tree this restatement (a chain per pixel) does not walk; round 3 rendered such surfaces black, which was wrong.
+// Glass: DirectProgressiveIntegrator::Li calls ComputeScatteringFunctions with allowMultipleLobes = false (interaction.h:130-133),
+// so GlassMaterial adds SpecularReflection + SpecularTransmission (glass.cpp:62-90) and Li recurses through both: a tree, walked here
+// by the recursion itself (round 3 assumed FresnelSpecular and rendered glass black; the device pass refuses glass).
 int oracle_iispt_direct(const iile_scene_desc *scene, int trig_mode, int n_passes, int first_pass, int n_threads, double *film_rgbw) {
     if (!scene || !film_rgbw || n_passes < 0) return 1;
     const iile_scene_desc &S = *scene;
     const iile_film_desc &F = S.film;
-    for (int m = 0; m < S.n_materials; ++m)
-        if (S.materials[m].type == IILE_MAT_GLASS) return 4;
     // (textures that only an environment light uses — n_textures counts its Lmap — need no ray differentials)
     bool textured_material = false;
     if (S.n_textures > 0)

@@ -8,7 +8,7 @@
 //
 //   k_centroid_bounds   bounds of the primitive centroids (:413-416): min / max are exact and order-free
 //   k_morton            30-bit Morton codes of the centroids, 10 bits per axis (:418-427, LeftShift3 / EncodeMorton3 :107-130)
-//   rocprim radix sort  (code, primitive number) pairs, stable, bits 0-29: the order RadixSort's five 6-bit passes give (:133-181, :430)
+//   device_sort_pairs_30  (code, primitive number) pairs, stable, five 6-bit passes over bits 0-29 as RadixSort (:133-181, :430): own kernels
 //   k_treelet_flags + scan + k_treelet_starts   runs of equal top 12 bits = treelets (:434-452)
 //   k_lbvh_*            emitLBVH (:555-618) for all treelets at once, one thread per sorted position (see below), nodes in
 //                       preorder into the treelet's own pool region; leaves take their primitives in sorted order, so
@@ -27,7 +27,6 @@
 #include <algorithm>
 #include <cstring>
 #include <limits>
-#include <rocprim/rocprim.hpp>
 #include <string>
 #include <vector>
 
@@ -410,6 +409,147 @@ struct Dev {
 
 int grid_for(int n) { return std::max(1, std::min((n + kBB - 1) / kBB, 256 * 8)); }
 
+// ---- scans and the Morton sort: own kernels (rounds 1-3 called rocPRIM here) ------------------------------------------------
+// Prefix sums of int arrays: blocks of 256 threads x 8 items scan their 2048 elements (thread-local sums, a wavefront scan by
+// DPP-free shuffles, the four wavefronts' totals through LDS) and leave their totals; the totals are scanned the same way
+// (recursively: one more level per factor of 2048) and added back.
+constexpr int kScanItems = 8, kScanTile = kBB * kScanItems;
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+__global__ __launch_bounds__(kBB) void k_scan_tiles(const int *in, int *out, int n, int *tile_sums, int inclusive) {
+    __shared__ int wave_tot[kBB / 64];
+    const int base = blockIdx.x * kScanTile + int(threadIdx.x) * kScanItems;
+    int v[kScanItems], sum = 0;
+    for (int j = 0; j < kScanItems; ++j) {
+        v[j] = base + j < n ? in[base + j] : 0;
+        sum += v[j];
+    }
+    const int incl = wave_inclusive_scan(sum);
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int before = incl - sum;  // exclusive over this wavefront's threads
+    for (int w = 0; w < int(threadIdx.x >> 6); ++w) before += wave_tot[w];
+    int run = before;
+    for (int j = 0; j < kScanItems; ++j) {
+        const int excl = run;
+        run += v[j];
+        if (base + j < n) out[base + j] = inclusive ? run : excl;
+    }
+    if (threadIdx.x == kBB - 1 && tile_sums) tile_sums[blockIdx.x] = run;
+}
+__global__ __launch_bounds__(kBB) void k_scan_add(int *out, int n, const int *tile_offsets) {
+    const int off = tile_offsets[blockIdx.x];
+    const int base = blockIdx.x * kScanTile + int(threadIdx.x) * kScanItems;
+    for (int j = 0; j < kScanItems; ++j)
+        if (base + j < n) out[base + j] += off;
+}
+// out[i] = in[0] + .. + in[i] (inclusive) or in[0] + .. + in[i - 1] (exclusive); in and out may not overlap
+int device_scan(const int *in, int *out, size_t n64, bool inclusive, hipStream_t s) {
+    if (n64 == 0) return IILE_OK;
+    if (n64 > size_t(0x7fffffff)) return api_fail(IILE_ERR_UNSUPPORTED, "device_scan: more than 2^31 elements");
+    const int n = int(n64), tiles = (n + kScanTile - 1) / kScanTile;
+    if (tiles == 1) {
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kBB), 0, s, in, out, n, static_cast<int *>(nullptr), inclusive ? 1 : 0);
+        return IILE_OK;
+    }
+    Dev<int> sums, offs;
+    HIP_TRYB(sums.alloc(size_t(tiles)));
+    HIP_TRYB(offs.alloc(size_t(tiles)));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kBB), 0, s, in, out, n, sums.p, inclusive ? 1 : 0);
+    const int rc = device_scan(sums.p, offs.p, size_t(tiles), false, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kBB), 0, s, out, n, offs.p);
+    HIP_TRYB(hipStreamSynchronize(s));  // (the two scratch arrays die with this scope)
+    return IILE_OK;
+}
+
+// RadixSort (bvh.cpp:133-181): least significant digit first, five passes of six bits over the 30-bit Morton codes, stable — the
+// same passes here, each as histogram -> scan -> scatter. A block takes 1024 consecutive pairs; its scatter keeps their order
+// within a digit: the four items of a thread are taken in four rounds (round j: element j * 256 + thread), the wavefronts of a
+// round one after the other, and inside a wavefront a lane's rank among the lanes with its digit comes from six ballots.
+constexpr int kSortBits = 6, kSortDigits = 1 << kSortBits, kSortItems = 4, kSortTile = kBB * kSortItems;
+__global__ __launch_bounds__(kBB) void k_sort_histogram(const uint32_t *keys, int n, int shift, int *counts, int n_tiles) {
+    __shared__ int hist[kSortDigits];
+    if (threadIdx.x < kSortDigits) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile;
+    for (int j = 0; j < kSortItems; ++j) {
+        const int i = base + j * kBB + int(threadIdx.x);
+        if (i < n) atomicAdd(&hist[(keys[i] >> shift) & (kSortDigits - 1)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < kSortDigits) counts[int(threadIdx.x) * n_tiles + blockIdx.x] = hist[threadIdx.x];  // digit-major: one scan gives every offset
+}
+__global__ __launch_bounds__(kBB) void k_sort_scatter(const uint32_t *keys, const int *vals, uint32_t *keys_out, int *vals_out, int n, int shift,
+                                                      const int *offsets, int n_tiles) {
+    __shared__ int run[kSortDigits];
+    if (threadIdx.x < kSortDigits) run[threadIdx.x] = offsets[int(threadIdx.x) * n_tiles + blockIdx.x];
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = 0; j < kSortItems; ++j) {
+        const int i = base + j * kBB + int(threadIdx.x);
+        const bool live = i < n;
+        const uint32_t key = live ? keys[i] : 0u;
+        const int val = live ? vals[i] : 0;
+        const uint32_t digit = (key >> shift) & (kSortDigits - 1);
+        for (int w = 0; w < kBB / 64; ++w) {
+            if (wave == w) {
+                // the lanes of this wavefront that hold the same digit (and an element at all)
+                unsigned long long peers = __ballot(live);
+                for (int b = 0; b < kSortBits; ++b) {
+                    const unsigned long long set = __ballot((digit >> b) & 1u);
+                    peers &= ((digit >> b) & 1u) ? set : ~set;
+                }
+                if (live) {
+                    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+                    const int pos = run[digit] + rank;
+                    keys_out[pos] = key;
+                    vals_out[pos] = val;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (live && (peers & ((1ull << lane) - 1ull)) == 0) run[digit] += __popcll(peers);  // the digit's first lane moves its cursor on
+            }
+            __syncthreads();
+        }
+    }
+}
+// (keys, vals) sorted by bits [0, 30) of the keys, stable, into (keys_out, vals_out); keys / vals are used as the other buffer
+int device_sort_pairs_30(uint32_t *keys, int *vals, uint32_t *keys_out, int *vals_out, int n, hipStream_t s) {
+    if (n <= 0) return IILE_OK;
+    const int tiles = (n + kSortTile - 1) / kSortTile;
+    Dev<int> counts, offsets;
+    Dev<uint32_t> keys_tmp;
+    Dev<int> vals_tmp;
+    HIP_TRYB(counts.alloc(size_t(kSortDigits) * tiles));
+    HIP_TRYB(offsets.alloc(size_t(kSortDigits) * tiles));
+    HIP_TRYB(keys_tmp.alloc(size_t(n)));
+    HIP_TRYB(vals_tmp.alloc(size_t(n)));
+    // five passes: in -> tmp -> out -> tmp -> out -> ... ending in `out` (the inputs stay untouched)
+    const uint32_t *src_k = keys;
+    const int *src_v = vals;
+    for (int pass = 0; pass < 5; ++pass) {
+        uint32_t *dst_k = (pass & 1) ? keys_tmp.p : keys_out;
+        int *dst_v = (pass & 1) ? vals_tmp.p : vals_out;
+        if (pass == 4) dst_k = keys_out, dst_v = vals_out;
+        if (dst_k == src_k) return api_fail(IILE_ERR_HIP, "device_sort_pairs_30: buffer schedule");
+        hipLaunchKernelGGL(k_sort_histogram, dim3(tiles), dim3(kBB), 0, s, src_k, n, pass * kSortBits, counts.p, tiles);
+        const int rc = device_scan(counts.p, offsets.p, size_t(kSortDigits) * tiles, false, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(kBB), 0, s, src_k, src_v, dst_k, dst_v, n, pass * kSortBits, offsets.p, tiles);
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    HIP_TRYB(hipGetLastError());
+    HIP_TRYB(hipStreamSynchronize(s));
+    return IILE_OK;
+}
+
 // ---- wide records -----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBB) void k_interior_flags(int n, const iile_bvh_node *nodes, int *flags) {
     for (int i = blockIdx.x * kBB + threadIdx.x; i < n; i += gridDim.x * kBB) flags[i] = nodes[i].nprims == 0 ? 1 : 0;
@@ -490,11 +630,10 @@ int pack_wide_records(const iile_bvh_node *d_nodes, int n_nodes, int n_interior,
     HIP_TRYB(bad.alloc(1));
     HIP_TRYB(hipMemsetAsync(bad.p, 0, sizeof(int), nullptr));
     hipLaunchKernelGGL(k_interior_flags, dim3(grid_for(n_nodes)), dim3(kBB), 0, nullptr, n_nodes, d_nodes, flags.p);
-    size_t tmp_bytes = 0;
-    HIP_TRYB(rocprim::exclusive_scan(nullptr, tmp_bytes, flags.p, excl.p, 0, size_t(n_nodes), rocprim::plus<int>(), nullptr));
-    Dev<char> tmp;
-    HIP_TRYB(tmp.alloc(tmp_bytes));
-    HIP_TRYB(rocprim::exclusive_scan(tmp.p, tmp_bytes, flags.p, excl.p, 0, size_t(n_nodes), rocprim::plus<int>(), nullptr));
+    {
+        const int rc = device_scan(flags.p, excl.p, size_t(n_nodes), false, nullptr);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_pack_wide, dim3(grid_for(n_nodes)), dim3(kBB), 0, nullptr, n_nodes, d_nodes, excl.p, d_remap, d_wide, d_wide4, bad.p);
     HIP_TRYB(hipGetLastError());
     int not_nested = 0;
@@ -560,21 +699,14 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     hipLaunchKernelGGL(k_morton, dim3(grid_for(n)), dim3(kBB), 0, s, n, d_bounds.p, keys6.p, codes.p, numbers.p);
     HIP_TRYB(hipEventRecord(ev[1], s));
     {
-        size_t tmp_bytes = 0;
-        HIP_TRYB(rocprim::radix_sort_pairs(nullptr, tmp_bytes, codes.p, codes_sorted.p, numbers.p, numbers_sorted.p, size_t(n), 0, 30, s));
-        Dev<char> tmp;
-        HIP_TRYB(tmp.alloc(tmp_bytes));
-        HIP_TRYB(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, codes.p, codes_sorted.p, numbers.p, numbers_sorted.p, size_t(n), 0, 30, s));
-        HIP_TRYB(hipStreamSynchronize(s));
+        const int rc = device_sort_pairs_30(codes.p, numbers.p, codes_sorted.p, numbers_sorted.p, n, s);
+        if (rc) return rc;
     }
     HIP_TRYB(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(k_treelet_flags, dim3(grid_for(n)), dim3(kBB), 0, s, n, codes_sorted.p, flags.p);
     {
-        size_t tmp_bytes = 0;
-        HIP_TRYB(rocprim::inclusive_scan(nullptr, tmp_bytes, flags.p, incl.p, size_t(n), rocprim::plus<int>(), s));
-        Dev<char> tmp;
-        HIP_TRYB(tmp.alloc(tmp_bytes));
-        HIP_TRYB(rocprim::inclusive_scan(tmp.p, tmp_bytes, flags.p, incl.p, size_t(n), rocprim::plus<int>(), s));
+        const int rc = device_scan(flags.p, incl.p, size_t(n), true, s);
+        if (rc) return rc;
         HIP_TRYB(hipStreamSynchronize(s));
     }
     hipLaunchKernelGGL(k_treelet_starts, dim3(grid_for(n)), dim3(kBB), 0, s, n, flags.p, incl.p, starts.p);
@@ -598,14 +730,11 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
         LbvhArrays A{codes_sorted.p, numbers_sorted.p, flags.p, incl.p, starts.p, ap[0], ap[1], ap[2], aI, aF, ap[5],
                      ap[6], aEnds, aPE, ap[9], ap[10]};
         hipLaunchKernelGGL(k_lbvh_ranges, dim3(grid_for(n)), dim3(kBB), 0, s, n, A, max_prims);
-        size_t tmp_bytes = 0, tmp2 = 0;
-        HIP_TRYB(rocprim::inclusive_scan(nullptr, tmp_bytes, aI, aF, size_t(n), rocprim::plus<int>(), s));
-        HIP_TRYB(rocprim::inclusive_scan(nullptr, tmp2, aEnds, aPE, size_t(n) + 1, rocprim::plus<int>(), s));
-        Dev<char> tmp;
-        HIP_TRYB(tmp.alloc(std::max(tmp_bytes, tmp2)));
-        HIP_TRYB(rocprim::inclusive_scan(tmp.p, tmp_bytes, aI, aF, size_t(n), rocprim::plus<int>(), s));
+        int rc = device_scan(aI, aF, size_t(n), true, s);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_lbvh_parents, dim3(grid_for(n)), dim3(kBB), 0, s, n, A);
-        HIP_TRYB(rocprim::inclusive_scan(tmp.p, tmp2, aEnds, aPE, size_t(n) + 1, rocprim::plus<int>(), s));
+        rc = device_scan(aEnds, aPE, size_t(n) + 1, true, s);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_lbvh_interior, dim3(grid_for(n)), dim3(kBB), 0, s, n, A, pool.p);
         hipLaunchKernelGGL(k_lbvh_leaves, dim3(grid_for(n)), dim3(kBB), 0, s, n, A, d_bounds.p, pool.p, n_nodes_t.p, err_flag.p);
         HIP_TRYB(hipGetLastError());

@@ -65,15 +65,45 @@ def test_merge_normalises_both_monitors(oracle):
     assert np.array_equal(out[0, 0], (d[0, 0, :3] / 16.0).astype(np.float32))
 
 
-def test_direct_pass_refuses_glass(binding, oracle, tmp_path):
-    """What the restatement does not cover is refused, not approximated (round-3 advisor): with allowMultipleLobes = false
-    (interaction.h:130-133) GlassMaterial adds separate reflection and transmission lobes (glass.cpp:62-90) and the direct
-    integrator's Li recurses through both — a tree, where this pass walks a chain per pixel."""
-    import boxroom
-    path = tmp_path / "glass.pbrt"
-    path.write_text(boxroom.boxroom_pbrt(ico_levels=1, n_blobs=4, wall_n=2, xres=16, yres=16, spp=1, materials="glass"))
-    with pytest.raises(RuntimeError, match="oracle_iispt_direct: 4"):
-        oracle.iispt_direct(binding.HostScene(path=str(path)), 1)
+_SLAB_SCENE = """LookAt 0 -5 0  0 0 0  0 0 1
+Camera "perspective" "float fov" [3]
+Film "image" "integer xresolution" [8] "integer yresolution" [8]
+Sampler "halton" "integer pixelsamples" [1]
+Integrator "path"
+WorldBegin
+AttributeBegin
+  Material "glass" "color Kr" [%s] "color Kt" [%s] "float index" [1.5]
+  Shape "trianglemesh" "point P" [ -2 0 -2  2 0 -2  2 0 2  -2 0 2 ] "integer indices" [ 0 1 2  0 2 3 ]
+  Shape "trianglemesh" "point P" [ -2 0.5 -2  2 0.5 -2  2 0.5 2  -2 0.5 2 ] "integer indices" [ 0 2 1  0 3 2 ]
+AttributeEnd
+AttributeBegin
+  Material "matte" "color Kd" [0 0 0]
+  AreaLightSource "diffuse" "color L" [1 1 1]
+  Shape "trianglemesh" "point P" [ -20 3 -20  20 3 -20  20 3 20  -20 3 20 ] "integer indices" [ 0 1 2  0 2 3 ]
+AttributeEnd
+WorldEnd
+"""
+
+
+def test_direct_pass_through_a_glass_slab(binding, oracle, tmp_path):
+    """DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133): glass is then a
+    SpecularReflection(R, FresnelDielectric(1, eta)) and a SpecularTransmission(T, 1, eta) lobe (glass.cpp:62-90) and Li recurses
+    through BOTH — a tree (round 3 assumed FresnelSpecular, matched neither recursion and rendered glass black: ADVICE r03). The
+    analytic case: an emitting wall seen at normal incidence through a slab of index 1.5. With F = ((eta - 1) / (eta + 1))^2 =
+    0.04 per face, the light paths within five vertices are transmit-transmit, (1 - F)^2, and transmit-reflect-reflect-transmit,
+    (1 - F)^2 F^2 (the radiance scaling eta_i^2 / eta_t^2 of the two transmissions cancels): 0.92307. Without the reflection
+    lobe (Kr = 0): (1 - F)^2 = 0.9216; without the transmission lobe: 0."""
+    def mean(kr, kt):
+        path = tmp_path / "slab.pbrt"
+        path.write_text(_SLAB_SCENE % (kr, kt))
+        film = oracle.iispt_direct(binding.HostScene(path=str(path)), 2, trig_mode=ob.TRIG_LIBM)
+        return float((film[..., :3] / film[..., 3:4]).mean())
+
+    F = 0.04
+    assert abs(mean("1 1 1", "1 1 1") - (1 - F) ** 2 * (1 + F ** 2)) < 2e-6
+    assert abs(mean("0 0 0", "1 1 1") - (1 - F) ** 2) < 2e-6
+    assert mean("1 1 1", "0 0 0") == 0.0
+    assert abs(mean(".5 .5 .5", "1 1 1") - (1 - F) ** 2 * (1 + (0.5 * F) ** 2)) < 2e-6
 
 
 _PANEL_SCENE = """LookAt 0 -3.5 0.8  0 0 0  0 0 1
