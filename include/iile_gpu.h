@@ -155,9 +155,11 @@ int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, c
  * accumulate == 0: the film is zeroed first. Every light is sampled Light::nSamples times per vertex (iile_light::n_samples;
  * UniformSampleAllLights, integrator.cpp:54-83), infinite lights included (escaped rays return Le at every depth,
  * directprogressiveintegrator.cpp:29-32); the NEE record planes are sized for pixels x (sum of the lights' nSamples) records
- * per level, at most 64 light samples per vertex. Not built, IILE_ERR_UNSUPPORTED: image textures combined with mirror lobes
- * (the reflected ray's differentials); glass (with allowMultipleLobes = false the direct integrator's Li branches into a
- * reflection and a transmission recursion at every glass vertex, glass.cpp:62-90). */
+ * per level, at most 64 light samples per vertex. Reflected rays carry differentials in textured scenes
+ * (directprogressiveintegrator.cpp:165-184). Scenes with glass — where Li branches into a reflection and a transmission recursion
+ * at every glass vertex (allowMultipleLobes = false: glass.cpp:62-90) and the sampler's stream follows the recursion's depth-first
+ * order — are rendered by one thread per pixel walking its tree (k_direct_tree), the others by the wavefront. Not built,
+ * IILE_ERR_UNSUPPORTED: image textures combined with a specular SPHERE (its dndu / dndv). */
 typedef struct iile_direct_params {
     int32_t n_passes, first_pass;
     int32_t accumulate;

@@ -1744,10 +1744,10 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     if (reflect_diffs && sc->specular_sphere)
         return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: image textures together with a specular sphere (the reflected ray's differentials need the sphere's dndu / dndv)");
     if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
-    // DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), so GlassMaterial
-    // adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and BOTH SpecularReflect and SpecularTransmit
-    // recurse: Li is a tree there, which this pass (a chain per pixel) does not walk. Rejected rather than rendered black.
-    if (S.has_glass) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: glass (the direct integrator's reflection + transmission recursion tree) is not built");
+    // Glass: DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), GlassMaterial
+    // then adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and both recursions fire — Li is a tree,
+    // walked depth first by one thread per pixel (k_direct_tree) instead of the wavefront below.
+    const bool tree = S.has_glass != 0;
     S.diff_scale = 0.25f;  // ScaleDifferentials(1 / sqrt(16)): the RandomSampler's samples per pixel
     hipStream_t stream = static_cast<hipStream_t>(prm->stream);
     LaunchCfg cfg{sc->n_cus, stream, false};
@@ -1785,15 +1785,15 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     const uint64_t n_records64 = n_paths64 * uint64_t(std::max(total_samples, 1));
     if (n_records64 > 400000000ull)
         return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: pixels x light samples = " + std::to_string(n_records64) + " NEE records per level exceed one pass");
-    rc = ensure_workspace(sc, uint32_t(n_records64));
+    rc = ensure_workspace(sc, tree ? 1024u : uint32_t(n_records64));  // (the per-pixel tree walk queues nothing)
     if (rc) return rc;
     sc->pb.nray_out = nullptr;
     sc->pb.flag_count = nullptr;
     // E, F (5 levels) and D (5 levels x light samples) of every path, the PCG jump table, the film
     const size_t np = P.n_paths, vec = sizeof(float4);
-    const size_t d_bytes = std::max<size_t>(size_t(5) * size_t(total_samples) * np * vec, vec), ef_bytes = size_t(5) * np * vec;
+    const size_t d_bytes = tree ? vec : std::max<size_t>(size_t(5) * size_t(total_samples) * np * vec, vec), ef_bytes = tree ? vec : size_t(5) * np * vec;
     const size_t jump_bytes = (size_t(n_arrays) + 1) * 2 * sizeof(unsigned long long);
-    const size_t rd_bytes = reflect_diffs ? size_t(4) * np * vec : 0;
+    const size_t rd_bytes = (reflect_diffs && !tree) ? size_t(4) * np * vec : 0;
     DevBuf<char> block;
     {
         void *p = nullptr;
@@ -1808,7 +1808,7 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     at += ef_bytes;
     float4 *F = reinterpret_cast<float4 *>(at);
     at += ef_bytes;
-    float4 *RD = reflect_diffs ? reinterpret_cast<float4 *>(at) : nullptr;
+    float4 *RD = rd_bytes ? reinterpret_cast<float4 *>(at) : nullptr;
     at += rd_bytes;
     unsigned long long *jump_dev = reinterpret_cast<unsigned long long *>(at);
     at += (jump_bytes + 255) & ~size_t(255);
@@ -1843,6 +1843,11 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     P.direct_jump = jump_dev;
     for (int i = 0; i < prm->n_passes; ++i) {
         P.direct_seed = uint32_t(6284 + 17 * (prm->first_pass + i));
+        if (tree) {
+            launch_direct_tree(S, P, B, film_dev, cfg);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         HIP_TRY(hipMemsetAsync(B.counts, 0, kCntWords * sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(D, 0, d_bytes + 2 * ef_bytes, stream));
         launch_direct_generate(S, P, B, cfg);
