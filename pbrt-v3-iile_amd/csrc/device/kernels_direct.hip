@@ -468,6 +468,66 @@ __global__ __launch_bounds__(kBlock) void k_direct_fold(DScene S, PassDesc P, Pa
 // heavy); it is the corner the wavefront cannot do, not the product's path for anything else. Held to the oracle's recursion
 // bit for bit and, through it, to the analytic slab (tests/test_iispt_direct.py).
 namespace {
+// The walk below is one large kernel; with everything inlined hipcc 7.2 builds 250 KB of code at 256 VGPRs and ~280 spilled
+// SGPRs — the regime in which it produced wrong code for the one-kernel IISPT gather (iispt.hip's header) and a memory fault
+// here. Its heavy pieces are therefore real calls (speed is not what this kernel is for).
+#define TREE_CALL __device__ __noinline__
+TREE_CALL bool tree_trace(const DScene &S, F3 ro, F3 rd, float tmax, bool any_hit, lds_int *stack, int *spill, uint32_t spill_stride, HitRec *h) {
+    TraceStats st = {0, 0, 0, 0};
+    h->t = h->b0 = h->b1 = h->b2 = 0;
+    h->prim = -1;
+    if (any_hit) return traverse<true, false>(S, ro, rd, tmax, stack, spill, spill_stride, h, &st);
+    return traverse<false, false>(S, ro, rd, tmax, stack, spill, spill_stride, h, &st);
+}
+// the SurfaceInteraction of a hit (and the light / material of its primitive)
+TREE_CALL void tree_interaction(const DScene &S, int prim, F3 ro, F3 rd, float b0, float b1, float b2, Isect *is, int *material, int *light) {
+    const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1], v2 = S.tri_verts[3 * size_t(prim) + 2];
+    const uint32_t flags = f2b(v0.w);
+    *material = int(f2b(v1.w));
+    *light = int(f2b(v2.w));
+    if (flags & 1u) {
+        float t;
+        F3 od, ph;
+        const DSphere &sp = S.spheres[S.prim_shape[prim]];
+        sphere_test(sp, ro, rd, IILE_INF, &t, &od, &ph);
+        sphere_interaction(sp, od, ph, is);
+    } else {
+        triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, rd, b0, b1, b2, is);
+    }
+}
+template <bool TEX>
+TREE_CALL void tree_bsdf(const DScene &S, int material, const TexDiff &td, Isect *is, Bsdf *bsdf) {
+    const DMaterial &m0 = S.materials[material];
+    const bool mat_tex = m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0;
+    if (TEX && S.textured_materials && mat_tex) {
+        if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, is);
+        *bsdf = make_bsdf<true>(textured_material(S, m0, *is, td), *is);
+    } else {
+        *bsdf = make_bsdf<true>(m0, *is);
+    }
+}
+TREE_CALL uint32_t tree_light_request(const DScene &S, int li, const Isect &is, const Bsdf &bsdf, float ul0, float ul1, float us0, float us1, F3 *so,
+                                      F3 *sd, F3 *A, F3 *mo, F3 *md, F3 *Bc) {
+    return direct_light_request(S, S.lights[li], is, bsdf, ul0, ul1, us0, us1, *so, *sd, *A, *mo, *md, *Bc);
+}
+// did the BSDF-sampled ray of EstimateDirect end on light `li`, on its emitting side? (k_mis + k_mis_lit of the wavefront)
+TREE_CALL bool tree_mis_lit(const DScene &S, int li, bool hit, const HitRec &hm, F3 mo, F3 md) {
+    const DLight &lt = S.lights[li];
+    if (!hit) return lt.type == kLightInfinite;  // `else Li = light.Le(ray)`, integrator.cpp:209-210
+    const float4 w0 = S.tri_verts[3 * size_t(hm.prim)], w1 = S.tri_verts[3 * size_t(hm.prim) + 1], w2 = S.tri_verts[3 * size_t(hm.prim) + 2];
+    if (int(f2b(w2.w)) != li) return false;  // lightIsect.primitive->GetAreaLight() == &light
+    Isect lis;
+    if (f2b(w0.w) & 1u) {
+        float th;
+        F3 od, ph;
+        const DSphere &sp = S.spheres[lt.sphere];
+        sphere_test(sp, mo, md, IILE_INF, &th, &od, &ph);
+        sphere_interaction(sp, od, ph, &lis);
+    } else {
+        triangle_interaction(S, hm.prim, f2b(w0.w), F3{w0.x, w0.y, w0.z}, F3{w1.x, w1.y, w1.z}, F3{w2.x, w2.y, w2.z}, md, hm.b0, hm.b1, hm.b2, &lis);
+    }
+    return lt.two_sided || dot(lis.n, -md) > 0;
+}
 struct TreeLevel {
     F3 L;                 // Le + direct light (+ the reflection's share once it is back)
     F3 f_r, f_t;          // SpecularReflect / SpecularTransmit: f of the lobe's sample
@@ -486,7 +546,6 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
     const uint32_t spill_stride = gridDim.x * kBlock;
     int *my_spill = B.spill + blockIdx.x * kBlock + threadIdx.x;
     const int fw = S.crop_x1 - S.crop_x0;
-    TraceStats st = {0, 0, 0, 0};
     for (uint32_t pid = blockIdx.x * kBlock + threadIdx.x; pid < P.n_paths; pid += gridDim.x * kBlock) {
         int px = 0, py = 0;
         uint32_t kk = 0;
@@ -513,8 +572,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
             if (descend) {
                 // ---- Li(ray) at `depth`: intersect, shade, decide the two recursions
                 HitRec h;
-                h.t = h.b0 = h.b1 = h.b2 = 0;
-                const bool found = traverse<false, false>(S, ro, rd, depth == 0 ? tmax : IILE_INF, my_stack, my_spill, spill_stride, &h, &st);
+                const bool found = tree_trace(S, ro, rd, depth == 0 ? tmax : IILE_INF, false, my_stack, my_spill, spill_stride, &h);
                 if (!found) {  // `for (const auto &light : scene.lights) L += light->Le(ray)`
                     F3 L = F3{0, 0, 0};
                     for (int l = 0; l < S.n_lights; ++l)
@@ -525,32 +583,14 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                     if (depth < 0) break;
                     continue;
                 }
-                const int prim = h.prim;
-                const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1], v2 = S.tri_verts[3 * size_t(prim) + 2];
-                const uint32_t flags = f2b(v0.w);
-                const int material = int(f2b(v1.w)), light = int(f2b(v2.w));
                 Isect is;
-                if (flags & 1u) {
-                    float t;
-                    F3 od, ph;
-                    const DSphere &sp = S.spheres[S.prim_shape[prim]];
-                    sphere_test(sp, ro, rd, IILE_INF, &t, &od, &ph);
-                    sphere_interaction(sp, od, ph, &is);
-                } else {
-                    triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, rd, h.b0, h.b1, h.b2, &is);
-                }
+                int material = 0, light = -1;
+                tree_interaction(S, h.prim, ro, rd, h.b0, h.b1, h.b2, &is, &material, &light);
                 TexDiff td = TexDiff{0, 0, 0, 0};
                 F3 dpdx = F3{0, 0, 0}, dpdy = F3{0, 0, 0};
-                const DMaterial &m0 = S.materials[material];
-                const bool mat_tex = m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0;
                 if (TEX && has_diff) td = compute_differentials(is, rdiff, &dpdx, &dpdy);
                 Bsdf bsdf;
-                if (TEX && S.textured_materials && mat_tex) {
-                    if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, &is);
-                    bsdf = make_bsdf<true>(textured_material(S, m0, is, td), is);
-                } else {
-                    bsdf = make_bsdf<true>(m0, is);
-                }
+                tree_bsdf<TEX>(S, material, td, &is, &bsdf);
                 TreeLevel &me = lv[depth];
                 me.L = F3{0, 0, 0};
                 if (light >= 0) me.L = me.L + area_light_L(S.lights[light], is.n, -rd);  // L += isect.Le(wo)
@@ -558,7 +598,6 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                 if (S.n_lights > 0) {
                     F3 all = F3{0, 0, 0};
                     for (int li = 0; li < S.n_lights; ++li) {
-                        const DLight &lt = S.lights[li];
                         const bool arrays = visited < 5;  // Get2DArray hands out the requested arrays, then nullptr
                         const int n = arrays ? P.direct_nsamples[li] : 1;
                         DPcg ra{0, 1}, rb{0, 1};
@@ -577,40 +616,17 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                             }
                             F3 so = F3{0, 0, 0}, sd = F3{0, 0, 1}, mo = F3{0, 0, 0}, md = F3{0, 0, 1}, A = F3{0, 0, 0}, Bc = F3{0, 0, 0};
                             uint32_t nf = 0;
-                            if (n_nonspec(bsdf) > 0) nf = direct_light_request(S, lt, is, bsdf, ul0, ul1, us0, us1, so, sd, A, mo, md, Bc);
+                            if (n_nonspec(bsdf) > 0) nf = tree_light_request(S, li, is, bsdf, ul0, ul1, us0, us1, &so, &sd, &A, &mo, &md, &Bc);
                             // one EstimateDirect: (0 + [unoccluded] A) + [the BSDF-sampled ray ended on this light] Bc — the sums k_shadow forms
                             F3 Le1 = F3{0, 0, 0};
                             if (nf & NEE_HAS_SHADOW) {
                                 HitRec hs;
-                                hs.t = hs.b0 = hs.b1 = hs.b2 = 0;
-                                if (!traverse<true, false>(S, so, sd, 1 - kShadowEpsilon, my_stack, my_spill, spill_stride, &hs, &st)) Le1 = Le1 + A;
+                                if (!tree_trace(S, so, sd, 1 - kShadowEpsilon, true, my_stack, my_spill, spill_stride, &hs)) Le1 = Le1 + A;
                             }
                             if (nf & NEE_HAS_MIS) {
                                 HitRec hm;
-                                hm.t = hm.b0 = hm.b1 = hm.b2 = 0;
-                                const bool hit = traverse<false, false>(S, mo, md, IILE_INF, my_stack, my_spill, spill_stride, &hm, &st);
-                                bool lit = false;
-                                if (!hit) {
-                                    lit = lt.type == kLightInfinite;  // `else Li = light.Le(ray)`, integrator.cpp:209-210
-                                } else {
-                                    const float4 w0 = S.tri_verts[3 * size_t(hm.prim)], w1 = S.tri_verts[3 * size_t(hm.prim) + 1],
-                                                 w2 = S.tri_verts[3 * size_t(hm.prim) + 2];
-                                    if (int(f2b(w2.w)) == li) {  // lightIsect.primitive->GetAreaLight() == &light
-                                        Isect lis;
-                                        if (f2b(w0.w) & 1u) {
-                                            float th;
-                                            F3 od, ph;
-                                            const DSphere &sp = S.spheres[lt.sphere];
-                                            sphere_test(sp, mo, md, IILE_INF, &th, &od, &ph);
-                                            sphere_interaction(sp, od, ph, &lis);
-                                        } else {
-                                            triangle_interaction(S, hm.prim, f2b(w0.w), F3{w0.x, w0.y, w0.z}, F3{w1.x, w1.y, w1.z}, F3{w2.x, w2.y, w2.z}, md,
-                                                                 hm.b0, hm.b1, hm.b2, &lis);
-                                        }
-                                        lit = lt.two_sided || dot(lis.n, -md) > 0;
-                                    }
-                                }
-                                if (lit) Le1 = Le1 + Bc;
+                                const bool hit = tree_trace(S, mo, md, IILE_INF, false, my_stack, my_spill, spill_stride, &hm);
+                                if (tree_mis_lit(S, li, hit, hm, mo, md)) Le1 = Le1 + Bc;
                             }
                             if (arrays)
                                 Ld = Ld + (F3{0, 0, 0} + F3{1.f, 1.f, 1.f} * sdiv(Le1, 1.f));  // the slot k_shadow leaves: L_old (0) + beta (1) * Ld / lightPdf (1)
