@@ -837,6 +837,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 }
         }
         std::vector<DLight> lts(d->n_lights);
+        S.all_lights_infinite = d->n_lights > 0 ? 1 : 0;
         for (int i = 0; i < d->n_lights; ++i) {
             for (int c = 0; c < 3; ++c) lts[i].lemit[c] = d->lights[i].lemit[c];
             lts[i].two_sided = d->lights[i].two_sided;
@@ -853,6 +854,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             lts[i].dist_w = d->lights[i].dist_w;
             lts[i].dist_h = d->lights[i].dist_h;
             lts[i].dist_offset = d->lights[i].dist_offset;
+            if (d->lights[i].type != IILE_LIGHT_INFINITE) S.all_lights_infinite = 0;
             if (d->lights[i].type == IILE_LIGHT_INFINITE) {
                 S.has_infinite = 1;
                 const iile_light &il = d->lights[i];

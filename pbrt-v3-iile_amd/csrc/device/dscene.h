@@ -140,6 +140,7 @@ struct DScene {
     int light_nv[3];
     int has_infinite;         // some light is an InfiniteAreaLight: escaped rays carry radiance (k_miss)
     int extended_features;    // anything beyond one emitting sphere + matte / plastic: k_shade<.., EXT = true>
+    int all_lights_infinite;  // every light is an InfiniteAreaLight: k_mis walks unordered (kernels_trav.hip)
     int has_glass;            // some material transmits: the paths' etaScale is tracked
     int has_specular;         // some material has a specular lobe (mirror, glass, uber): emitted light after such a bounce
     int has_alpha;            // some mesh has an alpha mask: the ALPHA builds of the traversal kernels run

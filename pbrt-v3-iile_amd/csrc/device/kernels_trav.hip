@@ -379,7 +379,9 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
     }
 }
 
-template <bool COUNT, bool ALPHA>
+// ANYORDER: every light of the scene is an infinite one, so every ray of this queue ends at its first hit (below) and the
+// four-wide records are walked unordered, as k_shadow walks them
+template <bool COUNT, bool ALPHA, bool ANYORDER = false>
 __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     __shared__ __attribute__((aligned(16))) char lds_top[COUNT ? 16 : kMaxTop * kTopStride];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
     t.cur = 0;
     t.sp = 0;
     t.hit_prim = -1;
-    bool active = false;
+    bool active = false, first_hit_ends = false;
     uint32_t q = 0, e = 0;
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
@@ -417,6 +419,11 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
                 if (f2b(n2.w) != kInvalid) {
                     const float4 n3 = B.nee[3 * size_t(plane) + q];
                     e = f2b(n2.w);
+                    // EstimateDirect asks of this ray whether it ends on the sampled light (integrator.cpp:204-211). For an INFINITE light
+                    // that is "does it leave the scene": the first primitive it meets settles it (no hit is found later that was not
+                    // found first: until one is, nothing prunes but the slab tests, whose outcome does not depend on the order), so
+                    // the uninstrumented walk stops there instead of looking for the closest one. Alpha masks as Intersect applies them.
+                    first_hit_ends = !COUNT && S.has_infinite && S.lights[f2b(n3.w)].type == kLightInfinite;
                     trav_begin<COUNT>(S, t, F3{n2.x, n2.y, n2.z}, F3{n3.x, n3.y, n3.z}, IILE_INF, &st, sr.root);
                     active = true;
                     ++n_traced;
@@ -437,8 +444,8 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
             if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
-                if (wi) trav_step<COUNT>(S, t, sr, &st);
-                IILE_MORE_INTERIOR_STEPS(trav_step<COUNT>(S, t, sr, &st));
+                if (wi) trav_step<COUNT, ANYORDER>(S, t, sr, &st);
+                IILE_MORE_INTERIOR_STEPS((trav_step<COUNT, ANYORDER>(S, t, sr, &st)));
             } else if (n_leaf > 0) {
                 if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * size_t(plane) + q]);
             }
@@ -447,6 +454,7 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassB
         while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
         if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * size_t(plane) + q]);
 #endif
+        if (first_hit_ends && active && t.hit_prim >= 0) t.have = false;
         if (active && !t.have) {
             // store only: (area light index + 1) of the primitive the MIS ray ended on, 0 for none
             // 255: the ray escaped (matters to an infinite light only)
@@ -550,7 +558,12 @@ void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_
         hipLaunchKernelGGL((k_mis<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     else
         {
-        if (S.has_alpha)
+        if (S.all_lights_infinite) {
+            if (S.has_alpha)
+                hipLaunchKernelGGL((k_mis<false, true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+            else
+                hipLaunchKernelGGL((k_mis<false, false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+        } else if (S.has_alpha)
             hipLaunchKernelGGL((k_mis<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
         else
             hipLaunchKernelGGL((k_mis<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);

@@ -1,6 +1,6 @@
 """BASELINE config 1 in full: killeroo-simple 1920x1080 x 64 spp rendered by the GPU kernels bench.py times and by
 the CPU oracle on all host cores, compared bit for bit (film {X, Y, Z, weight} and the traversal counters).
-usage: python tools/full_frame_parity.py [out.json] [boxroom-textured SPP | killeroo SPP]   (default: killeroo-simple at 64 spp)"""
+usage: python tools/full_frame_parity.py [out.json] [boxroom-textured SPP | boxroom SPP | killeroo SPP]   (default: killeroo-simple at 64 spp)"""
 import json
 import os
 import sys
@@ -27,6 +27,16 @@ if len(sys.argv) > 2 and sys.argv[2] == "boxroom-textured":
     tmp.close()
     scene = b.HostScene(path=tmp.name)
     workload = f"synthetic textured boxroom (tests/boxroom.py: environment map, image / scale textures, bump maps, alpha masks) 1920x1080, {spp} spp"
+elif len(sys.argv) > 2 and sys.argv[2] == "boxroom":
+    # BASELINE config 4's stand-in (Sponza does not ship with the reference): the closed 287 k-triangle room, at BASELINE's 256 spp by default
+    import tempfile
+    import boxroom
+    spp = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".pbrt", delete=False)
+    tmp.write(boxroom.boxroom_pbrt(xres=1920, yres=1080, spp=spp, ico_levels=5, n_blobs=12, wall_n=64))
+    tmp.close()
+    scene = b.HostScene(path=tmp.name)
+    workload = f"synthetic boxroom (287k triangles, tests/boxroom.py) 1920x1080, {spp} spp, path maxdepth 5 (BASELINE.json configs[3]'s stand-in)"
 elif len(sys.argv) > 3 and sys.argv[2] == "killeroo":
     spp = int(sys.argv[3])
     scene = b.HostScene(xres=1920, yres=1080, spp=spp)
