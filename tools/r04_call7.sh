@@ -21,4 +21,4 @@ timeout 600 python3 bench.py --sampler sobol --steps 10 --warmup 2 --cpu-seconds
 timeout 900 python3 bench.py --workload boxroom --spp 256 --steps 2 --warmup 1 --cpu-seconds 0 --alone-steps 1 > $O/bench_boxroom_256spp.json 2> $O/bench_boxroom_256spp.err
 timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --steps 3 --warmup 1 --scaling strong --cpu-seconds 0 --other-steps 0 > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
 ls -la $O | head -40
-head -c 600 $O/bench.json; echo; head -c 300 $O/bench_boxroom.json; echo; tail -3 $O/bench.err $O/bench_boxroom.err $O/bench_torchrun1.err
+head -c 600 $O/bench.json; echo; head -c 300 $O/bench_boxroom.json; echo; for f in bench bench_boxroom bench_torchrun1; do tail -n 2 $O/$f.err; done
