@@ -2,7 +2,7 @@
 # round-4 robustness + config-5 figures: randomised rooms / gather / builder sweeps, the 1080p x 1024 spp frame against the oracle
 # (sixteen passes: the device film finish across passes), the IISPT frame in fp32 and bf16
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r04_call9
+O=$R/gpurun_out/robustness
 mkdir -p $O
 cd $R
 timeout 1500 python3 tools/fuzz_rooms.py 4000 120 > $O/fuzz_rooms.txt 2>&1; tail -2 $O/fuzz_rooms.txt
