@@ -31,6 +31,13 @@ namespace iile {
 
 constexpr int kBlock = 256;            // 4 wavefronts
 constexpr int kWavesPerBlock = kBlock / 64;
+#ifndef IILE_TRAV_BLOCK
+#define IILE_TRAV_BLOCK 256  // threads per block of k_extend / k_shadow / k_mis: a larger block shares one LDS copy of the tree's top among more wavefronts
+#endif
+constexpr int kTravBlock = IILE_TRAV_BLOCK;
+constexpr int kTravWavesPerBlock = kTravBlock / 64;
+constexpr int kTravBlocksPerCu = IILE_TRAV_WAVES * kBlock / kTravBlock;  // same wavefronts per CU whatever the block size
+static_assert(kTravBlock % 64 == 0 && kTravBlocksPerCu * kTravBlock == IILE_TRAV_WAVES * kBlock, "IILE_TRAV_BLOCK must divide the CU's traversal threads");
 #ifndef IILE_SHADE_CHUNK
 #define IILE_SHADE_CHUNK 1024
 #endif
@@ -98,8 +105,8 @@ DEV void flush_counter(unsigned long long *dst, unsigned long long v) {
     v = wave_sum(v);
     if (lane_id() == 0 && v) atomicAdd(dst, v);
 }
-static inline int grid_blocks(uint32_t n, int n_cus, int per_cu) {
-    long want = (long(n) + kBlock - 1) / kBlock;
+static inline int grid_blocks(uint32_t n, int n_cus, int per_cu, int block = kBlock) {
+    long want = (long(n) + block - 1) / block;
     long cap = long(n_cus) * per_cu;
     if (want < 1) want = 1;
     return int(want < cap ? want : cap);

@@ -30,13 +30,13 @@ namespace iile {
 // GEN (first bounce, PassDesc::gen_fused): the queue is the dense range of path ids and a lane makes its camera ray
 // itself (what k_generate would have written and this kernel read back: 64 B per path)
 template <bool COUNT, bool ALPHA, bool GEN>
-__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, PassDesc P, PassBuffers B, int bounce) {
-    __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
+__global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_extend(DScene S, PassDesc P, PassBuffers B, int bounce) {
+    __shared__ int lds_stack[kTravWavesPerBlock][2 * kLdsStackDepth][64];
     __shared__ __attribute__((aligned(16))) char lds_top[COUNT ? 16 : kMaxTop * kTopStride];
-    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kTravBlock + threadIdx.x, gridDim.x * kTravBlock};
     sr.root = S.root_ref;
     if (!COUNT && S.n_top > 0) {  // the instrumented build walks the binary records: no four-wide steps, no top
-        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kBlock);
+        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kTravBlock);
         __syncthreads();
         sr.top = (lds_char *)lds_top;
         sr.root = S.root_ref_top;
@@ -227,13 +227,13 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_extend(DScene S, Pa
 
 
 template <bool COUNT, bool ALPHA>
-__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane) {
-    __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
+__global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, PassBuffers B, int bounce, uint32_t plane) {
+    __shared__ int lds_stack[kTravWavesPerBlock][2 * kLdsStackDepth][64];
     __shared__ __attribute__((aligned(16))) char lds_top[COUNT ? 16 : kMaxTop * kTopStride];
-    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kTravBlock + threadIdx.x, gridDim.x * kTravBlock};
     sr.root = S.root_ref;
     if (!COUNT && S.n_top > 0) {  // the instrumented build walks the binary records: no four-wide steps, no top
-        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kBlock);
+        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kTravBlock);
         __syncthreads();
         sr.top = (lds_char *)lds_top;
         sr.root = S.root_ref_top;
@@ -291,7 +291,11 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
                     // ray carries beta * (A / lightPdf) ready made (k_shade) and no throughput plane.
                     const float4 n0 = B.nee[e], a4 = B.nee[4 * size_t(plane) + e];
                     pid = f2b(a4.w);
+#ifdef IILE_DIAG_SHADOW_NO_L  // timing probe only (wrong film): what the record's one scattered access costs
+                    const float4 L4 = make_float4(0, 0, 0, 0);
+#else
                     const float4 L4 = B.L[pid];
+#endif
                     const bool has_shadow = (flags & NEE_HAS_SHADOW) != 0;
                     if (flags & NEE_HAS_MIS) {
                         const float4 be = B.nee[6 * size_t(plane) + e];
@@ -359,7 +363,11 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
             const F3 Ln = L_old + add;  // store only: nothing is loaded here
             // (an occluded light sample without a lit MIS ray adds +0: L stands as it is — a sum of non-negative terms from +0,
             //  never -0 — and the scattered 16-byte store is left out: a sixth of the records)
+#ifdef IILE_DIAG_SHADOW_NO_L
+            if (Ln.x == 12345.678f) B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
+#else
             if (!is_black(add)) B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
+#endif
             if (COUNT && is_black(add)) ++n_zero;
             active = false;
         }
@@ -382,13 +390,13 @@ __global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_shadow(DScene S, Pa
 // ANYORDER: every light of the scene is an infinite one, so every ray of this queue ends at its first hit (below) and the
 // four-wide records are walked unordered, as k_shadow walks them
 template <bool COUNT, bool ALPHA, bool ANYORDER = false>
-__global__ __launch_bounds__(kBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane) {
-    __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
+__global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_mis(DScene S, PassBuffers B, int bounce, uint32_t plane) {
+    __shared__ int lds_stack[kTravWavesPerBlock][2 * kLdsStackDepth][64];
     __shared__ __attribute__((aligned(16))) char lds_top[COUNT ? 16 : kMaxTop * kTopStride];
-    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock};
+    StackRef sr{(lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63], B.spill, blockIdx.x * kTravBlock + threadIdx.x, gridDim.x * kTravBlock};
     sr.root = S.root_ref;
     if (!COUNT && S.n_top > 0) {  // the instrumented build walks the binary records: no four-wide steps, no top
-        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kBlock);
+        stage_top_records(S, (lds_char *)lds_top, int(threadIdx.x), kTravBlock);
         __syncthreads();
         sr.top = (lds_char *)lds_top;
         sr.root = S.root_ref_top;
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DScene S, int n, const float4 
 
 // ---------------------------------------------------------------------------
 // launchers
-constexpr int kTraverseBlocksPerCu = IILE_TRAV_WAVES;  // resident blocks per CU (LDS stacks, VGPRs)
+constexpr int kTraverseBlocksPerCu = IILE_TRAV_WAVES;  // resident 256-thread blocks per CU (LDS stacks, VGPRs); k_extend / k_shadow / k_mis run the same threads as kTravBlocksPerCu blocks of kTravBlock
 int default_trav_blocks_per_cu() { return kTraverseBlocksPerCu; }
 constexpr int kMaxTraverseBlocksPerCu = 8;  // spill columns are sized for this many
 uint32_t max_traversal_threads(int n_cus) {
@@ -523,50 +531,54 @@ uint32_t queue_capacity(uint32_t n_paths, int n_cus) {
     const uint64_t waves = std::min<uint64_t>(uint64_t(n_cus) * kTraverseBlocksPerCu * kWavesPerBlock, n_paths / 64 + 8);
     return uint32_t(std::min<uint64_t>(uint64_t(n_paths) + n_paths / 8 + waves * kOutBlock, 0xffff0000ull));
 }
+static dim3 trav_grid(uint32_t n, const LaunchCfg &cfg) {
+    const int per_cu256 = cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu;
+    return dim3(grid_blocks(n, cfg.n_cus, std::max(1, per_cu256 * kBlock / kTravBlock), kTravBlock));
+}
 void launch_extend(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
+    const dim3 grid = trav_grid(max_rays, cfg);
     const bool gen = bounce == 0 && P.gen_fused && !cfg.count_stats;
     if (cfg.count_stats)
-        hipLaunchKernelGGL((k_extend<true, true, false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
+        hipLaunchKernelGGL((k_extend<true, true, false>), grid, dim3(kTravBlock), 0, cfg.stream, S, P, B, bounce);
     else if (S.has_alpha) {
         if (gen)
-            hipLaunchKernelGGL((k_extend<false, true, true>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
+            hipLaunchKernelGGL((k_extend<false, true, true>), grid, dim3(kTravBlock), 0, cfg.stream, S, P, B, bounce);
         else
-            hipLaunchKernelGGL((k_extend<false, true, false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
+            hipLaunchKernelGGL((k_extend<false, true, false>), grid, dim3(kTravBlock), 0, cfg.stream, S, P, B, bounce);
     } else {
         if (gen)
-            hipLaunchKernelGGL((k_extend<false, false, true>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
+            hipLaunchKernelGGL((k_extend<false, false, true>), grid, dim3(kTravBlock), 0, cfg.stream, S, P, B, bounce);
         else
-            hipLaunchKernelGGL((k_extend<false, false, false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, bounce);
+            hipLaunchKernelGGL((k_extend<false, false, false>), grid, dim3(kTravBlock), 0, cfg.stream, S, P, B, bounce);
     }
 }
 void launch_shadow(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
+    const dim3 grid = trav_grid(max_rays, cfg);
     if (cfg.count_stats)
-        hipLaunchKernelGGL((k_shadow<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+        hipLaunchKernelGGL((k_shadow<true, true>), grid, dim3(kTravBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     else
         {
         if (S.has_alpha)
-            hipLaunchKernelGGL((k_shadow<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+            hipLaunchKernelGGL((k_shadow<false, true>), grid, dim3(kTravBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
         else
-            hipLaunchKernelGGL((k_shadow<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+            hipLaunchKernelGGL((k_shadow<false, false>), grid, dim3(kTravBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     }
 }
 void launch_mis(const DScene &S, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, cfg.trav_blocks_per_cu > 0 ? cfg.trav_blocks_per_cu : kTraverseBlocksPerCu));
+    const dim3 grid = trav_grid(max_rays, cfg);
     if (cfg.count_stats)
-        hipLaunchKernelGGL((k_mis<true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+        hipLaunchKernelGGL((k_mis<true, true>), grid, dim3(kTravBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     else
         {
         if (S.all_lights_infinite) {
             if (S.has_alpha)
-                hipLaunchKernelGGL((k_mis<false, true, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+                hipLaunchKernelGGL((k_mis<false, true, true>), grid, dim3(kTravBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
             else
-                hipLaunchKernelGGL((k_mis<false, false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+                hipLaunchKernelGGL((k_mis<false, false, true>), grid, dim3(kTravBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
         } else if (S.has_alpha)
-            hipLaunchKernelGGL((k_mis<false, true>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+            hipLaunchKernelGGL((k_mis<false, true>), grid, dim3(kTravBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
         else
-            hipLaunchKernelGGL((k_mis<false, false>), grid, dim3(kBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
+            hipLaunchKernelGGL((k_mis<false, false>), grid, dim3(kTravBlock), 0, cfg.stream, S, B, bounce, B.queue_cap);
     }
 }
 void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, float4 *hits, int any_hit,
