@@ -13,9 +13,9 @@
 //   k_lbvh_*            emitLBVH (:555-618) for all treelets at once, one thread per sorted position (see below), nodes in
 //                       preorder into the treelet's own pool region; leaves take their primitives in sorted order, so
 //                       the leaf order IS the sorted order
-//   host: buildUpperSAH (:620-638+) over the <= 4096 treelet roots — a sequential SAH with std::partition over a few
-//                       thousand boxes (the reference runs it on one thread too) — and the preorder offsets of the subtrees
-//   k_place_nodes / k_place_upper   flattenBVHTree: every node to its depth-first index, second-child offsets rebased
+//   k_upper_sah         buildUpperSAH (:527-638) over the <= 4096 treelet roots and the preorder offsets of all subtrees: one
+//                       block, spans of roots as work items for its wavefronts (round 4; a host loop before)
+//   k_place_nodes       flattenBVHTree: every treelet node to its depth-first index, second-child offsets rebased
 //
 // The result must equal the host builder's (csrc/host/bvh_build.cpp, split method "hlbvh") node for node:
 // tests/test_gpu_bvh_build.py. Float arithmetic is IEEE (no contraction, correctly rounded division) like the rest.
@@ -301,102 +301,265 @@ __global__ __launch_bounds__(kBB) void k_place_nodes(int n, const int *incl, con
         out[base[t] + local] = nd;
     }
 }
-struct PlacedNode {
-    int index;
-    iile_bvh_node node;
+// ---- buildUpperSAH on the device (bvh.cpp:527-638): 12-bucket SAH over the treelet roots ------------------------------
+// The reference recurses over a span of treelet roots: bounds and centroid bounds of the span, twelve buckets along the
+// widest centroid axis, the cheapest of eleven splits, std::partition, two recursive calls. Everything it computes is a
+// function of the SET of roots in the span — min / max unions, counts, the cost expression — so the order std::partition
+// leaves the two sides in decides nothing: the tree is the same whichever way each side is ordered, and the layout
+// (flattenBVHTree's preorder) follows from the tree. One block builds it:
+//   * spans are work items in an LDS queue; a wavefront takes the next ticket, waits until that slot is published, and
+//     processes the span: three passes over its roots (bounds; buckets, LDS atomics on order-preserving keys; a stable
+//     partition into the other of two LDS index arrays by ballot ranks), the eleven costs on eleven lanes in the reference's
+//     float expression, the first minimum in bucket order. A side of one root is a leaf of the upper tree, a larger side
+//     is published as a new slot. The slot number IS the upper node's number, so a parent's number is smaller than its
+//     children's, and exactly n - 1 slots exist for n roots — a ticket past that ends the wavefront.
+//   * sizes and boxes then climb from the treelets (the second child to arrive at a node finishes it: InitInterior's
+//     Union(c0, c1), operand order kept because std::min / std::max return their first argument on a tie of -0 and +0),
+//   * and every upper node and treelet sums its preorder offset along its path to the root; upper nodes are written to the
+//     output array in place, treelets get the base k_place_nodes moves their blocks to.
+// A span whose centroids coincide on the chosen axis (the reference stops with CHECK_NE there) or whose split leaves a side
+// empty is cut in the middle, so the kernel always ends.
+constexpr int kUpMax = 4096;      // treelets are runs of equal top 12 Morton bits: at most 4096
+constexpr int kUpThreads = 512;   // 8 wavefronts
+constexpr int kUpBuckets = 12;
+struct UpperDev {
+    const Box *roots;       // [n_t] treelet root bounds
+    const int *n_nodes_t;   // [n_t] nodes per treelet
+    int *parent;            // [n_t - 1] upper node -> parent node * 2 + which child, -1 for the root
+    int *tparent;           // [n_t] the same for treelets
+    int *axis;              // [n_t - 1]
+    Box *cbox;              // [2 (n_t - 1)] boxes of the two children of every upper node
+    int *base;              // [n_t] out: preorder offset of every treelet's block
+    iile_bvh_node *out;     // the flattened tree: upper nodes are written here
+    int *err;               // set to 2 if the queue bookkeeping ever disagrees with n_t - 1 (never seen)
 };
-__global__ __launch_bounds__(kBB) void k_place_upper(int n, const PlacedNode *upper, iile_bvh_node *out) {
-    const int i = blockIdx.x * kBB + threadIdx.x;
-    if (i < n) out[upper[i].index] = upper[i].node;
+__device__ __forceinline__ float box_area(const float mn[3], const float mx[3]) {  // Bounds3::SurfaceArea, geometry.h:782-785
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return 2 * (dx * dy + dx * dz + dy * dz);
 }
-
-// ---- buildUpperSAH on the host (bvh.cpp:474-553): 12-bucket SAH over the treelet roots -----------------------------
-struct HBox {
-    float mn[3], mx[3];
-    HBox() {  // Bounds3(), geometry.h:752-757
-        for (int a = 0; a < 3; ++a) mn[a] = std::numeric_limits<float>::max(), mx[a] = std::numeric_limits<float>::lowest();
+__device__ __forceinline__ float union_min(float a, float b) { return b < a ? b : a; }  // std::min(a, b)
+__device__ __forceinline__ float union_max(float a, float b) { return a < b ? b : a; }  // std::max(a, b)
+__device__ __forceinline__ float wave_min_f(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
+    __shared__ int refs[2][kUpMax];         // treelet numbers, ping-pong between a span and its two sides
+    __shared__ uint32_t q_seg[kUpMax];      // slot -> start | end << 13 | array << 26; 0 = not published yet
+    __shared__ int q_link[kUpMax];          // slot -> parent * 2 + which, -1 for the root span
+    __shared__ uint32_t bk[kUpThreads / 64][kUpBuckets][8];  // per wavefront: count, 3 min keys, 3 max keys
+    __shared__ float cost_s[kUpThreads / 64][kUpBuckets];
+    __shared__ int q_head, q_tail;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n_upper = n_t - 1;
+    for (int i = tid; i < kUpMax; i += kUpThreads) {
+        refs[0][i] = i;
+        q_seg[i] = 0;
+        q_link[i] = -1;
     }
-    void add(const HBox &b) {
-        for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], b.mn[a]), mx[a] = std::max(mx[a], b.mx[a]);
+    if (tid == 0) {
+        q_head = 0;
+        q_tail = 1;
     }
-    void add_point(const float p[3]) {
-        for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], p[a]), mx[a] = std::max(mx[a], p[a]);
-    }
-    float area() const {  // geometry.h:782-785
-        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
-        return 2 * (dx * dy + dx * dz + dy * dz);
-    }
-    int max_extent() const {  // geometry.h:790-798
-        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
-        if (dx > dy && dx > dz) return 0;
-        return dy > dz ? 1 : 2;
-    }
-};
-struct UpperNode {
-    HBox box;
-    int child[2];  // >= 0: upper node, < 0: ~treelet
-    int axis;
-};
-struct UpperBuilder {
-    const std::vector<HBox> &roots;  // per treelet
-    std::vector<UpperNode> nodes;
-    explicit UpperBuilder(const std::vector<HBox> &r) : roots(r) {}
-    const HBox &box_of(int ref) const { return ref >= 0 ? nodes[size_t(ref)].box : roots[size_t(~ref)]; }
-
-    int build(std::vector<int> &refs, int start, int end) {
-        if (end - start == 1) return refs[size_t(start)];
-        nodes.emplace_back();
-        const int node = int(nodes.size()) - 1;
-        HBox bounds, cb;
-        for (int i = start; i < end; ++i) bounds.add(box_of(refs[size_t(i)]));
-        for (int i = start; i < end; ++i) {
-            const HBox &b = box_of(refs[size_t(i)]);
-            const float c[3] = {(b.mn[0] + b.mx[0]) * 0.5f, (b.mn[1] + b.mx[1]) * 0.5f, (b.mn[2] + b.mx[2]) * 0.5f};
-            cb.add_point(c);
+    __syncthreads();
+    if (tid == 0) q_seg[0] = 0u | (uint32_t(n_t) << 13);
+    __syncthreads();
+    volatile uint32_t *vseg = q_seg;
+    while (true) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&q_head, 1);
+        slot = __shfl(slot, 0);
+        if (slot >= n_upper) break;
+        uint32_t seg;
+        int spins = 0;
+        while ((seg = vseg[slot]) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+        if (seg == 0) {  // (never seen: n roots make exactly n - 1 spans) give up rather than hang
+            if (lane == 0) *U.err = 3;
+            break;
         }
-        const int dim = cb.max_extent();
-        constexpr int nBuckets = 12;
-        struct Bucket {
-            int count = 0;
-            HBox bounds;
-        } buckets[nBuckets];
-        const float lo = cb.mn[dim], hi = cb.mx[dim];
-        auto bucket_of = [&](int ref) {
-            const HBox &b = box_of(ref);
+        __threadfence_block();
+        const int s = int(seg & 8191u), e = int((seg >> 13) & 8191u), buf = int(seg >> 26);
+        const int *src = refs[buf];
+        int *dst = refs[buf ^ 1];
+        // bounds of the span and of its centroids (bvh.cpp:537-549)
+        float bmn[3] = {kFltMax, kFltMax, kFltMax}, bmx[3] = {-kFltMax, -kFltMax, -kFltMax};
+        float cmn[3] = {kFltMax, kFltMax, kFltMax}, cmx[3] = {-kFltMax, -kFltMax, -kFltMax};
+        for (int i = s + lane; i < e; i += 64) {
+            const Box b = U.roots[src[i]];
+            for (int a = 0; a < 3; ++a) {
+                bmn[a] = fminf(bmn[a], b.mn[a]), bmx[a] = fmaxf(bmx[a], b.mx[a]);
+                const float c = (b.mn[a] + b.mx[a]) * 0.5f;
+                cmn[a] = fminf(cmn[a], c), cmx[a] = fmaxf(cmx[a], c);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            bmn[a] = wave_min_f(bmn[a]), bmx[a] = wave_max_f(bmx[a]);
+            cmn[a] = wave_min_f(cmn[a]), cmx[a] = wave_max_f(cmx[a]);
+        }
+        int dim;  // Bounds3::MaximumExtent, geometry.h:790-798
+        {
+            const float dx = cmx[0] - cmn[0], dy = cmx[1] - cmn[1], dz = cmx[2] - cmn[2];
+            dim = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);
+        }
+        const float lo = cmn[dim], hi = cmx[dim];
+        auto bucket_of = [&](const Box &b) {  // bvh.cpp:576-582
             const float centroid = (b.mn[dim] + b.mx[dim]) * 0.5f;
-            int k = int(nBuckets * ((centroid - lo) / (hi - lo)));
-            if (k == nBuckets) k = nBuckets - 1;
+            int k = int(kUpBuckets * ((centroid - lo) / (hi - lo)));
+            if (k == kUpBuckets) k = kUpBuckets - 1;
             return k;
         };
-        for (int i = start; i < end; ++i) {
-            const int k = bucket_of(refs[size_t(i)]);
-            buckets[k].count++;
-            buckets[k].bounds.add(box_of(refs[size_t(i)]));
+        const bool flat = !(lo < hi);  // every centroid at one coordinate: no bucket means anything
+        int n_left = (e - s) / 2;
+        int min_bucket = -1;
+        if (!flat) {
+            for (int i = lane; i < kUpBuckets * 8; i += 64) {
+                const int f = i & 7;
+                bk[w][i >> 3][f] = f == 0 ? 0u : (f <= 3 ? order_key(kFltMax) : order_key(-kFltMax));
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = s + lane; i < e; i += 64) {
+                const Box b = U.roots[src[i]];
+                int k = bucket_of(b);
+                k = k < 0 ? 0 : (k > kUpBuckets - 1 ? kUpBuckets - 1 : k);  // (the reference CHECKs 0 <= b < 12)
+                atomicAdd(&bk[w][k][0], 1u);
+                for (int a = 0; a < 3; ++a) {
+                    atomicMin(&bk[w][k][1 + a], order_key(b.mn[a]));
+                    atomicMax(&bk[w][k][4 + a], order_key(b.mx[a]));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            if (lane < kUpBuckets - 1) {  // bvh.cpp:588-602, one candidate split per lane
+                float mn0[3] = {kFltMax, kFltMax, kFltMax}, mx0[3] = {-kFltMax, -kFltMax, -kFltMax};
+                float mn1[3] = {kFltMax, kFltMax, kFltMax}, mx1[3] = {-kFltMax, -kFltMax, -kFltMax};
+                int c0 = 0, c1 = 0;
+                for (int j = 0; j < kUpBuckets; ++j) {
+                    const int cnt = int(bk[w][j][0]);
+                    float jm[3], jx[3];
+                    for (int a = 0; a < 3; ++a) jm[a] = key_float(bk[w][j][1 + a]), jx[a] = key_float(bk[w][j][4 + a]);
+                    if (j <= lane) {
+                        for (int a = 0; a < 3; ++a) mn0[a] = fminf(mn0[a], jm[a]), mx0[a] = fmaxf(mx0[a], jx[a]);
+                        c0 += cnt;
+                    } else {
+                        for (int a = 0; a < 3; ++a) mn1[a] = fminf(mn1[a], jm[a]), mx1[a] = fmaxf(mx1[a], jx[a]);
+                        c1 += cnt;
+                    }
+                }
+                cost_s[w][lane] = .125f + (float(c0) * box_area(mn0, mx0) + float(c1) * box_area(mn1, mx1)) / box_area(bmn, bmx);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            float min_cost = cost_s[w][0];  // bvh.cpp:605-612: the first minimum; a NaN cost (an empty side) is never smaller
+            min_bucket = 0;
+            for (int i = 1; i < kUpBuckets - 1; ++i) {
+                const float c = cost_s[w][i];
+                if (c < min_cost) min_cost = c, min_bucket = i;
+            }
+            int cnt = 0;
+            for (int i = s + lane; i < e; i += 64) cnt += bucket_of(U.roots[src[i]]) <= min_bucket ? 1 : 0;
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            if (cnt > 0 && cnt < e - s)
+                n_left = cnt;
+            else
+                min_bucket = -1;  // an empty side: the middle cut
         }
-        float cost[nBuckets - 1];
-        for (int i = 0; i < nBuckets - 1; ++i) {
-            HBox b0, b1;
-            int c0 = 0, c1 = 0;
-            for (int j = 0; j <= i; ++j) b0.add(buckets[j].bounds), c0 += buckets[j].count;
-            for (int j = i + 1; j < nBuckets; ++j) b1.add(buckets[j].bounds), c1 += buckets[j].count;
-            cost[i] = .125f + (c0 * b0.area() + c1 * b1.area()) / bounds.area();
+        const int mid = s + n_left;
+        {  // stable partition into the other array
+            int done_l = 0, done_r = 0;
+            for (int base = s; base < e; base += 64) {
+                const int i = base + lane;
+                const bool in = i < e;
+                int t = 0;
+                bool left = false;
+                if (in) {
+                    t = src[i];
+                    left = min_bucket >= 0 ? bucket_of(U.roots[t]) <= min_bucket : (i - s) < n_left;
+                }
+                const unsigned long long ml = __ballot(in && left), mr = __ballot(in && !left);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (in) {
+                    if (left)
+                        dst[s + done_l + __popcll(ml & below)] = t;
+                    else
+                        dst[mid + done_r + __popcll(mr & below)] = t;
+                }
+                done_l += __popcll(ml), done_r += __popcll(mr);
+            }
         }
-        float min_cost = cost[0];
-        int min_bucket = 0;
-        for (int i = 1; i < nBuckets - 1; ++i)
-            if (cost[i] < min_cost) min_cost = cost[i], min_bucket = i;
-        int *pmid = std::partition(&refs[size_t(start)], &refs[size_t(end - 1)] + 1, [&](int r) { return bucket_of(r) <= min_bucket; });
-        const int mid = int(pmid - &refs[0]);
-        const int c0 = build(refs, start, mid);
-        const int c1 = build(refs, mid, end);
-        UpperNode &nd = nodes[size_t(node)];
-        nd.child[0] = c0, nd.child[1] = c1;
-        nd.box = box_of(c0);
-        nd.box.add(box_of(c1));
-        nd.axis = dim;
-        return node;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (lane == 0) {
+            U.axis[slot] = dim;
+            U.parent[slot] = q_link[slot];
+            for (int which = 0; which < 2; ++which) {
+                const int cs = which ? mid : s, ce = which ? e : mid;
+                if (ce - cs == 1) {
+                    U.tparent[dst[cs]] = slot * 2 + which;
+                } else {
+                    const int child = atomicAdd(&q_tail, 1);
+                    if (child >= n_upper) {
+                        *U.err = 2;
+                    } else {
+                        q_link[child] = slot * 2 + which;
+                        __threadfence_block();
+                        vseg[child] = uint32_t(cs) | (uint32_t(ce) << 13) | (uint32_t(buf ^ 1) << 26);
+                    }
+                }
+            }
+        }
     }
-};
+    __syncthreads();
+    // sizes and boxes climb from the treelets; refs[] is free now: child sizes in refs[0] / refs[1], arrivals in q_seg
+    int *size0 = refs[0], *size1 = refs[1];
+    for (int i = tid; i < kUpMax; i += kUpThreads) q_seg[i] = 0;
+    __syncthreads();
+    for (int t = tid; t < n_t; t += kUpThreads) {
+        int link = U.tparent[t];
+        int size = U.n_nodes_t[t];
+        Box box = U.roots[t];
+        while (link >= 0) {
+            const int node = link >> 1, which = link & 1;
+            (which ? size1 : size0)[node] = size;
+            U.cbox[2 * node + which] = box;
+            __threadfence();
+            if (atomicAdd(&q_seg[node], 1u) == 0u) break;  // the other child finishes this node
+            __threadfence();
+            const Box b0 = U.cbox[2 * node], b1 = U.cbox[2 * node + 1];  // InitInterior: Union(c0, c1), bvh.cpp:66-72
+            for (int a = 0; a < 3; ++a) box.mn[a] = union_min(b0.mn[a], b1.mn[a]), box.mx[a] = union_max(b0.mx[a], b1.mx[a]);
+            size = 1 + ((volatile int *)size0)[node] + ((volatile int *)size1)[node];
+            U.cbox[2 * n_upper + node] = box;  // the node's own box (read again below, after the barrier)
+            link = q_link[node];
+        }
+    }
+    __syncthreads();
+    // preorder offsets: 1 per ancestor, plus the first child's subtree wherever the path goes through a second child
+    for (int i = tid; i < n_upper + n_t; i += kUpThreads) {
+        const bool is_node = i < n_upper;
+        int link = is_node ? q_link[i] : U.tparent[i - n_upper];
+        int off = 0;
+        while (link >= 0) {
+            const int p = link >> 1;
+            off += 1 + ((link & 1) ? size0[p] : 0);
+            link = q_link[p];
+        }
+        if (is_node) {
+            iile_bvh_node nd;
+            const Box box = U.cbox[2 * n_upper + i];
+            for (int a = 0; a < 3; ++a) nd.bmin[a] = box.mn[a], nd.bmax[a] = box.mx[a];
+            nd.offset = off + 1 + size0[i];  // secondChildOffset (bvh.cpp:651-656)
+            nd.nprims = 0;
+            nd.axis = uint8_t(U.axis[i]);
+            nd.pad = 0;
+            U.out[off] = nd;
+        } else {
+            U.base[i - n_upper] = off;
+        }
+    }
+}
 
 template <typename T>
 struct Dev {
@@ -718,7 +881,7 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     Dev<int> err_flag;
     HIP_TRYB(err_flag.alloc(1));
     HIP_TRYB(hipMemsetAsync(err_flag.p, 0, sizeof(int), s));
-    int n_splits = 0;
+    int n_splits = 0, h_err = 0;
     {
         Dev<int> arena;  // eleven int arrays of n (+ 1) entries in one allocation
         const size_t stride = (size_t(n) + 1 + 63) & ~size_t(63);
@@ -739,78 +902,40 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
         hipLaunchKernelGGL(k_lbvh_leaves, dim3(grid_for(n)), dim3(kBB), 0, s, n, A, d_bounds.p, pool.p, n_nodes_t.p, err_flag.p);
         HIP_TRYB(hipGetLastError());
         HIP_TRYB(hipMemcpyAsync(&n_splits, aF + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRYB(hipMemcpyAsync(&h_err, err_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRYB(hipStreamSynchronize(s));
     }
-    HIP_TRYB(hipEventRecord(ev[3], s));
-    // the treelet roots come to the host: the upper SAH tree and the preorder offsets of all subtrees
-    Dev<Box> d_roots;
-    HIP_TRYB(d_roots.alloc(size_t(n_treelets)));
-    hipLaunchKernelGGL(k_treelet_roots, dim3((n_treelets + kBB - 1) / kBB), dim3(kBB), 0, s, n_treelets, starts.p, pool.p, d_roots.p);
-    std::vector<HBox> roots(static_cast<size_t>(n_treelets));
-    std::vector<int> counts(static_cast<size_t>(n_treelets));
-    int h_err = 0;
-    static_assert(sizeof(HBox) == sizeof(Box), "box layouts");
-    HIP_TRYB(hipMemcpyAsync(roots.data(), d_roots.p, size_t(n_treelets) * sizeof(Box), hipMemcpyDeviceToHost, s));
-    HIP_TRYB(hipMemcpyAsync(counts.data(), n_nodes_t.p, size_t(n_treelets) * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRYB(hipMemcpyAsync(&h_err, err_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRYB(hipStreamSynchronize(s));
     if (h_err) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: a leaf holds more than 65535 primitives (equal Morton codes)");
-    UpperBuilder ub(roots);
-    std::vector<int> refs(static_cast<size_t>(n_treelets));
-    for (int t = 0; t < n_treelets; ++t) refs[size_t(t)] = ~t;
-    ub.nodes.reserve(size_t(n_treelets));
-    const int root = ub.build(refs, 0, n_treelets);
-    // flattenBVHTree over the upper tree; a treelet reference places its whole preorder block
-    std::vector<int> h_base(static_cast<size_t>(n_treelets));
-    std::vector<PlacedNode> placed;
-    placed.reserve(ub.nodes.size());
-    int cursor = 0;
-    {
-        struct Item {
-            int ref, placed_index;  // placed_index >= 0: the second child of that placed node starts here
-        };
-        // iterative preorder: explicit stack of (ref, owner whose second-child offset this is)
-        std::vector<Item> stack;
-        stack.push_back({root, -1});
-        while (!stack.empty()) {
-            const Item it = stack.back();
-            stack.pop_back();
-            if (it.placed_index >= 0) placed[size_t(it.placed_index)].node.offset = cursor;
-            if (it.ref < 0) {
-                h_base[size_t(~it.ref)] = cursor;
-                cursor += counts[size_t(~it.ref)];
-                continue;
-            }
-            const UpperNode &u = ub.nodes[size_t(it.ref)];
-            PlacedNode pn;
-            std::memset(&pn, 0, sizeof(pn));
-            pn.index = cursor++;
-            for (int a = 0; a < 3; ++a) pn.node.bmin[a] = u.box.mn[a], pn.node.bmax[a] = u.box.mx[a];
-            pn.node.nprims = 0;
-            pn.node.axis = uint8_t(u.axis);
-            placed.push_back(pn);
-            const int me = int(placed.size()) - 1;
-            stack.push_back({u.child[1], me});  // visited after the whole first subtree
-            stack.push_back({u.child[0], -1});
-        }
-    }
-    const int n_nodes = cursor;
-    HIP_TRYB(hipEventRecord(ev[4], s));
+    if (n_treelets > kUpMax) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: more than 4096 treelets");
+    HIP_TRYB(hipEventRecord(ev[3], s));
+    // buildUpperSAH + the preorder offsets of all subtrees, on the device (k_upper_sah): every treelet has emitted
+    // n_nodes_t nodes, the upper tree adds n_treelets - 1
+    const int n_upper = n_treelets - 1;
+    const int n_nodes = 2 * n_splits + 2 * n_treelets - 1;
+    Dev<Box> d_roots, d_cbox;
+    Dev<int> up_parent, up_tparent, up_axis;
+    HIP_TRYB(d_roots.alloc(size_t(n_treelets)));
+    HIP_TRYB(d_cbox.alloc(3 * size_t(std::max(n_upper, 1))));
+    HIP_TRYB(up_parent.alloc(size_t(std::max(n_upper, 1))));
+    HIP_TRYB(up_axis.alloc(size_t(std::max(n_upper, 1))));
+    HIP_TRYB(up_tparent.alloc(size_t(n_treelets)));
     HIP_TRYB(out.alloc(size_t(n_nodes)));
-    HIP_TRYB(hipMemcpyAsync(base.p, h_base.data(), size_t(n_treelets) * sizeof(int), hipMemcpyHostToDevice, s));
-    Dev<PlacedNode> d_placed;
-    HIP_TRYB(d_placed.alloc(placed.size()));
-    if (!placed.empty())
-        HIP_TRYB(hipMemcpyAsync(d_placed.p, placed.data(), placed.size() * sizeof(PlacedNode), hipMemcpyHostToDevice, s));
+    HIP_TRYB(hipMemsetAsync(up_tparent.p, 0xff, size_t(n_treelets) * sizeof(int), s));  // -1: the treelet is the whole tree
+    hipLaunchKernelGGL(k_treelet_roots, dim3((n_treelets + kBB - 1) / kBB), dim3(kBB), 0, s, n_treelets, starts.p, pool.p, d_roots.p);
+    {
+        UpperDev U{d_roots.p, n_nodes_t.p, up_parent.p, up_tparent.p, up_axis.p, d_cbox.p, base.p, out.p, err_flag.p};
+        hipLaunchKernelGGL(k_upper_sah, dim3(1), dim3(kUpThreads), 0, s, n_treelets, U);
+    }
+    HIP_TRYB(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(k_place_nodes, dim3(grid_for(2 * n)), dim3(kBB), 0, s, n, incl.p, starts.p, n_nodes_t.p, base.p, pool.p, out.p);
-    if (!placed.empty())
-        hipLaunchKernelGGL(k_place_upper, dim3((int(placed.size()) + kBB - 1) / kBB), dim3(kBB), 0, s, int(placed.size()), d_placed.p, out.p);
     HIP_TRYB(hipGetLastError());
     HIP_TRYB(hipEventRecord(ev[5], s));
     HIP_TRYB(hipMemcpyAsync(nodes_out, out.p, size_t(n_nodes) * sizeof(iile_bvh_node), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipMemcpyAsync(order_out, numbers_sorted.p, size_t(n) * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipEventRecord(ev[6], s));
+    HIP_TRYB(hipMemcpyAsync(&h_err, err_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipStreamSynchronize(s));
+    if (h_err) return api_fail(IILE_ERR_HIP, "iile_bvh_build_hlbvh: the upper SAH kernel lost track of its spans (code " + std::to_string(h_err) + ")");
     *n_nodes_out = n_nodes;
     auto ms = [&](int a, int b) {
         float v = 0;
@@ -821,7 +946,7 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     st.ms_download = ms(5, 6), st.ms_total = ms(0, 6);
     st.n_treelets = n_treelets;
     st.n_nodes = n_nodes;
-    st.n_interior = n_splits + int(ub.nodes.size());
+    st.n_interior = n_splits + n_upper;
     st.n_leaf = n_splits + n_treelets;
     if (stats) *stats = st;
     return IILE_OK;
