@@ -320,12 +320,12 @@ __global__ __launch_bounds__(kBB) void k_place_nodes(int n, const int *incl, con
 // A span whose centroids coincide on the chosen axis (the reference stops with CHECK_NE there) or whose split leaves a side
 // empty is cut in the middle, so the kernel always ends.
 constexpr int kUpMax = 4096;      // treelets are runs of equal top 12 Morton bits: at most 4096
-constexpr int kUpThreads = 512;   // 8 wavefronts
+constexpr int kUpThreads = 1024;  // 16 wavefronts
 constexpr int kUpBuckets = 12;
+constexpr uint32_t kSegDone = 0xffffffffu;  // queue entry of a span its parent has already split
 struct UpperDev {
     const Box *roots;       // [n_t] treelet root bounds
     const int *n_nodes_t;   // [n_t] nodes per treelet
-    int *parent;            // [n_t - 1] upper node -> parent node * 2 + which child, -1 for the root
     int *tparent;           // [n_t] the same for treelets
     int *axis;              // [n_t - 1]
     Box *cbox;              // [2 (n_t - 1)] boxes of the two children of every upper node
@@ -339,27 +339,62 @@ __device__ __forceinline__ float box_area(const float mn[3], const float mx[3]) 
 }
 __device__ __forceinline__ float union_min(float a, float b) { return b < a ? b : a; }  // std::min(a, b)
 __device__ __forceinline__ float union_max(float a, float b) { return a < b ? b : a; }  // std::max(a, b)
-__device__ __forceinline__ float wave_min_f(float v) {
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
+// Cross-lane steps as DPP operands of the min / max / add itself (one instruction per step; __shfl_xor is an LDS round trip):
+// row_shr / row_shl move inside a row of 16 lanes, row_bcast:15 / :31 carry a row's last lane into the next row / the upper half
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float ident, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int ident, int v) {
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, 0xf, 0xf, false);
+}
+constexpr int kRowShr = 0x110, kRowShl = 0x100, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+__device__ __forceinline__ float wave_min_f(float v) {  // all 64 lanes active; the result is uniform
+    v = fminf(v, dpp_f<kRowShr + 1>(kFltMax, v)), v = fminf(v, dpp_f<kRowShr + 2>(kFltMax, v));
+    v = fminf(v, dpp_f<kRowShr + 4>(kFltMax, v)), v = fminf(v, dpp_f<kRowShr + 8>(kFltMax, v));
+    v = fminf(v, dpp_f<kRowBcast15, 0xa>(kFltMax, v)), v = fminf(v, dpp_f<kRowBcast31, 0xc>(kFltMax, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    v = fmaxf(v, dpp_f<kRowShr + 1>(-kFltMax, v)), v = fmaxf(v, dpp_f<kRowShr + 2>(-kFltMax, v));
+    v = fmaxf(v, dpp_f<kRowShr + 4>(-kFltMax, v)), v = fmaxf(v, dpp_f<kRowShr + 8>(-kFltMax, v));
+    v = fmaxf(v, dpp_f<kRowBcast15, 0xa>(-kFltMax, v)), v = fmaxf(v, dpp_f<kRowBcast31, 0xc>(-kFltMax, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// inclusive scans over the lanes of a row, towards higher lanes (prefix) and towards lower lanes (suffix)
+#define ROW_SCAN(v, ident, OP, DIR)                                                               \
+    do {                                                                                          \
+        v = OP(v, dpp_f<DIR + 1>(ident, v)), v = OP(v, dpp_f<DIR + 2>(ident, v));                   \
+        v = OP(v, dpp_f<DIR + 4>(ident, v)), v = OP(v, dpp_f<DIR + 8>(ident, v));                   \
+    } while (0)
+__device__ __forceinline__ int row_scan_add(int v, bool prefix) {
+    if (prefix) {
+        v += dpp_i<kRowShr + 1>(0, v), v += dpp_i<kRowShr + 2>(0, v), v += dpp_i<kRowShr + 4>(0, v), v += dpp_i<kRowShr + 8>(0, v);
+    } else {
+        v += dpp_i<kRowShl + 1>(0, v), v += dpp_i<kRowShl + 2>(0, v), v += dpp_i<kRowShl + 4>(0, v), v += dpp_i<kRowShl + 8>(0, v);
+    }
     return v;
 }
 __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
-    __shared__ int refs[2][kUpMax];         // treelet numbers, ping-pong between a span and its two sides
-    __shared__ uint32_t q_seg[kUpMax];      // slot -> start | end << 13 | array << 26; 0 = not published yet
-    __shared__ int q_link[kUpMax];          // slot -> parent * 2 + which, -1 for the root span
-    __shared__ uint32_t bk[kUpThreads / 64][kUpBuckets][8];  // per wavefront: count, 3 min keys, 3 max keys
-    __shared__ float cost_s[kUpThreads / 64][kUpBuckets];
+    // 139 KB of the CU's 160 KB of LDS: the root boxes themselves (every pass over a span reads them), the two index arrays,
+    // the queue
     __shared__ int q_head, q_tail;
+    __shared__ uint32_t bk[kUpThreads / 64][kUpBuckets][8];  // per wavefront: count, 3 min keys, 3 max keys
+    __shared__ uint32_t q_seg[kUpMax];       // slot -> start | end << 13 | array << 26; 0 = not published yet
+    __shared__ uint16_t q_link[kUpMax];      // slot -> parent * 2 + which, 0xffff for the root span
+    __shared__ uint16_t refs[2][kUpMax];     // treelet numbers, ping-pong between a span and its two sides
+    __shared__ float bx[6][kUpMax];          // root boxes, one plane per coordinate; after the build: child sizes (below)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n_upper = n_t - 1;
     for (int i = tid; i < kUpMax; i += kUpThreads) {
-        refs[0][i] = i;
+        refs[0][i] = uint16_t(i);
         q_seg[i] = 0;
-        q_link[i] = -1;
+        q_link[i] = 0xffffu;
+        if (i < n_t) {
+            const Box b = U.roots[i];
+            for (int a = 0; a < 3; ++a) bx[a][i] = b.mn[a], bx[3 + a][i] = b.mx[a];
+        }
     }
     if (tid == 0) {
         q_head = 0;
@@ -369,30 +404,36 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
     if (tid == 0) q_seg[0] = 0u | (uint32_t(n_t) << 13);
     __syncthreads();
     volatile uint32_t *vseg = q_seg;
+    auto link_of = [&](int slot) { return q_link[slot] == 0xffffu ? -1 : int(q_link[slot]); };
     while (true) {
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&q_head, 1);
-        slot = __shfl(slot, 0);
+        // Everything that steers this loop is wave-uniform BY CONSTRUCTION: values come through readfirstlane, and what one
+        // lane would do (take a ticket, publish a span) every lane does with the same operands — the ticket counter is
+        // bumped by lane 0's operand alone. With `if (lane == 0)` at both ends of the loop body the compiler threaded lane 0's
+        // path from the publishing block into the next round's ticket and let lanes 1-63 run ahead without it: they read
+        // "ticket 0" from an inactive lane for ever.
+        const int slot = __builtin_amdgcn_readfirstlane(atomicAdd(&q_head, lane == 0 ? 1 : 0));
         if (slot >= n_upper) break;
         uint32_t seg;
         int spins = 0;
-        while ((seg = vseg[slot]) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+        while ((seg = uint32_t(__builtin_amdgcn_readfirstlane(int(vseg[slot])))) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
         if (seg == 0) {  // (never seen: n roots make exactly n - 1 spans) give up rather than hang
-            if (lane == 0) *U.err = 3;
+            *U.err = 3;
             break;
         }
+        if (seg == kSegDone) continue;  // its parent finished it
         __threadfence_block();
         const int s = int(seg & 8191u), e = int((seg >> 13) & 8191u), buf = int(seg >> 26);
-        const int *src = refs[buf];
-        int *dst = refs[buf ^ 1];
+        const int dbuf = buf ^ 1;  // (LDS arrays are indexed in place: a pointer to one of them would be a generic pointer, and
+                                   //  every access through it a flat instruction, several times an LDS instruction's latency)
         // bounds of the span and of its centroids (bvh.cpp:537-549)
         float bmn[3] = {kFltMax, kFltMax, kFltMax}, bmx[3] = {-kFltMax, -kFltMax, -kFltMax};
         float cmn[3] = {kFltMax, kFltMax, kFltMax}, cmx[3] = {-kFltMax, -kFltMax, -kFltMax};
         for (int i = s + lane; i < e; i += 64) {
-            const Box b = U.roots[src[i]];
+            const int t = refs[buf][i];
             for (int a = 0; a < 3; ++a) {
-                bmn[a] = fminf(bmn[a], b.mn[a]), bmx[a] = fmaxf(bmx[a], b.mx[a]);
-                const float c = (b.mn[a] + b.mx[a]) * 0.5f;
+                const float lo_a = bx[a][t], hi_a = bx[3 + a][t];
+                bmn[a] = fminf(bmn[a], lo_a), bmx[a] = fmaxf(bmx[a], hi_a);
+                const float c = (lo_a + hi_a) * 0.5f;
                 cmn[a] = fminf(cmn[a], c), cmx[a] = fmaxf(cmx[a], c);
             }
         }
@@ -401,13 +442,17 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
             cmn[a] = wave_min_f(cmn[a]), cmx[a] = wave_max_f(cmx[a]);
         }
         int dim;  // Bounds3::MaximumExtent, geometry.h:790-798
+        float lo, hi;
         {
             const float dx = cmx[0] - cmn[0], dy = cmx[1] - cmn[1], dz = cmx[2] - cmn[2];
-            dim = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);
+            dim = __builtin_amdgcn_readfirstlane((dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2));
+            lo = dim == 0 ? cmn[0] : (dim == 1 ? cmn[1] : cmn[2]);
+            hi = dim == 0 ? cmx[0] : (dim == 1 ? cmx[1] : cmx[2]);
+            lo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lo)));
+            hi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hi)));
         }
-        const float lo = cmn[dim], hi = cmx[dim];
-        auto bucket_of = [&](const Box &b) {  // bvh.cpp:576-582
-            const float centroid = (b.mn[dim] + b.mx[dim]) * 0.5f;
+        auto bucket_of = [&](int t) {  // bvh.cpp:576-582
+            const float centroid = (bx[dim][t] + bx[3 + dim][t]) * 0.5f;
             int k = int(kUpBuckets * ((centroid - lo) / (hi - lo)));
             if (k == kUpBuckets) k = kUpBuckets - 1;
             return k;
@@ -422,46 +467,53 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
             }
             __builtin_amdgcn_wave_barrier();
             for (int i = s + lane; i < e; i += 64) {
-                const Box b = U.roots[src[i]];
-                int k = bucket_of(b);
+                const int t = refs[buf][i];
+                int k = bucket_of(t);
                 k = k < 0 ? 0 : (k > kUpBuckets - 1 ? kUpBuckets - 1 : k);  // (the reference CHECKs 0 <= b < 12)
                 atomicAdd(&bk[w][k][0], 1u);
                 for (int a = 0; a < 3; ++a) {
-                    atomicMin(&bk[w][k][1 + a], order_key(b.mn[a]));
-                    atomicMax(&bk[w][k][4 + a], order_key(b.mx[a]));
+                    atomicMin(&bk[w][k][1 + a], order_key(bx[a][t]));
+                    atomicMax(&bk[w][k][4 + a], order_key(bx[3 + a][t]));
                 }
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            if (lane < kUpBuckets - 1) {  // bvh.cpp:588-602, one candidate split per lane
-                float mn0[3] = {kFltMax, kFltMax, kFltMax}, mx0[3] = {-kFltMax, -kFltMax, -kFltMax};
-                float mn1[3] = {kFltMax, kFltMax, kFltMax}, mx1[3] = {-kFltMax, -kFltMax, -kFltMax};
-                int c0 = 0, c1 = 0;
-                for (int j = 0; j < kUpBuckets; ++j) {
-                    const int cnt = int(bk[w][j][0]);
-                    float jm[3], jx[3];
-                    for (int a = 0; a < 3; ++a) jm[a] = key_float(bk[w][j][1 + a]), jx[a] = key_float(bk[w][j][4 + a]);
-                    if (j <= lane) {
-                        for (int a = 0; a < 3; ++a) mn0[a] = fminf(mn0[a], jm[a]), mx0[a] = fmaxf(mx0[a], jx[a]);
-                        c0 += cnt;
-                    } else {
-                        for (int a = 0; a < 3; ++a) mn1[a] = fminf(mn1[a], jm[a]), mx1[a] = fmaxf(mx1[a], jx[a]);
-                        c1 += cnt;
-                    }
+            // bvh.cpp:588-602. Bucket j sits in lane j (lanes 12-63: empty buckets); the union and count of buckets 0..i are a
+            // prefix scan over the lanes, those of buckets i+1..11 a suffix scan read one lane over; lane i < 11 prices split i.
+            // (min / max unions are exact in any order; the cost expression is the reference's, operation for operation.)
+            float cost;
+            int c_prefix;
+            {
+                const int j = lane < kUpBuckets ? lane : kUpBuckets - 1;
+                const bool real = lane < kUpBuckets;
+                const int cnt_j = real ? int(bk[w][j][0]) : 0;
+                float p_mn[3], p_mx[3], s_mn[3], s_mx[3];
+                for (int a = 0; a < 3; ++a) {
+                    p_mn[a] = real ? key_float(bk[w][j][1 + a]) : kFltMax;
+                    p_mx[a] = real ? key_float(bk[w][j][4 + a]) : -kFltMax;
+                    s_mn[a] = p_mn[a], s_mx[a] = p_mx[a];
+                    ROW_SCAN(p_mn[a], kFltMax, fminf, kRowShr);
+                    ROW_SCAN(p_mx[a], -kFltMax, fmaxf, kRowShr);
+                    ROW_SCAN(s_mn[a], kFltMax, fminf, kRowShl);
+                    ROW_SCAN(s_mx[a], -kFltMax, fmaxf, kRowShl);
+                    s_mn[a] = dpp_f<kRowShl + 1>(kFltMax, s_mn[a]);  // buckets lane+1 .. 11
+                    s_mx[a] = dpp_f<kRowShl + 1>(-kFltMax, s_mx[a]);
                 }
-                cost_s[w][lane] = .125f + (float(c0) * box_area(mn0, mx0) + float(c1) * box_area(mn1, mx1)) / box_area(bmn, bmx);
+                c_prefix = row_scan_add(cnt_j, true);
+                const int c1 = dpp_i<kRowShl + 1>(0, row_scan_add(cnt_j, false));
+                cost = .125f + (float(c_prefix) * box_area(p_mn, p_mx) + float(c1) * box_area(s_mn, s_mx)) / box_area(bmn, bmx);
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            float min_cost = cost_s[w][0];  // bvh.cpp:605-612: the first minimum; a NaN cost (an empty side) is never smaller
-            min_bucket = 0;
-            for (int i = 1; i < kUpBuckets - 1; ++i) {
-                const float c = cost_s[w][i];
-                if (c < min_cost) min_cost = c, min_bucket = i;
+            // bvh.cpp:605-612: minCost starts at cost[0] and moves to a later cost only if that is smaller — the first of the
+            // smallest; a NaN cost (0 x inf: a side without roots) is never smaller, and nothing is smaller than a NaN cost[0]
+            {
+                const bool cand = lane < kUpBuckets - 1;
+                const bool first_is_nan = __builtin_amdgcn_readfirstlane(cost != cost ? 1 : 0) != 0;
+                const float c = (cand && cost == cost) ? cost : __builtin_inff();
+                const float m = wave_min_f(c);
+                const unsigned long long at_min = __ballot(cand && cost == m);
+                min_bucket = (first_is_nan || at_min == 0) ? 0 : __builtin_ctzll(at_min);
             }
-            int cnt = 0;
-            for (int i = s + lane; i < e; i += 64) cnt += bucket_of(U.roots[src[i]]) <= min_bucket ? 1 : 0;
-            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            const int cnt = __builtin_amdgcn_readlane(c_prefix, min_bucket);  // roots in buckets 0 .. min_bucket
             if (cnt > 0 && cnt < e - s)
                 n_left = cnt;
             else
@@ -476,45 +528,61 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
                 int t = 0;
                 bool left = false;
                 if (in) {
-                    t = src[i];
-                    left = min_bucket >= 0 ? bucket_of(U.roots[t]) <= min_bucket : (i - s) < n_left;
+                    t = refs[buf][i];
+                    left = min_bucket >= 0 ? bucket_of(t) <= min_bucket : (i - s) < n_left;
                 }
                 const unsigned long long ml = __ballot(in && left), mr = __ballot(in && !left);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (in) {
                     if (left)
-                        dst[s + done_l + __popcll(ml & below)] = t;
+                        refs[dbuf][s + done_l + __popcll(ml & below)] = uint16_t(t);
                     else
-                        dst[mid + done_r + __popcll(mr & below)] = t;
+                        refs[dbuf][mid + done_r + __popcll(mr & below)] = uint16_t(t);
                 }
                 done_l += __popcll(ml), done_r += __popcll(mr);
             }
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        if (lane == 0) {
-            U.axis[slot] = dim;
-            U.parent[slot] = q_link[slot];
-            for (int which = 0; which < 2; ++which) {
-                const int cs = which ? mid : s, ce = which ? e : mid;
-                if (ce - cs == 1) {
-                    U.tparent[dst[cs]] = slot * 2 + which;
-                } else {
-                    const int child = atomicAdd(&q_tail, 1);
-                    if (child >= n_upper) {
-                        *U.err = 2;
-                    } else {
-                        q_link[child] = slot * 2 + which;
-                        __threadfence_block();
-                        vseg[child] = uint32_t(cs) | (uint32_t(ce) << 13) | (uint32_t(buf ^ 1) << 26);
+        U.axis[slot] = dim;
+        for (int which = 0; which < 2; ++which) {
+            const int cs = which ? mid : s, ce = which ? e : mid;
+            if (ce - cs == 1) {  // (uniform)
+                U.tparent[refs[dbuf][cs]] = slot * 2 + which;
+            } else {
+                const int child = __builtin_amdgcn_readfirstlane(atomicAdd(&q_tail, lane == 0 ? 1 : 0));
+                if (child >= n_upper) {
+                    *U.err = 2;
+                } else if (ce - cs == 2) {
+                    // A span of two roots needs no pricing: the centroid span runs from one to the other, so one falls into
+                    // bucket 0, the other into bucket 11, every split costs the same and the first (after bucket 0) is taken:
+                    // the root at the low end goes left. Finished here, published as done (a third of all spans).
+                    const int t0 = refs[dbuf][cs], t1 = refs[dbuf][cs + 1];
+                    float c0[3], c1[3], ext[3];
+                    for (int a = 0; a < 3; ++a) {
+                        c0[a] = (bx[a][t0] + bx[3 + a][t0]) * 0.5f, c1[a] = (bx[a][t1] + bx[3 + a][t1]) * 0.5f;
+                        ext[a] = fmaxf(c0[a], c1[a]) - fminf(c0[a], c1[a]);
                     }
+                    const int cdim = (ext[0] > ext[1] && ext[0] > ext[2]) ? 0 : (ext[1] > ext[2] ? 1 : 2);
+                    const float a0 = cdim == 0 ? c0[0] : (cdim == 1 ? c0[1] : c0[2]), a1 = cdim == 0 ? c1[0] : (cdim == 1 ? c1[1] : c1[2]);
+                    const bool swap = a1 < a0;  // (equal centroids: array order, the middle cut)
+                    U.tparent[swap ? t1 : t0] = child * 2;
+                    U.tparent[swap ? t0 : t1] = child * 2 + 1;
+                    U.axis[child] = cdim;
+                    q_link[child] = uint16_t(slot * 2 + which);
+                    __threadfence_block();
+                    vseg[child] = kSegDone;
+                } else {
+                    q_link[child] = uint16_t(slot * 2 + which);
+                    __threadfence_block();
+                    vseg[child] = uint32_t(cs) | (uint32_t(ce) << 13) | (uint32_t(dbuf) << 26);
                 }
             }
         }
     }
     __syncthreads();
-    // sizes and boxes climb from the treelets; refs[] is free now: child sizes in refs[0] / refs[1], arrivals in q_seg
-    int *size0 = refs[0], *size1 = refs[1];
+    // sizes and boxes climb from the treelets. The box planes are free now: child sizes in bx[0] / bx[1], arrivals in q_seg
+    int *size0 = reinterpret_cast<int *>(bx[0]), *size1 = reinterpret_cast<int *>(bx[1]);
     for (int i = tid; i < kUpMax; i += kUpThreads) q_seg[i] = 0;
     __syncthreads();
     for (int t = tid; t < n_t; t += kUpThreads) {
@@ -532,19 +600,19 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
             for (int a = 0; a < 3; ++a) box.mn[a] = union_min(b0.mn[a], b1.mn[a]), box.mx[a] = union_max(b0.mx[a], b1.mx[a]);
             size = 1 + ((volatile int *)size0)[node] + ((volatile int *)size1)[node];
             U.cbox[2 * n_upper + node] = box;  // the node's own box (read again below, after the barrier)
-            link = q_link[node];
+            link = link_of(node);
         }
     }
     __syncthreads();
     // preorder offsets: 1 per ancestor, plus the first child's subtree wherever the path goes through a second child
     for (int i = tid; i < n_upper + n_t; i += kUpThreads) {
         const bool is_node = i < n_upper;
-        int link = is_node ? q_link[i] : U.tparent[i - n_upper];
+        int link = is_node ? link_of(i) : U.tparent[i - n_upper];
         int off = 0;
         while (link >= 0) {
             const int p = link >> 1;
             off += 1 + ((link & 1) ? size0[p] : 0);
-            link = q_link[p];
+            link = link_of(p);
         }
         if (is_node) {
             iile_bvh_node nd;
@@ -853,6 +921,21 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     HIP_TRYB(incl.alloc(size_t(n)));
     HIP_TRYB(starts.alloc(size_t(n) + 1));
     HIP_TRYB(pool.alloc(2 * size_t(n)));
+    // (everything is allocated before the first kernel: a hipMalloc between two stages costs more than the upper tree's kernel)
+    Dev<Box> d_roots, d_cbox;
+    Dev<int> up_tparent, up_axis;
+    HIP_TRYB(d_roots.alloc(size_t(kUpMax)));
+    HIP_TRYB(d_cbox.alloc(3 * size_t(kUpMax)));
+    HIP_TRYB(up_axis.alloc(size_t(kUpMax)));
+    HIP_TRYB(up_tparent.alloc(size_t(kUpMax)));
+    HIP_TRYB(out.alloc(2 * size_t(n)));  // 2 n - 1 nodes at most (one primitive per leaf)
+    Dev<int> arena;  // emitLBVH's eleven int arrays of n (+ 1) entries in one allocation
+    const size_t stride = (size_t(n) + 1 + 63) & ~size_t(63);
+    HIP_TRYB(arena.alloc(11 * stride));
+    HIP_TRYB(n_nodes_t.alloc(size_t(kUpMax)));
+    HIP_TRYB(base.alloc(size_t(kUpMax)));
+    Dev<int> err_flag;
+    HIP_TRYB(err_flag.alloc(1));
     HIP_TRYB(hipMemcpyAsync(d_bounds.p, bounds6, 6 * size_t(n) * sizeof(float), hipMemcpyHostToDevice, s));
     const uint32_t key_init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     HIP_TRYB(hipMemcpyAsync(keys6.p, key_init, sizeof(key_init), hipMemcpyHostToDevice, s));
@@ -873,19 +956,10 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
         HIP_TRYB(hipStreamSynchronize(s));
     }
     hipLaunchKernelGGL(k_treelet_starts, dim3(grid_for(n)), dim3(kBB), 0, s, n, flags.p, incl.p, starts.p);
-    int n_treelets = 0;
-    HIP_TRYB(hipMemcpyAsync(&n_treelets, incl.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRYB(hipStreamSynchronize(s));
-    HIP_TRYB(n_nodes_t.alloc(size_t(n_treelets)));
-    HIP_TRYB(base.alloc(size_t(n_treelets)));
-    Dev<int> err_flag;
-    HIP_TRYB(err_flag.alloc(1));
+    int n_treelets = 0;  // runs of equal top 12 bits: at most 4096 (read back with the split count below)
     HIP_TRYB(hipMemsetAsync(err_flag.p, 0, sizeof(int), s));
     int n_splits = 0, h_err = 0;
     {
-        Dev<int> arena;  // eleven int arrays of n (+ 1) entries in one allocation
-        const size_t stride = (size_t(n) + 1 + 63) & ~size_t(63);
-        HIP_TRYB(arena.alloc(11 * stride));
         int *ap[11];
         for (int k = 0; k < 11; ++k) ap[k] = arena.p + size_t(k) * stride;
         int *const aEnds = ap[7], *const aPE = ap[8], *const aI = ap[3], *const aF = ap[4];
@@ -903,6 +977,7 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
         HIP_TRYB(hipGetLastError());
         HIP_TRYB(hipMemcpyAsync(&n_splits, aF + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRYB(hipMemcpyAsync(&h_err, err_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRYB(hipMemcpyAsync(&n_treelets, incl.p + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRYB(hipStreamSynchronize(s));
     }
     if (h_err) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: a leaf holds more than 65535 primitives (equal Morton codes)");
@@ -912,18 +987,10 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     // n_nodes_t nodes, the upper tree adds n_treelets - 1
     const int n_upper = n_treelets - 1;
     const int n_nodes = 2 * n_splits + 2 * n_treelets - 1;
-    Dev<Box> d_roots, d_cbox;
-    Dev<int> up_parent, up_tparent, up_axis;
-    HIP_TRYB(d_roots.alloc(size_t(n_treelets)));
-    HIP_TRYB(d_cbox.alloc(3 * size_t(std::max(n_upper, 1))));
-    HIP_TRYB(up_parent.alloc(size_t(std::max(n_upper, 1))));
-    HIP_TRYB(up_axis.alloc(size_t(std::max(n_upper, 1))));
-    HIP_TRYB(up_tparent.alloc(size_t(n_treelets)));
-    HIP_TRYB(out.alloc(size_t(n_nodes)));
     HIP_TRYB(hipMemsetAsync(up_tparent.p, 0xff, size_t(n_treelets) * sizeof(int), s));  // -1: the treelet is the whole tree
     hipLaunchKernelGGL(k_treelet_roots, dim3((n_treelets + kBB - 1) / kBB), dim3(kBB), 0, s, n_treelets, starts.p, pool.p, d_roots.p);
     {
-        UpperDev U{d_roots.p, n_nodes_t.p, up_parent.p, up_tparent.p, up_axis.p, d_cbox.p, base.p, out.p, err_flag.p};
+        UpperDev U{d_roots.p, n_nodes_t.p, up_tparent.p, up_axis.p, d_cbox.p, base.p, out.p, err_flag.p};
         hipLaunchKernelGGL(k_upper_sah, dim3(1), dim3(kUpThreads), 0, s, n_treelets, U);
     }
     HIP_TRYB(hipEventRecord(ev[4], s));
