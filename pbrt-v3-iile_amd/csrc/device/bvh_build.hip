@@ -607,10 +607,19 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
             const int node = link >> 1, which = link & 1;
             (which ? size1 : size0)[node] = size;
             U.cbox[2 * node + which] = box;
-            __threadfence();
+            // Both children's threads run in this block, on this CU: the stores are complete (in L2) once the wave has waited
+            // for them, which a workgroup-scope fence does, and the reader loads past L1 (agent-scope relaxed loads: `sc1`).
+            // A device-scope fence pair here is an L2 write-back and an L1 invalidate per step, ~3.5 us each on gfx950.
+            __threadfence_block();
             if (atomicAdd(&q_seg[node], 1u) == 0u) break;  // the other child finishes this node
-            __threadfence();
-            const Box b0 = U.cbox[2 * node], b1 = U.cbox[2 * node + 1];  // InitInterior: Union(c0, c1), bvh.cpp:66-72
+            __threadfence_block();
+            Box b0, b1;  // InitInterior: Union(c0, c1), bvh.cpp:66-72
+            for (int a = 0; a < 3; ++a) {
+                b0.mn[a] = __hip_atomic_load(&U.cbox[2 * node].mn[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b0.mx[a] = __hip_atomic_load(&U.cbox[2 * node].mx[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b1.mn[a] = __hip_atomic_load(&U.cbox[2 * node + 1].mn[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b1.mx[a] = __hip_atomic_load(&U.cbox[2 * node + 1].mx[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             for (int a = 0; a < 3; ++a) box.mn[a] = union_min(b0.mn[a], b1.mn[a]), box.mx[a] = union_max(b0.mx[a], b1.mx[a]);
             size = 1 + ((volatile int *)size0)[node] + ((volatile int *)size1)[node];
             U.cbox[2 * n_upper + node] = box;  // the node's own box (read again below, after the barrier)
