@@ -176,11 +176,20 @@ int iile_render_direct(iile_scene *scene, const iile_direct_params *params, doub
  *                           (:142-178) over the four neighbouring predicted hemispheres. nn_films: per hemi point (valid or
  *                           not) hemi x hemi RGB, row 0 the top scanline as the network emits it (device memory when
  *                           nn_on_device); out_rgbw: per film pixel of the task, row-major, {f_beta * L, weight} as handed
- *                           to IisptFilmMonitor::add_n_samples (zeros where the runner records nothing).
+ *                           to IisptFilmMonitor::add_n_samples (zeros where the runner records nothing). With
+ *                           out_on_device the call returns once its kernels are queued on the null stream (use the output
+ *                           on that stream, or synchronise); with a host output it returns when the pixels are there.
+ * Both keep their device buffers in the scene (grown on demand), so a frame's hundreds of calls allocate nothing.
  * Needs the scene's Halton sampler (the runner clones the scene's sampler) and probe setup. */
 int iile_iispt_hemi_points(iile_scene *scene, const iile_iispt_task *task, uint8_t *valid, float *pos3, float *dir3);
 int iile_iispt_gather(iile_scene *scene, const iile_iispt_task *task, const uint8_t *valid, const float *pos3, const float *dir3,
                       const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device);
+/* The same for n_tasks tasks in one set of launches (a 100 x 100-pixel task alone fills a sixth of the chip): every array is
+ * the per-task arrays of the single-task calls, task after task — hemi points (valid, pos3, dir3, nn_films) in the tasks'
+ * own row-by-row order, film pixels (out_rgbw) row-major per task. Results are those of the single-task calls, bit for bit. */
+int iile_iispt_hemi_points_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, uint8_t *valid, float *pos3, float *dir3);
+int iile_iispt_gather_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, const uint8_t *valid, const float *pos3,
+                            const float *dir3, const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device);
 /* BVHAccel's HLBVH build (src/accelerators/bvh.cpp:404-472: Morton codes :413-427, RadixSort :133-181, treelets and
  * emitLBVH :434-452, 555-618, buildUpperSAH :474-553) and flattenBVHTree (:640-658) — SURVEY.md §8 f4. bounds6: per
  * primitive WorldBound() as {min xyz, max xyz} (host memory); nodes_out: room for 2 * n_prims nodes; order_out[i] = the

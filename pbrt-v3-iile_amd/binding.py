@@ -120,7 +120,7 @@ GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iil
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
                "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download",
-               "iile_iispt_hemi_points", "iile_iispt_gather", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct",
+               "iile_iispt_hemi_points", "iile_iispt_gather", "iile_iispt_hemi_points_batch", "iile_iispt_gather_batch", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct",
                "iile_wide_ref_shift"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size", "iile_dist_ranks_seen",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
@@ -233,6 +233,8 @@ def gpu_lib():
         lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
         lib.iile_iispt_hemi_points.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_vp, c_vp, c_vp]
         lib.iile_iispt_gather.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32]
+        lib.iile_iispt_hemi_points_batch.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_vp]
+        lib.iile_iispt_gather_batch.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32]
         lib.iile_bvh_build_hlbvh.argtypes = [c_i32, c_vp, c_i32, c_vp, ctypes.POINTER(c_i32), c_vp, ctypes.POINTER(BvhBuildStats)]
         lib.iile_bvh_pack_probe.argtypes = [c_i32, c_vp, c_i32, c_vp, c_vp, ctypes.POINTER(c_i32)]
         _gpu = lib
@@ -563,6 +565,31 @@ class GpuScene:
                                                 nn.ctypes.data if nn is not None else c_vp(int(nn_device_ptr)), int(nn is None),
                                                 out.ctypes.data if out is not None else c_vp(int(out_device_ptr)), int(out is None)),
                     "iile_iispt_gather")
+        return out
+
+    def iispt_hemi_points_batch(self, tasks):
+        """iile_iispt_hemi_points_batch: the hemi points of several tasks from one set of launches — (valid (n,), origins (n, 3),
+        directions (n, 3)) with the tasks' hemi points one task after the other, each in its own row-by-row order."""
+        arr = (IisptTask * len(tasks))(*tasks)
+        n = sum(t.grid()[0] * t.grid()[1] for t in tasks)
+        valid, pos, dr = np.zeros(n, np.uint8), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        self._check(gpu_lib().iile_iispt_hemi_points_batch(self._s, arr, len(tasks), valid.ctypes.data, pos.ctypes.data, dr.ctypes.data),
+                    "iile_iispt_hemi_points_batch")
+        return valid, pos, dr
+
+    def iispt_gather_batch(self, tasks, valid, pos, direction, nn_films=None, nn_device_ptr=None, out_device_ptr=None):
+        """iile_iispt_gather_batch: the per-pixel loop of several tasks from one set of launches. valid / pos / direction / nn_films
+        (n_hemi, 32, 32, 3) as iispt_hemi_points_batch orders them; the result is (n_pixels, 4), the tasks' pixels one task after the
+        other, row-major inside a task (None when written to out_device_ptr)."""
+        arr = (IisptTask * len(tasks))(*tasks)
+        valid, pos, direction = np.ascontiguousarray(valid, np.uint8), _f32(pos), _f32(direction)
+        n_pix = sum((t.x1 - t.x0) * (t.y1 - t.y0) for t in tasks)
+        out = None if out_device_ptr is not None else np.zeros((n_pix, 4), np.float32)
+        nn = _f32(nn_films) if nn_device_ptr is None else None
+        self._check(gpu_lib().iile_iispt_gather_batch(self._s, arr, len(tasks), valid.ctypes.data, pos.ctypes.data, direction.ctypes.data,
+                                                      nn.ctypes.data if nn is not None else c_vp(int(nn_device_ptr)), int(nn is None),
+                                                      out.ctypes.data if out is not None else c_vp(int(out_device_ptr)), int(out is None)),
+                    "iile_iispt_gather_batch")
         return out
 
     def render_direct(self, n_passes, first_pass=0, film_device_ptr=None, accumulate=False, stream=None):

@@ -2094,53 +2094,92 @@ int iispt_check(iile_scene *sc, const iile_iispt_task *t, int *nx, int *ny) {
 }  // namespace
 
 namespace {
-// the items of a task in HBM: hemi points first, then (with_pixels) the film pixels
-struct ItemBuffers {
-    DevBuf<float4> planes;
-    DevBuf<uint32_t> words;
-    IisptItems I;
-    int make(int n_hemi, int n_pix, int nx) {
-        const size_t n = size_t(n_hemi) + size_t(n_pix);
-        int rc;
-        if ((rc = planes.alloc(5 * n)) || (rc = words.alloc(n + 64))) return rc;
-        I.ro = planes.p, I.rd = planes.p + n, I.beta = planes.p + 2 * n, I.hit = planes.p + 3 * n, I.pf = planes.p + 4 * n;
-        I.idx = words.p + 64;
-        I.n_active = words.p;
-        I.n_items = int(n), I.n_hemi = n_hemi, I.nx = nx;
-        return IILE_OK;
-    }
-};
-}  // namespace
+// The items of a task in HBM: hemi points first, then (with_pixels) the film pixels. Everything a call needs on the device is
+// carved from the scene's scratch block (grown on demand, kept): the runner makes hundreds of calls per frame.
+size_t carve_bytes(size_t n, size_t elem) { return (std::max<size_t>(n, 1) * elem + 255) & ~size_t(255); }
+constexpr int kIisptMaxJobs = 1024;  // tasks per launch (blockIdx.y); longer batches run in slices
 
-int iile_iispt_hemi_points(iile_scene *sc, const iile_iispt_task *t, uint8_t *valid, float *pos3, float *dir3) {
-    int nx = 0, ny = 0;
-    int rc = iispt_check(sc, t, &nx, &ny);
+// A slice of a batch laid out in the scratch block: per task its items (five float4 planes and the Halton indices, task after
+// task), the job array the kernels read, one counter of items still on a specular chain.
+struct IisptSlice {
+    std::vector<IisptJob> jobs;
+    std::vector<size_t> hemi_off, pix_off;  // per task: first hemi point / first film pixel of the slice's concatenated arrays
+    size_t n_hemi = 0, n_pix = 0, n_items = 0;
+    int max_items = 0, max_hemi = 0, max_pix = 0;
+    IisptJob *d_jobs = nullptr;
+    uint32_t *n_active = nullptr;
+};
+int plan_slice(iile_scene *sc, const iile_iispt_task *tasks, int n_tasks, bool with_pixels, IisptSlice *sl) {
+    sl->jobs.resize(size_t(n_tasks));
+    sl->hemi_off.resize(size_t(n_tasks));
+    sl->pix_off.resize(size_t(n_tasks));
+    for (int k = 0; k < n_tasks; ++k) {
+        int nx = 0, ny = 0;
+        const int rc = iispt_check(sc, &tasks[k], &nx, &ny);
+        if (rc) return rc;
+        IisptJob &J = sl->jobs[size_t(k)];
+        std::memset(&J, 0, sizeof(J));
+        J.T = tasks[k];
+        J.ny = ny;
+        const size_t nh = size_t(nx) * ny, np = with_pixels ? size_t(tasks[k].x1 - tasks[k].x0) * size_t(tasks[k].y1 - tasks[k].y0) : 0;
+        J.I.n_hemi = int(nh), J.I.n_items = int(nh + np), J.I.nx = nx;
+        sl->hemi_off[size_t(k)] = sl->n_hemi, sl->pix_off[size_t(k)] = sl->n_pix;
+        sl->n_hemi += nh, sl->n_pix += np, sl->n_items += nh + np;
+        sl->max_items = std::max(sl->max_items, int(nh + np)), sl->max_hemi = std::max(sl->max_hemi, int(nh)), sl->max_pix = std::max(sl->max_pix, int(np));
+    }
+    if (sl->n_items >= 0x7fffffffull) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: more than 2^31 items in one slice of a batch");
+    return IILE_OK;
+}
+size_t slice_item_bytes(const IisptSlice &sl) {
+    return carve_bytes(5 * sl.n_items, sizeof(float4)) + carve_bytes(sl.n_items + 64, sizeof(uint32_t)) + carve_bytes(sl.jobs.size(), sizeof(IisptJob));
+}
+// carve the item planes and point every job at its part (after scratch_reserve)
+void carve_slice(iile_scene *sc, IisptSlice *sl) {
+    float4 *planes = scratch_take<float4>(sc, 5 * sl->n_items);
+    uint32_t *words = scratch_take<uint32_t>(sc, sl->n_items + 64);
+    sl->d_jobs = scratch_take<IisptJob>(sc, sl->jobs.size());
+    sl->n_active = words;
+    size_t first = 0;
+    for (IisptJob &J : sl->jobs) {
+        const size_t n = sl->n_items;
+        J.I.ro = planes + first, J.I.rd = planes + n + first, J.I.beta = planes + 2 * n + first, J.I.hit = planes + 3 * n + first, J.I.pf = planes + 4 * n + first;
+        J.I.idx = words + 64 + first;
+        J.I.n_active = words;
+        first += size_t(J.I.n_items);
+    }
+}
+
+int hemi_points_slice(iile_scene *sc, const iile_iispt_task *tasks, int n_tasks, uint8_t *valid, float *pos3, float *dir3) {
+    IisptSlice sl;
+    int rc = plan_slice(sc, tasks, n_tasks, false, &sl);
     if (rc) return rc;
-    if (!valid || !pos3 || !dir3) return fail(IILE_ERR_ARG, "iile_iispt_hemi_points: null output");
-    const size_t n = size_t(nx) * ny;
-    DevBuf<uint8_t> dv;
-    DevBuf<float> dp, dd;
-    ItemBuffers items;
-    if ((rc = dv.alloc(n)) || (rc = dp.alloc(3 * n)) || (rc = dd.alloc(3 * n)) || (rc = items.make(int(n), 0, nx))) return rc;
+    const size_t n = sl.n_hemi;
+    if ((rc = scratch_reserve(sc, slice_item_bytes(sl) + carve_bytes(n, 1) + 2 * carve_bytes(3 * n, sizeof(float)), nullptr))) return rc;
+    carve_slice(sc, &sl);
+    uint8_t *dv = scratch_take<uint8_t>(sc, n);
+    float *dp = scratch_take<float>(sc, 3 * n), *dd = scratch_take<float>(sc, 3 * n);
+    for (size_t k = 0; k < sl.jobs.size(); ++k)
+        sl.jobs[k].valid = dv + sl.hemi_off[k], sl.jobs[k].pos3 = dp + 3 * sl.hemi_off[k], sl.jobs[k].dir3 = dd + 3 * sl.hemi_off[k];
+    // (synchronous copies on the null stream: each follows whatever used the block last, and the kernels before it)
+    HIP_TRY(hipMemcpy(sl.d_jobs, sl.jobs.data(), sl.jobs.size() * sizeof(IisptJob), hipMemcpyHostToDevice));
     DScene S = sc->ds;
     S.diff_scale = 1.f;  // r.ScaleDifferentials(1.0), iisptrenderrunner.cpp:272
     LaunchCfg cfg{sc->n_cus, nullptr, false};
-    uint32_t active = 0;
-    launch_iispt_first_hits(S, *t, items.I, sc->spill, &active, cfg);
-    launch_iispt_hemi_out(S, items.I, dv.p, dp.p, dd.p, cfg);
+    launch_iispt_first_hits(S, sl.d_jobs, n_tasks, sl.max_items, sl.n_active, sc->spill, cfg);
+    launch_iispt_hemi_out(S, sl.d_jobs, n_tasks, sl.max_hemi, cfg);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    if ((rc = dv.get(valid, n)) || (rc = dp.get(pos3, 3 * n)) || (rc = dd.get(dir3, 3 * n))) return rc;
+    HIP_TRY(hipMemcpy(valid, dv, n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos3, dp, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dir3, dd, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
     return IILE_OK;
 }
 
-int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *valid, const float *pos3, const float *dir3, const float *nn_films,
-                      int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
-    int nx = 0, ny = 0;
-    int rc = iispt_check(sc, t, &nx, &ny);
+int gather_slice(iile_scene *sc, const iile_iispt_task *tasks, int n_tasks, const uint8_t *valid, const float *pos3, const float *dir3,
+                 const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
+    IisptSlice sl;
+    int rc = plan_slice(sc, tasks, n_tasks, true, &sl);
     if (rc) return rc;
-    if (!valid || !pos3 || !dir3 || !nn_films || !out_rgbw) return fail(IILE_ERR_ARG, "iile_iispt_gather: null argument");
-    const size_t n = size_t(nx) * ny, n_pix = size_t(t->x1 - t->x0) * size_t(t->y1 - t->y0);
+    const size_t n = sl.n_hemi, n_pix = sl.n_pix;
     const int hemi = sc->probe.hemi_size;
     // the hemi points' cameras: CreateHemisphericCamera (hemispheric.cpp:109-160) — CameraToWorld from LookAt, WorldToCamera
     // its numerical inverse, the look direction and origin as given
@@ -2152,7 +2191,7 @@ int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *v
         DProbeCam pc;
         float inv[16];
         if (!make_probe_camera(pos3 + 3 * k, dir3 + 3 * k, &pc) || !invert4(pc.c2w.m, inv))
-            return fail(IILE_ERR_ARG, "iile_iispt_gather: degenerate hemi point direction (hemi point " + std::to_string(k) + ")");
+            return fail(IILE_ERR_ARG, "iile_iispt_gather: degenerate hemi point direction (hemi point " + std::to_string(k) + " of the slice)");
         hc.c2w = pc.c2w;
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) hc.w2c[3 * r + c] = inv[4 * r + c];
@@ -2165,31 +2204,77 @@ int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *v
         const float polar_vertical_value = float(M_PI * abs_vertical_value);
         jac[size_t(y)] = std::sin(polar_vertical_value);  // sin(Float): the float overload (sinf), as in the reference
     }
-    DevBuf<DHemiCam> dc;
-    DevBuf<float> dj, dnn;
-    DevBuf<float4> dout;
-    ItemBuffers items;
-    if ((rc = dc.put(cams.data(), n)) || (rc = dj.put(jac.data(), jac.size())) || (rc = items.make(int(n), int(n_pix), nx))) return rc;
+    const size_t per_hemi = size_t(hemi) * hemi * 3, nn_floats = n * per_hemi;
+    if ((rc = scratch_reserve(sc, slice_item_bytes(sl) + carve_bytes(n, sizeof(DHemiCam)) + carve_bytes(jac.size(), sizeof(float)) +
+                                      (nn_on_device ? 0 : carve_bytes(nn_floats, sizeof(float))) + (out_on_device ? 0 : carve_bytes(n_pix, sizeof(float4))),
+                              nullptr)))
+        return rc;
+    carve_slice(sc, &sl);
+    DHemiCam *dc = scratch_take<DHemiCam>(sc, n);
+    float *dj = scratch_take<float>(sc, jac.size());
     const float *nn_dev = nn_films;
-    if (!nn_on_device) {
-        if ((rc = dnn.put(nn_films, n * size_t(hemi) * hemi * 3))) return rc;
-        nn_dev = dnn.p;
-    }
+    float *dnn = nullptr;
+    if (!nn_on_device) nn_dev = dnn = scratch_take<float>(sc, nn_floats);
     float4 *out_dev = reinterpret_cast<float4 *>(out_rgbw);
-    if (!out_on_device) {
-        if ((rc = dout.alloc(n_pix))) return rc;
-        out_dev = dout.p;
-    }
+    if (!out_on_device) out_dev = scratch_take<float4>(sc, n_pix);
+    for (size_t k = 0; k < sl.jobs.size(); ++k)
+        sl.jobs[k].cams = dc + sl.hemi_off[k], sl.jobs[k].nn_films = nn_dev + sl.hemi_off[k] * per_hemi, sl.jobs[k].out = out_dev + sl.pix_off[k];
+    // (synchronous copies from these short-lived host vectors; on the null stream they also follow whatever used the block last)
+    HIP_TRY(hipMemcpy(sl.d_jobs, sl.jobs.data(), sl.jobs.size() * sizeof(IisptJob), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dc, cams.data(), n * sizeof(DHemiCam), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dj, jac.data(), jac.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (dnn) HIP_TRY(hipMemcpy(dnn, nn_films, nn_floats * sizeof(float), hipMemcpyHostToDevice));
     DScene S = sc->ds;
     S.diff_scale = 1.f;
     LaunchCfg cfg{sc->n_cus, nullptr, false};
-    uint32_t active = 0;
-    launch_iispt_first_hits(S, *t, items.I, sc->spill, &active, cfg);
-    launch_iispt_gather(S, *t, items.I, ny, dc.p, nn_dev, dj.p, out_dev, cfg);
+    launch_iispt_first_hits(S, sl.d_jobs, n_tasks, sl.max_items, sl.n_active, sc->spill, cfg);
+    launch_iispt_gather(S, sl.d_jobs, n_tasks, sl.max_pix, dj, cfg);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    if (!out_on_device && (rc = dout.get(reinterpret_cast<float4 *>(out_rgbw), n_pix))) return rc;
+    // Results on the device: the kernels are in the null stream's order and the call returns (the caller's next use of the
+    // output, on that stream or one that synchronises with it, follows them). Results for the host: the copy waits.
+    if (!out_on_device) HIP_TRY(hipMemcpy(out_rgbw, out_dev, n_pix * sizeof(float4), hipMemcpyDeviceToHost));
     return IILE_OK;
+}
+}  // namespace
+
+int iile_iispt_hemi_points_batch(iile_scene *sc, const iile_iispt_task *tasks, int32_t n_tasks, uint8_t *valid, float *pos3, float *dir3) {
+    if (!sc || !tasks || n_tasks < 1) return fail(IILE_ERR_ARG, "iile_iispt_hemi_points: no task");
+    if (!valid || !pos3 || !dir3) return fail(IILE_ERR_ARG, "iile_iispt_hemi_points: null output");
+    size_t first = 0;
+    for (int k0 = 0; k0 < n_tasks; k0 += kIisptMaxJobs) {
+        const int nk = std::min(kIisptMaxJobs, n_tasks - k0);
+        const int rc = hemi_points_slice(sc, tasks + k0, nk, valid + first, pos3 + 3 * first, dir3 + 3 * first);
+        if (rc) return rc;
+        for (int k = k0; k < k0 + nk; ++k)
+            first += size_t(iile_iispt_grid_count(tasks[k].x0, tasks[k].x1, tasks[k].tilesize)) * size_t(iile_iispt_grid_count(tasks[k].y0, tasks[k].y1, tasks[k].tilesize));
+    }
+    return IILE_OK;
+}
+int iile_iispt_hemi_points(iile_scene *sc, const iile_iispt_task *t, uint8_t *valid, float *pos3, float *dir3) {
+    return iile_iispt_hemi_points_batch(sc, t, 1, valid, pos3, dir3);
+}
+
+int iile_iispt_gather_batch(iile_scene *sc, const iile_iispt_task *tasks, int32_t n_tasks, const uint8_t *valid, const float *pos3, const float *dir3,
+                            const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
+    if (!sc || !tasks || n_tasks < 1) return fail(IILE_ERR_ARG, "iile_iispt_gather: no task");
+    if (!valid || !pos3 || !dir3 || !nn_films || !out_rgbw) return fail(IILE_ERR_ARG, "iile_iispt_gather: null argument");
+    const size_t per_hemi = size_t(sc->probe.hemi_size) * sc->probe.hemi_size * 3;
+    size_t first_h = 0, first_p = 0;
+    for (int k0 = 0; k0 < n_tasks; k0 += kIisptMaxJobs) {
+        const int nk = std::min(kIisptMaxJobs, n_tasks - k0);
+        const int rc = gather_slice(sc, tasks + k0, nk, valid + first_h, pos3 + 3 * first_h, dir3 + 3 * first_h, nn_films + first_h * per_hemi, nn_on_device,
+                                    out_rgbw + 4 * first_p, out_on_device);
+        if (rc) return rc;
+        for (int k = k0; k < k0 + nk; ++k) {
+            first_h += size_t(iile_iispt_grid_count(tasks[k].x0, tasks[k].x1, tasks[k].tilesize)) * size_t(iile_iispt_grid_count(tasks[k].y0, tasks[k].y1, tasks[k].tilesize));
+            first_p += size_t(tasks[k].x1 - tasks[k].x0) * size_t(tasks[k].y1 - tasks[k].y0);
+        }
+    }
+    return IILE_OK;
+}
+int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *valid, const float *pos3, const float *dir3, const float *nn_films,
+                      int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
+    return iile_iispt_gather_batch(sc, t, 1, valid, pos3, dir3, nn_films, nn_on_device, out_rgbw, out_on_device);
 }
 
 // ---- kernel-level entry points ---------------------------------------------

@@ -103,7 +103,11 @@ DEV void vertex_state(const DScene &S, const float4 o4, const float4 d4, const f
 // Per-item records (IisptItems, kernels.h; float4 planes of n_items each, api.hip allocates them):
 //   ro = (ray o, tMax)   rd = (ray d, bitcast {state | bounce << 8 | sampler dimension << 16})   beta = (rgb, -)
 //   hit = (bitcast prim, b0, b1, b2)   pf = (pFilm.xy, lens u)   idx[] = Halton index of the item's camera sample
-__global__ __launch_bounds__(kIisptBlock) void k_iispt_begin(DScene S, iile_iispt_task T, IisptItems I) {
+// Every kernel runs all tasks of a batch at once: blockIdx.y is the task (its IisptJob is read from HBM, uniform loads),
+// blockIdx.x strides over that task's items. A frame's tasks are 100 x 100 pixels: alone, one fills a sixth of the chip.
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_begin(DScene S, const IisptJob *jobs) {
+    const iile_iispt_task T = jobs[blockIdx.y].T;
+    const IisptItems I = jobs[blockIdx.y].I;
     for (int item = blockIdx.x * kIisptBlock + threadIdx.x; item < I.n_items; item += gridDim.x * kIisptBlock) {
         int fx, fy;
         item_pixel(T, I.nx, I.n_hemi, item, &fx, &fy);
@@ -128,11 +132,12 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_begin(DScene S, iile_iisp
     }
 }
 
-__global__ __launch_bounds__(kIisptBlock) void k_iispt_trace(DScene S, IisptItems I, int *SPILL) {
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_trace(DScene S, const IisptJob *jobs, int *SPILL) {
     __shared__ int lds_stack[kIisptBlock / 64][2 * kLdsStackDepth][64];
+    const IisptItems I = jobs[blockIdx.y].I;
     lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
-    const uint32_t spill_stride = gridDim.x * kIisptBlock;
-    int *my_spill = SPILL + blockIdx.x * kIisptBlock + threadIdx.x;
+    const uint32_t spill_stride = gridDim.x * gridDim.y * kIisptBlock;
+    int *my_spill = SPILL + (blockIdx.y * gridDim.x + blockIdx.x) * kIisptBlock + threadIdx.x;
     TraceStats st = {0, 0, 0, 0};
     for (int item = blockIdx.x * kIisptBlock + threadIdx.x; item < I.n_items; item += gridDim.x * kIisptBlock) {
         const float4 o4 = I.ro[item], d4 = I.rd[item];
@@ -146,7 +151,9 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_trace(DScene S, IisptItem
 }
 
 // one iteration of find_intersection's loop for every active item
-__global__ __launch_bounds__(kIisptBlock) void k_iispt_vertex(DScene S, iile_iispt_task T, IisptItems I) {
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_vertex(DScene S, const IisptJob *jobs) {
+    const iile_iispt_task T = jobs[blockIdx.y].T;
+    const IisptItems I = jobs[blockIdx.y].I;
     for (int item = blockIdx.x * kIisptBlock + threadIdx.x; item < I.n_items; item += gridDim.x * kIisptBlock) {
         const float4 o4 = I.ro[item], d4 = I.rd[item];
         const uint32_t word = f2b(d4.w);
@@ -225,7 +232,10 @@ DEV void iispt_aux_ray(const Isect &is, F3 ray_d, F3 *o, F3 *d) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(kIisptBlock) void k_iispt_hemi_out(DScene S, IisptItems I, uint8_t *valid, float *pos3, float *dir3) {
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_hemi_out(DScene S, const IisptJob *jobs) {
+    const IisptItems I = jobs[blockIdx.y].I;
+    uint8_t *valid = jobs[blockIdx.y].valid;
+    float *pos3 = jobs[blockIdx.y].pos3, *dir3 = jobs[blockIdx.y].dir3;
     for (int k = blockIdx.x * kIisptBlock + threadIdx.x; k < I.n_hemi; k += gridDim.x * kIisptBlock) {
         const float4 o4 = I.ro[k], d4 = I.rd[k], beta4 = I.beta[k];
         F3 o = F3{0, 0, 0}, d = F3{0, 0, 0};
@@ -306,8 +316,12 @@ DEV F3 estimate_direct_nn(const Isect &it, const Bsdf &bsdf, int rx, int ry, con
 }
 }  // namespace
 
-__global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iispt_task T, IisptItems I, int ny, const DHemiCam *cams,
-                                                             const float *nn_films, const float *jac, float4 *out) {
+__global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, const IisptJob *jobs, const float *jac) {
+    const iile_iispt_task T = jobs[blockIdx.y].T;
+    const IisptItems I = jobs[blockIdx.y].I;
+    const DHemiCam *cams = jobs[blockIdx.y].cams;
+    const float *nn_films = jobs[blockIdx.y].nn_films;
+    float4 *out = jobs[blockIdx.y].out;
     const int nx = I.nx;
     const int hemi = 32;  // PbrtOptions.iisptHemiSize (checked on the host)
     const int w = T.x1 - T.x0, n = w * (T.y1 - T.y0), ts = T.tilesize;
@@ -410,29 +424,32 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, iile_iis
     }
 }
 
-void launch_iispt_first_hits(const DScene &S, const iile_iispt_task &T, const IisptItems &I, int *spill, uint32_t *host_active, const LaunchCfg &cfg) {
-    const int blocks = std::max(1, std::min((I.n_items + kIisptBlock - 1) / kIisptBlock, cfg.n_cus * 6));
-    hipLaunchKernelGGL(k_iispt_begin, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, T, I);
-    // find_intersection's loop: trace, then one vertex step; again while some item follows a specular bounce
+namespace {
+// blocks per task: enough for its items, and no more blocks in all than the traversal stacks' spill columns were sized for
+dim3 job_grid(int max_items, int n_jobs, const LaunchCfg &cfg) {
+    const int budget = std::max(1, cfg.n_cus * 6 / std::max(n_jobs, 1));
+    return dim3(unsigned(std::max(1, std::min((max_items + kIisptBlock - 1) / kIisptBlock, budget))), unsigned(n_jobs));
+}
+}  // namespace
+void launch_iispt_first_hits(const DScene &S, const IisptJob *jobs, int n_jobs, int max_items, uint32_t *n_active, int *spill, const LaunchCfg &cfg) {
+    const dim3 grid = job_grid(max_items, n_jobs, cfg);
+    hipLaunchKernelGGL(k_iispt_begin, grid, dim3(kIisptBlock), 0, cfg.stream, S, jobs);
+    // find_intersection's loop: trace, then one vertex step; again while some item (of any task) follows a specular bounce
     for (int bounce = 0; bounce < 24; ++bounce) {
-        (void)hipMemsetAsync(I.n_active, 0, sizeof(uint32_t), cfg.stream);
-        hipLaunchKernelGGL(k_iispt_trace, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, I, spill);
-        hipLaunchKernelGGL(k_iispt_vertex, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, T, I);
-        *host_active = 0;
-        if (hipMemcpyAsync(host_active, I.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, cfg.stream) != hipSuccess) return;
+        (void)hipMemsetAsync(n_active, 0, sizeof(uint32_t), cfg.stream);
+        hipLaunchKernelGGL(k_iispt_trace, grid, dim3(kIisptBlock), 0, cfg.stream, S, jobs, spill);
+        hipLaunchKernelGGL(k_iispt_vertex, grid, dim3(kIisptBlock), 0, cfg.stream, S, jobs);
+        uint32_t host_active = 0;
+        if (hipMemcpyAsync(&host_active, n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, cfg.stream) != hipSuccess) return;
         if (hipStreamSynchronize(cfg.stream) != hipSuccess) return;
-        if (*host_active == 0) break;
+        if (host_active == 0) break;
     }
 }
-void launch_iispt_hemi_out(const DScene &S, const IisptItems &I, uint8_t *valid, float *pos3, float *dir3, const LaunchCfg &cfg) {
-    const int blocks = std::max(1, std::min((I.n_hemi + kIisptBlock - 1) / kIisptBlock, cfg.n_cus * 6));
-    hipLaunchKernelGGL(k_iispt_hemi_out, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, I, valid, pos3, dir3);
+void launch_iispt_hemi_out(const DScene &S, const IisptJob *jobs, int n_jobs, int max_hemi, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_iispt_hemi_out, job_grid(max_hemi, n_jobs, cfg), dim3(kIisptBlock), 0, cfg.stream, S, jobs);
 }
-void launch_iispt_gather(const DScene &S, const iile_iispt_task &T, const IisptItems &I, int ny, const DHemiCam *cams, const float *nn_films,
-                         const float *jac, float4 *out, const LaunchCfg &cfg) {
-    const int n = (T.x1 - T.x0) * (T.y1 - T.y0);
-    const int blocks = std::max(1, std::min((n + kIisptBlock - 1) / kIisptBlock, cfg.n_cus * 6));
-    hipLaunchKernelGGL(k_iispt_gather, dim3(blocks), dim3(kIisptBlock), 0, cfg.stream, S, T, I, ny, cams, nn_films, jac, out);
+void launch_iispt_gather(const DScene &S, const IisptJob *jobs, int n_jobs, int max_pixels, const float *jac, const LaunchCfg &cfg) {
+    hipLaunchKernelGGL(k_iispt_gather, job_grid(max_pixels, n_jobs, cfg), dim3(kIisptBlock), 0, cfg.stream, S, jobs, jac);
 }
 
 }  // namespace iile

@@ -170,11 +170,22 @@ struct IisptItems {
     uint32_t *n_active;
     int n_items, n_hemi, nx;
 };
-// camera samples + find_intersection for every item (hemi points, then film pixels); synchronises cfg.stream
-void launch_iispt_first_hits(const DScene &S, const iile_iispt_task &T, const IisptItems &I, int *spill, uint32_t *host_active, const LaunchCfg &cfg);
-void launch_iispt_hemi_out(const DScene &S, const IisptItems &I, uint8_t *valid, float *pos3, float *dir3, const LaunchCfg &cfg);
-void launch_iispt_gather(const DScene &S, const iile_iispt_task &T, const IisptItems &I, int ny, const DHemiCam *cams, const float *nn_films,
-                         const float *jac, float4 *out, const LaunchCfg &cfg);
+// One task of a batch as the kernels see it (an array of these in HBM, one per blockIdx.y): the task, its slice of the item
+// planes, and where its hemi-point outputs / cameras / predicted hemispheres / film pixels are
+struct IisptJob {
+    iile_iispt_task T;
+    IisptItems I;
+    int ny;
+    uint8_t *valid;  // hemi_out
+    float *pos3, *dir3;
+    const DHemiCam *cams;  // gather
+    const float *nn_films;
+    float4 *out;
+};
+// camera samples + find_intersection for every item (hemi points, then film pixels) of every job; synchronises cfg.stream
+void launch_iispt_first_hits(const DScene &S, const IisptJob *jobs, int n_jobs, int max_items, uint32_t *n_active, int *spill, const LaunchCfg &cfg);
+void launch_iispt_hemi_out(const DScene &S, const IisptJob *jobs, int n_jobs, int max_hemi, const LaunchCfg &cfg);
+void launch_iispt_gather(const DScene &S, const IisptJob *jobs, int n_jobs, int max_pixels, const float *jac, const LaunchCfg &cfg);
 
 // kernel-level entry points for parity tests
 void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, float4 *hits, int any_hit,

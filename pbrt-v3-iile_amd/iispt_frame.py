@@ -106,41 +106,41 @@ class IisptFrame:
 
         i = 0
         while i < len(tasks):
-            group, n_pts = [], 0
+            group, n_pts, n_pix = [], 0, 0
             while i < len(tasks) and (not group or n_pts < max_probes):
                 x0, y0, x1, y1, ts = tasks[i]
                 task = self.b.IisptTask(x0, y0, x1, y1, ts, self.counter, self.rng_seed)
                 nx, ny = task.grid()
-                t0 = time.time()
-                valid, pos, dr = self.gpu.iispt_hemi_points(task)
-                tick("hemi_points", t0)
-                group.append((task, valid, pos, dr, nx, ny))
+                group.append(task)
                 n_pts += nx * ny
+                n_pix += (x1 - x0) * (y1 - y0)
                 self.counter += nx * ny + (x1 - x0) * (y1 - y0)
                 self.rng_seed += (x1 - x0) * (y1 - y0)
                 i += 1
+            # every stage runs over the whole group at once (iile_iispt_*_batch: one set of launches for all its tasks)
             t0 = time.time()
-            sel = np.concatenate([g[1].reshape(-1) == 1 for g in group])
-            pos_all = np.concatenate([g[2].reshape(-1, 3) for g in group])[sel]
-            dir_all = np.concatenate([g[3].reshape(-1, 3) for g in group])[sel]
+            valid, pos, dr = self.gpu.iispt_hemi_points_batch(group)
+            tick("hemi_points", t0)
+            t0 = time.time()
+            sel = valid == 1
             nn = torch.zeros((n_pts, 32, 32, 3), dtype=torch.float32, device="cuda")
-            if len(pos_all):
-                pred, _, _, _ = self.pipe(pos_all, dir_all)
+            if sel.any():
+                pred, _, _, _ = self.pipe(pos[sel], dr[sel])
                 nn[torch.from_numpy(sel).cuda()] = torch.flip(pred, dims=(1,))
             tick("probes_and_network", t0)
+            t0 = time.time()
+            out = torch.empty((n_pix, 4), dtype=torch.float32, device="cuda")
+            self.gpu.iispt_gather_batch(group, valid, pos, dr, nn_device_ptr=nn.data_ptr(), out_device_ptr=out.data_ptr())
             first = 0
-            for task, valid, pos, dr, nx, ny in group:
-                t0 = time.time()
+            for task in group:
                 th, tw = task.y1 - task.y0, task.x1 - task.x0
-                out = torch.empty((th, tw, 4), dtype=torch.float32, device="cuda")
-                self.gpu.iispt_gather(task, valid, pos, dr, nn_device_ptr=nn[first:first + nx * ny].data_ptr(), out_device_ptr=out.data_ptr())
-                self.film[task.y0:task.y1, task.x0:task.x1] += out.double()
-                first += nx * ny
-                tick("gather", t0)
+                self.film[task.y0:task.y1, task.x0:task.x1] += out[first:first + th * tw].view(th, tw, 4).double()
+                first += th * tw
                 self.stats["tasks"] += 1
-                self.stats["hemi_points"] += nx * ny
-                self.stats["probes"] += int((valid == 1).sum())
                 self.stats["pixels"] += tw * th
+            tick("gather", t0)
+            self.stats["hemi_points"] += n_pts
+            self.stats["probes"] += int(sel.sum())
         torch.cuda.synchronize()
         return self.image()
 

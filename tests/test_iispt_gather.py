@@ -74,6 +74,36 @@ def test_gather_on_device_matches_oracle(binding, oracle):
 
 
 @pytest.mark.gpu
+def test_batched_calls_equal_the_single_task_calls(binding, oracle):
+    """iile_iispt_hemi_points_batch / iile_iispt_gather_batch: several tasks (different rectangles, tile sizes, sampler counters
+    and seeds; one of a single pixel) from one set of launches — the single-task results, concatenated, bit for bit; and the
+    oracle's for one of them."""
+    scene = binding.HostScene(xres=96, yres=80, spp=4)
+    gpu = binding.GpuScene(scene)
+    tasks = [_task(binding, 96, 80, 10), binding.IisptTask(16, 8, 90, 71, 7, 500, 3), binding.IisptTask(40, 40, 41, 41, 5, 9000, 77),
+             binding.IisptTask(0, 50, 96, 80, 30, 12000, 5), binding.IisptTask(60, 0, 96, 33, 4, 20000, 11)]
+    singles = [gpu.iispt_hemi_points(t) for t in tasks]
+    valid, pos, dr = gpu.iispt_hemi_points_batch(tasks)
+    assert np.array_equal(valid, np.concatenate([s[0].reshape(-1) for s in singles]))
+    assert _bits_equal(pos, np.concatenate([s[1].reshape(-1, 3) for s in singles]))
+    assert _bits_equal(dr, np.concatenate([s[2].reshape(-1, 3) for s in singles]))
+    rng = np.random.default_rng(31)
+    nn = rng.uniform(0.0, 3.0, (len(valid), 32, 32, 3)).astype(np.float32)
+    nn[rng.uniform(size=nn.shape[:3]) < 0.1] = 0
+    out = gpu.iispt_gather_batch(tasks, valid, pos, dr, nn)
+    first_h = first_p = 0
+    for t, (v, p, d) in zip(tasks, singles):
+        nh, npix = v.size, (t.x1 - t.x0) * (t.y1 - t.y0)
+        one = gpu.iispt_gather(t, v, p, d, nn[first_h:first_h + nh].reshape(v.shape + (32, 32, 3)))
+        assert _bits_equal(out[first_p:first_p + npix], one.reshape(-1, 4))
+        if t is tasks[1]:
+            assert _bits_equal(one, oracle.iispt_gather(scene, t, v, p, d, nn[first_h:first_h + nh].reshape(v.shape + (32, 32, 3))))
+        first_h += nh
+        first_p += npix
+    assert first_p == len(out) and (out[:, 3] == 0.5).sum() > 2000
+
+
+@pytest.mark.gpu
 def test_gather_in_a_textured_room_with_specular_chains(binding, oracle, tmp_path):
     """find_intersection's specular chain (mirror / glass blobs), textured and bump-mapped first hits, plastic and uber BSDFs
     under sample_hemisphere; the predictions stay in HBM (device pointers in and out)."""
