@@ -137,10 +137,11 @@ def cpu_baseline(scene_path, xres, yres, target_seconds, workload_name="killeroo
     }
 
 
-def load_pmc(world, args):
+def load_pmc(world, args, total_spp):
     """The committed counter summaries (tools/summarize_profiles.py): newest profiles/*_pmc_traffic.json and
     *_pmc_lanes.json of this workload on one GPU (killeroo-simple: the default frame; boxroom: files tagged `_room`)."""
-    if not (world == 1 and (args.xres, args.yres, args.spp) == (1920, 1080, 64) and args.workload in ("killeroo", "boxroom") and not args.sampler):
+    # (the counters were collected on the 64-spp step: they say nothing about a step of another size, e.g. --scaling strong)
+    if not (world == 1 and (args.xres, args.yres, total_spp) == (1920, 1080, 64) and args.workload in ("killeroo", "boxroom") and not args.sampler):
         return {}, {}, None, None
     room = args.workload == "boxroom"
 
@@ -405,7 +406,7 @@ def main():
             "k_mis_lit": (agg["ms_resolve"], agg["n_connect_launches"], 1 * nee, nee, "one result byte per NEE record"),
             "k_film": (agg["ms_film"], primary["n_passes"] * steps, 16 * cst["camera_rays"], cst["camera_rays"], "L read per sample"),
         }
-        pmc_traffic, pmc_lanes, tr_src, la_src = load_pmc(world, args)
+        pmc_traffic, pmc_lanes, tr_src, la_src = load_pmc(world, args, total_spp)
         vmem_peak, vmem_src = load_vmem_calibration()
         # What the counters say binds each kernel family (profiles/*_pmc_mem.json, *_pmc_lanes.json, r04_vmem_calib.json):
         BINDS = {
