@@ -1793,7 +1793,9 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     sc->pb.flag_count = nullptr;
     // E, F (5 levels) and D (5 levels x light samples) of every path, the PCG jump table, the film
     const size_t np = P.n_paths, vec = sizeof(float4);
-    const size_t d_bytes = tree ? vec : std::max<size_t>(size_t(5) * size_t(total_samples) * np * vec, vec), ef_bytes = tree ? vec : size_t(5) * np * vec;
+    const int levels = S.has_specular ? 5 : 1;  // Li recurses through specular lobes only (the pass loop below stops likewise)
+    P.direct_levels = levels;
+    const size_t d_bytes = tree ? vec : std::max<size_t>(size_t(levels) * size_t(total_samples) * np * vec, vec), ef_bytes = tree ? vec : size_t(levels) * np * vec;
     const size_t jump_bytes = (size_t(n_arrays) + 1) * 2 * sizeof(unsigned long long);
     const size_t rd_bytes = (reflect_diffs && !tree) ? size_t(4) * np * vec : 0;
     DevBuf<char> block;

@@ -42,6 +42,7 @@ struct PassDesc {
     // their sum: UniformSampleAllLights makes that many EstimateDirect calls per vertex, each with a result slot of its own
     int direct_nsamples[8];
     int direct_total_samples;
+    int direct_levels;         // vertices along Li's recursion that can exist: 5 with a specular lobe in the scene, else 1
 };
 static_assert(kMaxLights <= 8, "PassDesc::direct_nsamples");
 

@@ -164,17 +164,28 @@ DEV uint32_t direct_light_request(const DScene &S, const DLight &lt, const Isect
                 nee_flags |= NEE_HAS_SHADOW;
             }
         }
-        // BSDF-sampling half (integrator.cpp:165-213); every such ray is traced (no culling here)
+        // BSDF-sampling half (integrator.cpp:165-213). A ray that the light's sphere rejects at tMax = inf can never end on the
+        // light whatever else it hits (DESIGN.md "MIS rays that cannot score": every tMax-dependent branch of Sphere::Intersect is
+        // a rejection), so its term is exactly zero and it is not queued — with nSamples = 8 that is most of the pass's rays.
         F3 f2 = bsdf_sample_f(bsdf, is.wo, &wi, us0, us1, &scattering_pdf);
         f2 = f2 * absdot(wi, is.sn);
         if (!is_black(f2) && scattering_pdf > 0) {
-            unsigned long long nt = 0, nh = 0;
-            const float lp = shape_pdf(S, lt, is, wi, &nt, &nh);
-            if (lp != 0) {
-                mo = offset_ray_origin(is.p, is.perr, is.n, wi);
-                md = wi;
-                Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * power_heuristic(scattering_pdf, lp), scattering_pdf);
-                nee_flags |= NEE_HAS_MIS;
+            const F3 m_o = offset_ray_origin(is.p, is.perr, is.n, wi);
+            bool can_reach = true;
+            if (lt.type == kLightDiffuseArea) {
+                float t_l;
+                F3 od_l, ph_l;
+                can_reach = sphere_test(S.spheres[lt.sphere], m_o, wi, IILE_INF, &t_l, &od_l, &ph_l);
+            }
+            if (can_reach) {
+                unsigned long long nt = 0, nh = 0;
+                const float lp = shape_pdf(S, lt, is, wi, &nt, &nh);
+                if (lp != 0) {
+                    mo = m_o;
+                    md = wi;
+                    Bc = sdiv(f2 * F3{lt.lemit[0], lt.lemit[1], lt.lemit[2]} * power_heuristic(scattering_pdf, lp), scattering_pdf);
+                    nee_flags |= NEE_HAS_MIS;
+                }
             }
         }
     }
@@ -416,7 +427,9 @@ __global__ __launch_bounds__(kBlock) void k_direct_fold(DScene S, PassDesc P, Pa
         uint32_t k = 0;
         if (!(path_pixel(S, P, pid, &px, &py, &k) && px >= S.crop_x0 && px < S.crop_x1 && py >= S.crop_y0 && py < S.crop_y1)) continue;
         F3 Lnext = F3{0, 0, 0};
-        for (int d = 4; d >= 0; --d) {
+        // (levels that cannot exist — no specular lobe in the scene: everything past the camera vertex — would add zeros only:
+        //  they are neither stored nor read)
+        for (int d = P.direct_levels - 1; d >= 0; --d) {
             const float4 e4 = B.dir_E[size_t(d) * B.dir_paths + pid];
             F3 L = F3{0, 0, 0};
             L = L + F3{e4.x, e4.y, e4.z};  // L += isect.Le(wo)
