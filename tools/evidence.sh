@@ -2,7 +2,7 @@
 # round-4 evidence: rocprofv3 stats + PMC passes of the bench command (killeroo, room), the summaries, the bench lines that read them,
 # the vmem calibration's own counters, the 1-rank torchrun line, the room at BASELINE's 256 spp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r04c}
+TAG=${1:-r04d}
 O=$R/gpurun_out/${TAG}_evidence
 mkdir -p $O
 cd $R
