@@ -13,8 +13,8 @@
 //   k_lbvh_*            emitLBVH (:555-618) for all treelets at once, one thread per sorted position (see below), nodes in
 //                       preorder into the treelet's own pool region; leaves take their primitives in sorted order, so
 //                       the leaf order IS the sorted order
-//   k_upper_sah         buildUpperSAH (:527-638) over the <= 4096 treelet roots and the preorder offsets of all subtrees: one
-//                       block, spans of roots as work items for its wavefronts (round 4; a host loop before)
+//   k_upper_split / k_upper_finish   buildUpperSAH (:527-638) over the <= 4096 treelet roots, one launch per level of the
+//                       recursion, and the preorder offsets of all subtrees (round 4; a host loop before)
 //   k_place_nodes       flattenBVHTree: every treelet node to its depth-first index, second-child offsets rebased
 //
 // The result must equal the host builder's (csrc/host/bvh_build.cpp, split method "hlbvh") node for node:
@@ -320,32 +320,41 @@ __global__ __launch_bounds__(kBB) void k_place_nodes(int n, const int *incl, con
 // widest centroid axis, the cheapest of eleven splits, std::partition, two recursive calls. Everything it computes is a
 // function of the SET of roots in the span — min / max unions, counts, the cost expression — so the order std::partition
 // leaves the two sides in decides nothing: the tree is the same whichever way each side is ordered, and the layout
-// (flattenBVHTree's preorder) follows from the tree. One block builds it:
-//   * spans are work items in an LDS queue; a wavefront takes the next ticket, waits until that slot is published, and
-//     processes the span: three passes over its roots (bounds; buckets, LDS atomics on order-preserving keys; a stable
-//     partition into the other of two LDS index arrays by ballot ranks), the eleven costs on eleven lanes in the reference's
-//     float expression, the first minimum in bucket order. A side of one root is a leaf of the upper tree, a larger side
-//     is published as a new slot. The slot number IS the upper node's number, so a parent's number is smaller than its
-//     children's, and exactly n - 1 slots exist for n roots — a ticket past that ends the wavefront.
-//   * sizes and boxes then climb from the treelets (the second child to arrive at a node finishes it: InitInterior's
-//     Union(c0, c1), operand order kept because std::min / std::max return their first argument on a tie of -0 and +0),
-//   * and every upper node and treelet sums its preorder offset along its path to the root; upper nodes are written to the
-//     output array in place, treelets get the base k_place_nodes moves their blocks to.
+// (flattenBVHTree's preorder) follows from the tree. The recursion runs level by level, one launch per level:
+//   k_upper_split   every span of the level is split by one wavefront: a pass over its roots for the bounds (wave reductions as
+//                   DPP operands), one for the buckets (LDS atomics on order-preserving keys), the eleven costs on eleven
+//                   lanes — bucket j in lane j, prefix and suffix scans over the lanes give every candidate's two boxes and
+//                   counts, the cost in the reference's float expression —, the first minimum, a stable partition by ballot
+//                   ranks into the other of two index arrays. A side of one root is a leaf of the upper tree; a larger side
+//                   joins the next level's queue. Upper nodes are numbered level by level in queue order, so a parent's
+//                   number is smaller than its children's and the children's numbers are known when they are queued.
+//   k_upper_finish  one block: InitInterior's sizes and boxes, deepest level first (Union(c0, c1), operand order kept: std::min /
+//                   std::max return their first argument on a tie of -0 and +0), then every upper node and treelet sums its
+//                   preorder offset along its path to the root; upper nodes are written to the output array in place, treelets
+//                   get the base k_place_nodes moves their blocks to.
 // A span whose centroids coincide on the chosen axis (the reference stops with CHECK_NE there) or whose split leaves a side
-// empty is cut in the middle, so the kernel always ends.
-constexpr int kUpMax = 4096;      // treelets are runs of equal top 12 Morton bits: at most 4096
-constexpr int kUpThreads = 1024;  // 16 wavefronts
+// empty is cut in the middle, so the recursion always ends. (First version, same round: one block, an LDS queue of spans for its
+// sixteen wavefronts — correct, but one CU at idle clocks made 0.55 us per span, 0.9 ms at 1 582 treelets, where the host loop it
+// replaced took 0.6; the levels in parallel over the chip take a fifth of that.)
+constexpr int kUpMax = 4096;  // treelets are runs of equal top 12 Morton bits: at most 4096
 constexpr int kUpBuckets = 12;
-constexpr uint32_t kSegDone = 0xffffffffu;  // queue entry of a span its parent has already split
+constexpr int kUpBatch = 14;  // levels launched before the host looks whether the last one still had spans
 struct UpperDev {
-    const Box *roots;       // [n_t] treelet root bounds
-    const int *n_nodes_t;   // [n_t] nodes per treelet
-    int *tparent;           // [n_t] the same for treelets
-    int *axis;              // [n_t - 1]
-    Box *cbox;              // [2 (n_t - 1)] boxes of the two children of every upper node
-    int *base;              // [n_t] out: preorder offset of every treelet's block
-    iile_bvh_node *out;     // the flattened tree: upper nodes are written here
-    int *err;               // set to 2 if the queue bookkeeping ever disagrees with n_t - 1 (never seen)
+    const Box *roots;      // [n_t] treelet root bounds
+    const int *n_nodes_t;  // [n_t] nodes per treelet
+    int *refs;             // [2][kUpMax] treelet numbers: level L reads array L & 1 and writes the other
+    uint32_t *qseg;        // [2][kUpMax] spans of a level: start | end << 13
+    int *qlink;            // [2][kUpMax] parent node * 2 + which child, -1 for the root span
+    int *qcount;           // [kUpMax + 2] spans per level
+    int *level_base;       // [kUpMax + 2] number of the first node of a level
+    int *node_link;        // [kUpMax] upper node -> parent * 2 + which, -1 for the root
+    int *cref;             // [kUpMax][2] children: >= 0 upper node, < 0 ~treelet
+    int *axis;             // [kUpMax]
+    int *tparent;          // [kUpMax] treelet -> parent * 2 + which (-1: the treelet is the whole tree)
+    int *size;             // [kUpMax] nodes in the subtree of an upper node
+    Box *nbox;             // [kUpMax] its box
+    int *base;             // [n_t] out: preorder offset of every treelet's block
+    iile_bvh_node *out;    // the flattened tree: upper nodes are written here
 };
 __device__ __forceinline__ float box_area(const float mn[3], const float mx[3]) {  // Bounds3::SurfaceArea, geometry.h:782-785
     const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
@@ -390,64 +399,46 @@ __device__ __forceinline__ int row_scan_add(int v, bool prefix) {
     }
     return v;
 }
-__global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
-    // 139 KB of the CU's 160 KB of LDS: the root boxes themselves (every pass over a span reads them), the two index arrays,
-    // the queue
-    __shared__ int q_head, q_tail;
-    __shared__ uint32_t bk[kUpThreads / 64][kUpBuckets][8];  // per wavefront: count, 3 min keys, 3 max keys
-    __shared__ uint32_t q_seg[kUpMax];       // slot -> start | end << 13 | array << 26; 0 = not published yet
-    __shared__ uint16_t q_link[kUpMax];      // slot -> parent * 2 + which, 0xffff for the root span
-    __shared__ uint16_t refs[2][kUpMax];     // treelet numbers, ping-pong between a span and its two sides
-    __shared__ float bx[6][kUpMax];          // root boxes, one plane per coordinate; after the build: child sizes (below)
+__global__ __launch_bounds__(kBB) void k_upper_init(int n_t, UpperDev U) {
+    for (int i = blockIdx.x * kBB + threadIdx.x; i < kUpMax + 2; i += gridDim.x * kBB) {
+        U.qcount[i] = (i == 0 && n_t > 1) ? 1 : 0;
+        U.level_base[i] = 0;
+        if (i < kUpMax) {
+            U.refs[i] = i;
+            U.tparent[i] = -1;
+        }
+        if (i == 0) {
+            U.qseg[0] = 0u | (uint32_t(n_t) << 13);
+            U.qlink[0] = -1;
+        }
+    }
+}
+__global__ __launch_bounds__(kBB) void k_upper_split(int level, UpperDev U) {
+    __shared__ uint32_t bk[kBB / 64][kUpBuckets][8];  // per wavefront: count, 3 min keys, 3 max keys
+    const int count = U.qcount[level];
+    if (count == 0) return;
+    const int lb = U.level_base[level];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int n_upper = n_t - 1;
-    for (int i = tid; i < kUpMax; i += kUpThreads) {
-        refs[0][i] = uint16_t(i);
-        q_seg[i] = 0;
-        q_link[i] = 0xffffu;
-        if (i < n_t) {
-            const Box b = U.roots[i];
-            for (int a = 0; a < 3; ++a) bx[a][i] = b.mn[a], bx[3 + a][i] = b.mx[a];
-        }
-    }
-    if (tid == 0) {
-        q_head = 0;
-        q_tail = 1;
-    }
-    __syncthreads();
-    if (tid == 0) q_seg[0] = 0u | (uint32_t(n_t) << 13);
-    __syncthreads();
-    volatile uint32_t *vseg = q_seg;
-    auto link_of = [&](int slot) { return q_link[slot] == 0xffffu ? -1 : int(q_link[slot]); };
-    while (true) {
-        // Everything that steers this loop is wave-uniform BY CONSTRUCTION: values come through readfirstlane, and what one
-        // lane would do (take a ticket, publish a span) every lane does with the same operands — the ticket counter is
-        // bumped by lane 0's operand alone. With `if (lane == 0)` at both ends of the loop body the compiler threaded lane 0's
-        // path from the publishing block into the next round's ticket and let lanes 1-63 run ahead without it: they read
-        // "ticket 0" from an inactive lane for ever.
-        const int slot = __builtin_amdgcn_readfirstlane(atomicAdd(&q_head, lane == 0 ? 1 : 0));
-        if (slot >= n_upper) break;
-        uint32_t seg;
-        int spins = 0;
-        while ((seg = uint32_t(__builtin_amdgcn_readfirstlane(int(vseg[slot])))) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
-        if (seg == 0) {  // (never seen: n roots make exactly n - 1 spans) give up rather than hang
-            *U.err = 3;
-            break;
-        }
-        if (seg == kSegDone) continue;  // its parent finished it
-        __threadfence_block();
-        const int s = int(seg & 8191u), e = int((seg >> 13) & 8191u), buf = int(seg >> 26);
-        const int dbuf = buf ^ 1;  // (LDS arrays are indexed in place: a pointer to one of them would be a generic pointer, and
-                                   //  every access through it a flat instruction, several times an LDS instruction's latency)
+    if (blockIdx.x == 0 && tid == 0) U.level_base[level + 1] = lb + count;  // (read by later launches only)
+    const int par = level & 1;
+    const int *src = U.refs + par * kUpMax;
+    int *dst = U.refs + (par ^ 1) * kUpMax;
+    // Everything that steers a wavefront here is wave-uniform BY CONSTRUCTION: values come through readfirstlane, and what one
+    // lane would do (queue a span) every lane does with the same operands, the counter bumped by lane 0's operand alone.
+    // (In the one-block version `if (lane == 0)` at both ends of a loop body let the compiler thread lane 0's path from the
+    // publishing block into the next round and run lanes 1-63 ahead without it — a hang that cost a GPU call to see.)
+    for (int sp = blockIdx.x * (kBB / 64) + w; sp < count; sp += gridDim.x * (kBB / 64)) {
+        const uint32_t seg = U.qseg[par * kUpMax + sp];
+        const int s = int(seg & 8191u), e = int((seg >> 13) & 8191u);
+        const int node = lb + sp;
         // bounds of the span and of its centroids (bvh.cpp:537-549)
         float bmn[3] = {kFltMax, kFltMax, kFltMax}, bmx[3] = {-kFltMax, -kFltMax, -kFltMax};
         float cmn[3] = {kFltMax, kFltMax, kFltMax}, cmx[3] = {-kFltMax, -kFltMax, -kFltMax};
         for (int i = s + lane; i < e; i += 64) {
-            const int t = refs[buf][i];
+            const Box b = U.roots[src[i]];
             for (int a = 0; a < 3; ++a) {
-                const float lo_a = bx[a][t], hi_a = bx[3 + a][t];
-                bmn[a] = fminf(bmn[a], lo_a), bmx[a] = fmaxf(bmx[a], hi_a);
-                const float c = (lo_a + hi_a) * 0.5f;
+                bmn[a] = fminf(bmn[a], b.mn[a]), bmx[a] = fmaxf(bmx[a], b.mx[a]);
+                const float c = (b.mn[a] + b.mx[a]) * 0.5f;
                 cmn[a] = fminf(cmn[a], c), cmx[a] = fmaxf(cmx[a], c);
             }
         }
@@ -465,8 +456,8 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
             lo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lo)));
             hi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hi)));
         }
-        auto bucket_of = [&](int t) {  // bvh.cpp:576-582
-            const float centroid = (bx[dim][t] + bx[3 + dim][t]) * 0.5f;
+        auto bucket_of = [&](const Box &b) {  // bvh.cpp:576-582
+            const float centroid = ((dim == 0 ? b.mn[0] : (dim == 1 ? b.mn[1] : b.mn[2])) + (dim == 0 ? b.mx[0] : (dim == 1 ? b.mx[1] : b.mx[2]))) * 0.5f;
             int k = int(kUpBuckets * ((centroid - lo) / (hi - lo)));
             if (k == kUpBuckets) k = kUpBuckets - 1;
             return k;
@@ -481,13 +472,13 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
             }
             __builtin_amdgcn_wave_barrier();
             for (int i = s + lane; i < e; i += 64) {
-                const int t = refs[buf][i];
-                int k = bucket_of(t);
+                const Box b = U.roots[src[i]];
+                int k = bucket_of(b);
                 k = k < 0 ? 0 : (k > kUpBuckets - 1 ? kUpBuckets - 1 : k);  // (the reference CHECKs 0 <= b < 12)
                 atomicAdd(&bk[w][k][0], 1u);
                 for (int a = 0; a < 3; ++a) {
-                    atomicMin(&bk[w][k][1 + a], order_key(bx[a][t]));
-                    atomicMax(&bk[w][k][4 + a], order_key(bx[3 + a][t]));
+                    atomicMin(&bk[w][k][1 + a], order_key(b.mn[a]));
+                    atomicMax(&bk[w][k][4 + a], order_key(b.mx[a]));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -534,6 +525,7 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
                 min_bucket = -1;  // an empty side: the middle cut
         }
         const int mid = s + n_left;
+        int first_of[2] = {0, 0};  // the first root of each side (a side of one root is a leaf: no trip through memory for it)
         {  // stable partition into the other array
             int done_l = 0, done_r = 0;
             for (int base = s; base < e; base += 64) {
@@ -542,106 +534,81 @@ __global__ __launch_bounds__(kUpThreads) void k_upper_sah(int n_t, UpperDev U) {
                 int t = 0;
                 bool left = false;
                 if (in) {
-                    t = refs[buf][i];
-                    left = min_bucket >= 0 ? bucket_of(t) <= min_bucket : (i - s) < n_left;
+                    t = src[i];
+                    left = min_bucket >= 0 ? bucket_of(U.roots[t]) <= min_bucket : (i - s) < n_left;
                 }
                 const unsigned long long ml = __ballot(in && left), mr = __ballot(in && !left);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (in) {
                     if (left)
-                        refs[dbuf][s + done_l + __popcll(ml & below)] = uint16_t(t);
+                        dst[s + done_l + __popcll(ml & below)] = t;
                     else
-                        refs[dbuf][mid + done_r + __popcll(mr & below)] = uint16_t(t);
+                        dst[mid + done_r + __popcll(mr & below)] = t;
                 }
+                if (done_l == 0 && ml != 0) first_of[0] = __builtin_amdgcn_readlane(t, __builtin_ctzll(ml));
+                if (done_r == 0 && mr != 0) first_of[1] = __builtin_amdgcn_readlane(t, __builtin_ctzll(mr));
                 done_l += __popcll(ml), done_r += __popcll(mr);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        U.axis[slot] = dim;
+        U.node_link[node] = U.qlink[par * kUpMax + sp];
+        U.axis[node] = dim;
         for (int which = 0; which < 2; ++which) {
             const int cs = which ? mid : s, ce = which ? e : mid;
             if (ce - cs == 1) {  // (uniform)
-                U.tparent[refs[dbuf][cs]] = slot * 2 + which;
+                const int t = first_of[which];
+                U.tparent[t] = node * 2 + which;
+                U.cref[node * 2 + which] = ~t;
             } else {
-                const int child = __builtin_amdgcn_readfirstlane(atomicAdd(&q_tail, lane == 0 ? 1 : 0));
-                if (child >= n_upper) {
-                    *U.err = 2;
-                } else if (ce - cs == 2) {
-                    // A span of two roots needs no pricing: the centroid span runs from one to the other, so one falls into
-                    // bucket 0, the other into bucket 11, every split costs the same and the first (after bucket 0) is taken:
-                    // the root at the low end goes left. Finished here, published as done (a third of all spans).
-                    const int t0 = refs[dbuf][cs], t1 = refs[dbuf][cs + 1];
-                    float c0[3], c1[3], ext[3];
-                    for (int a = 0; a < 3; ++a) {
-                        c0[a] = (bx[a][t0] + bx[3 + a][t0]) * 0.5f, c1[a] = (bx[a][t1] + bx[3 + a][t1]) * 0.5f;
-                        ext[a] = fmaxf(c0[a], c1[a]) - fminf(c0[a], c1[a]);
-                    }
-                    const int cdim = (ext[0] > ext[1] && ext[0] > ext[2]) ? 0 : (ext[1] > ext[2] ? 1 : 2);
-                    const float a0 = cdim == 0 ? c0[0] : (cdim == 1 ? c0[1] : c0[2]), a1 = cdim == 0 ? c1[0] : (cdim == 1 ? c1[1] : c1[2]);
-                    const bool swap = a1 < a0;  // (equal centroids: array order, the middle cut)
-                    U.tparent[swap ? t1 : t0] = child * 2;
-                    U.tparent[swap ? t0 : t1] = child * 2 + 1;
-                    U.axis[child] = cdim;
-                    q_link[child] = uint16_t(slot * 2 + which);
-                    __threadfence_block();
-                    vseg[child] = kSegDone;
-                } else {
-                    q_link[child] = uint16_t(slot * 2 + which);
-                    __threadfence_block();
-                    vseg[child] = uint32_t(cs) | (uint32_t(ce) << 13) | (uint32_t(dbuf) << 26);
-                }
+                const int idx = __builtin_amdgcn_readfirstlane(atomicAdd(&U.qcount[level + 1], lane == 0 ? 1 : 0));
+                U.qseg[(par ^ 1) * kUpMax + idx] = uint32_t(cs) | (uint32_t(ce) << 13);
+                U.qlink[(par ^ 1) * kUpMax + idx] = node * 2 + which;
+                U.cref[node * 2 + which] = lb + count + idx;  // the next level's nodes are numbered from lb + count in queue order
             }
         }
     }
-    __syncthreads();
-    // sizes and boxes climb from the treelets. The box planes are free now: child sizes in bx[0] / bx[1], arrivals in q_seg
-    int *size0 = reinterpret_cast<int *>(bx[0]), *size1 = reinterpret_cast<int *>(bx[1]);
-    for (int i = tid; i < kUpMax; i += kUpThreads) q_seg[i] = 0;
-    __syncthreads();
-    for (int t = tid; t < n_t; t += kUpThreads) {
-        int link = U.tparent[t];
-        int size = U.n_nodes_t[t];
-        Box box = U.roots[t];
-        while (link >= 0) {
-            const int node = link >> 1, which = link & 1;
-            (which ? size1 : size0)[node] = size;
-            U.cbox[2 * node + which] = box;
-            // Both children's threads run in this block, on this CU: the stores are complete (in L2) once the wave has waited
-            // for them, which a workgroup-scope fence does, and the reader loads past L1 (agent-scope relaxed loads: `sc1`).
-            // A device-scope fence pair here is an L2 write-back and an L1 invalidate per step, ~3.5 us each on gfx950.
-            __threadfence_block();
-            if (atomicAdd(&q_seg[node], 1u) == 0u) break;  // the other child finishes this node
-            __threadfence_block();
-            Box b0, b1;  // InitInterior: Union(c0, c1), bvh.cpp:66-72
-            for (int a = 0; a < 3; ++a) {
-                b0.mn[a] = __hip_atomic_load(&U.cbox[2 * node].mn[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b0.mx[a] = __hip_atomic_load(&U.cbox[2 * node].mx[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b1.mn[a] = __hip_atomic_load(&U.cbox[2 * node + 1].mn[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b1.mx[a] = __hip_atomic_load(&U.cbox[2 * node + 1].mx[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One block finishes the tree (at most 4 095 upper nodes): sizes and boxes level by level from the deepest up — InitInterior's
+// Union(c0, c1) — with a block barrier between levels, then the preorder offsets: 1 per ancestor plus the first child's subtree
+// wherever the path to the root goes through a second child. (A launch per level cost more than the levels' work.)
+constexpr int kUpFinishThreads = 1024;
+__global__ __launch_bounds__(kUpFinishThreads) void k_upper_finish(int n_t, int depth, UpperDev U) {
+    for (int level = depth - 1; level >= 0; --level) {
+        const int first = U.level_base[level], last = U.level_base[level + 1];
+        for (int node = first + int(threadIdx.x); node < last; node += kUpFinishThreads) {
+            Box b[2];
+            int sz[2];
+            for (int which = 0; which < 2; ++which) {
+                const int r = U.cref[node * 2 + which];
+                b[which] = r < 0 ? U.roots[~r] : U.nbox[r];
+                sz[which] = r < 0 ? U.n_nodes_t[~r] : U.size[r];
             }
-            for (int a = 0; a < 3; ++a) box.mn[a] = union_min(b0.mn[a], b1.mn[a]), box.mx[a] = union_max(b0.mx[a], b1.mx[a]);
-            size = 1 + ((volatile int *)size0)[node] + ((volatile int *)size1)[node];
-            U.cbox[2 * n_upper + node] = box;  // the node's own box (read again below, after the barrier)
-            link = link_of(node);
+            Box box;  // bvh.cpp:66-72
+            for (int a = 0; a < 3; ++a) box.mn[a] = union_min(b[0].mn[a], b[1].mn[a]), box.mx[a] = union_max(b[0].mx[a], b[1].mx[a]);
+            U.nbox[node] = box;
+            U.size[node] = 1 + sz[0] + sz[1];
         }
+        __syncthreads();  // (one block, one CU: the level's stores are visible to the next level's loads)
     }
-    __syncthreads();
-    // preorder offsets: 1 per ancestor, plus the first child's subtree wherever the path goes through a second child
-    for (int i = tid; i < n_upper + n_t; i += kUpThreads) {
+    const int n_upper = n_t - 1;
+    for (int i = int(threadIdx.x); i < n_upper + n_t; i += kUpFinishThreads) {
         const bool is_node = i < n_upper;
-        int link = is_node ? link_of(i) : U.tparent[i - n_upper];
+        int link = is_node ? U.node_link[i] : U.tparent[i - n_upper];
         int off = 0;
         while (link >= 0) {
             const int p = link >> 1;
-            off += 1 + ((link & 1) ? size0[p] : 0);
-            link = link_of(p);
+            if (link & 1) {
+                const int r = U.cref[p * 2];
+                off += r < 0 ? U.n_nodes_t[~r] : U.size[r];
+            }
+            off += 1;
+            link = U.node_link[p];
         }
         if (is_node) {
             iile_bvh_node nd;
-            const Box box = U.cbox[2 * n_upper + i];
+            const Box box = U.nbox[i];
             for (int a = 0; a < 3; ++a) nd.bmin[a] = box.mn[a], nd.bmax[a] = box.mx[a];
-            nd.offset = off + 1 + size0[i];  // secondChildOffset (bvh.cpp:651-656)
+            const int r0 = U.cref[i * 2];
+            nd.offset = off + 1 + (r0 < 0 ? U.n_nodes_t[~r0] : U.size[r0]);  // secondChildOffset (bvh.cpp:651-656)
             nd.nprims = 0;
             nd.axis = uint8_t(U.axis[i]);
             nd.pad = 0;
@@ -946,11 +913,10 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     HIP_TRYB(pool.alloc(2 * size_t(n)));
     // (everything is allocated before the first kernel: a hipMalloc between two stages costs more than the upper tree's kernel)
     Dev<Box> d_roots, d_cbox;
-    Dev<int> up_tparent, up_axis;
+    Dev<int> up_ints;  // the upper tree's index arrays, queues and per-node words (UpperDev), one allocation
     HIP_TRYB(d_roots.alloc(size_t(kUpMax)));
-    HIP_TRYB(d_cbox.alloc(3 * size_t(kUpMax)));
-    HIP_TRYB(up_axis.alloc(size_t(kUpMax)));
-    HIP_TRYB(up_tparent.alloc(size_t(kUpMax)));
+    HIP_TRYB(d_cbox.alloc(size_t(kUpMax)));
+    HIP_TRYB(up_ints.alloc(14 * size_t(kUpMax) + 8));
     HIP_TRYB(out.alloc(2 * size_t(n)));  // 2 n - 1 nodes at most (one primitive per leaf)
     Dev<int> arena;  // emitLBVH's eleven int arrays of n (+ 1) entries in one allocation
     const size_t stride = (size_t(n) + 1 + 63) & ~size_t(63);
@@ -1007,15 +973,44 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     if (h_err) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: a leaf holds more than 65535 primitives (equal Morton codes)");
     if (n_treelets > kUpMax) return api_fail(IILE_ERR_UNSUPPORTED, "iile_bvh_build_hlbvh: more than 4096 treelets");
     HIP_TRYB(hipEventRecord(ev[3], s));
-    // buildUpperSAH + the preorder offsets of all subtrees, on the device (k_upper_sah): every treelet has emitted
-    // n_nodes_t nodes, the upper tree adds n_treelets - 1
+    // buildUpperSAH + the preorder offsets of all subtrees, on the device: every treelet has emitted n_nodes_t nodes, the
+    // upper tree adds n_treelets - 1
     const int n_upper = n_treelets - 1;
     const int n_nodes = 2 * n_splits + 2 * n_treelets - 1;
-    HIP_TRYB(hipMemsetAsync(up_tparent.p, 0xff, size_t(n_treelets) * sizeof(int), s));  // -1: the treelet is the whole tree
     hipLaunchKernelGGL(k_treelet_roots, dim3((n_treelets + kBB - 1) / kBB), dim3(kBB), 0, s, n_treelets, starts.p, pool.p, d_roots.p);
     {
-        UpperDev U{d_roots.p, n_nodes_t.p, up_tparent.p, up_axis.p, d_cbox.p, base.p, out.p, err_flag.p};
-        hipLaunchKernelGGL(k_upper_sah, dim3(1), dim3(kUpThreads), 0, s, n_treelets, U);
+        int *ui = up_ints.p;
+        UpperDev U;
+        U.roots = d_roots.p, U.n_nodes_t = n_nodes_t.p;
+        U.refs = ui, ui += 2 * kUpMax;
+        U.qseg = reinterpret_cast<uint32_t *>(ui), ui += 2 * kUpMax;
+        U.qlink = ui, ui += 2 * kUpMax;
+        U.qcount = ui, ui += kUpMax + 2;
+        U.level_base = ui, ui += kUpMax + 2;
+        U.node_link = ui, ui += kUpMax;
+        U.cref = ui, ui += 2 * kUpMax;
+        U.axis = ui, ui += kUpMax;
+        U.tparent = ui, ui += kUpMax;
+        U.size = ui, ui += kUpMax;
+        U.nbox = d_cbox.p, U.base = base.p, U.out = out.p;
+        hipLaunchKernelGGL(k_upper_init, dim3(4), dim3(kBB), 0, s, n_treelets, U);
+        // the levels of the recursion, a batch of launches at a time (a launch for a level without spans returns at once); the
+        // depth is 11-14 for the scenes at hand and at most n_treelets - 1
+        std::vector<int> level_count(size_t(kUpMax) + 2, 0);
+        int depth = 0;
+        const int split_blocks = std::max(1, std::min((n_treelets / 2 + kBB / 64 - 1) / (kBB / 64), 512));
+        for (int l0 = 0; l0 < n_upper; l0 += kUpBatch) {
+            const int l1 = std::min(l0 + kUpBatch, n_upper);
+            for (int level = l0; level < l1; ++level) hipLaunchKernelGGL(k_upper_split, dim3(split_blocks), dim3(kBB), 0, s, level, U);
+            HIP_TRYB(hipMemcpyAsync(level_count.data() + l0, U.qcount + l0, size_t(l1 - l0 + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRYB(hipStreamSynchronize(s));
+            depth = l1;
+            bool done = false;
+            for (int level = l0; level <= l1 && !done; ++level)
+                if (level_count[size_t(level)] == 0) depth = level, done = true;
+            if (done) break;
+        }
+        hipLaunchKernelGGL(k_upper_finish, dim3(1), dim3(kUpFinishThreads), 0, s, n_treelets, depth, U);
     }
     HIP_TRYB(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(k_place_nodes, dim3(grid_for(2 * n)), dim3(kBB), 0, s, n, incl.p, starts.p, n_nodes_t.p, base.p, pool.p, out.p);
@@ -1024,9 +1019,7 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
     HIP_TRYB(hipMemcpyAsync(nodes_out, out.p, size_t(n_nodes) * sizeof(iile_bvh_node), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipMemcpyAsync(order_out, numbers_sorted.p, size_t(n) * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipEventRecord(ev[6], s));
-    HIP_TRYB(hipMemcpyAsync(&h_err, err_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRYB(hipStreamSynchronize(s));
-    if (h_err) return api_fail(IILE_ERR_HIP, "iile_bvh_build_hlbvh: the upper SAH kernel lost track of its spans (code " + std::to_string(h_err) + ")");
     *n_nodes_out = n_nodes;
     auto ms = [&](int a, int b) {
         float v = 0;
