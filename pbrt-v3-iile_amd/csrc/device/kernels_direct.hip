@@ -218,8 +218,11 @@ __global__ __launch_bounds__(kBlock) void k_direct_generate(DScene S, PassDesc P
 }
 
 // One vertex of DirectProgressiveIntegrator::Li for every hit of the bounce's shade queue.
+#ifndef IILE_DIRECT_SHADE_WAVES
+#define IILE_DIRECT_SHADE_WAVES 2  // waves per SIMD the register allocation aims at
+#endif
 template <bool TEX>
-__global__ __launch_bounds__(kBlock, 2) void k_direct_shade(DScene S, PassDesc P, PassBuffers B, int depth, uint32_t plane) {
+__global__ __launch_bounds__(kBlock, IILE_DIRECT_SHADE_WAVES) void k_direct_shade(DScene S, PassDesc P, PassBuffers B, int depth, uint32_t plane) {
     const uint32_t count = B.counts[kCntShade + depth];
     const float4 *ro = B.ray_o[depth & 1], *rd = B.ray_d[depth & 1];
     float4 *no = B.ray_o[(depth + 1) & 1], *nd = B.ray_d[(depth + 1) & 1];
