@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(kBB) void k_place_nodes(int n, const int *incl, con
 // replaced took 0.6; the levels in parallel over the chip take a fifth of that.)
 constexpr int kUpMax = 4096;  // treelets are runs of equal top 12 Morton bits: at most 4096
 constexpr int kUpBuckets = 12;
-constexpr int kUpBatch = 14;  // levels launched before the host looks whether the last one still had spans
+constexpr int kUpBatch = 14;  // levels launched before the host looks whether the last one still had spans (IILE_UPPER_BATCH overrides: tests)
 struct UpperDev {
     const Box *roots;      // [n_t] treelet root bounds
     const int *n_nodes_t;  // [n_t] nodes per treelet
@@ -999,8 +1000,10 @@ extern "C" int iile_bvh_build_hlbvh(int32_t n_prims, const float *bounds6, int32
         std::vector<int> level_count(size_t(kUpMax) + 2, 0);
         int depth = 0;
         const int split_blocks = std::max(1, std::min((n_treelets / 2 + kBB / 64 - 1) / (kBB / 64), 512));
-        for (int l0 = 0; l0 < n_upper; l0 += kUpBatch) {
-            const int l1 = std::min(l0 + kUpBatch, n_upper);
+        int batch = kUpBatch;
+        if (const char *e = std::getenv("IILE_UPPER_BATCH")) batch = std::max(1, std::min(atoi(e), kUpMax));
+        for (int l0 = 0; l0 < n_upper; l0 += batch) {
+            const int l1 = std::min(l0 + batch, n_upper);
             for (int level = l0; level < l1; ++level) hipLaunchKernelGGL(k_upper_split, dim3(split_blocks), dim3(kBB), 0, s, level, U);
             HIP_TRYB(hipMemcpyAsync(level_count.data() + l0, U.qcount + l0, size_t(l1 - l0 + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
             HIP_TRYB(hipStreamSynchronize(s));

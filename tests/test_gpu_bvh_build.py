@@ -68,6 +68,26 @@ def test_device_builder_matches_the_oracle_on_soups(binding, oracle, seed):
     tob.same_tree(dn, on)
 
 
+def test_upper_tree_in_short_batches_of_levels(binding, oracle, monkeypatch):
+    """buildUpperSAH runs one launch per level of its recursion, a batch of levels between two looks of the host; with batches
+    of two levels every scene takes the continuation path several times (depth 11-14) — the same tree."""
+    rng = np.random.default_rng(77)
+    n = 60000
+    c = (rng.random((64, 3))[rng.integers(0, 64, n)] + rng.normal(0, 0.03, (n, 3))).astype(np.float32)
+    h = (rng.random((n, 3)) * 0.002 + 1e-4).astype(np.float32)
+    b6 = np.concatenate([c - h, c + h], axis=1).astype(np.float32)
+    want_nodes, want_order, st = binding.bvh_build_hlbvh(b6, 4)
+    on, oo, _ = oracle.bvh_hlbvh(b6, 4)
+    assert np.array_equal(want_order, oo)
+    tob.same_tree(want_nodes, on)
+    assert st["n_treelets"] > 64
+    for batch in ("1", "2", "5"):
+        monkeypatch.setenv("IILE_UPPER_BATCH", batch)
+        nodes, order, _ = binding.bvh_build_hlbvh(b6, 4)
+        assert np.array_equal(order, want_order)
+        _same_tree(nodes, want_nodes)
+
+
 def test_killeroo_tree_is_the_host_builders(binding):
     host = binding.HostScene(xres=64, yres=48, spp=1, accel_split="hlbvh")
     dev = binding.HostScene(xres=64, yres=48, spp=1, accel_split="hlbvh", bvh_on_device=True)
