@@ -18,7 +18,7 @@ b = ge._load_binding()
 o = oracle_binding.Oracle()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-lights = ["area", "quad", "multi", "spot", "point"]
+lights = ["area", "quad", "multi", "spot", "point", "envmap", "sky"]  # (the last two: infinite lights — k_mis ends at the first hit)
 mats = ["plain", "all", "mixed"]
 bad = 0
 with tempfile.TemporaryDirectory() as td:
@@ -28,6 +28,11 @@ with tempfile.TemporaryDirectory() as td:
                   n_blobs=int(rng.integers(1, 12)), wall_n=int(rng.integers(2, 16)), seed=seed, maxdepth=int(rng.integers(1, 8)),
                   light=lights[seed % len(lights)], materials=mats[(seed // len(lights)) % len(mats)])
         path = os.path.join(td, "room.pbrt")
+        if kw["light"] == "envmap":  # the map's directory; every other seed with image textures / bump maps / alpha masks as well
+            if seed % 2:
+                kw["textures"] = os.path.join(td, f"tex{seed}")
+            else:
+                kw["env_dir"] = os.path.join(td, f"env{seed}")
         try:
             open(path, "w").write(boxroom.boxroom_pbrt(**kw))
         except TypeError as e:
