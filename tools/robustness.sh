@@ -6,6 +6,7 @@ O=$R/gpurun_out/robustness
 mkdir -p $O
 cd $R
 timeout 1500 python3 tools/fuzz_rooms.py 4000 120 > $O/fuzz_rooms.txt 2>&1; tail -2 $O/fuzz_rooms.txt
+timeout 900 python3 tools/fuzz_direct.py 300 72 > $O/fuzz_direct.txt 2>&1; tail -2 $O/fuzz_direct.txt
 timeout 600 python3 tools/fuzz_gather.py > $O/fuzz_gather.txt 2>&1; tail -2 $O/fuzz_gather.txt
 timeout 600 python3 tools/fuzz_bvh.py > $O/fuzz_bvh.txt 2>&1; tail -2 $O/fuzz_bvh.txt
 timeout 1800 python3 tools/full_frame_parity.py $O/full_frame_parity_1024spp.json killeroo 1024 > $O/full_frame_1024.txt 2>&1; tail -3 $O/full_frame_1024.txt
