@@ -190,6 +190,32 @@ int iile_iispt_gather(iile_scene *scene, const iile_iispt_task *task, const uint
 int iile_iispt_hemi_points_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, uint8_t *valid, float *pos3, float *dir3);
 int iile_iispt_gather_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, const uint8_t *valid, const float *pos3,
                             const float *dir3, const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device);
+/* The IISPT network itself: `IISPTNet.forward` of ml/iispt_net.py:8-109 in eval mode, as the child process
+ * of ml/main_stdio_net.py:44-106 runs it once per probe (`net(torch_img)`, one CPU thread, fp32) — here over a whole batch
+ * of probes with hand-written gfx950 kernels (csrc/device/iispt_net.hip: implicit-GEMM 3 x 3 convolutions on the bf16 matrix
+ * pipe over split operands, fp32 accumulation; max-pool / bilinear upsample + concatenation folded into the loads; bias,
+ * LeakyReLU and the BatchNorm affine into the stores). Agreement with the reference module on the fixture of
+ * tests/golden/iispt_net_fixture.npz: within 1e-4 of the largest output (tests/test_iispt_nn.py).
+ *   iile_iispt_net_create   takes the tensors of the reference's `state_dict()` (host memory, the checkpoint's own shapes:
+ *                           Conv2d [out][in][k][k], ConvTranspose2d [in][out][k][k]) in forward order: convolutions
+ *                           encoder0.0, encoder0.2, encoder1.1, encoder1.4, encoder2.1, encoder2.4, encoder3.1, encoder3.4,
+ *                           decoder0.0, decoder0.3, decoder1.0, decoder1.3, decoder2.0, decoder2.2, decoder2.4; BatchNorm2d
+ *                           encoder1.3, encoder2.3, encoder3.3, decoder0.2, decoder1.2 (weight, bias, running_mean, running_var)
+ *   iile_iispt_net_forward  in_dev: (n, 7, 32, 32) floats as `read_input` (ml/main_stdio_net.py:47-72) builds them; out_dev:
+ *                           (n, 3, 32, 32) as `output_to_stdout` (:77-86) reads them; both DEVICE memory. The kernels are
+ *                           queued on `stream` (NULL = the null stream) and the call returns; activations live in a workspace
+ *                           the object owns (0.94 MiB per probe of a batch, at most max_batch probes at a time; <= 0: 16384).
+ *                           layer_out_dev != NULL (tests): also copies the NHWC output of convolution `layer` (0..13) there. */
+typedef struct iile_iispt_net iile_iispt_net;
+typedef struct iile_iispt_net_weights {
+    const float *conv_weight[15], *conv_bias[15];
+    const float *bn_weight[5], *bn_bias[5], *bn_mean[5], *bn_var[5];
+    float bn_eps;   /* BatchNorm2d's eps (1e-5) */
+} iile_iispt_net_weights;
+int iile_iispt_net_create(const iile_iispt_net_weights *weights, iile_iispt_net **out);
+int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_dev, int32_t n, int32_t max_batch, void *stream,
+                           float *layer_out_dev, int32_t layer);
+void iile_iispt_net_destroy(iile_iispt_net *net);
 /* BVHAccel's HLBVH build (src/accelerators/bvh.cpp:404-472: Morton codes :413-427, RadixSort :133-181, treelets and
  * emitLBVH :434-452, 555-618, buildUpperSAH :474-553) and flattenBVHTree (:640-658) — SURVEY.md §8 f4. bounds6: per
  * primitive WorldBound() as {min xyz, max xyz} (host memory); nodes_out: room for 2 * n_prims nodes; order_out[i] = the

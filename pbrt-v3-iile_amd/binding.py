@@ -111,6 +111,12 @@ HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_
                 "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table",
                 "iile_host_sobol_matrices", "iile_host_sobol_vdc", "iile_host_write_exr", "iile_host_write_image",
                 "iile_host_scene_film_filename"]
+class NetWeights(ctypes.Structure):
+    """iile_iispt_net_weights (include/iile_gpu.h)."""
+    _fields_ = [("conv_weight", c_vp * 15), ("conv_bias", c_vp * 15), ("bn_weight", c_vp * 5), ("bn_bias", c_vp * 5),
+                ("bn_mean", c_vp * 5), ("bn_var", c_vp * 5), ("bn_eps", c_f32)]
+
+
 class DirectParams(ctypes.Structure):  # iile_direct_params
     _fields_ = [("n_passes", ctypes.c_int32), ("first_pass", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("film_on_device", ctypes.c_int32),
                 ("stream", ctypes.c_void_p)]
@@ -237,6 +243,10 @@ def gpu_lib():
         lib.iile_iispt_gather_batch.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32]
         lib.iile_bvh_build_hlbvh.argtypes = [c_i32, c_vp, c_i32, c_vp, ctypes.POINTER(c_i32), c_vp, ctypes.POINTER(BvhBuildStats)]
         lib.iile_bvh_pack_probe.argtypes = [c_i32, c_vp, c_i32, c_vp, c_vp, ctypes.POINTER(c_i32)]
+        lib.iile_iispt_net_create.argtypes = [ctypes.POINTER(NetWeights), ctypes.POINTER(c_vp)]
+        lib.iile_iispt_net_forward.argtypes = [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32]
+        lib.iile_iispt_net_destroy.argtypes = [c_vp]
+        lib.iile_iispt_net_destroy.restype = None
         _gpu = lib
     return _gpu
 
@@ -622,6 +632,56 @@ class GpuScene:
         if self._s:
             gpu_lib().iile_scene_destroy(self._s)
             self._s = c_vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# the reference's state_dict names in forward order (ml/iispt_net.py:27-88): the 15 convolutions, the 5 BatchNorm2d
+NET_CONVS = ("encoder0.0", "encoder0.2", "encoder1.1", "encoder1.4", "encoder2.1", "encoder2.4", "encoder3.1", "encoder3.4",
+             "decoder0.0", "decoder0.3", "decoder1.0", "decoder1.3", "decoder2.0", "decoder2.2", "decoder2.4")
+NET_BNS = ("encoder1.3", "encoder2.3", "encoder3.3", "decoder0.2", "decoder1.2")
+
+
+class GpuNet:
+    """The IISPT network on the device (iile_iispt_net_*): built from a state_dict with the reference's entry names
+    (numpy arrays or torch tensors), run on device pointers."""
+
+    def __init__(self, state_dict, bn_eps=1e-5):
+        self._lib = gpu_lib()
+        self._h = c_vp()
+        keep = []
+
+        def arr(name):
+            t = state_dict[name]
+            a = np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+            keep.append(a)
+            return a.ctypes.data
+
+        w = NetWeights()
+        for i, k in enumerate(NET_CONVS):
+            w.conv_weight[i], w.conv_bias[i] = arr(k + ".weight"), arr(k + ".bias")
+        for i, k in enumerate(NET_BNS):
+            w.bn_weight[i], w.bn_bias[i] = arr(k + ".weight"), arr(k + ".bias")
+            w.bn_mean[i], w.bn_var[i] = arr(k + ".running_mean"), arr(k + ".running_var")
+        w.bn_eps = bn_eps
+        rc = self._lib.iile_iispt_net_create(ctypes.byref(w), ctypes.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"iile_iispt_net_create failed ({rc}): {self._lib.iile_last_error().decode()}")
+
+    def forward(self, in_ptr, out_ptr, n, max_batch=0, stream=None, layer_out_ptr=None, layer=0):
+        """(n, 7, 32, 32) -> (n, 3, 32, 32), device pointers; queued on `stream`."""
+        rc = self._lib.iile_iispt_net_forward(self._h, in_ptr, out_ptr, int(n), int(max_batch), stream, layer_out_ptr, int(layer))
+        if rc != 0:
+            raise RuntimeError(f"iile_iispt_net_forward failed ({rc}): {self._lib.iile_last_error().decode()}")
+
+    def close(self):
+        if self._h:
+            self._lib.iile_iispt_net_destroy(self._h)
+            self._h = c_vp()
 
     def __del__(self):
         try:

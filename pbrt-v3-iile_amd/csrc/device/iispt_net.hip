@@ -1,0 +1,524 @@
+// iispt_net.hip — the IISPT network (ml/iispt_net.py:8-109) as hand-written gfx950 kernels behind a C ABI
+// (include/iile_gpu.h, iile_iispt_net_*). The reference pipes every probe through a child Python process that runs this
+// U-Net in fp32 on one CPU thread (ml/main_stdio_net.py:44-106, 47 ms per probe, Doc.md:55-64); here a batch of thousands
+// of probes runs layer by layer over activations that stay in HBM.
+//
+// Arithmetic. gfx950's fp32 matrix pipe runs at the vector rate (157 TFLOP/s), its bf16 pipe sixteen times faster, so
+// every 3 x 3 convolution is an implicit GEMM on v_mfma_f32_32x32x16_bf16 over SPLIT operands: a = a_hi + a_lo with
+// a_hi = bf16(a), a_lo = bf16(a - a_hi) (16 significant bits), and the product a * w is accumulated in fp32 as
+// a_hi w_hi + a_hi w_lo + a_lo w_hi (the dropped a_lo w_lo term is 2^-16 of the product). Three matrix instructions per
+// tile instead of one; against the reference module's output (tests/golden/iispt_net_fixture.npz) the whole network lands
+// 3e-5 of the largest value away, the bound held by tests/test_iispt_nn.py being 1e-4 (plain bf16: 2.2e-2).
+//
+// Layout. Activations: NHWC fp32, one tensor per layer. Weights: packed once on the host into the matrix instruction's
+// B-fragment order, hi and lo, k = (channel chunk, tap, channel in chunk) — a wave reads 4 KB contiguous per k-step straight
+// from L2 into registers (every workgroup walks the same few MB). A workgroup (4 waves) owns 256 pixels x 64 output
+// channels; per chunk of input channels it stages the 256 pixels plus their one-pixel halo into LDS as bf16 hi / lo rows
+// (80-byte rows: conflict-free ds_read_b128), applying on the way whatever sits in front of the convolution in the
+// reference's Sequential: MaxPool2d(2) (max of four loads), or Upsample(x2, bilinear) + torch.cat (four loads and the
+// blend for the channels that come from the level below, one load for the skip channels). Behind it: bias, LeakyReLU(0.2)
+// and the eval-mode BatchNorm2d affine in the accumulator registers, then one 128-byte store per 32 lanes.
+// ConvTranspose2d(k = 3, stride 1, padding 1) is the same convolution with the kernel mirrored and its channel axes
+// swapped (done by the packer).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/iile_gpu.h"
+
+namespace iile {
+int api_fail(int code, const std::string &msg);
+}
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+enum { PRE_NONE = 0, PRE_POOL = 1, PRE_UPCAT = 2 };
+
+constexpr int kBM = 256;      // pixels per workgroup
+constexpr int kBN = 64;       // output channels per workgroup
+constexpr int kThreads = 256;
+
+// geometry of one workgroup's pixel tile for H x H images
+template <int H>
+struct Tile {
+    static constexpr int ROWS = H >= 32 ? kBM / H : H;            // image rows per tile
+    static constexpr int IMGS = H >= 32 ? 1 : kBM / (H * H);      // whole images per tile (H < 32)
+    static constexpr int TILES_PER_IMG = H >= 32 ? H / ROWS : 1;
+    static constexpr int HP = ROWS + 2, WP = H + 2;               // haloed extent
+    static constexpr int NLP = IMGS * HP * WP;                    // haloed pixels staged per chunk
+};
+
+__device__ inline void split_store(float4 v, char *hi, char *lo) {
+    // a = hi + lo, both bf16 (round to nearest even); a - float(hi) is exact in fp32
+    f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+    uint32_t ua = __builtin_bit_cast(uint32_t, ha), ub = __builtin_bit_cast(uint32_t, hb);
+    f32x2 ra = {v.x - __builtin_bit_cast(float, ua << 16), v.y - __builtin_bit_cast(float, ua & 0xffff0000u)};
+    f32x2 rb = {v.z - __builtin_bit_cast(float, ub << 16), v.w - __builtin_bit_cast(float, ub & 0xffff0000u)};
+    bf16x2 la = __builtin_convertvector(ra, bf16x2), lb = __builtin_convertvector(rb, bf16x2);
+    *reinterpret_cast<uint2 *>(hi) = make_uint2(ua, ub);
+    *reinterpret_cast<uint2 *>(lo) = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+}
+
+__device__ inline float4 max4(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
+__device__ inline float4 lerp4(float wa, float4 a, float wb, float4 b) {
+    return make_float4(wa * a.x + wb * b.x, wa * a.y + wb * b.y, wa * a.z + wb * b.z, wa * a.w + wb * b.w);
+}
+
+// nn.Upsample(scale_factor=2, mode="bilinear") (align_corners False): source index and weight of destination d
+__device__ inline void up_coord(int d, int n_in, int &i0, int &i1, float &l1) {
+    float s = (float(d) + 0.5f) * 0.5f - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = int(s);
+    i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+    l1 = s - float(i0);
+}
+
+struct ConvArgs {
+    const float *in0;      // PRE_NONE: [n][H][H][CIN]; PRE_POOL: [n][2H][2H][CIN]; PRE_UPCAT: the level below, [n][H/2][H/2][CIN/2]
+    const float *in1;      // PRE_UPCAT: the skip tensor [n][H][H][CIN/2]
+    const uint4 *wpack;    // [COUT/64][k-steps][n-tile 2][hi, lo][lane 64] x 16 bytes
+    const float *bias, *bn_scale, *bn_shift;   // [COUT]; bn_* only when BNORM
+    float *out;            // [n][H][H][COUT]
+    int n_img;
+};
+
+// One 3 x 3, padding-1 convolution layer with its pre- and post-operations (file header).
+template <int H, int CIN, int COUT, int PRE, int CHUNK, bool BNORM>
+__global__ __launch_bounds__(kThreads, 2) void k_conv3x3(ConvArgs p) {
+    using T = Tile<H>;
+    constexpr int ROWB = CHUNK * 2 + 16;          // bytes per staged pixel and plane: odd multiple of 16 -> conflict-free b128 reads
+    constexpr int NCHUNK = CIN / CHUNK;
+    constexpr int SUB = CHUNK / 16;               // k-steps per tap and chunk
+    constexpr int NT = COUT / kBN;
+    constexpr int C4 = CHUNK / 4;                 // float4 items per staged pixel
+    constexpr int KSTEPS = NCHUNK * 9 * SUB;
+    static_assert(CIN % CHUNK == 0 && COUT % kBN == 0 && CHUNK % 16 == 0, "shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_hi = smem, *s_lo = smem + T::NLP * ROWB;
+
+    // blocks b, b + 8, b + 16 ... share an XCD's L2 under round-robin placement (speed only): give those the same pixels
+    const int b = blockIdx.x;
+    const int grp = b / (8 * NT), in_grp = b % (8 * NT);
+    const int mtile = grp * 8 + (in_grp & 7), ntile = in_grp >> 3;
+    const int n_mtiles = H >= 32 ? p.n_img * T::TILES_PER_IMG : (p.n_img + T::IMGS - 1) / T::IMGS;
+    if (mtile >= n_mtiles) return;
+    const int img0 = H >= 32 ? mtile / T::TILES_PER_IMG : mtile * T::IMGS;
+    const int y0 = H >= 32 ? (mtile % T::TILES_PER_IMG) * T::ROWS : 0;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // the two 32-pixel row blocks of this wave: staged-pixel index of each lane's pixel (tap 0, 0)
+    int lp_c[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int m = wave * 64 + mt * 32 + r;
+        int il = m / (T::ROWS * H), y = (m / H) % T::ROWS, x = m % H;
+        lp_c[mt] = (il * T::HP + y + 1) * T::WP + x + 1;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const uint4 *wp = p.wpack + size_t(ntile) * KSTEPS * 256 + lane;
+
+    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+        if (chunk) __syncthreads();   // every wave has read the previous chunk
+        // ---- stage the haloed tile of channels [chunk * CHUNK, + CHUNK) ----
+        const int c_base = chunk * CHUNK;
+        for (int it = tid; it < T::NLP * C4; it += kThreads) {
+            int lp = it / C4, c4 = it % C4;
+            int il = lp / (T::HP * T::WP), rem = lp % (T::HP * T::WP);
+            int y = y0 + rem / T::WP - 1, x = rem % T::WP - 1;
+            int img = img0 + il;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < H && x >= 0 && x < H && img < p.n_img) {
+                int c = c_base + c4 * 4;
+                if (PRE == PRE_NONE) {
+                    v = *reinterpret_cast<const float4 *>(p.in0 + ((size_t(img) * H + y) * H + x) * CIN + c);
+                } else if (PRE == PRE_POOL) {
+                    const float *q = p.in0 + ((size_t(img) * 2 * H + 2 * y) * 2 * H + 2 * x) * CIN + c;
+                    float4 a = *reinterpret_cast<const float4 *>(q), bb = *reinterpret_cast<const float4 *>(q + CIN);
+                    float4 cc = *reinterpret_cast<const float4 *>(q + 2 * H * CIN), d = *reinterpret_cast<const float4 *>(q + 2 * H * CIN + CIN);
+                    v = max4(max4(a, bb), max4(cc, d));
+                } else {
+                    constexpr int CU = CIN / 2, HL = H / 2;
+                    if (c < CU) {   // uniform per chunk: CU is a multiple of CHUNK
+                        int ya, yb, xa, xb;
+                        float ly, lx;
+                        up_coord(y, HL, ya, yb, ly);
+                        up_coord(x, HL, xa, xb, lx);
+                        const float *q = p.in0 + size_t(img) * HL * HL * CU + c;
+                        float4 a = *reinterpret_cast<const float4 *>(q + (ya * HL + xa) * CU), bb = *reinterpret_cast<const float4 *>(q + (ya * HL + xb) * CU);
+                        float4 cc = *reinterpret_cast<const float4 *>(q + (yb * HL + xa) * CU), d = *reinterpret_cast<const float4 *>(q + (yb * HL + xb) * CU);
+                        float4 top = lerp4(1.f - lx, a, lx, bb), bot = lerp4(1.f - lx, cc, lx, d);
+                        v = lerp4(1.f - ly, top, ly, bot);
+                    } else {
+                        v = *reinterpret_cast<const float4 *>(p.in1 + ((size_t(img) * H + y) * H + x) * CU + (c - CU));
+                    }
+                }
+            }
+            split_store(v, s_hi + lp * ROWB + c4 * 8, s_lo + lp * ROWB + c4 * 8);
+        }
+        __syncthreads();
+        // ---- 9 taps x SUB k-steps: no barrier inside; B fragments come straight from L2 ----
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = ((tap / 3 - 1) * T::WP + (tap % 3 - 1)) * ROWB;
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    bh[nt] = __builtin_bit_cast(bf16x8, wp[(nt * 2 + 0) * 64]);
+                    bl[nt] = __builtin_bit_cast(bf16x8, wp[(nt * 2 + 1) * 64]);
+                }
+                wp += 256;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    int off = lp_c[mt] * ROWB + toff + sub * 32 + h * 16;
+                    ah[mt] = *reinterpret_cast<const bf16x8 *>(s_hi + off);
+                    al[mt] = *reinterpret_cast<const bf16x8 *>(s_lo + off);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- bias, LeakyReLU(0.2), BatchNorm affine; accumulator column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h ----
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = ntile * kBN + nt * 32 + r;
+        const float bias = p.bias[co];
+        float sc = 1.f, sh = 0.f;
+        if (BNORM) {
+            sc = p.bn_scale[co];
+            sh = p.bn_shift[co];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int m = wave * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                int il = m / (T::ROWS * H), y = y0 + (m / H) % T::ROWS, x = m % H;
+                int img = img0 + il;
+                if (img >= p.n_img) continue;
+                float v = acc[mt][nt][e] + bias;
+                v = v > 0.f ? v : 0.2f * v;
+                if (BNORM) v = v * sc + sh;
+                p.out[((size_t(img) * H + y) * H + x) * COUT + co] = v;
+            }
+    }
+}
+
+// (n, 7, 32, 32) as the network sees it (read_input, ml/main_stdio_net.py:47-72) -> NHWC with the channels padded to 16
+__global__ void k_net_input(const float *in, float *x16, int n) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;   // one thread per pixel
+    if (i >= size_t(n) * 1024) return;
+    size_t img = i >> 10, px = i & 1023;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = c < 7 ? in[(img * 7 + c) * 1024 + px] : 0.f;
+    float4 *o = reinterpret_cast<float4 *>(x16 + i * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// decoder2's Conv2d(K, 3, 1) + ReLU: NHWC 64 channels -> (n, 3, 32, 32). 16 lanes per pixel, 4 channels each.
+__global__ void k_net_output(const float *in, const float *w /* [3][64] */, const float *bias, float *out, int n) {
+    size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t pix = t >> 4;
+    int q = int(t & 15);
+    bool live = pix < size_t(n) * 1024;
+    float4 v = live ? *reinterpret_cast<const float4 *>(in + pix * 64 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float *wo = w + o * 64 + q * 4;
+        s[o] = v.x * wo[0] + v.y * wo[1] + v.z * wo[2] + v.w * wo[3];
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) s[o] += __shfl_xor(s[o], d, 16);
+    }
+    if (live && q < 3) {
+        float r = (q == 0 ? s[0] : q == 1 ? s[1] : s[2]) + bias[q];
+        size_t img = pix >> 10, px = pix & 1023;
+        out[(img * 3 + q) * 1024 + px] = r > 0.f ? r : 0.f;
+    }
+}
+
+// ---- host side ----
+
+struct LayerDef {
+    int h, cin, cout, pre, chunk;
+    bool bn, deconv;
+    int cin_real;   // channels the checkpoint has (7 for the first layer, padded to 16 with zero weights)
+};
+// forward order (ml/iispt_net.py:27-88): encoder0.0, encoder0.2, encoder1.1, encoder1.4, encoder2.1, encoder2.4, encoder3.1,
+// encoder3.4, decoder0.0, decoder0.3, decoder1.0, decoder1.3, decoder2.0, decoder2.2 (decoder2.4 is k_net_output)
+const LayerDef kLayers[14] = {
+    {32, 16, 64, PRE_NONE, 16, false, false, 7},  {32, 64, 64, PRE_NONE, 32, false, false, 64},
+    {16, 64, 128, PRE_POOL, 32, true, false, 64}, {16, 128, 128, PRE_NONE, 32, false, false, 128},
+    {8, 128, 256, PRE_POOL, 32, true, false, 128}, {8, 256, 256, PRE_NONE, 32, false, false, 256},
+    {4, 256, 512, PRE_POOL, 16, true, false, 256}, {4, 512, 256, PRE_NONE, 16, false, false, 512},
+    {8, 512, 256, PRE_UPCAT, 32, true, true, 512}, {8, 256, 128, PRE_NONE, 32, false, true, 256},
+    {16, 256, 128, PRE_UPCAT, 32, true, true, 256}, {16, 128, 64, PRE_NONE, 32, false, true, 128},
+    {32, 128, 64, PRE_UPCAT, 32, false, true, 128}, {32, 64, 64, PRE_NONE, 32, false, true, 64},
+};
+const int kBnOfLayer[14] = {-1, -1, 0, -1, 1, -1, 2, -1, 3, -1, 4, -1, -1, -1};
+
+uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return uint16_t((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);   // weights are finite
+}
+float bf16_to_float(uint16_t b) {
+    uint32_t u = uint32_t(b) << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+template <int H, int CIN, int COUT, int PRE, int CHUNK, bool BNORM>
+hipError_t launch_conv(const ConvArgs &a, hipStream_t s) {
+    using T = Tile<H>;
+    constexpr int ROWB = CHUNK * 2 + 16;
+    constexpr size_t lds = size_t(T::NLP) * ROWB * 2;
+    static bool attr_set = false;
+    auto kern = k_conv3x3<H, CIN, COUT, PRE, CHUNK, BNORM>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int n_mtiles = H >= 32 ? a.n_img * T::TILES_PER_IMG : (a.n_img + T::IMGS - 1) / T::IMGS;
+    int groups = (n_mtiles + 7) / 8;
+    int blocks = groups * 8 * (COUT / kBN);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_layer(int layer, const ConvArgs &a, hipStream_t s) {
+    switch (layer) {
+        case 0: return launch_conv<32, 16, 64, PRE_NONE, 16, false>(a, s);
+        case 1: return launch_conv<32, 64, 64, PRE_NONE, 32, false>(a, s);
+        case 2: return launch_conv<16, 64, 128, PRE_POOL, 32, true>(a, s);
+        case 3: return launch_conv<16, 128, 128, PRE_NONE, 32, false>(a, s);
+        case 4: return launch_conv<8, 128, 256, PRE_POOL, 32, true>(a, s);
+        case 5: return launch_conv<8, 256, 256, PRE_NONE, 32, false>(a, s);
+        case 6: return launch_conv<4, 256, 512, PRE_POOL, 16, true>(a, s);
+        case 7: return launch_conv<4, 512, 256, PRE_NONE, 16, false>(a, s);
+        case 8: return launch_conv<8, 512, 256, PRE_UPCAT, 32, true>(a, s);
+        case 9: return launch_conv<8, 256, 128, PRE_NONE, 32, false>(a, s);
+        case 10: return launch_conv<16, 256, 128, PRE_UPCAT, 32, true>(a, s);
+        case 11: return launch_conv<16, 128, 64, PRE_NONE, 32, false>(a, s);
+        case 12: return launch_conv<32, 128, 64, PRE_UPCAT, 32, false>(a, s);
+        case 13: return launch_conv<32, 64, 64, PRE_NONE, 32, false>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// floats per probe of each activation tensor; buffer assignment (two ping-pong buffers P, Q and the three skip tensors)
+enum { BUF_P = 0, BUF_Q = 1, BUF_E0 = 2, BUF_E1 = 3, BUF_E2 = 4, N_BUF = 5 };
+const size_t kBufFloats[N_BUF] = {65536, 65536, 65536, 32768, 16384};
+// per layer: {in0, in1 (-1: none), out}; the network input (padded to 16 channels) sits in P
+const int kRoute[14][3] = {
+    {BUF_P, -1, BUF_Q},  {BUF_Q, -1, BUF_E0}, {BUF_E0, -1, BUF_P}, {BUF_P, -1, BUF_E1}, {BUF_E1, -1, BUF_P}, {BUF_P, -1, BUF_E2},
+    {BUF_E2, -1, BUF_P}, {BUF_P, -1, BUF_Q},  {BUF_Q, BUF_E2, BUF_P}, {BUF_P, -1, BUF_Q}, {BUF_Q, BUF_E1, BUF_P}, {BUF_P, -1, BUF_Q},
+    {BUF_Q, BUF_E0, BUF_P}, {BUF_P, -1, BUF_Q},
+};
+
+}  // namespace
+
+struct iile_iispt_net {
+    uint4 *wpack[14] = {};
+    float *bias[14] = {};
+    float *bn_scale[5] = {}, *bn_shift[5] = {};
+    float *w_out = nullptr, *b_out = nullptr;
+    float *ws = nullptr;      // activations of the current batch
+    int ws_probes = 0;
+    std::vector<void *> allocs;
+};
+
+#define NET_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return iile::api_fail(IILE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+int net_upload(iile_iispt_net *net, const void *host, size_t bytes, void **dev) {
+    void *p = nullptr;
+    NET_TRY(hipMalloc(&p, bytes));
+    net->allocs.push_back(p);
+    NET_TRY(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+    *dev = p;
+    return IILE_OK;
+}
+
+// B fragments of v_mfma_f32_32x32x16_bf16: lane l holds B[k = 8 (l >> 5) + j][column l & 31], j = 0..7
+std::vector<uint16_t> pack_weights(const LayerDef &L, const float *w) {
+    const int sub = L.chunk / 16, nchunk = L.cin / L.chunk, ksteps = nchunk * 9 * sub, ntiles = L.cout / kBN;
+    std::vector<uint16_t> out(size_t(ntiles) * ksteps * 256 * 8);
+    for (int nt64 = 0; nt64 < ntiles; ++nt64)
+        for (int chunk = 0; chunk < nchunk; ++chunk)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int s = 0; s < sub; ++s) {
+                    int ks = (chunk * 9 + tap) * sub + s;
+                    int ky = tap / 3, kx = tap % 3;
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                int ci = chunk * L.chunk + s * 16 + 8 * (lane >> 5) + j;
+                                int co = nt64 * kBN + nt * 32 + (lane & 31);
+                                float v = 0.f;
+                                if (ci < L.cin_real) {
+                                    if (!L.deconv)   // Conv2d: weight[co][ci][ky][kx]
+                                        v = w[((size_t(co) * L.cin_real + ci) * 3 + ky) * 3 + kx];
+                                    else             // ConvTranspose2d: weight[ci][co][ky][kx], mirrored
+                                        v = w[((size_t(ci) * L.cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+                                }
+                                uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_float(hi));
+                                size_t base = ((size_t(nt64) * ksteps + ks) * 4 + nt * 2) * 64 * 8;
+                                out[base + size_t(lane) * 8 + j] = hi;
+                                out[base + 64 * 8 + size_t(lane) * 8 + j] = lo;
+                            }
+                }
+    return out;
+}
+
+int ensure_workspace(iile_iispt_net *net, int n) {
+    if (n <= net->ws_probes) return IILE_OK;
+    if (net->ws) (void)hipFree(net->ws);
+    net->ws = nullptr;
+    net->ws_probes = 0;
+    size_t per = 0;
+    for (size_t f : kBufFloats) per += f;
+    NET_TRY(hipMalloc(reinterpret_cast<void **>(&net->ws), per * sizeof(float) * size_t(n)));
+    net->ws_probes = n;
+    return IILE_OK;
+}
+
+float *buffer_of(iile_iispt_net *net, int buf, int n_alloc) {
+    size_t off = 0;
+    for (int i = 0; i < buf; ++i) off += kBufFloats[i] * size_t(n_alloc);
+    return net->ws + off;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iile_iispt_net_create(const iile_iispt_net_weights *w, iile_iispt_net **out) {
+    if (!w || !out) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return iile::api_fail(IILE_ERR_NO_DEVICE, "iile_iispt_net_create: no HIP device (the network has no CPU fallback)");
+    for (int i = 0; i < 15; ++i)
+        if (!w->conv_weight[i] || !w->conv_bias[i]) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_create: missing convolution tensor");
+    auto *net = new iile_iispt_net();
+    auto bail = [&](int rc) {
+        iile_iispt_net_destroy(net);
+        return rc;
+    };
+    for (int l = 0; l < 14; ++l) {
+        std::vector<uint16_t> pk = pack_weights(kLayers[l], w->conv_weight[l]);
+        int rc = net_upload(net, pk.data(), pk.size() * 2, reinterpret_cast<void **>(&net->wpack[l]));
+        if (rc) return bail(rc);
+        rc = net_upload(net, w->conv_bias[l], size_t(kLayers[l].cout) * 4, reinterpret_cast<void **>(&net->bias[l]));
+        if (rc) return bail(rc);
+        int bn = kBnOfLayer[l];
+        if (bn >= 0) {
+            // BatchNorm2d in eval mode: y = (x - running_mean) / sqrt(running_var + eps) * weight + bias
+            int c = kLayers[l].cout;
+            std::vector<float> sc(c), sh(c);
+            for (int i = 0; i < c; ++i) {
+                float inv = 1.0f / std::sqrt(w->bn_var[bn][i] + w->bn_eps);
+                sc[i] = inv * w->bn_weight[bn][i];
+                sh[i] = w->bn_bias[bn][i] - w->bn_mean[bn][i] * sc[i];
+            }
+            rc = net_upload(net, sc.data(), size_t(c) * 4, reinterpret_cast<void **>(&net->bn_scale[bn]));
+            if (rc) return bail(rc);
+            rc = net_upload(net, sh.data(), size_t(c) * 4, reinterpret_cast<void **>(&net->bn_shift[bn]));
+            if (rc) return bail(rc);
+        }
+    }
+    int rc = net_upload(net, w->conv_weight[14], 3 * 64 * 4, reinterpret_cast<void **>(&net->w_out));
+    if (rc) return bail(rc);
+    rc = net_upload(net, w->conv_bias[14], 3 * 4, reinterpret_cast<void **>(&net->b_out));
+    if (rc) return bail(rc);
+    *out = net;
+    return IILE_OK;
+}
+
+void iile_iispt_net_destroy(iile_iispt_net *net) {
+    if (!net) return;
+    for (void *p : net->allocs) (void)hipFree(p);
+    if (net->ws) (void)hipFree(net->ws);
+    delete net;
+}
+
+int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_dev, int32_t n, int32_t max_batch, void *stream,
+                           float *layer_out_dev, int32_t layer) {
+    if (!net || !in_dev || !out_dev || n < 0) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_forward: bad argument");
+    if (layer_out_dev && (layer < 0 || layer > 13)) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_forward: layer out of range");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (max_batch <= 0) max_batch = 16384;
+    const int cap = n < max_batch ? n : max_batch;
+    if (n == 0) return IILE_OK;
+    int rc = ensure_workspace(net, cap);
+    if (rc) return rc;
+    const int na = net->ws_probes;
+    for (int first = 0; first < n; first += cap) {
+        const int nb = n - first < cap ? n - first : cap;
+        hipLaunchKernelGGL(k_net_input, dim3((size_t(nb) * 1024 + 255) / 256), dim3(256), 0, s, in_dev + size_t(first) * 7 * 1024,
+                           buffer_of(net, BUF_P, na), nb);
+        NET_TRY(hipGetLastError());
+        for (int l = 0; l < 14; ++l) {
+            ConvArgs a{};
+            a.in0 = buffer_of(net, kRoute[l][0], na);
+            a.in1 = kRoute[l][1] >= 0 ? buffer_of(net, kRoute[l][1], na) : nullptr;
+            a.out = buffer_of(net, kRoute[l][2], na);
+            a.wpack = net->wpack[l];
+            a.bias = net->bias[l];
+            int bn = kBnOfLayer[l];
+            a.bn_scale = bn >= 0 ? net->bn_scale[bn] : nullptr;
+            a.bn_shift = bn >= 0 ? net->bn_shift[bn] : nullptr;
+            a.n_img = nb;
+            NET_TRY(launch_layer(l, a, s));
+            if (layer_out_dev && l == layer) {   // test probe: this layer's NHWC activations
+                size_t fl = size_t(kLayers[l].h) * kLayers[l].h * kLayers[l].cout;
+                NET_TRY(hipMemcpyAsync(layer_out_dev + size_t(first) * fl, a.out, fl * size_t(nb) * 4, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        hipLaunchKernelGGL(k_net_output, dim3((size_t(nb) * 1024 * 16 + 255) / 256), dim3(256), 0, s, buffer_of(net, BUF_Q, na), net->w_out,
+                           net->b_out, out_dev + size_t(first) * 3 * 1024, nb);
+        NET_TRY(hipGetLastError());
+    }
+    return IILE_OK;
+}
+
+}  // extern "C"

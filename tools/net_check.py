@@ -1,0 +1,102 @@
+"""The hand-written IISPT network (iile_iispt_net_*) on the GPU: layer-by-layer agreement with the PyTorch module on the CPU,
+the reference fixture, and its time per batch beside eager PyTorch + MIOpen. usage: net_check.py [n_time] [--no-torch]"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+b = importlib.import_module("pbrt-v3-iile_amd.binding")
+import iispt_net_recipe as recipe
+
+# the module index whose OUTPUT is convolution layer l's output as the kernel writes it (behind LeakyReLU / BatchNorm)
+TAPS = [("encoder0", 1), ("encoder0", 3), ("encoder1", 3), ("encoder1", 5), ("encoder2", 3), ("encoder2", 5), ("encoder3", 3),
+        ("encoder3", 5), ("decoder0", 2), ("decoder0", 4), ("decoder1", 2), ("decoder1", 4), ("decoder2", 1), ("decoder2", 3)]
+
+
+def main():
+    n_time = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8192
+    torch.cuda.init()
+    fx = np.load(os.path.join(REPO, "tests", "golden", "iispt_net_fixture.npz"))
+    net = nn_mod.IISPTNet()
+    recipe.fill_state_dict(net)
+    net.eval()
+    g = b.GpuNet(net.state_dict())
+    res = {}
+    # fixture
+    x = torch.from_numpy(fx["input"]).cuda()
+    y = torch.empty((4, 3, 32, 32), device="cuda")
+    g.forward(x.data_ptr(), y.data_ptr(), 4)
+    torch.cuda.synchronize()
+    want = fx["output"]
+    res["fixture_err_over_max"] = float(np.abs(y.cpu().numpy() - want).max() / np.abs(want).max())
+    # layer by layer, a batch that fills no tile exactly
+    n = 37
+    xin = torch.from_numpy(recipe.fixture_input(n))
+    acts = {}
+    hooks = []
+    for l, (blk, idx) in enumerate(TAPS):
+        hooks.append(getattr(net, blk)[idx].register_forward_hook(lambda m, i, o, l=l: acts.__setitem__(l, o.detach())))
+    with torch.no_grad():
+        ref = net(xin)
+    for h in hooks:
+        h.remove()
+    xd = xin.cuda()
+    yd = torch.empty((n, 3, 32, 32), device="cuda")
+    res["layers"] = []
+    for l in range(14):
+        a = acts[l]
+        lo = torch.empty((n, a.shape[2], a.shape[3], a.shape[1]), device="cuda")
+        g.forward(xd.data_ptr(), yd.data_ptr(), n, layer_out_ptr=lo.data_ptr(), layer=l)
+        torch.cuda.synchronize()
+        got = lo.cpu().permute(0, 3, 1, 2)
+        err = float((got - a).abs().max() / a.abs().max())
+        res["layers"].append(round(err, 9))
+    res["n37_err_over_max"] = float((yd.cpu() - ref).abs().max() / ref.abs().max())
+    # small batches through the max_batch path
+    yd2 = torch.empty_like(yd)
+    g.forward(xd.data_ptr(), yd2.data_ptr(), n, max_batch=10)
+    torch.cuda.synchronize()
+    res["sub_batches_equal"] = bool(torch.equal(yd, yd2))
+    # time
+    xt = torch.from_numpy(recipe.fixture_input(64)).cuda().repeat((n_time + 63) // 64, 1, 1, 1)[:n_time].contiguous()
+    yt = torch.empty((n_time, 3, 32, 32), device="cuda")
+    for _ in range(2):
+        g.forward(xt.data_ptr(), yt.data_ptr(), n_time)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    reps = 5
+    for _ in range(reps):
+        g.forward(xt.data_ptr(), yt.data_ptr(), n_time)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / reps
+    res["hip_net"] = {"n": n_time, "ms": dt * 1e3, "tflops_fp32_equiv": 0.99e9 * n_time / dt / 1e12}
+    if "--no-torch" not in sys.argv:
+        netc = net.cuda().to(memory_format=torch.channels_last)
+        xc = xt.contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            for _ in range(2):
+                yy = netc(xc)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(reps):
+                yy = netc(xc)
+            torch.cuda.synchronize()
+        dt2 = (time.time() - t0) / reps
+        res["torch_miopen"] = {"n": n_time, "ms": dt2 * 1e3, "tflops": 0.99e9 * n_time / dt2 / 1e12}
+        res["hip_vs_torch_err_over_max"] = float((yt - yy).abs().max() / yy.abs().max())
+    print(json.dumps(res))
+    out = os.path.join(REPO, "gpurun_out", "net_check.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
