@@ -177,6 +177,192 @@ def load_vmem_calibration():
     return {}, None
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: the IISPT integrator's frame (--workload iispt)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md ("~2.5 PF dense")
+MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-input matrix instructions run at the vector rate (same guide)
+# IISPTNet.forward per probe (ml/iispt_net.py:8-109): 2 * k * k * C_in * C_out * H * W over its 15 convolutions
+NET_FLOP_PER_PROBE = 2 * 9 * (7 * 64 * 1024 + 64 * 64 * 1024 + 64 * 128 * 256 + 128 * 128 * 256 + 128 * 256 * 64 + 256 * 256 * 64
+                              + 256 * 512 * 16 + 512 * 256 * 16 + 512 * 256 * 64 + 256 * 128 * 64 + 256 * 128 * 256 + 128 * 64 * 256
+                              + 128 * 64 * 1024 + 64 * 64 * 1024) + 2 * 64 * 3 * 1024
+
+
+def iispt_cpu_baseline(b, nn_mod, frame_mod, scene, net_module, target_seconds):
+    """The reference's per-probe loop on this box's host, on a bounded sample: the CPU oracle's hemi points of the frame's
+    first task(s), one oracle probe render per point, the network ONE probe at a time on ONE thread (as
+    ml/main_stdio_net.py:104-118 runs it: torch.set_num_threads(1), one `net(x)` per request), the oracle's gather."""
+    import numpy as np
+    import torch
+    import oracle_binding as ob
+    orc = ob.Oracle()
+    h, w = scene.film_shape
+    torch.set_num_threads(1)
+    net_module = net_module.cpu().eval()
+    t_probe = t_net = t_gather = t_hemi = 0.0
+    n_probes = n_pixels = n_tasks = 0
+    counter = 0
+    t_start = time.perf_counter()
+    for (x0, y0, x1, y1, ts) in frame_mod.schedule((0, 0, w, h), 10 ** 6, 10.0):
+        task = b.IisptTask(x0, y0, x1, y1, ts, counter, 0)
+        nx, ny = task.grid()
+        t0 = time.perf_counter()
+        valid, pos, dr = orc.iispt_hemi_points(scene, task, trig_mode=ob.TRIG_LIBM)
+        t_hemi += time.perf_counter() - t0
+        nn_films = np.zeros((ny * nx, 32, 32, 3), np.float32)
+        for i in np.flatnonzero(valid.reshape(-1) == 1):
+            t0 = time.perf_counter()
+            inten, nrm, dist = orc.render_probe(scene, pos.reshape(-1, 3)[i], dr.reshape(-1, 3)[i], trig_mode=ob.TRIG_LIBM)
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                x, means = nn_mod.normalize_downstream(torch.from_numpy(inten[None]), torch.from_numpy(nrm[None]), torch.from_numpy(dist[None]))
+                pred = nn_mod.transform_upstream(net_module(x), means)
+            nn_films[i] = pred[0].numpy()[::-1]
+            t2 = time.perf_counter()
+            t_probe += t1 - t0
+            t_net += t2 - t1
+            n_probes += 1
+        t0 = time.perf_counter()
+        orc.iispt_gather(scene, task, valid, pos, dr, nn_films, trig_mode=ob.TRIG_LIBM)
+        t_gather += time.perf_counter() - t0
+        n_pixels += (x1 - x0) * (y1 - y0)
+        n_tasks += 1
+        counter += nx * ny + (x1 - x0) * (y1 - y0)
+        if time.perf_counter() - t_start > target_seconds:
+            break
+    total = t_hemi + t_probe + t_net + t_gather
+    return {"value": round(n_probes / max(total, 1e-9), 3), "unit": "probes/s", "cores": 1, "kind": "port",
+            "sample": f"the first {n_tasks} task(s) of the frame's schedule (100 x 100 pixels each): {n_probes} probes, {n_pixels} pixels gathered, "
+                      f"{total:.1f} s on one thread (hemi points {t_hemi:.2f} s, probe renders {t_probe:.2f} s, network + transforms {t_net:.2f} s, gather {t_gather:.2f} s)",
+            "ms_per_probe": {"probe_render": round(t_probe / max(n_probes, 1) * 1e3, 2), "network_and_transforms": round(t_net / max(n_probes, 1) * 1e3, 2)},
+            "reference_quoted_ms_per_probe": {"network_round_trip": 47, "network_alone": 27, "source": "Doc.md:55-64 (the reference authors' machine)"},
+            "note": "a port, not the reference binary: the CPU oracle (oracle/) for hemi points, probe renders and the gather, and the PyTorch module on "
+                    "ONE thread, one probe per call, for the network — the reference's IISPT runner is one process per render thread piping each "
+                    "probe to a single-threaded Python child (ml/main_stdio_net.py:106); its other threads would scale this by the host's cores"}
+
+
+def main_iispt(args):
+    """One step = one IISPT frame over killeroo-simple at args.xres x args.yres (default 1080p): the indirect pass at radius 10
+    (IisptRenderRunner::run over one sweep of the schedule: hemi points, probe pass, network, gather), the direct pass (16 passes
+    of DirectProgressiveIntegrator) and the merge of the two film monitors (pbrt-v3-iile_amd/iispt_frame.py). Prints the
+    contract's line: value = probes per second over the whole frame; roofline = the network's convolution kernels against the
+    bf16 matrix peak; cpu_baseline = the reference's per-probe loop on one host thread on a bounded sample."""
+    import importlib
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    compiled_now = ge.build_if_needed()
+    b = ge._load_binding()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--workload iispt is a one-GPU workload (the frame's tasks do not shard in the reference either: "
+                         "its render threads share one schedule monitor); run --gpus 1")
+    torch.cuda.set_device(0)
+    nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+    frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
+    scene = b.HostScene(path=args.scene, xres=args.xres, yres=args.yres, spp=1)
+    gpu = b.GpuScene(scene)
+    torch.manual_seed(0)
+    module = nn_mod.IISPTNet().eval()   # no trained weights ship with the reference: random-initialised, same architecture and cost
+    pipe = nn_mod.IisptPipeline(gpu, net=module, binding=b)
+    radius = 10.0
+    size = int(radius) * frame_mod.NUMBER_TILES
+    n_tasks = -(-args.xres // size) * -(-args.yres // size)
+
+    def step(record=None):
+        pipe.events = record
+        frame = frame_mod.IisptFrame(b, gpu, pipe)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        frame.run_batched(n_tasks, radius_start=radius)
+        ev[1].record()
+        frame.run_direct(frame_mod.DIRECT_SAMPLES)
+        ev[2].record()
+        img = frame.image()
+        ev[3].record()
+        pipe.events = None
+        return frame, img, ev
+
+    for _ in range(max(args.warmup, 1)):   # (the first frame allocates the workspaces)
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    stage_events, frame_events = [], []
+    for _ in range(args.steps):
+        rec = []
+        last = step(rec)
+        stage_events.append(rec)
+        frame_events.append(last[2])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    frame, img, _ = last
+    probes = frame.stats["probes"]
+    stage_ms = {}
+    for rec in stage_events:
+        for name, e0, e1 in rec:
+            stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / args.steps
+    indirect_ms = sum(e[0].elapsed_time(e[1]) for e in frame_events) / args.steps
+    stage_ms["hemi_points_gather_and_film"] = indirect_ms - sum(stage_ms.values())
+    stage_ms["direct_pass_16"] = sum(e[1].elapsed_time(e[2]) for e in frame_events) / args.steps
+    stage_ms["merge"] = sum(e[2].elapsed_time(e[3]) for e in frame_events) / args.steps
+    # the network alone, over the frame's probes: HIP events around iile_iispt_net_forward on its stream (the `network` stage)
+    net_ms = stage_ms["network"]
+    net_launches = sum(1 for n_, _, _ in stage_events[-1] if n_ == "network")
+    flop = NET_FLOP_PER_PROBE * probes
+    ach = flop / (net_ms * 1e-3) / 1e12
+    # agreement of the timed network with the PyTorch module on the CPU, on a sample of the frame's own probes
+    chk = {}
+    with torch.no_grad():
+        rng = np.random.default_rng(0)
+        pos = rng.uniform((-150, -100, -130), (250, 150, 0), (8, 3)).astype(np.float32)
+        d = rng.standard_normal((8, 3)).astype(np.float32)
+        _, inten, nrm, dist = pipe(pos, d)
+        x, _m = nn_mod.normalize_downstream(inten, nrm, dist)
+        y_hip = pipe.infer(x).cpu()
+        y_ref = module(x.cpu())
+        chk = {"probes": 8, "max_abs_err_over_max": float((y_hip - y_ref).abs().max() / max(float(y_ref.abs().max()), 1e-30)), "bound": 1e-4}
+    if not (chk["max_abs_err_over_max"] < 1e-4) or not bool(torch.isfinite(img).all()):
+        raise SystemExit(f"bench.py: the timed network disagrees with the PyTorch module ({chk}) or the frame is not finite; no number is reported")
+    out = {
+        "metric": "IISPT probes/s on killeroo-simple 1080p (one frame: hemi points + probe pass + network + gather, direct pass, merge)",
+        "value": round(probes * args.steps / elapsed, 1),
+        "unit": "probes/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 activations and accumulation; matrix products on bf16 pairs (hi + lo) of every operand",
+        "data": "scenes/killeroo-simple.pbrt; IISPTNet with random-initialised weights (none ship with the reference): the image means nothing, the work is the reference's",
+        "config": {"workload": f"IISPT frame, killeroo-simple {args.xres}x{args.yres}: radius 10 -> {n_tasks} tasks of 100 x 100 pixels, {frame.stats['hemi_points']} hemi points, "
+                               f"{probes} probes of 32 x 32, every pixel gathered from 4 probes; 16 direct passes; merge",
+                   "baseline_config": "5 (IISPT integrator: hemisphere probes + network on the GPU)", "xres": args.xres, "yres": args.yres,
+                   "probes": probes, "pixels": frame.stats["pixels"]},
+        "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
+        "stage_note": "HIP events on the stream every stage runs on; `hemi_points_gather_and_film` = the indirect pass minus its four timed stages",
+        "roofline": {
+            "kernel": "k_conv3x3 (the 14 3x3 convolutions of IISPTNet, csrc/device/iispt_net.hip; with the two layout kernels of a forward)",
+            "bound": "mfma",
+            "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "algorithmic_flop_per_unit": NET_FLOP_PER_PROBE, "units_per_step": probes,
+            "algorithmic_note": "2 k^2 C_in C_out H W over the network's 15 convolutions = 0.990 GFLOP per probe (fp32 multiply-adds of the reference's "
+                                "module); `achieved` = that x probes / the network's HIP-event time",
+            "executed_bf16_tflops": round(3 * ach, 1), "frac_executed": round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "executed_note": "every product runs as three bf16 matrix instructions (a_hi w_hi + a_hi w_lo + a_lo w_hi), so the matrix pipe executes 3x the "
+                             "algorithmic flops (the first layer also multiplies 9 zero-padded input channels)",
+            "vs_fp32_matrix_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 3),
+            "vs_fp32_matrix_peak_note": "the fp32-input matrix instructions peak at 157.3 TFLOP/s on gfx950: a ratio above 1 is what the split buys",
+            "network_ms_per_step": round(net_ms, 3), "forward_calls_per_step": net_launches,
+            "agreement_with_the_module": chk},
+        "built": ge.build_provenance(compiled_now),
+    }
+    if args.cpu_seconds > 0:
+        out["cpu_baseline"] = iispt_cpu_baseline(b, nn_mod, frame_mod, scene, module, args.cpu_seconds)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,16 +385,19 @@ def main():
     ap.add_argument("--sampler", choices=["halton", "sobol"], default=None,
                     help="sampler in place of the scene file's (sobol: what the fork's path integrator renders with under "
                          "IILE_PATH_SAMPLES_OVERRIDE; the headline metric is quoted with the scene's own Halton sampler)")
-    ap.add_argument("--workload", choices=["killeroo", "boxroom", "boxroom-textured"], default="killeroo",
+    ap.add_argument("--workload", choices=["killeroo", "boxroom", "boxroom-textured", "iispt"], default="killeroo",
                     help="boxroom: the synthetic ~287 k-triangle closed room of tests/boxroom.py (deep-BVH stress, "
                          "SURVEY.md 8d's stand-in for the Sponza config that does not ship with the reference); "
                          "boxroom-textured: the same room open to an environment-mapped sky, with image textures, "
-                         "alpha masks and specular materials (the whole feature set of SURVEY.md 8 f1)")
+                         "alpha masks and specular materials (the whole feature set of SURVEY.md 8 f1); "
+                         "iispt: BASELINE config 5, one frame of the IISPT integrator (probe pass, network, gather, direct pass)")
     args = ap.parse_args()
 
     bad_env = sorted(k for k in os.environ if k.startswith("IILE_DEBUG") or k.startswith("IILE_NO_"))
     if bad_env:
         raise SystemExit(f"bench.py refuses to run with {bad_env} set: those switches change what the kernels do")
+    if args.workload == "iispt":
+        return main_iispt(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

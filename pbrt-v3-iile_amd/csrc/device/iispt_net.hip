@@ -136,7 +136,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv3x3(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // B fragments of k-step ks sit at wp + ks * 256: {n-tile 0 hi, lo, n-tile 1 hi, lo} x 64 lanes x 16 bytes. The fragments of
+    // step ks + 1 (A from LDS, B from L2) are requested before the 12 matrix instructions of step ks are issued.
     const uint4 *wp = p.wpack + size_t(ntile) * KSTEPS * 256 + lane;
+    constexpr int KPC = 9 * SUB;   // k-steps per chunk
+    uint4 bq[2][4];
+    bf16x8 aq[2][4];               // {hi, lo} x {m-tile 0, 1}
+#pragma unroll
+    for (int f = 0; f < 4; ++f) bq[0][f] = wp[f * 64];
+
+    auto load_a = [&](int k, bf16x8(&dst)[4]) {   // k: k-step inside the chunk (compile-time after unrolling)
+        const int tap = k / SUB, sub = k % SUB;
+        const int toff = ((tap / 3 - 1) * T::WP + (tap % 3 - 1)) * ROWB + sub * 32 + h * 16;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            dst[mt * 2 + 0] = *reinterpret_cast<const bf16x8 *>(s_hi + lp_c[mt] * ROWB + toff);
+            dst[mt * 2 + 1] = *reinterpret_cast<const bf16x8 *>(s_lo + lp_c[mt] * ROWB + toff);
+        }
+    };
 
     for (int chunk = 0; chunk < NCHUNK; ++chunk) {
         if (chunk) __syncthreads();   // every wave has read the previous chunk
@@ -177,34 +194,33 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv3x3(ConvArgs p) {
             split_store(v, s_hi + lp * ROWB + c4 * 8, s_lo + lp * ROWB + c4 * 8);
         }
         __syncthreads();
-        // ---- 9 taps x SUB k-steps: no barrier inside; B fragments come straight from L2 ----
+        // ---- 9 taps x SUB k-steps: no barrier inside ----
+        load_a(0, aq[0]);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3 - 1) * T::WP + (tap % 3 - 1)) * ROWB;
+        for (int k = 0; k < KPC; ++k) {
+            const int cur = k & 1, nxt = cur ^ 1;
+            // next step's fragments (the B stream runs on into the next chunk; the last step of all re-reads itself)
+            const bool last = chunk == NCHUNK - 1 && k == KPC - 1;
+            wp += last ? 0 : 256;
 #pragma unroll
-            for (int sub = 0; sub < SUB; ++sub) {
-                bf16x8 ah[2], al[2], bh[2], bl[2];
+            for (int f = 0; f < 4; ++f) bq[nxt][f] = wp[f * 64];
+            if (k + 1 < KPC) load_a(k + 1, aq[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    bh[nt] = __builtin_bit_cast(bf16x8, wp[(nt * 2 + 0) * 64]);
-                    bl[nt] = __builtin_bit_cast(bf16x8, wp[(nt * 2 + 1) * 64]);
+                    const bf16x8 ah = aq[cur][mt * 2], al = aq[cur][mt * 2 + 1];
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[cur][nt * 2]), bl = __builtin_bit_cast(bf16x8, bq[cur][nt * 2 + 1]);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt][nt], 0, 0, 0);
                 }
-                wp += 256;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (KPC & 1) {   // an odd number of steps per chunk: bring the prefetched B fragments back to slot 0
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    int off = lp_c[mt] * ROWB + toff + sub * 32 + h * 16;
-                    ah[mt] = *reinterpret_cast<const bf16x8 *>(s_hi + off);
-                    al[mt] = *reinterpret_cast<const bf16x8 *>(s_lo + off);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                    }
-            }
+            for (int f = 0; f < 4; ++f) bq[0][f] = bq[1][f];
         }
     }
 

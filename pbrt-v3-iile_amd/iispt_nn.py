@@ -127,17 +127,69 @@ def transform_upstream(out, chan_mean):
     return torch.flip(network_output_to_wire(y), dims=(1,)).contiguous()
 
 
-class IisptPipeline:
-    """render probes -> normalise -> network -> rescale, everything resident in HBM."""
+def _load_binding():
+    """binding.py beside this file, under the name __graft_entry__ / tests/conftest.py load it by (one copy per process)."""
+    import importlib.util
+    import os
+    import sys
+    if "iile_binding" in sys.modules:
+        return sys.modules["iile_binding"]
+    spec = importlib.util.spec_from_file_location("iile_binding", os.path.join(os.path.dirname(os.path.abspath(__file__)), "binding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["iile_binding"] = mod
+    spec.loader.exec_module(mod)
+    return mod
 
-    def __init__(self, gpu_scene, net=None, dtype=torch.float32, device="cuda"):
+
+class IisptPipeline:
+    """render probes -> normalise -> network -> rescale, everything resident in HBM.
+
+    The network runs on the hand-written kernels of csrc/device/iispt_net.hip through the C ABI (iile_iispt_net_*,
+    binding.GpuNet); `net` (an IISPTNet, e.g. with a checkpoint of the reference's training loaded) only supplies the
+    weights. backend="torch" runs the PyTorch module instead (eager, MIOpen convolutions): kept for tests and A/B timing,
+    never the default — without the HIP library the constructor raises."""
+
+    def __init__(self, gpu_scene, net=None, dtype=torch.float32, device="cuda", backend="hip", binding=None):
         self.gpu = gpu_scene
         self.device = torch.device(device)
-        self.net = (net if net is not None else IISPTNet()).to(self.device).eval()
+        self.backend = backend
         self.dtype = dtype
-        if dtype != torch.float32:
-            self.net = self.net.to(dtype)
-        self.net = self.net.to(memory_format=torch.channels_last)
+        module = (net if net is not None else IISPTNet()).eval()
+        if backend == "hip":
+            if dtype != torch.float32:
+                raise ValueError("the HIP network computes in split bf16 with fp32 accumulation; dtype selects nothing there")
+            if binding is None:
+                binding = _load_binding()
+            self.hip_net = binding.GpuNet(module.state_dict(), bn_eps=module.encoder1[3].eps)
+            self.net = None
+        elif backend == "torch":
+            self.hip_net = None
+            self.net = module.to(self.device)
+            if dtype != torch.float32:
+                self.net = self.net.to(dtype)
+            self.net = self.net.to(memory_format=torch.channels_last)
+        else:
+            raise ValueError(backend)
+        self.events = None   # bench.py: a list that receives (stage, start event, end event) on the current stream
+
+    def _timed(self, stage, fn):
+        if self.events is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.events.append((stage, e0, e1))
+        return out
+
+    def infer(self, x):
+        """(n, 7, h, h) float32 on the device -> (n, 3, h, h) float32."""
+        if self.hip_net is not None:
+            x = x.contiguous()
+            y = torch.empty((x.shape[0], 3, HEMI, HEMI), dtype=torch.float32, device=x.device)
+            self.hip_net.forward(x.data_ptr(), y.data_ptr(), x.shape[0], stream=torch.cuda.current_stream().cuda_stream)
+            return y
+        return self.net(x.to(self.dtype).contiguous(memory_format=torch.channels_last)).float()
 
     @torch.no_grad()
     def __call__(self, pos, direction, batch=8192):
@@ -147,11 +199,11 @@ class IisptPipeline:
         inten = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         nrm = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         dist = torch.empty((n, HEMI, HEMI), dtype=torch.float32, device=self.device)
-        self.gpu.render_probes(pos, direction, device_out=(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr()))
+        self._timed("probe_pass", lambda: self.gpu.render_probes(pos, direction, device_out=(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr())))
         pred = torch.empty_like(inten)
         for first in range(0, n, batch):
             sl = slice(first, min(n, first + batch))
-            x, means = normalize_downstream(inten[sl], nrm[sl], dist[sl])
-            y = self.net(x.to(self.dtype).contiguous(memory_format=torch.channels_last))
-            pred[sl] = transform_upstream(y, means)
+            x, means = self._timed("normalize", lambda: normalize_downstream(inten[sl], nrm[sl], dist[sl]))
+            y = self._timed("network", lambda: self.infer(x))
+            pred[sl] = self._timed("rescale", lambda: transform_upstream(y, means))
         return pred, inten, nrm, dist

@@ -98,3 +98,21 @@ def test_bvh_builder_has_no_cpu_path_either(binding):
     nodes["offset"][0] = 2
     with pytest.raises(RuntimeError, match="no HIP device"):
         binding.bvh_pack_probe(nodes)
+
+
+def test_network_has_no_cpu_path_either(binding):
+    """iile_iispt_net_create: argument errors are reported as such; without a GPU it fails loudly (no CPU network)."""
+    import pytest
+    import torch
+    import importlib
+    lib = binding.gpu_lib()
+    h = ctypes.c_void_p()
+    assert lib.iile_iispt_net_create(None, ctypes.byref(h)) == 1  # IILE_ERR_ARG
+    assert ctypes.sizeof(binding.NetWeights) == (15 * 2 + 5 * 4) * 8 + 8
+    if binding.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        binding.GpuNet(nn_mod.IISPTNet().state_dict())
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        nn_mod.IisptPipeline(None, binding=binding)

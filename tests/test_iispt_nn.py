@@ -152,26 +152,102 @@ def test_wire_order_is_the_references():
     assert np.array_equal(back.ravel(), fx["wire_out"])
 
 
+# the module whose OUTPUT is what convolution layer l of csrc/device/iispt_net.hip stores (behind LeakyReLU / BatchNorm)
+_LAYER_TAPS = [("encoder0", 1), ("encoder0", 3), ("encoder1", 3), ("encoder1", 5), ("encoder2", 3), ("encoder2", 5), ("encoder3", 3),
+               ("encoder3", 5), ("decoder0", 2), ("decoder0", 4), ("decoder1", 2), ("decoder1", 4), ("decoder2", 1), ("decoder2", 3)]
+
+
 @pytest.mark.gpu
-def test_network_on_the_gpu_against_the_reference_fixture():
-    """The fp32 network on the device against the reference module's output (fixture): within 1e-4 of the largest value.
-    The bf16 deviation is measured and bounded here because every bf16 throughput figure quoted in README / DESIGN / profiles
-    has to carry it (the reference infers in fp32 on the CPU)."""
+def test_network_on_the_gpu_against_the_reference_fixture(binding):
+    """The product's network — the hand-written kernels behind iile_iispt_net_* (split-bf16 matrix instructions, fp32
+    accumulation) — against the REFERENCE module's output (fixture): within 1e-4 of the largest value. Beside it, for the
+    record, eager PyTorch on the same device in fp32 and in plain bf16 (neither is the product path)."""
     torch.cuda.init()
     fx = _fixture()
     net, _ = _recipe_net()
     x = torch.from_numpy(fx["input"]).cuda()
     want = fx["output"]
     scale = float(np.abs(want).max())
+    g = binding.GpuNet(net.state_dict())
+    y = torch.empty((4, 3, 32, 32), dtype=torch.float32, device="cuda")
+    g.forward(x.data_ptr(), y.data_ptr(), 4)
+    torch.cuda.synchronize()
+    err_hip = float(np.abs(y.cpu().numpy() - want).max()) / scale
     with torch.no_grad():
         y32 = net.cuda()(x.contiguous(memory_format=torch.channels_last)).float().cpu().numpy()
         y16 = net.to(torch.bfloat16)(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)).float().cpu().numpy()
     err32 = float(np.abs(y32 - want).max()) / scale
     err16 = float(np.abs(y16 - want).max()) / scale
-    rms16 = float(np.sqrt(np.mean((y16 - want) ** 2))) / scale
-    print(f"IISPTNet on the GPU vs the reference fixture: fp32 max err {err32:.2e}, bf16 max err {err16:.2e} (rms {rms16:.2e}) of the largest output")
+    print(f"IISPTNet vs the reference fixture, max error over the largest output: HIP kernels {err_hip:.2e}; eager PyTorch fp32 {err32:.2e}, bf16 {err16:.2e}")
+    assert err_hip < 1e-4, err_hip
     assert err32 < 1e-4, err32
-    assert err16 < 0.1, err16    # measured, not a parity claim: bf16 keeps 8 significant bits through 15 convolutions
+    assert err16 < 0.1, err16    # measured, not a parity claim: plain bf16 keeps 8 significant bits through 15 convolutions
+
+
+@pytest.mark.gpu
+def test_hip_network_layer_by_layer_against_the_module(binding):
+    """Every convolution layer of the HIP network (with the pooling / upsampling + concatenation folded into its loads and
+    the activation / BatchNorm folded into its stores) against the same point of the PyTorch module on the CPU, on a batch
+    that fills no tile exactly (37 probes: tiles hold 1, 4 or 16 images); then the batch cut into pieces of 10 must give the
+    same bits, and so must a batch of one."""
+    torch.cuda.init()
+    import iispt_net_recipe as recipe
+    net, _ = _recipe_net()
+    n = 37
+    xin = torch.from_numpy(recipe.fixture_input(n))
+    acts, hooks = {}, []
+    for l, (blk, idx) in enumerate(_LAYER_TAPS):
+        hooks.append(getattr(net, blk)[idx].register_forward_hook(lambda m, i, o, l=l: acts.__setitem__(l, o.detach())))
+    with torch.no_grad():
+        ref = net(xin)
+    for h in hooks:
+        h.remove()
+    g = binding.GpuNet(net.state_dict())
+    xd = xin.cuda()
+    yd = torch.empty((n, 3, 32, 32), dtype=torch.float32, device="cuda")
+    for l in range(14):
+        a = acts[l]
+        lo = torch.empty((n, a.shape[2], a.shape[3], a.shape[1]), dtype=torch.float32, device="cuda")
+        g.forward(xd.data_ptr(), yd.data_ptr(), n, layer_out_ptr=lo.data_ptr(), layer=l)
+        torch.cuda.synchronize()
+        err = float((lo.cpu().permute(0, 3, 1, 2) - a).abs().max() / a.abs().max())
+        assert err < 5e-5, (l, err)
+    assert float((yd.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+    y2 = torch.empty_like(yd)
+    g.forward(xd.data_ptr(), y2.data_ptr(), n, max_batch=10)
+    y1 = torch.empty((1, 3, 32, 32), dtype=torch.float32, device="cuda")
+    g.forward(xd[5:6].contiguous().data_ptr(), y1.data_ptr(), 1)
+    torch.cuda.synchronize()
+    assert torch.equal(yd, y2) and torch.equal(yd[5:6], y1)
+    g.forward(xd.data_ptr(), y2.data_ptr(), 0)   # nothing to do is not an error
+    with pytest.raises(RuntimeError):
+        g.forward(0, y2.data_ptr(), 3)
+
+
+@pytest.mark.gpu
+def test_hip_network_follows_a_checkpoint_not_the_recipe(binding):
+    """Weights of another kind (PyTorch's default initialisation, BatchNorm statistics moved off their defaults): the HIP
+    network built from that state_dict agrees with the module — the packer reads the checkpoint, not a fixed recipe."""
+    torch.cuda.init()
+    torch.manual_seed(11)
+    net = nn_mod.IISPTNet().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.3, 0.3)
+                m.running_var.uniform_(0.4, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+        net.decoder2[4].bias.fill_(0.5)
+    x = torch.randn(9, 7, 32, 32)
+    with torch.no_grad():
+        ref = net(x)
+    assert float(ref.max()) > 0
+    g = binding.GpuNet(net.state_dict())
+    y = torch.empty((9, 3, 32, 32), dtype=torch.float32, device="cuda")
+    g.forward(x.cuda().data_ptr(), y.data_ptr(), 9)
+    torch.cuda.synchronize()
+    assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
 
 
 @pytest.mark.gpu
@@ -187,7 +263,8 @@ def test_pipeline_keeps_everything_on_the_device(binding):
     d = rng.standard_normal((24, 3)).astype(np.float32)
     torch.manual_seed(3)
     net = nn_mod.IISPTNet()
-    pipe = nn_mod.IisptPipeline(gpu, net=net)
+    pipe = nn_mod.IisptPipeline(gpu, net=net, binding=binding)
+    assert pipe.hip_net is not None and pipe.net is None   # the product path: the HIP kernels, not the PyTorch module
     pred, inten, nrm, dist = pipe(pos, d, batch=10)
     hi, hn, hd, _ = gpu.render_probes(pos, d)
     assert np.array_equal(inten.cpu().numpy(), hi) and np.array_equal(nrm.cpu().numpy(), hn) and np.array_equal(dist.cpu().numpy(), hd)

@@ -92,6 +92,11 @@ def main():
         dt2 = (time.time() - t0) / reps
         res["torch_miopen"] = {"n": n_time, "ms": dt2 * 1e3, "tflops": 0.99e9 * n_time / dt2 / 1e12}
         res["hip_vs_torch_err_over_max"] = float((yt - yy).abs().max() / yy.abs().max())
+        with torch.no_grad():
+            ref64 = net.cpu()(xt[:64].cpu())
+        res["timed_batch_first64_vs_cpu"] = {"hip": float((yt[:64].cpu() - ref64).abs().max() / ref64.abs().max()),
+                                             "torch_miopen": float((yy[:64].cpu() - ref64).abs().max() / ref64.abs().max()),
+                                             "hip_last64_vs_first64_equal": bool(torch.equal(yt[:64], yt[n_time - n_time % 64 - 64:n_time - n_time % 64]))}
     print(json.dumps(res))
     out = os.path.join(REPO, "gpurun_out", "net_check.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
