@@ -204,7 +204,7 @@ int iile_iispt_gather_batch(iile_scene *scene, const iile_iispt_task *tasks, int
  *   iile_iispt_net_forward  in_dev: (n, 7, 32, 32) floats as `read_input` (ml/main_stdio_net.py:47-72) builds them; out_dev:
  *                           (n, 3, 32, 32) as `output_to_stdout` (:77-86) reads them; both DEVICE memory. The kernels are
  *                           queued on `stream` (NULL = the null stream) and the call returns; activations live in a workspace
- *                           the object owns (0.94 MiB per probe of a batch, at most max_batch probes at a time; <= 0: 16384).
+ *                           the object owns (1.19 MiB per probe of a batch, at most max_batch probes at a time; <= 0: 32768).
  *                           layer_out_dev != NULL (tests): also copies the NHWC output of convolution `layer` (0..13) there. */
 typedef struct iile_iispt_net iile_iispt_net;
 typedef struct iile_iispt_net_weights {

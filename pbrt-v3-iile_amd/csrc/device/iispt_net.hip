@@ -40,24 +40,56 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { PRE_NONE = 0, PRE_POOL = 1, PRE_UPCAT = 2 };
+enum { PRE_NONE = 0, PRE_CAT = 1 };
 
-constexpr int kBM = 256;      // pixels per workgroup
-constexpr int kBN = 64;       // output channels per workgroup
-constexpr int kThreads = 256;
+constexpr int kBM = 256;      // pixels per workgroup tile
+constexpr int kBN = 64;       // output channels per workgroup tile
+constexpr int kChunk = 16;    // input channels per step = one k-step of the matrix instruction per tap
+constexpr int kLoaders = 512; // threads of the 8 staging waves
+constexpr int kThreads = 256 + kLoaders;   // 4 matrix waves + 8 staging waves
+constexpr int kRowB = kChunk * 2 + 16;   // bytes per staged pixel and plane (48: an odd multiple of 16 -> b128 reads of consecutive pixels hit 16 different bank groups)
+constexpr int kKPC = 9;       // k-steps per step (one per tap)
+constexpr int kBStep = kKPC * 4 * 64 * 16;   // bytes of packed weights per step and 64-channel n-tile (36 864)
 
-// geometry of one workgroup's pixel tile for H x H images
+// geometry of one workgroup's pixel tile for H x H images. H = 32: eight rows of one image, with a halo row above and below and a
+// halo column either side. H < 32: 256 / H^2 whole images laid out as a G x G grid whose neighbours SHARE their one-pixel
+// zero border (H = 4: 16 images in 21 x 21 staged pixels instead of 16 x 6 x 6).
 template <int H>
 struct Tile {
     static constexpr int ROWS = H >= 32 ? kBM / H : H;            // image rows per tile
     static constexpr int IMGS = H >= 32 ? 1 : kBM / (H * H);      // whole images per tile (H < 32)
+    static constexpr int G = IMGS == 1 ? 1 : IMGS == 4 ? 2 : 4;   // images per grid row
     static constexpr int TILES_PER_IMG = H >= 32 ? H / ROWS : 1;
-    static constexpr int HP = ROWS + 2, WP = H + 2;               // haloed extent
-    static constexpr int NLP = IMGS * HP * WP;                    // haloed pixels staged per chunk
+    static constexpr int HP = H >= 32 ? ROWS + 2 : 1 + (H + 1) * G;
+    static constexpr int WP = H >= 32 ? H + 2 : 1 + (H + 1) * G;
+    static constexpr int NLP = HP * WP;                           // staged pixels per step
+    // staged-pixel index of pixel m (0..255) of the tile
+    __device__ static int lp_of(int m) {
+        if (H >= 32) return (m / H + 1) * WP + m % H + 1;
+        int il = m / (H * H), y = (m / H) % H, x = m % H;
+        return (1 + (H + 1) * (il / G) + y) * WP + 1 + (H + 1) * (il % G) + x;
+    }
+    // staged pixel -> (image in tile, y relative to the tile's first row, x); false: a border position (always zero)
+    __device__ static bool decode(int lp, int &il, int &y, int &x) {
+        int Y = lp / WP, X = lp % WP;
+        if (H >= 32) {
+            il = 0;
+            y = Y - 1;
+            x = X - 1;
+            return x >= 0 && x < H;   // (rows above / below the image are checked by the caller against y0)
+        }
+        if (Y % (H + 1) == 0 || X % (H + 1) == 0) return false;
+        il = ((Y - 1) / (H + 1)) * G + (X - 1) / (H + 1);
+        y = (Y - 1) % (H + 1);
+        x = (X - 1) % (H + 1);
+        return true;
+    }
 };
 
-__device__ inline void split_store(float4 v, char *hi, char *lo) {
+__device__ inline void split_store(f32x4 v, char *hi, char *lo) {
     // a = hi + lo, both bf16 (round to nearest even); a - float(hi) is exact in fp32
     f32x2 a = {v.x, v.y}, b = {v.z, v.w};
     bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
@@ -69,10 +101,8 @@ __device__ inline void split_store(float4 v, char *hi, char *lo) {
     *reinterpret_cast<uint2 *>(lo) = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
 }
 
-__device__ inline float4 max4(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
-__device__ inline float4 lerp4(float wa, float4 a, float wb, float4 b) {
-    return make_float4(wa * a.x + wb * b.x, wa * a.y + wb * b.y, wa * a.z + wb * b.z, wa * a.w + wb * b.w);
-}
+__device__ inline f32x4 max4(f32x4 a, f32x4 b) { return __builtin_elementwise_max(a, b); }
+__device__ inline f32x4 lerp4(float wa, f32x4 a, float wb, f32x4 b) { return wa * a + wb * b; }
 
 // nn.Upsample(scale_factor=2, mode="bilinear") (align_corners False): source index and weight of destination d
 __device__ inline void up_coord(int d, int n_in, int &i0, int &i1, float &l1) {
@@ -84,8 +114,8 @@ __device__ inline void up_coord(int d, int n_in, int &i0, int &i1, float &l1) {
 }
 
 struct ConvArgs {
-    const float *in0;      // PRE_NONE: [n][H][H][CIN]; PRE_POOL: [n][2H][2H][CIN]; PRE_UPCAT: the level below, [n][H/2][H/2][CIN/2]
-    const float *in1;      // PRE_UPCAT: the skip tensor [n][H][H][CIN/2]
+    const float *in0;      // PRE_NONE: [n][H][H][CIN]; PRE_CAT: the first CIN / 2 channels, [n][H][H][CIN/2]
+    const float *in1;      // PRE_CAT: the other CIN / 2 channels (the skip tensor)
     const uint4 *wpack;    // [COUT/64][k-steps][n-tile 2][hi, lo][lane 64] x 16 bytes
     const float *bias, *bn_scale, *bn_shift;   // [COUT]; bn_* only when BNORM
     float *out;            // [n][H][H][COUT]
@@ -93,40 +123,126 @@ struct ConvArgs {
 };
 
 // One 3 x 3, padding-1 convolution layer with its pre- and post-operations (file header).
-template <int H, int CIN, int COUT, int PRE, int CHUNK, bool BNORM>
-__global__ __launch_bounds__(kThreads, 2) void k_conv3x3(ConvArgs p) {
+//
+// Persistent workgroups of 8 waves, one per CU: waves 0-3 issue matrix instructions (each owns 64 pixels x 64 channels of the
+// tile), waves 4-7 stage. The work of a workgroup is a stream of steps (tile, 16-channel chunk). During step s the matrix waves
+// run 9 k-steps (one per tap, 12 matrix instructions each) out of LDS buffer s & 1 — A fragments and B fragments both: no
+// vector-memory instruction on that side — while the staging waves
+//   * convert and store what they loaded during step s - 1 (the A tile of step s + 1, split into bf16 hi / lo; its packed
+//     weights, copied as they are) into buffer (s + 1) & 1, and
+//   * issue the global loads of step s + 2 into registers, all of them at once: every load has a whole step to land.
+// One workgroup barrier per step is the only synchronisation.
+template <int H, int CIN, int COUT, int PRE, bool BNORM>
+__global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
     using T = Tile<H>;
-    constexpr int ROWB = CHUNK * 2 + 16;          // bytes per staged pixel and plane: odd multiple of 16 -> conflict-free b128 reads
-    constexpr int NCHUNK = CIN / CHUNK;
-    constexpr int SUB = CHUNK / 16;               // k-steps per tap and chunk
+    constexpr int NCHUNK = CIN / kChunk;
     constexpr int NT = COUT / kBN;
-    constexpr int C4 = CHUNK / 4;                 // float4 items per staged pixel
-    constexpr int KSTEPS = NCHUNK * 9 * SUB;
-    static_assert(CIN % CHUNK == 0 && COUT % kBN == 0 && CHUNK % 16 == 0, "shape");
+    constexpr int KSTEPS = NCHUNK * kKPC;
+    constexpr int PLANE = T::NLP * kRowB;                 // bytes of one plane (hi or lo)
+    constexpr int BUF = 2 * PLANE + kBStep;               // bytes of one buffer: A hi, A lo, B
+    constexpr int NITEMS = T::NLP * 4;                    // float4 items of an A tile
+    constexpr int NA = (NITEMS + kLoaders - 1) / kLoaders;  // ... per staging thread
+    constexpr int NB = (kBStep / 16 + kLoaders - 1) / kLoaders;   // 16-byte pieces of B per staging thread
+    static_assert(CIN % kChunk == 0 && COUT % kBN == 0, "shape");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *s_hi = smem, *s_lo = smem + T::NLP * ROWB;
-
-    // blocks b, b + 8, b + 16 ... share an XCD's L2 under round-robin placement (speed only): give those the same pixels
-    const int b = blockIdx.x;
-    const int grp = b / (8 * NT), in_grp = b % (8 * NT);
-    const int mtile = grp * 8 + (in_grp & 7), ntile = in_grp >> 3;
-    const int n_mtiles = H >= 32 ? p.n_img * T::TILES_PER_IMG : (p.n_img + T::IMGS - 1) / T::IMGS;
-    if (mtile >= n_mtiles) return;
-    const int img0 = H >= 32 ? mtile / T::TILES_PER_IMG : mtile * T::IMGS;
-    const int y0 = H >= 32 ? (mtile % T::TILES_PER_IMG) * T::ROWS : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [buffer 2]{A hi [NLP][48], A lo [NLP][48], B [9][4][64][16]}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const bool loader = wave >= 4;
+    const int n_mtiles = H >= 32 ? p.n_img * T::TILES_PER_IMG : (p.n_img + T::IMGS - 1) / T::IMGS;
+    const int n_tiles = ((n_mtiles + 7) / 8) * 8 * NT;   // tile t: group t / (8 NT), n-tile (t % (8 NT)) >> 3, m-tile 8 group + (t & 7)
+    const int my_tiles = (n_tiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);   // t = blockIdx.x + i gridDim.x: with
+    const int n_steps = my_tiles * NCHUNK;   // gridDim.x a multiple of 8, a workgroup's tiles and the n-tiles of a pixel tile share an XCD (speed only)
 
-    // the two 32-pixel row blocks of this wave: staged-pixel index of each lane's pixel (tap 0, 0)
-    int lp_c[2];
+    auto tile_of = [&](int i, int &mtile, int &ntile) __attribute__((always_inline)) {
+        int t = int(blockIdx.x) + i * int(gridDim.x);
+        int grp = t / (8 * NT), in_grp = t % (8 * NT);
+        mtile = grp * 8 + (in_grp & 7);
+        ntile = in_grp >> 3;
+    };
+
+    if (loader) {
+        // ------------------------------------------------ staging waves ------------------------------------------------
+        const int ltid = tid - 256;
+        struct Regs {   // what a staging thread holds of one step between its loads and its LDS stores
+            f32x4 va[NA];
+            u32x4 vb[NB];
+        };
+        Regs r0, r1;   // steps alternate between the two sets: a step's loads are issued two steps before they are stored
+
+#ifdef NET_DIAG_NO_GLOBAL
+#define NET_LD(ptr) (f32x4{float(ltid), 1.f, 2.f, 3.f})
+#define NET_LDB(ptr) (u32x4{uint32_t(ltid), 1u, 2u, 3u})
+#else
+#define NET_LD(ptr) (*reinterpret_cast<const f32x4 *>(ptr))
+#define NET_LDB(ptr) (*(ptr))
+#endif
+        auto issue = [&](int step, Regs &R) __attribute__((always_inline)) {   // global loads of a step into registers
+            int mtile, ntile;
+            tile_of(step / NCHUNK, mtile, ntile);
+            const int c_base = (step % NCHUNK) * kChunk;
+            const int img0 = H >= 32 ? mtile / T::TILES_PER_IMG : mtile * T::IMGS;
+            const int y0 = H >= 32 ? (mtile % T::TILES_PER_IMG) * T::ROWS : 0;
+            const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(p.wpack) + (size_t(ntile) * KSTEPS + size_t(step % NCHUNK) * kKPC) * 256;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int m = wave * 64 + mt * 32 + r;
-        int il = m / (T::ROWS * H), y = (m / H) % T::ROWS, x = m % H;
-        lp_c[mt] = (il * T::HP + y + 1) * T::WP + x + 1;
+            for (int j = 0; j < NB; ++j)
+                if (ltid + kLoaders * j < kBStep / 16) R.vb[j] = NET_LDB(wsrc + ltid + kLoaders * j);
+            // torch.cat((below, skip), 1): which tensor this step's 16 channels come from is uniform per step
+            constexpr int CSRC = PRE == PRE_CAT ? CIN / 2 : CIN;
+            const bool second = PRE == PRE_CAT && c_base >= CSRC;
+            const float *src = (second ? p.in1 : p.in0) + (second ? c_base - CSRC : c_base);
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int it = ltid + kLoaders * u;
+                R.va[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int il, yl, x;
+                if (it >= NITEMS || !T::decode(it >> 2, il, yl, x)) continue;
+                const int y = y0 + yl, img = img0 + il;
+                if (!(y >= 0 && y < H && img < p.n_img && mtile < n_mtiles)) continue;
+                R.va[u] = NET_LD(src + ((size_t(img) * H + y) * H + x) * CSRC + (it & 3) * 4);
+            }
+        };
+        auto store = [&](int step, Regs &R) __attribute__((always_inline)) {   // registers -> LDS buffer step & 1
+            char *s_hi = smem + (step & 1) * BUF, *s_lo = s_hi + PLANE;
+            u32x4 *s_b = reinterpret_cast<u32x4 *>(s_hi + 2 * PLANE);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (ltid + kLoaders * j < kBStep / 16) s_b[ltid + kLoaders * j] = R.vb[j];
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int it = ltid + kLoaders * u;
+                if (it >= NITEMS) continue;
+                split_store(R.va[u], s_hi + (it >> 2) * kRowB + (it & 3) * 8, s_lo + (it >> 2) * kRowB + (it & 3) * 8);
+            }
+        };
+        // iteration i (beside the matrix waves' step i): request step i + 2 into the set step i used, then store step i + 1
+        auto iter = [&](int i, Regs &Ra, Regs &Rb) __attribute__((always_inline)) {
+#ifndef NET_DIAG_NO_STAGE
+            if (i + 2 < n_steps) issue(i + 2, Ra);
+            if (i + 1 < n_steps) store(i + 1, Rb);
+#endif
+            __syncthreads();
+        };
+#ifndef NET_DIAG_NO_STAGE
+        if (n_steps > 0) issue(0, r0);
+        if (n_steps > 1) issue(1, r1);
+        if (n_steps > 0) store(0, r0);
+#endif
+        __syncthreads();
+        for (int step = 0; step < n_steps; step += 2) {
+            iter(step, r0, r1);
+            if (step + 1 < n_steps) iter(step + 1, r1, r0);
+        }
+        return;
     }
+
+    // ---------------------------------------------------- matrix waves ----------------------------------------------------
+    __builtin_amdgcn_s_setprio(1);
+    const int r = lane & 31, h = lane >> 5;
+    // the two 32-pixel row blocks of this wave: byte offset of each lane's pixel in a plane (tap 0, 0), this lane's k half
+    int a_off[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) a_off[mt] = T::lp_of(wave * 64 + mt * 32 + r) * kRowB + h * 16;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -136,118 +252,120 @@ __global__ __launch_bounds__(kThreads, 2) void k_conv3x3(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // B fragments of k-step ks sit at wp + ks * 256: {n-tile 0 hi, lo, n-tile 1 hi, lo} x 64 lanes x 16 bytes. The fragments of
-    // step ks + 1 (A from LDS, B from L2) are requested before the 12 matrix instructions of step ks are issued.
-    const uint4 *wp = p.wpack + size_t(ntile) * KSTEPS * 256 + lane;
-    constexpr int KPC = 9 * SUB;   // k-steps per chunk
-    uint4 bq[2][4];
-    bf16x8 aq[2][4];               // {hi, lo} x {m-tile 0, 1}
-#pragma unroll
-    for (int f = 0; f < 4; ++f) bq[0][f] = wp[f * 64];
+    __syncthreads();   // step 0 is staged
 
-    auto load_a = [&](int k, bf16x8(&dst)[4]) {   // k: k-step inside the chunk (compile-time after unrolling)
-        const int tap = k / SUB, sub = k % SUB;
-        const int toff = ((tap / 3 - 1) * T::WP + (tap % 3 - 1)) * ROWB + sub * 32 + h * 16;
+    for (int step = 0; step < n_steps; ++step) {
+        const char *s_hi = smem + (step & 1) * BUF, *s_lo = s_hi + PLANE;
+        const uint4 *s_b = reinterpret_cast<const uint4 *>(s_hi + 2 * PLANE) + lane;
+#ifndef NET_DIAG_NO_MFMA
+        bf16x8 aq[2][4];   // {m block 0 hi, lo, m block 1 hi, lo}
+        uint4 bq[2][4];    // {n half 0 hi, lo, n half 1 hi, lo}
+        auto load_ab = [&](int k, bf16x8(&da)[4], uint4(&db)[4]) __attribute__((always_inline)) {
+            const int toff = ((k / 3 - 1) * T::WP + (k % 3 - 1)) * kRowB;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            dst[mt * 2 + 0] = *reinterpret_cast<const bf16x8 *>(s_hi + lp_c[mt] * ROWB + toff);
-            dst[mt * 2 + 1] = *reinterpret_cast<const bf16x8 *>(s_lo + lp_c[mt] * ROWB + toff);
-        }
-    };
-
-    for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-        if (chunk) __syncthreads();   // every wave has read the previous chunk
-        // ---- stage the haloed tile of channels [chunk * CHUNK, + CHUNK) ----
-        const int c_base = chunk * CHUNK;
-        for (int it = tid; it < T::NLP * C4; it += kThreads) {
-            int lp = it / C4, c4 = it % C4;
-            int il = lp / (T::HP * T::WP), rem = lp % (T::HP * T::WP);
-            int y = y0 + rem / T::WP - 1, x = rem % T::WP - 1;
-            int img = img0 + il;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y >= 0 && y < H && x >= 0 && x < H && img < p.n_img) {
-                int c = c_base + c4 * 4;
-                if (PRE == PRE_NONE) {
-                    v = *reinterpret_cast<const float4 *>(p.in0 + ((size_t(img) * H + y) * H + x) * CIN + c);
-                } else if (PRE == PRE_POOL) {
-                    const float *q = p.in0 + ((size_t(img) * 2 * H + 2 * y) * 2 * H + 2 * x) * CIN + c;
-                    float4 a = *reinterpret_cast<const float4 *>(q), bb = *reinterpret_cast<const float4 *>(q + CIN);
-                    float4 cc = *reinterpret_cast<const float4 *>(q + 2 * H * CIN), d = *reinterpret_cast<const float4 *>(q + 2 * H * CIN + CIN);
-                    v = max4(max4(a, bb), max4(cc, d));
-                } else {
-                    constexpr int CU = CIN / 2, HL = H / 2;
-                    if (c < CU) {   // uniform per chunk: CU is a multiple of CHUNK
-                        int ya, yb, xa, xb;
-                        float ly, lx;
-                        up_coord(y, HL, ya, yb, ly);
-                        up_coord(x, HL, xa, xb, lx);
-                        const float *q = p.in0 + size_t(img) * HL * HL * CU + c;
-                        float4 a = *reinterpret_cast<const float4 *>(q + (ya * HL + xa) * CU), bb = *reinterpret_cast<const float4 *>(q + (ya * HL + xb) * CU);
-                        float4 cc = *reinterpret_cast<const float4 *>(q + (yb * HL + xa) * CU), d = *reinterpret_cast<const float4 *>(q + (yb * HL + xb) * CU);
-                        float4 top = lerp4(1.f - lx, a, lx, bb), bot = lerp4(1.f - lx, cc, lx, d);
-                        v = lerp4(1.f - ly, top, ly, bot);
-                    } else {
-                        v = *reinterpret_cast<const float4 *>(p.in1 + ((size_t(img) * H + y) * H + x) * CU + (c - CU));
-                    }
-                }
+            for (int mt = 0; mt < 2; ++mt) {
+                da[mt * 2 + 0] = *reinterpret_cast<const bf16x8 *>(s_hi + a_off[mt] + toff);
+                da[mt * 2 + 1] = *reinterpret_cast<const bf16x8 *>(s_lo + a_off[mt] + toff);
             }
-            split_store(v, s_hi + lp * ROWB + c4 * 8, s_lo + lp * ROWB + c4 * 8);
-        }
-        __syncthreads();
-        // ---- 9 taps x SUB k-steps: no barrier inside ----
-        load_a(0, aq[0]);
 #pragma unroll
-        for (int k = 0; k < KPC; ++k) {
-            const int cur = k & 1, nxt = cur ^ 1;
-            // next step's fragments (the B stream runs on into the next chunk; the last step of all re-reads itself)
-            const bool last = chunk == NCHUNK - 1 && k == KPC - 1;
-            wp += last ? 0 : 256;
+            for (int f = 0; f < 4; ++f) db[f] = s_b[(k * 4 + f) * 64];
+        };
+        load_ab(0, aq[0], bq[0]);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) bq[nxt][f] = wp[f * 64];
-            if (k + 1 < KPC) load_a(k + 1, aq[nxt]);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < kKPC; ++k) {
+            if (k + 1 < kKPC) load_ab(k + 1, aq[(k + 1) & 1], bq[(k + 1) & 1]);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const bf16x8 ah = aq[cur][mt * 2], al = aq[cur][mt * 2 + 1];
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[cur][nt * 2]), bl = __builtin_bit_cast(bf16x8, bq[cur][nt * 2 + 1]);
+                    const bf16x8 ah = aq[k & 1][mt * 2], al = aq[k & 1][mt * 2 + 1];
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[k & 1][nt * 2]), bl = __builtin_bit_cast(bf16x8, bq[k & 1][nt * 2 + 1]);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt][nt], 0, 0, 0);
                 }
+            // issue order inside the k-step: one LDS read of the next k-step behind each of the first eight matrix
+            // instructions (eight reads in a row stall the matrix pipe for the time the LDS takes to accept them)
+            if (k + 1 < kKPC) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (KPC & 1) {   // an odd number of steps per chunk: bring the prefetched B fragments back to slot 0
+#endif
+        if (step % NCHUNK == NCHUNK - 1) {
+            // ---- bias, LeakyReLU(0.2), BatchNorm affine; accumulator column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h ----
+            int mtile, ntile;
+            tile_of(step / NCHUNK, mtile, ntile);
+            const int img0 = H >= 32 ? mtile / T::TILES_PER_IMG : mtile * T::IMGS;
+            const int y0 = H >= 32 ? (mtile % T::TILES_PER_IMG) * T::ROWS : 0;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) bq[0][f] = bq[1][f];
-        }
-    }
-
-    // ---- bias, LeakyReLU(0.2), BatchNorm affine; accumulator column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h ----
+            for (int nt = 0; nt < 2; ++nt) {
+                const int co = ntile * kBN + nt * 32 + r;
+                const float bias = p.bias[co];
+                float sc = 1.f, sh = 0.f;
+                if (BNORM) {
+                    sc = p.bn_scale[co];
+                    sh = p.bn_shift[co];
+                }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int co = ntile * kBN + nt * 32 + r;
-        const float bias = p.bias[co];
-        float sc = 1.f, sh = 0.f;
-        if (BNORM) {
-            sc = p.bn_scale[co];
-            sh = p.bn_shift[co];
-        }
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                int m = wave * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                int il = m / (T::ROWS * H), y = y0 + (m / H) % T::ROWS, x = m % H;
-                int img = img0 + il;
-                if (img >= p.n_img) continue;
-                float v = acc[mt][nt][e] + bias;
-                v = v > 0.f ? v : 0.2f * v;
-                if (BNORM) v = v * sc + sh;
-                p.out[((size_t(img) * H + y) * H + x) * COUT + co] = v;
+                    for (int e = 0; e < 16; ++e) {
+                        int m = wave * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        int il = m / (T::ROWS * H), y = y0 + (m / H) % T::ROWS, x = m % H;
+                        int img = img0 + il;
+                        float v = acc[mt][nt][e] + bias;
+                        acc[mt][nt][e] = 0.f;
+                        if (img >= p.n_img || mtile >= n_mtiles) continue;
+                        v = v > 0.f ? v : 0.2f * v;
+                        if (BNORM) v = v * sc + sh;
+                        p.out[((size_t(img) * H + y) * H + x) * COUT + co] = v;
+                    }
             }
+        }
+        __syncthreads();   // buffer step & 1 may be refilled; buffer (step + 1) & 1 is staged
     }
+}
+
+// nn.MaxPool2d(2): [n][2H][2H][C] -> [n][H][H][C]; one thread per output pixel and four channels
+template <int H, int C>
+__global__ void k_pool2(const float *in, float *out, int n) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(n) * H * H * (C / 4)) return;
+    int c4 = int(i % (C / 4));
+    size_t px = i / (C / 4);
+    int x = int(px % H), y = int((px / H) % H);
+    size_t img = px / (H * H);
+    const float *q = in + ((img * 2 * H + 2 * y) * 2 * H + 2 * x) * C + c4 * 4;
+    f32x4 a = *reinterpret_cast<const f32x4 *>(q), b = *reinterpret_cast<const f32x4 *>(q + C);
+    f32x4 c = *reinterpret_cast<const f32x4 *>(q + 2 * H * C), d = *reinterpret_cast<const f32x4 *>(q + 2 * H * C + C);
+    *reinterpret_cast<f32x4 *>(out + px * C + c4 * 4) = max4(max4(a, b), max4(c, d));
+}
+
+// nn.Upsample(scale_factor=2, mode="bilinear"): [n][H/2][H/2][C] -> [n][H][H][C]
+template <int H, int C>
+__global__ void k_up2(const float *in, float *out, int n) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(n) * H * H * (C / 4)) return;
+    constexpr int HL = H / 2;
+    int c4 = int(i % (C / 4));
+    size_t px = i / (C / 4);
+    int x = int(px % H), y = int((px / H) % H);
+    size_t img = px / (H * H);
+    int ya, yb, xa, xb;
+    float ly, lx;
+    up_coord(y, HL, ya, yb, ly);
+    up_coord(x, HL, xa, xb, lx);
+    const float *q = in + img * HL * HL * C + c4 * 4;
+    f32x4 a = *reinterpret_cast<const f32x4 *>(q + (ya * HL + xa) * C), b = *reinterpret_cast<const f32x4 *>(q + (ya * HL + xb) * C);
+    f32x4 c = *reinterpret_cast<const f32x4 *>(q + (yb * HL + xa) * C), d = *reinterpret_cast<const f32x4 *>(q + (yb * HL + xb) * C);
+    f32x4 top = lerp4(1.f - lx, a, lx, b), bot = lerp4(1.f - lx, c, lx, d);
+    *reinterpret_cast<f32x4 *>(out + px * C + c4 * 4) = lerp4(1.f - ly, top, ly, bot);
 }
 
 // (n, 7, 32, 32) as the network sees it (read_input, ml/main_stdio_net.py:47-72) -> NHWC with the channels padded to 16
@@ -269,7 +387,8 @@ __global__ void k_net_output(const float *in, const float *w /* [3][64] */, cons
     size_t pix = t >> 4;
     int q = int(t & 15);
     bool live = pix < size_t(n) * 1024;
-    float4 v = live ? *reinterpret_cast<const float4 *>(in + pix * 64 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (live) v = *reinterpret_cast<const f32x4 *>(in + pix * 64 + q * 4);
     float s[3];
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
@@ -295,13 +414,13 @@ struct LayerDef {
 // forward order (ml/iispt_net.py:27-88): encoder0.0, encoder0.2, encoder1.1, encoder1.4, encoder2.1, encoder2.4, encoder3.1,
 // encoder3.4, decoder0.0, decoder0.3, decoder1.0, decoder1.3, decoder2.0, decoder2.2 (decoder2.4 is k_net_output)
 const LayerDef kLayers[14] = {
-    {32, 16, 64, PRE_NONE, 16, false, false, 7},  {32, 64, 64, PRE_NONE, 32, false, false, 64},
-    {16, 64, 128, PRE_POOL, 32, true, false, 64}, {16, 128, 128, PRE_NONE, 32, false, false, 128},
-    {8, 128, 256, PRE_POOL, 32, true, false, 128}, {8, 256, 256, PRE_NONE, 32, false, false, 256},
-    {4, 256, 512, PRE_POOL, 16, true, false, 256}, {4, 512, 256, PRE_NONE, 16, false, false, 512},
-    {8, 512, 256, PRE_UPCAT, 32, true, true, 512}, {8, 256, 128, PRE_NONE, 32, false, true, 256},
-    {16, 256, 128, PRE_UPCAT, 32, true, true, 256}, {16, 128, 64, PRE_NONE, 32, false, true, 128},
-    {32, 128, 64, PRE_UPCAT, 32, false, true, 128}, {32, 64, 64, PRE_NONE, 32, false, true, 64},
+    {32, 16, 64, PRE_NONE, 16, false, false, 7},  {32, 64, 64, PRE_NONE, 16, false, false, 64},
+    {16, 64, 128, PRE_NONE, 16, true, false, 64}, {16, 128, 128, PRE_NONE, 16, false, false, 128},
+    {8, 128, 256, PRE_NONE, 16, true, false, 128}, {8, 256, 256, PRE_NONE, 16, false, false, 256},
+    {4, 256, 512, PRE_NONE, 16, true, false, 256}, {4, 512, 256, PRE_NONE, 16, false, false, 512},
+    {8, 512, 256, PRE_CAT, 16, true, true, 512}, {8, 256, 128, PRE_NONE, 16, false, true, 256},
+    {16, 256, 128, PRE_CAT, 16, true, true, 256}, {16, 128, 64, PRE_NONE, 16, false, true, 128},
+    {32, 128, 64, PRE_CAT, 16, false, true, 128}, {32, 64, 64, PRE_NONE, 16, false, true, 64},
 };
 const int kBnOfLayer[14] = {-1, -1, 0, -1, 1, -1, 2, -1, 3, -1, 4, -1, -1, -1};
 
@@ -317,54 +436,81 @@ float bf16_to_float(uint16_t b) {
     return f;
 }
 
-template <int H, int CIN, int COUT, int PRE, int CHUNK, bool BNORM>
-hipError_t launch_conv(const ConvArgs &a, hipStream_t s) {
+template <int H, int CIN, int COUT, int PRE, bool BNORM>
+hipError_t launch_conv(const ConvArgs &a, int n_cus, hipStream_t s) {
     using T = Tile<H>;
-    constexpr int ROWB = CHUNK * 2 + 16;
-    constexpr size_t lds = size_t(T::NLP) * ROWB * 2;
+    constexpr size_t lds = 2 * (size_t(T::NLP) * kRowB * 2 + kBStep);   // two buffers of {A hi, A lo, B}
+    static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false;
-    auto kern = k_conv3x3<H, CIN, COUT, PRE, CHUNK, BNORM>;
+    auto kern = k_conv3x3<H, CIN, COUT, PRE, BNORM>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     int n_mtiles = H >= 32 ? a.n_img * T::TILES_PER_IMG : (a.n_img + T::IMGS - 1) / T::IMGS;
-    int groups = (n_mtiles + 7) / 8;
-    int blocks = groups * 8 * (COUT / kBN);
+    int tiles = ((n_mtiles + 7) / 8) * 8 * (COUT / kBN);
+    int blocks = tiles < n_cus ? tiles : n_cus;   // one persistent workgroup per CU (a multiple of 8 either way)
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(kThreads), lds, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_layer(int layer, const ConvArgs &a, hipStream_t s) {
+hipError_t launch_layer(int layer, const ConvArgs &a, int n_cus, hipStream_t s) {
     switch (layer) {
-        case 0: return launch_conv<32, 16, 64, PRE_NONE, 16, false>(a, s);
-        case 1: return launch_conv<32, 64, 64, PRE_NONE, 32, false>(a, s);
-        case 2: return launch_conv<16, 64, 128, PRE_POOL, 32, true>(a, s);
-        case 3: return launch_conv<16, 128, 128, PRE_NONE, 32, false>(a, s);
-        case 4: return launch_conv<8, 128, 256, PRE_POOL, 32, true>(a, s);
-        case 5: return launch_conv<8, 256, 256, PRE_NONE, 32, false>(a, s);
-        case 6: return launch_conv<4, 256, 512, PRE_POOL, 16, true>(a, s);
-        case 7: return launch_conv<4, 512, 256, PRE_NONE, 16, false>(a, s);
-        case 8: return launch_conv<8, 512, 256, PRE_UPCAT, 32, true>(a, s);
-        case 9: return launch_conv<8, 256, 128, PRE_NONE, 32, false>(a, s);
-        case 10: return launch_conv<16, 256, 128, PRE_UPCAT, 32, true>(a, s);
-        case 11: return launch_conv<16, 128, 64, PRE_NONE, 32, false>(a, s);
-        case 12: return launch_conv<32, 128, 64, PRE_UPCAT, 32, false>(a, s);
-        case 13: return launch_conv<32, 64, 64, PRE_NONE, 32, false>(a, s);
+        case 0: return launch_conv<32, 16, 64, PRE_NONE, false>(a, n_cus, s);
+        case 1: return launch_conv<32, 64, 64, PRE_NONE, false>(a, n_cus, s);
+        case 2: return launch_conv<16, 64, 128, PRE_NONE, true>(a, n_cus, s);
+        case 3: return launch_conv<16, 128, 128, PRE_NONE, false>(a, n_cus, s);
+        case 4: return launch_conv<8, 128, 256, PRE_NONE, true>(a, n_cus, s);
+        case 5: return launch_conv<8, 256, 256, PRE_NONE, false>(a, n_cus, s);
+        case 6: return launch_conv<4, 256, 512, PRE_NONE, true>(a, n_cus, s);
+        case 7: return launch_conv<4, 512, 256, PRE_NONE, false>(a, n_cus, s);
+        case 8: return launch_conv<8, 512, 256, PRE_CAT, true>(a, n_cus, s);
+        case 9: return launch_conv<8, 256, 128, PRE_NONE, false>(a, n_cus, s);
+        case 10: return launch_conv<16, 256, 128, PRE_CAT, true>(a, n_cus, s);
+        case 11: return launch_conv<16, 128, 64, PRE_NONE, false>(a, n_cus, s);
+        case 12: return launch_conv<32, 128, 64, PRE_CAT, false>(a, n_cus, s);
+        case 13: return launch_conv<32, 64, 64, PRE_NONE, false>(a, n_cus, s);
     }
     return hipErrorInvalidValue;
 }
 
-// floats per probe of each activation tensor; buffer assignment (two ping-pong buffers P, Q and the three skip tensors)
-enum { BUF_P = 0, BUF_Q = 1, BUF_E0 = 2, BUF_E1 = 3, BUF_E2 = 4, N_BUF = 5 };
-const size_t kBufFloats[N_BUF] = {65536, 65536, 65536, 32768, 16384};
-// per layer: {in0, in1 (-1: none), out}; the network input (padded to 16 channels) sits in P
-const int kRoute[14][3] = {
-    {BUF_P, -1, BUF_Q},  {BUF_Q, -1, BUF_E0}, {BUF_E0, -1, BUF_P}, {BUF_P, -1, BUF_E1}, {BUF_E1, -1, BUF_P}, {BUF_P, -1, BUF_E2},
-    {BUF_E2, -1, BUF_P}, {BUF_P, -1, BUF_Q},  {BUF_Q, BUF_E2, BUF_P}, {BUF_P, -1, BUF_Q}, {BUF_Q, BUF_E1, BUF_P}, {BUF_P, -1, BUF_Q},
-    {BUF_Q, BUF_E0, BUF_P}, {BUF_P, -1, BUF_Q},
+// floats per probe of each activation tensor; buffer assignment: two ping-pong buffers P and Q, R for the pooled / upsampled
+// copies, and the three skip tensors
+enum { BUF_P = 0, BUF_Q = 1, BUF_R = 2, BUF_E0 = 3, BUF_E1 = 4, BUF_E2 = 5, N_BUF = 6 };
+const size_t kBufFloats[N_BUF] = {65536, 65536, 65536, 65536, 32768, 16384};
+// per layer: {in0, in1 (-1: none), out, what runs on `out` afterwards into R: 0 nothing, 1 MaxPool2d(2), 2 Upsample(x2)};
+// the network input (padded to 16 channels) sits in P
+const int kRoute[14][4] = {
+    {BUF_P, -1, BUF_Q, 0},      {BUF_Q, -1, BUF_E0, 1}, {BUF_R, -1, BUF_P, 0},      {BUF_P, -1, BUF_E1, 1}, {BUF_R, -1, BUF_P, 0},
+    {BUF_P, -1, BUF_E2, 1},     {BUF_R, -1, BUF_P, 0},  {BUF_P, -1, BUF_Q, 2},      {BUF_R, BUF_E2, BUF_P, 0}, {BUF_P, -1, BUF_Q, 2},
+    {BUF_R, BUF_E1, BUF_P, 0},  {BUF_P, -1, BUF_Q, 2},  {BUF_R, BUF_E0, BUF_P, 0},  {BUF_P, -1, BUF_Q, 0},
 };
+
+template <int H, int C>
+hipError_t launch_pool(const float *in, float *out, int n, hipStream_t s) {   // H: output size
+    size_t items = size_t(n) * H * H * (C / 4);
+    hipLaunchKernelGGL((k_pool2<H, C>), dim3((items + 255) / 256), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+template <int H, int C>
+hipError_t launch_up(const float *in, float *out, int n, hipStream_t s) {   // H: output size
+    size_t items = size_t(n) * H * H * (C / 4);
+    hipLaunchKernelGGL((k_up2<H, C>), dim3((items + 255) / 256), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+// the resampling step behind convolution layer l (kRoute[l][3])
+hipError_t launch_resample(int layer, const float *in, float *out, int n, hipStream_t s) {
+    switch (layer) {
+        case 1: return launch_pool<16, 64>(in, out, n, s);
+        case 3: return launch_pool<8, 128>(in, out, n, s);
+        case 5: return launch_pool<4, 256>(in, out, n, s);
+        case 7: return launch_up<8, 256>(in, out, n, s);
+        case 9: return launch_up<16, 128>(in, out, n, s);
+        case 11: return launch_up<32, 64>(in, out, n, s);
+    }
+    return hipErrorInvalidValue;
+}
 
 }  // namespace
 
@@ -375,6 +521,7 @@ struct iile_iispt_net {
     float *w_out = nullptr, *b_out = nullptr;
     float *ws = nullptr;      // activations of the current batch
     int ws_probes = 0;
+    int n_cus = 256;          // persistent grid of the convolution kernels (rounded down to a multiple of 8)
     std::vector<void *> allocs;
 };
 
@@ -456,6 +603,12 @@ int iile_iispt_net_create(const iile_iispt_net_weights *w, iile_iispt_net **out)
     for (int i = 0; i < 15; ++i)
         if (!w->conv_weight[i] || !w->conv_bias[i]) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_create: missing convolution tensor");
     auto *net = new iile_iispt_net();
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+            net->n_cus = prop.multiProcessorCount / 8 * 8;
+    }
     auto bail = [&](int rc) {
         iile_iispt_net_destroy(net);
         return rc;
@@ -502,7 +655,7 @@ int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_
     if (!net || !in_dev || !out_dev || n < 0) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_forward: bad argument");
     if (layer_out_dev && (layer < 0 || layer > 13)) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_forward: layer out of range");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (max_batch <= 0) max_batch = 16384;
+    if (max_batch <= 0) max_batch = 32768;
     const int cap = n < max_batch ? n : max_batch;
     if (n == 0) return IILE_OK;
     int rc = ensure_workspace(net, cap);
@@ -524,7 +677,8 @@ int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_
             a.bn_scale = bn >= 0 ? net->bn_scale[bn] : nullptr;
             a.bn_shift = bn >= 0 ? net->bn_shift[bn] : nullptr;
             a.n_img = nb;
-            NET_TRY(launch_layer(l, a, s));
+            NET_TRY(launch_layer(l, a, net->n_cus, s));
+            if (kRoute[l][3]) NET_TRY(launch_resample(l, a.out, buffer_of(net, BUF_R, na), nb, s));
             if (layer_out_dev && l == layer) {   // test probe: this layer's NHWC activations
                 size_t fl = size_t(kLayers[l].h) * kLayers[l].h * kLayers[l].cout;
                 NET_TRY(hipMemcpyAsync(layer_out_dev + size_t(first) * fl, a.out, fl * size_t(nb) * 4, hipMemcpyDeviceToDevice, s));

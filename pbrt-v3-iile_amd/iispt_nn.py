@@ -192,7 +192,7 @@ class IisptPipeline:
         return self.net(x.to(self.dtype).contiguous(memory_format=torch.channels_last)).float()
 
     @torch.no_grad()
-    def __call__(self, pos, direction, batch=8192):
+    def __call__(self, pos, direction, batch=32768):
         """(n, 3) probe origins and directions -> (predicted intensity (n, h, h, 3), rendered intensity, normals,
         distance), all torch tensors on the device, raster order."""
         n = len(pos)
