@@ -380,6 +380,11 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--alone-steps", type=int, default=2,
                     help="untimed extra steps with every kernel on one stream, for per-kernel durations without overlap (0: skip)")
+    ap.add_argument("--schedule", choices=["two-stream", "one-stream"], default="two-stream",
+                    help="two-stream: the product's schedule (the NEE kernels of a bounce beside the next bounce's extend / shade); "
+                         "one-stream: every kernel of the timed steps alone on the GPU — for kernel traces whose per-kernel averages are "
+                         "not mixed with time spent sharing the chip (profiles/*_one_stream_kernel_stats.csv); `value` is then the "
+                         "one-stream schedule's and says so")
     ap.add_argument("--scene", default=os.path.join(REPO, "scenes", "killeroo-simple.pbrt"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--sampler", choices=["halton", "sobol"], default=None,
@@ -504,7 +509,7 @@ def main():
                "n_shade_launches": 0}
         st = None
         for _ in range(steps):
-            st = step(timed=want_kernels, clock=True)
+            st = step(timed=(2 if args.schedule == "one-stream" else 1) if want_kernels else False, clock=True)
             for k in agg:
                 agg[k] += st[k]
         barrier()
@@ -609,13 +614,36 @@ def main():
             "registers+vmem": "waves per SIMD (128 VGPRs: four) and vector-memory instructions per hit; VALU issue at ~0.6 of the calibrated ceiling (DESIGN.md section 6)",
             "hbm": "streams its records once: HBM bandwidth",
         }
+        # Per-kernel durations: a kernel ALONE on the GPU — the one-stream steps after the timed region (or the timed steps themselves
+        # under --schedule one-stream). In the two-stream timed steps the NEE kernels of a bounce share the chip with the next
+        # bounce's extend / shade: those HIP-event durations overlap, sum to more than a step and say how long a kernel was
+        # resident, not how fast it is; they are kept under `overlapped` and never summed.
+        fam_key = {"k_extend": "ms_extend", "k_shade": "ms_shade", "k_shadow": "ms_shadow", "k_mis": "ms_mis", "k_mis_lit": "ms_resolve",
+                   "k_film": "ms_film"}
+        one_stream_timed = args.schedule == "one-stream"
+        have_alone = primary["n_alone"] > 0 or one_stream_timed
+
+        def alone_ms(k):   # ms per step of kernel family k with the GPU to itself
+            if one_stream_timed:
+                return agg[fam_key[k]] / steps
+            return primary["alone"][fam_key[k]] / primary["n_alone"]
+
         per_kernel = {}
         step_counter_bytes, step_counter_kernels = 0, []
-        for k, (ms_k, n_l, by, units, note) in fam.items():
-            if ms_k <= 0:
+        for k, (ms_sum, n_l, by, units, note) in fam.items():
+            if ms_sum <= 0:
                 continue
-            e = {"ms_per_step": round(ms_k / steps, 3), "launches_per_step": round(n_l / steps, 2), "bound": BINDS.get(k, "hbm"),
-                 "algorithmic_gbs": round(by * steps / ms_k / 1e6, 1), "algorithmic_bytes_note": note}
+            ms_step = alone_ms(k) if have_alone else ms_sum / steps   # ms per step this entry is priced with
+            if ms_step <= 0:
+                continue
+            by_step = by   # (the counts come from ONE instrumented step)
+            e = {"ms_per_step": round(ms_step, 3), "schedule": "one-stream (the kernel alone on the GPU)" if have_alone else "two-stream (overlapped: no one-stream steps in this run)",
+                 "launches_per_step": round(n_l / steps, 2), "bound": BINDS.get(k, "hbm"),
+                 "algorithmic_gbs": round(by_step / ms_step / 1e6, 1), "algorithmic_bytes_note": note}
+            if have_alone and not one_stream_timed:
+                e["overlapped"] = {"ms_per_step": round(ms_sum / steps, 3),
+                                   "note": "HIP-event duration in the two-stream timed steps: includes time spent sharing the GPU with the other stream's "
+                                           "kernels; not a kernel speed, never summed"}
             tr = pmc_traffic.get(k if k != "k_film" else "k_film_accumulate")
             if tr:
                 # The counters sit at the L2's memory side: they count what the Infinity Cache serves as well as what HBM
@@ -634,8 +662,8 @@ def main():
                                 "results out); reads beyond its input records are scene data missing the 4 MiB L2 and found in the 256 MiB "
                                 "Infinity Cache (FETCH_SIZE counts those too): an upper estimate of what is not HBM traffic"}
                 e["hbm_counter_bytes_per_step"] = tr["hbm_bytes_per_step"]
-                e["hbm_counter_gbs"] = round(tr["hbm_bytes_per_step"] / (ms_k / steps) / 1e6, 1)
-                # ONE definition for every kernel: counted memory-side bytes / the kernel's HIP-event time / 8 TB/s
+                e["hbm_counter_gbs"] = round(tr["hbm_bytes_per_step"] / ms_step / 1e6, 1)
+                # ONE definition for every kernel: counted memory-side bytes / the kernel's time alone on the GPU / 8 TB/s
                 e["frac"] = round(e["hbm_counter_gbs"] / HBM_PEAK_GBS, 4)
                 step_counter_bytes += tr["hbm_bytes_per_step"]
                 step_counter_kernels.append(k)
@@ -643,49 +671,45 @@ def main():
                     step_counter_bytes += pmc_traffic["k_film_resolve"]["hbm_bytes_per_step"]
             la = pmc_lanes.get(k)
             if la:
-                # VALU issue: wave-instructions x 64 lane slots against CUs x SIMDs x 32 lanes x clock, over THIS run's time
-                tl = la["SQ_INSTS_VALU"] * 64 / (ms_k / steps * 1e-3) / 1e12
+                # VALU issue: wave-instructions x 64 lane slots against CUs x SIMDs x 32 lanes x clock, over the kernel's time alone
+                tl = la["SQ_INSTS_VALU"] * 64 / (ms_step * 1e-3) / 1e12
                 e["valu"] = {"issued_tlaneops": round(tl, 2), "peak_tlaneops": round(VALU_PEAK_TLANEOPS, 1),
                              "issue_frac": round(tl / VALU_PEAK_TLANEOPS, 4), "lane_util": la.get("lane_util"),
                              "valu_busy": la.get("valu_busy"), "insts_valu_per_step": la["SQ_INSTS_VALU"],
                              # where a resident wave's time goes (SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES)
                              "wave_wait_any_frac": la.get("wave_wait_any_frac"), "wave_wait_inst_frac": la.get("wave_wait_inst_frac"),
                              "wave_active_inst_frac": la.get("wave_active_inst_frac"),
+                             "counters_schedule": "the counter passes ran the two-stream command: the wave_* fractions describe the kernel beside its "
+                                                  "neighbours of the other stream (a kernel queued behind another stream reads as waiting)",
                              "calibration": "profiles/r03_valu_calib.json: independent v_fma_f32 saturate at 0.5 wave-instructions per cycle per "
                                             "SIMD (= peak_tlaneops) from ~4 ready waves per SIMD, one wave alone issues 0.19-0.25; `valu_busy` "
                                             "(4 x SQ_ACTIVE_INST_VALU / SIMDs / busy cycles) reads 0.76 for one wave per SIMD and 1.5-1.8 when "
                                             "saturated, so it is not a utilisation out of 1; FP64 / packed FP32 cost 2 issue slots, "
                                             "transcendentals 4, a correctly rounded a/b ~17, sqrt ~22 — `issue_frac` counts every instruction as one slot"}
                 if "TCC_REQ_sum" in la:
-                    l2 = la["TCC_REQ_sum"] * 128 / (ms_k / steps * 1e-3) / 1e9
+                    l2 = la["TCC_REQ_sum"] * 128 / (ms_step * 1e-3) / 1e9
                     e["l2"] = {"requests_per_step": la["TCC_REQ_sum"], "hit_rate": la.get("l2_hit_rate"),
                                "gbs_at_128B_per_request": round(l2, 1), "frac_of_l2_peak": round(l2 / L2_PEAK_GBS, 4)}
                 if "TCP_TOTAL_CACHE_ACCESSES_sum" in la and vmem_peak:
                     # the vector-memory roofline: L1 accesses (one per lane and load instruction when the lanes diverge) per ns per
                     # CU against the ceiling measured for the same access shape (scene-sized table: 18 MB for the room, 1 MB when the
                     # tree fits an XCD's L2 many times over)
-                    rate = la["TCP_TOTAL_CACHE_ACCESSES_sum"] / (ms_k / steps * 1e6) / 256.0
+                    rate = la["TCP_TOTAL_CACHE_ACCESSES_sum"] / (ms_step * 1e6) / 256.0
                     peak = vmem_peak.get(18 if args.workload.startswith("boxroom") else 1) or max(vmem_peak.values())
                     e["vmem"] = {"l1_accesses_per_step": la["TCP_TOTAL_CACHE_ACCESSES_sum"], "l1_accesses_per_ns_cu": round(rate, 3),
                                  "calibrated_peak_per_ns_cu": peak, "frac": round(rate / peak, 4), "calibration": vmem_src,
                                  "ta_busy": la.get("ta_busy"), "td_busy": la.get("td_busy")}
             per_kernel[k] = e
-        # the dominant kernel: by the one-stream steps when there are any (with two streams the HIP-event durations of the
-        # timed region depend on what happened to run beside a kernel, and the order of the top two flips from run to run)
-        fam_key = {"k_extend": "ms_extend", "k_shade": "ms_shade", "k_shadow": "ms_shadow", "k_mis": "ms_mis", "k_mis_lit": "ms_resolve",
-                   "k_film": "ms_film"}
-        if primary["n_alone"] > 0:
-            dom = max(per_kernel, key=lambda k: primary["alone"][fam_key[k]])
-        else:
-            dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
-        ms_k, n_launch, bytes_all, units_k, note_k = fam[dom]
+        # the dominant kernel: the largest time alone on the GPU
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
+        ms_sum, n_launch, bytes_all, units_k, note_k = fam[dom]
         launches_per_step = n_launch / steps
-        avg_ms = ms_k / max(n_launch, 1)
+        ms_dom_step = alone_ms(dom) if have_alone else ms_sum / steps
+        avg_ms = ms_dom_step / max(launches_per_step, 1)
         achieved = (bytes_all / launches_per_step) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         if dom in pmc_traffic:
             traffic = int(pmc_traffic[dom]["hbm_bytes_per_step"] / max(pmc_traffic[dom]["launches_in_step"], 1))
-        cache_resident = dom in ("k_extend", "k_shadow", "k_mis")
         frac_alg = achieved / HBM_PEAK_GBS
         frac_traffic = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None
         roof = {
@@ -693,6 +717,7 @@ def main():
             "bound": BINDS.get(dom, "hbm"),
             "bound_note": BIND_NOTES[BINDS.get(dom, "hbm")],
             "priced_against": "hbm",
+            "schedule": per_kernel[dom]["schedule"],
             # the contract's pair: algorithmic bytes per launch / launch time, against the HBM peak ...
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
@@ -701,7 +726,8 @@ def main():
             # (`traffic` / avg_launch_ms / 8 TB/s; null without a committed counter set for this workload)
             "frac": frac_traffic,
             "frac_definition": "traffic / avg_launch_ms / peak: PMC-counted memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc "
-                               "passes of this command, profiles/" + str(tr_src) + "), the same definition for every kernel of roofline_all_kernels",
+                               "passes of this command, profiles/" + str(tr_src) + ") over the kernel's launch time ALONE on the GPU (HIP events of the "
+                               "one-stream steps of this run), the same definition for every kernel of roofline_all_kernels",
             "frac_algorithmic": round(frac_alg, 4),
             "frac_algorithmic_note": "achieved / peak with SURVEY.md 8(d)'s bytes (32 B per BVH node of the REFERENCE's layout + 48 B per triangle test "
                                      "+ 48 B per ray). It can exceed 1 for the traversal kernels: the scene (7 MB; the room 35 MB) is served from L2 / "
@@ -718,29 +744,20 @@ def main():
             "l2": per_kernel[dom].get("l2"),
             "vmem": per_kernel[dom].get("vmem"),
             "lanes_source": la_src,
-            "kernel_choice": ("largest HIP-event time over all kernels of a step with every kernel alone on the GPU (the one-stream steps of this run)"
-                              if primary["n_alone"] > 0 else "largest HIP-event time over all kernels of the step (this run)"),
+            "kernel_choice": "largest HIP-event time per step over all kernels, every kernel alone on the GPU" if have_alone
+                             else "largest HIP-event time over all kernels of the (two-stream) step: this run had no one-stream steps",
         }
-        # the same kernel with the GPU to itself (one-stream steps after the timed region)
-        if primary["n_alone"] > 0:
-            al, na = primary["alone"], primary["n_alone"]
-            key = fam_key[dom]
-            a_ms = al[key] / na / max(launches_per_step, 1)
-            a_ach = (bytes_all / launches_per_step) / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
-            one = {"avg_launch_ms": round(a_ms, 4), "achieved": round(a_ach, 1), "frac_algorithmic": round(a_ach / HBM_PEAK_GBS, 4),
-                   "steps": na, "frac": round(traffic / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
-            la = pmc_lanes.get(dom)
-            if la:
-                one["valu_issue_frac"] = round(la["SQ_INSTS_VALU"] * 64 / (al[key] / na * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4)
-                if "TCP_TOTAL_CACHE_ACCESSES_sum" in la and per_kernel[dom].get("vmem"):
-                    r1 = la["TCP_TOTAL_CACHE_ACCESSES_sum"] / (al[key] / na * 1e6) / 256.0
-                    one["vmem_frac"] = round(r1 / per_kernel[dom]["vmem"]["calibrated_peak_per_ns_cu"], 4)
-            roof["one_stream"] = one
-            roof["one_stream_note"] = ("In the timed steps the shadow / MIS kernels of a bounce run on a second stream beside the next bounce's "
-                                       "k_extend and k_shade (each fills the other's tail), so the HIP-event durations of the timed region — the ones "
-                                       "`achieved`, `frac` and a rocprofv3 trace of this command show — include time spent sharing the GPU and sum to "
-                                       "more than a step; `one_stream` prices the same kernel from extra untimed steps in which every kernel has "
-                                       "the GPU to itself.")
+        if have_alone and not one_stream_timed:
+            # the same kernel as the timed two-stream steps saw it (sharing the chip): what a rocprofv3 trace of the DEFAULT command shows
+            o_ms = (ms_sum / steps) / max(launches_per_step, 1)
+            o_ach = (bytes_all / launches_per_step) / (o_ms * 1e-3) / 1e9 if o_ms > 0 else 0.0
+            roof["overlapped"] = {"avg_launch_ms": round(o_ms, 4), "achieved": round(o_ach, 1), "frac_algorithmic": round(o_ach / HBM_PEAK_GBS, 4),
+                                  "frac": round(traffic / (o_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                                  "note": "In the timed steps the shadow / MIS kernels of a bounce run on a second stream beside the next bounce's "
+                                          "k_extend and k_shade (each fills the other's tail): these HIP-event durations — the ones a rocprofv3 "
+                                          "trace of the default command shows — include time spent sharing the GPU. Kept for comparison with such a "
+                                          "trace; profiles/*_one_stream_kernel_stats.csv is the trace of `--schedule one-stream`, which agrees with "
+                                          "the figures above"}
         copy_gbs = measured_copy_gbs(torch)
         roof["peak_measured_copy_gbs"] = round(copy_gbs, 1)
         # the whole step against HBM: counted bytes of every kernel of a step / ms_per_step / peak; and SURVEY.md 8(d)'s own
@@ -789,8 +806,9 @@ def main():
             "n_tri_per_ray": round(n_tri, 4),
             "b_ray_bytes": round(b_ray, 1),
             "job_algorithmic_gbs": round(mray * 1e6 * b_ray / 1e9, 1),
-            "kernel_ms_per_step_rank0": {k: round(agg[k] / steps, 3) for k in
-                                         ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_resolve", "ms_film", "ms_total")},
+            "schedule": args.schedule,
+            "kernel_ms_per_step_overlapped_rank0": {k: round(agg[k] / steps, 3) for k in
+                                                    ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_resolve", "ms_film", "ms_total")},
             "kernel_ms_per_step_one_stream": ({k: round(primary["alone"][k] / primary["n_alone"], 3) for k in
                                                ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_mis", "ms_resolve", "ms_film", "ms_total")}
                                               if primary["n_alone"] else None),

@@ -107,6 +107,15 @@ void iile_scene_destroy(iile_scene *scene);
  * With tile sharding each rank's film holds its own tiles' contributions
  * (zeros elsewhere); ranks are combined with one sum-reduction. */
 int iile_render(iile_scene *scene, const iile_render_params *params, float *film_xyzw, iile_stats *stats);
+/* iile_render(film_on_device = 1, stats = NULL) returns as soon as its kernels are queued on `stream`: it cannot know yet whether
+ * the exact finish of whole-number film positions (FilmTile's one-pixel halo) ran out of the room the frame was
+ * sized for. iile_render_status waits for `stream` and returns IILE_ERR_UNSUPPORTED if it did (that film is wrong), IILE_OK
+ * otherwise; the next iile_render on the scene makes the same check on entry, so the error cannot go unseen. The reference has
+ * no such state: SamplerIntegrator::Render returns when the film is complete (integrator.cpp:331-339). */
+int iile_render_status(iile_scene *scene, void *stream);
+/* Test probe: force the capacity (pixel hits per pass and tile sums per render) of the exact film finish for the scene's next
+ * renders; 0 = sized from the frame again. */
+int iile_test_patch_capacity(iile_scene *scene, uint32_t capacity);
 
 /* ---- kernel-level entry points (parity tests; host pointers, synchronous) ---- */
 /* BVHAccel::Intersect on n rays. prim[i] = -1 on miss; tb[4i..] = {t, b0, b1, b2}.

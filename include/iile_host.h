@@ -42,7 +42,8 @@ typedef struct iile_host_overrides {
     int (*bvh_build)(int32_t n_prims, const float *bounds6, int32_t max_prims_in_node, iile_bvh_node *nodes_out,
                      int32_t *n_nodes_out, int32_t *order_out, void *stats);
     int32_t quick_render; /* pbrt --quick (PbrtOptions.quickRender): a quarter of the file's resolution per axis (film.cpp:284-285)
-                             and one pixel sample (halton.cpp:136, sobol.cpp:69); explicit xres / yres / spp above still win */
+                             and one pixel sample (halton.cpp:136, sobol.cpp:69), a quarter of the light samples of area and infinite lights
+                             (diffuse.cpp:143, infinite.cpp:183); explicit xres / yres / spp above still win */
 } iile_host_overrides;
 #define IILE_SPLIT_KEEP 0
 #define IILE_SPLIT_SAH 1
@@ -95,6 +96,8 @@ int iile_host_read_image(const char *path, int32_t *width, int32_t *height, floa
 /* The MIP pyramid built for image texture `index` of a loaded scene (ImageTexture::GetTexture + MIPMap's
  * constructor, src/textures/imagemap.cpp:53-101, src/core/mipmap.h:111-208). */
 int iile_host_scene_texture(const iile_host_scene *scene, int32_t index, iile_texture *out);
+/* Copies light `index` of a loaded scene (Light::nSamples, type, emission ... as iile_scene_desc::lights holds them). */
+int iile_host_scene_light(const iile_host_scene *scene, int32_t index, iile_light *out);
 /* Copies level `level` (level_w x level_h RGB texels, row 0 = bottom scanline) of that texture. */
 int iile_host_scene_texture_level(const iile_host_scene *scene, int32_t index, int32_t level, float *rgb);
 

@@ -138,7 +138,9 @@ typedef struct iile_light {
     int32_t prim;       /* triangle area light: its primitive, in BVH order */
     /* Light::nSamples (area and infinite lights: "samples" / "nsamples", diffuse.cpp:140-141, infinite.cpp:181-182; 0 means 1).
      * The path integrator never looks at it (UniformSampleOneLight); the IISPT direct pass's UniformSampleAllLights does
-     * (integrator.cpp:54-83) and is built for 1 only: iile_render_direct rejects a scene where it is larger. */
+     * (integrator.cpp:54-83): iile_render_direct takes n_samples light samples per vertex from every light, at most 64 per
+     * vertex over all lights (it rejects a scene that asks for more). pbrt --quick divides it by 4 (diffuse.cpp:143,
+     * infinite.cpp:183: iile_host_overrides::quick_render). */
     int32_t n_samples;
     /* infinite: lemit is L * scale; w2l as for the spot light; world_radius as for the distant light; and */
     float l2w[9];       /* upper 3x3 of LightToWorld, row major */

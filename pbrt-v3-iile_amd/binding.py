@@ -49,6 +49,13 @@ class Texture(ctypes.Structure):
                 ("level_offset", ctypes.c_int64 * 16)]
 
 
+class Light(ctypes.Structure):
+    """iile_light (include/iile_scene.h)."""
+    _fields_ = [("lemit", c_f32 * 3), ("two_sided", c_i32), ("sphere", c_i32), ("type", c_i32), ("pos", c_f32 * 3), ("w2l", c_f32 * 9),
+                ("cos_total_width", c_f32), ("cos_falloff_start", c_f32), ("world_radius", c_f32), ("prim", c_i32), ("n_samples", c_i32),
+                ("l2w", c_f32 * 9), ("env_tex", c_i32), ("dist_w", c_i32), ("dist_h", c_i32), ("dist_offset", ctypes.c_int64)]
+
+
 class RenderParams(ctypes.Structure):
     _fields_ = [("k_begin", c_i32), ("k_end", c_i32), ("tile_rank", c_i32), ("tile_nranks", c_i32),
                 ("spp_per_pass", c_i32), ("collect_stats", c_i32), ("time_kernels", c_i32),
@@ -110,7 +117,7 @@ HOST_SYMBOLS = ["iile_host_load_pbrt", "iile_host_scene_desc", "iile_host_scene_
                 "iile_host_scene_free", "iile_host_film_to_rgb", "iile_host_write_pfm", "iile_host_last_error", "iile_host_read_image",
                 "iile_host_scene_texture", "iile_host_scene_texture_level", "iile_host_scene_filter_table",
                 "iile_host_sobol_matrices", "iile_host_sobol_vdc", "iile_host_write_exr", "iile_host_write_image",
-                "iile_host_scene_film_filename"]
+                "iile_host_scene_film_filename", "iile_host_scene_light"]
 class NetWeights(ctypes.Structure):
     """iile_iispt_net_weights (include/iile_gpu.h)."""
     _fields_ = [("conv_weight", c_vp * 15), ("conv_bias", c_vp * 15), ("bn_weight", c_vp * 5), ("bn_bias", c_vp * 5),
@@ -127,7 +134,7 @@ GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iil
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
                "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download",
                "iile_iispt_hemi_points", "iile_iispt_gather", "iile_iispt_hemi_points_batch", "iile_iispt_gather_batch", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct",
-               "iile_wide_ref_shift", "iile_iispt_net_create", "iile_iispt_net_forward", "iile_iispt_net_destroy"]
+               "iile_wide_ref_shift", "iile_render_status", "iile_test_patch_capacity", "iile_iispt_net_create", "iile_iispt_net_forward", "iile_iispt_net_destroy"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size", "iile_dist_ranks_seen",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_rendezvous_file_token", "iile_dist_rendezvous_done", "iile_dist_all_ok",
@@ -243,6 +250,8 @@ def gpu_lib():
         lib.iile_iispt_gather_batch.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32]
         lib.iile_bvh_build_hlbvh.argtypes = [c_i32, c_vp, c_i32, c_vp, ctypes.POINTER(c_i32), c_vp, ctypes.POINTER(BvhBuildStats)]
         lib.iile_bvh_pack_probe.argtypes = [c_i32, c_vp, c_i32, c_vp, c_vp, ctypes.POINTER(c_i32)]
+        lib.iile_render_status.argtypes = [c_vp, c_vp]
+        lib.iile_test_patch_capacity.argtypes = [c_vp, c_u32]
         lib.iile_iispt_net_create.argtypes = [ctypes.POINTER(NetWeights), ctypes.POINTER(c_vp)]
         lib.iile_iispt_net_forward.argtypes = [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32]
         lib.iile_iispt_net_destroy.argtypes = [c_vp]
@@ -398,6 +407,13 @@ class HostScene:
         wide = host_lib().iile_host_scene_filter_table(self._h, t.ctypes.data)
         return t, bool(wide)
 
+    def light(self, index):
+        """iile_light number `index` of the scene (a copy)."""
+        lt = Light()
+        if host_lib().iile_host_scene_light(self._h, int(index), ctypes.byref(lt)) != 0:
+            raise RuntimeError(host_lib().iile_host_last_error().decode())
+        return lt
+
     def texture(self, index):
         """(iile_texture, [level arrays (h, w, 3), row 0 = bottom scanline]) of image texture `index`."""
         lib = host_lib()
@@ -472,6 +488,13 @@ class GpuScene:
         rc = gpu_lib().iile_render(self._s, ctypes.byref(prm), ptr, ctypes.byref(st) if want_stats else None)
         self._check(rc, "iile_render")
         return film, (st.as_dict() if want_stats else None)
+
+    def render_status(self, stream=None):
+        """iile_render_status: waits for `stream`; raises if the last asynchronous render's exact film finish overflowed."""
+        self._check(gpu_lib().iile_render_status(self._s, c_vp(stream) if stream else None), "iile_render_status")
+
+    def test_patch_capacity(self, capacity):
+        self._check(gpu_lib().iile_test_patch_capacity(self._s, int(capacity)), "iile_test_patch_capacity")
 
     def trace_closest(self, o, d, tmax, instrumented=True):
         """instrumented=False runs the traversal of the uninstrumented render kernels."""
@@ -590,7 +613,10 @@ class GpuScene:
     def iispt_gather_batch(self, tasks, valid, pos, direction, nn_films=None, nn_device_ptr=None, out_device_ptr=None):
         """iile_iispt_gather_batch: the per-pixel loop of several tasks from one set of launches. valid / pos / direction / nn_films
         (n_hemi, 32, 32, 3) as iispt_hemi_points_batch orders them; the result is (n_pixels, 4), the tasks' pixels one task after the
-        other, row-major inside a task (None when written to out_device_ptr)."""
+        other, row-major inside a task (None when written to out_device_ptr).
+        With out_device_ptr the call returns once its kernels are queued on the NULL stream and they read the scene's shared
+        scratch block: consume the output on the null stream (PyTorch's default stream is that stream) or synchronise the device
+        first — the C ABI has no stream argument for this call."""
         arr = (IisptTask * len(tasks))(*tasks)
         valid, pos, direction = np.ascontiguousarray(valid, np.uint8), _f32(pos), _f32(direction)
         n_pix = sum((t.x1 - t.x0) * (t.y1 - t.y0) for t in tasks)

@@ -98,6 +98,9 @@ struct iile_scene {
     // the exact film finish on the device (kernels.hip): hit / entry records and the hash table, allocated at the first render
     PatchDev patch{};
     void *patch_block = nullptr;
+    uint32_t patch_cap_override = 0;     // iile_test_patch_capacity: hits / entries capacity forced by a test
+    bool overflow_unchecked = false;     // an asynchronous render left patch.counters[2] unread
+    hipStream_t overflow_stream = nullptr;
     // grow-only device scratch of the host-side film finish (IILE_DEBUG_HOST_FILM_FINISH: index lists in, gathered values out)
     char *scratch = nullptr;
     size_t scratch_cap = 0, scratch_used = 0;
@@ -177,16 +180,28 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     return IILE_OK;
 }
 
-int ensure_patch(iile_scene *sc) {
-    if (sc->patch_block) return IILE_OK;
+// Room for the exact film finish (kernels.hip), sized from the frame: a flagged camera sample reaches at most three more
+// pixels (hits), every hit becomes at most one tile sum (entries, kept for the whole render). paths_per_pass / samples_in_render
+// bound the flagged samples of a pass / of the render; the flagged list itself holds kMaxFlagged records per pass.
+int ensure_patch(iile_scene *sc, uint64_t paths_per_pass, uint64_t samples_in_render) {
     PatchDev &D = sc->patch;
-    D.cap_hits = 1u << 21;
-    D.cap_entries = 1u << 21;
-    const uint32_t table = 1u << 22;
+    uint64_t want_hits = 3 * std::min<uint64_t>(kMaxFlagged, paths_per_pass);
+    uint64_t want_entries = 3 * std::min<uint64_t>(kMaxFlagged, samples_in_render);
+    want_hits = std::max<uint64_t>(want_hits, 4096);
+    want_entries = std::max<uint64_t>(want_entries, 4096);
+    if (sc->patch_cap_override) want_hits = want_entries = sc->patch_cap_override;   // iile_test_patch_capacity
+    if (sc->patch_block && want_hits == D.cap_hits && want_entries == D.cap_entries) return IILE_OK;
+    if (sc->patch_block && !sc->patch_cap_override && want_hits <= D.cap_hits && want_entries <= D.cap_entries) return IILE_OK;
+    if (sc->patch_block) HIP_TRY(hipFree(sc->patch_block));
+    sc->patch_block = nullptr;
+    D.cap_hits = uint32_t(want_hits);
+    D.cap_entries = uint32_t(want_entries);
+    uint32_t table = 1024;
+    while (table < 2 * D.cap_entries) table <<= 1;
     D.table_mask = table - 1;
     const size_t bytes = 256 + size_t(D.cap_hits) * sizeof(uint4) + size_t(table) * 8 + size_t(D.cap_entries) * (sizeof(uint4) + sizeof(float4));
     void *blk = nullptr;
-    if (hipMalloc(&blk, bytes) != hipSuccess) return fail(IILE_ERR_HIP, "out of device memory for the exact film finish (128 MiB)");
+    if (hipMalloc(&blk, bytes) != hipSuccess) return fail(IILE_ERR_HIP, "out of device memory for the exact film finish");
     sc->patch_block = blk;
     char *p = static_cast<char *>(blk);
     D.counters = reinterpret_cast<uint32_t *>(p);
@@ -200,6 +215,21 @@ int ensure_patch(iile_scene *sc) {
     D.ent_a = reinterpret_cast<uint4 *>(p);
     p += size_t(D.cap_entries) * sizeof(uint4);
     D.ent_b = reinterpret_cast<float4 *>(p);
+    return IILE_OK;
+}
+
+// The exact film finish reports running out of room through patch.counters[2]; a render that returns before its stream has
+// drained (film on the device, no statistics) cannot look. Whoever waits next does: iile_render_status, or the next iile_render.
+int check_pending_overflow(iile_scene *sc) {
+    if (!sc->overflow_unchecked || !sc->patch_block) return IILE_OK;
+    HIP_TRY(hipStreamSynchronize(sc->overflow_stream));
+    uint32_t pc[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(pc, sc->patch.counters, sizeof(pc), hipMemcpyDeviceToHost));
+    sc->overflow_unchecked = false;
+    if (pc[2] != 0)
+        return fail(IILE_ERR_UNSUPPORTED, "the exact film finish of the previous asynchronous iile_render ran out of room (camera samples with whole-number "
+                                          "film positions: more than 2^20 in one pass, or more pixel hits / tile sums than the frame was sized for): "
+                                          "that film is wrong");
     return IILE_OK;
 }
 
@@ -1549,6 +1579,8 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (!sc || !prm || !film_xyzw) return fail(IILE_ERR_ARG, "iile_render: null argument");
     int rc = ensure_device();
     if (rc) return rc;
+    rc = check_pending_overflow(sc);   // of an earlier render that returned before its stream had drained
+    if (rc) return rc;
     const DScene &S = sc->ds;
     int k_begin = prm->k_begin, k_end = prm->k_end;
     if (k_end <= 0) {
@@ -1609,7 +1641,7 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     std::vector<PatchEntry> entries;
     const bool host_finish = std::getenv("IILE_DEBUG_HOST_FILM_FINISH") != nullptr;
     if (!S.filter_wide && !host_finish) {
-        rc = ensure_patch(sc);
+        rc = ensure_patch(sc, uint64_t(tiles_per_pass) * paths_per_tile, uint64_t(P.n_owned_tiles) * paths_per_tile);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(sc->patch.counters, 0, 16, stream));
     }
@@ -1697,6 +1729,10 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     // The film is complete once the stream drains. Statistics need the drain; a device-resident film without stats
     // stays asynchronous on `stream` past the last pass (the exact film finish waits for each pass on that stream, and
     // only on it: nothing here touches the null stream or synchronises the device).
+    if (!(stats || !prm->film_on_device) && pix_slots && !S.filter_wide && !host_finish) {
+        sc->overflow_unchecked = true;   // nobody waits here: iile_render_status / the next iile_render reads the error word
+        sc->overflow_stream = stream;
+    }
     if (stats || !prm->film_on_device) {
         HIP_TRY(hipStreamSynchronize(stream));
         float ms = 0;
@@ -1711,8 +1747,8 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
             HIP_TRY(hipMemcpyAsync(pc, sc->patch.counters, sizeof(pc), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             if (pc[2] != 0)
-                return fail(IILE_ERR_UNSUPPORTED, "the exact film finish ran out of room (more than 2^20 camera samples with whole-number film "
-                                                  "positions in one pass, or more than 2^21 pixel hits / tile sums in one render)");
+                return fail(IILE_ERR_UNSUPPORTED, "the exact film finish ran out of room (camera samples with whole-number film positions: more than "
+                                                  "2^20 in one pass, or more pixel hits / tile sums than the frame was sized for)");
         }
         if (pix_slots) {
             DCounters c;
@@ -2100,6 +2136,9 @@ namespace {
 // carved from the scene's scratch block (grown on demand, kept): the runner makes hundreds of calls per frame.
 size_t carve_bytes(size_t n, size_t elem) { return (std::max<size_t>(n, 1) * elem + 255) & ~size_t(255); }
 constexpr int kIisptMaxJobs = 1024;  // tasks per launch (blockIdx.y); longer batches run in slices
+// The traversal kernel of a slice runs max(tasks, ~6 blocks per CU) blocks and every block owns a column of the stack spill
+// array, which is sized for 8 blocks per CU (max_traversal_threads): a slice never holds more tasks than that.
+int iispt_slice_jobs(const iile_scene *sc) { return std::max(1, std::min(kIisptMaxJobs, sc->n_cus * 8)); }
 
 // A slice of a batch laid out in the scratch block: per task its items (five float4 planes and the Halton indices, task after
 // task), the job array the kernels read, one counter of items still on a specular chain.
@@ -2243,8 +2282,9 @@ int iile_iispt_hemi_points_batch(iile_scene *sc, const iile_iispt_task *tasks, i
     if (!sc || !tasks || n_tasks < 1) return fail(IILE_ERR_ARG, "iile_iispt_hemi_points: no task");
     if (!valid || !pos3 || !dir3) return fail(IILE_ERR_ARG, "iile_iispt_hemi_points: null output");
     size_t first = 0;
-    for (int k0 = 0; k0 < n_tasks; k0 += kIisptMaxJobs) {
-        const int nk = std::min(kIisptMaxJobs, n_tasks - k0);
+    const int slice = iispt_slice_jobs(sc);
+    for (int k0 = 0; k0 < n_tasks; k0 += slice) {
+        const int nk = std::min(slice, n_tasks - k0);
         const int rc = hemi_points_slice(sc, tasks + k0, nk, valid + first, pos3 + 3 * first, dir3 + 3 * first);
         if (rc) return rc;
         for (int k = k0; k < k0 + nk; ++k)
@@ -2262,8 +2302,9 @@ int iile_iispt_gather_batch(iile_scene *sc, const iile_iispt_task *tasks, int32_
     if (!valid || !pos3 || !dir3 || !nn_films || !out_rgbw) return fail(IILE_ERR_ARG, "iile_iispt_gather: null argument");
     const size_t per_hemi = size_t(sc->probe.hemi_size) * sc->probe.hemi_size * 3;
     size_t first_h = 0, first_p = 0;
-    for (int k0 = 0; k0 < n_tasks; k0 += kIisptMaxJobs) {
-        const int nk = std::min(kIisptMaxJobs, n_tasks - k0);
+    const int slice = iispt_slice_jobs(sc);
+    for (int k0 = 0; k0 < n_tasks; k0 += slice) {
+        const int nk = std::min(slice, n_tasks - k0);
         const int rc = gather_slice(sc, tasks + k0, nk, valid + first_h, pos3 + 3 * first_h, dir3 + 3 * first_h, nn_films + first_h * per_hemi, nn_on_device,
                                     out_rgbw + 4 * first_p, out_on_device);
         if (rc) return rc;
@@ -2317,6 +2358,20 @@ static int trace_common(iile_scene *sc, int32_t n, const float *o3, const float 
     (void)hipFree(drd);
     (void)hipFree(dh);
     (void)hipFree(dc);
+    return IILE_OK;
+}
+
+int iile_render_status(iile_scene *sc, void *stream) {
+    if (!sc) return fail(IILE_ERR_ARG, "iile_render_status: null scene");
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return check_pending_overflow(sc);
+}
+
+int iile_test_patch_capacity(iile_scene *sc, uint32_t capacity) {
+    if (!sc) return fail(IILE_ERR_ARG, "iile_test_patch_capacity: null scene");
+    sc->patch_cap_override = capacity;
     return IILE_OK;
 }
 

@@ -39,6 +39,9 @@ int iile_host_load_pbrt(const char *path, const iile_host_overrides *ov, iile_ho
                 hs->s.xres = std::max(1, hs->s.xres / 4);
                 hs->s.yres = std::max(1, hs->s.yres / 4);
                 hs->s.spp = 1;
+                // Light::nSamples of area and infinite lights: max(1, nSamples / 4) (diffuse.cpp:143, infinite.cpp:183)
+                for (iile_light &lt : hs->s.lights)
+                    if (lt.n_samples > 1) lt.n_samples = std::max(1, lt.n_samples / 4);
             }
             if (ov->xres > 0) hs->s.xres = ov->xres;
             if (ov->yres > 0) hs->s.yres = ov->yres;
@@ -73,6 +76,15 @@ const iile_film_desc *iile_host_scene_film(const iile_host_scene *scene) {
 }
 
 const char *iile_host_scene_film_filename(const iile_host_scene *scene) { return scene ? scene->s.film_filename.c_str() : ""; }
+
+int iile_host_scene_light(const iile_host_scene *scene, int32_t index, iile_light *out) {
+    if (!scene || !out || index < 0 || size_t(index) >= scene->s.lights.size()) {
+        g_err = "iile_host_scene_light: null argument or light index out of range";
+        return 1;
+    }
+    *out = scene->s.lights[size_t(index)];
+    return 0;
+}
 
 int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info *info) {
     if (!scene || !info) {

@@ -553,6 +553,7 @@ class Loader {
                 lt.cos_falloff_start = std::cos(radians(coneangle - conedelta));
             } else if (name == "infinite" || name == "exinfinite") {  // CreateInfiniteLight, lights/infinite.cpp:176-186
                 lt.type = IILE_LIGHT_INFINITE;
+                lt.n_samples = ps.one_int("samples", ps.one_int("nsamples", 1));   // infinite.cpp:181-182
                 for (int r = 0; r < 3; ++r)
                     for (int c = 0; c < 3; ++c) {
                         lt.l2w[3 * r + c] = ctm_.m.m[r][c];

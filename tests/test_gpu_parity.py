@@ -782,6 +782,36 @@ def test_whole_number_film_positions_bitwise(binding, oracle):
         assert_bitwise(part, pref, f"strip, shard {rank} of 2")
 
 
+def test_exact_finish_overflow_reaches_the_asynchronous_caller(binding, oracle):
+    """The exact finish is sized from the frame; when it runs out of room anyway the film is wrong and the caller must hear of
+    it. iile_render(film on the device, no statistics) only enqueues and returns IILE_OK, so the error has to come later:
+    iile_render_status (waits for the stream) reports it once, and if nobody asks, the next iile_render does on entry. A render
+    that waits (host film, or statistics) reports it itself. With the capacity sized from the frame again, the same strip is
+    the oracle's bit for bit."""
+    import torch
+    torch.cuda.init()
+    scene = binding.HostScene(xres=1900, yres=24, spp=48)   # dozens of whole-number film positions (test above)
+    gpu = binding.GpuScene(scene)
+    h, w = scene.film_shape
+    film = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    gpu.test_patch_capacity(8)   # room for 8 pixel hits: far too few
+    gpu.render(film_device_ptr=film.data_ptr(), stream=stream, want_stats=False)   # returns IILE_OK: nothing has run yet
+    with pytest.raises(RuntimeError, match="ran out of room"):
+        gpu.render_status(stream)
+    gpu.render_status(stream)   # reported once; the flag is cleared
+    gpu.render(film_device_ptr=film.data_ptr(), stream=stream, want_stats=False)
+    with pytest.raises(RuntimeError, match="previous asynchronous"):
+        gpu.render(film_device_ptr=film.data_ptr(), stream=stream, want_stats=False)   # nobody asked: the next call does
+    with pytest.raises(RuntimeError, match="ran out of room"):
+        gpu.render()   # a render that waits reports its own overflow
+    gpu.test_patch_capacity(0)
+    ref, _ = oracle.render(scene)
+    gpu.render(film_device_ptr=film.data_ptr(), stream=stream, want_stats=False)
+    gpu.render_status(stream)
+    assert_bitwise(film.cpu().numpy(), ref, "strip, capacity sized from the frame")
+
+
 def test_device_film_is_finished_without_a_host_wait(binding, oracle):
     """The exact finish of the pixels reached by whole-number film positions runs on the device (kernels.hip "exact film
     finish"): iile_render with a device-resident film and no statistics only ENQUEUES — two renders and a reduction of their

@@ -631,3 +631,38 @@ def test_quick_render_override(binding):
     assert (q.info["xres"], q.info["yres"], q.info["spp"]) == (max(1, full.info["xres"] // 4), max(1, full.info["yres"] // 4), 1)
     q2 = binding.HostScene(quick=True, xres=50, spp=3)
     assert (q2.info["xres"], q2.info["yres"], q2.info["spp"]) == (50, max(1, full.info["yres"] // 4), 3)
+
+
+def test_light_samples_of_area_and_infinite_lights(binding, tmp_path):
+    """Light::nSamples: "samples" (else "nsamples", else 1) for area lights (diffuse.cpp:140-141) AND infinite lights
+    (infinite.cpp:181-182); pbrt --quick turns n into max(1, n / 4) for both (diffuse.cpp:143, infinite.cpp:183). Point lights
+    have none. UniformSampleAllLights of the IISPT direct pass draws that many samples per light, so a wrong count shifts every
+    later random number of the pixel."""
+    import ctypes
+    assert ctypes.sizeof(binding.Light) == 152   # sizeof(iile_light): 36 four-byte members and one int64
+    text = '''LookAt 0 0 5  0 0 0  0 1 0
+Camera "perspective" "float fov" [40]
+Film "image" "integer xresolution" [16] "integer yresolution" [16]
+Sampler "halton" "integer pixelsamples" [1]
+WorldBegin
+LightSource "infinite" "color L" [1 1 1] "integer samples" [6] "integer nsamples" [2]
+LightSource "infinite" "color L" [.1 .1 .1] "integer nsamples" [9]
+LightSource "infinite" "color L" [.1 .1 .1]
+LightSource "point" "color I" [1 1 1]
+AttributeBegin
+  AreaLightSource "diffuse" "color L" [5 5 5] "integer samples" [8]
+  Shape "sphere" "float radius" [.5]
+AttributeEnd
+Material "matte"
+Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-1 -1 0  1 -1 0  0 1 0]
+WorldEnd
+'''
+    path = tmp_path / "lights.pbrt"
+    path.write_text(text)
+    s = binding.HostScene(path=str(path))
+    assert s.info["n_lights"] == 5
+    assert [max(1, s.light(i).n_samples) for i in range(5)] == [6, 9, 1, 1, 8]
+    q = binding.HostScene(path=str(path), quick=True)
+    assert [max(1, q.light(i).n_samples) for i in range(5)] == [1, 2, 1, 1, 2]
+    with pytest.raises(RuntimeError):
+        s.light(5)

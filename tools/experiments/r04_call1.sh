@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-4 first measurement call: vector-memory calibration, A/B of the traversal variants on the room and killeroo,
 # record-order scramble, vote statistics
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r04_call1
 mkdir -p $O
 cd $R

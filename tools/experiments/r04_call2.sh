@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 second measurement call: load-width calibration, occupancy / stack-depth / vote variants on top of leaf3, vote statistics
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r04_call2
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 third measurement call: refill rule (fixed idle-lane thresholds against the wasted-lane-steps rule), direct-pass and network tests
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r04_call3
 mkdir -p $O
 cd $R

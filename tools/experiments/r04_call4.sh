@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 fourth measurement call: the ramp refill rule, the split axes in the refs; parity of the combination
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r04_call4
 mkdir -p $O
 cd $R

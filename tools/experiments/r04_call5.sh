@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 fifth measurement call: adaptive refill batch; infinite lights in the direct pass
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r04_call5
 mkdir -p $O
 cd $R
