@@ -106,6 +106,7 @@ void oracle_texture_eval(const iile_scene_desc *scene, int trig_mode, int tex, i
                          float *rgb3);
 /* first hit of the camera ray through film point (pfx, pfy): {u, v, du/dx, dv/dx, du/dy, dv/dy} as
  * ComputeDifferentials leaves them (interaction.cpp:103-149); returns 0 when the ray escapes */
+int oracle_hit_geometry(const iile_scene_desc *scene, int trig_mode, const float *o3, const float *d3, float *out24);
 int oracle_camera_hit_differentials(const iile_scene_desc *scene, int trig_mode, float pfx, float pfy, float *out6);
 /* Distribution1D (sampling.h:55-109) over func[0..n), n <= 8: mode 0 SampleDiscrete, mode 1 SampleContinuous */
 int oracle_distribution1d(const float *func, int n, int mode, float u, float *value, float *pdf);

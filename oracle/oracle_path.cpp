@@ -1353,6 +1353,25 @@ struct Oracle {
         V3 snw = normalize(xf_normal(mi, sn));
         is->sdpdu = xf_vector(m, dpdu);
         is->sn = faceforward(snw, is->n);
+        // dndu / dndv from the fundamental forms (sphere.cpp:122-143) and, with dpdu / dpdv, their object-to-world images
+        // (transform.cpp:275-283: vectors by the matrix, Normal3f by the inverse transpose). Only the direct pass's
+        // reflected-ray differentials read them (directprogressiveintegrator.cpp:165-184): no texture is ever looked up on a sphere.
+        const float dt = sp.theta_max - sp.theta_min;
+        const V3 d2Pduu = (-sp.phi_max * sp.phi_max) * V3(ph.x, ph.y, 0);
+        const V3 d2Pduv = (dt * ph.z * sp.phi_max) * V3(-sin_phi, cos_phi, 0.f);
+        const V3 d2Pdvv = (-dt * dt) * V3(ph.x, ph.y, ph.z);
+        const float E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+        const V3 N = normalize(cross(dpdu, dpdv));
+        const float e = dot(N, d2Pduu), f = dot(N, d2Pduv), g = dot(N, d2Pdvv);
+        const float inv_egf2 = 1 / (E * G - F * F);
+        const V3 dndu = ((f * F - e * G) * inv_egf2) * dpdu + ((e * F - f * E) * inv_egf2) * dpdv;
+        const V3 dndv = ((g * F - f * G) * inv_egf2) * dpdu + ((f * F - g * E) * inv_egf2) * dpdv;
+        is->dpdu = is->sdpdu;
+        is->dpdv = is->sdpdv = xf_vector(m, dpdv);
+        is->dndu = xf_normal(mi, dndu);
+        is->dndv = xf_normal(mi, dndv);
+        is->uv[0] = is->uv[1] = 0;
+        is->flip = sp.reverse_orientation ^ sp.swaps_handedness;
     }
 
     // ------------------------------------------------------------------------
@@ -2693,8 +2712,7 @@ struct Oracle {
     }
     // DirectProgressiveIntegrator::Li, directprogressiveintegrator.cpp:22-58. Differentials: the camera ray's, and — they feed
     // the texture filtering of whatever a mirror shows — the reflected rays' (SpecularReflect, :165-184), from the hit's dpdx /
-    // dpdy, du/dx .. and shading.dndu / dndv (triangles; a textured scene with a specular SPHERE is rejected by
-    // oracle_iispt_direct: its dndu / dndv are not restated).
+    // dpdy, du/dx .. and shading.dndu / dndv (triangle_interaction, sphere_interaction).
     Rgb direct_li(Ray ray, DirectSampler &smp, RayDiff rdiff, int depth) const {
         Rgb L(0.f);
         Isect is;
@@ -3542,6 +3560,23 @@ int oracle_camera_hit_differentials(const iile_scene_desc *scene, int trig_mode,
     out6[5] = is.dvdy;
     return 1;
 }
+// The closest hit's differential geometry as the direct pass reads it: out24 = {p, n, shading n, dpdu, dpdv, shading dndu, dndv, {prim, -, -}}
+int oracle_hit_geometry(const iile_scene_desc *scene, int trig_mode, const float *o3, const float *d3, float *out24) {
+    Counters c;
+    Oracle orc(*scene, trig_mode, &c);
+    Ray ray{V3(o3[0], o3[1], o3[2]), V3(d3[0], d3[1], d3[2]), std::numeric_limits<float>::infinity()};
+    Isect is;
+    if (!orc.intersect(ray, &is)) return 0;
+    const V3 v[7] = {is.p, is.n, is.sn, is.dpdu, is.dpdv, is.dndu, is.dndv};
+    for (int i = 0; i < 7; ++i) {
+        out24[3 * i] = v[i].x;
+        out24[3 * i + 1] = v[i].y;
+        out24[3 * i + 2] = v[i].z;
+    }
+    out24[21] = float(is.prim);
+    out24[22] = out24[23] = 0;
+    return 1;
+}
 // Distribution1D over func[0 .. n), n <= IILE_MAX_LIGHTS (src/tests/sampling.cpp:231-304): mode 0 SampleDiscrete (the
 // light selection of UniformSampleOneLight) -> returns the offset, *pdf = DiscretePDF-style pdf; mode 1
 // SampleContinuous (the environment map's rows and columns) -> *value, *pdf, returns the offset
@@ -3772,7 +3807,7 @@ extern "C" {
 // The IISPT direct pass into a film monitor (IisptFilmMonitor::add_n_samples, iisptfilmmonitor.cpp:47-72: doubles): n_passes
 // passes of DirectProgressiveIntegrator::RenderOnePass, pass p seeded as described at DirectSampler, added in pass order into
 // film_rgbw[(y * w + x) * 4] = {sum r, sum g, sum b, sum of ray weights} over the film's cropped pixel bounds (zeroed first).
-// 0 = ok, 1 = bad arguments, 3 = image textures together with a specular SPHERE (the reflected ray's differentials need its dndu / dndv),
+// 0 = ok, 1 = bad arguments.
 // Glass: DirectProgressiveIntegrator::Li calls ComputeScatteringFunctions with allowMultipleLobes = false (interaction.h:130-133),
 // so GlassMaterial adds SpecularReflection + SpecularTransmission (glass.cpp:62-90) and Li recurses through both: a tree, walked here
 // by the recursion itself (round 3 assumed FresnelSpecular and rendered glass black; the device pass refuses glass).
@@ -3780,20 +3815,6 @@ int oracle_iispt_direct(const iile_scene_desc *scene, int trig_mode, int n_passe
     if (!scene || !film_rgbw || n_passes < 0) return 1;
     const iile_scene_desc &S = *scene;
     const iile_film_desc &F = S.film;
-    // (textures that only an environment light uses — n_textures counts its Lmap — need no ray differentials)
-    bool textured_material = false;
-    if (S.n_textures > 0)
-        for (int m = 0; m < S.n_materials; ++m) {
-            const iile_material &mm = S.materials[m];
-            for (int t : {mm.kd_tex, mm.ks_tex, mm.kr_tex, mm.kt_tex, mm.bump_tex, mm.rough_tex, mm.sigma_tex})
-                if (t >= 0) textured_material = true;
-        }
-    if (textured_material)  // a specular SPHERE in a textured scene: the reflected ray's differentials need the sphere's dndu / dndv
-        for (int i = 0; i < S.n_prims; ++i) {
-            if (!(S.prim_flags[i] & IILE_PRIM_SPHERE) || S.prim_material[i] < 0) continue;
-            const iile_material &mm = S.materials[S.prim_material[i]];
-            if (mm.type == IILE_MAT_MIRROR || (mm.type == IILE_MAT_UBER && (mm.kr[0] > 0 || mm.kr[1] > 0 || mm.kr[2] > 0))) return 3;
-        }
     const int fw = F.crop_x1 - F.crop_x0, fh = F.crop_y1 - F.crop_y0;
     std::memset(film_rgbw, 0, sizeof(double) * 4 * size_t(fw) * fh);
     if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());

@@ -53,7 +53,6 @@ struct iile_scene {
     int n_cus = 256;
     int max_depth = 5;
     int spp = 1;
-    bool specular_sphere = false;  // a sphere with a mirror / uber-Kr material (the direct pass's reflected-ray differentials)
     int light_samples[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // Light::nSamples (iile_light::n_samples), the direct pass's nLightSamples
     // wavefront workspace, grown on demand and kept across renders
     uint32_t ws_paths = 0;
@@ -1042,11 +1041,6 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     S.rr_threshold = d->integrator.rr_threshold;
     sc->max_depth = d->integrator.max_depth;
     for (int i = 0; i < d->n_lights && i < 8; ++i) sc->light_samples[i] = std::max(1, int(d->lights[i].n_samples));
-    for (int i = 0; i < d->n_prims; ++i) {
-        if (!(d->prim_flags[i] & IILE_PRIM_SPHERE) || d->prim_material[i] < 0 || d->prim_material[i] >= d->n_materials) continue;
-        const iile_material &mm = d->materials[d->prim_material[i]];
-        if (mm.type == IILE_MAT_MIRROR || (mm.type == IILE_MAT_UBER && (mm.kr[0] > 0 || mm.kr[1] > 0 || mm.kr[2] > 0))) sc->specular_sphere = true;
-    }
     {
         void *p = nullptr;
         if (hipMalloc(&p, size_t(max_traversal_threads(sc->n_cus)) * sizeof(int)) != hipSuccess)
@@ -1777,10 +1771,8 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     if (rc) return rc;
     DScene S = sc->ds;
     // reflected rays carry differentials in textured scenes (SpecularReflect, directprogressiveintegrator.cpp:165-184), built from the
-    // hit's shading.dndu / dndv — which this build has for triangles only
+    // hit's dpdu / dpdv and shading.dndu / dndv (triangles: triangle_interaction; spheres: sphere_interaction<true>)
     const bool reflect_diffs = S.textured_materials && S.has_specular;
-    if (reflect_diffs && sc->specular_sphere)
-        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: image textures together with a specular sphere (the reflected ray's differentials need the sphere's dndu / dndv)");
     if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
     // Glass: DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), GlassMaterial
     // then adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and both recursions fire — Li is a tree,

@@ -538,6 +538,7 @@ struct Isect {
 
 // Sphere::Intersect's interaction + Transform::operator()(SurfaceInteraction)
 // (sphere.cpp:104-155, interaction.cpp:44-70, transform.cpp:262-297)
+template <bool DIFFS = false>
 DEV void sphere_interaction(const DSphere &sp, F3 obj_d, F3 ph, Isect *is) {
     float theta = acos_f(clampf(ph.z / sp.radius, -1, 1));
     float z_radius = sqrtf(ph.x * ph.x + ph.y * ph.y);
@@ -562,6 +563,27 @@ DEV void sphere_interaction(const DSphere &sp, F3 obj_d, F3 ph, Isect *is) {
     F3 snw = normalize(xf_normal(sp.o2w_inv, sn));
     is->sdpdu = xf_vector(sp.o2w, dpdu);
     is->sn = faceforward(snw, is->n);
+    if (DIFFS) {
+        // what the direct pass's reflected-ray differentials need of a sphere hit (directprogressiveintegrator.cpp:165-184):
+        // dpdu / dpdv for ComputeDifferentials and dndu / dndv from the fundamental forms (sphere.cpp:122-143), in world space
+        // (transform.cpp:275-283: vectors by the matrix, Normal3f by the inverse transpose)
+        const float dt = sp.theta_max - sp.theta_min;
+        const F3 d2Pduu = (-sp.phi_max * sp.phi_max) * F3{ph.x, ph.y, 0};
+        const F3 d2Pduv = (dt * ph.z * sp.phi_max) * F3{-sin_phi, cos_phi, 0.f};
+        const F3 d2Pdvv = (-dt * dt) * F3{ph.x, ph.y, ph.z};
+        const float E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+        const F3 N = normalize(cross(dpdu, dpdv));
+        const float e = dot(N, d2Pduu), f = dot(N, d2Pduv), g = dot(N, d2Pdvv);
+        const float inv_egf2 = 1 / (E * G - F * F);
+        const F3 dndu = ((f * F - e * G) * inv_egf2) * dpdu + ((e * F - f * E) * inv_egf2) * dpdv;
+        const F3 dndv = ((g * F - f * G) * inv_egf2) * dpdu + ((f * F - g * E) * inv_egf2) * dpdv;
+        is->dpdu = is->sdpdu;
+        is->dpdv = is->sdpdv = xf_vector(sp.o2w, dpdv);
+        is->dndu = xf_normal(sp.o2w_inv, dndu);
+        is->dndv = xf_normal(sp.o2w_inv, dndv);
+        is->u = is->v = 0;   // (no texture is ever looked up on a sphere: the loader refuses one)
+        is->flip = sp.reverse_orientation ^ sp.swaps_handedness;
+    }
 }
 
 // Triangle::Intersect's interaction (triangle.cpp:277-400) from the stored

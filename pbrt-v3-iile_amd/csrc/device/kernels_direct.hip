@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlock, IILE_DIRECT_SHADE_WAVES) void k_direct_shad
                 F3 od, ph;
                 const DSphere &sp = S.spheres[S.prim_shape[prim]];
                 sphere_test(sp, ray_o, ray_d, IILE_INF, &t, &od, &ph);
-                sphere_interaction(sp, od, ph, &is);
+                sphere_interaction<TEX>(sp, od, ph, &is);
             } else {
                 triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, ray_d, h4.y, h4.z,
                                      h4.w, &is);
@@ -496,6 +496,7 @@ TREE_CALL bool tree_trace(const DScene &S, F3 ro, F3 rd, float tmax, bool any_hi
     return traverse<false, false>(S, ro, rd, tmax, stack, spill, spill_stride, h, &st);
 }
 // the SurfaceInteraction of a hit (and the light / material of its primitive)
+template <bool TEX>
 TREE_CALL void tree_interaction(const DScene &S, int prim, F3 ro, F3 rd, float b0, float b1, float b2, Isect *is, int *material, int *light) {
     const float4 v0 = S.tri_verts[3 * size_t(prim)], v1 = S.tri_verts[3 * size_t(prim) + 1], v2 = S.tri_verts[3 * size_t(prim) + 2];
     const uint32_t flags = f2b(v0.w);
@@ -506,7 +507,7 @@ TREE_CALL void tree_interaction(const DScene &S, int prim, F3 ro, F3 rd, float b
         F3 od, ph;
         const DSphere &sp = S.spheres[S.prim_shape[prim]];
         sphere_test(sp, ro, rd, IILE_INF, &t, &od, &ph);
-        sphere_interaction(sp, od, ph, is);
+        sphere_interaction<TEX>(sp, od, ph, is);
     } else {
         triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, rd, b0, b1, b2, is);
     }
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                 }
                 Isect is;
                 int material = 0, light = -1;
-                tree_interaction(S, h.prim, ro, rd, h.b0, h.b1, h.b2, &is, &material, &light);
+                tree_interaction<TEX>(S, h.prim, ro, rd, h.b0, h.b1, h.b2, &is, &material, &light);
                 TexDiff td = TexDiff{0, 0, 0, 0};
                 F3 dpdx = F3{0, 0, 0}, dpdy = F3{0, 0, 0};
                 if (TEX && has_diff) td = compute_differentials(is, rdiff, &dpdx, &dpdy);

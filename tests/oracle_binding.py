@@ -302,6 +302,15 @@ class Oracle:
         self.lib.oracle_texture_eval(scene.desc, trig_mode, tex, len(uv), uv.ctypes.data, duv.ctypes.data, out.ctypes.data)
         return out
 
+    def hit_geometry(self, scene, o, d, trig_mode=TRIG_LIBM):
+        """{p, n, ns, dpdu, dpdv, dndu, dndv} (7, 3) of the closest hit along (o, d), or None."""
+        o, d = _f32(o), _f32(d)
+        out = np.zeros(24, np.float32)
+        self.lib.oracle_hit_geometry.argtypes = [c_vp, ctypes.c_int, c_vp, c_vp, c_vp]
+        if not self.lib.oracle_hit_geometry(scene.desc, trig_mode, o.ctypes.data, d.ctypes.data, out.ctypes.data):
+            return None
+        return out[:21].reshape(7, 3)
+
     def camera_hit_differentials(self, scene, pfx, pfy, trig_mode=TRIG_PORTABLE):
         out = np.zeros(6, np.float32)
         if not self.lib.oracle_camera_hit_differentials(scene.desc, trig_mode, pfx, pfy, out.ctypes.data):

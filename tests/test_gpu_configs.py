@@ -146,6 +146,30 @@ def test_config4_full_size_room_1080p(binding, oracle, tmp_path):
     assert _bits_equal(plain, ref).all()
 
 
+def test_config4_room_past_sample_8(binding, oracle, tmp_path):
+    """The same deep tree at 960x540 and 16 samples per pixel: past sample 8 the Halton samples of a pixel meet
+    whole-number film positions (round 1's film bug only showed there) and the adaptive refill of the persistent traversal
+    waves has run through many queue generations. Film and every counter with the instrumented kernels, film with the plain
+    ones, and the plain kernels again in passes of 5 samples' worth of paths — all against the oracle, bit for bit."""
+    import boxroom
+    path = tmp_path / "room16.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(ico_levels=5, n_blobs=12, wall_n=64, xres=960, yres=540, spp=16))
+    scene = binding.HostScene(path=str(path))
+    assert scene.info["n_triangles"] > 250000 and scene.info["spp"] == 16
+    gpu = binding.GpuScene(scene)
+    ref, ost = oracle.render(scene)
+    film, st = gpu.render(collect_stats=True)
+    assert _bits_equal(film, ref).all()
+    assert st["camera_rays"] == 960 * 540 * 16 == ost["camera_rays"]
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["nodes_closest"] == ost["nodes_closest"] and st["nodes_any"] == ost["nodes_any"]
+    assert st["tri_tests"] == ost["tri_tests"] and st["path_length"] == ost["path_length"]
+    plain, pst = gpu.render()
+    assert pst["n_passes"] == 1 and _bits_equal(plain, ref).all()
+    passes, pst = gpu.render(spp_per_pass=5)
+    assert pst["n_passes"] >= 3 and _bits_equal(passes, ref).all()
+
+
 def test_dist_world1_film_reduce(binding, gpu_small, scene_small):
     """libiile_dist.so on hardware, as far as one GPU allows: a one-rank communicator, the in-place film reduction on
     the stream the render ran on, the host-side totals."""

@@ -968,3 +968,58 @@ WorldEnd
             assert np.allclose(pdf_again, pdf_s[ok], rtol=2e-3, atol=1e-6), f"material {mat}: Sample_f's pdf is not Pdf()"
             albedo = (f_s[ok] * np.abs(wi_s[ok, 2:3]) / pdf_s[ok, None]).sum(0) / len(u)
             assert (albedo >= 0).all() and (albedo <= 1.02).all(), (mat, albedo)
+
+
+def test_sphere_hit_differentials_are_the_spheres(binding, oracle, tmp_path):
+    """The oracle's sphere dpdu / dpdv / dndu / dndv (sphere.cpp:111-143, object -> world by transform.cpp:275-283) against what
+    differential geometry says of a sphere, on an untransformed ball, one with reversed orientation and a scaled + rotated +
+    translated one: (1) dpdu, dpdv are tangent; (2) on the round ball the Weingarten map is the identity over the radius,
+    dndu = dpdu / r and dndv = dpdv / r — for the normal of Cross(dpdu, dpdv), which ReverseOrientation flips in n but not in
+    dndu (interaction.cpp:62-68 touches n and shading.n only) — and a finite difference of the unit normal between two hits a
+    small step along dpdu apart reproduces dndu; (3) under the transform L (linear part of Translate . Rotate . Scale) the
+    reference maps dpdu as a vector and dndu as a Normal3f, so L^T dndu_world = (L^-1 dpdu_world) / r — NOT the derivative of
+    the world-space unit normal when L is no rotation, and the restatement must make the same choice. No reference output exists for these
+    (the reference has no test of Sphere's derivatives): this pins the restatement the device is compared with."""
+    import numpy as np
+    header = 'LookAt 0 -8 0  0 0 0  0 0 1\nCamera "perspective" "float fov" [40]\nFilm "image" "integer xresolution" [16] "integer yresolution" [16]\n' \
+             'Sampler "halton" "integer pixelsamples" [1]\nWorldBegin\nLightSource "point" "color I" [1 1 1] "point from" [0 -8 4]\n'
+    cases = {"round": ('Shape "sphere" "float radius" [1.5]', 1.5, 1.0),
+             "reversed": ('ReverseOrientation\nShape "sphere" "float radius" [1.5]', 1.5, -1.0),
+             "squashed": ('Translate 0.3 0.2 -0.1\nRotate 35 0 1 1\nScale 1.4 0.6 0.9\nShape "sphere" "float radius" [1.2]', None, 1.0)}
+    rng = np.random.default_rng(3)
+    for name, (shape, radius, orient) in cases.items():
+        path = tmp_path / f"{name}.pbrt"
+        path.write_text(header + 'AttributeBegin\nMaterial "matte"\n' + shape + "\nAttributeEnd\nWorldEnd\n")
+        scene = binding.HostScene(path=str(path))
+        n_checked = 0
+        for _ in range(40):
+            target = rng.uniform(-0.6, 0.6, 3)
+            o = np.array([0, -8, 0], np.float32) + rng.uniform(-1, 1, 3).astype(np.float32)
+            g = oracle.hit_geometry(scene, o, (target - o).astype(np.float32))
+            if g is None:
+                continue
+            p, n, ns, dpdu, dpdv, dndu, dndv = (g[i].astype(np.float64) for i in range(7))
+            assert abs(np.dot(dpdu, n)) < 1e-4 * np.linalg.norm(dpdu) and abs(np.dot(dpdv, n)) < 1e-4 * np.linalg.norm(dpdv)
+            if radius is None:
+                ax = np.array([0, 1, 1]) / np.sqrt(2.0)
+                th = np.radians(35.0)
+                K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                L = (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K) @ np.diag([1.4, 0.6, 0.9])
+                for dn, dp in ((dndu, dpdu), (dndv, dpdv)):
+                    assert np.allclose(L.T @ dn, np.linalg.solve(L, dp) / 1.2, rtol=1e-3, atol=1e-4), (name, L.T @ dn, np.linalg.solve(L, dp) / 1.2)
+                n_checked += 1
+                continue
+            assert abs(np.dot(dndu, n)) < 1e-3 * np.linalg.norm(dndu) + 1e-6 and abs(np.dot(dndv, n)) < 1e-3 * np.linalg.norm(dndv) + 1e-6
+            if radius is not None:
+                assert np.sign(np.dot(n, p)) == orient
+                assert np.allclose(dndu, dpdu / radius, rtol=2e-4, atol=1e-5), (name, dndu, dpdu)
+                assert np.allclose(dndv, dpdv / radius, rtol=2e-4, atol=1e-5), (name, dndv, dpdv)
+            # a step of eps in u: the surface point moves by eps * dpdu, the (unflipped) normal by eps * dndu
+            eps = 2e-3
+            g2 = oracle.hit_geometry(scene, o, (p + eps * dpdu - o).astype(np.float32))
+            if g2 is None or np.linalg.norm(dndu) < 1e-3:
+                continue
+            fd = orient * (g2[1].astype(np.float64) - n) / eps
+            assert np.linalg.norm(fd - dndu) < 0.03 * np.linalg.norm(dndu) + 2e-3, (name, fd, dndu)
+            n_checked += 1
+        assert n_checked > 15, name
