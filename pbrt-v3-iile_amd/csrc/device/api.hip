@@ -347,7 +347,7 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
     PassBuffers &B = sc->pb;
     PassDesc P = P_in;
     // camera rays made inside the first extend / shade (see PassDesc::gen_fused) where nothing else reads queue 0
-    P.gen_fused = !cfg.count_stats && !P.list_px && !S.has_infinite && !S.probe_mode && !B.nray_out && !std::getenv("IILE_NO_FUSED_GEN");
+    P.gen_fused = !cfg.count_stats && !P.list_px && !S.has_infinite && !S.probe_mode && !B.nray_out;
     HIP_TRY(hipMemsetAsync(B.counts, 0, kCntWords * sizeof(uint32_t), cfg.stream));
     auto timed_launch_on = [&](hipStream_t stream, int kind, auto &&fn) -> int {
         EventPair *ep = nullptr;
@@ -366,7 +366,7 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
     // by side and each fills the idle compute units of the other's tail; k_shade of bounce b + 1 waits for both (it
     // overwrites the NEE records, and may add emitted light to L after the NEE contribution of bounce b as path.cpp
     // does). Not with infinite lights (k_miss adds to L between the two) and not in the instrumented pass.
-    const bool two_streams = sc->nee_stream && !one_stream && !cfg.count_stats && !S.has_infinite && max_depth < 15 && !std::getenv("IILE_ONE_STREAM");
+    const bool two_streams = sc->nee_stream && !one_stream && !cfg.count_stats && !S.has_infinite && max_depth < 15;
     // Without specular lobes k_shade touches L at bounce 0 only, and with the NEE arrays doubled (even / odd bounces) it
     // need not wait for k_shadow of the bounce before: the NEE stream then trails the main one by up to a bounce.
     const bool nee_doubled = two_streams && !S.has_specular && B.nee_alt;
@@ -394,7 +394,7 @@ int run_pass(iile_scene *sc, const DScene &S, int max_depth, const PassDesc &P_i
     // lobe are the only ones whose intersection can still add something: the others are dropped there (1); without
     // either, the whole bounce is (2).
     P.skip_last_bounce = 0;
-    if (!cfg.count_stats && max_depth >= 1 && !S.probe_mode && !B.nray_out && !std::getenv("IILE_TRACE_LAST_BOUNCE"))
+    if (!cfg.count_stats && max_depth >= 1 && !S.probe_mode && !B.nray_out)
         P.skip_last_bounce = S.has_specular ? 1 : 2;
     const int last_bounce = (P.skip_last_bounce == 2) ? max_depth - 1 : max_depth;
     for (int b = 0; b <= last_bounce; ++b) {
@@ -632,26 +632,12 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         // its parent's (Union in recursiveBuild is exact). pack_wide_records verifies it for the tree we were handed; a
         // tree that violates it is traversed with binary steps only.
         S.boxes_nested = 1;
-        // Where the records sit in memory is free (a reference is a record slot): depth-first rank by default. The diagnostic
-        // order IILE_RECORD_ORDER=scramble scatters them (rank * prime mod n) to measure what the order is worth at all.
-        std::vector<int> remap;
-        const int *d_remap = nullptr;
-        if (const char *e = std::getenv("IILE_RECORD_ORDER")) {
-            if (std::string(e) == "scramble" && n_interior > 2) {
-                long long prime = 7919;
-                while (std::gcd<long long>(prime, n_interior) != 1) prime += 2;
-                remap.resize(size_t(n_interior));
-                for (int j = 0; j < n_interior; ++j) remap[size_t(j)] = int((j * prime) % n_interior);
-            }
-        }
-        if (!remap.empty()) {
-            rc = upload(sc, remap.data(), remap.size(), &d_remap);
-            if (rc) return bail(rc);
-        }
-        rc = pack_wide_records(d_nodes, n, n_interior, wide, wide4, &S.boxes_nested, d_remap);
+        // (where the records sit in memory is free — a reference is a record slot — and worth nothing: depth-first rank 476.2 ms,
+        // scattered 476.0 on the room, profiles/r04_ab_traversal_scheduling.txt)
+        rc = pack_wide_records(d_nodes, n, n_interior, wide, wide4, &S.boxes_nested, nullptr);
         if (rc) return bail(rc);
-        // the four-wide step addresses its records with 32-bit byte offsets (and, with IILE_AXES_IN_REFS, gives two bits of
-        // every ref to a split axis: leaf refs ~prim must survive the shift)
+        // the four-wide step addresses its records with 32-bit byte offsets and gives two bits of every ref to a split axis:
+        // leaf refs ~prim must survive the shift
         if (n_interior >= (1 << 25) || (kRefShift && d->n_prims >= (1 << 28))) S.boxes_nested = 0;
         S.wide = wide;
         S.wide4 = wide4;
@@ -660,7 +646,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 S.root_box[c] = d->nodes[0].bmin[c];
                 S.root_box[3 + c] = d->nodes[0].bmax[c];
             }
-            S.root_ref = d->nodes[0].nprims == 0 ? (remap.empty() ? 0 : remap[0]) : ~d->nodes[0].offset;  // the root is interior rank 0
+            S.root_ref = d->nodes[0].nprims == 0 ? 0 : ~d->nodes[0].offset;  // the root is interior rank 0
         }
         // The top of the four-wide tree, breadth first, for the traversal kernels' LDS copies (dpath.h, load_wide4): the
         // records are read back once, the references among the chosen ones become kTopFlag | slot, each copy keeps its own
@@ -669,7 +655,6 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
         S.n_top = 0;
         S.root_ref_top = S.root_ref;
         int want_top = kMaxTop;
-        if (const char *e = std::getenv("IILE_TOP_RECORDS")) want_top = std::max(0, std::min(kMaxTop, atoi(e)));
         if (n_interior > 0 && S.boxes_nested && want_top > 0 && S.root_ref >= 0) {
             std::vector<float4> all(8 * size_t(n_interior));
             if (hipMemcpy(all.data(), wide4, all.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess)
@@ -684,7 +669,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 for (int j = 0; j < 4 && int(order.size()) < want_top; ++j) {
                     int r;
                     std::memcpy(&r, &rf[j], sizeof(r));
-                    r >>= kRefShift;  // (IILE_AXES_IN_REFS: the low bits are a split axis)
+                    r >>= kRefShift;  // (the low bits are a split axis)
                     // (an empty slot — the second one of a leaf child — holds no box: its planes are +-inf and its ref is unused)
                     const float bmin_x = (&all[8 * size_t(order[at]) + 0].x)[j];
                     if (r < 0 || r >= n_interior || !(bmin_x < std::numeric_limits<float>::infinity()) || slot_of.count(r)) continue;
@@ -1218,7 +1203,7 @@ struct PatchEntry {
     bool nonplain;  // involves a sample that k_film_resolve does not place
 };
 struct PatchTimer {
-    bool on = std::getenv("IILE_PATCH_DEBUG") != nullptr;
+    bool on = false;   // (laps of the host-side film finish to stderr: flip when debugging IILE_DEBUG_HOST_FILM_FINISH)
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char *what) {
         if (!on) return;
@@ -1590,7 +1575,6 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
     if (rank < 0 || rank >= nranks) return fail(IILE_ERR_ARG, "iile_render: tile_rank out of range");
     hipStream_t stream = static_cast<hipStream_t>(prm->stream);
     LaunchCfg cfg{sc->n_cus, stream, prm->collect_stats != 0};
-    if (const char *e = std::getenv("IILE_TRAV_BLOCKS")) cfg.trav_blocks_per_cu = std::max(1, std::min(8, atoi(e)));
     const bool timed = prm->time_kernels != 0;
 
     PassDesc P;
@@ -2043,7 +2027,6 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
 
     hipStream_t stream = nullptr;
     LaunchCfg cfg{sc->n_cus, stream, false};
-    if (const char *e = std::getenv("IILE_TRAV_BLOCKS")) cfg.trav_blocks_per_cu = std::max(1, std::min(8, atoi(e)));
     const uint64_t batch_paths = uint64_t(batch) * slots_per_probe;
     rc = ensure_workspace(sc, uint32_t(batch_paths));
     if (rc) return rc;

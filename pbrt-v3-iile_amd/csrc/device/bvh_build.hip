@@ -828,7 +828,7 @@ __global__ __launch_bounds__(kBB) void k_pack_wide(int n, const iile_bvh_node *n
         }
         float4 *w4 = wide4 + 8 * size_t(my_slot);
         for (int pl = 0; pl < 6; ++pl) w4[pl] = make_float4(bx[pl][0], bx[pl][1], bx[pl][2], bx[pl][3]);
-        if (kRefShift) {  // IILE_AXES_IN_REFS: ref << 2 | axis of {the node, its first child, its second child, -}
+        if (kRefShift) {  // ref << 2 | axis of {the node, its first child, its second child, -}
             refs[0] = int((uint32_t(refs[0]) << kRefShift) | (meta & 3u));
             refs[1] = int((uint32_t(refs[1]) << kRefShift) | ((meta >> 2) & 3u));
             refs[2] = int((uint32_t(refs[2]) << kRefShift) | ((meta >> 4) & 3u));

@@ -695,12 +695,6 @@ DEV void triangle_interaction(const DScene &S, int prim, uint32_t flags, F3 p0, 
 // LDS pointers carry their address space explicitly so that pushes and pops
 // compile to ds_write_b32 / ds_read_b32 (a generic pointer would go through flat_*).
 typedef __attribute__((address_space(3))) int lds_int;
-#ifndef IILE_LEAF_LOAD3
-#define IILE_LEAF_LOAD3 1  // round 4: the room 474 -> 455 ms, killeroo 47.3 -> 46.7 (profiles/r04_ab_traversal_scheduling.txt)
-#endif
-#ifndef IILE_LEAF_ONE
-#define IILE_LEAF_ONE 1
-#endif
 #ifndef IILE_LDS_STACK
 #define IILE_LDS_STACK 11  // 22 KB per block + the 3 KB copy of the tree's top: six blocks per 160 KB CU
 #endif
@@ -1007,7 +1001,7 @@ DEV Wide4Planes load_wide4(const float4 *wide4, int cur, int neg_mask, lds_char 
     }
     return w;
 }
-// the four refs of a record as the step uses them, and its axes word (IILE_AXES_IN_REFS: both unpacked from the refs)
+// the four refs of a record as the step uses them, and its axes word (both unpacked from the refs)
 DEV void unpack_refs(const Wide4Planes &w, int *r0, int *r1, int *r2, int *r3, uint32_t *meta) {
     const int p0 = __float_as_int(w.refs.x), p1 = __float_as_int(w.refs.y), p2 = __float_as_int(w.refs.z), p3 = __float_as_int(w.refs.w);
     if (kRefShift) {
@@ -1107,13 +1101,10 @@ DEV void trav_interior4_any(Trav &t, const StackRef &sr, const Wide4Planes &w) {
 // One interior step of the uninstrumented kernels: the four-wide record, unless a lane of the
 // wavefront carries a NaN-capable ray (or the scene's boxes are not nested, which a BVH built as
 // bvh.cpp:236-402 builds it cannot produce; iile_scene_create checks).
-#ifndef IILE_ANYHIT_UNORDERED
-#define IILE_ANYHIT_UNORDERED 1
-#endif
 template <bool ANY = false>
 DEV void trav_interior_step_fast(const DScene &S, Trav &t, const StackRef &sr) {
     if (__builtin_expect(S.boxes_nested && __ballot(t.rc.neg_mask & 0x80) == 0, 1)) {
-        if (ANY && IILE_ANYHIT_UNORDERED)
+        if (ANY)   // an any-hit ray takes its children in record order (no near-first sort: any hit ends it)
             trav_interior4_any(t, sr, load_wide4<false>(S.wide4, t.cur, t.rc.neg_mask, sr.top));
         else
             trav_interior4(t, sr, load_wide4<true>(S.wide4, t.cur, t.rc.neg_mask, sr.top));
@@ -1171,16 +1162,13 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
     int prim = t.cur < 0 ? ~t.cur : 0;  // clamped like trav_interior's index; tri_verts has one pad record
     bool last;
     do {
-#if IILE_LEAF_LOAD3
         // the primitive's three records in one round trip: the flag word (sphere? last of its leaf?) rides in the first one, and
         // waiting for it before asking for the other two made every leaf step two dependent trips to memory
+        // (the room 474 -> 455 ms, killeroo 47.3 -> 46.7: profiles/r04_ab_traversal_scheduling.txt)
         float4 v0 = S.tri_verts[3 * size_t(prim)];
         float4 v1_ = S.tri_verts[3 * size_t(prim) + 1];
         float4 v2_ = S.tri_verts[3 * size_t(prim) + 2];
         asm volatile("" : "+v"(v0.w), "+v"(v1_.x), "+v"(v2_.x));  // (keeps the compiler from sinking the two loads behind the flag test)
-#else
-        const float4 v0 = S.tri_verts[3 * size_t(prim)];
-#endif
         const uint32_t flags = f2b(v0.w);
         last = (flags & 16u) != 0;
         if (flags & 1u) {
@@ -1209,12 +1197,7 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
                 t.b0 = t.b1 = t.b2 = 0;
             }
         } else {
-#if IILE_LEAF_LOAD3
             const float4 v1 = v1_, v2 = v2_;
-#else
-            const float4 v1 = S.tri_verts[3 * size_t(prim) + 1];
-            const float4 v2 = S.tri_verts[3 * size_t(prim) + 2];
-#endif
             if (COUNT) ++st->tris;
             float th, b0, b1, b2;
             if (triangle_test(t.rc, t.tmax, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, &th, &b0,
@@ -1233,14 +1216,12 @@ DEV bool trav_leaf(const DScene &S, Trav &t, const StackRef &sr, TraceStats *st,
             }
         }
         ++prim;
-#if IILE_LEAF_ONE
         // one primitive per step: the wavefront's next vote sees the lanes whose leaf goes on,
         // instead of every lane waiting for the longest leaf (most leaves hold one primitive)
         if (!last) {
             t.cur = ~prim;
             return false;
         }
-#endif
     } while (!last);
     trav_pop<COUNT>(t, sr, st);
     return false;
@@ -1507,9 +1488,7 @@ DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect
 // Matte / Plastic / Uber / Mirror ComputeScatteringFunctions (matte.cpp:45-62, plastic.cpp:45-70,
 // uber.cpp:45-100 with opacity 1 and Kt 0, mirror.cpp:44-55)
 // EXT = false: the scene has matte and plastic only (checked at upload); the specular lobes then fold away
-// MICRO = false: the caller knows the material has no microfacet lobe (a matte-only build of k_shade): has_micro is a
-// constant and everything behind it folds away
-template <bool EXT = true, bool MICRO = true>
+template <bool EXT = true>
 DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     Bsdf b;
     b.ns = is.sn;
@@ -1535,7 +1514,7 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.on_b = m.on_b;
     b.mtype = EXT ? m_type : kMatPlastic;
     b.eta = EXT ? m.eta : 1.f;  // (only uber, mirror and glass read it)
-    if (MICRO && (m_type == kMatPlastic || (EXT && m_type == kMatUber))) {
+    if (m_type == kMatPlastic || (EXT && m_type == kMatUber)) {
         b.ks = F3{clampf(m_ks.x, 0, IILE_INF), clampf(m_ks.y, 0, IILE_INF), clampf(m_ks.z, 0, IILE_INF)};
         b.has_micro = !is_black(b.ks);
         if (b.has_micro) ++b.n_lobes;

@@ -95,15 +95,13 @@ struct DProbeCam {
 #define IILE_TOP_RECORDS 21  // levels 0..2 of the four-wide tree (1 + 4 + 16); 85 = levels 0..3
 #endif
 constexpr int kMaxTop = IILE_TOP_RECORDS;  // records of the tree's top kept in LDS by the traversal kernels (dpath.h)
-// IILE_AXES_IN_REFS: the three split axes of a four-wide record ride in the low two bits of its first three refs (ref << 2 |
-// axis) instead of a word of their own, so that k_extend's interior step issues 7 vector loads per lane instead of 8 — on the
-// deep-tree room the traversal kernels retire vector-memory lane-loads at the rate the L1 path allows at all
-// (tools/vmem_calib.hip, profiles/r04_vmem_calib.json), and the only way to go faster is fewer of them.
-#ifndef IILE_AXES_IN_REFS
-#define IILE_AXES_IN_REFS 1
-#endif
-constexpr int kRefShift = IILE_AXES_IN_REFS ? 2 : 0;
-constexpr int kTopFlag = IILE_AXES_IN_REFS ? (1 << 28) : (1 << 30);  // reference to one of them: kTopFlag | slot (survives the shift)
+// The three split axes of a four-wide record ride in the low two bits of its first three refs (ref << kRefShift | axis) instead of
+// a word of their own, so that k_extend's interior step issues 7 vector loads per lane instead of 8 — on the deep-tree room the
+// traversal kernels retire vector-memory lane-loads at the rate the L1 path allows at all (tools/vmem_calib.hip,
+// profiles/r04_vmem_calib.json), and the only way to go faster is fewer of them. (The code paths for kRefShift == 0 — an axes word
+// of its own at byte 112 of the record — are what the packing test probe iile_bvh_pack_probe / iile_wide_ref_shift describe.)
+constexpr int kRefShift = 2;
+constexpr int kTopFlag = 1 << 28;  // reference to a record of the LDS top: kTopFlag | slot (survives the shift)
 
 struct DScene {
     // HBM arrays

@@ -10,29 +10,30 @@
 
 namespace iile {
 
-// Phase scheduling of the traversal kernels: 1 = one step per iteration for the whole
-// wavefront, interior or leaf, whichever has more lanes waiting; 0 = strict while-while.
-#ifndef IILE_FLAT_EXTEND
-#define IILE_FLAT_EXTEND 1
-#endif
-#ifndef IILE_FLAT_SHADOW
-#define IILE_FLAT_SHADOW 1
-#endif
-#ifndef IILE_FLAT_MIS
-#define IILE_FLAT_MIS 1
-#endif
+// ---- build parameters of the kernels (every one of them: -DNAME=value through tools/build_variant.sh; the defaults are what is
+// tested and benched). Dead ends of earlier rounds are not switches any more: tools/experiments/*.patch restores them.
+//   IILE_TRAV_WAVES            waves per SIMD (= resident 256-thread blocks per CU) the traversal kernels are built for
+//   IILE_TRAV_BLOCK            threads per block of k_extend / k_shadow / k_mis (a larger block shares one LDS copy of the tree's top)
+//   IILE_TOP_RECORDS           four-wide records of the tree's top kept in LDS (dscene.h)
+//   IILE_LDS_STACK             traversal stack levels per lane in LDS; deeper levels spill to HBM (dpath.h)
+//   IILE_CHUNK                 queue slots a wavefront reserves per atomic on a queue's cursor
+//   IILE_SHADE_CHUNK           hits a k_shade wavefront regroups by shading class at a time
+//   IILE_REFILL_IDLE / _GEN    idle lanes that trigger a refill (rays that end fast); _GEN: the build that generates camera rays
+//   IILE_REFILL_IDLE_SLOW / _GEN_SLOW   the same while the wavefront's lanes go idle slowly (deep trees)
+//   IILE_SHADE_WAVES / _TEX    waves per SIMD k_shade's register allocation aims at (untextured / textured build)
+//   IILE_DIRECT_SHADE_WAVES    the same for k_direct_shade (kernels_direct.hip)
+// Diagnostic builds (tools/*_stamps.py, never shipped): IILE_SHADE_STAMPS, IILE_TRAV_STAMPS, IILE_SHADOW_STAMPS, IILE_TRAV_ITERSTATS.
 #ifndef IILE_TRAV_WAVES
-#define IILE_TRAV_WAVES 6  // waves per SIMD = resident blocks per CU of the traversal kernels (<= 80 VGPRs, no scratch)
+#define IILE_TRAV_WAVES 6  // <= 80 VGPRs, no scratch
 #endif
-#ifndef IILE_VOTE_NUM
-#define IILE_VOTE_NUM 4
-#define IILE_VOTE_DEN 5
-#endif
+// The traversal kernels take ONE step per iteration for the whole wavefront, interior or leaf, whichever has more lanes waiting: an
+// interior step when interior lanes x kVoteNum >= leaf lanes x kVoteDen (leaf steps are the dearer ones).
+constexpr int kVoteNum = 4, kVoteDen = 5;
 
 constexpr int kBlock = 256;            // 4 wavefronts
 constexpr int kWavesPerBlock = kBlock / 64;
 #ifndef IILE_TRAV_BLOCK
-#define IILE_TRAV_BLOCK 256  // threads per block of k_extend / k_shadow / k_mis: a larger block shares one LDS copy of the tree's top among more wavefronts
+#define IILE_TRAV_BLOCK 256
 #endif
 constexpr int kTravBlock = IILE_TRAV_BLOCK;
 constexpr int kTravWavesPerBlock = kTravBlock / 64;
@@ -41,7 +42,7 @@ static_assert(kTravBlock % 64 == 0 && kTravBlocksPerCu * kTravBlock == IILE_TRAV
 #ifndef IILE_SHADE_CHUNK
 #define IILE_SHADE_CHUNK 1024
 #endif
-constexpr int kShadeChunk = IILE_SHADE_CHUNK;  // hits one k_shade wavefront regroups by shading class at a time
+constexpr int kShadeChunk = IILE_SHADE_CHUNK;
 constexpr int kTile = 16;
 
 DEV int lane_id() { return int(threadIdx.x & 63); }
@@ -121,8 +122,7 @@ constexpr int kCntConHead = 64;  // [bounce] chunk cursor of the NEE queue (shad
 constexpr int kCntMisHead = 80;  // [bounce] chunk cursor of the NEE queue (MIS kernel)
 constexpr int kCntShdHead = 96;  // [bounce] chunk cursor of the shade queue
 constexpr int kCntMis = 112;     // [bounce] MIS rays (a dense queue of its own: most NEE records have none)
-constexpr int kCntShdHead2 = 128; // [bounce] chunk cursor of the shade queue, the second class-specialised k_shade build
-static_assert(kCntShdHead2 + 16 <= kCntWords, "PassBuffers::counts layout");
+static_assert(kCntMis + 16 <= kCntWords, "PassBuffers::counts layout");
 
 // Persistent-wavefront work feed. A wavefront reserves kChunk consecutive queue
 // slots with one atomic and hands them to its lanes as they go idle, so lanes
@@ -140,92 +140,41 @@ constexpr uint32_t kChunk = IILE_CHUNK;
 #ifndef IILE_REFILL_IDLE_GEN
 #define IILE_REFILL_IDLE_GEN 56  // 47.5 -> 47.1 ms against 32: profiles/r03_ab_gen_refill.txt
 #endif
-constexpr int kRefillIdle = IILE_REFILL_IDLE;  // refill once this many lanes are idle (or all)
-#ifndef IILE_REFILL_START_SLOW
-#define IILE_REFILL_START_SLOW 0
+#ifndef IILE_REFILL_IDLE_SLOW
+#define IILE_REFILL_IDLE_SLOW 12
 #endif
+#ifndef IILE_REFILL_IDLE_GEN_SLOW
+#define IILE_REFILL_IDLE_GEN_SLOW 24
+#endif
+constexpr int kRefillIdle = IILE_REFILL_IDLE;
+constexpr int kRefillSlowRate = 3;   // lanes per vote: below it a wavefront's lanes "go idle slowly"
 struct WaveFeed {
     uint32_t cur, end;
     bool exhausted;
-    uint32_t tried = 0;  // IILE_XCD_FEED: partitions of the queue this wavefront has found empty (its own XCD's first)
-    uint32_t waste = 0;  // votes with idle lanes (or lane-steps lost to them) since the last refill (refill_due)
-    bool slow = IILE_REFILL_START_SLOW != 0;  // IILE_REFILL_ADAPT: this wavefront's lanes go idle slowly: refill in small batches
+    uint32_t votes = 0;  // votes with idle lanes since the last refill
+    bool slow = false;   // this wavefront's lanes go idle slowly: refill in small batches
 };
 // When to refill. A refill runs with only the idle lanes active, so it should wait for a batch of them; but every step it
 // waits costs one lane-step per idle lane, and how fast lanes go idle differs by an order of magnitude between workloads:
 // killeroo-simple's rays end after ~14 steps (5.8 lanes per vote go idle, 5.5 votes between refills at a batch of 32), the deep
 // room's after ~90 (0.6 lanes per vote, 52 votes). A fixed batch of 32 idle lanes — right for the former — left the room's
-// wavefronts a quarter empty (15.8 idle lanes per vote, profiles/r04_vote_stats.json); 12 is right for the room (432 vs 455 ms)
-// and wrong for killeroo. Measured on both (profiles/r04_ab_refill_rule.txt): fixed batches of 8 / 12 / 16 / 24 / 32; a budget of
-// wasted lane-steps (the economic-order-quantity rule: worse than any fixed batch on both scenes — it refills two or three lanes
-// at a time once they have waited long enough); a batch that shrinks by one lane per step waited (between the fixed batches);
-// and the rule kept (IILE_REFILL_ADAPT): every wavefront measures the rate at which ITS lanes go idle — idle lanes at a refill /
-// votes since the one before — and uses the small batch while that rate is below kRefillSlowRate lanes per vote.
-#ifndef IILE_REFILL_ADAPT
-#define IILE_REFILL_ADAPT 1
-#endif
-#ifndef IILE_REFILL_IDLE_SLOW
-#define IILE_REFILL_IDLE_SLOW 12      // batch for slowly finishing rays (deep trees)
-#endif
-#ifndef IILE_REFILL_IDLE_GEN_SLOW
-#define IILE_REFILL_IDLE_GEN_SLOW 24  // the same for the camera-ray build
-#endif
-#ifndef IILE_REFILL_SLOW_RATE
-#define IILE_REFILL_SLOW_RATE 3       // lanes per vote
-#endif
-#ifndef IILE_REFILL_RAMP
-#define IILE_REFILL_RAMP 0
-#endif
-#ifndef IILE_REFILL_FLOOR
-#define IILE_REFILL_FLOOR 8
-#endif
-#ifndef IILE_REFILL_WASTE
-#define IILE_REFILL_WASTE 0
-#endif
-#ifndef IILE_REFILL_WASTE_GEN
-#define IILE_REFILL_WASTE_GEN 0
-#endif
-constexpr int kRefillFloor = IILE_REFILL_FLOOR;
-constexpr int kRefillSlowRate = IILE_REFILL_SLOW_RATE;
-DEV bool refill_due(unsigned long long idle_mask, WaveFeed &f, int idle_min, uint32_t waste_max, int idle_min_slow = IILE_REFILL_IDLE_SLOW) {
+// wavefronts a quarter empty (profiles/r04_vote_stats.json); 12 is right for the room (432 vs 455 ms) and wrong for killeroo.
+// The rule (profiles/r04_ab_refill_rule.txt holds the alternatives measured against it): every wavefront measures the rate at
+// which ITS lanes go idle — idle lanes at a refill / votes since the one before — and uses the small batch while that rate is
+// below kRefillSlowRate lanes per vote.
+DEV bool refill_due(unsigned long long idle_mask, WaveFeed &f, int idle_min, int idle_min_slow = IILE_REFILL_IDLE_SLOW) {
     if (f.exhausted || idle_mask == 0) return false;
     const uint32_t n_idle = uint32_t(__popcll(idle_mask));
-    bool due;
-    if (IILE_REFILL_ADAPT) {
-        f.waste += 1;  // votes with idle lanes since the last refill
-        const uint32_t batch = f.slow ? uint32_t(idle_min_slow) : uint32_t(idle_min);
-        due = n_idle >= batch || idle_mask == ~0ull;
-        if (due) {
-            f.slow = n_idle < uint32_t(kRefillSlowRate) * f.waste;  // fewer than kRefillSlowRate lanes per vote went idle
-            f.waste = 0;
-        }
-    } else if (IILE_REFILL_RAMP) {
-        f.waste += 1;  // steps with idle lanes since the last refill
-        due = (n_idle >= uint32_t(kRefillFloor) && n_idle + f.waste >= uint32_t(idle_min)) || idle_mask == ~0ull;
-        if (due) f.waste = 0;
-    } else if (waste_max > 0) {
-        f.waste += n_idle;
-        due = f.waste >= waste_max || idle_mask == ~0ull;
-        if (due) f.waste = 0;
-    } else {
-        due = int(n_idle) >= idle_min || idle_mask == ~0ull;
+    f.votes += 1;
+    const uint32_t batch = f.slow ? uint32_t(idle_min_slow) : uint32_t(idle_min);
+    const bool due = n_idle >= batch || idle_mask == ~0ull;
+    if (due) {
+        f.slow = n_idle < uint32_t(kRefillSlowRate) * f.votes;
+        f.votes = 0;
     }
     return due;
 }
 
-// IILE_XCD_FEED: a queue is cut into eight contiguous partitions, one per XCD, each with a chunk cursor of its own; a wavefront
-// draws from the partition of the XCD it runs on and moves on to the next one when that is used up, so that rays that are
-// neighbours in a queue walk the tree behind ONE 4 MiB L2 instead of all eight. Measured and left off: the room 484 vs 474 ms,
-// killeroo 52.4 vs 47.3 (profiles/r04_ab_traversal_scheduling.txt) — the L2s' hit rates are not what the traversal waits for.
-#ifndef IILE_XCD_FEED
-#define IILE_XCD_FEED 0
-#endif
-constexpr int kCntXcd = 144;  // [kind 0..2: extend, shadow, MIS][bounce 0..15][partition 0..7] chunk cursors (IILE_XCD_FEED)
-static_assert(kCntXcd + 3 * 16 * 8 <= kCntWords, "PassBuffers::counts layout");
-DEV uint32_t xcd_id() {
-    // XCC_ID hardware register (id 20), bits 0..3
-    return uint32_t(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & 7u;
-}
 // `warm(first_slot)` is called once per new chunk: the wavefront touches every 128-byte
 // line of the chunk's records (lane l -> records first+8l .. first+8l+7), so the per-lane
 // refill loads that follow hit L2 instead of paying an HBM round trip each time a few
@@ -236,26 +185,8 @@ DEV bool feed_take(WaveFeed &f, uint32_t *head, uint32_t count, bool idle, uint3
     const uint32_t n_idle = uint32_t(__popcll(mask));
     if (f.cur == f.end) {
         uint32_t base = 0;
-#if IILE_XCD_FEED
-        // `head` = the eight partition cursors of this queue (counted in chunks)
-        const uint32_t n_chunks = (count + kChunk - 1) / kChunk, home = xcd_id();
-        base = count;
-        while (f.tried < 8) {
-            const uint32_t p = (home + f.tried) & 7u;
-            const uint32_t lo = uint32_t((uint64_t(n_chunks) * p) >> 3), hi = uint32_t((uint64_t(n_chunks) * (p + 1)) >> 3);
-            uint32_t c = 0;
-            if (lane_id() == 0) c = atomicAdd(head + p, 1u);
-            c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
-            if (c < hi - lo) {
-                base = (lo + c) * kChunk;
-                break;
-            }
-            ++f.tried;
-        }
-#else
         if (lane_id() == 0) base = atomicAdd(head, kChunk);
         base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
-#endif
         if (base >= count) {
             f.exhausted = true;
             f.cur = f.end = 0;

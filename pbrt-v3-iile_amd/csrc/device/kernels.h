@@ -50,7 +50,7 @@ static_assert(kMaxLights <= 8, "PassDesc::direct_nsamples");
 // pass plus the padding that block-reserved appends leave behind (kernels.hip).
 // shade-queue entries carry the shading class above the slot number
 constexpr int kSlotBits = 28;
-constexpr int kCntWords = 144 + 3 * 16 * 8;  // words of PassBuffers::counts (layout in kcommon.h)
+constexpr int kCntWords = 128;  // words of PassBuffers::counts (layout in kcommon.h)
 struct PassBuffers {
     uint32_t queue_cap;
     float4 *L;          // [n_paths] radiance so far (xyz)

@@ -142,12 +142,6 @@ DEV int sample_light(const DScene &S, F3 p, float u, float *pdf) {
     return offset;
 }
 
-// one dword per lane from global memory straight into LDS row `row` (lane l -> row[l]), no destination register
-template <typename T>
-DEV void pf_touch(const T *src, uint32_t *row) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)row, 4, 0, 0);
-}
-
 // shade: one bounce of PathIntegrator::Li (path.cpp:81-191) for every hit of the
 // queue that extend just resolved.
 // Waves per SIMD = resident blocks per CU. The plain and the extended builds run at 4 (<= 128 VGPRs, ~10 spilled to scratch
@@ -155,27 +149,15 @@ DEV void pf_touch(const T *src, uint32_t *row) {
 // — at the 168 VGPRs the kernel wanted before its uniform table reads became scalar loads, 4 waves lost: 23.6 vs 22.0 ms);
 // the textured build is better off at 3 (<= 168 VGPRs; 50.2 vs 52.8 ms at 4).
 // TEX: some material takes a parameter from an image texture (implies EXT)
-// ONLY: 0 = every hit of the queue; the two class-specialised builds share one queue and each takes its classes out of
-// every chunk: 1 = hits on matte triangles only (shading class 0: no microfacet lobe, so none of that code or its
-// registers: more waves per SIMD), 2 = every other class.
 #ifndef IILE_SHADE_WAVES
 #define IILE_SHADE_WAVES 4
 #endif
 #ifndef IILE_SHADE_WAVES_TEX
 #define IILE_SHADE_WAVES_TEX 3
 #endif
-#ifndef IILE_SHADE_PREFETCH
-#define IILE_SHADE_PREFETCH 0
-#endif
-#ifndef IILE_SHADE_SPLIT_DEFAULT
-#define IILE_SHADE_SPLIT_DEFAULT 0
-#endif
-#ifndef IILE_SHADE_WAVES_MATTE
-#define IILE_SHADE_WAVES_MATTE 4
-#endif
-constexpr int shade_waves(bool tex, int only) { return only == 1 ? IILE_SHADE_WAVES_MATTE : (tex ? IILE_SHADE_WAVES_TEX : IILE_SHADE_WAVES); }
-template <bool COUNT, bool EXT, bool TEX, int ONLY = 0>
-__global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
+constexpr int shade_waves(bool tex) { return tex ? IILE_SHADE_WAVES_TEX : IILE_SHADE_WAVES; }
+template <bool COUNT, bool EXT, bool TEX>
+__global__ __launch_bounds__(kBlock, shade_waves(TEX)) void k_shade(DScene S, PassDesc P, PassBuffers B, int bounce, uint32_t plane) {
     // digit permutations of the Halton sampler staged in LDS (dynamic shared memory)
     extern __shared__ __attribute__((aligned(16))) uint16_t s_perms_raw[];
     if (S.sobol) {
@@ -214,10 +196,7 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene
     auto pad_mis = [&](uint32_t sl) { B.nee[2 * plane + sl] = make_float4(0, 0, 0, b2f(kInvalid)); };
     __shared__ uint32_t s_entry[kWavesPerBlock][kShadeChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *const head = &B.counts[(ONLY == 2 ? kCntShdHead2 : kCntShdHead) + bounce];
-#if IILE_SHADE_PREFETCH
-    __shared__ uint32_t s_pf[kWavesPerBlock][3][64];  // next round's primitive, path id; a dump row
-#endif
+    uint32_t *const head = &B.counts[kCntShdHead + bounce];
     for (;;) {
         // chunks are drawn dynamically: a chunk of glossy hits costs several matte ones
         uint32_t base = 0;
@@ -234,12 +213,9 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene
         for (int j = 0; j < kShadeChunk / 64; ++j) {
             const uint32_t qi = base + uint32_t(j) * 64u + uint32_t(lane);
             ent[j] = qi < count ? B.shade_q[qi] : kInvalid;
-            if (ONLY == 1 && (ent[j] >> kSlotBits) != 0u) ent[j] = kInvalid;  // (kInvalid >> kSlotBits is not 0 either)
-            if (ONLY == 2 && (ent[j] >> kSlotBits) == 0u) ent[j] = kInvalid;
         }
         uint32_t run = 0;
         for (uint32_t c = 0; c < 8; ++c) {
-            if ((ONLY == 1 && c != 0 && c != 7) || (ONLY == 2 && c == 0)) continue;
 #pragma unroll
             for (int j = 0; j < kShadeChunk / 64; ++j) {
                 const bool is_c = (ent[j] == kInvalid ? 7u : ent[j] >> kSlotBits) == c;
@@ -257,25 +233,6 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene
         const bool valid = mine != kInvalid;
         if (__ballot(valid) == 0) break;  // padding sorts last
         const uint32_t slot = mine & ((1u << kSlotBits) - 1u);
-#if IILE_SHADE_PREFETCH
-        // The round's inputs hang on each other — queue entry -> hit / ray records -> path id, primitive -> throughput, Halton
-        // index, vertices — and the records come from HBM (the queues are written by the kernel before): three serialized
-        // misses at the head of every round, which three resident waves per SIMD do not cover. So the NEXT round's records are
-        // touched one level ahead of their use: the hit and ray records here (dependent on nothing but LDS), what hangs on them
-        // in the middle of the round. The touches are LDS-DMA loads (global_load_lds_dword): no destination register that
-        // would have to stay allocated, nobody waits for them; primitive and path id land in s_pf for the second level, the
-        // rest in a dump row. Loads only: results and their order are untouched.
-        const uint32_t nxt = round + 1 < kShadeChunk / 64 ? s_entry[wave][(round + 1) * 64 + lane] : kInvalid;
-        const bool pf = nxt != kInvalid;
-        const uint32_t slot_n = nxt & ((1u << kSlotBits) - 1u);
-        if (pf) {
-            pf_touch(&B.hits[slot_n].x, &s_pf[wave][0][0]);
-            if (!(bounce == 0 && P.gen_fused)) {
-                pf_touch(&ro[slot_n].w, &s_pf[wave][1][0]);
-                pf_touch(&rd[slot_n].x, &s_pf[wave][2][0]);
-            }
-        }
-#endif
         // The loop body is two converged sections, each ending in a queue append, so that the
         // NEE record's ~20 registers are dead before the continuation is sampled:
         //   A: interaction, Le, BSDF, both halves of EstimateDirect  -> NEE record
@@ -345,7 +302,7 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene
                 keep_whole(v0, v1, v2);  // three 16-byte loads (not three of 12 bytes and three of 4)
                 const uint32_t flags = f2b(v0.w);
                 const int material = int(f2b(v1.w)), light = int(f2b(v2.w));
-                if (ONLY != 1 && (flags & 1u)) {
+                if (flags & 1u) {
                     // the closest hit was the sphere: redo its (deterministic) root
                     // selection to recover the object-space ray and refined hit point
                     float t;
@@ -399,12 +356,12 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene
                             }
                             if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, &is);  // `if (bumpMap) Bump(bumpMap, si)` comes first
                             const DMaterial mm = textured_material(S, m0, is, td);
-                            bsdf = make_bsdf<EXT, ONLY != 1>(mm, is);
+                            bsdf = make_bsdf<EXT>(mm, is);
                         } else {
-                            bsdf = make_bsdf<EXT, ONLY != 1>(m0, is);
+                            bsdf = make_bsdf<EXT>(m0, is);
                         }
                     } else {
-                        bsdf = make_bsdf<EXT, ONLY != 1>(S.materials[material], is);
+                        bsdf = make_bsdf<EXT>(S.materials[material], is);
                     }
                     SHADE_STAMP(2);
                     if (n_nonspec(bsdf) > 0) {  // NumComponents(BSDF_ALL & ~BSDF_SPECULAR) > 0, path.cpp:118
@@ -578,20 +535,6 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene
                     }
                 }
             }
-#if IILE_SHADE_PREFETCH
-            if (pf) {  // second level of the next round's inputs (see the head of the round)
-                const uint32_t pf_prim = s_pf[wave][0][lane];
-                const uint32_t pf_pid = (bounce == 0 && P.gen_fused) ? slot_n : s_pf[wave][1][lane];
-                if (bounce > 0) pf_touch(&B.beta[pf_pid].x, &s_pf[wave][2][0]);
-                pf_touch(&B.hindex[pf_pid], &s_pf[wave][2][0]);
-                pf_touch(&S.tri_verts[3 * size_t(pf_prim)].x, &s_pf[wave][2][0]);
-                pf_touch(&S.tri_verts[3 * size_t(pf_prim) + 2].w, &s_pf[wave][2][0]);
-#if IILE_SHADE_PREFETCH > 1
-                pf_touch(&S.tri_norms[3 * size_t(pf_prim)].x, &s_pf[wave][2][0]);
-                pf_touch(&S.tri_norms[3 * size_t(pf_prim) + 2].w, &s_pf[wave][2][0]);
-#endif
-            }
-#endif
             SHADE_STAMP(4);
             const uint32_t eslot = out_take(nee_out, &B.counts[kCntNee + bounce], emit_nee, pad_nee);
             // the MIS rays go to a dense queue of their own (planes 2 and 3): most records have none
@@ -703,17 +646,10 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX, ONLY)) void k_shade(DScene
 
 // ---------------------------------------------------------------------------
 // launchers
-static bool shade_split() {
-    static const bool on = [] {
-        const char *e = std::getenv("IILE_SHADE_SPLIT");
-        return e ? e[0] != '0' : (IILE_SHADE_SPLIT_DEFAULT != 0);
-    }();
-    return on;
-}
 void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int bounce, uint32_t max_rays, const LaunchCfg &cfg) {
     // as many blocks as are resident at the build's waves per SIMD: the static split has no tail
     const bool tex_build = cfg.count_stats || S.textured_materials || S.probe_mode;
-    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, shade_waves(tex_build, 0)));
+    const dim3 grid(grid_blocks(max_rays, cfg.n_cus, shade_waves(tex_build)));
     const size_t perm_bytes = S.sobol ? size_t(16) : (size_t(S.n_perms) * sizeof(uint16_t) + 15) & ~size_t(15);
     if (cfg.count_stats)
         hipLaunchKernelGGL((k_shade<true, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
@@ -725,12 +661,7 @@ void launch_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int 
             hipLaunchKernelGGL((k_shade<false, true, true>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
         else if (S.extended_features)
             hipLaunchKernelGGL((k_shade<false, true, false>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
-        else if (shade_split()) {
-            // two class-specialised builds over the same queue (see k_shade's ONLY): the matte one first, it has most of the hits
-            const dim3 grid_m(grid_blocks(max_rays, cfg.n_cus, IILE_SHADE_WAVES_MATTE));
-            hipLaunchKernelGGL((k_shade<false, false, false, 1>), grid_m, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
-            hipLaunchKernelGGL((k_shade<false, false, false, 2>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
-        } else
+        else
             hipLaunchKernelGGL((k_shade<false, false, false>), grid, dim3(kBlock), perm_bytes, cfg.stream, S, P, B, bounce, B.queue_cap);
 }
 void launch_light_distributions(const DScene &S, const float *samples, float *out, const LaunchCfg &cfg) {

@@ -5,25 +5,6 @@
 
 namespace iile {
 
-// Several interior steps per vote (IILE_INT_STEPS > 1): once the wavefront has voted for an interior step, the lanes that still
-// stand at an interior record take up to IILE_INT_STEPS - 1 more without going round the loop head (refill test, finish test,
-// two ballots and the vote), as long as three quarters of the lanes that voted are still walking; lanes that reached a leaf wait.
-#ifndef IILE_INT_STEPS
-#define IILE_INT_STEPS 1
-#endif
-#if IILE_INT_STEPS > 1
-#define IILE_MORE_INTERIOR_STEPS(STEP)                                       \
-    for (int more_ = 1; more_ < IILE_INT_STEPS; ++more_) {                   \
-        const bool wi2_ = active && t.have && t.cur >= 0;                    \
-        if (__popcll(__ballot(wi2_)) * 4 < n_int * 3) break;                 \
-        if (wi2_) STEP;                                                      \
-    }
-#else
-#define IILE_MORE_INTERIOR_STEPS(STEP) \
-    do {                               \
-    } while (0)
-#endif
-
 // ---------------------------------------------------------------------------
 // extend: BVHAccel::Intersect for every ray of queue `bounce & 1`; hits are
 // appended (ballot-compacted) to the shade queue.
@@ -42,7 +23,7 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_extend(DScene S
         sr.root = S.root_ref_top;
     }
     const uint32_t count = B.counts[kCntRay + bounce];
-    uint32_t *head = IILE_XCD_FEED ? &B.counts[kCntXcd + (0 * 16 + bounce) * 8] : &B.counts[kCntExtHead + bounce];
+    uint32_t *head = &B.counts[kCntExtHead + bounce];
     const float4 *ro = B.ray_o[bounce & 1], *rd = B.ray_d[bounce & 1];
     TraceStats st = {0, 0, 0, 0};
     unsigned long long n_rays = 0, n_term = 0;
@@ -100,8 +81,7 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_extend(DScene S
         TRAV_STAMP(3);
         const unsigned long long idle_mask = __ballot(!active);
         // (the camera-ray build makes its rays here, some 400 instructions each: it waits for more idle lanes than the others)
-        if (refill_due(idle_mask, feed, GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle, GEN ? IILE_REFILL_WASTE_GEN : IILE_REFILL_WASTE,
-                       GEN ? IILE_REFILL_IDLE_GEN_SLOW : IILE_REFILL_IDLE_SLOW)) {
+        if (refill_due(idle_mask, feed, GEN ? IILE_REFILL_IDLE_GEN : kRefillIdle, GEN ? IILE_REFILL_IDLE_GEN_SLOW : IILE_REFILL_IDLE_SLOW)) {
             uint32_t s_new;
 #ifdef IILE_TRAV_ITERSTATS
             iter_stat[7] += 1;
@@ -154,20 +134,14 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_extend(DScene S
             if (feed.exhausted) break;
             continue;
         }
-        // while-while: every lane walks interior records until it stands at a leaf (or is
-        // done), then all lanes at a leaf run the primitive tests together. Main-path rays
-        // are coherent enough that this beats finer-grained phase scheduling (measured:
-        // 96 ms vs 180+ ms per 1080p/64spp step).
-#if IILE_FLAT_EXTEND
         // one step per iteration for the whole wavefront, interior or leaf, whichever has more
         // lanes waiting (25.9 ms vs 34.6 ms for strict while-while on the 1080p/64spp step)
         {
             const bool wi = active && t.have && t.cur >= 0;
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
-            if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
+            if (n_int > 0 && n_int * kVoteNum >= n_leaf * kVoteDen) {
                 if (wi) trav_step<COUNT>(S, t, sr, &st);
-                IILE_MORE_INTERIOR_STEPS(trav_step<COUNT>(S, t, sr, &st));
                 ITER_STAT(0, n_int, n_leaf);
                 TRAV_STAMP(1);
             } else if (n_leaf > 0) {
@@ -176,10 +150,6 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_extend(DScene S
                 TRAV_STAMP(2);
             }
         }
-#else
-        while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
-        if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, GEN ? &gen_d : &rd[slot]);
-#endif
         const bool fin = active && !t.have;
         const bool is_hit = fin && t.hit_prim >= 0;
         if (fin) {
@@ -239,7 +209,7 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_shadow(DScene S
         sr.root = S.root_ref_top;
     }
     const uint32_t count = B.counts[kCntNee + bounce];
-    uint32_t *head = IILE_XCD_FEED ? &B.counts[kCntXcd + (1 * 16 + bounce) * 8] : &B.counts[kCntConHead + bounce];
+    uint32_t *head = &B.counts[kCntConHead + bounce];
     TraceStats st = {0, 0, 0, 0};
     unsigned long long n_shadow = 0, n_zero = 0;
     WaveFeed feed{0, 0, count == 0};
@@ -275,7 +245,7 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_shadow(DScene S
     while (true) {
         SHADOW_STAMP(3);
         const unsigned long long idle_mask = __ballot(!active);
-        if (refill_due(idle_mask, feed, kRefillIdle, IILE_REFILL_WASTE)) {
+        if (refill_due(idle_mask, feed, kRefillIdle)) {
             uint32_t e_new;
             if (feed_take(feed, head, count, !active, &e_new, [&](uint32_t first) {
                     warm_plane(B.nee, first, count);
@@ -291,11 +261,7 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_shadow(DScene S
                     // ray carries beta * (A / lightPdf) ready made (k_shade) and no throughput plane.
                     const float4 n0 = B.nee[e], a4 = B.nee[4 * size_t(plane) + e];
                     pid = f2b(a4.w);
-#ifdef IILE_DIAG_SHADOW_NO_L  // timing probe only (wrong film): what the record's one scattered access costs
-                    const float4 L4 = make_float4(0, 0, 0, 0);
-#else
                     const float4 L4 = B.L[pid];
-#endif
                     const bool has_shadow = (flags & NEE_HAS_SHADOW) != 0;
                     if (flags & NEE_HAS_MIS) {
                         const float4 be = B.nee[6 * size_t(plane) + e];
@@ -337,7 +303,6 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_shadow(DScene S
             if (feed.exhausted) break;
             continue;
         }
-#if IILE_FLAT_SHADOW
         // Shadow rays end at their first hit, so lanes leave at very different times: one
         // step per iteration, interior or leaf, whichever keeps more lanes busy
         // (17.9 ms vs 22.1 ms for strict while-while on the 1080p/64spp step).
@@ -345,29 +310,20 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_shadow(DScene S
             const bool wi = active && t.have && t.cur >= 0;
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
-            if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
+            if (n_int > 0 && n_int * kVoteNum >= n_leaf * kVoteDen) {
                 if (wi) trav_step<COUNT, true>(S, t, sr, &st);
-                IILE_MORE_INTERIOR_STEPS((trav_step<COUNT, true>(S, t, sr, &st)));
                 SHADOW_STAMP(1);
             } else if (n_leaf > 0) {
                 if (wl && trav_leaf<COUNT, ALPHA>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
                 SHADOW_STAMP(2);
             }
         }
-#else
-        while (active && t.have && t.cur >= 0) trav_step<COUNT, true>(S, t, sr, &st);
-        if (active && t.have && trav_leaf<COUNT, ALPHA>(S, t, sr, &st, true, &B.nee[plane + e])) occluded = true;
-#endif
         if (active && !t.have) {
             const F3 add = occluded ? add_occluded : add_unoccluded;
             const F3 Ln = L_old + add;  // store only: nothing is loaded here
             // (an occluded light sample without a lit MIS ray adds +0: L stands as it is — a sum of non-negative terms from +0,
             //  never -0 — and the scattered 16-byte store is left out: a sixth of the records)
-#ifdef IILE_DIAG_SHADOW_NO_L
-            if (Ln.x == 12345.678f) B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
-#else
             if (!is_black(add)) B.L[pid] = make_float4(Ln.x, Ln.y, Ln.z, 0);
-#endif
             if (COUNT && is_black(add)) ++n_zero;
             active = false;
         }
@@ -403,7 +359,7 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_mis(DScene S, P
     }
     // the dense queue of MIS rays k_shade wrote beside the NEE records: (o, record) in plane 2, (d, light) in plane 3
     const uint32_t count = B.counts[kCntMis + bounce];
-    uint32_t *head = IILE_XCD_FEED ? &B.counts[kCntXcd + (2 * 16 + bounce) * 8] : &B.counts[kCntMisHead + bounce];
+    uint32_t *head = &B.counts[kCntMisHead + bounce];
     TraceStats st = {0, 0, 0, 0};
     unsigned long long n_closest = 0, n_traced = 0;
     WaveFeed feed{0, 0, count == 0};
@@ -416,7 +372,7 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_mis(DScene S, P
     uint32_t q = 0, e = 0;
     while (true) {
         const unsigned long long idle_mask = __ballot(!active);
-        if (refill_due(idle_mask, feed, kRefillIdle, IILE_REFILL_WASTE)) {
+        if (refill_due(idle_mask, feed, kRefillIdle)) {
             uint32_t q_new;
             if (feed_take(feed, head, count, !active, &q_new, [&](uint32_t first) {
                     warm_plane(B.nee + 2 * size_t(plane), first, count);
@@ -446,22 +402,16 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_mis(DScene S, P
             if (feed.exhausted) break;
             continue;
         }
-#if IILE_FLAT_MIS
         {
             const bool wi = active && t.have && t.cur >= 0;
             const bool wl = active && t.have && t.cur < 0;
             const int n_int = __popcll(__ballot(wi)), n_leaf = __popcll(__ballot(wl));
-            if (n_int > 0 && n_int * IILE_VOTE_NUM >= n_leaf * IILE_VOTE_DEN) {
+            if (n_int > 0 && n_int * kVoteNum >= n_leaf * kVoteDen) {
                 if (wi) trav_step<COUNT, ANYORDER>(S, t, sr, &st);
-                IILE_MORE_INTERIOR_STEPS((trav_step<COUNT, ANYORDER>(S, t, sr, &st)));
             } else if (n_leaf > 0) {
                 if (wl) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * size_t(plane) + q]);
             }
         }
-#else
-        while (active && t.have && t.cur >= 0) trav_step<COUNT>(S, t, sr, &st);
-        if (active && t.have) trav_leaf<COUNT, ALPHA>(S, t, sr, &st, false, &B.nee[3 * size_t(plane) + q]);
-#endif
         if (first_hit_ends && active && t.hit_prim >= 0) t.have = false;
         if (active && !t.have) {
             // store only: (area light index + 1) of the primitive the MIS ray ended on, 0 for none

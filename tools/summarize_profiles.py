@@ -26,6 +26,11 @@ WORKLOAD = ("bench.py --steps 1 --warmup 0 --other-steps 0 " + bench_args).strip
     else " (killeroo-simple 1920x1080, 64 spp, 1 GPU)")
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+for f in glob.glob(os.path.join(src, "stats_one_stream", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, f"{tag}_one_stream_kernel_stats.csv"))
+b1 = os.path.join(src, "bench_one_stream_under_profiler.json")
+if os.path.exists(b1) and os.path.getsize(b1):
+    shutil.copy(b1, os.path.join(dst, f"{tag}_bench_one_stream_under_profiler.json"))
 b = os.path.join(src, "bench_under_profiler.json")
 if os.path.exists(b) and os.path.getsize(b):
     shutil.copy(b, os.path.join(dst, f"{tag}_bench_under_profiler.json"))
