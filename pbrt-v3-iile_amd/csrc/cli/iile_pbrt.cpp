@@ -1,8 +1,12 @@
 // iile_pbrt — command-line front end: `pbrt scene.pbrt` for the GPU path.
 //
-//   iile_pbrt scene.pbrt [--outfile out.exr|out.pfm] [--xres N --yres N --spp N --maxdepth N] [--stats]
+//   iile_pbrt scene.pbrt [--outfile out.exr|out.pfm] [--xres N --yres N --spp N --maxdepth N] [--stats] [--gpus N]
 //             [--gpurank R/N --rendezvous FILE [--job TOKEN]]
 //
+// One process, the whole node (default): with several GPUs visible the frame's tiles are dealt over all of them, one host
+// thread per device, and merged by one RCCL reduction — `pbrt scene.pbrt` needs no launcher, as the reference's one Render()
+// call fans out over its threads (src/core/api.cpp:1650-1662). --gpus N uses N of them (--gpus 1 runs the same code with a
+// communicator of one rank).
 // Multi-GPU: start N copies, one per GPU, with --gpurank 0/N .. N-1/N and a common --rendezvous file on a shared
 // file system (rank 0 publishes the RCCL id there; --job TOKEN, any number the launcher picks per launch, ties the file
 // to this launch). Rank R uses GPU R modulo the visible devices, renders its tiles
@@ -25,6 +29,8 @@ int main(int argc, char **argv) {
     iile::ParamSet ps;
     bool stats = false, quiet = false;
     int gpu_rank = 0, gpu_nranks = 1;
+    int gpus = 0;   // --gpus N: devices of THIS process (0: all visible)
+    bool gpus_given = false;
     bool ranked = false;  // --gpurank given: render through the communicator branch, also for N = 1
     unsigned long long job_token = 0;
     std::string rendezvous;
@@ -59,6 +65,14 @@ int main(int argc, char **argv) {
             arg_int(ps.maxdepth);
         else if (!strcmp(argv[i], "--stats"))
             stats = true;
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) {
+            gpus = atoi(argv[++i]);
+            gpus_given = true;
+            if (gpus < 1) {
+                fprintf(stderr, "iile_pbrt: --gpus wants a number >= 1\n");
+                return 1;
+            }
+        }
         else if (!strcmp(argv[i], "--sampler") && i + 1 < argc) {
             const char *sn = argv[++i];
             ps.sampler = !strcmp(sn, "sobol") ? IILE_SAMPLER_SOBOL : (!strcmp(sn, "halton") ? IILE_SAMPLER_HALTON : IILE_SAMPLER_KEEP);
@@ -89,7 +103,7 @@ int main(int argc, char **argv) {
         }
         else if (argv[i][0] == '-') {
             fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.exr|f.pfm] [--quick] [--quiet] [--nthreads N] [--xres N] [--yres N] [--spp N] "
-                            "[--maxdepth N] [--stats] [--sampler halton|sobol] [--splitmethod sah|hlbvh|middle|equal] [--bvh-device] "
+                            "[--maxdepth N] [--stats] [--gpus N] [--sampler halton|sobol] [--splitmethod sah|hlbvh|middle|equal] [--bvh-device] "
                             "[--gpurank R/N --rendezvous FILE [--job TOKEN]]\n");
             return 1;
         } else
@@ -126,6 +140,7 @@ int main(int argc, char **argv) {
     iile::Scene scene(scene_file, ps);
     if (out.empty()) out = scene.ok() ? scene.film_filename() : std::string("pbrt.exr");
     std::unique_ptr<iile::GpuPathIntegrator> integrator(iile::CreateGpuPathIntegrator(ps, out, 0, 1, stats, comm));
+    if (!ranked) integrator->UseDevices(gpus_given ? gpus : 0);
     const bool ok = integrator->Render(scene);
     if (comm) iile_dist_destroy(comm);
     if (!ok) return 1;

@@ -437,16 +437,15 @@ float bf16_to_float(uint16_t b) {
 }
 
 template <int H, int CIN, int COUT, int PRE, bool BNORM>
-hipError_t launch_conv(const ConvArgs &a, int n_cus, hipStream_t s) {
+hipError_t launch_conv(const ConvArgs &a, int n_cus, bool *attr_set, hipStream_t s) {
     using T = Tile<H>;
     constexpr size_t lds = 2 * (size_t(T::NLP) * kRowB * 2 + kBStep);   // two buffers of {A hi, A lo, B}
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_set = false;
     auto kern = k_conv3x3<H, CIN, COUT, PRE, BNORM>;
-    if (!attr_set) {
+    if (!*attr_set) {   // once per network object, i.e. per device the object was made on (the attribute is per device)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        *attr_set = true;
     }
     int n_mtiles = H >= 32 ? a.n_img * T::TILES_PER_IMG : (a.n_img + T::IMGS - 1) / T::IMGS;
     int tiles = ((n_mtiles + 7) / 8) * 8 * (COUT / kBN);
@@ -455,22 +454,22 @@ hipError_t launch_conv(const ConvArgs &a, int n_cus, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_layer(int layer, const ConvArgs &a, int n_cus, hipStream_t s) {
+hipError_t launch_layer(int layer, const ConvArgs &a, int n_cus, bool *attr_set, hipStream_t s) {
     switch (layer) {
-        case 0: return launch_conv<32, 16, 64, PRE_NONE, false>(a, n_cus, s);
-        case 1: return launch_conv<32, 64, 64, PRE_NONE, false>(a, n_cus, s);
-        case 2: return launch_conv<16, 64, 128, PRE_NONE, true>(a, n_cus, s);
-        case 3: return launch_conv<16, 128, 128, PRE_NONE, false>(a, n_cus, s);
-        case 4: return launch_conv<8, 128, 256, PRE_NONE, true>(a, n_cus, s);
-        case 5: return launch_conv<8, 256, 256, PRE_NONE, false>(a, n_cus, s);
-        case 6: return launch_conv<4, 256, 512, PRE_NONE, true>(a, n_cus, s);
-        case 7: return launch_conv<4, 512, 256, PRE_NONE, false>(a, n_cus, s);
-        case 8: return launch_conv<8, 512, 256, PRE_CAT, true>(a, n_cus, s);
-        case 9: return launch_conv<8, 256, 128, PRE_NONE, false>(a, n_cus, s);
-        case 10: return launch_conv<16, 256, 128, PRE_CAT, true>(a, n_cus, s);
-        case 11: return launch_conv<16, 128, 64, PRE_NONE, false>(a, n_cus, s);
-        case 12: return launch_conv<32, 128, 64, PRE_CAT, false>(a, n_cus, s);
-        case 13: return launch_conv<32, 64, 64, PRE_NONE, false>(a, n_cus, s);
+        case 0: return launch_conv<32, 16, 64, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 1: return launch_conv<32, 64, 64, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 2: return launch_conv<16, 64, 128, PRE_NONE, true>(a, n_cus, attr_set, s);
+        case 3: return launch_conv<16, 128, 128, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 4: return launch_conv<8, 128, 256, PRE_NONE, true>(a, n_cus, attr_set, s);
+        case 5: return launch_conv<8, 256, 256, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 6: return launch_conv<4, 256, 512, PRE_NONE, true>(a, n_cus, attr_set, s);
+        case 7: return launch_conv<4, 512, 256, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 8: return launch_conv<8, 512, 256, PRE_CAT, true>(a, n_cus, attr_set, s);
+        case 9: return launch_conv<8, 256, 128, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 10: return launch_conv<16, 256, 128, PRE_CAT, true>(a, n_cus, attr_set, s);
+        case 11: return launch_conv<16, 128, 64, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 12: return launch_conv<32, 128, 64, PRE_CAT, false>(a, n_cus, attr_set, s);
+        case 13: return launch_conv<32, 64, 64, PRE_NONE, false>(a, n_cus, attr_set, s);
     }
     return hipErrorInvalidValue;
 }
@@ -521,6 +520,7 @@ struct iile_iispt_net {
     float *w_out = nullptr, *b_out = nullptr;
     float *ws = nullptr;      // activations of the current batch
     int ws_probes = 0;
+    bool attr_set[14] = {};   // the dynamic-LDS attribute of layer l's kernel has been raised on this object's device
     int n_cus = 256;          // persistent grid of the convolution kernels (rounded down to a multiple of 8)
     std::vector<void *> allocs;
 };
@@ -677,7 +677,7 @@ int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_
             a.bn_scale = bn >= 0 ? net->bn_scale[bn] : nullptr;
             a.bn_shift = bn >= 0 ? net->bn_shift[bn] : nullptr;
             a.n_img = nb;
-            NET_TRY(launch_layer(l, a, net->n_cus, s));
+            NET_TRY(launch_layer(l, a, net->n_cus, &net->attr_set[l], s));
             if (kRoute[l][3]) NET_TRY(launch_resample(l, a.out, buffer_of(net, BUF_R, na), nb, s));
             if (layer_out_dev && l == layer) {   // test probe: this layer's NHWC activations
                 size_t fl = size_t(kLayers[l].h) * kLayers[l].h * kLayers[l].cout;

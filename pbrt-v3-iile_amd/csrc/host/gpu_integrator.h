@@ -20,6 +20,7 @@
 #pragma once
 #include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/iile_dist.h"
@@ -79,9 +80,17 @@ class GpuPathIntegrator : public Integrator {
     GpuPathIntegrator(std::string output_pfm, int tile_rank = 0, int tile_nranks = 1, bool print_stats = false, iile_dist *comm = nullptr)
         : output_(std::move(output_pfm)), rank_(comm ? iile_dist_rank(comm) : tile_rank), nranks_(comm ? iile_dist_size(comm) : tile_nranks),
           stats_(print_stats), comm_(comm) {}
+    // One process, several devices: Render() of an integrator made without a communicator and without a shard uses
+    // `devices` GPUs of this process (0 = every visible one; 1 GPU visible: the plain single-device path below).
+    void UseDevices(int devices) { devices_ = devices; }
 
     bool Render(const Scene &scene) override {
         if (comm_) return RenderRanks(scene);
+        if (nranks_ == 1 && devices_ >= 0) {
+            const int visible = iile_device_count();
+            const int n = devices_ == 0 ? visible : devices_;
+            if (devices_ > 0 || visible > 1) return RenderAllDevices(scene, n);
+        }
         if (!scene.ok()) return false;
         iile_scene *gpu = nullptr;
         if (iile_scene_create(scene.desc(), &gpu) != IILE_OK) {
@@ -106,6 +115,52 @@ class GpuPathIntegrator : public Integrator {
         return WriteFilm(f, xyzw);
     }
     iile_stats last_stats = {};
+
+    // The reference enters integrator->Render(*scene) ONCE, in one process (src/core/api.cpp:1650-1662), and fans the tiles out
+    // itself (ParallelFor2D over its thread pool, src/core/parallel.cpp:247-299). The same here over the GPUs of the process:
+    // one host thread per device, each with its own iile_scene, the tiles dealt by iile_tile_owner, the films merged by the ONE
+    // RCCL reduction of the N-process path — the threads rendezvous through an in-process unique id (ncclCommInitRank from N
+    // threads of one process) and then run exactly RenderRanks. Rank 0's thread writes the image. n == 1 is the same code with a
+    // communicator of one rank (what the one-GPU boxes of this pool can run: tests/test_gpu_parity.py).
+    bool RenderAllDevices(const Scene &scene, int n) {
+        const int visible = iile_device_count();
+        if (n < 1 || visible < 1) {
+            fprintf(stderr, "Error: GPU path: %s\n", visible < 1 ? "no HIP device" : "no device asked for");
+            return false;
+        }
+        uint8_t id[IILE_DIST_ID_BYTES];
+        if (iile_dist_unique_id(id) != IILE_OK) {
+            fprintf(stderr, "Error: multi-GPU set-up: %s\n", iile_dist_last_error());
+            return false;
+        }
+        std::vector<char> ok(size_t(n), 0);
+        std::vector<iile_stats> stats;
+        stats.resize(size_t(n));
+        auto worker = [&](int r) {
+            // (error strings are thread-local in both libraries: every thread reports its own)
+            if (iile_device_select(r % visible) != IILE_OK) {
+                fprintf(stderr, "Error: GPU path: device %d: %s\n", r % visible, iile_last_error());
+                // this rank cannot join: the others would wait in ncclCommInitRank — leave through the communicator anyway
+            }
+            iile_dist *comm = nullptr;
+            if (iile_dist_create(id, r, n, &comm) != IILE_OK) {
+                fprintf(stderr, "Error: multi-GPU set-up (device %d of %d): %s\n", r, n, iile_dist_last_error());
+                return;
+            }
+            GpuPathIntegrator part(output_, 0, 1, stats_, comm);
+            ok[size_t(r)] = part.RenderRanks(scene) ? 1 : 0;
+            stats[size_t(r)] = part.last_stats;
+            iile_dist_destroy(comm);
+        };
+        std::vector<std::thread> threads;
+        for (int r = 1; r < n; ++r) threads.emplace_back(worker, r);
+        worker(0);   // rank 0 on the calling thread: it writes the image
+        for (std::thread &t : threads) t.join();
+        for (int r = 0; r < n; ++r)
+            if (!ok[size_t(r)]) return false;
+        last_stats = stats[0];   // job totals (RenderRanks sums the counters over the ranks)
+        return true;
+    }
 
   private:
     bool WriteFilm(const iile_film_desc *f, const std::vector<float> &xyzw) {
@@ -201,6 +256,7 @@ class GpuPathIntegrator : public Integrator {
     int rank_, nranks_;
     bool stats_;
     iile_dist *comm_;
+    int devices_ = -1;   // >= 0: Render() may use several devices of this process (UseDevices)
 };
 
 inline GpuPathIntegrator *CreateGpuPathIntegrator(const ParamSet &, const std::string &output_pfm, int tile_rank = 0,

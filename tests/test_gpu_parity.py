@@ -325,6 +325,14 @@ def test_cpp_cli_ranked_branch_world1(scene_small, gpu_small, tmp_path):
     img = np.frombuffer(raw[len(head):], "<f4").reshape(120, 160, 3)[::-1]
     film, _ = gpu_small.render()
     assert_bitwise(img, scene_small.film_to_rgb(film), "ranked CLI image")
+    # one process, the devices of the node: `--gpus 1` runs GpuPathIntegrator::RenderAllDevices — a host thread per device, an
+    # in-process RCCL rendezvous, the same communicator branch — with one device: the same image and statistics again. (With
+    # several GPUs visible that path is the default of `iile_pbrt scene.pbrt`; the one-GPU boxes of this pool take the plain one.)
+    allp = tmp_path / "all.pfm"
+    p3 = subprocess.run([exe, scene, *size, "--outfile", str(allp), "--gpus", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p3.returncode == 0, p3.stdout
+    assert allp.read_bytes() == plain.read_bytes()
+    assert [l for l in p3.stdout.splitlines() if l.startswith("rays:")] == stats[0], p3.stdout
     # a rank whose scene does not load leaves through the status exchange with an error, not a hang
     p2 = subprocess.run([exe, str(tmp_path / "missing.pbrt"), "--gpurank", "0/1", "--rendezvous", str(rv)],
                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
