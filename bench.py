@@ -501,7 +501,7 @@ def main():
         torch.cuda.synchronize()
         film_check = film.clone()
         for _ in range(warmup):
-            step()
+            step(timed=2 if (args.schedule == "one-stream" and want_kernels) else False)   # (a trace of the run then holds one schedule only)
         barrier()
         t0 = time.perf_counter()
         agg = {"ms_extend": 0.0, "ms_connect": 0.0, "ms_shadow": 0.0, "ms_mis": 0.0, "ms_resolve": 0.0, "ms_shade": 0.0,

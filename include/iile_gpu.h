@@ -229,8 +229,8 @@ void iile_iispt_net_destroy(iile_iispt_net *net);
  * emitLBVH :434-452, 555-618, buildUpperSAH :474-553) and flattenBVHTree (:640-658) — SURVEY.md §8 f4. bounds6: per
  * primitive WorldBound() as {min xyz, max xyz} (host memory); nodes_out: room for 2 * n_prims nodes; order_out[i] = the
  * number of the primitive at position i of BVHAccel::primitives after the build. The tree is the one the reference
- * builds with one thread (treelets in index order); Morton codes, the sort, the treelets and the flattening run on the
- * device, the SAH over the <= 4096 treelet roots on the host. The signature doubles as the `bvh_build` hook of
+ * builds with one thread (treelets in index order); Morton codes, the sort, the treelets, buildUpperSAH (level by level, a wavefront
+ * per span) and the flattening all run on the device. The signature doubles as the `bvh_build` hook of
  * iile_host_overrides (include/iile_host.h). */
 typedef struct iile_bvh_build_stats {
     float ms_total, ms_morton, ms_sort, ms_treelets, ms_upper, ms_flatten, ms_download;

@@ -8,18 +8,21 @@
 // a_hi = bf16(a), a_lo = bf16(a - a_hi) (16 significant bits), and the product a * w is accumulated in fp32 as
 // a_hi w_hi + a_hi w_lo + a_lo w_hi (the dropped a_lo w_lo term is 2^-16 of the product). Three matrix instructions per
 // tile instead of one; against the reference module's output (tests/golden/iispt_net_fixture.npz) the whole network lands
-// 3e-5 of the largest value away, the bound held by tests/test_iispt_nn.py being 1e-4 (plain bf16: 2.2e-2).
+// 2.4e-5 of the largest value away, the bound held by tests/test_iispt_nn.py being 1e-4 (plain bf16: 2.3e-2).
 //
 // Layout. Activations: NHWC fp32, one tensor per layer. Weights: packed once on the host into the matrix instruction's
-// B-fragment order, hi and lo, k = (channel chunk, tap, channel in chunk) — a wave reads 4 KB contiguous per k-step straight
-// from L2 into registers (every workgroup walks the same few MB). A workgroup (4 waves) owns 256 pixels x 64 output
-// channels; per chunk of input channels it stages the 256 pixels plus their one-pixel halo into LDS as bf16 hi / lo rows
-// (80-byte rows: conflict-free ds_read_b128), applying on the way whatever sits in front of the convolution in the
-// reference's Sequential: MaxPool2d(2) (max of four loads), or Upsample(x2, bilinear) + torch.cat (four loads and the
-// blend for the channels that come from the level below, one load for the skip channels). Behind it: bias, LeakyReLU(0.2)
-// and the eval-mode BatchNorm2d affine in the accumulator registers, then one 128-byte store per 32 lanes.
-// ConvTranspose2d(k = 3, stride 1, padding 1) is the same convolution with the kernel mirrored and its channel axes
-// swapped (done by the packer).
+// B-fragment order, hi and lo, k = (16-channel chunk, tap): 36 KB per (chunk, 64 output channels). A persistent workgroup
+// (one per CU; 4 matrix waves + 8 staging waves, k_conv3x3 below) owns a stream of (256-pixel tile, chunk) steps: the staging
+// waves bring a step's pixels — with their one-pixel halo, split into bf16 hi / lo rows of 48 bytes — and its packed weights
+// into one of two LDS buffers while the matrix waves run the step before out of the other; the matrix waves read LDS only.
+// Behind the last chunk of a tile: bias, LeakyReLU(0.2) and the eval-mode BatchNorm2d affine in the accumulator registers, one
+// 128-byte store per 32 lanes. MaxPool2d(2) and Upsample(x2, bilinear) are streaming kernels of their own (k_pool2, k_up2);
+// torch.cat costs nothing (a step's 16 channels come from one of two tensors). ConvTranspose2d(k = 3, stride 1, padding 1) is
+// the same convolution with the kernel mirrored and its channel axes swapped (done by the packer). Measurements, and the two
+// designs this one replaced: DESIGN.md section 4.6.
+//
+// Timing-only diagnostics (wrong results; tools/net_layers.sh, tools/net_pmc.sh build them as variants):
+// -DNET_DIAG_NO_STAGE (the staging waves only keep the barriers), -DNET_DIAG_NO_MFMA, -DNET_DIAG_NO_GLOBAL (no global loads).
 #include <hip/hip_runtime.h>
 
 #include <cmath>

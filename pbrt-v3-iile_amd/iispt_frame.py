@@ -107,7 +107,8 @@ class IisptFrame:
         i = 0
         while i < len(tasks):
             group, n_pts, n_pix = [], 0, 0
-            while i < len(tasks) and (not group or n_pts < max_probes):
+            # (a group never spans two sweeps: inside one sweep no two tasks share a pixel, which the one-launch film update needs)
+            while i < len(tasks) and (not group or (n_pts < max_probes and tasks[i][4] == group[0].tilesize)):
                 x0, y0, x1, y1, ts = tasks[i]
                 task = self.b.IisptTask(x0, y0, x1, y1, ts, self.counter, self.rng_seed)
                 nx, ny = task.grid()
@@ -131,13 +132,20 @@ class IisptFrame:
             t0 = time.time()
             out = torch.empty((n_pix, 4), dtype=torch.float32, device="cuda")
             self.gpu.iispt_gather_batch(group, valid, pos, dr, nn_device_ptr=nn.data_ptr(), out_device_ptr=out.data_ptr())
-            first = 0
+            # add_n_samples for every pixel of every task of the group in ONE launch: the tasks' pixels (task after task, row-major
+            # inside a task) scattered to their film pixels — tasks of one sweep do not overlap, so no two rows meet
+            key = (w, tuple((t.x0, t.y0, t.x1, t.y1) for t in group))
+            cache = self.gpu.__dict__.setdefault("_iispt_scatter_cache", {})   # lives with the scene: the next frame has the same tasks
+            if key not in cache:
+                if len(cache) > 64:
+                    cache.clear()
+                idx = np.concatenate([(np.arange(t.y0, t.y1, dtype=np.int64)[:, None] * w + np.arange(t.x0, t.x1, dtype=np.int64)[None, :]).reshape(-1)
+                                      for t in group])
+                cache[key] = torch.from_numpy(idx).cuda()
+            self.film.view(-1, 4).index_add_(0, cache[key], out.double())
             for task in group:
-                th, tw = task.y1 - task.y0, task.x1 - task.x0
-                self.film[task.y0:task.y1, task.x0:task.x1] += out[first:first + th * tw].view(th, tw, 4).double()
-                first += th * tw
                 self.stats["tasks"] += 1
-                self.stats["pixels"] += tw * th
+                self.stats["pixels"] += (task.y1 - task.y0) * (task.x1 - task.x0)
             tick("gather", t0)
             self.stats["hemi_points"] += n_pts
             self.stats["probes"] += int(sel.sum())
