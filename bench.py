@@ -304,6 +304,8 @@ def main_iispt(args):
         for name, e0, e1 in rec:
             stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / args.steps
     indirect_ms = sum(e[0].elapsed_time(e[1]) for e in frame_events) / args.steps
+    for name in ("normalize", "rescale"):   # (inside `network` with the HIP backend: iile_iispt_net_predict runs the two transforms)
+        stage_ms.setdefault(name, 0.0)
     stage_ms["hemi_points_gather_and_film"] = indirect_ms - sum(stage_ms.values())
     stage_ms["direct_pass_16"] = sum(e[1].elapsed_time(e[2]) for e in frame_events) / args.steps
     stage_ms["merge"] = sum(e[2].elapsed_time(e[3]) for e in frame_events) / args.steps
@@ -339,7 +341,9 @@ def main_iispt(args):
                    "baseline_config": "5 (IISPT integrator: hemisphere probes + network on the GPU)", "xres": args.xres, "yres": args.yres,
                    "probes": probes, "pixels": frame.stats["pixels"]},
         "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
-        "stage_note": "HIP events on the stream every stage runs on; `hemi_points_gather_and_film` = the indirect pass minus its four timed stages",
+        "stage_note": "HIP events on the stream every stage runs on; `network` = iile_iispt_net_predict: normalizeMapsDownstream, the 15 convolutions, "
+                      "transformMapsUpstream (`normalize` / `rescale` are 0: they are kernels of that call); `hemi_points_gather_and_film` = the "
+                      "indirect pass minus its timed stages",
         "roofline": {
             "kernel": "k_conv3x3 (the 14 3x3 convolutions of IISPTNet, csrc/device/iispt_net.hip; with the two layout kernels of a forward)",
             "bound": "mfma",

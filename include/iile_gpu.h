@@ -224,6 +224,14 @@ typedef struct iile_iispt_net_weights {
 int iile_iispt_net_create(const iile_iispt_net_weights *weights, iile_iispt_net **out);
 int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_dev, int32_t n, int32_t max_batch, void *stream,
                            float *layer_out_dev, int32_t layer);
+/* The network with the two transforms IisptRenderRunner applies around it, as one call over a batch of rendered probes:
+ * normalizeMapsDownstream (src/integrators/iisptrenderrunner.cpp:1041-1092) -> IISPTNet -> transformMapsUpstream (:1095-1133).
+ * intensity_dev / normals_dev: (n, 32, 32, 3), distance_dev: (n, 32, 32), raster order as iile_render_probes leaves them (device
+ * memory); pred_dev: (n, 32, 32, 3) predicted intensity, rescaled per channel to the rendered probe's mean — film_rows != 0: rows in
+ * ImageFilm order (row 0 = the top scanline: what iile_iispt_gather reads as nn_films), else raster order. Means are double sums,
+ * log(1.0 + v) / exp(v) - 1.0 are evaluated in double as the reference does, everything else in float. Queued on `stream`. */
+int iile_iispt_net_predict(iile_iispt_net *net, const float *intensity_dev, const float *normals_dev, const float *distance_dev,
+                           float *pred_dev, int32_t n, int32_t film_rows, int32_t max_batch, void *stream);
 void iile_iispt_net_destroy(iile_iispt_net *net);
 /* BVHAccel's HLBVH build (src/accelerators/bvh.cpp:404-472: Morton codes :413-427, RadixSort :133-181, treelets and
  * emitLBVH :434-452, 555-618, buildUpperSAH :474-553) and flattenBVHTree (:640-658) — SURVEY.md §8 f4. bounds6: per

@@ -134,7 +134,7 @@ GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iil
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
                "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download",
                "iile_iispt_hemi_points", "iile_iispt_gather", "iile_iispt_hemi_points_batch", "iile_iispt_gather_batch", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct",
-               "iile_wide_ref_shift", "iile_render_status", "iile_test_patch_capacity", "iile_iispt_net_create", "iile_iispt_net_forward", "iile_iispt_net_destroy"]
+               "iile_wide_ref_shift", "iile_render_status", "iile_test_patch_capacity", "iile_iispt_net_create", "iile_iispt_net_forward", "iile_iispt_net_predict", "iile_iispt_net_destroy"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size", "iile_dist_ranks_seen",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_rendezvous_file_token", "iile_dist_rendezvous_done", "iile_dist_all_ok",
@@ -254,6 +254,7 @@ def gpu_lib():
         lib.iile_test_patch_capacity.argtypes = [c_vp, c_u32]
         lib.iile_iispt_net_create.argtypes = [ctypes.POINTER(NetWeights), ctypes.POINTER(c_vp)]
         lib.iile_iispt_net_forward.argtypes = [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32]
+        lib.iile_iispt_net_predict.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]
         lib.iile_iispt_net_destroy.argtypes = [c_vp]
         lib.iile_iispt_net_destroy.restype = None
         _gpu = lib
@@ -703,6 +704,13 @@ class GpuNet:
         rc = self._lib.iile_iispt_net_forward(self._h, in_ptr, out_ptr, int(n), int(max_batch), stream, layer_out_ptr, int(layer))
         if rc != 0:
             raise RuntimeError(f"iile_iispt_net_forward failed ({rc}): {self._lib.iile_last_error().decode()}")
+
+    def predict(self, intensity_ptr, normals_ptr, distance_ptr, pred_ptr, n, film_rows=False, max_batch=0, stream=None):
+        """normalizeMapsDownstream -> network -> transformMapsUpstream over n rendered probes (device pointers; raster order in,
+        (n, 32, 32, 3) out: ImageFilm row order when film_rows, else raster)."""
+        rc = self._lib.iile_iispt_net_predict(self._h, intensity_ptr, normals_ptr, distance_ptr, pred_ptr, int(n), int(bool(film_rows)), int(max_batch), stream)
+        if rc != 0:
+            raise RuntimeError(f"iile_iispt_net_predict failed ({rc}): {self._lib.iile_last_error().decode()}")
 
     def close(self):
         if self._h:

@@ -407,6 +407,106 @@ __global__ void k_net_output(const float *in, const float *w /* [3][64] */, cons
     }
 }
 
+// ---- the two transforms the runner applies around the network, one workgroup per probe ----
+__device__ inline double block_sum(double v, double *s_red) {   // 256 threads; every thread gets the sum
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// normalizeMapsDownstream (src/integrators/iisptrenderrunner.cpp:1041-1092 over ImageFilm's operations, src/film/imagefilm.cpp:
+// 203-254, 298-379) + read_input's layout (ml/main_stdio_net.py:47-72): the probe's intensity / normals / distance images in
+// raster order -> the network's input, NHWC padded to 16 channels, in ImageFilm row order (row h - 1 - y), and the probe's
+// channel means for transformMapsUpstream. Double sums for the means, log(1.0 + v) in double, everything else float.
+__global__ __launch_bounds__(256) void k_net_normalize(const float *inten, const float *nrm, const float *dist, float *x16, float *chan_mean, int n) {
+    __shared__ double s_red[4];
+    const int probe = blockIdx.x, t = threadIdx.x;
+    const float *ip = inten + size_t(probe) * 3072, *np_ = nrm + size_t(probe) * 3072, *dp = dist + size_t(probe) * 1024;
+    double sc[3] = {0, 0, 0}, sd = 0;
+    for (int px = t; px < 1024; px += 256) {
+        sc[0] += double(ip[3 * px]);
+        sc[1] += double(ip[3 * px + 1]);
+        sc[2] += double(ip[3 * px + 2]);
+        sd += double(dp[px]);
+    }
+    const double s0 = block_sum(sc[0], s_red), s1 = block_sum(sc[1], s_red), s2 = block_sum(sc[2], s_red), s3 = block_sum(sd, s_red);
+    const float mean = float((s0 + s1 + s2) / 3072.0);
+    const float ratio = mean == 0.f ? 0.f : float(1.0 / (10.0 * double(mean)));
+    const float z_mean = float(s3 / 1024.0);
+    float div = float(10.0 * (double(z_mean) + 1.0));
+    if (div == 0.f) div = 1.f;
+    const float rdiv = float(1.0 / double(div));
+    if (t < 3) chan_mean[size_t(probe) * 3 + t] = float((t == 0 ? s0 : t == 1 ? s1 : s2) / 1024.0);
+    for (int px = t; px < 1024; px += 256) {
+        const int y = px >> 5, x = px & 31;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = ip[3 * px + c] * ratio;
+            a = a > 0.f ? a : 0.f;
+            v[c] = float(log(1.0 + double(a))) + -0.1f;
+            float b = np_[3 * px + c];
+            v[3 + c] = b < -1.f ? -1.f : (b > 1.f ? 1.f : b);
+        }
+        float d = (dp[px] + 1.0f) * rdiv;
+        d = d > 0.f ? d : 0.f;
+        v[6] = float(log(1.0 + double(d))) + -0.1f;
+        v[7] = 0.f;
+        f32x4 *o = reinterpret_cast<f32x4 *>(x16 + ((size_t(probe) * 32 + (31 - y)) * 32 + x) * 16);
+        o[0] = f32x4{v[0], v[1], v[2], v[3]};
+        o[1] = f32x4{v[4], v[5], v[6], v[7]};
+        o[2] = o[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// decoder2's Conv2d(K, 3, 1) + ReLU, then transformMapsUpstream (iisptrenderrunner.cpp:1095-1133): exp(v) - 1 in double, every
+// channel rescaled so that its mean is the rendered probe's. pred: (n, 32, 32, 3); film_rows != 0: rows as the network emits
+// them (ImageFilm order: what iile_iispt_gather reads), else raster order (row h - 1 - y).
+__global__ __launch_bounds__(256) void k_net_predict_out(const float *in, const float *w /* [3][64] */, const float *bias, const float *chan_mean,
+                                                          float *pred, int film_rows, int n) {
+    __shared__ double s_red[4];
+    __shared__ float s_w[192];
+    const int probe = blockIdx.x, t = threadIdx.x;
+    if (t < 192) s_w[t] = w[t];
+    __syncthreads();
+    float e[4][3];
+    double sum[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int px = t + 256 * k;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(in + (size_t(probe) * 1024 + px) * 64);
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 a = src[q];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) acc[o] += a.x * s_w[o * 64 + 4 * q] + a.y * s_w[o * 64 + 4 * q + 1] + a.z * s_w[o * 64 + 4 * q + 2] + a.w * s_w[o * 64 + 4 * q + 3];
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float r = acc[o] + bias[o];
+            r = r > 0.f ? r : 0.f;                       // the network's final ReLU (and positiveLogInverse's clamp)
+            e[k][o] = float(exp(double(r)) - 1.0);
+            sum[o] += double(e[k][o]);
+        }
+    }
+    float mul[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float actual = float(block_sum(sum[o], s_red) / 1024.0);
+        mul[o] = actual > 1e-10f ? chan_mean[size_t(probe) * 3 + o] / actual : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int px = t + 256 * k, y = px >> 5, x = px & 31;
+        float *o = pred + ((size_t(probe) * 32 + (film_rows ? y : 31 - y)) * 32 + x) * 3;
+        o[0] = e[k][0] * mul[0];
+        o[1] = e[k][1] * mul[1];
+        o[2] = e[k][2] * mul[2];
+    }
+}
+
 // ---- host side ----
 
 struct LayerDef {
@@ -522,6 +622,7 @@ struct iile_iispt_net {
     float *bn_scale[5] = {}, *bn_shift[5] = {};
     float *w_out = nullptr, *b_out = nullptr;
     float *ws = nullptr;      // activations of the current batch
+    size_t ws_floats_per_probe = 0;
     int ws_probes = 0;
     bool attr_set[14] = {};   // the dynamic-LDS attribute of layer l's kernel has been raised on this object's device
     int n_cus = 256;          // persistent grid of the convolution kernels (rounded down to a multiple of 8)
@@ -583,7 +684,8 @@ int ensure_workspace(iile_iispt_net *net, int n) {
     net->ws_probes = 0;
     size_t per = 0;
     for (size_t f : kBufFloats) per += f;
-    NET_TRY(hipMalloc(reinterpret_cast<void **>(&net->ws), per * sizeof(float) * size_t(n)));
+    net->ws_floats_per_probe = per;
+    NET_TRY(hipMalloc(reinterpret_cast<void **>(&net->ws), (per + 4) * sizeof(float) * size_t(n)));   // + the channel means of a probe
     net->ws_probes = n;
     return IILE_OK;
 }
@@ -653,6 +755,35 @@ void iile_iispt_net_destroy(iile_iispt_net *net) {
     delete net;
 }
 
+}  // extern "C"
+
+namespace {
+// the 14 convolution layers (and the resampling kernels between them) over the nb probes whose input sits in buffer P
+int run_layers(iile_iispt_net *net, int nb, int na, hipStream_t s, float *layer_out_dev, int layer, size_t first) {
+    for (int l = 0; l < 14; ++l) {
+        ConvArgs a{};
+        a.in0 = buffer_of(net, kRoute[l][0], na);
+        a.in1 = kRoute[l][1] >= 0 ? buffer_of(net, kRoute[l][1], na) : nullptr;
+        a.out = buffer_of(net, kRoute[l][2], na);
+        a.wpack = net->wpack[l];
+        a.bias = net->bias[l];
+        int bn = kBnOfLayer[l];
+        a.bn_scale = bn >= 0 ? net->bn_scale[bn] : nullptr;
+        a.bn_shift = bn >= 0 ? net->bn_shift[bn] : nullptr;
+        a.n_img = nb;
+        NET_TRY(launch_layer(l, a, net->n_cus, &net->attr_set[l], s));
+        if (kRoute[l][3]) NET_TRY(launch_resample(l, a.out, buffer_of(net, BUF_R, na), nb, s));
+        if (layer_out_dev && l == layer) {   // test probe: this layer's NHWC activations
+            size_t fl = size_t(kLayers[l].h) * kLayers[l].h * kLayers[l].cout;
+            NET_TRY(hipMemcpyAsync(layer_out_dev + first * fl, a.out, fl * size_t(nb) * 4, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    return IILE_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_dev, int32_t n, int32_t max_batch, void *stream,
                            float *layer_out_dev, int32_t layer) {
     if (!net || !in_dev || !out_dev || n < 0) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_forward: bad argument");
@@ -669,26 +800,36 @@ int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_
         hipLaunchKernelGGL(k_net_input, dim3((size_t(nb) * 1024 + 255) / 256), dim3(256), 0, s, in_dev + size_t(first) * 7 * 1024,
                            buffer_of(net, BUF_P, na), nb);
         NET_TRY(hipGetLastError());
-        for (int l = 0; l < 14; ++l) {
-            ConvArgs a{};
-            a.in0 = buffer_of(net, kRoute[l][0], na);
-            a.in1 = kRoute[l][1] >= 0 ? buffer_of(net, kRoute[l][1], na) : nullptr;
-            a.out = buffer_of(net, kRoute[l][2], na);
-            a.wpack = net->wpack[l];
-            a.bias = net->bias[l];
-            int bn = kBnOfLayer[l];
-            a.bn_scale = bn >= 0 ? net->bn_scale[bn] : nullptr;
-            a.bn_shift = bn >= 0 ? net->bn_shift[bn] : nullptr;
-            a.n_img = nb;
-            NET_TRY(launch_layer(l, a, net->n_cus, &net->attr_set[l], s));
-            if (kRoute[l][3]) NET_TRY(launch_resample(l, a.out, buffer_of(net, BUF_R, na), nb, s));
-            if (layer_out_dev && l == layer) {   // test probe: this layer's NHWC activations
-                size_t fl = size_t(kLayers[l].h) * kLayers[l].h * kLayers[l].cout;
-                NET_TRY(hipMemcpyAsync(layer_out_dev + size_t(first) * fl, a.out, fl * size_t(nb) * 4, hipMemcpyDeviceToDevice, s));
-            }
-        }
+        rc = run_layers(net, nb, na, s, layer_out_dev, layer, size_t(first));
+        if (rc) return rc;
         hipLaunchKernelGGL(k_net_output, dim3((size_t(nb) * 1024 * 16 + 255) / 256), dim3(256), 0, s, buffer_of(net, BUF_Q, na), net->w_out,
                            net->b_out, out_dev + size_t(first) * 3 * 1024, nb);
+        NET_TRY(hipGetLastError());
+    }
+    return IILE_OK;
+}
+
+int iile_iispt_net_predict(iile_iispt_net *net, const float *intensity_dev, const float *normals_dev, const float *distance_dev,
+                           float *pred_dev, int32_t n, int32_t film_rows, int32_t max_batch, void *stream) {
+    if (!net || !intensity_dev || !normals_dev || !distance_dev || !pred_dev || n < 0)
+        return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_predict: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (max_batch <= 0) max_batch = 32768;
+    const int cap = n < max_batch ? n : max_batch;
+    if (n == 0) return IILE_OK;
+    int rc = ensure_workspace(net, cap);
+    if (rc) return rc;
+    const int na = net->ws_probes;
+    float *means = net->ws + net->ws_floats_per_probe * size_t(na);   // 3 floats per probe behind the activation buffers
+    for (int first = 0; first < n; first += cap) {
+        const int nb = n - first < cap ? n - first : cap;
+        hipLaunchKernelGGL(k_net_normalize, dim3(nb), dim3(256), 0, s, intensity_dev + size_t(first) * 3072, normals_dev + size_t(first) * 3072,
+                           distance_dev + size_t(first) * 1024, buffer_of(net, BUF_P, na), means, nb);
+        NET_TRY(hipGetLastError());
+        rc = run_layers(net, nb, na, s, nullptr, 0, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_net_predict_out, dim3(nb), dim3(256), 0, s, buffer_of(net, BUF_Q, na), net->w_out, net->b_out, means,
+                           pred_dev + size_t(first) * 3072, film_rows, nb);
         NET_TRY(hipGetLastError());
     }
     return IILE_OK;

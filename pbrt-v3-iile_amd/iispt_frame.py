@@ -68,9 +68,9 @@ class IisptFrame:
         sel = valid.reshape(-1) == 1
         nn = torch.zeros((ny * nx, 32, 32, 3), dtype=torch.float32, device="cuda")
         if sel.any():
-            pred, _, _, _ = self.pipe(pos.reshape(-1, 3)[sel], dr.reshape(-1, 3)[sel])
-            # the gather reads the network's own row order (ImageFilm: row 0 = top scanline); the pipeline hands back raster order
-            nn[torch.from_numpy(sel).cuda()] = torch.flip(pred, dims=(1,))
+            # the gather reads the network's own row order (ImageFilm: row 0 = top scanline)
+            pred, _, _, _ = self.pipe(pos.reshape(-1, 3)[sel], dr.reshape(-1, 3)[sel], film_rows=True)
+            nn[torch.from_numpy(sel).cuda()] = pred
         h, w = y1 - y0, x1 - x0
         out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
         self.gpu.iispt_gather(task, valid, pos, dr, nn_device_ptr=nn.data_ptr(), out_device_ptr=out.data_ptr())
@@ -126,8 +126,8 @@ class IisptFrame:
             sel = valid == 1
             nn = torch.zeros((n_pts, 32, 32, 3), dtype=torch.float32, device="cuda")
             if sel.any():
-                pred, _, _, _ = self.pipe(pos[sel], dr[sel])
-                nn[torch.from_numpy(sel).cuda()] = torch.flip(pred, dims=(1,))
+                pred, _, _, _ = self.pipe(pos[sel], dr[sel], film_rows=True)
+                nn[torch.from_numpy(sel).cuda()] = pred
             tick("probes_and_network", t0)
             t0 = time.time()
             out = torch.empty((n_pix, 4), dtype=torch.float32, device="cuda")

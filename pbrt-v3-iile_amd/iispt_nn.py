@@ -192,18 +192,26 @@ class IisptPipeline:
         return self.net(x.to(self.dtype).contiguous(memory_format=torch.channels_last)).float()
 
     @torch.no_grad()
-    def __call__(self, pos, direction, batch=32768):
+    def __call__(self, pos, direction, batch=32768, film_rows=False):
         """(n, 3) probe origins and directions -> (predicted intensity (n, h, h, 3), rendered intensity, normals,
-        distance), all torch tensors on the device, raster order."""
+        distance), all torch tensors on the device, raster order (film_rows: the prediction in the network's own row order,
+        ImageFilm's, as iile_iispt_gather reads it). With the HIP network the two transforms run inside iile_iispt_net_predict;
+        the PyTorch backend keeps them as the tensor expressions above (tests hold the two against each other)."""
         n = len(pos)
         inten = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         nrm = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         dist = torch.empty((n, HEMI, HEMI), dtype=torch.float32, device=self.device)
         self._timed("probe_pass", lambda: self.gpu.render_probes(pos, direction, device_out=(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr())))
         pred = torch.empty_like(inten)
+        if self.hip_net is not None:
+            self._timed("network", lambda: self.hip_net.predict(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr(), pred.data_ptr(), n, film_rows=film_rows,
+                                                                max_batch=batch, stream=torch.cuda.current_stream().cuda_stream))
+            return pred, inten, nrm, dist
         for first in range(0, n, batch):
             sl = slice(first, min(n, first + batch))
             x, means = self._timed("normalize", lambda: normalize_downstream(inten[sl], nrm[sl], dist[sl]))
             y = self._timed("network", lambda: self.infer(x))
             pred[sl] = self._timed("rescale", lambda: transform_upstream(y, means))
+        if film_rows:
+            pred = torch.flip(pred, dims=(1,))
         return pred, inten, nrm, dist

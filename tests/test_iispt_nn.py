@@ -251,6 +251,46 @@ def test_hip_network_follows_a_checkpoint_not_the_recipe(binding):
 
 
 @pytest.mark.gpu
+def test_predict_runs_the_two_transforms_as_the_tensor_expressions_do(binding):
+    """iile_iispt_net_predict = normalizeMapsDownstream -> network -> transformMapsUpstream in three kernels around the
+    convolutions. Against the same three steps as tensor expressions (normalize_downstream / transform_upstream above, held to a
+    scalar restatement of the reference's ImageFilm arithmetic by test_transforms_follow_the_reference_arithmetic) with the
+    SAME network kernels in between: equal up to the order of the double sums and one ulp of log / exp (1e-5 of the largest
+    value); a black probe stays black, escaped rays (distance -1) and out-of-range normals are clamped, and film_rows returns
+    the rows in the network's own order."""
+    torch.cuda.init()
+    rng = np.random.default_rng(7)
+    n, h = 21, 32
+    inten = (rng.random((n, h, h, 3)) ** 3 * 5).astype(np.float32)
+    inten[1] = 0
+    nrm = rng.uniform(-1.2, 1.2, (n, h, h, 3)).astype(np.float32)
+    dist = rng.uniform(0, 40, (n, h, h)).astype(np.float32)
+    dist[2, :10] = -1
+    net, _ = _recipe_net()
+    g = binding.GpuNet(net.state_dict())
+    di, dn, dd = (torch.from_numpy(a).cuda() for a in (inten, nrm, dist))
+    with torch.no_grad():
+        x, means = nn_mod.normalize_downstream(di, dn, dd)
+        x = x.contiguous()
+        y = torch.empty((n, 3, h, h), dtype=torch.float32, device="cuda")
+        g.forward(x.data_ptr(), y.data_ptr(), n)
+        want = nn_mod.transform_upstream(y, means)
+    got = torch.empty((n, h, h, 3), dtype=torch.float32, device="cuda")
+    g.predict(di.data_ptr(), dn.data_ptr(), dd.data_ptr(), got.data_ptr(), n)
+    rows = torch.empty_like(got)
+    g.predict(di.data_ptr(), dn.data_ptr(), dd.data_ptr(), rows.data_ptr(), n, film_rows=True, max_batch=8)
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    assert scale > 0 and float((got - want).abs().max()) <= 1e-5 * scale, float((got - want).abs().max()) / scale
+    assert bool((got[1] == 0).all())
+    assert torch.equal(rows, torch.flip(got, dims=(1,)))
+    # every channel of a predicted hemisphere has the mean of its rendered probe (where the network leaves it above zero)
+    gm = got.double().reshape(n, -1, 3).mean(1).cpu().numpy()
+    lit = (means.cpu().numpy() > 1e-6) & (gm > 0)
+    assert lit.sum() > n and np.allclose(gm[lit], means.cpu().numpy()[lit], rtol=1e-5)
+
+
+@pytest.mark.gpu
 def test_pipeline_keeps_everything_on_the_device(binding):
     """render -> normalise -> network -> rescale over a batch of probes with the images left in HBM: the rendered
     images equal the host-copied ones, the network's fp32 output on the GPU agrees with the same module on the CPU,
