@@ -161,7 +161,9 @@ int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, c
  * DOUBLES, over the film's cropped pixel bounds. The reference consumes ONE random stream per thread, and which thread renders
  * which pass is a race; here pass p (= first_pass + i) is seeded 6284 + 17 p — the seed a runner thread with that number would
  * clone its sampler with — and every pixel of it has its own PCG32 stream, consumed in the reference's per-pixel order (kernels_direct.hip).
- * accumulate == 0: the film is zeroed first. Every light is sampled Light::nSamples times per vertex (iile_light::n_samples;
+ * Up to four passes run in one set of launches (path id = (pixel, pass): one pass of one sample per pixel leaves most of a persistent
+ * traversal grid idle); each keeps its seed and records, and a pixel's passes are added to the monitor in pass order — the result is
+ * the same, bit for bit, whatever the grouping. accumulate == 0: the film is zeroed first. Every light is sampled Light::nSamples times per vertex (iile_light::n_samples;
  * UniformSampleAllLights, integrator.cpp:54-83), infinite lights included (escaped rays return Le at every depth,
  * directprogressiveintegrator.cpp:29-32); the NEE record planes are sized for pixels x (sum of the lights' nSamples) records
  * per level, at most 64 light samples per vertex. Reflected rays carry differentials in textured scenes

@@ -1776,8 +1776,18 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     P.slot0 = 0;
     P.n_pass_tiles = P.n_owned_tiles;
     P.k0 = 0;
-    P.kc = 1;
-    const uint64_t n_paths64 = uint64_t(P.n_owned_tiles) * 256;
+    // One launch renders `batch` passes of the frame at once: path id = (pixel slot, pass of the batch) — the "sample of the pixel"
+    // coordinate of the path tracer's enumeration (path_pixel). A pass of one sample per pixel leaves most of a persistent
+    // traversal grid without a second ray (2 M paths over 393 k lanes); four at a time run at the path integrator's rates. Each
+    // pass keeps its own seed and its own records; the fold adds a pixel's passes in pass order. Glass (one thread per pixel
+    // walking a tree) stays at one pass per launch.
+    int total_samples_pre = 0;
+    for (int l = 0; l < std::max(S.n_lights, 0) && l < 8; ++l) total_samples_pre += std::max(1, sc->light_samples[l]);
+    const uint64_t pixels64 = uint64_t(P.n_owned_tiles) * 256;
+    int batch = (S.has_glass != 0) ? 1 : std::max(1, std::min(prm->n_passes, 4));
+    while (batch > 1 && pixels64 * uint64_t(batch) * uint64_t(std::max(total_samples_pre, 1)) > 100000000ull) --batch;   // NEE records per level (8 passes at a time measured no faster than 4)
+    P.kc = batch;
+    const uint64_t n_paths64 = pixels64 * uint64_t(batch);
     if (n_paths64 > 200000000ull) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: frame too large for one pass");
     P.n_paths = uint32_t(n_paths64);
     const uint32_t fw = uint32_t(S.crop_x1 - S.crop_x0), fh = uint32_t(S.crop_y1 - S.crop_y0);
@@ -1857,7 +1867,11 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     B.spill = sc->spill;
     P.direct_arrays = n_arrays;
     P.direct_jump = jump_dev;
-    for (int i = 0; i < prm->n_passes; ++i) {
+    for (int i = 0; i < prm->n_passes; i += batch) {
+        const int nb = std::min(batch, prm->n_passes - i);   // (the last launch may hold fewer passes: same buffers, fewer paths)
+        P.kc = nb;
+        P.n_paths = uint32_t(pixels64 * uint64_t(nb));
+        B.dir_paths = P.n_paths;
         P.direct_seed = uint32_t(6284 + 17 * (prm->first_pass + i));
         if (tree) {
             launch_direct_tree(S, P, B, film_dev, cfg);

@@ -54,9 +54,11 @@ DEV DPcg pcg_at(const DPcg &base, const unsigned long long *jump, int i) {
     r.inc = base.inc;
     return r;
 }
-DEV DPcg pixel_stream(const DScene &S, const PassDesc &P, int px, int py) {
+// pass: the pass inside this launch (a launch renders PassDesc::kc passes of the frame at once: path id = (pixel slot, pass);
+// P.direct_seed is the first one's seed, 6284 + 17 p for pass p)
+DEV DPcg pixel_stream(const DScene &S, const PassDesc &P, int px, int py, uint32_t pass) {
     const uint32_t rank = uint32_t(py - S.samp_y0) * uint32_t(S.samp_x1 - S.samp_x0) + uint32_t(px - S.samp_x0);
-    return pcg_seed((static_cast<unsigned long long>(P.direct_seed) << 32) + rank);
+    return pcg_seed((static_cast<unsigned long long>(P.direct_seed + 17u * pass) << 32) + rank);
 }
 
 DEV F3 area_light_L(const DLight &lt, F3 n, F3 w) {  // DiffuseAreaLight::L, lights/diffuse.h:56-58
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_direct_generate(DScene S, PassDesc P
         F3 o = F3{0, 0, 0}, d = F3{0, 0, 1};
         float tmax = 0;
         if (valid) {
-            DPcg r = pcg_at(pixel_stream(S, P, px, py), P.direct_jump, P.direct_arrays);
+            DPcg r = pcg_at(pixel_stream(S, P, px, py, k), P.direct_jump, P.direct_arrays);
             // GetCameraSample: pFilm = pixel + Get2D(), time = Get1D(), pLens = Get2D()
             const float u0 = pcg_float(r), u1 = pcg_float(r);
             (void)pcg_float(r);
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(kBlock, IILE_DIRECT_SHADE_WAVES) void k_direct_shad
             int px = 0, py = 0;
             uint32_t kk = 0;
             path_pixel(S, P, pid, &px, &py, &kk);
-            stream = pixel_stream(S, P, px, py);
+            stream = pixel_stream(S, P, px, py, kk);
             // isect.ComputeScatteringFunctions(ray, arena): the differentials of the camera ray at depth 0, of the reflected ray
             // (left by the vertex before, below) further on; computed for every hit when reflected rays carry them, else only
             // where a texture is looked up
@@ -425,7 +427,12 @@ __global__ __launch_bounds__(kBlock) void k_direct_miss(DScene S, PassBuffers B,
 // (directprogressiveintegrator.cpp:104-127), IisptFilmMonitor::add_n_samples (iisptfilmmonitor.cpp:47-72: doubles)
 __global__ __launch_bounds__(kBlock) void k_direct_fold(DScene S, PassDesc P, PassBuffers B, double *film_rgbw) {
     const int fw = S.crop_x1 - S.crop_x0;
-    for (uint32_t pid = blockIdx.x * kBlock + threadIdx.x; pid < P.n_paths; pid += gridDim.x * kBlock) {
+    // one thread per pixel slot; the launch's passes of that pixel are added to the film monitor one after the other, in pass
+    // order (add_n_samples runs once per pass in the reference: the order of the double additions is part of the result)
+    const uint32_t kc = uint32_t(P.kc);
+    for (uint32_t pt = blockIdx.x * kBlock + threadIdx.x; pt < P.n_paths / kc; pt += gridDim.x * kBlock)
+    for (uint32_t pass = 0; pass < kc; ++pass) {
+        const uint32_t pid = pt * kc + pass;
         int px = 0, py = 0;
         uint32_t k = 0;
         if (!(path_pixel(S, P, pid, &px, &py, &k) && px >= S.crop_x0 && px < S.crop_x1 && py >= S.crop_y0 && py < S.crop_y1)) continue;
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
         int px = 0, py = 0;
         uint32_t kk = 0;
         if (!(path_pixel(S, P, pid, &px, &py, &kk) && px >= S.crop_x0 && px < S.crop_x1 && py >= S.crop_y0 && py < S.crop_y1)) continue;
-        const DPcg stream = pixel_stream(S, P, px, py);
+        const DPcg stream = pixel_stream(S, P, px, py, kk);
         DPcg rng = pcg_at(stream, P.direct_jump, P.direct_arrays);  // behind the arrays StartPixel filled: the camera sample
         const float u0 = pcg_float(rng), u1 = pcg_float(rng);
         (void)pcg_float(rng);
@@ -825,7 +832,7 @@ void launch_direct_miss(const DScene &S, const PassBuffers &B, int depth, uint32
     hipLaunchKernelGGL(k_direct_miss, dim3(grid_blocks(max_rays, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, B, depth);
 }
 void launch_direct_fold(const DScene &S, const PassDesc &P, const PassBuffers &B, double *film_rgbw, const LaunchCfg &cfg) {
-    hipLaunchKernelGGL(k_direct_fold, dim3(grid_blocks(P.n_paths, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
+    hipLaunchKernelGGL(k_direct_fold, dim3(grid_blocks(P.n_paths / uint32_t(P.kc), cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
 }
 
 }  // namespace iile
