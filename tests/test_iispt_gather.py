@@ -166,12 +166,13 @@ def test_iispt_frame_end_to_end(binding):
     assert set(torch.unique(w2).tolist()) <= {0.0, 0.5, 1.0}
     assert abs(float(w2.mean()) / float(w1.mean()) - 2.0) < 0.02  # (a silhouette pixel may find a surface in one sweep only)
     # task-major staging (one probe pass + one network call per group of tasks) is the same frame: the same samples are
-    # recorded (weights exactly equal); values agree up to the network's batch-size dependent convolution algorithms
+    # recorded (weights exactly equal) and the values agree — the network's kernels do not depend on the batch (bit for bit:
+    # tests/test_iispt_nn.py); what is left is the film monitor adding a pixel's two sweeps in one order or the other
     batched = frame_mod.IisptFrame(binding, gpu, pipe)
     batched.run_batched(len(sweep) + (-(-96 // 30)) * (-(-80 // 30)), radius_start=4.0, max_probes=150)
     assert torch.equal(batched.film[..., 3], w2) and batched.stats == frame.stats
     scale = float(frame.film[..., :3].abs().max())
-    assert float((batched.film[..., :3] - frame.film[..., :3]).abs().max()) <= 2e-3 * scale
+    assert float((batched.film[..., :3] - frame.film[..., :3]).abs().max()) <= 1e-6 * scale
     # the direct pass and the merge (iispt.cpp:405-446): the direct monitor is the oracle's bit for bit, also when it is filled
     # in two calls; the frame's image is merge_into + to_intensity_film of the two monitors as the oracle computes it
     import oracle_binding

@@ -11,7 +11,7 @@ scene = b.HostScene(xres=1920, yres=1080, spp=1)
 gpu = b.GpuScene(scene)
 torch.manual_seed(0)
 dtype = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
-pipe = nn_mod.IisptPipeline(gpu, dtype=dtype)
+pipe = nn_mod.IisptPipeline(gpu, dtype=dtype, backend="torch")   # (round 4 timed the PyTorch / MIOpen network; the product path is backend="hip")
 rng = np.random.default_rng(1)
 n = 25058
 pos = rng.uniform((-150, -100, -130), (250, 150, 0), (n, 3)).astype(np.float32)

@@ -2,7 +2,8 @@
 (hemi points, probe pass, in-process network, per-pixel gather), the direct pass (16 passes of DirectProgressiveIntegrator) and
 the merge of the two film monitors (pbrt-v3-iile_amd/iispt_frame.py) — timed per stage.
 The network has random weights (none ship with the reference), so the image is meaningless; the data flow and the cost are real.
-usage: python tools/probe_bench.py [xres=1920] [yres=1080] [radius_start=10] [sweeps=1] [dtype=bf16|f32]
+usage: python tools/probe_bench.py [xres=1920] [yres=1080] [radius_start=10] [sweeps=1] [backend=hip|torch-f32|torch-bf16]
+(hip: the product path, iile_iispt_net_*; the torch backends run the PyTorch module through MIOpen, for comparison only)
 IILE_IISPT_BATCHED=0: task by task as the reference's runner; IILE_IISPT_TIMERS=1: seconds per stage (adds syncs)"""
 import importlib
 import json
@@ -23,14 +24,15 @@ xres = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 yres = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
 radius = float(sys.argv[3]) if len(sys.argv) > 3 else 10.0
 sweeps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-dtype = torch.float32 if (len(sys.argv) > 5 and sys.argv[5] == "f32") else torch.bfloat16
+backend = sys.argv[5] if len(sys.argv) > 5 else "hip"
+dtype = torch.bfloat16 if backend == "torch-bf16" else torch.float32
 b = ge._load_binding()
 scene = b.HostScene(xres=xres, yres=yres, spp=1)
 gpu = b.GpuScene(scene)
 nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
 frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
 torch.manual_seed(0)
-pipe = nn_mod.IisptPipeline(gpu, dtype=dtype)
+pipe = nn_mod.IisptPipeline(gpu, dtype=dtype, backend="hip" if backend == "hip" else "torch", binding=b)
 size = int(radius) * frame_mod.NUMBER_TILES
 tasks_per_sweep = -(-xres // size) * -(-yres // size)
 batched = os.environ.get("IILE_IISPT_BATCHED", "1") != "0"
@@ -68,7 +70,7 @@ print(json.dumps({"workload": f"IISPT frame (indirect pass + 16 direct passes + 
                   "tasks": st["tasks"], "hemi_points": st["hemi_points"], "probes": st["probes"], "pixels": st["pixels"],
                   "wall_s": round(wall, 3), "probes_per_s": round(st["probes"] / wall, 1), "mpixels_gathered_per_s": round(st["pixels"] / wall / 1e6, 3),
                   "order": "task-major stages (run_batched)" if batched else "task by task (run)", "stage_seconds": timers,
-                  "network_dtype": str(dtype).split(".")[-1], "pixels_with_a_sample": round(rec, 4),
+                  "network_backend": backend, "pixels_with_a_sample": round(rec, 4),
                   "indirect_image_mean": float(frame.indirect_image().mean()), "finite": bool(torch.isfinite(final).all()),
                   "direct_passes": frame_mod.DIRECT_SAMPLES, "direct_wall_s": round(wall_direct, 4),
                   "direct_msamples_per_s": round(frame_mod.DIRECT_SAMPLES * xres * yres / wall_direct / 1e6, 1), "merge_wall_s": round(wall_merge, 4),
