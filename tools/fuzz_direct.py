@@ -42,7 +42,7 @@ with tempfile.TemporaryDirectory() as td:
             print("seed", seed, "skipped:", str(e)[:100])
             continue
         gpu = b.GpuScene(scene)
-        passes, first_pass = int(rng.integers(1, 4)), int(rng.integers(0, 5))
+        passes, first_pass = int(rng.integers(1, 11)), int(rng.integers(0, 5))   # (four passes run per set of launches: 1 .. 10 crosses that)
         what = f'{kw["light"]} {kw["materials"]}{" textured" if "textures" in kw else ""} {kw["xres"]}x{kw["yres"]} passes {first_pass}+{passes}'
         try:
             ref = o.iispt_direct(scene, passes, first_pass=first_pass)

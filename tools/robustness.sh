@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 robustness + config-5 figures: randomised rooms / gather / builder sweeps, the 1080p x 1024 spp frame against the oracle
+# robustness + config-5 figures (rounds 4, 5): randomised rooms / gather / builder sweeps, the 1080p x 1024 spp frame against the oracle
 # (sixteen passes: the device film finish across passes), the IISPT frame in fp32 and bf16
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/robustness
@@ -11,5 +11,4 @@ timeout 600 python3 tools/fuzz_gather.py > $O/fuzz_gather.txt 2>&1; tail -2 $O/f
 timeout 600 python3 tools/fuzz_bvh.py > $O/fuzz_bvh.txt 2>&1; tail -2 $O/fuzz_bvh.txt
 timeout 1800 python3 tools/full_frame_parity.py $O/full_frame_parity_1024spp.json killeroo 1024 > $O/full_frame_1024.txt 2>&1; tail -3 $O/full_frame_1024.txt
 timeout 1200 python3 tools/full_frame_parity.py $O/full_frame_parity_boxroom_textured.json boxroom-textured 16 > $O/full_frame_tex.txt 2>&1; tail -3 $O/full_frame_tex.txt
-timeout 900 python3 tools/probe_bench.py 1920 1080 10 1 f32 > $O/iispt_frame_f32.json 2> $O/iispt_frame_f32.err; cat $O/iispt_frame_f32.json | cut -c1-600
-timeout 900 python3 tools/probe_bench.py 1920 1080 10 1 bf16 > $O/iispt_frame_bf16.json 2> $O/iispt_frame_bf16.err; cat $O/iispt_frame_bf16.json | cut -c1-600
+timeout 900 python3 tools/probe_bench.py 1920 1080 10 1 hip > $O/iispt_frame_hip.json 2> $O/iispt_frame_hip.err; cat $O/iispt_frame_hip.json | cut -c1-600
