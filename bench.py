@@ -314,6 +314,19 @@ def main_iispt(args):
     net_launches = sum(1 for n_, _, _ in stage_events[-1] if n_ == "network")
     flop = NET_FLOP_PER_PROBE * probes
     ach = flop / (net_ms * 1e-3) / 1e12
+    # memory-side bytes of a forward from the committed counter passes (tools/net_traffic.sh: FETCH_SIZE doubled + WRITE_SIZE of every
+    # network kernel at 8 192 probes, per probe) x this frame's probes
+    net_traffic, net_traffic_note = None, "no committed counter set (profiles/*_net_traffic.json)"
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_net_traffic.json")))[::-1]:
+        try:
+            tj = json.load(open(f))
+            net_traffic = int(tj["per_probe_bytes"] * probes)
+            net_traffic_note = (f"profiles/{os.path.basename(f)}: {tj['per_probe_bytes'] / 1e6:.2f} MB per probe (activations written once: 2.44 MB; read once: "
+                                f"2.88 MB; the rest is halo rows, tiles re-read per 64 output channels, weights) = "
+                                f"{net_traffic / (net_ms * 1e-3) / 1e9 / HBM_PEAK_GBS:.3f} of the 8 TB/s HBM peak at this run's network time")
+            break
+        except Exception:
+            pass
     # agreement of the timed network with the PyTorch module on the CPU, on a sample of the frame's own probes
     chk = {}
     with torch.no_grad():
@@ -348,7 +361,8 @@ def main_iispt(args):
             "kernel": "k_conv3x3 (the 14 3x3 convolutions of IISPTNet, csrc/device/iispt_net.hip; with the two layout kernels of a forward)",
             "bound": "mfma",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": net_traffic,
+            "traffic_note": net_traffic_note,
             "algorithmic_flop_per_unit": NET_FLOP_PER_PROBE, "units_per_step": probes,
             "algorithmic_note": "2 k^2 C_in C_out H W over the network's 15 convolutions = 0.990 GFLOP per probe (fp32 multiply-adds of the reference's "
                                 "module); `achieved` = that x probes / the network's HIP-event time",
