@@ -99,6 +99,8 @@ int iile_device_select(int32_t device);
 int iile_device_alloc(uint64_t bytes, void **out_dev);
 void iile_device_free(void *dev);
 int iile_device_download(void *dst_host, const void *src_dev, uint64_t bytes, void *stream); /* waits for `stream` */
+int iile_device_upload(void *dst_dev, const void *src_host, uint64_t bytes, void *stream);   /* waits for `stream` */
+int iile_device_zero(void *dev, uint64_t bytes, void *stream);                               /* queued on `stream` */
 
 int iile_scene_create(const iile_scene_desc *desc, iile_scene **out);
 void iile_scene_destroy(iile_scene *scene);
@@ -169,8 +171,8 @@ int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, c
  * per level, at most 64 light samples per vertex. Reflected rays carry differentials in textured scenes
  * (directprogressiveintegrator.cpp:165-184). Scenes with glass — where Li branches into a reflection and a transmission recursion
  * at every glass vertex (allowMultipleLobes = false: glass.cpp:62-90) and the sampler's stream follows the recursion's depth-first
- * order — are rendered by one thread per pixel walking its tree (k_direct_tree), the others by the wavefront. Not built,
- * IILE_ERR_UNSUPPORTED: image textures combined with a specular SPHERE (its dndu / dndv). */
+ * order — are rendered by one thread per pixel walking its tree (k_direct_tree), the others by the wavefront. Specular spheres
+ * in textured scenes carry Sphere::Intersect's dndu / dndv (src/shapes/sphere.cpp:122-143) into the reflected differentials. */
 typedef struct iile_direct_params {
     int32_t n_passes, first_pass;
     int32_t accumulate;
@@ -201,6 +203,17 @@ int iile_iispt_gather(iile_scene *scene, const iile_iispt_task *task, const uint
 int iile_iispt_hemi_points_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, uint8_t *valid, float *pos3, float *dir3);
 int iile_iispt_gather_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, const uint8_t *valid, const float *pos3,
                             const float *dir3, const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device);
+/* The two film monitors of IISPTIntegrator::render_normal_2 (src/integrators/iispt.cpp:357-446), kept in HBM as {r, g, b, weight}
+ * double sums per film pixel (IisptPixel, src/integrators/iisptpixel.h):
+ *   iile_iispt_film_add    IisptFilmMonitor::add_n_samples (src/integrators/iisptfilmmonitor.cpp:47-72) for every pixel of n_tasks
+ *                          tasks in one launch: out_rgbw_dev is what iile_iispt_gather_batch left for these tasks (device memory),
+ *                          film_rgbw_dev the film_w x film_h monitor. The tasks of one call must not overlap (tasks of one sweep of
+ *                          IisptScheduleMonitor never do). Waits for `stream`'s earlier work, then queues its kernel there.
+ *   iile_iispt_film_merge  film_monitor_direct->merge_into(film_monitor_indirect) + to_intensity_film (:231-275, :158-196): both
+ *                          monitors normalised (sums over the weight where it is positive), added, as float RGB. Queued on `stream`. */
+int iile_iispt_film_add(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, const float *out_rgbw_dev, double *film_rgbw_dev,
+                        int32_t film_w, int32_t film_h, void *stream);
+int iile_iispt_film_merge(const double *direct_rgbw_dev, const double *indirect_rgbw_dev, int64_t n_pixels, float *rgb_dev, void *stream);
 /* The IISPT network itself: `IISPTNet.forward` of ml/iispt_net.py:8-109 in eval mode, as the child process
  * of ml/main_stdio_net.py:44-106 runs it once per probe (`net(torch_img)`, one CPU thread, fp32) — here over a whole batch
  * of probes with hand-written gfx950 kernels (csrc/device/iispt_net.hip: implicit-GEMM 3 x 3 convolutions on the bf16 matrix
@@ -224,6 +237,9 @@ typedef struct iile_iispt_net_weights {
     float bn_eps;   /* BatchNorm2d's eps (1e-5) */
 } iile_iispt_net_weights;
 int iile_iispt_net_create(const iile_iispt_net_weights *weights, iile_iispt_net **out);
+/* The same from a flat file (hosts without Python; binding.save_net_weights writes it from a checkpoint's state_dict): the 8 bytes
+ * "IILENET1", BatchNorm2d's eps, then the float32 tensors in the order above, convolutions {weight, bias} first. */
+int iile_iispt_net_load(const char *path, iile_iispt_net **out);
 int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_dev, int32_t n, int32_t max_batch, void *stream,
                            float *layer_out_dev, int32_t layer);
 /* The network with the two transforms IisptRenderRunner applies around it, as one call over a batch of rendered probes:
@@ -231,9 +247,11 @@ int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_
  * intensity_dev / normals_dev: (n, 32, 32, 3), distance_dev: (n, 32, 32), raster order as iile_render_probes leaves them (device
  * memory); pred_dev: (n, 32, 32, 3) predicted intensity, rescaled per channel to the rendered probe's mean — film_rows != 0: rows in
  * ImageFilm order (row 0 = the top scanline: what iile_iispt_gather reads as nn_films), else raster order. Means are double sums,
- * log(1.0 + v) / exp(v) - 1.0 are evaluated in double as the reference does, everything else in float. Queued on `stream`. */
+ * log(1.0 + v) / exp(v) - 1.0 are evaluated in double as the reference does, everything else in float. slot_of_probe_dev: null, or
+ * n indices (device memory) — probe i's prediction is then written to image slot_of_probe_dev[i] of pred_dev instead of image i (the
+ * integrator renders probes for the valid hemi points only and hands the gather one image per hemi point). Queued on `stream`. */
 int iile_iispt_net_predict(iile_iispt_net *net, const float *intensity_dev, const float *normals_dev, const float *distance_dev,
-                           float *pred_dev, int32_t n, int32_t film_rows, int32_t max_batch, void *stream);
+                           float *pred_dev, const int32_t *slot_of_probe_dev, int32_t n, int32_t film_rows, int32_t max_batch, void *stream);
 void iile_iispt_net_destroy(iile_iispt_net *net);
 /* BVHAccel's HLBVH build (src/accelerators/bvh.cpp:404-472: Morton codes :413-427, RadixSort :133-181, treelets and
  * emitLBVH :434-452, 555-618, buildUpperSAH :474-553) and flattenBVHTree (:640-658) — SURVEY.md §8 f4. bounds6: per

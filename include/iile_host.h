@@ -60,7 +60,10 @@ typedef struct iile_host_scene_info {
     int32_t n_materials, n_lights;
     int32_t xres, yres, spp, max_depth;
     int32_t probe_hemi_size; /* side of the IISPT probe films iile_render_probes writes (iile_scene_desc::probe) */
+    int32_t integrator;      /* IILE_INTEGRATOR_*: the file's Integrator directive ("path" when it has none is pbrt's default) */
 } iile_host_scene_info;
+#define IILE_INTEGRATOR_PATH 0
+#define IILE_INTEGRATOR_IISPT 1
 
 /* Parse a .pbrt file (plus its Includes), tessellate, build the BVH and the
  * sampler tables. Stands where ParseFile + pbrtWorldEnd's MakeScene /

@@ -34,7 +34,7 @@ SPLITS = {None: 0, "": 0, "sah": 1, "hlbvh": 2, "middle": 3, "equal": 4}  # IILE
 
 class HostSceneInfo(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("n_prims n_triangles n_spheres n_meshes n_nodes n_interior_nodes "
-                                      "n_leaf_nodes n_materials n_lights xres yres spp max_depth probe_hemi_size").split()]
+                                      "n_leaf_nodes n_materials n_lights xres yres spp max_depth probe_hemi_size integrator").split()]
 
 
 class FilmDesc(ctypes.Structure):
@@ -132,9 +132,10 @@ class DirectParams(ctypes.Structure):  # iile_direct_params
 GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iile_scene_destroy", "iile_render",
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
-               "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download",
+               "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download", "iile_device_upload", "iile_device_zero",
+               "iile_iispt_film_add", "iile_iispt_film_merge",
                "iile_iispt_hemi_points", "iile_iispt_gather", "iile_iispt_hemi_points_batch", "iile_iispt_gather_batch", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct",
-               "iile_wide_ref_shift", "iile_render_status", "iile_test_patch_capacity", "iile_iispt_net_create", "iile_iispt_net_forward", "iile_iispt_net_predict", "iile_iispt_net_destroy"]
+               "iile_wide_ref_shift", "iile_render_status", "iile_test_patch_capacity", "iile_iispt_net_create", "iile_iispt_net_load", "iile_iispt_net_forward", "iile_iispt_net_predict", "iile_iispt_net_destroy"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size", "iile_dist_ranks_seen",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_rendezvous_file_token", "iile_dist_rendezvous_done", "iile_dist_all_ok",
@@ -253,8 +254,13 @@ def gpu_lib():
         lib.iile_render_status.argtypes = [c_vp, c_vp]
         lib.iile_test_patch_capacity.argtypes = [c_vp, c_u32]
         lib.iile_iispt_net_create.argtypes = [ctypes.POINTER(NetWeights), ctypes.POINTER(c_vp)]
+        lib.iile_iispt_net_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(c_vp)]
         lib.iile_iispt_net_forward.argtypes = [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32]
-        lib.iile_iispt_net_predict.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]
+        lib.iile_iispt_net_predict.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]
+        lib.iile_iispt_film_add.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]
+        lib.iile_iispt_film_merge.argtypes = [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp]
+        lib.iile_device_upload.argtypes = [c_vp, c_vp, ctypes.c_uint64, c_vp]
+        lib.iile_device_zero.argtypes = [c_vp, ctypes.c_uint64, c_vp]
         lib.iile_iispt_net_destroy.argtypes = [c_vp]
         lib.iile_iispt_net_destroy.restype = None
         _gpu = lib
@@ -629,6 +635,14 @@ class GpuScene:
                     "iile_iispt_gather_batch")
         return out
 
+    def iispt_film_add(self, tasks, out_device_ptr, film_device_ptr, stream=None):
+        """iile_iispt_film_add: IisptFilmMonitor::add_n_samples for every pixel of the (non-overlapping) tasks, whose gathered
+        {f_beta * L, weight} lie at out_device_ptr, into the (h, w, 4) float64 monitor at film_device_ptr."""
+        h, w = self.host.film_shape
+        arr = (IisptTask * len(tasks))(*tasks)
+        self._check(gpu_lib().iile_iispt_film_add(self._s, arr, len(tasks), c_vp(int(out_device_ptr)), c_vp(int(film_device_ptr)), w, h,
+                                                  c_vp(stream) if stream else None), "iile_iispt_film_add")
+
     def render_direct(self, n_passes, first_pass=0, film_device_ptr=None, accumulate=False, stream=None):
         """The IISPT direct pass (iile_render_direct): the direct film monitor {sum r, g, b, weight} as (h, w, 4) float64, or
         accumulated into device memory at film_device_ptr (returns None)."""
@@ -673,13 +687,43 @@ NET_CONVS = ("encoder0.0", "encoder0.2", "encoder1.1", "encoder1.4", "encoder2.1
 NET_BNS = ("encoder1.3", "encoder2.3", "encoder3.3", "decoder0.2", "decoder1.2")
 
 
+def save_net_weights(state_dict, path, bn_eps=1e-5):
+    """The flat file iile_iispt_net_load reads (and `iile_pbrt --iisptNet=`): "IILENET1", eps, the tensors of a state_dict of
+    IISPTNet in iile_iispt_net_weights' order, float32."""
+    def arr(name):
+        t = state_dict[name]
+        return np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+    with open(path, "wb") as f:
+        f.write(b"IILENET1")
+        f.write(np.float32(bn_eps).tobytes())
+        for k in NET_CONVS:
+            f.write(arr(k + ".weight").tobytes())
+            f.write(arr(k + ".bias").tobytes())
+        for k in NET_BNS:
+            for q in ("weight", "bias", "running_mean", "running_var"):
+                f.write(arr(k + "." + q).tobytes())
+
+
+def iispt_film_merge(direct_ptr, indirect_ptr, n_pixels, rgb_ptr, stream=None):
+    """iile_iispt_film_merge: the two monitors normalised and added -> float RGB (device pointers)."""
+    lib = gpu_lib()
+    rc = lib.iile_iispt_film_merge(c_vp(int(direct_ptr)), c_vp(int(indirect_ptr)), int(n_pixels), c_vp(int(rgb_ptr)), c_vp(stream) if stream else None)
+    if rc != 0:
+        raise RuntimeError(f"iile_iispt_film_merge failed ({rc}): {lib.iile_last_error().decode()}")
+
+
 class GpuNet:
     """The IISPT network on the device (iile_iispt_net_*): built from a state_dict with the reference's entry names
     (numpy arrays or torch tensors), run on device pointers."""
 
-    def __init__(self, state_dict, bn_eps=1e-5):
+    def __init__(self, state_dict=None, bn_eps=1e-5, path=None):
         self._lib = gpu_lib()
         self._h = c_vp()
+        if path is not None:   # an IILENET1 file (save_net_weights)
+            rc = self._lib.iile_iispt_net_load(os.fsencode(path), ctypes.byref(self._h))
+            if rc != 0:
+                raise RuntimeError(f"iile_iispt_net_load failed ({rc}): {self._lib.iile_last_error().decode()}")
+            return
         keep = []
 
         def arr(name):
@@ -705,10 +749,12 @@ class GpuNet:
         if rc != 0:
             raise RuntimeError(f"iile_iispt_net_forward failed ({rc}): {self._lib.iile_last_error().decode()}")
 
-    def predict(self, intensity_ptr, normals_ptr, distance_ptr, pred_ptr, n, film_rows=False, max_batch=0, stream=None):
+    def predict(self, intensity_ptr, normals_ptr, distance_ptr, pred_ptr, n, film_rows=False, max_batch=0, stream=None, slot_ptr=None):
         """normalizeMapsDownstream -> network -> transformMapsUpstream over n rendered probes (device pointers; raster order in,
-        (n, 32, 32, 3) out: ImageFilm row order when film_rows, else raster)."""
-        rc = self._lib.iile_iispt_net_predict(self._h, intensity_ptr, normals_ptr, distance_ptr, pred_ptr, int(n), int(bool(film_rows)), int(max_batch), stream)
+        (n, 32, 32, 3) out: ImageFilm row order when film_rows, else raster). slot_ptr: n int32 on the device — probe i's image goes to
+        image slot[i] of pred_ptr."""
+        rc = self._lib.iile_iispt_net_predict(self._h, intensity_ptr, normals_ptr, distance_ptr, pred_ptr, slot_ptr, int(n), int(bool(film_rows)),
+                                              int(max_batch), stream)
         if rc != 0:
             raise RuntimeError(f"iile_iispt_net_predict failed ({rc}): {self._lib.iile_last_error().decode()}")
 

@@ -2,6 +2,13 @@
 //
 //   iile_pbrt scene.pbrt [--outfile out.exr|out.pfm] [--xres N --yres N --spp N --maxdepth N] [--stats] [--gpus N]
 //             [--gpurank R/N --rendezvous FILE [--job TOKEN]]
+//             [--integrator path|iispt] [--iisptNet=FILE] [--iileIndirect=TASKS] [--iileDirect=SAMPLES] [--iispt_hemi_size=32]
+//
+// Which integrator renders the frame is the scene file's Integrator line, as in MakeIntegrator (src/core/api.cpp:1720-1750): "path" ->
+// GpuPathIntegrator, "iispt" -> GpuIisptIntegrator (csrc/host/gpu_iispt_integrator.h; --iileIndirect= / --iileDirect= /
+// --iispt_hemi_size= keep the reference's spellings and defaults, src/main/pbrt.cpp:167-178). The reference starts one Python child per
+// thread for the network (IISPT_STDIO_NET_PY_PATH); here --iisptNet=FILE (or $IILE_IISPT_NET) names the weights, an IILENET1 file as
+// binding.save_net_weights writes from a checkpoint. --integrator overrides the file's line. The IISPT frame is a one-device job.
 //
 // One process, the whole node (default): with several GPUs visible the frame's tiles are dealt over all of them, one host
 // thread per device, and merged by one RCCL reduction — `pbrt scene.pbrt` needs no launcher, as the reference's one Render()
@@ -22,7 +29,7 @@
 #include <cstring>
 #include <memory>
 
-#include "../host/gpu_integrator.h"
+#include "../host/gpu_iispt_integrator.h"
 
 int main(int argc, char **argv) {
     std::string scene_file, out;  // --outfile, else the scene's Film "filename" (as pbrt: src/main/pbrt.cpp:137, film.cpp:262)
@@ -34,6 +41,9 @@ int main(int argc, char **argv) {
     bool ranked = false;  // --gpurank given: render through the communicator branch, also for N = 1
     unsigned long long job_token = 0;
     std::string rendezvous;
+    iile::IisptOptions iispt;
+    int integrator_choice = -1;   // --integrator: IILE_INTEGRATOR_*; -1: the scene file's
+    if (const char *e = getenv("IILE_IISPT_NET")) iispt.net_file = e;
     for (int i = 1; i < argc; ++i) {
         auto arg_int = [&](int &dst) {
             if (i + 1 < argc) dst = atoi(argv[++i]);
@@ -55,6 +65,26 @@ int main(int argc, char **argv) {
                   !strcmp(argv[i], "--minloglevel") || !strcmp(argv[i], "-minloglevel") || !strcmp(argv[i], "--v") || !strcmp(argv[i], "-v")) &&
                  i + 1 < argc)
             ++i;
+        else if (!strncmp(argv[i], "--iileIndirect=", 15))
+            iispt.indirect_tasks = atoi(argv[i] + 15);
+        else if (!strncmp(argv[i], "--iileDirect=", 13))
+            iispt.direct_samples = atoi(argv[i] + 13);
+        else if (!strncmp(argv[i], "--iispt_hemi_size=", 18))
+            iispt.hemi_size = atoi(argv[i] + 18);
+        else if (!strncmp(argv[i], "--iisptNet=", 11))
+            iispt.net_file = argv[i] + 11;
+        else if (!strncmp(argv[i], "--iisptIndirectOut=", 19))
+            iispt.indirect_out = argv[i] + 19;
+        else if (!strncmp(argv[i], "--iisptDirectOut=", 17))
+            iispt.direct_out = argv[i] + 17;
+        else if (!strcmp(argv[i], "--integrator") && i + 1 < argc) {
+            const char *in = argv[++i];
+            if (strcmp(in, "path") && strcmp(in, "iispt")) {
+                fprintf(stderr, "iile_pbrt: --integrator wants path or iispt\n");
+                return 1;
+            }
+            integrator_choice = !strcmp(in, "iispt") ? IILE_INTEGRATOR_IISPT : IILE_INTEGRATOR_PATH;
+        }
         else if (!strcmp(argv[i], "--xres"))
             arg_int(ps.xresolution);
         else if (!strcmp(argv[i], "--yres"))
@@ -104,7 +134,8 @@ int main(int argc, char **argv) {
         else if (argv[i][0] == '-') {
             fprintf(stderr, "usage: iile_pbrt scene.pbrt [--outfile f.exr|f.pfm] [--quick] [--quiet] [--nthreads N] [--xres N] [--yres N] [--spp N] "
                             "[--maxdepth N] [--stats] [--gpus N] [--sampler halton|sobol] [--splitmethod sah|hlbvh|middle|equal] [--bvh-device] "
-                            "[--gpurank R/N --rendezvous FILE [--job TOKEN]]\n");
+                            "[--gpurank R/N --rendezvous FILE [--job TOKEN]] [--integrator path|iispt] [--iisptNet=FILE] [--iileIndirect=TASKS] "
+                            "[--iileDirect=SAMPLES] [--iispt_hemi_size=32] [--iisptIndirectOut=FILE] [--iisptDirectOut=FILE]\n");
             return 1;
         } else
             scene_file = argv[i];
@@ -139,6 +170,20 @@ int main(int argc, char **argv) {
     }
     iile::Scene scene(scene_file, ps);
     if (out.empty()) out = scene.ok() ? scene.film_filename() : std::string("pbrt.exr");
+    if (integrator_choice < 0) integrator_choice = scene.ok() ? scene.integrator() : IILE_INTEGRATOR_PATH;
+    if (integrator_choice == IILE_INTEGRATOR_IISPT) {
+        if (ranked || (gpus_given && gpus != 1)) {
+            fprintf(stderr, "iile_pbrt: the IISPT frame runs on one device (its tasks share two film monitors and one network)\n");
+            if (comm) iile_dist_destroy(comm);
+            return 1;
+        }
+        std::unique_ptr<iile::GpuIisptIntegrator> ii(iile::CreateGpuIisptIntegrator(ps, out, iispt));
+        if (!ii->Render(scene)) return 1;
+        if (!quiet)
+            printf("IISPT: %d tasks, %lld hemi points, %lld probes, %lld pixels gathered, %d direct passes -> %s\n", ii->stats.tasks, ii->stats.hemi_points,
+                   ii->stats.probes, ii->stats.pixels, iispt.direct_samples, out.c_str());
+        return 0;
+    }
     std::unique_ptr<iile::GpuPathIntegrator> integrator(iile::CreateGpuPathIntegrator(ps, out, 0, 1, stats, comm));
     if (!ranked) integrator->UseDevices(gpus_given ? gpus : 0);
     const bool ok = integrator->Render(scene);

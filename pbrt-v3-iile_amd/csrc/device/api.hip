@@ -97,6 +97,8 @@ struct iile_scene {
     // the exact film finish on the device (kernels.hip): hit / entry records and the hash table, allocated at the first render
     PatchDev patch{};
     void *patch_block = nullptr;
+    void *film_add_buf = nullptr;        // iile_iispt_film_add's task table (rectangles, first pixels)
+    size_t film_add_cap = 0;
     uint32_t patch_cap_override = 0;     // iile_test_patch_capacity: hits / entries capacity forced by a test
     bool overflow_unchecked = false;     // an asynchronous render left patch.counters[2] unread
     hipStream_t overflow_stream = nullptr;
@@ -537,6 +539,19 @@ int iile_device_download(void *dst_host, const void *src_dev, uint64_t bytes, vo
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemcpyAsync(dst_host, src_dev, size_t(bytes), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return IILE_OK;
+}
+
+int iile_device_upload(void *dst_dev, const void *src_host, uint64_t bytes, void *stream) {
+    if (!dst_dev || !src_host) return fail(IILE_ERR_ARG, "iile_device_upload: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, size_t(bytes), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // (the host buffer may be reused on return)
+    return IILE_OK;
+}
+int iile_device_zero(void *dev, uint64_t bytes, void *stream) {
+    if (!dev) return fail(IILE_ERR_ARG, "iile_device_zero: null argument");
+    HIP_TRY(hipMemsetAsync(dev, 0, size_t(bytes), static_cast<hipStream_t>(stream)));
     return IILE_OK;
 }
 
@@ -1139,6 +1154,7 @@ void iile_scene_destroy(iile_scene *sc) {
     if (sc->film_block) (void)hipFree(sc->film_block);
     if (sc->d_tile_tables) (void)hipFree(sc->d_tile_tables);
     if (sc->patch_block) (void)hipFree(sc->patch_block);
+    if (sc->film_add_buf) (void)hipFree(sc->film_add_buf);
     if (sc->scratch) (void)hipFree(sc->scratch);
     if (sc->wide_block) (void)hipFree(sc->wide_block);
     if (sc->flag_host) (void)hipHostFree(sc->flag_host);
@@ -2304,6 +2320,56 @@ int iile_iispt_gather_batch(iile_scene *sc, const iile_iispt_task *tasks, int32_
     }
     return IILE_OK;
 }
+int iile_iispt_film_add(iile_scene *sc, const iile_iispt_task *tasks, int32_t n_tasks, const float *out_rgbw_dev, double *film_rgbw_dev,
+                        int32_t film_w, int32_t film_h, void *stream) {
+    if (!sc || !tasks || n_tasks < 1 || !out_rgbw_dev || !film_rgbw_dev || film_w < 1 || film_h < 1)
+        return fail(IILE_ERR_ARG, "iile_iispt_film_add: bad argument");
+    if (n_tasks > 65535) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt_film_add: more than 65535 tasks in one call");
+    std::vector<int4> rects(static_cast<size_t>(n_tasks));
+    std::vector<uint32_t> first(static_cast<size_t>(n_tasks));
+    uint64_t at = 0;
+    int max_pixels = 1;
+    for (int k = 0; k < n_tasks; ++k) {
+        const iile_iispt_task &t = tasks[k];
+        if (t.x0 < 0 || t.y0 < 0 || t.x1 > film_w || t.y1 > film_h || t.x1 <= t.x0 || t.y1 <= t.y0)
+            return fail(IILE_ERR_ARG, "iile_iispt_film_add: a task lies outside the film");
+        rects[size_t(k)] = make_int4(t.x0, t.y0, t.x1, t.y1);
+        first[size_t(k)] = uint32_t(at);
+        const uint64_t n = uint64_t(t.x1 - t.x0) * uint64_t(t.y1 - t.y0);
+        at += n;
+        max_pixels = std::max<int>(max_pixels, int(std::min<uint64_t>(n, 1u << 30)));
+    }
+    if (at >= 0xffffffffull) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt_film_add: more than 2^32 pixels in one call");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = size_t(n_tasks) * (sizeof(int4) + sizeof(uint32_t));
+    if (bytes > sc->film_add_cap) {   // a table of its own (the scene's shared scratch may still be read by the gather's kernels)
+        HIP_TRY(hipStreamSynchronize(s));
+        if (sc->film_add_buf) HIP_TRY(hipFree(sc->film_add_buf));
+        sc->film_add_buf = nullptr;
+        sc->film_add_cap = 0;
+        HIP_TRY(hipMalloc(&sc->film_add_buf, 2 * bytes));
+        sc->film_add_cap = 2 * bytes;
+    }
+    int4 *d_rects = static_cast<int4 *>(sc->film_add_buf);
+    uint32_t *d_first = reinterpret_cast<uint32_t *>(d_rects + n_tasks);
+    HIP_TRY(hipMemcpyAsync(d_rects, rects.data(), rects.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // (the vectors die with this call; the kernels before have to finish anyway)
+    launch_iispt_film_add(d_rects, d_first, n_tasks, max_pixels, reinterpret_cast<const float4 *>(out_rgbw_dev), film_rgbw_dev, film_w, s);
+    HIP_TRY(hipGetLastError());
+    return IILE_OK;
+}
+
+int iile_iispt_film_merge(const double *direct_rgbw_dev, const double *indirect_rgbw_dev, int64_t n_pixels, float *rgb_dev, void *stream) {
+    if (!direct_rgbw_dev || !indirect_rgbw_dev || !rgb_dev || n_pixels < 0) return fail(IILE_ERR_ARG, "iile_iispt_film_merge: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_pixels == 0) return IILE_OK;
+    launch_iispt_film_merge(direct_rgbw_dev, indirect_rgbw_dev, rgb_dev, (long long)n_pixels, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return IILE_OK;
+}
+
 int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *valid, const float *pos3, const float *dir3, const float *nn_films,
                       int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
     return iile_iispt_gather_batch(sc, t, 1, valid, pos3, dir3, nn_films, nn_on_device, out_rgbw, out_on_device);

@@ -452,4 +452,49 @@ void launch_iispt_gather(const DScene &S, const IisptJob *jobs, int n_jobs, int 
     hipLaunchKernelGGL(k_iispt_gather, job_grid(max_pixels, n_jobs, cfg), dim3(kIisptBlock), 0, cfg.stream, S, jobs, jac);
 }
 
+// IisptFilmMonitor::add_n_samples (src/integrators/iisptfilmmonitor.cpp:47-72) for every pixel of every task of a batch: the
+// gather's {f_beta * L, weight} per task pixel (task after task, row-major inside a task) added to the monitor's double sums.
+// rects[t] = {x0, y0, x1, y1} in film pixels, first[t] = the task's first pixel in `out`. The tasks must not overlap (one sweep).
+namespace {
+__global__ __launch_bounds__(256) void k_iispt_film_add(const int4 *rects, const uint32_t *first, const float4 *out, double *film, int film_w) {
+    const int4 r = rects[blockIdx.y];
+    const int w = r.z - r.x, n = w * (r.w - r.y);
+    const float4 *src = out + first[blockIdx.y];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        const float4 v = src[p];
+        double *d = film + 4 * (size_t(r.y + p / w) * film_w + size_t(r.x + p % w));
+        d[0] += double(v.x);
+        d[1] += double(v.y);
+        d[2] += double(v.z);
+        d[3] += double(v.w);
+    }
+}
+// IisptFilmMonitor::merge_into + to_intensity_film (iisptfilmmonitor.cpp:231-275, iisptpixel.h): both monitors normalised
+// (sums over the weight where it is positive), added, as float RGB
+__global__ __launch_bounds__(256) void k_iispt_film_merge(const double *a, const double *b, float *rgb, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double pa[3] = {a[4 * i], a[4 * i + 1], a[4 * i + 2]}, pb[3] = {b[4 * i], b[4 * i + 1], b[4 * i + 2]};
+    const double wa = a[4 * i + 3], wb = b[4 * i + 3];
+    if (wa > 0.0) {
+        pa[0] /= wa;
+        pa[1] /= wa;
+        pa[2] /= wa;
+    }
+    if (wb > 0.0) {
+        pb[0] /= wb;
+        pb[1] /= wb;
+        pb[2] /= wb;
+    }
+    for (int c = 0; c < 3; ++c) rgb[3 * i + c] = float(pa[c] + pb[c]);   // (the merged pixel's weight is 1)
+}
+}  // namespace
+void launch_iispt_film_add(const int4 *rects, const uint32_t *first, int n_tasks, int max_pixels, const float4 *out, double *film, int film_w, hipStream_t stream) {
+    const unsigned gx = unsigned(std::max(1, std::min((max_pixels + 255) / 256, 64)));
+    hipLaunchKernelGGL(k_iispt_film_add, dim3(gx, unsigned(n_tasks)), dim3(256), 0, stream, rects, first, out, film, film_w);
+}
+void launch_iispt_film_merge(const double *a, const double *b, float *rgb, long long n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_iispt_film_merge, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, a, b, rgb, n);
+}
+
 }  // namespace iile

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void k_net_normalize(const float *inten, const
 // channel rescaled so that its mean is the rendered probe's. pred: (n, 32, 32, 3); film_rows != 0: rows as the network emits
 // them (ImageFilm order: what iile_iispt_gather reads), else raster order (row h - 1 - y).
 __global__ __launch_bounds__(256) void k_net_predict_out(const float *in, const float *w /* [3][64] */, const float *bias, const float *chan_mean,
-                                                          float *pred, int film_rows, int n) {
+                                                          float *pred, const int32_t *slot, int film_rows, int n) {
     __shared__ double s_red[4];
     __shared__ float s_w[192];
     const int probe = blockIdx.x, t = threadIdx.x;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256) void k_net_predict_out(const float *in, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int px = t + 256 * k, y = px >> 5, x = px & 31;
-        float *o = pred + ((size_t(probe) * 32 + (film_rows ? y : 31 - y)) * 32 + x) * 3;
+        float *o = pred + ((size_t(slot ? slot[probe] : probe) * 32 + (film_rows ? y : 31 - y)) * 32 + x) * 3;
         o[0] = e[k][0] * mul[0];
         o[1] = e[k][1] * mul[1];
         o[2] = e[k][2] * mul[2];
@@ -748,6 +749,45 @@ int iile_iispt_net_create(const iile_iispt_net_weights *w, iile_iispt_net **out)
     return IILE_OK;
 }
 
+// The weights as a flat file (what a host without Python hands over; written by binding.save_net_weights from a state_dict of the
+// reference's ml/ training): "IILENET1", BatchNorm2d's eps, then float32 tensors in iile_iispt_net_weights' order — the 15
+// convolutions {weight, bias}, the 5 batch norms {weight, bias, running_mean, running_var} — in the checkpoint's own shapes.
+int iile_iispt_net_load(const char *path, iile_iispt_net **out) {
+    if (!path || !out) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_load: null argument");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return iile::api_fail(IILE_ERR_ARG, (std::string("iile_iispt_net_load: cannot open ") + path).c_str());
+    std::vector<std::vector<float>> t;
+    char magic[8];
+    float eps = 0.f;
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "IILENET1", 8) == 0 && std::fread(&eps, 4, 1, f) == 1;
+    auto tensor = [&](size_t n) {
+        t.emplace_back(n);
+        ok = ok && std::fread(t.back().data(), 4, n, f) == n;
+        return t.size() - 1;
+    };
+    size_t conv_w[15], conv_b[15], bn[5][4];
+    for (int l = 0; l < 15 && ok; ++l) {
+        const size_t cout = l < 14 ? size_t(kLayers[l].cout) : 3, cin = l < 14 ? size_t(kLayers[l].cin_real) : 64, k = l < 14 ? 9 : 1;
+        conv_w[l] = tensor(cout * cin * k);
+        conv_b[l] = tensor(cout);
+    }
+    for (int l = 0, b = 0; l < 14 && ok; ++l)
+        if (kBnOfLayer[l] >= 0) {
+            for (int q = 0; q < 4; ++q) bn[b][q] = tensor(size_t(kLayers[l].cout));
+            ++b;
+        }
+    char extra;
+    ok = ok && std::fread(&extra, 1, 1, f) == 0;   // exactly these tensors: a file of another architecture is refused
+    std::fclose(f);
+    if (!ok) return iile::api_fail(IILE_ERR_ARG, (std::string("iile_iispt_net_load: ") + path + " is not an IILENET1 file of IISPTNet's tensors").c_str());
+    iile_iispt_net_weights w = {};
+    for (int l = 0; l < 15; ++l) w.conv_weight[l] = t[conv_w[l]].data(), w.conv_bias[l] = t[conv_b[l]].data();
+    for (int b = 0; b < 5; ++b)
+        w.bn_weight[b] = t[bn[b][0]].data(), w.bn_bias[b] = t[bn[b][1]].data(), w.bn_mean[b] = t[bn[b][2]].data(), w.bn_var[b] = t[bn[b][3]].data();
+    w.bn_eps = eps;
+    return iile_iispt_net_create(&w, out);
+}
+
 void iile_iispt_net_destroy(iile_iispt_net *net) {
     if (!net) return;
     for (void *p : net->allocs) (void)hipFree(p);
@@ -810,7 +850,7 @@ int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_
 }
 
 int iile_iispt_net_predict(iile_iispt_net *net, const float *intensity_dev, const float *normals_dev, const float *distance_dev,
-                           float *pred_dev, int32_t n, int32_t film_rows, int32_t max_batch, void *stream) {
+                           float *pred_dev, const int32_t *slot_of_probe_dev, int32_t n, int32_t film_rows, int32_t max_batch, void *stream) {
     if (!net || !intensity_dev || !normals_dev || !distance_dev || !pred_dev || n < 0)
         return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_predict: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -829,7 +869,8 @@ int iile_iispt_net_predict(iile_iispt_net *net, const float *intensity_dev, cons
         rc = run_layers(net, nb, na, s, nullptr, 0, 0);
         if (rc) return rc;
         hipLaunchKernelGGL(k_net_predict_out, dim3(nb), dim3(256), 0, s, buffer_of(net, BUF_Q, na), net->w_out, net->b_out, means,
-                           pred_dev + size_t(first) * 3072, film_rows, nb);
+                           slot_of_probe_dev ? pred_dev : pred_dev + size_t(first) * 3072, slot_of_probe_dev ? slot_of_probe_dev + first : nullptr,
+                           film_rows, nb);
         NET_TRY(hipGetLastError());
     }
     return IILE_OK;

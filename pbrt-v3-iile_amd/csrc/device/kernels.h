@@ -187,6 +187,8 @@ struct IisptJob {
 void launch_iispt_first_hits(const DScene &S, const IisptJob *jobs, int n_jobs, int max_items, uint32_t *n_active, int *spill, const LaunchCfg &cfg);
 void launch_iispt_hemi_out(const DScene &S, const IisptJob *jobs, int n_jobs, int max_hemi, const LaunchCfg &cfg);
 void launch_iispt_gather(const DScene &S, const IisptJob *jobs, int n_jobs, int max_pixels, const float *jac, const LaunchCfg &cfg);
+void launch_iispt_film_add(const int4 *rects, const uint32_t *first, int n_tasks, int max_pixels, const float4 *out, double *film, int film_w, hipStream_t stream);
+void launch_iispt_film_merge(const double *a, const double *b, float *rgb, long long n, hipStream_t stream);
 
 // kernel-level entry points for parity tests
 void launch_trace(const DScene &S, int n, const float4 *ro, const float4 *rd, float4 *hits, int any_hit,

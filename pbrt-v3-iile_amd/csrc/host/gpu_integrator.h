@@ -59,6 +59,10 @@ class Scene {
     bool ok() const { return host_ != nullptr; }
     const iile_scene_desc *desc() const { return iile_host_scene_desc(host_); }
     const iile_film_desc *film() const { return iile_host_scene_film(host_); }
+    int integrator() const {   // IILE_INTEGRATOR_*: the file's Integrator line (renderOptions->IntegratorName)
+        iile_host_scene_info info = {};
+        return host_ && iile_host_scene_get_info(host_, &info) == 0 ? info.integrator : IILE_INTEGRATOR_PATH;
+    }
     std::string film_filename() const { return host_ ? iile_host_scene_film_filename(host_) : std::string(); }
 
   private:

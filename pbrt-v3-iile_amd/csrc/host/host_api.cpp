@@ -106,6 +106,7 @@ int iile_host_scene_get_info(const iile_host_scene *scene, iile_host_scene_info 
     info->spp = s.spp;
     info->max_depth = s.max_depth;
     info->probe_hemi_size = s.desc.probe.hemi_size;
+    info->integrator = s.integrator_iispt ? IILE_INTEGRATOR_IISPT : IILE_INTEGRATOR_PATH;
     return 0;
 }
 

@@ -58,6 +58,7 @@ struct HostScene {
     bool sample_at_pixel_center = false;
     std::string integrator_name = "path";
     int max_depth = 5;
+    bool integrator_iispt = false;   // Integrator "iispt" (MakeIntegrator, src/core/api.cpp:1738-1760)
     float rr_threshold = 1.f;
     std::string light_strategy = "spatial";
     std::string accel_split = "sah";

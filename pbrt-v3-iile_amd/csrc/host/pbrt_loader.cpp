@@ -473,7 +473,10 @@ class Loader {
             } else
                 return fail("Filter \"" + name + "\" unknown.");
         } else if (d == "Integrator") {  // integrators/path.cpp:214-231
-            if (name != "path") return fail("only Integrator \"path\" is supported, got " + name);
+            // "iispt" (CreateIISPTIntegrator, src/integrators/iispt.cpp:790-820) reads the same parameters; which of the two renders
+            // the frame is the host's choice (iile_host_scene_info::integrator)
+            if (name != "path" && name != "iispt") return fail("only Integrator \"path\" and \"iispt\" are supported, got " + name);
+            s.integrator_iispt = name == "iispt";
             s.max_depth = ps.one_int("maxdepth", 5);
             s.rr_threshold = ps.one_float("rrthreshold", 1.);
             s.light_strategy = ps.one_string("lightsamplestrategy", "spatial");

@@ -8,9 +8,12 @@ tiles of `radius` pixels, the radius shrinking by sqrt(0.795...) after every swe
 
     hemi points of the task  --iile_iispt_hemi_points-->  probe cameras
     probe pass               --iile_render_probes------>  intensity / normals / distance images (HBM)
-    normalizeMapsDownstream, IISPTNet, transformMapsUpstream (iispt_nn.py, PyTorch-ROCm, HBM)
+    normalizeMapsDownstream, IISPTNet, transformMapsUpstream  --iile_iispt_net_predict-->  one image per hemi point (HBM)
     per-pixel gather         --iile_iispt_gather------->  {f_beta * L, weight} per pixel (HBM)
-    IisptFilmMonitor::add_n_samples (src/integrators/iisptfilmmonitor.cpp:47-72): sums of RGB and weight per pixel, doubles
+    IisptFilmMonitor::add_n_samples (src/integrators/iisptfilmmonitor.cpp:47-72)  --iile_iispt_film_add-->  double sums per pixel
+
+The same frame from C++: csrc/host/gpu_iispt_integrator.h (`iile_pbrt --integrator iispt`); tests/test_iispt_host.py holds the two
+hosts' images against each other bit for bit.
 
 Nothing but the hemi points' positions (a few KB per task) crosses PCIe. No trained weights ship with the reference:
 with the default random-initialised network the numbers mean nothing; a checkpoint of the reference's ml/ training
@@ -24,13 +27,15 @@ import torch
 NUMBER_TILES = 10  # iisptschedulemonitor.h:33
 
 
-def schedule(bounds, n_tasks, radius_start=100.0, update_multiplier=math.sqrt(0.79541357)):
+def schedule(bounds, n_tasks, radius_start=100.0, update_multiplier=None):
     """IisptScheduleMonitor::next_task for task numbers 0 .. n_tasks - 1 over film bounds (x0, y0, x1, y1):
-    yields (x0, y0, x1, y1, tilesize)."""
+    yields (x0, y0, x1, y1, tilesize). current_radius and update_multiplier are floats there (iisptschedulemonitor.h:36-38)."""
     bx0, by0, bx1, by1 = bounds
-    radius, nextx, nexty = float(radius_start), bx0, by0
+    if update_multiplier is None:
+        update_multiplier = np.sqrt(np.float32(0.79541357))   # std::sqrt(0.79541357f)
+    radius, nextx, nexty = np.float32(radius_start), bx0, by0
     for _ in range(n_tasks):
-        eff = max(1, int(math.floor(radius)))
+        eff = max(1, int(math.floor(float(radius))))
         size = eff * NUMBER_TILES
         yield nextx, nexty, min(nextx + size, bx1), min(nexty + size, by1), eff
         nextx += size
@@ -39,7 +44,7 @@ def schedule(bounds, n_tasks, radius_start=100.0, update_multiplier=math.sqrt(0.
             nexty += size
         if nexty >= by1:
             nexty = by0
-            radius *= float(np.float32(update_multiplier))
+            radius = np.float32(radius * np.float32(update_multiplier))
 
 
 DIRECT_SAMPLES = 16  # PbrtOptions.iileDirectSamples, pbrt.h:178
@@ -108,7 +113,7 @@ class IisptFrame:
         while i < len(tasks):
             group, n_pts, n_pix = [], 0, 0
             # (a group never spans two sweeps: inside one sweep no two tasks share a pixel, which the one-launch film update needs)
-            while i < len(tasks) and (not group or (n_pts < max_probes and tasks[i][4] == group[0].tilesize)):
+            while i < len(tasks) and (not group or (n_pts < max_probes and tasks[i][:2] != (0, 0))):   # (a sweep starts at the film's corner)
                 x0, y0, x1, y1, ts = tasks[i]
                 task = self.b.IisptTask(x0, y0, x1, y1, ts, self.counter, self.rng_seed)
                 nx, ny = task.grid()
@@ -126,23 +131,16 @@ class IisptFrame:
             sel = valid == 1
             nn = torch.zeros((n_pts, 32, 32, 3), dtype=torch.float32, device="cuda")
             if sel.any():
-                pred, _, _, _ = self.pipe(pos[sel], dr[sel], film_rows=True)
-                nn[torch.from_numpy(sel).cuda()] = pred
+                # every probe's prediction lands in its hemi point's image (iile_iispt_net_predict's slot index)
+                slot = torch.from_numpy(np.flatnonzero(sel).astype(np.int32)).cuda()
+                self.pipe(pos[sel], dr[sel], film_rows=True, pred_out=nn, slot=slot)
             tick("probes_and_network", t0)
             t0 = time.time()
             out = torch.empty((n_pix, 4), dtype=torch.float32, device="cuda")
             self.gpu.iispt_gather_batch(group, valid, pos, dr, nn_device_ptr=nn.data_ptr(), out_device_ptr=out.data_ptr())
-            # add_n_samples for every pixel of every task of the group in ONE launch: the tasks' pixels (task after task, row-major
-            # inside a task) scattered to their film pixels — tasks of one sweep do not overlap, so no two rows meet
-            key = (w, tuple((t.x0, t.y0, t.x1, t.y1) for t in group))
-            cache = self.gpu.__dict__.setdefault("_iispt_scatter_cache", {})   # lives with the scene: the next frame has the same tasks
-            if key not in cache:
-                if len(cache) > 64:
-                    cache.clear()
-                idx = np.concatenate([(np.arange(t.y0, t.y1, dtype=np.int64)[:, None] * w + np.arange(t.x0, t.x1, dtype=np.int64)[None, :]).reshape(-1)
-                                      for t in group])
-                cache[key] = torch.from_numpy(idx).cuda()
-            self.film.view(-1, 4).index_add_(0, cache[key], out.double())
+            # add_n_samples for every pixel of every task of the group in ONE launch (iile_iispt_film_add: tasks of one sweep do not
+            # overlap, so no two of its threads meet on a film pixel)
+            self.gpu.iispt_film_add(group, out.data_ptr(), self.film.data_ptr())
             for task in group:
                 self.stats["tasks"] += 1
                 self.stats["pixels"] += (task.y1 - task.y0) * (task.x1 - task.x0)
@@ -177,4 +175,7 @@ class IisptFrame:
     def image(self):
         """The integrator's output (iispt.cpp:436-446): film_monitor_direct->merge_into(film_monitor_indirect) — both
         monitors normalised, added, weight 1 — through to_intensity_film: float RGB per pixel."""
-        return (self._normalised(self.film_direct) + self._normalised(self.film)).float()
+        h, w = self.gpu.host.film_shape
+        rgb = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+        self.b.iispt_film_merge(self.film_direct.data_ptr(), self.film.data_ptr(), h * w, rgb.data_ptr())
+        return rgb

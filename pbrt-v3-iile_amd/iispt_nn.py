@@ -192,21 +192,25 @@ class IisptPipeline:
         return self.net(x.to(self.dtype).contiguous(memory_format=torch.channels_last)).float()
 
     @torch.no_grad()
-    def __call__(self, pos, direction, batch=32768, film_rows=False):
+    def __call__(self, pos, direction, batch=32768, film_rows=False, pred_out=None, slot=None):
         """(n, 3) probe origins and directions -> (predicted intensity (n, h, h, 3), rendered intensity, normals,
         distance), all torch tensors on the device, raster order (film_rows: the prediction in the network's own row order,
         ImageFilm's, as iile_iispt_gather reads it). With the HIP network the two transforms run inside iile_iispt_net_predict;
-        the PyTorch backend keeps them as the tensor expressions above (tests hold the two against each other)."""
+        the PyTorch backend keeps them as the tensor expressions above (tests hold the two against each other).
+        pred_out (m, h, h, 3) with slot (n,) int32 on the device: probe i's prediction is written to pred_out[slot[i]] (the frame keeps
+        one image per hemi point, valid or not) and pred_out is returned in place of the (n, ...) tensor."""
         n = len(pos)
         inten = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         nrm = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         dist = torch.empty((n, HEMI, HEMI), dtype=torch.float32, device=self.device)
         self._timed("probe_pass", lambda: self.gpu.render_probes(pos, direction, device_out=(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr())))
-        pred = torch.empty_like(inten)
         if self.hip_net is not None:
+            pred = pred_out if pred_out is not None else torch.empty_like(inten)
             self._timed("network", lambda: self.hip_net.predict(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr(), pred.data_ptr(), n, film_rows=film_rows,
-                                                                max_batch=batch, stream=torch.cuda.current_stream().cuda_stream))
+                                                                max_batch=batch, stream=torch.cuda.current_stream().cuda_stream,
+                                                                slot_ptr=slot.data_ptr() if pred_out is not None else None))
             return pred, inten, nrm, dist
+        pred = torch.empty_like(inten)
         for first in range(0, n, batch):
             sl = slice(first, min(n, first + batch))
             x, means = self._timed("normalize", lambda: normalize_downstream(inten[sl], nrm[sl], dist[sl]))
@@ -214,4 +218,7 @@ class IisptPipeline:
             pred[sl] = self._timed("rescale", lambda: transform_upstream(y, means))
         if film_rows:
             pred = torch.flip(pred, dims=(1,))
+        if pred_out is not None:
+            pred_out[slot.long()] = pred
+            pred = pred_out
         return pred, inten, nrm, dist

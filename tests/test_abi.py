@@ -51,7 +51,7 @@ def test_struct_sizes_match_headers(binding):
     assert ctypes.sizeof(binding.FilmDesc) == 14 * 4
     assert ctypes.sizeof(binding.HostOverrides) == 6 * 4 + 8 + 8  # five ints, accel_split, the bvh_build hook, quick_render (+ padding)
     assert ctypes.sizeof(binding.BvhBuildStats) == 7 * 4 + 4 * 4 and binding.BVH_NODE.itemsize == 32
-    assert ctypes.sizeof(binding.HostSceneInfo) == 14 * 4
+    assert ctypes.sizeof(binding.HostSceneInfo) == 15 * 4
     assert ctypes.sizeof(binding.RenderParams) == 8 * 4 + 8
     assert ctypes.sizeof(binding.GpuStats) == 10 * 8 + 8 * 8 + 6 * 8 + 4 * 4 + 2 * 8 + 4 * 8 + 4 * 8 + 8 + 8
 
