@@ -2091,15 +2091,17 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
         P.n_paths = uint32_t(uint64_t(nb) * slots_per_probe);
         rc = run_pass(sc, S, pr.max_depth, P, cfg, false);
         if (rc) return rc;
-        launch_film_store(S, P, sc->pb, sc->fb, 0, 1, cfg);
-        launch_film_gather(S, P, sc->fb, 1, cfg);
         const size_t px = size_t(nb) * per_pixels, off = size_t(first) * per_pixels;
-        if (outputs_on_device) {  // the images stay in HBM for whatever consumes them next (the network)
-            launch_probe_finish(S, P, sc->pb, sc->fb, nb, intensity_rgb + 3 * off, normals_xyz + 3 * off, distance + off, cfg);
-            HIP_TRY(hipGetLastError());
-        } else {
-            launch_probe_finish(S, P, sc->pb, sc->fb, nb, d_int, d_nrm, d_dist, cfg);
-            HIP_TRY(hipGetLastError());
+        // the images stay in HBM for whatever consumes them next (the network), or go through the batch's device block
+        float *o_int = outputs_on_device ? intensity_rgb + 3 * off : d_int, *o_nrm = outputs_on_device ? normals_xyz + 3 * off : d_nrm;
+        float *o_dist = outputs_on_device ? distance + off : d_dist;
+        if (!launch_probe_film(S, P, sc->pb, nb, o_int, o_nrm, o_dist, cfg)) {
+            launch_film_store(S, P, sc->pb, sc->fb, 0, 1, cfg);
+            launch_film_gather(S, P, sc->fb, 1, cfg);
+            launch_probe_finish(S, P, sc->pb, sc->fb, nb, o_int, o_nrm, o_dist, cfg);
+        }
+        HIP_TRY(hipGetLastError());
+        if (!outputs_on_device) {
             HIP_TRY(hipMemcpyAsync(intensity_rgb + 3 * off, d_int, px * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(normals_xyz + 3 * off, d_nrm, px * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(distance + off, d_dist, px * sizeof(float), hipMemcpyDeviceToHost, stream));

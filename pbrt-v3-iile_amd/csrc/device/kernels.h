@@ -148,6 +148,9 @@ void launch_film_accumulate(const DScene &S, const PassDesc &P, const PassBuffer
 void launch_film_store(const DScene &S, const PassDesc &P, const PassBuffers &B, const FilmBuffers &F, int k_begin, int n_samples,
                        const LaunchCfg &cfg);
 void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F, int n_samples, const LaunchCfg &cfg);
+// the probe pass's film store + gather + finish in one kernel; false (nothing launched): the probe film is too large for it
+bool launch_probe_film(const DScene &S, const PassDesc &P, const PassBuffers &B, int n_probes, float *intensity, float *normals, float *distance,
+                       const LaunchCfg &cfg);
 void launch_direct_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg);
 void launch_direct_shade(const DScene &S, const PassDesc &P, const PassBuffers &B, int depth, uint32_t max_rays, const LaunchCfg &cfg);
 void launch_direct_tree(const DScene &S, const PassDesc &P, const PassBuffers &B, double *film_rgbw, const LaunchCfg &cfg);

@@ -259,6 +259,90 @@ __global__ __launch_bounds__(kBlock) void k_probe_finish(DScene S, PassDesc P, P
     }
 }
 
+// One film pixel of the gather: the sum over the tiles whose FilmTile holds (x, y), in tile index order, of the samples
+// FilmTile::AddSample would have added to it, in pixel then sample order. rec1(qx, qy, row): the record {film position, radiance} of
+// sample pixel (qx, qy) when there is one sample per pixel; the several-samples form reads F directly.
+template <typename Rec1>
+DEV float4 film_gather_pixel(const DScene &S, const PassDesc &P, const FilmBuffers &F, const float *s_table, int x, int y, int n_samples, Rec1 rec1) {
+    const float rx = S.filter_rx, ry = S.filter_ry;
+    const float inv_rx = 1 / rx, inv_ry = 1 / ry;  // Filter::invRadius
+    // sample pixels that can reach (x, y): |q + u - 0.5 - x| <= r with u in [0, 1), i.e. x - r - 0.5 < q <= x + r + 0.5
+    // (floor / ceil keep a pixel of slack on either side against the rounding of the sums in AddSample)
+    // (a probe's RenderView takes no samples outside the film's pixel bounds: those records do not exist)
+    const int lo_x = P.probe_mode ? S.crop_x0 : S.samp_x0, hi_x = P.probe_mode ? S.crop_x1 : S.samp_x1;
+    const int lo_y = P.probe_mode ? S.crop_y0 : S.samp_y0, hi_y = P.probe_mode ? S.crop_y1 : S.samp_y1;
+    const int qx0 = max(int(floorf(float(x) - rx - 0.5f)), lo_x), qx1 = min(int(ceilf(float(x) + rx + 0.5f)), hi_x - 1);
+    const int qy0 = max(int(floorf(float(y) - ry - 0.5f)), lo_y), qy1 = min(int(ceilf(float(y) + ry + 0.5f)), hi_y - 1);
+    float4 out = make_float4(0, 0, 0, 0);
+    if (qx0 <= qx1 && qy0 <= qy1) {
+        const int tx0 = (qx0 - S.samp_x0) / kTile, tx1 = (qx1 - S.samp_x0) / kTile;
+        const int ty0 = (qy0 - S.samp_y0) / kTile, ty1 = (qy1 - S.samp_y0) / kTile;
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) {  // tile index order
+                uint32_t slot = 0;  // (probe pass: the tiles here are the reference's, the records are found per pixel)
+                if (!P.probe_mode && !tile_owned(P, tx, ty, &slot)) continue;
+                // the tile's FilmTile (Film::GetFilmTile, film.cpp:92-103) must hold (x, y)
+                const int sx0 = S.samp_x0 + tx * kTile, sy0 = S.samp_y0 + ty * kTile;
+                const int sx1 = min(sx0 + kTile, S.samp_x1), sy1 = min(sy0 + kTile, S.samp_y1);
+                const int fx0 = max(int(ceilf(float(sx0) - 0.5f - rx)), S.crop_x0), fx1 = min(int(floorf(float(sx1) - 0.5f + rx)) + 1, S.crop_x1);
+                const int fy0 = max(int(ceilf(float(sy0) - 0.5f - ry)), S.crop_y0), fy1 = min(int(floorf(float(sy1) - 0.5f + ry)) + 1, S.crop_y1);
+                if (x < fx0 || x >= fx1 || y < fy0 || y >= fy1) continue;
+                float r = 0, g = 0, b = 0, w = 0;
+                // FilmTile::AddSample's support test and table lookup for this pixel (film.h:159-188)
+                auto add_sample = [&](float2 pf, float4 L) {
+                    const float dxf = pf.x - 0.5f, dyf = pf.y - 0.5f;
+                    const bool in = x >= max(int(ceilf(dxf - rx)), fx0) && x < min(int(floorf(dxf + rx)) + 1, fx1) &&
+                                    y >= max(int(ceilf(dyf - ry)), fy0) && y < min(int(floorf(dyf + ry)) + 1, fy1);
+                    if (in) {
+                        const float ffx = fabsf((float(x) - dxf) * inv_rx * 16.f), ffy = fabsf((float(y) - dyf) * inv_ry * 16.f);
+                        const int ifx = min(int(floorf(ffx)), 15), ify = min(int(floorf(ffy)), 15);
+                        const float fwt = s_table[ify * 16 + ifx];
+                        r += L.x * 1.f * fwt;
+                        g += L.y * 1.f * fwt;
+                        b += L.z * 1.f * fwt;
+                        w += fwt;
+                    }
+                };
+                const int xa = max(qx0, sx0), xb = min(qx1, sx1 - 1);
+                for (int qy = max(qy0, sy0); qy <= min(qy1, sy1 - 1); ++qy) {
+                    const size_t row = size_t(slot) * size_t(n_samples) * 256u + size_t((qy - sy0) * kTile - sx0);
+                    if (n_samples == 1) {
+                        // one sample per pixel (the probe pass): four neighbouring pixels' records in flight
+                        for (int q4 = xa; q4 <= xb; q4 += 4) {
+                            float2 pfb[4];
+                            float4 Lb[4];
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) rec1(q4 + jj <= xb ? q4 + jj : q4, qy, row, &pfb[jj], &Lb[jj]);
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                if (q4 + jj <= xb) add_sample(pfb[jj], Lb[jj]);
+                        }
+                        continue;
+                    }
+                    for (int qx = xa; qx <= xb; ++qx) {
+                        const size_t base = row + size_t(qx);
+                        for (int k4 = 0; k4 < n_samples; k4 += 4) {
+                            // four records in flight, then summed in sample order
+                            float2 pfb[4];
+                            float4 Lb[4];
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const size_t at = base + size_t(k4 + jj < n_samples ? k4 + jj : k4) * 256u;
+                                pfb[jj] = F.wide_pf[at];
+                                Lb[jj] = F.wide_L[at];
+                            }
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                if (k4 + jj < n_samples) add_sample(pfb[jj], Lb[jj]);
+                        }
+                    }
+                }
+                add_xyz(&out, r, g, b, w);
+            }
+    }
+    return out;
+}
+
 __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, FilmBuffers F, int n_samples) {
     __shared__ float s_table[256];
     for (int j = threadIdx.x; j < 256; j += kBlock) s_table[j] = S.filter_table[j];
@@ -266,91 +350,64 @@ __global__ __launch_bounds__(kBlock) void k_film_gather(DScene S, PassDesc P, Fi
     const int fw = S.crop_x1 - S.crop_x0, fh = S.crop_y1 - S.crop_y0;
     const uint32_t per = uint32_t(fw) * uint32_t(fh);
     const uint32_t n = per * (P.probe_mode ? uint32_t(P.n_owned_tiles / P.probe_tiles) : 1u);  // one film per probe
-    const float rx = S.filter_rx, ry = S.filter_ry;
-    const float inv_rx = 1 / rx, inv_ry = 1 / ry;  // Filter::invRadius
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const uint32_t probe = i / per, loc = i % per;
         const int x = S.crop_x0 + int(loc % uint32_t(fw)), y = S.crop_y0 + int(loc / uint32_t(fw));
-        // sample pixels that can reach (x, y): |q + u - 0.5 - x| <= r with u in [0, 1), i.e. x - r - 0.5 < q <= x + r + 0.5
-        // (floor / ceil keep a pixel of slack on either side against the rounding of the sums in AddSample)
-        // (a probe's RenderView takes no samples outside the film's pixel bounds: those records do not exist)
-        const int lo_x = P.probe_mode ? S.crop_x0 : S.samp_x0, hi_x = P.probe_mode ? S.crop_x1 : S.samp_x1;
-        const int lo_y = P.probe_mode ? S.crop_y0 : S.samp_y0, hi_y = P.probe_mode ? S.crop_y1 : S.samp_y1;
-        const int qx0 = max(int(floorf(float(x) - rx - 0.5f)), lo_x), qx1 = min(int(ceilf(float(x) + rx + 0.5f)), hi_x - 1);
-        const int qy0 = max(int(floorf(float(y) - ry - 0.5f)), lo_y), qy1 = min(int(ceilf(float(y) + ry + 0.5f)), hi_y - 1);
-        float4 out = make_float4(0, 0, 0, 0);
-        if (qx0 <= qx1 && qy0 <= qy1) {
-            const int tx0 = (qx0 - S.samp_x0) / kTile, tx1 = (qx1 - S.samp_x0) / kTile;
-            const int ty0 = (qy0 - S.samp_y0) / kTile, ty1 = (qy1 - S.samp_y0) / kTile;
-            for (int ty = ty0; ty <= ty1; ++ty)
-                for (int tx = tx0; tx <= tx1; ++tx) {  // tile index order
-                    uint32_t slot = 0;  // (probe pass: the tiles here are the reference's, the records are found per pixel)
-                    if (!P.probe_mode && !tile_owned(P, tx, ty, &slot)) continue;
-                    // the tile's FilmTile (Film::GetFilmTile, film.cpp:92-103) must hold (x, y)
-                    const int sx0 = S.samp_x0 + tx * kTile, sy0 = S.samp_y0 + ty * kTile;
-                    const int sx1 = min(sx0 + kTile, S.samp_x1), sy1 = min(sy0 + kTile, S.samp_y1);
-                    const int fx0 = max(int(ceilf(float(sx0) - 0.5f - rx)), S.crop_x0), fx1 = min(int(floorf(float(sx1) - 0.5f + rx)) + 1, S.crop_x1);
-                    const int fy0 = max(int(ceilf(float(sy0) - 0.5f - ry)), S.crop_y0), fy1 = min(int(floorf(float(sy1) - 0.5f + ry)) + 1, S.crop_y1);
-                    if (x < fx0 || x >= fx1 || y < fy0 || y >= fy1) continue;
-                    float r = 0, g = 0, b = 0, w = 0;
-                    // FilmTile::AddSample's support test and table lookup for this pixel (film.h:159-188)
-                    auto add_sample = [&](float2 pf, float4 L) {
-                        const float dxf = pf.x - 0.5f, dyf = pf.y - 0.5f;
-                        const bool in = x >= max(int(ceilf(dxf - rx)), fx0) && x < min(int(floorf(dxf + rx)) + 1, fx1) &&
-                                        y >= max(int(ceilf(dyf - ry)), fy0) && y < min(int(floorf(dyf + ry)) + 1, fy1);
-                        if (in) {
-                            const float ffx = fabsf((float(x) - dxf) * inv_rx * 16.f), ffy = fabsf((float(y) - dyf) * inv_ry * 16.f);
-                            const int ifx = min(int(floorf(ffx)), 15), ify = min(int(floorf(ffy)), 15);
-                            const float fwt = s_table[ify * 16 + ifx];
-                            r += L.x * 1.f * fwt;
-                            g += L.y * 1.f * fwt;
-                            b += L.z * 1.f * fwt;
-                            w += fwt;
-                        }
-                    };
-                    const int xa = max(qx0, sx0), xb = min(qx1, sx1 - 1);
-                    for (int qy = max(qy0, sy0); qy <= min(qy1, sy1 - 1); ++qy) {
-                        const size_t row = size_t(slot) * size_t(n_samples) * 256u + size_t((qy - sy0) * kTile - sx0);
-                        if (n_samples == 1) {
-                            // one sample per pixel (the probe pass): four neighbouring pixels' records in flight
-                            for (int q4 = xa; q4 <= xb; q4 += 4) {
-                                float2 pfb[4];
-                                float4 Lb[4];
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj) {
-                                    const int qx = q4 + jj <= xb ? q4 + jj : q4;
-                                    const size_t at = P.probe_mode ? probe_record(S, P, probe, qx, qy) : row + size_t(qx);
-                                    pfb[jj] = F.wide_pf[at];
-                                    Lb[jj] = F.wide_L[at];
-                                }
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj)
-                                    if (q4 + jj <= xb) add_sample(pfb[jj], Lb[jj]);
-                            }
-                            continue;
-                        }
-                        for (int qx = xa; qx <= xb; ++qx) {
-                            const size_t base = row + size_t(qx);
-                            for (int k4 = 0; k4 < n_samples; k4 += 4) {
-                                // four records in flight, then summed in sample order
-                                float2 pfb[4];
-                                float4 Lb[4];
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj) {
-                                    const size_t at = base + size_t(k4 + jj < n_samples ? k4 + jj : k4) * 256u;
-                                    pfb[jj] = F.wide_pf[at];
-                                    Lb[jj] = F.wide_L[at];
-                                }
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj)
-                                    if (k4 + jj < n_samples) add_sample(pfb[jj], Lb[jj]);
-                            }
-                        }
-                    }
-                    add_xyz(&out, r, g, b, w);
-                }
+        F.film_xyzw[i] = film_gather_pixel(S, P, F, s_table, x, y, n_samples, [&](int qx, int qy, size_t row, float2 *pf, float4 *L) {
+            const size_t at = P.probe_mode ? probe_record(S, P, probe, qx, qy) : row + size_t(qx);
+            *pf = F.wide_pf[at];
+            *L = F.wide_L[at];
+        });
+    }
+}
+
+// The probe pass's film in one kernel (k_film_store + k_film_gather + k_probe_finish for films of at most kProbeFilmMax pixels, the
+// IISPT network's 32 x 32): a block takes a probe, keeps the film's samples — guarded radiance, film position — in LDS, and
+// every thread gathers its pixels from there (each sample is read by up to 36 pixels) and writes the three images.
+constexpr int kProbeFilmMax = 1024;
+__global__ __launch_bounds__(kBlock) void k_probe_film(DScene S, PassDesc P, PassBuffers B, int n_probes, float *intensity, float *normals, float *distance) {
+    __shared__ float s_table[256];
+    __shared__ float2 s_pf[kProbeFilmMax];
+    __shared__ float4 s_L[kProbeFilmMax];
+    for (int j = threadIdx.x; j < 256; j += kBlock) s_table[j] = S.filter_table[j];
+    const int fw = S.crop_x1 - S.crop_x0, fh = S.crop_y1 - S.crop_y0;
+    const int per = fw * fh;
+    FilmBuffers none = {};
+    for (uint32_t probe = blockIdx.x; probe < uint32_t(n_probes); probe += gridDim.x) {
+        __syncthreads();   // (the table; the previous probe's gathers)
+        for (int j = threadIdx.x; j < per; j += kBlock) {   // k_film_store
+            const int x = S.crop_x0 + j % fw, y = S.crop_y0 + j / fw;
+            const float4 L4 = B.L[probe_record(S, P, probe, x, y)];
+            const F3 L = guard_radiance(S, F3{L4.x, L4.y, L4.z});
+            const uint32_t idx = sample_index(S, x, y, 0);
+            s_L[j] = make_float4(L.x, L.y, L.z, 0.f);
+            s_pf[j] = make_float2(float(x) + sample_dimension(S, idx, 0, x, y), float(y) + sample_dimension(S, idx, 1, x, y));
         }
-        F.film_xyzw[i] = out;
+        __syncthreads();
+        for (int j = threadIdx.x; j < per; j += kBlock) {
+            const int x = S.crop_x0 + j % fw, y = S.crop_y0 + j / fw;
+            const float4 px = film_gather_pixel(S, P, none, s_table, x, y, 1, [&](int qx, int qy, size_t, float2 *pf, float4 *L) {
+                const int at = (qy - S.crop_y0) * fw + (qx - S.crop_x0);
+                *pf = s_pf[at];
+                *L = s_L[at];
+            });
+            // k_probe_finish
+            float rgb[3];
+            rgb[0] = 3.240479f * px.x - 1.537150f * px.y - 0.498535f * px.z;  // XYZToRGB, spectrum.h:56-60
+            rgb[1] = -0.969256f * px.x + 1.875991f * px.y + 0.041556f * px.z;
+            rgb[2] = 0.055648f * px.x - 0.204043f * px.y + 1.057311f * px.z;
+            if (px.w != 0) {
+                const float inv_wt = 1.f / px.w;
+                for (int c = 0; c < 3; ++c) rgb[c] = mx(0.f, rgb[c] * inv_wt);
+            }
+            const size_t i = size_t(probe) * size_t(per) + size_t(j);
+            for (int c = 0; c < 3; ++c) intensity[3 * i + c] = (rgb[c] + 0.f) * 1.f;
+            const float4 a = B.aux[probe_record(S, P, probe, x, y) * size_t(P.kc)];
+            normals[3 * i] = a.x;
+            normals[3 * i + 1] = a.y;
+            normals[3 * i + 2] = a.z;
+            distance[i] = a.w;
+        }
     }
 }
 
@@ -520,6 +577,14 @@ void launch_probe_finish(const DScene &S, const PassDesc &P, const PassBuffers &
     const uint32_t n = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0) * uint32_t(n_probes);
     hipLaunchKernelGGL(k_probe_finish, dim3(grid_blocks(n, cfg.n_cus, 8)), dim3(kBlock), 0, cfg.stream, S, P, B, F, n_probes, intensity,
                        normals, distance);
+}
+bool launch_probe_film(const DScene &S, const PassDesc &P, const PassBuffers &B, int n_probes, float *intensity, float *normals, float *distance,
+                       const LaunchCfg &cfg) {
+    const uint32_t per = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0);
+    if (per > uint32_t(kProbeFilmMax) || P.kc != 1) return false;   // (larger probe films: the three general kernels)
+    hipLaunchKernelGGL(k_probe_film, dim3(unsigned(std::min(n_probes, cfg.n_cus * 8))), dim3(kBlock), 0, cfg.stream, S, P, B, n_probes, intensity, normals,
+                       distance);
+    return true;
 }
 void launch_film_gather(const DScene &S, const PassDesc &P, const FilmBuffers &F, int n_samples, const LaunchCfg &cfg) {
     const uint32_t n = uint32_t(S.crop_x1 - S.crop_x0) * uint32_t(S.crop_y1 - S.crop_y0) *
