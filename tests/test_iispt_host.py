@@ -99,6 +99,32 @@ def test_cli_refuses_an_iispt_frame_it_cannot_render(tmp_path):
     assert not (tmp_path / "o.pfm").exists()
 
 
+def test_cpp_schedule_is_the_python_schedule(tmp_path):
+    """IisptSchedule (C++) and iispt_frame.schedule (Python) are IisptScheduleMonitor::next_task (iisptschedulemonitor.cpp:40-79):
+    the same tasks, the float radius and its floor included, over many sweeps and with the reference's environment overrides."""
+    frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
+    exe = tmp_path / "schedule_probe"
+    subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(REPO, "tests", "cpp", "schedule_probe.cpp"), "-o", str(exe)], check=True, timeout=300)
+    for bounds, n, start, ratio in (((0, 0, 1920, 1080), 3000, None, None), ((0, 0, 96, 80), 400, "4", None), ((-2, -2, 1282, 722), 900, "37.5", None),
+                                    ((0, 0, 700, 700), 500, "100", "0.5"), ((0, 0, 33, 17), 300, "1.9", None)):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("IISPT_SCHEDULE_")}
+        kw = {}
+        if start is not None:
+            env["IISPT_SCHEDULE_RADIUS_START"] = start
+            kw["radius_start"] = float(np.float32(start))
+        if ratio is not None:
+            env["IISPT_SCHEDULE_RADIUS_RATIO"] = ratio
+            kw["update_multiplier"] = float(np.float32(ratio))
+        out = subprocess.run([str(exe), *map(str, bounds), str(n)], stdout=subprocess.PIPE, text=True, check=True, env=env, timeout=60).stdout
+        got = [tuple(int(v) for v in line.split()) for line in out.splitlines()]
+        want = list(frame_mod.schedule(bounds, n, **kw))
+        assert len(got) == n and [g[:5] for g in got] == want, (bounds, start, ratio)
+        assert [g[6] for g in got] == list(range(n))
+        # `pass` counts the sweeps: it steps exactly where a task starts at the bounds' corner again
+        assert all((g[5] != p[5]) == (g[:2] == bounds[:2]) for p, g in zip(got, got[1:]))
+        assert got[-1][4] >= 1
+
+
 def _read_pfm(path, w, h):
     raw = open(path, "rb").read()
     head = f"PF\n{w} {h}\n-1.0\n".encode()
