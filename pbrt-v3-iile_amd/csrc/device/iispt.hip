@@ -399,19 +399,29 @@ __global__ __launch_bounds__(kIisptBlock) void k_iispt_gather(DScene S, const Ii
             Pcg rng(T.rng_seed + (unsigned long long)(j));
             F3 L = F3{0, 0, 0};
             int samples_taken = 0;
-            for (int i = 0; i < 4; ++i)
-                for (int s = 0; s < 16; ++s) {
-                    const float rr = rng.uniform_float();
-                    if (rr < weights[i]) {
+            // `for (i < 4) for (s < 16) if (uniform_float() < weights[i]) { taken; if (camera i) L += estimate_direct(...) }`, the same
+            // draws in the same order per pixel, arranged for 64 lanes: a lane runs ahead through the draws it does not take (a PCG
+            // step and a comparison each) to its next estimate, and the wavefront evaluates estimates with every lane that still has
+            // one — taking the estimate inside the double loop leaves three lanes in four idle (a quarter of the draws are taken).
+            int c = 0;   // draws done: neighbour c >> 4, its sample c & 15
+            while (true) {
+                int ci = -1;
+                while (c < 64) {
+                    const int i = c >> 4;
+                    ++c;
+                    if (rng.uniform_float() < weights[i]) {
                         samples_taken++;
                         if (cam_index[i] >= 0) {
-                            const int rx = int(rng.uniform_u32(uint32_t(hemi)));
-                            const int ry = int(rng.uniform_u32(uint32_t(hemi)));
-                            L = L + estimate_direct_nn(f_is, f_bsdf, rx, ry, cams[cam_index[i]], nn_films + size_t(cam_index[i]) * hemi * hemi * 3, hemi,
-                                                       jac, rng);
+                            ci = cam_index[i];
+                            break;
                         }
                     }
                 }
+                if (ci < 0) break;
+                const int rx = int(rng.uniform_u32(uint32_t(hemi)));
+                const int ry = int(rng.uniform_u32(uint32_t(hemi)));
+                L = L + estimate_direct_nn(f_is, f_bsdf, rx, ry, cams[ci], nn_films + size_t(ci) * hemi * hemi * 3, hemi, jac, rng);
+            }
             if (samples_taken > 0) {
                 L = sdiv(L, float(samples_taken));
                 const F3 v = f_beta * L;
