@@ -52,8 +52,11 @@ enum { PRE_NONE = 0, PRE_CAT = 1 };
 constexpr int kBM = 256;      // pixels per workgroup tile
 constexpr int kBN = 64;       // output channels per workgroup tile
 constexpr int kChunk = 16;    // input channels per step = one k-step of the matrix instruction per tap
-constexpr int kLoaders = 512; // threads of the 8 staging waves
-constexpr int kThreads = 256 + kLoaders;   // 4 matrix waves + 8 staging waves
+#ifndef NET_LOADER_WAVES
+#define NET_LOADER_WAVES 8   // (4 stage as fast, and a wave may then hold 256 registers: what the experiments under tools/experiments/r05_net_* used)
+#endif
+constexpr int kLoaders = 64 * NET_LOADER_WAVES; // threads of the staging waves
+constexpr int kThreads = 256 + kLoaders;   // 4 matrix waves + the staging waves
 constexpr int kRowB = kChunk * 2 + 16;   // bytes per staged pixel and plane (48: an odd multiple of 16 -> b128 reads of consecutive pixels hit 16 different bank groups)
 constexpr int kKPC = 9;       // k-steps per step (one per tap)
 constexpr int kBStep = kKPC * 4 * 64 * 16;   // bytes of packed weights per step and 64-channel n-tile (36 864)
@@ -153,6 +156,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = wave >= 4;
+    // the layer's bias and BatchNorm affine behind the two buffers: the epilogue reads them from LDS (a global load there — the first
+    // thing a tile's epilogue would wait for — stalls the matrix pipe for its whole round trip, once per tile)
+    // (where the buffers leave no room — the 4 x 4 layers with 512 output channels, 16 steps per tile — it stays a global load)
+    constexpr bool PAR_LDS = 2 * size_t(BUF) + 3 * size_t(COUT) * 4 <= 160 * 1024;
+    float *s_par = reinterpret_cast<float *>(smem + 2 * BUF);   // [bias COUT][scale COUT][shift COUT]
+    if (PAR_LDS)
+        for (int i = tid; i < COUT; i += kThreads) {
+            s_par[i] = p.bias[i];
+            s_par[COUT + i] = BNORM ? p.bn_scale[i] : 1.f;
+            s_par[2 * COUT + i] = BNORM ? p.bn_shift[i] : 0.f;
+        }
+    // (the first __syncthreads below — before anybody's first epilogue — publishes them)
     const int n_mtiles = H >= 32 ? p.n_img * T::TILES_PER_IMG : (p.n_img + T::IMGS - 1) / T::IMGS;
     const int n_tiles = ((n_mtiles + 7) / 8) * 8 * NT;   // tile t: group t / (8 NT), n-tile (t % (8 NT)) >> 3, m-tile 8 group + (t & 7)
     const int my_tiles = (n_tiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);   // t = blockIdx.x + i gridDim.x: with
@@ -165,6 +180,18 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
         ntile = in_grp >> 3;
     };
 
+#ifdef NET_DIAG_SKEW
+    // experiment, not the default: every workgroup has the same work per tile, so all 256 reach their epilogues — 16 MB of stores —
+    // together; started in up to eight phases spread over one tile period they stay apart. Measured: the 32 x 32 layers gain 6 %, the
+    // deep ones lose as much (their workgroups idle up to a tile period at the start).
+    {
+        constexpr int P = NCHUNK < 8 ? NCHUNK : 8;
+        constexpr unsigned long long kStepTicks = 4000;   // s_memtime ticks of one step's 108 matrix instructions (measured)
+        const unsigned long long wait = (unsigned long long)((int(blockIdx.x) / 8) % P) * (NCHUNK / P) * kStepTicks;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     if (loader) {
         // ------------------------------------------------ staging waves ------------------------------------------------
         const int ltid = tid - 256;
@@ -172,7 +199,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
             f32x4 va[NA];
             u32x4 vb[NB];
         };
-        Regs r0, r1;   // steps alternate between the two sets: a step's loads are issued two steps before they are stored
+#ifndef NET_PREFETCH_SETS
+#define NET_PREFETCH_SETS 2
+#endif
+        Regs r0, r1, r2;   // steps rotate through the sets: a step's loads are issued NET_PREFETCH_SETS steps before they are stored
 
 #ifdef NET_DIAG_NO_GLOBAL
 #define NET_LD(ptr) (f32x4{float(ltid), 1.f, 2.f, 3.f})
@@ -181,6 +211,19 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
 #define NET_LD(ptr) (*reinterpret_cast<const f32x4 *>(ptr))
 #define NET_LDB(ptr) (*(ptr))
 #endif
+        // where this thread's A items sit, once (staged pixel -> image of the tile, row, column is the same every step: only the tile's
+        // first image / row and the channel chunk move): element offset from the tile's first pixel, the row and image for the bounds
+        int a_rel[NA], a_yl[NA], a_il[NA];   // a_il < 0: a border position (stays zero) or no item
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int it = ltid + kLoaders * u;
+            int il = 0, yl = 0, x = 0;
+            const bool ok = it < NITEMS && T::decode(it >> 2, il, yl, x);
+            constexpr int CS = PRE == PRE_CAT ? CIN / 2 : CIN;
+            a_rel[u] = ((il * H + yl) * H + x) * CS + (it & 3) * 4;
+            a_yl[u] = yl;
+            a_il[u] = ok ? il : -1;
+        }
         auto issue = [&](int step, Regs &R) __attribute__((always_inline)) {   // global loads of a step into registers
             int mtile, ntile;
             tile_of(step / NCHUNK, mtile, ntile);
@@ -195,15 +238,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
             constexpr int CSRC = PRE == PRE_CAT ? CIN / 2 : CIN;
             const bool second = PRE == PRE_CAT && c_base >= CSRC;
             const float *src = (second ? p.in1 : p.in0) + (second ? c_base - CSRC : c_base);
+            const float *tile0 = src + (size_t(img0) * H + y0) * H * CSRC;   // the tile's first pixel (uniform)
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
-                const int it = ltid + kLoaders * u;
                 R.va[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                int il, yl, x;
-                if (it >= NITEMS || !T::decode(it >> 2, il, yl, x)) continue;
-                const int y = y0 + yl, img = img0 + il;
-                if (!(y >= 0 && y < H && img < p.n_img && mtile < n_mtiles)) continue;
-                R.va[u] = NET_LD(src + ((size_t(img) * H + y) * H + x) * CSRC + (it & 3) * 4);
+                const int y = y0 + a_yl[u], img = img0 + a_il[u];
+                if (a_il[u] < 0 || !(y >= 0 && y < H && img < p.n_img && mtile < n_mtiles)) continue;
+                R.va[u] = NET_LD(tile0 + a_rel[u]);
             }
         };
         auto store = [&](int step, Regs &R) __attribute__((always_inline)) {   // registers -> LDS buffer step & 1
@@ -219,24 +260,54 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
                 split_store(R.va[u], s_hi + (it >> 2) * kRowB + (it & 3) * 8, s_lo + (it >> 2) * kRowB + (it & 3) * 8);
             }
         };
-        // iteration i (beside the matrix waves' step i): request step i + 2 into the set step i used, then store step i + 1
+        // iteration i (beside the matrix waves' step i): request step i + SETS into the set step i used, then store step i + 1
+        constexpr int SETS = NET_PREFETCH_SETS;
+#ifdef NET_DIAG_STAMPS
+        unsigned long long lt_issue = 0, lt_store = 0, lt_bar = 0, lt_t = __builtin_amdgcn_s_memtime();
+#define NET_LSTAMP(acc_)                                              \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        acc_ += now_ - lt_t;                                          \
+        lt_t = now_;                                                  \
+    } while (0)
+#else
+#define NET_LSTAMP(acc_) \
+    do {                 \
+    } while (0)
+#endif
         auto iter = [&](int i, Regs &Ra, Regs &Rb) __attribute__((always_inline)) {
 #ifndef NET_DIAG_NO_STAGE
-            if (i + 2 < n_steps) issue(i + 2, Ra);
+            if (i + SETS < n_steps) issue(i + SETS, Ra);
+            NET_LSTAMP(lt_issue);
             if (i + 1 < n_steps) store(i + 1, Rb);
+            NET_LSTAMP(lt_store);
 #endif
             __syncthreads();
+            NET_LSTAMP(lt_bar);
         };
 #ifndef NET_DIAG_NO_STAGE
         if (n_steps > 0) issue(0, r0);
         if (n_steps > 1) issue(1, r1);
+        if (SETS > 2 && n_steps > 2) issue(2, r2);
         if (n_steps > 0) store(0, r0);
 #endif
         __syncthreads();
-        for (int step = 0; step < n_steps; step += 2) {
-            iter(step, r0, r1);
-            if (step + 1 < n_steps) iter(step + 1, r1, r0);
+        if (SETS == 2) {
+            for (int step = 0; step < n_steps; step += 2) {
+                iter(step, r0, r1);
+                if (step + 1 < n_steps) iter(step + 1, r1, r0);
+            }
+        } else {
+            for (int step = 0; step < n_steps; step += 3) {
+                iter(step, r0, r1);
+                if (step + 1 < n_steps) iter(step + 1, r1, r2);
+                if (step + 2 < n_steps) iter(step + 2, r2, r0);
+            }
         }
+#ifdef NET_DIAG_STAMPS
+        if (blockIdx.x == 17 && ltid == 0)
+            printf("k_conv3x3<%d,%d,%d> block 17 staging: %d steps, ticks issue %llu store %llu barrier %llu\n", H, CIN, COUT, n_steps, lt_issue, lt_store, lt_bar);
+#endif
         return;
     }
 
@@ -248,15 +319,43 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) a_off[mt] = T::lp_of(wave * 64 + mt * 32 + r) * kRowB + h * 16;
 
+    // The accumulators of a tile START at the bias of their channels (where the parameters sit in LDS): the epilogue then has no
+    // additions, and the start costs what zeroing did. The epilogue is the one place where the matrix pipe idles by construction — one
+    // matrix wave per SIMD runs its vector instructions alone: 8 % of the network's time (timing-only build NET_DIAG_NO_ARITH +
+    // NET_DIAG_KEEP_ONLY: 20.7 against 22.6 ms per 8192 probes; a fifth of the 32 x 32 layers, NET_DIAG_STAMPS). Measured and not kept:
+    // the same arithmetic woven between the next step's matrix instructions (each vector instruction delays them as much), a second
+    // register set stored two pieces per k-step, and the raw sums handed to the staging waves through the LDS buffer the tile's last
+    // step has just finished with (those waves are bound by the address path: 58 loads per step) — tools/experiments/r05_net_*.patch.
     f32x16 acc[2][2];
+    auto start_tile = [&](int tile_i) __attribute__((always_inline)) {
+        int mtile, ntile;
+        tile_of(tile_i, mtile, ntile);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PAR_LDS) b4 = *reinterpret_cast<const f32x4 *>(s_par + ntile * kBN + nt * 32 + 8 * g + 4 * h);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int q = 0; q < 4; ++q) acc[0][nt][4 * g + q] = acc[1][nt][4 * g + q] = b4[q];
+            }
+    };
 
-    __syncthreads();   // step 0 is staged
+    __syncthreads();   // step 0 is staged (and the parameters)
+    start_tile(0);
+#ifdef NET_DIAG_STAMPS   // timing only: where a matrix wave's time goes (REFCLK ticks): matrix instructions, epilogue, barrier
+    unsigned long long st_mfma = 0, st_epi = 0, st_bar = 0, st_t = __builtin_amdgcn_s_memtime();
+#define NET_STAMP(acc_)                                              \
+    do {                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        acc_ += now_ - st_t;                                         \
+        st_t = now_;                                                 \
+    } while (0)
+#else
+#define NET_STAMP(acc_) \
+    do {                \
+    } while (0)
+#endif
 
     for (int step = 0; step < n_steps; ++step) {
         const char *s_hi = smem + (step & 1) * BUF, *s_lo = s_hi + PLANE;
@@ -284,9 +383,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
                 for (int nt = 0; nt < 2; ++nt) {
                     const bf16x8 ah = aq[k & 1][mt * 2], al = aq[k & 1][mt * 2 + 1];
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[k & 1][nt * 2]), bl = __builtin_bit_cast(bf16x8, bq[k & 1][nt * 2 + 1]);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt][nt], 0, 0, 0);
+                    // the weights are the instruction's A operand (rows = output channels), the pixels its B operand (columns): a lane
+                    // then holds four CONSECUTIVE channels of its pixel per accumulator quad, and the epilogue stores 16 bytes at a time
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[mt][nt], 0, 0, 0);
                 }
             // issue order inside the k-step: one LDS read of the next k-step behind each of the first eight matrix
             // instructions (eight reads in a row stall the matrix pipe for the time the LDS takes to accept them)
@@ -301,39 +402,59 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
+        NET_STAMP(st_mfma);
         if (step % NCHUNK == NCHUNK - 1) {
-            // ---- bias, LeakyReLU(0.2), BatchNorm affine; accumulator column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h ----
+            // ---- bias, LeakyReLU(0.2), BatchNorm affine; accumulator column (pixel of the block) = lane & 31, row (channel of the
+            // block) = (e & 3) + 8 (e >> 2) + 4 h: per quad e >> 2 four consecutive channels, one 16-byte store ----
             int mtile, ntile;
             tile_of(step / NCHUNK, mtile, ntile);
             const int img0 = H >= 32 ? mtile / T::TILES_PER_IMG : mtile * T::IMGS;
             const int y0 = H >= 32 ? (mtile % T::TILES_PER_IMG) * T::ROWS : 0;
+            // (one matrix wave per SIMD runs this alone — the matrix pipe idles meanwhile — so the arithmetic is written four values
+            //  wide: four independent adds, multiplies, maxima in a row instead of a dependent chain per value)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int co = ntile * kBN + nt * 32 + r;
-                const float bias = p.bias[co];
-                float sc = 1.f, sh = 0.f;
-                if (BNORM) {
-                    sc = p.bn_scale[co];
-                    sh = p.bn_shift[co];
-                }
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = wave * 64 + mt * 32 + r;
+                const int il = m / (T::ROWS * H), y = y0 + (m / H) % T::ROWS, x = m % H;
+                const int img = img0 + il;
+                const bool live = img < p.n_img && mtile < n_mtiles;
+                float *dst = p.out + ((size_t(img) * H + y) * H + x) * COUT;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        int m = wave * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        int il = m / (T::ROWS * H), y = y0 + (m / H) % T::ROWS, x = m % H;
-                        int img = img0 + il;
-                        float v = acc[mt][nt][e] + bias;
-                        acc[mt][nt][e] = 0.f;
-                        if (img >= p.n_img || mtile >= n_mtiles) continue;
-                        v = v > 0.f ? v : 0.2f * v;
-                        if (BNORM) v = v * sc + sh;
-                        p.out[((size_t(img) * H + y) * H + x) * COUT + co] = v;
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = ntile * kBN + nt * 32 + 8 * g + 4 * h;
+                        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (!PAR_LDS) bias = *reinterpret_cast<const f32x4 *>(p.bias + co);
+                        f32x4 t = f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+#ifdef NET_DIAG_NO_ARITH   // timing only: the sums consumed as they are
+                        f32x4 v = t;
+#else
+                        if (!PAR_LDS) t = t + bias;   // (with the parameters in LDS the sums started at the bias)
+                        f32x4 v = max4(t, 0.2f * t);   // LeakyReLU(0.2): t for t > 0, 0.2 t below
+#endif
+                        if (BNORM) {
+                            const f32x4 sc = PAR_LDS ? *reinterpret_cast<const f32x4 *>(s_par + COUT + co) : *reinterpret_cast<const f32x4 *>(p.bn_scale + co);
+                            const f32x4 sh = PAR_LDS ? *reinterpret_cast<const f32x4 *>(s_par + 2 * COUT + co) : *reinterpret_cast<const f32x4 *>(p.bn_shift + co);
+                            v = v * sc + sh;
+                        }
+#ifdef NET_DIAG_KEEP_ONLY   // timing only: the arithmetic kept alive, nothing written
+                        asm volatile("" ::"v"(v));
+#else
+                        if (live) *reinterpret_cast<f32x4 *>(dst + co) = v;
+#endif
                     }
             }
+            start_tile(step / NCHUNK + 1);   // (the workgroup's tile after its last: parameters of some n-tile, never used)
         }
+        NET_STAMP(st_epi);
         __syncthreads();   // buffer step & 1 may be refilled; buffer (step + 1) & 1 is staged
+        NET_STAMP(st_bar);
     }
+#ifdef NET_DIAG_STAMPS
+    if (blockIdx.x == 17 && tid == 0)
+        printf("k_conv3x3<%d,%d,%d> block 17: %d steps, ticks mfma %llu epilogue %llu barrier %llu\n", H, CIN, COUT, n_steps, st_mfma, st_epi, st_bar);
+#endif
 }
 
 // nn.MaxPool2d(2): [n][2H][2H][C] -> [n][H][H][C]; one thread per output pixel and four channels
@@ -543,7 +664,8 @@ float bf16_to_float(uint16_t b) {
 template <int H, int CIN, int COUT, int PRE, bool BNORM>
 hipError_t launch_conv(const ConvArgs &a, int n_cus, bool *attr_set, hipStream_t s) {
     using T = Tile<H>;
-    constexpr size_t lds = 2 * (size_t(T::NLP) * kRowB * 2 + kBStep);   // two buffers of {A hi, A lo, B}
+    constexpr size_t buffers = 2 * (size_t(T::NLP) * kRowB * 2 + kBStep);   // two buffers of {A hi, A lo, B}
+    constexpr size_t lds = buffers + 3 * size_t(COUT) * 4 <= 160 * 1024 ? buffers + 3 * size_t(COUT) * 4 : buffers;   // + bias, scale, shift where they fit
     static_assert(lds <= 160 * 1024, "LDS");
     auto kern = k_conv3x3<H, CIN, COUT, PRE, BNORM>;
     if (!*attr_set) {   // once per network object, i.e. per device the object was made on (the attribute is per device)
