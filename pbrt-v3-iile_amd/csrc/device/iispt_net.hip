@@ -109,6 +109,21 @@ __device__ inline void split_store(f32x4 v, char *hi, char *lo) {
 }
 
 __device__ inline f32x4 max4(f32x4 a, f32x4 b) { return __builtin_elementwise_max(a, b); }
+// LeakyReLU(0.2) = max(t, 0.2 t) as the bare instruction. fmaxf / elementwise_max quiet their operands first (IEEE maxNum: `v_max x, x, x`
+// before every real maximum — and the register allocator runs all of those through ONE temporary, which turns the epilogue's 64
+// independent maxima into a serial chain of 128: the disassembly of round 5's kernel). The operands here are sums of products: a
+// signalling NaN cannot reach this point.
+__device__ inline f32x4 leaky4(f32x4 t) {
+    const f32x4 m = 0.2f * t;
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float o;
+        asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(t[q]), "v"(m[q]));
+        r[q] = o;
+    }
+    return r;
+}
 __device__ inline f32x4 lerp4(float wa, f32x4 a, float wb, f32x4 b) { return wa * a + wb * b; }
 
 // nn.Upsample(scale_factor=2, mode="bilinear") (align_corners False): source index and weight of destination d
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
                         f32x4 v = t;
 #else
                         if (!PAR_LDS) t = t + bias;   // (with the parameters in LDS the sums started at the bias)
-                        f32x4 v = max4(t, 0.2f * t);   // LeakyReLU(0.2): t for t > 0, 0.2 t below
+                        f32x4 v = leaky4(t);   // LeakyReLU(0.2): t for t > 0, 0.2 t below
 #endif
                         if (BNORM) {
                             const f32x4 sc = PAR_LDS ? *reinterpret_cast<const f32x4 *>(s_par + COUT + co) : *reinterpret_cast<const f32x4 *>(p.bn_scale + co);
