@@ -217,8 +217,8 @@ int iile_iispt_film_merge(const double *direct_rgbw_dev, const double *indirect_
 /* The IISPT network itself: `IISPTNet.forward` of ml/iispt_net.py:8-109 in eval mode, as the child process
  * of ml/main_stdio_net.py:44-106 runs it once per probe (`net(torch_img)`, one CPU thread, fp32) — here over a whole batch
  * of probes with hand-written gfx950 kernels (csrc/device/iispt_net.hip: implicit-GEMM 3 x 3 convolutions on the bf16 matrix
- * pipe over split operands, fp32 accumulation; max-pool / bilinear upsample + concatenation folded into the loads; bias,
- * LeakyReLU and the BatchNorm affine into the stores). Agreement with the reference module on the fixture of
+ * pipe over split operands, fp32 accumulation; max-pool and bilinear upsampling as streaming kernels of their own, the
+ * concatenation free in the loads; bias, LeakyReLU and the BatchNorm affine in the accumulator registers before the stores). Agreement with the reference module on the fixture of
  * tests/golden/iispt_net_fixture.npz: within 1e-4 of the largest output (tests/test_iispt_nn.py).
  *   iile_iispt_net_create   takes the tensors of the reference's `state_dict()` (host memory, the checkpoint's own shapes:
  *                           Conv2d [out][in][k][k], ConvTranspose2d [in][out][k][k]) in forward order: convolutions

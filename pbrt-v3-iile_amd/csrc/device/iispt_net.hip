@@ -15,14 +15,18 @@
 // (one per CU; 4 matrix waves + 8 staging waves, k_conv3x3 below) owns a stream of (256-pixel tile, chunk) steps: the staging
 // waves bring a step's pixels — with their one-pixel halo, split into bf16 hi / lo rows of 48 bytes — and its packed weights
 // into one of two LDS buffers while the matrix waves run the step before out of the other; the matrix waves read LDS only.
-// Behind the last chunk of a tile: bias, LeakyReLU(0.2) and the eval-mode BatchNorm2d affine in the accumulator registers, one
-// 128-byte store per 32 lanes. MaxPool2d(2) and Upsample(x2, bilinear) are streaming kernels of their own (k_pool2, k_up2);
+// The weights are the matrix instruction's A operand, the pixels its B operand: a lane holds four consecutive channels of its pixel
+// per accumulator quad. The sums start at the bias; behind the last chunk of a tile: LeakyReLU(0.2) and the eval-mode BatchNorm2d
+// affine in the accumulator registers (parameters in LDS), 16-byte stores. MaxPool2d(2) and Upsample(x2, bilinear) are streaming kernels of their own (k_pool2, k_up2);
 // torch.cat costs nothing (a step's 16 channels come from one of two tensors). ConvTranspose2d(k = 3, stride 1, padding 1) is
 // the same convolution with the kernel mirrored and its channel axes swapped (done by the packer). Measurements, and the two
 // designs this one replaced: DESIGN.md section 4.6.
 //
 // Timing-only diagnostics (wrong results; tools/net_layers.sh, tools/net_pmc.sh build them as variants):
-// -DNET_DIAG_NO_STAGE (the staging waves only keep the barriers), -DNET_DIAG_NO_MFMA, -DNET_DIAG_NO_GLOBAL (no global loads).
+// -DNET_DIAG_NO_STAGE (the staging waves only keep the barriers), -DNET_DIAG_NO_MFMA, -DNET_DIAG_NO_GLOBAL (no global loads),
+// -DNET_DIAG_NO_ARITH / _KEEP_ONLY / _ARITH_TWICE (the epilogue without its arithmetic / its stores / with three times the arithmetic);
+// -DNET_DIAG_STAMPS prints where one workgroup's matrix and staging wave spend their cycles (correct results);
+// profiles/r05_net_epilogue_study.txt has what they showed.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
