@@ -24,7 +24,7 @@
 //
 // Timing-only diagnostics (wrong results; tools/net_layers.sh, tools/net_pmc.sh build them as variants):
 // -DNET_DIAG_NO_STAGE (the staging waves only keep the barriers), -DNET_DIAG_NO_MFMA, -DNET_DIAG_NO_GLOBAL (no global loads),
-// -DNET_DIAG_NO_ARITH / _KEEP_ONLY / _ARITH_TWICE (the epilogue without its arithmetic / its stores / with three times the arithmetic);
+// -DNET_DIAG_NO_ARITH / -DNET_DIAG_KEEP_ONLY (the epilogue without its arithmetic / its stores);
 // -DNET_DIAG_STAMPS prints where one workgroup's matrix and staging wave spend their cycles (correct results);
 // profiles/r05_net_epilogue_study.txt has what they showed.
 #include <hip/hip_runtime.h>
@@ -56,11 +56,8 @@ enum { PRE_NONE = 0, PRE_CAT = 1 };
 constexpr int kBM = 256;      // pixels per workgroup tile
 constexpr int kBN = 64;       // output channels per workgroup tile
 constexpr int kChunk = 16;    // input channels per step = one k-step of the matrix instruction per tap
-#ifndef NET_LOADER_WAVES
-#define NET_LOADER_WAVES 8   // (4 stage as fast, and a wave may then hold 256 registers: what the experiments under tools/experiments/r05_net_* used)
-#endif
-constexpr int kLoaders = 64 * NET_LOADER_WAVES; // threads of the staging waves
-constexpr int kThreads = 256 + kLoaders;   // 4 matrix waves + the staging waves
+constexpr int kLoaders = 512; // threads of the 8 staging waves (4 stage as fast and leave a wave 256 registers: the experiments' builds)
+constexpr int kThreads = 256 + kLoaders;   // 4 matrix waves + 8 staging waves
 constexpr int kRowB = kChunk * 2 + 16;   // bytes per staged pixel and plane (48: an odd multiple of 16 -> b128 reads of consecutive pixels hit 16 different bank groups)
 constexpr int kKPC = 9;       // k-steps per step (one per tap)
 constexpr int kBStep = kKPC * 4 * 64 * 16;   // bytes of packed weights per step and 64-channel n-tile (36 864)
@@ -199,18 +196,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
         ntile = in_grp >> 3;
     };
 
-#ifdef NET_DIAG_SKEW
-    // experiment, not the default: every workgroup has the same work per tile, so all 256 reach their epilogues — 16 MB of stores —
-    // together; started in up to eight phases spread over one tile period they stay apart. Measured: the 32 x 32 layers gain 6 %, the
-    // deep ones lose as much (their workgroups idle up to a tile period at the start).
-    {
-        constexpr int P = NCHUNK < 8 ? NCHUNK : 8;
-        constexpr unsigned long long kStepTicks = 4000;   // s_memtime ticks of one step's 108 matrix instructions (measured)
-        const unsigned long long wait = (unsigned long long)((int(blockIdx.x) / 8) % P) * (NCHUNK / P) * kStepTicks;
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
     if (loader) {
         // ------------------------------------------------ staging waves ------------------------------------------------
         const int ltid = tid - 256;
@@ -218,10 +203,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
             f32x4 va[NA];
             u32x4 vb[NB];
         };
-#ifndef NET_PREFETCH_SETS
-#define NET_PREFETCH_SETS 2
-#endif
-        Regs r0, r1, r2;   // steps rotate through the sets: a step's loads are issued NET_PREFETCH_SETS steps before they are stored
+        Regs r0, r1;   // steps alternate between the two sets: a step's loads are issued two steps before they are stored (three sets: no faster)
 
 #ifdef NET_DIAG_NO_GLOBAL
 #define NET_LD(ptr) (f32x4{float(ltid), 1.f, 2.f, 3.f})
@@ -279,8 +261,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
                 split_store(R.va[u], s_hi + (it >> 2) * kRowB + (it & 3) * 8, s_lo + (it >> 2) * kRowB + (it & 3) * 8);
             }
         };
-        // iteration i (beside the matrix waves' step i): request step i + SETS into the set step i used, then store step i + 1
-        constexpr int SETS = NET_PREFETCH_SETS;
+        // iteration i (beside the matrix waves' step i): request step i + 2 into the set step i used, then store step i + 1
 #ifdef NET_DIAG_STAMPS
         unsigned long long lt_issue = 0, lt_store = 0, lt_bar = 0, lt_t = __builtin_amdgcn_s_memtime();
 #define NET_LSTAMP(acc_)                                              \
@@ -296,7 +277,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
 #endif
         auto iter = [&](int i, Regs &Ra, Regs &Rb) __attribute__((always_inline)) {
 #ifndef NET_DIAG_NO_STAGE
-            if (i + SETS < n_steps) issue(i + SETS, Ra);
+            if (i + 2 < n_steps) issue(i + 2, Ra);
             NET_LSTAMP(lt_issue);
             if (i + 1 < n_steps) store(i + 1, Rb);
             NET_LSTAMP(lt_store);
@@ -307,21 +288,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
 #ifndef NET_DIAG_NO_STAGE
         if (n_steps > 0) issue(0, r0);
         if (n_steps > 1) issue(1, r1);
-        if (SETS > 2 && n_steps > 2) issue(2, r2);
         if (n_steps > 0) store(0, r0);
 #endif
         __syncthreads();
-        if (SETS == 2) {
-            for (int step = 0; step < n_steps; step += 2) {
-                iter(step, r0, r1);
-                if (step + 1 < n_steps) iter(step + 1, r1, r0);
-            }
-        } else {
-            for (int step = 0; step < n_steps; step += 3) {
-                iter(step, r0, r1);
-                if (step + 1 < n_steps) iter(step + 1, r1, r2);
-                if (step + 2 < n_steps) iter(step + 2, r2, r0);
-            }
+        for (int step = 0; step < n_steps; step += 2) {
+            iter(step, r0, r1);
+            if (step + 1 < n_steps) iter(step + 1, r1, r0);
         }
 #ifdef NET_DIAG_STAMPS
         if (blockIdx.x == 17 && ltid == 0)
