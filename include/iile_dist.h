@@ -33,7 +33,19 @@ typedef struct iile_dist iile_dist;
 int iile_dist_unique_id(uint8_t id[IILE_DIST_ID_BYTES]);
 /* Every rank, after hipSetDevice: join the communicator of `id` as `rank` of `nranks` (collective call). */
 int iile_dist_create(const uint8_t id[IILE_DIST_ID_BYTES], int32_t rank, int32_t nranks, iile_dist **out);
+/* The same for hosts with no launcher that would tear a stuck job down (the threads of one process, iile_pbrt --gpurank):
+ * RCCL's non-blocking set-up (ncclCommInitRankConfig, blocking = 0) polled against a deadline. If a rank never arrives the call
+ * returns IILE_ERR_TIMEOUT after timeout_s seconds — the reference's ParallelFor cannot lose a worker (src/core/parallel.cpp:
+ * 247-299: threads of one pool); processes and devices can. The same deadline then bounds every wait on the communicator
+ * (iile_dist_wait, _sum_u64, _max_f64, _all_ok, _rendezvous_done): when one expires the communicator is aborted locally
+ * (ncclCommAbort) and every later call on it fails at once with IILE_ERR_TIMEOUT. */
+int iile_dist_create_deadline(const uint8_t id[IILE_DIST_ID_BYTES], int32_t rank, int32_t nranks, double timeout_s, iile_dist **out);
 void iile_dist_destroy(iile_dist *comm);
+/* Leave without the peers' help (ncclCommAbort) and free the object: for a rank that knows the job is over. */
+void iile_dist_abort(iile_dist *comm);
+/* Everything queued on `stream` so far — the film merge — has completed. A communicator with a deadline waits that long at most
+ * (then: aborted, IILE_ERR_TIMEOUT); one made by iile_dist_create waits as hipStreamSynchronize does. */
+int iile_dist_wait(iile_dist *comm, void *stream);
 int iile_dist_rank(const iile_dist *comm);
 int iile_dist_size(const iile_dist *comm);
 /* ncclCommCount of the communicator as RCCL reports it after ncclCommInitRank (0 if the query failed): bench.py prints it

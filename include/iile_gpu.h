@@ -47,7 +47,8 @@ enum {
     IILE_ERR_ARG = 1,
     IILE_ERR_NO_DEVICE = 2,
     IILE_ERR_HIP = 3,
-    IILE_ERR_UNSUPPORTED = 4
+    IILE_ERR_UNSUPPORTED = 4,
+    IILE_ERR_TIMEOUT = 5      /* libiile_dist: the other ranks did not answer within the communicator's deadline; it was aborted */
 };
 
 typedef struct iile_render_params {
@@ -101,6 +102,11 @@ void iile_device_free(void *dev);
 int iile_device_download(void *dst_host, const void *src_dev, uint64_t bytes, void *stream); /* waits for `stream` */
 int iile_device_upload(void *dst_dev, const void *src_host, uint64_t bytes, void *stream);   /* waits for `stream` */
 int iile_device_zero(void *dev, uint64_t bytes, void *stream);                               /* queued on `stream` */
+/* A HIP stream of the caller's own (non-blocking: it does not synchronise with the null stream) for every `stream` argument of this
+ * header; iile_stream_wait returns when everything queued on it has finished. */
+int iile_stream_create(void **out_stream);
+int iile_stream_wait(void *stream);
+void iile_stream_destroy(void *stream);
 
 int iile_scene_create(const iile_scene_desc *desc, iile_scene **out);
 void iile_scene_destroy(iile_scene *scene);
@@ -151,9 +157,10 @@ int iile_bsdf_sample(iile_scene *scene, int32_t n, int32_t mat, const float *wo3
  * in the probe camera's raster coordinates (the reference's ImageFilm keeps row hemi - 1 - y): intensity RGB,
  * camera-space normals, distances (-1 where the ray escaped). Film, sampler and depth come from
  * iile_scene_desc::probe. outputs_on_device != 0: the three output pointers are device memory (the images stay in
- * HBM for the network); pos3 / dir3 are host memory either way. */
+ * HBM for the network); pos3 / dir3 are host memory either way. `stream`: every copy and kernel of the call is queued on it (NULL =
+ * the null stream); the call returns when they have finished. */
 int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, const float *dir3, float *intensity_rgb,
-                       float *normals_xyz, float *distance, int32_t outputs_on_device, iile_stats *stats);
+                       float *normals_xyz, float *distance, int32_t outputs_on_device, iile_stats *stats, void *stream);
 /* The IISPT integrator's DIRECT pass: what IisptRenderRunner::run_direct
  * (src/integrators/iisptrenderrunner.cpp:601-633) leaves in film_monitor_direct — n_passes calls of
  * DirectProgressiveIntegrator::RenderOnePass (src/integrators/directprogressiveintegrator.cpp:60-150: one camera sample per
@@ -199,10 +206,15 @@ int iile_iispt_gather(iile_scene *scene, const iile_iispt_task *task, const uint
                       const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device);
 /* The same for n_tasks tasks in one set of launches (a 100 x 100-pixel task alone fills a sixth of the chip): every array is
  * the per-task arrays of the single-task calls, task after task — hemi points (valid, pos3, dir3, nn_films) in the tasks'
- * own row-by-row order, film pixels (out_rgbw) row-major per task. Results are those of the single-task calls, bit for bit. */
-int iile_iispt_hemi_points_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, uint8_t *valid, float *pos3, float *dir3);
+ * own row-by-row order, film pixels (out_rgbw) row-major per task. Results are those of the single-task calls, bit for bit.
+ * `stream`: every copy and kernel of the call is queued on it (NULL = the null stream, which the single-task calls use). The whole
+ * indirect pass — these two, iile_render_probes, iile_iispt_net_predict, iile_iispt_film_add — given ONE stream is ordered by that
+ * stream alone (the scene's scratch block is shared by the IISPT calls: calls on one scene go on one stream, or the caller orders
+ * them). hemi_points returns once its host arrays are written; gather with out_on_device returns with its kernels queued. */
+int iile_iispt_hemi_points_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, uint8_t *valid, float *pos3, float *dir3,
+                                 void *stream);
 int iile_iispt_gather_batch(iile_scene *scene, const iile_iispt_task *tasks, int32_t n_tasks, const uint8_t *valid, const float *pos3,
-                            const float *dir3, const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device);
+                            const float *dir3, const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device, void *stream);
 /* The two film monitors of IISPTIntegrator::render_normal_2 (src/integrators/iispt.cpp:357-446), kept in HBM as {r, g, b, weight}
  * double sums per film pixel (IisptPixel, src/integrators/iisptpixel.h):
  *   iile_iispt_film_add    IisptFilmMonitor::add_n_samples (src/integrators/iisptfilmmonitor.cpp:47-72) for every pixel of n_tasks
@@ -228,7 +240,8 @@ int iile_iispt_film_merge(const double *direct_rgbw_dev, const double *indirect_
  *   iile_iispt_net_forward  in_dev: (n, 7, 32, 32) floats as `read_input` (ml/main_stdio_net.py:47-72) builds them; out_dev:
  *                           (n, 3, 32, 32) as `output_to_stdout` (:77-86) reads them; both DEVICE memory. The kernels are
  *                           queued on `stream` (NULL = the null stream) and the call returns; activations live in a workspace
- *                           the object owns (1.19 MiB per probe of a batch, at most max_batch probes at a time; <= 0: 32768).
+ *                           the object owns (1.19 MiB per probe of a batch, at most max_batch probes at a time; <= 0: 8192 — no
+ *                           faster beyond. If the device cannot hold that many the batch is halved until it can: a speed matter only).
  *                           layer_out_dev != NULL (tests): also copies the NHWC output of convolution `layer` (0..13) there. */
 typedef struct iile_iispt_net iile_iispt_net;
 typedef struct iile_iispt_net_weights {

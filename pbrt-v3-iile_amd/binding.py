@@ -133,10 +133,11 @@ GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iil
                "iile_trace_closest", "iile_trace_any", "iile_halton_samples", "iile_camera_rays", "iile_li_samples",
                "iile_bsdf_eval", "iile_bsdf_sample", "iile_trig_probe", "iile_texture_eval", "iile_render_probes",
                "iile_device_select", "iile_device_alloc", "iile_device_free", "iile_device_download", "iile_device_upload", "iile_device_zero",
+               "iile_stream_create", "iile_stream_wait", "iile_stream_destroy",
                "iile_iispt_film_add", "iile_iispt_film_merge",
                "iile_iispt_hemi_points", "iile_iispt_gather", "iile_iispt_hemi_points_batch", "iile_iispt_gather_batch", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct",
                "iile_wide_ref_shift", "iile_render_status", "iile_test_patch_capacity", "iile_iispt_net_create", "iile_iispt_net_load", "iile_iispt_net_forward", "iile_iispt_net_predict", "iile_iispt_net_destroy"]
-DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size", "iile_dist_ranks_seen",
+DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_create_deadline", "iile_dist_abort", "iile_dist_wait", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size", "iile_dist_ranks_seen",
                 "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_rendezvous_file_token", "iile_dist_rendezvous_done", "iile_dist_all_ok",
                 "iile_dist_last_error"]
@@ -242,13 +243,13 @@ def gpu_lib():
         lib.iile_li_samples.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         lib.iile_bsdf_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_texture_eval.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
-        lib.iile_render_probes.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(GpuStats)]
+        lib.iile_render_probes.argtypes = [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(GpuStats), c_vp]
         lib.iile_bsdf_sample.argtypes = [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]
         lib.iile_trig_probe.argtypes = [c_i32, c_vp, c_vp]
         lib.iile_iispt_hemi_points.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_vp, c_vp, c_vp]
         lib.iile_iispt_gather.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32]
-        lib.iile_iispt_hemi_points_batch.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_vp]
-        lib.iile_iispt_gather_batch.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32]
+        lib.iile_iispt_hemi_points_batch.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_vp, c_vp]
+        lib.iile_iispt_gather_batch.argtypes = [c_vp, ctypes.POINTER(IisptTask), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]
         lib.iile_bvh_build_hlbvh.argtypes = [c_i32, c_vp, c_i32, c_vp, ctypes.POINTER(c_i32), c_vp, ctypes.POINTER(BvhBuildStats)]
         lib.iile_bvh_pack_probe.argtypes = [c_i32, c_vp, c_i32, c_vp, c_vp, ctypes.POINTER(c_i32)]
         lib.iile_render_status.argtypes = [c_vp, c_vp]
@@ -278,6 +279,10 @@ def dist_lib():
         lib.iile_dist_last_error.restype = ctypes.c_char_p
         lib.iile_dist_unique_id.argtypes = [c_vp]
         lib.iile_dist_create.argtypes = [c_vp, c_i32, c_i32, ctypes.POINTER(c_vp)]
+        lib.iile_dist_create_deadline.argtypes = [c_vp, c_i32, c_i32, ctypes.c_double, ctypes.POINTER(c_vp)]
+        lib.iile_dist_wait.argtypes = [c_vp, c_vp]
+        lib.iile_dist_abort.argtypes = [c_vp]
+        lib.iile_dist_abort.restype = None
         lib.iile_dist_destroy.argtypes = [c_vp]
         lib.iile_dist_destroy.restype = None
         lib.iile_dist_rank.argtypes = [c_vp]
@@ -305,13 +310,20 @@ class Dist:
             raise RuntimeError(f"iile_dist_unique_id failed: {lib.iile_dist_last_error().decode()}")
         return bytes(buf)
 
-    def __init__(self, unique_id, rank, nranks):
+    def __init__(self, unique_id, rank, nranks, timeout_s=None):
+        """timeout_s: None -> iile_dist_create (RCCL's blocking set-up: a launcher owns the job's tear-down); a number ->
+        iile_dist_create_deadline (non-blocking set-up polled against that deadline, which then bounds every wait on the communicator)."""
         lib = dist_lib()
         self._c = c_vp()
         buf = (ctypes.c_uint8 * DIST_ID_BYTES).from_buffer_copy(unique_id)
-        rc = lib.iile_dist_create(buf, int(rank), int(nranks), ctypes.byref(self._c))
+        if timeout_s is None:
+            rc, what = lib.iile_dist_create(buf, int(rank), int(nranks), ctypes.byref(self._c)), "iile_dist_create"
+        else:
+            rc, what = lib.iile_dist_create_deadline(buf, int(rank), int(nranks), float(timeout_s), ctypes.byref(self._c)), "iile_dist_create_deadline"
         if rc != 0:
-            raise RuntimeError(f"iile_dist_create failed ({rc}): {lib.iile_dist_last_error().decode()}")
+            err = RuntimeError(f"{what} failed ({rc}): {lib.iile_dist_last_error().decode()}")
+            err.code = rc
+            raise err
         self.rank, self.size = int(rank), int(nranks)
         lib.iile_dist_ranks_seen.restype = ctypes.c_int
         lib.iile_dist_ranks_seen.argtypes = [c_vp]
@@ -327,6 +339,20 @@ class Dist:
 
     def barrier(self, stream=None):
         self._check(dist_lib().iile_dist_barrier(self._c, c_vp(stream) if stream else None), "iile_dist_barrier")
+
+    def wait(self, stream=None):
+        """iile_dist_wait: what was queued on `stream` (the film merge) has finished, or the communicator's deadline has passed."""
+        self._check(dist_lib().iile_dist_wait(self._c, c_vp(stream) if stream else None), "iile_dist_wait")
+
+    def all_ok(self, ok):
+        out = c_i32(0)
+        self._check(dist_lib().iile_dist_all_ok(self._c, 1 if ok else 0, ctypes.byref(out)), "iile_dist_all_ok")
+        return bool(out.value)
+
+    def abort(self):
+        if self._c:
+            dist_lib().iile_dist_abort(self._c)
+            self._c = c_vp()
 
     def sum_u64(self, values):
         a = np.ascontiguousarray(values, dtype=np.uint64).copy()
@@ -560,12 +586,12 @@ class GpuScene:
                     "iile_bsdf_eval")
         return out
 
-    def render_probes(self, pos, direction, hemi=None, device_out=None):
+    def render_probes(self, pos, direction, hemi=None, device_out=None, stream=None):
         """IISPT probe pass: (n, 3) origins and directions -> intensity (n, hemi, hemi, 3), camera-space normals
         (n, hemi, hemi, 3), distances (n, hemi, hemi), [y][x] in raster order; plus the stats dict. hemi is the
         scene's probe film size (iile_scene_desc::probe.hemi_size through iile_host_scene_get_info); passing another
         value is an error. device_out: three device pointers (ints), each with room for n * hemi * hemi pixels, to
-        write the images to instead (they then stay in HBM)."""
+        write the images to instead (they then stay in HBM). stream: the HIP stream the pass is queued on (None: the null stream)."""
         pos, direction = _f32(pos).reshape(-1, 3), _f32(direction).reshape(-1, 3)
         n = len(pos)
         scene_hemi = int(self.host.info["probe_hemi_size"])
@@ -575,13 +601,13 @@ class GpuScene:
         st = GpuStats()
         if device_out is not None:
             self._check(gpu_lib().iile_render_probes(self._s, n, pos.ctypes.data, direction.ctypes.data, device_out[0], device_out[1],
-                                                     device_out[2], 1, ctypes.byref(st)), "iile_render_probes")
+                                                     device_out[2], 1, ctypes.byref(st), stream), "iile_render_probes")
             return None, None, None, st.as_dict()
         inten = np.zeros((n, hemi, hemi, 3), np.float32)
         nrm = np.zeros((n, hemi, hemi, 3), np.float32)
         dist = np.zeros((n, hemi, hemi), np.float32)
         self._check(gpu_lib().iile_render_probes(self._s, n, pos.ctypes.data, direction.ctypes.data, inten.ctypes.data,
-                                                 nrm.ctypes.data, dist.ctypes.data, 0, ctypes.byref(st)), "iile_render_probes")
+                                                 nrm.ctypes.data, dist.ctypes.data, 0, ctypes.byref(st), stream), "iile_render_probes")
         return inten, nrm, dist, st.as_dict()
 
     def iispt_hemi_points(self, task):
@@ -607,23 +633,23 @@ class GpuScene:
                     "iile_iispt_gather")
         return out
 
-    def iispt_hemi_points_batch(self, tasks):
+    def iispt_hemi_points_batch(self, tasks, stream=None):
         """iile_iispt_hemi_points_batch: the hemi points of several tasks from one set of launches — (valid (n,), origins (n, 3),
-        directions (n, 3)) with the tasks' hemi points one task after the other, each in its own row-by-row order."""
+        directions (n, 3)) with the tasks' hemi points one task after the other, each in its own row-by-row order. stream: the HIP
+        stream the call's copies and kernels are queued on (None: the null stream)."""
         arr = (IisptTask * len(tasks))(*tasks)
         n = sum(t.grid()[0] * t.grid()[1] for t in tasks)
         valid, pos, dr = np.zeros(n, np.uint8), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
-        self._check(gpu_lib().iile_iispt_hemi_points_batch(self._s, arr, len(tasks), valid.ctypes.data, pos.ctypes.data, dr.ctypes.data),
+        self._check(gpu_lib().iile_iispt_hemi_points_batch(self._s, arr, len(tasks), valid.ctypes.data, pos.ctypes.data, dr.ctypes.data, stream),
                     "iile_iispt_hemi_points_batch")
         return valid, pos, dr
 
-    def iispt_gather_batch(self, tasks, valid, pos, direction, nn_films=None, nn_device_ptr=None, out_device_ptr=None):
+    def iispt_gather_batch(self, tasks, valid, pos, direction, nn_films=None, nn_device_ptr=None, out_device_ptr=None, stream=None):
         """iile_iispt_gather_batch: the per-pixel loop of several tasks from one set of launches. valid / pos / direction / nn_films
         (n_hemi, 32, 32, 3) as iispt_hemi_points_batch orders them; the result is (n_pixels, 4), the tasks' pixels one task after the
         other, row-major inside a task (None when written to out_device_ptr).
-        With out_device_ptr the call returns once its kernels are queued on the NULL stream and they read the scene's shared
-        scratch block: consume the output on the null stream (PyTorch's default stream is that stream) or synchronise the device
-        first — the C ABI has no stream argument for this call."""
+        With out_device_ptr the call returns once its kernels are queued on `stream` (None: the null stream, which is PyTorch's
+        default stream); they read the scene's shared scratch block: keep a scene's IISPT calls on one stream."""
         arr = (IisptTask * len(tasks))(*tasks)
         valid, pos, direction = np.ascontiguousarray(valid, np.uint8), _f32(pos), _f32(direction)
         n_pix = sum((t.x1 - t.x0) * (t.y1 - t.y0) for t in tasks)
@@ -631,7 +657,7 @@ class GpuScene:
         nn = _f32(nn_films) if nn_device_ptr is None else None
         self._check(gpu_lib().iile_iispt_gather_batch(self._s, arr, len(tasks), valid.ctypes.data, pos.ctypes.data, direction.ctypes.data,
                                                       nn.ctypes.data if nn is not None else c_vp(int(nn_device_ptr)), int(nn is None),
-                                                      out.ctypes.data if out is not None else c_vp(int(out_device_ptr)), int(out is None)),
+                                                      out.ctypes.data if out is not None else c_vp(int(out_device_ptr)), int(out is None), stream),
                     "iile_iispt_gather_batch")
         return out
 

@@ -16,7 +16,8 @@
 // communicator of one rank).
 // Multi-GPU: start N copies, one per GPU, with --gpurank 0/N .. N-1/N and a common --rendezvous file on a shared
 // file system (rank 0 publishes the RCCL id there; --job TOKEN, any number the launcher picks per launch, ties the file
-// to this launch). Rank R uses GPU R modulo the visible devices, renders its tiles
+// to this launch; a rank that does not show up within $IILE_DIST_TIMEOUT_S — default 120 s — makes the others exit 1 instead of
+// waiting for ever). Rank R uses GPU R modulo the visible devices, renders its tiles
 // and the films are merged on rank 0 by one RCCL reduction (include/iile_dist.h); rank 0 writes the image.
 // --gpurank 0/1 is the same code path with a communicator of one rank (tools/multi_gpu_cmdline.sh prints the N-rank
 // command lines).
@@ -161,10 +162,16 @@ int main(int argc, char **argv) {
             fprintf(stderr, "Error: GPU path: %s\n", n_dev < 1 ? "no HIP device" : iile_last_error());
             return 1;
         }
+        // no launcher tears this job down if a rank is missing: the communicator carries a deadline ($IILE_DIST_TIMEOUT_S, default
+        // 120 s) — set-up and every later wait on it end with an error instead of hanging (include/iile_dist.h)
+        double timeout_s = 120.0;
+        if (const char *e = getenv("IILE_DIST_TIMEOUT_S")) timeout_s = atof(e) > 0 ? atof(e) : timeout_s;
         uint8_t id[IILE_DIST_ID_BYTES];
-        if (iile_dist_rendezvous_file_token(rendezvous.c_str(), gpu_rank, job_token, id, 120) != IILE_OK ||
-            iile_dist_create(id, gpu_rank, gpu_nranks, &comm) != IILE_OK || iile_dist_rendezvous_done(comm, rendezvous.c_str()) != IILE_OK) {
+        if (iile_dist_rendezvous_file_token(rendezvous.c_str(), gpu_rank, job_token, id, int(timeout_s + 0.999)) != IILE_OK ||
+            iile_dist_create_deadline(id, gpu_rank, gpu_nranks, timeout_s, &comm) != IILE_OK ||
+            iile_dist_rendezvous_done(comm, rendezvous.c_str()) != IILE_OK) {
             fprintf(stderr, "Error: multi-GPU set-up: %s\n", iile_dist_last_error());
+            if (comm) iile_dist_abort(comm);
             return 1;
         }
     }
@@ -187,7 +194,10 @@ int main(int argc, char **argv) {
     std::unique_ptr<iile::GpuPathIntegrator> integrator(iile::CreateGpuPathIntegrator(ps, out, 0, 1, stats, comm));
     if (!ranked) integrator->UseDevices(gpus_given ? gpus : 0);
     const bool ok = integrator->Render(scene);
-    if (comm) iile_dist_destroy(comm);
+    if (comm) {
+        if (ok) iile_dist_destroy(comm);
+        else iile_dist_abort(comm);   // (the job is over: do not wait for the other ranks in ncclCommDestroy)
+    }
     if (!ok) return 1;
     if (gpu_rank != 0) return 0;
     const iile_stats &st = integrator->last_stats;

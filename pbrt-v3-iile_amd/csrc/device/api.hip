@@ -549,6 +549,24 @@ int iile_device_upload(void *dst_dev, const void *src_host, uint64_t bytes, void
     HIP_TRY(hipStreamSynchronize(s));   // (the host buffer may be reused on return)
     return IILE_OK;
 }
+// A stream of the caller's own for hosts built without hipcc (the C++ IISPT host runs its whole indirect pass on one): a
+// non-blocking stream, i.e. one that does not synchronise with the null stream.
+int iile_stream_create(void **out_stream) {
+    if (!out_stream) return fail(IILE_ERR_ARG, "iile_stream_create: null argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out_stream = s;
+    return IILE_OK;
+}
+int iile_stream_wait(void *stream) {
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return IILE_OK;
+}
+void iile_stream_destroy(void *stream) {
+    if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+}
 int iile_device_zero(void *dev, uint64_t bytes, void *stream) {
     if (!dev) return fail(IILE_ERR_ARG, "iile_device_zero: null argument");
     HIP_TRY(hipMemsetAsync(dev, 0, size_t(bytes), static_cast<hipStream_t>(stream)));
@@ -1991,7 +2009,7 @@ bool make_probe_camera(const float *pos, const float *dir, DProbeCam *cam) {
 }  // namespace
 
 int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, const float *dir3, float *intensity_rgb, float *normals_xyz,
-                       float *distance, int32_t outputs_on_device, iile_stats *stats) {
+                       float *distance, int32_t outputs_on_device, iile_stats *stats, void *stream_arg) {
     if (!sc || n_probes < 0 || !pos3 || !dir3 || !intensity_rgb || !normals_xyz || !distance)
         return fail(IILE_ERR_ARG, "iile_render_probes: null argument");
     int rc = ensure_device();
@@ -2055,7 +2073,7 @@ int iile_render_probes(iile_scene *sc, int32_t n_probes, const float *pos3, cons
         if (!make_probe_camera(pos3 + 3 * size_t(i), dir3 + 3 * size_t(i), &cams[size_t(i)]))
             return fail(IILE_ERR_ARG, "iile_render_probes: degenerate probe direction (probe " + std::to_string(i) + ")");
 
-    hipStream_t stream = nullptr;
+    hipStream_t stream = static_cast<hipStream_t>(stream_arg);
     LaunchCfg cfg{sc->n_cus, stream, false};
     const uint64_t batch_paths = uint64_t(batch) * slots_per_probe;
     rc = ensure_workspace(sc, uint32_t(batch_paths));
@@ -2197,33 +2215,34 @@ void carve_slice(iile_scene *sc, IisptSlice *sl) {
     }
 }
 
-int hemi_points_slice(iile_scene *sc, const iile_iispt_task *tasks, int n_tasks, uint8_t *valid, float *pos3, float *dir3) {
+int hemi_points_slice(iile_scene *sc, const iile_iispt_task *tasks, int n_tasks, uint8_t *valid, float *pos3, float *dir3, hipStream_t s) {
     IisptSlice sl;
     int rc = plan_slice(sc, tasks, n_tasks, false, &sl);
     if (rc) return rc;
     const size_t n = sl.n_hemi;
-    if ((rc = scratch_reserve(sc, slice_item_bytes(sl) + carve_bytes(n, 1) + 2 * carve_bytes(3 * n, sizeof(float)), nullptr))) return rc;
+    if ((rc = scratch_reserve(sc, slice_item_bytes(sl) + carve_bytes(n, 1) + 2 * carve_bytes(3 * n, sizeof(float)), s))) return rc;
     carve_slice(sc, &sl);
     uint8_t *dv = scratch_take<uint8_t>(sc, n);
     float *dp = scratch_take<float>(sc, 3 * n), *dd = scratch_take<float>(sc, 3 * n);
     for (size_t k = 0; k < sl.jobs.size(); ++k)
         sl.jobs[k].valid = dv + sl.hemi_off[k], sl.jobs[k].pos3 = dp + 3 * sl.hemi_off[k], sl.jobs[k].dir3 = dd + 3 * sl.hemi_off[k];
-    // (synchronous copies on the null stream: each follows whatever used the block last, and the kernels before it)
-    HIP_TRY(hipMemcpy(sl.d_jobs, sl.jobs.data(), sl.jobs.size() * sizeof(IisptJob), hipMemcpyHostToDevice));
+    // (everything in the caller's stream's order: the copy follows whatever that stream did with the block last, the kernels follow it)
+    HIP_TRY(hipMemcpyAsync(sl.d_jobs, sl.jobs.data(), sl.jobs.size() * sizeof(IisptJob), hipMemcpyHostToDevice, s));
     DScene S = sc->ds;
     S.diff_scale = 1.f;  // r.ScaleDifferentials(1.0), iisptrenderrunner.cpp:272
-    LaunchCfg cfg{sc->n_cus, nullptr, false};
+    LaunchCfg cfg{sc->n_cus, s, false};
     launch_iispt_first_hits(S, sl.d_jobs, n_tasks, sl.max_items, sl.n_active, sc->spill, cfg);
     launch_iispt_hemi_out(S, sl.d_jobs, n_tasks, sl.max_hemi, cfg);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(valid, dv, n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pos3, dp, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(dir3, dd, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(valid, dv, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pos3, dp, 3 * n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dir3, dd, 3 * n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));   // (the results are for the host, and `sl` dies with this call)
     return IILE_OK;
 }
 
 int gather_slice(iile_scene *sc, const iile_iispt_task *tasks, int n_tasks, const uint8_t *valid, const float *pos3, const float *dir3,
-                 const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
+                 const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device, hipStream_t s) {
     IisptSlice sl;
     int rc = plan_slice(sc, tasks, n_tasks, true, &sl);
     if (rc) return rc;
@@ -2255,7 +2274,7 @@ int gather_slice(iile_scene *sc, const iile_iispt_task *tasks, int n_tasks, cons
     const size_t per_hemi = size_t(hemi) * hemi * 3, nn_floats = n * per_hemi;
     if ((rc = scratch_reserve(sc, slice_item_bytes(sl) + carve_bytes(n, sizeof(DHemiCam)) + carve_bytes(jac.size(), sizeof(float)) +
                                       (nn_on_device ? 0 : carve_bytes(nn_floats, sizeof(float))) + (out_on_device ? 0 : carve_bytes(n_pix, sizeof(float4))),
-                              nullptr)))
+                              s)))
         return rc;
     carve_slice(sc, &sl);
     DHemiCam *dc = scratch_take<DHemiCam>(sc, n);
@@ -2267,32 +2286,36 @@ int gather_slice(iile_scene *sc, const iile_iispt_task *tasks, int n_tasks, cons
     if (!out_on_device) out_dev = scratch_take<float4>(sc, n_pix);
     for (size_t k = 0; k < sl.jobs.size(); ++k)
         sl.jobs[k].cams = dc + sl.hemi_off[k], sl.jobs[k].nn_films = nn_dev + sl.hemi_off[k] * per_hemi, sl.jobs[k].out = out_dev + sl.pix_off[k];
-    // (synchronous copies from these short-lived host vectors; on the null stream they also follow whatever used the block last)
-    HIP_TRY(hipMemcpy(sl.d_jobs, sl.jobs.data(), sl.jobs.size() * sizeof(IisptJob), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dc, cams.data(), n * sizeof(DHemiCam), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dj, jac.data(), jac.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (dnn) HIP_TRY(hipMemcpy(dnn, nn_films, nn_floats * sizeof(float), hipMemcpyHostToDevice));
+    // (copies from these short-lived host vectors, in the caller's stream's order: they follow whatever that stream did with the block
+    // last — and the network's kernels that wrote nn_films, when the caller queued them on the same stream)
+    HIP_TRY(hipMemcpyAsync(sl.d_jobs, sl.jobs.data(), sl.jobs.size() * sizeof(IisptJob), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dc, cams.data(), n * sizeof(DHemiCam), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dj, jac.data(), jac.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    if (dnn) HIP_TRY(hipMemcpyAsync(dnn, nn_films, nn_floats * sizeof(float), hipMemcpyHostToDevice, s));
     DScene S = sc->ds;
     S.diff_scale = 1.f;
-    LaunchCfg cfg{sc->n_cus, nullptr, false};
-    launch_iispt_first_hits(S, sl.d_jobs, n_tasks, sl.max_items, sl.n_active, sc->spill, cfg);
+    LaunchCfg cfg{sc->n_cus, s, false};
+    launch_iispt_first_hits(S, sl.d_jobs, n_tasks, sl.max_items, sl.n_active, sc->spill, cfg);   // (waits on the stream between its rounds: the vectors above are consumed)
     launch_iispt_gather(S, sl.d_jobs, n_tasks, sl.max_pix, dj, cfg);
     HIP_TRY(hipGetLastError());
-    // Results on the device: the kernels are in the null stream's order and the call returns (the caller's next use of the
-    // output, on that stream or one that synchronises with it, follows them). Results for the host: the copy waits.
-    if (!out_on_device) HIP_TRY(hipMemcpy(out_rgbw, out_dev, n_pix * sizeof(float4), hipMemcpyDeviceToHost));
+    // Results on the device: the kernels are in the stream's order and the call returns (the caller's next use of the output, on that
+    // stream or one that synchronises with it, follows them). Results for the host: the copy waits.
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out_rgbw, out_dev, n_pix * sizeof(float4), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     return IILE_OK;
 }
 }  // namespace
 
-int iile_iispt_hemi_points_batch(iile_scene *sc, const iile_iispt_task *tasks, int32_t n_tasks, uint8_t *valid, float *pos3, float *dir3) {
+int iile_iispt_hemi_points_batch(iile_scene *sc, const iile_iispt_task *tasks, int32_t n_tasks, uint8_t *valid, float *pos3, float *dir3, void *stream) {
     if (!sc || !tasks || n_tasks < 1) return fail(IILE_ERR_ARG, "iile_iispt_hemi_points: no task");
     if (!valid || !pos3 || !dir3) return fail(IILE_ERR_ARG, "iile_iispt_hemi_points: null output");
     size_t first = 0;
     const int slice = iispt_slice_jobs(sc);
     for (int k0 = 0; k0 < n_tasks; k0 += slice) {
         const int nk = std::min(slice, n_tasks - k0);
-        const int rc = hemi_points_slice(sc, tasks + k0, nk, valid + first, pos3 + 3 * first, dir3 + 3 * first);
+        const int rc = hemi_points_slice(sc, tasks + k0, nk, valid + first, pos3 + 3 * first, dir3 + 3 * first, static_cast<hipStream_t>(stream));
         if (rc) return rc;
         for (int k = k0; k < k0 + nk; ++k)
             first += size_t(iile_iispt_grid_count(tasks[k].x0, tasks[k].x1, tasks[k].tilesize)) * size_t(iile_iispt_grid_count(tasks[k].y0, tasks[k].y1, tasks[k].tilesize));
@@ -2300,11 +2323,11 @@ int iile_iispt_hemi_points_batch(iile_scene *sc, const iile_iispt_task *tasks, i
     return IILE_OK;
 }
 int iile_iispt_hemi_points(iile_scene *sc, const iile_iispt_task *t, uint8_t *valid, float *pos3, float *dir3) {
-    return iile_iispt_hemi_points_batch(sc, t, 1, valid, pos3, dir3);
+    return iile_iispt_hemi_points_batch(sc, t, 1, valid, pos3, dir3, nullptr);
 }
 
 int iile_iispt_gather_batch(iile_scene *sc, const iile_iispt_task *tasks, int32_t n_tasks, const uint8_t *valid, const float *pos3, const float *dir3,
-                            const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
+                            const float *nn_films, int32_t nn_on_device, float *out_rgbw, int32_t out_on_device, void *stream) {
     if (!sc || !tasks || n_tasks < 1) return fail(IILE_ERR_ARG, "iile_iispt_gather: no task");
     if (!valid || !pos3 || !dir3 || !nn_films || !out_rgbw) return fail(IILE_ERR_ARG, "iile_iispt_gather: null argument");
     const size_t per_hemi = size_t(sc->probe.hemi_size) * sc->probe.hemi_size * 3;
@@ -2313,7 +2336,7 @@ int iile_iispt_gather_batch(iile_scene *sc, const iile_iispt_task *tasks, int32_
     for (int k0 = 0; k0 < n_tasks; k0 += slice) {
         const int nk = std::min(slice, n_tasks - k0);
         const int rc = gather_slice(sc, tasks + k0, nk, valid + first_h, pos3 + 3 * first_h, dir3 + 3 * first_h, nn_films + first_h * per_hemi, nn_on_device,
-                                    out_rgbw + 4 * first_p, out_on_device);
+                                    out_rgbw + 4 * first_p, out_on_device, static_cast<hipStream_t>(stream));
         if (rc) return rc;
         for (int k = k0; k < k0 + nk; ++k) {
             first_h += size_t(iile_iispt_grid_count(tasks[k].x0, tasks[k].x1, tasks[k].tilesize)) * size_t(iile_iispt_grid_count(tasks[k].y0, tasks[k].y1, tasks[k].tilesize));
@@ -2374,7 +2397,7 @@ int iile_iispt_film_merge(const double *direct_rgbw_dev, const double *indirect_
 
 int iile_iispt_gather(iile_scene *sc, const iile_iispt_task *t, const uint8_t *valid, const float *pos3, const float *dir3, const float *nn_films,
                       int32_t nn_on_device, float *out_rgbw, int32_t out_on_device) {
-    return iile_iispt_gather_batch(sc, t, 1, valid, pos3, dir3, nn_films, nn_on_device, out_rgbw, out_on_device);
+    return iile_iispt_gather_batch(sc, t, 1, valid, pos3, dir3, nn_films, nn_on_device, out_rgbw, out_on_device, nullptr);
 }
 
 // ---- kernel-level entry points ---------------------------------------------

@@ -30,8 +30,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -791,17 +793,35 @@ std::vector<uint16_t> pack_weights(const LayerDef &L, const float *w) {
     return out;
 }
 
-int ensure_workspace(iile_iispt_net *net, int n) {
-    if (n <= net->ws_probes) return IILE_OK;
+// The activation workspace for up to *cap probes per set of launches (1.19 MiB + 16 B each). The batch is a speed knob only (results do
+// not depend on it, tests/test_iispt_nn.py): if the device cannot give that much — a smaller card, or one shared with another job — the
+// batch is halved until the allocation succeeds (down to 64 probes) and *cap says what was got. IILE_NET_WORKSPACE_MB caps the
+// allocation from outside (tests use it to walk this path on a 288 GB device).
+constexpr int kDefaultBatch = 8192;   // probes per set of launches when the caller names none: 9.5 GiB of activations; no faster beyond (tools/net_check.py)
+int ensure_workspace(iile_iispt_net *net, int *cap) {
+    if (*cap <= net->ws_probes) return IILE_OK;
     if (net->ws) (void)hipFree(net->ws);
     net->ws = nullptr;
     net->ws_probes = 0;
     size_t per = 0;
     for (size_t f : kBufFloats) per += f;
     net->ws_floats_per_probe = per;
-    NET_TRY(hipMalloc(reinterpret_cast<void **>(&net->ws), (per + 4) * sizeof(float) * size_t(n)));   // + the channel means of a probe
-    net->ws_probes = n;
-    return IILE_OK;
+    size_t limit = ~size_t(0);
+    if (const char *e = std::getenv("IILE_NET_WORKSPACE_MB")) limit = size_t(std::max(1.0, atof(e)) * 1048576.0);
+    for (int n = *cap;; n = (n + 1) / 2) {
+        const size_t bytes = (per + 4) * sizeof(float) * size_t(n);   // + the channel means of a probe
+        hipError_t e = bytes > limit ? hipErrorOutOfMemory : hipMalloc(reinterpret_cast<void **>(&net->ws), bytes);
+        if (e == hipSuccess) {
+            net->ws_probes = n;
+            *cap = n;
+            return IILE_OK;
+        }
+        (void)hipGetLastError();
+        net->ws = nullptr;
+        if (e != hipErrorOutOfMemory || n <= 64)
+            return iile::api_fail(IILE_ERR_HIP, std::string("iile_iispt_net: no room for the activations of ") + std::to_string(n) + " probes (" +
+                                                    std::to_string(bytes >> 20) + " MiB): " + hipGetErrorString(e));
+    }
 }
 
 float *buffer_of(iile_iispt_net *net, int buf, int n_alloc) {
@@ -942,10 +962,10 @@ int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_
     if (!net || !in_dev || !out_dev || n < 0) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_forward: bad argument");
     if (layer_out_dev && (layer < 0 || layer > 13)) return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_forward: layer out of range");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (max_batch <= 0) max_batch = 32768;
-    const int cap = n < max_batch ? n : max_batch;
+    if (max_batch <= 0) max_batch = kDefaultBatch;
+    int cap = n < max_batch ? n : max_batch;
     if (n == 0) return IILE_OK;
-    int rc = ensure_workspace(net, cap);
+    int rc = ensure_workspace(net, &cap);
     if (rc) return rc;
     const int na = net->ws_probes;
     for (int first = 0; first < n; first += cap) {
@@ -967,10 +987,10 @@ int iile_iispt_net_predict(iile_iispt_net *net, const float *intensity_dev, cons
     if (!net || !intensity_dev || !normals_dev || !distance_dev || !pred_dev || n < 0)
         return iile::api_fail(IILE_ERR_ARG, "iile_iispt_net_predict: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (max_batch <= 0) max_batch = 32768;
-    const int cap = n < max_batch ? n : max_batch;
+    if (max_batch <= 0) max_batch = kDefaultBatch;
+    int cap = n < max_batch ? n : max_batch;
     if (n == 0) return IILE_OK;
-    int rc = ensure_workspace(net, cap);
+    int rc = ensure_workspace(net, &cap);
     if (rc) return rc;
     const int na = net->ws_probes;
     float *means = net->ws + net->ws_floats_per_probe * size_t(na);   // 3 floats per probe behind the activation buffers

@@ -39,6 +39,12 @@ static_assert(sizeof(ncclUniqueId) == IILE_DIST_ID_BYTES, "RCCL unique id size")
 struct iile_dist {
     ncclComm_t comm = nullptr;
     int rank = 0, size = 1;
+    // > 0: the communicator was made by iile_dist_create_deadline — non-blocking in RCCL's sense (a call may return
+    // ncclInProgress; settle() polls it to its end), and nothing on it waits longer than this many seconds for the other ranks:
+    // when a wait expires the communicator is aborted (ncclCommAbort: local, needs no peer), `dead` is set and every later call
+    // fails at once. 0: made by iile_dist_create — RCCL's blocking calls; a launcher with its own tear-down owns the job.
+    double timeout_s = 0.0;
+    bool dead = false;
     void *scratch = nullptr;  // device staging of the small host-side totals
     size_t scratch_bytes = 0;
     // the host-value collectives (iile_dist_sum_u64 / _max_f64 / _all_ok) run on a non-blocking stream of the communicator's
@@ -48,6 +54,62 @@ struct iile_dist {
 };
 
 namespace {
+using Clock = std::chrono::steady_clock;
+double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+// give the communicator up without the peers' help; later calls on it fail at once
+int expire(iile_dist *d, const std::string &what) {
+    if (d->comm) (void)ncclCommAbort(d->comm);
+    d->comm = nullptr;
+    d->dead = true;
+    return fail(IILE_ERR_TIMEOUT, what + ": no answer from the other ranks within " + std::to_string(int(d->timeout_s + 0.5)) +
+                                      " s; the communicator was aborted (a rank that failed or never started?)");
+}
+// r = what an RCCL call on d->comm returned. Blocking communicators: success or an error. Non-blocking ones: ncclInProgress means
+// "still being set up / enqueued" — poll ncclCommGetAsyncError until it settles or the communicator's deadline passes.
+int settle(iile_dist *d, ncclResult_t r, const char *what) {
+    if (r == ncclInProgress && d->timeout_s > 0) {
+        const Clock::time_point t0 = Clock::now();
+        for (;;) {
+            ncclResult_t q = ncclInProgress;
+            if (ncclCommGetAsyncError(d->comm, &q) != ncclSuccess) q = ncclSystemError;
+            if (q != ncclInProgress) {
+                r = q;
+                break;
+            }
+            if (seconds_since(t0) > d->timeout_s) return expire(d, what);
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    if (r != ncclSuccess) return fail(IILE_ERR_HIP, std::string(what) + ": " + ncclGetErrorString(r));
+    return IILE_OK;
+}
+// wait for `stream` (where a collective was queued): forever on a blocking communicator, at most the deadline on the other kind
+int wait_stream(iile_dist *d, hipStream_t stream, const char *what) {
+    if (d->timeout_s <= 0) {
+        HIPD_TRY(hipStreamSynchronize(stream));
+        return IILE_OK;
+    }
+    const Clock::time_point t0 = Clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return IILE_OK;
+        if (e != hipErrorNotReady) return fail(IILE_ERR_HIP, std::string(what) + ": hipStreamQuery: " + hipGetErrorString(e));
+        ncclResult_t q = ncclSuccess;
+        if (ncclCommGetAsyncError(d->comm, &q) == ncclSuccess && q != ncclSuccess && q != ncclInProgress) {
+            const std::string msg = std::string(what) + ": " + ncclGetErrorString(q);
+            (void)ncclCommAbort(d->comm);
+            d->comm = nullptr;
+            d->dead = true;
+            return fail(IILE_ERR_HIP, msg);
+        }
+        if (seconds_since(t0) > d->timeout_s) return expire(d, what);
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
+#define DEAD_CHECK(d, name) \
+    if ((d)->dead || !(d)->comm) return fail(IILE_ERR_TIMEOUT, name ": the communicator was aborted by an earlier call")
+
 int ensure_scratch(iile_dist *d, size_t bytes) {
     if (bytes <= d->scratch_bytes) return IILE_OK;
     if (d->scratch) HIPD_TRY(hipFree(d->scratch));
@@ -60,15 +122,15 @@ int ensure_scratch(iile_dist *d, size_t bytes) {
 template <typename T>
 int all_reduce_host(iile_dist *d, T *values, int n, ncclDataType_t type, ncclRedOp_t op) {
     if (!d || !values || n < 0) return fail(IILE_ERR_ARG, "iile_dist: bad argument");
+    DEAD_CHECK(d, "iile_dist");
     if (n == 0) return IILE_OK;
     int rc = ensure_scratch(d, size_t(n) * sizeof(T));
     if (rc) return rc;
     if (!d->host_stream) HIPD_TRY(hipStreamCreateWithFlags(&d->host_stream, hipStreamNonBlocking));
     HIPD_TRY(hipMemcpyAsync(d->scratch, values, size_t(n) * sizeof(T), hipMemcpyHostToDevice, d->host_stream));
-    NCCL_TRY(ncclAllReduce(d->scratch, d->scratch, size_t(n), type, op, d->comm, d->host_stream));
+    if ((rc = settle(d, ncclAllReduce(d->scratch, d->scratch, size_t(n), type, op, d->comm, d->host_stream), "ncclAllReduce"))) return rc;
     HIPD_TRY(hipMemcpyAsync(values, d->scratch, size_t(n) * sizeof(T), hipMemcpyDeviceToHost, d->host_stream));
-    HIPD_TRY(hipStreamSynchronize(d->host_stream));  // the caller wants the values: it waits for THIS stream only
-    return IILE_OK;
+    return wait_stream(d, d->host_stream, "iile_dist: host totals");  // the caller wants the values: it waits for THIS stream only
 }
 }  // namespace
 
@@ -105,12 +167,70 @@ int iile_dist_create(const uint8_t id[IILE_DIST_ID_BYTES], int32_t rank, int32_t
     return IILE_OK;
 }
 
+// The communicator for hosts that have no launcher to tear a stuck job down (several threads of one process, iile_pbrt
+// --gpurank): RCCL's non-blocking set-up (ncclCommInitRankConfig, blocking = 0) polled against a deadline. A rank that never
+// arrives — it failed before this call, or was never started — makes every other rank's call return IILE_ERR_TIMEOUT after
+// timeout_s seconds instead of waiting in ncclCommInitRank for ever, and the same deadline bounds every later wait on the
+// communicator (iile_dist_wait, the host totals, iile_dist_all_ok).
+int iile_dist_create_deadline(const uint8_t id[IILE_DIST_ID_BYTES], int32_t rank, int32_t nranks, double timeout_s, iile_dist **out) {
+    if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks || !(timeout_s > 0)) return fail(IILE_ERR_ARG, "iile_dist_create_deadline: bad argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(IILE_ERR_NO_DEVICE, "iile_dist_create: no HIP device (the film merge runs on the GPUs)");
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    iile_dist *d = new iile_dist;
+    d->rank = rank;
+    d->size = nranks;
+    d->timeout_s = timeout_s;
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;
+    ncclResult_t r = ncclCommInitRankConfig(&d->comm, nranks, u, rank, &cfg);
+    int rc = (r == ncclSuccess || r == ncclInProgress) && d->comm ? settle(d, r, "ncclCommInitRankConfig")
+                                                                    : fail(IILE_ERR_HIP, std::string("ncclCommInitRankConfig: ") + ncclGetErrorString(r));
+    if (rc) {
+        const std::string keep = g_err;
+        if (d->comm) (void)ncclCommAbort(d->comm);
+        delete d;
+        g_err = keep;
+        return rc;
+    }
+    if (ncclCommCount(d->comm, &d->ranks_seen) != ncclSuccess) d->ranks_seen = 0;
+    *out = d;
+    return IILE_OK;
+}
+
 void iile_dist_destroy(iile_dist *d) {
     if (!d) return;
     if (d->host_stream) (void)hipStreamDestroy(d->host_stream);
     if (d->scratch) (void)hipFree(d->scratch);
-    if (d->comm) (void)ncclCommDestroy(d->comm);
+    if (d->comm) {
+        // a non-blocking communicator is finalised first and given its deadline to finish; one that does not is aborted
+        if (d->timeout_s > 0) {
+            if (settle(d, ncclCommFinalize(d->comm), "ncclCommFinalize") == IILE_OK && d->comm) (void)ncclCommDestroy(d->comm);
+            else if (d->comm) (void)ncclCommAbort(d->comm);
+        } else {
+            (void)ncclCommDestroy(d->comm);
+        }
+    }
     delete d;
+}
+
+// Leave without the peers: ncclCommAbort frees the communicator locally whatever the other ranks are doing (a rank that
+// learned — from its own error or from the gang's vote — that the job is over must not wait in ncclCommDestroy for them).
+void iile_dist_abort(iile_dist *d) {
+    if (!d) return;
+    if (d->comm) (void)ncclCommAbort(d->comm);
+    d->comm = nullptr;
+    iile_dist_destroy(d);
+}
+
+// Everything queued on `stream` so far (the film merge) has completed — or the communicator's deadline has passed, in which
+// case it is aborted and the call fails. On a communicator made by iile_dist_create this is hipStreamSynchronize.
+int iile_dist_wait(iile_dist *d, void *stream) {
+    if (!d) return fail(IILE_ERR_ARG, "iile_dist_wait: null communicator");
+    DEAD_CHECK(d, "iile_dist_wait");
+    return wait_stream(d, static_cast<hipStream_t>(stream), "iile_dist_wait (film merge)");
 }
 
 int iile_dist_rank(const iile_dist *d) { return d ? d->rank : 0; }
@@ -119,18 +239,18 @@ int iile_dist_ranks_seen(const iile_dist *d) { return d ? d->ranks_seen : 0; }
 
 int iile_dist_film_reduce(iile_dist *d, float *film, int64_t n_pixels, int32_t root, void *stream) {
     if (!d || !film || n_pixels < 0 || root < 0 || root >= d->size) return fail(IILE_ERR_ARG, "iile_dist_film_reduce: bad argument");
+    DEAD_CHECK(d, "iile_dist_film_reduce");
     if (n_pixels == 0) return IILE_OK;
     // in place: sendbuff == recvbuff; RCCL leaves the non-root buffers as they are
-    NCCL_TRY(ncclReduce(film, film, size_t(n_pixels) * 4, ncclFloat32, ncclSum, root, d->comm, static_cast<hipStream_t>(stream)));
-    return IILE_OK;
+    return settle(d, ncclReduce(film, film, size_t(n_pixels) * 4, ncclFloat32, ncclSum, root, d->comm, static_cast<hipStream_t>(stream)), "ncclReduce");
 }
 
 int iile_dist_barrier(iile_dist *d, void *stream) {
     if (!d) return fail(IILE_ERR_ARG, "iile_dist_barrier: null communicator");
+    DEAD_CHECK(d, "iile_dist_barrier");
     int rc = ensure_scratch(d, 256);
     if (rc) return rc;
-    NCCL_TRY(ncclAllReduce(d->scratch, d->scratch, 1, ncclInt32, ncclSum, d->comm, static_cast<hipStream_t>(stream)));
-    return IILE_OK;
+    return settle(d, ncclAllReduce(d->scratch, d->scratch, 1, ncclInt32, ncclSum, d->comm, static_cast<hipStream_t>(stream)), "ncclAllReduce");
 }
 
 int iile_dist_sum_u64(iile_dist *d, uint64_t *values, int32_t n) { return all_reduce_host(d, values, n, ncclUint64, ncclSum); }

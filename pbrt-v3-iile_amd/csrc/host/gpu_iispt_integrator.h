@@ -34,7 +34,8 @@ struct IisptOptions {
     int direct_samples = 16;   // PbrtOptions.iileDirectSamples
     int hemi_size = 32;        // PbrtOptions.iisptHemiSize (the network's input side: 32 is the only one it is trained for)
     std::string net_file;      // --iisptNet= / $IILE_IISPT_NET: IILENET1 weights (iile_iispt_net_load)
-    int max_probes = 32768;    // hemi points per group of tasks
+    int max_probes = 32768;    // hemi points per group of tasks (one set of probe-pass / gather launches each)
+    int net_batch = 8192;      // probes per set of network launches: 1.19 MiB of activations each; no faster beyond (iile_iispt_net_predict halves it if the device is short of memory)
     std::string indirect_out, direct_out;   // /tmp/iispt_indirect.exr, /tmp/iispt_direct.exr of the reference; empty: not written
 };
 
@@ -95,12 +96,14 @@ class GpuIisptIntegrator : public Integrator {
         const int w = f->xres, h = f->yres;
         const size_t n_pix = size_t(w) * size_t(h);
         bool ok = true;
-        if (iile_scene_create(scene.desc(), &gpu_) != IILE_OK || iile_iispt_net_load(opt_.net_file.c_str(), &net_) != IILE_OK) ok = Fail(iile_last_error());
+        if (iile_scene_create(scene.desc(), &gpu_) != IILE_OK || iile_iispt_net_load(opt_.net_file.c_str(), &net_) != IILE_OK ||
+            iile_stream_create(&stream_) != IILE_OK)   // ONE stream orders the frame: no stage relies on the null stream's implicit order
+            ok = Fail(iile_last_error());
         double *film_indirect = nullptr, *film_direct = nullptr;
         float *rgb_dev = nullptr;
         ok = ok && Alloc(reinterpret_cast<void **>(&film_indirect), n_pix * 4 * sizeof(double)) &&
              Alloc(reinterpret_cast<void **>(&film_direct), n_pix * 4 * sizeof(double)) && Alloc(reinterpret_cast<void **>(&rgb_dev), n_pix * 3 * sizeof(float)) &&
-             Check(iile_device_zero(film_indirect, n_pix * 4 * sizeof(double), nullptr));
+             Check(iile_device_zero(film_indirect, n_pix * 4 * sizeof(double), stream_));
         // ---- the indirect pass: IisptRenderRunner::run for task numbers 0 .. iileIndirectTasks - 1
         if (ok) {
             // camera->film->GetSampleBounds(): the film's pixels under the box filter of radius 0.5 (pbrt's default; BASELINE's scene).
@@ -140,17 +143,18 @@ class GpuIisptIntegrator : public Integrator {
             iile_direct_params dp = {};
             dp.n_passes = opt_.direct_samples;
             dp.film_on_device = 1;
+            dp.stream = stream_;
             if (opt_.direct_samples > 0)
                 ok = Check(iile_render_direct(gpu_, &dp, film_direct));
             else
-                ok = Check(iile_device_zero(film_direct, n_pix * 4 * sizeof(double), nullptr));
+                ok = Check(iile_device_zero(film_direct, n_pix * 4 * sizeof(double), stream_));
         }
         // ---- iispt.cpp:425-446: the two monitors as images, their merge as the frame
         std::vector<float> rgb(n_pix * 3);
         auto write = [&](const double *a, const double *b, const std::string &path) {
             if (path.empty()) return true;
-            if (!Check(iile_iispt_film_merge(a, b, int64_t(n_pix), rgb_dev, nullptr)) ||
-                !Check(iile_device_download(rgb.data(), rgb_dev, n_pix * 3 * sizeof(float), nullptr)))
+            if (!Check(iile_iispt_film_merge(a, b, int64_t(n_pix), rgb_dev, stream_)) ||
+                !Check(iile_device_download(rgb.data(), rgb_dev, n_pix * 3 * sizeof(float), stream_)))
                 return false;
             if (iile_host_write_image(path.c_str(), f, rgb.data()) != 0) return Fail(iile_host_last_error());
             return true;
@@ -158,10 +162,11 @@ class GpuIisptIntegrator : public Integrator {
         if (ok && (!opt_.indirect_out.empty() || !opt_.direct_out.empty())) {
             // to_intensity_film of ONE monitor = the merge with an empty one (a pixel of weight 0 contributes its sums, zeros)
             double *zero = nullptr;
-            ok = Alloc(reinterpret_cast<void **>(&zero), n_pix * 4 * sizeof(double)) && Check(iile_device_zero(zero, n_pix * 4 * sizeof(double), nullptr)) &&
+            ok = Alloc(reinterpret_cast<void **>(&zero), n_pix * 4 * sizeof(double)) && Check(iile_device_zero(zero, n_pix * 4 * sizeof(double), stream_)) &&
                  write(film_indirect, zero, opt_.indirect_out) && write(film_direct, zero, opt_.direct_out);
         }
         ok = ok && write(film_direct, film_indirect, output_);
+        if (stream_) (void)iile_stream_wait(stream_);
         for (void *p : allocs_) iile_device_free(p);
         allocs_.clear();
         for (Buffer *b : {&inten_, &nrm_, &dist_, &nn_, &slot_, &out_}) {
@@ -170,6 +175,8 @@ class GpuIisptIntegrator : public Integrator {
         }
         if (net_) iile_iispt_net_destroy(net_);
         if (gpu_) iile_scene_destroy(gpu_);
+        if (stream_) iile_stream_destroy(stream_);
+        stream_ = nullptr;
         net_ = nullptr;
         gpu_ = nullptr;
         return ok;
@@ -209,7 +216,7 @@ class GpuIisptIntegrator : public Integrator {
         valid_.resize(n_pts);
         pos_.resize(3 * n_pts);
         dir_.resize(3 * n_pts);
-        if (!Check(iile_iispt_hemi_points_batch(gpu_, tasks.data(), n_tasks, valid_.data(), pos_.data(), dir_.data()))) return false;
+        if (!Check(iile_iispt_hemi_points_batch(gpu_, tasks.data(), n_tasks, valid_.data(), pos_.data(), dir_.data(), stream_))) return false;
         // the probes: one per hemi point that found a scattering surface, its image written to that hemi point's slot
         cpos_.clear();
         cdir_.clear();
@@ -222,22 +229,22 @@ class GpuIisptIntegrator : public Integrator {
             }
         const size_t n_probes = slots_.size();
         const size_t img = 32 * 32 * sizeof(float);
-        if (!Reserve(nn_, n_pts * 3 * img) || !Reserve(out_, n_pix * 4 * sizeof(float)) || !Check(iile_device_zero(nn_.p, n_pts * 3 * img, nullptr))) return false;
+        if (!Reserve(nn_, n_pts * 3 * img) || !Reserve(out_, n_pix * 4 * sizeof(float)) || !Check(iile_device_zero(nn_.p, n_pts * 3 * img, stream_))) return false;
         if (n_probes) {
             if (!Reserve(inten_, n_probes * 3 * img) || !Reserve(nrm_, n_probes * 3 * img) || !Reserve(dist_, n_probes * img) ||
                 !Reserve(slot_, n_probes * sizeof(int32_t)))
                 return false;
             if (!Check(iile_render_probes(gpu_, int32_t(n_probes), cpos_.data(), cdir_.data(), static_cast<float *>(inten_.p), static_cast<float *>(nrm_.p),
-                                          static_cast<float *>(dist_.p), 1, nullptr)) ||
-                !Check(iile_device_upload(slot_.p, slots_.data(), n_probes * sizeof(int32_t), nullptr)) ||
+                                          static_cast<float *>(dist_.p), 1, nullptr, stream_)) ||
+                !Check(iile_device_upload(slot_.p, slots_.data(), n_probes * sizeof(int32_t), stream_)) ||
                 // (film_rows: the gather reads the network's own row order, ImageFilm's)
                 !Check(iile_iispt_net_predict(net_, static_cast<float *>(inten_.p), static_cast<float *>(nrm_.p), static_cast<float *>(dist_.p),
-                                              static_cast<float *>(nn_.p), static_cast<const int32_t *>(slot_.p), int32_t(n_probes), 1, opt_.max_probes, nullptr)))
+                                              static_cast<float *>(nn_.p), static_cast<const int32_t *>(slot_.p), int32_t(n_probes), 1, opt_.net_batch, stream_)))
                 return false;
         }
         if (!Check(iile_iispt_gather_batch(gpu_, tasks.data(), n_tasks, valid_.data(), pos_.data(), dir_.data(), static_cast<float *>(nn_.p), 1,
-                                           static_cast<float *>(out_.p), 1)) ||
-            !Check(iile_iispt_film_add(gpu_, tasks.data(), n_tasks, static_cast<float *>(out_.p), film, w, h, nullptr)))
+                                           static_cast<float *>(out_.p), 1, stream_)) ||
+            !Check(iile_iispt_film_add(gpu_, tasks.data(), n_tasks, static_cast<float *>(out_.p), film, w, h, stream_)))
             return false;
         stats.tasks += n_tasks;
         stats.hemi_points += (long long)n_pts;
@@ -250,6 +257,7 @@ class GpuIisptIntegrator : public Integrator {
     IisptOptions opt_;
     iile_scene *gpu_ = nullptr;
     iile_iispt_net *net_ = nullptr;
+    void *stream_ = nullptr;   // the frame's one stream (iile_stream_create)
     std::vector<void *> allocs_;
     Buffer inten_, nrm_, dist_, nn_, slot_, out_;
     std::vector<uint8_t> valid_;

@@ -19,9 +19,12 @@
 // Error() (src/core/error.h:54): a message on stderr, Render() returns false.
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include "device_gang.h"
 
 #include "../../../include/iile_dist.h"
 #include "../../../include/iile_gpu.h"
@@ -123,46 +126,67 @@ class GpuPathIntegrator : public Integrator {
     // The reference enters integrator->Render(*scene) ONCE, in one process (src/core/api.cpp:1650-1662), and fans the tiles out
     // itself (ParallelFor2D over its thread pool, src/core/parallel.cpp:247-299). The same here over the GPUs of the process:
     // one host thread per device, each with its own iile_scene, the tiles dealt by iile_tile_owner, the films merged by the ONE
-    // RCCL reduction of the N-process path — the threads rendezvous through an in-process unique id (ncclCommInitRank from N
-    // threads of one process) and then run exactly RenderRanks. Rank 0's thread writes the image. n == 1 is the same code with a
-    // communicator of one rank (what the one-GPU boxes of this pool can run: tests/test_gpu_parity.py).
+    // RCCL reduction of the N-process path — the threads rendezvous through an in-process unique id and then run exactly
+    // RenderRanks. Rank 0's thread writes the image. n == 1 is the same code with a communicator of one rank (what the one-GPU
+    // boxes of this pool can run: tests/test_gpu_parity.py).
+    // Leaving together (device_gang.h): more devices asked for than visible is refused before a thread starts; a thread whose
+    // device cannot be selected, or whose communicator set-up fails, votes no and NOBODY enters a collective; the communicator is
+    // RCCL's non-blocking kind with a deadline (iile_dist_create_deadline; $IILE_DIST_TIMEOUT_S, default 120 s), so a rank that
+    // stops answering later makes the others return an error instead of waiting in ncclReduce. Render() then returns false; the
+    // process is never restarted or re-executed (it has touched the GPU).
     bool RenderAllDevices(const Scene &scene, int n) {
         const int visible = iile_device_count();
-        if (n < 1 || visible < 1) {
-            fprintf(stderr, "Error: GPU path: %s\n", visible < 1 ? "no HIP device" : "no device asked for");
-            return false;
-        }
+        double timeout_s = 120.0;
+        if (const char *e = getenv("IILE_DIST_TIMEOUT_S")) timeout_s = atof(e) > 0 ? atof(e) : timeout_s;
         uint8_t id[IILE_DIST_ID_BYTES];
-        if (iile_dist_unique_id(id) != IILE_OK) {
+        if (visible >= 1 && n >= 1 && n <= visible && iile_dist_unique_id(id) != IILE_OK) {
             fprintf(stderr, "Error: multi-GPU set-up: %s\n", iile_dist_last_error());
             return false;
         }
-        std::vector<char> ok(size_t(n), 0);
-        std::vector<iile_stats> stats;
-        stats.resize(size_t(n));
-        auto worker = [&](int r) {
-            // (error strings are thread-local in both libraries: every thread reports its own)
-            if (iile_device_select(r % visible) != IILE_OK) {
-                fprintf(stderr, "Error: GPU path: device %d: %s\n", r % visible, iile_last_error());
-                // this rank cannot join: the others would wait in ncclCommInitRank — leave through the communicator anyway
+        struct Backend {
+            GpuPathIntegrator *self;
+            const Scene &scene;
+            const uint8_t *id;
+            double timeout_s;
+            std::vector<iile_stats> stats;
+            int fault_rank = -1;
+            std::string fault;   // $IILE_DEBUG_GANG_FAULT = select:R | create:R — fault injection for the tests (what a lost device looks like)
+            bool SelectDevice(int r) {
+                // (error strings are thread-local in both libraries: every thread reports its own)
+                if ((fault == "select" && r == fault_rank) || iile_device_select(r) != IILE_OK) {
+                    fprintf(stderr, "Error: GPU path: device %d: %s\n", r, fault == "select" && r == fault_rank ? "injected fault" : iile_last_error());
+                    return false;
+                }
+                return true;
             }
-            iile_dist *comm = nullptr;
-            if (iile_dist_create(id, r, n, &comm) != IILE_OK) {
-                fprintf(stderr, "Error: multi-GPU set-up (device %d of %d): %s\n", r, n, iile_dist_last_error());
-                return;
+            void *CreateComm(int r, int n) {
+                iile_dist *comm = nullptr;
+                if ((fault == "create" && r == fault_rank) || iile_dist_create_deadline(id, r, n, timeout_s, &comm) != IILE_OK) {
+                    fprintf(stderr, "Error: multi-GPU set-up (device %d of %d): %s\n", r, n, fault == "create" && r == fault_rank ? "injected fault" : iile_dist_last_error());
+                    return nullptr;
+                }
+                return comm;
             }
-            GpuPathIntegrator part(output_, 0, 1, stats_, comm);
-            ok[size_t(r)] = part.RenderRanks(scene) ? 1 : 0;
-            stats[size_t(r)] = part.last_stats;
-            iile_dist_destroy(comm);
-        };
-        std::vector<std::thread> threads;
-        for (int r = 1; r < n; ++r) threads.emplace_back(worker, r);
-        worker(0);   // rank 0 on the calling thread: it writes the image
-        for (std::thread &t : threads) t.join();
-        for (int r = 0; r < n; ++r)
-            if (!ok[size_t(r)]) return false;
-        last_stats = stats[0];   // job totals (RenderRanks sums the counters over the ranks)
+            bool Run(int r, void *comm) {
+                GpuPathIntegrator part(self->output_, 0, 1, self->stats_, static_cast<iile_dist *>(comm));
+                const bool ok = part.RenderRanks(scene);
+                stats[size_t(r)] = part.last_stats;
+                return ok;
+            }
+            void DestroyComm(void *comm) { iile_dist_destroy(static_cast<iile_dist *>(comm)); }
+            void AbortComm(void *comm) { iile_dist_abort(static_cast<iile_dist *>(comm)); }
+        } be{this, scene, id, timeout_s, std::vector<iile_stats>(size_t(n > 0 ? n : 0)), -1, std::string()};
+        if (const char *f = getenv("IILE_DEBUG_GANG_FAULT")) {
+            const std::string spec(f);
+            const size_t colon = spec.find(':');
+            if (colon != std::string::npos) be.fault = spec.substr(0, colon), be.fault_rank = atoi(spec.c_str() + colon + 1);
+        }
+        std::string why;
+        if (!RunGang(be, n, visible, timeout_s, &why)) {
+            fprintf(stderr, "Error: GPU path: the frame was given up on every device: %s\n", why.c_str());
+            return false;
+        }
+        last_stats = be.stats[0];   // job totals (RenderRanks sums the counters over the ranks)
         return true;
     }
 
@@ -221,7 +245,9 @@ class GpuPathIntegrator : public Integrator {
         }
         std::vector<float> xyzw;
         if (Agree(ok)) {  // all films are ready: the one collective of the frame (Film::MergeFilmTile, film.cpp:135-148)
-            if (iile_dist_film_reduce(comm_, static_cast<float *>(film_dev), int64_t(n_pix), 0, nullptr) != IILE_OK) {
+            // (iile_dist_wait: the merge has finished, or the communicator's deadline has passed and this rank gives up)
+            if (iile_dist_film_reduce(comm_, static_cast<float *>(film_dev), int64_t(n_pix), 0, nullptr) != IILE_OK ||
+                iile_dist_wait(comm_, nullptr) != IILE_OK) {
                 fprintf(stderr, "Error: film merge: %s\n", iile_dist_last_error());
                 ok = false;
             }

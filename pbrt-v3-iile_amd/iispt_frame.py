@@ -125,7 +125,8 @@ class IisptFrame:
                 i += 1
             # every stage runs over the whole group at once (iile_iispt_*_batch: one set of launches for all its tasks)
             t0 = time.time()
-            valid, pos, dr = self.gpu.iispt_hemi_points_batch(group)
+            stream = torch.cuda.current_stream().cuda_stream   # ONE stream orders the whole indirect pass (include/iile_gpu.h)
+            valid, pos, dr = self.gpu.iispt_hemi_points_batch(group, stream=stream)
             tick("hemi_points", t0)
             t0 = time.time()
             sel = valid == 1
@@ -137,10 +138,10 @@ class IisptFrame:
             tick("probes_and_network", t0)
             t0 = time.time()
             out = torch.empty((n_pix, 4), dtype=torch.float32, device="cuda")
-            self.gpu.iispt_gather_batch(group, valid, pos, dr, nn_device_ptr=nn.data_ptr(), out_device_ptr=out.data_ptr())
+            self.gpu.iispt_gather_batch(group, valid, pos, dr, nn_device_ptr=nn.data_ptr(), out_device_ptr=out.data_ptr(), stream=stream)
             # add_n_samples for every pixel of every task of the group in ONE launch (iile_iispt_film_add: tasks of one sweep do not
             # overlap, so no two of its threads meet on a film pixel)
-            self.gpu.iispt_film_add(group, out.data_ptr(), self.film.data_ptr())
+            self.gpu.iispt_film_add(group, out.data_ptr(), self.film.data_ptr(), stream=stream)
             for task in group:
                 self.stats["tasks"] += 1
                 self.stats["pixels"] += (task.y1 - task.y0) * (task.x1 - task.x0)

@@ -4,127 +4,23 @@ The reference pipes every probe through a child Python process (`ml/main_stdio_n
 `Doc.md:58-61`): `IisptRenderRunner` normalises the three probe images (`normalizeMapsDownstream`,
 `src/integrators/iisptrenderrunner.cpp:1041-1092`), writes 32*32*7 floats to the pipe, reads 32*32*3 back and
 rescales them (`transformMapsUpstream`, `:1095-1133`). Here the probe images never leave HBM: `iile_render_probes`
-(include/iile_gpu.h) writes them into torch tensors, the two transforms run batched over all probes, and the
-network runs once over the whole batch.
+(include/iile_gpu.h) writes them into device tensors and `iile_iispt_net_predict` runs the two transforms and `IISPTNet.forward`
+(`ml/iispt_net.py:8-109`) over the whole batch on the hand-written kernels of csrc/device/iispt_net.hip.
 
-* `normalize_downstream` / `transform_upstream`: the two transforms, per probe, in the reference's arithmetic
-  (double sums for the means, `log(1.0 + v)` / `exp(v) - 1.0` in double, everything else in float).
-* `IISPTNet`: the U-Net of `ml/iispt_net.py:8-109` (K = 64; 7 -> 3 channels at 32 x 32). Its `state_dict` has the
-  reference's parameter names and shapes, so a checkpoint trained with the reference's `ml/main_train.py` loads
-  unchanged. **No weights ship with the reference**: with random weights the output means nothing; what is pinned is the
-  function — `tests/golden/iispt_net_fixture.npz` holds a forward of the REFERENCE's module (imported in the build
-  container, weights from the recipe of tests/iispt_net_recipe.py) and the pipe's wire order as `read_input` /
-  `output_to_stdout` of `ml/main_stdio_net.py:47-86` produce it; this module must reproduce both (tests/test_iispt_nn.py).
+This file is plumbing over the C ABI and holds ONE backend: no PyTorch module, no eager fallback. Weights arrive as a `state_dict`
+with the reference's parameter names and shapes (what `torch.load` of a checkpoint of the reference's `ml/main_train.py` yields;
+binding.GpuNet packs it). The PyTorch statement of the network and of the transforms that the kernels are tested against lives in
+tests/iispt_torch_reference.py.
 
 Image layout: the reference's `ImageFilm` stores raster row y at index h - 1 - y (`src/film/imagefilm.cpp:26-31`,
-`src/core/film.cpp:245-254`) and the network was trained on that; `iile_render_probes` returns raster order.
-`normalize_downstream` flips on the way in, `transform_upstream` flips back.
+`src/core/film.cpp:245-254`) and the network was trained on that; `iile_render_probes` returns raster order and
+`iile_iispt_net_predict` flips on the way in and back on the way out (film_rows: leaves the network's own row order, which is what
+`iile_iispt_gather` reads).
 """
 import torch
-from torch import nn
 
 HEMI = 32
-K = 64
-
-# One row per block: (name, layers). Layers: ("pool",), ("conv", cin, cout, kernel), ("deconv", cin, cout, kernel),
-# ("lrelu",), ("bn", channels), ("up",), ("relu",). Order and indices inside a block fix the state_dict keys.
-_BLOCKS = (
-    ("encoder0", (("conv", 7, K, 3), ("lrelu",), ("conv", K, K, 3), ("lrelu",))),
-    ("encoder1", (("pool",), ("conv", K, 2 * K, 3), ("lrelu",), ("bn", 2 * K), ("conv", 2 * K, 2 * K, 3), ("lrelu",))),
-    ("encoder2", (("pool",), ("conv", 2 * K, 4 * K, 3), ("lrelu",), ("bn", 4 * K), ("conv", 4 * K, 4 * K, 3), ("lrelu",))),
-    ("encoder3", (("pool",), ("conv", 4 * K, 8 * K, 3), ("lrelu",), ("bn", 8 * K), ("conv", 8 * K, 4 * K, 3), ("lrelu",), ("up",))),
-    ("decoder0", (("deconv", 8 * K, 4 * K, 3), ("lrelu",), ("bn", 4 * K), ("deconv", 4 * K, 2 * K, 3), ("lrelu",), ("up",))),
-    ("decoder1", (("deconv", 4 * K, 2 * K, 3), ("lrelu",), ("bn", 2 * K), ("deconv", 2 * K, K, 3), ("lrelu",), ("up",))),
-    ("decoder2", (("deconv", 2 * K, K, 3), ("lrelu",), ("deconv", K, K, 3), ("lrelu",), ("conv", K, 3, 1), ("relu",))),
-)
-
-
-def _layer(spec):
-    kind = spec[0]
-    if kind == "conv":
-        return nn.Conv2d(spec[1], spec[2], spec[3], stride=1, padding=spec[3] // 2)
-    if kind == "deconv":
-        return nn.ConvTranspose2d(spec[1], spec[2], spec[3], stride=1, padding=spec[3] // 2)
-    if kind == "lrelu":
-        return nn.LeakyReLU(0.2)
-    if kind == "relu":
-        return nn.ReLU()
-    if kind == "bn":
-        return nn.BatchNorm2d(spec[1])
-    if kind == "pool":
-        return nn.MaxPool2d(2)
-    if kind == "up":
-        return nn.Upsample(scale_factor=2, mode="bilinear")
-    raise ValueError(kind)
-
-
-class IISPTNet(nn.Module):
-    """ml/iispt_net.py:8-109: three encoder levels, a bottleneck that upsamples back, three decoder levels fed by
-    the concatenation of the level below with the matching encoder output."""
-
-    def __init__(self):
-        super().__init__()
-        for name, layers in _BLOCKS:
-            setattr(self, name, nn.Sequential(*[_layer(s) for s in layers]))
-
-    def forward(self, x):
-        e0 = self.encoder0(x)
-        e1 = self.encoder1(e0)
-        e2 = self.encoder2(e1)
-        y = self.encoder3(e2)
-        y = self.decoder0(torch.cat((y, e2), 1))
-        y = self.decoder1(torch.cat((y, e1), 1))
-        return self.decoder2(torch.cat((y, e0), 1))
-
-
-def wire_to_network_input(intensity, normals, distance):
-    """The pipe's layout -> the network's (`read_input`, ml/main_stdio_net.py:47-72): three images as the runner writes them,
-    (n, h, w, 3), (n, h, w, 3) and (n, h, w) in ImageFilm row order, become (n, 7, h, w): intensity RGB, normal XYZ,
-    distance. Pinned against the reference's own function by tests/golden/iispt_net_fixture.npz."""
-    x7 = torch.cat((intensity, normals, distance.unsqueeze(-1)), -1)
-    return x7.permute(0, 3, 1, 2).contiguous()
-
-
-def network_output_to_wire(out):
-    """`output_to_stdout` (ml/main_stdio_net.py:77-86): the network's (n, 3, h, w) goes back as (n, h, w, 3)."""
-    return out.permute(0, 2, 3, 1)
-
-
-def normalize_downstream(intensity, normals, distance):
-    """normalizeMapsDownstream, batched: intensity (n, h, h, 3), normals (n, h, h, 3), distance (n, h, h) in raster
-    order -> network input (n, 7, h, h) float32 in the reference's row order, and the per-probe channel means
-    (n, 3) that transform_upstream needs."""
-    n = intensity.shape[0]
-    i64 = intensity.double()
-    # computeMeanChannels / computeMean: double sums over float texels (imagefilm.cpp:203-254)
-    chan_mean = i64.reshape(n, -1, 3).mean(1).float()
-    mean = i64.reshape(n, -1).mean(1).float()
-    ratio = torch.where(mean == 0, torch.zeros_like(mean, dtype=torch.float64), 1.0 / (10.0 * mean.double())).float()
-    x = intensity * ratio.view(n, 1, 1, 1)                                  # multiply(float)
-    x = torch.log(1.0 + torch.clamp(x, min=0).double()).float()             # positiveLog: log(1.0 + v) in double
-    x = x + torch.tensor(-0.1, dtype=torch.float32, device=x.device)        # add(-0.1)
-    nrm = torch.clamp((normals - 0.0) / 1.0, -1.0, 1.0)                      # normalize(-1, 1): mid 0, r 1
-    z_mean = distance.double().reshape(n, -1).mean(1).float()
-    d = distance + 1.0
-    div = (10.0 * (z_mean.double() + 1.0)).float()
-    div = torch.where(div == 0, torch.ones_like(div), div)
-    d = d * (1.0 / div.double()).float().view(n, 1, 1)
-    d = torch.log(1.0 + torch.clamp(d, min=0).double()).float()
-    d = d + torch.tensor(-0.1, dtype=torch.float32, device=d.device)
-    # ImageFilm row = h - 1 - y; then the pipe's (h, w, c) images become (channels, height, width) per probe
-    return wire_to_network_input(torch.flip(x, dims=(1,)), torch.flip(nrm, dims=(1,)), torch.flip(d, dims=(1,))), chan_mean
-
-
-def transform_upstream(out, chan_mean):
-    """transformMapsUpstream, batched: network output (n, 3, h, h) -> predicted intensity (n, h, h, 3) in raster order,
-    rescaled so that each channel's mean is the rendered probe's."""
-    n = out.shape[0]
-    y = torch.exp(torch.clamp(out.float(), min=0).double()) - 1.0           # positiveLogInverse in double
-    y = y.float()
-    actual = y.double().reshape(n, 3, -1).mean(2).float()                   # computeMeanChannels
-    mul = torch.where(actual > 1e-10, chan_mean / actual, torch.zeros_like(actual))
-    y = y * mul.view(n, 3, 1, 1)
-    return torch.flip(network_output_to_wire(y), dims=(1,)).contiguous()
+BN_EPS = 1e-5   # nn.BatchNorm2d's default, which ml/iispt_net.py:27-88 does not override
 
 
 def _load_binding():
@@ -142,34 +38,18 @@ def _load_binding():
 
 
 class IisptPipeline:
-    """render probes -> normalise -> network -> rescale, everything resident in HBM.
+    """render probes -> normalise -> network -> rescale, everything resident in HBM, through the C ABI
+    (iile_render_probes, iile_iispt_net_predict; binding.GpuNet). `net` supplies the weights: a state_dict (name -> tensor / array,
+    the reference's names) or anything with a `.state_dict()` (e.g. a module with a checkpoint of the reference's training loaded).
+    Without the HIP library the constructor raises: there is no other backend."""
 
-    The network runs on the hand-written kernels of csrc/device/iispt_net.hip through the C ABI (iile_iispt_net_*,
-    binding.GpuNet); `net` (an IISPTNet, e.g. with a checkpoint of the reference's training loaded) only supplies the
-    weights. backend="torch" runs the PyTorch module instead (eager, MIOpen convolutions): kept for tests and A/B timing,
-    never the default — without the HIP library the constructor raises."""
-
-    def __init__(self, gpu_scene, net=None, dtype=torch.float32, device="cuda", backend="hip", binding=None):
+    def __init__(self, gpu_scene, net, device="cuda", binding=None, bn_eps=BN_EPS):
         self.gpu = gpu_scene
         self.device = torch.device(device)
-        self.backend = backend
-        self.dtype = dtype
-        module = (net if net is not None else IISPTNet()).eval()
-        if backend == "hip":
-            if dtype != torch.float32:
-                raise ValueError("the HIP network computes in split bf16 with fp32 accumulation; dtype selects nothing there")
-            if binding is None:
-                binding = _load_binding()
-            self.hip_net = binding.GpuNet(module.state_dict(), bn_eps=module.encoder1[3].eps)
-            self.net = None
-        elif backend == "torch":
-            self.hip_net = None
-            self.net = module.to(self.device)
-            if dtype != torch.float32:
-                self.net = self.net.to(dtype)
-            self.net = self.net.to(memory_format=torch.channels_last)
-        else:
-            raise ValueError(backend)
+        if binding is None:
+            binding = _load_binding()
+        state = net.state_dict() if hasattr(net, "state_dict") else net
+        self.hip_net = binding.GpuNet(state, bn_eps=bn_eps)
         self.events = None   # bench.py: a list that receives (stage, start event, end event) on the current stream
 
     def _timed(self, stage, fn):
@@ -183,42 +63,28 @@ class IisptPipeline:
         return out
 
     def infer(self, x):
-        """(n, 7, h, h) float32 on the device -> (n, 3, h, h) float32."""
-        if self.hip_net is not None:
-            x = x.contiguous()
-            y = torch.empty((x.shape[0], 3, HEMI, HEMI), dtype=torch.float32, device=x.device)
-            self.hip_net.forward(x.data_ptr(), y.data_ptr(), x.shape[0], stream=torch.cuda.current_stream().cuda_stream)
-            return y
-        return self.net(x.to(self.dtype).contiguous(memory_format=torch.channels_last)).float()
+        """(n, 7, h, h) float32 on the device -> (n, 3, h, h) float32: the bare network (iile_iispt_net_forward)."""
+        x = x.contiguous()
+        y = torch.empty((x.shape[0], 3, HEMI, HEMI), dtype=torch.float32, device=x.device)
+        self.hip_net.forward(x.data_ptr(), y.data_ptr(), x.shape[0], stream=torch.cuda.current_stream().cuda_stream)
+        return y
 
     @torch.no_grad()
-    def __call__(self, pos, direction, batch=32768, film_rows=False, pred_out=None, slot=None):
+    def __call__(self, pos, direction, batch=8192, film_rows=False, pred_out=None, slot=None):
         """(n, 3) probe origins and directions -> (predicted intensity (n, h, h, 3), rendered intensity, normals,
         distance), all torch tensors on the device, raster order (film_rows: the prediction in the network's own row order,
-        ImageFilm's, as iile_iispt_gather reads it). With the HIP network the two transforms run inside iile_iispt_net_predict;
-        the PyTorch backend keeps them as the tensor expressions above (tests hold the two against each other).
+        ImageFilm's, as iile_iispt_gather reads it). The two transforms run inside iile_iispt_net_predict.
         pred_out (m, h, h, 3) with slot (n,) int32 on the device: probe i's prediction is written to pred_out[slot[i]] (the frame keeps
-        one image per hemi point, valid or not) and pred_out is returned in place of the (n, ...) tensor."""
+        one image per hemi point, valid or not) and pred_out is returned in place of the (n, ...) tensor.
+        batch: probes per network launch set (the activation workspace is 1.19 MiB x batch; 8 192 is as fast as any larger one)."""
         n = len(pos)
         inten = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         nrm = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         dist = torch.empty((n, HEMI, HEMI), dtype=torch.float32, device=self.device)
-        self._timed("probe_pass", lambda: self.gpu.render_probes(pos, direction, device_out=(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr())))
-        if self.hip_net is not None:
-            pred = pred_out if pred_out is not None else torch.empty_like(inten)
-            self._timed("network", lambda: self.hip_net.predict(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr(), pred.data_ptr(), n, film_rows=film_rows,
-                                                                max_batch=batch, stream=torch.cuda.current_stream().cuda_stream,
-                                                                slot_ptr=slot.data_ptr() if pred_out is not None else None))
-            return pred, inten, nrm, dist
-        pred = torch.empty_like(inten)
-        for first in range(0, n, batch):
-            sl = slice(first, min(n, first + batch))
-            x, means = self._timed("normalize", lambda: normalize_downstream(inten[sl], nrm[sl], dist[sl]))
-            y = self._timed("network", lambda: self.infer(x))
-            pred[sl] = self._timed("rescale", lambda: transform_upstream(y, means))
-        if film_rows:
-            pred = torch.flip(pred, dims=(1,))
-        if pred_out is not None:
-            pred_out[slot.long()] = pred
-            pred = pred_out
+        stream = torch.cuda.current_stream().cuda_stream   # every stage of the indirect pass goes on the caller's current stream
+        self._timed("probe_pass", lambda: self.gpu.render_probes(pos, direction, device_out=(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr()), stream=stream))
+        pred = pred_out if pred_out is not None else torch.empty_like(inten)
+        self._timed("network", lambda: self.hip_net.predict(inten.data_ptr(), nrm.data_ptr(), dist.data_ptr(), pred.data_ptr(), n, film_rows=film_rows,
+                                                            max_batch=batch, stream=stream,
+                                                            slot_ptr=slot.data_ptr() if pred_out is not None else None))
         return pred, inten, nrm, dist

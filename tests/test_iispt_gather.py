@@ -147,7 +147,8 @@ def test_iispt_frame_end_to_end(binding):
     scene = binding.HostScene(xres=96, yres=80, spp=1)
     gpu = binding.GpuScene(scene)
     torch.manual_seed(0)
-    pipe = nn_mod.IisptPipeline(gpu)
+    import iispt_torch_reference as ref_mod
+    pipe = nn_mod.IisptPipeline(gpu, net=ref_mod.IISPTNet())
     frame = frame_mod.IisptFrame(binding, gpu, pipe)
     tasks = list(frame_mod.schedule((0, 0, 96, 80), 100, radius_start=4.0))
     sweep = [t for t in tasks if t[4] == 4]

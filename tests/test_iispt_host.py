@@ -175,10 +175,11 @@ def test_cpp_iispt_integrator_writes_the_python_frames_image(binding, tmp_path):
         pytest.skip("torch sees no GPU")
     sys.path.insert(0, REPO)
     nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+    import iispt_torch_reference as ref_mod
     frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
     w, h, n_tasks, n_direct = 96, 80, 21, 3
     torch.manual_seed(3)
-    module = nn_mod.IISPTNet().eval()
+    module = ref_mod.IISPTNet().eval()
     net_file = tmp_path / "net.iilenet"
     binding.save_net_weights(module.state_dict(), str(net_file), bn_eps=module.encoder1[3].eps)
     out, ind, direct = tmp_path / "frame.pfm", tmp_path / "indirect.pfm", tmp_path / "direct.pfm"

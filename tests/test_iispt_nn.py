@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")   # the product: HIP only
+import iispt_torch_reference as ref_mod                          # the PyTorch statement it is held against (tests/)
 
 
 def _downstream_scalar(inten, nrm, dist):
@@ -54,7 +55,7 @@ def test_transforms_follow_the_reference_arithmetic():
     nrm = rng.uniform(-1.2, 1.2, (n, h, h, 3)).astype(np.float32)     # a little outside [-1, 1]: clamped
     dist = rng.uniform(0, 40, (n, h, h)).astype(np.float32)
     dist[2, :10] = -1                                                 # escaped rays
-    x, means = nn_mod.normalize_downstream(torch.from_numpy(inten), torch.from_numpy(nrm), torch.from_numpy(dist))
+    x, means = ref_mod.normalize_downstream(torch.from_numpy(inten), torch.from_numpy(nrm), torch.from_numpy(dist))
     assert x.shape == (n, 7, h, h) and means.shape == (n, 3)
     for i in range(n):
         want, chan = _downstream_scalar(inten[i], nrm[i], dist[i])
@@ -63,7 +64,7 @@ def test_transforms_follow_the_reference_arithmetic():
         assert np.allclose(x[i].numpy(), want, rtol=0, atol=3e-6)
     # upstream: exp(max(v, 0)) - 1, then every channel rescaled to the rendered probe's mean; rows flipped back
     out = torch.from_numpy(rng.uniform(-0.2, 2.0, (n, 3, h, h)).astype(np.float32))
-    y = nn_mod.transform_upstream(out, means).numpy()
+    y = ref_mod.transform_upstream(out, means).numpy()
     assert y.shape == (n, h, h, 3)
     for i in range(n):
         e = np.exp(np.maximum(out[i].numpy().astype(np.float64), 0)) - 1
@@ -79,7 +80,7 @@ def test_transforms_follow_the_reference_arithmetic():
 def test_network_has_the_reference_checkpoint_layout():
     """ml/iispt_net.py:8-109: parameter names and shapes as `torch.save(net.state_dict())` of the reference writes
     them (K = 64), 7 -> 3 channels at 32 x 32, non-negative output (final ReLU), batch-independent in eval mode."""
-    net = nn_mod.IISPTNet().eval()
+    net = ref_mod.IISPTNet().eval()
     sd = net.state_dict()
     K = 64
     convs = {"encoder0.0": (K, 7, 3), "encoder0.2": (K, K, 3), "encoder1.1": (2 * K, K, 3), "encoder1.4": (2 * K, 2 * K, 3),
@@ -113,7 +114,7 @@ def _fixture():
 
 def _recipe_net():
     import iispt_net_recipe as recipe
-    net = nn_mod.IISPTNet()
+    net = ref_mod.IISPTNet()
     state = recipe.fill_state_dict(net)
     return net.eval(), state
 
@@ -146,9 +147,9 @@ def test_wire_order_is_the_references():
     inten = torch.from_numpy(w[: h * h * 3].reshape(1, h, h, 3))
     nrm = torch.from_numpy(w[h * h * 3: h * h * 6].reshape(1, h, h, 3))
     dist = torch.from_numpy(w[h * h * 6:].reshape(1, h, h))
-    got = nn_mod.wire_to_network_input(inten, nrm, dist)[0].numpy()
+    got = ref_mod.wire_to_network_input(inten, nrm, dist)[0].numpy()
     assert got.shape == (7, h, h) and np.array_equal(got, fx["wire_net_input"])
-    back = nn_mod.network_output_to_wire(torch.from_numpy(fx["wire_net_output"]).unsqueeze(0))[0].contiguous().numpy()
+    back = ref_mod.network_output_to_wire(torch.from_numpy(fx["wire_net_output"]).unsqueeze(0))[0].contiguous().numpy()
     assert np.array_equal(back.ravel(), fx["wire_out"])
 
 
@@ -230,7 +231,7 @@ def test_hip_network_follows_a_checkpoint_not_the_recipe(binding):
     network built from that state_dict agrees with the module — the packer reads the checkpoint, not a fixed recipe."""
     torch.cuda.init()
     torch.manual_seed(11)
-    net = nn_mod.IISPTNet().eval()
+    net = ref_mod.IISPTNet().eval()
     with torch.no_grad():
         for m in net.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
@@ -270,11 +271,11 @@ def test_predict_runs_the_two_transforms_as_the_tensor_expressions_do(binding):
     g = binding.GpuNet(net.state_dict())
     di, dn, dd = (torch.from_numpy(a).cuda() for a in (inten, nrm, dist))
     with torch.no_grad():
-        x, means = nn_mod.normalize_downstream(di, dn, dd)
+        x, means = ref_mod.normalize_downstream(di, dn, dd)
         x = x.contiguous()
         y = torch.empty((n, 3, h, h), dtype=torch.float32, device="cuda")
         g.forward(x.data_ptr(), y.data_ptr(), n)
-        want = nn_mod.transform_upstream(y, means)
+        want = ref_mod.transform_upstream(y, means)
     got = torch.empty((n, h, h, 3), dtype=torch.float32, device="cuda")
     g.predict(di.data_ptr(), dn.data_ptr(), dd.data_ptr(), got.data_ptr(), n)
     rows = torch.empty_like(got)
@@ -302,15 +303,15 @@ def test_pipeline_keeps_everything_on_the_device(binding):
     pos = rng.uniform((-150, -100, -130), (250, 150, 0), (24, 3)).astype(np.float32)
     d = rng.standard_normal((24, 3)).astype(np.float32)
     torch.manual_seed(3)
-    net = nn_mod.IISPTNet()
+    net = ref_mod.IISPTNet()
     pipe = nn_mod.IisptPipeline(gpu, net=net, binding=binding)
     assert pipe.hip_net is not None and pipe.net is None   # the product path: the HIP kernels, not the PyTorch module
     pred, inten, nrm, dist = pipe(pos, d, batch=10)
     hi, hn, hd, _ = gpu.render_probes(pos, d)
     assert np.array_equal(inten.cpu().numpy(), hi) and np.array_equal(nrm.cpu().numpy(), hn) and np.array_equal(dist.cpu().numpy(), hd)
-    x, means = nn_mod.normalize_downstream(torch.from_numpy(hi), torch.from_numpy(hn), torch.from_numpy(hd))
+    x, means = ref_mod.normalize_downstream(torch.from_numpy(hi), torch.from_numpy(hn), torch.from_numpy(hd))
     with torch.no_grad():
-        want = nn_mod.transform_upstream(net.cpu().eval()(x), means).numpy()
+        want = ref_mod.transform_upstream(net.cpu().eval()(x), means).numpy()
     got = pred.cpu().numpy()
     assert np.isfinite(got).all()
     scale = np.abs(want).max() + 1e-12

@@ -6,12 +6,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, REPO)
 import __graft_entry__ as ge
 b = ge._load_binding()
-nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import iispt_torch_reference as ref_mod
 scene = b.HostScene(xres=1920, yres=1080, spp=1)
 gpu = b.GpuScene(scene)
 torch.manual_seed(0)
 dtype = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
-pipe = nn_mod.IisptPipeline(gpu, dtype=dtype, backend="torch")   # (round 4 timed the PyTorch / MIOpen network; the product path is backend="hip")
+pipe = ref_mod.TorchPipeline(gpu, dtype=dtype)   # (round 4 timed the PyTorch / MIOpen network; the product path is backend="hip")
 rng = np.random.default_rng(1)
 n = 25058
 pos = rng.uniform((-150, -100, -130), (250, 150, 0), (n, 3)).astype(np.float32)
@@ -28,8 +29,8 @@ for rep in range(3):
     with torch.no_grad():
         for first in range(0, n, 8192):
             sl = slice(first, min(n, first + 8192))
-            a = sync(); x, means = nn_mod.normalize_downstream(inten[sl], nrm[sl], dist[sl]); bb = sync()
+            a = sync(); x, means = ref_mod.normalize_downstream(inten[sl], nrm[sl], dist[sl]); bb = sync()
             y = pipe.net(x.to(dtype).contiguous(memory_format=torch.channels_last)); c = sync()
-            p = nn_mod.transform_upstream(y, means); e = sync()
+            p = ref_mod.transform_upstream(y, means); e = sync()
             tn += bb - a; tnet += c - bb; tu += e - c
     print(f"rep {rep}: render_probes {t1 - t0:.4f} s, normalise {tn:.4f}, network {tnet:.4f}, rescale {tu:.4f}")

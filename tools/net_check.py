@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
 b = importlib.import_module("pbrt-v3-iile_amd.binding")
 import iispt_net_recipe as recipe
+import iispt_torch_reference as ref_mod
 
 # the module index whose OUTPUT is convolution layer l's output as the kernel writes it (behind LeakyReLU / BatchNorm)
 TAPS = [("encoder0", 1), ("encoder0", 3), ("encoder1", 3), ("encoder1", 5), ("encoder2", 3), ("encoder2", 5), ("encoder3", 3),
@@ -25,7 +26,7 @@ def main():
     n_time = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8192
     torch.cuda.init()
     fx = np.load(os.path.join(REPO, "tests", "golden", "iispt_net_fixture.npz"))
-    net = nn_mod.IISPTNet()
+    net = ref_mod.IISPTNet()
     recipe.fill_state_dict(net)
     net.eval()
     g = b.GpuNet(net.state_dict())

@@ -29,10 +29,12 @@ dtype = torch.bfloat16 if backend == "torch-bf16" else torch.float32
 b = ge._load_binding()
 scene = b.HostScene(xres=xres, yres=yres, spp=1)
 gpu = b.GpuScene(scene)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import iispt_torch_reference as ref_mod  # noqa: E402  (tests/: the PyTorch module)
 nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
 frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
 torch.manual_seed(0)
-pipe = nn_mod.IisptPipeline(gpu, dtype=dtype, backend="hip" if backend == "hip" else "torch", binding=b)
+pipe = nn_mod.IisptPipeline(gpu, net=ref_mod.IISPTNet(), binding=b) if backend == "hip" else ref_mod.TorchPipeline(gpu, dtype=dtype)
 size = int(radius) * frame_mod.NUMBER_TILES
 tasks_per_sweep = -(-xres // size) * -(-yres // size)
 batched = os.environ.get("IILE_IISPT_BATCHED", "1") != "0"
