@@ -266,7 +266,7 @@ def main_iispt(args):
     gpu = b.GpuScene(scene)
     torch.manual_seed(0)
     module = ref_mod.IISPTNet().eval()   # no trained weights ship with the reference: random-initialised, same architecture and cost
-    pipe = nn_mod.IisptPipeline(gpu, net=module, binding=b)
+    pipe = nn_mod.IisptPipeline(gpu, net=module, binding=b, batch=args.net_batch)
     radius = 10.0
     size = int(radius) * frame_mod.NUMBER_TILES
     n_tasks = -(-args.xres // size) * -(-args.yres // size)
@@ -426,6 +426,7 @@ def parse_args(argv=None):
                          "boxroom-textured: the same room open to an environment-mapped sky, with image textures, "
                          "alpha masks and specular materials (the whole feature set of SURVEY.md 8 f1); "
                          "iispt: BASELINE config 5, one frame of the IISPT integrator (probe pass, network, gather, direct pass)")
+    ap.add_argument("--net-batch", type=int, default=8192, help="--workload iispt: probes per set of network launches (iile_iispt_net_predict's max_batch)")
     ap.add_argument("--sub-configs", default="4_room,5_iispt",
                     help="with the default workload on one GPU: BASELINE configs measured after the headline steps and printed as sub-blocks "
                          "`configs` of the same JSON line (4_room: the deep-tree room, 1080p x 64 spp; 5_iispt: one IISPT frame at 1080p); "

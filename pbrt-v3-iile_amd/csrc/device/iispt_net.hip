@@ -3,17 +3,21 @@
 // U-Net in fp32 on one CPU thread (ml/main_stdio_net.py:44-106, 47 ms per probe, Doc.md:55-64); here a batch of thousands
 // of probes runs layer by layer over activations that stay in HBM.
 //
-// Arithmetic. gfx950's fp32 matrix pipe runs at the vector rate (157 TFLOP/s), its bf16 pipe sixteen times faster, so
-// every 3 x 3 convolution is an implicit GEMM on v_mfma_f32_32x32x16_bf16 over SPLIT operands: a = a_hi + a_lo with
-// a_hi = bf16(a), a_lo = bf16(a - a_hi) (16 significant bits), and the product a * w is accumulated in fp32 as
-// a_hi w_hi + a_hi w_lo + a_lo w_hi (the dropped a_lo w_lo term is 2^-16 of the product). Three matrix instructions per
-// tile instead of one; against the reference module's output (tests/golden/iispt_net_fixture.npz) the whole network lands
-// 2.4e-5 of the largest value away, the bound held by tests/test_iispt_nn.py being 1e-4 (plain bf16: 2.3e-2).
+// Arithmetic. gfx950's fp32 matrix pipe runs at the vector rate (157 TFLOP/s), its 16-bit pipes sixteen times faster, so
+// every 3 x 3 convolution is an implicit GEMM on v_mfma_f32_32x32x16_f16 over SPLIT operands: a = a_hi + a_lo with
+// a_hi = fp16(a), a_lo = fp16(a - a_hi) — 22 significant bits — and the product a * w is accumulated in fp32 as
+// a_hi w_hi + a_hi w_lo + a_lo w_hi (the dropped a_lo w_lo term is 2^-22 of the product). Three matrix instructions per tile
+// instead of one. The weights go in times 2^8 (exact; their low halves would be fp16 subnormals otherwise), operands are clamped
+// into fp16's range. Against the reference module's output (tests/golden/iispt_net_fixture.npz) and the fp32 module on the CPU the
+// network is PER ELEMENT inside north_star's band (|err| <= 1e-4 |want| + 1e-6 max on > 99.9 % of the elements, mean relative
+// error 5e-6: the fp32 module's own distance from exact arithmetic), 2e-6 of the largest value at worst — tests/test_iispt_nn.py.
+// (Rounds 5's bf16 halves — 16 significant bits — reached 2.4e-5 of the largest value and 96 % of the elements: same instruction
+// count, same rate; tools/net_split_emulation.py compares the variants on the CPU.)
 //
 // Layout. Activations: NHWC fp32, one tensor per layer. Weights: packed once on the host into the matrix instruction's
 // B-fragment order, hi and lo, k = (16-channel chunk, tap): 36 KB per (chunk, 64 output channels). A persistent workgroup
 // (one per CU; 4 matrix waves + 8 staging waves, k_conv3x3 below) owns a stream of (256-pixel tile, chunk) steps: the staging
-// waves bring a step's pixels — with their one-pixel halo, split into bf16 hi / lo rows of 48 bytes — and its packed weights
+// waves bring a step's pixels — with their one-pixel halo, split into fp16 hi / lo rows of 48 bytes — and its packed weights
 // into one of two LDS buffers while the matrix waves run the step before out of the other; the matrix waves read LDS only.
 // The weights are the matrix instruction's A operand, the pixels its B operand: a lane holds four consecutive channels of its pixel
 // per accumulator quad. The sums start at the bias; behind the last chunk of a tile: LeakyReLU(0.2) and the eval-mode BatchNorm2d
@@ -46,14 +50,26 @@ int api_fail(int code, const std::string &msg);
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 enum { PRE_NONE = 0, PRE_CAT = 1 };
+
+// Power-of-two scales of the split operands (exact: they move exponents only). Weights are small (|w| ~ 0.05): w x 2^kWShift keeps
+// the LOW half of a weight a normal fp16 number (unscaled it is subnormal with 8 significant bits left: measured, 99.84 % of the
+// outputs inside the per-element band instead of 99.996 %, tools/net_split_emulation.py). Activations are O(1..16) and go in as they
+// are (kAShift = 0). Every activation tensor in HBM holds 2^(kAShift + kWShift) x the module's value — LeakyReLU, max-pooling and
+// bilinear upsampling commute with the factor, bias and BatchNorm shift are uploaded times it, the final 1 x 1 convolution's weights
+// divided by it — so the epilogue has no multiply; the staging waves multiply by 2^-kWShift on the way into LDS.
+// Range: |activation| < 65504 / 2^kAShift, |weight| < 65504 / 2^kWShift (both clamped, never inf).
+constexpr int kAShift = 0, kWShift = 8;
+constexpr float kDomain = float(1 << (kAShift + kWShift));   // stored activation / module activation
+constexpr float kStageScale = 1.0f / float(1 << kWShift);    // stored activation -> staged operand (2^kAShift x the module's)
+constexpr float kF16Max = 65504.0f;
 
 constexpr int kBM = 256;      // pixels per workgroup tile
 constexpr int kBN = 64;       // output channels per workgroup tile
@@ -100,15 +116,36 @@ struct Tile {
 };
 
 __device__ inline void split_store(f32x4 v, char *hi, char *lo) {
-    // a = hi + lo, both bf16 (round to nearest even); a - float(hi) is exact in fp32
-    f32x2 a = {v.x, v.y}, b = {v.z, v.w};
-    bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
-    uint32_t ua = __builtin_bit_cast(uint32_t, ha), ub = __builtin_bit_cast(uint32_t, hb);
-    f32x2 ra = {v.x - __builtin_bit_cast(float, ua << 16), v.y - __builtin_bit_cast(float, ua & 0xffff0000u)};
-    f32x2 rb = {v.z - __builtin_bit_cast(float, ub << 16), v.w - __builtin_bit_cast(float, ub & 0xffff0000u)};
-    bf16x2 la = __builtin_convertvector(ra, bf16x2), lb = __builtin_convertvector(rb, bf16x2);
-    *reinterpret_cast<uint2 *>(hi) = make_uint2(ua, ub);
-    *reinterpret_cast<uint2 *>(lo) = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+    // a' = a x kStageScale = hi + lo, both fp16 (round to nearest even): 22 significant bits.
+    // (a is clamped so that a' stays inside fp16's range: beyond it hi would be inf and lo = a' - inf, a NaN for every sum the pixel feeds)
+    constexpr float kClamp = kF16Max / kStageScale;
+#ifdef NET_SPLIT_PLAIN   // the same values with conversions and a subtraction (18 vector instructions per four values; A/B witness of the path below)
+    v = v * kStageScale;
+    v = __builtin_elementwise_min(__builtin_elementwise_max(v, f32x4{-kF16Max, -kF16Max, -kF16Max, -kF16Max}), f32x4{kF16Max, kF16Max, kF16Max, kF16Max});
+    const f16x4 h = __builtin_convertvector(v, f16x4);
+    const f32x4 r = v - __builtin_convertvector(h, f32x4);
+    const f16x4 l = __builtin_convertvector(r, f16x4);
+    *reinterpret_cast<uint2 *>(hi) = __builtin_bit_cast(uint2, h);
+    *reinterpret_cast<uint2 *>(lo) = __builtin_bit_cast(uint2, l);
+#else
+    // v_fma_mix: one instruction scales and rounds to fp16 (hi = f16(a s)), one more forms the exact remainder a s - hi in the fused
+    // multiply-add and rounds it (lo): 12 vector instructions per four values with the clamps. The staging waves store for ~45 % of a
+    // step; the plain sequence cost the network 3 % when the halves became fp16.
+    const float s = kStageScale;
+    float a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = __builtin_amdgcn_fmed3f(v[q], -kClamp, kClamp);
+    uint32_t h[2], l[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[q]) : "v"(a[2 * q]), "s"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[q]) : "v"(a[2 * q + 1]), "s"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l[q]) : "v"(a[2 * q]), "s"(s), "v"(h[q]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[q]) : "v"(a[2 * q + 1]), "s"(s), "v"(h[q]));
+    }
+    *reinterpret_cast<uint2 *>(hi) = make_uint2(h[0], h[1]);
+    *reinterpret_cast<uint2 *>(lo) = make_uint2(l[0], l[1]);
+#endif
 }
 
 __device__ inline f32x4 max4(f32x4 a, f32x4 b) { return __builtin_elementwise_max(a, b); }
@@ -149,11 +186,11 @@ struct ConvArgs {
 
 // One 3 x 3, padding-1 convolution layer with its pre- and post-operations (file header).
 //
-// Persistent workgroups of 8 waves, one per CU: waves 0-3 issue matrix instructions (each owns 64 pixels x 64 channels of the
-// tile), waves 4-7 stage. The work of a workgroup is a stream of steps (tile, 16-channel chunk). During step s the matrix waves
+// Persistent workgroups of 12 waves (kThreads = 768, __launch_bounds__(768, 1): the LDS and register budgets below follow from it),
+// one per CU: waves 0-3 issue matrix instructions (each owns 64 pixels x 64 channels of the tile), waves 4-11 stage. The work of a workgroup is a stream of steps (tile, 16-channel chunk). During step s the matrix waves
 // run 9 k-steps (one per tap, 12 matrix instructions each) out of LDS buffer s & 1 — A fragments and B fragments both: no
 // vector-memory instruction on that side — while the staging waves
-//   * convert and store what they loaded during step s - 1 (the A tile of step s + 1, split into bf16 hi / lo; its packed
+//   * convert and store what they loaded during step s - 1 (the A tile of step s + 1, split into fp16 hi / lo; its packed
 //     weights, copied as they are) into buffer (s + 1) & 1, and
 //   * issue the global loads of step s + 2 into registers, all of them at once: every load has a whole step to land.
 // One workgroup barrier per step is the only synchronisation.
@@ -354,14 +391,14 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
         const char *s_hi = smem + (step & 1) * BUF, *s_lo = s_hi + PLANE;
         const uint4 *s_b = reinterpret_cast<const uint4 *>(s_hi + 2 * PLANE) + lane;
 #ifndef NET_DIAG_NO_MFMA
-        bf16x8 aq[2][4];   // {m block 0 hi, lo, m block 1 hi, lo}
+        f16x8 aq[2][4];    // {m block 0 hi, lo, m block 1 hi, lo}
         uint4 bq[2][4];    // {n half 0 hi, lo, n half 1 hi, lo}
-        auto load_ab = [&](int k, bf16x8(&da)[4], uint4(&db)[4]) __attribute__((always_inline)) {
+        auto load_ab = [&](int k, f16x8(&da)[4], uint4(&db)[4]) __attribute__((always_inline)) {
             const int toff = ((k / 3 - 1) * T::WP + (k % 3 - 1)) * kRowB;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                da[mt * 2 + 0] = *reinterpret_cast<const bf16x8 *>(s_hi + a_off[mt] + toff);
-                da[mt * 2 + 1] = *reinterpret_cast<const bf16x8 *>(s_lo + a_off[mt] + toff);
+                da[mt * 2 + 0] = *reinterpret_cast<const f16x8 *>(s_hi + a_off[mt] + toff);
+                da[mt * 2 + 1] = *reinterpret_cast<const f16x8 *>(s_lo + a_off[mt] + toff);
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f) db[f] = s_b[(k * 4 + f) * 64];
@@ -374,13 +411,13 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const bf16x8 ah = aq[k & 1][mt * 2], al = aq[k & 1][mt * 2 + 1];
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[k & 1][nt * 2]), bl = __builtin_bit_cast(bf16x8, bq[k & 1][nt * 2 + 1]);
+                    const f16x8 ah = aq[k & 1][mt * 2], al = aq[k & 1][mt * 2 + 1];
+                    const f16x8 bh = __builtin_bit_cast(f16x8, bq[k & 1][nt * 2]), bl = __builtin_bit_cast(f16x8, bq[k & 1][nt * 2 + 1]);
                     // the weights are the instruction's A operand (rows = output channels), the pixels its B operand (columns): a lane
                     // then holds four CONSECUTIVE channels of its pixel per accumulator quad, and the epilogue stores 16 bytes at a time
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[mt][nt], 0, 0, 0);
                 }
             // issue order inside the k-step: one LDS read of the next k-step behind each of the first eight matrix
             // instructions (eight reads in a row stall the matrix pipe for the time the LDS takes to accept them)
@@ -493,10 +530,16 @@ __global__ void k_net_input(const float *in, float *x16, int n) {
     size_t img = i >> 10, px = i & 1023;
     float v[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) v[c] = c < 7 ? in[(img * 7 + c) * 1024 + px] : 0.f;
+    for (int c = 0; c < 16; ++c) v[c] = c < 7 ? in[(img * 7 + c) * 1024 + px] * kDomain : 0.f;   // (activation tensors hold kDomain x the module's values)
     float4 *o = reinterpret_cast<float4 *>(x16 + i * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// test probe: a stored activation tensor / kDomain
+__global__ void k_net_unscale(const float *in, float *out, size_t n4) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n4) reinterpret_cast<f32x4 *>(out)[i] = reinterpret_cast<const f32x4 *>(in)[i] * (1.0f / kDomain);
 }
 
 // decoder2's Conv2d(K, 3, 1) + ReLU: NHWC 64 channels -> (n, 3, 32, 32). 16 lanes per pixel, 4 channels each.
@@ -540,11 +583,14 @@ __global__ __launch_bounds__(256) void k_net_normalize(const float *inten, const
     const int probe = blockIdx.x, t = threadIdx.x;
     const float *ip = inten + size_t(probe) * 3072, *np_ = nrm + size_t(probe) * 3072, *dp = dist + size_t(probe) * 1024;
     double sc[3] = {0, 0, 0}, sd = 0;
+    // (a non-finite probe value — the probe pass guards its radiance as SamplerIntegrator::Render does, so none is expected — counts as 0,
+    //  the film's own rule for such samples: one inf would otherwise turn the probe's means, and with them the whole prediction, into NaN)
+    auto fin = [](float v) { return __builtin_isfinite(v) ? v : 0.f; };
     for (int px = t; px < 1024; px += 256) {
-        sc[0] += double(ip[3 * px]);
-        sc[1] += double(ip[3 * px + 1]);
-        sc[2] += double(ip[3 * px + 2]);
-        sd += double(dp[px]);
+        sc[0] += double(fin(ip[3 * px]));
+        sc[1] += double(fin(ip[3 * px + 1]));
+        sc[2] += double(fin(ip[3 * px + 2]));
+        sd += double(fin(dp[px]));
     }
     const double s0 = block_sum(sc[0], s_red), s1 = block_sum(sc[1], s_red), s2 = block_sum(sc[2], s_red), s3 = block_sum(sd, s_red);
     const float mean = float((s0 + s1 + s2) / 3072.0);
@@ -559,15 +605,15 @@ __global__ __launch_bounds__(256) void k_net_normalize(const float *inten, const
         float v[8];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float a = ip[3 * px + c] * ratio;
+            float a = fin(ip[3 * px + c]) * ratio;
             a = a > 0.f ? a : 0.f;
-            v[c] = float(log(1.0 + double(a))) + -0.1f;
+            v[c] = (float(log(1.0 + double(a))) + -0.1f) * kDomain;
             float b = np_[3 * px + c];
-            v[3 + c] = b < -1.f ? -1.f : (b > 1.f ? 1.f : b);
+            v[3 + c] = (b < -1.f ? -1.f : (b > 1.f ? 1.f : (b == b ? b : 0.f))) * kDomain;
         }
-        float d = (dp[px] + 1.0f) * rdiv;
+        float d = (fin(dp[px]) + 1.0f) * rdiv;
         d = d > 0.f ? d : 0.f;
-        v[6] = float(log(1.0 + double(d))) + -0.1f;
+        v[6] = (float(log(1.0 + double(d))) + -0.1f) * kDomain;
         v[7] = 0.f;
         f32x4 *o = reinterpret_cast<f32x4 *>(x16 + ((size_t(probe) * 32 + (31 - y)) * 32 + x) * 16);
         o[0] = f32x4{v[0], v[1], v[2], v[3]};
@@ -642,16 +688,14 @@ const LayerDef kLayers[14] = {
 };
 const int kBnOfLayer[14] = {-1, -1, 0, -1, 1, -1, 2, -1, 3, -1, 4, -1, -1, -1};
 
-uint16_t bf16_rne(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    return uint16_t((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);   // weights are finite
-}
-float bf16_to_float(uint16_t b) {
-    uint32_t u = uint32_t(b) << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
+// fp16 halves of a (scaled) weight on the host: round to nearest even through the compiler's _Float16; out-of-range weights saturate
+void f16_split(float v, uint16_t *hi, uint16_t *lo) {
+    v = std::fmin(std::fmax(v, -kF16Max), kF16Max);
+    if (!(v == v)) v = 0.f;
+    const _Float16 h = static_cast<_Float16>(v);
+    const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+    std::memcpy(hi, &h, 2);
+    std::memcpy(lo, &l, 2);
 }
 
 template <int H, int CIN, int COUT, int PRE, bool BNORM>
@@ -762,7 +806,7 @@ int net_upload(iile_iispt_net *net, const void *host, size_t bytes, void **dev) 
     return IILE_OK;
 }
 
-// B fragments of v_mfma_f32_32x32x16_bf16: lane l holds B[k = 8 (l >> 5) + j][column l & 31], j = 0..7
+// B fragments of v_mfma_f32_32x32x16_f16: lane l holds B[k = 8 (l >> 5) + j][column l & 31], j = 0..7; weights times 2^kWShift
 std::vector<uint16_t> pack_weights(const LayerDef &L, const float *w) {
     const int sub = L.chunk / 16, nchunk = L.cin / L.chunk, ksteps = nchunk * 9 * sub, ntiles = L.cout / kBN;
     std::vector<uint16_t> out(size_t(ntiles) * ksteps * 256 * 8);
@@ -784,7 +828,8 @@ std::vector<uint16_t> pack_weights(const LayerDef &L, const float *w) {
                                     else             // ConvTranspose2d: weight[ci][co][ky][kx], mirrored
                                         v = w[((size_t(ci) * L.cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
                                 }
-                                uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_float(hi));
+                                uint16_t hi, lo;
+                                f16_split(v * float(1 << kWShift), &hi, &lo);
                                 size_t base = ((size_t(nt64) * ksteps + ks) * 4 + nt * 2) * 64 * 8;
                                 out[base + size_t(lane) * 8 + j] = hi;
                                 out[base + 64 * 8 + size_t(lane) * 8 + j] = lo;
@@ -795,7 +840,7 @@ std::vector<uint16_t> pack_weights(const LayerDef &L, const float *w) {
 
 // The activation workspace for up to *cap probes per set of launches (1.19 MiB + 16 B each). The batch is a speed knob only (results do
 // not depend on it, tests/test_iispt_nn.py): if the device cannot give that much — a smaller card, or one shared with another job — the
-// batch is halved until the allocation succeeds (down to 64 probes) and *cap says what was got. IILE_NET_WORKSPACE_MB caps the
+// batch is halved until the allocation succeeds (down to 8 probes) and *cap says what was got. IILE_NET_WORKSPACE_MB caps the
 // allocation from outside (tests use it to walk this path on a 288 GB device).
 constexpr int kDefaultBatch = 8192;   // probes per set of launches when the caller names none: 9.5 GiB of activations; no faster beyond (tools/net_check.py)
 int ensure_workspace(iile_iispt_net *net, int *cap) {
@@ -818,10 +863,18 @@ int ensure_workspace(iile_iispt_net *net, int *cap) {
         }
         (void)hipGetLastError();
         net->ws = nullptr;
-        if (e != hipErrorOutOfMemory || n <= 64)
+        if (e != hipErrorOutOfMemory || n <= 8)
             return iile::api_fail(IILE_ERR_HIP, std::string("iile_iispt_net: no room for the activations of ") + std::to_string(n) + " probes (" +
                                                     std::to_string(bytes >> 20) + " MiB): " + hipGetErrorString(e));
     }
+}
+
+// n probes in sets of at most cap: as many sets as that needs, all of (nearly) the same size — 25 058 probes under a cap of 8 192 run as
+// 4 x 6 265, not 3 x 8 192 + 482 (a set of 482 leaves most of the persistent grid idle for 14 layers: measured + 6 % on the frame)
+int even_batch(int n, int cap) {
+    if (n <= cap) return cap;
+    const int sets = (n + cap - 1) / cap;
+    return (n + sets - 1) / sets;
 }
 
 float *buffer_of(iile_iispt_net *net, int buf, int n_alloc) {
@@ -856,7 +909,10 @@ int iile_iispt_net_create(const iile_iispt_net_weights *w, iile_iispt_net **out)
         std::vector<uint16_t> pk = pack_weights(kLayers[l], w->conv_weight[l]);
         int rc = net_upload(net, pk.data(), pk.size() * 2, reinterpret_cast<void **>(&net->wpack[l]));
         if (rc) return bail(rc);
-        rc = net_upload(net, w->conv_bias[l], size_t(kLayers[l].cout) * 4, reinterpret_cast<void **>(&net->bias[l]));
+        // (activation tensors hold kDomain x the module's values: so do the accumulators' starting values and the BatchNorm shift)
+        std::vector<float> b_scaled(w->conv_bias[l], w->conv_bias[l] + kLayers[l].cout);
+        for (float &b : b_scaled) b *= kDomain;
+        rc = net_upload(net, b_scaled.data(), size_t(kLayers[l].cout) * 4, reinterpret_cast<void **>(&net->bias[l]));
         if (rc) return bail(rc);
         int bn = kBnOfLayer[l];
         if (bn >= 0) {
@@ -866,7 +922,7 @@ int iile_iispt_net_create(const iile_iispt_net_weights *w, iile_iispt_net **out)
             for (int i = 0; i < c; ++i) {
                 float inv = 1.0f / std::sqrt(w->bn_var[bn][i] + w->bn_eps);
                 sc[i] = inv * w->bn_weight[bn][i];
-                sh[i] = w->bn_bias[bn][i] - w->bn_mean[bn][i] * sc[i];
+                sh[i] = (w->bn_bias[bn][i] - w->bn_mean[bn][i] * sc[i]) * kDomain;
             }
             rc = net_upload(net, sc.data(), size_t(c) * 4, reinterpret_cast<void **>(&net->bn_scale[bn]));
             if (rc) return bail(rc);
@@ -874,7 +930,9 @@ int iile_iispt_net_create(const iile_iispt_net_weights *w, iile_iispt_net **out)
             if (rc) return bail(rc);
         }
     }
-    int rc = net_upload(net, w->conv_weight[14], 3 * 64 * 4, reinterpret_cast<void **>(&net->w_out));
+    std::vector<float> w_out(w->conv_weight[14], w->conv_weight[14] + 3 * 64);
+    for (float &v : w_out) v *= 1.0f / kDomain;   // the 1 x 1 convolution reads kDomain x its input: exact either way (a power of two)
+    int rc = net_upload(net, w_out.data(), 3 * 64 * 4, reinterpret_cast<void **>(&net->w_out));
     if (rc) return bail(rc);
     rc = net_upload(net, w->conv_bias[14], 3 * 4, reinterpret_cast<void **>(&net->b_out));
     if (rc) return bail(rc);
@@ -946,9 +1004,10 @@ int run_layers(iile_iispt_net *net, int nb, int na, hipStream_t s, float *layer_
         a.n_img = nb;
         NET_TRY(launch_layer(l, a, net->n_cus, &net->attr_set[l], s));
         if (kRoute[l][3]) NET_TRY(launch_resample(l, a.out, buffer_of(net, BUF_R, na), nb, s));
-        if (layer_out_dev && l == layer) {   // test probe: this layer's NHWC activations
+        if (layer_out_dev && l == layer) {   // test probe: this layer's NHWC activations, as the module has them
             size_t fl = size_t(kLayers[l].h) * kLayers[l].h * kLayers[l].cout;
-            NET_TRY(hipMemcpyAsync(layer_out_dev + first * fl, a.out, fl * size_t(nb) * 4, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(k_net_unscale, dim3(unsigned((fl * size_t(nb) / 4 + 255) / 256)), dim3(256), 0, s, a.out, layer_out_dev + first * fl, fl * size_t(nb) / 4);
+            NET_TRY(hipGetLastError());
         }
     }
     return IILE_OK;
@@ -968,6 +1027,7 @@ int iile_iispt_net_forward(iile_iispt_net *net, const float *in_dev, float *out_
     int rc = ensure_workspace(net, &cap);
     if (rc) return rc;
     const int na = net->ws_probes;
+    cap = even_batch(n, cap);
     for (int first = 0; first < n; first += cap) {
         const int nb = n - first < cap ? n - first : cap;
         hipLaunchKernelGGL(k_net_input, dim3((size_t(nb) * 1024 + 255) / 256), dim3(256), 0, s, in_dev + size_t(first) * 7 * 1024,
@@ -994,6 +1054,7 @@ int iile_iispt_net_predict(iile_iispt_net *net, const float *intensity_dev, cons
     if (rc) return rc;
     const int na = net->ws_probes;
     float *means = net->ws + net->ws_floats_per_probe * size_t(na);   // 3 floats per probe behind the activation buffers
+    cap = even_batch(n, cap);
     for (int first = 0; first < n; first += cap) {
         const int nb = n - first < cap ? n - first : cap;
         hipLaunchKernelGGL(k_net_normalize, dim3(nb), dim3(256), 0, s, intensity_dev + size_t(first) * 3072, normals_dev + size_t(first) * 3072,

@@ -43,8 +43,11 @@ class IisptPipeline:
     the reference's names) or anything with a `.state_dict()` (e.g. a module with a checkpoint of the reference's training loaded).
     Without the HIP library the constructor raises: there is no other backend."""
 
-    def __init__(self, gpu_scene, net, device="cuda", binding=None, bn_eps=BN_EPS):
+    def __init__(self, gpu_scene, net, device="cuda", binding=None, bn_eps=BN_EPS, batch=8192):
+        """batch: probes per set of network launches (the activation workspace is 1.19 MiB x batch; 8 192 is as fast as any larger one;
+        iile_iispt_net_predict cuts a larger call into equal sets and halves the batch if the device is short of memory)."""
         self.gpu = gpu_scene
+        self.batch = int(batch)
         self.device = torch.device(device)
         if binding is None:
             binding = _load_binding()
@@ -70,14 +73,15 @@ class IisptPipeline:
         return y
 
     @torch.no_grad()
-    def __call__(self, pos, direction, batch=8192, film_rows=False, pred_out=None, slot=None):
+    def __call__(self, pos, direction, batch=None, film_rows=False, pred_out=None, slot=None):
         """(n, 3) probe origins and directions -> (predicted intensity (n, h, h, 3), rendered intensity, normals,
         distance), all torch tensors on the device, raster order (film_rows: the prediction in the network's own row order,
         ImageFilm's, as iile_iispt_gather reads it). The two transforms run inside iile_iispt_net_predict.
         pred_out (m, h, h, 3) with slot (n,) int32 on the device: probe i's prediction is written to pred_out[slot[i]] (the frame keeps
         one image per hemi point, valid or not) and pred_out is returned in place of the (n, ...) tensor.
-        batch: probes per network launch set (the activation workspace is 1.19 MiB x batch; 8 192 is as fast as any larger one)."""
+        batch: this call's probes per set of network launches (default: the pipeline's)."""
         n = len(pos)
+        batch = self.batch if batch is None else int(batch)
         inten = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         nrm = torch.empty((n, HEMI, HEMI, 3), dtype=torch.float32, device=self.device)
         dist = torch.empty((n, HEMI, HEMI), dtype=torch.float32, device=self.device)

@@ -128,14 +128,18 @@ class TorchPipeline:
     """render probes (HIP, through the C ABI) -> normalise -> the eager PyTorch module -> rescale: the same call signature as
     pbrt-v3-iile_amd/iispt_nn.IisptPipeline, for A/B timing and end-to-end comparisons only."""
 
-    def __init__(self, gpu_scene, net=None, dtype=torch.float32, device="cuda"):
+    def __init__(self, gpu_scene, net=None, dtype=torch.float32, device="cuda", net_device=None):
+        """net_device="cpu": the module itself runs on the CPU (the reference's own arithmetic: fp32, no MIOpen) and only the probe
+        pass is the GPU's — the statement the HIP network's frames are compared with."""
         self.gpu = gpu_scene
         self.device = torch.device(device)
+        self.net_device = torch.device(net_device) if net_device is not None else self.device
         self.dtype = dtype
-        self.net = (net if net is not None else IISPTNet()).eval().to(self.device)
+        self.net = (net if net is not None else IISPTNet()).eval().to(self.net_device)
         if dtype != torch.float32:
             self.net = self.net.to(dtype)
-        self.net = self.net.to(memory_format=torch.channels_last)
+        if self.net_device.type == "cuda":
+            self.net = self.net.to(memory_format=torch.channels_last)
         self.events = None
 
     def _timed(self, stage, fn):
@@ -149,6 +153,8 @@ class TorchPipeline:
         return out
 
     def infer(self, x):
+        if self.net_device.type != "cuda":
+            return self.net(x.to(self.net_device, self.dtype)).float().to(self.device)
         return self.net(x.to(self.dtype).contiguous(memory_format=torch.channels_last)).float()
 
     @torch.no_grad()
@@ -161,6 +167,10 @@ class TorchPipeline:
         pred = torch.empty_like(inten)
         for first in range(0, n, batch):
             sl = slice(first, min(n, first + batch))
+            if self.net_device.type != "cuda":   # the whole statement on the CPU
+                x, means = normalize_downstream(inten[sl].cpu(), nrm[sl].cpu(), dist[sl].cpu())
+                pred[sl] = transform_upstream(self.net(x), means).to(self.device)
+                continue
             x, means = self._timed("normalize", lambda: normalize_downstream(inten[sl], nrm[sl], dist[sl]))
             y = self._timed("network", lambda: self.infer(x))
             pred[sl] = self._timed("rescale", lambda: transform_upstream(y, means))

@@ -153,6 +153,23 @@ def test_wire_order_is_the_references():
     assert np.array_equal(back.ravel(), fx["wire_out"])
 
 
+def per_element(got, want):
+    """north_star's tolerance, per element (VERDICT r05 "next" 2): the share of elements with
+    |err| <= 1e-4 |want| + 1e-6 max|want|, the mean relative error over the elements that are not zero, max|err| / max|want|."""
+    got, want = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
+    mx = float(np.abs(want).max())
+    err = np.abs(got - want)
+    nz = np.abs(want) > 1e-6 * mx
+    return float((err <= 1e-4 * np.abs(want) + 1e-6 * mx).mean()), float((err[nz] / np.abs(want[nz])).mean()), float(err.max() / mx)
+
+
+def assert_per_element(got, want, what):
+    inside, mean_rel, max_over_max = per_element(got, want)
+    print(f"{what}: {inside * 100:.4f} % of elements within 1e-4 relative (+ 1e-6 of the maximum), mean relative error {mean_rel:.2e}, max error / max {max_over_max:.2e}")
+    assert inside >= 0.999 and mean_rel <= 1e-5, (what, inside, mean_rel, max_over_max)
+    return inside, mean_rel, max_over_max
+
+
 # the module whose OUTPUT is what convolution layer l of csrc/device/iispt_net.hip stores (behind LeakyReLU / BatchNorm)
 _LAYER_TAPS = [("encoder0", 1), ("encoder0", 3), ("encoder1", 3), ("encoder1", 5), ("encoder2", 3), ("encoder2", 5), ("encoder3", 3),
                ("encoder3", 5), ("decoder0", 2), ("decoder0", 4), ("decoder1", 2), ("decoder1", 4), ("decoder2", 1), ("decoder2", 3)]
@@ -160,9 +177,10 @@ _LAYER_TAPS = [("encoder0", 1), ("encoder0", 3), ("encoder1", 3), ("encoder1", 5
 
 @pytest.mark.gpu
 def test_network_on_the_gpu_against_the_reference_fixture(binding):
-    """The product's network — the hand-written kernels behind iile_iispt_net_* (split-bf16 matrix instructions, fp32
-    accumulation) — against the REFERENCE module's output (fixture): within 1e-4 of the largest value. Beside it, for the
-    record, eager PyTorch on the same device in fp32 and in plain bf16 (neither is the product path)."""
+    """The product's network — the hand-written kernels behind iile_iispt_net_* (split-fp16 matrix instructions: 22 significant
+    bits per operand, fp32 accumulation) — against the REFERENCE module's output (fixture): PER ELEMENT inside north_star's 1e-4
+    relative band (>= 99.9 % of elements, mean relative error <= 1e-5) and within 1e-5 of the largest value everywhere. Beside it,
+    for the record, eager PyTorch on the same device in fp32 and in plain bf16 (neither is the product path)."""
     torch.cuda.init()
     fx = _fixture()
     net, _ = _recipe_net()
@@ -180,7 +198,8 @@ def test_network_on_the_gpu_against_the_reference_fixture(binding):
     err32 = float(np.abs(y32 - want).max()) / scale
     err16 = float(np.abs(y16 - want).max()) / scale
     print(f"IISPTNet vs the reference fixture, max error over the largest output: HIP kernels {err_hip:.2e}; eager PyTorch fp32 {err32:.2e}, bf16 {err16:.2e}")
-    assert err_hip < 1e-4, err_hip
+    assert err_hip < 1e-5, err_hip      # (round 5's split-bf16 kernels: 2.4e-5, and 96 % of the elements inside the band)
+    assert_per_element(y.cpu().numpy(), want, "HIP network vs the reference module's fixture (4 probes)")
     assert err32 < 1e-4, err32
     assert err16 < 0.1, err16    # measured, not a parity claim: plain bf16 keeps 8 significant bits through 15 convolutions
 
@@ -212,8 +231,8 @@ def test_hip_network_layer_by_layer_against_the_module(binding):
         g.forward(xd.data_ptr(), yd.data_ptr(), n, layer_out_ptr=lo.data_ptr(), layer=l)
         torch.cuda.synchronize()
         err = float((lo.cpu().permute(0, 3, 1, 2) - a).abs().max() / a.abs().max())
-        assert err < 5e-5, (l, err)
-    assert float((yd.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+        assert err < 5e-6, (l, err)
+    assert float((yd.cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
     y2 = torch.empty_like(yd)
     g.forward(xd.data_ptr(), y2.data_ptr(), n, max_batch=10)
     y1 = torch.empty((1, 3, 32, 32), dtype=torch.float32, device="cuda")
@@ -248,7 +267,105 @@ def test_hip_network_follows_a_checkpoint_not_the_recipe(binding):
     y = torch.empty((9, 3, 32, 32), dtype=torch.float32, device="cuda")
     g.forward(x.cuda().data_ptr(), y.data_ptr(), 9)
     torch.cuda.synchronize()
-    assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+    assert float((y.cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
+    assert_per_element(y.cpu().numpy(), ref.numpy(), "HIP network vs the module with a foreign checkpoint (9 probes)")
+
+
+@pytest.mark.gpu
+def test_network_and_predicted_hemispheres_per_element_on_256_probes(binding):
+    """north_star's tolerance where it is hardest to meet (VERDICT r05 "next" 2): 256 probes — rendered ones, of killeroo-simple —
+    through iile_iispt_net_forward and through iile_iispt_net_predict, against the fp32 module on the CPU and the tensor-expression
+    transforms, PER ELEMENT: |err| <= 1e-4 |want| + 1e-6 max on >= 99.9 % of the elements, mean relative error <= 1e-5 — for the
+    network's output and for the predicted hemispheres AFTER transformMapsUpstream (exp(v) - 1 and the per-channel rescale:
+    iisptrenderrunner.cpp:1095-1133). A three-product split of bf16 halves (round 5) reaches 96 % / 7e-5 here; fp16 halves with
+    the weights' exponents moved into the normal range reach the fp32 module's own distance from exact arithmetic."""
+    torch.cuda.init()
+    scene = binding.HostScene(xres=64, yres=64, spp=1)
+    gpu = binding.GpuScene(scene)
+    rng = np.random.default_rng(17)
+    n = 256
+    pos = rng.uniform((-150, -100, -130), (250, 150, 0), (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    net, _ = _recipe_net()
+    pipe = nn_mod.IisptPipeline(gpu, net=net, binding=binding)
+    pred, inten, nrm, dist = pipe(pos, d, batch=100)
+    with torch.no_grad():
+        x, means = ref_mod.normalize_downstream(inten.cpu(), nrm.cpu(), dist.cpu())
+        y_ref = net(x)
+        want = ref_mod.transform_upstream(y_ref, means)
+        y_hip = pipe.infer(x.cuda()).cpu()
+    assert bool(torch.isfinite(pred).all()) and float(want.abs().max()) > 0
+    assert_per_element(y_hip.numpy(), y_ref.numpy(), "network output, 256 rendered probes, HIP vs the fp32 module on the CPU")
+    assert_per_element(pred.cpu().numpy(), want.numpy(), "predicted hemispheres after transformMapsUpstream, 256 probes")
+
+
+@pytest.mark.gpu
+def test_a_non_finite_probe_value_does_not_poison_the_prediction(binding):
+    """an inf / NaN in a probe image (the probe pass guards its radiance, so none is expected) used to turn the whole
+    256-pixel tile's sums into NaN through inf - inf in the operand split. k_net_normalize now counts such a value as 0 — the
+    film's own rule for such samples — and the staged operands are clamped into fp16's range: the prediction is finite, and equal
+    to the prediction of the same probe with zeros in those places; a huge activation saturates instead of becoming inf."""
+    torch.cuda.init()
+    rng = np.random.default_rng(3)
+    n, h = 5, 32
+    inten = (rng.random((n, h, h, 3)) * 2).astype(np.float32)
+    nrm = rng.uniform(-1, 1, (n, h, h, 3)).astype(np.float32)
+    dist = rng.uniform(0, 40, (n, h, h)).astype(np.float32)
+    bad_i, bad_n, bad_d = inten.copy(), nrm.copy(), dist.copy()
+    bad_i[1, 3, 4, 0] = np.inf
+    bad_i[1, 9, 9, 2] = np.nan
+    bad_d[2, 0, 0] = np.inf
+    bad_n[3, 5, 5, 1] = np.nan
+    zero_i, zero_n, zero_d = inten.copy(), nrm.copy(), dist.copy()
+    zero_i[1, 3, 4, 0] = 0
+    zero_i[1, 9, 9, 2] = 0
+    zero_d[2, 0, 0] = 0
+    zero_n[3, 5, 5, 1] = 0
+    net, _ = _recipe_net()
+    g = binding.GpuNet(net.state_dict())
+    outs = []
+    for a, b_, c in ((bad_i, bad_n, bad_d), (zero_i, zero_n, zero_d)):
+        da, db, dc = (torch.from_numpy(v).cuda() for v in (a, b_, c))
+        out = torch.empty((n, h, h, 3), dtype=torch.float32, device="cuda")
+        g.predict(da.data_ptr(), db.data_ptr(), dc.data_ptr(), out.data_ptr(), n)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+    # the bare network with an input far outside fp16's range: finite output (saturated operands), the other probes untouched
+    x = torch.from_numpy(rng.standard_normal((3, 7, h, h)).astype(np.float32))
+    x_big = x.clone()
+    x_big[1, 0, 5, 5] = 3e7
+    ya, yb = (torch.empty((3, 3, h, h), dtype=torch.float32, device="cuda") for _ in range(2))
+    g.forward(x.cuda().data_ptr(), ya.data_ptr(), 3)
+    g.forward(x_big.cuda().data_ptr(), yb.data_ptr(), 3)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(yb).all()) and torch.equal(ya[0], yb[0]) and torch.equal(ya[2], yb[2])
+
+
+@pytest.mark.gpu
+def test_network_batch_shrinks_when_the_workspace_does_not_fit(binding, monkeypatch):
+    """the activation workspace is 1.19 MiB per probe of a batch. When the device cannot hold the batch asked for
+    (here: a 40 MiB cap through IILE_NET_WORKSPACE_MB) the batch is halved until it fits — same bits, more launches — and below 64
+    probes the call fails with a message instead of crashing."""
+    torch.cuda.init()
+    import iispt_net_recipe as recipe
+    net, _ = _recipe_net()
+    n = 150
+    x = torch.from_numpy(recipe.fixture_input(n)).cuda()
+    g = binding.GpuNet(net.state_dict())
+    y = torch.empty((n, 3, 32, 32), dtype=torch.float32, device="cuda")
+    g.forward(x.data_ptr(), y.data_ptr(), n)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("IILE_NET_WORKSPACE_MB", "40")     # room for 33 probes: 150 -> 75 -> 38 -> 19
+    g2 = binding.GpuNet(net.state_dict())
+    y2 = torch.empty_like(y)
+    g2.forward(x.data_ptr(), y2.data_ptr(), n)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    monkeypatch.setenv("IILE_NET_WORKSPACE_MB", "1")
+    g3 = binding.GpuNet(net.state_dict())
+    with pytest.raises(RuntimeError, match="no room for the activations"):
+        g3.forward(x.data_ptr(), y2.data_ptr(), n)
 
 
 @pytest.mark.gpu
@@ -305,7 +422,7 @@ def test_pipeline_keeps_everything_on_the_device(binding):
     torch.manual_seed(3)
     net = ref_mod.IISPTNet()
     pipe = nn_mod.IisptPipeline(gpu, net=net, binding=binding)
-    assert pipe.hip_net is not None and pipe.net is None   # the product path: the HIP kernels, not the PyTorch module
+    assert pipe.hip_net is not None and not hasattr(pipe, "net")   # the product holds ONE backend: the HIP kernels
     pred, inten, nrm, dist = pipe(pos, d, batch=10)
     hi, hn, hd, _ = gpu.render_probes(pos, d)
     assert np.array_equal(inten.cpu().numpy(), hi) and np.array_equal(nrm.cpu().numpy(), hn) and np.array_equal(dist.cpu().numpy(), hd)
@@ -314,9 +431,35 @@ def test_pipeline_keeps_everything_on_the_device(binding):
         want = ref_mod.transform_upstream(net.cpu().eval()(x), means).numpy()
     got = pred.cpu().numpy()
     assert np.isfinite(got).all()
-    scale = np.abs(want).max() + 1e-12
-    assert np.abs(got - want).max() < 2e-3 * scale
+    # measured bounds (the MIOpen era's 2e-3 / 1e-3 are gone): per element inside north_star's band, 3e-6 of the maximum at worst
+    _, _, worst = assert_per_element(got, want, "pipeline (render -> normalise -> network -> rescale), 24 probes")
+    assert worst < 1e-5
     got_means = got.reshape(24, -1, 3).astype(np.float64).mean(1)
     lit = (means.numpy() > 1e-6) & (got_means > 0)   # a channel the (random) network leaves at 0 stays 0: mul = 0
     assert lit.sum() >= 8
-    assert np.allclose(got_means[lit], means.numpy()[lit], rtol=1e-3)
+    assert np.allclose(got_means[lit], means.numpy()[lit], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_indirect_film_of_a_small_frame_against_the_fp32_module(binding):
+    """What the network's arithmetic does to the FILM ("no test states what the split does to the indirect film
+    after exp(v) - 1 and the rescale"): the indirect pass of a 96 x 80 frame of killeroo-simple (two sweeps, radius 4 then 3; every
+    stage but the network identical — same hemi points, same probe images, same gather) with the HIP network and with the fp32
+    module on the CPU behind the tensor-expression transforms. Per film pixel and channel: inside north_star's 1e-4 relative band
+    on >= 99.9 %, mean relative error <= 1e-5; the weights (which samples were recorded) equal."""
+    torch.cuda.init()
+    frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
+    scene = binding.HostScene(xres=96, yres=80, spp=1)
+    gpu = binding.GpuScene(scene)
+    net, _ = _recipe_net()
+    n_tasks = 6 + 12
+    hip = frame_mod.IisptFrame(binding, gpu, nn_mod.IisptPipeline(gpu, net=net, binding=binding))
+    hip.run_batched(n_tasks, radius_start=4.0)
+    ref = frame_mod.IisptFrame(binding, gpu, ref_mod.TorchPipeline(gpu, net=net, net_device="cpu"))
+    ref.run_batched(n_tasks, radius_start=4.0)
+    assert hip.stats == ref.stats and hip.stats["probes"] > 300
+    assert torch.equal(hip.film[..., 3], ref.film[..., 3]) and float((hip.film[..., 3] > 0).double().mean()) > 0.9
+    want = ref.film[..., :3].cpu().numpy()
+    assert float(np.abs(want).max()) > 0
+    assert_per_element(hip.film[..., :3].cpu().numpy(), want, "indirect film monitor, 96 x 80, two sweeps, HIP network vs the fp32 module")
+    assert_per_element(hip.indirect_image().cpu().numpy(), ref.indirect_image().cpu().numpy(), "indirect image (normalised monitor)")

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-6 call 3: the operand split of the staging waves as v_fma_mix (default) against conversions + subtraction (variant): same bits? time?
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+O=$R/gpurun_out/r06_call3
+mkdir -p $O
+cd $R
+for rep in 1 2; do
+for v in default split_plain; do
+  if [ $v = default ]; then unset IILE_GPU_LIB; else export IILE_GPU_LIB=$R/pbrt-v3-iile_amd/lib/variants/libiile_gpu_$v.so; fi
+  timeout 600 python3 tools/net_check.py 8192 --no-torch > $O/net_check_${v}_$rep.json 2> $O/net_check_${v}_$rep.err
+  python3 -c "
+import json; j=json.loads(open('$O/net_check_${v}_$rep.json').readline()); print('$v', $rep, j['hip_net']['ms'], j['n37_output_sha256'], j['fixture_err_over_max'])"
+done
+done
+unset IILE_GPU_LIB
+timeout 600 python3 bench.py --workload iispt --steps 5 --warmup 2 --cpu-seconds 0 > $O/bench_iispt.json 2> $O/bench_iispt.err; python3 -c "
+import json; j=json.loads(open('$O/bench_iispt.json').readline()); print(j['ms_per_step'], j['stage_ms_per_step'], j['roofline']['frac_executed'])"
+timeout 900 python3 -m pytest tests/test_iispt_nn.py -m gpu -x -q > $O/tests.txt 2>&1; tail -2 $O/tests.txt
