@@ -165,6 +165,34 @@ __device__ inline f32x4 leaky4(f32x4 t) {
     return r;
 }
 __device__ inline f32x4 lerp4(float wa, f32x4 a, float wb, f32x4 b) { return wa * a + wb * b; }
+// the bare maximum of four values (no quieting moves: see leaky4)
+__device__ inline f32x4 max4_raw(f32x4 a, f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float o;
+        asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a[q]), "v"(b[q]));
+        r[q] = o;
+    }
+    return r;
+}
+// the value of the lane whose number differs in bit 0 (quad_perm [1,0,3,2]), in bit 3 (row_ror:8 inside a row of 16 lanes), in bit 4
+// (ds_swizzle, swap of 16-lane halves): register-to-register, no memory
+template <int BIT>
+__device__ inline f32x4 other_lane4(f32x4 v) {
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float f = v[q];
+        const int x = __float_as_int(f);   // (__builtin_bit_cast on the vector ELEMENT reads element 0 four times with this compiler)
+        int y;
+        if (BIT == 0) y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);
+        else if (BIT == 3) y = __builtin_amdgcn_mov_dpp(x, 0x128, 0xf, 0xf, true);
+        else y = __builtin_amdgcn_ds_swizzle(x, 0x401F);
+        r[q] = __int_as_float(y);
+    }
+    return r;
+}
 
 // nn.Upsample(scale_factor=2, mode="bilinear") (align_corners False): source index and weight of destination d
 __device__ inline void up_coord(int d, int n_in, int &i0, int &i1, float &l1) {
@@ -181,6 +209,7 @@ struct ConvArgs {
     const uint4 *wpack;    // [COUT/64][k-steps][n-tile 2][hi, lo][lane 64] x 16 bytes
     const float *bias, *bn_scale, *bn_shift;   // [COUT]; bn_* only when BNORM
     float *out;            // [n][H][H][COUT]
+    float *pool_out;       // POOL: nn.MaxPool2d(2) of `out`, [n][H/2][H/2][COUT] (the next level's input), written by the same epilogue
     int n_img;
 };
 
@@ -194,7 +223,7 @@ struct ConvArgs {
 //     weights, copied as they are) into buffer (s + 1) & 1, and
 //   * issue the global loads of step s + 2 into registers, all of them at once: every load has a whole step to land.
 // One workgroup barrier per step is the only synchronisation.
-template <int H, int CIN, int COUT, int PRE, bool BNORM>
+template <int H, int CIN, int COUT, int PRE, bool BNORM, bool POOL>
 __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
     using T = Tile<H>;
     constexpr int NCHUNK = CIN / kChunk;
@@ -442,39 +471,77 @@ __global__ __launch_bounds__(kThreads, 1) void k_conv3x3(ConvArgs p) {
             const int y0 = H >= 32 ? (mtile % T::TILES_PER_IMG) * T::ROWS : 0;
             // (one matrix wave per SIMD runs this alone — the matrix pipe idles meanwhile — so the arithmetic is written four values
             //  wide: four independent adds, multiplies, maxima in a row instead of a dependent chain per value)
+            float *dst[2];
+            bool live[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int m = wave * 64 + mt * 32 + r;
                 const int il = m / (T::ROWS * H), y = y0 + (m / H) % T::ROWS, x = m % H;
                 const int img = img0 + il;
-                const bool live = img < p.n_img && mtile < n_mtiles;
-                float *dst = p.out + ((size_t(img) * H + y) * H + x) * COUT;
+                live[mt] = img < p.n_img && mtile < n_mtiles;
+                dst[mt] = p.out + ((size_t(img) * H + y) * H + x) * COUT;
+            }
+            // MaxPool2d(2) of this layer's output in the same registers (POOL: the three encoder levels whose output is both a skip
+            // tensor and, pooled, the next level's input). Where the four pixels of a 2 x 2 block sit: H = 32 — a wave's two pixel
+            // blocks are rows 2 wave and 2 wave + 1, a lane's pixel is x = r: the other row is the other block of the SAME lane, the
+            // other column the lane next door. H = 16 — a block is two rows of 16: lanes r, r ^ 1, r ^ 16. H = 8 — a block is four
+            // rows of 8 of one image: lanes r, r ^ 1, r ^ 8. One lane of each four stores the block's 16 bytes per channel quad.
+            constexpr int HP2 = H / 2;
+            float *pdst[2] = {nullptr, nullptr};
+            bool pstore[2] = {false, false};
+            if (POOL) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int m = wave * 64 + mt * 32 + r;
+                    const int il = m / (T::ROWS * H), y = y0 + (m / H) % T::ROWS, x = m % H;
+                    const int img = img0 + il;
+                    pdst[mt] = p.pool_out + ((size_t(img) * HP2 + (y >> 1)) * HP2 + (x >> 1)) * COUT;
+                    pstore[mt] = live[mt] && (x & 1) == 0 && (y & 1) == 0;   // (H = 32: y is even for block 0, the one that stores)
+                }
+            }
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int co = ntile * kBN + nt * 32 + 8 * g + 4 * h;
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = ntile * kBN + nt * 32 + 8 * g + 4 * h;
+                    f32x4 v[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
                         f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
                         if (!PAR_LDS) bias = *reinterpret_cast<const f32x4 *>(p.bias + co);
                         f32x4 t = f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
 #ifdef NET_DIAG_NO_ARITH   // timing only: the sums consumed as they are
-                        f32x4 v = t;
+                        v[mt] = t;
 #else
                         if (!PAR_LDS) t = t + bias;   // (with the parameters in LDS the sums started at the bias)
-                        f32x4 v = leaky4(t);   // LeakyReLU(0.2): t for t > 0, 0.2 t below
+                        v[mt] = leaky4(t);   // LeakyReLU(0.2): t for t > 0, 0.2 t below
 #endif
                         if (BNORM) {
                             const f32x4 sc = PAR_LDS ? *reinterpret_cast<const f32x4 *>(s_par + COUT + co) : *reinterpret_cast<const f32x4 *>(p.bn_scale + co);
                             const f32x4 sh = PAR_LDS ? *reinterpret_cast<const f32x4 *>(s_par + 2 * COUT + co) : *reinterpret_cast<const f32x4 *>(p.bn_shift + co);
-                            v = v * sc + sh;
+                            v[mt] = v[mt] * sc + sh;
                         }
 #ifdef NET_DIAG_KEEP_ONLY   // timing only: the arithmetic kept alive, nothing written
-                        asm volatile("" ::"v"(v));
+                        asm volatile("" ::"v"(v[mt]));
 #else
-                        if (live) *reinterpret_cast<f32x4 *>(dst + co) = v;
+                        if (live[mt]) *reinterpret_cast<f32x4 *>(dst[mt] + co) = v[mt];
 #endif
                     }
-            }
+                    if (POOL) {
+                        if (H >= 32) {
+                            f32x4 m4 = max4_raw(v[0], v[1]);
+                            m4 = max4_raw(m4, other_lane4<0>(m4));
+                            if (pstore[0]) *reinterpret_cast<f32x4 *>(pdst[0] + co) = m4;
+                        } else {
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) {
+                                f32x4 m4 = max4_raw(v[mt], other_lane4<0>(v[mt]));
+                                m4 = max4_raw(m4, H == 16 ? other_lane4<4>(m4) : other_lane4<3>(m4));
+                                if (pstore[mt]) *reinterpret_cast<f32x4 *>(pdst[mt] + co) = m4;
+                            }
+                        }
+                    }
+                }
             start_tile(step / NCHUNK + 1);   // (the workgroup's tile after its last: parameters of some n-tile, never used)
         }
         NET_STAMP(st_epi);
@@ -698,13 +765,13 @@ void f16_split(float v, uint16_t *hi, uint16_t *lo) {
     std::memcpy(lo, &l, 2);
 }
 
-template <int H, int CIN, int COUT, int PRE, bool BNORM>
+template <int H, int CIN, int COUT, int PRE, bool BNORM, bool POOL = false>
 hipError_t launch_conv(const ConvArgs &a, int n_cus, bool *attr_set, hipStream_t s) {
     using T = Tile<H>;
     constexpr size_t buffers = 2 * (size_t(T::NLP) * kRowB * 2 + kBStep);   // two buffers of {A hi, A lo, B}
     constexpr size_t lds = buffers + 3 * size_t(COUT) * 4 <= 160 * 1024 ? buffers + 3 * size_t(COUT) * 4 : buffers;   // + bias, scale, shift where they fit
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = k_conv3x3<H, CIN, COUT, PRE, BNORM>;
+    auto kern = k_conv3x3<H, CIN, COUT, PRE, BNORM, POOL>;
     if (!*attr_set) {   // once per network object, i.e. per device the object was made on (the attribute is per device)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
@@ -717,14 +784,22 @@ hipError_t launch_conv(const ConvArgs &a, int n_cus, bool *attr_set, hipStream_t
     return hipGetLastError();
 }
 
+// MaxPool2d(2) behind encoder0 / 1 / 2's second convolution: in that convolution's epilogue (default), or k_pool2 (-DNET_POOL_KERNEL:
+// the A/B witness — same bits)
+#ifdef NET_POOL_KERNEL
+constexpr bool kPoolInEpilogue = false;
+#else
+constexpr bool kPoolInEpilogue = true;
+#endif
+
 hipError_t launch_layer(int layer, const ConvArgs &a, int n_cus, bool *attr_set, hipStream_t s) {
     switch (layer) {
         case 0: return launch_conv<32, 16, 64, PRE_NONE, false>(a, n_cus, attr_set, s);
-        case 1: return launch_conv<32, 64, 64, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 1: return launch_conv<32, 64, 64, PRE_NONE, false, kPoolInEpilogue>(a, n_cus, attr_set, s);
         case 2: return launch_conv<16, 64, 128, PRE_NONE, true>(a, n_cus, attr_set, s);
-        case 3: return launch_conv<16, 128, 128, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 3: return launch_conv<16, 128, 128, PRE_NONE, false, kPoolInEpilogue>(a, n_cus, attr_set, s);
         case 4: return launch_conv<8, 128, 256, PRE_NONE, true>(a, n_cus, attr_set, s);
-        case 5: return launch_conv<8, 256, 256, PRE_NONE, false>(a, n_cus, attr_set, s);
+        case 5: return launch_conv<8, 256, 256, PRE_NONE, false, kPoolInEpilogue>(a, n_cus, attr_set, s);
         case 6: return launch_conv<4, 256, 512, PRE_NONE, true>(a, n_cus, attr_set, s);
         case 7: return launch_conv<4, 512, 256, PRE_NONE, false>(a, n_cus, attr_set, s);
         case 8: return launch_conv<8, 512, 256, PRE_CAT, true>(a, n_cus, attr_set, s);
@@ -1002,8 +1077,10 @@ int run_layers(iile_iispt_net *net, int nb, int na, hipStream_t s, float *layer_
         a.bn_scale = bn >= 0 ? net->bn_scale[bn] : nullptr;
         a.bn_shift = bn >= 0 ? net->bn_shift[bn] : nullptr;
         a.n_img = nb;
+        const bool pooled_here = kPoolInEpilogue && kRoute[l][3] == 1;
+        a.pool_out = pooled_here ? buffer_of(net, BUF_R, na) : nullptr;
         NET_TRY(launch_layer(l, a, net->n_cus, &net->attr_set[l], s));
-        if (kRoute[l][3]) NET_TRY(launch_resample(l, a.out, buffer_of(net, BUF_R, na), nb, s));
+        if (kRoute[l][3] && !pooled_here) NET_TRY(launch_resample(l, a.out, buffer_of(net, BUF_R, na), nb, s));
         if (layer_out_dev && l == layer) {   // test probe: this layer's NHWC activations, as the module has them
             size_t fl = size_t(kLayers[l].h) * kLayers[l].h * kLayers[l].cout;
             hipLaunchKernelGGL(k_net_unscale, dim3(unsigned((fl * size_t(nb) / 4 + 255) / 256)), dim3(256), 0, s, a.out, layer_out_dev + first * fl, fl * size_t(nb) / 4);
