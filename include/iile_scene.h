@@ -66,8 +66,9 @@ enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1, IILE_MAT_UBER = 2, IILE_MAT_MIR
 
 /* MatteMaterial / PlasticMaterial / UberMaterial / MirrorMaterial / GlassMaterial with constant
  * textures (src/materials/matte.cpp:45-62, plastic.cpp:45-70, uber.cpp:45-100, mirror.cpp:44-55,
- * glass.cpp:45-92). Uber: opacity 1 and Kt 0 only, uroughness == vroughness. Glass: smooth only
- * (uroughness = vroughness = 0: one FresnelSpecular lobe, as the path integrator gets it). */
+ * glass.cpp:45-92). Uber: uroughness == vroughness; its two SpecularTransmission lobes (the pass-through of opacity < 1 and Kt,
+ * uber.cpp:53-61, 94-99) are rendered by iile_render and the probe pass — the IISPT runner and direct pass refuse such scenes.
+ * Glass: smooth only (uroughness = vroughness = 0: one FresnelSpecular lobe, as the path integrator gets it). */
 typedef struct iile_material {
     int32_t type;
     float kd[3];     /* matte, plastic, uber; 0 for mirror */
@@ -79,7 +80,7 @@ typedef struct iile_material {
     int32_t remap_roughness;
     float eta;       /* uber, glass: index of refraction of FresnelDielectric(1, eta) */
     float kr[3];     /* uber, mirror, glass: specular reflectance */
-    float kt[3];     /* glass: specular transmittance */
+    float kt[3];     /* glass, uber: specular transmittance */
     float on_a, on_b; /* matte with sigma != 0: the Oren-Nayar constants A, B (reflection.h:416-419) */
     /* image textures (index into iile_scene_desc::textures) whose value at a hit, multiplied by the constant kd /
      * ks / kr / kt (1 for a plain "imagemap", the constant factor of a "scale" texture, textures/scale.h:56-58),
@@ -93,6 +94,9 @@ typedef struct iile_material {
     int32_t rough_tex;
     /* "sigma" of matte as a float image texture (degrees, clamped to [0, 90] at the hit: matte.cpp:56-61), or -1 */
     int32_t sigma_tex;
+    /* uber: "opacity" (constant; {1, 1, 1} for every other material): 1 - opacity is the pass-through lobe, every other
+     * coefficient is multiplied by it (uber.cpp:53-99) */
+    float opacity[3];
 } iile_material;
 
 /* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (src/textures/imagemap.h:78-112,

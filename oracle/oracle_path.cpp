@@ -1541,6 +1541,11 @@ struct Oracle {
         float spec_eta = 1.f;
         bool spec_glass = false;                      // the specular lobe is FresnelSpecular(kr, kt, 1, spec_eta)
         Rgb kt;
+        // UberMaterial's two SpecularTransmission lobes (uber.cpp:53-61, 94-99): the pass-through of a surface that is not opaque —
+        // SpecularTransmission(1 - opacity, 1, 1), the FIRST lobe of the BSDF — and SpecularTransmission(opacity Kt, 1, eta), the LAST
+        bool has_t0 = false, has_t1 = false;
+        Rgb t0, t1;
+        float t1_eta = 1.f;
         float eta = 1.f;                              // BSDF::eta (path.cpp:152)
         int n_nonspec() const { return (has_lambert ? 1 : 0) + (has_micro ? 1 : 0); }
         V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
@@ -1591,7 +1596,21 @@ struct Oracle {
             Rgb v = tex_evaluate(tex, is) * Rgb(constant[0], constant[1], constant[2]);  // ScaleTexture: tex1 * tex2 (x 1 if plain)
             return clamp0(v.c);
         };
+        // UberMaterial (uber.cpp:53-61): op = opacity.Clamp(), t = (-op + Spectrum(1.f)).Clamp(); a surface that is not opaque gets
+        // BSDF(*si, 1.f) with SpecularTransmission(t, 1.f, 1.f, mode) as its first lobe, and every other coefficient is op * K.Clamp()
+        Rgb op(1.f);
+        if (m.type == IILE_MAT_UBER) {
+            op = clamp0(m.opacity);
+            const float tt[3] = {-op.c[0] + 1.f, -op.c[1] + 1.f, -op.c[2] + 1.f};
+            const Rgb t = clamp0(tt);
+            if (!t.is_black()) {
+                b.has_t0 = true;
+                b.t0 = t;
+                ++b.n_lobes;
+            }
+        }
         Rgb kd = param(m.kd, m.kd_tex);
+        if (m.type == IILE_MAT_UBER) kd = op * kd;
         if (!kd.is_black()) {
             b.has_lambert = true;
             b.kd = kd;
@@ -1613,6 +1632,7 @@ struct Oracle {
         }
         if (m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) {
             Rgb ks = param(m.ks, m.ks_tex);
+            if (m.type == IILE_MAT_UBER) ks = op * ks;
             if (!ks.is_black()) {
                 b.has_micro = true;
                 b.ks = ks;
@@ -1635,6 +1655,7 @@ struct Oracle {
         }
         if (m.type == IILE_MAT_UBER || m.type == IILE_MAT_MIRROR) {
             Rgb kr = param(m.kr, m.kr_tex);
+            if (m.type == IILE_MAT_UBER) kr = op * kr;
             if (!kr.is_black()) {
                 b.has_spec = true;
                 b.kr = kr;
@@ -1642,7 +1663,16 @@ struct Oracle {
                 b.spec_eta = m.eta;
                 ++b.n_lobes;
             }
-            if (m.type == IILE_MAT_UBER) b.eta = m.eta;  // BSDF(*si, e), uber.cpp:58
+            if (m.type == IILE_MAT_UBER) {
+                b.eta = b.has_t0 ? 1.f : m.eta;  // BSDF(*si, 1.f) / BSDF(*si, e), uber.cpp:56-61
+                Rgb kt = op * param(m.kt, m.kt_tex);   // uber.cpp:94-99
+                if (!kt.is_black()) {
+                    b.has_t1 = true;
+                    b.t1 = kt;
+                    b.t1_eta = m.eta;
+                    ++b.n_lobes;
+                }
+            }
         }
         if (m.type == IILE_MAT_GLASS) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
             b.eta = m.eta;
@@ -1841,11 +1871,13 @@ struct Oracle {
             return Rgb(0);
         }
         int comp = std::min((int)std::floor(u[0] * matching), matching - 1);
-        // BxDF order: Lambertian, microfacet, specular reflection (plastic.cpp:53-69, uber.cpp:62-92)
-        int pick = -1, count = comp;  // 0 Lambertian, 1 microfacet, 2 specular
-        if (b.has_lambert && count-- == 0) pick = 0;
+        // BxDF order: [uber's pass-through], Lambertian, microfacet, specular reflection, [uber's Kt lobe] (plastic.cpp:53-69, uber.cpp:53-99)
+        int pick = -1, count = comp;  // 0 Lambertian, 1 microfacet, 2 specular, 3 / 4 uber's SpecularTransmission lobes
+        if (b.has_t0 && allow_specular && count-- == 0) pick = 3;
+        if (pick < 0 && b.has_lambert && count-- == 0) pick = 0;
         if (pick < 0 && b.has_micro && count-- == 0) pick = 1;
         if (pick < 0 && b.has_spec && allow_specular && count-- == 0) pick = 2;
+        if (pick < 0 && b.has_t1 && allow_specular && count-- == 0) pick = 4;
         float ur[2] = {std::min(u[0] * matching - comp, OneMinusEpsilon), u[1]};
         V3 wi, wo = b.to_local(woW);
         if (wo.z == 0) return Rgb(0.);
@@ -1866,6 +1898,25 @@ struct Oracle {
                 *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
                 f = micro_f(b, wo, wi);
             }
+        } else if (pick >= 3) {  // SpecularTransmission::Sample_f, reflection.cpp:154-170 (mode == Radiance)
+            const float eta_a = 1.f, eta_b = pick == 3 ? 1.f : b.t1_eta;
+            const bool entering = wo.z > 0;
+            const float eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
+            // Refract(wo, Faceforward(Normal3f(0, 0, 1), wo), etaI / etaT, wi), reflection.h:96-108
+            V3 n = (wo.z < 0.f) ? -V3(0, 0, 1) : V3(0, 0, 1);
+            const float eta = eta_i / eta_t;
+            const float cos_i = dot(n, wo);
+            const float sin2_i = std::max(0.f, 1 - cos_i * cos_i);
+            const float sin2_t = eta * eta * sin2_i;
+            if (sin2_t >= 1) return Rgb(0);  // `return 0`, pdf stays 0
+            const float cos_t = std::sqrt(1 - sin2_t);
+            wi = eta * -wo + (eta * cos_i - cos_t) * n;
+            *pdf = 1;
+            Rgb ft = (pick == 3 ? b.t0 : b.t1) * (1.f - fr_dielectric(wi.z, eta_a, eta_b));
+            ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+            f = ft / std::abs(wi.z);
+            if (sampled_specular) *sampled_specular = true;
+            if (sampled_transmission) *sampled_transmission = true;
         } else if (b.spec_glass) {  // FresnelSpecular::Sample_f, reflection.cpp:629-672 (mode == Radiance)
             const float eta_a = 1.f, eta_b = b.spec_eta;
             float F = fr_dielectric(wo.z, eta_a, eta_b);
@@ -1905,7 +1956,7 @@ struct Oracle {
             return Rgb(0);
         }
         *wiW = b.to_world(wi);
-        const bool specular = pick == 2;
+        const bool specular = pick >= 2;
         if (!specular && matching > 1) {  // a specular lobe's Pdf() is 0
             if (pick == 1 && b.has_lambert) *pdf += lambert_pdf(wo, wi);
             if (pick == 0 && b.has_micro) *pdf += micro_pdf(b, wo, wi);

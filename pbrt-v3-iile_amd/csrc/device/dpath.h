@@ -1255,7 +1255,13 @@ struct Bsdf {
     F3 ns, ng, ss, ts;
     F3 kd, ks, kr, kt;
     float alpha, eta;
-    int n_lobes;  // nBxDFs; BxDF order: Lambertian, microfacet, specular reflection
+    // UberMaterial's SpecularTransmission lobes (uber.cpp:53-61, 94-99): the pass-through of a surface that is not opaque —
+    // SpecularTransmission(t0 = 1 - opacity, 1, 1), the FIRST lobe — and SpecularTransmission(kt = opacity Kt, 1, eta), the LAST;
+    // path_eta = BSDF::eta (1 with the pass-through, else the material's: path.cpp:151-157 reads it)
+    F3 t0;
+    bool has_t0, has_t1;
+    float path_eta;
+    int n_lobes;  // nBxDFs; BxDF order: [pass-through], Lambertian, microfacet, specular reflection, [uber's Kt lobe]
     float on_a, on_b;  // Oren-Nayar constants of the diffuse lobe (oren_nayar set)
     bool oren_nayar;
     int mtype;    // kMat*: selects the Fresnel terms (plastic 1.5/1; uber 1/eta; mirror none) and, for
@@ -1503,7 +1509,19 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     keep_whole(m_kd);
     keep_whole(m_ks);
     const int m_type = int(f2b(m_kd.x));
+    // UberMaterial (uber.cpp:53-61): op = opacity.Clamp(), t = (-op + Spectrum(1.f)).Clamp(); every other coefficient is op * K.Clamp()
+    const bool uber = EXT && m_type == kMatUber;
+    F3 op = F3{1.f, 1.f, 1.f};
+    b.t0 = F3{0, 0, 0};
+    b.has_t0 = b.has_t1 = false;
+    if (uber) {
+        op = F3{clampf(m.opacity[0], 0, IILE_INF), clampf(m.opacity[1], 0, IILE_INF), clampf(m.opacity[2], 0, IILE_INF)};
+        b.t0 = F3{clampf(-op.x + 1.f, 0, IILE_INF), clampf(-op.y + 1.f, 0, IILE_INF), clampf(-op.z + 1.f, 0, IILE_INF)};
+        b.has_t0 = !is_black(b.t0);
+        if (b.has_t0) ++b.n_lobes;
+    }
     b.kd = F3{clampf(m_kd.y, 0, IILE_INF), clampf(m_kd.z, 0, IILE_INF), clampf(m_kd.w, 0, IILE_INF)};
+    if (uber) b.kd = op * b.kd;
     b.has_lambert = !is_black(b.kd);
     if (b.has_lambert) ++b.n_lobes;
     b.ks = F3{0, 0, 0};
@@ -1514,8 +1532,10 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.on_b = m.on_b;
     b.mtype = EXT ? m_type : kMatPlastic;
     b.eta = EXT ? m.eta : 1.f;  // (only uber, mirror and glass read it)
+    b.path_eta = b.has_t0 ? 1.f : b.eta;   // BSDF(*si, 1.f) / BSDF(*si, e), uber.cpp:56-61
     if (m_type == kMatPlastic || (EXT && m_type == kMatUber)) {
         b.ks = F3{clampf(m_ks.x, 0, IILE_INF), clampf(m_ks.y, 0, IILE_INF), clampf(m_ks.z, 0, IILE_INF)};
+        if (uber) b.ks = op * b.ks;
         b.has_micro = !is_black(b.ks);
         if (b.has_micro) ++b.n_lobes;
     }
@@ -1524,8 +1544,14 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.has_spec = false;
     if (EXT && (m_type == kMatUber || m_type == kMatMirror)) {
         b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
+        if (uber) b.kr = op * b.kr;
         b.has_spec = !is_black(b.kr);
         if (b.has_spec) ++b.n_lobes;
+    }
+    if (uber) {   // SpecularTransmission(op * Kt.Clamp(), 1, e), uber.cpp:94-99
+        b.kt = op * F3{clampf(m.kt[0], 0, IILE_INF), clampf(m.kt[1], 0, IILE_INF), clampf(m.kt[2], 0, IILE_INF)};
+        b.has_t1 = !is_black(b.kt);
+        if (b.has_t1) ++b.n_lobes;
     }
     if (EXT && m_type == kMatGlass) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
         b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
@@ -1716,14 +1742,18 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
     }
     int comp = int(floorf(u0 * matching));
     if (comp > matching - 1) comp = matching - 1;
-    // the comp-th present lobe in BxDF order: 0 Lambertian, 1 microfacet, 2 specular reflection
+    // the comp-th present lobe in BxDF order: [3 uber's pass-through], 0 Lambertian, 1 microfacet, 2 specular reflection, [4 uber's Kt lobe]
     int pick, count = comp;
-    if (b.has_lambert && count-- == 0)
+    if (allow_specular && b.has_t0 && count-- == 0)
+        pick = 3;
+    else if (b.has_lambert && count-- == 0)
         pick = 0;
     else if (b.has_micro && count-- == 0)
         pick = 1;
-    else
+    else if (!(allow_specular && b.has_t1) || (b.has_spec && count-- == 0))
         pick = 2;
+    else
+        pick = 4;
     // (comp < matching: the specular lobe is only ever picked when there is one — said aloud so that the builds whose
     // materials have none, where has_spec is a constant, drop that branch and the loads that feed it)
     if (pick == 2 && !b.has_spec) __builtin_unreachable();
@@ -1746,6 +1776,25 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
             *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
             f = micro_f(b, wo, wi);
         }
+    } else if (pick >= 3) {  // SpecularTransmission::Sample_f, reflection.cpp:154-170 (mode == Radiance)
+        const float eta_a = 1.f, eta_b = pick == 3 ? 1.f : b.eta;
+        const bool entering = wo.z > 0;
+        const float eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
+        // Refract(wo, Faceforward(Normal3f(0, 0, 1), wo), etaI / etaT, wi), reflection.h:96-108; -n carries negative zeros, as there
+        const F3 n = (wo.z < 0.f) ? -F3{0, 0, 1} : F3{0, 0, 1};
+        const float eta = eta_i / eta_t;
+        const float cos_i = dot(n, wo);
+        const float sin2_i = mx(0.f, 1 - cos_i * cos_i);
+        const float sin2_t = eta * eta * sin2_i;
+        if (sin2_t >= 1) return F3{0, 0, 0};  // `return 0`, pdf stays 0
+        const float cos_t = sqrtf(1 - sin2_t);
+        wi = eta * -wo + (eta * cos_i - cos_t) * n;
+        *pdf = 1;
+        F3 ft = (pick == 3 ? b.t0 : b.kt) * (1.f - fr_dielectric(wi.z, eta_a, eta_b));
+        ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
+        f = sdiv(ft, fabsf(wi.z));
+        if (sampled_specular) *sampled_specular = true;
+        if (sampled_transmission) *sampled_transmission = true;
     } else if (b.mtype == kMatGlass) {  // FresnelSpecular::Sample_f, reflection.cpp:477-511 (mode == Radiance)
         const float eta_a = 1.f, eta_b = b.eta;
         const float F = fr_dielectric(wo.z, eta_a, eta_b);
@@ -1786,12 +1835,12 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
         return F3{0, 0, 0};
     }
     *wiW = to_world(b, wi);
-    if (pick != 2 && matching > 1) {  // a specular lobe's Pdf() and f() are 0
+    if (pick < 2 && matching > 1) {  // a specular lobe's Pdf() and f() are 0
         if (pick == 1 && b.has_lambert) *pdf += lambert_pdf(wo, wi);
         if (pick == 0 && b.has_micro) *pdf += micro_pdf(b, wo, wi);
     }
     if (matching > 1) *pdf /= matching;
-    if (pick != 2 && matching > 1) {
+    if (pick < 2 && matching > 1) {
         bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
         f = reflect ? lobes_f(b, wo, wi) : F3{0, 0, 0};
     }

@@ -34,12 +34,13 @@ struct alignas(16) DMaterial {
     float alpha;
     float kr[3];  // uber, mirror, glass: specular reflectance
     float eta;    // uber, glass: FresnelDielectric(1, eta)
-    float kt[3];  // glass: specular transmittance
+    float kt[3];  // glass, uber: specular transmittance
     float on_a, on_b;  // matte with sigma != 0: Oren-Nayar A, B (on_b == 0 and on_a == 1 otherwise)
     int kd_tex, ks_tex, kr_tex, kt_tex;  // image texture replacing the constant at a hit, or -1
     int bump_tex;                        // float image texture displacing the shading geometry (Material::Bump), or -1
     int sigma_tex;                       // float image texture for matte's "sigma" (Oren-Nayar A, B per hit), or -1
     int rough_tex, remap_roughness;      // float image texture for "roughness" (-1: the constant alpha), RoughnessToAlpha or not
+    float opacity[3];                    // uber: "opacity" ({1, 1, 1} otherwise)
 };
 // ImageTexture + MIPMap (iile_texture): level l holds w x h float4 texels (rgb, w unused) at
 // texels[offset[l] + t * w + s], row 0 = bottom scanline
@@ -140,6 +141,7 @@ struct DScene {
     int extended_features;    // anything beyond one emitting sphere + matte / plastic: k_shade<.., EXT = true>
     int all_lights_infinite;  // every light is an InfiniteAreaLight: k_mis walks unordered (kernels_trav.hip)
     int has_glass;            // some material transmits: the paths' etaScale is tracked
+    int has_uber_trans;       // some uber material has a SpecularTransmission lobe (opacity < 1 or Kt): the IISPT runner / direct pass refuse
     int has_specular;         // some material has a specular lobe (mirror, glass, uber): emitted light after such a bounce
     int has_alpha;            // some mesh has an alpha mask: the ALPHA builds of the traversal kernels run
     int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide

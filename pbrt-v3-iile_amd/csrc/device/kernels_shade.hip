@@ -591,7 +591,7 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX)) void k_shade(DScene S, Pa
                     next_d = wi;
                     alive = true;
                     if (sampled_specular && sampled_transmission) {
-                        const float eta = bsdf.eta;
+                        const float eta = bsdf.path_eta;   // BSDF::eta
                         eta_scale *= (dot(-ray_d, is.n) > 0) ? (eta * eta) : 1 / (eta * eta);
                     }
                     // Russian roulette on rrBeta = beta * etaScale (path.cpp:182-190)

@@ -756,6 +756,7 @@ class Loader {
         iile_material m;
         std::memset(&m, 0, sizeof(m));
         m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = -1;
+        m.opacity[0] = m.opacity[1] = m.opacity[2] = 1.f;
         auto image = [&](const char *param) {
             auto it = image_of.find(param);
             return it == image_of.end() ? -1 : it->second;
@@ -788,11 +789,7 @@ class Loader {
                 ps.rgb("Kr", kr);
                 ps.rgb("Kt", kt);
                 ps.rgb("opacity", op);
-                if (kt[0] != 0 || kt[1] != 0 || kt[2] != 0 || op[0] != 1 || op[1] != 1 || op[2] != 1) {
-                    fail("uber: specular transmission (Kt, opacity < 1) is not supported");
-                    return -1;
-                }
-                for (int i = 0; i < 3; ++i) m.kr[i] = kr[i];
+                for (int i = 0; i < 3; ++i) m.kr[i] = kr[i], m.kt[i] = kt[i], m.opacity[i] = op[i];
                 const float ur = ps.one_float("uroughness", m.roughness), vr = ps.one_float("vroughness", ur);
                 if (ur != vr) {
                     fail("uber: anisotropic roughness is not supported");
@@ -839,9 +836,9 @@ class Loader {
         if (m.type == IILE_MAT_MATTE || m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) m.kd_tex = image("Kd");
         if (m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) m.ks_tex = image("Ks");
         if (m.type == IILE_MAT_UBER || m.type == IILE_MAT_MIRROR || m.type == IILE_MAT_GLASS) m.kr_tex = image("Kr");
-        if (m.type == IILE_MAT_GLASS) m.kt_tex = image("Kt");
-        if (m.type == IILE_MAT_UBER && image("Kt") >= 0) {
-            fail("uber: specular transmission (Kt) is not supported");
+        if (m.type == IILE_MAT_GLASS || m.type == IILE_MAT_UBER) m.kt_tex = image("Kt");
+        if (m.type == IILE_MAT_UBER && image("opacity") >= 0) {
+            fail("uber: \"opacity\" as an image texture is not supported (a constant is; cut-outs: the shape's \"alpha\" texture)");
             return -1;
         }
         if (const Param *sp = ps.find("sigma"))

@@ -227,7 +227,17 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         c = np.array([rng.uniform(-6, 6), rng.uniform(-4, 7), rng.uniform(-2, 5)])
         noise = 1.0 + 0.18 * rng.standard_normal(len(V)).clip(-2.5, 2.5)
         P = c + V * (r * noise)[:, None]
-        if materials == "mixed" and b % 3 == 1:  # specular lobes: uber (diffuse + glossy + mirror-like) and mirror
+        if materials == "ubertrans" and b % 4 == 0:  # UberMaterial's pass-through (uber.cpp:53-61): a grey and a coloured opacity
+            op = (.35, .35, .35) if b % 8 == 0 else tuple(rng.uniform(.1, .9, 3))
+            mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "float roughness" [%g] "color opacity" [%g %g %g] "float index" [%g]' % (
+                *rng.uniform(.2, .7, 3), rng.uniform(.05, .3), *op, rng.uniform(1.2, 1.8))
+        elif materials == "ubertrans" and b % 4 == 1:  # ... its Kt lobe (uber.cpp:94-99) beside the other four: closed refractive blobs
+            mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.1 .1 .1] "color Kr" [.2 .2 .2] "color Kt" [%g %g %g] "float roughness" [.1] "float index" [%g]' % (
+                *rng.uniform(.05, .3, 3), *rng.uniform(.5, .9, 3), rng.uniform(1.2, 1.7))
+        elif materials == "ubertrans" and b % 4 == 2:  # ... both, and nothing else: every lobe specular, no light sampling at these vertices
+            mat = 'Material "uber" "color Kd" [0 0 0] "color Ks" [0 0 0] "color Kt" [%g %g %g] "color opacity" [.6 .6 .6] "float index" [%g]' % (
+                *rng.uniform(.6, 1, 3), rng.uniform(1.3, 1.6))
+        elif materials == "mixed" and b % 3 == 1:  # specular lobes: uber (diffuse + glossy + mirror-like) and mirror
             mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "color Kr" [.3 .3 .3] "float roughness" [%g] "float index" [%g]' % (
                 *rng.uniform(.1, .4, 3), rng.uniform(.05, .3), rng.uniform(1.2, 1.8))
         elif materials == "mixed" and b % 3 == 2:

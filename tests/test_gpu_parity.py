@@ -413,6 +413,31 @@ def test_specular_materials_bitwise(binding, oracle, tmp_path):
         assert_bitwise(plain, ref, f"{name} (specular materials) film, uninstrumented kernels")
 
 
+def test_uber_transmission_bitwise(binding, oracle, tmp_path):
+    """UberMaterial's two SpecularTransmission lobes (uber.cpp:53-61, 94-99; refused until round 6): the pass-through of a surface
+    that is not opaque — grey and coloured opacities — and the Kt lobe, alone and beside the diffuse / glossy / mirror lobes, on
+    blobs of the box room at maxdepth 8 (BSDF::eta is 1 with the pass-through, the material's index without: etaScale and the
+    roulette see the difference). Film and every counter against the oracle bit for bit, both kernel sets; the oracle's lobes are
+    pinned by tests/test_oracle_pins.py::test_uber_transmission_pins. The IISPT runner and direct pass refuse such scenes."""
+    import boxroom
+    path = tmp_path / "boxroom_ubertrans.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, materials="ubertrans", maxdepth=8))
+    room = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(room)
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(room)
+    assert_bitwise(film, ref, "uber transmission film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["nee_evals"] == ost["nee_evals"] and st["path_length"] == ost["path_length"]
+    plain, _ = gpu.render()
+    assert_bitwise(plain, ref, "uber transmission film, uninstrumented kernels")
+    assert sum(ost["path_length"][5:]) > 0   # paths do get past bounce 4: the roulette ran
+    with pytest.raises(RuntimeError, match="uber materials with specular transmission"):
+        gpu.render_direct(1)
+    with pytest.raises(RuntimeError, match="uber materials with specular transmission"):
+        gpu.iispt_hemi_points(binding.IisptTask(0, 0, 40, 40, 4, 0, 0))
+
+
 def test_glass_scenes_bitwise(binding, oracle, tmp_path):
     """GlassMaterial (FresnelSpecular: specular reflection + transmission, the etaScale branch of Li
     and of its Russian roulette). No test of the reference covers glass; the restatement is checked

@@ -1023,3 +1023,54 @@ def test_sphere_hit_differentials_are_the_spheres(binding, oracle, tmp_path):
             assert np.linalg.norm(fd - dndu) < 0.03 * np.linalg.norm(dndu) + 2e-3, (name, fd, dndu)
             n_checked += 1
         assert n_checked > 15, name
+
+
+def test_uber_transmission_pins(binding, oracle, tmp_path):
+    """UberMaterial's two SpecularTransmission lobes (uber.cpp:53-61, 94-99) have no test in the reference; the restatement
+    (make_bsdf's lobe order and `op *` factors, SpecularTransmission::Sample_f inside BSDF::Sample_f, BSDF::eta = 1 with the
+    pass-through) is held to three properties inside the analytic furnace of src/tests/analytic_scenes.cpp:135-165 (radiance 1
+    from every direction):
+      (a) a ball of opacity 0.4 whose diffuse lobe is lossless (Kd = 1): (1 - op) of the radiance passes, op x 1 is reflected —
+          every pixel stays at 1 (the lobe weights, the 1 / matchingComps of BSDF::Sample_f, no light sampling through the
+          pass-through);
+      (b) Kt = 1 at index 1 and nothing else: the ball cannot be seen (Refract with eta = 1, FresnelDielectric(1, 1) = 0);
+      (c) Kt alone at index 1.5 is GlassMaterial with Kr = 0 in expectation (FresnelSpecular picks transmission with probability
+          1 - F and weight T eta^2; the uber lobe always, with weight T (1 - F) eta^2): equal mean radiance, and etaScale returns to 1."""
+    head = '''Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [10] "integer yresolution" [10]
+Sampler "halton" "integer pixelsamples" [256]
+Integrator "path" "integer maxdepth" [12]
+WorldBegin
+AttributeBegin
+  ReverseOrientation
+  Material "matte" "color Kd" [.5 .5 .5]
+  AreaLightSource "diffuse" "color L" [.5 .5 .5]
+  Shape "sphere" "float radius" [1]
+AttributeEnd
+AttributeBegin
+  %s
+  Translate 0 0 0.55
+  Shape "sphere" "float radius" [0.25]
+AttributeEnd
+WorldEnd
+'''
+
+    def mean_and_range(material):
+        path = tmp_path / "furnace_ball.pbrt"
+        path.write_text(head % material)
+        scene = binding.HostScene(path=str(path))
+        film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+        rgb = scene.film_to_rgb(film)
+        return float(rgb.mean(dtype=np.float64)), float(rgb.min()), float(rgb.max()), st
+
+    m, lo, hi, st = mean_and_range('Material "uber" "color Kd" [1 1 1] "color Ks" [0 0 0] "color opacity" [.4 .4 .4]')
+    assert abs(m - 1.0) < 0.01 and lo > 0.9 and hi < 1.1, (m, lo, hi)
+    assert st["nee_evals"] > 0   # the diffuse lobe is there: light is sampled at the ball's vertices
+    m, lo, hi, st = mean_and_range('Material "uber" "color Kd" [0 0 0] "color Ks" [0 0 0] "color Kt" [1 1 1] "float index" [1]')
+    assert abs(m - 1.0) < 3e-3 and lo > 0.9 and hi < 1.1, (m, lo, hi)   # (the furnace's own pixels scatter by a few per cent at 256 spp)
+    m_uber, _, _, _ = mean_and_range('Material "uber" "color Kd" [0 0 0] "color Ks" [0 0 0] "color Kt" [.9 .8 .7] "float index" [1.5]')
+    m_glass, _, _, _ = mean_and_range('Material "glass" "color Kr" [0 0 0] "color Kt" [.9 .8 .7] "float index" [1.5]')
+    assert 0.5 < m_glass < 1.0 and abs(m_uber - m_glass) < 0.01 * m_glass, (m_uber, m_glass)
+    # a fully transparent surface (opacity 0) is not there at all, whatever its other coefficients
+    m, lo, hi, _ = mean_and_range('Material "uber" "color Kd" [.3 .3 .3] "color Ks" [.5 .5 .5] "color Kr" [.5 .5 .5] "color opacity" [0 0 0]')
+    assert abs(m - 1.0) < 3e-3 and lo > 0.9 and hi < 1.1, (m, lo, hi)
