@@ -261,7 +261,11 @@ __global__ __launch_bounds__(kTravBlock, IILE_TRAV_WAVES) void k_shadow(DScene S
                     // ray carries beta * (A / lightPdf) ready made (k_shade) and no throughput plane.
                     const float4 n0 = B.nee[e], a4 = B.nee[4 * size_t(plane) + e];
                     pid = f2b(a4.w);
+#ifdef IILE_SHADOW_DIAG_NO_L_READ   // timing only (wrong film): what the scattered 16-byte read of L costs this kernel (profiles/r06_ab_shadow_L_read.txt)
+                    const float4 L4 = make_float4(0, 0, 0, 0);
+#else
                     const float4 L4 = B.L[pid];
+#endif
                     const bool has_shadow = (flags & NEE_HAS_SHADOW) != 0;
                     if (flags & NEE_HAS_MIS) {
                         const float4 be = B.nee[6 * size_t(plane) + e];
