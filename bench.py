@@ -180,7 +180,7 @@ def load_vmem_calibration():
 # ---------------------------------------------------------------------------------------------------------------------------
 # BASELINE config 5: the IISPT integrator's frame (--workload iispt)
 
-MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak, /opt/skills/guides/MI355X_MICROARCH.md ("~2.5 PF dense")
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 / f16 matrix peak (the F16 forms take the same cycles), /opt/skills/guides/MI355X_MICROARCH.md ("~2.5 PF dense")
 MFMA_F32_PEAK_TFLOPS = 157.3     # fp32-input matrix instructions run at the vector rate (same guide)
 # IISPTNet.forward per probe (ml/iispt_net.py:8-109): 2 * k * k * C_in * C_out * H * W over its 15 convolutions
 NET_FLOP_PER_PROBE = 2 * 9 * (7 * 64 * 1024 + 64 * 64 * 1024 + 64 * 128 * 256 + 128 * 128 * 256 + 128 * 256 * 64 + 256 * 256 * 64
@@ -246,7 +246,7 @@ def main_iispt(args):
     (IisptRenderRunner::run over one sweep of the schedule: hemi points, probe pass, network, gather), the direct pass (16 passes
     of DirectProgressiveIntegrator) and the merge of the two film monitors (pbrt-v3-iile_amd/iispt_frame.py). Prints the
     contract's line: value = probes per second over the whole frame; roofline = the network's convolution kernels against the
-    bf16 matrix peak; cpu_baseline = the reference's per-probe loop on one host thread on a bounded sample."""
+    16-bit matrix peak; cpu_baseline = the reference's per-probe loop on one host thread on a bounded sample."""
     import importlib
     import numpy as np
     import torch
@@ -343,10 +343,10 @@ def main_iispt(args):
         err = np.abs(got - want)
         chk = {"probes": int(len(sel)), "what": "iile_iispt_net_predict vs normalize_downstream -> IISPTNet (fp32, CPU) -> transform_upstream on the first valid "
                                                  "hemi points of the timed frame's first task",
-               "max_abs_err_over_max": float(err.max() / max(mx, 1e-30)), "bound": 1e-4,
+               "max_abs_err_over_max": float(err.max() / max(mx, 1e-30)), "bound": 1e-5,
                "elements_within_1e-4_rel_plus_1e-6_of_max": float((err <= 1e-4 * np.abs(want) + 1e-6 * mx).mean()),
                "mean_rel_err_where_nonzero": float((err[np.abs(want) > 1e-6 * mx] / np.abs(want[np.abs(want) > 1e-6 * mx])).mean())}
-    if not (chk["max_abs_err_over_max"] < 1e-4) or not bool(torch.isfinite(img).all()):
+    if not (chk["max_abs_err_over_max"] < 1e-5 and chk["elements_within_1e-4_rel_plus_1e-6_of_max"] >= 0.999) or not bool(torch.isfinite(img).all()):
         raise SystemExit(f"bench.py: the timed network disagrees with the PyTorch module ({chk}) or the frame is not finite; no number is reported")
     out = {
         "metric": "IISPT probes/s on killeroo-simple 1080p (one frame: hemi points + probe pass + network + gather, direct pass, merge)",
@@ -355,7 +355,7 @@ def main_iispt(args):
         "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
         "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 activations and accumulation; matrix products on bf16 pairs (hi + lo) of every operand",
+        "dtype": "f32 activations and accumulation; matrix products on fp16 pairs (hi + lo: 22 significant bits) of every operand",
         "data": "scenes/killeroo-simple.pbrt; IISPTNet with random-initialised weights (none ship with the reference): the image means nothing, the work is the reference's",
         "config": {"workload": f"IISPT frame, killeroo-simple {args.xres}x{args.yres}: radius 10 -> {n_tasks} tasks of 100 x 100 pixels, {frame.stats['hemi_points']} hemi points, "
                                f"{probes} probes of 32 x 32, every pixel gathered from 4 probes; 16 direct passes; merge",
@@ -374,8 +374,8 @@ def main_iispt(args):
             "algorithmic_flop_per_unit": NET_FLOP_PER_PROBE, "units_per_step": probes,
             "algorithmic_note": "2 k^2 C_in C_out H W over the network's 15 convolutions = 0.990 GFLOP per probe (fp32 multiply-adds of the reference's "
                                 "module); `achieved` = that x probes / the network's HIP-event time",
-            "executed_bf16_tflops": round(3 * ach, 1), "frac_executed": round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            "executed_note": "every product runs as three bf16 matrix instructions (a_hi w_hi + a_hi w_lo + a_lo w_hi), so the matrix pipe executes 3x the "
+            "executed_f16_tflops": round(3 * ach, 1), "frac_executed": round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "executed_note": "every product runs as three f16 matrix instructions (a_hi w_hi + a_hi w_lo + a_lo w_hi; same cycles as the bf16 forms), so the matrix pipe executes 3x the "
                              "algorithmic flops (the first layer also multiplies 9 zero-padded input channels)",
             "vs_fp32_matrix_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 3),
             "vs_fp32_matrix_peak_note": "the fp32-input matrix instructions peak at 157.3 TFLOP/s on gfx950: a ratio above 1 is what the split buys",
