@@ -26,6 +26,7 @@
 // the C ABI: libiile_host loads and flattens the scene, libiile_gpu renders it,
 // the film is normalised and written as PFM.
 #include <cerrno>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -33,6 +34,12 @@
 #include "../host/gpu_iispt_integrator.h"
 
 int main(int argc, char **argv) {
+    // $IILE_TIMING: wall time of the process's phases to stderr (where does a slow start come from?)
+    const bool timing = getenv("IILE_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "iile_pbrt timing: %8.3f s  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), what);
+    };
     std::string scene_file, out;  // --outfile, else the scene's Film "filename" (as pbrt: src/main/pbrt.cpp:137, film.cpp:262)
     iile::ParamSet ps;
     bool stats = false, quiet = false;
@@ -175,7 +182,9 @@ int main(int argc, char **argv) {
             return 1;
         }
     }
+    lap("arguments read");
     iile::Scene scene(scene_file, ps);
+    lap("scene file parsed, BVH built (host)");
     if (out.empty()) out = scene.ok() ? scene.film_filename() : std::string("pbrt.exr");
     if (integrator_choice < 0) integrator_choice = scene.ok() ? scene.integrator() : IILE_INTEGRATOR_PATH;
     if (integrator_choice == IILE_INTEGRATOR_IISPT) {
@@ -186,6 +195,7 @@ int main(int argc, char **argv) {
         }
         std::unique_ptr<iile::GpuIisptIntegrator> ii(iile::CreateGpuIisptIntegrator(ps, out, iispt));
         if (!ii->Render(scene)) return 1;
+        lap("IISPT frame rendered and written");
         if (!quiet)
             printf("IISPT: %d tasks, %lld hemi points, %lld probes, %lld pixels gathered, %d direct passes -> %s\n", ii->stats.tasks, ii->stats.hemi_points,
                    ii->stats.probes, ii->stats.pixels, iispt.direct_samples, out.c_str());
@@ -194,6 +204,7 @@ int main(int argc, char **argv) {
     std::unique_ptr<iile::GpuPathIntegrator> integrator(iile::CreateGpuPathIntegrator(ps, out, 0, 1, stats, comm));
     if (!ranked) integrator->UseDevices(gpus_given ? gpus : 0);
     const bool ok = integrator->Render(scene);
+    lap("frame rendered and written");
     if (comm) {
         if (ok) iile_dist_destroy(comm);
         else iile_dist_abort(comm);   // (the job is over: do not wait for the other ranks in ncclCommDestroy)

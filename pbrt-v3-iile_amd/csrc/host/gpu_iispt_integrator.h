@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <chrono>
+
 #include "gpu_integrator.h"
 
 namespace iile {
@@ -88,6 +90,13 @@ class GpuIisptIntegrator : public Integrator {
 
     bool Render(const Scene &scene) override {
         if (!scene.ok()) return false;
+        const bool timing = std::getenv("IILE_TIMING") != nullptr;
+        const auto t_start = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            if (stream_) (void)iile_stream_wait(stream_);
+            fprintf(stderr, "iile_pbrt timing:   + %8.3f s  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), what);
+        };
         const iile_film_desc *f = scene.film();
         if (scene.desc()->probe.hemi_size != 32 || opt_.hemi_size != 32) return Fail("the IISPT network takes 32 x 32 probes (--iispt_hemi_size=32)");
         if (f->crop_x0 != 0 || f->crop_y0 != 0 || f->crop_x1 != f->xres || f->crop_y1 != f->yres)
@@ -104,6 +113,7 @@ class GpuIisptIntegrator : public Integrator {
         ok = ok && Alloc(reinterpret_cast<void **>(&film_indirect), n_pix * 4 * sizeof(double)) &&
              Alloc(reinterpret_cast<void **>(&film_direct), n_pix * 4 * sizeof(double)) && Alloc(reinterpret_cast<void **>(&rgb_dev), n_pix * 3 * sizeof(float)) &&
              Check(iile_device_zero(film_indirect, n_pix * 4 * sizeof(double), stream_));
+        lap("device initialised, scene uploaded, network loaded, films allocated");
         // ---- the indirect pass: IisptRenderRunner::run for task numbers 0 .. iileIndirectTasks - 1
         if (ok) {
             // camera->film->GetSampleBounds(): the film's pixels under the box filter of radius 0.5 (pbrt's default; BASELINE's scene).
@@ -138,6 +148,7 @@ class GpuIisptIntegrator : public Integrator {
             }
             ok = ok && flush();
         }
+        lap("indirect pass");
         // ---- the direct pass: IisptRenderRunner::run_direct, passes 0 .. iileDirectSamples - 1
         if (ok) {
             iile_direct_params dp = {};
@@ -149,6 +160,7 @@ class GpuIisptIntegrator : public Integrator {
             else
                 ok = Check(iile_device_zero(film_direct, n_pix * 4 * sizeof(double), stream_));
         }
+        lap("direct pass");
         // ---- iispt.cpp:425-446: the two monitors as images, their merge as the frame
         std::vector<float> rgb(n_pix * 3);
         auto write = [&](const double *a, const double *b, const std::string &path) {
@@ -166,6 +178,7 @@ class GpuIisptIntegrator : public Integrator {
                  write(film_indirect, zero, opt_.indirect_out) && write(film_direct, zero, opt_.direct_out);
         }
         ok = ok && write(film_direct, film_indirect, output_);
+        lap("images written");
         if (stream_) (void)iile_stream_wait(stream_);
         for (void *p : allocs_) iile_device_free(p);
         allocs_.clear();
