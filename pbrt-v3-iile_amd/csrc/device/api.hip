@@ -144,7 +144,11 @@ int ensure_workspace(iile_scene *sc, uint32_t n_paths) {
     size_t bytes = 2 * n * f4 + 2 * n * sizeof(uint32_t) + 23 * cap * f4 + cap * sizeof(uint32_t) + 2 * cap +
                    kCntWords * sizeof(uint32_t) + sizeof(DCounters) + 16384;
     void *blk = nullptr;
+    const auto t_alloc = std::chrono::steady_clock::now();
     HIP_TRY(hipMalloc(&blk, bytes));
+    if (std::getenv("IILE_TIMING"))   // (a fresh process's large allocation can wait seconds for memory another process has just freed)
+        fprintf(stderr, "iile timing: workspace of %.1f GiB for %u paths allocated in %.3f s\n", double(bytes) / 1073741824.0, n_paths,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count());
     sc->ws_block = blk;
     sc->ws_bytes = bytes;
     char *p = static_cast<char *>(blk);

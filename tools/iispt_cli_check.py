@@ -49,7 +49,7 @@ with tempfile.TemporaryDirectory() as td:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
         walls.append(time.time() - t0)
         assert p.returncode == 0, p.stdout
-        phases.append([ln.split("timing:")[1].strip() for ln in p.stdout.splitlines() if "iile_pbrt timing:" in ln])
+        phases.append([ln.split("timing:", 1)[1].strip() for ln in p.stdout.splitlines() if "iile_pbrt timing:" in ln or "iile timing:" in ln])
     scene = b.HostScene(xres=W, yres=H, spp=1)
     gpu = b.GpuScene(scene)
     frame = frame_mod.IisptFrame(b, gpu, nn_mod.IisptPipeline(gpu, net=module))
