@@ -68,13 +68,15 @@ enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1, IILE_MAT_UBER = 2, IILE_MAT_MIR
  * textures (src/materials/matte.cpp:45-62, plastic.cpp:45-70, uber.cpp:45-100, mirror.cpp:44-55,
  * glass.cpp:45-92). Uber: uroughness == vroughness; its two SpecularTransmission lobes (the pass-through of opacity < 1 and Kt,
  * uber.cpp:53-61, 94-99) are rendered by iile_render and the probe pass — the IISPT runner and direct pass refuse such scenes.
- * Glass: smooth only (uroughness = vroughness = 0: one FresnelSpecular lobe, as the path integrator gets it). */
+ * Glass: smooth (uroughness = vroughness = 0: one FresnelSpecular lobe, as the path integrator gets it) or rough and isotropic
+ * (roughness = uroughness = vroughness != 0: MicrofacetReflection + MicrofacetTransmission, glass.cpp:66-90 — iile_render and the probe
+ * pass; the IISPT runner and direct pass refuse it). */
 typedef struct iile_material {
     int32_t type;
     float kd[3];     /* matte, plastic, uber; 0 for mirror */
     float ks[3];     /* plastic, uber: glossy (microfacet) reflectance */
     float sigma;     /* matte: Clamp(sigma, 0, 90) degrees; 0 = Lambertian, else Oren-Nayar (reflection.h:410-427) */
-    float roughness; /* plastic, uber: as given */
+    float roughness; /* plastic, uber: as given; glass: uroughness (= vroughness), 0 = smooth */
     float alpha;     /* plastic, uber: RoughnessToAlpha(roughness) if remap else roughness
                         (src/core/microfacet.h:123-128) */
     int32_t remap_roughness;

@@ -1546,8 +1546,12 @@ struct Oracle {
         bool has_t0 = false, has_t1 = false;
         Rgb t0, t1;
         float t1_eta = 1.f;
+        // rough glass (glass.cpp:66-90, uroughness / vroughness != 0): MicrofacetReflection(kr -> ks, FresnelDielectric(1, eta)) is the
+        // microfacet lobe above; MicrofacetTransmission(kt, distrib, 1, mt_eta, Radiance) — BSDF_TRANSMISSION | BSDF_GLOSSY: not specular
+        bool has_mtrans = false;
+        float mt_eta = 1.f;
         float eta = 1.f;                              // BSDF::eta (path.cpp:152)
-        int n_nonspec() const { return (has_lambert ? 1 : 0) + (has_micro ? 1 : 0); }
+        int n_nonspec() const { return (has_lambert ? 1 : 0) + (has_micro ? 1 : 0) + (has_mtrans ? 1 : 0); }
         V3 to_local(V3 v) const { return V3(dot(v, ss), dot(v, ts), dot(v, ns)); }
         V3 to_world(V3 v) const {
             return V3(ss.x * v.x + ts.x * v.y + ns.x * v.z, ss.y * v.x + ts.y * v.y + ns.y * v.z,
@@ -1580,13 +1584,13 @@ struct Oracle {
         is->sdpdu = dpdu;
         is->sdpdv = dpdv;
     }
-    Bsdf make_bsdf(const Isect &is) const {
+    Bsdf make_bsdf(const Isect &is) const { return make_bsdf_of(S.materials[S.prim_material[is.prim]], is); }
+    Bsdf make_bsdf_of(const iile_material &m, const Isect &is) const {
         Bsdf b;
         b.ns = is.sn;
         b.ng = is.n;
         b.ss = normalize(is.sdpdu);
         b.ts = cross(b.ns, b.ss);
-        const iile_material &m = S.materials[S.prim_material[is.prim]];
         auto clamp0 = [](const float *c) {
             return Rgb(clampf(c[0], 0, Infinity), clampf(c[1], 0, Infinity), clampf(c[2], 0, Infinity));
         };
@@ -1674,7 +1678,25 @@ struct Oracle {
                 }
             }
         }
-        if (m.type == IILE_MAT_GLASS) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
+        if (m.type == IILE_MAT_GLASS && m.roughness != 0) {  // glass.cpp:66-90: a rough dielectric (isotropic: uroughness == vroughness)
+            b.eta = m.eta;
+            Rgb R = param(m.kr, m.kr_tex), T = param(m.kt, m.kt_tex);
+            if (!R.is_black()) {  // MicrofacetReflection(R, distrib, FresnelDielectric(1, eta))
+                b.has_micro = true;
+                b.ks = R;
+                b.alpha = m.alpha;
+                b.micro_eta_i = 1.f;
+                b.micro_eta_t = m.eta;
+                ++b.n_lobes;
+            }
+            if (!T.is_black()) {  // MicrofacetTransmission(T, distrib, 1, eta, mode)
+                b.has_mtrans = true;
+                b.kt = T;
+                b.alpha = m.alpha;
+                b.mt_eta = m.eta;
+                ++b.n_lobes;
+            }
+        } else if (m.type == IILE_MAT_GLASS) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
             b.eta = m.eta;
             Rgb R = param(m.kr, m.kr_tex), T = param(m.kt, m.kt_tex);
             if (!(R.is_black() && T.is_black())) {
@@ -1806,6 +1828,43 @@ struct Oracle {
         V3 wh = normalize(wo + wi);
         return tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
     }
+    // Refract, reflection.h:96-108
+    static bool refract(V3 wi, V3 n, float eta, V3 *wt) {
+        float cos_i = dot(n, wi);
+        float sin2_i = std::max(0.f, 1 - cos_i * cos_i);
+        float sin2_t = eta * eta * sin2_i;
+        if (sin2_t >= 1) return false;
+        float cos_t = std::sqrt(1 - sin2_t);
+        *wt = eta * -wi + (eta * cos_i - cos_t) * n;
+        return true;
+    }
+    // MicrofacetTransmission::f, reflection.cpp:244-266 (etaA = 1, mode == Radiance)
+    static Rgb mtrans_f(const Bsdf &b, V3 wo, V3 wi) {
+        if (same_hemisphere(wo, wi)) return Rgb(0.f);  // transmission only
+        float cos_o = wo.z, cos_i = wi.z;
+        if (cos_i == 0 || cos_o == 0) return Rgb(0.f);
+        const float eta_a = 1.f, eta_b = b.mt_eta;
+        float eta = wo.z > 0 ? (eta_b / eta_a) : (eta_a / eta_b);
+        V3 wh = normalize(wo + wi * eta);
+        if (wh.z < 0) wh = -wh;
+        float F = fr_dielectric(dot(wo, wh), eta_a, eta_b);
+        float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        float factor = 1 / eta;
+        Rgb one_minus_f(1.f - F);
+        return one_minus_f * b.kt *
+               std::abs(tr_d(wh, b.alpha, b.alpha) * tr_g(wo, wi, b.alpha) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+                        (cos_i * cos_o * sqrt_denom * sqrt_denom));
+    }
+    // MicrofacetTransmission::Pdf, reflection.cpp:435-447
+    static float mtrans_pdf(const Bsdf &b, V3 wo, V3 wi) {
+        if (same_hemisphere(wo, wi)) return 0;
+        const float eta_a = 1.f, eta_b = b.mt_eta;
+        float eta = wo.z > 0 ? (eta_b / eta_a) : (eta_a / eta_b);
+        V3 wh = normalize(wo + wi * eta);
+        float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        float dwh_dwi = std::abs((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
+        return tr_pdf(wo, wh, b.alpha) * dwh_dwi;
+    }
     // LambertianReflection::f (reflection.cpp:178-180) or OrenNayar::f (reflection.cpp:197-219)
     static Rgb diffuse_f(const Bsdf &b, V3 wo, V3 wi) {
         if (!b.oren_nayar) return b.kd * InvPi;
@@ -1838,6 +1897,8 @@ struct Oracle {
         if (reflect) {
             if (b.has_lambert) f = f + diffuse_f(b, wo, wi);
             if (b.has_micro) f = f + micro_f(b, wo, wi);
+        } else if (b.has_mtrans) {  // `(!reflect && (bxdfs[i]->type & BSDF_TRANSMISSION))`
+            f = f + mtrans_f(b, wo, wi);
         }
         return f;
     }
@@ -1855,6 +1916,10 @@ struct Oracle {
         if (b.has_micro) {
             ++matching;
             pdf += micro_pdf(b, wo, wi);
+        }
+        if (b.has_mtrans) {
+            ++matching;
+            pdf += mtrans_pdf(b, wo, wi);
         }
         return matching > 0 ? pdf / matching : 0.f;
     }
@@ -1876,6 +1941,7 @@ struct Oracle {
         if (b.has_t0 && allow_specular && count-- == 0) pick = 3;
         if (pick < 0 && b.has_lambert && count-- == 0) pick = 0;
         if (pick < 0 && b.has_micro && count-- == 0) pick = 1;
+        if (pick < 0 && b.has_mtrans && count-- == 0) pick = 5;   // rough glass: MicrofacetTransmission behind MicrofacetReflection (glass.cpp:74-90)
         if (pick < 0 && b.has_spec && allow_specular && count-- == 0) pick = 2;
         if (pick < 0 && b.has_t1 && allow_specular && count-- == 0) pick = 4;
         float ur[2] = {std::min(u[0] * matching - comp, OneMinusEpsilon), u[1]};
@@ -1898,6 +1964,13 @@ struct Oracle {
                 *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
                 f = micro_f(b, wo, wi);
             }
+        } else if (pick == 5) {  // MicrofacetTransmission::Sample_f, reflection.cpp:425-433
+            V3 wh = tr_sample_wh(wo, ur, b.alpha);
+            const float eta_a = 1.f, eta_b = b.mt_eta;
+            float eta = wo.z > 0 ? (eta_a / eta_b) : (eta_b / eta_a);
+            if (!refract(wo, wh, eta, &wi)) return Rgb(0);  // `return 0`, pdf stays 0
+            *pdf = mtrans_pdf(b, wo, wi);
+            f = mtrans_f(b, wo, wi);
         } else if (pick >= 3) {  // SpecularTransmission::Sample_f, reflection.cpp:154-170 (mode == Radiance)
             const float eta_a = 1.f, eta_b = pick == 3 ? 1.f : b.t1_eta;
             const bool entering = wo.z > 0;
@@ -1956,10 +2029,11 @@ struct Oracle {
             return Rgb(0);
         }
         *wiW = b.to_world(wi);
-        const bool specular = pick >= 2;
+        const bool specular = pick >= 2 && pick != 5;
         if (!specular && matching > 1) {  // a specular lobe's Pdf() is 0
-            if (pick == 1 && b.has_lambert) *pdf += lambert_pdf(wo, wi);
-            if (pick == 0 && b.has_micro) *pdf += micro_pdf(b, wo, wi);
+            if (pick != 0 && b.has_lambert) *pdf += lambert_pdf(wo, wi);
+            if (pick != 1 && b.has_micro) *pdf += micro_pdf(b, wo, wi);
+            if (pick != 5 && b.has_mtrans) *pdf += mtrans_pdf(b, wo, wi);
         }
         if (matching > 1) *pdf /= matching;
         if (!specular && matching > 1) {  // a specular lobe's f() is 0
@@ -1968,6 +2042,8 @@ struct Oracle {
             if (reflect) {
                 if (b.has_lambert) f = f + diffuse_f(b, wo, wi);
                 if (b.has_micro) f = f + micro_f(b, wo, wi);
+            } else if (b.has_mtrans) {
+                f = f + mtrans_f(b, wo, wi);
             }
         }
         return f;
@@ -3506,29 +3582,14 @@ void oracle_li(const iile_scene_desc *scene, int trig_mode, int n, const int32_t
         }
     }
 }
-static Oracle::Bsdf local_bsdf(const Oracle &, const iile_scene_desc *scene, int mat) {
-    Oracle::Bsdf b;
-    b.ns = V3(0, 0, 1);
-    b.ng = V3(0, 0, 1);
-    b.ss = V3(1, 0, 0);
-    b.ts = cross(b.ns, b.ss);
-    const iile_material &m = scene->materials[mat];
-    Rgb kd(clampf(m.kd[0], 0, Infinity), clampf(m.kd[1], 0, Infinity), clampf(m.kd[2], 0, Infinity));
-    if (!kd.is_black()) {
-        b.has_lambert = true;
-        b.kd = kd;
-        ++b.n_lobes;
-    }
-    if (m.type == IILE_MAT_PLASTIC) {
-        Rgb ks(clampf(m.ks[0], 0, Infinity), clampf(m.ks[1], 0, Infinity), clampf(m.ks[2], 0, Infinity));
-        if (!ks.is_black()) {
-            b.has_micro = true;
-            b.ks = ks;
-            b.alpha = m.alpha;
-            ++b.n_lobes;
-        }
-    }
-    return b;
+// the material's BSDF in the canonical frame ns = ng = +z, ss = +x (constant parameters: image textures are not looked up)
+static Oracle::Bsdf local_bsdf(const Oracle &orc, const iile_scene_desc *scene, int mat) {
+    iile_material m = scene->materials[mat];
+    m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = -1;
+    Isect is;
+    is.sn = is.n = V3(0, 0, 1);
+    is.sdpdu = V3(1, 0, 0);
+    return orc.make_bsdf_of(m, is);
 }
 void oracle_bsdf_eval(const iile_scene_desc *scene, int trig_mode, int mat, const float *wo3, const float *wi3,
                       float *f3, float *pdf) {

@@ -1261,6 +1261,9 @@ struct Bsdf {
     F3 t0;
     bool has_t0, has_t1;
     float path_eta;
+    // rough glass (glass.cpp:66-90): MicrofacetReflection(kr -> ks, FresnelDielectric(1, eta)) is the microfacet lobe;
+    // MicrofacetTransmission(kt, distrib, 1, eta, Radiance) — glossy, not specular
+    bool has_mtrans;
     int n_lobes;  // nBxDFs; BxDF order: [pass-through], Lambertian, microfacet, specular reflection, [uber's Kt lobe]
     float on_a, on_b;  // Oren-Nayar constants of the diffuse lobe (oren_nayar set)
     bool oren_nayar;
@@ -1268,7 +1271,7 @@ struct Bsdf {
                   // glass, makes the specular lobe a FresnelSpecular(kr, kt, 1, eta)
     bool has_lambert, has_micro, has_spec;
 };
-DEV int n_nonspec(const Bsdf &b) { return (b.has_lambert ? 1 : 0) + (b.has_micro ? 1 : 0); }
+DEV int n_nonspec(const Bsdf &b) { return (b.has_lambert ? 1 : 0) + (b.has_micro ? 1 : 0) + (b.has_mtrans ? 1 : 0); }
 DEV F3 to_local(const Bsdf &b, F3 v) { return F3{dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)}; }
 DEV F3 to_world(const Bsdf &b, F3 v) {
     return F3{b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
@@ -1553,7 +1556,15 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
         b.has_t1 = !is_black(b.kt);
         if (b.has_t1) ++b.n_lobes;
     }
-    if (EXT && m_type == kMatGlass) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
+    b.has_mtrans = false;
+    if (EXT && m_type == kMatGlass && m_ks.w != 0.f) {  // glass.cpp:66-90: a rough dielectric (alpha != 0)
+        b.ks = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};   // R: MicrofacetReflection
+        b.kt = F3{clampf(m.kt[0], 0, IILE_INF), clampf(m.kt[1], 0, IILE_INF), clampf(m.kt[2], 0, IILE_INF)};   // T: MicrofacetTransmission
+        b.has_micro = !is_black(b.ks);
+        b.has_mtrans = !is_black(b.kt);
+        if (b.has_micro) ++b.n_lobes;
+        if (b.has_mtrans) ++b.n_lobes;
+    } else if (EXT && m_type == kMatGlass) {  // glass.cpp:45-66 with isSpecular && allowMultipleLobes
         b.kr = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};
         b.kt = F3{clampf(m.kt[0], 0, IILE_INF), clampf(m.kt[1], 0, IILE_INF), clampf(m.kt[2], 0, IILE_INF)};
         b.has_spec = !(is_black(b.kr) && is_black(b.kt));
@@ -1673,7 +1684,7 @@ DEV F3 micro_f(const Bsdf &b, F3 wo, F3 wi) {
     if (cos_i == 0 || cos_o == 0) return F3{0, 0, 0};
     if (wh.x == 0 && wh.y == 0 && wh.z == 0) return F3{0, 0, 0};
     wh = normalize(wh);
-    float Fr = b.mtype == kMatUber ? fr_dielectric(dot(wi, wh), 1.f, b.eta) : fr_dielectric(dot(wi, wh), 1.5f, 1.f);
+    float Fr = (b.mtype == kMatUber || b.mtype == kMatGlass) ? fr_dielectric(dot(wi, wh), 1.f, b.eta) : fr_dielectric(dot(wi, wh), 1.5f, 1.f);
     F3 F = F3{Fr, Fr, Fr};
     return sdiv(b.ks * tr_d(wh, b.alpha) * tr_g(wo, wi, b.alpha) * F, 4 * cos_i * cos_o);
 }
@@ -1704,6 +1715,43 @@ DEV F3 diffuse_f(const Bsdf &b, F3 wo, F3 wi) {
     return b.kd * kInvPi * (b.on_a + b.on_b * max_cos * sin_alpha * tan_beta);
 }
 DEV float lambert_pdf(F3 wo, F3 wi) { return same_hemisphere(wo, wi) ? fabsf(wi.z) * kInvPi : 0; }
+// Refract, reflection.h:96-108
+DEV bool refract_dir(F3 wi, F3 n, float eta, F3 *wt) {
+    const float cos_i = dot(n, wi);
+    const float sin2_i = mx(0.f, 1 - cos_i * cos_i);
+    const float sin2_t = eta * eta * sin2_i;
+    if (sin2_t >= 1) return false;
+    const float cos_t = sqrtf(1 - sin2_t);
+    *wt = eta * -wi + (eta * cos_i - cos_t) * n;
+    return true;
+}
+// MicrofacetTransmission::f, reflection.cpp:244-266 (etaA = 1, etaB = b.eta, mode == Radiance)
+DEV F3 mtrans_f(const Bsdf &b, F3 wo, F3 wi) {
+    if (same_hemisphere(wo, wi)) return F3{0, 0, 0};
+    const float cos_o = wo.z, cos_i = wi.z;
+    if (cos_i == 0 || cos_o == 0) return F3{0, 0, 0};
+    const float eta_a = 1.f, eta_b = b.eta;
+    const float eta = wo.z > 0 ? (eta_b / eta_a) : (eta_a / eta_b);
+    F3 wh = normalize(wo + wi * eta);
+    if (wh.z < 0) wh = -wh;
+    const float F = fr_dielectric(dot(wo, wh), eta_a, eta_b);
+    const float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+    const float factor = 1 / eta;
+    const float omf = 1.f - F;
+    return F3{omf, omf, omf} * b.kt *
+           fabsf(tr_d(wh, b.alpha) * tr_g(wo, wi, b.alpha) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+                 (cos_i * cos_o * sqrt_denom * sqrt_denom));
+}
+// MicrofacetTransmission::Pdf, reflection.cpp:435-447
+DEV float mtrans_pdf(const Bsdf &b, F3 wo, F3 wi) {
+    if (same_hemisphere(wo, wi)) return 0;
+    const float eta_a = 1.f, eta_b = b.eta;
+    const float eta = wo.z > 0 ? (eta_b / eta_a) : (eta_a / eta_b);
+    const F3 wh = normalize(wo + wi * eta);
+    const float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+    const float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
+    return tr_pdf(wo, wh, b.alpha) * dwh_dwi;
+}
 DEV F3 lobes_f(const Bsdf &b, F3 wo, F3 wi) {
     F3 f = F3{0, 0, 0};
     if (b.has_lambert) f = f + diffuse_f(b, wo, wi);
@@ -1715,7 +1763,8 @@ DEV F3 bsdf_f(const Bsdf &b, F3 woW, F3 wiW) {
     F3 wi = to_local(b, wiW), wo = to_local(b, woW);
     if (wo.z == 0) return F3{0, 0, 0};
     bool reflect = dot(wiW, b.ng) * dot(woW, b.ng) > 0;
-    return reflect ? lobes_f(b, wo, wi) : F3{0, 0, 0};
+    if (reflect) return lobes_f(b, wo, wi);
+    return b.has_mtrans ? F3{0, 0, 0} + mtrans_f(b, wo, wi) : F3{0, 0, 0};   // `(!reflect && (bxdfs[i]->type & BSDF_TRANSMISSION))`
 }
 // BSDF::Pdf, reflection.cpp:786-801
 DEV float bsdf_pdf(const Bsdf &b, F3 woW, F3 wiW) {
@@ -1725,6 +1774,7 @@ DEV float bsdf_pdf(const Bsdf &b, F3 woW, F3 wiW) {
     float pdf = 0.f;
     if (b.has_lambert) pdf += lambert_pdf(wo, wi);
     if (b.has_micro) pdf += micro_pdf(b, wo, wi);
+    if (b.has_mtrans) pdf += mtrans_pdf(b, wo, wi);
     const int matching = n_nonspec(b);  // flags = BSDF_ALL & ~BSDF_SPECULAR
     return matching > 0 ? pdf / matching : 0.f;
 }
@@ -1750,6 +1800,8 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
         pick = 0;
     else if (b.has_micro && count-- == 0)
         pick = 1;
+    else if (b.has_mtrans && count-- == 0)
+        pick = 5;   // rough glass: MicrofacetTransmission behind MicrofacetReflection (glass.cpp:74-90)
     else if (!(allow_specular && b.has_t1) || (b.has_spec && count-- == 0))
         pick = 2;
     else
@@ -1776,6 +1828,13 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
             *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
             f = micro_f(b, wo, wi);
         }
+    } else if (pick == 5) {  // MicrofacetTransmission::Sample_f, reflection.cpp:425-433
+        const F3 wh = tr_sample_wh(wo, ur0, u1, b.alpha);
+        const float eta_a = 1.f, eta_b = b.eta;
+        const float eta = wo.z > 0 ? (eta_a / eta_b) : (eta_b / eta_a);
+        if (!refract_dir(wo, wh, eta, &wi)) return F3{0, 0, 0};  // `return 0`, pdf stays 0
+        *pdf = mtrans_pdf(b, wo, wi);
+        f = mtrans_f(b, wo, wi);
     } else if (pick >= 3) {  // SpecularTransmission::Sample_f, reflection.cpp:154-170 (mode == Radiance)
         const float eta_a = 1.f, eta_b = pick == 3 ? 1.f : b.eta;
         const bool entering = wo.z > 0;
@@ -1835,14 +1894,16 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
         return F3{0, 0, 0};
     }
     *wiW = to_world(b, wi);
-    if (pick < 2 && matching > 1) {  // a specular lobe's Pdf() and f() are 0
-        if (pick == 1 && b.has_lambert) *pdf += lambert_pdf(wo, wi);
-        if (pick == 0 && b.has_micro) *pdf += micro_pdf(b, wo, wi);
+    const bool glossy = pick < 2 || pick == 5;
+    if (glossy && matching > 1) {  // a specular lobe's Pdf() and f() are 0
+        if (pick != 0 && b.has_lambert) *pdf += lambert_pdf(wo, wi);
+        if (pick != 1 && b.has_micro) *pdf += micro_pdf(b, wo, wi);
+        if (pick != 5 && b.has_mtrans) *pdf += mtrans_pdf(b, wo, wi);
     }
     if (matching > 1) *pdf /= matching;
-    if (pick < 2 && matching > 1) {
+    if (glossy && matching > 1) {
         bool reflect = dot(*wiW, b.ng) * dot(woW, b.ng) > 0;
-        f = reflect ? lobes_f(b, wo, wi) : F3{0, 0, 0};
+        f = reflect ? lobes_f(b, wo, wi) : (b.has_mtrans ? F3{0, 0, 0} + mtrans_f(b, wo, wi) : F3{0, 0, 0});
     }
     return f;
 }

@@ -31,7 +31,7 @@ struct alignas(16) DMaterial {
     int type;
     float kd[3];
     float ks[3];
-    float alpha;
+    float alpha;  // plastic, uber: the microfacet distribution's alpha; glass: the same, 0 = smooth
     float kr[3];  // uber, mirror, glass: specular reflectance
     float eta;    // uber, glass: FresnelDielectric(1, eta)
     float kt[3];  // glass, uber: specular transmittance

@@ -818,9 +818,22 @@ class Loader {
                 m.kt[i] = kt[i];
             }
             m.eta = ps.find("eta") ? ps.one_float("eta", 1.5f) : ps.one_float("index", 1.5f);
-            if (ps.one_float("uroughness", 0.f) != 0.f || ps.one_float("vroughness", 0.f) != 0.f) {
-                fail("glass: rough dielectrics (uroughness / vroughness) are not supported");
+            // glass.cpp:52-73: urough == vrough == 0 is the smooth dielectric; otherwise MicrofacetReflection + MicrofacetTransmission over
+            // one TrowbridgeReitzDistribution(RoughnessToAlpha(urough), ...(vrough)) — isotropic ones here
+            const float ur = ps.one_float("uroughness", 0.f), vr = ps.one_float("vroughness", 0.f);
+            if (ur != vr) {
+                fail("glass: anisotropic roughness (uroughness != vroughness) is not supported");
                 return -1;
+            }
+            m.roughness = ur;
+            m.remap_roughness = ps.one_bool("remaproughness", true) ? 1 : 0;
+            if (ur != 0.f) {
+                if (m.remap_roughness) {  // TrowbridgeReitzDistribution::RoughnessToAlpha, microfacet.h:123-128
+                    float r = std::max(m.roughness, 1e-3f);
+                    float x = std::log(r);
+                    m.alpha = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+                } else
+                    m.alpha = m.roughness;
             }
         } else if (name == "mirror") {  // CreateMirrorMaterial, mirror.cpp:57-63
             m.type = IILE_MAT_MIRROR;

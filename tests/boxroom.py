@@ -227,7 +227,11 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         c = np.array([rng.uniform(-6, 6), rng.uniform(-4, 7), rng.uniform(-2, 5)])
         noise = 1.0 + 0.18 * rng.standard_normal(len(V)).clip(-2.5, 2.5)
         P = c + V * (r * noise)[:, None]
-        if materials == "ubertrans" and b % 4 == 0:  # UberMaterial's pass-through (uber.cpp:53-61): a grey and a coloured opacity
+        if materials == "roughglass" and b % 3 != 2:  # GlassMaterial with uroughness = vroughness != 0 (glass.cpp:66-90): closed refractive blobs
+            rough = (.05, .2, .5)[b % 3] if b % 2 else rng.uniform(.02, .6)
+            mat = 'Material "glass" "color Kr" [%g %g %g] "color Kt" [%g %g %g] "float uroughness" [%g] "float vroughness" [%g] "float index" [%g]%s' % (
+                *((1, 1, 1) if b % 4 else (0, 0, 0)), *rng.uniform(.7, 1, 3), rough, rough, rng.uniform(1.3, 1.7), ' "bool remaproughness" ["false"]' if b % 5 == 0 else "")
+        elif materials == "ubertrans" and b % 4 == 0:  # UberMaterial's pass-through (uber.cpp:53-61): a grey and a coloured opacity
             op = (.35, .35, .35) if b % 8 == 0 else tuple(rng.uniform(.1, .9, 3))
             mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "float roughness" [%g] "color opacity" [%g %g %g] "float index" [%g]' % (
                 *rng.uniform(.2, .7, 3), rng.uniform(.05, .3), *op, rng.uniform(1.2, 1.8))

@@ -254,12 +254,15 @@ def test_reference_reintersect_property(oracle, scene_c1, binding):
     assert bad == 0, f"{bad} of {tested} spawned rays re-hit their own primitive"
 
 
-@pytest.mark.parametrize("mat,label", [(0, "Lambertian"), (1, "TR_VA_0p5"), (2, "TR_VA_0p3")])
+@pytest.mark.parametrize("mat,label", [(0, "Lambertian"), (1, "TR_VA_0p5"), (2, "TR_VA_0p3"), (4, "RoughGlass_alpha_0p1_T_only")])
 def test_bsdf_sampling_chi_square(binding, oracle, tmp_path, mat, label):
     """BSDFSampling.{Lambertian, TR_VA_0p5, TR_VA_0p3} of src/tests/bsdfs.cpp:372-560: for random
     outgoing directions, the histogram of 10^6 directions drawn by BSDF::Sample_f must match the
     integral of BSDF::Pdf over the same (theta, phi) cells — chi-square test at significance 0.01
-    with the Sidak correction for 5 runs, cells with expected frequency < 5 pooled."""
+    with the Sidak correction for 5 runs, cells with expected frequency < 5 pooled. The same test on rough glass (round 6; the
+    reference has none for MicrofacetTransmission): reflection + transmission lobes over the whole sphere of directions, from outside
+    and — every other run — from inside the glass (Sample_wh / Refract / the Jacobian of MicrofacetTransmission::Pdf), as a bound
+    on the total variation distance (see below why not chi-square)."""
     from scipy.stats import chi2
     path = tmp_path / "mats.pbrt"
     path.write_text(
@@ -268,6 +271,8 @@ def test_bsdf_sampling_chi_square(binding, oracle, tmp_path, mat, label):
         'Material "matte" "color Kd" [1 1 1]\nShape "sphere"\n'
         'Material "plastic" "color Kd" [0 0 0] "color Ks" [1 1 1] "float roughness" [.5]\nShape "sphere"\n'
         'Material "plastic" "color Kd" [0 0 0] "color Ks" [1 1 1] "float roughness" [.3]\nShape "sphere"\n'
+        'Material "glass" "float uroughness" [.3] "float vroughness" [.3] "float index" [1.5]\nShape "sphere"\n'
+        'Material "glass" "color Kr" [0 0 0] "float uroughness" [.1] "float vroughness" [.1] "bool remaproughness" ["false"] "float index" [1.33]\nShape "sphere"\n'
         'AttributeBegin\nAreaLightSource "diffuse"\nShape "sphere"\nAttributeEnd\nWorldEnd\n')
     scene = binding.HostScene(path=str(path))
     theta_res, phi_res, n, runs, q = 10, 20, 1000000, 5, 24
@@ -276,6 +281,8 @@ def test_bsdf_sampling_chi_square(binding, oracle, tmp_path, mat, label):
         # CosineSampleHemisphere for wo (bsdfs.cpp:412-414)
         r, ph = np.sqrt(rng.random()), 2 * np.pi * rng.random()
         wo = np.array([r * np.cos(ph), r * np.sin(ph), np.sqrt(max(0.0, 1 - r * r))], np.float32)
+        if mat >= 3 and run % 2 == 1:
+            wo[2] = -wo[2]   # from inside the glass
         wi, pdf = oracle.bsdf_sample_batch(scene, mat, wo, rng.random((n, 2), dtype=np.float32))
         ok = pdf > 0
         th = np.arccos(np.clip(wi[ok, 2], -1, 1)) * (theta_res / np.pi)
@@ -311,6 +318,17 @@ def test_bsdf_sampling_chi_square(binding, oracle, tmp_path, mat, label):
         assert dof > 0
         pval = chi2.sf(chsq, dof)
         alpha = 1.0 - (1.0 - 0.01) ** (1.0 / runs)
+        if mat >= 3:
+            # The reference's MicrofacetTransmission::Pdf / f (reflection.cpp:244-266, 435-447) lack the test that wo and wi lie on
+            # opposite sides of the microfacet: Pdf() has a thin tail of directions (about 1 % of its integral, towards grazing) that
+            # Sample_f — a refraction at a sampled microfacet — never produces. Restated as it is, so no chi-square here: the
+            # sampled histogram and the integrated Pdf() must agree in total variation within 3 %, and within 3 % cell by cell where the lobe's mass is
+            # (at alpha = 0.1; a wide lobe — the scene's material 3, alpha 0.55 — is 9 % apart: the tail grows with the roughness).
+            tv = 0.5 * np.abs(freq / n - exp / n).sum()
+            assert tv < 0.03, f"{label} run {run}: total variation distance {tv:.4f}"
+            big = exp > 0.5 * exp.max()   # where the lobe's mass is, the two agree closely
+            assert big.sum() >= 1 and np.allclose(freq[big], exp[big], rtol=0.03), (label, run, tv, freq[big], exp[big])
+            continue
         assert pval >= alpha, f"{label} run {run}: chi2 {chsq:.1f} over {dof} dof, p = {pval:.2e} < {alpha:.2e}"
 
 
@@ -937,11 +955,14 @@ Material "mirror" "color Kr" [.9 .9 .9]
 Shape "trianglemesh" "point P" [0 0 9 1 0 9 0 1 9] "integer indices" [0 1 2]
 Material "glass" "color Kr" [1 1 1] "color Kt" [1 1 1] "float index" [1.5]
 Shape "trianglemesh" "point P" [0 0 10 1 0 10 0 1 10] "integer indices" [0 1 2]
+Material "glass" "color Kr" [.9 .9 .9] "color Kt" [.8 .9 1] "float uroughness" [.2] "float vroughness" [.2] "float index" [1.5]
+Shape "trianglemesh" "point P" [0 0 11 1 0 11 0 1 11] "integer indices" [0 1 2]
 WorldEnd
 ''')
     scene = binding.HostScene(path=str(path))
     n_mat = scene.info["n_materials"]
-    assert n_mat >= 6
+    assert n_mat >= 7   # (the last: rough glass — its reflection lobe is reciprocal, Sample_f's pdf is Pdf() on both sides of the surface,
+    #                   and seen from outside it returns at most what arrives: the radiance scaling 1 / eta^2 only shrinks what enters)
     rng = np.random.default_rng(9)
 
     def hemi(n):
@@ -1074,3 +1095,58 @@ WorldEnd
     # a fully transparent surface (opacity 0) is not there at all, whatever its other coefficients
     m, lo, hi, _ = mean_and_range('Material "uber" "color Kd" [.3 .3 .3] "color Ks" [.5 .5 .5] "color Kr" [.5 .5 .5] "color opacity" [0 0 0]')
     assert abs(m - 1.0) < 3e-3 and lo > 0.9 and hi < 1.1, (m, lo, hi)
+
+
+def test_rough_glass_pins(binding, oracle, tmp_path):
+    """GlassMaterial with uroughness = vroughness != 0 (glass.cpp:66-90: MicrofacetReflection + MicrofacetTransmission; refused until
+    round 6) has no test in the reference. Beside the sampling and pdf / energy checks above, the restatement is tied to the smooth
+    dielectric, which the white furnace pins: as the roughness goes to zero each microfacet lobe must turn into its specular
+    counterpart. In the analytic furnace, a ball with alpha = 0.003:
+      * transmission alone (Kr = 0): MicrofacetTransmission against FresnelSpecular with R = 0 — the (1 - F) term, the eta^2 / radiance
+        factors and the Jacobian: equal mean radiance within 1 %;
+      * reflection alone (Kt = 0): MicrofacetReflection(FresnelDielectric(1, eta)) against FresnelSpecular with T = 0: within 1.5 %;
+      * both lobes: BELOW the smooth ball's 1.0, by 2-5 % — the reference evaluates the reflection lobe's Fresnel term as
+        `fresnel->Evaluate(Dot(wi, wh))` (reflection.cpp:233, no Faceforward of wh), i.e. with the outside's indices on both sides of
+        the surface: inside the glass there is no total internal reflection in that lobe, and what the transmission lobe refuses
+        there is lost. Restated as it is (a later pbrt-v3 fixed it); the bound keeps the loss from growing or turning into a gain.
+    At alpha = 0.2 single scattering loses more, and never creates energy."""
+    head = '''Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [10] "integer yresolution" [10]
+Sampler "halton" "integer pixelsamples" [256]
+Integrator "path" "integer maxdepth" [12]
+WorldBegin
+AttributeBegin
+  ReverseOrientation
+  Material "matte" "color Kd" [.5 .5 .5]
+  AreaLightSource "diffuse" "color L" [.5 .5 .5]
+  Shape "sphere" "float radius" [1]
+AttributeEnd
+AttributeBegin
+  %s
+  Translate 0 0 0.55
+  Shape "sphere" "float radius" [0.25]
+AttributeEnd
+WorldEnd
+'''
+
+    def mean_of(material):
+        path = tmp_path / "furnace_ball.pbrt"
+        path.write_text(head % material)
+        scene = binding.HostScene(path=str(path))
+        film, st = oracle.render(scene, trig_mode=ob.TRIG_LIBM)
+        rgb = scene.film_to_rgb(film)
+        return float(rgb.mean(dtype=np.float64)), st
+
+    nearly = '"float uroughness" [.003] "float vroughness" [.003] "bool remaproughness" ["false"]'
+    t_smooth, _ = mean_of('Material "glass" "color Kr" [0 0 0] "float index" [1.5]')
+    t_rough, st = mean_of('Material "glass" "color Kr" [0 0 0] "float index" [1.5] ' + nearly)
+    assert 0.7 < t_smooth < 0.95 and abs(t_rough - t_smooth) < 0.01 * t_smooth, (t_smooth, t_rough)
+    assert st["nee_evals"] > 0            # the rough lobes are not specular: light is sampled at the ball's vertices
+    r_smooth, _ = mean_of('Material "glass" "color Kt" [0 0 0] "float index" [1.5]')
+    r_rough, _ = mean_of('Material "glass" "color Kt" [0 0 0] "float index" [1.5] ' + nearly)
+    assert 0.05 < r_smooth < 0.2 and abs(r_rough - r_smooth) < 0.015 * r_smooth, (r_smooth, r_rough)
+    both_smooth, _ = mean_of('Material "glass" "float index" [1.5]')
+    both_rough, _ = mean_of('Material "glass" "float index" [1.5] ' + nearly)
+    assert abs(both_smooth - 1.0) < 0.01 and 0.95 < both_rough < 0.985, (both_smooth, both_rough)
+    rough, _ = mean_of('Material "glass" "float index" [1.5] "float uroughness" [.2] "float vroughness" [.2] "bool remaproughness" ["false"]')
+    assert 0.6 < rough < both_rough, rough

@@ -19,7 +19,7 @@ o = oracle_binding.Oracle()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 lights = ["area", "quad", "multi", "spot", "point", "envmap", "sky"]  # (the last two: infinite lights — k_mis ends at the first hit)
-mats = ["plain", "all", "mixed", "ubertrans"]   # (ubertrans: round 6 — uber with opacity < 1 and Kt)
+mats = ["plain", "all", "mixed", "ubertrans", "roughglass"]   # (round 6: uber with opacity < 1 and Kt; rough glass)
 bad = 0
 with tempfile.TemporaryDirectory() as td:
     for seed in range(first, first + n):
