@@ -1307,7 +1307,8 @@ struct Oracle {
             return ph;
         };
         V3 ph = refine(ts.v);
-        float phi = std::atan2(ph.y, ph.x);
+        // (the trig mode's atan2: the device evaluates the same operations; a full sphere's phi never exceeds phiMax = Radians(360) in either)
+        float phi = trig.atan2_f(ph.y, ph.x);
         if (phi < 0) phi += 2 * Pi;
         if ((sp.zmin > -sp.radius && ph.z < sp.zmin) || (sp.zmax < sp.radius && ph.z > sp.zmax) ||
             phi > sp.phi_max) {
@@ -1315,7 +1316,7 @@ struct Oracle {
             if (t1.high > ray.tmax) return false;
             ts = t1;
             ph = refine(ts.v);
-            phi = std::atan2(ph.y, ph.x);
+            phi = trig.atan2_f(ph.y, ph.x);
             if (phi < 0) phi += 2 * Pi;
             if ((sp.zmin > -sp.radius && ph.z < sp.zmin) || (sp.zmax < sp.radius && ph.z > sp.zmax) ||
                 phi > sp.phi_max)
@@ -1355,7 +1356,7 @@ struct Oracle {
         is->sn = faceforward(snw, is->n);
         // dndu / dndv from the fundamental forms (sphere.cpp:122-143) and, with dpdu / dpdv, their object-to-world images
         // (transform.cpp:275-283: vectors by the matrix, Normal3f by the inverse transpose). Only the direct pass's
-        // reflected-ray differentials read them (directprogressiveintegrator.cpp:165-184): no texture is ever looked up on a sphere.
+        // reflected-ray differentials read them (directprogressiveintegrator.cpp:165-184), Material::Bump and — with uv below — the texture lookups on a sphere.
         const float dt = sp.theta_max - sp.theta_min;
         const V3 d2Pduu = (-sp.phi_max * sp.phi_max) * V3(ph.x, ph.y, 0);
         const V3 d2Pduv = (dt * ph.z * sp.phi_max) * V3(-sin_phi, cos_phi, 0.f);
@@ -1370,7 +1371,12 @@ struct Oracle {
         is->dpdv = is->sdpdv = xf_vector(m, dpdv);
         is->dndu = xf_normal(mi, dndu);
         is->dndv = xf_normal(mi, dndv);
-        is->uv[0] = is->uv[1] = 0;
+        // Point2f(u, v) of the hit (sphere.cpp:107-109): u = phi / phiMax, v = (theta - thetaMin) / (thetaMax - thetaMin); phi as
+        // Sphere::Intersect computes it from the refined hit point
+        float phi = trig.atan2_f(ph.y, ph.x);
+        if (phi < 0) phi += 2 * Pi;
+        is->uv[0] = phi / sp.phi_max;
+        is->uv[1] = (theta - sp.theta_min) / (sp.theta_max - sp.theta_min);
         is->flip = sp.reverse_orientation ^ sp.swaps_handedness;
     }
 

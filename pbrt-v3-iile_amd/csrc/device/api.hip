@@ -592,11 +592,6 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     if (d->n_prims >= (1 << 24)) return fail(IILE_ERR_UNSUPPORTED, "more than 2^24 primitives");
     if (d->n_spheres > kMaxSpheres || d->n_materials > kMaxMaterials || d->n_lights > kMaxLights)
         return fail(IILE_ERR_UNSUPPORTED, "too many spheres / materials / lights");
-    for (int i = 0; i < d->n_spheres; ++i) {
-        const iile_sphere &s = d->spheres[i];
-        if (!(s.zmin == -s.radius && s.zmax == s.radius && s.phi_max >= 6.2831850f))
-            return fail(IILE_ERR_UNSUPPORTED, "partial spheres (zmin/zmax/phimax) are not supported on device");
-    }
     for (int i = 0; i < d->n_lights; ++i) {
         const iile_light &l = d->lights[i];
         if (l.type == IILE_LIGHT_DIFFUSE_AREA) {
@@ -890,13 +885,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             if (rc) return bail(rc);
             rc = upload(sc, d->ewa_lut, size_t(IILE_EWA_LUT_SIZE), &S.ewa_lut);
             if (rc) return bail(rc);
-            // textures are looked up through a triangle's (u, v): a sphere would need its own parametrisation
-            for (int i = 0; i < d->n_prims; ++i)
-                if ((d->prim_flags[i] & IILE_PRIM_SPHERE) && d->prim_material[i] >= 0) {
-                    const iile_material &m = d->materials[d->prim_material[i]];
-                    if (m.kd_tex >= 0 || m.ks_tex >= 0 || m.kr_tex >= 0 || m.kt_tex >= 0 || m.bump_tex >= 0 || m.rough_tex >= 0 || m.sigma_tex >= 0)
-                        return bail(fail(IILE_ERR_UNSUPPORTED, "image textures on spheres are not supported"));
-                }
+            // (a sphere's (u, v) = (phi / phiMax, (theta - thetaMin) / (thetaMax - thetaMin)), sphere.cpp:107-109: sphere_interaction)
         }
         std::vector<DLight> lts(d->n_lights);
         S.all_lights_infinite = d->n_lights > 0 ? 1 : 0;

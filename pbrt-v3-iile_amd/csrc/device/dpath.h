@@ -466,9 +466,8 @@ DEV bool triangle_test(const RayCtx &rc, float tmax, F3 p0, F3 p1, F3 p2, float 
     return true;
 }
 
-// Sphere::Intersect / IntersectP up to the hit decision (sphere.cpp:49-103).
-// Full spheres only (zmin=-r, zmax=r, phimax=360 — enforced at scene upload),
-// so the phi / z clipping branch cannot reject and phi (atan2) is dead.
+// Sphere::Intersect / IntersectP up to the hit decision (sphere.cpp:49-103), partial spheres included (zmin / zmax / phimax: the
+// clipping branch of :89-104 — taken, and phi's atan2 evaluated, only for a sphere that is cut: a full sphere's test cannot fail).
 // Outputs the object-space ray and refined hit point for sphere_interaction.
 DEV bool sphere_test(const DSphere &sp, F3 ro, F3 rd, float tmax, float *t_hit, F3 *obj_d, F3 *phit) {
     F3 oerr, derr;
@@ -519,6 +518,28 @@ DEV bool sphere_test(const DSphere &sp, F3 ro, F3 rd, float tmax, float *t_hit, 
     float scale = sp.radius / length(ph);
     ph = F3{ph.x * scale, ph.y * scale, ph.z * scale};
     if (ph.x == 0 && ph.y == 0) ph.x = 1e-5f * sp.radius;
+    const bool z_cut = sp.zmin > -sp.radius || sp.zmax < sp.radius, phi_cut = sp.phi_max < 6.2831853f;   // Radians(360) = 6.2831855f
+    if (z_cut || phi_cut) {
+        auto clipped = [&](F3 q) {
+            bool out = (sp.zmin > -sp.radius && q.z < sp.zmin) || (sp.zmax < sp.radius && q.z > sp.zmax);
+            if (phi_cut) {
+                float phi = atan2_f(q.y, q.x);
+                if (phi < 0) phi += 2 * kPi;
+                out = out || phi > sp.phi_max;
+            }
+            return out;
+        };
+        if (clipped(ph)) {
+            if (ts.v == t1.v) return false;
+            if (t1.hi > tmax) return false;
+            ts = t1;
+            ph = o + d * ts.v;
+            scale = sp.radius / length(ph);
+            ph = F3{ph.x * scale, ph.y * scale, ph.z * scale};
+            if (ph.x == 0 && ph.y == 0) ph.x = 1e-5f * sp.radius;
+            if (clipped(ph)) return false;
+        }
+    }
     *t_hit = ts.v;
     *obj_d = d;
     *phit = ph;
@@ -581,7 +602,11 @@ DEV void sphere_interaction(const DSphere &sp, F3 obj_d, F3 ph, Isect *is) {
         is->dpdv = is->sdpdv = xf_vector(sp.o2w, dpdv);
         is->dndu = xf_normal(sp.o2w_inv, dndu);
         is->dndv = xf_normal(sp.o2w_inv, dndv);
-        is->u = is->v = 0;   // (no texture is ever looked up on a sphere: the loader refuses one)
+        // Point2f(u, v) of the hit (sphere.cpp:107-109); phi as Sphere::Intersect computes it from the refined hit point
+        float phi = atan2_f(ph.y, ph.x);
+        if (phi < 0) phi += 2 * kPi;
+        is->u = phi / sp.phi_max;
+        is->v = (theta - sp.theta_min) / (sp.theta_max - sp.theta_min);
         is->flip = sp.reverse_orientation ^ sp.swaps_handedness;
     }
 }

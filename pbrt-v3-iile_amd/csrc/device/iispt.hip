@@ -80,7 +80,7 @@ DEV void vertex_state(const DScene &S, const float4 o4, const float4 d4, const f
         F3 od, ph;
         const DSphere &sp = S.spheres[S.prim_shape[prim]];
         sphere_test(sp, ro, rd, IILE_INF, &t, &od, &ph);
-        sphere_interaction(sp, od, ph, is);
+        sphere_interaction<true>(sp, od, ph, is);   // (with (u, v) and the derivatives: a textured or bump-mapped sphere looks them up below)
     } else {
         triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z}, F3{v2.x, v2.y, v2.z}, rd, h4.y, h4.z, h4.w, is);
     }

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX)) void k_shade(DScene S, Pa
                     F3 od, ph;
                     const DSphere &sp = S.spheres[S.prim_shape[prim]];
                     sphere_test(sp, ray_o, ray_d, IILE_INF, &t, &od, &ph);
-                    sphere_interaction(sp, od, ph, &is);
+                    sphere_interaction<TEX>(sp, od, ph, &is);   // (TEX: with (u, v), dp/du, dp/dv and dn/du, dn/dv for the texture lookups and Material::Bump)
                 } else {
                     triangle_interaction(S, prim, flags, F3{v0.x, v0.y, v0.z}, F3{v1.x, v1.y, v1.z},
                                          F3{v2.x, v2.y, v2.z}, ray_d, h4.y, h4.z, h4.w, &is);

@@ -894,11 +894,6 @@ class Loader {
         int mat = current_material();
         if (mat < 0) return false;
         if (name == "sphere") {  // shapes/sphere.cpp:318-327, sphere.h:50-60
-            {
-                const iile_material &sm = s.materials[size_t(mat)];
-                if (sm.kd_tex >= 0 || sm.ks_tex >= 0 || sm.kr_tex >= 0 || sm.kt_tex >= 0 || sm.bump_tex >= 0 || sm.rough_tex >= 0 || sm.sigma_tex >= 0)
-                    return fail("image textures on spheres are not supported (triangle meshes only)");
-            }
             float radius = ps.one_float("radius", 1.f);
             float zmin = ps.one_float("zmin", -radius);
             float zmax = ps.one_float("zmax", radius);

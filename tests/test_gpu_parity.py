@@ -616,6 +616,90 @@ def test_several_spheres_with_transforms_bitwise(binding, oracle, tmp_path):
     assert_bitwise(plain, ref, "three spheres film, uninstrumented kernels")
 
 
+PARTIAL_SPHERES_SCENE = """LookAt 0 -8 3  0 0 1  0 0 1
+Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [96] "integer yresolution" [64]
+Sampler "halton" "integer pixelsamples" [4]
+Integrator "path" "integer maxdepth" [5]
+WorldBegin
+AttributeBegin
+  Translate 1 -1 4
+  Rotate 30 0 1 0
+  AreaLightSource "area" "color L" [30 30 30]
+  Shape "sphere" "float radius" [0.5] "float zmin" [-0.4] "float phimax" [300]
+AttributeEnd
+Texture "checks" "spectrum" "imagemap" "string filename" ["checks.pfm"]
+Texture "bumps" "float" "imagemap" "string filename" ["bumps.pfm"]
+AttributeBegin
+  Material "plastic" "texture Kd" ["checks"] "color Ks" [.3 .3 .3] "float roughness" [0.1] "texture bumpmap" ["bumps"]
+  Translate -1.5 0 1
+  Rotate 40 1 1 0
+  Scale 1 0.6 1.3
+  Shape "sphere" "float radius" [0.8]
+AttributeEnd
+AttributeBegin
+  Material "matte" "texture Kd" ["checks"]
+  Translate 1.2 0.5 0.9
+  Rotate -25 1 0 0
+  Shape "sphere" "float radius" [0.9] "float zmax" [0.35] "float phimax" [250]
+AttributeEnd
+AttributeBegin
+  Material "mirror" "color Kr" [.8 .8 .8]
+  Translate 0 1.8 1.2
+  Rotate 70 0 1 0
+  Shape "sphere" "float radius" [1.1] "float zmin" [-0.3] "float zmax" [0.8] "float phimax" [200]
+AttributeEnd
+AttributeBegin
+  Material "matte" "color Kd" [.5 .5 .5]
+  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-5 -5 0  5 -5 0  5 5 0  -5 5 0]
+AttributeEnd
+WorldEnd
+"""
+
+
+def test_partial_and_textured_spheres_bitwise(binding, oracle, tmp_path):
+    """Sphere::Intersect's clipping (zmin / zmax / phimax: sphere.cpp:89-104, the second root tried when the first is cut away) and a
+    sphere hit's (u, v), dp/du, dp/dv, dn/du, dn/dv for image textures and bump maps (:107-143) — both refused on the device until
+    round 6: a cut emitter (its Sample still draws from the whole sphere, as the reference's does), a textured and bump-mapped
+    ellipsoid, a textured bowl and a mirror band over a floor; closest / any hits of random rays, then film and every counter
+    against the oracle bit for bit, both kernel sets. Pins of the oracle: tests/test_oracle_pins.py::test_partial_and_textured_spheres_pins."""
+    rng = np.random.default_rng(21)
+    chk = np.zeros((8, 8, 3), np.float32)
+    chk[::2, ::2] = chk[1::2, 1::2] = (.8, .3, .2)
+    chk[::2, 1::2] = chk[1::2, ::2] = (.2, .4, .8)
+    (tmp_path / "checks.pfm").write_bytes(b"PF\n8 8\n-1.0\n" + chk.tobytes())
+    bmp = np.repeat(rng.uniform(0, .05, (16, 16, 1)).astype(np.float32), 3, 2)
+    (tmp_path / "bumps.pfm").write_bytes(b"PF\n16 16\n-1.0\n" + bmp.tobytes())
+    path = tmp_path / "partial_spheres.pbrt"
+    path.write_text(PARTIAL_SPHERES_SCENE)
+    scene = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(scene)
+    # kernel level: rays at and around the spheres
+    n = 20000
+    o = rng.uniform((-4, -6, 0.05), (4, 4, 5), (n, 3)).astype(np.float32)
+    tgt = rng.uniform((-3, -2, 0), (3, 3, 4.5), (n, 3)).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    tmax = np.where(rng.random(n) < 0.5, np.float32(np.inf), rng.uniform(0.5, 2.0, n).astype(np.float32)).astype(np.float32)
+    for instrumented in (True, False):
+        prim, tb, _ = gpu.trace_closest(o, d, tmax, instrumented=instrumented)
+        rprim, rtb = oracle.intersect(scene, o, d, tmax)
+        assert np.array_equal(prim, rprim) and (prim >= 0).mean() > 0.3
+        assert_bitwise(tb[prim >= 0], rtb[prim >= 0], "partial spheres closest hit")
+        hit = gpu.trace_any(o, d, tmax, instrumented=instrumented)[0]
+        assert np.array_equal(hit, oracle.intersect_p(scene, o, d, tmax))
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(scene)
+    assert float(scene.film_to_rgb(ref).mean()) > 1e-3
+    assert_bitwise(film, ref, "partial / textured spheres film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["sphere_tests"] == ost["sphere_tests"] and st["nee_evals"] == ost["nee_evals"] and st["path_length"] == ost["path_length"]
+    plain, _ = gpu.render()
+    assert_bitwise(plain, ref, "partial / textured spheres film, uninstrumented kernels")
+    # the IISPT direct pass on the same scene (its kernels build the same interactions)
+    direct = gpu.render_direct(2)
+    assert np.array_equal(direct.view(np.uint64), oracle.iispt_direct(scene, 2).view(np.uint64))
+
+
 @pytest.mark.parametrize("seed,light", [(1, "quad"), (2, "multi"), (3, "area"), (4, "spot")])
 def test_random_rooms_bitwise(binding, oracle, tmp_path, seed, light):
     """Differently seeded box rooms (other blob positions, sizes, noise, material parameters) with all

@@ -1150,3 +1150,106 @@ WorldEnd
     assert abs(both_smooth - 1.0) < 0.01 and 0.95 < both_rough < 0.985, (both_smooth, both_rough)
     rough, _ = mean_of('Material "glass" "float index" [1.5] "float uroughness" [.2] "float vroughness" [.2] "bool remaproughness" ["false"]')
     assert 0.6 < rough < both_rough, rough
+
+
+def test_partial_and_textured_spheres_pins(binding, oracle, tmp_path):
+    """Sphere::Intersect's clipping (sphere.cpp:89-104: zmin / zmax / phimax, second root tried when the first is cut away) and the
+    hit's (u, v) = (phi / phiMax, (theta - thetaMin) / (thetaMax - thetaMin)) (:107-109) — refused on the device until round 6.
+    Pins: rays through a sphere cut to a bowl (zmax = 0.3 r) and to a wedge (phimax = 90) hit exactly where the geometry says —
+    the far wall through the cut-away part, nothing outside the wedge — and a sphere wearing a constant image texture renders like the
+    constant, while a two-texel texture splits it along u = 1/2 (the meridian phi = 180 degrees)."""
+    scene_txt = '''Camera "perspective" "float fov" [40]
+Film "image" "integer xresolution" [4] "integer yresolution" [4]
+Sampler "halton" "integer pixelsamples" [1]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "color L" [1 1 1]
+  Translate 0 0 50
+  Shape "sphere" "float radius" [1]
+AttributeEnd
+Material "matte"
+Shape "sphere" "float radius" [2] "float zmax" [0.6]
+AttributeBegin
+  Translate 10 0 0
+  Shape "sphere" "float radius" [2] "float phimax" [90]
+AttributeEnd
+WorldEnd
+'''
+    path = tmp_path / "partial.pbrt"
+    path.write_text(scene_txt)
+    scene = binding.HostScene(path=str(path))
+    inf = np.float32(np.inf)
+    # the bowl: straight down the axis from above: the cap z > 0.6 is cut away, the ray enters through the opening and hits the inside at z = -2
+    o = np.array([[0, 0, 10], [0, 0, -10], [1.95, 0, 10], [0.5, 0, 10]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, 1], [0, 0, -1], [0, 0, -1]], np.float32)
+    prim, tb = oracle.intersect(scene, o, d, np.full(4, inf, np.float32))
+    assert (prim >= 0).all()
+    assert abs(tb[0, 0] - 12.0) < 1e-4          # through the opening to the far inside (z = -2)
+    assert abs(tb[1, 0] - 8.0) < 1e-4           # from below: the outside at z = -2
+    z_hit = 10 - tb[2, 0]
+    assert abs(z_hit - np.sqrt(4 - 1.95 ** 2)) < 1e-3 and z_hit <= 0.6   # near the rim, below the cut (z = 0.44): the first root stands
+    assert abs((10 - tb[3, 0]) + np.sqrt(4 - 0.25)) < 1e-3                       # x = 0.5: the first root (z = 1.94) is cut away, the second stands
+    # the wedge (phi in [0, 90 degrees] about its own centre at x = 10): a ray towards a point at phi = 45 hits, one towards phi = 200 passes
+    c = np.array([10, 0, 0], np.float32)
+    p_in = c + 2 * np.array([np.cos(np.pi / 4) * np.cos(0.2), np.sin(np.pi / 4) * np.cos(0.2), np.sin(0.2)], np.float32)
+    p_out = c + 2 * np.array([np.cos(3.5) * np.cos(0.2), np.sin(3.5) * np.cos(0.2), np.sin(0.2)], np.float32)
+    for target, expect in ((p_in, True), (p_out, False)):
+        away = (target - c) / 2
+        oo = (target + 5 * away).astype(np.float32)[None]
+        prim, tb = oracle.intersect(scene, oo, (-away).astype(np.float32)[None], np.full(1, inf, np.float32))
+        if expect:
+            assert prim[0] >= 0 and abs(tb[0, 0] - 5.0) < 1e-3
+        else:
+            assert prim[0] < 0 or tb[0, 0] > 5.5   # (the ray may leave through the far side of the wedge, or miss it altogether)
+    # textures on a sphere: the white furnace's wall (an emitting sphere seen from inside) with its Kd read from a constant 0.5 image is the
+    # furnace with the constant — whatever (u, v) the hits get —; and a texture that is red for u < 1/2 and blue beyond splits a sphere
+    # seen from outside along the meridians phi = 0 / 180 degrees (u = phi / 2 pi about the sphere's own z axis)
+    furnace = '''Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [8] "integer yresolution" [8]
+Sampler "halton" "integer pixelsamples" [64]
+Integrator "path" "integer maxdepth" [12]
+WorldBegin
+%s
+AttributeBegin
+  ReverseOrientation
+  %s
+  AreaLightSource "diffuse" "color L" [.5 .5 .5]
+  Shape "sphere" "float radius" [1]
+AttributeEnd
+WorldEnd
+'''
+    (tmp_path / "half.pfm").write_bytes(b"PF\n4 4\n-1.0\n" + np.full((4, 4, 3), np.float32(.5), np.float32).tobytes())
+    films = []
+    for tex, mat in (("", 'Material "matte" "color Kd" [.5 .5 .5]'),
+                     ('Texture "half" "spectrum" "imagemap" "string filename" ["half.pfm"]', 'Material "matte" "texture Kd" ["half"]')):
+        path = tmp_path / "furnace_tex.pbrt"
+        path.write_text(furnace % (tex, mat))
+        sc = binding.HostScene(path=str(path))
+        film, _ = oracle.render(sc, trig_mode=ob.TRIG_LIBM)
+        films.append(sc.film_to_rgb(film))
+    assert abs(float(films[0].mean()) - 1.0) < 0.02 and np.allclose(films[0], films[1], rtol=2e-5, atol=1e-6)
+    two = np.zeros((1, 2, 3), np.float32)
+    two[0, 0] = (1, 0, 0)
+    two[0, 1] = (0, 0, 1)
+    (tmp_path / "two.pfm").write_bytes(b"PF\n2 1\n-1.0\n" + two.tobytes())
+    split = '''LookAt 0 -10 0  0 0 0  0 0 1
+Camera "perspective" "float fov" [30]
+Film "image" "integer xresolution" [32] "integer yresolution" [8]
+Sampler "halton" "integer pixelsamples" [4]
+Integrator "path" "integer maxdepth" [1]
+WorldBegin
+LightSource "distant" "point from" [0 -1 0] "point to" [0 0 0] "color L" [3 3 3]
+Texture "two" "spectrum" "imagemap" "string filename" ["two.pfm"] "string wrap" ["clamp"] "bool trilinear" ["true"]
+Material "matte" "texture Kd" ["two"]
+Shape "sphere" "float radius" [2]
+WorldEnd
+'''
+    path = tmp_path / "split.pbrt"
+    path.write_text(split)
+    sc = binding.HostScene(path=str(path))
+    film, _ = oracle.render(sc, trig_mode=ob.TRIG_LIBM)
+    rgb = sc.film_to_rgb(film)
+    # seen from -y: the visible half is phi in (180, 360) degrees, i.e. u in (1/2, 1): the second texel (blue) everywhere on the ball
+    ball = rgb.sum(2) > 0.05
+    assert ball.sum() > 20 and (rgb[ball][:, 2] > 3 * rgb[ball][:, 0]).mean() > 0.8 and rgb[ball][:, 2].sum() > 8 * rgb[ball][:, 0].sum(), rgb[ball][:5]
+    # (the pixels at the limbs see u near 1/2 and 1, where the filter blends the two texels)
