@@ -829,7 +829,6 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             mats[i].on_a = oren_nayar ? m.on_a : 1.f;
             mats[i].on_b = oren_nayar ? m.on_b : 0.f;
             if (m.type == IILE_MAT_GLASS) S.has_glass = 1;
-            if (m.type == IILE_MAT_GLASS && m.roughness != 0.f) S.has_uber_trans = 1;   // rough glass: its glossy transmission is the path integrator's only
             for (int c = 0; c < 3; ++c) mats[i].opacity[c] = m.type == IILE_MAT_UBER ? m.opacity[c] : 1.f;
             if (m.type == IILE_MAT_UBER) {
                 // uber.cpp:53-61, 94-99: a SpecularTransmission lobe exists if 1 - opacity or opacity x Kt is not black (an image for Kt: may be)
@@ -1797,7 +1796,7 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     const bool reflect_diffs = S.textured_materials && S.has_specular;
     if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
     if (S.has_uber_trans)
-        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: uber materials with specular transmission (opacity < 1 or Kt) and rough glass are rendered by iile_render and the probe pass only");
+        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: uber materials with specular transmission (opacity < 1 or Kt) are rendered by iile_render and the probe pass only");
     // Glass: DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), GlassMaterial
     // then adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and both recursions fire — Li is a tree,
     // walked depth first by one thread per pixel (k_direct_tree) instead of the wavefront below.
@@ -2154,7 +2153,7 @@ int iispt_check(iile_scene *sc, const iile_iispt_task *t, int *nx, int *ny) {
     if (t->x1 <= t->x0 || t->y1 <= t->y0 || t->tilesize < 1) return fail(IILE_ERR_ARG, "iile_iispt: empty task or tilesize < 1");
     if (sc->ds.sobol) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the runner's camera samples need the scene's Halton sampler");
     if (sc->ds.has_uber_trans)
-        return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: uber materials with specular transmission (opacity < 1 or Kt) and rough glass are rendered by iile_render and the probe pass only");
+        return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: uber materials with specular transmission (opacity < 1 or Kt) are rendered by iile_render and the probe pass only");
     if (sc->probe.hemi_size != 32) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the gather is built for 32 x 32 hemispheres (iisptHemiSize)");
     *nx = iile_iispt_grid_count(t->x0, t->x1, t->tilesize);
     *ny = iile_iispt_grid_count(t->y0, t->y1, t->tilesize);

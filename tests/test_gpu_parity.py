@@ -444,7 +444,7 @@ def test_rough_glass_bitwise(binding, oracle, tmp_path):
     BSDF::f / Pdf / Sample_f carry a transmission term. The lobes in the canonical frame for every material kind the loader makes
     (f, pdf, Sample_f over the whole sphere of directions), then the box room with rough refractive blobs at maxdepth 8: film and
     every counter against the oracle bit for bit, both kernel sets. The oracle's lobes are pinned by
-    tests/test_oracle_pins.py::test_rough_glass_pins. The IISPT runner and direct pass refuse such scenes."""
+    tests/test_oracle_pins.py::test_rough_glass_pins. The IISPT runner's stages and the direct pass on the same room likewise."""
     import boxroom
     mats = tmp_path / "mats.pbrt"
     mats.write_text('''Camera "perspective"
@@ -500,8 +500,17 @@ WorldEnd
     assert st["nee_evals"] == ost["nee_evals"] and st["path_length"] == ost["path_length"]
     plain, _ = gpu.render()
     assert_bitwise(plain, ref, "rough glass film, uninstrumented kernels")
-    with pytest.raises(RuntimeError, match="rough glass"):
-        gpu.render_direct(1)
+    # the IISPT stages on the same room (the runner's first-intersection search, the gather over predicted hemispheres, the direct pass
+    # — per-pixel tree walk, as for every scene with glass): the rough lobes are glossy, so Li does not recurse through them
+    direct = gpu.render_direct(2)
+    assert np.array_equal(direct.view(np.uint64), oracle.iispt_direct(room, 2).view(np.uint64))
+    task = binding.IisptTask(0, 0, 96, 64, 8, 0, 0)
+    valid, pos, dr = gpu.iispt_hemi_points(task)
+    rv, rp, rd = oracle.iispt_hemi_points(room, task)
+    assert np.array_equal(valid, rv) and np.array_equal(pos.view(np.uint32), rp.view(np.uint32)) and np.array_equal(dr.view(np.uint32), rd.view(np.uint32))
+    nn = np.random.default_rng(3).uniform(0.0, 3.0, valid.shape + (32, 32, 3)).astype(np.float32)
+    out = gpu.iispt_gather(task, valid, pos, dr, nn)
+    assert np.array_equal(out.view(np.uint32), oracle.iispt_gather(room, task, valid, pos, dr, nn).view(np.uint32)) and (out[..., 3] == 0.5).sum() > 500
 
 
 def test_glass_scenes_bitwise(binding, oracle, tmp_path):
