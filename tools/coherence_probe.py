@@ -100,6 +100,11 @@ def run_orders(o1, d1, label):
                   "sorted by (32^3 origin cell, direction octant) — the 18-bit key of VERDICT r05 next 4": np.argsort((cell15 << np.uint64(3)) | octant, kind="stable"),
                   "sorted by the full 30-bit origin code": np.argsort(code, kind="stable"),
                   "shuffled": rng.permutation(m)}
+        # what k_shade could do at no extra pass: its output rays binned by direction octant as they are appended (eight cursors per
+        # wavefront), i.e. the pipeline's order with a stable sort by octant inside consecutive blocks of the queue
+        for blk in (4096, 65536):
+            key = (np.arange(m, dtype=np.uint64) // np.uint64(blk)) * np.uint64(8) + octant
+            orders[f"the pipeline's order, octants grouped inside blocks of {blk}"] = np.argsort(key, kind="stable")
     gpu.trace_closest(o1[:1000], d1[:1000], inf1[:1000], instrumented=False)
     res = None
     for name, idx in orders.items():

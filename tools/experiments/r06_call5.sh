@@ -13,6 +13,6 @@ import csv, glob
 f = glob.glob('$O/trace_$scene/**/*kernel_trace.csv', recursive=True)
 rows = [r for f_ in f for r in csv.DictReader(open(f_)) if 'k_trace' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-print("$scene k_trace launches (ms; first wave, then per bounce: warm-up + 3 x 4 orders):", [round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, 3) for r in rows])
+print("$scene k_trace launches (ms; first wave, then per bounce: warm-up + 3 x 6 orders):", [round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, 3) for r in rows])
 PY
 done
