@@ -178,7 +178,8 @@ int iile_render_probes(iile_scene *scene, int32_t n_probes, const float *pos3, c
  * per level, at most 64 light samples per vertex. Reflected rays carry differentials in textured scenes
  * (directprogressiveintegrator.cpp:165-184). Scenes with glass — where Li branches into a reflection and a transmission recursion
  * at every glass vertex (allowMultipleLobes = false: glass.cpp:62-90) and the sampler's stream follows the recursion's depth-first
- * order — are rendered by one thread per pixel walking its tree (k_direct_tree), the others by the wavefront. Specular spheres
+ * order — are rendered by one thread per pixel walking its tree (k_direct_tree), the others by the wavefront; an uber material's
+ * specular transmissions (opacity < 1, Kt) likewise, SpecularTransmit's u[0] choosing between the two lobes. Specular spheres
  * in textured scenes carry Sphere::Intersect's dndu / dndv (src/shapes/sphere.cpp:122-143) into the reflected differentials. */
 typedef struct iile_direct_params {
     int32_t n_passes, first_pass;

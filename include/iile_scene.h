@@ -67,7 +67,7 @@ enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1, IILE_MAT_UBER = 2, IILE_MAT_MIR
 /* MatteMaterial / PlasticMaterial / UberMaterial / MirrorMaterial / GlassMaterial with constant
  * textures (src/materials/matte.cpp:45-62, plastic.cpp:45-70, uber.cpp:45-100, mirror.cpp:44-55,
  * glass.cpp:45-92). Uber: uroughness == vroughness; its two SpecularTransmission lobes (the pass-through of opacity < 1 and Kt,
- * uber.cpp:53-61, 94-99) are rendered by iile_render and the probe pass — the IISPT runner and direct pass refuse such scenes.
+ * uber.cpp:53-61, 94-99) are rendered by every entry point (the path and probe passes, the IISPT runner's stages, the direct pass).
  * Glass: smooth (uroughness = vroughness = 0: one FresnelSpecular lobe, as the path integrator gets it) or rough and isotropic
  * (roughness = uroughness = vroughness != 0: MicrofacetReflection + MicrofacetTransmission, glass.cpp:66-90). */
 typedef struct iile_material {

@@ -2797,15 +2797,24 @@ struct Oracle {
         *wiW = b.to_world(wi);
         return f;
     }
-    // BSDF::Sample_f(wo, &wi, u, &pdf, BSDF_TRANSMISSION | BSDF_SPECULAR): the SpecularTransmission(T, 1, eta, Radiance) lobe glass
-    // carries beside its SpecularReflection when ComputeScatteringFunctions runs with allowMultipleLobes = false (glass.cpp:62-90,
-    // interaction.h:130-133 — the direct integrator's Li does): SpecularTransmission::Sample_f, reflection.cpp:154-170
-    Rgb sample_specular_transmission(const Bsdf &b, V3 woW, V3 *wiW, float *pdf) const {
+    // BSDF::Sample_f(wo, &wi, u, &pdf, BSDF_TRANSMISSION | BSDF_SPECULAR) (reflection.cpp:719-784). The lobes of that type: the
+    // SpecularTransmission(T, 1, eta, Radiance) glass carries beside its SpecularReflection when ComputeScatteringFunctions runs
+    // with allowMultipleLobes = false (glass.cpp:62-90, interaction.h:130-133 — the direct integrator's Li does), and UberMaterial's
+    // pass-through (first) and Kt lobe (last), uber.cpp:53-61, 94-99. With two of them u[0] picks one and the pdf is halved;
+    // SpecularTransmission::Sample_f, reflection.cpp:154-170
+    Rgb sample_specular_transmission(const Bsdf &b, V3 woW, const float u[2], V3 *wiW, float *pdf) const {
         *pdf = 0;
-        if (!b.has_spec || !b.spec_glass || b.kt.is_black()) return Rgb(0.f);
+        Rgb lobe_t[3];
+        float lobe_eta[3];
+        int matching = 0;
+        if (b.has_t0) lobe_t[matching] = b.t0, lobe_eta[matching++] = 1.f;
+        if (b.has_spec && b.spec_glass && !b.kt.is_black()) lobe_t[matching] = b.kt, lobe_eta[matching++] = b.spec_eta;
+        if (b.has_t1) lobe_t[matching] = b.t1, lobe_eta[matching++] = b.t1_eta;
+        if (matching == 0) return Rgb(0.f);
+        const int comp = std::min(int(std::floor(u[0] * matching)), matching - 1);
         V3 wo = b.to_local(woW);
         if (wo.z == 0) return Rgb(0.f);
-        const float eta_a = 1.f, eta_b = b.spec_eta;
+        const float eta_a = 1.f, eta_b = lobe_eta[comp];
         const bool entering = wo.z > 0;
         const float eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
         // Refract(wo, Faceforward(Normal3f(0, 0, 1), wo), etaI / etaT, wi), reflection.h:96-108
@@ -2818,9 +2827,10 @@ struct Oracle {
         const float cos_t = std::sqrt(1 - sin2_t);
         V3 wi = eta * -wo + (eta * cos_i - cos_t) * n;
         *pdf = 1;
-        Rgb ft = b.kt * (1.f - fr_dielectric(wi.z, eta_a, eta_b));  // T * (Spectrum(1.) - fresnel.Evaluate(CosTheta(*wi)))
+        Rgb ft = lobe_t[comp] * (1.f - fr_dielectric(wi.z, eta_a, eta_b));  // T * (Spectrum(1.) - fresnel.Evaluate(CosTheta(*wi)))
         ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
         *wiW = b.to_world(wi);
+        if (matching > 1) *pdf /= matching;  // (a specular lobe: the other lobes' pdf and f are not added)
         return ft / std::abs(wi.z);
     }
     // UniformSampleAllLights, integrator.cpp:54-83
@@ -2890,12 +2900,12 @@ struct Oracle {
                 }
                 L = L + R;
             }
-            {  // SpecularTransmit, :190-237: glass alone has a lobe that is BSDF_TRANSMISSION | BSDF_SPECULAR
+            {  // SpecularTransmit, :190-237: glass's and uber's SpecularTransmission lobes
                 float u[2];
                 smp.get2d(u);
                 V3 wi;
                 float pdf;
-                Rgb f = sample_specular_transmission(bsdf, wo, &wi, &pdf);
+                Rgb f = sample_specular_transmission(bsdf, wo, u, &wi, &pdf);
                 Rgb T(0.f);
                 if (pdf > 0.f && !f.is_black() && absdot(wi, is.sn) != 0.f) {
                     RayDiff rd;

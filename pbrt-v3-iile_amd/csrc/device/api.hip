@@ -1795,8 +1795,6 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     // hit's dpdu / dpdv and shading.dndu / dndv (triangles: triangle_interaction; spheres: sphere_interaction<true>)
     const bool reflect_diffs = S.textured_materials && S.has_specular;
     if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
-    if (S.has_uber_trans)
-        return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: uber materials with specular transmission (opacity < 1 or Kt) are rendered by iile_render and the probe pass only");
     // Glass: DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), GlassMaterial
     // then adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and both recursions fire — Li is a tree,
     // walked depth first by one thread per pixel (k_direct_tree) instead of the wavefront below.
@@ -2152,8 +2150,6 @@ int iispt_check(iile_scene *sc, const iile_iispt_task *t, int *nx, int *ny) {
     if (rc) return rc;
     if (t->x1 <= t->x0 || t->y1 <= t->y0 || t->tilesize < 1) return fail(IILE_ERR_ARG, "iile_iispt: empty task or tilesize < 1");
     if (sc->ds.sobol) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the runner's camera samples need the scene's Halton sampler");
-    if (sc->ds.has_uber_trans)
-        return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: uber materials with specular transmission (opacity < 1 or Kt) are rendered by iile_render and the probe pass only");
     if (sc->probe.hemi_size != 32) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the gather is built for 32 x 32 hemispheres (iisptHemiSize)");
     *nx = iile_iispt_grid_count(t->x0, t->x1, t->tilesize);
     *ny = iile_iispt_grid_count(t->y0, t->y1, t->tilesize);

@@ -141,7 +141,7 @@ struct DScene {
     int extended_features;    // anything beyond one emitting sphere + matte / plastic: k_shade<.., EXT = true>
     int all_lights_infinite;  // every light is an InfiniteAreaLight: k_mis walks unordered (kernels_trav.hip)
     int has_glass;            // some material transmits: the paths' etaScale is tracked
-    int has_uber_trans;       // some uber material has a SpecularTransmission lobe (opacity < 1 or Kt): the IISPT runner / direct pass refuse
+    int has_uber_trans;       // some uber material has a SpecularTransmission lobe (opacity < 1 or Kt): a vertex can hold two such lobes (k_direct_tree<.., 2>)
     int has_specular;         // some material has a specular lobe (mirror, glass, uber): emitted light after such a bounce
     int has_alpha;            // some mesh has an alpha mask: the ALPHA builds of the traversal kernels run
     int boxes_nested;         // every child box lies inside its parent's (checked at upload): the four-wide

@@ -552,18 +552,24 @@ TREE_CALL bool tree_mis_lit(const DScene &S, int li, bool hit, const HitRec &hm,
     }
     return lt.two_sided || dot(lis.n, -md) > 0;
 }
+// NT: the number of BSDF_TRANSMISSION | BSDF_SPECULAR lobes a BSDF of the scene can hold — 1 (glass) or 2 (an uber material's
+// pass-through and its Kt lobe): SpecularTransmit's u[0] picks among them AFTER the reflection subtree has drawn its samples, so
+// every lobe's transmitted ray is made when the vertex is shaded and the choice is taken when the reflection is back
+template <int NT>
 struct TreeLevel {
     F3 L;                 // Le + direct light (+ the reflection's share once it is back)
-    F3 f_r, f_t;          // SpecularReflect / SpecularTransmit: f of the lobe's sample
-    float ad_r, ad_t;     // AbsDot(wi, ns); 0 = that recursion does not happen
-    F3 t_o, t_d;          // the transmitted ray, made when the vertex is shaded, traced after the reflection subtree
-    RayDiff t_rd;
-    bool t_has_diff;
+    F3 f_r, f_t[NT];      // SpecularReflect / SpecularTransmit: f of the lobe's sample
+    float ad_r, ad_t[NT]; // AbsDot(wi, ns); 0 = that recursion does not happen
+    F3 t_o[NT], t_d[NT];  // the transmitted ray, made when the vertex is shaded, traced after the reflection subtree
+    RayDiff t_rd[NT];
+    bool t_has_diff[NT];
+    int n_t;              // matchingComps of SpecularTransmit's Sample_f; slot 0 holds the chosen lobe from stage 2 on
+    float pdf_t;          // 1 / matchingComps
     int stage;            // 1: the reflection subtree is being walked, 2: the transmission subtree
 };
 }  // namespace
 
-template <bool TEX>
+template <bool TEX, int NT>
 __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P, PassBuffers B, double *film_rgbw) {
     __shared__ int lds_stack[kWavesPerBlock][2 * kLdsStackDepth][64];
     lds_int *my_stack = (lds_int *)&lds_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
             rdiff = camera_differentials(S, float(px) + u0, float(py) + u1, l0, l1, ro, rd);
             has_diff = true;
         }
-        TreeLevel lv[5];
+        TreeLevel<NT> lv[5];
         int depth = 0, visited = 0;  // visited: vertices shaded so far = pairs of sample arrays used up / n_lights
         F3 ret = F3{0, 0, 0};
         bool descend = true;         // true: (ro, rd) is a ray to trace at `depth`; false: `ret` is what the subtree below returned
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                 if (TEX && has_diff) td = compute_differentials(is, rdiff, &dpdx, &dpdy);
                 Bsdf bsdf;
                 tree_bsdf<TEX>(S, material, td, &is, &bsdf);
-                TreeLevel &me = lv[depth];
+                TreeLevel<NT> &me = lv[depth];
                 me.L = F3{0, 0, 0};
                 if (light >= 0) me.L = me.L + area_light_L(S.lights[light], is.n, -rd);  // L += isect.Le(wo)
                 // ---- UniformSampleAllLights, integrator.cpp:54-83
@@ -662,7 +668,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                     me.L = me.L + all;
                 }
                 ++visited;
-                me.ad_r = me.ad_t = 0.f;
+                me.ad_r = 0.f;
+                for (int q = 0; q < NT; ++q) me.ad_t[q] = 0.f, me.t_has_diff[q] = false;
+                me.n_t = 0;
+                me.pdf_t = 1.f;
                 me.stage = 0;
                 if (depth + 1 >= 5) {  // `if (depth + 1 < maxDepth)`: no recursion below the fifth vertex
                     ret = me.L;
@@ -705,10 +714,17 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                         }
                     }
                 }
-                me.t_has_diff = false;
-                if (bsdf.has_spec && bsdf.mtype == kMatGlass && !is_black(bsdf.kt) && wo.z != 0) {
+                // the BSDF_TRANSMISSION | BSDF_SPECULAR lobes in the order the material added them: uber's pass-through, glass's
+                // SpecularTransmission (allowMultipleLobes = false) or uber's Kt lobe
+                const bool glass_t = bsdf.has_spec && bsdf.mtype == kMatGlass && !is_black(bsdf.kt);
+                for (int lobe = 0; lobe < 2; ++lobe) {
+                    const bool present = lobe == 0 ? bsdf.has_t0 : (glass_t || bsdf.has_t1);
+                    if (!present || me.n_t >= NT) continue;
+                    const int q = me.n_t++;
+                    if (wo.z == 0) continue;
                     // SpecularTransmission::Sample_f, reflection.cpp:154-170
-                    const float eta_a = 1.f, eta_b = bsdf.eta;
+                    const F3 T = lobe == 0 ? bsdf.t0 : bsdf.kt;
+                    const float eta_a = 1.f, eta_b = lobe == 0 ? 1.f : bsdf.eta;
                     const bool entering = wo.z > 0;
                     const float eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
                     const F3 n = (wo.z < 0.f) ? -F3{0, 0, 1} : F3{0, 0, 1};
@@ -719,27 +735,27 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                     if (!(sin2_t >= 1)) {
                         const float cos_t = sqrtf(1 - sin2_t);
                         const F3 wi_l = eta * -wo + (eta * cos_i - cos_t) * n;
-                        F3 ft = bsdf.kt * (1.f - fr_dielectric(wi_l.z, eta_a, eta_b));
+                        F3 ft = T * (1.f - fr_dielectric(wi_l.z, eta_a, eta_b));
                         ft = ft * ((eta_i * eta_i) / (eta_t * eta_t));
                         const F3 f = sdiv(ft, fabsf(wi_l.z));
                         const F3 wi = to_world(bsdf, wi_l);
                         const float ad = absdot(wi, ns);
                         if (!is_black(f) && ad != 0.f) {
-                            me.f_t = f;
-                            me.ad_t = ad;
-                            me.t_o = offset_ray_origin(is.p, is.perr, is.n, wi);
-                            me.t_d = wi;
-                            if (TEX && has_diff) {  // directprogressiveintegrator.cpp:203-233
-                                me.t_has_diff = true;
-                                float e2 = bsdf.eta;
+                            me.f_t[q] = f;
+                            me.ad_t[q] = ad;
+                            me.t_o[q] = offset_ray_origin(is.p, is.perr, is.n, wi);
+                            me.t_d[q] = wi;
+                            if (TEX && has_diff) {  // directprogressiveintegrator.cpp:203-233; `Float eta = bsdf.eta`: BSDF::eta
+                                me.t_has_diff[q] = true;
+                                float e2 = bsdf.path_eta;
                                 const F3 w = -wo_w;
                                 if (dot(wo_w, ns) < 0) e2 = 1.f / e2;
                                 const float mu = e2 * dot(w, ns) - dot(wi, ns);
                                 const float dmudx = (e2 - (e2 * e2 * dot(w, ns)) / dot(wi, ns)) * dDNdx;
                                 const float dmudy = (e2 - (e2 * e2 * dot(w, ns)) / dot(wi, ns)) * dDNdy;
-                                me.t_rd.rxo = is.p + dpdx, me.t_rd.ryo = is.p + dpdy;
-                                me.t_rd.rxd = wi + e2 * dwodx - (mu * dndx + dmudx * ns);
-                                me.t_rd.ryd = wi + e2 * dwody - (mu * dndy + dmudy * ns);
+                                me.t_rd[q].rxo = is.p + dpdx, me.t_rd[q].ryo = is.p + dpdy;
+                                me.t_rd[q].rxd = wi + e2 * dwodx - (mu * dndx + dmudx * ns);
+                                me.t_rd[q].ryd = wi + e2 * dwody - (mu * dndy + dmudy * ns);
                             }
                         }
                     }
@@ -764,19 +780,28 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
                 // a subtree returned into lv[depth]
             }
             // ---- back in lv[depth] with `ret`
-            TreeLevel &me = lv[depth];
+            TreeLevel<NT> &me = lv[depth];
             if (me.stage == 1) {
                 // L += SpecularReflect(...) = f * Li(rd) * AbsDot(wi, ns) / pdf (1), or 0
                 F3 R = F3{0, 0, 0};
                 if (me.ad_r != 0.f) R = sdiv(me.f_r * ret * me.ad_r, 1.f);
                 me.L = me.L + R;
-                // SpecularTransmit: Get2D, then its subtree
+                // SpecularTransmit: Get2D, then its subtree. BSDF::Sample_f picks `comp = min(floor(u[0] * matchingComps),
+                // matchingComps - 1)` (reflection.cpp:733-735) and, the lobe being specular, only divides the pdf by matchingComps
+                const float ut = pcg_float(rng);
                 (void)pcg_float(rng);
-                (void)pcg_float(rng);
+                if (NT > 1 && me.n_t > 1) {
+                    const int c0 = int(floorf(ut * float(me.n_t))), comp = c0 < me.n_t - 1 ? c0 : me.n_t - 1;
+                    me.pdf_t = 1.f / float(me.n_t);
+                    if (comp != 0) {
+                        me.f_t[0] = me.f_t[comp], me.ad_t[0] = me.ad_t[comp], me.t_o[0] = me.t_o[comp], me.t_d[0] = me.t_d[comp];
+                        me.t_rd[0] = me.t_rd[comp], me.t_has_diff[0] = me.t_has_diff[comp];
+                    }
+                }
                 me.stage = 2;
-                if (me.ad_t != 0.f) {
-                    ro = me.t_o, rd = me.t_d;
-                    if (TEX && me.t_has_diff) rdiff = me.t_rd;
+                if (me.ad_t[0] != 0.f) {
+                    ro = me.t_o[0], rd = me.t_d[0];
+                    if (TEX && me.t_has_diff[0]) rdiff = me.t_rd[0];
                     ++depth;
                     descend = true;
                     continue;
@@ -786,7 +811,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
             // stage 2: L += SpecularTransmit(...)
             {
                 F3 T = F3{0, 0, 0};
-                if (me.ad_t != 0.f) T = sdiv(me.f_t * ret * me.ad_t, 1.f);
+                if (me.ad_t[0] != 0.f) T = sdiv(me.f_t[0] * ret * me.ad_t[0], me.pdf_t);
                 me.L = me.L + T;
                 ret = me.L;
                 descend = false;
@@ -812,10 +837,16 @@ __global__ __launch_bounds__(kBlock, 1) void k_direct_tree(DScene S, PassDesc P,
 
 void launch_direct_tree(const DScene &S, const PassDesc &P, const PassBuffers &B, double *film_rgbw, const LaunchCfg &cfg) {
     const dim3 grid(grid_blocks(P.n_paths, cfg.n_cus, 4));
-    if (S.textured_materials || S.n_textures > 0)
-        hipLaunchKernelGGL((k_direct_tree<true>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
+    const bool tex = S.textured_materials || S.n_textures > 0;
+    if (S.has_uber_trans) {
+        if (tex)
+            hipLaunchKernelGGL((k_direct_tree<true, 2>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
+        else
+            hipLaunchKernelGGL((k_direct_tree<false, 2>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
+    } else if (tex)
+        hipLaunchKernelGGL((k_direct_tree<true, 1>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
     else
-        hipLaunchKernelGGL((k_direct_tree<false>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
+        hipLaunchKernelGGL((k_direct_tree<false, 1>), grid, dim3(kBlock), 0, cfg.stream, S, P, B, film_rgbw);
 }
 
 void launch_direct_generate(const DScene &S, const PassDesc &P, const PassBuffers &B, const LaunchCfg &cfg) {

@@ -418,7 +418,7 @@ def test_uber_transmission_bitwise(binding, oracle, tmp_path):
     that is not opaque — grey and coloured opacities — and the Kt lobe, alone and beside the diffuse / glossy / mirror lobes, on
     blobs of the box room at maxdepth 8 (BSDF::eta is 1 with the pass-through, the material's index without: etaScale and the
     roulette see the difference). Film and every counter against the oracle bit for bit, both kernel sets; the oracle's lobes are
-    pinned by tests/test_oracle_pins.py::test_uber_transmission_pins. The IISPT runner and direct pass refuse such scenes."""
+    pinned by tests/test_oracle_pins.py::test_uber_transmission_pins. The IISPT runner's stages and the direct pass likewise."""
     import boxroom
     path = tmp_path / "boxroom_ubertrans.pbrt"
     path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, materials="ubertrans", maxdepth=8))
@@ -432,10 +432,20 @@ def test_uber_transmission_bitwise(binding, oracle, tmp_path):
     plain, _ = gpu.render()
     assert_bitwise(plain, ref, "uber transmission film, uninstrumented kernels")
     assert sum(ost["path_length"][5:]) > 0   # paths do get past bounce 4: the roulette ran
-    with pytest.raises(RuntimeError, match="uber materials with specular transmission"):
-        gpu.render_direct(1)
-    with pytest.raises(RuntimeError, match="uber materials with specular transmission"):
-        gpu.iispt_hemi_points(binding.IisptTask(0, 0, 40, 40, 4, 0, 0))
+    # the IISPT stages on the same room. The direct pass: DirectProgressiveIntegrator::Li recurses through BOTH specular
+    # transmissions of such a BSDF's vertex — SpecularTransmit's u[0] picks one of the two lobes, pdf 1/2 — walked per pixel
+    # (k_direct_tree<.., 2>); the runner's first-intersection search follows whichever specular lobe Sample_f picked
+    direct = gpu.render_direct(3)
+    ref_direct = oracle.iispt_direct(room, 3)
+    assert np.array_equal(direct.view(np.uint64), ref_direct.view(np.uint64))
+    assert (direct[..., :3] > 0).any()
+    task = binding.IisptTask(0, 0, 96, 64, 8, 0, 0)
+    valid, pos, dr = gpu.iispt_hemi_points(task)
+    rv, rp, rd = oracle.iispt_hemi_points(room, task)
+    assert np.array_equal(valid, rv) and np.array_equal(pos.view(np.uint32), rp.view(np.uint32)) and np.array_equal(dr.view(np.uint32), rd.view(np.uint32))
+    nn = np.random.default_rng(4).uniform(0.0, 3.0, valid.shape + (32, 32, 3)).astype(np.float32)
+    out = gpu.iispt_gather(task, valid, pos, dr, nn)
+    assert np.array_equal(out.view(np.uint32), oracle.iispt_gather(room, task, valid, pos, dr, nn).view(np.uint32)) and (out[..., 3] == 0.5).sum() > 500
 
 
 def test_rough_glass_bitwise(binding, oracle, tmp_path):

@@ -1097,6 +1097,58 @@ WorldEnd
     assert abs(m - 1.0) < 3e-3 and lo > 0.9 and hi < 1.1, (m, lo, hi)
 
 
+def test_uber_transmission_direct_pass_pins(binding, oracle, tmp_path):
+    """DirectProgressiveIntegrator::Li through UberMaterial's SpecularTransmission lobes (SpecularTransmit, directprogressive
+    integrator.cpp:190-237 over BSDF::Sample_f, reflection.cpp:719-784): with TWO lobes of the requested type u[0] picks one and
+    the pdf is 1/2. No test of the reference covers it; inside the analytic furnace the direct integrator sees the wall at
+    Le + one bounce of direct light (0.5 + 0.25, less the ball's shadow), and
+      (a) Kt = 1 at index 1 (one lobe, pdf 1): the ball is invisible — the image equals the empty furnace's;
+      (b) opacity 0.4 AND Kt = 1 at index 1, no other lobe: pass-through 0.6 or Kt lobe 0.4, each with probability 1/2 and weight
+          x 2: invisible in expectation (a wrong pdf, a lobe picked twice or a dropped lobe changes the ball's pixels by 20 % or more);
+      (c) opacity 0.4 over a black surface: 0.6 of the wall behind."""
+    head = '''Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [16] "integer yresolution" [16]
+Sampler "halton" "integer pixelsamples" [1]
+WorldBegin
+AttributeBegin
+  ReverseOrientation
+  Material "matte" "color Kd" [.5 .5 .5]
+  AreaLightSource "diffuse" "color L" [.5 .5 .5]
+  Shape "sphere" "float radius" [1]
+AttributeEnd
+AttributeBegin
+  %s
+  Translate 0 0 0.55
+  Shape "sphere" "float radius" [0.25]
+AttributeEnd
+WorldEnd
+'''
+
+    def centre_mean(material, passes=24):
+        path = tmp_path / "furnace_ball_direct.pbrt"
+        path.write_text(head % material)
+        scene = binding.HostScene(path=str(path))
+        film = oracle.iispt_direct(scene, passes, trig_mode=ob.TRIG_LIBM)
+        assert (film[..., 3] == passes).all()
+        rgb = film[..., :3] / film[..., 3:4]
+        return float(rgb[5:11, 5:11].mean()), float(rgb.mean())   # the ball covers the centre of the image
+
+    # (shadow rays stop at a transparent surface all the same — Scene::IntersectP is binary — so the ball's presence darkens the wall's
+    # direct light; the baseline is the ball with opacity 0, which tests/test_oracle_pins.py::test_uber_transmission_pins shows is
+    # not there for radiance. A matte ball in the same place casts the same shadows: equal image away from the centre.)
+    wall, wall_all = centre_mean('Material "uber" "color Kd" [.3 .3 .3] "color opacity" [0 0 0]')
+    _, matte_all = centre_mean('Material "matte" "color Kd" [0 0 0]')
+    assert 0.6 < wall < 0.75 and 0.6 < wall_all < 0.75, (wall, wall_all)
+    assert matte_all < wall_all - 0.02   # the black ball shows in the mean; the transparent one only through its shadows
+    one, _ = centre_mean('Material "uber" "color Kd" [0 0 0] "color Ks" [0 0 0] "color Kt" [1 1 1] "float index" [1]')
+    assert abs(one - wall) < 0.02, (one, wall)
+    two, _ = centre_mean('Material "uber" "color Kd" [0 0 0] "color Ks" [0 0 0] "color Kt" [1 1 1] "float index" [1] "color opacity" [.4 .4 .4]')
+    assert abs(two - wall) < 0.03, (two, wall)
+    # the ball is crossed twice: (1 - 0.4)^2 of the wall behind it
+    dim, _ = centre_mean('Material "uber" "color Kd" [0 0 0] "color Ks" [0 0 0] "color opacity" [.4 .4 .4]')
+    assert abs(dim - 0.36 * wall) < 0.02, (dim, wall)
+
+
 def test_rough_glass_pins(binding, oracle, tmp_path):
     """GlassMaterial with uroughness = vroughness != 0 (glass.cpp:66-90: MicrofacetReflection + MicrofacetTransmission; refused until
     round 6) has no test in the reference. Beside the sampling and pdf / energy checks above, the restatement is tied to the smooth

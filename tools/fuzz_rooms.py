@@ -1,6 +1,8 @@
 """One-off robustness sweep: differently seeded box rooms (tests/boxroom.py) under every light set-up and material mix,
 odd resolutions, sample counts and depths — the uninstrumented and the instrumented film against the oracle, counters too.
-usage: python tools/fuzz_rooms.py [first_seed=100] [n=24]"""
+With `iispt` as a third argument the IISPT stages run on every room as well: two direct passes, the runner's hemi points and its
+gather over random hemispheres, each against the oracle bit for bit.
+usage: python tools/fuzz_rooms.py [first_seed=100] [n=24] [iispt]"""
 import os
 import sys
 import tempfile
@@ -18,6 +20,7 @@ b = ge._load_binding()
 o = oracle_binding.Oracle()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+iispt = len(sys.argv) > 3 and sys.argv[3] == "iispt"
 lights = ["area", "quad", "multi", "spot", "point", "envmap", "sky"]  # (the last two: infinite lights — k_mis ends at the first hit)
 mats = ["plain", "all", "mixed", "ubertrans", "roughglass"]   # (round 6: uber with opacity < 1 and Kt; rough glass)
 bad = 0
@@ -49,8 +52,24 @@ with tempfile.TemporaryDirectory() as td:
         plain, pst = gpu.render(spp_per_pass=int(rng.integers(0, 3)))
         ok = np.array_equal(film.view(np.uint32), ref.view(np.uint32)) and np.array_equal(plain.view(np.uint32), ref.view(np.uint32))
         ok = ok and st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"] and st["nodes_closest"] == ost["nodes_closest"]
+        stages = ""
+        if iispt:
+            try:
+                direct = gpu.render_direct(2)
+                ok_d = np.array_equal(direct.view(np.uint64), o.iispt_direct(scene, 2).view(np.uint64))
+                task = b.IisptTask(0, 0, kw["xres"], kw["yres"], int(rng.integers(3, 12)), 0, 0)
+                valid, pos, dr = gpu.iispt_hemi_points(task)
+                rv, rp, rd = o.iispt_hemi_points(scene, task)
+                ok_h = np.array_equal(valid, rv) and np.array_equal(pos.view(np.uint32), rp.view(np.uint32)) and np.array_equal(dr.view(np.uint32), rd.view(np.uint32))
+                nn = rng.uniform(0.0, 3.0, valid.shape + (32, 32, 3)).astype(np.float32)
+                out = gpu.iispt_gather(task, valid, pos, dr, nn)
+                ok_g = np.array_equal(out.view(np.uint32), o.iispt_gather(scene, task, valid, pos, dr, nn).view(np.uint32))
+                stages = f" iispt direct/hemi/gather {'OK' if ok_d else 'MISMATCH'}/{'OK' if ok_h else 'MISMATCH'}/{'OK' if ok_g else 'MISMATCH'}"
+                ok = ok and ok_d and ok_h and ok_g
+            except RuntimeError as e:
+                stages = " iispt refused: " + str(e)[:80]
         print("seed", seed, kw["light"], kw["materials"], f'{kw["xres"]}x{kw["yres"]}x{kw["spp"]} depth {kw["maxdepth"]}', "OK" if ok else "MISMATCH",
-              "traced", pst["ext_rays_traced"], "of", st["ext_rays"])
+              "traced", pst["ext_rays_traced"], "of", st["ext_rays"], stages)
         bad += 0 if ok else 1
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
