@@ -66,16 +66,16 @@ enum { IILE_MAT_MATTE = 0, IILE_MAT_PLASTIC = 1, IILE_MAT_UBER = 2, IILE_MAT_MIR
 
 /* MatteMaterial / PlasticMaterial / UberMaterial / MirrorMaterial / GlassMaterial with constant
  * textures (src/materials/matte.cpp:45-62, plastic.cpp:45-70, uber.cpp:45-100, mirror.cpp:44-55,
- * glass.cpp:45-92). Uber: uroughness == vroughness; its two SpecularTransmission lobes (the pass-through of opacity < 1 and Kt,
+ * glass.cpp:45-92). Uber: its two SpecularTransmission lobes (the pass-through of opacity < 1 and Kt,
  * uber.cpp:53-61, 94-99) are rendered by every entry point (the path and probe passes, the IISPT runner's stages, the direct pass).
- * Glass: smooth (uroughness = vroughness = 0: one FresnelSpecular lobe, as the path integrator gets it) or rough and isotropic
- * (roughness = uroughness = vroughness != 0: MicrofacetReflection + MicrofacetTransmission, glass.cpp:66-90). */
+ * Glass: smooth (uroughness = vroughness = 0: one FresnelSpecular lobe, as the path integrator gets it) or rough
+ * (uroughness or vroughness != 0: MicrofacetReflection + MicrofacetTransmission, glass.cpp:66-90). */
 typedef struct iile_material {
     int32_t type;
     float kd[3];     /* matte, plastic, uber; 0 for mirror */
     float ks[3];     /* plastic, uber: glossy (microfacet) reflectance */
     float sigma;     /* matte: Clamp(sigma, 0, 90) degrees; 0 = Lambertian, else Oren-Nayar (reflection.h:410-427) */
-    float roughness; /* plastic, uber: as given; glass: uroughness (= vroughness), 0 = smooth */
+    float roughness; /* plastic, uber: as given (uber: "uroughness" if given); glass: uroughness */
     float alpha;     /* plastic, uber: RoughnessToAlpha(roughness) if remap else roughness
                         (src/core/microfacet.h:123-128) */
     int32_t remap_roughness;
@@ -98,6 +98,9 @@ typedef struct iile_material {
     /* uber: "opacity" (constant; {1, 1, 1} for every other material): 1 - opacity is the pass-through lobe, every other
      * coefficient is multiplied by it (uber.cpp:53-99) */
     float opacity[3];
+    /* uber, glass: "vroughness" and its alpha where it differs from "uroughness" (roughness / alpha above): an anisotropic
+     * TrowbridgeReitzDistribution(alphax, alphay) (uber.cpp:73-86, glass.cpp:52-73); equal to roughness / alpha otherwise */
+    float roughness_v, alpha_v;
 } iile_material;
 
 /* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (src/textures/imagemap.h:78-112,

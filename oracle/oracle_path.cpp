@@ -1541,7 +1541,7 @@ struct Oracle {
         bool oren_nayar = false;  // the diffuse lobe is OrenNayar(kd, sigma) instead of LambertianReflection
         float on_a = 1, on_b = 0;
         Rgb kd, ks, kr;
-        float alpha = 0;
+        float alpha = 0, alpha_y = 0;   // TrowbridgeReitzDistribution(alphax, alphay)
         float micro_eta_i = 1.5f, micro_eta_t = 1.f;  // FresnelDielectric of the microfacet lobe
         bool spec_noop = true;                        // FresnelNoOp (mirror) or FresnelDielectric(1, spec_eta)
         float spec_eta = 1.f;
@@ -1656,6 +1656,8 @@ struct Oracle {
                     }
                     b.alpha = rough;
                 }
+                // uber: roughv = vroughness or roughu (uber.cpp:73-86); plastic: one roughness (plastic.cpp:60-64)
+                b.alpha_y = (m.type == IILE_MAT_UBER && m.rough_tex < 0) ? m.alpha_v : b.alpha;
                 if (m.type == IILE_MAT_UBER) {  // FresnelDielectric(1.f, e), uber.cpp:70
                     b.micro_eta_i = 1.f;
                     b.micro_eta_t = m.eta;
@@ -1684,13 +1686,14 @@ struct Oracle {
                 }
             }
         }
-        if (m.type == IILE_MAT_GLASS && m.roughness != 0) {  // glass.cpp:66-90: a rough dielectric (isotropic: uroughness == vroughness)
+        if (m.type == IILE_MAT_GLASS && (m.roughness != 0 || m.roughness_v != 0)) {  // glass.cpp:63-90: a rough dielectric
             b.eta = m.eta;
             Rgb R = param(m.kr, m.kr_tex), T = param(m.kt, m.kt_tex);
             if (!R.is_black()) {  // MicrofacetReflection(R, distrib, FresnelDielectric(1, eta))
                 b.has_micro = true;
                 b.ks = R;
                 b.alpha = m.alpha;
+                b.alpha_y = m.alpha_v;
                 b.micro_eta_i = 1.f;
                 b.micro_eta_t = m.eta;
                 ++b.n_lobes;
@@ -1699,6 +1702,7 @@ struct Oracle {
                 b.has_mtrans = true;
                 b.kt = T;
                 b.alpha = m.alpha;
+                b.alpha_y = m.alpha_v;
                 b.mt_eta = m.eta;
                 ++b.n_lobes;
             }
@@ -1765,10 +1769,10 @@ struct Oracle {
         float a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
         return (-1 + std::sqrt(1.f + a2t2)) / 2;
     }
-    static float tr_g1(V3 w, float a) { return 1 / (1 + tr_lambda(w, a, a)); }
-    static float tr_g(V3 wo, V3 wi, float a) { return 1 / (1 + tr_lambda(wo, a, a) + tr_lambda(wi, a, a)); }
+    static float tr_g1(V3 w, float ax, float ay) { return 1 / (1 + tr_lambda(w, ax, ay)); }
+    static float tr_g(V3 wo, V3 wi, float ax, float ay) { return 1 / (1 + tr_lambda(wo, ax, ay) + tr_lambda(wi, ax, ay)); }
     // MicrofacetDistribution::Pdf with sampleVisibleArea, microfacet.cpp:338-344
-    static float tr_pdf(V3 wo, V3 wh, float a) { return tr_d(wh, a, a) * tr_g1(wo, a) * absdot(wo, wh) / std::abs(wo.z); }
+    static float tr_pdf(V3 wo, V3 wh, float ax, float ay) { return tr_d(wh, ax, ay) * tr_g1(wo, ax, ay) * absdot(wo, wh) / std::abs(wo.z); }
     // TrowbridgeReitzSample11, microfacet.cpp:238-283 (unqualified sqrt/cos/sin:
     // double overloads, see DESIGN.md "Double precision islands")
     void tr_sample11(float cos_theta, float U1, float U2, float *slope_x, float *slope_y) const {
@@ -1804,18 +1808,18 @@ struct Oracle {
         *slope_y = Sg * z * std::sqrt(1.f + *slope_x * *slope_x);
     }
     // TrowbridgeReitzSample + Sample_wh (visible area), microfacet.cpp:285-336
-    V3 tr_sample_wh(V3 wo, const float *u, float a) const {
+    V3 tr_sample_wh(V3 wo, const float *u, float ax, float ay) const {
         bool flip = wo.z < 0;
         V3 wi = flip ? -wo : wo;
-        V3 ws = normalize(V3(a * wi.x, a * wi.y, wi.z));
+        V3 ws = normalize(V3(ax * wi.x, ay * wi.y, wi.z));   // 1. stretch wi
         float sx, sy;
-        tr_sample11(ws.z, u[0], u[1], &sx, &sy);
-        float tmp = cos_phi(ws) * sx - sin_phi(ws) * sy;
+        tr_sample11(ws.z, u[0], u[1], &sx, &sy);             // 2. simulate P22_{wi}(x_slope, y_slope, 1, 1)
+        float tmp = cos_phi(ws) * sx - sin_phi(ws) * sy;     // 3. rotate
         sy = sin_phi(ws) * sx + cos_phi(ws) * sy;
         sx = tmp;
-        sx = a * sx;
-        sy = a * sy;
-        V3 wh = normalize(V3(-sx, -sy, 1.));
+        sx = ax * sx;                                        // 4. unstretch
+        sy = ay * sy;
+        V3 wh = normalize(V3(-sx, -sy, 1.));                 // 5. compute normal
         if (flip) wh = -wh;
         return wh;
     }
@@ -1827,12 +1831,12 @@ struct Oracle {
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Rgb(0.);
         wh = normalize(wh);
         Rgb F(fr_dielectric(dot(wi, wh), b.micro_eta_i, b.micro_eta_t));
-        return b.ks * tr_d(wh, b.alpha, b.alpha) * tr_g(wo, wi, b.alpha) * F / (4 * cos_i * cos_o);
+        return b.ks * tr_d(wh, b.alpha, b.alpha_y) * tr_g(wo, wi, b.alpha, b.alpha_y) * F / (4 * cos_i * cos_o);
     }
     static float micro_pdf(const Bsdf &b, V3 wo, V3 wi) {  // reflection.cpp:419-423
         if (!same_hemisphere(wo, wi)) return 0;
         V3 wh = normalize(wo + wi);
-        return tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
+        return tr_pdf(wo, wh, b.alpha, b.alpha_y) / (4 * dot(wo, wh));
     }
     // Refract, reflection.h:96-108
     static bool refract(V3 wi, V3 n, float eta, V3 *wt) {
@@ -1858,7 +1862,7 @@ struct Oracle {
         float factor = 1 / eta;
         Rgb one_minus_f(1.f - F);
         return one_minus_f * b.kt *
-               std::abs(tr_d(wh, b.alpha, b.alpha) * tr_g(wo, wi, b.alpha) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+               std::abs(tr_d(wh, b.alpha, b.alpha_y) * tr_g(wo, wi, b.alpha, b.alpha_y) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
                         (cos_i * cos_o * sqrt_denom * sqrt_denom));
     }
     // MicrofacetTransmission::Pdf, reflection.cpp:435-447
@@ -1869,7 +1873,7 @@ struct Oracle {
         V3 wh = normalize(wo + wi * eta);
         float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
         float dwh_dwi = std::abs((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
-        return tr_pdf(wo, wh, b.alpha) * dwh_dwi;
+        return tr_pdf(wo, wh, b.alpha, b.alpha_y) * dwh_dwi;
     }
     // LambertianReflection::f (reflection.cpp:178-180) or OrenNayar::f (reflection.cpp:197-219)
     static Rgb diffuse_f(const Bsdf &b, V3 wo, V3 wi) {
@@ -1962,16 +1966,16 @@ struct Oracle {
             f = diffuse_f(b, wo, wi);
         } else if (pick == 1) {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
             // `if (wo.z == 0) return 0.` is unreachable here
-            V3 wh = tr_sample_wh(wo, ur, b.alpha);
+            V3 wh = tr_sample_wh(wo, ur, b.alpha, b.alpha_y);
             wi = -wo + 2 * dot(wo, wh) * wh;  // Reflect(), reflection.h:86-88
             if (!same_hemisphere(wo, wi))
                 f = Rgb(0.f);
             else {
-                *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
+                *pdf = tr_pdf(wo, wh, b.alpha, b.alpha_y) / (4 * dot(wo, wh));
                 f = micro_f(b, wo, wi);
             }
         } else if (pick == 5) {  // MicrofacetTransmission::Sample_f, reflection.cpp:425-433
-            V3 wh = tr_sample_wh(wo, ur, b.alpha);
+            V3 wh = tr_sample_wh(wo, ur, b.alpha, b.alpha_y);
             const float eta_a = 1.f, eta_b = b.mt_eta;
             float eta = wo.z > 0 ? (eta_a / eta_b) : (eta_b / eta_a);
             if (!refract(wo, wh, eta, &wi)) return Rgb(0);  // `return 0`, pdf stays 0

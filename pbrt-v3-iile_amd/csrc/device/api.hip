@@ -823,6 +823,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 mats[i].ks[c] = m.ks[c];
             }
             mats[i].alpha = m.alpha;
+            mats[i].alpha_y = (m.type == IILE_MAT_UBER || m.type == IILE_MAT_GLASS) ? m.alpha_v : m.alpha;
             for (int c = 0; c < 3; ++c) mats[i].kr[c] = m.kr[c];
             for (int c = 0; c < 3; ++c) mats[i].kt[c] = m.kt[c];
             const bool oren_nayar = m.type == IILE_MAT_MATTE && m.sigma != 0;

@@ -1280,6 +1280,7 @@ struct Bsdf {
     F3 ns, ng, ss, ts;
     F3 kd, ks, kr, kt;
     float alpha, eta;
+    float alpha_y;  // TrowbridgeReitzDistribution(alphax = alpha, alphay): uber's / glass's "vroughness"; the same value as alpha otherwise
     // UberMaterial's SpecularTransmission lobes (uber.cpp:53-61, 94-99): the pass-through of a surface that is not opaque —
     // SpecularTransmission(t0 = 1 - opacity, 1, 1), the FIRST lobe — and SpecularTransmission(kt = opacity Kt, 1, eta), the LAST;
     // path_eta = BSDF::eta (1 with the pass-through, else the material's: path.cpp:151-157 reads it)
@@ -1511,6 +1512,7 @@ DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect
             rough = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
         }
         r.alpha = rough;
+        r.alpha_y = rough;   // (a roughness image is accepted without uroughness / vroughness only)
     }
     if (m.kt_tex >= 0) {
         const F3 c = tex_evaluate(S, m.kt_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
@@ -1555,6 +1557,7 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
     b.ks = F3{0, 0, 0};
     b.has_micro = false;
     b.alpha = m_ks.w;
+    b.alpha_y = (EXT && (m_type == kMatUber || m_type == kMatGlass)) ? m.alpha_y : b.alpha;   // (uber with a roughness image: textured_material sets both)
     b.oren_nayar = EXT && m_type == kMatMatte && m.on_b != 0.f;  // matte.cpp:56-61 (B == 0 iff sigma == 0)
     b.on_a = m.on_a;
     b.on_b = m.on_b;
@@ -1582,7 +1585,7 @@ DEV Bsdf make_bsdf(const DMaterial &m, const Isect &is) {
         if (b.has_t1) ++b.n_lobes;
     }
     b.has_mtrans = false;
-    if (EXT && m_type == kMatGlass && m_ks.w != 0.f) {  // glass.cpp:66-90: a rough dielectric (alpha != 0)
+    if (EXT && m_type == kMatGlass && (m_ks.w != 0.f || m.alpha_y != 0.f)) {  // glass.cpp:63-90: a rough dielectric (an alpha != 0)
         b.ks = F3{clampf(m.kr[0], 0, IILE_INF), clampf(m.kr[1], 0, IILE_INF), clampf(m.kr[2], 0, IILE_INF)};   // R: MicrofacetReflection
         b.kt = F3{clampf(m.kt[0], 0, IILE_INF), clampf(m.kt[1], 0, IILE_INF), clampf(m.kt[2], 0, IILE_INF)};   // T: MicrofacetTransmission
         b.has_micro = !is_black(b.ks);
@@ -1633,23 +1636,25 @@ DEV float fr_dielectric(float cos_i, float eta_i, float eta_t) {
     return (r_parl * r_parl + r_perp * r_perp) / 2;
 }
 // TrowbridgeReitzDistribution::D / Lambda, microfacet.cpp:155-163, 176-184
-DEV float tr_d(F3 wh, float a) {
+// (ax, ay: alphax, alphay. Where the scene has no anisotropic material — the plain build always — the two are one value and the
+//  expressions below compile to what they were with one alpha)
+DEV float tr_d(F3 wh, float ax, float ay) {
     float t2 = tan2_theta(wh);
     if (is_inf(t2)) return 0.f;
     const float cos4 = cos2_theta(wh) * cos2_theta(wh);
-    float e = (cos2_phi(wh) / (a * a) + sin2_phi(wh) / (a * a)) * t2;
-    return 1 / (kPi * a * a * cos4 * (1 + e) * (1 + e));
+    float e = (cos2_phi(wh) / (ax * ax) + sin2_phi(wh) / (ay * ay)) * t2;
+    return 1 / (kPi * ax * ay * cos4 * (1 + e) * (1 + e));
 }
-DEV float tr_lambda(F3 w, float a) {
+DEV float tr_lambda(F3 w, float ax, float ay) {
     float abs_tan = fabsf(tan_theta(w));
     if (is_inf(abs_tan)) return 0.f;
-    float alpha = sqrtf(cos2_phi(w) * a * a + sin2_phi(w) * a * a);
+    float alpha = sqrtf(cos2_phi(w) * ax * ax + sin2_phi(w) * ay * ay);
     float a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
     return (-1 + sqrtf(1.f + a2t2)) / 2;
 }
-DEV float tr_g1(F3 w, float a) { return 1 / (1 + tr_lambda(w, a)); }
-DEV float tr_g(F3 wo, F3 wi, float a) { return 1 / (1 + tr_lambda(wo, a) + tr_lambda(wi, a)); }
-DEV float tr_pdf(F3 wo, F3 wh, float a) { return tr_d(wh, a) * tr_g1(wo, a) * absdot(wo, wh) / fabsf(wo.z); }
+DEV float tr_g1(F3 w, float ax, float ay) { return 1 / (1 + tr_lambda(w, ax, ay)); }
+DEV float tr_g(F3 wo, F3 wi, float ax, float ay) { return 1 / (1 + tr_lambda(wo, ax, ay) + tr_lambda(wi, ax, ay)); }
+DEV float tr_pdf(F3 wo, F3 wh, float ax, float ay) { return tr_d(wh, ax, ay) * tr_g1(wo, ax, ay) * absdot(wo, wh) / fabsf(wo.z); }
 // TrowbridgeReitzSample11, microfacet.cpp:238-283. The normal-incidence branch
 // evaluates sqrt/cos/sin through the C (double) overloads in the reference.
 DEV void tr_sample11(float cos_theta, float U1, float U2, float *slope_x, float *slope_y) {
@@ -1687,17 +1692,17 @@ DEV void tr_sample11(float cos_theta, float U1, float U2, float *slope_x, float 
     *slope_y = Sg * z * sqrtf(1.f + *slope_x * *slope_x);
 }
 // TrowbridgeReitzSample + Sample_wh (visible-area), microfacet.cpp:285-336
-DEV F3 tr_sample_wh(F3 wo, float u0, float u1, float a) {
+DEV F3 tr_sample_wh(F3 wo, float u0, float u1, float ax, float ay) {
     bool flip = wo.z < 0;
     F3 wi = flip ? -wo : wo;
-    F3 ws = normalize(F3{a * wi.x, a * wi.y, wi.z});
+    F3 ws = normalize(F3{ax * wi.x, ay * wi.y, wi.z});
     float sx, sy;
     tr_sample11(ws.z, u0, u1, &sx, &sy);
     float tmp = cos_phi(ws) * sx - sin_phi(ws) * sy;
     sy = sin_phi(ws) * sx + cos_phi(ws) * sy;
     sx = tmp;
-    sx = a * sx;
-    sy = a * sy;
+    sx = ax * sx;
+    sy = ay * sy;
     F3 wh = normalize(F3{-sx, -sy, 1.f});
     if (flip) wh = -wh;
     return wh;
@@ -1711,12 +1716,12 @@ DEV F3 micro_f(const Bsdf &b, F3 wo, F3 wi) {
     wh = normalize(wh);
     float Fr = (b.mtype == kMatUber || b.mtype == kMatGlass) ? fr_dielectric(dot(wi, wh), 1.f, b.eta) : fr_dielectric(dot(wi, wh), 1.5f, 1.f);
     F3 F = F3{Fr, Fr, Fr};
-    return sdiv(b.ks * tr_d(wh, b.alpha) * tr_g(wo, wi, b.alpha) * F, 4 * cos_i * cos_o);
+    return sdiv(b.ks * tr_d(wh, b.alpha, b.alpha_y) * tr_g(wo, wi, b.alpha, b.alpha_y) * F, 4 * cos_i * cos_o);
 }
 DEV float micro_pdf(const Bsdf &b, F3 wo, F3 wi) {
     if (!same_hemisphere(wo, wi)) return 0;
     F3 wh = normalize(wo + wi);
-    return tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
+    return tr_pdf(wo, wh, b.alpha, b.alpha_y) / (4 * dot(wo, wh));
 }
 // LambertianReflection::f (reflection.cpp:178-180) or OrenNayar::f (reflection.cpp:197-219)
 DEV F3 diffuse_f(const Bsdf &b, F3 wo, F3 wi) {
@@ -1764,7 +1769,7 @@ DEV F3 mtrans_f(const Bsdf &b, F3 wo, F3 wi) {
     const float factor = 1 / eta;
     const float omf = 1.f - F;
     return F3{omf, omf, omf} * b.kt *
-           fabsf(tr_d(wh, b.alpha) * tr_g(wo, wi, b.alpha) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
+           fabsf(tr_d(wh, b.alpha, b.alpha_y) * tr_g(wo, wi, b.alpha, b.alpha_y) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
                  (cos_i * cos_o * sqrt_denom * sqrt_denom));
 }
 // MicrofacetTransmission::Pdf, reflection.cpp:435-447
@@ -1775,7 +1780,7 @@ DEV float mtrans_pdf(const Bsdf &b, F3 wo, F3 wi) {
     const F3 wh = normalize(wo + wi * eta);
     const float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
     const float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
-    return tr_pdf(wo, wh, b.alpha) * dwh_dwi;
+    return tr_pdf(wo, wh, b.alpha, b.alpha_y) * dwh_dwi;
 }
 DEV F3 lobes_f(const Bsdf &b, F3 wo, F3 wi) {
     F3 f = F3{0, 0, 0};
@@ -1845,16 +1850,16 @@ DEV F3 bsdf_sample_f(const Bsdf &b, F3 woW, F3 *wiW, float u0, float u1, float *
         *pdf = lambert_pdf(wo, wi);
         f = diffuse_f(b, wo, wi);
     } else if (pick == 1) {  // MicrofacetReflection::Sample_f, reflection.cpp:405-417
-        F3 wh = tr_sample_wh(wo, ur0, u1, b.alpha);
+        F3 wh = tr_sample_wh(wo, ur0, u1, b.alpha, b.alpha_y);
         wi = -wo + 2 * dot(wo, wh) * wh;
         if (!same_hemisphere(wo, wi))
             f = F3{0, 0, 0};
         else {
-            *pdf = tr_pdf(wo, wh, b.alpha) / (4 * dot(wo, wh));
+            *pdf = tr_pdf(wo, wh, b.alpha, b.alpha_y) / (4 * dot(wo, wh));
             f = micro_f(b, wo, wi);
         }
     } else if (pick == 5) {  // MicrofacetTransmission::Sample_f, reflection.cpp:425-433
-        const F3 wh = tr_sample_wh(wo, ur0, u1, b.alpha);
+        const F3 wh = tr_sample_wh(wo, ur0, u1, b.alpha, b.alpha_y);
         const float eta_a = 1.f, eta_b = b.eta;
         const float eta = wo.z > 0 ? (eta_a / eta_b) : (eta_b / eta_a);
         if (!refract_dir(wo, wh, eta, &wi)) return F3{0, 0, 0};  // `return 0`, pdf stays 0

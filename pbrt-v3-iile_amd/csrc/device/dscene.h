@@ -41,6 +41,7 @@ struct alignas(16) DMaterial {
     int sigma_tex;                       // float image texture for matte's "sigma" (Oren-Nayar A, B per hit), or -1
     int rough_tex, remap_roughness;      // float image texture for "roughness" (-1: the constant alpha), RoughnessToAlpha or not
     float opacity[3];                    // uber: "opacity" ({1, 1, 1} otherwise)
+    float alpha_y;                       // uber, glass: the distribution's alpha along v ("vroughness"); = alpha otherwise
 };
 // ImageTexture + MIPMap (iile_texture): level l holds w x h float4 texels (rgb, w unused) at
 // texels[offset[l] + t * w + s], row 0 = bottom scanline

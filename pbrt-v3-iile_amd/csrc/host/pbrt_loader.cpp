@@ -749,6 +749,12 @@ class Loader {
         }
         return true;
     }
+    // TrowbridgeReitzDistribution::RoughnessToAlpha, microfacet.h:123-128
+    static float roughness_to_alpha(float roughness) {
+        roughness = std::max(roughness, 1e-3f);
+        const float x = std::log(roughness);
+        return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+    }
     int make_material(const std::string &name, const ParamSet &ps_in) {
         ParamSet ps;
         std::map<std::string, int> image_of;
@@ -790,24 +796,18 @@ class Loader {
                 ps.rgb("Kt", kt);
                 ps.rgb("opacity", op);
                 for (int i = 0; i < 3; ++i) m.kr[i] = kr[i], m.kt[i] = kt[i], m.opacity[i] = op[i];
+                // uber.cpp:73-86: roughu = uroughness or roughness, roughv = vroughness or roughu
                 const float ur = ps.one_float("uroughness", m.roughness), vr = ps.one_float("vroughness", ur);
-                if (ur != vr) {
-                    fail("uber: anisotropic roughness is not supported");
-                    return -1;
-                }
                 m.roughness = ur;
+                m.roughness_v = vr;
                 m.eta = ps.find("eta") ? ps.one_float("eta", 1.5f) : ps.one_float("index", 1.5f);
             }
+            if (!uber) m.roughness_v = m.roughness;
             m.remap_roughness = ps.one_bool("remaproughness", true) ? 1 : 0;
-            if (m.remap_roughness) {
-                // The reference re-evaluates this per hit (plastic.cpp:61-63, uber.cpp:79-82);
-                // it is a per-material constant, so it is evaluated once here.
-                float r = std::max(m.roughness, 1e-3f);
-                float x = std::log(r);
-                m.alpha = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x +
-                          0.000640711f * x * x * x * x;
-            } else
-                m.alpha = m.roughness;
+            // The reference re-evaluates this per hit (plastic.cpp:61-63, uber.cpp:79-84); it is a per-material constant, so it is
+            // evaluated once here.
+            m.alpha = m.remap_roughness ? roughness_to_alpha(m.roughness) : m.roughness;
+            m.alpha_v = m.remap_roughness ? roughness_to_alpha(m.roughness_v) : m.roughness_v;
         } else if (name == "glass") {  // CreateGlassMaterial, glass.cpp:94-113
             m.type = IILE_MAT_GLASS;
             float kr[3] = {1, 1, 1}, kt[3] = {1, 1, 1};
@@ -819,21 +819,14 @@ class Loader {
             }
             m.eta = ps.find("eta") ? ps.one_float("eta", 1.5f) : ps.one_float("index", 1.5f);
             // glass.cpp:52-73: urough == vrough == 0 is the smooth dielectric; otherwise MicrofacetReflection + MicrofacetTransmission over
-            // one TrowbridgeReitzDistribution(RoughnessToAlpha(urough), ...(vrough)) — isotropic ones here
+            // one TrowbridgeReitzDistribution(RoughnessToAlpha(urough), ...(vrough))
             const float ur = ps.one_float("uroughness", 0.f), vr = ps.one_float("vroughness", 0.f);
-            if (ur != vr) {
-                fail("glass: anisotropic roughness (uroughness != vroughness) is not supported");
-                return -1;
-            }
             m.roughness = ur;
+            m.roughness_v = vr;
             m.remap_roughness = ps.one_bool("remaproughness", true) ? 1 : 0;
-            if (ur != 0.f) {
-                if (m.remap_roughness) {  // TrowbridgeReitzDistribution::RoughnessToAlpha, microfacet.h:123-128
-                    float r = std::max(m.roughness, 1e-3f);
-                    float x = std::log(r);
-                    m.alpha = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
-                } else
-                    m.alpha = m.roughness;
+            if (ur != 0.f || vr != 0.f) {   // `bool isSpecular = urough == 0 && vrough == 0`, glass.cpp:63
+                m.alpha = m.remap_roughness ? roughness_to_alpha(ur) : ur;
+                m.alpha_v = m.remap_roughness ? roughness_to_alpha(vr) : vr;
             }
         } else if (name == "mirror") {  // CreateMirrorMaterial, mirror.cpp:57-63
             m.type = IILE_MAT_MIRROR;
@@ -865,7 +858,7 @@ class Loader {
         if (const Param *rp = ps.find("roughness"))
             if (rp->type == "roughimage") {
                 if ((m.type != IILE_MAT_PLASTIC && m.type != IILE_MAT_UBER) || ps.find("uroughness") || ps.find("vroughness")) {
-                    fail("roughness: a float \"imagemap\" texture is supported on plastic and isotropic uber only");
+                    fail("roughness: a float \"imagemap\" texture is supported on plastic and on uber without uroughness / vroughness only");
                     return -1;
                 }
                 m.rough_tex = image("roughness");

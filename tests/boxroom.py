@@ -231,6 +231,14 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
             rough = (.05, .2, .5)[b % 3] if b % 2 else rng.uniform(.02, .6)
             mat = 'Material "glass" "color Kr" [%g %g %g] "color Kt" [%g %g %g] "float uroughness" [%g] "float vroughness" [%g] "float index" [%g]%s' % (
                 *((1, 1, 1) if b % 4 else (0, 0, 0)), *rng.uniform(.7, 1, 3), rough, rough, rng.uniform(1.3, 1.7), ' "bool remaproughness" ["false"]' if b % 5 == 0 else "")
+        elif materials == "aniso" and b % 3 == 0:  # anisotropic Trowbridge-Reitz (uroughness != vroughness) on rough glass, glass.cpp:52-73 ...
+            ur, vr = ((0., .3), (.4, .05), (.08, .5))[(b // 3) % 3] if b % 2 else tuple(rng.uniform(.02, .6, 2))
+            mat = 'Material "glass" "color Kr" [%g %g %g] "color Kt" [%g %g %g] "float uroughness" [%g] "float vroughness" [%g] "float index" [%g]%s' % (
+                *((1, 1, 1) if b % 4 else (0, 0, 0)), *rng.uniform(.7, 1, 3), ur, vr, rng.uniform(1.3, 1.7), ' "bool remaproughness" ["false"]' if b % 5 == 0 and ur > 0 else "")
+        elif materials == "aniso" and b % 3 == 1:  # ... and on uber's glossy lobe (uber.cpp:73-86), beside its other lobes
+            mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [%g %g %g] "color Kr" [.1 .1 .1] "float uroughness" [%g] "float vroughness" [%g] "float index" [%g]%s' % (
+                *rng.uniform(.05, .4, 3), *rng.uniform(.3, .8, 3), rng.uniform(.02, .5), rng.uniform(.02, .5), rng.uniform(1.2, 1.8),
+                ' "color opacity" [.7 .7 .7]' if b % 2 else "")
         elif materials == "ubertrans" and b % 4 == 0:  # UberMaterial's pass-through (uber.cpp:53-61): a grey and a coloured opacity
             op = (.35, .35, .35) if b % 8 == 0 else tuple(rng.uniform(.1, .9, 3))
             mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "float roughness" [%g] "color opacity" [%g %g %g] "float index" [%g]' % (

@@ -523,6 +523,76 @@ WorldEnd
     assert np.array_equal(out.view(np.uint32), oracle.iispt_gather(room, task, valid, pos, dr, nn).view(np.uint32)) and (out[..., 3] == 0.5).sum() > 500
 
 
+def test_anisotropic_roughness_bitwise(binding, oracle, tmp_path):
+    """uroughness != vroughness on uber and glass (uber.cpp:73-86, glass.cpp:52-73; refused until round 6): an anisotropic
+    TrowbridgeReitzDistribution(alphax, alphay) in D, Lambda and the visible-normal sampling. BSDF f / pdf / Sample_f in the canonical
+    frame against the oracle bit for bit, then the box room with such blobs at maxdepth 8 — film and counters, both kernel sets — and
+    the IISPT stages on it. Pins: tests/test_oracle_pins.py::test_anisotropic_roughness_pins and the reference's own
+    BSDFSampling.TR_VA_0p3_0p15 (test_bsdf_sampling_chi_square)."""
+    import boxroom
+    mats = tmp_path / "mats.pbrt"
+    mats.write_text('''Camera "perspective"
+Film "image" "integer xresolution" [4] "integer yresolution" [4]
+Sampler "halton" "integer pixelsamples" [1]
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "color L" [1 1 1]
+  Shape "sphere" "float radius" [1]
+AttributeEnd
+Material "uber" "color Kd" [.2 .3 .4] "color Ks" [.6 .5 .4] "color Kr" [.1 .1 .1] "float uroughness" [.3] "float vroughness" [.15]
+Shape "trianglemesh" "point P" [0 0 5 1 0 5 0 1 5] "integer indices" [0 1 2]
+Material "uber" "color Kd" [0 0 0] "color Ks" [1 1 1] "float uroughness" [.02] "float vroughness" [.6] "bool remaproughness" ["false"] "color opacity" [.8 .7 .6]
+Shape "trianglemesh" "point P" [0 0 6 1 0 6 0 1 6] "integer indices" [0 1 2]
+Material "glass" "float uroughness" [0] "float vroughness" [.3] "float index" [1.5]
+Shape "trianglemesh" "point P" [0 0 7 1 0 7 0 1 7] "integer indices" [0 1 2]
+Material "glass" "color Kr" [.9 .8 .7] "color Kt" [.7 .8 .9] "float uroughness" [.4] "float vroughness" [.05] "bool remaproughness" ["false"] "float index" [1.33]
+Shape "trianglemesh" "point P" [0 0 8 1 0 8 0 1 8] "integer indices" [0 1 2]
+WorldEnd
+''')
+    scene = binding.HostScene(path=str(mats))
+    gpu = binding.GpuScene(scene)
+    rng = np.random.default_rng(16)
+    n = 4096
+
+    def dirs(m):
+        v = rng.normal(size=(m, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return v.astype(np.float32)
+
+    wo, wi = dirs(n), dirs(n)
+    wo[:8, 2] = [0, 1e-8, -1e-8, 1, -1, 0.99995, 0.5, -0.5]
+    u = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    u[:4] = [[0, 0], [0.99999994, 0.99999994], [0.5, 0.5], [0.49999997, 0.5]]
+    assert scene.info["n_materials"] >= 5
+    for mat in range(scene.info["n_materials"]):
+        ev = gpu.bsdf_eval(mat, wo, wi)
+        assert_bitwise(ev, oracle.bsdf_eval(scene, mat, wo, wi), f"BSDF f/pdf material {mat}")
+        assert_bitwise(gpu.bsdf_sample(mat, wo, u), oracle.bsdf_sample(scene, mat, wo, u), f"BSDF Sample_f material {mat}")
+    # anisotropy is really there: swapping x and y of both directions changes f for material 1 (the light's default matte is material 0)
+    sw = lambda v: np.ascontiguousarray(v[:, [1, 0, 2]])
+    assert not np.array_equal(gpu.bsdf_eval(1, wo, wi)[:, :3], gpu.bsdf_eval(1, sw(wo), sw(wi))[:, :3])
+    path = tmp_path / "boxroom_aniso.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, materials="aniso", maxdepth=8, n_blobs=9))
+    room = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(room)
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(room)
+    assert_bitwise(film, ref, "anisotropic roughness film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+    assert st["nee_evals"] == ost["nee_evals"] and st["path_length"] == ost["path_length"]
+    plain, _ = gpu.render()
+    assert_bitwise(plain, ref, "anisotropic roughness film, uninstrumented kernels")
+    direct = gpu.render_direct(2)
+    assert np.array_equal(direct.view(np.uint64), oracle.iispt_direct(room, 2).view(np.uint64))
+    task = binding.IisptTask(0, 0, 96, 64, 8, 0, 0)
+    valid, pos, dr = gpu.iispt_hemi_points(task)
+    rv, rp, rd = oracle.iispt_hemi_points(room, task)
+    assert np.array_equal(valid, rv) and np.array_equal(pos.view(np.uint32), rp.view(np.uint32)) and np.array_equal(dr.view(np.uint32), rd.view(np.uint32))
+    nn = np.random.default_rng(5).uniform(0.0, 3.0, valid.shape + (32, 32, 3)).astype(np.float32)
+    out = gpu.iispt_gather(task, valid, pos, dr, nn)
+    assert np.array_equal(out.view(np.uint32), oracle.iispt_gather(room, task, valid, pos, dr, nn).view(np.uint32)) and (out[..., 3] == 0.5).sum() > 500
+
+
 def test_glass_scenes_bitwise(binding, oracle, tmp_path):
     """GlassMaterial (FresnelSpecular: specular reflection + transmission, the etaScale branch of Li
     and of its Russian roulette). No test of the reference covers glass; the restatement is checked

@@ -22,7 +22,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 iispt = len(sys.argv) > 3 and sys.argv[3] == "iispt"
 lights = ["area", "quad", "multi", "spot", "point", "envmap", "sky"]  # (the last two: infinite lights — k_mis ends at the first hit)
-mats = ["plain", "all", "mixed", "ubertrans", "roughglass"]   # (round 6: uber with opacity < 1 and Kt; rough glass)
+mats = ["plain", "all", "mixed", "ubertrans", "roughglass", "aniso"]   # (round 6: uber with opacity < 1 and Kt; rough glass; uroughness != vroughness)
 bad = 0
 with tempfile.TemporaryDirectory() as td:
     for seed in range(first, first + n):
