@@ -101,6 +101,8 @@ typedef struct iile_material {
     /* uber, glass: "vroughness" and its alpha where it differs from "uroughness" (roughness / alpha above): an anisotropic
      * TrowbridgeReitzDistribution(alphax, alphay) (uber.cpp:73-86, glass.cpp:52-73); equal to roughness / alpha otherwise */
     float roughness_v, alpha_v;
+    /* uber: "opacity" as an image texture (times the constant `opacity`, as kd_tex .. kt_tex), or -1 */
+    int32_t opacity_tex;
 } iile_material;
 
 /* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (src/textures/imagemap.h:78-112,

@@ -1610,7 +1610,7 @@ struct Oracle {
         // BSDF(*si, 1.f) with SpecularTransmission(t, 1.f, 1.f, mode) as its first lobe, and every other coefficient is op * K.Clamp()
         Rgb op(1.f);
         if (m.type == IILE_MAT_UBER) {
-            op = clamp0(m.opacity);
+            op = param(m.opacity, m.opacity_tex);   // opacity->Evaluate(*si).Clamp(), uber.cpp:53
             const float tt[3] = {-op.c[0] + 1.f, -op.c[1] + 1.f, -op.c[2] + 1.f};
             const Rgb t = clamp0(tt);
             if (!t.is_black()) {
@@ -3605,7 +3605,7 @@ void oracle_li(const iile_scene_desc *scene, int trig_mode, int n, const int32_t
 // the material's BSDF in the canonical frame ns = ng = +z, ss = +x (constant parameters: image textures are not looked up)
 static Oracle::Bsdf local_bsdf(const Oracle &orc, const iile_scene_desc *scene, int mat) {
     iile_material m = scene->materials[mat];
-    m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = -1;
+    m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = m.opacity_tex = -1;
     Isect is;
     is.sn = is.n = V3(0, 0, 1);
     is.sdpdu = V3(1, 0, 0);

@@ -833,7 +833,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             for (int c = 0; c < 3; ++c) mats[i].opacity[c] = m.type == IILE_MAT_UBER ? m.opacity[c] : 1.f;
             if (m.type == IILE_MAT_UBER) {
                 // uber.cpp:53-61, 94-99: a SpecularTransmission lobe exists if 1 - opacity or opacity x Kt is not black (an image for Kt: may be)
-                bool trans = m.kt_tex >= 0 && d->n_textures > 0;
+                bool trans = (m.kt_tex >= 0 || m.opacity_tex >= 0) && d->n_textures > 0;
                 for (int c = 0; c < 3; ++c) {
                     const float op = m.opacity[c] > 0.f ? m.opacity[c] : 0.f;
                     trans = trans || (-op + 1.f) > 0.f || op * (m.kt[c] > 0.f ? m.kt[c] : 0.f) != 0.f;
@@ -845,13 +845,14 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             mats[i].ks_tex = d->n_textures > 0 ? m.ks_tex : -1;
             mats[i].kr_tex = d->n_textures > 0 ? m.kr_tex : -1;
             mats[i].kt_tex = d->n_textures > 0 ? m.kt_tex : -1;
+            mats[i].opacity_tex = (d->n_textures > 0 && m.type == IILE_MAT_UBER) ? m.opacity_tex : -1;
             mats[i].bump_tex = d->n_textures > 0 ? m.bump_tex : -1;
             mats[i].rough_tex = d->n_textures > 0 ? m.rough_tex : -1;
             mats[i].sigma_tex = d->n_textures > 0 ? m.sigma_tex : -1;
             mats[i].remap_roughness = m.remap_roughness;
-            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex})
+            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex, mats[i].opacity_tex})
                 if (t >= 0) S.textured_materials = 1;
-            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex})
+            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex, mats[i].opacity_tex})
                 if (t >= d->n_textures) return bail(fail(IILE_ERR_ARG, "material refers to a texture that does not exist"));
         }
         rc = upload(sc, mats.data(), mats.size(), &S.materials);

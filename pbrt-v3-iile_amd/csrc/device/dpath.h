@@ -1514,6 +1514,10 @@ DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect
         r.alpha = rough;
         r.alpha_y = rough;   // (a roughness image is accepted without uroughness / vroughness only)
     }
+    if (m.opacity_tex >= 0) {  // opacity->Evaluate(*si), uber.cpp:53
+        const F3 c = tex_evaluate(S, m.opacity_tex, is.u, is.v, td);
+        r.opacity[0] = c.x * m.opacity[0], r.opacity[1] = c.y * m.opacity[1], r.opacity[2] = c.z * m.opacity[2];
+    }
     if (m.kt_tex >= 0) {
         const F3 c = tex_evaluate(S, m.kt_tex, is.u, is.v, td);  // times the constant: 1, or a "scale" texture's factor
         r.kt[0] = c.x * m.kt[0], r.kt[1] = c.y * m.kt[1], r.kt[2] = c.z * m.kt[2];

@@ -42,6 +42,7 @@ struct alignas(16) DMaterial {
     int rough_tex, remap_roughness;      // float image texture for "roughness" (-1: the constant alpha), RoughnessToAlpha or not
     float opacity[3];                    // uber: "opacity" ({1, 1, 1} otherwise)
     float alpha_y;                       // uber, glass: the distribution's alpha along v ("vroughness"); = alpha otherwise
+    int opacity_tex;                     // uber: image texture for "opacity" (times the constant), or -1
 };
 // ImageTexture + MIPMap (iile_texture): level l holds w x h float4 texels (rgb, w unused) at
 // texels[offset[l] + t * w + s], row 0 = bottom scanline

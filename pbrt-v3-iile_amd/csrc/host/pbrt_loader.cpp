@@ -727,8 +727,8 @@ class Loader {
                 continue;
             }
             if (it->second.image >= 0) {
-                if (it->second.is_float || (p.name != "Kd" && p.name != "Ks" && p.name != "Kr" && p.name != "Kt"))
-                    return fail("image texture \"" + p.strs[0] + "\" on parameter \"" + p.name + "\" is not supported (Kd, Ks, Kr, Kt)");
+                if (it->second.is_float || (p.name != "Kd" && p.name != "Ks" && p.name != "Kr" && p.name != "Kt" && p.name != "opacity"))
+                    return fail("image texture \"" + p.strs[0] + "\" on parameter \"" + p.name + "\" is not supported (Kd, Ks, Kr, Kt, opacity)");
                 (*image_of)[p.name] = it->second.image;
                 p.strs.clear();
                 p.type = "color";  // the constant the image's value is multiplied with at the hit (1 unless "scale"d)
@@ -761,7 +761,7 @@ class Loader {
         if (!resolve_textures(ps_in, &ps, &image_of)) return -1;
         iile_material m;
         std::memset(&m, 0, sizeof(m));
-        m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = -1;
+        m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = m.opacity_tex = -1;
         m.opacity[0] = m.opacity[1] = m.opacity[2] = 1.f;
         auto image = [&](const char *param) {
             auto it = image_of.find(param);
@@ -843,10 +843,7 @@ class Loader {
         if (m.type == IILE_MAT_PLASTIC || m.type == IILE_MAT_UBER) m.ks_tex = image("Ks");
         if (m.type == IILE_MAT_UBER || m.type == IILE_MAT_MIRROR || m.type == IILE_MAT_GLASS) m.kr_tex = image("Kr");
         if (m.type == IILE_MAT_GLASS || m.type == IILE_MAT_UBER) m.kt_tex = image("Kt");
-        if (m.type == IILE_MAT_UBER && image("opacity") >= 0) {
-            fail("uber: \"opacity\" as an image texture is not supported (a constant is; cut-outs: the shape's \"alpha\" texture)");
-            return -1;
-        }
+        if (m.type == IILE_MAT_UBER) m.opacity_tex = image("opacity");   // GetSpectrumTexture("opacity", 1.f), uber.cpp:117
         if (const Param *sp = ps.find("sigma"))
             if (sp->type == "sigmaimage") {
                 if (m.type != IILE_MAT_MATTE) {

@@ -249,6 +249,9 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
         elif materials == "ubertrans" and b % 4 == 2:  # ... both, and nothing else: every lobe specular, no light sampling at these vertices
             mat = 'Material "uber" "color Kd" [0 0 0] "color Ks" [0 0 0] "color Kt" [%g %g %g] "color opacity" [.6 .6 .6] "float index" [%g]' % (
                 *rng.uniform(.6, 1, 3), rng.uniform(1.3, 1.6))
+        elif materials == "ubertrans" and tex is not None and b % 4 == 3:  # "opacity" (and Kt) from image textures: the pass-through varies over the surface
+            mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "texture opacity" ["%s"] "texture Kt" ["stripes"] "float index" [%g]' % (
+                *rng.uniform(.2, .7, 3), ("noise", "noise-tint", "checker")[(b // 4) % 3], rng.uniform(1.2, 1.6))
         elif materials == "mixed" and b % 3 == 1:  # specular lobes: uber (diffuse + glossy + mirror-like) and mirror
             mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "color Kr" [.3 .3 .3] "float roughness" [%g] "float index" [%g]' % (
                 *rng.uniform(.1, .4, 3), rng.uniform(.05, .3), rng.uniform(1.2, 1.8))

@@ -446,6 +446,23 @@ def test_uber_transmission_bitwise(binding, oracle, tmp_path):
     nn = np.random.default_rng(4).uniform(0.0, 3.0, valid.shape + (32, 32, 3)).astype(np.float32)
     out = gpu.iispt_gather(task, valid, pos, dr, nn)
     assert np.array_equal(out.view(np.uint32), oracle.iispt_gather(room, task, valid, pos, dr, nn).view(np.uint32)) and (out[..., 3] == 0.5).sum() > 500
+    # "opacity" and Kt as image textures (uber.cpp:117, 53: the pass-through varies over the surface), in the textured room: the film
+    # and counters, the direct pass (differentials through the transmissions), hemi points
+    path = tmp_path / "boxroom_ubertrans_tex.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, materials="ubertrans", maxdepth=8, n_blobs=12, ico_levels=3, textures=str(tmp_path / "tex")))
+    room = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(room)
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(room)
+    assert_bitwise(film, ref, "uber with opacity / Kt images: film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"] and st["path_length"] == ost["path_length"]
+    plain, _ = gpu.render()
+    assert_bitwise(plain, ref, "uber with opacity / Kt images: film, uninstrumented kernels")
+    direct = gpu.render_direct(2)
+    assert np.array_equal(direct.view(np.uint64), oracle.iispt_direct(room, 2).view(np.uint64))
+    valid, pos, dr = gpu.iispt_hemi_points(task)
+    rv, rp, rd = oracle.iispt_hemi_points(room, task)
+    assert np.array_equal(valid, rv) and np.array_equal(pos.view(np.uint32), rp.view(np.uint32)) and np.array_equal(dr.view(np.uint32), rd.view(np.uint32))
 
 
 def test_rough_glass_bitwise(binding, oracle, tmp_path):

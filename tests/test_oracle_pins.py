@@ -1097,6 +1097,14 @@ WorldEnd
     # a fully transparent surface (opacity 0) is not there at all, whatever its other coefficients
     m, lo, hi, _ = mean_and_range('Material "uber" "color Kd" [.3 .3 .3] "color Ks" [.5 .5 .5] "color Kr" [.5 .5 .5] "color opacity" [0 0 0]')
     assert abs(m - 1.0) < 3e-3 and lo > 0.9 and hi < 1.1, (m, lo, hi)
+    # "opacity" as an image texture (GetSpectrumTexture("opacity", 1.f), uber.cpp:117; refused until round 6): an image whose texels all
+    # hold 0.4 is the constant 0.4 (the same paths: equal ray counts; radiance equal up to the rounding of the filtered lookup)
+    img = tmp_path / "flat.pfm"
+    img.write_bytes(b"PF\n4 4\n-1.0\n" + np.full((4, 4, 3), 0.4, np.float32).tobytes())
+    tex = 'Texture "flat" "spectrum" "imagemap" "string filename" ["%s"]\n  ' % img
+    m_c, _, _, st_c = mean_and_range('Material "uber" "color Kd" [1 1 1] "color Ks" [0 0 0] "color opacity" [.4 .4 .4]')
+    m_t, _, _, st_t = mean_and_range(tex + 'Material "uber" "color Kd" [1 1 1] "color Ks" [0 0 0] "texture opacity" ["flat"]')
+    assert abs(m_t - m_c) < 1e-4 and st_t["regular_rays"] == st_c["regular_rays"] and st_t["shadow_rays"] == st_c["shadow_rays"], (m_t, m_c)
 
 
 def test_uber_transmission_direct_pass_pins(binding, oracle, tmp_path):
