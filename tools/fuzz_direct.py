@@ -21,7 +21,7 @@ o = oracle_binding.Oracle()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 lights = ["area", "quad", "multi", "spot", "point", "envmap", "sky", "many"]
-mats = ["plain", "all", "mixed"]
+mats = ["plain", "all", "mixed", "ubertrans", "roughglass", "aniso"]   # (the last three: round 6)
 bad = 0
 with tempfile.TemporaryDirectory() as td:
     for seed in range(first, first + n):
