@@ -15,13 +15,13 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-ONE="$R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --other-steps 0 --alone-steps 0 $EXTRA"
+ONE="$R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --other-steps 0 --alone-steps 0 --sub-configs none $EXTRA"   # (--sub-configs none: the default line's config-4 / config-5 blocks would put their kernels into these traces)
 echo "$EXTRA" > "$O/bench_args.txt"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --other-steps 0 --alone-steps 0 $EXTRA > "$O/stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --other-steps 0 --alone-steps 0 --sub-configs none $EXTRA > "$O/stats.log" 2>&1
 grep -h '"metric"' "$O/stats.log" | tail -1 > "$O/bench_under_profiler.json"
 # the same trace with every kernel of the timed steps alone on the GPU (bench.py --schedule one-stream): the per-kernel averages the
 # bench line's `roofline` / `roofline_all_kernels` are priced with
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_one_stream" -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --other-steps 0 --alone-steps 0 --schedule one-stream $EXTRA > "$O/stats_one_stream.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_one_stream" -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --other-steps 0 --alone-steps 0 --sub-configs none --schedule one-stream $EXTRA > "$O/stats_one_stream.log" 2>&1
 grep -h '"metric"' "$O/stats_one_stream.log" | tail -1 > "$O/bench_one_stream_under_profiler.json"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/fetch" -- python3 $ONE > "$O/fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/write" -- python3 $ONE > "$O/write.log" 2>&1

@@ -19,7 +19,7 @@ timeout 600 python3 bench.py --workload boxroom --steps 5 --warmup 1 > $O/bench_
 timeout 600 python3 bench.py --workload boxroom-textured --steps 5 --warmup 1 --cpu-seconds 0 > $O/bench_boxroom_textured.json 2> $O/bench_boxroom_textured.err
 timeout 600 python3 bench.py --sampler sobol --steps 10 --warmup 2 --cpu-seconds 0 --other-steps 0 > $O/bench_sobol.json 2> $O/bench_sobol.err
 timeout 900 python3 bench.py --workload boxroom --spp 256 --steps 2 --warmup 1 --cpu-seconds 0 --alone-steps 1 > $O/bench_boxroom_256spp.json 2> $O/bench_boxroom_256spp.err
-timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --steps 3 --warmup 1 --scaling strong --cpu-seconds 0 --other-steps 0 > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
+timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --steps 3 --warmup 1 --scaling strong --cpu-seconds 0 --other-steps 0 --sub-configs none > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
 # BASELINE config 5: the IISPT frame — the contract line, its steady-state kernel trace (two warm-up frames first), the
 # network kernels' matrix-pipe counters, and ten fresh processes of the same line (is any process at half speed?)
 timeout 600 python3 bench.py --workload iispt --steps 5 --warmup 2 > $O/bench_iispt.json 2> $O/bench_iispt.err
