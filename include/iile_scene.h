@@ -224,6 +224,10 @@ typedef struct iile_integrator {
     float rr_threshold;
     int32_t light_strategy;             /* "lightsamplestrategy" of the path integrator (path.cpp:231), IILE_LIGHTS_* */
     float light_power[IILE_MAX_LIGHTS]; /* power strategy: Power().y() of every light */
+    /* "pixelbounds" (path.cpp:216-229): {x0, y0, x1, y1} = Intersect(film->GetSampleBounds(), the four values given); pixels of the
+     * sample bounds outside it take no samples (SamplerIntegrator::Render, integrator.cpp:272). The sample bounds when not given;
+     * all four zero = not given (what a caller that does not know the field leaves); the host writes an empty intersection as {0, 0, -1, -1} */
+    int32_t pixel_bounds[4];
 } iile_integrator;
 
 /* The IISPT probe pass: what IISPTdIntegrator::RenderView renders from a HemisphericCamera

@@ -3253,6 +3253,9 @@ static int render_impl(const iile_scene_desc *scene, int trig_mode, int n_thread
                 for (int px = x0; px < x1; ++px)
                     for (int64_t k = k_begin; k < k_end; ++k) {
                         if (probe && (px < F.crop_x0 || px >= F.crop_x1 || py < F.crop_y0 || py >= F.crop_y1)) continue;
+                        // `if (!InsideExclusive(pixel, pixelBounds)) continue;` (integrator.cpp:272; "pixelbounds", path.cpp:216-229)
+                        const int32_t *pb = S.integrator.pixel_bounds;
+                        if (!probe && !(px >= pb[0] && px < pb[2] && py >= pb[1] && py < pb[3])) continue;
                         float pf[2];
                         Rgb L = orc.sample_radiance(px, py, k, pf);
                         if (probe && aux_nd)

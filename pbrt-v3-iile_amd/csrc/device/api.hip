@@ -1057,6 +1057,13 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
     S.samp_y0 = f.samp_y0;
     S.samp_x1 = f.samp_x1;
     S.samp_y1 = f.samp_y1;
+    {   // "pixelbounds" (iile_integrator::pixel_bounds; all zero = not given, as a caller that never heard of the field leaves it)
+        const int32_t *pb = d->integrator.pixel_bounds;
+        const bool given = pb[0] != 0 || pb[1] != 0 || pb[2] != 0 || pb[3] != 0;
+        S.pb_x0 = given ? std::max(pb[0], f.samp_x0) : f.samp_x0, S.pb_y0 = given ? std::max(pb[1], f.samp_y0) : f.samp_y0;
+        S.pb_x1 = given ? std::min(pb[2], f.samp_x1) : f.samp_x1, S.pb_y1 = given ? std::min(pb[3], f.samp_y1) : f.samp_y1;
+        S.pb_set = (S.pb_x0 != f.samp_x0 || S.pb_y0 != f.samp_y0 || S.pb_x1 != f.samp_x1 || S.pb_y1 != f.samp_y1) ? 1 : 0;
+    }
     S.filter_rx = f.filter_rx;
     S.filter_ry = f.filter_ry;
     S.max_sample_luminance = f.max_sample_luminance;
@@ -1369,6 +1376,7 @@ int patch_prepare(iile_scene *sc, const DScene &S, const PassDesc &Pf, hipStream
             }
             if (d.own_in_pass && fl[i].tile == d.tile && fl[i].pix < d.pix) d.need_own = true;
         }
+        if (!(d.qx >= S.pb_x0 && d.qx < S.pb_x1 && d.qy >= S.pb_y0 && d.qy < S.pb_y1)) d.need_own = false;   // (no samples of its own: k_patch_dests)
         dests.push_back(d);
         a = b;
     }
@@ -1672,7 +1680,10 @@ int iile_render(iile_scene *sc, const iile_render_params *prm, float *film_xyzw,
 
     HIP_TRY(hipEventRecord(sc->ev_begin, stream));
     if (pix_slots) HIP_TRY(hipMemsetAsync(sc->pb.counters, 0, sizeof(DCounters), stream));
-    if (pix_slots) HIP_TRY(hipMemsetAsync(sc->fb.tile_rgbw, 0, size_t(pix_slots) * sizeof(float4) * 2, stream));
+    // (the two planes are sized for the largest share this scene has rendered: k0_rgbv starts film_tiles * 256 records behind tile_rgbw,
+    //  not pix_slots — each is cleared where it lies; a pixel outside "pixelbounds" keeps these zeros)
+    if (pix_slots) HIP_TRY(hipMemsetAsync(sc->fb.tile_rgbw, 0, size_t(pix_slots) * sizeof(float4), stream));
+    if (pix_slots) HIP_TRY(hipMemsetAsync(sc->fb.k0_rgbv, 0, size_t(pix_slots) * sizeof(float4), stream));
     P.k0 = k_begin;
     P.kc = n_samples;
     for (int slot0 = 0; slot0 < P.n_owned_tiles; slot0 += tiles_per_pass) {
@@ -1797,6 +1808,7 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     // hit's dpdu / dpdv and shading.dndu / dndv (triangles: triangle_interaction; spheres: sphere_interaction<true>)
     const bool reflect_diffs = S.textured_materials && S.has_specular;
     if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
+    if (S.pb_set) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: \"pixelbounds\" is read by the path integrator only");
     // Glass: DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), GlassMaterial
     // then adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and both recursions fire — Li is a tree,
     // walked depth first by one thread per pixel (k_direct_tree) instead of the wavefront below.
@@ -2152,6 +2164,7 @@ int iispt_check(iile_scene *sc, const iile_iispt_task *t, int *nx, int *ny) {
     if (rc) return rc;
     if (t->x1 <= t->x0 || t->y1 <= t->y0 || t->tilesize < 1) return fail(IILE_ERR_ARG, "iile_iispt: empty task or tilesize < 1");
     if (sc->ds.sobol) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the runner's camera samples need the scene's Halton sampler");
+    if (sc->ds.pb_set) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: \"pixelbounds\" is read by the path integrator only");
     if (sc->probe.hemi_size != 32) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the gather is built for 32 x 32 hemispheres (iisptHemiSize)");
     *nx = iile_iispt_grid_count(t->x0, t->x1, t->tilesize);
     *ny = iile_iispt_grid_count(t->y0, t->y1, t->tilesize);

@@ -157,6 +157,8 @@ struct DScene {
     int xres, yres;
     int crop_x0, crop_y0, crop_x1, crop_y1;
     int samp_x0, samp_y0, samp_x1, samp_y1;
+    int pb_x0, pb_y0, pb_x1, pb_y1;   // the integrator's pixelBounds ("pixelbounds"): inside the sample bounds; pixels outside take no samples
+    int pb_set;                       // 1: the pixel bounds are smaller than the sample bounds
     float filter_rx, filter_ry, max_sample_luminance;
     int probe_mode;              // IISPT probe pass: hemispheric cameras, IISPTdIntegrator::Li (k_shade / k_miss)
     int filter_wide;             // not the one-pixel box: samples are kept and gathered (k_film_store / k_film_gather)

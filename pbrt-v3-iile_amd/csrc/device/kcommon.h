@@ -241,7 +241,8 @@ DEV bool path_pixel(const DScene &S, const PassDesc &P, uint32_t pid, int *px, i
     *px = S.samp_x0 + tx * kTile + int(pix & 15u);
     *py = S.samp_y0 + ty * kTile + int(pix >> 4);
     *k = uint32_t(P.k0) + kk;
-    return *px < S.samp_x1 && *py < S.samp_y1;
+    // (pb = the sample bounds unless "pixelbounds" was given: `if (!InsideExclusive(pixel, pixelBounds)) continue;`, integrator.cpp:272)
+    return *px < S.pb_x1 && *py < S.pb_y1 && *px >= S.pb_x0 && *py >= S.pb_y0;
 }
 
 // probe pass: the record ((storage slot) * 256 + pixel of the tile) of sample pixel (x, y) of probe `probe`

@@ -269,8 +269,9 @@ DEV float4 film_gather_pixel(const DScene &S, const PassDesc &P, const FilmBuffe
     // sample pixels that can reach (x, y): |q + u - 0.5 - x| <= r with u in [0, 1), i.e. x - r - 0.5 < q <= x + r + 0.5
     // (floor / ceil keep a pixel of slack on either side against the rounding of the sums in AddSample)
     // (a probe's RenderView takes no samples outside the film's pixel bounds: those records do not exist)
-    const int lo_x = P.probe_mode ? S.crop_x0 : S.samp_x0, hi_x = P.probe_mode ? S.crop_x1 : S.samp_x1;
-    const int lo_y = P.probe_mode ? S.crop_y0 : S.samp_y0, hi_y = P.probe_mode ? S.crop_y1 : S.samp_y1;
+    // (the path pass takes none outside the integrator's pixel bounds — the sample bounds unless "pixelbounds" was given)
+    const int lo_x = P.probe_mode ? S.crop_x0 : S.pb_x0, hi_x = P.probe_mode ? S.crop_x1 : S.pb_x1;
+    const int lo_y = P.probe_mode ? S.crop_y0 : S.pb_y0, hi_y = P.probe_mode ? S.crop_y1 : S.pb_y1;
     const int qx0 = max(int(floorf(float(x) - rx - 0.5f)), lo_x), qx1 = min(int(ceilf(float(x) + rx + 0.5f)), hi_x - 1);
     const int qy0 = max(int(floorf(float(y) - ry - 0.5f)), lo_y), qy1 = min(int(ceilf(float(y) + ry + 0.5f)), hi_y - 1);
     float4 out = make_float4(0, 0, 0, 0);
@@ -776,6 +777,9 @@ __global__ __launch_bounds__(kBlock) void k_patch_dests(DScene S, PassDesc P, Pa
             all_plain = all_plain && f.plain_k0;
             if (own_in_pass && f.tile == d_tile && f.pix < d_pix) need_own = true;
         }
+        // a destination outside the integrator's pixel bounds took no samples of its own ("pixelbounds"): nothing to put in order, and
+        // its slot of tile_rgbw holds the zeros it was cleared to
+        if (!(qx >= S.pb_x0 && qx < S.pb_x1 && qy >= S.pb_y0 && qy < S.pb_y1)) need_own = false;
         // the pass is the whole frame: a pixel reached only by samples k_film_resolve places itself needs nothing
         if (whole_frame && all_plain) continue;
         float rr = 0, gg = 0, bb = 0, ww = 0;

@@ -307,6 +307,19 @@ bool finalize_scene(HostScene *s, std::string *err) {
 
     d.integrator.max_depth = s->max_depth;
     d.integrator.rr_threshold = s->rr_threshold;
+    {   // pixelBounds = Intersect(camera->film->GetSampleBounds(), Bounds2i{{pb[0], pb[2]}, {pb[1], pb[3]}}), path.cpp:217-227
+        int32_t *pb = d.integrator.pixel_bounds;
+        pb[0] = d.film.samp_x0, pb[1] = d.film.samp_y0, pb[2] = d.film.samp_x1, pb[3] = d.film.samp_y1;
+        if (s->has_pixel_bounds) {
+            const int *g = s->pixel_bounds_given;
+            // (Bounds2i's two-point constructor orders the corners: geometry.h:690-693)
+            const int gx0 = std::min(g[0], g[1]), gx1 = std::max(g[0], g[1]), gy0 = std::min(g[2], g[3]), gy1 = std::max(g[2], g[3]);
+            pb[0] = std::max(pb[0], gx0), pb[1] = std::max(pb[1], gy0), pb[2] = std::min(pb[2], gx1), pb[3] = std::min(pb[3], gy1);
+            if ((pb[2] - pb[0]) * (pb[3] - pb[1]) == 0) std::fprintf(stderr, "Error: Degenerate \"pixelbounds\" specified.\n");
+            // (empty bounds — no pixel is inside — in one form that is not "all zero": iile_scene_create reads all zero as "not given")
+            if (pb[2] <= pb[0] || pb[3] <= pb[1]) pb[0] = pb[1] = 0, pb[2] = pb[3] = -1;
+        }
+    }
     d.integrator.light_strategy = s->light_strategy == "uniform" ? IILE_LIGHTS_UNIFORM : (s->light_strategy == "power" ? IILE_LIGHTS_POWER : IILE_LIGHTS_SPATIAL);
     // Light::Power().y() of every light (ComputeLightPowerDistribution, integrator.cpp:217-225)
     for (int i = 0; i < IILE_MAX_LIGHTS; ++i) d.integrator.light_power[i] = 0;

@@ -60,6 +60,8 @@ struct HostScene {
     int max_depth = 5;
     bool integrator_iispt = false;   // Integrator "iispt" (MakeIntegrator, src/core/api.cpp:1738-1760)
     float rr_threshold = 1.f;
+    bool has_pixel_bounds = false;   // "pixelbounds" of the path integrator: x0, x1, y0, y1 as given (path.cpp:216-229)
+    int pixel_bounds_given[4] = {0, 0, 0, 0};
     std::string light_strategy = "spatial";
     std::string accel_split = "sah";
     int max_node_prims = 4;

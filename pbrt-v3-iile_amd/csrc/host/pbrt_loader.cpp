@@ -485,7 +485,15 @@ class Loader {
                 std::fprintf(stderr, "Error: Light sample distribution type \"%s\" unknown. Using \"spatial\".\n", s.light_strategy.c_str());
                 s.light_strategy = "spatial";
             }
-            if (ps.find("pixelbounds")) return fail("pixelbounds is not supported");
+            if (const Param *pb = ps.find("pixelbounds")) {  // path.cpp:216-229
+                if (s.integrator_iispt) return fail("pixelbounds with Integrator \"iispt\" is not supported");
+                if (pb->type != "integer" || pb->nums.size() != 4)
+                    std::fprintf(stderr, "Error: Expected four values for \"pixelbounds\" parameter. Got %d.\n", int(pb->nums.size()));
+                else {
+                    s.has_pixel_bounds = true;
+                    for (int i = 0; i < 4; ++i) s.pixel_bounds_given[i] = int(pb->nums[size_t(i)]);
+                }
+            }
         } else if (d == "Accelerator") {  // accelerators/bvh.cpp:740-760
             if (name != "bvh") return fail("only Accelerator \"bvh\" is supported");
             s.accel_split = ps.one_string("splitmethod", "sah");

@@ -1071,6 +1071,54 @@ def test_whole_number_film_positions_bitwise(binding, oracle):
         assert_bitwise(part, pref, f"strip, shard {rank} of 2")
 
 
+def test_pixelbounds_bitwise(binding, oracle, tmp_path):
+    """"pixelbounds" of the path integrator (path.cpp:216-229, integrator.cpp:272; refused until round 6): pixels of the sample
+    bounds outside the rectangle take no samples — no paths, no film weight — while tiles, sample indices and the film's sums keep
+    their places. Film and counters against the oracle bit for bit: rectangles inside a tile, across tiles, ragged, one pixel, empty;
+    the box film in one pass and in several, both kernel sets, two shards; a wide filter (samples near the rectangle's edge reach
+    pixels outside it and pixels inside miss their outside neighbours'); Sobol'; and the strip of
+    test_whole_number_film_positions_bitwise cut by a rectangle (whole-number film positions land in a neighbour that took no samples
+    of its own, and the other way round: the exact finish's ordering). The IISPT entry points refuse such a scene. Pins:
+    tests/test_oracle_pins.py::test_pixelbounds_pins."""
+    from test_oracle_pins import _killeroo_with
+    X, Y, S = 112, 80, 5
+    for k, (rect, flt, sampler) in enumerate(((( 21,  70,  9, 50), "", ""), ((16, 48, 16, 32), "", ""), ((17, 19, 33, 34), "", ""), ((0, 112, 40, 80), "", ""),
+                                              ((90, 300, -4, 7), "", ""), ((200, 300, 0, 10), "", ""), ((21, 70, 9, 50), 'PixelFilter "gaussian"', ""),
+                                              ((30, 33, 30, 33), 'PixelFilter "mitchell" "float xwidth" [3] "float ywidth" [1.5]', ""), ((21, 70, 9, 50), "", "sobol"))):
+        line = 'Integrator "path" "integer pixelbounds" [%d %d %d %d]' % rect
+        scene = binding.HostScene(path=_killeroo_with(tmp_path, line, X, Y, S, flt), **({"sampler": sampler} if sampler else {}))
+        gpu = binding.GpuScene(scene)
+        ref, ost = oracle.render(scene)
+        film, st = gpu.render(collect_stats=True)
+        assert_bitwise(film, ref, f"pixelbounds {rect} {flt} {sampler}: instrumented kernels")
+        assert st["camera_rays"] == ost["camera_rays"] and st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+        assert_bitwise(gpu.render()[0], ref, f"pixelbounds {rect} {flt} {sampler}")
+        assert_bitwise(gpu.render(spp_per_pass=2)[0], ref, f"pixelbounds {rect} {flt} {sampler}: three passes")
+        if k == 0:
+            for rank in range(2):
+                part, _ = gpu.render(tile_rank=rank, tile_nranks=2)
+                assert_bitwise(part, oracle.render(scene, tile_rank=rank, tile_nranks=2)[0], f"pixelbounds {rect}: shard {rank} of 2")
+            with pytest.raises(RuntimeError, match="pixelbounds"):
+                gpu.render_direct(1)
+            with pytest.raises(RuntimeError, match="pixelbounds"):
+                gpu.iispt_hemi_points(binding.IisptTask(0, 0, 40, 40, 4, 0, 0))
+        if rect[0] >= 200:
+            assert (ref == 0).all() and ost["camera_rays"] == 0
+    # whole-number film positions across the rectangle's edges (48 spp: dozens of them beyond x = 1024)
+    for rect in ((1030, 1700, 3, 21), (1101, 1102, 0, 24), (0, 1900, 7, 8)):
+        line = 'Integrator "path" "integer pixelbounds" [%d %d %d %d]' % rect
+        scene = binding.HostScene(path=_killeroo_with(tmp_path, line, 1900, 24, 48))
+        gpu = binding.GpuScene(scene)
+        ref, _ = oracle.render(scene)
+        assert_bitwise(gpu.render()[0], ref, f"strip with pixelbounds {rect}, one pass")
+        assert_bitwise(gpu.render(spp_per_pass=10)[0], ref, f"strip with pixelbounds {rect}, five passes")
+        assert_bitwise(gpu.render(collect_stats=True)[0], ref, f"strip with pixelbounds {rect}, instrumented kernels")
+        if rect[0] == 1030:
+            w = ref[..., 3]
+            assert (w[:, :1030] > 0).sum() + (w[:, 1700:] > 0).sum() + (w[:3] > 0).sum() + (w[21:] > 0).sum() > 0   # a sample did land outside
+            assert (w[3:21, 1030:1700] > 48).sum() > 10
+
+
 def test_exact_finish_overflow_reaches_the_asynchronous_caller(binding, oracle):
     """The exact finish is sized from the frame; when it runs out of room anyway the film is wrong and the caller must hear of
     it. iile_render(film on the device, no statistics) only enqueues and returns IILE_OK, so the error has to come later:
