@@ -1808,7 +1808,8 @@ int iile_render_direct(iile_scene *sc, const iile_direct_params *prm, double *fi
     // hit's dpdu / dpdv and shading.dndu / dndv (triangles: triangle_interaction; spheres: sphere_interaction<true>)
     const bool reflect_diffs = S.textured_materials && S.has_specular;
     if (S.filter_wide) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: the direct pass is defined for the one-pixel box film");
-    if (S.pb_set) return fail(IILE_ERR_UNSUPPORTED, "iile_render_direct: \"pixelbounds\" is read by the path integrator only");
+    // ("pixelbounds" belongs to the path integrator: the IISPT runner hands DirectProgressiveIntegrator the film's bounds, iisptrenderrunner.cpp:608-613)
+    S.pb_x0 = S.samp_x0, S.pb_y0 = S.samp_y0, S.pb_x1 = S.samp_x1, S.pb_y1 = S.samp_y1, S.pb_set = 0;
     // Glass: DirectProgressiveIntegrator::Li builds its BSDF with allowMultipleLobes = false (interaction.h:130-133), GlassMaterial
     // then adds a SpecularReflection and a SpecularTransmission lobe (glass.cpp:62-90) and both recursions fire — Li is a tree,
     // walked depth first by one thread per pixel (k_direct_tree) instead of the wavefront below.
@@ -2164,7 +2165,6 @@ int iispt_check(iile_scene *sc, const iile_iispt_task *t, int *nx, int *ny) {
     if (rc) return rc;
     if (t->x1 <= t->x0 || t->y1 <= t->y0 || t->tilesize < 1) return fail(IILE_ERR_ARG, "iile_iispt: empty task or tilesize < 1");
     if (sc->ds.sobol) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the runner's camera samples need the scene's Halton sampler");
-    if (sc->ds.pb_set) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: \"pixelbounds\" is read by the path integrator only");
     if (sc->probe.hemi_size != 32) return fail(IILE_ERR_UNSUPPORTED, "iile_iispt: the gather is built for 32 x 32 hemispheres (iisptHemiSize)");
     *nx = iile_iispt_grid_count(t->x0, t->x1, t->tilesize);
     *ny = iile_iispt_grid_count(t->y0, t->y1, t->tilesize);

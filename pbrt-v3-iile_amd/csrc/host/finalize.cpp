@@ -310,7 +310,7 @@ bool finalize_scene(HostScene *s, std::string *err) {
     {   // pixelBounds = Intersect(camera->film->GetSampleBounds(), Bounds2i{{pb[0], pb[2]}, {pb[1], pb[3]}}), path.cpp:217-227
         int32_t *pb = d.integrator.pixel_bounds;
         pb[0] = d.film.samp_x0, pb[1] = d.film.samp_y0, pb[2] = d.film.samp_x1, pb[3] = d.film.samp_y1;
-        if (s->has_pixel_bounds) {
+        if (s->has_pixel_bounds && !s->integrator_iispt) {
             const int *g = s->pixel_bounds_given;
             // (Bounds2i's two-point constructor orders the corners: geometry.h:690-693)
             const int gx0 = std::min(g[0], g[1]), gx1 = std::max(g[0], g[1]), gy0 = std::min(g[2], g[3]), gy1 = std::max(g[2], g[3]);

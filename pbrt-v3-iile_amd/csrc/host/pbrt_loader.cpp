@@ -486,7 +486,8 @@ class Loader {
                 s.light_strategy = "spatial";
             }
             if (const Param *pb = ps.find("pixelbounds")) {  // path.cpp:216-229
-                if (s.integrator_iispt) return fail("pixelbounds with Integrator \"iispt\" is not supported");
+                // (CreateIISPTIntegrator reads it too, iispt.cpp:797-811, but nothing of IISPTIntegrator::Render looks at the member: the
+                //  runners get film->GetSampleBounds(), iispt.cpp:395-409 — finalize leaves the sample bounds in place for "iispt")
                 if (pb->type != "integer" || pb->nums.size() != 4)
                     std::fprintf(stderr, "Error: Expected four values for \"pixelbounds\" parameter. Got %d.\n", int(pb->nums.size()));
                 else {

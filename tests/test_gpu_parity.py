@@ -1078,7 +1078,7 @@ def test_pixelbounds_bitwise(binding, oracle, tmp_path):
     the box film in one pass and in several, both kernel sets, two shards; a wide filter (samples near the rectangle's edge reach
     pixels outside it and pixels inside miss their outside neighbours'); Sobol'; and the strip of
     test_whole_number_film_positions_bitwise cut by a rectangle (whole-number film positions land in a neighbour that took no samples
-    of its own, and the other way round: the exact finish's ordering). The IISPT entry points refuse such a scene. Pins:
+    of its own, and the other way round: the exact finish's ordering). The IISPT entry points ignore it, as the reference's IISPT integrator does. Pins:
     tests/test_oracle_pins.py::test_pixelbounds_pins."""
     from test_oracle_pins import _killeroo_with
     X, Y, S = 112, 80, 5
@@ -1098,10 +1098,10 @@ def test_pixelbounds_bitwise(binding, oracle, tmp_path):
             for rank in range(2):
                 part, _ = gpu.render(tile_rank=rank, tile_nranks=2)
                 assert_bitwise(part, oracle.render(scene, tile_rank=rank, tile_nranks=2)[0], f"pixelbounds {rect}: shard {rank} of 2")
-            with pytest.raises(RuntimeError, match="pixelbounds"):
-                gpu.render_direct(1)
-            with pytest.raises(RuntimeError, match="pixelbounds"):
-                gpu.iispt_hemi_points(binding.IisptTask(0, 0, 40, 40, 4, 0, 0))
+            # the IISPT integrator never looks at the parameter (its runners get film->GetSampleBounds(), iispt.cpp:395-409; the direct
+            # integrator the film's bounds, iisptrenderrunner.cpp:608-613): the same direct pass as without it
+            plain_scene = binding.HostScene(path=_killeroo_with(tmp_path, 'Integrator "path"', X, Y, S))
+            assert np.array_equal(gpu.render_direct(2).view(np.uint64), oracle.iispt_direct(plain_scene, 2).view(np.uint64))
         if rect[0] >= 200:
             assert (ref == 0).all() and ost["camera_rays"] == 0
     # whole-number film positions across the rectangle's edges (48 spp: dozens of them beyond x = 1024)
