@@ -12,3 +12,4 @@ bash tools/evidence.sh $TAG > $O/evidence.log 2>&1; tail -12 $O/evidence.log | c
 bash tools/net_traffic.sh > $O/net_traffic.log 2>&1; cp gpurun_out/net_traffic/traffic.json $O/${TAG}_net_traffic.json; tail -1 $O/net_traffic.log
 ls profiles | grep "^$TAG" | head -40
 mkdir -p $O/profiles_made; cp profiles/${TAG}_* $O/profiles_made/ 2>/dev/null
+( time timeout 1500 python3 tools/fuzz_rooms.py 75000 840 iispt ) > $O/fuzz_rooms.txt 2>&1; tail -5 $O/fuzz_rooms.txt | head -2; grep -c "OK/OK/OK" $O/fuzz_rooms.txt; grep -c "+pb" $O/fuzz_rooms.txt; grep MISMATCH $O/fuzz_rooms.txt | head -5

@@ -37,7 +37,13 @@ with tempfile.TemporaryDirectory() as td:
             else:
                 kw["env_dir"] = os.path.join(td, f"env{seed}")
         try:
-            open(path, "w").write(boxroom.boxroom_pbrt(**kw))
+            text = boxroom.boxroom_pbrt(**kw)
+            if seed % 5 == 0:   # "pixelbounds" (round 6): a random rectangle x0 x1 y0 y1, sometimes reaching past the film
+                xs = sorted(int(v) for v in rng.integers(-8, kw["xres"] + 8, 2))
+                ys = sorted(int(v) for v in rng.integers(-8, kw["yres"] + 8, 2))
+                text = text.replace('Integrator "path"', 'Integrator "path" "integer pixelbounds" [%d %d %d %d]' % (xs[0], xs[1] + 1, ys[0], ys[1] + 1))
+                kw["materials"] += "+pb"
+            open(path, "w").write(text)
         except TypeError as e:
             print("skip", kw, e)
             continue
