@@ -1102,6 +1102,17 @@ def test_pixelbounds_bitwise(binding, oracle, tmp_path):
             # integrator the film's bounds, iisptrenderrunner.cpp:608-613): the same direct pass as without it
             plain_scene = binding.HostScene(path=_killeroo_with(tmp_path, 'Integrator "path"', X, Y, S))
             assert np.array_equal(gpu.render_direct(2).view(np.uint64), oracle.iispt_direct(plain_scene, 2).view(np.uint64))
+            # and through the C++ host: `iile_pbrt scene.pbrt` writes the same image
+            import os
+            import subprocess
+            exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pbrt-v3-iile_amd", "lib", "iile_pbrt")
+            out = tmp_path / "pb_cli.pfm"
+            p = subprocess.run([exe, _killeroo_with(tmp_path, line, X, Y, S, flt), "--outfile", str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+            assert p.returncode == 0, p.stdout
+            raw = out.read_bytes()
+            head = b"PF\n%d %d\n-1.0\n" % (X, Y)
+            assert raw.startswith(head)
+            assert_bitwise(np.frombuffer(raw[len(head):], "<f4").reshape(Y, X, 3)[::-1], scene.film_to_rgb(ref), "pixelbounds through iile_pbrt")
         if rect[0] >= 200:
             assert (ref == 0).all() and ost["camera_rays"] == 0
     # whole-number film positions across the rectangle's edges (48 spp: dozens of them beyond x = 1024)
