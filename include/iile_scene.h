@@ -103,6 +103,10 @@ typedef struct iile_material {
     float roughness_v, alpha_v;
     /* uber: "opacity" as an image texture (times the constant `opacity`, as kd_tex .. kt_tex), or -1 */
     int32_t opacity_tex;
+    /* uber: where alpha_v comes from at a hit — -1: the constant alpha_v above ("vroughness" given as a number); -2: whatever the hit's
+     * alpha along u is ("vroughness" not given: roughv = roughu, uber.cpp:83-84), the value for plastic too; >= 0: a float image texture
+     * for "vroughness", mapped like rough_tex. rough_tex is then "uroughness" if that parameter is given, else "roughness" (uber.cpp:79-82) */
+    int32_t rough_tex_v;
 } iile_material;
 
 /* ImageTexture<RGBSpectrum, Spectrum> over a UVMapping2D (src/textures/imagemap.h:78-112,

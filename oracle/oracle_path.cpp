@@ -1656,8 +1656,18 @@ struct Oracle {
                     }
                     b.alpha = rough;
                 }
-                // uber: roughv = vroughness or roughu (uber.cpp:73-86); plastic: one roughness (plastic.cpp:60-64)
-                b.alpha_y = (m.type == IILE_MAT_UBER && m.rough_tex < 0) ? m.alpha_v : b.alpha;
+                // uber: roughv = vroughness (a number or a float image) or roughu (uber.cpp:73-86); plastic: one roughness (plastic.cpp:60-64)
+                b.alpha_y = b.alpha;
+                if (m.type == IILE_MAT_UBER && m.rough_tex_v == -1) b.alpha_y = m.alpha_v;
+                if (m.type == IILE_MAT_UBER && m.rough_tex_v >= 0) {
+                    float rough = tex_evaluate(m.rough_tex_v, is).c[0];
+                    if (m.remap_roughness) {
+                        rough = std::max(rough, 1e-3f);
+                        const float x = trig.log_f(rough);
+                        rough = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+                    }
+                    b.alpha_y = rough;
+                }
                 if (m.type == IILE_MAT_UBER) {  // FresnelDielectric(1.f, e), uber.cpp:70
                     b.micro_eta_i = 1.f;
                     b.micro_eta_t = m.eta;
@@ -3609,6 +3619,7 @@ void oracle_li(const iile_scene_desc *scene, int trig_mode, int n, const int32_t
 static Oracle::Bsdf local_bsdf(const Oracle &orc, const iile_scene_desc *scene, int mat) {
     iile_material m = scene->materials[mat];
     m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = m.opacity_tex = -1;
+    if (m.rough_tex_v >= 0) m.rough_tex_v = -1;
     Isect is;
     is.sn = is.n = V3(0, 0, 1);
     is.sdpdu = V3(1, 0, 0);

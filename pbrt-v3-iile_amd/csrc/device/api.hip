@@ -823,7 +823,7 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
                 mats[i].ks[c] = m.ks[c];
             }
             mats[i].alpha = m.alpha;
-            mats[i].alpha_y = (m.type == IILE_MAT_UBER || m.type == IILE_MAT_GLASS) ? m.alpha_v : m.alpha;
+            mats[i].alpha_y = m.type == IILE_MAT_GLASS ? m.alpha_v : (m.type == IILE_MAT_UBER && m.rough_tex_v != -2) ? m.alpha_v : m.alpha;
             for (int c = 0; c < 3; ++c) mats[i].kr[c] = m.kr[c];
             for (int c = 0; c < 3; ++c) mats[i].kt[c] = m.kt[c];
             const bool oren_nayar = m.type == IILE_MAT_MATTE && m.sigma != 0;
@@ -846,13 +846,14 @@ int iile_scene_create(const iile_scene_desc *d, iile_scene **out) {
             mats[i].kr_tex = d->n_textures > 0 ? m.kr_tex : -1;
             mats[i].kt_tex = d->n_textures > 0 ? m.kt_tex : -1;
             mats[i].opacity_tex = (d->n_textures > 0 && m.type == IILE_MAT_UBER) ? m.opacity_tex : -1;
+            mats[i].rough_tex_v = m.type == IILE_MAT_UBER ? ((m.rough_tex_v >= 0 && d->n_textures == 0) ? -1 : m.rough_tex_v) : -2;
             mats[i].bump_tex = d->n_textures > 0 ? m.bump_tex : -1;
             mats[i].rough_tex = d->n_textures > 0 ? m.rough_tex : -1;
             mats[i].sigma_tex = d->n_textures > 0 ? m.sigma_tex : -1;
             mats[i].remap_roughness = m.remap_roughness;
-            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex, mats[i].opacity_tex})
+            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex, mats[i].opacity_tex, mats[i].rough_tex_v})
                 if (t >= 0) S.textured_materials = 1;
-            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex, mats[i].opacity_tex})
+            for (int t : {mats[i].kd_tex, mats[i].ks_tex, mats[i].kr_tex, mats[i].kt_tex, mats[i].bump_tex, mats[i].rough_tex, mats[i].sigma_tex, mats[i].opacity_tex, mats[i].rough_tex_v})
                 if (t >= d->n_textures) return bail(fail(IILE_ERR_ARG, "material refers to a texture that does not exist"));
         }
         rc = upload(sc, mats.data(), mats.size(), &S.materials);

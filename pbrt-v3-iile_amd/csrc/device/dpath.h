@@ -1512,7 +1512,16 @@ DEV DMaterial textured_material(const DScene &S, const DMaterial &m, const Isect
             rough = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
         }
         r.alpha = rough;
-        r.alpha_y = rough;   // (a roughness image is accepted without uroughness / vroughness only)
+        if (m.rough_tex_v == -2) r.alpha_y = rough;   // roughv = roughu, uber.cpp:83-84 (plastic: one roughness)
+    }
+    if (m.rough_tex_v >= 0) {  // "vroughness" as a float image (uber.cpp:76, 83)
+        float rough = tex_evaluate(S, m.rough_tex_v, is.u, is.v, td).x;
+        if (m.remap_roughness) {
+            rough = mx(rough, 1e-3f);
+            const float x = log_f(rough);
+            rough = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+        }
+        r.alpha_y = rough;
     }
     if (m.opacity_tex >= 0) {  // opacity->Evaluate(*si), uber.cpp:53
         const F3 c = tex_evaluate(S, m.opacity_tex, is.u, is.v, td);

@@ -43,6 +43,7 @@ struct alignas(16) DMaterial {
     float opacity[3];                    // uber: "opacity" ({1, 1, 1} otherwise)
     float alpha_y;                       // uber, glass: the distribution's alpha along v ("vroughness"); = alpha otherwise
     int opacity_tex;                     // uber: image texture for "opacity" (times the constant), or -1
+    int rough_tex_v;                     // uber: -1 alpha_y is the constant, -2 alpha_y = the hit's alpha, >= 0 float image for "vroughness"
 };
 // ImageTexture + MIPMap (iile_texture): level l holds w x h float4 texels (rgb, w unused) at
 // texels[offset[l] + t * w + s], row 0 = bottom scanline

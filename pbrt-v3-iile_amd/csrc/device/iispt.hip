@@ -87,7 +87,7 @@ DEV void vertex_state(const DScene &S, const float4 o4, const float4 d4, const f
     if (material < 0) return;
     const DMaterial &m0 = S.materials[material];
     if (S.textured_materials &&
-        (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0 || m0.opacity_tex >= 0)) {
+        (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0 || m0.opacity_tex >= 0 || m0.rough_tex_v >= 0)) {
         TexDiff td = TexDiff{0, 0, 0, 0};
         // only the camera ray carries differentials (r.ScaleDifferentials(1.0): S.diff_scale is 1 in these kernels)
         if (camera_ray_hit) td = compute_differentials(*is, camera_differentials(S, pf4.x, pf4.y, pf4.z, pf4.w, ro, rd));

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kBlock, IILE_DIRECT_SHADE_WAVES) void k_direct_shad
             // (left by the vertex before, below) further on; computed for every hit when reflected rays carry them, else only
             // where a texture is looked up
             const DMaterial &m0 = S.materials[material];
-            const bool mat_tex = m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0 || m0.opacity_tex >= 0;
+            const bool mat_tex = m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0 || m0.opacity_tex >= 0 || m0.rough_tex_v >= 0;
             if (TEX && S.textured_materials && (mat_tex || B.dir_RD)) {
                 if (depth == 0) {
                     const float4 cs = B.beta[pid];  // pFilm, pLens left by k_direct_generate
@@ -522,7 +522,7 @@ TREE_CALL void tree_interaction(const DScene &S, int prim, F3 ro, F3 rd, float b
 template <bool TEX>
 TREE_CALL void tree_bsdf(const DScene &S, int material, const TexDiff &td, Isect *is, Bsdf *bsdf) {
     const DMaterial &m0 = S.materials[material];
-    const bool mat_tex = m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0 || m0.opacity_tex >= 0;
+    const bool mat_tex = m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0 || m0.opacity_tex >= 0 || m0.rough_tex_v >= 0;
     if (TEX && S.textured_materials && mat_tex) {
         if (m0.bump_tex >= 0) bump(S, m0.bump_tex, td, is);
         *bsdf = make_bsdf<true>(textured_material(S, m0, *is, td), *is);

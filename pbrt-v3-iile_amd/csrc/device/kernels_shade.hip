@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kBlock, shade_waves(TEX)) void k_shade(DScene S, Pa
                         // (path.cpp:159 spawns plain Rays); its auxiliary rays are a function of the camera
                         // sample, rebuilt here from the path's pixel instead of travelling with the ray.
                         const DMaterial &m0 = S.materials[material];
-                        if (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0 || m0.opacity_tex >= 0) {
+                        if (m0.kd_tex >= 0 || m0.ks_tex >= 0 || m0.kr_tex >= 0 || m0.kt_tex >= 0 || m0.bump_tex >= 0 || m0.rough_tex >= 0 || m0.sigma_tex >= 0 || m0.opacity_tex >= 0 || m0.rough_tex_v >= 0) {
                             TexDiff td = TexDiff{0, 0, 0, 0};
                             if (bounce == 0) {
                                 int px = 0, py = 0;

@@ -729,7 +729,8 @@ class Loader {
             if (p.strs.size() != 1) return fail("bad texture reference for \"" + p.name + "\"");
             auto it = gs_.textures.find(p.strs[0]);
             if (it == gs_.textures.end()) return fail("Couldn't find texture named \"" + p.strs[0] + "\" for parameter \"" + p.name + "\"");
-            if (it->second.image >= 0 && it->second.is_float && (p.name == "bumpmap" || p.name == "roughness" || p.name == "sigma")) {
+            if (it->second.image >= 0 && it->second.is_float &&
+                (p.name == "bumpmap" || p.name == "roughness" || p.name == "uroughness" || p.name == "vroughness" || p.name == "sigma")) {
                 (*image_of)[p.name] = it->second.image;
                 p.strs.clear();
                 p.type = p.name == "bumpmap" ? "bumpimage" : (p.name == "sigma" ? "sigmaimage" : "roughimage");  // consumed below; no material reads a parameter of these types
@@ -771,6 +772,7 @@ class Loader {
         iile_material m;
         std::memset(&m, 0, sizeof(m));
         m.kd_tex = m.ks_tex = m.kr_tex = m.kt_tex = m.bump_tex = m.rough_tex = m.sigma_tex = m.opacity_tex = -1;
+        m.rough_tex_v = -2;   // (alpha_v follows alpha: every material but an uber / glass with "vroughness")
         m.opacity[0] = m.opacity[1] = m.opacity[2] = 1.f;
         auto image = [&](const char *param) {
             auto it = image_of.find(param);
@@ -805,10 +807,11 @@ class Loader {
                 ps.rgb("Kt", kt);
                 ps.rgb("opacity", op);
                 for (int i = 0; i < 3; ++i) m.kr[i] = kr[i], m.kt[i] = kt[i], m.opacity[i] = op[i];
-                // uber.cpp:73-86: roughu = uroughness or roughness, roughv = vroughness or roughu
+                // uber.cpp:73-86: roughu = uroughness or roughness, roughv = vroughness or roughu (numbers here; images: below)
                 const float ur = ps.one_float("uroughness", m.roughness), vr = ps.one_float("vroughness", ur);
                 m.roughness = ur;
                 m.roughness_v = vr;
+                if (const Param *pv = ps.find("vroughness")) m.rough_tex_v = pv->type == "roughimage" ? image("vroughness") : -1;
                 m.eta = ps.find("eta") ? ps.one_float("eta", 1.5f) : ps.one_float("index", 1.5f);
             }
             if (!uber) m.roughness_v = m.roughness;
@@ -832,6 +835,7 @@ class Loader {
             const float ur = ps.one_float("uroughness", 0.f), vr = ps.one_float("vroughness", 0.f);
             m.roughness = ur;
             m.roughness_v = vr;
+            m.rough_tex_v = -1;
             m.remap_roughness = ps.one_bool("remaproughness", true) ? 1 : 0;
             if (ur != 0.f || vr != 0.f) {   // `bool isSpecular = urough == 0 && vrough == 0`, glass.cpp:63
                 m.alpha = m.remap_roughness ? roughness_to_alpha(ur) : ur;
@@ -861,14 +865,19 @@ class Loader {
                 }
                 m.sigma_tex = image("sigma");
             }
-        if (const Param *rp = ps.find("roughness"))
-            if (rp->type == "roughimage") {
-                if ((m.type != IILE_MAT_PLASTIC && m.type != IILE_MAT_UBER) || ps.find("uroughness") || ps.find("vroughness")) {
-                    fail("roughness: a float \"imagemap\" texture is supported on plastic and on uber without uroughness / vroughness only");
-                    return -1;
-                }
-                m.rough_tex = image("roughness");
+        {   // float images for the roughness parameters: "roughness" (plastic, uber), "uroughness" / "vroughness" (uber)
+            const Param *rp = ps.find("roughness"), *up = ps.find("uroughness"), *vp = ps.find("vroughness");
+            const bool r_img = rp && rp->type == "roughimage", u_img = up && up->type == "roughimage", v_img = vp && vp->type == "roughimage";
+            if ((r_img && m.type != IILE_MAT_PLASTIC && m.type != IILE_MAT_UBER) || ((u_img || v_img) && m.type != IILE_MAT_UBER)) {
+                fail("roughness: a float \"imagemap\" texture is supported on plastic (\"roughness\") and uber (\"roughness\", \"uroughness\", \"vroughness\") only");
+                return -1;
             }
+            // roughu = roughnessu ? roughnessu : roughness (uber.cpp:79-82): "roughness" is not looked at when "uroughness" is there
+            if (m.type == IILE_MAT_UBER && up)
+                m.rough_tex = u_img ? image("uroughness") : -1;
+            else if (r_img)
+                m.rough_tex = image("roughness");
+        }
         if (const Param *bp = ps.find("bumpmap")) {  // GetFloatTextureOrNull("bumpmap") of every material's Create*
             if (bp->type != "bumpimage" || m.type == IILE_MAT_GLASS) {
                 fail("bumpmap: only a float \"imagemap\" texture on matte / plastic / uber / mirror is supported");

@@ -239,6 +239,12 @@ def boxroom_pbrt(xres=64, yres=64, spp=4, ico_levels=4, n_blobs=6, wall_n=24, se
             mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [%g %g %g] "color Kr" [.1 .1 .1] "float uroughness" [%g] "float vroughness" [%g] "float index" [%g]%s' % (
                 *rng.uniform(.05, .4, 3), *rng.uniform(.3, .8, 3), rng.uniform(.02, .5), rng.uniform(.02, .5), rng.uniform(1.2, 1.8),
                 ' "color opacity" [.7 .7 .7]' if b % 2 else "")
+        elif materials == "aniso" and tex is not None and b % 3 == 2:  # ... with float images for uroughness / vroughness / roughness (uber.cpp:73-86)
+            which = ('"texture uroughness" ["rough"] "float vroughness" [.1]',                                  # u from an image, v a number
+                     '"texture roughness" ["rough"] "texture vroughness" ["sigma"] "bool remaproughness" ["false"]',  # u from "roughness", v from another image
+                     '"texture roughness" ["rough"] "float uroughness" [.3] "texture vroughness" ["rough"]',      # "roughness" is not looked at
+                     '"texture uroughness" ["rough"]')[(b // 3) % 4]                                             # v follows u
+            mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.5 .5 .5] %s "float index" [%g]' % (*rng.uniform(.1, .4, 3), which, rng.uniform(1.2, 1.8))
         elif materials == "ubertrans" and b % 4 == 0:  # UberMaterial's pass-through (uber.cpp:53-61): a grey and a coloured opacity
             op = (.35, .35, .35) if b % 8 == 0 else tuple(rng.uniform(.1, .9, 3))
             mat = 'Material "uber" "color Kd" [%g %g %g] "color Ks" [.2 .2 .2] "float roughness" [%g] "color opacity" [%g %g %g] "float index" [%g]' % (

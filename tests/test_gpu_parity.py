@@ -608,6 +608,18 @@ WorldEnd
     nn = np.random.default_rng(5).uniform(0.0, 3.0, valid.shape + (32, 32, 3)).astype(np.float32)
     out = gpu.iispt_gather(task, valid, pos, dr, nn)
     assert np.array_equal(out.view(np.uint32), oracle.iispt_gather(room, task, valid, pos, dr, nn).view(np.uint32)) and (out[..., 3] == 0.5).sum() > 500
+    # float images for "uroughness" / "vroughness" / "roughness" (uber.cpp:73-86: u from an image and v a number, both from images, "roughness"
+    # ignored beside "uroughness", v following u's image), in the textured room
+    path = tmp_path / "boxroom_aniso_tex.pbrt"
+    path.write_text(boxroom.boxroom_pbrt(xres=96, yres=64, spp=4, materials="aniso", maxdepth=8, n_blobs=12, ico_levels=3, textures=str(tmp_path / "tex")))
+    room = binding.HostScene(path=str(path))
+    gpu = binding.GpuScene(room)
+    film, st = gpu.render(collect_stats=True)
+    ref, ost = oracle.render(room)
+    assert_bitwise(film, ref, "roughness images per axis: film")
+    assert st["closest_rays"] == ost["regular_rays"] and st["shadow_rays"] == ost["shadow_rays"] and st["path_length"] == ost["path_length"]
+    assert_bitwise(gpu.render()[0], ref, "roughness images per axis: film, uninstrumented kernels")
+    assert np.array_equal(gpu.render_direct(2).view(np.uint64), oracle.iispt_direct(room, 2).view(np.uint64))
 
 
 def test_glass_scenes_bitwise(binding, oracle, tmp_path):

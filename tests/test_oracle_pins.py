@@ -1286,6 +1286,24 @@ WorldEnd
     ball = rgb[3:7, 3:7]
     # (single scattering on a rough surface loses energy, and a lossy ball lowers the whole furnace's equilibrium: below 1 everywhere)
     assert 0.3 < float(ball.mean()) < float(rgb.max()) < 1.005, (float(ball.mean()), float(rgb.max()))
+    # "uroughness" / "vroughness" / "roughness" as float images (uber.cpp:73-86): flat images are the numbers they hold — the same paths
+    # (equal ray counts), radiance equal up to the rounding of the filtered lookups; "roughness" is not looked at beside "uroughness"
+    for val, name in ((0.4, "flat4"), (0.05, "flat05"), (0.9, "flat9")):
+        (tmp_path / (name + ".pfm")).write_bytes(b"PF\n4 4\n-1.0\n" + np.full((4, 4, 3), val, np.float32).tobytes())
+    tex = "".join('Texture "%s" "float" "imagemap" "string filename" ["%s"] "bool gamma" ["false"]\n  ' % (n, tmp_path / (n + ".pfm")) for n in ("flat4", "flat05", "flat9"))
+    const = 'Material "uber" "color Kd" [0 0 0] "color Ks" [1 1 1] "float uroughness" [.4] "float vroughness" [.05] "float index" [50]'
+    results = []
+    for mat in (const,
+                tex + 'Material "uber" "color Kd" [0 0 0] "color Ks" [1 1 1] "texture uroughness" ["flat4"] "texture vroughness" ["flat05"] "float index" [50]',
+                tex + 'Material "uber" "color Kd" [0 0 0] "color Ks" [1 1 1] "texture roughness" ["flat9"] "texture uroughness" ["flat4"] "float vroughness" [.05] "float index" [50]',
+                tex + 'Material "uber" "color Kd" [0 0 0] "color Ks" [1 1 1] "texture roughness" ["flat4"] "texture vroughness" ["flat05"] "float index" [50]'):
+        fp.write_text(head.replace(const, mat))
+        assert mat in fp.read_text()
+        sc = binding.HostScene(path=str(fp))
+        film, st = oracle.render(sc, trig_mode=ob.TRIG_LIBM)
+        results.append((float(sc.film_to_rgb(film).mean(dtype=np.float64)), st["regular_rays"], st["shadow_rays"]))
+    for r in results[1:]:
+        assert abs(r[0] - results[0][0]) < 1e-4 and r[1:] == results[0][1:], results
 
 
 def _killeroo_with(tmp_path, integrator_line, xres, yres, spp, pixel_filter=""):
