@@ -255,10 +255,25 @@ def main_iispt(args):
     b = ge._load_binding()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
-        raise SystemExit("--workload iispt is a one-GPU workload (the frame's tasks do not shard in the reference either: "
-                         "its render threads share one schedule monitor); run --gpus 1")
-    torch.cuda.set_device(0)
+    # N > 1 (strong scaling of the ONE frame): tasks dealt by their number, direct passes in contiguous blocks, one all-reduce (RCCL)
+    # per film monitor — iispt_frame.py; the reference's render threads draw tasks and pass numbers from one schedule monitor
+    # (iispt.cpp:386-427), and a task / a pass is the same whoever renders it
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --workload iispt --gpus {args.gpus} ...`")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
     nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
     import iispt_torch_reference as ref_mod   # tests/: the PyTorch module (random weights for the frame; the checker of the in-run agreement test)
     frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
@@ -276,10 +291,11 @@ def main_iispt(args):
         frame = frame_mod.IisptFrame(b, gpu, pipe)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        frame.run_batched(n_tasks, radius_start=radius)
+        frame.run_batched(n_tasks, radius_start=radius, rank=rank, nranks=world)
         ev[1].record()
-        frame.run_direct(frame_mod.DIRECT_SAMPLES)
+        frame.run_direct(frame_mod.DIRECT_SAMPLES, rank=rank, nranks=world)
         ev[2].record()
+        frame.reduce_monitors(dist)   # (N = 1: nothing to add)
         img = frame.image()
         ev[3].record()
         pipe.events = None
@@ -287,7 +303,7 @@ def main_iispt(args):
 
     for _ in range(max(args.warmup, 1)):   # (the first frame allocates the workspaces)
         step()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     last = None
     stage_events, frame_events = [], []
@@ -296,10 +312,24 @@ def main_iispt(args):
         last = step(rec)
         stage_events.append(rec)
         frame_events.append(last[2])
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     frame, img, _ = last
     probes = frame.stats["probes"]
+    if dist is not None:   # the slowest rank's time; every rank's probes (a rank's statistics cover its own tasks)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        n = torch.tensor([probes, frame.stats["hemi_points"], frame.stats["pixels"]], dtype=torch.int64, device="cuda")
+        per_rank = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(per_rank, n)
+        n = sum(per_rank)
+        probes, frame.stats["hemi_points"], frame.stats["pixels"] = int(n[0]), int(n[1]), int(n[2])
+        rank_probes = [int(x[0]) for x in per_rank]
+        if rank != 0:
+            dist.barrier()
+            dist.destroy_process_group()
+            return None
     stage_ms = {}
     for rec in stage_events:
         for name, e0, e1 in rec:
@@ -335,8 +365,8 @@ def main_iispt(args):
         task0 = b.IisptTask(x0, y0, x1, y1, ts, 0, 0)
         valid, hp, hd = gpu.iispt_hemi_points_batch([task0])
         sel = np.flatnonzero(valid == 1)[:16]
-        pred, inten, nrm, dist = pipe(hp[sel], hd[sel])
-        xr, means = ref_mod.normalize_downstream(inten.cpu(), nrm.cpu(), dist.cpu())
+        pred, inten, nrm, dst = pipe(hp[sel], hd[sel])
+        xr, means = ref_mod.normalize_downstream(inten.cpu(), nrm.cpu(), dst.cpu())
         want = ref_mod.transform_upstream(module(xr), means).double().numpy().ravel()
         got = pred.cpu().double().numpy().ravel()
         mx = float(np.abs(want).max())
@@ -352,9 +382,9 @@ def main_iispt(args):
         "metric": "IISPT probes/s on killeroo-simple 1080p (one frame: hemi points + probe pass + network + gather, direct pass, merge)",
         "value": round(probes * args.steps / elapsed, 1),
         "unit": "probes/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
         "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
         "dtype": "f32 activations and accumulation; matrix products on fp16 pairs (hi + lo: 22 significant bits) of every operand",
         "data": "scenes/killeroo-simple.pbrt; IISPTNet with random-initialised weights (none ship with the reference): the image means nothing, the work is the reference's",
         "config": {"workload": f"IISPT frame, killeroo-simple {args.xres}x{args.yres}: radius 10 -> {n_tasks} tasks of 100 x 100 pixels, {frame.stats['hemi_points']} hemi points, "
@@ -383,7 +413,12 @@ def main_iispt(args):
             "agreement_with_the_module": chk},
         "built": ge.build_provenance(compiled_now),
     }
-    if args.cpu_seconds > 0:
+    if world > 1:
+        out["per_rank"] = {"probes": rank_probes, "note": "tasks dealt by their number (rank = task mod N), the 16 direct passes in contiguous blocks, one RCCL all-reduce per "
+                                                             "film monitor (2 x 66 MB of doubles at 1080p); stage times above are rank 0's share"}
+        dist.barrier()
+        dist.destroy_process_group()
+    if args.cpu_seconds > 0 and world == 1:
         out["cpu_baseline"] = iispt_cpu_baseline(b, ref_mod, frame_mod, scene, module, args.cpu_seconds)
         out["speedup_vs_one_cpu_thread"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
         threads, _q = effective_cpus()
@@ -443,7 +478,9 @@ def main():
         raise SystemExit(f"bench.py refuses to run with {bad_env} set: those switches change what the kernels do")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.workload == "iispt":
-        print(json.dumps(main_iispt(args)), flush=True)
+        line = main_iispt(args)
+        if line is not None:   # (rank 0 prints)
+            print(json.dumps(line), flush=True)
         return
     out = main_path(args)
     subs = [x for x in args.sub_configs.split(",") if x and x != "none"]

@@ -95,11 +95,15 @@ class IisptFrame:
         return self.image()
 
     @torch.no_grad()
-    def run_batched(self, n_tasks, radius_start=100.0, max_probes=32768, timers=None):
+    def run_batched(self, n_tasks, radius_start=100.0, max_probes=32768, timers=None, rank=0, nranks=1):
         """The same film as run(): a task's result depends only on its rectangle, its sampler counter and its seed, all of
         which the schedule fixes in advance — so the stages run task-major instead of interleaved: hemi points of a group of
         tasks, ONE probe pass and ONE network call over all their probes (the reference pays a pipe round trip per probe),
-        then the gathers. Groups are cut at max_probes hemi points. timers: dict that receives seconds per stage."""
+        then the gathers. Groups are cut at max_probes hemi points. timers: dict that receives seconds per stage.
+        rank / nranks: this process renders the tasks whose number is rank modulo nranks (the reference's render threads draw
+        tasks from one schedule monitor, iispt.cpp:386-427: which thread renders which task does not change the task); counters and
+        seeds advance over ALL tasks, so a task is the same task whoever renders it, and the monitors of the ranks add up to the
+        single-rank frame's (reduce_monitors)."""
         import time
         h, w = self.gpu.host.film_shape
         tasks = list(schedule((0, 0, w, h), n_tasks, radius_start))
@@ -117,12 +121,17 @@ class IisptFrame:
                 x0, y0, x1, y1, ts = tasks[i]
                 task = self.b.IisptTask(x0, y0, x1, y1, ts, self.counter, self.rng_seed)
                 nx, ny = task.grid()
-                group.append(task)
-                n_pts += nx * ny
-                n_pix += (x1 - x0) * (y1 - y0)
+                if i % nranks == rank:
+                    group.append(task)
+                    n_pts += nx * ny
+                    n_pix += (x1 - x0) * (y1 - y0)
                 self.counter += nx * ny + (x1 - x0) * (y1 - y0)
                 self.rng_seed += (x1 - x0) * (y1 - y0)
                 i += 1
+            if not group and i < len(tasks):
+                continue   # (none of this stretch of the schedule is this rank's)
+            if not group:
+                break
             # every stage runs over the whole group at once (iile_iispt_*_batch: one set of launches for all its tasks)
             t0 = time.time()
             stream = torch.cuda.current_stream().cuda_stream   # ONE stream orders the whole indirect pass (include/iile_gpu.h)
@@ -151,13 +160,35 @@ class IisptFrame:
         torch.cuda.synchronize()
         return self.image()
 
-    def run_direct(self, n_passes=DIRECT_SAMPLES):
+    def run_direct(self, n_passes=DIRECT_SAMPLES, rank=0, nranks=1):
         """IisptRenderRunner::run_direct: n_passes more passes of DirectProgressiveIntegrator::RenderOnePass into the direct
-        monitor (iile_render_direct; pass numbers continue where the last call stopped)."""
-        self.gpu.render_direct(n_passes, first_pass=self.direct_passes, film_device_ptr=self.film_direct.data_ptr(),
-                               accumulate=self.direct_passes > 0, stream=torch.cuda.current_stream().cuda_stream)
+        monitor (iile_render_direct; pass numbers continue where the last call stopped). rank / nranks: this process renders
+        the contiguous block [n rank / N, n (rank + 1) / N) of them (a pass is its number — seed 6284 + 17 p — whoever renders it:
+        the reference's threads draw pass numbers from the schedule monitor, iisptrenderrunner.cpp:617-627)."""
+        p0, p1 = (n_passes * rank) // nranks, (n_passes * (rank + 1)) // nranks
+        if p1 > p0:
+            self.gpu.render_direct(p1 - p0, first_pass=self.direct_passes + p0, film_device_ptr=self.film_direct.data_ptr(),
+                                   accumulate=self.direct_passes > 0, stream=torch.cuda.current_stream().cuda_stream)
+        elif self.direct_passes == 0:
+            self.film_direct.zero_()
         self.direct_passes += n_passes
         return self.film_direct
+
+    def reduce_monitors(self, dist=None, others=()):
+        """The ranks' film monitors added up: IisptFilmMonitor::add_n_samples is a sum of doubles per pixel, so the monitors of
+        ranks that rendered disjoint tasks and passes add to the frame's (an indirect pixel belongs to one task per sweep; a direct
+        pixel's passes are float values summed in doubles — exact whatever the order, short of 2^29 between the largest and the
+        smallest). dist: an initialised torch.distributed (one all-reduce per monitor, RCCL); others: frames of the other ranks
+        in THIS process (what the tests and tools/iispt_shard_probe.py do on one GPU)."""
+        for o in others:
+            self.film += o.film
+            self.film_direct += o.film_direct
+            for k in self.stats:
+                self.stats[k] += o.stats[k]
+        if dist is not None:
+            dist.all_reduce(self.film)
+            dist.all_reduce(self.film_direct)
+        return self
 
     @staticmethod
     def _normalised(monitor):

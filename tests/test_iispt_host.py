@@ -212,3 +212,45 @@ def test_cpp_iispt_integrator_writes_the_python_frames_image(binding, tmp_path):
     b.forward(x.data_ptr(), yb.data_ptr(), 5)
     torch.cuda.synchronize()
     assert torch.equal(ya, yb)
+
+
+@pytest.mark.gpu
+def test_frame_shards_add_up_to_the_frame(binding):
+    """The IISPT frame over several GPUs (iispt_frame.py: rank / nranks): tasks dealt by their number, direct passes in contiguous
+    blocks, counters and seeds advancing over ALL tasks — so every rank renders exactly the tasks and passes the single process
+    would, and the ranks' film monitors (sums of doubles per pixel, IisptFilmMonitor::add_n_samples) add up to the frame's. The
+    ranks are played one after the other on this GPU; their monitors added as the all-reduce would add them: indirect monitor,
+    direct monitor and merged image equal to the single-rank frame's bit for bit, for 2, 3 and 5 ranks, over two sweeps and the start
+    of a third (a pixel then belongs to tasks of different ranks)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    sys.path.insert(0, REPO)
+    nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+    import iispt_torch_reference as ref_mod
+    frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
+    w, h, n_tasks, n_direct = 96, 80, 21, 5
+    torch.manual_seed(3)
+    scene = binding.HostScene(xres=w, yres=h, spp=1)
+    gpu = binding.GpuScene(scene)
+    pipe = nn_mod.IisptPipeline(gpu, net=ref_mod.IISPTNet().eval())
+    whole = frame_mod.IisptFrame(binding, gpu, pipe)
+    whole.run_batched(n_tasks, radius_start=4.0)
+    whole.run_direct(n_direct)
+    want = whole.image().cpu().numpy()
+    assert float(want.max()) > 0 and whole.stats["tasks"] == n_tasks
+    for nranks in (2, 3, 5):
+        parts = []
+        for rank in range(nranks):
+            f = frame_mod.IisptFrame(binding, gpu, pipe)
+            f.run_batched(n_tasks, radius_start=4.0, rank=rank, nranks=nranks)
+            f.run_direct(n_direct, rank=rank, nranks=nranks)
+            parts.append(f)
+        assert all(0 < f.stats["tasks"] < n_tasks for f in parts) and sum(f.stats["tasks"] for f in parts) == n_tasks
+        # a rank's indirect monitor covers its own tasks only
+        assert (parts[0].film[..., 3] > 0).sum() < (whole.film[..., 3] > 0).sum()
+        total = parts[0].reduce_monitors(others=parts[1:])
+        assert total.stats == whole.stats
+        assert torch.equal(total.film, whole.film), nranks
+        assert torch.equal(total.film_direct, whole.film_direct), nranks
+        assert np.array_equal(total.image().cpu().numpy().view(np.uint32), want.view(np.uint32)), nranks
