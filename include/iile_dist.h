@@ -56,6 +56,10 @@ int iile_dist_ranks_seen(const iile_dist *comm);
  * the ranks, in place, into rank `root`'s buffer; the other ranks' buffers are unchanged. Enqueued on `stream`
  * (a hipStream_t, NULL = the null stream) behind the render that filled the film; returns without waiting. */
 int iile_dist_film_reduce(iile_dist *comm, float *film_xyzw_dev, int64_t n_pixels, int32_t root, void *stream);
+/* The IISPT frame's film monitors (IisptFilmMonitor: sums of doubles per pixel, add_n_samples, iisptfilmmonitor.cpp:47-72) when the
+ * frame's tasks and direct passes are shared out over the ranks: n_doubles doubles in device memory summed over the ranks, in place,
+ * into rank `root`'s buffer; enqueued on `stream` like the film merge above. */
+int iile_dist_monitor_reduce(iile_dist *comm, double *monitor_dev, int64_t n_doubles, int32_t root, void *stream);
 /* All ranks have enqueued everything before it: completes on `stream` when every rank has reached it. */
 int iile_dist_barrier(iile_dist *comm, void *stream);
 /* Job totals for the host's report (ray counters, wall time): n values summed / maximised over the ranks in place,

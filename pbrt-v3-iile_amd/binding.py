@@ -138,7 +138,7 @@ GPU_SYMBOLS = ["iile_device_count", "iile_last_error", "iile_scene_create", "iil
                "iile_iispt_hemi_points", "iile_iispt_gather", "iile_iispt_hemi_points_batch", "iile_iispt_gather_batch", "iile_bvh_build_hlbvh", "iile_bvh_pack_probe", "iile_render_direct",
                "iile_wide_ref_shift", "iile_render_status", "iile_test_patch_capacity", "iile_iispt_net_create", "iile_iispt_net_load", "iile_iispt_net_forward", "iile_iispt_net_predict", "iile_iispt_net_destroy"]
 DIST_SYMBOLS = ["iile_dist_unique_id", "iile_dist_create", "iile_dist_create_deadline", "iile_dist_abort", "iile_dist_wait", "iile_dist_destroy", "iile_dist_rank", "iile_dist_size", "iile_dist_ranks_seen",
-                "iile_dist_film_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
+                "iile_dist_film_reduce", "iile_dist_monitor_reduce", "iile_dist_barrier", "iile_dist_sum_u64", "iile_dist_max_f64",
                 "iile_dist_rendezvous_file", "iile_dist_rendezvous_file_token", "iile_dist_rendezvous_done", "iile_dist_all_ok",
                 "iile_dist_last_error"]
 DIST_ID_BYTES = 128

@@ -21,6 +21,8 @@
 // and the films are merged on rank 0 by one RCCL reduction (include/iile_dist.h); rank 0 writes the image.
 // --gpurank 0/1 is the same code path with a communicator of one rank (tools/multi_gpu_cmdline.sh prints the N-rank
 // command lines).
+// The IISPT integrator over several GPUs is --gpurank too: rank R renders the tasks whose number is R modulo N and its block of the
+// direct passes, the two film monitors are summed on rank 0 (iile_dist_monitor_reduce), which merges and writes the images.
 //
 // Mirrors src/main/pbrt.cpp:97-219 (argument loop, ParseFile, Render) on top of
 // the C ABI: libiile_host loads and flattens the scene, libiile_gpu renders it,
@@ -188,14 +190,25 @@ int main(int argc, char **argv) {
     if (out.empty()) out = scene.ok() ? scene.film_filename() : std::string("pbrt.exr");
     if (integrator_choice < 0) integrator_choice = scene.ok() ? scene.integrator() : IILE_INTEGRATOR_PATH;
     if (integrator_choice == IILE_INTEGRATOR_IISPT) {
-        if (ranked || (gpus_given && gpus != 1)) {
-            fprintf(stderr, "iile_pbrt: the IISPT frame runs on one device (its tasks share two film monitors and one network)\n");
+        if (gpus_given && gpus != 1) {
+            fprintf(stderr, "iile_pbrt: the IISPT frame over several GPUs is one process per GPU (--gpurank R/N --rendezvous FILE), not --gpus N\n");
             if (comm) iile_dist_destroy(comm);
             return 1;
         }
+        if (ranked) iispt.rank = gpu_rank, iispt.nranks = gpu_nranks, iispt.comm = comm;
+        if (const char *e = getenv("IILE_DEBUG_IISPT_SHARD")) {   // tests: the share of rank R of N alone, no communicator ("R/N")
+            int r = 0, n = 1;
+            if (!ranked && sscanf(e, "%d/%d", &r, &n) == 2 && n >= 1 && r >= 0 && r < n) iispt.rank = r, iispt.nranks = n;
+        }
         std::unique_ptr<iile::GpuIisptIntegrator> ii(iile::CreateGpuIisptIntegrator(ps, out, iispt));
-        if (!ii->Render(scene)) return 1;
+        const bool ok_ii = ii->Render(scene);
+        if (comm) {
+            if (ok_ii) iile_dist_destroy(comm);
+            else iile_dist_abort(comm);
+        }
+        if (!ok_ii) return 1;
         lap("IISPT frame rendered and written");
+        if (gpu_rank != 0) return 0;
         if (!quiet)
             printf("IISPT: %d tasks, %lld hemi points, %lld probes, %lld pixels gathered, %d direct passes -> %s\n", ii->stats.tasks, ii->stats.hemi_points,
                    ii->stats.probes, ii->stats.pixels, iispt.direct_samples, out.c_str());

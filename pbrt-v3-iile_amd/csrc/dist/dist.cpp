@@ -245,6 +245,13 @@ int iile_dist_film_reduce(iile_dist *d, float *film, int64_t n_pixels, int32_t r
     return settle(d, ncclReduce(film, film, size_t(n_pixels) * 4, ncclFloat32, ncclSum, root, d->comm, static_cast<hipStream_t>(stream)), "ncclReduce");
 }
 
+int iile_dist_monitor_reduce(iile_dist *d, double *monitor, int64_t n_doubles, int32_t root, void *stream) {
+    if (!d || !monitor || n_doubles < 0 || root < 0 || root >= d->size) return fail(IILE_ERR_ARG, "iile_dist_monitor_reduce: bad argument");
+    DEAD_CHECK(d, "iile_dist_monitor_reduce");
+    if (n_doubles == 0) return IILE_OK;
+    return settle(d, ncclReduce(monitor, monitor, size_t(n_doubles), ncclFloat64, ncclSum, root, d->comm, static_cast<hipStream_t>(stream)), "ncclReduce");
+}
+
 int iile_dist_barrier(iile_dist *d, void *stream) {
     if (!d) return fail(IILE_ERR_ARG, "iile_dist_barrier: null communicator");
     DEAD_CHECK(d, "iile_dist_barrier");

@@ -39,6 +39,12 @@ struct IisptOptions {
     int max_probes = 32768;    // hemi points per group of tasks (one set of probe-pass / gather launches each)
     int net_batch = 8192;      // probes per set of network launches: 1.19 MiB of activations each; no faster beyond (iile_iispt_net_predict halves it if the device is short of memory)
     std::string indirect_out, direct_out;   // /tmp/iispt_indirect.exr, /tmp/iispt_direct.exr of the reference; empty: not written
+    // The frame over several GPUs, one process each (iile_pbrt --gpurank r/N): this process renders the tasks whose number is rank modulo
+    // nranks and the block [n rank / N, n (rank + 1) / N) of the direct passes — what the reference's threads draw from ONE schedule
+    // monitor (iispt.cpp:386-427) is the same task or pass whoever renders it — and the two film monitors are summed to rank 0
+    // (iile_dist_monitor_reduce) before the merge. comm == nullptr with nranks > 1: the share alone (its images cover its tasks: tests).
+    int rank = 0, nranks = 1;
+    iile_dist *comm = nullptr;
 };
 
 struct IisptScheduleTask {
@@ -141,8 +147,10 @@ class GpuIisptIntegrator : public Integrator {
                 group_pass = s.pass;
                 const long long pts = (long long)iile_iispt_grid_count(t.x0, t.x1, t.tilesize) * iile_iispt_grid_count(t.y0, t.y1, t.tilesize);
                 const long long pix = (long long)(t.x1 - t.x0) * (t.y1 - t.y0);
-                group.push_back(t);
-                n_pts += pts;
+                if (k % opt_.nranks == opt_.rank) {   // (counter and seed advance over every task: a task is the same task whoever renders it)
+                    group.push_back(t);
+                    n_pts += pts;
+                }
                 counter += uint32_t(pts + pix);
                 seed += uint64_t(pix);
             }
@@ -152,15 +160,31 @@ class GpuIisptIntegrator : public Integrator {
         // ---- the direct pass: IisptRenderRunner::run_direct, passes 0 .. iileDirectSamples - 1
         if (ok) {
             iile_direct_params dp = {};
-            dp.n_passes = opt_.direct_samples;
+            dp.first_pass = (opt_.direct_samples * opt_.rank) / opt_.nranks;
+            dp.n_passes = (opt_.direct_samples * (opt_.rank + 1)) / opt_.nranks - dp.first_pass;
             dp.film_on_device = 1;
             dp.stream = stream_;
-            if (opt_.direct_samples > 0)
+            if (dp.n_passes > 0)
                 ok = Check(iile_render_direct(gpu_, &dp, film_direct));
             else
                 ok = Check(iile_device_zero(film_direct, n_pix * 4 * sizeof(double), stream_));
         }
         lap("direct pass");
+        // ---- several GPUs: every rank says whether its share is whole, then the two monitors are summed to rank 0
+        if (opt_.comm) {
+            int32_t all_ok = 0;
+            if (iile_dist_all_ok(opt_.comm, ok ? 1 : 0, &all_ok) != IILE_OK) ok = Fail(iile_dist_last_error());
+            ok = ok && all_ok != 0;
+            if (ok && (iile_dist_monitor_reduce(opt_.comm, film_indirect, int64_t(n_pix) * 4, 0, stream_) != IILE_OK ||
+                       iile_dist_monitor_reduce(opt_.comm, film_direct, int64_t(n_pix) * 4, 0, stream_) != IILE_OK ||
+                       iile_dist_wait(opt_.comm, stream_) != IILE_OK))
+                ok = Fail(iile_dist_last_error());
+            uint64_t totals[4] = {uint64_t(stats.tasks), uint64_t(stats.hemi_points), uint64_t(stats.probes), uint64_t(stats.pixels)};
+            if (ok && iile_dist_sum_u64(opt_.comm, totals, 4) != IILE_OK) ok = Fail(iile_dist_last_error());
+            stats.tasks = int(totals[0]), stats.hemi_points = (long long)totals[1], stats.probes = (long long)totals[2], stats.pixels = (long long)totals[3];
+            lap("monitors summed over the ranks");
+        }
+        const bool writes = !opt_.comm || opt_.rank == 0;   // (rank 0 holds the summed monitors)
         // ---- iispt.cpp:425-446: the two monitors as images, their merge as the frame
         std::vector<float> rgb(n_pix * 3);
         auto write = [&](const double *a, const double *b, const std::string &path) {
@@ -171,13 +195,13 @@ class GpuIisptIntegrator : public Integrator {
             if (iile_host_write_image(path.c_str(), f, rgb.data()) != 0) return Fail(iile_host_last_error());
             return true;
         };
-        if (ok && (!opt_.indirect_out.empty() || !opt_.direct_out.empty())) {
+        if (ok && writes && (!opt_.indirect_out.empty() || !opt_.direct_out.empty())) {
             // to_intensity_film of ONE monitor = the merge with an empty one (a pixel of weight 0 contributes its sums, zeros)
             double *zero = nullptr;
             ok = Alloc(reinterpret_cast<void **>(&zero), n_pix * 4 * sizeof(double)) && Check(iile_device_zero(zero, n_pix * 4 * sizeof(double), stream_)) &&
                  write(film_indirect, zero, opt_.indirect_out) && write(film_direct, zero, opt_.direct_out);
         }
-        ok = ok && write(film_direct, film_indirect, output_);
+        ok = ok && (!writes || write(film_direct, film_indirect, output_));
         lap("images written");
         if (stream_) (void)iile_stream_wait(stream_);
         for (void *p : allocs_) iile_device_free(p);

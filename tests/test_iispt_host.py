@@ -81,7 +81,8 @@ def test_weights_file_layout(binding, tmp_path):
 
 
 def test_cli_refuses_an_iispt_frame_it_cannot_render(tmp_path):
-    """Errors of the IISPT branch that need no device: no weights, several devices, a probe side the network does not take."""
+    """Errors of the IISPT branch that need no device: no weights, several devices in one process (the frame over several GPUs is
+    one process per GPU: --gpurank), a probe side the network does not take."""
     def run(*args, env=None):
         e = dict(os.environ)
         e.pop("IILE_IISPT_NET", None)
@@ -91,7 +92,7 @@ def test_cli_refuses_an_iispt_frame_it_cannot_render(tmp_path):
     p = run("--integrator", "iispt")
     assert p.returncode == 1 and "needs the network's weights" in p.stdout
     p = run("--integrator", "iispt", "--gpus", "2", "--iisptNet=x")
-    assert p.returncode == 1 and "runs on one device" in p.stdout
+    assert p.returncode == 1 and "one process per GPU" in p.stdout
     p = run("--integrator", "iispt", "--iisptNet=x", "--iispt_hemi_size=16")
     assert p.returncode == 1 and "32 x 32 probes" in p.stdout
     p = run("--integrator", "bdpt")
@@ -254,3 +255,52 @@ def test_frame_shards_add_up_to_the_frame(binding):
         assert torch.equal(total.film, whole.film), nranks
         assert torch.equal(total.film_direct, whole.film_direct), nranks
         assert np.array_equal(total.image().cpu().numpy().view(np.uint32), want.view(np.uint32)), nranks
+
+
+@pytest.mark.gpu
+def test_cpp_iispt_frame_in_shards(binding, tmp_path):
+    """The C++ IISPT host over several GPUs (`iile_pbrt --integrator iispt --gpurank R/N`: gpu_iispt_integrator.h rank / nranks /
+    comm). (1) Through the communicator branch with ONE rank — all_ok, the two `iile_dist_monitor_reduce` (doubles over RCCL), the summed
+    statistics — the three images are the plain CLI's byte for byte. (2) The share a rank renders is the share IisptFrame renders for
+    that rank (whose shares add up to the frame: test_frame_shards_add_up_to_the_frame): the images of rank R of 3 alone
+    ($IILE_DEBUG_IISPT_SHARD, no communicator) against the Python share's, bit for bit."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    sys.path.insert(0, REPO)
+    nn_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_nn")
+    import iispt_torch_reference as ref_mod
+    frame_mod = importlib.import_module("pbrt-v3-iile_amd.iispt_frame")
+    w, h, n_tasks, n_direct = 96, 80, 21, 5
+    torch.manual_seed(3)
+    module = ref_mod.IISPTNet().eval()
+    net_file = tmp_path / "net.iilenet"
+    binding.save_net_weights(module.state_dict(), str(net_file), bn_eps=module.encoder1[3].eps)
+
+    def cli(tag, *extra, env=None):
+        outs = [tmp_path / f"{tag}_{k}.pfm" for k in ("frame", "indirect", "direct")]
+        e = dict(os.environ, IISPT_SCHEDULE_RADIUS_START="4")
+        e.update(env or {})
+        p = subprocess.run([EXE, KILLEROO, "--xres", str(w), "--yres", str(h), "--spp", "1", "--integrator", "iispt", f"--iisptNet={net_file}",
+                            f"--iileIndirect={n_tasks}", f"--iileDirect={n_direct}", "--outfile", str(outs[0]), f"--iisptIndirectOut={outs[1]}",
+                            f"--iisptDirectOut={outs[2]}", *extra], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=e)
+        assert p.returncode == 0, p.stdout
+        return outs, p.stdout
+
+    plain, out0 = cli("plain")
+    ranked, out1 = cli("ranked", "--gpurank", "0/1", "--rendezvous", str(tmp_path / "rv"), "--job", "5")
+    for a, b_ in zip(plain, ranked):
+        assert a.read_bytes() == b_.read_bytes()
+    assert [l for l in out0.splitlines() if l.startswith("IISPT:")][0].split("->")[0] == [l for l in out1.splitlines() if l.startswith("IISPT:")][0].split("->")[0]
+    scene = binding.HostScene(xres=w, yres=h, spp=1)
+    gpu = binding.GpuScene(scene)
+    pipe = nn_mod.IisptPipeline(gpu, net=module)
+    for rank in range(3):
+        outs, _ = cli(f"shard{rank}", env={"IILE_DEBUG_IISPT_SHARD": f"{rank}/3"})
+        f = frame_mod.IisptFrame(binding, gpu, pipe)
+        f.run_batched(n_tasks, radius_start=4.0, rank=rank, nranks=3)
+        f.run_direct(n_direct, rank=rank, nranks=3)
+        torch.cuda.synchronize()
+        for path, want, name in ((outs[0], f.image(), "merged"), (outs[1], f.indirect_image(), "indirect"), (outs[2], f.direct_image(), "direct")):
+            got = _read_pfm(path, w, h)
+            assert np.array_equal(got.view(np.uint32), want.cpu().numpy().view(np.uint32)), (rank, name)
