@@ -21,8 +21,9 @@
 // and the films are merged on rank 0 by one RCCL reduction (include/iile_dist.h); rank 0 writes the image.
 // --gpurank 0/1 is the same code path with a communicator of one rank (tools/multi_gpu_cmdline.sh prints the N-rank
 // command lines).
-// The IISPT integrator over several GPUs is --gpurank too: rank R renders the tasks whose number is R modulo N and its block of the
-// direct passes, the two film monitors are summed on rank 0 (iile_dist_monitor_reduce), which merges and writes the images.
+// The IISPT integrator over several GPUs is --gpurank too (or --gpus N: threads of one process): rank R renders the tasks whose number is
+// R modulo N and its block of the direct passes, the two film monitors are summed on rank 0 (iile_dist_monitor_reduce), which merges and
+// writes the images.
 //
 // Mirrors src/main/pbrt.cpp:97-219 (argument loop, ParseFile, Render) on top of
 // the C ABI: libiile_host loads and flattens the scene, libiile_gpu renders it,
@@ -190,8 +191,8 @@ int main(int argc, char **argv) {
     if (out.empty()) out = scene.ok() ? scene.film_filename() : std::string("pbrt.exr");
     if (integrator_choice < 0) integrator_choice = scene.ok() ? scene.integrator() : IILE_INTEGRATOR_PATH;
     if (integrator_choice == IILE_INTEGRATOR_IISPT) {
-        if (gpus_given && gpus != 1) {
-            fprintf(stderr, "iile_pbrt: the IISPT frame over several GPUs is one process per GPU (--gpurank R/N --rendezvous FILE), not --gpus N\n");
+        if (ranked && gpus_given) {
+            fprintf(stderr, "iile_pbrt: --gpurank (one process per GPU) and --gpus (one process, several devices) exclude each other\n");
             if (comm) iile_dist_destroy(comm);
             return 1;
         }
@@ -201,7 +202,8 @@ int main(int argc, char **argv) {
             if (!ranked && sscanf(e, "%d/%d", &r, &n) == 2 && n >= 1 && r >= 0 && r < n) iispt.rank = r, iispt.nranks = n;
         }
         std::unique_ptr<iile::GpuIisptIntegrator> ii(iile::CreateGpuIisptIntegrator(ps, out, iispt));
-        const bool ok_ii = ii->Render(scene);
+        // --gpus N: one process, N devices (a host thread each; --gpus 1 is the same code with a communicator of one rank)
+        const bool ok_ii = (gpus_given && !ranked) ? ii->RenderAllDevices(scene, gpus) : ii->Render(scene);
         if (comm) {
             if (ok_ii) iile_dist_destroy(comm);
             else iile_dist_abort(comm);

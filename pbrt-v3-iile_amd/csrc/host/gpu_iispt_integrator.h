@@ -94,6 +94,67 @@ class GpuIisptIntegrator : public Integrator {
         long long hemi_points = 0, probes = 0, pixels = 0;
     } stats;
 
+    // One process, several devices (iile_pbrt --integrator iispt --gpus N): a host thread per device, each a GpuIisptIntegrator of its own with
+    // rank r of n and a communicator made in the thread — the frame's shares and the monitor reduction of the one-process-per-GPU form —
+    // under the path integrator's rules for leaving together (device_gang.h: votes with deadlines before anybody enters a collective).
+    bool RenderAllDevices(const Scene &scene, int n) {
+        const int visible = iile_device_count();
+        double timeout_s = 120.0;
+        if (const char *e = std::getenv("IILE_DIST_TIMEOUT_S")) timeout_s = std::atof(e) > 0 ? std::atof(e) : timeout_s;
+        uint8_t id[IILE_DIST_ID_BYTES];
+        if (visible >= 1 && n >= 1 && n <= visible && iile_dist_unique_id(id) != IILE_OK) {
+            fprintf(stderr, "Error: multi-GPU set-up: %s\n", iile_dist_last_error());
+            return false;
+        }
+        struct Backend {
+            GpuIisptIntegrator *self;
+            const Scene &scene;
+            const uint8_t *id;
+            double timeout_s;
+            int n;
+            std::vector<Stats> stats;
+            int fault_rank = -1;
+            std::string fault;   // $IILE_DEBUG_GANG_FAULT = select:R | create:R (tests)
+            bool SelectDevice(int r) {
+                if ((fault == "select" && r == fault_rank) || iile_device_select(r) != IILE_OK) {
+                    fprintf(stderr, "Error: IISPT: device %d: %s\n", r, fault == "select" && r == fault_rank ? "injected fault" : iile_last_error());
+                    return false;
+                }
+                return true;
+            }
+            void *CreateComm(int r, int nn) {
+                iile_dist *comm = nullptr;
+                if ((fault == "create" && r == fault_rank) || iile_dist_create_deadline(id, r, nn, timeout_s, &comm) != IILE_OK) {
+                    fprintf(stderr, "Error: multi-GPU set-up (device %d of %d): %s\n", r, nn, fault == "create" && r == fault_rank ? "injected fault" : iile_dist_last_error());
+                    return nullptr;
+                }
+                return comm;
+            }
+            bool Run(int r, void *comm) {
+                IisptOptions o = self->opt_;
+                o.rank = r, o.nranks = n, o.comm = static_cast<iile_dist *>(comm);
+                GpuIisptIntegrator part(self->output_, o);
+                const bool ok = part.Render(scene);
+                stats[size_t(r)] = part.stats;
+                return ok;
+            }
+            void DestroyComm(void *comm) { iile_dist_destroy(static_cast<iile_dist *>(comm)); }
+            void AbortComm(void *comm) { iile_dist_abort(static_cast<iile_dist *>(comm)); }
+        } be{this, scene, id, timeout_s, n, std::vector<Stats>(size_t(n > 0 ? n : 0)), -1, std::string()};
+        if (const char *f = std::getenv("IILE_DEBUG_GANG_FAULT")) {
+            const std::string spec(f);
+            const size_t colon = spec.find(':');
+            if (colon != std::string::npos) be.fault = spec.substr(0, colon), be.fault_rank = std::atoi(spec.c_str() + colon + 1);
+        }
+        std::string why;
+        if (!RunGang(be, n, visible, timeout_s, &why)) {
+            fprintf(stderr, "Error: IISPT: the frame was given up on every device: %s\n", why.c_str());
+            return false;
+        }
+        stats = be.stats[0];   // (Render sums the ranks' statistics)
+        return true;
+    }
+
     bool Render(const Scene &scene) override {
         if (!scene.ok()) return false;
         const bool timing = std::getenv("IILE_TIMING") != nullptr;

@@ -81,8 +81,8 @@ def test_weights_file_layout(binding, tmp_path):
 
 
 def test_cli_refuses_an_iispt_frame_it_cannot_render(tmp_path):
-    """Errors of the IISPT branch that need no device: no weights, several devices in one process (the frame over several GPUs is
-    one process per GPU: --gpurank), a probe side the network does not take."""
+    """Errors of the IISPT branch that need no device: no weights, devices that are not there, --gpus with --gpurank, a probe side the
+    network does not take."""
     def run(*args, env=None):
         e = dict(os.environ)
         e.pop("IILE_IISPT_NET", None)
@@ -91,8 +91,10 @@ def test_cli_refuses_an_iispt_frame_it_cannot_render(tmp_path):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=e)
     p = run("--integrator", "iispt")
     assert p.returncode == 1 and "needs the network's weights" in p.stdout
-    p = run("--integrator", "iispt", "--gpus", "2", "--iisptNet=x")
-    assert p.returncode == 1 and "one process per GPU" in p.stdout
+    p = run("--integrator", "iispt", "--gpus", "2", "--iisptNet=x")   # (one process, two devices: none is there)
+    assert p.returncode == 1 and "given up on every device" in p.stdout
+    p = run("--integrator", "iispt", "--gpus", "2", "--gpurank", "0/2", "--rendezvous", str(tmp_path / "rv"), "--iisptNet=x")
+    assert p.returncode == 1
     p = run("--integrator", "iispt", "--iisptNet=x", "--iispt_hemi_size=16")
     assert p.returncode == 1 and "32 x 32 probes" in p.stdout
     p = run("--integrator", "bdpt")
@@ -291,6 +293,17 @@ def test_cpp_iispt_frame_in_shards(binding, tmp_path):
     ranked, out1 = cli("ranked", "--gpurank", "0/1", "--rendezvous", str(tmp_path / "rv"), "--job", "5")
     for a, b_ in zip(plain, ranked):
         assert a.read_bytes() == b_.read_bytes()
+    # one process, the devices of the node: `--gpus 1` runs GpuIisptIntegrator::RenderAllDevices — a host thread per device, an in-process
+    # rendezvous, the same shares and monitor reduction — with one device: the same images; an injected set-up fault ends the run with
+    # exit code 1 and no image instead of a hang
+    threaded, _ = cli("threaded", "--gpus", "1")
+    for a, b_ in zip(plain, threaded):
+        assert a.read_bytes() == b_.read_bytes()
+    bad = tmp_path / "bad.pfm"
+    e = dict(os.environ, IISPT_SCHEDULE_RADIUS_START="4", IILE_DEBUG_GANG_FAULT="create:0", IILE_DIST_TIMEOUT_S="5")
+    p = subprocess.run([EXE, KILLEROO, "--xres", str(w), "--yres", str(h), "--spp", "1", "--integrator", "iispt", f"--iisptNet={net_file}", f"--iileIndirect={n_tasks}",
+                        "--gpus", "1", "--outfile", str(bad)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=e)
+    assert p.returncode == 1 and "given up on every device" in p.stdout and not bad.exists(), p.stdout
     assert [l for l in out0.splitlines() if l.startswith("IISPT:")][0].split("->")[0] == [l for l in out1.splitlines() if l.startswith("IISPT:")][0].split("->")[0]
     scene = binding.HostScene(xres=w, yres=h, spp=1)
     gpu = binding.GpuScene(scene)
